@@ -1,0 +1,243 @@
+#!/usr/bin/env python3
+"""Headline benchmark: MD steps/s + achieved HBM GB/s, 131 072 particles, NN = 128.
+
+    python bench.py --gpus N --steps K --warmup W          (N=1)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over the whole particle batch, exactly what
+HOOMD's run loop does around TensorflowCompute::computeForces (TensorflowCompute.cc:
+129-216): neighbor-list distance check (rebuild when tripped), pair-vector build,
+force/energy evaluation written into the HOOMD force array, and the integrator update
+that moves the particles so the next step sees new input.  All inputs are resident in
+HBM before the timed region starts.
+
+Workload (SURVEY 8(d) "C3-LJ", BASELINE.json metric): fcc 4*32^3 = 131 072 particles,
+rho = 0.8442, Gaussian jitter 0.05 a (seed 3), r_cut = 3.0, r_buff = 0.4, NN = 128,
+LJModel, fp32, dt = 0.005, Maxwell velocities kT = 1.0.  Weak scaling: every rank owns
+one such domain (config 5: 8 x 131 072 = 1.05 M particles).
+
+Prints ONE JSON line (rank 0).  roofline.achieved = ALGORITHMIC bytes per launch /
+average launch duration measured with hipEvents on the launch stream inside the timed
+region (htf_profile_*); see DESIGN.md "Measurement".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md "Chip-level parameters")
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="lj", choices=["lj", "wca", "mlp", "mlp-bf16"])
+    ap.add_argument("--cells", type=int, default=32, help="fcc cells per side (N = 4 cells^3 per rank)")
+    ap.add_argument("--nn", type=int, default=128)
+    ap.add_argument("--rcut", type=float, default=3.0)
+    ap.add_argument("--rbuff", type=float, default=0.4)
+    ap.add_argument("--dt", type=float, default=0.005)
+    ap.add_argument("--check-period", type=int, default=5, help="nlist distance-check period (HOOMD check_period)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def make_potential(htf, workload):
+    if workload == "lj":
+        return htf.Potential.lj()
+    if workload == "wca":
+        return htf.Potential.wca(1.0)
+    from hoomd_tf_amd.initializers import mlp_params
+    prec = "bf16" if workload == "mlp-bf16" else "fp32"
+    return htf.Potential.pair_mlp(mlp_params(seed=3), 0.0, 3.0, activation="tanh", precision=prec)
+
+
+def algorithmic_bytes(N, NN, n_list_entries, n_tot):
+    """per-launch algorithmic bytes of each kernel (fp32)."""
+    eval_b = N * NN * 16 + N * 16
+    build_b = N * 8 + n_list_entries * 4 + n_tot * 16 + N * NN * 16
+    integ_b = N * 16 * 5  # pos r/w, vel r/w, force r
+    return eval_b, build_b, integ_b
+
+
+def cpu_baseline(sysm, nl, args):
+    """Time the C restatement of the same computeForces pass (oracle/htf_oracle_c.c,
+    OpenMP over all host cores) on the SAME inputs.  Baseline only, never the product."""
+    from oracle import c_oracle
+    lib = c_oracle.load()
+    pos4 = sysm.pos.cpu().numpy().astype(np.float32)
+    nn = nl.n_neigh.cpu().numpy().view(np.uint32)
+    head = nl.head_list.cpu().numpy().view(np.uint32)
+    nlist = nl.nlist.cpu().numpy().view(np.uint32)
+    scratch = np.empty((sysm.N, args.nn, 4), dtype=np.float32)
+    f = c_oracle.compute_forces_lj(lib, pos4, nn, head, nlist, sysm.box3x3, args.rcut, args.nn, scratch)
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        c_oracle.compute_forces_lj(lib, pos4, nn, head, nlist, sysm.box3x3, args.rcut, args.nn, scratch)
+        reps += 1
+        el = time.perf_counter() - t0
+        if el > args.cpu_seconds or reps >= 400:
+            break
+    return {"value": reps / el, "unit": "steps/s", "cores": int(lib.htfo_num_threads()), "kind": "port",
+            "sample": "%d computeForces passes (prepareNeighbors + LJModel, C/OpenMP restatement, fp32) "
+                      "over the same %d x %d workload; integrator not included" % (reps, sysm.N, args.nn)}, f
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the evaluator has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import hoomd_tf_amd as htf
+    from hoomd_tf_amd import standin
+
+    if args.workload != "lj":
+        args.no_cpu_baseline = True  # the C port restates LJModel only
+
+    # ---- synthetic system, resident in HBM -------------------------------------------------
+    pos, L, a = standin.fcc_positions(args.cells, 0.8442)
+    rng = np.random.default_rng(3 + rank)
+    pos = pos + 0.05 * a * rng.standard_normal(pos.shape)
+    pos -= np.round(pos / L) * L
+    sysm = standin.System(pos, L, dtype=torch.float32, device=dev)
+    sysm.randomize_velocities(kT=1.0, seed=3 + rank)
+    nl = standin.CellNlist(sysm, r_cut=args.rcut, r_buff=args.rbuff, check_period=args.check_period)
+    nl.build()
+    N, NN = sysm.N, args.nn
+
+    ctx = htf.Context(r_cut=args.rcut, nneighs=NN, scalar_dtype=torch.float32, max_n=N)
+    pot = make_potential(htf, args.workload)
+    ctx.set_potential(pot)
+    nve = standin.NVE(sysm, args.dt)
+
+    def arrays():
+        return ctx.make_arrays(sysm.pos, N, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, sysm.force)
+
+    state = {"arr": arrays(), "builds": nl.n_builds, "ts": 0}
+
+    def step():
+        ts = state["ts"]
+        nl.compute(ts)
+        if nl.n_builds != state["builds"]:
+            state["arr"] = arrays()
+            state["builds"] = nl.n_builds
+        ctx.compute_forces(ts, state["arr"])
+        nve.step()
+        state["ts"] = ts + 1
+
+    # overflow guard: NN must hold every neighbor within r_cut (check_nlist semantics)
+    mc = torch.zeros(1, dtype=torch.int32, device=dev)
+    htf.ops.build_pair_vectors(sysm.pos, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, args.rcut, NN, max_count=mc)
+    max_kept = int(mc.item())
+    if max_kept > NN:
+        raise SystemExit("NN=%d too small: a particle has %d neighbors within r_cut" % (NN, max_kept))
+
+    for _ in range(args.warmup):
+        step()
+    ctx.profile_enable(True)
+    builds0 = nl.n_builds
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    build_ms, eval_ms, ncalls = ctx.profile_read()
+    ctx.profile_enable(False)
+    rebuilds = nl.n_builds - builds0
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # sanity: the run must still be a valid simulation
+    f = sysm.force
+    assert bool(torch.isfinite(f).all()), "non-finite forces"
+    e_per_particle = float(f[:, 3].double().sum().item()) / N
+
+    n_entries = int(nl.n_neigh.long().sum().item())
+    eval_b, build_b, integ_b = algorithmic_bytes(N, NN, n_entries, N + sysm.n_ghost)
+    eval_avg_s = eval_ms / max(ncalls, 1) * 1e-3
+    build_avg_s = build_ms / max(ncalls, 1) * 1e-3
+    kern = {
+        "eval_forces": {"avg_us": eval_avg_s * 1e6, "algorithmic_bytes": eval_b,
+                        "GBps": eval_b / eval_avg_s / 1e9 if eval_avg_s > 0 else None},
+        "build_pair_vectors": {"avg_us": build_avg_s * 1e6, "algorithmic_bytes": build_b,
+                               "GBps": build_b / build_avg_s / 1e9 if build_avg_s > 0 else None},
+    }
+    dom = "build_pair_vectors" if build_avg_s > eval_avg_s else "eval_forces"
+    mfma = args.workload.startswith("mlp")
+    if mfma:
+        flops = 4.0 * (32 * 64 + 64 * 64 + 64) * N * NN
+        peak = 2500.0 if args.workload == "mlp-bf16" else 157.3
+        ach = flops / eval_avg_s / 1e12
+        roof = {"bound": "mfma", "kernel": "eval_forces(pair_mlp)", "achieved": ach, "peak": peak,
+                "unit": "TFLOP/s", "frac": ach / peak, "traffic": None}
+    else:
+        ach = kern[dom]["GBps"]
+        roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBS, "traffic": None}
+
+    ms_per_step = elapsed / args.steps * 1e3
+    step_bytes = eval_b + build_b + integ_b
+    out = {
+        "metric": "MD steps/sec (131072-particle LJ domain steps, NN=128; summed over ranks) + achieved HBM GB/s",
+        "value": world * args.steps / elapsed,
+        "unit": "steps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "C3-%s: fcc %d^3x4 = %d particles/GPU, rho 0.8442, r_cut %.1f, r_buff %.1f, NN %d, dt %g"
+                               % (args.workload.upper(), args.cells, N, args.rcut, args.rbuff, NN, args.dt),
+                   "global_particles": N * world, "parallelism": "dd%dx1x1" % world,
+                   "nlist_rebuilds_in_timed_region": rebuilds, "max_neighbors_within_rcut": max_kept},
+        "hbm_GBps_full_step": world * step_bytes / (elapsed / args.steps) / 1e9,
+        "hbm_frac_full_step": step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
+        "energy_per_particle": e_per_particle,
+        "kernels": kern,
+        "roofline": roof,
+    }
+    if rank == 0 and not args.no_cpu_baseline:
+        cb, f_cpu = cpu_baseline(sysm, nl, args)
+        out["cpu_baseline"] = cb
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

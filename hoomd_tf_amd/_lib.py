@@ -1,0 +1,142 @@
+"""ctypes binding of ``libhtf_amd.so`` (the C ABI of ``include/htf_amd.h``).
+
+This is the only place the package touches native code.  There is NO fallback: if
+the HIP library is missing the import fails loudly (a product path that silently
+ran on the CPU would void every parity claim).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhtf_amd.so")
+
+HTF_OK, HTF_ERR_INVALID, HTF_ERR_DEVICE, HTF_ERR_NLIST_OVERFLOW, HTF_ERR_SKEWED_BOX, HTF_ERR_NOMEM = range(6)
+HTF_F32, HTF_F64 = 0, 1
+HTF_TF2HOOMD, HTF_HOOMD2TF = 0, 1
+POT_NONE, POT_LJ, POT_WCA, POT_RINV_POLY, POT_SIMPLE, POT_PAIR_MLP = range(6)
+ACT_LINEAR, ACT_TANH = 0, 1
+MLP_FP32, MLP_BF16 = 0, 1
+MAX_POLY_TERMS = 8
+
+
+class NlistOverflowError(RuntimeError):
+    """'Neighbor list is full!' -- tf.errors.InvalidArgumentError upstream
+    (simmodel.py:220-224, test_tensorflow.py:830-848)."""
+
+
+class SkewedBoxError(RuntimeError):
+    """'box is skewed' -- tf.errors.InvalidArgumentError upstream (simmodel.py:195)."""
+
+
+class Box(C.Structure):
+    _fields_ = [("lo", C.c_double * 3), ("hi", C.c_double * 3), ("tilt", C.c_double * 3),
+                ("periodic", C.c_int * 3)]
+
+
+class PotentialDesc(C.Structure):
+    _fields_ = [("kind", C.c_int), ("sigma", C.c_double), ("n_terms", C.c_int),
+                ("coef", C.c_double * MAX_POLY_TERMS), ("power", C.c_int * MAX_POLY_TERMS),
+                ("K", C.c_int), ("H1", C.c_int), ("H2", C.c_int), ("activation", C.c_int),
+                ("mlp_precision", C.c_int), ("rbf_low", C.c_double), ("rbf_high", C.c_double),
+                ("W1", C.c_void_p), ("b1", C.c_void_p), ("W2", C.c_void_p), ("b2", C.c_void_p),
+                ("W3", C.c_void_p), ("b3", C.c_void_p)]
+
+
+class Config(C.Structure):
+    _fields_ = [("r_cut", C.c_double), ("nneighs", C.c_uint), ("force_mode", C.c_int),
+                ("period", C.c_uint), ("batch_size", C.c_uint), ("scalar_dtype", C.c_int),
+                ("check_nlist", C.c_int), ("virial", C.c_int), ("max_n", C.c_uint)]
+
+
+class HoomdArrays(C.Structure):
+    _fields_ = [("pos", C.c_void_p), ("N", C.c_uint), ("n_ghost", C.c_uint),
+                ("n_neigh", C.c_void_p), ("nlist", C.c_void_p), ("head_list", C.c_void_p),
+                ("box", Box), ("force", C.c_void_p), ("virial", C.c_void_p),
+                ("virial_pitch", C.c_size_t)]
+
+
+_vp, _u, _i, _d, _sz = C.c_void_p, C.c_uint, C.c_int, C.c_double, C.c_size_t
+
+# name -> (restype, argtypes); must list every HTF_API symbol of include/htf_amd.h
+PROTOTYPES = {
+    "htf_last_error": (C.c_char_p, []),
+    "htf_abi_version": (_i, []),
+    "htf_device_count": (_i, []),
+    "htf_potential_create": (_i, [C.POINTER(PotentialDesc), C.POINTER(_vp)]),
+    "htf_potential_destroy": (None, [_vp]),
+    "htf_build_pair_vectors": (_i, [_vp, _i, _vp, _i, _u, _u, _u, _u, _u, C.POINTER(Box), _vp, _vp, _vp, _d, _vp, _vp]),
+    "htf_eval_forces": (_i, [_vp, _vp, _i, _u, _u, _vp, _i, _vp, _vp]),
+    "htf_add_virial": (_i, [_vp, _vp, _i, _u, _sz, _vp]),
+    "htf_add_scalar4": (_i, [_vp, _vp, _i, _u, _vp]),
+    "htf_copy_positions": (_i, [_vp, _i, _vp, _i, _u, _u, _i, _vp]),
+    "htf_check_nlist": (_i, [_vp, _i, _u, _u, _vp, _vp]),
+    "htf_nlist_rinv": (_i, [_vp, _i, _u, _u, _vp, _vp]),
+    "htf_create": (_i, [C.POINTER(Config), C.POINTER(_vp)]),
+    "htf_destroy": (None, [_vp]),
+    "htf_set_potential": (_i, [_vp, _vp]),
+    "htf_resize": (_i, [_vp, _u]),
+    "htf_compute_forces": (_i, [_vp, _u, C.POINTER(HoomdArrays), _vp]),
+    "htf_get_nlist_buffer": (_vp, [_vp]),
+    "htf_get_positions_buffer": (_vp, [_vp]),
+    "htf_get_virial_buffer": (_vp, [_vp]),
+    "htf_get_batch_capacity": (_u, [_vp]),
+    "htf_profile_enable": (_i, [_vp, _i]),
+    "htf_profile_read": (_i, [_vp, C.POINTER(_d), C.POINTER(_d), C.POINTER(_u)]),
+}
+
+# HOOMD stand-in entry points (include/htf_standin.h) -- outside the drop-in boundary
+STANDIN_PROTOTYPES = {
+    "htfs_nve_step": (_i, [_vp, _vp, _vp, _i, _u, _d, C.POINTER(Box), _vp]),
+    "htfs_max_displacement2": (_i, [_vp, _vp, _i, _u, C.POINTER(Box), _vp, _vp]),
+    "htfs_build_nlist": (_i, [_vp, _i, _u, _u, C.POINTER(Box), _d, C.POINTER(_i * 3), _vp, _vp, _u, _vp, _vp, _vp, _vp, _vp]),
+    "htfs_cell_index": (_i, [_vp, _i, _u, C.POINTER(Box), C.POINTER(_i * 3), _vp, _vp]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "hoomd_tf_amd: %s is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C hoomd_tf_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in list(PROTOTYPES.items()) + list(STANDIN_PROTOTYPES.items()):
+        fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.htf_abi_version() != 1:
+        raise ImportError("hoomd_tf_amd: ABI version mismatch (library %d, binding 1)" % lib.htf_abi_version())
+    return lib
+
+
+lib = _load()
+
+
+def last_error():
+    return lib.htf_last_error().decode("utf-8", "replace")
+
+
+def check(rc):
+    """Map C status codes to the exception types the reference raises."""
+    if rc == HTF_OK:
+        return
+    msg = last_error()
+    if rc == HTF_ERR_INVALID:
+        raise ValueError(msg)
+    if rc == HTF_ERR_NLIST_OVERFLOW:
+        raise NlistOverflowError(msg)
+    if rc == HTF_ERR_SKEWED_BOX:
+        raise SkewedBoxError(msg)
+    if rc == HTF_ERR_NOMEM:
+        raise MemoryError(msg)
+    raise RuntimeError(msg)
+
+
+def make_box(box3x3, periodic=(1, 1, 1)):
+    """3x3 [[lo],[hi],[xy,xz,yz]] (TensorflowCompute.cc:271-282) -> htf_box."""
+    b = Box()
+    for d in range(3):
+        b.lo[d] = float(box3x3[0][d])
+        b.hi[d] = float(box3x3[1][d])
+        b.tilt[d] = float(box3x3[2][d])
+        b.periodic[d] = int(periodic[d])
+    return b

@@ -1,0 +1,111 @@
+// Small companions of the force path: the reference's bookkeeping kernels, kept
+// because HOOMD-facing semantics depend on them (accumulating virial fold-in,
+// reference-force summation, type un-stuffing).  All are trivially HBM-bound and
+// touch O(N) bytes (<= 4.5 MiB at N = 131072) -- three orders below the nlist.
+#include "htf_common.h"
+
+namespace htf {
+
+// TensorflowCompute.cu:41-55 htf_gpu_add_virial_kernel / .cc:284-301 receiveVirial
+template <typename T>
+__global__ __launch_bounds__(256) void add_virial_kernel(T *__restrict__ dest, const T *__restrict__ src,
+                                                         unsigned N, size_t pitch) {
+    unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const T *s = src + (size_t)i * 9;
+    dest[0 * pitch + i] += s[0]; // xx
+    dest[1 * pitch + i] += s[1]; // xy
+    dest[2 * pitch + i] += s[2]; // xz
+    dest[3 * pitch + i] += s[4]; // yy
+    dest[4 * pitch + i] += s[5]; // yz
+    dest[5 * pitch + i] += s[8]; // zz
+}
+
+// TensorflowCompute.cu:11-23 htf_gpu_add_scalar4_kernel
+template <typename V>
+__global__ __launch_bounds__(256) void add_scalar4_kernel(V *__restrict__ dest, const V *__restrict__ src, unsigned N) {
+    unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    V d = dest[i], s = src[i];
+    d.x += s.x;
+    d.y += s.y;
+    d.z += s.z;
+    d.w += s.w;
+    dest[i] = d;
+}
+
+__device__ __forceinline__ int w_as_int(float w) { return __float_as_int(w); }
+__device__ __forceinline__ int w_as_int(double w) { return (int)(__double_as_longlong(w) & 0xffffffffll); }
+
+// TFArrayComm.h:86-130 receiveArray + TFArrayComm.cu:9-15 htf_gpu_unstuff4_kerenl
+template <typename ST, typename DT>
+__global__ __launch_bounds__(256) void copy_positions_kernel(typename Vec4<DT>::type *__restrict__ dest,
+                                                             const typename Vec4<ST>::type *__restrict__ src,
+                                                             unsigned offset, unsigned N, int unstuff4) {
+    unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    auto s = src[offset + i];
+    typename Vec4<DT>::type d;
+    d.x = (DT)s.x;
+    d.y = (DT)s.y;
+    d.z = (DT)s.z;
+    d.w = unstuff4 ? (DT)w_as_int(s.w) : (DT)s.w;
+    dest[i] = d;
+}
+
+} // namespace htf
+
+extern "C" int htf_add_virial(void *d_dest, const void *d_src9, int dtype, unsigned N, size_t pitch, htf_stream stream) {
+    using namespace htf;
+    HTF_REQUIRE(d_dest && d_src9, "htf_add_virial: null pointer");
+    HTF_REQUIRE(pitch >= N, "htf_add_virial: pitch %zu < N %u", pitch, N);
+    if (N == 0) return HTF_OK;
+    unsigned grid = (N + 255) / 256;
+    if (dtype == HTF_F32)
+        hipLaunchKernelGGL((add_virial_kernel<float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (float *)d_dest, (const float *)d_src9, N, pitch);
+    else if (dtype == HTF_F64)
+        hipLaunchKernelGGL((add_virial_kernel<double>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (double *)d_dest, (const double *)d_src9, N, pitch);
+    else {
+        set_error("htf_add_virial: bad dtype %d", dtype);
+        return HTF_ERR_INVALID;
+    }
+    return check_launch("add_virial_kernel");
+}
+
+extern "C" int htf_add_scalar4(void *d_dest, const void *d_src, int dtype, unsigned N, htf_stream stream) {
+    using namespace htf;
+    HTF_REQUIRE(d_dest && d_src, "htf_add_scalar4: null pointer");
+    if (N == 0) return HTF_OK;
+    unsigned grid = (N + 255) / 256;
+    if (dtype == HTF_F32)
+        hipLaunchKernelGGL((add_scalar4_kernel<float4>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (float4 *)d_dest, (const float4 *)d_src, N);
+    else if (dtype == HTF_F64)
+        hipLaunchKernelGGL((add_scalar4_kernel<double4>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (double4 *)d_dest, (const double4 *)d_src, N);
+    else {
+        set_error("htf_add_scalar4: bad dtype %d", dtype);
+        return HTF_ERR_INVALID;
+    }
+    return check_launch("add_scalar4_kernel");
+}
+
+extern "C" int htf_copy_positions(void *d_dest, int dest_dtype, const void *d_src, int src_dtype, unsigned offset,
+                                  unsigned N, int unstuff4, htf_stream stream) {
+    using namespace htf;
+    HTF_REQUIRE(d_dest && d_src, "htf_copy_positions: null pointer");
+    if (N == 0) return HTF_OK;
+    unsigned grid = (N + 255) / 256;
+    hipStream_t s = (hipStream_t)stream;
+    if (src_dtype == HTF_F32 && dest_dtype == HTF_F32)
+        hipLaunchKernelGGL((copy_positions_kernel<float, float>), dim3(grid), dim3(256), 0, s, (float4 *)d_dest, (const float4 *)d_src, offset, N, unstuff4);
+    else if (src_dtype == HTF_F64 && dest_dtype == HTF_F32)
+        hipLaunchKernelGGL((copy_positions_kernel<double, float>), dim3(grid), dim3(256), 0, s, (float4 *)d_dest, (const double4 *)d_src, offset, N, unstuff4);
+    else if (src_dtype == HTF_F64 && dest_dtype == HTF_F64)
+        hipLaunchKernelGGL((copy_positions_kernel<double, double>), dim3(grid), dim3(256), 0, s, (double4 *)d_dest, (const double4 *)d_src, offset, N, unstuff4);
+    else if (src_dtype == HTF_F32 && dest_dtype == HTF_F64)
+        hipLaunchKernelGGL((copy_positions_kernel<float, double>), dim3(grid), dim3(256), 0, s, (double4 *)d_dest, (const float4 *)d_src, offset, N, unstuff4);
+    else {
+        set_error("htf_copy_positions: bad dtype (%d, %d)", src_dtype, dest_dtype);
+        return HTF_ERR_INVALID;
+    }
+    return check_launch("copy_positions_kernel");
+}

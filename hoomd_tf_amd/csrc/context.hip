@@ -1,0 +1,331 @@
+// Host side of the C ABI: error channel, potential handles, htf_eval_forces dispatch
+// and the TensorflowCompute::computeForces driver (TensorflowCompute.cc:129-216)
+// re-stated over raw HOOMD-layout device pointers with no Python, no TF and no
+// device-wide synchronisation in the loop.
+#include <cmath>
+#include <cstdarg>
+#include <cstdlib>
+#include <new>
+#include <vector>
+
+#include "htf_common.h"
+#include "htf_internal.h"
+
+namespace htf {
+
+static thread_local std::string g_last_error;
+
+void set_error(const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+
+} // namespace htf
+
+struct htf_potential {
+    htf::PotParams pp;
+    htf::MlpDevice *mlp = nullptr;
+};
+
+struct htf_ctx {
+    htf_config cfg;
+    const htf_potential *pot = nullptr;
+    unsigned capacity = 0;     // rows the scratch can hold (batch_size or max_n)
+    float4 *nlist = nullptr;   // [capacity, NN] fp32 pair vectors  (m_nlist_array, .cc:113)
+    float4 *positions = nullptr; // [capacity] fp32 positions, type un-stuffed (m_positions_array, .cc:100)
+    void *virial = nullptr;    // [capacity, 9] Scalar              (m_virial_array, .cc:117)
+    unsigned *flag = nullptr;  // device word for check_nlist / overflow counts
+    // profiler scopes: event triples (before build, between, after eval) per batch
+    bool profiling = false;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+};
+
+static hipEvent_t next_event(htf_ctx *c) {
+    if (c->ev_used == c->ev_pool.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        c->ev_pool.push_back(e);
+    }
+    return c->ev_pool[c->ev_used++];
+}
+
+extern "C" const char *htf_last_error(void) { return htf::g_last_error.c_str(); }
+extern "C" int htf_abi_version(void) { return HTF_AMD_ABI_VERSION; }
+
+extern "C" int htf_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ------------------------------------------------------------------------------ potentials
+extern "C" int htf_potential_create(const htf_potential_desc *d, htf_potential **out) {
+    using namespace htf;
+    HTF_REQUIRE(d && out, "htf_potential_create: null pointer");
+    htf_potential *p = new (std::nothrow) htf_potential();
+    if (!p) {
+        set_error("htf_potential_create: out of host memory");
+        return HTF_ERR_NOMEM;
+    }
+    std::memset(&p->pp, 0, sizeof p->pp);
+    p->pp.kind = d->kind;
+    int rc = HTF_OK;
+    switch (d->kind) {
+    case HTF_POT_LJ:
+    case HTF_POT_SIMPLE:
+        break;
+    case HTF_POT_WCA:
+        if (!(d->sigma > 0)) {
+            set_error("htf_potential_create: WCA sigma must be > 0 (got %g)", d->sigma);
+            rc = HTF_ERR_INVALID;
+        }
+        p->pp.sigma = (float)d->sigma;
+        // layers.py:97 `true_sig * 2**(1/3)`: fp32 weight times the python double rounded to fp32
+        p->pp.wca_cut = p->pp.sigma * (float)1.2599210498948732;
+        break;
+    case HTF_POT_RINV_POLY:
+        if (d->n_terms < 1 || d->n_terms > HTF_MAX_POLY_TERMS) {
+            set_error("htf_potential_create: n_terms %d outside [1, %d]", d->n_terms, HTF_MAX_POLY_TERMS);
+            rc = HTF_ERR_INVALID;
+            break;
+        }
+        p->pp.n_terms = d->n_terms;
+        for (int k = 0; k < d->n_terms; ++k) {
+            if (d->power[k] < 1 || d->power[k] > 64) {
+                set_error("htf_potential_create: rinv power %d outside [1, 64]", d->power[k]);
+                rc = HTF_ERR_INVALID;
+            }
+            p->pp.coef[k] = (float)d->coef[k];
+            p->pp.power[k] = d->power[k];
+        }
+        break;
+    case HTF_POT_PAIR_MLP:
+        rc = mlp_create(d, &p->mlp);
+        break;
+    default:
+        set_error("htf_potential_create: unknown potential kind %d", d->kind);
+        rc = HTF_ERR_INVALID;
+    }
+    if (rc != HTF_OK) {
+        delete p;
+        return rc;
+    }
+    *out = p;
+    return HTF_OK;
+}
+
+extern "C" void htf_potential_destroy(htf_potential *pot) {
+    if (!pot) return;
+    if (pot->mlp) htf::mlp_destroy(pot->mlp);
+    delete pot;
+}
+
+extern "C" int htf_eval_forces(const htf_potential *pot, const void *d_nlist, int nlist_dtype, unsigned B,
+                               unsigned NN, void *d_force, int force_dtype, void *d_virial9, htf_stream stream) {
+    using namespace htf;
+    HTF_REQUIRE(pot, "htf_eval_forces: no potential");
+    HTF_REQUIRE(d_nlist && d_force, "htf_eval_forces: null pointer");
+    HTF_REQUIRE(NN > 0, "htf_eval_forces: NN must be > 0");
+    HTF_REQUIRE(nlist_dtype == HTF_F32 || nlist_dtype == HTF_F64, "htf_eval_forces: bad nlist dtype %d", nlist_dtype);
+    HTF_REQUIRE(force_dtype == HTF_F32 || force_dtype == HTF_F64, "htf_eval_forces: bad force dtype %d", force_dtype);
+    if (B == 0) return HTF_OK;
+    if (pot->pp.kind == HTF_POT_PAIR_MLP) {
+        HTF_REQUIRE(d_virial9 == nullptr, "htf_eval_forces: virial is not implemented for the pair-MLP");
+        return mlp_eval(pot->mlp, d_nlist, nlist_dtype, B, NN, d_force, force_dtype, (hipStream_t)stream);
+    }
+    HTF_REQUIRE(!(pot->pp.kind == HTF_POT_SIMPLE && d_virial9), "htf_eval_forces: SimplePotential has no energy, hence no virial");
+    return eval_pair_dispatch(pot->pp, d_nlist, nlist_dtype, B, NN, d_force, force_dtype, d_virial9, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------ context
+static void ctx_free(htf_ctx *c) {
+    if (c->nlist) (void)hipFree(c->nlist);
+    if (c->positions) (void)hipFree(c->positions);
+    if (c->virial) (void)hipFree(c->virial);
+    c->nlist = nullptr;
+    c->positions = nullptr;
+    c->virial = nullptr;
+    c->capacity = 0;
+}
+
+// TensorflowCompute::reallocate (.cc:91-121): side buffers sized by batch_size, or by
+// getMaxN() when unbatched; virial zeroed once (memsetArray(0), :120).
+static int ctx_alloc(htf_ctx *c, unsigned max_n) {
+    using namespace htf;
+    ctx_free(c);
+    unsigned cap = c->cfg.batch_size ? c->cfg.batch_size : max_n;
+    if (cap == 0) cap = 1;
+    size_t ssz = c->cfg.scalar_dtype == HTF_F64 ? 8 : 4;
+    if (c->cfg.nneighs > 0) HTF_CHECK_HIP(hipMalloc((void **)&c->nlist, (size_t)cap * c->cfg.nneighs * sizeof(float4)));
+    HTF_CHECK_HIP(hipMalloc((void **)&c->positions, (size_t)cap * sizeof(float4)));
+    HTF_CHECK_HIP(hipMalloc(&c->virial, (size_t)cap * 9 * ssz));
+    HTF_CHECK_HIP(hipMemset(c->virial, 0, (size_t)cap * 9 * ssz));
+    c->capacity = cap;
+    c->cfg.max_n = max_n;
+    return HTF_OK;
+}
+
+extern "C" int htf_create(const htf_config *cfg, htf_ctx **out) {
+    using namespace htf;
+    HTF_REQUIRE(cfg && out, "htf_create: null pointer");
+    HTF_REQUIRE(cfg->period >= 1, "htf_create: period must be >= 1");
+    HTF_REQUIRE(cfg->scalar_dtype == HTF_F32 || cfg->scalar_dtype == HTF_F64, "htf_create: bad scalar dtype %d", cfg->scalar_dtype);
+    HTF_REQUIRE(cfg->force_mode == HTF_TF2HOOMD || cfg->force_mode == HTF_HOOMD2TF, "htf_create: bad force mode %d", cfg->force_mode);
+    HTF_REQUIRE(cfg->nneighs == 0 || cfg->r_cut > 0, "htf_create: r_cut must be > 0 when nneighs > 0");
+    htf_ctx *c = new (std::nothrow) htf_ctx();
+    if (!c) {
+        set_error("htf_create: out of host memory");
+        return HTF_ERR_NOMEM;
+    }
+    c->cfg = *cfg;
+    hipError_t e = hipMalloc((void **)&c->flag, sizeof(unsigned));
+    if (e != hipSuccess) {
+        set_error("htf_create: hipMalloc failed: %s", hipGetErrorString(e));
+        delete c;
+        return HTF_ERR_DEVICE;
+    }
+    int rc = ctx_alloc(c, cfg->max_n);
+    if (rc != HTF_OK) {
+        htf_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return HTF_OK;
+}
+
+extern "C" void htf_destroy(htf_ctx *ctx) {
+    if (!ctx) return;
+    ctx_free(ctx);
+    if (ctx->flag) (void)hipFree(ctx->flag);
+    for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
+    delete ctx;
+}
+
+extern "C" int htf_set_potential(htf_ctx *ctx, const htf_potential *pot) {
+    using namespace htf;
+    HTF_REQUIRE(ctx, "htf_set_potential: null context");
+    ctx->pot = pot;
+    return HTF_OK;
+}
+
+extern "C" int htf_resize(htf_ctx *ctx, unsigned max_n) {
+    using namespace htf;
+    HTF_REQUIRE(ctx, "htf_resize: null context");
+    return ctx_alloc(ctx, max_n);
+}
+
+extern "C" void *htf_get_nlist_buffer(htf_ctx *ctx) { return ctx ? ctx->nlist : nullptr; }
+extern "C" void *htf_get_positions_buffer(htf_ctx *ctx) { return ctx ? ctx->positions : nullptr; }
+extern "C" void *htf_get_virial_buffer(htf_ctx *ctx) { return ctx ? ctx->virial : nullptr; }
+extern "C" unsigned htf_get_batch_capacity(htf_ctx *ctx) { return ctx ? ctx->capacity : 0; }
+
+extern "C" int htf_compute_forces(htf_ctx *ctx, unsigned timestep, const htf_hoomd_arrays *a, htf_stream stream) {
+    using namespace htf;
+    HTF_REQUIRE(ctx && a, "htf_compute_forces: null pointer");
+    const htf_config &cfg = ctx->cfg;
+    if (timestep % cfg.period != 0) return HTF_OK; // .cc:133 -- previous forces stay in m_force
+    HTF_REQUIRE(a->pos, "htf_compute_forces: null positions");
+    HTF_REQUIRE(cfg.force_mode == HTF_TF2HOOMD, "htf_compute_forces: FORCE_MODE::hoomd2tf (training) is not built yet");
+    HTF_REQUIRE(a->force, "htf_compute_forces: null force array");
+    // SimModel.compute_inputs: tf.Assert(reduce_sum(box[2]) < 0.0001)  simmodel.py:195
+    if (!(a->box.tilt[0] + a->box.tilt[1] + a->box.tilt[2] < 0.0001)) {
+        set_error("box is skewed");
+        return HTF_ERR_SKEWED_BOX;
+    }
+    const unsigned N = a->N;
+    if (N == 0) return HTF_OK;
+    if (cfg.batch_size == 0 && N > ctx->capacity) {
+        int rc = ctx_alloc(ctx, N); // MaxParticleNumberChange -> reallocate (.cc:88)
+        if (rc != HTF_OK) return rc;
+    }
+    const size_t ssz = cfg.scalar_dtype == HTF_F64 ? 8 : 4;
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned bs = cfg.batch_size == 0 ? N : cfg.batch_size;
+    for (unsigned i = 0; i < N / bs + 1; ++i) { // .cc:143
+        const unsigned offset = i * bs;
+        if (offset >= N) break;
+        const unsigned n = std::min(N - offset, bs);
+        int rc;
+        const bool prof = ctx->profiling && cfg.nneighs > 0 && ctx->pot != nullptr;
+        hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+        if (prof) {
+            e0 = next_event(ctx);
+            e1 = next_event(ctx);
+            e2 = next_event(ctx);
+            HTF_REQUIRE(e0 && e1 && e2, "htf_compute_forces: hipEventCreate failed");
+            HTF_CHECK_HIP(hipEventRecord(e0, s));
+        }
+        if (cfg.nneighs > 0) {
+            HTF_REQUIRE(a->n_neigh && a->nlist && a->head_list, "htf_compute_forces: null neighbor list");
+            rc = htf_build_pair_vectors(ctx->nlist, HTF_F32, a->pos, cfg.scalar_dtype, N, cfg.nneighs, offset, n,
+                                        a->n_ghost, &a->box, a->n_neigh, a->nlist, a->head_list, cfg.r_cut,
+                                        nullptr, stream);
+            if (rc != HTF_OK) return rc;
+        }
+        if (prof) HTF_CHECK_HIP(hipEventRecord(e1, s));
+        if (cfg.nneighs == 0 || ctx->pot == nullptr) {
+            rc = htf_copy_positions(ctx->positions, HTF_F32, a->pos, cfg.scalar_dtype, offset, n, 1, stream);
+            if (rc != HTF_OK) return rc;
+            continue;
+        } // positions-only models live above the ABI
+        if (cfg.check_nlist) {
+            unsigned h = 0;
+            HTF_CHECK_HIP(hipMemsetAsync(ctx->flag, 0, sizeof(unsigned), s));
+            rc = htf_check_nlist(ctx->nlist, HTF_F32, n, cfg.nneighs, ctx->flag, stream);
+            if (rc != HTF_OK) return rc;
+            HTF_CHECK_HIP(hipMemcpyAsync(&h, ctx->flag, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+            HTF_CHECK_HIP(hipStreamSynchronize(s));
+            if (!(h < cfg.nneighs)) { // tf.debugging.assert_less(NN, nneighbor_cutoff)  simmodel.py:220-224
+                set_error("Neighbor list is full!");
+                return HTF_ERR_NLIST_OVERFLOW;
+            }
+        }
+        void *force_out = (char *)a->force + (size_t)offset * 4 * ssz; // m_forces_comm.setOffset(offset) .cc:192
+        rc = htf_eval_forces(ctx->pot, ctx->nlist, HTF_F32, n, cfg.nneighs, force_out, cfg.scalar_dtype,
+                             cfg.virial ? ctx->virial : nullptr, stream);
+        if (rc != HTF_OK) return rc;
+        if (prof) HTF_CHECK_HIP(hipEventRecord(e2, s));
+        // m_positions_comm.receiveArray(..., unstuff4) .cc:172 -- side buffer for get_positions_array / models
+        rc = htf_copy_positions(ctx->positions, HTF_F32, a->pos, cfg.scalar_dtype, offset, n, 1, stream);
+        if (rc != HTF_OK) return rc;
+        if (cfg.virial && a->virial) { // receiveVirial(offset, N) .cc:200-204
+            rc = htf_add_virial((char *)a->virial + (size_t)offset * ssz, ctx->virial, cfg.scalar_dtype, n,
+                                a->virial_pitch, stream);
+            if (rc != HTF_OK) return rc;
+        }
+    }
+    return HTF_OK;
+}
+
+extern "C" int htf_profile_enable(htf_ctx *ctx, int on) {
+    using namespace htf;
+    HTF_REQUIRE(ctx, "htf_profile_enable: null context");
+    ctx->profiling = on != 0;
+    ctx->ev_used = 0;
+    return HTF_OK;
+}
+
+extern "C" int htf_profile_read(htf_ctx *ctx, double *build_ms, double *eval_ms, unsigned *n_calls) {
+    using namespace htf;
+    HTF_REQUIRE(ctx, "htf_profile_read: null context");
+    double b = 0, e = 0;
+    const size_t triples = ctx->ev_used / 3;
+    for (size_t t = 0; t < triples; ++t) {
+        float ms = 0;
+        HTF_CHECK_HIP(hipEventSynchronize(ctx->ev_pool[3 * t + 2]));
+        HTF_CHECK_HIP(hipEventElapsedTime(&ms, ctx->ev_pool[3 * t], ctx->ev_pool[3 * t + 1]));
+        b += ms;
+        HTF_CHECK_HIP(hipEventElapsedTime(&ms, ctx->ev_pool[3 * t + 1], ctx->ev_pool[3 * t + 2]));
+        e += ms;
+    }
+    if (build_ms) *build_ms = b;
+    if (eval_ms) *eval_ms = e;
+    if (n_calls) *n_calls = (unsigned)triples;
+    ctx->ev_used = 0;
+    return HTF_OK;
+}

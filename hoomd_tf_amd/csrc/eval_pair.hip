@@ -1,0 +1,308 @@
+// Fused streaming evaluator for the closed-form pair potentials:
+//   nlist [B, NN, 4]  ->  force [B] Scalar4 (fx, fy, fz, E_i)  (+ virial [B, 9])
+//
+// Replaces the TF2 graph the reference runs per step (SURVEY 3.1 "HOT LOOP"):
+//   nlist_rinv (simmodel.py:618-635) -> model energy (build_examples.py / layers.py)
+//   -> tf.gradients -> *2 -> reduce_sum over neighbors (simmodel.py:526-555)
+//   -> _add_energy (:558-578) [-> _compute_virial (:509-523)] -> TfToHoomd copy.
+// TF streams [N,NN] / [N,NN,3] tensors through ~30 elementwise kernels; here each
+// 16-B slot is read from HBM exactly once and everything else stays in registers.
+//
+// MI355X mapping (HBM-bound: ~40 flop per 16-B slot): a group of G consecutive
+// lanes owns one particle row; lane g reads slots g, g+G, g+2G, ... as float4, so
+// every wave-level load instruction fetches (64/G) fully-used contiguous segments
+// of G*16 B (>= one 128-B line for G >= 8).  Eight independent 16-B loads per lane
+// are issued before the first use (128 B in flight per lane).  The pair->particle
+// sum is a DPP row reduction inside the group -- no LDS, no atomics -- and lane 0 of
+// each group stores the Scalar4.  No LDS staging: there is no reuse to exploit.
+#include <cmath>
+
+#include "htf_common.h"
+#include "htf_internal.h"
+
+namespace htf {
+
+
+// shared forward of every rinv-based energy: t = x + 1e-7, r' = |t|, s = nlist_rinv
+struct RinvFwd {
+    float tx, ty, tz, rp, s;
+    bool cond;
+};
+
+__device__ __forceinline__ RinvFwd rinv_fwd(float x, float y, float z) {
+    RinvFwd f;
+    f.tx = x + kNormDelta;
+    f.ty = y + kNormDelta;
+    f.tz = z + kNormDelta;
+    f.rp = sqrtf(f.tx * f.tx + f.ty * f.ty + f.tz * f.tz);
+    f.cond = f.rp > kRinvDelta;
+    f.s = f.cond ? 1.0f / (f.rp + kRinvDelta) : 0.0f;
+    return f;
+}
+
+// Each potential returns the pair energy e (its share of E_i) and nlist_forces_ij =
+// 2 * dE/dx_ij (the reference's "nlist_forces", simmodel.py:548) in (fx, fy, fz).
+template <int KIND>
+__device__ __forceinline__ void pair_eval(float x, float y, float z, const PotParams &p,
+                                          float &e, float &fx, float &fy, float &fz) {
+    if constexpr (KIND == HTF_POT_SIMPLE) {
+        // build_examples.py:9-22: -1 * ((1/|x|) * x), non-finite -> 0 (forward only)
+        float rs = sqrtf(x * x + y * y + z * z);
+        float inv = 1.0f / rs;
+        float ax = -1.0f * (inv * x), ay = -1.0f * (inv * y), az = -1.0f * (inv * z);
+        fx = isfinite(ax) ? ax : 0.0f;
+        fy = isfinite(ay) ? ay : 0.0f;
+        fz = isfinite(az) ? az : 0.0f;
+        e = 0.0f;
+        return;
+    } else {
+        RinvFwd f = rinv_fwd(x, y, z);
+        const float s = f.s, s2 = s * s;
+        float dEds;
+        if constexpr (KIND == HTF_POT_LJ) {
+            // build_examples.py:70-74: inv_r6 = rinv**6; 4/2 * (inv_r6*inv_r6 - inv_r6)
+            float s6 = s2 * s2 * s2;
+            e = 2.0f * (s6 * s6 - s6);
+            dEds = 2.0f * (2.0f * s6 - 1.0f) * (6.0f * (s2 * s2 * s));
+        } else if constexpr (KIND == HTF_POT_WCA) {
+            // layers.py:91-98
+            float q = p.sigma * s, q2 = q * q;
+            float q6 = q2 * q2 * q2;
+            float r = sqrtf(x * x + y * y + z * z);
+            bool in = r < p.wca_cut;
+            float e_raw = in ? q6 : 0.0f;
+            e = fminf(fmaxf(e_raw, 0.0f), 10.0f);
+            bool pass = in && (e_raw >= 0.0f) && (e_raw <= 10.0f); // clip_by_value gradient
+            dEds = pass ? 6.0f * (q2 * q2 * q) * p.sigma : 0.0f;
+        } else { // HTF_POT_RINV_POLY
+            e = 0.0f;
+            dEds = 0.0f;
+            for (int k = 0; k < p.n_terms; ++k) {
+                int pw = p.power[k] - 1; // powers validated >= 1 on the host
+                float b = s, acc = 1.0f;
+                while (pw > 0) {
+                    if (pw & 1) acc *= b;
+                    b *= b;
+                    pw >>= 1;
+                }
+                dEds += p.coef[k] * (float)p.power[k] * acc;
+                e += p.coef[k] * (acc * s);
+            }
+        }
+        // d s / d r' = -s^2 (where cond), d r' / d t = t / r'; times 2 (simmodel.py:548)
+        float c = f.cond ? 2.0f * (dEds * (-s2)) / f.rp : 0.0f;
+        fx = c * f.tx;
+        fy = c * f.ty;
+        fz = c * f.tz;
+        if (!f.cond) e = 0.0f;
+    }
+}
+
+constexpr int kUnroll = 8;
+
+template <typename IT>
+__device__ __forceinline__ float4 load_slot(const typename Vec4<IT>::type *p) {
+    auto v = *p;
+    return make_float4((float)v.x, (float)v.y, (float)v.z, (float)v.w);
+}
+
+template <int KIND, int G, bool VIRIAL, typename IT>
+__global__ __launch_bounds__(256) void eval_pair_kernel(const typename Vec4<IT>::type *__restrict__ nlist,
+                                                        unsigned B, unsigned NN, void *__restrict__ force,
+                                                        void *__restrict__ virial9, int out_f64, PotParams p) {
+    constexpr int RPW = 64 / G; // particle rows per wave
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned g = lane % G, sub = lane / G;
+    const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const unsigned row = wave * RPW + sub;
+    const bool active = row < B;
+    const typename Vec4<IT>::type *rp = nlist + (size_t)(active ? row : B - 1) * NN;
+
+    float fx = 0.f, fy = 0.f, fz = 0.f, en = 0.f;
+    float vxx = 0.f, vxy = 0.f, vxz = 0.f, vyy = 0.f, vyz = 0.f, vzz = 0.f;
+
+    for (unsigned j0 = 0; j0 < NN; j0 += kUnroll * G) {
+        float4 v[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            unsigned j = j0 + u * G + g;
+            v[u] = (j < NN) ? load_slot<IT>(rp + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            float e, ax, ay, az;
+            pair_eval<KIND>(v[u].x, v[u].y, v[u].z, p, e, ax, ay, az);
+            fx += ax;
+            fy += ay;
+            fz += az;
+            en += e;
+            if constexpr (VIRIAL) {
+                // simmodel.py:509-523: -(|nf| / (2 |x|)) x (x) x, divide_no_nan
+                float x = v[u].x, y = v[u].y, z = v[u].z;
+                float fmag = sqrtf(ax * ax + ay * ay + az * az);
+                float den = 2.0f * sqrtf(x * x + y * y + z * z);
+                float frs = (den == 0.0f) ? 0.0f : fmag / den;
+                vxx -= frs * x * x;
+                vxy -= frs * x * y;
+                vxz -= frs * x * z;
+                vyy -= frs * y * y;
+                vyz -= frs * y * z;
+                vzz -= frs * z * z;
+            }
+        }
+    }
+
+    fx = group_sum<G>(fx);
+    fy = group_sum<G>(fy);
+    fz = group_sum<G>(fz);
+    en = group_sum<G>(en);
+    if constexpr (VIRIAL) {
+        vxx = group_sum<G>(vxx);
+        vxy = group_sum<G>(vxy);
+        vxz = group_sum<G>(vxz);
+        vyy = group_sum<G>(vyy);
+        vyz = group_sum<G>(vyz);
+        vzz = group_sum<G>(vzz);
+    }
+
+    if (g == 0 && active) {
+        if (out_f64) {
+            ((double4 *)force)[row] = make_double4(fx, fy, fz, en);
+        } else {
+            ((float4 *)force)[row] = make_float4(fx, fy, fz, en);
+        }
+        if constexpr (VIRIAL) {
+            const float v9[9] = {vxx, vxy, vxz, vxy, vyy, vyz, vxz, vyz, vzz};
+            if (out_f64) {
+                double *o = (double *)virial9 + (size_t)row * 9;
+#pragma unroll
+                for (int c = 0; c < 9; ++c) o[c] = v9[c];
+            } else {
+                float *o = (float *)virial9 + (size_t)row * 9;
+#pragma unroll
+                for (int c = 0; c < 9; ++c) o[c] = v9[c];
+            }
+        }
+    }
+}
+
+template <int KIND, int G, bool VIRIAL, typename IT>
+static int launch_eval_g(const void *nlist, unsigned B, unsigned NN, void *force, void *virial9,
+                         int out_f64, const PotParams &p, hipStream_t stream) {
+    constexpr unsigned rows_per_block = 4 * (64 / G);
+    unsigned grid = (B + rows_per_block - 1) / rows_per_block;
+    hipLaunchKernelGGL((eval_pair_kernel<KIND, G, VIRIAL, IT>), dim3(grid), dim3(256), 0, stream,
+                       (const typename Vec4<IT>::type *)nlist, B, NN, force, virial9, out_f64, p);
+    return check_launch("eval_pair_kernel");
+}
+
+// lanes per particle row: 8 slots per lane where NN allows (NN=128 -> 16 lanes)
+static int pick_group(unsigned NN) {
+    if (NN >= 128) return 16;
+    if (NN >= 64) return 8;
+    return 4;
+}
+
+template <int KIND, bool VIRIAL, typename IT>
+static int launch_eval_k(const void *nlist, unsigned B, unsigned NN, void *force, void *virial9,
+                         int out_f64, const PotParams &p, hipStream_t stream) {
+    switch (pick_group(NN)) {
+    case 16: return launch_eval_g<KIND, 16, VIRIAL, IT>(nlist, B, NN, force, virial9, out_f64, p, stream);
+    case 8: return launch_eval_g<KIND, 8, VIRIAL, IT>(nlist, B, NN, force, virial9, out_f64, p, stream);
+    default: return launch_eval_g<KIND, 4, VIRIAL, IT>(nlist, B, NN, force, virial9, out_f64, p, stream);
+    }
+}
+
+template <int KIND>
+static int launch_eval(const void *nlist, int in_dtype, unsigned B, unsigned NN, void *force,
+                       void *virial9, int out_f64, const PotParams &p, hipStream_t stream) {
+    if (in_dtype == HTF_F32) {
+        return virial9 ? launch_eval_k<KIND, true, float>(nlist, B, NN, force, virial9, out_f64, p, stream)
+                       : launch_eval_k<KIND, false, float>(nlist, B, NN, force, virial9, out_f64, p, stream);
+    }
+    return virial9 ? launch_eval_k<KIND, true, double>(nlist, B, NN, force, virial9, out_f64, p, stream)
+                   : launch_eval_k<KIND, false, double>(nlist, B, NN, force, virial9, out_f64, p, stream);
+}
+
+int eval_pair_dispatch(const PotParams &p, const void *nlist, int in_dtype, unsigned B, unsigned NN,
+                       void *force, int force_dtype, void *virial9, hipStream_t stream) {
+    const int out_f64 = force_dtype == HTF_F64;
+    switch (p.kind) {
+    case HTF_POT_LJ: return launch_eval<HTF_POT_LJ>(nlist, in_dtype, B, NN, force, virial9, out_f64, p, stream);
+    case HTF_POT_WCA: return launch_eval<HTF_POT_WCA>(nlist, in_dtype, B, NN, force, virial9, out_f64, p, stream);
+    case HTF_POT_RINV_POLY: return launch_eval<HTF_POT_RINV_POLY>(nlist, in_dtype, B, NN, force, virial9, out_f64, p, stream);
+    case HTF_POT_SIMPLE: return launch_eval<HTF_POT_SIMPLE>(nlist, in_dtype, B, NN, force, virial9, out_f64, p, stream);
+    default:
+        set_error("eval_pair_dispatch: potential kind %d is not a closed-form pair potential", p.kind);
+        return HTF_ERR_INVALID;
+    }
+}
+
+// ---- small elementwise companions -------------------------------------------------
+
+template <typename IT>
+__global__ __launch_bounds__(256) void nlist_rinv_kernel(const typename Vec4<IT>::type *__restrict__ nlist,
+                                                         size_t n, float *__restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        float4 v = load_slot<IT>(nlist + i);
+        out[i] = rinv_fwd(v.x, v.y, v.z).s;
+    }
+}
+
+// simmodel.py:214-219: max over rows of the number of slots with dx > 0
+template <typename IT, int G>
+__global__ __launch_bounds__(256) void check_nlist_kernel(const typename Vec4<IT>::type *__restrict__ nlist,
+                                                          unsigned B, unsigned NN, unsigned *__restrict__ out) {
+    constexpr int RPW = 64 / G;
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned g = lane % G, sub = lane / G;
+    const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const unsigned row = wave * RPW + sub;
+    unsigned cnt = 0;
+    if (row < B) {
+        const typename Vec4<IT>::type *rp = nlist + (size_t)row * NN;
+        for (unsigned j = g; j < NN; j += G) cnt += (rp[j].x > (IT)0) ? 1u : 0u;
+    }
+    cnt = group_sum_u<G>(cnt);
+    // wave max, then one atomic per wave
+    for (int m = G; m < 64; m <<= 1) {
+        unsigned o = (unsigned)__shfl_xor((int)cnt, m);
+        cnt = o > cnt ? o : cnt;
+    }
+    if (lane == 0 && cnt > 0) atomicMax(out, cnt);
+}
+
+} // namespace htf
+
+extern "C" int htf_nlist_rinv(const void *d_nlist, int nlist_dtype, unsigned B, unsigned NN, float *d_out,
+                              htf_stream stream) {
+    using namespace htf;
+    HTF_REQUIRE(d_nlist && d_out, "htf_nlist_rinv: null pointer");
+    HTF_REQUIRE(nlist_dtype == HTF_F32 || nlist_dtype == HTF_F64, "htf_nlist_rinv: bad dtype %d", nlist_dtype);
+    size_t n = (size_t)B * NN;
+    if (n == 0) return HTF_OK;
+    unsigned grid = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    if (nlist_dtype == HTF_F32)
+        hipLaunchKernelGGL((nlist_rinv_kernel<float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float4 *)d_nlist, n, d_out);
+    else
+        hipLaunchKernelGGL((nlist_rinv_kernel<double>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const double4 *)d_nlist, n, d_out);
+    return check_launch("nlist_rinv_kernel");
+}
+
+extern "C" int htf_check_nlist(const void *d_nlist, int nlist_dtype, unsigned B, unsigned NN, unsigned *d_out,
+                               htf_stream stream) {
+    using namespace htf;
+    HTF_REQUIRE(d_nlist && d_out, "htf_check_nlist: null pointer");
+    HTF_REQUIRE(nlist_dtype == HTF_F32 || nlist_dtype == HTF_F64, "htf_check_nlist: bad dtype %d", nlist_dtype);
+    if (B == 0 || NN == 0) return HTF_OK;
+    constexpr int G = 16;
+    constexpr unsigned rows_per_block = 4 * (64 / G);
+    unsigned grid = (B + rows_per_block - 1) / rows_per_block;
+    if (nlist_dtype == HTF_F32)
+        hipLaunchKernelGGL((check_nlist_kernel<float, G>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float4 *)d_nlist, B, NN, d_out);
+    else
+        hipLaunchKernelGGL((check_nlist_kernel<double, G>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const double4 *)d_nlist, B, NN, d_out);
+    return check_launch("check_nlist_kernel");
+}

@@ -1,0 +1,75 @@
+// Internal helpers shared by the HIP translation units (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "htf_amd.h"
+
+namespace htf {
+
+void set_error(const char *fmt, ...);
+
+#define HTF_CHECK_HIP(expr)                                                              \
+    do {                                                                                 \
+        hipError_t _e = (expr);                                                          \
+        if (_e != hipSuccess) {                                                          \
+            htf::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return HTF_ERR_DEVICE;                                                       \
+        }                                                                                \
+    } while (0)
+
+#define HTF_REQUIRE(cond, ...)                                                           \
+    do {                                                                                 \
+        if (!(cond)) {                                                                   \
+            htf::set_error(__VA_ARGS__);                                                 \
+            return HTF_ERR_INVALID;                                                      \
+        }                                                                                \
+    } while (0)
+
+inline int check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("launch of %s failed: %s", what, hipGetErrorString(e));
+        return HTF_ERR_DEVICE;
+    }
+    return HTF_OK;
+}
+
+// reference constants: simmodel.py:627-628 (nlist_rinv), :581 (safe_norm default)
+constexpr float kRinvDelta = 3e-6f;
+constexpr float kNormDelta = 1e-7f;
+
+template <typename T> struct Vec4;
+template <> struct Vec4<float> { using type = float4; };
+template <> struct Vec4<double> { using type = double4; };
+
+// -------- wave64 lane-group reductions (G consecutive lanes, G a power of two) --------
+// DPP row operations cover groups up to 16 lanes without touching LDS; 32/64 need
+// the cross-row bpermute path.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+    static_assert(G >= 1 && G <= 64 && (G & (G - 1)) == 0, "G must be a power of two <= 64");
+    if constexpr (G >= 2) v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+    if constexpr (G >= 4) v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+    if constexpr (G >= 8) v += dpp_mov<0x141>(v);  // row_half_mirror
+    if constexpr (G >= 16) v += dpp_mov<0x140>(v); // row_mirror
+    if constexpr (G >= 32) v += __shfl_xor(v, 16);
+    if constexpr (G >= 64) v += __shfl_xor(v, 32);
+    return v;
+}
+
+template <int G>
+__device__ __forceinline__ unsigned group_sum_u(unsigned v) {
+#pragma unroll
+    for (int m = 1; m < G; m <<= 1) v += (unsigned)__shfl_xor((int)v, m);
+    return v;
+}
+
+} // namespace htf

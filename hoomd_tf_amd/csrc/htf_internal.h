@@ -1,0 +1,25 @@
+// Cross-translation-unit declarations (internal; not part of the ABI).
+#pragma once
+#include "htf_common.h"
+
+namespace htf {
+
+struct PotParams {
+    int kind;
+    float sigma;   // WCA sigma (fp32, as the Keras weight is)
+    float wca_cut; // fp32(sigma) * fp32(2^(1/3))   layers.py:97
+    int n_terms;
+    float coef[HTF_MAX_POLY_TERMS];
+    int power[HTF_MAX_POLY_TERMS];
+};
+
+int eval_pair_dispatch(const PotParams &p, const void *nlist, int in_dtype, unsigned B, unsigned NN,
+                       void *force, int force_dtype, void *virial9, hipStream_t stream);
+
+struct MlpDevice;
+int mlp_create(const htf_potential_desc *d, MlpDevice **out);
+void mlp_destroy(MlpDevice *m);
+int mlp_eval(const MlpDevice *m, const void *nlist, int in_dtype, unsigned B, unsigned NN, void *force,
+             int force_dtype, hipStream_t stream);
+
+} // namespace htf

@@ -1,0 +1,188 @@
+// Pair-vector build: HOOMD ragged index neighbor list -> dense zero-padded
+// [B, NN, 4] pair vectors (dx, dy, dz, type_j).
+//
+// Replaces htf_gpu_reshape_nlist_kernel (TensorflowCompute.cu:80-151, thread per
+// particle, uncoalesced stride-NN stores) and follows the CPU prepareNeighbors
+// semantics (TensorflowCompute.cc:303-374): zero fill, keep unless rsq > rcut^2,
+// slot = (slot + 1) % NN so that on overflow the LAST writer wins.
+//
+// MI355X mapping: one wave64 per particle.  Lanes take consecutive neighbor indices
+// (coalesced 256-B index reads), gather pos[k] (2 MB table, L2/Infinity-Cache
+// resident), apply the minimum image and compact the survivors with a wave ballot +
+// mbcnt prefix, so kept neighbors land in consecutive float4 slots (coalesced
+// stores).  The zero tail is written by the same wave: no separate memset pass.
+//
+// Compiled with -ffp-contract=off: the arithmetic is then op-for-op the oracle's
+// (oracle/htf_oracle.py:min_image / prepare_neighbors), so pair vectors are
+// bit-exact, not merely within tolerance.
+#include "htf_common.h"
+
+namespace htf {
+
+template <typename T>
+struct BoxT {
+    T L[3], Linv[3], xy, xz, yz;
+    int periodic[3];
+};
+
+template <typename T> __device__ __forceinline__ T rint_t(T x);
+template <> __device__ __forceinline__ float rint_t<float>(float x) { return rintf(x); }
+template <> __device__ __forceinline__ double rint_t<double>(double x) { return rint(x); }
+
+// HOOMD-blue 2.x BoxDim::minImage, device (rint) form.
+template <typename T>
+__device__ __forceinline__ void min_image(T &x, T &y, T &z, const BoxT<T> &b) {
+    if (b.periodic[2]) {
+        T img = rint_t<T>(z * b.Linv[2]);
+        z -= b.L[2] * img;
+        y -= b.L[2] * b.yz * img;
+        x -= b.L[2] * b.xz * img;
+    }
+    if (b.periodic[1]) {
+        T img = rint_t<T>(y * b.Linv[1]);
+        y -= b.L[1] * img;
+        x -= b.L[1] * b.xy * img;
+    }
+    if (b.periodic[0]) {
+        T img = rint_t<T>(x * b.Linv[0]);
+        x -= b.L[0] * img;
+    }
+}
+
+// HOOMD __scalar_as_int: the int type id lives in the (low) 32 bits of pos.w
+__device__ __forceinline__ int scalar_as_int(float w) { return __float_as_int(w); }
+__device__ __forceinline__ int scalar_as_int(double w) { return (int)(__double_as_longlong(w) & 0xffffffffll); }
+
+constexpr int kChunk = 4; // index loads hoisted per lane: covers n_neigh <= 256 in one trip
+
+template <typename PT, typename DT, bool REPLAY>
+__device__ __forceinline__ unsigned sweep(typename Vec4<DT>::type *__restrict__ row,
+                                          const typename Vec4<PT>::type *__restrict__ pos,
+                                          const unsigned *__restrict__ nl, unsigned nn,
+                                          const typename Vec4<PT>::type pi, const BoxT<PT> &box,
+                                          PT rmaxsq, unsigned NN, unsigned lane, unsigned lo) {
+    using PV = typename Vec4<PT>::type;
+    using DV = typename Vec4<DT>::type;
+    unsigned Q = 0;
+    for (unsigned base = 0; base < nn; base += 64 * kChunk) {
+        unsigned k[kChunk];
+        PV pk[kChunk];
+#pragma unroll
+        for (int t = 0; t < kChunk; ++t) {
+            unsigned j = base + t * 64 + lane;
+            k[t] = nl[j < nn ? j : nn - 1];
+        }
+#pragma unroll
+        for (int t = 0; t < kChunk; ++t) pk[t] = pos[k[t]];
+#pragma unroll
+        for (int t = 0; t < kChunk; ++t) {
+            if (base + t * 64 >= nn) break; // wave-uniform
+            unsigned j = base + t * 64 + lane;
+            PT dx = pk[t].x - pi.x, dy = pk[t].y - pi.y, dz = pk[t].z - pi.z;
+            min_image<PT>(dx, dy, dz, box);
+            PT rsq = dx * dx + dy * dy + dz * dz;
+            bool keep = (j < nn) && !(rsq > rmaxsq);
+            unsigned long long m = __ballot(keep);
+            unsigned q = Q + __popcll(m & ((1ull << lane) - 1ull));
+            Q += __popcll(m);
+            DV out;
+            out.x = (DT)dx; out.y = (DT)dy; out.z = (DT)dz;
+            out.w = (DT)scalar_as_int(pk[t].w);
+            if constexpr (!REPLAY) {
+                if (keep && q < NN) row[q] = out;
+            } else {
+                if (keep && q >= lo) row[q % NN] = out;
+            }
+        }
+    }
+    return Q;
+}
+
+template <typename PT, typename DT>
+__global__ __launch_bounds__(256) void build_pair_vectors_kernel(
+    typename Vec4<DT>::type *__restrict__ dest, const typename Vec4<PT>::type *__restrict__ pos,
+    unsigned N, unsigned NN, unsigned offset, unsigned batch, BoxT<PT> box,
+    const unsigned *__restrict__ n_neigh, const unsigned *__restrict__ nlist,
+    const unsigned *__restrict__ head_list, PT rmaxsq, unsigned *__restrict__ max_count) {
+    using DV = typename Vec4<DT>::type;
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned w = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (w >= batch) return;
+    const unsigned idx = w + offset;
+    if (idx >= N) return;
+    const unsigned nn = n_neigh[idx];
+    const unsigned *nl = nlist + head_list[idx];
+    const auto pi = pos[idx];
+    DV *row = dest + (size_t)w * NN;
+
+    unsigned Q = nn ? sweep<PT, DT, false>(row, pos, nl, nn, pi, box, rmaxsq, NN, lane, 0u) : 0u;
+
+    DV zero;
+    zero.x = zero.y = zero.z = zero.w = (DT)0;
+    for (unsigned s = (Q < NN ? Q : NN) + lane; s < NN; s += 64) row[s] = zero;
+
+    if (Q > NN) {
+        // Overflow (an error condition upstream, caught by check_nlist): reproduce the
+        // reference's wrap exactly.  Entry q lands in slot q % NN and survives iff no
+        // later entry maps to the same slot, i.e. q >= Q - NN.  Slots already hold
+        // entries q < NN; replay, in order, the survivors with q >= max(NN, Q - NN)
+        // after the first sweep's stores have retired.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned lo = Q - NN > NN ? Q - NN : NN;
+        sweep<PT, DT, true>(row, pos, nl, nn, pi, box, rmaxsq, NN, lane, lo);
+    }
+    if (max_count != nullptr && lane == 0) atomicMax(max_count, Q);
+}
+
+template <typename PT, typename DT>
+static int launch_build(void *dest, const void *pos, unsigned N, unsigned NN, unsigned offset,
+                        unsigned batch, const htf_box *hb, const unsigned *n_neigh,
+                        const unsigned *nlist, const unsigned *head_list, double rmax,
+                        unsigned *max_count, hipStream_t stream) {
+    BoxT<PT> b;
+    for (int d = 0; d < 3; ++d) {
+        b.L[d] = (PT)hb->hi[d] - (PT)hb->lo[d];
+        b.Linv[d] = (PT)1 / b.L[d];
+        b.periodic[d] = hb->periodic[d];
+    }
+    b.xy = (PT)hb->tilt[0];
+    b.xz = (PT)hb->tilt[1];
+    b.yz = (PT)hb->tilt[2];
+    PT rc = (PT)rmax;
+    PT rmaxsq = rc * rc;
+    const unsigned waves_per_block = 4;
+    unsigned grid = (batch + waves_per_block - 1) / waves_per_block;
+    hipLaunchKernelGGL((build_pair_vectors_kernel<PT, DT>), dim3(grid), dim3(64 * waves_per_block), 0, stream,
+                       (typename Vec4<DT>::type *)dest, (const typename Vec4<PT>::type *)pos, N, NN,
+                       offset, batch, b, n_neigh, nlist, head_list, rmaxsq, max_count);
+    return check_launch("build_pair_vectors_kernel");
+}
+
+} // namespace htf
+
+extern "C" int htf_build_pair_vectors(void *dest, int dest_dtype, const void *d_pos, int pos_dtype,
+                                      unsigned N, unsigned NN, unsigned offset, unsigned batch_size,
+                                      unsigned n_ghost, const htf_box *box, const unsigned *d_n_neigh,
+                                      const unsigned *d_nlist, const unsigned *d_head_list, double rmax,
+                                      unsigned *d_max_count, htf_stream stream) {
+    using namespace htf;
+    (void)n_ghost; // ghosts are addressed through the index list (k >= N); nothing to size
+    HTF_REQUIRE(dest && d_pos && d_n_neigh && d_nlist && d_head_list && box, "htf_build_pair_vectors: null pointer");
+    HTF_REQUIRE(NN > 0, "htf_build_pair_vectors: NN must be > 0");
+    HTF_REQUIRE(offset <= N && batch_size <= N - offset, "htf_build_pair_vectors: batch [%u, %u) exceeds N=%u", offset, offset + batch_size, N);
+    HTF_REQUIRE(rmax > 0, "htf_build_pair_vectors: rmax must be > 0");
+    for (int d = 0; d < 3; ++d)
+        HTF_REQUIRE(box->hi[d] > box->lo[d], "htf_build_pair_vectors: empty box along %d", d);
+    if (batch_size == 0) return HTF_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (pos_dtype == HTF_F32 && dest_dtype == HTF_F32)
+        return launch_build<float, float>(dest, d_pos, N, NN, offset, batch_size, box, d_n_neigh, d_nlist, d_head_list, rmax, d_max_count, s);
+    if (pos_dtype == HTF_F64 && dest_dtype == HTF_F32)
+        return launch_build<double, float>(dest, d_pos, N, NN, offset, batch_size, box, d_n_neigh, d_nlist, d_head_list, rmax, d_max_count, s);
+    if (pos_dtype == HTF_F64 && dest_dtype == HTF_F64)
+        return launch_build<double, double>(dest, d_pos, N, NN, offset, batch_size, box, d_n_neigh, d_nlist, d_head_list, rmax, d_max_count, s);
+    if (pos_dtype == HTF_F32 && dest_dtype == HTF_F64)
+        return launch_build<float, double>(dest, d_pos, N, NN, offset, batch_size, box, d_n_neigh, d_nlist, d_head_list, rmax, d_max_count, s);
+    set_error("htf_build_pair_vectors: bad dtype (%d, %d)", pos_dtype, dest_dtype);
+    return HTF_ERR_INVALID;
+}

@@ -1,0 +1,224 @@
+// HOOMD stand-in kernels (include/htf_standin.h): leapfrog NVE step, displacement
+// check, binned neighbor search.  Outside the drop-in boundary; exists so the force
+// path can be driven and timed as MD without HOOMD-blue in the image.
+#include "htf_common.h"
+#include "htf_standin.h"
+
+namespace htf {
+
+template <typename T>
+struct SBox {
+    T lo[3], L[3], Linv[3];
+    int periodic[3];
+};
+
+template <typename T>
+static SBox<T> make_sbox(const htf_box *b) {
+    SBox<T> s;
+    for (int d = 0; d < 3; ++d) {
+        s.lo[d] = (T)b->lo[d];
+        s.L[d] = (T)b->hi[d] - (T)b->lo[d];
+        s.Linv[d] = (T)1 / s.L[d];
+        s.periodic[d] = b->periodic[d];
+    }
+    return s;
+}
+
+template <typename T>
+__device__ __forceinline__ T wrap1(T x, T lo, T L, T Linv, int periodic) {
+    if (!periodic) return x;
+    T f = floor((x - lo) * Linv);
+    return x - f * L;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void nve_step_kernel(typename Vec4<T>::type *__restrict__ pos,
+                                                       typename Vec4<T>::type *__restrict__ vel,
+                                                       const typename Vec4<T>::type *__restrict__ force,
+                                                       unsigned N, T dt, SBox<T> b) {
+    unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    auto p = pos[i];
+    auto v = vel[i];
+    auto f = force[i];
+    v.x += dt * f.x;
+    v.y += dt * f.y;
+    v.z += dt * f.z;
+    p.x = wrap1<T>(p.x + dt * v.x, b.lo[0], b.L[0], b.Linv[0], b.periodic[0]);
+    p.y = wrap1<T>(p.y + dt * v.y, b.lo[1], b.L[1], b.Linv[1], b.periodic[1]);
+    p.z = wrap1<T>(p.z + dt * v.z, b.lo[2], b.L[2], b.Linv[2], b.periodic[2]);
+    pos[i] = p;
+    vel[i] = v;
+}
+
+template <typename T>
+__device__ __forceinline__ T mimg(T d, T L, T Linv, int periodic) {
+    return periodic ? d - L * rint(d * Linv) : d;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void max_disp_kernel(const typename Vec4<T>::type *__restrict__ pos,
+                                                       const typename Vec4<T>::type *__restrict__ ref, unsigned N,
+                                                       SBox<T> b, float *__restrict__ out) {
+    unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    float d2 = 0.f;
+    if (i < N) {
+        auto p = pos[i];
+        auto r = ref[i];
+        T dx = mimg<T>(p.x - r.x, b.L[0], b.Linv[0], b.periodic[0]);
+        T dy = mimg<T>(p.y - r.y, b.L[1], b.Linv[1], b.periodic[1]);
+        T dz = mimg<T>(p.z - r.z, b.L[2], b.Linv[2], b.periodic[2]);
+        d2 = (float)(dx * dx + dy * dy + dz * dz);
+    }
+    for (int m = 1; m < 64; m <<= 1) d2 = fmaxf(d2, __shfl_xor(d2, m));
+    if ((threadIdx.x & 63) == 0) atomicMax((unsigned *)out, __float_as_uint(d2)); // d2 >= 0: uint order == float order
+}
+
+template <typename T>
+__device__ __forceinline__ int cell_coord(T x, T lo, T Linv, int n) {
+    int c = (int)floor((x - lo) * Linv * (T)n);
+    return c < 0 ? 0 : (c >= n ? n - 1 : c);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cell_index_kernel(const typename Vec4<T>::type *__restrict__ pos, unsigned Ntot,
+                                                         SBox<T> b, int nx, int ny, int nz,
+                                                         unsigned *__restrict__ cell_of) {
+    unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Ntot) return;
+    auto p = pos[i];
+    int cx = cell_coord<T>(p.x, b.lo[0], b.Linv[0], nx);
+    int cy = cell_coord<T>(p.y, b.lo[1], b.Linv[1], ny);
+    int cz = cell_coord<T>(p.z, b.lo[2], b.Linv[2], nz);
+    cell_of[i] = (unsigned)((cz * ny + cy) * nx + cx);
+}
+
+// one 16-lane group per particle: lanes stride over the members of each of the 27
+// neighbor cells; hits are compacted with a ballot restricted to the group.
+template <typename T>
+__global__ __launch_bounds__(256) void build_nlist_kernel(const typename Vec4<T>::type *__restrict__ pos, unsigned N,
+                                                          SBox<T> b, T rl2, int nx, int ny, int nz,
+                                                          const unsigned *__restrict__ order,
+                                                          const unsigned *__restrict__ cell_start, unsigned pitch,
+                                                          unsigned *__restrict__ n_neigh, unsigned *__restrict__ head_list,
+                                                          unsigned *__restrict__ nlist, unsigned *__restrict__ max_neigh) {
+    constexpr int G = 16;
+    const unsigned lane = threadIdx.x & 63u, g = lane % G, sub = lane / G;
+    const unsigned i = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * (64 / G) + sub;
+    const bool active = i < N;
+    const auto pi = pos[active ? i : 0];
+    const int cx = cell_coord<T>(pi.x, b.lo[0], b.Linv[0], nx);
+    const int cy = cell_coord<T>(pi.y, b.lo[1], b.Linv[1], ny);
+    const int cz = cell_coord<T>(pi.z, b.lo[2], b.Linv[2], nz);
+    const unsigned long long gmask = 0xFFFFull << (sub * G);
+    unsigned count = 0;
+    unsigned *row = nlist + (size_t)(active ? i : 0) * pitch;
+    // 27-cell walk; a dimension with a single cell (thin / 2-D boxes) contributes offset 0 only.
+    // Out-of-range cells of a non-periodic dimension are visited with an empty range rather
+    // than skipped, so every lane of the wave runs the same trip counts (ballot/shfl safe).
+    const int x0 = nx >= 3 ? -1 : 0, x1 = nx >= 3 ? 1 : 0;
+    const int y0 = ny >= 3 ? -1 : 0, y1 = ny >= 3 ? 1 : 0;
+    const int z0 = nz >= 3 ? -1 : 0, z1 = nz >= 3 ? 1 : 0;
+    for (int dz = z0; dz <= z1; ++dz)
+        for (int dy = y0; dy <= y1; ++dy)
+            for (int dx = x0; dx <= x1; ++dx) {
+                int ax = cx + dx, ay = cy + dy, az = cz + dz;
+                bool skip = false;
+                if (ax < 0) { skip |= !b.periodic[0]; ax += nx; } else if (ax >= nx) { skip |= !b.periodic[0]; ax -= nx; }
+                if (ay < 0) { skip |= !b.periodic[1]; ay += ny; } else if (ay >= ny) { skip |= !b.periodic[1]; ay -= ny; }
+                if (az < 0) { skip |= !b.periodic[2]; az += nz; } else if (az >= nz) { skip |= !b.periodic[2]; az -= nz; }
+                const unsigned c = (unsigned)((az * ny + ay) * nx + ax);
+                const unsigned beg = cell_start[c], end = skip ? beg : cell_start[c + 1];
+                // all lanes of a group share beg/end; groups in one wave may differ, so
+                // iterate to the wave-wide maximum trip count to keep ballots converged
+                unsigned len = end - beg, maxlen = len;
+                for (int m = G; m < 64; m <<= 1) {
+                    unsigned o = (unsigned)__shfl_xor((int)maxlen, m);
+                    maxlen = o > maxlen ? o : maxlen;
+                }
+                for (unsigned t = 0; t < maxlen; t += G) {
+                    unsigned m_idx = t + g;
+                    bool hit = false;
+                    unsigned k = 0;
+                    if (active && m_idx < len) {
+                        k = order[beg + m_idx];
+                        auto pk = pos[k];
+                        T ddx = mimg<T>(pk.x - pi.x, b.L[0], b.Linv[0], b.periodic[0]);
+                        T ddy = mimg<T>(pk.y - pi.y, b.L[1], b.Linv[1], b.periodic[1]);
+                        T ddz = mimg<T>(pk.z - pi.z, b.L[2], b.Linv[2], b.periodic[2]);
+                        hit = (k != i) && (ddx * ddx + ddy * ddy + ddz * ddz <= rl2);
+                    }
+                    unsigned long long bal = __ballot(hit) & gmask;
+                    unsigned rank = count + __popcll(bal & ((1ull << lane) - 1ull));
+                    if (hit && rank < pitch) row[rank] = k;
+                    count += __popcll(bal);
+                }
+            }
+    if (active && g == 0) {
+        n_neigh[i] = count < pitch ? count : pitch;
+        head_list[i] = i * pitch;
+        atomicMax(max_neigh, count);
+    }
+}
+
+} // namespace htf
+
+using namespace htf;
+
+extern "C" int htfs_nve_step(void *d_pos, void *d_vel, const void *d_force, int dtype, unsigned N, double dt,
+                             const htf_box *box, htf_stream stream) {
+    HTF_REQUIRE(d_pos && d_vel && d_force && box, "htfs_nve_step: null pointer");
+    if (N == 0) return HTF_OK;
+    unsigned grid = (N + 255) / 256;
+    if (dtype == HTF_F32)
+        hipLaunchKernelGGL((nve_step_kernel<float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (float4 *)d_pos, (float4 *)d_vel, (const float4 *)d_force, N, (float)dt, make_sbox<float>(box));
+    else
+        hipLaunchKernelGGL((nve_step_kernel<double>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (double4 *)d_pos, (double4 *)d_vel, (const double4 *)d_force, N, dt, make_sbox<double>(box));
+    return check_launch("nve_step_kernel");
+}
+
+extern "C" int htfs_max_displacement2(const void *d_pos, const void *d_ref, int dtype, unsigned N, const htf_box *box,
+                                      float *d_out, htf_stream stream) {
+    HTF_REQUIRE(d_pos && d_ref && box && d_out, "htfs_max_displacement2: null pointer");
+    if (N == 0) return HTF_OK;
+    unsigned grid = (N + 255) / 256;
+    if (dtype == HTF_F32)
+        hipLaunchKernelGGL((max_disp_kernel<float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float4 *)d_pos, (const float4 *)d_ref, N, make_sbox<float>(box), d_out);
+    else
+        hipLaunchKernelGGL((max_disp_kernel<double>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const double4 *)d_pos, (const double4 *)d_ref, N, make_sbox<double>(box), d_out);
+    return check_launch("max_disp_kernel");
+}
+
+extern "C" int htfs_cell_index(const void *d_pos, int dtype, unsigned Ntot, const htf_box *box, const int *ncell3,
+                               unsigned *d_cell_of, htf_stream stream) {
+    HTF_REQUIRE(d_pos && box && ncell3 && d_cell_of, "htfs_cell_index: null pointer");
+    if (Ntot == 0) return HTF_OK;
+    unsigned grid = (Ntot + 255) / 256;
+    if (dtype == HTF_F32)
+        hipLaunchKernelGGL((cell_index_kernel<float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float4 *)d_pos, Ntot, make_sbox<float>(box), ncell3[0], ncell3[1], ncell3[2], d_cell_of);
+    else
+        hipLaunchKernelGGL((cell_index_kernel<double>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const double4 *)d_pos, Ntot, make_sbox<double>(box), ncell3[0], ncell3[1], ncell3[2], d_cell_of);
+    return check_launch("cell_index_kernel");
+}
+
+extern "C" int htfs_build_nlist(const void *d_pos, int dtype, unsigned N, unsigned Ntot, const htf_box *box,
+                                double r_list, const int *ncell3, const unsigned *d_order,
+                                const unsigned *d_cell_start, unsigned pitch, unsigned *d_n_neigh,
+                                unsigned *d_head_list, unsigned *d_nlist, unsigned *d_max_neigh, htf_stream stream) {
+    (void)Ntot;
+    HTF_REQUIRE(d_pos && box && ncell3 && d_order && d_cell_start && d_n_neigh && d_head_list && d_nlist && d_max_neigh,
+                "htfs_build_nlist: null pointer");
+    HTF_REQUIRE(pitch > 0, "htfs_build_nlist: pitch must be > 0");
+    for (int d = 0; d < 3; ++d) {
+        double w = (box->hi[d] - box->lo[d]) / ncell3[d];
+        HTF_REQUIRE(ncell3[d] == 1 || (ncell3[d] >= 3 && w >= r_list),
+                    "htfs_build_nlist: need 1 cell or >= 3 cells of width >= r_list along %d (got %d cells of %g, r_list %g)", d, ncell3[d], w, r_list);
+    }
+    if (N == 0) return HTF_OK;
+    unsigned grid = (N + 15) / 16; // 4 waves x 4 particles per block
+    if (dtype == HTF_F32)
+        hipLaunchKernelGGL((build_nlist_kernel<float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float4 *)d_pos, N, make_sbox<float>(box), (float)(r_list * r_list), ncell3[0], ncell3[1], ncell3[2], d_order, d_cell_start, pitch, d_n_neigh, d_head_list, d_nlist, d_max_neigh);
+    else
+        hipLaunchKernelGGL((build_nlist_kernel<double>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const double4 *)d_pos, N, make_sbox<double>(box), r_list * r_list, ncell3[0], ncell3[1], ncell3[2], d_order, d_cell_start, pitch, d_n_neigh, d_head_list, d_nlist, d_max_neigh);
+    return check_launch("build_nlist_kernel");
+}

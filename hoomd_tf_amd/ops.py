@@ -1,0 +1,278 @@
+"""Torch-tensor front of the C ABI: every function takes HOOMD-layout device tensors,
+passes their raw pointers (zero-copy) and the current HIP stream to libhtf_amd.so and
+returns torch tensors.  torch is plumbing here (device memory + streams); all
+arithmetic happens in the HIP kernels.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import lib, check
+
+
+def _dt(t):
+    if t.dtype == torch.float32:
+        return _lib.HTF_F32
+    if t.dtype == torch.float64:
+        return _lib.HTF_F64
+    raise ValueError("expected a float32/float64 tensor, got %s" % t.dtype)
+
+
+def _stream(t):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _dev(t, name, dtype=None):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise ValueError("%s must be a CUDA/HIP device tensor (the evaluator has no CPU path)" % name)
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+    if dtype is not None and t.dtype != dtype:
+        raise ValueError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    return t
+
+
+def _u32(t, name):
+    _dev(t, name)
+    if t.dtype not in (torch.int32, torch.uint32):
+        raise ValueError("%s must be int32/uint32 (HOOMD unsigned int), got %s" % (name, t.dtype))
+    return t
+
+
+class Potential:
+    """Owns an ``htf_potential`` handle (device copies of any weights)."""
+
+    def __init__(self, kind, sigma=0.0, coefs=(), powers=(), mlp=None, rbf=(0.0, 0.0),
+                 activation="linear", mlp_precision="fp32"):
+        d = _lib.PotentialDesc()
+        d.kind = kind
+        d.sigma = float(sigma)
+        d.n_terms = len(coefs)
+        if len(coefs) != len(powers):
+            raise ValueError("coefs and powers differ in length")
+        if len(coefs) > _lib.MAX_POLY_TERMS:
+            raise ValueError("at most %d polynomial terms" % _lib.MAX_POLY_TERMS)
+        for k, (c, p) in enumerate(zip(coefs, powers)):
+            d.coef[k] = float(c)
+            d.power[k] = int(p)
+        self._keep = []
+        if mlp is not None:
+            ws = [np.ascontiguousarray(mlp[k], dtype=np.float32) for k in ("W1", "b1", "W2", "b2", "W3", "b3")]
+            self._keep = ws
+            d.K, d.H1 = ws[0].shape
+            d.H2 = ws[2].shape[1]
+            if ws[2].shape[0] != d.H1 or ws[4].shape != (d.H2, 1):
+                raise ValueError("inconsistent MLP weight shapes")
+            d.W1, d.b1, d.W2, d.b2, d.W3, d.b3 = (w.ctypes.data for w in ws)
+            d.rbf_low, d.rbf_high = float(rbf[0]), float(rbf[1])
+            d.activation = {"linear": _lib.ACT_LINEAR, None: _lib.ACT_LINEAR, "tanh": _lib.ACT_TANH}[activation]
+            d.mlp_precision = {"fp32": _lib.MLP_FP32, "bf16": _lib.MLP_BF16}[mlp_precision]
+        self.kind = kind
+        self._h = C.c_void_p()
+        check(lib.htf_potential_create(C.byref(d), C.byref(self._h)))
+
+    @property
+    def handle(self):
+        return self._h
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            lib.htf_potential_destroy(h)
+            self._h = None
+
+    # the reference's declarative models
+    @classmethod
+    def lj(cls):
+        return cls(_lib.POT_LJ)
+
+    @classmethod
+    def wca(cls, sigma):
+        return cls(_lib.POT_WCA, sigma=sigma)
+
+    @classmethod
+    def simple(cls):
+        return cls(_lib.POT_SIMPLE)
+
+    @classmethod
+    def rinv_poly(cls, coefs, powers):
+        return cls(_lib.POT_RINV_POLY, coefs=coefs, powers=powers)
+
+    @classmethod
+    def pair_mlp(cls, params, low, high, activation="tanh", precision="fp32"):
+        return cls(_lib.POT_PAIR_MLP, mlp=params, rbf=(low, high), activation=activation,
+                   mlp_precision=precision)
+
+
+def build_pair_vectors(pos, n_neigh, head_list, nlist, box, r_cut, NN, offset=0, batch_size=None,
+                       n_local=None, out=None, out_dtype=torch.float32, max_count=None, periodic=(1, 1, 1)):
+    """prepareNeighbors (TensorflowCompute.cc:303-374): -> [B, NN, 4]."""
+    _dev(pos, "pos")
+    N = int(n_neigh.shape[0]) if n_local is None else int(n_local)
+    B = N - offset if batch_size is None else int(batch_size)
+    if out is None:
+        out = torch.empty((B, NN, 4), dtype=out_dtype, device=pos.device)
+    _dev(out, "out")
+    b = box if isinstance(box, _lib.Box) else _lib.make_box(box, periodic)
+    check(lib.htf_build_pair_vectors(
+        out.data_ptr(), _dt(out), pos.data_ptr(), _dt(pos), N, NN, offset, B, pos.shape[0] - N, C.byref(b),
+        _u32(n_neigh, "n_neigh").data_ptr(), _u32(nlist, "nlist").data_ptr(),
+        _u32(head_list, "head_list").data_ptr(), float(r_cut),
+        max_count.data_ptr() if max_count is not None else None, _stream(pos)))
+    return out
+
+
+def eval_forces(potential, nlist, virial=False, out=None, out_dtype=None, virial_out=None):
+    """SimModel.compute for a declarative potential: nlist [B,NN,4] -> forces [B,4]
+    (fx, fy, fz, energy) and, if ``virial``, the [B,3,3] virial."""
+    _dev(nlist, "nlist")
+    if nlist.dim() != 3 or nlist.shape[2] != 4:
+        raise ValueError("nlist must be [B, NN, 4]")
+    B, NN = int(nlist.shape[0]), int(nlist.shape[1])
+    od = out_dtype or (out.dtype if out is not None else nlist.dtype)
+    if out is None:
+        out = torch.empty((B, 4), dtype=od, device=nlist.device)
+    _dev(out, "out")
+    v = None
+    if virial:
+        v = virial_out if virial_out is not None else torch.empty((B, 3, 3), dtype=out.dtype, device=nlist.device)
+        _dev(v, "virial_out", out.dtype)
+    check(lib.htf_eval_forces(potential.handle, nlist.data_ptr(), _dt(nlist), B, NN, out.data_ptr(), _dt(out),
+                              v.data_ptr() if v is not None else None, _stream(nlist)))
+    return (out, v) if virial else out
+
+
+def add_virial(dest, src9, N, pitch):
+    """receiveVirial (TensorflowCompute.cc:284-301)."""
+    _dev(dest, "dest")
+    _dev(src9, "src9", dest.dtype)
+    check(lib.htf_add_virial(dest.data_ptr(), src9.data_ptr(), _dt(dest), int(N), int(pitch), _stream(dest)))
+    return dest
+
+
+def add_scalar4(dest, src):
+    """sumReferenceForces (TensorflowCompute.cc:250-269)."""
+    _dev(dest, "dest")
+    _dev(src, "src", dest.dtype)
+    check(lib.htf_add_scalar4(dest.data_ptr(), src.data_ptr(), _dt(dest), int(dest.shape[0]), _stream(dest)))
+    return dest
+
+
+def copy_positions(src, offset=0, N=None, unstuff4=True, out_dtype=None):
+    """TFArrayComm::receiveArray (TFArrayComm.h:86-130)."""
+    _dev(src, "src")
+    N = int(src.shape[0]) - offset if N is None else int(N)
+    out = torch.empty((N, 4), dtype=out_dtype or src.dtype, device=src.device)
+    check(lib.htf_copy_positions(out.data_ptr(), _dt(out), src.data_ptr(), _dt(src), int(offset), N,
+                                 1 if unstuff4 else 0, _stream(src)))
+    return out
+
+
+def check_nlist(nlist):
+    """simmodel.py:214-219: max_i sum_j [nlist[i,j,0] > 0] (synchronises)."""
+    _dev(nlist, "nlist")
+    flag = torch.zeros(1, dtype=torch.int32, device=nlist.device)
+    check(lib.htf_check_nlist(nlist.data_ptr(), _dt(nlist), int(nlist.shape[0]), int(nlist.shape[1]),
+                              flag.data_ptr(), _stream(nlist)))
+    return int(flag.item())
+
+
+def nlist_rinv(nlist):
+    """simmodel.py:618-635 -> [B, NN] fp32."""
+    _dev(nlist, "nlist")
+    out = torch.empty(nlist.shape[:2], dtype=torch.float32, device=nlist.device)
+    check(lib.htf_nlist_rinv(nlist.data_ptr(), _dt(nlist), int(nlist.shape[0]), int(nlist.shape[1]),
+                             out.data_ptr(), _stream(nlist)))
+    return out
+
+
+def stuff_types(pos_xyz, types, dtype=torch.float32):
+    """Build a HOOMD position array: w carries the int type id's BITS
+    (ParticleData: __int_as_scalar)."""
+    N = pos_xyz.shape[0]
+    out = torch.zeros((N, 4), dtype=dtype, device=pos_xyz.device)
+    out[:, :3] = pos_xyz.to(dtype)
+    t = types.to(torch.int32).contiguous()
+    if dtype == torch.float32:
+        out[:, 3] = t.view(torch.float32)
+    else:
+        out[:, 3] = t.to(torch.int64).view(torch.float64)
+    return out
+
+
+class Context:
+    """htf_ctx: the TensorflowCompute object (TensorflowCompute.h:75-250)."""
+
+    def __init__(self, r_cut, nneighs, period=1, batch_size=0, scalar_dtype=torch.float32,
+                 check_nlist=False, virial=False, max_n=0, force_mode=_lib.HTF_TF2HOOMD):
+        cfg = _lib.Config(float(r_cut), int(nneighs), int(force_mode), int(period), int(batch_size),
+                          _lib.HTF_F64 if scalar_dtype == torch.float64 else _lib.HTF_F32,
+                          int(bool(check_nlist)), int(bool(virial)), int(max_n))
+        self.cfg = cfg
+        self.scalar_dtype = scalar_dtype
+        self._h = C.c_void_p()
+        self._pot = None
+        check(lib.htf_create(C.byref(cfg), C.byref(self._h)))
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            lib.htf_destroy(h)
+            self._h = None
+
+    def set_potential(self, pot):
+        self._pot = pot  # keep alive: the C side only borrows it
+        check(lib.htf_set_potential(self._h, pot.handle if pot is not None else None))
+
+    def make_arrays(self, pos, n_local, n_neigh, head_list, nlist, box, force, virial=None, virial_pitch=0,
+                    periodic=(1, 1, 1)):
+        a = _lib.HoomdArrays()
+        a.pos = _dev(pos, "pos", self.scalar_dtype).data_ptr()
+        a.N = int(n_local)
+        a.n_ghost = int(pos.shape[0]) - int(n_local)
+        a.n_neigh = _u32(n_neigh, "n_neigh").data_ptr() if n_neigh is not None else None
+        a.nlist = _u32(nlist, "nlist").data_ptr() if nlist is not None else None
+        a.head_list = _u32(head_list, "head_list").data_ptr() if head_list is not None else None
+        a.box = box if isinstance(box, _lib.Box) else _lib.make_box(box, periodic)
+        a.force = _dev(force, "force", self.scalar_dtype).data_ptr()
+        a.virial = _dev(virial, "virial", self.scalar_dtype).data_ptr() if virial is not None else None
+        a.virial_pitch = int(virial_pitch)
+        return a
+
+    def compute_forces(self, timestep, arrays, stream=None):
+        s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        check(lib.htf_compute_forces(self._h, int(timestep), C.byref(arrays), C.c_void_p(s)))
+
+    def profile_enable(self, on=True):
+        """Event-bracket the build and eval scopes (HOOMD Profiler analogue)."""
+        check(lib.htf_profile_enable(self._h, int(bool(on))))
+
+    def profile_read(self):
+        """-> (build_ms_total, eval_ms_total, n_calls) since the last read."""
+        b, e, n = C.c_double(), C.c_double(), C.c_uint()
+        check(lib.htf_profile_read(self._h, C.byref(b), C.byref(e), C.byref(n)))
+        return b.value, e.value, n.value
+
+    def _view(self, ptr, shape, dtype, device):
+        n = int(np.prod(shape))
+        if not ptr or n == 0:
+            return torch.empty(shape, dtype=dtype, device=device)
+        class _Holder:
+            pass
+        h = _Holder()
+        typestr = {torch.float32: "<f4", torch.float64: "<f8"}[dtype]
+        h.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False),
+                                      "version": 2, "strides": None}
+        return torch.as_tensor(h, device=device)
+
+    def nlist_buffer(self, B, device="cuda"):
+        """getNlistBuffer (TensorflowCompute.cc:406): zero-copy [B, NN, 4] fp32 view."""
+        return self._view(lib.htf_get_nlist_buffer(self._h), (B, self.cfg.nneighs, 4), torch.float32, device)
+
+    def positions_buffer(self, B, device="cuda"):
+        return self._view(lib.htf_get_positions_buffer(self._h), (B, 4), torch.float32, device)
+
+    def virial_buffer(self, B, device="cuda"):
+        return self._view(lib.htf_get_virial_buffer(self._h), (B, 9), self.scalar_dtype, device)

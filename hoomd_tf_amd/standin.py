@@ -1,0 +1,176 @@
+"""Stand-in for the slice of HOOMD-blue the force path sits in: particle data in HOOMD
+layout, a binned FULL neighbor list, a leapfrog NVE integrator.
+
+HOOMD-blue is not installable in this image, so ``tfcompute.attach`` binds to these
+objects instead of ``hoomd.context.current``.  Everything here is OUTSIDE the drop-in
+boundary (include/htf_amd.h): with a real HOOMD the plugin shim of INTEGRATION.md
+passes HOOMD's own arrays to the same C entry points.  torch supplies device memory
+and the sort used for cell binning; the search/integration kernels are HIP
+(csrc/standin.hip).
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from ._lib import lib, check
+
+
+def fcc_positions(n_cells, rho):
+    """4*n^3 particles on an fcc lattice at number density rho, box centred on 0."""
+    a = (4.0 / rho) ** (1.0 / 3.0)
+    L = n_cells * a
+    ijk = np.stack(np.meshgrid(*[np.arange(n_cells)] * 3, indexing="ij"), -1).reshape(-1, 3)
+    base = np.array([[0.25, 0.25, 0.25], [0.75, 0.75, 0.25], [0.75, 0.25, 0.75], [0.25, 0.75, 0.75]])
+    pos = ((ijk[:, None, :] + base[None]) * a).reshape(-1, 3) - L / 2
+    return pos, np.array([L, L, L]), a
+
+
+def sc_positions(n_cells, rho):
+    a = (1.0 / rho) ** (1.0 / 3.0)
+    L = n_cells * a
+    ijk = np.stack(np.meshgrid(*[np.arange(n_cells)] * 3, indexing="ij"), -1).reshape(-1, 3)
+    return (ijk + 0.5) * a - L / 2, np.array([L, L, L]), a
+
+
+class System:
+    """ParticleData + BoxDim analogue: HOOMD-layout device arrays.
+
+    pos   Scalar4 [N + n_ghost]  (x, y, z, int type bits in w)
+    vel   Scalar4 [N]            (vx, vy, vz, mass)
+    force Scalar4 [N]            (fx, fy, fz, energy)  -- ForceCompute::m_force
+    virial Scalar [6 * N]        -- ForceCompute::m_virial, pitch N
+    """
+
+    def __init__(self, positions, box_L, types=None, dtype=torch.float32, device="cuda", periodic=(1, 1, 1)):
+        positions = np.asarray(positions, dtype=np.float64)
+        self.N = int(positions.shape[0])
+        self.n_ghost = 0
+        self.dtype = dtype
+        self.device = torch.device(device)
+        L = np.asarray(box_L, dtype=np.float64)
+        self.box3x3 = np.array([-L / 2, L / 2, [0.0, 0.0, 0.0]])
+        self.periodic = tuple(int(p) for p in periodic)
+        self.box = _lib.make_box(self.box3x3, self.periodic)
+        types = np.zeros(self.N, dtype=np.int32) if types is None else np.asarray(types, dtype=np.int32)
+        self.pos = ops.stuff_types(torch.from_numpy(positions).to(self.device),
+                                   torch.from_numpy(types).to(self.device), dtype)
+        self.vel = torch.zeros((self.N, 4), dtype=dtype, device=self.device)
+        self.vel[:, 3] = 1.0
+        self.force = torch.zeros((self.N, 4), dtype=dtype, device=self.device)
+        self.virial = torch.zeros(6 * self.N, dtype=dtype, device=self.device)
+        self.timestep = 0
+
+    @property
+    def scalar_code(self):
+        return _lib.HTF_F64 if self.dtype == torch.float64 else _lib.HTF_F32
+
+    def randomize_velocities(self, kT, seed):
+        g = torch.Generator(device="cpu").manual_seed(int(seed))
+        v = torch.randn((self.N, 3), generator=g, dtype=torch.float64) * math.sqrt(kT)
+        v -= v.mean(dim=0, keepdim=True)
+        self.vel[:, :3] = v.to(self.dtype).to(self.device)
+
+    def positions_numpy(self):
+        return self.pos[: self.N, :3].double().cpu().numpy()
+
+    def types_numpy(self):
+        w = self.pos[: self.N, 3].contiguous()
+        if self.dtype == torch.float32:
+            return w.view(torch.int32).cpu().numpy()
+        return (w.view(torch.int64) & 0xFFFFFFFF).to(torch.int32).cpu().numpy()
+
+
+class CellNlist:
+    """hoomd.md.nlist.cell analogue: FULL neighbor list, fixed pitch head list, rebuilt
+    when any particle has moved more than r_buff / 2 (NeighborList::distanceCheck)."""
+
+    def __init__(self, system, r_cut, r_buff=0.4, pitch=None, check_period=1):
+        self.sys = system
+        self.r_cut = float(r_cut)
+        self.r_buff = float(r_buff)
+        self.check_period = int(check_period)
+        self.pitch = pitch
+        self.n_neigh = self.head_list = self.nlist = None
+        self._ref = None
+        self._disp = torch.zeros(1, dtype=torch.float32, device=system.device)
+        self._max = torch.zeros(1, dtype=torch.int32, device=system.device)
+        self.n_builds = 0
+
+    @property
+    def r_list(self):
+        return self.r_cut + self.r_buff
+
+    def _ncell(self):
+        L = self.sys.box3x3[1] - self.sys.box3x3[0]
+        n = np.floor(L / self.r_list).astype(int)
+        n[n < 3] = 1
+        return n
+
+    def build(self):
+        s = self.sys
+        Ntot = s.N + s.n_ghost
+        n = self._ncell()
+        n3 = (C.c_int * 3)(*[int(x) for x in n])
+        ncell = int(n[0] * n[1] * n[2])
+        stream = C.c_void_p(torch.cuda.current_stream(s.device).cuda_stream)
+        cell_of = torch.empty(Ntot, dtype=torch.int32, device=s.device)
+        check(lib.htfs_cell_index(s.pos.data_ptr(), s.scalar_code, Ntot, C.byref(s.box), C.byref(n3),
+                                  cell_of.data_ptr(), stream))
+        sorted_cells, order = torch.sort(cell_of)
+        order = order.to(torch.int32)
+        counts = torch.bincount(sorted_cells.long(), minlength=ncell)
+        cell_start = torch.zeros(ncell + 1, dtype=torch.int32, device=s.device)
+        cell_start[1:] = torch.cumsum(counts, 0).to(torch.int32)
+        if self.pitch is None:
+            # a sphere of r_list at the mean density, with generous head-room
+            L = s.box3x3[1] - s.box3x3[0]
+            rho = Ntot / float(np.prod(L))
+            dims = int(np.sum(n > 1)) or 3
+            est = rho * (4.0 / 3.0 * math.pi * self.r_list ** 3 if dims == 3 else math.pi * self.r_list ** 2 * L[2])
+            self.pitch = max(8, int(math.ceil(est * 1.5 / 8.0)) * 8)
+        while True:
+            self.n_neigh = torch.empty(s.N, dtype=torch.int32, device=s.device)
+            self.head_list = torch.empty(s.N, dtype=torch.int32, device=s.device)
+            self.nlist = torch.zeros(s.N * self.pitch, dtype=torch.int32, device=s.device)
+            self._max.zero_()
+            check(lib.htfs_build_nlist(s.pos.data_ptr(), s.scalar_code, s.N, Ntot, C.byref(s.box), self.r_list,
+                                       C.byref(n3), order.data_ptr(), cell_start.data_ptr(), self.pitch,
+                                       self.n_neigh.data_ptr(), self.head_list.data_ptr(), self.nlist.data_ptr(),
+                                       self._max.data_ptr(), stream))
+            mx = int(self._max.item())
+            if mx <= self.pitch:
+                break
+            self.pitch = int(math.ceil(mx * 1.2 / 8.0)) * 8
+        self._ref = s.pos[: s.N].clone()
+        self.n_builds += 1
+
+    def needs_update(self):
+        if self._ref is None:
+            return True
+        s = self.sys
+        self._disp.zero_()
+        check(lib.htfs_max_displacement2(s.pos.data_ptr(), self._ref.data_ptr(), s.scalar_code, s.N,
+                                         C.byref(s.box), self._disp.data_ptr(),
+                                         C.c_void_p(torch.cuda.current_stream(s.device).cuda_stream)))
+        return float(self._disp.item()) > (self.r_buff / 2.0) ** 2
+
+    def compute(self, timestep):
+        """NeighborList::compute(timestep): rebuild if the distance check trips."""
+        if self._ref is None or (timestep % self.check_period == 0 and self.needs_update()):
+            self.build()
+
+
+class NVE:
+    """hoomd.md.integrate.nve analogue (leapfrog form, unit mass)."""
+
+    def __init__(self, system, dt):
+        self.sys = system
+        self.dt = float(dt)
+
+    def step(self):
+        s = self.sys
+        check(lib.htfs_nve_step(s.pos.data_ptr(), s.vel.data_ptr(), s.force.data_ptr(), s.scalar_code, s.N,
+                                self.dt, C.byref(s.box), C.c_void_p(torch.cuda.current_stream(s.device).cuda_stream)))

@@ -1,0 +1,217 @@
+/* htf_amd.h -- C ABI of the MI355X-native hoomd-tf force/energy evaluator.
+ *
+ * This is the drop-in boundary (DESIGN.md "Boundary"): plain C,
+ * raw device pointers and sizes, no torch / pybind / HOOMD / TensorFlow types.
+ * Every entry point names the reference interface it replaces (paths relative to
+ * the hoomd-tf v2.4.0 tree).  All device work is enqueued on the caller's
+ * hipStream_t; nothing here synchronises the device.  Caller-owned pointers are
+ * never retained past the call (reference: valid only inside computeForces,
+ * TensorflowCompute.cc:129-216).
+ *
+ * Array layouts are HOOMD-blue 2.x's:
+ *   Scalar4 pos[N + n_ghost]   (x, y, z, w = int type bits)      ParticleData
+ *   unsigned n_neigh[N], head_list[N], nlist[..]   FULL neighbor list
+ *   Scalar4 force[N]           (fx, fy, fz, per-particle energy) ForceCompute::m_force
+ *   Scalar  virial[6 * pitch]  (xx, xy, xz, yy, yz, zz SoA)       ForceCompute::m_virial
+ * Scalar is float or double (htf_dtype); the evaluator computes in fp32 exactly as
+ * the reference model does (simmodel.py:15, tf.cast at :226-227).
+ */
+#ifndef HTF_AMD_H_
+#define HTF_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HTF_AMD_ABI_VERSION 1
+
+/* the library is built with -fvisibility=hidden (as the reference is,
+ * htf/CMakeLists.txt:48); only these entry points are exported */
+#if defined(__GNUC__)
+#define HTF_API __attribute__((visibility("default")))
+#else
+#define HTF_API
+#endif
+
+typedef void *htf_stream; /* hipStream_t */
+
+/* status codes (reference: C++ exceptions / tf.errors, SURVEY 8(b) "Errors") */
+enum htf_status {
+    HTF_OK = 0,
+    HTF_ERR_INVALID = 1,        /* ValueError: bad argument / configuration       */
+    HTF_ERR_DEVICE = 2,         /* RuntimeError: HIP runtime failure               */
+    HTF_ERR_NLIST_OVERFLOW = 3, /* tf InvalidArgumentError 'Neighbor list is full!' simmodel.py:214-224 */
+    HTF_ERR_SKEWED_BOX = 4,     /* tf InvalidArgumentError 'box is skewed'  simmodel.py:195 */
+    HTF_ERR_NOMEM = 5
+};
+
+enum htf_dtype { HTF_F32 = 0, HTF_F64 = 1 };
+
+/* TensorflowCompute.h:44-48 enum class FORCE_MODE */
+enum htf_force_mode { HTF_TF2HOOMD = 0, HTF_HOOMD2TF = 1 };
+
+/* HOOMD BoxDim as the plugin sees it: lo/hi/tilt as TensorflowCompute.cc:271-282
+ * updateBox() lays them out, plus the periodic flags minImage needs. */
+typedef struct htf_box {
+    double lo[3];
+    double hi[3];
+    double tilt[3]; /* xy, xz, yz */
+    int periodic[3];
+} htf_box;
+
+/* ---- potentials: the declarative models of build_examples.py / layers.py ---- */
+enum htf_potential_kind {
+    HTF_POT_NONE = 0,
+    HTF_POT_LJ = 1,        /* build_examples.py:67-77 LJModel, :104-115 LJVirialModel */
+    HTF_POT_WCA = 2,       /* layers.py:52-98 WCARepulsion + build_examples.py:221-228 */
+    HTF_POT_RINV_POLY = 3, /* E_i = sum_j sum_k coef_k * rinv^power_k (BenchmarkPotential :25-30, example 01) */
+    HTF_POT_SIMPLE = 4,    /* build_examples.py:9-22 SimplePotential (forward only) */
+    HTF_POT_PAIR_MLP = 5   /* safe_norm -> RBFExpansion -> Dense-Dense-Dense */
+};
+
+enum htf_activation { HTF_ACT_LINEAR = 0, HTF_ACT_TANH = 1 };
+enum htf_mlp_precision { HTF_MLP_FP32 = 0, HTF_MLP_BF16 = 1 };
+
+#define HTF_MAX_POLY_TERMS 8
+
+typedef struct htf_potential_desc {
+    int kind;   /* htf_potential_kind */
+    /* WCA */
+    double sigma;
+    /* RINV_POLY */
+    int n_terms;
+    double coef[HTF_MAX_POLY_TERMS];
+    int power[HTF_MAX_POLY_TERMS];
+    /* PAIR_MLP: host pointers, row-major [in, out] like Keras Dense kernels; copied */
+    int K, H1, H2;
+    int activation;    /* htf_activation */
+    int mlp_precision; /* htf_mlp_precision: MFMA operand type; accumulation is fp32 */
+    double rbf_low, rbf_high;
+    const float *W1, *b1, *W2, *b2, *W3, *b3;
+} htf_potential_desc;
+
+typedef struct htf_potential htf_potential; /* opaque; owns device copies of weights */
+
+HTF_API const char *htf_last_error(void); /* thread-local message for the last non-OK status */
+HTF_API int htf_abi_version(void);
+HTF_API int htf_device_count(void);
+
+HTF_API int htf_potential_create(const htf_potential_desc *desc, htf_potential **out);
+HTF_API void htf_potential_destroy(htf_potential *pot);
+
+/* ------------------------------------------------------------------------- *
+ * Stateless kernels -- one per reference kernel / TF graph on the path.
+ * ------------------------------------------------------------------------- */
+
+/* Replaces htf_gpu_reshape_nlist (TensorflowCompute.cuh:32-48, .cu:80-209) and the
+ * CPU prepareNeighbors (TensorflowCompute.cc:303-374), whose semantics it follows:
+ * zero fill, neighbor kept unless rsq > rmax^2, slot index wraps modulo NN.
+ * dest: [batch_size * NN] Scalar4 of dest_dtype.  d_max_count (nullable): device
+ * unsigned, atomically max'ed with the largest kept-neighbor count of the batch
+ * (> NN means the list overflowed). */
+HTF_API int htf_build_pair_vectors(void *dest, int dest_dtype,
+                           const void *d_pos, int pos_dtype,
+                           unsigned N, unsigned NN, unsigned offset, unsigned batch_size,
+                           unsigned n_ghost, const htf_box *box,
+                           const unsigned *d_n_neigh, const unsigned *d_nlist,
+                           const unsigned *d_head_list, double rmax,
+                           unsigned *d_max_count, htf_stream stream);
+
+/* Replaces the TF2 graph SimModel.compute -> compute_nlist_forces (simmodel.py:
+ * 526-555) + compute_outputs / TfToHoomd (simmodel.py:240-255, tf2hoomd.cc:17-82):
+ * nlist [B, NN, 4] (nlist_dtype) -> force [B] Scalar4 (force_dtype) written in
+ * place (fx, fy, fz, energy).  virial9 (nullable): [B, 9] row-major 3x3 of
+ * force_dtype, as _compute_virial returns (simmodel.py:509-523). */
+HTF_API int htf_eval_forces(const htf_potential *pot,
+                    const void *d_nlist, int nlist_dtype, unsigned B, unsigned NN,
+                    void *d_force, int force_dtype, void *d_virial9, htf_stream stream);
+
+/* Replaces htf_gpu_add_virial (TensorflowCompute.cu:41-71; CPU .cc:284-301):
+ * dest[c*pitch + i] += src[i*9 + {0,1,2,4,5,8}]. */
+HTF_API int htf_add_virial(void *d_dest, const void *d_src9, int dtype, unsigned N, size_t pitch, htf_stream stream);
+
+/* Replaces htf_gpu_add_scalar4 (TensorflowCompute.cu:11-39): dest[i] += src[i]. */
+HTF_API int htf_add_scalar4(void *d_dest, const void *d_src, int dtype, unsigned N, htf_stream stream);
+
+/* Replaces TFArrayComm::receiveArray(+unstuff4) (TFArrayComm.h:86-130,
+ * TFArrayComm.cu:9-29): dest[i] = src[offset+i], w = (Scalar)int_bits(w) when
+ * unstuff4 != 0.  dest may be of a different dtype than src (fused cast). */
+HTF_API int htf_copy_positions(void *d_dest, int dest_dtype, const void *d_src, int src_dtype,
+                       unsigned offset, unsigned N, int unstuff4, htf_stream stream);
+
+/* SimModel.compute_inputs check_nlist (simmodel.py:214-219): *d_out =
+ * max(*d_out, max_i sum_j [nlist[i,j,0] > 0]).  The caller zeroes *d_out. */
+HTF_API int htf_check_nlist(const void *d_nlist, int nlist_dtype, unsigned B, unsigned NN,
+                    unsigned *d_out, htf_stream stream);
+
+/* nlist_rinv (simmodel.py:618-635): out[B*NN] fp32. */
+HTF_API int htf_nlist_rinv(const void *d_nlist, int nlist_dtype, unsigned B, unsigned NN,
+                   float *d_out, htf_stream stream);
+
+/* ------------------------------------------------------------------------- *
+ * Context: TensorflowCompute<M> (TensorflowCompute.h:75-250, .cc:29-216).
+ * ------------------------------------------------------------------------- */
+typedef struct htf_config {
+    double r_cut;        /* ctor arg r_cut            TensorflowCompute.h:85 */
+    unsigned nneighs;    /* ctor arg nneighs          :86 */
+    int force_mode;      /* FORCE_MODE                :87 */
+    unsigned period;     /* ctor arg period           :88 */
+    unsigned batch_size; /* 0 = all local particles   :89, .cc:143 */
+    int scalar_dtype;    /* HOOMD Scalar: HTF_F32 / HTF_F64 (isDoublePrecision, .h:117-124) */
+    int check_nlist;     /* SimModel(check_nlist=True) simmodel.py:15 */
+    int virial;          /* SimModel(virial=True)      simmodel.py:15 */
+    unsigned max_n;      /* m_pdata->getMaxN(): sizes the scratch, reallocate() .cc:91-121 */
+} htf_config;
+
+/* What HOOMD hands over each step (raw device pointers; see layouts above). */
+typedef struct htf_hoomd_arrays {
+    const void *pos;            /* Scalar4[N + n_ghost]                            */
+    unsigned N;                 /* m_pdata->getN()                                  */
+    unsigned n_ghost;           /* m_pdata->getNGhosts()                            */
+    const unsigned *n_neigh;    /* NeighborList::getNNeighArray()                   */
+    const unsigned *nlist;      /* NeighborList::getNListArray()                    */
+    const unsigned *head_list;  /* NeighborList::getHeadList()                      */
+    htf_box box;                /* m_pdata->getBox()                                */
+    void *force;                /* Scalar4[N]  ForceCompute::m_force (written)      */
+    void *virial;               /* Scalar[6*pitch] ForceCompute::m_virial (+=) or 0 */
+    size_t virial_pitch;
+} htf_hoomd_arrays;
+
+typedef struct htf_ctx htf_ctx;
+
+HTF_API int htf_create(const htf_config *cfg, htf_ctx **out);
+HTF_API void htf_destroy(htf_ctx *ctx);
+HTF_API int htf_set_potential(htf_ctx *ctx, const htf_potential *pot); /* borrowed; must outlive ctx use */
+HTF_API int htf_resize(htf_ctx *ctx, unsigned max_n);                   /* reallocate(), .cc:88,91-121 */
+
+/* TensorflowCompute<M>::computeForces(timestep) (.cc:129-216): period gate, batch
+ * loop, pair-vector build, evaluation into force[offset..], virial fold-in.
+ * Returns HTF_ERR_SKEWED_BOX / HTF_ERR_NLIST_OVERFLOW like the reference's asserts
+ * (the overflow check reads one device word back and therefore synchronises the
+ * stream; it only runs when cfg.check_nlist is set). */
+HTF_API int htf_compute_forces(htf_ctx *ctx, unsigned timestep, const htf_hoomd_arrays *arrays, htf_stream stream);
+
+/* Buffer getters (TensorflowCompute.cc:398-407 get*Buffer): device pointers of the
+ * context-owned side buffers, for zero-copy views.  nlist: fp32 [B, NN, 4];
+ * positions: fp32 [B, 4] (type un-stuffed); virial: Scalar [B, 9]. */
+HTF_API void *htf_get_nlist_buffer(htf_ctx *ctx);
+HTF_API void *htf_get_positions_buffer(htf_ctx *ctx);
+HTF_API void *htf_get_virial_buffer(htf_ctx *ctx);
+HTF_API unsigned htf_get_batch_capacity(htf_ctx *ctx);
+
+/* Profiler scopes (reference: HOOMD Profiler push/pop "TensorflowCompute::reshapeNeighbors"
+ * and "TensorflowCompute::Force Update", TensorflowCompute.cc:164-168,196-206).  When
+ * enabled, htf_compute_forces brackets the pair-vector build and the evaluator with
+ * hipEvents on the caller's stream; htf_profile_read synchronises on the recorded
+ * events, returns the summed kernel milliseconds and call count since the last read,
+ * and resets the accumulators. */
+HTF_API int htf_profile_enable(htf_ctx *ctx, int on);
+HTF_API int htf_profile_read(htf_ctx *ctx, double *build_ms, double *eval_ms, unsigned *n_calls);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HTF_AMD_H_ */

@@ -1,0 +1,44 @@
+/* htf_standin.h -- stand-in for the parts of HOOMD-blue that sit either side of the
+ * force path (integrator, cell-list neighbor search) so that "MD steps/s" can be
+ * measured without HOOMD.  NOT part of the drop-in boundary (that is htf_amd.h): a real
+ * deployment keeps HOOMD's own integrator and NeighborList and never links this.
+ * Arrays use HOOMD layouts (Scalar4 pos/vel/force; n_neigh/head_list/nlist, FULL mode).
+ */
+#ifndef HTF_STANDIN_H_
+#define HTF_STANDIN_H_
+#include "htf_amd.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Leapfrog form of velocity Verlet (unit mass): v += dt*f; x += dt*v; wrap into the
+ * periodic box; pos.w (type bits) untouched.  IntegratorTwoStep + TwoStepNVE analogue. */
+HTF_API int htfs_nve_step(void *d_pos, void *d_vel, const void *d_force, int dtype, unsigned N,
+                          double dt, const htf_box *box, htf_stream stream);
+
+/* *d_out (float, caller zeroes) = max_i |minimage(pos_i - ref_i)|^2: the neighbor list
+ * must be rebuilt once this exceeds (r_buff/2)^2 (NeighborList::distanceCheck). */
+HTF_API int htfs_max_displacement2(const void *d_pos, const void *d_ref, int dtype, unsigned N,
+                                   const htf_box *box, float *d_out, htf_stream stream);
+
+/* Cell-list neighbor search in HOOMD layout (NeighborListGPUBinned analogue).
+ * d_cell_of [Ntot], d_order [Ntot] (particle ids sorted by cell), d_cell_start
+ * [ncell+1] are produced by the caller (binning + sort are plumbing); this kernel walks
+ * the 27 neighbor cells of each local particle and writes
+ *   nlist[i*pitch + c] = k  for every k != i with |minimage(r_k - r_i)| <= r_list,
+ *   n_neigh[i] = count, head_list[i] = i*pitch.
+ * *d_max_neigh is max'ed with the largest count (> pitch means the list overflowed and
+ * must be rebuilt with a larger pitch). */
+HTF_API int htfs_build_nlist(const void *d_pos, int dtype, unsigned N, unsigned Ntot, const htf_box *box,
+                             double r_list, const int *ncell3, const unsigned *d_order,
+                             const unsigned *d_cell_start, unsigned pitch, unsigned *d_n_neigh,
+                             unsigned *d_head_list, unsigned *d_nlist, unsigned *d_max_neigh, htf_stream stream);
+
+/* cell index of every particle (x fastest): d_cell_of[i] */
+HTF_API int htfs_cell_index(const void *d_pos, int dtype, unsigned Ntot, const htf_box *box,
+                            const int *ncell3, unsigned *d_cell_of, htf_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,63 @@
+"""ctypes loader for oracle/_build/libhtf_oracle.so (TEST INFRASTRUCTURE ONLY)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libhtf_oracle.so")
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def load():
+    if not os.path.exists(_SO):
+        build()
+    lib = C.CDLL(_SO)
+    lib.htfo_num_threads.restype = C.c_int
+    return lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _box_args(box, periodic):
+    lo = np.ascontiguousarray(box[0], dtype=np.float64)
+    hi = np.ascontiguousarray(box[1], dtype=np.float64)
+    tilt = np.ascontiguousarray(box[2], dtype=np.float64)
+    per = np.ascontiguousarray(periodic, dtype=np.int32)
+    return lo, hi, tilt, per
+
+
+def prepare_neighbors(lib, pos4, n_neigh, head, nlist, box, r_cut, NN, offset=0, batch=None, periodic=(1, 1, 1)):
+    N = len(n_neigh)
+    B = N - offset if batch is None else batch
+    f64 = pos4.dtype == np.float64
+    dest = np.empty((B, NN, 4), dtype=pos4.dtype)
+    lo, hi, tilt, per = _box_args(box, periodic)
+    fn = lib.htfo_prepare_neighbors_f64 if f64 else lib.htfo_prepare_neighbors_f32
+    fn(_p(dest), _p(np.ascontiguousarray(pos4)), _p(n_neigh), _p(head), _p(nlist), _p(lo), _p(hi), _p(tilt), _p(per),
+       C.c_double(r_cut), C.c_uint(NN), C.c_uint(offset), C.c_uint(B))
+    return dest
+
+
+def lj_from_nlist(lib, nl):
+    N, NN = nl.shape[:2]
+    out = np.empty((N, 4), dtype=np.float32)
+    lib.htfo_lj_from_nlist(_p(np.ascontiguousarray(nl, dtype=np.float32)), C.c_uint(N), C.c_uint(NN), _p(out))
+    return out
+
+
+def compute_forces_lj(lib, pos4, n_neigh, head, nlist, box, r_cut, NN, scratch=None, periodic=(1, 1, 1)):
+    N = len(n_neigh)
+    force = np.empty((N, 4), dtype=np.float32)
+    if scratch is None:
+        scratch = np.empty((N, NN, 4), dtype=np.float32)
+    lo, hi, tilt, per = _box_args(box, periodic)
+    lib.htfo_compute_forces_lj_f32(_p(pos4), C.c_uint(N), _p(n_neigh), _p(head), _p(nlist), _p(lo), _p(hi), _p(tilt),
+                                   _p(per), C.c_double(r_cut), C.c_uint(NN), _p(scratch), _p(force))
+    return force

@@ -1,0 +1,346 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the
+same seeded inputs.  Run on the MI355X box with ``pytest -m gpu``.
+
+Stated tolerances (DESIGN.md "Parity"):
+  * pair vectors: BIT-EXACT (the build kernel is compiled -ffp-contract=off and
+    performs the oracle's operations in the oracle's order);
+  * forces / energies / virials (fp32 compute): |d| <= 1e-5 + 2e-5 * |ref| against
+    the fp64 oracle evaluated on the same fp32 inputs, plus a condition term
+    2e-6 * sum_j |f_ij| for rows where large pair forces cancel (fp32 summation
+    order differs between a wave reduction and TF's reduce_sum).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import ROOT, brute_nlist, fcc_lattice, random_nlist, sq_lattice
+from oracle import htf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+STATS = {}
+
+
+def _record(name, **kw):
+    STATS[name] = {k: float(v) for k, v in kw.items()}
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "parity_stats.json"), "w") as f:
+        json.dump(STATS, f, indent=1, sort_keys=True)
+
+
+def _cond_scale(nl64, model_pair_forces):
+    """sum_j |f_ij| per row: the condition number scale of the row sum."""
+    return np.abs(model_pair_forces).sum(axis=(1, 2))
+
+
+def assert_forces_close(name, got, ref, cond=None, atol=1e-5, rtol=2e-5, ctol=2e-6):
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape
+    assert np.all(np.isfinite(got)), name
+    bound = atol + rtol * np.abs(ref)
+    if cond is not None:
+        bound = bound + ctol * np.asarray(cond).reshape(-1, *([1] * (ref.ndim - 1)))
+    err = np.abs(got - ref)
+    _record(name, max_abs_err=err.max(), max_ratio=(err / bound).max(), max_ref=np.abs(ref).max())
+    assert np.all(err <= bound), "%s: worst err/bound = %.3g (max abs err %.3g)" % (name, (err / bound).max(), err.max())
+
+
+def _pair_forces_lj(nl64):
+    s, t, rp, cond = O._rinv_and_grad_factor(nl64)
+    inv_r6 = s ** 6
+    dEds = 2.0 * (2.0 * inv_r6 - 1.0) * (6.0 * s ** 5)
+    return 2.0 * O._grad_from_dEds(dEds, s, t, rp, cond)
+
+
+# --------------------------------------------------------------------------- pair vectors
+def _system(n, a, jitter, seed, r_list, hdt, three_d=False, ntypes=3):
+    if three_d:
+        pos, L = fcc_lattice(n, a)
+    else:
+        pos, L = sq_lattice(n, a)
+    rng = np.random.default_rng(seed)
+    d = 3 if three_d else 2
+    pos[:, :d] += jitter * rng.standard_normal((len(pos), d))
+    pos = pos.astype(hdt)
+    types = rng.integers(0, ntypes, size=len(pos)).astype(np.int32)
+    nn, head, nl = brute_nlist(pos, L, r_list, shuffle_seed=seed)
+    return pos, types, L, nn, head, nl
+
+
+def _to_dev(htf, pos, types, nn, head, nl, hdt, cuda):
+    tdt = torch.float64 if hdt == np.float64 else torch.float32
+    p4 = htf.ops.stuff_types(torch.from_numpy(pos).to(cuda), torch.from_numpy(types).to(cuda), tdt)
+    return (p4, torch.from_numpy(nn.astype(np.int32)).to(cuda), torch.from_numpy(head.astype(np.int32)).to(cuda),
+            torch.from_numpy(nl.astype(np.int32)).to(cuda))
+
+
+@pytest.mark.parametrize("hdt", [np.float32, np.float64])
+@pytest.mark.parametrize("NN", [4, 8, 32, 128])
+def test_pair_vectors_bit_exact(htf, cuda, hdt, NN):
+    """prepareNeighbors parity incl. the overflow wrap (NN=4: Q > 2*NN rows exist)."""
+    pos, types, L, nn, head, nl = _system(4, 1.6, 0.08, 11, 3.4, hdt, three_d=True)
+    box = O.make_box(L, dtype=hdt)
+    ref = O.prepare_neighbors(pos, types, nn, head, nl, box, 3.0, NN)
+    p4, dnn, dhead, dnl = _to_dev(htf, pos, types, nn, head, nl, hdt, cuda)
+    mc = torch.zeros(1, dtype=torch.int32, device=cuda)
+    out = htf.ops.build_pair_vectors(p4, dnn, dhead, dnl, box, 3.0, NN, max_count=mc,
+                                     out_dtype=torch.float64 if hdt == np.float64 else torch.float32)
+    np.testing.assert_array_equal(out.cpu().numpy(), ref)
+    # kept-count side channel == the largest number of neighbors within r_cut
+    assert int(mc.item()) == int(np.sum(np.sum(O.prepare_neighbors(
+        pos, types, nn, head, nl, box, 3.0, 512)[..., :3] ** 2, axis=2) > 0, axis=1).max())
+    # fp32 destination from fp64 positions == the reference's tf.cast of the fp64 buffer
+    if hdt == np.float64:
+        out32 = htf.ops.build_pair_vectors(p4, dnn, dhead, dnl, box, 3.0, NN, out_dtype=torch.float32)
+        np.testing.assert_array_equal(out32.cpu().numpy(), ref.astype(np.float32))
+
+
+def test_pair_vectors_batches_and_ragged(htf, cuda):
+    pos, types, L, nn, head, nl = _system(6, 2.0, 0.2, 5, 3.0, np.float32)
+    # make it ragged: particle 7 has no neighbors at all, 9 keeps only one
+    nn = nn.copy()
+    nn[7] = 0
+    nn[9] = 1
+    box = O.make_box(L, dtype=np.float32)
+    p4, dnn, dhead, dnl = _to_dev(htf, pos, types, nn, head, nl, np.float32, cuda)
+    for off, bs in ((0, 36), (0, 4), (4, 4), (32, 4), (35, 1), (10, 0)):
+        ref = O.prepare_neighbors(pos, types, nn, head, nl, box, 2.6, 16, offset=off, batch_size=bs)
+        out = htf.ops.build_pair_vectors(p4, dnn, dhead, dnl, box, 2.6, 16, offset=off, batch_size=bs)
+        np.testing.assert_array_equal(out.cpu().numpy(), ref)
+
+
+def test_pair_vectors_fixed_pitch_and_cutoff_edge(htf, cuda):
+    """HOOMD's fixed-stride head list, and r == r_cut is KEPT (TensorflowCompute.cc:359)."""
+    pos, L = sq_lattice(4, 2.0, dtype=np.float32)  # exact lattice: neighbors at exactly r = 2.0
+    types = np.zeros(16, np.int32)
+    nn, head, nl = brute_nlist(pos, L, 2.5, pitch=12)
+    box = O.make_box(L, dtype=np.float32)
+    ref = O.prepare_neighbors(pos, types, nn, head, nl, box, 2.0, 8)
+    assert np.all(np.sum(np.sum(ref[..., :3] ** 2, axis=2) > 0, axis=1) == 4)
+    p4, dnn, dhead, dnl = _to_dev(htf, pos, types, nn, head, nl, np.float32, cuda)
+    out = htf.ops.build_pair_vectors(p4, dnn, dhead, dnl, box, 2.0, 8)
+    np.testing.assert_array_equal(out.cpu().numpy(), ref)
+
+
+def test_reference_force_overwrite_on_gpu(htf, cuda):
+    """test_tensorflow.py:81-129 through the whole device path (ctx driver, batch 4)."""
+    from test_reference_kats import reference_test_compute_forces
+    pos, types, L, nn, head, nl = _system(3, 4.0, 0.15, 2, 5.4, np.float64, ntypes=1)
+    box = O.make_box(L)
+    p4, dnn, dhead, dnl = _to_dev(htf, pos, types, nn, head, nl, np.float64, cuda)
+    for bs in (0, 4):
+        ctx = htf.Context(r_cut=5.0, nneighs=8, batch_size=bs, scalar_dtype=torch.float64, max_n=9)
+        ctx.set_potential(htf.Potential.simple())
+        force = torch.full((9, 4), 7.0, dtype=torch.float64, device=cuda)
+        ctx.compute_forces(0, ctx.make_arrays(p4, 9, dnn, dhead, dnl, box, force))
+        ref = reference_test_compute_forces(pos, L, 5.0)
+        np.testing.assert_allclose(force.cpu().numpy()[:, :3], ref, atol=1e-5)
+        assert np.all(force.cpu().numpy()[:, 3] == 0)
+
+
+# --------------------------------------------------------------------------- evaluators
+def _nlist_case(seed, N=512, NN=128, dtype=np.float32, rmin=0.9):
+    rng = np.random.default_rng(seed)
+    nl, cnt = random_nlist(rng, N, NN, fill=0.74, rmin=rmin, rmax=3.0, ntypes=2, dtype=dtype)
+    nl[0] = 0  # fully padded row
+    return nl
+
+
+@pytest.mark.parametrize("NN", [8, 32, 64, 128, 160])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_lj_forces_energy_virial(htf, cuda, NN, dtype):
+    nl = _nlist_case(NN, N=300, NN=NN, dtype=dtype)
+    nl64 = nl.astype(np.float32).astype(np.float64)  # the model casts the wire dtype to fp32
+    ref_f, ref_v = O.lj_model(nl64, virial=True)
+    cond = _cond_scale(nl64, _pair_forces_lj(nl64))
+    pot = htf.Potential.lj()
+    f, v = htf.ops.eval_forces(pot, torch.from_numpy(nl).to(cuda), virial=True)
+    assert f.dtype == (torch.float64 if dtype == np.float64 else torch.float32)
+    assert_forces_close("lj_f_NN%d_%s" % (NN, dtype.__name__), f.cpu().numpy(), ref_f, cond)
+    assert_forces_close("lj_v_NN%d_%s" % (NN, dtype.__name__), v.cpu().numpy(), ref_v, cond * 3.0)
+    f2 = htf.ops.eval_forces(pot, torch.from_numpy(nl).to(cuda))
+    np.testing.assert_array_equal(f2.cpu().numpy(), f.cpu().numpy())  # virial flag must not change forces
+    # against the fp32 restatement too (what TF itself would produce)
+    ref32 = O.lj_model(nl.astype(np.float32))
+    assert_forces_close("lj_f32_NN%d_%s" % (NN, dtype.__name__), f.cpu().numpy(), ref32, cond, ctol=4e-6)
+
+
+@pytest.mark.parametrize("sigma", [0.5, 1.0])
+def test_wca_forces(htf, cuda, sigma):
+    nl = _nlist_case(3, N=400, NN=128, rmin=0.55 * sigma)
+    # clip and cut edges (layers.py:96-98)
+    r10 = sigma * 10 ** (-1 / 6)
+    nl[1, 0, :3] = [r10 * 1.002, 0, 0]
+    nl[1, 1, :3] = [0, r10 * 0.998, 0]
+    nl[1, 2, :3] = [0, 0, sigma * 2 ** (1 / 3) * 1.001]
+    nl[1, 3, :3] = [0, 0, -sigma * 2 ** (1 / 3) * 0.999]
+    nl64 = nl.astype(np.float64)
+    ref = O.wca_model(nl64, sigma)
+    f = htf.ops.eval_forces(htf.Potential.wca(sigma), torch.from_numpy(nl).to(cuda))
+    s, t, rp, cond = O._rinv_and_grad_factor(nl64)
+    pf = 2 * O._grad_from_dEds(6 * sigma ** 6 * s ** 5, s, t, rp, cond)
+    assert_forces_close("wca_%g" % sigma, f.cpu().numpy(), ref, _cond_scale(nl64, pf))
+
+
+def test_rinv_poly_and_benchmark_potential(htf, cuda):
+    nl = _nlist_case(4, N=200, NN=64)
+    nl64 = nl.astype(np.float64)
+    f = htf.ops.eval_forces(htf.Potential.rinv_poly([1.0], [1]), torch.from_numpy(nl).to(cuda))
+    assert_forces_close("benchmark_potential", f.cpu().numpy(), O.benchmark_potential(nl64))
+    # LJ written as a polynomial == the dedicated LJ kernel within tolerance
+    f = htf.ops.eval_forces(htf.Potential.rinv_poly([2.0, -2.0], [12, 6]), torch.from_numpy(nl).to(cuda))
+    assert_forces_close("poly_lj", f.cpu().numpy(), O.lj_model(nl64), _cond_scale(nl64, _pair_forces_lj(nl64)))
+    # example 01's r^-12: e = rinv^12
+    f, v = htf.ops.eval_forces(htf.Potential.rinv_poly([1.0], [12]), torch.from_numpy(nl).to(cuda), virial=True)
+    rf, rv = O.rinv_poly_model(nl64, [1.0], [12], virial=True)
+    s, t, rp, cond = O._rinv_and_grad_factor(nl64)
+    c = _cond_scale(nl64, 2 * O._grad_from_dEds(12 * s ** 11, s, t, rp, cond))
+    assert_forces_close("poly_r12_f", f.cpu().numpy(), rf, c)
+    assert_forces_close("poly_r12_v", v.cpu().numpy(), rv, 3 * c)
+
+
+def test_simple_potential(htf, cuda):
+    nl = _nlist_case(5, N=100, NN=32)
+    f = htf.ops.eval_forces(htf.Potential.simple(), torch.from_numpy(nl).to(cuda))
+    ref = O.compute_outputs(O.simple_potential(nl.astype(np.float64)), np.float64)
+    assert_forces_close("simple", f.cpu().numpy(), ref)
+
+
+def test_rinv_mask_edges(htf, cuda):
+    """nlist_rinv's where(r' > 3e-6) mask, slot by slot (simmodel.py:627-635)."""
+    nl = np.zeros((4, 8, 4), np.float32)
+    nl[1, 0, :3] = [1.6e-6, 1.6e-6, 1.6e-6]
+    nl[1, 1, :3] = [1.8e-6, 1.8e-6, 1.8e-6]
+    nl[2, 0, :3] = [-1e-7, -1e-7, -1e-7]
+    nl[3, 0, :3] = [1.0, 0, 0]
+    s = htf.ops.nlist_rinv(torch.from_numpy(nl).to(cuda)).cpu().numpy()
+    ref = O.nlist_rinv(nl)
+    np.testing.assert_allclose(s, ref, rtol=1e-6)
+    assert s[0].max() == 0 and s[1, 0] == 0 and s[1, 1] > 1e5 and s[2, 0] == 0
+    f = htf.ops.eval_forces(htf.Potential.rinv_poly([1.0], [1]), torch.from_numpy(nl).to(cuda)).cpu().numpy()
+    assert np.all(np.isfinite(f))
+
+
+# --------------------------------------------------------------------------- aux kernels
+@pytest.mark.parametrize("tdt", [torch.float32, torch.float64])
+def test_aux_kernels(htf, cuda, tdt):
+    g = torch.Generator(device="cpu").manual_seed(0)
+    N, pitch = 37, 40
+    src9 = torch.randn(N, 9, generator=g, dtype=tdt)
+    dest = torch.randn(6 * pitch, generator=g, dtype=tdt)
+    ref = O.receive_virial(dest.numpy().copy(), src9.numpy(), pitch, 0, N)
+    out = htf.ops.add_virial(dest.to(cuda), src9.to(cuda), N, pitch)
+    np.testing.assert_array_equal(out.cpu().numpy(), ref)
+    a, b = torch.randn(N, 4, generator=g, dtype=tdt), torch.randn(N, 4, generator=g, dtype=tdt)
+    np.testing.assert_array_equal(htf.ops.add_scalar4(a.to(cuda), b.to(cuda)).cpu().numpy(), (a + b).numpy())
+    xyz = torch.randn(N, 3, generator=g, dtype=tdt)
+    types = torch.arange(N) % 5
+    p4 = htf.ops.stuff_types(xyz.to(cuda), types.to(cuda), tdt)
+    un = htf.ops.copy_positions(p4, offset=3, N=20)
+    np.testing.assert_array_equal(un.cpu().numpy()[:, :3], xyz.numpy()[3:23])
+    np.testing.assert_array_equal(un.cpu().numpy()[:, 3], types.numpy()[3:23].astype(np.float64))
+    un32 = htf.ops.copy_positions(p4, out_dtype=torch.float32)
+    np.testing.assert_array_equal(un32.cpu().numpy()[:, 3], types.numpy().astype(np.float32))
+
+
+# --------------------------------------------------------------------------- context driver
+def test_context_lj_batched_period_virial(htf, cuda):
+    """computeForces semantics: batching leaves results identical (test_force_overwrite_batched),
+    period gating reuses old forces (TensorflowCompute.cc:133), virial folds in with +=."""
+    pos, types, L, nn, head, nl = _system(5, 3.0, 0.08, 1, 5.4, np.float64, ntypes=1)
+    N = 25
+    box = O.make_box(L)
+    p4, dnn, dhead, dnl = _to_dev(htf, pos, types, nn, head, nl, np.float64, cuda)
+    ref_f, ref_v = O.compute_forces(pos, types, nn, head, nl, box, 5.0, 32,
+                                    lambda x: O.lj_model(x.astype(np.float64), virial=True), virial=True,
+                                    model_dtype=np.float32)
+    outs = []
+    for bs in (0, 4, 25, 7):
+        ctx = htf.Context(r_cut=5.0, nneighs=32, batch_size=bs, period=3, scalar_dtype=torch.float64,
+                          virial=True, max_n=N)
+        ctx.set_potential(htf.Potential.lj())
+        force = torch.zeros((N, 4), dtype=torch.float64, device=cuda)
+        vir = torch.zeros(6 * N, dtype=torch.float64, device=cuda)
+        arrays = ctx.make_arrays(p4, N, dnn, dhead, dnl, box, force, vir, N)
+        ctx.compute_forces(0, arrays)
+        assert_forces_close("ctx_lj_bs%d" % bs, force.cpu().numpy(), ref_f)
+        assert_forces_close("ctx_virial_bs%d" % bs, vir.cpu().numpy(), ref_v, atol=2e-5)
+        outs.append(force.cpu().numpy().copy())
+        # period gate: timestep 1, 2 leave the arrays untouched
+        force.fill_(-1.0)
+        ctx.compute_forces(1, arrays)
+        ctx.compute_forces(2, arrays)
+        assert torch.all(force == -1.0)
+        ctx.compute_forces(3, arrays)
+        np.testing.assert_array_equal(force.cpu().numpy(), outs[-1])
+        np.testing.assert_allclose(vir.cpu().numpy(), 2 * ref_v, atol=4e-5)  # accumulated (+=)
+        if bs in (0, 25):
+            nlb = ctx.nlist_buffer(N).cpu().numpy()
+            ref_nl = O.prepare_neighbors(pos, types, nn, head, nl, box, 5.0, 32).astype(np.float32)
+            np.testing.assert_array_equal(nlb, ref_nl)
+            np.testing.assert_array_equal(ctx.positions_buffer(N).cpu().numpy()[:, :3], pos.astype(np.float32))
+    for o in outs[1:]:
+        np.testing.assert_array_equal(o, outs[0])
+
+
+def test_context_errors(htf, cuda):
+    """test_overflow (test_tensorflow.py:830-848) and test_skew_fails (:321-333)."""
+    pos, L = sq_lattice(8, 4.0)
+    rng = np.random.default_rng(1)
+    pos[:, :2] += 0.05 * rng.standard_normal((64, 2))
+    types = np.zeros(64, np.int32)
+    nn, head, nl = brute_nlist(pos, L, 10.0, shuffle_seed=3)
+    p4, dnn, dhead, dnl = _to_dev(htf, pos, types, nn, head, nl, np.float64, cuda)
+    force = torch.zeros((64, 4), dtype=torch.float64, device=cuda)
+    ctx = htf.Context(r_cut=10.0, nneighs=4, scalar_dtype=torch.float64, check_nlist=True, max_n=64)
+    ctx.set_potential(htf.Potential.lj())
+    with pytest.raises(htf.NlistOverflowError):
+        ctx.compute_forces(0, ctx.make_arrays(p4, 64, dnn, dhead, dnl, O.make_box(L), force))
+    ctx = htf.Context(r_cut=10.0, nneighs=64, scalar_dtype=torch.float64, check_nlist=True, max_n=64)
+    ctx.set_potential(htf.Potential.lj())
+    ctx.compute_forces(0, ctx.make_arrays(p4, 64, dnn, dhead, dnl, O.make_box(L), force))
+    with pytest.raises(htf.SkewedBoxError):
+        ctx.compute_forces(0, ctx.make_arrays(p4, 64, dnn, dhead, dnl, O.make_box(L, tilt=(0.5, 0, 0)), force))
+    assert htf.ops.check_nlist(ctx.nlist_buffer(64)) == O.check_nlist_count(
+        O.prepare_neighbors(pos, types, nn, head, nl, O.make_box(L), 10.0, 64))
+
+
+# --------------------------------------------------------------------------- full size
+def test_full_size_lj_rows_and_properties(htf, cuda):
+    """BASELINE size (131072 x 128): rows are independent, so a random sample of rows
+    is checked against the oracle exactly as in the small tests; plus properties
+    that do not depend on the oracle: slot-permutation invariance and determinism."""
+    N, NN = 131072, 128
+    g = torch.Generator(device="cuda").manual_seed(3)
+    cnt = torch.randint(70, 125, (N, 1), generator=g, device=cuda)
+    v = torch.randn(N, NN, 3, generator=g, device=cuda)
+    v = v / v.norm(dim=2, keepdim=True)
+    r = 0.9 + 2.1 * torch.rand(N, NN, 1, generator=g, device=cuda) ** (1 / 3)
+    nl = torch.zeros(N, NN, 4, device=cuda)
+    nl[..., :3] = v * r
+    nl *= (torch.arange(NN, device=cuda)[None, :, None] < cnt[:, :, None])
+    pot = htf.Potential.lj()
+    f = htf.ops.eval_forces(pot, nl)
+    f_again = htf.ops.eval_forces(pot, nl)
+    assert torch.equal(f, f_again)
+    rows = torch.randint(0, N, (384,), generator=g, device=cuda)
+    sub = nl[rows].cpu().numpy().astype(np.float64)
+    ref = O.lj_model(sub)
+    assert_forces_close("full_lj_rows", f[rows].cpu().numpy(), ref, _cond_scale(sub, _pair_forces_lj(sub)))
+    # permuting the real slots of each row only reorders the sum
+    perm = torch.argsort(torch.rand(N, NN, generator=g, device=cuda), dim=1)
+    nl_p = torch.gather(nl, 1, perm[:, :, None].expand(-1, -1, 4)).contiguous()
+    f_p = htf.ops.eval_forces(pot, nl_p)
+    scale = f.abs().max().item()
+    assert (f_p - f).abs().max().item() <= 2e-5 * scale
+    # total energy: checksum of checksums against a float64 torch reduction of pair terms
+    tx = (nl[..., :3].double() + 1e-7)
+    rp = tx.norm(dim=2)
+    s = torch.where(rp > 3e-6, 1.0 / (rp + 3e-6), torch.zeros_like(rp))
+    e_ref = (2.0 * (s ** 12 - s ** 6)).sum().item()
+    assert abs(f[:, 3].double().sum().item() - e_ref) <= 2e-6 * abs(e_ref) + 1e-3

@@ -1,0 +1,77 @@
+"""HOOMD stand-in kernels on the GPU: the binned neighbor search must produce the same
+FULL neighbor sets as the O(N^2) brute force, and the leapfrog step must match numpy."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import brute_nlist, sq_lattice
+
+pytestmark = pytest.mark.gpu
+
+
+def _rows(nn, head, nl):
+    return [np.sort(nl[int(head[i]): int(head[i]) + int(nn[i])]) for i in range(len(nn))]
+
+
+@pytest.mark.parametrize("tdt", [torch.float32, torch.float64])
+def test_cell_nlist_matches_brute_force(htf, cuda, tdt):
+    from hoomd_tf_amd import standin
+    pos, L, a = standin.fcc_positions(7, 0.8442)
+    rng = np.random.default_rng(0)
+    pos = pos + 0.08 * a * rng.standard_normal(pos.shape)
+    pos -= np.round(pos / L) * L
+    sysm = standin.System(pos, L, dtype=tdt, device=cuda)
+    nl = standin.CellNlist(sysm, r_cut=2.5, r_buff=0.4)
+    nl.build()
+    p = sysm.pos.cpu().numpy()[:, :3].astype(np.float64)
+    bn, bh, bl = brute_nlist(p, L, 2.9)
+    got = _rows(nl.n_neigh.cpu().numpy(), nl.head_list.cpu().numpy(), nl.nlist.cpu().numpy())
+    ref = _rows(bn, bh, bl)
+    mism = 0
+    for g, r in zip(got, ref):
+        if len(g) != len(r) or np.any(g != r):
+            # pairs within 1e-5 of r_list may flip with fp32 rounding; anything else is a bug
+            sym = set(g.tolist()) ^ set(r.tolist())
+            mism += len(sym)
+    assert mism <= (4 if tdt == torch.float32 else 0)
+    assert nl.pitch >= int(bn.max())
+
+
+def test_cell_nlist_2d_and_small_pitch_regrow(htf, cuda):
+    from hoomd_tf_amd import standin
+    pos, L = sq_lattice(16, 2.0)
+    rng = np.random.default_rng(1)
+    pos[:, :2] += 0.1 * rng.standard_normal((256, 2))
+    sysm = standin.System(pos, L, dtype=torch.float64, device=cuda)
+    nl = standin.CellNlist(sysm, r_cut=3.0, r_buff=0.4, pitch=8)  # too small on purpose
+    nl.build()
+    bn, bh, bl = brute_nlist(sysm.pos.cpu().numpy()[:, :3], L, 3.4)
+    assert nl.pitch >= bn.max()
+    got = _rows(nl.n_neigh.cpu().numpy(), nl.head_list.cpu().numpy(), nl.nlist.cpu().numpy())
+    for g, r in zip(got, _rows(bn, bh, bl)):
+        np.testing.assert_array_equal(g, r)
+
+
+def test_nve_step_and_displacement(htf, cuda):
+    from hoomd_tf_amd import standin
+    pos, L, a = standin.fcc_positions(3, 0.8)
+    sysm = standin.System(pos, L, dtype=torch.float64, device=cuda, types=np.arange(len(pos)) % 4)
+    sysm.randomize_velocities(1.0, 5)
+    g = torch.Generator().manual_seed(0)
+    sysm.force[:, :3] = torch.randn(sysm.N, 3, generator=g, dtype=torch.float64).to(cuda)
+    p0, v0, f0 = sysm.pos.cpu().numpy().copy(), sysm.vel.cpu().numpy().copy(), sysm.force.cpu().numpy().copy()
+    nl = standin.CellNlist(sysm, r_cut=2.0, r_buff=0.4)
+    nl.build()
+    nve = standin.NVE(sysm, 0.05)
+    nve.step()
+    v1 = v0[:, :3] + 0.05 * f0[:, :3]
+    x1 = p0[:, :3] + 0.05 * v1
+    x1 = x1 - np.floor((x1 + L / 2) / L) * L
+    np.testing.assert_allclose(sysm.vel.cpu().numpy()[:, :3], v1, rtol=1e-14, atol=1e-14)
+    np.testing.assert_allclose(sysm.pos.cpu().numpy()[:, :3], x1, rtol=1e-13, atol=1e-13)
+    np.testing.assert_array_equal(sysm.types_numpy(), np.arange(sysm.N) % 4)  # w (type bits) untouched
+    # distance check trips once something moved more than r_buff/2
+    assert not nl.needs_update() or np.max(np.linalg.norm(0.05 * v1, axis=1)) > 0.2
+    for _ in range(20):
+        nve.step()
+    assert nl.needs_update()

@@ -1,0 +1,48 @@
+"""The C restatement (cpu_baseline 'port') must agree with the numpy oracle."""
+import numpy as np
+import pytest
+
+from helpers import brute_nlist, fcc_lattice, random_nlist
+from oracle import c_oracle
+from oracle import htf_oracle as O
+
+
+@pytest.fixture(scope="module")
+def clib():
+    return c_oracle.load()
+
+
+def _stuff(pos, types, dtype):
+    p4 = np.zeros((len(pos), 4), dtype=dtype)
+    p4[:, :3] = pos
+    if dtype == np.float32:
+        p4[:, 3] = types.astype(np.int32).view(np.float32)
+    else:
+        p4[:, 3] = types.astype(np.int64).view(np.float64)
+    return p4
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_prepare_neighbors_bit_exact(clib, dtype):
+    pos, L = fcc_lattice(3, 1.7)
+    rng = np.random.default_rng(0)
+    pos = (pos + 0.1 * rng.standard_normal(pos.shape)).astype(dtype)
+    types = rng.integers(0, 3, len(pos))
+    nn, head, nl = brute_nlist(pos, L, 3.0, shuffle_seed=1)
+    box = O.make_box(L, dtype=dtype)
+    for NN in (4, 16, 64):
+        ref = O.prepare_neighbors(pos, types, nn, head, nl, box, 2.6, NN)
+        got = c_oracle.prepare_neighbors(clib, _stuff(pos, types, dtype), nn, head, nl, box, 2.6, NN)
+        np.testing.assert_array_equal(got, ref)
+    ref = O.prepare_neighbors(pos, types, nn, head, nl, box, 2.6, 16, offset=5, batch_size=9)
+    got = c_oracle.prepare_neighbors(clib, _stuff(pos, types, dtype), nn, head, nl, box, 2.6, 16, offset=5, batch=9)
+    np.testing.assert_array_equal(got, ref)
+
+
+def test_lj_matches_numpy_oracle(clib):
+    rng = np.random.default_rng(1)
+    nl, _ = random_nlist(rng, 256, 64, fill=0.7, rmin=0.9)
+    ref = O.lj_model(nl.astype(np.float64))
+    got = c_oracle.lj_from_nlist(clib, nl)
+    np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-4)
+    assert clib.htfo_num_threads() >= 1
