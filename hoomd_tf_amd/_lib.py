@@ -7,6 +7,13 @@ ran on the CPU would void every parity claim).
 import ctypes as C
 import os
 
+# torch must be imported BEFORE libhtf_amd.so is loaded: torch ships its own
+# libamdhip64.so.7 and dlopens it by path; loading ours first would pull the system HIP
+# runtime as well and leave two runtimes in one process (the second one then sees no
+# device).  With torch first, our DT_NEEDED libamdhip64.so.7 binds to the copy that is
+# already loaded, so kernels, streams and tensors share one runtime.
+import torch  # noqa: F401  (plumbing: device memory + streams)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhtf_amd.so")
 

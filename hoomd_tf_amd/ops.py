@@ -115,6 +115,8 @@ def build_pair_vectors(pos, n_neigh, head_list, nlist, box, r_cut, NN, offset=0,
     if out is None:
         out = torch.empty((B, NN, 4), dtype=out_dtype, device=pos.device)
     _dev(out, "out")
+    if B == 0:
+        return out
     b = box if isinstance(box, _lib.Box) else _lib.make_box(box, periodic)
     check(lib.htf_build_pair_vectors(
         out.data_ptr(), _dt(out), pos.data_ptr(), _dt(pos), N, NN, offset, B, pos.shape[0] - N, C.byref(b),

@@ -18,6 +18,11 @@ def load():
         build()
     lib = C.CDLL(_SO)
     lib.htfo_num_threads.restype = C.c_int
+    # use the cores this process may actually run on (cgroup/affinity), not the host total
+    try:
+        lib.htfo_set_threads(C.c_int(len(os.sched_getaffinity(0))))
+    except AttributeError:
+        pass
     return lib
 
 

@@ -24,6 +24,14 @@
 #define RINV_DELTA 3e-6f
 #define NORM_DELTA 1e-7f
 
+void htfo_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int htfo_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();
