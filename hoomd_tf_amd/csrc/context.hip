@@ -262,17 +262,19 @@ extern "C" int htf_compute_forces(htf_ctx *ctx, unsigned timestep, const htf_hoo
         }
         if (cfg.nneighs > 0) {
             HTF_REQUIRE(a->n_neigh && a->nlist && a->head_list, "htf_compute_forces: null neighbor list");
-            rc = htf_build_pair_vectors(ctx->nlist, HTF_F32, a->pos, cfg.scalar_dtype, N, cfg.nneighs, offset, n,
-                                        a->n_ghost, &a->box, a->n_neigh, a->nlist, a->head_list, cfg.r_cut,
-                                        nullptr, stream);
+            // positions side buffer (m_positions_comm.receiveArray, .cc:172) is staged by the same kernel
+            rc = build_pair_vectors_impl(ctx->nlist, HTF_F32, a->pos, cfg.scalar_dtype, N, cfg.nneighs, offset, n,
+                                         &a->box, a->n_neigh, a->nlist, a->head_list, cfg.r_cut, nullptr,
+                                         ctx->positions, s);
             if (rc != HTF_OK) return rc;
         }
         if (prof) HTF_CHECK_HIP(hipEventRecord(e1, s));
-        if (cfg.nneighs == 0 || ctx->pot == nullptr) {
+        if (cfg.nneighs == 0) { // positions-only models (nneighbor_cutoff = 0) live above the ABI
             rc = htf_copy_positions(ctx->positions, HTF_F32, a->pos, cfg.scalar_dtype, offset, n, 1, stream);
             if (rc != HTF_OK) return rc;
             continue;
-        } // positions-only models live above the ABI
+        }
+        if (ctx->pot == nullptr) continue;
         if (cfg.check_nlist) {
             unsigned h = 0;
             HTF_CHECK_HIP(hipMemsetAsync(ctx->flag, 0, sizeof(unsigned), s));
@@ -290,9 +292,6 @@ extern "C" int htf_compute_forces(htf_ctx *ctx, unsigned timestep, const htf_hoo
                              cfg.virial ? ctx->virial : nullptr, stream);
         if (rc != HTF_OK) return rc;
         if (prof) HTF_CHECK_HIP(hipEventRecord(e2, s));
-        // m_positions_comm.receiveArray(..., unstuff4) .cc:172 -- side buffer for get_positions_array / models
-        rc = htf_copy_positions(ctx->positions, HTF_F32, a->pos, cfg.scalar_dtype, offset, n, 1, stream);
-        if (rc != HTF_OK) return rc;
         if (cfg.virial && a->virial) { // receiveVirial(offset, N) .cc:200-204
             rc = htf_add_virial((char *)a->virial + (size_t)offset * ssz, ctx->virial, cfg.scalar_dtype, n,
                                 a->virial_pitch, stream);

@@ -16,6 +16,12 @@ struct PotParams {
 int eval_pair_dispatch(const PotParams &p, const void *nlist, int in_dtype, unsigned B, unsigned NN,
                        void *force, int force_dtype, void *virial9, hipStream_t stream);
 
+// pair-vector build with the positions side buffer staged by the same kernel
+int build_pair_vectors_impl(void *dest, int dest_dtype, const void *d_pos, int pos_dtype, unsigned N, unsigned NN,
+                            unsigned offset, unsigned batch_size, const htf_box *box, const unsigned *d_n_neigh,
+                            const unsigned *d_nlist, const unsigned *d_head_list, double rmax,
+                            unsigned *d_max_count, float4 *positions_out, hipStream_t s);
+
 struct MlpDevice;
 int mlp_create(const htf_potential_desc *d, MlpDevice **out);
 void mlp_destroy(MlpDevice *m);

@@ -1,9 +1,324 @@
-// placeholder until the MFMA pair-MLP evaluator lands (next commit)
+// Fused pair-MLP evaluator on the matrix cores:
+//   nlist [B, NN, 4] -> force [B] Scalar4,   per slot:
+//   r = safe_norm(x) (simmodel.py:581-594) -> phi = RBFExpansion(r) (layers.py:46-49)
+//   -> Dense(H1) -> act -> Dense(H2) -> act -> Dense(1) = u      (Keras Dense, a18)
+//   E_i = 1/2 sum_j [r > 3e-6] u_ij ;  F_i = 2 sum_j dE_i/dx_ij   (simmodel.py:526-555)
+// with the analytic backward pass (du/dr) fused in, so nothing but the 16-B slot is read
+// and one Scalar4 per particle is written.  TF would materialise [N,NN,K] and
+// [N,NN,H] tensors (2-4 GiB at N = 131072) forward and backward.
+//
+// MI355X mapping (MFMA-bound: 24.6 kflop per 16-B slot).  One wave owns a tile of 32
+// pairs.  Every layer is computed TRANSPOSED, Z^T[feature][pair] = W^T X^T, with
+// v_mfma_f32_32x32x2_f32 (exact fp32): features run over the accumulator rows
+// (registers), pairs over the lanes.  A 32x32 accumulator register v of lane (p, h)
+// holds feature f0(v) + 4h, f0(v) = (v&3) + 8(v>>2), of pair p -- which is exactly a B
+// operand (k on the lane half, column on lane&31) of the next layer's MFMA if the
+// k-steps are taken in that permuted order.  The k order of a sum is free, so the
+// weight (A) operands are stored pre-permuted and the activations never leave
+// registers: no LDS round trip, no transposes, for the forward AND the backward chain.
+// The weights live in LDS as four operand-ordered images (48 KiB, read with
+// conflict-free ds_read_b128, 4 k-steps per read); blocks are persistent so the images
+// are loaded once.  ~150 VGPRs -> 3 waves/SIMD, 3 blocks/CU (148 KiB LDS), so one
+// wave's tanh/exp VALU phase overlaps another's MFMA phase.  Fully padded tiles (the
+// tail of every row) are skipped with a wave-uniform ballot.
+#include <cmath>
+#include <vector>
+
 #include "htf_common.h"
 #include "htf_internal.h"
+
 namespace htf {
-struct MlpDevice { int unused; };
-int mlp_create(const htf_potential_desc *, MlpDevice **) { set_error("pair-MLP evaluator is not built yet"); return HTF_ERR_INVALID; }
-void mlp_destroy(MlpDevice *m) { delete m; }
-int mlp_eval(const MlpDevice *, const void *, int, unsigned, unsigned, void *, int, hipStream_t) { set_error("pair-MLP evaluator is not built yet"); return HTF_ERR_INVALID; }
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int kK = 32;  // RBF count (padded with zero weights below 32)
+constexpr int kH = 64;  // hidden width (padded with zero weights below 64)
+
+// float offsets inside the device image buffer / LDS
+constexpr int kImgL1 = 0;                      // [nb 2][g 4][lane 64][4]
+constexpr int kImgL2 = kImgL1 + 2 * 16 * 64;   // [nb 2][kb 2][g 4][lane 64][4]
+constexpr int kImgB2 = kImgL2 + 4 * 16 * 64;   // [fb 2][kb 2][g 4][lane 64][4]
+constexpr int kImgB1 = kImgB2 + 4 * 16 * 64;   // [kb 2][g 4][lane 64][4]
+constexpr int kTabB1 = kImgB1 + 2 * 16 * 64;   // [b 2][h 2][v 16]
+constexpr int kTabB2 = kTabB1 + 64;
+constexpr int kTabW3 = kTabB2 + 64;
+constexpr int kTabC = kTabW3 + 64;             // [h 2][v 16] RBF centers
+constexpr int kImgFloats = kTabC + 32;         // 12512 floats = 50048 B
+
+struct MlpDevice {
+    float *images = nullptr; // kImgFloats floats, operand order
+    float b3 = 0.f, gap = 1.f;
+    int act = HTF_ACT_LINEAR;
+    int precision = HTF_MLP_FP32;
+    int n_cu = 256;
+};
+
+__host__ __device__ constexpr int f0(int v) { return (v & 3) + 8 * (v >> 2); }
+
+template <bool TANH>
+__device__ __forceinline__ float act_fwd(float z) {
+    if constexpr (!TANH) return z;
+    // tanh(z) = sign(z) (1 - e) / (1 + e),  e = exp(-2|z|)  (abs error ~2e-7)
+    float e = __expf(-2.0f * fabsf(z));
+    float t = __fdividef(1.0f - e, 1.0f + e);
+    return copysignf(t, z);
 }
+
+#define HTF_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+// acc += A(image) * B(prev), over one 32-feature block of the previous layer:
+// 16 k-steps, the image supplies 4 steps per ds_read_b128
+__device__ __forceinline__ void mfma_block(f32x16 &acc, const float *img, unsigned lane, const f32x16 &prev) {
+    const float4 *p = reinterpret_cast<const float4 *>(img) + lane;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        float4 w = p[g * 64];
+        acc = HTF_MFMA(w.x, prev[4 * g + 0], acc);
+        acc = HTF_MFMA(w.y, prev[4 * g + 1], acc);
+        acc = HTF_MFMA(w.z, prev[4 * g + 2], acc);
+        acc = HTF_MFMA(w.w, prev[4 * g + 3], acc);
+    }
+}
+
+__device__ __forceinline__ f32x16 load_tab(const float *tab, int b, unsigned h) {
+    const float4 *p = reinterpret_cast<const float4 *>(tab + (b * 2 + h) * 16);
+    float4 a = p[0], bq = p[1], c = p[2], d = p[3];
+    f32x16 r;
+    r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w;
+    r[4] = bq.x; r[5] = bq.y; r[6] = bq.z; r[7] = bq.w;
+    r[8] = c.x; r[9] = c.y; r[10] = c.z; r[11] = c.w;
+    r[12] = d.x; r[13] = d.y; r[14] = d.z; r[15] = d.w;
+    return r;
+}
+
+template <bool TANH, typename IT>
+__global__ __launch_bounds__(256, 3) void pair_mlp_kernel(const typename Vec4<IT>::type *__restrict__ nlist,
+                                                          unsigned B, unsigned NN, void *__restrict__ force,
+                                                          int out_f64, const float *__restrict__ images, float b3,
+                                                          float gap) {
+    __shared__ __attribute__((aligned(16))) float lds[kImgFloats];
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(images);
+        float4 *dst = reinterpret_cast<float4 *>(lds);
+        for (int i = threadIdx.x; i < kImgFloats / 4; i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned p = lane & 31u, h = lane >> 5;
+    const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const unsigned nwaves = (gridDim.x * blockDim.x) >> 6;
+    const unsigned ntiles = (NN + 31) / 32;
+    const float ginv = 1.0f / gap;
+    const f32x16 cen = load_tab(lds + kTabC, 0, h); // centers of this lane's 16 RBF indices
+
+    for (unsigned row = wave; row < B; row += nwaves) {
+        const typename Vec4<IT>::type *rp = nlist + (size_t)row * NN;
+        float fx = 0.f, fy = 0.f, fz = 0.f, en = 0.f;
+        for (unsigned tile = 0; tile < ntiles; ++tile) {
+            const unsigned slot = tile * 32 + p;
+            float x = 0.f, y = 0.f, z = 0.f;
+            if (slot < NN) {
+                auto v = rp[slot];
+                x = (float)v.x; y = (float)v.y; z = (float)v.z;
+            }
+            const float tx = x + kNormDelta, ty = y + kNormDelta, tz = z + kNormDelta;
+            const float r = sqrtf(tx * tx + ty * ty + tz * tz);
+            const bool m = r > kRinvDelta;
+            if (__ballot(m) == 0ull) continue; // every slot of this tile is padding
+
+            // RBF expansion: lane (p, h) evaluates centres k = f0(v) + 4h, v = 0..15
+            f32x16 phi;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                float d = r - cen[v];
+                phi[v] = __expf(-(d * d) * ginv);
+            }
+
+            // ---- layer 1: a1^T[f][p] = b1 + W1^T phi^T
+            f32x16 a1[2];
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                a1[nb] = load_tab(lds + kTabB1, nb, h);
+                mfma_block(a1[nb], lds + kImgL1 + nb * 1024, lane, phi);
+#pragma unroll
+                for (int v = 0; v < 16; ++v) a1[nb][v] = act_fwd<TANH>(a1[nb][v]);
+            }
+            // ---- layer 2
+            f32x16 a2[2];
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                a2[nb] = load_tab(lds + kTabB2, nb, h);
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+                    mfma_block(a2[nb], lds + kImgL2 + (nb * 2 + kb) * 1024, lane, a1[kb]);
+#pragma unroll
+                for (int v = 0; v < 16; ++v) a2[nb][v] = act_fwd<TANH>(a2[nb][v]);
+            }
+            // ---- layer 3 (dot with w3) and dz2 = w3 * act'(z2), in place
+            float upart = 0.f;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const f32x16 w3 = load_tab(lds + kTabW3, b, h);
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const float hv = a2[b][v];
+                    upart += hv * w3[v];
+                    a2[b][v] = TANH ? w3[v] * (1.0f - hv * hv) : w3[v];
+                }
+            }
+            const float u = upart + __shfl_xor(upart, 32) + b3;
+
+            // ---- backward 2: dh1^T = W2 dz2^T, then dz1 = dh1 * act'(z1) into a1
+#pragma unroll
+            for (int fb = 0; fb < 2; ++fb) {
+                f32x16 d1;
+#pragma unroll
+                for (int v = 0; v < 16; ++v) d1[v] = 0.f;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+                    mfma_block(d1, lds + kImgB2 + (fb * 2 + kb) * 1024, lane, a2[kb]);
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const float hv = a1[fb][v];
+                    a1[fb][v] = TANH ? d1[v] * (1.0f - hv * hv) : d1[v];
+                }
+            }
+            // ---- backward 1: dphi^T = W1 dz1^T
+            f32x16 dphi;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) dphi[v] = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) mfma_block(dphi, lds + kImgB1 + kb * 1024, lane, a1[kb]);
+
+            // du/dr = sum_k dphi_k * (-2 (r - c_k) / gap) * phi_k
+            float dpart = 0.f;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                float d = r - cen[v];
+                dpart += dphi[v] * (-2.0f * d * ginv) * phi[v];
+            }
+            const float dudr = dpart + __shfl_xor(dpart, 32);
+
+            // E_i += 1/2 u ; F_i += 2 * (1/2) du/dr * t / r   (masked; upper half duplicates)
+            if (m && h == 0) {
+                const float c = dudr / r;
+                fx += c * tx;
+                fy += c * ty;
+                fz += c * tz;
+                en += 0.5f * u;
+            }
+        }
+        fx = group_sum<64>(fx);
+        fy = group_sum<64>(fy);
+        fz = group_sum<64>(fz);
+        en = group_sum<64>(en);
+        if (lane == 0) {
+            if (out_f64)
+                ((double4 *)force)[row] = make_double4(fx, fy, fz, en);
+            else
+                ((float4 *)force)[row] = make_float4(fx, fy, fz, en);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------ host side
+static void fill_image(std::vector<float> &img, const htf_potential_desc *d, float *gap_out) {
+    const int K = d->K, H1 = d->H1, H2 = d->H2;
+    auto W1 = [&](int k, int f) { return (k < K && f < H1) ? d->W1[(size_t)k * H1 + f] : 0.f; };
+    auto W2 = [&](int a, int b) { return (a < H1 && b < H2) ? d->W2[(size_t)a * H2 + b] : 0.f; };
+    img.assign(kImgFloats, 0.f);
+    for (int g = 0; g < 4; ++g)
+        for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 4; ++j) {
+                const int r = 4 * g + j, i = lane & 31, hh = lane >> 5, kk = f0(r) + 4 * hh;
+                const int o = (g * 64 + lane) * 4 + j;
+                for (int nb = 0; nb < 2; ++nb) img[kImgL1 + nb * 1024 + o] = W1(kk, 32 * nb + i);
+                for (int kb = 0; kb < 2; ++kb) img[kImgB1 + kb * 1024 + o] = W1(i, 32 * kb + kk);
+                for (int nb = 0; nb < 2; ++nb)
+                    for (int kb = 0; kb < 2; ++kb) {
+                        img[kImgL2 + (nb * 2 + kb) * 1024 + o] = W2(32 * kb + kk, 32 * nb + i);
+                        img[kImgB2 + (nb * 2 + kb) * 1024 + o] = W2(32 * nb + i, 32 * kb + kk);
+                    }
+            }
+    // RBF centres: float32 linspace, gap = c[1] - c[0]  (layers.py:31-34)
+    std::vector<float> c(kK, 0.f);
+    for (int k = 0; k < K; ++k) {
+        double step = (d->rbf_high - d->rbf_low) / (double)(K - 1);
+        c[k] = (float)(k == K - 1 ? d->rbf_high : d->rbf_low + k * step);
+    }
+    *gap_out = c[1] - c[0];
+    for (int b = 0; b < 2; ++b)
+        for (int hh = 0; hh < 2; ++hh)
+            for (int v = 0; v < 16; ++v) {
+                const int f = 32 * b + f0(v) + 4 * hh, o = (b * 2 + hh) * 16 + v;
+                img[kTabB1 + o] = f < H1 ? d->b1[f] : 0.f;
+                img[kTabB2 + o] = f < H2 ? d->b2[f] : 0.f;
+                img[kTabW3 + o] = f < H2 ? d->W3[f] : 0.f;
+                if (b == 0) img[kTabC + hh * 16 + v] = c[f0(v) + 4 * hh];
+            }
+}
+
+int mlp_create(const htf_potential_desc *d, MlpDevice **out) {
+    HTF_REQUIRE(d->W1 && d->b1 && d->W2 && d->b2 && d->W3 && d->b3, "pair-MLP: null weight pointer");
+    HTF_REQUIRE(d->K >= 2 && d->K <= kK, "pair-MLP: K=%d outside [2, %d]", d->K, kK);
+    HTF_REQUIRE(d->H1 >= 1 && d->H1 <= kH && d->H2 >= 1 && d->H2 <= kH, "pair-MLP: hidden widths (%d, %d) must be <= %d", d->H1, d->H2, kH);
+    HTF_REQUIRE(d->rbf_high > d->rbf_low, "pair-MLP: rbf_high must exceed rbf_low");
+    HTF_REQUIRE(d->activation == HTF_ACT_LINEAR || d->activation == HTF_ACT_TANH, "pair-MLP: unknown activation %d", d->activation);
+    HTF_REQUIRE(d->mlp_precision == HTF_MLP_FP32, "pair-MLP: only the fp32 MFMA path is built (bf16 operands: next round)");
+    std::vector<float> img;
+    float gap = 1.f;
+    fill_image(img, d, &gap);
+    MlpDevice *m = new (std::nothrow) MlpDevice();
+    if (!m) {
+        set_error("pair-MLP: out of host memory");
+        return HTF_ERR_NOMEM;
+    }
+    m->b3 = d->b3[0];
+    m->gap = gap;
+    m->act = d->activation;
+    m->precision = d->mlp_precision;
+    hipError_t e = hipMalloc((void **)&m->images, kImgFloats * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(m->images, img.data(), kImgFloats * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        set_error("pair-MLP: device upload failed: %s", hipGetErrorString(e));
+        mlp_destroy(m);
+        return HTF_ERR_DEVICE;
+    }
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+        m->n_cu = prop.multiProcessorCount;
+    *out = m;
+    return HTF_OK;
+}
+
+void mlp_destroy(MlpDevice *m) {
+    if (!m) return;
+    if (m->images) (void)hipFree(m->images);
+    delete m;
+}
+
+template <bool TANH>
+static int launch_mlp(const MlpDevice *m, const void *nlist, int in_dtype, unsigned B, unsigned NN, void *force,
+                      int out_f64, hipStream_t s) {
+    // persistent blocks: 3 per CU (LDS 48.9 KiB each), 4 waves per block, one row per wave trip
+    unsigned grid = (unsigned)m->n_cu * 3u;
+    unsigned need = (B + 3) / 4;
+    if (grid > need) grid = need;
+    if (in_dtype == HTF_F32)
+        hipLaunchKernelGGL((pair_mlp_kernel<TANH, float>), dim3(grid), dim3(256), 0, s, (const float4 *)nlist, B, NN, force, out_f64, m->images, m->b3, m->gap);
+    else
+        hipLaunchKernelGGL((pair_mlp_kernel<TANH, double>), dim3(grid), dim3(256), 0, s, (const double4 *)nlist, B, NN, force, out_f64, m->images, m->b3, m->gap);
+    return check_launch("pair_mlp_kernel");
+}
+
+int mlp_eval(const MlpDevice *m, const void *nlist, int in_dtype, unsigned B, unsigned NN, void *force,
+             int force_dtype, hipStream_t stream) {
+    HTF_REQUIRE(m, "pair-MLP: null potential");
+    const int out_f64 = force_dtype == HTF_F64;
+    return m->act == HTF_ACT_TANH ? launch_mlp<true>(m, nlist, in_dtype, B, NN, force, out_f64, stream)
+                                  : launch_mlp<false>(m, nlist, in_dtype, B, NN, force, out_f64, stream);
+}
+
+} // namespace htf

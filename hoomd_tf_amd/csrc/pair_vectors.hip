@@ -103,7 +103,8 @@ __global__ __launch_bounds__(256) void build_pair_vectors_kernel(
     typename Vec4<DT>::type *__restrict__ dest, const typename Vec4<PT>::type *__restrict__ pos,
     unsigned N, unsigned NN, unsigned offset, unsigned batch, BoxT<PT> box,
     const unsigned *__restrict__ n_neigh, const unsigned *__restrict__ nlist,
-    const unsigned *__restrict__ head_list, PT rmaxsq, unsigned *__restrict__ max_count) {
+    const unsigned *__restrict__ head_list, PT rmaxsq, unsigned *__restrict__ max_count,
+    float4 *__restrict__ positions_out) {
     using DV = typename Vec4<DT>::type;
     const unsigned lane = threadIdx.x & 63u;
     const unsigned w = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
@@ -114,6 +115,10 @@ __global__ __launch_bounds__(256) void build_pair_vectors_kernel(
     const unsigned *nl = nlist + head_list[idx];
     const auto pi = pos[idx];
     DV *row = dest + (size_t)w * NN;
+    // m_positions_comm.receiveArray(..., unstuff4=true) (TensorflowCompute.cc:172) for free:
+    // this wave already holds pos[idx]
+    if (positions_out != nullptr && lane == 0)
+        positions_out[w] = make_float4((float)pi.x, (float)pi.y, (float)pi.z, (float)scalar_as_int(pi.w));
 
     unsigned Q = nn ? sweep<PT, DT, false>(row, pos, nl, nn, pi, box, rmaxsq, NN, lane, 0u) : 0u;
 
@@ -131,14 +136,14 @@ __global__ __launch_bounds__(256) void build_pair_vectors_kernel(
         unsigned lo = Q - NN > NN ? Q - NN : NN;
         sweep<PT, DT, true>(row, pos, nl, nn, pi, box, rmaxsq, NN, lane, lo);
     }
-    if (max_count != nullptr && lane == 0) atomicMax(max_count, Q);
+    if (max_count != nullptr && lane == 0 && Q > *(volatile unsigned *)max_count) atomicMax(max_count, Q);
 }
 
 template <typename PT, typename DT>
 static int launch_build(void *dest, const void *pos, unsigned N, unsigned NN, unsigned offset,
                         unsigned batch, const htf_box *hb, const unsigned *n_neigh,
                         const unsigned *nlist, const unsigned *head_list, double rmax,
-                        unsigned *max_count, hipStream_t stream) {
+                        unsigned *max_count, float4 *positions_out, hipStream_t stream) {
     BoxT<PT> b;
     for (int d = 0; d < 3; ++d) {
         b.L[d] = (PT)hb->hi[d] - (PT)hb->lo[d];
@@ -154,19 +159,17 @@ static int launch_build(void *dest, const void *pos, unsigned N, unsigned NN, un
     unsigned grid = (batch + waves_per_block - 1) / waves_per_block;
     hipLaunchKernelGGL((build_pair_vectors_kernel<PT, DT>), dim3(grid), dim3(64 * waves_per_block), 0, stream,
                        (typename Vec4<DT>::type *)dest, (const typename Vec4<PT>::type *)pos, N, NN,
-                       offset, batch, b, n_neigh, nlist, head_list, rmaxsq, max_count);
+                       offset, batch, b, n_neigh, nlist, head_list, rmaxsq, max_count, positions_out);
     return check_launch("build_pair_vectors_kernel");
 }
 
 } // namespace htf
 
-extern "C" int htf_build_pair_vectors(void *dest, int dest_dtype, const void *d_pos, int pos_dtype,
-                                      unsigned N, unsigned NN, unsigned offset, unsigned batch_size,
-                                      unsigned n_ghost, const htf_box *box, const unsigned *d_n_neigh,
-                                      const unsigned *d_nlist, const unsigned *d_head_list, double rmax,
-                                      unsigned *d_max_count, htf_stream stream) {
-    using namespace htf;
-    (void)n_ghost; // ghosts are addressed through the index list (k >= N); nothing to size
+namespace htf {
+int build_pair_vectors_impl(void *dest, int dest_dtype, const void *d_pos, int pos_dtype, unsigned N, unsigned NN,
+                            unsigned offset, unsigned batch_size, const htf_box *box, const unsigned *d_n_neigh,
+                            const unsigned *d_nlist, const unsigned *d_head_list, double rmax,
+                            unsigned *d_max_count, float4 *positions_out, hipStream_t s) {
     HTF_REQUIRE(dest && d_pos && d_n_neigh && d_nlist && d_head_list && box, "htf_build_pair_vectors: null pointer");
     HTF_REQUIRE(NN > 0, "htf_build_pair_vectors: NN must be > 0");
     HTF_REQUIRE(offset <= N && batch_size <= N - offset, "htf_build_pair_vectors: batch [%u, %u) exceeds N=%u", offset, offset + batch_size, N);
@@ -174,15 +177,25 @@ extern "C" int htf_build_pair_vectors(void *dest, int dest_dtype, const void *d_
     for (int d = 0; d < 3; ++d)
         HTF_REQUIRE(box->hi[d] > box->lo[d], "htf_build_pair_vectors: empty box along %d", d);
     if (batch_size == 0) return HTF_OK;
-    hipStream_t s = (hipStream_t)stream;
     if (pos_dtype == HTF_F32 && dest_dtype == HTF_F32)
-        return launch_build<float, float>(dest, d_pos, N, NN, offset, batch_size, box, d_n_neigh, d_nlist, d_head_list, rmax, d_max_count, s);
+        return launch_build<float, float>(dest, d_pos, N, NN, offset, batch_size, box, d_n_neigh, d_nlist, d_head_list, rmax, d_max_count, positions_out, s);
     if (pos_dtype == HTF_F64 && dest_dtype == HTF_F32)
-        return launch_build<double, float>(dest, d_pos, N, NN, offset, batch_size, box, d_n_neigh, d_nlist, d_head_list, rmax, d_max_count, s);
+        return launch_build<double, float>(dest, d_pos, N, NN, offset, batch_size, box, d_n_neigh, d_nlist, d_head_list, rmax, d_max_count, positions_out, s);
     if (pos_dtype == HTF_F64 && dest_dtype == HTF_F64)
-        return launch_build<double, double>(dest, d_pos, N, NN, offset, batch_size, box, d_n_neigh, d_nlist, d_head_list, rmax, d_max_count, s);
+        return launch_build<double, double>(dest, d_pos, N, NN, offset, batch_size, box, d_n_neigh, d_nlist, d_head_list, rmax, d_max_count, positions_out, s);
     if (pos_dtype == HTF_F32 && dest_dtype == HTF_F64)
-        return launch_build<float, double>(dest, d_pos, N, NN, offset, batch_size, box, d_n_neigh, d_nlist, d_head_list, rmax, d_max_count, s);
+        return launch_build<float, double>(dest, d_pos, N, NN, offset, batch_size, box, d_n_neigh, d_nlist, d_head_list, rmax, d_max_count, positions_out, s);
     set_error("htf_build_pair_vectors: bad dtype (%d, %d)", pos_dtype, dest_dtype);
     return HTF_ERR_INVALID;
+}
+} // namespace htf
+
+extern "C" int htf_build_pair_vectors(void *dest, int dest_dtype, const void *d_pos, int pos_dtype,
+                                      unsigned N, unsigned NN, unsigned offset, unsigned batch_size,
+                                      unsigned n_ghost, const htf_box *box, const unsigned *d_n_neigh,
+                                      const unsigned *d_nlist, const unsigned *d_head_list, double rmax,
+                                      unsigned *d_max_count, htf_stream stream) {
+    (void)n_ghost; // ghosts are addressed through the index list (k >= N); nothing to size
+    return htf::build_pair_vectors_impl(dest, dest_dtype, d_pos, pos_dtype, N, NN, offset, batch_size, box, d_n_neigh,
+                                        d_nlist, d_head_list, rmax, d_max_count, nullptr, (hipStream_t)stream);
 }

@@ -71,7 +71,10 @@ __global__ __launch_bounds__(256) void max_disp_kernel(const typename Vec4<T>::t
         d2 = (float)(dx * dx + dy * dy + dz * dz);
     }
     for (int m = 1; m < 64; m <<= 1) d2 = fmaxf(d2, __shfl_xor(d2, m));
-    if ((threadIdx.x & 63) == 0) atomicMax((unsigned *)out, __float_as_uint(d2)); // d2 >= 0: uint order == float order
+    // d2 >= 0: uint order == float order.  The plain read only filters (a stale value
+    // just means one redundant atomic); without it 2048 same-address atomics serialise.
+    if ((threadIdx.x & 63) == 0 && __float_as_uint(d2) > *(volatile unsigned *)out)
+        atomicMax((unsigned *)out, __float_as_uint(d2));
 }
 
 template <typename T>
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(256) void build_nlist_kernel(const typename Vec4<T>
     if (active && g == 0) {
         n_neigh[i] = count < pitch ? count : pitch;
         head_list[i] = i * pitch;
-        atomicMax(max_neigh, count);
+        if (count > *(volatile unsigned *)max_neigh) atomicMax(max_neigh, count);
     }
 }
 

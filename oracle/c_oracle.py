@@ -19,11 +19,23 @@ def load():
     lib = C.CDLL(_SO)
     lib.htfo_num_threads.restype = C.c_int
     # use the cores this process may actually run on (cgroup/affinity), not the host total
-    try:
-        lib.htfo_set_threads(C.c_int(len(os.sched_getaffinity(0))))
-    except AttributeError:
-        pass
+    lib.htfo_set_threads(C.c_int(usable_cpus()))
     return lib
+
+
+def usable_cpus():
+    """CPUs this process can really use: min(affinity mask, cgroup cpu.max quota)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
 
 
 def _p(a):

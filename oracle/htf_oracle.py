@@ -399,7 +399,7 @@ def make_mlp_params(seed=3, K=32, H1=64, H2=64, dtype=np.float32, bias_scale=0.0
     return p
 
 
-def pair_mlp_model(nlist, params, low=0.0, high=3.0, act="tanh"):
+def pair_mlp_model(nlist, params, low=0.0, high=3.0, act="tanh", return_grad=False):
     """Pair-MLP composite (no reference model exists -- PARITY UNPINNED; defined in
     SURVEY 8(a) from a10 + a16 + a18 + a12):
 
@@ -439,6 +439,8 @@ def pair_mlp_model(nlist, params, low=0.0, high=3.0, act="tanh"):
     g = np.zeros(nlist.shape, dtype=dt)
     with np.errstate(divide="ignore", invalid="ignore"):
         g[..., :3] = dEdr[..., None] * t / r[..., None]
+    if return_grad:
+        return nlist_forces_from_grad(nlist, g, E), g
     return nlist_forces_from_grad(nlist, g, E)
 
 

@@ -226,6 +226,66 @@ def test_rinv_mask_edges(htf, cuda):
     assert np.all(np.isfinite(f))
 
 
+# --------------------------------------------------------------------------- pair-MLP (MFMA)
+@pytest.mark.parametrize("act", ["tanh", "linear"])
+@pytest.mark.parametrize("NN", [128, 40])
+def test_pair_mlp_fp32_mfma(htf, cuda, act, NN):
+    """C3 potential: RBF(0,3,32) -> 64 -> 64 -> 1 on the fp32 matrix cores vs the fp64
+    oracle on the same fp32 inputs.  Non-zero biases and asymmetric random weights so a
+    transposed / permuted operand cannot pass; NN=40 exercises the ragged last tile."""
+    from hoomd_tf_amd.initializers import mlp_params
+    params = mlp_params(seed=3, K=32, H1=64, H2=64, bias_scale=0.2)
+    nl = _nlist_case(7, N=257, NN=NN, rmin=0.6)
+    nl[1] = 0
+    nl[1, 5, :3] = [1.0, -0.5, 0.25]      # a lone real slot after padding (tile skip must not drop it)
+    nl64 = nl.astype(np.float64)
+    ref, g = O.pair_mlp_model(nl64, params, 0.0, 3.0, act, return_grad=True)
+    pot = htf.Potential.pair_mlp(params, 0.0, 3.0, activation=act)
+    f = htf.ops.eval_forces(pot, torch.from_numpy(nl).to(cuda))
+    cond = np.abs(2 * g).sum(axis=(1, 2))
+    assert_forces_close("mlp_%s_NN%d" % (act, NN), f.cpu().numpy(), ref, cond, atol=2e-5, rtol=5e-5, ctol=5e-6)
+    assert np.all(f.cpu().numpy()[0] == 0)
+    f64 = htf.ops.eval_forces(pot, torch.from_numpy(nl64).to(cuda))
+    assert f64.dtype == torch.float64
+    # the fp64-wire instantiation casts to fp32 on load: same arithmetic up to fma contraction choices
+    assert_forces_close("mlp64_%s_NN%d" % (act, NN), f64.cpu().numpy(), ref, cond, atol=2e-5, rtol=5e-5, ctol=5e-6)
+
+
+def test_pair_mlp_padded_widths(htf, cuda):
+    """K < 32 / H < 64 are zero-padded into the fixed 32/64 MFMA tiling."""
+    from hoomd_tf_amd.initializers import mlp_params
+    params = mlp_params(seed=11, K=8, H1=16, H2=24, bias_scale=0.3)
+    nl = _nlist_case(9, N=64, NN=32, rmin=0.7)
+    ref, g = O.pair_mlp_model(nl.astype(np.float64), params, 0.5, 2.5, "tanh", return_grad=True)
+    f = htf.ops.eval_forces(htf.Potential.pair_mlp(params, 0.5, 2.5), torch.from_numpy(nl).to(cuda))
+    assert_forces_close("mlp_padded", f.cpu().numpy(), ref, np.abs(2 * g).sum(axis=(1, 2)), atol=2e-5, rtol=5e-5, ctol=5e-6)
+    with pytest.raises(ValueError):
+        htf.Potential.pair_mlp(mlp_params(seed=1, K=40), 0, 3)
+
+
+def test_pair_mlp_full_size_rows(htf, cuda):
+    """131072 x 128 through the MFMA kernel; sampled rows vs the oracle, determinism."""
+    from hoomd_tf_amd.initializers import mlp_params
+    N, NN = 131072, 128
+    g = torch.Generator(device="cuda").manual_seed(5)
+    cnt = torch.randint(70, 125, (N, 1), generator=g, device=cuda)
+    v = torch.randn(N, NN, 3, generator=g, device=cuda)
+    v = v / v.norm(dim=2, keepdim=True)
+    r = 0.8 + 2.2 * torch.rand(N, NN, 1, generator=g, device=cuda) ** (1 / 3)
+    nl = torch.zeros(N, NN, 4, device=cuda)
+    nl[..., :3] = v * r
+    nl *= (torch.arange(NN, device=cuda)[None, :, None] < cnt[:, :, None])
+    params = mlp_params(seed=3)
+    pot = htf.Potential.pair_mlp(params, 0.0, 3.0)
+    f = htf.ops.eval_forces(pot, nl)
+    assert torch.equal(f, htf.ops.eval_forces(pot, nl))
+    rows = torch.randint(0, N, (96,), generator=g, device=cuda)
+    sub = nl[rows].cpu().numpy().astype(np.float64)
+    ref, gg = O.pair_mlp_model(sub, params, 0.0, 3.0, "tanh", return_grad=True)
+    assert_forces_close("mlp_full_rows", f[rows].cpu().numpy(), ref, np.abs(2 * gg).sum(axis=(1, 2)),
+                        atol=2e-5, rtol=5e-5, ctol=5e-6)
+
+
 # --------------------------------------------------------------------------- aux kernels
 @pytest.mark.parametrize("tdt", [torch.float32, torch.float64])
 def test_aux_kernels(htf, cuda, tdt):
