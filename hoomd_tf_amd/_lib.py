@@ -87,6 +87,11 @@ PROTOTYPES = {
     "htf_get_positions_buffer": (_vp, [_vp]),
     "htf_get_virial_buffer": (_vp, [_vp]),
     "htf_get_batch_capacity": (_u, [_vp]),
+    "htf_rdf_histogram": (_i, [_vp, _i, _u, _u, C.c_float, C.c_float, _u, _vp, _u, _i, _i, _vp, _vp]),
+    "htf_rdf_finalize": (_i, [_vp, _u, C.c_float, C.c_float, _vp, _vp, _vp]),
+    "htf_rbf_expansion": (_i, [_vp, _sz, _d, _d, _u, _vp, _vp]),
+    "htf_eds_update": (_i, [_vp, _vp, C.c_float, _i, C.c_float, C.c_float, _vp]),
+    "htf_wrap_vector": (_i, [_vp, _i, _sz, C.POINTER(Box), _vp, _vp]),
     "htf_profile_enable": (_i, [_vp, _i]),
     "htf_profile_read": (_i, [_vp, C.POINTER(_d), C.POINTER(_d), C.POINTER(_u)]),
 }

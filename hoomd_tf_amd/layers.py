@@ -1,0 +1,124 @@
+"""Counterpart of ``hoomd/htf/layers.py``: RBFExpansion, WCARepulsion, EDSLayer, plus the
+declarative pair-MLP (RBF -> Dense -> Dense -> Dense) that config C3 evaluates on MFMA."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, ops, simmodel
+from ._lib import lib, check
+from .initializers import mlp_params
+
+
+class RBFExpansion:
+    """layers.py:7-49: ``exp(-(d - mu)^2 / gap)`` on an evenly spaced grid of ``count``
+    centres from ``low`` to ``high`` (inclusive); gap = centre spacing (not squared)."""
+
+    def __init__(self, low, high, count):
+        self.low, self.high, self.count = float(low), float(high), int(count)
+        self.centers = np.linspace(self.low, self.high, self.count).astype(np.float32)
+        self.gap = np.float32(self.centers[1] - self.centers[0])
+
+    def get_config(self):
+        return {'low': self.low, 'high': self.high, 'count': self.count}
+
+    def __call__(self, inputs):
+        if isinstance(inputs, simmodel.SafeNorm):
+            inputs = inputs.tensor()
+        x = inputs.to(torch.float32).contiguous()
+        ops._dev(x, "inputs")
+        out = torch.empty(tuple(x.shape) + (self.count,), dtype=torch.float32, device=x.device)
+        check(lib.htf_rbf_expansion(x.data_ptr(), x.numel(), self.low, self.high, self.count, out.data_ptr(),
+                                    ops._stream(x)))
+        return out
+
+
+class WCARepulsion:
+    """layers.py:52-98: trainable WCA repulsion ``(sigma/r)^6`` inside ``2^(1/3) sigma``,
+    clipped to [0, 10].  Called on the neighbor list; returns the pair energy."""
+
+    def __init__(self, sigma, regularization_strength=1e-3):
+        self.sigma = float(np.float32(sigma))
+        self.regularization_strength = regularization_strength
+
+    def get_config(self):
+        return {'sigma': float(self.sigma)}
+
+    def __call__(self, nlist):
+        return simmodel.WCAPair(simmodel._as_nlist(nlist), self.sigma)
+
+
+class PairMLP:
+    """safe_norm -> RBFExpansion(low, high, K) -> Dense(H1) -> Dense(H2) -> Dense(1), masked
+    with the nlist_rinv criterion and halved per pair (SURVEY 8(a) closed forms).  Keras
+    Dense defaults: glorot-uniform kernels, zero biases, ``activation=None``; pass
+    ``activation='tanh'`` for the C3 benchmark model."""
+
+    def __init__(self, K=32, H1=64, H2=64, low=0.0, high=3.0, activation=None, seed=3, precision="fp32"):
+        self.low, self.high = float(low), float(high)
+        self.activation = activation or "linear"
+        self.precision = precision
+        self.params = mlp_params(seed=seed, K=K, H1=H1, H2=H2)
+        self._version = 0
+
+    def get_weights(self):
+        return [self.params[k].copy() for k in ("W1", "b1", "W2", "b2", "W3", "b3")]
+
+    def set_weights(self, ws):
+        for k, w in zip(("W1", "b1", "W2", "b2", "W3", "b3"), ws):
+            if np.shape(w) != self.params[k].shape:
+                raise ValueError("shape mismatch for %s" % k)
+            self.params[k] = np.asarray(w, dtype=np.float32).copy()
+        self._version += 1  # invalidates the cached device images
+
+    def save_weights(self, path):
+        np.savez(path, **self.params)
+
+    def load_weights(self, path):
+        with np.load(path) as z:
+            self.set_weights([z[k] for k in ("W1", "b1", "W2", "b2", "W3", "b3")])
+
+    def __call__(self, nlist):
+        return simmodel.MLPEnergy(simmodel._as_nlist(nlist), self)
+
+
+class EDSLayer:
+    """layers.py:101-195.  Call it on the collective variable every step; returns alpha,
+    the EDS coupling constant.  The running mean / ssd / TF1-Adam state lives on the
+    device and advances in a one-thread kernel, so a device-resident CV never visits
+    the host."""
+
+    def __init__(self, set_point, period, learning_rate=1e-2, cv_scale=1.0, name='eds-layer', device="cuda"):
+        if isinstance(set_point, (int, np.integer)) and not isinstance(set_point, bool):
+            raise ValueError('EDS only works with floats, not dtype' + str(type(set_point)))
+        self.set_point = float(set_point)
+        self.period = int(period)
+        self.cv_scale = float(cv_scale)
+        self.learning_rate = float(learning_rate)
+        self.name = name
+        self.state = torch.zeros(8, dtype=torch.float32, device=device)
+
+    def get_config(self):
+        return {'set_point': self.set_point, 'period': self.period, 'cv_scale': self.cv_scale,
+                'learning_rate': self.learning_rate}
+
+    @property
+    def alpha(self):
+        return self.state[2]
+
+    @property
+    def mean(self):
+        return self.state[0]
+
+    @property
+    def n(self):
+        return int(self.state[5].item())
+
+    def __call__(self, cv):
+        if not isinstance(cv, torch.Tensor):
+            cv = torch.tensor(float(cv), dtype=torch.float32, device=self.state.device)
+        cv = cv.detach().to(torch.float32).reshape(1).contiguous()
+        check(lib.htf_eds_update(self.state.data_ptr(), cv.data_ptr(), self.set_point, self.period,
+                                 self.learning_rate, self.cv_scale, ops._stream(self.state)))
+        simmodel._trace_log().append({"stateful": self.name})
+        return self.state[2]

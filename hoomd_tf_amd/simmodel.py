@@ -1,0 +1,402 @@
+"""Model API of the force path: the counterpart of ``hoomd/htf/simmodel.py``.
+
+The reference lets users write ``compute(nlist, positions, box)`` in TensorFlow and
+differentiates the energy with ``tf.gradients``.  Here the same method bodies are
+written against a small *declarative* expression layer: ``nlist_rinv``, ``safe_norm``,
+``RBFExpansion``, ``WCARepulsion``, ``PairMLP`` return symbolic pair-energy
+expressions, and ``compute_nlist_forces`` lowers the expression to ONE fused HIP kernel
+(energy, analytic gradient, x2, neighbor sum, energy column, optional virial) -- the
+analogue of ``tf.function`` tracing ``compute`` into a graph.  Names, argument meaning
+and error behaviour follow the reference (cited per function).
+"""
+import ctypes as C
+import threading
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from ._lib import lib, check, NlistOverflowError, SkewedBoxError  # noqa: F401
+
+_trace = threading.local()
+
+
+def _trace_log():
+    if not hasattr(_trace, "calls"):
+        _trace.calls = []
+    return _trace.calls
+
+
+# --------------------------------------------------------------------------- tensors
+class Nlist:
+    """The ``N x NN x 4`` neighbor tensor handed to ``compute`` (simmodel.py:99-105):
+    a zero-copy view of the pair-vector buffer plus the identity the expression layer
+    needs.  ``nlist[:, :, :3]`` stays symbolic; anything else indexes the tensor."""
+
+    def __init__(self, tensor):
+        self.tensor = tensor
+
+    shape = property(lambda self: self.tensor.shape)
+    dtype = property(lambda self: self.tensor.dtype)
+    device = property(lambda self: self.tensor.device)
+
+    def __getitem__(self, idx):
+        full = slice(None)
+        if isinstance(idx, tuple) and len(idx) == 3 and idx[0] == full and idx[1] == full and idx[2] == slice(None, 3):
+            return NlistXYZ(self)
+        return self.tensor[idx]
+
+    def numpy(self):
+        return self.tensor.cpu().numpy()
+
+
+class NlistXYZ:
+    """``nlist[:, :, :3]``"""
+
+    def __init__(self, parent):
+        self.parent = parent
+
+    @property
+    def tensor(self):
+        return self.parent.tensor[:, :, :3]
+
+    def numpy(self):
+        return self.tensor.cpu().numpy()
+
+
+def _as_nlist(x):
+    if isinstance(x, Nlist):
+        return x
+    if isinstance(x, torch.Tensor):
+        return Nlist(x)
+    raise ValueError("expected the nlist tensor")
+
+
+# --------------------------------------------------------------------------- expressions
+class PairEnergy:
+    """Base of the symbolic per-pair energies.  ``reduced`` marks a per-particle sum."""
+    reduced = False
+
+    def potential(self):
+        raise NotImplementedError
+
+    def key(self):
+        raise NotImplementedError
+
+
+class RinvPoly(PairEnergy):
+    """sum_k c_k * rinv^p_k with rinv = nlist_rinv(nlist)."""
+
+    def __init__(self, nlist, terms, reduced=False):
+        self.nlist = nlist
+        self.terms = {p: c for p, c in terms.items() if c != 0}
+        self.reduced = reduced
+
+    def _bin(self, other, sign):
+        if isinstance(other, RinvPoly):
+            if other.nlist is not self.nlist:
+                raise ValueError("expressions come from different neighbor lists")
+            t = dict(self.terms)
+            for p, c in other.terms.items():
+                t[p] = t.get(p, 0.0) + sign * c
+            return RinvPoly(self.nlist, t, self.reduced and other.reduced)
+        raise TypeError("cannot combine a rinv polynomial with %r (constants carry no force)" % (other,))
+
+    def __add__(self, o):
+        return self._bin(o, 1.0)
+
+    def __sub__(self, o):
+        return self._bin(o, -1.0)
+
+    def __neg__(self):
+        return RinvPoly(self.nlist, {p: -c for p, c in self.terms.items()}, self.reduced)
+
+    def __mul__(self, o):
+        if isinstance(o, (int, float)):
+            return RinvPoly(self.nlist, {p: c * o for p, c in self.terms.items()}, self.reduced)
+        if isinstance(o, RinvPoly):
+            if o.nlist is not self.nlist or self.reduced or o.reduced:
+                raise ValueError("can only multiply per-pair expressions of one neighbor list")
+            t = {}
+            for p1, c1 in self.terms.items():
+                for p2, c2 in o.terms.items():
+                    t[p1 + p2] = t.get(p1 + p2, 0.0) + c1 * c2
+            return RinvPoly(self.nlist, t)
+        return NotImplemented
+
+    __rmul__ = __mul__
+
+    def __truediv__(self, o):
+        return self * (1.0 / o)
+
+    def __pow__(self, n):
+        if int(n) != n or n < 1:
+            raise ValueError("only positive integer powers of rinv are supported")
+        out = self
+        for _ in range(int(n) - 1):
+            out = out * self
+        return out
+
+    def key(self):
+        return ("poly", tuple(sorted(self.terms.items())))
+
+    def potential(self):
+        t = dict(self.terms)
+        if len(t) == 2 and t.get(12) == 2.0 and t.get(6) == -2.0:
+            return ops.Potential.lj()  # LJModel: 4/2 (rinv^12 - rinv^6), build_examples.py:67-77
+        if any(p < 1 for p in t):
+            raise ValueError("rinv powers must be >= 1")
+        powers = sorted(t)
+        return ops.Potential.rinv_poly([t[p] for p in powers], powers)
+
+    def tensor(self):
+        """Eager value [N, NN] (or [N] once reduced) for model outputs other than forces."""
+        s = ops.nlist_rinv(self.nlist.tensor)
+        out = torch.zeros_like(s)
+        for p, c in self.terms.items():
+            out += c * s ** p
+        return out.sum(dim=1) if self.reduced else out
+
+
+class WCAPair(PairEnergy):
+    """WCARepulsion(sigma)(nlist): layers.py:91-98."""
+
+    def __init__(self, nlist, sigma):
+        self.nlist, self.sigma = nlist, float(sigma)
+
+    def key(self):
+        return ("wca", self.sigma)
+
+    def potential(self):
+        return ops.Potential.wca(self.sigma)
+
+
+class MLPEnergy(PairEnergy):
+    """1/2 sum_j [r > 3e-6] MLP(RBF(safe_norm(x_ij))): the C3 pair potential."""
+    reduced = True
+
+    def __init__(self, nlist, layer):
+        self.nlist, self.layer = nlist, layer
+
+    def key(self):
+        return ("mlp", id(self.layer), self.layer._version)
+
+    def potential(self):
+        L = self.layer
+        return ops.Potential.pair_mlp(L.params, L.low, L.high, activation=L.activation, precision=L.precision)
+
+
+class SafeNorm:
+    """safe_norm(nlist[:, :, :3], axis=2) kept symbolic so RBF/MLP layers can fuse."""
+
+    def __init__(self, nlist, delta):
+        self.nlist, self.delta = nlist, delta
+
+    def tensor(self):
+        t = self.nlist.tensor[:, :, :3] + self.delta
+        return torch.sqrt((t * t).sum(dim=2))
+
+
+def reduce_sum(x, axis=None):
+    """tf.reduce_sum for expressions (axis=1: per-particle energy) and tensors."""
+    if isinstance(x, RinvPoly):
+        if axis not in (1, -1):
+            raise ValueError("pair energies reduce over the neighbor axis (axis=1)")
+        return RinvPoly(x.nlist, x.terms, reduced=True)
+    if isinstance(x, WCAPair):
+        return x
+    return x.sum() if axis is None else x.sum(dim=axis)
+
+
+# --------------------------------------------------------------------------- free functions
+def nlist_rinv(nlist):
+    """simmodel.py:618-635: 1/r per neighbor, padded slots exactly 0, differentiable."""
+    return RinvPoly(_as_nlist(nlist), {1: 1.0})
+
+
+def safe_norm(tensor, delta=1e-7, axis=None, **kwargs):
+    """simmodel.py:581-594: ``tf.norm(tensor + delta)``."""
+    if isinstance(tensor, NlistXYZ):
+        if axis not in (2, -1):
+            raise ValueError("safe_norm of the pair vectors reduces axis=2")
+        return SafeNorm(tensor.parent, delta)
+    t = tensor + delta
+    return torch.sqrt((t * t).sum()) if axis is None else torch.sqrt((t * t).sum(dim=axis))
+
+
+def compute_nlist_forces(nlist, energy, virial=False):
+    """simmodel.py:526-555.  Returns forces [N,4] (fx,fy,fz,energy), or (forces, virial
+    [N,3,3]) when ``virial``.  Raises ValueError when energy does not depend on nlist
+    ('Did you put them in wrong order?')."""
+    if not isinstance(energy, PairEnergy):
+        raise ValueError('Could not find dependence between energy and nlist.'
+                         ' Did you put them in wrong order?')
+    nl = _as_nlist(nlist)
+    if energy.nlist is not nl and energy.nlist.tensor is not nl.tensor:
+        raise ValueError('Could not find dependence between energy and nlist.'
+                         ' Did you put them in wrong order?')
+    cache = getattr(compute_nlist_forces, "_cache", None)
+    if cache is None:
+        cache = compute_nlist_forces._cache = {}
+    k = energy.key()
+    pot = cache.get(k)
+    if pot is None:
+        if len(cache) > 64:
+            cache.clear()
+        pot = cache[k] = energy.potential()
+    out = ops.eval_forces(pot, nl.tensor, virial=virial)
+    f = out[0] if virial else out
+    _trace_log().append({"potential": pot, "nlist": nl, "virial": virial, "forces": f})
+    return out
+
+
+def pairwise_unit_forces(nlist):
+    """SimplePotential's body (build_examples.py:9-22) as one fused op:
+    F_i = -sum_j x_ij / |x_ij| with non-finite terms dropped.  Returns [N, 4] (w = 0)."""
+    nl = _as_nlist(nlist)
+    cache = getattr(pairwise_unit_forces, "_pot", None)
+    if cache is None:
+        cache = pairwise_unit_forces._pot = ops.Potential.simple()
+    f = ops.eval_forces(cache, nl.tensor)
+    _trace_log().append({"potential": cache, "nlist": nl, "virial": False, "forces": f})
+    return f
+
+
+def compute_positions_forces(positions, energy):
+    """simmodel.py:492-506: ``-dE/dpositions`` with the energy column appended.  CV-bias
+    models are O(few particles); this generic path differentiates with torch.autograd
+    (SURVEY 8(f)-3 fallback), not a fused kernel."""
+    if not (isinstance(energy, torch.Tensor) and energy.requires_grad):
+        raise ValueError('Could not find dependence between energy and positions.')
+    (g,) = torch.autograd.grad(energy.sum(), positions, allow_unused=False)
+    forces = -g
+    N = positions.shape[0]
+    e = energy.detach()
+    if e.dim() == 0:
+        col = e.reshape(1).repeat(N)
+    elif e.dim() > 1:
+        col = e.reshape(N, -1).sum(dim=1)
+    else:
+        col = e
+    return torch.cat([forces[:, :3], col.reshape(N, 1)], dim=-1)
+
+
+def box_size(box):
+    """simmodel.py:597-603."""
+    return box[1, :] - box[0, :]
+
+
+def wrap_vector(r, box):
+    """simmodel.py:606-615: minimum image of ``r`` (orthorhombic)."""
+    r2 = r.reshape(-1, 3).contiguous()
+    if not r2.is_cuda or r2.requires_grad:
+        bs = box_size(box).to(r.dtype)
+        return r - torch.round(r / bs) * bs
+    out = torch.empty_like(r2)
+    b = _lib.make_box(box.detach().cpu().numpy())
+    check(lib.htf_wrap_vector(r2.data_ptr(), ops._dt(r2), r2.shape[0], C.byref(b), out.data_ptr(), ops._stream(r2)))
+    return out.reshape(r.shape)
+
+
+def masked_nlist(nlist, type_tensor, type_i=None, type_j=None):
+    """simmodel.py:676-693 (eager; pure data movement)."""
+    t = nlist.tensor if isinstance(nlist, Nlist) else nlist
+    if type_i is not None:
+        t = t[type_tensor == type_i]
+    if type_j is not None:
+        t = t * (t[:, :, 3] == type_j).to(t.dtype)[:, :, None]
+    return t
+
+
+def compute_rdf(nlist, r_range, type_tensor=None, nbins=100, type_i=None, type_j=None):
+    """simmodel.py:638-673 -> (rdf[nbins], bin midpoints), both fp32 device tensors.
+    One fused histogram pass over the pair vectors (type masking included)."""
+    t = nlist.tensor if isinstance(nlist, Nlist) else nlist
+    ops._dev(t, "nlist")
+    r0, r1 = float(r_range[0]), float(r_range[1])
+    hist = torch.zeros(nbins + 2, dtype=torch.int32, device=t.device)
+    tt, stride = None, 0
+    if type_tensor is not None:
+        tt = type_tensor.to(torch.float32)
+        stride = tt.stride(0) if tt.dim() == 1 else 1
+        if not tt.is_cuda:
+            raise ValueError("type_tensor must live on the device")
+    else:
+        type_i = type_j = None
+    check(lib.htf_rdf_histogram(t.data_ptr(), ops._dt(t), int(t.shape[0]), int(t.shape[1]), r0, r1, nbins + 2,
+                                tt.data_ptr() if tt is not None else None, int(stride),
+                                -1 if type_i is None else int(type_i), -1 if type_j is None else int(type_j),
+                                hist.data_ptr(), ops._stream(t)))
+    rdf = torch.empty(nbins, dtype=torch.float32, device=t.device)
+    rs = torch.empty(nbins, dtype=torch.float32, device=t.device)
+    check(lib.htf_rdf_finalize(hist.data_ptr(), nbins, r0, r1, rdf.data_ptr(), rs.data_ptr(), ops._stream(t)))
+    return rdf, rs
+
+
+# --------------------------------------------------------------------------- SimModel
+class SimModel:
+    """simmodel.py:8-145.  Subclass and implement ``compute``; optionally ``setup``."""
+
+    def __init__(self, nneighbor_cutoff, output_forces=True, virial=False, check_nlist=False,
+                 dtype=torch.float32, name='htf-model', **kwargs):
+        self.nneighbor_cutoff = nneighbor_cutoff
+        self.output_forces = output_forces
+        self.virial = virial
+        self.check_nlist = check_nlist
+        self.dtype = dtype
+        self.name = name
+        self._map_nlist = False
+        self.loss = None
+        if SimModel.compute == self.__class__.compute:
+            raise AttributeError('You must implement compute method in subclass')
+        try:
+            code = self.compute.__code__
+            self._arg_count = code.co_argcount - 1  # - 1 for self
+            self._pass_training = 'training' == code.co_varnames[self._arg_count]
+            if self._pass_training:
+                self._arg_count -= 1
+        except AttributeError:
+            raise AttributeError('SimModel child class must implement compute method, and should not implement call')
+        self.batch_steps = 0
+        self.setup(**kwargs)
+
+    def get_config(self):
+        return {'nneighbor_cutoff': self.nneighbor_cutoff, 'output_forces': self.output_forces,
+                'virial': self.virial, 'check_nlist': self.check_nlist, 'name': self.name, 'dtype': self.dtype}
+
+    def compute(self, nlist, positions, box, training=True):
+        raise AttributeError('You must implement compute in your subclass')
+
+    def setup(self, **kwargs):
+        pass
+
+    def retrace_compute(self):
+        """simmodel.py:147-163: forget the fused plan so the next step re-traces compute."""
+        self._plan = None
+
+    def __call__(self, inputs, training=False):
+        args = list(inputs[:self._arg_count])
+        out = self.compute(*args, training) if self._pass_training else self.compute(*args)
+        if not isinstance(out, (tuple, list)):
+            out = (out,)
+        return tuple(out)
+
+    def compute_inputs(self, nlist, positions, box):
+        """simmodel.py:165-238 minus the copies: box-skew assert, optional check_nlist,
+        cast to the model dtype (a no-op view when the wire dtype already matches)."""
+        if not float(box[2].sum()) < 0.0001:
+            raise SkewedBoxError('box is skewed')
+        if self.check_nlist and self.nneighbor_cutoff > 0:
+            if not ops.check_nlist(nlist) < self.nneighbor_cutoff:
+                raise NlistOverflowError('Neighbor list is full!')
+        positions = positions.to(self.dtype)
+        if self.nneighbor_cutoff == 0:
+            positions.requires_grad_(True)  # CV-bias models differentiate w.r.t. positions
+        return [Nlist(nlist.to(self.dtype)), positions, box.to(self.dtype)]
+
+    @staticmethod
+    def compute_outputs(forces, out_dtype):
+        """simmodel.py:240-255: pad [N,3] -> [N,4] with a zero energy column, cast."""
+        if forces.shape[1] == 3:
+            forces = torch.cat([forces, torch.zeros_like(forces[:, :1])], dim=1)
+        return forces.to(out_dtype)

@@ -98,6 +98,14 @@ class CellNlist:
         self._disp = torch.zeros(1, dtype=torch.float32, device=system.device)
         self._max = torch.zeros(1, dtype=torch.int32, device=system.device)
         self.n_builds = 0
+        self._subscribers = []
+
+    def subscribe(self, rcut_fn):
+        """NeighborList r_cut subscription (tensorflowcompute.py:116-120): the list is
+        built for the largest cutoff any attached compute asks for."""
+        self._subscribers.append(rcut_fn)
+        self.r_cut = max([self.r_cut] + [float(fn()) for fn in self._subscribers])
+        self._ref = None
 
     @property
     def r_list(self):
@@ -174,3 +182,58 @@ class NVE:
         s = self.sys
         check(lib.htfs_nve_step(s.pos.data_ptr(), s.vel.data_ptr(), s.force.data_ptr(), s.scalar_code, s.N,
                                 self.dt, C.byref(s.box), C.c_void_p(torch.cuda.current_stream(s.device).cuda_stream)))
+
+
+# --------------------------------------------------------------------------- run loop
+_current = {"sim": None}
+
+
+def current_simulation():
+    """hoomd.context.current analogue."""
+    return _current["sim"]
+
+
+class Simulation:
+    """System::run analogue: per step, every attached force computes (ForceCompute::
+    compute), the net force is formed, the integrator advances, computes observe."""
+
+    def __init__(self, system):
+        self.system = system
+        self.forces = []     # hoomd.context.current.forces
+        self.computes = []   # system.addCompute(...) without forces
+        self.integrator = None
+        _current["sim"] = self
+
+    def nlist_cell(self, r_buff=0.4, check_period=1, pitch=None):
+        """hoomd.md.nlist.cell(): r_cut comes from the subscribers (nlist.subscribe)."""
+        return CellNlist(self.system, r_cut=0.0, r_buff=r_buff, pitch=pitch, check_period=check_period)
+
+    def integrate_nve(self, dt):
+        self.integrator = NVE(self.system, dt)
+        return self.integrator
+
+    @property
+    def net_force(self):
+        return self.system.force
+
+    def compute_forces(self):
+        s = self.system
+        ts = s.timestep
+        for f in self.forces:
+            f.compute(ts)
+        if len(self.forces) == 1:
+            s.force = self.forces[0].force
+        elif self.forces:
+            s.force = self.forces[0].force.clone()
+            for f in self.forces[1:]:
+                ops.add_scalar4(s.force, f.force)
+        for c in self.computes:
+            c.compute(ts)
+
+    def run(self, nsteps):
+        s = self.system
+        for _ in range(int(nsteps)):
+            self.compute_forces()
+            if self.integrator is not None:
+                self.integrator.step()
+            s.timestep += 1

@@ -1,0 +1,204 @@
+"""``tfcompute``: the counterpart of ``hoomd/htf/tensorflowcompute.py`` -- wires a
+``SimModel`` into the MD loop as a force.
+
+Where the reference constructs ``_htf.TensorflowCompute[GPU]`` and is called back from C++
+once per batch (``_finish_update``), this class owns an ``htf_ctx`` (the C-ABI
+TensorflowCompute) and has two execution paths:
+
+* traced (default for declarative models): the first step runs ``model.compute`` eagerly;
+  if it consisted of a single ``compute_nlist_forces`` over the full neighbor tensor and
+  nothing else needs saving, the lowered potential is installed in the context and every
+  later step is ONE C call (``htf_compute_forces``): no Python per batch, like a traced
+  ``tf.function``.
+* eager: ``_finish_update(batch_index)`` per batch exactly as the reference orders it:
+  compute_inputs -> model(inputs) -> outputs capture -> compute_outputs.
+"""
+import numpy as np
+import torch
+
+from . import _lib, ops, simmodel, standin
+from .simmodel import SimModel
+
+
+class tfcompute:
+    """tensorflowcompute.py:20-36."""
+
+    def __init__(self, model):
+        self.model = model
+        self.cpp_force = None
+        self._nlist = None
+        self.map_types = set()
+
+    def attach(self, nlist=None, r_cut=0, period=1, batch_size=None, train=False, save_output_period=None):
+        """tensorflowcompute.py:38-188 (same arguments and error behaviour)."""
+        sim = standin.current_simulation()
+        if sim is None:
+            raise RuntimeError('Must initialize hoomd first')
+        self.sim = sim
+        self.system = sim.system
+        self.enabled = True
+        self.force_name = 'tfcompute'
+        self.r_cut = float(r_cut)
+        self.batch_size = 0 if batch_size is None else int(batch_size)
+        self.period = int(period)
+        self.save_output_period = save_output_period
+        self.outputs = None
+        self._calls = 0
+        self._output_offset = 0
+        if self.model.output_forces:
+            self._output_offset = 1
+        if self.model.virial:
+            self._output_offset = 2
+        if train:
+            if getattr(self.model, 'loss', None) is None:
+                raise ValueError('SimModel has not been compiled')
+            raise NotImplementedError('FORCE_MODE::hoomd2tf (online training) is the next row of SURVEY 8(f)')
+        self.train = train
+        self.nneighbor_cutoff = self.model.nneighbor_cutoff
+        if nlist is not None:
+            nlist.subscribe(self.rcut)
+            self._nlist = nlist
+        elif self.nneighbor_cutoff != 0:
+            raise ValueError('Must provide an nlist if you have nneighbor_cutoff > 0')
+        self.force_mode_code = _lib.HTF_TF2HOOMD if self.model.output_forces else _lib.HTF_HOOMD2TF
+        s = self.system
+        self.dtype = s.dtype  # isDoublePrecision() (tensorflowcompute.py:166-168)
+        self.cpp_force = ops.Context(r_cut=self.r_cut if self.nneighbor_cutoff else 0.0,
+                                     nneighs=self.nneighbor_cutoff, period=self.period,
+                                     batch_size=self.batch_size, scalar_dtype=s.dtype,
+                                     check_nlist=self.model.check_nlist, virial=self.model.virial, max_n=s.N)
+        # ForceCompute::m_force / m_virial of this compute
+        self.force = torch.zeros((s.N, 4), dtype=s.dtype, device=s.device)
+        self.virial = torch.zeros(6 * s.N, dtype=s.dtype, device=s.device)
+        self._plan = None
+        self.model._plan = None
+        if self.force_mode_code == _lib.HTF_TF2HOOMD:
+            sim.forces.append(self)   # hoomd.context.current.forces.append(self)
+        else:
+            sim.computes.append(self)  # outputs only (system.addCompute)
+
+    def rcut(self):
+        """tensorflowcompute.py:284-305: the cutoff this compute subscribes to the nlist."""
+        return self.r_cut
+
+    def set_reference_forces(self, *forces):
+        """tensorflowcompute.py:265-282."""
+        if self.force_mode_code == _lib.HTF_TF2HOOMD:
+            raise ValueError('Only valid to set reference forces if mode is hoomd2tf')
+        raise NotImplementedError('reference-force labels belong to the training row (SURVEY 8(f)-1)')
+
+    # ------------------------------------------------------------------ per step
+    def _arrays(self):
+        s, nl = self.system, self._nlist
+        if nl is not None:
+            return self.cpp_force.make_arrays(s.pos, s.N, nl.n_neigh, nl.head_list, nl.nlist, s.box, self.force,
+                                              self.virial, s.N)
+        return self.cpp_force.make_arrays(s.pos, s.N, None, None, None, s.box, self.force, self.virial, s.N)
+
+    def compute(self, timestep):
+        """ForceCompute::compute -> TensorflowCompute::computeForces (.cc:129-216)."""
+        if timestep % self.period != 0:
+            return
+        if self._nlist is not None:
+            self._nlist.compute(timestep)  # m_nlist->compute(timestep), .cc:162-163
+        if self._plan is not None and self.model._plan is self._plan:
+            self._calls += 1
+            self.cpp_force.compute_forces(timestep, self._arrays())
+            return
+        s = self.system
+        bs = s.N if self.batch_size == 0 else self.batch_size
+        simmodel._trace_log().clear()
+        nbatch = 0
+        for i in range(s.N // bs + 1):
+            offset = i * bs
+            n = min(s.N - offset, bs)
+            if n < 1:
+                break
+            self._finish_update(i, offset, n)
+            nbatch += 1
+        self._maybe_install_plan(nbatch)
+
+    def _maybe_install_plan(self, nbatch):
+        log = simmodel._trace_log()
+        fused = [e for e in log if "potential" in e]
+        if (self.force_mode_code == _lib.HTF_TF2HOOMD and len(log) == nbatch and len(fused) == nbatch
+                and all(e.get("is_output") for e in fused) and not self.save_output_period
+                and all(e["virial"] == bool(self.model.virial) for e in fused)
+                and len({id(e["potential"]) for e in fused}) == 1):
+            self._plan = fused[0]["potential"]
+            self.model._plan = self._plan
+            self.cpp_force.set_potential(self._plan)
+        log.clear()
+
+    def _finish_update(self, batch_index, offset, n):
+        """tensorflowcompute.py:313-345 (inference branch)."""
+        if batch_index == 0:
+            self._calls += 1
+        s, nl, m = self.system, self._nlist, self.model
+        NN = self.nneighbor_cutoff
+        if NN > 0:
+            nlist_t = ops.build_pair_vectors(s.pos, nl.n_neigh, nl.head_list, nl.nlist, s.box, self.r_cut, NN,
+                                             offset=offset, batch_size=n, n_local=s.N, out_dtype=torch.float32)
+        else:
+            nlist_t = torch.zeros((1, 1, 4), dtype=m.dtype, device=s.device)  # simmodel.py:179
+        pos_t = ops.copy_positions(s.pos, offset=offset, N=n, unstuff4=True)
+        box_t = torch.as_tensor(s.box3x3, dtype=s.dtype, device=s.device)
+        self._last = (nlist_t, pos_t, offset, n)
+        inputs = m.compute_inputs(nlist_t, pos_t, box_t)
+        mark = len(simmodel._trace_log())
+        output = m(inputs, self.train)
+        for e in simmodel._trace_log()[mark:]:
+            if "forces" in e and len(output) > 0 and output[0] is e["forces"] and e["nlist"] is inputs[0]:
+                e["is_output"] = True
+        if self.save_output_period and self._calls % self.save_output_period == 0:
+            extra = [_np(o)[np.newaxis, ...] for o in output[self._output_offset:]]
+            if self.outputs is None:
+                self.outputs = extra
+            else:
+                self.outputs = [np.append(o1, o2, axis=0) for o1, o2 in zip(self.outputs, extra)]
+        if self.force_mode_code == _lib.HTF_TF2HOOMD:
+            f = SimModel.compute_outputs(_t(output[0]), s.dtype)
+            self.force[offset:offset + n] = f
+            if m.virial:
+                v = _t(output[1]).to(s.dtype).reshape(n, 9).contiguous()
+                ops.add_virial(self.virial[offset:], v, n, s.N)  # receiveVirial, .cc:200-204
+                self._last_virial = (offset, v)
+
+    # ------------------------------------------------------------------ array getters
+    def get_positions_array(self):
+        """tensorflowcompute.py:372-375 (last batch's positions side buffer)."""
+        if self._plan is not None:
+            n = self.system.N if self.batch_size == 0 else min(self.batch_size, self.system.N)
+            return self.cpp_force.positions_buffer(n, self.system.device).double().cpu().numpy()
+        return self._last[1].double().cpu().numpy()
+
+    def get_nlist_array(self):
+        """tensorflowcompute.py:377-381 -> [B, NN, 4]."""
+        if self._plan is not None:
+            n = self.system.N if self.batch_size == 0 else min(self.batch_size, self.system.N)
+            return self.cpp_force.nlist_buffer(n, self.system.device).double().cpu().numpy()
+        return self._last[0].double().cpu().numpy().reshape(-1, self.nneighbor_cutoff, 4)
+
+    def get_forces_array(self):
+        """tensorflowcompute.py:383-386."""
+        return self.force.double().cpu().numpy()
+
+    def get_virial_array(self):
+        """tensorflowcompute.py:388-392: the [B, 9] side buffer."""
+        if self._plan is not None:
+            n = self.system.N if self.batch_size == 0 else min(self.batch_size, self.system.N)
+            return self.cpp_force.virial_buffer(n, self.system.device).double().cpu().numpy().reshape(-1, 9)
+        if getattr(self, "_last_virial", None) is not None:
+            return self._last_virial[1].double().cpu().numpy().reshape(-1, 9)
+        return np.zeros((self.system.N, 9))
+
+
+def _t(x):
+    return x.tensor() if hasattr(x, "tensor") and callable(x.tensor) else x
+
+
+def _np(x):
+    x = _t(x)
+    if isinstance(x, torch.Tensor):
+        return x.detach().cpu().numpy()
+    return np.asarray(x)

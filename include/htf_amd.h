@@ -151,6 +151,39 @@ HTF_API int htf_check_nlist(const void *d_nlist, int nlist_dtype, unsigned B, un
 HTF_API int htf_nlist_rinv(const void *d_nlist, int nlist_dtype, unsigned B, unsigned NN,
                    float *d_out, htf_stream stream);
 
+/* compute_rdf + masked_nlist (simmodel.py:638-693).  Histogram of |nlist xyz| with
+ * tf.histogram_fixed_width semantics over nbins_total = nbins + 2 bins (values clamp
+ * into the end bins; padded slots land in bin 0).  type_tensor (nullable): one float
+ * per row at stride type_stride floats (e.g. positions[:,3]); type_i >= 0 keeps only rows
+ * of that type (boolean_mask), type_j >= 0 zeroes slots whose neighbor type differs.
+ * d_hist [nbins_total] is ACCUMULATED into (caller zeroes). */
+HTF_API int htf_rdf_histogram(const void *d_nlist, int nlist_dtype, unsigned B, unsigned NN,
+                      float r0, float r1, unsigned nbins_total,
+                      const float *d_type_tensor, unsigned type_stride, int type_i, int type_j,
+                      unsigned *d_hist, htf_stream stream);
+
+/* compute_rdf's tail (simmodel.py:663-668): rdf[b] = hist[b+1] / (shell[b+1]^3 - shell[b]^3),
+ * rs[b] = (shell[b] + shell[b+1]) / 2 with shell = linspace(r0, r1, nbins + 1), fp32. */
+HTF_API int htf_rdf_finalize(const unsigned *d_hist, unsigned nbins, float r0, float r1,
+                     float *d_rdf, float *d_rs, htf_stream stream);
+
+/* RBFExpansion.call (layers.py:46-49): out[i, k] = exp(-(x[i] - c_k)^2 / gap), c = fp32
+ * linspace(low, high, count), gap = c[1] - c[0]. */
+HTF_API int htf_rbf_expansion(const float *d_x, size_t n, double low, double high, unsigned count,
+                      float *d_out, htf_stream stream);
+
+/* EDSLayer.call (layers.py:159-195) as a device-resident state machine: one step of the
+ * running-mean / ssd / TF1-Adam update on a scalar collective variable read from
+ * *d_cv.  d_state: 8 floats {mean, ssd, alpha, adam_m, adam_v, n, t, 0}, zero-initialised by
+ * the caller; alpha after the call is d_state[2].  No host round trip. */
+HTF_API int htf_eds_update(float *d_state, const float *d_cv, float set_point, int period,
+                   float learning_rate, float cv_scale, htf_stream stream);
+
+/* wrap_vector (simmodel.py:606-615): out = r - round(r / bs) * bs, bs = hi - lo, on n
+ * 3-vectors (orthorhombic; round half to even). */
+HTF_API int htf_wrap_vector(const void *d_r, int dtype, size_t n, const htf_box *box, void *d_out,
+                    htf_stream stream);
+
 /* ------------------------------------------------------------------------- *
  * Context: TensorflowCompute<M> (TensorflowCompute.h:75-250, .cc:29-216).
  * ------------------------------------------------------------------------- */

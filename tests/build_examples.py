@@ -1,0 +1,136 @@
+"""The reference's model zoo (htf/test-py/build_examples.py) written against
+hoomd_tf_amd -- same class names, same compute bodies, the TF calls replaced by the
+declarative ops of hoomd_tf_amd.simmodel / layers."""
+import torch
+
+import hoomd_tf_amd as htf
+
+
+class SimplePotential(htf.SimModel):
+    # build_examples.py:9-22
+    def compute(self, nlist, positions):
+        return htf.pairwise_unit_forces(nlist)
+
+
+class BenchmarkPotential(htf.SimModel):
+    # build_examples.py:25-30
+    def compute(self, nlist):
+        rinv = htf.nlist_rinv(nlist)
+        energy = rinv
+        forces = htf.compute_nlist_forces(nlist, energy)
+        return forces
+
+
+class LJModel(htf.SimModel):
+    # build_examples.py:67-77
+    def compute(self, nlist, positions, box):
+        rinv = htf.nlist_rinv(nlist)
+        inv_r6 = rinv**6
+        # pairwise energy. Double count -> divide by 2
+        p_energy = 4.0 / 2.0 * (inv_r6 * inv_r6 - inv_r6)
+        energy = htf.reduce_sum(p_energy, axis=1)
+        forces = htf.compute_nlist_forces(nlist, energy)
+        return forces
+
+
+class LJVirialModel(htf.SimModel):
+    # build_examples.py:104-115
+    def compute(self, nlist, positions, box):
+        rinv = htf.nlist_rinv(nlist)
+        inv_r6 = rinv**6
+        p_energy = 4.0 / 2.0 * (inv_r6 * inv_r6 - inv_r6)
+        energy = htf.reduce_sum(p_energy, axis=1)
+        forces_and_virial = htf.compute_nlist_forces(nlist, energy, virial=True)
+        return forces_and_virial
+
+
+class LJRDF(htf.SimModel):
+    # build_examples.py:287-304 (LJ through nlist_rinv; the reference's divide_no_nan variant is out of scope)
+    def setup(self):
+        self.rdfs = []
+
+    def compute(self, nlist, positions, box):
+        rinv = htf.nlist_rinv(nlist)
+        inv_r6 = rinv**6
+        p_energy = 4.0 / 2.0 * (inv_r6 * inv_r6 - inv_r6)
+        rdf, rs = htf.compute_rdf(nlist, [3, 5], positions[:, 3])
+        _, _ = htf.compute_rdf(nlist, [3, 5])
+        self.rdfs.append(rdf)
+        forces = htf.compute_nlist_forces(nlist, p_energy)
+        return forces, rdf
+
+
+class LJTypedModel(htf.SimModel):
+    # build_examples.py:80-101
+    def setup(self):
+        self.rdfa, self.rdfb = [], []
+
+    def compute(self, nlist, positions, box):
+        rinv = htf.nlist_rinv(nlist)
+        inv_r6 = rinv**6
+        p_energy = 1e-10 * (inv_r6 * inv_r6 - inv_r6)
+        energy = htf.reduce_sum(p_energy, axis=1)
+        forces = htf.compute_nlist_forces(nlist, energy)
+        rdfa, rs = htf.compute_rdf(nlist, [0, 10], positions[:, 3], type_i=0, type_j=1)
+        rdfb, rs = htf.compute_rdf(nlist, [0, 10], positions[:, 3], type_i=1, type_j=0)
+        self.rdfa.append(rdfa)
+        self.rdfb.append(rdfb)
+        return forces
+
+
+class WCA(htf.SimModel):
+    # build_examples.py:221-228
+    def setup(self):
+        self.wca = htf.WCARepulsion(0.5)
+
+    def compute(self, nlist):
+        energy = self.wca(nlist)
+        forces = htf.compute_nlist_forces(nlist, energy)
+        return forces
+
+
+class PairMLPModel(htf.SimModel):
+    # RBFExpansion + 2x64 MLP pair potential
+    def setup(self, activation='tanh', seed=3):
+        self.mlp = htf.PairMLP(32, 64, 64, 0.0, 3.0, activation=activation, seed=seed)
+
+    def compute(self, nlist):
+        energy = self.mlp(nlist)
+        return htf.compute_nlist_forces(nlist, energy)
+
+
+class WrapModel(htf.SimModel):
+    # build_examples.py:49-56
+    def compute(self, nlist, positions, box):
+        p1 = positions[0, :3]
+        p2 = positions[-1, :3]
+        r = p1 - p2
+        rwrap = htf.wrap_vector(r, box)
+        return rwrap
+
+
+class NoForceModel(htf.SimModel):
+    # build_examples.py:33-41 (energy via nlist_rinv instead of divide_no_nan)
+    def compute(self, nlist, positions):
+        energy = htf.nlist_rinv(nlist)
+        pos_norm = positions.detach().norm(dim=1)
+        return energy, pos_norm
+
+
+class EDSModel(htf.SimModel):
+    # build_examples.py:118-135
+    def setup(self, set_point):
+        self.cv_sum, self.cv_n = 0.0, 0
+        self.eds_bias = htf.EDSLayer(set_point, 5, 1 / 5)
+
+    def compute(self, nlist, positions, box):
+        # get distance from center
+        rvec = htf.wrap_vector(positions[0, :3], box)
+        cv = torch.sqrt((rvec * rvec).sum())
+        self.cv_sum += float(cv)
+        self.cv_n += 1
+        alpha = self.eds_bias(cv)
+        # eds + harmonic bond
+        energy = (cv - 5) ** 2 + cv * alpha.detach()
+        forces = htf.compute_positions_forces(positions, energy)
+        return forces, alpha
