@@ -27,6 +27,7 @@ class RBFExpansion:
             inputs = inputs.tensor()
         x = inputs.to(torch.float32).contiguous()
         ops._dev(x, "inputs")
+        simmodel._trace_log().append({"op": "rbf"})
         out = torch.empty(tuple(x.shape) + (self.count,), dtype=torch.float32, device=x.device)
         check(lib.htf_rbf_expansion(x.data_ptr(), x.numel(), self.low, self.high, self.count, out.data_ptr(),
                                     ops._stream(x)))

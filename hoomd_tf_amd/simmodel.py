@@ -151,6 +151,7 @@ class RinvPoly(PairEnergy):
 
     def tensor(self):
         """Eager value [N, NN] (or [N] once reduced) for model outputs other than forces."""
+        _trace_log().append({"op": "eager_value"})
         s = ops.nlist_rinv(self.nlist.tensor)
         out = torch.zeros_like(s)
         for p, c in self.terms.items():
@@ -288,6 +289,7 @@ def box_size(box):
 
 def wrap_vector(r, box):
     """simmodel.py:606-615: minimum image of ``r`` (orthorhombic)."""
+    _trace_log().append({"op": "wrap_vector"})
     r2 = r.reshape(-1, 3).contiguous()
     if not r2.is_cuda or r2.requires_grad:
         bs = box_size(box).to(r.dtype)
@@ -301,6 +303,7 @@ def wrap_vector(r, box):
 def masked_nlist(nlist, type_tensor, type_i=None, type_j=None):
     """simmodel.py:676-693 (eager; pure data movement)."""
     t = nlist.tensor if isinstance(nlist, Nlist) else nlist
+    _trace_log().append({"op": "masked_nlist"})
     if type_i is not None:
         t = t[type_tensor == type_i]
     if type_j is not None:
@@ -313,6 +316,7 @@ def compute_rdf(nlist, r_range, type_tensor=None, nbins=100, type_i=None, type_j
     One fused histogram pass over the pair vectors (type masking included)."""
     t = nlist.tensor if isinstance(nlist, Nlist) else nlist
     ops._dev(t, "nlist")
+    _trace_log().append({"op": "compute_rdf"})  # an observable: keeps the model on the eager path
     r0, r1 = float(r_range[0]), float(r_range[1])
     hist = torch.zeros(nbins + 2, dtype=torch.int32, device=t.device)
     tt, stride = None, 0

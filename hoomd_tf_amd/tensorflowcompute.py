@@ -71,6 +71,7 @@ class tfcompute:
         self.force = torch.zeros((s.N, 4), dtype=s.dtype, device=s.device)
         self.virial = torch.zeros(6 * s.N, dtype=s.dtype, device=s.device)
         self._plan = None
+        self._ctx_ran = False
         self.model._plan = None
         if self.force_mode_code == _lib.HTF_TF2HOOMD:
             sim.forces.append(self)   # hoomd.context.current.forces.append(self)
@@ -104,6 +105,7 @@ class tfcompute:
         if self._plan is not None and self.model._plan is self._plan:
             self._calls += 1
             self.cpp_force.compute_forces(timestep, self._arrays())
+            self._ctx_ran = True
             return
         s = self.system
         bs = s.N if self.batch_size == 0 else self.batch_size
@@ -167,14 +169,14 @@ class tfcompute:
     # ------------------------------------------------------------------ array getters
     def get_positions_array(self):
         """tensorflowcompute.py:372-375 (last batch's positions side buffer)."""
-        if self._plan is not None:
+        if self._ctx_ran:
             n = self.system.N if self.batch_size == 0 else min(self.batch_size, self.system.N)
             return self.cpp_force.positions_buffer(n, self.system.device).double().cpu().numpy()
         return self._last[1].double().cpu().numpy()
 
     def get_nlist_array(self):
         """tensorflowcompute.py:377-381 -> [B, NN, 4]."""
-        if self._plan is not None:
+        if self._ctx_ran:
             n = self.system.N if self.batch_size == 0 else min(self.batch_size, self.system.N)
             return self.cpp_force.nlist_buffer(n, self.system.device).double().cpu().numpy()
         return self._last[0].double().cpu().numpy().reshape(-1, self.nneighbor_cutoff, 4)
@@ -185,7 +187,7 @@ class tfcompute:
 
     def get_virial_array(self):
         """tensorflowcompute.py:388-392: the [B, 9] side buffer."""
-        if self._plan is not None:
+        if self._ctx_ran:
             n = self.system.N if self.batch_size == 0 else min(self.batch_size, self.system.N)
             return self.cpp_force.virial_buffer(n, self.system.device).double().cpu().numpy().reshape(-1, 9)
         if getattr(self, "_last_virial", None) is not None:
