@@ -120,13 +120,21 @@ def main():
         args.no_cpu_baseline = True  # the C port restates LJModel only
 
     # ---- synthetic system, resident in HBM -------------------------------------------------
+    # Each rank owns one 131 072-particle block; the global periodic box is `world` blocks
+    # side by side along x (config 5 at 8 ranks: 1.05 M particles, 8 x 1 x 1 slabs).
     pos, L, a = standin.fcc_positions(args.cells, 0.8442)
     rng = np.random.default_rng(3 + rank)
     pos = pos + 0.05 * a * rng.standard_normal(pos.shape)
     pos -= np.round(pos / L) * L
-    sysm = standin.System(pos, L, dtype=torch.float32, device=dev)
+    Lg = L.copy()
+    Lg[0] = L[0] * world
+    pos[:, 0] += (rank - (world - 1) / 2.0) * L[0]
+    sysm = standin.System(pos, Lg, dtype=torch.float32, device=dev)
     sysm.randomize_velocities(kT=1.0, seed=3 + rank)
     nl = standin.CellNlist(sysm, r_cut=args.rcut, r_buff=args.rbuff, check_period=args.check_period)
+    if world > 1:
+        from hoomd_tf_amd.domain import SlabDomain
+        nl.domain = SlabDomain(sysm, rank, world, r_ghost=args.rcut + args.rbuff)
     nl.build()
     N, NN = sysm.N, args.nn
 
@@ -136,7 +144,8 @@ def main():
     nve = standin.NVE(sysm, args.dt)
 
     def arrays():
-        return ctx.make_arrays(sysm.pos, N, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, sysm.force)
+        # N changes when particles migrate between ranks at a rebuild
+        return ctx.make_arrays(sysm.pos, sysm.N, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, sysm.force)
 
     state = {"arr": arrays(), "builds": nl.n_builds, "ts": 0}
 
@@ -171,7 +180,7 @@ def main():
         f3.mul_(torch.clamp(200.0 / fm, max=1.0))
         nve.step()
         v3 = sysm.vel[:, :3]
-        v3.mul_(torch.sqrt(1.0 / ((v3 * v3).sum() / (3.0 * N))))
+        v3.mul_(torch.sqrt(1.0 / ((v3 * v3).sum() / (3.0 * sysm.N))))
         state["ts"] = ts + 1
 
     for _ in range(args.warmup):
@@ -200,8 +209,8 @@ def main():
     # sanity: the run must still be a valid simulation
     f = sysm.force
     assert bool(torch.isfinite(f).all()), "non-finite forces"
-    e_per_particle = float(f[:, 3].double().sum().item()) / N
-    kT_final = float((sysm.vel[:, :3].double() ** 2).sum().item()) / (3.0 * N)
+    e_per_particle = float(f[:, 3].double().sum().item()) / sysm.N
+    kT_final = float((sysm.vel[:, :3].double() ** 2).sum().item()) / (3.0 * sysm.N)
 
     n_entries = int(nl.n_neigh.long().sum().item())
     eval_b, build_b, integ_b = algorithmic_bytes(N, NN, n_entries, N + sysm.n_ghost)
@@ -239,7 +248,9 @@ def main():
         "config": {"workload": "C3-%s: fcc %d^3x4 = %d particles/GPU, rho 0.8442, r_cut %.1f, r_buff %.1f, NN %d, dt %g"
                                % (args.workload.upper(), args.cells, N, args.rcut, args.rbuff, NN, args.dt),
                    "global_particles": N * world, "parallelism": "dd%dx1x1" % world,
-                   "nlist_rebuilds_in_timed_region": rebuilds, "max_neighbors_within_rcut": max_kept},
+                   "nlist_rebuilds_in_timed_region": rebuilds, "max_neighbors_within_rcut": max_kept,
+                   "halo": None if world == 1 else {"ghosts_rank0": sysm.n_ghost, "migrated_rank0": nl.domain.n_migrated,
+                                                    "exchange": "forward ghost positions, RCCL send/recv, every step"}},
         "hbm_GBps_full_step": world * step_bytes / (elapsed / args.steps) / 1e9,
         "hbm_frac_full_step": step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
         "energy_per_particle": e_per_particle, "kT_final": kT_final,

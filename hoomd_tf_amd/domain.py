@@ -1,0 +1,138 @@
+"""Particle domain decomposition for the force path: 1-D slabs along x, one rank per GPU,
+forward ghost-POSITION halo over ``torch.distributed`` P2P (RCCL send/recv over xGMI on
+the GPU box, gloo in the CPU tests).
+
+What the reference inherits from HOOMD's ``Communicator``: particle
+migration + ghost exchange when the neighbor list is rebuilt, and a ghost position update
+every step.  Because F_i is a pure row reduction over particle i's own neighbor slots
+(simmodel.py:542-555) there is NO reverse/force communication and no all-reduce in
+inference: the only per-step message is ~0.5 MB of float4 positions per slab face.
+
+Layout after ``rebuild()`` (HOOMD's): ``pos[:N]`` local particles, ``pos[N:N+n_ghost]``
+ghosts = [from left neighbor | from right neighbor].  Ghosts keep the owner's raw
+coordinates; the pair-vector build applies the minimum image of the GLOBAL box.
+
+Message naming: "L>" = sent to my left neighbor (my particles within r_ghost of my left
+face), "R>" = sent to my right neighbor.  Every rank posts sends in the order [L>, R>] and
+receives in the order [L> from right, R> from left], which keeps grouped NCCL send/recv
+pairs matched even when left == right (world size 2).
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+TAG_L, TAG_R = 11, 12
+
+
+class SlabDomain:
+    def __init__(self, system, rank, world, r_ghost, fractions=None, group=None):
+        self.sys = system
+        self.rank, self.world = int(rank), int(world)
+        self.r_ghost = float(r_ghost)
+        self.group = group
+        lo, hi = float(system.box3x3[0][0]), float(system.box3x3[1][0])
+        if fractions is None:
+            cuts = np.linspace(0.0, 1.0, self.world + 1)
+        else:  # comm.decomposition(x=[0.33]) style interior cut fractions
+            cuts = np.concatenate([[0.0], np.asarray(fractions, dtype=np.float64), [1.0]])
+            if len(cuts) != self.world + 1 or np.any(np.diff(cuts) <= 0):
+                raise ValueError("need world-1 increasing cut fractions in (0, 1)")
+        self.bounds = lo + cuts * (hi - lo)
+        self.xlo, self.xhi = float(self.bounds[self.rank]), float(self.bounds[self.rank + 1])
+        if self.world > 1 and min(np.diff(self.bounds)) < 2.0 * self.r_ghost:
+            raise ValueError("slab thinner than 2 * r_ghost: a particle would be a ghost on both sides")
+        self.left = (self.rank - 1) % self.world
+        self.right = (self.rank + 1) % self.world
+        self.send_left = self.send_right = None
+        self.n_from_left = self.n_from_right = 0
+        self.n_migrated = 0
+
+    # ------------------------------------------------------------------ helpers
+    def _all_counts(self, a, b):
+        t = torch.tensor([int(a), int(b)], dtype=torch.int64, device=self.sys.pos.device)
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(out, t, group=self.group)
+        return [(int(o[0]), int(o[1])) for o in out]
+
+    def _swap(self, to_left, to_right, n_from_right, n_from_left):
+        """send [L>, R>], receive [L> from right, R> from left]; returns the two buffers."""
+        width = to_left.shape[1:]
+        from_right = torch.empty((n_from_right,) + tuple(width), dtype=to_left.dtype, device=to_left.device)
+        from_left = torch.empty((n_from_left,) + tuple(width), dtype=to_left.dtype, device=to_left.device)
+        self._swap_into(to_left, to_right, from_right, from_left)
+        return from_right, from_left
+
+    def _swap_into(self, to_left, to_right, from_right, from_left):
+        ops = []
+        if to_left.numel():
+            ops.append(dist.P2POp(dist.isend, to_left, self.left, self.group, TAG_L))
+        if to_right.numel():
+            ops.append(dist.P2POp(dist.isend, to_right, self.right, self.group, TAG_R))
+        if from_right.numel():
+            ops.append(dist.P2POp(dist.irecv, from_right, self.right, self.group, TAG_L))
+        if from_left.numel():
+            ops.append(dist.P2POp(dist.irecv, from_left, self.left, self.group, TAG_R))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+
+    # ------------------------------------------------------------------ migration + ghost plan
+    def rebuild(self):
+        """Communicator::migrateParticles + exchangeGhosts: call before every neighbor-list
+        build.  Afterwards system.N / pos / vel describe this rank's slab plus its ghosts."""
+        s = self.sys
+        if self.world == 1:
+            s.n_ghost = 0
+            return
+        N = s.N
+        pos, vel = s.pos[:N], s.vel[:N]
+        x = pos[:, 0]
+        # The integrator wraps into the global box, so the new owner is found by position and
+        # is an adjacent slab by construction (rebuilds happen before anything moves r_buff/2).
+        cuts = torch.as_tensor(self.bounds[1:-1], dtype=x.dtype, device=x.device)
+        owner = torch.bucketize(x.contiguous(), cuts, right=True)
+        if self.world == 2:
+            go_right = owner != self.rank      # one peer: everything travels as the R> message
+            go_left = torch.zeros_like(go_right)
+        else:
+            go_left = owner == self.left
+            go_right = owner == self.right
+            lost = (owner != self.rank) & ~go_left & ~go_right
+            if bool(lost.any()):
+                raise RuntimeError("a particle crossed more than one slab between neighbor-list rebuilds")
+        stay = ~(go_left | go_right)
+        pack_l = torch.cat([pos[go_left], vel[go_left]], dim=1).contiguous()
+        pack_r = torch.cat([pos[go_right], vel[go_right]], dim=1).contiguous()
+        counts = self._all_counts(pack_l.shape[0], pack_r.shape[0])
+        got_r, got_l = self._swap(pack_l, pack_r, counts[self.right][0], counts[self.left][1])
+        self.n_migrated += int(got_r.shape[0] + got_l.shape[0])
+        new_pos = torch.cat([pos[stay], got_r[:, :4], got_l[:, :4]], dim=0)
+        new_vel = torch.cat([vel[stay], got_r[:, 4:], got_l[:, 4:]], dim=0)
+        N = int(new_pos.shape[0])
+        # ghost plan: who sits within r_ghost of a face
+        x = new_pos[:, 0]
+        self.send_left = torch.nonzero(x < self.xlo + self.r_ghost).flatten()
+        self.send_right = torch.nonzero(x >= self.xhi - self.r_ghost).flatten()
+        counts = self._all_counts(self.send_left.numel(), self.send_right.numel())
+        self.n_from_right = counts[self.right][0]
+        self.n_from_left = counts[self.left][1]
+        s.N = N
+        s.n_ghost = self.n_from_left + self.n_from_right
+        s.pos = torch.cat([new_pos, torch.zeros((s.n_ghost, 4), dtype=new_pos.dtype, device=new_pos.device)], dim=0)
+        s.vel = new_vel.contiguous()
+        if s.force.shape[0] != N:
+            s.force = torch.zeros((N, 4), dtype=s.dtype, device=s.pos.device)
+            s.virial = torch.zeros(6 * N, dtype=s.dtype, device=s.pos.device)
+        self.exchange()
+
+    def exchange(self):
+        """Per-step forward halo: refresh ghost positions from their owners."""
+        if self.world == 1 or self.send_left is None:
+            return
+        s = self.sys
+        N = s.N
+        to_left = s.pos[:N].index_select(0, self.send_left)
+        to_right = s.pos[:N].index_select(0, self.send_right)
+        from_left = s.pos[N:N + self.n_from_left]                 # R> of my left neighbor
+        from_right = s.pos[N + self.n_from_left:N + s.n_ghost]    # L> of my right neighbor
+        self._swap_into(to_left, to_right, from_right, from_left)

@@ -99,6 +99,7 @@ class CellNlist:
         self._max = torch.zeros(1, dtype=torch.int32, device=system.device)
         self.n_builds = 0
         self._subscribers = []
+        self.domain = None  # SlabDomain when the box is decomposed over ranks
 
     def subscribe(self, rcut_fn):
         """NeighborList r_cut subscription (tensorflowcompute.py:116-120): the list is
@@ -119,6 +120,8 @@ class CellNlist:
 
     def build(self):
         s = self.sys
+        if self.domain is not None:
+            self.domain.rebuild()  # Communicator: migrate particles, re-plan + fill ghosts
         Ntot = s.N + s.n_ghost
         n = self._ncell()
         n3 = (C.c_int * 3)(*[int(x) for x in n])
@@ -163,12 +166,18 @@ class CellNlist:
         check(lib.htfs_max_displacement2(s.pos.data_ptr(), self._ref.data_ptr(), s.scalar_code, s.N,
                                          C.byref(s.box), self._disp.data_ptr(),
                                          C.c_void_p(torch.cuda.current_stream(s.device).cuda_stream)))
+        if self.domain is not None and self.domain.world > 1:
+            # every rank must take the same rebuild decision (the rebuild communicates)
+            import torch.distributed as dist
+            dist.all_reduce(self._disp, op=dist.ReduceOp.MAX, group=self.domain.group)
         return float(self._disp.item()) > (self.r_buff / 2.0) ** 2
 
     def compute(self, timestep):
         """NeighborList::compute(timestep): rebuild if the distance check trips."""
         if self._ref is None or (timestep % self.check_period == 0 and self.needs_update()):
             self.build()
+        elif self.domain is not None:
+            self.domain.exchange()  # per-step forward halo of ghost positions
 
 
 class NVE:
