@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--dt", type=float, default=0.005)
     ap.add_argument("--check-period", type=int, default=5, help="nlist distance-check period (HOOMD check_period)")
     ap.add_argument("--equil", type=int, default=300, help="untimed relaxation steps (force cap + velocity rescale)")
+    ap.add_argument("--no-fused", action="store_true", help="skip the extra fused gather-evaluate measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -257,6 +258,48 @@ def main():
         "kernels": kern,
         "roofline": roof,
     }
+    # ---- extra, reported separately: the same MD with the pair vectors kept in
+    # registers (htf_config.fused) -- different algorithmic bytes, never mixed into `roofline`.
+    if not args.no_fused and not mfma:
+        ctx_f = htf.Context(r_cut=args.rcut, nneighs=NN, scalar_dtype=torch.float32, max_n=sysm.N, fused=True)
+        ctx_f.set_potential(pot)
+
+        def step_f():
+            ts = state["ts"]
+            nl.compute(ts)
+            if nl.n_builds != state["builds"] or state.get("arr_f") is None:
+                state["arr"] = arrays()
+                state["arr_f"] = ctx_f.make_arrays(sysm.pos, sysm.N, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, sysm.force)
+                state["builds"] = nl.n_builds
+            ctx_f.compute_forces(ts, state["arr_f"])
+            nve.step()
+            state["ts"] = ts + 1
+
+        for _ in range(args.warmup):
+            step_f()
+        ctx_f.profile_enable(True)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step_f()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        el_f = time.perf_counter() - t0
+        _, fused_ms, ncf = ctx_f.profile_read()
+        if dist is not None:
+            t = torch.tensor([el_f], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el_f = float(t.item())
+        fb = sysm.N * 8 + n_entries * 4 + (sysm.N + sysm.n_ghost) * 16 + sysm.N * 16
+        fus = fused_ms / max(ncf, 1) * 1e-3
+        out["fused_variant"] = {
+            "note": "pair vectors evaluated in registers (htf_config.fused=1); the [N,NN,4] tensor is not materialised",
+            "value": world * args.steps / el_f, "unit": "steps/s", "ms_per_step": el_f / args.steps * 1e3,
+            "kernel_avg_us": fus * 1e6, "algorithmic_bytes": fb, "GBps": fb / fus / 1e9 if fus > 0 else None,
+            "energy_per_particle": float(sysm.force[:, 3].double().sum().item()) / sysm.N}
     if rank == 0 and not args.no_cpu_baseline:
         cb, f_cpu = cpu_baseline(sysm, nl, args)
         out["cpu_baseline"] = cb

@@ -52,7 +52,7 @@ class PotentialDesc(C.Structure):
 class Config(C.Structure):
     _fields_ = [("r_cut", C.c_double), ("nneighs", C.c_uint), ("force_mode", C.c_int),
                 ("period", C.c_uint), ("batch_size", C.c_uint), ("scalar_dtype", C.c_int),
-                ("check_nlist", C.c_int), ("virial", C.c_int), ("max_n", C.c_uint)]
+                ("check_nlist", C.c_int), ("virial", C.c_int), ("max_n", C.c_uint), ("fused", C.c_int)]
 
 
 class HoomdArrays(C.Structure):
@@ -73,6 +73,7 @@ PROTOTYPES = {
     "htf_potential_destroy": (None, [_vp]),
     "htf_build_pair_vectors": (_i, [_vp, _i, _vp, _i, _u, _u, _u, _u, _u, C.POINTER(Box), _vp, _vp, _vp, _d, _vp, _vp]),
     "htf_eval_forces": (_i, [_vp, _vp, _i, _u, _u, _vp, _i, _vp, _vp]),
+    "htf_fused_forces": (_i, [_vp, _vp, _i, _u, _u, _u, _u, C.POINTER(Box), _vp, _vp, _vp, _d, _vp, _i, _vp, _vp, _vp]),
     "htf_add_virial": (_i, [_vp, _vp, _i, _u, _sz, _vp]),
     "htf_add_scalar4": (_i, [_vp, _vp, _i, _u, _vp]),
     "htf_copy_positions": (_i, [_vp, _i, _vp, _i, _u, _u, _i, _vp]),
@@ -100,7 +101,7 @@ PROTOTYPES = {
 STANDIN_PROTOTYPES = {
     "htfs_nve_step": (_i, [_vp, _vp, _vp, _i, _u, _d, C.POINTER(Box), _vp]),
     "htfs_max_displacement2": (_i, [_vp, _vp, _i, _u, C.POINTER(Box), _vp, _vp]),
-    "htfs_build_nlist": (_i, [_vp, _i, _u, _u, C.POINTER(Box), _d, C.POINTER(_i * 3), _vp, _vp, _u, _vp, _vp, _vp, _vp, _vp]),
+    "htfs_build_nlist": (_i, [_vp, _vp, _i, _u, _u, C.POINTER(Box), _d, C.POINTER(_i * 3), _vp, _vp, _u, _vp, _vp, _vp, _vp, _vp]),
     "htfs_cell_index": (_i, [_vp, _i, _u, C.POINTER(Box), C.POINTER(_i * 3), _vp, _vp]),
 }
 

@@ -1,0 +1,70 @@
+// HOOMD BoxDim arithmetic shared by the pair-vector build and the fused evaluator.
+// Every function here pins fp contraction OFF so that pair vectors (and therefore the
+// keep / drop decision at r_cut) are bit-identical in both kernels and to the oracle
+// (oracle/htf_oracle.py:min_image), whatever flags the including TU is built with.
+#pragma once
+#include "htf_common.h"
+
+namespace htf {
+
+template <typename T>
+struct BoxT {
+    T L[3], Linv[3], xy, xz, yz;
+    int periodic[3];
+};
+
+template <typename T>
+static BoxT<T> make_boxt(const htf_box *hb) {
+    BoxT<T> b;
+    for (int d = 0; d < 3; ++d) {
+        b.L[d] = (T)hb->hi[d] - (T)hb->lo[d];
+        b.Linv[d] = (T)1 / b.L[d];
+        b.periodic[d] = hb->periodic[d];
+    }
+    b.xy = (T)hb->tilt[0];
+    b.xz = (T)hb->tilt[1];
+    b.yz = (T)hb->tilt[2];
+    return b;
+}
+
+template <typename T> __device__ __forceinline__ T rint_t(T x);
+template <> __device__ __forceinline__ float rint_t<float>(float x) { return rintf(x); }
+template <> __device__ __forceinline__ double rint_t<double>(double x) { return rint(x); }
+
+// HOOMD-blue 2.x BoxDim::minImage, device (rint) form.
+template <typename T>
+__device__ __forceinline__ void min_image(T &x, T &y, T &z, const BoxT<T> &b) {
+#pragma clang fp contract(off)
+    if (b.periodic[2]) {
+        T img = rint_t<T>(z * b.Linv[2]);
+        z -= b.L[2] * img;
+        y -= b.L[2] * b.yz * img;
+        x -= b.L[2] * b.xz * img;
+    }
+    if (b.periodic[1]) {
+        T img = rint_t<T>(y * b.Linv[1]);
+        y -= b.L[1] * img;
+        x -= b.L[1] * b.xy * img;
+    }
+    if (b.periodic[0]) {
+        T img = rint_t<T>(x * b.Linv[0]);
+        x -= b.L[0] * img;
+    }
+}
+
+// dx = minimage(pk - pi) and |dx|^2, exactly as prepareNeighbors computes them
+template <typename T, typename V>
+__device__ __forceinline__ T pair_vector(const V &pk, const V &pi, const BoxT<T> &b, T &dx, T &dy, T &dz) {
+#pragma clang fp contract(off)
+    dx = pk.x - pi.x;
+    dy = pk.y - pi.y;
+    dz = pk.z - pi.z;
+    min_image<T>(dx, dy, dz, b);
+    return dx * dx + dy * dy + dz * dz;
+}
+
+// HOOMD __scalar_as_int: the int type id lives in the (low) 32 bits of pos.w
+__device__ __forceinline__ int scalar_as_int(float w) { return __float_as_int(w); }
+__device__ __forceinline__ int scalar_as_int(double w) { return (int)(__double_as_longlong(w) & 0xffffffffll); }
+
+} // namespace htf

@@ -142,6 +142,17 @@ extern "C" int htf_eval_forces(const htf_potential *pot, const void *d_nlist, in
     return eval_pair_dispatch(pot->pp, d_nlist, nlist_dtype, B, NN, d_force, force_dtype, d_virial9, (hipStream_t)stream);
 }
 
+extern "C" int htf_fused_forces(const htf_potential *pot, const void *d_pos, int pos_dtype, unsigned N, unsigned NN,
+                                unsigned offset, unsigned batch_size, const htf_box *box, const unsigned *d_n_neigh,
+                                const unsigned *d_nlist, const unsigned *d_head_list, double rmax, void *d_force,
+                                int force_dtype, void *d_virial9, unsigned *d_check_count, htf_stream stream) {
+    using namespace htf;
+    HTF_REQUIRE(pot, "htf_fused_forces: no potential");
+    HTF_REQUIRE(force_dtype == HTF_F32 || force_dtype == HTF_F64, "htf_fused_forces: bad force dtype %d", force_dtype);
+    return fused_forces_impl(pot->pp, d_pos, pos_dtype, N, NN, offset, batch_size, box, d_n_neigh, d_nlist, d_head_list,
+                             rmax, d_force, force_dtype, d_virial9, d_check_count, nullptr, (hipStream_t)stream);
+}
+
 // ------------------------------------------------------------------------------ context
 static void ctx_free(htf_ctx *c) {
     if (c->nlist) (void)hipFree(c->nlist);
@@ -259,6 +270,34 @@ extern "C" int htf_compute_forces(htf_ctx *ctx, unsigned timestep, const htf_hoo
             e2 = next_event(ctx);
             HTF_REQUIRE(e0 && e1 && e2, "htf_compute_forces: hipEventCreate failed");
             HTF_CHECK_HIP(hipEventRecord(e0, s));
+        }
+        const bool fused = cfg.fused && cfg.nneighs > 0 && ctx->pot != nullptr && ctx->pot->pp.kind != HTF_POT_PAIR_MLP;
+        if (fused) {
+            HTF_REQUIRE(a->n_neigh && a->nlist && a->head_list, "htf_compute_forces: null neighbor list");
+            if (prof) HTF_CHECK_HIP(hipEventRecord(e1, s)); // no separate build scope in fused mode
+            if (cfg.check_nlist) HTF_CHECK_HIP(hipMemsetAsync(ctx->flag, 0, sizeof(unsigned), s));
+            void *fo = (char *)a->force + (size_t)offset * 4 * ssz;
+            rc = fused_forces_impl(ctx->pot->pp, a->pos, cfg.scalar_dtype, N, cfg.nneighs, offset, n, &a->box, a->n_neigh,
+                                   a->nlist, a->head_list, cfg.r_cut, fo, cfg.scalar_dtype,
+                                   cfg.virial ? ctx->virial : nullptr, cfg.check_nlist ? ctx->flag : nullptr,
+                                   ctx->positions, s);
+            if (rc != HTF_OK) return rc;
+            if (prof) HTF_CHECK_HIP(hipEventRecord(e2, s));
+            if (cfg.check_nlist) {
+                unsigned h = 0;
+                HTF_CHECK_HIP(hipMemcpyAsync(&h, ctx->flag, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+                HTF_CHECK_HIP(hipStreamSynchronize(s));
+                if (!(h < cfg.nneighs)) {
+                    set_error("Neighbor list is full!");
+                    return HTF_ERR_NLIST_OVERFLOW;
+                }
+            }
+            if (cfg.virial && a->virial) {
+                rc = htf_add_virial((char *)a->virial + (size_t)offset * ssz, ctx->virial, cfg.scalar_dtype, n,
+                                    a->virial_pitch, stream);
+                if (rc != HTF_OK) return rc;
+            }
+            continue;
         }
         if (cfg.nneighs > 0) {
             HTF_REQUIRE(a->n_neigh && a->nlist && a->head_list, "htf_compute_forces: null neighbor list");

@@ -1,0 +1,185 @@
+// Fused gather-evaluate: HOOMD index neighbor list + positions -> forces, WITHOUT
+// materialising the [N, NN, 4] pair-vector tensor.
+//
+// The contract path writes 268 MB of pair vectors per step and reads them straight back
+// (build_pair_vectors -> eval_forces, ~621 MB of algorithmic traffic at C3).  When nothing
+// needs the tensor itself -- a traced declarative model, nobody calling get_nlist_array --
+// the same arithmetic can run on the pair vector while it is still in registers: per
+// particle the kernel reads its index row (4 B per neighbor) and gathers 16-B positions
+// from the L2-resident position table, i.e. ~76 MB per step.  Semantics are those of the
+// two-kernel path: identical dx (box_math.h pins contraction off), keep unless
+// rsq > r_cut^2, NN-slot wrap on overflow (only the last NN kept neighbors contribute),
+// zero padding contributes nothing, same per-slot math (pair_math.h).
+// Opt-in (htf_config.fused): the nlist side buffer is not filled in this mode.
+#include <cstdlib>
+
+#include "box_math.h"
+#include "htf_common.h"
+#include "htf_internal.h"
+#include "pair_math.h"
+
+namespace htf {
+
+constexpr int kFChunk = 4;
+
+struct FusedAcc {
+    float fx = 0.f, fy = 0.f, fz = 0.f, en = 0.f;
+    Virial6 v;
+    unsigned npos = 0; // slots with dx > 0: SimModel check_nlist's count (simmodel.py:214-219)
+};
+
+template <int KIND, bool VIRIAL, typename PT>
+__device__ __forceinline__ unsigned fused_sweep(FusedAcc &acc, const typename Vec4<PT>::type *__restrict__ pos,
+                                                const unsigned *__restrict__ nl, unsigned nn,
+                                                const typename Vec4<PT>::type pi, const BoxT<PT> &box, PT rmaxsq,
+                                                unsigned lane, unsigned q_lo, unsigned q_hi, const PotParams &p) {
+    using PV = typename Vec4<PT>::type;
+    unsigned Q = 0;
+    for (unsigned base = 0; base < nn; base += 64 * kFChunk) {
+        unsigned k[kFChunk];
+        PV pk[kFChunk];
+#pragma unroll
+        for (int t = 0; t < kFChunk; ++t) {
+            unsigned j = base + t * 64 + lane;
+            k[t] = nl[j < nn ? j : nn - 1];
+        }
+#pragma unroll
+        for (int t = 0; t < kFChunk; ++t) pk[t] = pos[k[t]];
+#pragma unroll
+        for (int t = 0; t < kFChunk; ++t) {
+            if (base + t * 64 >= nn) break; // wave-uniform
+            unsigned j = base + t * 64 + lane;
+            PT dx, dy, dz;
+            PT rsq = pair_vector<PT>(pk[t], pi, box, dx, dy, dz);
+            bool keep = (j < nn) && !(rsq > rmaxsq);
+            unsigned long long m = __ballot(keep);
+            unsigned q = Q + __popcll(m & ((1ull << lane) - 1ull));
+            Q += __popcll(m);
+            if (keep && q >= q_lo && q < q_hi) {
+                // the model sees the pair vector after tf.cast to fp32 (simmodel.py:226-227)
+                const float x = (float)dx, y = (float)dy, z = (float)dz;
+                float e, ax, ay, az;
+                pair_eval<KIND>(x, y, z, p, e, ax, ay, az);
+                acc.fx += ax;
+                acc.fy += ay;
+                acc.fz += az;
+                acc.en += e;
+                acc.npos += x > 0.f ? 1u : 0u;
+                if constexpr (VIRIAL) acc.v.add(x, y, z, ax, ay, az);
+            }
+        }
+    }
+    return Q;
+}
+
+template <int KIND, bool VIRIAL, typename PT>
+__global__ __launch_bounds__(256) void fused_forces_kernel(const typename Vec4<PT>::type *__restrict__ pos, unsigned N,
+                                                           unsigned NN, unsigned offset, unsigned batch,
+                                                           BoxT<PT> box, const unsigned *__restrict__ n_neigh,
+                                                           const unsigned *__restrict__ nlist,
+                                                           const unsigned *__restrict__ head_list, PT rmaxsq,
+                                                           void *__restrict__ force, void *__restrict__ virial9,
+                                                           int out_f64, PotParams p, unsigned *__restrict__ check_count,
+                                                           float4 *__restrict__ positions_out) {
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned w = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (w >= batch) return;
+    const unsigned idx = w + offset;
+    if (idx >= N) return;
+    const unsigned nn = n_neigh[idx];
+    const unsigned *nl = nlist + head_list[idx];
+    const auto pi = pos[idx];
+    if (positions_out != nullptr && lane == 0)
+        positions_out[w] = make_float4((float)pi.x, (float)pi.y, (float)pi.z, (float)scalar_as_int(pi.w));
+
+    FusedAcc acc;
+    unsigned Q = nn ? fused_sweep<KIND, VIRIAL, PT>(acc, pos, nl, nn, pi, box, rmaxsq, lane, 0u, NN, p) : 0u;
+    if (Q > NN) {
+        // overflow: the reference's slot wrap leaves exactly the last NN kept neighbors
+        acc = FusedAcc();
+        fused_sweep<KIND, VIRIAL, PT>(acc, pos, nl, nn, pi, box, rmaxsq, lane, Q - NN, Q, p);
+    }
+    float fx = group_sum<64>(acc.fx), fy = group_sum<64>(acc.fy), fz = group_sum<64>(acc.fz);
+    float en = group_sum<64>(acc.en);
+    float v6[6];
+    if constexpr (VIRIAL) {
+        v6[0] = group_sum<64>(acc.v.xx);
+        v6[1] = group_sum<64>(acc.v.xy);
+        v6[2] = group_sum<64>(acc.v.xz);
+        v6[3] = group_sum<64>(acc.v.yy);
+        v6[4] = group_sum<64>(acc.v.yz);
+        v6[5] = group_sum<64>(acc.v.zz);
+    }
+    unsigned npos = 0;
+    if (check_count != nullptr) npos = group_sum_u<64>(acc.npos);
+    if (lane == 0) {
+        if (out_f64)
+            ((double4 *)force)[w] = make_double4(fx, fy, fz, en);
+        else
+            ((float4 *)force)[w] = make_float4(fx, fy, fz, en);
+        if constexpr (VIRIAL) {
+            const float v9[9] = {v6[0], v6[1], v6[2], v6[1], v6[3], v6[4], v6[2], v6[4], v6[5]};
+            if (out_f64) {
+                double *o = (double *)virial9 + (size_t)w * 9;
+#pragma unroll
+                for (int c = 0; c < 9; ++c) o[c] = v9[c];
+            } else {
+                float *o = (float *)virial9 + (size_t)w * 9;
+#pragma unroll
+                for (int c = 0; c < 9; ++c) o[c] = v9[c];
+            }
+        }
+        if (check_count != nullptr && npos > *(volatile unsigned *)check_count) atomicMax(check_count, npos);
+    }
+}
+
+template <int KIND, bool VIRIAL, typename PT>
+static int launch_fused(const void *pos, unsigned N, unsigned NN, unsigned offset, unsigned batch, const htf_box *hb,
+                        const unsigned *n_neigh, const unsigned *nlist, const unsigned *head_list, double rmax,
+                        void *force, void *virial9, int out_f64, const PotParams &p, unsigned *check_count,
+                        float4 *positions_out, hipStream_t s) {
+    BoxT<PT> b = make_boxt<PT>(hb);
+    PT rc = (PT)rmax;
+    hipLaunchKernelGGL((fused_forces_kernel<KIND, VIRIAL, PT>), dim3((batch + 3) / 4), dim3(256), 0, s,
+                       (const typename Vec4<PT>::type *)pos, N, NN, offset, batch, b, n_neigh, nlist, head_list,
+                       (PT)(rc * rc), force, virial9, out_f64, p, check_count, positions_out);
+    return check_launch("fused_forces_kernel");
+}
+
+template <int KIND>
+static int launch_fused_k(const void *pos, int pos_dtype, unsigned N, unsigned NN, unsigned offset, unsigned batch,
+                          const htf_box *hb, const unsigned *n_neigh, const unsigned *nlist,
+                          const unsigned *head_list, double rmax, void *force, void *virial9, int out_f64,
+                          const PotParams &p, unsigned *check_count, float4 *positions_out, hipStream_t s) {
+#define HTF_FUSED(V, T) launch_fused<KIND, V, T>(pos, N, NN, offset, batch, hb, n_neigh, nlist, head_list, rmax, force, virial9, out_f64, p, check_count, positions_out, s)
+    if (pos_dtype == HTF_F32) return virial9 ? HTF_FUSED(true, float) : HTF_FUSED(false, float);
+    return virial9 ? HTF_FUSED(true, double) : HTF_FUSED(false, double);
+#undef HTF_FUSED
+}
+
+int fused_forces_impl(const PotParams &p, const void *pos, int pos_dtype, unsigned N, unsigned NN, unsigned offset,
+                      unsigned batch, const htf_box *box, const unsigned *n_neigh, const unsigned *nlist,
+                      const unsigned *head_list, double rmax, void *force, int force_dtype, void *virial9,
+                      unsigned *check_count, float4 *positions_out, hipStream_t s) {
+    HTF_REQUIRE(pos && n_neigh && nlist && head_list && box && force, "htf_fused_forces: null pointer");
+    HTF_REQUIRE(NN > 0 && rmax > 0, "htf_fused_forces: NN and rmax must be > 0");
+    HTF_REQUIRE(offset <= N && batch <= N - offset, "htf_fused_forces: batch [%u, %u) exceeds N=%u", offset, offset + batch, N);
+    HTF_REQUIRE(pos_dtype == HTF_F32 || pos_dtype == HTF_F64, "htf_fused_forces: bad position dtype %d", pos_dtype);
+    if (batch == 0) return HTF_OK;
+    const int out_f64 = force_dtype == HTF_F64;
+#define HTF_FK(K) launch_fused_k<K>(pos, pos_dtype, N, NN, offset, batch, box, n_neigh, nlist, head_list, rmax, force, virial9, out_f64, p, check_count, positions_out, s)
+    switch (p.kind) {
+    case HTF_POT_LJ: return HTF_FK(HTF_POT_LJ);
+    case HTF_POT_WCA: return HTF_FK(HTF_POT_WCA);
+    case HTF_POT_RINV_POLY: return HTF_FK(HTF_POT_RINV_POLY);
+    case HTF_POT_SIMPLE:
+        HTF_REQUIRE(virial9 == nullptr, "htf_fused_forces: SimplePotential has no virial");
+        return HTF_FK(HTF_POT_SIMPLE);
+    default:
+        set_error("htf_fused_forces: potential kind %d has no fused form (the pair-MLP is MFMA-bound, not traffic-bound)", p.kind);
+        return HTF_ERR_INVALID;
+    }
+#undef HTF_FK
+}
+
+} // namespace htf

@@ -22,6 +22,11 @@ int build_pair_vectors_impl(void *dest, int dest_dtype, const void *d_pos, int p
                             const unsigned *d_nlist, const unsigned *d_head_list, double rmax,
                             unsigned *d_max_count, float4 *positions_out, hipStream_t s);
 
+int fused_forces_impl(const PotParams &p, const void *pos, int pos_dtype, unsigned N, unsigned NN, unsigned offset,
+                      unsigned batch, const htf_box *box, const unsigned *n_neigh, const unsigned *nlist,
+                      const unsigned *head_list, double rmax, void *force, int force_dtype, void *virial9,
+                      unsigned *check_count, float4 *positions_out, hipStream_t s);
+
 struct MlpDevice;
 int mlp_create(const htf_potential_desc *d, MlpDevice **out);
 void mlp_destroy(MlpDevice *m);

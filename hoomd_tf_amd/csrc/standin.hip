@@ -57,9 +57,10 @@ __device__ __forceinline__ T mimg(T d, T L, T Linv, int periodic) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void max_disp_kernel(const typename Vec4<T>::type *__restrict__ pos,
-                                                       const typename Vec4<T>::type *__restrict__ ref, unsigned N,
-                                                       SBox<T> b, float *__restrict__ out) {
+__global__ __launch_bounds__(1024) void max_disp_kernel(const typename Vec4<T>::type *__restrict__ pos,
+                                                        const typename Vec4<T>::type *__restrict__ ref, unsigned N,
+                                                        SBox<T> b, float *__restrict__ out) {
+    __shared__ float s_max[16];
     unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     float d2 = 0.f;
     if (i < N) {
@@ -71,10 +72,16 @@ __global__ __launch_bounds__(256) void max_disp_kernel(const typename Vec4<T>::t
         d2 = (float)(dx * dx + dy * dy + dz * dz);
     }
     for (int m = 1; m < 64; m <<= 1) d2 = fmaxf(d2, __shfl_xor(d2, m));
-    // d2 >= 0: uint order == float order.  The plain read only filters (a stale value
-    // just means one redundant atomic); without it 2048 same-address atomics serialise.
-    if ((threadIdx.x & 63) == 0 && __float_as_uint(d2) > *(volatile unsigned *)out)
-        atomicMax((unsigned *)out, __float_as_uint(d2));
+    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = d2;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        d2 = s_max[threadIdx.x];
+        for (int m = 1; m < 16; m <<= 1) d2 = fmaxf(d2, __shfl_xor(d2, m));
+        // d2 >= 0: uint order == float order.  One atomic per 1024 particles (same-address
+        // atomics serialise at ~12 ns each: one per wave cost 25 us at N = 131072).
+        if (threadIdx.x == 0 && __float_as_uint(d2) > *(volatile unsigned *)out)
+            atomicMax((unsigned *)out, __float_as_uint(d2));
+    }
 }
 
 template <typename T>
@@ -96,11 +103,17 @@ __global__ __launch_bounds__(256) void cell_index_kernel(const typename Vec4<T>:
     cell_of[i] = (unsigned)((cz * ny + cy) * nx + cx);
 }
 
-// one 16-lane group per particle: lanes stride over the members of each of the 27
-// neighbor cells; hits are compacted with a ballot restricted to the group.
+// One 16-lane group per particle.  For every (dy, dz) row of the 27-cell stencil the up to
+// three x-adjacent cells are contiguous in the cell-sorted arrays, so they are walked as
+// one range (plus a second, usually empty, range when the stencil wraps around the box).
+// Candidates are read from the CELL-SORTED position copy: 16 lanes x 16 B contiguous.
+// Hits are compacted with a ballot restricted to the group.  Every lane of the wave runs
+// the same trip counts (ranges of other groups are padded to the wave maximum) so the
+// ballots and shuffles are convergent.
 template <typename T>
-__global__ __launch_bounds__(256) void build_nlist_kernel(const typename Vec4<T>::type *__restrict__ pos, unsigned N,
-                                                          SBox<T> b, T rl2, int nx, int ny, int nz,
+__global__ __launch_bounds__(256) void build_nlist_kernel(const typename Vec4<T>::type *__restrict__ pos,
+                                                          const typename Vec4<T>::type *__restrict__ pos_sorted,
+                                                          unsigned N, SBox<T> b, T rl2, int nx, int ny, int nz,
                                                           const unsigned *__restrict__ order,
                                                           const unsigned *__restrict__ cell_start, unsigned pitch,
                                                           unsigned *__restrict__ n_neigh, unsigned *__restrict__ head_list,
@@ -116,47 +129,60 @@ __global__ __launch_bounds__(256) void build_nlist_kernel(const typename Vec4<T>
     const unsigned long long gmask = 0xFFFFull << (sub * G);
     unsigned count = 0;
     unsigned *row = nlist + (size_t)(active ? i : 0) * pitch;
-    // 27-cell walk; a dimension with a single cell (thin / 2-D boxes) contributes offset 0 only.
-    // Out-of-range cells of a non-periodic dimension are visited with an empty range rather
-    // than skipped, so every lane of the wave runs the same trip counts (ballot/shfl safe).
-    const int x0 = nx >= 3 ? -1 : 0, x1 = nx >= 3 ? 1 : 0;
+    // x extent of the stencil as up to two cell ranges [a0, a1] and [b0, b1] (b empty if b1 < b0)
+    int a0 = cx, a1 = cx, b0 = 0, b1 = -1;
+    if (nx >= 3) {
+        a0 = cx - 1;
+        a1 = cx + 1;
+        if (a0 < 0) {
+            a0 = 0;
+            if (b.periodic[0]) b0 = b1 = nx - 1;
+        } else if (a1 >= nx) {
+            a1 = nx - 1;
+            if (b.periodic[0]) b0 = b1 = 0;
+        }
+    }
     const int y0 = ny >= 3 ? -1 : 0, y1 = ny >= 3 ? 1 : 0;
     const int z0 = nz >= 3 ? -1 : 0, z1 = nz >= 3 ? 1 : 0;
     for (int dz = z0; dz <= z1; ++dz)
-        for (int dy = y0; dy <= y1; ++dy)
-            for (int dx = x0; dx <= x1; ++dx) {
-                int ax = cx + dx, ay = cy + dy, az = cz + dz;
-                bool skip = false;
-                if (ax < 0) { skip |= !b.periodic[0]; ax += nx; } else if (ax >= nx) { skip |= !b.periodic[0]; ax -= nx; }
-                if (ay < 0) { skip |= !b.periodic[1]; ay += ny; } else if (ay >= ny) { skip |= !b.periodic[1]; ay -= ny; }
-                if (az < 0) { skip |= !b.periodic[2]; az += nz; } else if (az >= nz) { skip |= !b.periodic[2]; az -= nz; }
-                const unsigned c = (unsigned)((az * ny + ay) * nx + ax);
-                const unsigned beg = cell_start[c], end = skip ? beg : cell_start[c + 1];
-                // all lanes of a group share beg/end; groups in one wave may differ, so
-                // iterate to the wave-wide maximum trip count to keep ballots converged
-                unsigned len = end - beg, maxlen = len;
+        for (int dy = y0; dy <= y1; ++dy) {
+            int ay = cy + dy, az = cz + dz;
+            bool skip = false;
+            if (ay < 0) { skip |= !b.periodic[1]; ay += ny; } else if (ay >= ny) { skip |= !b.periodic[1]; ay -= ny; }
+            if (az < 0) { skip |= !b.periodic[2]; az += nz; } else if (az >= nz) { skip |= !b.periodic[2]; az -= nz; }
+            const unsigned rowbase = (unsigned)((az * ny + ay) * nx);
+#pragma unroll
+            for (int part = 0; part < 2; ++part) {
+                const int c0 = part ? b0 : a0, c1 = part ? b1 : a1;
+                unsigned beg = 0, len = 0;
+                if (!skip && c1 >= c0) {
+                    beg = cell_start[rowbase + c0];
+                    len = cell_start[rowbase + c1 + 1] - beg;
+                }
+                unsigned maxlen = len;
                 for (int m = G; m < 64; m <<= 1) {
                     unsigned o = (unsigned)__shfl_xor((int)maxlen, m);
                     maxlen = o > maxlen ? o : maxlen;
                 }
                 for (unsigned t = 0; t < maxlen; t += G) {
-                    unsigned m_idx = t + g;
+                    const unsigned m_idx = t + g;
                     bool hit = false;
                     unsigned k = 0;
                     if (active && m_idx < len) {
                         k = order[beg + m_idx];
-                        auto pk = pos[k];
+                        const auto pk = pos_sorted[beg + m_idx];
                         T ddx = mimg<T>(pk.x - pi.x, b.L[0], b.Linv[0], b.periodic[0]);
                         T ddy = mimg<T>(pk.y - pi.y, b.L[1], b.Linv[1], b.periodic[1]);
                         T ddz = mimg<T>(pk.z - pi.z, b.L[2], b.Linv[2], b.periodic[2]);
                         hit = (k != i) && (ddx * ddx + ddy * ddy + ddz * ddz <= rl2);
                     }
-                    unsigned long long bal = __ballot(hit) & gmask;
-                    unsigned rank = count + __popcll(bal & ((1ull << lane) - 1ull));
+                    const unsigned long long bal = __ballot(hit) & gmask;
+                    const unsigned rank = count + __popcll(bal & ((1ull << lane) - 1ull));
                     if (hit && rank < pitch) row[rank] = k;
                     count += __popcll(bal);
                 }
             }
+        }
     if (active && g == 0) {
         n_neigh[i] = count < pitch ? count : pitch;
         head_list[i] = i * pitch;
@@ -184,11 +210,11 @@ extern "C" int htfs_max_displacement2(const void *d_pos, const void *d_ref, int 
                                       float *d_out, htf_stream stream) {
     HTF_REQUIRE(d_pos && d_ref && box && d_out, "htfs_max_displacement2: null pointer");
     if (N == 0) return HTF_OK;
-    unsigned grid = (N + 255) / 256;
+    unsigned grid = (N + 1023) / 1024;
     if (dtype == HTF_F32)
-        hipLaunchKernelGGL((max_disp_kernel<float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float4 *)d_pos, (const float4 *)d_ref, N, make_sbox<float>(box), d_out);
+        hipLaunchKernelGGL((max_disp_kernel<float>), dim3(grid), dim3(1024), 0, (hipStream_t)stream, (const float4 *)d_pos, (const float4 *)d_ref, N, make_sbox<float>(box), d_out);
     else
-        hipLaunchKernelGGL((max_disp_kernel<double>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const double4 *)d_pos, (const double4 *)d_ref, N, make_sbox<double>(box), d_out);
+        hipLaunchKernelGGL((max_disp_kernel<double>), dim3(grid), dim3(1024), 0, (hipStream_t)stream, (const double4 *)d_pos, (const double4 *)d_ref, N, make_sbox<double>(box), d_out);
     return check_launch("max_disp_kernel");
 }
 
@@ -204,12 +230,12 @@ extern "C" int htfs_cell_index(const void *d_pos, int dtype, unsigned Ntot, cons
     return check_launch("cell_index_kernel");
 }
 
-extern "C" int htfs_build_nlist(const void *d_pos, int dtype, unsigned N, unsigned Ntot, const htf_box *box,
-                                double r_list, const int *ncell3, const unsigned *d_order,
+extern "C" int htfs_build_nlist(const void *d_pos, const void *d_pos_sorted, int dtype, unsigned N, unsigned Ntot,
+                                const htf_box *box, double r_list, const int *ncell3, const unsigned *d_order,
                                 const unsigned *d_cell_start, unsigned pitch, unsigned *d_n_neigh,
                                 unsigned *d_head_list, unsigned *d_nlist, unsigned *d_max_neigh, htf_stream stream) {
     (void)Ntot;
-    HTF_REQUIRE(d_pos && box && ncell3 && d_order && d_cell_start && d_n_neigh && d_head_list && d_nlist && d_max_neigh,
+    HTF_REQUIRE(d_pos && d_pos_sorted && box && ncell3 && d_order && d_cell_start && d_n_neigh && d_head_list && d_nlist && d_max_neigh,
                 "htfs_build_nlist: null pointer");
     HTF_REQUIRE(pitch > 0, "htfs_build_nlist: pitch must be > 0");
     for (int d = 0; d < 3; ++d) {
@@ -220,8 +246,8 @@ extern "C" int htfs_build_nlist(const void *d_pos, int dtype, unsigned N, unsign
     if (N == 0) return HTF_OK;
     unsigned grid = (N + 15) / 16; // 4 waves x 4 particles per block
     if (dtype == HTF_F32)
-        hipLaunchKernelGGL((build_nlist_kernel<float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float4 *)d_pos, N, make_sbox<float>(box), (float)(r_list * r_list), ncell3[0], ncell3[1], ncell3[2], d_order, d_cell_start, pitch, d_n_neigh, d_head_list, d_nlist, d_max_neigh);
+        hipLaunchKernelGGL((build_nlist_kernel<float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float4 *)d_pos, (const float4 *)d_pos_sorted, N, make_sbox<float>(box), (float)(r_list * r_list), ncell3[0], ncell3[1], ncell3[2], d_order, d_cell_start, pitch, d_n_neigh, d_head_list, d_nlist, d_max_neigh);
     else
-        hipLaunchKernelGGL((build_nlist_kernel<double>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const double4 *)d_pos, N, make_sbox<double>(box), r_list * r_list, ncell3[0], ncell3[1], ncell3[2], d_order, d_cell_start, pitch, d_n_neigh, d_head_list, d_nlist, d_max_neigh);
+        hipLaunchKernelGGL((build_nlist_kernel<double>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const double4 *)d_pos, (const double4 *)d_pos_sorted, N, make_sbox<double>(box), r_list * r_list, ncell3[0], ncell3[1], ncell3[2], d_order, d_cell_start, pitch, d_n_neigh, d_head_list, d_nlist, d_max_neigh);
     return check_launch("build_nlist_kernel");
 }

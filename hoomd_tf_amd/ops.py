@@ -146,6 +146,26 @@ def eval_forces(potential, nlist, virial=False, out=None, out_dtype=None, virial
     return (out, v) if virial else out
 
 
+def fused_forces(potential, pos, n_neigh, head_list, nlist, box, r_cut, NN, offset=0, batch_size=None,
+                 n_local=None, virial=False, out_dtype=None, check_count=None, periodic=(1, 1, 1)):
+    """build_pair_vectors + eval_forces without materialising the pair-vector tensor."""
+    _dev(pos, "pos")
+    N = int(n_neigh.shape[0]) if n_local is None else int(n_local)
+    B = N - offset if batch_size is None else int(batch_size)
+    od = out_dtype or pos.dtype
+    out = torch.empty((B, 4), dtype=od, device=pos.device)
+    v = torch.empty((B, 3, 3), dtype=od, device=pos.device) if virial else None
+    if B == 0:
+        return (out, v) if virial else out
+    b = box if isinstance(box, _lib.Box) else _lib.make_box(box, periodic)
+    check(lib.htf_fused_forces(potential.handle, pos.data_ptr(), _dt(pos), N, NN, offset, B, C.byref(b),
+                               _u32(n_neigh, "n_neigh").data_ptr(), _u32(nlist, "nlist").data_ptr(),
+                               _u32(head_list, "head_list").data_ptr(), float(r_cut), out.data_ptr(), _dt(out),
+                               v.data_ptr() if v is not None else None,
+                               check_count.data_ptr() if check_count is not None else None, _stream(pos)))
+    return (out, v) if virial else out
+
+
 def add_virial(dest, src9, N, pitch):
     """receiveVirial (TensorflowCompute.cc:284-301)."""
     _dev(dest, "dest")
@@ -208,10 +228,10 @@ class Context:
     """htf_ctx: the TensorflowCompute object (TensorflowCompute.h:75-250)."""
 
     def __init__(self, r_cut, nneighs, period=1, batch_size=0, scalar_dtype=torch.float32,
-                 check_nlist=False, virial=False, max_n=0, force_mode=_lib.HTF_TF2HOOMD):
+                 check_nlist=False, virial=False, max_n=0, force_mode=_lib.HTF_TF2HOOMD, fused=False):
         cfg = _lib.Config(float(r_cut), int(nneighs), int(force_mode), int(period), int(batch_size),
                           _lib.HTF_F64 if scalar_dtype == torch.float64 else _lib.HTF_F32,
-                          int(bool(check_nlist)), int(bool(virial)), int(max_n))
+                          int(bool(check_nlist)), int(bool(virial)), int(max_n), int(bool(fused)))
         self.cfg = cfg
         self.scalar_dtype = scalar_dtype
         self._h = C.c_void_p()

@@ -131,6 +131,7 @@ class CellNlist:
         check(lib.htfs_cell_index(s.pos.data_ptr(), s.scalar_code, Ntot, C.byref(s.box), C.byref(n3),
                                   cell_of.data_ptr(), stream))
         sorted_cells, order = torch.sort(cell_of)
+        pos_sorted = s.pos.index_select(0, order)  # cell members contiguous: coalesced candidate reads
         order = order.to(torch.int32)
         counts = torch.bincount(sorted_cells.long(), minlength=ncell)
         cell_start = torch.zeros(ncell + 1, dtype=torch.int32, device=s.device)
@@ -147,7 +148,7 @@ class CellNlist:
             self.head_list = torch.empty(s.N, dtype=torch.int32, device=s.device)
             self.nlist = torch.zeros(s.N * self.pitch, dtype=torch.int32, device=s.device)
             self._max.zero_()
-            check(lib.htfs_build_nlist(s.pos.data_ptr(), s.scalar_code, s.N, Ntot, C.byref(s.box), self.r_list,
+            check(lib.htfs_build_nlist(s.pos.data_ptr(), pos_sorted.data_ptr(), s.scalar_code, s.N, Ntot, C.byref(s.box), self.r_list,
                                        C.byref(n3), order.data_ptr(), cell_start.data_ptr(), self.pitch,
                                        self.n_neigh.data_ptr(), self.head_list.data_ptr(), self.nlist.data_ptr(),
                                        self._max.data_ptr(), stream))

@@ -129,6 +129,16 @@ HTF_API int htf_eval_forces(const htf_potential *pot,
                     const void *d_nlist, int nlist_dtype, unsigned B, unsigned NN,
                     void *d_force, int force_dtype, void *d_virial9, htf_stream stream);
 
+/* htf_build_pair_vectors + htf_eval_forces in one pass with the pair vectors kept in
+ * registers (no [B, NN, 4] tensor): same semantics and per-slot arithmetic, ~8x less HBM
+ * traffic.  Closed-form potentials only.  d_check_count (nullable, caller zeroes): max'ed
+ * with max_i sum_j [dx_ij > 0], the quantity SimModel's check_nlist asserts on. */
+HTF_API int htf_fused_forces(const htf_potential *pot, const void *d_pos, int pos_dtype,
+                     unsigned N, unsigned NN, unsigned offset, unsigned batch_size, const htf_box *box,
+                     const unsigned *d_n_neigh, const unsigned *d_nlist, const unsigned *d_head_list,
+                     double rmax, void *d_force, int force_dtype, void *d_virial9,
+                     unsigned *d_check_count, htf_stream stream);
+
 /* Replaces htf_gpu_add_virial (TensorflowCompute.cu:41-71; CPU .cc:284-301):
  * dest[c*pitch + i] += src[i*9 + {0,1,2,4,5,8}]. */
 HTF_API int htf_add_virial(void *d_dest, const void *d_src9, int dtype, unsigned N, size_t pitch, htf_stream stream);
@@ -197,6 +207,8 @@ typedef struct htf_config {
     int check_nlist;     /* SimModel(check_nlist=True) simmodel.py:15 */
     int virial;          /* SimModel(virial=True)      simmodel.py:15 */
     unsigned max_n;      /* m_pdata->getMaxN(): sizes the scratch, reallocate() .cc:91-121 */
+    int fused;           /* 1: evaluate pair vectors in registers (htf_fused_forces); the nlist
+                          * side buffer is then NOT filled.  0 (default): reference dataflow. */
 } htf_config;
 
 /* What HOOMD hands over each step (raw device pointers; see layouts above). */

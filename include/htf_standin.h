@@ -22,15 +22,16 @@ HTF_API int htfs_max_displacement2(const void *d_pos, const void *d_ref, int dty
                                    const htf_box *box, float *d_out, htf_stream stream);
 
 /* Cell-list neighbor search in HOOMD layout (NeighborListGPUBinned analogue).
- * d_cell_of [Ntot], d_order [Ntot] (particle ids sorted by cell), d_cell_start
- * [ncell+1] are produced by the caller (binning + sort are plumbing); this kernel walks
+ * d_cell_of [Ntot], d_order [Ntot] (particle ids sorted by cell), d_pos_sorted [Ntot]
+ * (= pos[order], so a cell's members are contiguous) and d_cell_start [ncell+1] are
+ * produced by the caller (binning + sort + gather are plumbing); this kernel walks
  * the 27 neighbor cells of each local particle and writes
  *   nlist[i*pitch + c] = k  for every k != i with |minimage(r_k - r_i)| <= r_list,
  *   n_neigh[i] = count, head_list[i] = i*pitch.
  * *d_max_neigh is max'ed with the largest count (> pitch means the list overflowed and
  * must be rebuilt with a larger pitch). */
-HTF_API int htfs_build_nlist(const void *d_pos, int dtype, unsigned N, unsigned Ntot, const htf_box *box,
-                             double r_list, const int *ncell3, const unsigned *d_order,
+HTF_API int htfs_build_nlist(const void *d_pos, const void *d_pos_sorted, int dtype, unsigned N, unsigned Ntot,
+                             const htf_box *box, double r_list, const int *ncell3, const unsigned *d_order,
                              const unsigned *d_cell_start, unsigned pitch, unsigned *d_n_neigh,
                              unsigned *d_head_list, unsigned *d_nlist, unsigned *d_max_neigh, htf_stream stream);
 
