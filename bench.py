@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--dt", type=float, default=0.005)
     ap.add_argument("--check-period", type=int, default=5, help="nlist distance-check period (HOOMD check_period)")
     ap.add_argument("--equil", type=int, default=300, help="untimed relaxation steps (force cap + velocity rescale)")
+    ap.add_argument("--sort", action="store_true", help="enable the stand-in's particle sorter (HOOMD SFCPack analogue; measured: no kernel gain)")
     ap.add_argument("--no-fused", action="store_true", help="skip the extra fused gather-evaluate measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -132,7 +133,8 @@ def main():
     pos[:, 0] += (rank - (world - 1) / 2.0) * L[0]
     sysm = standin.System(pos, Lg, dtype=torch.float32, device=dev)
     sysm.randomize_velocities(kT=1.0, seed=3 + rank)
-    nl = standin.CellNlist(sysm, r_cut=args.rcut, r_buff=args.rbuff, check_period=args.check_period)
+    nl = standin.CellNlist(sysm, r_cut=args.rcut, r_buff=args.rbuff, check_period=args.check_period,
+                           sort_particles=args.sort)
     if world > 1:
         from hoomd_tf_amd.domain import SlabDomain
         nl.domain = SlabDomain(sysm, rank, world, r_ghost=args.rcut + args.rbuff)

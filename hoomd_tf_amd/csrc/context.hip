@@ -39,6 +39,7 @@ struct htf_ctx {
     float4 *positions = nullptr; // [capacity] fp32 positions, type un-stuffed (m_positions_array, .cc:100)
     void *virial = nullptr;    // [capacity, 9] Scalar              (m_virial_array, .cc:117)
     unsigned *flag = nullptr;  // device word for check_nlist / overflow counts
+    unsigned *counts = nullptr; // [capacity] live slots per scratch row (delta zero-fill + padding skip)
     // profiler scopes: event triples (before build, between, after eval) per batch
     bool profiling = false;
     std::vector<hipEvent_t> ev_pool;
@@ -139,7 +140,7 @@ extern "C" int htf_eval_forces(const htf_potential *pot, const void *d_nlist, in
         return mlp_eval(pot->mlp, d_nlist, nlist_dtype, B, NN, d_force, force_dtype, (hipStream_t)stream);
     }
     HTF_REQUIRE(!(pot->pp.kind == HTF_POT_SIMPLE && d_virial9), "htf_eval_forces: SimplePotential has no energy, hence no virial");
-    return eval_pair_dispatch(pot->pp, d_nlist, nlist_dtype, B, NN, d_force, force_dtype, d_virial9, (hipStream_t)stream);
+    return eval_pair_dispatch(pot->pp, d_nlist, nlist_dtype, B, NN, d_force, force_dtype, d_virial9, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int htf_fused_forces(const htf_potential *pot, const void *d_pos, int pos_dtype, unsigned N, unsigned NN,
@@ -158,6 +159,8 @@ static void ctx_free(htf_ctx *c) {
     if (c->nlist) (void)hipFree(c->nlist);
     if (c->positions) (void)hipFree(c->positions);
     if (c->virial) (void)hipFree(c->virial);
+    if (c->counts) (void)hipFree(c->counts);
+    c->counts = nullptr;
     c->nlist = nullptr;
     c->positions = nullptr;
     c->virial = nullptr;
@@ -172,7 +175,14 @@ static int ctx_alloc(htf_ctx *c, unsigned max_n) {
     unsigned cap = c->cfg.batch_size ? c->cfg.batch_size : max_n;
     if (cap == 0) cap = 1;
     size_t ssz = c->cfg.scalar_dtype == HTF_F64 ? 8 : 4;
-    if (c->cfg.nneighs > 0) HTF_CHECK_HIP(hipMalloc((void **)&c->nlist, (size_t)cap * c->cfg.nneighs * sizeof(float4)));
+    if (c->cfg.nneighs > 0) {
+        // zeroed once: from then on every row is [live slots | zeros] and the build only
+        // re-zeroes the slots a row has lost since the previous call (counts)
+        HTF_CHECK_HIP(hipMalloc((void **)&c->nlist, (size_t)cap * c->cfg.nneighs * sizeof(float4)));
+        HTF_CHECK_HIP(hipMemset(c->nlist, 0, (size_t)cap * c->cfg.nneighs * sizeof(float4)));
+        HTF_CHECK_HIP(hipMalloc((void **)&c->counts, (size_t)cap * sizeof(unsigned)));
+        HTF_CHECK_HIP(hipMemset(c->counts, 0, (size_t)cap * sizeof(unsigned)));
+    }
     HTF_CHECK_HIP(hipMalloc((void **)&c->positions, (size_t)cap * sizeof(float4)));
     HTF_CHECK_HIP(hipMalloc(&c->virial, (size_t)cap * 9 * ssz));
     HTF_CHECK_HIP(hipMemset(c->virial, 0, (size_t)cap * 9 * ssz));
@@ -304,7 +314,7 @@ extern "C" int htf_compute_forces(htf_ctx *ctx, unsigned timestep, const htf_hoo
             // positions side buffer (m_positions_comm.receiveArray, .cc:172) is staged by the same kernel
             rc = build_pair_vectors_impl(ctx->nlist, HTF_F32, a->pos, cfg.scalar_dtype, N, cfg.nneighs, offset, n,
                                          &a->box, a->n_neigh, a->nlist, a->head_list, cfg.r_cut, nullptr,
-                                         ctx->positions, s);
+                                         ctx->positions, ctx->counts, s);
             if (rc != HTF_OK) return rc;
         }
         if (prof) HTF_CHECK_HIP(hipEventRecord(e1, s));
@@ -327,8 +337,12 @@ extern "C" int htf_compute_forces(htf_ctx *ctx, unsigned timestep, const htf_hoo
             }
         }
         void *force_out = (char *)a->force + (size_t)offset * 4 * ssz; // m_forces_comm.setOffset(offset) .cc:192
-        rc = htf_eval_forces(ctx->pot, ctx->nlist, HTF_F32, n, cfg.nneighs, force_out, cfg.scalar_dtype,
-                             cfg.virial ? ctx->virial : nullptr, stream);
+        if (ctx->pot->pp.kind == HTF_POT_PAIR_MLP)
+            rc = htf_eval_forces(ctx->pot, ctx->nlist, HTF_F32, n, cfg.nneighs, force_out, cfg.scalar_dtype,
+                                 cfg.virial ? ctx->virial : nullptr, stream);
+        else
+            rc = eval_pair_dispatch(ctx->pot->pp, ctx->nlist, HTF_F32, n, cfg.nneighs, force_out, cfg.scalar_dtype,
+                                    cfg.virial ? ctx->virial : nullptr, ctx->counts, s);
         if (rc != HTF_OK) return rc;
         if (prof) HTF_CHECK_HIP(hipEventRecord(e2, s));
         if (cfg.virial && a->virial) { // receiveVirial(offset, N) .cc:200-204

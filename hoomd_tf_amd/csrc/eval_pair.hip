@@ -35,24 +35,36 @@ __device__ __forceinline__ float4 load_slot(const typename Vec4<IT>::type *p) {
 template <int KIND, int G, bool VIRIAL, typename IT>
 __global__ __launch_bounds__(256) void eval_pair_kernel(const typename Vec4<IT>::type *__restrict__ nlist,
                                                         unsigned B, unsigned NN, void *__restrict__ force,
-                                                        void *__restrict__ virial9, int out_f64, PotParams p) {
+                                                        void *__restrict__ virial9, int out_f64, PotParams p,
+                                                        const unsigned *__restrict__ counts) {
     constexpr int RPW = 64 / G; // particle rows per wave
     const unsigned lane = threadIdx.x & 63u;
     const unsigned g = lane % G, sub = lane / G;
-    const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    // Blocks walk the rows from the END of the tensor: in computeForces this kernel runs right
+    // after the pair-vector build, whose most recently written rows are the ones still
+    // resident in the 256 MiB Infinity Cache (the 268 MB tensor does not fit; reading in
+    // write order would miss everywhere, LRU-style).
+    const unsigned wave = ((gridDim.x - 1 - blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
     const unsigned row = wave * RPW + sub;
     const bool active = row < B;
     const typename Vec4<IT>::type *rp = nlist + (size_t)(active ? row : B - 1) * NN;
 
     float fx = 0.f, fy = 0.f, fz = 0.f, en = 0.f;
     float vxx = 0.f, vxy = 0.f, vxz = 0.f, vyy = 0.f, vyz = 0.f, vzz = 0.f;
+    // live slots of this row when the producer recorded them (context path): the zero
+    // padding behind them contributes nothing and is not fetched
+    unsigned cnt = NN;
+    if (counts != nullptr && active) {
+        cnt = counts[row];
+        cnt = cnt < NN ? cnt : NN;
+    }
 
     for (unsigned j0 = 0; j0 < NN; j0 += kUnroll * G) {
         float4 v[kUnroll];
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
             unsigned j = j0 + u * G + g;
-            v[u] = (j < NN) ? load_slot<IT>(rp + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+            v[u] = (j < cnt) ? load_slot<IT>(rp + j) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
@@ -114,11 +126,11 @@ __global__ __launch_bounds__(256) void eval_pair_kernel(const typename Vec4<IT>:
 
 template <int KIND, int G, bool VIRIAL, typename IT>
 static int launch_eval_g(const void *nlist, unsigned B, unsigned NN, void *force, void *virial9,
-                         int out_f64, const PotParams &p, hipStream_t stream) {
+                         int out_f64, const PotParams &p, const unsigned *counts, hipStream_t stream) {
     constexpr unsigned rows_per_block = 4 * (64 / G);
     unsigned grid = (B + rows_per_block - 1) / rows_per_block;
     hipLaunchKernelGGL((eval_pair_kernel<KIND, G, VIRIAL, IT>), dim3(grid), dim3(256), 0, stream,
-                       (const typename Vec4<IT>::type *)nlist, B, NN, force, virial9, out_f64, p);
+                       (const typename Vec4<IT>::type *)nlist, B, NN, force, virial9, out_f64, p, counts);
     return check_launch("eval_pair_kernel");
 }
 
@@ -131,33 +143,33 @@ static int pick_group(unsigned NN) {
 
 template <int KIND, bool VIRIAL, typename IT>
 static int launch_eval_k(const void *nlist, unsigned B, unsigned NN, void *force, void *virial9,
-                         int out_f64, const PotParams &p, hipStream_t stream) {
+                         int out_f64, const PotParams &p, const unsigned *counts, hipStream_t stream) {
     switch (pick_group(NN)) {
-    case 16: return launch_eval_g<KIND, 16, VIRIAL, IT>(nlist, B, NN, force, virial9, out_f64, p, stream);
-    case 8: return launch_eval_g<KIND, 8, VIRIAL, IT>(nlist, B, NN, force, virial9, out_f64, p, stream);
-    default: return launch_eval_g<KIND, 4, VIRIAL, IT>(nlist, B, NN, force, virial9, out_f64, p, stream);
+    case 16: return launch_eval_g<KIND, 16, VIRIAL, IT>(nlist, B, NN, force, virial9, out_f64, p, counts, stream);
+    case 8: return launch_eval_g<KIND, 8, VIRIAL, IT>(nlist, B, NN, force, virial9, out_f64, p, counts, stream);
+    default: return launch_eval_g<KIND, 4, VIRIAL, IT>(nlist, B, NN, force, virial9, out_f64, p, counts, stream);
     }
 }
 
 template <int KIND>
 static int launch_eval(const void *nlist, int in_dtype, unsigned B, unsigned NN, void *force,
-                       void *virial9, int out_f64, const PotParams &p, hipStream_t stream) {
+                       void *virial9, int out_f64, const PotParams &p, const unsigned *counts, hipStream_t stream) {
     if (in_dtype == HTF_F32) {
-        return virial9 ? launch_eval_k<KIND, true, float>(nlist, B, NN, force, virial9, out_f64, p, stream)
-                       : launch_eval_k<KIND, false, float>(nlist, B, NN, force, virial9, out_f64, p, stream);
+        return virial9 ? launch_eval_k<KIND, true, float>(nlist, B, NN, force, virial9, out_f64, p, counts, stream)
+                       : launch_eval_k<KIND, false, float>(nlist, B, NN, force, virial9, out_f64, p, counts, stream);
     }
-    return virial9 ? launch_eval_k<KIND, true, double>(nlist, B, NN, force, virial9, out_f64, p, stream)
-                   : launch_eval_k<KIND, false, double>(nlist, B, NN, force, virial9, out_f64, p, stream);
+    return virial9 ? launch_eval_k<KIND, true, double>(nlist, B, NN, force, virial9, out_f64, p, counts, stream)
+                   : launch_eval_k<KIND, false, double>(nlist, B, NN, force, virial9, out_f64, p, counts, stream);
 }
 
 int eval_pair_dispatch(const PotParams &p, const void *nlist, int in_dtype, unsigned B, unsigned NN,
-                       void *force, int force_dtype, void *virial9, hipStream_t stream) {
+                       void *force, int force_dtype, void *virial9, const unsigned *counts, hipStream_t stream) {
     const int out_f64 = force_dtype == HTF_F64;
     switch (p.kind) {
-    case HTF_POT_LJ: return launch_eval<HTF_POT_LJ>(nlist, in_dtype, B, NN, force, virial9, out_f64, p, stream);
-    case HTF_POT_WCA: return launch_eval<HTF_POT_WCA>(nlist, in_dtype, B, NN, force, virial9, out_f64, p, stream);
-    case HTF_POT_RINV_POLY: return launch_eval<HTF_POT_RINV_POLY>(nlist, in_dtype, B, NN, force, virial9, out_f64, p, stream);
-    case HTF_POT_SIMPLE: return launch_eval<HTF_POT_SIMPLE>(nlist, in_dtype, B, NN, force, virial9, out_f64, p, stream);
+    case HTF_POT_LJ: return launch_eval<HTF_POT_LJ>(nlist, in_dtype, B, NN, force, virial9, out_f64, p, counts, stream);
+    case HTF_POT_WCA: return launch_eval<HTF_POT_WCA>(nlist, in_dtype, B, NN, force, virial9, out_f64, p, counts, stream);
+    case HTF_POT_RINV_POLY: return launch_eval<HTF_POT_RINV_POLY>(nlist, in_dtype, B, NN, force, virial9, out_f64, p, counts, stream);
+    case HTF_POT_SIMPLE: return launch_eval<HTF_POT_SIMPLE>(nlist, in_dtype, B, NN, force, virial9, out_f64, p, counts, stream);
     default:
         set_error("eval_pair_dispatch: potential kind %d is not a closed-form pair potential", p.kind);
         return HTF_ERR_INVALID;

@@ -13,14 +13,15 @@ struct PotParams {
     int power[HTF_MAX_POLY_TERMS];
 };
 
+// counts (nullable): live slots per row; slots >= counts[row] are known zero padding and not loaded
 int eval_pair_dispatch(const PotParams &p, const void *nlist, int in_dtype, unsigned B, unsigned NN,
-                       void *force, int force_dtype, void *virial9, hipStream_t stream);
+                       void *force, int force_dtype, void *virial9, const unsigned *counts, hipStream_t stream);
 
 // pair-vector build with the positions side buffer staged by the same kernel
 int build_pair_vectors_impl(void *dest, int dest_dtype, const void *d_pos, int pos_dtype, unsigned N, unsigned NN,
                             unsigned offset, unsigned batch_size, const htf_box *box, const unsigned *d_n_neigh,
                             const unsigned *d_nlist, const unsigned *d_head_list, double rmax,
-                            unsigned *d_max_count, float4 *positions_out, hipStream_t s);
+                            unsigned *d_max_count, float4 *positions_out, unsigned *counts_io, hipStream_t s);
 
 int fused_forces_impl(const PotParams &p, const void *pos, int pos_dtype, unsigned N, unsigned NN, unsigned offset,
                       unsigned batch, const htf_box *box, const unsigned *n_neigh, const unsigned *nlist,

@@ -6,6 +6,11 @@
 
 namespace htf {
 
+// v_rcp_f32: 1 ulp, no IEEE div expansion (v_div_scale/fmas/fixup: ~10 instructions each).
+// Worst amplification is s^13 in the LJ force: 13 ulp ~ 1.5e-6 relative, inside the 2e-5
+// parity tolerance (measured: tests/test_gpu_parity.py ratios in gpurun_out/parity_stats.json).
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
 // shared forward of every rinv-based energy: t = x + 1e-7, r' = |t|, s = nlist_rinv
 struct RinvFwd {
     float tx, ty, tz, rp, s;
@@ -19,7 +24,7 @@ __device__ __forceinline__ RinvFwd rinv_fwd(float x, float y, float z) {
     f.tz = z + kNormDelta;
     f.rp = sqrtf(f.tx * f.tx + f.ty * f.ty + f.tz * f.tz);
     f.cond = f.rp > kRinvDelta;
-    f.s = f.cond ? 1.0f / (f.rp + kRinvDelta) : 0.0f;
+    f.s = f.cond ? fast_rcp(f.rp + kRinvDelta) : 0.0f;
     return f;
 }
 
@@ -73,7 +78,7 @@ __device__ __forceinline__ void pair_eval(float x, float y, float z, const PotPa
             }
         }
         // d s / d r' = -s^2 (where cond), d r' / d t = t / r'; times 2 (simmodel.py:548)
-        float c = f.cond ? 2.0f * (dEds * (-s2)) / f.rp : 0.0f;
+        float c = f.cond ? 2.0f * (dEds * (-s2)) * fast_rcp(f.rp) : 0.0f;
         fx = c * f.tx;
         fy = c * f.ty;
         fz = c * f.tz;

@@ -16,6 +16,13 @@
 // 119 us.  The kernel is bound by the 16-B position gathers (one L1 line lookup per lane:
 // 18.2 M lanes / 256 CUs ~ 30 us at one lane per clock) plus the 268 MB row write, not by
 // the dependent-load latency the restructurings targeted.
+// Ablation (same harness): 84 us full, 76 us with the random gather replaced by a local
+// one, 35 us with the row stores removed.  A wave keeps its slot until its stores have
+// completed (~3 us under load, 60 % of its lifetime), and gfx950 retires loads and stores
+// on ONE in-order counter, so a multi-particle-per-wave pipeline only overlaps them if the
+// number of stores between a load and its use is a compile-time constant (otherwise hipcc
+// falls back to vmcnt(0) at the loop head -- measured 130 us).  Next step: transpose the
+// compacted row through LDS so that every row is exactly NN/64 full-line stores.
 //
 // Compiled with -ffp-contract=off: the arithmetic is then op-for-op the oracle's
 // (oracle/htf_oracle.py:min_image / prepare_neighbors), so pair vectors are
@@ -76,7 +83,7 @@ __global__ __launch_bounds__(256) void build_pair_vectors_kernel(
     unsigned N, unsigned NN, unsigned offset, unsigned batch, BoxT<PT> box,
     const unsigned *__restrict__ n_neigh, const unsigned *__restrict__ nlist,
     const unsigned *__restrict__ head_list, PT rmaxsq, unsigned *__restrict__ max_count,
-    float4 *__restrict__ positions_out) {
+    float4 *__restrict__ positions_out, unsigned *__restrict__ counts_io) {
     using DV = typename Vec4<DT>::type;
     const unsigned lane = threadIdx.x & 63u;
     const unsigned w = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
@@ -96,7 +103,13 @@ __global__ __launch_bounds__(256) void build_pair_vectors_kernel(
 
     DV zero;
     zero.x = zero.y = zero.z = zero.w = (DT)0;
-    for (unsigned s = (Q < NN ? Q : NN) + lane; s < NN; s += 64) row[s] = zero;
+    const unsigned filled = Q < NN ? Q : NN;
+    // Context-owned scratch (counts_io != null): the row held counts_io[w] live slots after the
+    // previous call and zeros behind them, so only slots [filled, previous) need re-zeroing --
+    // the padding (26 % of the tensor at C3) is not rewritten every step.
+    const unsigned zero_end = counts_io != nullptr ? counts_io[w] : NN;
+    for (unsigned s = filled + lane; s < zero_end; s += 64) row[s] = zero;
+    if (counts_io != nullptr && lane == 0) counts_io[w] = filled;
 
     if (Q > NN) {
         // Overflow (an error condition upstream, caught by check_nlist): reproduce the
@@ -115,7 +128,7 @@ template <typename PT, typename DT>
 static int launch_build(void *dest, const void *pos, unsigned N, unsigned NN, unsigned offset,
                         unsigned batch, const htf_box *hb, const unsigned *n_neigh,
                         const unsigned *nlist, const unsigned *head_list, double rmax,
-                        unsigned *max_count, float4 *positions_out, hipStream_t stream) {
+                        unsigned *max_count, float4 *positions_out, unsigned *counts_io, hipStream_t stream) {
     BoxT<PT> b = make_boxt<PT>(hb);
     PT rc = (PT)rmax;
     PT rmaxsq = rc * rc;
@@ -123,7 +136,7 @@ static int launch_build(void *dest, const void *pos, unsigned N, unsigned NN, un
     unsigned grid = (batch + waves_per_block - 1) / waves_per_block;
     hipLaunchKernelGGL((build_pair_vectors_kernel<PT, DT>), dim3(grid), dim3(64 * waves_per_block), 0, stream,
                        (typename Vec4<DT>::type *)dest, (const typename Vec4<PT>::type *)pos, N, NN,
-                       offset, batch, b, n_neigh, nlist, head_list, rmaxsq, max_count, positions_out);
+                       offset, batch, b, n_neigh, nlist, head_list, rmaxsq, max_count, positions_out, counts_io);
     return check_launch("build_pair_vectors_kernel");
 }
 
@@ -133,7 +146,7 @@ namespace htf {
 int build_pair_vectors_impl(void *dest, int dest_dtype, const void *d_pos, int pos_dtype, unsigned N, unsigned NN,
                             unsigned offset, unsigned batch_size, const htf_box *box, const unsigned *d_n_neigh,
                             const unsigned *d_nlist, const unsigned *d_head_list, double rmax,
-                            unsigned *d_max_count, float4 *positions_out, hipStream_t s) {
+                            unsigned *d_max_count, float4 *positions_out, unsigned *counts_io, hipStream_t s) {
     HTF_REQUIRE(dest && d_pos && d_n_neigh && d_nlist && d_head_list && box, "htf_build_pair_vectors: null pointer");
     HTF_REQUIRE(NN > 0, "htf_build_pair_vectors: NN must be > 0");
     HTF_REQUIRE(offset <= N && batch_size <= N - offset, "htf_build_pair_vectors: batch [%u, %u) exceeds N=%u", offset, offset + batch_size, N);
@@ -142,13 +155,13 @@ int build_pair_vectors_impl(void *dest, int dest_dtype, const void *d_pos, int p
         HTF_REQUIRE(box->hi[d] > box->lo[d], "htf_build_pair_vectors: empty box along %d", d);
     if (batch_size == 0) return HTF_OK;
     if (pos_dtype == HTF_F32 && dest_dtype == HTF_F32)
-        return launch_build<float, float>(dest, d_pos, N, NN, offset, batch_size, box, d_n_neigh, d_nlist, d_head_list, rmax, d_max_count, positions_out, s);
+        return launch_build<float, float>(dest, d_pos, N, NN, offset, batch_size, box, d_n_neigh, d_nlist, d_head_list, rmax, d_max_count, positions_out, counts_io, s);
     if (pos_dtype == HTF_F64 && dest_dtype == HTF_F32)
-        return launch_build<double, float>(dest, d_pos, N, NN, offset, batch_size, box, d_n_neigh, d_nlist, d_head_list, rmax, d_max_count, positions_out, s);
+        return launch_build<double, float>(dest, d_pos, N, NN, offset, batch_size, box, d_n_neigh, d_nlist, d_head_list, rmax, d_max_count, positions_out, counts_io, s);
     if (pos_dtype == HTF_F64 && dest_dtype == HTF_F64)
-        return launch_build<double, double>(dest, d_pos, N, NN, offset, batch_size, box, d_n_neigh, d_nlist, d_head_list, rmax, d_max_count, positions_out, s);
+        return launch_build<double, double>(dest, d_pos, N, NN, offset, batch_size, box, d_n_neigh, d_nlist, d_head_list, rmax, d_max_count, positions_out, counts_io, s);
     if (pos_dtype == HTF_F32 && dest_dtype == HTF_F64)
-        return launch_build<float, double>(dest, d_pos, N, NN, offset, batch_size, box, d_n_neigh, d_nlist, d_head_list, rmax, d_max_count, positions_out, s);
+        return launch_build<float, double>(dest, d_pos, N, NN, offset, batch_size, box, d_n_neigh, d_nlist, d_head_list, rmax, d_max_count, positions_out, counts_io, s);
     set_error("htf_build_pair_vectors: bad dtype (%d, %d)", pos_dtype, dest_dtype);
     return HTF_ERR_INVALID;
 }
@@ -161,5 +174,5 @@ extern "C" int htf_build_pair_vectors(void *dest, int dest_dtype, const void *d_
                                       unsigned *d_max_count, htf_stream stream) {
     (void)n_ghost; // ghosts are addressed through the index list (k >= N); nothing to size
     return htf::build_pair_vectors_impl(dest, dest_dtype, d_pos, pos_dtype, N, NN, offset, batch_size, box, d_n_neigh,
-                                        d_nlist, d_head_list, rmax, d_max_count, nullptr, (hipStream_t)stream);
+                                        d_nlist, d_head_list, rmax, d_max_count, nullptr, nullptr, (hipStream_t)stream);
 }

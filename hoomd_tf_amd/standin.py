@@ -87,8 +87,13 @@ class CellNlist:
     """hoomd.md.nlist.cell analogue: FULL neighbor list, fixed pitch head list, rebuilt
     when any particle has moved more than r_buff / 2 (NeighborList::distanceCheck)."""
 
-    def __init__(self, system, r_cut, r_buff=0.4, pitch=None, check_period=1):
+    def __init__(self, system, r_cut, r_buff=0.4, pitch=None, check_period=1, sort_particles=False):
         self.sys = system
+        # HOOMD's SFCPackUpdater analogue: renumber the local particles in cell order at every
+        # rebuild, so that a particle's neighbors sit in a few contiguous index runs and the
+        # position gathers of the force path coalesce.  Off by default (it changes particle
+        # indices, as HOOMD's sorter does; the reference's tests disable it where they track ids).
+        self.sort_particles = bool(sort_particles)
         self.r_cut = float(r_cut)
         self.r_buff = float(r_buff)
         self.check_period = int(check_period)
@@ -130,7 +135,12 @@ class CellNlist:
         cell_of = torch.empty(Ntot, dtype=torch.int32, device=s.device)
         check(lib.htfs_cell_index(s.pos.data_ptr(), s.scalar_code, Ntot, C.byref(s.box), C.byref(n3),
                                   cell_of.data_ptr(), stream))
-        sorted_cells, order = torch.sort(cell_of)
+        if self.sort_particles and s.N > 0:
+            perm = torch.sort(cell_of[: s.N], stable=True)[1]
+            s.pos[: s.N] = s.pos[: s.N].index_select(0, perm)
+            s.vel = s.vel.index_select(0, perm)
+            cell_of[: s.N] = cell_of[: s.N].index_select(0, perm)
+        sorted_cells, order = torch.sort(cell_of, stable=True)
         pos_sorted = s.pos.index_select(0, order)  # cell members contiguous: coalesced candidate reads
         order = order.to(torch.int32)
         counts = torch.bincount(sorted_cells.long(), minlength=ncell)
@@ -144,9 +154,10 @@ class CellNlist:
             est = rho * (4.0 / 3.0 * math.pi * self.r_list ** 3 if dims == 3 else math.pi * self.r_list ** 2 * L[2])
             self.pitch = max(8, int(math.ceil(est * 1.5 / 8.0)) * 8)
         while True:
-            self.n_neigh = torch.empty(s.N, dtype=torch.int32, device=s.device)
-            self.head_list = torch.empty(s.N, dtype=torch.int32, device=s.device)
-            self.nlist = torch.zeros(s.N * self.pitch, dtype=torch.int32, device=s.device)
+            if self.nlist is None or self.nlist.numel() != s.N * self.pitch:
+                self.n_neigh = torch.empty(s.N, dtype=torch.int32, device=s.device)
+                self.head_list = torch.empty(s.N, dtype=torch.int32, device=s.device)
+                self.nlist = torch.empty(s.N * self.pitch, dtype=torch.int32, device=s.device)
             self._max.zero_()
             check(lib.htfs_build_nlist(s.pos.data_ptr(), pos_sorted.data_ptr(), s.scalar_code, s.N, Ntot, C.byref(s.box), self.r_list,
                                        C.byref(n3), order.data_ptr(), cell_start.data_ptr(), self.pitch,
