@@ -237,6 +237,20 @@ def main():
         ach = kern[dom]["GBps"]
         roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS, "traffic": None}
+        # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
+        # (PMC cannot be read from inside the process); null when the file is absent.
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_lj_pmc_hbm.json")))
+            key = {"build_pair_vectors": "void htf::build_pair_vectors_kernel<float, float>",
+                   "eval_forces": "void htf::eval_pair_kernel<1, 16, false, float>"}[dom]
+            rd, wr = pmc["FETCH_SIZE"][key]["avg_KiB"], pmc["WRITE_SIZE"][key]["avg_KiB"]
+            # gfx950: FETCH_SIZE counts half of a wide (16 B/lane) coalesced read stream; the build
+            # kernel's reads are 4-B index loads + 16-B gathers, for which the counter is uncalibrated
+            corr = 2.0 if dom == "eval_forces" else 1.0
+            roof["traffic"] = (rd * corr + wr) * 1024.0
+            roof["traffic_source"] = "profiles/r01_bench_lj_pmc_hbm.json (FETCH_SIZE x%g + WRITE_SIZE)" % corr
+        except (OSError, KeyError, ValueError):
+            pass
 
     ms_per_step = elapsed / args.steps * 1e3
     step_bytes = eval_b + build_b + integ_b

@@ -28,6 +28,9 @@ class tfcompute:
         self.cpp_force = None
         self._nlist = None
         self.map_types = set()
+        # opt-in: evaluate pair vectors in registers on the traced path (htf_config.fused);
+        # get_nlist_array() then has no side buffer to read
+        self.fused = False
 
     def attach(self, nlist=None, r_cut=0, period=1, batch_size=None, train=False, save_output_period=None):
         """tensorflowcompute.py:38-188 (same arguments and error behaviour)."""
@@ -66,7 +69,8 @@ class tfcompute:
         self.cpp_force = ops.Context(r_cut=self.r_cut if self.nneighbor_cutoff else 0.0,
                                      nneighs=self.nneighbor_cutoff, period=self.period,
                                      batch_size=self.batch_size, scalar_dtype=s.dtype,
-                                     check_nlist=self.model.check_nlist, virial=self.model.virial, max_n=s.N)
+                                     check_nlist=self.model.check_nlist, virial=self.model.virial, max_n=s.N,
+                                     fused=self.fused)
         # ForceCompute::m_force / m_virial of this compute
         self.force = torch.zeros((s.N, 4), dtype=s.dtype, device=s.device)
         self.virial = torch.zeros(6 * s.N, dtype=s.dtype, device=s.device)
@@ -176,6 +180,8 @@ class tfcompute:
 
     def get_nlist_array(self):
         """tensorflowcompute.py:377-381 -> [B, NN, 4]."""
+        if self._ctx_ran and self.fused:
+            raise RuntimeError('fused mode keeps the pair vectors in registers; there is no nlist buffer to read')
         if self._ctx_ran:
             n = self.system.N if self.batch_size == 0 else min(self.batch_size, self.system.N)
             return self.cpp_force.nlist_buffer(n, self.system.device).double().cpu().numpy()
