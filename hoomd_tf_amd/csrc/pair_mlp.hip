@@ -22,6 +22,7 @@
 // wave's tanh/exp VALU phase overlaps another's MFMA phase.  Fully padded tiles (the
 // tail of every row) are skipped with a wave-uniform ballot.
 #include <cmath>
+#include <cstring>
 #include <vector>
 
 #include "htf_common.h"
@@ -34,19 +35,25 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 constexpr int kK = 32;  // RBF count (padded with zero weights below 32)
 constexpr int kH = 64;  // hidden width (padded with zero weights below 64)
 
-// float offsets inside the device image buffer / LDS
-constexpr int kImgL1 = 0;                      // [nb 2][g 4][lane 64][4]
-constexpr int kImgL2 = kImgL1 + 2 * 16 * 64;   // [nb 2][kb 2][g 4][lane 64][4]
-constexpr int kImgB2 = kImgL2 + 4 * 16 * 64;   // [fb 2][kb 2][g 4][lane 64][4]
-constexpr int kImgB1 = kImgB2 + 4 * 16 * 64;   // [kb 2][g 4][lane 64][4]
-constexpr int kTabB1 = kImgB1 + 2 * 16 * 64;   // [b 2][h 2][v 16]
-constexpr int kTabB2 = kTabB1 + 64;
-constexpr int kTabW3 = kTabB2 + 64;
-constexpr int kTabC = kTabW3 + 64;             // [h 2][v 16] RBF centers
-constexpr int kImgFloats = kTabC + 32;         // 12512 floats = 50048 B
+// Offsets (in floats) inside the device image buffer / LDS.  One operand block covers a
+// 32 x 32 (feature x feature) weight tile: fp32 [g 4][lane 64][4 floats] = 1024 floats,
+// bf16 [s 2][lane 64][8 bf16] = 512 floats.
+template <bool BF16>
+struct Img {
+    static constexpr int BS = BF16 ? 512 : 1024;
+    static constexpr int L1 = 0;            // [nb 2]
+    static constexpr int L2 = 2 * BS;       // [nb 2][kb 2]
+    static constexpr int B2 = 6 * BS;       // [fb 2][kb 2]
+    static constexpr int B1 = 10 * BS;      // [kb 2]
+    static constexpr int TabB1 = 12 * BS;   // [b 2][h 2][v 16]
+    static constexpr int TabB2 = TabB1 + 64;
+    static constexpr int TabW3 = TabB2 + 64;
+    static constexpr int TabC = TabW3 + 64; // [h 2][v 16] RBF centres
+    static constexpr int Floats = TabC + 32; // fp32: 12512 floats (50 KB); bf16: 6368 floats (25 KB)
+};
 
 struct MlpDevice {
-    float *images = nullptr; // kImgFloats floats, operand order
+    float *images = nullptr; // Img<>::Floats floats, operand order
     float b3 = 0.f, gap = 1.f;
     int act = HTF_ACT_LINEAR;
     int precision = HTF_MLP_FP32;
@@ -80,6 +87,33 @@ __device__ __forceinline__ void mfma_block(f32x16 &acc, const float *img, unsign
     }
 }
 
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+
+// bf16 operands, fp32 accumulation: v_mfma_f32_32x32x16_bf16, two k-steps per 32-feature
+// block.  Accumulator registers 8s..8s+7, converted pairwise (v_cvt_pk_bf16_f32), ARE the B
+// fragment of k-step s: element j of lane half h is feature 16s + 8(j>>2) + 4h + (j&3) --
+// the same feature set f0(8s+j) + 4h as in the fp32 path, so tables and RBF centres are
+// shared and only the weight images differ.
+__device__ __forceinline__ void mfma_block_bf16(f32x16 &acc, const float *img, unsigned lane, const f32x16 &prev) {
+    const bf16x8 *p = reinterpret_cast<const bf16x8 *>(img) + lane;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        bf16x8 a = p[s * 64];
+        bf16x8 b;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) b[j] = (__bf16)prev[8 * s + j];
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+    }
+}
+
+template <bool BF16>
+__device__ __forceinline__ void mfma_blk(f32x16 &acc, const float *img, unsigned lane, const f32x16 &prev) {
+    if constexpr (BF16)
+        mfma_block_bf16(acc, img, lane, prev);
+    else
+        mfma_block(acc, img, lane, prev);
+}
+
 __device__ __forceinline__ f32x16 load_tab(const float *tab, int b, unsigned h) {
     const float4 *p = reinterpret_cast<const float4 *>(tab + (b * 2 + h) * 16);
     float4 a = p[0], bq = p[1], c = p[2], d = p[3];
@@ -91,16 +125,17 @@ __device__ __forceinline__ f32x16 load_tab(const float *tab, int b, unsigned h) 
     return r;
 }
 
-template <bool TANH, typename IT>
+template <bool TANH, typename IT, bool BF16>
 __global__ __launch_bounds__(256, 3) void pair_mlp_kernel(const typename Vec4<IT>::type *__restrict__ nlist,
                                                           unsigned B, unsigned NN, void *__restrict__ force,
                                                           int out_f64, const float *__restrict__ images, float b3,
                                                           float gap) {
-    __shared__ __attribute__((aligned(16))) float lds[kImgFloats];
+    using I = Img<BF16>;
+    __shared__ __attribute__((aligned(16))) float lds[I::Floats];
     {
         const float4 *src = reinterpret_cast<const float4 *>(images);
         float4 *dst = reinterpret_cast<float4 *>(lds);
-        for (int i = threadIdx.x; i < kImgFloats / 4; i += blockDim.x) dst[i] = src[i];
+        for (int i = threadIdx.x; i < I::Floats / 4; i += blockDim.x) dst[i] = src[i];
     }
     __syncthreads();
 
@@ -110,7 +145,7 @@ __global__ __launch_bounds__(256, 3) void pair_mlp_kernel(const typename Vec4<IT
     const unsigned nwaves = (gridDim.x * blockDim.x) >> 6;
     const unsigned ntiles = (NN + 31) / 32;
     const float ginv = 1.0f / gap;
-    const f32x16 cen = load_tab(lds + kTabC, 0, h); // centers of this lane's 16 RBF indices
+    const f32x16 cen = load_tab(lds + I::TabC, 0, h); // centers of this lane's 16 RBF indices
 
     for (unsigned row = wave; row < B; row += nwaves) {
         const typename Vec4<IT>::type *rp = nlist + (size_t)row * NN;
@@ -139,8 +174,8 @@ __global__ __launch_bounds__(256, 3) void pair_mlp_kernel(const typename Vec4<IT
             f32x16 a1[2];
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb) {
-                a1[nb] = load_tab(lds + kTabB1, nb, h);
-                mfma_block(a1[nb], lds + kImgL1 + nb * 1024, lane, phi);
+                a1[nb] = load_tab(lds + I::TabB1, nb, h);
+                mfma_blk<BF16>(a1[nb], lds + I::L1 + nb * I::BS, lane, phi);
 #pragma unroll
                 for (int v = 0; v < 16; ++v) a1[nb][v] = act_fwd<TANH>(a1[nb][v]);
             }
@@ -148,10 +183,10 @@ __global__ __launch_bounds__(256, 3) void pair_mlp_kernel(const typename Vec4<IT
             f32x16 a2[2];
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb) {
-                a2[nb] = load_tab(lds + kTabB2, nb, h);
+                a2[nb] = load_tab(lds + I::TabB2, nb, h);
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
-                    mfma_block(a2[nb], lds + kImgL2 + (nb * 2 + kb) * 1024, lane, a1[kb]);
+                    mfma_blk<BF16>(a2[nb], lds + I::L2 + (nb * 2 + kb) * I::BS, lane, a1[kb]);
 #pragma unroll
                 for (int v = 0; v < 16; ++v) a2[nb][v] = act_fwd<TANH>(a2[nb][v]);
             }
@@ -159,7 +194,7 @@ __global__ __launch_bounds__(256, 3) void pair_mlp_kernel(const typename Vec4<IT
             float upart = 0.f;
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
-                const f32x16 w3 = load_tab(lds + kTabW3, b, h);
+                const f32x16 w3 = load_tab(lds + I::TabW3, b, h);
 #pragma unroll
                 for (int v = 0; v < 16; ++v) {
                     const float hv = a2[b][v];
@@ -177,7 +212,7 @@ __global__ __launch_bounds__(256, 3) void pair_mlp_kernel(const typename Vec4<IT
                 for (int v = 0; v < 16; ++v) d1[v] = 0.f;
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
-                    mfma_block(d1, lds + kImgB2 + (fb * 2 + kb) * 1024, lane, a2[kb]);
+                    mfma_blk<BF16>(d1, lds + I::B2 + (fb * 2 + kb) * I::BS, lane, a2[kb]);
 #pragma unroll
                 for (int v = 0; v < 16; ++v) {
                     const float hv = a1[fb][v];
@@ -189,7 +224,7 @@ __global__ __launch_bounds__(256, 3) void pair_mlp_kernel(const typename Vec4<IT
 #pragma unroll
             for (int v = 0; v < 16; ++v) dphi[v] = 0.f;
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) mfma_block(dphi, lds + kImgB1 + kb * 1024, lane, a1[kb]);
+            for (int kb = 0; kb < 2; ++kb) mfma_blk<BF16>(dphi, lds + I::B1 + kb * I::BS, lane, a1[kb]);
 
             // du/dr = sum_k dphi_k * (-2 (r - c_k) / gap) * phi_k
             float dpart = 0.f;
@@ -223,24 +258,42 @@ __global__ __launch_bounds__(256, 3) void pair_mlp_kernel(const typename Vec4<IT
 }
 
 // ------------------------------------------------------------------------------ host side
+static unsigned short f2bf16(float f) { // round to nearest even (finite weights)
+    unsigned u;
+    std::memcpy(&u, &f, 4);
+    return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+
+template <bool BF16>
 static void fill_image(std::vector<float> &img, const htf_potential_desc *d, float *gap_out) {
+    using I = Img<BF16>;
     const int K = d->K, H1 = d->H1, H2 = d->H2;
     auto W1 = [&](int k, int f) { return (k < K && f < H1) ? d->W1[(size_t)k * H1 + f] : 0.f; };
     auto W2 = [&](int a, int b) { return (a < H1 && b < H2) ? d->W2[(size_t)a * H2 + b] : 0.f; };
-    img.assign(kImgFloats, 0.f);
-    for (int g = 0; g < 4; ++g)
-        for (int lane = 0; lane < 64; ++lane)
-            for (int j = 0; j < 4; ++j) {
-                const int r = 4 * g + j, i = lane & 31, hh = lane >> 5, kk = f0(r) + 4 * hh;
-                const int o = (g * 64 + lane) * 4 + j;
-                for (int nb = 0; nb < 2; ++nb) img[kImgL1 + nb * 1024 + o] = W1(kk, 32 * nb + i);
-                for (int kb = 0; kb < 2; ++kb) img[kImgB1 + kb * 1024 + o] = W1(i, 32 * kb + kk);
-                for (int nb = 0; nb < 2; ++nb)
-                    for (int kb = 0; kb < 2; ++kb) {
-                        img[kImgL2 + (nb * 2 + kb) * 1024 + o] = W2(32 * kb + kk, 32 * nb + i);
-                        img[kImgB2 + (nb * 2 + kb) * 1024 + o] = W2(32 * nb + i, 32 * kb + kk);
-                    }
-            }
+    img.assign(I::Floats, 0.f);
+    unsigned short *h16 = reinterpret_cast<unsigned short *>(img.data());
+    // element e of a block: k-step-local index r (fp32: 16 steps of 1; bf16: 2 steps of 8) and lane
+    auto put = [&](int block_off, int r, int lane, float v) {
+        if constexpr (BF16) {
+            const int sidx = r >> 3, j = r & 7;
+            h16[(size_t)block_off * 2 + ((sidx * 64 + lane) * 8 + j)] = f2bf16(v);
+        } else {
+            const int g = r >> 2, j = r & 3;
+            img[block_off + (g * 64 + lane) * 4 + j] = v;
+        }
+    };
+    for (int r = 0; r < 16; ++r)
+        for (int lane = 0; lane < 64; ++lane) {
+            // accumulator register r of lane half hh holds feature f0(r) + 4 hh of its 32-block
+            const int i = lane & 31, hh = lane >> 5, kk = f0(r) + 4 * hh;
+            for (int nb = 0; nb < 2; ++nb) put(I::L1 + nb * I::BS, r, lane, W1(kk, 32 * nb + i));
+            for (int kb = 0; kb < 2; ++kb) put(I::B1 + kb * I::BS, r, lane, W1(i, 32 * kb + kk));
+            for (int nb = 0; nb < 2; ++nb)
+                for (int kb = 0; kb < 2; ++kb) {
+                    put(I::L2 + (nb * 2 + kb) * I::BS, r, lane, W2(32 * kb + kk, 32 * nb + i));
+                    put(I::B2 + (nb * 2 + kb) * I::BS, r, lane, W2(32 * nb + i, 32 * kb + kk));
+                }
+        }
     // RBF centres: float32 linspace, gap = c[1] - c[0]  (layers.py:31-34)
     std::vector<float> c(kK, 0.f);
     for (int k = 0; k < K; ++k) {
@@ -252,10 +305,10 @@ static void fill_image(std::vector<float> &img, const htf_potential_desc *d, flo
         for (int hh = 0; hh < 2; ++hh)
             for (int v = 0; v < 16; ++v) {
                 const int f = 32 * b + f0(v) + 4 * hh, o = (b * 2 + hh) * 16 + v;
-                img[kTabB1 + o] = f < H1 ? d->b1[f] : 0.f;
-                img[kTabB2 + o] = f < H2 ? d->b2[f] : 0.f;
-                img[kTabW3 + o] = f < H2 ? d->W3[f] : 0.f;
-                if (b == 0) img[kTabC + hh * 16 + v] = c[f0(v) + 4 * hh];
+                img[I::TabB1 + o] = f < H1 ? d->b1[f] : 0.f;
+                img[I::TabB2 + o] = f < H2 ? d->b2[f] : 0.f;
+                img[I::TabW3 + o] = f < H2 ? d->W3[f] : 0.f;
+                if (b == 0) img[I::TabC + hh * 16 + v] = c[f0(v) + 4 * hh];
             }
 }
 
@@ -265,10 +318,13 @@ int mlp_create(const htf_potential_desc *d, MlpDevice **out) {
     HTF_REQUIRE(d->H1 >= 1 && d->H1 <= kH && d->H2 >= 1 && d->H2 <= kH, "pair-MLP: hidden widths (%d, %d) must be <= %d", d->H1, d->H2, kH);
     HTF_REQUIRE(d->rbf_high > d->rbf_low, "pair-MLP: rbf_high must exceed rbf_low");
     HTF_REQUIRE(d->activation == HTF_ACT_LINEAR || d->activation == HTF_ACT_TANH, "pair-MLP: unknown activation %d", d->activation);
-    HTF_REQUIRE(d->mlp_precision == HTF_MLP_FP32, "pair-MLP: only the fp32 MFMA path is built (bf16 operands: next round)");
+    HTF_REQUIRE(d->mlp_precision == HTF_MLP_FP32 || d->mlp_precision == HTF_MLP_BF16, "pair-MLP: unknown precision %d", d->mlp_precision);
     std::vector<float> img;
     float gap = 1.f;
-    fill_image(img, d, &gap);
+    if (d->mlp_precision == HTF_MLP_BF16)
+        fill_image<true>(img, d, &gap);
+    else
+        fill_image<false>(img, d, &gap);
     MlpDevice *m = new (std::nothrow) MlpDevice();
     if (!m) {
         set_error("pair-MLP: out of host memory");
@@ -278,8 +334,8 @@ int mlp_create(const htf_potential_desc *d, MlpDevice **out) {
     m->gap = gap;
     m->act = d->activation;
     m->precision = d->mlp_precision;
-    hipError_t e = hipMalloc((void **)&m->images, kImgFloats * sizeof(float));
-    if (e == hipSuccess) e = hipMemcpy(m->images, img.data(), kImgFloats * sizeof(float), hipMemcpyHostToDevice);
+    hipError_t e = hipMalloc((void **)&m->images, img.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(m->images, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         set_error("pair-MLP: device upload failed: %s", hipGetErrorString(e));
         mlp_destroy(m);
@@ -299,7 +355,7 @@ void mlp_destroy(MlpDevice *m) {
     delete m;
 }
 
-template <bool TANH>
+template <bool TANH, bool BF16>
 static int launch_mlp(const MlpDevice *m, const void *nlist, int in_dtype, unsigned B, unsigned NN, void *force,
                       int out_f64, hipStream_t s) {
     // persistent blocks: 3 per CU (LDS 48.9 KiB each), 4 waves per block, one row per wave trip
@@ -307,9 +363,9 @@ static int launch_mlp(const MlpDevice *m, const void *nlist, int in_dtype, unsig
     unsigned need = (B + 3) / 4;
     if (grid > need) grid = need;
     if (in_dtype == HTF_F32)
-        hipLaunchKernelGGL((pair_mlp_kernel<TANH, float>), dim3(grid), dim3(256), 0, s, (const float4 *)nlist, B, NN, force, out_f64, m->images, m->b3, m->gap);
+        hipLaunchKernelGGL((pair_mlp_kernel<TANH, float, BF16>), dim3(grid), dim3(256), 0, s, (const float4 *)nlist, B, NN, force, out_f64, m->images, m->b3, m->gap);
     else
-        hipLaunchKernelGGL((pair_mlp_kernel<TANH, double>), dim3(grid), dim3(256), 0, s, (const double4 *)nlist, B, NN, force, out_f64, m->images, m->b3, m->gap);
+        hipLaunchKernelGGL((pair_mlp_kernel<TANH, double, BF16>), dim3(grid), dim3(256), 0, s, (const double4 *)nlist, B, NN, force, out_f64, m->images, m->b3, m->gap);
     return check_launch("pair_mlp_kernel");
 }
 
@@ -317,8 +373,11 @@ int mlp_eval(const MlpDevice *m, const void *nlist, int in_dtype, unsigned B, un
              int force_dtype, hipStream_t stream) {
     HTF_REQUIRE(m, "pair-MLP: null potential");
     const int out_f64 = force_dtype == HTF_F64;
-    return m->act == HTF_ACT_TANH ? launch_mlp<true>(m, nlist, in_dtype, B, NN, force, out_f64, stream)
-                                  : launch_mlp<false>(m, nlist, in_dtype, B, NN, force, out_f64, stream);
+    if (m->precision == HTF_MLP_BF16)
+        return m->act == HTF_ACT_TANH ? launch_mlp<true, true>(m, nlist, in_dtype, B, NN, force, out_f64, stream)
+                                      : launch_mlp<false, true>(m, nlist, in_dtype, B, NN, force, out_f64, stream);
+    return m->act == HTF_ACT_TANH ? launch_mlp<true, false>(m, nlist, in_dtype, B, NN, force, out_f64, stream)
+                                  : launch_mlp<false, false>(m, nlist, in_dtype, B, NN, force, out_f64, stream);
 }
 
 } // namespace htf

@@ -251,6 +251,28 @@ def test_pair_mlp_fp32_mfma(htf, cuda, act, NN):
     assert_forces_close("mlp64_%s_NN%d" % (act, NN), f64.cpu().numpy(), ref, cond, atol=2e-5, rtol=5e-5, ctol=5e-6)
 
 
+@pytest.mark.parametrize("act", ["tanh", "linear"])
+def test_pair_mlp_bf16_operands(htf, cuda, act):
+    """Reduced-precision variant (bf16 MFMA operands, fp32 accumulation): NOT a parity
+    claim -- bf16 carries 8 mantissa bits, so forces agree with the fp64 oracle only to
+    ~1e-2 of the row scale.  Checked: the operand permutation is right (a wrong image
+    would be O(1) off), determinism, and that the fp32 path is strictly closer."""
+    from hoomd_tf_amd.initializers import mlp_params
+    params = mlp_params(seed=3, K=32, H1=64, H2=64, bias_scale=0.2)
+    nl = _nlist_case(7, N=257, NN=128, rmin=0.6)
+    ref, g = O.pair_mlp_model(nl.astype(np.float64), params, 0.0, 3.0, act, return_grad=True)
+    x = torch.from_numpy(nl).to(cuda)
+    f16 = htf.ops.eval_forces(htf.Potential.pair_mlp(params, 0.0, 3.0, activation=act, precision="bf16"), x)
+    f32 = htf.ops.eval_forces(htf.Potential.pair_mlp(params, 0.0, 3.0, activation=act), x)
+    cond = np.abs(2 * g).sum(axis=(1, 2))[:, None]
+    e16 = np.abs(f16.cpu().numpy() - ref) / (1e-3 + cond)
+    e32 = np.abs(f32.cpu().numpy() - ref) / (1e-3 + cond)
+    _record("mlp_bf16_" + act, max_abs_err=np.abs(f16.cpu().numpy() - ref).max(), max_ratio=e16.max(), max_ref=np.abs(ref).max())
+    assert e16.max() < 2e-2, e16.max()
+    assert e32.max() < e16.max()
+    assert torch.equal(f16, htf.ops.eval_forces(htf.Potential.pair_mlp(params, 0.0, 3.0, activation=act, precision="bf16"), x))
+
+
 def test_pair_mlp_padded_widths(htf, cuda):
     """K < 32 / H < 64 are zero-padded into the fixed 32/64 MFMA tiling."""
     from hoomd_tf_amd.initializers import mlp_params
