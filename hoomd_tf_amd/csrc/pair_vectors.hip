@@ -21,8 +21,11 @@
 // completed (~3 us under load, 60 % of its lifetime), and gfx950 retires loads and stores
 // on ONE in-order counter, so a multi-particle-per-wave pipeline only overlaps them if the
 // number of stores between a load and its use is a compile-time constant (otherwise hipcc
-// falls back to vmcnt(0) at the loop head -- measured 130 us).  Next step: transpose the
-// compacted row through LDS so that every row is exactly NN/64 full-line stores.
+// falls back to vmcnt(0) at the loop head -- measured 130 us).  A loader/storer split (waves
+// 0-3 only load + compact into an LDS row ring, waves 4-7 only store, raw s_barrier hand-over)
+// was also built and is bit-exact, but ran 101 us: hipcc drains the loader's prefetched loads
+// (vmcnt(0)) in front of every stage barrier, so the prefetch never spans a stage.  Getting
+// past ~85 us needs hand-counted waits (inline-asm loads), not another restructuring in C++.
 //
 // Compiled with -ffp-contract=off: the arithmetic is then op-for-op the oracle's
 // (oracle/htf_oracle.py:min_image / prepare_neighbors), so pair vectors are
