@@ -25,13 +25,15 @@
 // 0-3 only load + compact into an LDS row ring, waves 4-7 only store, raw s_barrier hand-over)
 // was also built and is bit-exact, but ran 101 us: hipcc drains the loader's prefetched loads
 // (vmcnt(0)) in front of every stage barrier, so the prefetch never spans a stage.  Getting
-// past ~85 us needs hand-counted waits (inline-asm loads), not another restructuring in C++.
+// Finally, 2 and 4 particles per wave with ALL their loads issued up front (same dependent
+// chain, 2-4x the rows behind every wave slot) ran 81.4 / 80.8 us against 82.0: the kernel is
+// not wave-slot- or latency-bound either, and writing 190 MB instead of 268 MB (delta
+// zero-fill, PMC-verified) does not move it.  What remains is the store side itself: ~4
+// partial, unaligned store instructions per row (one per compacted chunk plus the zero tail).
 //
 // Compiled with -ffp-contract=off: the arithmetic is then op-for-op the oracle's
 // (oracle/htf_oracle.py:min_image / prepare_neighbors), so pair vectors are
 // bit-exact, not merely within tolerance.
-#include <cstdlib>
-
 #include "htf_common.h"
 #include "box_math.h"
 
@@ -129,93 +131,6 @@ __global__ __launch_bounds__(256) void build_pair_vectors_kernel(
     if (max_count != nullptr && lane == 0 && Q > *(volatile unsigned *)max_count) atomicMax(max_count, Q);
 }
 
-// PPW particles per wave, all of their loads issued up front (index rows, then gathers), then
-// compacted and stored one after the other.  Same dependent chain per wave as the
-// one-particle kernel, but PPW rows of work behind every wave slot.
-template <typename PT, typename DT, int PPW>
-__global__ __launch_bounds__(256) void build_pair_vectors_multi_kernel(
-    typename Vec4<DT>::type *__restrict__ dest, const typename Vec4<PT>::type *__restrict__ pos,
-    unsigned N, unsigned NN, unsigned offset, unsigned batch, BoxT<PT> box,
-    const unsigned *__restrict__ n_neigh, const unsigned *__restrict__ nlist,
-    const unsigned *__restrict__ head_list, PT rmaxsq, unsigned *__restrict__ max_count,
-    float4 *__restrict__ positions_out, unsigned *__restrict__ counts_io) {
-    using DV = typename Vec4<DT>::type;
-    using PV = typename Vec4<PT>::type;
-    const unsigned lane = threadIdx.x & 63u;
-    const unsigned wave = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-    const unsigned w0 = wave * PPW;
-    if (w0 >= batch || w0 + offset >= N) return;
-    unsigned nn[PPW];
-    const unsigned *nl[PPW];
-    PV pi[PPW];
-    bool live[PPW];
-#pragma unroll
-    for (int p = 0; p < PPW; ++p) {
-        const unsigned w = w0 + p;
-        live[p] = w < batch && w + offset < N;
-        const unsigned idx = live[p] ? w + offset : w0 + offset;
-        nn[p] = live[p] ? n_neigh[idx] : 0u;
-        nl[p] = nlist + head_list[idx];
-        pi[p] = pos[idx];
-        if (positions_out != nullptr && live[p] && lane == 0)
-            positions_out[w] = make_float4((float)pi[p].x, (float)pi[p].y, (float)pi[p].z, (float)scalar_as_int(pi[p].w));
-    }
-    unsigned k[PPW][kChunk];
-    PV pk[PPW][kChunk];
-#pragma unroll
-    for (int p = 0; p < PPW; ++p)
-#pragma unroll
-        for (int t = 0; t < kChunk; ++t) {
-            const unsigned j = t * 64 + lane;
-            k[p][t] = nn[p] ? nl[p][j < nn[p] ? j : nn[p] - 1] : 0u;
-        }
-#pragma unroll
-    for (int p = 0; p < PPW; ++p)
-#pragma unroll
-        for (int t = 0; t < kChunk; ++t) pk[p][t] = pos[k[p][t]];
-
-    unsigned qmax = 0;
-#pragma unroll
-    for (int p = 0; p < PPW; ++p) {
-        if (!live[p]) continue;
-        const unsigned w = w0 + p;
-        DV *row = dest + (size_t)w * NN;
-        unsigned Q = 0;
-#pragma unroll
-        for (int t = 0; t < kChunk; ++t) {
-            if (t * 64u >= nn[p]) break; // wave-uniform
-            const unsigned j = t * 64 + lane;
-            PT dx = pk[p][t].x - pi[p].x, dy = pk[p][t].y - pi[p].y, dz = pk[p][t].z - pi[p].z;
-            min_image<PT>(dx, dy, dz, box);
-            const PT rsq = dx * dx + dy * dy + dz * dz;
-            const bool keep = (j < nn[p]) && !(rsq > rmaxsq);
-            const unsigned long long m = __ballot(keep);
-            const unsigned q = Q + __popcll(m & ((1ull << lane) - 1ull));
-            Q += __popcll(m);
-            DV out;
-            out.x = (DT)dx; out.y = (DT)dy; out.z = (DT)dz;
-            out.w = (DT)scalar_as_int(pk[p][t].w);
-            if (keep && q < NN) row[q] = out;
-        }
-        if (nn[p] > 64u * kChunk) { // rows longer than one trip: start over un-hoisted (rare)
-            Q = sweep<PT, DT, false>(row, pos, nl[p], nn[p], pi[p], box, rmaxsq, NN, lane, 0u);
-        }
-        DV zero;
-        zero.x = zero.y = zero.z = zero.w = (DT)0;
-        const unsigned filled = Q < NN ? Q : NN;
-        const unsigned zero_end = counts_io != nullptr ? counts_io[w] : NN;
-        for (unsigned sl = filled + lane; sl < zero_end; sl += 64) row[sl] = zero;
-        if (counts_io != nullptr && lane == 0) counts_io[w] = filled;
-        if (Q > NN) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            unsigned lo = Q - NN > NN ? Q - NN : NN;
-            sweep<PT, DT, true>(row, pos, nl[p], nn[p], pi[p], box, rmaxsq, NN, lane, lo);
-        }
-        qmax = Q > qmax ? Q : qmax;
-    }
-    if (max_count != nullptr && lane == 0 && qmax > *(volatile unsigned *)max_count) atomicMax(max_count, qmax);
-}
-
 template <typename PT, typename DT>
 static int launch_build(void *dest, const void *pos, unsigned N, unsigned NN, unsigned offset,
                         unsigned batch, const htf_box *hb, const unsigned *n_neigh,
@@ -224,16 +139,6 @@ static int launch_build(void *dest, const void *pos, unsigned N, unsigned NN, un
     BoxT<PT> b = make_boxt<PT>(hb);
     PT rc = (PT)rmax;
     PT rmaxsq = rc * rc;
-    static const int variant = getenv("HTF_BUILD_VARIANT") ? atoi(getenv("HTF_BUILD_VARIANT")) : 0;
-    if (variant == 2 || variant == 4) {
-        const unsigned ppw = variant;
-        const unsigned gridm = (batch + 4 * ppw - 1) / (4 * ppw);
-        if (variant == 2)
-            hipLaunchKernelGGL((build_pair_vectors_multi_kernel<PT, DT, 2>), dim3(gridm), dim3(256), 0, stream, (typename Vec4<DT>::type *)dest, (const typename Vec4<PT>::type *)pos, N, NN, offset, batch, b, n_neigh, nlist, head_list, rmaxsq, max_count, positions_out, counts_io);
-        else
-            hipLaunchKernelGGL((build_pair_vectors_multi_kernel<PT, DT, 4>), dim3(gridm), dim3(256), 0, stream, (typename Vec4<DT>::type *)dest, (const typename Vec4<PT>::type *)pos, N, NN, offset, batch, b, n_neigh, nlist, head_list, rmaxsq, max_count, positions_out, counts_io);
-        return check_launch("build_pair_vectors_multi_kernel");
-    }
     const unsigned waves_per_block = 4;
     unsigned grid = (batch + waves_per_block - 1) / waves_per_block;
     hipLaunchKernelGGL((build_pair_vectors_kernel<PT, DT>), dim3(grid), dim3(64 * waves_per_block), 0, stream,
