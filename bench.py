@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="lj", choices=["lj", "wca", "mlp", "mlp-bf16"])
+    ap.add_argument("--workload", default="lj", choices=["lj", "wca", "mlp", "mlp-bf16", "eds"])
     ap.add_argument("--cells", type=int, default=32, help="fcc cells per side (N = 4 cells^3 per rank)")
     ap.add_argument("--nn", type=int, default=128)
     ap.add_argument("--rcut", type=float, default=3.0)
@@ -97,6 +97,106 @@ def cpu_baseline(sysm, nl, args):
                       "over the same %d x %d workload; integrator not included" % (reps, sysm.N, args.nn)}, f
 
 
+def run_eds(args, htf, standin, dev):
+    """Config C4 (BASELINE configs[3]): 262 144 particles (sc 64^3), NN 128, LJModel
+    + EDS bias on the soft RDF collective variable, hard compute_rdf [0, 3.5] as an observable
+    every step.  One sweep over the pair vectors yields the LJ forces, the unit-bias forces
+    and the CV; the EDS state machine and the force assembly run on the device."""
+    import ctypes as C
+    cells = args.cells if args.cells != 32 else 64
+    pos, L, a = standin.sc_positions(cells, 0.8442)
+    rng = np.random.default_rng(4)
+    pos = pos + 0.05 * a * rng.standard_normal(pos.shape)
+    pos -= np.round(pos / L) * L
+    sysm = standin.System(pos, L, dtype=torch.float32, device=dev)
+    sysm.randomize_velocities(kT=1.0, seed=4)
+    nl = standin.CellNlist(sysm, r_cut=args.rcut, r_buff=args.rbuff, check_period=args.check_period)
+    nl.build()
+    N, NN = sysm.N, args.nn
+    pv = torch.zeros((N, NN, 4), dtype=torch.float32, device=dev)
+    bias = torch.empty((N, 4), dtype=torch.float32, device=dev)
+    npart = htf.ops.num_partials(N, NN)
+    partials = torch.empty(npart, dtype=torch.float32, device=dev)
+    cv = torch.zeros(1, dtype=torch.float32, device=dev)
+    lj, gauss = htf.Potential.lj(), htf.Potential.gauss(1.1, 0.05, 1.0)
+    eds = htf.EDSLayer(13.5, 25, 5.0, device=dev)
+    nve = standin.NVE(sysm, args.dt)
+    ev = {k: [] for k in ("build", "eval2", "rdf")}
+    state = {"ts": 0, "rdf": None, "time": False}
+
+    def mark():
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def step(relax=False):
+        ts = state["ts"]
+        nl.compute(ts)
+        t0 = mark() if state["time"] else None
+        htf.ops.build_pair_vectors(sysm.pos, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, args.rcut, NN, out=pv)
+        t1 = mark() if state["time"] else None
+        htf.ops.eval_forces2(lj, gauss, pv, out_a=sysm.force, out_b=bias, partials=partials)
+        t2 = mark() if state["time"] else None
+        htf.ops.reduce_partials(partials, npart, 1.0 / N, cv)
+        eds(cv)
+        htf.ops.bias_combine(sysm.force, bias, eds.state[2:3], cv)
+        t3 = mark() if state["time"] else None
+        state["rdf"] = htf.compute_rdf(pv, [0, 3.5])[0]
+        t4 = mark() if state["time"] else None
+        if relax:
+            f3 = sysm.force[:, :3]
+            f3.mul_(torch.clamp(200.0 / f3.norm(dim=1, keepdim=True).clamp_min(1e-12), max=1.0))
+        nve.step()
+        if relax:
+            v3 = sysm.vel[:, :3]
+            v3.mul_(torch.sqrt(1.0 / ((v3 * v3).sum() / (3.0 * N))))
+        if state["time"]:
+            ev["build"].append((t0, t1))
+            ev["eval2"].append((t1, t2))
+            ev["rdf"].append((t3, t4))
+        state["ts"] = ts + 1
+
+    for _ in range(args.equil):
+        step(relax=True)
+    for _ in range(args.warmup):
+        step()
+    state["time"] = True
+    b0 = nl.n_builds
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    us = {k: 1e3 * sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in ev.items()}
+    assert bool(torch.isfinite(sysm.force).all())
+    eval_b = N * NN * 16 + 2 * N * 16
+    build_b = N * 8 + int(nl.n_neigh.long().sum().item()) * 4 + N * 16 + N * NN * 16
+    rdf_b = N * NN * 16
+    dom = max(us, key=us.get)
+    dom_b = {"build": build_b, "eval2": eval_b, "rdf": rdf_b}[dom]
+    ach = dom_b / (us[dom] * 1e-6) / 1e9
+    out = {
+        "metric": "MD steps/sec (262144-particle EDS-on-RDF-CV domain steps, NN=128) + achieved HBM GB/s",
+        "value": args.steps / elapsed, "unit": "steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "C4-EDS: sc %d^3 = %d particles, rho 0.8442, r_cut %.1f, r_buff %.1f, NN %d, LJModel + "
+                               "EDSLayer(13.5, period 25, lr 5) on soft RDF bin r0 1.1 gap 0.05, compute_rdf [0,3.5] every step"
+                               % (cells, N, args.rcut, args.rbuff, NN),
+                   "nlist_rebuilds_in_timed_region": nl.n_builds - b0},
+        "cv": float(cv), "alpha": float(eds.state[2]), "energy_per_particle": float(sysm.force[:, 3].double().sum()) / N,
+        "rdf_peak": float(state["rdf"].max()),
+        "kernels": {"build_pair_vectors": {"avg_us": us["build"], "algorithmic_bytes": build_b, "GBps": build_b / us["build"] / 1e3},
+                    "eval_forces2(lj+gauss)": {"avg_us": us["eval2"], "algorithmic_bytes": eval_b, "GBps": eval_b / us["eval2"] / 1e3},
+                    "rdf_histogram": {"avg_us": us["rdf"], "algorithmic_bytes": rdf_b, "GBps": rdf_b / us["rdf"] / 1e3}},
+        "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": ach / HBM_PEAK_GBS, "traffic": None},
+        "cpu_baseline": None,
+    }
+    print(json.dumps(out))
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -120,6 +220,10 @@ def main():
 
     if args.workload != "lj":
         args.no_cpu_baseline = True  # the C port restates LJModel only
+    if args.workload == "eds":
+        if world > 1:
+            raise SystemExit("the C4 workload is a single-GPU configuration")
+        return run_eds(args, htf, standin, dev)
 
     # ---- synthetic system, resident in HBM -------------------------------------------------
     # Each rank owns one 131 072-particle block; the global periodic box is `world` blocks

@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(_HERE, "libhtf_amd.so")
 HTF_OK, HTF_ERR_INVALID, HTF_ERR_DEVICE, HTF_ERR_NLIST_OVERFLOW, HTF_ERR_SKEWED_BOX, HTF_ERR_NOMEM = range(6)
 HTF_F32, HTF_F64 = 0, 1
 HTF_TF2HOOMD, HTF_HOOMD2TF = 0, 1
-POT_NONE, POT_LJ, POT_WCA, POT_RINV_POLY, POT_SIMPLE, POT_PAIR_MLP = range(6)
+POT_NONE, POT_LJ, POT_WCA, POT_RINV_POLY, POT_SIMPLE, POT_PAIR_MLP, POT_GAUSS = range(7)
 ACT_LINEAR, ACT_TANH = 0, 1
 MLP_FP32, MLP_BF16 = 0, 1
 MAX_POLY_TERMS = 8
@@ -41,7 +41,8 @@ class Box(C.Structure):
 
 
 class PotentialDesc(C.Structure):
-    _fields_ = [("kind", C.c_int), ("sigma", C.c_double), ("n_terms", C.c_int),
+    _fields_ = [("kind", C.c_int), ("sigma", C.c_double),
+                ("gauss_r0", C.c_double), ("gauss_gap", C.c_double), ("gauss_coef", C.c_double), ("n_terms", C.c_int),
                 ("coef", C.c_double * MAX_POLY_TERMS), ("power", C.c_int * MAX_POLY_TERMS),
                 ("K", C.c_int), ("H1", C.c_int), ("H2", C.c_int), ("activation", C.c_int),
                 ("mlp_precision", C.c_int), ("rbf_low", C.c_double), ("rbf_high", C.c_double),
@@ -74,6 +75,10 @@ PROTOTYPES = {
     "htf_build_pair_vectors": (_i, [_vp, _i, _vp, _i, _u, _u, _u, _u, _u, C.POINTER(Box), _vp, _vp, _vp, _d, _vp, _vp]),
     "htf_eval_forces": (_i, [_vp, _vp, _i, _u, _u, _vp, _i, _vp, _vp]),
     "htf_fused_forces": (_i, [_vp, _vp, _i, _u, _u, _u, _u, C.POINTER(Box), _vp, _vp, _vp, _d, _vp, _i, _vp, _vp, _vp]),
+    "htf_eval_forces2": (_i, [_vp, _vp, _vp, _i, _u, _u, _vp, _vp, _i, _vp, _vp]),
+    "htf_eval2_num_partials": (_u, [_u, _u]),
+    "htf_reduce_partials": (_i, [_vp, _u, C.c_float, _vp, _vp]),
+    "htf_bias_combine": (_i, [_vp, _vp, _vp, _vp, _i, _u, _vp]),
     "htf_add_virial": (_i, [_vp, _vp, _i, _u, _sz, _vp]),
     "htf_add_scalar4": (_i, [_vp, _vp, _i, _u, _vp]),
     "htf_copy_positions": (_i, [_vp, _i, _vp, _i, _u, _u, _i, _vp]),

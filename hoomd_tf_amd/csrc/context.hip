@@ -105,6 +105,15 @@ extern "C" int htf_potential_create(const htf_potential_desc *d, htf_potential *
             p->pp.power[k] = d->power[k];
         }
         break;
+    case HTF_POT_GAUSS:
+        if (!(d->gauss_gap > 0)) {
+            set_error("htf_potential_create: GAUSS gap must be > 0 (got %g)", d->gauss_gap);
+            rc = HTF_ERR_INVALID;
+        }
+        p->pp.gauss_r0 = (float)d->gauss_r0;
+        p->pp.gauss_ginv = 1.0f / (float)d->gauss_gap;
+        p->pp.gauss_coef = (float)d->gauss_coef;
+        break;
     case HTF_POT_PAIR_MLP:
         rc = mlp_create(d, &p->mlp);
         break;
@@ -153,6 +162,23 @@ extern "C" int htf_fused_forces(const htf_potential *pot, const void *d_pos, int
     return fused_forces_impl(pot->pp, d_pos, pos_dtype, N, NN, offset, batch_size, box, d_n_neigh, d_nlist, d_head_list,
                              rmax, d_force, force_dtype, d_virial9, d_check_count, nullptr, (hipStream_t)stream);
 }
+
+extern "C" int htf_eval_forces2(const htf_potential *potA, const htf_potential *potB, const void *d_nlist,
+                                int nlist_dtype, unsigned B, unsigned NN, void *d_forceA, void *d_forceB,
+                                int force_dtype, float *d_partials, htf_stream stream) {
+    using namespace htf;
+    HTF_REQUIRE(potA && potB, "htf_eval_forces2: no potential");
+    HTF_REQUIRE(d_nlist && d_forceA && d_forceB, "htf_eval_forces2: null pointer");
+    HTF_REQUIRE(NN > 0, "htf_eval_forces2: NN must be > 0");
+    HTF_REQUIRE(nlist_dtype == HTF_F32 || nlist_dtype == HTF_F64, "htf_eval_forces2: bad nlist dtype %d", nlist_dtype);
+    HTF_REQUIRE(force_dtype == HTF_F32 || force_dtype == HTF_F64, "htf_eval_forces2: bad force dtype %d", force_dtype);
+    HTF_REQUIRE(potB->pp.kind == HTF_POT_GAUSS, "htf_eval_forces2: potB must be HTF_POT_GAUSS");
+    if (B == 0) return HTF_OK;
+    return eval_pair2_dispatch(potA->pp, potB->pp, d_nlist, nlist_dtype, B, NN, d_forceA, d_forceB, force_dtype,
+                               d_partials, (hipStream_t)stream);
+}
+
+extern "C" unsigned htf_eval2_num_partials(unsigned B, unsigned NN) { return htf::eval_pair2_num_partials(B, NN); }
 
 // ------------------------------------------------------------------------------ context
 static void ctx_free(htf_ctx *c) {

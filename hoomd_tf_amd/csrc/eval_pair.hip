@@ -170,10 +170,133 @@ int eval_pair_dispatch(const PotParams &p, const void *nlist, int in_dtype, unsi
     case HTF_POT_WCA: return launch_eval<HTF_POT_WCA>(nlist, in_dtype, B, NN, force, virial9, out_f64, p, counts, stream);
     case HTF_POT_RINV_POLY: return launch_eval<HTF_POT_RINV_POLY>(nlist, in_dtype, B, NN, force, virial9, out_f64, p, counts, stream);
     case HTF_POT_SIMPLE: return launch_eval<HTF_POT_SIMPLE>(nlist, in_dtype, B, NN, force, virial9, out_f64, p, counts, stream);
+    case HTF_POT_GAUSS: return launch_eval<HTF_POT_GAUSS>(nlist, in_dtype, B, NN, force, virial9, out_f64, p, counts, stream);
     default:
         set_error("eval_pair_dispatch: potential kind %d is not a closed-form pair potential", p.kind);
         return HTF_ERR_INVALID;
     }
+}
+
+// ---- two potentials in one pass (EDS-biased models: base potential + Gaussian CV channel) ----
+template <int KA, int G, typename IT>
+__global__ __launch_bounds__(256) void eval_pair2_kernel(const typename Vec4<IT>::type *__restrict__ nlist, unsigned B,
+                                                         unsigned NN, void *__restrict__ forceA,
+                                                         void *__restrict__ forceB, int out_f64, PotParams pa,
+                                                         PotParams pb, float *__restrict__ partials) {
+    constexpr int RPW = 64 / G;
+    __shared__ float s_part[4];
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned g = lane % G, sub = lane / G;
+    const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const unsigned row = wave * RPW + sub;
+    const bool active = row < B;
+    const typename Vec4<IT>::type *rp = nlist + (size_t)(active ? row : B - 1) * NN;
+    float ax = 0.f, ay = 0.f, az = 0.f, ae = 0.f, bx = 0.f, by = 0.f, bz = 0.f, be = 0.f;
+    for (unsigned j0 = 0; j0 < NN; j0 += kUnroll * G) {
+        float4 v[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            unsigned j = j0 + u * G + g;
+            v[u] = (j < NN) ? load_slot<IT>(rp + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            float e, fx, fy, fz;
+            pair_eval<KA>(v[u].x, v[u].y, v[u].z, pa, e, fx, fy, fz);
+            ax += fx; ay += fy; az += fz; ae += e;
+            pair_eval<HTF_POT_GAUSS>(v[u].x, v[u].y, v[u].z, pb, e, fx, fy, fz);
+            bx += fx; by += fy; bz += fz; be += e;
+        }
+    }
+    ax = group_sum<G>(ax); ay = group_sum<G>(ay); az = group_sum<G>(az); ae = group_sum<G>(ae);
+    bx = group_sum<G>(bx); by = group_sum<G>(by); bz = group_sum<G>(bz); be = group_sum<G>(be);
+    if (g == 0 && active) {
+        if (out_f64) {
+            ((double4 *)forceA)[row] = make_double4(ax, ay, az, ae);
+            ((double4 *)forceB)[row] = make_double4(bx, by, bz, be);
+        } else {
+            ((float4 *)forceA)[row] = make_float4(ax, ay, az, ae);
+            ((float4 *)forceB)[row] = make_float4(bx, by, bz, be);
+        }
+    }
+    if (partials != nullptr) { // block sum of the B energy column, fixed order -> deterministic
+        float c = (g == 0 && active) ? be : 0.f;
+        c = group_sum<64>(c);
+        if (lane == 0) s_part[threadIdx.x >> 6] = c;
+        __syncthreads();
+        if (threadIdx.x == 0) partials[blockIdx.x] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+    }
+}
+
+template <int KA, int G, typename IT>
+static int launch_eval2_g(const void *nlist, unsigned B, unsigned NN, void *fa, void *fb, int out_f64,
+                          const PotParams &pa, const PotParams &pb, float *partials, hipStream_t stream) {
+    constexpr unsigned rows_per_block = 4 * (64 / G);
+    unsigned grid = (B + rows_per_block - 1) / rows_per_block;
+    hipLaunchKernelGGL((eval_pair2_kernel<KA, G, IT>), dim3(grid), dim3(256), 0, stream,
+                       (const typename Vec4<IT>::type *)nlist, B, NN, fa, fb, out_f64, pa, pb, partials);
+    return check_launch("eval_pair2_kernel");
+}
+
+template <int KA, typename IT>
+static int launch_eval2_k(const void *nlist, unsigned B, unsigned NN, void *fa, void *fb, int out_f64,
+                          const PotParams &pa, const PotParams &pb, float *partials, hipStream_t stream) {
+    switch (pick_group(NN)) {
+    case 16: return launch_eval2_g<KA, 16, IT>(nlist, B, NN, fa, fb, out_f64, pa, pb, partials, stream);
+    case 8: return launch_eval2_g<KA, 8, IT>(nlist, B, NN, fa, fb, out_f64, pa, pb, partials, stream);
+    default: return launch_eval2_g<KA, 4, IT>(nlist, B, NN, fa, fb, out_f64, pa, pb, partials, stream);
+    }
+}
+
+unsigned eval_pair2_num_partials(unsigned B, unsigned NN) {
+    const unsigned rows_per_block = 4 * (64 / pick_group(NN));
+    return (B + rows_per_block - 1) / rows_per_block;
+}
+
+int eval_pair2_dispatch(const PotParams &pa, const PotParams &pb, const void *nlist, int in_dtype, unsigned B,
+                        unsigned NN, void *forceA, void *forceB, int force_dtype, float *partials, hipStream_t stream) {
+    const int out_f64 = force_dtype == HTF_F64;
+#define HTF_E2(K) (in_dtype == HTF_F32 ? launch_eval2_k<K, float>(nlist, B, NN, forceA, forceB, out_f64, pa, pb, partials, stream) \
+                                       : launch_eval2_k<K, double>(nlist, B, NN, forceA, forceB, out_f64, pa, pb, partials, stream))
+    switch (pa.kind) {
+    case HTF_POT_LJ: return HTF_E2(HTF_POT_LJ);
+    case HTF_POT_WCA: return HTF_E2(HTF_POT_WCA);
+    case HTF_POT_RINV_POLY: return HTF_E2(HTF_POT_RINV_POLY);
+    default:
+        set_error("htf_eval_forces2: base potential kind %d is not a closed-form rinv potential", pa.kind);
+        return HTF_ERR_INVALID;
+    }
+#undef HTF_E2
+}
+
+__global__ __launch_bounds__(1024) void reduce_partials_kernel(const float *__restrict__ partials, unsigned n, float scale,
+                                                               float *__restrict__ out) {
+    __shared__ double s[16];
+    double acc = 0.0;
+    for (unsigned i = threadIdx.x; i < n; i += 1024) acc += (double)partials[i];
+    for (int m = 1; m < 64; m <<= 1) acc += __shfl_xor(acc, m);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < 16; ++i) t += s[i];
+        *out = (float)(t * (double)scale);
+    }
+}
+
+template <typename V>
+__global__ __launch_bounds__(256) void bias_combine_kernel(V *__restrict__ force, const V *__restrict__ bias,
+                                                           const float *__restrict__ alpha_p,
+                                                           const float *__restrict__ cv_p, unsigned N) {
+    unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const float alpha = *alpha_p, cv = *cv_p;
+    V f = force[i], b = bias[i];
+    f.x += alpha * b.x;
+    f.y += alpha * b.y;
+    f.z += alpha * b.z;
+    f.w += alpha * cv; // rank-0 energy term tiled into every particle (simmodel.py:567-572)
+    force[i] = f;
 }
 
 // ---- small elementwise companions -------------------------------------------------
@@ -243,4 +366,28 @@ extern "C" int htf_check_nlist(const void *d_nlist, int nlist_dtype, unsigned B,
     else
         hipLaunchKernelGGL((check_nlist_kernel<double, G>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const double4 *)d_nlist, B, NN, d_out);
     return check_launch("check_nlist_kernel");
+}
+
+extern "C" int htf_reduce_partials(const float *d_partials, unsigned n, float scale, float *d_out, htf_stream stream) {
+    using namespace htf;
+    HTF_REQUIRE(d_partials && d_out, "htf_reduce_partials: null pointer");
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, d_partials, n, scale, d_out);
+    return check_launch("reduce_partials_kernel");
+}
+
+extern "C" int htf_bias_combine(void *d_force, const void *d_bias, const float *d_alpha, const float *d_cv, int dtype,
+                                unsigned N, htf_stream stream) {
+    using namespace htf;
+    HTF_REQUIRE(d_force && d_bias && d_alpha && d_cv, "htf_bias_combine: null pointer");
+    if (N == 0) return HTF_OK;
+    unsigned grid = (N + 255) / 256;
+    if (dtype == HTF_F32)
+        hipLaunchKernelGGL((bias_combine_kernel<float4>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (float4 *)d_force, (const float4 *)d_bias, d_alpha, d_cv, N);
+    else if (dtype == HTF_F64)
+        hipLaunchKernelGGL((bias_combine_kernel<double4>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (double4 *)d_force, (const double4 *)d_bias, d_alpha, d_cv, N);
+    else {
+        set_error("htf_bias_combine: bad dtype %d", dtype);
+        return HTF_ERR_INVALID;
+    }
+    return check_launch("bias_combine_kernel");
 }

@@ -172,6 +172,7 @@ int fused_forces_impl(const PotParams &p, const void *pos, int pos_dtype, unsign
     case HTF_POT_LJ: return HTF_FK(HTF_POT_LJ);
     case HTF_POT_WCA: return HTF_FK(HTF_POT_WCA);
     case HTF_POT_RINV_POLY: return HTF_FK(HTF_POT_RINV_POLY);
+    case HTF_POT_GAUSS: return HTF_FK(HTF_POT_GAUSS);
     case HTF_POT_SIMPLE:
         HTF_REQUIRE(virial9 == nullptr, "htf_fused_forces: SimplePotential has no virial");
         return HTF_FK(HTF_POT_SIMPLE);

@@ -8,6 +8,7 @@ struct PotParams {
     int kind;
     float sigma;   // WCA sigma (fp32, as the Keras weight is)
     float wca_cut; // fp32(sigma) * fp32(2^(1/3))   layers.py:97
+    float gauss_r0, gauss_ginv, gauss_coef; // HTF_POT_GAUSS: centre, 1/gap, coefficient
     int n_terms;
     float coef[HTF_MAX_POLY_TERMS];
     int power[HTF_MAX_POLY_TERMS];
@@ -27,6 +28,10 @@ int fused_forces_impl(const PotParams &p, const void *pos, int pos_dtype, unsign
                       unsigned batch, const htf_box *box, const unsigned *n_neigh, const unsigned *nlist,
                       const unsigned *head_list, double rmax, void *force, int force_dtype, void *virial9,
                       unsigned *check_count, float4 *positions_out, hipStream_t s);
+
+int eval_pair2_dispatch(const PotParams &pa, const PotParams &pb, const void *nlist, int in_dtype, unsigned B,
+                        unsigned NN, void *forceA, void *forceB, int force_dtype, float *partials, hipStream_t stream);
+unsigned eval_pair2_num_partials(unsigned B, unsigned NN);
 
 struct MlpDevice;
 int mlp_create(const htf_potential_desc *d, MlpDevice **out);

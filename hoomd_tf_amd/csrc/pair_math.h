@@ -43,6 +43,21 @@ __device__ __forceinline__ void pair_eval(float x, float y, float z, const PotPa
         fz = isfinite(az) ? az : 0.0f;
         e = 0.0f;
         return;
+    } else if constexpr (KIND == HTF_POT_GAUSS) {
+        // one RBFExpansion channel as a pair energy: r = safe_norm(x) (simmodel.py:581-594),
+        // phi = exp(-(r - r0)^2 / gap) (layers.py:46-49), masked with the nlist_rinv criterion.
+        // nlist_forces = 2 * c * dphi/dr * t / r,  dphi/dr = -2 (r - r0) / gap * phi
+        const float tx = x + kNormDelta, ty = y + kNormDelta, tz = z + kNormDelta;
+        const float r = sqrtf(tx * tx + ty * ty + tz * tz);
+        const bool m = r > kRinvDelta;
+        const float d = r - p.gauss_r0;
+        const float phi = m ? __expf(-(d * d) * p.gauss_ginv) : 0.0f;
+        e = p.gauss_coef * phi;
+        const float c = m ? 2.0f * p.gauss_coef * (-2.0f * d * p.gauss_ginv) * phi * fast_rcp(r) : 0.0f;
+        fx = c * tx;
+        fy = c * ty;
+        fz = c * tz;
+        return;
     } else {
         RinvFwd f = rinv_fwd(x, y, z);
         const float s = f.s, s2 = s * s;

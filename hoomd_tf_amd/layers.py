@@ -49,6 +49,21 @@ class WCARepulsion:
         return simmodel.WCAPair(simmodel._as_nlist(nlist), self.sigma)
 
 
+class SoftRDFCV:
+    """Differentiable stand-in for one RDF bin: cv = (1/N) sum_i sum_j
+    exp(-(r_ij - r0)^2 / gap), r = safe_norm, padded slots masked -- a single RBFExpansion
+    channel summed over the neighbor list.  Call it on the nlist; feed the result to EDSLayer."""
+
+    def __init__(self, r0, gap):
+        self.r0, self.gap = float(r0), float(gap)
+
+    def get_config(self):
+        return {'r0': self.r0, 'gap': self.gap}
+
+    def __call__(self, nlist):
+        return simmodel.PairCV(simmodel._as_nlist(nlist), self.r0, self.gap)
+
+
 class PairMLP:
     """safe_norm -> RBFExpansion(low, high, K) -> Dense(H1) -> Dense(H2) -> Dense(1), masked
     with the nlist_rinv criterion and halved per pair (SURVEY 8(a) closed forms).  Keras
@@ -116,6 +131,8 @@ class EDSLayer:
         return int(self.state[5].item())
 
     def __call__(self, cv):
+        if isinstance(cv, simmodel.PairCV):
+            return simmodel.DeferredAlpha(self, cv)  # advances when the biased energy is lowered
         if not isinstance(cv, torch.Tensor):
             cv = torch.tensor(float(cv), dtype=torch.float32, device=self.state.device)
         cv = cv.detach().to(torch.float32).reshape(1).contiguous()

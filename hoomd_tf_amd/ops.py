@@ -45,10 +45,11 @@ class Potential:
     """Owns an ``htf_potential`` handle (device copies of any weights)."""
 
     def __init__(self, kind, sigma=0.0, coefs=(), powers=(), mlp=None, rbf=(0.0, 0.0),
-                 activation="linear", mlp_precision="fp32"):
+                 activation="linear", mlp_precision="fp32", gauss=(0.0, 1.0, 0.0)):
         d = _lib.PotentialDesc()
         d.kind = kind
         d.sigma = float(sigma)
+        d.gauss_r0, d.gauss_gap, d.gauss_coef = (float(x) for x in gauss)
         d.n_terms = len(coefs)
         if len(coefs) != len(powers):
             raise ValueError("coefs and powers differ in length")
@@ -99,6 +100,11 @@ class Potential:
     @classmethod
     def rinv_poly(cls, coefs, powers):
         return cls(_lib.POT_RINV_POLY, coefs=coefs, powers=powers)
+
+    @classmethod
+    def gauss(cls, r0, gap, coef=1.0):
+        """c * exp(-(r - r0)^2 / gap): one RBFExpansion channel as a pair energy (C4's soft RDF bin)."""
+        return cls(_lib.POT_GAUSS, gauss=(r0, gap, coef))
 
     @classmethod
     def pair_mlp(cls, params, low, high, activation="tanh", precision="fp32"):
@@ -164,6 +170,42 @@ def fused_forces(potential, pos, n_neigh, head_list, nlist, box, r_cut, NN, offs
                                v.data_ptr() if v is not None else None,
                                check_count.data_ptr() if check_count is not None else None, _stream(pos)))
     return (out, v) if virial else out
+
+
+def eval_forces2(pot_a, pot_b, nlist, out_a=None, out_b=None, partials=None, out_dtype=None):
+    """Two potentials in one pass: -> (forces_a [B,4], forces_b [B,4]); ``partials`` receives
+    the per-block sums of forces_b[:, 3] (see reduce_partials)."""
+    _dev(nlist, "nlist")
+    B, NN = int(nlist.shape[0]), int(nlist.shape[1])
+    od = out_dtype or (out_a.dtype if out_a is not None else nlist.dtype)
+    if out_a is None:
+        out_a = torch.empty((B, 4), dtype=od, device=nlist.device)
+    if out_b is None:
+        out_b = torch.empty((B, 4), dtype=od, device=nlist.device)
+    _dev(out_a, "out_a")
+    _dev(out_b, "out_b", out_a.dtype)
+    check(lib.htf_eval_forces2(pot_a.handle, pot_b.handle, nlist.data_ptr(), _dt(nlist), B, NN, out_a.data_ptr(),
+                               out_b.data_ptr(), _dt(out_a), partials.data_ptr() if partials is not None else None,
+                               _stream(nlist)))
+    return out_a, out_b
+
+
+def num_partials(B, NN):
+    return int(lib.htf_eval2_num_partials(int(B), int(NN)))
+
+
+def reduce_partials(partials, n, scale, out):
+    check(lib.htf_reduce_partials(partials.data_ptr(), int(n), float(scale), out.data_ptr(), _stream(partials)))
+    return out
+
+
+def bias_combine(force, bias, alpha, cv):
+    """force += alpha * (bias.xyz, cv) with alpha, cv device scalars (fp32)."""
+    _dev(force, "force")
+    _dev(bias, "bias", force.dtype)
+    check(lib.htf_bias_combine(force.data_ptr(), bias.data_ptr(), alpha.data_ptr(), cv.data_ptr(), _dt(force),
+                               int(force.shape[0]), _stream(force)))
+    return force
 
 
 def add_virial(dest, src9, N, pitch):

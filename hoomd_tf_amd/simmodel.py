@@ -103,7 +103,11 @@ class RinvPoly(PairEnergy):
         raise TypeError("cannot combine a rinv polynomial with %r (constants carry no force)" % (other,))
 
     def __add__(self, o):
+        if isinstance(o, BiasTerm):
+            return BiasedEnergy(self, o)
         return self._bin(o, 1.0)
+
+    __radd__ = __add__
 
     def __sub__(self, o):
         return self._bin(o, -1.0)
@@ -187,6 +191,86 @@ class MLPEnergy(PairEnergy):
         return ops.Potential.pair_mlp(L.params, L.low, L.high, activation=L.activation, precision=L.precision)
 
 
+class PairCV:
+    """Scalar collective variable (1/N) sum_i sum_j phi(r_ij) with phi one masked
+    RBFExpansion channel (layers.SoftRDFCV): the soft RDF bin of config C4.  Stays symbolic
+    so that an EDS-biased energy lowers to one pass over the pair vectors."""
+
+    def __init__(self, nlist, r0, gap):
+        self.nlist, self.r0, self.gap = nlist, float(r0), float(gap)
+        self.value = None  # device scalar once evaluated
+
+    def potential(self):
+        return ops.Potential.gauss(self.r0, self.gap, 1.0)
+
+    def tensor(self):
+        if self.value is None:
+            _trace_log().append({"op": "eager_value"})
+            f = ops.eval_forces(self.potential(), self.nlist.tensor)
+            self.value = (f[:, 3].sum() / f.shape[0]).reshape(1)
+        return self.value.reshape(())
+
+    def __rmul__(self, o):
+        if isinstance(o, DeferredAlpha):
+            return BiasTerm(o, self)
+        return NotImplemented
+
+    def __mul__(self, o):
+        if isinstance(o, DeferredAlpha):
+            return BiasTerm(o, self)
+        return NotImplemented
+
+
+class DeferredAlpha:
+    """alpha = EDSLayer(cv) for a symbolic cv: the state machine advances when the biased
+    energy is lowered (exactly once per model call), on the device."""
+
+    def __init__(self, eds, cv):
+        self.eds, self.cv = eds, cv
+        self.done = False
+
+    def tensor(self):
+        if not self.done:  # alpha requested as an output without a biased force: advance here
+            self.eds(self.cv.tensor())
+            self.done = True
+        return self.eds.state[2].clone()
+
+    def __mul__(self, o):
+        if isinstance(o, PairCV):
+            return BiasTerm(self, o)
+        return NotImplemented
+
+    __rmul__ = __mul__
+
+
+class BiasTerm:
+    """alpha * cv"""
+
+    def __init__(self, alpha, cv):
+        self.alpha, self.cv = alpha, cv
+
+    def __radd__(self, base):
+        return BiasedEnergy(base, self)
+
+    def __add__(self, base):
+        return BiasedEnergy(base, self)
+
+
+class BiasedEnergy(PairEnergy):
+    """E_base,i + alpha * cv  (a scalar bias added to every particle's energy)."""
+    reduced = True
+
+    def __init__(self, base, term):
+        if not isinstance(base, RinvPoly) and not isinstance(base, WCAPair):
+            raise TypeError("the EDS bias adds to a closed-form pair energy")
+        if base.nlist is not term.cv.nlist:
+            raise ValueError("expressions come from different neighbor lists")
+        self.nlist, self.base, self.term = base.nlist, base, term
+
+    def key(self):
+        return ("biased",) + self.base.key()
+
+
 class SafeNorm:
     """safe_norm(nlist[:, :, :3], axis=2) kept symbolic so RBF/MLP layers can fuse."""
 
@@ -236,6 +320,10 @@ def compute_nlist_forces(nlist, energy, virial=False):
     if energy.nlist is not nl and energy.nlist.tensor is not nl.tensor:
         raise ValueError('Could not find dependence between energy and nlist.'
                          ' Did you put them in wrong order?')
+    if isinstance(energy, BiasedEnergy):
+        if virial:
+            raise ValueError("virial of an EDS-biased energy is not implemented")
+        return _biased_forces(nl, energy)
     cache = getattr(compute_nlist_forces, "_cache", None)
     if cache is None:
         cache = compute_nlist_forces._cache = {}
@@ -249,6 +337,34 @@ def compute_nlist_forces(nlist, energy, virial=False):
     f = out[0] if virial else out
     _trace_log().append({"potential": pot, "nlist": nl, "virial": virial, "forces": f})
     return out
+
+
+def _biased_forces(nl, energy):
+    """E_base + alpha * cv in one sweep: base forces and unit-bias forces from
+    htf_eval_forces2, cv from a deterministic block reduction, alpha from the device-side EDS
+    state machine, then force = base + alpha * bias -- nothing returns to the host."""
+    cache = getattr(compute_nlist_forces, "_cache", None)
+    if cache is None:
+        cache = compute_nlist_forces._cache = {}
+    base, cv, alpha = energy.base, energy.term.cv, energy.term.alpha
+    kb, kg = base.key(), ("gauss", cv.r0, cv.gap)
+    if kb not in cache:
+        cache[kb] = base.potential()
+    if kg not in cache:
+        cache[kg] = cv.potential()
+    t = nl.tensor
+    B, NN = int(t.shape[0]), int(t.shape[1])
+    n = ops.num_partials(B, NN)
+    partials = torch.empty(n, dtype=torch.float32, device=t.device)
+    fa, fb = ops.eval_forces2(cache[kb], cache[kg], t, partials=partials)
+    cv.value = torch.empty(1, dtype=torch.float32, device=t.device)
+    ops.reduce_partials(partials, n, 1.0 / B, cv.value)
+    if not alpha.done:
+        alpha.eds(cv.value)  # htf_eds_update on the device scalar
+        alpha.done = True
+    ops.bias_combine(fa, fb, alpha.eds.state[2:3], cv.value)
+    _trace_log().append({"stateful": "eds-bias"})
+    return fa
 
 
 def pairwise_unit_forces(nlist):

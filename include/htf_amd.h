@@ -69,7 +69,9 @@ enum htf_potential_kind {
     HTF_POT_WCA = 2,       /* layers.py:52-98 WCARepulsion + build_examples.py:221-228 */
     HTF_POT_RINV_POLY = 3, /* E_i = sum_j sum_k coef_k * rinv^power_k (BenchmarkPotential :25-30, example 01) */
     HTF_POT_SIMPLE = 4,    /* build_examples.py:9-22 SimplePotential (forward only) */
-    HTF_POT_PAIR_MLP = 5   /* safe_norm -> RBFExpansion -> Dense-Dense-Dense */
+    HTF_POT_PAIR_MLP = 5,  /* safe_norm -> RBFExpansion -> Dense-Dense-Dense */
+    HTF_POT_GAUSS = 6      /* e = c * exp(-(r - r0)^2 / gap) * [r > 3e-6], r = safe_norm(x): one RBFExpansion
+                            * channel (layers.py:46-49) as a pair energy -- the soft RDF bin of config C4 */
 };
 
 enum htf_activation { HTF_ACT_LINEAR = 0, HTF_ACT_TANH = 1 };
@@ -81,6 +83,8 @@ typedef struct htf_potential_desc {
     int kind;   /* htf_potential_kind */
     /* WCA */
     double sigma;
+    /* GAUSS */
+    double gauss_r0, gauss_gap, gauss_coef;
     /* RINV_POLY */
     int n_terms;
     double coef[HTF_MAX_POLY_TERMS];
@@ -138,6 +142,27 @@ HTF_API int htf_fused_forces(const htf_potential *pot, const void *d_pos, int po
                      const unsigned *d_n_neigh, const unsigned *d_nlist, const unsigned *d_head_list,
                      double rmax, void *d_force, int force_dtype, void *d_virial9,
                      unsigned *d_check_count, htf_stream stream);
+
+/* Two potentials in ONE pass over the pair vectors: forceA <- potA, forceB <- potB (both [B]
+ * Scalar4).  potB must be HTF_POT_GAUSS, potA a closed-form potential.  d_partials (nullable,
+ * >= htf_eval2_num_partials(B, NN) floats): per-block sums of forceB[i].w, to be reduced with
+ * htf_reduce_partials -- the collective-variable sum of an EDS-biased model (config C4)
+ * without a second sweep over the 268 MB tensor and without float atomics. */
+HTF_API int htf_eval_forces2(const htf_potential *potA, const htf_potential *potB,
+                     const void *d_nlist, int nlist_dtype, unsigned B, unsigned NN,
+                     void *d_forceA, void *d_forceB, int force_dtype,
+                     float *d_partials, htf_stream stream);
+HTF_API unsigned htf_eval2_num_partials(unsigned B, unsigned NN);
+
+/* *d_out = scale * sum(d_partials[0..n)) in a fixed order (one block; deterministic). */
+HTF_API int htf_reduce_partials(const float *d_partials, unsigned n, float scale, float *d_out, htf_stream stream);
+
+/* EDS-biased force assembly: force[i] = (base.xyz + alpha * bias.xyz, base.w + alpha * cv) with
+ * alpha = *d_alpha, cv = *d_cv read on the device: compute_nlist_forces(nlist, E_base + alpha*cv)
+ * for a scalar collective variable cv whose unit-alpha forces are `bias` (simmodel.py:526-578:
+ * a rank-0 energy term is tiled into every particle's energy column). */
+HTF_API int htf_bias_combine(void *d_force, const void *d_bias, const float *d_alpha, const float *d_cv,
+                     int dtype, unsigned N, htf_stream stream);
 
 /* Replaces htf_gpu_add_virial (TensorflowCompute.cu:41-71; CPU .cc:284-301):
  * dest[c*pitch + i] += src[i*9 + {0,1,2,4,5,8}]. */

@@ -115,3 +115,18 @@ def pair_mlp_model(nlist, params, low=0.0, high=3.0, act="tanh"):
     mask = (r > RINV_DELTA).to(dt).detach()
     energy = 0.5 * (u * mask).sum(dim=1)
     return compute_nlist_forces(nlist, energy)
+
+
+def eds_rdf_model(nlist, alpha, r0, gap):
+    # config C4: see htf_oracle.eds_rdf_model
+    nlist = nlist.clone().requires_grad_(True)
+    dt = nlist.dtype
+    rinv = nlist_rinv(nlist)
+    inv_r6 = rinv ** 6
+    lj = (4.0 / 2.0 * (inv_r6 * inv_r6 - inv_r6)).sum(dim=1)
+    r = safe_norm(nlist[:, :, :3], dim=2)
+    mask = (r > RINV_DELTA).to(dt).detach()
+    phi = torch.exp(-(r - r0) ** 2 / gap) * mask
+    cv = phi.sum() / nlist.shape[0]
+    energy = lj + alpha * cv
+    return compute_nlist_forces(nlist, energy), cv.detach()

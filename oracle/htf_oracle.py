@@ -444,6 +444,52 @@ def pair_mlp_model(nlist, params, low=0.0, high=3.0, act="tanh", return_grad=Fal
     return nlist_forces_from_grad(nlist, g, E)
 
 
+def gauss_pair_terms(nlist, r0, gap):
+    """One RBFExpansion channel (layers.py:46-49) on r = safe_norm(x) (simmodel.py:581-594),
+    masked with the nlist_rinv criterion (r > 3e-6).  Returns (phi [N,NN], g [N,NN,4]) with
+    g = d(sum phi)/d nlist."""
+    dt = nlist.dtype
+    t = nlist[:, :, :3] + dt.type(1e-7)
+    r = np.sqrt(np.sum(t * t, axis=2))
+    mask = (r > dt.type(RINV_DELTA)).astype(dt)
+    d = r - dt.type(r0)
+    phi = np.exp(-(d * d) / dt.type(gap)) * mask
+    dphidr = dt.type(-2.0) * d / dt.type(gap) * phi
+    g = np.zeros(nlist.shape, dtype=dt)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        g[..., :3] = np.where(mask[..., None] > 0, dphidr[..., None] * t / r[..., None], dt.type(0))
+    return phi, g
+
+
+def gauss_model(nlist, r0, gap, coef=1.0):
+    """E_i = coef * sum_j phi(r_ij); forces = compute_nlist_forces(nlist, E).  PARITY UNPINNED
+    (composite of a10 + a16 + a12 defined for config C4)."""
+    dt = nlist.dtype
+    phi, g = gauss_pair_terms(nlist, r0, gap)
+    return nlist_forces_from_grad(nlist, dt.type(coef) * g, dt.type(coef) * phi.sum(axis=1))
+
+
+def eds_rdf_model(nlist, alpha, r0, gap):
+    """Config C4: LJModel + EDS bias on the soft RDF collective variable
+        cv = (1/N) sum_i sum_j phi(r_ij),  energy_i = E_lj,i + alpha * cv,
+        forces = compute_nlist_forces(nlist, energy).
+    alpha is the EDS coupling (a variable read: no gradient flows through it).  The scalar
+    alpha*cv is added to every particle's energy, so d(sum_i energy_i) = dE_lj + N alpha dcv.
+    Returns (forces [N,4], cv)."""
+    dt = nlist.dtype
+    N = nlist.shape[0]
+    s, t, rp, cond = _rinv_and_grad_factor(nlist)
+    inv_r6 = s ** 6
+    e_lj = (dt.type(2.0) * (inv_r6 * inv_r6 - inv_r6)).sum(axis=1)
+    dEds = dt.type(2.0) * (dt.type(2.0) * inv_r6 - dt.type(1.0)) * (dt.type(6.0) * s ** 5)
+    g_lj = _grad_from_dEds(dEds, s, t, rp, cond)
+    phi, g_phi = gauss_pair_terms(nlist, r0, gap)
+    cv = phi.sum() / dt.type(N)
+    a = dt.type(alpha)
+    g = g_lj + a * g_phi  # N * alpha * d cv = alpha * d(sum phi)
+    return nlist_forces_from_grad(nlist, g, e_lj + a * cv), cv
+
+
 # --------------------------------------------------------------------------- #
 # a8: compute_inputs checks;  a23: compute_outputs;  a6: receiveVirial
 # --------------------------------------------------------------------------- #

@@ -134,3 +134,22 @@ class EDSModel(htf.SimModel):
         energy = (cv - 5) ** 2 + cv * alpha.detach()
         forces = htf.compute_positions_forces(positions, energy)
         return forces, alpha
+
+
+class EDSRDFModel(htf.SimModel):
+    # config C4: LJModel + EDS bias on a soft RDF collective variable, with the
+    # hard compute_rdf as an observable
+    def setup(self, set_point, r0=1.1, gap=0.05, period=25, learning_rate=5.0):
+        self.soft_bin = htf.SoftRDFCV(r0, gap)
+        self.eds_bias = htf.EDSLayer(set_point, period, learning_rate)
+
+    def compute(self, nlist, positions, box):
+        rinv = htf.nlist_rinv(nlist)
+        inv_r6 = rinv**6
+        lj_energy = htf.reduce_sum(4.0 / 2.0 * (inv_r6 * inv_r6 - inv_r6), axis=1)
+        cv = self.soft_bin(nlist)
+        alpha = self.eds_bias(cv)
+        energy = lj_energy + alpha * cv
+        forces = htf.compute_nlist_forces(nlist, energy)
+        rdf, rs = htf.compute_rdf(nlist, [0, 3.5])
+        return forces, cv, alpha, rdf

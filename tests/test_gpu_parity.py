@@ -308,6 +308,35 @@ def test_pair_mlp_full_size_rows(htf, cuda):
                         atol=2e-5, rtol=5e-5, ctol=5e-6)
 
 
+# --------------------------------------------------------------------------- config C4 pieces
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_gauss_potential_and_eval2(htf, cuda, dtype):
+    """HTF_POT_GAUSS alone, and base + Gaussian in one pass with the deterministic CV sum."""
+    nl = _nlist_case(13, N=333, NN=128, dtype=dtype, rmin=0.8)
+    nl64 = nl.astype(np.float32).astype(np.float64)
+    x = torch.from_numpy(nl).to(cuda)
+    pg = htf.Potential.gauss(1.1, 0.05, 1.0)
+    ref_g = O.gauss_model(nl64, 1.1, 0.05, 1.0)
+    _, g = O.gauss_pair_terms(nl64, 1.1, 0.05)
+    cond_g = np.abs(2 * g).sum(axis=(1, 2))
+    assert_forces_close("gauss_" + dtype.__name__, htf.ops.eval_forces(pg, x).cpu().numpy(), ref_g, cond_g, ctol=4e-6)
+    n = htf.ops.num_partials(nl.shape[0], 128)
+    partials = torch.zeros(n, device=cuda)
+    fa, fb = htf.ops.eval_forces2(htf.Potential.lj(), pg, x, partials=partials)
+    assert_forces_close("eval2_lj_" + dtype.__name__, fa.cpu().numpy(), O.lj_model(nl64), _cond_scale(nl64, _pair_forces_lj(nl64)))
+    assert_forces_close("eval2_gauss_" + dtype.__name__, fb.cpu().numpy(), ref_g, cond_g, ctol=4e-6)
+    cv = torch.zeros(1, device=cuda)
+    htf.ops.reduce_partials(partials, n, 1.0 / nl.shape[0], cv)
+    np.testing.assert_allclose(float(cv), ref_g[:, 3].sum() / nl.shape[0], rtol=2e-6)
+    # EDS-biased assembly == the oracle composite at the same alpha
+    alpha = torch.tensor([0.7], device=cuda)
+    out = htf.ops.bias_combine(fa.clone(), fb, alpha, cv)
+    ref, rcv = O.eds_rdf_model(nl64, 0.7, 1.1, 0.05)
+    assert_forces_close("eds_rdf_" + dtype.__name__, out.cpu().numpy(), ref, _cond_scale(nl64, _pair_forces_lj(nl64)) + 0.7 * cond_g)
+    with pytest.raises(ValueError):
+        htf.ops.eval_forces2(htf.Potential.lj(), htf.Potential.lj(), x)
+
+
 # --------------------------------------------------------------------------- aux kernels
 @pytest.mark.parametrize("tdt", [torch.float32, torch.float64])
 def test_aux_kernels(htf, cuda, tdt):

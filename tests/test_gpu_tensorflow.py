@@ -262,6 +262,34 @@ def test_rdf(htf, cuda):
     assert ref.sum() > 0
 
 
+def test_eds_rdf_model_steps_match_oracle(htf, cuda):
+    """config C4 through SimModel/tfcompute: every step's forces, cv and alpha against the
+    oracle composite driven by the oracle EDSLayer on the same pair vectors."""
+    from hoomd_tf_amd import standin
+    pos, L, a = standin.fcc_positions(4, 0.8442)
+    pos = pos + 0.03 * a * np.random.default_rng(2).standard_normal(pos.shape)
+    system = standin.System(pos, L, dtype=torch.float32, device=cuda)
+    sim = standin.Simulation(system)
+    sim.integrate_nve(0.002)
+    model = build_examples.EDSRDFModel(64, set_point=9.0, r0=1.1, gap=0.05, period=8, learning_rate=0.5)
+    tfc = htf.tfcompute(model)
+    tfc.attach(sim.nlist_cell(check_period=1), r_cut=2.5, save_output_period=1)
+    ref_eds = O.EDSLayer(9.0, 8, 0.5)
+    for step in range(20):
+        sim.run(1)
+        nl = tfc.get_nlist_array().astype(np.float32).astype(np.float64)
+        _, cv_ref = O.eds_rdf_model(nl, 0.0, 1.1, 0.05)
+        a_ref = float(ref_eds(cv_ref))
+        f_ref, _ = O.eds_rdf_model(nl, a_ref, 1.1, 0.05)
+        np.testing.assert_allclose(tfc.outputs[0][-1], cv_ref, rtol=2e-5)
+        np.testing.assert_allclose(tfc.outputs[1][-1], a_ref, rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(tfc.get_forces_array(), f_ref, rtol=2e-4, atol=2e-3)
+    assert abs(a_ref) > 1e-3  # the bias is actually on
+    assert tfc._plan is None  # stateful model: stays on the eager path
+    rdf_ref, _ = O.compute_rdf(tfc.get_nlist_array().astype(np.float32), [0, 3.5])
+    np.testing.assert_allclose(tfc.outputs[2][-1], rdf_ref, rtol=1e-4)
+
+
 def test_pair_mlp_model_runs_traced(htf, cuda):
     """config-3 style model through SimModel/tfcompute: traced path, finite forces."""
     from hoomd_tf_amd import standin

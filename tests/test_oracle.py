@@ -87,6 +87,23 @@ def test_pair_mlp_vs_autograd(dtype, act):
     assert np.all(f[0] == 0)
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_eds_rdf_composite_vs_autograd(dtype):
+    """config C4 closed form (LJ + alpha * soft-RDF CV) against the torch graph."""
+    nl = _nl(dtype, seed=9)
+    nl[1, :2] = 0
+    f, cv = O.eds_rdf_model(nl, 0.7, 1.1, 0.05)
+    tf_, tcv = G.eds_rdf_model(torch.from_numpy(nl), 0.7, 1.1, 0.05)
+    scale = np.abs(f).max()
+    np.testing.assert_allclose(f / scale, tf_.numpy() / scale, **_tol(dtype))
+    np.testing.assert_allclose(cv, float(tcv), rtol=1e-5)
+    # alpha = 0 reduces to LJModel; the gauss model alone reproduces the bias part
+    f0, _ = O.eds_rdf_model(nl, 0.0, 1.1, 0.05)
+    np.testing.assert_allclose(f0, O.lj_model(nl), rtol=1e-6, atol=1e-6)
+    fg = O.gauss_model(nl, 1.1, 0.05, 1.0)
+    np.testing.assert_allclose((f - f0)[:, :3], 0.7 * fg[:, :3], rtol=2e-3 if dtype == np.float32 else 1e-9, atol=1e-4 if dtype == np.float32 else 1e-9)
+
+
 def test_rinv_poly_is_lj():
     nl = _nl(np.float64)
     nl[1, :2] = 0
