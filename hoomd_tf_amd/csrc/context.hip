@@ -165,7 +165,8 @@ extern "C" int htf_fused_forces(const htf_potential *pot, const void *d_pos, int
 
 extern "C" int htf_eval_forces2(const htf_potential *potA, const htf_potential *potB, const void *d_nlist,
                                 int nlist_dtype, unsigned B, unsigned NN, void *d_forceA, void *d_forceB,
-                                int force_dtype, float *d_partials, htf_stream stream) {
+                                int force_dtype, float *d_partials, float rdf_r0, float rdf_r1,
+                                unsigned rdf_nbins_total, unsigned *d_rdf_hist, htf_stream stream) {
     using namespace htf;
     HTF_REQUIRE(potA && potB, "htf_eval_forces2: no potential");
     HTF_REQUIRE(d_nlist && d_forceA && d_forceB, "htf_eval_forces2: null pointer");
@@ -175,7 +176,7 @@ extern "C" int htf_eval_forces2(const htf_potential *potA, const htf_potential *
     HTF_REQUIRE(potB->pp.kind == HTF_POT_GAUSS, "htf_eval_forces2: potB must be HTF_POT_GAUSS");
     if (B == 0) return HTF_OK;
     return eval_pair2_dispatch(potA->pp, potB->pp, d_nlist, nlist_dtype, B, NN, d_forceA, d_forceB, force_dtype,
-                               d_partials, (hipStream_t)stream);
+                               d_partials, rdf_r0, rdf_r1, rdf_nbins_total, d_rdf_hist, (hipStream_t)stream);
 }
 
 extern "C" unsigned htf_eval2_num_partials(unsigned B, unsigned NN) { return htf::eval_pair2_num_partials(B, NN); }

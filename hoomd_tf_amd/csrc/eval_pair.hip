@@ -178,73 +178,117 @@ int eval_pair_dispatch(const PotParams &p, const void *nlist, int in_dtype, unsi
 }
 
 // ---- two potentials in one pass (EDS-biased models: base potential + Gaussian CV channel) ----
+struct RdfArgs { // optional compute_rdf histogram fused into the same sweep (hist == nullptr: off)
+    float r0, r1;
+    unsigned nb;
+    unsigned *hist;
+};
+constexpr unsigned kRdfMaxBins = 1024;
+
 template <int KA, int G, typename IT>
 __global__ __launch_bounds__(256) void eval_pair2_kernel(const typename Vec4<IT>::type *__restrict__ nlist, unsigned B,
                                                          unsigned NN, void *__restrict__ forceA,
                                                          void *__restrict__ forceB, int out_f64, PotParams pa,
-                                                         PotParams pb, float *__restrict__ partials) {
+                                                         PotParams pb, float *__restrict__ partials, RdfArgs rdf) {
     constexpr int RPW = 64 / G;
     __shared__ float s_part[4];
+    __shared__ unsigned s_hist[kRdfMaxBins];
+    if (rdf.hist != nullptr) {
+        for (unsigned i = threadIdx.x; i < rdf.nb; i += blockDim.x) s_hist[i] = 0;
+        __syncthreads();
+    }
     const unsigned lane = threadIdx.x & 63u;
     const unsigned g = lane % G, sub = lane / G;
-    const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const unsigned row = wave * RPW + sub;
-    const bool active = row < B;
-    const typename Vec4<IT>::type *rp = nlist + (size_t)(active ? row : B - 1) * NN;
-    float ax = 0.f, ay = 0.f, az = 0.f, ae = 0.f, bx = 0.f, by = 0.f, bz = 0.f, be = 0.f;
-    for (unsigned j0 = 0; j0 < NN; j0 += kUnroll * G) {
-        float4 v[kUnroll];
+    const unsigned ngroups = (B + 4 * RPW - 1) / (4 * RPW); // one group = the 4*RPW rows a block sweeps per trip
+    unsigned n_lo = 0, n_hi = 0;
+    // persistent blocks: the LDS histogram is flushed once per block, not once per 16 rows
+    // (16 384 flushes x ~100 same-address global atomics cost 200 us at C4)
+    for (unsigned grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        // walk the rows cache-first (see eval_pair_kernel)
+        const unsigned rgrp = ngroups - 1 - grp;
+        const unsigned row = (rgrp * 4 + (threadIdx.x >> 6)) * RPW + sub;
+        const bool active = row < B;
+        const typename Vec4<IT>::type *rp = nlist + (size_t)(active ? row : B - 1) * NN;
+        float ax = 0.f, ay = 0.f, az = 0.f, ae = 0.f, bx = 0.f, by = 0.f, bz = 0.f, be = 0.f;
+        for (unsigned j0 = 0; j0 < NN; j0 += kUnroll * G) {
+            float4 v[kUnroll];
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
-            unsigned j = j0 + u * G + g;
-            v[u] = (j < NN) ? load_slot<IT>(rp + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int u = 0; u < kUnroll; ++u) {
+                unsigned j = j0 + u * G + g;
+                v[u] = (j < NN) ? load_slot<IT>(rp + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                float e, fx, fy, fz;
+                pair_eval<KA>(v[u].x, v[u].y, v[u].z, pa, e, fx, fy, fz);
+                ax += fx; ay += fy; az += fz; ae += e;
+                pair_eval<HTF_POT_GAUSS>(v[u].x, v[u].y, v[u].z, pb, e, fx, fy, fz);
+                bx += fx; by += fy; bz += fz; be += e;
+                if (rdf.hist != nullptr && active && j0 + u * G + g < NN) {
+                    // compute_rdf (simmodel.py:661-662): plain norm, histogram_fixed_width clamping
+                    const float r = sqrtf(v[u].x * v[u].x + v[u].y * v[u].y + v[u].z * v[u].z);
+                    const float fi = floorf((float)rdf.nb * ((r - rdf.r0) / (rdf.r1 - rdf.r0)));
+                    const int idx = fi < 0.f ? 0 : (fi > (float)(rdf.nb - 1) ? (int)(rdf.nb - 1) : (int)fi);
+                    // the clamped end bins take every padded slot (26 % of the tensor lands in bin 0):
+                    // count those in a register, only interior bins go through LDS atomics
+                    if (idx == 0) ++n_lo;
+                    else if (idx == (int)rdf.nb - 1) ++n_hi;
+                    else atomicAdd(&s_hist[idx], 1u);
+                }
+            }
         }
-#pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
-            float e, fx, fy, fz;
-            pair_eval<KA>(v[u].x, v[u].y, v[u].z, pa, e, fx, fy, fz);
-            ax += fx; ay += fy; az += fz; ae += e;
-            pair_eval<HTF_POT_GAUSS>(v[u].x, v[u].y, v[u].z, pb, e, fx, fy, fz);
-            bx += fx; by += fy; bz += fz; be += e;
+        ax = group_sum<G>(ax); ay = group_sum<G>(ay); az = group_sum<G>(az); ae = group_sum<G>(ae);
+        bx = group_sum<G>(bx); by = group_sum<G>(by); bz = group_sum<G>(bz); be = group_sum<G>(be);
+        if (g == 0 && active) {
+            if (out_f64) {
+                ((double4 *)forceA)[row] = make_double4(ax, ay, az, ae);
+                ((double4 *)forceB)[row] = make_double4(bx, by, bz, be);
+            } else {
+                ((float4 *)forceA)[row] = make_float4(ax, ay, az, ae);
+                ((float4 *)forceB)[row] = make_float4(bx, by, bz, be);
+            }
+        }
+        if (partials != nullptr) { // per-group sum of the B energy column, fixed order -> deterministic
+            float c = (g == 0 && active) ? be : 0.f;
+            c = group_sum<64>(c);
+            __syncthreads(); // s_part reuse across trips
+            if (lane == 0) s_part[threadIdx.x >> 6] = c;
+            __syncthreads();
+            if (threadIdx.x == 0) partials[rgrp] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
         }
     }
-    ax = group_sum<G>(ax); ay = group_sum<G>(ay); az = group_sum<G>(az); ae = group_sum<G>(ae);
-    bx = group_sum<G>(bx); by = group_sum<G>(by); bz = group_sum<G>(bz); be = group_sum<G>(be);
-    if (g == 0 && active) {
-        if (out_f64) {
-            ((double4 *)forceA)[row] = make_double4(ax, ay, az, ae);
-            ((double4 *)forceB)[row] = make_double4(bx, by, bz, be);
-        } else {
-            ((float4 *)forceA)[row] = make_float4(ax, ay, az, ae);
-            ((float4 *)forceB)[row] = make_float4(bx, by, bz, be);
+    if (rdf.hist != nullptr) {
+        n_lo = group_sum_u<64>(n_lo);
+        n_hi = group_sum_u<64>(n_hi);
+        if (lane == 0) {
+            if (n_lo) atomicAdd(&s_hist[0], n_lo);
+            if (n_hi) atomicAdd(&s_hist[rdf.nb - 1], n_hi);
         }
-    }
-    if (partials != nullptr) { // block sum of the B energy column, fixed order -> deterministic
-        float c = (g == 0 && active) ? be : 0.f;
-        c = group_sum<64>(c);
-        if (lane == 0) s_part[threadIdx.x >> 6] = c;
         __syncthreads();
-        if (threadIdx.x == 0) partials[blockIdx.x] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+        for (unsigned i = threadIdx.x; i < rdf.nb; i += blockDim.x)
+            if (s_hist[i]) atomicAdd(&rdf.hist[i], s_hist[i]);
     }
 }
 
 template <int KA, int G, typename IT>
 static int launch_eval2_g(const void *nlist, unsigned B, unsigned NN, void *fa, void *fb, int out_f64,
-                          const PotParams &pa, const PotParams &pb, float *partials, hipStream_t stream) {
+                          const PotParams &pa, const PotParams &pb, float *partials, const RdfArgs &rdf, hipStream_t stream) {
     constexpr unsigned rows_per_block = 4 * (64 / G);
     unsigned grid = (B + rows_per_block - 1) / rows_per_block;
+    if (grid > 2048u) grid = 2048u; // persistent: 8 blocks per CU
     hipLaunchKernelGGL((eval_pair2_kernel<KA, G, IT>), dim3(grid), dim3(256), 0, stream,
-                       (const typename Vec4<IT>::type *)nlist, B, NN, fa, fb, out_f64, pa, pb, partials);
+                       (const typename Vec4<IT>::type *)nlist, B, NN, fa, fb, out_f64, pa, pb, partials, rdf);
     return check_launch("eval_pair2_kernel");
 }
 
 template <int KA, typename IT>
 static int launch_eval2_k(const void *nlist, unsigned B, unsigned NN, void *fa, void *fb, int out_f64,
-                          const PotParams &pa, const PotParams &pb, float *partials, hipStream_t stream) {
+                          const PotParams &pa, const PotParams &pb, float *partials, const RdfArgs &rdf,
+                          hipStream_t stream) {
     switch (pick_group(NN)) {
-    case 16: return launch_eval2_g<KA, 16, IT>(nlist, B, NN, fa, fb, out_f64, pa, pb, partials, stream);
-    case 8: return launch_eval2_g<KA, 8, IT>(nlist, B, NN, fa, fb, out_f64, pa, pb, partials, stream);
-    default: return launch_eval2_g<KA, 4, IT>(nlist, B, NN, fa, fb, out_f64, pa, pb, partials, stream);
+    case 16: return launch_eval2_g<KA, 16, IT>(nlist, B, NN, fa, fb, out_f64, pa, pb, partials, rdf, stream);
+    case 8: return launch_eval2_g<KA, 8, IT>(nlist, B, NN, fa, fb, out_f64, pa, pb, partials, rdf, stream);
+    default: return launch_eval2_g<KA, 4, IT>(nlist, B, NN, fa, fb, out_f64, pa, pb, partials, rdf, stream);
     }
 }
 
@@ -254,10 +298,16 @@ unsigned eval_pair2_num_partials(unsigned B, unsigned NN) {
 }
 
 int eval_pair2_dispatch(const PotParams &pa, const PotParams &pb, const void *nlist, int in_dtype, unsigned B,
-                        unsigned NN, void *forceA, void *forceB, int force_dtype, float *partials, hipStream_t stream) {
+                        unsigned NN, void *forceA, void *forceB, int force_dtype, float *partials, float rdf_r0,
+                        float rdf_r1, unsigned rdf_nbins_total, unsigned *rdf_hist, hipStream_t stream) {
     const int out_f64 = force_dtype == HTF_F64;
-#define HTF_E2(K) (in_dtype == HTF_F32 ? launch_eval2_k<K, float>(nlist, B, NN, forceA, forceB, out_f64, pa, pb, partials, stream) \
-                                       : launch_eval2_k<K, double>(nlist, B, NN, forceA, forceB, out_f64, pa, pb, partials, stream))
+    RdfArgs rdf{rdf_r0, rdf_r1, rdf_nbins_total, rdf_hist};
+    if (rdf_hist != nullptr && (rdf_nbins_total < 3 || rdf_nbins_total > kRdfMaxBins || !(rdf_r1 > rdf_r0))) {
+        set_error("htf_eval_forces2: bad fused rdf arguments (nbins+2 = %u, range [%g, %g])", rdf_nbins_total, rdf_r0, rdf_r1);
+        return HTF_ERR_INVALID;
+    }
+#define HTF_E2(K) (in_dtype == HTF_F32 ? launch_eval2_k<K, float>(nlist, B, NN, forceA, forceB, out_f64, pa, pb, partials, rdf, stream) \
+                                       : launch_eval2_k<K, double>(nlist, B, NN, forceA, forceB, out_f64, pa, pb, partials, rdf, stream))
     switch (pa.kind) {
     case HTF_POT_LJ: return HTF_E2(HTF_POT_LJ);
     case HTF_POT_WCA: return HTF_E2(HTF_POT_WCA);

@@ -30,7 +30,8 @@ int fused_forces_impl(const PotParams &p, const void *pos, int pos_dtype, unsign
                       unsigned *check_count, float4 *positions_out, hipStream_t s);
 
 int eval_pair2_dispatch(const PotParams &pa, const PotParams &pb, const void *nlist, int in_dtype, unsigned B,
-                        unsigned NN, void *forceA, void *forceB, int force_dtype, float *partials, hipStream_t stream);
+                        unsigned NN, void *forceA, void *forceB, int force_dtype, float *partials, float rdf_r0,
+                        float rdf_r1, unsigned rdf_nbins_total, unsigned *rdf_hist, hipStream_t stream);
 unsigned eval_pair2_num_partials(unsigned B, unsigned NN);
 
 struct MlpDevice;

@@ -21,6 +21,7 @@ __global__ __launch_bounds__(256) void rdf_hist_kernel(const typename Vec4<IT>::
     const float width = r1 - r0;
     const size_t total = (size_t)B * NN;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
+    unsigned n_lo = 0, n_hi = 0; // end bins (all padded slots land in bin 0) counted in registers
     for (size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x; s < total; s += stride) {
         const unsigned row = (unsigned)(s / NN);
         // masked_nlist type_i: boolean_mask drops whole rows (simmodel.py:684-686)
@@ -33,7 +34,15 @@ __global__ __launch_bounds__(256) void rdf_hist_kernel(const typename Vec4<IT>::
         // tf.histogram_fixed_width: floor(nbins * (v - lo) / (hi - lo)) clipped to [0, nbins-1]
         float fi = floorf((float)nb * ((r - r0) / width));
         int idx = fi < 0.f ? 0 : (fi > (float)(nb - 1) ? (int)(nb - 1) : (int)fi);
-        atomicAdd(&sh[idx], 1u);
+        if (idx == 0) ++n_lo;
+        else if (idx == (int)nb - 1) ++n_hi;
+        else atomicAdd(&sh[idx], 1u);
+    }
+    n_lo = group_sum_u<64>(n_lo);
+    n_hi = group_sum_u<64>(n_hi);
+    if ((threadIdx.x & 63) == 0) {
+        if (n_lo) atomicAdd(&sh[0], n_lo);
+        if (n_hi) atomicAdd(&sh[nb - 1], n_hi);
     }
     __syncthreads();
     for (unsigned i = threadIdx.x; i < nb; i += blockDim.x)

@@ -80,7 +80,7 @@ class Potential:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h:
+        if h and lib is not None:  # lib is None once the interpreter is tearing modules down
             lib.htf_potential_destroy(h)
             self._h = None
 
@@ -172,9 +172,10 @@ def fused_forces(potential, pos, n_neigh, head_list, nlist, box, r_cut, NN, offs
     return (out, v) if virial else out
 
 
-def eval_forces2(pot_a, pot_b, nlist, out_a=None, out_b=None, partials=None, out_dtype=None):
+def eval_forces2(pot_a, pot_b, nlist, out_a=None, out_b=None, partials=None, out_dtype=None, rdf=None):
     """Two potentials in one pass: -> (forces_a [B,4], forces_b [B,4]); ``partials`` receives
-    the per-block sums of forces_b[:, 3] (see reduce_partials)."""
+    the per-block sums of forces_b[:, 3] (see reduce_partials).  ``rdf = (r0, r1, hist)`` with a
+    zeroed int32 ``hist`` of nbins + 2 entries fuses the compute_rdf histogram into the sweep."""
     _dev(nlist, "nlist")
     B, NN = int(nlist.shape[0]), int(nlist.shape[1])
     od = out_dtype or (out_a.dtype if out_a is not None else nlist.dtype)
@@ -184,8 +185,10 @@ def eval_forces2(pot_a, pot_b, nlist, out_a=None, out_b=None, partials=None, out
         out_b = torch.empty((B, 4), dtype=od, device=nlist.device)
     _dev(out_a, "out_a")
     _dev(out_b, "out_b", out_a.dtype)
+    r0, r1, nbt, hist = (0.0, 1.0, 0, None) if rdf is None else (rdf[0], rdf[1], int(rdf[2].numel()), rdf[2])
     check(lib.htf_eval_forces2(pot_a.handle, pot_b.handle, nlist.data_ptr(), _dt(nlist), B, NN, out_a.data_ptr(),
                                out_b.data_ptr(), _dt(out_a), partials.data_ptr() if partials is not None else None,
+                               float(r0), float(r1), nbt, hist.data_ptr() if hist is not None else None,
                                _stream(nlist)))
     return out_a, out_b
 
@@ -282,7 +285,7 @@ class Context:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h:
+        if h and lib is not None:
             lib.htf_destroy(h)
             self._h = None
 

@@ -447,9 +447,16 @@ def compute_rdf(nlist, r_range, type_tensor=None, nbins=100, type_i=None, type_j
                                 tt.data_ptr() if tt is not None else None, int(stride),
                                 -1 if type_i is None else int(type_i), -1 if type_j is None else int(type_j),
                                 hist.data_ptr(), ops._stream(t)))
-    rdf = torch.empty(nbins, dtype=torch.float32, device=t.device)
-    rs = torch.empty(nbins, dtype=torch.float32, device=t.device)
-    check(lib.htf_rdf_finalize(hist.data_ptr(), nbins, r0, r1, rdf.data_ptr(), rs.data_ptr(), ops._stream(t)))
+    return rdf_from_histogram(hist, r0, r1)
+
+
+def rdf_from_histogram(hist, r0, r1):
+    """compute_rdf's tail (simmodel.py:663-668) for a histogram of nbins + 2 counts."""
+    nbins = int(hist.numel()) - 2
+    rdf = torch.empty(nbins, dtype=torch.float32, device=hist.device)
+    rs = torch.empty(nbins, dtype=torch.float32, device=hist.device)
+    check(lib.htf_rdf_finalize(hist.data_ptr(), nbins, float(r0), float(r1), rdf.data_ptr(), rs.data_ptr(),
+                               ops._stream(hist)))
     return rdf, rs
 
 

@@ -147,11 +147,15 @@ HTF_API int htf_fused_forces(const htf_potential *pot, const void *d_pos, int po
  * Scalar4).  potB must be HTF_POT_GAUSS, potA a closed-form potential.  d_partials (nullable,
  * >= htf_eval2_num_partials(B, NN) floats): per-block sums of forceB[i].w, to be reduced with
  * htf_reduce_partials -- the collective-variable sum of an EDS-biased model (config C4)
- * without a second sweep over the 268 MB tensor and without float atomics. */
+ * without a second sweep over the 268 MB tensor and without float atomics.  d_rdf_hist
+ * (nullable, [rdf_nbins_total], accumulated into): the untyped compute_rdf histogram
+ * (htf_rdf_histogram semantics) of the same pair vectors, fused into the sweep. */
 HTF_API int htf_eval_forces2(const htf_potential *potA, const htf_potential *potB,
                      const void *d_nlist, int nlist_dtype, unsigned B, unsigned NN,
                      void *d_forceA, void *d_forceB, int force_dtype,
-                     float *d_partials, htf_stream stream);
+                     float *d_partials,
+                     float rdf_r0, float rdf_r1, unsigned rdf_nbins_total, unsigned *d_rdf_hist,
+                     htf_stream stream);
 HTF_API unsigned htf_eval2_num_partials(unsigned B, unsigned NN);
 
 /* *d_out = scale * sum(d_partials[0..n)) in a fixed order (one block; deterministic). */

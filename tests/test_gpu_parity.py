@@ -335,6 +335,15 @@ def test_gauss_potential_and_eval2(htf, cuda, dtype):
     assert_forces_close("eds_rdf_" + dtype.__name__, out.cpu().numpy(), ref, _cond_scale(nl64, _pair_forces_lj(nl64)) + 0.7 * cond_g)
     with pytest.raises(ValueError):
         htf.ops.eval_forces2(htf.Potential.lj(), htf.Potential.lj(), x)
+    # compute_rdf fused into the same sweep == the stand-alone histogram kernel == the oracle
+    hist = torch.zeros(22, dtype=torch.int32, device=cuda)
+    htf.ops.eval_forces2(htf.Potential.lj(), pg, x, rdf=(0.0, 3.5, hist))
+    from hoomd_tf_amd.simmodel import rdf_from_histogram
+    rdf_fused, _ = rdf_from_histogram(hist, 0.0, 3.5)
+    rdf_plain, _ = htf.compute_rdf(x, [0, 3.5], nbins=20)
+    assert torch.equal(rdf_fused, rdf_plain)
+    ref_rdf, _ = O.compute_rdf(nl.astype(np.float32), [0, 3.5], nbins=20)
+    np.testing.assert_allclose(rdf_fused.cpu().numpy(), ref_rdf, rtol=1e-4)
 
 
 # --------------------------------------------------------------------------- aux kernels
