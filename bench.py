@@ -131,20 +131,42 @@ def run_eds(args, htf, standin, dev):
         e.record()
         return e
 
+    # The sweep is ~0.4 ms of GPU work per step; keep the host side to a handful of raw C-ABI
+    # calls with cached pointers so that the loop stays GPU-bound (torch only allocates once).
+    from hoomd_tf_amd._lib import lib, check
+    rdf_out = torch.empty(100, dtype=torch.float32, device=dev)
+    rs_out = torch.empty(100, dtype=torch.float32, device=dev)
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    F32 = 0
+    ptr = {"nl": None}
+
+    def refresh_ptrs():
+        ptr["nl"] = (nl.n_neigh.data_ptr(), nl.nlist.data_ptr(), nl.head_list.data_ptr(), nl.n_builds)
+
+    refresh_ptrs()
+
     def step(relax=False):
         ts = state["ts"]
         nl.compute(ts)
+        if nl.n_builds != ptr["nl"][3]:
+            refresh_ptrs()
         t0 = mark() if state["time"] else None
-        htf.ops.build_pair_vectors(sysm.pos, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, args.rcut, NN, out=pv)
+        check(lib.htf_build_pair_vectors(pv.data_ptr(), F32, sysm.pos.data_ptr(), F32, N, NN, 0, N, 0, C.byref(sysm.box),
+                                         ptr["nl"][0], ptr["nl"][1], ptr["nl"][2], args.rcut, None, stream))
         t1 = mark() if state["time"] else None
         hist.zero_()
-        htf.ops.eval_forces2(lj, gauss, pv, out_a=sysm.force, out_b=bias, partials=partials, rdf=(0.0, 3.5, hist))
+        check(lib.htf_eval_forces2(lj.handle, gauss.handle, pv.data_ptr(), F32, N, NN, sysm.force.data_ptr(),
+                                   bias.data_ptr(), F32, partials.data_ptr(), 0.0, 3.5, 102, hist.data_ptr(), stream))
         t2 = mark() if state["time"] else None
-        htf.ops.reduce_partials(partials, npart, 1.0 / N, cv)
-        if eds is not None:
-            eds(cv)
-            htf.ops.bias_combine(sysm.force, bias, eds.state[2:3], cv)
-        state["rdf"] = rdf_from_histogram(hist, 0.0, 3.5)[0]  # compute_rdf(nlist, [0, 3.5]) every step
+        check(lib.htf_reduce_partials(partials.data_ptr(), npart, 1.0 / N, cv.data_ptr(), stream))
+        if eds is not None:  # EDSLayer.__call__ + bias assembly, all on the device
+            check(lib.htf_eds_update(eds.state.data_ptr(), cv.data_ptr(), eds.set_point, eds.period,
+                                     eds.learning_rate, eds.cv_scale, stream))
+            check(lib.htf_bias_combine(sysm.force.data_ptr(), bias.data_ptr(), eds.state.data_ptr() + 8,
+                                       cv.data_ptr(), F32, N, stream))
+        # compute_rdf(nlist, [0, 3.5]) every step: histogram fused above, tail here
+        check(lib.htf_rdf_finalize(hist.data_ptr(), 100, 0.0, 3.5, rdf_out.data_ptr(), rs_out.data_ptr(), stream))
+        state["rdf"] = rdf_out
         if relax:
             f3 = sysm.force[:, :3]
             f3.mul_(torch.clamp(200.0 / f3.norm(dim=1, keepdim=True).clamp_min(1e-12), max=1.0))
