@@ -28,8 +28,12 @@
 // Finally, 2 and 4 particles per wave with ALL their loads issued up front (same dependent
 // chain, 2-4x the rows behind every wave slot) ran 81.4 / 80.8 us against 82.0: the kernel is
 // not wave-slot- or latency-bound either, and writing 190 MB instead of 268 MB (delta
-// zero-fill, PMC-verified) does not move it.  What remains is the store side itself: ~4
-// partial, unaligned store instructions per row (one per compacted chunk plus the zero tail).
+// zero-fill, PMC-verified) does not move it.  Assembling the row in LDS and leaving with aligned
+// full-width stores (2 x 1 KiB per row instead of ~4 partial ones): 82.1 us, no change either.
+// For scale (tools/bw_probe.py on the same box): memset of the 268 MB tensor 37 us (6.9-7.3
+// TB/s), 268 MB copy 98 us (5.5 TB/s r+w).  The load phase (35 us) and the store phase (~40 us)
+// of this kernel simply add up: a CU's vector-memory pipeline issues in order, so stores that
+// wait for write-buffer space hold back the loads of the other waves on that CU.
 //
 // Compiled with -ffp-contract=off: the arithmetic is then op-for-op the oracle's
 // (oracle/htf_oracle.py:min_image / prepare_neighbors), so pair vectors are
