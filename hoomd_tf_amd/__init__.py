@@ -12,7 +12,8 @@ from .ops import Potential, Context
 from . import standin
 from .simmodel import (SimModel, compute_nlist_forces, compute_positions_forces, nlist_rinv, safe_norm,
                        box_size, wrap_vector, compute_rdf, masked_nlist, reduce_sum, pairwise_unit_forces, Nlist)
-from .layers import RBFExpansion, WCARepulsion, EDSLayer, PairMLP, SoftRDFCV
+from .layers import RBFExpansion, WCARepulsion, EDSLayer, PairMLP, SoftRDFCV, LJLayer
+from . import optimizers
 from .tensorflowcompute import tfcompute
 
 __version__ = "0.1.0"

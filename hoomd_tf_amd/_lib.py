@@ -20,7 +20,9 @@ LIB_PATH = os.path.join(_HERE, "libhtf_amd.so")
 HTF_OK, HTF_ERR_INVALID, HTF_ERR_DEVICE, HTF_ERR_NLIST_OVERFLOW, HTF_ERR_SKEWED_BOX, HTF_ERR_NOMEM = range(6)
 HTF_F32, HTF_F64 = 0, 1
 HTF_TF2HOOMD, HTF_HOOMD2TF = 0, 1
-POT_NONE, POT_LJ, POT_WCA, POT_RINV_POLY, POT_SIMPLE, POT_PAIR_MLP, POT_GAUSS = range(7)
+POT_NONE, POT_LJ, POT_WCA, POT_RINV_POLY, POT_SIMPLE, POT_PAIR_MLP, POT_GAUSS, POT_LJ_PARAM = range(8)
+OPT_SGD, OPT_ADAM, OPT_NADAM = range(3)
+OPT_STATE_FLOATS = 24
 ACT_LINEAR, ACT_TANH = 0, 1
 MLP_FP32, MLP_BF16 = 0, 1
 MAX_POLY_TERMS = 8
@@ -42,12 +44,18 @@ class Box(C.Structure):
 
 class PotentialDesc(C.Structure):
     _fields_ = [("kind", C.c_int), ("sigma", C.c_double),
-                ("gauss_r0", C.c_double), ("gauss_gap", C.c_double), ("gauss_coef", C.c_double), ("n_terms", C.c_int),
+                ("gauss_r0", C.c_double), ("gauss_gap", C.c_double), ("gauss_coef", C.c_double),
+                ("lj_w0", C.c_double), ("lj_w1", C.c_double), ("d_theta", C.c_void_p), ("n_terms", C.c_int),
                 ("coef", C.c_double * MAX_POLY_TERMS), ("power", C.c_int * MAX_POLY_TERMS),
                 ("K", C.c_int), ("H1", C.c_int), ("H2", C.c_int), ("activation", C.c_int),
                 ("mlp_precision", C.c_int), ("rbf_low", C.c_double), ("rbf_high", C.c_double),
                 ("W1", C.c_void_p), ("b1", C.c_void_p), ("W2", C.c_void_p), ("b2", C.c_void_p),
                 ("W3", C.c_void_p), ("b3", C.c_void_p)]
+
+
+class OptimizerDesc(C.Structure):
+    _fields_ = [("kind", C.c_int), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
+                ("epsilon", C.c_float), ("nonneg_mask", C.c_uint), ("l1_reg", C.c_float * 8)]
 
 
 class Config(C.Structure):
@@ -79,6 +87,10 @@ PROTOTYPES = {
     "htf_eval2_num_partials": (_u, [_u, _u]),
     "htf_reduce_partials": (_i, [_vp, _u, C.c_float, _vp, _vp]),
     "htf_bias_combine": (_i, [_vp, _vp, _vp, _vp, _i, _u, _vp]),
+    "htf_potential_num_params": (_i, [_vp]),
+    "htf_train_scratch_floats": (_sz, [_vp, _u, _u]),
+    "htf_train_pair_grad": (_i, [_vp, _vp, _i, _u, _u, _vp, _i, _vp, _vp, _vp, _vp]),
+    "htf_optimizer_step": (_i, [_vp, _u, _vp, C.c_float, _vp, C.POINTER(OptimizerDesc), _vp]),
     "htf_add_virial": (_i, [_vp, _vp, _i, _u, _sz, _vp]),
     "htf_add_scalar4": (_i, [_vp, _vp, _i, _u, _vp]),
     "htf_copy_positions": (_i, [_vp, _i, _vp, _i, _u, _u, _i, _vp]),

@@ -105,6 +105,10 @@ extern "C" int htf_potential_create(const htf_potential_desc *d, htf_potential *
             p->pp.power[k] = d->power[k];
         }
         break;
+    case HTF_POT_LJ_PARAM:
+        p->pp.lj_w0 = (float)d->lj_w0;
+        p->pp.lj_w1 = (float)d->lj_w1;
+        break;
     case HTF_POT_GAUSS:
         if (!(d->gauss_gap > 0)) {
             set_error("htf_potential_create: GAUSS gap must be > 0 (got %g)", d->gauss_gap);
@@ -125,8 +129,35 @@ extern "C" int htf_potential_create(const htf_potential_desc *d, htf_potential *
         delete p;
         return rc;
     }
+    if (d->d_theta != nullptr) {
+        if (potential_num_params(p->pp) == 0) {
+            set_error("htf_potential_create: potential kind %d has no trainable parameters", d->kind);
+            delete p;
+            return HTF_ERR_INVALID;
+        }
+        p->pp.theta = d->d_theta;
+    }
     *out = p;
     return HTF_OK;
+}
+
+extern "C" int htf_potential_num_params(const htf_potential *pot) { return pot ? htf::potential_num_params(pot->pp) : 0; }
+
+extern "C" size_t htf_train_scratch_floats(const htf_potential *pot, unsigned B, unsigned NN) {
+    return pot ? htf::train_scratch_floats(pot->pp, B, NN) : 0;
+}
+
+extern "C" int htf_train_pair_grad(const htf_potential *pot, const void *d_nlist, int nlist_dtype, unsigned B,
+                                   unsigned NN, const void *d_labels, int label_dtype, void *d_pred, float *d_accum,
+                                   float *d_scratch, htf_stream stream) {
+    using namespace htf;
+    HTF_REQUIRE(pot, "htf_train_pair_grad: no potential");
+    HTF_REQUIRE(d_nlist && d_labels && d_accum && d_scratch, "htf_train_pair_grad: null pointer");
+    HTF_REQUIRE(NN > 0 && B > 0, "htf_train_pair_grad: empty batch");
+    HTF_REQUIRE(nlist_dtype == HTF_F32 || nlist_dtype == HTF_F64, "htf_train_pair_grad: bad nlist dtype %d", nlist_dtype);
+    HTF_REQUIRE(label_dtype == HTF_F32 || label_dtype == HTF_F64, "htf_train_pair_grad: bad label dtype %d", label_dtype);
+    return train_pair_dispatch(pot->pp, d_nlist, nlist_dtype, B, NN, d_labels, label_dtype, d_pred, d_accum, d_scratch,
+                               (hipStream_t)stream);
 }
 
 extern "C" void htf_potential_destroy(htf_potential *pot) {

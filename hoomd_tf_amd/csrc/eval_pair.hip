@@ -35,9 +35,10 @@ __device__ __forceinline__ float4 load_slot(const typename Vec4<IT>::type *p) {
 template <int KIND, int G, bool VIRIAL, typename IT>
 __global__ __launch_bounds__(256) void eval_pair_kernel(const typename Vec4<IT>::type *__restrict__ nlist,
                                                         unsigned B, unsigned NN, void *__restrict__ force,
-                                                        void *__restrict__ virial9, int out_f64, PotParams p,
+                                                        void *__restrict__ virial9, int out_f64, PotParams pin,
                                                         const unsigned *__restrict__ counts) {
     constexpr int RPW = 64 / G; // particle rows per wave
+    const PotParams p = resolve_theta(pin);
     const unsigned lane = threadIdx.x & 63u;
     const unsigned g = lane % G, sub = lane / G;
     // Blocks walk the rows from the END of the tensor: in computeForces this kernel runs right
@@ -171,6 +172,7 @@ int eval_pair_dispatch(const PotParams &p, const void *nlist, int in_dtype, unsi
     case HTF_POT_RINV_POLY: return launch_eval<HTF_POT_RINV_POLY>(nlist, in_dtype, B, NN, force, virial9, out_f64, p, counts, stream);
     case HTF_POT_SIMPLE: return launch_eval<HTF_POT_SIMPLE>(nlist, in_dtype, B, NN, force, virial9, out_f64, p, counts, stream);
     case HTF_POT_GAUSS: return launch_eval<HTF_POT_GAUSS>(nlist, in_dtype, B, NN, force, virial9, out_f64, p, counts, stream);
+    case HTF_POT_LJ_PARAM: return launch_eval<HTF_POT_LJ_PARAM>(nlist, in_dtype, B, NN, force, virial9, out_f64, p, counts, stream);
     default:
         set_error("eval_pair_dispatch: potential kind %d is not a closed-form pair potential", p.kind);
         return HTF_ERR_INVALID;
@@ -188,9 +190,10 @@ constexpr unsigned kRdfMaxBins = 1024;
 template <int KA, int G, typename IT>
 __global__ __launch_bounds__(256) void eval_pair2_kernel(const typename Vec4<IT>::type *__restrict__ nlist, unsigned B,
                                                          unsigned NN, void *__restrict__ forceA,
-                                                         void *__restrict__ forceB, int out_f64, PotParams pa,
+                                                         void *__restrict__ forceB, int out_f64, PotParams pa_in,
                                                          PotParams pb, float *__restrict__ partials, RdfArgs rdf) {
     constexpr int RPW = 64 / G;
+    const PotParams pa = resolve_theta(pa_in);
     __shared__ float s_part[4];
     __shared__ unsigned s_hist[kRdfMaxBins];
     if (rdf.hist != nullptr) {

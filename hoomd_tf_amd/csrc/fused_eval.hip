@@ -79,8 +79,9 @@ __global__ __launch_bounds__(256) void fused_forces_kernel(const typename Vec4<P
                                                            const unsigned *__restrict__ nlist,
                                                            const unsigned *__restrict__ head_list, PT rmaxsq,
                                                            void *__restrict__ force, void *__restrict__ virial9,
-                                                           int out_f64, PotParams p, unsigned *__restrict__ check_count,
+                                                           int out_f64, PotParams pin, unsigned *__restrict__ check_count,
                                                            float4 *__restrict__ positions_out) {
+    const PotParams p = resolve_theta(pin);
     const unsigned lane = threadIdx.x & 63u;
     const unsigned w = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     if (w >= batch) return;
@@ -173,6 +174,7 @@ int fused_forces_impl(const PotParams &p, const void *pos, int pos_dtype, unsign
     case HTF_POT_WCA: return HTF_FK(HTF_POT_WCA);
     case HTF_POT_RINV_POLY: return HTF_FK(HTF_POT_RINV_POLY);
     case HTF_POT_GAUSS: return HTF_FK(HTF_POT_GAUSS);
+    case HTF_POT_LJ_PARAM: return HTF_FK(HTF_POT_LJ_PARAM);
     case HTF_POT_SIMPLE:
         HTF_REQUIRE(virial9 == nullptr, "htf_fused_forces: SimplePotential has no virial");
         return HTF_FK(HTF_POT_SIMPLE);

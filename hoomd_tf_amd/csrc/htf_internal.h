@@ -9,6 +9,8 @@ struct PotParams {
     float sigma;   // WCA sigma (fp32, as the Keras weight is)
     float wca_cut; // fp32(sigma) * fp32(2^(1/3))   layers.py:97
     float gauss_r0, gauss_ginv, gauss_coef; // HTF_POT_GAUSS: centre, 1/gap, coefficient
+    float lj_w0, lj_w1;                     // HTF_POT_LJ_PARAM
+    const float *theta;                     // device parameter vector of a trainable potential (nullable)
     int n_terms;
     float coef[HTF_MAX_POLY_TERMS];
     int power[HTF_MAX_POLY_TERMS];
@@ -33,6 +35,12 @@ int eval_pair2_dispatch(const PotParams &pa, const PotParams &pb, const void *nl
                         unsigned NN, void *forceA, void *forceB, int force_dtype, float *partials, float rdf_r0,
                         float rdf_r1, unsigned rdf_nbins_total, unsigned *rdf_hist, hipStream_t stream);
 unsigned eval_pair2_num_partials(unsigned B, unsigned NN);
+
+int potential_num_params(const PotParams &p);
+size_t train_scratch_floats(const PotParams &p, unsigned B, unsigned NN);
+int train_pair_dispatch(const PotParams &p, const void *nlist, int in_dtype, unsigned B, unsigned NN,
+                        const void *labels, int label_dtype, void *pred, float *accum, float *scratch,
+                        hipStream_t stream);
 
 struct MlpDevice;
 int mlp_create(const htf_potential_desc *d, MlpDevice **out);

@@ -11,6 +11,23 @@ namespace htf {
 // parity tolerance (measured: tests/test_gpu_parity.py ratios in gpurun_out/parity_stats.json).
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
+// Trainable potentials keep theta on the device; every kernel resolves it once at entry
+// (wave-uniform scalar loads) so an optimizer step is visible to the next launch.
+__device__ __forceinline__ PotParams resolve_theta(PotParams p) {
+    if (p.theta != nullptr) {
+        if (p.kind == HTF_POT_LJ_PARAM) {
+            p.lj_w0 = p.theta[0];
+            p.lj_w1 = p.theta[1];
+        } else if (p.kind == HTF_POT_WCA) {
+            p.sigma = p.theta[0];
+            p.wca_cut = p.sigma * 1.2599210498948732f;
+        } else if (p.kind == HTF_POT_RINV_POLY) {
+            for (int k = 0; k < p.n_terms; ++k) p.coef[k] = p.theta[k];
+        }
+    }
+    return p;
+}
+
 // shared forward of every rinv-based energy: t = x + 1e-7, r' = |t|, s = nlist_rinv
 struct RinvFwd {
     float tx, ty, tz, rp, s;
@@ -42,6 +59,22 @@ __device__ __forceinline__ void pair_eval(float x, float y, float z, const PotPa
         fy = isfinite(ay) ? ay : 0.0f;
         fz = isfinite(az) ? az : 0.0f;
         e = 0.0f;
+        return;
+    } else if constexpr (KIND == HTF_POT_LJ_PARAM) {
+        // example 06 LJLayer on r = safe_norm(x): q = w1^6 / r^6 (divide_no_nan; TF's kernels flush
+        // the padded slots' r^6 ~ 2.7e-41 to zero, i.e. q = 0 there: same as the r > 3e-6 mask),
+        // e = w0 * 4 (q^2 - q) / 2,  de/dr = 2 w0 (2q - 1) (-6 q / r),  nlist_forces = 2 de/dr t / r
+        const float tx = x + kNormDelta, ty = y + kNormDelta, tz = z + kNormDelta;
+        const float r = sqrtf(tx * tx + ty * ty + tz * tz);
+        const bool m = r > kRinvDelta;
+        const float ri = m ? fast_rcp(r) : 0.0f;
+        const float a = p.lj_w1 * ri, a2 = a * a;
+        const float q = a2 * a2 * a2;
+        e = 2.0f * p.lj_w0 * (q * q - q);
+        const float c = 2.0f * (2.0f * p.lj_w0 * (2.0f * q - 1.0f) * (-6.0f * q * ri)) * ri;
+        fx = c * tx;
+        fy = c * ty;
+        fz = c * tz;
         return;
     } else if constexpr (KIND == HTF_POT_GAUSS) {
         // one RBFExpansion channel as a pair energy: r = safe_norm(x) (simmodel.py:581-594),
@@ -101,6 +134,84 @@ __device__ __forceinline__ void pair_eval(float x, float y, float z, const PotPa
     }
 }
 
+
+// Per-slot derivatives through the force for training: d(e, nlist_forces)/d(theta_k), k < P.
+// dd[k] = (d fx, d fy, d fz, d e)/d theta_k.  Returns e, (fx, fy, fz) as pair_eval does.
+template <int KIND> struct NumParams;
+template <> struct NumParams<HTF_POT_LJ_PARAM> { static constexpr int value = 2; };
+template <> struct NumParams<HTF_POT_WCA> { static constexpr int value = 1; };
+template <> struct NumParams<HTF_POT_RINV_POLY> { static constexpr int value = HTF_MAX_POLY_TERMS; };
+
+template <int KIND>
+__device__ __forceinline__ void pair_eval_grad(float x, float y, float z, const PotParams &p, float &e, float &fx,
+                                               float &fy, float &fz, float4 (&dd)[NumParams<KIND>::value]) {
+    constexpr int P = NumParams<KIND>::value;
+#pragma unroll
+    for (int k = 0; k < P; ++k) dd[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (KIND == HTF_POT_LJ_PARAM) {
+        const float tx = x + kNormDelta, ty = y + kNormDelta, tz = z + kNormDelta;
+        const float r = sqrtf(tx * tx + ty * ty + tz * tz);
+        const bool m = r > kRinvDelta;
+        const float ri = m ? fast_rcp(r) : 0.0f;
+        const float a = p.lj_w1 * ri, a2 = a * a;
+        const float q = a2 * a2 * a2;
+        const float w0 = p.lj_w0, w1 = p.lj_w1;
+        e = 2.0f * w0 * (q * q - q);
+        const float dedr = 2.0f * w0 * (2.0f * q - 1.0f) * (-6.0f * q * ri);
+        const float c = 2.0f * dedr * ri;
+        fx = c * tx; fy = c * ty; fz = c * tz;
+        // d/dw0: everything is linear in w0
+        const float c0 = 2.0f * (2.0f * (2.0f * q - 1.0f) * (-6.0f * q * ri)) * ri;
+        dd[0] = make_float4(c0 * tx, c0 * ty, c0 * tz, 2.0f * (q * q - q));
+        // d/dw1: dq/dw1 = 6 q / w1
+        const float dq = w1 != 0.0f ? 6.0f * q / w1 : 0.0f;
+        const float c1 = 2.0f * (2.0f * w0 * (-6.0f * ri) * (4.0f * q - 1.0f) * dq) * ri;
+        dd[1] = make_float4(c1 * tx, c1 * ty, c1 * tz, 2.0f * w0 * (2.0f * q - 1.0f) * dq);
+    } else {
+        RinvFwd f = rinv_fwd(x, y, z);
+        const float s = f.s, s2 = s * s;
+        const float geo = f.cond ? 2.0f * (-s2) * fast_rcp(f.rp) : 0.0f; // nlist_forces = geo * dE/ds * t
+        float dEds;
+        if constexpr (KIND == HTF_POT_WCA) {
+            const float sig = p.sigma;
+            const float q = sig * s, q2 = q * q, q5 = q2 * q2 * q, q6 = q5 * q;
+            const float r = sqrtf(x * x + y * y + z * z);
+            const bool in = r < p.wca_cut;
+            const float e_raw = in ? q6 : 0.0f;
+            e = fminf(fmaxf(e_raw, 0.0f), 10.0f);
+            const bool pass = in && (e_raw >= 0.0f) && (e_raw <= 10.0f);
+            dEds = pass ? 6.0f * q5 * sig : 0.0f;
+            // d e / d sigma = 6 sigma^5 s^6 ; d(dE/ds)/d sigma = 36 sigma^5 s^5 (mask and clip are piecewise constant)
+            const float s5 = s2 * s2 * s, sg5 = sig * sig * sig * sig * sig;
+            const float de = pass ? 6.0f * sg5 * s5 * s : 0.0f;
+            const float dd_ds = pass ? 36.0f * sg5 * s5 : 0.0f;
+            dd[0] = make_float4(geo * dd_ds * f.tx, geo * dd_ds * f.ty, geo * dd_ds * f.tz, de);
+        } else { // RINV_POLY: linear in the coefficients
+            e = 0.0f;
+            dEds = 0.0f;
+#pragma unroll
+            for (int k = 0; k < P; ++k) {
+                if (k < p.n_terms) {
+                    int pw = p.power[k] - 1;
+                    float b = s, acc = 1.0f;
+                    while (pw > 0) {
+                        if (pw & 1) acc *= b;
+                        b *= b;
+                        pw >>= 1;
+                    }
+                    const float dk = (float)p.power[k] * acc; // d(dE/ds)/dc_k
+                    const float ek = acc * s;                 // d e / d c_k
+                    dEds += p.coef[k] * dk;
+                    e += p.coef[k] * ek;
+                    dd[k] = make_float4(geo * dk * f.tx, geo * dk * f.ty, geo * dk * f.tz, f.cond ? ek : 0.0f);
+                }
+            }
+        }
+        const float c = geo * dEds;
+        fx = c * f.tx; fy = c * f.ty; fz = c * f.tz;
+        if (!f.cond) e = 0.0f;
+    }
+}
 
 // simmodel.py:509-523 per-slot virial term: -(|nf| / (2 |x|)) x (x) x with divide_no_nan
 struct Virial6 {

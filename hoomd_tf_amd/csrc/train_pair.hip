@@ -1,0 +1,216 @@
+// Online training of the closed-form trainable potentials (FORCE_MODE::hoomd2tf).
+//
+// Reference: tfcompute._finish_update(train) -> model.train_on_batch(x=inputs, y=labels)
+// (tensorflowcompute.py:347-370) with loss MeanSquaredError over the [B, 4] force/energy
+// columns; Keras differentiates the loss through compute_nlist_forces, i.e. through a
+// gradient (second order).  For the parametric pair potentials the parameter-derivative of
+// the per-slot force is closed form, so one sweep over the pair vectors accumulates, per
+// particle row, the prediction F_i (4 values) AND J_i = d F_i / d theta (4 x P values) in
+// registers; after the row reduction  d(sum res^2)/d theta_k = 2 sum_c (F_ic - Y_ic) J_ick.
+// Per-block partials are written in a fixed order and reduced by one block (deterministic);
+// the optimizer (Keras SGD / Adam / Nadam rules + NonNeg + L1 regulariser) is a one-thread
+// kernel on the device parameter vector that every evaluation kernel reads at launch.
+#include <cmath>
+
+#include "htf_common.h"
+#include "htf_internal.h"
+#include "pair_math.h"
+
+namespace htf {
+
+constexpr int kTrainG = 16; // lanes per row (as the evaluator at NN = 128); smaller NN just idle lanes
+
+template <int KIND, typename IT>
+__global__ __launch_bounds__(256) void train_pair_kernel(const typename Vec4<IT>::type *__restrict__ nlist, unsigned B,
+                                                         unsigned NN, const void *__restrict__ labels, int lab_f64,
+                                                         void *__restrict__ pred, PotParams pin,
+                                                         float *__restrict__ partials) {
+    constexpr int G = kTrainG, RPW = 64 / G, P = NumParams<KIND>::value;
+    __shared__ float s_part[4][1 + P];
+    const PotParams p = resolve_theta(pin);
+    const unsigned lane = threadIdx.x & 63u, g = lane % G, sub = lane / G;
+    const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const unsigned row = wave * RPW + sub;
+    const bool active = row < B;
+    const typename Vec4<IT>::type *rp = nlist + (size_t)(active ? row : B - 1) * NN;
+    float F[4] = {0.f, 0.f, 0.f, 0.f};
+    float4 J[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) J[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (unsigned j = g; j < NN; j += G) {
+        auto v = rp[j];
+        float e, fx, fy, fz;
+        float4 dd[P];
+        pair_eval_grad<KIND>((float)v.x, (float)v.y, (float)v.z, p, e, fx, fy, fz, dd);
+        F[0] += fx; F[1] += fy; F[2] += fz; F[3] += e;
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+            J[k].x += dd[k].x; J[k].y += dd[k].y; J[k].z += dd[k].z; J[k].w += dd[k].w;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) F[c] = group_sum<G>(F[c]);
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+        J[k].x = group_sum<G>(J[k].x); J[k].y = group_sum<G>(J[k].y);
+        J[k].z = group_sum<G>(J[k].z); J[k].w = group_sum<G>(J[k].w);
+    }
+    float out[1 + P];
+#pragma unroll
+    for (int k = 0; k <= P; ++k) out[k] = 0.f;
+    if (g == 0 && active) {
+        float Y[4];
+        if (lab_f64) {
+            const double4 y = ((const double4 *)labels)[row];
+            Y[0] = (float)y.x; Y[1] = (float)y.y; Y[2] = (float)y.z; Y[3] = (float)y.w;
+        } else {
+            const float4 y = ((const float4 *)labels)[row];
+            Y[0] = y.x; Y[1] = y.y; Y[2] = y.z; Y[3] = y.w;
+        }
+        const float r0 = F[0] - Y[0], r1 = F[1] - Y[1], r2 = F[2] - Y[2], r3 = F[3] - Y[3];
+        out[0] = r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3;
+#pragma unroll
+        for (int k = 0; k < P; ++k) out[1 + k] = 2.0f * (r0 * J[k].x + r1 * J[k].y + r2 * J[k].z + r3 * J[k].w);
+        if (pred != nullptr) ((float4 *)pred)[row] = make_float4(F[0], F[1], F[2], F[3]);
+    }
+    // block partial: rows of a wave (lanes with g == 0), then the four waves, fixed order
+#pragma unroll
+    for (int k = 0; k <= P; ++k) {
+        float v = out[k];
+        for (int m = G; m < 64; m <<= 1) v += __shfl_xor(v, m);
+        if (lane == 0) s_part[threadIdx.x >> 6][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x <= (unsigned)P)
+        partials[(size_t)blockIdx.x * (1 + P) + threadIdx.x] =
+            (s_part[0][threadIdx.x] + s_part[1][threadIdx.x]) + (s_part[2][threadIdx.x] + s_part[3][threadIdx.x]);
+}
+
+// accum[w] = sum_b partials[b][w]  (one block, fixed order, fp64 accumulation)
+__global__ __launch_bounds__(1024) void reduce_columns_kernel(const float *__restrict__ partials, unsigned nblocks,
+                                                              unsigned width, float *__restrict__ accum) {
+    __shared__ double s[16];
+    for (unsigned w = 0; w < width; ++w) {
+        double acc = 0.0;
+        for (unsigned b = threadIdx.x; b < nblocks; b += 1024) acc += (double)partials[(size_t)b * width + w];
+        for (int m = 1; m < 64; m <<= 1) acc += __shfl_xor(acc, m);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+            for (int i = 0; i < 16; ++i) t += s[i];
+            accum[w] = (float)t;
+        }
+    }
+}
+
+template <int KIND>
+static int launch_train(const PotParams &p, const void *nlist, int in_dtype, unsigned B, unsigned NN,
+                        const void *labels, int lab_f64, void *pred, float *accum, float *scratch, hipStream_t s) {
+    constexpr unsigned rows_per_block = 4 * (64 / kTrainG);
+    constexpr unsigned width = 1 + NumParams<KIND>::value;
+    const unsigned grid = (B + rows_per_block - 1) / rows_per_block;
+    if (in_dtype == HTF_F32)
+        hipLaunchKernelGGL((train_pair_kernel<KIND, float>), dim3(grid), dim3(256), 0, s, (const float4 *)nlist, B, NN, labels, lab_f64, pred, p, scratch);
+    else
+        hipLaunchKernelGGL((train_pair_kernel<KIND, double>), dim3(grid), dim3(256), 0, s, (const double4 *)nlist, B, NN, labels, lab_f64, pred, p, scratch);
+    int rc = check_launch("train_pair_kernel");
+    if (rc != HTF_OK) return rc;
+    hipLaunchKernelGGL(reduce_columns_kernel, dim3(1), dim3(1024), 0, s, scratch, grid, width, accum);
+    return check_launch("reduce_columns_kernel");
+}
+
+int potential_num_params(const PotParams &p) {
+    switch (p.kind) {
+    case HTF_POT_LJ_PARAM: return 2;
+    case HTF_POT_WCA: return 1;
+    case HTF_POT_RINV_POLY: return p.n_terms;
+    default: return 0;
+    }
+}
+
+static unsigned train_width(const PotParams &p) {
+    switch (p.kind) {
+    case HTF_POT_LJ_PARAM: return 3;
+    case HTF_POT_WCA: return 2;
+    default: return 1 + HTF_MAX_POLY_TERMS;
+    }
+}
+
+size_t train_scratch_floats(const PotParams &p, unsigned B, unsigned NN) {
+    (void)NN;
+    const unsigned rows_per_block = 4 * (64 / kTrainG);
+    return (size_t)((B + rows_per_block - 1) / rows_per_block) * train_width(p);
+}
+
+int train_pair_dispatch(const PotParams &p, const void *nlist, int in_dtype, unsigned B, unsigned NN,
+                        const void *labels, int label_dtype, void *pred, float *accum, float *scratch,
+                        hipStream_t stream) {
+    const int lab_f64 = label_dtype == HTF_F64;
+    switch (p.kind) {
+    case HTF_POT_LJ_PARAM: return launch_train<HTF_POT_LJ_PARAM>(p, nlist, in_dtype, B, NN, labels, lab_f64, pred, accum, scratch, stream);
+    case HTF_POT_WCA: return launch_train<HTF_POT_WCA>(p, nlist, in_dtype, B, NN, labels, lab_f64, pred, accum, scratch, stream);
+    case HTF_POT_RINV_POLY: return launch_train<HTF_POT_RINV_POLY>(p, nlist, in_dtype, B, NN, labels, lab_f64, pred, accum, scratch, stream);
+    default:
+        set_error("htf_train_pair_grad: potential kind %d has no trainable closed form (pair-MLP training: next round)", p.kind);
+        return HTF_ERR_INVALID;
+    }
+}
+
+// tf.keras.optimizers.{SGD, Adam, Nadam} (TF 2.3/2.4 optimizer_v2 update rules)
+__global__ void optimizer_kernel(float *__restrict__ theta, unsigned P, const float *__restrict__ accum, float scale,
+                                 float *__restrict__ st, htf_optimizer_desc d) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float *m = st, *v = st + 8;
+    float t = st[16] + 1.0f;
+    float m_sched = st[17] == 0.0f ? 1.0f : st[17];
+    const float loss = accum[0] * scale;
+    st[18] += loss;
+    st[19] += 1.0f;
+    st[20] = loss;
+    const float b1 = d.beta1, b2 = d.beta2;
+    float u_t = 0.f, u_t1 = 0.f, m_sched_new = m_sched, m_sched_next = m_sched;
+    if (d.kind == HTF_OPT_NADAM) { // Nadam._prepare_local: momentum schedule, decay base 0.96, 0.004
+        u_t = b1 * (1.0f - 0.5f * powf(0.96f, 0.004f * t));
+        u_t1 = b1 * (1.0f - 0.5f * powf(0.96f, 0.004f * (t + 1.0f)));
+        m_sched_new = m_sched * u_t;
+        m_sched_next = m_sched_new * u_t1;
+    }
+    for (unsigned k = 0; k < P; ++k) {
+        const float g = accum[1 + k] * scale + d.l1_reg[k];
+        float th = theta[k];
+        if (d.kind == HTF_OPT_SGD) {
+            th -= d.lr * g;
+        } else if (d.kind == HTF_OPT_ADAM) {
+            const float lr_t = d.lr * sqrtf(1.0f - powf(b2, t)) / (1.0f - powf(b1, t));
+            m[k] += (g - m[k]) * (1.0f - b1);
+            v[k] += (g * g - v[k]) * (1.0f - b2);
+            th -= lr_t * m[k] / (sqrtf(v[k]) + d.epsilon);
+        } else {
+            const float g_prime = g / (1.0f - m_sched_new);
+            m[k] = b1 * m[k] + (1.0f - b1) * g;
+            const float m_prime = m[k] / (1.0f - m_sched_next);
+            v[k] = b2 * v[k] + (1.0f - b2) * g * g;
+            const float v_prime = v[k] / (1.0f - powf(b2, t));
+            const float m_bar = (1.0f - u_t) * g_prime + u_t1 * m_prime;
+            th -= d.lr * m_bar / (sqrtf(v_prime) + d.epsilon);
+        }
+        if ((d.nonneg_mask >> k) & 1u) th = fmaxf(th, 0.0f); // tf.keras.constraints.NonNeg
+        theta[k] = th;
+    }
+    st[16] = t;
+    st[17] = m_sched_new;
+}
+
+} // namespace htf
+
+extern "C" int htf_optimizer_step(float *d_theta, unsigned P, const float *d_accum, float scale, float *d_state,
+                                  const htf_optimizer_desc *desc, htf_stream stream) {
+    using namespace htf;
+    HTF_REQUIRE(d_theta && d_accum && d_state && desc, "htf_optimizer_step: null pointer");
+    HTF_REQUIRE(P >= 1 && P <= 8, "htf_optimizer_step: P=%u outside [1, 8]", P);
+    HTF_REQUIRE(desc->kind >= HTF_OPT_SGD && desc->kind <= HTF_OPT_NADAM, "htf_optimizer_step: unknown optimizer %d", desc->kind);
+    hipLaunchKernelGGL(optimizer_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d_theta, P, d_accum, scale, d_state, *desc);
+    return check_launch("optimizer_kernel");
+}

@@ -36,17 +36,76 @@ class RBFExpansion:
 
 class WCARepulsion:
     """layers.py:52-98: trainable WCA repulsion ``(sigma/r)^6`` inside ``2^(1/3) sigma``,
-    clipped to [0, 10].  Called on the neighbor list; returns the pair energy."""
+    clipped to [0, 10].  Called on the neighbor list; returns the pair energy.  ``sigma`` is
+    a trainable scalar weight with regulariser ``-regularization_strength * sigma``; it lives
+    on the device once the layer takes part in training."""
+    name = 'wca-repulsion'
 
     def __init__(self, sigma, regularization_strength=1e-3):
-        self.sigma = float(np.float32(sigma))
+        self._sigma0 = float(np.float32(sigma))
         self.regularization_strength = regularization_strength
+        self.w = None  # device weight, created on first training use
+
+    @property
+    def sigma(self):
+        return float(self.w[0]) if self.w is not None else self._sigma0
 
     def get_config(self):
         return {'sigma': float(self.sigma)}
 
+    # trainable-layer protocol used by tfcompute's training step
+    nonneg_mask = 0
+
+    @property
+    def l1_reg(self):
+        return (-float(self.regularization_strength),)
+
+    def make_trainable(self, device):
+        if self.w is None:
+            self.w = torch.tensor([self._sigma0], dtype=torch.float32, device=device)
+        return self.w
+
+    @property
+    def trainable_weights(self):
+        return [self.w] if self.w is not None else []
+
+    def potential(self):
+        return ops.Potential.wca(self.sigma, theta=self.w)
+
     def __call__(self, nlist):
-        return simmodel.WCAPair(simmodel._as_nlist(nlist), self.sigma)
+        return simmodel.WCAPair(simmodel._as_nlist(nlist), self.sigma, layer=self)
+
+
+class LJLayer:
+    """The trainable Lennard-Jones layer of example 06 and build_examples.py:336-359: weights
+    ``w = [sig, eps]`` (NonNeg constraint); called on ``r = safe_norm(nlist[:, :, :3], axis=2)``
+    it returns the pair energy ``w[0] * 4 * (r6**2 - r6) / 2`` with ``r6 = w[1]**6 / r**6``."""
+    name = 'lj'
+    nonneg_mask = 0b11
+    l1_reg = (0.0, 0.0)
+
+    def __init__(self, sig, eps, device="cuda"):
+        self.start = [sig, eps]
+        self.w = torch.tensor([sig, eps], dtype=torch.float32, device=device)
+
+    def get_config(self):
+        return {'sig': self.start[0], 'eps': self.start[1]}
+
+    def make_trainable(self, device):
+        return self.w
+
+    @property
+    def trainable_weights(self):
+        return [self.w]
+
+    def potential(self):
+        w = self.w.cpu().numpy()
+        return ops.Potential.lj_param(float(w[0]), float(w[1]), theta=self.w)
+
+    def __call__(self, r):
+        if not isinstance(r, simmodel.SafeNorm):
+            raise ValueError("LJLayer expects r = safe_norm(nlist[:, :, :3], axis=2)")
+        return simmodel.LJParamEnergy(r.nlist, self)
 
 
 class SoftRDFCV:

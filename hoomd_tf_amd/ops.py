@@ -45,11 +45,17 @@ class Potential:
     """Owns an ``htf_potential`` handle (device copies of any weights)."""
 
     def __init__(self, kind, sigma=0.0, coefs=(), powers=(), mlp=None, rbf=(0.0, 0.0),
-                 activation="linear", mlp_precision="fp32", gauss=(0.0, 1.0, 0.0)):
+                 activation="linear", mlp_precision="fp32", gauss=(0.0, 1.0, 0.0), lj_param=(1.0, 1.0),
+                 theta=None):
         d = _lib.PotentialDesc()
         d.kind = kind
         d.sigma = float(sigma)
         d.gauss_r0, d.gauss_gap, d.gauss_coef = (float(x) for x in gauss)
+        d.lj_w0, d.lj_w1 = float(lj_param[0]), float(lj_param[1])
+        self.theta = theta  # device parameter vector of a trainable potential (kept alive here)
+        if theta is not None:
+            _dev(theta, "theta", torch.float32)
+            d.d_theta = theta.data_ptr()
         d.n_terms = len(coefs)
         if len(coefs) != len(powers):
             raise ValueError("coefs and powers differ in length")
@@ -90,16 +96,25 @@ class Potential:
         return cls(_lib.POT_LJ)
 
     @classmethod
-    def wca(cls, sigma):
-        return cls(_lib.POT_WCA, sigma=sigma)
+    def wca(cls, sigma, theta=None):
+        return cls(_lib.POT_WCA, sigma=sigma, theta=theta)
 
     @classmethod
     def simple(cls):
         return cls(_lib.POT_SIMPLE)
 
     @classmethod
-    def rinv_poly(cls, coefs, powers):
-        return cls(_lib.POT_RINV_POLY, coefs=coefs, powers=powers)
+    def rinv_poly(cls, coefs, powers, theta=None):
+        return cls(_lib.POT_RINV_POLY, coefs=coefs, powers=powers, theta=theta)
+
+    @classmethod
+    def lj_param(cls, w0, w1, theta=None):
+        """Trainable LJ of example 06: e = w0 * 4 (q^2 - q) / 2, q = w1^6 / safe_norm(x)^6."""
+        return cls(_lib.POT_LJ_PARAM, lj_param=(w0, w1), theta=theta)
+
+    @property
+    def num_params(self):
+        return int(lib.htf_potential_num_params(self._h))
 
     @classmethod
     def gauss(cls, r0, gap, coef=1.0):
@@ -209,6 +224,34 @@ def bias_combine(force, bias, alpha, cv):
     check(lib.htf_bias_combine(force.data_ptr(), bias.data_ptr(), alpha.data_ptr(), cv.data_ptr(), _dt(force),
                                int(force.shape[0]), _stream(force)))
     return force
+
+
+def train_pair_grad(potential, nlist, labels, pred=None, accum=None):
+    """One training sweep (train_on_batch's forward + gradient for MSE over [B, 4]): returns
+    accum [1 + P] = {sum of squared residuals, d/dtheta_k} on the device (and fills ``pred``)."""
+    _dev(nlist, "nlist")
+    _dev(labels, "labels")
+    B, NN = int(nlist.shape[0]), int(nlist.shape[1])
+    P = potential.num_params
+    if P == 0:
+        raise ValueError("this potential has no trainable parameters")
+    if accum is None:
+        accum = torch.empty(1 + P, dtype=torch.float32, device=nlist.device)
+    scratch = torch.empty(int(lib.htf_train_scratch_floats(potential.handle, B, NN)), dtype=torch.float32,
+                          device=nlist.device)
+    if pred is not None:
+        _dev(pred, "pred", torch.float32)
+    check(lib.htf_train_pair_grad(potential.handle, nlist.data_ptr(), _dt(nlist), B, NN, labels.data_ptr(), _dt(labels),
+                                  pred.data_ptr() if pred is not None else None, accum.data_ptr(), scratch.data_ptr(),
+                                  _stream(nlist)))
+    return accum
+
+
+def optimizer_step(theta, accum, scale, state, desc):
+    """Keras SGD / Adam / Nadam step on the device parameter vector (no host round trip)."""
+    check(lib.htf_optimizer_step(theta.data_ptr(), int(theta.numel()), accum.data_ptr(), float(scale),
+                                 state.data_ptr(), C.byref(desc), _stream(theta)))
+    return theta
 
 
 def add_virial(dest, src9, N, pitch):

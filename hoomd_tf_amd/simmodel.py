@@ -166,14 +166,37 @@ class RinvPoly(PairEnergy):
 class WCAPair(PairEnergy):
     """WCARepulsion(sigma)(nlist): layers.py:91-98."""
 
-    def __init__(self, nlist, sigma):
-        self.nlist, self.sigma = nlist, float(sigma)
+    def __init__(self, nlist, sigma, layer=None):
+        self.nlist, self.sigma, self.layer = nlist, float(sigma), layer
 
     def key(self):
+        if self.layer is not None and self.layer.w is not None:
+            return ("wca-trainable", id(self.layer))
         return ("wca", self.sigma)
 
     def potential(self):
+        if self.layer is not None and self.layer.w is not None:
+            return self.layer.potential()
         return ops.Potential.wca(self.sigma)
+
+
+class LJParamEnergy(PairEnergy):
+    """LJLayer(r): the trainable LJ pair energy of example 06 (per pair; reduce_sum(axis=1)
+    gives the per-particle energy)."""
+
+    def __init__(self, nlist, layer, reduced=False):
+        self.nlist, self.layer, self.reduced = nlist, layer, reduced
+
+    def key(self):
+        return ("ljparam", id(self.layer))
+
+    def potential(self):
+        return self.layer.potential()
+
+    def tensor(self):
+        _trace_log().append({"op": "eager_value"})
+        f = ops.eval_forces(self.layer.potential(), self.nlist.tensor)
+        return f[:, 3].clone()
 
 
 class MLPEnergy(PairEnergy):
@@ -290,6 +313,8 @@ def reduce_sum(x, axis=None):
         return RinvPoly(x.nlist, x.terms, reduced=True)
     if isinstance(x, WCAPair):
         return x
+    if isinstance(x, LJParamEnergy):
+        return LJParamEnergy(x.nlist, x.layer, reduced=True)
     return x.sum() if axis is None else x.sum(dim=axis)
 
 
@@ -335,7 +360,8 @@ def compute_nlist_forces(nlist, energy, virial=False):
         pot = cache[k] = energy.potential()
     out = ops.eval_forces(pot, nl.tensor, virial=virial)
     f = out[0] if virial else out
-    _trace_log().append({"potential": pot, "nlist": nl, "virial": virial, "forces": f})
+    _trace_log().append({"potential": pot, "nlist": nl, "virial": virial, "forces": f,
+                         "layer": getattr(energy, "layer", None)})
     return out
 
 
@@ -460,6 +486,20 @@ def rdf_from_histogram(hist, r0, r1):
     return rdf, rs
 
 
+class _LossMetric:
+    """model.metrics[0]: running mean of the training loss (kept on the device by the
+    optimizer kernel; read back only when asked)."""
+    name = 'loss'
+
+    def __init__(self):
+        self.state = None
+
+    def result(self):
+        if self.state is None or float(self.state[19]) == 0:
+            return torch.tensor(0.0)
+        return (self.state[18] / self.state[19]).cpu()
+
+
 # --------------------------------------------------------------------------- SimModel
 class SimModel:
     """simmodel.py:8-145.  Subclass and implement ``compute``; optionally ``setup``."""
@@ -485,7 +525,21 @@ class SimModel:
         except AttributeError:
             raise AttributeError('SimModel child class must implement compute method, and should not implement call')
         self.batch_steps = 0
+        self.optimizer = None
+        self.metrics = []
         self.setup(**kwargs)
+
+    def compile(self, optimizer='rmsprop', loss=None, **kwargs):
+        """tf.keras.Model.compile for the training path (tensorflowcompute.py:83-95 reads
+        ``model.loss``).  Losses: 'MeanSquaredError' (or a list whose first entry is it and the
+        rest None, as example 06 passes)."""
+        from . import optimizers
+        self.optimizer = optimizers.get(optimizer)
+        first = loss[0] if isinstance(loss, (list, tuple)) else loss
+        if first not in ('MeanSquaredError', 'mse', 'mean_squared_error'):
+            raise ValueError("loss %r is not built; available: 'MeanSquaredError'" % (first,))
+        self.loss = list(loss) if isinstance(loss, (list, tuple)) else [loss]
+        self.metrics = [_LossMetric()]
 
     def get_config(self):
         return {'nneighbor_cutoff': self.nneighbor_cutoff, 'output_forces': self.output_forces,

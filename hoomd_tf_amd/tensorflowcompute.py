@@ -53,10 +53,19 @@ class tfcompute:
         if self.model.virial:
             self._output_offset = 2
         if train:
+            # figure out from losses (tensorflowcompute.py:87-95)
             if getattr(self.model, 'loss', None) is None:
                 raise ValueError('SimModel has not been compiled')
-            raise NotImplementedError('FORCE_MODE::hoomd2tf (online training) is the next row of SURVEY 8(f)')
+            for i, l in enumerate(self.model.loss):
+                if l is None:
+                    break
+            else:
+                i = len(self.model.loss)
+            self._output_offset = i
         self.train = train
+        self._ref_forces = []
+        self._labels = None
+        self._opt_state = None
         self.nneighbor_cutoff = self.model.nneighbor_cutoff
         if nlist is not None:
             nlist.subscribe(self.rcut)
@@ -90,7 +99,10 @@ class tfcompute:
         """tensorflowcompute.py:265-282."""
         if self.force_mode_code == _lib.HTF_TF2HOOMD:
             raise ValueError('Only valid to set reference forces if mode is hoomd2tf')
-        raise NotImplementedError('reference-force labels belong to the training row (SURVEY 8(f)-1)')
+        for f in forces:
+            if not hasattr(f, 'force') and not hasattr(f, 'cpp_force'):
+                raise ValueError('given force does not seem like a hoomd force')
+            self._ref_forces.append(f)
 
     # ------------------------------------------------------------------ per step
     def _arrays(self):
@@ -114,6 +126,8 @@ class tfcompute:
         s = self.system
         bs = s.N if self.batch_size == 0 else self.batch_size
         simmodel._trace_log().clear()
+        if self.train:
+            self._stage_labels()
         nbatch = 0
         for i in range(s.N // bs + 1):
             offset = i * bs
@@ -122,7 +136,53 @@ class tfcompute:
                 break
             self._finish_update(i, offset, n)
             nbatch += 1
-        self._maybe_install_plan(nbatch)
+        if not self.train:
+            self._maybe_install_plan(nbatch)
+        simmodel._trace_log().clear()
+
+    def _stage_labels(self):
+        """TensorflowCompute.cc:177-187: labels = HOOMD net force, or the sum of the selected
+        reference forces (sumReferenceForces, :250-269), staged once per step for all batches."""
+        s = self.system
+        if not self._ref_forces:
+            self._labels = self.sim.net_force
+        else:
+            lab = self._ref_forces[0].force.clone()
+            for f in self._ref_forces[1:]:
+                ops.add_scalar4(lab, f.force)
+            self._labels = lab
+
+    def _train_on_batch(self, nlist_t, offset, n, fused_entries):
+        """model.train_on_batch(x=inputs, y=labels) (tensorflowcompute.py:366-370) for a model
+        whose forces come from one trainable closed-form layer: loss + parameter gradient in
+        one sweep (htf_train_pair_grad), optimizer step on the device (htf_optimizer_step)."""
+        entries = [e for e in fused_entries if e.get("layer") is not None]
+        m = self.model
+        if self._opt_state is None:
+            self._opt_state = torch.zeros(_lib.OPT_STATE_FLOATS, dtype=torch.float32, device=self.system.device)
+            if m.metrics:
+                m.metrics[0].state = self._opt_state
+        if not entries:
+            # no trainable weights (test_force_output trains LJModel): train_on_batch only
+            # evaluates the loss; O(N) elementwise on the [n, 4] prediction
+            if not fused_entries:
+                raise ValueError('training needs the model forces to come from compute_nlist_forces')
+            d = fused_entries[-1]["forces"].to(torch.float32) - self._labels[offset:offset + n].to(torch.float32)
+            self._opt_state[18] += (d * d).mean()
+            self._opt_state[19] += 1.0
+            return
+        if len(entries) != 1:
+            raise ValueError('training needs exactly one compute_nlist_forces over a trainable layer '
+                             '(LJLayer, WCARepulsion); found %d' % len(entries))
+        layer = entries[0]["layer"]
+        theta = layer.make_trainable(self.system.device)
+        pot = layer.potential()
+        if getattr(self, "_opt_desc", None) is None:
+            self._opt_desc = m.optimizer.desc(layer.nonneg_mask, layer.l1_reg)
+        labels = self._labels[offset:offset + n]
+        accum = ops.train_pair_grad(pot, nlist_t, labels)
+        ops.optimizer_step(theta, accum, 1.0 / (4.0 * n), self._opt_state, self._opt_desc)
+        self._train_potential = pot  # keep alive until the stream has consumed it
 
     def _maybe_install_plan(self, nbatch):
         log = simmodel._trace_log()
@@ -153,6 +213,7 @@ class tfcompute:
         inputs = m.compute_inputs(nlist_t, pos_t, box_t)
         mark = len(simmodel._trace_log())
         output = m(inputs, self.train)
+        fused_entries = [e for e in simmodel._trace_log()[mark:] if "potential" in e]
         for e in simmodel._trace_log()[mark:]:
             if "forces" in e and len(output) > 0 and output[0] is e["forces"] and e["nlist"] is inputs[0]:
                 e["is_output"] = True
@@ -162,6 +223,9 @@ class tfcompute:
                 self.outputs = extra
             else:
                 self.outputs = [np.append(o1, o2, axis=0) for o1, o2 in zip(self.outputs, extra)]
+        if self.train:
+            self._train_on_batch(nlist_t, offset, n, fused_entries)
+            return
         if self.force_mode_code == _lib.HTF_TF2HOOMD:
             f = SimModel.compute_outputs(_t(output[0]), s.dtype)
             self.force[offset:offset + n] = f

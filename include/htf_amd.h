@@ -70,8 +70,10 @@ enum htf_potential_kind {
     HTF_POT_RINV_POLY = 3, /* E_i = sum_j sum_k coef_k * rinv^power_k (BenchmarkPotential :25-30, example 01) */
     HTF_POT_SIMPLE = 4,    /* build_examples.py:9-22 SimplePotential (forward only) */
     HTF_POT_PAIR_MLP = 5,  /* safe_norm -> RBFExpansion -> Dense-Dense-Dense */
-    HTF_POT_GAUSS = 6      /* e = c * exp(-(r - r0)^2 / gap) * [r > 3e-6], r = safe_norm(x): one RBFExpansion
+    HTF_POT_GAUSS = 6,     /* e = c * exp(-(r - r0)^2 / gap) * [r > 3e-6], r = safe_norm(x): one RBFExpansion
                             * channel (layers.py:46-49) as a pair energy -- the soft RDF bin of config C4 */
+    HTF_POT_LJ_PARAM = 7   /* trainable LJ of example 06 / build_examples.py:336-372 (LJLayer): r = safe_norm(x),
+                            * q = w1^6 / r^6 (divide_no_nan), e = w0 * 4 (q^2 - q) / 2; params (w0, w1) */
 };
 
 enum htf_activation { HTF_ACT_LINEAR = 0, HTF_ACT_TANH = 1 };
@@ -85,6 +87,12 @@ typedef struct htf_potential_desc {
     double sigma;
     /* GAUSS */
     double gauss_r0, gauss_gap, gauss_coef;
+    /* LJ_PARAM start values */
+    double lj_w0, lj_w1;
+    /* Trainable potentials (LJ_PARAM: w0, w1; WCA: sigma; RINV_POLY: coef[0..n_terms)): optional
+     * DEVICE parameter vector, read by the kernels at launch instead of the host values above,
+     * so that an optimizer step on the device is seen by the next evaluation.  Borrowed. */
+    const float *d_theta;
     /* RINV_POLY */
     int n_terms;
     double coef[HTF_MAX_POLY_TERMS];
@@ -167,6 +175,35 @@ HTF_API int htf_reduce_partials(const float *d_partials, unsigned n, float scale
  * a rank-0 energy term is tiled into every particle's energy column). */
 HTF_API int htf_bias_combine(void *d_force, const void *d_bias, const float *d_alpha, const float *d_cv,
                      int dtype, unsigned N, htf_stream stream);
+
+/* ---- online training, FORCE_MODE::hoomd2tf (tensorflowcompute.py:347-370) ----
+ * One pass over the pair vectors of a batch for a trainable closed-form potential:
+ * predicted [F, E] per particle, residual against the labels (HOOMD net / reference forces,
+ * Scalar4), and d(sum of squared residuals)/d(theta) through the force.  d_accum [1 + P] floats
+ * (P = htf_potential_num_params) receives {sum_i sum_c res_ic^2, d/dtheta_0, ...}; it is
+ * OVERWRITTEN.  d_pred (nullable): the predicted forces [B] Scalar4.  d_scratch: at least
+ * htf_train_scratch_floats(pot, B, NN) floats.  Keras 'MeanSquaredError' over the [B, 4]
+ * batch is accum[0] / (4 B). */
+HTF_API int htf_potential_num_params(const htf_potential *pot);
+HTF_API size_t htf_train_scratch_floats(const htf_potential *pot, unsigned B, unsigned NN);
+HTF_API int htf_train_pair_grad(const htf_potential *pot, const void *d_nlist, int nlist_dtype,
+                        unsigned B, unsigned NN, const void *d_labels, int label_dtype,
+                        void *d_pred, float *d_accum, float *d_scratch, htf_stream stream);
+
+enum htf_optimizer_kind { HTF_OPT_SGD = 0, HTF_OPT_ADAM = 1, HTF_OPT_NADAM = 2 };
+typedef struct htf_optimizer_desc {
+    int kind;                  /* tf.keras.optimizers.{SGD, Adam, Nadam} update rules */
+    float lr, beta1, beta2, epsilon;
+    unsigned nonneg_mask;      /* bit k: tf.keras.constraints.NonNeg on theta_k            */
+    float l1_reg[8];           /* d(regulariser)/d(theta_k) added to the gradient (WCARepulsion: -strength) */
+} htf_optimizer_desc;
+#define HTF_OPT_STATE_FLOATS 24 /* m[8], v[8], t, nadam m_schedule, loss_sum, n_steps, last_loss, pad */
+
+/* One optimizer step ON THE DEVICE: grad_k = scale * d_accum[1 + k] + l1_reg[k]; loss = scale *
+ * d_accum[0] is added to the running metric in d_state.  d_state: HTF_OPT_STATE_FLOATS floats,
+ * zero-initialised by the caller (m_schedule is set to 1 on the first step). */
+HTF_API int htf_optimizer_step(float *d_theta, unsigned P, const float *d_accum, float scale,
+                       float *d_state, const htf_optimizer_desc *desc, htf_stream stream);
 
 /* Replaces htf_gpu_add_virial (TensorflowCompute.cu:41-71; CPU .cc:284-301):
  * dest[c*pitch + i] += src[i*9 + {0,1,2,4,5,8}]. */

@@ -130,3 +130,40 @@ def eds_rdf_model(nlist, alpha, r0, gap):
     cv = phi.sum() / nlist.shape[0]
     energy = lj + alpha * cv
     return compute_nlist_forces(nlist, energy), cv.detach()
+
+
+def lj_param_forces(nlist, w, create_graph=False):
+    # example 06: LJLayer on safe_norm; divide_no_nan with TF's flush-to-zero == mask r > 3e-6
+    if not nlist.requires_grad:
+        nlist = nlist.clone().requires_grad_(True)
+    r = safe_norm(nlist[:, :, :3], dim=2)
+    mask = (r > RINV_DELTA)
+    rs = torch.where(mask, r, torch.ones_like(r))
+    r6 = torch.where(mask, w[1] ** 6 / rs ** 6, torch.zeros_like(r))
+    energy = (w[0] * 4.0 * (r6 ** 2 - r6) / 2.0).sum(dim=1)
+    (g,) = torch.autograd.grad(energy.sum(), nlist, create_graph=create_graph)
+    return _add_energy((g * 2.0).sum(dim=1), energy)
+
+
+def mse_grad_wrt_params(forces_fn, nlist, labels, theta):
+    """d(MeanSquaredError over [B,4])/d(theta) by double backward: what Keras' train_on_batch
+    computes for a model whose output comes from compute_nlist_forces."""
+    w = torch.tensor(theta, dtype=nlist.dtype, requires_grad=True)
+    pred = forces_fn(nlist.clone().requires_grad_(True), w)
+    loss = ((pred - labels) ** 2).mean()
+    (g,) = torch.autograd.grad(loss, w)
+    return float(loss.detach()), g.numpy()
+
+
+def wca_param_forces(nlist, w, create_graph=False):
+    # WCARepulsion with sigma = w[0] as a differentiable parameter (layers.py:91-98)
+    if not nlist.requires_grad:
+        nlist = nlist.clone().requires_grad_(True)
+    rinv = nlist_rinv(nlist)
+    rp = (w[0] * rinv) ** 6
+    n3 = nlist[:, :, :3]
+    r = torch.sqrt(torch.sum(n3 * n3, dim=2)).detach()
+    e = (r < w[0].detach() * 2 ** (1 / 3)).to(nlist.dtype) * rp  # float cast of a comparison: no gradient
+    e = torch.clamp(e, 0, 10)
+    (g,) = torch.autograd.grad(e.sum(), nlist, create_graph=create_graph)
+    return _add_energy((g * 2.0).sum(dim=1), e)

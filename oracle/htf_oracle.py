@@ -444,6 +444,84 @@ def pair_mlp_model(nlist, params, low=0.0, high=3.0, act="tanh", return_grad=Fal
     return nlist_forces_from_grad(nlist, g, E)
 
 
+def lj_param_model(nlist, w0, w1):
+    """Example 06 TrainableLJ / build_examples.py:336-372 LJLayer on r = safe_norm(x):
+    r6 = divide_no_nan(w1**6, r**6); e = w0 * 4 (r6^2 - r6) / 2.  TensorFlow's kernels flush the
+    padded slots' r**6 (~2.7e-41, an fp32 denormal) to zero, so divide_no_nan yields 0 there;
+    restated as the r > 3e-6 mask.  PARITY UNPINNED (no reference test pins its values)."""
+    dt = nlist.dtype
+    t = nlist[:, :, :3] + dt.type(1e-7)
+    r = np.sqrt(np.sum(t * t, axis=2))
+    mask = r > dt.type(RINV_DELTA)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        q = np.where(mask, (dt.type(w1) / r) ** 6, dt.type(0))
+        e = dt.type(2.0 * w0) * (q * q - q)
+        dedr = np.where(mask, dt.type(2.0 * w0) * (dt.type(2) * q - dt.type(1)) * (dt.type(-6) * q / r), dt.type(0))
+        g3 = np.where(mask[..., None], dedr[..., None] * t / r[..., None], dt.type(0))
+    g = np.zeros(nlist.shape, dtype=dt)
+    g[..., :3] = g3
+    return nlist_forces_from_grad(nlist, g, e.sum(axis=1))
+
+
+def mse_loss(pred, labels):
+    """Keras 'MeanSquaredError' over the [B, 4] force/energy columns (running.rst:68-71)."""
+    d = np.asarray(pred, dtype=np.float64) - np.asarray(labels, dtype=np.float64)
+    return float(np.mean(d * d))
+
+
+def fd_loss_grad(model_of_theta, theta, labels, h=1e-5):
+    """Central finite-difference d(MSE)/d(theta): the test-side check of the training kernels."""
+    theta = np.asarray(theta, dtype=np.float64)
+    g = np.zeros_like(theta)
+    for k in range(len(theta)):
+        tp, tm = theta.copy(), theta.copy()
+        tp[k] += h
+        tm[k] -= h
+        g[k] = (mse_loss(model_of_theta(tp), labels) - mse_loss(model_of_theta(tm), labels)) / (2 * h)
+    return g
+
+
+class KerasAdam:
+    """tf.keras.optimizers.Adam (optimizer_v2) update rule, numpy."""
+
+    def __init__(self, lr=1e-3, b1=0.9, b2=0.999, eps=1e-7):
+        self.lr, self.b1, self.b2, self.eps, self.t, self.m, self.v = lr, b1, b2, eps, 0, None, None
+
+    def step(self, theta, g):
+        if self.m is None:
+            self.m, self.v = np.zeros_like(theta), np.zeros_like(theta)
+        self.t += 1
+        lr_t = self.lr * math.sqrt(1 - self.b2 ** self.t) / (1 - self.b1 ** self.t)
+        self.m += (g - self.m) * (1 - self.b1)
+        self.v += (g * g - self.v) * (1 - self.b2)
+        return theta - lr_t * self.m / (np.sqrt(self.v) + self.eps)
+
+
+class KerasNadam:
+    """tf.keras.optimizers.Nadam (optimizer_v2) update rule, numpy."""
+
+    def __init__(self, lr=1e-3, b1=0.9, b2=0.999, eps=1e-7):
+        self.lr, self.b1, self.b2, self.eps, self.t, self.m, self.v, self.ms = lr, b1, b2, eps, 0, None, None, 1.0
+
+    def step(self, theta, g):
+        if self.m is None:
+            self.m, self.v = np.zeros_like(theta), np.zeros_like(theta)
+        self.t += 1
+        t = self.t
+        u_t = self.b1 * (1 - 0.5 * 0.96 ** (0.004 * t))
+        u_t1 = self.b1 * (1 - 0.5 * 0.96 ** (0.004 * (t + 1)))
+        ms_new = self.ms * u_t
+        ms_next = ms_new * u_t1
+        g_prime = g / (1 - ms_new)
+        self.m = self.b1 * self.m + (1 - self.b1) * g
+        m_prime = self.m / (1 - ms_next)
+        self.v = self.b2 * self.v + (1 - self.b2) * g * g
+        v_prime = self.v / (1 - self.b2 ** t)
+        m_bar = (1 - u_t) * g_prime + u_t1 * m_prime
+        self.ms = ms_new
+        return theta - self.lr * m_bar / (np.sqrt(v_prime) + self.eps)
+
+
 def gauss_pair_terms(nlist, r0, gap):
     """One RBFExpansion channel (layers.py:46-49) on r = safe_norm(x) (simmodel.py:581-594),
     masked with the nlist_rinv criterion (r > 3e-6).  Returns (phi [N,NN], g [N,NN,4]) with

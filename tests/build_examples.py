@@ -153,3 +153,20 @@ class EDSRDFModel(htf.SimModel):
         forces = htf.compute_nlist_forces(nlist, energy)
         rdf, rs = htf.compute_rdf(nlist, [0, 3.5])
         return forces, cv, alpha, rdf
+
+
+class TrainableGraph(htf.SimModel):
+    # build_examples.py:362-372 + example 06 TrainableLJ
+    def setup(self, sig=1.0, eps=1.0):
+        self.lj = htf.LJLayer(sig, eps)
+
+    def get_layer(self, name):
+        return {'lj': self.lj}[name]
+
+    def compute(self, nlist, positions, box):
+        # get r
+        r = htf.safe_norm(nlist[:, :, :3], axis=2)
+        p_energy = self.lj(r)
+        energy = htf.reduce_sum(p_energy, axis=1)
+        forces = htf.compute_nlist_forces(nlist, energy)
+        return forces, self.lj.w, energy

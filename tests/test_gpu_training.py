@@ -1,0 +1,180 @@
+"""Online training (FORCE_MODE::hoomd2tf) on the GPU: the loss/gradient sweep
+against torch double-backward and finite differences of the oracle, the device optimizers
+against the Keras update rules in numpy, and the reference's training tests re-run."""
+import numpy as np
+import pytest
+import torch
+
+import build_examples
+from helpers import random_nlist, sq_lattice
+from oracle import graph_torch as G
+from oracle import htf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(seed=0, N=300, NN=64):
+    rng = np.random.default_rng(seed)
+    nl, _ = random_nlist(rng, N, NN, fill=0.7, rmin=0.9, rmax=2.8, dtype=np.float32)
+    nl[0] = 0
+    return nl
+
+
+def test_lj_param_forward_and_loss_gradient(htf, cuda):
+    nl = _case()
+    nl64 = nl.astype(np.float64)
+    labels = O.lj_model(nl64)  # "HOOMD LJ" labels: eps = sig = 1
+    theta = [1.2, 0.9]
+    w = torch.tensor(theta, dtype=torch.float32, device=cuda)
+    pot = htf.Potential.lj_param(*theta, theta=w)
+    x = torch.from_numpy(nl).to(cuda)
+    # forward == the oracle restatement of example 06's LJLayer
+    f = htf.ops.eval_forces(pot, x).cpu().numpy()
+    ref = O.lj_param_model(nl64, *theta)
+    np.testing.assert_allclose(f, ref, rtol=2e-4, atol=2e-4 * np.abs(ref).max())
+    # the device weights are what the kernel reads: changing them changes the next launch
+    w[0] = 2.4
+    f2 = htf.ops.eval_forces(pot, x).cpu().numpy()
+    np.testing.assert_allclose(f2, 2 * f, rtol=1e-5, atol=1e-4)
+    w[0] = 1.2
+    # loss + gradient through the force
+    pred = torch.empty((nl.shape[0], 4), device=cuda)
+    accum = htf.ops.train_pair_grad(pot, x, torch.from_numpy(labels).to(cuda), pred=pred).cpu().numpy()
+    np.testing.assert_allclose(pred.cpu().numpy(), f, rtol=1e-5, atol=1e-4)
+    B = nl.shape[0]
+    loss, g = G.mse_grad_wrt_params(lambda n, ww: G.lj_param_forces(n, ww, create_graph=True),
+                                    torch.from_numpy(nl64), torch.from_numpy(labels), theta)
+    np.testing.assert_allclose(accum[0] / (4 * B), loss, rtol=1e-4)
+    np.testing.assert_allclose(accum[1:] / (4 * B), g, rtol=1e-3)
+    fd = O.fd_loss_grad(lambda t: O.lj_param_model(nl64, t[0], t[1]), theta, labels)
+    np.testing.assert_allclose(accum[1:] / (4 * B), fd, rtol=1e-3)
+
+
+def test_wca_and_poly_loss_gradients(htf, cuda):
+    nl = _case(3, NN=32)
+    nl[:, :, :3] *= 0.45  # inside the WCA cut
+    nl64 = nl.astype(np.float64)
+    x = torch.from_numpy(nl).to(cuda)
+    B = nl.shape[0]
+    labels = O.wca_model(nl64, 0.55)
+    w = torch.tensor([0.5], dtype=torch.float32, device=cuda)
+    accum = htf.ops.train_pair_grad(htf.Potential.wca(0.5, theta=w), x, torch.from_numpy(labels).to(cuda)).cpu().numpy()
+    # autograd, not finite differences: the cut mask and the clip are piecewise constant in TF's
+    # gradient, while a finite difference in sigma sees pairs jump across them
+    loss, g = G.mse_grad_wrt_params(lambda n, ww: G.wca_param_forces(n, ww, create_graph=True),
+                                    torch.from_numpy(nl64), torch.from_numpy(labels), [0.5])
+    np.testing.assert_allclose(accum[0] / (4 * B), loss, rtol=1e-3)
+    np.testing.assert_allclose(accum[1:] / (4 * B), g, rtol=5e-3)
+    # rinv polynomial with trainable coefficients (linear model): LJ written as 2 s^12 - 2 s^6
+    nl = _case(4, NN=32)
+    nl64 = nl.astype(np.float64)
+    x = torch.from_numpy(nl).to(cuda)
+    labels = O.lj_model(nl64)
+    c = torch.tensor([1.5, -2.5], dtype=torch.float32, device=cuda)
+    accum = htf.ops.train_pair_grad(htf.Potential.rinv_poly([1.5, -2.5], [12, 6], theta=c), x,
+                                    torch.from_numpy(labels).to(cuda)).cpu().numpy()
+    fd = O.fd_loss_grad(lambda t: O.rinv_poly_model(nl64, list(t), [12, 6]), [1.5, -2.5], labels, h=1e-5)
+    np.testing.assert_allclose(accum[1:3] / (4 * nl.shape[0]), fd, rtol=2e-3)
+    with pytest.raises(ValueError):
+        htf.ops.train_pair_grad(htf.Potential.lj(), x, torch.from_numpy(labels).to(cuda))
+
+
+@pytest.mark.parametrize("name", ["SGD", "Adam", "Nadam"])
+def test_device_optimizers_follow_keras_rules(htf, cuda, name):
+    from hoomd_tf_amd import optimizers, _lib
+    rng = np.random.default_rng(1)
+    theta = np.array([0.9, 1.2], dtype=np.float64)
+    dev_theta = torch.tensor(theta, dtype=torch.float32, device=cuda)
+    state = torch.zeros(_lib.OPT_STATE_FLOATS, dtype=torch.float32, device=cuda)
+    opt = getattr(optimizers, name)(0.01)
+    desc = opt.desc(nonneg_mask=0b11)
+    ref = {"SGD": None, "Adam": O.KerasAdam(0.01), "Nadam": O.KerasNadam(0.01)}[name]
+    for step in range(40):
+        g = rng.standard_normal(2)
+        accum = torch.tensor([3.0, g[0], g[1]], dtype=torch.float32, device=cuda)
+        htf.ops.optimizer_step(dev_theta, accum, 0.5, state, desc)
+        theta = theta - 0.01 * 0.5 * g if ref is None else ref.step(theta, 0.5 * g)
+        theta = np.maximum(theta, 0.0)
+        np.testing.assert_allclose(dev_theta.cpu().numpy(), theta, rtol=2e-4, atol=2e-6)
+    assert float(state[19]) == 40 and abs(float(state[18]) - 40 * 1.5) < 1e-3
+
+
+def _training_sim(htf, cuda, n, a, seed, kT, dt=0.005):
+    from hoomd_tf_amd import standin
+    pos, L = sq_lattice(n, a)
+    pos[:, :2] += 0.1 * np.random.default_rng(seed).standard_normal((n * n, 2))
+    system = standin.System(pos, L, dtype=torch.float32, device=cuda)
+    sim = standin.Simulation(system)
+    system.randomize_velocities(kT, seed)
+    system.vel[:, 2] = 0
+    sim.integrate_nve(dt)
+    return sim, system
+
+
+def test_trainable(htf, cuda):
+    """test_tensorflow.py:155-174 test_trainable: TrainableGraph(16, output_forces=False), Nadam(0.01),
+    batch_size=4, labels = the other force (LJ eps 1.1 sig 0.9 upstream; here LJModel): the
+    LJ weights move by more than 0.01."""
+    sim, system = _training_sim(htf, cuda, 3, 1.3, 2, kT=0.5)
+    lj = htf.tfcompute(build_examples.LJModel(16))
+    nlist = sim.nlist_cell(check_period=1)
+    lj.attach(nlist, r_cut=3.0)
+    model = build_examples.TrainableGraph(16, output_forces=False, sig=0.9, eps=1.1)
+    model.compile(optimizer=htf.optimizers.Nadam(0.01), loss='MeanSquaredError')
+    start = model.get_layer('lj').trainable_weights[0].cpu().numpy().copy()
+    tfcompute = htf.tfcompute(model)
+    tfcompute.attach(nlist, r_cut=3.0, batch_size=4, train=True)
+    sim.run(25)
+    end = model.get_layer('lj').trainable_weights[0].cpu().numpy()
+    assert np.sum((start - end) ** 2) > 0.01 ** 2, 'No training observed'
+    assert np.all(np.isfinite(end)) and np.all(end >= 0)
+
+
+def test_force_matching_recovers_lj(htf, cuda):
+    """examples/06 Force Matching: TrainableLJ(sig 0.9, eps 1.2) trained online against LJ
+    (eps = sig = 1) labels approaches them; the loss falls by orders of magnitude."""
+    sim, system = _training_sim(htf, cuda, 16, 1.25, 3, kT=0.3, dt=0.002)
+    lj = htf.tfcompute(build_examples.LJModel(64))
+    nlist = sim.nlist_cell(check_period=1)
+    lj.attach(nlist, r_cut=3.0)
+    model = build_examples.TrainableGraph(64, output_forces=False, sig=0.9, eps=1.2)
+    model.compile(htf.optimizers.Adam(0.01), loss=['MeanSquaredError', None, None])
+    tfcompute = htf.tfcompute(model)
+    tfcompute.attach(nlist, train=True, r_cut=3.0, save_output_period=5)
+    tfcompute.set_reference_forces(lj)
+    sim.run(5)
+    first = float(tfcompute._opt_state[20])
+    sim.run(400)
+    w = model.lj.w.cpu().numpy()
+    last = float(tfcompute._opt_state[20])
+    assert last < 0.02 * first, (first, last)
+    # eps and sig trade off along the valley w0 * w1^12 = const of the repulsive wall; 400 Adam
+    # steps reach the valley floor (start: 1.2 * 0.9^12 = 0.34) and creep along it towards (1, 1)
+    assert abs(w[0] * w[1] ** 12 - 1.0) < 0.2 and abs(w[1] - 1.0) < 0.05, w
+    # outputs beyond the loss list: the weights trace and the energy (example 06 plots them)
+    assert tfcompute.outputs[0].shape[1] == 2 and tfcompute.outputs[0].shape[0] >= 80
+    assert float(model.metrics[0].result()) > 0
+
+
+def test_force_output(htf, cuda):
+    """test_tensorflow.py:400-431: LJModel(32, output_forces=False) 'trained' against the LJ
+    reference force: the MSE metric over all four columns stays < 1e-5."""
+    sim, system = _training_sim(htf, cuda, 5, 2.0, 1, kT=0.8, dt=0.01)
+    nlist = sim.nlist_cell(check_period=1)
+    lj = htf.tfcompute(build_examples.LJModel(32))
+    lj.attach(nlist, r_cut=3.0)
+    lj2 = htf.tfcompute(build_examples.BenchmarkPotential(32))
+    lj2.attach(nlist, r_cut=3.0)
+    model = build_examples.LJModel(32, output_forces=False)
+    model.compile(loss='MeanSquaredError', optimizer='adam')
+    tfcompute = htf.tfcompute(model)
+    tfcompute.attach(nlist, train=True, r_cut=3.0, period=100)
+    tfcompute.set_reference_forces(lj)
+    sim.run(300)
+    error = float(model.metrics[0].result())
+    assert abs(error) < 1e-5
+    with pytest.raises(ValueError):
+        lj.set_reference_forces(lj2)
+    m2 = build_examples.LJModel(8, output_forces=False)
+    with pytest.raises(ValueError):
+        htf.tfcompute(m2).attach(nlist, train=True, r_cut=3.0)  # not compiled
