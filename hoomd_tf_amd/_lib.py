@@ -91,6 +91,8 @@ PROTOTYPES = {
     "htf_train_scratch_floats": (_sz, [_vp, _u, _u]),
     "htf_train_pair_grad": (_i, [_vp, _vp, _i, _u, _u, _vp, _i, _vp, _vp, _vp, _vp]),
     "htf_optimizer_step": (_i, [_vp, _u, _vp, C.c_float, _vp, C.POINTER(OptimizerDesc), _vp]),
+    "htf_optimizer_step_n": (_i, [_vp, _u, _vp, C.c_float, _vp, C.POINTER(OptimizerDesc), _vp]),
+    "htf_potential_refresh": (_i, [_vp, _vp]),
     "htf_add_virial": (_i, [_vp, _vp, _i, _u, _sz, _vp]),
     "htf_add_scalar4": (_i, [_vp, _vp, _i, _u, _vp]),
     "htf_copy_positions": (_i, [_vp, _i, _vp, _i, _u, _u, _i, _vp]),

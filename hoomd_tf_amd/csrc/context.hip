@@ -10,6 +10,7 @@
 
 #include "htf_common.h"
 #include "htf_internal.h"
+#include "pair_mlp.h"
 
 namespace htf {
 
@@ -129,7 +130,7 @@ extern "C" int htf_potential_create(const htf_potential_desc *d, htf_potential *
         delete p;
         return rc;
     }
-    if (d->d_theta != nullptr) {
+    if (d->d_theta != nullptr && d->kind != HTF_POT_PAIR_MLP) { // (the pair-MLP keeps theta in its own record)
         if (potential_num_params(p->pp) == 0) {
             set_error("htf_potential_create: potential kind %d has no trainable parameters", d->kind);
             delete p;
@@ -141,10 +142,21 @@ extern "C" int htf_potential_create(const htf_potential_desc *d, htf_potential *
     return HTF_OK;
 }
 
-extern "C" int htf_potential_num_params(const htf_potential *pot) { return pot ? htf::potential_num_params(pot->pp) : 0; }
+extern "C" int htf_potential_num_params(const htf_potential *pot) {
+    if (!pot) return 0;
+    return pot->mlp ? pot->mlp->num_params() : htf::potential_num_params(pot->pp);
+}
 
 extern "C" size_t htf_train_scratch_floats(const htf_potential *pot, unsigned B, unsigned NN) {
-    return pot ? htf::train_scratch_floats(pot->pp, B, NN) : 0;
+    if (!pot) return 0;
+    return pot->mlp ? htf::mlp_train_scratch_floats(pot->mlp, B) : htf::train_scratch_floats(pot->pp, B, NN);
+}
+
+extern "C" int htf_potential_refresh(htf_potential *pot, htf_stream stream) {
+    using namespace htf;
+    HTF_REQUIRE(pot, "htf_potential_refresh: no potential");
+    if (!pot->mlp) return HTF_OK; // closed forms read theta directly
+    return mlp_refresh(pot->mlp, (hipStream_t)stream);
 }
 
 extern "C" int htf_train_pair_grad(const htf_potential *pot, const void *d_nlist, int nlist_dtype, unsigned B,
@@ -156,6 +168,9 @@ extern "C" int htf_train_pair_grad(const htf_potential *pot, const void *d_nlist
     HTF_REQUIRE(NN > 0 && B > 0, "htf_train_pair_grad: empty batch");
     HTF_REQUIRE(nlist_dtype == HTF_F32 || nlist_dtype == HTF_F64, "htf_train_pair_grad: bad nlist dtype %d", nlist_dtype);
     HTF_REQUIRE(label_dtype == HTF_F32 || label_dtype == HTF_F64, "htf_train_pair_grad: bad label dtype %d", label_dtype);
+    if (pot->mlp)
+        return mlp_train_grad(pot->mlp, d_nlist, nlist_dtype, B, NN, d_labels, label_dtype == HTF_F64, d_pred, d_accum,
+                              d_scratch, (hipStream_t)stream);
     return train_pair_dispatch(pot->pp, d_nlist, nlist_dtype, B, NN, d_labels, label_dtype, d_pred, d_accum, d_scratch,
                                (hipStream_t)stream);
 }

@@ -1,0 +1,64 @@
+// Shared definitions of the pair-MLP potential: operand-image layout (pair_mlp.hip), the
+// trainable flat parameter vector and the map between the two (mlp_train.hip).
+#pragma once
+#include "htf_common.h"
+#include "htf_internal.h"
+
+namespace htf {
+
+constexpr int kK = 32;  // RBF count (padded with zero weights below 32)
+constexpr int kH = 64;  // hidden width (padded with zero weights below 64)
+
+// Offsets (in floats) inside the device image buffer / LDS.  One operand block covers a
+// 32 x 32 (feature x feature) weight tile: fp32 [g 4][lane 64][4 floats] = 1024 floats,
+// bf16 [s 2][lane 64][8 bf16] = 512 floats.
+template <bool BF16>
+struct Img {
+    static constexpr int BS = BF16 ? 512 : 1024;
+    static constexpr int L1 = 0;            // [nb 2]
+    static constexpr int L2 = 2 * BS;       // [nb 2][kb 2]
+    static constexpr int B2 = 6 * BS;       // [fb 2][kb 2]
+    static constexpr int B1 = 10 * BS;      // [kb 2]
+    static constexpr int TabB1 = 12 * BS;   // [b 2][h 2][v 16]
+    static constexpr int TabB2 = TabB1 + 64;
+    static constexpr int TabW3 = TabB2 + 64;
+    static constexpr int TabC = TabW3 + 64; // [h 2][v 16] RBF centres
+    static constexpr int TabB3 = TabC + 32; // output bias (+3 pad floats)
+    static constexpr int Floats = TabB3 + 4; // fp32: 12516 floats (50 KB); bf16: 6372 floats (25 KB)
+};
+
+// Every weight-carrying element of an image is theta[map[e]] (or 0 when map[e] < 0):
+// e < kMapW indexes the operand blocks element-wise (fp32 float / bf16 half, both 12288),
+// then 192 table floats (TabB1, TabB2, TabW3) and the output bias.
+constexpr int kMapW = 12 * 1024;
+constexpr int kMapT = 192;
+constexpr int kMapN = kMapW + kMapT + 1;
+
+// theta, flat, Keras get_weights() order: W1 [K][H1] | b1 [H1] | W2 [H1][H2] | b2 [H2] | W3 [H2] | b3
+struct MlpDevice {
+    float *images = nullptr;      // Img<>::Floats floats, operand order
+    int *map = nullptr;           // kMapN ints
+    const float *theta = nullptr; // device parameter vector the images are built from
+    float *own_theta = nullptr;   // ... owned copy unless the caller supplied d_theta
+    float centers[kK];            // float32 linspace(low, high, K), 0 beyond K
+    float gap = 1.f;
+    int K = 0, H1 = 0, H2 = 0;
+    int act = HTF_ACT_LINEAR;
+    int precision = HTF_MLP_FP32;
+    int n_cu = 256;
+    int num_params() const { return K * H1 + H1 + H1 * H2 + H2 + H2 + 1; }
+    int off_b1() const { return K * H1; }
+    int off_W2() const { return K * H1 + H1; }
+    int off_b2() const { return off_W2() + H1 * H2; }
+    int off_W3() const { return off_b2() + H2; }
+    int off_b3() const { return off_W3() + H2; }
+};
+
+__host__ __device__ constexpr int f0(int v) { return (v & 3) + 8 * (v >> 2); }
+
+int mlp_refresh(const MlpDevice *m, hipStream_t stream);
+int mlp_train_grad(const MlpDevice *m, const void *nlist, int in_dtype, unsigned B, unsigned NN, const void *labels,
+                   int lab_f64, void *pred, float *accum, float *scratch, hipStream_t stream);
+size_t mlp_train_scratch_floats(const MlpDevice *m, unsigned B);
+
+} // namespace htf

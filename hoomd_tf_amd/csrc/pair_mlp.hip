@@ -27,40 +27,12 @@
 
 #include "htf_common.h"
 #include "htf_internal.h"
+#include "pair_mlp.h"
 
 namespace htf {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-constexpr int kK = 32;  // RBF count (padded with zero weights below 32)
-constexpr int kH = 64;  // hidden width (padded with zero weights below 64)
-
-// Offsets (in floats) inside the device image buffer / LDS.  One operand block covers a
-// 32 x 32 (feature x feature) weight tile: fp32 [g 4][lane 64][4 floats] = 1024 floats,
-// bf16 [s 2][lane 64][8 bf16] = 512 floats.
-template <bool BF16>
-struct Img {
-    static constexpr int BS = BF16 ? 512 : 1024;
-    static constexpr int L1 = 0;            // [nb 2]
-    static constexpr int L2 = 2 * BS;       // [nb 2][kb 2]
-    static constexpr int B2 = 6 * BS;       // [fb 2][kb 2]
-    static constexpr int B1 = 10 * BS;      // [kb 2]
-    static constexpr int TabB1 = 12 * BS;   // [b 2][h 2][v 16]
-    static constexpr int TabB2 = TabB1 + 64;
-    static constexpr int TabW3 = TabB2 + 64;
-    static constexpr int TabC = TabW3 + 64; // [h 2][v 16] RBF centres
-    static constexpr int Floats = TabC + 32; // fp32: 12512 floats (50 KB); bf16: 6368 floats (25 KB)
-};
-
-struct MlpDevice {
-    float *images = nullptr; // Img<>::Floats floats, operand order
-    float b3 = 0.f, gap = 1.f;
-    int act = HTF_ACT_LINEAR;
-    int precision = HTF_MLP_FP32;
-    int n_cu = 256;
-};
-
-__host__ __device__ constexpr int f0(int v) { return (v & 3) + 8 * (v >> 2); }
 
 template <bool TANH>
 __device__ __forceinline__ float act_fwd(float z) {
@@ -128,8 +100,7 @@ __device__ __forceinline__ f32x16 load_tab(const float *tab, int b, unsigned h) 
 template <bool TANH, typename IT, bool BF16>
 __global__ __launch_bounds__(256, 3) void pair_mlp_kernel(const typename Vec4<IT>::type *__restrict__ nlist,
                                                           unsigned B, unsigned NN, void *__restrict__ force,
-                                                          int out_f64, const float *__restrict__ images, float b3,
-                                                          float gap) {
+                                                          int out_f64, const float *__restrict__ images, float gap) {
     using I = Img<BF16>;
     __shared__ __attribute__((aligned(16))) float lds[I::Floats];
     {
@@ -145,6 +116,7 @@ __global__ __launch_bounds__(256, 3) void pair_mlp_kernel(const typename Vec4<IT
     const unsigned nwaves = (gridDim.x * blockDim.x) >> 6;
     const unsigned ntiles = (NN + 31) / 32;
     const float ginv = 1.0f / gap;
+    const float b3 = lds[I::TabB3];
     const f32x16 cen = load_tab(lds + I::TabC, 0, h); // centers of this lane's 16 RBF indices
 
     for (unsigned row = wave; row < B; row += nwaves) {
@@ -258,33 +230,24 @@ __global__ __launch_bounds__(256, 3) void pair_mlp_kernel(const typename Vec4<IT
 }
 
 // ------------------------------------------------------------------------------ host side
-static unsigned short f2bf16(float f) { // round to nearest even (finite weights)
-    unsigned u;
-    std::memcpy(&u, &f, 4);
-    return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
-}
-
+// theta index feeding each image element (see pair_mlp.h): mirrors the operand order the
+// kernel reads -- accumulator register r of lane half hh holds feature f0(r) + 4 hh.
 template <bool BF16>
-static void fill_image(std::vector<float> &img, const htf_potential_desc *d, float *gap_out) {
+static void build_map(const MlpDevice *m, std::vector<int> &map) {
     using I = Img<BF16>;
-    const int K = d->K, H1 = d->H1, H2 = d->H2;
-    auto W1 = [&](int k, int f) { return (k < K && f < H1) ? d->W1[(size_t)k * H1 + f] : 0.f; };
-    auto W2 = [&](int a, int b) { return (a < H1 && b < H2) ? d->W2[(size_t)a * H2 + b] : 0.f; };
-    img.assign(I::Floats, 0.f);
-    unsigned short *h16 = reinterpret_cast<unsigned short *>(img.data());
-    // element e of a block: k-step-local index r (fp32: 16 steps of 1; bf16: 2 steps of 8) and lane
-    auto put = [&](int block_off, int r, int lane, float v) {
-        if constexpr (BF16) {
-            const int sidx = r >> 3, j = r & 7;
-            h16[(size_t)block_off * 2 + ((sidx * 64 + lane) * 8 + j)] = f2bf16(v);
-        } else {
-            const int g = r >> 2, j = r & 3;
-            img[block_off + (g * 64 + lane) * 4 + j] = v;
-        }
+    const int K = m->K, H1 = m->H1, H2 = m->H2;
+    auto W1 = [&](int k, int f) { return (k < K && f < H1) ? k * H1 + f : -1; };
+    auto W2 = [&](int a, int b) { return (a < H1 && b < H2) ? m->off_W2() + a * H2 + b : -1; };
+    map.assign(kMapN, -1);
+    // element of a block: k-step-local index r (fp32: 16 steps of 1; bf16: 2 steps of 8) and lane
+    auto put = [&](int block_off, int r, int lane, int idx) {
+        if constexpr (BF16)
+            map[(size_t)block_off * 2 + (((r >> 3) * 64 + lane) * 8 + (r & 7))] = idx;
+        else
+            map[block_off + ((r >> 2) * 64 + lane) * 4 + (r & 3)] = idx;
     };
     for (int r = 0; r < 16; ++r)
         for (int lane = 0; lane < 64; ++lane) {
-            // accumulator register r of lane half hh holds feature f0(r) + 4 hh of its 32-block
             const int i = lane & 31, hh = lane >> 5, kk = f0(r) + 4 * hh;
             for (int nb = 0; nb < 2; ++nb) put(I::L1 + nb * I::BS, r, lane, W1(kk, 32 * nb + i));
             for (int kb = 0; kb < 2; ++kb) put(I::B1 + kb * I::BS, r, lane, W1(i, 32 * kb + kk));
@@ -294,52 +257,112 @@ static void fill_image(std::vector<float> &img, const htf_potential_desc *d, flo
                     put(I::B2 + (nb * 2 + kb) * I::BS, r, lane, W2(32 * nb + i, 32 * kb + kk));
                 }
         }
-    // RBF centres: float32 linspace, gap = c[1] - c[0]  (layers.py:31-34)
-    std::vector<float> c(kK, 0.f);
-    for (int k = 0; k < K; ++k) {
-        double step = (d->rbf_high - d->rbf_low) / (double)(K - 1);
-        c[k] = (float)(k == K - 1 ? d->rbf_high : d->rbf_low + k * step);
-    }
-    *gap_out = c[1] - c[0];
     for (int b = 0; b < 2; ++b)
         for (int hh = 0; hh < 2; ++hh)
             for (int v = 0; v < 16; ++v) {
                 const int f = 32 * b + f0(v) + 4 * hh, o = (b * 2 + hh) * 16 + v;
-                img[I::TabB1 + o] = f < H1 ? d->b1[f] : 0.f;
-                img[I::TabB2 + o] = f < H2 ? d->b2[f] : 0.f;
-                img[I::TabW3 + o] = f < H2 ? d->W3[f] : 0.f;
-                if (b == 0) img[I::TabC + hh * 16 + v] = c[f0(v) + 4 * hh];
+                map[kMapW + o] = f < H1 ? m->off_b1() + f : -1;
+                map[kMapW + 64 + o] = f < H2 ? m->off_b2() + f : -1;
+                map[kMapW + 128 + o] = f < H2 ? m->off_W3() + f : -1;
             }
+    map[kMapW + kMapT] = m->off_b3();
+}
+
+// images <- theta (device side, so a training step never visits the host)
+template <bool BF16>
+__global__ void mlp_refresh_kernel(float *__restrict__ images, const int *__restrict__ map,
+                                   const float *__restrict__ theta) {
+    using I = Img<BF16>;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= kMapN) return;
+    const int idx = map[e];
+    const float v = idx >= 0 ? theta[idx] : 0.f;
+    if (e < kMapW) {
+        if constexpr (BF16) { // round to nearest even (finite weights)
+            const unsigned u = __float_as_uint(v);
+            reinterpret_cast<unsigned short *>(images)[e] = (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+        } else {
+            images[e] = v;
+        }
+    } else if (e < kMapW + kMapT) {
+        images[I::TabB1 + (e - kMapW)] = v;
+    } else {
+        images[I::TabB3] = v;
+    }
+}
+
+int mlp_refresh(const MlpDevice *m, hipStream_t stream) {
+    HTF_REQUIRE(m, "pair-MLP: null potential");
+    const unsigned grid = (kMapN + 255) / 256;
+    if (m->precision == HTF_MLP_BF16)
+        hipLaunchKernelGGL(mlp_refresh_kernel<true>, dim3(grid), dim3(256), 0, stream, m->images, m->map, m->theta);
+    else
+        hipLaunchKernelGGL(mlp_refresh_kernel<false>, dim3(grid), dim3(256), 0, stream, m->images, m->map, m->theta);
+    return check_launch("mlp_refresh_kernel");
 }
 
 int mlp_create(const htf_potential_desc *d, MlpDevice **out) {
-    HTF_REQUIRE(d->W1 && d->b1 && d->W2 && d->b2 && d->W3 && d->b3, "pair-MLP: null weight pointer");
+    HTF_REQUIRE(d->d_theta || (d->W1 && d->b1 && d->W2 && d->b2 && d->W3 && d->b3), "pair-MLP: null weight pointer");
     HTF_REQUIRE(d->K >= 2 && d->K <= kK, "pair-MLP: K=%d outside [2, %d]", d->K, kK);
     HTF_REQUIRE(d->H1 >= 1 && d->H1 <= kH && d->H2 >= 1 && d->H2 <= kH, "pair-MLP: hidden widths (%d, %d) must be <= %d", d->H1, d->H2, kH);
     HTF_REQUIRE(d->rbf_high > d->rbf_low, "pair-MLP: rbf_high must exceed rbf_low");
     HTF_REQUIRE(d->activation == HTF_ACT_LINEAR || d->activation == HTF_ACT_TANH, "pair-MLP: unknown activation %d", d->activation);
     HTF_REQUIRE(d->mlp_precision == HTF_MLP_FP32 || d->mlp_precision == HTF_MLP_BF16, "pair-MLP: unknown precision %d", d->mlp_precision);
-    std::vector<float> img;
-    float gap = 1.f;
-    if (d->mlp_precision == HTF_MLP_BF16)
-        fill_image<true>(img, d, &gap);
-    else
-        fill_image<false>(img, d, &gap);
     MlpDevice *m = new (std::nothrow) MlpDevice();
     if (!m) {
         set_error("pair-MLP: out of host memory");
         return HTF_ERR_NOMEM;
     }
-    m->b3 = d->b3[0];
-    m->gap = gap;
+    const bool bf16 = d->mlp_precision == HTF_MLP_BF16;
+    m->K = d->K; m->H1 = d->H1; m->H2 = d->H2;
     m->act = d->activation;
     m->precision = d->mlp_precision;
+    // RBF centres: float32 linspace, gap = c[1] - c[0]  (layers.py:31-34)
+    for (int k = 0; k < kK; ++k) m->centers[k] = 0.f;
+    for (int k = 0; k < m->K; ++k) {
+        double step = (d->rbf_high - d->rbf_low) / (double)(m->K - 1);
+        m->centers[k] = (float)(k == m->K - 1 ? d->rbf_high : d->rbf_low + k * step);
+    }
+    m->gap = m->centers[1] - m->centers[0];
+    const int n_img = bf16 ? Img<true>::Floats : Img<false>::Floats;
+    const int tabc = bf16 ? Img<true>::TabC : Img<false>::TabC;
+    std::vector<float> img(n_img, 0.f);
+    for (int hh = 0; hh < 2; ++hh)
+        for (int v = 0; v < 16; ++v) img[tabc + hh * 16 + v] = m->centers[f0(v) + 4 * hh];
+    std::vector<int> map;
+    if (bf16) build_map<true>(m, map); else build_map<false>(m, map);
+    const int P = m->num_params();
     hipError_t e = hipMalloc((void **)&m->images, img.size() * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(m->images, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void **)&m->map, map.size() * sizeof(int));
+    if (e == hipSuccess) e = hipMemcpy(m->map, map.data(), map.size() * sizeof(int), hipMemcpyHostToDevice);
+    if (e == hipSuccess && d->d_theta) {
+        m->theta = d->d_theta; // caller-owned, trainable: htf_potential_refresh after every update
+    } else if (e == hipSuccess) {
+        std::vector<float> th((size_t)P);
+        std::memcpy(&th[0], d->W1, sizeof(float) * m->K * m->H1);
+        std::memcpy(&th[m->off_b1()], d->b1, sizeof(float) * m->H1);
+        std::memcpy(&th[m->off_W2()], d->W2, sizeof(float) * m->H1 * m->H2);
+        std::memcpy(&th[m->off_b2()], d->b2, sizeof(float) * m->H2);
+        std::memcpy(&th[m->off_W3()], d->W3, sizeof(float) * m->H2);
+        th[m->off_b3()] = d->b3[0];
+        e = hipMalloc((void **)&m->own_theta, th.size() * sizeof(float));
+        if (e == hipSuccess) e = hipMemcpy(m->own_theta, th.data(), th.size() * sizeof(float), hipMemcpyHostToDevice);
+        m->theta = m->own_theta;
+    }
     if (e != hipSuccess) {
         set_error("pair-MLP: device upload failed: %s", hipGetErrorString(e));
         mlp_destroy(m);
         return HTF_ERR_DEVICE;
+    }
+    int rc = mlp_refresh(m, nullptr);
+    if (rc == HTF_OK && hipStreamSynchronize(nullptr) != hipSuccess) {
+        set_error("pair-MLP: image build failed");
+        rc = HTF_ERR_DEVICE;
+    }
+    if (rc != HTF_OK) {
+        mlp_destroy(m);
+        return rc;
     }
     int dev = 0;
     hipDeviceProp_t prop;
@@ -352,6 +375,8 @@ int mlp_create(const htf_potential_desc *d, MlpDevice **out) {
 void mlp_destroy(MlpDevice *m) {
     if (!m) return;
     if (m->images) (void)hipFree(m->images);
+    if (m->map) (void)hipFree(m->map);
+    if (m->own_theta) (void)hipFree(m->own_theta);
     delete m;
 }
 
@@ -363,9 +388,9 @@ static int launch_mlp(const MlpDevice *m, const void *nlist, int in_dtype, unsig
     unsigned need = (B + 3) / 4;
     if (grid > need) grid = need;
     if (in_dtype == HTF_F32)
-        hipLaunchKernelGGL((pair_mlp_kernel<TANH, float, BF16>), dim3(grid), dim3(256), 0, s, (const float4 *)nlist, B, NN, force, out_f64, m->images, m->b3, m->gap);
+        hipLaunchKernelGGL((pair_mlp_kernel<TANH, float, BF16>), dim3(grid), dim3(256), 0, s, (const float4 *)nlist, B, NN, force, out_f64, m->images, m->gap);
     else
-        hipLaunchKernelGGL((pair_mlp_kernel<TANH, double, BF16>), dim3(grid), dim3(256), 0, s, (const double4 *)nlist, B, NN, force, out_f64, m->images, m->b3, m->gap);
+        hipLaunchKernelGGL((pair_mlp_kernel<TANH, double, BF16>), dim3(grid), dim3(256), 0, s, (const double4 *)nlist, B, NN, force, out_f64, m->images, m->gap);
     return check_launch("pair_mlp_kernel");
 }
 

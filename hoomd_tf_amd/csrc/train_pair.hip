@@ -203,7 +203,71 @@ __global__ void optimizer_kernel(float *__restrict__ theta, unsigned P, const fl
     st[17] = m_sched_new;
 }
 
+// The same update rules for a parameter vector of any length (pair-MLP: 6337 weights): one
+// thread per parameter, then one thread advances the shared scalars.  State: the 24-float
+// header of htf_optimizer_step (scalars at [16..20]) followed by m[P], v[P].
+__global__ void optimizer_vec_kernel(float *__restrict__ theta, unsigned P, const float *__restrict__ accum, float scale,
+                                     float *__restrict__ st, htf_optimizer_desc d) {
+    const unsigned k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= P) return;
+    float *m = st + HTF_OPT_STATE_FLOATS, *v = m + P;
+    const float t = st[16] + 1.0f;
+    const float m_sched = st[17] == 0.0f ? 1.0f : st[17];
+    const float b1 = d.beta1, b2 = d.beta2;
+    const float g = accum[1 + k] * scale;
+    float th = theta[k];
+    if (d.kind == HTF_OPT_SGD) {
+        th -= d.lr * g;
+    } else if (d.kind == HTF_OPT_ADAM) {
+        const float lr_t = d.lr * sqrtf(1.0f - powf(b2, t)) / (1.0f - powf(b1, t));
+        const float mk = m[k] + (g - m[k]) * (1.0f - b1);
+        const float vk = v[k] + (g * g - v[k]) * (1.0f - b2);
+        m[k] = mk;
+        v[k] = vk;
+        th -= lr_t * mk / (sqrtf(vk) + d.epsilon);
+    } else {
+        const float u_t = b1 * (1.0f - 0.5f * powf(0.96f, 0.004f * t));
+        const float u_t1 = b1 * (1.0f - 0.5f * powf(0.96f, 0.004f * (t + 1.0f)));
+        const float m_sched_new = m_sched * u_t, m_sched_next = m_sched_new * u_t1;
+        const float g_prime = g / (1.0f - m_sched_new);
+        const float mk = b1 * m[k] + (1.0f - b1) * g;
+        const float vk = b2 * v[k] + (1.0f - b2) * g * g;
+        m[k] = mk;
+        v[k] = vk;
+        const float m_bar = (1.0f - u_t) * g_prime + u_t1 * (mk / (1.0f - m_sched_next));
+        th -= d.lr * m_bar / (sqrtf(vk / (1.0f - powf(b2, t))) + d.epsilon);
+    }
+    theta[k] = th;
+}
+
+__global__ void optimizer_vec_finish_kernel(const float *__restrict__ accum, float scale, float *__restrict__ st,
+                                            htf_optimizer_desc d) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float t = st[16] + 1.0f;
+    const float m_sched = st[17] == 0.0f ? 1.0f : st[17];
+    const float loss = accum[0] * scale;
+    st[18] += loss;
+    st[19] += 1.0f;
+    st[20] = loss;
+    st[16] = t;
+    st[17] = d.kind == HTF_OPT_NADAM ? m_sched * d.beta1 * (1.0f - 0.5f * powf(0.96f, 0.004f * t)) : m_sched;
+}
+
 } // namespace htf
+
+extern "C" int htf_optimizer_step_n(float *d_theta, unsigned P, const float *d_accum, float scale, float *d_state,
+                                    const htf_optimizer_desc *desc, htf_stream stream) {
+    using namespace htf;
+    HTF_REQUIRE(d_theta && d_accum && d_state && desc, "htf_optimizer_step_n: null pointer");
+    HTF_REQUIRE(P >= 1, "htf_optimizer_step_n: empty parameter vector");
+    HTF_REQUIRE(desc->kind >= HTF_OPT_SGD && desc->kind <= HTF_OPT_NADAM, "htf_optimizer_step_n: unknown optimizer %d", desc->kind);
+    hipLaunchKernelGGL(optimizer_vec_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_theta, P, d_accum,
+                       scale, d_state, *desc);
+    int rc = check_launch("optimizer_vec_kernel");
+    if (rc != HTF_OK) return rc;
+    hipLaunchKernelGGL(optimizer_vec_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d_accum, scale, d_state, *desc);
+    return check_launch("optimizer_vec_finish_kernel");
+}
 
 extern "C" int htf_optimizer_step(float *d_theta, unsigned P, const float *d_accum, float scale, float *d_state,
                                   const htf_optimizer_desc *desc, htf_stream stream) {

@@ -129,29 +129,73 @@ class PairMLP:
     Dense defaults: glorot-uniform kernels, zero biases, ``activation=None``; pass
     ``activation='tanh'`` for the C3 benchmark model."""
 
+    name = 'pair-mlp'
+    nonneg_mask = 0
+    l1_reg = (0.0,)
+    _KEYS = ("W1", "b1", "W2", "b2", "W3", "b3")
+
     def __init__(self, K=32, H1=64, H2=64, low=0.0, high=3.0, activation=None, seed=3, precision="fp32"):
         self.low, self.high = float(low), float(high)
         self.activation = activation or "linear"
         self.precision = precision
         self.params = mlp_params(seed=seed, K=K, H1=H1, H2=H2)
-        self._version = 0
+        self.w = None      # flat device weights (Keras get_weights() order) once the potential exists
+        self._pot = None
+
+    def _flat(self):
+        return np.concatenate([np.asarray(self.params[k], dtype=np.float32).ravel() for k in self._KEYS])
+
+    def make_trainable(self, device="cuda"):
+        if self.w is None:
+            self.w = torch.tensor(self._flat(), dtype=torch.float32, device=device)
+        return self.w
+
+    @property
+    def trainable_weights(self):
+        return [self.w] if self.w is not None else []
+
+    def potential(self):
+        """One persistent potential reading ``self.w``: an optimizer step or set_weights only
+        rebuilds its operand images on the device (htf_potential_refresh)."""
+        if self._pot is None:
+            self._pot = ops.Potential.pair_mlp(self.params, self.low, self.high, activation=self.activation,
+                                               precision=self.precision, theta=self.make_trainable())
+        return self._pot
+
+    def after_update(self):
+        if self._pot is not None:
+            self._pot.refresh()
+
+    def _sync_host(self):
+        if self.w is None:
+            return
+        flat, o = self.w.detach().cpu().numpy(), 0
+        for k in self._KEYS:
+            n = self.params[k].size
+            self.params[k] = flat[o:o + n].reshape(self.params[k].shape).copy()
+            o += n
 
     def get_weights(self):
-        return [self.params[k].copy() for k in ("W1", "b1", "W2", "b2", "W3", "b3")]
+        self._sync_host()
+        return [self.params[k].copy() for k in self._KEYS]
 
     def set_weights(self, ws):
-        for k, w in zip(("W1", "b1", "W2", "b2", "W3", "b3"), ws):
+        for k, w in zip(self._KEYS, ws):
             if np.shape(w) != self.params[k].shape:
                 raise ValueError("shape mismatch for %s" % k)
+        for k, w in zip(self._KEYS, ws):
             self.params[k] = np.asarray(w, dtype=np.float32).copy()
-        self._version += 1  # invalidates the cached device images
+        if self.w is not None:
+            self.w.copy_(torch.from_numpy(self._flat()))
+            self.after_update()
 
     def save_weights(self, path):
+        self._sync_host()
         np.savez(path, **self.params)
 
     def load_weights(self, path):
         with np.load(path) as z:
-            self.set_weights([z[k] for k in ("W1", "b1", "W2", "b2", "W3", "b3")])
+            self.set_weights([z[k] for k in self._KEYS])
 
     def __call__(self, nlist):
         return simmodel.MLPEnergy(simmodel._as_nlist(nlist), self)

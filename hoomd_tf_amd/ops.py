@@ -122,9 +122,15 @@ class Potential:
         return cls(_lib.POT_GAUSS, gauss=(r0, gap, coef))
 
     @classmethod
-    def pair_mlp(cls, params, low, high, activation="tanh", precision="fp32"):
+    def pair_mlp(cls, params, low, high, activation="tanh", precision="fp32", theta=None):
+        """``theta``: flat device weights (Keras get_weights() order) the potential keeps reading;
+        call ``refresh()`` after changing them."""
         return cls(_lib.POT_PAIR_MLP, mlp=params, rbf=(low, high), activation=activation,
-                   mlp_precision=precision)
+                   mlp_precision=precision, theta=theta)
+
+    def refresh(self):
+        """Rebuild derived device data (pair-MLP operand images) from the parameter vector."""
+        check(lib.htf_potential_refresh(self._h, _stream(self.theta) if self.theta is not None else None))
 
 
 def build_pair_vectors(pos, n_neigh, head_list, nlist, box, r_cut, NN, offset=0, batch_size=None,
@@ -248,10 +254,18 @@ def train_pair_grad(potential, nlist, labels, pred=None, accum=None):
 
 
 def optimizer_step(theta, accum, scale, state, desc):
-    """Keras SGD / Adam / Nadam step on the device parameter vector (no host round trip)."""
-    check(lib.htf_optimizer_step(theta.data_ptr(), int(theta.numel()), accum.data_ptr(), float(scale),
-                                 state.data_ptr(), C.byref(desc), _stream(theta)))
+    """Keras SGD / Adam / Nadam step on the device parameter vector (no host round trip).
+    ``state``: optimizer_state_floats(P) zero-initialised floats."""
+    P = int(theta.numel())
+    if int(state.numel()) < optimizer_state_floats(P):
+        raise ValueError("optimizer state too small for %d parameters" % P)
+    fn = lib.htf_optimizer_step if P <= 8 else lib.htf_optimizer_step_n
+    check(fn(theta.data_ptr(), P, accum.data_ptr(), float(scale), state.data_ptr(), C.byref(desc), _stream(theta)))
     return theta
+
+
+def optimizer_state_floats(P):
+    return _lib.OPT_STATE_FLOATS + (2 * int(P) if P > 8 else 0)
 
 
 def add_virial(dest, src9, N, pitch):

@@ -207,11 +207,10 @@ class MLPEnergy(PairEnergy):
         self.nlist, self.layer = nlist, layer
 
     def key(self):
-        return ("mlp", id(self.layer), self.layer._version)
+        return ("mlp", id(self.layer))
 
     def potential(self):
-        L = self.layer
-        return ops.Potential.pair_mlp(L.params, L.low, L.high, activation=L.activation, precision=L.precision)
+        return self.layer.potential()
 
 
 class PairCV:

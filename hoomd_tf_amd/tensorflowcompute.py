@@ -158,8 +158,10 @@ class tfcompute:
         one sweep (htf_train_pair_grad), optimizer step on the device (htf_optimizer_step)."""
         entries = [e for e in fused_entries if e.get("layer") is not None]
         m = self.model
+        n_theta = sum(int(e["layer"].make_trainable(self.system.device).numel()) for e in entries[:1])
         if self._opt_state is None:
-            self._opt_state = torch.zeros(_lib.OPT_STATE_FLOATS, dtype=torch.float32, device=self.system.device)
+            self._opt_state = torch.zeros(ops.optimizer_state_floats(n_theta), dtype=torch.float32,
+                                          device=self.system.device)
             if m.metrics:
                 m.metrics[0].state = self._opt_state
         if not entries:
@@ -173,7 +175,7 @@ class tfcompute:
             return
         if len(entries) != 1:
             raise ValueError('training needs exactly one compute_nlist_forces over a trainable layer '
-                             '(LJLayer, WCARepulsion); found %d' % len(entries))
+                             '(LJLayer, WCARepulsion, PairMLP); found %d' % len(entries))
         layer = entries[0]["layer"]
         theta = layer.make_trainable(self.system.device)
         pot = layer.potential()
@@ -181,7 +183,19 @@ class tfcompute:
             self._opt_desc = m.optimizer.desc(layer.nonneg_mask, layer.l1_reg)
         labels = self._labels[offset:offset + n]
         accum = ops.train_pair_grad(pot, nlist_t, labels)
-        ops.optimizer_step(theta, accum, 1.0 / (4.0 * n), self._opt_state, self._opt_desc)
+        n_total = float(n)
+        domain = getattr(self._nlist, "domain", None)
+        if domain is not None and domain.world > 1:
+            # data-parallel training over the slabs: ONE all-reduce of [loss, gradient, count]
+            # per batch (26 KB for the pair-MLP) keeps the replicas' weights identical; the
+            # reference trains each MPI rank's copy independently
+            import torch.distributed as dist
+            packed = torch.cat([accum, accum.new_tensor([n_total])])
+            dist.all_reduce(packed, group=domain.group)
+            accum, n_total = packed[:-1].contiguous(), float(packed[-1].item())
+        ops.optimizer_step(theta, accum, 1.0 / (4.0 * n_total), self._opt_state, self._opt_desc)
+        if hasattr(layer, "after_update"):
+            layer.after_update()  # pair-MLP: operand images <- theta, on the device
         self._train_potential = pot  # keep alive until the stream has consumed it
 
     def _maybe_install_plan(self, nbatch):

@@ -205,6 +205,19 @@ typedef struct htf_optimizer_desc {
 HTF_API int htf_optimizer_step(float *d_theta, unsigned P, const float *d_accum, float scale,
                        float *d_state, const htf_optimizer_desc *desc, htf_stream stream);
 
+/* Same rules for a parameter vector of any length (pair-MLP weights).  d_state:
+ * HTF_OPT_STATE_FLOATS + 2 P floats, zero-initialised (header as above, then m[P], v[P]);
+ * nonneg_mask / l1_reg are ignored. */
+HTF_API int htf_optimizer_step_n(float *d_theta, unsigned P, const float *d_accum, float scale, float *d_state,
+                         const htf_optimizer_desc *desc, htf_stream stream);
+
+/* Pair-MLP potentials created with desc.d_theta (flat Keras get_weights() order: W1 [K][H1] |
+ * b1 | W2 [H1][H2] | b2 | W3 [H2] | b3; the host weight pointers may then be NULL) keep reading
+ * that caller-owned device vector: after it changes (optimizer step, set_weights), rebuild the
+ * MFMA operand images on the device.  A no-op for closed-form potentials. */
+HTF_API int htf_potential_refresh(htf_potential *pot, htf_stream stream);
+
+
 /* Replaces htf_gpu_add_virial (TensorflowCompute.cu:41-71; CPU .cc:284-301):
  * dest[c*pitch + i] += src[i*9 + {0,1,2,4,5,8}]. */
 HTF_API int htf_add_virial(void *d_dest, const void *d_src9, int dtype, unsigned N, size_t pitch, htf_stream stream);

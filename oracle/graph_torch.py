@@ -167,3 +167,28 @@ def wca_param_forces(nlist, w, create_graph=False):
     e = torch.clamp(e, 0, 10)
     (g,) = torch.autograd.grad(e.sum(), nlist, create_graph=create_graph)
     return _add_energy((g * 2.0).sum(dim=1), e)
+
+
+def pair_mlp_param_forces(nlist, w, dims, low=0.0, high=3.0, act="tanh", create_graph=False):
+    """pair_mlp_model with the weights as ONE flat differentiable vector in Keras get_weights()
+    order (W1 [K,H1] | b1 | W2 [H1,H2] | b2 | W3 [H2] | b3): the training reference."""
+    K, H1, H2 = dims
+    if not nlist.requires_grad:
+        nlist = nlist.clone().requires_grad_(True)
+    o = 0
+    W1 = w[o:o + K * H1].reshape(K, H1); o += K * H1
+    b1 = w[o:o + H1]; o += H1
+    W2 = w[o:o + H1 * H2].reshape(H1, H2); o += H1 * H2
+    b2 = w[o:o + H2]; o += H2
+    W3 = w[o:o + H2]; o += H2
+    b3 = w[o]
+    r = safe_norm(nlist[:, :, :3], dim=2)
+    phi = rbf_expansion(r, low, high, K)
+    f = torch.tanh if act == "tanh" else (lambda z: z)
+    h1 = f(phi @ W1 + b1)
+    h2 = f(h1 @ W2 + b2)
+    u = h2 @ W3 + b3
+    mask = (r > RINV_DELTA).to(nlist.dtype).detach()
+    energy = 0.5 * (u * mask).sum(dim=1)
+    (g,) = torch.autograd.grad(energy.sum(), nlist, create_graph=create_graph)
+    return _add_energy((g * 2.0).sum(dim=1), energy)

@@ -178,3 +178,116 @@ def test_force_output(htf, cuda):
     m2 = build_examples.LJModel(8, output_forces=False)
     with pytest.raises(ValueError):
         htf.tfcompute(m2).attach(nlist, train=True, r_cut=3.0)  # not compiled
+
+
+# ------------------------------------------------------------------ pair-MLP weights (C5b)
+def _flat_params(params):
+    return np.concatenate([np.asarray(params[k], dtype=np.float64).ravel() for k in ("W1", "b1", "W2", "b2", "W3", "b3")])
+
+
+@pytest.mark.parametrize("dims,act", [((32, 64, 64), "tanh"), ((12, 20, 28), "tanh"), ((32, 64, 64), "linear")])
+def test_pair_mlp_loss_gradient_matches_double_backward(htf, cuda, dims, act):
+    """One sweep (value + r-tangent forward, one reverse) == torch's double backward through
+    the force, for every one of the 6337 weights; ragged widths exercise the zero padding."""
+    from hoomd_tf_amd import initializers
+    K, H1, H2 = dims
+    nl = _case(5, N=40, NN=24)
+    nl64 = nl.astype(np.float64)
+    params = initializers.mlp_params(seed=11, K=K, H1=H1, H2=H2)
+    rng = np.random.default_rng(4)
+    for k in ("b1", "b2", "b3"):  # Keras starts biases at zero; make them count
+        params[k] = (0.1 * rng.standard_normal(params[k].shape)).astype(np.float32)
+    theta = _flat_params(params)
+    labels = O.lj_model(nl64) * 0.05
+    w = torch.tensor(theta, dtype=torch.float32, device=cuda)
+    pot = htf.Potential.pair_mlp(params, 0.0, 3.0, activation=act, theta=w)
+    assert pot.num_params == theta.size == K * H1 + H1 + H1 * H2 + 2 * H2 + 1
+    x = torch.from_numpy(nl).to(cuda)
+    pred = torch.empty((nl.shape[0], 4), device=cuda)
+    accum = htf.ops.train_pair_grad(pot, x, torch.from_numpy(labels).to(cuda), pred=pred).cpu().numpy()
+    fwd = lambda n, ww: G.pair_mlp_param_forces(n, ww, dims, act=act, create_graph=True)
+    ref_pred = G.pair_mlp_param_forces(torch.from_numpy(nl64), torch.from_numpy(theta), dims, act=act).detach().numpy()
+    np.testing.assert_allclose(pred.cpu().numpy(), ref_pred, rtol=1e-4, atol=1e-4 * np.abs(ref_pred).max())
+    loss, g = G.mse_grad_wrt_params(fwd, torch.from_numpy(nl64), torch.from_numpy(labels), theta)
+    B = nl.shape[0]
+    np.testing.assert_allclose(accum[0] / (4 * B), loss, rtol=2e-4)
+    got = accum[1:] / (4 * B)
+    # fp32 accumulation over ~700 pairs against an fp64 reference: tolerance relative to the gradient scale
+    assert np.abs(got - g).max() < 2e-4 * np.abs(g).max(), (np.abs(got - g).max(), np.abs(g).max())
+    # every block of theta carries signal (no silently-zero slice)
+    o = 0
+    for n in (K * H1, H1, H1 * H2, H2, H2, 1):
+        assert np.abs(got[o:o + n]).max() > 0
+        o += n
+
+
+def test_pair_mlp_refresh_tracks_device_weights(htf, cuda):
+    """The persistent potential reads the flat device vector: after an in-place change +
+    refresh, the MFMA evaluator gives what a freshly built potential gives."""
+    layer = htf.PairMLP(32, 64, 64, 0.0, 3.0, activation="tanh", seed=5)
+    nl = _case(6, N=64, NN=32)
+    x = torch.from_numpy(nl).to(cuda)
+    pot = layer.potential()
+    f0 = htf.ops.eval_forces(pot, x).cpu().numpy()
+    ws = layer.get_weights()
+    rng = np.random.default_rng(0)
+    ws2 = [w + 0.05 * rng.standard_normal(w.shape).astype(np.float32) for w in ws]
+    layer.set_weights(ws2)
+    assert layer.potential() is pot
+    f1 = htf.ops.eval_forces(pot, x).cpu().numpy()
+    fresh = htf.Potential.pair_mlp(dict(zip(("W1", "b1", "W2", "b2", "W3", "b3"), ws2)), 0.0, 3.0, activation="tanh")
+    f2 = htf.ops.eval_forces(fresh, x).cpu().numpy()
+    assert np.abs(f1 - f0).max() > 1e-3
+    np.testing.assert_array_equal(f1, f2)
+    for a, b in zip(layer.get_weights(), ws2):
+        np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("name", ["SGD", "Adam", "Nadam"])
+def test_vector_optimizer_follows_keras_rules(htf, cuda, name):
+    from hoomd_tf_amd import optimizers
+    rng = np.random.default_rng(2)
+    P = 700
+    theta = rng.standard_normal(P)
+    dev_theta = torch.tensor(theta, dtype=torch.float32, device=cuda)
+    state = torch.zeros(htf.ops.optimizer_state_floats(P), dtype=torch.float32, device=cuda)
+    opt = getattr(optimizers, name)(0.01)
+    desc = opt.desc(0, (0.0,))
+    ref = {"SGD": None, "Adam": O.KerasAdam(0.01), "Nadam": O.KerasNadam(0.01)}[name]
+    for step in range(25):
+        g = rng.standard_normal(P)
+        accum = torch.tensor(np.concatenate([[3.0], g]), dtype=torch.float32, device=cuda)
+        htf.ops.optimizer_step(dev_theta, accum, 0.5, state, desc)
+        theta = theta - 0.01 * 0.5 * g if ref is None else ref.step(theta, 0.5 * g)
+        np.testing.assert_allclose(dev_theta.cpu().numpy(), theta, rtol=3e-4, atol=3e-6)
+    assert float(state[19]) == 25 and abs(float(state[18]) - 25 * 1.5) < 1e-3
+
+
+def test_pair_mlp_force_matching_online(htf, cuda):
+    """C5b: PairMLPModel trained online (hoomd2tf) against LJ reference forces every step; the
+    loss falls, the weights on the device move, and inference afterwards uses them."""
+    sim, system = _training_sim(htf, cuda, 12, 1.25, 4, kT=0.3, dt=0.002)
+    lj = htf.tfcompute(build_examples.LJModel(48))
+    nlist = sim.nlist_cell(check_period=1)
+    lj.attach(nlist, r_cut=3.0)
+    model = build_examples.PairMLPModel(48, output_forces=False, activation='tanh', seed=9)
+    model.compile(htf.optimizers.Adam(0.003), loss='MeanSquaredError')
+    start = np.concatenate([w.ravel() for w in model.mlp.get_weights()])
+    tfcompute = htf.tfcompute(model)
+    tfcompute.attach(nlist, train=True, r_cut=3.0)
+    tfcompute.set_reference_forces(lj)
+    sim.run(3)
+    first = float(tfcompute._opt_state[20])
+    sim.run(150)
+    last = float(tfcompute._opt_state[20])
+    assert np.isfinite(last) and last < 0.5 * first, (first, last)
+    end = np.concatenate([w.ravel() for w in model.mlp.get_weights()])
+    assert np.abs(end - start).max() > 1e-3 and np.all(np.isfinite(end))
+    # the evaluator now predicts with the trained weights
+    ws = dict(zip(("W1", "b1", "W2", "b2", "W3", "b3"), model.mlp.get_weights()))
+    rng = np.random.default_rng(1)
+    probe, _ = random_nlist(rng, 32, 48, fill=0.6, rmin=0.9, rmax=2.8, dtype=np.float32)
+    x = torch.from_numpy(probe).to(cuda)
+    got = htf.ops.eval_forces(model.mlp.potential(), x).cpu().numpy()
+    want = htf.ops.eval_forces(htf.Potential.pair_mlp(ws, 0.0, 3.0, activation='tanh'), x).cpu().numpy()
+    np.testing.assert_array_equal(got, want)
