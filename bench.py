@@ -40,7 +40,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="lj", choices=["lj", "wca", "mlp", "mlp-bf16", "eds"])
+    ap.add_argument("--workload", default="lj", choices=["lj", "wca", "mlp", "mlp-bf16", "mlp-train", "eds"])
+    ap.add_argument("--train-period", type=int, default=100, help="mlp-train (C5b): force-matching step every this many MD steps")
     ap.add_argument("--cells", type=int, default=32, help="fcc cells per side (N = 4 cells^3 per rank)")
     ap.add_argument("--nn", type=int, default=128)
     ap.add_argument("--rcut", type=float, default=3.0)
@@ -61,6 +62,11 @@ def make_potential(htf, workload):
     if workload == "wca":
         return htf.Potential.wca(1.0)
     from hoomd_tf_amd.initializers import mlp_params
+    if workload == "mlp-train":
+        # C5b = online force matching (example 06, FORCE_MODE::hoomd2tf): the reference LJ force
+        # drives the MD; the pair-MLP is the model being trained, it does not push particles
+        make_potential.layer = htf.PairMLP(32, 64, 64, 0.0, 3.0, activation="tanh", seed=3)
+        return htf.Potential.lj()
     prec = "bf16" if workload == "mlp-bf16" else "fp32"
     return htf.Potential.pair_mlp(mlp_params(seed=3), 0.0, 3.0, activation="tanh", precision=prec)
 
@@ -244,6 +250,8 @@ def main():
 
     if args.workload != "lj":
         args.no_cpu_baseline = True  # the C port restates LJModel only
+    if args.workload == "mlp-train":
+        args.no_fused = True
     if args.workload == "eds":
         if world > 1:
             raise SystemExit("the C4 workload is a single-GPU configuration")
@@ -278,15 +286,49 @@ def main():
         # N changes when particles migrate between ranks at a rebuild
         return ctx.make_arrays(sysm.pos, sysm.N, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, sysm.force)
 
-    state = {"arr": arrays(), "builds": nl.n_builds, "ts": 0}
+    state = {"arr": arrays(), "builds": nl.n_builds, "ts": 0, "train_s": 0.0, "train_n": 0}
 
-    def step():
+    train = None
+    if args.workload == "mlp-train":
+        # C5b: every --train-period steps (attach(train=True, period=100), running.rst:77-81)
+        # one train_on_batch of the pair-MLP on THIS step's pair vectors, labels = this step's
+        # LJ forces: prediction (MFMA evaluator) + loss-gradient sweep -> one RCCL all-reduce
+        # of [loss, 6337 gradients, count] -> Adam on the device -> operand images rebuilt on
+        # the device.  Inside the timed region.
+        layer = make_potential.layer
+        pot_mlp = layer.potential()
+        opt_desc = htf.optimizers.Adam(1e-3).desc(0, (0.0,))
+        opt_state = torch.zeros(htf.ops.optimizer_state_floats(layer.w.numel()), dtype=torch.float32, device=dev)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+        def train(timed):
+            n = sysm.N
+            if timed:
+                ev0.record()
+            x = ctx.nlist_buffer(n, dev)
+            accum = htf.ops.train_pair_grad(pot_mlp, x, sysm.force[:n])
+            n_total = float(n)
+            if dist is not None:
+                packed = torch.cat([accum, accum.new_tensor([n_total])])
+                dist.all_reduce(packed)
+                accum, n_total = packed[:-1].contiguous(), float(packed[-1].item())
+            htf.ops.optimizer_step(layer.w, accum, 1.0 / (4.0 * n_total), opt_state, opt_desc)
+            layer.after_update()
+            if timed:
+                ev1.record()
+                ev1.synchronize()
+                state["train_s"] += ev0.elapsed_time(ev1) * 1e-3
+                state["train_n"] += 1
+
+    def step(timed=False):
         ts = state["ts"]
         nl.compute(ts)
         if nl.n_builds != state["builds"]:
             state["arr"] = arrays()
             state["builds"] = nl.n_builds
         ctx.compute_forces(ts, state["arr"])
+        if train is not None and ts % args.train_period == 0:
+            train(timed)
         nve.step()
         state["ts"] = ts + 1
 
@@ -323,7 +365,7 @@ def main():
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        step(True)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -354,7 +396,11 @@ def main():
                                "GBps": build_b / build_avg_s / 1e9 if build_avg_s > 0 else None},
     }
     dom = "build_pair_vectors" if build_avg_s > eval_avg_s else "eval_forces"
-    mfma = args.workload.startswith("mlp")
+    mfma = args.workload in ("mlp", "mlp-bf16")
+    if train is not None and state["train_n"]:
+        kern["train_step"] = {"avg_ms": state["train_s"] / state["train_n"] * 1e3, "count": state["train_n"],
+                              "period": args.train_period, "loss": float(opt_state[20]),
+                              "what": "pair-MLP prediction + loss-gradient sweep + all-reduce + Adam + image refresh"}
     if mfma:
         flops = 4.0 * (32 * 64 + 64 * 64 + 64) * N * NN
         peak = 2500.0 if args.workload == "mlp-bf16" else 157.3
@@ -390,8 +436,10 @@ def main():
         "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "C3-%s: fcc %d^3x4 = %d particles/GPU, rho 0.8442, r_cut %.1f, r_buff %.1f, NN %d, dt %g"
-                               % (args.workload.upper(), args.cells, N, args.rcut, args.rbuff, NN, args.dt),
+        "config": {"workload": "%s: fcc %d^3x4 = %d particles/GPU, rho 0.8442, r_cut %.1f, r_buff %.1f, NN %d, dt %g"
+                               % ("C5b (pair-MLP MD + force-matching step every %d steps vs LJ labels)" % args.train_period
+                                  if args.workload == "mlp-train" else "C3-" + args.workload.upper(),
+                                  args.cells, N, args.rcut, args.rbuff, NN, args.dt),
                    "global_particles": N * world, "parallelism": "dd%dx1x1" % world,
                    "nlist_rebuilds_in_timed_region": rebuilds, "max_neighbors_within_rcut": max_kept,
                    "halo": None if world == 1 else {"ghosts_rank0": sysm.n_ghost, "migrated_rank0": nl.domain.n_migrated,
