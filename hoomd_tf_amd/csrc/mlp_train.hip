@@ -16,6 +16,8 @@
 // accumulators dW1[k][f], dW2[f1][f] held in registers (96 VGPRs) for the whole kernel:
 // no LDS, no atomics, one partial per wave, reduced in a fixed order (deterministic).
 // ~900 VALU instructions per live pair; 4 waves per CU (one per SIMD, ~300 VGPRs).
+#include <cstdlib>
+
 #include "htf_common.h"
 #include "htf_internal.h"
 #include "pair_mlp.h"
@@ -30,7 +32,7 @@ template <bool TANH>
 __device__ __forceinline__ float act_val(float z) {
     if constexpr (!TANH) return z;
     float e = __expf(-2.0f * fabsf(z));
-    float t = __fdividef(1.0f - e, 1.0f + e);
+    float t = (1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e);
     return copysignf(t, z);
 }
 
@@ -157,6 +159,381 @@ __global__ __launch_bounds__(256, 1) void mlp_grad_kernel(const typename Vec4<IT
     }
 }
 
+// ------------------------------------------------------------------ matrix-core version (fp32)
+// The same sweep on the MFMA units.  Layers are computed transposed as in pair_mlp.hip
+// (features on accumulator rows, a tile of 32 pairs on the lanes) for the value chain, its
+// r-tangent chain and the one reverse pass over both (320 MFMAs per tile).  The weight
+// gradients are contractions over PAIRS,
+//     dW2[f1][f2] += sum_p h1[f1][p] zb2[f2][p] + hd1[f1][p] zdb2[f2][p]     (dW1 likewise),
+// i.e. MFMAs whose k index is the pair: both operands are needed as [feature][pair] rows.
+// Each wave publishes its tile's blocks through LDS (row stride 36 floats: conflict-free
+// ds_write_b32 by pair, ds_read_b128 by feature; k order p = 16 h + t on both operands) and
+// the four waves of a block split the accumulators: wave w owns the (w>>1, w&1) 32x32 block
+// of dW2 over all four tiles and the (w&1) block of dW1 over two of them, so a wave carries
+// 32 accumulator registers instead of 96.  192 MFMAs per tile in this phase; 8 block
+// barriers per round.  Bias / w3 gradients ride along on the VALU.  One partial per block,
+// combined in a fixed order -> deterministic.
+constexpr int kPS = 36;         // published row stride (floats)
+constexpr int kPB = 32 * kPS;   // one published 32 x 32 block
+constexpr int kSlots = 6;       // per wave: A0 A1 | B0 B1 | phi phid  (108 KB + 49 KB of images: one block per CU)
+
+__device__ __forceinline__ void mfma_pair(f32x16 &acc0, f32x16 &acc1, const float *img, unsigned lane,
+                                          const f32x16 &p0, const f32x16 &p1) {
+    const float4 *p = reinterpret_cast<const float4 *>(img) + lane;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 w = p[g * 64];
+        acc0 = HTF_MFMA(w.x, p0[4 * g + 0], acc0);
+        acc1 = HTF_MFMA(w.x, p1[4 * g + 0], acc1);
+        acc0 = HTF_MFMA(w.y, p0[4 * g + 1], acc0);
+        acc1 = HTF_MFMA(w.y, p1[4 * g + 1], acc1);
+        acc0 = HTF_MFMA(w.z, p0[4 * g + 2], acc0);
+        acc1 = HTF_MFMA(w.z, p1[4 * g + 2], acc1);
+        acc0 = HTF_MFMA(w.w, p0[4 * g + 3], acc0);
+        acc1 = HTF_MFMA(w.w, p1[4 * g + 3], acc1);
+    }
+}
+
+__device__ __forceinline__ void publish(float *blk, unsigned p, unsigned h, const f32x16 &a) {
+#pragma unroll
+    for (int v = 0; v < 16; ++v) blk[(f0(v) + 4 * h) * kPS + p] = a[v];
+}
+
+__device__ __forceinline__ f32x16 load_op(const float *blk, unsigned i, unsigned h) {
+    const float4 *q = reinterpret_cast<const float4 *>(blk + i * kPS + 16 * h);
+    const float4 a = q[0], b = q[1], c = q[2], d = q[3];
+    f32x16 r;
+    r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w;
+    r[4] = b.x; r[5] = b.y; r[6] = b.z; r[7] = b.w;
+    r[8] = c.x; r[9] = c.y; r[10] = c.z; r[11] = c.w;
+    r[12] = d.x; r[13] = d.y; r[14] = d.z; r[15] = d.w;
+    return r;
+}
+
+__device__ __forceinline__ float sum16(const f32x16 &a) {
+    float s = 0.f;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) s += a[v];
+    return s;
+}
+
+__device__ __forceinline__ void outer16(f32x16 &acc, const f32x16 &A, const f32x16 &Bm) {
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc = HTF_MFMA(A[t], Bm[t], acc);
+}
+
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 r;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) r[v] = 0.f;
+    return r;
+}
+
+__device__ __forceinline__ float4 residual(const float4 *pred, const void *labels, int lab_f64, unsigned row) {
+    const float4 pr = pred[row];
+    if (lab_f64) {
+        const double4 l = ((const double4 *)labels)[row];
+        return make_float4(pr.x - (float)l.x, pr.y - (float)l.y, pr.z - (float)l.z, pr.w - (float)l.w);
+    }
+    const float4 l = ((const float4 *)labels)[row];
+    return make_float4(pr.x - l.x, pr.y - l.y, pr.z - l.z, pr.w - l.w);
+}
+
+// FUSED (ntiles in {1, 2, 4}, i.e. NN <= 64 or 97..128): the block also forms the row's
+// predicted (F_i, E_i) from the value/tangent outputs it has in hand, so the separate
+// evaluator pass is skipped; `pred_out` (nullable) receives the prediction.
+template <bool TANH, typename IT, bool FUSED>
+__global__ __launch_bounds__(256, 1) void mlp_grad_mfma_kernel(const typename Vec4<IT>::type *__restrict__ nlist,
+                                                               unsigned B, unsigned NN,
+                                                               const void *__restrict__ labels, int lab_f64,
+                                                               const float4 *__restrict__ pred,
+                                                               float4 *__restrict__ pred_out,
+                                                               const float *__restrict__ images, MlpDims dm, float gap,
+                                                               float *__restrict__ partial, unsigned stride) {
+    using I = Img<false>;
+    __shared__ __attribute__((aligned(16))) float lds[I::Floats];
+    __shared__ __attribute__((aligned(16))) float pub[4 * kSlots * kPB];
+    __shared__ int live_flag[4];
+    __shared__ float4 rowsum[4];
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(images);
+        float4 *dst = reinterpret_cast<float4 *>(lds);
+        for (int i = threadIdx.x; i < I::Floats / 4; i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned p = lane & 31u, h = lane >> 5;
+    const unsigned w = threadIdx.x >> 6;
+    const unsigned ntiles = (NN + 31) / 32;
+    const unsigned long long U = (unsigned long long)B * ntiles;
+    const float ginv = 1.0f / gap;
+    float *mine = pub + w * kSlots * kPB;
+
+    f32x16 acc2 = zero16(), acc1 = zero16();
+    f32x16 gw3[2] = {zero16(), zero16()};
+    float gb1 = 0.f, gb2 = 0.f, gb3 = 0.f, loss = 0.f;
+
+    for (unsigned long long base = (unsigned long long)blockIdx.x * 4; base < U; base += (unsigned long long)gridDim.x * 4) {
+        const unsigned long long u = base + w;
+        const bool valid = u < U;
+        const unsigned row = valid ? (unsigned)(u / ntiles) : 0u, tile = valid ? (unsigned)(u % ntiles) : 0u;
+        const unsigned slot = tile * 32 + p;
+        float x = 0.f, y = 0.f, z = 0.f;
+        if (valid && slot < NN) {
+            const auto v = nlist[(size_t)row * NN + slot];
+            x = (float)v.x; y = (float)v.y; z = (float)v.z;
+        }
+        const float tx = x + kNormDelta, ty = y + kNormDelta, tz = z + kNormDelta;
+        const float r = sqrtf(tx * tx + ty * ty + tz * tz);
+        const bool m = valid && slot < NN && r > kRinvDelta;
+        const bool live = __ballot(m) != 0ull;
+
+        f32x16 h1[2] = {zero16(), zero16()}, hd1[2] = {zero16(), zero16()};
+        f32x16 q2[2] = {zero16(), zero16()}, qd2[2] = {zero16(), zero16()}; // zb2, zdb2
+        f32x16 q1[2] = {zero16(), zero16()}, qd1[2] = {zero16(), zero16()}; // zb1, zdb1
+        float4 part = make_float4(0.f, 0.f, 0.f, 0.f); // this tile's share of (F_i, E_i)
+        if (live) {
+            // ---- value + r-tangent, forward.  phi / phid go to LDS at once (needed again only
+            // for dW1 at the end of the round)
+            f32x16 phi, phid;
+            {
+                const f32x16 cen = load_tab(lds + I::TabC, 0, h);
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const float d = r - cen[v];
+                    phi[v] = __expf(-(d * d) * ginv);
+                    phid[v] = -2.0f * d * ginv * phi[v];
+                }
+            }
+            publish(mine + 4 * kPB, p, h, phi);
+            publish(mine + 5 * kPB, p, h, phid);
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                f32x16 zz = load_tab(lds + I::TabB1, nb, h), zd = zero16();
+                mfma_pair(zz, zd, lds + I::L1 + nb * I::BS, lane, phi, phid);
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const float hv = act_fwd<TANH>(zz[v]);
+                    h1[nb][v] = hv;
+                    hd1[nb][v] = TANH ? (1.0f - hv * hv) * zd[v] : zd[v];
+                }
+            }
+            float upart = 0.f, dpart = 0.f;
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                f32x16 zz = load_tab(lds + I::TabB2, nb, h), zd = zero16();
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) mfma_pair(zz, zd, lds + I::L2 + (nb * 2 + kb) * I::BS, lane, h1[kb], hd1[kb]);
+                const f32x16 w3 = load_tab(lds + I::TabW3, nb, h);
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const float hv = act_fwd<TANH>(zz[v]);
+                    const float hdv = TANH ? (1.0f - hv * hv) * zd[v] : zd[v];
+                    q2[nb][v] = hv;   // h2  (becomes zb2 below)
+                    qd2[nb][v] = hdv; // hd2 (becomes zdb2)
+                    upart = fmaf(hv, w3[v], upart);
+                    dpart = fmaf(hdv, w3[v], dpart);
+                }
+            }
+            if (FUSED) { // u = w3 . h2 + b3, u' = w3 . hd2: the prediction itself (pair_mlp.hip)
+                const float uu = upart + __shfl_xor(upart, 32) + lds[I::TabB3];
+                const float du = dpart + __shfl_xor(dpart, 32);
+                if (m && h == 0) {
+                    const float c = du / r;
+                    part = make_float4(c * tx, c * ty, c * tz, 0.5f * uu);
+                }
+            }
+        }
+        // ---- residual of this wave's row
+        float4 rs;
+        if (FUSED) {
+            // ntiles in {1, 2, 4}: the row's tiles all sit in this round; sum them in wave order
+            part.x = group_sum<64>(part.x);
+            part.y = group_sum<64>(part.y);
+            part.z = group_sum<64>(part.z);
+            part.w = group_sum<64>(part.w);
+            if (lane == 0) rowsum[w] = part;
+            __syncthreads();
+            float4 F = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (unsigned t = 0; t < 4; ++t) {
+                const unsigned long long ut = base + t;
+                if (ut < U && (unsigned)(ut / ntiles) == row) {
+                    const float4 q = rowsum[t];
+                    F.x += q.x; F.y += q.y; F.z += q.z; F.w += q.w;
+                }
+            }
+            if (pred_out && valid && tile == 0 && lane == 0) pred_out[row] = F;
+            float lx, ly, lz, lw;
+            if (lab_f64) {
+                const double4 l = ((const double4 *)labels)[row];
+                lx = (float)l.x; ly = (float)l.y; lz = (float)l.z; lw = (float)l.w;
+            } else {
+                const float4 l = ((const float4 *)labels)[row];
+                lx = l.x; ly = l.y; lz = l.z; lw = l.w;
+            }
+            rs = make_float4(F.x - lx, F.y - ly, F.z - lz, F.w - lw);
+        } else {
+            rs = residual(pred, labels, lab_f64, row);
+        }
+        if (valid && tile == 0 && lane == 0) loss += rs.x * rs.x + rs.y * rs.y + rs.z * rs.z + rs.w * rs.w;
+        if (live) {
+            // ---- reverse seed: S = a u' + b u
+            const float aq = m ? 2.0f * (rs.x * tx + rs.y * ty + rs.z * tz) / r : 0.f;
+            const float bq = m ? rs.w : 0.f;
+            if (h == 0) gb3 += bq;
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                const f32x16 w3 = load_tab(lds + I::TabW3, nb, h);
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const float hv = q2[nb][v], hdv = qd2[nb][v];
+                    const float s2 = TANH ? 1.0f - hv * hv : 1.0f;
+                    gw3[nb][v] += bq * hv + aq * hdv;
+                    const float hb = bq * w3[v], hdb = aq * w3[v];
+                    q2[nb][v] = TANH ? hb * s2 - 2.0f * hdb * hv * hdv : hb; // zb2
+                    qd2[nb][v] = hdb * s2;                                     // zdb2
+                }
+            }
+        }
+        // ---- weight gradients: contractions over the pairs of the block's four tiles
+        if (lane == 0) live_flag[w] = live ? 1 : 0;
+        // D1: dW2 += h1 (x) zb2
+        if (live) {
+            publish(mine + 0 * kPB, p, h, h1[0]);
+            publish(mine + 1 * kPB, p, h, h1[1]);
+            publish(mine + 2 * kPB, p, h, q2[0]);
+            publish(mine + 3 * kPB, p, h, q2[1]);
+        }
+        __syncthreads();
+        const unsigned f1b = w >> 1, f2b = w & 1u;
+#pragma unroll 1
+        for (unsigned t = 0; t < 4; ++t) {
+            if (!live_flag[t]) continue;
+            const float *src = pub + t * kSlots * kPB;
+            const f32x16 A = load_op(src + f1b * kPB, p, h), Bm = load_op(src + (2 + f2b) * kPB, p, h);
+            outer16(acc2, A, Bm);
+            if (f1b == 0) gb2 += sum16(Bm);
+        }
+        __syncthreads();
+        // D2: dW2 += hd1 (x) zdb2
+        if (live) {
+            publish(mine + 0 * kPB, p, h, hd1[0]);
+            publish(mine + 1 * kPB, p, h, hd1[1]);
+            publish(mine + 2 * kPB, p, h, qd2[0]);
+            publish(mine + 3 * kPB, p, h, qd2[1]);
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (unsigned t = 0; t < 4; ++t) {
+            if (!live_flag[t]) continue;
+            const float *src = pub + t * kSlots * kPB;
+            const f32x16 A = load_op(src + f1b * kPB, p, h), Bm = load_op(src + (2 + f2b) * kPB, p, h);
+            outer16(acc2, A, Bm);
+        }
+        __syncthreads();
+        if (live) {
+            // ---- reverse through layer 2: (hb1, hdb1) = W2 (zb2, zdb2), then through act at z1
+#pragma unroll
+            for (int fb = 0; fb < 2; ++fb) {
+                f32x16 hb = zero16(), hdb = zero16();
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) mfma_pair(hb, hdb, lds + I::B2 + (fb * 2 + kb) * I::BS, lane, q2[kb], qd2[kb]);
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const float hv = h1[fb][v];
+                    const float s1 = TANH ? 1.0f - hv * hv : 1.0f;
+                    q1[fb][v] = TANH ? hb[v] * s1 - 2.0f * hdb[v] * hv * hd1[fb][v] : hb[v]; // zb1
+                    qd1[fb][v] = hdb[v] * s1;                                                  // zdb1
+                }
+            }
+                }
+        // D3: dW1 += phi (x) zb1  (wave w: feature block w&1, tiles 2(w>>1), 2(w>>1)+1)
+        if (live) {
+            publish(mine + 2 * kPB, p, h, q1[0]);
+            publish(mine + 3 * kPB, p, h, q1[1]);
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (unsigned t = 2 * (w >> 1); t < 2 * (w >> 1) + 2; ++t) {
+            if (!live_flag[t]) continue;
+            const float *src = pub + t * kSlots * kPB;
+            const f32x16 A = load_op(src + 4 * kPB, p, h), Bm = load_op(src + (2 + (w & 1u)) * kPB, p, h);
+            outer16(acc1, A, Bm);
+            gb1 += sum16(Bm);
+        }
+        __syncthreads();
+        // D4: dW1 += phid (x) zdb1
+        if (live) {
+            publish(mine + 2 * kPB, p, h, qd1[0]);
+            publish(mine + 3 * kPB, p, h, qd1[1]);
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (unsigned t = 2 * (w >> 1); t < 2 * (w >> 1) + 2; ++t) {
+            if (!live_flag[t]) continue;
+            const float *src = pub + t * kSlots * kPB;
+            const f32x16 A = load_op(src + 5 * kPB, p, h), Bm = load_op(src + (2 + (w & 1u)) * kPB, p, h);
+            outer16(acc1, A, Bm);
+        }
+        __syncthreads();
+    }
+
+    // ---- block partial in LDS, waves in a fixed order
+    float *red = pub; // 1 + P <= 6338 floats
+    for (unsigned c = threadIdx.x; c < stride; c += blockDim.x) red[c] = 0.f;
+    __syncthreads();
+    // gw3: sum over the 32 pairs of each lane half
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            float s = gw3[b][v];
+            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+            s += __shfl_xor(s, 8); s += __shfl_xor(s, 16);
+            gw3[b][v] = s;
+        }
+    gb1 += __shfl_xor(gb1, 32);
+    gb2 += __shfl_xor(gb2, 32);
+    gb3 = group_sum<64>(gb3);
+    for (unsigned turn = 0; turn < 4; ++turn) {
+        if (w == turn) {
+            // acc2: lane (j, h) register v = dW2[32 (w>>1) + f0(v) + 4h][32 (w&1) + j]
+            const int f2 = 32 * (int)(w & 1u) + (int)p;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int f1 = 32 * (int)(w >> 1) + f0(v) + 4 * (int)h;
+                if (f1 < dm.H1 && f2 < dm.H2) red[1 + dm.oW2 + f1 * dm.H2 + f2] += acc2[v];
+            }
+            // acc1: lane (j, h) register v = dW1[f0(v) + 4h][32 (w&1) + j]
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int k = f0(v) + 4 * (int)h;
+                if (k < dm.K && f2 < dm.H1) red[1 + k * dm.H1 + f2] += acc1[v];
+            }
+            if (h == 0 && f2 < dm.H1) red[1 + dm.oB1 + f2] += gb1;
+            if (h == 0 && (w >> 1) == 0 && f2 < dm.H2) red[1 + dm.oB2 + f2] += gb2;
+            if (p == 0) {
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) {
+                        const int f = 32 * b + f0(v) + 4 * (int)h;
+                        if (f < dm.H2) red[1 + dm.oW3 + f] += gw3[b][v];
+                    }
+            }
+            if (lane == 0) {
+                red[1 + dm.oB3] += gb3;
+                red[0] += loss;
+            }
+        }
+        __syncthreads();
+    }
+    float *out = partial + (size_t)blockIdx.x * stride;
+    for (unsigned c = threadIdx.x; c < stride; c += blockDim.x) out[c] = red[c];
+}
+
 // accum[c] = sum over waves, fixed order
 __global__ void mlp_reduce_partials_kernel(const float *__restrict__ partial, unsigned nwaves, unsigned stride,
                                            unsigned ncols, float *__restrict__ accum) {
@@ -186,13 +563,48 @@ int mlp_train_grad(const MlpDevice *m, const void *nlist, int in_dtype, unsigned
     const unsigned nw = train_waves(m, B), stride = train_stride(m);
     float *partial = scratch;
     float4 *predbuf = pred ? (float4 *)pred : (float4 *)(scratch + (size_t)nw * stride);
-    int rc = mlp_eval(m, nlist, in_dtype, B, NN, predbuf, HTF_F32, stream);
-    if (rc != HTF_OK) return rc;
+    static const bool force_valu = getenv("HTF_MLP_TRAIN_VALU") != nullptr;
+    static const bool no_fuse = getenv("HTF_MLP_TRAIN_NOFUSE") != nullptr;
+    const unsigned ntiles = (NN + 31) / 32;
+    const bool mfma = m->precision == HTF_MLP_FP32 && !force_valu;
+    const bool fused = mfma && !no_fuse && (ntiles == 1 || ntiles == 2 || ntiles == 4);
+    int rc = HTF_OK;
+    if (!fused) {
+        rc = mlp_eval(m, nlist, in_dtype, B, NN, predbuf, HTF_F32, stream);
+        if (rc != HTF_OK) return rc;
+    }
     MlpDims dm{m->K, m->H1, m->H2, m->off_b1(), m->off_W2(), m->off_b2(), m->off_W3(), m->off_b3()};
+    const bool th = m->act == HTF_ACT_TANH;
+    const unsigned ncols = (unsigned)m->num_params() + 1u;
+    // matrix-core kernel for fp32 potentials; the VALU kernel serves bf16-image potentials
+    // (their LDS images are not fp32 operands) and HTF_MLP_TRAIN_VALU=1 (A/B runs)
+    if (mfma) {
+        const unsigned long long units = (unsigned long long)B * ntiles;
+        unsigned nblk = (unsigned)m->n_cu;
+        if ((unsigned long long)nblk * 4 > units) nblk = (unsigned)((units + 3) / 4);
+#define HTF_LAUNCH_MLPM(T, IT, V4, F)                                                                                  \
+    hipLaunchKernelGGL((mlp_grad_mfma_kernel<T, IT, F>), dim3(nblk), dim3(256), 0, stream, (const V4 *)nlist, B, NN,   \
+                       labels, lab_f64, predbuf, (float4 *)pred, m->images, dm, m->gap, partial, stride)
+#define HTF_LAUNCH_MLPM2(T, IT, V4)                                                                                    \
+    do {                                                                                                               \
+        if (fused) HTF_LAUNCH_MLPM(T, IT, V4, true); else HTF_LAUNCH_MLPM(T, IT, V4, false);                           \
+    } while (0)
+        if (in_dtype == HTF_F32) {
+            if (th) HTF_LAUNCH_MLPM2(true, float, float4); else HTF_LAUNCH_MLPM2(false, float, float4);
+        } else {
+            if (th) HTF_LAUNCH_MLPM2(true, double, double4); else HTF_LAUNCH_MLPM2(false, double, double4);
+        }
+#undef HTF_LAUNCH_MLPM2
+#undef HTF_LAUNCH_MLPM
+        rc = check_launch("mlp_grad_mfma_kernel");
+        if (rc != HTF_OK) return rc;
+        hipLaunchKernelGGL(mlp_reduce_partials_kernel, dim3((ncols + 63) / 64), dim3(64), 0, stream, partial, nblk, stride,
+                           ncols, accum);
+        return check_launch("mlp_reduce_partials_kernel");
+    }
     const float *tab_c = m->images + (m->precision == HTF_MLP_BF16 ? Img<true>::TabC : Img<false>::TabC);
     const float ginv = 1.0f / m->gap;
     const dim3 grid(nw / 4), block(256);
-    const bool th = m->act == HTF_ACT_TANH;
 #define HTF_LAUNCH_MLPG(T, IT, V4)                                                                                     \
     hipLaunchKernelGGL((mlp_grad_kernel<T, IT>), grid, block, 0, stream, (const V4 *)nlist, B, NN, labels, lab_f64,    \
                        predbuf, m->theta, dm, tab_c, ginv, partial, stride)
@@ -204,7 +616,6 @@ int mlp_train_grad(const MlpDevice *m, const void *nlist, int in_dtype, unsigned
 #undef HTF_LAUNCH_MLPG
     rc = check_launch("mlp_grad_kernel");
     if (rc != HTF_OK) return rc;
-    const unsigned ncols = (unsigned)m->num_params() + 1u;
     hipLaunchKernelGGL(mlp_reduce_partials_kernel, dim3((ncols + 63) / 64), dim3(64), 0, stream, partial, nw, stride,
                        ncols, accum);
     return check_launch("mlp_reduce_partials_kernel");

@@ -56,6 +56,33 @@ struct MlpDevice {
 
 __host__ __device__ constexpr int f0(int v) { return (v & 3) + 8 * (v >> 2); }
 
+
+// ---- device helpers shared by the evaluator and the training kernel
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+
+template <bool TANH>
+__device__ __forceinline__ float act_fwd(float z) {
+    if constexpr (!TANH) return z;
+    // tanh(z) = sign(z) (1 - e) / (1 + e),  e = exp(-2|z|)  (abs error ~2e-7)
+    float e = __expf(-2.0f * fabsf(z));
+    float t = (1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e); // v_rcp_f32 (1 ulp); a/b would expand to the 10-instruction IEEE division
+    return copysignf(t, z);
+}
+
+#define HTF_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ f32x16 load_tab(const float *tab, int b, unsigned h) {
+    const float4 *p = reinterpret_cast<const float4 *>(tab + (b * 2 + h) * 16);
+    float4 a = p[0], bq = p[1], c = p[2], d = p[3];
+    f32x16 r;
+    r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w;
+    r[4] = bq.x; r[5] = bq.y; r[6] = bq.z; r[7] = bq.w;
+    r[8] = c.x; r[9] = c.y; r[10] = c.z; r[11] = c.w;
+    r[12] = d.x; r[13] = d.y; r[14] = d.z; r[15] = d.w;
+    return r;
+}
+
 int mlp_refresh(const MlpDevice *m, hipStream_t stream);
 int mlp_train_grad(const MlpDevice *m, const void *nlist, int in_dtype, unsigned B, unsigned NN, const void *labels,
                    int lab_f64, void *pred, float *accum, float *scratch, hipStream_t stream);

@@ -31,20 +31,6 @@
 
 namespace htf {
 
-using f32x16 = __attribute__((ext_vector_type(16))) float;
-
-
-template <bool TANH>
-__device__ __forceinline__ float act_fwd(float z) {
-    if constexpr (!TANH) return z;
-    // tanh(z) = sign(z) (1 - e) / (1 + e),  e = exp(-2|z|)  (abs error ~2e-7)
-    float e = __expf(-2.0f * fabsf(z));
-    float t = __fdividef(1.0f - e, 1.0f + e);
-    return copysignf(t, z);
-}
-
-#define HTF_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
-
 // acc += A(image) * B(prev), over one 32-feature block of the previous layer:
 // 16 k-steps, the image supplies 4 steps per ds_read_b128
 __device__ __forceinline__ void mfma_block(f32x16 &acc, const float *img, unsigned lane, const f32x16 &prev) {
@@ -84,17 +70,6 @@ __device__ __forceinline__ void mfma_blk(f32x16 &acc, const float *img, unsigned
         mfma_block_bf16(acc, img, lane, prev);
     else
         mfma_block(acc, img, lane, prev);
-}
-
-__device__ __forceinline__ f32x16 load_tab(const float *tab, int b, unsigned h) {
-    const float4 *p = reinterpret_cast<const float4 *>(tab + (b * 2 + h) * 16);
-    float4 a = p[0], bq = p[1], c = p[2], d = p[3];
-    f32x16 r;
-    r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w;
-    r[4] = bq.x; r[5] = bq.y; r[6] = bq.z; r[7] = bq.w;
-    r[8] = c.x; r[9] = c.y; r[10] = c.z; r[11] = c.w;
-    r[12] = d.x; r[13] = d.y; r[14] = d.z; r[15] = d.w;
-    return r;
 }
 
 template <bool TANH, typename IT, bool BF16>

@@ -185,13 +185,16 @@ def _flat_params(params):
     return np.concatenate([np.asarray(params[k], dtype=np.float64).ravel() for k in ("W1", "b1", "W2", "b2", "W3", "b3")])
 
 
-@pytest.mark.parametrize("dims,act", [((32, 64, 64), "tanh"), ((12, 20, 28), "tanh"), ((32, 64, 64), "linear")])
-def test_pair_mlp_loss_gradient_matches_double_backward(htf, cuda, dims, act):
+@pytest.mark.parametrize("dims,act,NN", [((32, 64, 64), "tanh", 24), ((12, 20, 28), "tanh", 24), ((32, 64, 64), "linear", 24),
+                                         ((32, 64, 64), "tanh", 72), ((32, 64, 64), "tanh", 128)])
+def test_pair_mlp_loss_gradient_matches_double_backward(htf, cuda, dims, act, NN):
     """One sweep (value + r-tangent forward, one reverse) == torch's double backward through
     the force, for every one of the 6337 weights; ragged widths exercise the zero padding."""
     from hoomd_tf_amd import initializers
     K, H1, H2 = dims
-    nl = _case(5, N=40, NN=24)
+    # NN = 72 (3 tiles per row) takes the two-pass route (evaluator, then gradient kernel);
+    # 1, 2 or 4 tiles per row form the prediction inside the gradient kernel
+    nl = _case(5, N=40 if NN == 24 else 21, NN=NN)
     nl64 = nl.astype(np.float64)
     params = initializers.mlp_params(seed=11, K=K, H1=H1, H2=H2)
     rng = np.random.default_rng(4)
