@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void eval_pair_kernel(const typename Vec4<IT>:
                                                         void *__restrict__ virial9, int out_f64, PotParams pin,
                                                         const unsigned *__restrict__ counts) {
     constexpr int RPW = 64 / G; // particle rows per wave
-    const PotParams p = resolve_theta(pin);
+    const PotParams p = resolve_theta<KIND>(pin);
     const unsigned lane = threadIdx.x & 63u;
     const unsigned g = lane % G, sub = lane / G;
     // Blocks walk the rows from the END of the tensor: in computeForces this kernel runs right
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void eval_pair2_kernel(const typename Vec4<IT>
                                                          void *__restrict__ forceB, int out_f64, PotParams pa_in,
                                                          PotParams pb, float *__restrict__ partials, RdfArgs rdf) {
     constexpr int RPW = 64 / G;
-    const PotParams pa = resolve_theta(pa_in);
+    const PotParams pa = resolve_theta<KA>(pa_in);
     __shared__ float s_part[4];
     __shared__ unsigned s_hist[kRdfMaxBins];
     if (rdf.hist != nullptr) {

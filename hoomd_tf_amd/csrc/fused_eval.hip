@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void fused_forces_kernel(const typename Vec4<P
                                                            void *__restrict__ force, void *__restrict__ virial9,
                                                            int out_f64, PotParams pin, unsigned *__restrict__ check_count,
                                                            float4 *__restrict__ positions_out) {
-    const PotParams p = resolve_theta(pin);
+    const PotParams p = resolve_theta<KIND>(pin);
     const unsigned lane = threadIdx.x & 63u;
     const unsigned w = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     if (w >= batch) return;

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void train_pair_kernel(const typename Vec4<IT>
                                                          float *__restrict__ partials) {
     constexpr int G = kTrainG, RPW = 64 / G, P = NumParams<KIND>::value;
     __shared__ float s_part[4][1 + P];
-    const PotParams p = resolve_theta(pin);
+    const PotParams p = resolve_theta<KIND>(pin);
     const unsigned lane = threadIdx.x & 63u, g = lane % G, sub = lane / G;
     const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const unsigned row = wave * RPW + sub;
