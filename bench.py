@@ -326,7 +326,7 @@ def main():
         if nl.n_builds != state["builds"]:
             state["arr"] = arrays()
             state["builds"] = nl.n_builds
-        ctx.compute_forces(ts, state["arr"])
+        ctx.compute_forces_overlapped(ts, state["arr"], nl.domain)
         if train is not None and ts % args.train_period == 0:
             train(timed)
         nve.step()
@@ -347,7 +347,7 @@ def main():
         if nl.n_builds != state["builds"]:
             state["arr"] = arrays()
             state["builds"] = nl.n_builds
-        ctx.compute_forces(ts, state["arr"])
+        ctx.compute_forces_overlapped(ts, state["arr"], nl.domain)
         f3 = sysm.force[:, :3]
         fm = f3.norm(dim=1, keepdim=True).clamp_min(1e-12)
         f3.mul_(torch.clamp(200.0 / fm, max=1.0))
@@ -387,8 +387,10 @@ def main():
 
     n_entries = int(nl.n_neigh.long().sum().item())
     eval_b, build_b, integ_b = algorithmic_bytes(N, NN, n_entries, N + sysm.n_ghost)
-    eval_avg_s = eval_ms / max(ncalls, 1) * 1e-3
-    build_avg_s = build_ms / max(ncalls, 1) * 1e-3
+    # per STEP (with slabs a step is two row ranges = two launches of each kernel; the
+    # algorithmic bytes below are per step as well)
+    eval_avg_s = eval_ms / max(args.steps, 1) * 1e-3 if ncalls else 0.0
+    build_avg_s = build_ms / max(args.steps, 1) * 1e-3 if ncalls else 0.0
     kern = {
         "eval_forces": {"avg_us": eval_avg_s * 1e6, "algorithmic_bytes": eval_b,
                         "GBps": eval_b / eval_avg_s / 1e9 if eval_avg_s > 0 else None},
@@ -463,7 +465,7 @@ def main():
                 state["arr"] = arrays()
                 state["arr_f"] = ctx_f.make_arrays(sysm.pos, sysm.N, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, sysm.force)
                 state["builds"] = nl.n_builds
-            ctx_f.compute_forces(ts, state["arr_f"])
+            ctx_f.compute_forces_overlapped(ts, state["arr_f"], nl.domain)
             nve.step()
             state["ts"] = ts + 1
 

@@ -103,6 +103,7 @@ PROTOTYPES = {
     "htf_set_potential": (_i, [_vp, _vp]),
     "htf_resize": (_i, [_vp, _u]),
     "htf_compute_forces": (_i, [_vp, _u, C.POINTER(HoomdArrays), _vp]),
+    "htf_compute_forces_rows": (_i, [_vp, _u, C.POINTER(HoomdArrays), _u, _u, _vp]),
     "htf_get_nlist_buffer": (_vp, [_vp]),
     "htf_get_positions_buffer": (_vp, [_vp]),
     "htf_get_virial_buffer": (_vp, [_vp]),

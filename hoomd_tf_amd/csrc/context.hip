@@ -318,7 +318,12 @@ extern "C" void *htf_get_positions_buffer(htf_ctx *ctx) { return ctx ? ctx->posi
 extern "C" void *htf_get_virial_buffer(htf_ctx *ctx) { return ctx ? ctx->virial : nullptr; }
 extern "C" unsigned htf_get_batch_capacity(htf_ctx *ctx) { return ctx ? ctx->capacity : 0; }
 
-extern "C" int htf_compute_forces(htf_ctx *ctx, unsigned timestep, const htf_hoomd_arrays *a, htf_stream stream) {
+// Rows [row_begin, row_begin + row_count) of one computeForces call.  batch_size == 0: the scratch
+// holds all N rows, row i in slot i, so a step may be computed in several row ranges (interior
+// rows while the ghost halo is in flight, boundary rows after it) and the buffers still end
+// up holding the whole step.  batch_size > 0: slot = row - batch offset, as upstream.
+static int compute_rows(htf_ctx *ctx, unsigned timestep, const htf_hoomd_arrays *a, unsigned row_begin,
+                        unsigned row_count, htf_stream stream) {
     using namespace htf;
     HTF_REQUIRE(ctx && a, "htf_compute_forces: null pointer");
     const htf_config &cfg = ctx->cfg;
@@ -332,18 +337,23 @@ extern "C" int htf_compute_forces(htf_ctx *ctx, unsigned timestep, const htf_hoo
         return HTF_ERR_SKEWED_BOX;
     }
     const unsigned N = a->N;
-    if (N == 0) return HTF_OK;
+    if (N == 0 || row_count == 0) return HTF_OK;
+    HTF_REQUIRE(row_begin < N && row_count <= N - row_begin, "htf_compute_forces_rows: rows [%u, +%u) outside [0, %u)", row_begin, row_count, N);
     if (cfg.batch_size == 0 && N > ctx->capacity) {
         int rc = ctx_alloc(ctx, N); // MaxParticleNumberChange -> reallocate (.cc:88)
         if (rc != HTF_OK) return rc;
     }
     const size_t ssz = cfg.scalar_dtype == HTF_F64 ? 8 : 4;
     hipStream_t s = (hipStream_t)stream;
-    const unsigned bs = cfg.batch_size == 0 ? N : cfg.batch_size;
-    for (unsigned i = 0; i < N / bs + 1; ++i) { // .cc:143
-        const unsigned offset = i * bs;
-        if (offset >= N) break;
-        const unsigned n = std::min(N - offset, bs);
+    const unsigned bs = cfg.batch_size == 0 ? row_count : cfg.batch_size;
+    const unsigned row_end = row_begin + row_count;
+    for (unsigned offset = row_begin; offset < row_end; offset += bs) { // .cc:143
+        const unsigned n = std::min(row_end - offset, bs);
+        const size_t slot0 = cfg.batch_size == 0 ? offset : 0;
+        float4 *c_nlist = ctx->nlist ? ctx->nlist + slot0 * cfg.nneighs : nullptr;
+        float4 *c_positions = ctx->positions + slot0;
+        unsigned *c_counts = ctx->counts ? ctx->counts + slot0 : nullptr;
+        void *c_virial = (char *)ctx->virial + slot0 * 9 * ssz;
         int rc;
         const bool prof = ctx->profiling && cfg.nneighs > 0 && ctx->pot != nullptr;
         hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
@@ -362,8 +372,8 @@ extern "C" int htf_compute_forces(htf_ctx *ctx, unsigned timestep, const htf_hoo
             void *fo = (char *)a->force + (size_t)offset * 4 * ssz;
             rc = fused_forces_impl(ctx->pot->pp, a->pos, cfg.scalar_dtype, N, cfg.nneighs, offset, n, &a->box, a->n_neigh,
                                    a->nlist, a->head_list, cfg.r_cut, fo, cfg.scalar_dtype,
-                                   cfg.virial ? ctx->virial : nullptr, cfg.check_nlist ? ctx->flag : nullptr,
-                                   ctx->positions, s);
+                                   cfg.virial ? c_virial : nullptr, cfg.check_nlist ? ctx->flag : nullptr,
+                                   c_positions, s);
             if (rc != HTF_OK) return rc;
             if (prof) HTF_CHECK_HIP(hipEventRecord(e2, s));
             if (cfg.check_nlist) {
@@ -376,7 +386,7 @@ extern "C" int htf_compute_forces(htf_ctx *ctx, unsigned timestep, const htf_hoo
                 }
             }
             if (cfg.virial && a->virial) {
-                rc = htf_add_virial((char *)a->virial + (size_t)offset * ssz, ctx->virial, cfg.scalar_dtype, n,
+                rc = htf_add_virial((char *)a->virial + (size_t)offset * ssz, c_virial, cfg.scalar_dtype, n,
                                     a->virial_pitch, stream);
                 if (rc != HTF_OK) return rc;
             }
@@ -385,14 +395,14 @@ extern "C" int htf_compute_forces(htf_ctx *ctx, unsigned timestep, const htf_hoo
         if (cfg.nneighs > 0) {
             HTF_REQUIRE(a->n_neigh && a->nlist && a->head_list, "htf_compute_forces: null neighbor list");
             // positions side buffer (m_positions_comm.receiveArray, .cc:172) is staged by the same kernel
-            rc = build_pair_vectors_impl(ctx->nlist, HTF_F32, a->pos, cfg.scalar_dtype, N, cfg.nneighs, offset, n,
+            rc = build_pair_vectors_impl(c_nlist, HTF_F32, a->pos, cfg.scalar_dtype, N, cfg.nneighs, offset, n,
                                          &a->box, a->n_neigh, a->nlist, a->head_list, cfg.r_cut, nullptr,
-                                         ctx->positions, ctx->counts, s);
+                                         c_positions, c_counts, s);
             if (rc != HTF_OK) return rc;
         }
         if (prof) HTF_CHECK_HIP(hipEventRecord(e1, s));
         if (cfg.nneighs == 0) { // positions-only models (nneighbor_cutoff = 0) live above the ABI
-            rc = htf_copy_positions(ctx->positions, HTF_F32, a->pos, cfg.scalar_dtype, offset, n, 1, stream);
+            rc = htf_copy_positions(c_positions, HTF_F32, a->pos, cfg.scalar_dtype, offset, n, 1, stream);
             if (rc != HTF_OK) return rc;
             continue;
         }
@@ -400,7 +410,7 @@ extern "C" int htf_compute_forces(htf_ctx *ctx, unsigned timestep, const htf_hoo
         if (cfg.check_nlist) {
             unsigned h = 0;
             HTF_CHECK_HIP(hipMemsetAsync(ctx->flag, 0, sizeof(unsigned), s));
-            rc = htf_check_nlist(ctx->nlist, HTF_F32, n, cfg.nneighs, ctx->flag, stream);
+            rc = htf_check_nlist(c_nlist, HTF_F32, n, cfg.nneighs, ctx->flag, stream);
             if (rc != HTF_OK) return rc;
             HTF_CHECK_HIP(hipMemcpyAsync(&h, ctx->flag, sizeof(unsigned), hipMemcpyDeviceToHost, s));
             HTF_CHECK_HIP(hipStreamSynchronize(s));
@@ -411,20 +421,29 @@ extern "C" int htf_compute_forces(htf_ctx *ctx, unsigned timestep, const htf_hoo
         }
         void *force_out = (char *)a->force + (size_t)offset * 4 * ssz; // m_forces_comm.setOffset(offset) .cc:192
         if (ctx->pot->pp.kind == HTF_POT_PAIR_MLP)
-            rc = htf_eval_forces(ctx->pot, ctx->nlist, HTF_F32, n, cfg.nneighs, force_out, cfg.scalar_dtype,
-                                 cfg.virial ? ctx->virial : nullptr, stream);
+            rc = htf_eval_forces(ctx->pot, c_nlist, HTF_F32, n, cfg.nneighs, force_out, cfg.scalar_dtype,
+                                 cfg.virial ? c_virial : nullptr, stream);
         else
-            rc = eval_pair_dispatch(ctx->pot->pp, ctx->nlist, HTF_F32, n, cfg.nneighs, force_out, cfg.scalar_dtype,
-                                    cfg.virial ? ctx->virial : nullptr, ctx->counts, s);
+            rc = eval_pair_dispatch(ctx->pot->pp, c_nlist, HTF_F32, n, cfg.nneighs, force_out, cfg.scalar_dtype,
+                                    cfg.virial ? c_virial : nullptr, c_counts, s);
         if (rc != HTF_OK) return rc;
         if (prof) HTF_CHECK_HIP(hipEventRecord(e2, s));
         if (cfg.virial && a->virial) { // receiveVirial(offset, N) .cc:200-204
-            rc = htf_add_virial((char *)a->virial + (size_t)offset * ssz, ctx->virial, cfg.scalar_dtype, n,
+            rc = htf_add_virial((char *)a->virial + (size_t)offset * ssz, c_virial, cfg.scalar_dtype, n,
                                 a->virial_pitch, stream);
             if (rc != HTF_OK) return rc;
         }
     }
     return HTF_OK;
+}
+
+extern "C" int htf_compute_forces(htf_ctx *ctx, unsigned timestep, const htf_hoomd_arrays *a, htf_stream stream) {
+    return compute_rows(ctx, timestep, a, 0, a ? a->N : 0, stream);
+}
+
+extern "C" int htf_compute_forces_rows(htf_ctx *ctx, unsigned timestep, const htf_hoomd_arrays *a, unsigned row_begin,
+                                       unsigned row_count, htf_stream stream) {
+    return compute_rows(ctx, timestep, a, row_begin, row_count, stream);
 }
 
 extern "C" int htf_profile_enable(htf_ctx *ctx, int on) {

@@ -11,6 +11,10 @@ inference: the only per-step message is ~0.5 MB of float4 positions per slab fac
 Layout after ``rebuild()`` (HOOMD's): ``pos[:N]`` local particles, ``pos[N:N+n_ghost]``
 ghosts = [from left neighbor | from right neighbor].  Ghosts keep the owner's raw
 coordinates; the pair-vector build applies the minimum image of the GLOBAL box.
+Local particles are ordered [interior | within r_ghost of the left face | ... of the right
+face]: the two halo messages are contiguous slices of ``pos`` (sent in place, no packing
+kernel), and rows ``[0, n_interior)`` have no ghost in their neighbor lists, so their forces
+can be evaluated while the halo is in flight (``exchange_begin`` / ``exchange_end``).
 
 Message naming: "L>" = sent to my left neighbor (my particles within r_ghost of my left
 face), "R>" = sent to my right neighbor.  Every rank posts sends in the order [L>, R>] and
@@ -22,6 +26,28 @@ import torch
 import torch.distributed as dist
 
 TAG_L, TAG_R = 11, 12
+
+
+class _StagedHalo:
+    """gloo transport for device buffers: bounce through host copies.  Only the 2-ranks-on-one-GPU
+    test rig uses it; on the GPU box the backend is nccl (= RCCL) and messages go device to
+    device over xGMI."""
+
+    def __init__(self, ops):
+        self._back = []
+        staged = []
+        for op in ops:
+            host = op.tensor.cpu() if op.op is dist.isend else torch.empty(op.tensor.shape, dtype=op.tensor.dtype)
+            if op.op is dist.irecv:
+                self._back.append((op.tensor, host))
+            staged.append(dist.P2POp(op.op, host, op.peer, op.group, op.tag))
+        self._works = dist.batch_isend_irecv(staged)
+
+    def wait(self):
+        for w in self._works:
+            w.wait()
+        for dev, host in self._back:
+            dev.copy_(host)
 
 
 class SlabDomain:
@@ -43,9 +69,16 @@ class SlabDomain:
             raise ValueError("slab thinner than 2 * r_ghost: a particle would be a ghost on both sides")
         self.left = (self.rank - 1) % self.world
         self.right = (self.rank + 1) % self.world
-        self.send_left = self.send_right = None
+        self.send_left = self.send_right = None   # (start, stop) row ranges of pos
+        self.n_interior = 0
         self.n_from_left = self.n_from_right = 0
         self.n_migrated = 0
+        self._works = None
+
+    @property
+    def pending(self):
+        """True between exchange_begin() and exchange_end()."""
+        return self._works is not None
 
     # ------------------------------------------------------------------ helpers
     def _all_counts(self, a, b):
@@ -62,7 +95,7 @@ class SlabDomain:
         self._swap_into(to_left, to_right, from_right, from_left)
         return from_right, from_left
 
-    def _swap_into(self, to_left, to_right, from_right, from_left):
+    def _post(self, to_left, to_right, from_right, from_left):
         ops = []
         if to_left.numel():
             ops.append(dist.P2POp(dist.isend, to_left, self.left, self.group, TAG_L))
@@ -72,9 +105,15 @@ class SlabDomain:
             ops.append(dist.P2POp(dist.irecv, from_right, self.right, self.group, TAG_L))
         if from_left.numel():
             ops.append(dist.P2POp(dist.irecv, from_left, self.left, self.group, TAG_R))
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
+        if not ops:
+            return []
+        if to_left.is_cuda and dist.get_backend(self.group) == "gloo":
+            return [_StagedHalo(ops)]  # gloo moves host memory only (single-GPU test rigs)
+        return dist.batch_isend_irecv(ops)
+
+    def _swap_into(self, to_left, to_right, from_right, from_left):
+        for w in self._post(to_left, to_right, from_right, from_left):
+            w.wait()
 
     # ------------------------------------------------------------------ migration + ghost plan
     def rebuild(self):
@@ -109,11 +148,18 @@ class SlabDomain:
         new_pos = torch.cat([pos[stay], got_r[:, :4], got_l[:, :4]], dim=0)
         new_vel = torch.cat([vel[stay], got_r[:, 4:], got_l[:, 4:]], dim=0)
         N = int(new_pos.shape[0])
-        # ghost plan: who sits within r_ghost of a face
+        # ghost plan: who sits within r_ghost of a face.  Slabs are >= 2 r_ghost thick, so the two
+        # sets are disjoint; a stable sort on the class puts them behind the interior particles.
         x = new_pos[:, 0]
-        self.send_left = torch.nonzero(x < self.xlo + self.r_ghost).flatten()
-        self.send_right = torch.nonzero(x >= self.xhi - self.r_ghost).flatten()
-        counts = self._all_counts(self.send_left.numel(), self.send_right.numel())
+        cls = (x < self.xlo + self.r_ghost).to(torch.int8) + 2 * (x >= self.xhi - self.r_ghost).to(torch.int8)
+        perm = torch.sort(cls, stable=True)[1]
+        new_pos = new_pos.index_select(0, perm)
+        new_vel = new_vel.index_select(0, perm)
+        n_l, n_r = int((cls == 1).sum()), int((cls == 2).sum())
+        self.n_interior = N - n_l - n_r
+        self.send_left = (self.n_interior, self.n_interior + n_l)
+        self.send_right = (self.n_interior + n_l, N)
+        counts = self._all_counts(n_l, n_r)
         self.n_from_right = counts[self.right][0]
         self.n_from_left = counts[self.left][1]
         s.N = N
@@ -125,14 +171,29 @@ class SlabDomain:
             s.virial = torch.zeros(6 * N, dtype=s.dtype, device=s.pos.device)
         self.exchange()
 
-    def exchange(self):
-        """Per-step forward halo: refresh ghost positions from their owners."""
+    def exchange_begin(self):
+        """Post the per-step forward halo (ghost positions from their owners).  The messages
+        are slices of ``pos`` itself; on RCCL the transfer runs on the communicator's stream
+        after everything already queued on the current stream, so interior rows can be
+        evaluated meanwhile.  Nothing may write ``pos`` until exchange_end()."""
         if self.world == 1 or self.send_left is None:
             return
         s = self.sys
         N = s.N
-        to_left = s.pos[:N].index_select(0, self.send_left)
-        to_right = s.pos[:N].index_select(0, self.send_right)
+        to_left = s.pos[self.send_left[0]:self.send_left[1]]
+        to_right = s.pos[self.send_right[0]:self.send_right[1]]
         from_left = s.pos[N:N + self.n_from_left]                 # R> of my left neighbor
         from_right = s.pos[N + self.n_from_left:N + s.n_ghost]    # L> of my right neighbor
-        self._swap_into(to_left, to_right, from_right, from_left)
+        self._works = self._post(to_left, to_right, from_right, from_left)
+
+    def exchange_end(self):
+        """Make the current stream wait for the halo posted by exchange_begin()."""
+        if self._works is not None:
+            for w in self._works:
+                w.wait()
+            self._works = None
+
+    def exchange(self):
+        """Per-step forward halo, blocking form."""
+        self.exchange_begin()
+        self.exchange_end()

@@ -365,9 +365,25 @@ class Context:
         a.virial_pitch = int(virial_pitch)
         return a
 
-    def compute_forces(self, timestep, arrays, stream=None):
+    def compute_forces(self, timestep, arrays, stream=None, rows=None):
+        """``rows=(begin, count)``: only those particle rows (htf_compute_forces_rows)."""
         s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
-        check(lib.htf_compute_forces(self._h, int(timestep), C.byref(arrays), C.c_void_p(s)))
+        if rows is None:
+            check(lib.htf_compute_forces(self._h, int(timestep), C.byref(arrays), C.c_void_p(s)))
+        elif rows[1] > 0:
+            check(lib.htf_compute_forces_rows(self._h, int(timestep), C.byref(arrays), int(rows[0]), int(rows[1]),
+                                              C.c_void_p(s)))
+
+    def compute_forces_overlapped(self, timestep, arrays, domain, stream=None):
+        """One step under domain decomposition: interior rows (no ghost neighbors) while the
+        ghost-position halo is in flight, boundary rows once it has landed."""
+        if domain is None or not domain.pending:
+            self.compute_forces(timestep, arrays, stream)
+            return
+        n_int = domain.n_interior
+        self.compute_forces(timestep, arrays, stream, rows=(0, n_int))
+        domain.exchange_end()
+        self.compute_forces(timestep, arrays, stream, rows=(n_int, arrays.N - n_int))
 
     def profile_enable(self, on=True):
         """Event-bracket the build and eval scopes (HOOMD Profiler analogue)."""

@@ -189,7 +189,13 @@ class CellNlist:
         if self._ref is None or (timestep % self.check_period == 0 and self.needs_update()):
             self.build()
         elif self.domain is not None:
-            self.domain.exchange()  # per-step forward halo of ghost positions
+            # per-step forward halo of ghost positions: posted here, awaited by the force compute
+            # after its interior rows (Context.compute_forces_overlapped) or by finish_halo()
+            self.domain.exchange_begin()
+
+    def finish_halo(self):
+        if self.domain is not None:
+            self.domain.exchange_end()
 
 
 class NVE:

@@ -118,11 +118,15 @@ class tfcompute:
             return
         if self._nlist is not None:
             self._nlist.compute(timestep)  # m_nlist->compute(timestep), .cc:162-163
+        domain = getattr(self._nlist, "domain", None)
         if self._plan is not None and self.model._plan is self._plan:
             self._calls += 1
-            self.cpp_force.compute_forces(timestep, self._arrays())
+            # interior rows while the ghost halo is in flight, boundary rows after it
+            self.cpp_force.compute_forces_overlapped(timestep, self._arrays(), domain)
             self._ctx_ran = True
             return
+        if domain is not None:
+            domain.exchange_end()
         s = self.system
         bs = s.N if self.batch_size == 0 else self.batch_size
         simmodel._trace_log().clear()

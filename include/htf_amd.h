@@ -318,6 +318,15 @@ HTF_API int htf_resize(htf_ctx *ctx, unsigned max_n);                   /* reall
  * stream; it only runs when cfg.check_nlist is set). */
 HTF_API int htf_compute_forces(htf_ctx *ctx, unsigned timestep, const htf_hoomd_arrays *arrays, htf_stream stream);
 
+/* The same call restricted to particle rows [row_begin, row_begin + row_count): lets a
+ * domain-decomposed caller evaluate the rows that have no ghost neighbors while HOOMD's
+ * Communicator (or hoomd_tf_amd/domain.py) is still refreshing ghost positions, and the
+ * boundary rows afterwards.  With batch_size == 0 the context buffers (htf_get_*_buffer)
+ * hold row i in slot i, so after the ranges of a step have been computed they describe the
+ * whole step exactly as one htf_compute_forces call would. */
+HTF_API int htf_compute_forces_rows(htf_ctx *ctx, unsigned timestep, const htf_hoomd_arrays *arrays,
+                            unsigned row_begin, unsigned row_count, htf_stream stream);
+
 /* Buffer getters (TensorflowCompute.cc:398-407 get*Buffer): device pointers of the
  * context-owned side buffers, for zero-copy views.  nlist: fp32 [B, NN, 4];
  * positions: fp32 [B, 4] (type un-stuffed); virial: Scalar [B, 9]. */

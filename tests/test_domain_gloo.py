@@ -75,6 +75,18 @@ def _worker(rank, world, port, fractions, q):
             fg, _ = O.compute_forces(global_pos.copy(), np.zeros(n * n, np.int32), gn, gh, gl, O.make_box(L), rcut, 64,
                                      lambda t: O.lj_model(t.astype(np.float64)), model_dtype=np.float64)
             np.testing.assert_allclose(f, fg[my_ids], atol=1e-5)
+            # (4) layout [interior | near-left | near-right]: the halo messages are the two tail
+            # slices, and no interior row has a ghost in its neighbor list -- what lets the
+            # force compute run rows [0, n_interior) while the halo is in flight
+            ni = dom.n_interior
+            assert dom.send_left == (ni, dom.send_left[1]) and dom.send_right == (dom.send_left[1], N)
+            x = p_all[:N, 0]
+            assert np.all(x[dom.send_left[0]:dom.send_left[1]] < dom.xlo + dom.r_ghost)
+            assert np.all(x[dom.send_right[0]:dom.send_right[1]] >= dom.xhi - dom.r_ghost)
+            assert np.all((x[:ni] >= dom.xlo + dom.r_ghost) & (x[:ni] < dom.xhi - dom.r_ghost))
+            for i in range(ni):
+                assert np.all(nl[head[i]:head[i] + nn[i]] < N), "interior row %d has a ghost neighbor" % i
+            assert 0 < ni < N
             return my_ids
 
         gpos = pos.copy()
@@ -87,7 +99,13 @@ def _worker(rank, world, port, fractions, q):
             N = system.N
             my_ids = system.types_numpy()
             system.pos[:N, :3] = torch.from_numpy(gpos[my_ids])
-            dom.exchange()
+            if step == 1:  # split form: interior work would go between the two calls
+                dom.exchange_begin()
+                assert dom.pending
+                dom.exchange_end()
+                assert not dom.pending
+            else:
+                dom.exchange()
             gid = (system.pos[N:, 3].contiguous().view(torch.int64) & 0xFFFFFFFF).numpy()
             np.testing.assert_array_equal(system.pos[N:, :3].numpy(), gpos[gid])
         ids_after = check(gpos)

@@ -1,0 +1,127 @@
+"""Domain-decomposed MD on the GPU kernels: 2 ranks share the one GPU of the test box (gloo
+transport with host bounce buffers -- RCCL refuses two ranks on one device), run LJ MD
+with migration, ghost halo and the interior/boundary split of htf_compute_forces_rows, and
+every rank's forces must equal the single-domain forces of the gathered configuration (the
+reference's MPI assertion, test_mpi_tensorflow.py:57-79, on the HIP path)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from helpers import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        sys.path.insert(0, ROOT)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import hoomd_tf_amd as htf
+        from hoomd_tf_amd import standin
+        from hoomd_tf_amd.domain import SlabDomain
+
+        dev = torch.device("cuda:0")
+        rcut, rbuf, NN = 2.5, 0.4, 80
+        cells = (12, 6, 6)  # 12 x 6 x 6 fcc cells: two slabs of 6 cells (8.4 sigma >= 2 r_ghost)
+        a = (4.0 / 0.8442) ** (1.0 / 3.0)
+        base = np.array([[0, 0, 0], [.5, .5, 0], [.5, 0, .5], [0, .5, .5]])
+        grid = np.stack(np.meshgrid(*[np.arange(c) for c in cells], indexing="ij"), -1).reshape(-1, 3)
+        pos = ((grid[:, None, :] + base[None]) * a).reshape(-1, 3)
+        L = np.array(cells, dtype=np.float64) * a
+        pos = pos - L / 2
+        rng = np.random.default_rng(5)
+        pos += 0.05 * a * rng.standard_normal(pos.shape)
+        pos -= np.round(pos / L) * L
+        Ng = len(pos)
+        ids = np.arange(Ng)
+        vel = np.zeros((Ng, 4))
+        vel[:, :3] = 1.5 * rng.standard_normal((Ng, 3))
+        vel[:, 3] = 1.0
+        bounds = -L[0] / 2 + np.linspace(0, 1, world + 1) * L[0]
+        mine = (pos[:, 0] >= bounds[rank]) & (pos[:, 0] < bounds[rank + 1])
+        sysm = standin.System(pos[mine], L, types=ids[mine], dtype=torch.float32, device=dev)
+        sysm.vel = torch.from_numpy(vel[mine]).to(torch.float32).to(dev)
+        nl = standin.CellNlist(sysm, r_cut=rcut, r_buff=rbuf, check_period=1)
+        nl.domain = SlabDomain(sysm, rank, world, r_ghost=rcut + rbuf)
+        nl.build()
+        ctx = htf.Context(r_cut=rcut, nneighs=NN, scalar_dtype=torch.float32, max_n=sysm.N)
+        pot = htf.Potential.lj()
+        ctx.set_potential(pot)
+        nve = standin.NVE(sysm, 0.004)
+        builds, arr = -1, None
+        overlapped = 0
+        for ts in range(80):
+            nl.compute(ts)
+            if nl.n_builds != builds:
+                arr = ctx.make_arrays(sysm.pos, sysm.N, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, sysm.force)
+                builds = nl.n_builds
+            overlapped += int(nl.domain.pending)
+            ctx.compute_forces_overlapped(ts, arr, nl.domain)
+            if ts < 79:
+                nve.step()
+        torch.cuda.synchronize()
+        assert nl.n_builds >= 2 and overlapped >= 20, (nl.n_builds, overlapped)
+        # gather the configuration by particle id
+        N = sysm.N
+        my_ids = sysm.types_numpy()
+        loc = torch.zeros((Ng, 3), dtype=torch.float64)
+        loc[my_ids] = sysm.pos[:N, :3].double().cpu()
+        owned = torch.zeros(Ng, dtype=torch.float64)
+        owned[my_ids] = 1
+        dist.all_reduce(loc)
+        dist.all_reduce(owned)
+        assert bool((owned == 1).all()), "particles lost or duplicated"
+        # single-domain forces of that configuration on the same kernels
+        ref_sys = standin.System(loc.numpy(), L, dtype=torch.float32, device=dev)
+        ref_nl = standin.CellNlist(ref_sys, r_cut=rcut, r_buff=rbuf)
+        ref_nl.build()
+        ref_ctx = htf.Context(r_cut=rcut, nneighs=NN, scalar_dtype=torch.float32, max_n=Ng)
+        ref_ctx.set_potential(pot)
+        ref_arr = ref_ctx.make_arrays(ref_sys.pos, Ng, ref_nl.n_neigh, ref_nl.head_list, ref_nl.nlist, ref_sys.box, ref_sys.force)
+        ref_ctx.compute_forces(0, ref_arr)
+        torch.cuda.synchronize()
+        want = ref_sys.force.cpu().numpy()[my_ids]
+        got = sysm.force[:N].cpu().numpy()
+        # same pair set, different summation order (neighbor order differs between the two lists)
+        scale = np.abs(want).max()
+        assert np.abs(got - want).max() < 2e-5 * scale, (np.abs(got - want).max(), scale)
+        moved = torch.tensor([nl.domain.n_migrated])
+        dist.all_reduce(moved)
+        assert int(moved) > 0, "test must exercise migration"
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+def test_two_slabs_on_one_gpu(htf, cuda):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in results:
+        assert msg == "ok", "rank %d failed:\n%s" % (rank, msg)

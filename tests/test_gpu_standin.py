@@ -75,3 +75,55 @@ def test_nve_step_and_displacement(htf, cuda):
     for _ in range(20):
         nve.step()
     assert nl.needs_update()
+
+
+@pytest.mark.parametrize("mode", ["plain", "virial", "fused", "mlp"])
+def test_compute_forces_in_row_ranges_equals_whole(htf, cuda, mode):
+    """htf_compute_forces_rows: a step computed as [0, n1) then [n1, N) (interior rows while the
+    halo is in flight, boundary rows after it) leaves forces, virial and the context's
+    pair-vector / positions buffers exactly as one htf_compute_forces call does."""
+    from hoomd_tf_amd import standin
+    pos, L, a = standin.fcc_positions(6, 0.8442)
+    rng = np.random.default_rng(2)
+    pos = pos + 0.06 * a * rng.standard_normal(pos.shape)
+    pos -= np.round(pos / L) * L
+    sysm = standin.System(pos, L, dtype=torch.float32, device=cuda)
+    nl = standin.CellNlist(sysm, r_cut=2.5, r_buff=0.3)
+    nl.build()
+    N, NN = sysm.N, 80
+    pot = htf.Potential.pair_mlp(__import__("hoomd_tf_amd").initializers.mlp_params(seed=3), 0.0, 3.0, activation="tanh") \
+        if mode == "mlp" else htf.Potential.lj()
+    virial = mode == "virial"
+
+    def run(split):
+        ctx = htf.Context(r_cut=2.5, nneighs=NN, scalar_dtype=torch.float32, max_n=N, virial=virial,
+                          fused=(mode == "fused"))
+        ctx.set_potential(pot)
+        force = torch.zeros((N, 4), device=cuda)
+        vir = torch.zeros(6 * N, device=cuda) if virial else None
+        arr = ctx.make_arrays(sysm.pos, N, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, force, vir, N)
+        for ts in range(2):  # second pass exercises the delta zero-fill bookkeeping per row
+            if virial:
+                vir.zero_()
+            if split:
+                n1 = 317
+                ctx.compute_forces(ts, arr, rows=(0, n1))
+                ctx.compute_forces(ts, arr, rows=(n1, N - n1))
+            else:
+                ctx.compute_forces(ts, arr)
+        torch.cuda.synchronize()
+        bufs = None if mode == "fused" else (ctx.nlist_buffer(N, cuda).clone(), ctx.positions_buffer(N, cuda).clone())
+        return force.clone(), (vir.clone() if virial else None), bufs
+
+    f0, v0, b0 = run(False)
+    f1, v1, b1 = run(True)
+    assert torch.equal(f0, f1) and float(f0.abs().sum()) > 0
+    if virial:
+        assert torch.equal(v0, v1) and float(v0.abs().sum()) > 0
+    if b0 is not None:
+        assert torch.equal(b0[0], b1[0]) and torch.equal(b0[1], b1[1])
+    with pytest.raises(ValueError):
+        ctx = htf.Context(r_cut=2.5, nneighs=NN, scalar_dtype=torch.float32, max_n=N)
+        ctx.set_potential(pot)
+        arr = ctx.make_arrays(sysm.pos, N, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, torch.zeros((N, 4), device=cuda))
+        ctx.compute_forces(0, arr, rows=(N - 3, 10))
