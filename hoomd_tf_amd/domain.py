@@ -81,11 +81,12 @@ class SlabDomain:
         return self._works is not None
 
     # ------------------------------------------------------------------ helpers
-    def _all_counts(self, a, b):
-        t = torch.tensor([int(a), int(b)], dtype=torch.int64, device=self.sys.pos.device)
-        out = [torch.empty_like(t) for _ in range(self.world)]
-        dist.all_gather(out, t, group=self.group)
-        return [(int(o[0]), int(o[1])) for o in out]
+    def _gather_counts(self, cnt):
+        """cnt: small int64 device vector -> [world, len] host array.  One all_gather and ONE
+        device->host copy: the only host synchronisation of a migration / ghost-plan phase."""
+        out = [torch.empty_like(cnt) for _ in range(self.world)]
+        dist.all_gather(out, cnt, group=self.group)
+        return torch.stack(out).cpu().numpy()
 
     def _swap(self, to_left, to_right, n_from_right, n_from_left):
         """send [L>, R>], receive [L> from right, R> from left]; returns the two buffers."""
@@ -124,44 +125,47 @@ class SlabDomain:
             s.n_ghost = 0
             return
         N = s.N
-        pos, vel = s.pos[:N], s.vel[:N]
-        x = pos[:, 0]
+        pv = torch.cat([s.pos[:N], s.vel[:N]], dim=1)  # [N, 8]: a particle travels as one record
+        x = pv[:, 0].contiguous()
         # The integrator wraps into the global box, so the new owner is found by position and
         # is an adjacent slab by construction (rebuilds happen before anything moves r_buff/2).
         cuts = torch.as_tensor(self.bounds[1:-1], dtype=x.dtype, device=x.device)
-        owner = torch.bucketize(x.contiguous(), cuts, right=True)
+        owner = torch.bucketize(x, cuts, right=True)
         if self.world == 2:
-            go_right = owner != self.rank      # one peer: everything travels as the R> message
-            go_left = torch.zeros_like(go_right)
+            dest = (owner != self.rank).to(torch.int64) * 2  # one peer: everything travels as the R> message
         else:
-            go_left = owner == self.left
-            go_right = owner == self.right
+            go_left, go_right = owner == self.left, owner == self.right
             lost = (owner != self.rank) & ~go_left & ~go_right
-            if bool(lost.any()):
-                raise RuntimeError("a particle crossed more than one slab between neighbor-list rebuilds")
-        stay = ~(go_left | go_right)
-        pack_l = torch.cat([pos[go_left], vel[go_left]], dim=1).contiguous()
-        pack_r = torch.cat([pos[go_right], vel[go_right]], dim=1).contiguous()
-        counts = self._all_counts(pack_l.shape[0], pack_r.shape[0])
-        got_r, got_l = self._swap(pack_l, pack_r, counts[self.right][0], counts[self.left][1])
+            dest = go_left.to(torch.int64) + 2 * go_right.to(torch.int64) + 3 * lost.to(torch.int64)
+        # partition [stay | L> | R>] with one stable sort; sizes come back with the neighbors' in
+        # one gather (no masked selects: each of those is a hidden host synchronisation)
+        ones = torch.ones_like(dest)
+        cnt = torch.zeros(4, dtype=torch.int64, device=x.device).index_add_(0, dest, ones)
+        allc = self._gather_counts(cnt)
+        if allc[:, 3].any():
+            raise RuntimeError("a particle crossed more than one slab between neighbor-list rebuilds")
+        n_stay, n_l, n_r = (int(v) for v in allc[self.rank][:3])
+        pv = pv.index_select(0, torch.sort(dest, stable=True)[1])
+        pack_l = pv[n_stay:n_stay + n_l].contiguous()
+        pack_r = pv[n_stay + n_l:n_stay + n_l + n_r].contiguous()
+        got_r, got_l = self._swap(pack_l, pack_r, int(allc[self.right][1]), int(allc[self.left][2]))
         self.n_migrated += int(got_r.shape[0] + got_l.shape[0])
-        new_pos = torch.cat([pos[stay], got_r[:, :4], got_l[:, :4]], dim=0)
-        new_vel = torch.cat([vel[stay], got_r[:, 4:], got_l[:, 4:]], dim=0)
-        N = int(new_pos.shape[0])
+        pv = torch.cat([pv[:n_stay], got_r, got_l], dim=0)
+        N = int(pv.shape[0])
         # ghost plan: who sits within r_ghost of a face.  Slabs are >= 2 r_ghost thick, so the two
         # sets are disjoint; a stable sort on the class puts them behind the interior particles.
-        x = new_pos[:, 0]
-        cls = (x < self.xlo + self.r_ghost).to(torch.int8) + 2 * (x >= self.xhi - self.r_ghost).to(torch.int8)
-        perm = torch.sort(cls, stable=True)[1]
-        new_pos = new_pos.index_select(0, perm)
-        new_vel = new_vel.index_select(0, perm)
-        n_l, n_r = int((cls == 1).sum()), int((cls == 2).sum())
+        x = pv[:, 0]
+        cls = (x < self.xlo + self.r_ghost).to(torch.int64) + 2 * (x >= self.xhi - self.r_ghost).to(torch.int64)
+        cnt = torch.zeros(3, dtype=torch.int64, device=x.device).index_add_(0, cls, torch.ones_like(cls))
+        allc = self._gather_counts(cnt)
+        pv = pv.index_select(0, torch.sort(cls, stable=True)[1])
+        new_pos, new_vel = pv[:, :4], pv[:, 4:]
+        n_l, n_r = int(allc[self.rank][1]), int(allc[self.rank][2])
         self.n_interior = N - n_l - n_r
         self.send_left = (self.n_interior, self.n_interior + n_l)
         self.send_right = (self.n_interior + n_l, N)
-        counts = self._all_counts(n_l, n_r)
-        self.n_from_right = counts[self.right][0]
-        self.n_from_left = counts[self.left][1]
+        self.n_from_right = int(allc[self.right][1])
+        self.n_from_left = int(allc[self.left][2])
         s.N = N
         s.n_ghost = self.n_from_left + self.n_from_right
         s.pos = torch.cat([new_pos, torch.zeros((s.n_ghost, 4), dtype=new_pos.dtype, device=new_pos.device)], dim=0)

@@ -143,9 +143,8 @@ class CellNlist:
         sorted_cells, order = torch.sort(cell_of, stable=True)
         pos_sorted = s.pos.index_select(0, order)  # cell members contiguous: coalesced candidate reads
         order = order.to(torch.int32)
-        counts = torch.bincount(sorted_cells.long(), minlength=ncell)
-        cell_start = torch.zeros(ncell + 1, dtype=torch.int32, device=s.device)
-        cell_start[1:] = torch.cumsum(counts, 0).to(torch.int32)
+        # first member of every cell (torch.bincount would synchronise with the host to size its output)
+        cell_start = torch.searchsorted(sorted_cells, torch.arange(ncell + 1, dtype=torch.int32, device=s.device)).to(torch.int32)
         if self.pitch is None:
             # a sphere of r_list at the mean density, with generous head-room
             L = s.box3x3[1] - s.box3x3[0]
