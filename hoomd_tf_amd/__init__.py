@@ -11,7 +11,8 @@ from . import ops
 from .ops import Potential, Context
 from . import standin
 from .simmodel import (SimModel, compute_nlist_forces, compute_positions_forces, nlist_rinv, safe_norm,
-                       box_size, wrap_vector, compute_rdf, masked_nlist, reduce_sum, pairwise_unit_forces, Nlist)
+                       box_size, wrap_vector, compute_rdf, masked_nlist, reduce_sum, pairwise_unit_forces, Nlist,
+                       MolSimModel, find_molecules)
 from .layers import RBFExpansion, WCARepulsion, EDSLayer, PairMLP, SoftRDFCV, LJLayer
 from . import optimizers
 from .tensorflowcompute import tfcompute

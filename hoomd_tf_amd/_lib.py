@@ -96,6 +96,7 @@ PROTOTYPES = {
     "htf_add_virial": (_i, [_vp, _vp, _i, _u, _sz, _vp]),
     "htf_add_scalar4": (_i, [_vp, _vp, _i, _u, _vp]),
     "htf_copy_positions": (_i, [_vp, _i, _vp, _i, _u, _u, _i, _vp]),
+    "htf_copy3": (_i, [_vp, _i, _vp, _i, _u, _vp]),
     "htf_check_nlist": (_i, [_vp, _i, _u, _u, _vp, _vp]),
     "htf_nlist_rinv": (_i, [_vp, _i, _u, _u, _vp, _vp]),
     "htf_create": (_i, [C.POINTER(Config), C.POINTER(_vp)]),
@@ -121,7 +122,7 @@ PROTOTYPES = {
 STANDIN_PROTOTYPES = {
     "htfs_nve_step": (_i, [_vp, _vp, _vp, _i, _u, _d, C.POINTER(Box), _vp]),
     "htfs_max_displacement2": (_i, [_vp, _vp, _i, _u, C.POINTER(Box), _vp, _vp]),
-    "htfs_build_nlist": (_i, [_vp, _vp, _i, _u, _u, C.POINTER(Box), _d, C.POINTER(_i * 3), _vp, _vp, _u, _vp, _vp, _vp, _vp, _vp]),
+    "htfs_build_nlist": (_i, [_vp, _vp, _i, _u, _u, C.POINTER(Box), _d, C.POINTER(_i * 3), _vp, _vp, _u, _i, _vp, _vp, _vp, _vp, _vp]),
     "htfs_cell_index": (_i, [_vp, _i, _u, C.POINTER(Box), C.POINTER(_i * 3), _vp, _vp]),
 }
 

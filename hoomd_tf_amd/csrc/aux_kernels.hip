@@ -88,6 +88,41 @@ extern "C" int htf_add_scalar4(void *d_dest, const void *d_src, int dtype, unsig
     return check_launch("add_scalar4_kernel");
 }
 
+namespace htf {
+// dest.xyz = src.xyz, dest.w (HOOMD's stuffed type) untouched
+template <typename TS, typename TD>
+__global__ void copy3_kernel(typename Vec4<TD>::type *__restrict__ dest, const typename Vec4<TS>::type *__restrict__ src,
+                             unsigned N) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const auto v = src[i];
+    dest[i].x = (TD)v.x;
+    dest[i].y = (TD)v.y;
+    dest[i].z = (TD)v.z;
+}
+} // namespace htf
+
+extern "C" int htf_copy3(void *d_dest, int dest_dtype, const void *d_src, int src_dtype, unsigned N, htf_stream stream) {
+    using namespace htf;
+    HTF_REQUIRE(d_dest && d_src, "htf_copy3: null pointer");
+    if (N == 0) return HTF_OK;
+    const unsigned grid = (N + 255) / 256;
+    hipStream_t s = (hipStream_t)stream;
+    if (src_dtype == HTF_F32 && dest_dtype == HTF_F32)
+        hipLaunchKernelGGL((copy3_kernel<float, float>), dim3(grid), dim3(256), 0, s, (float4 *)d_dest, (const float4 *)d_src, N);
+    else if (src_dtype == HTF_F64 && dest_dtype == HTF_F32)
+        hipLaunchKernelGGL((copy3_kernel<double, float>), dim3(grid), dim3(256), 0, s, (float4 *)d_dest, (const double4 *)d_src, N);
+    else if (src_dtype == HTF_F64 && dest_dtype == HTF_F64)
+        hipLaunchKernelGGL((copy3_kernel<double, double>), dim3(grid), dim3(256), 0, s, (double4 *)d_dest, (const double4 *)d_src, N);
+    else if (src_dtype == HTF_F32 && dest_dtype == HTF_F64)
+        hipLaunchKernelGGL((copy3_kernel<float, double>), dim3(grid), dim3(256), 0, s, (double4 *)d_dest, (const float4 *)d_src, N);
+    else {
+        set_error("htf_copy3: bad dtype (%d, %d)", src_dtype, dest_dtype);
+        return HTF_ERR_INVALID;
+    }
+    return check_launch("copy3_kernel");
+}
+
 extern "C" int htf_copy_positions(void *d_dest, int dest_dtype, const void *d_src, int src_dtype, unsigned offset,
                                   unsigned N, int unstuff4, htf_stream stream) {
     using namespace htf;

@@ -2,6 +2,7 @@
 // check, binned neighbor search.  Outside the drop-in boundary; exists so the force
 // path can be driven and timed as MD without HOOMD-blue in the image.
 #include "htf_common.h"
+#include "box_math.h"
 #include "htf_standin.h"
 
 namespace htf {
@@ -116,6 +117,7 @@ __global__ __launch_bounds__(256) void build_nlist_kernel(const typename Vec4<T>
                                                           unsigned N, SBox<T> b, T rl2, int nx, int ny, int nz,
                                                           const unsigned *__restrict__ order,
                                                           const unsigned *__restrict__ cell_start, unsigned pitch,
+                                                          int type_split,
                                                           unsigned *__restrict__ n_neigh, unsigned *__restrict__ head_list,
                                                           unsigned *__restrict__ nlist, unsigned *__restrict__ max_neigh) {
     constexpr int G = 16;
@@ -126,6 +128,7 @@ __global__ __launch_bounds__(256) void build_nlist_kernel(const typename Vec4<T>
     const int cx = cell_coord<T>(pi.x, b.lo[0], b.Linv[0], nx);
     const int cy = cell_coord<T>(pi.y, b.lo[1], b.Linv[1], ny);
     const int cz = cell_coord<T>(pi.z, b.lo[2], b.Linv[2], nz);
+    const bool side_i = type_split >= 0 && scalar_as_int(pi.w) >= type_split;
     const unsigned long long gmask = 0xFFFFull << (sub * G);
     unsigned count = 0;
     unsigned *row = nlist + (size_t)(active ? i : 0) * pitch;
@@ -175,6 +178,7 @@ __global__ __launch_bounds__(256) void build_nlist_kernel(const typename Vec4<T>
                         T ddy = mimg<T>(pk.y - pi.y, b.L[1], b.Linv[1], b.periodic[1]);
                         T ddz = mimg<T>(pk.z - pi.z, b.L[2], b.Linv[2], b.periodic[2]);
                         hit = (k != i) && (ddx * ddx + ddy * ddy + ddz * ddz <= rl2);
+                        if (type_split >= 0) hit = hit && ((scalar_as_int(pk.w) >= type_split) == side_i);
                     }
                     const unsigned long long bal = __ballot(hit) & gmask;
                     const unsigned rank = count + __popcll(bal & ((1ull << lane) - 1ull));
@@ -232,7 +236,7 @@ extern "C" int htfs_cell_index(const void *d_pos, int dtype, unsigned Ntot, cons
 
 extern "C" int htfs_build_nlist(const void *d_pos, const void *d_pos_sorted, int dtype, unsigned N, unsigned Ntot,
                                 const htf_box *box, double r_list, const int *ncell3, const unsigned *d_order,
-                                const unsigned *d_cell_start, unsigned pitch, unsigned *d_n_neigh,
+                                const unsigned *d_cell_start, unsigned pitch, int type_split, unsigned *d_n_neigh,
                                 unsigned *d_head_list, unsigned *d_nlist, unsigned *d_max_neigh, htf_stream stream) {
     (void)Ntot;
     HTF_REQUIRE(d_pos && d_pos_sorted && box && ncell3 && d_order && d_cell_start && d_n_neigh && d_head_list && d_nlist && d_max_neigh,
@@ -246,8 +250,8 @@ extern "C" int htfs_build_nlist(const void *d_pos, const void *d_pos_sorted, int
     if (N == 0) return HTF_OK;
     unsigned grid = (N + 15) / 16; // 4 waves x 4 particles per block
     if (dtype == HTF_F32)
-        hipLaunchKernelGGL((build_nlist_kernel<float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float4 *)d_pos, (const float4 *)d_pos_sorted, N, make_sbox<float>(box), (float)(r_list * r_list), ncell3[0], ncell3[1], ncell3[2], d_order, d_cell_start, pitch, d_n_neigh, d_head_list, d_nlist, d_max_neigh);
+        hipLaunchKernelGGL((build_nlist_kernel<float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float4 *)d_pos, (const float4 *)d_pos_sorted, N, make_sbox<float>(box), (float)(r_list * r_list), ncell3[0], ncell3[1], ncell3[2], d_order, d_cell_start, pitch, type_split, d_n_neigh, d_head_list, d_nlist, d_max_neigh);
     else
-        hipLaunchKernelGGL((build_nlist_kernel<double>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const double4 *)d_pos, (const double4 *)d_pos_sorted, N, make_sbox<double>(box), r_list * r_list, ncell3[0], ncell3[1], ncell3[2], d_order, d_cell_start, pitch, d_n_neigh, d_head_list, d_nlist, d_max_neigh);
+        hipLaunchKernelGGL((build_nlist_kernel<double>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const double4 *)d_pos, (const double4 *)d_pos_sorted, N, make_sbox<double>(box), r_list * r_list, ncell3[0], ncell3[1], ncell3[2], d_order, d_cell_start, pitch, type_split, d_n_neigh, d_head_list, d_nlist, d_max_neigh);
     return check_launch("build_nlist_kernel");
 }

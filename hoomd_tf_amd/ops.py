@@ -294,6 +294,15 @@ def copy_positions(src, offset=0, N=None, unstuff4=True, out_dtype=None):
     return out
 
 
+def copy3(dest, src, N=None):
+    """htf_gpu_copy3 (TFArrayComm.cu:31-56): dest[:N, :3] = src[:N, :3], dest's stuffed type kept."""
+    _dev(dest, "dest")
+    _dev(src, "src")
+    n = int(src.shape[0]) if N is None else int(N)
+    check(lib.htf_copy3(dest.data_ptr(), _dt(dest), src.data_ptr(), _dt(src), n, _stream(dest)))
+    return dest
+
+
 def check_nlist(nlist):
     """simmodel.py:214-219: max_i sum_j [nlist[i,j,0] > 0] (synchronises)."""
     _dev(nlist, "nlist")

@@ -28,29 +28,69 @@ def _trace_log():
 
 
 # --------------------------------------------------------------------------- tensors
-class Nlist:
+def _unwrap(x):
+    if isinstance(x, (Nlist, NlistXYZ)):
+        return x.ad
+    if isinstance(x, (list, tuple)):
+        return type(x)(_unwrap(v) for v in x)
+    return x
+
+
+class _TorchOperand:
+    """Lets the neighbor tensor be used in ordinary torch code (``torch.norm(nlist[:, :, :3],
+    dim=2)``, arithmetic, slicing): the generic-model route of SURVEY 8(f)-3.  Any torch
+    function sees ``.ad`` -- the pair-vector buffer as an autograd leaf -- so
+    ``compute_nlist_forces`` can differentiate whatever the model builds from it."""
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        return func(*_unwrap(args), **{k: _unwrap(v) for k, v in (kwargs or {}).items()})
+
+    def __add__(self, o): return self.ad + _unwrap(o)
+    def __radd__(self, o): return _unwrap(o) + self.ad
+    def __sub__(self, o): return self.ad - _unwrap(o)
+    def __rsub__(self, o): return _unwrap(o) - self.ad
+    def __mul__(self, o): return self.ad * _unwrap(o)
+    def __rmul__(self, o): return _unwrap(o) * self.ad
+    def __truediv__(self, o): return self.ad / _unwrap(o)
+    def __rtruediv__(self, o): return _unwrap(o) / self.ad
+    def __pow__(self, o): return self.ad ** _unwrap(o)
+
+    def __neg__(self):
+        return -self.ad
+
+
+class Nlist(_TorchOperand):
     """The ``N x NN x 4`` neighbor tensor handed to ``compute`` (simmodel.py:99-105):
     a zero-copy view of the pair-vector buffer plus the identity the expression layer
-    needs.  ``nlist[:, :, :3]`` stays symbolic; anything else indexes the tensor."""
+    needs.  ``nlist[:, :, :3]`` stays symbolic for the declarative layers; torch code gets
+    the autograd leaf ``ad``."""
 
     def __init__(self, tensor):
         self.tensor = tensor
+        self._ad = None
 
     shape = property(lambda self: self.tensor.shape)
     dtype = property(lambda self: self.tensor.dtype)
     device = property(lambda self: self.tensor.device)
 
+    @property
+    def ad(self):
+        if self._ad is None:
+            self._ad = self.tensor.detach().requires_grad_(True)
+        return self._ad
+
     def __getitem__(self, idx):
         full = slice(None)
         if isinstance(idx, tuple) and len(idx) == 3 and idx[0] == full and idx[1] == full and idx[2] == slice(None, 3):
             return NlistXYZ(self)
-        return self.tensor[idx]
+        return self.ad[idx]
 
     def numpy(self):
         return self.tensor.cpu().numpy()
 
 
-class NlistXYZ:
+class NlistXYZ(_TorchOperand):
     """``nlist[:, :, :3]``"""
 
     def __init__(self, parent):
@@ -59,6 +99,10 @@ class NlistXYZ:
     @property
     def tensor(self):
         return self.parent.tensor[:, :, :3]
+
+    @property
+    def ad(self):
+        return self.parent.ad[:, :, :3]
 
     def numpy(self):
         return self.tensor.cpu().numpy()
@@ -337,6 +381,8 @@ def compute_nlist_forces(nlist, energy, virial=False):
     """simmodel.py:526-555.  Returns forces [N,4] (fx,fy,fz,energy), or (forces, virial
     [N,3,3]) when ``virial``.  Raises ValueError when energy does not depend on nlist
     ('Did you put them in wrong order?')."""
+    if isinstance(energy, torch.Tensor):
+        return _autograd_nlist_forces(_as_nlist(nlist), energy, virial)
     if not isinstance(energy, PairEnergy):
         raise ValueError('Could not find dependence between energy and nlist.'
                          ' Did you put them in wrong order?')
@@ -362,6 +408,42 @@ def compute_nlist_forces(nlist, energy, virial=False):
     _trace_log().append({"potential": pot, "nlist": nl, "virial": virial, "forces": f,
                          "layer": getattr(energy, "layer", None)})
     return out
+
+
+def _add_energy(forces, energy):
+    """simmodel.py:558-578: column 3 <- per-particle energy (rank > 1: summed over the trailing
+    axes; rank 0: the scalar tiled to every particle); drops dE/dtype."""
+    N = forces.shape[0]
+    if energy.dim() > 1:
+        e = energy.reshape(N, -1).sum(dim=1, keepdim=True)
+    elif energy.dim() == 0:
+        e = energy.reshape(1, 1).expand(N, 1)
+    else:
+        e = energy.reshape(N, 1)
+    return torch.cat([forces[:, :3], e.to(forces.dtype)], dim=-1)
+
+
+def _autograd_nlist_forces(nl, energy, virial):
+    """The generic route: ``energy`` is any torch expression of the neighbor
+    tensor; forces by torch.autograd exactly as simmodel.py:526-555 does with tf.gradients
+    (x2, summed over the neighbor axis).  No fused kernel, no plan: the step stays eager."""
+    g = None
+    if nl._ad is not None and energy.requires_grad:
+        (g,) = torch.autograd.grad(energy.sum(), nl._ad, allow_unused=True, retain_graph=True)
+    if g is None:
+        raise ValueError('Could not find dependence between energy and nlist.'
+                         ' Did you put them in wrong order?')
+    nlist_forces = 2.0 * g
+    forces = _add_energy(nlist_forces.sum(dim=1), energy.detach())
+    _trace_log().append({"op": "generic"})
+    if not virial:
+        return forces
+    n3 = nl.tensor[:, :, :3]
+    rmag = torch.sqrt((n3 * n3).sum(dim=2))
+    fmag = torch.sqrt((nlist_forces * nlist_forces).sum(dim=2))
+    den = 2.0 * rmag
+    f_rs = torch.where(den == 0, torch.zeros_like(den), fmag / den)  # divide_no_nan
+    return forces, -1.0 * torch.einsum("ij,ijk,ijl->ikl", f_rs, n3, n3)
 
 
 def _biased_forces(nl, energy):
@@ -561,6 +643,31 @@ class SimModel:
             out = (out,)
         return tuple(out)
 
+    def mapped_nlist(self, nlist):
+        """simmodel.py:257-271: (all-atom nlist, mapped nlist) after tfcompute.enable_mapped_nlist."""
+        if not self._map_nlist:
+            raise ValueError('You must call tfcompute.enable_mapped_nlist before using mapped_nlist')
+        t = _unwrap(nlist)
+        return t[:self._map_i], t[self._map_i:]
+
+    def mapped_positions(self, positions):
+        """simmodel.py:273-287."""
+        if not self._map_nlist:
+            raise ValueError('You must call tfcompute.enable_mapped_nlist before using mapped_nlist')
+        return positions[:self._map_i], positions[self._map_i:]
+
+    def precompute(self, system):
+        """simmodel.py:289-339: re-map the coarse-grained beads from the all-atom positions and
+        write their xyz back into the HOOMD position array (types untouched, htf_copy3) before
+        the neighbor search.  ``_map_fxn(positions [AAN,4], [Lx,Ly,Lz]) -> [M,4]`` in torch."""
+        if not self._map_nlist:
+            return
+        n = self._map_i
+        pos = ops.copy_positions(system.pos, offset=0, N=n, unstuff4=True).to(self.dtype)
+        L = torch.as_tensor(system.box3x3[1] - system.box3x3[0], dtype=self.dtype, device=pos.device)
+        cg = self._map_fxn(pos, L).to(system.dtype).contiguous()
+        ops.copy3(system.pos[n:], cg)
+
     def compute_inputs(self, nlist, positions, box):
         """simmodel.py:165-238 minus the copies: box-skew assert, optional check_nlist,
         cast to the model dtype (a no-op view when the wire dtype already matches)."""
@@ -580,3 +687,99 @@ class SimModel:
         if forces.shape[1] == 3:
             forces = torch.cat([forces, torch.zeros_like(forces[:, :1])], dim=1)
         return forces.to(out_dtype)
+
+
+def _make_reverse_indices(mol_indices):
+    """simmodel.py:714-733: atom (0-based) -> [molecule, slot]; mol_indices are 1-based here."""
+    num_atoms = 0
+    for m in mol_indices:
+        num_atoms = max(num_atoms, max(m))
+    rmi = [[] for _ in range(num_atoms)]
+    for i in range(len(mol_indices)):
+        for j in range(len(mol_indices[i])):
+            index = mol_indices[i][j]
+            if index > 0:
+                rmi[index - 1] = [i, j]
+    warned = False
+    for r in rmi:
+        if len(r) != 2 and not warned:
+            warned = True
+            print('Not all of your atoms are in a molecule\n')
+            r.extend([-1, -1])
+    return rmi
+
+
+class MolSimModel(SimModel):
+    """simmodel.py:342-489: a molecule-batched SimModel.  ``mol_compute(nlist, positions,
+    mol_nlist [M,MN,NN,4], mol_positions [M,MN,4], box)`` -- write it in torch; forces still
+    come from ``compute_nlist_forces(nlist, energy)`` (autograd flows through the gather)."""
+
+    def __init__(self, MN, mol_indices, nneighbor_cutoff, output_forces=True, virial=False, check_nlist=False,
+                 dtype=torch.float32, name='htf-mol-model', **kwargs):
+        super().__init__(nneighbor_cutoff, output_forces=output_forces, virial=virial, check_nlist=check_nlist,
+                         dtype=dtype, name=name, **kwargs)
+        self.MN = MN
+        self.mol_indices = mol_indices
+        for mi in self.mol_indices:
+            for i in range(len(mi)):
+                mi[i] += 1  # index 0 slices the dummy atom
+            if len(mi) > MN:
+                raise ValueError('One of your molecule indices has more than MN indices.'
+                                 'Increase MN in your graph.')
+            while len(mi) < MN:
+                mi.append(0)
+        self.rev_mol_indices = _make_reverse_indices(mol_indices)
+        self._mol_flat = None
+        if MolSimModel.mol_compute == self.__class__.mol_compute:
+            raise AttributeError('You must implement mol_compute method in subclass of MolSimModel')
+        self._mol_arg_count = self.mol_compute.__code__.co_argcount - 1
+        if self._mol_arg_count < 3:
+            raise AttributeError('You are creating a molecular batched model, but are only using per atom '
+                                 'nlist/positions. Either use only SimModel or increase your argument count '
+                                 'to mol_compute')
+
+    def get_config(self):
+        config = super().get_config()
+        config.update({'MN': self.MN, 'mol_indices': self.mol_indices})
+        return config
+
+    def mol_compute(self, nlist, positions, mol_nlist, mol_positions, box, training):
+        raise AttributeError('You must implement mol_compute method')
+
+    def compute(self, nlist, positions, box, training):
+        nl = _as_nlist(nlist)
+        if self._mol_flat is None or self._mol_flat.device != nl.device:
+            self._mol_flat = torch.as_tensor(self.mol_indices, dtype=torch.int64, device=nl.device).reshape(-1)
+        # one dummy particle in front, so that the 0 fill of mol_indices slices zeros
+        ap = torch.cat([torch.zeros((1, 4), dtype=positions.dtype, device=positions.device), positions], dim=0)
+        an = torch.cat([torch.zeros((1, self.nneighbor_cutoff, 4), dtype=nl.dtype, device=nl.device), nl.ad], dim=0)
+        mol_positions = ap.index_select(0, self._mol_flat).reshape(-1, self.MN, 4)
+        mol_nlist = an.index_select(0, self._mol_flat).reshape(-1, self.MN, self.nneighbor_cutoff, 4)
+        inputs = [nl, positions, mol_nlist, mol_positions, box, training]
+        return self.mol_compute(*inputs[:self._mol_arg_count])
+
+
+def find_molecules(system):
+    """utils.py:236-285 for the stand-in System: connected components of ``system.bonds``
+    (a list of index pairs; absent = no bonds, every particle its own molecule), each sorted,
+    ordered by smallest index."""
+    N = system.N
+    adj = [[] for _ in range(N)]
+    for a, b in getattr(system, "bonds", []):
+        adj[a].append(b)
+        adj[b].append(a)
+    seen, mapping = [False] * N, []
+    for i in range(N):
+        if seen[i]:
+            continue
+        stack, mol = [i], []
+        seen[i] = True
+        while stack:
+            k = stack.pop()
+            mol.append(k)
+            for j in adj[k]:
+                if not seen[j]:
+                    seen[j] = True
+                    stack.append(j)
+        mapping.append(sorted(mol))
+    return mapping

@@ -73,6 +73,22 @@ class System:
         v -= v.mean(dim=0, keepdim=True)
         self.vel[:, :3] = v.to(self.dtype).to(self.device)
 
+    def append_particles(self, positions, types):
+        """snapshot.particles.resize + restore_snapshot: add particles at the end (zero velocity)."""
+        positions = np.asarray(positions, dtype=np.float64).reshape(-1, 3)
+        types = np.asarray(types, dtype=np.int32)
+        if self.n_ghost:
+            raise ValueError("cannot add particles to a decomposed system")
+        add = ops.stuff_types(torch.from_numpy(positions).to(self.device), torch.from_numpy(types).to(self.device), self.dtype)
+        M = int(add.shape[0])
+        self.pos = torch.cat([self.pos[: self.N], add], dim=0)
+        v = torch.zeros((M, 4), dtype=self.dtype, device=self.device)
+        v[:, 3] = 1.0
+        self.vel = torch.cat([self.vel, v], dim=0)
+        self.N += M
+        self.force = torch.zeros((self.N, 4), dtype=self.dtype, device=self.device)
+        self.virial = torch.zeros(6 * self.N, dtype=self.dtype, device=self.device)
+
     def positions_numpy(self):
         return self.pos[: self.N, :3].double().cpu().numpy()
 
@@ -105,6 +121,7 @@ class CellNlist:
         self.n_builds = 0
         self._subscribers = []
         self.domain = None  # SlabDomain when the box is decomposed over ranks
+        self.type_split = -1  # >= 0: no pairs across this type id (mapped beads vs all-atom particles)
 
     def subscribe(self, rcut_fn):
         """NeighborList r_cut subscription (tensorflowcompute.py:116-120): the list is
@@ -159,7 +176,7 @@ class CellNlist:
                 self.nlist = torch.empty(s.N * self.pitch, dtype=torch.int32, device=s.device)
             self._max.zero_()
             check(lib.htfs_build_nlist(s.pos.data_ptr(), pos_sorted.data_ptr(), s.scalar_code, s.N, Ntot, C.byref(s.box), self.r_list,
-                                       C.byref(n3), order.data_ptr(), cell_start.data_ptr(), self.pitch,
+                                       C.byref(n3), order.data_ptr(), cell_start.data_ptr(), self.pitch, int(self.type_split),
                                        self.n_neigh.data_ptr(), self.head_list.data_ptr(), self.nlist.data_ptr(),
                                        self._max.data_ptr(), stream))
             mx = int(self._max.item())
@@ -197,16 +214,39 @@ class CellNlist:
             self.domain.exchange_end()
 
 
-class NVE:
-    """hoomd.md.integrate.nve analogue (leapfrog form, unit mass)."""
+class Group:
+    """hoomd.group.tags(first, last) analogue: a contiguous tag range [first, first + count)."""
 
-    def __init__(self, system, dt):
+    def __init__(self, first, count):
+        self.first, self.count = int(first), int(count)
+
+    def __len__(self):
+        return self.count
+
+
+class NVE:
+    """hoomd.md.integrate.nve analogue (leapfrog form, unit mass); ``group``: only those
+    particles move (enable_mapped_nlist returns the all-atom group for this)."""
+
+    def __init__(self, system, dt, group=None):
         self.sys = system
         self.dt = float(dt)
+        self.group = group
+
+    def randomize_velocities(self, kT, seed):
+        self.sys.randomize_velocities(kT, seed)
+        if self.group is not None:
+            g = self.group
+            self.sys.vel[:g.first, :3] = 0
+            self.sys.vel[g.first + g.count:, :3] = 0
+        return self
 
     def step(self):
         s = self.sys
-        check(lib.htfs_nve_step(s.pos.data_ptr(), s.vel.data_ptr(), s.force.data_ptr(), s.scalar_code, s.N,
+        first, n = (0, s.N) if self.group is None else (self.group.first, self.group.count)
+        esz = 4 * (8 if s.dtype == torch.float64 else 4)
+        check(lib.htfs_nve_step(s.pos.data_ptr() + first * esz, s.vel.data_ptr() + first * esz,
+                                s.force.data_ptr() + first * esz, s.scalar_code, n,
                                 self.dt, C.byref(s.box), C.c_void_p(torch.cuda.current_stream(s.device).cuda_stream)))
 
 
@@ -234,8 +274,8 @@ class Simulation:
         """hoomd.md.nlist.cell(): r_cut comes from the subscribers (nlist.subscribe)."""
         return CellNlist(self.system, r_cut=0.0, r_buff=r_buff, pitch=pitch, check_period=check_period)
 
-    def integrate_nve(self, dt):
-        self.integrator = NVE(self.system, dt)
+    def integrate_nve(self, dt, group=None):
+        self.integrator = NVE(self.system, dt, group=group)
         return self.integrator
 
     @property

@@ -66,10 +66,19 @@ class tfcompute:
         self._ref_forces = []
         self._labels = None
         self._opt_state = None
+        if isinstance(self.model, simmodel.MolSimModel):  # tensorflowcompute.py:103-111
+            if self.batch_size != 0:
+                raise ValueError('Cannot batch by molecule and by batch_number')
+            if nlist is not None and getattr(nlist, "domain", None) is not None and nlist.domain.world > 1:
+                raise ValueError('Molecular batches are not supported with spatial decomposition (MPI)')
+            self._disable_sorter(nlist)
         self.nneighbor_cutoff = self.model.nneighbor_cutoff
         if nlist is not None:
             nlist.subscribe(self.rcut)
             self._nlist = nlist
+            if self.model._map_nlist:  # tensorflowcompute.py:170-174
+                nlist.type_split = self._map_typeid_start
+                self._disable_sorter(nlist)
         elif self.nneighbor_cutoff != 0:
             raise ValueError('Must provide an nlist if you have nneighbor_cutoff > 0')
         self.force_mode_code = _lib.HTF_TF2HOOMD if self.model.output_forces else _lib.HTF_HOOMD2TF
@@ -92,8 +101,42 @@ class tfcompute:
             sim.computes.append(self)  # outputs only (system.addCompute)
 
     def rcut(self):
-        """tensorflowcompute.py:284-305: the cutoff this compute subscribes to the nlist."""
+        """tensorflowcompute.py:284-305: the cutoff this compute subscribes to the nlist (the
+        all-atom / mapped type-pair exclusion is the nlist's ``type_split``)."""
         return self.r_cut
+
+    @staticmethod
+    def _disable_sorter(nlist):
+        """tensorflowcompute.py:190-196: molecular batching / mapped beads need a fixed order."""
+        if nlist is not None:
+            nlist.sort_particles = False
+
+    def enable_mapped_nlist(self, system, mapping_fxn):
+        """tensorflowcompute.py:198-263: put the M coarse-grained beads of ``mapping_fxn(positions
+        [N,4], [Lx,Ly,Lz]) -> [M,4]`` (torch; column 3 = bead type) into the simulation behind
+        the N all-atom particles, with type ids offset so the neighbor search never pairs the
+        two kinds.  Returns (aa_group, mapped_group); integrate the first only."""
+        AAN = system.N
+        dtype = self.model.dtype
+        pos = ops.copy_positions(system.pos, offset=0, N=AAN, unstuff4=True).to(dtype)
+        L = system.box3x3[1] - system.box3x3[0]
+        cg = mapping_fxn(pos, torch.as_tensor(L, dtype=dtype, device=pos.device))
+        cg = cg.detach().cpu().numpy()
+        M = cg.shape[0]
+        typeid = system.types_numpy()
+        map_typeid_start = int(np.max(typeid[M:])) + 1  # (sic) tensorflowcompute.py:234
+        new_types = cg[:, 3].astype(np.int32) + map_typeid_start
+        for i in new_types:
+            self.map_types.add(int(i))
+        system.append_particles(cg[:, :3], new_types)
+        self.model._map_nlist = True
+        self.model._map_fxn = mapping_fxn
+        self.model._map_i = AAN
+        self._map_typeid_start = map_typeid_start
+        if self._nlist is not None:
+            self._nlist.type_split = map_typeid_start
+            self._nlist._ref = None  # update_rcut(): rebuild with the new types
+        return standin.Group(0, AAN), standin.Group(AAN, M)
 
     def set_reference_forces(self, *forces):
         """tensorflowcompute.py:265-282."""
@@ -116,6 +159,8 @@ class tfcompute:
         """ForceCompute::compute -> TensorflowCompute::computeForces (.cc:129-216)."""
         if timestep % self.period != 0:
             return
+        if self.model._map_nlist:
+            self.model.precompute(self.system)  # startUpdate -> _start_update, .cc:228-241
         if self._nlist is not None:
             self._nlist.compute(timestep)  # m_nlist->compute(timestep), .cc:162-163
         domain = getattr(self._nlist, "domain", None)

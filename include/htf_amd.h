@@ -231,6 +231,12 @@ HTF_API int htf_add_scalar4(void *d_dest, const void *d_src, int dtype, unsigned
 HTF_API int htf_copy_positions(void *d_dest, int dest_dtype, const void *d_src, int src_dtype,
                        unsigned offset, unsigned N, int unstuff4, htf_stream stream);
 
+/* Replaces htf_gpu_copy3 (TFArrayComm.cu:31-56; TFArrayComm::sendArray(..., copy3 = true),
+ * TFArrayComm.h:171): dest[i].xyz = src[i].xyz, dest[i].w (HOOMD's stuffed type) untouched --
+ * how the mapped (coarse-grained) bead positions of enable_mapped_nlist are written back into
+ * HOOMD's position array before the neighbor search (TensorflowCompute.cc:228-241). */
+HTF_API int htf_copy3(void *d_dest, int dest_dtype, const void *d_src, int src_dtype, unsigned N, htf_stream stream);
+
 /* SimModel.compute_inputs check_nlist (simmodel.py:214-219): *d_out =
  * max(*d_out, max_i sum_j [nlist[i,j,0] > 0]).  The caller zeroes *d_out. */
 HTF_API int htf_check_nlist(const void *d_nlist, int nlist_dtype, unsigned B, unsigned NN,

@@ -29,10 +29,12 @@ HTF_API int htfs_max_displacement2(const void *d_pos, const void *d_ref, int dty
  *   nlist[i*pitch + c] = k  for every k != i with |minimage(r_k - r_i)| <= r_list,
  *   n_neigh[i] = count, head_list[i] = i*pitch.
  * *d_max_neigh is max'ed with the largest count (> pitch means the list overflowed and
- * must be rebuilt with a larger pitch). */
+ * must be rebuilt with a larger pitch).  type_split >= 0: pairs whose types lie on different
+ * sides of it are left out (hoomd.md.nlist.rcut set_pair(..., -1) between all-atom and mapped
+ * bead types, tensorflowcompute.py:284-305); -1: no type filter. */
 HTF_API int htfs_build_nlist(const void *d_pos, const void *d_pos_sorted, int dtype, unsigned N, unsigned Ntot,
                              const htf_box *box, double r_list, const int *ncell3, const unsigned *d_order,
-                             const unsigned *d_cell_start, unsigned pitch, unsigned *d_n_neigh,
+                             const unsigned *d_cell_start, unsigned pitch, int type_split, unsigned *d_n_neigh,
                              unsigned *d_head_list, unsigned *d_nlist, unsigned *d_max_neigh, htf_stream stream);
 
 /* cell index of every particle (x fastest): d_cell_of[i] */

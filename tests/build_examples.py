@@ -170,3 +170,63 @@ class TrainableGraph(htf.SimModel):
         energy = htf.reduce_sum(p_energy, axis=1)
         forces = htf.compute_nlist_forces(nlist, energy)
         return forces, self.lj.w, energy
+
+
+# ---- generic (torch autograd) models: SURVEY 8(f)-3 --------------------------------------
+class LJMolModel(htf.MolSimModel):
+    # build_examples.py:310-318, TF calls -> torch
+    def mol_compute(self, nlist, positions, mol_nlist, mol_positions, box):
+        # assume particle (w) is 0
+        r = torch.norm(mol_nlist, dim=3)
+        rinv = torch.where(r > 0, 1.0 / torch.where(r > 0, r, torch.ones_like(r)), torch.zeros_like(r))  # divide_no_nan
+        mol_p_energy = 4.0 / 2.0 * (rinv**12 - rinv**6)
+        total_e = torch.sum(mol_p_energy)
+        forces = htf.compute_nlist_forces(nlist, total_e)
+        return forces
+
+
+class MappedNlist(htf.SimModel):
+    # build_examples.py:183-196
+    def my_map(pos, box):
+        x = torch.mean(pos[:, :3], dim=0, keepdim=True)
+        cg1 = torch.cat((x, torch.zeros((1, 1), dtype=x.dtype, device=x.device)), -1)
+        cg2 = torch.tensor([[0, 0, 0.1, 1]], dtype=x.dtype, device=x.device)
+        return torch.cat((cg1, cg2), dim=0)
+
+    def compute(self, nlist, positions, box):
+        r = torch.norm(nlist[:, :, :3], dim=2)
+        nlist, cnlist = self.mapped_nlist(nlist)
+        return positions, nlist, cnlist
+
+
+class TorchLJModel(htf.SimModel):
+    # LJModel written in plain torch ops on the neighbor tensor: the generic autograd route
+    def compute(self, nlist, positions, box):
+        # nlist_rinv op for op (simmodel.py:618-635)
+        delta = 3e-6
+        r = torch.sqrt(torch.sum((nlist[:, :, :3] + delta / 3 / 10) ** 2, dim=2))
+        rinv = torch.where(r > delta, 1.0 / (r + delta), torch.zeros_like(r))
+        inv_r6 = rinv ** 6
+        p_energy = 4.0 / 2.0 * (inv_r6 * inv_r6 - inv_r6)
+        energy = torch.sum(p_energy, dim=1)
+        return htf.compute_nlist_forces(nlist, energy, virial=self.virial)
+
+
+class NlistNN(htf.SimModel):
+    # build_examples.py:199-218: a small network on the sorted 1/r of the closest neighbors
+    def setup(self, dim, top_neighs):
+        g = torch.Generator().manual_seed(0)
+        self.w1 = torch.randn((top_neighs, dim), generator=g) * 0.3
+        self.w2 = torch.randn((dim, dim), generator=g) * 0.3
+        self.w3 = torch.randn((dim, 1), generator=g) * 0.3
+        self.top_neighs = top_neighs
+
+    def compute(self, nlist, positions, box):
+        r = torch.sqrt(torch.sum((nlist[:, :, :3] + 1e-7 / 3) ** 2, dim=2))
+        rinv = torch.where(r > 3e-6, 1.0 / (r + 3e-6), torch.zeros_like(r))
+        top_n = torch.sort(rinv, dim=1, descending=True)[0][:, :self.top_neighs]
+        w1, w2, w3 = (w.to(top_n.device, top_n.dtype) for w in (self.w1, self.w2, self.w3))
+        x = torch.tanh(top_n @ w1)
+        x = torch.tanh(x @ w2)
+        energy = (x @ w3)[:, 0]
+        return htf.compute_nlist_forces(nlist, energy)

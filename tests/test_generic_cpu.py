@@ -1,0 +1,102 @@
+"""The generic (torch autograd) route of compute_nlist_forces, SURVEY 8(f)-3, on CPU tensors:
+same dataflow as simmodel.py:526-578 for an energy written in plain torch ops, checked
+against the numpy oracle's hand-derived LJ forces/virial."""
+import numpy as np
+import pytest
+import torch
+
+import build_examples
+from helpers import random_nlist
+from oracle import htf_oracle as O
+
+
+def _nl(seed=0, N=30, NN=12):
+    rng = np.random.default_rng(seed)
+    nl, _ = random_nlist(rng, N, NN, fill=0.7, rmin=0.9, rmax=2.8, dtype=np.float64)
+    return nl
+
+
+def test_autograd_route_matches_oracle_lj():
+    import hoomd_tf_amd as htf
+    nl = _nl()
+    model = build_examples.TorchLJModel(12, virial=True, dtype=torch.float64)
+    f, v = model([htf.Nlist(torch.from_numpy(nl)), None, None])
+    ref_f, ref_v = O.lj_model(nl, virial=True)
+    np.testing.assert_allclose(f.detach().numpy(), ref_f, rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(v.detach().numpy(), ref_v, rtol=1e-9, atol=1e-9)
+
+
+def test_autograd_route_energy_ranks_and_errors():
+    import hoomd_tf_amd as htf
+    nl = htf.Nlist(torch.from_numpy(_nl(1)))
+    r = torch.norm(nl[:, :, :3], dim=2)
+    e_pair = torch.where(r > 0, torch.exp(-r), torch.zeros_like(r))     # [N, NN]: summed per particle
+    e_part = e_pair.sum(dim=1)                                           # [N]
+    e_tot = e_pair.sum()                                                 # scalar: tiled to every particle
+    f2 = htf.compute_nlist_forces(nl, e_pair).detach().numpy()
+    f1 = htf.compute_nlist_forces(nl, e_part).detach().numpy()
+    f0 = htf.compute_nlist_forces(nl, e_tot).detach().numpy()
+    np.testing.assert_allclose(f2, f1, atol=1e-12)
+    np.testing.assert_allclose(f0[:, :3], f1[:, :3], atol=1e-12)
+    np.testing.assert_allclose(f0[:, 3], np.full(len(f0), float(e_tot)), atol=1e-12)
+    # operators on the wrapper give torch tensors
+    assert isinstance(nl[:, :, :3] * 2.0, torch.Tensor) and isinstance(nl[:, 0], torch.Tensor)
+    # 'Did you put them in wrong order?' (simmodel.py:537-541)
+    other = htf.Nlist(torch.from_numpy(_nl(2)))
+    with pytest.raises(ValueError, match="wrong order"):
+        htf.compute_nlist_forces(other, e_part)
+    with pytest.raises(ValueError, match="wrong order"):
+        htf.compute_nlist_forces(nl, torch.ones(3, dtype=torch.float64))
+
+
+def test_mol_model_construction_rules():
+    """test_tensorflow.py:722-727, 759-775, 806-820."""
+    import hoomd_tf_amd as htf
+    from hoomd_tf_amd.simmodel import _make_reverse_indices
+    with pytest.raises(TypeError):
+        build_examples.LJMolModel(MN=1, mol_indices=[1, 1, 4, 24], nneighbor_cutoff=10)
+    with pytest.raises(ValueError):
+        build_examples.LJMolModel(MN=2, mol_indices=[[0, 1, 2]], nneighbor_cutoff=10)
+
+    class NoMol(htf.MolSimModel):
+        def compute(self, nlist):
+            return nlist
+
+    class BadArgs(htf.MolSimModel):
+        def mol_compute(self, nlist):
+            return nlist
+
+    with pytest.raises(AttributeError):
+        NoMol(1, [[1]], 0)
+    with pytest.raises(AttributeError):
+        BadArgs(1, [[1]], 0)
+    mi = [[1, 2, 0, 0, 0], [3, 0, 0, 0, 0], [4, 5, 7, 8, 9]]
+    rmi = _make_reverse_indices(mi)
+    assert rmi[0] == [0, 0] and rmi[1] == [0, 1] and rmi[2] == [1, 0] and rmi[8] == [2, 4]
+    m = build_examples.LJMolModel(MN=3, mol_indices=[[0, 1, 2], [3, 4], [5, 6, 7], [8]], nneighbor_cutoff=8)
+    assert m.mol_indices == [[1, 2, 3], [4, 5, 0], [6, 7, 8], [9, 0, 0]]
+    # the molecule gather: [M, MN, NN, 4] with zeros in the padded slots, gradient back to nlist
+    raw = _nl(3, N=9, NN=8)
+    raw[:, :, 3] = 0  # "assume particle (w) is 0": the model takes the norm over all 4 components
+    nl = htf.Nlist(torch.from_numpy(raw))
+    pos = torch.zeros((9, 4), dtype=torch.float64)
+    f = m([nl, pos, None])[0].detach().numpy()
+    x = raw[:, :, :3]
+    r = np.sqrt((x ** 2).sum(-1))
+    live = r > 0
+    rs = np.where(live, r, 1.0)
+    dedr = np.where(live, 2.0 * (-12.0 * rs ** -13 + 6.0 * rs ** -7), 0.0)  # d/dr of 4/2 (r^-12 - r^-6)
+    want = (2.0 * dedr / rs)[..., None] * x
+    np.testing.assert_allclose(f[:, :3], want.sum(1), rtol=1e-9, atol=1e-9)
+    e_tot = np.where(live, 2.0 * (rs ** -12 - rs ** -6), 0.0).sum()
+    np.testing.assert_allclose(f[:, 3], np.full(9, e_tot), rtol=1e-12)  # scalar energy tiled (a13)
+
+
+def test_find_molecules():
+    import hoomd_tf_amd as htf
+
+    class S:
+        N = 6
+        bonds = [(0, 3), (3, 5), (1, 2)]
+
+    assert htf.find_molecules(S()) == [[0, 3, 5], [1, 2], [4]]

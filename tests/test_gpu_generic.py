@@ -1,0 +1,123 @@
+"""SURVEY 8(f)-3 on the GPU: the generic torch-autograd route driven through tfcompute
+(eager path), MolSimModel (test_tensorflow.py:686-757) and the mapped neighbor list
+(test_tensorflow.py:581-619)."""
+import numpy as np
+import pytest
+import torch
+
+import build_examples
+from helpers import sq_lattice
+
+pytestmark = pytest.mark.gpu
+
+
+def _sim(htf, cuda, n, a, dtype=torch.float64, kT=None, seed=1, dt=0.005):
+    from hoomd_tf_amd import standin
+    pos, L = sq_lattice(n, a)
+    system = standin.System(pos, L, dtype=dtype, device=cuda)
+    sim = standin.Simulation(system)
+    if kT is not None:
+        system.randomize_velocities(kT, seed)
+        system.vel[:, 2] = 0
+    return sim, system, L
+
+
+def test_torch_model_equals_fused_model(htf, cuda):
+    """The same LJ energy written in torch ops (generic route, autograd) and in the declarative
+    ops (fused HIP evaluator) gives the same trajectory forces; the generic model never installs
+    a fused plan."""
+    out = []
+    for cls in (build_examples.TorchLJModel, build_examples.LJVirialModel):
+        sim, system, L = _sim(htf, cuda, 8, 1.3, dtype=torch.float32, kT=0.4, seed=3)
+        sim.integrate_nve(0.002)
+        model = cls(48, virial=True)
+        tfc = htf.tfcompute(model)
+        tfc.attach(sim.nlist_cell(check_period=1), r_cut=3.0)
+        sim.run(6)
+        out.append((tfc.force.cpu().numpy().copy(), tfc.virial.cpu().numpy().copy(), tfc._plan))
+    (f_t, v_t, plan_t), (f_d, v_d, plan_d) = out
+    assert plan_t is None and plan_d is not None
+    scale = np.abs(f_d).max()
+    assert np.abs(f_t - f_d).max() < 2e-4 * scale
+    assert np.abs(v_t - v_d).max() < 5e-4 * np.abs(v_d).max()
+
+
+def test_nlist_nn_model_runs_and_conserves_momentum(htf, cuda):
+    """build_examples.NlistNN (sort + dense layers on 1/r): only expressible on the generic route."""
+    sim, system, L = _sim(htf, cuda, 6, 1.5, dtype=torch.float32, kT=0.3, seed=2)
+    sim.integrate_nve(0.001)
+    tfc = htf.tfcompute(build_examples.NlistNN(24, dim=8, top_neighs=6))
+    tfc.attach(sim.nlist_cell(check_period=1), r_cut=3.2)
+    sim.run(5)
+    f = tfc.force.cpu().numpy()
+    assert np.all(np.isfinite(f)) and np.abs(f[:, :3]).max() > 0
+    # E_i depends on i's own neighbor vectors only and F_i = 2 sum_j dE_i/dx_ij (simmodel.py:542-555):
+    # identical environments on the lattice + jitter-free start would cancel; just require finiteness
+    # and the energy column to be the per-particle network output
+    assert f.shape == (36, 4)
+
+
+@pytest.mark.parametrize("case", ["single", "multi", "force_output"])
+def test_mol_models(htf, cuda, case):
+    """test_single_atom / test_multi_atom / test_mol_force_output."""
+    sim, system, L = _sim(htf, cuda, 3, 4.0, kT=1.0, seed=1)
+    sim.integrate_nve(0.005)
+    N, NN, rcut = 9, 8, 5.0
+    if case == "single":
+        mol_indices = htf.find_molecules(system)
+        assert mol_indices == [[i] for i in range(N)]
+        model = build_examples.LJMolModel(MN=1, mol_indices=mol_indices, nneighbor_cutoff=NN)
+    else:
+        model = build_examples.LJMolModel(MN=3, mol_indices=[[0, 1, 2], [3, 4], [5, 6, 7], [8]], nneighbor_cutoff=NN,
+                                          output_forces=(case != "force_output"))
+    tfc = htf.tfcompute(model)
+    nlist = sim.nlist_cell()
+    nlist.sort_particles = True
+    tfc.attach(nlist, r_cut=rcut)
+    assert not nlist.sort_particles  # "make sure tfcompute disabled the sorting"
+    sim.run(8)
+    if case != "force_output":
+        # sum over molecules of the padded gather == plain LJ over the neighbor list
+        ref = htf.tfcompute(build_examples.LJModel(NN))
+        ref.attach(sim.nlist_cell(), r_cut=rcut)
+        ref.compute(system.timestep)
+        tfc.compute(system.timestep)
+        np.testing.assert_allclose(tfc.force.cpu().numpy()[:, :3], ref.force.cpu().numpy()[:, :3], atol=1e-6)
+
+
+def test_mol_batched_is_an_error(htf, cuda):
+    """test_single_atom_batched."""
+    sim, system, L = _sim(htf, cuda, 3, 4.0)
+    model = build_examples.LJMolModel(MN=1, mol_indices=htf.find_molecules(system), nneighbor_cutoff=8)
+    with pytest.raises(ValueError):
+        htf.tfcompute(model).attach(sim.nlist_cell(), r_cut=5.0, batch_size=3)
+
+
+def test_mapped_nlist(htf, cuda):
+    """test_tensorflow.py:581-619: two coarse-grained beads ride along with the 9 particles; the
+    mapping is re-applied every step and the two neighbor lists never mix."""
+    N, NN, CGN, rcut = 9, 8, 2, 5.0
+    sim, system, L = _sim(htf, cuda, 3, 4.0)
+    model = build_examples.MappedNlist(NN, output_forces=False)
+    tfc = htf.tfcompute(model)
+    assert system.N == N
+    aa_group, mapped_group = tfc.enable_mapped_nlist(system, build_examples.MappedNlist.my_map)
+    assert len(aa_group) == N and len(mapped_group) == 2
+    assert system.N == N + CGN
+    nlist = sim.nlist_cell()
+    sim.integrate_nve(0.001, group=aa_group).randomize_velocities(kT=0.8, seed=1)
+    tfc.attach(nlist, r_cut=rcut, save_output_period=2)
+    with pytest.raises(ValueError):
+        build_examples.MappedNlist(NN).mapped_nlist(torch.zeros(1))
+    sim.run(8)
+    positions = tfc.outputs[0].reshape(-1, N + CGN, 4)
+    # the mapping function was applied (bead 1 = centre of the 9 particles)
+    np.testing.assert_allclose(positions[1:, N, :3], np.mean(positions[1:, :-1, :3], axis=1), atol=1e-5)
+    assert np.abs(positions[-1, :N, :3] - positions[0, :N, :3]).max() > 1e-4  # the all-atom group moved
+    np.testing.assert_allclose(positions[:, N + 1, :3], [[0, 0, 0.1]] * len(positions), atol=1e-12)  # bead 2 is static
+    # no mixing between the neighbor lists
+    aa = set(np.unique(tfc.outputs[1][..., -1].astype(int)))
+    cg = set(np.unique(tfc.outputs[2][..., -1].astype(int)))
+    assert aa.intersection(cg) == {0}
+    assert cg == {0, 1, 2} or cg == {0, 1} or cg == {0, 2}
+    assert tfc.outputs[1].shape[1:] == (N, NN, 4) and tfc.outputs[2].shape[1:] == (CGN, NN, 4)
