@@ -95,6 +95,7 @@ PROTOTYPES = {
     "htf_potential_refresh": (_i, [_vp, _vp]),
     "htf_add_virial": (_i, [_vp, _vp, _i, _u, _sz, _vp]),
     "htf_add_scalar4": (_i, [_vp, _vp, _i, _u, _vp]),
+    "htf_energy_sum": (_i, [_vp, _i, _u, _vp, _vp]),
     "htf_copy_positions": (_i, [_vp, _i, _vp, _i, _u, _u, _i, _vp]),
     "htf_copy3": (_i, [_vp, _i, _vp, _i, _u, _vp]),
     "htf_check_nlist": (_i, [_vp, _i, _u, _u, _vp, _vp]),

@@ -102,6 +102,38 @@ __global__ void copy3_kernel(typename Vec4<TD>::type *__restrict__ dest, const t
 }
 } // namespace htf
 
+namespace htf {
+// sum_i force[i].w in double, one block, fixed order (ForceCompute::calcEnergySum)
+template <typename V4>
+__global__ __launch_bounds__(1024) void energy_sum_kernel(const V4 *__restrict__ force, unsigned N, double *__restrict__ out) {
+    __shared__ double part[16];
+    double s = 0.0;
+    for (unsigned i = threadIdx.x; i < N; i += blockDim.x) s += (double)force[i].w;
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+    if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (unsigned w = 0; w < blockDim.x / 64; ++w) t += part[w];
+        *out = t;
+    }
+}
+} // namespace htf
+
+extern "C" int htf_energy_sum(const void *d_force, int dtype, unsigned N, double *d_out, htf_stream stream) {
+    using namespace htf;
+    HTF_REQUIRE(d_force && d_out, "htf_energy_sum: null pointer");
+    if (dtype == HTF_F32)
+        hipLaunchKernelGGL((energy_sum_kernel<float4>), dim3(1), dim3(1024), 0, (hipStream_t)stream, (const float4 *)d_force, N, d_out);
+    else if (dtype == HTF_F64)
+        hipLaunchKernelGGL((energy_sum_kernel<double4>), dim3(1), dim3(1024), 0, (hipStream_t)stream, (const double4 *)d_force, N, d_out);
+    else {
+        set_error("htf_energy_sum: bad dtype %d", dtype);
+        return HTF_ERR_INVALID;
+    }
+    return check_launch("energy_sum_kernel");
+}
+
 extern "C" int htf_copy3(void *d_dest, int dest_dtype, const void *d_src, int src_dtype, unsigned N, htf_stream stream) {
     using namespace htf;
     HTF_REQUIRE(d_dest && d_src, "htf_copy3: null pointer");

@@ -294,6 +294,15 @@ def copy_positions(src, offset=0, N=None, unstuff4=True, out_dtype=None):
     return out
 
 
+def energy_sum(force, out=None):
+    """calcEnergySum: sum of the energy column, in double, on the device."""
+    _dev(force, "force")
+    if out is None:
+        out = torch.empty(1, dtype=torch.float64, device=force.device)
+    check(lib.htf_energy_sum(force.data_ptr(), _dt(force), int(force.shape[0]), out.data_ptr(), _stream(force)))
+    return out
+
+
 def copy3(dest, src, N=None):
     """htf_gpu_copy3 (TFArrayComm.cu:31-56): dest[:N, :3] = src[:N, :3], dest's stuffed type kept."""
     _dev(dest, "dest")

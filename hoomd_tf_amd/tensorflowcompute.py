@@ -95,10 +95,15 @@ class tfcompute:
         self._plan = None
         self._ctx_ran = False
         self.model._plan = None
+        self.log_name = 'tensorflow'  # m_log_name, TensorflowCompute.cc:62
         if self.force_mode_code == _lib.HTF_TF2HOOMD:
             sim.forces.append(self)   # hoomd.context.current.forces.append(self)
         else:
-            sim.computes.append(self)  # outputs only (system.addCompute)
+            # tensorflowcompute.py:183-188: hoomd2tf computes run from the integrator's half-step
+            # hook, i.e. once the step's forces exist; the stand-in calls sim.computes right there
+            if sim.integrator is None:
+                raise ValueError('Must have integrator set to receive forces')
+            sim.computes.append(self)
 
     def rcut(self):
         """tensorflowcompute.py:284-305: the cutoff this compute subscribes to the nlist (the
@@ -137,6 +142,22 @@ class tfcompute:
             self._nlist.type_split = map_typeid_start
             self._nlist._ref = None  # update_rcut(): rebuild with the new types
         return standin.Group(0, AAN), standin.Group(AAN, M)
+
+    def get_log_value(self, quantity, timestep):
+        """TensorflowCompute::getLogValue (.cc:376-395): 'tensorflow' -> compute(timestep), then
+        the energy sum over the particles (all ranks when the box is decomposed)."""
+        if quantity != self.log_name:
+            raise RuntimeError('Error getting log value: tensorflow:%s is not a valid log quantity' % quantity)
+        self.compute(timestep)
+        e = ops.energy_sum(self.force)
+        domain = getattr(self._nlist, "domain", None)
+        if domain is not None and domain.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(e, group=domain.group)
+        return float(e.item())
+
+    def update_coeffs(self):
+        pass
 
     def set_reference_forces(self, *forces):
         """tensorflowcompute.py:265-282."""

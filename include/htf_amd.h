@@ -231,6 +231,10 @@ HTF_API int htf_add_scalar4(void *d_dest, const void *d_src, int dtype, unsigned
 HTF_API int htf_copy_positions(void *d_dest, int dest_dtype, const void *d_src, int src_dtype,
                        unsigned offset, unsigned N, int unstuff4, htf_stream stream);
 
+/* ForceCompute::calcEnergySum behind getLogValue("tensorflow") (TensorflowCompute.cc:376-395):
+ * *d_out = sum_i force[i].w, accumulated in double in a fixed order. */
+HTF_API int htf_energy_sum(const void *d_force, int dtype, unsigned N, double *d_out, htf_stream stream);
+
 /* Replaces htf_gpu_copy3 (TFArrayComm.cu:31-56; TFArrayComm::sendArray(..., copy3 = true),
  * TFArrayComm.h:171): dest[i].xyz = src[i].xyz, dest[i].w (HOOMD's stuffed type) untouched --
  * how the mapped (coarse-grained) bead positions of enable_mapped_nlist are written back into

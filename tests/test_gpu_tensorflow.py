@@ -330,3 +330,23 @@ def test_api_errors(htf, cuda):
     standin._current["sim"] = None
     with pytest.raises(RuntimeError):
         htf.tfcompute(build_examples.LJModel(8)).attach(None, r_cut=3.0)
+
+
+def test_log_value_and_hook_rules(htf, cuda):
+    """getLogValue('tensorflow') == potential energy (TensorflowCompute.cc:376-395); a hoomd2tf
+    compute needs an integrator to hook into (tensorflowcompute.py:183-188)."""
+    sim, system, L = _sim(htf, cuda, 4, 1.4, kT=0.3, seed=2)
+    tfc = htf.tfcompute(build_examples.LJModel(32))
+    tfc.attach(sim.nlist_cell(), r_cut=3.0)
+    sim.run(3)
+    e = tfc.get_log_value('tensorflow', system.timestep)
+    assert abs(e - float(tfc.force[:, 3].double().sum())) < 1e-9 and e != 0.0
+    assert abs(float(htf.ops.energy_sum(tfc.force.float())) - e) < 1e-4 * abs(e)
+    with pytest.raises(RuntimeError):
+        tfc.get_log_value('kinetic', 0)
+    tfc.update_coeffs()
+    from hoomd_tf_amd import standin
+    pos, L2 = sq_lattice(3, 4.0)
+    bare = standin.Simulation(standin.System(pos, L2, dtype=torch.float64, device=cuda))
+    with pytest.raises(ValueError, match='integrator'):
+        htf.tfcompute(build_examples.LJModel(8, output_forces=False)).attach(bare.nlist_cell(), r_cut=5.0)
