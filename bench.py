@@ -488,13 +488,13 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el_f = float(t.item())
         fb = sysm.N * 8 + n_entries * 4 + (sysm.N + sysm.n_ghost) * 16 + sysm.N * 16
-        fus = fused_ms / max(ncf, 1) * 1e-3
+        fus = fused_ms / max(args.steps, 1) * 1e-3 if ncf else 0.0  # per step (two row ranges per step with slabs)
         out["fused_variant"] = {
             "note": "pair vectors evaluated in registers (htf_config.fused=1); the [N,NN,4] tensor is not materialised",
             "value": world * args.steps / el_f, "unit": "steps/s", "ms_per_step": el_f / args.steps * 1e3,
             "kernel_avg_us": fus * 1e6, "algorithmic_bytes": fb, "GBps": fb / fus / 1e9 if fus > 0 else None,
             "energy_per_particle": float(sysm.force[:, 3].double().sum().item()) / sysm.N}
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cb, f_cpu = cpu_baseline(sysm, nl, args)
         out["cpu_baseline"] = cb
     elif rank == 0:
