@@ -237,13 +237,21 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the evaluator has no CPU path")
+    # HTF_BENCH_BACKEND=gloo: rehearsal of the multi-rank code path with several ranks on ONE
+    # GPU (RCCL refuses that); messages then bounce through host memory -- not a measurement
+    backend = os.environ.get("HTF_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import hoomd_tf_amd as htf
     from hoomd_tf_amd import standin
@@ -416,6 +424,8 @@ def main():
         # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
         # (PMC cannot be read from inside the process); null when the file is absent.
         try:
+            if args.cells != 32:
+                raise KeyError("PMC passes were collected at the default size")
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_lj_pmc_hbm.json")))
             key = {"build_pair_vectors": "void htf::build_pair_vectors_kernel<float, float>",
                    "eval_forces": "void htf::eval_pair_kernel<1, 16, false, float>"}[dom]

@@ -73,7 +73,7 @@ __device__ __forceinline__ void mfma_blk(f32x16 &acc, const float *img, unsigned
 }
 
 template <bool TANH, typename IT, bool BF16>
-__global__ __launch_bounds__(256, 3) void pair_mlp_kernel(const typename Vec4<IT>::type *__restrict__ nlist,
+__global__ __launch_bounds__(256, BF16 ? 2 : 3) void pair_mlp_kernel(const typename Vec4<IT>::type *__restrict__ nlist,
                                                           unsigned B, unsigned NN, void *__restrict__ force,
                                                           int out_f64, const float *__restrict__ images, float gap) {
     using I = Img<BF16>;
@@ -359,7 +359,8 @@ template <bool TANH, bool BF16>
 static int launch_mlp(const MlpDevice *m, const void *nlist, int in_dtype, unsigned B, unsigned NN, void *force,
                       int out_f64, hipStream_t s) {
     // persistent blocks: 3 per CU (LDS 48.9 KiB each), 4 waves per block, one row per wave trip
-    unsigned grid = (unsigned)m->n_cu * 3u;
+    // (bf16: 2 per CU -- the VALU-bound variant needs > 168 VGPRs to stay out of scratch)
+    unsigned grid = (unsigned)m->n_cu * (BF16 ? 2u : 3u);
     unsigned need = (B + 3) / 4;
     if (grid > need) grid = need;
     if (in_dtype == HTF_F32)
