@@ -215,6 +215,9 @@ def test_pair_mlp_loss_gradient_matches_double_backward(htf, cuda, dims, act, NN
     B = nl.shape[0]
     np.testing.assert_allclose(accum[0] / (4 * B), loss, rtol=2e-4)
     got = accum[1:] / (4 * B)
+    if NN == 24 and act == "tanh":  # fp64 pair vectors on the wire (HOOMD double build): same sweep
+        accum64 = htf.ops.train_pair_grad(pot, torch.from_numpy(nl64).to(cuda), torch.from_numpy(labels).to(cuda)).cpu().numpy()
+        np.testing.assert_allclose(accum64, accum, rtol=1e-4, atol=1e-5 * np.abs(accum).max())
     # fp32 accumulation over ~700 pairs against an fp64 reference: tolerance relative to the gradient scale
     assert np.abs(got - g).max() < 2e-4 * np.abs(g).max(), (np.abs(got - g).max(), np.abs(g).max())
     # every block of theta carries signal (no silently-zero slice)
