@@ -563,10 +563,10 @@ int mlp_train_grad(const MlpDevice *m, const void *nlist, int in_dtype, unsigned
     const unsigned nw = train_waves(m, B), stride = train_stride(m);
     float *partial = scratch;
     float4 *predbuf = pred ? (float4 *)pred : (float4 *)(scratch + (size_t)nw * stride);
-    static const bool force_valu = getenv("HTF_MLP_TRAIN_VALU") != nullptr;
-    static const bool no_fuse = getenv("HTF_MLP_TRAIN_NOFUSE") != nullptr;
+    const bool force_valu = getenv("HTF_MLP_TRAIN_VALU") != nullptr; // read per call: tests toggle it
+    const bool no_fuse = getenv("HTF_MLP_TRAIN_NOFUSE") != nullptr;
     const unsigned ntiles = (NN + 31) / 32;
-    const bool mfma = m->precision == HTF_MLP_FP32 && !force_valu;
+    const bool mfma = !force_valu; // bf16-image potentials train on their fp32 image set
     const bool fused = mfma && !no_fuse && (ntiles == 1 || ntiles == 2 || ntiles == 4);
     int rc = HTF_OK;
     if (!fused) {
@@ -576,15 +576,14 @@ int mlp_train_grad(const MlpDevice *m, const void *nlist, int in_dtype, unsigned
     MlpDims dm{m->K, m->H1, m->H2, m->off_b1(), m->off_W2(), m->off_b2(), m->off_W3(), m->off_b3()};
     const bool th = m->act == HTF_ACT_TANH;
     const unsigned ncols = (unsigned)m->num_params() + 1u;
-    // matrix-core kernel for fp32 potentials; the VALU kernel serves bf16-image potentials
-    // (their LDS images are not fp32 operands) and HTF_MLP_TRAIN_VALU=1 (A/B runs)
+    // matrix-core kernel; the first-generation VALU kernel stays behind HTF_MLP_TRAIN_VALU=1 (A/B runs)
     if (mfma) {
         const unsigned long long units = (unsigned long long)B * ntiles;
         unsigned nblk = (unsigned)m->n_cu;
         if ((unsigned long long)nblk * 4 > units) nblk = (unsigned)((units + 3) / 4);
 #define HTF_LAUNCH_MLPM(T, IT, V4, F)                                                                                  \
     hipLaunchKernelGGL((mlp_grad_mfma_kernel<T, IT, F>), dim3(nblk), dim3(256), 0, stream, (const V4 *)nlist, B, NN,   \
-                       labels, lab_f64, predbuf, (float4 *)pred, m->images, dm, m->gap, partial, stride)
+                       labels, lab_f64, predbuf, (float4 *)pred, m->train_images, dm, m->gap, partial, stride)
 #define HTF_LAUNCH_MLPM2(T, IT, V4)                                                                                    \
     do {                                                                                                               \
         if (fused) HTF_LAUNCH_MLPM(T, IT, V4, true); else HTF_LAUNCH_MLPM(T, IT, V4, false);                           \

@@ -38,6 +38,8 @@ constexpr int kMapN = kMapW + kMapT + 1;
 struct MlpDevice {
     float *images = nullptr;      // Img<>::Floats floats, operand order
     int *map = nullptr;           // kMapN ints
+    float *train_images = nullptr; // fp32 operand images for the training sweep (== images unless bf16)
+    int *train_map = nullptr;
     const float *theta = nullptr; // device parameter vector the images are built from
     float *own_theta = nullptr;   // ... owned copy unless the caller supplied d_theta
     float centers[kK];            // float32 linspace(low, high, K), 0 beyond K

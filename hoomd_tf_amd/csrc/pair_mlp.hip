@@ -273,6 +273,8 @@ int mlp_refresh(const MlpDevice *m, hipStream_t stream) {
         hipLaunchKernelGGL(mlp_refresh_kernel<true>, dim3(grid), dim3(256), 0, stream, m->images, m->map, m->theta);
     else
         hipLaunchKernelGGL(mlp_refresh_kernel<false>, dim3(grid), dim3(256), 0, stream, m->images, m->map, m->theta);
+    if (m->train_images != m->images) // bf16 evaluator images: the training sweep reads its own fp32 set
+        hipLaunchKernelGGL(mlp_refresh_kernel<false>, dim3(grid), dim3(256), 0, stream, m->train_images, m->train_map, m->theta);
     return check_launch("mlp_refresh_kernel");
 }
 
@@ -311,6 +313,21 @@ int mlp_create(const htf_potential_desc *d, MlpDevice **out) {
     if (e == hipSuccess) e = hipMemcpy(m->images, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc((void **)&m->map, map.size() * sizeof(int));
     if (e == hipSuccess) e = hipMemcpy(m->map, map.data(), map.size() * sizeof(int), hipMemcpyHostToDevice);
+    m->train_images = m->images;
+    m->train_map = m->map;
+    if (e == hipSuccess && bf16) {
+        std::vector<float> img32(Img<false>::Floats, 0.f);
+        for (int hh = 0; hh < 2; ++hh)
+            for (int v = 0; v < 16; ++v) img32[Img<false>::TabC + hh * 16 + v] = m->centers[f0(v) + 4 * hh];
+        std::vector<int> map32;
+        build_map<false>(m, map32);
+        m->train_images = nullptr;
+        m->train_map = nullptr;
+        e = hipMalloc((void **)&m->train_images, img32.size() * sizeof(float));
+        if (e == hipSuccess) e = hipMemcpy(m->train_images, img32.data(), img32.size() * sizeof(float), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMalloc((void **)&m->train_map, map32.size() * sizeof(int));
+        if (e == hipSuccess) e = hipMemcpy(m->train_map, map32.data(), map32.size() * sizeof(int), hipMemcpyHostToDevice);
+    }
     if (e == hipSuccess && d->d_theta) {
         m->theta = d->d_theta; // caller-owned, trainable: htf_potential_refresh after every update
     } else if (e == hipSuccess) {
@@ -349,6 +366,8 @@ int mlp_create(const htf_potential_desc *d, MlpDevice **out) {
 
 void mlp_destroy(MlpDevice *m) {
     if (!m) return;
+    if (m->train_images && m->train_images != m->images) (void)hipFree(m->train_images);
+    if (m->train_map && m->train_map != m->map) (void)hipFree(m->train_map);
     if (m->images) (void)hipFree(m->images);
     if (m->map) (void)hipFree(m->map);
     if (m->own_theta) (void)hipFree(m->own_theta);

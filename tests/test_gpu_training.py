@@ -227,6 +227,37 @@ def test_pair_mlp_loss_gradient_matches_double_backward(htf, cuda, dims, act, NN
         o += n
 
 
+@pytest.mark.parametrize("route", ["valu", "nofuse", "bf16-images"])
+def test_pair_mlp_gradient_alternate_routes(htf, cuda, route, monkeypatch):
+    """The first-generation VALU kernel (HTF_MLP_TRAIN_VALU), the two-pass matrix-core route
+    (HTF_MLP_TRAIN_NOFUSE) and a bf16-image potential (which trains on its own fp32 image set)
+    all give the default route's loss gradient."""
+    from hoomd_tf_amd import initializers
+    nl = _case(8, N=33, NN=40)
+    params = initializers.mlp_params(seed=12)
+    theta = _flat_params(params)
+    labels = torch.from_numpy((O.lj_model(nl.astype(np.float64)) * 0.05).astype(np.float32)).to(cuda)
+    x = torch.from_numpy(nl).to(cuda)
+
+    def grad(precision="fp32"):
+        w = torch.tensor(theta, dtype=torch.float32, device=cuda)
+        pot = htf.Potential.pair_mlp(params, 0.0, 3.0, activation="tanh", precision=precision, theta=w)
+        return htf.ops.train_pair_grad(pot, x, labels).cpu().numpy()
+
+    base = grad()
+    if route == "valu":
+        monkeypatch.setenv("HTF_MLP_TRAIN_VALU", "1")
+        got = grad()
+    elif route == "nofuse":
+        monkeypatch.setenv("HTF_MLP_TRAIN_NOFUSE", "1")
+        got = grad()
+    else:
+        got = grad("bf16")
+    scale = np.abs(base[1:]).max()
+    assert np.abs(got[1:] - base[1:]).max() < 5e-5 * scale
+    np.testing.assert_allclose(got[0], base[0], rtol=1e-5)
+
+
 def test_pair_mlp_refresh_tracks_device_weights(htf, cuda):
     """The persistent potential reads the flat device vector: after an in-place change +
     refresh, the MFMA evaluator gives what a freshly built potential gives."""
