@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdlib>
+#include <dlfcn.h>
 #include <new>
 #include <vector>
 
@@ -25,6 +26,38 @@ void set_error(const char *fmt, ...) {
     g_last_error = buf;
 }
 
+} // namespace htf
+
+// HOOMD Profiler scopes of the reference (TensorflowCompute.cc:139-140,164-168,196-206) as roctx
+// ranges, visible in `rocprofv3 --marker-trace`.  librocprofiler-sdk-roctx is loaded on demand
+// and only when HTF_ROCTX is set, so a normal run neither links nor calls it.
+namespace htf {
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        if (!getenv("HTF_ROCTX")) return;
+        void *h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return;
+        push = (int (*)(const char *))dlsym(h, "roctxRangePushA");
+        pop = (int (*)())dlsym(h, "roctxRangePop");
+        if (!push || !pop) push = nullptr;
+    }
+};
+static Roctx &roctx() {
+    static Roctx r;
+    return r;
+}
+struct RoctxScope {
+    bool on;
+    explicit RoctxScope(const char *name) : on(roctx().push != nullptr) {
+        if (on) roctx().push(name);
+    }
+    ~RoctxScope() {
+        if (on) roctx().pop();
+    }
+};
 } // namespace htf
 
 struct htf_potential {
@@ -345,6 +378,7 @@ static int compute_rows(htf_ctx *ctx, unsigned timestep, const htf_hoomd_arrays 
     }
     const size_t ssz = cfg.scalar_dtype == HTF_F64 ? 8 : 4;
     hipStream_t s = (hipStream_t)stream;
+    RoctxScope scope_all("TensorflowCompute");
     const unsigned bs = cfg.batch_size == 0 ? row_count : cfg.batch_size;
     const unsigned row_end = row_begin + row_count;
     for (unsigned offset = row_begin; offset < row_end; offset += bs) { // .cc:143
@@ -395,6 +429,7 @@ static int compute_rows(htf_ctx *ctx, unsigned timestep, const htf_hoomd_arrays 
         if (cfg.nneighs > 0) {
             HTF_REQUIRE(a->n_neigh && a->nlist && a->head_list, "htf_compute_forces: null neighbor list");
             // positions side buffer (m_positions_comm.receiveArray, .cc:172) is staged by the same kernel
+            RoctxScope scope_build("TensorflowCompute::reshapeNeighbors");
             rc = build_pair_vectors_impl(c_nlist, HTF_F32, a->pos, cfg.scalar_dtype, N, cfg.nneighs, offset, n,
                                          &a->box, a->n_neigh, a->nlist, a->head_list, cfg.r_cut, nullptr,
                                          c_positions, c_counts, s);
@@ -419,6 +454,7 @@ static int compute_rows(htf_ctx *ctx, unsigned timestep, const htf_hoomd_arrays 
                 return HTF_ERR_NLIST_OVERFLOW;
             }
         }
+        RoctxScope scope_eval("TensorflowCompute::Force Update");
         void *force_out = (char *)a->force + (size_t)offset * 4 * ssz; // m_forces_comm.setOffset(offset) .cc:192
         if (ctx->pot->pp.kind == HTF_POT_PAIR_MLP)
             rc = htf_eval_forces(ctx->pot, c_nlist, HTF_F32, n, cfg.nneighs, force_out, cfg.scalar_dtype,
