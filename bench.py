@@ -50,7 +50,9 @@ def parse():
     ap.add_argument("--check-period", type=int, default=5, help="nlist distance-check period (HOOMD check_period)")
     ap.add_argument("--equil", type=int, default=300, help="untimed relaxation steps (force cap + velocity rescale)")
     ap.add_argument("--sort", action="store_true", help="enable the stand-in's particle sorter (HOOMD SFCPack analogue; measured: no kernel gain)")
-    ap.add_argument("--no-fused", action="store_true", help="skip the extra fused gather-evaluate measurement")
+    ap.add_argument("--no-fused", action="store_true", help="skip the extra variants (two-kernel dataflow, tensor-less fused mode)")
+    ap.add_argument("--two-kernel", action="store_true",
+                    help="headline run with separate build and evaluator kernels (htf_config.fused = 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -285,7 +287,11 @@ def main():
     nl.build()
     N, NN = sysm.N, args.nn
 
-    ctx = htf.Context(r_cut=args.rcut, nneighs=NN, scalar_dtype=torch.float32, max_n=N)
+    # closed-form potentials: ONE kernel builds the pair-vector tensor and evaluates it while it is in
+    # registers (htf_config.fused = 2, the tfcompute default); the pair-MLP has its own MFMA evaluator
+    closed_form = args.workload in ("lj", "wca", "mlp-train")
+    one_kernel = closed_form and not args.two_kernel
+    ctx = htf.Context(r_cut=args.rcut, nneighs=NN, scalar_dtype=torch.float32, max_n=N, fused=2 if one_kernel else 0)
     pot = make_potential(htf, args.workload)
     ctx.set_potential(pot)
     nve = standin.NVE(sysm, args.dt)
@@ -399,13 +405,25 @@ def main():
     # algorithmic bytes below are per step as well)
     eval_avg_s = eval_ms / max(args.steps, 1) * 1e-3 if ncalls else 0.0
     build_avg_s = build_ms / max(args.steps, 1) * 1e-3 if ncalls else 0.0
-    kern = {
-        "eval_forces": {"avg_us": eval_avg_s * 1e6, "algorithmic_bytes": eval_b,
-                        "GBps": eval_b / eval_avg_s / 1e9 if eval_avg_s > 0 else None},
-        "build_pair_vectors": {"avg_us": build_avg_s * 1e6, "algorithmic_bytes": build_b,
-                               "GBps": build_b / build_avg_s / 1e9 if build_avg_s > 0 else None},
-    }
-    dom = "build_pair_vectors" if build_avg_s > eval_avg_s else "eval_forces"
+    if one_kernel:
+        # its own compulsory traffic only: the build's bytes + the force write (the evaluator's
+        # N*NN*16 re-read of SURVEY 8(d) no longer happens and is NOT credited)
+        be_b = build_b + N * 16
+        kern = {"build_eval_forces": {"avg_us": eval_avg_s * 1e6, "algorithmic_bytes": be_b,
+                                      "GBps": be_b / eval_avg_s / 1e9 if eval_avg_s > 0 else None,
+                                      # SURVEY 8(d) would credit this launch with the build's AND the evaluator's bytes
+                                      "contract_GBps": (build_b + eval_b) / eval_avg_s / 1e9 if eval_avg_s > 0 else None,
+                                      "what": "pair-vector build with the evaluator as its epilogue: the [N,NN,4] "
+                                              "tensor is written once (bit-identical) and not re-read"}}
+        dom = "build_eval_forces"
+    else:
+        kern = {
+            "eval_forces": {"avg_us": eval_avg_s * 1e6, "algorithmic_bytes": eval_b,
+                            "GBps": eval_b / eval_avg_s / 1e9 if eval_avg_s > 0 else None},
+            "build_pair_vectors": {"avg_us": build_avg_s * 1e6, "algorithmic_bytes": build_b,
+                                   "GBps": build_b / build_avg_s / 1e9 if build_avg_s > 0 else None},
+        }
+        dom = "build_pair_vectors" if build_avg_s > eval_avg_s else "eval_forces"
     mfma = args.workload in ("mlp", "mlp-bf16")
     if train is not None and state["train_n"]:
         kern["train_step"] = {"avg_ms": state["train_s"] / state["train_n"] * 1e3, "count": state["train_n"],
@@ -428,7 +446,8 @@ def main():
                 raise KeyError("PMC passes were collected at the default size")
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_lj_pmc_hbm.json")))
             key = {"build_pair_vectors": "void htf::build_pair_vectors_kernel<float, float>",
-                   "eval_forces": "void htf::eval_pair_kernel<1, 16, false, float>"}[dom]
+                   "eval_forces": "void htf::eval_pair_kernel<1, 16, false, float>",
+                   "build_eval_forces": "void htf::fused_forces_kernel<1, false, true, float>"}[dom]
             rd, wr = pmc["FETCH_SIZE"][key]["avg_KiB"], pmc["WRITE_SIZE"][key]["avg_KiB"]
             # gfx950: FETCH_SIZE counts half of a wide (16 B/lane) coalesced read stream; the build
             # kernel's reads are 4-B index loads + 16-B gathers, for which the counter is uncalibrated
@@ -462,47 +481,60 @@ def main():
         "kernels": kern,
         "roofline": roof,
     }
-    # ---- extra, reported separately: the same MD with the pair vectors kept in
-    # registers (htf_config.fused) -- different algorithmic bytes, never mixed into `roofline`.
-    if not args.no_fused and not mfma:
-        ctx_f = htf.Context(r_cut=args.rcut, nneighs=NN, scalar_dtype=torch.float32, max_n=sysm.N, fused=True)
-        ctx_f.set_potential(pot)
+    # ---- extras, reported separately and never mixed into `roofline`: the same MD (a) with the
+    # reference's two-kernel dataflow (build kernel, then evaluator kernel re-reading the tensor)
+    # and (b) with the pair vectors kept in registers and NO tensor.
+    def run_variant(mode):
+        ctx_v = htf.Context(r_cut=args.rcut, nneighs=NN, scalar_dtype=torch.float32, max_n=sysm.N, fused=mode)
+        ctx_v.set_potential(pot)
+        state["arr_v"] = None
 
-        def step_f():
+        def step_v():
             ts = state["ts"]
             nl.compute(ts)
-            if nl.n_builds != state["builds"] or state.get("arr_f") is None:
+            if nl.n_builds != state["builds"] or state["arr_v"] is None:
                 state["arr"] = arrays()
-                state["arr_f"] = ctx_f.make_arrays(sysm.pos, sysm.N, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, sysm.force)
+                state["arr_v"] = ctx_v.make_arrays(sysm.pos, sysm.N, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, sysm.force)
                 state["builds"] = nl.n_builds
-            ctx_f.compute_forces_overlapped(ts, state["arr_f"], nl.domain)
+            ctx_v.compute_forces_overlapped(ts, state["arr_v"], nl.domain)
             nve.step()
             state["ts"] = ts + 1
 
         for _ in range(args.warmup):
-            step_f()
-        ctx_f.profile_enable(True)
+            step_v()
+        ctx_v.profile_enable(True)
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            step_f()
+            step_v()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-        el_f = time.perf_counter() - t0
-        _, fused_ms, ncf = ctx_f.profile_read()
+        el = time.perf_counter() - t0
+        b_ms, e_ms, nc = ctx_v.profile_read()
         if dist is not None:
-            t = torch.tensor([el_f], dtype=torch.float64, device=dev)
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el_f = float(t.item())
+            el = float(t.item())
+        per = 1e-3 / max(args.steps, 1)
+        return el, (b_ms * per if nc else 0.0), (e_ms * per if nc else 0.0)
+
+    if not args.no_fused and closed_form and train is None:
+        if one_kernel:
+            el, b_s, e_s = run_variant(0)
+            out["two_kernel_variant"] = {
+                "note": "htf_config.fused = 0: build kernel, then evaluator kernel re-reading the tensor (SURVEY 8(d) dataflow)",
+                "value": world * args.steps / el, "unit": "steps/s", "ms_per_step": el / args.steps * 1e3,
+                "build_pair_vectors": {"avg_us": b_s * 1e6, "algorithmic_bytes": build_b, "GBps": build_b / b_s / 1e9 if b_s > 0 else None},
+                "eval_forces": {"avg_us": e_s * 1e6, "algorithmic_bytes": eval_b, "GBps": eval_b / e_s / 1e9 if e_s > 0 else None}}
+        el, _, f_s = run_variant(1)
         fb = sysm.N * 8 + n_entries * 4 + (sysm.N + sysm.n_ghost) * 16 + sysm.N * 16
-        fus = fused_ms / max(args.steps, 1) * 1e-3 if ncf else 0.0  # per step (two row ranges per step with slabs)
         out["fused_variant"] = {
             "note": "pair vectors evaluated in registers (htf_config.fused=1); the [N,NN,4] tensor is not materialised",
-            "value": world * args.steps / el_f, "unit": "steps/s", "ms_per_step": el_f / args.steps * 1e3,
-            "kernel_avg_us": fus * 1e6, "algorithmic_bytes": fb, "GBps": fb / fus / 1e9 if fus > 0 else None,
+            "value": world * args.steps / el, "unit": "steps/s", "ms_per_step": el / args.steps * 1e3,
+            "kernel_avg_us": f_s * 1e6, "algorithmic_bytes": fb, "GBps": fb / f_s / 1e9 if f_s > 0 else None,
             "energy_per_particle": float(sysm.force[:, 3].double().sum().item()) / sysm.N}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cb, f_cpu = cpu_baseline(sysm, nl, args)

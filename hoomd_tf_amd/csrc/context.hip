@@ -239,7 +239,22 @@ extern "C" int htf_fused_forces(const htf_potential *pot, const void *d_pos, int
     HTF_REQUIRE(pot, "htf_fused_forces: no potential");
     HTF_REQUIRE(force_dtype == HTF_F32 || force_dtype == HTF_F64, "htf_fused_forces: bad force dtype %d", force_dtype);
     return fused_forces_impl(pot->pp, d_pos, pos_dtype, N, NN, offset, batch_size, box, d_n_neigh, d_nlist, d_head_list,
-                             rmax, d_force, force_dtype, d_virial9, d_check_count, nullptr, (hipStream_t)stream);
+                             rmax, d_force, force_dtype, d_virial9, d_check_count, nullptr, nullptr, nullptr,
+                             (hipStream_t)stream);
+}
+
+extern "C" int htf_build_eval_forces(const htf_potential *pot, void *d_dest, const void *d_pos, int pos_dtype, unsigned N,
+                                     unsigned NN, unsigned offset, unsigned batch_size, const htf_box *box,
+                                     const unsigned *d_n_neigh, const unsigned *d_nlist, const unsigned *d_head_list,
+                                     double rmax, void *d_force, int force_dtype, void *d_virial9,
+                                     unsigned *d_check_count, htf_stream stream) {
+    using namespace htf;
+    HTF_REQUIRE(pot, "htf_build_eval_forces: no potential");
+    HTF_REQUIRE(d_dest, "htf_build_eval_forces: null pair-vector tensor");
+    HTF_REQUIRE(force_dtype == HTF_F32 || force_dtype == HTF_F64, "htf_build_eval_forces: bad force dtype %d", force_dtype);
+    return fused_forces_impl(pot->pp, d_pos, pos_dtype, N, NN, offset, batch_size, box, d_n_neigh, d_nlist, d_head_list,
+                             rmax, d_force, force_dtype, d_virial9, d_check_count, nullptr, (float4 *)d_dest, nullptr,
+                             (hipStream_t)stream);
 }
 
 extern "C" int htf_eval_forces2(const htf_potential *potA, const htf_potential *potB, const void *d_nlist,
@@ -407,7 +422,7 @@ static int compute_rows(htf_ctx *ctx, unsigned timestep, const htf_hoomd_arrays 
             rc = fused_forces_impl(ctx->pot->pp, a->pos, cfg.scalar_dtype, N, cfg.nneighs, offset, n, &a->box, a->n_neigh,
                                    a->nlist, a->head_list, cfg.r_cut, fo, cfg.scalar_dtype,
                                    cfg.virial ? c_virial : nullptr, cfg.check_nlist ? ctx->flag : nullptr,
-                                   c_positions, s);
+                                   c_positions, cfg.fused == 2 ? c_nlist : nullptr, cfg.fused == 2 ? c_counts : nullptr, s);
             if (rc != HTF_OK) return rc;
             if (prof) HTF_CHECK_HIP(hipEventRecord(e2, s));
             if (cfg.check_nlist) {

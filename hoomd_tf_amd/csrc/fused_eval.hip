@@ -10,7 +10,11 @@
 // two-kernel path: identical dx (box_math.h pins contraction off), keep unless
 // rsq > r_cut^2, NN-slot wrap on overflow (only the last NN kept neighbors contribute),
 // zero padding contributes nothing, same per-slot math (pair_math.h).
-// Opt-in (htf_config.fused): the nlist side buffer is not filled in this mode.
+// htf_config.fused = 1: the nlist side buffer is not filled (opt-in, reported separately).
+// htf_config.fused = 2 (STORE): the SAME kernel also writes the pair vectors it has in
+// registers -- rows, zero tails and live counts exactly as build_pair_vectors_kernel does
+// (bit-identical tensor) -- so the tensor exists for get_nlist_array / training / observables
+// but is never read back: the evaluator's 268 MB re-read and its launch disappear from the step.
 #include <cstdlib>
 
 #include "box_math.h"
@@ -20,7 +24,7 @@
 
 namespace htf {
 
-constexpr int kFChunk = 4;
+constexpr int kFChunk = 3; // index loads hoisted per lane per trip (as pair_vectors.hip: n_neigh <= 192 in one trip)
 
 struct FusedAcc {
     float fx = 0.f, fy = 0.f, fz = 0.f, en = 0.f;
@@ -28,11 +32,13 @@ struct FusedAcc {
     unsigned npos = 0; // slots with dx > 0: SimModel check_nlist's count (simmodel.py:214-219)
 };
 
-template <int KIND, bool VIRIAL, typename PT>
+// STORE: 0 none; 1 first pass (slot q for q < NN); 2 overflow replay (slot q % NN for q >= s_lo)
+template <int KIND, bool VIRIAL, int STORE, typename PT>
 __device__ __forceinline__ unsigned fused_sweep(FusedAcc &acc, const typename Vec4<PT>::type *__restrict__ pos,
                                                 const unsigned *__restrict__ nl, unsigned nn,
                                                 const typename Vec4<PT>::type pi, const BoxT<PT> &box, PT rmaxsq,
-                                                unsigned lane, unsigned q_lo, unsigned q_hi, const PotParams &p) {
+                                                unsigned lane, unsigned q_lo, unsigned q_hi, const PotParams &p,
+                                                float4 *__restrict__ row, unsigned NN, unsigned s_lo) {
     using PV = typename Vec4<PT>::type;
     unsigned Q = 0;
     for (unsigned base = 0; base < nn; base += 64 * kFChunk) {
@@ -55,6 +61,15 @@ __device__ __forceinline__ unsigned fused_sweep(FusedAcc &acc, const typename Ve
             unsigned long long m = __ballot(keep);
             unsigned q = Q + __popcll(m & ((1ull << lane) - 1ull));
             Q += __popcll(m);
+            if constexpr (STORE != 0) {
+                // the tensor row, as build_pair_vectors_kernel writes it (fp32 wire, type as a float)
+                const float4 out = make_float4((float)dx, (float)dy, (float)dz, (float)scalar_as_int(pk[t].w));
+                if constexpr (STORE == 1) {
+                    if (keep && q < NN) row[q] = out;
+                } else {
+                    if (keep && q >= s_lo) row[q % NN] = out;
+                }
+            }
             if (keep && q >= q_lo && q < q_hi) {
                 // the model sees the pair vector after tf.cast to fp32 (simmodel.py:226-227)
                 const float x = (float)dx, y = (float)dy, z = (float)dz;
@@ -72,7 +87,7 @@ __device__ __forceinline__ unsigned fused_sweep(FusedAcc &acc, const typename Ve
     return Q;
 }
 
-template <int KIND, bool VIRIAL, typename PT>
+template <int KIND, bool VIRIAL, bool STORE, typename PT>
 __global__ __launch_bounds__(256) void fused_forces_kernel(const typename Vec4<PT>::type *__restrict__ pos, unsigned N,
                                                            unsigned NN, unsigned offset, unsigned batch,
                                                            BoxT<PT> box, const unsigned *__restrict__ n_neigh,
@@ -80,7 +95,8 @@ __global__ __launch_bounds__(256) void fused_forces_kernel(const typename Vec4<P
                                                            const unsigned *__restrict__ head_list, PT rmaxsq,
                                                            void *__restrict__ force, void *__restrict__ virial9,
                                                            int out_f64, PotParams pin, unsigned *__restrict__ check_count,
-                                                           float4 *__restrict__ positions_out) {
+                                                           float4 *__restrict__ positions_out,
+                                                           float4 *__restrict__ dest, unsigned *__restrict__ counts_io) {
     const PotParams p = resolve_theta<KIND>(pin);
     const unsigned lane = threadIdx.x & 63u;
     const unsigned w = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
@@ -94,11 +110,21 @@ __global__ __launch_bounds__(256) void fused_forces_kernel(const typename Vec4<P
         positions_out[w] = make_float4((float)pi.x, (float)pi.y, (float)pi.z, (float)scalar_as_int(pi.w));
 
     FusedAcc acc;
-    unsigned Q = nn ? fused_sweep<KIND, VIRIAL, PT>(acc, pos, nl, nn, pi, box, rmaxsq, lane, 0u, NN, p) : 0u;
+    float4 *row = STORE ? dest + (size_t)w * NN : nullptr;
+    unsigned Q = nn ? fused_sweep<KIND, VIRIAL, STORE ? 1 : 0, PT>(acc, pos, nl, nn, pi, box, rmaxsq, lane, 0u, NN, p, row, NN, 0u) : 0u;
+    if constexpr (STORE) {
+        // zero tail / delta zero-fill / live count: pair_vectors.hip, same bookkeeping
+        const unsigned filled = Q < NN ? Q : NN;
+        const unsigned zero_end = counts_io != nullptr ? counts_io[w] : NN;
+        for (unsigned sl = filled + lane; sl < zero_end; sl += 64) row[sl] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (counts_io != nullptr && lane == 0) counts_io[w] = filled;
+    }
     if (Q > NN) {
         // overflow: the reference's slot wrap leaves exactly the last NN kept neighbors
         acc = FusedAcc();
-        fused_sweep<KIND, VIRIAL, PT>(acc, pos, nl, nn, pi, box, rmaxsq, lane, Q - NN, Q, p);
+        if constexpr (STORE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // first-pass stores retire before the wrap overwrites them
+        const unsigned s_lo = Q - NN > NN ? Q - NN : NN;
+        fused_sweep<KIND, VIRIAL, STORE ? 2 : 0, PT>(acc, pos, nl, nn, pi, box, rmaxsq, lane, Q - NN, Q, p, row, NN, s_lo);
     }
     float fx = group_sum<64>(acc.fx), fy = group_sum<64>(acc.fy), fz = group_sum<64>(acc.fz);
     float en = group_sum<64>(acc.en);
@@ -138,12 +164,17 @@ template <int KIND, bool VIRIAL, typename PT>
 static int launch_fused(const void *pos, unsigned N, unsigned NN, unsigned offset, unsigned batch, const htf_box *hb,
                         const unsigned *n_neigh, const unsigned *nlist, const unsigned *head_list, double rmax,
                         void *force, void *virial9, int out_f64, const PotParams &p, unsigned *check_count,
-                        float4 *positions_out, hipStream_t s) {
+                        float4 *positions_out, float4 *dest, unsigned *counts_io, hipStream_t s) {
     BoxT<PT> b = make_boxt<PT>(hb);
     PT rc = (PT)rmax;
-    hipLaunchKernelGGL((fused_forces_kernel<KIND, VIRIAL, PT>), dim3((batch + 3) / 4), dim3(256), 0, s,
-                       (const typename Vec4<PT>::type *)pos, N, NN, offset, batch, b, n_neigh, nlist, head_list,
-                       (PT)(rc * rc), force, virial9, out_f64, p, check_count, positions_out);
+    if (dest != nullptr)
+        hipLaunchKernelGGL((fused_forces_kernel<KIND, VIRIAL, true, PT>), dim3((batch + 3) / 4), dim3(256), 0, s,
+                           (const typename Vec4<PT>::type *)pos, N, NN, offset, batch, b, n_neigh, nlist, head_list,
+                           (PT)(rc * rc), force, virial9, out_f64, p, check_count, positions_out, dest, counts_io);
+    else
+        hipLaunchKernelGGL((fused_forces_kernel<KIND, VIRIAL, false, PT>), dim3((batch + 3) / 4), dim3(256), 0, s,
+                           (const typename Vec4<PT>::type *)pos, N, NN, offset, batch, b, n_neigh, nlist, head_list,
+                           (PT)(rc * rc), force, virial9, out_f64, p, check_count, positions_out, dest, counts_io);
     return check_launch("fused_forces_kernel");
 }
 
@@ -151,8 +182,9 @@ template <int KIND>
 static int launch_fused_k(const void *pos, int pos_dtype, unsigned N, unsigned NN, unsigned offset, unsigned batch,
                           const htf_box *hb, const unsigned *n_neigh, const unsigned *nlist,
                           const unsigned *head_list, double rmax, void *force, void *virial9, int out_f64,
-                          const PotParams &p, unsigned *check_count, float4 *positions_out, hipStream_t s) {
-#define HTF_FUSED(V, T) launch_fused<KIND, V, T>(pos, N, NN, offset, batch, hb, n_neigh, nlist, head_list, rmax, force, virial9, out_f64, p, check_count, positions_out, s)
+                          const PotParams &p, unsigned *check_count, float4 *positions_out, float4 *dest,
+                          unsigned *counts_io, hipStream_t s) {
+#define HTF_FUSED(V, T) launch_fused<KIND, V, T>(pos, N, NN, offset, batch, hb, n_neigh, nlist, head_list, rmax, force, virial9, out_f64, p, check_count, positions_out, dest, counts_io, s)
     if (pos_dtype == HTF_F32) return virial9 ? HTF_FUSED(true, float) : HTF_FUSED(false, float);
     return virial9 ? HTF_FUSED(true, double) : HTF_FUSED(false, double);
 #undef HTF_FUSED
@@ -161,14 +193,14 @@ static int launch_fused_k(const void *pos, int pos_dtype, unsigned N, unsigned N
 int fused_forces_impl(const PotParams &p, const void *pos, int pos_dtype, unsigned N, unsigned NN, unsigned offset,
                       unsigned batch, const htf_box *box, const unsigned *n_neigh, const unsigned *nlist,
                       const unsigned *head_list, double rmax, void *force, int force_dtype, void *virial9,
-                      unsigned *check_count, float4 *positions_out, hipStream_t s) {
+                      unsigned *check_count, float4 *positions_out, float4 *dest, unsigned *counts_io, hipStream_t s) {
     HTF_REQUIRE(pos && n_neigh && nlist && head_list && box && force, "htf_fused_forces: null pointer");
     HTF_REQUIRE(NN > 0 && rmax > 0, "htf_fused_forces: NN and rmax must be > 0");
     HTF_REQUIRE(offset <= N && batch <= N - offset, "htf_fused_forces: batch [%u, %u) exceeds N=%u", offset, offset + batch, N);
     HTF_REQUIRE(pos_dtype == HTF_F32 || pos_dtype == HTF_F64, "htf_fused_forces: bad position dtype %d", pos_dtype);
     if (batch == 0) return HTF_OK;
     const int out_f64 = force_dtype == HTF_F64;
-#define HTF_FK(K) launch_fused_k<K>(pos, pos_dtype, N, NN, offset, batch, box, n_neigh, nlist, head_list, rmax, force, virial9, out_f64, p, check_count, positions_out, s)
+#define HTF_FK(K) launch_fused_k<K>(pos, pos_dtype, N, NN, offset, batch, box, n_neigh, nlist, head_list, rmax, force, virial9, out_f64, p, check_count, positions_out, dest, counts_io, s)
     switch (p.kind) {
     case HTF_POT_LJ: return HTF_FK(HTF_POT_LJ);
     case HTF_POT_WCA: return HTF_FK(HTF_POT_WCA);

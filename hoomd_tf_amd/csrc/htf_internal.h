@@ -29,7 +29,7 @@ int build_pair_vectors_impl(void *dest, int dest_dtype, const void *d_pos, int p
 int fused_forces_impl(const PotParams &p, const void *pos, int pos_dtype, unsigned N, unsigned NN, unsigned offset,
                       unsigned batch, const htf_box *box, const unsigned *n_neigh, const unsigned *nlist,
                       const unsigned *head_list, double rmax, void *force, int force_dtype, void *virial9,
-                      unsigned *check_count, float4 *positions_out, hipStream_t s);
+                      unsigned *check_count, float4 *positions_out, float4 *dest, unsigned *counts_io, hipStream_t s);
 
 int eval_pair2_dispatch(const PotParams &pa, const PotParams &pb, const void *nlist, int in_dtype, unsigned B,
                         unsigned NN, void *forceA, void *forceB, int force_dtype, float *partials, float rdf_r0,

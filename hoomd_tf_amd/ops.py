@@ -174,8 +174,10 @@ def eval_forces(potential, nlist, virial=False, out=None, out_dtype=None, virial
 
 
 def fused_forces(potential, pos, n_neigh, head_list, nlist, box, r_cut, NN, offset=0, batch_size=None,
-                 n_local=None, virial=False, out_dtype=None, check_count=None, periodic=(1, 1, 1)):
-    """build_pair_vectors + eval_forces without materialising the pair-vector tensor."""
+                 n_local=None, virial=False, out_dtype=None, check_count=None, periodic=(1, 1, 1), pair_vectors=None):
+    """build_pair_vectors + eval_forces in one kernel.  ``pair_vectors`` (fp32 [B, NN, 4]) also
+    receives the tensor, bit-identical to build_pair_vectors' (htf_build_eval_forces); without it
+    the tensor is never materialised (htf_fused_forces)."""
     _dev(pos, "pos")
     N = int(n_neigh.shape[0]) if n_local is None else int(n_local)
     B = N - offset if batch_size is None else int(batch_size)
@@ -185,11 +187,18 @@ def fused_forces(potential, pos, n_neigh, head_list, nlist, box, r_cut, NN, offs
     if B == 0:
         return (out, v) if virial else out
     b = box if isinstance(box, _lib.Box) else _lib.make_box(box, periodic)
-    check(lib.htf_fused_forces(potential.handle, pos.data_ptr(), _dt(pos), N, NN, offset, B, C.byref(b),
-                               _u32(n_neigh, "n_neigh").data_ptr(), _u32(nlist, "nlist").data_ptr(),
-                               _u32(head_list, "head_list").data_ptr(), float(r_cut), out.data_ptr(), _dt(out),
-                               v.data_ptr() if v is not None else None,
-                               check_count.data_ptr() if check_count is not None else None, _stream(pos)))
+    tail = (pos.data_ptr(), _dt(pos), N, NN, offset, B, C.byref(b),
+            _u32(n_neigh, "n_neigh").data_ptr(), _u32(nlist, "nlist").data_ptr(),
+            _u32(head_list, "head_list").data_ptr(), float(r_cut), out.data_ptr(), _dt(out),
+            v.data_ptr() if v is not None else None,
+            check_count.data_ptr() if check_count is not None else None, _stream(pos))
+    if pair_vectors is None:
+        check(lib.htf_fused_forces(potential.handle, *tail))
+    else:
+        _dev(pair_vectors, "pair_vectors", torch.float32)
+        if tuple(pair_vectors.shape) != (B, NN, 4):
+            raise ValueError("pair_vectors must be [%d, %d, 4]" % (B, NN))
+        check(lib.htf_build_eval_forces(potential.handle, pair_vectors.data_ptr(), *tail))
     return (out, v) if virial else out
 
 
@@ -345,13 +354,15 @@ def stuff_types(pos_xyz, types, dtype=torch.float32):
 
 
 class Context:
-    """htf_ctx: the TensorflowCompute object (TensorflowCompute.h:75-250)."""
+    """htf_ctx: the TensorflowCompute object (TensorflowCompute.h:75-250).  ``fused``: 0 two
+    kernels (build, then evaluate), 2 one kernel that writes the tensor and evaluates it in
+    registers, 1 / True the same without writing the tensor."""
 
     def __init__(self, r_cut, nneighs, period=1, batch_size=0, scalar_dtype=torch.float32,
                  check_nlist=False, virial=False, max_n=0, force_mode=_lib.HTF_TF2HOOMD, fused=False):
         cfg = _lib.Config(float(r_cut), int(nneighs), int(force_mode), int(period), int(batch_size),
                           _lib.HTF_F64 if scalar_dtype == torch.float64 else _lib.HTF_F32,
-                          int(bool(check_nlist)), int(bool(virial)), int(max_n), int(bool(fused)))
+                          int(bool(check_nlist)), int(bool(virial)), int(max_n), int(fused))
         self.cfg = cfg
         self.scalar_dtype = scalar_dtype
         self._h = C.c_void_p()

@@ -28,9 +28,10 @@ class tfcompute:
         self.cpp_force = None
         self._nlist = None
         self.map_types = set()
-        # opt-in: evaluate pair vectors in registers on the traced path (htf_config.fused);
-        # get_nlist_array() then has no side buffer to read
-        self.fused = False
+        # traced path (htf_config.fused): 2 = one kernel writes the pair-vector tensor and evaluates
+        # it while it is in registers (default); 0 = build kernel, then evaluator kernel; 1 = opt-in,
+        # no tensor at all (get_nlist_array() then has no side buffer to read)
+        self.fused = 2
 
     def attach(self, nlist=None, r_cut=0, period=1, batch_size=None, train=False, save_output_period=None):
         """tensorflowcompute.py:38-188 (same arguments and error behaviour)."""
@@ -328,7 +329,7 @@ class tfcompute:
 
     def get_nlist_array(self):
         """tensorflowcompute.py:377-381 -> [B, NN, 4]."""
-        if self._ctx_ran and self.fused:
+        if self._ctx_ran and int(self.fused) == 1:
             raise RuntimeError('fused mode keeps the pair vectors in registers; there is no nlist buffer to read')
         if self._ctx_ran:
             n = self.system.N if self.batch_size == 0 else min(self.batch_size, self.system.N)

@@ -151,6 +151,16 @@ HTF_API int htf_fused_forces(const htf_potential *pot, const void *d_pos, int po
                      double rmax, void *d_force, int force_dtype, void *d_virial9,
                      unsigned *d_check_count, htf_stream stream);
 
+/* htf_build_pair_vectors and htf_eval_forces as ONE kernel: d_dest ([batch, NN, 4] fp32) receives
+ * exactly what htf_build_pair_vectors writes (bit-identical, zero padded) while the forces are
+ * evaluated on the pair vectors still in registers -- the producing kernel carries the
+ * evaluator as its epilogue, so the tensor is written once and not re-read. */
+HTF_API int htf_build_eval_forces(const htf_potential *pot, void *d_dest, const void *d_pos, int pos_dtype,
+                          unsigned N, unsigned NN, unsigned offset, unsigned batch_size, const htf_box *box,
+                          const unsigned *d_n_neigh, const unsigned *d_nlist, const unsigned *d_head_list,
+                          double rmax, void *d_force, int force_dtype, void *d_virial9,
+                          unsigned *d_check_count, htf_stream stream);
+
 /* Two potentials in ONE pass over the pair vectors: forceA <- potA, forceB <- potB (both [B]
  * Scalar4).  potB must be HTF_POT_GAUSS, potA a closed-form potential.  d_partials (nullable,
  * >= htf_eval2_num_partials(B, NN) floats): per-block sums of forceB[i].w, to be reduced with
@@ -296,8 +306,13 @@ typedef struct htf_config {
     int check_nlist;     /* SimModel(check_nlist=True) simmodel.py:15 */
     int virial;          /* SimModel(virial=True)      simmodel.py:15 */
     unsigned max_n;      /* m_pdata->getMaxN(): sizes the scratch, reallocate() .cc:91-121 */
-    int fused;           /* 1: evaluate pair vectors in registers (htf_fused_forces); the nlist
-                          * side buffer is then NOT filled.  0 (default): reference dataflow. */
+    int fused;           /* 0: two kernels, build then evaluate (the reference's dataflow).
+                          * 2: ONE kernel writes the pair-vector tensor AND evaluates it while it is
+                          *    in registers (htf_build_eval_forces): the tensor is bit-identical and
+                          *    available through htf_get_nlist_buffer, but never read back.
+                          * 1: as 2 without writing the tensor (htf_fused_forces); the nlist side
+                          *    buffer is then NOT filled.  Closed-form potentials; the pair-MLP
+                          *    always takes the two-kernel route. */
 } htf_config;
 
 /* What HOOMD hands over each step (raw device pointers; see layouts above). */

@@ -450,6 +450,13 @@ def test_fused_matches_two_kernel_path_and_oracle(htf, cuda, hdt, NN):
         scale = max(1.0, float(f2.abs().max()))
         assert float((f - f2).abs().max()) <= 2e-5 * scale
         assert int(cc.item()) == htf.ops.check_nlist(pv)
+        # htf_build_eval_forces: the same kernel also writes the tensor -- bit-identical to the
+        # build kernel's (zero padding and the overflow wrap included), forces identical to the
+        # tensor-less fused call
+        pv2 = torch.full_like(pv, 7.0)
+        out2 = htf.ops.fused_forces(pot, p4, dnn, dhead, dnl, box, 3.0, NN, virial=virial, pair_vectors=pv2)
+        assert torch.equal(pv2, pv)
+        assert torch.equal(out2[0] if virial else out2, f)
         if virial:
             assert float((out[1] - two[1]).abs().max()) <= 2e-5 * max(1.0, float(two[1].abs().max()))
             ref_nl = O.prepare_neighbors(pos, types, nn, head, nl, box, 3.0, NN).astype(np.float32).astype(np.float64)
@@ -473,17 +480,22 @@ def test_context_fused_mode(htf, cuda):
     box = O.make_box(L)
     p4, dnn, dhead, dnl = _to_dev(htf, pos, types, nn, head, nl, np.float64, cuda)
     res = []
-    for fused in (False, True):
+    for fused in (0, 1, 2):
         ctx = htf.Context(r_cut=5.0, nneighs=32, batch_size=7, scalar_dtype=torch.float64, virial=True,
                           check_nlist=True, max_n=N, fused=fused)
         ctx.set_potential(htf.Potential.lj())
         force = torch.zeros((N, 4), dtype=torch.float64, device=cuda)
         vir = torch.zeros(6 * N, dtype=torch.float64, device=cuda)
         ctx.compute_forces(0, ctx.make_arrays(p4, N, dnn, dhead, dnl, box, force, vir, N))
-        res.append((force.cpu().numpy(), vir.cpu().numpy(), ctx.positions_buffer(4).cpu().numpy()))
-    np.testing.assert_allclose(res[0][0], res[1][0], rtol=2e-5, atol=1e-7)
-    np.testing.assert_allclose(res[0][1], res[1][1], rtol=2e-5, atol=1e-7)
-    np.testing.assert_array_equal(res[0][2], res[1][2])
+        res.append((force.cpu().numpy(), vir.cpu().numpy(), ctx.positions_buffer(4).cpu().numpy(),
+                    ctx.nlist_buffer(4, cuda).cpu().numpy()))
+    for k in (1, 2):
+        np.testing.assert_allclose(res[0][0], res[k][0], rtol=2e-5, atol=1e-7)
+        np.testing.assert_allclose(res[0][1], res[k][1], rtol=2e-5, atol=1e-7)
+        np.testing.assert_array_equal(res[0][2], res[k][2])
+    # mode 2 leaves the last batch's pair vectors in the side buffer exactly as the build kernel does
+    np.testing.assert_array_equal(res[0][3], res[2][3])
+    assert np.abs(res[0][3]).max() > 0
     # test_overflow's system (8x8, r_cut 10, NN 4): the dx > 0 count certainly reaches NN
     pos, L = sq_lattice(8, 4.0)
     pos[:, :2] += 0.05 * np.random.default_rng(1).standard_normal((64, 2))

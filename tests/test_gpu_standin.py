@@ -77,7 +77,7 @@ def test_nve_step_and_displacement(htf, cuda):
     assert nl.needs_update()
 
 
-@pytest.mark.parametrize("mode", ["plain", "virial", "fused", "mlp"])
+@pytest.mark.parametrize("mode", ["plain", "virial", "fused", "fused-store", "mlp"])
 def test_compute_forces_in_row_ranges_equals_whole(htf, cuda, mode):
     """htf_compute_forces_rows: a step computed as [0, n1) then [n1, N) (interior rows while the
     halo is in flight, boundary rows after it) leaves forces, virial and the context's
@@ -97,7 +97,7 @@ def test_compute_forces_in_row_ranges_equals_whole(htf, cuda, mode):
 
     def run(split):
         ctx = htf.Context(r_cut=2.5, nneighs=NN, scalar_dtype=torch.float32, max_n=N, virial=virial,
-                          fused=(mode == "fused"))
+                          fused={"fused": 1, "fused-store": 2}.get(mode, 0))
         ctx.set_potential(pot)
         force = torch.zeros((N, 4), device=cuda)
         vir = torch.zeros(6 * N, device=cuda) if virial else None
@@ -117,6 +117,10 @@ def test_compute_forces_in_row_ranges_equals_whole(htf, cuda, mode):
 
     f0, v0, b0 = run(False)
     f1, v1, b1 = run(True)
+    if mode == "fused-store":  # the one-kernel mode keeps the side buffers of the two-kernel mode
+        mode = "plain"
+        _, _, b_plain = run(False)
+        assert torch.equal(b_plain[0], b0[0]) and torch.equal(b_plain[1], b0[1])
     assert torch.equal(f0, f1) and float(f0.abs().sum()) > 0
     if virial:
         assert torch.equal(v0, v1) and float(v0.abs().sum()) > 0

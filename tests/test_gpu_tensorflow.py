@@ -103,18 +103,23 @@ def test_lj_forces(htf, cuda, dtype):
 
 
 def test_traced_equals_eager(htf, cuda):
-    """The one-C-call traced path and the per-batch eager path give identical forces."""
+    """The one-C-call traced path and the per-batch eager path give the same forces: bit-equal
+    when the traced path uses the same two kernels (fused = 0), to summation-order rounding with
+    the default one-kernel mode (the evaluator rides in the build kernel: 64-lane instead of
+    16-lane row sums)."""
     outs = []
-    for force_eager in (False, True):
+    for force_eager, fused in ((False, 0), (True, 0), (False, 2)):
         sim, system, L = _sim(htf, cuda, 6, 1.3, kT=0.5, seed=4, jitter=0.05)
         model = build_examples.LJModel(32)
         tfc = htf.tfcompute(model)
+        tfc.fused = fused
         tfc.attach(sim.nlist_cell(check_period=1), r_cut=2.5, save_output_period=1 if force_eager else None)
         sim.run(15)
         sim.compute_forces()
         assert (tfc._plan is None) == force_eager
         outs.append(sim.net_force.cpu().numpy().copy())
     np.testing.assert_array_equal(outs[0], outs[1])
+    np.testing.assert_allclose(outs[2], outs[1], rtol=1e-4, atol=1e-5 * np.abs(outs[1]).max())
 
 
 def test_lj_energy(htf, cuda):
