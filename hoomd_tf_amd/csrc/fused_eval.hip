@@ -88,19 +88,13 @@ __device__ __forceinline__ unsigned fused_sweep(FusedAcc &acc, const typename Ve
 }
 
 template <int KIND, bool VIRIAL, bool STORE, typename PT>
-__global__ __launch_bounds__(256) void fused_forces_kernel(const typename Vec4<PT>::type *__restrict__ pos, unsigned N,
-                                                           unsigned NN, unsigned offset, unsigned batch,
-                                                           BoxT<PT> box, const unsigned *__restrict__ n_neigh,
-                                                           const unsigned *__restrict__ nlist,
-                                                           const unsigned *__restrict__ head_list, PT rmaxsq,
-                                                           void *__restrict__ force, void *__restrict__ virial9,
-                                                           int out_f64, PotParams pin, unsigned *__restrict__ check_count,
-                                                           float4 *__restrict__ positions_out,
-                                                           float4 *__restrict__ dest, unsigned *__restrict__ counts_io) {
-    const PotParams p = resolve_theta<KIND>(pin);
-    const unsigned lane = threadIdx.x & 63u;
-    const unsigned w = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-    if (w >= batch) return;
+__device__ __forceinline__ void fused_row(const unsigned w, const unsigned lane, const typename Vec4<PT>::type *__restrict__ pos,
+                                          unsigned N, unsigned NN, unsigned offset, const BoxT<PT> &box,
+                                          const unsigned *__restrict__ n_neigh, const unsigned *__restrict__ nlist,
+                                          const unsigned *__restrict__ head_list, PT rmaxsq, void *__restrict__ force,
+                                          void *__restrict__ virial9, int out_f64, const PotParams &p,
+                                          unsigned *__restrict__ check_count, float4 *__restrict__ positions_out,
+                                          float4 *__restrict__ dest, unsigned *__restrict__ counts_io) {
     const unsigned idx = w + offset;
     if (idx >= N) return;
     const unsigned nn = n_neigh[idx];
@@ -160,6 +154,132 @@ __global__ __launch_bounds__(256) void fused_forces_kernel(const typename Vec4<P
     }
 }
 
+template <int KIND, bool VIRIAL, bool STORE, typename PT>
+__global__ __launch_bounds__(256) void fused_forces_kernel(const typename Vec4<PT>::type *__restrict__ pos, unsigned N,
+                                                           unsigned NN, unsigned offset, unsigned batch,
+                                                           BoxT<PT> box, const unsigned *__restrict__ n_neigh,
+                                                           const unsigned *__restrict__ nlist,
+                                                           const unsigned *__restrict__ head_list, PT rmaxsq,
+                                                           void *__restrict__ force, void *__restrict__ virial9,
+                                                           int out_f64, PotParams pin, unsigned *__restrict__ check_count,
+                                                           float4 *__restrict__ positions_out,
+                                                           float4 *__restrict__ dest, unsigned *__restrict__ counts_io) {    const PotParams p = resolve_theta<KIND>(pin);
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned w = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (w >= batch) return;
+    fused_row<KIND, VIRIAL, STORE, PT>(w, lane, pos, N, NN, offset, box, n_neigh, nlist, head_list, rmaxsq, force, virial9,
+                                       out_f64, p, check_count, positions_out, dest, counts_io);
+}
+
+// Two rows per wave with ALL their index loads, then all their gathers, issued before any
+// arithmetic: twice the bytes in flight per wave slot while the evaluator's VALU work (which,
+// unlike the plain build, this kernel has plenty of) runs under the other row's memory latency.
+// Fast path for the common case (every row of the pair has 1..192 list entries and does not
+// overflow NN); anything else is redone by the generic single-row routine.
+template <int KIND, bool STORE, typename PT>
+__global__ __launch_bounds__(256) void fused_forces_rows2_kernel(
+    const typename Vec4<PT>::type *__restrict__ pos, unsigned N, unsigned NN, unsigned offset, unsigned batch,
+    BoxT<PT> box, const unsigned *__restrict__ n_neigh, const unsigned *__restrict__ nlist,
+    const unsigned *__restrict__ head_list, PT rmaxsq, void *__restrict__ force, int out_f64, PotParams pin,
+    unsigned *__restrict__ check_count, float4 *__restrict__ positions_out, float4 *__restrict__ dest,
+    unsigned *__restrict__ counts_io) {
+    using PV = typename Vec4<PT>::type;
+    const PotParams p = resolve_theta<KIND>(pin);
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned wv = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const unsigned w0 = 2 * wv, w1 = w0 + 1;
+    if (w0 >= batch) return;
+    const bool two = w1 < batch;
+    const unsigned i0 = w0 + offset, i1 = (two ? w1 : w0) + offset;
+    const unsigned nn0 = n_neigh[i0], nn1 = n_neigh[i1];
+    if (!two || nn0 == 0 || nn1 == 0 || nn0 > 64 * kFChunk || nn1 > 64 * kFChunk) {
+        fused_row<KIND, false, STORE, PT>(w0, lane, pos, N, NN, offset, box, n_neigh, nlist, head_list, rmaxsq, force,
+                                          nullptr, out_f64, p, check_count, positions_out, dest, counts_io);
+        if (two)
+            fused_row<KIND, false, STORE, PT>(w1, lane, pos, N, NN, offset, box, n_neigh, nlist, head_list, rmaxsq, force,
+                                              nullptr, out_f64, p, check_count, positions_out, dest, counts_io);
+        return;
+    }
+    const unsigned *nl0 = nlist + head_list[i0], *nl1 = nlist + head_list[i1];
+    const PV pi0 = pos[i0], pi1 = pos[i1];
+    unsigned k0[kFChunk], k1[kFChunk];
+    PV q0[kFChunk], q1[kFChunk];
+#pragma unroll
+    for (int t = 0; t < kFChunk; ++t) {
+        const unsigned j = t * 64 + lane;
+        k0[t] = nl0[j < nn0 ? j : nn0 - 1];
+        k1[t] = nl1[j < nn1 ? j : nn1 - 1];
+    }
+#pragma unroll
+    for (int t = 0; t < kFChunk; ++t) {
+        q0[t] = pos[k0[t]];
+        q1[t] = pos[k1[t]];
+    }
+    unsigned redo = 0;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const unsigned w = r ? w1 : w0, nn = r ? nn1 : nn0;
+        const PV pi = r ? pi1 : pi0;
+        if (positions_out != nullptr && lane == 0)
+            positions_out[w] = make_float4((float)pi.x, (float)pi.y, (float)pi.z, (float)scalar_as_int(pi.w));
+        float4 *row = STORE ? dest + (size_t)w * NN : nullptr;
+        float fx = 0.f, fy = 0.f, fz = 0.f, en = 0.f;
+        unsigned npos = 0, Q = 0;
+#pragma unroll
+        for (int t = 0; t < kFChunk; ++t) {
+            if ((unsigned)t * 64 >= nn) break; // wave-uniform
+            const unsigned j = t * 64 + lane;
+            const PV pk = r ? q1[t] : q0[t];
+            PT dx, dy, dz;
+            const PT rsq = pair_vector<PT>(pk, pi, box, dx, dy, dz);
+            const bool keep = (j < nn) && !(rsq > rmaxsq);
+            const unsigned long long m = __ballot(keep);
+            const unsigned q = Q + __popcll(m & ((1ull << lane) - 1ull));
+            Q += __popcll(m);
+            if (keep && q < NN) {
+                const float x = (float)dx, y = (float)dy, z = (float)dz;
+                if constexpr (STORE) row[q] = make_float4(x, y, z, (float)scalar_as_int(pk.w));
+                float e, ax, ay, az;
+                pair_eval<KIND>(x, y, z, p, e, ax, ay, az);
+                fx += ax;
+                fy += ay;
+                fz += az;
+                en += e;
+                npos += x > 0.f ? 1u : 0u;
+            }
+        }
+        const unsigned filled = Q < NN ? Q : NN;
+        if constexpr (STORE) {
+            const unsigned zero_end = counts_io != nullptr ? counts_io[w] : NN;
+            for (unsigned sl = filled + lane; sl < zero_end; sl += 64) row[sl] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (counts_io != nullptr && lane == 0) counts_io[w] = filled;
+        }
+        if (Q > NN) { // overflow (an error upstream): the generic routine reproduces the slot wrap
+            redo |= 1u << r;
+            continue;
+        }
+        fx = group_sum<64>(fx);
+        fy = group_sum<64>(fy);
+        fz = group_sum<64>(fz);
+        en = group_sum<64>(en);
+        if (check_count != nullptr) npos = group_sum_u<64>(npos);
+        if (lane == 0) {
+            if (out_f64)
+                ((double4 *)force)[w] = make_double4(fx, fy, fz, en);
+            else
+                ((float4 *)force)[w] = make_float4(fx, fy, fz, en);
+            if (check_count != nullptr && npos > *(volatile unsigned *)check_count) atomicMax(check_count, npos);
+        }
+    }
+#pragma unroll 1
+    for (unsigned r = 0; r < 2; ++r) // ONE code copy: a row's result must not depend on its place in the pair
+        if ((redo >> r) & 1u) {
+            if constexpr (STORE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            fused_row<KIND, false, STORE, PT>(w0 + r, lane, pos, N, NN, offset, box, n_neigh, nlist, head_list, rmaxsq,
+                                              force, nullptr, out_f64, p, check_count, positions_out, dest, counts_io);
+        }
+}
+
 template <int KIND, bool VIRIAL, typename PT>
 static int launch_fused(const void *pos, unsigned N, unsigned NN, unsigned offset, unsigned batch, const htf_box *hb,
                         const unsigned *n_neigh, const unsigned *nlist, const unsigned *head_list, double rmax,
@@ -167,6 +287,21 @@ static int launch_fused(const void *pos, unsigned N, unsigned NN, unsigned offse
                         float4 *positions_out, float4 *dest, unsigned *counts_io, hipStream_t s) {
     BoxT<PT> b = make_boxt<PT>(hb);
     PT rc = (PT)rmax;
+    if constexpr (!VIRIAL) {
+        static const bool one_row = getenv("HTF_FUSED_ONE_ROW") != nullptr; // A/B runs
+        if (!one_row) {
+            const unsigned grid2 = ((batch + 1) / 2 + 3) / 4;
+            if (dest != nullptr)
+                hipLaunchKernelGGL((fused_forces_rows2_kernel<KIND, true, PT>), dim3(grid2), dim3(256), 0, s,
+                                   (const typename Vec4<PT>::type *)pos, N, NN, offset, batch, b, n_neigh, nlist, head_list,
+                                   (PT)(rc * rc), force, out_f64, p, check_count, positions_out, dest, counts_io);
+            else
+                hipLaunchKernelGGL((fused_forces_rows2_kernel<KIND, false, PT>), dim3(grid2), dim3(256), 0, s,
+                                   (const typename Vec4<PT>::type *)pos, N, NN, offset, batch, b, n_neigh, nlist, head_list,
+                                   (PT)(rc * rc), force, out_f64, p, check_count, positions_out, dest, counts_io);
+            return check_launch("fused_forces_rows2_kernel");
+        }
+    }
     if (dest != nullptr)
         hipLaunchKernelGGL((fused_forces_kernel<KIND, VIRIAL, true, PT>), dim3((batch + 3) / 4), dim3(256), 0, s,
                            (const typename Vec4<PT>::type *)pos, N, NN, offset, batch, b, n_neigh, nlist, head_list,

@@ -45,7 +45,7 @@ def test_hot_kernels_use_no_scratch(tmp_path):
     assert len(meta) > 50
     hot = [n for n in meta if any(t in n for t in (
         "build_pair_vectors_kernel", "eval_pair_kernel", "eval_pair2_kernel", "train_pair_kernel",
-        "mlp_grad_mfma_kernel", "mlp_grad_kernel", "rdf_hist", "nve_step_kernel"))]
+        "mlp_grad_mfma_kernel", "mlp_grad_kernel", "rdf_hist", "nve_step_kernel", "fused_forces_rows2_kernel"))]
     hot += [n for n in meta if "fused_forces_kernel" in n and not n.startswith("_ZN3htf19fused_forces_kernelILi3ELb1Ed")]
     hot += [n for n in meta if "pair_mlp_kernel" in n and "Lb0EE" in n.split("pair_mlp_kernel")[1][:14]]  # fp32 images
     assert len(hot) > 40
