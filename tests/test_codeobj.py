@@ -46,7 +46,9 @@ def test_hot_kernels_use_no_scratch(tmp_path):
     hot = [n for n in meta if any(t in n for t in (
         "build_pair_vectors_kernel", "eval_pair_kernel", "eval_pair2_kernel", "train_pair_kernel",
         "mlp_grad_mfma_kernel", "mlp_grad_kernel", "rdf_hist", "nve_step_kernel", "fused_forces_rows2_kernel"))]
-    hot += [n for n in meta if "fused_forces_kernel" in n and not n.startswith("_ZN3htf19fused_forces_kernelILi3ELb1Ed")]
+    # (polynomial + virial + fp64 positions spills a few SGPRs: a rare combination, left alone)
+    hot += [n for n in meta if "fused_forces_kernel" in n
+            and not re.match(r"_ZN3htf19fused_forces_kernelILi3ELb1ELb[01]EdEE", n)]
     hot += [n for n in meta if "pair_mlp_kernel" in n and "Lb0EE" in n.split("pair_mlp_kernel")[1][:14]]  # fp32 images
     assert len(hot) > 40
     bad = {n: meta[n] for n in hot if meta[n]["private_segment_fixed_size"] or meta[n]["vgpr_spill_count"]}
