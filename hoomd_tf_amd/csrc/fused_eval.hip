@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void fused_forces_kernel(const typename Vec4<P
 // unlike the plain build, this kernel has plenty of) runs under the other row's memory latency.
 // Fast path for the common case (every row of the pair has 1..192 list entries and does not
 // overflow NN); anything else is redone by the generic single-row routine.
-template <int KIND, bool STORE, typename PT>
+template <int KIND, bool STORE, int R, typename PT>
 __global__ __launch_bounds__(256) void fused_forces_rows2_kernel(
     const typename Vec4<PT>::type *__restrict__ pos, unsigned N, unsigned NN, unsigned offset, unsigned batch,
     BoxT<PT> box, const unsigned *__restrict__ n_neigh, const unsigned *__restrict__ nlist,
@@ -187,58 +187,62 @@ __global__ __launch_bounds__(256) void fused_forces_rows2_kernel(
     const PotParams p = resolve_theta<KIND>(pin);
     const unsigned lane = threadIdx.x & 63u;
     const unsigned wv = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-    const unsigned w0 = 2 * wv, w1 = w0 + 1;
+    const unsigned w0 = R * wv;
     if (w0 >= batch) return;
-    const bool two = w1 < batch;
-    const unsigned i0 = w0 + offset, i1 = (two ? w1 : w0) + offset;
-    const unsigned nn0 = n_neigh[i0], nn1 = n_neigh[i1];
-    if (!two || nn0 == 0 || nn1 == 0 || nn0 > 64 * kFChunk || nn1 > 64 * kFChunk) {
-        fused_row<KIND, false, STORE, PT>(w0, lane, pos, N, NN, offset, box, n_neigh, nlist, head_list, rmaxsq, force,
-                                          nullptr, out_f64, p, check_count, positions_out, dest, counts_io);
-        if (two)
-            fused_row<KIND, false, STORE, PT>(w1, lane, pos, N, NN, offset, box, n_neigh, nlist, head_list, rmaxsq, force,
-                                              nullptr, out_f64, p, check_count, positions_out, dest, counts_io);
+    unsigned nn[R];
+    bool fast = w0 + R <= batch;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        nn[r] = n_neigh[(w0 + r < batch ? w0 + r : w0) + offset];
+        fast = fast && nn[r] != 0 && nn[r] <= 64 * kFChunk;
+    }
+    if (!fast) {
+#pragma unroll 1
+        for (unsigned r = 0; r < (unsigned)R && w0 + r < batch; ++r)
+            fused_row<KIND, false, STORE, PT>(w0 + r, lane, pos, N, NN, offset, box, n_neigh, nlist, head_list, rmaxsq,
+                                              force, nullptr, out_f64, p, check_count, positions_out, dest, counts_io);
         return;
     }
-    const unsigned *nl0 = nlist + head_list[i0], *nl1 = nlist + head_list[i1];
-    const PV pi0 = pos[i0], pi1 = pos[i1];
-    unsigned k0[kFChunk], k1[kFChunk];
-    PV q0[kFChunk], q1[kFChunk];
+    PV pi[R];
+    unsigned k[R][kFChunk];
+    PV q[R][kFChunk];
 #pragma unroll
-    for (int t = 0; t < kFChunk; ++t) {
-        const unsigned j = t * 64 + lane;
-        k0[t] = nl0[j < nn0 ? j : nn0 - 1];
-        k1[t] = nl1[j < nn1 ? j : nn1 - 1];
+    for (int r = 0; r < R; ++r) {
+        const unsigned *nl = nlist + head_list[w0 + r + offset];
+        pi[r] = pos[w0 + r + offset];
+#pragma unroll
+        for (int t = 0; t < kFChunk; ++t) {
+            const unsigned j = t * 64 + lane;
+            k[r][t] = nl[j < nn[r] ? j : nn[r] - 1];
+        }
     }
 #pragma unroll
-    for (int t = 0; t < kFChunk; ++t) {
-        q0[t] = pos[k0[t]];
-        q1[t] = pos[k1[t]];
-    }
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int t = 0; t < kFChunk; ++t) q[r][t] = pos[k[r][t]];
     unsigned redo = 0;
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const unsigned w = r ? w1 : w0, nn = r ? nn1 : nn0;
-        const PV pi = r ? pi1 : pi0;
+    for (int r = 0; r < R; ++r) {
+        const unsigned w = w0 + r;
         if (positions_out != nullptr && lane == 0)
-            positions_out[w] = make_float4((float)pi.x, (float)pi.y, (float)pi.z, (float)scalar_as_int(pi.w));
+            positions_out[w] = make_float4((float)pi[r].x, (float)pi[r].y, (float)pi[r].z, (float)scalar_as_int(pi[r].w));
         float4 *row = STORE ? dest + (size_t)w * NN : nullptr;
         float fx = 0.f, fy = 0.f, fz = 0.f, en = 0.f;
         unsigned npos = 0, Q = 0;
 #pragma unroll
         for (int t = 0; t < kFChunk; ++t) {
-            if ((unsigned)t * 64 >= nn) break; // wave-uniform
+            if ((unsigned)t * 64 >= nn[r]) break; // wave-uniform
             const unsigned j = t * 64 + lane;
-            const PV pk = r ? q1[t] : q0[t];
+            const PV pk = q[r][t];
             PT dx, dy, dz;
-            const PT rsq = pair_vector<PT>(pk, pi, box, dx, dy, dz);
-            const bool keep = (j < nn) && !(rsq > rmaxsq);
+            const PT rsq = pair_vector<PT>(pk, pi[r], box, dx, dy, dz);
+            const bool keep = (j < nn[r]) && !(rsq > rmaxsq);
             const unsigned long long m = __ballot(keep);
-            const unsigned q = Q + __popcll(m & ((1ull << lane) - 1ull));
+            const unsigned qq = Q + __popcll(m & ((1ull << lane) - 1ull));
             Q += __popcll(m);
-            if (keep && q < NN) {
+            if (keep && qq < NN) {
                 const float x = (float)dx, y = (float)dy, z = (float)dz;
-                if constexpr (STORE) row[q] = make_float4(x, y, z, (float)scalar_as_int(pk.w));
+                if constexpr (STORE) row[qq] = make_float4(x, y, z, (float)scalar_as_int(pk.w));
                 float e, ax, ay, az;
                 pair_eval<KIND>(x, y, z, p, e, ax, ay, az);
                 fx += ax;
@@ -272,7 +276,7 @@ __global__ __launch_bounds__(256) void fused_forces_rows2_kernel(
         }
     }
 #pragma unroll 1
-    for (unsigned r = 0; r < 2; ++r) // ONE code copy: a row's result must not depend on its place in the pair
+    for (unsigned r = 0; r < (unsigned)R; ++r) // ONE code copy: a row's result must not depend on its place in the group
         if ((redo >> r) & 1u) {
             if constexpr (STORE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             fused_row<KIND, false, STORE, PT>(w0 + r, lane, pos, N, NN, offset, box, n_neigh, nlist, head_list, rmaxsq,
@@ -288,19 +292,21 @@ static int launch_fused(const void *pos, unsigned N, unsigned NN, unsigned offse
     BoxT<PT> b = make_boxt<PT>(hb);
     PT rc = (PT)rmax;
     if constexpr (!VIRIAL) {
-        static const bool one_row = getenv("HTF_FUSED_ONE_ROW") != nullptr; // A/B runs
-        if (!one_row) {
-            const unsigned grid2 = ((batch + 1) / 2 + 3) / 4;
-            if (dest != nullptr)
-                hipLaunchKernelGGL((fused_forces_rows2_kernel<KIND, true, PT>), dim3(grid2), dim3(256), 0, s,
-                                   (const typename Vec4<PT>::type *)pos, N, NN, offset, batch, b, n_neigh, nlist, head_list,
-                                   (PT)(rc * rc), force, out_f64, p, check_count, positions_out, dest, counts_io);
-            else
-                hipLaunchKernelGGL((fused_forces_rows2_kernel<KIND, false, PT>), dim3(grid2), dim3(256), 0, s,
-                                   (const typename Vec4<PT>::type *)pos, N, NN, offset, batch, b, n_neigh, nlist, head_list,
-                                   (PT)(rc * rc), force, out_f64, p, check_count, positions_out, dest, counts_io);
+        static const char *rows_env = getenv("HTF_FUSED_ROWS"); // A/B runs: 1 | 2 | 4 rows per wave
+        const int rows = rows_env ? atoi(rows_env) : 2;
+#define HTF_ROWS_LAUNCH(ST, RR)                                                                                        \
+    hipLaunchKernelGGL((fused_forces_rows2_kernel<KIND, ST, RR, PT>), dim3(((batch + RR - 1) / RR + 3) / 4), dim3(256), 0, s, \
+                       (const typename Vec4<PT>::type *)pos, N, NN, offset, batch, b, n_neigh, nlist, head_list,       \
+                       (PT)(rc * rc), force, out_f64, p, check_count, positions_out, dest, counts_io)
+        if (rows == 2 || rows == 4) {
+            if (rows == 2) {
+                if (dest != nullptr) HTF_ROWS_LAUNCH(true, 2); else HTF_ROWS_LAUNCH(false, 2);
+            } else {
+                if (dest != nullptr) HTF_ROWS_LAUNCH(true, 4); else HTF_ROWS_LAUNCH(false, 4);
+            }
             return check_launch("fused_forces_rows2_kernel");
         }
+#undef HTF_ROWS_LAUNCH
     }
     if (dest != nullptr)
         hipLaunchKernelGGL((fused_forces_kernel<KIND, VIRIAL, true, PT>), dim3((batch + 3) / 4), dim3(256), 0, s,
