@@ -153,19 +153,16 @@ def run_eds(args, htf, standin, dev):
 
     refresh_ptrs()
 
-    def step(relax=False):
-        ts = state["ts"]
-        nl.compute(ts)
-        if nl.n_builds != ptr["nl"][3]:
-            refresh_ptrs()
-        t0 = mark() if state["time"] else None
+    def launch_all(stream, timed):
+        """One C4 step on `stream`: 6 C-ABI launches + one memset, no host synchronisation."""
+        t0 = mark() if timed else None
         check(lib.htf_build_pair_vectors(pv.data_ptr(), F32, sysm.pos.data_ptr(), F32, N, NN, 0, N, 0, C.byref(sysm.box),
                                          ptr["nl"][0], ptr["nl"][1], ptr["nl"][2], args.rcut, None, stream))
-        t1 = mark() if state["time"] else None
+        t1 = mark() if timed else None
         hist.zero_()
         check(lib.htf_eval_forces2(lj.handle, gauss.handle, pv.data_ptr(), F32, N, NN, sysm.force.data_ptr(),
                                    bias.data_ptr(), F32, partials.data_ptr(), 0.0, 3.5, 102, hist.data_ptr(), stream))
-        t2 = mark() if state["time"] else None
+        t2 = mark() if timed else None
         check(lib.htf_reduce_partials(partials.data_ptr(), npart, 1.0 / N, cv.data_ptr(), stream))
         if eds is not None:  # EDSLayer.__call__ + bias assembly, all on the device
             check(lib.htf_eds_update(eds.state.data_ptr(), cv.data_ptr(), eds.set_point, eds.period,
@@ -174,6 +171,16 @@ def run_eds(args, htf, standin, dev):
                                        cv.data_ptr(), F32, N, stream))
         # compute_rdf(nlist, [0, 3.5]) every step: histogram fused above, tail here
         check(lib.htf_rdf_finalize(hist.data_ptr(), 100, 0.0, 3.5, rdf_out.data_ptr(), rs_out.data_ptr(), stream))
+        if timed:
+            ev["build"].append((t0, t1))
+            ev["eval2"].append((t1, t2))
+
+    def step(relax=False):
+        ts = state["ts"]
+        nl.compute(ts)
+        if nl.n_builds != ptr["nl"][3]:
+            refresh_ptrs()
+        launch_all(stream, state["time"])
         state["rdf"] = rdf_out
         if relax:
             f3 = sysm.force[:, :3]
@@ -182,18 +189,23 @@ def run_eds(args, htf, standin, dev):
         if relax:
             v3 = sysm.vel[:, :3]
             v3.mul_(torch.sqrt(1.0 / ((v3 * v3).sum() / (3.0 * N))))
-        if state["time"]:
-            ev["build"].append((t0, t1))
-            ev["eval2"].append((t1, t2))
         state["ts"] = ts + 1
 
     for _ in range(args.equil):
         step(relax=True)
     cv_nat = float(cv)
     eds = htf.EDSLayer(1.02 * cv_nat, 25, 0.05, device=dev)
-    for _ in range(args.warmup):
-        step()
+    # kernel times from event-bracketed steps, wall time from un-instrumented ones: three event
+    # objects per step made the loop host-bound (0.62 instead of 0.44 ms/step).  A hipGraph replay
+    # of the step was tried as well: no gain, the loop is GPU-bound once the events are gone.
     state["time"] = True
+    for _ in range(max(args.warmup, 10)):
+        step()
+    state["time"] = False
+    torch.cuda.synchronize()
+    us = {k: 1e3 * sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in ev.items()}
+    for _ in range(5):
+        step()
     b0 = nl.n_builds
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -201,7 +213,6 @@ def run_eds(args, htf, standin, dev):
         step()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    us = {k: 1e3 * sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in ev.items()}
     assert bool(torch.isfinite(sysm.force).all())
     eval_b = N * NN * 16 + 2 * N * 16
     build_b = N * 8 + int(nl.n_neigh.long().sum().item()) * 4 + N * 16 + N * NN * 16
