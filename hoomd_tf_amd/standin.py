@@ -201,7 +201,12 @@ class CellNlist:
         return float(self._disp.item()) > (self.r_buff / 2.0) ** 2
 
     def compute(self, timestep):
-        """NeighborList::compute(timestep): rebuild if the distance check trips."""
+        """NeighborList::compute(timestep): rebuild if the distance check trips.  Under domain
+        decomposition a second compute sharing this list in the same step finds the step's
+        check / halo already done (HOOMD's NeighborList caches per timestep too)."""
+        if self.domain is not None and self._ref is not None and getattr(self, "_step_done", None) == timestep:
+            return
+        self._step_done = timestep
         if self._ref is None or (timestep % self.check_period == 0 and self.needs_update()):
             self.build()
         elif self.domain is not None:

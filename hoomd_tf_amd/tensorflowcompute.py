@@ -186,6 +186,11 @@ class tfcompute:
         if self._nlist is not None:
             self._nlist.compute(timestep)  # m_nlist->compute(timestep), .cc:162-163
         domain = getattr(self._nlist, "domain", None)
+        if self.force.shape[0] != self.system.N:
+            # MaxParticleNumberChange -> reallocate (.cc:88): particles migrated between ranks
+            s = self.system
+            self.force = torch.zeros((s.N, 4), dtype=s.dtype, device=s.device)
+            self.virial = torch.zeros(6 * s.N, dtype=s.dtype, device=s.device)
         if self._plan is not None and self.model._plan is self._plan:
             self._calls += 1
             # interior rows while the ghost halo is in flight, boundary rows after it

@@ -112,6 +112,95 @@ def _worker(rank, world, port, q):
         q.put((rank, traceback.format_exc()))
 
 
+def _train_worker(rank, world, port, q):
+    """tfcompute-driven online force matching under slabs: LJ drives the MD (traced one-kernel
+    path, halo overlapped), a pair-MLP is trained on it every step; the [loss, gradient, count]
+    all-reduce must keep every rank's weights bit-identical and equal to single-domain training."""
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        sys.path.insert(0, ROOT)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        if world > 1:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        import hoomd_tf_amd as htf
+        from hoomd_tf_amd import standin
+        from hoomd_tf_amd.domain import SlabDomain
+        import build_examples
+
+        dev = torch.device("cuda:0")
+        rcut, NN = 2.5, 64
+        cells = (12, 5, 5)
+        a = (4.0 / 0.8442) ** (1.0 / 3.0)
+        base = np.array([[0, 0, 0], [.5, .5, 0], [.5, 0, .5], [0, .5, .5]])
+        grid = np.stack(np.meshgrid(*[np.arange(c) for c in cells], indexing="ij"), -1).reshape(-1, 3)
+        pos = ((grid[:, None, :] + base[None]) * a).reshape(-1, 3)
+        L = np.array(cells, dtype=np.float64) * a
+        pos = pos - L / 2
+        rng = np.random.default_rng(6)
+        pos += 0.04 * a * rng.standard_normal(pos.shape)
+        pos -= np.round(pos / L) * L
+        Ng = len(pos)
+        vel = np.zeros((Ng, 4))
+        vel[:, :3] = 0.8 * rng.standard_normal((Ng, 3))
+        vel[:, 3] = 1.0
+        bounds = -L[0] / 2 + np.linspace(0, 1, world + 1) * L[0]
+        mine = (pos[:, 0] >= bounds[rank]) & (pos[:, 0] < bounds[rank + 1])
+        system = standin.System(pos[mine], L, types=np.arange(Ng)[mine], dtype=torch.float32, device=dev)
+        system.vel = torch.from_numpy(vel[mine]).to(torch.float32).to(dev)
+        sim = standin.Simulation(system)
+        sim.integrate_nve(0.002)
+        nlist = sim.nlist_cell(check_period=1)
+        if world > 1:
+            nlist.domain = SlabDomain(system, rank, world, r_ghost=rcut + nlist.r_buff)
+        lj = htf.tfcompute(build_examples.LJModel(NN))
+        lj.attach(nlist, r_cut=rcut)
+        model = build_examples.PairMLPModel(NN, output_forces=False, activation='tanh', seed=9)
+        model.compile(htf.optimizers.Adam(0.003), loss='MeanSquaredError')
+        tfc = htf.tfcompute(model)
+        tfc.attach(nlist, train=True, r_cut=rcut)
+        tfc.set_reference_forces(lj)
+        sim.run(12)
+        torch.cuda.synchronize()
+        w = np.concatenate([x.ravel() for x in model.mlp.get_weights()])
+        loss = float(tfc._opt_state[20])
+        assert np.all(np.isfinite(w)) and np.isfinite(loss)
+        if world > 1:
+            both = [torch.zeros(len(w), dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(both, torch.from_numpy(w.astype(np.float64)))
+            for o in both[1:]:
+                assert torch.equal(o, both[0]), "ranks hold different weights after training"
+            n_all = torch.tensor([system.N])
+            dist.all_reduce(n_all)
+            assert int(n_all) == Ng
+            dist.barrier()
+            dist.destroy_process_group()
+        q.put((rank, world, w, loss))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, world, None, traceback.format_exc()))
+
+
+def test_training_under_slabs_matches_single_domain(htf, cuda):
+    ctx = mp.get_context("spawn")
+    out = {}
+    for world in (1, 2):
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_train_worker, args=(r, world, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = [q.get(timeout=600) for _ in procs]
+        for p in procs:
+            p.join(timeout=60)
+        for rank, wd, w, loss in res:
+            assert w is not None, "rank %d of %d failed:\n%s" % (rank, wd, loss)
+        out[world] = res[0]
+    w1, w2 = out[1][2], out[2][2]
+    assert np.abs(w1).max() > 0 and np.abs(w2 - w1).max() < 2e-4 * np.abs(w1).max(), np.abs(w2 - w1).max()
+    assert abs(out[2][3] - out[1][3]) < 2e-3 * abs(out[1][3])
+
+
 def test_two_slabs_on_one_gpu(htf, cuda):
     world = 2
     ctx = mp.get_context("spawn")
