@@ -362,6 +362,24 @@ extern "C" int htfs_max_displacement2(const void *d_pos, const void *d_ref, int 
     return check_launch("max_disp_kernel");
 }
 
+namespace htf {
+template <typename V>
+__global__ void gather4_kernel(V *__restrict__ dest, const V *__restrict__ src, const int *__restrict__ order, unsigned n) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dest[i] = src[order[i]];
+}
+} // namespace htf
+
+extern "C" int htfs_gather4(void *d_dest, const void *d_src, const int *d_order, int dtype, unsigned n, htf_stream stream) {
+    HTF_REQUIRE(d_dest && d_src && d_order, "htfs_gather4: null pointer");
+    if (n == 0) return HTF_OK;
+    if (dtype == HTF_F32)
+        hipLaunchKernelGGL((gather4_kernel<float4>), dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (float4 *)d_dest, (const float4 *)d_src, d_order, n);
+    else
+        hipLaunchKernelGGL((gather4_kernel<double4>), dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (double4 *)d_dest, (const double4 *)d_src, d_order, n);
+    return check_launch("gather4_kernel");
+}
+
 extern "C" int htfs_cell_index(const void *d_pos, int dtype, unsigned Ntot, const htf_box *box, const int *ncell3,
                                unsigned *d_cell_of, htf_stream stream) {
     HTF_REQUIRE(d_pos && box && ncell3 && d_cell_of, "htfs_cell_index: null pointer");

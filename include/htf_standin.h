@@ -37,6 +37,9 @@ HTF_API int htfs_build_nlist(const void *d_pos, const void *d_pos_sorted, int dt
                              const unsigned *d_cell_start, unsigned pitch, int type_split, unsigned *d_n_neigh,
                              unsigned *d_head_list, unsigned *d_nlist, unsigned *d_max_neigh, htf_stream stream);
 
+/* dest[i] = src[order[i]] for Scalar4 arrays: the cell-sorted position copy */
+HTF_API int htfs_gather4(void *d_dest, const void *d_src, const int *d_order, int dtype, unsigned n, htf_stream stream);
+
 /* cell index of every particle (x fastest): d_cell_of[i] */
 HTF_API int htfs_cell_index(const void *d_pos, int dtype, unsigned Ntot, const htf_box *box,
                             const int *ncell3, unsigned *d_cell_of, htf_stream stream);
