@@ -59,7 +59,7 @@ __device__ __forceinline__ unsigned fused_sweep(FusedAcc &acc, const typename Ve
             PT rsq = pair_vector<PT>(pk[t], pi, box, dx, dy, dz);
             bool keep = (j < nn) && !(rsq > rmaxsq);
             unsigned long long m = __ballot(keep);
-            unsigned q = Q + __popcll(m & ((1ull << lane) - 1ull));
+            unsigned q = Q + ballot_rank(m);
             Q += __popcll(m);
             if constexpr (STORE != 0) {
                 // the tensor row, as build_pair_vectors_kernel writes it (fp32 wire, type as a float)
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void fused_forces_rows2_kernel(
             const PT rsq = pair_vector<PT>(pk, pi[r], box, dx, dy, dz);
             const bool keep = (j < nn[r]) && !(rsq > rmaxsq);
             const unsigned long long m = __ballot(keep);
-            const unsigned qq = Q + __popcll(m & ((1ull << lane) - 1ull));
+            const unsigned qq = Q + ballot_rank(m);
             Q += __popcll(m);
             if (keep && qq < NN) {
                 const float x = (float)dx, y = (float)dy, z = (float)dz;

@@ -65,6 +65,12 @@ __device__ __forceinline__ float group_sum(float v) {
     return v;
 }
 
+// number of set bits of a wave ballot below this lane: v_mbcnt_lo/hi, two instructions
+// (the portable popcount(m & ((1 << lane) - 1)) costs a 64-bit shift, mask and two bit counts)
+__device__ __forceinline__ unsigned ballot_rank(unsigned long long m) {
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+
 template <int G>
 __device__ __forceinline__ unsigned group_sum_u(unsigned v) {
 #pragma unroll

@@ -10,6 +10,10 @@ namespace htf {
 // Worst amplification is s^13 in the LJ force: 13 ulp ~ 1.5e-6 relative, inside the 2e-5
 // parity tolerance (measured: tests/test_gpu_parity.py ratios in gpurun_out/parity_stats.json).
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+// v_sqrt_f32 (1 ulp).  sqrtf() is correctly rounded under hipcc's defaults: 16 instructions (scale,
+// two fma fix-ups, class checks) where the evaluators need one; PMC showed the fused kernel
+// VALU-issue-bound (48 M wave-instructions = 78 us of its 95 us), so this matters.
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 
 // Trainable potentials keep theta on the device; every kernel resolves it once at entry
 // (wave-uniform scalar loads) so an optimizer step is visible to the next launch.
@@ -48,9 +52,10 @@ __device__ __forceinline__ RinvFwd rinv_fwd(float x, float y, float z) {
     f.tx = x + kNormDelta;
     f.ty = y + kNormDelta;
     f.tz = z + kNormDelta;
-    f.rp = sqrtf(f.tx * f.tx + f.ty * f.ty + f.tz * f.tz);
+    f.rp = fast_sqrt(f.tx * f.tx + f.ty * f.ty + f.tz * f.tz);
     f.cond = f.rp > kRinvDelta;
-    f.s = f.cond ? fast_rcp(f.rp + kRinvDelta) : 0.0f;
+    const float sr = fast_rcp(f.rp + kRinvDelta); // unconditional (argument > 0): a select, not a branch
+    f.s = f.cond ? sr : 0.0f;
     return f;
 }
 
@@ -74,9 +79,10 @@ __device__ __forceinline__ void pair_eval(float x, float y, float z, const PotPa
         // the padded slots' r^6 ~ 2.7e-41 to zero, i.e. q = 0 there: same as the r > 3e-6 mask),
         // e = w0 * 4 (q^2 - q) / 2,  de/dr = 2 w0 (2q - 1) (-6 q / r),  nlist_forces = 2 de/dr t / r
         const float tx = x + kNormDelta, ty = y + kNormDelta, tz = z + kNormDelta;
-        const float r = sqrtf(tx * tx + ty * ty + tz * tz);
+        const float r = fast_sqrt(tx * tx + ty * ty + tz * tz);
         const bool m = r > kRinvDelta;
-        const float ri = m ? fast_rcp(r) : 0.0f;
+        const float rr = fast_rcp(r);
+        const float ri = m ? rr : 0.0f;
         const float a = p.lj_w1 * ri, a2 = a * a;
         const float q = a2 * a2 * a2;
         e = 2.0f * p.lj_w0 * (q * q - q);
@@ -90,7 +96,7 @@ __device__ __forceinline__ void pair_eval(float x, float y, float z, const PotPa
         // phi = exp(-(r - r0)^2 / gap) (layers.py:46-49), masked with the nlist_rinv criterion.
         // nlist_forces = 2 * c * dphi/dr * t / r,  dphi/dr = -2 (r - r0) / gap * phi
         const float tx = x + kNormDelta, ty = y + kNormDelta, tz = z + kNormDelta;
-        const float r = sqrtf(tx * tx + ty * ty + tz * tz);
+        const float r = fast_sqrt(tx * tx + ty * ty + tz * tz);
         const bool m = r > kRinvDelta;
         const float d = r - p.gauss_r0;
         const float phi = m ? __expf(-(d * d) * p.gauss_ginv) : 0.0f;
@@ -162,9 +168,10 @@ __device__ __forceinline__ void pair_eval_grad(float x, float y, float z, const 
     for (int k = 0; k < P; ++k) dd[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     if constexpr (KIND == HTF_POT_LJ_PARAM) {
         const float tx = x + kNormDelta, ty = y + kNormDelta, tz = z + kNormDelta;
-        const float r = sqrtf(tx * tx + ty * ty + tz * tz);
+        const float r = fast_sqrt(tx * tx + ty * ty + tz * tz);
         const bool m = r > kRinvDelta;
-        const float ri = m ? fast_rcp(r) : 0.0f;
+        const float rr = fast_rcp(r);
+        const float ri = m ? rr : 0.0f;
         const float a = p.lj_w1 * ri, a2 = a * a;
         const float q = a2 * a2 * a2;
         const float w0 = p.lj_w0, w1 = p.lj_w1;

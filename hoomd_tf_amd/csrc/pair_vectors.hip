@@ -73,7 +73,7 @@ __device__ __forceinline__ unsigned sweep(typename Vec4<DT>::type *__restrict__ 
             PT rsq = dx * dx + dy * dy + dz * dz;
             bool keep = (j < nn) && !(rsq > rmaxsq);
             unsigned long long m = __ballot(keep);
-            unsigned q = Q + __popcll(m & ((1ull << lane) - 1ull));
+            unsigned q = Q + ballot_rank(m);
             Q += __popcll(m);
             DV out;
             out.x = (DT)dx; out.y = (DT)dy; out.z = (DT)dz;
