@@ -478,7 +478,7 @@ def main():
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_lj_pmc_hbm.json")))
             key = {"build_pair_vectors": "void htf::build_pair_vectors_kernel<float, float>",
                    "eval_forces": "void htf::eval_pair_kernel<1, 16, false, float>",
-                   "build_eval_forces": "void htf::fused_forces_kernel<1, false, true, float>"}[dom]
+                   "build_eval_forces": "void htf::fused_forces_rows2_kernel<1, true, 2, float>"}[dom]
             rd, wr = pmc["FETCH_SIZE"][key]["avg_KiB"], pmc["WRITE_SIZE"][key]["avg_KiB"]
             # gfx950: FETCH_SIZE counts half of a wide (16 B/lane) coalesced read stream; the build
             # kernel's reads are 4-B index loads + 16-B gathers, for which the counter is uncalibrated
