@@ -30,10 +30,7 @@ struct MlpDims {
 
 template <bool TANH>
 __device__ __forceinline__ float act_val(float z) {
-    if constexpr (!TANH) return z;
-    float e = __expf(-2.0f * fabsf(z));
-    float t = (1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e);
-    return copysignf(t, z);
+    return act_fwd<TANH>(z);
 }
 
 __device__ __forceinline__ float bcast(float v, int lane) {
