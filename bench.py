@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--equil", type=int, default=300, help="untimed relaxation steps (force cap + velocity rescale)")
     ap.add_argument("--sort", action="store_true", help="enable the stand-in's particle sorter (HOOMD SFCPack analogue; measured: no kernel gain)")
     ap.add_argument("--no-fused", action="store_true", help="skip the extra variants (two-kernel dataflow, tensor-less fused mode)")
+    ap.add_argument("--one-kernel", action="store_true",
+                    help="eds workload: the whole C4 sweep as one kernel (htf_build_eval_forces2); measured no faster "
+                         "than build + eval2 (VALU-bound), so the two kernels stay the default there")
     ap.add_argument("--two-kernel", action="store_true",
                     help="headline run with separate build and evaluator kernels (htf_config.fused = 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -173,17 +176,39 @@ def run_eds(args, htf, standin, dev):
 
     refresh_ptrs()
 
+    npart_f = htf.ops.num_partials_fused(N)
+    partials_f = torch.empty(npart_f, dtype=torch.float32, device=dev)
+    ev["fused2"] = []
+
     def launch_all(stream, timed):
-        """One C4 step on `stream`: 6 C-ABI launches + one memset, no host synchronisation."""
-        t0 = mark() if timed else None
-        check(lib.htf_build_pair_vectors(pv.data_ptr(), F32, sysm.pos.data_ptr(), F32, N, NN, 0, N, 0, C.byref(sysm.box),
-                                         ptr["nl"][0], ptr["nl"][1], ptr["nl"][2], args.rcut, None, stream))
-        t1 = mark() if timed else None
+        """One C4 step on `stream`: a handful of C-ABI launches + one memset, no host synchronisation.
+        Default: the build kernel, then htf_eval_forces2 re-reading the tensor.  --one-kernel: the
+        whole sweep as ONE kernel (htf_build_eval_forces2 writes the tensor and evaluates both
+        potentials, the CV partials and the RDF histogram from registers) -- 369 us against
+        190 + 169 us: with two potentials, an exp and the histogram per candidate the fused form
+        is VALU-bound, so here fusion buys nothing."""
         hist.zero_()
-        check(lib.htf_eval_forces2(lj.handle, gauss.handle, pv.data_ptr(), F32, N, NN, sysm.force.data_ptr(),
-                                   bias.data_ptr(), F32, partials.data_ptr(), 0.0, 3.5, 102, hist.data_ptr(), stream))
-        t2 = mark() if timed else None
-        check(lib.htf_reduce_partials(partials.data_ptr(), npart, 1.0 / N, cv.data_ptr(), stream))
+        t0 = mark() if timed else None
+        if args.one_kernel:
+            check(lib.htf_build_eval_forces2(lj.handle, gauss.handle, pv.data_ptr(), sysm.pos.data_ptr(), F32, N, NN, 0, N,
+                                             C.byref(sysm.box), ptr["nl"][0], ptr["nl"][1], ptr["nl"][2], args.rcut,
+                                             sysm.force.data_ptr(), bias.data_ptr(), F32, partials_f.data_ptr(),
+                                             0.0, 3.5, 102, hist.data_ptr(), stream))
+            t2 = mark() if timed else None
+            if timed:
+                ev["fused2"].append((t0, t2))
+            check(lib.htf_reduce_partials(partials_f.data_ptr(), npart_f, 1.0 / N, cv.data_ptr(), stream))
+        else:
+            check(lib.htf_build_pair_vectors(pv.data_ptr(), F32, sysm.pos.data_ptr(), F32, N, NN, 0, N, 0, C.byref(sysm.box),
+                                             ptr["nl"][0], ptr["nl"][1], ptr["nl"][2], args.rcut, None, stream))
+            t1 = mark() if timed else None
+            check(lib.htf_eval_forces2(lj.handle, gauss.handle, pv.data_ptr(), F32, N, NN, sysm.force.data_ptr(),
+                                       bias.data_ptr(), F32, partials.data_ptr(), 0.0, 3.5, 102, hist.data_ptr(), stream))
+            t2 = mark() if timed else None
+            if timed:
+                ev["build"].append((t0, t1))
+                ev["eval2"].append((t1, t2))
+            check(lib.htf_reduce_partials(partials.data_ptr(), npart, 1.0 / N, cv.data_ptr(), stream))
         if eds is not None:  # EDSLayer.__call__ + bias assembly, all on the device
             check(lib.htf_eds_update(eds.state.data_ptr(), cv.data_ptr(), eds.set_point, eds.period,
                                      eds.learning_rate, eds.cv_scale, stream))
@@ -191,9 +216,6 @@ def run_eds(args, htf, standin, dev):
                                        cv.data_ptr(), F32, N, stream))
         # compute_rdf(nlist, [0, 3.5]) every step: histogram fused above, tail here
         check(lib.htf_rdf_finalize(hist.data_ptr(), 100, 0.0, 3.5, rdf_out.data_ptr(), rs_out.data_ptr(), stream))
-        if timed:
-            ev["build"].append((t0, t1))
-            ev["eval2"].append((t1, t2))
 
     def step(relax=False):
         ts = state["ts"]
@@ -223,7 +245,7 @@ def run_eds(args, htf, standin, dev):
         step()
     state["time"] = False
     torch.cuda.synchronize()
-    us = {k: 1e3 * sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in ev.items()}
+    us = {k: 1e3 * sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in ev.items() if v}
     for _ in range(5):
         step()
     b0 = nl.n_builds
@@ -237,8 +259,15 @@ def run_eds(args, htf, standin, dev):
     eval_b = N * NN * 16 + 2 * N * 16
     build_b = N * 8 + int(nl.n_neigh.long().sum().item()) * 4 + N * 16 + N * NN * 16
     dom = max(us, key=us.get)
-    dom_b = {"build": build_b, "eval2": eval_b}[dom]
+    # the one-kernel sweep is priced against its own compulsory bytes: the build's + the two force writes
+    fused_b = build_b + 2 * N * 16
+    dom_b = {"build": build_b, "eval2": eval_b, "fused2": fused_b}[dom]
     ach = dom_b / (us[dom] * 1e-6) / 1e9
+    names = {"build": ("build_pair_vectors", build_b), "eval2": ("eval_forces2(lj+gauss+rdf)", eval_b),
+             "fused2": ("build_eval_forces2(tensor + lj + gauss + cv + rdf)", fused_b)}
+    kern = {names[k][0]: {"avg_us": v, "algorithmic_bytes": names[k][1], "GBps": names[k][1] / v / 1e3} for k, v in us.items()}
+    if "fused2" in us:
+        kern[names["fused2"][0]]["contract_GBps"] = (build_b + eval_b) / us["fused2"] / 1e3
     out = {
         "metric": "MD steps/sec (262144-particle EDS-on-RDF-CV domain steps, NN=128) + achieved HBM GB/s",
         "value": args.steps / elapsed, "unit": "steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -251,9 +280,8 @@ def run_eds(args, htf, standin, dev):
                    "nlist_rebuilds_in_timed_region": nl.n_builds - b0},
         "cv": float(cv), "alpha": float(eds.state[2]), "energy_per_particle": float(sysm.force[:, 3].double().sum()) / N,
         "rdf_peak": float(state["rdf"].max()),
-        "kernels": {"build_pair_vectors": {"avg_us": us["build"], "algorithmic_bytes": build_b, "GBps": build_b / us["build"] / 1e3},
-                    "eval_forces2(lj+gauss+rdf)": {"avg_us": us["eval2"], "algorithmic_bytes": eval_b, "GBps": eval_b / us["eval2"] / 1e3}},
-        "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "kernels": kern,
+        "roofline": {"bound": "hbm", "kernel": names[dom][0], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": ach / HBM_PEAK_GBS, "traffic": None},
         "cpu_baseline": None,
     }

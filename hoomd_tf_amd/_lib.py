@@ -85,6 +85,9 @@ PROTOTYPES = {
     "htf_fused_forces": (_i, [_vp, _vp, _i, _u, _u, _u, _u, C.POINTER(Box), _vp, _vp, _vp, _d, _vp, _i, _vp, _vp, _vp]),
     "htf_build_eval_forces": (_i, [_vp, _vp, _vp, _i, _u, _u, _u, _u, C.POINTER(Box), _vp, _vp, _vp, _d, _vp, _i, _vp, _vp, _vp]),
     "htf_eval_forces2": (_i, [_vp, _vp, _vp, _i, _u, _u, _vp, _vp, _i, _vp, C.c_float, C.c_float, _u, _vp, _vp]),
+    "htf_build_eval_forces2": (_i, [_vp, _vp, _vp, _vp, _i, _u, _u, _u, _u, C.POINTER(Box), _vp, _vp, _vp, _d, _vp, _vp, _i, _vp,
+                                    C.c_float, C.c_float, _u, _vp, _vp]),
+    "htf_build_eval2_num_partials": (_u, [_u]),
     "htf_eval2_num_partials": (_u, [_u, _u]),
     "htf_reduce_partials": (_i, [_vp, _u, C.c_float, _vp, _vp]),
     "htf_bias_combine": (_i, [_vp, _vp, _vp, _vp, _i, _u, _vp]),

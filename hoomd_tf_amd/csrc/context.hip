@@ -275,6 +275,22 @@ extern "C" int htf_eval_forces2(const htf_potential *potA, const htf_potential *
 
 extern "C" unsigned htf_eval2_num_partials(unsigned B, unsigned NN) { return htf::eval_pair2_num_partials(B, NN); }
 
+extern "C" int htf_build_eval_forces2(const htf_potential *potA, const htf_potential *potB, void *d_dest, const void *d_pos,
+                                      int pos_dtype, unsigned N, unsigned NN, unsigned offset, unsigned batch_size,
+                                      const htf_box *box, const unsigned *d_n_neigh, const unsigned *d_nlist,
+                                      const unsigned *d_head_list, double rmax, void *d_forceA, void *d_forceB,
+                                      int force_dtype, float *d_partials, float rdf_r0, float rdf_r1,
+                                      unsigned rdf_nbins_total, unsigned *d_rdf_hist, htf_stream stream) {
+    using namespace htf;
+    HTF_REQUIRE(potA && potB, "htf_build_eval_forces2: no potential");
+    HTF_REQUIRE(force_dtype == HTF_F32 || force_dtype == HTF_F64, "htf_build_eval_forces2: bad force dtype %d", force_dtype);
+    return fused_forces2_impl(potA->pp, potB->pp, d_pos, pos_dtype, N, NN, offset, batch_size, box, d_n_neigh, d_nlist,
+                              d_head_list, rmax, d_forceA, d_forceB, force_dtype, d_partials, rdf_r0, rdf_r1,
+                              rdf_nbins_total, d_rdf_hist, (float4 *)d_dest, nullptr, (hipStream_t)stream);
+}
+
+extern "C" unsigned htf_build_eval2_num_partials(unsigned batch_size) { return htf::fused_forces2_num_partials(batch_size); }
+
 // ------------------------------------------------------------------------------ context
 static void ctx_free(htf_ctx *c) {
     if (c->nlist) (void)hipFree(c->nlist);

@@ -331,6 +331,232 @@ static int launch_fused_k(const void *pos, int pos_dtype, unsigned N, unsigned N
 #undef HTF_FUSED
 }
 
+// ---------------------------------------------------------------------------- config C4 in ONE kernel
+// htf_build_pair_vectors + htf_eval_forces2 fused: base potential A, Gaussian CV channel B,
+// the per-block CV partial sums and the compute_rdf histogram, all from the pair vectors while
+// they are in registers; the tensor is written too when `dest` is given (bit-identical).
+// Rows with <= 192 list entries keep their pair vectors in registers between the counting pass
+// and the evaluating pass; longer rows re-gather.  Overflow (Q > NN, an error upstream) needs no
+// replay here: only the NN survivors q >= Q - NN are stored / evaluated, each into its own slot
+// q % NN.  Persistent blocks: the LDS histogram is flushed once per block.
+constexpr unsigned kRdfMaxBins2 = 1024;
+
+struct Rdf2 {
+    float r0, r1;
+    unsigned nb;
+    unsigned *hist;
+};
+
+template <int KA, bool STORE, typename PT>
+__global__ __launch_bounds__(256) void fused_forces2_kernel(
+    const typename Vec4<PT>::type *__restrict__ pos, unsigned N, unsigned NN, unsigned offset, unsigned batch,
+    BoxT<PT> box, const unsigned *__restrict__ n_neigh, const unsigned *__restrict__ nlist,
+    const unsigned *__restrict__ head_list, PT rmaxsq, void *__restrict__ forceA, void *__restrict__ forceB,
+    int out_f64, PotParams pa_in, PotParams pb, float *__restrict__ partials, Rdf2 rdf,
+    float4 *__restrict__ dest, unsigned *__restrict__ counts_io) {
+    using PV = typename Vec4<PT>::type;
+    const PotParams pa = resolve_theta<KA>(pa_in);
+    __shared__ float s_part[4];
+    __shared__ unsigned s_hist[kRdfMaxBins2];
+    const bool do_rdf = rdf.hist != nullptr;
+    if (do_rdf) {
+        for (unsigned i = threadIdx.x; i < rdf.nb; i += blockDim.x) s_hist[i] = 0;
+        __syncthreads();
+    }
+    const unsigned lane = threadIdx.x & 63u, wb = threadIdx.x >> 6;
+    const float rdf_scale = do_rdf ? (float)rdf.nb / (rdf.r1 - rdf.r0) : 0.f;
+    // bin of a zero pair vector (the padded slots of the tensor are part of compute_rdf's input)
+    int pad_bin = 0;
+    if (do_rdf) {
+        const float fi = floorf((float)rdf.nb * ((0.f - rdf.r0) / (rdf.r1 - rdf.r0)));
+        pad_bin = fi < 0.f ? 0 : (fi > (float)(rdf.nb - 1) ? (int)(rdf.nb - 1) : (int)fi);
+    }
+    unsigned n_lo = 0, n_hi = 0;
+    float cv_wave = 0.f; // sum of the B energy column over this wave's rows, in row order
+
+    auto one = [&](const PV &pk, const PV &pi, bool keep, unsigned q, unsigned lo, unsigned Q, float4 *row, float &ax,
+                   float &ay, float &az, float &ae, float &bx, float &by, float &bz, float &be) {
+        PT dx, dy, dz;
+        (void)pair_vector<PT>(pk, pi, box, dx, dy, dz);
+        if (keep && q >= lo) {
+            const float x = (float)dx, y = (float)dy, z = (float)dz;
+            if constexpr (STORE) row[Q > NN ? q % NN : q] = make_float4(x, y, z, (float)scalar_as_int(pk.w));
+            float e, fx, fy, fz;
+            pair_eval<KA>(x, y, z, pa, e, fx, fy, fz);
+            ax += fx; ay += fy; az += fz; ae += e;
+            pair_eval<HTF_POT_GAUSS>(x, y, z, pb, e, fx, fy, fz);
+            bx += fx; by += fy; bz += fz; be += e;
+            if (do_rdf) {
+                const float r = sqrtf(x * x + y * y + z * z);
+                const float fi = floorf((r - rdf.r0) * rdf_scale);
+                const int idx = fi < 0.f ? 0 : (fi > (float)(rdf.nb - 1) ? (int)(rdf.nb - 1) : (int)fi);
+                if (idx == 0) ++n_lo;
+                else if (idx == (int)rdf.nb - 1) ++n_hi;
+                else atomicAdd(&s_hist[idx], 1u);
+            }
+        }
+    };
+
+    const unsigned ngroups = (batch + 3) / 4;
+#pragma unroll 1
+    for (unsigned grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const unsigned w = grp * 4 + wb;
+        if (w >= batch) continue; // wave-uniform
+        const unsigned idx = w + offset;
+        const unsigned nn = n_neigh[idx];
+        const unsigned *nl = nlist + head_list[idx];
+        const PV pi = pos[idx];
+        float4 *row = STORE ? dest + (size_t)w * NN : nullptr;
+        float ax = 0.f, ay = 0.f, az = 0.f, ae = 0.f, bx = 0.f, by = 0.f, bz = 0.f, be = 0.f;
+        unsigned Q = 0;
+        if (nn <= 64 * kFChunk) {
+            // pair vectors stay in registers between the two passes
+            unsigned k[kFChunk];
+            PV pk[kFChunk];
+            unsigned q[kFChunk];
+            bool keep[kFChunk];
+#pragma unroll
+            for (int t = 0; t < kFChunk; ++t) {
+                const unsigned j = t * 64 + lane;
+                k[t] = nn ? nl[j < nn ? j : nn - 1] : 0u;
+            }
+#pragma unroll
+            for (int t = 0; t < kFChunk; ++t) pk[t] = pos[k[t]];
+#pragma unroll
+            for (int t = 0; t < kFChunk; ++t) {
+                const unsigned j = t * 64 + lane;
+                PT dx, dy, dz;
+                const PT rsq = pair_vector<PT>(pk[t], pi, box, dx, dy, dz);
+                keep[t] = (j < nn) && !(rsq > rmaxsq);
+                const unsigned long long m = __ballot(keep[t]);
+                q[t] = Q + ballot_rank(m);
+                Q += __popcll(m);
+            }
+            const unsigned lo = Q > NN ? Q - NN : 0u;
+#pragma unroll
+            for (int t = 0; t < kFChunk; ++t) {
+                if ((unsigned)t * 64 >= nn) break; // wave-uniform
+                one(pk[t], pi, keep[t], q[t], lo, Q, row, ax, ay, az, ae, bx, by, bz, be);
+            }
+        } else {
+            for (unsigned base = 0; base < nn; base += 64) { // counting pass
+                const unsigned j = base + lane;
+                const PV pk = pos[nl[j < nn ? j : nn - 1]];
+                PT dx, dy, dz;
+                const PT rsq = pair_vector<PT>(pk, pi, box, dx, dy, dz);
+                Q += __popcll(__ballot((j < nn) && !(rsq > rmaxsq)));
+            }
+            const unsigned lo = Q > NN ? Q - NN : 0u;
+            unsigned Q2 = 0;
+            for (unsigned base = 0; base < nn; base += 64) { // evaluating pass
+                const unsigned j = base + lane;
+                const PV pk = pos[nl[j < nn ? j : nn - 1]];
+                PT dx, dy, dz;
+                const PT rsq = pair_vector<PT>(pk, pi, box, dx, dy, dz);
+                const bool kp = (j < nn) && !(rsq > rmaxsq);
+                const unsigned long long m = __ballot(kp);
+                const unsigned qq = Q2 + ballot_rank(m);
+                Q2 += __popcll(m);
+                one(pk, pi, kp, qq, lo, Q, row, ax, ay, az, ae, bx, by, bz, be);
+            }
+        }
+        const unsigned filled = Q < NN ? Q : NN;
+        if constexpr (STORE) {
+            const unsigned zero_end = counts_io != nullptr ? counts_io[w] : NN;
+            for (unsigned sl = filled + lane; sl < zero_end; sl += 64) row[sl] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (counts_io != nullptr && lane == 0) counts_io[w] = filled;
+        }
+        if (do_rdf && lane == 0 && filled < NN) { // the row's zero padding
+            const unsigned npad = NN - filled;
+            if (pad_bin == 0) n_lo += npad;
+            else if (pad_bin == (int)rdf.nb - 1) n_hi += npad;
+            else atomicAdd(&s_hist[pad_bin], npad);
+        }
+        ax = group_sum<64>(ax); ay = group_sum<64>(ay); az = group_sum<64>(az); ae = group_sum<64>(ae);
+        bx = group_sum<64>(bx); by = group_sum<64>(by); bz = group_sum<64>(bz); be = group_sum<64>(be);
+        if (lane == 0) {
+            if (out_f64) {
+                ((double4 *)forceA)[w] = make_double4(ax, ay, az, ae);
+                ((double4 *)forceB)[w] = make_double4(bx, by, bz, be);
+            } else {
+                ((float4 *)forceA)[w] = make_float4(ax, ay, az, ae);
+                ((float4 *)forceB)[w] = make_float4(bx, by, bz, be);
+            }
+        }
+        cv_wave += be;
+    }
+    if (partials != nullptr) { // one partial per block, fixed order -> deterministic
+        if (lane == 0) s_part[wb] = cv_wave;
+        __syncthreads();
+        if (threadIdx.x == 0) partials[blockIdx.x] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+    }
+    if (do_rdf) {
+        n_lo = group_sum_u<64>(n_lo);
+        n_hi = group_sum_u<64>(n_hi);
+        if (lane == 0) {
+            if (n_lo) atomicAdd(&s_hist[0], n_lo);
+            if (n_hi) atomicAdd(&s_hist[rdf.nb - 1], n_hi);
+        }
+        __syncthreads();
+        for (unsigned i = threadIdx.x; i < rdf.nb; i += blockDim.x)
+            if (s_hist[i]) atomicAdd(&rdf.hist[i], s_hist[i]);
+    }
+}
+
+unsigned fused_forces2_num_partials(unsigned batch) {
+    const unsigned ngroups = (batch + 3) / 4;
+    return ngroups < 2048u ? ngroups : 2048u;
+}
+
+template <int KA, typename PT>
+static int launch_fused2(const PotParams &pa, const PotParams &pb, const void *pos, unsigned N, unsigned NN, unsigned offset,
+                         unsigned batch, const htf_box *hb, const unsigned *n_neigh, const unsigned *nlist,
+                         const unsigned *head_list, double rmax, void *fa, void *fb, int out_f64, float *partials,
+                         const Rdf2 &rdf, float4 *dest, unsigned *counts_io, hipStream_t s) {
+    BoxT<PT> b = make_boxt<PT>(hb);
+    PT rc = (PT)rmax;
+    const unsigned grid = fused_forces2_num_partials(batch);
+    if (dest != nullptr)
+        hipLaunchKernelGGL((fused_forces2_kernel<KA, true, PT>), dim3(grid), dim3(256), 0, s,
+                           (const typename Vec4<PT>::type *)pos, N, NN, offset, batch, b, n_neigh, nlist, head_list,
+                           (PT)(rc * rc), fa, fb, out_f64, pa, pb, partials, rdf, dest, counts_io);
+    else
+        hipLaunchKernelGGL((fused_forces2_kernel<KA, false, PT>), dim3(grid), dim3(256), 0, s,
+                           (const typename Vec4<PT>::type *)pos, N, NN, offset, batch, b, n_neigh, nlist, head_list,
+                           (PT)(rc * rc), fa, fb, out_f64, pa, pb, partials, rdf, dest, counts_io);
+    return check_launch("fused_forces2_kernel");
+}
+
+int fused_forces2_impl(const PotParams &pa, const PotParams &pb, const void *pos, int pos_dtype, unsigned N, unsigned NN,
+                       unsigned offset, unsigned batch, const htf_box *box, const unsigned *n_neigh,
+                       const unsigned *nlist, const unsigned *head_list, double rmax, void *fa, void *fb,
+                       int force_dtype, float *partials, float rdf_r0, float rdf_r1, unsigned rdf_nb,
+                       unsigned *rdf_hist, float4 *dest, unsigned *counts_io, hipStream_t s) {
+    HTF_REQUIRE(pos && n_neigh && nlist && head_list && box && fa && fb, "htf_build_eval_forces2: null pointer");
+    HTF_REQUIRE(NN > 0 && rmax > 0, "htf_build_eval_forces2: NN and rmax must be > 0");
+    HTF_REQUIRE(offset <= N && batch <= N - offset, "htf_build_eval_forces2: batch [%u, %u) exceeds N=%u", offset, offset + batch, N);
+    HTF_REQUIRE(pos_dtype == HTF_F32 || pos_dtype == HTF_F64, "htf_build_eval_forces2: bad position dtype %d", pos_dtype);
+    HTF_REQUIRE(pb.kind == HTF_POT_GAUSS, "htf_build_eval_forces2: potB must be HTF_POT_GAUSS");
+    if (rdf_hist != nullptr)
+        HTF_REQUIRE(rdf_nb >= 3 && rdf_nb <= kRdfMaxBins2 && rdf_r1 > rdf_r0, "htf_build_eval_forces2: need 3 <= bins <= %u and r1 > r0", kRdfMaxBins2);
+    if (batch == 0) return HTF_OK;
+    const Rdf2 rdf{rdf_r0, rdf_r1, rdf_nb, rdf_hist};
+    const int out_f64 = force_dtype == HTF_F64;
+#define HTF_F2(K)                                                                                                      \
+    (pos_dtype == HTF_F32 ? launch_fused2<K, float>(pa, pb, pos, N, NN, offset, batch, box, n_neigh, nlist, head_list, rmax, fa, fb, out_f64, partials, rdf, dest, counts_io, s) \
+                          : launch_fused2<K, double>(pa, pb, pos, N, NN, offset, batch, box, n_neigh, nlist, head_list, rmax, fa, fb, out_f64, partials, rdf, dest, counts_io, s))
+    switch (pa.kind) {
+    case HTF_POT_LJ: return HTF_F2(HTF_POT_LJ);
+    case HTF_POT_WCA: return HTF_F2(HTF_POT_WCA);
+    case HTF_POT_RINV_POLY: return HTF_F2(HTF_POT_RINV_POLY);
+    case HTF_POT_LJ_PARAM: return HTF_F2(HTF_POT_LJ_PARAM);
+    default:
+        set_error("htf_build_eval_forces2: potential kind %d is not a closed-form base potential", pa.kind);
+        return HTF_ERR_INVALID;
+    }
+#undef HTF_F2
+}
+
 int fused_forces_impl(const PotParams &p, const void *pos, int pos_dtype, unsigned N, unsigned NN, unsigned offset,
                       unsigned batch, const htf_box *box, const unsigned *n_neigh, const unsigned *nlist,
                       const unsigned *head_list, double rmax, void *force, int force_dtype, void *virial9,

@@ -42,6 +42,13 @@ int train_pair_dispatch(const PotParams &p, const void *nlist, int in_dtype, uns
                         const void *labels, int label_dtype, void *pred, float *accum, float *scratch,
                         hipStream_t stream);
 
+int fused_forces2_impl(const PotParams &pa, const PotParams &pb, const void *pos, int pos_dtype, unsigned N, unsigned NN,
+                       unsigned offset, unsigned batch, const htf_box *box, const unsigned *n_neigh,
+                       const unsigned *nlist, const unsigned *head_list, double rmax, void *fa, void *fb,
+                       int force_dtype, float *partials, float rdf_r0, float rdf_r1, unsigned rdf_nb,
+                       unsigned *rdf_hist, float4 *dest, unsigned *counts_io, hipStream_t s);
+unsigned fused_forces2_num_partials(unsigned batch);
+
 struct MlpDevice;
 int mlp_create(const htf_potential_desc *d, MlpDevice **out);
 void mlp_destroy(MlpDevice *m);

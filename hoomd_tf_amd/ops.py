@@ -223,6 +223,39 @@ def eval_forces2(pot_a, pot_b, nlist, out_a=None, out_b=None, partials=None, out
     return out_a, out_b
 
 
+def build_eval_forces2(pot_a, pot_b, pos, n_neigh, head_list, nlist, box, r_cut, NN, offset=0, batch_size=None,
+                       n_local=None, out_dtype=None, partials=None, rdf=None, pair_vectors=None, periodic=(1, 1, 1)):
+    """build_pair_vectors + eval_forces2 in ONE kernel (config C4's sweep): -> (forces_a, forces_b).
+    ``partials``: num_partials_fused(B) floats; ``rdf = (r0, r1, hist)``; ``pair_vectors`` (fp32
+    [B, NN, 4], optional) also receives the tensor."""
+    _dev(pos, "pos")
+    N = int(n_neigh.shape[0]) if n_local is None else int(n_local)
+    B = N - offset if batch_size is None else int(batch_size)
+    od = out_dtype or pos.dtype
+    out_a = torch.empty((B, 4), dtype=od, device=pos.device)
+    out_b = torch.empty((B, 4), dtype=od, device=pos.device)
+    if B == 0:
+        return out_a, out_b
+    b = box if isinstance(box, _lib.Box) else _lib.make_box(box, periodic)
+    r0, r1, nbt, hist = (0.0, 1.0, 0, None) if rdf is None else (rdf[0], rdf[1], int(rdf[2].numel()), rdf[2])
+    if pair_vectors is not None:
+        _dev(pair_vectors, "pair_vectors", torch.float32)
+        if tuple(pair_vectors.shape) != (B, NN, 4):
+            raise ValueError("pair_vectors must be [%d, %d, 4]" % (B, NN))
+    check(lib.htf_build_eval_forces2(pot_a.handle, pot_b.handle, pair_vectors.data_ptr() if pair_vectors is not None else None,
+                                     pos.data_ptr(), _dt(pos), N, NN, offset, B, C.byref(b),
+                                     _u32(n_neigh, "n_neigh").data_ptr(), _u32(nlist, "nlist").data_ptr(),
+                                     _u32(head_list, "head_list").data_ptr(), float(r_cut), out_a.data_ptr(),
+                                     out_b.data_ptr(), _dt(out_a), partials.data_ptr() if partials is not None else None,
+                                     float(r0), float(r1), nbt, hist.data_ptr() if hist is not None else None,
+                                     _stream(pos)))
+    return out_a, out_b
+
+
+def num_partials_fused(B):
+    return int(lib.htf_build_eval2_num_partials(int(B)))
+
+
 def num_partials(B, NN):
     return int(lib.htf_eval2_num_partials(int(B), int(NN)))
 

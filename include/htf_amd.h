@@ -176,6 +176,20 @@ HTF_API int htf_eval_forces2(const htf_potential *potA, const htf_potential *pot
                      htf_stream stream);
 HTF_API unsigned htf_eval2_num_partials(unsigned B, unsigned NN);
 
+/* htf_build_pair_vectors + htf_eval_forces2 as ONE kernel (config C4's whole sweep): the pair
+ * vectors are evaluated for both potentials, summed into the CV partials and binned into the
+ * compute_rdf histogram while they are in registers; d_dest (nullable, fp32 [batch, NN, 4]) also
+ * receives the tensor, bit-identical to htf_build_pair_vectors'.  d_partials: at least
+ * htf_build_eval2_num_partials(batch_size) floats (one per persistent block). */
+HTF_API int htf_build_eval_forces2(const htf_potential *potA, const htf_potential *potB, void *d_dest,
+                           const void *d_pos, int pos_dtype, unsigned N, unsigned NN, unsigned offset,
+                           unsigned batch_size, const htf_box *box, const unsigned *d_n_neigh,
+                           const unsigned *d_nlist, const unsigned *d_head_list, double rmax,
+                           void *d_forceA, void *d_forceB, int force_dtype, float *d_partials,
+                           float rdf_r0, float rdf_r1, unsigned rdf_nbins_total, unsigned *d_rdf_hist,
+                           htf_stream stream);
+HTF_API unsigned htf_build_eval2_num_partials(unsigned batch_size);
+
 /* *d_out = scale * sum(d_partials[0..n)) in a fixed order (one block; deterministic). */
 HTF_API int htf_reduce_partials(const float *d_partials, unsigned n, float scale, float *d_out, htf_stream stream);
 

@@ -473,6 +473,40 @@ def test_fused_matches_two_kernel_path_and_oracle(htf, cuda, hdt, NN):
         htf.ops.fused_forces(htf.Potential.pair_mlp(mlp_params(), 0, 3), p4, dnn, dhead, dnl, box, 3.0, NN)
 
 
+@pytest.mark.parametrize("hdt", [np.float32, np.float64])
+@pytest.mark.parametrize("NN", [8, 32, 128])
+def test_build_eval_forces2_equals_build_then_eval2(htf, cuda, hdt, NN):
+    """Config C4's sweep as ONE kernel (htf_build_eval_forces2) against htf_build_pair_vectors ->
+    htf_eval_forces2: tensor and compute_rdf histogram identical (the padded slots and, at NN = 8,
+    the overflow wrap included), both force sets and the CV sum to summation-order rounding."""
+    pos, types, L, nn, head, nl = _system(4, 1.6, 0.08, 11, 3.4, hdt, three_d=True)
+    box = O.make_box(L, dtype=hdt)
+    p4, dnn, dhead, dnl = _to_dev(htf, pos, types, nn, head, nl, hdt, cuda)
+    N = len(pos)
+    lj, gauss = htf.Potential.lj(), htf.Potential.gauss(1.1, 0.05, 1.0)
+    pv = htf.ops.build_pair_vectors(p4, dnn, dhead, dnl, box, 3.0, NN)
+    hist0 = torch.zeros(102, dtype=torch.int32, device=cuda)
+    part0 = torch.zeros(htf.ops.num_partials(N, NN), device=cuda)
+    fa0, fb0 = htf.ops.eval_forces2(lj, gauss, pv, partials=part0, rdf=(0.0, 3.5, hist0), out_dtype=p4.dtype)
+    hist1 = torch.zeros(102, dtype=torch.int32, device=cuda)
+    part1 = torch.zeros(htf.ops.num_partials_fused(N), device=cuda)
+    pv1 = torch.full_like(pv, 3.0)
+    fa1, fb1 = htf.ops.build_eval_forces2(lj, gauss, p4, dnn, dhead, dnl, box, 3.0, NN, partials=part1,
+                                          rdf=(0.0, 3.5, hist1), pair_vectors=pv1)
+    assert torch.equal(pv1, pv)
+    assert torch.equal(hist1, hist0) and int(hist0.sum()) == N * NN
+    for a, b in ((fa1, fa0), (fb1, fb0)):
+        assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max()))
+    assert abs(float(part1.sum()) - float(part0.sum())) <= 2e-5 * abs(float(part0.sum()))
+    # tensor-less form, and a batch
+    fa2, fb2 = htf.ops.build_eval_forces2(lj, gauss, p4, dnn, dhead, dnl, box, 3.0, NN)
+    assert torch.equal(fa2, fa1) and torch.equal(fb2, fb1)
+    fa3, _ = htf.ops.build_eval_forces2(lj, gauss, p4, dnn, dhead, dnl, box, 3.0, NN, offset=5, batch_size=30)
+    assert torch.equal(fa3, fa1[5:35])
+    with pytest.raises(ValueError):
+        htf.ops.build_eval_forces2(lj, lj, p4, dnn, dhead, dnl, box, 3.0, NN)
+
+
 def test_context_fused_mode(htf, cuda):
     """htf_config.fused: same forces / virial / errors as the reference dataflow."""
     pos, types, L, nn, head, nl = _system(5, 3.0, 0.08, 1, 5.4, np.float64, ntypes=1)
