@@ -106,23 +106,26 @@ __global__ __launch_bounds__(256) void cell_index_kernel(const typename Vec4<T>:
     cell_of[i] = (unsigned)((cz * ny + cy) * nx + cx);
 }
 
-// One 16-lane group per particle.  For every (dy, dz) row of the 27-cell stencil the up to
-// three x-adjacent cells are contiguous in the cell-sorted arrays, so they are walked as
-// one range (plus a second, usually empty, range when the stencil wraps around the box).
+// One G-lane group per particle.  The stencil reaches w = 1 cell (cells of width >= r_list) or
+// w = 2 cells (width >= r_list / 2: 125 cells of 1/8 the volume, 1.7x fewer candidate checks --
+// the search is VALU-issue bound, PMC: 120 M wave-instructions at C3) per direction.  For every
+// (dy, dz) row of the stencil the 2 wx + 1 x-adjacent cells are contiguous in the cell-sorted
+// arrays, so they are walked as one range (plus a second, usually empty, range when the stencil
+// wraps around the box).
 // Candidates are read from the CELL-SORTED position copy: 16 lanes x 16 B contiguous.
 // Hits are compacted with a ballot restricted to the group.  Every lane of the wave runs
 // the same trip counts (ranges of other groups are padded to the wave maximum) so the
 // ballots and shuffles are convergent.
-template <typename T>
+template <typename T, int G>
 __global__ __launch_bounds__(256) void build_nlist_kernel(const typename Vec4<T>::type *__restrict__ pos,
                                                           const typename Vec4<T>::type *__restrict__ pos_sorted,
                                                           unsigned N, SBox<T> b, T rl2, int nx, int ny, int nz,
+                                                          int wx, int wy, int wz,
                                                           const unsigned *__restrict__ order,
                                                           const unsigned *__restrict__ cell_start, unsigned pitch,
                                                           int type_split,
                                                           unsigned *__restrict__ n_neigh, unsigned *__restrict__ head_list,
                                                           unsigned *__restrict__ nlist, unsigned *__restrict__ max_neigh) {
-    constexpr int G = 16;
     const unsigned lane = threadIdx.x & 63u, g = lane % G, sub = lane / G;
     const unsigned i = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * (64 / G) + sub;
     const bool active = i < N;
@@ -131,26 +134,21 @@ __global__ __launch_bounds__(256) void build_nlist_kernel(const typename Vec4<T>
     const int cy = cell_coord<T>(pi.y, b.lo[1], b.Linv[1], ny);
     const int cz = cell_coord<T>(pi.z, b.lo[2], b.Linv[2], nz);
     const bool side_i = type_split >= 0 && scalar_as_int(pi.w) >= type_split;
-    const unsigned long long gmask = 0xFFFFull << (sub * G);
+    const unsigned long long gmask = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << (sub * G);
     unsigned count = 0;
     unsigned *row = nlist + (size_t)(active ? i : 0) * pitch;
-    // x extent of the stencil as up to two cell ranges [a0, a1] and [b0, b1] (b empty if b1 < b0)
-    int a0 = cx, a1 = cx, b0 = 0, b1 = -1;
-    if (nx >= 3) {
-        a0 = cx - 1;
-        a1 = cx + 1;
-        if (a0 < 0) {
-            a0 = 0;
-            if (b.periodic[0]) b0 = b1 = nx - 1;
-        } else if (a1 >= nx) {
-            a1 = nx - 1;
-            if (b.periodic[0]) b0 = b1 = 0;
-        }
+    // x extent of the stencil as up to two cell ranges [a0, a1] and [b0, b1] (b empty if b1 < b0):
+    // the 2 wx + 1 x-adjacent cells are contiguous in the cell-sorted arrays unless they wrap
+    int a0 = cx - wx, a1 = cx + wx, b0 = 0, b1 = -1;
+    if (a0 < 0) {
+        if (b.periodic[0]) { b0 = nx + a0; b1 = nx - 1; }
+        a0 = 0;
+    } else if (a1 >= nx) {
+        if (b.periodic[0]) { b0 = 0; b1 = a1 - nx; }
+        a1 = nx - 1;
     }
-    const int y0 = ny >= 3 ? -1 : 0, y1 = ny >= 3 ? 1 : 0;
-    const int z0 = nz >= 3 ? -1 : 0, z1 = nz >= 3 ? 1 : 0;
-    for (int dz = z0; dz <= z1; ++dz)
-        for (int dy = y0; dy <= y1; ++dy) {
+    for (int dz = -wz; dz <= wz; ++dz)
+        for (int dy = -wy; dy <= wy; ++dy) {
             int ay = cy + dy, az = cz + dz;
             bool skip = false;
             if (ay < 0) { skip |= !b.periodic[1]; ay += ny; } else if (ay >= ny) { skip |= !b.periodic[1]; ay -= ny; }
@@ -183,7 +181,7 @@ __global__ __launch_bounds__(256) void build_nlist_kernel(const typename Vec4<T>
                         if (type_split >= 0) hit = hit && ((scalar_as_int(pk.w) >= type_split) == side_i);
                     }
                     const unsigned long long bal = __ballot(hit) & gmask;
-                    const unsigned rank = count + ballot_rank(bal);
+                    const unsigned rank = count + __popcll(bal & ((1ull << lane) - 1ull));
                     if (hit && rank < pitch) row[rank] = k;
                     count += __popcll(bal);
                 }
@@ -196,143 +194,6 @@ __global__ __launch_bounds__(256) void build_nlist_kernel(const typename Vec4<T>
     }
 }
 
-
-// One BLOCK per cell (HTF_STANDIN_NLIST=cell): the stencil's candidates -- the same (dz, dy,
-// x-range) walk, hence the same neighbor order as the per-particle kernel above -- are staged
-// ONCE per cell in LDS tiles and shared by the cell's ~39 members, instead of every member
-// streaming its own 16.8 KB of candidates from L2 (2.2 GB per build at C3).  A 16-lane group
-// owns one member per round, 4 rounds per staged tile, group-restricted ballot compaction.
-// Measured at C3: 190 us against 180 us for the per-particle kernel -- the search is bound by
-// the ~40 instructions per 64 candidate checks (138 M checks, 15 % hit rate with cells of
-// width r_list), not by L2 traffic, so the per-particle kernel stays the default; the next
-// step would be half-width cells (1.7x fewer candidates) and pre-shifted periodic images.
-constexpr int kNlTile = 1024;   // candidates per LDS tile
-constexpr int kNlRounds = 4;    // members per group per pass: 16 groups x 4 = 64 members
-
-template <typename T>
-__global__ __launch_bounds__(256) void build_nlist_cells_kernel(const typename Vec4<T>::type *__restrict__ pos_sorted,
-                                                                unsigned N, SBox<T> b, T rl2, int nx, int ny, int nz,
-                                                                const unsigned *__restrict__ order,
-                                                                const unsigned *__restrict__ cell_start, unsigned pitch,
-                                                                int type_split, unsigned *__restrict__ n_neigh,
-                                                                unsigned *__restrict__ head_list,
-                                                                unsigned *__restrict__ nlist,
-                                                                unsigned *__restrict__ max_neigh) {
-    using V = typename Vec4<T>::type;
-    constexpr int G = 16;
-    __shared__ V s_pos[kNlTile];
-    __shared__ unsigned s_idx[kNlTile];
-    __shared__ unsigned s_beg[18], s_off[19];
-    const unsigned c = blockIdx.x;
-    const int cx = (int)(c % (unsigned)nx), cy = (int)((c / (unsigned)nx) % (unsigned)ny), cz = (int)(c / (unsigned)(nx * ny));
-    if (threadIdx.x == 0) {
-        int a0 = cx, a1 = cx, b0 = 0, b1 = -1;
-        if (nx >= 3) {
-            a0 = cx - 1;
-            a1 = cx + 1;
-            if (a0 < 0) {
-                a0 = 0;
-                if (b.periodic[0]) b0 = b1 = nx - 1;
-            } else if (a1 >= nx) {
-                a1 = nx - 1;
-                if (b.periodic[0]) b0 = b1 = 0;
-            }
-        }
-        const int y0 = ny >= 3 ? -1 : 0, y1 = ny >= 3 ? 1 : 0;
-        const int z0 = nz >= 3 ? -1 : 0, z1 = nz >= 3 ? 1 : 0;
-        unsigned nr = 0, off = 0;
-        for (int dz = z0; dz <= z1; ++dz)
-            for (int dy = y0; dy <= y1; ++dy) {
-                int ay = cy + dy, az = cz + dz;
-                bool skip = false;
-                if (ay < 0) { skip |= !b.periodic[1]; ay += ny; } else if (ay >= ny) { skip |= !b.periodic[1]; ay -= ny; }
-                if (az < 0) { skip |= !b.periodic[2]; az += nz; } else if (az >= nz) { skip |= !b.periodic[2]; az -= nz; }
-                const unsigned rowbase = (unsigned)((az * ny + ay) * nx);
-                for (int part = 0; part < 2; ++part) {
-                    const int c0 = part ? b0 : a0, c1 = part ? b1 : a1;
-                    unsigned beg = 0, len = 0;
-                    if (!skip && c1 >= c0) {
-                        beg = cell_start[rowbase + c0];
-                        len = cell_start[rowbase + c1 + 1] - beg;
-                    }
-                    s_beg[nr] = beg;
-                    s_off[nr] = off;
-                    off += len;
-                    ++nr;
-                }
-            }
-        for (; nr < 18; ++nr) { s_beg[nr] = 0; s_off[nr] = off; }
-        s_off[18] = off;
-    }
-    __syncthreads();
-    const unsigned total = s_off[18];
-    const unsigned mbeg = cell_start[c], mcnt = cell_start[c + 1] - mbeg;
-    const unsigned lane = threadIdx.x & 63u, g = lane % G, sub = lane / G;
-    const unsigned grp = (threadIdx.x >> 6) * (64 / G) + sub; // 0..15
-    const unsigned long long gmask = 0xFFFFull << (sub * G);
-
-    for (unsigned mbase = 0; mbase < mcnt; mbase += 16 * kNlRounds) {
-        V pi[kNlRounds];
-        unsigned mi[kNlRounds], count[kNlRounds];
-        bool act[kNlRounds], side[kNlRounds];
-#pragma unroll
-        for (int r = 0; r < kNlRounds; ++r) {
-            const unsigned m = mbase + r * 16 + grp;
-            act[r] = m < mcnt;
-            const unsigned sidx = mbeg + (act[r] ? m : 0);
-            mi[r] = order[sidx];
-            pi[r] = pos_sorted[sidx];
-            act[r] = act[r] && mi[r] < N; // ghosts are candidates only
-            side[r] = type_split >= 0 && scalar_as_int(pi[r].w) >= type_split;
-            count[r] = 0;
-        }
-        for (unsigned tbase = 0; tbase < total; tbase += kNlTile) {
-            const unsigned ntile = total - tbase < (unsigned)kNlTile ? total - tbase : (unsigned)kNlTile;
-            __syncthreads(); // the previous tile has been consumed
-            for (unsigned e = threadIdx.x; e < ntile; e += blockDim.x) {
-                const unsigned ge = tbase + e;
-                unsigned r = 0;
-#pragma unroll
-                for (int q = 1; q < 18; ++q) r += (ge >= s_off[q]) ? 1u : 0u;
-                const unsigned src = s_beg[r] + (ge - s_off[r]);
-                s_pos[e] = pos_sorted[src];
-                s_idx[e] = order[src];
-            }
-            __syncthreads();
-#pragma unroll
-            for (int r = 0; r < kNlRounds; ++r) {
-                if (mbase + r * 16 >= mcnt) break; // block-uniform
-                unsigned *row = nlist + (size_t)(act[r] ? mi[r] : 0) * pitch;
-                for (unsigned t = 0; t < ntile; t += G) {
-                    const unsigned e = t + g;
-                    bool hit = false;
-                    unsigned k = 0;
-                    if (act[r] && e < ntile) {
-                        k = s_idx[e];
-                        const V pk = s_pos[e];
-                        T ddx = mimg<T>(pk.x - pi[r].x, b.L[0], b.Linv[0], b.periodic[0]);
-                        T ddy = mimg<T>(pk.y - pi[r].y, b.L[1], b.Linv[1], b.periodic[1]);
-                        T ddz = mimg<T>(pk.z - pi[r].z, b.L[2], b.Linv[2], b.periodic[2]);
-                        hit = (k != mi[r]) && (ddx * ddx + ddy * ddy + ddz * ddz <= rl2);
-                        if (type_split >= 0) hit = hit && ((scalar_as_int(pk.w) >= type_split) == side[r]);
-                    }
-                    const unsigned long long bal = __ballot(hit) & gmask;
-                    const unsigned rank = count[r] + ballot_rank(bal);
-                    if (hit && rank < pitch) row[rank] = k;
-                    count[r] += __popcll(bal);
-                }
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < kNlRounds; ++r) {
-            if (act[r] && g == 0) {
-                n_neigh[mi[r]] = count[r] < pitch ? count[r] : pitch;
-                head_list[mi[r]] = mi[r] * pitch;
-                if (count[r] > *(volatile unsigned *)max_neigh) atomicMax(max_neigh, count[r]);
-            }
-        }
-    }
-}
 
 } // namespace htf
 
@@ -393,33 +254,33 @@ extern "C" int htfs_cell_index(const void *d_pos, int dtype, unsigned Ntot, cons
 }
 
 extern "C" int htfs_build_nlist(const void *d_pos, const void *d_pos_sorted, int dtype, unsigned N, unsigned Ntot,
-                                const htf_box *box, double r_list, const int *ncell3, const unsigned *d_order,
-                                const unsigned *d_cell_start, unsigned pitch, int type_split, unsigned *d_n_neigh,
-                                unsigned *d_head_list, unsigned *d_nlist, unsigned *d_max_neigh, htf_stream stream) {
+                                const htf_box *box, double r_list, const int *ncell3, const int *stencil3,
+                                const unsigned *d_order, const unsigned *d_cell_start, unsigned pitch, int type_split,
+                                unsigned *d_n_neigh, unsigned *d_head_list, unsigned *d_nlist, unsigned *d_max_neigh,
+                                htf_stream stream) {
     (void)Ntot;
-    HTF_REQUIRE(d_pos && d_pos_sorted && box && ncell3 && d_order && d_cell_start && d_n_neigh && d_head_list && d_nlist && d_max_neigh,
+    HTF_REQUIRE(d_pos && d_pos_sorted && box && ncell3 && stencil3 && d_order && d_cell_start && d_n_neigh && d_head_list && d_nlist && d_max_neigh,
                 "htfs_build_nlist: null pointer");
     HTF_REQUIRE(pitch > 0, "htfs_build_nlist: pitch must be > 0");
     for (int d = 0; d < 3; ++d) {
-        double w = (box->hi[d] - box->lo[d]) / ncell3[d];
-        HTF_REQUIRE(ncell3[d] == 1 || (ncell3[d] >= 3 && w >= r_list),
-                    "htfs_build_nlist: need 1 cell or >= 3 cells of width >= r_list along %d (got %d cells of %g, r_list %g)", d, ncell3[d], w, r_list);
+        const double w = (box->hi[d] - box->lo[d]) / ncell3[d];
+        const int sw = stencil3[d];
+        HTF_REQUIRE((sw == 0 && ncell3[d] == 1) || (sw >= 1 && sw <= 2 && ncell3[d] >= 2 * sw + 1 && w * sw >= r_list * (1.0 - 1e-12)),
+                    "htfs_build_nlist: along %d need 1 cell, or >= 2w+1 cells with w cells spanning r_list (got %d cells of %g, stencil %d, r_list %g)",
+                    d, ncell3[d], w, sw, r_list);
     }
     if (N == 0) return HTF_OK;
-    const unsigned ncell = (unsigned)(ncell3[0] * ncell3[1] * ncell3[2]);
-    const char *force = getenv("HTF_STANDIN_NLIST"); // "particle" | "cell": A/B runs and tests
-    const bool by_cell = force != nullptr && force[0] == 'c';
-    if (by_cell) {
-        if (dtype == HTF_F32)
-            hipLaunchKernelGGL((build_nlist_cells_kernel<float>), dim3(ncell), dim3(256), 0, (hipStream_t)stream, (const float4 *)d_pos_sorted, N, make_sbox<float>(box), (float)(r_list * r_list), ncell3[0], ncell3[1], ncell3[2], d_order, d_cell_start, pitch, type_split, d_n_neigh, d_head_list, d_nlist, d_max_neigh);
-        else
-            hipLaunchKernelGGL((build_nlist_cells_kernel<double>), dim3(ncell), dim3(256), 0, (hipStream_t)stream, (const double4 *)d_pos_sorted, N, make_sbox<double>(box), r_list * r_list, ncell3[0], ncell3[1], ncell3[2], d_order, d_cell_start, pitch, type_split, d_n_neigh, d_head_list, d_nlist, d_max_neigh);
-        return check_launch("build_nlist_cells_kernel");
+    const bool fine = stencil3[0] == 2 || stencil3[1] == 2 || stencil3[2] == 2; // short ranges: 8-lane groups waste fewer lanes
+#define HTFS_NL(T, V4, G)                                                                                              \
+    hipLaunchKernelGGL((build_nlist_kernel<T, G>), dim3((N + 4 * (64 / G) - 1) / (4 * (64 / G))), dim3(256), 0, (hipStream_t)stream, \
+                       (const V4 *)d_pos, (const V4 *)d_pos_sorted, N, make_sbox<T>(box), (T)(r_list * r_list), ncell3[0],  \
+                       ncell3[1], ncell3[2], stencil3[0], stencil3[1], stencil3[2], d_order, d_cell_start, pitch,      \
+                       type_split, d_n_neigh, d_head_list, d_nlist, d_max_neigh)
+    if (dtype == HTF_F32) {
+        if (fine) HTFS_NL(float, float4, 8); else HTFS_NL(float, float4, 16);
+    } else {
+        if (fine) HTFS_NL(double, double4, 8); else HTFS_NL(double, double4, 16);
     }
-    unsigned grid = (N + 15) / 16; // 4 waves x 4 particles per block
-    if (dtype == HTF_F32)
-        hipLaunchKernelGGL((build_nlist_kernel<float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float4 *)d_pos, (const float4 *)d_pos_sorted, N, make_sbox<float>(box), (float)(r_list * r_list), ncell3[0], ncell3[1], ncell3[2], d_order, d_cell_start, pitch, type_split, d_n_neigh, d_head_list, d_nlist, d_max_neigh);
-    else
-        hipLaunchKernelGGL((build_nlist_kernel<double>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const double4 *)d_pos, (const double4 *)d_pos_sorted, N, make_sbox<double>(box), r_list * r_list, ncell3[0], ncell3[1], ncell3[2], d_order, d_cell_start, pitch, type_split, d_n_neigh, d_head_list, d_nlist, d_max_neigh);
+#undef HTFS_NL
     return check_launch("build_nlist_kernel");
 }

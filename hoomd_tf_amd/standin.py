@@ -135,18 +135,28 @@ class CellNlist:
         return self.r_cut + self.r_buff
 
     def _ncell(self):
+        """cells per direction and stencil half-width: cells at least r_list / 2 wide (5 per direction
+        searched) when the box holds >= 5 of them, else at least r_list wide (3 searched), else one."""
         L = self.sys.box3x3[1] - self.sys.box3x3[0]
-        n = np.floor(L / self.r_list).astype(int)
-        n[n < 3] = 1
-        return n
+        n = np.ones(3, dtype=int)
+        w = np.zeros(3, dtype=int)
+        for d in range(3):
+            fine = int(np.floor(L[d] / (self.r_list / 2.0)))
+            coarse = int(np.floor(L[d] / self.r_list))
+            if fine >= 5:
+                n[d], w[d] = fine, 2
+            elif coarse >= 3:
+                n[d], w[d] = coarse, 1
+        return n, w
 
     def build(self):
         s = self.sys
         if self.domain is not None:
             self.domain.rebuild()  # Communicator: migrate particles, re-plan + fill ghosts
         Ntot = s.N + s.n_ghost
-        n = self._ncell()
+        n, w = self._ncell()
         n3 = (C.c_int * 3)(*[int(x) for x in n])
+        w3 = (C.c_int * 3)(*[int(x) for x in w])
         ncell = int(n[0] * n[1] * n[2])
         stream = C.c_void_p(torch.cuda.current_stream(s.device).cuda_stream)
         cell_of = torch.empty(Ntot, dtype=torch.int32, device=s.device)
@@ -180,7 +190,7 @@ class CellNlist:
                 self.nlist = torch.empty(s.N * self.pitch, dtype=torch.int32, device=s.device)
             self._max.zero_()
             check(lib.htfs_build_nlist(s.pos.data_ptr(), pos_sorted.data_ptr(), s.scalar_code, s.N, Ntot, C.byref(s.box), self.r_list,
-                                       C.byref(n3), order.data_ptr(), cell_start.data_ptr(), self.pitch, int(self.type_split),
+                                       C.byref(n3), C.byref(w3), order.data_ptr(), cell_start.data_ptr(), self.pitch, int(self.type_split),
                                        self.n_neigh.data_ptr(), self.head_list.data_ptr(), self.nlist.data_ptr(),
                                        self._max.data_ptr(), stream))
             mx = int(self._max.item())

@@ -25,7 +25,8 @@ HTF_API int htfs_max_displacement2(const void *d_pos, const void *d_ref, int dty
  * d_cell_of [Ntot], d_order [Ntot] (particle ids sorted by cell), d_pos_sorted [Ntot]
  * (= pos[order], so a cell's members are contiguous) and d_cell_start [ncell+1] are
  * produced by the caller (binning + sort + gather are plumbing); this kernel walks
- * the 27 neighbor cells of each local particle and writes
+ * the neighbor cells of each local particle -- stencil3[d] = 0 (one cell along d), 1 (cells at
+ * least r_list wide, 3 per direction) or 2 (at least r_list / 2 wide, 5 per direction) -- and writes
  *   nlist[i*pitch + c] = k  for every k != i with |minimage(r_k - r_i)| <= r_list,
  *   n_neigh[i] = count, head_list[i] = i*pitch.
  * *d_max_neigh is max'ed with the largest count (> pitch means the list overflowed and
@@ -33,9 +34,10 @@ HTF_API int htfs_max_displacement2(const void *d_pos, const void *d_ref, int dty
  * sides of it are left out (hoomd.md.nlist.rcut set_pair(..., -1) between all-atom and mapped
  * bead types, tensorflowcompute.py:284-305); -1: no type filter. */
 HTF_API int htfs_build_nlist(const void *d_pos, const void *d_pos_sorted, int dtype, unsigned N, unsigned Ntot,
-                             const htf_box *box, double r_list, const int *ncell3, const unsigned *d_order,
-                             const unsigned *d_cell_start, unsigned pitch, int type_split, unsigned *d_n_neigh,
-                             unsigned *d_head_list, unsigned *d_nlist, unsigned *d_max_neigh, htf_stream stream);
+                             const htf_box *box, double r_list, const int *ncell3, const int *stencil3,
+                             const unsigned *d_order, const unsigned *d_cell_start, unsigned pitch, int type_split,
+                             unsigned *d_n_neigh, unsigned *d_head_list, unsigned *d_nlist, unsigned *d_max_neigh,
+                             htf_stream stream);
 
 /* dest[i] = src[order[i]] for Scalar4 arrays: the cell-sorted position copy */
 HTF_API int htfs_gather4(void *d_dest, const void *d_src, const int *d_order, int dtype, unsigned n, htf_stream stream);

@@ -131,41 +131,3 @@ def test_compute_forces_in_row_ranges_equals_whole(htf, cuda, mode):
         ctx.set_potential(pot)
         arr = ctx.make_arrays(sysm.pos, N, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, torch.zeros((N, 4), device=cuda))
         ctx.compute_forces(0, arr, rows=(N - 3, 10))
-
-
-@pytest.mark.parametrize("case", ["3d-f32", "3d-f64", "2d", "ghosts", "type-split"])
-def test_cell_block_nlist_kernel_equals_per_particle_kernel(htf, cuda, case, monkeypatch):
-    """The LDS-tiled one-block-per-cell neighbor search (HTF_STANDIN_NLIST=cell)
-    walks the stencil in the same order as the per-particle kernel: identical lists, not just
-    identical sets."""
-    from hoomd_tf_amd import standin
-    rng = np.random.default_rng(4)
-    if case == "2d":
-        pos, L = sq_lattice(40, 1.2)
-        pos[:, :2] += 0.1 * rng.standard_normal((len(pos), 2))
-        types = None
-    else:
-        pos, L, a = standin.fcc_positions(9, 0.8442)
-        pos = pos + 0.08 * a * rng.standard_normal(pos.shape)
-        pos -= np.round(pos / L) * L
-        types = (rng.random(len(pos)) < 0.3).astype(np.int32) if case == "type-split" else None
-    dt = torch.float64 if case == "3d-f64" else torch.float32
-    out = {}
-    for kern in ("particle", "cell"):
-        monkeypatch.setenv("HTF_STANDIN_NLIST", kern)
-        sysm = standin.System(pos, L, types=types, dtype=dt, device=cuda)
-        if case == "ghosts":  # the last 500 particles are candidates only
-            sysm.N -= 500
-            sysm.n_ghost = 500
-        nl = standin.CellNlist(sysm, r_cut=2.5, r_buff=0.4)
-        if case == "type-split":
-            nl.type_split = 1
-        nl.build()
-        out[kern] = (nl.n_neigh.cpu().numpy().copy(), nl.head_list.cpu().numpy().copy(),
-                     nl.nlist.cpu().numpy().copy(), nl.pitch)
-    (n0, h0, l0, p0), (n1, h1, l1, p1) = out["particle"], out["cell"]
-    assert p0 == p1 and n0.max() >= 10
-    np.testing.assert_array_equal(n0, n1)
-    np.testing.assert_array_equal(h0, h1)
-    for i in range(len(n0)):
-        np.testing.assert_array_equal(l0[h0[i]:h0[i] + n0[i]], l1[h1[i]:h1[i] + n1[i]])
