@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void build_nlist_kernel(const typename Vec4<T>
                         if (type_split >= 0) hit = hit && ((scalar_as_int(pk.w) >= type_split) == side_i);
                     }
                     const unsigned long long bal = __ballot(hit) & gmask;
-                    const unsigned rank = count + __popcll(bal & ((1ull << lane) - 1ull));
+                    const unsigned rank = count + ballot_rank(bal);
                     if (hit && rank < pitch) row[rank] = k;
                     count += __popcll(bal);
                 }
