@@ -528,7 +528,7 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s: fcc %d^3x4 = %d particles/GPU, rho 0.8442, r_cut %.1f, r_buff %.1f, NN %d, dt %g"
                                % ("C5b (pair-MLP MD + force-matching step every %d steps vs LJ labels)" % args.train_period
-                                  if args.workload == "mlp-train" else "C3-" + args.workload.upper(),
+                                  if args.workload == "mlp-train" else ("C2-WCA" if args.workload == "wca" and args.cells == 20 else "C3-" + args.workload.upper()),
                                   args.cells, N, args.rcut, args.rbuff, NN, args.dt),
                    "global_particles": N * world, "parallelism": "dd%dx1x1" % world,
                    "nlist_rebuilds_in_timed_region": rebuilds, "max_neighbors_within_rcut": max_kept,
