@@ -171,6 +171,11 @@ __global__ __launch_bounds__(256) void fused_forces_kernel(const typename Vec4<P
                                        out_f64, p, check_count, positions_out, dest, counts_io);
 }
 
+// Measured alternatives for the fast path below (C3, tensor written / not written): one row per
+// wave 102 / 65 us; two rows 92 / 53 us (this kernel); four rows 97 / 66 us; survivors compacted
+// into a wave-private LDS row first and evaluated from there in two trips instead of three, with
+// full-width tensor stores, 94 / 57 us; evaluation made branch-free so that the two rows' arithmetic
+// can pack into v_pk_* instructions 96 / 56 us.
 // Two rows per wave with ALL their index loads, then all their gathers, issued before any
 // arithmetic: twice the bytes in flight per wave slot while the evaluator's VALU work (which,
 // unlike the plain build, this kernel has plenty of) runs under the other row's memory latency.
