@@ -46,3 +46,23 @@ def test_lj_matches_numpy_oracle(clib):
     got = c_oracle.lj_from_nlist(clib, nl)
     np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-4)
     assert clib.htfo_num_threads() >= 1
+
+
+def test_c_oracle_under_sanitizers(tmp_path):
+    """the CPU restatement built with -fsanitize=address,undefined and run on a system whose
+    rows overflow NN (the slot wrap must stay inside the row), a batch, both precisions, 1 and 4 threads."""
+    import os
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "san_drv"
+    build = subprocess.run(["gcc", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fopenmp",
+                            os.path.join(root, "oracle", "sanitize_driver.c"), os.path.join(root, "oracle", "htf_oracle_c.c"),
+                            "-lm", "-o", str(exe)], capture_output=True, text=True)
+    if build.returncode != 0 and "sanitize" in build.stderr:
+        pytest.skip("sanitizer runtime not installed")
+    assert build.returncode == 0, build.stderr
+    run = subprocess.run([str(exe)], capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
+    assert run.returncode == 0 and "sanitize_driver ok" in run.stdout, run.stdout + run.stderr
