@@ -53,6 +53,15 @@ class WCARepulsion:
     def get_config(self):
         return {'sigma': float(self.sigma)}
 
+    def get_weights(self):
+        return [np.array([self.sigma], dtype=np.float32)]
+
+    def set_weights(self, ws):
+        v = float(np.asarray(ws[0]).reshape(-1)[0])
+        if self.w is not None:
+            self.w[0] = v
+        self._sigma0 = float(np.float32(v))
+
     # trainable-layer protocol used by tfcompute's training step
     nonneg_mask = 0
 
@@ -90,6 +99,12 @@ class LJLayer:
 
     def get_config(self):
         return {'sig': self.start[0], 'eps': self.start[1]}
+
+    def get_weights(self):
+        return [self.w.detach().cpu().numpy().copy()]
+
+    def set_weights(self, ws):
+        self.w.copy_(torch.as_tensor(np.asarray(ws[0], dtype=np.float32).reshape(2)))
 
     def make_trainable(self, device):
         return self.w

@@ -20,6 +20,17 @@ class Optimizer:
         return d
 
 
+    def torch(self, params):
+        """The same rule as a torch optimizer: the generic (autograd) training route of SURVEY 8(f)-3."""
+        import torch
+        if self.kind == _lib.OPT_SGD:
+            return torch.optim.SGD(params, lr=self.learning_rate)
+        if self.kind == _lib.OPT_ADAM:
+            return torch.optim.Adam(params, lr=self.learning_rate, betas=(self.beta_1, self.beta_2), eps=self.epsilon)
+        return torch.optim.NAdam(params, lr=self.learning_rate, betas=(self.beta_1, self.beta_2), eps=self.epsilon,
+                                 momentum_decay=0.004)
+
+
 class SGD(Optimizer):
     kind = _lib.OPT_SGD
 

@@ -429,12 +429,14 @@ def _autograd_nlist_forces(nl, energy, virial):
     (x2, summed over the neighbor axis).  No fused kernel, no plan: the step stays eager."""
     g = None
     if nl._ad is not None and energy.requires_grad:
-        (g,) = torch.autograd.grad(energy.sum(), nl._ad, allow_unused=True, retain_graph=True)
+        # while a generic model is being trained the forces must stay differentiable w.r.t. its weights
+        (g,) = torch.autograd.grad(energy.sum(), nl._ad, allow_unused=True, retain_graph=True,
+                                   create_graph=bool(getattr(_trace, "training_graph", False)))
     if g is None:
         raise ValueError('Could not find dependence between energy and nlist.'
                          ' Did you put them in wrong order?')
     nlist_forces = 2.0 * g
-    forces = _add_energy(nlist_forces.sum(dim=1), energy.detach())
+    forces = _add_energy(nlist_forces.sum(dim=1), energy if getattr(_trace, "training_graph", False) else energy.detach())
     _trace_log().append({"op": "generic"})
     if not virial:
         return forces
@@ -621,6 +623,44 @@ class SimModel:
             raise ValueError("loss %r is not built; available: 'MeanSquaredError'" % (first,))
         self.loss = list(loss) if isinstance(loss, (list, tuple)) else [loss]
         self.metrics = [_LossMetric()]
+
+    # ---- Keras weights API over whatever the model's layers hold (simmodel.py inherits it from tf.keras.Model)
+    def _weight_holders(self):
+        return [v for _, v in sorted(vars(self).items()) if hasattr(v, "get_weights") and hasattr(v, "set_weights")]
+
+    def parameters(self):
+        """torch tensors with requires_grad among the model's attributes (generic-route models)."""
+        out = []
+        for _, v in sorted(vars(self).items()):
+            if isinstance(v, torch.Tensor) and v.requires_grad:
+                out.append(v)
+            elif isinstance(v, torch.nn.Module):
+                out.extend(p for p in v.parameters() if p.requires_grad)
+        return out
+
+    def get_weights(self):
+        ws = []
+        for h in self._weight_holders():
+            ws.extend(h.get_weights())
+        ws.extend(p.detach().cpu().numpy().copy() for p in self.parameters())
+        return ws
+
+    def set_weights(self, ws):
+        ws = list(ws)
+        for h in self._weight_holders():
+            n = len(h.get_weights())
+            h.set_weights(ws[:n])
+            ws = ws[n:]
+        for p, w in zip(self.parameters(), ws):
+            with torch.no_grad():
+                p.copy_(torch.as_tensor(w, dtype=p.dtype))
+
+    def save_weights(self, path):
+        np.savez(path, *self.get_weights())
+
+    def load_weights(self, path):
+        with np.load(path if str(path).endswith(".npz") else str(path) + ".npz") as z:
+            self.set_weights([z["arr_%d" % i] for i in range(len(z.files))])
 
     def get_config(self):
         return {'nneighbor_cutoff': self.nneighbor_cutoff, 'output_forces': self.output_forces,

@@ -228,6 +228,29 @@ class tfcompute:
                 ops.add_scalar4(lab, f.force)
             self._labels = lab
 
+    def _train_generic(self, output, offset, n):
+        """train_on_batch for a generic (torch-op) model: MSE over the loss-list outputs by
+        autograd -- the forces were built with create_graph, so the gradient flows through them
+        into the model's torch parameters -- and the compiled optimizer's torch twin."""
+        m = self.model
+        params = m.parameters()
+        pred = output[0]
+        d = pred.to(torch.float32) - self._labels[offset:offset + n].to(torch.float32)
+        loss = (d * d).mean()
+        if self._opt_state is None:
+            self._opt_state = torch.zeros(_lib.OPT_STATE_FLOATS, dtype=torch.float32, device=self.system.device)
+            if m.metrics:
+                m.metrics[0].state = self._opt_state
+        if params:
+            if getattr(self, "_torch_opt", None) is None:
+                self._torch_opt = m.optimizer.torch(params)
+            self._torch_opt.zero_grad(set_to_none=True)
+            loss.backward()
+            self._torch_opt.step()
+        self._opt_state[18] += loss.detach()
+        self._opt_state[19] += 1.0
+        self._opt_state[20] = loss.detach()
+
     def _train_on_batch(self, nlist_t, offset, n, fused_entries):
         """model.train_on_batch(x=inputs, y=labels) (tensorflowcompute.py:366-370) for a model
         whose forces come from one trainable closed-form layer: loss + parameter gradient in
@@ -302,7 +325,11 @@ class tfcompute:
         self._last = (nlist_t, pos_t, offset, n)
         inputs = m.compute_inputs(nlist_t, pos_t, box_t)
         mark = len(simmodel._trace_log())
-        output = m(inputs, self.train)
+        simmodel._trace.training_graph = bool(self.train)  # generic route: forces stay differentiable
+        try:
+            output = m(inputs, self.train)
+        finally:
+            simmodel._trace.training_graph = False
         fused_entries = [e for e in simmodel._trace_log()[mark:] if "potential" in e]
         for e in simmodel._trace_log()[mark:]:
             if "forces" in e and len(output) > 0 and output[0] is e["forces"] and e["nlist"] is inputs[0]:
@@ -314,10 +341,13 @@ class tfcompute:
             else:
                 self.outputs = [np.append(o1, o2, axis=0) for o1, o2 in zip(self.outputs, extra)]
         if self.train:
-            self._train_on_batch(nlist_t, offset, n, fused_entries)
+            if any(e.get("op") == "generic" for e in simmodel._trace_log()[mark:]):
+                self._train_generic(output, offset, n)
+            else:
+                self._train_on_batch(nlist_t, offset, n, fused_entries)
             return
         if self.force_mode_code == _lib.HTF_TF2HOOMD:
-            f = SimModel.compute_outputs(_t(output[0]), s.dtype)
+            f = SimModel.compute_outputs(_t(output[0]).detach(), s.dtype)
             self.force[offset:offset + n] = f
             if m.virial:
                 v = _t(output[1]).to(s.dtype).reshape(n, 9).contiguous()

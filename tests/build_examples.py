@@ -230,3 +230,40 @@ class NlistNN(htf.SimModel):
         x = torch.tanh(x @ w2)
         energy = (x @ w3)[:, 0]
         return htf.compute_nlist_forces(nlist, energy)
+
+
+class NoForceModel(htf.SimModel):
+    # build_examples.py:33-40
+    def compute(self, nlist, positions):
+        neighs_rs = torch.norm(nlist[:, :, :3], dim=2)
+        energy = torch.where(neighs_rs > 0, 1.0 / torch.where(neighs_rs > 0, neighs_rs, torch.ones_like(neighs_rs)),
+                             torch.zeros_like(neighs_rs))
+        pos_norm = torch.norm(positions, dim=1)
+        return energy, pos_norm
+
+
+class TrainModel(htf.SimModel):
+    # build_examples.py:244-268: Dense layers on the sorted 1/r of the closest neighbors; the
+    # `training` flag doubles the energy; `output_zero` zeroes the extra output
+    def setup(self, dim, top_neighs):
+        g = torch.Generator().manual_seed(1)
+        dev = "cuda" if torch.cuda.is_available() else "cpu"
+        self.w1 = (0.3 * torch.randn((top_neighs, dim), generator=g)).to(dev).requires_grad_(True)
+        self.w2 = (0.3 * torch.randn((dim, dim), generator=g)).to(dev).requires_grad_(True)
+        self.w3 = (0.3 * torch.randn((dim, 1), generator=g)).to(dev).requires_grad_(True)
+        self.top_neighs = top_neighs
+        self.output_zero = False
+
+    def compute(self, nlist, positions, training):
+        r = torch.sqrt(torch.sum((nlist[:, :, :3] + 1e-7 / 3) ** 2, dim=2))
+        rinv = torch.where(r > 3e-6, 1.0 / (r + 3e-6), torch.zeros_like(r))
+        top_n = torch.sort(rinv, dim=1, descending=True)[0][:, :self.top_neighs]
+        x = top_n.to(self.w1.dtype) @ self.w1
+        x = x @ self.w2
+        energy = x @ self.w3
+        if training:
+            energy = energy * 2
+        forces = htf.compute_nlist_forces(nlist, energy)
+        if self.output_zero:
+            energy = energy * 0.
+        return forces, energy

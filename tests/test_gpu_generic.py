@@ -121,3 +121,62 @@ def test_mapped_nlist(htf, cuda):
     assert aa.intersection(cg) == {0}
     assert cg == {0, 1, 2} or cg == {0, 1} or cg == {0, 2}
     assert tfc.outputs[1].shape[1:] == (N, NN, 4) and tfc.outputs[2].shape[1:] == (CGN, NN, 4)
+
+
+def test_noforce_graph(htf, cuda):
+    """test_tensorflow.py:300-318: a model that outputs no forces leaves the net force at zero."""
+    sim, system, L = _sim(htf, cuda, 3, 4.0)
+    sim.integrate_nve(0.005)
+    tfc = htf.tfcompute(build_examples.NoForceModel(9, output_forces=False))
+    tfc.attach(sim.nlist_cell(check_period=1), r_cut=5.0, save_output_period=1)
+    for _ in range(3):
+        sim.run(1)
+        np.testing.assert_allclose(sim.net_force.cpu().numpy()[:, :3], 0.0, atol=1e-12)
+    assert tfc.outputs[0].shape[1:] == (9, 9) and tfc.outputs[1].shape[1:] == (9,)
+    assert np.abs(tfc.outputs[0]).max() > 0
+
+
+def test_training_flag_and_generic_training(htf, cuda):
+    """test_tensorflow.py:487-505 test_training_flag: TrainModel (dense layers on sorted 1/r: generic
+    route) trains in batches with Nadam, then is re-attached for inference; the weights moved."""
+    sim, system, L = _sim(htf, cuda, 3, 4.0, dtype=torch.float32, kT=0.8, seed=1)
+    sim.integrate_nve(0.001)
+    model = build_examples.TrainModel(4, dim=1, top_neighs=2, dtype=torch.float32)
+    model.compile(optimizer=htf.optimizers.Nadam(0.01), loss='MeanSquaredError')
+    w0 = [w.copy() for w in model.get_weights()]
+    tfc = htf.tfcompute(model)
+    nlist = sim.nlist_cell()
+    tfc.attach(nlist, train=True, r_cut=5.0, batch_size=4)
+    sim.run(10)
+    w1 = model.get_weights()
+    assert any(np.abs(a - b).max() > 1e-4 for a, b in zip(w0, w1)) and all(np.all(np.isfinite(w)) for w in w1)
+    assert float(model.metrics[0].result()) >= 0.0
+    tfc.attach(nlist, train=False, r_cut=5.0, batch_size=4)
+    sim.run(10)
+    assert np.all(np.isfinite(sim.net_force.cpu().numpy()))
+
+
+def test_model_save_and_load(htf, cuda, tmp_path):
+    """test_tensorflow.py:176-230: train TrainableGraph, save its weights, load them into an
+    inference model (output_forces=True) and run it."""
+    sim, system, L = _sim(htf, cuda, 3, 4.0, dtype=torch.float32, kT=2.0, seed=2)
+    sim.integrate_nve(0.005)
+    model = build_examples.TrainableGraph(16, output_forces=False)
+    model.compile(optimizer=htf.optimizers.Nadam(0.01), loss='MeanSquaredError')
+    tfc = htf.tfcompute(model)
+    nlist = sim.nlist_cell(check_period=1)
+    tfc.attach(nlist, train=True, r_cut=5.0)
+    sim.run(5)
+    path = str(tmp_path / "test-model")
+    model.save_weights(path)
+    trained = model.get_weights()
+    infer = build_examples.TrainableGraph(16, output_forces=True)
+    infer.load_weights(path)
+    for a, b in zip(infer.get_weights(), trained):
+        np.testing.assert_array_equal(a, b)
+    assert np.abs(trained[0] - np.array([1.0, 1.0], dtype=np.float32)).max() > 0  # it did train
+    sim.computes.remove(tfc)  # tfcompute.disable()
+    tfc2 = htf.tfcompute(infer)
+    tfc2.attach(nlist, r_cut=5.0)
+    sim.run(5)
+    assert np.all(np.isfinite(tfc2.force.cpu().numpy())) and np.abs(tfc2.force.cpu().numpy()).max() > 0
