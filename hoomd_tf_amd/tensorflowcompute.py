@@ -160,6 +160,18 @@ class tfcompute:
     def update_coeffs(self):
         pass
 
+    def disable(self):
+        """hoomd compute.disable(): take this compute out of the step loop."""
+        for lst in (self.sim.forces, self.sim.computes):
+            if self in lst:
+                lst.remove(self)
+        self.enabled = False
+
+    def enable(self):
+        if not self.enabled:
+            (self.sim.forces if self.force_mode_code == _lib.HTF_TF2HOOMD else self.sim.computes).append(self)
+            self.enabled = True
+
     def set_reference_forces(self, *forces):
         """tensorflowcompute.py:265-282."""
         if self.force_mode_code == _lib.HTF_TF2HOOMD:

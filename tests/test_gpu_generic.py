@@ -175,7 +175,8 @@ def test_model_save_and_load(htf, cuda, tmp_path):
     for a, b in zip(infer.get_weights(), trained):
         np.testing.assert_array_equal(a, b)
     assert np.abs(trained[0] - np.array([1.0, 1.0], dtype=np.float32)).max() > 0  # it did train
-    sim.computes.remove(tfc)  # tfcompute.disable()
+    tfc.disable()
+    assert tfc not in sim.computes
     tfc2 = htf.tfcompute(infer)
     tfc2.attach(nlist, r_cut=5.0)
     sim.run(5)
