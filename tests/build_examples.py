@@ -109,14 +109,6 @@ class WrapModel(htf.SimModel):
         return rwrap
 
 
-class NoForceModel(htf.SimModel):
-    # build_examples.py:33-41 (energy via nlist_rinv instead of divide_no_nan)
-    def compute(self, nlist, positions):
-        energy = htf.nlist_rinv(nlist)
-        pos_norm = positions.detach().norm(dim=1)
-        return energy, pos_norm
-
-
 class EDSModel(htf.SimModel):
     # build_examples.py:118-135
     def setup(self, set_point):
@@ -267,3 +259,49 @@ class TrainModel(htf.SimModel):
         if self.output_zero:
             energy = energy * 0.
         return forces, energy
+
+
+class TensorSaveModel(htf.SimModel):
+    # build_examples.py:43-46
+    def compute(self, nlist, positions):
+        pos_norm = torch.norm(positions, dim=1)
+        return pos_norm
+
+
+class BenchmarkNonlistModel(htf.SimModel):
+    # build_examples.py:59-64
+    def compute(self, nlist, positions, box):
+        ps = torch.norm(positions, dim=1)
+        energy = torch.where(ps > 0, 1.0 / torch.where(ps > 0, ps, torch.ones_like(ps)), torch.zeros_like(ps))
+        forces = htf.compute_positions_forces(positions, energy)
+        return forces
+
+
+class _Mean:
+    """tf.keras.metrics.Mean"""
+
+    def __init__(self):
+        self.total, self.count = 0.0, 0
+
+    def update_state(self, x):
+        x = x.detach().double()
+        self.total += float(x.sum())
+        self.count += x.numel()
+
+    def result(self):
+        return self.total / max(self.count, 1)
+
+
+class LJRunningMeanModel(htf.SimModel):
+    # build_examples.py:270-286 (plain norm + divide_no_nan: the generic route)
+    def setup(self):
+        self.avg_energy = _Mean()
+
+    def compute(self, nlist, positions, box):
+        r = torch.norm(nlist[:, :, :3], dim=2)
+        inv_r6 = torch.where(r > 0, 1.0 / torch.where(r > 0, r, torch.ones_like(r)) ** 6, torch.zeros_like(r))
+        p_energy = 4.0 / 2.0 * (inv_r6 * inv_r6 - inv_r6)
+        energy = torch.sum(p_energy, dim=1)
+        self.avg_energy.update_state(energy)
+        forces = htf.compute_nlist_forces(nlist, energy)
+        return forces

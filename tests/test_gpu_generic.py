@@ -181,3 +181,45 @@ def test_model_save_and_load(htf, cuda, tmp_path):
     tfc2.attach(nlist, r_cut=5.0)
     sim.run(5)
     assert np.all(np.isfinite(tfc2.force.cpu().numpy())) and np.abs(tfc2.force.cpu().numpy()).max() > 0
+
+
+@pytest.mark.parametrize("batch_size", [0, None])
+def test_nonlist(htf, cuda, batch_size):
+    """test_tensorflow.py:131-153 test_nonlist / test_full_batch: a positions-only model (no neighbor
+    list, compute_positions_forces) on the 32 x 32 lattice."""
+    sim, system, L = _sim(htf, cuda, 32, 4.0, kT=2.0, seed=2)
+    sim.integrate_nve(0.005)
+    tfc = htf.tfcompute(build_examples.BenchmarkNonlistModel(0))
+    if batch_size is None:
+        tfc.attach(batch_size=None)
+    else:
+        tfc.attach()
+    sim.run(10)
+    sim.compute_forces()  # forces of the CURRENT positions
+    f = tfc.force.cpu().numpy()
+    p = system.positions_numpy()
+    r = np.linalg.norm(np.concatenate([p, np.zeros((len(p), 1))], axis=1), axis=1)
+    assert np.all(np.isfinite(f)) and np.abs(f[:, :3]).max() > 0
+    np.testing.assert_allclose(f[:, 3], 1.0 / r, rtol=1e-6)
+
+
+def test_running_mean(htf, cuda):
+    """test_tensorflow.py:384-398: a metric updated from inside compute() over batches of 4."""
+    sim, system, L = _sim(htf, cuda, 3, 4.0, kT=0.8, seed=1)
+    sim.integrate_nve(0.001)
+    model = build_examples.LJRunningMeanModel(32)
+    tfc = htf.tfcompute(model)
+    tfc.attach(sim.nlist_cell(), r_cut=5.0, batch_size=4)
+    sim.run(10)
+    assert model.avg_energy.result() < 0 and model.avg_energy.count == 10 * 9
+
+
+def test_tensor_save(htf, cuda):
+    """test_tensorflow.py:775-788: outputs captured every 2nd call, batches of 3 over 9 particles."""
+    sim, system, L = _sim(htf, cuda, 3, 4.0, kT=1.0, seed=1)
+    sim.integrate_nve(0.005)
+    tfc = htf.tfcompute(build_examples.TensorSaveModel(0, output_forces=False))
+    tfc.attach(batch_size=3, save_output_period=2)
+    sim.run(8)
+    array = tfc.outputs[0].reshape(-1, 9)
+    assert array.shape == (4, 9)
