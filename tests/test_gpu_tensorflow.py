@@ -355,3 +355,41 @@ def test_log_value_and_hook_rules(htf, cuda):
     bare = standin.Simulation(standin.System(pos, L2, dtype=torch.float64, device=cuda))
     with pytest.raises(ValueError, match='integrator'):
         htf.tfcompute(build_examples.LJModel(8, output_forces=False)).attach(bare.nlist_cell(), r_cut=5.0)
+
+
+def test_retrace(htf, cuda):
+    """test_tensorflow.py:507-530: a Python attribute read inside compute() is baked into the traced
+    step; flipping it has no effect until retrace_compute() drops the installed plan."""
+    class Switchable(htf.SimModel):
+        def setup(self):
+            self.double = False
+
+        def compute(self, nlist, positions, box):
+            rinv = htf.nlist_rinv(nlist)
+            inv_r6 = rinv**6
+            p_energy = (8.0 if self.double else 4.0) / 2.0 * (inv_r6 * inv_r6 - inv_r6)
+            return htf.compute_nlist_forces(nlist, htf.reduce_sum(p_energy, axis=1))
+
+    sim, system, L = _sim(htf, cuda, 4, 1.5, kT=None)
+    model = Switchable(32)
+    tfc = htf.tfcompute(model)
+    tfc.attach(sim.nlist_cell(), r_cut=3.0)
+    sim.compute_forces()
+    sim.compute_forces()
+    assert tfc._plan is not None
+    f1 = tfc.force.cpu().numpy().copy()
+    model.double = True  # without retrace
+    sim.compute_forces()
+    np.testing.assert_array_equal(tfc.force.cpu().numpy(), f1)
+    model.retrace_compute()  # with retrace
+    sim.compute_forces()
+    np.testing.assert_allclose(tfc.force.cpu().numpy(), 2.0 * f1, rtol=1e-5, atol=1e-5)  # eager step after the retrace: other summation order
+
+
+def test_sorted(htf, cuda):
+    """test_tensorflow.py:850-866: NlistNN(64, dim=32, top_neighs=8) on the 8 x 8 lattice, r_cut 10."""
+    sim, system, L = _sim(htf, cuda, 8, 4.0, kT=1.0, seed=1)
+    tfc = htf.tfcompute(build_examples.NlistNN(64, dim=32, top_neighs=8))
+    tfc.attach(sim.nlist_cell(check_period=1), r_cut=10.0)
+    sim.run(10)
+    assert np.all(np.isfinite(tfc.force.cpu().numpy()))
