@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--one-kernel", action="store_true",
                     help="eds workload: the whole C4 sweep as one kernel (htf_build_eval_forces2); measured no faster "
                          "than build + eval2 (VALU-bound), so the two kernels stay the default there")
+    ap.add_argument("--sync-train", action="store_true", help="mlp-train: run the training step on the MD stream (no overlap)")
     ap.add_argument("--two-kernel", action="store_true",
                     help="headline run with separate build and evaluator kernels (htf_config.fused = 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -372,26 +373,50 @@ def main():
         pot_mlp = layer.potential()
         opt_desc = htf.optimizers.Adam(1e-3).desc(0, (0.0,))
         opt_state = torch.zeros(htf.ops.optimizer_state_floats(layer.w.numel()), dtype=torch.float32, device=dev)
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        # The trained model does not push particles (hoomd2tf), so the training step need not hold the MD
+        # up: the step's pair vectors and labels are copied to a staging buffer (~0.1 ms on the main
+        # stream) and the 11 ms sweep + all-reduce + optimizer + image refresh run on a SECOND stream
+        # beside the following MD steps (MFMA-bound work next to HBM-bound work).  Same arithmetic,
+        # same weights at the next training step; --sync-train keeps it on the main stream.
+        side = torch.cuda.Stream(device=dev)
+        cap = int(sysm.N * 1.1) + 1024
+        stage_x = torch.empty((cap, NN, 4), dtype=torch.float32, device=dev)
+        stage_y = torch.empty((cap, 4), dtype=torch.float32, device=dev)
+        n_global = float(sysm.N)
+        if dist is not None:
+            t = torch.tensor([n_global], dtype=torch.float64, device=dev)
+            dist.all_reduce(t)
+            n_global = float(t.item())  # particles are conserved: no per-step count exchange
+        train_events = []
 
         def train(timed):
+            nonlocal stage_x, stage_y
             n = sysm.N
-            if timed:
-                ev0.record()
-            x = ctx.nlist_buffer(n, dev)
-            accum = htf.ops.train_pair_grad(pot_mlp, x, sysm.force[:n])
-            n_total = float(n)
-            if dist is not None:
-                packed = torch.cat([accum, accum.new_tensor([n_total])])
-                dist.all_reduce(packed)
-                accum, n_total = packed[:-1].contiguous(), float(packed[-1].item())
-            htf.ops.optimizer_step(layer.w, accum, 1.0 / (4.0 * n_total), opt_state, opt_desc)
-            layer.after_update()
-            if timed:
-                ev1.record()
-                ev1.synchronize()
-                state["train_s"] += ev0.elapsed_time(ev1) * 1e-3
-                state["train_n"] += 1
+            main = torch.cuda.current_stream(dev)
+            if n > stage_x.shape[0]:
+                main.wait_stream(side)
+                stage_x = torch.empty((int(n * 1.1), NN, 4), dtype=torch.float32, device=dev)
+                stage_y = torch.empty((int(n * 1.1), 4), dtype=torch.float32, device=dev)
+            if args.sync_train:
+                x, y, where = ctx.nlist_buffer(n, dev), sysm.force[:n], main
+            else:
+                main.wait_stream(side)  # the previous training step has left the staging buffers
+                stage_x[:n].copy_(ctx.nlist_buffer(n, dev))
+                stage_y[:n].copy_(sysm.force[:n])
+                side.wait_stream(main)
+                x, y, where = stage_x[:n], stage_y[:n], side
+            with torch.cuda.stream(where):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                if timed:
+                    e0.record()
+                accum = htf.ops.train_pair_grad(pot_mlp, x, y)
+                if dist is not None:
+                    dist.all_reduce(accum)
+                htf.ops.optimizer_step(layer.w, accum, 1.0 / (4.0 * n_global), opt_state, opt_desc)
+                layer.after_update()
+                if timed:
+                    e1.record()
+                    train_events.append((e0, e1))
 
     def step(timed=False):
         ts = state["ts"]
@@ -484,8 +509,11 @@ def main():
         }
         dom = "build_pair_vectors" if build_avg_s > eval_avg_s else "eval_forces"
     mfma = args.workload in ("mlp", "mlp-bf16")
-    if train is not None and state["train_n"]:
+    if train is not None and train_events:
+        state["train_n"] = len(train_events)
+        state["train_s"] = sum(a.elapsed_time(b) for a, b in train_events) * 1e-3
         kern["train_step"] = {"avg_ms": state["train_s"] / state["train_n"] * 1e3, "count": state["train_n"],
+                              "stream": "main" if args.sync_train else "second stream, beside the following MD steps",
                               "period": args.train_period, "loss": float(opt_state[20]),
                               "what": "pair-MLP prediction + loss-gradient sweep + all-reduce + Adam + image refresh"}
     if mfma:
