@@ -170,6 +170,11 @@ __global__ __launch_bounds__(256, 1) void mlp_grad_kernel(const typename Vec4<IT
 // 32 accumulator registers instead of 96.  192 MFMAs per tile in this phase; 8 block
 // barriers per round.  Bias / w3 gradients ride along on the VALU.  One partial per block,
 // combined in a fixed order -> deterministic.
+// Measured alternative: the same sweep with v_mfma_f32_16x16x4_f32 and 16-pair tiles (every
+// per-wave array half the size, 242 VGPRs, eight waves = two per SIMD on a CU) was built and is
+// correct, but ran 11.5 ms against 11.05 ms: the block-wide barriers keep both waves of a SIMD
+// in the same phase, so one wave's VALU/LDS work does not land under the other's MFMAs.  Two
+// independently scheduled 4-wave blocks per CU would, but need 166 KB of LDS.
 constexpr int kPS = 36;         // published row stride (floats)
 constexpr int kPB = 32 * kPS;   // one published 32 x 32 block
 constexpr int kSlots = 6;       // per wave: A0 A1 | B0 B1 | phi phid  (108 KB + 49 KB of images: one block per CU)
