@@ -38,7 +38,7 @@ def _worker(rank, world, port, q):
 
         dev = torch.device("cuda:0")
         rcut, rbuf, NN = 2.5, 0.4, 80
-        cells = (12, 6, 6)  # 12 x 6 x 6 fcc cells: two slabs of 6 cells (8.4 sigma >= 2 r_ghost)
+        cells = (6 * world, 6, 6)  # slabs of 6 fcc cells (10 sigma >= 2 r_ghost) side by side
         a = (4.0 / 0.8442) ** (1.0 / 3.0)
         base = np.array([[0, 0, 0], [.5, .5, 0], [.5, 0, .5], [0, .5, .5]])
         grid = np.stack(np.meshgrid(*[np.arange(c) for c in cells], indexing="ij"), -1).reshape(-1, 3)
@@ -201,8 +201,8 @@ def test_training_under_slabs_matches_single_domain(htf, cuda):
     assert abs(out[2][3] - out[1][3]) < 2e-3 * abs(out[1][3])
 
 
-def test_two_slabs_on_one_gpu(htf, cuda):
-    world = 2
+@pytest.mark.parametrize("world", [2, 3])
+def test_slabs_on_one_gpu(htf, cuda, world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
