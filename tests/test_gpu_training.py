@@ -328,3 +328,32 @@ def test_pair_mlp_force_matching_online(htf, cuda):
     got = htf.ops.eval_forces(model.mlp.potential(), x).cpu().numpy()
     want = htf.ops.eval_forces(htf.Potential.pair_mlp(ws, 0.0, 3.0, activation='tanh'), x).cpu().numpy()
     np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_pair_mlp_gradient_random_shapes(htf, cuda, seed):
+    """Random widths (zero-padded operand blocks), NN (fused / two-pass route), activation and label
+    precision against torch double backward."""
+    from hoomd_tf_amd import initializers
+    rng = np.random.default_rng(500 + seed)
+    K, H1, H2 = int(rng.integers(2, 33)), int(rng.integers(1, 65)), int(rng.integers(1, 65))
+    NN = int(rng.choice([5, 17, 33, 64, 90, 128]))
+    act = "tanh" if rng.integers(0, 2) else "linear"
+    N = int(rng.integers(3, 40))
+    nl = _case(600 + seed, N=N, NN=NN)
+    nl64 = nl.astype(np.float64)
+    params = initializers.mlp_params(seed=20 + seed, K=K, H1=H1, H2=H2)
+    for k in ("b1", "b2", "b3"):
+        params[k] = (0.1 * rng.standard_normal(params[k].shape)).astype(np.float32)
+    theta = _flat_params(params)
+    labels = O.lj_model(nl64) * 0.05
+    lab = torch.from_numpy(labels if rng.integers(0, 2) else labels.astype(np.float32)).to(cuda)
+    w = torch.tensor(theta, dtype=torch.float32, device=cuda)
+    pot = htf.Potential.pair_mlp(params, 0.0, 3.0, activation=act, theta=w)
+    accum = htf.ops.train_pair_grad(pot, torch.from_numpy(nl).to(cuda), lab).cpu().numpy()
+    dims = (K, H1, H2)
+    loss, g = G.mse_grad_wrt_params(lambda n, ww: G.pair_mlp_param_forces(n, ww, dims, act=act, create_graph=True),
+                                    torch.from_numpy(nl64), torch.from_numpy(labels), theta)
+    np.testing.assert_allclose(accum[0] / (4 * N), loss, rtol=3e-4)
+    got = accum[1:] / (4 * N)
+    assert np.abs(got - g).max() < 3e-4 * max(np.abs(g).max(), 1e-6), (K, H1, H2, NN, act, np.abs(got - g).max(), np.abs(g).max())
