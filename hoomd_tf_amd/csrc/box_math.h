@@ -11,6 +11,7 @@ template <typename T>
 struct BoxT {
     T L[3], Linv[3], xy, xz, yz;
     int periodic[3];
+    int ortho; // all tilt factors are zero: the shear corrections below subtract exact zeros, skip them
 };
 
 template <typename T>
@@ -24,6 +25,7 @@ static BoxT<T> make_boxt(const htf_box *hb) {
     b.xy = (T)hb->tilt[0];
     b.xz = (T)hb->tilt[1];
     b.yz = (T)hb->tilt[2];
+    b.ortho = (b.xy == (T)0 && b.xz == (T)0 && b.yz == (T)0) ? 1 : 0;
     return b;
 }
 
@@ -38,13 +40,15 @@ __device__ __forceinline__ void min_image(T &x, T &y, T &z, const BoxT<T> &b) {
     if (b.periodic[2]) {
         T img = rint_t<T>(z * b.Linv[2]);
         z -= b.L[2] * img;
-        y -= b.L[2] * b.yz * img;
-        x -= b.L[2] * b.xz * img;
+        if (!b.ortho) { // wave-uniform
+            y -= b.L[2] * b.yz * img;
+            x -= b.L[2] * b.xz * img;
+        }
     }
     if (b.periodic[1]) {
         T img = rint_t<T>(y * b.Linv[1]);
         y -= b.L[1] * img;
-        x -= b.L[1] * b.xy * img;
+        if (!b.ortho) x -= b.L[1] * b.xy * img;
     }
     if (b.periodic[0]) {
         T img = rint_t<T>(x * b.Linv[0]);
