@@ -111,10 +111,17 @@ __device__ __forceinline__ void pair_eval(float x, float y, float z, const PotPa
         const float s = f.s, s2 = s * s;
         float dEds;
         if constexpr (KIND == HTF_POT_LJ) {
-            // build_examples.py:70-74: inv_r6 = rinv**6; 4/2 * (inv_r6*inv_r6 - inv_r6)
-            float s6 = s2 * s2 * s2;
-            e = 2.0f * (s6 * s6 - s6);
-            dEds = 2.0f * (2.0f * s6 - 1.0f) * (6.0f * (s2 * s2 * s));
+            // build_examples.py:70-74: inv_r6 = rinv**6; 4/2 * (inv_r6*inv_r6 - inv_r6).  The chain
+            // 2 dE/ds (ds/dr') / r' = 2 [12 (2 s^6 - 1) s^5] (-s^2) / r' is folded to
+            // -24 (2 s^6 - 1) s^7 / r': five multiplies instead of eight (the evaluators are
+            // VALU-issue bound); s = 0 on masked slots makes e and c vanish by themselves.
+            const float s6 = s2 * s2 * s2;
+            e = 2.0f * fmaf(s6, s6, -s6);
+            const float c = f.cond ? (fmaf(2.0f, s6, -1.0f) * (s6 * s)) * fast_rcp(f.rp) * -24.0f : 0.0f;
+            fx = c * f.tx;
+            fy = c * f.ty;
+            fz = c * f.tz;
+            return;
         } else if constexpr (KIND == HTF_POT_WCA) {
             // layers.py:91-98
             float q = p.sigma * s, q2 = q * q;
