@@ -12,6 +12,7 @@
 #include "htf_common.h"
 #include "htf_internal.h"
 #include "pair_mlp.h"
+#include "pair_math.h"
 
 namespace htf {
 
@@ -122,6 +123,7 @@ extern "C" int htf_potential_create(const htf_potential_desc *d, htf_potential *
         p->pp.sigma = (float)d->sigma;
         // layers.py:97 `true_sig * 2**(1/3)`: fp32 weight times the python double rounded to fp32
         p->pp.wca_cut = p->pp.sigma * (float)1.2599210498948732;
+        p->pp.wca_cut_r2 = sqrt_threshold(p->pp.wca_cut);
         break;
     case HTF_POT_RINV_POLY:
         if (d->n_terms < 1 || d->n_terms > HTF_MAX_POLY_TERMS) {

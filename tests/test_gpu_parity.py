@@ -576,3 +576,25 @@ def test_full_size_lj_rows_and_properties(htf, cuda):
     s = torch.where(rp > 3e-6, 1.0 / (rp + 3e-6), torch.zeros_like(rp))
     e_ref = (2.0 * (s ** 12 - s ** 6)).sum().item()
     assert abs(f[:, 3].double().sum().item() - e_ref) <= 2e-6 * abs(e_ref) + 1e-3
+
+
+@pytest.mark.parametrize("sigma", [0.5, 1.0, 0.8371, 1.7])
+def test_wca_mask_at_the_cutoff_is_the_sqrt_mask(htf, cuda, sigma):
+    """The WCA mask is evaluated as r2 < t (no square root in the kernel) with t chosen so that it equals
+    float32 sqrt(r2) < cut for EVERY r2: sweep +-200 ulps around the cutoff."""
+    cut = np.float32(np.float32(sigma) * np.float32(1.2599210498948732))
+    xs = [cut]
+    for _ in range(200):
+        xs.append(np.nextafter(xs[-1], np.float32(10), dtype=np.float32))
+    lo = cut
+    for _ in range(200):
+        lo = np.nextafter(lo, np.float32(0), dtype=np.float32)
+        xs.append(lo)
+    x = np.array(sorted(xs), dtype=np.float32)
+    nl = np.zeros((len(x), 1, 4), dtype=np.float32)
+    nl[:, 0, 0] = x
+    f = htf.ops.eval_forces(htf.Potential.wca(sigma), torch.from_numpy(nl).to(cuda)).cpu().numpy()
+    inside_gpu = f[:, 3] != 0
+    inside_ref = np.sqrt((x * x).astype(np.float32)).astype(np.float32) < cut
+    np.testing.assert_array_equal(inside_gpu, inside_ref)
+    assert inside_ref.any() and not inside_ref.all()
