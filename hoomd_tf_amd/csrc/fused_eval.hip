@@ -65,9 +65,9 @@ __device__ __forceinline__ unsigned fused_sweep(FusedAcc &acc, const typename Ve
                 // the tensor row, as build_pair_vectors_kernel writes it (fp32 wire, type as a float)
                 const float4 out = make_float4((float)dx, (float)dy, (float)dz, (float)scalar_as_int(pk[t].w));
                 if constexpr (STORE == 1) {
-                    if (keep && q < NN) row[q] = out;
+                    if (keep && q < NN) store_stream(&row[q], out);
                 } else {
-                    if (keep && q >= s_lo) row[q % NN] = out;
+                    if (keep && q >= s_lo) store_stream(&row[q % NN], out);
                 }
             }
             if (keep && q >= q_lo && q < q_hi) {
@@ -110,7 +110,7 @@ __device__ __forceinline__ void fused_row(const unsigned w, const unsigned lane,
         // zero tail / delta zero-fill / live count: pair_vectors.hip, same bookkeeping
         const unsigned filled = Q < NN ? Q : NN;
         const unsigned zero_end = counts_io != nullptr ? counts_io[w] : NN;
-        for (unsigned sl = filled + lane; sl < zero_end; sl += 64) row[sl] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (unsigned sl = filled + lane; sl < zero_end; sl += 64) store_stream(&row[sl], make_float4(0.f, 0.f, 0.f, 0.f));
         if (counts_io != nullptr && lane == 0) counts_io[w] = filled;
     }
     if (Q > NN) {
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void fused_forces_rows2_kernel(
             Q += __popcll(m);
             if (keep && qq < NN) {
                 const float x = (float)dx, y = (float)dy, z = (float)dz;
-                if constexpr (STORE) row[qq] = make_float4(x, y, z, (float)scalar_as_int(pk.w));
+                if constexpr (STORE) store_stream(&row[qq], make_float4(x, y, z, (float)scalar_as_int(pk.w)));
                 float e, ax, ay, az;
                 pair_eval<KIND>(x, y, z, p, e, ax, ay, az);
                 fx += ax;
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void fused_forces_rows2_kernel(
         const unsigned filled = Q < NN ? Q : NN;
         if constexpr (STORE) {
             const unsigned zero_end = counts_io != nullptr ? counts_io[w] : NN;
-            for (unsigned sl = filled + lane; sl < zero_end; sl += 64) row[sl] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (unsigned sl = filled + lane; sl < zero_end; sl += 64) store_stream(&row[sl], make_float4(0.f, 0.f, 0.f, 0.f));
             if (counts_io != nullptr && lane == 0) counts_io[w] = filled;
         }
         if (Q > NN) { // overflow (an error upstream): the generic routine reproduces the slot wrap
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256) void fused_forces2_kernel(
         (void)pair_vector<PT>(pk, pi, box, dx, dy, dz);
         if (keep && q >= lo) {
             const float x = (float)dx, y = (float)dy, z = (float)dz;
-            if constexpr (STORE) row[Q > NN ? q % NN : q] = make_float4(x, y, z, (float)scalar_as_int(pk.w));
+            if constexpr (STORE) store_stream(&row[Q > NN ? q % NN : q], make_float4(x, y, z, (float)scalar_as_int(pk.w)));
             float e, fx, fy, fz;
             pair_eval<KA>(x, y, z, pa, e, fx, fy, fz);
             ax += fx; ay += fy; az += fz; ae += e;
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(256) void fused_forces2_kernel(
         const unsigned filled = Q < NN ? Q : NN;
         if constexpr (STORE) {
             const unsigned zero_end = counts_io != nullptr ? counts_io[w] : NN;
-            for (unsigned sl = filled + lane; sl < zero_end; sl += 64) row[sl] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (unsigned sl = filled + lane; sl < zero_end; sl += 64) store_stream(&row[sl], make_float4(0.f, 0.f, 0.f, 0.f));
             if (counts_io != nullptr && lane == 0) counts_io[w] = filled;
         }
         if (do_rdf && lane == 0 && filled < NN) { // the row's zero padding

@@ -65,6 +65,24 @@ __device__ __forceinline__ float group_sum(float v) {
     return v;
 }
 
+// Streaming (nontemporal) 16/32-byte store for the pair-vector tensor.  The tensor is 268 MB per step
+// at C3 and is written once; with ordinary (write-back, allocating) stores it sweeps the L2 and the
+// Infinity Cache clean of the index rows and the 2 MB position table the same kernel is gathering
+// from, and the kernel's load and store phases add up instead of overlapping: 93 us.  With `nt`
+// stores: 63 us.  The compiler merges the component stores into one global_store_dwordx4 ... nt.
+__device__ __forceinline__ void store_stream(float4 *p, const float4 &v) {
+    __builtin_nontemporal_store(v.x, &p->x);
+    __builtin_nontemporal_store(v.y, &p->y);
+    __builtin_nontemporal_store(v.z, &p->z);
+    __builtin_nontemporal_store(v.w, &p->w);
+}
+__device__ __forceinline__ void store_stream(double4 *p, const double4 &v) {
+    __builtin_nontemporal_store(v.x, &p->x);
+    __builtin_nontemporal_store(v.y, &p->y);
+    __builtin_nontemporal_store(v.z, &p->z);
+    __builtin_nontemporal_store(v.w, &p->w);
+}
+
 // number of set bits of a wave ballot below this lane: v_mbcnt_lo/hi, two instructions
 // (the portable popcount(m & ((1 << lane) - 1)) costs a 64-bit shift, mask and two bit counts)
 __device__ __forceinline__ unsigned ballot_rank(unsigned long long m) {

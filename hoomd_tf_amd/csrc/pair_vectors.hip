@@ -79,9 +79,9 @@ __device__ __forceinline__ unsigned sweep(typename Vec4<DT>::type *__restrict__ 
             out.x = (DT)dx; out.y = (DT)dy; out.z = (DT)dz;
             out.w = (DT)scalar_as_int(pk[t].w);
             if constexpr (!REPLAY) {
-                if (keep && q < NN) row[q] = out;
+                if (keep && q < NN) store_stream(&row[q], out);
             } else {
-                if (keep && q >= lo) row[q % NN] = out;
+                if (keep && q >= lo) store_stream(&row[q % NN], out);
             }
         }
     }
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void build_pair_vectors_kernel(
     // previous call and zeros behind them, so only slots [filled, previous) need re-zeroing --
     // the padding (26 % of the tensor at C3) is not rewritten every step.
     const unsigned zero_end = counts_io != nullptr ? counts_io[w] : NN;
-    for (unsigned s = filled + lane; s < zero_end; s += 64) row[s] = zero;
+    for (unsigned s = filled + lane; s < zero_end; s += 64) store_stream(&row[s], zero);
     if (counts_io != nullptr && lane == 0) counts_io[w] = filled;
 
     if (Q > NN) {
