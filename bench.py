@@ -52,8 +52,8 @@ def parse():
     ap.add_argument("--sort", action="store_true", help="enable the stand-in's particle sorter (HOOMD SFCPack analogue; measured: no kernel gain)")
     ap.add_argument("--no-fused", action="store_true", help="skip the extra variants (two-kernel dataflow, tensor-less fused mode)")
     ap.add_argument("--one-kernel", action="store_true",
-                    help="eds workload: the whole C4 sweep as one kernel (htf_build_eval_forces2); measured no faster "
-                         "than build + eval2 (VALU-bound), so the two kernels stay the default there")
+                    help="eds workload: the whole C4 sweep as one kernel (htf_build_eval_forces2) -- the default since the "
+                         "tensor is written with streaming stores; --two-kernel selects build + eval2")
     ap.add_argument("--sync-train", action="store_true", help="mlp-train: run the training step on the MD stream (no overlap)")
     ap.add_argument("--two-kernel", action="store_true",
                     help="headline run with separate build and evaluator kernels (htf_config.fused = 0)")
@@ -183,14 +183,14 @@ def run_eds(args, htf, standin, dev):
 
     def launch_all(stream, timed):
         """One C4 step on `stream`: a handful of C-ABI launches + one memset, no host synchronisation.
-        Default: the build kernel, then htf_eval_forces2 re-reading the tensor.  --one-kernel: the
-        whole sweep as ONE kernel (htf_build_eval_forces2 writes the tensor and evaluates both
-        potentials, the CV partials and the RDF histogram from registers) -- 369 us against
-        190 + 169 us: with two potentials, an exp and the histogram per candidate the fused form
-        is VALU-bound, so here fusion buys nothing."""
+        Default: the whole sweep as ONE kernel (htf_build_eval_forces2 writes the tensor with
+        streaming stores and evaluates both potentials, the CV partials and the RDF histogram from
+        registers): 251 us.  --two-kernel: the build kernel, then htf_eval_forces2 re-reading the
+        tensor: 191 + 157 us.  (Before the tensor stores were nontemporal the one-kernel form took
+        369 us and the two kernels were the default.)"""
         hist.zero_()
         t0 = mark() if timed else None
-        if args.one_kernel:
+        if not args.two_kernel:
             check(lib.htf_build_eval_forces2(lj.handle, gauss.handle, pv.data_ptr(), sysm.pos.data_ptr(), F32, N, NN, 0, N,
                                              C.byref(sysm.box), ptr["nl"][0], ptr["nl"][1], ptr["nl"][2], args.rcut,
                                              sysm.force.data_ptr(), bias.data_ptr(), F32, partials_f.data_ptr(),

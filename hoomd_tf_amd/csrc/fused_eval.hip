@@ -171,29 +171,26 @@ __global__ __launch_bounds__(256) void fused_forces_kernel(const typename Vec4<P
                                        out_f64, p, check_count, positions_out, dest, counts_io);
 }
 
-// Measured alternatives for the fast path below (C3, tensor written / not written): one row per
-// wave 102 / 65 us; two rows 92 / 53 us (this kernel); four rows 97 / 66 us; survivors compacted
+// Measured alternatives for the fast path below (C3, tensor written / not written), with ordinary
+// tensor stores: one row per wave 102 / 65 us; two rows 92 / 53 us (this kernel); four rows
+// 97 / 66 us; survivors compacted
 // into a wave-private LDS row first and evaluated from there in two trips instead of three, with
 // full-width tensor stores, 94 / 57 us; evaluation made branch-free so that the two rows' arithmetic
-// can pack into v_pk_* instructions 96 / 56 us.
+// can pack into v_pk_* instructions 96 / 56 us.  With streaming tensor stores (store_stream,
+// htf_common.h) the written variant takes 63 us for one, two and four rows per wave alike.
 // Two rows per wave with ALL their index loads, then all their gathers, issued before any
 // arithmetic: twice the bytes in flight per wave slot while the evaluator's VALU work (which,
 // unlike the plain build, this kernel has plenty of) runs under the other row's memory latency.
 // Fast path for the common case (every row of the pair has 1..192 list entries and does not
 // overflow NN); anything else is redone by the generic single-row routine.
 template <int KIND, bool STORE, int R, typename PT>
-__global__ __launch_bounds__(256) void fused_forces_rows2_kernel(
-    const typename Vec4<PT>::type *__restrict__ pos, unsigned N, unsigned NN, unsigned offset, unsigned batch,
-    BoxT<PT> box, const unsigned *__restrict__ n_neigh, const unsigned *__restrict__ nlist,
-    const unsigned *__restrict__ head_list, PT rmaxsq, void *__restrict__ force, int out_f64, PotParams pin,
-    unsigned *__restrict__ check_count, float4 *__restrict__ positions_out, float4 *__restrict__ dest,
-    unsigned *__restrict__ counts_io) {
+__device__ __forceinline__ void fused_rows_group(
+    const unsigned w0, const unsigned lane, const typename Vec4<PT>::type *__restrict__ pos, unsigned N, unsigned NN,
+    unsigned offset, unsigned batch, const BoxT<PT> &box, const unsigned *__restrict__ n_neigh,
+    const unsigned *__restrict__ nlist, const unsigned *__restrict__ head_list, PT rmaxsq, void *__restrict__ force,
+    int out_f64, const PotParams &p, unsigned *__restrict__ check_count, float4 *__restrict__ positions_out,
+    float4 *__restrict__ dest, unsigned *__restrict__ counts_io) {
     using PV = typename Vec4<PT>::type;
-    const PotParams p = resolve_theta<KIND>(pin);
-    const unsigned lane = threadIdx.x & 63u;
-    const unsigned wv = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-    const unsigned w0 = R * wv;
-    if (w0 >= batch) return;
     unsigned nn[R];
     bool fast = w0 + R <= batch;
 #pragma unroll
@@ -289,6 +286,28 @@ __global__ __launch_bounds__(256) void fused_forces_rows2_kernel(
         }
 }
 
+// The kernel strides over the row groups so that HTF_FUSED_GRID=<workgroups per CU> can launch it
+// persistently for A/B runs.  tools/store_probe.hip says a persistent grid helps a bare
+// load-chain + streaming-store kernel (65 -> 46 us); this kernel, whose rows differ in length
+// and which has arithmetic to hide its loads under, is best with one group per wave
+// (C3, tensor written: 62.5 us; 4 / 8 / 12 / 16 workgroups per CU: 84 / 78 / 69 / 68 us), the default.
+template <int KIND, bool STORE, int R, typename PT>
+__global__ __launch_bounds__(256) void fused_forces_rows2_kernel(
+    const typename Vec4<PT>::type *__restrict__ pos, unsigned N, unsigned NN, unsigned offset, unsigned batch,
+    BoxT<PT> box, const unsigned *__restrict__ n_neigh, const unsigned *__restrict__ nlist,
+    const unsigned *__restrict__ head_list, PT rmaxsq, void *__restrict__ force, int out_f64, PotParams pin,
+    unsigned *__restrict__ check_count, float4 *__restrict__ positions_out, float4 *__restrict__ dest,
+    unsigned *__restrict__ counts_io) {
+    const PotParams p = resolve_theta<KIND>(pin);
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned wv = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const unsigned nw = (gridDim.x * blockDim.x) >> 6;
+#pragma unroll 1
+    for (unsigned w0 = R * wv; w0 < batch; w0 += R * nw)
+        fused_rows_group<KIND, STORE, R, PT>(w0, lane, pos, N, NN, offset, batch, box, n_neigh, nlist, head_list, rmaxsq,
+                                             force, out_f64, p, check_count, positions_out, dest, counts_io);
+}
+
 template <int KIND, bool VIRIAL, typename PT>
 static int launch_fused(const void *pos, unsigned N, unsigned NN, unsigned offset, unsigned batch, const htf_box *hb,
                         const unsigned *n_neigh, const unsigned *nlist, const unsigned *head_list, double rmax,
@@ -299,15 +318,20 @@ static int launch_fused(const void *pos, unsigned N, unsigned NN, unsigned offse
     if constexpr (!VIRIAL) {
         static const char *rows_env = getenv("HTF_FUSED_ROWS"); // A/B runs: 1 | 2 | 4 rows per wave
         const int rows = rows_env ? atoi(rows_env) : 2;
+        static const char *grid_env = getenv("HTF_FUSED_GRID"); // A/B runs: workgroups per CU, 0 = one wave per group
+        static const int per_cu = grid_env ? atoi(grid_env) : 0;
+        static const int n_cu = device_cu_count();
 #define HTF_ROWS_LAUNCH(ST, RR)                                                                                        \
-    hipLaunchKernelGGL((fused_forces_rows2_kernel<KIND, ST, RR, PT>), dim3(((batch + RR - 1) / RR + 3) / 4), dim3(256), 0, s, \
+    const unsigned full = ((batch + RR - 1) / RR + 3) / 4;                                                             \
+    const unsigned grid = per_cu > 0 && (unsigned)(per_cu * n_cu) < full ? (unsigned)(per_cu * n_cu) : full;           \
+    hipLaunchKernelGGL((fused_forces_rows2_kernel<KIND, ST, RR, PT>), dim3(grid), dim3(256), 0, s, \
                        (const typename Vec4<PT>::type *)pos, N, NN, offset, batch, b, n_neigh, nlist, head_list,       \
                        (PT)(rc * rc), force, out_f64, p, check_count, positions_out, dest, counts_io)
         if (rows == 2 || rows == 4) {
             if (rows == 2) {
-                if (dest != nullptr) HTF_ROWS_LAUNCH(true, 2); else HTF_ROWS_LAUNCH(false, 2);
+                if (dest != nullptr) { HTF_ROWS_LAUNCH(true, 2); } else { HTF_ROWS_LAUNCH(false, 2); }
             } else {
-                if (dest != nullptr) HTF_ROWS_LAUNCH(true, 4); else HTF_ROWS_LAUNCH(false, 4);
+                if (dest != nullptr) { HTF_ROWS_LAUNCH(true, 4); } else { HTF_ROWS_LAUNCH(false, 4); }
             }
             return check_launch("fused_forces_rows2_kernel");
         }

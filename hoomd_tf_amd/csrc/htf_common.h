@@ -65,6 +65,15 @@ __device__ __forceinline__ float group_sum(float v) {
     return v;
 }
 
+// compute units of the current device (host side; 256 on MI355X)
+inline int device_cu_count() {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+        return 256;
+    return n;
+}
+
 // Streaming (nontemporal) 16/32-byte store for the pair-vector tensor.  The tensor is 268 MB per step
 // at C3 and is written once; with ordinary (write-back, allocating) stores it sweeps the L2 and the
 // Infinity Cache clean of the index rows and the 2 MB position table the same kernel is gathering

@@ -224,16 +224,23 @@ def eval_forces2(pot_a, pot_b, nlist, out_a=None, out_b=None, partials=None, out
 
 
 def build_eval_forces2(pot_a, pot_b, pos, n_neigh, head_list, nlist, box, r_cut, NN, offset=0, batch_size=None,
-                       n_local=None, out_dtype=None, partials=None, rdf=None, pair_vectors=None, periodic=(1, 1, 1)):
+                       n_local=None, out_dtype=None, partials=None, rdf=None, pair_vectors=None, periodic=(1, 1, 1),
+                       out_a=None, out_b=None):
     """build_pair_vectors + eval_forces2 in ONE kernel (config C4's sweep): -> (forces_a, forces_b).
     ``partials``: num_partials_fused(B) floats; ``rdf = (r0, r1, hist)``; ``pair_vectors`` (fp32
     [B, NN, 4], optional) also receives the tensor."""
     _dev(pos, "pos")
     N = int(n_neigh.shape[0]) if n_local is None else int(n_local)
     B = N - offset if batch_size is None else int(batch_size)
-    od = out_dtype or pos.dtype
-    out_a = torch.empty((B, 4), dtype=od, device=pos.device)
-    out_b = torch.empty((B, 4), dtype=od, device=pos.device)
+    od = out_dtype or (out_a.dtype if out_a is not None else pos.dtype)
+    if out_a is None:
+        out_a = torch.empty((B, 4), dtype=od, device=pos.device)
+    if out_b is None:
+        out_b = torch.empty((B, 4), dtype=od, device=pos.device)
+    _dev(out_a, "out_a")
+    _dev(out_b, "out_b", out_a.dtype)
+    if out_a.shape[0] < B or out_b.shape[0] < B:
+        raise ValueError("out_a / out_b must hold %d rows" % B)
     if B == 0:
         return out_a, out_b
     b = box if isinstance(box, _lib.Box) else _lib.make_box(box, periodic)

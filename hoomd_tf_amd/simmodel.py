@@ -469,10 +469,14 @@ def _biased_forces(nl, energy):
     cv.value = torch.empty(1, dtype=torch.float32, device=t.device)
     ops.reduce_partials(partials, n, 1.0 / B, cv.value)
     if not alpha.done:
+        mark = len(_trace_log())
         alpha.eds(cv.value)  # htf_eds_update on the device scalar
+        del _trace_log()[mark:]  # the layer's own "stateful" entry: covered by the "biased" entry below
         alpha.done = True
     ops.bias_combine(fa, fb, alpha.eds.state[2:3], cv.value)
-    _trace_log().append({"stateful": "eds-bias"})
+    # "biased": what tfcompute needs to replay this step as ONE kernel (htf_build_eval_forces2)
+    _trace_log().append({"stateful": "eds-bias", "forces": fa, "nlist": nl,
+                         "biased": {"pot_a": cache[kb], "pot_b": cache[kg], "cv": cv, "eds": alpha.eds}})
     return fa
 
 
@@ -541,7 +545,9 @@ def compute_rdf(nlist, r_range, type_tensor=None, nbins=100, type_i=None, type_j
     One fused histogram pass over the pair vectors (type masking included)."""
     t = nlist.tensor if isinstance(nlist, Nlist) else nlist
     ops._dev(t, "nlist")
-    _trace_log().append({"op": "compute_rdf"})  # an observable: keeps the model on the eager path
+    # an observable: a model whose outputs are saved stays on the eager path; when nothing reads the
+    # outputs (save_output_period None) tfcompute may replay the step without it
+    _trace_log().append({"op": "compute_rdf", "observable": True})
     r0, r1 = float(r_range[0]), float(r_range[1])
     hist = torch.zeros(nbins + 2, dtype=torch.int32, device=t.device)
     tt, stride = None, 0

@@ -94,6 +94,7 @@ class tfcompute:
         self.force = torch.zeros((s.N, 4), dtype=s.dtype, device=s.device)
         self.virial = torch.zeros(6 * s.N, dtype=s.dtype, device=s.device)
         self._plan = None
+        self._bplan = None  # EDS-biased model replayed as one kernel (see _maybe_install_plan)
         self._ctx_ran = False
         self.model._plan = None
         self.log_name = 'tensorflow'  # m_log_name, TensorflowCompute.cc:62
@@ -211,6 +212,10 @@ class tfcompute:
             return
         if domain is not None:
             domain.exchange_end()
+        if self._bplan is not None and self.model._plan is self._bplan:
+            self._calls += 1
+            self._run_biased_plan()
+            return
         s = self.system
         bs = s.N if self.batch_size == 0 else self.batch_size
         simmodel._trace_log().clear()
@@ -319,7 +324,39 @@ class tfcompute:
             self._plan = fused[0]["potential"]
             self.model._plan = self._plan
             self.cpp_force.set_potential(self._plan)
+        else:
+            # config C4's shape: closed-form base energy + alpha * soft-RDF CV (+ observables nobody
+            # saves).  Replayed as htf_build_eval_forces2: tensor, both force sets and the CV partials
+            # from one kernel, then the device-side EDS update and the force assembly.
+            biased = [e for e in log if "biased" in e]
+            rest = [e for e in log if "biased" not in e and not e.get("observable")]
+            if (self.force_mode_code == _lib.HTF_TF2HOOMD and nbatch == 1 and len(biased) == 1 and not rest
+                    and biased[0].get("is_output") and not self.save_output_period and not self.model.virial
+                    and not self.model.check_nlist and int(self.fused) == 2 and self.system.dtype == torch.float32
+                    and getattr(self._nlist, "domain", None) is None):
+                self._bplan = dict(biased[0]["biased"])
+                self.model._plan = self._bplan
         log.clear()
+
+    def _run_biased_plan(self):
+        s, nl, bp = self.system, self._nlist, self._bplan
+        NN = self.nneighbor_cutoff
+        if bp.get("n") != s.N:
+            bp["n"] = s.N
+            bp["pv"] = torch.empty((s.N, NN, 4), dtype=torch.float32, device=s.device)
+            bp["fb"] = torch.empty((s.N, 4), dtype=s.dtype, device=s.device)
+            bp["np"] = ops.num_partials_fused(s.N)
+            bp["partials"] = torch.empty(bp["np"], dtype=torch.float32, device=s.device)
+            bp["cv_value"] = torch.empty(1, dtype=torch.float32, device=s.device)
+        ops.build_eval_forces2(bp["pot_a"], bp["pot_b"], s.pos, nl.n_neigh, nl.head_list, nl.nlist, s.box, self.r_cut, NN,
+                               n_local=s.N, partials=bp["partials"], pair_vectors=bp["pv"], out_a=self.force, out_b=bp["fb"])
+        ops.reduce_partials(bp["partials"], bp["np"], 1.0 / s.N, bp["cv_value"])
+        bp["cv"].value = bp["cv_value"]
+        eds = bp["eds"]  # EDSLayer.__call__ without the trace entry
+        _lib.check(_lib.lib.htf_eds_update(eds.state.data_ptr(), bp["cv_value"].data_ptr(), eds.set_point, eds.period,
+                                           eds.learning_rate, eds.cv_scale, ops._stream(eds.state)))
+        ops.bias_combine(self.force, bp["fb"], eds.state[2:3], bp["cv_value"])
+        self._last = (bp["pv"], ops.copy_positions(s.pos, offset=0, N=s.N, unstuff4=True), 0, s.N)
 
     def _finish_update(self, batch_index, offset, n):
         """tensorflowcompute.py:313-345 (inference branch)."""

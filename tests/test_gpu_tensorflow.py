@@ -295,6 +295,50 @@ def test_eds_rdf_model_steps_match_oracle(htf, cuda):
     np.testing.assert_allclose(tfc.outputs[2][-1], rdf_ref, rtol=1e-4)
 
 
+def test_eds_rdf_model_replayed_as_one_kernel(htf, cuda):
+    """config C4 with nobody saving the outputs: after the first (eager) step tfcompute replays
+    the step as htf_build_eval_forces2 + device-side EDS update.  Every step's forces, cv and
+    alpha against the oracle composite on the same pair vectors, as in the eager test above."""
+    from hoomd_tf_amd import standin
+    pos, L, a = standin.fcc_positions(4, 0.8442)
+    pos = pos + 0.03 * a * np.random.default_rng(2).standard_normal(pos.shape)
+    system = standin.System(pos, L, dtype=torch.float32, device=cuda)
+    sim = standin.Simulation(system)
+    sim.integrate_nve(0.002)
+    model = build_examples.EDSRDFModel(64, set_point=9.0, r0=1.1, gap=0.05, period=8, learning_rate=0.5)
+    tfc = htf.tfcompute(model)
+    cell = sim.nlist_cell(check_period=1)
+    tfc.attach(cell, r_cut=2.5)
+    ref_eds = O.EDSLayer(9.0, 8, 0.5)
+    for step in range(20):
+        pos_before = system.pos.clone()
+        sim.run(1)
+        assert tfc._bplan is not None  # installed by the first (eager) step
+        nl = tfc.get_nlist_array().astype(np.float32).astype(np.float64)
+        _, cv_ref = O.eds_rdf_model(nl, 0.0, 1.1, 0.05)
+        a_ref = float(ref_eds(cv_ref))
+        f_ref, _ = O.eds_rdf_model(nl, a_ref, 1.1, 0.05)
+        np.testing.assert_allclose(float(tfc._bplan["cv"].value), cv_ref, rtol=2e-5)
+        np.testing.assert_allclose(float(model.eds_bias.alpha), a_ref, rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(tfc.get_forces_array(), f_ref, rtol=2e-4, atol=2e-3)
+        if step > 0:  # the replay's tensor is the build kernel's tensor, bit for bit
+            want = htf.ops.build_pair_vectors(pos_before, cell.n_neigh, cell.head_list, cell.nlist, system.box, 2.5, 64)
+            assert torch.equal(tfc._last[0], want)
+            np.testing.assert_array_equal(tfc.get_positions_array()[:, :3], pos_before[:, :3].double().cpu().numpy())
+    assert abs(a_ref) > 1e-3
+    # the same trajectory as the eager path (summation order differs between the one-kernel and two-kernel sweeps)
+    system2 = standin.System(pos, L, dtype=torch.float32, device=cuda)
+    sim2 = standin.Simulation(system2)
+    sim2.integrate_nve(0.002)
+    model2 = build_examples.EDSRDFModel(64, set_point=9.0, r0=1.1, gap=0.05, period=8, learning_rate=0.5)
+    tfc2 = htf.tfcompute(model2)
+    tfc2.attach(sim2.nlist_cell(check_period=1), r_cut=2.5, save_output_period=1)
+    sim2.run(20)
+    assert tfc2._bplan is None
+    np.testing.assert_allclose(system.pos.cpu().numpy(), system2.pos.cpu().numpy(), atol=2e-4)
+    np.testing.assert_allclose(float(model.eds_bias.alpha), float(model2.eds_bias.alpha), rtol=1e-3, atol=1e-5)
+
+
 def test_pair_mlp_model_runs_traced(htf, cuda):
     """config-3 style model through SimModel/tfcompute: traced path, finite forces."""
     from hoomd_tf_amd import standin

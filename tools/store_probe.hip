@@ -8,7 +8,15 @@
 // MODE 0: stores only.  MODE 1: one dependent load (n[idx]) before the stores.
 // MODE 2: chain of three dependent loads (n -> head -> idx list element) before the stores.
 // ROWS: rows per wave (sequential).  PERSIST: grid-stride over rows with a fixed grid.
-template <int MODE, int ROWS, bool PERSIST>
+__device__ __forceinline__ void st_nt(float4 *p, const float4 &v) {
+    __builtin_nontemporal_store(v.x, &p->x);
+    __builtin_nontemporal_store(v.y, &p->y);
+    __builtin_nontemporal_store(v.z, &p->z);
+    __builtin_nontemporal_store(v.w, &p->w);
+}
+
+// NT: streaming (nontemporal) stores instead of ordinary write-back stores
+template <int MODE, int ROWS, bool PERSIST, bool NT = false>
 __global__ __launch_bounds__(256) void k(float4 *__restrict__ dest, const unsigned *__restrict__ a,
                                          const unsigned *__restrict__ b, const unsigned *__restrict__ c,
                                          unsigned nrows) {
@@ -33,8 +41,13 @@ __global__ __launch_bounds__(256) void k(float4 *__restrict__ dest, const unsign
             }
             float4 o = make_float4(v, v, v, v);
             float4 *p = dest + (size_t)row * 128;
-            p[lane] = o;
-            p[64 + lane] = o;
+            if (NT) {
+                st_nt(p + lane, o);
+                st_nt(p + 64 + lane, o);
+            } else {
+                p[lane] = o;
+                p[64 + lane] = o;
+            }
         }
     }
 }
@@ -86,7 +99,7 @@ static void run_front(const char *name, float4 *d, unsigned *a, unsigned *b, uns
     printf("%-52s %7.1f us  %.2f TB/s\n", name, best * 1e3, nrows * 2048.0 / best / 1e9);
 }
 
-template <int MODE, int ROWS, bool PERSIST>
+template <int MODE, int ROWS, bool PERSIST, bool NT = false>
 static void run(const char *name, float4 *d, unsigned *a, unsigned *b, unsigned *c, unsigned nrows) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
@@ -96,7 +109,7 @@ static void run(const char *name, float4 *d, unsigned *a, unsigned *b, unsigned 
     float best = 1e9;
     for (int rep = 0; rep < 5; ++rep) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL((k<MODE, ROWS, PERSIST>), dim3(grid), dim3(256), 0, 0, d, a, b, c, nrows);
+        hipLaunchKernelGGL((k<MODE, ROWS, PERSIST, NT>), dim3(grid), dim3(256), 0, 0, d, a, b, c, nrows);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms;
@@ -128,6 +141,11 @@ int main() {
     run<2, 4, false>("3 dependent loads, 4 rows/wave (sequential)", d, a, b, c, nrows);
     run<2, 1, true>("3 dependent loads, persistent 2048 blocks", d, a, b, c, nrows);
     run<2, 4, true>("3 dependent loads, persistent, 4 rows/trip", d, a, b, c, nrows);
+    run<0, 1, false, true>("NT stores only, 1 row/wave", d, a, b, c, nrows);
+    run<1, 1, false, true>("NT, 1 dependent load, 1 row/wave", d, a, b, c, nrows);
+    run<2, 1, false, true>("NT, 3 dependent loads, 1 row/wave", d, a, b, c, nrows);
+    run<2, 4, false, true>("NT, 3 dependent loads, 4 rows/wave (sequential)", d, a, b, c, nrows);
+    run<2, 1, true, true>("NT, 3 dependent loads, persistent 2048 blocks", d, a, b, c, nrows);
     run_front<2>("3 dependent loads, 2 rows/wave, loads up front", d, a, b, c, nrows);
     run_front<4>("3 dependent loads, 4 rows/wave, loads up front", d, a, b, c, nrows);
     run_front<8>("3 dependent loads, 8 rows/wave, loads up front", d, a, b, c, nrows);
