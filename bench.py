@@ -541,6 +541,10 @@ def main():
             corr = 2.0 if dom == "eval_forces" else 1.0
             roof["traffic"] = (rd * corr + wr) * 1024.0
             roof["traffic_source"] = "profiles/r01_bench_lj_pmc_hbm.json (FETCH_SIZE x%g + WRITE_SIZE)" % corr
+            # the rate the memory system actually ran at: below `achieved` because the zero tail of a row is
+            # only rewritten where the row shrank since the last step (htf_context keeps per-row counts), so
+            # fewer bytes move than the [N, NN, 4] contract counts
+            roof["traffic_GBps"] = roof["traffic"] / (kern[dom]["avg_us"] * 1e-6) / 1e9
         except (OSError, KeyError, ValueError):
             pass
 
