@@ -11,10 +11,11 @@ constexpr int kH = 64;  // hidden width (padded with zero weights below 64)
 
 // Offsets (in floats) inside the device image buffer / LDS.  One operand block covers a
 // 32 x 32 (feature x feature) weight tile: fp32 [g 4][lane 64][4 floats] = 1024 floats,
-// bf16 [s 2][lane 64][8 bf16] = 512 floats.
-template <bool BF16>
+// bf16 [s 2][lane 64][8 bf16] = 512 floats; split (HTF_MLP_SPLIT) three such bf16 blocks
+// [part 3: hi, mid, lo][s 2][lane 64][8 bf16] = 1536 floats.  P = htf_mlp_precision.
+template <int P>
 struct Img {
-    static constexpr int BS = BF16 ? 512 : 1024;
+    static constexpr int BS = P == 0 ? 1024 : (P == 1 ? 512 : 1536);
     static constexpr int L1 = 0;            // [nb 2]
     static constexpr int L2 = 2 * BS;       // [nb 2][kb 2]
     static constexpr int B2 = 6 * BS;       // [fb 2][kb 2]
@@ -24,11 +25,12 @@ struct Img {
     static constexpr int TabW3 = TabB2 + 64;
     static constexpr int TabC = TabW3 + 64; // [h 2][v 16] RBF centres
     static constexpr int TabB3 = TabC + 32; // output bias (+3 pad floats)
-    static constexpr int Floats = TabB3 + 4; // fp32: 12516 floats (50 KB); bf16: 6372 floats (25 KB)
+    static constexpr int Floats = TabB3 + 4; // fp32: 12516 floats (50 KB); bf16: 6372 (25 KB); split: 18660 (75 KB)
 };
 
 // Every weight-carrying element of an image is theta[map[e]] (or 0 when map[e] < 0):
-// e < kMapW indexes the operand blocks element-wise (fp32 float / bf16 half, both 12288),
+// e < kMapW indexes the operand blocks element-wise (fp32 float / bf16 half, both 12288; the split
+// images use the bf16 order, element e of block b landing in each of the block's three parts),
 // then 192 table floats (TabB1, TabB2, TabW3) and the output bias.
 constexpr int kMapW = 12 * 1024;
 constexpr int kMapT = 192;

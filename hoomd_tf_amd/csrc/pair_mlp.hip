@@ -31,52 +31,106 @@
 
 namespace htf {
 
-// acc += A(image) * B(prev), over one 32-feature block of the previous layer:
-// 16 k-steps, the image supplies 4 steps per ds_read_b128
-__device__ __forceinline__ void mfma_block(f32x16 &acc, const float *img, unsigned lane, const f32x16 &prev) {
-    const float4 *p = reinterpret_cast<const float4 *>(img) + lane;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        float4 w = p[g * 64];
-        acc = HTF_MFMA(w.x, prev[4 * g + 0], acc);
-        acc = HTF_MFMA(w.y, prev[4 * g + 1], acc);
-        acc = HTF_MFMA(w.z, prev[4 * g + 2], acc);
-        acc = HTF_MFMA(w.w, prev[4 * g + 3], acc);
-    }
-}
-
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 
-// bf16 operands, fp32 accumulation: v_mfma_f32_32x32x16_bf16, two k-steps per 32-feature
-// block.  Accumulator registers 8s..8s+7, converted pairwise (v_cvt_pk_bf16_f32), ARE the B
-// fragment of k-step s: element j of lane half h is feature 16s + 8(j>>2) + 4h + (j&3) --
-// the same feature set f0(8s+j) + 4h as in the fp32 path, so tables and RBF centres are
-// shared and only the weight images differ.
-__device__ __forceinline__ void mfma_block_bf16(f32x16 &acc, const float *img, unsigned lane, const f32x16 &prev) {
-    const bf16x8 *p = reinterpret_cast<const bf16x8 *>(img) + lane;
+// B operand of one 32-feature block of the previous layer (an accumulator tile, see above), in the
+// form the precision's MFMA takes.  Prepared once per tile and used by every output block.
+template <int P> struct BOp;
+template <> struct BOp<HTF_MLP_FP32> { f32x16 v; };
+template <> struct BOp<HTF_MLP_BF16> { bf16x8 b[2]; };
+template <> struct BOp<HTF_MLP_SPLIT> { bf16x8 hi[2], mid[2], lo[2]; };
+
+// bf16 operands: accumulator registers 8s..8s+7, converted pairwise (v_cvt_pk_bf16_f32), ARE the B
+// fragment of k-step s of v_mfma_f32_32x32x16_bf16: element j of lane half h is feature
+// 16s + 8(j>>2) + 4h + (j&3) -- the same feature set f0(8s+j) + 4h as in the fp32 path, so tables
+// and RBF centres are shared and only the weight images differ.
+//
+// Split operands: x = hi + mid + lo EXACTLY, each part 8 significand bits (bf16's), by masking --
+// hi = top 16 bits of x, mid = top 16 bits of x - hi, lo = x - hi - mid (at most 8 bits are left,
+// so its low 16 bits are zero).  v_perm_b32 packs two upper halves into one register.
+template <int P>
+__device__ __forceinline__ BOp<P> prep(const f32x16 &x) {
+    BOp<P> o;
+    if constexpr (P == HTF_MLP_FP32) {
+        o.v = x;
+    } else if constexpr (P == HTF_MLP_BF16) {
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        bf16x8 a = p[s * 64];
-        bf16x8 b;
+        for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) b[j] = (__bf16)prev[8 * s + j];
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+            for (int j = 0; j < 8; ++j) o.b[s][j] = (__bf16)x[8 * s + j];
+    } else {
+        constexpr unsigned kTop = 0xFFFF0000u, kSel = 0x07060302u; // {hi16(second), hi16(first)}
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            u32x4 ph, pm, pl;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a = x[8 * s + 2 * j], b = x[8 * s + 2 * j + 1];
+                const unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
+                const float ra = a - __uint_as_float(ua & kTop), rb = b - __uint_as_float(ub & kTop);
+                const unsigned va = __float_as_uint(ra), vb = __float_as_uint(rb);
+                const float la = ra - __uint_as_float(va & kTop), lb = rb - __uint_as_float(vb & kTop);
+                ph[j] = __builtin_amdgcn_perm(ub, ua, kSel);
+                pm[j] = __builtin_amdgcn_perm(vb, va, kSel);
+                pl[j] = __builtin_amdgcn_perm(__float_as_uint(lb), __float_as_uint(la), kSel);
+            }
+            o.hi[s] = __builtin_bit_cast(bf16x8, ph);
+            o.mid[s] = __builtin_bit_cast(bf16x8, pm);
+            o.lo[s] = __builtin_bit_cast(bf16x8, pl);
+        }
+    }
+    return o;
+}
+
+#define HTF_MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+// acc += A(image) * B(prev), over one 32-feature block of the previous layer.
+// fp32: 16 k-steps, the image supplies 4 steps per ds_read_b128.  bf16: two k-steps of 16.
+// split: per k-step the six partial products of (a_hi + a_mid + a_lo)(b_hi + b_mid + b_lo) that are
+// >= 2^-16 of the product, smallest first; mid*lo, lo*mid and lo*lo (<= 2^-24) are dropped.
+template <int P>
+__device__ __forceinline__ void mfma_blk(f32x16 &acc, const float *img, unsigned lane, const BOp<P> &prev) {
+    if constexpr (P == HTF_MLP_FP32) {
+        const float4 *p = reinterpret_cast<const float4 *>(img) + lane;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 w = p[g * 64];
+            acc = HTF_MFMA(w.x, prev.v[4 * g + 0], acc);
+            acc = HTF_MFMA(w.y, prev.v[4 * g + 1], acc);
+            acc = HTF_MFMA(w.z, prev.v[4 * g + 2], acc);
+            acc = HTF_MFMA(w.w, prev.v[4 * g + 3], acc);
+        }
+    } else if constexpr (P == HTF_MLP_BF16) {
+        const bf16x8 *p = reinterpret_cast<const bf16x8 *>(img) + lane;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) acc = HTF_MFMA_BF16(p[s * 64], prev.b[s], acc);
+    } else {
+        const bf16x8 *p = reinterpret_cast<const bf16x8 *>(img) + lane; // [part 3][s 2][lane 64]
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const bf16x8 ah = p[s * 64], am = p[(2 + s) * 64], al = p[(4 + s) * 64];
+            acc = HTF_MFMA_BF16(al, prev.hi[s], acc);
+            acc = HTF_MFMA_BF16(ah, prev.lo[s], acc);
+            acc = HTF_MFMA_BF16(am, prev.mid[s], acc);
+            acc = HTF_MFMA_BF16(am, prev.hi[s], acc);
+            acc = HTF_MFMA_BF16(ah, prev.mid[s], acc);
+            acc = HTF_MFMA_BF16(ah, prev.hi[s], acc);
+        }
     }
 }
 
-template <bool BF16>
-__device__ __forceinline__ void mfma_blk(f32x16 &acc, const float *img, unsigned lane, const f32x16 &prev) {
-    if constexpr (BF16)
-        mfma_block_bf16(acc, img, lane, prev);
-    else
-        mfma_block(acc, img, lane, prev);
-}
+// hipcc's second launch bound is waves per SIMD: LDS images of 49 / 25 / 73 KiB allow 3 / 2 / 2
+// workgroups of four waves per CU.  (bf16 is VALU-bound and needs > 168 VGPRs to stay out of
+// scratch; split with six waves per workgroup = 3 per SIMD spills 50-60 registers: 2.87 ms
+// against 1.95 ms at C3.)
+template <int P> struct MlpLaunch { static constexpr int kPerCU = P == HTF_MLP_FP32 ? 3 : 2; };
 
-template <bool TANH, typename IT, bool BF16>
-__global__ __launch_bounds__(256, BF16 ? 2 : 3) void pair_mlp_kernel(const typename Vec4<IT>::type *__restrict__ nlist,
+template <bool TANH, typename IT, int P>
+__global__ __launch_bounds__(256, MlpLaunch<P>::kPerCU) void pair_mlp_kernel(const typename Vec4<IT>::type *__restrict__ nlist,
                                                           unsigned B, unsigned NN, void *__restrict__ force,
                                                           int out_f64, const float *__restrict__ images, float gap) {
-    using I = Img<BF16>;
+    using I = Img<P>;
     __shared__ __attribute__((aligned(16))) float lds[I::Floats];
     {
         const float4 *src = reinterpret_cast<const float4 *>(images);
@@ -119,23 +173,29 @@ __global__ __launch_bounds__(256, BF16 ? 2 : 3) void pair_mlp_kernel(const typen
 
             // ---- layer 1: a1^T[f][p] = b1 + W1^T phi^T
             f32x16 a1[2];
+            {
+                const BOp<P> phi_b = prep<P>(phi);
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
-                a1[nb] = load_tab(lds + I::TabB1, nb, h);
-                mfma_blk<BF16>(a1[nb], lds + I::L1 + nb * I::BS, lane, phi);
+                for (int nb = 0; nb < 2; ++nb) {
+                    a1[nb] = load_tab(lds + I::TabB1, nb, h);
+                    mfma_blk<P>(a1[nb], lds + I::L1 + nb * I::BS, lane, phi_b);
 #pragma unroll
-                for (int v = 0; v < 16; ++v) a1[nb][v] = act_fwd<TANH>(a1[nb][v]);
+                    for (int v = 0; v < 16; ++v) a1[nb][v] = act_fwd<TANH>(a1[nb][v]);
+                }
             }
             // ---- layer 2
             f32x16 a2[2];
+            {
+                const BOp<P> a1_b[2] = {prep<P>(a1[0]), prep<P>(a1[1])};
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
-                a2[nb] = load_tab(lds + I::TabB2, nb, h);
+                for (int nb = 0; nb < 2; ++nb) {
+                    a2[nb] = load_tab(lds + I::TabB2, nb, h);
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-                    mfma_blk<BF16>(a2[nb], lds + I::L2 + (nb * 2 + kb) * I::BS, lane, a1[kb]);
+                    for (int kb = 0; kb < 2; ++kb)
+                        mfma_blk<P>(a2[nb], lds + I::L2 + (nb * 2 + kb) * I::BS, lane, a1_b[kb]);
 #pragma unroll
-                for (int v = 0; v < 16; ++v) a2[nb][v] = act_fwd<TANH>(a2[nb][v]);
+                    for (int v = 0; v < 16; ++v) a2[nb][v] = act_fwd<TANH>(a2[nb][v]);
+                }
             }
             // ---- layer 3 (dot with w3) and dz2 = w3 * act'(z2), in place
             float upart = 0.f;
@@ -152,26 +212,32 @@ __global__ __launch_bounds__(256, BF16 ? 2 : 3) void pair_mlp_kernel(const typen
             const float u = upart + __shfl_xor(upart, 32) + b3;
 
             // ---- backward 2: dh1^T = W2 dz2^T, then dz1 = dh1 * act'(z1) into a1
+            {
+                const BOp<P> dz2_b[2] = {prep<P>(a2[0]), prep<P>(a2[1])};
 #pragma unroll
-            for (int fb = 0; fb < 2; ++fb) {
-                f32x16 d1;
+                for (int fb = 0; fb < 2; ++fb) {
+                    f32x16 d1;
 #pragma unroll
-                for (int v = 0; v < 16; ++v) d1[v] = 0.f;
+                    for (int v = 0; v < 16; ++v) d1[v] = 0.f;
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-                    mfma_blk<BF16>(d1, lds + I::B2 + (fb * 2 + kb) * I::BS, lane, a2[kb]);
+                    for (int kb = 0; kb < 2; ++kb)
+                        mfma_blk<P>(d1, lds + I::B2 + (fb * 2 + kb) * I::BS, lane, dz2_b[kb]);
 #pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    const float hv = a1[fb][v];
-                    a1[fb][v] = TANH ? d1[v] * (1.0f - hv * hv) : d1[v];
+                    for (int v = 0; v < 16; ++v) {
+                        const float hv = a1[fb][v];
+                        a1[fb][v] = TANH ? d1[v] * (1.0f - hv * hv) : d1[v];
+                    }
                 }
             }
             // ---- backward 1: dphi^T = W1 dz1^T
             f32x16 dphi;
 #pragma unroll
             for (int v = 0; v < 16; ++v) dphi[v] = 0.f;
+            {
+                const BOp<P> dz1_b[2] = {prep<P>(a1[0]), prep<P>(a1[1])};
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) mfma_blk<BF16>(dphi, lds + I::B1 + kb * I::BS, lane, a1[kb]);
+                for (int kb = 0; kb < 2; ++kb) mfma_blk<P>(dphi, lds + I::B1 + kb * I::BS, lane, dz1_b[kb]);
+            }
 
             // du/dr = sum_k dphi_k * (-2 (r - c_k) / gap) * phi_k
             float dpart = 0.f;
@@ -244,18 +310,27 @@ static void build_map(const MlpDevice *m, std::vector<int> &map) {
 }
 
 // images <- theta (device side, so a training step never visits the host)
-template <bool BF16>
+template <int P>
 __global__ void mlp_refresh_kernel(float *__restrict__ images, const int *__restrict__ map,
                                    const float *__restrict__ theta) {
-    using I = Img<BF16>;
+    using I = Img<P>;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= kMapN) return;
     const int idx = map[e];
     const float v = idx >= 0 ? theta[idx] : 0.f;
     if (e < kMapW) {
-        if constexpr (BF16) { // round to nearest even (finite weights)
+        if constexpr (P == HTF_MLP_BF16) { // round to nearest even (finite weights)
             const unsigned u = __float_as_uint(v);
             reinterpret_cast<unsigned short *>(images)[e] = (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+        } else if constexpr (P == HTF_MLP_SPLIT) { // exact three-way split, see prep<>
+            const unsigned u = __float_as_uint(v);
+            const float r1 = v - __uint_as_float(u & 0xFFFF0000u);
+            const unsigned u1 = __float_as_uint(r1);
+            const float r2 = r1 - __uint_as_float(u1 & 0xFFFF0000u);
+            unsigned short *blk = reinterpret_cast<unsigned short *>(images) + (size_t)(e >> 10) * 3072 + (e & 1023);
+            blk[0] = (unsigned short)(u >> 16);
+            blk[1024] = (unsigned short)(u1 >> 16);
+            blk[2048] = (unsigned short)(__float_as_uint(r2) >> 16);
         } else {
             images[e] = v;
         }
@@ -270,11 +345,13 @@ int mlp_refresh(const MlpDevice *m, hipStream_t stream) {
     HTF_REQUIRE(m, "pair-MLP: null potential");
     const unsigned grid = (kMapN + 255) / 256;
     if (m->precision == HTF_MLP_BF16)
-        hipLaunchKernelGGL(mlp_refresh_kernel<true>, dim3(grid), dim3(256), 0, stream, m->images, m->map, m->theta);
+        hipLaunchKernelGGL(mlp_refresh_kernel<HTF_MLP_BF16>, dim3(grid), dim3(256), 0, stream, m->images, m->map, m->theta);
+    else if (m->precision == HTF_MLP_SPLIT)
+        hipLaunchKernelGGL(mlp_refresh_kernel<HTF_MLP_SPLIT>, dim3(grid), dim3(256), 0, stream, m->images, m->map, m->theta);
     else
-        hipLaunchKernelGGL(mlp_refresh_kernel<false>, dim3(grid), dim3(256), 0, stream, m->images, m->map, m->theta);
-    if (m->train_images != m->images) // bf16 evaluator images: the training sweep reads its own fp32 set
-        hipLaunchKernelGGL(mlp_refresh_kernel<false>, dim3(grid), dim3(256), 0, stream, m->train_images, m->train_map, m->theta);
+        hipLaunchKernelGGL(mlp_refresh_kernel<HTF_MLP_FP32>, dim3(grid), dim3(256), 0, stream, m->images, m->map, m->theta);
+    if (m->train_images != m->images) // bf16 / split evaluator images: the training sweep reads its own fp32 set
+        hipLaunchKernelGGL(mlp_refresh_kernel<HTF_MLP_FP32>, dim3(grid), dim3(256), 0, stream, m->train_images, m->train_map, m->theta);
     return check_launch("mlp_refresh_kernel");
 }
 
@@ -284,13 +361,15 @@ int mlp_create(const htf_potential_desc *d, MlpDevice **out) {
     HTF_REQUIRE(d->H1 >= 1 && d->H1 <= kH && d->H2 >= 1 && d->H2 <= kH, "pair-MLP: hidden widths (%d, %d) must be <= %d", d->H1, d->H2, kH);
     HTF_REQUIRE(d->rbf_high > d->rbf_low, "pair-MLP: rbf_high must exceed rbf_low");
     HTF_REQUIRE(d->activation == HTF_ACT_LINEAR || d->activation == HTF_ACT_TANH, "pair-MLP: unknown activation %d", d->activation);
-    HTF_REQUIRE(d->mlp_precision == HTF_MLP_FP32 || d->mlp_precision == HTF_MLP_BF16, "pair-MLP: unknown precision %d", d->mlp_precision);
+    HTF_REQUIRE(d->mlp_precision == HTF_MLP_FP32 || d->mlp_precision == HTF_MLP_BF16 || d->mlp_precision == HTF_MLP_SPLIT,
+                "pair-MLP: unknown precision %d", d->mlp_precision);
     MlpDevice *m = new (std::nothrow) MlpDevice();
     if (!m) {
         set_error("pair-MLP: out of host memory");
         return HTF_ERR_NOMEM;
     }
-    const bool bf16 = d->mlp_precision == HTF_MLP_BF16;
+    const bool bf16 = d->mlp_precision != HTF_MLP_FP32; // bf16-typed images (one part, or three for the split)
+    const bool split = d->mlp_precision == HTF_MLP_SPLIT;
     m->K = d->K; m->H1 = d->H1; m->H2 = d->H2;
     m->act = d->activation;
     m->precision = d->mlp_precision;
@@ -301,8 +380,8 @@ int mlp_create(const htf_potential_desc *d, MlpDevice **out) {
         m->centers[k] = (float)(k == m->K - 1 ? d->rbf_high : d->rbf_low + k * step);
     }
     m->gap = m->centers[1] - m->centers[0];
-    const int n_img = bf16 ? Img<true>::Floats : Img<false>::Floats;
-    const int tabc = bf16 ? Img<true>::TabC : Img<false>::TabC;
+    const int n_img = split ? Img<2>::Floats : (bf16 ? Img<1>::Floats : Img<0>::Floats);
+    const int tabc = split ? Img<2>::TabC : (bf16 ? Img<1>::TabC : Img<0>::TabC);
     std::vector<float> img(n_img, 0.f);
     for (int hh = 0; hh < 2; ++hh)
         for (int v = 0; v < 16; ++v) img[tabc + hh * 16 + v] = m->centers[f0(v) + 4 * hh];
@@ -374,18 +453,18 @@ void mlp_destroy(MlpDevice *m) {
     delete m;
 }
 
-template <bool TANH, bool BF16>
+template <bool TANH, int P>
 static int launch_mlp(const MlpDevice *m, const void *nlist, int in_dtype, unsigned B, unsigned NN, void *force,
                       int out_f64, hipStream_t s) {
     // persistent blocks: 3 per CU (LDS 48.9 KiB each), 4 waves per block, one row per wave trip
-    // (bf16: 2 per CU -- the VALU-bound variant needs > 168 VGPRs to stay out of scratch)
-    unsigned grid = (unsigned)m->n_cu * (BF16 ? 2u : 3u);
+    // (bf16 and split: 2 per CU, see MlpLaunch)
+    unsigned grid = (unsigned)m->n_cu * (unsigned)MlpLaunch<P>::kPerCU;
     unsigned need = (B + 3) / 4;
     if (grid > need) grid = need;
     if (in_dtype == HTF_F32)
-        hipLaunchKernelGGL((pair_mlp_kernel<TANH, float, BF16>), dim3(grid), dim3(256), 0, s, (const float4 *)nlist, B, NN, force, out_f64, m->images, m->gap);
+        hipLaunchKernelGGL((pair_mlp_kernel<TANH, float, P>), dim3(grid), dim3(256), 0, s, (const float4 *)nlist, B, NN, force, out_f64, m->images, m->gap);
     else
-        hipLaunchKernelGGL((pair_mlp_kernel<TANH, double, BF16>), dim3(grid), dim3(256), 0, s, (const double4 *)nlist, B, NN, force, out_f64, m->images, m->gap);
+        hipLaunchKernelGGL((pair_mlp_kernel<TANH, double, P>), dim3(grid), dim3(256), 0, s, (const double4 *)nlist, B, NN, force, out_f64, m->images, m->gap);
     return check_launch("pair_mlp_kernel");
 }
 
@@ -394,10 +473,13 @@ int mlp_eval(const MlpDevice *m, const void *nlist, int in_dtype, unsigned B, un
     HTF_REQUIRE(m, "pair-MLP: null potential");
     const int out_f64 = force_dtype == HTF_F64;
     if (m->precision == HTF_MLP_BF16)
-        return m->act == HTF_ACT_TANH ? launch_mlp<true, true>(m, nlist, in_dtype, B, NN, force, out_f64, stream)
-                                      : launch_mlp<false, true>(m, nlist, in_dtype, B, NN, force, out_f64, stream);
-    return m->act == HTF_ACT_TANH ? launch_mlp<true, false>(m, nlist, in_dtype, B, NN, force, out_f64, stream)
-                                  : launch_mlp<false, false>(m, nlist, in_dtype, B, NN, force, out_f64, stream);
+        return m->act == HTF_ACT_TANH ? launch_mlp<true, HTF_MLP_BF16>(m, nlist, in_dtype, B, NN, force, out_f64, stream)
+                                      : launch_mlp<false, HTF_MLP_BF16>(m, nlist, in_dtype, B, NN, force, out_f64, stream);
+    if (m->precision == HTF_MLP_SPLIT)
+        return m->act == HTF_ACT_TANH ? launch_mlp<true, HTF_MLP_SPLIT>(m, nlist, in_dtype, B, NN, force, out_f64, stream)
+                                      : launch_mlp<false, HTF_MLP_SPLIT>(m, nlist, in_dtype, B, NN, force, out_f64, stream);
+    return m->act == HTF_ACT_TANH ? launch_mlp<true, HTF_MLP_FP32>(m, nlist, in_dtype, B, NN, force, out_f64, stream)
+                                  : launch_mlp<false, HTF_MLP_FP32>(m, nlist, in_dtype, B, NN, force, out_f64, stream);
 }
 
 } // namespace htf

@@ -77,7 +77,13 @@ enum htf_potential_kind {
 };
 
 enum htf_activation { HTF_ACT_LINEAR = 0, HTF_ACT_TANH = 1 };
-enum htf_mlp_precision { HTF_MLP_FP32 = 0, HTF_MLP_BF16 = 1 };
+enum htf_mlp_precision {
+    HTF_MLP_FP32 = 0,  /* v_mfma_f32_32x32x2_f32 on fp32 operands */
+    HTF_MLP_BF16 = 1,  /* bf16 operands (weights and activations rounded), fp32 accumulation: reduced precision */
+    HTF_MLP_SPLIT = 2  /* fp32-level results on the bf16 matrix pipeline: every fp32 operand is split EXACTLY
+                        * into three bf16 values (8 + 8 + 8 significand bits) and a product is the six partial
+                        * products down to 2^-16 of it; what is dropped (2^-24) is the size of fp32's own rounding */
+};
 
 #define HTF_MAX_POLY_TERMS 8
 
