@@ -34,6 +34,52 @@ namespace htf {
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 
+// Packed fp32 arithmetic (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32: two lanes' worth per
+// instruction).  It matters more than its instruction count suggests: fp32 VALU arithmetic does
+// NOT run in the shadow of MFMA work on gfx950, neither inside a wave nor across the waves of a
+// SIMD (tools/mfma_valu_probe.hip: 12 MFMAs + 96 v_fma take the SUM of their times; integer ops
+// and v_exp / v_rcp do overlap), so every arithmetic instruction saved comes off the tile time.
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 pk_exp2(f32x2 x) { return f32x2{__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])}; }
+__device__ __forceinline__ f32x2 pk_rcp(f32x2 x) { return f32x2{__builtin_amdgcn_rcpf(x[0]), __builtin_amdgcn_rcpf(x[1])}; }
+
+// tanh(z) = 1 - 2 / (1 + exp(2z)) on a whole accumulator tile: per element half a v_pk_mul
+// (2 log2(e) folded into one constant), v_exp_f32, half a v_pk_add, v_rcp_f32, half a v_pk_fma
+template <bool TANH>
+__device__ __forceinline__ void act_tile(f32x16 &a) {
+    if constexpr (TANH) {
+#pragma unroll
+        for (int v = 0; v < 16; v += 2) {
+            const f32x2 z = {a[v], a[v + 1]};
+            const f32x2 e = pk_exp2(z * 2.8853900817779268f);
+            const f32x2 o = pk_fma(pk_rcp(e + 1.0f), f32x2{-2.0f, -2.0f}, f32x2{1.0f, 1.0f});
+            a[v] = o[0];
+            a[v + 1] = o[1];
+        }
+    }
+}
+
+// d <- g * act'(z) given h = act(z):  g * (1 - h^2)
+template <bool TANH>
+__device__ __forceinline__ void act_bwd_tile(f32x16 &h_inout, const f32x16 &g) {
+#pragma unroll
+    for (int v = 0; v < 16; v += 2) {
+        const f32x2 gv = {g[v], g[v + 1]};
+        if constexpr (TANH) {
+            const f32x2 hv = {h_inout[v], h_inout[v + 1]};
+            const f32x2 o = gv * pk_fma(-hv, hv, f32x2{1.0f, 1.0f});
+            h_inout[v] = o[0];
+            h_inout[v + 1] = o[1];
+        } else {
+            h_inout[v] = gv[0];
+            h_inout[v + 1] = gv[1];
+        }
+    }
+}
+
 // B operand of one 32-feature block of the previous layer (an accumulator tile, see above), in the
 // form the precision's MFMA takes.  Prepared once per tile and used by every output block.
 template <int P> struct BOp;
@@ -66,14 +112,14 @@ __device__ __forceinline__ BOp<P> prep(const f32x16 &x) {
             u32x4 ph, pm, pl;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float a = x[8 * s + 2 * j], b = x[8 * s + 2 * j + 1];
-                const unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
-                const float ra = a - __uint_as_float(ua & kTop), rb = b - __uint_as_float(ub & kTop);
-                const unsigned va = __float_as_uint(ra), vb = __float_as_uint(rb);
-                const float la = ra - __uint_as_float(va & kTop), lb = rb - __uint_as_float(vb & kTop);
-                ph[j] = __builtin_amdgcn_perm(ub, ua, kSel);
-                pm[j] = __builtin_amdgcn_perm(vb, va, kSel);
-                pl[j] = __builtin_amdgcn_perm(__float_as_uint(lb), __float_as_uint(la), kSel);
+                const f32x2 x2 = {x[8 * s + 2 * j], x[8 * s + 2 * j + 1]};
+                const u32x2 u = __builtin_bit_cast(u32x2, x2);
+                const f32x2 r = x2 - __builtin_bit_cast(f32x2, u & kTop); // v_pk_add_f32
+                const u32x2 w = __builtin_bit_cast(u32x2, r);
+                const u32x2 l = __builtin_bit_cast(u32x2, r - __builtin_bit_cast(f32x2, w & kTop));
+                ph[j] = __builtin_amdgcn_perm(u[1], u[0], kSel);
+                pm[j] = __builtin_amdgcn_perm(w[1], w[0], kSel);
+                pl[j] = __builtin_amdgcn_perm(l[1], l[0], kSel);
             }
             o.hi[s] = __builtin_bit_cast(bf16x8, ph);
             o.mid[s] = __builtin_bit_cast(bf16x8, pm);
@@ -145,6 +191,7 @@ __global__ __launch_bounds__(256, MlpLaunch<P>::kPerCU) void pair_mlp_kernel(con
     const unsigned nwaves = (gridDim.x * blockDim.x) >> 6;
     const unsigned ntiles = (NN + 31) / 32;
     const float ginv = 1.0f / gap;
+    const float nginv_l2e = -1.4426950408889634f * ginv;
     const float b3 = lds[I::TabB3];
     const f32x16 cen = load_tab(lds + I::TabC, 0, h); // centers of this lane's 16 RBF indices
 
@@ -166,9 +213,11 @@ __global__ __launch_bounds__(256, MlpLaunch<P>::kPerCU) void pair_mlp_kernel(con
             // RBF expansion: lane (p, h) evaluates centres k = f0(v) + 4h, v = 0..15
             f32x16 phi;
 #pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                float d = r - cen[v];
-                phi[v] = __expf(-(d * d) * ginv);
+            for (int v = 0; v < 16; v += 2) { // exp(-(r - c)^2 / gap) = exp2(d^2 * (-log2(e) / gap))
+                const f32x2 d = f32x2{r, r} - f32x2{cen[v], cen[v + 1]};
+                const f32x2 e = pk_exp2((d * d) * nginv_l2e);
+                phi[v] = e[0];
+                phi[v + 1] = e[1];
             }
 
             // ---- layer 1: a1^T[f][p] = b1 + W1^T phi^T
@@ -179,8 +228,7 @@ __global__ __launch_bounds__(256, MlpLaunch<P>::kPerCU) void pair_mlp_kernel(con
                 for (int nb = 0; nb < 2; ++nb) {
                     a1[nb] = load_tab(lds + I::TabB1, nb, h);
                     mfma_blk<P>(a1[nb], lds + I::L1 + nb * I::BS, lane, phi_b);
-#pragma unroll
-                    for (int v = 0; v < 16; ++v) a1[nb][v] = act_fwd<TANH>(a1[nb][v]);
+                    act_tile<TANH>(a1[nb]);
                 }
             }
             // ---- layer 2
@@ -193,22 +241,19 @@ __global__ __launch_bounds__(256, MlpLaunch<P>::kPerCU) void pair_mlp_kernel(con
 #pragma unroll
                     for (int kb = 0; kb < 2; ++kb)
                         mfma_blk<P>(a2[nb], lds + I::L2 + (nb * 2 + kb) * I::BS, lane, a1_b[kb]);
-#pragma unroll
-                    for (int v = 0; v < 16; ++v) a2[nb][v] = act_fwd<TANH>(a2[nb][v]);
+                    act_tile<TANH>(a2[nb]);
                 }
             }
             // ---- layer 3 (dot with w3) and dz2 = w3 * act'(z2), in place
-            float upart = 0.f;
+            f32x2 up2 = {0.f, 0.f};
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
                 const f32x16 w3 = load_tab(lds + I::TabW3, b, h);
 #pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    const float hv = a2[b][v];
-                    upart += hv * w3[v];
-                    a2[b][v] = TANH ? w3[v] * (1.0f - hv * hv) : w3[v];
-                }
+                for (int v = 0; v < 16; v += 2) up2 = pk_fma(f32x2{a2[b][v], a2[b][v + 1]}, f32x2{w3[v], w3[v + 1]}, up2);
+                act_bwd_tile<TANH>(a2[b], w3);
             }
+            const float upart = up2[0] + up2[1];
             const float u = upart + __shfl_xor(upart, 32) + b3;
 
             // ---- backward 2: dh1^T = W2 dz2^T, then dz1 = dh1 * act'(z1) into a1
@@ -222,11 +267,7 @@ __global__ __launch_bounds__(256, MlpLaunch<P>::kPerCU) void pair_mlp_kernel(con
 #pragma unroll
                     for (int kb = 0; kb < 2; ++kb)
                         mfma_blk<P>(d1, lds + I::B2 + (fb * 2 + kb) * I::BS, lane, dz2_b[kb]);
-#pragma unroll
-                    for (int v = 0; v < 16; ++v) {
-                        const float hv = a1[fb][v];
-                        a1[fb][v] = TANH ? d1[v] * (1.0f - hv * hv) : d1[v];
-                    }
+                    act_bwd_tile<TANH>(a1[fb], d1);
                 }
             }
             // ---- backward 1: dphi^T = W1 dz1^T
@@ -240,12 +281,14 @@ __global__ __launch_bounds__(256, MlpLaunch<P>::kPerCU) void pair_mlp_kernel(con
             }
 
             // du/dr = sum_k dphi_k * (-2 (r - c_k) / gap) * phi_k
-            float dpart = 0.f;
+            f32x2 dp2 = {0.f, 0.f};
+            const float m2ginv = -2.0f * ginv;
 #pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                float d = r - cen[v];
-                dpart += dphi[v] * (-2.0f * d * ginv) * phi[v];
+            for (int v = 0; v < 16; v += 2) {
+                const f32x2 d = f32x2{r, r} - f32x2{cen[v], cen[v + 1]};
+                dp2 = pk_fma((f32x2{dphi[v], dphi[v + 1]} * f32x2{phi[v], phi[v + 1]}) * m2ginv, d, dp2);
             }
+            const float dpart = dp2[0] + dp2[1];
             const float dudr = dpart + __shfl_xor(dpart, 32);
 
             // E_i += 1/2 u ; F_i += 2 * (1/2) du/dr * t / r   (masked; upper half duplicates)
