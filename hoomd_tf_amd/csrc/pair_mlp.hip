@@ -34,49 +34,77 @@ namespace htf {
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 
-// Packed fp32 arithmetic (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32: two lanes' worth per
-// instruction).  It matters more than its instruction count suggests: fp32 VALU arithmetic does
-// NOT run in the shadow of MFMA work on gfx950, neither inside a wave nor across the waves of a
-// SIMD (tools/mfma_valu_probe.hip: 12 MFMAs + 96 v_fma take the SUM of their times; integer ops
-// and v_exp / v_rcp do overlap), so every arithmetic instruction saved comes off the tile time.
+// VALU work beside the matrix pipe (tools/mfma_valu_probe2.hip, one wave per SIMD, 8 VALU
+// instructions after each of 12 dependent MFMAs):
+//  * beside v_mfma_f32_32x32x16_bf16 ordinary VALU instructions -- VOP1/VOP2/VOP3, fp32 or
+//    integer -- run in the MFMA's shadow (about two thirds of the matrix time can be filled),
+//    v_exp/v_rcp half as well; the PACKED fp32 instructions (v_pk_mul/add/fma_f32) do not
+//    overlap at all: 12 MFMAs + 96 v_pk_fma take the sum of their times;
+//  * beside v_mfma_f32_32x32x2_f32 NOTHING overlaps: the fp32 matrix instruction and the vector
+//    ALU exclude each other, so the fp32 evaluator's time is its MFMA time plus its VALU time.
+// Hence two styles in this file (compiled with -fno-slp-vectorize so that hipcc does not form
+// v_pk_* on its own): the fp32 path (PK = true) halves its VALU instruction count with packed
+// arithmetic; the bf16 and split paths keep element-wise arithmetic and interleave it with
+// their MFMAs (HTF_PIPE in the kernel).
 using f32x2 = __attribute__((ext_vector_type(2))) float;
-using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
 
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f32x2 pk_exp2(f32x2 x) { return f32x2{__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])}; }
 __device__ __forceinline__ f32x2 pk_rcp(f32x2 x) { return f32x2{__builtin_amdgcn_rcpf(x[0]), __builtin_amdgcn_rcpf(x[1])}; }
 
-// tanh(z) = 1 - 2 / (1 + exp(2z)) on a whole accumulator tile: per element half a v_pk_mul
-// (2 log2(e) folded into one constant), v_exp_f32, half a v_pk_add, v_rcp_f32, half a v_pk_fma
-template <bool TANH>
+// tanh(z) = 1 - 2 / (1 + exp(2z)) on a whole accumulator tile: v_mul (2 log2(e) folded into one
+// constant), v_exp_f32, v_add, v_rcp_f32, v_fma per element
+template <bool TANH, bool PK>
 __device__ __forceinline__ void act_tile(f32x16 &a) {
-    if constexpr (TANH) {
+    if constexpr (TANH && PK) {
 #pragma unroll
         for (int v = 0; v < 16; v += 2) {
-            const f32x2 z = {a[v], a[v + 1]};
-            const f32x2 e = pk_exp2(z * 2.8853900817779268f);
+            const f32x2 e = pk_exp2(f32x2{a[v], a[v + 1]} * 2.8853900817779268f);
             const f32x2 o = pk_fma(pk_rcp(e + 1.0f), f32x2{-2.0f, -2.0f}, f32x2{1.0f, 1.0f});
             a[v] = o[0];
             a[v + 1] = o[1];
+        }
+    } else if constexpr (TANH) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const float e = __builtin_amdgcn_exp2f(a[v] * 2.8853900817779268f);
+            a[v] = fmaf(__builtin_amdgcn_rcpf(e + 1.0f), -2.0f, 1.0f);
         }
     }
 }
 
 // d <- g * act'(z) given h = act(z):  g * (1 - h^2)
-template <bool TANH>
+template <bool TANH, bool PK>
 __device__ __forceinline__ void act_bwd_tile(f32x16 &h_inout, const f32x16 &g) {
+    if constexpr (TANH && PK) {
 #pragma unroll
-    for (int v = 0; v < 16; v += 2) {
-        const f32x2 gv = {g[v], g[v + 1]};
-        if constexpr (TANH) {
+        for (int v = 0; v < 16; v += 2) {
             const f32x2 hv = {h_inout[v], h_inout[v + 1]};
-            const f32x2 o = gv * pk_fma(-hv, hv, f32x2{1.0f, 1.0f});
+            const f32x2 o = f32x2{g[v], g[v + 1]} * pk_fma(-hv, hv, f32x2{1.0f, 1.0f});
             h_inout[v] = o[0];
             h_inout[v + 1] = o[1];
-        } else {
-            h_inout[v] = gv[0];
-            h_inout[v + 1] = gv[1];
         }
+    } else {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const float hv = h_inout[v];
+            h_inout[v] = TANH ? g[v] * fmaf(-hv, hv, 1.0f) : g[v];
+        }
+    }
+}
+
+// sum_v a[v] * b[v] into two partial sums (even / odd v)
+template <bool PK>
+__device__ __forceinline__ void dot_tile(float (&acc)[2], const f32x16 &a, const f32x16 &b) {
+    if constexpr (PK) {
+        f32x2 s = {acc[0], acc[1]};
+#pragma unroll
+        for (int v = 0; v < 16; v += 2) s = pk_fma(f32x2{a[v], a[v + 1]}, f32x2{b[v], b[v + 1]}, s);
+        acc[0] = s[0];
+        acc[1] = s[1];
+    } else {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[v & 1] = fmaf(a[v], b[v], acc[v & 1]);
     }
 }
 
@@ -112,14 +140,14 @@ __device__ __forceinline__ BOp<P> prep(const f32x16 &x) {
             u32x4 ph, pm, pl;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const f32x2 x2 = {x[8 * s + 2 * j], x[8 * s + 2 * j + 1]};
-                const u32x2 u = __builtin_bit_cast(u32x2, x2);
-                const f32x2 r = x2 - __builtin_bit_cast(f32x2, u & kTop); // v_pk_add_f32
-                const u32x2 w = __builtin_bit_cast(u32x2, r);
-                const u32x2 l = __builtin_bit_cast(u32x2, r - __builtin_bit_cast(f32x2, w & kTop));
-                ph[j] = __builtin_amdgcn_perm(u[1], u[0], kSel);
-                pm[j] = __builtin_amdgcn_perm(w[1], w[0], kSel);
-                pl[j] = __builtin_amdgcn_perm(l[1], l[0], kSel);
+                const float a = x[8 * s + 2 * j], b = x[8 * s + 2 * j + 1];
+                const unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
+                const float ra = a - __uint_as_float(ua & kTop), rb = b - __uint_as_float(ub & kTop);
+                const unsigned va = __float_as_uint(ra), vb = __float_as_uint(rb);
+                const float la = ra - __uint_as_float(va & kTop), lb = rb - __uint_as_float(vb & kTop);
+                ph[j] = __builtin_amdgcn_perm(ub, ua, kSel);
+                pm[j] = __builtin_amdgcn_perm(vb, va, kSel);
+                pl[j] = __builtin_amdgcn_perm(__float_as_uint(lb), __float_as_uint(la), kSel);
             }
             o.hi[s] = __builtin_bit_cast(bf16x8, ph);
             o.mid[s] = __builtin_bit_cast(bf16x8, pm);
@@ -170,6 +198,8 @@ __device__ __forceinline__ void mfma_blk(f32x16 &acc, const float *img, unsigned
 // workgroups of four waves per CU.  (bf16 is VALU-bound and needs > 168 VGPRs to stay out of
 // scratch; split with six waves per workgroup = 3 per SIMD spills 50-60 registers: 2.87 ms
 // against 1.95 ms at C3.)
+constexpr int pipe_per(int valu, int mfma) { return (valu + mfma - 1) / mfma > 0 ? (valu + mfma - 1) / mfma : 1; }
+
 template <int P> struct MlpLaunch { static constexpr int kPerCU = P == HTF_MLP_FP32 ? 3 : 2; };
 
 template <bool TANH, typename IT, int P>
@@ -177,6 +207,7 @@ __global__ __launch_bounds__(256, MlpLaunch<P>::kPerCU) void pair_mlp_kernel(con
                                                           unsigned B, unsigned NN, void *__restrict__ force,
                                                           int out_f64, const float *__restrict__ images, float gap) {
     using I = Img<P>;
+    constexpr bool PK = P == HTF_MLP_FP32; // packed VALU arithmetic where nothing overlaps with the MFMAs anyway
     __shared__ __attribute__((aligned(16))) float lds[I::Floats];
     {
         const float4 *src = reinterpret_cast<const float4 *>(images);
@@ -214,79 +245,118 @@ __global__ __launch_bounds__(256, MlpLaunch<P>::kPerCU) void pair_mlp_kernel(con
             f32x16 phi;
 #pragma unroll
             for (int v = 0; v < 16; v += 2) { // exp(-(r - c)^2 / gap) = exp2(d^2 * (-log2(e) / gap))
-                const f32x2 d = f32x2{r, r} - f32x2{cen[v], cen[v + 1]};
-                const f32x2 e = pk_exp2((d * d) * nginv_l2e);
-                phi[v] = e[0];
-                phi[v + 1] = e[1];
+                if constexpr (PK) {
+                    const f32x2 d = f32x2{r, r} - f32x2{cen[v], cen[v + 1]};
+                    const f32x2 e = pk_exp2((d * d) * nginv_l2e);
+                    phi[v] = e[0];
+                    phi[v + 1] = e[1];
+                } else {
+                    const float d0 = r - cen[v], d1 = r - cen[v + 1];
+                    phi[v] = __builtin_amdgcn_exp2f((d0 * d0) * nginv_l2e);
+                    phi[v + 1] = __builtin_amdgcn_exp2f((d1 * d1) * nginv_l2e);
+                }
             }
 
+            // The chain phi -> L1 -> act -> L2 -> act -> L3 -> backward 2 -> backward 1 is software-pipelined by
+            // hand: while the matrix pipe works on one 32-feature block, the wave's VALU turns the PREVIOUS block
+            // into the next operand (activation, derivative, operand split).  hipcc clusters each kind of work
+            // into its own phase otherwise, and with two or three waves per SIMD the phases of different waves
+            // rarely complement each other.  HTF_PIPE pins the interleave (one MFMA, then `per` VALU
+            // instructions, `n` times) inside a region closed by a full scheduling barrier.
+#define HTF_PIPE(n, per)                                                                                               \
+    if constexpr (!PK) {                                                                                               \
+        _Pragma("unroll") for (int q_ = 0; q_ < (n); ++q_) {                                                           \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                         \
+            __builtin_amdgcn_sched_group_barrier(0x002, (per), 0);                                                     \
+        }                                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+    }
+            constexpr int kM = P == HTF_MLP_FP32 ? 16 : (P == HTF_MLP_BF16 ? 2 : 12); // MFMAs per block
+            constexpr int kAct = TANH ? 56 : 0, kPrep = P == HTF_MLP_SPLIT ? 76 : (P == HTF_MLP_BF16 ? 8 : 0);
+            constexpr int kBwd = TANH ? 16 : 0, kDot = 8;
+
+            f32x16 a1[2], a2[2];
             // ---- layer 1: a1^T[f][p] = b1 + W1^T phi^T
-            f32x16 a1[2];
-            {
-                const BOp<P> phi_b = prep<P>(phi);
-#pragma unroll
-                for (int nb = 0; nb < 2; ++nb) {
-                    a1[nb] = load_tab(lds + I::TabB1, nb, h);
-                    mfma_blk<P>(a1[nb], lds + I::L1 + nb * I::BS, lane, phi_b);
-                    act_tile<TANH>(a1[nb]);
-                }
-            }
+            const BOp<P> phi_b = prep<P>(phi);
+            a1[0] = load_tab(lds + I::TabB1, 0, h);
+            mfma_blk<P>(a1[0], lds + I::L1, lane, phi_b);
+            if constexpr (!PK) __builtin_amdgcn_sched_barrier(0);
+            a1[1] = load_tab(lds + I::TabB1, 1, h);
+            mfma_blk<P>(a1[1], lds + I::L1 + I::BS, lane, phi_b);
+            act_tile<TANH, PK>(a1[0]);
+            const BOp<P> a1_b0 = prep<P>(a1[0]);
+            HTF_PIPE(kM, pipe_per(kAct + kPrep, kM));
             // ---- layer 2
-            f32x16 a2[2];
+            a2[0] = load_tab(lds + I::TabB2, 0, h);
+            a2[1] = load_tab(lds + I::TabB2, 1, h);
+            mfma_blk<P>(a2[0], lds + I::L2 + (0 * 2 + 0) * I::BS, lane, a1_b0);
+            mfma_blk<P>(a2[1], lds + I::L2 + (1 * 2 + 0) * I::BS, lane, a1_b0);
+            act_tile<TANH, PK>(a1[1]);
+            const BOp<P> a1_b1 = prep<P>(a1[1]);
+            HTF_PIPE(2 * kM, pipe_per(kAct + kPrep, 2 * kM));
+            mfma_blk<P>(a2[0], lds + I::L2 + (0 * 2 + 1) * I::BS, lane, a1_b1);
+            if constexpr (!PK) __builtin_amdgcn_sched_barrier(0);
+            // ---- layer 3 (dot with w3) and dz2 = w3 * act'(z2), in place, block 0 under the last L2 block
+            float up2[2] = {0.f, 0.f};
+            mfma_blk<P>(a2[1], lds + I::L2 + (1 * 2 + 1) * I::BS, lane, a1_b1);
+            act_tile<TANH, PK>(a2[0]);
             {
-                const BOp<P> a1_b[2] = {prep<P>(a1[0]), prep<P>(a1[1])};
-#pragma unroll
-                for (int nb = 0; nb < 2; ++nb) {
-                    a2[nb] = load_tab(lds + I::TabB2, nb, h);
-#pragma unroll
-                    for (int kb = 0; kb < 2; ++kb)
-                        mfma_blk<P>(a2[nb], lds + I::L2 + (nb * 2 + kb) * I::BS, lane, a1_b[kb]);
-                    act_tile<TANH>(a2[nb]);
-                }
+                const f32x16 w3 = load_tab(lds + I::TabW3, 0, h);
+                dot_tile<PK>(up2, a2[0], w3);
+                act_bwd_tile<TANH, PK>(a2[0], w3);
             }
-            // ---- layer 3 (dot with w3) and dz2 = w3 * act'(z2), in place
-            f32x2 up2 = {0.f, 0.f};
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const f32x16 w3 = load_tab(lds + I::TabW3, b, h);
-#pragma unroll
-                for (int v = 0; v < 16; v += 2) up2 = pk_fma(f32x2{a2[b][v], a2[b][v + 1]}, f32x2{w3[v], w3[v + 1]}, up2);
-                act_bwd_tile<TANH>(a2[b], w3);
-            }
-            const float upart = up2[0] + up2[1];
-            const float u = upart + __shfl_xor(upart, 32) + b3;
-
+            const BOp<P> dz2_b0 = prep<P>(a2[0]);
+            HTF_PIPE(kM, pipe_per(kAct + kDot + kBwd + kPrep, kM));
             // ---- backward 2: dh1^T = W2 dz2^T, then dz1 = dh1 * act'(z1) into a1
+            f32x16 d1[2];
+#pragma unroll
+            for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) d1[fb][v] = 0.f;
+            mfma_blk<P>(d1[0], lds + I::B2 + (0 * 2 + 0) * I::BS, lane, dz2_b0);
+            mfma_blk<P>(d1[1], lds + I::B2 + (1 * 2 + 0) * I::BS, lane, dz2_b0);
+            act_tile<TANH, PK>(a2[1]);
             {
-                const BOp<P> dz2_b[2] = {prep<P>(a2[0]), prep<P>(a2[1])};
-#pragma unroll
-                for (int fb = 0; fb < 2; ++fb) {
-                    f32x16 d1;
-#pragma unroll
-                    for (int v = 0; v < 16; ++v) d1[v] = 0.f;
-#pragma unroll
-                    for (int kb = 0; kb < 2; ++kb)
-                        mfma_blk<P>(d1, lds + I::B2 + (fb * 2 + kb) * I::BS, lane, dz2_b[kb]);
-                    act_bwd_tile<TANH>(a1[fb], d1);
-                }
+                const f32x16 w3 = load_tab(lds + I::TabW3, 1, h);
+                dot_tile<PK>(up2, a2[1], w3);
+                act_bwd_tile<TANH, PK>(a2[1], w3);
             }
+            const BOp<P> dz2_b1 = prep<P>(a2[1]);
+            HTF_PIPE(2 * kM, pipe_per(kAct + kDot + kBwd + kPrep, 2 * kM));
+            mfma_blk<P>(d1[0], lds + I::B2 + (0 * 2 + 1) * I::BS, lane, dz2_b1);
+            if constexpr (!PK) __builtin_amdgcn_sched_barrier(0);
+            mfma_blk<P>(d1[1], lds + I::B2 + (1 * 2 + 1) * I::BS, lane, dz2_b1);
+            act_bwd_tile<TANH, PK>(a1[0], d1[0]);
+            const BOp<P> dz1_b0 = prep<P>(a1[0]);
+            HTF_PIPE(kM, pipe_per(kBwd + kPrep, kM));
             // ---- backward 1: dphi^T = W1 dz1^T
             f32x16 dphi;
 #pragma unroll
             for (int v = 0; v < 16; ++v) dphi[v] = 0.f;
-            {
-                const BOp<P> dz1_b[2] = {prep<P>(a1[0]), prep<P>(a1[1])};
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb) mfma_blk<P>(dphi, lds + I::B1 + kb * I::BS, lane, dz1_b[kb]);
-            }
+            mfma_blk<P>(dphi, lds + I::B1, lane, dz1_b0);
+            act_bwd_tile<TANH, PK>(a1[1], d1[1]);
+            const BOp<P> dz1_b1 = prep<P>(a1[1]);
+            HTF_PIPE(kM, pipe_per(kBwd + kPrep, kM));
+            mfma_blk<P>(dphi, lds + I::B1 + I::BS, lane, dz1_b1);
+            if constexpr (!PK) __builtin_amdgcn_sched_barrier(0);
+#undef HTF_PIPE
+            const float upart = up2[0] + up2[1];
+            const float u = upart + __shfl_xor(upart, 32) + b3;
 
             // du/dr = sum_k dphi_k * (-2 (r - c_k) / gap) * phi_k
-            f32x2 dp2 = {0.f, 0.f};
+            float dp2[2] = {0.f, 0.f};
             const float m2ginv = -2.0f * ginv;
 #pragma unroll
             for (int v = 0; v < 16; v += 2) {
-                const f32x2 d = f32x2{r, r} - f32x2{cen[v], cen[v + 1]};
-                dp2 = pk_fma((f32x2{dphi[v], dphi[v + 1]} * f32x2{phi[v], phi[v + 1]}) * m2ginv, d, dp2);
+                if constexpr (PK) {
+                    const f32x2 d = f32x2{r, r} - f32x2{cen[v], cen[v + 1]};
+                    const f32x2 t = pk_fma((f32x2{dphi[v], dphi[v + 1]} * f32x2{phi[v], phi[v + 1]}) * m2ginv, d, f32x2{dp2[0], dp2[1]});
+                    dp2[0] = t[0];
+                    dp2[1] = t[1];
+                } else {
+                    dp2[0] = fmaf((dphi[v] * phi[v]) * m2ginv, r - cen[v], dp2[0]);
+                    dp2[1] = fmaf((dphi[v + 1] * phi[v + 1]) * m2ginv, r - cen[v + 1], dp2[1]);
+                }
             }
             const float dpart = dp2[0] + dp2[1];
             const float dudr = dpart + __shfl_xor(dpart, 32);
