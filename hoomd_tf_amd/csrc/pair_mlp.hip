@@ -194,13 +194,14 @@ __device__ __forceinline__ void mfma_blk(f32x16 &acc, const float *img, unsigned
     }
 }
 
-// hipcc's second launch bound is waves per SIMD: LDS images of 49 / 25 / 73 KiB allow 3 / 2 / 2
-// workgroups of four waves per CU.  (bf16 is VALU-bound and needs > 168 VGPRs to stay out of
-// scratch; split with six waves per workgroup = 3 per SIMD spills 50-60 registers: 2.87 ms
-// against 1.95 ms at C3.)
+// hipcc's second launch bound is waves per SIMD.  Two workgroups of four waves per CU for every
+// precision (LDS images of 49 / 25 / 73 KiB): at three waves per SIMD (168 VGPRs) the fp32 kernel
+// spills a handful of registers whichever way its arithmetic is written and is no faster (3.00 ms
+// either way at C3); split with six waves per workgroup spills 50-60 registers: 2.87 ms against
+// 1.92 ms.
 constexpr int pipe_per(int valu, int mfma) { return (valu + mfma - 1) / mfma > 0 ? (valu + mfma - 1) / mfma : 1; }
 
-template <int P> struct MlpLaunch { static constexpr int kPerCU = P == HTF_MLP_FP32 ? 3 : 2; };
+template <int P> struct MlpLaunch { static constexpr int kPerCU = 2; };
 
 template <bool TANH, typename IT, int P>
 __global__ __launch_bounds__(256, MlpLaunch<P>::kPerCU) void pair_mlp_kernel(const typename Vec4<IT>::type *__restrict__ nlist,
@@ -275,7 +276,58 @@ __global__ __launch_bounds__(256, MlpLaunch<P>::kPerCU) void pair_mlp_kernel(con
             constexpr int kAct = TANH ? 56 : 0, kPrep = P == HTF_MLP_SPLIT ? 76 : (P == HTF_MLP_BF16 ? 8 : 0);
             constexpr int kBwd = TANH ? 16 : 0, kDot = 8;
 
-            f32x16 a1[2], a2[2];
+            f32x16 a1[2], a2[2], dphi;
+            float up2[2] = {0.f, 0.f};
+            if constexpr (PK) {
+                // fp32 MFMA: nothing runs beside it, so the plain layer-by-layer order with the fewest live registers
+                // (three waves per SIMD at 168 VGPRs) and packed arithmetic
+                {
+                    const BOp<P> phi_b = prep<P>(phi);
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) {
+                        a1[nb] = load_tab(lds + I::TabB1, nb, h);
+                        mfma_blk<P>(a1[nb], lds + I::L1 + nb * I::BS, lane, phi_b);
+                        act_tile<TANH, PK>(a1[nb]);
+                    }
+                }
+                {
+                    const BOp<P> a1_b[2] = {prep<P>(a1[0]), prep<P>(a1[1])};
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) {
+                        a2[nb] = load_tab(lds + I::TabB2, nb, h);
+#pragma unroll
+                        for (int kb = 0; kb < 2; ++kb)
+                            mfma_blk<P>(a2[nb], lds + I::L2 + (nb * 2 + kb) * I::BS, lane, a1_b[kb]);
+                        act_tile<TANH, PK>(a2[nb]);
+                    }
+                }
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const f32x16 w3 = load_tab(lds + I::TabW3, b, h);
+                    dot_tile<PK>(up2, a2[b], w3);
+                    act_bwd_tile<TANH, PK>(a2[b], w3);
+                }
+                {
+                    const BOp<P> dz2_b[2] = {prep<P>(a2[0]), prep<P>(a2[1])};
+#pragma unroll
+                    for (int fb = 0; fb < 2; ++fb) {
+                        f32x16 d1;
+#pragma unroll
+                        for (int v = 0; v < 16; ++v) d1[v] = 0.f;
+#pragma unroll
+                        for (int kb = 0; kb < 2; ++kb)
+                            mfma_blk<P>(d1, lds + I::B2 + (fb * 2 + kb) * I::BS, lane, dz2_b[kb]);
+                        act_bwd_tile<TANH, PK>(a1[fb], d1);
+                    }
+                }
+#pragma unroll
+                for (int v = 0; v < 16; ++v) dphi[v] = 0.f;
+                {
+                    const BOp<P> dz1_b[2] = {prep<P>(a1[0]), prep<P>(a1[1])};
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb) mfma_blk<P>(dphi, lds + I::B1 + kb * I::BS, lane, dz1_b[kb]);
+                }
+            } else {
             // ---- layer 1: a1^T[f][p] = b1 + W1^T phi^T
             const BOp<P> phi_b = prep<P>(phi);
             a1[0] = load_tab(lds + I::TabB1, 0, h);
@@ -297,7 +349,6 @@ __global__ __launch_bounds__(256, MlpLaunch<P>::kPerCU) void pair_mlp_kernel(con
             mfma_blk<P>(a2[0], lds + I::L2 + (0 * 2 + 1) * I::BS, lane, a1_b1);
             if constexpr (!PK) __builtin_amdgcn_sched_barrier(0);
             // ---- layer 3 (dot with w3) and dz2 = w3 * act'(z2), in place, block 0 under the last L2 block
-            float up2[2] = {0.f, 0.f};
             mfma_blk<P>(a2[1], lds + I::L2 + (1 * 2 + 1) * I::BS, lane, a1_b1);
             act_tile<TANH, PK>(a2[0]);
             {
@@ -330,7 +381,6 @@ __global__ __launch_bounds__(256, MlpLaunch<P>::kPerCU) void pair_mlp_kernel(con
             const BOp<P> dz1_b0 = prep<P>(a1[0]);
             HTF_PIPE(kM, pipe_per(kBwd + kPrep, kM));
             // ---- backward 1: dphi^T = W1 dz1^T
-            f32x16 dphi;
 #pragma unroll
             for (int v = 0; v < 16; ++v) dphi[v] = 0.f;
             mfma_blk<P>(dphi, lds + I::B1, lane, dz1_b0);
@@ -339,6 +389,7 @@ __global__ __launch_bounds__(256, MlpLaunch<P>::kPerCU) void pair_mlp_kernel(con
             HTF_PIPE(kM, pipe_per(kBwd + kPrep, kM));
             mfma_blk<P>(dphi, lds + I::B1 + I::BS, lane, dz1_b1);
             if constexpr (!PK) __builtin_amdgcn_sched_barrier(0);
+            }
 #undef HTF_PIPE
             const float upart = up2[0] + up2[1];
             const float u = upart + __shfl_xor(upart, 32) + b3;

@@ -7,6 +7,9 @@ python bench.py > gpurun_out/final/bench_lj.json 2>gpurun_out/final/bench_lj.err
 python bench.py --workload wca > gpurun_out/final/bench_wca.json 2>/dev/null
 python bench.py --workload mlp --steps 100 --warmup 10 > gpurun_out/final/bench_mlp.json 2>/dev/null
 python bench.py --workload mlp-bf16 --steps 100 --warmup 10 > gpurun_out/final/bench_mlp_bf16.json 2>/dev/null
+python bench.py --workload mlp-split --steps 100 --warmup 10 > gpurun_out/final/bench_mlp_split.json 2>/dev/null
+./tools/mfma_valu_probe2 > gpurun_out/final/mfma_valu_probe2.txt 2>&1
+./tools/store_probe > gpurun_out/final/store_probe.txt 2>&1
 python bench.py --workload mlp-train --steps 400 --warmup 20 > gpurun_out/final/bench_mlp_train.json 2>/dev/null
 python bench.py --workload eds > gpurun_out/final/bench_eds.json 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_lj -o lj -- python3 bench.py --no-cpu-baseline > /dev/null 2>&1
