@@ -29,7 +29,8 @@ for name,d in (("FETCH_SIZE","/tmp/c_f"),("WRITE_SIZE","/tmp/c_w")):
         for r in csv.DictReader(open(f)):
             if r.get("Counter_Name")==name:
                 agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
-    out[name]={k[:70]:{"launches":len(v),"avg_KiB":sum(v)/len(v)} for k,v in agg.items() if k.startswith("void htf::") and len(v)>5}
+    out[name]={k.split("(")[0]:{"launches":len(v),"avg_KiB":sum(v)/len(v)} for k,v in agg.items() if k.startswith("void htf::") and len(v)>5}
+out["_note"]="rocprofv3 --pmc (separate passes), bench.py --steps 50 --warmup 5 (tools/evidence_pass.sh). gfx950: FETCH_SIZE counts 1/2 of wide coalesced reads (MI355X_MICROARCH.md HBM); WRITE_SIZE exact for 16-B/lane stores."
 json.dump(out,open("gpurun_out/final/pmc_hbm.json","w"),indent=1)
 print(json.dumps(out)[:1500])
 PY
