@@ -70,6 +70,7 @@ __global__ __launch_bounds__(256) void k(float *out, float seed) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+static int g_blocks = 256; // 256 = one wave per SIMD, 512 = two
 template <int OP, int MODE, bool F32 = false>
 static float run(float *out) {
     hipEvent_t e0, e1;
@@ -78,7 +79,7 @@ static float run(float *out) {
     float best = 1e9;
     for (int rep = 0; rep < 3; ++rep) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL((k<OP, MODE, F32>), dim3(256), dim3(256), 0, 0, out, 1e-3f);
+        hipLaunchKernelGGL((k<OP, MODE, F32>), dim3(g_blocks), dim3(256), 0, 0, out, 1e-3f);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms;
@@ -97,7 +98,7 @@ static void report(const char *name, float mfma, float *out) {
 
 int main() {
     float *out;
-    hipMalloc(&out, 256 * 256 * sizeof(float));
+    hipMalloc(&out, 512 * 256 * sizeof(float));
     const float mfma = run<0, 0>(out);
     printf("per round: %d dependent MFMAs alone = %.0f cycles; %d VALU instructions of one kind, 8 after every MFMA\n", NM, mfma, NM * PER);
 #define X(id, name, text, _) report<id>(name, mfma, out);
@@ -106,6 +107,15 @@ int main() {
     report<20>("v_pk_mul_f32  (VOP3P)", mfma, out);
     report<21>("v_pk_add_f32  (VOP3P)", mfma, out);
     report<22>("v_pk_fma_f32  (VOP3P)", mfma, out);
+    g_blocks = 512;
+    const float mfma2 = run<0, 0>(out);
+    printf("-- TWO waves per SIMD, bf16 MFMA: %d dependent MFMAs per wave alone = %.0f cycles per round\n", NM, mfma2);
+    report<0>("v_mul_f32_e32  (VOP2)", mfma2, out);
+    report<4>("v_fma_f32      (VOP3)", mfma2, out);
+    report<5>("v_and_b32_e32  (VOP2)", mfma2, out);
+    report<7>("v_perm_b32     (VOP3)", mfma2, out);
+    report<8>("v_exp_f32_e32  (VOP1)", mfma2, out);
+    g_blocks = 256;
     const float mfma32 = run<0, 0, true>(out);
     printf("-- beside %d dependent v_mfma_f32_32x32x2_f32 (64 cycles each): alone = %.0f cycles\n", NM, mfma32);
     report<0, true>("v_mul_f32_e32  (VOP2)", mfma32, out);
