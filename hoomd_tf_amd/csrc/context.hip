@@ -76,8 +76,10 @@ struct htf_ctx {
     unsigned *flag = nullptr;  // device word for check_nlist / overflow counts
     unsigned *counts = nullptr; // [capacity] live slots per scratch row (delta zero-fill + padding skip)
     // profiler scopes: event triples (before build, between, after eval) per batch
-    bool profiling = false;
+    unsigned profiling = 0;      // 0 = off, k = bracket every k-th htf_compute_forces batch
+    unsigned prof_tick = 0;
     std::vector<hipEvent_t> ev_pool;
+    std::vector<char> ev_one_scope; // per triple: the one-kernel step records no middle event
     size_t ev_used = 0;
 };
 
@@ -422,19 +424,20 @@ static int compute_rows(htf_ctx *ctx, unsigned timestep, const htf_hoomd_arrays 
         unsigned *c_counts = ctx->counts ? ctx->counts + slot0 : nullptr;
         void *c_virial = (char *)ctx->virial + slot0 * 9 * ssz;
         int rc;
-        const bool prof = ctx->profiling && cfg.nneighs > 0 && ctx->pot != nullptr;
+        const bool prof = ctx->profiling && cfg.nneighs > 0 && ctx->pot != nullptr && (ctx->prof_tick++ % ctx->profiling) == 0;
         hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
         if (prof) {
             e0 = next_event(ctx);
             e1 = next_event(ctx);
             e2 = next_event(ctx);
             HTF_REQUIRE(e0 && e1 && e2, "htf_compute_forces: hipEventCreate failed");
+            ctx->ev_one_scope.push_back(0);
             HTF_CHECK_HIP(hipEventRecord(e0, s));
         }
         const bool fused = cfg.fused && cfg.nneighs > 0 && ctx->pot != nullptr && ctx->pot->pp.kind != HTF_POT_PAIR_MLP;
         if (fused) {
             HTF_REQUIRE(a->n_neigh && a->nlist && a->head_list, "htf_compute_forces: null neighbor list");
-            if (prof) HTF_CHECK_HIP(hipEventRecord(e1, s)); // no separate build scope in fused mode
+            if (prof) ctx->ev_one_scope.back() = 1; // no separate build scope in fused mode: e1 stays unrecorded
             if (cfg.check_nlist) HTF_CHECK_HIP(hipMemsetAsync(ctx->flag, 0, sizeof(unsigned), s));
             void *fo = (char *)a->force + (size_t)offset * 4 * ssz;
             rc = fused_forces_impl(ctx->pot->pp, a->pos, cfg.scalar_dtype, N, cfg.nneighs, offset, n, &a->box, a->n_neigh,
@@ -518,8 +521,10 @@ extern "C" int htf_compute_forces_rows(htf_ctx *ctx, unsigned timestep, const ht
 extern "C" int htf_profile_enable(htf_ctx *ctx, int on) {
     using namespace htf;
     HTF_REQUIRE(ctx, "htf_profile_enable: null context");
-    ctx->profiling = on != 0;
+    ctx->profiling = on > 0 ? (unsigned)on : 0u;
+    ctx->prof_tick = 0;
     ctx->ev_used = 0;
+    ctx->ev_one_scope.clear();
     return HTF_OK;
 }
 
@@ -531,6 +536,11 @@ extern "C" int htf_profile_read(htf_ctx *ctx, double *build_ms, double *eval_ms,
     for (size_t t = 0; t < triples; ++t) {
         float ms = 0;
         HTF_CHECK_HIP(hipEventSynchronize(ctx->ev_pool[3 * t + 2]));
+        if (t < ctx->ev_one_scope.size() && ctx->ev_one_scope[t]) {
+            HTF_CHECK_HIP(hipEventElapsedTime(&ms, ctx->ev_pool[3 * t], ctx->ev_pool[3 * t + 2]));
+            e += ms;
+            continue;
+        }
         HTF_CHECK_HIP(hipEventElapsedTime(&ms, ctx->ev_pool[3 * t], ctx->ev_pool[3 * t + 1]));
         b += ms;
         HTF_CHECK_HIP(hipEventElapsedTime(&ms, ctx->ev_pool[3 * t + 1], ctx->ev_pool[3 * t + 2]));
@@ -540,5 +550,6 @@ extern "C" int htf_profile_read(htf_ctx *ctx, double *build_ms, double *eval_ms,
     if (eval_ms) *eval_ms = e;
     if (n_calls) *n_calls = (unsigned)triples;
     ctx->ev_used = 0;
+    ctx->ev_one_scope.clear();
     return HTF_OK;
 }

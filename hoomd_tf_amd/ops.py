@@ -457,8 +457,9 @@ class Context:
         self.compute_forces(timestep, arrays, stream, rows=(n_int, arrays.N - n_int))
 
     def profile_enable(self, on=True):
-        """Event-bracket the build and eval scopes (HOOMD Profiler analogue)."""
-        check(lib.htf_profile_enable(self._h, int(bool(on))))
+        """Event-bracket the build and eval scopes (HOOMD Profiler analogue); ``on=k`` (int > 1)
+        brackets every k-th batch only."""
+        check(lib.htf_profile_enable(self._h, int(on)))
 
     def profile_read(self):
         """-> (build_ms_total, eval_ms_total, n_calls) since the last read."""

@@ -383,9 +383,10 @@ HTF_API unsigned htf_get_batch_capacity(htf_ctx *ctx);
 /* Profiler scopes (reference: HOOMD Profiler push/pop "TensorflowCompute::reshapeNeighbors"
  * and "TensorflowCompute::Force Update", TensorflowCompute.cc:164-168,196-206).  When
  * enabled, htf_compute_forces brackets the pair-vector build and the evaluator with
- * hipEvents on the caller's stream; htf_profile_read synchronises on the recorded
- * events, returns the summed kernel milliseconds and call count since the last read,
- * and resets the accumulators. */
+ * hipEvents on the caller's stream (`on` = k > 1: only every k-th batch, for loops where two event
+ * records per step are a measurable share of the step; the one-kernel step is one scope, returned
+ * as eval_ms); htf_profile_read synchronises on the recorded events, returns the summed kernel
+ * milliseconds and the number of bracketed batches since the last read, and resets the accumulators. */
 HTF_API int htf_profile_enable(htf_ctx *ctx, int on);
 HTF_API int htf_profile_read(htf_ctx *ctx, double *build_ms, double *eval_ms, unsigned *n_calls);
 

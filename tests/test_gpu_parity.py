@@ -143,6 +143,37 @@ def test_reference_force_overwrite_on_gpu(htf, cuda):
         assert np.all(force.cpu().numpy()[:, 3] == 0)
 
 
+@pytest.mark.parametrize("fused", [0, 2])
+def test_profiler_scopes(htf, cuda, fused):
+    """htf_profile_*: the build / evaluator scopes of TensorflowCompute.cc:164-168,196-206 as hipEvent
+    brackets.  Every batch, or every k-th one; the one-kernel step is a single scope (eval)."""
+    pos, types, L, nn, head, nl = _system(3, 4.0, 0.15, 2, 5.4, np.float64, ntypes=1)
+    box = O.make_box(L)
+    p4, dnn, dhead, dnl = _to_dev(htf, pos, types, nn, head, nl, np.float64, cuda)
+    ctx = htf.Context(r_cut=5.0, nneighs=8, scalar_dtype=torch.float64, max_n=9, fused=fused)
+    ctx.set_potential(htf.Potential.lj())
+    force = torch.zeros((9, 4), dtype=torch.float64, device=cuda)
+    arrays = ctx.make_arrays(p4, 9, dnn, dhead, dnl, box, force)
+    ctx.compute_forces(0, arrays)
+    want = force.clone()
+    assert ctx.profile_read() == (0.0, 0.0, 0)  # off by default
+    ctx.profile_enable(True)
+    for ts in range(6):
+        ctx.compute_forces(ts, arrays)
+    b, e, n = ctx.profile_read()
+    assert n == 6 and e > 0 and (b > 0) == (fused == 0)
+    assert ctx.profile_read()[2] == 0  # read resets
+    ctx.profile_enable(3)
+    for ts in range(7):
+        ctx.compute_forces(ts, arrays)
+    b, e, n = ctx.profile_read()
+    assert n == 3 and e > 0  # batches 0, 3, 6
+    ctx.profile_enable(False)
+    ctx.compute_forces(0, arrays)
+    assert ctx.profile_read()[2] == 0
+    assert torch.equal(force, want)
+
+
 # --------------------------------------------------------------------------- evaluators
 def _nlist_case(seed, N=512, NN=128, dtype=np.float32, rmin=0.9):
     rng = np.random.default_rng(seed)
