@@ -51,3 +51,35 @@ for name, fn in (("compute_forces_overlapped", lambda: ctx.compute_forces_overla
     t1 = time.perf_counter()
     torch.cuda.synchronize()
     print("%-28s host %.1f us/call" % (name, (t1 - t0) / 300 * 1e6))
+# latency of one distance check on an idle GPU (kernel + D2H + host wake-up)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(200):
+    nl.needs_update()
+t1 = time.perf_counter()
+print("needs_update() on an idle GPU: %.1f us" % ((t1 - t0) / 200 * 1e6))
+x = torch.zeros(1, device=dev)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(200):
+    float(x.item())
+t1 = time.perf_counter()
+print(".item() of a resident scalar:  %.1f us" % ((t1 - t0) / 200 * 1e6))
+ph = torch.zeros(1).pin_memory()
+ev = torch.cuda.Event()
+t0 = time.perf_counter()
+for _ in range(200):
+    ph.copy_(x, non_blocking=True)
+    ev.record()
+    ev.synchronize()
+    float(ph[0])
+t1 = time.perf_counter()
+print("pinned copy + event sync:      %.1f us" % ((t1 - t0) / 200 * 1e6))
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(50):
+    nl.build()
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+print("nl.build(): host enqueue %.0f us, total %.0f us per rebuild" % ((t1 - t0) / 50 * 1e6, (t2 - t0) / 50 * 1e6))
