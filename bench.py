@@ -547,8 +547,8 @@ def main():
         # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
         # (PMC cannot be read from inside the process); null when the file is absent.
         try:
-            if args.cells != 32:
-                raise KeyError("PMC passes were collected at the default size")
+            if args.cells != 32 or args.workload != "lj":
+                raise KeyError("PMC passes were collected for the default workload at the default size")
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_lj_pmc_hbm.json")))
             key = {"build_pair_vectors": "void htf::build_pair_vectors_kernel<float, float>",
                    "eval_forces": "void htf::eval_pair_kernel<1, 16, false, float>",
