@@ -91,8 +91,8 @@ class WCA(htf.SimModel):
 
 class PairMLPModel(htf.SimModel):
     # RBFExpansion + 2x64 MLP pair potential
-    def setup(self, activation='tanh', seed=3):
-        self.mlp = htf.PairMLP(32, 64, 64, 0.0, 3.0, activation=activation, seed=seed)
+    def setup(self, activation='tanh', seed=3, precision='fp32'):
+        self.mlp = htf.PairMLP(32, 64, 64, 0.0, 3.0, activation=activation, seed=seed, precision=precision)
 
     def compute(self, nlist):
         energy = self.mlp(nlist)

@@ -339,15 +339,17 @@ def test_eds_rdf_model_replayed_as_one_kernel(htf, cuda):
     np.testing.assert_allclose(float(model.eds_bias.alpha), float(model2.eds_bias.alpha), rtol=1e-3, atol=1e-5)
 
 
-def test_pair_mlp_model_runs_traced(htf, cuda):
-    """config-3 style model through SimModel/tfcompute: traced path, finite forces."""
+@pytest.mark.parametrize("precision", ["fp32", "split"])
+def test_pair_mlp_model_runs_traced(htf, cuda, precision):
+    """config-3 style model through SimModel/tfcompute: traced path, forces against the oracle --
+    on the fp32 matrix instruction and on the bf16 one with exactly split operands, same tolerance."""
     from hoomd_tf_amd import standin
     pos, L, a = standin.fcc_positions(5, 0.8442)
     pos = pos + 0.03 * a * np.random.default_rng(0).standard_normal(pos.shape)
     system = standin.System(pos, L, dtype=torch.float32, device=cuda)
     sim = standin.Simulation(system)
     sim.integrate_nve(0.001)
-    model = build_examples.PairMLPModel(128)
+    model = build_examples.PairMLPModel(128, precision=precision)
     tfc = htf.tfcompute(model)
     tfc.attach(sim.nlist_cell(), r_cut=2.5)
     sim.run(5)

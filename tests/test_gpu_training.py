@@ -227,11 +227,11 @@ def test_pair_mlp_loss_gradient_matches_double_backward(htf, cuda, dims, act, NN
         o += n
 
 
-@pytest.mark.parametrize("route", ["valu", "nofuse", "bf16-images"])
+@pytest.mark.parametrize("route", ["valu", "nofuse", "bf16-images", "split-images"])
 def test_pair_mlp_gradient_alternate_routes(htf, cuda, route, monkeypatch):
     """The first-generation VALU kernel (HTF_MLP_TRAIN_VALU), the two-pass matrix-core route
-    (HTF_MLP_TRAIN_NOFUSE) and a bf16-image potential (which trains on its own fp32 image set)
-    all give the default route's loss gradient."""
+    (HTF_MLP_TRAIN_NOFUSE) and bf16- / split-image potentials (which train on their own fp32 image
+    set) all give the default route's loss gradient."""
     from hoomd_tf_amd import initializers
     nl = _case(8, N=33, NN=40)
     params = initializers.mlp_params(seed=12)
@@ -251,6 +251,8 @@ def test_pair_mlp_gradient_alternate_routes(htf, cuda, route, monkeypatch):
     elif route == "nofuse":
         monkeypatch.setenv("HTF_MLP_TRAIN_NOFUSE", "1")
         got = grad()
+    elif route == "split-images":
+        got = grad("split")
     else:
         got = grad("bf16")
     scale = np.abs(base[1:]).max()
