@@ -403,10 +403,8 @@ __global__ __launch_bounds__(256) void fused_forces2_kernel(
     unsigned n_lo = 0, n_hi = 0;
     float cv_wave = 0.f; // sum of the B energy column over this wave's rows, in row order
 
-    auto one = [&](const PV &pk, const PV &pi, bool keep, unsigned q, unsigned lo, unsigned Q, float4 *row, float &ax,
+    auto one = [&](PT dx, PT dy, PT dz, const PV &pk, bool keep, unsigned q, unsigned lo, unsigned Q, float4 *row, float &ax,
                    float &ay, float &az, float &ae, float &bx, float &by, float &bz, float &be) {
-        PT dx, dy, dz;
-        (void)pair_vector<PT>(pk, pi, box, dx, dy, dz);
         if (keep && q >= lo) {
             const float x = (float)dx, y = (float)dy, z = (float)dz;
             if constexpr (STORE) store_stream(&row[Q > NN ? q % NN : q], make_float4(x, y, z, (float)scalar_as_int(pk.w)));
@@ -444,6 +442,7 @@ __global__ __launch_bounds__(256) void fused_forces2_kernel(
             PV pk[kFChunk];
             unsigned q[kFChunk];
             bool keep[kFChunk];
+            PT vx[kFChunk], vy[kFChunk], vz[kFChunk];
 #pragma unroll
             for (int t = 0; t < kFChunk; ++t) {
                 const unsigned j = t * 64 + lane;
@@ -454,8 +453,7 @@ __global__ __launch_bounds__(256) void fused_forces2_kernel(
 #pragma unroll
             for (int t = 0; t < kFChunk; ++t) {
                 const unsigned j = t * 64 + lane;
-                PT dx, dy, dz;
-                const PT rsq = pair_vector<PT>(pk[t], pi, box, dx, dy, dz);
+                const PT rsq = pair_vector<PT>(pk[t], pi, box, vx[t], vy[t], vz[t]);
                 keep[t] = (j < nn) && !(rsq > rmaxsq);
                 const unsigned long long m = __ballot(keep[t]);
                 q[t] = Q + ballot_rank(m);
@@ -465,7 +463,7 @@ __global__ __launch_bounds__(256) void fused_forces2_kernel(
 #pragma unroll
             for (int t = 0; t < kFChunk; ++t) {
                 if ((unsigned)t * 64 >= nn) break; // wave-uniform
-                one(pk[t], pi, keep[t], q[t], lo, Q, row, ax, ay, az, ae, bx, by, bz, be);
+                one(vx[t], vy[t], vz[t], pk[t], keep[t], q[t], lo, Q, row, ax, ay, az, ae, bx, by, bz, be);
             }
         } else {
             for (unsigned base = 0; base < nn; base += 64) { // counting pass
@@ -486,7 +484,7 @@ __global__ __launch_bounds__(256) void fused_forces2_kernel(
                 const unsigned long long m = __ballot(kp);
                 const unsigned qq = Q2 + ballot_rank(m);
                 Q2 += __popcll(m);
-                one(pk, pi, kp, qq, lo, Q, row, ax, ay, az, ae, bx, by, bz, be);
+                one(dx, dy, dz, pk, kp, qq, lo, Q, row, ax, ay, az, ae, bx, by, bz, be);
             }
         }
         const unsigned filled = Q < NN ? Q : NN;
