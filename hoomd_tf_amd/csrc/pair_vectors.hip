@@ -38,6 +38,8 @@
 // Compiled with -ffp-contract=off: the arithmetic is then op-for-op the oracle's
 // (oracle/htf_oracle.py:min_image / prepare_neighbors), so pair vectors are
 // bit-exact, not merely within tolerance.
+#include <cstdlib>
+
 #include "htf_common.h"
 #include "box_math.h"
 
@@ -89,16 +91,12 @@ __device__ __forceinline__ unsigned sweep(typename Vec4<DT>::type *__restrict__ 
 }
 
 template <typename PT, typename DT>
-__global__ __launch_bounds__(256) void build_pair_vectors_kernel(
-    typename Vec4<DT>::type *__restrict__ dest, const typename Vec4<PT>::type *__restrict__ pos,
-    unsigned N, unsigned NN, unsigned offset, unsigned batch, BoxT<PT> box,
-    const unsigned *__restrict__ n_neigh, const unsigned *__restrict__ nlist,
-    const unsigned *__restrict__ head_list, PT rmaxsq, unsigned *__restrict__ max_count,
-    float4 *__restrict__ positions_out, unsigned *__restrict__ counts_io) {
+__device__ __forceinline__ void build_row(
+    const unsigned w, const unsigned lane, typename Vec4<DT>::type *__restrict__ dest,
+    const typename Vec4<PT>::type *__restrict__ pos, unsigned N, unsigned NN, unsigned offset, const BoxT<PT> &box,
+    const unsigned *__restrict__ n_neigh, const unsigned *__restrict__ nlist, const unsigned *__restrict__ head_list,
+    PT rmaxsq, unsigned *__restrict__ max_count, float4 *__restrict__ positions_out, unsigned *__restrict__ counts_io) {
     using DV = typename Vec4<DT>::type;
-    const unsigned lane = threadIdx.x & 63u;
-    const unsigned w = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-    if (w >= batch) return;
     const unsigned idx = w + offset;
     if (idx >= N) return;
     const unsigned nn = n_neigh[idx];
@@ -135,6 +133,101 @@ __global__ __launch_bounds__(256) void build_pair_vectors_kernel(
     if (max_count != nullptr && lane == 0 && Q > *(volatile unsigned *)max_count) atomicMax(max_count, Q);
 }
 
+// Two rows per wave with ALL their index loads, then all their gathers, issued before any store (the
+// structure of fused_forces_rows2_kernel, fused_eval.hip, which builds AND evaluates in 63 us).  Fast
+// path for the common case (both rows have 1..192 list entries and do not overflow NN); anything else
+// is redone by build_row.  R = 1 is the plain wave-per-row kernel.
+// Measured at C3 with streaming stores (run-to-run spread ~10 %): one row per wave 67-75 us; 2 / 4 / 8
+// rows per wave taken one after the other 74 / 74 / 77 us; loads up front, 2 / 4 / 8 rows: 64-71 /
+// 60-68 / 72 us.
+template <typename PT, typename DT, int R>
+__global__ __launch_bounds__(256) void build_pair_vectors_kernel(
+    typename Vec4<DT>::type *__restrict__ dest, const typename Vec4<PT>::type *__restrict__ pos,
+    unsigned N, unsigned NN, unsigned offset, unsigned batch, BoxT<PT> box,
+    const unsigned *__restrict__ n_neigh, const unsigned *__restrict__ nlist,
+    const unsigned *__restrict__ head_list, PT rmaxsq, unsigned *__restrict__ max_count,
+    float4 *__restrict__ positions_out, unsigned *__restrict__ counts_io) {
+    using PV = typename Vec4<PT>::type;
+    using DV = typename Vec4<DT>::type;
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned wv = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const unsigned w0 = wv * R;
+    if (w0 >= batch) return;
+    unsigned nn[R];
+    bool fast = R > 1 && w0 + R <= batch && w0 + R - 1 + offset < N;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        nn[r] = fast ? n_neigh[w0 + r + offset] : 0u;
+        fast = fast && nn[r] != 0 && nn[r] <= 64 * kChunk;
+    }
+    if (!fast) {
+#pragma unroll 1
+        for (unsigned r = 0; r < (unsigned)R && w0 + r < batch; ++r)
+            build_row<PT, DT>(w0 + r, lane, dest, pos, N, NN, offset, box, n_neigh, nlist, head_list, rmaxsq, max_count,
+                              positions_out, counts_io);
+        return;
+    }
+    PV pi[R];
+    unsigned k[R][kChunk];
+    PV pk[R][kChunk];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const unsigned *nl = nlist + head_list[w0 + r + offset];
+        pi[r] = pos[w0 + r + offset];
+#pragma unroll
+        for (int t = 0; t < kChunk; ++t) {
+            const unsigned j = t * 64 + lane;
+            k[r][t] = nl[j < nn[r] ? j : nn[r] - 1];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int t = 0; t < kChunk; ++t) pk[r][t] = pos[k[r][t]];
+    unsigned redo = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const unsigned w = w0 + r;
+        if (positions_out != nullptr && lane == 0)
+            positions_out[w] = make_float4((float)pi[r].x, (float)pi[r].y, (float)pi[r].z, (float)scalar_as_int(pi[r].w));
+        DV *row = dest + (size_t)w * NN;
+        unsigned Q = 0;
+#pragma unroll
+        for (int t = 0; t < kChunk; ++t) {
+            if ((unsigned)t * 64 >= nn[r]) break; // wave-uniform
+            const unsigned j = t * 64 + lane;
+            PT dx = pk[r][t].x - pi[r].x, dy = pk[r][t].y - pi[r].y, dz = pk[r][t].z - pi[r].z;
+            min_image<PT>(dx, dy, dz, box);
+            const PT rsq = dx * dx + dy * dy + dz * dz;
+            const bool keep = (j < nn[r]) && !(rsq > rmaxsq);
+            const unsigned long long m = __ballot(keep);
+            const unsigned q = Q + ballot_rank(m);
+            Q += __popcll(m);
+            DV out;
+            out.x = (DT)dx; out.y = (DT)dy; out.z = (DT)dz;
+            out.w = (DT)scalar_as_int(pk[r][t].w);
+            if (keep && q < NN) store_stream(&row[q], out);
+        }
+        if (Q > NN) { // overflow (an error upstream): build_row redoes the whole row, slot wrap included
+            redo |= 1u << r;
+            continue;
+        }
+        DV zero;
+        zero.x = zero.y = zero.z = zero.w = (DT)0;
+        const unsigned zero_end = counts_io != nullptr ? counts_io[w] : NN;
+        for (unsigned sl = Q + lane; sl < zero_end; sl += 64) store_stream(&row[sl], zero);
+        if (counts_io != nullptr && lane == 0) counts_io[w] = Q;
+        if (max_count != nullptr && lane == 0 && Q > *(volatile unsigned *)max_count) atomicMax(max_count, Q);
+    }
+#pragma unroll 1
+    for (unsigned r = 0; r < (unsigned)R; ++r)
+        if ((redo >> r) & 1u) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            build_row<PT, DT>(w0 + r, lane, dest, pos, N, NN, offset, box, n_neigh, nlist, head_list, rmaxsq, max_count,
+                              positions_out, counts_io);
+        }
+}
+
 template <typename PT, typename DT>
 static int launch_build(void *dest, const void *pos, unsigned N, unsigned NN, unsigned offset,
                         unsigned batch, const htf_box *hb, const unsigned *n_neigh,
@@ -143,11 +236,17 @@ static int launch_build(void *dest, const void *pos, unsigned N, unsigned NN, un
     BoxT<PT> b = make_boxt<PT>(hb);
     PT rc = (PT)rmax;
     PT rmaxsq = rc * rc;
-    const unsigned waves_per_block = 4;
-    unsigned grid = (batch + waves_per_block - 1) / waves_per_block;
-    hipLaunchKernelGGL((build_pair_vectors_kernel<PT, DT>), dim3(grid), dim3(64 * waves_per_block), 0, stream,
-                       (typename Vec4<DT>::type *)dest, (const typename Vec4<PT>::type *)pos, N, NN,
-                       offset, batch, b, n_neigh, nlist, head_list, rmaxsq, max_count, positions_out, counts_io);
+    static const char *rows_env = getenv("HTF_BUILD_ROWS"); // A/B runs: 1 | 2 | 4 | 8 rows per wave
+    const int rows = rows_env ? atoi(rows_env) : (sizeof(PT) == 4 ? 4 : 2); // fp64 positions: 4 rows spill SGPRs
+#define HTF_BUILD_LAUNCH(RR)                                                                                           \
+    hipLaunchKernelGGL((build_pair_vectors_kernel<PT, DT, RR>), dim3((batch + 4 * RR - 1) / (4 * RR)), dim3(256), 0, stream, \
+                       (typename Vec4<DT>::type *)dest, (const typename Vec4<PT>::type *)pos, N, NN, offset, batch, b, \
+                       n_neigh, nlist, head_list, rmaxsq, max_count, positions_out, counts_io)
+    if (rows == 1) HTF_BUILD_LAUNCH(1);
+    else if (rows == 4) HTF_BUILD_LAUNCH(4);
+    else if (rows == 8) HTF_BUILD_LAUNCH(8);
+    else HTF_BUILD_LAUNCH(2);
+#undef HTF_BUILD_LAUNCH
     return check_launch("build_pair_vectors_kernel");
 }
 
