@@ -174,6 +174,50 @@ def test_profiler_scopes(htf, cuda, fused):
     assert torch.equal(force, want)
 
 
+@pytest.mark.parametrize("hdt", [np.float32, np.float64])
+@pytest.mark.parametrize("fused", [False, True])
+def test_pair_vectors_ragged_row_lengths(htf, cuda, hdt, fused):
+    """Rows of 0, 1, 63..65, 191..193 and 300 list entries side by side, batch sizes that are not a
+    multiple of the rows a wave takes: the multi-row fast path (<= 192 entries, no overflow), its
+    single-row fallback and the overflow wrap must all give the oracle's tensor bit for bit --
+    through the build kernel and through the one-kernel build+evaluate."""
+    rng = np.random.default_rng(21)
+    lens = [5, 0, 64, 1, 192, 193, 63, 300, 65, 191, 2, 0, 130, 7, 128, 129, 256, 3, 77, 190, 1, 64, 12]
+    N = len(lens)
+    L = np.array([9.0, 10.0, 11.0])
+    pos = ((rng.random((N, 3)) - 0.5) * L).astype(hdt)
+    types = rng.integers(0, 3, N).astype(np.int32)
+    nn = np.array(lens, dtype=np.int64)
+    head = np.concatenate([[0], np.cumsum(nn)[:-1]]).astype(np.int64)
+    nl = np.concatenate([rng.integers(0, N, n) for n in lens]).astype(np.int64)
+    box = O.make_box(L, dtype=hdt)
+    p4, dnn, dhead, dnl = _to_dev(htf, pos, types, nn, head, nl, hdt, cuda)
+    for NN, r_cut in ((128, 4.0), (256, 100.0), (16, 100.0)):
+        for offset, bs in ((0, N), (1, N - 1), (3, 13), (0, 5), (6, 2)):
+            ref = O.prepare_neighbors(pos, types, nn, head, nl, box, r_cut, NN, offset=offset, batch_size=bs)
+            if fused:
+                pv = torch.full((bs, NN, 4), 7.0, dtype=torch.float32, device=cuda)
+                htf.ops.fused_forces(htf.Potential.lj(), p4, dnn, dhead, dnl, box, r_cut, NN, offset=offset, batch_size=bs,
+                                     pair_vectors=pv)
+                np.testing.assert_array_equal(pv.cpu().numpy(), ref.astype(np.float32))
+            else:
+                mc = torch.zeros(1, dtype=torch.int32, device=cuda)
+                out = htf.ops.build_pair_vectors(p4, dnn, dhead, dnl, box, r_cut, NN, offset=offset, batch_size=bs, max_count=mc,
+                                                 out_dtype=torch.float64 if hdt == np.float64 else torch.float32)
+                np.testing.assert_array_equal(out.cpu().numpy(), ref)
+                if hdt == np.float64:
+                    out32 = htf.ops.build_pair_vectors(p4, dnn, dhead, dnl, box, r_cut, NN, offset=offset, batch_size=bs,
+                                                       out_dtype=torch.float32)
+                    np.testing.assert_array_equal(out32.cpu().numpy(), ref.astype(np.float32))
+                # kept-count side channel: the largest number of list entries within r_cut among the batch rows
+                want = 0
+                for i in range(offset, offset + bs):
+                    d = pos[nl[head[i]:head[i] + nn[i]]].astype(np.float64) - pos[i].astype(np.float64)
+                    d -= np.round(d / L) * L
+                    want = max(want, int(((d * d).sum(axis=1) <= r_cut * r_cut).sum()))  # self pairs and repeats count
+                assert int(mc.item()) == want
+
+
 # --------------------------------------------------------------------------- evaluators
 def _nlist_case(seed, N=512, NN=128, dtype=np.float32, rmin=0.9):
     rng = np.random.default_rng(seed)
