@@ -425,14 +425,56 @@ __global__ __launch_bounds__(256) void fused_forces2_kernel(
     };
 
     const unsigned ngroups = (batch + 3) / 4;
+    // The persistent loop is software-pipelined over its rows: while row i is evaluated, the metadata
+    // (count, list head, own position) and then the first 192 list entries of the row this wave takes
+    // NEXT are already on their way -- PMC had the waves of the unpipelined loop waiting on memory
+    // 48 % of the time (three dependent loads at the head of every row, eight waves per SIMD).
+    struct Meta {
+        unsigned nn, head;
+        PV pi;
+        bool have;
+    };
+    auto fetch_meta = [&](unsigned grp) {
+        Meta m;
+        m.have = grp < ngroups && grp * 4 + wb < batch; // wave-uniform
+        m.nn = 0;
+        m.head = 0;
+        m.pi = pos[offset]; // any valid element
+        if (m.have) {
+            const unsigned idx = grp * 4 + wb + offset;
+            m.nn = n_neigh[idx];
+            m.head = head_list[idx];
+            m.pi = pos[idx];
+        }
+        return m;
+    };
+    auto fetch_idx = [&](const Meta &m, unsigned (&k)[kFChunk]) {
+        const unsigned *nl = nlist + m.head;
+#pragma unroll
+        for (int t = 0; t < kFChunk; ++t) {
+            const unsigned j = t * 64 + lane;
+            k[t] = (m.have && m.nn != 0 && m.nn <= 64 * kFChunk) ? nl[j < m.nn ? j : m.nn - 1] : 0u;
+        }
+    };
+    Meta cur = fetch_meta(blockIdx.x);
+    unsigned k_cur[kFChunk];
+    fetch_idx(cur, k_cur);
 #pragma unroll 1
     for (unsigned grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
         const unsigned w = grp * 4 + wb;
-        if (w >= batch) continue; // wave-uniform
-        const unsigned idx = w + offset;
-        const unsigned nn = n_neigh[idx];
-        const unsigned *nl = nlist + head_list[idx];
-        const PV pi = pos[idx];
+        Meta nxt;
+        unsigned k_nxt[kFChunk];
+        if (!cur.have) { // wave-uniform: this wave has no row in the group (tail of the batch)
+            nxt = fetch_meta(grp + gridDim.x);
+            fetch_idx(nxt, k_nxt);
+            cur = nxt;
+#pragma unroll
+            for (int t = 0; t < kFChunk; ++t) k_cur[t] = k_nxt[t];
+            continue;
+        }
+        const unsigned nn = cur.nn;
+        const unsigned *nl = nlist + cur.head;
+        const PV pi = cur.pi;
         float4 *row = STORE ? dest + (size_t)w * NN : nullptr;
         float ax = 0.f, ay = 0.f, az = 0.f, ae = 0.f, bx = 0.f, by = 0.f, bz = 0.f, be = 0.f;
         unsigned Q = 0;
@@ -444,12 +486,10 @@ __global__ __launch_bounds__(256) void fused_forces2_kernel(
             bool keep[kFChunk];
             PT vx[kFChunk], vy[kFChunk], vz[kFChunk];
 #pragma unroll
-            for (int t = 0; t < kFChunk; ++t) {
-                const unsigned j = t * 64 + lane;
-                k[t] = nn ? nl[j < nn ? j : nn - 1] : 0u;
-            }
+            for (int t = 0; t < kFChunk; ++t) k[t] = k_cur[t];
 #pragma unroll
             for (int t = 0; t < kFChunk; ++t) pk[t] = pos[k[t]];
+            nxt = fetch_meta(grp + gridDim.x); // in flight beside this row's gathers
 #pragma unroll
             for (int t = 0; t < kFChunk; ++t) {
                 const unsigned j = t * 64 + lane;
@@ -459,6 +499,7 @@ __global__ __launch_bounds__(256) void fused_forces2_kernel(
                 q[t] = Q + ballot_rank(m);
                 Q += __popcll(m);
             }
+            fetch_idx(nxt, k_nxt); // in flight under this row's evaluation
             const unsigned lo = Q > NN ? Q - NN : 0u;
 #pragma unroll
             for (int t = 0; t < kFChunk; ++t) {
@@ -466,6 +507,8 @@ __global__ __launch_bounds__(256) void fused_forces2_kernel(
                 one(vx[t], vy[t], vz[t], pk[t], keep[t], q[t], lo, Q, row, ax, ay, az, ae, bx, by, bz, be);
             }
         } else {
+            nxt = fetch_meta(grp + gridDim.x);
+            fetch_idx(nxt, k_nxt);
             for (unsigned base = 0; base < nn; base += 64) { // counting pass
                 const unsigned j = base + lane;
                 const PV pk = pos[nl[j < nn ? j : nn - 1]];
@@ -511,6 +554,9 @@ __global__ __launch_bounds__(256) void fused_forces2_kernel(
             }
         }
         cv_wave += be;
+        cur = nxt;
+#pragma unroll
+        for (int t = 0; t < kFChunk; ++t) k_cur[t] = k_nxt[t];
     }
     if (partials != nullptr) { // one partial per block, fixed order -> deterministic
         if (lane == 0) s_part[wb] = cv_wave;
