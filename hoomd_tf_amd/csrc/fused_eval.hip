@@ -578,7 +578,12 @@ __global__ __launch_bounds__(256) void fused_forces2_kernel(
 
 unsigned fused_forces2_num_partials(unsigned batch) {
     const unsigned ngroups = (batch + 3) / 4;
-    return ngroups < 2048u ? ngroups : 2048u;
+    // persistent workgroups: 4096 = 16 per CU, about twice what is resident -- measured at C4
+    // 1024 / 2048 / 4096 / 8192 / 16384 workgroups: 244 / 220 / 204 / 212 / 372 us (every workgroup ends with a
+    // flush of its LDS histogram)
+    static const char *env = getenv("HTF_FUSED2_GRID");
+    const unsigned cap = env ? (unsigned)atoi(env) : 4096u;
+    return ngroups < cap ? ngroups : cap;
 }
 
 template <int KA, typename PT>
