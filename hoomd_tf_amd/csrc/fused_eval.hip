@@ -177,7 +177,10 @@ __global__ __launch_bounds__(256) void fused_forces_kernel(const typename Vec4<P
 // into a wave-private LDS row first and evaluated from there in two trips instead of three, with
 // full-width tensor stores, 94 / 57 us; evaluation made branch-free so that the two rows' arithmetic
 // can pack into v_pk_* instructions 96 / 56 us.  With streaming tensor stores (store_stream,
-// htf_common.h) the written variant takes 63 us for one, two and four rows per wave alike.
+// htf_common.h) the written variant takes 63 us for one, two and four rows per wave alike; a
+// persistent kernel software-pipelined over rows (next row's metadata and list entries in flight
+// during the current row's evaluation -- what took the C4 sweep below from 241 to 217 us) 67-77 /
+// 63-70 us with 8192-2048 workgroups: here the hardware's own wave turnover does better.
 // Two rows per wave with ALL their index loads, then all their gathers, issued before any
 // arithmetic: twice the bytes in flight per wave slot while the evaluator's VALU work (which,
 // unlike the plain build, this kernel has plenty of) runs under the other row's memory latency.
