@@ -143,6 +143,21 @@ def test_reference_force_overwrite_on_gpu(htf, cuda):
         assert np.all(force.cpu().numpy()[:, 3] == 0)
 
 
+@pytest.mark.parametrize("rows", ["1", "2", "8"])
+def test_rows_per_wave_variants_are_bit_identical(htf, cuda, rows):
+    """The rows-per-wave launch geometries kept for A/B runs (HTF_BUILD_ROWS / HTF_FUSED_ROWS; defaults 4
+    and 2) must produce the same tensors and forces: the bit-exact pair-vector tests and the
+    fused-vs-two-kernel test are re-run in a child process under each setting."""
+    import subprocess
+    import sys
+    env = dict(os.environ, HTF_BUILD_ROWS=rows, HTF_FUSED_ROWS=rows if rows != "8" else "4")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        "-k", "pair_vectors_bit_exact or ragged_row_lengths or fused_matches_two_kernel"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
 @pytest.mark.parametrize("fused", [0, 2])
 def test_profiler_scopes(htf, cuda, fused):
     """htf_profile_*: the build / evaluator scopes of TensorflowCompute.cc:164-168,196-206 as hipEvent
