@@ -65,11 +65,10 @@ __device__ __forceinline__ void act_tile(f32x16 &a) {
             a[v + 1] = o[1];
         }
     } else if constexpr (TANH) {
+        // bf16-typed images carry 2 log2(e) W and 2 log2(e) b in their forward blocks (mlp_refresh_kernel):
+        // the accumulator IS the exponent, one multiply per element less
 #pragma unroll
-        for (int v = 0; v < 16; ++v) {
-            const float e = __builtin_amdgcn_exp2f(a[v] * 2.8853900817779268f);
-            a[v] = fmaf(__builtin_amdgcn_rcpf(e + 1.0f), -2.0f, 1.0f);
-        }
+        for (int v = 0; v < 16; ++v) a[v] = fmaf(__builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(a[v]) + 1.0f), -2.0f, 1.0f);
     }
 }
 
@@ -474,14 +473,18 @@ static void build_map(const MlpDevice *m, std::vector<int> &map) {
 }
 
 // images <- theta (device side, so a training step never visits the host)
+// fwd_scale: factor on the FORWARD operand blocks (L1, L2: the first six) and on the two bias tables --
+// 2 log2(e) for a tanh network evaluated from bf16-typed images (see act_tile), 1 otherwise.  The
+// backward blocks (B2, B1), w3 and b3 are never scaled.
 template <int P>
 __global__ void mlp_refresh_kernel(float *__restrict__ images, const int *__restrict__ map,
-                                   const float *__restrict__ theta) {
+                                   const float *__restrict__ theta, float fwd_scale) {
     using I = Img<P>;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= kMapN) return;
     const int idx = map[e];
-    const float v = idx >= 0 ? theta[idx] : 0.f;
+    const bool fwd = e < 6 * 1024 || (e >= kMapW && e < kMapW + 128);
+    const float v = (idx >= 0 ? theta[idx] : 0.f) * (fwd ? fwd_scale : 1.0f);
     if (e < kMapW) {
         if constexpr (P == HTF_MLP_BF16) { // round to nearest even (finite weights)
             const unsigned u = __float_as_uint(v);
@@ -508,14 +511,15 @@ __global__ void mlp_refresh_kernel(float *__restrict__ images, const int *__rest
 int mlp_refresh(const MlpDevice *m, hipStream_t stream) {
     HTF_REQUIRE(m, "pair-MLP: null potential");
     const unsigned grid = (kMapN + 255) / 256;
+    const float fwd_scale = m->act == HTF_ACT_TANH ? 2.8853900817779268f : 1.0f; // bf16-typed images only
     if (m->precision == HTF_MLP_BF16)
-        hipLaunchKernelGGL(mlp_refresh_kernel<HTF_MLP_BF16>, dim3(grid), dim3(256), 0, stream, m->images, m->map, m->theta);
+        hipLaunchKernelGGL(mlp_refresh_kernel<HTF_MLP_BF16>, dim3(grid), dim3(256), 0, stream, m->images, m->map, m->theta, fwd_scale);
     else if (m->precision == HTF_MLP_SPLIT)
-        hipLaunchKernelGGL(mlp_refresh_kernel<HTF_MLP_SPLIT>, dim3(grid), dim3(256), 0, stream, m->images, m->map, m->theta);
+        hipLaunchKernelGGL(mlp_refresh_kernel<HTF_MLP_SPLIT>, dim3(grid), dim3(256), 0, stream, m->images, m->map, m->theta, fwd_scale);
     else
-        hipLaunchKernelGGL(mlp_refresh_kernel<HTF_MLP_FP32>, dim3(grid), dim3(256), 0, stream, m->images, m->map, m->theta);
+        hipLaunchKernelGGL(mlp_refresh_kernel<HTF_MLP_FP32>, dim3(grid), dim3(256), 0, stream, m->images, m->map, m->theta, 1.0f);
     if (m->train_images != m->images) // bf16 / split evaluator images: the training sweep reads its own fp32 set
-        hipLaunchKernelGGL(mlp_refresh_kernel<HTF_MLP_FP32>, dim3(grid), dim3(256), 0, stream, m->train_images, m->train_map, m->theta);
+        hipLaunchKernelGGL(mlp_refresh_kernel<HTF_MLP_FP32>, dim3(grid), dim3(256), 0, stream, m->train_images, m->train_map, m->theta, 1.0f);
     return check_launch("mlp_refresh_kernel");
 }
 
