@@ -495,6 +495,9 @@ def main():
     eval_b, build_b, integ_b = algorithmic_bytes(N, NN, n_entries, N + sysm.n_ghost)
     # per STEP (with slabs a step is two row ranges = two launches of each kernel; the
     # algorithmic bytes below are per step as well)
+    # per STEP = mean bracketed batch x batches per step; under slabs a rebuild step is ONE whole-range batch
+    # (the rebuild's own exchange is blocking), every other step two (interior rows, boundary rows)
+    batches_per_step = (batches_per_step * args.steps - (rebuilds if batches_per_step == 2 else 0)) / max(args.steps, 1)
     eval_avg_s = eval_ms / ncalls * batches_per_step * 1e-3 if ncalls else 0.0
     build_avg_s = build_ms / ncalls * batches_per_step * 1e-3 if ncalls else 0.0
     if one_kernel:
