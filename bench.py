@@ -602,9 +602,9 @@ def main():
     # ---- extras, reported separately and never mixed into `roofline`: the same MD (a) with the
     # reference's two-kernel dataflow (build kernel, then evaluator kernel re-reading the tensor)
     # and (b) with the pair vectors kept in registers and NO tensor.
-    def run_variant(mode):
+    def run_variant(mode, pot_v=None):
         ctx_v = htf.Context(r_cut=args.rcut, nneighs=NN, scalar_dtype=torch.float32, max_n=sysm.N, fused=mode)
-        ctx_v.set_potential(pot)
+        ctx_v.set_potential(pot if pot_v is None else pot_v)
         state["arr_v"] = None
 
         def step_v():
@@ -654,6 +654,25 @@ def main():
             "value": world * args.steps / el, "unit": "steps/s", "ms_per_step": el / args.steps * 1e3,
             "kernel_avg_us": f_s * 1e6, "algorithmic_bytes": fb, "GBps": fb / f_s / 1e9 if f_s > 0 else None,
             "energy_per_particle": float(sysm.force[:, 3].double().sum().item()) / sysm.N}
+    # (b') pair-MLP: the same network and weights evaluated on the bf16 matrix pipeline with every fp32 operand
+    # split exactly into three bf16 parts (DESIGN 3.3a'): same accuracy class as the fp32-MFMA headline above
+    # (tests/test_gpu_parity.py::test_pair_mlp_split_operands), reported beside it, never as `value`
+    if not args.no_fused and args.workload == "mlp":
+        from hoomd_tf_amd.initializers import mlp_params
+        pot_s = htf.Potential.pair_mlp(mlp_params(seed=3), 0.0, 3.0, activation="tanh", precision="split")
+        # same pair vectors, both precisions: the largest force difference relative to the largest force
+        pv_now = ctx.nlist_buffer(sysm.N, dev)
+        fa = htf.ops.eval_forces(pot, pv_now)
+        fs = htf.ops.eval_forces(pot_s, pv_now)
+        rel = float((fa - fs).abs().max() / fa.abs().max())
+        el, _, e_s = run_variant(0, pot_s)
+        out["split_variant"] = {
+            "note": "precision='split': fp32 operands split exactly into 3 bf16 parts, 6 partial products per multiply on "
+                    "v_mfma_f32_32x32x16_bf16, fp32 accumulation; forces agree with the fp32-MFMA evaluator on the same "
+                    "pair vectors to max|dF|/max|F| = %.1e" % rel,
+            "value": world * args.steps / el, "unit": "steps/s", "ms_per_step": el / args.steps * 1e3,
+            "eval_forces_avg_us": e_s * 1e6, "executed_TFLOPs": flops / e_s / 1e12 if e_s > 0 else None,
+            "max_rel_force_difference_vs_fp32_mfma": rel}
     # (c) the same MD through the plugin surface a user touches: an htf.SimModel written op by op as in the
     # reference's LJModel (build_examples.py:67-77), htf.tfcompute(model).attach(nlist, r_cut), and the
     # stand-in's System::run loop.  tfcompute traces the model on its first step and replays it as the
