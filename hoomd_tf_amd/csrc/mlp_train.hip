@@ -266,9 +266,14 @@ __global__ __launch_bounds__(256, 1) void mlp_grad_mfma_kernel(const typename Ve
 
     const unsigned lane = threadIdx.x & 63u;
     const unsigned p = lane & 31u, h = lane >> 5;
-    const unsigned w = threadIdx.x >> 6;
+    const unsigned w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned ntiles = (NN + 31) / 32;
     const unsigned long long U = (unsigned long long)B * ntiles;
+    // unit -> (row, tile).  FUSED launches have 1, 2 or 4 tiles per row: a shift and a mask instead of
+    // 64-bit divisions (five per trip, each a ~100-instruction emulation)
+    const unsigned tsh = ntiles == 4 ? 2u : (ntiles == 2 ? 1u : 0u);
+    auto row_of = [&](unsigned long long u) { return FUSED ? (unsigned)(u >> tsh) : (unsigned)(u / ntiles); };
+    auto tile_of = [&](unsigned long long u) { return FUSED ? (unsigned)u & (ntiles - 1u) : (unsigned)(u % ntiles); };
     const float ginv = 1.0f / gap;
     float *mine = pub + w * kSlots * kPB;
 
@@ -279,7 +284,7 @@ __global__ __launch_bounds__(256, 1) void mlp_grad_mfma_kernel(const typename Ve
     for (unsigned long long base = (unsigned long long)blockIdx.x * 4; base < U; base += (unsigned long long)gridDim.x * 4) {
         const unsigned long long u = base + w;
         const bool valid = u < U;
-        const unsigned row = valid ? (unsigned)(u / ntiles) : 0u, tile = valid ? (unsigned)(u % ntiles) : 0u;
+        const unsigned row = valid ? row_of(u) : 0u, tile = valid ? tile_of(u) : 0u;
         const unsigned slot = tile * 32 + p;
         float x = 0.f, y = 0.f, z = 0.f;
         if (valid && slot < NN) {
@@ -361,7 +366,7 @@ __global__ __launch_bounds__(256, 1) void mlp_grad_mfma_kernel(const typename Ve
 #pragma unroll
             for (unsigned t = 0; t < 4; ++t) {
                 const unsigned long long ut = base + t;
-                if (ut < U && (unsigned)(ut / ntiles) == row) {
+                if (ut < U && row_of(ut) == row) {
                     const float4 q = rowsum[t];
                     F.x += q.x; F.y += q.y; F.z += q.z; F.w += q.w;
                 }
