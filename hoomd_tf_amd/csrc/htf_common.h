@@ -53,6 +53,20 @@ __device__ __forceinline__ float dpp_mov(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
 }
 
+// v + (v of lane ^ 32) and v + (v of lane ^ 16) without the LDS crossbar: gfx950's
+// v_permlane32_swap / v_permlane16_swap exchange the upper half (odd rows) of one register with the
+// lower half (even rows) of another; fed the same value twice they return (own half | own half) and
+// (other half | other half), whose sum is the butterfly step.  Same bits as v + __shfl_xor(v, 32 / 16)
+// (fp addition commutes), one VALU instruction instead of a ds_bpermute round trip.
+__device__ __forceinline__ float sum_xor32(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float sum_xor16(float v) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 template <int G>
 __device__ __forceinline__ float group_sum(float v) {
     static_assert(G >= 1 && G <= 64 && (G & (G - 1)) == 0, "G must be a power of two <= 64");
@@ -60,8 +74,8 @@ __device__ __forceinline__ float group_sum(float v) {
     if constexpr (G >= 4) v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
     if constexpr (G >= 8) v += dpp_mov<0x141>(v);  // row_half_mirror
     if constexpr (G >= 16) v += dpp_mov<0x140>(v); // row_mirror
-    if constexpr (G >= 32) v += __shfl_xor(v, 16);
-    if constexpr (G >= 64) v += __shfl_xor(v, 32);
+    if constexpr (G >= 32) v = sum_xor16(v);
+    if constexpr (G >= 64) v = sum_xor32(v);
     return v;
 }
 

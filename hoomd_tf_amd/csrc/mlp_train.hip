@@ -344,8 +344,8 @@ __global__ __launch_bounds__(256, 1) void mlp_grad_mfma_kernel(const typename Ve
                 }
             }
             if (FUSED) { // u = w3 . h2 + b3, u' = w3 . hd2: the prediction itself (pair_mlp.hip)
-                const float uu = upart + __shfl_xor(upart, 32) + lds[I::TabB3];
-                const float du = dpart + __shfl_xor(dpart, 32);
+                const float uu = sum_xor32(upart) + lds[I::TabB3];
+                const float du = sum_xor32(dpart);
                 if (m && h == 0) {
                     const float c = du / r;
                     part = make_float4(c * tx, c * ty, c * tz, 0.5f * uu);
@@ -501,8 +501,8 @@ __global__ __launch_bounds__(256, 1) void mlp_grad_mfma_kernel(const typename Ve
             s += __shfl_xor(s, 8); s += __shfl_xor(s, 16);
             gw3[b][v] = s;
         }
-    gb1 += __shfl_xor(gb1, 32);
-    gb2 += __shfl_xor(gb2, 32);
+    gb1 = sum_xor32(gb1);
+    gb2 = sum_xor32(gb2);
     gb3 = group_sum<64>(gb3);
     for (unsigned turn = 0; turn < 4; ++turn) {
         if (w == turn) {

@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256, MlpLaunch<P>::kPerCU) void pair_mlp_kernel(con
             }
 #undef HTF_PIPE
             const float upart = up2[0] + up2[1];
-            const float u = upart + __shfl_xor(upart, 32) + b3;
+            const float u = sum_xor32(upart) + b3;
 
             // du/dr = sum_k dphi_k * (-2 (r - c_k) / gap) * phi_k
             float dp2[2] = {0.f, 0.f};
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(256, MlpLaunch<P>::kPerCU) void pair_mlp_kernel(con
                 }
             }
             const float dpart = dp2[0] + dp2[1];
-            const float dudr = dpart + __shfl_xor(dpart, 32);
+            const float dudr = sum_xor32(dpart);
 
             // E_i += 1/2 u ; F_i += 2 * (1/2) du/dr * t / r   (masked; upper half duplicates)
             if (m && h == 0) {
