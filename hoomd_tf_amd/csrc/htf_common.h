@@ -57,7 +57,9 @@ __device__ __forceinline__ float dpp_mov(float v) {
 // v_permlane32_swap / v_permlane16_swap exchange the upper half (odd rows) of one register with the
 // lower half (even rows) of another; fed the same value twice they return (own half | own half) and
 // (other half | other half), whose sum is the butterfly step.  Same bits as v + __shfl_xor(v, 32 / 16)
-// (fp addition commutes), one VALU instruction instead of a ds_bpermute round trip.
+// (fp addition commutes), one VALU instruction instead of a ds_bpermute round trip.  A/B on one box
+// (the LJ step, the C4 sweep, the pair-MLP evaluators): no measurable time difference either way;
+// run-to-run spread between GPU boxes is ~5 %.
 __device__ __forceinline__ float sum_xor32(float v) {
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
