@@ -15,7 +15,8 @@ import os
 import torch  # noqa: F401  (plumbing: device memory + streams)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhtf_amd.so")
+# HTF_AMD_LIB: another build of the same ABI, for same-box A/B runs of kernel variants (tools/)
+LIB_PATH = os.environ.get("HTF_AMD_LIB") or os.path.join(_HERE, "libhtf_amd.so")
 
 HTF_OK, HTF_ERR_INVALID, HTF_ERR_DEVICE, HTF_ERR_NLIST_OVERFLOW, HTF_ERR_SKEWED_BOX, HTF_ERR_NOMEM = range(6)
 HTF_F32, HTF_F64 = 0, 1
