@@ -231,6 +231,81 @@ __global__ void gather4_kernel(V *__restrict__ dest, const V *__restrict__ src, 
 }
 } // namespace htf
 
+namespace htf {
+// ---- cell binning: a counting sort with a deterministic order inside each cell (ascending particle
+// index), in four small kernels -- what the stand-in used torch.sort + searchsorted for (38 + 10 us of
+// kernels and a dozen launches per rebuild)
+__global__ __launch_bounds__(256) void cell_count_kernel(const unsigned *__restrict__ cell_of, unsigned n,
+                                                         unsigned *__restrict__ count) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) atomicAdd(&count[cell_of[i]], 1u);
+}
+
+// exclusive scan of count[0..ncell) into start[0..ncell], one workgroup; cursor <- start
+__global__ __launch_bounds__(1024) void cell_scan_kernel(const unsigned *__restrict__ count, unsigned ncell,
+                                                         unsigned *__restrict__ start, unsigned *__restrict__ cursor) {
+    __shared__ unsigned s_sum[1024];
+    const unsigned t = threadIdx.x;
+    const unsigned per = (ncell + 1023u) / 1024u;
+    const unsigned lo = t * per, hi = lo + per < ncell ? lo + per : ncell;
+    unsigned sum = 0;
+    for (unsigned c = lo; c < hi; ++c) sum += count[c];
+    s_sum[t] = sum;
+    __syncthreads();
+    for (unsigned off = 1; off < 1024; off <<= 1) { // Hillis-Steele inclusive scan of the chunk sums
+        const unsigned v = t >= off ? s_sum[t - off] : 0u;
+        __syncthreads();
+        s_sum[t] += v;
+        __syncthreads();
+    }
+    unsigned run = t ? s_sum[t - 1] : 0u;
+    for (unsigned c = lo; c < hi; ++c) {
+        start[c] = run;
+        cursor[c] = run;
+        run += count[c];
+    }
+    if (t == 1023) start[ncell] = s_sum[1023];
+}
+
+__global__ __launch_bounds__(256) void cell_scatter_kernel(const unsigned *__restrict__ cell_of, unsigned n,
+                                                           unsigned *__restrict__ cursor, unsigned *__restrict__ order) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) order[atomicAdd(&cursor[cell_of[i]], 1u)] = i;
+}
+
+// the scatter's order inside a cell depends on the atomics' timing: sort each cell's few members
+__global__ __launch_bounds__(256) void cell_order_kernel(const unsigned *__restrict__ start, unsigned ncell,
+                                                         unsigned *__restrict__ order) {
+    const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncell) return;
+    const unsigned b = start[c], e = start[c + 1];
+    for (unsigned i = b + 1; i < e; ++i) { // insertion sort (cells hold a handful of particles)
+        const unsigned v = order[i];
+        unsigned j = i;
+        while (j > b && order[j - 1] > v) {
+            order[j] = order[j - 1];
+            --j;
+        }
+        order[j] = v;
+    }
+}
+} // namespace htf
+
+extern "C" int htfs_cell_sort(const unsigned *d_cell_of, unsigned Ntot, unsigned ncell, unsigned *d_scratch,
+                              unsigned *d_cell_start, unsigned *d_order, htf_stream stream) {
+    using namespace htf;
+    HTF_REQUIRE(d_cell_of && d_scratch && d_cell_start && d_order, "htfs_cell_sort: null pointer");
+    HTF_REQUIRE(ncell > 0, "htfs_cell_sort: no cells");
+    hipStream_t s = (hipStream_t)stream;
+    unsigned *count = d_scratch, *cursor = d_scratch + ncell;
+    HTF_CHECK_HIP(hipMemsetAsync(count, 0, (size_t)ncell * sizeof(unsigned), s));
+    if (Ntot) hipLaunchKernelGGL(cell_count_kernel, dim3((Ntot + 255) / 256), dim3(256), 0, s, d_cell_of, Ntot, count);
+    hipLaunchKernelGGL(cell_scan_kernel, dim3(1), dim3(1024), 0, s, count, ncell, d_cell_start, cursor);
+    if (Ntot) hipLaunchKernelGGL(cell_scatter_kernel, dim3((Ntot + 255) / 256), dim3(256), 0, s, d_cell_of, Ntot, cursor, d_order);
+    hipLaunchKernelGGL(cell_order_kernel, dim3((ncell + 255) / 256), dim3(256), 0, s, d_cell_start, ncell, d_order);
+    return check_launch("htfs_cell_sort");
+}
+
 extern "C" int htfs_gather4(void *d_dest, const void *d_src, const int *d_order, int dtype, unsigned n, htf_stream stream) {
     HTF_REQUIRE(d_dest && d_src && d_order, "htfs_gather4: null pointer");
     if (n == 0) return HTF_OK;

@@ -40,6 +40,10 @@ HTF_API int htfs_build_nlist(const void *d_pos, const void *d_pos_sorted, int dt
                              htf_stream stream);
 
 /* dest[i] = src[order[i]] for Scalar4 arrays: the cell-sorted position copy */
+/* Cell binning: d_order <- particle indices sorted by cell (ascending index inside a cell: deterministic),
+ * d_cell_start[c] <- first slot of cell c (ncell + 1 entries).  d_scratch: 2 * ncell words. */
+HTF_API int htfs_cell_sort(const unsigned *d_cell_of, unsigned Ntot, unsigned ncell, unsigned *d_scratch,
+                           unsigned *d_cell_start, unsigned *d_order, htf_stream stream);
 HTF_API int htfs_gather4(void *d_dest, const void *d_src, const int *d_order, int dtype, unsigned n, htf_stream stream);
 
 /* cell index of every particle (x fastest): d_cell_of[i] */
