@@ -181,6 +181,7 @@ __global__ __launch_bounds__(256) void fused_forces_kernel(const typename Vec4<P
 // persistent kernel software-pipelined over rows (next row's metadata and list entries in flight
 // during the current row's evaluation -- what took the C4 sweep below from 241 to 217 us) 67-77 /
 // 63-70 us with 8192-2048 workgroups: here the hardware's own wave turnover does better.
+// Workgroups of one or two waves instead of four: 64.5-66 / 65 us against 62.4.
 // Two rows per wave with ALL their index loads, then all their gathers, issued before any
 // arithmetic: twice the bytes in flight per wave slot while the evaluator's VALU work (which,
 // unlike the plain build, this kernel has plenty of) runs under the other row's memory latency.
