@@ -296,9 +296,11 @@ __global__ __launch_bounds__(256, 1) void mlp_grad_mfma_kernel(const typename Ve
         const bool m = valid && slot < NN && r > kRinvDelta;
         const bool live = __ballot(m) != 0ull;
 
-        f32x16 h1[2] = {zero16(), zero16()}, hd1[2] = {zero16(), zero16()};
-        f32x16 q2[2] = {zero16(), zero16()}, qd2[2] = {zero16(), zero16()}; // zb2, zdb2
-        f32x16 q1[2] = {zero16(), zero16()}, qd1[2] = {zero16(), zero16()}; // zb1, zdb1
+        // written and read only under `live` (wave-uniform): no initialisation -- twelve tiles of v_mov 0
+        // per trip are VALU time the fp32 MFMAs cannot hide (pair_mlp.hip)
+        f32x16 h1[2], hd1[2];
+        f32x16 q2[2], qd2[2]; // zb2, zdb2
+        f32x16 q1[2], qd1[2]; // zb1, zdb1
         float4 part = make_float4(0.f, 0.f, 0.f, 0.f); // this tile's share of (F_i, E_i)
         if (live) {
             // ---- value + r-tangent, forward.  phi / phid go to LDS at once (needed again only
