@@ -131,3 +131,55 @@ def test_compute_forces_in_row_ranges_equals_whole(htf, cuda, mode):
         ctx.set_potential(pot)
         arr = ctx.make_arrays(sysm.pos, N, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, torch.zeros((N, 4), device=cuda))
         ctx.compute_forces(0, arr, rows=(N - 3, 10))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fused", [0, 2])
+def test_nve_energy_is_conserved(htf, cuda, fused):
+    """End-to-end sanity of the whole step (neighbor search with rebuilds, pair-vector build, LJModel
+    forces, leapfrog): 3000 NVE steps of a 4000-particle liquid.  LJModel's energy is cut (not shifted)
+    at r_cut, so the total energy random-walks by the jumps at the cutoff; a wrong force, a missed
+    neighbor or a stale list would show as drift orders of magnitude larger."""
+    from hoomd_tf_amd import standin
+    pos, L, a = standin.fcc_positions(10, 0.8442)
+    rng = np.random.default_rng(5)
+    pos = pos + 0.03 * a * rng.standard_normal(pos.shape)
+    pos -= np.round(pos / L) * L
+    s = standin.System(pos, L, dtype=torch.float32, device=cuda)
+    s.randomize_velocities(kT=0.8, seed=5)
+    nl = standin.CellNlist(s, r_cut=3.0, r_buff=0.4, check_period=1)
+    nl.build()
+    ctx = htf.Context(r_cut=3.0, nneighs=128, scalar_dtype=torch.float32, max_n=s.N, fused=fused)
+    ctx.set_potential(htf.Potential.lj())
+    nve = standin.NVE(s, 0.002)
+    arr = {"a": ctx.make_arrays(s.pos, s.N, nl.n_neigh, nl.head_list, nl.nlist, s.box, s.force), "b": nl.n_builds}
+
+    def step(ts):
+        nl.compute(ts)
+        if nl.n_builds != arr["b"]:
+            arr["a"] = ctx.make_arrays(s.pos, s.N, nl.n_neigh, nl.head_list, nl.nlist, s.box, s.force)
+            arr["b"] = nl.n_builds
+        ctx.compute_forces(ts, arr["a"])
+        nve.step()
+
+    def energy():
+        # leapfrog: velocities live at half steps; the kinetic energy at the force's time needs v(t) --
+        # average of the neighbouring half-step energies is accurate to O(dt^2)
+        pe = float(s.force[:, 3].double().sum())
+        ke = 0.5 * float((s.vel[:, :3].double() ** 2).sum())
+        return pe, ke
+
+    for ts in range(300):  # settle
+        step(ts)
+    tot = []
+    for ts in range(300, 3300):
+        step(ts)
+        if ts % 50 == 0:
+            pe, ke = energy()
+            tot.append((pe + ke) / s.N)
+    tot = np.array(tot)
+    assert nl.n_builds > 20
+    assert np.all(np.isfinite(tot))
+    drift = abs(np.polyfit(np.arange(len(tot)), tot, 1)[0]) * len(tot)
+    print("energy per particle: mean %.5f drift %.2e std %.2e rebuilds %d" % (tot.mean(), drift, tot.std(), nl.n_builds))
+    assert drift < 2e-3 and tot.std() < 2e-3, (drift, tot.std(), tot[:5], tot[-5:])  # measured 1.5e-4 / 3e-4
