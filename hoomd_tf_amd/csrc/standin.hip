@@ -116,6 +116,44 @@ __global__ __launch_bounds__(256) void cell_index_kernel(const typename Vec4<T>:
 // Hits are compacted with a ballot restricted to the group.  Every lane of the wave runs
 // the same trip counts (ranges of other groups are padded to the wave maximum) so the
 // ballots and shuffles are convergent.
+// Per cell and per (dy, dz) row of its stencil: the candidate ranges of the cell-sorted arrays, as
+// (begin, length) of the main x-run and of the run that wraps around the box (length 0 if none).
+// Every particle of a cell walks the same ranges: the search kernel then needs ONE load per row
+// instead of index arithmetic and two dependent cell_start loads.
+__global__ __launch_bounds__(256) void cell_ranges_kernel(int nx, int ny, int nz, int wx, int wy, int wz, int px, int py, int pz,
+                                                          const unsigned *__restrict__ cell_start, uint4 *__restrict__ table) {
+    const int nrow = (2 * wy + 1) * (2 * wz + 1);
+    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned ncell = (unsigned)(nx * ny * nz);
+    if (t >= ncell * (unsigned)nrow) return;
+    const int c = (int)(t / nrow), r = (int)(t % nrow);
+    const int cx = c % nx, cy = (c / nx) % ny, cz = c / (nx * ny);
+    const int dz = r / (2 * wy + 1) - wz, dy = r % (2 * wy + 1) - wy;
+    int a0 = cx - wx, a1 = cx + wx, b0 = 0, b1 = -1;
+    if (a0 < 0) {
+        if (px) { b0 = nx + a0; b1 = nx - 1; }
+        a0 = 0;
+    } else if (a1 >= nx) {
+        if (px) { b0 = 0; b1 = a1 - nx; }
+        a1 = nx - 1;
+    }
+    int ay = cy + dy, az = cz + dz;
+    bool skip = false;
+    if (ay < 0) { skip |= !py; ay += ny; } else if (ay >= ny) { skip |= !py; ay -= ny; }
+    if (az < 0) { skip |= !pz; az += nz; } else if (az >= nz) { skip |= !pz; az -= nz; }
+    uint4 o = make_uint4(0u, 0u, 0u, 0u);
+    if (!skip) {
+        const unsigned rowbase = (unsigned)((az * ny + ay) * nx);
+        o.x = cell_start[rowbase + a0];
+        o.y = cell_start[rowbase + a1 + 1] - o.x;
+        if (b1 >= b0) {
+            o.z = cell_start[rowbase + b0];
+            o.w = cell_start[rowbase + b1 + 1] - o.z;
+        }
+    }
+    table[t] = o;
+}
+
 template <typename T, int G>
 __global__ __launch_bounds__(256) void build_nlist_kernel(const typename Vec4<T>::type *__restrict__ pos,
                                                           const typename Vec4<T>::type *__restrict__ pos_sorted,
@@ -125,7 +163,8 @@ __global__ __launch_bounds__(256) void build_nlist_kernel(const typename Vec4<T>
                                                           const unsigned *__restrict__ cell_start, unsigned pitch,
                                                           int type_split,
                                                           unsigned *__restrict__ n_neigh, unsigned *__restrict__ head_list,
-                                                          unsigned *__restrict__ nlist, unsigned *__restrict__ max_neigh) {
+                                                          unsigned *__restrict__ nlist, unsigned *__restrict__ max_neigh,
+                                                          const uint4 *__restrict__ ranges) {
     const unsigned lane = threadIdx.x & 63u, g = lane % G, sub = lane / G;
     const unsigned i = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * (64 / G) + sub;
     const bool active = i < N;
@@ -137,56 +176,43 @@ __global__ __launch_bounds__(256) void build_nlist_kernel(const typename Vec4<T>
     const unsigned long long gmask = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << (sub * G);
     unsigned count = 0;
     unsigned *row = nlist + (size_t)(active ? i : 0) * pitch;
-    // x extent of the stencil as up to two cell ranges [a0, a1] and [b0, b1] (b empty if b1 < b0):
-    // the 2 wx + 1 x-adjacent cells are contiguous in the cell-sorted arrays unless they wrap
-    int a0 = cx - wx, a1 = cx + wx, b0 = 0, b1 = -1;
-    if (a0 < 0) {
-        if (b.periodic[0]) { b0 = nx + a0; b1 = nx - 1; }
-        a0 = 0;
-    } else if (a1 >= nx) {
-        if (b.periodic[0]) { b0 = 0; b1 = a1 - nx; }
-        a1 = nx - 1;
-    }
-    for (int dz = -wz; dz <= wz; ++dz)
-        for (int dy = -wy; dy <= wy; ++dy) {
-            int ay = cy + dy, az = cz + dz;
-            bool skip = false;
-            if (ay < 0) { skip |= !b.periodic[1]; ay += ny; } else if (ay >= ny) { skip |= !b.periodic[1]; ay -= ny; }
-            if (az < 0) { skip |= !b.periodic[2]; az += nz; } else if (az >= nz) { skip |= !b.periodic[2]; az -= nz; }
-            const unsigned rowbase = (unsigned)((az * ny + ay) * nx);
+    // the cell's candidate ranges come from the table (cell_ranges_kernel); the next row's entry is
+    // requested before the current row is walked
+    const int nrow = (2 * wy + 1) * (2 * wz + 1);
+    const uint4 *mine = ranges + (size_t)((cz * ny + cy) * nx + cx) * nrow;
+    uint4 rg_next = active ? mine[0] : make_uint4(0u, 0u, 0u, 0u);
+    for (int r = 0; r < nrow; ++r) {
+        const uint4 rg = rg_next;
+        if (r + 1 < nrow) rg_next = active ? mine[r + 1] : make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
-            for (int part = 0; part < 2; ++part) {
-                const int c0 = part ? b0 : a0, c1 = part ? b1 : a1;
-                unsigned beg = 0, len = 0;
-                if (!skip && c1 >= c0) {
-                    beg = cell_start[rowbase + c0];
-                    len = cell_start[rowbase + c1 + 1] - beg;
+        for (int part = 0; part < 2; ++part) {
+            const unsigned beg = part ? rg.z : rg.x, len = part ? rg.w : rg.y;
+            if (part == 1 && !__any(len != 0u)) break; // nobody in the wave wraps around the box in x
+            unsigned maxlen = len;
+            for (int m = G; m < 64; m <<= 1) {
+                unsigned o = (unsigned)__shfl_xor((int)maxlen, m);
+                maxlen = o > maxlen ? o : maxlen;
+            }
+            for (unsigned t = 0; t < maxlen; t += G) {
+                const unsigned m_idx = t + g;
+                bool hit = false;
+                unsigned k = 0;
+                if (active && m_idx < len) {
+                    k = order[beg + m_idx];
+                    const auto pk = pos_sorted[beg + m_idx];
+                    T ddx = mimg<T>(pk.x - pi.x, b.L[0], b.Linv[0], b.periodic[0]);
+                    T ddy = mimg<T>(pk.y - pi.y, b.L[1], b.Linv[1], b.periodic[1]);
+                    T ddz = mimg<T>(pk.z - pi.z, b.L[2], b.Linv[2], b.periodic[2]);
+                    hit = (k != i) && (ddx * ddx + ddy * ddy + ddz * ddz <= rl2);
+                    if (type_split >= 0) hit = hit && ((scalar_as_int(pk.w) >= type_split) == side_i);
                 }
-                unsigned maxlen = len;
-                for (int m = G; m < 64; m <<= 1) {
-                    unsigned o = (unsigned)__shfl_xor((int)maxlen, m);
-                    maxlen = o > maxlen ? o : maxlen;
-                }
-                for (unsigned t = 0; t < maxlen; t += G) {
-                    const unsigned m_idx = t + g;
-                    bool hit = false;
-                    unsigned k = 0;
-                    if (active && m_idx < len) {
-                        k = order[beg + m_idx];
-                        const auto pk = pos_sorted[beg + m_idx];
-                        T ddx = mimg<T>(pk.x - pi.x, b.L[0], b.Linv[0], b.periodic[0]);
-                        T ddy = mimg<T>(pk.y - pi.y, b.L[1], b.Linv[1], b.periodic[1]);
-                        T ddz = mimg<T>(pk.z - pi.z, b.L[2], b.Linv[2], b.periodic[2]);
-                        hit = (k != i) && (ddx * ddx + ddy * ddy + ddz * ddz <= rl2);
-                        if (type_split >= 0) hit = hit && ((scalar_as_int(pk.w) >= type_split) == side_i);
-                    }
-                    const unsigned long long bal = __ballot(hit) & gmask;
-                    const unsigned rank = count + ballot_rank(bal);
-                    if (hit && rank < pitch) row[rank] = k;
-                    count += __popcll(bal);
-                }
+                const unsigned long long bal = __ballot(hit) & gmask;
+                const unsigned rank = count + ballot_rank(bal);
+                if (hit && rank < pitch) row[rank] = k;
+                count += __popcll(bal);
             }
         }
+    }
     if (active && g == 0) {
         n_neigh[i] = count < pitch ? count : pitch;
         head_list[i] = i * pitch;
@@ -345,12 +371,35 @@ extern "C" int htfs_build_nlist(const void *d_pos, const void *d_pos_sorted, int
                     d, ncell3[d], w, sw, r_list);
     }
     if (N == 0) return HTF_OK;
+    // candidate ranges per cell and stencil row (2.7 MB at C3), kept across calls
+    const unsigned ncell = (unsigned)(ncell3[0] * ncell3[1] * ncell3[2]);
+    const unsigned nrow = (unsigned)((2 * stencil3[1] + 1) * (2 * stencil3[2] + 1));
+    static thread_local uint4 *d_ranges = nullptr;
+    static thread_local size_t ranges_cap = 0;
+    static thread_local int ranges_dev = -1;
+    int dev_now = 0;
+    HTF_CHECK_HIP(hipGetDevice(&dev_now));
+    if (dev_now != ranges_dev) { // a buffer of another device is not this call's to use (or to free here)
+        d_ranges = nullptr;
+        ranges_cap = 0;
+        ranges_dev = dev_now;
+    }
+    if ((size_t)ncell * nrow > ranges_cap) {
+        if (d_ranges) (void)hipFree(d_ranges);
+        d_ranges = nullptr;
+        ranges_cap = 0;
+        HTF_CHECK_HIP(hipMalloc((void **)&d_ranges, (size_t)ncell * nrow * sizeof(uint4)));
+        ranges_cap = (size_t)ncell * nrow;
+    }
+    hipLaunchKernelGGL(cell_ranges_kernel, dim3((ncell * nrow + 255) / 256), dim3(256), 0, (hipStream_t)stream, ncell3[0], ncell3[1],
+                       ncell3[2], stencil3[0], stencil3[1], stencil3[2], (int)box->periodic[0], (int)box->periodic[1],
+                       (int)box->periodic[2], d_cell_start, d_ranges);
     const bool fine = stencil3[0] == 2 || stencil3[1] == 2 || stencil3[2] == 2; // short ranges: 8-lane groups waste fewer lanes
 #define HTFS_NL(T, V4, G)                                                                                              \
     hipLaunchKernelGGL((build_nlist_kernel<T, G>), dim3((N + 4 * (64 / G) - 1) / (4 * (64 / G))), dim3(256), 0, (hipStream_t)stream, \
                        (const V4 *)d_pos, (const V4 *)d_pos_sorted, N, make_sbox<T>(box), (T)(r_list * r_list), ncell3[0],  \
                        ncell3[1], ncell3[2], stencil3[0], stencil3[1], stencil3[2], d_order, d_cell_start, pitch,      \
-                       type_split, d_n_neigh, d_head_list, d_nlist, d_max_neigh)
+                       type_split, d_n_neigh, d_head_list, d_nlist, d_max_neigh, (const uint4 *)d_ranges)
     if (dtype == HTF_F32) {
         if (fine) HTFS_NL(float, float4, 8); else HTFS_NL(float, float4, 16);
     } else {
