@@ -62,6 +62,9 @@ def parse():
     ap.add_argument("--two-kernel", action="store_true",
                     help="headline run with separate build and evaluator kernels (htf_config.fused = 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--f64", action="store_true",
+                    help="HOOMD built in double precision: fp64 positions / velocities / forces on the wire, fp32 pair vectors "
+                         "and model arithmetic (the reference casts the fp64 buffer to the model dtype, simmodel.py:226-238)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -81,11 +84,12 @@ def make_potential(htf, workload):
     return htf.Potential.pair_mlp(mlp_params(seed=3), 0.0, 3.0, activation="tanh", precision=prec)
 
 
-def algorithmic_bytes(N, NN, n_list_entries, n_tot):
-    """per-launch algorithmic bytes of each kernel (fp32)."""
-    eval_b = N * NN * 16 + N * 16
-    build_b = N * 8 + n_list_entries * 4 + n_tot * 16 + N * NN * 16
-    integ_b = N * 16 * 5  # pos r/w, vel r/w, force r
+def algorithmic_bytes(N, NN, n_list_entries, n_tot, s4=16):
+    """per-launch algorithmic bytes of each kernel; s4 = bytes of a HOOMD Scalar4 (16 fp32, 32 fp64).
+    The pair-vector tensor is fp32 either way."""
+    eval_b = N * NN * 16 + N * s4
+    build_b = N * 8 + n_list_entries * 4 + n_tot * s4 + N * NN * 16
+    integ_b = N * s4 * 5  # pos r/w, vel r/w, force r
     return eval_b, build_b, integ_b
 
 
@@ -341,7 +345,11 @@ def main():
     Lg = L.copy()
     Lg[0] = L[0] * world
     pos[:, 0] += (rank - (world - 1) / 2.0) * L[0]
-    sysm = standin.System(pos, Lg, dtype=torch.float32, device=dev)
+    sdt = torch.float64 if args.f64 else torch.float32
+    s4 = 32 if args.f64 else 16
+    if args.f64:
+        args.no_cpu_baseline = True  # the C port is the fp32 build
+    sysm = standin.System(pos, Lg, dtype=sdt, device=dev)
     sysm.randomize_velocities(kT=1.0, seed=3 + rank)
     nl = standin.CellNlist(sysm, r_cut=args.rcut, r_buff=args.rbuff, check_period=args.check_period,
                            sort_particles=args.sort)
@@ -355,7 +363,7 @@ def main():
     # registers (htf_config.fused = 2, the tfcompute default); the pair-MLP has its own MFMA evaluator
     closed_form = args.workload in ("lj", "wca", "mlp-train")
     one_kernel = closed_form and not args.two_kernel
-    ctx = htf.Context(r_cut=args.rcut, nneighs=NN, scalar_dtype=torch.float32, max_n=N, fused=2 if one_kernel else 0)
+    ctx = htf.Context(r_cut=args.rcut, nneighs=NN, scalar_dtype=sdt, max_n=N, fused=2 if one_kernel else 0)
     pot = make_potential(htf, args.workload)
     ctx.set_potential(pot)
     nve = standin.NVE(sysm, args.dt)
@@ -492,7 +500,7 @@ def main():
     kT_final = float((sysm.vel[:, :3].double() ** 2).sum().item()) / (3.0 * sysm.N)
 
     n_entries = int(nl.n_neigh.long().sum().item())
-    eval_b, build_b, integ_b = algorithmic_bytes(N, NN, n_entries, N + sysm.n_ghost)
+    eval_b, build_b, integ_b = algorithmic_bytes(N, NN, n_entries, N + sysm.n_ghost, s4)
     # per STEP (with slabs a step is two row ranges = two launches of each kernel; the
     # algorithmic bytes below are per step as well)
     # per STEP = mean bracketed batch x batches per step; under slabs a rebuild step is ONE whole-range batch
@@ -503,7 +511,7 @@ def main():
     if one_kernel:
         # its own compulsory traffic only: the build's bytes + the force write (the evaluator's
         # N*NN*16 re-read of SURVEY 8(d) no longer happens and is NOT credited)
-        be_b = build_b + N * 16
+        be_b = build_b + N * s4
         kern = {"build_eval_forces": {"avg_us": eval_avg_s * 1e6, "algorithmic_bytes": be_b,
                                       "GBps": be_b / eval_avg_s / 1e9 if eval_avg_s > 0 else None,
                                       # SURVEY 8(d) would credit this launch with the build's AND the evaluator's bytes
@@ -583,7 +591,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": {"mlp-bf16": "bf16 operands, f32 accumulation",
                   "mlp-split": "f32 (each operand split exactly into 3 bf16 parts, 6 partial products, f32 accumulation)"
-                  }.get(args.workload, "f32"),
+                  }.get(args.workload, "f32" if not args.f64 else "f32 arithmetic on an f64 wire (HOOMD in double precision)"),
         "data": "synthetic",
         "config": {"workload": "%s: fcc %d^3x4 = %d particles/GPU, rho 0.8442, r_cut %.1f, r_buff %.1f, NN %d, dt %g"
                                % ("C5b (pair-MLP MD + force-matching step every %d steps vs LJ labels)" % args.train_period
@@ -603,7 +611,7 @@ def main():
     # reference's two-kernel dataflow (build kernel, then evaluator kernel re-reading the tensor)
     # and (b) with the pair vectors kept in registers and NO tensor.
     def run_variant(mode, pot_v=None):
-        ctx_v = htf.Context(r_cut=args.rcut, nneighs=NN, scalar_dtype=torch.float32, max_n=sysm.N, fused=mode)
+        ctx_v = htf.Context(r_cut=args.rcut, nneighs=NN, scalar_dtype=sdt, max_n=sysm.N, fused=mode)
         ctx_v.set_potential(pot if pot_v is None else pot_v)
         state["arr_v"] = None
 
@@ -648,7 +656,7 @@ def main():
                 "build_pair_vectors": {"avg_us": b_s * 1e6, "algorithmic_bytes": build_b, "GBps": build_b / b_s / 1e9 if b_s > 0 else None},
                 "eval_forces": {"avg_us": e_s * 1e6, "algorithmic_bytes": eval_b, "GBps": eval_b / e_s / 1e9 if e_s > 0 else None}}
         el, _, f_s = run_variant(1)
-        fb = sysm.N * 8 + n_entries * 4 + (sysm.N + sysm.n_ghost) * 16 + sysm.N * 16
+        fb = sysm.N * 8 + n_entries * 4 + (sysm.N + sysm.n_ghost) * s4 + sysm.N * s4
         out["fused_variant"] = {
             "note": "pair vectors evaluated in registers (htf_config.fused=1); the [N,NN,4] tensor is not materialised",
             "value": world * args.steps / el, "unit": "steps/s", "ms_per_step": el / args.steps * 1e3,

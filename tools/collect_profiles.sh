@@ -4,6 +4,7 @@ R=${1:-r01}
 cd "$(dirname "$0")/.."
 F=gpurun_out/final
 cp $F/bench_lj.json profiles/${R}_bench_lj.json
+cp $F/bench_lj_f64.json profiles/${R}_bench_lj_f64.json
 cp $F/bench_wca.json profiles/${R}_bench_wca.json
 cp $F/bench_wca_c2.json profiles/${R}_bench_wca_c2.json
 cp $F/bench_mlp.json profiles/${R}_bench_mlp.json

@@ -4,6 +4,7 @@ mkdir -p gpurun_out/final
 python -m pytest tests -q -m gpu > gpurun_out/final/pytest_gpu.log 2>&1; tail -2 gpurun_out/final/pytest_gpu.log
 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/final/smoke.log 2>&1; tail -2 gpurun_out/final/smoke.log
 python bench.py > gpurun_out/final/bench_lj.json 2>gpurun_out/final/bench_lj.err
+python bench.py --f64 > gpurun_out/final/bench_lj_f64.json 2>/dev/null
 python bench.py --workload wca > gpurun_out/final/bench_wca.json 2>/dev/null
 python bench.py --workload wca --cells 20 > gpurun_out/final/bench_wca_c2.json 2>/dev/null
 python bench.py --workload mlp --steps 100 --warmup 10 > gpurun_out/final/bench_mlp.json 2>/dev/null
