@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Headline benchmark: MD steps/s + achieved HBM GB/s, 131 072 particles, NN = 128.
 
-    python bench.py --gpus N --steps K --warmup W          (N=1)
+    python bench.py --gpus N --steps K --warmup W
+        N > 1 without WORLD_SIZE in the environment: this process starts N rank processes itself
+        (fresh children, before anything touches the GPU) and relays rank 0's JSON line
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one pass of the hot path over the whole particle batch, exactly what
@@ -13,8 +15,11 @@ HBM before the timed region starts.
 
 Workload (SURVEY 8(d) "C3-LJ", BASELINE.json metric): fcc 4*32^3 = 131 072 particles,
 rho = 0.8442, Gaussian jitter 0.05 a (seed 3), r_cut = 3.0, r_buff = 0.4, NN = 128,
-LJModel, fp32, dt = 0.005, Maxwell velocities kT = 1.0.  Weak scaling: every rank owns
-one such domain (config 5: 8 x 131 072 = 1.05 M particles).
+LJModel, fp32, dt = 0.005, Maxwell velocities kT = 1.0.
+N > 1, --scaling strong (default): THAT box decomposed into N slabs along x (BASELINE metric:
+"131k particles ... at 1/2/4/8 GPUs"); --scaling weak: every rank owns one such block of an
+N-block box (config 5: 8 x 131 072 = 1.05 M particles).  `value` is always the MD steps/s of the
+GLOBAL system; `particle_steps_per_s` = global particles x value.
 
 Prints ONE JSON line (rank 0).  roofline.achieved = ALGORITHMIC bytes per launch /
 average launch duration measured with hipEvents on the launch stream inside the timed
@@ -61,6 +66,15 @@ def parse():
     ap.add_argument("--sync-train", action="store_true", help="mlp-train: run the training step on the MD stream (no overlap)")
     ap.add_argument("--two-kernel", action="store_true",
                     help="headline run with separate build and evaluator kernels (htf_config.fused = 0)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N > 1: strong = the --cells box itself cut into N slabs (default; the BASELINE metric), "
+                         "weak = N such boxes side by side, one per rank (config 5)")
+    ap.add_argument("--windows", type=int, default=0,
+                    help="timed windows of --steps steps each; `value` is their median (0 = 5 windows when --steps <= 50, else 1)")
+    ap.add_argument("--host-nlist-decision", action="store_true",
+                    help="read the neighbor-list distance check back to the host (round-1 behaviour); default: the "
+                         "rebuild is gated on the device, the step loop never synchronises")
+    ap.add_argument("--no-mlp", action="store_true", help="default N = 1 run: skip the pair-MLP sub-records")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--f64", action="store_true",
                     help="HOOMD built in double precision: fp64 positions / velocities / forces on the wire, fp32 pair vectors "
@@ -94,27 +108,63 @@ def algorithmic_bytes(N, NN, n_list_entries, n_tot, s4=16):
 
 
 def cpu_baseline(sysm, nl, args):
-    """Time the C restatement of the same computeForces pass (oracle/htf_oracle_c.c,
-    OpenMP over all host cores) on the SAME inputs.  Baseline only, never the product."""
+    """Time the C restatement of the same computeForces pass (oracle/htf_oracle_c.c, OpenMP over the host
+    cores this process may use) on the SAME inputs, for a bounded ~10 s.  Baseline only, never the product."""
     from oracle import c_oracle
     lib = c_oracle.load()
     pos4 = sysm.pos.cpu().numpy().astype(np.float32)
     nn = nl.n_neigh.cpu().numpy().view(np.uint32)
     head = nl.head_list.cpu().numpy().view(np.uint32)
     nlist = nl.nlist.cpu().numpy().view(np.uint32)
-    scratch = np.empty((sysm.N, args.nn, 4), dtype=np.float32)
-    f = c_oracle.compute_forces_lj(lib, pos4, nn, head, nlist, sysm.box3x3, args.rcut, args.nn, scratch)
+    N, NN = sysm.N, args.nn
+    cores = int(lib.htfo_num_threads())
+    if args.workload in ("mlp", "mlp-split", "mlp-bf16"):
+        # 24.8 kflop per slot with libm tanhf / expf: a full pass takes seconds, so a contiguous row
+        # sample is timed (rows are independent) and scaled to the box
+        from hoomd_tf_amd.initializers import mlp_params
+        params = mlp_params(seed=3)
+        rows = min(N, 8192)
+        out = np.empty((rows, 4), dtype=np.float32)
+
+        def one():
+            pv = c_oracle.prepare_neighbors(lib, pos4, nn, head, nlist, sysm.box3x3, args.rcut, NN, offset=0, batch=rows)
+            c_oracle.mlp_from_nlist(lib, pv, params, 0.0, 3.0, act="tanh", out=out)
+        what = ("computeForces passes (prepareNeighbors + pair-MLP RBF(0,3,32)-64-64-1 tanh with the analytic backward, "
+                "C/OpenMP restatement, fp32) over rows [0, %d) of the same %d x %d workload, scaled to all rows" % (rows, N, NN))
+        scale = rows / float(N)
+    else:
+        rows = N
+        scratch = np.empty((N, NN, 4), dtype=np.float32)
+        if args.workload == "wca":
+            import ctypes as C
+            force = np.empty((N, 4), dtype=np.float32)
+            lo, hi, tilt, per = c_oracle._box_args(sysm.box3x3, (1, 1, 1))
+            p = c_oracle._p
+
+            def one():
+                lib.htfo_compute_forces_wca_f32(p(pos4), C.c_uint(N), p(nn), p(head), p(nlist), p(lo), p(hi), p(tilt), p(per),
+                                                C.c_double(args.rcut), C.c_uint(NN), C.c_float(1.0), p(scratch), p(force))
+            model = "WCA model (WCARepulsion sigma 1.0)"
+        else:
+            def one():
+                c_oracle.compute_forces_lj(lib, pos4, nn, head, nlist, sysm.box3x3, args.rcut, NN, scratch)
+            model = "LJModel"
+        what = ("computeForces passes (prepareNeighbors + %s, C/OpenMP restatement, fp32) over the same %d x %d workload"
+                % (model, N, NN))
+        scale = 1.0
+    one()
     t0 = time.perf_counter()
     reps = 0
     while True:
-        c_oracle.compute_forces_lj(lib, pos4, nn, head, nlist, sysm.box3x3, args.rcut, args.nn, scratch)
+        one()
         reps += 1
         el = time.perf_counter() - t0
         if el > args.cpu_seconds or reps >= 400:
             break
-    out = {"value": reps / el, "unit": "steps/s", "cores": int(lib.htfo_num_threads()), "kind": "port",
-           "sample": "%d computeForces passes (prepareNeighbors + LJModel, C/OpenMP restatement, fp32) "
-                     "over the same %d x %d workload; integrator not included" % (reps, sysm.N, args.nn)}
+    out = {"value": reps / el * scale, "unit": "steps/s", "cores": cores, "kind": "port",
+           "sample": "%d %s; integrator not included" % (reps, what)}
+    if args.workload != "lj":
+        return out
     # SURVEY 8(d) also asks for the GRAPH-STYLE restatement: the reference's op sequence (one pass
     # over [rows, NN] per TF op, forward + tf.gradients) as torch-CPU ops on a bounded row sample
     try:
@@ -134,7 +184,7 @@ def cpu_baseline(sysm, nl, args):
                                                        % (r2, rows, sysm.N)}
     except Exception as e:  # noqa: BLE001 -- the baseline is informational
         out["graph_style"] = {"error": str(e)}
-    return out, f
+    return out
 
 
 def run_eds(args, htf, standin, dev):
@@ -297,24 +347,65 @@ def run_eds(args, htf, standin, dev):
     print(json.dumps(out))
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with no launcher: start the N rank processes from here -- plain children
+    of a parent that has not touched the GPU (never a re-exec) -- and relay rank 0's JSON line."""
+    import socket
+    import subprocess
+    backend = os.environ.get("HTF_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()  # counting devices does not initialise the GPU
+    if backend == "nccl" and ndev < args.gpus:
+        print("bench.py --gpus %d: this node shows %d GPU(s).  RCCL wants one device per rank; "
+              "HTF_BENCH_BACKEND=gloo rehearses the multi-rank path with the ranks sharing devices."
+              % (args.gpus, ndev), file=sys.stderr)
+        return 2
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else None))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode]
+    for pr in procs[1:]:
+        try:
+            rcs.append(pr.wait(timeout=120))
+        except subprocess.TimeoutExpired:
+            pr.kill()
+            rcs.append(-9)
+    sys.stdout.write(out.decode("utf-8", "replace"))
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
+
+
+class Env:
+    """What one rank process knows about the job."""
+
+
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args))
+    E = Env()
+    E.world = world = int(os.environ.get("WORLD_SIZE", "1"))
+    E.rank = rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the evaluator has no CPU path")
     # HTF_BENCH_BACKEND=gloo: rehearsal of the multi-rank code path with several ranks on ONE
     # GPU (RCCL refuses that); messages then bounce through host memory -- not a measurement
-    backend = os.environ.get("HTF_BENCH_BACKEND", "nccl")
+    E.backend = backend = os.environ.get("HTF_BENCH_BACKEND", "nccl")
     if backend != "nccl":
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
+    E.dev = dev = torch.device("cuda", local_rank)
+    E.dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -322,37 +413,80 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+        E.dist = dist
 
     import hoomd_tf_amd as htf
     from hoomd_tf_amd import standin
+    E.htf, E.standin = htf, standin
 
-    if args.workload != "lj":
-        args.no_cpu_baseline = True  # the C port restates LJModel only
-    if args.workload == "mlp-train":
-        args.no_fused = True
     if args.workload == "eds":
         if world > 1:
             raise SystemExit("the C4 workload is a single-GPU configuration")
         return run_eds(args, htf, standin, dev)
+    headline = args.workload == "lj" and world == 1 and not args.f64 and not args.two_kernel
+    out = run_md(args, E, args.workload, variants=not args.no_fused, cpu=not args.no_cpu_baseline)
+    if headline and not args.no_mlp and args.cells == 32:
+        # north_star: "LJ AND MLP pair-potential boxes": the same C3 system driven by the pair-MLP, fp32 MFMA
+        # (its split-operand twin rides along as `split_variant`), a bounded number of steps (~3 ms each)
+        import copy
+        a2 = copy.copy(args)
+        a2.steps, a2.warmup, a2.equil, a2.windows = min(args.steps, 40), min(args.warmup, 5), min(args.equil, 100), 1
+        sub = run_md(a2, E, "mlp", variants=not args.no_fused, cpu=not args.no_cpu_baseline)
+        out["mlp"] = {k: sub[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "kernels",
+                                         "roofline", "split_variant", "cpu_baseline", "energy_per_particle") if k in sub}
+    if rank == 0:
+        print(json.dumps(out))
+    if E.dist is not None:
+        E.dist.barrier()
+        E.dist.destroy_process_group()
 
+
+def run_md(args, E, workload, variants=True, cpu=True):
+    """One MD workload (lj | wca | mlp | mlp-split | mlp-bf16 | mlp-train) on this job's ranks -> the JSON record."""
+    import copy
+    args = copy.copy(args)
+    args.workload = workload
+    args.no_fused = not variants
+    args.no_cpu_baseline = not cpu
+    world, rank, dev, dist, htf, standin = E.world, E.rank, E.dev, E.dist, E.htf, E.standin
+    if args.workload == "mlp-train":
+        args.no_fused = True
     # ---- synthetic system, resident in HBM -------------------------------------------------
-    # Each rank owns one 131 072-particle block; the global periodic box is `world` blocks
-    # side by side along x (config 5 at 8 ranks: 1.05 M particles, 8 x 1 x 1 slabs).
+    # strong (default): the ONE 4*cells^3-particle box of the metric, every rank generates it identically
+    # and keeps the particles of its slab.  weak: each rank owns one such block; the global periodic box
+    # is `world` blocks side by side along x (config 5 at 8 ranks: 1.05 M particles, 8 x 1 x 1 slabs).
+    strong = world > 1 and args.scaling == "strong"
     pos, L, a = standin.fcc_positions(args.cells, 0.8442)
-    rng = np.random.default_rng(3 + rank)
+    rng = np.random.default_rng(3 + (0 if strong else rank))
     pos = pos + 0.05 * a * rng.standard_normal(pos.shape)
     pos -= np.round(pos / L) * L
+    n_block = len(pos)
     Lg = L.copy()
-    Lg[0] = L[0] * world
-    pos[:, 0] += (rank - (world - 1) / 2.0) * L[0]
+    vel0 = None
+    if strong:
+        g = torch.Generator(device="cpu").manual_seed(3)
+        vel0 = torch.randn((n_block, 3), generator=g, dtype=torch.float64)
+        vel0 -= vel0.mean(dim=0, keepdim=True)
+        bounds = -L[0] / 2 + np.linspace(0.0, 1.0, world + 1) * L[0]
+        mine = (pos[:, 0] >= bounds[rank]) & ((pos[:, 0] < bounds[rank + 1]) | (rank == world - 1))
+        pos, vel0 = pos[mine], vel0[torch.from_numpy(mine)]
+        n_global = n_block
+    else:
+        Lg[0] = L[0] * world
+        pos[:, 0] += (rank - (world - 1) / 2.0) * L[0]
+        n_global = n_block * world
     sdt = torch.float64 if args.f64 else torch.float32
     s4 = 32 if args.f64 else 16
     if args.f64:
         args.no_cpu_baseline = True  # the C port is the fp32 build
     sysm = standin.System(pos, Lg, dtype=sdt, device=dev)
-    sysm.randomize_velocities(kT=1.0, seed=3 + rank)
+    if vel0 is None:
+        sysm.randomize_velocities(kT=1.0, seed=3 + rank)
+    else:
+        sysm.vel[:, :3] = vel0.to(sdt).to(dev)
     nl = standin.CellNlist(sysm, r_cut=args.rcut, r_buff=args.rbuff, check_period=args.check_period,
-                           sort_particles=args.sort)
+                           sort_particles=args.sort,
+                           device_decision=(world == 1 and not args.sort and not args.host_nlist_decision))
     if world > 1:
         from hoomd_tf_amd.domain import SlabDomain
         nl.domain = SlabDomain(sysm, rank, world, r_ghost=args.rcut + args.rbuff)
@@ -466,32 +600,43 @@ def main():
         v3.mul_(torch.sqrt(1.0 / ((v3 * v3).sum() / (3.0 * sysm.N))))
         state["ts"] = ts + 1
 
+    def builds_now():
+        return nl.n_builds + nl.device_builds()
+
+    def timed_window():
+        """EXACTLY args.steps steps between barrier + synchronize on both sides; max over ranks."""
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(True)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
     for _ in range(args.warmup):
         step()
     # kernel durations: hipEvents around every PROF_EVERY-th htf_compute_forces batch of the timed region
     # (an odd period, so that with slabs interior and boundary launches are sampled alike); bracketing every
     # launch costs the 0.1 ms step about 8 %
     ctx.profile_enable(PROF_EVERY)
-    batches_per_step = 2 if (nl.domain is not None and world > 1) else 1
-    builds0 = nl.n_builds
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+    batches_per_step = 2 if (nl.domain is not None and world > 1 and nl.domain.n_interior > 0) else 1
+    # `value` = median over the windows: a 20-step window is 2 ms and holds one to three neighbor-list
+    # rebuilds (~0.25 ms each), so a single short window swings by +-10 % with where the rebuilds fall
+    n_windows = args.windows if args.windows > 0 else (5 if args.steps <= 50 else 1)
+    builds0 = builds_now()
+    windows = [timed_window() for _ in range(n_windows)]
+    elapsed = float(np.median(windows))
     build_ms, eval_ms, ncalls = ctx.profile_read()
     ctx.profile_enable(False)
-    rebuilds = nl.n_builds - builds0
-
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    rebuilds = (builds_now() - builds0) / n_windows  # per window of args.steps steps
 
     # sanity: the run must still be a valid simulation
     f = sysm.force
@@ -585,24 +730,36 @@ def main():
     # re-read the tensor, so the evaluator's bytes are not counted for it)
     step_bytes = (build_b + N * s4 if one_kernel else eval_b + build_b) + integ_b
     out = {
-        "metric": "MD steps/sec (131072-particle LJ domain steps, NN=128; summed over ranks) + achieved HBM GB/s",
-        "value": world * args.steps / elapsed,
+        "metric": "MD steps/sec + achieved HBM GB/s, %d particles NN=%d (%s)" % (
+            n_global, NN, "131k-particle box of the BASELINE metric" if n_global == 131072 else
+            ("config 5 block layout: one 131072-particle block per rank" if not strong and world > 1 else "non-default size")),
+        # MD steps per second of the GLOBAL system (every rank advances its share of every step)
+        "value": args.steps / elapsed,
         "unit": "steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "strong" if (strong or world == 1) else "weak", "vs_baseline": None,
+        "particle_steps_per_s": n_global * args.steps / elapsed,
+        "windows_ms_per_step": [w / args.steps * 1e3 for w in windows],
+        "value_is": "median of %d timed windows of %d steps each" % (n_windows, args.steps) if n_windows > 1 else "one timed window",
         "dtype": {"mlp-bf16": "bf16 operands, f32 accumulation",
                   "mlp-split": "f32 (each operand split exactly into 3 bf16 parts, 6 partial products, f32 accumulation)"
                   }.get(args.workload, "f32" if not args.f64 else "f32 arithmetic on an f64 wire (HOOMD in double precision)"),
         "data": "synthetic",
-        "config": {"workload": "%s: fcc %d^3x4 = %d particles/GPU, rho 0.8442, r_cut %.1f, r_buff %.1f, NN %d, dt %g"
+        "config": {"workload": "%s: fcc %d^3x4 = %d particles %s, rho 0.8442, r_cut %.1f, r_buff %.1f, NN %d, dt %g"
                                % ("C5b (pair-MLP MD + force-matching step every %d steps vs LJ labels)" % args.train_period
                                   if args.workload == "mlp-train" else ("C2-WCA" if args.workload == "wca" and args.cells == 20 else "C3-" + args.workload.upper()),
-                                  args.cells, N, args.rcut, args.rbuff, NN, args.dt),
-                   "global_particles": N * world, "parallelism": "dd%dx1x1" % world,
-                   "nlist_rebuilds_in_timed_region": rebuilds, "max_neighbors_within_rcut": max_kept,
+                                  args.cells, n_block, "in all, cut into %d slabs" % world if strong else ("per GPU" if world > 1 else "on one GPU"),
+                                  args.rcut, args.rbuff, NN, args.dt),
+                   "global_particles": n_global, "particles_rank0": N, "parallelism": "dd%dx1x1" % world,
+                   "nlist_rebuilds_per_window": rebuilds, "max_neighbors_within_rcut": max_kept,
+                   "nlist_decision": "device (gated rebuild kernels, no read-back in the step loop)" if nl.device_decision and world == 1 and not args.sort
+                                     else "host (distance check read back every %d steps%s)" % (args.check_period, ", all-reduced over ranks" if world > 1 else ""),
                    "halo": None if world == 1 else {"ghosts_rank0": sysm.n_ghost, "migrated_rank0": nl.domain.n_migrated,
-                                                    "exchange": "forward ghost positions, RCCL send/recv, every step"}},
+                                                    "interior_rows_rank0": nl.domain.n_interior,
+                                                    "transport": E.backend if E.backend != "nccl" else "RCCL (torch.distributed nccl backend)",
+                                                    "exchange": "forward ghost positions, grouped send/recv, every step"}},
+        # sum over ranks of the algorithmic bytes a step moves (rank 0's count x ranks) / step time
         "hbm_GBps_full_step": world * step_bytes / (elapsed / args.steps) / 1e9,
         "hbm_frac_full_step": step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
         "energy_per_particle": e_per_particle, "kT_final": kT_final,
@@ -654,14 +811,14 @@ def main():
             el, b_s, e_s = run_variant(0)
             out["two_kernel_variant"] = {
                 "note": "htf_config.fused = 0: build kernel, then evaluator kernel re-reading the tensor (SURVEY 8(d) dataflow)",
-                "value": world * args.steps / el, "unit": "steps/s", "ms_per_step": el / args.steps * 1e3,
+                "value": args.steps / el, "unit": "steps/s", "ms_per_step": el / args.steps * 1e3,
                 "build_pair_vectors": {"avg_us": b_s * 1e6, "algorithmic_bytes": build_b, "GBps": build_b / b_s / 1e9 if b_s > 0 else None},
                 "eval_forces": {"avg_us": e_s * 1e6, "algorithmic_bytes": eval_b, "GBps": eval_b / e_s / 1e9 if e_s > 0 else None}}
         el, _, f_s = run_variant(1)
         fb = sysm.N * 8 + n_entries * 4 + (sysm.N + sysm.n_ghost) * s4 + sysm.N * s4
         out["fused_variant"] = {
             "note": "pair vectors evaluated in registers (htf_config.fused=1); the [N,NN,4] tensor is not materialised",
-            "value": world * args.steps / el, "unit": "steps/s", "ms_per_step": el / args.steps * 1e3,
+            "value": args.steps / el, "unit": "steps/s", "ms_per_step": el / args.steps * 1e3,
             "kernel_avg_us": f_s * 1e6, "algorithmic_bytes": fb, "GBps": fb / f_s / 1e9 if f_s > 0 else None,
             "energy_per_particle": float(sysm.force[:, 3].double().sum().item()) / sysm.N}
     # (b') pair-MLP: the same network and weights evaluated on the bf16 matrix pipeline with every fp32 operand
@@ -680,7 +837,7 @@ def main():
             "note": "precision='split': fp32 operands split exactly into 3 bf16 parts, 6 partial products per multiply on "
                     "v_mfma_f32_32x32x16_bf16, fp32 accumulation; forces agree with the fp32-MFMA evaluator on the same "
                     "pair vectors to max|dF|/max|F| = %.1e" % rel,
-            "value": world * args.steps / el, "unit": "steps/s", "ms_per_step": el / args.steps * 1e3,
+            "value": args.steps / el, "unit": "steps/s", "ms_per_step": el / args.steps * 1e3,
             "eval_forces_avg_us": e_s * 1e6, "executed_TFLOPs": flops / e_s / 1e12 if e_s > 0 else None,
             "max_rel_force_difference_vs_fp32_mfma": rel}
     # (c) the same MD through the plugin surface a user touches: an htf.SimModel written op by op as in the
@@ -714,15 +871,10 @@ def main():
             "replayed": tfc._plan is not None,
             "energy_per_particle": float(tfc.force[:, 3].double().sum().item()) / sysm.N}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cb, f_cpu = cpu_baseline(sysm, nl, args)
-        out["cpu_baseline"] = cb
+        out["cpu_baseline"] = cpu_baseline(sysm, nl, args)
     elif rank == 0:
         out["cpu_baseline"] = None
-    if rank == 0:
-        print(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    return out
 
 
 if __name__ == "__main__":

@@ -24,6 +24,12 @@
 
 namespace htf {
 
+#ifndef HTF_ROWS2_THREADS
+#define HTF_ROWS2_THREADS 256
+#endif
+#ifndef HTF_ROWS2_WAVES
+#define HTF_ROWS2_WAVES 1
+#endif
 constexpr int kFChunk = 3; // index loads hoisted per lane per trip (as pair_vectors.hip: n_neigh <= 192 in one trip)
 
 struct FusedAcc {
@@ -296,7 +302,7 @@ __device__ __forceinline__ void fused_rows_group(
 // and which has arithmetic to hide its loads under, is best with one group per wave
 // (C3, tensor written: 62.5 us; 4 / 8 / 12 / 16 workgroups per CU: 84 / 78 / 69 / 68 us), the default.
 template <int KIND, bool STORE, int R, typename PT>
-__global__ __launch_bounds__(256) void fused_forces_rows2_kernel(
+__global__ __launch_bounds__(HTF_ROWS2_THREADS, HTF_ROWS2_WAVES) void fused_forces_rows2_kernel(
     const typename Vec4<PT>::type *__restrict__ pos, unsigned N, unsigned NN, unsigned offset, unsigned batch,
     BoxT<PT> box, const unsigned *__restrict__ n_neigh, const unsigned *__restrict__ nlist,
     const unsigned *__restrict__ head_list, PT rmaxsq, void *__restrict__ force, int out_f64, PotParams pin,
@@ -325,10 +331,14 @@ static int launch_fused(const void *pos, unsigned N, unsigned NN, unsigned offse
         static const char *grid_env = getenv("HTF_FUSED_GRID"); // A/B runs: workgroups per CU, 0 = one wave per group
         static const int per_cu = grid_env ? atoi(grid_env) : 0;
         static const int n_cu = device_cu_count();
+        static const char *blk_env = getenv("HTF_FUSED_BLOCK"); // A/B runs: threads per workgroup
+        const unsigned wpb = (blk_env ? (unsigned)atoi(blk_env) : 256u) / 64u;
+        static const char *pad_env = getenv("HTF_FUSED_LDSPAD"); // A/B runs: dynamic LDS bytes per workgroup (caps occupancy)
+        const unsigned lds_pad = pad_env ? (unsigned)atoi(pad_env) : 0u;
 #define HTF_ROWS_LAUNCH(ST, RR)                                                                                        \
-    const unsigned full = ((batch + RR - 1) / RR + 3) / 4;                                                             \
+    const unsigned full = ((batch + RR - 1) / RR + wpb - 1) / wpb;                                                     \
     const unsigned grid = per_cu > 0 && (unsigned)(per_cu * n_cu) < full ? (unsigned)(per_cu * n_cu) : full;           \
-    hipLaunchKernelGGL((fused_forces_rows2_kernel<KIND, ST, RR, PT>), dim3(grid), dim3(256), 0, s, \
+    hipLaunchKernelGGL((fused_forces_rows2_kernel<KIND, ST, RR, PT>), dim3(grid), dim3(wpb * 64), lds_pad, s, \
                        (const typename Vec4<PT>::type *)pos, N, NN, offset, batch, b, n_neigh, nlist, head_list,       \
                        (PT)(rc * rc), force, out_f64, p, check_count, positions_out, dest, counts_io)
         if (rows == 2 || rows == 4) {

@@ -9,6 +9,17 @@
 
 namespace htf {
 
+// Device-side gate of a conditional neighbor-list rebuild: between htfs_set_gate(d_disp2, thr2) and
+// htfs_set_gate(NULL, 0) every binning / search kernel launched through this file returns at entry
+// unless *d_disp2 > thr2 -- the decision NeighborList::distanceCheck takes on the host is taken by the
+// kernels themselves, so the step loop never waits for a read-back.
+struct Gate {
+    const float *disp2;
+    float thr2;
+    __device__ __forceinline__ bool closed() const { return disp2 != nullptr && !(*disp2 > thr2); }
+};
+static thread_local Gate g_gate = {nullptr, 0.f};
+
 template <typename T>
 struct SBox {
     T lo[3], L[3], Linv[3];
@@ -96,7 +107,8 @@ __device__ __forceinline__ int cell_coord(T x, T lo, T Linv, int n) {
 template <typename T>
 __global__ __launch_bounds__(256) void cell_index_kernel(const typename Vec4<T>::type *__restrict__ pos, unsigned Ntot,
                                                          SBox<T> b, int nx, int ny, int nz,
-                                                         unsigned *__restrict__ cell_of) {
+                                                         unsigned *__restrict__ cell_of, Gate gate) {
+    if (gate.closed()) return;
     unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= Ntot) return;
     auto p = pos[i];
@@ -121,7 +133,8 @@ __global__ __launch_bounds__(256) void cell_index_kernel(const typename Vec4<T>:
 // Every particle of a cell walks the same ranges: the search kernel then needs ONE load per row
 // instead of index arithmetic and two dependent cell_start loads.
 __global__ __launch_bounds__(256) void cell_ranges_kernel(int nx, int ny, int nz, int wx, int wy, int wz, int px, int py, int pz,
-                                                          const unsigned *__restrict__ cell_start, uint4 *__restrict__ table) {
+                                                          const unsigned *__restrict__ cell_start, uint4 *__restrict__ table, Gate gate) {
+    if (gate.closed()) return;
     const int nrow = (2 * wy + 1) * (2 * wz + 1);
     const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned ncell = (unsigned)(nx * ny * nz);
@@ -164,7 +177,8 @@ __global__ __launch_bounds__(256) void build_nlist_kernel(const typename Vec4<T>
                                                           int type_split,
                                                           unsigned *__restrict__ n_neigh, unsigned *__restrict__ head_list,
                                                           unsigned *__restrict__ nlist, unsigned *__restrict__ max_neigh,
-                                                          const uint4 *__restrict__ ranges) {
+                                                          const uint4 *__restrict__ ranges, Gate gate) {
+    if (gate.closed()) return;
     const unsigned lane = threadIdx.x & 63u, g = lane % G, sub = lane / G;
     const unsigned i = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * (64 / G) + sub;
     const bool active = i < N;
@@ -251,7 +265,8 @@ extern "C" int htfs_max_displacement2(const void *d_pos, const void *d_ref, int 
 
 namespace htf {
 template <typename V>
-__global__ void gather4_kernel(V *__restrict__ dest, const V *__restrict__ src, const int *__restrict__ order, unsigned n) {
+__global__ void gather4_kernel(V *__restrict__ dest, const V *__restrict__ src, const int *__restrict__ order, unsigned n, Gate gate) {
+    if (gate.closed()) return;
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dest[i] = src[order[i]];
 }
@@ -262,14 +277,16 @@ namespace htf {
 // index), in four small kernels -- what the stand-in used torch.sort + searchsorted for (38 + 10 us of
 // kernels and a dozen launches per rebuild)
 __global__ __launch_bounds__(256) void cell_count_kernel(const unsigned *__restrict__ cell_of, unsigned n,
-                                                         unsigned *__restrict__ count) {
+                                                         unsigned *__restrict__ count, Gate gate) {
+    if (gate.closed()) return;
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) atomicAdd(&count[cell_of[i]], 1u);
 }
 
 // exclusive scan of count[0..ncell) into start[0..ncell], one workgroup; cursor <- start
 __global__ __launch_bounds__(1024) void cell_scan_kernel(const unsigned *__restrict__ count, unsigned ncell,
-                                                         unsigned *__restrict__ start, unsigned *__restrict__ cursor) {
+                                                         unsigned *__restrict__ start, unsigned *__restrict__ cursor, Gate gate) {
+    if (gate.closed()) return;
     __shared__ unsigned s_sum[1024];
     const unsigned t = threadIdx.x;
     const unsigned per = (ncell + 1023u) / 1024u;
@@ -294,14 +311,16 @@ __global__ __launch_bounds__(1024) void cell_scan_kernel(const unsigned *__restr
 }
 
 __global__ __launch_bounds__(256) void cell_scatter_kernel(const unsigned *__restrict__ cell_of, unsigned n,
-                                                           unsigned *__restrict__ cursor, unsigned *__restrict__ order) {
+                                                           unsigned *__restrict__ cursor, unsigned *__restrict__ order, Gate gate) {
+    if (gate.closed()) return;
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) order[atomicAdd(&cursor[cell_of[i]], 1u)] = i;
 }
 
 // the scatter's order inside a cell depends on the atomics' timing: sort each cell's few members
 __global__ __launch_bounds__(256) void cell_order_kernel(const unsigned *__restrict__ start, unsigned ncell,
-                                                         unsigned *__restrict__ order) {
+                                                         unsigned *__restrict__ order, Gate gate) {
+    if (gate.closed()) return;
     const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= ncell) return;
     const unsigned b = start[c], e = start[c + 1];
@@ -325,10 +344,10 @@ extern "C" int htfs_cell_sort(const unsigned *d_cell_of, unsigned Ntot, unsigned
     hipStream_t s = (hipStream_t)stream;
     unsigned *count = d_scratch, *cursor = d_scratch + ncell;
     HTF_CHECK_HIP(hipMemsetAsync(count, 0, (size_t)ncell * sizeof(unsigned), s));
-    if (Ntot) hipLaunchKernelGGL(cell_count_kernel, dim3((Ntot + 255) / 256), dim3(256), 0, s, d_cell_of, Ntot, count);
-    hipLaunchKernelGGL(cell_scan_kernel, dim3(1), dim3(1024), 0, s, count, ncell, d_cell_start, cursor);
-    if (Ntot) hipLaunchKernelGGL(cell_scatter_kernel, dim3((Ntot + 255) / 256), dim3(256), 0, s, d_cell_of, Ntot, cursor, d_order);
-    hipLaunchKernelGGL(cell_order_kernel, dim3((ncell + 255) / 256), dim3(256), 0, s, d_cell_start, ncell, d_order);
+    if (Ntot) hipLaunchKernelGGL(cell_count_kernel, dim3((Ntot + 255) / 256), dim3(256), 0, s, d_cell_of, Ntot, count, g_gate);
+    hipLaunchKernelGGL(cell_scan_kernel, dim3(1), dim3(1024), 0, s, count, ncell, d_cell_start, cursor, g_gate);
+    if (Ntot) hipLaunchKernelGGL(cell_scatter_kernel, dim3((Ntot + 255) / 256), dim3(256), 0, s, d_cell_of, Ntot, cursor, d_order, g_gate);
+    hipLaunchKernelGGL(cell_order_kernel, dim3((ncell + 255) / 256), dim3(256), 0, s, d_cell_start, ncell, d_order, g_gate);
     return check_launch("htfs_cell_sort");
 }
 
@@ -336,9 +355,9 @@ extern "C" int htfs_gather4(void *d_dest, const void *d_src, const int *d_order,
     HTF_REQUIRE(d_dest && d_src && d_order, "htfs_gather4: null pointer");
     if (n == 0) return HTF_OK;
     if (dtype == HTF_F32)
-        hipLaunchKernelGGL((gather4_kernel<float4>), dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (float4 *)d_dest, (const float4 *)d_src, d_order, n);
+        hipLaunchKernelGGL((gather4_kernel<float4>), dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (float4 *)d_dest, (const float4 *)d_src, d_order, n, g_gate);
     else
-        hipLaunchKernelGGL((gather4_kernel<double4>), dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (double4 *)d_dest, (const double4 *)d_src, d_order, n);
+        hipLaunchKernelGGL((gather4_kernel<double4>), dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (double4 *)d_dest, (const double4 *)d_src, d_order, n, g_gate);
     return check_launch("gather4_kernel");
 }
 
@@ -348,9 +367,9 @@ extern "C" int htfs_cell_index(const void *d_pos, int dtype, unsigned Ntot, cons
     if (Ntot == 0) return HTF_OK;
     unsigned grid = (Ntot + 255) / 256;
     if (dtype == HTF_F32)
-        hipLaunchKernelGGL((cell_index_kernel<float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float4 *)d_pos, Ntot, make_sbox<float>(box), ncell3[0], ncell3[1], ncell3[2], d_cell_of);
+        hipLaunchKernelGGL((cell_index_kernel<float>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float4 *)d_pos, Ntot, make_sbox<float>(box), ncell3[0], ncell3[1], ncell3[2], d_cell_of, g_gate);
     else
-        hipLaunchKernelGGL((cell_index_kernel<double>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const double4 *)d_pos, Ntot, make_sbox<double>(box), ncell3[0], ncell3[1], ncell3[2], d_cell_of);
+        hipLaunchKernelGGL((cell_index_kernel<double>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const double4 *)d_pos, Ntot, make_sbox<double>(box), ncell3[0], ncell3[1], ncell3[2], d_cell_of, g_gate);
     return check_launch("cell_index_kernel");
 }
 
@@ -393,13 +412,13 @@ extern "C" int htfs_build_nlist(const void *d_pos, const void *d_pos_sorted, int
     }
     hipLaunchKernelGGL(cell_ranges_kernel, dim3((ncell * nrow + 255) / 256), dim3(256), 0, (hipStream_t)stream, ncell3[0], ncell3[1],
                        ncell3[2], stencil3[0], stencil3[1], stencil3[2], (int)box->periodic[0], (int)box->periodic[1],
-                       (int)box->periodic[2], d_cell_start, d_ranges);
+                       (int)box->periodic[2], d_cell_start, d_ranges, g_gate);
     const bool fine = stencil3[0] == 2 || stencil3[1] == 2 || stencil3[2] == 2; // short ranges: 8-lane groups waste fewer lanes
 #define HTFS_NL(T, V4, G)                                                                                              \
     hipLaunchKernelGGL((build_nlist_kernel<T, G>), dim3((N + 4 * (64 / G) - 1) / (4 * (64 / G))), dim3(256), 0, (hipStream_t)stream, \
                        (const V4 *)d_pos, (const V4 *)d_pos_sorted, N, make_sbox<T>(box), (T)(r_list * r_list), ncell3[0],  \
                        ncell3[1], ncell3[2], stencil3[0], stencil3[1], stencil3[2], d_order, d_cell_start, pitch,      \
-                       type_split, d_n_neigh, d_head_list, d_nlist, d_max_neigh, (const uint4 *)d_ranges)
+                       type_split, d_n_neigh, d_head_list, d_nlist, d_max_neigh, (const uint4 *)d_ranges, g_gate)
     if (dtype == HTF_F32) {
         if (fine) HTFS_NL(float, float4, 8); else HTFS_NL(float, float4, 16);
     } else {
@@ -407,4 +426,33 @@ extern "C" int htfs_build_nlist(const void *d_pos, const void *d_pos_sorted, int
     }
 #undef HTFS_NL
     return check_launch("build_nlist_kernel");
+}
+
+namespace htf {
+// the tail of a (conditional) rebuild: reference positions <- current positions, rebuild counter + 1
+template <typename V>
+__global__ __launch_bounds__(256) void commit_rebuild_kernel(V *__restrict__ ref, const V *__restrict__ pos, unsigned n,
+                                                             unsigned *__restrict__ counter, Gate gate) {
+    if (gate.closed()) return;
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) ref[i] = pos[i];
+    if (i == 0 && counter != nullptr) *counter += 1u;
+}
+} // namespace htf
+
+extern "C" int htfs_set_gate(const float *d_disp2, double threshold2) {
+    g_gate.disp2 = d_disp2;
+    g_gate.thr2 = (float)threshold2;
+    return HTF_OK;
+}
+
+extern "C" int htfs_commit_rebuild(void *d_ref, const void *d_pos, int dtype, unsigned N, unsigned *d_counter,
+                                   htf_stream stream) {
+    HTF_REQUIRE(d_ref && d_pos, "htfs_commit_rebuild: null pointer");
+    const unsigned grid = (N + 255) / 256 > 0 ? (N + 255) / 256 : 1;
+    if (dtype == HTF_F32)
+        hipLaunchKernelGGL((commit_rebuild_kernel<float4>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (float4 *)d_ref, (const float4 *)d_pos, N, d_counter, g_gate);
+    else
+        hipLaunchKernelGGL((commit_rebuild_kernel<double4>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (double4 *)d_ref, (const double4 *)d_pos, N, d_counter, g_gate);
+    return check_launch("commit_rebuild_kernel");
 }

@@ -11,10 +11,15 @@ inference: the only per-step message is ~0.5 MB of float4 positions per slab fac
 Layout after ``rebuild()`` (HOOMD's): ``pos[:N]`` local particles, ``pos[N:N+n_ghost]``
 ghosts = [from left neighbor | from right neighbor].  Ghosts keep the owner's raw
 coordinates; the pair-vector build applies the minimum image of the GLOBAL box.
-Local particles are ordered [interior | within r_ghost of the left face | ... of the right
-face]: the two halo messages are contiguous slices of ``pos`` (sent in place, no packing
+Local particles are ordered [interior | near the left face only | near BOTH faces | near the
+right face only] ("near" = within r_ghost): the two halo messages are contiguous -- and, in a
+slab thinner than 2 r_ghost, overlapping -- slices of ``pos`` (sent in place, no packing
 kernel), and rows ``[0, n_interior)`` have no ghost in their neighbor lists, so their forces
 can be evaluated while the halo is in flight (``exchange_begin`` / ``exchange_end``).
+A slab may be as thin as r_ghost (then every ghost still comes from an adjacent slab); with two
+ranks the two faces lead to the same peer, so there the slabs must be 2 r_ghost thick or a
+particle would arrive twice.  The 131 072-particle box of the headline metric (L = 53.75,
+r_ghost = 3.4) decomposes over 8 ranks this way (slab 6.72).
 
 Message naming: "L>" = sent to my left neighbor (my particles within r_ghost of my left
 face), "R>" = sent to my right neighbor.  Every rank posts sends in the order [L>, R>] and
@@ -65,11 +70,16 @@ class SlabDomain:
                 raise ValueError("need world-1 increasing cut fractions in (0, 1)")
         self.bounds = lo + cuts * (hi - lo)
         self.xlo, self.xhi = float(self.bounds[self.rank]), float(self.bounds[self.rank + 1])
-        if self.world > 1 and min(np.diff(self.bounds)) < 2.0 * self.r_ghost:
-            raise ValueError("slab thinner than 2 * r_ghost: a particle would be a ghost on both sides")
+        thinnest = float(min(np.diff(self.bounds)))
+        if self.world == 2 and thinnest < 2.0 * self.r_ghost:
+            raise ValueError("two slabs thinner than 2 * r_ghost: both faces lead to the same peer, a particle "
+                             "near both would arrive there twice")
+        if self.world > 2 and thinnest < self.r_ghost:
+            raise ValueError("slab thinner than r_ghost: ghosts would have to come from beyond the adjacent slab")
         self.left = (self.rank - 1) % self.world
         self.right = (self.rank + 1) % self.world
         self.send_left = self.send_right = None   # (start, stop) row ranges of pos
+        self.class_counts = (0, 0, 0, 0)          # rows: interior | left only | both | right only
         self.n_interior = 0
         self.n_from_left = self.n_from_right = 0
         self.n_migrated = 0
@@ -152,20 +162,23 @@ class SlabDomain:
         self.n_migrated += int(got_r.shape[0] + got_l.shape[0])
         pv = torch.cat([pv[:n_stay], got_r, got_l], dim=0)
         N = int(pv.shape[0])
-        # ghost plan: who sits within r_ghost of a face.  Slabs are >= 2 r_ghost thick, so the two
-        # sets are disjoint; a stable sort on the class puts them behind the interior particles.
+        # ghost plan: who sits within r_ghost of a face.  Classes 0 interior, 1 left face only,
+        # 2 both faces (only in slabs thinner than 2 r_ghost), 3 right face only; a stable sort on
+        # the class puts the two send sets behind the interior particles as [1 | 2] and [2 | 3].
         x = pv[:, 0]
-        cls = (x < self.xlo + self.r_ghost).to(torch.int64) + 2 * (x >= self.xhi - self.r_ghost).to(torch.int64)
-        cnt = torch.zeros(3, dtype=torch.int64, device=x.device).index_add_(0, cls, torch.ones_like(cls))
+        near_l, near_r = x < self.xlo + self.r_ghost, x >= self.xhi - self.r_ghost
+        cls = torch.where(near_l, torch.where(near_r, 2, 1), torch.where(near_r, 3, 0))
+        cnt = torch.zeros(4, dtype=torch.int64, device=x.device).index_add_(0, cls, torch.ones_like(cls))
         allc = self._gather_counts(cnt)
         pv = pv.index_select(0, torch.sort(cls, stable=True)[1])
         new_pos, new_vel = pv[:, :4], pv[:, 4:]
-        n_l, n_r = int(allc[self.rank][1]), int(allc[self.rank][2])
-        self.n_interior = N - n_l - n_r
-        self.send_left = (self.n_interior, self.n_interior + n_l)
-        self.send_right = (self.n_interior + n_l, N)
-        self.n_from_right = int(allc[self.right][1])
-        self.n_from_left = int(allc[self.left][2])
+        c0, c1, c2, c3 = (int(v) for v in allc[self.rank])
+        self.class_counts = (c0, c1, c2, c3)
+        self.n_interior = c0
+        self.send_left = (c0, c0 + c1 + c2)
+        self.send_right = (c0 + c1, N)
+        self.n_from_right = int(allc[self.right][1] + allc[self.right][2])
+        self.n_from_left = int(allc[self.left][2] + allc[self.left][3])
         s.N = N
         s.n_ghost = self.n_from_left + self.n_from_right
         s.pos = torch.cat([new_pos, torch.zeros((s.n_ghost, 4), dtype=new_pos.dtype, device=new_pos.device)], dim=0)
@@ -174,6 +187,12 @@ class SlabDomain:
             s.force = torch.zeros((N, 4), dtype=s.dtype, device=s.pos.device)
             s.virial = torch.zeros(6 * N, dtype=s.dtype, device=s.pos.device)
         self.exchange()
+
+    def row_classes(self):
+        """Class id (0..3, see rebuild) of every local row: a particle sorter may only permute
+        rows inside a class, or the send slices and the interior range no longer mean anything."""
+        c = torch.as_tensor(self.class_counts, dtype=torch.int64, device=self.sys.pos.device)
+        return torch.repeat_interleave(torch.arange(4, device=c.device), c)
 
     def exchange_begin(self):
         """Post the per-step forward halo (ghost positions from their owners).  The messages

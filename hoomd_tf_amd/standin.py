@@ -103,8 +103,16 @@ class CellNlist:
     """hoomd.md.nlist.cell analogue: FULL neighbor list, fixed pitch head list, rebuilt
     when any particle has moved more than r_buff / 2 (NeighborList::distanceCheck)."""
 
-    def __init__(self, system, r_cut, r_buff=0.4, pitch=None, check_period=1, sort_particles=False):
+    def __init__(self, system, r_cut, r_buff=0.4, pitch=None, check_period=1, sort_particles=False,
+                 device_decision=False):
         self.sys = system
+        # device_decision: after the first build the distance check and the rebuild it may trigger are
+        # enqueued together, the binning / search kernels gated on the device by the check's result
+        # (htfs_set_gate): the step loop never reads the check back.  The buffers keep their addresses, a
+        # neighbor-row overflow (more entries than ``pitch``) is reported one check late.  Single-rank,
+        # unsorted systems only; otherwise the host decides as NeighborList::distanceCheck does.
+        self.device_decision = bool(device_decision)
+        self._stat = self._stat_host = self._stat_event = None
         # HOOMD's SFCPackUpdater analogue: renumber the local particles in cell order at every
         # rebuild, so that a particle's neighbors sit in a few contiguous index runs and the
         # position gathers of the force path coalesce.  Off by default (it changes particle
@@ -159,22 +167,30 @@ class CellNlist:
         w3 = (C.c_int * 3)(*[int(x) for x in w])
         ncell = int(n[0] * n[1] * n[2])
         stream = C.c_void_p(torch.cuda.current_stream(s.device).cuda_stream)
-        cell_of = torch.empty(Ntot, dtype=torch.int32, device=s.device)
+        if getattr(self, "_scr_n", None) != (Ntot, ncell):
+            self._scr_n = (Ntot, ncell)
+            self._cell_of = torch.empty(Ntot, dtype=torch.int32, device=s.device)
+            self._order = torch.empty(Ntot, dtype=torch.int32, device=s.device)
+            self._cell_start = torch.empty(ncell + 1, dtype=torch.int32, device=s.device)
+            self._bin_scratch = torch.empty(2 * ncell, dtype=torch.int32, device=s.device)
+            self._pos_sorted = torch.empty((Ntot, 4), dtype=s.pos.dtype, device=s.device)
+        cell_of, order, cell_start, pos_sorted = self._cell_of, self._order, self._cell_start, self._pos_sorted
         check(lib.htfs_cell_index(s.pos.data_ptr(), s.scalar_code, Ntot, C.byref(s.box), C.byref(n3),
                                   cell_of.data_ptr(), stream))
         if self.sort_particles and s.N > 0:
-            perm = torch.sort(cell_of[: s.N], stable=True)[1]
+            key = cell_of[: s.N].to(torch.int64)
+            if self.domain is not None and self.domain.world > 1:
+                # the slab layout [interior | left | both | right] (domain.py) carries the halo slices and
+                # the interior row range: renumber inside each class only
+                key = key + self.domain.row_classes() * int(n[0] * n[1] * n[2])
+            perm = torch.sort(key, stable=True)[1]
             s.pos[: s.N] = s.pos[: s.N].index_select(0, perm)
             s.vel = s.vel.index_select(0, perm)
             cell_of[: s.N] = cell_of[: s.N].index_select(0, perm)
         # bin the particles: counting sort by cell, ascending index inside a cell (deterministic)
-        if getattr(self, "_bin_scratch", None) is None or self._bin_scratch.numel() < 2 * ncell:
-            self._bin_scratch = torch.empty(2 * ncell, dtype=torch.int32, device=s.device)
-        order = torch.empty(Ntot, dtype=torch.int32, device=s.device)
-        cell_start = torch.empty(ncell + 1, dtype=torch.int32, device=s.device)
         check(lib.htfs_cell_sort(cell_of.data_ptr(), Ntot, ncell, self._bin_scratch.data_ptr(), cell_start.data_ptr(),
                                  order.data_ptr(), stream))
-        pos_sorted = torch.empty_like(s.pos[:Ntot])  # cell members contiguous: coalesced candidate reads
+        # cell members contiguous: coalesced candidate reads
         check(lib.htfs_gather4(pos_sorted.data_ptr(), s.pos.data_ptr(), order.data_ptr(), s.scalar_code, Ntot, stream))
         if self.pitch is None:
             # a sphere of r_list at the mean density, with generous head-room
@@ -197,8 +213,66 @@ class CellNlist:
             if mx <= self.pitch:
                 break
             self.pitch = int(math.ceil(mx * 1.2 / 8.0)) * 8
-        self._ref = s.pos[: s.N].clone()
+        if self._ref is None or self._ref.shape[0] != s.N:
+            self._ref = s.pos[: s.N].clone()
+        else:
+            self._ref.copy_(s.pos[: s.N])
+        self._grid = (n3, w3, ncell)
         self.n_builds += 1
+
+    # ------------------------------------------------------------------ device-side decision
+    def _device_ok(self):
+        return (self.device_decision and self._ref is not None and not self.sort_particles
+                and (self.domain is None or self.domain.world == 1) and self.sys.n_ghost == 0
+                and self._ref.shape[0] == self.sys.N and getattr(self, "_scr_n", (None,))[0] == self.sys.N)
+
+    def _poll_overflow(self):
+        """The previous check's (largest row, rebuild count), copied to pinned host memory behind it."""
+        if self._stat_event is not None:
+            self._stat_event.synchronize()  # recorded a whole check period ago: long since complete
+            self._stat_event = None
+            if int(self._stat_host[0]) > self.pitch:
+                raise RuntimeError("neighbor list row overflow (%d entries, pitch %d) in a device-decided rebuild: "
+                                   "construct CellNlist with a larger pitch" % (int(self._stat_host[0]), self.pitch))
+
+    def check_and_rebuild_on_device(self):
+        """NeighborList::compute at a check step with the decision left to the device: distance check, then
+        the whole rebuild gated on its result.  No host synchronisation."""
+        s = self.sys
+        self._poll_overflow()
+        if self._stat is None:
+            self._stat = torch.zeros(2, dtype=torch.int32, device=s.device)  # [largest row of the last rebuild, rebuilds]
+            self._stat_host = torch.zeros(2, dtype=torch.int32).pin_memory()
+        n3, w3, ncell = self._grid
+        stream = C.c_void_p(torch.cuda.current_stream(s.device).cuda_stream)
+        self._disp.zero_()
+        check(lib.htfs_max_displacement2(s.pos.data_ptr(), self._ref.data_ptr(), s.scalar_code, s.N,
+                                         C.byref(s.box), self._disp.data_ptr(), stream))
+        self._stat[:1].zero_()
+        check(lib.htfs_set_gate(self._disp.data_ptr(), (self.r_buff / 2.0) ** 2))
+        try:
+            check(lib.htfs_cell_index(s.pos.data_ptr(), s.scalar_code, s.N, C.byref(s.box), C.byref(n3),
+                                      self._cell_of.data_ptr(), stream))
+            check(lib.htfs_cell_sort(self._cell_of.data_ptr(), s.N, ncell, self._bin_scratch.data_ptr(),
+                                     self._cell_start.data_ptr(), self._order.data_ptr(), stream))
+            check(lib.htfs_gather4(self._pos_sorted.data_ptr(), s.pos.data_ptr(), self._order.data_ptr(), s.scalar_code,
+                                   s.N, stream))
+            check(lib.htfs_build_nlist(s.pos.data_ptr(), self._pos_sorted.data_ptr(), s.scalar_code, s.N, s.N,
+                                       C.byref(s.box), self.r_list, C.byref(n3), C.byref(w3), self._order.data_ptr(),
+                                       self._cell_start.data_ptr(), self.pitch, int(self.type_split),
+                                       self.n_neigh.data_ptr(), self.head_list.data_ptr(), self.nlist.data_ptr(),
+                                       self._stat.data_ptr(), stream))
+            check(lib.htfs_commit_rebuild(self._ref.data_ptr(), s.pos.data_ptr(), s.scalar_code, s.N,
+                                          self._stat.data_ptr() + 4, stream))
+        finally:
+            check(lib.htfs_set_gate(None, 0.0))
+        self._stat_host.copy_(self._stat, non_blocking=True)
+        self._stat_event = torch.cuda.Event()
+        self._stat_event.record()
+
+    def device_builds(self):
+        """Rebuilds the device has decided on so far (synchronises; for reports, not for the step loop)."""
+        return int(self._stat[1].item()) if self._stat is not None else 0
 
     def needs_update(self):
         if self._ref is None:
@@ -212,7 +286,8 @@ class CellNlist:
             # every rank must take the same rebuild decision (the rebuild communicates)
             import torch.distributed as dist
             dist.all_reduce(self._disp, op=dist.ReduceOp.MAX, group=self.domain.group)
-        return float(self._disp.item()) > (self.r_buff / 2.0) ** 2
+        # the threshold in fp32, as the device-side gate compares it (htfs_set_gate)
+        return float(self._disp.item()) > float(np.float32((self.r_buff / 2.0) ** 2))
 
     def compute(self, timestep):
         """NeighborList::compute(timestep): rebuild if the distance check trips.  Under domain
@@ -221,6 +296,10 @@ class CellNlist:
         if self.domain is not None and self._ref is not None and getattr(self, "_step_done", None) == timestep:
             return
         self._step_done = timestep
+        if self._device_ok():
+            if timestep % self.check_period == 0:
+                self.check_and_rebuild_on_device()
+            return
         if self._ref is None or (timestep % self.check_period == 0 and self.needs_update()):
             self.build()
         elif self.domain is not None:

@@ -50,6 +50,17 @@ HTF_API int htfs_gather4(void *d_dest, const void *d_src, const int *d_order, in
 HTF_API int htfs_cell_index(const void *d_pos, int dtype, unsigned Ntot, const htf_box *box,
                             const int *ncell3, unsigned *d_cell_of, htf_stream stream);
 
+/* Conditional rebuild WITHOUT a host decision: after htfs_set_gate(d_disp2, threshold2) every binning /
+ * search kernel of this header launched by the calling thread (htfs_cell_index, htfs_cell_sort, htfs_gather4,
+ * htfs_build_nlist, htfs_commit_rebuild) returns at entry unless *d_disp2 > threshold2 when it RUNS, with
+ * d_disp2 the word htfs_max_displacement2 has just filled on the same stream; htfs_set_gate(NULL, 0) ends
+ * it.  The caller enqueues the whole rebuild behind every distance check and never reads the result back. */
+HTF_API int htfs_set_gate(const float *d_disp2, double threshold2);
+
+/* Tail of a rebuild (gated like the rest): ref[i] = pos[i] for i < N, and *d_counter (nullable) += 1. */
+HTF_API int htfs_commit_rebuild(void *d_ref, const void *d_pos, int dtype, unsigned N, unsigned *d_counter,
+                                htf_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

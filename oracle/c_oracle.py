@@ -78,3 +78,25 @@ def compute_forces_lj(lib, pos4, n_neigh, head, nlist, box, r_cut, NN, scratch=N
     lib.htfo_compute_forces_lj_f32(_p(pos4), C.c_uint(N), _p(n_neigh), _p(head), _p(nlist), _p(lo), _p(hi), _p(tilt),
                                    _p(per), C.c_double(r_cut), C.c_uint(NN), _p(scratch), _p(force))
     return force
+
+
+def wca_from_nlist(lib, nl, sigma):
+    N, NN = nl.shape[:2]
+    out = np.empty((N, 4), dtype=np.float32)
+    lib.htfo_wca_from_nlist(_p(np.ascontiguousarray(nl, dtype=np.float32)), C.c_uint(N), C.c_uint(NN), C.c_float(sigma), _p(out))
+    return out
+
+
+def mlp_from_nlist(lib, nl, params, low=0.0, high=3.0, act="tanh", out=None):
+    """Pair-MLP composite on a dense [N, NN, 4] fp32 tensor -> [N, 4]."""
+    N, NN = nl.shape[:2]
+    ws = [np.ascontiguousarray(params[k], dtype=np.float32) for k in ("W1", "b1", "W2", "b2", "W3", "b3")]
+    K, H1 = ws[0].shape
+    H2 = ws[2].shape[1]
+    assert max(K, H1, H2) <= 64
+    if out is None:
+        out = np.empty((N, 4), dtype=np.float32)
+    nl = nl if (nl.dtype == np.float32 and nl.flags.c_contiguous) else np.ascontiguousarray(nl, dtype=np.float32)
+    lib.htfo_mlp_from_nlist(_p(nl), C.c_uint(N), C.c_uint(NN), C.c_int(K), C.c_int(H1), C.c_int(H2), C.c_float(low),
+                            C.c_float(high), *[_p(w) for w in ws], C.c_int(1 if act == "tanh" else 0), _p(out))
+    return out

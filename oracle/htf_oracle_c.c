@@ -186,3 +186,105 @@ void htfo_compute_forces_lj_f32(const float *pos4, unsigned N, const uint32_t *n
     htfo_prepare_neighbors_f32(scratch, pos4, n_neigh, head_list, nlist, lo, hi, tilt, periodic, r_cut, NN, 0, N);
     htfo_lj_from_nlist(scratch, N, NN, force);
 }
+
+/* WCA model (build_examples.py:221-228 over layers.py:52-98 WCARepulsion) on a dense fp32 nlist:
+ * rinv = nlist_rinv; e = [|x| < sigma 2^(1/3)] (sigma rinv)^6; energy column = sum_j clip(e, 0, 10)
+ * (no 1/2); clip_by_value passes the gradient only where 0 <= e <= 10. */
+void htfo_wca_from_nlist(const float *nl, unsigned N, unsigned NN, float sigma, float *force) {
+    const float cut = sigma * (float)1.2599210498948732;
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < (long)N; ++i) {
+        const float *row = nl + (size_t)i * NN * 4;
+        float fx = 0, fy = 0, fz = 0, en = 0;
+        for (unsigned j = 0; j < NN; ++j) {
+            const float x = row[4 * j], y = row[4 * j + 1], z = row[4 * j + 2];
+            const float tx = x + NORM_DELTA, ty = y + NORM_DELTA, tz = z + NORM_DELTA;
+            const float rp = sqrtf(tx * tx + ty * ty + tz * tz);
+            if (!(rp > RINV_DELTA)) continue;
+            if (!(sqrtf(x * x + y * y + z * z) < cut)) continue;
+            const float s = 1.0f / (rp + RINV_DELTA);
+            const float q = sigma * s, q2 = q * q, q6 = q2 * q2 * q2;
+            en += fminf(fmaxf(q6, 0.0f), 10.0f);
+            if (!(q6 >= 0.0f && q6 <= 10.0f)) continue;
+            const float dEds = 6.0f * (q2 * q2 * q) * sigma;
+            const float c = 2.0f * (dEds * (-(s * s))) / rp;
+            fx += c * tx;
+            fy += c * ty;
+            fz += c * tz;
+        }
+        force[4 * i] = fx;
+        force[4 * i + 1] = fy;
+        force[4 * i + 2] = fz;
+        force[4 * i + 3] = en;
+    }
+}
+
+/* Pair-MLP composite (oracle/htf_oracle.py:pair_mlp_model): r = safe_norm(x);
+ * phi_k = exp(-(r - c_k)^2 / gap), c = linspace(low, high, K) in fp32; Dense(H1) - act - Dense(H2) - act -
+ * Dense(1); u masked with r > 3e-6; E_i = 1/2 sum_j u; nlist_forces = 2 dE/dx = du/dr t / r.
+ * Row-major Keras kernels W1 [K][H1], W2 [H1][H2], W3 [H2].  K, H1, H2 <= 64.  tanh_act: 1 tanh, 0 linear. */
+void htfo_mlp_from_nlist(const float *nl, unsigned N, unsigned NN, int K, int H1, int H2, float low, float high,
+                         const float *W1, const float *b1, const float *W2, const float *b2, const float *W3,
+                         const float *b3, int tanh_act, float *force) {
+    float c[64];
+    for (int k = 0; k < K; ++k) c[k] = K > 1 ? low + (high - low) * (float)k / (float)(K - 1) : low;
+    c[K - 1] = high;
+    const float gap = c[1] - c[0];
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < (long)N; ++i) {
+        const float *row = nl + (size_t)i * NN * 4;
+        float fx = 0, fy = 0, fz = 0, en = 0;
+        float phi[64], d[64], h1[64], h2[64], g2[64], g1[64];
+        for (unsigned j = 0; j < NN; ++j) {
+            const float tx = row[4 * j] + NORM_DELTA, ty = row[4 * j + 1] + NORM_DELTA, tz = row[4 * j + 2] + NORM_DELTA;
+            const float r = sqrtf(tx * tx + ty * ty + tz * tz);
+            if (!(r > RINV_DELTA)) continue;
+            for (int k = 0; k < K; ++k) {
+                d[k] = r - c[k];
+                phi[k] = expf(-(d[k] * d[k]) / gap);
+            }
+            for (int a = 0; a < H1; ++a) {
+                float z = b1[a];
+                for (int k = 0; k < K; ++k) z += phi[k] * W1[k * H1 + a];
+                h1[a] = tanh_act ? tanhf(z) : z;
+            }
+            float u = b3[0];
+            for (int b = 0; b < H2; ++b) {
+                float z = b2[b];
+                for (int a = 0; a < H1; ++a) z += h1[a] * W2[a * H2 + b];
+                h2[b] = tanh_act ? tanhf(z) : z;
+                u += h2[b] * W3[b];
+                g2[b] = tanh_act ? W3[b] * (1.0f - h2[b] * h2[b]) : W3[b];
+            }
+            for (int a = 0; a < H1; ++a) {
+                float s = 0;
+                for (int b = 0; b < H2; ++b) s += g2[b] * W2[a * H2 + b];
+                g1[a] = tanh_act ? s * (1.0f - h1[a] * h1[a]) : s;
+            }
+            float dudr = 0;
+            for (int k = 0; k < K; ++k) {
+                float s = 0;
+                for (int a = 0; a < H1; ++a) s += g1[a] * W1[k * H1 + a];
+                dudr += s * (-2.0f * d[k] / gap) * phi[k];
+            }
+            en += 0.5f * u;
+            const float cc = dudr / r; /* 2 * (1/2) du/dr / r */
+            fx += cc * tx;
+            fy += cc * ty;
+            fz += cc * tz;
+        }
+        force[4 * i] = fx;
+        force[4 * i + 1] = fy;
+        force[4 * i + 2] = fz;
+        force[4 * i + 3] = en;
+    }
+}
+
+/* One computeForces pass for the WCA / pair-MLP models (prepareNeighbors, then the model). */
+void htfo_compute_forces_wca_f32(const float *pos4, unsigned N, const uint32_t *n_neigh, const uint32_t *head_list,
+                                 const uint32_t *nlist, const double *lo, const double *hi, const double *tilt,
+                                 const int *periodic, double r_cut, unsigned NN, float sigma, float *scratch,
+                                 float *force) {
+    htfo_prepare_neighbors_f32(scratch, pos4, n_neigh, head_list, nlist, lo, hi, tilt, periodic, r_cut, NN, 0, N);
+    htfo_wca_from_nlist(scratch, N, NN, sigma, force);
+}

@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, fractions, q):
+def _worker(rank, world, port, fractions, q, n=32, thin=False):
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
@@ -35,7 +35,7 @@ def _worker(rank, world, port, fractions, q):
         from oracle import htf_oracle as O
 
         # global system: 32 x 32 square lattice (N = 1024) as in test_mpi_tensorflow.py, a = 1.3
-        n, a, rcut, rbuf = 32, 1.3, 2.5, 0.4
+        a, rcut, rbuf = 1.3, 2.5, 0.4
         pos, L = sq_lattice(n, a)
         rng = np.random.default_rng(7)
         pos[:, :2] += 0.08 * rng.standard_normal((n * n, 2))
@@ -75,18 +75,28 @@ def _worker(rank, world, port, fractions, q):
             fg, _ = O.compute_forces(global_pos.copy(), np.zeros(n * n, np.int32), gn, gh, gl, O.make_box(L), rcut, 64,
                                      lambda t: O.lj_model(t.astype(np.float64)), model_dtype=np.float64)
             np.testing.assert_allclose(f, fg[my_ids], atol=1e-5)
-            # (4) layout [interior | near-left | near-right]: the halo messages are the two tail
-            # slices, and no interior row has a ghost in its neighbor list -- what lets the
-            # force compute run rows [0, n_interior) while the halo is in flight
+            # (4) layout [interior | left only | both | right only]: the halo messages are two
+            # (possibly overlapping) tail slices, and no interior row has a ghost in its neighbor
+            # list -- what lets the force compute run rows [0, n_interior) while the halo is in flight
             ni = dom.n_interior
-            assert dom.send_left == (ni, dom.send_left[1]) and dom.send_right == (dom.send_left[1], N)
+            assert dom.send_left[0] == ni and dom.send_right[1] == N and dom.send_right[0] <= dom.send_left[1]
+            near_l, near_r = x_near = (p_all[:N, 0] < dom.xlo + dom.r_ghost), (p_all[:N, 0] >= dom.xhi - dom.r_ghost)
+            assert np.array_equal(np.nonzero(near_l)[0], np.arange(*dom.send_left))
+            assert np.array_equal(np.nonzero(near_r)[0], np.arange(*dom.send_right))
             x = p_all[:N, 0]
             assert np.all(x[dom.send_left[0]:dom.send_left[1]] < dom.xlo + dom.r_ghost)
             assert np.all(x[dom.send_right[0]:dom.send_right[1]] >= dom.xhi - dom.r_ghost)
             assert np.all((x[:ni] >= dom.xlo + dom.r_ghost) & (x[:ni] < dom.xhi - dom.r_ghost))
             for i in range(ni):
                 assert np.all(nl[head[i]:head[i] + nn[i]] < N), "interior row %d has a ghost neighbor" % i
-            assert 0 < ni < N
+            c0, c1, c2, c3 = dom.class_counts
+            assert (c0, c0 + c1 + c2 + c3) == (ni, N)
+            if thin:
+                # slab < 2 r_ghost: nothing is interior, some particles are ghosts on BOTH sides and
+                # the two send slices overlap on exactly those rows
+                assert ni == 0 and c2 > 0 and dom.send_left[1] - dom.send_right[0] == c2
+            else:
+                assert 0 < ni < N and c2 == 0
             return my_ids
 
         gpos = pos.copy()
@@ -122,12 +132,27 @@ def _worker(rank, world, port, fractions, q):
         q.put((rank, traceback.format_exc()))
 
 
-@pytest.mark.parametrize("world,fractions", [(2, None), (2, [0.33]), (3, None)])
-def test_slab_domain_gloo(world, fractions):
+def test_two_thin_slabs_are_refused():
+    from hoomd_tf_amd import standin
+    from hoomd_tf_amd.domain import SlabDomain
+    pos, L = sq_lattice(8, 1.3)
+    system = standin.System(pos, L, dtype=torch.float64, device="cpu")
+    with pytest.raises(ValueError, match="same peer"):
+        SlabDomain(system, 0, 2, r_ghost=2.9)          # slabs 5.2 < 2 * 2.9
+    with pytest.raises(ValueError, match="beyond the adjacent slab"):
+        SlabDomain(system, 0, 4, r_ghost=2.9)          # slabs 2.6 < 2.9
+    SlabDomain(system, 0, 3, r_ghost=2.9)              # slabs 3.47: thin but legal
+
+
+# world 8, n 24: L = 31.2, slabs 3.9 wide, r_ghost 2.9 < 3.9 < 5.8 -- the geometry of the 131 072-particle
+# box over 8 ranks (slab 6.72 against r_ghost 3.4), which the round-1 layout refused
+@pytest.mark.parametrize("world,fractions,n,thin", [(2, None, 32, False), (2, [0.33], 32, False), (3, None, 32, False),
+                                                     (8, None, 24, True)])
+def test_slab_domain_gloo(world, fractions, n, thin):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, fractions, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, fractions, q, n, thin)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=300) for _ in procs]

@@ -183,3 +183,63 @@ def test_nve_energy_is_conserved(htf, cuda, fused):
     drift = abs(np.polyfit(np.arange(len(tot)), tot, 1)[0]) * len(tot)
     print("energy per particle: mean %.5f drift %.2e std %.2e rebuilds %d" % (tot.mean(), drift, tot.std(), nl.n_builds))
     assert drift < 2e-3 and tot.std() < 2e-3, (drift, tot.std(), tot[:5], tot[-5:])  # measured 1.5e-4 / 3e-4
+
+
+def test_device_decided_rebuild_equals_host_decided(htf, cuda):
+    """The distance check's verdict taken by the gated kernels themselves (CellNlist(device_decision=True):
+    no read-back in the step loop) must reproduce the host-decided run bit for bit: same rebuild steps,
+    same neighbor rows, same trajectory."""
+    from hoomd_tf_amd import standin
+
+    def run(device_decision):
+        pos, L, a = standin.fcc_positions(8, 0.8442)
+        rng = np.random.default_rng(5)
+        pos = pos + 0.05 * a * rng.standard_normal(pos.shape)
+        pos -= np.round(pos / L) * L
+        sysm = standin.System(pos, L, dtype=torch.float32, device=cuda)
+        sysm.randomize_velocities(kT=1.2, seed=5)
+        nl = standin.CellNlist(sysm, r_cut=2.5, r_buff=0.4, check_period=2, device_decision=device_decision)
+        ctx = htf.Context(r_cut=2.5, nneighs=96, max_n=sysm.N, fused=2)
+        ctx.set_potential(htf.Potential.lj())
+        nve = standin.NVE(sysm, 0.004)
+        snaps = []
+        for ts in range(120):
+            nl.compute(ts)
+            arr = ctx.make_arrays(sysm.pos, sysm.N, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, sysm.force)
+            ctx.compute_forces(ts, arr)
+            f3 = sysm.force[:, :3]
+            f3.mul_(torch.clamp(100.0 / f3.norm(dim=1, keepdim=True).clamp_min(1e-12), max=1.0))
+            nve.step()
+            if ts % 20 == 19:
+                snaps.append((sysm.pos.clone(), nl.n_neigh.clone(), nl.nlist.clone()))
+        torch.cuda.synchronize()
+        nl._poll_overflow()
+        builds = nl.n_builds + nl.device_builds()
+        return snaps, builds, nl
+
+    host, hb, _ = run(False)
+    dev, db, nl = run(True)
+    assert hb == db and hb >= 4, (hb, db)
+    assert nl.n_builds == 1  # only the first build went through the host path
+    for (p0, n0, l0), (p1, n1, l1) in zip(host, dev):
+        assert torch.equal(p0, p1) and torch.equal(n0, n1)
+        pitch = nl.pitch
+        # rows are compared over their live entries (the tail of a row is stale scratch)
+        live = torch.arange(pitch, device=cuda)[None, :] < n0[:, None]
+        assert torch.equal(l0.view(-1, pitch)[live], l1.view(-1, pitch)[live])
+
+
+def test_device_decided_rebuild_reports_row_overflow_late(htf, cuda):
+    from hoomd_tf_amd import standin
+    pos, L, a = standin.fcc_positions(6, 0.8442)
+    sysm = standin.System(pos, L, dtype=torch.float32, device=cuda)
+    nl = standin.CellNlist(sysm, r_cut=2.5, r_buff=0.4, check_period=1, device_decision=True)
+    nl.compute(0)                                   # host-path first build sizes the pitch
+    nl.pitch = 8                                    # pretend the rows were sized far too small
+    nl.n_neigh = torch.empty(sysm.N, dtype=torch.int32, device=cuda)
+    nl.head_list = torch.empty(sysm.N, dtype=torch.int32, device=cuda)
+    nl.nlist = torch.empty(sysm.N * 8, dtype=torch.int32, device=cuda)
+    sysm.pos[:, :3] += 0.3                          # everything moved: the gate opens
+    nl.compute(1)
+    with pytest.raises(RuntimeError, match="row overflow"):
+        nl.compute(2)

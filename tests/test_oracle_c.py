@@ -48,6 +48,28 @@ def test_lj_matches_numpy_oracle(clib):
     assert clib.htfo_num_threads() >= 1
 
 
+@pytest.mark.parametrize("sigma", [0.5, 1.0])
+def test_wca_matches_numpy_oracle(clib, sigma):
+    rng = np.random.default_rng(2)
+    nl, _ = random_nlist(rng, 256, 64, fill=0.7, rmin=0.6 * sigma, rmax=1.6 * sigma)
+    ref = O.wca_model(nl.astype(np.float64), sigma)
+    got = c_oracle.wca_from_nlist(clib, nl, sigma)
+    # fp32 port against the fp64 oracle: s^7 amplifies the rounding of s seven-fold
+    np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-4)
+    assert np.abs(ref[:, :3]).max() > 1.0  # the sample reaches inside the cut
+
+
+@pytest.mark.parametrize("act", ["tanh", "linear"])
+def test_pair_mlp_matches_numpy_oracle(clib, act):
+    rng = np.random.default_rng(3)
+    nl, _ = random_nlist(rng, 128, 32, fill=0.7, rmin=0.5, rmax=3.0)
+    params = O.make_mlp_params(seed=3, bias_scale=0.1)
+    ref = O.pair_mlp_model(nl.astype(np.float64), params, 0.0, 3.0, act=act)
+    got = c_oracle.mlp_from_nlist(clib, nl, params, 0.0, 3.0, act=act)
+    scale = np.abs(ref).max()
+    np.testing.assert_allclose(got, ref, rtol=1e-4, atol=2e-5 * scale + 2e-5)
+
+
 def test_c_oracle_under_sanitizers(tmp_path):
     """the CPU restatement built with -fsanitize=address,undefined and run on a system whose
     rows overflow NN (the slot wrap must stay inside the row), a batch, both precisions, 1 and 4 threads."""
