@@ -21,7 +21,7 @@ LIB_PATH = os.environ.get("HTF_AMD_LIB") or os.path.join(_HERE, "libhtf_amd.so")
 HTF_OK, HTF_ERR_INVALID, HTF_ERR_DEVICE, HTF_ERR_NLIST_OVERFLOW, HTF_ERR_SKEWED_BOX, HTF_ERR_NOMEM = range(6)
 HTF_F32, HTF_F64 = 0, 1
 HTF_TF2HOOMD, HTF_HOOMD2TF = 0, 1
-POT_NONE, POT_LJ, POT_WCA, POT_RINV_POLY, POT_SIMPLE, POT_PAIR_MLP, POT_GAUSS, POT_LJ_PARAM = range(8)
+POT_NONE, POT_LJ, POT_WCA, POT_RINV_POLY, POT_SIMPLE, POT_PAIR_MLP, POT_GAUSS, POT_LJ_PARAM, POT_TOPK_MLP = range(9)
 OPT_SGD, OPT_ADAM, OPT_NADAM = range(3)
 OPT_STATE_FLOATS = 24
 ACT_LINEAR, ACT_TANH = 0, 1
@@ -103,6 +103,7 @@ PROTOTYPES = {
     "htf_energy_sum": (_i, [_vp, _i, _u, _vp, _vp]),
     "htf_copy_positions": (_i, [_vp, _i, _vp, _i, _u, _u, _i, _vp]),
     "htf_copy3": (_i, [_vp, _i, _vp, _i, _u, _vp]),
+    "htf_positions_forces_radial": (_i, [_vp, _i, _u, _i, _i, _d, _vp, _i, _vp]),
     "htf_check_nlist": (_i, [_vp, _i, _u, _u, _vp, _vp]),
     "htf_nlist_rinv": (_i, [_vp, _i, _u, _u, _vp, _vp]),
     "htf_create": (_i, [C.POINTER(Config), C.POINTER(_vp)]),
@@ -115,6 +116,7 @@ PROTOTYPES = {
     "htf_get_positions_buffer": (_vp, [_vp]),
     "htf_get_virial_buffer": (_vp, [_vp]),
     "htf_get_batch_capacity": (_u, [_vp]),
+    "htf_top_k": (_i, [_vp, _u, _u, _u, _vp, _vp, _vp]),
     "htf_rdf_histogram": (_i, [_vp, _i, _u, _u, C.c_float, C.c_float, _u, _vp, _u, _i, _i, _vp, _vp]),
     "htf_rdf_finalize": (_i, [_vp, _u, C.c_float, C.c_float, _vp, _vp, _vp]),
     "htf_rbf_expansion": (_i, [_vp, _sz, _d, _d, _u, _vp, _vp]),

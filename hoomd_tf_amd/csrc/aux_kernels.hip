@@ -176,3 +176,55 @@ extern "C" int htf_copy_positions(void *d_dest, int dest_dtype, const void *d_sr
     }
     return check_launch("copy_positions_kernel");
 }
+
+namespace htf {
+// compute_positions_forces (simmodel.py:492-506) for a per-particle radial energy of the positions row,
+// e_i = coef * |p_i|^power over the first `ncomp` columns (tf.norm(positions, axis=1) takes all four, the
+// un-stuffed type included: build_examples.py:59-64 BenchmarkNonlistModel, e = divide_no_nan(1., |p|)):
+// force_i = -d(sum e)/d p_i[:3] = -coef * power * |p_i|^(power - 2) * p_i[:3], energy column = e_i.
+// |p| = 0: divide_no_nan gives e = 0 for negative powers, and TensorFlow's norm gradient is 0/0 there; the
+// kernel returns zeros (a particle exactly at the origin with type 0 -- measure zero).
+template <typename T>
+__global__ __launch_bounds__(256) void positions_radial_kernel(const typename Vec4<T>::type *__restrict__ pos, unsigned N,
+                                                               int ncomp, int power, float coef,
+                                                               void *__restrict__ force, int out_f64) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const auto p = pos[i];
+    const float x = (float)p.x, y = (float)p.y, z = (float)p.z, w = ncomp == 4 ? (float)p.w : 0.f;
+    const float n2 = x * x + y * y + z * z + w * w;
+    float e = 0.f, c = 0.f;
+    if (n2 > 0.f) {
+        const float n = sqrtf(n2);
+        // |p|^power and |p|^(power - 2) by repeated multiplication of n or 1 / n (power is a small integer)
+        const float b = power >= 0 ? n : 1.0f / n;
+        float pw = 1.f;
+        for (int k = 0, a = power >= 0 ? power : -power; k < a; ++k) pw *= b;
+        e = coef * pw;
+        c = -coef * (float)power * (pw / n2);
+    }
+    if (out_f64)
+        ((double4 *)force)[i] = make_double4(c * x, c * y, c * z, e);
+    else
+        ((float4 *)force)[i] = make_float4(c * x, c * y, c * z, e);
+}
+} // namespace htf
+
+extern "C" int htf_positions_forces_radial(const void *d_positions, int dtype, unsigned N, int ncomp, int power,
+                                           double coef, void *d_force, int force_dtype, htf_stream stream) {
+    using namespace htf;
+    HTF_REQUIRE(d_positions && d_force, "htf_positions_forces_radial: null pointer");
+    HTF_REQUIRE(dtype == HTF_F32 || dtype == HTF_F64, "htf_positions_forces_radial: bad dtype %d", dtype);
+    HTF_REQUIRE(force_dtype == HTF_F32 || force_dtype == HTF_F64, "htf_positions_forces_radial: bad force dtype %d", force_dtype);
+    HTF_REQUIRE(ncomp == 3 || ncomp == 4, "htf_positions_forces_radial: the norm runs over 3 or 4 columns (got %d)", ncomp);
+    HTF_REQUIRE(power >= -16 && power <= 16 && power != 0, "htf_positions_forces_radial: power %d outside [-16, 16] \\ {0}", power);
+    if (N == 0) return HTF_OK;
+    const unsigned grid = (N + 255) / 256;
+    if (dtype == HTF_F32)
+        hipLaunchKernelGGL((positions_radial_kernel<float>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                           (const float4 *)d_positions, N, ncomp, power, (float)coef, d_force, force_dtype == HTF_F64);
+    else
+        hipLaunchKernelGGL((positions_radial_kernel<double>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                           (const double4 *)d_positions, N, ncomp, power, (float)coef, d_force, force_dtype == HTF_F64);
+    return check_launch("positions_radial_kernel");
+}

@@ -64,7 +64,11 @@ struct RoctxScope {
 struct htf_potential {
     htf::PotParams pp;
     htf::MlpDevice *mlp = nullptr;
+    htf::TopkDevice *topk = nullptr;
 };
+
+// potentials with an evaluator of their own (everything else goes through eval_pair_dispatch / the fused kernels)
+static inline bool own_evaluator(const htf_potential *p) { return p->pp.kind == HTF_POT_PAIR_MLP || p->pp.kind == HTF_POT_TOPK_MLP; }
 
 struct htf_ctx {
     htf_config cfg;
@@ -159,6 +163,9 @@ extern "C" int htf_potential_create(const htf_potential_desc *d, htf_potential *
     case HTF_POT_PAIR_MLP:
         rc = mlp_create(d, &p->mlp);
         break;
+    case HTF_POT_TOPK_MLP:
+        rc = topk_create(d, &p->topk);
+        break;
     default:
         set_error("htf_potential_create: unknown potential kind %d", d->kind);
         rc = HTF_ERR_INVALID;
@@ -167,7 +174,7 @@ extern "C" int htf_potential_create(const htf_potential_desc *d, htf_potential *
         delete p;
         return rc;
     }
-    if (d->d_theta != nullptr && d->kind != HTF_POT_PAIR_MLP) { // (the pair-MLP keeps theta in its own record)
+    if (d->d_theta != nullptr && d->kind != HTF_POT_PAIR_MLP && d->kind != HTF_POT_TOPK_MLP) { // (the pair-MLP keeps theta in its own record)
         if (potential_num_params(p->pp) == 0) {
             set_error("htf_potential_create: potential kind %d has no trainable parameters", d->kind);
             delete p;
@@ -215,6 +222,7 @@ extern "C" int htf_train_pair_grad(const htf_potential *pot, const void *d_nlist
 extern "C" void htf_potential_destroy(htf_potential *pot) {
     if (!pot) return;
     if (pot->mlp) htf::mlp_destroy(pot->mlp);
+    if (pot->topk) htf::topk_destroy(pot->topk);
     delete pot;
 }
 
@@ -227,10 +235,10 @@ extern "C" int htf_eval_forces(const htf_potential *pot, const void *d_nlist, in
     HTF_REQUIRE(nlist_dtype == HTF_F32 || nlist_dtype == HTF_F64, "htf_eval_forces: bad nlist dtype %d", nlist_dtype);
     HTF_REQUIRE(force_dtype == HTF_F32 || force_dtype == HTF_F64, "htf_eval_forces: bad force dtype %d", force_dtype);
     if (B == 0) return HTF_OK;
-    if (pot->pp.kind == HTF_POT_PAIR_MLP) {
-        HTF_REQUIRE(d_virial9 == nullptr, "htf_eval_forces: virial is not implemented for the pair-MLP");
-        return mlp_eval(pot->mlp, d_nlist, nlist_dtype, B, NN, d_force, force_dtype, (hipStream_t)stream);
-    }
+    if (pot->pp.kind == HTF_POT_PAIR_MLP)
+        return mlp_eval(pot->mlp, d_nlist, nlist_dtype, B, NN, d_force, force_dtype, d_virial9, (hipStream_t)stream);
+    if (pot->pp.kind == HTF_POT_TOPK_MLP)
+        return topk_eval(pot->topk, d_nlist, nlist_dtype, B, NN, d_force, force_dtype, d_virial9, (hipStream_t)stream);
     HTF_REQUIRE(!(pot->pp.kind == HTF_POT_SIMPLE && d_virial9), "htf_eval_forces: SimplePotential has no energy, hence no virial");
     return eval_pair_dispatch(pot->pp, d_nlist, nlist_dtype, B, NN, d_force, force_dtype, d_virial9, nullptr, (hipStream_t)stream);
 }
@@ -434,7 +442,7 @@ static int compute_rows(htf_ctx *ctx, unsigned timestep, const htf_hoomd_arrays 
             ctx->ev_one_scope.push_back(0);
             HTF_CHECK_HIP(hipEventRecord(e0, s));
         }
-        const bool fused = cfg.fused && cfg.nneighs > 0 && ctx->pot != nullptr && ctx->pot->pp.kind != HTF_POT_PAIR_MLP;
+        const bool fused = cfg.fused && cfg.nneighs > 0 && ctx->pot != nullptr && !own_evaluator(ctx->pot);
         if (fused) {
             HTF_REQUIRE(a->n_neigh && a->nlist && a->head_list, "htf_compute_forces: null neighbor list");
             if (prof) ctx->ev_one_scope.back() = 1; // no separate build scope in fused mode: e1 stays unrecorded
@@ -492,7 +500,7 @@ static int compute_rows(htf_ctx *ctx, unsigned timestep, const htf_hoomd_arrays 
         }
         RoctxScope scope_eval("TensorflowCompute::Force Update");
         void *force_out = (char *)a->force + (size_t)offset * 4 * ssz; // m_forces_comm.setOffset(offset) .cc:192
-        if (ctx->pot->pp.kind == HTF_POT_PAIR_MLP)
+        if (own_evaluator(ctx->pot))
             rc = htf_eval_forces(ctx->pot, c_nlist, HTF_F32, n, cfg.nneighs, force_out, cfg.scalar_dtype,
                                  cfg.virial ? c_virial : nullptr, stream);
         else

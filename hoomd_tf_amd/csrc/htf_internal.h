@@ -50,10 +50,16 @@ int fused_forces2_impl(const PotParams &pa, const PotParams &pb, const void *pos
                        unsigned *rdf_hist, float4 *dest, unsigned *counts_io, hipStream_t s);
 unsigned fused_forces2_num_partials(unsigned batch);
 
+struct TopkDevice;
+int topk_create(const htf_potential_desc *d, TopkDevice **out);
+void topk_destroy(TopkDevice *m);
+int topk_eval(const TopkDevice *m, const void *nlist, int in_dtype, unsigned B, unsigned NN, void *force,
+              int force_dtype, void *virial9, hipStream_t stream);
+
 struct MlpDevice;
 int mlp_create(const htf_potential_desc *d, MlpDevice **out);
 void mlp_destroy(MlpDevice *m);
 int mlp_eval(const MlpDevice *m, const void *nlist, int in_dtype, unsigned B, unsigned NN, void *force,
-             int force_dtype, hipStream_t stream);
+             int force_dtype, void *virial9, hipStream_t stream);
 
 } // namespace htf

@@ -579,7 +579,7 @@ int mlp_train_grad(const MlpDevice *m, const void *nlist, int in_dtype, unsigned
     const bool fused = mfma && !no_fuse && (ntiles == 1 || ntiles == 2 || ntiles == 4);
     int rc = HTF_OK;
     if (!fused) {
-        rc = mlp_eval(m, nlist, in_dtype, B, NN, predbuf, HTF_F32, stream);
+        rc = mlp_eval(m, nlist, in_dtype, B, NN, predbuf, HTF_F32, nullptr, stream);
         if (rc != HTF_OK) return rc;
     }
     MlpDims dm{m->K, m->H1, m->H2, m->off_b1(), m->off_W2(), m->off_b2(), m->off_W3(), m->off_b3()};

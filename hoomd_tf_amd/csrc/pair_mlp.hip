@@ -28,6 +28,7 @@
 #include "htf_common.h"
 #include "htf_internal.h"
 #include "pair_mlp.h"
+#include "pair_math.h"
 
 namespace htf {
 
@@ -202,10 +203,11 @@ constexpr int pipe_per(int valu, int mfma) { return (valu + mfma - 1) / mfma > 0
 
 template <int P> struct MlpLaunch { static constexpr int kPerCU = 2; };
 
-template <bool TANH, typename IT, int P>
+template <bool TANH, typename IT, int P, bool VIRIAL>
 __global__ __launch_bounds__(256, MlpLaunch<P>::kPerCU) void pair_mlp_kernel(const typename Vec4<IT>::type *__restrict__ nlist,
                                                           unsigned B, unsigned NN, void *__restrict__ force,
-                                                          int out_f64, const float *__restrict__ images, float gap) {
+                                                          int out_f64, const float *__restrict__ images, float gap,
+                                                          void *__restrict__ virial9) {
     using I = Img<P>;
     constexpr bool PK = P == HTF_MLP_FP32; // packed VALU arithmetic where nothing overlaps with the MFMAs anyway
     __shared__ __attribute__((aligned(16))) float lds[I::Floats];
@@ -229,6 +231,7 @@ __global__ __launch_bounds__(256, MlpLaunch<P>::kPerCU) void pair_mlp_kernel(con
     for (unsigned row = wave; row < B; row += nwaves) {
         const typename Vec4<IT>::type *rp = nlist + (size_t)row * NN;
         float fx = 0.f, fy = 0.f, fz = 0.f, en = 0.f;
+        Virial6 vir; // _compute_virial (simmodel.py:509-523) works for any energy: -(|nf| / (2 |x|)) x (x) x per slot
         for (unsigned tile = 0; tile < ntiles; ++tile) {
             const unsigned slot = tile * 32 + p;
             float x = 0.f, y = 0.f, z = 0.f;
@@ -418,17 +421,37 @@ __global__ __launch_bounds__(256, MlpLaunch<P>::kPerCU) void pair_mlp_kernel(con
                 fy += c * ty;
                 fz += c * tz;
                 en += 0.5f * u;
+                if constexpr (VIRIAL) vir.add(x, y, z, c * tx, c * ty, c * tz);
             }
         }
         fx = group_sum<64>(fx);
         fy = group_sum<64>(fy);
         fz = group_sum<64>(fz);
         en = group_sum<64>(en);
+        float v6[6];
+        if constexpr (VIRIAL) {
+            v6[0] = group_sum<64>(vir.xx);
+            v6[1] = group_sum<64>(vir.xy);
+            v6[2] = group_sum<64>(vir.xz);
+            v6[3] = group_sum<64>(vir.yy);
+            v6[4] = group_sum<64>(vir.yz);
+            v6[5] = group_sum<64>(vir.zz);
+        }
         if (lane == 0) {
             if (out_f64)
                 ((double4 *)force)[row] = make_double4(fx, fy, fz, en);
             else
                 ((float4 *)force)[row] = make_float4(fx, fy, fz, en);
+            if constexpr (VIRIAL) {
+                const float v9[9] = {v6[0], v6[1], v6[2], v6[1], v6[3], v6[4], v6[2], v6[4], v6[5]};
+#pragma unroll
+                for (int c9 = 0; c9 < 9; ++c9) {
+                    if (out_f64)
+                        ((double *)virial9)[(size_t)row * 9 + c9] = v9[c9];
+                    else
+                        ((float *)virial9)[(size_t)row * 9 + c9] = v9[c9];
+                }
+            }
         }
     }
 }
@@ -623,31 +646,36 @@ void mlp_destroy(MlpDevice *m) {
 
 template <bool TANH, int P>
 static int launch_mlp(const MlpDevice *m, const void *nlist, int in_dtype, unsigned B, unsigned NN, void *force,
-                      int out_f64, hipStream_t s) {
+                      int out_f64, void *virial9, hipStream_t s) {
     // persistent blocks: 3 per CU (LDS 48.9 KiB each), 4 waves per block, one row per wave trip
     // (bf16 and split: 2 per CU, see MlpLaunch)
     unsigned grid = (unsigned)m->n_cu * (unsigned)MlpLaunch<P>::kPerCU;
     unsigned need = (B + 3) / 4;
     if (grid > need) grid = need;
-    if (in_dtype == HTF_F32)
-        hipLaunchKernelGGL((pair_mlp_kernel<TANH, float, P>), dim3(grid), dim3(256), 0, s, (const float4 *)nlist, B, NN, force, out_f64, m->images, m->gap);
-    else
-        hipLaunchKernelGGL((pair_mlp_kernel<TANH, double, P>), dim3(grid), dim3(256), 0, s, (const double4 *)nlist, B, NN, force, out_f64, m->images, m->gap);
+#define HTF_MLP_LAUNCH(T, V4, VIR)                                                                                     \
+    hipLaunchKernelGGL((pair_mlp_kernel<TANH, T, P, VIR>), dim3(grid), dim3(256), 0, s, (const V4 *)nlist, B, NN, force, \
+                       out_f64, m->images, m->gap, virial9)
+    if (in_dtype == HTF_F32) {
+        if (virial9) HTF_MLP_LAUNCH(float, float4, true); else HTF_MLP_LAUNCH(float, float4, false);
+    } else {
+        if (virial9) HTF_MLP_LAUNCH(double, double4, true); else HTF_MLP_LAUNCH(double, double4, false);
+    }
+#undef HTF_MLP_LAUNCH
     return check_launch("pair_mlp_kernel");
 }
 
 int mlp_eval(const MlpDevice *m, const void *nlist, int in_dtype, unsigned B, unsigned NN, void *force,
-             int force_dtype, hipStream_t stream) {
+             int force_dtype, void *virial9, hipStream_t stream) {
     HTF_REQUIRE(m, "pair-MLP: null potential");
     const int out_f64 = force_dtype == HTF_F64;
     if (m->precision == HTF_MLP_BF16)
-        return m->act == HTF_ACT_TANH ? launch_mlp<true, HTF_MLP_BF16>(m, nlist, in_dtype, B, NN, force, out_f64, stream)
-                                      : launch_mlp<false, HTF_MLP_BF16>(m, nlist, in_dtype, B, NN, force, out_f64, stream);
+        return m->act == HTF_ACT_TANH ? launch_mlp<true, HTF_MLP_BF16>(m, nlist, in_dtype, B, NN, force, out_f64, virial9, stream)
+                                      : launch_mlp<false, HTF_MLP_BF16>(m, nlist, in_dtype, B, NN, force, out_f64, virial9, stream);
     if (m->precision == HTF_MLP_SPLIT)
-        return m->act == HTF_ACT_TANH ? launch_mlp<true, HTF_MLP_SPLIT>(m, nlist, in_dtype, B, NN, force, out_f64, stream)
-                                      : launch_mlp<false, HTF_MLP_SPLIT>(m, nlist, in_dtype, B, NN, force, out_f64, stream);
-    return m->act == HTF_ACT_TANH ? launch_mlp<true, HTF_MLP_FP32>(m, nlist, in_dtype, B, NN, force, out_f64, stream)
-                                  : launch_mlp<false, HTF_MLP_FP32>(m, nlist, in_dtype, B, NN, force, out_f64, stream);
+        return m->act == HTF_ACT_TANH ? launch_mlp<true, HTF_MLP_SPLIT>(m, nlist, in_dtype, B, NN, force, out_f64, virial9, stream)
+                                      : launch_mlp<false, HTF_MLP_SPLIT>(m, nlist, in_dtype, B, NN, force, out_f64, virial9, stream);
+    return m->act == HTF_ACT_TANH ? launch_mlp<true, HTF_MLP_FP32>(m, nlist, in_dtype, B, NN, force, out_f64, virial9, stream)
+                                  : launch_mlp<false, HTF_MLP_FP32>(m, nlist, in_dtype, B, NN, force, out_f64, virial9, stream);
 }
 
 } // namespace htf

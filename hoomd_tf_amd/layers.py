@@ -34,6 +34,47 @@ class RBFExpansion:
         return out
 
 
+class Dense:
+    """tf.keras.layers.Dense for the per-particle networks of the force path (example 08): ``x W + b``,
+    glorot-uniform kernel, zero bias, ``activation=None`` unless given ('tanh').  Built on first call, like
+    Keras.  Applied to the symbolic top-k features it stays symbolic (three of them lower to one kernel);
+    applied to a tensor it is a torch matmul."""
+
+    def __init__(self, units, activation=None, seed=0):
+        self.units, self.activation, self.seed = int(units), activation, int(seed)
+        self.kernel = self.bias = None
+        self.version = 0
+
+    def build(self, fan_in):
+        if self.kernel is None:
+            rng = np.random.default_rng(self.seed)
+            lim = np.sqrt(6.0 / (fan_in + self.units))
+            self.kernel = rng.uniform(-lim, lim, size=(fan_in, self.units)).astype(np.float32)
+            self.bias = np.zeros(self.units, dtype=np.float32)
+
+    def get_weights(self):
+        return [] if self.kernel is None else [self.kernel.copy(), self.bias.copy()]
+
+    def set_weights(self, ws):
+        k, b = np.asarray(ws[0], dtype=np.float32), np.asarray(ws[1], dtype=np.float32)
+        if k.shape[1] != self.units or b.shape != (self.units,):
+            raise ValueError("Dense(%d): weight shapes %r, %r do not fit" % (self.units, k.shape, b.shape))
+        self.kernel, self.bias = k.copy(), b.copy()
+        self.version += 1
+
+    def __call__(self, x):
+        if isinstance(x, simmodel.TopRinv):
+            self.build(x.k)
+            return simmodel.DenseOut(x, [self])
+        if isinstance(x, simmodel.DenseOut):
+            self.build(x.layers[-1].units)
+            return simmodel.DenseOut(x.top, x.layers + [self])
+        t = x.tensor() if hasattr(x, "tensor") and callable(x.tensor) else x
+        self.build(int(t.shape[-1]))
+        y = t @ torch.as_tensor(self.kernel, dtype=t.dtype, device=t.device) + torch.as_tensor(self.bias, dtype=t.dtype, device=t.device)
+        return torch.tanh(y) if self.activation == "tanh" else y
+
+
 class WCARepulsion:
     """layers.py:52-98: trainable WCA repulsion ``(sigma/r)^6`` inside ``2^(1/3) sigma``,
     clipped to [0, 10].  Called on the neighbor list; returns the pair energy.  ``sigma`` is
@@ -79,7 +120,12 @@ class WCARepulsion:
         return [self.w] if self.w is not None else []
 
     def potential(self):
-        return ops.Potential.wca(self.sigma, theta=self.w)
+        """The layer's own potential: kept while the layer lives, rebuilt when sigma is reset on the host
+        or the device weight appears."""
+        key = ("theta", id(self.w)) if self.w is not None else ("sigma", self._sigma0)
+        if getattr(self, "_pot", None) is None or self._pot[0] != key:
+            self._pot = (key, ops.Potential.wca(self.sigma, theta=self.w))
+        return self._pot[1]
 
     def __call__(self, nlist):
         return simmodel.WCAPair(simmodel._as_nlist(nlist), self.sigma, layer=self)
@@ -114,8 +160,11 @@ class LJLayer:
         return [self.w]
 
     def potential(self):
-        w = self.w.cpu().numpy()
-        return ops.Potential.lj_param(float(w[0]), float(w[1]), theta=self.w)
+        """The layer's own potential (reads ``self.w`` on the device at every launch)."""
+        if getattr(self, "_pot", None) is None:
+            w = self.w.cpu().numpy()
+            self._pot = ops.Potential.lj_param(float(w[0]), float(w[1]), theta=self.w)
+        return self._pot
 
     def __call__(self, r):
         if not isinstance(r, simmodel.SafeNorm):

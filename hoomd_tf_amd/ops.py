@@ -130,6 +130,12 @@ class Potential:
         return cls(_lib.POT_PAIR_MLP, mlp=params, rbf=(low, high), activation=activation,
                    mlp_precision=precision, theta=theta)
 
+    @classmethod
+    def topk_mlp(cls, params, activation=None):
+        """Example 08's per-particle network on the ``K = W1.shape[0]`` largest 1/r of each row (descending):
+        Dense(H1) -> Dense(H2) -> Dense(1); ``params``: W1 [K, H1], b1, W2 [H1, H2], b2, W3 [H2, 1], b3."""
+        return cls(_lib.POT_TOPK_MLP, mlp=params, activation=activation or "linear")
+
     def refresh(self):
         """Rebuild derived device data (pair-MLP operand images) from the parameter vector."""
         check(lib.htf_potential_refresh(self._h, _stream(self.theta) if self.theta is not None else None))
@@ -343,6 +349,31 @@ def copy_positions(src, offset=0, N=None, unstuff4=True, out_dtype=None):
     check(lib.htf_copy_positions(out.data_ptr(), _dt(out), src.data_ptr(), _dt(src), int(offset), N,
                                  1 if unstuff4 else 0, _stream(src)))
     return out
+
+
+def positions_forces_radial(positions, coef=1.0, power=-1, ncomp=4, out=None, out_dtype=None):
+    """compute_positions_forces(positions, coef * |positions[:, :ncomp]|^power) in one kernel -> [N, 4]."""
+    _dev(positions, "positions")
+    if positions.dim() != 2 or positions.shape[1] != 4:
+        raise ValueError("positions must be [N, 4]")
+    N = int(positions.shape[0])
+    if out is None:
+        out = torch.empty((N, 4), dtype=out_dtype or positions.dtype, device=positions.device)
+    _dev(out, "out")
+    check(lib.htf_positions_forces_radial(positions.data_ptr(), _dt(positions), N, int(ncomp), int(power), float(coef),
+                                          out.data_ptr(), _dt(out), _stream(positions)))
+    return out
+
+
+def topk_desc(x, k):
+    """tf.math.top_k(x, k) along the last axis of a [B, n] fp32 tensor: (values, indices), largest first,
+    equal values in index order."""
+    _dev(x, "x", torch.float32)
+    B, n = int(x.shape[0]), int(x.shape[1])
+    vals = torch.empty((B, int(k)), dtype=torch.float32, device=x.device)
+    idx = torch.empty((B, int(k)), dtype=torch.int32, device=x.device)
+    check(lib.htf_top_k(x.data_ptr(), B, n, int(k), vals.data_ptr(), idx.data_ptr(), _stream(x)))
+    return vals, idx
 
 
 def energy_sum(force, out=None):

@@ -29,7 +29,7 @@ def _trace_log():
 
 # --------------------------------------------------------------------------- tensors
 def _unwrap(x):
-    if isinstance(x, (Nlist, NlistXYZ)):
+    if isinstance(x, _TorchOperand):
         return x.ad
     if isinstance(x, (list, tuple)):
         return type(x)(_unwrap(v) for v in x)
@@ -106,6 +106,93 @@ class NlistXYZ(_TorchOperand):
 
     def numpy(self):
         return self.tensor.cpu().numpy()
+
+
+class Positions(_TorchOperand):
+    """The ``N x 4`` positions tensor (x, y, z, type) handed to ``compute`` of a positions-only model
+    (nneighbor_cutoff = 0): behaves like the torch tensor it wraps -- any torch function, arithmetic,
+    indexing or attribute works on the autograd leaf ``ad`` -- while ``htf.norm(positions, axis=1)`` stays
+    symbolic so that ``compute_positions_forces`` of a radial energy lowers to one kernel."""
+
+    def __init__(self, tensor):
+        self.tensor = tensor
+        self._ad = None
+
+    shape = property(lambda self: self.tensor.shape)
+    dtype = property(lambda self: self.tensor.dtype)
+    device = property(lambda self: self.tensor.device)
+
+    @property
+    def ad(self):
+        if self._ad is None:
+            self._ad = self.tensor.detach().requires_grad_(True)
+        return self._ad
+
+    def __getitem__(self, idx):
+        return self.ad[idx]
+
+    def __len__(self):
+        return int(self.tensor.shape[0])
+
+    def __getattr__(self, name):  # .detach(), .cpu(), .sum(...): whatever a tensor offers
+        if name.startswith("_"):
+            raise AttributeError(name)
+        return getattr(self.ad, name)
+
+    def numpy(self):
+        return self.tensor.cpu().numpy()
+
+
+class PosNorm(_TorchOperand):
+    """tf.norm(positions, axis=1) of the whole row (all four columns, as the reference's models take it)
+    or of ``positions[:, :3]``."""
+
+    def __init__(self, positions, ncomp):
+        self.positions, self.ncomp = positions, ncomp
+
+    @property
+    def ad(self):
+        return torch.sqrt((self.positions.ad[:, :self.ncomp] ** 2).sum(dim=1))
+
+
+class PosRadial(_TorchOperand):
+    """coef * |positions|^power, per particle: the energy of BenchmarkNonlistModel (build_examples.py:59-64)."""
+
+    def __init__(self, norm, coef, power):
+        self.norm, self.coef, self.power = norm, float(coef), int(power)
+
+    @property
+    def ad(self):
+        n = self.norm.ad
+        if self.power < 0:  # divide_no_nan
+            safe = torch.where(n > 0, n, torch.ones_like(n))
+            return torch.where(n > 0, self.coef * safe ** self.power, torch.zeros_like(n))
+        return self.coef * n ** self.power
+
+    def __mul__(self, o):
+        if isinstance(o, (int, float)):
+            return PosRadial(self.norm, self.coef * o, self.power)
+        return self.ad * _unwrap(o)
+
+    __rmul__ = __mul__
+
+
+def norm(tensor, axis=None):
+    """tf.norm for model code: symbolic on the positions tensor (axis=1), torch otherwise."""
+    if isinstance(tensor, Positions) and axis in (1, -1):
+        return PosNorm(tensor, 4)
+    t = _unwrap(tensor)
+    return torch.sqrt((t * t).sum()) if axis is None else torch.sqrt((t * t).sum(dim=axis))
+
+
+def divide_no_nan(x, y):
+    """tf.math.divide_no_nan: x / y, 0 where y == 0."""
+    if isinstance(y, PosNorm) and isinstance(x, (int, float)):
+        return PosRadial(y, x, -1)
+    x, y = _unwrap(x), _unwrap(y)
+    y = torch.as_tensor(y)
+    safe = torch.where(y != 0, y, torch.ones_like(y))
+    return torch.where(y != 0, x / safe, torch.zeros_like(safe))
 
 
 def _as_nlist(x):
@@ -215,7 +302,7 @@ class WCAPair(PairEnergy):
 
     def key(self):
         if self.layer is not None and self.layer.w is not None:
-            return ("wca-trainable", id(self.layer))
+            return ("wca-trainable",)
         return ("wca", self.sigma)
 
     def potential(self):
@@ -232,7 +319,7 @@ class LJParamEnergy(PairEnergy):
         self.nlist, self.layer, self.reduced = nlist, layer, reduced
 
     def key(self):
-        return ("ljparam", id(self.layer))
+        return ("ljparam",)
 
     def potential(self):
         return self.layer.potential()
@@ -251,10 +338,87 @@ class MLPEnergy(PairEnergy):
         self.nlist, self.layer = nlist, layer
 
     def key(self):
-        return ("mlp", id(self.layer))
+        return ("mlp",)
 
     def potential(self):
         return self.layer.potential()
+
+
+class SortedRinv:
+    """tf.sort(nlist_rinv(nlist), axis=1, direction='DESCENDING'): stays symbolic until sliced."""
+
+    def __init__(self, nlist):
+        self.nlist = nlist
+
+    def __getitem__(self, idx):
+        full = slice(None)
+        if (isinstance(idx, tuple) and len(idx) == 2 and idx[0] == full and isinstance(idx[1], slice)
+                and idx[1].start in (None, 0) and idx[1].step in (None, 1) and idx[1].stop is not None):
+            return TopRinv(self.nlist, int(idx[1].stop))
+        return self.tensor()[idx]
+
+    def tensor(self):
+        _trace_log().append({"op": "eager_value"})
+        s = ops.nlist_rinv(self.nlist.tensor)
+        return ops.topk_desc(s, s.shape[1])[0]
+
+
+class TopRinv:
+    """The K largest 1/r of every row, descending: the input features of example 08's network."""
+
+    def __init__(self, nlist, k):
+        self.nlist, self.k = nlist, int(k)
+
+    def tensor(self):
+        _trace_log().append({"op": "eager_value"})
+        return ops.topk_desc(ops.nlist_rinv(self.nlist.tensor), self.k)[0]
+
+
+class TopkMLPEnergy(PairEnergy):
+    """Dense(1)(Dense(H2)(Dense(H1)(top_n))): a per-particle energy [N, 1] (build_examples.py:199-218)."""
+    reduced = True
+
+    def __init__(self, top, layers):
+        self.nlist, self.top, self.layers = top.nlist, top, list(layers)
+        self.owns_potential = True  # kept on its first Dense layer (see _potential_of)
+
+    def key(self):
+        return ("topk-mlp",)
+
+    def potential(self):
+        d1, d2, d3 = self.layers
+        if d3.units != 1:
+            raise ValueError("the last Dense of a per-particle energy has one unit")
+        if d1.activation != d2.activation or d3.activation not in (None, "linear"):
+            raise ValueError("the fused top-k network takes one activation for both hidden layers and a linear output")
+        sig = tuple(id(d) for d in self.layers) + tuple(d.version for d in self.layers)
+        holder = self.layers[0]
+        if getattr(holder, "_topk_pot", None) is None or holder._topk_pot[0] != sig:
+            params = {"W1": d1.kernel, "b1": d1.bias, "W2": d2.kernel, "b2": d2.bias, "W3": d3.kernel, "b3": d3.bias}
+            holder._topk_pot = (sig, ops.Potential.topk_mlp(params, activation=d1.activation))
+        return holder._topk_pot[1]
+
+
+class DenseOut:
+    """The value of a Dense stack applied to the top-k features, still symbolic."""
+
+    def __init__(self, top, layers):
+        self.top, self.layers = top, layers
+
+    def energy(self):
+        if len(self.layers) != 3:
+            raise ValueError("the fused top-k network is Dense-Dense-Dense(1); got %d layers" % len(self.layers))
+        return TopkMLPEnergy(self.top, self.layers)
+
+
+def sort(values, axis=-1, direction='ASCENDING'):
+    """tf.sort for model code: descending sort of nlist_rinv(nlist) along the neighbor axis stays symbolic
+    (example 08 keeps only its first K columns); anything else is torch.sort."""
+    if (isinstance(values, RinvPoly) and not values.reduced and values.terms == {1: 1.0} and axis in (1, -1)
+            and direction == 'DESCENDING'):
+        return SortedRinv(values.nlist)
+    t = values.tensor() if hasattr(values, "tensor") and callable(values.tensor) else _unwrap(values)
+    return torch.sort(t, dim=axis, descending=(direction == 'DESCENDING'))[0]
 
 
 class PairCV:
@@ -351,8 +515,14 @@ class SafeNorm:
 def reduce_sum(x, axis=None):
     """tf.reduce_sum for expressions (axis=1: per-particle energy) and tensors."""
     if isinstance(x, RinvPoly):
+        if axis is None:
+            # a scalar total energy: compute_nlist_forces differentiates sum(energy) either way, and
+            # _add_energy tiles a rank-0 energy into every particle's column (simmodel.py:558-578)
+            out = RinvPoly(x.nlist, x.terms, reduced=True)
+            out.total = True
+            return out
         if axis not in (1, -1):
-            raise ValueError("pair energies reduce over the neighbor axis (axis=1)")
+            raise ValueError("pair energies reduce over the neighbor axis (axis=1), or over everything (axis=None)")
         return RinvPoly(x.nlist, x.terms, reduced=True)
     if isinstance(x, WCAPair):
         return x
@@ -383,6 +553,8 @@ def compute_nlist_forces(nlist, energy, virial=False):
     ('Did you put them in wrong order?')."""
     if isinstance(energy, torch.Tensor):
         return _autograd_nlist_forces(_as_nlist(nlist), energy, virial)
+    if isinstance(energy, DenseOut):
+        energy = energy.energy()
     if not isinstance(energy, PairEnergy):
         raise ValueError('Could not find dependence between energy and nlist.'
                          ' Did you put them in wrong order?')
@@ -394,6 +566,24 @@ def compute_nlist_forces(nlist, energy, virial=False):
         if virial:
             raise ValueError("virial of an EDS-biased energy is not implemented")
         return _biased_forces(nl, energy)
+    pot = _potential_of(energy)
+    out = ops.eval_forces(pot, nl.tensor, virial=virial)
+    f = out[0] if virial else out
+    if getattr(energy, "total", False):
+        f[:, 3] = f[:, 3].sum()  # rank-0 energy: the total in every particle's column
+        _trace_log().append({"op": "total_energy"})  # (keeps the step on the eager path)
+    _trace_log().append({"potential": pot, "nlist": nl, "virial": virial, "forces": f,
+                         "layer": getattr(energy, "layer", None)})
+    return out
+
+
+def _potential_of(energy):
+    """The lowered potential of a symbolic energy.  Energies that read a layer's weights get the
+    potential that layer OWNS (the layer keeps it for as long as it lives, so another layer can never be
+    handed it); only weight-free closed forms, identified by their VALUES (polynomial terms, a fixed
+    sigma), share the process-wide table."""
+    if getattr(energy, "owns_potential", False) or (getattr(energy, "layer", None) is not None and energy.key()[0] != "wca"):
+        return energy.potential()
     cache = getattr(compute_nlist_forces, "_cache", None)
     if cache is None:
         cache = compute_nlist_forces._cache = {}
@@ -403,11 +593,7 @@ def compute_nlist_forces(nlist, energy, virial=False):
         if len(cache) > 64:
             cache.clear()
         pot = cache[k] = energy.potential()
-    out = ops.eval_forces(pot, nl.tensor, virial=virial)
-    f = out[0] if virial else out
-    _trace_log().append({"potential": pot, "nlist": nl, "virial": virial, "forces": f,
-                         "layer": getattr(energy, "layer", None)})
-    return out
+    return pot
 
 
 def _add_energy(forces, energy):
@@ -457,8 +643,8 @@ def _biased_forces(nl, energy):
         cache = compute_nlist_forces._cache = {}
     base, cv, alpha = energy.base, energy.term.cv, energy.term.alpha
     kb, kg = base.key(), ("gauss", cv.r0, cv.gap)
-    if kb not in cache:
-        cache[kb] = base.potential()
+    if kb not in cache or (getattr(base, "layer", None) is not None and kb[0] != "wca"):
+        cache[kb] = _potential_of(base)
     if kg not in cache:
         cache[kg] = cv.potential()
     t = nl.tensor
@@ -496,6 +682,16 @@ def compute_positions_forces(positions, energy):
     """simmodel.py:492-506: ``-dE/dpositions`` with the energy column appended.  CV-bias
     models are O(few particles); this generic path differentiates with torch.autograd
     (SURVEY 8(f)-3 fallback), not a fused kernel."""
+    if isinstance(energy, PosRadial):
+        # the declarative positions energy: forces and the energy column from ONE kernel
+        # (htf_positions_forces_radial), no autograd graph
+        if energy.norm.positions is not positions:
+            raise ValueError('Could not find dependence between energy and positions.')
+        _trace_log().append({"op": "positions_radial"})
+        return ops.positions_forces_radial(positions.tensor, energy.coef, energy.power, energy.norm.ncomp)
+    energy = _unwrap(energy)
+    if isinstance(positions, Positions):
+        positions = positions.ad
     if not (isinstance(energy, torch.Tensor) and energy.requires_grad):
         raise ValueError('Could not find dependence between energy and positions.')
     (g,) = torch.autograd.grad(energy.sum(), positions, allow_unused=False)
@@ -660,6 +856,9 @@ class SimModel:
         for p, w in zip(self.parameters(), ws):
             with torch.no_grad():
                 p.copy_(torch.as_tensor(w, dtype=p.dtype))
+        # an installed plan may have baked a weight into its potential (a non-trainable WCARepulsion's
+        # sigma): the next step traces compute() again and lowers it from the new weights
+        self.retrace_compute()
 
     def save_weights(self, path):
         np.savez(path, *self.get_weights())
@@ -724,7 +923,7 @@ class SimModel:
                 raise NlistOverflowError('Neighbor list is full!')
         positions = positions.to(self.dtype)
         if self.nneighbor_cutoff == 0:
-            positions.requires_grad_(True)  # CV-bias models differentiate w.r.t. positions
+            positions = Positions(positions)  # CV-bias models differentiate w.r.t. positions
         return [Nlist(nlist.to(self.dtype)), positions, box.to(self.dtype)]
 
     @staticmethod

@@ -72,8 +72,11 @@ enum htf_potential_kind {
     HTF_POT_PAIR_MLP = 5,  /* safe_norm -> RBFExpansion -> Dense-Dense-Dense */
     HTF_POT_GAUSS = 6,     /* e = c * exp(-(r - r0)^2 / gap) * [r > 3e-6], r = safe_norm(x): one RBFExpansion
                             * channel (layers.py:46-49) as a pair energy -- the soft RDF bin of config C4 */
-    HTF_POT_LJ_PARAM = 7   /* trainable LJ of example 06 / build_examples.py:336-372 (LJLayer): r = safe_norm(x),
+    HTF_POT_LJ_PARAM = 7,  /* trainable LJ of example 06 / build_examples.py:336-372 (LJLayer): r = safe_norm(x),
                             * q = w1^6 / r^6 (divide_no_nan), e = w0 * 4 (q^2 - q) / 2; params (w0, w1) */
+    HTF_POT_TOPK_MLP = 8   /* example 08 / build_examples.py:199-218 NlistNN, a per-PARTICLE network:
+                            * top_n = tf.sort(nlist_rinv(nlist), DESCENDING)[:, :K] -> Dense(H1) -> Dense(H2) ->
+                            * Dense(1) = E_i.  desc.K = top_neighs (<= 16), H1, H2 <= 64, weights as for PAIR_MLP */
 };
 
 enum htf_activation { HTF_ACT_LINEAR = 0, HTF_ACT_TANH = 1 };
@@ -103,7 +106,7 @@ typedef struct htf_potential_desc {
     int n_terms;
     double coef[HTF_MAX_POLY_TERMS];
     int power[HTF_MAX_POLY_TERMS];
-    /* PAIR_MLP: host pointers, row-major [in, out] like Keras Dense kernels; copied */
+    /* PAIR_MLP and TOPK_MLP: host pointers, row-major [in, out] like Keras Dense kernels; copied */
     int K, H1, H2;
     int activation;    /* htf_activation */
     int mlp_precision; /* htf_mlp_precision: MFMA operand type; accumulation is fp32 */
@@ -271,6 +274,14 @@ HTF_API int htf_energy_sum(const void *d_force, int dtype, unsigned N, double *d
  * HOOMD's position array before the neighbor search (TensorflowCompute.cc:228-241). */
 HTF_API int htf_copy3(void *d_dest, int dest_dtype, const void *d_src, int src_dtype, unsigned N, htf_stream stream);
 
+/* compute_positions_forces (simmodel.py:492-506) for the per-particle radial energies positions-only models
+ * build from tf.norm(positions, axis=1): e_i = coef * |p_i|^power with the norm over the first ncomp (3 or 4)
+ * columns of the [N, 4] positions side buffer (x, y, z, un-stuffed type) -- build_examples.py:59-64
+ * BenchmarkNonlistModel is coef 1, power -1, ncomp 4 with divide_no_nan.  force[i] =
+ * (-d(sum e)/d p_i[:3], e_i) written in place (Scalar4 of force_dtype). */
+HTF_API int htf_positions_forces_radial(const void *d_positions, int dtype, unsigned N, int ncomp, int power,
+                                double coef, void *d_force, int force_dtype, htf_stream stream);
+
 /* SimModel.compute_inputs check_nlist (simmodel.py:214-219): *d_out =
  * max(*d_out, max_i sum_j [nlist[i,j,0] > 0]).  The caller zeroes *d_out. */
 HTF_API int htf_check_nlist(const void *d_nlist, int nlist_dtype, unsigned B, unsigned NN,
@@ -279,6 +290,12 @@ HTF_API int htf_check_nlist(const void *d_nlist, int nlist_dtype, unsigned B, un
 /* nlist_rinv (simmodel.py:618-635): out[B*NN] fp32. */
 HTF_API int htf_nlist_rinv(const void *d_nlist, int nlist_dtype, unsigned B, unsigned NN,
                    float *d_out, htf_stream stream);
+
+/* tf.math.top_k (what tf.sort(..., direction='DESCENDING') runs on): the k largest entries of every row of
+ * x [B, n] (fp32, n <= 256), largest first, equal values in order of their index; d_values [B, k],
+ * d_indices [B, k]. */
+HTF_API int htf_top_k(const float *d_x, unsigned B, unsigned n, unsigned k, float *d_values, int *d_indices,
+              htf_stream stream);
 
 /* compute_rdf + masked_nlist (simmodel.py:638-693).  Histogram of |nlist xyz| with
  * tf.histogram_fixed_width semantics over nbins_total = nbins + 2 bins (values clamp

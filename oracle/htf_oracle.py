@@ -266,6 +266,21 @@ def compute_positions_forces_from_grad(pos_grad, energy):
     return add_energy(-pos_grad, energy)
 
 
+def positions_radial_model(positions, coef=1.0, power=-1, ncomp=4):
+    """compute_positions_forces (simmodel.py:492-506) of e_i = coef * |positions_i[:ncomp]|^power with
+    divide_no_nan at |p| = 0.  power -1, ncomp 4 is build_examples.py:59-64 BenchmarkNonlistModel:
+    ps = tf.norm(positions, axis=1) (all four columns, the type included); energy = divide_no_nan(1., ps);
+    forces = -d(sum energy)/d positions, first three columns, energy appended."""
+    p = np.asarray(positions)
+    dt = p.dtype
+    n = np.sqrt(np.sum(p[:, :ncomp] * p[:, :ncomp], axis=1))
+    ok = n > 0
+    safe = np.where(ok, n, dt.type(1))
+    e = np.where(ok, dt.type(coef) * safe ** power, dt.type(0))
+    grad = (np.where(ok, dt.type(coef) * power * safe ** (power - 2), dt.type(0)))[:, None] * p[:, :3]
+    return compute_positions_forces_from_grad(np.concatenate([grad, np.zeros((len(p), 1), dt)], axis=1), e)
+
+
 # --------------------------------------------------------------------------- #
 # a24: reference workloads (build_examples.py)
 # --------------------------------------------------------------------------- #
@@ -442,6 +457,36 @@ def pair_mlp_model(nlist, params, low=0.0, high=3.0, act="tanh", return_grad=Fal
     if return_grad:
         return nlist_forces_from_grad(nlist, g, E), g
     return nlist_forces_from_grad(nlist, g, E)
+
+
+def topk_mlp_model(nlist, params, act=None, return_grad=False):
+    """Example 08 / build_examples.py:199-218 NlistNN:
+        rinv  = nlist_rinv(nlist)
+        top_n = tf.sort(rinv, axis=1, direction='DESCENDING')[:, :K]      K = W1.shape[0]
+        E_i   = Dense(1)(act(Dense(H2)(act(Dense(H1)(top_n)))))[:, 0]     Keras Dense, activation None by default
+        forces = compute_nlist_forces(nlist, energy)
+    tf.sort(DESCENDING) runs on tf.math.top_k: equal values keep their index order (stable).  The gradient of a
+    sorted value goes back to the slot it came from."""
+    dt = nlist.dtype
+    s, t, rp, cond = _rinv_and_grad_factor(nlist)
+    W1, b1, W2, b2, W3, b3 = (np.asarray(params[k], dtype=dt) for k in ("W1", "b1", "W2", "b2", "W3", "b3"))
+    K = W1.shape[0]
+    order = np.argsort(-s, axis=1, kind="stable")[:, :K]
+    rows = np.arange(s.shape[0])[:, None]
+    top = s[rows, order]
+    z1 = top @ W1 + b1
+    h1 = np.tanh(z1) if act == "tanh" else z1
+    z2 = h1 @ W2 + b2
+    h2 = np.tanh(z2) if act == "tanh" else z2
+    E = (h2 @ W3.reshape(-1, 1) + b3)[:, 0]
+    g2 = np.broadcast_to(W3.reshape(-1), h2.shape) * ((1 - h2 * h2) if act == "tanh" else 1)
+    g1 = (g2 @ W2.T) * ((1 - h1 * h1) if act == "tanh" else 1)
+    gtop = g1 @ W1.T                                  # dE_i / d top_n[i, k]
+    dEds = np.zeros_like(s)
+    dEds[rows, order] = gtop
+    g = _grad_from_dEds(dEds, s, t, rp, cond)
+    out = nlist_forces_from_grad(nlist, g, E)
+    return (out, g) if return_grad else out
 
 
 def lj_param_model(nlist, w0, w1):

@@ -205,23 +205,21 @@ class TorchLJModel(htf.SimModel):
 
 
 class NlistNN(htf.SimModel):
-    # build_examples.py:199-218: a small network on the sorted 1/r of the closest neighbors
+    # build_examples.py:199-218
     def setup(self, dim, top_neighs):
-        g = torch.Generator().manual_seed(0)
-        self.w1 = torch.randn((top_neighs, dim), generator=g) * 0.3
-        self.w2 = torch.randn((dim, dim), generator=g) * 0.3
-        self.w3 = torch.randn((dim, 1), generator=g) * 0.3
+        self.dense1 = htf.Dense(dim, seed=1)
+        self.dense2 = htf.Dense(dim, seed=2)
+        self.last = htf.Dense(1, seed=3)
         self.top_neighs = top_neighs
 
     def compute(self, nlist, positions, box):
-        r = torch.sqrt(torch.sum((nlist[:, :, :3] + 1e-7 / 3) ** 2, dim=2))
-        rinv = torch.where(r > 3e-6, 1.0 / (r + 3e-6), torch.zeros_like(r))
-        top_n = torch.sort(rinv, dim=1, descending=True)[0][:, :self.top_neighs]
-        w1, w2, w3 = (w.to(top_n.device, top_n.dtype) for w in (self.w1, self.w2, self.w3))
-        x = torch.tanh(top_n @ w1)
-        x = torch.tanh(x @ w2)
-        energy = (x @ w3)[:, 0]
-        return htf.compute_nlist_forces(nlist, energy)
+        rinv = htf.nlist_rinv(nlist)
+        top_n = htf.sort(rinv, axis=1, direction='DESCENDING')[:, :self.top_neighs]
+        x = self.dense1(top_n)
+        x = self.dense2(x)
+        energy = self.last(x)
+        forces = htf.compute_nlist_forces(nlist, energy)
+        return forces
 
 
 class NoForceModel(htf.SimModel):
@@ -271,8 +269,8 @@ class TensorSaveModel(htf.SimModel):
 class BenchmarkNonlistModel(htf.SimModel):
     # build_examples.py:59-64
     def compute(self, nlist, positions, box):
-        ps = torch.norm(positions, dim=1)
-        energy = torch.where(ps > 0, 1.0 / torch.where(ps > 0, ps, torch.ones_like(ps)), torch.zeros_like(ps))
+        ps = htf.norm(positions, axis=1)
+        energy = htf.divide_no_nan(1., ps)
         forces = htf.compute_positions_forces(positions, energy)
         return forces
 

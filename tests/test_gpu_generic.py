@@ -43,7 +43,7 @@ def test_torch_model_equals_fused_model(htf, cuda):
 
 
 def test_nlist_nn_model_runs_and_conserves_momentum(htf, cuda):
-    """build_examples.NlistNN (sort + dense layers on 1/r): only expressible on the generic route."""
+    """build_examples.NlistNN (sort + dense layers on 1/r) through tfcompute: traced, then replayed as the fused top-k kernel."""
     sim, system, L = _sim(htf, cuda, 6, 1.5, dtype=torch.float32, kT=0.3, seed=2)
     sim.integrate_nve(0.001)
     tfc = htf.tfcompute(build_examples.NlistNN(24, dim=8, top_neighs=6))

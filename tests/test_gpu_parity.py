@@ -37,17 +37,30 @@ def _cond_scale(nl64, model_pair_forces):
     return np.abs(model_pair_forces).sum(axis=(1, 2))
 
 
-def assert_forces_close(name, got, ref, cond=None, atol=1e-5, rtol=2e-5, ctol=2e-6):
+def assert_forces_close(name, got, ref, cond=None, atol=1e-5, rtol=2e-5, ctol=2e-6, cancelling_rows=None):
+    """SURVEY 8(c)'s bound, |d| <= atol + rtol |ref|, asserted as it stands.  The condition term
+    ctol * sum_j |f_ij| is added ONLY for call sites that name why they need it (``cancelling_rows``:
+    rows whose pair forces are orders of magnitude larger than their sum, where the fp32 summation order
+    of a 64-lane wave reduction and of the oracle's fp64 sum differ by more than the strict bound).
+    Both ratios are recorded (gpurun_out/parity_stats.json)."""
     got = np.asarray(got, dtype=np.float64)
     ref = np.asarray(ref, dtype=np.float64)
     assert got.shape == ref.shape
     assert np.all(np.isfinite(got)), name
-    bound = atol + rtol * np.abs(ref)
-    if cond is not None:
-        bound = bound + ctol * np.asarray(cond).reshape(-1, *([1] * (ref.ndim - 1)))
+    strict = atol + rtol * np.abs(ref)
     err = np.abs(got - ref)
-    _record(name, max_abs_err=err.max(), max_ratio=(err / bound).max(), max_ref=np.abs(ref).max())
-    assert np.all(err <= bound), "%s: worst err/bound = %.3g (max abs err %.3g)" % (name, (err / bound).max(), err.max())
+    rec = dict(max_abs_err=err.max(), max_ratio_strict=(err / strict).max(), max_ref=np.abs(ref).max())
+    bound = strict
+    if cond is not None:
+        with_cond = strict + ctol * np.asarray(cond).reshape(-1, *([1] * (ref.ndim - 1)))
+        rec["max_ratio_with_condition_term"] = (err / with_cond).max()
+        if cancelling_rows:
+            bound = with_cond
+            rec["condition_term_used"] = 1.0
+    _record(name, **rec)
+    assert np.all(err <= bound), "%s: worst err/bound = %.3g (max abs err %.3g)%s" % (
+        name, (err / bound).max(), err.max(), "" if cancelling_rows or cond is None else
+        "; with the condition term: %.3g" % rec["max_ratio_with_condition_term"])
 
 
 def _pair_forces_lj(nl64):
@@ -734,3 +747,130 @@ def test_wca_mask_at_the_cutoff_is_the_sqrt_mask(htf, cuda, sigma):
     inside_ref = np.sqrt((x * x).astype(np.float32)).astype(np.float32) < cut
     np.testing.assert_array_equal(inside_gpu, inside_ref)
     assert inside_ref.any() and not inside_ref.all()
+
+
+# --------------------------------------------------------------------------- round-2 additions
+@pytest.mark.parametrize("precision", ["fp32", "split"])
+@pytest.mark.parametrize("act", ["tanh", "linear"])
+def test_pair_mlp_virial(htf, cuda, act, precision):
+    """compute_nlist_forces(nlist, energy, virial=True) works for ANY energy upstream (simmodel.py:552-554,
+    509-523): the pair-MLP evaluator forms -(|nf| / (2 |x|)) x (x) x per slot where it forms du/dr."""
+    from hoomd_tf_amd.initializers import mlp_params
+    params = mlp_params(seed=5, K=32, H1=64, H2=64, bias_scale=0.2)
+    nl = _nlist_case(11, N=130, NN=72, rmin=0.6)
+    nl[3] = 0
+    nl64 = nl.astype(np.float64)
+    ref, g = O.pair_mlp_model(nl64, params, 0.0, 3.0, act, return_grad=True)
+    vref = O.compute_virial(nl64, 2.0 * g)
+    pot = htf.Potential.pair_mlp(params, 0.0, 3.0, activation=act, precision=precision)
+    f, v = htf.ops.eval_forces(pot, torch.from_numpy(nl).to(cuda), virial=True)
+    f0 = htf.ops.eval_forces(pot, torch.from_numpy(nl).to(cuda))
+    assert torch.equal(f, f0)  # the virial instantiation leaves the forces bit for bit alone
+    cond = np.abs(2 * g).sum(axis=(1, 2))
+    assert_forces_close("mlp_virial_f_%s_%s" % (act, precision), f.cpu().numpy(), ref, cond, atol=2e-5, rtol=5e-5, ctol=5e-6)
+    vcond = (np.linalg.norm(2 * g, axis=2) * np.linalg.norm(nl64[:, :, :3], axis=2) / 2).sum(axis=1)
+    assert_forces_close("mlp_virial_v_%s_%s" % (act, precision), v.cpu().numpy(), vref, vcond, atol=2e-5, rtol=5e-5, ctol=5e-6)
+    assert np.all(v.cpu().numpy()[3] == 0)
+    v_np = v.cpu().numpy()
+    np.testing.assert_array_equal(v_np, np.transpose(v_np, (0, 2, 1)))  # symmetric by construction
+    # and through the context (SimModel(virial=True) + htf_add_virial's 6-component pick)
+    f64, v64 = htf.ops.eval_forces(pot, torch.from_numpy(nl64).to(cuda), virial=True)
+    assert v64.dtype == torch.float64
+    assert_forces_close("mlp_virial_v64_%s_%s" % (act, precision), v64.cpu().numpy(), vref, vcond, atol=2e-5, rtol=5e-5, ctol=5e-6)
+
+
+@pytest.mark.parametrize("tdt", [torch.float32, torch.float64])
+def test_positions_forces_radial(htf, cuda, tdt):
+    """a15 on the device: compute_positions_forces of BenchmarkNonlistModel's energy
+    (build_examples.py:59-64: divide_no_nan(1., tf.norm(positions, axis=1)), the type column included)."""
+    rng = np.random.default_rng(4)
+    p = rng.uniform(-30, 30, size=(1000, 4))
+    p[:, 3] = rng.integers(0, 3, size=1000)
+    p[7] = 0.0
+    p[8] = [3.0, 0.0, 4.0, 0.0]
+    p[9] = [1.0, 2.0, 2.0, 4.0]
+    pt = torch.tensor(p, dtype=tdt, device=cuda)
+    got = htf.ops.positions_forces_radial(pt).cpu().numpy()
+    ref = O.positions_radial_model(p.astype(np.float32 if tdt == torch.float32 else np.float64).astype(np.float64))
+    assert_forces_close("positions_radial_%s" % str(tdt)[-7:], got, ref)
+    np.testing.assert_allclose(got[8], [3 / 125, 0.0, 4 / 125, 0.2], rtol=1e-6)   # by hand
+    np.testing.assert_allclose(got[9], [1 / 125, 2 / 125, 2 / 125, 0.2], rtol=1e-6)
+    assert np.all(got[7] == 0.0)
+    # other powers / three columns against the same closed form
+    for power, ncomp, coef in ((-2, 3, 0.5), (2, 4, 0.25), (1, 3, -1.5)):
+        got = htf.ops.positions_forces_radial(pt, coef=coef, power=power, ncomp=ncomp).cpu().numpy()
+        assert_forces_close("positions_radial_p%d_c%d" % (power, ncomp), got,
+                            O.positions_radial_model(p, coef=coef, power=power, ncomp=ncomp), atol=2e-5, rtol=2e-5)
+    with pytest.raises(ValueError):
+        htf.ops.positions_forces_radial(pt, power=0)
+
+
+def test_scalar_total_energy_is_tiled(htf, cuda):
+    """_add_energy (simmodel.py:558-578): a rank-0 energy lands in EVERY particle's energy column; the
+    forces are those of the per-particle form (tf.gradients sums the energy either way)."""
+    nl = _nlist_case(3, N=50, NN=16, rmin=0.9)
+    x = htf.Nlist(torch.from_numpy(nl).to(cuda))
+    rinv = htf.nlist_rinv(x)
+    e_pair = 2.0 * (rinv ** 12 - rinv ** 6)
+    f_row = htf.compute_nlist_forces(x, htf.reduce_sum(e_pair, axis=1)).cpu().numpy()
+    f_tot = htf.compute_nlist_forces(x, htf.reduce_sum(e_pair)).cpu().numpy()
+    np.testing.assert_array_equal(f_tot[:, :3], f_row[:, :3])
+    np.testing.assert_allclose(f_tot[:, 3], np.full(50, f_row[:, 3].astype(np.float64).sum()), rtol=1e-5)
+    ref = O.lj_model(nl.astype(np.float64))
+    assert_forces_close("lj_total_energy", f_tot[:, :3], ref[:, :3])
+
+
+@pytest.mark.parametrize("act", [None, "tanh"])
+@pytest.mark.parametrize("NN,K,H", [(64, 8, 16), (128, 8, 32), (24, 6, 8), (200, 16, 64)])
+def test_topk_mlp_example08(htf, cuda, act, NN, K, H):
+    """Example 08's model as ONE kernel (htf_potential_kind TOPK_MLP): wave arg-max top-k of 1/r, the per-particle
+    Dense stack forward and backward, the gradient routed back to the slots the sorted values came from."""
+    rng = np.random.default_rng(NN + K)
+    nl, _ = random_nlist(rng, 203, NN, fill=0.6, rmin=0.8, rmax=3.0, dtype=np.float32)
+    nl[0] = 0
+    nl[1, 3:] = 0          # fewer real neighbors than K
+    nl[2, 1, :3] = nl[2, 0, :3][::-1]   # two slots at exactly the same distance (a lattice tie)
+    params = {"W1": rng.normal(0, 0.4, (K, H)), "b1": rng.normal(0, 0.1, H), "W2": rng.normal(0, 0.3, (H, H)),
+              "b2": rng.normal(0, 0.1, H), "W3": rng.normal(0, 0.3, (H, 1)), "b3": rng.normal(0, 0.1, 1)}
+    params = {k: v.astype(np.float32) for k, v in params.items()}
+    nl64 = nl.astype(np.float64)
+    ref, g = O.topk_mlp_model(nl64, {k: v.astype(np.float64) for k, v in params.items()}, act=act, return_grad=True)
+    pot = htf.Potential.topk_mlp(params, activation=act)
+    x = torch.from_numpy(nl).to(cuda)
+    f, v = htf.ops.eval_forces(pot, x, virial=True)
+    cond = np.abs(2 * g).sum(axis=(1, 2))
+    assert_forces_close("topk_mlp_%s_NN%d" % (act, NN), f.cpu().numpy(), ref, cond, atol=2e-5, rtol=5e-5)
+    assert_forces_close("topk_mlp_v_%s_NN%d" % (act, NN), v.cpu().numpy(), O.compute_virial(nl64, 2.0 * g), atol=2e-5, rtol=5e-5)
+    assert torch.equal(htf.ops.eval_forces(pot, x), f)
+    f64 = htf.ops.eval_forces(pot, torch.from_numpy(nl64).to(cuda))
+    assert f64.dtype == torch.float64
+    assert_forces_close("topk_mlp64_%s_NN%d" % (act, NN), f64.cpu().numpy(), ref, cond, atol=2e-5, rtol=5e-5)
+    # the sorted features themselves: tf.math.top_k semantics (values descending, ties by index)
+    s = htf.ops.nlist_rinv(x)
+    vals, idx = htf.ops.topk_desc(s, K)
+    s_np = s.cpu().numpy()
+    order = np.argsort(-s_np, axis=1, kind="stable")[:, :K]
+    np.testing.assert_array_equal(idx.cpu().numpy(), order)
+    np.testing.assert_array_equal(vals.cpu().numpy(), np.take_along_axis(s_np, order, axis=1))
+
+
+def test_topk_mlp_through_the_model_surface(htf, cuda):
+    """build_examples.NlistNN written as the reference writes it (sort -> Dense -> Dense -> Dense ->
+    compute_nlist_forces) lowers to the fused kernel and equals the oracle on the same pair vectors."""
+    import build_examples
+    rng = np.random.default_rng(5)
+    nl, _ = random_nlist(rng, 64, 32, fill=0.7, rmin=0.8, rmax=3.0, dtype=np.float32)
+    model = build_examples.NlistNN(32, dim=16, top_neighs=8)
+    x = htf.Nlist(torch.from_numpy(nl).to(cuda))
+    (f,) = model([x, None, None])
+    d1, d2, d3 = model.dense1, model.dense2, model.last
+    assert d1.kernel.shape == (8, 16) and d3.kernel.shape == (16, 1) and not d1.bias.any()   # built on first call
+    params = {"W1": d1.kernel, "b1": d1.bias, "W2": d2.kernel, "b2": d2.bias, "W3": d3.kernel, "b3": d3.bias}
+    ref = O.topk_mlp_model(nl.astype(np.float64), {k: v.astype(np.float64) for k, v in params.items()})
+    assert_forces_close("nlistnn_model", f.cpu().numpy(), ref, atol=2e-5, rtol=5e-5)
+    # new weights reach the kernel
+    d1.set_weights([2.0 * d1.kernel, d1.bias + 0.1])
+    (f2,) = model([x, None, None])
+    params["W1"], params["b1"] = d1.kernel, d1.bias
+    ref2 = O.topk_mlp_model(nl.astype(np.float64), {k: v.astype(np.float64) for k, v in params.items()})
+    assert_forces_close("nlistnn_model_reweighted", f2.cpu().numpy(), ref2, atol=2e-5, rtol=5e-5)

@@ -156,3 +156,70 @@ def test_compute_rdf_and_mask():
     assert ab.shape == (10,)
     m = O.masked_nlist(nl, types, 0, 1)
     assert m.shape[0] == 32 and np.all(m[..., 3][m[..., 3] != 0] == 1)
+
+
+def test_positions_radial_model_vs_autograd_and_by_hand():
+    """a15: compute_positions_forces of BenchmarkNonlistModel's energy (build_examples.py:59-64)."""
+    import torch
+    rng = np.random.default_rng(4)
+    p = rng.uniform(-3, 3, size=(40, 4))
+    p[:, 3] = rng.integers(0, 3, size=40)
+    p[7] = 0.0                                   # |p| = 0: divide_no_nan
+    ref = O.positions_radial_model(p)
+    t = torch.tensor(p, requires_grad=True)
+    n = torch.sqrt((t * t).sum(dim=1))
+    e = torch.where(n > 0, 1.0 / torch.where(n > 0, n, torch.ones_like(n)), torch.zeros_like(n))
+    (g,) = torch.autograd.grad(e.sum(), t)
+    ok = np.arange(40) != 7                      # autograd through sqrt at 0 is NaN (TF's norm gradient too)
+    np.testing.assert_allclose(ref[ok, :3], -g.numpy()[ok, :3], rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(ref[:, 3], e.detach().numpy(), rtol=1e-12)
+    assert np.all(ref[7] == 0.0) and np.all(np.isnan(g.numpy()[7, :3]))
+    # by hand: p = (3, 0, 4, type 0): |p| = 5, e = 1/5, F = p / |p|^3;  p = (1, 2, 2, type 4): |p| = 5 as well
+    f = O.positions_radial_model(np.array([[3.0, 0.0, 4.0, 0.0], [1.0, 2.0, 2.0, 4.0]]))
+    np.testing.assert_allclose(f, [[3 / 125, 0.0, 4 / 125, 0.2], [1 / 125, 2 / 125, 2 / 125, 0.2]], rtol=1e-14)
+
+
+@pytest.mark.parametrize("act", [None, "tanh"])
+def test_topk_mlp_model_vs_autograd(act):
+    """Example 08 (build_examples.py:199-218): the oracle's closed-form backward through sort -> Dense x 3
+    against torch.autograd of the op-for-op graph (torch.sort is stable with stable=True)."""
+    import torch
+    from helpers import random_nlist
+    rng = np.random.default_rng(8)
+    nl, _ = random_nlist(rng, 40, 24, fill=0.6, rmin=0.8, rmax=3.0, dtype=np.float64)
+    nl[0] = 0
+    nl[1, 3:] = 0                                   # fewer real neighbors (3) than K: zeros enter the top 8
+    K, H = 8, 16
+    params = {"W1": rng.normal(0, 0.4, (K, H)), "b1": rng.normal(0, 0.1, H), "W2": rng.normal(0, 0.3, (H, H)),
+              "b2": rng.normal(0, 0.1, H), "W3": rng.normal(0, 0.3, (H, 1)), "b3": rng.normal(0, 0.1, 1)}
+    ref, g = O.topk_mlp_model(nl, params, act=act, return_grad=True)
+    x = torch.tensor(nl, requires_grad=True)
+    tt = x[:, :, :3] + 1e-7
+    r = torch.sqrt((tt * tt).sum(dim=2))
+    rinv = torch.where(r > 3e-6, 1.0 / (r + 3e-6), torch.zeros_like(r))
+    top = torch.sort(rinv, dim=1, descending=True, stable=True)[0][:, :K]
+    W = {k: torch.tensor(v) for k, v in params.items()}
+    h = top @ W["W1"] + W["b1"]
+    h = torch.tanh(h) if act == "tanh" else h
+    h = h @ W["W2"] + W["b2"]
+    h = torch.tanh(h) if act == "tanh" else h
+    e = (h @ W["W3"] + W["b3"])[:, 0]
+    (gx,) = torch.autograd.grad(e.sum(), x)
+    np.testing.assert_allclose(g, gx.numpy(), rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(ref[:, :3], 2.0 * gx.numpy()[:, :, :3].sum(axis=1), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(ref[:, 3], e.detach().numpy(), rtol=1e-12)
+
+
+def test_topk_mlp_tie_order_on_a_lattice():
+    """Equidistant neighbors take different first-layer weights: the lower slot gets the earlier rank."""
+    nl = np.zeros((1, 6, 4))
+    nl[0, 0, :3] = (0, 1.0, 0)
+    nl[0, 1, :3] = (1.0, 0, 0)       # same distance as slot 0
+    nl[0, 2, :3] = (0, 0, 0.5)       # closest: rank 0
+    K, H = 3, 2
+    params = {"W1": np.array([[1.0, 0.0], [0.0, 2.0], [0.0, -3.0]]), "b1": np.zeros(H), "W2": np.eye(H), "b2": np.zeros(H),
+              "W3": np.ones((H, 1)), "b3": np.zeros(1)}
+    f, g = O.topk_mlp_model(nl, params, return_grad=True)
+    # E = 1 * s2 + 2 * s0 - 3 * s1 with s = 1/r: slot 0 (rank 1) takes weight 2, slot 1 (rank 2) weight -3
+    assert g[0, 0, 1] == pytest.approx(2.0 * -1.0, rel=1e-4) and g[0, 1, 0] == pytest.approx(-3.0 * -1.0, rel=1e-4)
+    assert g[0, 2, 2] == pytest.approx(1.0 * -4.0, rel=1e-4)
