@@ -405,8 +405,11 @@ static int compute_rows(htf_ctx *ctx, unsigned timestep, const htf_hoomd_arrays 
     const htf_config &cfg = ctx->cfg;
     if (timestep % cfg.period != 0) return HTF_OK; // .cc:133 -- previous forces stay in m_force
     HTF_REQUIRE(a->pos, "htf_compute_forces: null positions");
-    HTF_REQUIRE(cfg.force_mode == HTF_TF2HOOMD, "htf_compute_forces: FORCE_MODE::hoomd2tf (training) is not built yet");
-    HTF_REQUIRE(a->force, "htf_compute_forces: null force array");
+    // FORCE_MODE::hoomd2tf (TensorflowCompute.cc:177-187): forces flow FROM HOOMD to the model as training
+    // labels; this call then only stages the model inputs (pair vectors, positions) and writes no force --
+    // the training sweep (htf_train_pair_grad on htf_get_nlist_buffer) is the caller's next call
+    const bool to_hoomd = cfg.force_mode == HTF_TF2HOOMD;
+    HTF_REQUIRE(a->force || !to_hoomd, "htf_compute_forces: null force array");
     // SimModel.compute_inputs: tf.Assert(reduce_sum(box[2]) < 0.0001)  simmodel.py:195
     if (!(a->box.tilt[0] + a->box.tilt[1] + a->box.tilt[2] < 0.0001)) {
         set_error("box is skewed");
@@ -442,7 +445,7 @@ static int compute_rows(htf_ctx *ctx, unsigned timestep, const htf_hoomd_arrays 
             ctx->ev_one_scope.push_back(0);
             HTF_CHECK_HIP(hipEventRecord(e0, s));
         }
-        const bool fused = cfg.fused && cfg.nneighs > 0 && ctx->pot != nullptr && !own_evaluator(ctx->pot);
+        const bool fused = to_hoomd && cfg.fused && cfg.nneighs > 0 && ctx->pot != nullptr && !own_evaluator(ctx->pot);
         if (fused) {
             HTF_REQUIRE(a->n_neigh && a->nlist && a->head_list, "htf_compute_forces: null neighbor list");
             if (prof) ctx->ev_one_scope.back() = 1; // no separate build scope in fused mode: e1 stays unrecorded
@@ -485,7 +488,7 @@ static int compute_rows(htf_ctx *ctx, unsigned timestep, const htf_hoomd_arrays 
             if (rc != HTF_OK) return rc;
             continue;
         }
-        if (ctx->pot == nullptr) continue;
+        if (ctx->pot == nullptr || !to_hoomd) continue;
         if (cfg.check_nlist) {
             unsigned h = 0;
             HTF_CHECK_HIP(hipMemsetAsync(ctx->flag, 0, sizeof(unsigned), s));
