@@ -367,8 +367,9 @@ def self_launch(args):
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        # rank 0's stdout carries the JSON line; the other ranks' stdout (library chatter) goes to stderr
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else None))
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
     out, _ = procs[0].communicate()
     rcs = [procs[0].returncode]
     for pr in procs[1:]:
@@ -377,7 +378,9 @@ def self_launch(args):
         except subprocess.TimeoutExpired:
             pr.kill()
             rcs.append(-9)
-    sys.stdout.write(out.decode("utf-8", "replace"))
+    for line in out.decode("utf-8", "replace").splitlines():
+        # ONE JSON line on stdout; anything else a library printed there (gloo's connection notes) is passed to stderr
+        (sys.stdout if line.startswith("{") else sys.stderr).write(line + "\n")
     sys.stdout.flush()
     return max(abs(rc) for rc in rcs)
 
@@ -757,7 +760,9 @@ def run_md(args, E, workload, variants=True, cpu=True):
                                      else "host (distance check read back every %d steps%s)" % (args.check_period, ", all-reduced over ranks" if world > 1 else ""),
                    "halo": None if world == 1 else {"ghosts_rank0": sysm.n_ghost, "migrated_rank0": nl.domain.n_migrated,
                                                     "interior_rows_rank0": nl.domain.n_interior,
-                                                    "transport": E.backend if E.backend != "nccl" else "RCCL (torch.distributed nccl backend)",
+                                                    "transport": ("RCCL: the library's own communicator and halo stream (csrc/halo.hip)" if nl.domain.transport == "native"
+                                                                  else (E.backend if E.backend != "nccl" else "RCCL (torch.distributed nccl backend)")),
+                                                    "transport_note": getattr(nl.domain, "transport_note", None),
                                                     "exchange": "forward ghost positions, grouped send/recv, every step"}},
         # sum over ranks of the algorithmic bytes a step moves (rank 0's count x ranks) / step time
         "hbm_GBps_full_step": world * step_bytes / (elapsed / args.steps) / 1e9,

@@ -122,6 +122,12 @@ PROTOTYPES = {
     "htf_rbf_expansion": (_i, [_vp, _sz, _d, _d, _u, _vp, _vp]),
     "htf_eds_update": (_i, [_vp, _vp, C.c_float, _i, C.c_float, C.c_float, _vp]),
     "htf_wrap_vector": (_i, [_vp, _i, _sz, C.POINTER(Box), _vp, _vp]),
+    "htf_halo_available": (_i, []),
+    "htf_halo_unique_id": (_i, [_vp]),
+    "htf_halo_create": (_i, [_vp, _i, _i, C.POINTER(_vp)]),
+    "htf_halo_destroy": (None, [_vp]),
+    "htf_halo_exchange_begin": (_i, [_vp, _vp, _i, _i, _i, _u, _u, _u, _u, _u, _u, _u, _u, _vp]),
+    "htf_halo_exchange_end": (_i, [_vp, _vp]),
     "htf_profile_enable": (_i, [_vp, _i]),
     "htf_profile_read": (_i, [_vp, C.POINTER(_d), C.POINTER(_d), C.POINTER(_u)]),
 }

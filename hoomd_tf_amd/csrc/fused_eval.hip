@@ -296,6 +296,132 @@ __device__ __forceinline__ void fused_rows_group(
         }
 }
 
+// Variant for NN <= 128 with the tensor written: the survivors of a row are first COMPACTED into a
+// wave-private LDS row (slot = rank among the kept), then evaluated from there -- ceil(NN / 64) trips over the
+// ~95 survivors instead of three over the ~139 candidates -- and stored, zero tail included, as full-width
+// 1-KiB lines (two store instructions per row instead of three partial ones and a tail).  Round-2 PMC has this
+// kernel bound by the CU's texture-address path (TA busy ~85 %: one cycle per gathered lane, 16 per 1-KiB
+// store), with the VALU at ~50 %: the variant trades both for LDS traffic, which is otherwise idle here.
+// Same per-slot arithmetic; the row sums run over slots instead of candidates, so forces differ from the
+// register path by summation-order rounding only.  Overflowing / long / empty rows: generic routine, as above.
+template <int KIND, int R, typename PT>
+__global__ __launch_bounds__(256) void fused_forces_lds_kernel(
+    const typename Vec4<PT>::type *__restrict__ pos, unsigned N, unsigned NN, unsigned offset, unsigned batch,
+    BoxT<PT> box, const unsigned *__restrict__ n_neigh, const unsigned *__restrict__ nlist,
+    const unsigned *__restrict__ head_list, PT rmaxsq, void *__restrict__ force, int out_f64, PotParams pin,
+    unsigned *__restrict__ check_count, float4 *__restrict__ positions_out, float4 *__restrict__ dest,
+    unsigned *__restrict__ counts_io) {
+    using PV = typename Vec4<PT>::type;
+    extern __shared__ float4 s_rows[]; // [waves per block][R][NN]
+    const PotParams p = resolve_theta<KIND>(pin);
+    const unsigned lane = threadIdx.x & 63u;
+    float4 *mine = s_rows + (size_t)(threadIdx.x >> 6) * R * NN;
+    const unsigned w0 = R * __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (w0 >= batch) return;
+    unsigned nn[R];
+    bool fast = w0 + R <= batch;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        nn[r] = n_neigh[(w0 + r < batch ? w0 + r : w0) + offset];
+        fast = fast && nn[r] != 0 && nn[r] <= 64 * kFChunk;
+    }
+    if (!fast) {
+#pragma unroll 1
+        for (unsigned r = 0; r < (unsigned)R && w0 + r < batch; ++r)
+            fused_row<KIND, false, true, PT>(w0 + r, lane, pos, N, NN, offset, box, n_neigh, nlist, head_list, rmaxsq, force,
+                                             nullptr, out_f64, p, check_count, positions_out, dest, counts_io);
+        return;
+    }
+    PV pi[R];
+    unsigned k[R][kFChunk];
+    PV q[R][kFChunk];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const unsigned *nl = nlist + head_list[w0 + r + offset];
+        pi[r] = pos[w0 + r + offset];
+#pragma unroll
+        for (int t = 0; t < kFChunk; ++t) {
+            const unsigned j = t * 64 + lane;
+            k[r][t] = nl[j < nn[r] ? j : nn[r] - 1];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int t = 0; t < kFChunk; ++t) q[r][t] = pos[k[r][t]];
+    unsigned Q[R];
+    // pass 1: pair vectors, keep / drop, compaction into LDS
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        Q[r] = 0;
+#pragma unroll
+        for (int t = 0; t < kFChunk; ++t) {
+            if ((unsigned)t * 64 >= nn[r]) break; // wave-uniform
+            const unsigned j = t * 64 + lane;
+            const PV pk = q[r][t];
+            PT dx, dy, dz;
+            const PT rsq = pair_vector<PT>(pk, pi[r], box, dx, dy, dz);
+            const bool keep = (j < nn[r]) && !(rsq > rmaxsq);
+            const unsigned long long m = __ballot(keep);
+            const unsigned qq = Q[r] + ballot_rank(m);
+            Q[r] += __popcll(m);
+            if (keep && qq < NN) mine[r * NN + qq] = make_float4((float)dx, (float)dy, (float)dz, (float)scalar_as_int(pk.w));
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // pass 2: evaluate the survivors slot by slot, store full-width lines (live slots, then the zero tail)
+    unsigned redo = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const unsigned w = w0 + r;
+        if (positions_out != nullptr && lane == 0)
+            positions_out[w] = make_float4((float)pi[r].x, (float)pi[r].y, (float)pi[r].z, (float)scalar_as_int(pi[r].w));
+        if (Q[r] > NN) { // overflow (an error upstream): the generic routine reproduces the slot wrap, tensor row included
+            redo |= 1u << r;
+            continue;
+        }
+        const unsigned filled = Q[r];
+        const unsigned prev = counts_io != nullptr ? counts_io[w] : NN;
+        const unsigned store_end = filled > prev ? filled : prev;
+        float4 *row = dest + (size_t)w * NN;
+        float fx = 0.f, fy = 0.f, fz = 0.f, en = 0.f;
+        unsigned npos = 0;
+        for (unsigned sl = lane; sl < store_end; sl += 64) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (sl < filled) {
+                v = mine[r * NN + sl];
+                float e, ax, ay, az;
+                pair_eval<KIND>(v.x, v.y, v.z, p, e, ax, ay, az);
+                fx += ax;
+                fy += ay;
+                fz += az;
+                en += e;
+                npos += v.x > 0.f ? 1u : 0u;
+            }
+            store_stream(&row[sl], v);
+        }
+        if (counts_io != nullptr && lane == 0) counts_io[w] = filled;
+        fx = group_sum<64>(fx);
+        fy = group_sum<64>(fy);
+        fz = group_sum<64>(fz);
+        en = group_sum<64>(en);
+        if (check_count != nullptr) npos = group_sum_u<64>(npos);
+        if (lane == 0) {
+            if (out_f64)
+                ((double4 *)force)[w] = make_double4(fx, fy, fz, en);
+            else
+                ((float4 *)force)[w] = make_float4(fx, fy, fz, en);
+            if (check_count != nullptr && npos > *(volatile unsigned *)check_count) atomicMax(check_count, npos);
+        }
+    }
+#pragma unroll 1
+    for (unsigned r = 0; r < (unsigned)R; ++r)
+        if ((redo >> r) & 1u)
+            fused_row<KIND, false, true, PT>(w0 + r, lane, pos, N, NN, offset, box, n_neigh, nlist, head_list, rmaxsq, force,
+                                             nullptr, out_f64, p, check_count, positions_out, dest, counts_io);
+}
+
 // The kernel strides over the row groups so that HTF_FUSED_GRID=<workgroups per CU> can launch it
 // persistently for A/B runs.  tools/store_probe.hip says a persistent grid helps a bare
 // load-chain + streaming-store kernel (65 -> 46 us); this kernel, whose rows differ in length
@@ -341,6 +467,20 @@ static int launch_fused(const void *pos, unsigned N, unsigned NN, unsigned offse
     hipLaunchKernelGGL((fused_forces_rows2_kernel<KIND, ST, RR, PT>), dim3(grid), dim3(wpb * 64), lds_pad, s, \
                        (const typename Vec4<PT>::type *)pos, N, NN, offset, batch, b, n_neigh, nlist, head_list,       \
                        (PT)(rc * rc), force, out_f64, p, check_count, positions_out, dest, counts_io)
+        static const char *lds_env = getenv("HTF_FUSED_LDS"); // A/B runs: 1 = survivors compacted through LDS
+        const bool use_lds = lds_env ? atoi(lds_env) != 0 : false;
+        if (use_lds && dest != nullptr && NN <= 128) {
+            const unsigned lrows = rows == 1 ? 1u : 2u;
+            const unsigned groups = (batch + lrows - 1) / lrows;
+            const size_t lds = (size_t)4 * lrows * NN * sizeof(float4);
+#define HTF_LDS_LAUNCH(RR)                                                                                             \
+    hipLaunchKernelGGL((fused_forces_lds_kernel<KIND, RR, PT>), dim3((groups + 3) / 4), dim3(256), lds, s,            \
+                       (const typename Vec4<PT>::type *)pos, N, NN, offset, batch, b, n_neigh, nlist, head_list,       \
+                       (PT)(rc * rc), force, out_f64, p, check_count, positions_out, dest, counts_io)
+            if (lrows == 1) { HTF_LDS_LAUNCH(1); } else { HTF_LDS_LAUNCH(2); }
+#undef HTF_LDS_LAUNCH
+            return check_launch("fused_forces_lds_kernel");
+        }
         if (rows == 2 || rows == 4) {
             if (rows == 2) {
                 if (dest != nullptr) { HTF_ROWS_LAUNCH(true, 2); } else { HTF_ROWS_LAUNCH(false, 2); }

@@ -1,0 +1,170 @@
+// Forward ghost-POSITION halo over RCCL, from the C side: per step, each rank sends the
+// positions of its particles within r_ghost of a slab face to that face's neighbor and receives its ghosts'
+// new positions --
+//
+//     ncclGroupStart; ncclSend(left); ncclSend(right); ncclRecv(right); ncclRecv(left); ncclGroupEnd
+//
+// on a dedicated halo stream, ordered against the force kernels with two events: the exchange starts after
+// everything already queued on the caller's stream (the integrator has written the positions), and the
+// caller's stream waits for it only when htf_halo_exchange_end is called -- so htf_compute_forces_rows can
+// evaluate the rows that have no ghost neighbor in between.  This is what HOOMD-blue's Communicator does for the
+// reference under MPI (ghost update each step; the plugin reads ghosts through pos[N .. N + n_ghost),
+// TensorflowCompute.cc:143-148); outside HOOMD, hoomd_tf_amd/domain.py drives it.
+//
+// librccl is bound at run time (dlopen, the copy torch has already loaded when there is one): a build box
+// without a GPU, and a single-GPU run, never need it.
+#include <dlfcn.h>
+
+#include <new>
+
+#include "htf_common.h"
+
+namespace htf {
+
+typedef struct ncclComm *ncclComm_t;
+struct NcclUniqueId { char internal[128]; };
+enum { kNcclSuccess = 0, kNcclChar = 0 };
+
+struct Rccl {
+    int (*GetUniqueId)(NcclUniqueId *) = nullptr;
+    int (*CommInitRank)(ncclComm_t *, int, NcclUniqueId, int) = nullptr;
+    int (*CommDestroy)(ncclComm_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    bool ok = false;
+    Rccl() {
+        void *h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD); // torch's copy, if torch is in the process
+        if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return;
+        GetUniqueId = (decltype(GetUniqueId))dlsym(h, "ncclGetUniqueId");
+        CommInitRank = (decltype(CommInitRank))dlsym(h, "ncclCommInitRank");
+        CommDestroy = (decltype(CommDestroy))dlsym(h, "ncclCommDestroy");
+        GroupStart = (decltype(GroupStart))dlsym(h, "ncclGroupStart");
+        GroupEnd = (decltype(GroupEnd))dlsym(h, "ncclGroupEnd");
+        Send = (decltype(Send))dlsym(h, "ncclSend");
+        Recv = (decltype(Recv))dlsym(h, "ncclRecv");
+        GetErrorString = (decltype(GetErrorString))dlsym(h, "ncclGetErrorString");
+        ok = GetUniqueId && CommInitRank && CommDestroy && GroupStart && GroupEnd && Send && Recv && GetErrorString;
+    }
+};
+
+static Rccl &rccl() {
+    static Rccl r;
+    return r;
+}
+
+#define HTF_CHECK_NCCL(expr)                                                                                           \
+    do {                                                                                                               \
+        int _r = (expr);                                                                                               \
+        if (_r != kNcclSuccess) {                                                                                      \
+            htf::set_error("%s failed: %s", #expr, htf::rccl().GetErrorString(_r));                                   \
+            return HTF_ERR_DEVICE;                                                                                     \
+        }                                                                                                              \
+    } while (0)
+
+} // namespace htf
+
+struct htf_halo {
+    htf::ncclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+    hipStream_t stream = nullptr;
+    hipEvent_t ready = nullptr, done = nullptr; // positions ready on the caller's stream; exchange done on the halo stream
+    bool pending = false;
+};
+
+extern "C" int htf_halo_available(void) { return htf::rccl().ok ? 1 : 0; }
+
+extern "C" int htf_halo_unique_id(void *id128) {
+    using namespace htf;
+    HTF_REQUIRE(id128, "htf_halo_unique_id: null pointer");
+    HTF_REQUIRE(rccl().ok, "htf_halo_unique_id: librccl could not be loaded");
+    NcclUniqueId id;
+    HTF_CHECK_NCCL(rccl().GetUniqueId(&id));
+    std::memcpy(id128, id.internal, sizeof id.internal);
+    return HTF_OK;
+}
+
+extern "C" int htf_halo_create(const void *id128, int rank, int world, htf_halo **out) {
+    using namespace htf;
+    HTF_REQUIRE(id128 && out, "htf_halo_create: null pointer");
+    HTF_REQUIRE(world >= 1 && rank >= 0 && rank < world, "htf_halo_create: rank %d outside [0, %d)", rank, world);
+    HTF_REQUIRE(rccl().ok, "htf_halo_create: librccl could not be loaded");
+    htf_halo *h = new (std::nothrow) htf_halo();
+    if (!h) {
+        set_error("htf_halo_create: out of host memory");
+        return HTF_ERR_NOMEM;
+    }
+    h->rank = rank;
+    h->world = world;
+    NcclUniqueId id;
+    std::memcpy(id.internal, id128, sizeof id.internal);
+    int rc = rccl().CommInitRank(&h->comm, world, id, rank);
+    if (rc != kNcclSuccess) {
+        set_error("ncclCommInitRank failed: %s", rccl().GetErrorString(rc));
+        delete h;
+        return HTF_ERR_DEVICE;
+    }
+    hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ready, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->done, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        set_error("htf_halo_create: stream / event creation failed: %s", hipGetErrorString(e));
+        htf_halo_destroy(h);
+        return HTF_ERR_DEVICE;
+    }
+    *out = h;
+    return HTF_OK;
+}
+
+extern "C" void htf_halo_destroy(htf_halo *h) {
+    if (!h) return;
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->comm) (void)htf::rccl().CommDestroy(h->comm);
+    if (h->ready) (void)hipEventDestroy(h->ready);
+    if (h->done) (void)hipEventDestroy(h->done);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+extern "C" int htf_halo_exchange_begin(htf_halo *h, void *d_pos, int dtype, int left, int right, unsigned send_left_first,
+                                       unsigned send_left_count, unsigned send_right_first, unsigned send_right_count,
+                                       unsigned recv_left_first, unsigned recv_left_count, unsigned recv_right_first,
+                                       unsigned recv_right_count, htf_stream stream) {
+    using namespace htf;
+    HTF_REQUIRE(h && d_pos, "htf_halo_exchange_begin: null pointer");
+    HTF_REQUIRE(dtype == HTF_F32 || dtype == HTF_F64, "htf_halo_exchange_begin: bad dtype %d", dtype);
+    HTF_REQUIRE(left >= 0 && left < h->world && right >= 0 && right < h->world, "htf_halo_exchange_begin: neighbor ranks %d, %d outside [0, %d)", left, right, h->world);
+    HTF_REQUIRE(!h->pending, "htf_halo_exchange_begin: the previous exchange has not been ended");
+    const size_t s4 = dtype == HTF_F64 ? 32 : 16; // bytes of a Scalar4
+    char *p = (char *)d_pos;
+    // the positions must be final on the caller's stream before the halo stream reads them
+    HTF_CHECK_HIP(hipEventRecord(h->ready, (hipStream_t)stream));
+    HTF_CHECK_HIP(hipStreamWaitEvent(h->stream, h->ready, 0));
+    // Every rank posts [send L>, send R>] and [recv L> (from the right neighbor), recv R> (from the left one)]:
+    // with two ranks both neighbors are the same peer and the pairs still match in order of issue.
+    HTF_CHECK_NCCL(rccl().GroupStart());
+    int rc = kNcclSuccess;
+    if (send_left_count) rc = rccl().Send(p + (size_t)send_left_first * s4, (size_t)send_left_count * s4, kNcclChar, left, h->comm, h->stream);
+    if (rc == kNcclSuccess && send_right_count) rc = rccl().Send(p + (size_t)send_right_first * s4, (size_t)send_right_count * s4, kNcclChar, right, h->comm, h->stream);
+    if (rc == kNcclSuccess && recv_right_count) rc = rccl().Recv(p + (size_t)recv_right_first * s4, (size_t)recv_right_count * s4, kNcclChar, right, h->comm, h->stream);
+    if (rc == kNcclSuccess && recv_left_count) rc = rccl().Recv(p + (size_t)recv_left_first * s4, (size_t)recv_left_count * s4, kNcclChar, left, h->comm, h->stream);
+    const int rc_end = rccl().GroupEnd();
+    HTF_CHECK_NCCL(rc);
+    HTF_CHECK_NCCL(rc_end);
+    HTF_CHECK_HIP(hipEventRecord(h->done, h->stream));
+    h->pending = true;
+    return HTF_OK;
+}
+
+extern "C" int htf_halo_exchange_end(htf_halo *h, htf_stream stream) {
+    using namespace htf;
+    HTF_REQUIRE(h, "htf_halo_exchange_end: null pointer");
+    if (!h->pending) return HTF_OK;
+    HTF_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, h->done, 0));
+    h->pending = false;
+    return HTF_OK;
+}

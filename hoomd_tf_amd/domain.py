@@ -55,9 +55,59 @@ class _StagedHalo:
             dev.copy_(host)
 
 
+class _NativeHalo:
+    """The per-step halo through libhtf_amd.so's own RCCL communicator (csrc/halo.hip): one grouped
+    ncclSend x2 / ncclRecv x2 on a dedicated stream, two events, no Python objects per message."""
+
+    def __init__(self, rank, world, group):
+        import ctypes as C
+        from ._lib import lib, check
+        self._C, self._lib, self._check = C, lib, check
+        ident = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            buf = (C.c_char * 128)()
+            check(lib.htf_halo_unique_id(buf))
+            ident = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+        if dist.get_backend(group) == "nccl":  # the id travels through whatever channel the job has
+            dev = ident.cuda()
+            dist.broadcast(dev, src=0, group=group)
+            ident = dev.cpu()
+        else:
+            dist.broadcast(ident, src=0, group=group)
+        self._h = C.c_void_p()
+        raw = (C.c_char * 128).from_buffer_copy(bytes(ident.numpy().tobytes()))
+        check(lib.htf_halo_create(raw, int(rank), int(world), C.byref(self._h)))
+
+    def begin(self, pos, left, right, send_left, send_right, recv_left, recv_right):
+        from . import ops
+        s = self._C.c_void_p(torch.cuda.current_stream(pos.device).cuda_stream)
+        self._check(self._lib.htf_halo_exchange_begin(
+            self._h, pos.data_ptr(), ops._dt(pos), int(left), int(right), send_left[0], send_left[1] - send_left[0],
+            send_right[0], send_right[1] - send_right[0], recv_left[0], recv_left[1] - recv_left[0],
+            recv_right[0], recv_right[1] - recv_right[0], s))
+
+    def wait(self):
+        # (called from exchange_end on whatever stream is current then)
+        s = self._C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        self._check(self._lib.htf_halo_exchange_end(self._h, s))
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h and self._lib is not None:
+            self._lib.htf_halo_destroy(h)
+            self._h = None
+
+
 class SlabDomain:
-    def __init__(self, system, rank, world, r_ghost, fractions=None, group=None):
+    def __init__(self, system, rank, world, r_ghost, fractions=None, group=None, transport="auto"):
+        """``transport``: "torch" = torch.distributed grouped P2P (RCCL underneath on the GPU box, gloo in the CPU
+        tests); "native" = libhtf_amd.so's own RCCL communicator and halo stream; "auto" = native when the job
+        runs on the nccl backend, the library could load librccl, and the first exchange reproduces what the
+        torch transport delivers (checked once, at the first rebuild), else torch."""
         self.sys = system
+        self.transport_request = transport
+        self.transport = "torch"
+        self._native = None
         self.rank, self.world = int(rank), int(world)
         self.r_ghost = float(r_ghost)
         self.group = group
@@ -207,6 +257,11 @@ class SlabDomain:
         to_right = s.pos[self.send_right[0]:self.send_right[1]]
         from_left = s.pos[N:N + self.n_from_left]                 # R> of my left neighbor
         from_right = s.pos[N + self.n_from_left:N + s.n_ghost]    # L> of my right neighbor
+        if self._native is not None:
+            self._native.begin(s.pos, self.left, self.right, self.send_left, self.send_right,
+                               (N, N + self.n_from_left), (N + self.n_from_left, N + s.n_ghost))
+            self._works = [self._native]
+            return
         self._works = self._post(to_left, to_right, from_right, from_left)
 
     def exchange_end(self):

@@ -397,6 +397,32 @@ HTF_API void *htf_get_positions_buffer(htf_ctx *ctx);
 HTF_API void *htf_get_virial_buffer(htf_ctx *ctx);
 HTF_API unsigned htf_get_batch_capacity(htf_ctx *ctx);
 
+/* ------------------------------------------------------------------------- *
+ * Ghost-position halo over RCCL (particle-domain decomposition).
+ * Under HOOMD-blue the Communicator refreshes ghost positions every step and the plugin just reads them
+ * (TensorflowCompute.cc:143-148); these entry points are that exchange for callers without HOOMD's
+ * Communicator: one grouped ncclSend x2 / ncclRecv x2 per step on a halo stream of its own.
+ * ------------------------------------------------------------------------- */
+typedef struct htf_halo htf_halo;
+#define HTF_HALO_ID_BYTES 128 /* sizeof(ncclUniqueId) */
+
+HTF_API int htf_halo_available(void);          /* 1 when librccl could be loaded */
+/* rank 0 obtains the id and ships its 128 bytes to every rank out of band (MPI_Bcast, torch.distributed ...) */
+HTF_API int htf_halo_unique_id(void *id128);
+/* collective over the `world` ranks: ncclCommInitRank on the calling thread's current device */
+HTF_API int htf_halo_create(const void *id128, int rank, int world, htf_halo **out);
+HTF_API void htf_halo_destroy(htf_halo *halo);
+/* Send pos[send_left_first, +send_left_count) to rank `left` and pos[send_right_first, +count) to rank `right`;
+ * receive the right neighbor's left-going message into pos[recv_right_first, +count) and the left neighbor's
+ * right-going one into pos[recv_left_first, +count) (element = Scalar4 of `dtype`).  Starts after everything
+ * already queued on `stream`; returns at once.  htf_halo_exchange_end makes `stream` wait for the arrival. */
+HTF_API int htf_halo_exchange_begin(htf_halo *halo, void *d_pos, int dtype, int left, int right,
+                            unsigned send_left_first, unsigned send_left_count,
+                            unsigned send_right_first, unsigned send_right_count,
+                            unsigned recv_left_first, unsigned recv_left_count,
+                            unsigned recv_right_first, unsigned recv_right_count, htf_stream stream);
+HTF_API int htf_halo_exchange_end(htf_halo *halo, htf_stream stream);
+
 /* Profiler scopes (reference: HOOMD Profiler push/pop "TensorflowCompute::reshapeNeighbors"
  * and "TensorflowCompute::Force Update", TensorflowCompute.cc:164-168,196-206).  When
  * enabled, htf_compute_forces brackets the pair-vector build and the evaluator with

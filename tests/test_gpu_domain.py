@@ -26,7 +26,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, per_slab=6):
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
@@ -38,7 +38,9 @@ def _worker(rank, world, port, q):
 
         dev = torch.device("cuda:0")
         rcut, rbuf, NN = 2.5, 0.4, 80
-        cells = (6 * world, 6, 6)  # slabs of 6 fcc cells (10 sigma >= 2 r_ghost) side by side
+        # slabs of 6 fcc cells (10 sigma >= 2 r_ghost) side by side; per_slab = 2: slabs 3.36 wide, r_ghost 2.9 --
+        # thinner than 2 r_ghost, every particle a ghost somewhere (the 131072-particle box over 8 ranks)
+        cells = (per_slab * world, 6, 6)
         a = (4.0 / 0.8442) ** (1.0 / 3.0)
         base = np.array([[0, 0, 0], [.5, .5, 0], [.5, 0, .5], [0, .5, .5]])
         grid = np.stack(np.meshgrid(*[np.arange(c) for c in cells], indexing="ij"), -1).reshape(-1, 3)
@@ -77,6 +79,7 @@ def _worker(rank, world, port, q):
                 nve.step()
         torch.cuda.synchronize()
         assert nl.n_builds >= 2 and overlapped >= 20, (nl.n_builds, overlapped)
+        assert (nl.domain.n_interior == 0) == (per_slab == 2)
         # gather the configuration by particle id
         N = sysm.N
         my_ids = sysm.types_numpy()
@@ -201,12 +204,144 @@ def test_training_under_slabs_matches_single_domain(htf, cuda):
     assert abs(out[2][3] - out[1][3]) < 2e-3 * abs(out[1][3])
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_slabs_on_one_gpu(htf, cuda, world):
+@pytest.mark.parametrize("world,per_slab", [(2, 6), (3, 6), (5, 2)])
+def test_slabs_on_one_gpu(htf, cuda, world, per_slab):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, per_slab)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in results:
+        assert msg == "ok", "rank %d failed:\n%s" % (rank, msg)
+
+
+@pytest.mark.parametrize("args", [["--gpus", "2"], ["--gpus", "3"], ["--gpus", "2", "--scaling", "weak"]])
+def test_bench_starts_its_own_ranks(htf, cuda, args):
+    """`python bench.py --gpus N` with no launcher around it (how the driver calls it): the parent starts the N rank
+    processes itself and relays ONE JSON line.  Rehearsed here with the ranks sharing the one GPU (gloo)."""
+    import json
+    import subprocess
+    env = dict(os.environ, HTF_BENCH_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args + ["--cells", "12", "--steps", "10", "--warmup", "3", "--equil", "40",
+                                                                                  "--no-cpu-baseline", "--no-fused", "--windows", "1"],
+                       capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    n = int(args[1])
+    weak = "weak" in args
+    assert d["n_gpus"] == n and d["scaling"] == ("weak" if weak else "strong")
+    assert d["config"]["global_particles"] == 4 * 12 ** 3 * (n if weak else 1)
+    assert d["value"] > 0 and abs(d["value"] * d["config"]["global_particles"] - d["particle_steps_per_s"]) < 1e-6 * d["particle_steps_per_s"]
+    assert -7.0 < d["energy_per_particle"] < -4.0 and 0.5 < d["kT_final"] < 1.5   # still the same liquid
+    assert d["config"]["halo"]["ghosts_rank0"] > 0
+
+
+def _self_exchange():
+    """Body of test_native_halo_single_rank_self_exchange (run in a child process: a transport that hung would
+    otherwise take the whole test session with it)."""
+    import ctypes as C
+    sys.path.insert(0, ROOT)
+    import hoomd_tf_amd  # noqa: F401
+    from hoomd_tf_amd._lib import lib, check
+    cuda = torch.device("cuda:0")
+    if not lib.htf_halo_available():
+        print("SKIP librccl not loadable")
+        return
+    ident = (C.c_char * 128)()
+    check(lib.htf_halo_unique_id(ident))
+    h = C.c_void_p()
+    check(lib.htf_halo_create(ident, 0, 1, C.byref(h)))
+    for tdt, code in ((torch.float32, 0), (torch.float64, 1)):
+        N, nl_, nr_ = 1000, 37, 53
+        pos = torch.zeros((N + nl_ + nr_, 4), dtype=tdt, device=cuda)
+        pos[:N] = torch.arange(N * 4, dtype=tdt, device=cuda).reshape(N, 4)
+        send_left, send_right = (N - nl_ - nr_, N - nr_), (N - nr_, N)
+        # ghosts: [from left (= my right-going message) | from right (= my left-going message)]
+        recv_left, recv_right = (N, N + nr_), (N + nr_, N + nr_ + nl_)
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for rep in range(3):   # more than once: pending flag, event reuse
+            pos[N:] = -1.0
+            check(lib.htf_halo_exchange_begin(h, pos.data_ptr(), code, 0, 0, send_left[0], nl_, send_right[0], nr_,
+                                              recv_left[0], nr_, recv_right[0], nl_, stream))
+            try:  # a second begin before the end is refused
+                check(lib.htf_halo_exchange_begin(h, pos.data_ptr(), code, 0, 0, 0, 1, 0, 1, N, 1, N + 1, 1, stream))
+                raise AssertionError("second begin accepted")
+            except ValueError:
+                pass
+            check(lib.htf_halo_exchange_end(h, stream))
+            torch.cuda.synchronize()
+            assert torch.equal(pos[recv_right[0]:recv_right[1]], pos[send_left[0]:send_left[1]])
+            assert torch.equal(pos[recv_left[0]:recv_left[1]], pos[send_right[0]:send_right[1]])
+    lib.htf_halo_destroy(h)
+    print("SELF-EXCHANGE OK")
+
+
+def test_native_halo_single_rank_self_exchange(htf, cuda):
+    """csrc/halo.hip on the real GPU with the one rank a 1-GPU box offers: communicator bring-up from a unique
+    id, the grouped ncclSend x2 / ncclRecv x2 (to and from itself: both neighbors of a lone slab are the slab),
+    the halo stream and its two events.  The slab's left-going message must land in the 'from right' ghosts and
+    the right-going one in the 'from left' ghosts, as with real neighbors."""
+    import subprocess
+    code = "import sys; sys.path.insert(0, %r); import test_gpu_domain as t; t._self_exchange()" % os.path.join(ROOT, "tests")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240, cwd=ROOT)
+    if "SKIP" in r.stdout:
+        pytest.skip(r.stdout.strip())
+    assert r.returncode == 0 and "SELF-EXCHANGE OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+def _rccl_worker(rank, world, port, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        sys.path.insert(0, ROOT)
+        torch.cuda.set_device(rank)
+        dev = torch.device("cuda", rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        from hoomd_tf_amd import standin
+        from hoomd_tf_amd.domain import SlabDomain
+        pos, L, a = standin.fcc_positions(12, 0.8442)
+        rng = np.random.default_rng(3)
+        pos = pos + 0.05 * a * rng.standard_normal(pos.shape)
+        pos -= np.round(pos / L) * L
+        bounds = -L[0] / 2 + np.linspace(0, 1, world + 1) * L[0]
+        mine = (pos[:, 0] >= bounds[rank]) & (pos[:, 0] < bounds[rank + 1])
+        out = {}
+        for transport in ("torch", "native"):
+            sysm = standin.System(pos[mine], L, types=np.arange(len(pos))[mine], dtype=torch.float32, device=dev)
+            dom = SlabDomain(sysm, rank, world, r_ghost=3.4, transport=transport)
+            dom.rebuild()
+            assert dom.transport == transport
+            sysm.pos[:sysm.N, :3] += 0.01   # move, then the per-step halo
+            dom.exchange_begin()
+            dom.exchange_end()
+            torch.cuda.synchronize()
+            out[transport] = sysm.pos.clone()
+        assert torch.equal(out["torch"], out["native"])
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+def test_rccl_halo_two_gpus(htf, cuda):
+    """The RCCL transports themselves (torch.distributed's and the native one) between two real devices:
+    both must deliver the same ghosts.  Needs a multi-GPU node; skipped on the 1-GPU test box."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL wants one device per rank)")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rccl_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
     results = [q.get(timeout=600) for _ in procs]
