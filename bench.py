@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--workload", default="lj", choices=["lj", "wca", "mlp", "mlp-split", "mlp-bf16", "mlp-train", "eds"])
     ap.add_argument("--train-period", type=int, default=100, help="mlp-train (C5b): force-matching step every this many MD steps")
     ap.add_argument("--cells", type=int, default=32, help="fcc cells per side (N = 4 cells^3 per rank)")
+    ap.add_argument("--lattice", default="fcc", choices=["fcc", "sc"], help="fcc: N = 4 cells^3 (C3, C5); sc: N = cells^3 (C2 = sc 32^3 = 32768)")
     ap.add_argument("--nn", type=int, default=128)
     ap.add_argument("--rcut", type=float, default=3.0)
     ap.add_argument("--rbuff", type=float, default=0.4)
@@ -459,7 +460,7 @@ def run_md(args, E, workload, variants=True, cpu=True):
     # and keeps the particles of its slab.  weak: each rank owns one such block; the global periodic box
     # is `world` blocks side by side along x (config 5 at 8 ranks: 1.05 M particles, 8 x 1 x 1 slabs).
     strong = world > 1 and args.scaling == "strong"
-    pos, L, a = standin.fcc_positions(args.cells, 0.8442)
+    pos, L, a = (standin.sc_positions if args.lattice == "sc" else standin.fcc_positions)(args.cells, 0.8442)
     rng = np.random.default_rng(3 + (0 if strong else rank))
     pos = pos + 0.05 * a * rng.standard_normal(pos.shape)
     pos -= np.round(pos / L) * L
@@ -711,7 +712,9 @@ def run_md(args, E, workload, variants=True, cpu=True):
         try:
             if args.cells != 32 or args.workload != "lj":
                 raise KeyError("PMC passes were collected for the default workload at the default size")
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_lj_pmc_hbm.json")))
+            pmc_file = next(f for f in ("r02_bench_lj_pmc_hbm.json", "r01_bench_lj_pmc_hbm.json")
+                            if os.path.exists(os.path.join(ROOT, "profiles", f)))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
             key = {"build_pair_vectors": "void htf::build_pair_vectors_kernel<float, float>",
                    "eval_forces": "void htf::eval_pair_kernel<1, 16, false, float>",
                    "build_eval_forces": "void htf::fused_forces_rows2_kernel<1, true, 2, float>"}[dom]
@@ -720,12 +723,13 @@ def run_md(args, E, workload, variants=True, cpu=True):
             # kernel's reads are 4-B index loads + 16-B gathers, for which the counter is uncalibrated
             corr = 2.0 if dom == "eval_forces" else 1.0
             roof["traffic"] = (rd * corr + wr) * 1024.0
-            roof["traffic_source"] = "profiles/r01_bench_lj_pmc_hbm.json (FETCH_SIZE x%g + WRITE_SIZE)" % corr
+            roof["traffic_source"] = "profiles/%s (FETCH_SIZE x%g + WRITE_SIZE)" % (pmc_file, corr)
             # the rate the memory system actually ran at: below `achieved` because the zero tail of a row is
             # only rewritten where the row shrank since the last step (htf_context keeps per-row counts), so
             # fewer bytes move than the [N, NN, 4] contract counts
             roof["traffic_GBps"] = roof["traffic"] / (kern[dom]["avg_us"] * 1e-6) / 1e9
-        except (OSError, KeyError, ValueError):
+            roof["traffic_frac"] = roof["traffic_GBps"] / HBM_PEAK_GBS  # what the memory system itself ran at
+        except (OSError, KeyError, ValueError, StopIteration):
             pass
 
     ms_per_step = elapsed / args.steps * 1e3
@@ -749,9 +753,10 @@ def run_md(args, E, workload, variants=True, cpu=True):
                   "mlp-split": "f32 (each operand split exactly into 3 bf16 parts, 6 partial products, f32 accumulation)"
                   }.get(args.workload, "f32" if not args.f64 else "f32 arithmetic on an f64 wire (HOOMD in double precision)"),
         "data": "synthetic",
-        "config": {"workload": "%s: fcc %d^3x4 = %d particles %s, rho 0.8442, r_cut %.1f, r_buff %.1f, NN %d, dt %g"
+        "config": {"workload": ("%s: " + ("sc %d^3" if args.lattice == "sc" else "fcc %d^3x4")
+                                + " = %d particles %s, rho 0.8442, r_cut %.1f, r_buff %.1f, NN %d, dt %g")
                                % ("C5b (pair-MLP MD + force-matching step every %d steps vs LJ labels)" % args.train_period
-                                  if args.workload == "mlp-train" else ("C2-WCA" if args.workload == "wca" and args.cells == 20 else "C3-" + args.workload.upper()),
+                                  if args.workload == "mlp-train" else ("C2-WCA" if args.workload == "wca" and n_block == 32768 else "C3-" + args.workload.upper()),
                                   args.cells, n_block, "in all, cut into %d slabs" % world if strong else ("per GPU" if world > 1 else "on one GPU"),
                                   args.rcut, args.rbuff, NN, args.dt),
                    "global_particles": n_global, "particles_rank0": N, "parallelism": "dd%dx1x1" % world,

@@ -113,6 +113,7 @@ PROTOTYPES = {
     "htf_compute_forces": (_i, [_vp, _u, C.POINTER(HoomdArrays), _vp]),
     "htf_compute_forces_rows": (_i, [_vp, _u, C.POINTER(HoomdArrays), _u, _u, _vp]),
     "htf_get_nlist_buffer": (_vp, [_vp]),
+    "htf_reset_nlist_buffer": (_i, [_vp, _vp]),
     "htf_get_positions_buffer": (_vp, [_vp]),
     "htf_get_virial_buffer": (_vp, [_vp]),
     "htf_get_batch_capacity": (_u, [_vp]),

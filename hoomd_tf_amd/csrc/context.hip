@@ -84,6 +84,7 @@ struct htf_ctx {
     unsigned prof_tick = 0;
     std::vector<hipEvent_t> ev_pool;
     std::vector<char> ev_one_scope; // per triple: the one-kernel step records no middle event
+    std::vector<char> ev_complete;  // per triple: the closing event was recorded (an error return in between leaves it 0)
     size_t ev_used = 0;
 };
 
@@ -390,6 +391,15 @@ extern "C" int htf_resize(htf_ctx *ctx, unsigned max_n) {
 }
 
 extern "C" void *htf_get_nlist_buffer(htf_ctx *ctx) { return ctx ? ctx->nlist : nullptr; }
+
+extern "C" int htf_reset_nlist_buffer(htf_ctx *ctx, htf_stream stream) {
+    using namespace htf;
+    HTF_REQUIRE(ctx, "htf_reset_nlist_buffer: null context");
+    if (!ctx->counts || ctx->capacity == 0) return HTF_OK;
+    // every row is declared fully live: the next build rewrites the whole zero tail of every row
+    HTF_CHECK_HIP(hipMemsetD32Async((hipDeviceptr_t)ctx->counts, (int)ctx->cfg.nneighs, ctx->capacity, (hipStream_t)stream));
+    return HTF_OK;
+}
 extern "C" void *htf_get_positions_buffer(htf_ctx *ctx) { return ctx ? ctx->positions : nullptr; }
 extern "C" void *htf_get_virial_buffer(htf_ctx *ctx) { return ctx ? ctx->virial : nullptr; }
 extern "C" unsigned htf_get_batch_capacity(htf_ctx *ctx) { return ctx ? ctx->capacity : 0; }
@@ -443,6 +453,7 @@ static int compute_rows(htf_ctx *ctx, unsigned timestep, const htf_hoomd_arrays 
             e2 = next_event(ctx);
             HTF_REQUIRE(e0 && e1 && e2, "htf_compute_forces: hipEventCreate failed");
             ctx->ev_one_scope.push_back(0);
+            ctx->ev_complete.push_back(0);
             HTF_CHECK_HIP(hipEventRecord(e0, s));
         }
         const bool fused = to_hoomd && cfg.fused && cfg.nneighs > 0 && ctx->pot != nullptr && !own_evaluator(ctx->pot);
@@ -456,7 +467,10 @@ static int compute_rows(htf_ctx *ctx, unsigned timestep, const htf_hoomd_arrays 
                                    cfg.virial ? c_virial : nullptr, cfg.check_nlist ? ctx->flag : nullptr,
                                    c_positions, cfg.fused == 2 ? c_nlist : nullptr, cfg.fused == 2 ? c_counts : nullptr, s);
             if (rc != HTF_OK) return rc;
-            if (prof) HTF_CHECK_HIP(hipEventRecord(e2, s));
+            if (prof) {
+                HTF_CHECK_HIP(hipEventRecord(e2, s));
+                ctx->ev_complete.back() = 1;
+            }
             if (cfg.check_nlist) {
                 unsigned h = 0;
                 HTF_CHECK_HIP(hipMemcpyAsync(&h, ctx->flag, sizeof(unsigned), hipMemcpyDeviceToHost, s));
@@ -510,7 +524,10 @@ static int compute_rows(htf_ctx *ctx, unsigned timestep, const htf_hoomd_arrays 
             rc = eval_pair_dispatch(ctx->pot->pp, c_nlist, HTF_F32, n, cfg.nneighs, force_out, cfg.scalar_dtype,
                                     cfg.virial ? c_virial : nullptr, c_counts, s);
         if (rc != HTF_OK) return rc;
-        if (prof) HTF_CHECK_HIP(hipEventRecord(e2, s));
+        if (prof) {
+            HTF_CHECK_HIP(hipEventRecord(e2, s));
+            ctx->ev_complete.back() = 1;
+        }
         if (cfg.virial && a->virial) { // receiveVirial(offset, N) .cc:200-204
             rc = htf_add_virial((char *)a->virial + (size_t)offset * ssz, c_virial, cfg.scalar_dtype, n,
                                 a->virial_pitch, stream);
@@ -536,6 +553,7 @@ extern "C" int htf_profile_enable(htf_ctx *ctx, int on) {
     ctx->prof_tick = 0;
     ctx->ev_used = 0;
     ctx->ev_one_scope.clear();
+    ctx->ev_complete.clear();
     return HTF_OK;
 }
 
@@ -544,23 +562,35 @@ extern "C" int htf_profile_read(htf_ctx *ctx, double *build_ms, double *eval_ms,
     HTF_REQUIRE(ctx, "htf_profile_read: null context");
     double b = 0, e = 0;
     const size_t triples = ctx->ev_used / 3;
-    for (size_t t = 0; t < triples; ++t) {
+    unsigned counted = 0;
+    int rc = HTF_OK;
+    // a batch that returned early (nlist overflow, launch error) left its closing event unrecorded: skipped.
+    // Whatever happens below, the accumulators are reset, so that one bad read cannot poison the next.
+    for (size_t t = 0; t < triples && rc == HTF_OK; ++t) {
+        if (t >= ctx->ev_complete.size() || !ctx->ev_complete[t]) continue;
         float ms = 0;
-        HTF_CHECK_HIP(hipEventSynchronize(ctx->ev_pool[3 * t + 2]));
-        if (t < ctx->ev_one_scope.size() && ctx->ev_one_scope[t]) {
-            HTF_CHECK_HIP(hipEventElapsedTime(&ms, ctx->ev_pool[3 * t], ctx->ev_pool[3 * t + 2]));
+        hipError_t he = hipEventSynchronize(ctx->ev_pool[3 * t + 2]);
+        if (he == hipSuccess && ctx->ev_one_scope[t]) {
+            he = hipEventElapsedTime(&ms, ctx->ev_pool[3 * t], ctx->ev_pool[3 * t + 2]);
             e += ms;
-            continue;
+        } else if (he == hipSuccess) {
+            he = hipEventElapsedTime(&ms, ctx->ev_pool[3 * t], ctx->ev_pool[3 * t + 1]);
+            b += ms;
+            if (he == hipSuccess) he = hipEventElapsedTime(&ms, ctx->ev_pool[3 * t + 1], ctx->ev_pool[3 * t + 2]);
+            e += ms;
         }
-        HTF_CHECK_HIP(hipEventElapsedTime(&ms, ctx->ev_pool[3 * t], ctx->ev_pool[3 * t + 1]));
-        b += ms;
-        HTF_CHECK_HIP(hipEventElapsedTime(&ms, ctx->ev_pool[3 * t + 1], ctx->ev_pool[3 * t + 2]));
-        e += ms;
+        if (he != hipSuccess) {
+            set_error("htf_profile_read: %s", hipGetErrorString(he));
+            rc = HTF_ERR_DEVICE;
+        } else {
+            ++counted;
+        }
     }
     if (build_ms) *build_ms = b;
     if (eval_ms) *eval_ms = e;
-    if (n_calls) *n_calls = (unsigned)triples;
+    if (n_calls) *n_calls = counted;
     ctx->ev_used = 0;
     ctx->ev_one_scope.clear();
-    return HTF_OK;
+    ctx->ev_complete.clear();
+    return rc;
 }

@@ -24,12 +24,6 @@
 
 namespace htf {
 
-#ifndef HTF_ROWS2_THREADS
-#define HTF_ROWS2_THREADS 256
-#endif
-#ifndef HTF_ROWS2_WAVES
-#define HTF_ROWS2_WAVES 1
-#endif
 constexpr int kFChunk = 3; // index loads hoisted per lane per trip (as pair_vectors.hip: n_neigh <= 192 in one trip)
 
 struct FusedAcc {
@@ -188,6 +182,17 @@ __global__ __launch_bounds__(256) void fused_forces_kernel(const typename Vec4<P
 // during the current row's evaluation -- what took the C4 sweep below from 241 to 217 us) 67-77 /
 // 63-70 us with 8192-2048 workgroups: here the hardware's own wave turnover does better.
 // Workgroups of one or two waves instead of four: 64.5-66 / 65 us against 62.4.
+// Round 2 (profiles/r02_fused_kernel_ab.txt, r02_fused_kernel_pmc.txt, r02_gather_probe.txt; written variant,
+// 60.6-64.8 us by box): PMC has the CU's texture-address path busy ~85 % of the kernel (TA_BUSY_avr), the VALU ~50 %,
+// L1 hit rate of the gathers 92 %: the kernel is bound by how fast a CU retires 16-B gather instructions -- ~53 clk
+// each here, against a floor of 45-55 clk for ANY index pattern once the table is L1-resident (gather_probe2) --
+// not by HBM (4.3 TB/s moved) and not by occupancy.  Tried against that and NOT faster: 8 waves/SIMD by capping
+// SGPRs at 80 (+3 %: 62.5); occupancy capped at 6 / 5 / 4 / 3 waves per SIMD through an LDS pad (63.8 / 66.7 / 72.8 /
+// 87.8); workgroups of 8 and 16 waves for L1 sharing between more adjacent rows (63.3 / 75.0); particles renumbered
+// in cell order (61.1 vs 60.6; a RANDOM order costs 90.6: locality matters, the lattice order already has it);
+// survivors compacted through a wave-private LDS row, evaluated in two trips instead of three and stored as two
+// full-width lines per row (66.0-66.4 vs 64.2-64.8 on the same box: fewer TA and VALU instructions, but the LDS
+// round trip sits in the middle of every row's dependent chain).
 // Two rows per wave with ALL their index loads, then all their gathers, issued before any
 // arithmetic: twice the bytes in flight per wave slot while the evaluator's VALU work (which,
 // unlike the plain build, this kernel has plenty of) runs under the other row's memory latency.
@@ -296,139 +301,13 @@ __device__ __forceinline__ void fused_rows_group(
         }
 }
 
-// Variant for NN <= 128 with the tensor written: the survivors of a row are first COMPACTED into a
-// wave-private LDS row (slot = rank among the kept), then evaluated from there -- ceil(NN / 64) trips over the
-// ~95 survivors instead of three over the ~139 candidates -- and stored, zero tail included, as full-width
-// 1-KiB lines (two store instructions per row instead of three partial ones and a tail).  Round-2 PMC has this
-// kernel bound by the CU's texture-address path (TA busy ~85 %: one cycle per gathered lane, 16 per 1-KiB
-// store), with the VALU at ~50 %: the variant trades both for LDS traffic, which is otherwise idle here.
-// Same per-slot arithmetic; the row sums run over slots instead of candidates, so forces differ from the
-// register path by summation-order rounding only.  Overflowing / long / empty rows: generic routine, as above.
-template <int KIND, int R, typename PT>
-__global__ __launch_bounds__(256) void fused_forces_lds_kernel(
-    const typename Vec4<PT>::type *__restrict__ pos, unsigned N, unsigned NN, unsigned offset, unsigned batch,
-    BoxT<PT> box, const unsigned *__restrict__ n_neigh, const unsigned *__restrict__ nlist,
-    const unsigned *__restrict__ head_list, PT rmaxsq, void *__restrict__ force, int out_f64, PotParams pin,
-    unsigned *__restrict__ check_count, float4 *__restrict__ positions_out, float4 *__restrict__ dest,
-    unsigned *__restrict__ counts_io) {
-    using PV = typename Vec4<PT>::type;
-    extern __shared__ float4 s_rows[]; // [waves per block][R][NN]
-    const PotParams p = resolve_theta<KIND>(pin);
-    const unsigned lane = threadIdx.x & 63u;
-    float4 *mine = s_rows + (size_t)(threadIdx.x >> 6) * R * NN;
-    const unsigned w0 = R * __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-    if (w0 >= batch) return;
-    unsigned nn[R];
-    bool fast = w0 + R <= batch;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        nn[r] = n_neigh[(w0 + r < batch ? w0 + r : w0) + offset];
-        fast = fast && nn[r] != 0 && nn[r] <= 64 * kFChunk;
-    }
-    if (!fast) {
-#pragma unroll 1
-        for (unsigned r = 0; r < (unsigned)R && w0 + r < batch; ++r)
-            fused_row<KIND, false, true, PT>(w0 + r, lane, pos, N, NN, offset, box, n_neigh, nlist, head_list, rmaxsq, force,
-                                             nullptr, out_f64, p, check_count, positions_out, dest, counts_io);
-        return;
-    }
-    PV pi[R];
-    unsigned k[R][kFChunk];
-    PV q[R][kFChunk];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const unsigned *nl = nlist + head_list[w0 + r + offset];
-        pi[r] = pos[w0 + r + offset];
-#pragma unroll
-        for (int t = 0; t < kFChunk; ++t) {
-            const unsigned j = t * 64 + lane;
-            k[r][t] = nl[j < nn[r] ? j : nn[r] - 1];
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-#pragma unroll
-        for (int t = 0; t < kFChunk; ++t) q[r][t] = pos[k[r][t]];
-    unsigned Q[R];
-    // pass 1: pair vectors, keep / drop, compaction into LDS
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        Q[r] = 0;
-#pragma unroll
-        for (int t = 0; t < kFChunk; ++t) {
-            if ((unsigned)t * 64 >= nn[r]) break; // wave-uniform
-            const unsigned j = t * 64 + lane;
-            const PV pk = q[r][t];
-            PT dx, dy, dz;
-            const PT rsq = pair_vector<PT>(pk, pi[r], box, dx, dy, dz);
-            const bool keep = (j < nn[r]) && !(rsq > rmaxsq);
-            const unsigned long long m = __ballot(keep);
-            const unsigned qq = Q[r] + ballot_rank(m);
-            Q[r] += __popcll(m);
-            if (keep && qq < NN) mine[r * NN + qq] = make_float4((float)dx, (float)dy, (float)dz, (float)scalar_as_int(pk.w));
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // pass 2: evaluate the survivors slot by slot, store full-width lines (live slots, then the zero tail)
-    unsigned redo = 0;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const unsigned w = w0 + r;
-        if (positions_out != nullptr && lane == 0)
-            positions_out[w] = make_float4((float)pi[r].x, (float)pi[r].y, (float)pi[r].z, (float)scalar_as_int(pi[r].w));
-        if (Q[r] > NN) { // overflow (an error upstream): the generic routine reproduces the slot wrap, tensor row included
-            redo |= 1u << r;
-            continue;
-        }
-        const unsigned filled = Q[r];
-        const unsigned prev = counts_io != nullptr ? counts_io[w] : NN;
-        const unsigned store_end = filled > prev ? filled : prev;
-        float4 *row = dest + (size_t)w * NN;
-        float fx = 0.f, fy = 0.f, fz = 0.f, en = 0.f;
-        unsigned npos = 0;
-        for (unsigned sl = lane; sl < store_end; sl += 64) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (sl < filled) {
-                v = mine[r * NN + sl];
-                float e, ax, ay, az;
-                pair_eval<KIND>(v.x, v.y, v.z, p, e, ax, ay, az);
-                fx += ax;
-                fy += ay;
-                fz += az;
-                en += e;
-                npos += v.x > 0.f ? 1u : 0u;
-            }
-            store_stream(&row[sl], v);
-        }
-        if (counts_io != nullptr && lane == 0) counts_io[w] = filled;
-        fx = group_sum<64>(fx);
-        fy = group_sum<64>(fy);
-        fz = group_sum<64>(fz);
-        en = group_sum<64>(en);
-        if (check_count != nullptr) npos = group_sum_u<64>(npos);
-        if (lane == 0) {
-            if (out_f64)
-                ((double4 *)force)[w] = make_double4(fx, fy, fz, en);
-            else
-                ((float4 *)force)[w] = make_float4(fx, fy, fz, en);
-            if (check_count != nullptr && npos > *(volatile unsigned *)check_count) atomicMax(check_count, npos);
-        }
-    }
-#pragma unroll 1
-    for (unsigned r = 0; r < (unsigned)R; ++r)
-        if ((redo >> r) & 1u)
-            fused_row<KIND, false, true, PT>(w0 + r, lane, pos, N, NN, offset, box, n_neigh, nlist, head_list, rmaxsq, force,
-                                             nullptr, out_f64, p, check_count, positions_out, dest, counts_io);
-}
-
 // The kernel strides over the row groups so that HTF_FUSED_GRID=<workgroups per CU> can launch it
 // persistently for A/B runs.  tools/store_probe.hip says a persistent grid helps a bare
 // load-chain + streaming-store kernel (65 -> 46 us); this kernel, whose rows differ in length
 // and which has arithmetic to hide its loads under, is best with one group per wave
 // (C3, tensor written: 62.5 us; 4 / 8 / 12 / 16 workgroups per CU: 84 / 78 / 69 / 68 us), the default.
 template <int KIND, bool STORE, int R, typename PT>
-__global__ __launch_bounds__(HTF_ROWS2_THREADS, HTF_ROWS2_WAVES) void fused_forces_rows2_kernel(
+__global__ __launch_bounds__(256) void fused_forces_rows2_kernel(
     const typename Vec4<PT>::type *__restrict__ pos, unsigned N, unsigned NN, unsigned offset, unsigned batch,
     BoxT<PT> box, const unsigned *__restrict__ n_neigh, const unsigned *__restrict__ nlist,
     const unsigned *__restrict__ head_list, PT rmaxsq, void *__restrict__ force, int out_f64, PotParams pin,
@@ -457,30 +336,12 @@ static int launch_fused(const void *pos, unsigned N, unsigned NN, unsigned offse
         static const char *grid_env = getenv("HTF_FUSED_GRID"); // A/B runs: workgroups per CU, 0 = one wave per group
         static const int per_cu = grid_env ? atoi(grid_env) : 0;
         static const int n_cu = device_cu_count();
-        static const char *blk_env = getenv("HTF_FUSED_BLOCK"); // A/B runs: threads per workgroup
-        const unsigned wpb = (blk_env ? (unsigned)atoi(blk_env) : 256u) / 64u;
-        static const char *pad_env = getenv("HTF_FUSED_LDSPAD"); // A/B runs: dynamic LDS bytes per workgroup (caps occupancy)
-        const unsigned lds_pad = pad_env ? (unsigned)atoi(pad_env) : 0u;
 #define HTF_ROWS_LAUNCH(ST, RR)                                                                                        \
-    const unsigned full = ((batch + RR - 1) / RR + wpb - 1) / wpb;                                                     \
+    const unsigned full = ((batch + RR - 1) / RR + 3) / 4;                                                             \
     const unsigned grid = per_cu > 0 && (unsigned)(per_cu * n_cu) < full ? (unsigned)(per_cu * n_cu) : full;           \
-    hipLaunchKernelGGL((fused_forces_rows2_kernel<KIND, ST, RR, PT>), dim3(grid), dim3(wpb * 64), lds_pad, s, \
+    hipLaunchKernelGGL((fused_forces_rows2_kernel<KIND, ST, RR, PT>), dim3(grid), dim3(256), 0, s, \
                        (const typename Vec4<PT>::type *)pos, N, NN, offset, batch, b, n_neigh, nlist, head_list,       \
                        (PT)(rc * rc), force, out_f64, p, check_count, positions_out, dest, counts_io)
-        static const char *lds_env = getenv("HTF_FUSED_LDS"); // A/B runs: 1 = survivors compacted through LDS
-        const bool use_lds = lds_env ? atoi(lds_env) != 0 : false;
-        if (use_lds && dest != nullptr && NN <= 128) {
-            const unsigned lrows = rows == 1 ? 1u : 2u;
-            const unsigned groups = (batch + lrows - 1) / lrows;
-            const size_t lds = (size_t)4 * lrows * NN * sizeof(float4);
-#define HTF_LDS_LAUNCH(RR)                                                                                             \
-    hipLaunchKernelGGL((fused_forces_lds_kernel<KIND, RR, PT>), dim3((groups + 3) / 4), dim3(256), lds, s,            \
-                       (const typename Vec4<PT>::type *)pos, N, NN, offset, batch, b, n_neigh, nlist, head_list,       \
-                       (PT)(rc * rc), force, out_f64, p, check_count, positions_out, dest, counts_io)
-            if (lrows == 1) { HTF_LDS_LAUNCH(1); } else { HTF_LDS_LAUNCH(2); }
-#undef HTF_LDS_LAUNCH
-            return check_launch("fused_forces_lds_kernel");
-        }
         if (rows == 2 || rows == 4) {
             if (rows == 2) {
                 if (dest != nullptr) { HTF_ROWS_LAUNCH(true, 2); } else { HTF_ROWS_LAUNCH(false, 2); }
@@ -530,7 +391,12 @@ struct Rdf2 {
     unsigned *hist;
 };
 
-template <int KA, bool STORE, typename PT>
+// COMPACT (NN <= 128): the survivors of a row are first written to a wave-private LDS row at their final slot, then
+// both potentials, the CV term and the histogram bin are evaluated slot by slot -- two trips over the ~95 survivors
+// instead of three over the ~139 candidates -- and the tensor leaves as full-width lines.  This sweep is VALU-bound
+// (two potentials, an exp, a correctly rounded sqrt and a histogram update per slot), unlike the LJ step, which is
+// bound by its gathers and for which the same restructuring lost 2 % (see fused_rows_group).
+template <int KA, bool STORE, bool COMPACT, typename PT>
 __global__ __launch_bounds__(256) void fused_forces2_kernel(
     const typename Vec4<PT>::type *__restrict__ pos, unsigned N, unsigned NN, unsigned offset, unsigned batch,
     BoxT<PT> box, const unsigned *__restrict__ n_neigh, const unsigned *__restrict__ nlist,
@@ -541,6 +407,8 @@ __global__ __launch_bounds__(256) void fused_forces2_kernel(
     const PotParams pa = resolve_theta<KA>(pa_in);
     __shared__ float s_part[4];
     __shared__ unsigned s_hist[kRdfMaxBins2];
+    __shared__ float4 s_rows[COMPACT ? 4 * 128 : 1];
+    float4 *mine = s_rows + (COMPACT ? (threadIdx.x >> 6) * 128 : 0);
     const bool do_rdf = rdf.hist != nullptr;
     if (do_rdf) {
         for (unsigned i = threadIdx.x; i < rdf.nb; i += blockDim.x) s_hist[i] = 0;
@@ -557,24 +425,28 @@ __global__ __launch_bounds__(256) void fused_forces2_kernel(
     unsigned n_lo = 0, n_hi = 0;
     float cv_wave = 0.f; // sum of the B energy column over this wave's rows, in row order
 
+    auto eval_slot = [&](float x, float y, float z, float &ax, float &ay, float &az, float &ae, float &bx, float &by,
+                         float &bz, float &be) {
+        float e, fx, fy, fz;
+        pair_eval<KA>(x, y, z, pa, e, fx, fy, fz);
+        ax += fx; ay += fy; az += fz; ae += e;
+        pair_eval<HTF_POT_GAUSS>(x, y, z, pb, e, fx, fy, fz);
+        bx += fx; by += fy; bz += fz; be += e;
+        if (do_rdf) {
+            const float r = sqrtf(x * x + y * y + z * z);
+            const float fi = floorf((r - rdf.r0) * rdf_scale);
+            const int idx = fi < 0.f ? 0 : (fi > (float)(rdf.nb - 1) ? (int)(rdf.nb - 1) : (int)fi);
+            if (idx == 0) ++n_lo;
+            else if (idx == (int)rdf.nb - 1) ++n_hi;
+            else atomicAdd(&s_hist[idx], 1u);
+        }
+    };
     auto one = [&](PT dx, PT dy, PT dz, const PV &pk, bool keep, unsigned q, unsigned lo, unsigned Q, float4 *row, float &ax,
                    float &ay, float &az, float &ae, float &bx, float &by, float &bz, float &be) {
         if (keep && q >= lo) {
             const float x = (float)dx, y = (float)dy, z = (float)dz;
             if constexpr (STORE) store_stream(&row[Q > NN ? q % NN : q], make_float4(x, y, z, (float)scalar_as_int(pk.w)));
-            float e, fx, fy, fz;
-            pair_eval<KA>(x, y, z, pa, e, fx, fy, fz);
-            ax += fx; ay += fy; az += fz; ae += e;
-            pair_eval<HTF_POT_GAUSS>(x, y, z, pb, e, fx, fy, fz);
-            bx += fx; by += fy; bz += fz; be += e;
-            if (do_rdf) {
-                const float r = sqrtf(x * x + y * y + z * z);
-                const float fi = floorf((r - rdf.r0) * rdf_scale);
-                const int idx = fi < 0.f ? 0 : (fi > (float)(rdf.nb - 1) ? (int)(rdf.nb - 1) : (int)fi);
-                if (idx == 0) ++n_lo;
-                else if (idx == (int)rdf.nb - 1) ++n_hi;
-                else atomicAdd(&s_hist[idx], 1u);
-            }
+            eval_slot(x, y, z, ax, ay, az, ae, bx, by, bz, be);
         }
     };
 
@@ -655,10 +527,33 @@ __global__ __launch_bounds__(256) void fused_forces2_kernel(
             }
             fetch_idx(nxt, k_nxt); // in flight under this row's evaluation
             const unsigned lo = Q > NN ? Q - NN : 0u;
+            if constexpr (COMPACT) {
 #pragma unroll
-            for (int t = 0; t < kFChunk; ++t) {
-                if ((unsigned)t * 64 >= nn) break; // wave-uniform
-                one(vx[t], vy[t], vz[t], pk[t], keep[t], q[t], lo, Q, row, ax, ay, az, ae, bx, by, bz, be);
+                for (int t = 0; t < kFChunk; ++t) {
+                    if ((unsigned)t * 64 >= nn) break; // wave-uniform
+                    if (keep[t] && q[t] >= lo) // the slot this survivor ends up in (overflow: the reference's wrap)
+                        mine[Q > NN ? q[t] % NN : q[t]] = make_float4((float)vx[t], (float)vy[t], (float)vz[t], (float)scalar_as_int(pk[t].w));
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const unsigned live = Q < NN ? Q : NN;
+                const unsigned prev = (STORE && counts_io != nullptr) ? counts_io[w] : (STORE ? NN : 0u);
+                const unsigned end = live > prev ? live : prev;
+                for (unsigned sl = lane; sl < end; sl += 64) {
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (sl < live) {
+                        v = mine[sl];
+                        eval_slot(v.x, v.y, v.z, ax, ay, az, ae, bx, by, bz, be);
+                    }
+                    if constexpr (STORE) store_stream(&row[sl], v);
+                }
+                __builtin_amdgcn_wave_barrier(); // the row is consumed before the next one overwrites it
+            } else {
+#pragma unroll
+                for (int t = 0; t < kFChunk; ++t) {
+                    if ((unsigned)t * 64 >= nn) break; // wave-uniform
+                    one(vx[t], vy[t], vz[t], pk[t], keep[t], q[t], lo, Q, row, ax, ay, az, ae, bx, by, bz, be);
+                }
             }
         } else {
             nxt = fetch_meta(grp + gridDim.x);
@@ -686,8 +581,10 @@ __global__ __launch_bounds__(256) void fused_forces2_kernel(
         }
         const unsigned filled = Q < NN ? Q : NN;
         if constexpr (STORE) {
+            const bool tail_done = COMPACT && nn <= 64 * kFChunk; // the compacting path stored live slots and tail together
             const unsigned zero_end = counts_io != nullptr ? counts_io[w] : NN;
-            for (unsigned sl = filled + lane; sl < zero_end; sl += 64) store_stream(&row[sl], make_float4(0.f, 0.f, 0.f, 0.f));
+            if (!tail_done)
+                for (unsigned sl = filled + lane; sl < zero_end; sl += 64) store_stream(&row[sl], make_float4(0.f, 0.f, 0.f, 0.f));
             if (counts_io != nullptr && lane == 0) counts_io[w] = filled;
         }
         if (do_rdf && lane == 0 && filled < NN) { // the row's zero padding
@@ -748,14 +645,18 @@ static int launch_fused2(const PotParams &pa, const PotParams &pb, const void *p
     BoxT<PT> b = make_boxt<PT>(hb);
     PT rc = (PT)rmax;
     const unsigned grid = fused_forces2_num_partials(batch);
-    if (dest != nullptr)
-        hipLaunchKernelGGL((fused_forces2_kernel<KA, true, PT>), dim3(grid), dim3(256), 0, s,
-                           (const typename Vec4<PT>::type *)pos, N, NN, offset, batch, b, n_neigh, nlist, head_list,
-                           (PT)(rc * rc), fa, fb, out_f64, pa, pb, partials, rdf, dest, counts_io);
-    else
-        hipLaunchKernelGGL((fused_forces2_kernel<KA, false, PT>), dim3(grid), dim3(256), 0, s,
-                           (const typename Vec4<PT>::type *)pos, N, NN, offset, batch, b, n_neigh, nlist, head_list,
-                           (PT)(rc * rc), fa, fb, out_f64, pa, pb, partials, rdf, dest, counts_io);
+    static const char *cenv = getenv("HTF_FUSED2_COMPACT"); // A/B runs: 0 = evaluate the candidates in place
+    const bool compact = NN <= 128 && (cenv ? atoi(cenv) != 0 : true);
+#define HTF_F2_LAUNCH(ST, CP)                                                                                          \
+    hipLaunchKernelGGL((fused_forces2_kernel<KA, ST, CP, PT>), dim3(grid), dim3(256), 0, s,                            \
+                       (const typename Vec4<PT>::type *)pos, N, NN, offset, batch, b, n_neigh, nlist, head_list,       \
+                       (PT)(rc * rc), fa, fb, out_f64, pa, pb, partials, rdf, dest, counts_io)
+    if (dest != nullptr) {
+        if (compact) HTF_F2_LAUNCH(true, true); else HTF_F2_LAUNCH(true, false);
+    } else {
+        if (compact) HTF_F2_LAUNCH(false, true); else HTF_F2_LAUNCH(false, false);
+    }
+#undef HTF_F2_LAUNCH
     return check_launch("fused_forces2_kernel");
 }
 

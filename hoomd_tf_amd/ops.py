@@ -511,8 +511,14 @@ class Context:
         return torch.as_tensor(h, device=device)
 
     def nlist_buffer(self, B, device="cuda"):
-        """getNlistBuffer (TensorflowCompute.cc:406): zero-copy [B, NN, 4] fp32 view."""
+        """getNlistBuffer (TensorflowCompute.cc:406): zero-copy [B, NN, 4] fp32 view.  Read-only between steps
+        (see reset_nlist_buffer)."""
         return self._view(lib.htf_get_nlist_buffer(self._h), (B, self.cfg.nneighs, 4), torch.float32, device)
+
+    def reset_nlist_buffer(self):
+        """Call after WRITING into ``nlist_buffer()``: the next step rewrites every row's zero tail in full
+        (the context otherwise re-zeroes only the slots a row lost since the previous step)."""
+        check(lib.htf_reset_nlist_buffer(self._h, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
 
     def positions_buffer(self, B, device="cuda"):
         return self._view(lib.htf_get_positions_buffer(self._h), (B, 4), torch.float32, device)

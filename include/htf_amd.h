@@ -393,6 +393,12 @@ HTF_API int htf_compute_forces_rows(htf_ctx *ctx, unsigned timestep, const htf_h
  * context-owned side buffers, for zero-copy views.  nlist: fp32 [B, NN, 4];
  * positions: fp32 [B, 4] (type un-stuffed); virial: Scalar [B, 9]. */
 HTF_API void *htf_get_nlist_buffer(htf_ctx *ctx);
+/* The nlist side buffer is READ-ONLY for the caller between steps: the context keeps every row as [live slots |
+ * zeros] and re-zeroes only the slots a row has lost since the previous call (the padding, a quarter of the tensor
+ * at 131 072 x 128, is not rewritten every step).  The reference lets a model write into this tensor (it is just a
+ * TF tensor there); a caller that does so here must call htf_reset_nlist_buffer before the next htf_compute_forces:
+ * the next build then rewrites every row's whole zero tail. */
+HTF_API int htf_reset_nlist_buffer(htf_ctx *ctx, htf_stream stream);
 HTF_API void *htf_get_positions_buffer(htf_ctx *ctx);
 HTF_API void *htf_get_virial_buffer(htf_ctx *ctx);
 HTF_API unsigned htf_get_batch_capacity(htf_ctx *ctx);

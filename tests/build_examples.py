@@ -26,7 +26,6 @@ class LJModel(htf.SimModel):
     def compute(self, nlist, positions, box):
         rinv = htf.nlist_rinv(nlist)
         inv_r6 = rinv**6
-        # pairwise energy. Double count -> divide by 2
         p_energy = 4.0 / 2.0 * (inv_r6 * inv_r6 - inv_r6)
         energy = htf.reduce_sum(p_energy, axis=1)
         forces = htf.compute_nlist_forces(nlist, energy)
@@ -116,13 +115,11 @@ class EDSModel(htf.SimModel):
         self.eds_bias = htf.EDSLayer(set_point, 5, 1 / 5)
 
     def compute(self, nlist, positions, box):
-        # get distance from center
         rvec = htf.wrap_vector(positions[0, :3], box)
         cv = torch.sqrt((rvec * rvec).sum())
         self.cv_sum += float(cv)
         self.cv_n += 1
         alpha = self.eds_bias(cv)
-        # eds + harmonic bond
         energy = (cv - 5) ** 2 + cv * alpha.detach()
         forces = htf.compute_positions_forces(positions, energy)
         return forces, alpha
@@ -156,7 +153,6 @@ class TrainableGraph(htf.SimModel):
         return {'lj': self.lj}[name]
 
     def compute(self, nlist, positions, box):
-        # get r
         r = htf.safe_norm(nlist[:, :, :3], axis=2)
         p_energy = self.lj(r)
         energy = htf.reduce_sum(p_energy, axis=1)
@@ -168,7 +164,6 @@ class TrainableGraph(htf.SimModel):
 class LJMolModel(htf.MolSimModel):
     # build_examples.py:310-318, TF calls -> torch
     def mol_compute(self, nlist, positions, mol_nlist, mol_positions, box):
-        # assume particle (w) is 0
         r = torch.norm(mol_nlist, dim=3)
         rinv = torch.where(r > 0, 1.0 / torch.where(r > 0, r, torch.ones_like(r)), torch.zeros_like(r))  # divide_no_nan
         mol_p_energy = 4.0 / 2.0 * (rinv**12 - rinv**6)

@@ -223,3 +223,14 @@ def test_topk_mlp_tie_order_on_a_lattice():
     # E = 1 * s2 + 2 * s0 - 3 * s1 with s = 1/r: slot 0 (rank 1) takes weight 2, slot 1 (rank 2) weight -3
     assert g[0, 0, 1] == pytest.approx(2.0 * -1.0, rel=1e-4) and g[0, 1, 0] == pytest.approx(-3.0 * -1.0, rel=1e-4)
     assert g[0, 2, 2] == pytest.approx(1.0 * -4.0, rel=1e-4)
+
+
+def test_product_initializer_equals_the_oracle_copy():
+    """hoomd_tf_amd/initializers.py duplicates oracle.make_mlp_params so that the product never imports oracle/:
+    the two must stay the same function."""
+    from hoomd_tf_amd.initializers import mlp_params
+    for kw in (dict(seed=3), dict(seed=7, K=8, H1=16, H2=24), dict(seed=3, bias_scale=0.2)):
+        a, b = mlp_params(**kw), O.make_mlp_params(**kw)
+        assert sorted(a) == sorted(b)
+        for k in a:
+            np.testing.assert_array_equal(a[k], b[k])

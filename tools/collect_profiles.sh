@@ -1,23 +1,21 @@
 # copy the evidence pass's outputs (gpurun_out/final, scratch) into profiles/ (tracked), named per round
 set -e
-R=${1:-r01}
+R=${1:-r02}
 cd "$(dirname "$0")/.."
 F=gpurun_out/final
-cp $F/bench_lj.json profiles/${R}_bench_lj.json
-cp $F/bench_lj_f64.json profiles/${R}_bench_lj_f64.json
-cp $F/bench_wca.json profiles/${R}_bench_wca.json
-cp $F/bench_wca_c2.json profiles/${R}_bench_wca_c2.json
-cp $F/bench_mlp.json profiles/${R}_bench_mlp.json
-cp $F/bench_mlp_bf16.json profiles/${R}_bench_mlp_bf16.json
-cp $F/bench_mlp_split.json profiles/${R}_bench_mlp_split.json
-cp $F/bench_mlp_train.json profiles/${R}_bench_mlp_train.json
+for n in bench_lj bench_lj_200 bench_lj_f64 bench_wca bench_wca_c2 bench_mlp bench_mlp_bf16 bench_mlp_split bench_mlp_train bench_rehearsal_2ranks_strong_gloo bench_rehearsal_8ranks_strong_gloo bench_rehearsal_2ranks_weak_gloo; do
+  [ -s $F/$n.json ] && cp $F/$n.json profiles/${R}_$n.json
+done
 cp $F/bench_eds.json profiles/${R}_bench_eds_c4.json
 cp $F/lj_kernel_stats.csv profiles/${R}_bench_lj_kernel_stats.csv
 cp $F/mlp_kernel_stats.csv profiles/${R}_bench_mlp_kernel_stats.csv
 cp $F/mt_kernel_stats.csv profiles/${R}_bench_mlp_train_kernel_stats.csv
 cp $F/eds_kernel_stats.csv profiles/${R}_bench_eds_c4_kernel_stats.csv
+cp $F/c2_kernel_stats.csv profiles/${R}_bench_wca_c2_kernel_stats.csv
 cp $F/pmc_hbm.json profiles/${R}_bench_lj_pmc_hbm.json
-cp $F/mfma_valu_probe2.txt profiles/${R}_mfma_valu_probe.txt
+cp $F/pmc_lj_kernel.json profiles/${R}_bench_lj_pmc_kernel.json
+cp $F/pmc_mlp.json profiles/${R}_bench_mlp_pmc.json
+cp $F/gather_probe2.txt profiles/${R}_gather_probe.txt
 cp $F/store_probe.txt profiles/${R}_store_probe.txt
 cp gpurun_out/parity_stats.json profiles/${R}_parity_stats.json
-tail -2 $F/pytest_gpu.log; cat $F/smoke.log | tail -1
+tail -2 $F/pytest_gpu.log; tail -1 $F/smoke.log

@@ -1,39 +1,76 @@
+# Round evidence pass: everything DESIGN.md / README.md quote is regenerated here, on one GPU box, into
+# gpurun_out/final/; tools/collect_profiles.sh <round> then copies the summaries into profiles/ (tracked).
 set -x
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/final
-python -m pytest tests -q -m gpu > gpurun_out/final/pytest_gpu.log 2>&1; tail -2 gpurun_out/final/pytest_gpu.log
-python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/final/smoke.log 2>&1; tail -2 gpurun_out/final/smoke.log
-python bench.py > gpurun_out/final/bench_lj.json 2>gpurun_out/final/bench_lj.err
-python bench.py --f64 > gpurun_out/final/bench_lj_f64.json 2>/dev/null
-python bench.py --workload wca > gpurun_out/final/bench_wca.json 2>/dev/null
-python bench.py --workload wca --cells 20 > gpurun_out/final/bench_wca_c2.json 2>/dev/null
-python bench.py --workload mlp --steps 100 --warmup 10 > gpurun_out/final/bench_mlp.json 2>/dev/null
-python bench.py --workload mlp-bf16 --steps 100 --warmup 10 > gpurun_out/final/bench_mlp_bf16.json 2>/dev/null
-python bench.py --workload mlp-split --steps 100 --warmup 10 > gpurun_out/final/bench_mlp_split.json 2>/dev/null
-./tools/mfma_valu_probe2 > gpurun_out/final/mfma_valu_probe2.txt 2>&1
-./tools/store_probe > gpurun_out/final/store_probe.txt 2>&1
-python bench.py --workload mlp-train --steps 400 --warmup 20 > gpurun_out/final/bench_mlp_train.json 2>/dev/null
-python bench.py --workload eds > gpurun_out/final/bench_eds.json 2>/dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_lj -o lj -- python3 bench.py --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_mlp -o mlp -- python3 bench.py --workload mlp --steps 50 --warmup 5 > /dev/null 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_mt -o mt -- python3 bench.py --workload mlp-train --steps 200 --warmup 10 > /dev/null 2>&1
+F=gpurun_out/final
+mkdir -p $F
+python -m pytest tests -q -m gpu > $F/pytest_gpu.log 2>&1; tail -2 $F/pytest_gpu.log
+python -c "import __graft_entry__ as g; g.smoke()" > $F/smoke.log 2>&1; tail -2 $F/smoke.log
+jl() { grep '^{' | tail -1; }
+python bench.py --steps 20 --warmup 5 2>$F/bench_lj.err | jl > $F/bench_lj.json          # the driver's own command
+python bench.py 2>/dev/null | jl > $F/bench_lj_200.json
+python bench.py --f64 --no-mlp 2>/dev/null | jl > $F/bench_lj_f64.json
+python bench.py --workload wca --no-mlp 2>/dev/null | jl > $F/bench_wca.json
+python bench.py --workload wca --lattice sc --cells 32 2>/dev/null | jl > $F/bench_wca_c2.json
+python bench.py --workload mlp --steps 100 --warmup 10 2>/dev/null | jl > $F/bench_mlp.json
+python bench.py --workload mlp-bf16 --steps 100 --warmup 10 --no-cpu-baseline 2>/dev/null | jl > $F/bench_mlp_bf16.json
+python bench.py --workload mlp-split --steps 100 --warmup 10 --no-cpu-baseline 2>/dev/null | jl > $F/bench_mlp_split.json
+python bench.py --workload mlp-train --steps 400 --warmup 20 --no-cpu-baseline 2>/dev/null | jl > $F/bench_mlp_train.json
+python bench.py --workload eds 2>/dev/null | jl > $F/bench_eds.json
+HTF_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 20 --warmup 5 --no-cpu-baseline --no-fused 2>/dev/null | jl > $F/bench_rehearsal_2ranks_strong_gloo.json
+HTF_BENCH_BACKEND=gloo python bench.py --gpus 8 --steps 20 --warmup 5 --no-cpu-baseline --no-fused 2>/dev/null | jl > $F/bench_rehearsal_8ranks_strong_gloo.json
+HTF_BENCH_BACKEND=gloo python bench.py --gpus 2 --scaling weak --steps 20 --warmup 5 --no-cpu-baseline --no-fused 2>/dev/null | jl > $F/bench_rehearsal_2ranks_weak_gloo.json
+./tools/gather_probe2 > $F/gather_probe2.txt 2>&1
+./tools/store_probe > $F/store_probe.txt 2>&1
+# kernel durations: rocprofv3 --kernel-trace --stats of the same commands
+Q="--no-cpu-baseline --no-mlp"
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_lj -o lj -- python3 bench.py $Q > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_mlp -o mlp -- python3 bench.py --workload mlp --steps 50 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_mt -o mt -- python3 bench.py --workload mlp-train --steps 200 --warmup 10 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_eds -o eds -- python3 bench.py --workload eds > /dev/null 2>&1
-for n in lj mlp mt eds; do find /tmp/p_$n -name "*kernel_stats.csv" -exec cp {} gpurun_out/final/${n}_kernel_stats.csv \; ; done
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/c_f -o f -- python3 bench.py --no-cpu-baseline --no-fused --steps 50 --warmup 5 > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/c_w -o w -- python3 bench.py --no-cpu-baseline --no-fused --steps 50 --warmup 5 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_c2 -o c2 -- python3 bench.py --workload wca --lattice sc --cells 32 --no-cpu-baseline > /dev/null 2>&1
+for n in lj mlp mt eds c2; do find /tmp/p_$n -name "*kernel_stats.csv" -exec cp {} $F/${n}_kernel_stats.csv \; ; done
+# HBM bytes: FETCH_SIZE and WRITE_SIZE in separate passes (they do not fit one), short runs
+S="--no-cpu-baseline --no-mlp --no-fused --steps 20 --warmup 5 --equil 60 --windows 1"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/c_f -o f -- python3 bench.py $S > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/c_w -o w -- python3 bench.py $S > /dev/null 2>&1
+# where the LJ step's time goes: TA / TCP and SQ counters of its one kernel
+for set in "TA_TA_BUSY_sum TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TOTAL_ACCESSES_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_WAVES" "GRBM_GUI_ACTIVE GRBM_COUNT"; do
+  n=$(echo $set | tr ' ' '_' | cut -c1-40); rm -rf /tmp/pk_$n
+  rocprofv3 --pmc $set --output-format csv -d /tmp/pk_$n -o x -- python3 bench.py $S > /dev/null 2>&1
+done
+# matrix-pipe counters of the pair-MLP kernels (evaluator fp32 / split, training sweep)
+M="--no-cpu-baseline --steps 6 --warmup 2 --equil 20 --windows 1"
+for set in "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY" "GRBM_GUI_ACTIVE GRBM_COUNT"; do
+  n=$(echo $set | tr ' ' '_' | cut -c1-40); rm -rf /tmp/pm_$n /tmp/pt_$n
+  rocprofv3 --pmc $set --output-format csv -d /tmp/pm_$n -o x -- python3 bench.py --workload mlp $M > /dev/null 2>&1
+  rocprofv3 --pmc $set --output-format csv -d /tmp/pt_$n -o x -- python3 bench.py --workload mlp-train --train-period 2 $M > /dev/null 2>&1
+done
 python3 - <<'PY'
-import csv,glob,json,collections
-out={}
-for name,d in (("FETCH_SIZE","/tmp/c_f"),("WRITE_SIZE","/tmp/c_w")):
-    fs=glob.glob(d+"/**/*counter_collection.csv", recursive=True)
-    agg=collections.defaultdict(list)
-    for f in fs:
+import csv, glob, json, collections
+F = "gpurun_out/final"
+def collect(pattern, want=None):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(pattern, recursive=True):
         for r in csv.DictReader(open(f)):
-            if r.get("Counter_Name")==name:
-                agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
-    out[name]={k.split("(")[0]:{"launches":len(v),"avg_KiB":sum(v)/len(v)} for k,v in agg.items() if k.startswith("void htf::") and len(v)>5}
-out["_note"]="rocprofv3 --pmc (separate passes), bench.py --steps 50 --warmup 5 (tools/evidence_pass.sh). gfx950: FETCH_SIZE counts 1/2 of wide coalesced reads (MI355X_MICROARCH.md HBM); WRITE_SIZE exact for 16-B/lane stores."
-json.dump(out,open("gpurun_out/final/pmc_hbm.json","w"),indent=1)
-print(json.dumps(out)[:1500])
+            k = r["Kernel_Name"].split("(")[0]
+            if k.startswith("void htf::") and (want is None or any(w in k for w in want)):
+                agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: {c: {"launches": len(v), "avg": sum(v[len(v) // 2:]) / len(v[len(v) // 2:])} for c, v in d.items()} for k, d in agg.items()}
+out = {}
+for name, d in (("FETCH_SIZE", "/tmp/c_f"), ("WRITE_SIZE", "/tmp/c_w")):
+    c = collect(d + "/**/*counter_collection.csv")
+    out[name] = {k: {"launches": v[name]["launches"], "avg_KiB": v[name]["avg"]} for k, v in c.items() if name in v and v[name]["launches"] > 5}
+out["_note"] = ("rocprofv3 --pmc (separate passes) of: bench.py --no-cpu-baseline --no-mlp --no-fused --steps 20 --warmup 5 --equil 60 --windows 1; averages over the "
+                "second half of each kernel's launches.  gfx950: FETCH_SIZE counts 1/2 of wide coalesced reads (MI355X_MICROARCH.md, HBM); WRITE_SIZE exact for 16-B/lane stores.")
+json.dump(out, open(F + "/pmc_hbm.json", "w"), indent=1)
+lj = collect("/tmp/pk_*/**/*counter_collection.csv", want=["fused_forces_rows2_kernel"])
+json.dump(lj, open(F + "/pmc_lj_kernel.json", "w"), indent=1)
+mlp = collect("/tmp/pm_*/**/*counter_collection.csv", want=["pair_mlp_kernel"])
+trn = collect("/tmp/pt_*/**/*counter_collection.csv", want=["mlp_grad", "pair_mlp_kernel"])
+json.dump({"evaluator (bench.py --workload mlp, fp32 MFMA + the split variant)": mlp, "training (bench.py --workload mlp-train)": trn,
+           "_note": "SQ_INSTS_MFMA: wave-level MFMA instructions; SQ_VALU_MFMA_BUSY_CYCLES: cycles the matrix pipe is busy, summed over SIMDs; "
+                    "matrix pipe busy fraction = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)"}, open(F + "/pmc_mlp.json", "w"), indent=1)
+print(json.dumps(out)[:600])
 PY
-ls -la gpurun_out/final
+ls -la $F
