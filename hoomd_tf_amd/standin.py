@@ -368,9 +368,11 @@ class Simulation:
         self.integrator = None
         _current["sim"] = self
 
-    def nlist_cell(self, r_buff=0.4, check_period=1, pitch=None):
-        """hoomd.md.nlist.cell(): r_cut comes from the subscribers (nlist.subscribe)."""
-        return CellNlist(self.system, r_cut=0.0, r_buff=r_buff, pitch=pitch, check_period=check_period)
+    def nlist_cell(self, r_buff=0.4, check_period=1, pitch=None, device_decision=True):
+        """hoomd.md.nlist.cell(): r_cut comes from the subscribers (nlist.subscribe).  The rebuild decision stays
+        on the device (CellNlist.device_decision) wherever the list qualifies: one rank, no particle sorter."""
+        return CellNlist(self.system, r_cut=0.0, r_buff=r_buff, pitch=pitch, check_period=check_period,
+                         device_decision=device_decision)
 
     def integrate_nve(self, dt, group=None):
         self.integrator = NVE(self.system, dt, group=group)
