@@ -192,7 +192,14 @@ __global__ __launch_bounds__(256) void fused_forces_kernel(const typename Vec4<P
 // in cell order (61.1 vs 60.6; a RANDOM order costs 90.6: locality matters, the lattice order already has it);
 // survivors compacted through a wave-private LDS row, evaluated in two trips instead of three and stored as two
 // full-width lines per row (66.0-66.4 vs 64.2-64.8 on the same box: fewer TA and VALU instructions, but the LDS
-// round trip sits in the middle of every row's dependent chain).
+// round trip sits in the middle of every row's dependent chain); the candidate lists of 2 / 3 / 4 rows laid end to end
+// and walked as ONE stream, 64 entries per trip (9 trips instead of 12 for four rows: a quarter fewer index loads,
+// gathers and evaluation trips; per-row scalars read back with v_readlane, two accumulator sets, a row reduced when
+// its last entry has passed): 81.6 / 78.8 / 77.8 us against 61.5, and 67.7 against 48.5 without the tensor -- the
+// wave-uniform but data-dependent bookkeeping between trips (current row, split lane, running counts, a branch per
+// trip) serialises what the straight-line two-row form lets the hardware overlap; the neighbor-index rows (read once,
+// 73 MB) loaded with the nontemporal hint so that they leave the 32-KB L1 to the position lines: 74.5-77.0 us against
+// 60.9-63.6 with the tensor written, 48.8-50.2 against 47.2-48.7 without.
 // Two rows per wave with ALL their index loads, then all their gathers, issued before any
 // arithmetic: twice the bytes in flight per wave slot while the evaluator's VALU work (which,
 // unlike the plain build, this kernel has plenty of) runs under the other row's memory latency.
@@ -301,6 +308,194 @@ __device__ __forceinline__ void fused_rows_group(
         }
 }
 
+// Tails merged: a row of ~139 candidates is two full trips and a third with ~11 live lanes, and a gather or an
+// evaluation trip costs the same whether 64 or 11 of its lanes are live.  Here the first 128 entries of each of the R
+// rows are walked as above (straight-line code, compile-time structure), and the R tails share ONE trip: lane l
+// belongs to the row whose tail covers it (prefix sums of the tail lengths; fast path: they fit 64 lanes together).
+// R = 4: 9 trips instead of 12.  Only the shared trip pays for per-lane row selection (list head, own position,
+// rank base, tensor row) and for splitting its contributions over R accumulator sets.
+template <int KIND, bool STORE, int R, typename PT>
+__device__ __forceinline__ void fused_rows_group_tails(
+    const unsigned w0, const unsigned lane, const typename Vec4<PT>::type *__restrict__ pos, unsigned N, unsigned NN,
+    unsigned offset, unsigned batch, const BoxT<PT> &box, const unsigned *__restrict__ n_neigh,
+    const unsigned *__restrict__ nlist, const unsigned *__restrict__ head_list, PT rmaxsq, void *__restrict__ force,
+    int out_f64, const PotParams &p, unsigned *__restrict__ check_count, float4 *__restrict__ positions_out,
+    float4 *__restrict__ dest, unsigned *__restrict__ counts_io) {
+    using PV = typename Vec4<PT>::type;
+    unsigned nn[R], S[R + 1];
+    bool fast = w0 + R <= batch;
+    S[0] = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        nn[r] = n_neigh[(w0 + r < batch ? w0 + r : w0) + offset];
+        fast = fast && nn[r] != 0 && nn[r] <= 192u;
+        S[r + 1] = S[r] + (nn[r] > 128u ? nn[r] - 128u : 0u);
+    }
+    if (!fast || S[R] > 64u) { // (wave-uniform) the plain two-rows-at-a-time form handles everything else
+#pragma unroll
+        for (int r = 0; r < R; r += 2)
+            if (w0 + r < batch)
+                fused_rows_group<KIND, STORE, 2, PT>(w0 + r, lane, pos, N, NN, offset, batch, box, n_neigh, nlist, head_list,
+                                                     rmaxsq, force, out_f64, p, check_count, positions_out, dest, counts_io);
+        return;
+    }
+    PV pi[R];
+    unsigned head[R];
+    unsigned k[R][2], kt;
+    PV q[R][2], qt;
+    // which row this lane's tail entry belongs to, and its entry index there
+    unsigned rl = 0;
+#pragma unroll
+    for (int r = 1; r < R; ++r) rl += lane >= S[r] ? 1u : 0u;
+    unsigned head_l = 0, s_l = 0, nn_l = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        head[r] = head_list[w0 + r + offset];
+        pi[r] = pos[w0 + r + offset];
+        const unsigned *nl = nlist + head[r];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const unsigned j = t * 64 + lane;
+            k[r][t] = nl[j < nn[r] ? j : nn[r] - 1];
+        }
+        head_l = rl == (unsigned)r ? head[r] : head_l;
+        s_l = rl == (unsigned)r ? S[r] : s_l;
+        nn_l = rl == (unsigned)r ? nn[r] : nn_l;
+    }
+    const bool tail_live = lane < S[R];
+    const unsigned jt = 128u + (lane - s_l);
+    kt = nlist[head_l + (tail_live ? jt : nn_l - 1)];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) q[r][t] = pos[k[r][t]];
+    qt = pos[kt];
+    float fx[R], fy[R], fz[R], en[R];
+    unsigned npos[R], Q[R];
+    // the first 128 entries of every row
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        float4 *row = STORE ? dest + (size_t)(w0 + r) * NN : nullptr;
+        fx[r] = fy[r] = fz[r] = en[r] = 0.f;
+        npos[r] = 0;
+        Q[r] = 0;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if ((unsigned)t * 64 >= nn[r]) break; // wave-uniform
+            const unsigned j = t * 64 + lane;
+            const PV pk = q[r][t];
+            PT dx, dy, dz;
+            const PT rsq = pair_vector<PT>(pk, pi[r], box, dx, dy, dz);
+            const bool keep = (j < nn[r]) && !(rsq > rmaxsq);
+            const unsigned long long m = __ballot(keep);
+            const unsigned qq = Q[r] + ballot_rank(m);
+            Q[r] += __popcll(m);
+            if (keep && qq < NN) {
+                const float x = (float)dx, y = (float)dy, z = (float)dz;
+                if constexpr (STORE) store_stream(&row[qq], make_float4(x, y, z, (float)scalar_as_int(pk.w)));
+                float e, ax, ay, az;
+                pair_eval<KIND>(x, y, z, p, e, ax, ay, az);
+                fx[r] += ax;
+                fy[r] += ay;
+                fz[r] += az;
+                en[r] += e;
+                npos[r] += x > 0.f ? 1u : 0u;
+            }
+        }
+    }
+    // the shared tail trip
+    if (S[R] != 0) {
+        PV pil = pi[0];
+#pragma unroll
+        for (int r = 1; r < R; ++r) {
+            pil.x = rl == (unsigned)r ? pi[r].x : pil.x;
+            pil.y = rl == (unsigned)r ? pi[r].y : pil.y;
+            pil.z = rl == (unsigned)r ? pi[r].z : pil.z;
+        }
+        PT dx, dy, dz;
+        const PT rsq = pair_vector<PT>(qt, pil, box, dx, dy, dz);
+        const bool keep = tail_live && !(rsq > rmaxsq);
+        const unsigned long long m = __ballot(keep);
+        // rank inside its own row: kept lanes below me, minus those that belong to earlier rows, plus the row's count so far
+        unsigned base_l = Q[0];
+#pragma unroll
+        for (int r = 1; r < R; ++r) {
+            const unsigned before = (unsigned)__popcll(S[r] >= 64u ? m : (m & ((1ull << S[r]) - 1ull)));
+            base_l = rl == (unsigned)r ? Q[r] - before : base_l;
+        }
+        const unsigned qq = base_l + ballot_rank(m);
+        float e = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
+        unsigned px = 0;
+        if (keep && qq < NN) {
+            const float x = (float)dx, y = (float)dy, z = (float)dz;
+            if constexpr (STORE) store_stream(dest + (size_t)(w0 + rl) * NN + qq, make_float4(x, y, z, (float)scalar_as_int(qt.w)));
+            pair_eval<KIND>(x, y, z, p, e, ax, ay, az);
+            px = x > 0.f ? 1u : 0u;
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const bool mine = rl == (unsigned)r;
+            fx[r] += mine ? ax : 0.f;
+            fy[r] += mine ? ay : 0.f;
+            fz[r] += mine ? az : 0.f;
+            en[r] += mine ? e : 0.f;
+            npos[r] += mine ? px : 0u;
+            const unsigned long long seg = (S[r + 1] >= 64u ? ~0ull : ((1ull << S[r + 1]) - 1ull)) & ~(S[r] >= 64u ? ~0ull : ((1ull << S[r]) - 1ull));
+            Q[r] += (unsigned)__popcll(m & seg);
+        }
+    }
+    unsigned redo = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const unsigned w = w0 + r;
+        if (positions_out != nullptr && lane == 0)
+            positions_out[w] = make_float4((float)pi[r].x, (float)pi[r].y, (float)pi[r].z, (float)scalar_as_int(pi[r].w));
+        const unsigned filled = Q[r] < NN ? Q[r] : NN;
+        if constexpr (STORE) {
+            float4 *row = dest + (size_t)w * NN;
+            const unsigned zero_end = counts_io != nullptr ? counts_io[w] : NN;
+            for (unsigned sl = filled + lane; sl < zero_end; sl += 64) store_stream(&row[sl], make_float4(0.f, 0.f, 0.f, 0.f));
+            if (counts_io != nullptr && lane == 0) counts_io[w] = filled;
+        }
+        if (Q[r] > NN) {
+            redo |= 1u << r;
+            continue;
+        }
+        const float sx = group_sum<64>(fx[r]), sy = group_sum<64>(fy[r]), sz = group_sum<64>(fz[r]), se = group_sum<64>(en[r]);
+        unsigned np = 0;
+        if (check_count != nullptr) np = group_sum_u<64>(npos[r]);
+        if (lane == 0) {
+            if (out_f64)
+                ((double4 *)force)[w] = make_double4(sx, sy, sz, se);
+            else
+                ((float4 *)force)[w] = make_float4(sx, sy, sz, se);
+            if (check_count != nullptr && np > *(volatile unsigned *)check_count) atomicMax(check_count, np);
+        }
+    }
+#pragma unroll 1
+    for (unsigned r = 0; r < (unsigned)R; ++r)
+        if ((redo >> r) & 1u) {
+            if constexpr (STORE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            fused_row<KIND, false, STORE, PT>(w0 + r, lane, pos, N, NN, offset, box, n_neigh, nlist, head_list, rmaxsq,
+                                              force, nullptr, out_f64, p, check_count, positions_out, dest, counts_io);
+        }
+}
+
+template <int KIND, bool STORE, int R, typename PT>
+__global__ __launch_bounds__(256) void fused_forces_tails_kernel(
+    const typename Vec4<PT>::type *__restrict__ pos, unsigned N, unsigned NN, unsigned offset, unsigned batch,
+    BoxT<PT> box, const unsigned *__restrict__ n_neigh, const unsigned *__restrict__ nlist,
+    const unsigned *__restrict__ head_list, PT rmaxsq, void *__restrict__ force, int out_f64, PotParams pin,
+    unsigned *__restrict__ check_count, float4 *__restrict__ positions_out, float4 *__restrict__ dest,
+    unsigned *__restrict__ counts_io) {
+    const PotParams p = resolve_theta<KIND>(pin);
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned w0 = R * __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (w0 >= batch) return;
+    fused_rows_group_tails<KIND, STORE, R, PT>(w0, lane, pos, N, NN, offset, batch, box, n_neigh, nlist, head_list, rmaxsq,
+                                               force, out_f64, p, check_count, positions_out, dest, counts_io);
+}
+
 // The kernel strides over the row groups so that HTF_FUSED_GRID=<workgroups per CU> can launch it
 // persistently for A/B runs.  tools/store_probe.hip says a persistent grid helps a bare
 // load-chain + streaming-store kernel (65 -> 46 us); this kernel, whose rows differ in length
@@ -342,6 +537,27 @@ static int launch_fused(const void *pos, unsigned N, unsigned NN, unsigned offse
     hipLaunchKernelGGL((fused_forces_rows2_kernel<KIND, ST, RR, PT>), dim3(grid), dim3(256), 0, s, \
                        (const typename Vec4<PT>::type *)pos, N, NN, offset, batch, b, n_neigh, nlist, head_list,       \
                        (PT)(rc * rc), force, out_f64, p, check_count, positions_out, dest, counts_io)
+        // default for fp32 positions and batches of >= 65 536 rows: four rows per wave with their tails in one trip
+        // (58.0 us against 60.5 for the two-row form at C3 in isolation, 61.5-62.1 against 62.5-63.3 inside the MD loop,
+        // 47.1 against 48.6 without the tensor, 80.7 against 85.4 beside the training stream; two rows with a shared
+        // tail: no gain; at 32 768 rows the four-row form LOSES, 24.0 against 22.8: a quarter of the waves on a grid that
+        // barely fills the chip).  HTF_FUSED_TAILS=0 selects the two-row form everywhere, whose forces do not depend on
+        // how a step is cut into batches / row ranges, bit for bit.
+        static const char *tails_env = getenv("HTF_FUSED_TAILS");
+        const int tails = tails_env ? atoi(tails_env) : ((sizeof(PT) == 4 && batch >= 65536u) ? 4 : 0);
+        if (tails == 2 || tails == 4) {
+#define HTF_TAILS_LAUNCH(ST, RR)                                                                                       \
+    hipLaunchKernelGGL((fused_forces_tails_kernel<KIND, ST, RR, PT>), dim3(((batch + RR - 1) / RR + 3) / 4), dim3(256), 0, s, \
+                       (const typename Vec4<PT>::type *)pos, N, NN, offset, batch, b, n_neigh, nlist, head_list,       \
+                       (PT)(rc * rc), force, out_f64, p, check_count, positions_out, dest, counts_io)
+            if (dest != nullptr) {
+                if (tails == 2) HTF_TAILS_LAUNCH(true, 2); else HTF_TAILS_LAUNCH(true, 4);
+            } else {
+                if (tails == 2) HTF_TAILS_LAUNCH(false, 2); else HTF_TAILS_LAUNCH(false, 4);
+            }
+#undef HTF_TAILS_LAUNCH
+            return check_launch("fused_forces_tails_kernel");
+        }
         if (rows == 2 || rows == 4) {
             if (rows == 2) {
                 if (dest != nullptr) { HTF_ROWS_LAUNCH(true, 2); } else { HTF_ROWS_LAUNCH(false, 2); }

@@ -627,7 +627,10 @@ def test_fused_matches_two_kernel_path_and_oracle(htf, cuda, hdt, NN):
     # batches
     full = htf.ops.fused_forces(htf.Potential.lj(), p4, dnn, dhead, dnl, box, 3.0, NN)
     part = htf.ops.fused_forces(htf.Potential.lj(), p4, dnn, dhead, dnl, box, 3.0, NN, offset=7, batch_size=20)
-    assert torch.equal(part, full[7:27])
+    # (four rows per wave share one trip for their tails when those fit 64 lanes: a row's partial sums then depend
+    #  on its neighbours in the group, i.e. on where the batch starts -- equal to rounding, not bit for bit)
+    scale = float(full.abs().max())
+    assert float((part - full[7:27]).abs().max()) <= 2e-6 * scale
     with pytest.raises(ValueError):
         from hoomd_tf_amd.initializers import mlp_params
         htf.ops.fused_forces(htf.Potential.pair_mlp(mlp_params(), 0, 3), p4, dnn, dhead, dnl, box, 3.0, NN)
@@ -948,7 +951,8 @@ def test_liquid_configuration_bounds(htf, cuda):
     f, v = htf.ops.eval_forces(htf.Potential.lj(), pv, virial=True)
     check("liquid_lj_two_kernel", f)
     assert_forces_close("liquid_lj_virial", v.cpu().numpy(), ref_v, 3.0 * cond, atol=2e-5, cancelling_rows=LIQUID)
-    check("liquid_lj_registers", htf.ops.fused_forces(htf.Potential.lj(), sysm.pos, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, 3.0, NN))
+    fr = htf.ops.fused_forces(htf.Potential.lj(), sysm.pos, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, 3.0, NN)
+    check("liquid_lj_registers", fr)
     pv2 = torch.empty_like(pv)
     fs = htf.ops.fused_forces(htf.Potential.lj(), sysm.pos, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, 3.0, NN, pair_vectors=pv2)
     assert torch.equal(pv2, pv)
@@ -958,6 +962,13 @@ def test_liquid_configuration_bounds(htf, cuda):
     force = torch.zeros((N, 4), dtype=torch.float32, device=cuda)
     ctx.compute_forces(0, ctx.make_arrays(sysm.pos, N, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, force))
     check("liquid_lj_context", force)
+    # batches and row ranges of the liquid (here the four-rows-per-wave form with merged tails runs: ~139 entries per
+    # row, tails of ~11): the tensor is bit-identical however the step is cut, forces agree to rounding
+    part = htf.ops.fused_forces(htf.Potential.lj(), sysm.pos, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, 3.0, NN, offset=5, batch_size=1001)
+    assert float((part - fr[5:1006]).abs().max()) <= 2e-7 * float(cond.max())
+    pv3 = torch.empty((1001, NN, 4), dtype=torch.float32, device=cuda)
+    htf.ops.fused_forces(htf.Potential.lj(), sysm.pos, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, 3.0, NN, offset=5, batch_size=1001, pair_vectors=pv3)
+    assert torch.equal(pv3, pv[5:1006])
     fw = htf.ops.eval_forces(htf.Potential.wca(1.0), pv).cpu().numpy()
     rw = O.wca_model(pv64, 1.0)
     s, t, rp, cnd = O._rinv_and_grad_factor(pv64)
