@@ -207,6 +207,8 @@ __global__ __launch_bounds__(256) void build_nlist_kernel(const typename Vec4<T>
                 unsigned o = (unsigned)__shfl_xor((int)maxlen, m);
                 maxlen = o > maxlen ? o : maxlen;
             }
+            // (four sub-trips per iteration with their loads hoisted: 149 us per rebuild at C3 either way -- the walk is
+            //  VALU-issue bound, ~35 instructions per candidate and 3.7 candidates per hit, not latency-bound)
             for (unsigned t = 0; t < maxlen; t += G) {
                 const unsigned m_idx = t + g;
                 bool hit = false;
