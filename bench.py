@@ -715,9 +715,10 @@ def run_md(args, E, workload, variants=True, cpu=True):
             pmc_file = next(f for f in ("r02_bench_lj_pmc_hbm.json", "r01_bench_lj_pmc_hbm.json")
                             if os.path.exists(os.path.join(ROOT, "profiles", f)))
             pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
-            key = {"build_pair_vectors": "void htf::build_pair_vectors_kernel<float, float>",
-                   "eval_forces": "void htf::eval_pair_kernel<1, 16, false, float>",
-                   "build_eval_forces": "void htf::fused_forces_rows2_kernel<1, true, 2, float>"}[dom]
+            want = {"build_pair_vectors": ("build_pair_vectors_kernel",), "eval_forces": ("eval_pair_kernel<1,",),
+                    # the one-kernel step: four rows per wave with merged tails (default) or the two-row form
+                    "build_eval_forces": ("fused_forces_tails_kernel<1, true", "fused_forces_rows2_kernel<1, true")}[dom]
+            key = next(k for w in want for k in pmc["FETCH_SIZE"] if w in k and k in pmc["WRITE_SIZE"])
             rd, wr = pmc["FETCH_SIZE"][key]["avg_KiB"], pmc["WRITE_SIZE"][key]["avg_KiB"]
             # gfx950: FETCH_SIZE counts half of a wide (16 B/lane) coalesced read stream; the build
             # kernel's reads are 4-B index loads + 16-B gathers, for which the counter is uncalibrated

@@ -1026,3 +1026,93 @@ def test_nlist_buffer_written_by_the_caller_needs_a_reset(htf, cuda):
         ctx.reset_nlist_buffer()
         ctx.compute_forces(1, arr)
         np.testing.assert_array_equal(ctx.nlist_buffer(N, cuda).cpu().numpy(), ref)
+
+
+def _jittered(standin, cuda, lattice, cells, seed):
+    pos, L, a = (standin.sc_positions if lattice == "sc" else standin.fcc_positions)(cells, 0.8442)
+    rng = np.random.default_rng(seed)
+    pos = pos + 0.05 * a * rng.standard_normal(pos.shape)
+    pos -= np.round(pos / L) * L
+    sysm = standin.System(pos, L, dtype=torch.float32, device=cuda)
+    nl = standin.CellNlist(sysm, r_cut=3.0, r_buff=0.4)
+    nl.build()
+    return sysm, nl, L
+
+
+def test_full_size_c2_wca(htf, cuda):
+    """BASELINE configs[1] at its own size -- WCARepulsion, 32 768 particles (sc 32^3), NN 128 -- from HOOMD-layout
+    arrays through the context: a row sample against the oracle, and size-independent properties."""
+    from hoomd_tf_amd import standin
+    sysm, nl, L = _jittered(standin, cuda, "sc", 32, 2)
+    N, NN = sysm.N, 128
+    assert N == 32768
+    pot = htf.Potential.wca(1.0)
+    forces = {}
+    for fused in (0, 1, 2):
+        ctx = htf.Context(r_cut=3.0, nneighs=NN, max_n=N, fused=fused)
+        ctx.set_potential(pot)
+        f = torch.zeros((N, 4), dtype=torch.float32, device=cuda)
+        ctx.compute_forces(0, ctx.make_arrays(sysm.pos, N, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, f))
+        forces[fused] = f
+        if fused != 1:
+            pv = ctx.nlist_buffer(N, cuda).clone()
+    rows = np.random.default_rng(0).choice(N, 512, replace=False)
+    p32 = sysm.pos.cpu().numpy()[:, :3]
+    ref_pv = O.prepare_neighbors(p32, np.zeros(N, np.int32), nl.n_neigh.cpu().numpy().view(np.uint32),
+                                 nl.head_list.cpu().numpy().view(np.uint32), nl.nlist.cpu().numpy().view(np.uint32),
+                                 O.make_box(L, dtype=np.float32), 3.0, NN)[rows]
+    np.testing.assert_array_equal(pv.cpu().numpy()[rows], ref_pv)                   # bit-exact pair vectors
+    sub = ref_pv.astype(np.float64)
+    ref = O.wca_model(sub, 1.0)
+    s, t, rp, cnd = O._rinv_and_grad_factor(sub)
+    cond = _cond_scale(sub, 2 * O._grad_from_dEds(6 * s ** 5, s, t, rp, cnd))
+    for fused, f in forces.items():
+        assert_forces_close("c2_wca_fused%d" % fused, f.cpu().numpy()[rows], ref, cond, cancelling_rows=CONTACTS)
+    # properties: Newton's third law over the whole periodic system (every pair appears in both rows), a
+    # repulsive energy, determinism
+    tot = forces[2][:, :3].double().sum(dim=0).abs().max().item()
+    assert tot <= 1e-4 * forces[2][:, :3].abs().double().sum().item() / N * 50
+    assert float(forces[2][:, 3].min()) >= 0.0 and float(forces[2][:, 3].max()) <= 10.0 * NN
+    f_again = torch.zeros_like(forces[2])
+    ctx.compute_forces(0, ctx.make_arrays(sysm.pos, N, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, f_again))
+    assert torch.equal(f_again, forces[2])
+
+
+def test_full_size_c4_eds_sweep(htf, cuda):
+    """BASELINE configs[3] at its own size -- 262 144 particles (sc 64^3), NN 128, LJ + Gaussian CV channel + RDF
+    histogram in ONE kernel: row samples of both force sets against the oracle, the CV against an fp64 sum, the
+    histogram against its total-count identity and against the stand-alone histogram kernel."""
+    from hoomd_tf_amd import standin
+    sysm, nl, L = _jittered(standin, cuda, "sc", 64, 4)
+    N, NN = sysm.N, 128
+    assert N == 262144
+    lj, gauss = htf.Potential.lj(), htf.Potential.gauss(1.1, 0.05, 1.0)
+    pv = torch.zeros((N, NN, 4), dtype=torch.float32, device=cuda)
+    npart = htf.ops.num_partials_fused(N)
+    partials = torch.empty(npart, dtype=torch.float32, device=cuda)
+    hist = torch.zeros(102, dtype=torch.int32, device=cuda)
+    fa, fb = htf.ops.build_eval_forces2(lj, gauss, sysm.pos, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, 3.0, NN, partials=partials,
+                                        rdf=(0.0, 3.5, hist), pair_vectors=pv)
+    cv = torch.zeros(1, dtype=torch.float32, device=cuda)
+    htf.ops.reduce_partials(partials, npart, 1.0 / N, cv)
+    rows = np.random.default_rng(1).choice(N, 384, replace=False)
+    sub = pv.cpu().numpy()[rows].astype(np.float64)
+    assert_forces_close("c4_lj_rows", fa.cpu().numpy()[rows], O.lj_model(sub), _cond_scale(sub, _pair_forces_lj(sub)), cancelling_rows=CONTACTS)
+    _, g = O.gauss_pair_terms(sub, 1.1, 0.05)
+    assert_forces_close("c4_gauss_rows", fb.cpu().numpy()[rows], O.gauss_model(sub, 1.1, 0.05, 1.0), np.abs(2 * g).sum(axis=(1, 2)),
+                        ctol=4e-6, cancelling_rows=CONTACTS)
+    # the tensor of the one-kernel sweep == the build kernel's
+    ref_pv = htf.ops.build_pair_vectors(sysm.pos, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, 3.0, NN)
+    assert torch.equal(pv, ref_pv)
+    # CV = (1/N) sum of the Gaussian energy column, in fp64
+    np.testing.assert_allclose(float(cv), fb[:, 3].double().sum().item() / N, rtol=2e-6)
+    # histogram: every slot of the tensor lands in exactly one bin; equal to the stand-alone kernel's
+    assert int(hist.sum()) == N * NN
+    h2 = torch.zeros(102, dtype=torch.int32, device=cuda)
+    import ctypes as C
+    from hoomd_tf_amd._lib import lib, check
+    check(lib.htf_rdf_histogram(pv.data_ptr(), 0, N, NN, 0.0, 3.5, 102, None, 0, -1, -1, h2.data_ptr(),
+                                C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    assert torch.equal(hist, h2)
+    rsub = np.sqrt((pv.cpu().numpy()[rows][:, :, :3].astype(np.float32) ** 2).sum(axis=2, dtype=np.float32))
+    np.testing.assert_array_equal(O.histogram_fixed_width(rsub.astype(np.float32), np.array([0.0, 3.5], np.float32), 102).sum(), 384 * NN)
