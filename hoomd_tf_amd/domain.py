@@ -55,6 +55,11 @@ class _StagedHalo:
             dev.copy_(host)
 
 
+def _lib_error():
+    from ._lib import last_error
+    return last_error()
+
+
 class _NativeHalo:
     """The per-step halo through libhtf_amd.so's own RCCL communicator (csrc/halo.hip): one grouped
     ncclSend x2 / ncclRecv x2 on a dedicated stream, two events, no Python objects per message."""
@@ -63,17 +68,23 @@ class _NativeHalo:
         import ctypes as C
         from ._lib import lib, check
         self._C, self._lib, self._check = C, lib, check
-        ident = torch.zeros(128, dtype=torch.uint8)
+        # 128 bytes of id + one status byte: if rank 0 cannot obtain an id, every rank learns it from the SAME
+        # broadcast and gives up together (no rank is left waiting in a collective)
+        ident = torch.zeros(129, dtype=torch.uint8)
         if rank == 0:
             buf = (C.c_char * 128)()
-            check(lib.htf_halo_unique_id(buf))
-            ident = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+            if lib.htf_halo_unique_id(buf) == 0:
+                ident[:128] = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8)
+                ident[128] = 1
         if dist.get_backend(group) == "nccl":  # the id travels through whatever channel the job has
             dev = ident.cuda()
             dist.broadcast(dev, src=0, group=group)
             ident = dev.cpu()
         else:
             dist.broadcast(ident, src=0, group=group)
+        if int(ident[128]) != 1:
+            raise RuntimeError("rank 0 could not obtain an RCCL unique id: " + _lib_error())
+        ident = ident[:128].contiguous()
         self._h = C.c_void_p()
         raw = (C.c_char * 128).from_buffer_copy(bytes(ident.numpy().tobytes()))
         check(lib.htf_halo_create(raw, int(rank), int(world), C.byref(self._h)))
@@ -189,54 +200,105 @@ class SlabDomain:
         x = pv[:, 0].contiguous()
         # The integrator wraps into the global box, so the new owner is found by position and
         # is an adjacent slab by construction (rebuilds happen before anything moves r_buff/2).
-        cuts = torch.as_tensor(self.bounds[1:-1], dtype=x.dtype, device=x.device)
-        owner = torch.bucketize(x, cuts, right=True)
+        bnd = torch.as_tensor(self.bounds, dtype=x.dtype, device=x.device)
+        owner = torch.bucketize(x, bnd[1:-1].contiguous(), right=True)
         if self.world == 2:
             dest = (owner != self.rank).to(torch.int64) * 2  # one peer: everything travels as the R> message
         else:
             go_left, go_right = owner == self.left, owner == self.right
             lost = (owner != self.rank) & ~go_left & ~go_right
             dest = go_left.to(torch.int64) + 2 * go_right.to(torch.int64) + 3 * lost.to(torch.int64)
-        # partition [stay | L> | R>] with one stable sort; sizes come back with the neighbors' in
-        # one gather (no masked selects: each of those is a hidden host synchronisation)
-        ones = torch.ones_like(dest)
-        cnt = torch.zeros(4, dtype=torch.int64, device=x.device).index_add_(0, dest, ones)
-        allc = self._gather_counts(cnt)
+        # Ghost class IN THE SLAB THE PARTICLE ENDS UP IN (the sender knows every slab's bounds): 0 interior,
+        # 1 near the left face only, 2 near both faces (slabs thinner than 2 r_ghost), 3 near the right face only.
+        # One stable sort on (destination, class) and ONE exchange of the 16 counts then carry both the migration
+        # plan and the ghost plan: each rank can work out every rank's class counts after the migration, so the
+        # second count exchange of the first version (and its device -> host round trip) is gone.
+        near_l, near_r = x < bnd[owner] + self.r_ghost, x >= bnd[owner + 1] - self.r_ghost
+        cls = torch.where(near_l, torch.where(near_r, 2, 1), torch.where(near_r, 3, 0))
+        key = dest * 4 + cls
+        cnt = torch.zeros(16, dtype=torch.int64, device=x.device).index_add_(0, key, torch.ones_like(key))
+        allc = self._gather_counts(cnt).reshape(self.world, 4, 4)  # [rank, destination, class]
         if allc[:, 3].any():
             raise RuntimeError("a particle crossed more than one slab between neighbor-list rebuilds")
-        n_stay, n_l, n_r = (int(v) for v in allc[self.rank][:3])
-        pv = pv.index_select(0, torch.sort(dest, stable=True)[1])
+        mine = allc[self.rank]
+        n_stay, n_l, n_r = (int(mine[d].sum()) for d in range(3))
+        pv = pv.index_select(0, torch.sort(key, stable=True)[1])
         pack_l = pv[n_stay:n_stay + n_l].contiguous()
         pack_r = pv[n_stay + n_l:n_stay + n_l + n_r].contiguous()
-        got_r, got_l = self._swap(pack_l, pack_r, int(allc[self.right][1]), int(allc[self.left][2]))
+        in_r, in_l = allc[self.right][1], allc[self.left][2]  # class counts of what arrives from the right / left
+        got_r, got_l = self._swap(pack_l, pack_r, int(in_r.sum()), int(in_l.sum()))
         self.n_migrated += int(got_r.shape[0] + got_l.shape[0])
         pv = torch.cat([pv[:n_stay], got_r, got_l], dim=0)
         N = int(pv.shape[0])
-        # ghost plan: who sits within r_ghost of a face.  Classes 0 interior, 1 left face only,
-        # 2 both faces (only in slabs thinner than 2 r_ghost), 3 right face only; a stable sort on
-        # the class puts the two send sets behind the interior particles as [1 | 2] and [2 | 3].
-        x = pv[:, 0]
-        near_l, near_r = x < self.xlo + self.r_ghost, x >= self.xhi - self.r_ghost
-        cls = torch.where(near_l, torch.where(near_r, 2, 1), torch.where(near_r, 3, 0))
-        cnt = torch.zeros(4, dtype=torch.int64, device=x.device).index_add_(0, cls, torch.ones_like(cls))
-        allc = self._gather_counts(cnt)
-        pv = pv.index_select(0, torch.sort(cls, stable=True)[1])
+        # every segment arrives sorted by class; one stable sort of the (known) class vector merges the three
+        seg = torch.as_tensor(np.concatenate([mine[0], in_r, in_l]), dtype=torch.int64, device=x.device)
+        cls_all = torch.repeat_interleave(torch.arange(4, device=x.device).repeat(3), seg)
+        pv = pv.index_select(0, torch.sort(cls_all, stable=True)[1])
         new_pos, new_vel = pv[:, :4], pv[:, 4:]
-        c0, c1, c2, c3 = (int(v) for v in allc[self.rank])
+
+        def after(q):  # rank q's class counts once everybody has migrated
+            return allc[q][0] + allc[(q + 1) % self.world][1] + allc[(q - 1) % self.world][2]
+
+        c0, c1, c2, c3 = (int(v) for v in after(self.rank))
+        assert c0 + c1 + c2 + c3 == N
         self.class_counts = (c0, c1, c2, c3)
         self.n_interior = c0
         self.send_left = (c0, c0 + c1 + c2)
         self.send_right = (c0 + c1, N)
-        self.n_from_right = int(allc[self.right][1] + allc[self.right][2])
-        self.n_from_left = int(allc[self.left][2] + allc[self.left][3])
+        cr, cl = after(self.right), after(self.left)
+        self.n_from_right = int(cr[1] + cr[2])
+        self.n_from_left = int(cl[2] + cl[3])
         s.N = N
         s.n_ghost = self.n_from_left + self.n_from_right
-        s.pos = torch.cat([new_pos, torch.zeros((s.n_ghost, 4), dtype=new_pos.dtype, device=new_pos.device)], dim=0)
+        # positions live in a buffer that only grows: no allocation per rebuild, and the pointer the force path
+        # and the halo see stays put
+        need = N + s.n_ghost
+        if getattr(self, "_pos_buf", None) is None or self._pos_buf.shape[0] < need or self._pos_buf.dtype != new_pos.dtype:
+            self._pos_buf = torch.zeros((int(need * 1.2) + 64, 4), dtype=new_pos.dtype, device=new_pos.device)
+        self._pos_buf[:N] = new_pos
+        s.pos = self._pos_buf[:need]
         s.vel = new_vel.contiguous()
         if s.force.shape[0] != N:
             s.force = torch.zeros((N, 4), dtype=s.dtype, device=s.pos.device)
             s.virial = torch.zeros(6 * N, dtype=s.dtype, device=s.pos.device)
+        if self.transport_request != "torch" and self._native is None:
+            self._try_native()
         self.exchange()
+
+    def _try_native(self):
+        """Bring up the native transport and check it ONCE against the torch one (same slices, same ghosts)."""
+        want, self.transport_request = self.transport_request, "torch"  # decided once
+        s = self.sys
+        try:
+            from ._lib import lib
+            if not s.pos.is_cuda or dist.get_backend(self.group) != "nccl" or not lib.htf_halo_available():
+                if want == "native":
+                    raise RuntimeError("native halo needs device positions, the nccl backend and a loadable librccl")
+                return
+            native, err = None, ""
+            try:
+                native = _NativeHalo(self.rank, self.world, self.group)
+            except Exception as e:  # noqa: BLE001 -- every rank must reach the agreement below
+                err = str(e)
+            agreed = torch.tensor([0.0 if native is None else 1.0], device=s.pos.device)
+            dist.all_reduce(agreed, op=dist.ReduceOp.MIN, group=self.group)
+            if float(agreed.item()) != 1.0:
+                raise RuntimeError("communicator bring-up failed on some rank" + (": " + err if err else ""))
+            self.exchange()  # torch transport: the reference result
+            ghosts = s.pos[s.N:s.N + s.n_ghost].clone()
+            s.pos[s.N:s.N + s.n_ghost] = float("nan")
+            self._native, self.transport = native, "native"
+            self.exchange()
+            same = torch.equal(s.pos[s.N:s.N + s.n_ghost], ghosts)
+            ok = torch.tensor([1.0 if same else 0.0], device=s.pos.device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+            if float(ok.item()) != 1.0:
+                raise RuntimeError("native halo delivered different ghosts than torch.distributed")
+        except Exception as e:  # noqa: BLE001
+            self._native, self.transport = None, "torch"
+            if want == "native":
+                raise
+            self.transport_note = "native halo not used: %s" % (e,)
 
     def row_classes(self):
         """Class id (0..3, see rebuild) of every local row: a particle sorter may only permute
