@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void eval_pair2_kernel(const typename Vec4<IT>
                 bx += fx; by += fy; bz += fz; be += e;
                 if (rdf.hist != nullptr && active && j0 + u * G + g < NN) {
                     // compute_rdf (simmodel.py:661-662): plain norm, histogram_fixed_width clamping
-                    const float r = sqrtf(v[u].x * v[u].x + v[u].y * v[u].y + v[u].z * v[u].z);
+                    const float r = plain_norm3(v[u].x, v[u].y, v[u].z);
                     const float fi = floorf((float)rdf.nb * ((r - rdf.r0) / (rdf.r1 - rdf.r0)));
                     const int idx = fi < 0.f ? 0 : (fi > (float)(rdf.nb - 1) ? (int)(rdf.nb - 1) : (int)fi);
                     // the clamped end bins take every padded slot (26 % of the tensor lands in bin 0):

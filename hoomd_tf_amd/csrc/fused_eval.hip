@@ -649,8 +649,15 @@ __global__ __launch_bounds__(256) void fused_forces2_kernel(
         pair_eval<HTF_POT_GAUSS>(x, y, z, pb, e, fx, fy, fz);
         bx += fx; by += fy; bz += fz; be += e;
         if (do_rdf) {
-            const float r = sqrtf(x * x + y * y + z * z);
-            const float fi = floorf((r - rdf.r0) * rdf_scale);
+            // tf.histogram_fixed_width: floor(nbins * ((v - lo) / (hi - lo))) in fp32, division included.  The
+            // multiply by nbins / (hi - lo) gives the same bin except within a few ulps of an edge: only there is the
+            // division taken (33 M slots at C4: the two forms disagreed on a handful -- caught by
+            // test_full_size_c4_eds_sweep, invisible at fixture size)
+            const float r = plain_norm3(x, y, z);
+            const float d = r - rdf.r0;
+            const float qf = d * rdf_scale;
+            float fi = floorf(qf);
+            if (fabsf(qf - rintf(qf)) <= 1e-5f * fmaxf(1.f, fabsf(qf))) fi = floorf((float)rdf.nb * (d / (rdf.r1 - rdf.r0)));
             const int idx = fi < 0.f ? 0 : (fi > (float)(rdf.nb - 1) ? (int)(rdf.nb - 1) : (int)fi);
             if (idx == 0) ++n_lo;
             else if (idx == (int)rdf.nb - 1) ++n_hi;

@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void rdf_hist_kernel(const typename Vec4<IT>::
         float x = (float)v.x, y = (float)v.y, z = (float)v.z;
         // masked_nlist type_j: nlist * mask zeroes the slot (simmodel.py:687-691)
         if (type_j >= 0 && (float)v.w != (float)type_j) x = y = z = 0.f;
-        const float r = sqrtf(x * x + y * y + z * z);
+        const float r = plain_norm3(x, y, z);
         // tf.histogram_fixed_width: floor(nbins * (v - lo) / (hi - lo)) clipped to [0, nbins-1]
         float fi = floorf((float)nb * ((r - r0) / width));
         int idx = fi < 0.f ? 0 : (fi > (float)(nb - 1) ? (int)(nb - 1) : (int)fi);

@@ -1070,8 +1070,10 @@ def test_full_size_c2_wca(htf, cuda):
         assert_forces_close("c2_wca_fused%d" % fused, f.cpu().numpy()[rows], ref, cond, cancelling_rows=CONTACTS)
     # properties: Newton's third law over the whole periodic system (every pair appears in both rows), a
     # repulsive energy, determinism
+    # (not exactly zero even in exact arithmetic: safe_norm adds 1e-7 to every component, so F_ij + F_ji is
+    #  2e-7 * |f_ij| / r, the reference's own asymmetry)
     tot = forces[2][:, :3].double().sum(dim=0).abs().max().item()
-    assert tot <= 1e-4 * forces[2][:, :3].abs().double().sum().item() / N * 50
+    assert tot <= 2e-6 * forces[2][:, :3].abs().double().sum().item()
     assert float(forces[2][:, 3].min()) >= 0.0 and float(forces[2][:, 3].max()) <= 10.0 * NN
     f_again = torch.zeros_like(forces[2])
     ctx.compute_forces(0, ctx.make_arrays(sysm.pos, N, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, f_again))
@@ -1114,5 +1116,10 @@ def test_full_size_c4_eds_sweep(htf, cuda):
     check(lib.htf_rdf_histogram(pv.data_ptr(), 0, N, NN, 0.0, 3.5, 102, None, 0, -1, -1, h2.data_ptr(),
                                 C.c_void_p(torch.cuda.current_stream().cuda_stream)))
     assert torch.equal(hist, h2)
-    rsub = np.sqrt((pv.cpu().numpy()[rows][:, :, :3].astype(np.float32) ** 2).sum(axis=2, dtype=np.float32))
-    np.testing.assert_array_equal(O.histogram_fixed_width(rsub.astype(np.float32), np.array([0.0, 3.5], np.float32), 102).sum(), 384 * NN)
+    # ... and to the oracle's tf.histogram_fixed_width over ALL 33.5 M slots, bin for bin: pairs within an ulp of a bin
+    # edge are decided by the roundings of tf.norm and of (v - lo) / (hi - lo) (uncontracted products and sums,
+    # correctly rounded sqrt and division) -- the first version of this sweep multiplied by nbins / (hi - lo) and let
+    # the compiler fuse x*x + y*y + z*z, and disagreed on 4 pairs at this size while passing every fixture-size test
+    x3 = pv.cpu().numpy()[:, :, :3]
+    r_all = np.sqrt((x3 * x3).sum(axis=2, dtype=np.float32)).astype(np.float32)
+    np.testing.assert_array_equal(hist.cpu().numpy(), O.histogram_fixed_width(r_all, np.array([0.0, 3.5], np.float32), 102))
