@@ -1123,3 +1123,28 @@ def test_full_size_c4_eds_sweep(htf, cuda):
     x3 = pv.cpu().numpy()[:, :, :3]
     r_all = np.sqrt((x3 * x3).sum(axis=2, dtype=np.float32)).astype(np.float32)
     np.testing.assert_array_equal(hist.cpu().numpy(), O.histogram_fixed_width(r_all, np.array([0.0, 3.5], np.float32), 102))
+
+
+@pytest.mark.parametrize("lattice,cells", [("sc", 32), ("fcc", 32)])
+def test_full_size_pair_vectors_every_row_bit_exact(htf, cuda, lattice, cells):
+    """prepareNeighbors at C2 (32 768) and C3 (131 072) size, EVERY row bit for bit: the build kernel, the one-kernel
+    step's tensor and the four-rows-per-wave form against the C restatement (itself bit-exact against the numpy
+    oracle, tests/test_oracle_c.py)."""
+    from hoomd_tf_amd import standin
+    from oracle import c_oracle
+    sysm, nl, L = _jittered(standin, cuda, lattice, cells, 7)
+    N, NN = sysm.N, 128
+    ref = c_oracle.prepare_neighbors(c_oracle.load(), sysm.pos.cpu().numpy(), nl.n_neigh.cpu().numpy().view(np.uint32),
+                                     nl.head_list.cpu().numpy().view(np.uint32), nl.nlist.cpu().numpy().view(np.uint32),
+                                     O.make_box(L, dtype=np.float32), 3.0, NN)
+    pv = htf.ops.build_pair_vectors(sysm.pos, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, 3.0, NN)
+    np.testing.assert_array_equal(pv.cpu().numpy(), ref)
+    pv2 = torch.full_like(pv, 3.0)
+    htf.ops.fused_forces(htf.Potential.lj(), sysm.pos, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, 3.0, NN, pair_vectors=pv2)
+    assert torch.equal(pv2, pv)
+    ctx = htf.Context(r_cut=3.0, nneighs=NN, max_n=N, fused=2)
+    ctx.set_potential(htf.Potential.lj())
+    f = torch.zeros((N, 4), dtype=torch.float32, device=cuda)
+    for ts in range(2):  # second call: the delta zero-fill path (rows keep their live counts)
+        ctx.compute_forces(ts, ctx.make_arrays(sysm.pos, N, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, f))
+        assert torch.equal(ctx.nlist_buffer(N, cuda), pv)

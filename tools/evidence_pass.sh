@@ -20,6 +20,8 @@ python bench.py --workload eds 2>/dev/null | jl > $F/bench_eds.json
 HTF_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 20 --warmup 5 --no-cpu-baseline --no-fused 2>/dev/null | jl > $F/bench_rehearsal_2ranks_strong_gloo.json
 HTF_BENCH_BACKEND=gloo python bench.py --gpus 8 --steps 20 --warmup 5 --no-cpu-baseline --no-fused 2>/dev/null | jl > $F/bench_rehearsal_8ranks_strong_gloo.json
 HTF_BENCH_BACKEND=gloo python bench.py --gpus 2 --scaling weak --steps 20 --warmup 5 --no-cpu-baseline --no-fused 2>/dev/null | jl > $F/bench_rehearsal_2ranks_weak_gloo.json
+# the driver's own launch form for N > 1 (torch.distributed.run), rehearsed the same way
+HTF_BENCH_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 20 --warmup 5 --no-cpu-baseline --no-fused 2>/dev/null | jl > $F/bench_rehearsal_2ranks_strong_torchrun_gloo.json
 # config 5 at its full size (8 x 131072 = 1.05 M particles, force matching on), the 8 ranks sharing this one GPU
 HTF_BENCH_BACKEND=gloo python bench.py --gpus 8 --scaling weak --workload mlp-train --train-period 10 --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | jl > $F/bench_rehearsal_c5_8ranks_weak_mlptrain_gloo.json
 ./tools/gather_probe2 > $F/gather_probe2.txt 2>&1
