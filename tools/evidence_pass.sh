@@ -22,6 +22,7 @@ HTF_BENCH_BACKEND=gloo python bench.py --gpus 8 --steps 20 --warmup 5 --no-cpu-b
 HTF_BENCH_BACKEND=gloo python bench.py --gpus 2 --scaling weak --steps 20 --warmup 5 --no-cpu-baseline --no-fused 2>/dev/null | jl > $F/bench_rehearsal_2ranks_weak_gloo.json
 # the driver's own launch form for N > 1 (torch.distributed.run), rehearsed the same way
 HTF_BENCH_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 20 --warmup 5 --no-cpu-baseline --no-fused 2>/dev/null | jl > $F/bench_rehearsal_2ranks_strong_torchrun_gloo.json
+HTF_BENCH_BACKEND=gloo python bench.py --gpus 2 --workload mlp --steps 10 --warmup 3 --equil 60 --no-cpu-baseline --no-fused 2>/dev/null | jl > $F/bench_rehearsal_2ranks_strong_mlp_gloo.json
 # config 5 at its full size (8 x 131072 = 1.05 M particles, force matching on), the 8 ranks sharing this one GPU
 HTF_BENCH_BACKEND=gloo python bench.py --gpus 8 --scaling weak --workload mlp-train --train-period 10 --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | jl > $F/bench_rehearsal_c5_8ranks_weak_mlptrain_gloo.json
 ./tools/gather_probe2 > $F/gather_probe2.txt 2>&1
@@ -42,6 +43,13 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/c_w -o w -- python3 bench
 for set in "TA_TA_BUSY_sum TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TOTAL_ACCESSES_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_WAVES" "GRBM_GUI_ACTIVE GRBM_COUNT"; do
   n=$(echo $set | tr ' ' '_' | cut -c1-40); rm -rf /tmp/pk_$n
   rocprofv3 --pmc $set --output-format csv -d /tmp/pk_$n -o x -- python3 bench.py $S > /dev/null 2>&1
+done
+# the C2 and C4 kernels: where their time goes (same counter sets as the LJ step)
+C2="--workload wca --lattice sc --cells 32 --no-cpu-baseline --no-fused --steps 20 --warmup 5 --equil 60 --windows 1"
+for set in "TA_TA_BUSY_sum TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES" "GRBM_GUI_ACTIVE GRBM_COUNT"; do
+  n=$(echo $set | tr ' ' '_' | cut -c1-40); rm -rf /tmp/p2_$n /tmp/p4_$n
+  rocprofv3 --pmc $set --output-format csv -d /tmp/p2_$n -o x -- python3 bench.py $C2 > /dev/null 2>&1
+  rocprofv3 --pmc $set --output-format csv -d /tmp/p4_$n -o x -- python3 bench.py --workload eds --steps 20 --warmup 5 --equil 40 > /dev/null 2>&1
 done
 # matrix-pipe counters of the pair-MLP kernels (evaluator fp32 / split, training sweep)
 M="--no-cpu-baseline --steps 6 --warmup 2 --equil 20 --windows 1"
@@ -72,6 +80,9 @@ lj = collect("/tmp/pk_*/**/*counter_collection.csv", want=["fused_forces_rows2_k
 json.dump(lj, open(F + "/pmc_lj_kernel.json", "w"), indent=1)
 mlp = collect("/tmp/pm_*/**/*counter_collection.csv", want=["pair_mlp_kernel"])
 trn = collect("/tmp/pt_*/**/*counter_collection.csv", want=["mlp_grad", "pair_mlp_kernel"])
+c2 = collect("/tmp/p2_*/**/*counter_collection.csv", want=["fused_forces_rows2_kernel", "fused_forces_tails_kernel"])
+c4 = collect("/tmp/p4_*/**/*counter_collection.csv", want=["fused_forces2_kernel"])
+json.dump({"C2 (bench.py --workload wca --lattice sc --cells 32)": c2, "C4 (bench.py --workload eds)": c4}, open(F + "/pmc_c2_c4.json", "w"), indent=1)
 json.dump({"evaluator (bench.py --workload mlp, fp32 MFMA + the split variant)": mlp, "training (bench.py --workload mlp-train)": trn,
            "_note": "SQ_INSTS_MFMA: wave-level MFMA instructions; SQ_VALU_MFMA_BUSY_CYCLES: cycles the matrix pipe is busy, summed over SIMDs; "
                     "matrix pipe busy fraction = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)"}, open(F + "/pmc_mlp.json", "w"), indent=1)
