@@ -345,6 +345,33 @@ def run_eds(args, htf, standin, dev):
                      "frac": ach / HBM_PEAK_GBS, "traffic": None},
         "cpu_baseline": None,
     }
+    if not args.no_cpu_baseline:
+        # the C/OpenMP restatement of the same step: prepareNeighbors + (LJ + alpha * soft-RDF CV forces, CV, compute_rdf
+        # histogram) over the same 262 144 x 128 workload, a bounded number of passes
+        from oracle import c_oracle
+        clib = c_oracle.load()
+        pos4 = sysm.pos.cpu().numpy().astype(np.float32)
+        nn_h = nl.n_neigh.cpu().numpy().view(np.uint32)
+        head_h = nl.head_list.cpu().numpy().view(np.uint32)
+        nl_h = nl.nlist.cpu().numpy().view(np.uint32)
+        f_h = np.empty((N, 4), dtype=np.float32)
+        alpha_h = float(eds.state[2])
+
+        def one():
+            pvh = c_oracle.prepare_neighbors(clib, pos4, nn_h, head_h, nl_h, sysm.box3x3, args.rcut, NN)
+            c_oracle.eds_from_nlist(clib, pvh, alpha_h, 1.1, 0.05, (0.0, 3.5), 102, out=f_h)
+        one()
+        t0, reps = time.perf_counter(), 0
+        while True:
+            one()
+            reps += 1
+            el = time.perf_counter() - t0
+            if el > args.cpu_seconds or reps >= 200:
+                break
+        out["cpu_baseline"] = {"value": reps / el, "unit": "steps/s", "cores": int(clib.htfo_num_threads()), "kind": "port",
+                               "sample": "%d computeForces passes (prepareNeighbors + LJModel + alpha * soft-RDF CV + compute_rdf histogram, "
+                                         "C/OpenMP restatement, fp32) over the same %d x %d workload; EDS update and integrator not included"
+                                         % (reps, N, NN)}
     print(json.dumps(out))
 
 

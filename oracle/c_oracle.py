@@ -100,3 +100,16 @@ def mlp_from_nlist(lib, nl, params, low=0.0, high=3.0, act="tanh", out=None):
     lib.htfo_mlp_from_nlist(_p(nl), C.c_uint(N), C.c_uint(NN), C.c_int(K), C.c_int(H1), C.c_int(H2), C.c_float(low),
                             C.c_float(high), *[_p(w) for w in ws], C.c_int(1 if act == "tanh" else 0), _p(out))
     return out
+
+
+def eds_from_nlist(lib, nl, alpha, r0, gap, rdf_range=(0.0, 3.5), nb_total=102, out=None):
+    """Config C4's model (LJ + alpha * soft-RDF CV, compute_rdf histogram) -> (forces [N, 4], cv, hist [nb_total])."""
+    N, NN = nl.shape[:2]
+    if out is None:
+        out = np.empty((N, 4), dtype=np.float32)
+    hist = np.zeros(nb_total, dtype=np.uint64)
+    nl = nl if (nl.dtype == np.float32 and nl.flags.c_contiguous) else np.ascontiguousarray(nl, dtype=np.float32)
+    lib.htfo_eds_from_nlist.restype = C.c_double
+    cv = lib.htfo_eds_from_nlist(_p(nl), C.c_uint(N), C.c_uint(NN), C.c_float(alpha), C.c_float(r0), C.c_float(gap),
+                                 C.c_float(rdf_range[0]), C.c_float(rdf_range[1]), C.c_uint(nb_total), _p(hist), _p(out))
+    return out, float(cv), hist

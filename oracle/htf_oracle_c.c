@@ -288,3 +288,62 @@ void htfo_compute_forces_wca_f32(const float *pos4, unsigned N, const uint32_t *
     htfo_prepare_neighbors_f32(scratch, pos4, n_neigh, head_list, nlist, lo, hi, tilt, periodic, r_cut, NN, 0, N);
     htfo_wca_from_nlist(scratch, N, NN, sigma, force);
 }
+
+/* Config C4's model on a dense fp32 nlist (oracle/htf_oracle.py:eds_rdf_model + compute_rdf): LJModel + alpha *
+ * soft-RDF CV with cv = (1/N) sum_i sum_j exp(-(r - r0)^2 / gap) [r > 3e-6], r = safe_norm(x); energy column
+ * E_lj,i + alpha * cv; forces = compute_nlist_forces; plus the compute_rdf histogram over nb_total bins of
+ * tf.histogram_fixed_width semantics (hist: nb_total uint64 counters, zeroed here).  Two passes, as the alpha * cv
+ * term of every energy needs the global cv.  Returns cv. */
+double htfo_eds_from_nlist(const float *nl, unsigned N, unsigned NN, float alpha, float r0, float gap, float rdf_r0,
+                           float rdf_r1, unsigned nb_total, unsigned long long *hist, float *force) {
+    double cv_sum = 0.0;
+    for (unsigned b = 0; b < nb_total; ++b) hist[b] = 0;
+#pragma omp parallel
+    {
+        unsigned long long *h = (unsigned long long *)calloc(nb_total, sizeof(unsigned long long));
+        double cv_local = 0.0;
+#pragma omp for schedule(static)
+        for (long i = 0; i < (long)N; ++i) {
+            const float *row = nl + (size_t)i * NN * 4;
+            float fx = 0, fy = 0, fz = 0, en = 0, phis = 0;
+            for (unsigned j = 0; j < NN; ++j) {
+                const float x = row[4 * j], y = row[4 * j + 1], z = row[4 * j + 2];
+                /* compute_rdf: plain norm, every slot (padding included) lands in a bin */
+                const float rr = sqrtf((x * x + y * y) + z * z);
+                float fi = floorf((float)nb_total * ((rr - rdf_r0) / (rdf_r1 - rdf_r0)));
+                const long bin = fi < 0.f ? 0 : (fi > (float)(nb_total - 1) ? (long)(nb_total - 1) : (long)fi);
+                h[bin] += 1;
+                const float tx = x + NORM_DELTA, ty = y + NORM_DELTA, tz = z + NORM_DELTA;
+                const float rp = sqrtf(tx * tx + ty * ty + tz * tz);
+                if (!(rp > RINV_DELTA)) continue;
+                const float s = 1.0f / (rp + RINV_DELTA);
+                const float s2 = s * s, s6 = s2 * s2 * s2;
+                en += 2.0f * (s6 * s6 - s6);
+                const float dEds = 2.0f * (2.0f * s6 - 1.0f) * (6.0f * (s2 * s2 * s));
+                float c = 2.0f * (dEds * (-s2)) / rp;
+                const float d = rp - r0;
+                const float phi = expf(-(d * d) / gap);
+                phis += phi;
+                c += 2.0f * alpha * (-2.0f * d / gap * phi) / rp;
+                fx += c * tx;
+                fy += c * ty;
+                fz += c * tz;
+            }
+            force[4 * i] = fx;
+            force[4 * i + 1] = fy;
+            force[4 * i + 2] = fz;
+            force[4 * i + 3] = en;
+            cv_local += (double)phis;
+        }
+#pragma omp critical
+        {
+            cv_sum += cv_local;
+            for (unsigned b = 0; b < nb_total; ++b) hist[b] += h[b];
+        }
+        free(h);
+    }
+    const float cv = (float)(cv_sum / (double)N);
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < (long)N; ++i) force[4 * i + 3] += alpha * cv;
+    return (double)cv;
+}

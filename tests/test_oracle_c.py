@@ -70,6 +70,17 @@ def test_pair_mlp_matches_numpy_oracle(clib, act):
     np.testing.assert_allclose(got, ref, rtol=1e-4, atol=2e-5 * scale + 2e-5)
 
 
+def test_eds_rdf_matches_numpy_oracle(clib):
+    rng = np.random.default_rng(4)
+    nl, _ = random_nlist(rng, 300, 48, fill=0.7, rmin=0.9, rmax=3.4)
+    ref, cv = O.eds_rdf_model(nl.astype(np.float64), 0.7, 1.1, 0.05)
+    got, cv_c, hist = c_oracle.eds_from_nlist(clib, nl, 0.7, 1.1, 0.05)
+    np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-4)
+    assert abs(cv_c - cv) < 2e-6 * abs(cv)
+    r = np.sqrt(np.sum(nl[:, :, :3] * nl[:, :, :3], axis=2, dtype=np.float32)).astype(np.float32)
+    np.testing.assert_array_equal(hist.astype(np.int64), O.histogram_fixed_width(r, np.array([0.0, 3.5], np.float32), 102))
+
+
 def test_c_oracle_under_sanitizers(tmp_path):
     """the CPU restatement built with -fsanitize=address,undefined and run on a system whose
     rows overflow NN (the slot wrap must stay inside the row), a batch, both precisions, 1 and 4 threads."""
