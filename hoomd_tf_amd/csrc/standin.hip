@@ -132,11 +132,16 @@ __global__ __launch_bounds__(256) void cell_index_kernel(const typename Vec4<T>:
 // (begin, length) of the main x-run and of the run that wraps around the box (length 0 if none).
 // Every particle of a cell walks the same ranges: the search kernel then needs ONE load per row
 // instead of index arithmetic and two dependent cell_start loads.
+// a range table entry: (start, length) of the row's run of candidates and of the run that wraps around the box in x; the top
+// four bits of a length say through which periodic image the run is seen (y, z codes on .y; the x code on .w)
+constexpr unsigned kRangeWrapShift = 28u, kRangeLenMask = (1u << kRangeWrapShift) - 1u;
 __global__ __launch_bounds__(256) void cell_ranges_kernel(int nx, int ny, int nz, int wx, int wy, int wz, int px, int py, int pz,
-                                                          const unsigned *__restrict__ cell_start, uint4 *__restrict__ table, Gate gate) {
+                                                          const unsigned *__restrict__ cell_start, uint4 *__restrict__ table,
+                                                          unsigned *__restrict__ max_neigh, Gate gate) {
     if (gate.closed()) return;
     const int nrow = (2 * wy + 1) * (2 * wz + 1);
     const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0) *max_neigh = 0u; // the search kernel behind this one accumulates the largest row into it
     const unsigned ncell = (unsigned)(nx * ny * nz);
     if (t >= ncell * (unsigned)nrow) return;
     const int c = (int)(t / nrow), r = (int)(t % nrow);
@@ -152,22 +157,24 @@ __global__ __launch_bounds__(256) void cell_ranges_kernel(int nx, int ny, int nz
     }
     int ay = cy + dy, az = cz + dz;
     bool skip = false;
-    if (ay < 0) { skip |= !py; ay += ny; } else if (ay >= ny) { skip |= !py; ay -= ny; }
-    if (az < 0) { skip |= !pz; az += nz; } else if (az >= nz) { skip |= !pz; az -= nz; }
+    // which periodic image the row's cells are seen through: 1 = the one a box length below, 2 = above (kRangeWrap*)
+    unsigned wrap_y = 0u, wrap_z = 0u;
+    if (ay < 0) { skip |= !py; ay += ny; wrap_y = 1u; } else if (ay >= ny) { skip |= !py; ay -= ny; wrap_y = 2u; }
+    if (az < 0) { skip |= !pz; az += nz; wrap_z = 1u; } else if (az >= nz) { skip |= !pz; az -= nz; wrap_z = 2u; }
     uint4 o = make_uint4(0u, 0u, 0u, 0u);
     if (!skip) {
         const unsigned rowbase = (unsigned)((az * ny + ay) * nx);
         o.x = cell_start[rowbase + a0];
-        o.y = cell_start[rowbase + a1 + 1] - o.x;
+        o.y = (cell_start[rowbase + a1 + 1] - o.x) | (wrap_y << kRangeWrapShift) | (wrap_z << (kRangeWrapShift + 2));
         if (b1 >= b0) {
             o.z = cell_start[rowbase + b0];
-            o.w = cell_start[rowbase + b1 + 1] - o.z;
+            o.w = (cell_start[rowbase + b1 + 1] - o.z) | ((b0 == 0 ? 2u : 1u) << kRangeWrapShift);
         }
     }
     table[t] = o;
 }
 
-template <typename T, int G>
+template <typename T, int G, bool SHIFT>
 __global__ __launch_bounds__(256) void build_nlist_kernel(const typename Vec4<T>::type *__restrict__ pos,
                                                           const typename Vec4<T>::type *__restrict__ pos_sorted,
                                                           unsigned N, SBox<T> b, T rl2, int nx, int ny, int nz,
@@ -198,29 +205,41 @@ __global__ __launch_bounds__(256) void build_nlist_kernel(const typename Vec4<T>
     for (int r = 0; r < nrow; ++r) {
         const uint4 rg = rg_next;
         if (r + 1 < nrow) rg_next = active ? mine[r + 1] : make_uint4(0u, 0u, 0u, 0u);
+        // SHIFT (every periodic axis has >= 7 cells): the cell a candidate sits in says which periodic image of it is the
+        // near one, so particle i is moved by that box vector once per row instead of rint() per candidate and axis
+        T piy = pi.y, piz = pi.z, six = (T)0;
+        if (SHIFT) {
+            const unsigned wy_ = (rg.y >> kRangeWrapShift) & 3u, wz_ = rg.y >> (kRangeWrapShift + 2), wx_ = rg.w >> kRangeWrapShift;
+            piy += wy_ == 1u ? b.L[1] : (wy_ == 2u ? -b.L[1] : (T)0);
+            piz += wz_ == 1u ? b.L[2] : (wz_ == 2u ? -b.L[2] : (T)0);
+            six = wx_ == 1u ? b.L[0] : -b.L[0];
+        }
 #pragma unroll
         for (int part = 0; part < 2; ++part) {
-            const unsigned beg = part ? rg.z : rg.x, len = part ? rg.w : rg.y;
-            if (part == 1 && !__any(len != 0u)) break; // nobody in the wave wraps around the box in x
-            unsigned maxlen = len;
-            for (int m = G; m < 64; m <<= 1) {
-                unsigned o = (unsigned)__shfl_xor((int)maxlen, m);
-                maxlen = o > maxlen ? o : maxlen;
-            }
-            // (four sub-trips per iteration with their loads hoisted: 149 us per rebuild at C3 either way -- the walk is
-            //  VALU-issue bound, ~35 instructions per candidate and 3.7 candidates per hit, not latency-bound)
-            for (unsigned t = 0; t < maxlen; t += G) {
+            const unsigned beg = part ? rg.z : rg.x, len = (part ? rg.w : rg.y) & kRangeLenMask;
+            const T pix = (SHIFT && part) ? pi.x + six : pi.x;
+            // a per-lane trip count: the lanes of a group share it and leave the loop together, so the ballot below still
+            // sees whole groups (a wave-wide maximum through three dependent cross-lane reads per row cost more)
+            // (four sub-trips per iteration with their loads hoisted: no gain -- the walk is VALU-issue bound, ~35
+            //  instructions per candidate and 3.7 candidates per hit, not latency-bound)
+            const unsigned n = active ? len : 0u;
+            for (unsigned t = 0; t < n; t += G) {
                 const unsigned m_idx = t + g;
                 bool hit = false;
                 unsigned k = 0;
-                if (active && m_idx < len) {
+                if (m_idx < n) {
                     k = order[beg + m_idx];
                     const auto pk = pos_sorted[beg + m_idx];
-                    T ddx = mimg<T>(pk.x - pi.x, b.L[0], b.Linv[0], b.periodic[0]);
-                    T ddy = mimg<T>(pk.y - pi.y, b.L[1], b.Linv[1], b.periodic[1]);
-                    T ddz = mimg<T>(pk.z - pi.z, b.L[2], b.Linv[2], b.periodic[2]);
-                    hit = (k != i) && (ddx * ddx + ddy * ddy + ddz * ddz <= rl2);
-                    if (type_split >= 0) hit = hit && ((scalar_as_int(pk.w) >= type_split) == side_i);
+                    T ddx = pk.x - pix, ddy = pk.y - piy, ddz = pk.z - piz;
+                    if (!SHIFT) {
+                        ddx = mimg<T>(ddx, b.L[0], b.Linv[0], b.periodic[0]);
+                        ddy = mimg<T>(ddy, b.L[1], b.Linv[1], b.periodic[1]);
+                        ddz = mimg<T>(ddz, b.L[2], b.Linv[2], b.periodic[2]);
+                    }
+                    // '&', not '&&': behind a short-circuit the compiler defers the position load until k has arrived
+                    // (two memory round trips per trip of the loop instead of one)
+                    hit = (k != i) & (ddx * ddx + ddy * ddy + ddz * ddz <= rl2);
+                    if (type_split >= 0) hit = hit & ((scalar_as_int(pk.w) >= type_split) == side_i);
                 }
                 const unsigned long long bal = __ballot(hit) & gmask;
                 const unsigned rank = count + ballot_rank(bal);
@@ -292,7 +311,7 @@ __global__ __launch_bounds__(256) void cell_count_kernel(const unsigned *__restr
 // strided, dependent accesses per thread from one CU: 61 us of every rebuild at 29 791 cells; this one: rocprofv3
 // `cell_scan_kernel` in profiles/.)
 constexpr unsigned kScanChunk = 32768, kScanPer = 32, kScanStride = 33;
-__global__ __launch_bounds__(1024) void cell_scan_kernel(const unsigned *__restrict__ count, unsigned ncell,
+__global__ __launch_bounds__(1024) void cell_scan_kernel(unsigned *__restrict__ count, unsigned ncell,
                                                          unsigned *__restrict__ start, unsigned *__restrict__ cursor, Gate gate) {
     if (gate.closed()) return;
     __shared__ unsigned s_cells[1024 * kScanStride]; // 1024 rows x 33 words (132 KiB of the CU's 160)
@@ -302,6 +321,7 @@ __global__ __launch_bounds__(1024) void cell_scan_kernel(const unsigned *__restr
     for (unsigned base = 0; base < ncell; base += kScanChunk) {
         const unsigned n = ncell - base < kScanChunk ? ncell - base : kScanChunk;
         for (unsigned j = t; j < kScanChunk; j += 1024) s_cells[(j / kScanPer) * kScanStride + j % kScanPer] = j < n ? count[base + j] : 0u;
+        for (unsigned j = t; j < n; j += 1024) count[base + j] = 0u; // left zeroed for the next call (htfs_cell_sort)
         __syncthreads();
         unsigned *mine = s_cells + t * kScanStride;
         unsigned sum = 0;
@@ -367,7 +387,9 @@ extern "C" int htfs_cell_sort(const unsigned *d_cell_of, unsigned Ntot, unsigned
     HTF_REQUIRE(ncell > 0, "htfs_cell_sort: no cells");
     hipStream_t s = (hipStream_t)stream;
     unsigned *count = d_scratch, *cursor = d_scratch + ncell;
-    HTF_CHECK_HIP(hipMemsetAsync(count, 0, (size_t)ncell * sizeof(unsigned), s));
+    // the counts are left zeroed by every call that runs (cell_scan_kernel) and untouched by one the gate holds back,
+    // so a gated call -- always preceded by an ungated one on the same scratch (htf_standin.h) -- needs no memset
+    if (!g_gate.disp2) HTF_CHECK_HIP(hipMemsetAsync(count, 0, (size_t)ncell * sizeof(unsigned), s));
     if (Ntot) hipLaunchKernelGGL(cell_count_kernel, dim3((Ntot + 255) / 256), dim3(256), 0, s, d_cell_of, Ntot, count, g_gate);
     hipLaunchKernelGGL(cell_scan_kernel, dim3(1), dim3(1024), 0, s, count, ncell, d_cell_start, cursor, g_gate);
     if (Ntot) hipLaunchKernelGGL(cell_scatter_kernel, dim3((Ntot + 255) / 256), dim3(256), 0, s, d_cell_of, Ntot, cursor, d_order, g_gate);
@@ -436,19 +458,26 @@ extern "C" int htfs_build_nlist(const void *d_pos, const void *d_pos_sorted, int
     }
     hipLaunchKernelGGL(cell_ranges_kernel, dim3((ncell * nrow + 255) / 256), dim3(256), 0, (hipStream_t)stream, ncell3[0], ncell3[1],
                        ncell3[2], stencil3[0], stencil3[1], stencil3[2], (int)box->periodic[0], (int)box->periodic[1],
-                       (int)box->periodic[2], d_cell_start, d_ranges, g_gate);
+                       (int)box->periodic[2], d_cell_start, d_ranges, d_max_neigh, g_gate);
     const bool fine = stencil3[0] == 2 || stencil3[1] == 2 || stencil3[2] == 2; // short ranges: 8-lane groups waste fewer lanes
 #define HTFS_NL(T, V4, G)                                                                                              \
-    hipLaunchKernelGGL((build_nlist_kernel<T, G>), dim3((N + 4 * (64 / G) - 1) / (4 * (64 / G))), dim3(256), 0, (hipStream_t)stream, \
+    if (shift) HTFS_NL_(T, V4, G, true); else HTFS_NL_(T, V4, G, false)
+#define HTFS_NL_(T, V4, G, S)                                                                                          \
+    hipLaunchKernelGGL((build_nlist_kernel<T, G, S>), dim3((N + 4 * (64 / G) - 1) / (4 * (64 / G))), dim3(256), 0, (hipStream_t)stream, \
                        (const V4 *)d_pos, (const V4 *)d_pos_sorted, N, make_sbox<T>(box), (T)(r_list * r_list), ncell3[0],  \
                        ncell3[1], ncell3[2], stencil3[0], stencil3[1], stencil3[2], d_order, d_cell_start, pitch,      \
                        type_split, d_n_neigh, d_head_list, d_nlist, d_max_neigh, (const uint4 *)d_ranges, g_gate)
+    // with >= 7 cells along every periodic axis a stencil (<= 2 cells each way, plus a particle's place inside its own cell)
+    // never reaches half a box length: the near image of a candidate follows from its cell alone
+    bool shift = true;
+    for (int d = 0; d < 3; ++d) shift = shift && (!box->periodic[d] || ncell3[d] >= 7);
     if (dtype == HTF_F32) {
-        if (fine) HTFS_NL(float, float4, 8); else HTFS_NL(float, float4, 16);
+        if (fine) { HTFS_NL(float, float4, 8); } else { HTFS_NL(float, float4, 16); }
     } else {
-        if (fine) HTFS_NL(double, double4, 8); else HTFS_NL(double, double4, 16);
+        if (fine) { HTFS_NL(double, double4, 8); } else { HTFS_NL(double, double4, 16); }
     }
 #undef HTFS_NL
+#undef HTFS_NL_
     return check_launch("build_nlist_kernel");
 }
 

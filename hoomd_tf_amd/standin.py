@@ -204,7 +204,6 @@ class CellNlist:
                 self.n_neigh = torch.empty(s.N, dtype=torch.int32, device=s.device)
                 self.head_list = torch.empty(s.N, dtype=torch.int32, device=s.device)
                 self.nlist = torch.empty(s.N * self.pitch, dtype=torch.int32, device=s.device)
-            self._max.zero_()
             check(lib.htfs_build_nlist(s.pos.data_ptr(), pos_sorted.data_ptr(), s.scalar_code, s.N, Ntot, C.byref(s.box), self.r_list,
                                        C.byref(n3), C.byref(w3), order.data_ptr(), cell_start.data_ptr(), self.pitch, int(self.type_split),
                                        self.n_neigh.data_ptr(), self.head_list.data_ptr(), self.nlist.data_ptr(),
@@ -248,7 +247,6 @@ class CellNlist:
         self._disp.zero_()
         check(lib.htfs_max_displacement2(s.pos.data_ptr(), self._ref.data_ptr(), s.scalar_code, s.N,
                                          C.byref(s.box), self._disp.data_ptr(), stream))
-        self._stat[:1].zero_()
         check(lib.htfs_set_gate(self._disp.data_ptr(), (self.r_buff / 2.0) ** 2))
         try:
             check(lib.htfs_cell_index(s.pos.data_ptr(), s.scalar_code, s.N, C.byref(s.box), C.byref(n3),

@@ -29,8 +29,8 @@ HTF_API int htfs_max_displacement2(const void *d_pos, const void *d_ref, int dty
  * least r_list wide, 3 per direction) or 2 (at least r_list / 2 wide, 5 per direction) -- and writes
  *   nlist[i*pitch + c] = k  for every k != i with |minimage(r_k - r_i)| <= r_list,
  *   n_neigh[i] = count, head_list[i] = i*pitch.
- * *d_max_neigh is max'ed with the largest count (> pitch means the list overflowed and
- * must be rebuilt with a larger pitch).  type_split >= 0: pairs whose types lie on different
+ * *d_max_neigh is set to the largest count (> pitch means the list overflowed and must be
+ * rebuilt with a larger pitch; a call the gate below holds back leaves the previous value).  type_split >= 0: pairs whose types lie on different
  * sides of it are left out (hoomd.md.nlist.rcut set_pair(..., -1) between all-atom and mapped
  * bead types, tensorflowcompute.py:284-305); -1: no type filter. */
 HTF_API int htfs_build_nlist(const void *d_pos, const void *d_pos_sorted, int dtype, unsigned N, unsigned Ntot,
@@ -41,7 +41,9 @@ HTF_API int htfs_build_nlist(const void *d_pos, const void *d_pos_sorted, int dt
 
 /* dest[i] = src[order[i]] for Scalar4 arrays: the cell-sorted position copy */
 /* Cell binning: d_order <- particle indices sorted by cell (ascending index inside a cell: deterministic),
- * d_cell_start[c] <- first slot of cell c (ncell + 1 entries).  d_scratch: 2 * ncell words. */
+ * d_cell_start[c] <- first slot of cell c (ncell + 1 entries).  d_scratch: 2 * ncell words; a call under
+ * htfs_set_gate must be given the scratch (and ncell) of the last call made outside one -- its first half is
+ * left zeroed by every call and a gated call does not clear it again. */
 HTF_API int htfs_cell_sort(const unsigned *d_cell_of, unsigned Ntot, unsigned ncell, unsigned *d_scratch,
                            unsigned *d_cell_start, unsigned *d_order, htf_stream stream);
 HTF_API int htfs_gather4(void *d_dest, const void *d_src, const int *d_order, int dtype, unsigned n, htf_stream stream);

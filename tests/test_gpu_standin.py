@@ -13,10 +13,13 @@ def _rows(nn, head, nl):
     return [np.sort(nl[int(head[i]): int(head[i]) + int(nn[i])]) for i in range(len(nn))]
 
 
+# 5 lattice cells: 5 search cells along an axis, the near image of a candidate needs rint(); 7 and 10: >= 7 search cells,
+# the image follows from the candidate's cell (build_nlist_kernel<.., SHIFT>)
+@pytest.mark.parametrize("cells", [5, 7, 10])
 @pytest.mark.parametrize("tdt", [torch.float32, torch.float64])
-def test_cell_nlist_matches_brute_force(htf, cuda, tdt):
+def test_cell_nlist_matches_brute_force(htf, cuda, tdt, cells):
     from hoomd_tf_amd import standin
-    pos, L, a = standin.fcc_positions(7, 0.8442)
+    pos, L, a = standin.fcc_positions(cells, 0.8442)
     rng = np.random.default_rng(0)
     pos = pos + 0.08 * a * rng.standard_normal(pos.shape)
     pos -= np.round(pos / L) * L
