@@ -136,10 +136,11 @@ PROTOTYPES = {
 # HOOMD stand-in entry points (include/htf_standin.h) -- outside the drop-in boundary
 STANDIN_PROTOTYPES = {
     "htfs_gather4": (_i, [_vp, _vp, _vp, _i, _u, _vp]),
+    "htfs_gather4_tagged": (_i, [_vp, _vp, _vp, _i, _u, _i, _vp]),
     "htfs_cell_sort": (_i, [_vp, _u, _u, _vp, _vp, _vp, _vp]),
     "htfs_nve_step": (_i, [_vp, _vp, _vp, _i, _u, _d, C.POINTER(Box), _vp]),
     "htfs_max_displacement2": (_i, [_vp, _vp, _i, _u, C.POINTER(Box), _vp, _vp]),
-    "htfs_build_nlist": (_i, [_vp, _vp, _i, _u, _u, C.POINTER(Box), _d, C.POINTER(_i * 3), C.POINTER(_i * 3), _vp, _vp, _u, _i, _vp, _vp, _vp,
+    "htfs_build_nlist": (_i, [_vp, _vp, _i, _u, _u, C.POINTER(Box), _d, C.POINTER(_i * 3), C.POINTER(_i * 3), _vp, _u, _i, _vp, _vp, _vp,
                               _vp, _vp]),
     "htfs_cell_index": (_i, [_vp, _i, _u, C.POINTER(Box), C.POINTER(_i * 3), _vp, _vp]),
     "htfs_set_gate": (_i, [_vp, _d]),

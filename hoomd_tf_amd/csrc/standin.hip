@@ -134,6 +134,8 @@ __global__ __launch_bounds__(256) void cell_index_kernel(const typename Vec4<T>:
 // instead of index arithmetic and two dependent cell_start loads.
 // a range table entry: (start, length) of the row's run of candidates and of the run that wraps around the box in x; the top
 // four bits of a length say through which periodic image the run is seen (y, z codes on .y; the x code on .w)
+// the w of a cell-sorted position (htfs_gather4_tagged): particle index | (type >= type_split) << 31
+constexpr unsigned kTagSide = 1u << 31;
 constexpr unsigned kRangeWrapShift = 28u, kRangeLenMask = (1u << kRangeWrapShift) - 1u;
 __global__ __launch_bounds__(256) void cell_ranges_kernel(int nx, int ny, int nz, int wx, int wy, int wz, int px, int py, int pz,
                                                           const unsigned *__restrict__ cell_start, uint4 *__restrict__ table,
@@ -179,7 +181,6 @@ __global__ __launch_bounds__(256) void build_nlist_kernel(const typename Vec4<T>
                                                           const typename Vec4<T>::type *__restrict__ pos_sorted,
                                                           unsigned N, SBox<T> b, T rl2, int nx, int ny, int nz,
                                                           int wx, int wy, int wz,
-                                                          const unsigned *__restrict__ order,
                                                           const unsigned *__restrict__ cell_start, unsigned pitch,
                                                           int type_split,
                                                           unsigned *__restrict__ n_neigh, unsigned *__restrict__ head_list,
@@ -228,8 +229,10 @@ __global__ __launch_bounds__(256) void build_nlist_kernel(const typename Vec4<T>
                 bool hit = false;
                 unsigned k = 0;
                 if (m_idx < n) {
-                    k = order[beg + m_idx];
+                    // one 16-B (32-B) load per candidate: its index rides in w (htfs_gather4_tagged)
                     const auto pk = pos_sorted[beg + m_idx];
+                    const unsigned tag = (unsigned)scalar_as_int(pk.w);
+                    k = tag & ~kTagSide;
                     T ddx = pk.x - pix, ddy = pk.y - piy, ddz = pk.z - piz;
                     if (!SHIFT) {
                         ddx = mimg<T>(ddx, b.L[0], b.Linv[0], b.periodic[0]);
@@ -239,7 +242,7 @@ __global__ __launch_bounds__(256) void build_nlist_kernel(const typename Vec4<T>
                     // '&', not '&&': behind a short-circuit the compiler defers the position load until k has arrived
                     // (two memory round trips per trip of the loop instead of one)
                     hit = (k != i) & (ddx * ddx + ddy * ddy + ddz * ddz <= rl2);
-                    if (type_split >= 0) hit = hit & ((scalar_as_int(pk.w) >= type_split) == side_i);
+                    if (type_split >= 0) hit = hit & (((tag & kTagSide) != 0u) == side_i);
                 }
                 const unsigned long long bal = __ballot(hit) & gmask;
                 const unsigned rank = count + ballot_rank(bal);
@@ -285,11 +288,19 @@ extern "C" int htfs_max_displacement2(const void *d_pos, const void *d_ref, int 
 }
 
 namespace htf {
-template <typename V>
-__global__ void gather4_kernel(V *__restrict__ dest, const V *__restrict__ src, const int *__restrict__ order, unsigned n, Gate gate) {
+__device__ __forceinline__ void set_tag(float &w, unsigned tag) { w = __uint_as_float(tag); }
+__device__ __forceinline__ void set_tag(double &w, unsigned tag) { w = __longlong_as_double((long long)tag); }
+
+template <typename V, bool TAG>
+__global__ void gather4_kernel(V *__restrict__ dest, const V *__restrict__ src, const int *__restrict__ order, unsigned n,
+                               int type_split, Gate gate) {
     if (gate.closed()) return;
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dest[i] = src[order[i]];
+    if (i >= n) return;
+    const unsigned k = (unsigned)order[i];
+    V p = src[k];
+    if (TAG) set_tag(p.w, k | ((type_split >= 0 && scalar_as_int(p.w) >= type_split) ? kTagSide : 0u));
+    dest[i] = p;
 }
 } // namespace htf
 
@@ -397,14 +408,31 @@ extern "C" int htfs_cell_sort(const unsigned *d_cell_of, unsigned Ntot, unsigned
     return check_launch("htfs_cell_sort");
 }
 
-extern "C" int htfs_gather4(void *d_dest, const void *d_src, const int *d_order, int dtype, unsigned n, htf_stream stream) {
+static int gather4(void *d_dest, const void *d_src, const int *d_order, int dtype, unsigned n, bool tag, int type_split,
+                   htf_stream stream) {
+    using namespace htf;
     HTF_REQUIRE(d_dest && d_src && d_order, "htfs_gather4: null pointer");
+    HTF_REQUIRE(!tag || n <= kTagSide, "htfs_gather4_tagged: %u particles do not fit the 31-bit tag", n);
     if (n == 0) return HTF_OK;
-    if (dtype == HTF_F32)
-        hipLaunchKernelGGL((gather4_kernel<float4>), dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (float4 *)d_dest, (const float4 *)d_src, d_order, n, g_gate);
-    else
-        hipLaunchKernelGGL((gather4_kernel<double4>), dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (double4 *)d_dest, (const double4 *)d_src, d_order, n, g_gate);
+    const dim3 grid((n + 255) / 256), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == HTF_F32) {
+        if (tag) hipLaunchKernelGGL((gather4_kernel<float4, true>), grid, block, 0, s, (float4 *)d_dest, (const float4 *)d_src, d_order, n, type_split, g_gate);
+        else hipLaunchKernelGGL((gather4_kernel<float4, false>), grid, block, 0, s, (float4 *)d_dest, (const float4 *)d_src, d_order, n, type_split, g_gate);
+    } else {
+        if (tag) hipLaunchKernelGGL((gather4_kernel<double4, true>), grid, block, 0, s, (double4 *)d_dest, (const double4 *)d_src, d_order, n, type_split, g_gate);
+        else hipLaunchKernelGGL((gather4_kernel<double4, false>), grid, block, 0, s, (double4 *)d_dest, (const double4 *)d_src, d_order, n, type_split, g_gate);
+    }
     return check_launch("gather4_kernel");
+}
+
+extern "C" int htfs_gather4(void *d_dest, const void *d_src, const int *d_order, int dtype, unsigned n, htf_stream stream) {
+    return gather4(d_dest, d_src, d_order, dtype, n, false, -1, stream);
+}
+
+extern "C" int htfs_gather4_tagged(void *d_dest, const void *d_src, const int *d_order, int dtype, unsigned n, int type_split,
+                                   htf_stream stream) {
+    return gather4(d_dest, d_src, d_order, dtype, n, true, type_split, stream);
 }
 
 extern "C" int htfs_cell_index(const void *d_pos, int dtype, unsigned Ntot, const htf_box *box, const int *ncell3,
@@ -421,11 +449,11 @@ extern "C" int htfs_cell_index(const void *d_pos, int dtype, unsigned Ntot, cons
 
 extern "C" int htfs_build_nlist(const void *d_pos, const void *d_pos_sorted, int dtype, unsigned N, unsigned Ntot,
                                 const htf_box *box, double r_list, const int *ncell3, const int *stencil3,
-                                const unsigned *d_order, const unsigned *d_cell_start, unsigned pitch, int type_split,
+                                const unsigned *d_cell_start, unsigned pitch, int type_split,
                                 unsigned *d_n_neigh, unsigned *d_head_list, unsigned *d_nlist, unsigned *d_max_neigh,
                                 htf_stream stream) {
     (void)Ntot;
-    HTF_REQUIRE(d_pos && d_pos_sorted && box && ncell3 && stencil3 && d_order && d_cell_start && d_n_neigh && d_head_list && d_nlist && d_max_neigh,
+    HTF_REQUIRE(d_pos && d_pos_sorted && box && ncell3 && stencil3 && d_cell_start && d_n_neigh && d_head_list && d_nlist && d_max_neigh,
                 "htfs_build_nlist: null pointer");
     HTF_REQUIRE(pitch > 0, "htfs_build_nlist: pitch must be > 0");
     for (int d = 0; d < 3; ++d) {
@@ -465,7 +493,7 @@ extern "C" int htfs_build_nlist(const void *d_pos, const void *d_pos_sorted, int
 #define HTFS_NL_(T, V4, G, S)                                                                                          \
     hipLaunchKernelGGL((build_nlist_kernel<T, G, S>), dim3((N + 4 * (64 / G) - 1) / (4 * (64 / G))), dim3(256), 0, (hipStream_t)stream, \
                        (const V4 *)d_pos, (const V4 *)d_pos_sorted, N, make_sbox<T>(box), (T)(r_list * r_list), ncell3[0],  \
-                       ncell3[1], ncell3[2], stencil3[0], stencil3[1], stencil3[2], d_order, d_cell_start, pitch,      \
+                       ncell3[1], ncell3[2], stencil3[0], stencil3[1], stencil3[2], d_cell_start, pitch,      \
                        type_split, d_n_neigh, d_head_list, d_nlist, d_max_neigh, (const uint4 *)d_ranges, g_gate)
     // with >= 7 cells along every periodic axis a stencil (<= 2 cells each way, plus a particle's place inside its own cell)
     // never reaches half a box length: the near image of a candidate follows from its cell alone

@@ -191,7 +191,8 @@ class CellNlist:
         check(lib.htfs_cell_sort(cell_of.data_ptr(), Ntot, ncell, self._bin_scratch.data_ptr(), cell_start.data_ptr(),
                                  order.data_ptr(), stream))
         # cell members contiguous: coalesced candidate reads
-        check(lib.htfs_gather4(pos_sorted.data_ptr(), s.pos.data_ptr(), order.data_ptr(), s.scalar_code, Ntot, stream))
+        check(lib.htfs_gather4_tagged(pos_sorted.data_ptr(), s.pos.data_ptr(), order.data_ptr(), s.scalar_code, Ntot,
+                                      int(self.type_split), stream))
         if self.pitch is None:
             # a sphere of r_list at the mean density, with generous head-room
             L = s.box3x3[1] - s.box3x3[0]
@@ -205,7 +206,7 @@ class CellNlist:
                 self.head_list = torch.empty(s.N, dtype=torch.int32, device=s.device)
                 self.nlist = torch.empty(s.N * self.pitch, dtype=torch.int32, device=s.device)
             check(lib.htfs_build_nlist(s.pos.data_ptr(), pos_sorted.data_ptr(), s.scalar_code, s.N, Ntot, C.byref(s.box), self.r_list,
-                                       C.byref(n3), C.byref(w3), order.data_ptr(), cell_start.data_ptr(), self.pitch, int(self.type_split),
+                                       C.byref(n3), C.byref(w3), cell_start.data_ptr(), self.pitch, int(self.type_split),
                                        self.n_neigh.data_ptr(), self.head_list.data_ptr(), self.nlist.data_ptr(),
                                        self._max.data_ptr(), stream))
             mx = int(self._max.item())
@@ -253,10 +254,10 @@ class CellNlist:
                                       self._cell_of.data_ptr(), stream))
             check(lib.htfs_cell_sort(self._cell_of.data_ptr(), s.N, ncell, self._bin_scratch.data_ptr(),
                                      self._cell_start.data_ptr(), self._order.data_ptr(), stream))
-            check(lib.htfs_gather4(self._pos_sorted.data_ptr(), s.pos.data_ptr(), self._order.data_ptr(), s.scalar_code,
-                                   s.N, stream))
+            check(lib.htfs_gather4_tagged(self._pos_sorted.data_ptr(), s.pos.data_ptr(), self._order.data_ptr(),
+                                          s.scalar_code, s.N, int(self.type_split), stream))
             check(lib.htfs_build_nlist(s.pos.data_ptr(), self._pos_sorted.data_ptr(), s.scalar_code, s.N, s.N,
-                                       C.byref(s.box), self.r_list, C.byref(n3), C.byref(w3), self._order.data_ptr(),
+                                       C.byref(s.box), self.r_list, C.byref(n3), C.byref(w3),
                                        self._cell_start.data_ptr(), self.pitch, int(self.type_split),
                                        self.n_neigh.data_ptr(), self.head_list.data_ptr(), self.nlist.data_ptr(),
                                        self._stat.data_ptr(), stream))

@@ -22,9 +22,9 @@ HTF_API int htfs_max_displacement2(const void *d_pos, const void *d_ref, int dty
                                    const htf_box *box, float *d_out, htf_stream stream);
 
 /* Cell-list neighbor search in HOOMD layout (NeighborListGPUBinned analogue).
- * d_cell_of [Ntot], d_order [Ntot] (particle ids sorted by cell), d_pos_sorted [Ntot]
- * (= pos[order], so a cell's members are contiguous) and d_cell_start [ncell+1] are
- * produced by the caller (binning + sort + gather are plumbing); this kernel walks
+ * d_pos_sorted [Ntot] (htfs_gather4_tagged: pos[order] with the particle's index in w, so a cell's
+ * members are contiguous and one load brings a candidate's position and identity) and d_cell_start
+ * [ncell+1] are produced by the caller (binning + sort + gather are plumbing); this kernel walks
  * the neighbor cells of each local particle -- stencil3[d] = 0 (one cell along d), 1 (cells at
  * least r_list wide, 3 per direction) or 2 (at least r_list / 2 wide, 5 per direction) -- and writes
  *   nlist[i*pitch + c] = k  for every k != i with |minimage(r_k - r_i)| <= r_list,
@@ -35,7 +35,7 @@ HTF_API int htfs_max_displacement2(const void *d_pos, const void *d_ref, int dty
  * bead types, tensorflowcompute.py:284-305); -1: no type filter. */
 HTF_API int htfs_build_nlist(const void *d_pos, const void *d_pos_sorted, int dtype, unsigned N, unsigned Ntot,
                              const htf_box *box, double r_list, const int *ncell3, const int *stencil3,
-                             const unsigned *d_order, const unsigned *d_cell_start, unsigned pitch, int type_split,
+                             const unsigned *d_cell_start, unsigned pitch, int type_split,
                              unsigned *d_n_neigh, unsigned *d_head_list, unsigned *d_nlist, unsigned *d_max_neigh,
                              htf_stream stream);
 
@@ -47,13 +47,17 @@ HTF_API int htfs_build_nlist(const void *d_pos, const void *d_pos_sorted, int dt
 HTF_API int htfs_cell_sort(const unsigned *d_cell_of, unsigned Ntot, unsigned ncell, unsigned *d_scratch,
                            unsigned *d_cell_start, unsigned *d_order, htf_stream stream);
 HTF_API int htfs_gather4(void *d_dest, const void *d_src, const int *d_order, int dtype, unsigned n, htf_stream stream);
+/* the same with w replaced by  order[i] | (type >= type_split) << 31  (type_split < 0: the index alone; n <= 2^31):
+ * the candidate array htfs_build_nlist reads, called with the same type_split */
+HTF_API int htfs_gather4_tagged(void *d_dest, const void *d_src, const int *d_order, int dtype, unsigned n, int type_split,
+                                htf_stream stream);
 
 /* cell index of every particle (x fastest): d_cell_of[i] */
 HTF_API int htfs_cell_index(const void *d_pos, int dtype, unsigned Ntot, const htf_box *box,
                             const int *ncell3, unsigned *d_cell_of, htf_stream stream);
 
 /* Conditional rebuild WITHOUT a host decision: after htfs_set_gate(d_disp2, threshold2) every binning /
- * search kernel of this header launched by the calling thread (htfs_cell_index, htfs_cell_sort, htfs_gather4,
+ * search kernel of this header launched by the calling thread (htfs_cell_index, htfs_cell_sort, htfs_gather4[_tagged],
  * htfs_build_nlist, htfs_commit_rebuild) returns at entry unless *d_disp2 > threshold2 when it RUNS, with
  * d_disp2 the word htfs_max_displacement2 has just filled on the same stream; htfs_set_gate(NULL, 0) ends
  * it.  The caller enqueues the whole rebuild behind every distance check and never reads the result back. */
