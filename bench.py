@@ -664,9 +664,13 @@ def run_md(args, E, workload, variants=True, cpu=True):
     # rebuilds (~0.25 ms each), so a single short window swings by +-10 % with where the rebuilds fall
     n_windows = args.windows if args.windows > 0 else (5 if args.steps <= 50 else 1)
     builds0 = builds_now()
-    windows = [timed_window() for _ in range(n_windows)]
+    windows, window_prof = [], []
+    for _ in range(n_windows):
+        windows.append(timed_window())
+        window_prof.append(ctx.profile_read())  # (build ms, eval ms, bracketed calls) of this window; resets
+    # the kernel durations are those of the window `value` is taken from (the median one)
     elapsed = float(np.median(windows))
-    build_ms, eval_ms, ncalls = ctx.profile_read()
+    build_ms, eval_ms, ncalls = window_prof[int(np.argsort(windows)[len(windows) // 2])]
     ctx.profile_enable(False)
     rebuilds = (builds_now() - builds0) / n_windows  # per window of args.steps steps
 
@@ -777,6 +781,8 @@ def run_md(args, E, workload, variants=True, cpu=True):
         "higher_is_better": True, "scaling": "strong" if (strong or world == 1) else "weak", "vs_baseline": None,
         "particle_steps_per_s": n_global * args.steps / elapsed,
         "windows_ms_per_step": [w / args.steps * 1e3 for w in windows],
+        # mean bracketed htf_compute_forces batch (build + eval kernels) per window; `kernels` / `roofline` quote the median window's
+        "windows_batch_us": [(b + e) / n * 1e3 if n else None for b, e, n in window_prof],
         "value_is": "median of %d timed windows of %d steps each" % (n_windows, args.steps) if n_windows > 1 else "one timed window",
         "dtype": {"mlp-bf16": "bf16 operands, f32 accumulation",
                   "mlp-split": "f32 (each operand split exactly into 3 bf16 parts, 6 partial products, f32 accumulation)"

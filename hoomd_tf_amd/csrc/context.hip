@@ -554,6 +554,12 @@ extern "C" int htf_profile_enable(htf_ctx *ctx, int on) {
     ctx->ev_used = 0;
     ctx->ev_one_scope.clear();
     ctx->ev_complete.clear();
+    // events for the first 64 bracketed calls exist before the caller's timed region starts (creating one costs microseconds)
+    while (on > 0 && ctx->ev_pool.size() < 192) {
+        hipEvent_t e;
+        HTF_CHECK_HIP(hipEventCreate(&e));
+        ctx->ev_pool.push_back(e);
+    }
     return HTF_OK;
 }
 
