@@ -21,6 +21,7 @@ ap.add_argument("--relax", type=int, default=0, help="MD steps before timing (li
 ap.add_argument("--cells", type=int, default=32)
 ap.add_argument("--reps", type=int, default=200)
 ap.add_argument("--tag", default="")
+ap.add_argument("--digest", default="", help="print sha1 digests of the tensor and the forces; save the forces to this .npy")
 args = ap.parse_args()
 
 dev = torch.device("cuda:0")
@@ -73,6 +74,18 @@ def timeit(reps):
     return e0.elapsed_time(e1) / reps * 1e3
 
 
+if args.digest:
+    # bit-level fingerprint of what one call leaves behind: the [N, NN, 4] tensor and the forces
+    import hashlib
+    ctx.compute_forces(0, arr)
+    torch.cuda.synchronize()
+    t = ctx.nlist_buffer(N).cpu().numpy()
+    f = sysm.force.cpu().numpy()
+    print("digest tensor %s  forces %s  sum|F| %.6f" % (hashlib.sha1(t.tobytes()).hexdigest()[:16],
+                                                     hashlib.sha1(f.tobytes()).hexdigest()[:16], float(np.abs(f).sum())))
+    np.save(args.digest, f)
+    if os.environ.get("HTF_DUMP_TENSOR"):
+        np.save(os.environ["HTF_DUMP_TENSOR"], t)
 ts = [timeit(args.reps) for _ in range(5)]
 print("%-28s lib=%s block=%s rows=%s order=%s relax=%d fused=%d: %s  median %.1f us  (entries/row %.1f)" % (
     args.tag, os.path.basename(os.environ.get("HTF_AMD_LIB", "default")), os.environ.get("HTF_FUSED_BLOCK", "256"),
