@@ -481,228 +481,12 @@ __device__ __forceinline__ void fused_rows_group_tails(
         }
 }
 
-// Four indices per lane (A/B variant, HTF_FUSED_IDX4=1): the wave's four rows each own 16 lanes, and a lane reads the
-// 16-B blocks [4s, 4s+4) and [64+4s, 64+4s+4) of its row's index list -- two index-load instructions for the first 128
-// entries of FOUR rows instead of eight -- gathers and evaluates its eight candidates, and takes their tensor slots
-// from the ballots of the eight evaluation steps (entries of lower lanes of the row, then its own earlier ones: the
-// HOOMD order, so the tensor is the same bit for bit).  The tails (entries >= 128) share one trip as above.  A lane
-// accumulates for ONE row; the row sums are 16-lane reductions.  Needs the rows' list heads and the list itself
-// 16-B aligned, and the list readable up to the end of a row's last 16-B block.
-template <int KIND, bool STORE, typename PT>
-__device__ __forceinline__ void fused_rows_group_idx4(
-    const unsigned w0, const unsigned lane, const typename Vec4<PT>::type *__restrict__ pos, unsigned N, unsigned NN,
-    unsigned offset, unsigned batch, const BoxT<PT> &box, const unsigned *__restrict__ n_neigh,
-    const unsigned *__restrict__ nlist, const unsigned *__restrict__ head_list, PT rmaxsq, void *__restrict__ force,
-    int out_f64, const PotParams &p, unsigned *__restrict__ check_count, float4 *__restrict__ positions_out,
-    float4 *__restrict__ dest, unsigned *__restrict__ counts_io) {
-    constexpr int R = 4;
-    using PV = typename Vec4<PT>::type;
-    unsigned nn[R], S[R + 1], head[R];
-    bool fast = w0 + R <= batch;
-    S[0] = 0;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const unsigned idx = (w0 + r < batch ? w0 + r : w0) + offset;
-        nn[r] = n_neigh[idx];
-        head[r] = head_list[idx];
-        fast = fast && nn[r] != 0 && nn[r] <= 192u && (head[r] & 3u) == 0u;
-        S[r + 1] = S[r] + (nn[r] > 128u ? nn[r] - 128u : 0u);
-    }
-    if (!fast || S[R] > 64u) { // (wave-uniform)
-#pragma unroll
-        for (int r = 0; r < R; r += 2)
-            if (w0 + r < batch)
-                fused_rows_group<KIND, STORE, 2, PT>(w0 + r, lane, pos, N, NN, offset, batch, box, n_neigh, nlist, head_list,
-                                                     rmaxsq, force, out_f64, p, check_count, positions_out, dest, counts_io);
-        return;
-    }
-    const unsigned q = lane >> 4, s = lane & 15u;
-    unsigned nn_q = nn[0], head_q = head[0];
-    // the row whose tail covers this lane (as in fused_rows_group_tails)
-    unsigned rl = 0, head_l = head[0], s_l = 0, nn_l = nn[0];
-#pragma unroll
-    for (int r = 1; r < R; ++r) {
-        nn_q = q == (unsigned)r ? nn[r] : nn_q;
-        head_q = q == (unsigned)r ? head[r] : head_q;
-        const bool in = lane >= S[r];
-        rl += in ? 1u : 0u;
-        head_l = in ? head[r] : head_l;
-        s_l = in ? S[r] : s_l;
-        nn_l = in ? nn[r] : nn_l;
-    }
-    const PV pi_q = pos[w0 + q + offset];
-    const PV pi_l = pos[w0 + rl + offset];
-    const uint4 *nl4 = (const uint4 *)(nlist + head_q);
-    const unsigned last_blk = (nn_q - 1u) >> 2;
-    const uint4 ka = nl4[s < last_blk ? s : last_blk], kb = nl4[16u + s < last_blk ? 16u + s : last_blk];
-    const bool tail_live = lane < S[R];
-    const unsigned kt = nlist[head_l + (tail_live ? 128u + (lane - s_l) : nn_l - 1u)];
-    unsigned kk[8] = {ka.x, ka.y, ka.z, ka.w, kb.x, kb.y, kb.z, kb.w};
-    bool valid[8];
-    PV qv[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const unsigned e = (c < 4 ? 0u : 64u) + 4u * s + (unsigned)(c & 3);
-        valid[c] = e < nn_q;
-        kk[c] = valid[c] ? kk[c] : w0 + q + offset; // any readable position
-    }
-#pragma unroll
-    for (int c = 0; c < 8; ++c) qv[c] = pos[kk[c]];
-    const PV qt = pos[kt];
-    // evaluate, then rank: a slot index needs the ballots of all four steps of its block
-    float x[8], y[8], z[8];
-    bool keep[8];
-    unsigned long long m[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        PT dx, dy, dz;
-        const PT rsq = pair_vector<PT>(qv[c], pi_q, box, dx, dy, dz);
-        keep[c] = valid[c] && !(rsq > rmaxsq);
-        m[c] = __ballot(keep[c]);
-        x[c] = (float)dx;
-        y[c] = (float)dy;
-        z[c] = (float)dz;
-    }
-    const unsigned sh = 16u * q, low = (1u << s) - 1u;
-    unsigned slot = 0, Q[R] = {0u, 0u, 0u, 0u};
-    float fx = 0.f, fy = 0.f, fz = 0.f, en = 0.f;
-    unsigned npos = 0;
-    float4 *row_q = STORE ? dest + (size_t)(w0 + q) * NN : nullptr;
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        unsigned below = 0, total = 0;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const unsigned seg = (unsigned)(m[4 * half + t] >> sh) & 0xffffu;
-            below += (unsigned)__popc(seg & low);
-            total += (unsigned)__popc(seg);
-#pragma unroll
-            for (int r = 0; r < R; ++r) Q[r] += (unsigned)__popc((unsigned)(m[4 * half + t] >> (16 * r)) & 0xffffu);
-        }
-        unsigned qq = slot + below;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int c = 4 * half + t;
-            if (keep[c] && qq < NN) {
-                if constexpr (STORE) {
-#ifdef HTF_IDX4_PLAIN_STORE
-                    row_q[qq] = make_float4(x[c], y[c], z[c], (float)scalar_as_int(qv[c].w));
-#else
-                    store_stream(&row_q[qq], make_float4(x[c], y[c], z[c], (float)scalar_as_int(qv[c].w)));
-#endif
-                }
-                float e, ax, ay, az;
-                pair_eval<KIND>(x[c], y[c], z[c], p, e, ax, ay, az);
-                fx += ax;
-                fy += ay;
-                fz += az;
-                en += e;
-                npos += x[c] > 0.f ? 1u : 0u;
-            }
-            qq += keep[c] ? 1u : 0u;
-        }
-        slot += total;
-    }
-    // the shared tail trip (lane -> row rl)
-    float tfx[R], tfy[R], tfz[R], ten[R];
-    unsigned tnp[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        tfx[r] = tfy[r] = tfz[r] = ten[r] = 0.f;
-        tnp[r] = 0;
-    }
-    if (S[R] != 0) {
-        PT dx, dy, dz;
-        const PT rsq = pair_vector<PT>(qt, pi_l, box, dx, dy, dz);
-        const bool keep_t = tail_live && !(rsq > rmaxsq);
-        const unsigned long long mt = __ballot(keep_t);
-        unsigned base_l = Q[0];
-#pragma unroll
-        for (int r = 1; r < R; ++r) {
-            const unsigned before = (unsigned)__popcll(S[r] >= 64u ? mt : (mt & ((1ull << S[r]) - 1ull)));
-            base_l = rl == (unsigned)r ? Q[r] - before : base_l;
-        }
-        const unsigned qq = base_l + ballot_rank(mt);
-        float e = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
-        unsigned px = 0;
-        if (keep_t && qq < NN) {
-            const float xt = (float)dx, yt = (float)dy, zt = (float)dz;
-            if constexpr (STORE) store_stream(dest + (size_t)(w0 + rl) * NN + qq, make_float4(xt, yt, zt, (float)scalar_as_int(qt.w)));
-            pair_eval<KIND>(xt, yt, zt, p, e, ax, ay, az);
-            px = xt > 0.f ? 1u : 0u;
-        }
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const bool mine = rl == (unsigned)r;
-            tfx[r] = group_sum<64>(mine ? ax : 0.f);
-            tfy[r] = group_sum<64>(mine ? ay : 0.f);
-            tfz[r] = group_sum<64>(mine ? az : 0.f);
-            ten[r] = group_sum<64>(mine ? e : 0.f);
-            if (check_count != nullptr) tnp[r] = (unsigned)__popcll(__ballot(mine && px != 0u));
-            const unsigned long long seg = (S[r + 1] >= 64u ? ~0ull : ((1ull << S[r + 1]) - 1ull)) & ~(S[r] >= 64u ? ~0ull : ((1ull << S[r]) - 1ull));
-            Q[r] += (unsigned)__popcll(mt & seg);
-        }
-    }
-    // per-lane view of its row's totals
-    unsigned Q_q = Q[0], redo = 0;
-    float ax_q = tfx[0], ay_q = tfy[0], az_q = tfz[0], e_q = ten[0];
-    unsigned np_q = tnp[0];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        if (r) {
-            const bool me = q == (unsigned)r;
-            Q_q = me ? Q[r] : Q_q;
-            ax_q = me ? tfx[r] : ax_q;
-            ay_q = me ? tfy[r] : ay_q;
-            az_q = me ? tfz[r] : az_q;
-            e_q = me ? ten[r] : e_q;
-            np_q = me ? tnp[r] : np_q;
-        }
-        if (Q[r] > NN) redo |= 1u << r;
-    }
-    const unsigned w = w0 + q;
-    if (positions_out != nullptr && s == 0)
-        positions_out[w] = make_float4((float)pi_q.x, (float)pi_q.y, (float)pi_q.z, (float)scalar_as_int(pi_q.w));
-    const unsigned filled = Q_q < NN ? Q_q : NN;
-    if constexpr (STORE) {
-        const unsigned zero_end = counts_io != nullptr ? counts_io[w] : NN;
-        for (unsigned sl = filled + s; sl < zero_end; sl += 16) store_stream(&row_q[sl], make_float4(0.f, 0.f, 0.f, 0.f));
-        if (counts_io != nullptr && s == 0) counts_io[w] = filled;
-    }
-    const float sx = group_sum<16>(fx) + ax_q, sy = group_sum<16>(fy) + ay_q, sz = group_sum<16>(fz) + az_q, se = group_sum<16>(en) + e_q;
-    unsigned np = 0;
-    if (check_count != nullptr) np = group_sum_u<16>(npos) + np_q;
-    if (s == 0 && !((redo >> q) & 1u)) {
-        if (out_f64)
-            ((double4 *)force)[w] = make_double4(sx, sy, sz, se);
-        else
-            ((float4 *)force)[w] = make_float4(sx, sy, sz, se);
-        if (check_count != nullptr && np > *(volatile unsigned *)check_count) atomicMax(check_count, np);
-    }
-#pragma unroll 1
-    for (unsigned r = 0; r < (unsigned)R; ++r)
-        if ((redo >> r) & 1u) {
-            if constexpr (STORE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            fused_row<KIND, false, STORE, PT>(w0 + r, lane, pos, N, NN, offset, box, n_neigh, nlist, head_list, rmaxsq,
-                                              force, nullptr, out_f64, p, check_count, positions_out, dest, counts_io);
-        }
-}
-
-template <int KIND, bool STORE, typename PT>
-__global__ __launch_bounds__(256) void fused_forces_idx4_kernel(
-    const typename Vec4<PT>::type *__restrict__ pos, unsigned N, unsigned NN, unsigned offset, unsigned batch,
-    BoxT<PT> box, const unsigned *__restrict__ n_neigh, const unsigned *__restrict__ nlist,
-    const unsigned *__restrict__ head_list, PT rmaxsq, void *__restrict__ force, int out_f64, PotParams pin,
-    unsigned *__restrict__ check_count, float4 *__restrict__ positions_out, float4 *__restrict__ dest,
-    unsigned *__restrict__ counts_io) {
-    const PotParams p = resolve_theta<KIND>(pin);
-    const unsigned lane = threadIdx.x & 63u;
-    const unsigned w0 = 4u * __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-    if (w0 >= batch) return;
-    fused_rows_group_idx4<KIND, STORE, PT>(w0, lane, pos, N, NN, offset, batch, box, n_neigh, nlist, head_list, rmaxsq,
-                                           force, out_f64, p, check_count, positions_out, dest, counts_io);
-}
-
+// (Measured and removed, commit 6b65261: FOUR INDICES PER LANE -- the wave's four rows own 16 lanes each and a lane reads the
+//  16-B blocks [4s, 4s+4) and [64+4s, 64+4s+4) of its row's index list, two index-load instructions for the first 128
+//  entries of four rows instead of eight; slots from the ballots of the eight evaluation steps, same tensor bit for bit.
+//  A lane's four survivors then land in consecutive slots and the lanes of one store instruction are ~43 B apart:
+//  245 us with streaming stores, 97 us with ordinary ones, against 61-66; and without the tensor 48.7 against 44.9 --
+//  the index-load instruction count is not what the kernel waits for.  profiles/r02_fused_kernel_ab.txt, batch 11.)
 template <int KIND, bool STORE, int R, typename PT>
 __global__ __launch_bounds__(256) void fused_forces_tails_kernel(
     const typename Vec4<PT>::type *__restrict__ pos, unsigned N, unsigned NN, unsigned offset, unsigned batch,
@@ -767,19 +551,6 @@ static int launch_fused(const void *pos, unsigned N, unsigned NN, unsigned offse
         // how a step is cut into batches / row ranges, bit for bit.
         static const char *tails_env = getenv("HTF_FUSED_TAILS");
         const int tails = tails_env ? atoi(tails_env) : ((sizeof(PT) == 4 && batch >= 65536u) ? 4 : 0);
-        static const char *idx4_env = getenv("HTF_FUSED_IDX4"); // A/B runs: four indices per lane (see fused_rows_group_idx4)
-        if (idx4_env && atoi(idx4_env) == 1 && tails == 4 && ((uintptr_t)nlist & 15u) == 0u) {
-            const dim3 grid(((batch + 3) / 4 + 3) / 4);
-            if (dest != nullptr)
-                hipLaunchKernelGGL((fused_forces_idx4_kernel<KIND, true, PT>), grid, dim3(256), 0, s,
-                                   (const typename Vec4<PT>::type *)pos, N, NN, offset, batch, b, n_neigh, nlist, head_list,
-                                   (PT)(rc * rc), force, out_f64, p, check_count, positions_out, dest, counts_io);
-            else
-                hipLaunchKernelGGL((fused_forces_idx4_kernel<KIND, false, PT>), grid, dim3(256), 0, s,
-                                   (const typename Vec4<PT>::type *)pos, N, NN, offset, batch, b, n_neigh, nlist, head_list,
-                                   (PT)(rc * rc), force, out_f64, p, check_count, positions_out, dest, counts_io);
-            return check_launch("fused_forces_idx4_kernel");
-        }
         if (tails == 2 || tails == 4) {
 #define HTF_TAILS_LAUNCH(ST, RR)                                                                                       \
     hipLaunchKernelGGL((fused_forces_tails_kernel<KIND, ST, RR, PT>), dim3(((batch + RR - 1) / RR + 3) / 4), dim3(256), 0, s, \
