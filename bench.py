@@ -399,14 +399,25 @@ def self_launch(args):
         # rank 0's stdout carries the JSON line; the other ranks' stdout (library chatter) goes to stderr
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode]
-    for pr in procs[1:]:
-        try:
-            rcs.append(pr.wait(timeout=120))
-        except subprocess.TimeoutExpired:
-            pr.kill()
-            rcs.append(-9)
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed_at = None
+    while True:
+        rcs = [pr.poll() for pr in procs]
+        if all(rc is not None for rc in rcs):
+            break
+        if failed_at is None and any(rc not in (None, 0) for rc in rcs):
+            failed_at = time.monotonic()  # a rank died: the others would wait for it in a collective forever
+        if failed_at is not None and time.monotonic() - failed_at > 20.0:
+            for pr in procs:
+                if pr.poll() is None:
+                    pr.kill()  # our own children, by handle
+        time.sleep(0.1)
+    rcs = [pr.wait() for pr in procs]
+    reader.join(timeout=10)
+    out = b"".join(chunks)
     for line in out.decode("utf-8", "replace").splitlines():
         # ONE JSON line on stdout; anything else a library printed there (gloo's connection notes) is passed to stderr
         (sys.stdout if line.startswith("{") else sys.stderr).write(line + "\n")
