@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="lj", choices=["lj", "wca", "mlp", "mlp-split", "mlp-bf16", "mlp-train", "eds"])
+    ap.add_argument("--workload", default="lj", choices=["lj", "wca", "mlp", "mlp-split", "mlp-bf16", "mlp-train", "eds", "ref-lj256"])
     ap.add_argument("--train-period", type=int, default=100, help="mlp-train (C5b): force-matching step every this many MD steps")
     ap.add_argument("--cells", type=int, default=32, help="fcc cells per side (N = 4 cells^3 per rank)")
     ap.add_argument("--lattice", default="fcc", choices=["fcc", "sc"], help="fcc: N = 4 cells^3 (C3, C5); sc: N = cells^3 (C2 = sc 32^3 = 32768)")
@@ -186,6 +186,63 @@ def cpu_baseline(sysm, nl, args):
     except Exception as e:  # noqa: BLE001 -- the baseline is informational
         out["graph_style"] = {"error": str(e)}
     return out
+
+
+def run_ref_lj256(args, htf, standin, dev):
+    """The one benchmark the reference publishes (htf/test-py/benchmark.py:25-48, ~498-510 steps/s on a
+    Xeon Gold 6130 / 6140 node): 256 particles on hoomd.lattice.sq(a=2.0), LJModel(NN=64) attached through
+    tfcompute with r_cut 3.0, nlist.cell(check_period=1), dt 0.005, 1000 steps x 5 rounds, median.  Upstream also runs
+    HOOMD's own pair.lj and a Langevin thermostat in the same steps; the stand-in integrates NVE at kT = 1 and has no second
+    force, so this line measures the plugin path's per-step cost at a size where nothing but overhead counts."""
+    n, a, NN, rcut = 16, 2.0, 64, 3.0
+    L = np.array([n * a, n * a, 1.0])
+    ij = np.stack(np.meshgrid(np.arange(n), np.arange(n), indexing="ij"), -1).reshape(-1, 2)
+    pos = np.zeros((n * n, 3))
+    pos[:, :2] = (ij + 0.5) * a - L[:2] / 2
+    sysm = standin.System(pos, L, dtype=torch.float32, device=dev)
+    sysm.randomize_velocities(kT=1.0, seed=42)
+    sysm.vel[:, 2] = 0.0  # two-dimensional, as hoomd.lattice.sq
+
+    class LJModel(htf.SimModel):
+        def compute(self, nlist, positions, box):
+            rinv = htf.nlist_rinv(nlist)
+            inv_r6 = rinv**6
+            p_energy = 4.0 / 2.0 * (inv_r6 * inv_r6 - inv_r6)
+            energy = htf.reduce_sum(p_energy, axis=1)
+            return htf.compute_nlist_forces(nlist, energy)
+
+    sim = standin.Simulation(sysm)
+    sim.integrate_nve(0.005)
+    tfc = htf.tfcompute(LJModel(NN))
+    cell = sim.nlist_cell(r_buff=0.4, check_period=1, pitch=NN)  # the 2-D fluid clusters: rows well above the mean density's
+    tfc.attach(cell, r_cut=rcut)
+    sim.run(max(args.equil, 200))  # first step traces the model; the rest mixes the lattice
+    rounds = []
+    for _ in range(5):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sim.run(1000)
+        torch.cuda.synchronize()
+        rounds.append(time.perf_counter() - t0)
+    el = float(np.median(rounds))
+    f = tfc.force
+    assert bool(torch.isfinite(f).all())
+    published = 1000.0 / 2.0071  # median of the newer of the two published runs (BASELINE.md)
+    out = {
+        "metric": "MD steps/sec, the reference's published benchmark workload (256 particles, LJModel NN=64, through tfcompute)",
+        "value": 1000.0 / el, "unit": "steps/s", "n_gpus": 1, "steps": 1000, "warmup": max(args.equil, 200),
+        "ms_per_step": el, "higher_is_better": True, "scaling": "weak", "dtype": "f32", "data": "synthetic",
+        "vs_baseline": (1000.0 / el) / published,
+        "baseline": {"value": published, "unit": "steps/s", "where": "BASELINE.md: test_lj_benchmark, median 2.0071 s per 1000 steps, "
+                     "Xeon Gold 6130 node, TF2 graph + HOOMD pair.lj + Langevin in the same steps (device mode not recorded)"},
+        "config": {"workload": "htf/test-py/benchmark.py: sq lattice 16 x 16, a = 2.0, r_cut 3.0, r_buff 0.4, check_period 1, dt 0.005; "
+                               "stand-in NVE at kT = 1 instead of HOOMD Langevin + pair.lj", "rounds_s": rounds},
+        "replayed": tfc._plan is not None,
+        "energy_per_particle": float(f[:, 3].double().sum().item()) / sysm.N,
+        "roofline": None, "cpu_baseline": None,
+        "note": "overhead-bound at this size: the whole step is host enqueue (nlist check + one kernel + integrate)",
+    }
+    print(json.dumps(out))
 
 
 def run_eds(args, htf, standin, dev):
@@ -466,6 +523,10 @@ def main():
         if world > 1:
             raise SystemExit("the C4 workload is a single-GPU configuration")
         return run_eds(args, htf, standin, dev)
+    if args.workload == "ref-lj256":
+        if world > 1:
+            raise SystemExit("the reference's own benchmark is a 256-particle, single-device workload")
+        return run_ref_lj256(args, htf, standin, dev)
     headline = args.workload == "lj" and world == 1 and not args.f64 and not args.two_kernel
     out = run_md(args, E, args.workload, variants=not args.no_fused, cpu=not args.no_cpu_baseline)
     if headline and not args.no_mlp and args.cells == 32:

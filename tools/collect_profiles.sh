@@ -3,7 +3,7 @@ set -e
 R=${1:-r02}
 cd "$(dirname "$0")/.."
 F=gpurun_out/final
-for n in bench_lj bench_lj_200 bench_lj_f64 bench_wca bench_wca_c2 bench_mlp bench_mlp_bf16 bench_mlp_split bench_mlp_train bench_rehearsal_2ranks_strong_gloo bench_rehearsal_8ranks_strong_gloo bench_rehearsal_2ranks_weak_gloo bench_rehearsal_c5_8ranks_weak_mlptrain_gloo bench_rehearsal_2ranks_strong_torchrun_gloo bench_rehearsal_2ranks_strong_mlp_gloo; do
+for n in bench_ref_lj256 bench_lj bench_lj_200 bench_lj_f64 bench_wca bench_wca_c2 bench_mlp bench_mlp_bf16 bench_mlp_split bench_mlp_train bench_rehearsal_2ranks_strong_gloo bench_rehearsal_8ranks_strong_gloo bench_rehearsal_2ranks_weak_gloo bench_rehearsal_c5_8ranks_weak_mlptrain_gloo bench_rehearsal_2ranks_strong_torchrun_gloo bench_rehearsal_2ranks_strong_mlp_gloo; do
   [ -s $F/$n.json ] && cp $F/$n.json profiles/${R}_$n.json
 done
 cp $F/bench_eds.json profiles/${R}_bench_eds_c4.json

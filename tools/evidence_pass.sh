@@ -17,6 +17,7 @@ python bench.py --workload mlp-bf16 --steps 100 --warmup 10 --no-cpu-baseline 2>
 python bench.py --workload mlp-split --steps 100 --warmup 10 --no-cpu-baseline 2>/dev/null | jl > $F/bench_mlp_split.json
 python bench.py --workload mlp-train --steps 400 --warmup 20 --no-cpu-baseline 2>/dev/null | jl > $F/bench_mlp_train.json
 python bench.py --workload eds 2>/dev/null | jl > $F/bench_eds.json
+python bench.py --workload ref-lj256 2>/dev/null | jl > $F/bench_ref_lj256.json          # the one workload the reference publishes a number for
 HTF_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 20 --warmup 5 --no-cpu-baseline --no-fused 2>/dev/null | jl > $F/bench_rehearsal_2ranks_strong_gloo.json
 HTF_BENCH_BACKEND=gloo python bench.py --gpus 8 --steps 20 --warmup 5 --no-cpu-baseline --no-fused 2>/dev/null | jl > $F/bench_rehearsal_8ranks_strong_gloo.json
 HTF_BENCH_BACKEND=gloo python bench.py --gpus 2 --scaling weak --steps 20 --warmup 5 --no-cpu-baseline --no-fused 2>/dev/null | jl > $F/bench_rehearsal_2ranks_weak_gloo.json
