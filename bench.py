@@ -225,6 +225,15 @@ def run_ref_lj256(args, htf, standin, dev):
         torch.cuda.synchronize()
         rounds.append(time.perf_counter() - t0)
     el = float(np.median(rounds))
+    # the same loop with whole steps replayed from a hipGraph (Simulation.run(graph=True)): one launch per step
+    g_rounds = []
+    for _ in range(5):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sim.run(1000, graph=True)
+        torch.cuda.synchronize()
+        g_rounds.append(time.perf_counter() - t0)
+    g_el = float(np.median(g_rounds[1:]))  # the first round captures
     f = tfc.force
     assert bool(torch.isfinite(f).all())
     published = 1000.0 / 2.0071  # median of the newer of the two published runs
@@ -238,6 +247,11 @@ def run_ref_lj256(args, htf, standin, dev):
         "config": {"workload": "htf/test-py/benchmark.py: sq lattice 16 x 16, a = 2.0, r_cut 3.0, r_buff 0.4, check_period 1, dt 0.005; "
                                "stand-in NVE at kT = 1 instead of HOOMD Langevin + pair.lj", "rounds_s": rounds},
         "replayed": tfc._plan is not None,
+        "graph_variant": {"value": 1000.0 / g_el, "unit": "steps/s", "vs_baseline": (1000.0 / g_el) / published,
+                          "captured": getattr(sim, "_graph", None) is not None, "rounds_s": g_rounds,
+                          "note": "sim.run(1000, graph=True): the step (device-side list check + gated rebuild + force kernel + "
+                                  "integrator) captured once, replayed as one hipGraph launch per step; same trajectory bit for bit "
+                                  "(tests/test_gpu_standin.py::test_graphed_run_equals_stepwise)"},
         "energy_per_particle": float(f[:, 3].double().sum().item()) / sysm.N,
         "roofline": None, "cpu_baseline": None,
         "note": "overhead-bound at this size: the whole step is host enqueue (nlist check + one kernel + integrate)",
@@ -957,6 +971,48 @@ def run_md(args, E, workload, variants=True, cpu=True):
             "value": args.steps / el, "unit": "steps/s", "ms_per_step": el / args.steps * 1e3,
             "eval_forces_avg_us": e_s * 1e6, "executed_TFLOPs": flops / e_s / 1e12 if e_s > 0 else None,
             "max_rel_force_difference_vs_fp32_mfma": rel}
+    # (b') the same step loop replayed from a hipGraph: one check period of steps (distance check, gated rebuild, force
+    # kernel, integrator) captured once, one launch per period afterwards.  Kernel durations cannot be bracketed inside a
+    # replay, so this is reported beside `value`, not as it.
+    if (not args.no_fused and args.workload in ("lj", "wca") and world == 1 and train is None and nl._device_ok()
+            and nl._stat is not None and args.steps % args.check_period == 0):
+        cyc = args.check_period
+        while state["ts"] % cyc != 0:
+            step()
+        torch.cuda.synchronize()
+        nl._poll_overflow()
+        b_before = nl.n_builds
+        g = torch.cuda.CUDAGraph()
+        ts0 = state["ts"]
+        nl._capturing = True
+        try:
+            with torch.cuda.graph(g):
+                for _ in range(cyc):
+                    step()
+        finally:
+            nl._capturing = False
+            state["ts"] = ts0
+        assert nl.n_builds == b_before
+
+        def graph_window():
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps // cyc):
+                g.replay()
+            torch.cuda.synchronize()
+            state["ts"] += args.steps
+            return time.perf_counter() - t0
+
+        graph_window()
+        gw = [graph_window() for _ in range(n_windows)]
+        nl.mark_check_enqueued()
+        torch.cuda.synchronize()
+        nl._poll_overflow()
+        assert bool(torch.isfinite(sysm.force).all())
+        out["graph_variant"] = {
+            "note": "the step loop replayed from a hipGraph of %d steps (one check period); same kernels, same decisions on the device" % cyc,
+            "value": args.steps / float(np.median(gw)), "unit": "steps/s", "ms_per_step": float(np.median(gw)) / args.steps * 1e3,
+            "windows_ms_per_step": [w / args.steps * 1e3 for w in gw]}
     # (c) the same MD through the plugin surface a user touches: an htf.SimModel written op by op as in the
     # reference's LJModel (build_examples.py:67-77), htf.tfcompute(model).attach(nlist, r_cut), and the
     # stand-in's System::run loop.  tfcompute traces the model on its first step and replays it as the

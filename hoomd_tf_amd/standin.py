@@ -10,6 +10,7 @@ and the sort used for cell binning; the search/integration kernels are HIP
 """
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import torch
@@ -239,7 +240,9 @@ class CellNlist:
         """NeighborList::compute at a check step with the decision left to the device: distance check, then
         the whole rebuild gated on its result.  No host synchronisation."""
         s = self.sys
-        self._poll_overflow()
+        capturing = getattr(self, "_capturing", False)  # inside Simulation's hipGraph capture: no host-side waits
+        if not capturing:
+            self._poll_overflow()
         if self._stat is None:
             self._stat = torch.zeros(2, dtype=torch.int32, device=s.device)  # [largest row of the last rebuild, rebuilds]
             self._stat_host = torch.zeros(2, dtype=torch.int32).pin_memory()
@@ -266,6 +269,11 @@ class CellNlist:
         finally:
             check(lib.htfs_set_gate(None, 0.0))
         self._stat_host.copy_(self._stat, non_blocking=True)
+        if not capturing:
+            self.mark_check_enqueued()
+
+    def mark_check_enqueued(self):
+        """An event behind the check's read-back; _poll_overflow waits for it one check later."""
         self._stat_event = torch.cuda.Event()
         self._stat_event.record()
 
@@ -395,10 +403,68 @@ class Simulation:
         for c in self.computes:
             c.compute(ts)
 
-    def run(self, nsteps):
+    def _graph_cycle(self):
+        """Steps per replayable cycle, or 0: one force compute that says its step is a fixed launch sequence
+        (tfcompute.graph_safe), whose neighbor list decides its rebuilds on the device, plain NVE, nothing observing."""
+        if len(self.forces) != 1 or self.computes or not isinstance(self.integrator, NVE) or self.integrator.group is not None:
+            return 0
+        f = self.forces[0]
+        nl = getattr(f, "_nlist", None)
+        if not getattr(f, "graph_safe", lambda: False)() or not isinstance(nl, CellNlist) or not nl._device_ok() or nl._stat is None:
+            return 0
+        return nl.check_period
+
+    def _run_graphed(self, nsteps):
+        """Launch-bound systems (a few thousand particles: a step is ~15 kernels of ~1 us behind ~70 us of host
+        enqueue): one check period of steps is captured into a hipGraph once and replayed, one launch per cycle.
+        Every kernel reads its decisions from the device (gated rebuild), so the captured sequence is the step."""
         s = self.system
-        for _ in range(int(nsteps)):
-            self.compute_forces()
-            if self.integrator is not None:
-                self.integrator.step()
-            s.timestep += 1
+        cycle = self._graph_cycle()
+        if cycle == 0 or nsteps < 4 * cycle:
+            return nsteps
+        while s.timestep % cycle != 0 and nsteps > 0:  # cycles start at a check step
+            self._step()
+            nsteps -= 1
+        f, nl = self.forces[0], self.forces[0]._nlist
+        key = (id(f), id(nl), id(self.integrator), cycle, s.N, nl.pitch, f.graph_key())
+        if getattr(self, "_graph_key", None) != key:
+            torch.cuda.synchronize()
+            nl._poll_overflow()
+            g = torch.cuda.CUDAGraph()
+            ts0 = s.timestep
+            nl._capturing = True
+            try:
+                with torch.cuda.graph(g):
+                    for _ in range(cycle):
+                        self._step()
+            finally:
+                nl._capturing = False
+                s.timestep = ts0  # a capture records, it does not run
+            self._graph, self._graph_key = g, key
+        polled = 0
+        while nsteps >= cycle:
+            if polled == 0:
+                nl._poll_overflow()  # the overflow report of ~8 cycles ago: long since on the host
+            self._graph.replay()
+            f._calls = getattr(f, "_calls", 0) + cycle
+            s.timestep += cycle
+            nsteps -= cycle
+            polled = (polled + 1) % 8
+            if polled == 1:
+                nl.mark_check_enqueued()
+        return nsteps
+
+    def _step(self):
+        self.compute_forces()
+        if self.integrator is not None:
+            self.integrator.step()
+        self.system.timestep += 1
+
+    def run(self, nsteps, graph=None):
+        """graph=True (or HTF_RUN_GRAPH=1): replay whole check periods as one hipGraph launch where the step
+        qualifies (_graph_cycle); anything else, and the remainder, runs step by step."""
+        nsteps = int(nsteps)
+        if graph if graph is not None else os.environ.get("HTF_RUN_GRAPH") == "1":
+            nsteps = self._run_graphed(nsteps)
+        for _ in range(nsteps):
+            self._step()

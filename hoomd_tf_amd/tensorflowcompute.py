@@ -190,6 +190,16 @@ class tfcompute:
                                               self.virial, s.N)
         return self.cpp_force.make_arrays(s.pos, s.N, None, None, None, s.box, self.force, self.virial, s.N)
 
+    def graph_safe(self):
+        """True when a step of this compute is a fixed sequence of launches (the installed one-kernel plan, every
+        step, no training, no output capture, no host-side precompute): Simulation.run may replay it from a hipGraph."""
+        return (self._plan is not None and self.model._plan is self._plan and self.period == 1 and not self.train
+                and not self.model._map_nlist and getattr(self._nlist, "domain", None) is None
+                and self.force.shape[0] == self.system.N and not getattr(self, "save_output_period", None))
+
+    def graph_key(self):
+        return (id(self._plan), self.force.data_ptr())
+
     def compute(self, timestep):
         """ForceCompute::compute -> TensorflowCompute::computeForces (.cc:129-216)."""
         if timestep % self.period != 0:

@@ -246,3 +246,42 @@ def test_device_decided_rebuild_reports_row_overflow_late(htf, cuda):
     nl.compute(1)
     with pytest.raises(RuntimeError, match="row overflow"):
         nl.compute(2)
+
+
+def test_graphed_run_equals_stepwise(htf, cuda):
+    """Simulation.run(n, graph=True): whole check periods replayed from a hipGraph (one launch per cycle) must give
+    the trajectory of the step-by-step loop bit for bit -- the captured launch sequence IS the step, every decision in
+    it (distance check, gated rebuild) is taken on the device."""
+    from hoomd_tf_amd import standin
+
+    class LJModel(htf.SimModel):
+        def compute(self, nlist, positions, box):
+            rinv = htf.nlist_rinv(nlist)
+            inv_r6 = rinv**6
+            energy = htf.reduce_sum(4.0 / 2.0 * (inv_r6 * inv_r6 - inv_r6), axis=1)
+            return htf.compute_nlist_forces(nlist, energy)
+
+    def run(graph):
+        pos, L, a = standin.fcc_positions(6, 0.8442)
+        rng = np.random.default_rng(11)
+        pos = pos + 0.03 * a * rng.standard_normal(pos.shape)
+        pos -= np.round(pos / L) * L
+        sysm = standin.System(pos, L, dtype=torch.float32, device=cuda)
+        sysm.randomize_velocities(kT=1.0, seed=11)
+        sim = standin.Simulation(sysm)
+        sim.integrate_nve(0.004)
+        tfc = htf.tfcompute(LJModel(96))
+        cell = sim.nlist_cell(r_buff=0.4, check_period=3, pitch=160)
+        tfc.attach(cell, r_cut=2.5)
+        sim.run(7)  # traces, installs the plan, first device-side check
+        sim.run(200, graph=graph)
+        sim.run(5)
+        torch.cuda.synchronize()
+        cell._poll_overflow()
+        return sysm.pos.clone(), sysm.vel.clone(), tfc.force.clone(), cell.device_builds(), getattr(sim, "_graph", None), sysm.timestep
+
+    p0, v0, f0, b0, g0, t0 = run(False)
+    p1, v1, f1, b1, g1, t1 = run(True)
+    assert g0 is None and g1 is not None, "the graphed run did not capture"
+    assert t0 == t1 == 212 and b0 == b1 and b0 >= 5, (t0, t1, b0, b1)
+    assert torch.equal(p0, p1) and torch.equal(v0, v1) and torch.equal(f0, f1)
