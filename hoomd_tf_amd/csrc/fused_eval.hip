@@ -17,6 +17,9 @@
 // but is never read back: the evaluator's 268 MB re-read and its launch disappear from the step.
 #include <cstdlib>
 
+#include <cstring>
+#include <vector>
+
 #include "box_math.h"
 #include "htf_common.h"
 #include "htf_internal.h"
@@ -611,7 +614,64 @@ struct Rdf2 {
     float r0, r1;
     unsigned nb;
     unsigned *hist;
+    const float *edges; // [nb + 1] bin thresholds on the SQUARED norm (rdf_edges below)
 };
+
+// tf.histogram_fixed_width's bin of a pair vector,  clamp(floor(nb * ((sqrt_rn(fl(fl(x x + y y) + z z)) - r0) / (r1 - r0)))),
+// is a non-decreasing step function of the squared norm s: every operation in it is monotone.  edges[b] = the smallest
+// fp32 s whose bin is >= b (b = 1 .. nb-1; edges[0] = -1, edges[nb] = +inf), found by bisection over the fp32 bit
+// patterns with the SAME host arithmetic (IEEE sqrtf, division, floorf).  The sweep then needs no correctly rounded
+// square root and no division per slot: a 1-ulp v_sqrt_f32 guess g, then  g - (s < edges[g]) + (s >= edges[g+1]).
+static float rdf_bin_exact_host(float s, float r0, float r1, unsigned nb) {
+    const volatile float r = sqrtf(s);
+    const volatile float d = r - r0;
+    const volatile float w = r1 - r0;
+    const volatile float q = d / w;
+    const volatile float pqr = (float)nb * q;
+    const float fi = floorf(pqr);
+    return fi < 0.f ? 0.f : (fi > (float)(nb - 1) ? (float)(nb - 1) : fi);
+}
+
+struct RdfEdgeCache {
+    float r0 = 0.f, r1 = 0.f;
+    unsigned nb = 0;
+    int dev = -1;
+    float *d = nullptr;
+    std::vector<float> h;
+};
+
+static int rdf_edges(float r0, float r1, unsigned nb, hipStream_t stream, const float **out) {
+    static thread_local RdfEdgeCache c;
+    int dev = 0;
+    HTF_CHECK_HIP(hipGetDevice(&dev));
+    if (c.d != nullptr && c.dev == dev && c.r0 == r0 && c.r1 == r1 && c.nb == nb) {
+        *out = c.d;
+        return HTF_OK;
+    }
+    c.h.assign((size_t)nb + 1, 0.f);
+    c.h[0] = -1.f;
+    c.h[nb] = __builtin_inff();
+    for (unsigned b = 1; b < nb; ++b) {
+        // smallest non-negative finite fp32 (by bit pattern) whose bin is >= b; none: +inf
+        unsigned lo = 0u, hi = 0x7f800000u; // hi is never a candidate: answer in [lo, hi]
+        while (lo < hi) {
+            const unsigned mid = lo + (hi - lo) / 2u;
+            float x;
+            std::memcpy(&x, &mid, 4);
+            if (rdf_bin_exact_host(x, r0, r1, nb) >= (float)b) hi = mid; else lo = mid + 1u;
+        }
+        std::memcpy(&c.h[b], &lo, 4);
+    }
+    if (c.d == nullptr || c.dev != dev) { // (a table of another device stays with that device)
+        c.d = nullptr;
+        HTF_CHECK_HIP(hipMalloc((void **)&c.d, (size_t)(kRdfMaxBins2 + 1) * sizeof(float)));
+    }
+    HTF_CHECK_HIP(hipMemcpyAsync(c.d, c.h.data(), ((size_t)nb + 1) * sizeof(float), hipMemcpyHostToDevice, stream));
+    HTF_CHECK_HIP(hipStreamSynchronize(stream)); // once per (range, bins): later calls on other streams find it complete
+    c.r0 = r0; c.r1 = r1; c.nb = nb; c.dev = dev;
+    *out = c.d;
+    return HTF_OK;
+}
 
 // COMPACT (NN <= 128): the survivors of a row are first written to a wave-private LDS row at their final slot, then
 // both potentials, the CV term and the histogram bin are evaluated slot by slot -- two trips over the ~95 survivors
@@ -631,9 +691,11 @@ __global__ __launch_bounds__(256) void fused_forces2_kernel(
     __shared__ unsigned s_hist[kRdfMaxBins2];
     __shared__ float4 s_rows[COMPACT ? 4 * 128 : 1];
     float4 *mine = s_rows + (COMPACT ? (threadIdx.x >> 6) * 128 : 0);
+    __shared__ float s_edge[kRdfMaxBins2 + 1];
     const bool do_rdf = rdf.hist != nullptr;
     if (do_rdf) {
         for (unsigned i = threadIdx.x; i < rdf.nb; i += blockDim.x) s_hist[i] = 0;
+        for (unsigned i = threadIdx.x; i <= rdf.nb; i += blockDim.x) s_edge[i] = rdf.edges[i];
         __syncthreads();
     }
     const unsigned lane = threadIdx.x & 63u, wb = threadIdx.x >> 6;
@@ -655,16 +717,13 @@ __global__ __launch_bounds__(256) void fused_forces2_kernel(
         pair_eval<HTF_POT_GAUSS>(x, y, z, pb, e, fx, fy, fz);
         bx += fx; by += fy; bz += fz; be += e;
         if (do_rdf) {
-            // tf.histogram_fixed_width: floor(nbins * ((v - lo) / (hi - lo))) in fp32, division included.  The
-            // multiply by nbins / (hi - lo) gives the same bin except within a few ulps of an edge: only there is the
-            // division taken (33 M slots at C4: the two forms disagreed on a handful -- caught by
-            // test_full_size_c4_eds_sweep, invisible at fixture size)
-            const float r = plain_norm3(x, y, z);
-            const float d = r - rdf.r0;
-            const float qf = d * rdf_scale;
-            float fi = floorf(qf);
-            if (fabsf(qf - rintf(qf)) <= 1e-5f * fmaxf(1.f, fabsf(qf))) fi = floorf((float)rdf.nb * (d / (rdf.r1 - rdf.r0)));
-            const int idx = fi < 0.f ? 0 : (fi > (float)(rdf.nb - 1) ? (int)(rdf.nb - 1) : (int)fi);
+            // tf.histogram_fixed_width's bin from the squared norm and the threshold table (rdf_edges): a 1-ulp square
+            // root and a multiply give a guess that is off by at most one, two LDS words settle it -- no correctly
+            // rounded sqrt, no division (33 M slots at C4 agree with the oracle bin for bin: test_full_size_c4_eds_sweep)
+            const float sq = plain_sq3(x, y, z);
+            const float qf = floorf((__builtin_amdgcn_sqrtf(sq) - rdf.r0) * rdf_scale);
+            int idx = (int)fminf(fmaxf(qf, 0.f), (float)(rdf.nb - 1));
+            idx += (sq >= s_edge[idx + 1] ? 1 : 0) - (sq < s_edge[idx] ? 1 : 0);
             if (idx == 0) ++n_lo;
             else if (idx == (int)rdf.nb - 1) ++n_hi;
             else atomicAdd(&s_hist[idx], 1u);
@@ -902,7 +961,12 @@ int fused_forces2_impl(const PotParams &pa, const PotParams &pb, const void *pos
     if (rdf_hist != nullptr)
         HTF_REQUIRE(rdf_nb >= 3 && rdf_nb <= kRdfMaxBins2 && rdf_r1 > rdf_r0, "htf_build_eval_forces2: need 3 <= bins <= %u and r1 > r0", kRdfMaxBins2);
     if (batch == 0) return HTF_OK;
-    const Rdf2 rdf{rdf_r0, rdf_r1, rdf_nb, rdf_hist};
+    const float *edges = nullptr;
+    if (rdf_hist != nullptr) {
+        const int rc_e = rdf_edges(rdf_r0, rdf_r1, rdf_nb, s, &edges);
+        if (rc_e != HTF_OK) return rc_e;
+    }
+    const Rdf2 rdf{rdf_r0, rdf_r1, rdf_nb, rdf_hist, edges};
     const int out_f64 = force_dtype == HTF_F64;
 #define HTF_F2(K)                                                                                                      \
     (pos_dtype == HTF_F32 ? launch_fused2<K, float>(pa, pb, pos, N, NN, offset, batch, box, n_neigh, nlist, head_list, rmax, fa, fb, out_f64, partials, rdf, dest, counts_io, s) \

@@ -112,11 +112,12 @@ __device__ __forceinline__ void store_stream(double4 *p, const double4 &v) {
 // and sum rounded on its own (no fused multiply-add), correctly rounded square root.  The histogram bin of a pair
 // sitting within an ulp of a bin edge depends on these roundings: at 33 M slots (C4) a contracted x*x + y*y + z*z
 // moves a handful of pairs across an edge relative to TensorFlow's (and the oracle's) arithmetic.
-__device__ __forceinline__ float plain_norm3(float x, float y, float z) {
+__device__ __forceinline__ float plain_sq3(float x, float y, float z) {
 #pragma clang fp contract(off)
     const float xx = x * x, yy = y * y, zz = z * z;
-    return sqrtf((xx + yy) + zz);
+    return (xx + yy) + zz;
 }
+__device__ __forceinline__ float plain_norm3(float x, float y, float z) { return sqrtf(plain_sq3(x, y, z)); }
 
 // number of set bits of a wave ballot below this lane: v_mbcnt_lo/hi, two instructions
 // (the portable popcount(m & ((1 << lane) - 1)) costs a 64-bit shift, mask and two bit counts)
