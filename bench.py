@@ -59,6 +59,7 @@ def parse():
     ap.add_argument("--dt", type=float, default=0.005)
     ap.add_argument("--check-period", type=int, default=5, help="nlist distance-check period (HOOMD check_period)")
     ap.add_argument("--equil", type=int, default=300, help="untimed relaxation steps (force cap + velocity rescale)")
+    ap.add_argument("--settle", type=int, default=100, help="untimed plain NVE steps between the relaxation and the warmup")
     ap.add_argument("--sort", action="store_true", help="enable the stand-in's particle sorter (HOOMD SFCPack analogue; measured: no kernel gain)")
     ap.add_argument("--no-fused", action="store_true", help="skip the extra variants (two-kernel dataflow, tensor-less fused mode)")
     ap.add_argument("--one-kernel", action="store_true",
@@ -739,6 +740,11 @@ def run_md(args, E, workload, variants=True, cpu=True):
             el = float(t.item())
         return el
 
+    # second half of the equilibration: plain NVE, the loop that is timed below.  (The relaxation above is a chain of small
+    # torch ops with the GPU mostly idle; the first ~40 steps after it ran 8 % slower than the rest, kernels included, until
+    # the clocks had followed the load.)
+    for _ in range(args.settle):
+        step()
     for _ in range(args.warmup):
         step()
     # kernel durations: hipEvents around every PROF_EVERY-th htf_compute_forces batch of the timed region

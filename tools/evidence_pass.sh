@@ -37,7 +37,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_eds -o eds -- pyt
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_c2 -o c2 -- python3 bench.py --workload wca --lattice sc --cells 32 --no-cpu-baseline > /dev/null 2>&1
 for n in lj mlp mt eds c2; do find /tmp/p_$n -name "*kernel_stats.csv" -exec cp {} $F/${n}_kernel_stats.csv \; ; done
 # HBM bytes: FETCH_SIZE and WRITE_SIZE in separate passes (they do not fit one), short runs
-S="--no-cpu-baseline --no-mlp --no-fused --steps 20 --warmup 5 --equil 60 --windows 1"
+S="--no-cpu-baseline --no-mlp --no-fused --steps 20 --warmup 5 --equil 60 --settle 0 --windows 1"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/c_f -o f -- python3 bench.py $S > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/c_w -o w -- python3 bench.py $S > /dev/null 2>&1
 # where the LJ step's time goes: TA / TCP and SQ counters of its one kernel
@@ -46,14 +46,14 @@ for set in "TA_TA_BUSY_sum TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_
   rocprofv3 --pmc $set --output-format csv -d /tmp/pk_$n -o x -- python3 bench.py $S > /dev/null 2>&1
 done
 # the C2 and C4 kernels: where their time goes (same counter sets as the LJ step)
-C2="--workload wca --lattice sc --cells 32 --no-cpu-baseline --no-fused --steps 20 --warmup 5 --equil 60 --windows 1"
+C2="--workload wca --lattice sc --cells 32 --no-cpu-baseline --no-fused --steps 20 --warmup 5 --equil 60 --settle 0 --windows 1"
 for set in "TA_TA_BUSY_sum TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES" "GRBM_GUI_ACTIVE GRBM_COUNT"; do
   n=$(echo $set | tr ' ' '_' | cut -c1-40); rm -rf /tmp/p2_$n /tmp/p4_$n
   rocprofv3 --pmc $set --output-format csv -d /tmp/p2_$n -o x -- python3 bench.py $C2 > /dev/null 2>&1
   rocprofv3 --pmc $set --output-format csv -d /tmp/p4_$n -o x -- python3 bench.py --workload eds --steps 20 --warmup 5 --equil 40 > /dev/null 2>&1
 done
 # matrix-pipe counters of the pair-MLP kernels (evaluator fp32 / split, training sweep)
-M="--no-cpu-baseline --steps 6 --warmup 2 --equil 20 --windows 1"
+M="--no-cpu-baseline --steps 6 --warmup 2 --equil 20 --settle 0 --windows 1"
 for set in "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY" "GRBM_GUI_ACTIVE GRBM_COUNT"; do
   n=$(echo $set | tr ' ' '_' | cut -c1-40); rm -rf /tmp/pm_$n /tmp/pt_$n
   rocprofv3 --pmc $set --output-format csv -d /tmp/pm_$n -o x -- python3 bench.py --workload mlp $M > /dev/null 2>&1
