@@ -886,6 +886,8 @@ def run_md(args, E, workload, variants=True, cpu=True):
                                   if args.workload == "mlp-train" else ("C2-WCA" if args.workload == "wca" and n_block == 32768 else "C3-" + args.workload.upper()),
                                   args.cells, n_block, "in all, cut into %d slabs" % world if strong else ("per GPU" if world > 1 else "on one GPU"),
                                   args.rcut, args.rbuff, NN, args.dt),
+                   "preparation": "untimed: %d relaxation steps (force cap + velocity rescale to kT = 1), %d plain NVE steps, then the %d warmup steps"
+                                  % (args.equil, args.settle, args.warmup),
                    "global_particles": n_global, "particles_rank0": N, "parallelism": "dd%dx1x1" % world,
                    "nlist_rebuilds_per_window": rebuilds, "max_neighbors_within_rcut": max_kept,
                    "nlist_decision": "device (gated rebuild kernels, no read-back in the step loop)" if nl.device_decision and world == 1 and not args.sort
