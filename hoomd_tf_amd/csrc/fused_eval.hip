@@ -915,278 +915,11 @@ __global__ __launch_bounds__(256) void fused_forces2_kernel(
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// The same sweep in the four-rows-per-wave form of fused_rows_group_tails (fp32 positions, NN >= 128 slots not needed):
-// the first 128 list entries of each of a wave's four rows straight-line, the four ~11-entry tails in ONE shared trip
-// (9 gather / evaluation trips per four rows instead of 12), no LDS round trip.  All pair vectors and ballots of the
-// group come first, so a row that overflows NN is known before anything has been stored or binned (the generic two-pass
-// row handles it, as it does short batches' ends and rows outside [1, 192] entries).  Persistent workgroups as above
-// (one histogram flush and one CV partial per workgroup); a workgroup iteration covers 16 rows.
-struct Acc8 {
-    float ax = 0.f, ay = 0.f, az = 0.f, ae = 0.f, bx = 0.f, by = 0.f, bz = 0.f, be = 0.f;
-};
-
-template <int KA>
-struct Sweep2 {
-    PotParams pa, pb;
-    bool do_rdf;
-    float r0, scale;
-    int nb;
-    unsigned *hist;    // LDS
-    const float *edge; // LDS
-    unsigned n_lo, n_hi;
-    __device__ __forceinline__ void slot(float x, float y, float z, Acc8 &a) {
-        float e, fx, fy, fz;
-        pair_eval<KA>(x, y, z, pa, e, fx, fy, fz);
-        a.ax += fx; a.ay += fy; a.az += fz; a.ae += e;
-        pair_eval<HTF_POT_GAUSS>(x, y, z, pb, e, fx, fy, fz);
-        a.bx += fx; a.by += fy; a.bz += fz; a.be += e;
-        if (do_rdf) { // see fused_forces2_kernel's eval_slot
-            const float sq = plain_sq3(x, y, z);
-            const float qf = floorf((__builtin_amdgcn_sqrtf(sq) - r0) * scale);
-            int idx = (int)fminf(fmaxf(qf, 0.f), (float)(nb - 1));
-            idx += (sq >= edge[idx + 1] ? 1 : 0) - (sq < edge[idx] ? 1 : 0);
-            if (idx == 0) ++n_lo;
-            else if (idx == nb - 1) ++n_hi;
-            else atomicAdd(&hist[idx], 1u);
-        }
-    }
-};
-
-template <int KA, bool STORE>
-__global__ __launch_bounds__(256) void fused_forces2_tails_kernel(
-    const float4 *__restrict__ pos, unsigned N, unsigned NN, unsigned offset, unsigned batch, BoxT<float> box,
-    const unsigned *__restrict__ n_neigh, const unsigned *__restrict__ nlist, const unsigned *__restrict__ head_list,
-    float rmaxsq, void *__restrict__ forceA, void *__restrict__ forceB, int out_f64, PotParams pa_in, PotParams pb,
-    float *__restrict__ partials, Rdf2 rdf, float4 *__restrict__ dest, unsigned *__restrict__ counts_io) {
-    constexpr int R = 4;
-    __shared__ float s_part[4];
-    __shared__ unsigned s_hist[kRdfMaxBins2];
-    __shared__ float s_edge[kRdfMaxBins2 + 1];
-    const bool do_rdf = rdf.hist != nullptr;
-    if (do_rdf) {
-        for (unsigned i = threadIdx.x; i < rdf.nb; i += blockDim.x) s_hist[i] = 0;
-        for (unsigned i = threadIdx.x; i <= rdf.nb; i += blockDim.x) s_edge[i] = rdf.edges[i];
-        __syncthreads();
-    }
-    const unsigned lane = threadIdx.x & 63u, wb = threadIdx.x >> 6;
-    Sweep2<KA> sw{resolve_theta<KA>(pa_in), pb, do_rdf, rdf.r0, do_rdf ? (float)rdf.nb / (rdf.r1 - rdf.r0) : 0.f, (int)rdf.nb, s_hist, s_edge, 0u, 0u};
-    int pad_bin = 0;
-    if (do_rdf) {
-        const float fi = floorf((float)rdf.nb * ((0.f - rdf.r0) / (rdf.r1 - rdf.r0)));
-        pad_bin = fi < 0.f ? 0 : (fi > (float)(rdf.nb - 1) ? (int)(rdf.nb - 1) : (int)fi);
-    }
-    float cv_wave = 0.f;
-
-    // a finished row: zero tail, padding's bin, row sums, outputs
-    auto finish_row = [&](unsigned w, unsigned Q, Acc8 a) {
-        const unsigned filled = Q < NN ? Q : NN;
-        if constexpr (STORE) {
-            float4 *row = dest + (size_t)w * NN;
-            const unsigned zero_end = counts_io != nullptr ? counts_io[w] : NN;
-            for (unsigned sl = filled + lane; sl < zero_end; sl += 64) store_stream(&row[sl], make_float4(0.f, 0.f, 0.f, 0.f));
-            if (counts_io != nullptr && lane == 0) counts_io[w] = filled;
-        }
-        if (do_rdf && lane == 0 && filled < NN) {
-            const unsigned npad = NN - filled;
-            if (pad_bin == 0) sw.n_lo += npad;
-            else if (pad_bin == (int)rdf.nb - 1) sw.n_hi += npad;
-            else atomicAdd(&s_hist[pad_bin], npad);
-        }
-        a.ax = group_sum<64>(a.ax); a.ay = group_sum<64>(a.ay); a.az = group_sum<64>(a.az); a.ae = group_sum<64>(a.ae);
-        a.bx = group_sum<64>(a.bx); a.by = group_sum<64>(a.by); a.bz = group_sum<64>(a.bz); a.be = group_sum<64>(a.be);
-        if (lane == 0) {
-            if (out_f64) {
-                ((double4 *)forceA)[w] = make_double4(a.ax, a.ay, a.az, a.ae);
-                ((double4 *)forceB)[w] = make_double4(a.bx, a.by, a.bz, a.be);
-            } else {
-                ((float4 *)forceA)[w] = make_float4(a.ax, a.ay, a.az, a.ae);
-                ((float4 *)forceB)[w] = make_float4(a.bx, a.by, a.bz, a.be);
-            }
-        }
-        cv_wave += a.be;
-    };
-    // any row, two passes: count the survivors, then place and evaluate them (the reference's wrap when they exceed NN)
-    auto row_generic = [&](unsigned w) {
-        const unsigned idx = w + offset;
-        const unsigned nn = n_neigh[idx];
-        const unsigned *nl = nlist + head_list[idx];
-        const float4 pi = pos[idx];
-        float4 *row = STORE ? dest + (size_t)w * NN : nullptr;
-        unsigned Q = 0;
-        for (unsigned base = 0; base < nn; base += 64) {
-            const unsigned j = base + lane;
-            const float4 pk = pos[nl[j < nn ? j : nn - 1]];
-            float dx, dy, dz;
-            const float rsq = pair_vector<float>(pk, pi, box, dx, dy, dz);
-            Q += __popcll(__ballot((j < nn) && !(rsq > rmaxsq)));
-        }
-        const unsigned lo = Q > NN ? Q - NN : 0u;
-        unsigned Q2 = 0;
-        Acc8 a;
-        for (unsigned base = 0; base < nn; base += 64) {
-            const unsigned j = base + lane;
-            const float4 pk = pos[nl[j < nn ? j : nn - 1]];
-            float dx, dy, dz;
-            const float rsq = pair_vector<float>(pk, pi, box, dx, dy, dz);
-            const bool kp = (j < nn) && !(rsq > rmaxsq);
-            const unsigned long long m = __ballot(kp);
-            const unsigned qq = Q2 + ballot_rank(m);
-            Q2 += __popcll(m);
-            if (kp && qq >= lo) {
-                if constexpr (STORE) store_stream(&row[Q > NN ? qq % NN : qq], make_float4(dx, dy, dz, (float)scalar_as_int(pk.w)));
-                sw.slot(dx, dy, dz, a);
-            }
-        }
-        finish_row(w, Q, a);
-    };
-
-    const unsigned ngroups16 = (batch + 15) / 16;
-#pragma unroll 1
-    for (unsigned g = blockIdx.x; g < ngroups16; g += gridDim.x) {
-        const unsigned w0 = g * 16 + wb * R;
-        if (w0 >= batch) continue; // wave-uniform
-        unsigned nn[R], S[R + 1];
-        bool fast = w0 + R <= batch;
-        S[0] = 0;
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            nn[r] = n_neigh[(w0 + r < batch ? w0 + r : w0) + offset];
-            fast = fast && nn[r] != 0 && nn[r] <= 192u;
-            S[r + 1] = S[r] + (nn[r] > 128u ? nn[r] - 128u : 0u);
-        }
-        if (!fast || S[R] > 64u) {
-#pragma unroll 1
-            for (unsigned r = 0; r < (unsigned)R; ++r)
-                if (w0 + r < batch) row_generic(w0 + r);
-            continue;
-        }
-        float4 pi[R];
-        unsigned head[R], k[R][2];
-        float4 q[R][2];
-        unsigned rl = 0;
-#pragma unroll
-        for (int r = 1; r < R; ++r) rl += lane >= S[r] ? 1u : 0u;
-        unsigned head_l = 0, s_l = 0, nn_l = 0;
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            head[r] = head_list[w0 + r + offset];
-            pi[r] = pos[w0 + r + offset];
-            const unsigned *nl = nlist + head[r];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const unsigned j = t * 64 + lane;
-                k[r][t] = nl[j < nn[r] ? j : nn[r] - 1];
-            }
-            head_l = rl == (unsigned)r ? head[r] : head_l;
-            s_l = rl == (unsigned)r ? S[r] : s_l;
-            nn_l = rl == (unsigned)r ? nn[r] : nn_l;
-        }
-        const bool tail_live = lane < S[R];
-        const unsigned kt = nlist[head_l + (tail_live ? 128u + (lane - s_l) : nn_l - 1)];
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-#pragma unroll
-            for (int t = 0; t < 2; ++t) q[r][t] = pos[k[r][t]];
-        float4 qt = pos[kt];
-        // phase 1: every pair vector and ballot of the group (q[r][t].xyz <- the pair vector, .w keeps the type)
-        unsigned long long m[R][2], mt = 0ull;
-        unsigned Q[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            Q[r] = 0;
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const unsigned j = t * 64 + lane;
-                float dx, dy, dz;
-                const float rsq = pair_vector<float>(q[r][t], pi[r], box, dx, dy, dz);
-                m[r][t] = __ballot((j < nn[r]) && !(rsq > rmaxsq));
-                q[r][t].x = dx; q[r][t].y = dy; q[r][t].z = dz;
-                Q[r] += (unsigned)__popcll(m[r][t]);
-            }
-        }
-        unsigned base_l = Q[0];
-        if (S[R] != 0) {
-            float4 pil = pi[0];
-#pragma unroll
-            for (int r = 1; r < R; ++r) {
-                pil.x = rl == (unsigned)r ? pi[r].x : pil.x;
-                pil.y = rl == (unsigned)r ? pi[r].y : pil.y;
-                pil.z = rl == (unsigned)r ? pi[r].z : pil.z;
-            }
-            float dx, dy, dz;
-            const float rsq = pair_vector<float>(qt, pil, box, dx, dy, dz);
-            mt = __ballot(tail_live && !(rsq > rmaxsq));
-            qt.x = dx; qt.y = dy; qt.z = dz;
-#pragma unroll
-            for (int r = 1; r < R; ++r) {
-                const unsigned before = (unsigned)__popcll(S[r] >= 64u ? mt : (mt & ((1ull << S[r]) - 1ull)));
-                base_l = rl == (unsigned)r ? Q[r] - before : base_l;
-            }
-        }
-        unsigned Qtot[R];
-        bool over = false;
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const unsigned long long seg = (S[r + 1] >= 64u ? ~0ull : ((1ull << S[r + 1]) - 1ull)) & ~(S[r] >= 64u ? ~0ull : ((1ull << S[r]) - 1ull));
-            Qtot[r] = Q[r] + (unsigned)__popcll(mt & seg);
-            over = over || Qtot[r] > NN;
-        }
-        if (over) { // (wave-uniform) nothing stored or binned yet
-#pragma unroll 1
-            for (unsigned r = 0; r < (unsigned)R; ++r) row_generic(w0 + r);
-            continue;
-        }
-        // phase 2: place and evaluate
-        Acc8 acc[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            float4 *row = STORE ? dest + (size_t)(w0 + r) * NN : nullptr;
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                if ((unsigned)t * 64 >= nn[r]) break; // wave-uniform
-                const bool keep = (m[r][t] >> lane) & 1ull;
-                const unsigned qq = (t ? (unsigned)__popcll(m[r][0]) : 0u) + ballot_rank(m[r][t]);
-                if (keep) {
-                    if constexpr (STORE) store_stream(&row[qq], make_float4(q[r][t].x, q[r][t].y, q[r][t].z, (float)scalar_as_int(q[r][t].w)));
-                    sw.slot(q[r][t].x, q[r][t].y, q[r][t].z, acc[r]);
-                }
-            }
-        }
-        if (S[R] != 0) {
-            Acc8 ta;
-            if ((mt >> lane) & 1ull) {
-                const unsigned qq = base_l + ballot_rank(mt);
-                if constexpr (STORE) store_stream(dest + (size_t)(w0 + rl) * NN + qq, make_float4(qt.x, qt.y, qt.z, (float)scalar_as_int(qt.w)));
-                sw.slot(qt.x, qt.y, qt.z, ta);
-            }
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const bool mine = rl == (unsigned)r;
-                acc[r].ax += mine ? ta.ax : 0.f; acc[r].ay += mine ? ta.ay : 0.f; acc[r].az += mine ? ta.az : 0.f; acc[r].ae += mine ? ta.ae : 0.f;
-                acc[r].bx += mine ? ta.bx : 0.f; acc[r].by += mine ? ta.by : 0.f; acc[r].bz += mine ? ta.bz : 0.f; acc[r].be += mine ? ta.be : 0.f;
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < R; ++r) finish_row(w0 + r, Qtot[r], acc[r]);
-    }
-    if (partials != nullptr) { // one partial per block, fixed order -> deterministic
-        if (lane == 0) s_part[wb] = cv_wave;
-        __syncthreads();
-        if (threadIdx.x == 0) partials[blockIdx.x] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
-    }
-    if (do_rdf) {
-        unsigned n_lo = group_sum_u<64>(sw.n_lo), n_hi = group_sum_u<64>(sw.n_hi);
-        if (lane == 0) {
-            if (n_lo) atomicAdd(&s_hist[0], n_lo);
-            if (n_hi) atomicAdd(&s_hist[rdf.nb - 1], n_hi);
-        }
-        __syncthreads();
-        for (unsigned i = threadIdx.x; i < rdf.nb; i += blockDim.x)
-            if (s_hist[i]) atomicAdd(&rdf.hist[i], s_hist[i]);
-    }
-}
-
+// (Measured and removed, commit 17bc8a6: this sweep in the four-rows-per-wave form of fused_rows_group_tails -- all pair vectors
+//  and ballots of a group first, so that an overflowing row is known before anything is stored or binned, then 9 evaluation
+//  trips per four rows instead of 12 and no LDS round trip; same tensor, histogram and forces (the 16 C4 / EDS / RDF parity
+//  tests pass).  Eight accumulators for each of four rows beside eight gathered positions: 128 VGPRs, 4 waves per SIMD,
+//  and 229.9 us against 206.2 on the same box (tensor-less and without the histogram: 155.5 against 150.9).)
 unsigned fused_forces2_num_partials(unsigned batch) {
     const unsigned ngroups = (batch + 3) / 4;
     // persistent workgroups: 4096 = 16 per CU, about twice what is resident -- measured at C4
@@ -1205,18 +938,6 @@ static int launch_fused2(const PotParams &pa, const PotParams &pb, const void *p
     BoxT<PT> b = make_boxt<PT>(hb);
     PT rc = (PT)rmax;
     const unsigned grid = fused_forces2_num_partials(batch);
-    static const char *tenv = getenv("HTF_FUSED2_TAILS"); // A/B runs: 1 = the four-rows-per-wave form
-    if constexpr (sizeof(PT) == 4) {
-        if (tenv && atoi(tenv) == 1) {
-            if (dest != nullptr)
-                hipLaunchKernelGGL((fused_forces2_tails_kernel<KA, true>), dim3(grid), dim3(256), 0, s, (const float4 *)pos, N, NN, offset, batch,
-                                   b, n_neigh, nlist, head_list, (float)(rc * rc), fa, fb, out_f64, pa, pb, partials, rdf, dest, counts_io);
-            else
-                hipLaunchKernelGGL((fused_forces2_tails_kernel<KA, false>), dim3(grid), dim3(256), 0, s, (const float4 *)pos, N, NN, offset, batch,
-                                   b, n_neigh, nlist, head_list, (float)(rc * rc), fa, fb, out_f64, pa, pb, partials, rdf, dest, counts_io);
-            return check_launch("fused_forces2_tails_kernel");
-        }
-    }
     static const char *cenv = getenv("HTF_FUSED2_COMPACT"); // A/B runs: 0 = evaluate the candidates in place
     const bool compact = NN <= 128 && (cenv ? atoi(cenv) != 0 : true);
 #define HTF_F2_LAUNCH(ST, CP)                                                                                          \
