@@ -285,3 +285,35 @@ def test_graphed_run_equals_stepwise(htf, cuda):
     assert g0 is None and g1 is not None, "the graphed run did not capture"
     assert t0 == t1 == 212 and b0 == b1 and b0 >= 5, (t0, t1, b0, b1)
     assert torch.equal(p0, p1) and torch.equal(v0, v1) and torch.equal(f0, f1)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_cell_nlist_random_boxes_match_brute_force(htf, cuda, seed):
+    """The binned search on random systems: anisotropic boxes (so that some periodic axes have fewer than 7 search
+    cells -- rint() images -- and others more -- images from the candidate's cell), random density and list radius,
+    both precisions, with and without the type split of a mapped neighbor list.  fp64: the exact brute-force sets;
+    fp32: pairs within rounding of r_list may differ, nothing else."""
+    from hoomd_tf_amd import standin
+    rng = np.random.default_rng(4000 + seed)
+    tdt = torch.float64 if seed % 2 else torch.float32
+    L = rng.uniform(6.0, 22.0, size=3)
+    rho = float(rng.uniform(0.3, 0.9))
+    N = int(min(6000, max(64, rho * np.prod(L))))
+    pos = (rng.random((N, 3)) - 0.5) * L
+    r_cut, r_buff = float(rng.uniform(1.2, 2.6)), float(rng.uniform(0.1, 0.5))
+    types = (rng.random(N) < 0.3).astype(np.int32) if seed % 4 >= 2 else None
+    sysm = standin.System(pos, L, types=types, dtype=tdt, device=cuda)
+    nl = standin.CellNlist(sysm, r_cut=r_cut, r_buff=r_buff)
+    nl.type_split = 1 if types is not None else -1
+    nl.build()
+    p = sysm.pos.cpu().numpy()[:, :3].astype(np.float64)
+    bn, bh, bl = brute_nlist(p, L, r_cut + r_buff)
+    ref = _rows(bn, bh, bl)
+    if types is not None:  # pairs whose types lie on different sides of the split are left out
+        ref = [r[types[r] == types[i]] for i, r in enumerate(ref)]
+    got = _rows(nl.n_neigh.cpu().numpy(), nl.head_list.cpu().numpy(), nl.nlist.cpu().numpy())
+    mism = sum(len(set(g.tolist()) ^ set(r.tolist())) for g, r in zip(got, ref))
+    assert mism <= (6 if tdt == torch.float32 else 0), (seed, mism, L, r_cut + r_buff)
+    for g in got[:: max(1, N // 50)]:  # rows hold no duplicates and never the particle itself
+        assert len(set(g.tolist())) == len(g)
+    assert all(i not in set(g.tolist()) for i, g in enumerate(got[:200]))
