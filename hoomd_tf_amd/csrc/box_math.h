@@ -37,10 +37,13 @@ template <> __device__ __forceinline__ double rint_t<double>(double x) { return 
 template <typename T>
 __device__ __forceinline__ void min_image(T &x, T &y, T &z, const BoxT<T> &b) {
 #pragma clang fp contract(off)
+    // (the empty asm keeps the wave-uniform tilt branches BRANCHES: if-converted, their six multiplies and subtractions
+    //  ran for every candidate of every orthorhombic box -- the kernels that call this are VALU-issue bound)
     if (b.periodic[2]) {
         T img = rint_t<T>(z * b.Linv[2]);
         z -= b.L[2] * img;
         if (!b.ortho) { // wave-uniform
+            asm volatile("" ::: "memory");
             y -= b.L[2] * b.yz * img;
             x -= b.L[2] * b.xz * img;
         }
@@ -48,7 +51,10 @@ __device__ __forceinline__ void min_image(T &x, T &y, T &z, const BoxT<T> &b) {
     if (b.periodic[1]) {
         T img = rint_t<T>(y * b.Linv[1]);
         y -= b.L[1] * img;
-        if (!b.ortho) x -= b.L[1] * b.xy * img;
+        if (!b.ortho) {
+            asm volatile("" ::: "memory");
+            x -= b.L[1] * b.xy * img;
+        }
     }
     if (b.periodic[0]) {
         T img = rint_t<T>(x * b.Linv[0]);

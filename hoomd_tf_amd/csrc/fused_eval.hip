@@ -359,7 +359,7 @@ __device__ __forceinline__ void fused_rows_group_tails(
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const unsigned j = t * 64 + lane;
-            k[r][t] = nl[j < nn[r] ? j : nn[r] - 1];
+            k[r][t] = nl[min(j, nn[r] - 1u)];
         }
         head_l = rl == (unsigned)r ? head[r] : head_l;
         s_l = rl == (unsigned)r ? S[r] : s_l;
@@ -390,7 +390,7 @@ __device__ __forceinline__ void fused_rows_group_tails(
             PT dx, dy, dz;
             const PT rsq = pair_vector<PT>(pk, pi[r], box, dx, dy, dz);
             const bool keep = (j < nn[r]) && !(rsq > rmaxsq);
-            const unsigned long long m = __ballot(keep);
+            const unsigned long long m = ballot64(keep);
             const unsigned qq = Q[r] + ballot_rank(m);
             Q[r] += __popcll(m);
             if (keep && qq < NN) {
@@ -402,7 +402,10 @@ __device__ __forceinline__ void fused_rows_group_tails(
                 fy[r] += ay;
                 fz[r] += az;
                 en[r] += e;
-                npos[r] += x > 0.f ? 1u : 0u;
+                if (check_count != nullptr) { // wave-uniform
+                    asm volatile("" ::: "memory");
+                    npos[r] += x > 0.f ? 1u : 0u;
+                }
             }
         }
     }
@@ -418,7 +421,7 @@ __device__ __forceinline__ void fused_rows_group_tails(
         PT dx, dy, dz;
         const PT rsq = pair_vector<PT>(qt, pil, box, dx, dy, dz);
         const bool keep = tail_live && !(rsq > rmaxsq);
-        const unsigned long long m = __ballot(keep);
+        const unsigned long long m = ballot64(keep);
         // rank inside its own row: kept lanes below me, minus those that belong to earlier rows, plus the row's count so far
         unsigned base_l = Q[0];
 #pragma unroll
@@ -464,15 +467,18 @@ __device__ __forceinline__ void fused_rows_group_tails(
             redo |= 1u << r;
             continue;
         }
-        const float sx = group_sum<64>(fx[r]), sy = group_sum<64>(fy[r]), sz = group_sum<64>(fz[r]), se = group_sum<64>(en[r]);
-        unsigned np = 0;
-        if (check_count != nullptr) np = group_sum_u<64>(npos[r]);
-        if (lane == 0) {
+        // the row's four sums together: rows 0..3 of `tot` hold fx, fz, fy, e; lanes 0 / 16 / 32 / 48 write one component each
+        const float tot = wave_sum4(fx[r], fy[r], fz[r], en[r]);
+        if ((lane & 15u) == 0u) {
+            const unsigned comp = ((lane >> 4) & 1u) * 2u + (lane >> 5); // 0, 2, 1, 3
             if (out_f64)
-                ((double4 *)force)[w] = make_double4(sx, sy, sz, se);
+                ((double *)force)[(size_t)w * 4 + comp] = (double)tot;
             else
-                ((float4 *)force)[w] = make_float4(sx, sy, sz, se);
-            if (check_count != nullptr && np > *(volatile unsigned *)check_count) atomicMax(check_count, np);
+                ((float *)force)[(size_t)w * 4 + comp] = tot;
+        }
+        if (check_count != nullptr) {
+            const unsigned np = group_sum_u<64>(npos[r]);
+            if (lane == 0 && np > *(volatile unsigned *)check_count) atomicMax(check_count, np);
         }
     }
 #pragma unroll 1

@@ -69,6 +69,30 @@ __device__ __forceinline__ float sum_xor16(float v) {
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
+// a + b reduced one butterfly step each, in ONE swap and ONE add: the lower half of the result holds a(l) + a(l + 32), the upper
+// half b(l - 32) + b(l) (v_permlane32_swap exchanges the upper half of its first operand with the lower half of its second);
+// the 16-lane form leaves (a.r0 + a.r1 | b.r0 + b.r1 | a.r2 + a.r3 | b.r2 + b.r3) in rows 0..3.  Two values per step instead of
+// one: the kernels that finish a row with several wave-wide sums (fx, fy, fz, e) are VALU-issue bound.
+__device__ __forceinline__ float pair_sum_xor32(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float pair_sum_xor16(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// wave-wide sums of four values in 10 instructions (32 one by one): rows 0..3 of the result hold sum(a), sum(c), sum(b), sum(d)
+__device__ __forceinline__ float wave_sum4(float a, float b, float c, float d) {
+    float v = pair_sum_xor16(pair_sum_xor32(a, b), pair_sum_xor32(c, d));
+    v += dpp_mov<0xB1>(v);  // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);  // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v); // row_half_mirror
+    v += dpp_mov<0x140>(v); // row_mirror
+    return v;
+}
+// the wave ballot of a bool as the compare mask itself (__ballot(int) re-materialises the predicate: two VALU instructions)
+__device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 template <int G>
 __device__ __forceinline__ float group_sum(float v) {
     static_assert(G >= 1 && G <= 64 && (G & (G - 1)) == 0, "G must be a power of two <= 64");
