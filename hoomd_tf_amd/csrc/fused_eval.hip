@@ -326,7 +326,9 @@ __device__ __forceinline__ void fused_rows_group_tails(
     float4 *__restrict__ dest, unsigned *__restrict__ counts_io) {
     using PV = typename Vec4<PT>::type;
     unsigned nn[R], S[R + 1];
-    bool fast = w0 + R <= batch;
+    // the straight-line path is the common case only: an orthorhombic box periodic in x, y and z, no check_nlist count.
+    // Everything else takes the two-row form below, which carries the general BoxDim arithmetic.
+    bool fast = w0 + R <= batch && box.ortho && box.periodic[0] && box.periodic[1] && box.periodic[2] && check_count == nullptr;
     S[0] = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -375,7 +377,21 @@ __device__ __forceinline__ void fused_rows_group_tails(
     qt = pos[kt];
     float fx[R], fy[R], fz[R], en[R];
     unsigned npos[R], Q[R];
-    // the first 128 entries of every row
+    // the first 128 entries of every row.  The VALU is the unit this kernel saturates, so: the minimum image without the
+    // tilt and non-periodic cases (12 instructions), the live-entry mask of a trip from scalar arithmetic, and the evaluation
+    // WITHOUT a branch -- a dropped candidate is evaluated at x = 1e18, where s^6 underflows and energy and force are
+    // exact zeros -- so that only the tensor store is predicated.
+    const PT Lx = box.L[0], Ly = box.L[1], Lz = box.L[2], ix = box.Linv[0], iy = box.Linv[1], iz = box.Linv[2];
+    auto pair_vec = [&](const PV &pk, const PV &pc, PT &dx, PT &dy, PT &dz) {
+#pragma clang fp contract(off)
+        dx = pk.x - pc.x;
+        dy = pk.y - pc.y;
+        dz = pk.z - pc.z;
+        dz -= Lz * rint_t<PT>(dz * iz); // BoxDim::minImage, orthorhombic and periodic (box_math.h: same operations, same order)
+        dy -= Ly * rint_t<PT>(dy * iy);
+        dx -= Lx * rint_t<PT>(dx * ix);
+        return dx * dx + dy * dy + dz * dz;
+    };
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         float4 *row = STORE ? dest + (size_t)(w0 + r) * NN : nullptr;
@@ -385,28 +401,30 @@ __device__ __forceinline__ void fused_rows_group_tails(
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             if ((unsigned)t * 64 >= nn[r]) break; // wave-uniform
-            const unsigned j = t * 64 + lane;
+            const unsigned left = nn[r] - (unsigned)t * 64; // >= 1
+            const unsigned long long valid = left >= 64u ? ~0ull : ((1ull << left) - 1ull);
             const PV pk = q[r][t];
             PT dx, dy, dz;
-            const PT rsq = pair_vector<PT>(pk, pi[r], box, dx, dy, dz);
-            const bool keep = (j < nn[r]) && !(rsq > rmaxsq);
-            const unsigned long long m = ballot64(keep);
+            const PT rsq = pair_vec(pk, pi[r], dx, dy, dz);
+            const unsigned long long m = ballot64(!(rsq > rmaxsq)) & valid;
             const unsigned qq = Q[r] + ballot_rank(m);
             Q[r] += __popcll(m);
-            if (keep && qq < NN) {
-                const float x = (float)dx, y = (float)dy, z = (float)dz;
-                if constexpr (STORE) store_stream(&row[qq], make_float4(x, y, z, (float)scalar_as_int(pk.w)));
-                float e, ax, ay, az;
-                pair_eval<KIND>(x, y, z, p, e, ax, ay, az);
-                fx[r] += ax;
-                fy[r] += ay;
-                fz[r] += az;
-                en[r] += e;
-                if (check_count != nullptr) { // wave-uniform
+            const bool keep = __builtin_amdgcn_inverse_ballot_w64(m); // the scalar mask read as this lane's predicate: no VALU
+            const float x = (float)dx, y = (float)dy, z = (float)dz;
+            if constexpr (STORE) {
+                unsigned long long ms = m;
+                if (Q[r] > NN) { // (wave-uniform) a row about to overflow: its slots are bounded lane by lane, and it is redone below
                     asm volatile("" ::: "memory");
-                    npos[r] += x > 0.f ? 1u : 0u;
+                    ms &= ballot64(qq < NN);
                 }
+                if (__builtin_amdgcn_inverse_ballot_w64(ms)) store_stream(&row[qq], make_float4(x, y, z, (float)scalar_as_int(pk.w)));
             }
+            float e, ax, ay, az;
+            pair_eval<KIND>(keep ? x : 1e18f, y, z, p, e, ax, ay, az);
+            fx[r] += ax;
+            fy[r] += ay;
+            fz[r] += az;
+            en[r] += e;
         }
     }
     // the shared tail trip
@@ -419,9 +437,8 @@ __device__ __forceinline__ void fused_rows_group_tails(
             pil.z = rl == (unsigned)r ? pi[r].z : pil.z;
         }
         PT dx, dy, dz;
-        const PT rsq = pair_vector<PT>(qt, pil, box, dx, dy, dz);
-        const bool keep = tail_live && !(rsq > rmaxsq);
-        const unsigned long long m = ballot64(keep);
+        const PT rsq = pair_vec(qt, pil, dx, dy, dz);
+        const unsigned long long m = ballot64(!(rsq > rmaxsq)) & (S[R] >= 64u ? ~0ull : ((1ull << S[R]) - 1ull));
         // rank inside its own row: kept lanes below me, minus those that belong to earlier rows, plus the row's count so far
         unsigned base_l = Q[0];
 #pragma unroll
@@ -430,14 +447,13 @@ __device__ __forceinline__ void fused_rows_group_tails(
             base_l = rl == (unsigned)r ? Q[r] - before : base_l;
         }
         const unsigned qq = base_l + ballot_rank(m);
-        float e = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
-        unsigned px = 0;
-        if (keep && qq < NN) {
-            const float x = (float)dx, y = (float)dy, z = (float)dz;
-            if constexpr (STORE) store_stream(dest + (size_t)(w0 + rl) * NN + qq, make_float4(x, y, z, (float)scalar_as_int(qt.w)));
-            pair_eval<KIND>(x, y, z, p, e, ax, ay, az);
-            px = x > 0.f ? 1u : 0u;
-        }
+        const bool keep = __builtin_amdgcn_inverse_ballot_w64(m);
+        const float xt = (float)dx, yt = (float)dy, zt = (float)dz;
+        if constexpr (STORE)
+            if (keep && qq < NN) store_stream(dest + (size_t)(w0 + rl) * NN + qq, make_float4(xt, yt, zt, (float)scalar_as_int(qt.w)));
+        float e, ax, ay, az;
+        pair_eval<KIND>(keep ? xt : 1e18f, yt, zt, p, e, ax, ay, az);
+        const unsigned px = 0;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const bool mine = rl == (unsigned)r;
