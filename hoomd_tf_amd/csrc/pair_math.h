@@ -59,19 +59,36 @@ __device__ __forceinline__ PotParams resolve_theta(PotParams p) {
 
 // shared forward of every rinv-based energy: t = x + 1e-7, r' = |t|, s = nlist_rinv
 struct RinvFwd {
-    float tx, ty, tz, rp, s;
+    float tx, ty, tz, rp, irp, s; // irp = 1 / r'
     bool cond;
 };
 
+// s = 1 / (r' + 3e-6) and 1 / r' from ONE transcendental instruction where there were three (v_sqrt_f32, v_rcp_f32 of the sum,
+// v_rcp_f32 of r'): they issue at a quarter of the VALU rate and the evaluators are VALU-bound.  With s0 = rsq(r'^2) = 1 / r'
+// and u = 3e-6 s0:  1 / (r' + 3e-6) = s0 / (1 + u) = s0 (1 - u + u^2) to within u^3, which for every wave whose live slots all
+// have r' > 0.015 (u < 2e-4, u^3 < 1e-11) is far below an ulp -- and ~2 ulp in all, against ~2.5 for sqrt + add + rcp.  A wave
+// with a closer (unphysical) live slot takes the three-instruction form; the mask r' > 3e-6 is taken on r' = r'^2 * s0.
 __device__ __forceinline__ RinvFwd rinv_fwd(float x, float y, float z) {
     RinvFwd f;
     f.tx = x + kNormDelta;
     f.ty = y + kNormDelta;
     f.tz = z + kNormDelta;
-    f.rp = fast_sqrt(f.tx * f.tx + f.ty * f.ty + f.tz * f.tz);
+    const float t2 = f.tx * f.tx + f.ty * f.ty + f.tz * f.tz;
+    const float s0 = __builtin_amdgcn_rsqf(t2);
+    const float u = kRinvDelta * s0;
+    f.rp = t2 * s0;
     f.cond = f.rp > kRinvDelta;
-    const float sr = fast_rcp(f.rp + kRinvDelta); // unconditional (argument > 0): a select, not a branch
-    f.s = f.cond ? sr : 0.0f;
+    if (__builtin_amdgcn_ballot_w64(f.cond && u >= 2e-4f) == 0ull) { // wave-uniform
+        f.irp = s0;
+        const float sr = fmaf(u * u, s0, fmaf(-u, s0, s0));
+        f.s = f.cond ? sr : 0.0f;
+    } else {
+        f.rp = fast_sqrt(t2);
+        f.cond = f.rp > kRinvDelta;
+        f.irp = fast_rcp(f.rp);
+        const float sr = fast_rcp(f.rp + kRinvDelta);
+        f.s = f.cond ? sr : 0.0f;
+    }
     return f;
 }
 
@@ -133,7 +150,7 @@ __device__ __forceinline__ void pair_eval(float x, float y, float z, const PotPa
             // VALU-issue bound); s = 0 on masked slots makes e and c vanish by themselves.
             const float s6 = s2 * s2 * s2;
             e = 2.0f * fmaf(s6, s6, -s6);
-            const float c = f.cond ? (fmaf(2.0f, s6, -1.0f) * (s6 * s)) * fast_rcp(f.rp) * -24.0f : 0.0f;
+            const float c = f.cond ? (fmaf(2.0f, s6, -1.0f) * (s6 * s)) * f.irp * -24.0f : 0.0f;
             fx = c * f.tx;
             fy = c * f.ty;
             fz = c * f.tz;
@@ -166,7 +183,7 @@ __device__ __forceinline__ void pair_eval(float x, float y, float z, const PotPa
             }
         }
         // d s / d r' = -s^2 (where cond), d r' / d t = t / r'; times 2 (simmodel.py:548)
-        float c = f.cond ? 2.0f * (dEds * (-s2)) * fast_rcp(f.rp) : 0.0f;
+        float c = f.cond ? 2.0f * (dEds * (-s2)) * f.irp : 0.0f;
         fx = c * f.tx;
         fy = c * f.ty;
         fz = c * f.tz;
@@ -211,7 +228,7 @@ __device__ __forceinline__ void pair_eval_grad(float x, float y, float z, const 
     } else {
         RinvFwd f = rinv_fwd(x, y, z);
         const float s = f.s, s2 = s * s;
-        const float geo = f.cond ? 2.0f * (-s2) * fast_rcp(f.rp) : 0.0f; // nlist_forces = geo * dE/ds * t
+        const float geo = f.cond ? 2.0f * (-s2) * f.irp : 0.0f; // nlist_forces = geo * dE/ds * t
         float dEds;
         if constexpr (KIND == HTF_POT_WCA) {
             const float sig = p.sigma;

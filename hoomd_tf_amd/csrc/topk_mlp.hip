@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void topk_mlp_kernel(const typename Vec4<IT>::
             float gt = 0.f;
             for (int a = 0; a < H1; ++a) gt = fmaf(s_x[a], W1[rank[t] * H1 + a], gt);
             // d s / d r' = -s^2, d r' / d x = t / r'; nlist_forces = 2 dE/dx  (simmodel.py:548)
-            const float c = 2.0f * (gt * (-(f[t].s * f[t].s))) * fast_rcp(f[t].rp);
+            const float c = 2.0f * (gt * (-(f[t].s * f[t].s))) * f[t].irp;
             const float ax = c * f[t].tx, ay = c * f[t].ty, az = c * f[t].tz;
             fx += ax; fy += ay; fz += az;
             if constexpr (VIRIAL) vir.add(x[t], y[t], z[t], ax, ay, az);
