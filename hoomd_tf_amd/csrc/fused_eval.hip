@@ -123,8 +123,16 @@ __device__ __forceinline__ void fused_row(const unsigned w, const unsigned lane,
         const unsigned s_lo = Q - NN > NN ? Q - NN : NN;
         fused_sweep<KIND, VIRIAL, STORE ? 2 : 0, PT>(acc, pos, nl, nn, pi, box, rmaxsq, lane, Q - NN, Q, p, row, NN, s_lo);
     }
-    float fx = group_sum<64>(acc.fx), fy = group_sum<64>(acc.fy), fz = group_sum<64>(acc.fz);
-    float en = group_sum<64>(acc.en);
+    // the four row sums as the row-group forms take them (wave_sum4: rows 0..3 of `tot` hold fx, fz, fy, e), so that a row's
+    // force does not depend on which routine computed it
+    const float tot = wave_sum4(acc.fx, acc.fy, acc.fz, acc.en);
+    if ((lane & 15u) == 0u) {
+        const unsigned comp = ((lane >> 4) & 1u) * 2u + (lane >> 5); // 0, 2, 1, 3
+        if (out_f64)
+            ((double *)force)[(size_t)w * 4 + comp] = (double)tot;
+        else
+            ((float *)force)[(size_t)w * 4 + comp] = tot;
+    }
     float v6[6];
     if constexpr (VIRIAL) {
         v6[0] = group_sum<64>(acc.v.xx);
@@ -137,10 +145,6 @@ __device__ __forceinline__ void fused_row(const unsigned w, const unsigned lane,
     unsigned npos = 0;
     if (check_count != nullptr) npos = group_sum_u<64>(acc.npos);
     if (lane == 0) {
-        if (out_f64)
-            ((double4 *)force)[w] = make_double4(fx, fy, fz, en);
-        else
-            ((float4 *)force)[w] = make_float4(fx, fy, fz, en);
         if constexpr (VIRIAL) {
             const float v9[9] = {v6[0], v6[1], v6[2], v6[1], v6[3], v6[4], v6[2], v6[4], v6[5]};
             if (out_f64) {
@@ -230,6 +234,7 @@ __device__ __forceinline__ void fused_rows_group(
                                               force, nullptr, out_f64, p, check_count, positions_out, dest, counts_io);
         return;
     }
+    const bool simple_box = box.ortho && box.periodic[0] && box.periodic[1] && box.periodic[2];
     PV pi[R];
     unsigned k[R][kFChunk];
     PV q[R][kFChunk];
@@ -240,7 +245,7 @@ __device__ __forceinline__ void fused_rows_group(
 #pragma unroll
         for (int t = 0; t < kFChunk; ++t) {
             const unsigned j = t * 64 + lane;
-            k[r][t] = nl[j < nn[r] ? j : nn[r] - 1];
+            k[r][t] = nl[min(j, nn[r] - 1u)];
         }
     }
 #pragma unroll
@@ -259,24 +264,41 @@ __device__ __forceinline__ void fused_rows_group(
 #pragma unroll
         for (int t = 0; t < kFChunk; ++t) {
             if ((unsigned)t * 64 >= nn[r]) break; // wave-uniform
-            const unsigned j = t * 64 + lane;
+            // (as in fused_rows_group_tails: live-entry mask from scalar arithmetic, the lane's predicate read back from the
+            //  scalar mask, evaluation without a branch -- a dropped candidate contributes exact zeros from x = 1e18)
+            const unsigned left = nn[r] - (unsigned)t * 64;
+            const unsigned long long valid = left >= 64u ? ~0ull : ((1ull << left) - 1ull);
             const PV pk = q[r][t];
             PT dx, dy, dz;
-            const PT rsq = pair_vector<PT>(pk, pi[r], box, dx, dy, dz);
-            const bool keep = (j < nn[r]) && !(rsq > rmaxsq);
-            const unsigned long long m = __ballot(keep);
+            PT rsq;
+            if (simple_box) { // wave-uniform: orthorhombic, periodic in x, y and z
+                asm volatile("" ::: "memory");
+                rsq = pair_vector_simple<PT>(pk, pi[r], box, dx, dy, dz);
+            } else {
+                rsq = pair_vector<PT>(pk, pi[r], box, dx, dy, dz);
+            }
+            const unsigned long long m = ballot64(!(rsq > rmaxsq)) & valid;
             const unsigned qq = Q + ballot_rank(m);
             Q += __popcll(m);
-            if (keep && qq < NN) {
-                const float x = (float)dx, y = (float)dy, z = (float)dz;
-                if constexpr (STORE) store_stream(&row[qq], make_float4(x, y, z, (float)scalar_as_int(pk.w)));
-                float e, ax, ay, az;
-                pair_eval<KIND>(x, y, z, p, e, ax, ay, az);
-                fx += ax;
-                fy += ay;
-                fz += az;
-                en += e;
-                npos += x > 0.f ? 1u : 0u;
+            const bool keep = __builtin_amdgcn_inverse_ballot_w64(m);
+            const float x = (float)dx, y = (float)dy, z = (float)dz;
+            if constexpr (STORE) {
+                unsigned long long ms = m;
+                if (Q > NN) { // (wave-uniform) about to overflow: slots bounded lane by lane; the row is redone below
+                    asm volatile("" ::: "memory");
+                    ms &= ballot64(qq < NN);
+                }
+                if (__builtin_amdgcn_inverse_ballot_w64(ms)) store_stream(&row[qq], make_float4(x, y, z, (float)scalar_as_int(pk.w)));
+            }
+            float e, ax, ay, az;
+            pair_eval_if<KIND>(keep, x, y, z, p, e, ax, ay, az);
+            fx += ax;
+            fy += ay;
+            fz += az;
+            en += e;
+            if (check_count != nullptr) { // wave-uniform
+                asm volatile("" ::: "memory");
+                npos += (keep && x > 0.f) ? 1u : 0u;
             }
         }
         const unsigned filled = Q < NN ? Q : NN;
@@ -289,17 +311,17 @@ __device__ __forceinline__ void fused_rows_group(
             redo |= 1u << r;
             continue;
         }
-        fx = group_sum<64>(fx);
-        fy = group_sum<64>(fy);
-        fz = group_sum<64>(fz);
-        en = group_sum<64>(en);
-        if (check_count != nullptr) npos = group_sum_u<64>(npos);
-        if (lane == 0) {
+        const float tot = wave_sum4(fx, fy, fz, en); // rows 0..3: fx, fz, fy, e
+        if ((lane & 15u) == 0u) {
+            const unsigned comp = ((lane >> 4) & 1u) * 2u + (lane >> 5); // 0, 2, 1, 3
             if (out_f64)
-                ((double4 *)force)[w] = make_double4(fx, fy, fz, en);
+                ((double *)force)[(size_t)w * 4 + comp] = (double)tot;
             else
-                ((float4 *)force)[w] = make_float4(fx, fy, fz, en);
-            if (check_count != nullptr && npos > *(volatile unsigned *)check_count) atomicMax(check_count, npos);
+                ((float *)force)[(size_t)w * 4 + comp] = tot;
+        }
+        if (check_count != nullptr) {
+            npos = group_sum_u<64>(npos);
+            if (lane == 0 && npos > *(volatile unsigned *)check_count) atomicMax(check_count, npos);
         }
     }
 #pragma unroll 1
@@ -380,18 +402,8 @@ __device__ __forceinline__ void fused_rows_group_tails(
     // the first 128 entries of every row.  The VALU is the unit this kernel saturates, so: the minimum image without the
     // tilt and non-periodic cases (12 instructions), the live-entry mask of a trip from scalar arithmetic, and the evaluation
     // WITHOUT a branch -- a dropped candidate is evaluated at x = 1e18, where s^6 underflows and energy and force are
-    // exact zeros -- so that only the tensor store is predicated.
-    const PT Lx = box.L[0], Ly = box.L[1], Lz = box.L[2], ix = box.Linv[0], iy = box.Linv[1], iz = box.Linv[2];
-    auto pair_vec = [&](const PV &pk, const PV &pc, PT &dx, PT &dy, PT &dz) {
-#pragma clang fp contract(off)
-        dx = pk.x - pc.x;
-        dy = pk.y - pc.y;
-        dz = pk.z - pc.z;
-        dz -= Lz * rint_t<PT>(dz * iz); // BoxDim::minImage, orthorhombic and periodic (box_math.h: same operations, same order)
-        dy -= Ly * rint_t<PT>(dy * iy);
-        dx -= Lx * rint_t<PT>(dx * ix);
-        return dx * dx + dy * dy + dz * dz;
-    };
+    // exact zeros (pair_eval_if) -- so that only the tensor store is predicated.
+    auto pair_vec = [&](const PV &pk, const PV &pc, PT &dx, PT &dy, PT &dz) { return pair_vector_simple<PT>(pk, pc, box, dx, dy, dz); };
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         float4 *row = STORE ? dest + (size_t)(w0 + r) * NN : nullptr;
@@ -420,7 +432,7 @@ __device__ __forceinline__ void fused_rows_group_tails(
                 if (__builtin_amdgcn_inverse_ballot_w64(ms)) store_stream(&row[qq], make_float4(x, y, z, (float)scalar_as_int(pk.w)));
             }
             float e, ax, ay, az;
-            pair_eval<KIND>(keep ? x : 1e18f, y, z, p, e, ax, ay, az);
+            pair_eval_if<KIND>(keep, x, y, z, p, e, ax, ay, az);
             fx[r] += ax;
             fy[r] += ay;
             fz[r] += az;
@@ -452,7 +464,7 @@ __device__ __forceinline__ void fused_rows_group_tails(
         if constexpr (STORE)
             if (keep && qq < NN) store_stream(dest + (size_t)(w0 + rl) * NN + qq, make_float4(xt, yt, zt, (float)scalar_as_int(qt.w)));
         float e, ax, ay, az;
-        pair_eval<KIND>(keep ? xt : 1e18f, yt, zt, p, e, ax, ay, az);
+        pair_eval_if<KIND>(keep, xt, yt, zt, p, e, ax, ay, az);
         const unsigned px = 0;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -568,14 +580,15 @@ static int launch_fused(const void *pos, unsigned N, unsigned NN, unsigned offse
     hipLaunchKernelGGL((fused_forces_rows2_kernel<KIND, ST, RR, PT>), dim3(grid), dim3(256), 0, s, \
                        (const typename Vec4<PT>::type *)pos, N, NN, offset, batch, b, n_neigh, nlist, head_list,       \
                        (PT)(rc * rc), force, out_f64, p, check_count, positions_out, dest, counts_io)
-        // default for fp32 positions and batches of >= 65 536 rows: four rows per wave with their tails in one trip
+        // default for fp32 positions and batches of >= 16 384 rows (65 536 until the VALU diet of round 2: at 32 000 rows the
+        // four-row form now takes 17.8 us against 19.0-19.4): four rows per wave with their tails in one trip
         // (58.0 us against 60.5 for the two-row form at C3 in isolation, 61.5-62.1 against 62.5-63.3 inside the MD loop,
         // 47.1 against 48.6 without the tensor, 80.7 against 85.4 beside the training stream; two rows with a shared
         // tail: no gain; at 32 768 rows the four-row form LOSES, 24.0 against 22.8: a quarter of the waves on a grid that
         // barely fills the chip).  HTF_FUSED_TAILS=0 selects the two-row form everywhere, whose forces do not depend on
         // how a step is cut into batches / row ranges, bit for bit.
         static const char *tails_env = getenv("HTF_FUSED_TAILS");
-        const int tails = tails_env ? atoi(tails_env) : ((sizeof(PT) == 4 && batch >= 65536u) ? 4 : 0);
+        const int tails = tails_env ? atoi(tails_env) : ((sizeof(PT) == 4 && batch >= 16384u) ? 4 : 0);
         if (tails == 2 || tails == 4) {
 #define HTF_TAILS_LAUNCH(ST, RR)                                                                                       \
     hipLaunchKernelGGL((fused_forces_tails_kernel<KIND, ST, RR, PT>), dim3(((batch + RR - 1) / RR + 3) / 4), dim3(256), 0, s, \

@@ -192,6 +192,24 @@ __device__ __forceinline__ void pair_eval(float x, float y, float z, const PotPa
 }
 
 
+// pair_eval for a slot that may have been dropped, WITHOUT a branch (the fused kernels are VALU-bound and a divergent
+// branch saves nothing unless a whole wave is dropped): potentials that vanish identically far out (s^6 underflows, the WCA
+// mask is false, exp(-r^2 / gap) is 0) are evaluated at x = 1e18, where energy and force come out as exact zeros -- one
+// select; the others are evaluated where they are and their four results selected.
+template <int KIND>
+__device__ __forceinline__ void pair_eval_if(bool keep, float x, float y, float z, const PotParams &p, float &e, float &fx,
+                                             float &fy, float &fz) {
+    if constexpr (KIND == HTF_POT_LJ || KIND == HTF_POT_WCA || KIND == HTF_POT_LJ_PARAM || KIND == HTF_POT_GAUSS) {
+        pair_eval<KIND>(keep ? x : 1e18f, y, z, p, e, fx, fy, fz);
+    } else {
+        pair_eval<KIND>(x, y, z, p, e, fx, fy, fz);
+        e = keep ? e : 0.0f;
+        fx = keep ? fx : 0.0f;
+        fy = keep ? fy : 0.0f;
+        fz = keep ? fz : 0.0f;
+    }
+}
+
 // Per-slot derivatives through the force for training: d(e, nlist_forces)/d(theta_k), k < P.
 // dd[k] = (d fx, d fy, d fz, d e)/d theta_k.  Returns e, (fx, fy, fz) as pair_eval does.
 template <int KIND> struct NumParams;
