@@ -734,6 +734,7 @@ __global__ __launch_bounds__(256) void fused_forces2_kernel(
         __syncthreads();
     }
     const unsigned lane = threadIdx.x & 63u, wb = threadIdx.x >> 6;
+    const bool simple_box = box.ortho && box.periodic[0] && box.periodic[1] && box.periodic[2];
     const float rdf_scale = do_rdf ? (float)rdf.nb / (rdf.r1 - rdf.r0) : 0.f;
     // bin of a zero pair vector (the padded slots of the tensor are part of compute_rdf's input)
     int pad_bin = 0;
@@ -841,10 +842,16 @@ __global__ __launch_bounds__(256) void fused_forces2_kernel(
             nxt = fetch_meta(grp + gridDim.x); // in flight beside this row's gathers
 #pragma unroll
             for (int t = 0; t < kFChunk; ++t) {
-                const unsigned j = t * 64 + lane;
-                const PT rsq = pair_vector<PT>(pk[t], pi, box, vx[t], vy[t], vz[t]);
-                keep[t] = (j < nn) && !(rsq > rmaxsq);
-                const unsigned long long m = __ballot(keep[t]);
+                PT rsq;
+                if (simple_box) { // wave-uniform
+                    asm volatile("" ::: "memory");
+                    rsq = pair_vector_simple<PT>(pk[t], pi, box, vx[t], vy[t], vz[t]);
+                } else {
+                    rsq = pair_vector<PT>(pk[t], pi, box, vx[t], vy[t], vz[t]);
+                }
+                const unsigned left = nn > (unsigned)t * 64 ? nn - (unsigned)t * 64 : 0u;
+                const unsigned long long m = ballot64(!(rsq > rmaxsq)) & (left >= 64u ? ~0ull : ((1ull << left) - 1ull));
+                keep[t] = __builtin_amdgcn_inverse_ballot_w64(m);
                 q[t] = Q + ballot_rank(m);
                 Q += __popcll(m);
             }
@@ -916,18 +923,19 @@ __global__ __launch_bounds__(256) void fused_forces2_kernel(
             else if (pad_bin == (int)rdf.nb - 1) n_hi += npad;
             else atomicAdd(&s_hist[pad_bin], npad);
         }
-        ax = group_sum<64>(ax); ay = group_sum<64>(ay); az = group_sum<64>(az); ae = group_sum<64>(ae);
-        bx = group_sum<64>(bx); by = group_sum<64>(by); bz = group_sum<64>(bz); be = group_sum<64>(be);
-        if (lane == 0) {
+        // eight row sums in 20 instructions (64 one by one): rows 0..3 of each result hold x, z, y, e
+        const float ta = wave_sum4(ax, ay, az, ae), tb = wave_sum4(bx, by, bz, be);
+        if ((lane & 15u) == 0u) {
+            const unsigned comp = ((lane >> 4) & 1u) * 2u + (lane >> 5); // 0, 2, 1, 3
             if (out_f64) {
-                ((double4 *)forceA)[w] = make_double4(ax, ay, az, ae);
-                ((double4 *)forceB)[w] = make_double4(bx, by, bz, be);
+                ((double *)forceA)[(size_t)w * 4 + comp] = (double)ta;
+                ((double *)forceB)[(size_t)w * 4 + comp] = (double)tb;
             } else {
-                ((float4 *)forceA)[w] = make_float4(ax, ay, az, ae);
-                ((float4 *)forceB)[w] = make_float4(bx, by, bz, be);
+                ((float *)forceA)[(size_t)w * 4 + comp] = ta;
+                ((float *)forceB)[(size_t)w * 4 + comp] = tb;
             }
         }
-        cv_wave += be;
+        cv_wave += __shfl(tb, 48); // the B energy sum sits in row 3
         cur = nxt;
 #pragma unroll
         for (int t = 0; t < kFChunk; ++t) k_cur[t] = k_nxt[t];
