@@ -454,23 +454,27 @@ static int compute_rows(htf_ctx *ctx, unsigned timestep, const htf_hoomd_arrays 
             HTF_REQUIRE(e0 && e1 && e2, "htf_compute_forces: hipEventCreate failed");
             ctx->ev_one_scope.push_back(0);
             ctx->ev_complete.push_back(0);
-            HTF_CHECK_HIP(hipEventRecord(e0, s));
         }
         const bool fused = to_hoomd && cfg.fused && cfg.nneighs > 0 && ctx->pot != nullptr && !own_evaluator(ctx->pot);
+        // the one-kernel step is timed by the launch itself (kernel begin / end, as rocprofv3 reports it); the two-kernel
+        // path by events recorded around its kernels
+        if (prof && !fused) HTF_CHECK_HIP(hipEventRecord(e0, s));
         if (fused) {
             HTF_REQUIRE(a->n_neigh && a->nlist && a->head_list, "htf_compute_forces: null neighbor list");
-            if (prof) ctx->ev_one_scope.back() = 1; // no separate build scope in fused mode: e1 stays unrecorded
+            if (prof) {
+                ctx->ev_one_scope.back() = 1; // no separate build scope in fused mode: e1 stays unrecorded
+                launch_events() = LaunchEvents{e0, e2, false};
+            }
             if (cfg.check_nlist) HTF_CHECK_HIP(hipMemsetAsync(ctx->flag, 0, sizeof(unsigned), s));
             void *fo = (char *)a->force + (size_t)offset * 4 * ssz;
             rc = fused_forces_impl(ctx->pot->pp, a->pos, cfg.scalar_dtype, N, cfg.nneighs, offset, n, &a->box, a->n_neigh,
                                    a->nlist, a->head_list, cfg.r_cut, fo, cfg.scalar_dtype,
                                    cfg.virial ? c_virial : nullptr, cfg.check_nlist ? ctx->flag : nullptr,
                                    c_positions, cfg.fused == 2 ? c_nlist : nullptr, cfg.fused == 2 ? c_counts : nullptr, s);
+            const bool stamped = launch_events().used;
+            launch_events() = LaunchEvents{};
             if (rc != HTF_OK) return rc;
-            if (prof) {
-                HTF_CHECK_HIP(hipEventRecord(e2, s));
-                ctx->ev_complete.back() = 1;
-            }
+            if (prof) ctx->ev_complete.back() = stamped ? 1 : 0; // (a launch form that took no events: the scope is skipped)
             if (cfg.check_nlist) {
                 unsigned h = 0;
                 HTF_CHECK_HIP(hipMemcpyAsync(&h, ctx->flag, sizeof(unsigned), hipMemcpyDeviceToHost, s));

@@ -18,6 +18,7 @@
 #include <cstdlib>
 
 #include <cstring>
+#include <hip/hip_ext.h>
 #include <vector>
 
 #include "box_math.h"
@@ -26,6 +27,24 @@
 #include "pair_math.h"
 
 namespace htf {
+
+LaunchEvents &launch_events() {
+    static thread_local LaunchEvents e;
+    return e;
+}
+
+// hipLaunchKernelGGL, or -- when the profiler has handed over a pair of events -- the launch that stamps them with the kernel's
+// own begin and end
+#define HTF_LAUNCH_TIMED(kernel, grid, block, stream, ...)                                                            \
+    do {                                                                                                               \
+        LaunchEvents &le_ = launch_events();                                                                           \
+        if (le_.start != nullptr && !le_.used) {                                                                       \
+            hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, le_.start, le_.stop, 0, __VA_ARGS__);                \
+            le_.used = true;                                                                                           \
+        } else {                                                                                                       \
+            hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);                                           \
+        }                                                                                                              \
+    } while (0)
 
 constexpr int kFChunk = 3; // index loads hoisted per lane per trip (as pair_vectors.hip: n_neigh <= 192 in one trip)
 
@@ -189,11 +208,10 @@ __global__ __launch_bounds__(256) void fused_forces_kernel(const typename Vec4<P
 // during the current row's evaluation -- what took the C4 sweep below from 241 to 217 us) 67-77 /
 // 63-70 us with 8192-2048 workgroups: here the hardware's own wave turnover does better.
 // Workgroups of one or two waves instead of four: 64.5-66 / 65 us against 62.4.
-// Round 2 (profiles/r02_fused_kernel_ab.txt, r02_fused_kernel_pmc.txt, r02_gather_probe.txt; written variant,
-// 60.6-64.8 us by box): PMC has the CU's texture-address path busy ~85 % of the kernel (TA_BUSY_avr), the VALU ~50 %,
-// L1 hit rate of the gathers 92 %: the kernel is bound by how fast a CU retires 16-B gather instructions -- ~53 clk
-// each here, against a floor of 45-55 clk for ANY index pattern once the table is L1-resident (gather_probe2) --
-// not by HBM (4.3 TB/s moved) and not by occupancy.  Tried against that and NOT faster: 8 waves/SIMD by capping
+// Round 2 (profiles/r02_fused_kernel_ab.txt, r02_fused_kernel_pmc.txt; written variant, 60.6-64.8 us by box).  A first reading
+// of the counters blamed the 16-B position gathers (texture-address path busy ~85 %); serving every gather from an LDS table
+// changed nothing (60.5 vs 60.9 us), and SQ_ACTIVE_INST_VALU, which counts QUAD-cycles, says the VALU was 99 % busy: the
+// kernel was VALU-issue bound.  Measured while the gathers were the suspect, and NOT faster: 8 waves/SIMD by capping
 // SGPRs at 80 (+3 %: 62.5); occupancy capped at 6 / 5 / 4 / 3 waves per SIMD through an LDS pad (63.8 / 66.7 / 72.8 /
 // 87.8); workgroups of 8 and 16 waves for L1 sharing between more adjacent rows (63.3 / 75.0); particles renumbered
 // in cell order (61.1 vs 60.6; a RANDOM order costs 90.6: locality matters, the lattice order already has it);
@@ -577,7 +595,7 @@ static int launch_fused(const void *pos, unsigned N, unsigned NN, unsigned offse
 #define HTF_ROWS_LAUNCH(ST, RR)                                                                                        \
     const unsigned full = ((batch + RR - 1) / RR + 3) / 4;                                                             \
     const unsigned grid = per_cu > 0 && (unsigned)(per_cu * n_cu) < full ? (unsigned)(per_cu * n_cu) : full;           \
-    hipLaunchKernelGGL((fused_forces_rows2_kernel<KIND, ST, RR, PT>), dim3(grid), dim3(256), 0, s, \
+    HTF_LAUNCH_TIMED((fused_forces_rows2_kernel<KIND, ST, RR, PT>), dim3(grid), dim3(256), s, \
                        (const typename Vec4<PT>::type *)pos, N, NN, offset, batch, b, n_neigh, nlist, head_list,       \
                        (PT)(rc * rc), force, out_f64, p, check_count, positions_out, dest, counts_io)
         // default for fp32 positions and batches of >= 16 384 rows (65 536 until the VALU diet of round 2: at 32 000 rows the
@@ -591,7 +609,7 @@ static int launch_fused(const void *pos, unsigned N, unsigned NN, unsigned offse
         const int tails = tails_env ? atoi(tails_env) : ((sizeof(PT) == 4 && batch >= 16384u) ? 4 : 0);
         if (tails == 2 || tails == 4) {
 #define HTF_TAILS_LAUNCH(ST, RR)                                                                                       \
-    hipLaunchKernelGGL((fused_forces_tails_kernel<KIND, ST, RR, PT>), dim3(((batch + RR - 1) / RR + 3) / 4), dim3(256), 0, s, \
+    HTF_LAUNCH_TIMED((fused_forces_tails_kernel<KIND, ST, RR, PT>), dim3(((batch + RR - 1) / RR + 3) / 4), dim3(256), s, \
                        (const typename Vec4<PT>::type *)pos, N, NN, offset, batch, b, n_neigh, nlist, head_list,       \
                        (PT)(rc * rc), force, out_f64, p, check_count, positions_out, dest, counts_io)
             if (dest != nullptr) {
@@ -613,11 +631,11 @@ static int launch_fused(const void *pos, unsigned N, unsigned NN, unsigned offse
 #undef HTF_ROWS_LAUNCH
     }
     if (dest != nullptr)
-        hipLaunchKernelGGL((fused_forces_kernel<KIND, VIRIAL, true, PT>), dim3((batch + 3) / 4), dim3(256), 0, s,
+        HTF_LAUNCH_TIMED((fused_forces_kernel<KIND, VIRIAL, true, PT>), dim3((batch + 3) / 4), dim3(256), s,
                            (const typename Vec4<PT>::type *)pos, N, NN, offset, batch, b, n_neigh, nlist, head_list,
                            (PT)(rc * rc), force, virial9, out_f64, p, check_count, positions_out, dest, counts_io);
     else
-        hipLaunchKernelGGL((fused_forces_kernel<KIND, VIRIAL, false, PT>), dim3((batch + 3) / 4), dim3(256), 0, s,
+        HTF_LAUNCH_TIMED((fused_forces_kernel<KIND, VIRIAL, false, PT>), dim3((batch + 3) / 4), dim3(256), s,
                            (const typename Vec4<PT>::type *)pos, N, NN, offset, batch, b, n_neigh, nlist, head_list,
                            (PT)(rc * rc), force, virial9, out_f64, p, check_count, positions_out, dest, counts_io);
     return check_launch("fused_forces_kernel");

@@ -27,6 +27,15 @@ int build_pair_vectors_impl(void *dest, int dest_dtype, const void *d_pos, int p
                             const unsigned *d_nlist, const unsigned *d_head_list, double rmax,
                             unsigned *d_max_count, float4 *positions_out, unsigned *counts_io, hipStream_t s);
 
+// Kernel-exact timing for the profiler (htf_profile_enable): when `start` is set, the next fused-step launch of this thread goes
+// through hipExtLaunchKernelGGL, which stamps the two events with the kernel's own begin and end (what rocprofv3 reports),
+// instead of being bracketed by hipEventRecord calls, which add the command processor's event handling to the interval.
+struct LaunchEvents {
+    hipEvent_t start = nullptr, stop = nullptr;
+    bool used = false;
+};
+LaunchEvents &launch_events();
+
 int fused_forces_impl(const PotParams &p, const void *pos, int pos_dtype, unsigned N, unsigned NN, unsigned offset,
                       unsigned batch, const htf_box *box, const unsigned *n_neigh, const unsigned *nlist,
                       const unsigned *head_list, double rmax, void *force, int force_dtype, void *virial9,

@@ -77,7 +77,7 @@ for name, d in (("FETCH_SIZE", "/tmp/c_f"), ("WRITE_SIZE", "/tmp/c_w")):
 out["_note"] = ("rocprofv3 --pmc (separate passes) of: bench.py --no-cpu-baseline --no-mlp --no-fused --steps 20 --warmup 5 --equil 60 --windows 1; averages over the "
                 "second half of each kernel's launches.  gfx950: FETCH_SIZE counts 1/2 of wide coalesced reads (MI355X_MICROARCH.md, HBM); WRITE_SIZE exact for 16-B/lane stores.")
 json.dump(out, open(F + "/pmc_hbm.json", "w"), indent=1)
-lj = collect("/tmp/pk_*/**/*counter_collection.csv", want=["fused_forces_rows2_kernel"])
+lj = collect("/tmp/pk_*/**/*counter_collection.csv", want=["fused_forces_tails_kernel<1, true", "fused_forces_rows2_kernel<1, true"])
 json.dump(lj, open(F + "/pmc_lj_kernel.json", "w"), indent=1)
 mlp = collect("/tmp/pm_*/**/*counter_collection.csv", want=["pair_mlp_kernel"])
 trn = collect("/tmp/pt_*/**/*counter_collection.csv", want=["mlp_grad", "pair_mlp_kernel"])

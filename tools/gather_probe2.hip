@@ -1,7 +1,7 @@
 // What does one wave-level gather instruction cost the CU's texture-address / L1 path (TA / TCP)?
-// Round-2 PMC on the one-kernel step (profiles/r02_*): TA busy ~85 % of the kernel, the VALU ~50 %, HBM ~55 % --
-// the step is bound by how fast a CU retires its 16-B position gathers.  This probe prices a gather by index
-// pattern, access width and table residency, with the index stream itself read coalesced.
+// Written when the one-kernel step's gathers were the suspect (TA busy ~85 % of the kernel); they turned out to be hidden under a
+// saturated VALU.  This probe prices a gather by index pattern, access width and table residency, with the index
+// stream itself read coalesced -- 100 MB of it, which sets the probe's own floor (~19 us).
 //   build: hipcc -O3 --offload-arch=gfx950 tools/gather_probe2.hip -o tools/gather_probe2
 #include <hip/hip_runtime.h>
 
