@@ -167,6 +167,7 @@ __global__ __launch_bounds__(256) void build_pair_vectors_kernel(
                               positions_out, counts_io);
         return;
     }
+    const bool simple_box = box.ortho && box.periodic[0] && box.periodic[1] && box.periodic[2];
     PV pi[R];
     unsigned k[R][kChunk];
     PV pk[R][kChunk];
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(256) void build_pair_vectors_kernel(
 #pragma unroll
         for (int t = 0; t < kChunk; ++t) {
             const unsigned j = t * 64 + lane;
-            k[r][t] = nl[j < nn[r] ? j : nn[r] - 1];
+            k[r][t] = nl[min(j, nn[r] - 1u)];
         }
     }
 #pragma unroll
@@ -195,18 +196,28 @@ __global__ __launch_bounds__(256) void build_pair_vectors_kernel(
 #pragma unroll
         for (int t = 0; t < kChunk; ++t) {
             if ((unsigned)t * 64 >= nn[r]) break; // wave-uniform
-            const unsigned j = t * 64 + lane;
-            PT dx = pk[r][t].x - pi[r].x, dy = pk[r][t].y - pi[r].y, dz = pk[r][t].z - pi[r].z;
-            min_image<PT>(dx, dy, dz, box);
-            const PT rsq = dx * dx + dy * dy + dz * dz;
-            const bool keep = (j < nn[r]) && !(rsq > rmaxsq);
-            const unsigned long long m = __ballot(keep);
+            // (as in fused_eval.hip: the common box on a 12-instruction minimum image behind a wave-uniform branch, the
+            //  live-entry mask from scalar arithmetic, the lane's predicate read back from the scalar mask)
+            const unsigned left = nn[r] - (unsigned)t * 64;
+            const unsigned long long valid = left >= 64u ? ~0ull : ((1ull << left) - 1ull);
+            PT dx, dy, dz, rsq;
+            if (simple_box) {
+                asm volatile("" ::: "memory");
+                rsq = pair_vector_simple<PT>(pk[r][t], pi[r], box, dx, dy, dz);
+            } else {
+                rsq = pair_vector<PT>(pk[r][t], pi[r], box, dx, dy, dz);
+            }
+            unsigned long long m = ballot64(!(rsq > rmaxsq)) & valid;
             const unsigned q = Q + ballot_rank(m);
             Q += __popcll(m);
+            if (Q > NN) { // (wave-uniform) about to overflow: slots bounded lane by lane; the row is redone below
+                asm volatile("" ::: "memory");
+                m &= ballot64(q < NN);
+            }
             DV out;
             out.x = (DT)dx; out.y = (DT)dy; out.z = (DT)dz;
             out.w = (DT)scalar_as_int(pk[r][t].w);
-            if (keep && q < NN) store_stream(&row[q], out);
+            if (__builtin_amdgcn_inverse_ballot_w64(m)) store_stream(&row[q], out);
         }
         if (Q > NN) { // overflow (an error upstream): build_row redoes the whole row, slot wrap included
             redo |= 1u << r;
