@@ -195,7 +195,6 @@ __global__ __launch_bounds__(256) void build_nlist_kernel(const typename Vec4<T>
     const int cy = cell_coord<T>(pi.y, b.lo[1], b.Linv[1], ny);
     const int cz = cell_coord<T>(pi.z, b.lo[2], b.Linv[2], nz);
     const bool side_i = type_split >= 0 && scalar_as_int(pi.w) >= type_split;
-    const unsigned long long gmask = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << (sub * G);
     unsigned count = 0;
     unsigned *row = nlist + (size_t)(active ? i : 0) * pitch;
     // the cell's candidate ranges come from the table (cell_ranges_kernel); the next row's entry is
@@ -225,29 +224,29 @@ __global__ __launch_bounds__(256) void build_nlist_kernel(const typename Vec4<T>
             //  instructions per candidate and 3.7 candidates per hit, not latency-bound)
             const unsigned n = active ? len : 0u;
             for (unsigned t = 0; t < n; t += G) {
+                // No branch inside: the load index is clamped into the run, and a candidate's verdict is the AND of
+                // single-compare wave masks (scalar), read back as the lane's predicate only for the store -- the walk is
+                // VALU-issue bound.  One 16-B (32-B) load per candidate: its index rides in w (htfs_gather4_tagged).
                 const unsigned m_idx = t + g;
-                bool hit = false;
-                unsigned k = 0;
-                if (m_idx < n) {
-                    // one 16-B (32-B) load per candidate: its index rides in w (htfs_gather4_tagged)
-                    const auto pk = pos_sorted[beg + m_idx];
-                    const unsigned tag = (unsigned)scalar_as_int(pk.w);
-                    k = tag & ~kTagSide;
-                    T ddx = pk.x - pix, ddy = pk.y - piy, ddz = pk.z - piz;
-                    if (!SHIFT) {
-                        ddx = mimg<T>(ddx, b.L[0], b.Linv[0], b.periodic[0]);
-                        ddy = mimg<T>(ddy, b.L[1], b.Linv[1], b.periodic[1]);
-                        ddz = mimg<T>(ddz, b.L[2], b.Linv[2], b.periodic[2]);
-                    }
-                    // '&', not '&&': behind a short-circuit the compiler defers the position load until k has arrived
-                    // (two memory round trips per trip of the loop instead of one)
-                    hit = (k != i) & (ddx * ddx + ddy * ddy + ddz * ddz <= rl2);
-                    if (type_split >= 0) hit = hit & (((tag & kTagSide) != 0u) == side_i);
+                const auto pk = pos_sorted[beg + min(m_idx, n - 1u)];
+                const unsigned tag = (unsigned)scalar_as_int(pk.w);
+                const unsigned k = tag & ~kTagSide;
+                T ddx = pk.x - pix, ddy = pk.y - piy, ddz = pk.z - piz;
+                if (!SHIFT) {
+                    ddx = mimg<T>(ddx, b.L[0], b.Linv[0], b.periodic[0]);
+                    ddy = mimg<T>(ddy, b.L[1], b.Linv[1], b.periodic[1]);
+                    ddz = mimg<T>(ddz, b.L[2], b.Linv[2], b.periodic[2]);
                 }
-                const unsigned long long bal = __ballot(hit) & gmask;
-                const unsigned rank = count + ballot_rank(bal);
-                if (hit && rank < pitch) row[rank] = k;
-                count += __popcll(bal);
+                unsigned long long hits = ballot64(m_idx < n) & ballot64(k != i) & ballot64(ddx * ddx + ddy * ddy + ddz * ddz <= rl2);
+                if (type_split >= 0) { // wave-uniform
+                    asm volatile("" ::: "memory");
+                    hits &= ballot64(((tag & kTagSide) != 0u) == side_i);
+                }
+                // the group's G bits of the wave mask: rank and count from two population counts of a 32-bit word
+                const unsigned seg = (unsigned)(hits >> (G * sub)) & (G >= 32 ? ~0u : ((1u << G) - 1u));
+                const unsigned rank = count + (unsigned)__popc(seg & ((1u << g) - 1u));
+                if (__builtin_amdgcn_inverse_ballot_w64(hits) && rank < pitch) row[rank] = k;
+                count += (unsigned)__popc(seg);
             }
         }
     }
