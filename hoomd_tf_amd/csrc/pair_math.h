@@ -194,13 +194,15 @@ __device__ __forceinline__ void pair_eval(float x, float y, float z, const PotPa
 
 // pair_eval for a slot that may have been dropped, WITHOUT a branch (the fused kernels are VALU-bound and a divergent
 // branch saves nothing unless a whole wave is dropped): potentials that vanish identically far out (s^6 underflows, the WCA
-// mask is false, exp(-r^2 / gap) is 0) are evaluated at x = 1e18, where energy and force come out as exact zeros -- one
+// mask is false, exp(-r^2 / gap) is 0) are evaluated at x = 1e18 (1e12 for the Gaussian), where energy and force come out as exact zeros -- one
 // select; the others are evaluated where they are and their four results selected.
 template <int KIND>
 __device__ __forceinline__ void pair_eval_if(bool keep, float x, float y, float z, const PotParams &p, float &e, float &fx,
                                              float &fy, float &fz) {
     if constexpr (KIND == HTF_POT_LJ || KIND == HTF_POT_WCA || KIND == HTF_POT_LJ_PARAM || KIND == HTF_POT_GAUSS) {
-        pair_eval<KIND>(keep ? x : 1e18f, y, z, p, e, fx, fy, fz);
+        // far enough that w1^6 / r^6 underflows for any sane w1 (1e18), near enough that (r - r0)^2 / gap stays finite (1e12)
+        constexpr float kFar = KIND == HTF_POT_GAUSS ? 1e12f : 1e18f;
+        pair_eval<KIND>(keep ? x : kFar, y, z, p, e, fx, fy, fz);
     } else {
         pair_eval<KIND>(x, y, z, p, e, fx, fy, fz);
         e = keep ? e : 0.0f;
