@@ -1148,3 +1148,31 @@ def test_full_size_pair_vectors_every_row_bit_exact(htf, cuda, lattice, cells):
     for ts in range(2):  # second call: the delta zero-fill path (rows keep their live counts)
         ctx.compute_forces(ts, ctx.make_arrays(sysm.pos, N, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, f))
         assert torch.equal(ctx.nlist_buffer(N, cuda), pv)
+
+
+@pytest.mark.parametrize("size", ["two-row form (500 rows)", "four-row form (16384 rows)"])
+def test_dropped_candidates_contribute_exact_zeros(htf, cuda, size):
+    """The fused kernels evaluate every candidate of a trip, dropped ones too -- at a far point where the potential vanishes
+    identically, or with their results selected away (pair_eval_if).  A list whose every candidate lies beyond r_cut must
+    therefore leave forces, energies and the tensor EXACTLY zero, for every closed-form potential, in every fused form."""
+    from hoomd_tf_amd import standin
+    cells = 5 if size.startswith("two") else 16
+    pos, L, a = standin.fcc_positions(cells, 0.8442)
+    rng = np.random.default_rng(3)
+    pos = pos + 0.03 * a * rng.standard_normal(pos.shape)
+    pos -= np.round(pos / L) * L
+    sysm = standin.System(pos, L, dtype=torch.float32, device=cuda)
+    nl = standin.CellNlist(sysm, r_cut=2.5, r_buff=0.3)
+    nl.build()
+    N, NN = sysm.N, 64
+    assert int(nl.n_neigh.min()) > 20  # every row has candidates ...
+    r_cut = 0.5                          # ... and none of them is within the cutoff (nearest neighbors sit at ~1.1)
+    pots = [htf.Potential.lj(), htf.Potential.wca(1.0), htf.Potential.lj_param(1.3, 0.9),
+            htf.Potential.rinv_poly([1.0, -0.5], [12, 1]), htf.Potential.simple()]
+    for pot in pots:
+        for with_tensor in (True, False):
+            pv = torch.full((N, NN, 4), 7.0, dtype=torch.float32, device=cuda) if with_tensor else None
+            f = htf.ops.fused_forces(pot, sysm.pos, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, r_cut, NN, pair_vectors=pv)
+            assert torch.count_nonzero(f) == 0, (pot.kind, with_tensor, float(f.abs().max()))
+            if with_tensor:
+                assert torch.count_nonzero(pv) == 0
