@@ -223,9 +223,10 @@ __global__ __launch_bounds__(256) void eval_pair2_kernel(const typename Vec4<IT>
 #pragma unroll
             for (int u = 0; u < kUnroll; ++u) {
                 float e, fx, fy, fz;
-                pair_eval<KA>(v[u].x, v[u].y, v[u].z, pa, e, fx, fy, fz);
+                const RinvFwd f = rinv_fwd(v[u].x, v[u].y, v[u].z); // once for both potentials
+                pair_eval_f<KA>(f, v[u].x, v[u].y, v[u].z, pa, e, fx, fy, fz);
                 ax += fx; ay += fy; az += fz; ae += e;
-                pair_eval<HTF_POT_GAUSS>(v[u].x, v[u].y, v[u].z, pb, e, fx, fy, fz);
+                pair_eval_f<HTF_POT_GAUSS>(f, v[u].x, v[u].y, v[u].z, pb, e, fx, fy, fz);
                 bx += fx; by += fy; bz += fz; be += e;
                 if (rdf.hist != nullptr && active && j0 + u * G + g < NN) {
                     // compute_rdf (simmodel.py:661-662): plain norm, histogram_fixed_width clamping

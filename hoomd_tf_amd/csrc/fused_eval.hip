@@ -766,9 +766,10 @@ __global__ __launch_bounds__(256) void fused_forces2_kernel(
     auto eval_slot = [&](float x, float y, float z, float &ax, float &ay, float &az, float &ae, float &bx, float &by,
                          float &bz, float &be) {
         float e, fx, fy, fz;
-        pair_eval<KA>(x, y, z, pa, e, fx, fy, fz);
+        const RinvFwd f = rinv_fwd(x, y, z); // t = x + 1e-7, r', 1 / r', s: once for both potentials
+        pair_eval_f<KA>(f, x, y, z, pa, e, fx, fy, fz);
         ax += fx; ay += fy; az += fz; ae += e;
-        pair_eval<HTF_POT_GAUSS>(x, y, z, pb, e, fx, fy, fz);
+        pair_eval_f<HTF_POT_GAUSS>(f, x, y, z, pb, e, fx, fy, fz);
         bx += fx; by += fy; bz += fz; be += e;
         if (do_rdf) {
             // tf.histogram_fixed_width's bin from the squared norm and the threshold table (rdf_edges): a 1-ulp square
@@ -778,16 +779,21 @@ __global__ __launch_bounds__(256) void fused_forces2_kernel(
             const float qf = floorf((__builtin_amdgcn_sqrtf(sq) - rdf.r0) * rdf_scale);
             int idx = (int)fminf(fmaxf(qf, 0.f), (float)(rdf.nb - 1));
             idx += (sq >= s_edge[idx + 1] ? 1 : 0) - (sq < s_edge[idx] ? 1 : 0);
-            if (idx == 0) ++n_lo;
-            else if (idx == (int)rdf.nb - 1) ++n_hi;
-            else atomicAdd(&s_hist[idx], 1u);
+            atomicAdd(&s_hist[idx], 1u); // live slots rarely land in the end bins (the padding, counted per row below, does)
         }
     };
     auto one = [&](PT dx, PT dy, PT dz, const PV &pk, bool keep, unsigned q, unsigned lo, unsigned Q, float4 *row, float &ax,
                    float &ay, float &az, float &ae, float &bx, float &by, float &bz, float &be) {
         if (keep && q >= lo) {
             const float x = (float)dx, y = (float)dy, z = (float)dz;
-            if constexpr (STORE) store_stream(&row[Q > NN ? q % NN : q], make_float4(x, y, z, (float)scalar_as_int(pk.w)));
+            if constexpr (STORE) {
+                unsigned slot = q;
+                if (Q > NN) { // wave-uniform
+                    asm volatile("" ::: "memory");
+                    slot = q % NN;
+                }
+                store_stream(&row[slot], make_float4(x, y, z, (float)scalar_as_int(pk.w)));
+            }
             eval_slot(x, y, z, ax, ay, az, ae, bx, by, bz, be);
         }
     };
@@ -879,8 +885,13 @@ __global__ __launch_bounds__(256) void fused_forces2_kernel(
 #pragma unroll
                 for (int t = 0; t < kFChunk; ++t) {
                     if ((unsigned)t * 64 >= nn) break; // wave-uniform
-                    if (keep[t] && q[t] >= lo) // the slot this survivor ends up in (overflow: the reference's wrap)
-                        mine[Q > NN ? q[t] % NN : q[t]] = make_float4((float)vx[t], (float)vy[t], (float)vz[t], (float)scalar_as_int(pk[t].w));
+                    unsigned slot = q[t]; // the slot this survivor ends up in (overflow: the reference's wrap, an integer division
+                    if (Q > NN) {         // kept behind a wave-uniform branch -- if-converted it ran for every trip)
+                        asm volatile("" ::: "memory");
+                        slot = q[t] % NN;
+                    }
+                    if (keep[t] && q[t] >= lo)
+                        mine[slot] = make_float4((float)vx[t], (float)vy[t], (float)vz[t], (float)scalar_as_int(pk[t].w));
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();

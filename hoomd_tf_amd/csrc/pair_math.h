@@ -94,9 +94,11 @@ __device__ __forceinline__ RinvFwd rinv_fwd(float x, float y, float z) {
 
 // Each potential returns the pair energy e (its share of E_i) and nlist_forces_ij =
 // 2 * dE/dx_ij (the reference's "nlist_forces", simmodel.py:548) in (fx, fy, fz).
+// (pair_eval_f takes the shared forward f = rinv_fwd(x, y, z) from its caller: a sweep that evaluates two potentials per slot --
+//  config C4 -- computes it once; pair_eval below is the one-potential form)
 template <int KIND>
-__device__ __forceinline__ void pair_eval(float x, float y, float z, const PotParams &p,
-                                          float &e, float &fx, float &fy, float &fz) {
+__device__ __forceinline__ void pair_eval_f(const RinvFwd &f, float x, float y, float z, const PotParams &p,
+                                            float &e, float &fx, float &fy, float &fz) {
     if constexpr (KIND == HTF_POT_SIMPLE) {
         // build_examples.py:9-22: -1 * ((1/|x|) * x), non-finite -> 0 (forward only)
         float rs = sqrtf(x * x + y * y + z * z);
@@ -128,19 +130,15 @@ __device__ __forceinline__ void pair_eval(float x, float y, float z, const PotPa
         // one RBFExpansion channel as a pair energy: r = safe_norm(x) (simmodel.py:581-594),
         // phi = exp(-(r - r0)^2 / gap) (layers.py:46-49), masked with the nlist_rinv criterion.
         // nlist_forces = 2 * c * dphi/dr * t / r,  dphi/dr = -2 (r - r0) / gap * phi
-        const float tx = x + kNormDelta, ty = y + kNormDelta, tz = z + kNormDelta;
-        const float r = fast_sqrt(tx * tx + ty * ty + tz * tz);
-        const bool m = r > kRinvDelta;
-        const float d = r - p.gauss_r0;
-        const float phi = m ? __expf(-(d * d) * p.gauss_ginv) : 0.0f;
+        const float d = f.rp - p.gauss_r0;
+        const float phi = f.cond ? __expf(-(d * d) * p.gauss_ginv) : 0.0f;
         e = p.gauss_coef * phi;
-        const float c = m ? 2.0f * p.gauss_coef * (-2.0f * d * p.gauss_ginv) * phi * fast_rcp(r) : 0.0f;
-        fx = c * tx;
-        fy = c * ty;
-        fz = c * tz;
+        const float c = f.cond ? 2.0f * p.gauss_coef * (-2.0f * d * p.gauss_ginv) * phi * f.irp : 0.0f;
+        fx = c * f.tx;
+        fy = c * f.ty;
+        fz = c * f.tz;
         return;
     } else {
-        RinvFwd f = rinv_fwd(x, y, z);
         const float s = f.s, s2 = s * s;
         float dEds;
         if constexpr (KIND == HTF_POT_LJ) {
@@ -191,6 +189,16 @@ __device__ __forceinline__ void pair_eval(float x, float y, float z, const PotPa
     }
 }
 
+
+template <int KIND>
+__device__ __forceinline__ void pair_eval(float x, float y, float z, const PotParams &p,
+                                          float &e, float &fx, float &fy, float &fz) {
+    if constexpr (KIND == HTF_POT_SIMPLE || KIND == HTF_POT_LJ_PARAM) {
+        pair_eval_f<KIND>(RinvFwd(), x, y, z, p, e, fx, fy, fz); // these two do not use the shared forward
+    } else {
+        pair_eval_f<KIND>(rinv_fwd(x, y, z), x, y, z, p, e, fx, fy, fz);
+    }
+}
 
 // pair_eval for a slot that may have been dropped, WITHOUT a branch (the fused kernels are VALU-bound and a divergent
 // branch saves nothing unless a whole wave is dropped): potentials that vanish identically far out (s^6 underflows, the WCA
