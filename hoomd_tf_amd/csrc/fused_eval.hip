@@ -754,6 +754,7 @@ __global__ __launch_bounds__(256) void fused_forces2_kernel(
     const unsigned lane = threadIdx.x & 63u, wb = threadIdx.x >> 6;
     const bool simple_box = box.ortho && box.periodic[0] && box.periodic[1] && box.periodic[2];
     const float rdf_scale = do_rdf ? (float)rdf.nb / (rdf.r1 - rdf.r0) : 0.f;
+    const bool coarse_bins = do_rdf && (rdf.r1 - rdf.r0) >= 1e-4f * (float)rdf.nb;
     // bin of a zero pair vector (the padded slots of the tensor are part of compute_rdf's input)
     int pad_bin = 0;
     if (do_rdf) {
@@ -772,11 +773,16 @@ __global__ __launch_bounds__(256) void fused_forces2_kernel(
         pair_eval_f<HTF_POT_GAUSS>(f, x, y, z, pb, e, fx, fy, fz);
         bx += fx; by += fy; bz += fz; be += e;
         if (do_rdf) {
-            // tf.histogram_fixed_width's bin from the squared norm and the threshold table (rdf_edges): a 1-ulp square
-            // root and a multiply give a guess that is off by at most one, two LDS words settle it -- no correctly
+            // tf.histogram_fixed_width's bin from the squared norm and the threshold table (rdf_edges): the evaluator's r'
+            // and a multiply give a guess that is off by at most one, two LDS words settle it -- no correctly
             // rounded sqrt, no division (33 M slots at C4 agree with the oracle bin for bin: test_full_size_c4_eds_sweep)
             const float sq = plain_sq3(x, y, z);
-            const float qf = floorf((__builtin_amdgcn_sqrtf(sq) - rdf.r0) * rdf_scale);
+            float rg = f.rp; // r' is within 2e-7 of the plain norm: with bins no narrower than 1e-4 a guess off by at most one
+            if (!coarse_bins) { // wave-uniform
+                asm volatile("" ::: "memory");
+                rg = __builtin_amdgcn_sqrtf(sq);
+            }
+            const float qf = floorf((rg - rdf.r0) * rdf_scale);
             int idx = (int)fminf(fmaxf(qf, 0.f), (float)(rdf.nb - 1));
             idx += (sq >= s_edge[idx + 1] ? 1 : 0) - (sq < s_edge[idx] ? 1 : 0);
             atomicAdd(&s_hist[idx], 1u); // live slots rarely land in the end bins (the padding, counted per row below, does)
