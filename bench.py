@@ -836,7 +836,7 @@ def run_md(args, E, workload, variants=True, cpu=True):
         try:
             if args.cells != 32 or args.workload != "lj":
                 raise KeyError("PMC passes were collected for the default workload at the default size")
-            pmc_file = next(f for f in ("r02_bench_lj_pmc_hbm.json", "r01_bench_lj_pmc_hbm.json")
+            pmc_file = next(f for f in ("r03_bench_lj_pmc_hbm.json", "r02_bench_lj_pmc_hbm.json", "r01_bench_lj_pmc_hbm.json")
                             if os.path.exists(os.path.join(ROOT, "profiles", f)))
             pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
             want = {"build_pair_vectors": ("build_pair_vectors_kernel",), "eval_forces": ("eval_pair_kernel<1,",),
@@ -844,16 +844,21 @@ def run_md(args, E, workload, variants=True, cpu=True):
                     "build_eval_forces": ("fused_forces_tails_kernel<1, true", "fused_forces_rows2_kernel<1, true")}[dom]
             key = next(k for w in want for k in pmc["FETCH_SIZE"] if w in k and k in pmc["WRITE_SIZE"])
             rd, wr = pmc["FETCH_SIZE"][key]["avg_KiB"], pmc["WRITE_SIZE"][key]["avg_KiB"]
-            # gfx950: FETCH_SIZE counts half of a wide (16 B/lane) coalesced read stream; the build
-            # kernel's reads are 4-B index loads + 16-B gathers, for which the counter is uncalibrated
-            corr = 2.0 if dom == "eval_forces" else 1.0
+            # gfx950: every fabric-side read request of the L2 is 128 B (TCC_EA0_RDREQ_32B = TCC_BUBBLE = 0) and FETCH_SIZE
+            # tallies it at 64 B.  Calibrated on known byte counts in THIS kernel's access patterns (tools/fetch_calib.hip,
+            # profiles/r03_fetch_calib.json): 4 B/lane index streams, clamped index rows, 16-B gathers from an L2-resident
+            # table and 16 B/lane streams all read known / FETCH_SIZE = 1.99-2.00; WRITE_SIZE is exact (0.993-0.998) for
+            # the nontemporal 16-B stores, full rows and live-slot rows alike.
+            corr = 2.0
             roof["traffic"] = (rd * corr + wr) * 1024.0
-            roof["traffic_source"] = "profiles/%s (FETCH_SIZE x%g + WRITE_SIZE)" % (pmc_file, corr)
+            roof["traffic_source"] = ("profiles/%s (FETCH_SIZE x%g + WRITE_SIZE; factor from tools/fetch_calib.hip, "
+                                      "profiles/r03_fetch_calib.json; counters of a separate run of this command, not of this run)" % (pmc_file, corr))
             # the rate the memory system actually ran at: below `achieved` because the zero tail of a row is
             # only rewritten where the row shrank since the last step (htf_context keeps per-row counts), so
             # fewer bytes move than the [N, NN, 4] contract counts
             roof["traffic_GBps"] = roof["traffic"] / (kern[dom]["avg_us"] * 1e-6) / 1e9
             roof["traffic_frac"] = roof["traffic_GBps"] / HBM_PEAK_GBS  # what the memory system itself ran at
+            roof["traffic_frac_of_achievable"] = roof["traffic_GBps"] / 6290.0  # 6.29 TB/s: the float4 copy ceiling this part sustains (MI355X_MICROARCH.md)
         except (OSError, KeyError, ValueError, StopIteration):
             pass
 

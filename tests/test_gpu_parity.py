@@ -962,8 +962,10 @@ def test_liquid_configuration_bounds(htf, cuda):
     force = torch.zeros((N, 4), dtype=torch.float32, device=cuda)
     ctx.compute_forces(0, ctx.make_arrays(sysm.pos, N, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, force))
     check("liquid_lj_context", force)
-    # batches and row ranges of the liquid (here the four-rows-per-wave form with merged tails runs: ~139 entries per
-    # row, tails of ~11): the tensor is bit-identical however the step is cut, forces agree to rounding
+    # batches and row ranges of the liquid (N = 2 048 < 16 384 rows: the two-row form runs here; the four-rows-per-wave form
+    # with merged tails is asserted against the oracle at its own size in
+    # test_full_size_pair_vectors_every_row_bit_exact and test_liquid_at_headline_size): the tensor is bit-identical
+    # however the step is cut, forces agree to rounding
     part = htf.ops.fused_forces(htf.Potential.lj(), sysm.pos, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, 3.0, NN, offset=5, batch_size=1001)
     assert float((part - fr[5:1006]).abs().max()) <= 2e-7 * float(cond.max())
     pv3 = torch.empty((1001, NN, 4), dtype=torch.float32, device=cuda)
@@ -973,6 +975,40 @@ def test_liquid_configuration_bounds(htf, cuda):
     rw = O.wca_model(pv64, 1.0)
     s, t, rp, cnd = O._rinv_and_grad_factor(pv64)
     assert_forces_close("liquid_wca", fw, rw, _cond_scale(pv64, 2 * O._grad_from_dEds(6 * s ** 5, s, t, rp, cnd)), cancelling_rows=LIQUID)
+
+
+def test_liquid_at_headline_size(htf, cuda):
+    """The equilibrated liquid at 16 384 rows (fcc 16^3), the smallest batch that takes the kernel the bench times
+    (fused_forces_tails_kernel: four rows per wave, merged tails; launch_fused's threshold): 512 sampled rows against the
+    oracle -- energy as stated, forces with the named condition term and within 3x of an independent fp32 evaluation's
+    own error -- with and without the tensor, and from the context."""
+    sysm, nl, L = _liquid(htf, cuda, cells=16, steps=200, seed=10)
+    N, NN = sysm.N, 128
+    assert N == 16384
+    pv = htf.ops.build_pair_vectors(sysm.pos, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, 3.0, NN)
+    rows = np.random.default_rng(6).choice(N, 512, replace=False)
+    pv32 = pv.cpu().numpy()[rows]
+    pv64 = pv32.astype(np.float64)
+    r = np.sqrt((pv64[:, :, :3] ** 2).sum(axis=2))
+    assert int((r > 0).sum(axis=1).max()) < NN and r[r > 0].min() > 0.8
+    ref_f = O.lj_model(pv64)
+    cond = _cond_scale(pv64, _pair_forces_lj(pv64))
+    fp32_err = np.abs(O.lj_model(pv32).astype(np.float64) - ref_f)[:, :3].max()
+    got = {}
+    got["registers"] = htf.ops.fused_forces(htf.Potential.lj(), sysm.pos, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, 3.0, NN)
+    pv2 = torch.empty_like(pv)
+    got["one_kernel"] = htf.ops.fused_forces(htf.Potential.lj(), sysm.pos, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, 3.0, NN, pair_vectors=pv2)
+    assert torch.equal(pv2, pv)
+    ctx = htf.Context(r_cut=3.0, nneighs=NN, max_n=N, fused=2)
+    ctx.set_potential(htf.Potential.lj())
+    force = torch.zeros((N, 4), dtype=torch.float32, device=cuda)
+    ctx.compute_forces(0, ctx.make_arrays(sysm.pos, N, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, force))
+    got["context"] = force
+    for name, f in got.items():
+        f = f.cpu().numpy()[rows]
+        assert_forces_close("liquid16k_lj_%s_energy" % name, f[:, 3], ref_f[:, 3])
+        assert_forces_close("liquid16k_lj_%s" % name, f[:, :3], ref_f[:, :3], cond, cancelling_rows=LIQUID)
+        assert np.abs(f[:, :3] - ref_f[:, :3]).max() <= 3.0 * fp32_err
 
 
 def test_profile_read_survives_an_error_return(htf, cuda):
@@ -1140,14 +1176,40 @@ def test_full_size_pair_vectors_every_row_bit_exact(htf, cuda, lattice, cells):
     pv = htf.ops.build_pair_vectors(sysm.pos, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, 3.0, NN)
     np.testing.assert_array_equal(pv.cpu().numpy(), ref)
     pv2 = torch.full_like(pv, 3.0)
-    htf.ops.fused_forces(htf.Potential.lj(), sysm.pos, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, 3.0, NN, pair_vectors=pv2)
+    forces = {}
+    forces["one_kernel"] = htf.ops.fused_forces(htf.Potential.lj(), sysm.pos, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, 3.0, NN, pair_vectors=pv2)
     assert torch.equal(pv2, pv)
+    forces["registers"] = htf.ops.fused_forces(htf.Potential.lj(), sysm.pos, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, 3.0, NN)
     ctx = htf.Context(r_cut=3.0, nneighs=NN, max_n=N, fused=2)
     ctx.set_potential(htf.Potential.lj())
     f = torch.zeros((N, 4), dtype=torch.float32, device=cuda)
     for ts in range(2):  # second call: the delta zero-fill path (rows keep their live counts)
+        f.zero_()
         ctx.compute_forces(ts, ctx.make_arrays(sysm.pos, N, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, f))
         assert torch.equal(ctx.nlist_buffer(N, cuda), pv)
+        forces["context_fused2_call%d" % ts] = f.clone()
+    ctx1 = htf.Context(r_cut=3.0, nneighs=NN, max_n=N, fused=1)
+    ctx1.set_potential(htf.Potential.lj())
+    f1 = torch.zeros((N, 4), dtype=torch.float32, device=cuda)
+    ctx1.compute_forces(0, ctx1.make_arrays(sysm.pos, N, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, f1))
+    forces["context_fused1"] = f1
+    # The LJ FORCES of the kernel the bench times (N >= 16 384 rows: fused_forces_tails_kernel<LJ, STORE, 4, float>, four
+    # rows per wave with merged tails; with and without the tensor, from the stateless entry point and from the context
+    # at fused = 2 / 1) against the oracle on 512 sampled rows of the bit-exact tensor; energy column as stated.
+    rows = np.random.default_rng(5).choice(N, 512, replace=False)
+    sub = ref[rows].astype(np.float64)
+    ref_f = O.lj_model(sub)
+    cond = _cond_scale(sub, _pair_forces_lj(sub))
+    s_, _, _, _ = O._rinv_and_grad_factor(sub)
+    e_cond = (2.0 * (s_ ** 12 + s_ ** 6)).sum(axis=1)   # sum_j |e_ij| scale of the energy column's row sum (jitter leaves contacts at r ~ 0.8)
+    for name, ff in forces.items():
+        got = ff.cpu().numpy()[rows]
+        tag = "full_%s%d_lj_%s" % (lattice, cells, name)
+        assert_forces_close(tag + "_energy", got[:, 3], ref_f[:, 3], e_cond, cancelling_rows=CONTACTS)
+        assert_forces_close(tag, got[:, :3], ref_f[:, :3], cond, cancelling_rows=CONTACTS)
+    # every row, not only the sample: the whole-system energy against the C restatement's fp64 sum over the tensor
+    e_ref = float(O.lj_model(ref[::64].astype(np.float64))[:, 3].sum())
+    np.testing.assert_allclose(forces["context_fused2_call1"][::64, 3].double().sum().item(), e_ref, rtol=1e-5)
 
 
 @pytest.mark.parametrize("size", ["two-row form (500 rows)", "four-row form (16384 rows)"])

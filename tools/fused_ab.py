@@ -21,6 +21,8 @@ ap.add_argument("--relax", type=int, default=0, help="MD steps before timing (li
 ap.add_argument("--cells", type=int, default=32)
 ap.add_argument("--reps", type=int, default=200)
 ap.add_argument("--tag", default="")
+ap.add_argument("--f64", action="store_true", help="HOOMD in double precision: fp64 positions and forces on the wire")
+ap.add_argument("--potential", default="lj", choices=["lj", "wca"])
 ap.add_argument("--digest", default="", help="print sha1 digests of the tensor and the forces; save the forces to this .npy")
 args = ap.parse_args()
 
@@ -31,13 +33,13 @@ pos = pos + 0.05 * a * rng.standard_normal(pos.shape)
 pos -= np.round(pos / L) * L
 if args.order == "shuffled":
     pos = pos[rng.permutation(len(pos))]
-sysm = standin.System(pos, L, dtype=torch.float32, device=dev)
+sysm = standin.System(pos, L, dtype=torch.float64 if args.f64 else torch.float32, device=dev)
 sysm.randomize_velocities(kT=1.0, seed=3)
 nl = standin.CellNlist(sysm, r_cut=3.0, r_buff=0.4, check_period=5, sort_particles=(args.order == "sorted"))
 nl.build()
 N, NN = sysm.N, 128
-ctx = htf.Context(r_cut=3.0, nneighs=NN, max_n=N, fused=args.fused)
-ctx.set_potential(htf.Potential.lj())
+ctx = htf.Context(r_cut=3.0, nneighs=NN, max_n=N, fused=args.fused, scalar_dtype=torch.float64 if args.f64 else torch.float32)
+ctx.set_potential(htf.Potential.lj() if args.potential == "lj" else htf.Potential.wca(1.0))
 nve = standin.NVE(sysm, 0.005)
 
 
