@@ -608,7 +608,9 @@ def run_md(args, E, workload, variants=True, cpu=True):
                            device_decision=(world == 1 and not args.sort and not args.host_nlist_decision))
     if world > 1:
         from hoomd_tf_amd.domain import SlabDomain
-        nl.domain = SlabDomain(sysm, rank, world, r_ghost=args.rcut + args.rbuff)
+        # the native RCCL halo (csrc/halo.hip) has never run between two real devices: opt-in until it has
+        nl.domain = SlabDomain(sysm, rank, world, r_ghost=args.rcut + args.rbuff,
+                               transport=os.environ.get("HTF_HALO_TRANSPORT", "torch"))
     nl.build()
     N, NN = sysm.N, args.nn
 

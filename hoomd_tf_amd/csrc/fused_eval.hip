@@ -19,6 +19,7 @@
 
 #include <cstring>
 #include <hip/hip_ext.h>
+#include <mutex>
 #include <vector>
 
 #include "box_math.h"
@@ -606,7 +607,11 @@ static int launch_fused(const void *pos, unsigned N, unsigned NN, unsigned offse
         // barely fills the chip).  HTF_FUSED_TAILS=0 selects the two-row form everywhere, whose forces do not depend on
         // how a step is cut into batches / row ranges, bit for bit.
         static const char *tails_env = getenv("HTF_FUSED_TAILS");
-        const int tails = tails_env ? atoi(tails_env) : ((sizeof(PT) == 4 && batch >= 16384u) ? 4 : 0);
+        // fp64 positions (HOOMD in double precision): two rows per wave with a shared tail trip -- 66.8-69.8 us at C3 against
+        // 78.1-78.4 for the plain two-row form and 68.7-72.9 for four rows (82 VGPRs, 83 spilled SGPRs); same-box A/B in
+        // profiles/r03_f64_kernel_ab.txt.  Every fp64 VALU instruction of the kernel issues at the fp32 rate
+        // (tools/valu_rate_probe.hip); what the fp64 wire costs is the second 16-B gather instruction per candidate.
+        const int tails = tails_env ? atoi(tails_env) : (batch >= 16384u ? (sizeof(PT) == 4 ? 4 : 2) : 0);
         if (tails == 2 || tails == 4) {
 #define HTF_TAILS_LAUNCH(ST, RR)                                                                                       \
     HTF_LAUNCH_TIMED((fused_forces_tails_kernel<KIND, ST, RR, PT>), dim3(((batch + RR - 1) / RR + 3) / 4), dim3(256), s, \
@@ -685,25 +690,38 @@ static float rdf_bin_exact_host(float s, float r0, float r1, unsigned nb) {
     return fi < 0.f ? 0.f : (fi > (float)(nb - 1) ? (float)(nb - 1) : fi);
 }
 
-struct RdfEdgeCache {
-    float r0 = 0.f, r1 = 0.f;
-    unsigned nb = 0;
-    int dev = -1;
-    float *d = nullptr;
-    std::vector<float> h;
+// One immutable device table per (device, range, bins), built the first time those parameters are seen and never rewritten:
+// a sweep of an earlier call -- on another stream, or replayed from a captured graph -- may still be reading its table when the
+// parameters change (the first version kept ONE table and overwrote it in place).  The build (a bisection on the
+// host, one H2D copy, one synchronize) therefore happens once per parameter set, before any kernel that uses the table is
+// enqueued; calls with known parameters do no host work here and are legal under stream capture.  The cache is process-wide
+// (a handful of 4-KB tables for any realistic run); entries are never freed.
+struct RdfEdgeTable {
+    float r0, r1;
+    unsigned nb;
+    int dev;
+    float *d;
 };
 
 static int rdf_edges(float r0, float r1, unsigned nb, hipStream_t stream, const float **out) {
-    static thread_local RdfEdgeCache c;
+    static std::mutex mu;
+    static std::vector<RdfEdgeTable> tables;
     int dev = 0;
     HTF_CHECK_HIP(hipGetDevice(&dev));
-    if (c.d != nullptr && c.dev == dev && c.r0 == r0 && c.r1 == r1 && c.nb == nb) {
-        *out = c.d;
-        return HTF_OK;
+    std::lock_guard<std::mutex> lock(mu);
+    for (const RdfEdgeTable &t : tables)
+        if (t.dev == dev && t.r0 == r0 && t.r1 == r1 && t.nb == nb) {
+            *out = t.d;
+            return HTF_OK;
+        }
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) {
+        set_error("compute_rdf range (%g, %g) / %u bins first seen during stream capture: run one eager step with these parameters first", r0, r1, nb);
+        return HTF_ERR_INVALID;
     }
-    c.h.assign((size_t)nb + 1, 0.f);
-    c.h[0] = -1.f;
-    c.h[nb] = __builtin_inff();
+    std::vector<float> h((size_t)nb + 1, 0.f);
+    h[0] = -1.f;
+    h[nb] = __builtin_inff();
     for (unsigned b = 1; b < nb; ++b) {
         // smallest non-negative finite fp32 (by bit pattern) whose bin is >= b; none: +inf
         unsigned lo = 0u, hi = 0x7f800000u; // hi is never a candidate: answer in [lo, hi]
@@ -713,16 +731,13 @@ static int rdf_edges(float r0, float r1, unsigned nb, hipStream_t stream, const 
             std::memcpy(&x, &mid, 4);
             if (rdf_bin_exact_host(x, r0, r1, nb) >= (float)b) hi = mid; else lo = mid + 1u;
         }
-        std::memcpy(&c.h[b], &lo, 4);
+        std::memcpy(&h[b], &lo, 4);
     }
-    if (c.d == nullptr || c.dev != dev) { // (a table of another device stays with that device)
-        c.d = nullptr;
-        HTF_CHECK_HIP(hipMalloc((void **)&c.d, (size_t)(kRdfMaxBins2 + 1) * sizeof(float)));
-    }
-    HTF_CHECK_HIP(hipMemcpyAsync(c.d, c.h.data(), ((size_t)nb + 1) * sizeof(float), hipMemcpyHostToDevice, stream));
-    HTF_CHECK_HIP(hipStreamSynchronize(stream)); // once per (range, bins): later calls on other streams find it complete
-    c.r0 = r0; c.r1 = r1; c.nb = nb; c.dev = dev;
-    *out = c.d;
+    RdfEdgeTable t{r0, r1, nb, dev, nullptr};
+    HTF_CHECK_HIP(hipMalloc((void **)&t.d, ((size_t)nb + 1) * sizeof(float)));
+    HTF_CHECK_HIP(hipMemcpy(t.d, h.data(), ((size_t)nb + 1) * sizeof(float), hipMemcpyHostToDevice)); // blocking: complete for every stream
+    tables.push_back(t);
+    *out = t.d;
     return HTF_OK;
 }
 

@@ -65,9 +65,11 @@ struct RinvFwd {
 
 // s = 1 / (r' + 3e-6) and 1 / r' from ONE transcendental instruction where there were three (v_sqrt_f32, v_rcp_f32 of the sum,
 // v_rcp_f32 of r'): they issue at a quarter of the VALU rate and the evaluators are VALU-bound.  With s0 = rsq(r'^2) = 1 / r'
-// and u = 3e-6 s0:  1 / (r' + 3e-6) = s0 / (1 + u) = s0 (1 - u + u^2) to within u^3, which for every wave whose live slots all
-// have r' > 0.015 (u < 2e-4, u^3 < 1e-11) is far below an ulp -- and ~2 ulp in all, against ~2.5 for sqrt + add + rcp.  A wave
-// with a closer (unphysical) live slot takes the three-instruction form; the mask r' > 3e-6 is taken on r' = r'^2 * s0.
+// and u = 3e-6 s0:  1 / (r' + 3e-6) = s0 / (1 + u) = s0 (1 - u + u^2) to within u^3, which for a slot with r' > 0.015
+// (u < 2e-4, u^3 < 1e-11) is far below an ulp -- and ~2 ulp in all, against ~2.5 for sqrt + add + rcp.  A closer (unphysical)
+// live slot takes the three-instruction form.  The CHOICE IS PER LANE (a slot's e and f depend on that slot alone, whatever
+// else shares its wave and whichever kernel evaluates it -- ADVICE r2); only the cost is per wave: the three transcendental
+// instructions are issued behind a wave-uniform branch that is taken when some lane needs them.
 __device__ __forceinline__ RinvFwd rinv_fwd(float x, float y, float z) {
     RinvFwd f;
     f.tx = x + kNormDelta;
@@ -78,16 +80,18 @@ __device__ __forceinline__ RinvFwd rinv_fwd(float x, float y, float z) {
     const float u = kRinvDelta * s0;
     f.rp = t2 * s0;
     f.cond = f.rp > kRinvDelta;
-    if (__builtin_amdgcn_ballot_w64(f.cond && u >= 2e-4f) == 0ull) { // wave-uniform
-        f.irp = s0;
-        const float sr = fmaf(u * u, s0, fmaf(-u, s0, s0));
-        f.s = f.cond ? sr : 0.0f;
-    } else {
-        f.rp = fast_sqrt(t2);
-        f.cond = f.rp > kRinvDelta;
-        f.irp = fast_rcp(f.rp);
-        const float sr = fast_rcp(f.rp + kRinvDelta);
-        f.s = f.cond ? sr : 0.0f;
+    f.irp = s0;
+    const float sr = fmaf(u * u, s0, fmaf(-u, s0, s0));
+    f.s = f.cond ? sr : 0.0f;
+    const bool near = f.cond && u >= 2e-4f;
+    if (__builtin_amdgcn_ballot_w64(near) != 0ull) { // wave-uniform, rare
+        const float rp = fast_sqrt(t2);
+        const float irp = fast_rcp(rp);
+        const float s3 = fast_rcp(rp + kRinvDelta);
+        // (rp > 3e-6 holds for every `near` lane: u >= 2e-4 with cond set means 3e-6 < r' <= 0.015)
+        f.rp = near ? rp : f.rp;
+        f.irp = near ? irp : f.irp;
+        f.s = near ? s3 : f.s;
     }
     return f;
 }

@@ -110,11 +110,13 @@ class _NativeHalo:
 
 
 class SlabDomain:
-    def __init__(self, system, rank, world, r_ghost, fractions=None, group=None, transport="auto"):
-        """``transport``: "torch" = torch.distributed grouped P2P (RCCL underneath on the GPU box, gloo in the CPU
-        tests); "native" = libhtf_amd.so's own RCCL communicator and halo stream; "auto" = native when the job
-        runs on the nccl backend, the library could load librccl, and the first exchange reproduces what the
-        torch transport delivers (checked once, at the first rebuild), else torch."""
+    def __init__(self, system, rank, world, r_ghost, fractions=None, group=None, transport="torch"):
+        """``transport``: "torch" (default) = torch.distributed grouped P2P (RCCL underneath on the GPU box, gloo in
+        the CPU tests); "native" = libhtf_amd.so's own RCCL communicator and halo stream; "auto" = native when the
+        job runs on the nccl backend, the library could load librccl, and the first exchange reproduces what the
+        torch transport delivers (checked once, at the first rebuild), else torch.  The native transport is OPT-IN
+        until it has moved bytes between two real devices (tests/test_gpu_domain.py::test_rccl_halo_two_gpus skips
+        on the 1-GPU boxes of this pool): ``HTF_HALO_TRANSPORT=auto|native`` selects it for bench.py."""
         self.sys = system
         self.transport_request = transport
         self.transport = "torch"
@@ -288,12 +290,22 @@ class SlabDomain:
             ghosts = s.pos[s.N:s.N + s.n_ghost].clone()
             s.pos[s.N:s.N + s.n_ghost] = float("nan")
             self._native, self.transport = native, "native"
-            self.exchange()
-            same = torch.equal(s.pos[s.N:s.N + s.n_ghost], ghosts)
+            # A failure of the native exchange on ONE rank must not let that rank skip the agreement below while
+            # its peers wait in it (mismatched collectives = a hang): catch locally, fold into the flag, and have
+            # every rank reach the all_reduce.
+            same, err = False, ""
+            try:
+                self.exchange()
+                same = torch.equal(s.pos[s.N:s.N + s.n_ghost], ghosts)
+            except Exception as e:  # noqa: BLE001
+                err = str(e)
+                self._works = None
             ok = torch.tensor([1.0 if same else 0.0], device=s.pos.device)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
             if float(ok.item()) != 1.0:
-                raise RuntimeError("native halo delivered different ghosts than torch.distributed")
+                # (every rank takes this branch together; the torch transport's ghosts are restored)
+                s.pos[s.N:s.N + s.n_ghost] = ghosts
+                raise RuntimeError("native halo " + ("failed: " + err if err else "delivered different ghosts than torch.distributed (here or on a peer)"))
         except Exception as e:  # noqa: BLE001
             self._native, self.transport = None, "torch"
             if want == "native":

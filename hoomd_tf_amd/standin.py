@@ -441,17 +441,24 @@ class Simulation:
                 nl._capturing = False
                 s.timestep = ts0  # a capture records, it does not run
             self._graph, self._graph_key = g, key
-        polled = 0
+        # The neighbor-row overflow report (a pinned copy inside the captured cycle) is polled EVERY cycle, on the event
+        # recorded two replays earlier -- long since complete, so the host still runs two cycles ahead of the device --
+        # instead of every 8th cycle: at most 3 check periods run on a truncated list before the RuntimeError.
+        behind = []
         while nsteps >= cycle:
-            if polled == 0:
-                nl._poll_overflow()  # the overflow report of ~8 cycles ago: long since on the host
+            if len(behind) >= 2:
+                nl._stat_event = behind.pop(0)
+                nl._poll_overflow()
             self._graph.replay()
             f._calls = getattr(f, "_calls", 0) + cycle
             s.timestep += cycle
             nsteps -= cycle
-            polled = (polled + 1) % 8
-            if polled == 1:
-                nl.mark_check_enqueued()
+            nl.mark_check_enqueued()
+            behind.append(nl._stat_event)
+            nl._stat_event = None
+        for ev in behind:
+            nl._stat_event = ev
+            nl._poll_overflow()
         return nsteps
 
     def _step(self):

@@ -193,7 +193,10 @@ class tfcompute:
     def graph_safe(self):
         """True when a step of this compute is a fixed sequence of launches (the installed one-kernel plan, every
         step, no training, no output capture, no host-side precompute): Simulation.run may replay it from a hipGraph."""
+        # (check_nlist reads a count back inside htf_compute_forces -- a host copy and a synchronize, illegal under stream
+        #  capture -- so a model that asks for it steps eagerly; ADVICE r2)
         return (self._plan is not None and self.model._plan is self._plan and self.period == 1 and not self.train
+                and not getattr(self.model, "check_nlist", False)
                 and not self.model._map_nlist and getattr(self._nlist, "domain", None) is None
                 and self.force.shape[0] == self.system.N and not getattr(self, "save_output_period", None))
 

@@ -13,7 +13,8 @@ using hoomd_tf_amd::TensorflowComputeAMD;
 
 void hoomd_tf_amd::export_TensorflowComputeAMD(py::module &m) {
     // not exported anywhere else in HOOMD 2.x (.cc:425-426)
-    py::class_<HalfStepHook, std::shared_ptr<HalfStepHook>>(m, "HalfStepHook");
+    // (HOOMD's integrator calls update() from C++ at the half step; exported so that a driver without one can too)
+    py::class_<HalfStepHook, std::shared_ptr<HalfStepHook>>(m, "HalfStepHook").def("update", &HalfStepHook::update);
 
     py::class_<TensorflowComputeAMD, std::shared_ptr<TensorflowComputeAMD>, ForceCompute>(m, "TensorflowComputeAMD")
         .def(py::init<py::object &, std::shared_ptr<SystemDefinition>, std::shared_ptr<NeighborList>, Scalar, unsigned int,

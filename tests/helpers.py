@@ -128,3 +128,44 @@ def random_nlist(rng, N, NN, fill=0.7, rmin=0.8, rmax=3.0, ntypes=1, dtype=np.fl
         nl[i, :c, :3] = v * r
         nl[i, :c, 3] = rng.integers(0, ntypes, size=c)
     return nl.astype(dtype), cnt
+
+
+# ---------------------------------------------------------------------------- the HOOMD-side shim against the fake HOOMD
+SHIM = os.path.join(ROOT, "integration", "hoomd_shim")
+STUB = os.path.join(ROOT, "integration", "hoomd_stub")
+
+
+def shim_flags(extra=()):
+    import sysconfig
+
+    import pybind11
+    return ["g++", "-std=c++14", "-Wall", "-Wextra", "-Wno-unused-parameter", "-Werror", "-fvisibility=hidden", "-fPIC",
+            "-D__HIP_PLATFORM_AMD__", "-I", STUB, "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+            "-I", sysconfig.get_paths()["include"], "-I", pybind11.get_include()] + list(extra)
+
+
+def build_shim(out_dir, lib_path, single=False):
+    """Compile and link integration/hoomd_shim/ (-> _htf_amd.so) and the fake HOOMD's module (-> _hoomd_stub.so) into
+    ``out_dir``; returns that directory.  g++ only: the shim is host code over the C ABI."""
+    import subprocess
+    extra = ["-DSINGLE_PRECISION"] if single else []
+    out_dir = str(out_dir)
+    libdir = os.path.dirname(lib_path)
+    objs = []
+    for src in ("TensorflowComputeAMD.cc", "module.cc"):
+        o = os.path.join(out_dir, src + ".o")
+        r = subprocess.run(shim_flags(extra) + ["-c", os.path.join(SHIM, src), "-o", o], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-4000:]
+        objs.append(o)
+    stub_o = os.path.join(out_dir, "stub.o")
+    r = subprocess.run(shim_flags(extra) + ["-c", os.path.join(STUB, "stub_module.cc"), "-o", stub_o], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-4000:]
+    r = subprocess.run(["g++", "-shared", "-o", os.path.join(out_dir, "_hoomd_stub.so"), stub_o, "-L", "/opt/rocm/lib", "-lamdhip64"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-4000:]
+    # libamdhip64: the one torch has loaded (our library's DT_NEEDED resolves to it too, see _lib.py)
+    r = subprocess.run(["g++", "-shared", "-o", os.path.join(out_dir, "_htf_amd.so")] + objs +
+                       ["-L", libdir, "-lhtf_amd", "-L", "/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + libdir],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-4000:]
+    return out_dir

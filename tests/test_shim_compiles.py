@@ -1,7 +1,8 @@
-"""The HOOMD-side shim (integration/hoomd_shim/) compiled against a stand-in for the HOOMD-blue 2.x headers
-(integration/hoomd_stub/): HOOMD-blue is not in the image, so this is a LINT -- syntax, types, overload
+"""The HOOMD-side shim (integration/hoomd_shim/) compiled against a FAKE of the HOOMD-blue 2.x headers
+(integration/hoomd_stub/): HOOMD-blue is not in the image, so this file is a LINT -- syntax, types, overload
 resolution, the pybind11 signatures, and that the module links against libhtf_amd.so and imports with
-every method the reference exports (htf/TensorflowCompute.cc:422-486) -- not a run of the plugin."""
+every method the reference exports (htf/TensorflowCompute.cc:422-486).  tests/test_gpu_shim.py RUNS the shim
+(computeForces, period, batches, virial pitch, reference forces, training) against the same fake on a GPU."""
 import os
 import shutil
 import subprocess
@@ -12,20 +13,12 @@ import pytest
 
 from helpers import ROOT
 
-SHIM = os.path.join(ROOT, "integration", "hoomd_shim")
-STUB = os.path.join(ROOT, "integration", "hoomd_stub")
+from helpers import SHIM, STUB, build_shim, shim_flags as _flags  # noqa: E402
 
 # htf/TensorflowCompute.cc:431-481, one .def each
 REFERENCE_EXPORTS = ["setMappedNlist", "getPositionsBuffer", "getNlistBuffer", "getForcesBuffer", "getBoxBuffer",
                      "getVirialBuffer", "getPositionsArray", "getNlistArray", "getForcesArray", "getBoxArray",
                      "getVirialArray", "isDoublePrecision", "getVirialPitch", "hook", "addReferenceForce"]
-
-
-def _flags(extra=()):
-    import pybind11
-    return ["g++", "-std=c++14", "-Wall", "-Wextra", "-Wno-unused-parameter", "-Werror", "-fvisibility=hidden", "-fPIC",
-            "-D__HIP_PLATFORM_AMD__", "-I", STUB, "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
-            "-I", sysconfig.get_paths()["include"], "-I", pybind11.get_include()] + list(extra)
 
 
 @pytest.mark.skipif(shutil.which("g++") is None, reason="no g++")
@@ -40,21 +33,7 @@ def test_shim_compiles_against_stub_headers(tmp_path, precision):
 
 @pytest.mark.skipif(shutil.which("g++") is None, reason="no g++")
 def test_shim_module_links_and_exports_the_reference_surface(tmp_path, htf):
-    objs = []
-    for src in ("TensorflowComputeAMD.cc", "module.cc"):
-        o = str(tmp_path / (src + ".o"))
-        subprocess.run(_flags() + ["-c", os.path.join(SHIM, src), "-o", o], check=True, capture_output=True)
-        objs.append(o)
-    # the base types come from HOOMD's own modules in a real build; here from a three-class stub module
-    stub_o, stub_so = str(tmp_path / "stub.o"), str(tmp_path / "_hoomd_stub.so")
-    subprocess.run(_flags() + ["-c", os.path.join(STUB, "stub_module.cc"), "-o", stub_o], check=True, capture_output=True)
-    subprocess.run(["g++", "-shared", "-o", stub_so, stub_o], check=True, capture_output=True)
-    so = str(tmp_path / "_htf_amd.so")
-    libdir = os.path.dirname(htf._lib.LIB_PATH)
-    # libamdhip64: the one torch has loaded (our library's DT_NEEDED resolves to it too, see _lib.py)
-    r = subprocess.run(["g++", "-shared", "-o", so] + objs + ["-L", libdir, "-lhtf_amd", "-L", "/opt/rocm/lib", "-lamdhip64",
-                                                            "-Wl,-rpath," + libdir], capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr[-4000:]
+    build_shim(tmp_path, htf._lib.LIB_PATH)
     code = ("import sys, torch; sys.path.insert(0, %r); import hoomd_tf_amd; sys.path.insert(0, %r); import _hoomd_stub; import _htf_amd as m; "
             "c = m.TensorflowComputeAMD; print(' '.join(n for n in dir(c) if not n.startswith('_'))); "
             "print(m.FORCE_MODE.tf2hoomd, m.FORCE_MODE.hoomd2tf, m.HalfStepHook.__name__); "
