@@ -82,6 +82,8 @@ template <class T> using GPUArray = GlobalArray<T>;
 //! release (unless read) -- HOOMD's acquire / release protocol, eagerly.
 template <class T>
 class ArrayHandle {
+    std::vector<T> m_host; // (declared before `data`: stage() fills it while `data` is being initialised)
+
 public:
     ArrayHandle(const GlobalArray<T> &a, access_location::Enum loc = access_location::host,
                 access_mode::Enum mode = access_mode::readwrite)
@@ -100,7 +102,6 @@ private:
             fake_hoomd_hip(hipMemcpy(m_host.data(), a.m_data, a.m_n * sizeof(T), hipMemcpyDeviceToHost), "hipMemcpy(ArrayHandle)");
         return m_host.data();
     }
-    std::vector<T> m_host;
     const GlobalArray<T> &m_array;
     access_location::Enum m_loc;
     access_mode::Enum m_mode;

@@ -53,7 +53,8 @@ class FakeHoomdRun:
         self.nve = standin.NVE(s, 0.005)
         self.sysdef = H.SystemDefinition()
         self.pdata = self.sysdef.getParticleData()
-        self.pdata.setN(s.N, s.N, 0)
+        self.max_n = s.N + 4                      # HOOMD's max N is rarely N: the virial pitch then differs from N too
+        self.pdata.setN(s.N, self.max_n, 0)
         half = [float(x) / 2 for x in L]
         self.pdata.setBox([-h for h in half], half, [0.0, 0.0, 0.0], [1, 1, 1])
         self.net_force = torch.zeros((s.N, 4), dtype=sdt, device=dev)
@@ -109,7 +110,7 @@ for virial, batch_size, period in ((True, 0, 1), (False, 0, 1), (True, 300, 1), 
     ctx.set_potential(pot)
     f_ref = torch.zeros((s.N, 4), dtype=sdt, device=dev)
     v6, pitch = run.virial6()
-    assert pitch >= s.N and pitch % 16 == 0 and run.c.getVirialPitch() == pitch
+    assert pitch > s.N and pitch % 16 == 0 and run.c.getVirialPitch() == pitch   # 864 particles, max N 868: pitch 880
     v_ref = torch.zeros((6, pitch), dtype=sdt, device=dev)
     calls0 = run.hnl.computeCalls()
     for ts in range(10):
@@ -147,8 +148,8 @@ pot = htf.Potential.lj()
 run.c.setPotential(pot.handle.value, False, False, 2)
 run.c.compute(0)
 before = run.force().clone()
-run.pdata.setN(run.sysm.N, run.sysm.N + 500, 0)   # max N grows: HOOMD re-makes m_force / m_virial, the plugin its side buffers
-assert run.c.forceElements() == run.sysm.N + 500
+run.pdata.setN(run.sysm.N, run.max_n + 500, 0)   # max N grows: HOOMD re-makes m_force / m_virial, the plugin its side buffers
+assert run.c.forceElements() == run.max_n + 500
 run.c.compute(1)
 torch.cuda.synchronize()
 assert torch.equal(run.force(), before)           # same positions, same list: same forces in the new arrays
@@ -214,7 +215,9 @@ for n_ref in (0, 2):
 # ------------------------------------------------------------------ 4. errors surface as Python exceptions
 run = FakeHoomdRun()
 pot = htf.Potential.lj()
-small = M.TensorflowComputeAMD(run, run.sysdef, run.hnl, R_CUT, 8, M.FORCE_MODE.tf2hoomd, 1, 0)   # NN = 8 overflows
+# (check_nlist counts the slots with dx > 0 per row, simmodel.py:214-219: NN = 2 fills both slots of some row with such
+#  neighbors for certain)
+small = M.TensorflowComputeAMD(run, run.sysdef, run.hnl, R_CUT, 2, M.FORCE_MODE.tf2hoomd, 1, 0)
 small.setPotential(pot.handle.value, False, True, 2)
 try:
     small.compute(0)

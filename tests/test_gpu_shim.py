@@ -22,7 +22,7 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("precision", ["double", "single"])
 def test_shim_runs_against_fake_hoomd(tmp_path, htf, cuda, precision):
     build_shim(tmp_path, htf._lib.LIB_PATH, single=(precision == "single"))
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "shim_driver.py"), str(tmp_path), precision],
+    r = subprocess.run([sys.executable, "-u", "-X", "faulthandler", os.path.join(ROOT, "tests", "shim_driver.py"), str(tmp_path), precision],
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
     for piece in ("OK forces virial=True batch_size=0 period=1", "OK forces virial=True batch_size=300 period=1",
