@@ -51,7 +51,7 @@ class PotentialDesc(C.Structure):
                 ("K", C.c_int), ("H1", C.c_int), ("H2", C.c_int), ("activation", C.c_int),
                 ("mlp_precision", C.c_int), ("rbf_low", C.c_double), ("rbf_high", C.c_double),
                 ("W1", C.c_void_p), ("b1", C.c_void_p), ("W2", C.c_void_p), ("b2", C.c_void_p),
-                ("W3", C.c_void_p), ("b3", C.c_void_p)]
+                ("W3", C.c_void_p), ("b3", C.c_void_p), ("poly_cut", C.c_double)]
 
 
 class OptimizerDesc(C.Structure):

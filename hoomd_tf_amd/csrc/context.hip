@@ -147,6 +147,12 @@ extern "C" int htf_potential_create(const htf_potential_desc *d, htf_potential *
             p->pp.coef[k] = (float)d->coef[k];
             p->pp.power[k] = d->power[k];
         }
+        if (d->poly_cut < 0) {
+            set_error("htf_potential_create: poly_cut must be >= 0 (got %g)", d->poly_cut);
+            rc = HTF_ERR_INVALID;
+        }
+        // `r < cut` on r = tf.norm (correctly rounded sqrt of the plain sum of squares) as a threshold on the squared norm
+        p->pp.poly_cut_r2 = d->poly_cut > 0 ? sqrt_threshold((float)d->poly_cut) : 0.0f;
         break;
     case HTF_POT_LJ_PARAM:
         p->pp.lj_w0 = (float)d->lj_w0;

@@ -15,6 +15,7 @@ struct PotParams {
     int n_terms;
     float coef[HTF_MAX_POLY_TERMS];
     int power[HTF_MAX_POLY_TERMS];
+    float poly_cut_r2; // RINV_POLY mask: smallest fp32 t with sqrtf(t) >= poly_cut (0: no mask)
 };
 
 // counts (nullable): live slots per row; slots >= counts[row] are known zero padding and not loaded

@@ -183,6 +183,12 @@ __device__ __forceinline__ void pair_eval_f(const RinvFwd &f, float x, float y, 
                     e += p.coef[k] * (acc * s);
                 }
             }
+            if (p.poly_cut_r2 > 0.0f) { // wave-uniform: example 01's `cast(norm < cut) * energy`, a mask without a gradient
+                asm volatile("" ::: "memory");
+                const bool in = plain_sq3(x, y, z) < p.poly_cut_r2;
+                e = in ? e : 0.0f;
+                dEds = in ? dEds : 0.0f;
+            }
         }
         // d s / d r' = -s^2 (where cond), d r' / d t = t / r'; times 2 (simmodel.py:548)
         float c = f.cond ? 2.0f * (dEds * (-s2)) * f.irp : 0.0f;
@@ -294,6 +300,12 @@ __device__ __forceinline__ void pair_eval_grad(float x, float y, float z, const 
                     e += p.coef[k] * ek;
                     dd[k] = make_float4(geo * dk * f.tx, geo * dk * f.ty, geo * dk * f.tz, f.cond ? ek : 0.0f);
                 }
+            }
+            if (p.poly_cut_r2 > 0.0f && !(plain_sq3(x, y, z) < p.poly_cut_r2)) {
+                e = 0.0f;
+                dEds = 0.0f;
+#pragma unroll
+                for (int k = 0; k < P; ++k) dd[k] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
         const float c = geo * dEds;

@@ -46,7 +46,7 @@ class Potential:
 
     def __init__(self, kind, sigma=0.0, coefs=(), powers=(), mlp=None, rbf=(0.0, 0.0),
                  activation="linear", mlp_precision="fp32", gauss=(0.0, 1.0, 0.0), lj_param=(1.0, 1.0),
-                 theta=None):
+                 theta=None, poly_cut=0.0):
         d = _lib.PotentialDesc()
         d.kind = kind
         d.sigma = float(sigma)
@@ -57,6 +57,7 @@ class Potential:
             _dev(theta, "theta", torch.float32)
             d.d_theta = theta.data_ptr()
         d.n_terms = len(coefs)
+        d.poly_cut = float(poly_cut)
         if len(coefs) != len(powers):
             raise ValueError("coefs and powers differ in length")
         if len(coefs) > _lib.MAX_POLY_TERMS:
@@ -106,8 +107,9 @@ class Potential:
         return cls(_lib.POT_SIMPLE)
 
     @classmethod
-    def rinv_poly(cls, coefs, powers, theta=None):
-        return cls(_lib.POT_RINV_POLY, coefs=coefs, powers=powers, theta=theta)
+    def rinv_poly(cls, coefs, powers, theta=None, cut=0.0):
+        """sum_k c_k rinv^p_k; ``cut`` > 0: times ``cast(norm(nlist[:, :, :3]) < cut)`` (example 01's truncated r^-12)."""
+        return cls(_lib.POT_RINV_POLY, coefs=coefs, powers=powers, theta=theta, poly_cut=cut)
 
     @classmethod
     def lj_param(cls, w0, w1, theta=None):

@@ -177,10 +177,67 @@ class PosRadial(_TorchOperand):
     __rmul__ = __mul__
 
 
+class PairNorm(_TorchOperand):
+    """``tf.norm(nlist[:, :, :3], axis=2)``: the plain pair distance.  Symbolic so that ``r < cut`` can become the hard
+    mask of a closed-form energy (examples/01. Quickstart.ipynb cell 3); torch code gets the autograd value ``ad``."""
+
+    def __init__(self, xyz):
+        self.xyz = xyz
+
+    @property
+    def ad(self):
+        t = self.xyz.ad
+        return torch.sqrt((t * t).sum(dim=2))
+
+    @property
+    def tensor(self):
+        t = self.xyz.tensor
+        return torch.sqrt((t * t).sum(dim=2))
+
+    def __lt__(self, cut):
+        if isinstance(cut, (int, float)):
+            return PairMask(self.xyz.parent, float(cut))
+        return self.ad < _unwrap(cut)
+
+    def __gt__(self, o): return self.ad > _unwrap(o)
+    def __le__(self, o): return self.ad <= _unwrap(o)
+    def __ge__(self, o): return self.ad >= _unwrap(o)
+
+
+class PairMask:
+    """``r < cut`` (and its ``tf.cast(..., tf.float32)``): multiplies a per-pair rinv polynomial into its truncated form --
+    one kernel (HTF_POT_RINV_POLY with ``poly_cut``); anything else gets the torch tensor."""
+
+    def __init__(self, nlist, cut):
+        self.nlist, self.cut = nlist, cut
+
+    def tensor(self):
+        t = self.nlist.tensor[:, :, :3]
+        return (torch.sqrt((t * t).sum(dim=2)) < self.cut)
+
+    def __mul__(self, o):
+        if isinstance(o, RinvPoly) and o.nlist is self.nlist and not o.reduced and o.cut in (None, self.cut):
+            return RinvPoly(o.nlist, o.terms, cut=self.cut)
+        return self.tensor().to(torch.float32) * _unwrap(o)
+
+    __rmul__ = __mul__
+
+
+def cast(x, dtype=None):
+    """tf.cast for model code: a symbolic mask stays symbolic, tensors are converted."""
+    if isinstance(x, PairMask):
+        return x
+    t = _unwrap(x)
+    return t.to(dtype) if dtype is not None and isinstance(t, torch.Tensor) else t
+
+
 def norm(tensor, axis=None):
-    """tf.norm for model code: symbolic on the positions tensor (axis=1), torch otherwise."""
+    """tf.norm for model code: symbolic on the positions tensor (axis=1) and on ``nlist[:, :, :3]`` (axis=2), torch
+    otherwise."""
     if isinstance(tensor, Positions) and axis in (1, -1):
         return PosNorm(tensor, 4)
+    if isinstance(tensor, NlistXYZ) and axis in (2, -1):
+        return PairNorm(tensor)
     t = _unwrap(tensor)
     return torch.sqrt((t * t).sum()) if axis is None else torch.sqrt((t * t).sum(dim=axis))
 
@@ -218,19 +275,22 @@ class PairEnergy:
 class RinvPoly(PairEnergy):
     """sum_k c_k * rinv^p_k with rinv = nlist_rinv(nlist)."""
 
-    def __init__(self, nlist, terms, reduced=False):
+    def __init__(self, nlist, terms, reduced=False, cut=None):
         self.nlist = nlist
         self.terms = {p: c for p, c in terms.items() if c != 0}
         self.reduced = reduced
+        self.cut = cut  # hard mask norm(nlist[:, :, :3]) < cut (no gradient), None: unmasked
 
     def _bin(self, other, sign):
         if isinstance(other, RinvPoly):
             if other.nlist is not self.nlist:
                 raise ValueError("expressions come from different neighbor lists")
+            if other.cut != self.cut:
+                raise ValueError("cannot add rinv polynomials with different masks in one kernel")
             t = dict(self.terms)
             for p, c in other.terms.items():
                 t[p] = t.get(p, 0.0) + sign * c
-            return RinvPoly(self.nlist, t, self.reduced and other.reduced)
+            return RinvPoly(self.nlist, t, self.reduced and other.reduced, cut=self.cut)
         raise TypeError("cannot combine a rinv polynomial with %r (constants carry no force)" % (other,))
 
     def __add__(self, o):
@@ -244,19 +304,23 @@ class RinvPoly(PairEnergy):
         return self._bin(o, -1.0)
 
     def __neg__(self):
-        return RinvPoly(self.nlist, {p: -c for p, c in self.terms.items()}, self.reduced)
+        return RinvPoly(self.nlist, {p: -c for p, c in self.terms.items()}, self.reduced, cut=self.cut)
 
     def __mul__(self, o):
         if isinstance(o, (int, float)):
-            return RinvPoly(self.nlist, {p: c * o for p, c in self.terms.items()}, self.reduced)
+            return RinvPoly(self.nlist, {p: c * o for p, c in self.terms.items()}, self.reduced, cut=self.cut)
+        if isinstance(o, PairMask):
+            return o.__mul__(self)
         if isinstance(o, RinvPoly):
             if o.nlist is not self.nlist or self.reduced or o.reduced:
                 raise ValueError("can only multiply per-pair expressions of one neighbor list")
+            if self.cut is not None and o.cut is not None and self.cut != o.cut:
+                raise ValueError("cannot multiply rinv polynomials with different masks in one kernel")
             t = {}
             for p1, c1 in self.terms.items():
                 for p2, c2 in o.terms.items():
                     t[p1 + p2] = t.get(p1 + p2, 0.0) + c1 * c2
-            return RinvPoly(self.nlist, t)
+            return RinvPoly(self.nlist, t, cut=self.cut if self.cut is not None else o.cut)
         return NotImplemented
 
     __rmul__ = __mul__
@@ -273,16 +337,16 @@ class RinvPoly(PairEnergy):
         return out
 
     def key(self):
-        return ("poly", tuple(sorted(self.terms.items())))
+        return ("poly", tuple(sorted(self.terms.items())), self.cut)
 
     def potential(self):
         t = dict(self.terms)
-        if len(t) == 2 and t.get(12) == 2.0 and t.get(6) == -2.0:
+        if self.cut is None and len(t) == 2 and t.get(12) == 2.0 and t.get(6) == -2.0:
             return ops.Potential.lj()  # LJModel: 4/2 (rinv^12 - rinv^6), build_examples.py:67-77
         if any(p < 1 for p in t):
             raise ValueError("rinv powers must be >= 1")
         powers = sorted(t)
-        return ops.Potential.rinv_poly([t[p] for p in powers], powers)
+        return ops.Potential.rinv_poly([t[p] for p in powers], powers, cut=self.cut or 0.0)
 
     def tensor(self):
         """Eager value [N, NN] (or [N] once reduced) for model outputs other than forces."""
@@ -291,6 +355,8 @@ class RinvPoly(PairEnergy):
         out = torch.zeros_like(s)
         for p, c in self.terms.items():
             out += c * s ** p
+        if self.cut is not None:
+            out = out * PairMask(self.nlist, self.cut).tensor().to(out.dtype)
         return out.sum(dim=1) if self.reduced else out
 
 
@@ -518,12 +584,12 @@ def reduce_sum(x, axis=None):
         if axis is None:
             # a scalar total energy: compute_nlist_forces differentiates sum(energy) either way, and
             # _add_energy tiles a rank-0 energy into every particle's column (simmodel.py:558-578)
-            out = RinvPoly(x.nlist, x.terms, reduced=True)
+            out = RinvPoly(x.nlist, x.terms, reduced=True, cut=x.cut)
             out.total = True
             return out
         if axis not in (1, -1):
             raise ValueError("pair energies reduce over the neighbor axis (axis=1), or over everything (axis=None)")
-        return RinvPoly(x.nlist, x.terms, reduced=True)
+        return RinvPoly(x.nlist, x.terms, reduced=True, cut=x.cut)
     if isinstance(x, WCAPair):
         return x
     if isinstance(x, LJParamEnergy):

@@ -112,6 +112,10 @@ typedef struct htf_potential_desc {
     int mlp_precision; /* htf_mlp_precision: MFMA operand type; accumulation is fp32 */
     double rbf_low, rbf_high;
     const float *W1, *b1, *W2, *b2, *W3, *b3;
+    /* RINV_POLY: optional hard mask `tf.cast(tf.norm(nlist[:, :, :3], axis=2) < poly_cut, tf.float32) * energy`
+     * (examples/01. Quickstart.ipynb cell 3: WCA as r^-12 inside 2^(1/6)); the mask carries no gradient.  0 = no mask.
+     * (appended in round 3: a zero-initialised desc of the earlier layout means "no mask") */
+    double poly_cut;
 } htf_potential_desc;
 
 typedef struct htf_potential htf_potential; /* opaque; owns device copies of weights */

@@ -284,9 +284,11 @@ def positions_radial_model(positions, coef=1.0, power=-1, ncomp=4):
 # --------------------------------------------------------------------------- #
 # a24: reference workloads (build_examples.py)
 # --------------------------------------------------------------------------- #
-def rinv_poly_model(nlist, coefs, powers, virial=False):
+def rinv_poly_model(nlist, coefs, powers, virial=False, cut=None):
     """Per-particle energy E_i = sum_j sum_k c_k * s_ij^p_k, forces via
-    compute_nlist_forces.  Generalises LJModel / BenchmarkPotential / example 01."""
+    compute_nlist_forces.  Generalises LJModel / BenchmarkPotential / example 01.
+    ``cut``: examples/01. Quickstart.ipynb cell 3, ``tf.cast(tf.norm(nlist[:, :, :3], axis=2) < cut, tf.float32) *
+    energy`` -- the comparison is taken in fp32 as TF takes it, and the cast carries no gradient."""
     dt = nlist.dtype
     s, t, rp, cond = _rinv_and_grad_factor(nlist)
     e = np.zeros_like(s)
@@ -294,6 +296,12 @@ def rinv_poly_model(nlist, coefs, powers, virial=False):
     for c, p in zip(coefs, powers):
         e = e + dt.type(c) * s ** int(p)
         de = de + dt.type(c * p) * s ** int(p - 1)
+    if cut is not None:
+        x32 = nlist[:, :, :3].astype(np.float32)
+        r32 = np.sqrt((x32 * x32).sum(axis=2, dtype=np.float32)).astype(np.float32)
+        inside = r32 < np.float32(cut)
+        e = np.where(inside, e, dt.type(0))
+        de = np.where(inside, de, dt.type(0))
     g = _grad_from_dEds(de, s, t, rp, cond)
     return nlist_forces_from_grad(nlist, g, e.sum(axis=1), virial)
 

@@ -270,6 +270,40 @@ class BenchmarkNonlistModel(htf.SimModel):
         return forces
 
 
+class _MeanTensor:
+    """tf.keras.metrics.MeanTensor"""
+
+    def __init__(self):
+        self.total, self.count = None, 0
+
+    def update_state(self, x):
+        x = torch.stack([torch.as_tensor(v) for v in x]).detach().double() if isinstance(x, (tuple, list)) else x.detach().double()
+        self.total = x.clone() if self.total is None else self.total + x
+        self.count += 1
+
+    def reset_states(self):
+        self.total, self.count = None, 0
+
+    def result(self):
+        return self.total / max(self.count, 1)
+
+
+class QuickstartWCA(htf.SimModel):
+    # examples/01. Quickstart.ipynb cell 3 (WCAPotential): r^-12 inside 2^(1/6) via a cast mask, an RDF averaged every step
+    def setup(self):
+        self.avg_rdf = _MeanTensor()
+
+    def compute(self, nlist):
+        r12 = htf.nlist_rinv(nlist)**12
+        r = htf.norm(nlist[:, :, :3], axis=2)
+        pair_energy = htf.cast(r < 2**(1 / 6), torch.float32) * r12
+        particle_energy = htf.reduce_sum(pair_energy, axis=1)
+        forces = htf.compute_nlist_forces(nlist, particle_energy)
+        inst_rdf = htf.compute_rdf(nlist, [0, 3.5])
+        self.avg_rdf.update_state(inst_rdf)
+        return forces
+
+
 class _Mean:
     """tf.keras.metrics.Mean"""
 

@@ -330,6 +330,36 @@ def test_rinv_poly_and_benchmark_potential(htf, cuda):
     assert_forces_close("poly_r12_v", v.cpu().numpy(), rv, 3 * c, cancelling_rows=CONTACTS)
 
 
+def test_rinv_poly_with_hard_cut_example01(htf, cuda):
+    """examples/01. Quickstart.ipynb cell 3: pair_energy = tf.cast(tf.norm(nlist[:, :, :3], axis=2) < 2**(1/6), tf.float32)
+    * nlist_rinv(nlist)**12 -- WCA as a truncated r^-12; the mask carries no gradient.  Evaluator and fused forms against
+    the oracle, and the mask bit at the cut itself: slots at the largest fp32 below 2^(1/6) contribute, at the cut do not."""
+    cut = 2 ** (1 / 6)
+    nl = _nlist_case(14, N=300, NN=64, rmin=0.85)
+    # a row of slots straddling the cut within an ulp (x axis only: the norm is then |x| exactly)
+    c32 = np.float32(cut)
+    below, above = np.nextafter(c32, np.float32(0)), np.nextafter(c32, np.float32(2))
+    nl[1] = 0
+    nl[1, :4, 0] = [below, c32, above, -below]
+    nl64 = nl.astype(np.float64)
+    pot = htf.Potential.rinv_poly([1.0], [12], cut=cut)
+    f, v = htf.ops.eval_forces(pot, torch.from_numpy(nl).to(cuda), virial=True)
+    rf, rv = O.rinv_poly_model(nl64, [1.0], [12], virial=True, cut=cut)
+    s, t, rp, cond = O._rinv_and_grad_factor(nl64)
+    r32 = np.sqrt((nl[:, :, :3] ** 2).sum(axis=2, dtype=np.float32))
+    g = 2 * O._grad_from_dEds(np.where(r32 < c32, 12 * s ** 11, 0.0), s, t, rp, cond)
+    c = _cond_scale(nl64, g)
+    assert_forces_close("poly_r12_cut_f", f.cpu().numpy(), rf, c, cancelling_rows=CONTACTS)
+    assert_forces_close("poly_r12_cut_v", v.cpu().numpy(), rv, 3 * c, cancelling_rows=CONTACTS)
+    # the straddling row: exactly the two slots below the cut count (their energies: rinv^12 at r = below)
+    e_one = float(O.rinv_poly_model(nl64[1:2, :1], [1.0], [12], cut=cut)[0, 3])
+    np.testing.assert_allclose(float(f[1, 3]), 2 * e_one, rtol=1e-5)
+    assert e_one > 0.2
+    # the unmasked potential differs (every slot inside r_cut contributes), so the mask is really applied
+    f0 = htf.ops.eval_forces(htf.Potential.rinv_poly([1.0], [12]), torch.from_numpy(nl).to(cuda))
+    assert float((f0[:, 3] - f[:, 3]).abs().max()) > 1e-3
+
+
 def test_simple_potential(htf, cuda):
     nl = _nlist_case(5, N=100, NN=32)
     f = htf.ops.eval_forces(htf.Potential.simple(), torch.from_numpy(nl).to(cuda))

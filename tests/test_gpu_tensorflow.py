@@ -267,6 +267,33 @@ def test_rdf(htf, cuda):
     assert ref.sum() > 0
 
 
+def test_quickstart_example01(htf, cuda):
+    """examples/01. Quickstart.ipynb as written (cells 3 and 5): 16 x 16 particles on sq(a = 1.2), WCAPotential(64) --
+    r^-12 times cast(r < 2^(1/6)) -- attached with r_cut 5, an RDF averaged every step.  Forces of a step against the
+    oracle on the same pair vectors; the symbolic mask lowers to ONE kernel (a masked rinv polynomial), the lattice
+    rows (60 candidates within 5.0 + buffer > NN = 64 only after the fluid has moved) do not overflow at first."""
+    sim, system, L = _sim(htf, cuda, 16, 1.2, kT=0.5, seed=1, dt=0.005)
+    model = build_examples.QuickstartWCA(64)
+    tfcompute = htf.tfcompute(model)
+    tfcompute.attach(sim.nlist_cell(), r_cut=5)
+    sim.run(20)
+    model.avg_rdf.reset_states()
+    sim.run(5)
+    nl = tfcompute.get_nlist_array().astype(np.float32)
+    ref = O.rinv_poly_model(nl.astype(np.float64), [1.0], [12], cut=2 ** (1 / 6))
+    f = tfcompute.get_forces_array()
+    np.testing.assert_allclose(f, ref, atol=1e-5, rtol=2e-5)
+    assert np.abs(ref[:, :3]).max() > 0.05              # neighbors at 1.2 -> inside 2^(1/6) only once they move: repulsion is on
+    rdf = model.avg_rdf.result().cpu().numpy()
+    assert rdf.shape == (2, 100) and model.avg_rdf.count == 5 and rdf[0].sum() > 0
+    ref_rdf, rs = O.compute_rdf(nl, [0, 3.5])
+    np.testing.assert_allclose(rs, rdf[1], rtol=1e-6)
+    # the lowered potential is the masked polynomial (one evaluator kernel), not the autograd fallback
+    from hoomd_tf_amd import simmodel
+    pots = [k for k in getattr(simmodel.compute_nlist_forces, "_cache", {}) if k[0] == "poly" and k[-1] is not None]
+    assert pots and abs(pots[0][-1] - 2 ** (1 / 6)) < 1e-12
+
+
 def test_eds_rdf_model_steps_match_oracle(htf, cuda):
     """config C4 through SimModel/tfcompute: every step's forces, cv and alpha against the
     oracle composite driven by the oracle EDSLayer on the same pair vectors."""
