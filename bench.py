@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="lj", choices=["lj", "wca", "mlp", "mlp-split", "mlp-bf16", "mlp-train", "eds", "ref-lj256"])
+    ap.add_argument("--workload", default="lj", choices=["lj", "wca", "mlp", "mlp-split", "mlp-bf16", "mlp-train", "eds", "ref-lj256", "c1", "ex01"])
     ap.add_argument("--train-period", type=int, default=100, help="mlp-train (C5b): force-matching step every this many MD steps")
     ap.add_argument("--cells", type=int, default=32, help="fcc cells per side (N = 4 cells^3 per rank)")
     ap.add_argument("--lattice", default="fcc", choices=["fcc", "sc"], help="fcc: N = 4 cells^3 (C3, C5); sc: N = cells^3 (C2 = sc 32^3 = 32768)")
@@ -260,6 +260,151 @@ def run_ref_lj256(args, htf, standin, dev):
     print(json.dumps(out))
 
 
+def run_small(args, htf, standin, dev):
+    """SURVEY 8(d) row C1 as written -- BASELINE configs[0], "LJ pair potential (example 01 Quickstart), 864 particles NN=64"
+    -- in both readings: `--workload c1`: LJModel on 864 = 4 x 6^3 fcc particles, rho 0.8442, r_cut 2.5, NN 64, fp64 wire
+    (HOOMD's default build) / fp32 model; `--workload ex01`: the notebook itself (examples/01. Quickstart.ipynb cells 3, 5):
+    16 x 16 particles on sq(a = 1.2), WCAPotential(64) = r^-12 x cast(r < 2^(1/6)), r_cut 5, compute_rdf averaged every
+    step, kT 0.5, dt 0.005 -- the notebook prints 488 steps/s (TF2 CPU path + HOOMD NVT, its own hardware).
+    Both are host-enqueue-bound: reported through tfcompute step by step and, where the step is a fixed launch sequence,
+    replayed from a hipGraph.  cpu_baseline: the numpy oracle of the same model on the same pair-vector shapes."""
+    from oracle import htf_oracle as O
+    ex01 = args.workload == "ex01"
+    if ex01:
+        n, a, NN, rcut = 16, 1.2, 64, 5.0
+        L = np.array([n * a, n * a, 1.0])
+        ij = np.stack(np.meshgrid(np.arange(n), np.arange(n), indexing="ij"), -1).reshape(-1, 2)
+        pos = np.zeros((n * n, 3))
+        pos[:, :2] = (ij + 0.5) * a - L[:2] / 2
+        sdt = torch.float64
+        sysm = standin.System(pos, L, dtype=sdt, device=dev)
+        sysm.randomize_velocities(kT=0.5, seed=1)
+        sysm.vel[:, 2] = 0.0
+
+        class Model(htf.SimModel):
+            def setup(self):
+                self.rdf_sum, self.rdf_n = None, 0
+
+            def compute(self, nlist):
+                r12 = htf.nlist_rinv(nlist)**12
+                r = htf.norm(nlist[:, :, :3], axis=2)
+                pair_energy = htf.cast(r < 2**(1 / 6), torch.float32) * r12
+                particle_energy = htf.reduce_sum(pair_energy, axis=1)
+                forces = htf.compute_nlist_forces(nlist, particle_energy)
+                inst_rdf = htf.compute_rdf(nlist, [0, 3.5])
+                self.rdf_sum = inst_rdf[0] if self.rdf_sum is None else self.rdf_sum + inst_rdf[0]  # MeanTensor.update_state
+                self.rdf_n += 1
+                return forces
+        what = ("examples/01. Quickstart.ipynb: sq lattice 16 x 16, a = 1.2 (256 particles, 2-D), WCAPotential(64) = rinv^12 x "
+                "cast(r < 2^(1/6)), r_cut 5.0, r_buff 0.4, compute_rdf [0, 3.5] averaged every step, kT 0.5, dt 0.005; stand-in NVE "
+                "instead of HOOMD NVT")
+        published, where = 488.064, "the notebook's own output cell: TPS 488.064 (TF2 CPU path + HOOMD NVT, hardware not recorded)"
+        pitch = 80
+    else:
+        NN, rcut = 64, 2.5
+        pos, L, a = standin.fcc_positions(6, 0.8442)
+        rng = np.random.default_rng(1)
+        pos = pos + 0.02 * a * rng.standard_normal(pos.shape)
+        pos -= np.round(pos / L) * L
+        sdt = torch.float64
+        sysm = standin.System(pos, L, dtype=sdt, device=dev)
+        sysm.randomize_velocities(kT=1.0, seed=1)
+
+        class Model(htf.SimModel):
+            def compute(self, nlist, positions, box):
+                rinv = htf.nlist_rinv(nlist)
+                inv_r6 = rinv**6
+                p_energy = 4.0 / 2.0 * (inv_r6 * inv_r6 - inv_r6)
+                energy = htf.reduce_sum(p_energy, axis=1)
+                return htf.compute_nlist_forces(nlist, energy)
+        what = ("C1: LJModel (build_examples.py:67-77), 864 = 4 x 6^3 fcc particles, rho 0.8442, r_cut 2.5, r_buff 0.4, NN 64, "
+                "fp64 wire / fp32 model, kT 1.0, dt 0.005, stand-in NVE")
+        published, where = None, None
+        pitch = None
+    sim = standin.Simulation(sysm)
+    sim.integrate_nve(0.005)
+    model = Model(NN)
+    tfc = htf.tfcompute(model)
+    cell = sim.nlist_cell(r_buff=0.4, check_period=1, pitch=pitch)
+    tfc.attach(cell, r_cut=rcut)
+    sim.run(max(args.equil, 200))
+    steps = 1000
+    rounds = []
+    for _ in range(5):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sim.run(steps)
+        torch.cuda.synchronize()
+        rounds.append(time.perf_counter() - t0)
+    el = float(np.median(rounds))
+    graph = None
+    if getattr(tfc, "graph_safe", lambda: False)():
+        g_rounds = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            sim.run(steps, graph=True)
+            torch.cuda.synchronize()
+            g_rounds.append(time.perf_counter() - t0)
+        g_el = float(np.median(g_rounds[1:]))
+        graph = {"value": steps / g_el, "unit": "steps/s", "captured": getattr(sim, "_graph", None) is not None, "rounds_s": g_rounds,
+                 "vs_baseline": (steps / g_el) / published if published else None,
+                 "note": "sim.run(n, graph=True): one check period of steps captured once and replayed as one hipGraph launch"}
+    else:
+        graph = {"value": None, "note": "not a fixed launch sequence: the model computes an observable (compute_rdf + its running "
+                                        "mean) in Python every step, so tfcompute keeps calling compute() -- the reference does too"}
+    f = tfc.force
+    assert bool(torch.isfinite(f).all())
+    # parity of the timed configuration's last step, against the oracle on the same pair vectors (rows are independent)
+    nlv = tfc.get_nlist_array().astype(np.float32).astype(np.float64)
+    ref = O.rinv_poly_model(nlv, [1.0], [12], cut=2 ** (1 / 6)) if ex01 else O.lj_model(nlv)
+    err = np.abs(tfc.get_forces_array() - ref)
+    bound = 1e-5 + 2e-5 * np.abs(ref)
+    # the condition scale of a row's fp32 sum, sum_j |f_ij| (DESIGN 4: an equilibrated liquid's rows cancel 300 -> 10)
+    s_, t_, rp_, cond_ = O._rinv_and_grad_factor(nlv)
+    if ex01:
+        x32 = nlv[:, :, :3].astype(np.float32)
+        inside = np.sqrt((x32 * x32).sum(axis=2, dtype=np.float32)) < np.float32(2 ** (1 / 6))
+        dEds = np.where(inside, 12.0 * s_ ** 11, 0.0)
+    else:
+        dEds = 2.0 * (2.0 * s_ ** 6 - 1.0) * (6.0 * s_ ** 5)
+    csum = np.abs(2.0 * O._grad_from_dEds(dEds, s_, t_, rp_, cond_)).sum(axis=(1, 2))
+    bound_c = bound + 2e-6 * csum[:, None]
+    cpu = None
+    if not args.no_cpu_baseline:
+        nl32 = nlv.astype(np.float32)
+        fn = (lambda: O.rinv_poly_model(nl32, [1.0], [12], cut=2 ** (1 / 6))) if ex01 else (lambda: O.lj_model(nl32))
+        fn()
+        t0, reps = time.perf_counter(), 0
+        while time.perf_counter() - t0 < min(args.cpu_seconds, 10.0):
+            fn()
+            reps += 1
+        cpu = {"value": reps / (time.perf_counter() - t0), "unit": "steps/s", "cores": 1, "kind": "port",
+               "sample": "%d evaluator passes of the numpy oracle (fp32, closed-form gradient) over this run's own [%d, %d, 4] pair "
+                         "vectors; pair-vector build, neighbor list and integrator not included" % (reps, sysm.N, NN)}
+    out = {
+        "metric": "MD steps/sec, BASELINE configs[0] (%s)" % ("the Quickstart notebook as written" if ex01 else "864 particles NN=64 LJ"),
+        "value": steps / el, "unit": "steps/s", "n_gpus": 1, "steps": steps, "warmup": max(args.equil, 200),
+        "ms_per_step": el / steps * 1e3, "higher_is_better": True, "scaling": "weak", "data": "synthetic",
+        "dtype": "f32 arithmetic on an f64 wire (HOOMD in double precision)",
+        "vs_baseline": (steps / el) / published if published else None,
+        "baseline": {"value": published, "unit": "steps/s", "where": where} if published else None,
+        "config": {"workload": what, "rounds_s": rounds, "particles": sysm.N, "max_neighbors_listed": int(cell.n_neigh.max())},
+        "replayed_as_one_kernel_plan": tfc._plan is not None,
+        "graph_variant": graph,
+        "parity_last_step": {"max_abs_err": float(err.max()), "max_err_over_bound": float((err / bound).max()),
+                             "max_err_over_bound_with_condition_term": float((err / bound_c).max()),
+                             "energy_max_err_over_bound": float((err[:, 3] / bound[:, 3]).max()),
+                             "bound": "1e-5 + 2e-5 |ref| (SURVEY 8(c), as stated; + 2e-6 sum_j |f_ij| for the condition-term figure) "
+                                      "vs the fp64 oracle on the same pair vectors, after %d MD steps" % (max(args.equil, 200) + 5 * steps)},
+        "energy_per_particle": float(f[:, 3].double().sum().item()) / sysm.N,
+        "roofline": None,
+        "roofline_note": "host-enqueue-bound at this size: every kernel is ~1-3 us; the step is the launch sequence",
+        "cpu_baseline": cpu,
+    }
+    print(json.dumps(out))
+
+
 def run_eds(args, htf, standin, dev):
     """Config C4 (BASELINE configs[3]): 262 144 particles (sc 64^3), NN 128, LJModel
     + EDS bias on the soft RDF collective variable, hard compute_rdf [0, 3.5] as an observable
@@ -448,13 +593,32 @@ def run_eds(args, htf, standin, dev):
     print(json.dumps(out))
 
 
+def count_gpus_sysfs():
+    """GPUs of this node from the KFD topology (nodes with SIMDs), without touching the HIP runtime: on ROCm builds without
+    amdsmi torch.cuda.device_count() falls through to hipGetDeviceCount, which initialises the GPU in the calling process."""
+    import glob
+    n = 0
+    for f in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            for line in open(f):
+                k, _, v = line.partition(" ")
+                if k == "simd_count" and int(v) > 0:
+                    n += 1
+        except OSError:
+            pass
+    vis = os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES"))
+    if vis is not None and vis.strip() != "":
+        n = min(n, len([x for x in vis.split(",") if x.strip() != ""]))
+    return n
+
+
 def self_launch(args):
     """`python bench.py --gpus N` with no launcher: start the N rank processes from here -- plain children
     of a parent that has not touched the GPU (never a re-exec) -- and relay rank 0's JSON line."""
     import socket
     import subprocess
     backend = os.environ.get("HTF_BENCH_BACKEND", "nccl")
-    ndev = torch.cuda.device_count()  # counting devices does not initialise the GPU
+    ndev = count_gpus_sysfs()  # the launcher parent stays GPU-free for certain: no HIP call, not even a device count
     if backend == "nccl" and ndev < args.gpus:
         print("bench.py --gpus %d: this node shows %d GPU(s).  RCCL wants one device per rank; "
               "HTF_BENCH_BACKEND=gloo rehearses the multi-rank path with the ranks sharing devices."
@@ -542,6 +706,10 @@ def main():
         if world > 1:
             raise SystemExit("the reference's own benchmark is a 256-particle, single-device workload")
         return run_ref_lj256(args, htf, standin, dev)
+    if args.workload in ("c1", "ex01"):
+        if world > 1:
+            raise SystemExit("BASELINE configs[0] is a single-device plumbing case")
+        return run_small(args, htf, standin, dev)
     headline = args.workload == "lj" and world == 1 and not args.f64 and not args.two_kernel
     out = run_md(args, E, args.workload, variants=not args.no_fused, cpu=not args.no_cpu_baseline)
     if headline and not args.no_mlp and args.cells == 32:
