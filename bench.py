@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="lj", choices=["lj", "wca", "mlp", "mlp-split", "mlp-bf16", "mlp-train", "eds", "ref-lj256", "c1", "ex01"])
+    ap.add_argument("--workload", default="lj", choices=["lj", "wca", "mlp", "mlp-fp32", "mlp-split", "mlp-bf16", "mlp-train", "eds", "ref-lj256", "c1", "ex01"])
     ap.add_argument("--train-period", type=int, default=100, help="mlp-train (C5b): force-matching step every this many MD steps")
     ap.add_argument("--cells", type=int, default=32, help="fcc cells per side (N = 4 cells^3 per rank)")
     ap.add_argument("--lattice", default="fcc", choices=["fcc", "sc"], help="fcc: N = 4 cells^3 (C3, C5); sc: N = cells^3 (C2 = sc 32^3 = 32768)")
@@ -96,7 +96,8 @@ def make_potential(htf, workload):
         # drives the MD; the pair-MLP is the model being trained, it does not push particles
         make_potential.layer = htf.PairMLP(32, 64, 64, 0.0, 3.0, activation="tanh", seed=3)
         return htf.Potential.lj()
-    prec = {"mlp-bf16": "bf16", "mlp-split": "split"}.get(workload, "fp32")
+    # "mlp": the default precision of PairMLP, fp32 operands as hi + lo in fp16 (DESIGN 3.3a''); the other three by name
+    prec = {"mlp-bf16": "bf16", "mlp-split": "split", "mlp-fp32": "fp32"}.get(workload, "split16")
     return htf.Potential.pair_mlp(mlp_params(seed=3), 0.0, 3.0, activation="tanh", precision=prec)
 
 
@@ -120,7 +121,7 @@ def cpu_baseline(sysm, nl, args):
     nlist = nl.nlist.cpu().numpy().view(np.uint32)
     N, NN = sysm.N, args.nn
     cores = int(lib.htfo_num_threads())
-    if args.workload in ("mlp", "mlp-split", "mlp-bf16"):
+    if args.workload in ("mlp", "mlp-fp32", "mlp-split", "mlp-bf16"):
         # 24.8 kflop per slot with libm tanhf / expf: a full pass takes seconds, so a contiguous row
         # sample is timed (rows are independent) and scaled to the box
         from hoomd_tf_amd.initializers import mlp_params
@@ -713,14 +714,14 @@ def main():
     headline = args.workload == "lj" and world == 1 and not args.f64 and not args.two_kernel
     out = run_md(args, E, args.workload, variants=not args.no_fused, cpu=not args.no_cpu_baseline)
     if headline and not args.no_mlp and args.cells == 32:
-        # north_star: "LJ AND MLP pair-potential boxes": the same C3 system driven by the pair-MLP, fp32 MFMA
-        # (its split-operand twin rides along as `split_variant`), a bounded number of steps (~3 ms each)
+        # north_star: "LJ AND MLP pair-potential boxes": the same C3 system driven by the pair-MLP in its default
+        # precision (split16; the fp32-MFMA and bf16-split evaluators ride along as variants), a bounded number of steps
         import copy
         a2 = copy.copy(args)
         a2.steps, a2.warmup, a2.equil, a2.windows = min(args.steps, 40), min(args.warmup, 5), min(args.equil, 100), 1
         sub = run_md(a2, E, "mlp", variants=not args.no_fused, cpu=not args.no_cpu_baseline)
         out["mlp"] = {k: sub[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "kernels",
-                                         "roofline", "split_variant", "cpu_baseline", "energy_per_particle") if k in sub}
+                                         "roofline", "fp32_variant", "split_variant", "cpu_baseline", "energy_per_particle") if k in sub}
     if rank == 0:
         print(json.dumps(out))
     if E.dist is not None:
@@ -970,7 +971,7 @@ def run_md(args, E, workload, variants=True, cpu=True):
                                    "GBps": build_b / build_avg_s / 1e9 if build_avg_s > 0 else None},
         }
         dom = "build_pair_vectors" if build_avg_s > eval_avg_s else "eval_forces"
-    mfma = args.workload in ("mlp", "mlp-bf16", "mlp-split")
+    mfma = args.workload in ("mlp", "mlp-fp32", "mlp-bf16", "mlp-split")
     if train is not None and train_events:
         state["train_n"] = len(train_events)
         state["train_s"] = sum(a.elapsed_time(b) for a, b in train_events) * 1e-3
@@ -989,7 +990,8 @@ def run_md(args, E, workload, variants=True, cpu=True):
         flops = per_slot * 32.0 * tiles
         # split: every algorithmic multiply-add is six bf16 MFMA multiply-adds, so the algorithmic rate is
         # priced against a sixth of the dense bf16 peak
-        peak = {"mlp-bf16": 2500.0, "mlp-split": 2500.0 / 6.0}.get(args.workload, 157.3)
+        # split16 (the default): three fp16 MFMA multiply-adds per algorithmic one -> a third of the dense fp16 / bf16 peak
+        peak = {"mlp-bf16": 2500.0, "mlp-split": 2500.0 / 6.0, "mlp": 2500.0 / 3.0}.get(args.workload, 157.3)
         ach = flops / eval_avg_s / 1e12
         roof = {"bound": "mfma", "kernel": "eval_forces(pair_mlp)", "achieved": ach, "peak": peak,
                 "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
@@ -997,6 +999,9 @@ def run_md(args, E, workload, variants=True, cpu=True):
                 "dense_TFLOPs": per_slot * N * NN / eval_avg_s / 1e12}
         if args.workload == "mlp-split":
             roof["peak_note"] = "dense bf16 MFMA peak / 6 partial products per fp32-level multiply (fp32 MFMA peak: 157.3)"
+        if args.workload == "mlp":
+            roof["peak_note"] = ("dense fp16 MFMA peak (2.5 PFLOP/s) / 3 partial products per fp32-level multiply; against the fp32 "
+                                 "MFMA peak (157.3 TFLOP/s), which the fp32-operand evaluator is priced on, frac would be %.2f" % (ach / 157.3))
     else:
         ach = kern[dom]["GBps"]
         roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -1052,7 +1057,8 @@ def run_md(args, E, workload, variants=True, cpu=True):
         "windows_batch_us": [(b + e) / n * 1e3 if n else None for b, e, n in window_prof],
         "value_is": "median of %d timed windows of %d steps each" % (n_windows, args.steps) if n_windows > 1 else "one timed window",
         "dtype": {"mlp-bf16": "bf16 operands, f32 accumulation",
-                  "mlp-split": "f32 (each operand split exactly into 3 bf16 parts, 6 partial products, f32 accumulation)"
+                  "mlp-split": "f32 (each operand split exactly into 3 bf16 parts, 6 partial products, f32 accumulation)",
+                  "mlp": "f32 (each operand as hi + lo in fp16, 2^-22; 3 partial products on the fp16 MFMA, f32 accumulation)"
                   }.get(args.workload, "f32" if not args.f64 else "f32 arithmetic on an f64 wire (HOOMD in double precision)"),
         "data": "synthetic",
         "config": {"workload": ("%s: " + ("sc %d^3" if args.lattice == "sc" else "fcc %d^3x4")
@@ -1135,25 +1141,26 @@ def run_md(args, E, workload, variants=True, cpu=True):
             "value": args.steps / el, "unit": "steps/s", "ms_per_step": el / args.steps * 1e3,
             "kernel_avg_us": f_s * 1e6, "algorithmic_bytes": fb, "GBps": fb / f_s / 1e9 if f_s > 0 else None,
             "energy_per_particle": float(sysm.force[:, 3].double().sum().item()) / sysm.N}
-    # (b') pair-MLP: the same network and weights evaluated on the bf16 matrix pipeline with every fp32 operand
-    # split exactly into three bf16 parts (DESIGN 3.3a'): same accuracy class as the fp32-MFMA headline above
-    # (tests/test_gpu_parity.py::test_pair_mlp_split_operands), reported beside it, never as `value`
+    # (b') pair-MLP: the same network and weights through the other two fp32-level evaluators -- fp32 operands on the fp32
+    # MFMA (v_mfma_f32_32x32x2_f32) and the exact three-part bf16 split (3.3a') -- on the same pair vectors;
+    # all three are held to the same tolerances against the fp64 oracle (test_pair_mlp_split_operands, test_pair_mlp_fp32_mfma)
     if not args.no_fused and args.workload == "mlp":
         from hoomd_tf_amd.initializers import mlp_params
-        pot_s = htf.Potential.pair_mlp(mlp_params(seed=3), 0.0, 3.0, activation="tanh", precision="split")
-        # same pair vectors, both precisions: the largest force difference relative to the largest force
         pv_now = ctx.nlist_buffer(sysm.N, dev)
         fa = htf.ops.eval_forces(pot, pv_now)
-        fs = htf.ops.eval_forces(pot_s, pv_now)
-        rel = float((fa - fs).abs().max() / fa.abs().max())
-        el, _, e_s = run_variant(0, pot_s)
-        out["split_variant"] = {
-            "note": "precision='split': fp32 operands split exactly into 3 bf16 parts, 6 partial products per multiply on "
-                    "v_mfma_f32_32x32x16_bf16, fp32 accumulation; forces agree with the fp32-MFMA evaluator on the same "
-                    "pair vectors to max|dF|/max|F| = %.1e" % rel,
-            "value": args.steps / el, "unit": "steps/s", "ms_per_step": el / args.steps * 1e3,
-            "eval_forces_avg_us": e_s * 1e6, "executed_TFLOPs": flops / e_s / 1e12 if e_s > 0 else None,
-            "max_rel_force_difference_vs_fp32_mfma": rel}
+        for key, prec, what in (("fp32_variant", "fp32", "fp32 operands on v_mfma_f32_32x32x2_f32 (exact fp32 products)"),
+                                ("split_variant", "split", "fp32 operands split exactly into 3 bf16 parts, 6 partial products per "
+                                                           "multiply on v_mfma_f32_32x32x16_bf16")):
+            pot_v = htf.Potential.pair_mlp(mlp_params(seed=3), 0.0, 3.0, activation="tanh", precision=prec)
+            fv = htf.ops.eval_forces(pot_v, pv_now)
+            rel = float((fa - fv).abs().max() / fa.abs().max())
+            el, _, e_s = run_variant(0, pot_v)
+            out[key] = {
+                "note": "precision=%r: %s, fp32 accumulation; forces agree with the default (split16) evaluator on the same "
+                        "pair vectors to max|dF|/max|F| = %.1e" % (prec, what, rel),
+                "value": args.steps / el, "unit": "steps/s", "ms_per_step": el / args.steps * 1e3,
+                "eval_forces_avg_us": e_s * 1e6, "executed_TFLOPs": flops / e_s / 1e12 if e_s > 0 else None,
+                "max_rel_force_difference_vs_default": rel}
     # (c) the same MD through the plugin surface a user touches: an htf.SimModel written op by op as in the
     # reference's LJModel (build_examples.py:67-77), htf.tfcompute(model).attach(nlist, r_cut), and the
     # stand-in's System::run loop.  tfcompute traces the model on its first step and replays it as the

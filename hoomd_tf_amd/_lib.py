@@ -25,7 +25,7 @@ POT_NONE, POT_LJ, POT_WCA, POT_RINV_POLY, POT_SIMPLE, POT_PAIR_MLP, POT_GAUSS, P
 OPT_SGD, OPT_ADAM, OPT_NADAM = range(3)
 OPT_STATE_FLOATS = 24
 ACT_LINEAR, ACT_TANH = 0, 1
-MLP_FP32, MLP_BF16, MLP_SPLIT = 0, 1, 2
+MLP_FP32, MLP_BF16, MLP_SPLIT, MLP_SPLIT16 = 0, 1, 2, 3
 MAX_POLY_TERMS = 8
 
 

@@ -611,7 +611,8 @@ int mlp_train_grad(const MlpDevice *m, const void *nlist, int in_dtype, unsigned
         return check_launch("mlp_reduce_partials_kernel");
     }
     const float *tab_c = m->images + (m->precision == HTF_MLP_SPLIT ? Img<2>::TabC
-                                      : m->precision == HTF_MLP_BF16 ? Img<1>::TabC : Img<0>::TabC);
+                                      : m->precision == HTF_MLP_BF16 ? Img<1>::TabC
+                                      : m->precision == HTF_MLP_SPLIT16 ? Img<3>::TabC : Img<0>::TabC);
     const float ginv = 1.0f / m->gap;
     const dim3 grid(nw / 4), block(256);
 #define HTF_LAUNCH_MLPG(T, IT, V4)                                                                                     \

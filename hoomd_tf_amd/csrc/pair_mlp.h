@@ -15,7 +15,7 @@ constexpr int kH = 64;  // hidden width (padded with zero weights below 64)
 // [part 3: hi, mid, lo][s 2][lane 64][8 bf16] = 1536 floats.  P = htf_mlp_precision.
 template <int P>
 struct Img {
-    static constexpr int BS = P == 0 ? 1024 : (P == 1 ? 512 : 1536);
+    static constexpr int BS = P == 0 ? 1024 : (P == 1 ? 512 : (P == 2 ? 1536 : 1024)); // split16: [part 2: hi, lo][s 2][lane 64][8 fp16]
     static constexpr int L1 = 0;            // [nb 2]
     static constexpr int L2 = 2 * BS;       // [nb 2][kb 2]
     static constexpr int B2 = 6 * BS;       // [fb 2][kb 2]
@@ -25,7 +25,7 @@ struct Img {
     static constexpr int TabW3 = TabB2 + 64;
     static constexpr int TabC = TabW3 + 64; // [h 2][v 16] RBF centres
     static constexpr int TabB3 = TabC + 32; // output bias (+3 pad floats)
-    static constexpr int Floats = TabB3 + 4; // fp32: 12516 floats (50 KB); bf16: 6372 (25 KB); split: 18660 (75 KB)
+    static constexpr int Floats = TabB3 + 4; // fp32: 12516 floats (50 KB); bf16: 6372 (25 KB); split: 18660 (75 KB); split16: 12516 (50 KB)
 };
 
 // Every weight-carrying element of an image is theta[map[e]] (or 0 when map[e] < 0):

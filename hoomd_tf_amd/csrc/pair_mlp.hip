@@ -33,6 +33,8 @@
 namespace htf {
 
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 
 // VALU work beside the matrix pipe (tools/mfma_valu_probe2.hip, one wave per SIMD, 8 VALU
@@ -114,6 +116,7 @@ template <int P> struct BOp;
 template <> struct BOp<HTF_MLP_FP32> { f32x16 v; };
 template <> struct BOp<HTF_MLP_BF16> { bf16x8 b[2]; };
 template <> struct BOp<HTF_MLP_SPLIT> { bf16x8 hi[2], mid[2], lo[2]; };
+template <> struct BOp<HTF_MLP_SPLIT16> { f16x8 hi[2], lo[2]; };
 
 // bf16 operands: accumulator registers 8s..8s+7, converted pairwise (v_cvt_pk_bf16_f32), ARE the B
 // fragment of k-step s of v_mfma_f32_32x32x16_bf16: element j of lane half h is feature
@@ -133,6 +136,27 @@ __device__ __forceinline__ BOp<P> prep(const f32x16 &x) {
         for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int j = 0; j < 8; ++j) o.b[s][j] = (__bf16)x[8 * s + j];
+    } else if constexpr (P == HTF_MLP_SPLIT16) {
+        // x = hi + lo + (<= 2^-22 |x|): hi = fp16(x) and lo = fp16(x - hi), both rounded to nearest, a PAIR of elements per
+        // v_cvt_pk_f16_f32; the residual x - hi is ONE v_fma_mix_f32 that reads hi straight from its half of the packed
+        // register (hi * -1 + x, exact: the difference of an fp32 and its 11-bit rounding fits fp32).  Four instructions per
+        // pair of elements where the three-part bf16 split needs eleven.
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            u32x4 ph, pl;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a = x[8 * s + 2 * j], b = x[8 * s + 2 * j + 1];
+                const unsigned hp = __builtin_bit_cast(unsigned, f16x2{(_Float16)a, (_Float16)b});
+                float ra, rb;
+                asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(hp), "v"(a));
+                asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(hp), "v"(b));
+                ph[j] = hp;
+                pl[j] = __builtin_bit_cast(unsigned, f16x2{(_Float16)ra, (_Float16)rb});
+            }
+            o.hi[s] = __builtin_bit_cast(f16x8, ph);
+            o.lo[s] = __builtin_bit_cast(f16x8, pl);
+        }
     } else {
         constexpr unsigned kTop = 0xFFFF0000u, kSel = 0x07060302u; // {hi16(second), hi16(first)}
 #pragma unroll
@@ -158,6 +182,7 @@ __device__ __forceinline__ BOp<P> prep(const f32x16 &x) {
 }
 
 #define HTF_MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+#define HTF_MFMA_F16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 
 // acc += A(image) * B(prev), over one 32-feature block of the previous layer.
 // fp32: 16 k-steps, the image supplies 4 steps per ds_read_b128.  bf16: two k-steps of 16.
@@ -179,6 +204,15 @@ __device__ __forceinline__ void mfma_blk(f32x16 &acc, const float *img, unsigned
         const bf16x8 *p = reinterpret_cast<const bf16x8 *>(img) + lane;
 #pragma unroll
         for (int s = 0; s < 2; ++s) acc = HTF_MFMA_BF16(p[s * 64], prev.b[s], acc);
+    } else if constexpr (P == HTF_MLP_SPLIT16) {
+        const f16x8 *p = reinterpret_cast<const f16x8 *>(img) + lane; // [part 2: hi, lo][s 2][lane 64]
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const f16x8 ah = p[s * 64], al = p[(2 + s) * 64];
+            acc = HTF_MFMA_F16(al, prev.hi[s], acc); // smallest first; lo * lo (<= 2^-22) is dropped
+            acc = HTF_MFMA_F16(ah, prev.lo[s], acc);
+            acc = HTF_MFMA_F16(ah, prev.hi[s], acc);
+        }
     } else {
         const bf16x8 *p = reinterpret_cast<const bf16x8 *>(img) + lane; // [part 3][s 2][lane 64]
 #pragma unroll
@@ -201,7 +235,10 @@ __device__ __forceinline__ void mfma_blk(f32x16 &acc, const float *img, unsigned
 // 1.92 ms.
 constexpr int pipe_per(int valu, int mfma) { return (valu + mfma - 1) / mfma > 0 ? (valu + mfma - 1) / mfma : 1; }
 
-template <int P> struct MlpLaunch { static constexpr int kPerCU = 2; };
+#ifndef HTF_MLP16_PER_CU
+#define HTF_MLP16_PER_CU 2
+#endif
+template <int P> struct MlpLaunch { static constexpr int kPerCU = P == HTF_MLP_SPLIT16 ? HTF_MLP16_PER_CU : 2; };
 
 template <bool TANH, typename IT, int P, bool VIRIAL>
 __global__ __launch_bounds__(256, MlpLaunch<P>::kPerCU) void pair_mlp_kernel(const typename Vec4<IT>::type *__restrict__ nlist,
@@ -274,8 +311,10 @@ __global__ __launch_bounds__(256, MlpLaunch<P>::kPerCU) void pair_mlp_kernel(con
         }                                                                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
     }
-            constexpr int kM = P == HTF_MLP_FP32 ? 16 : (P == HTF_MLP_BF16 ? 2 : 12); // MFMAs per block
-            constexpr int kAct = TANH ? 56 : 0, kPrep = P == HTF_MLP_SPLIT ? 76 : (P == HTF_MLP_BF16 ? 8 : 0);
+            constexpr int kM = P == HTF_MLP_FP32 ? 16 : (P == HTF_MLP_BF16 ? 2 : (P == HTF_MLP_SPLIT ? 12 : 6)); // MFMAs per block
+            constexpr int kAct = TANH ? 56 : 0;
+            // (split16: 16 v_cvt_pk; its 16 v_fma_mix are inline asm, which the scheduler places by their dependences)
+            constexpr int kPrep = P == HTF_MLP_SPLIT ? 76 : (P == HTF_MLP_BF16 ? 8 : (P == HTF_MLP_SPLIT16 ? 16 : 0));
             constexpr int kBwd = TANH ? 16 : 0, kDot = 8;
 
             f32x16 a1[2], a2[2], dphi;
@@ -512,6 +551,12 @@ __global__ void mlp_refresh_kernel(float *__restrict__ images, const int *__rest
         if constexpr (P == HTF_MLP_BF16) { // round to nearest even (finite weights)
             const unsigned u = __float_as_uint(v);
             reinterpret_cast<unsigned short *>(images)[e] = (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+        } else if constexpr (P == HTF_MLP_SPLIT16) { // hi = fp16(v), lo = fp16(v - hi), round to nearest: see prep<>
+            const _Float16 hh = (_Float16)v;
+            const _Float16 ll = (_Float16)(v - (float)hh);
+            unsigned short *blk = reinterpret_cast<unsigned short *>(images) + (size_t)(e >> 10) * 2048 + (e & 1023);
+            blk[0] = __builtin_bit_cast(unsigned short, hh);
+            blk[1024] = __builtin_bit_cast(unsigned short, ll);
         } else if constexpr (P == HTF_MLP_SPLIT) { // exact three-way split, see prep<>
             const unsigned u = __float_as_uint(v);
             const float r1 = v - __uint_as_float(u & 0xFFFF0000u);
@@ -539,6 +584,8 @@ int mlp_refresh(const MlpDevice *m, hipStream_t stream) {
         hipLaunchKernelGGL(mlp_refresh_kernel<HTF_MLP_BF16>, dim3(grid), dim3(256), 0, stream, m->images, m->map, m->theta, fwd_scale);
     else if (m->precision == HTF_MLP_SPLIT)
         hipLaunchKernelGGL(mlp_refresh_kernel<HTF_MLP_SPLIT>, dim3(grid), dim3(256), 0, stream, m->images, m->map, m->theta, fwd_scale);
+    else if (m->precision == HTF_MLP_SPLIT16)
+        hipLaunchKernelGGL(mlp_refresh_kernel<HTF_MLP_SPLIT16>, dim3(grid), dim3(256), 0, stream, m->images, m->map, m->theta, fwd_scale);
     else
         hipLaunchKernelGGL(mlp_refresh_kernel<HTF_MLP_FP32>, dim3(grid), dim3(256), 0, stream, m->images, m->map, m->theta, 1.0f);
     if (m->train_images != m->images) // bf16 / split evaluator images: the training sweep reads its own fp32 set
@@ -552,8 +599,20 @@ int mlp_create(const htf_potential_desc *d, MlpDevice **out) {
     HTF_REQUIRE(d->H1 >= 1 && d->H1 <= kH && d->H2 >= 1 && d->H2 <= kH, "pair-MLP: hidden widths (%d, %d) must be <= %d", d->H1, d->H2, kH);
     HTF_REQUIRE(d->rbf_high > d->rbf_low, "pair-MLP: rbf_high must exceed rbf_low");
     HTF_REQUIRE(d->activation == HTF_ACT_LINEAR || d->activation == HTF_ACT_TANH, "pair-MLP: unknown activation %d", d->activation);
-    HTF_REQUIRE(d->mlp_precision == HTF_MLP_FP32 || d->mlp_precision == HTF_MLP_BF16 || d->mlp_precision == HTF_MLP_SPLIT,
-                "pair-MLP: unknown precision %d", d->mlp_precision);
+    HTF_REQUIRE(d->mlp_precision == HTF_MLP_FP32 || d->mlp_precision == HTF_MLP_BF16 || d->mlp_precision == HTF_MLP_SPLIT ||
+                    d->mlp_precision == HTF_MLP_SPLIT16, "pair-MLP: unknown precision %d", d->mlp_precision);
+    if (d->mlp_precision == HTF_MLP_SPLIT16 && !d->d_theta) {
+        // fp16 operands: host-supplied weights are checked against the format's range here (times the 2 log2(e) folded into
+        // the forward images); a device parameter vector (training) is the caller's to keep there
+        float wmax = 0.f;
+        for (int i = 0; i < d->K * d->H1; ++i) wmax = fmaxf(wmax, fabsf(d->W1[i]));
+        for (int i = 0; i < d->H1 * d->H2; ++i) wmax = fmaxf(wmax, fabsf(d->W2[i]));
+        for (int i = 0; i < d->H1; ++i) wmax = fmaxf(wmax, fabsf(d->b1[i]));
+        for (int i = 0; i < d->H2; ++i) wmax = fmaxf(wmax, fabsf(d->b2[i]));
+        HTF_REQUIRE(wmax * 2.8853900817779268f < 6.0e4f, "pair-MLP: weights up to %g leave fp16's range; use precision 'split' (bf16 parts) or 'fp32'", wmax);
+        HTF_REQUIRE(d->activation == HTF_ACT_TANH || wmax * (float)(d->K > d->H1 ? d->K : d->H1) < 6.0e4f,
+                    "pair-MLP: a linear network with weights up to %g can leave fp16's range; use precision 'split' or 'fp32'", wmax);
+    }
     MlpDevice *m = new (std::nothrow) MlpDevice();
     if (!m) {
         set_error("pair-MLP: out of host memory");
@@ -561,6 +620,7 @@ int mlp_create(const htf_potential_desc *d, MlpDevice **out) {
     }
     const bool bf16 = d->mlp_precision != HTF_MLP_FP32; // bf16-typed images (one part, or three for the split)
     const bool split = d->mlp_precision == HTF_MLP_SPLIT;
+    const bool split16 = d->mlp_precision == HTF_MLP_SPLIT16;
     m->K = d->K; m->H1 = d->H1; m->H2 = d->H2;
     m->act = d->activation;
     m->precision = d->mlp_precision;
@@ -571,8 +631,8 @@ int mlp_create(const htf_potential_desc *d, MlpDevice **out) {
         m->centers[k] = (float)(k == m->K - 1 ? d->rbf_high : d->rbf_low + k * step);
     }
     m->gap = m->centers[1] - m->centers[0];
-    const int n_img = split ? Img<2>::Floats : (bf16 ? Img<1>::Floats : Img<0>::Floats);
-    const int tabc = split ? Img<2>::TabC : (bf16 ? Img<1>::TabC : Img<0>::TabC);
+    const int n_img = split ? Img<2>::Floats : (split16 ? Img<3>::Floats : (bf16 ? Img<1>::Floats : Img<0>::Floats));
+    const int tabc = split ? Img<2>::TabC : (split16 ? Img<3>::TabC : (bf16 ? Img<1>::TabC : Img<0>::TabC));
     std::vector<float> img(n_img, 0.f);
     for (int hh = 0; hh < 2; ++hh)
         for (int v = 0; v < 16; ++v) img[tabc + hh * 16 + v] = m->centers[f0(v) + 4 * hh];
@@ -671,6 +731,9 @@ int mlp_eval(const MlpDevice *m, const void *nlist, int in_dtype, unsigned B, un
     if (m->precision == HTF_MLP_BF16)
         return m->act == HTF_ACT_TANH ? launch_mlp<true, HTF_MLP_BF16>(m, nlist, in_dtype, B, NN, force, out_f64, virial9, stream)
                                       : launch_mlp<false, HTF_MLP_BF16>(m, nlist, in_dtype, B, NN, force, out_f64, virial9, stream);
+    if (m->precision == HTF_MLP_SPLIT16)
+        return m->act == HTF_ACT_TANH ? launch_mlp<true, HTF_MLP_SPLIT16>(m, nlist, in_dtype, B, NN, force, out_f64, virial9, stream)
+                                      : launch_mlp<false, HTF_MLP_SPLIT16>(m, nlist, in_dtype, B, NN, force, out_f64, virial9, stream);
     if (m->precision == HTF_MLP_SPLIT)
         return m->act == HTF_ACT_TANH ? launch_mlp<true, HTF_MLP_SPLIT>(m, nlist, in_dtype, B, NN, force, out_f64, virial9, stream)
                                       : launch_mlp<false, HTF_MLP_SPLIT>(m, nlist, in_dtype, B, NN, force, out_f64, virial9, stream);

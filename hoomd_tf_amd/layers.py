@@ -191,14 +191,20 @@ class PairMLP:
     """safe_norm -> RBFExpansion(low, high, K) -> Dense(H1) -> Dense(H2) -> Dense(1), masked
     with the nlist_rinv criterion and halved per pair (SURVEY 8(a) closed forms).  Keras
     Dense defaults: glorot-uniform kernels, zero biases, ``activation=None``; pass
-    ``activation='tanh'`` for the C3 benchmark model."""
+    ``activation='tanh'`` for the C3 benchmark model.
+    ``precision``: how the dense layers meet the matrix cores.  ``"split16"`` (default): every fp32 operand as hi + lo in
+    fp16 (2^-22), three partial products on the fp16 MFMA -- the fp32 evaluator's accuracy (same tolerances against the
+    fp64 oracle, tests/test_gpu_parity.py::test_pair_mlp_split_operands) at 2.5x its speed; weights and activations must
+    stay inside fp16's range (|x| < 6e4: always true of a tanh network with sane weights).  ``"fp32"``: exact fp32 products
+    on the fp32 MFMA.  ``"split"``: three bf16 parts, six partial products (no range limit).  ``"bf16"``: plain bf16
+    operands, reduced precision."""
 
     name = 'pair-mlp'
     nonneg_mask = 0
     l1_reg = (0.0,)
     _KEYS = ("W1", "b1", "W2", "b2", "W3", "b3")
 
-    def __init__(self, K=32, H1=64, H2=64, low=0.0, high=3.0, activation=None, seed=3, precision="fp32"):
+    def __init__(self, K=32, H1=64, H2=64, low=0.0, high=3.0, activation=None, seed=3, precision="split16"):
         self.low, self.high = float(low), float(high)
         self.activation = activation or "linear"
         self.precision = precision

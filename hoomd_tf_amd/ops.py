@@ -76,9 +76,10 @@ class Potential:
             d.W1, d.b1, d.W2, d.b2, d.W3, d.b3 = (w.ctypes.data for w in ws)
             d.rbf_low, d.rbf_high = float(rbf[0]), float(rbf[1])
             d.activation = {"linear": _lib.ACT_LINEAR, None: _lib.ACT_LINEAR, "tanh": _lib.ACT_TANH}[activation]
-            if mlp_precision not in ("fp32", "bf16", "split"):
-                raise ValueError("pair-MLP precision must be 'fp32', 'bf16' or 'split', not %r" % (mlp_precision,))
-            d.mlp_precision = {"fp32": _lib.MLP_FP32, "bf16": _lib.MLP_BF16, "split": _lib.MLP_SPLIT}[mlp_precision]
+            if mlp_precision not in ("fp32", "bf16", "split", "split16"):
+                raise ValueError("pair-MLP precision must be 'fp32', 'bf16', 'split' or 'split16', not %r" % (mlp_precision,))
+            d.mlp_precision = {"fp32": _lib.MLP_FP32, "bf16": _lib.MLP_BF16, "split": _lib.MLP_SPLIT,
+                               "split16": _lib.MLP_SPLIT16}[mlp_precision]
         self.kind = kind
         self._h = C.c_void_p()
         check(lib.htf_potential_create(C.byref(d), C.byref(self._h)))

@@ -83,9 +83,14 @@ enum htf_activation { HTF_ACT_LINEAR = 0, HTF_ACT_TANH = 1 };
 enum htf_mlp_precision {
     HTF_MLP_FP32 = 0,  /* v_mfma_f32_32x32x2_f32 on fp32 operands */
     HTF_MLP_BF16 = 1,  /* bf16 operands (weights and activations rounded), fp32 accumulation: reduced precision */
-    HTF_MLP_SPLIT = 2  /* fp32-level results on the bf16 matrix pipeline: every fp32 operand is split EXACTLY
+    HTF_MLP_SPLIT = 2, /* fp32-level results on the bf16 matrix pipeline: every fp32 operand is split EXACTLY
                         * into three bf16 values (8 + 8 + 8 significand bits) and a product is the six partial
                         * products down to 2^-16 of it; what is dropped (2^-24) is the size of fp32's own rounding */
+    HTF_MLP_SPLIT16 = 3 /* fp32-level results on the fp16 matrix pipeline: every fp32 operand as hi + lo, both fp16 and
+                        * rounded to nearest (11 + 11 significand bits: 2^-22 relative, never worse than 2^-25 absolute),
+                        * a product as hi*hi + hi*lo + lo*hi -- three MFMAs where SPLIT issues six, and two VALU
+                        * instructions per split element where SPLIT needs five.  Operands must stay inside fp16's
+                        * range (|x| < 65504: tanh activations always do; weights are checked at creation) */
 };
 
 #define HTF_MAX_POLY_TERMS 8

@@ -409,9 +409,11 @@ def test_pair_mlp_fp32_mfma(htf, cuda, act, NN):
 
 @pytest.mark.parametrize("act", ["tanh", "linear"])
 @pytest.mark.parametrize("NN", [128, 40])
-def test_pair_mlp_split_operands(htf, cuda, act, NN):
+@pytest.mark.parametrize("precision", ["split", "split16"])
+def test_pair_mlp_split_operands(htf, cuda, act, NN, precision):
     """HTF_MLP_SPLIT: fp32 operands split exactly into three bf16 parts, six partial products
-    per multiply on the bf16 matrix pipeline.  Held to the SAME tolerances against the fp64 oracle
+    per multiply on the bf16 matrix pipeline; HTF_MLP_SPLIT16: hi + lo in fp16 (2^-22), three partial
+    products on the fp16 pipeline.  Held to the SAME tolerances against the fp64 oracle
     as the fp32-MFMA path (same inputs, same weights), and its error must be of the fp32 path's
     size, not bf16's."""
     from hoomd_tf_amd.initializers import mlp_params
@@ -421,10 +423,10 @@ def test_pair_mlp_split_operands(htf, cuda, act, NN):
     nl[1, 5, :3] = [1.0, -0.5, 0.25]
     ref, g = O.pair_mlp_model(nl.astype(np.float64), params, 0.0, 3.0, act, return_grad=True)
     x = torch.from_numpy(nl).to(cuda)
-    pot = htf.Potential.pair_mlp(params, 0.0, 3.0, activation=act, precision="split")
+    pot = htf.Potential.pair_mlp(params, 0.0, 3.0, activation=act, precision=precision)
     fs = htf.ops.eval_forces(pot, x)
     cond = np.abs(2 * g).sum(axis=(1, 2))
-    assert_forces_close("mlp_split_%s_NN%d" % (act, NN), fs.cpu().numpy(), ref, cond, atol=2e-5, rtol=5e-5, ctol=5e-6)
+    assert_forces_close("mlp_%s_%s_NN%d" % (precision, act, NN), fs.cpu().numpy(), ref, cond, atol=2e-5, rtol=5e-5, ctol=5e-6)
     assert np.all(fs.cpu().numpy()[0] == 0)
     f32 = htf.ops.eval_forces(htf.Potential.pair_mlp(params, 0.0, 3.0, activation=act), x)
     f16 = htf.ops.eval_forces(htf.Potential.pair_mlp(params, 0.0, 3.0, activation=act, precision="bf16"), x)
@@ -432,12 +434,12 @@ def test_pair_mlp_split_operands(htf, cuda, act, NN):
     es = (np.abs(fs.cpu().numpy() - ref) / c).max()
     e32 = (np.abs(f32.cpu().numpy() - ref) / c).max()
     e16 = (np.abs(f16.cpu().numpy() - ref) / c).max()
-    _record("mlp_split_vs_fp32_%s_NN%d" % (act, NN), split=es, fp32=e32, bf16=e16)
+    _record("mlp_%s_vs_fp32_%s_NN%d" % (precision, act, NN), split=es, fp32=e32, bf16=e16)
     assert es < 4 * e32 + 1e-7 and es < 1e-3 * e16, (es, e32, e16)
     assert torch.equal(fs, htf.ops.eval_forces(pot, x))  # deterministic
     # fp64 wire: cast on load, as the other precisions
     f64 = htf.ops.eval_forces(pot, torch.from_numpy(nl.astype(np.float64)).to(cuda))
-    assert_forces_close("mlp64_split_%s_NN%d" % (act, NN), f64.cpu().numpy(), ref, cond, atol=2e-5, rtol=5e-5, ctol=5e-6)
+    assert_forces_close("mlp64_%s_%s_NN%d" % (precision, act, NN), f64.cpu().numpy(), ref, cond, atol=2e-5, rtol=5e-5, ctol=5e-6)
 
 
 @pytest.mark.parametrize("act", ["tanh", "linear"])

@@ -274,7 +274,8 @@ def test_pair_mlp_refresh_tracks_device_weights(htf, cuda):
     layer.set_weights(ws2)
     assert layer.potential() is pot
     f1 = htf.ops.eval_forces(pot, x).cpu().numpy()
-    fresh = htf.Potential.pair_mlp(dict(zip(("W1", "b1", "W2", "b2", "W3", "b3"), ws2)), 0.0, 3.0, activation="tanh")
+    fresh = htf.Potential.pair_mlp(dict(zip(("W1", "b1", "W2", "b2", "W3", "b3"), ws2)), 0.0, 3.0, activation="tanh",
+                                   precision=layer.precision)
     f2 = htf.ops.eval_forces(fresh, x).cpu().numpy()
     assert np.abs(f1 - f0).max() > 1e-3
     np.testing.assert_array_equal(f1, f2)
