@@ -166,6 +166,8 @@ extern "C" int htf_potential_create(const htf_potential_desc *d, htf_potential *
         p->pp.gauss_r0 = (float)d->gauss_r0;
         p->pp.gauss_ginv = 1.0f / (float)d->gauss_gap;
         p->pp.gauss_coef = (float)d->gauss_coef;
+        p->pp.gauss_k_exp = -1.4426950408889634f * p->pp.gauss_ginv;
+        p->pp.gauss_k_force = -4.0f * p->pp.gauss_coef * p->pp.gauss_ginv;
         break;
     case HTF_POT_PAIR_MLP:
         rc = mlp_create(d, &p->mlp);

@@ -755,20 +755,32 @@ __global__ __launch_bounds__(256) void fused_forces2_kernel(
     float4 *__restrict__ dest, unsigned *__restrict__ counts_io) {
     using PV = typename Vec4<PT>::type;
     const PotParams pa = resolve_theta<KA>(pa_in);
-    __shared__ float s_part[4];
-    __shared__ unsigned s_hist[kRdfMaxBins2];
-    __shared__ float4 s_rows[COMPACT ? 4 * 128 : 1];
-    float4 *mine = s_rows + (COMPACT ? (threadIdx.x >> 6) * 128 : 0);
-    __shared__ float s_edge[kRdfMaxBins2 + 1];
+    // ONE shared object, the edge table first: its LDS address is then the constant 0 and a bin's two thresholds are read at
+    // idx * 4 with the instruction's own offsets (separate __shared__ arrays cost an address add per slot)
+    struct Lds {
+        float edge[kRdfMaxBins2 + 4];
+        unsigned hist[kRdfMaxBins2];
+        float4 rows[COMPACT ? 4 * 128 : 1];
+        float part[4];
+    };
+    __shared__ __attribute__((aligned(16))) Lds lds;
+    float (&s_edge)[kRdfMaxBins2 + 4] = lds.edge;
+    unsigned (&s_hist)[kRdfMaxBins2] = lds.hist;
+    float (&s_part)[4] = lds.part;
+    float4 *mine = lds.rows + (COMPACT ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * 128 : 0);
     const bool do_rdf = rdf.hist != nullptr;
     if (do_rdf) {
         for (unsigned i = threadIdx.x; i < rdf.nb; i += blockDim.x) s_hist[i] = 0;
         for (unsigned i = threadIdx.x; i <= rdf.nb; i += blockDim.x) s_edge[i] = rdf.edges[i];
         __syncthreads();
     }
-    const unsigned lane = threadIdx.x & 63u, wb = threadIdx.x >> 6;
+    // (wb as a SCALAR: a row's count, list head and own position are then scalar loads and the live-entry masks of its trips
+    //  scalar arithmetic -- derived from threadIdx they were vector loads, and every trip built its mask with a dozen VALU
+    //  instructions and two v_readfirstlane on the unit this kernel saturates)
+    const unsigned lane = threadIdx.x & 63u, wb = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool simple_box = box.ortho && box.periodic[0] && box.periodic[1] && box.periodic[2];
     const float rdf_scale = do_rdf ? (float)rdf.nb / (rdf.r1 - rdf.r0) : 0.f;
+    const float rdf_bias = -rdf.r0 * rdf_scale; // (the guess may be off by one either way: the edge table settles it)
     const bool coarse_bins = do_rdf && (rdf.r1 - rdf.r0) >= 1e-4f * (float)rdf.nb;
     // bin of a zero pair vector (the padded slots of the tensor are part of compute_rdf's input)
     int pad_bin = 0;
@@ -797,10 +809,19 @@ __global__ __launch_bounds__(256) void fused_forces2_kernel(
                 asm volatile("" ::: "memory");
                 rg = __builtin_amdgcn_sqrtf(sq);
             }
-            const float qf = floorf((rg - rdf.r0) * rdf_scale);
-            int idx = (int)fminf(fmaxf(qf, 0.f), (float)(rdf.nb - 1));
-            idx += (sq >= s_edge[idx + 1] ? 1 : 0) - (sq < s_edge[idx] ? 1 : 0);
-            atomicAdd(&s_hist[idx], 1u); // live slots rarely land in the end bins (the padding, counted per row below, does)
+            // guess = clamp(floor((r' - r0) scale)): one fma (r0 scale folded), v_cvt_flr_i32_f32 (floor and convert in one
+            // instruction; out-of-range values saturate), one v_med3_i32; the two edge compares feed add-with-carry forms
+            int idx;
+            {
+                const float qf = fmaf(rg, rdf_scale, rdf_bias);
+                asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(idx) : "v"(qf));
+                asm("v_med3_i32 %0, %1, 0, %2" : "=v"(idx) : "v"(idx), "s"((int)rdf.nb - 1));
+            }
+            // (byte offsets from here on: the corrections are then two selects of +-4 and one three-operand add)
+            const unsigned off = (unsigned)idx << 2;
+            const float e0 = *(const float *)((const char *)s_edge + off), e1 = *(const float *)((const char *)s_edge + off + 4);
+            const unsigned off2 = off + (sq >= e1 ? 4u : 0u) + (sq < e0 ? (unsigned)-4 : 0u);
+            atomicAdd((unsigned *)((char *)s_hist + off2), 1u); // live slots rarely land in the end bins (the padding, counted per row below, does)
         }
     };
     auto one = [&](PT dx, PT dy, PT dz, const PV &pk, bool keep, unsigned q, unsigned lo, unsigned Q, float4 *row, float &ax,

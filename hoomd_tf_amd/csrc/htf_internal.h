@@ -10,6 +10,7 @@ struct PotParams {
     float wca_cut; // fp32(sigma) * fp32(2^(1/3))   layers.py:97
     float wca_cut_r2; // smallest fp32 t with sqrtf(t) >= wca_cut: (r2 < t) == (sqrtf(r2) < wca_cut), exactly
     float gauss_r0, gauss_ginv, gauss_coef; // HTF_POT_GAUSS: centre, 1/gap, coefficient
+    float gauss_k_exp, gauss_k_force;       // -log2(e) / gap and -4 coef / gap: the exponent and force chains as one multiply each
     float lj_w0, lj_w1;                     // HTF_POT_LJ_PARAM
     const float *theta;                     // device parameter vector of a trainable potential (nullable)
     int n_terms;

@@ -85,6 +85,7 @@ __device__ __forceinline__ RinvFwd rinv_fwd(float x, float y, float z) {
     f.s = f.cond ? sr : 0.0f;
     const bool near = f.cond && u >= 2e-4f;
     if (__builtin_amdgcn_ballot_w64(near) != 0ull) { // wave-uniform, rare
+        asm volatile("" ::: "memory"); // keeps this a BRANCH: if-converted, its three transcendentals and selects ran for every slot
         const float rp = fast_sqrt(t2);
         const float irp = fast_rcp(rp);
         const float s3 = fast_rcp(rp + kRinvDelta);
@@ -134,10 +135,17 @@ __device__ __forceinline__ void pair_eval_f(const RinvFwd &f, float x, float y, 
         // one RBFExpansion channel as a pair energy: r = safe_norm(x) (simmodel.py:581-594),
         // phi = exp(-(r - r0)^2 / gap) (layers.py:46-49), masked with the nlist_rinv criterion.
         // nlist_forces = 2 * c * dphi/dr * t / r,  dphi/dr = -2 (r - r0) / gap * phi
+        // (the sweeps that evaluate this are VALU-issue bound: exp(-d^2 / gap) as exp2 of ONE product with -log2(e) / gap, the
+        //  force factor 2 coef (-2 d / gap) phi / r' as three multiplies on the precomputed -4 coef / gap; a masked slot gets
+        //  phi = 0, which zeroes energy and force alike -- one select instead of two)
         const float d = f.rp - p.gauss_r0;
-        const float phi = f.cond ? __expf(-(d * d) * p.gauss_ginv) : 0.0f;
+        const float ex = __builtin_amdgcn_exp2f((d * d) * p.gauss_k_exp);
+        const float phi = f.cond ? ex : 0.0f;
         e = p.gauss_coef * phi;
-        const float c = f.cond ? 2.0f * p.gauss_coef * (-2.0f * d * p.gauss_ginv) * phi * f.irp : 0.0f;
+        // (v_mul_legacy_f32: 0 * inf = 0, so the one unphysical slot with r' = 0 exactly keeps a zero force without a select)
+        float phi_irp;
+        asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(phi_irp) : "v"(phi), "v"(f.irp));
+        const float c = (p.gauss_k_force * d) * phi_irp;
         fx = c * f.tx;
         fy = c * f.ty;
         fz = c * f.tz;
