@@ -774,7 +774,9 @@ def run_md(args, E, workload, variants=True, cpu=True):
         sysm.vel[:, :3] = vel0.to(sdt).to(dev)
     nl = standin.CellNlist(sysm, r_cut=args.rcut, r_buff=args.rbuff, check_period=args.check_period,
                            sort_particles=args.sort,
-                           device_decision=(world == 1 and not args.sort and not args.host_nlist_decision))
+                           # one rank: the rebuild is gated on the device; several ranks: the all-reduced distance check is
+                           # read one check late (standin.DeferredRebuildRule) -- no read-back in the step loop either way
+                           device_decision=(not args.sort and not args.host_nlist_decision))
     if world > 1:
         from hoomd_tf_amd.domain import SlabDomain
         # the native RCCL halo (csrc/halo.hip) has never run between two real devices: opt-in until it has
@@ -1071,7 +1073,9 @@ def run_md(args, E, workload, variants=True, cpu=True):
                                   % (args.equil, args.settle, args.warmup),
                    "global_particles": n_global, "particles_rank0": N, "parallelism": "dd%dx1x1" % world,
                    "nlist_rebuilds_per_window": rebuilds, "max_neighbors_within_rcut": max_kept,
-                   "nlist_decision": "device (gated rebuild kernels, no read-back in the step loop)" if nl.device_decision and world == 1 and not args.sort
+                   "nlist_decision": ("device: distance check all-reduced on the device, read one check late (DeferredRebuildRule), "
+                                      "dangerous builds: %d" % nl.dangerous_builds) if nl.device_decision and world > 1 and not args.sort
+                                     else "device (gated rebuild kernels, no read-back in the step loop)" if nl.device_decision and world == 1 and not args.sort
                                      else "host (distance check read back every %d steps%s)" % (args.check_period, ", all-reduced over ranks" if world > 1 else ""),
                    "halo": None if world == 1 else {"ghosts_rank0": sysm.n_ghost, "migrated_rank0": nl.domain.n_migrated,
                                                     "interior_rows_rank0": nl.domain.n_interior,

@@ -434,6 +434,96 @@ extern "C" int htfs_gather4_tagged(void *d_dest, const void *d_src, const int *d
     return gather4(d_dest, d_src, d_order, dtype, n, true, type_split, stream);
 }
 
+// ---------------------------------------------------------------------------- slab decomposition: migration plan
+// (the Communicator's part of a rebuild, hoomd_tf_amd/domain.py: SlabDomain.rebuild)
+// key = destination * 4 + ghost class, for every local particle:
+//   destination 0 stay | 1 the left neighbor | 2 the right neighbor | 3 further than an adjacent slab (an error upstream);
+//               with two slabs both faces lead to the one peer and everything that leaves travels as "right";
+//   class, IN THE SLAB THE PARTICLE ENDS UP IN: 0 interior | 1 within r_ghost of its left face only | 2 of both faces |
+//               3 of its right face only.
+// The arithmetic is the torch restatement's (domain.py), in the positions' own precision: owner = #(interior cuts <= x),
+// near_l = x < lo(owner) + r_ghost, near_r = x >= hi(owner) - r_ghost.
+template <typename T, typename V4>
+__global__ __launch_bounds__(256) void slab_classify_kernel(const V4 *__restrict__ pos, unsigned N, const T *__restrict__ bounds,
+                                                            int world, int rank, T r_ghost, unsigned *__restrict__ key) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const T x = pos[i].x;
+    int owner = 0;
+    for (int c = 1; c < world; ++c) owner += (bounds[c] <= x) ? 1 : 0;
+    const int left = (rank + world - 1) % world, right = (rank + 1) % world;
+    unsigned dest;
+    if (world == 2)
+        dest = owner != rank ? 2u : 0u;
+    else
+        dest = owner == rank ? 0u : (owner == left ? 1u : (owner == right ? 2u : 3u));
+    const bool near_l = x < bounds[owner] + r_ghost, near_r = x >= bounds[owner + 1] - r_ghost;
+    const unsigned cls = near_l ? (near_r ? 2u : 1u) : (near_r ? 3u : 0u);
+    key[i] = dest * 4u + cls;
+}
+
+extern "C" int htfs_slab_classify(const void *d_pos, int dtype, unsigned N, const void *d_bounds, int world, int rank,
+                                  double r_ghost, unsigned *d_key, htf_stream stream) {
+    HTF_REQUIRE(d_pos && d_bounds && d_key, "htfs_slab_classify: null pointer");
+    HTF_REQUIRE(world >= 2 && rank >= 0 && rank < world, "htfs_slab_classify: rank %d of %d", rank, world);
+    if (N == 0) return HTF_OK;
+    const unsigned grid = (N + 255) / 256;
+    if (dtype == HTF_F32)
+        hipLaunchKernelGGL((slab_classify_kernel<float, float4>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float4 *)d_pos, N,
+                           (const float *)d_bounds, world, rank, (float)r_ghost, d_key);
+    else
+        hipLaunchKernelGGL((slab_classify_kernel<double, double4>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const double4 *)d_pos,
+                           N, (const double *)d_bounds, world, rank, r_ghost, d_key);
+    return check_launch("slab_classify_kernel");
+}
+
+// up to HTFS_MAX_SEGMENTS row ranges copied in one launch: dst[dst_start[s] + j] = src[src_start[s] + j], j < count[s],
+// rows of `row_words` 32-bit words.  What merges three class-sorted segments (stayed | from the right | from the left)
+// into one class-sorted array without a sort: the 12 (segment, class) runs and their destinations are known on the host.
+struct SegTable {
+    unsigned n;
+    unsigned src[HTFS_MAX_SEGMENTS], dst[HTFS_MAX_SEGMENTS], cnt[HTFS_MAX_SEGMENTS];
+};
+
+__global__ __launch_bounds__(256) void segment_copy_kernel(unsigned *__restrict__ dst, const unsigned *__restrict__ src,
+                                                           unsigned row_words, SegTable t, unsigned total_rows) {
+    const unsigned w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= total_rows * row_words) return;
+    unsigned row = w / row_words;
+    const unsigned col = w - row * row_words;
+    unsigned seg = 0;
+#pragma unroll 1
+    while (seg + 1 < t.n && row >= t.cnt[seg]) { // rows are numbered segment after segment
+        row -= t.cnt[seg];
+        ++seg;
+    }
+    dst[(size_t)(t.dst[seg] + row) * row_words + col] = src[(size_t)(t.src[seg] + row) * row_words + col];
+}
+
+extern "C" int htfs_segment_copy(void *d_dst, const void *d_src, unsigned row_bytes, unsigned n_segments,
+                                 const unsigned *src_start, const unsigned *dst_start, const unsigned *count, htf_stream stream) {
+    HTF_REQUIRE(d_dst && d_src && src_start && dst_start && count, "htfs_segment_copy: null pointer");
+    HTF_REQUIRE(n_segments >= 1 && n_segments <= HTFS_MAX_SEGMENTS && row_bytes % 4 == 0 && row_bytes > 0,
+                "htfs_segment_copy: need 1..%d segments of whole 32-bit words", HTFS_MAX_SEGMENTS);
+    SegTable t;
+    t.n = 0;
+    unsigned total = 0;
+    for (unsigned s = 0; s < n_segments; ++s) {
+        if (count[s] == 0) continue; // (empty runs would stall the segment walk)
+        t.src[t.n] = src_start[s];
+        t.dst[t.n] = dst_start[s];
+        t.cnt[t.n] = count[s];
+        total += count[s];
+        ++t.n;
+    }
+    if (total == 0) return HTF_OK;
+    const unsigned words = row_bytes / 4;
+    const unsigned grid = (unsigned)(((size_t)total * words + 255) / 256);
+    hipLaunchKernelGGL(segment_copy_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (unsigned *)d_dst, (const unsigned *)d_src,
+                       words, t, total);
+    return check_launch("segment_copy_kernel");
+}
+
 extern "C" int htfs_cell_index(const void *d_pos, int dtype, unsigned Ntot, const htf_box *box, const int *ncell3,
                                unsigned *d_cell_of, htf_stream stream) {
     HTF_REQUIRE(d_pos && box && ncell3 && d_cell_of, "htfs_cell_index: null pointer");

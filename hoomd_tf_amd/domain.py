@@ -26,6 +26,8 @@ face), "R>" = sent to my right neighbor.  Every rank posts sends in the order [L
 receives in the order [L> from right, R> from left], which keeps grouped NCCL send/recv
 pairs matched even when left == right (world size 2).
 """
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -199,32 +201,41 @@ class SlabDomain:
             return
         N = s.N
         pv = torch.cat([s.pos[:N], s.vel[:N]], dim=1)  # [N, 8]: a particle travels as one record
-        x = pv[:, 0].contiguous()
+        # Destination and ghost class of every particle, and the stable (destination, class) order.
         # The integrator wraps into the global box, so the new owner is found by position and
         # is an adjacent slab by construction (rebuilds happen before anything moves r_buff/2).
-        bnd = torch.as_tensor(self.bounds, dtype=x.dtype, device=x.device)
-        owner = torch.bucketize(x, bnd[1:-1].contiguous(), right=True)
-        if self.world == 2:
-            dest = (owner != self.rank).to(torch.int64) * 2  # one peer: everything travels as the R> message
-        else:
-            go_left, go_right = owner == self.left, owner == self.right
-            lost = (owner != self.rank) & ~go_left & ~go_right
-            dest = go_left.to(torch.int64) + 2 * go_right.to(torch.int64) + 3 * lost.to(torch.int64)
         # Ghost class IN THE SLAB THE PARTICLE ENDS UP IN (the sender knows every slab's bounds): 0 interior,
         # 1 near the left face only, 2 near both faces (slabs thinner than 2 r_ghost), 3 near the right face only.
         # One stable sort on (destination, class) and ONE exchange of the 16 counts then carry both the migration
         # plan and the ghost plan: each rank can work out every rank's class counts after the migration, so the
         # second count exchange of the first version (and its device -> host round trip) is gone.
-        near_l, near_r = x < bnd[owner] + self.r_ghost, x >= bnd[owner + 1] - self.r_ghost
-        cls = torch.where(near_l, torch.where(near_r, 2, 1), torch.where(near_r, 3, 0))
-        key = dest * 4 + cls
-        cnt = torch.zeros(16, dtype=torch.int64, device=x.device).index_add_(0, key, torch.ones_like(key))
+        kernels = pv.is_cuda and os.environ.get("HTF_DOMAIN_TORCH") != "1"
+        if kernels:
+            # on the device: one classification kernel + the stand-in's counting sort over the 16 keys
+            # (csrc/standin.hip: slab_classify_kernel, htfs_cell_sort) -- three launches where the torch
+            # restatement below takes about twenty; the order and the counts are the same (tests/test_gpu_domain.py)
+            cnt, order = self._classify_sort_device(N)
+            pv = pv.index_select(0, order)
+        else:
+            x = pv[:, 0].contiguous()
+            bnd = torch.as_tensor(self.bounds, dtype=x.dtype, device=x.device)
+            owner = torch.bucketize(x, bnd[1:-1].contiguous(), right=True)
+            if self.world == 2:
+                dest = (owner != self.rank).to(torch.int64) * 2  # one peer: everything travels as the R> message
+            else:
+                go_left, go_right = owner == self.left, owner == self.right
+                lost = (owner != self.rank) & ~go_left & ~go_right
+                dest = go_left.to(torch.int64) + 2 * go_right.to(torch.int64) + 3 * lost.to(torch.int64)
+            near_l, near_r = x < bnd[owner] + self.r_ghost, x >= bnd[owner + 1] - self.r_ghost
+            cls = torch.where(near_l, torch.where(near_r, 2, 1), torch.where(near_r, 3, 0))
+            key = dest * 4 + cls
+            cnt = torch.zeros(16, dtype=torch.int64, device=x.device).index_add_(0, key, torch.ones_like(key))
+            pv = pv.index_select(0, torch.sort(key, stable=True)[1])
         allc = self._gather_counts(cnt).reshape(self.world, 4, 4)  # [rank, destination, class]
         if allc[:, 3].any():
             raise RuntimeError("a particle crossed more than one slab between neighbor-list rebuilds")
         mine = allc[self.rank]
         n_stay, n_l, n_r = (int(mine[d].sum()) for d in range(3))
-        pv = pv.index_select(0, torch.sort(key, stable=True)[1])
         pack_l = pv[n_stay:n_stay + n_l].contiguous()
         pack_r = pv[n_stay + n_l:n_stay + n_l + n_r].contiguous()
         in_r, in_l = allc[self.right][1], allc[self.left][2]  # class counts of what arrives from the right / left
@@ -232,10 +243,14 @@ class SlabDomain:
         self.n_migrated += int(got_r.shape[0] + got_l.shape[0])
         pv = torch.cat([pv[:n_stay], got_r, got_l], dim=0)
         N = int(pv.shape[0])
-        # every segment arrives sorted by class; one stable sort of the (known) class vector merges the three
-        seg = torch.as_tensor(np.concatenate([mine[0], in_r, in_l]), dtype=torch.int64, device=x.device)
-        cls_all = torch.repeat_interleave(torch.arange(4, device=x.device).repeat(3), seg)
-        pv = pv.index_select(0, torch.sort(cls_all, stable=True)[1])
+        # every segment arrives sorted by class: merging the three is 12 row-range copies whose sources and
+        # destinations follow from the counts already on the host
+        if kernels:
+            pv = self._merge_segments_device(pv, mine[0], in_r, in_l)
+        else:
+            seg = torch.as_tensor(np.concatenate([mine[0], in_r, in_l]), dtype=torch.int64, device=pv.device)
+            cls_all = torch.repeat_interleave(torch.arange(4, device=pv.device).repeat(3), seg)
+            pv = pv.index_select(0, torch.sort(cls_all, stable=True)[1])
         new_pos, new_vel = pv[:, :4], pv[:, 4:]
 
         def after(q):  # rank q's class counts once everybody has migrated
@@ -266,6 +281,49 @@ class SlabDomain:
         if self.transport_request != "torch" and self._native is None:
             self._try_native()
         self.exchange()
+
+    def _classify_sort_device(self, N):
+        """-> (counts of the 16 (destination, class) keys [int64, device], the stable order by key [int32, device])."""
+        import ctypes as C
+        from ._lib import lib, check
+        s = self.sys
+        dev = s.pos.device
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        st = getattr(self, "_plan_buf", None)
+        if st is None or st["key"].shape[0] < N or st["bnd"].dtype != s.pos.dtype:
+            st = self._plan_buf = {
+                "key": torch.empty(int(N * 1.2) + 64, dtype=torch.int32, device=dev),
+                "order": torch.empty(int(N * 1.2) + 64, dtype=torch.int32, device=dev),
+                "scratch": torch.zeros(32, dtype=torch.int32, device=dev),   # htfs_cell_sort: 2 * 16 words, first half kept zero
+                "start": torch.empty(17, dtype=torch.int32, device=dev),
+                "bnd": torch.as_tensor(self.bounds, dtype=s.pos.dtype, device=dev)}
+        check(lib.htfs_slab_classify(s.pos.data_ptr(), s.scalar_code, N, st["bnd"].data_ptr(), self.world, self.rank,
+                                     self.r_ghost, st["key"].data_ptr(), stream))
+        check(lib.htfs_cell_sort(st["key"].data_ptr(), N, 16, st["scratch"].data_ptr(), st["start"].data_ptr(),
+                                 st["order"].data_ptr(), stream))
+        cnt = (st["start"][1:] - st["start"][:-1]).to(torch.int64)
+        return cnt, st["order"][:N]
+
+    def _merge_segments_device(self, pv, stay, in_r, in_l):
+        """[stay by class | from the right by class | from the left by class] -> one array by class (inside a class: stayed,
+        from the right, from the left -- the order a stable sort of the class vector gives)."""
+        import ctypes as C
+        from ._lib import lib, check
+        segs = [np.asarray(v, dtype=np.int64) for v in (stay, in_r, in_l)]
+        src0 = np.concatenate([[0], np.cumsum([int(v.sum()) for v in segs])])
+        src, dst, cnt = [], [], []
+        off = 0
+        for c in range(4):
+            for k, v in enumerate(segs):
+                src.append(int(src0[k] + v[:c].sum()))
+                dst.append(off)
+                cnt.append(int(v[c]))
+                off += int(v[c])
+        out = torch.empty_like(pv)
+        U = C.c_uint * 12
+        check(lib.htfs_segment_copy(out.data_ptr(), pv.data_ptr(), int(pv.shape[1]) * pv.element_size(), 12, U(*src), U(*dst), U(*cnt),
+                                    C.c_void_p(torch.cuda.current_stream(pv.device).cuda_stream)))
+        return out
 
     def _try_native(self):
         """Bring up the native transport and check it ONCE against the torch one (same slices, same ghosts)."""

@@ -100,13 +100,56 @@ class System:
         return (w.view(torch.int64) & 0xFFFFFFFF).to(torch.int32).cpu().numpy()
 
 
+class DeferredRebuildRule:
+    """NeighborList::distanceCheck's decision taken ONE CHECK LATE, for a box decomposed over ranks.
+
+    Under decomposition every rank must take the same decision, so a check costs an all-reduce of the largest
+    displacement -- and, read back at once, a drained queue on every rank every ``check_period`` steps (at 16 k rows per
+    rank that stall is longer than the force kernel).  Here the all-reduced value of check k is read at check k + 1, when it
+    has long arrived, and the rebuild is decided from what is known then: with d the largest displacement since the last
+    rebuild (d = 0 there) and g its growth over the last period, rebuild NOW if d + 2 g > r_buff / 2 -- the value two
+    periods after the newest measurement, i.e. at the next opportunity to act, extrapolated linearly (the maximum over
+    particles of a ballistic-then-diffusive displacement grows sub-linearly, so the line errs on the early side).
+    A measurement that already exceeds r_buff / 2 when it is read is counted as a DANGEROUS build, as HOOMD counts them:
+    the list had been used beyond its guarantee; lower ``check_period``.  Pure host arithmetic on a handful of floats, shared
+    by the asynchronous path and by the synchronous reference path of the tests."""
+
+    def __init__(self, half_buffer, lookahead=2.0):
+        self.h = float(half_buffer)
+        self.lookahead = float(lookahead)
+        self.hist = []
+        self.dangerous = 0
+
+    def push(self, d):
+        self.hist.append(float(d))
+        if d > self.h:
+            self.dangerous += 1
+
+    def decide(self):
+        if not self.hist:
+            return False
+        d1 = self.hist[-1]
+        d0 = self.hist[-2] if len(self.hist) > 1 else 0.0
+        return d1 + self.lookahead * max(d1 - d0, 0.0) > self.h
+
+    def reset(self):
+        self.hist = []
+
+
 class CellNlist:
     """hoomd.md.nlist.cell analogue: FULL neighbor list, fixed pitch head list, rebuilt
     when any particle has moved more than r_buff / 2 (NeighborList::distanceCheck)."""
 
     def __init__(self, system, r_cut, r_buff=0.4, pitch=None, check_period=1, sort_particles=False,
-                 device_decision=False):
+                 device_decision=False, deferred_reference=False):
         self.sys = system
+        # Under domain decomposition ``device_decision`` selects DeferredRebuildRule fed without a host synchronisation
+        # (device all-reduce -> pinned copy -> read one check later); ``deferred_reference`` feeds the same rule from a
+        # blocking read at every check -- the host-decided twin the tests compare trajectories with.
+        self.deferred_reference = bool(deferred_reference)
+        self._rule = None
+        self._dd_prev = None
+        self._dd_i = 0
         # device_decision: after the first build the distance check and the rebuild it may trigger are
         # enqueued together, the binning / search kernels gated on the device by the check's result
         # (htfs_set_gate): the step loop never reads the check back.  The buffers keep their addresses, a
@@ -218,6 +261,9 @@ class CellNlist:
             self._ref = s.pos[: s.N].clone()
         else:
             self._ref.copy_(s.pos[: s.N])
+        if self._rule is not None:  # displacements are measured from the new reference positions
+            self._rule.reset()
+            self._dd_prev = None
         self._grid = (n3, w3, ncell)
         self.n_builds += 1
 
@@ -281,9 +327,57 @@ class CellNlist:
         """Rebuilds the device has decided on so far (synchronises; for reports, not for the step loop)."""
         return int(self._stat[1].item()) if self._stat is not None else 0
 
+    def _deferred_needs_update(self):
+        """One check of the deferred rule (see DeferredRebuildRule).  Asynchronous form: the displacement kernel, a 4-byte
+        MAX all-reduce on the device, a copy to pinned memory and an event -- nothing waits; the PREVIOUS check's value is
+        read (its event completed a whole check period ago) and the decision follows from it."""
+        import torch.distributed as dist
+        s = self.sys
+        if self._rule is None:
+            self._rule = DeferredRebuildRule(self.r_buff / 2.0)
+            self._dd_dev = [torch.zeros(1, dtype=torch.float32, device=s.device) for _ in range(3)]
+            self._dd_host = [torch.zeros(1, dtype=torch.float32).pin_memory() if s.device.type == "cuda"
+                             else torch.zeros(1, dtype=torch.float32) for _ in range(3)]
+        buf = self._dd_dev[self._dd_i % 3]
+        buf.zero_()
+        check(lib.htfs_max_displacement2(s.pos.data_ptr(), self._ref.data_ptr(), s.scalar_code, s.N,
+                                         C.byref(s.box), buf.data_ptr(),
+                                         C.c_void_p(torch.cuda.current_stream(s.device).cuda_stream)))
+        if self.deferred_reference:
+            # the host-decided twin: all-reduce and read NOW (a drained queue per check), same rule, same one-check lag
+            dist.all_reduce(buf, op=dist.ReduceOp.MAX, group=self.domain.group)
+            now = float(np.sqrt(max(float(buf.item()), 0.0)))
+            if self._dd_prev is not None:
+                self._rule.push(self._dd_prev)
+            self._dd_prev = now
+        else:
+            work = dist.all_reduce(buf, op=dist.ReduceOp.MAX, group=self.domain.group, async_op=True)
+            work.wait()  # (RCCL: the current stream waits for the collective; the host does not)
+            host = self._dd_host[self._dd_i % 3]
+            host.copy_(buf, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            if self._dd_prev is not None:
+                h_prev, ev_prev = self._dd_prev
+                ev_prev.synchronize()  # recorded a whole check period ago
+                self._rule.push(float(np.sqrt(max(float(h_prev[0]), 0.0))))
+            self._dd_prev = (host, ev)
+        self._dd_i += 1
+        if self._rule.decide():
+            self._rule.reset()
+            self._dd_prev = None  # what was measured against the old reference positions dies with them
+            return True
+        return False
+
+    @property
+    def dangerous_builds(self):
+        return self._rule.dangerous if self._rule is not None else 0
+
     def needs_update(self):
         if self._ref is None:
             return True
+        if self.domain is not None and self.domain.world > 1 and (self.device_decision or self.deferred_reference):
+            return self._deferred_needs_update()
         s = self.sys
         self._disp.zero_()
         check(lib.htfs_max_displacement2(s.pos.data_ptr(), self._ref.data_ptr(), s.scalar_code, s.N,

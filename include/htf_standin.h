@@ -67,6 +67,20 @@ HTF_API int htfs_set_gate(const float *d_disp2, double threshold2);
 HTF_API int htfs_commit_rebuild(void *d_ref, const void *d_pos, int dtype, unsigned N, unsigned *d_counter,
                                 htf_stream stream);
 
+/* Slab decomposition (the stand-in for HOOMD's Communicator; hoomd_tf_amd/domain.py): the migration + ghost plan of a
+ * rebuild.  d_key[i] = destination * 4 + ghost class of local particle i (destination: 0 stay, 1 left neighbor,
+ * 2 right neighbor, 3 beyond; class in the slab it ends up in: 0 interior, 1 near the left face only, 2 near both,
+ * 3 near the right face only).  d_bounds: world + 1 slab boundaries along x in the positions' dtype.  htfs_cell_sort over
+ * these 16 keys then yields the stable (destination, class) order and its counts in one pass. */
+HTF_API int htfs_slab_classify(const void *d_pos, int dtype, unsigned N, const void *d_bounds, int world, int rank,
+                               double r_ghost, unsigned *d_key, htf_stream stream);
+
+/* dst[dst_start[s] + j] = src[src_start[s] + j] for j < count[s], s < n_segments <= HTFS_MAX_SEGMENTS, rows of
+ * row_bytes (a multiple of 4): merges class-sorted segments into one class-sorted array in one launch. */
+#define HTFS_MAX_SEGMENTS 16
+HTF_API int htfs_segment_copy(void *d_dst, const void *d_src, unsigned row_bytes, unsigned n_segments,
+                              const unsigned *src_start, const unsigned *dst_start, const unsigned *count, htf_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

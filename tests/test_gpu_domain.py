@@ -219,6 +219,99 @@ def test_slabs_on_one_gpu(htf, cuda, world, per_slab):
         assert msg == "ok", "rank %d failed:\n%s" % (rank, msg)
 
 
+def _deferred_worker(rank, world, port, q, per_slab):
+    """Two runs of the same decomposed LJ MD: the rebuild decision (standin.DeferredRebuildRule) fed WITHOUT a host
+    synchronisation -- device all-reduce, pinned copy, read one check later -- and fed from a blocking read at every check
+    (the host-decided twin).  Same rule, same one-check lag: the two must rebuild at the same steps and end in bit-identical
+    positions on every rank; no build may be dangerous; forces of the final configuration are whole (nobody lost)."""
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        sys.path.insert(0, ROOT)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import hoomd_tf_amd as htf
+        from hoomd_tf_amd import standin
+        from hoomd_tf_amd.domain import SlabDomain
+
+        dev = torch.device("cuda:0")
+        rcut, rbuf, NN = 2.5, 0.4, 80
+        cells = (per_slab * world, 5, 5)
+        a = (4.0 / 0.8442) ** (1.0 / 3.0)
+        base = np.array([[0, 0, 0], [.5, .5, 0], [.5, 0, .5], [0, .5, .5]])
+        grid = np.stack(np.meshgrid(*[np.arange(c) for c in cells], indexing="ij"), -1).reshape(-1, 3)
+        pos0 = ((grid[:, None, :] + base[None]) * a).reshape(-1, 3)
+        L = np.array(cells, dtype=np.float64) * a
+        pos0 = pos0 - L / 2
+        rng = np.random.default_rng(11)
+        pos0 += 0.04 * a * rng.standard_normal(pos0.shape)
+        pos0 -= np.round(pos0 / L) * L
+        Ng = len(pos0)
+        vel0 = np.zeros((Ng, 4))
+        vel0[:, :3] = 1.0 * rng.standard_normal((Ng, 3))
+        bounds = -L[0] / 2 + np.linspace(0, 1, world + 1) * L[0]
+        mine = (pos0[:, 0] >= bounds[rank]) & (pos0[:, 0] < bounds[rank + 1])
+        out = {}
+        for mode in ("device", "host", "torch-plan"):
+            # "torch-plan": the migration / ghost plan of a rebuild through the torch restatement (HTF_DOMAIN_TORCH=1: the
+            # path the CPU gloo tests exercise) instead of the classification + counting-sort + segment-copy kernels
+            os.environ["HTF_DOMAIN_TORCH"] = "1" if mode == "torch-plan" else "0"
+            sysm = standin.System(pos0[mine], L, types=np.arange(Ng)[mine], dtype=torch.float32, device=dev)
+            sysm.vel = torch.from_numpy(vel0[mine]).to(torch.float32).to(dev)
+            nl = standin.CellNlist(sysm, r_cut=rcut, r_buff=rbuf, check_period=3, device_decision=(mode == "device"),
+                                   deferred_reference=(mode != "device"))
+            nl.domain = SlabDomain(sysm, rank, world, r_ghost=rcut + rbuf)
+            nl.build()
+            ctx = htf.Context(r_cut=rcut, nneighs=NN, scalar_dtype=torch.float32, max_n=sysm.N)
+            ctx.set_potential(htf.Potential.lj())
+            nve = standin.NVE(sysm, 0.004)
+            builds, arr, steps_built = -1, None, []
+            for ts in range(90):
+                nl.compute(ts)
+                if nl.n_builds != builds:
+                    arr = ctx.make_arrays(sysm.pos, sysm.N, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, sysm.force)
+                    builds = nl.n_builds
+                    steps_built.append(ts)
+                ctx.compute_forces_overlapped(ts, arr, nl.domain)
+                nve.step()
+            torch.cuda.synchronize()
+            assert nl._rule is not None and nl.dangerous_builds == 0, nl.dangerous_builds
+            assert len(steps_built) >= 4, steps_built
+            out[mode] = (steps_built, sysm.types_numpy().copy(), sysm.pos[:sysm.N].cpu().numpy().copy(),
+                         sysm.force[:sysm.N].cpu().numpy().copy())
+            tot = torch.tensor([sysm.N])
+            dist.all_reduce(tot)
+            assert int(tot) == Ng
+        for other in ("host", "torch-plan"):
+            assert out["device"][0] == out[other][0], (other, out["device"][0], out[other][0])  # rebuilt at the same steps
+            np.testing.assert_array_equal(out["device"][1], out[other][1])                      # same particles, same order
+            np.testing.assert_array_equal(out["device"][2], out[other][2])                      # bit-identical trajectories
+            np.testing.assert_array_equal(out["device"][3], out[other][3])
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+@pytest.mark.parametrize("world,per_slab", [(3, 4), (8, 2)])
+def test_deferred_device_decision_equals_host_decided(htf, cuda, world, per_slab):
+    """under decomposition the step loop has no read-back -- the distance check is all-reduced on the
+    device and read one check late -- and the trajectory is the one the host-decided twin produces, at world 3 and at
+    world 8 with slabs thinner than 2 r_ghost (the ranks share the one GPU of the test box over gloo)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_deferred_worker, args=(r, world, port, q, per_slab)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=900) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in results:
+        assert msg == "ok", "rank %d failed:\n%s" % (rank, msg)
+
+
 @pytest.mark.parametrize("args", [["--gpus", "2"], ["--gpus", "3"], ["--gpus", "2", "--scaling", "weak"]])
 def test_bench_starts_its_own_ranks(htf, cuda, args):
     """`python bench.py --gpus N` with no launcher around it (how the driver calls it): the parent starts the N rank

@@ -234,3 +234,29 @@ def test_product_initializer_equals_the_oracle_copy():
         assert sorted(a) == sorted(b)
         for k in a:
             np.testing.assert_array_equal(a[k], b[k])
+
+
+def test_deferred_rebuild_rule():
+    """standin.DeferredRebuildRule (host arithmetic of the multi-rank rebuild decision): fed the displacement of the
+    PREVIOUS check, it asks for a rebuild before a linearly growing displacement can exceed r_buff / 2 at the next
+    opportunity to act, never when nothing has been measured, and counts a measurement beyond the limit as dangerous."""
+    from hoomd_tf_amd.standin import DeferredRebuildRule
+    for growth in (0.013, 0.03, 0.049, 0.09):
+        rule = DeferredRebuildRule(0.2)
+        assert not rule.decide()
+        d, k, fired = 0.0, 0, None
+        while fired is None and k < 200:
+            k += 1                      # check k: displacement is now k * growth; the value of check k - 1 arrives
+            if k > 1:
+                rule.push((k - 1) * growth)
+            if rule.decide():
+                fired = k
+        assert fired is not None
+        assert fired * growth <= 0.2 + 1e-12, (growth, fired)      # the list was never used beyond its guarantee
+        assert (fired + 1) * growth > 0.2 - 2 * growth              # ... and not rebuilt more than two periods early
+        assert rule.dangerous == 0
+    rule = DeferredRebuildRule(0.2)
+    rule.push(0.25)
+    assert rule.decide() and rule.dangerous == 1
+    rule.reset()
+    assert not rule.decide()
