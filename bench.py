@@ -668,6 +668,10 @@ class Env:
 
 def main():
     args = parse()
+    if os.environ.get("HTF_BENCH_WATCHDOG"):
+        # a rank that hangs (mismatched collectives ...) dumps every thread's stack and exits instead of holding the box
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["HTF_BENCH_WATCHDOG"]), exit=True)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(self_launch(args))
     E = Env()

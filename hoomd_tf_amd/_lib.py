@@ -140,6 +140,7 @@ STANDIN_PROTOTYPES = {
     "htfs_cell_sort": (_i, [_vp, _u, _u, _vp, _vp, _vp, _vp]),
     "htfs_slab_classify": (_i, [_vp, _i, _u, _vp, _i, _i, _d, _vp, _vp]),
     "htfs_segment_copy": (_i, [_vp, _vp, _u, _u, _vp, _vp, _vp, _vp]),
+    "htfs_key_sort16": (_i, [_vp, _u, _vp, _vp, _vp, _vp]),
     "htfs_nve_step": (_i, [_vp, _vp, _vp, _i, _u, _d, C.POINTER(Box), _vp]),
     "htfs_max_displacement2": (_i, [_vp, _vp, _i, _u, C.POINTER(Box), _vp, _vp]),
     "htfs_build_nlist": (_i, [_vp, _vp, _i, _u, _u, C.POINTER(Box), _d, C.POINTER(_i * 3), C.POINTER(_i * 3), _vp, _u, _i, _vp, _vp, _vp,

@@ -211,8 +211,8 @@ class SlabDomain:
         # second count exchange of the first version (and its device -> host round trip) is gone.
         kernels = pv.is_cuda and os.environ.get("HTF_DOMAIN_TORCH") != "1"
         if kernels:
-            # on the device: one classification kernel + the stand-in's counting sort over the 16 keys
-            # (csrc/standin.hip: slab_classify_kernel, htfs_cell_sort) -- three launches where the torch
+            # on the device: one classification kernel + a stable counting sort over the 16 keys
+            # (csrc/standin.hip: slab_classify_kernel, htfs_key_sort16) -- four launches where the torch
             # restatement below takes about twenty; the order and the counts are the same (tests/test_gpu_domain.py)
             cnt, order = self._classify_sort_device(N)
             pv = pv.index_select(0, order)
@@ -294,13 +294,13 @@ class SlabDomain:
             st = self._plan_buf = {
                 "key": torch.empty(int(N * 1.2) + 64, dtype=torch.int32, device=dev),
                 "order": torch.empty(int(N * 1.2) + 64, dtype=torch.int32, device=dev),
-                "scratch": torch.zeros(32, dtype=torch.int32, device=dev),   # htfs_cell_sort: 2 * 16 words, first half kept zero
+                "scratch": torch.zeros(16 * ((int(N * 1.2) + 64 + 4095) // 4096), dtype=torch.int32, device=dev),
                 "start": torch.empty(17, dtype=torch.int32, device=dev),
                 "bnd": torch.as_tensor(self.bounds, dtype=s.pos.dtype, device=dev)}
         check(lib.htfs_slab_classify(s.pos.data_ptr(), s.scalar_code, N, st["bnd"].data_ptr(), self.world, self.rank,
                                      self.r_ghost, st["key"].data_ptr(), stream))
-        check(lib.htfs_cell_sort(st["key"].data_ptr(), N, 16, st["scratch"].data_ptr(), st["start"].data_ptr(),
-                                 st["order"].data_ptr(), stream))
+        check(lib.htfs_key_sort16(st["key"].data_ptr(), N, st["scratch"].data_ptr(), st["start"].data_ptr(),
+                                  st["order"].data_ptr(), stream))
         cnt = (st["start"][1:] - st["start"][:-1]).to(torch.int64)
         return cnt, st["order"][:N]
 

@@ -70,10 +70,16 @@ HTF_API int htfs_commit_rebuild(void *d_ref, const void *d_pos, int dtype, unsig
 /* Slab decomposition (the stand-in for HOOMD's Communicator; hoomd_tf_amd/domain.py): the migration + ghost plan of a
  * rebuild.  d_key[i] = destination * 4 + ghost class of local particle i (destination: 0 stay, 1 left neighbor,
  * 2 right neighbor, 3 beyond; class in the slab it ends up in: 0 interior, 1 near the left face only, 2 near both,
- * 3 near the right face only).  d_bounds: world + 1 slab boundaries along x in the positions' dtype.  htfs_cell_sort over
- * these 16 keys then yields the stable (destination, class) order and its counts in one pass. */
+ * 3 near the right face only).  d_bounds: world + 1 slab boundaries along x in the positions' dtype.  htfs_key_sort16 over
+ * these keys then yields the stable (destination, class) order and the 16 counts. */
 HTF_API int htfs_slab_classify(const void *d_pos, int dtype, unsigned N, const void *d_bounds, int world, int rank,
                                double r_ghost, unsigned *d_key, htf_stream stream);
+
+/* Stable counting sort of N elements by a key < 16: d_order <- indices grouped by key, ascending index inside a key;
+ * d_start[k] <- first slot of key k (17 entries).  d_scratch: 16 * ceil(N / 4096) words.  (htfs_cell_sort is the tool for
+ * many cells of a few members; this one for a few keys of many members.) */
+HTF_API int htfs_key_sort16(const unsigned *d_key, unsigned N, unsigned *d_scratch, unsigned *d_start, unsigned *d_order,
+                            htf_stream stream);
 
 /* dst[dst_start[s] + j] = src[src_start[s] + j] for j < count[s], s < n_segments <= HTFS_MAX_SEGMENTS, rows of
  * row_bytes (a multiple of 4): merges class-sorted segments into one class-sorted array in one launch. */

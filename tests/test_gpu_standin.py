@@ -317,3 +317,54 @@ def test_cell_nlist_random_boxes_match_brute_force(htf, cuda, seed):
     for g in got[:: max(1, N // 50)]:  # rows hold no duplicates and never the particle itself
         assert len(set(g.tolist())) == len(g)
     assert all(i not in set(g.tolist()) for i, g in enumerate(got[:200]))
+
+
+def test_slab_plan_kernels_match_torch(htf, cuda):
+    """The migration / ghost plan of a decomposed rebuild on the device (csrc/standin.hip: slab_classify_kernel,
+    htfs_key_sort16, segment_copy_kernel) against plain torch ops on the same data, at a size where one key holds tens of
+    thousands of members (the C3 box over two ranks: 65 536 particles per rank, most of them "stay, interior")."""
+    import ctypes as C
+    from hoomd_tf_amd._lib import lib, check
+    g = torch.Generator(device="cuda").manual_seed(4)
+    N, world, rank, r_ghost = 70001, 4, 1, 3.4
+    L = 53.75
+    bounds = np.linspace(-L / 2, L / 2, world + 1)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for dtype, code in ((torch.float32, 0), (torch.float64, 1)):
+        pos = torch.zeros((N, 4), dtype=dtype, device=cuda)
+        # mostly inside slab 1, a few hundred just across either face, a handful far away (destination 3)
+        x = bounds[1] + (bounds[2] - bounds[1]) * torch.rand(N, generator=g, device=cuda, dtype=torch.float64)
+        x[:300] = bounds[1] - 0.3 * torch.rand(300, generator=g, device=cuda, dtype=torch.float64)
+        x[300:700] = bounds[2] + 0.3 * torch.rand(400, generator=g, device=cuda, dtype=torch.float64)
+        x[700:705] = bounds[3] + 1.0
+        x = x[torch.randperm(N, generator=g, device=cuda)]
+        pos[:, 0] = x.to(dtype)
+        key = torch.empty(N, dtype=torch.int32, device=cuda)
+        bnd = torch.as_tensor(bounds, dtype=dtype, device=cuda)
+        check(lib.htfs_slab_classify(pos.data_ptr(), code, N, bnd.data_ptr(), world, rank, r_ghost, key.data_ptr(), stream))
+        xs = pos[:, 0].contiguous()
+        owner = torch.bucketize(xs, bnd[1:-1].contiguous(), right=True)
+        dest = (owner == rank - 1).long() + 2 * (owner == rank + 1).long() + 3 * ((owner != rank) & (owner != rank - 1) & (owner != rank + 1)).long()
+        near_l, near_r = xs < bnd[owner] + r_ghost, xs >= bnd[owner + 1] - r_ghost
+        cls = torch.where(near_l, torch.where(near_r, 2, 1), torch.where(near_r, 3, 0))
+        ref_key = dest * 4 + cls
+        assert torch.equal(key.long(), ref_key)
+        assert int((ref_key // 4 == 3).sum()) == 5 and int((ref_key == 0).sum()) > 30000
+        scratch = torch.zeros(16 * ((N + 4095) // 4096), dtype=torch.int32, device=cuda)
+        start = torch.empty(17, dtype=torch.int32, device=cuda)
+        order = torch.full((N,), -1, dtype=torch.int32, device=cuda)
+        check(lib.htfs_key_sort16(key.data_ptr(), N, scratch.data_ptr(), start.data_ptr(), order.data_ptr(), stream))
+        assert torch.equal(order.long(), torch.sort(ref_key, stable=True)[1])
+        cnt = torch.zeros(16, dtype=torch.int64, device=cuda).index_add_(0, ref_key, torch.ones_like(ref_key))
+        assert torch.equal((start[1:] - start[:-1]).long(), cnt) and int(start[0]) == 0
+    # segment copy: three class-sorted segments merged by class
+    rng = np.random.default_rng(2)
+    segs = [rng.integers(0, 900, size=4) for _ in range(3)]
+    segs[1][2] = 0
+    n = int(sum(int(v.sum()) for v in segs))
+    src = torch.arange(n * 8, dtype=torch.float32, device=cuda).reshape(n, 8)
+    cls_all = torch.repeat_interleave(torch.arange(4, device=cuda).repeat(3), torch.as_tensor(np.concatenate(segs), device=cuda))
+    want = src.index_select(0, torch.sort(cls_all, stable=True)[1])
+    from hoomd_tf_amd.domain import SlabDomain
+    got = SlabDomain._merge_segments_device(None, src, segs[0], segs[1], segs[2])
+    assert torch.equal(got, want)
