@@ -315,51 +315,90 @@ __global__ __launch_bounds__(256) void cell_count_kernel(const unsigned *__restr
 }
 
 // exclusive scan of count[0..ncell) into start[0..ncell], one workgroup; cursor <- start.
-// The counts pass through LDS in chunks of 32 768 cells: coalesced loads in, every thread owns 32 consecutive
-// cells of the chunk (row stride 33 words: conflict-free), serial sum, a 1024-wide scan of the partial sums, serial
-// prefix, coalesced stores out.  (The first version let every thread walk ITS cells in global memory -- 2 x 30
-// strided, dependent accesses per thread from one CU: 61 us of every rebuild at 29 791 cells; this one: rocprofv3
-// `cell_scan_kernel` in profiles/.)
-constexpr unsigned kScanChunk = 32768, kScanPer = 32, kScanStride = 33;
-__global__ __launch_bounds__(1024) void cell_scan_kernel(unsigned *__restrict__ count, unsigned ncell,
+// Exclusive scan of the cell counts by ONE block, in chunks of 32 768 cells: every thread owns 32 consecutive cells of the
+// chunk IN REGISTERS (eight 16-B loads of its own 128-B line: whole lines consumed), serial sum, a wave scan by shuffles, the
+// wave totals through a few words of LDS, serial prefix, eight 16-B stores to each output.  Round 2 staged the chunk through 132 KiB of
+// LDS (17 us at 29 791 cells; the first version walked global memory with strided dependent accesses: 61 us) -- and then could
+// not be scheduled beside the pair-MLP training kernel, whose persistent blocks hold 157 KiB of every CU's LDS for a whole
+// 10 ms sweep: 265 us per call in the C5b trace (profiles/r02_bench_mlp_train_kernel_stats.csv).  With 64 B it co-resides
+// with anything.
+// And 256 threads, not 1024: a 16-wave workgroup needs four wave slots AND 4 x 88 VGPRs on every SIMD of one CU at once, which
+// no CU has while a training wave (383 VGPRs) sits on each of its SIMDs -- the round-3 trace still showed 289 us per call (max
+// 8.4 ms: the end of the sweep) with the LDS gone.  Four waves, one per SIMD, fit beside it.
+constexpr unsigned kScanThreads = 256, kScanPer = 32, kScanChunk = kScanThreads * kScanPer;
+__global__ __launch_bounds__(kScanThreads) void cell_scan_kernel(unsigned *__restrict__ count, unsigned ncell,
                                                          unsigned *__restrict__ start, unsigned *__restrict__ cursor, Gate gate) {
     if (gate.closed()) return;
-    __shared__ unsigned s_cells[1024 * kScanStride]; // 1024 rows x 33 words (132 KiB of the CU's 160)
-    __shared__ unsigned s_sum[1024];
-    const unsigned t = threadIdx.x;
+    __shared__ unsigned s_wave[kScanThreads / 64];
+    const unsigned t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     unsigned carry = 0;
     for (unsigned base = 0; base < ncell; base += kScanChunk) {
-        const unsigned n = ncell - base < kScanChunk ? ncell - base : kScanChunk;
-        for (unsigned j = t; j < kScanChunk; j += 1024) s_cells[(j / kScanPer) * kScanStride + j % kScanPer] = j < n ? count[base + j] : 0u;
-        for (unsigned j = t; j < n; j += 1024) count[base + j] = 0u; // left zeroed for the next call (htfs_cell_sort)
-        __syncthreads();
-        unsigned *mine = s_cells + t * kScanStride;
+        const unsigned first = base + t * kScanPer;
+        unsigned c[kScanPer];
+        const bool whole = first + kScanPer <= ncell && (reinterpret_cast<size_t>(count + first) & 15u) == 0;
+        if (whole) { // (wave-divergent only in the last chunk)
+            const uint4 *p = reinterpret_cast<const uint4 *>(count + first);
+#pragma unroll
+            for (unsigned q = 0; q < kScanPer / 4; ++q) {
+                const uint4 v = p[q];
+                c[4 * q] = v.x; c[4 * q + 1] = v.y; c[4 * q + 2] = v.z; c[4 * q + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (unsigned i = 0; i < kScanPer; ++i) c[i] = first + i < ncell ? count[first + i] : 0u;
+        }
+        if (whole) { // left zeroed for the next call (htfs_cell_sort)
+            uint4 *p = reinterpret_cast<uint4 *>(count + first);
+#pragma unroll
+            for (unsigned q = 0; q < kScanPer / 4; ++q) p[q] = make_uint4(0u, 0u, 0u, 0u);
+        } else {
+#pragma unroll
+            for (unsigned i = 0; i < kScanPer; ++i)
+                if (first + i < ncell) count[first + i] = 0u;
+        }
         unsigned sum = 0;
 #pragma unroll
-        for (unsigned i = 0; i < kScanPer; ++i) sum += mine[i];
-        s_sum[t] = sum;
-        __syncthreads();
-        for (unsigned off = 1; off < 1024; off <<= 1) { // Hillis-Steele inclusive scan of the chunk sums
-            const unsigned v = t >= off ? s_sum[t - off] : 0u;
-            __syncthreads();
-            s_sum[t] += v;
-            __syncthreads();
+        for (unsigned i = 0; i < kScanPer; ++i) sum += c[i];
+        unsigned incl = sum; // inclusive scan over the wave's 64 lanes
+#pragma unroll
+        for (unsigned off = 1; off < 64; off <<= 1) {
+            const unsigned v = (unsigned)__shfl_up((int)incl, off);
+            if (lane >= off) incl += v;
         }
-        unsigned run = carry + (t ? s_sum[t - 1] : 0u);
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        unsigned before = 0, total = 0;
+#pragma unroll
+        for (unsigned w = 0; w < kScanThreads / 64; ++w) {
+            const unsigned v = s_wave[w];
+            before += w < wave ? v : 0u;
+            total += v;
+        }
+        unsigned run = carry + before + (incl - sum);
 #pragma unroll
         for (unsigned i = 0; i < kScanPer; ++i) { // exclusive prefix in place
-            const unsigned c = mine[i];
-            mine[i] = run;
-            run += c;
+            const unsigned v = c[i];
+            c[i] = run;
+            run += v;
         }
-        __syncthreads();
-        for (unsigned j = t; j < n; j += 1024) {
-            const unsigned v = s_cells[(j / kScanPer) * kScanStride + j % kScanPer];
-            start[base + j] = v;
-            cursor[base + j] = v;
+        if (whole && (reinterpret_cast<size_t>(start + first) & 15u) == 0 && (reinterpret_cast<size_t>(cursor + first) & 15u) == 0) {
+            uint4 *ps = reinterpret_cast<uint4 *>(start + first), *pc = reinterpret_cast<uint4 *>(cursor + first);
+#pragma unroll
+            for (unsigned q = 0; q < kScanPer / 4; ++q) {
+                const uint4 v = make_uint4(c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]);
+                ps[q] = v;
+                pc[q] = v;
+            }
+        } else {
+#pragma unroll
+            for (unsigned i = 0; i < kScanPer; ++i)
+                if (first + i < ncell) {
+                    start[first + i] = c[i];
+                    cursor[first + i] = c[i];
+                }
         }
-        carry += s_sum[1023];
-        __syncthreads();
+        carry += total;
+        __syncthreads(); // s_wave is rewritten by the next chunk
     }
     if (t == 0) start[ncell] = carry;
 }
@@ -401,7 +440,7 @@ extern "C" int htfs_cell_sort(const unsigned *d_cell_of, unsigned Ntot, unsigned
     // so a gated call -- always preceded by an ungated one on the same scratch (htf_standin.h) -- needs no memset
     if (!g_gate.disp2) HTF_CHECK_HIP(hipMemsetAsync(count, 0, (size_t)ncell * sizeof(unsigned), s));
     if (Ntot) hipLaunchKernelGGL(cell_count_kernel, dim3((Ntot + 255) / 256), dim3(256), 0, s, d_cell_of, Ntot, count, g_gate);
-    hipLaunchKernelGGL(cell_scan_kernel, dim3(1), dim3(1024), 0, s, count, ncell, d_cell_start, cursor, g_gate);
+    hipLaunchKernelGGL(cell_scan_kernel, dim3(1), dim3(kScanThreads), 0, s, count, ncell, d_cell_start, cursor, g_gate);
     if (Ntot) hipLaunchKernelGGL(cell_scatter_kernel, dim3((Ntot + 255) / 256), dim3(256), 0, s, d_cell_of, Ntot, cursor, d_order, g_gate);
     hipLaunchKernelGGL(cell_order_kernel, dim3((ncell + 255) / 256), dim3(256), 0, s, d_cell_start, ncell, d_order, g_gate);
     return check_launch("htfs_cell_sort");
