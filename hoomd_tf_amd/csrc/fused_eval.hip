@@ -611,7 +611,9 @@ static int launch_fused(const void *pos, unsigned N, unsigned NN, unsigned offse
         // 78.1-78.4 for the plain two-row form and 68.7-72.9 for four rows (82 VGPRs, 83 spilled SGPRs); same-box A/B in
         // profiles/r03_f64_kernel_ab.txt.  Every fp64 VALU instruction of the kernel issues at the fp32 rate
         // (tools/valu_rate_probe.hip); what the fp64 wire costs is the second 16-B gather instruction per candidate.
-        const int tails = tails_env ? atoi(tails_env) : (batch >= 16384u ? (sizeof(PT) == 4 ? 4 : 2) : 0);
+        // Round 3, 32 000 rows (C2): two rows 18.5 us, four rows 19.1, plain two-row form 19.4; 62 500 rows: 31.7 / 31.6 -- half
+        // as many waves on a grid that fills the chip only twice is what the four-row form loses there, so it starts at 49 152.
+        const int tails = tails_env ? atoi(tails_env) : (batch >= 16384u ? ((sizeof(PT) == 4 && batch >= 49152u) ? 4 : 2) : 0);
         if (tails == 2 || tails == 4) {
 #define HTF_TAILS_LAUNCH(ST, RR)                                                                                       \
     HTF_LAUNCH_TIMED((fused_forces_tails_kernel<KIND, ST, RR, PT>), dim3(((batch + RR - 1) / RR + 3) / 4), dim3(256), s, \
