@@ -994,7 +994,7 @@ def test_liquid_configuration_bounds(htf, cuda):
     force = torch.zeros((N, 4), dtype=torch.float32, device=cuda)
     ctx.compute_forces(0, ctx.make_arrays(sysm.pos, N, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, force))
     check("liquid_lj_context", force)
-    # batches and row ranges of the liquid (N = 2 048 < 16 384 rows: the two-row form runs here; the four-rows-per-wave form
+    # batches and row ranges of the liquid (N = 2 048 < 16 384 rows: the plain two-row form runs here; the four-rows-per-wave form
     # with merged tails is asserted against the oracle at its own size in
     # test_full_size_pair_vectors_every_row_bit_exact and test_liquid_at_headline_size): the tensor is bit-identical
     # however the step is cut, forces agree to rounding
@@ -1010,13 +1010,13 @@ def test_liquid_configuration_bounds(htf, cuda):
 
 
 def test_liquid_at_headline_size(htf, cuda):
-    """The equilibrated liquid at 16 384 rows (fcc 16^3), the smallest batch that takes the kernel the bench times
-    (fused_forces_tails_kernel: four rows per wave, merged tails; launch_fused's threshold): 512 sampled rows against the
-    oracle -- energy as stated, forces with the named condition term and within 3x of an independent fp32 evaluation's
-    own error -- with and without the tensor, and from the context."""
-    sysm, nl, L = _liquid(htf, cuda, cells=16, steps=200, seed=10)
+    """The equilibrated liquid at 55 296 rows (fcc 24^3), a batch that takes the kernel the bench times
+    (fused_forces_tails_kernel<LJ, STORE, 4, float>: four rows per wave, merged tails; launch_fused's threshold is 49 152
+    rows): 512 sampled rows against the oracle -- energy as stated, forces with the named condition term and within 3x of
+    an independent fp32 evaluation's own error -- with and without the tensor, and from the context."""
+    sysm, nl, L = _liquid(htf, cuda, cells=24, steps=200, seed=10)
     N, NN = sysm.N, 128
-    assert N == 16384
+    assert N == 55296
     pv = htf.ops.build_pair_vectors(sysm.pos, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, 3.0, NN)
     rows = np.random.default_rng(6).choice(N, 512, replace=False)
     pv32 = pv.cpu().numpy()[rows]
@@ -1244,13 +1244,13 @@ def test_full_size_pair_vectors_every_row_bit_exact(htf, cuda, lattice, cells):
     np.testing.assert_allclose(forces["context_fused2_call1"][::64, 3].double().sum().item(), e_ref, rtol=1e-5)
 
 
-@pytest.mark.parametrize("size", ["two-row form (500 rows)", "four-row form (16384 rows)"])
+@pytest.mark.parametrize("size", ["two-row form (500 rows)", "two rows, merged tails (16384 rows)", "four rows, merged tails (55296 rows)"])
 def test_dropped_candidates_contribute_exact_zeros(htf, cuda, size):
     """The fused kernels evaluate every candidate of a trip, dropped ones too -- at a far point where the potential vanishes
     identically, or with their results selected away (pair_eval_if).  A list whose every candidate lies beyond r_cut must
     therefore leave forces, energies and the tensor EXACTLY zero, for every closed-form potential, in every fused form."""
     from hoomd_tf_amd import standin
-    cells = 5 if size.startswith("two") else 16
+    cells = {"two-row form (500 rows)": 5, "two rows, merged tails (16384 rows)": 16, "four rows, merged tails (55296 rows)": 24}[size]
     pos, L, a = standin.fcc_positions(cells, 0.8442)
     rng = np.random.default_rng(3)
     pos = pos + 0.03 * a * rng.standard_normal(pos.shape)
