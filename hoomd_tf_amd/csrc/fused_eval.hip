@@ -49,6 +49,20 @@ LaunchEvents &launch_events() {
 
 constexpr int kFChunk = 3; // index loads hoisted per lane per trip (as pair_vectors.hip: n_neigh <= 192 in one trip)
 
+// A neighbor's position for the gather-evaluate kernels: x, y, z and the type bits, which are the LOW dword of w -- for fp64
+// positions 28 of the 32 bytes (a 16-B and a 12-B load instead of two 16-B ones: an eighth less data through the texture path
+// that the fp64 wire keeps busiest, one register less per gathered position)
+__device__ __forceinline__ float4 load_neighbor(const float4 *__restrict__ pos, unsigned k) { return pos[k]; }
+__device__ __forceinline__ double4 load_neighbor(const double4 *__restrict__ pos, unsigned k) {
+    const double *p = reinterpret_cast<const double *>(pos + k);
+    double4 r;
+    r.x = p[0];
+    r.y = p[1];
+    r.z = p[2];
+    r.w = __longlong_as_double((long long)(unsigned)reinterpret_cast<const int *>(p)[6]);
+    return r;
+}
+
 struct FusedAcc {
     float fx = 0.f, fy = 0.f, fz = 0.f, en = 0.f;
     Virial6 v;
@@ -414,8 +428,8 @@ __device__ __forceinline__ void fused_rows_group_tails(
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
-        for (int t = 0; t < 2; ++t) q[r][t] = pos[k[r][t]];
-    qt = pos[kt];
+        for (int t = 0; t < 2; ++t) q[r][t] = load_neighbor(pos, k[r][t]);
+    qt = load_neighbor(pos, kt);
     float fx[R], fy[R], fz[R], en[R];
     unsigned npos[R], Q[R];
     // the first 128 entries of every row.  The VALU is the unit this kernel saturates, so: the minimum image without the
@@ -543,8 +557,11 @@ __device__ __forceinline__ void fused_rows_group_tails(
 //  A lane's four survivors then land in consecutive slots and the lanes of one store instruction are ~43 B apart:
 //  245 us with streaming stores, 97 us with ordinary ones, against 61-66; and without the tensor 48.7 against 44.9 --
 //  the index-load instruction count is not what the kernel waits for.  profiles/r02_fused_kernel_ab.txt, batch 11.)
+#ifndef HTF_TAILS_MINB_F64
+#define HTF_TAILS_MINB_F64 1
+#endif
 template <int KIND, bool STORE, int R, typename PT>
-__global__ __launch_bounds__(256) void fused_forces_tails_kernel(
+__global__ __launch_bounds__(256, sizeof(PT) == 8 ? HTF_TAILS_MINB_F64 : 1) void fused_forces_tails_kernel(
     const typename Vec4<PT>::type *__restrict__ pos, unsigned N, unsigned NN, unsigned offset, unsigned batch,
     BoxT<PT> box, const unsigned *__restrict__ n_neigh, const unsigned *__restrict__ nlist,
     const unsigned *__restrict__ head_list, PT rmaxsq, void *__restrict__ force, int out_f64, PotParams pin,

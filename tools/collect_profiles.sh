@@ -1,9 +1,9 @@
 # copy the evidence pass's outputs (gpurun_out/final, scratch) into profiles/ (tracked), named per round
 set -e
-R=${1:-r02}
+R=${1:-r03}
 cd "$(dirname "$0")/.."
 F=gpurun_out/final
-for n in bench_ref_lj256 bench_lj bench_lj_200 bench_lj_f64 bench_wca bench_wca_c2 bench_mlp bench_mlp_bf16 bench_mlp_split bench_mlp_train bench_rehearsal_2ranks_strong_gloo bench_rehearsal_8ranks_strong_gloo bench_rehearsal_2ranks_weak_gloo bench_rehearsal_c5_8ranks_weak_mlptrain_gloo bench_rehearsal_2ranks_strong_torchrun_gloo bench_rehearsal_2ranks_strong_mlp_gloo; do
+for n in bench_ref_lj256 bench_lj bench_lj_200 bench_lj_f64 bench_wca bench_wca_c2 bench_mlp bench_mlp_fp32 bench_mlp_bf16 bench_mlp_split bench_c1 bench_ex01 bench_mlp_train bench_rehearsal_2ranks_strong_gloo bench_rehearsal_8ranks_strong_gloo bench_rehearsal_2ranks_weak_gloo bench_rehearsal_c5_8ranks_weak_mlptrain_gloo bench_rehearsal_2ranks_strong_torchrun_gloo bench_rehearsal_2ranks_strong_mlp_gloo; do
   [ -s $F/$n.json ] && cp $F/$n.json profiles/${R}_$n.json
 done
 cp $F/bench_eds.json profiles/${R}_bench_eds_c4.json
@@ -12,6 +12,8 @@ cp $F/mlp_kernel_stats.csv profiles/${R}_bench_mlp_kernel_stats.csv
 cp $F/mt_kernel_stats.csv profiles/${R}_bench_mlp_train_kernel_stats.csv
 cp $F/eds_kernel_stats.csv profiles/${R}_bench_eds_c4_kernel_stats.csv
 cp $F/c2_kernel_stats.csv profiles/${R}_bench_wca_c2_kernel_stats.csv
+[ -s $F/f64_kernel_stats.csv ] && cp $F/f64_kernel_stats.csv profiles/${R}_bench_lj_f64_kernel_stats.csv
+[ -s $F/fetch_calib.json ] && cp $F/fetch_calib.json profiles/${R}_fetch_calib.json
 cp $F/pmc_hbm.json profiles/${R}_bench_lj_pmc_hbm.json
 cp $F/pmc_lj_kernel.json profiles/${R}_bench_lj_pmc_kernel.json
 cp $F/pmc_mlp.json profiles/${R}_bench_mlp_pmc.json

@@ -4,28 +4,32 @@ set -x
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 F=gpurun_out/final
 mkdir -p $F
-python -m pytest tests -q -m gpu > $F/pytest_gpu.log 2>&1; tail -2 $F/pytest_gpu.log
+timeout 1500 python -m pytest tests -q -m gpu > $F/pytest_gpu.log 2>&1; tail -2 $F/pytest_gpu.log
 python -c "import __graft_entry__ as g; g.smoke()" > $F/smoke.log 2>&1; tail -2 $F/smoke.log
 jl() { grep '^{' | tail -1; }
-python bench.py --steps 20 --warmup 5 2>$F/bench_lj.err | jl > $F/bench_lj.json          # the driver's own command
-python bench.py 2>/dev/null | jl > $F/bench_lj_200.json
-python bench.py --f64 --no-mlp 2>/dev/null | jl > $F/bench_lj_f64.json
-python bench.py --workload wca --no-mlp 2>/dev/null | jl > $F/bench_wca.json
-python bench.py --workload wca --lattice sc --cells 32 2>/dev/null | jl > $F/bench_wca_c2.json
-python bench.py --workload mlp --steps 100 --warmup 10 2>/dev/null | jl > $F/bench_mlp.json
-python bench.py --workload mlp-bf16 --steps 100 --warmup 10 --no-cpu-baseline 2>/dev/null | jl > $F/bench_mlp_bf16.json
-python bench.py --workload mlp-split --steps 100 --warmup 10 --no-cpu-baseline 2>/dev/null | jl > $F/bench_mlp_split.json
-python bench.py --workload mlp-train --steps 400 --warmup 20 --no-cpu-baseline 2>/dev/null | jl > $F/bench_mlp_train.json
-python bench.py --workload eds 2>/dev/null | jl > $F/bench_eds.json
-python bench.py --workload ref-lj256 2>/dev/null | jl > $F/bench_ref_lj256.json          # the one workload the reference publishes a number for
-HTF_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 20 --warmup 5 --no-cpu-baseline --no-fused 2>/dev/null | jl > $F/bench_rehearsal_2ranks_strong_gloo.json
-HTF_BENCH_BACKEND=gloo python bench.py --gpus 8 --steps 20 --warmup 5 --no-cpu-baseline --no-fused 2>/dev/null | jl > $F/bench_rehearsal_8ranks_strong_gloo.json
-HTF_BENCH_BACKEND=gloo python bench.py --gpus 2 --scaling weak --steps 20 --warmup 5 --no-cpu-baseline --no-fused 2>/dev/null | jl > $F/bench_rehearsal_2ranks_weak_gloo.json
+timeout 900 python bench.py --steps 20 --warmup 5 2>$F/bench_lj.err | jl > $F/bench_lj.json          # the driver's own command
+timeout 900 python bench.py 2>/dev/null | jl > $F/bench_lj_200.json
+timeout 900 python bench.py --f64 --no-mlp 2>/dev/null | jl > $F/bench_lj_f64.json
+timeout 900 python bench.py --workload wca --no-mlp 2>/dev/null | jl > $F/bench_wca.json
+timeout 900 python bench.py --workload wca --lattice sc --cells 32 2>/dev/null | jl > $F/bench_wca_c2.json
+timeout 900 python bench.py --workload mlp --steps 100 --warmup 10 2>/dev/null | jl > $F/bench_mlp.json
+timeout 900 python bench.py --workload mlp-fp32 --steps 100 --warmup 10 --no-cpu-baseline 2>/dev/null | jl > $F/bench_mlp_fp32.json
+timeout 900 python bench.py --workload mlp-bf16 --steps 100 --warmup 10 --no-cpu-baseline 2>/dev/null | jl > $F/bench_mlp_bf16.json
+timeout 900 python bench.py --workload c1 2>/dev/null | jl > $F/bench_c1.json          # BASELINE configs[0], both readings
+timeout 900 python bench.py --workload ex01 2>/dev/null | jl > $F/bench_ex01.json
+timeout 900 python bench.py --workload mlp-split --steps 100 --warmup 10 --no-cpu-baseline 2>/dev/null | jl > $F/bench_mlp_split.json
+timeout 900 python bench.py --workload mlp-train --steps 400 --warmup 20 --no-cpu-baseline 2>/dev/null | jl > $F/bench_mlp_train.json
+timeout 900 python bench.py --workload eds 2>/dev/null | jl > $F/bench_eds.json
+timeout 900 python bench.py --workload ref-lj256 2>/dev/null | jl > $F/bench_ref_lj256.json          # the one workload the reference publishes a number for
+HTF_BENCH_WATCHDOG=400 HTF_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 20 --warmup 5 --no-cpu-baseline --no-fused 2>/dev/null | jl > $F/bench_rehearsal_2ranks_strong_gloo.json
+HTF_BENCH_WATCHDOG=400 HTF_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 8 --steps 20 --warmup 5 --no-cpu-baseline --no-fused 2>/dev/null | jl > $F/bench_rehearsal_8ranks_strong_gloo.json
+HTF_BENCH_WATCHDOG=400 HTF_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --scaling weak --steps 20 --warmup 5 --no-cpu-baseline --no-fused 2>/dev/null | jl > $F/bench_rehearsal_2ranks_weak_gloo.json
 # the driver's own launch form for N > 1 (torch.distributed.run), rehearsed the same way
 HTF_BENCH_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 20 --warmup 5 --no-cpu-baseline --no-fused 2>/dev/null | jl > $F/bench_rehearsal_2ranks_strong_torchrun_gloo.json
-HTF_BENCH_BACKEND=gloo python bench.py --gpus 2 --workload mlp --steps 10 --warmup 3 --equil 60 --no-cpu-baseline --no-fused 2>/dev/null | jl > $F/bench_rehearsal_2ranks_strong_mlp_gloo.json
+HTF_BENCH_WATCHDOG=400 HTF_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --workload mlp --steps 10 --warmup 3 --equil 60 --no-cpu-baseline --no-fused 2>/dev/null | jl > $F/bench_rehearsal_2ranks_strong_mlp_gloo.json
 # config 5 at its full size (8 x 131072 = 1.05 M particles, force matching on), the 8 ranks sharing this one GPU
-HTF_BENCH_BACKEND=gloo python bench.py --gpus 8 --scaling weak --workload mlp-train --train-period 10 --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | jl > $F/bench_rehearsal_c5_8ranks_weak_mlptrain_gloo.json
+HTF_BENCH_WATCHDOG=400 HTF_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 8 --scaling weak --workload mlp-train --train-period 10 --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | jl > $F/bench_rehearsal_c5_8ranks_weak_mlptrain_gloo.json
+bash tools/fetch_calib.sh > /dev/null 2>&1; cp gpurun_out/fetch_calib.json $F/fetch_calib.json
 ./tools/gather_probe2 > $F/gather_probe2.txt 2>&1
 ./tools/store_probe > $F/store_probe.txt 2>&1
 # kernel durations: rocprofv3 --kernel-trace --stats of the same commands
@@ -35,7 +39,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_mlp -o mlp -- pyt
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_mt -o mt -- python3 bench.py --workload mlp-train --steps 200 --warmup 10 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_eds -o eds -- python3 bench.py --workload eds > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_c2 -o c2 -- python3 bench.py --workload wca --lattice sc --cells 32 --no-cpu-baseline > /dev/null 2>&1
-for n in lj mlp mt eds c2; do find /tmp/p_$n -name "*kernel_stats.csv" -exec cp {} $F/${n}_kernel_stats.csv \; ; done
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_f64 -o f64 -- python3 bench.py --f64 $Q > /dev/null 2>&1
+for n in lj mlp mt eds c2 f64; do find /tmp/p_$n -name "*kernel_stats.csv" -exec cp {} $F/${n}_kernel_stats.csv \; ; done
 # HBM bytes: FETCH_SIZE and WRITE_SIZE in separate passes (they do not fit one), short runs
 S="--no-cpu-baseline --no-mlp --no-fused --steps 20 --warmup 5 --equil 60 --settle 0 --windows 1"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/c_f -o f -- python3 bench.py $S > /dev/null 2>&1
@@ -77,7 +82,7 @@ for name, d in (("FETCH_SIZE", "/tmp/c_f"), ("WRITE_SIZE", "/tmp/c_w")):
 out["_note"] = ("rocprofv3 --pmc (separate passes) of: bench.py --no-cpu-baseline --no-mlp --no-fused --steps 20 --warmup 5 --equil 60 --windows 1; averages over the "
                 "second half of each kernel's launches.  gfx950: FETCH_SIZE counts 1/2 of wide coalesced reads (MI355X_MICROARCH.md, HBM); WRITE_SIZE exact for 16-B/lane stores.")
 json.dump(out, open(F + "/pmc_hbm.json", "w"), indent=1)
-lj = collect("/tmp/pk_*/**/*counter_collection.csv", want=["fused_forces_tails_kernel<1, true", "fused_forces_rows2_kernel<1, true"])
+lj = collect("/tmp/pk_*/**/*counter_collection.csv", want=["fused_forces_tails_kernel<1, true, 4, float", "fused_forces_rows2_kernel<1, true"])
 json.dump(lj, open(F + "/pmc_lj_kernel.json", "w"), indent=1)
 mlp = collect("/tmp/pm_*/**/*counter_collection.csv", want=["pair_mlp_kernel"])
 trn = collect("/tmp/pt_*/**/*counter_collection.csv", want=["mlp_grad", "pair_mlp_kernel"])
