@@ -538,18 +538,24 @@ class Simulation:
         # The neighbor-row overflow report (a pinned copy inside the captured cycle) is polled EVERY cycle, on the event
         # recorded two replays earlier -- long since complete, so the host still runs two cycles ahead of the device --
         # instead of every 8th cycle: at most 3 check periods run on a truncated list before the RuntimeError.
+        # (an event per replay costs ~4 us of host time: with a one-step cycle -- check_period 1 -- that is every step, so
+        #  the poll runs every `every`-th replay, i.e. at least every 4 steps)
         behind = []
+        every = max(1, -(-4 // cycle))
+        n_replay = 0
         while nsteps >= cycle:
-            if len(behind) >= 2:
+            if n_replay % every == 0 and len(behind) >= 2:
                 nl._stat_event = behind.pop(0)
                 nl._poll_overflow()
             self._graph.replay()
             f._calls = getattr(f, "_calls", 0) + cycle
             s.timestep += cycle
             nsteps -= cycle
-            nl.mark_check_enqueued()
-            behind.append(nl._stat_event)
-            nl._stat_event = None
+            if n_replay % every == 0:
+                nl.mark_check_enqueued()
+                behind.append(nl._stat_event)
+                nl._stat_event = None
+            n_replay += 1
         for ev in behind:
             nl._stat_event = ev
             nl._poll_overflow()
