@@ -394,9 +394,14 @@ __device__ __forceinline__ void fused_rows_group_tails(
     if (!fast || S[R] > 64u) { // (wave-uniform) the plain two-rows-at-a-time form handles everything else
 #pragma unroll
         for (int r = 0; r < R; r += 2)
-            if (w0 + r < batch)
-                fused_rows_group<KIND, STORE, 2, PT>(w0 + r, lane, pos, N, NN, offset, batch, box, n_neigh, nlist, head_list,
-                                                     rmaxsq, force, out_f64, p, check_count, positions_out, dest, counts_io);
+            if (w0 + r < batch) {
+                if (r + 1 < R)
+                    fused_rows_group<KIND, STORE, 2, PT>(w0 + r, lane, pos, N, NN, offset, batch, box, n_neigh, nlist, head_list,
+                                                         rmaxsq, force, out_f64, p, check_count, positions_out, dest, counts_io);
+                else // (an odd group's last row: the row after it belongs to the next wave)
+                    fused_row<KIND, false, STORE, PT>(w0 + r, lane, pos, N, NN, offset, box, n_neigh, nlist, head_list, rmaxsq,
+                                                      force, nullptr, out_f64, p, check_count, positions_out, dest, counts_io);
+            }
         return;
     }
     PV pi[R];
@@ -630,16 +635,18 @@ static int launch_fused(const void *pos, unsigned N, unsigned NN, unsigned offse
         // (tools/valu_rate_probe.hip); what the fp64 wire costs is the second 16-B gather instruction per candidate.
         // Round 3, 32 000 rows (C2): two rows 18.5 us, four rows 19.1, plain two-row form 19.4; 62 500 rows: 31.7 / 31.6 -- half
         // as many waves on a grid that fills the chip only twice is what the four-row form loses there, so it starts at 49 152.
-        const int tails = tails_env ? atoi(tails_env) : (batch >= 16384u ? ((sizeof(PT) == 4 && batch >= 49152u) ? 4 : 2) : 0);
-        if (tails == 2 || tails == 4) {
+        // fp64 positions, after the 28-byte neighbor loads (one register less per gathered position): two / three / four rows
+        // 68.0-68.8 / 66.1-67.2 / 66.6-67.0 us on one box -- the four-row form for both precisions.
+        const int tails = tails_env ? atoi(tails_env) : (batch >= 16384u ? (batch >= 49152u ? 4 : 2) : 0);
+        if (tails == 2 || tails == 3 || tails == 4) {
 #define HTF_TAILS_LAUNCH(ST, RR)                                                                                       \
     HTF_LAUNCH_TIMED((fused_forces_tails_kernel<KIND, ST, RR, PT>), dim3(((batch + RR - 1) / RR + 3) / 4), dim3(256), s, \
                        (const typename Vec4<PT>::type *)pos, N, NN, offset, batch, b, n_neigh, nlist, head_list,       \
                        (PT)(rc * rc), force, out_f64, p, check_count, positions_out, dest, counts_io)
             if (dest != nullptr) {
-                if (tails == 2) HTF_TAILS_LAUNCH(true, 2); else HTF_TAILS_LAUNCH(true, 4);
+                if (tails == 2) HTF_TAILS_LAUNCH(true, 2); else if (tails == 3) HTF_TAILS_LAUNCH(true, 3); else HTF_TAILS_LAUNCH(true, 4);
             } else {
-                if (tails == 2) HTF_TAILS_LAUNCH(false, 2); else HTF_TAILS_LAUNCH(false, 4);
+                if (tails == 2) HTF_TAILS_LAUNCH(false, 2); else if (tails == 3) HTF_TAILS_LAUNCH(false, 3); else HTF_TAILS_LAUNCH(false, 4);
             }
 #undef HTF_TAILS_LAUNCH
             return check_launch("fused_forces_tails_kernel");
