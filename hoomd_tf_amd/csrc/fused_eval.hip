@@ -693,6 +693,9 @@ static int launch_fused_k(const void *pos, int pos_dtype, unsigned N, unsigned N
 // replay here: only the NN survivors q >= Q - NN are stored / evaluated, each into its own slot
 // q % NN.  Persistent blocks: the LDS histogram is flushed once per block.
 constexpr unsigned kRdfMaxBins2 = 1024;
+#ifndef HTF_FUSED2_ROWS_DEFAULT
+#define HTF_FUSED2_ROWS_DEFAULT 2
+#endif
 
 struct Rdf2 {
     float r0, r1;
@@ -1055,6 +1058,368 @@ __global__ __launch_bounds__(256) void fused_forces2_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------- the C4 sweep, R rows per wave, tails merged
+// Round 3.  The structure of fused_rows_group_tails (3.1) with the second potential, the CV row sums and the histogram added:
+// the first 128 list entries of each of the wave's R rows as straight-line code, the R tails in ONE trip -- 9 trips per four
+// rows, every one of them doing the pair vector, both potentials from one rinv_fwd and the bin of its kept candidates, where
+// the compacting form walks 12 gather trips and 8 evaluation trips through an LDS row.  (Round 2 built this form once and it
+// LOST at 128 VGPRs -- before the sweep's instruction diet; after it the per-trip code is ~85 VALU instructions and the
+// accumulators are what the registers go to.)  Persistent workgroups as the compacting kernel (the LDS histogram is flushed
+// once per workgroup); one CV partial per workgroup in wave order -> deterministic.  Rows the straight-line path does not
+// cover (> 192 list entries, NN overflow, a non-orthorhombic or non-periodic box, an incomplete group) go through ONE
+// generic single-row routine.
+struct Sweep2 {
+    PotParams pa, pb;
+    float *edge;      // LDS: bin thresholds on the squared norm (address 0 of the block's LDS)
+    unsigned *hist;   // LDS histogram
+    float r0, scale, bias;
+    int nb, pad_bin;
+    bool do_rdf, coarse;
+    unsigned n_lo, n_hi; // padded slots that fall into the first / last bin, counted in registers
+    float cv_wave;       // sum of the B energy column over this wave's rows, in row order
+};
+
+__device__ __forceinline__ void sweep2_bin(const Sweep2 &st, float x, float y, float z, float rp, unsigned delta = 1u) {
+    const float sq = plain_sq3(x, y, z);
+    float rg = rp;
+    if (!st.coarse) { // wave-uniform
+        asm volatile("" ::: "memory");
+        rg = __builtin_amdgcn_sqrtf(sq);
+    }
+    int idx;
+    const float qf = fmaf(rg, st.scale, st.bias);
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(idx) : "v"(qf));
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(idx) : "v"(idx), "s"(st.nb - 1));
+    const unsigned off = (unsigned)idx << 2;
+    const float e0 = *(const float *)((const char *)st.edge + off), e1 = *(const float *)((const char *)st.edge + off + 4);
+    const unsigned off2 = off + (sq >= e1 ? 4u : 0u) + (sq < e0 ? (unsigned)-4 : 0u);
+    atomicAdd((unsigned *)((char *)st.hist + off2), delta);
+}
+
+// both potentials of one candidate from ONE rinv_fwd; a dropped candidate is evaluated far out, where both vanish exactly
+template <int KA>
+__device__ __forceinline__ void sweep2_eval(const Sweep2 &st, bool keep, float x, float y, float z, float &ax, float &ay, float &az,
+                                            float &ae, float &bx, float &by, float &bz, float &be) {
+    static_assert(KA == HTF_POT_LJ || KA == HTF_POT_WCA || KA == HTF_POT_LJ_PARAM, "base potentials that vanish identically far out");
+    const float xe = keep ? x : 1e18f;
+    float e, fx, fy, fz;
+    if constexpr (KA == HTF_POT_LJ_PARAM) {
+        pair_eval_f<KA>(RinvFwd(), xe, y, z, st.pa, e, fx, fy, fz);
+        ax += fx; ay += fy; az += fz; ae += e;
+        const RinvFwd f = rinv_fwd(xe, y, z);
+        pair_eval_f<HTF_POT_GAUSS>(f, xe, y, z, st.pb, e, fx, fy, fz);
+        bx += fx; by += fy; bz += fz; be += e;
+        if (st.do_rdf && keep) sweep2_bin(st, x, y, z, f.rp);
+    } else {
+        const RinvFwd f = rinv_fwd(xe, y, z);
+        pair_eval_f<KA>(f, xe, y, z, st.pa, e, fx, fy, fz);
+        ax += fx; ay += fy; az += fz; ae += e;
+        pair_eval_f<HTF_POT_GAUSS>(f, xe, y, z, st.pb, e, fx, fy, fz);
+        bx += fx; by += fy; bz += fz; be += e;
+        if (st.do_rdf && keep) sweep2_bin(st, x, y, z, f.rp);
+    }
+}
+
+__device__ __forceinline__ void sweep2_finish_row(Sweep2 &st, unsigned w, unsigned lane, unsigned NN, unsigned filled, float ax, float ay,
+                                                  float az, float ae, float bx, float by, float bz, float be, void *__restrict__ forceA,
+                                                  void *__restrict__ forceB, int out_f64) {
+    if (st.do_rdf && lane == 0 && filled < NN) { // the row's zero padding is part of compute_rdf's input
+        const unsigned npad = NN - filled;
+        if (st.pad_bin == 0) st.n_lo += npad;
+        else if (st.pad_bin == st.nb - 1) st.n_hi += npad;
+        else atomicAdd(&st.hist[st.pad_bin], npad);
+    }
+    const float ta = wave_sum4(ax, ay, az, ae), tb = wave_sum4(bx, by, bz, be); // rows 0..3 of each: x, z, y, e
+    if ((lane & 15u) == 0u) {
+        const unsigned comp = ((lane >> 4) & 1u) * 2u + (lane >> 5); // 0, 2, 1, 3
+        if (out_f64) {
+            ((double *)forceA)[(size_t)w * 4 + comp] = (double)ta;
+            ((double *)forceB)[(size_t)w * 4 + comp] = (double)tb;
+        } else {
+            ((float *)forceA)[(size_t)w * 4 + comp] = ta;
+            ((float *)forceB)[(size_t)w * 4 + comp] = tb;
+        }
+    }
+    st.cv_wave += __shfl(tb, 48);
+}
+
+// any row: counting pass, then the evaluating pass over the NN survivors the reference's slot wrap keeps (fused_forces2_kernel's
+// long-row path as a routine)
+template <int KA, bool STORE, typename PT>
+__device__ __forceinline__ void sweep2_row_generic(Sweep2 &st, const unsigned w, const unsigned lane,
+                                                const typename Vec4<PT>::type *__restrict__ pos, unsigned NN, unsigned offset,
+                                                const BoxT<PT> &box, const unsigned *__restrict__ n_neigh,
+                                                const unsigned *__restrict__ nlist, const unsigned *__restrict__ head_list, PT rmaxsq,
+                                                void *__restrict__ forceA, void *__restrict__ forceB, int out_f64,
+                                                float4 *__restrict__ dest, unsigned *__restrict__ counts_io) {
+    using PV = typename Vec4<PT>::type;
+    const unsigned idx = w + offset;
+    const unsigned nn = n_neigh[idx];
+    const unsigned *nl = nlist + head_list[idx];
+    const PV pi = pos[idx];
+    float4 *row = STORE ? dest + (size_t)w * NN : nullptr;
+    unsigned Q = 0;
+    for (unsigned base = 0; base < nn; base += 64) {
+        const unsigned j = base + lane;
+        const PV pk = pos[nl[j < nn ? j : nn - 1]];
+        PT dx, dy, dz;
+        const PT rsq = pair_vector<PT>(pk, pi, box, dx, dy, dz);
+        Q += __popcll(__ballot((j < nn) && !(rsq > rmaxsq)));
+    }
+    const unsigned lo = Q > NN ? Q - NN : 0u;
+    float ax = 0.f, ay = 0.f, az = 0.f, ae = 0.f, bx = 0.f, by = 0.f, bz = 0.f, be = 0.f;
+    unsigned Q2 = 0;
+    for (unsigned base = 0; base < nn; base += 64) {
+        const unsigned j = base + lane;
+        const PV pk = pos[nl[j < nn ? j : nn - 1]];
+        PT dx, dy, dz;
+        const PT rsq = pair_vector<PT>(pk, pi, box, dx, dy, dz);
+        const bool kp = (j < nn) && !(rsq > rmaxsq);
+        const unsigned long long m = __ballot(kp);
+        const unsigned qq = Q2 + ballot_rank(m);
+        Q2 += __popcll(m);
+        const bool use = kp && qq >= lo;
+        const float x = (float)dx, y = (float)dy, z = (float)dz;
+        if constexpr (STORE)
+            if (use) store_stream(&row[qq % NN], make_float4(x, y, z, (float)scalar_as_int(pk.w)));
+        sweep2_eval<KA>(st, use, x, y, z, ax, ay, az, ae, bx, by, bz, be);
+    }
+    const unsigned filled = Q < NN ? Q : NN;
+    if constexpr (STORE) {
+        const unsigned zero_end = counts_io != nullptr ? counts_io[w] : NN;
+        for (unsigned sl = filled + lane; sl < zero_end; sl += 64) store_stream(&row[sl], make_float4(0.f, 0.f, 0.f, 0.f));
+        if (counts_io != nullptr && lane == 0) counts_io[w] = filled;
+    }
+    sweep2_finish_row(st, w, lane, NN, filled, ax, ay, az, ae, bx, by, bz, be, forceA, forceB, out_f64);
+}
+
+template <int KA, bool STORE, int R, typename PT>
+__device__ __forceinline__ void sweep2_rows_group_tails(Sweep2 &st, const unsigned w0, const unsigned lane,
+                                                        const typename Vec4<PT>::type *__restrict__ pos, unsigned NN, unsigned offset,
+                                                        unsigned batch, const BoxT<PT> &box, bool simple_box,
+                                                        const unsigned *__restrict__ n_neigh, const unsigned *__restrict__ nlist,
+                                                        const unsigned *__restrict__ head_list, PT rmaxsq, void *__restrict__ forceA,
+                                                        void *__restrict__ forceB, int out_f64, float4 *__restrict__ dest,
+                                                        unsigned *__restrict__ counts_io) {
+    using PV = typename Vec4<PT>::type;
+    unsigned nn[R], S[R + 1];
+    bool fast = w0 + R <= batch && simple_box;
+    S[0] = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        nn[r] = n_neigh[(w0 + r < batch ? w0 + r : w0) + offset];
+        fast = fast && nn[r] != 0 && nn[r] <= 192u;
+        S[r + 1] = S[r] + (nn[r] > 128u ? nn[r] - 128u : 0u);
+    }
+    if (!fast || S[R] > 64u) { // (wave-uniform)
+#pragma unroll 1
+        for (unsigned r = 0; r < (unsigned)R; ++r)
+            if (w0 + r < batch)
+                sweep2_row_generic<KA, STORE, PT>(st, w0 + r, lane, pos, NN, offset, box, n_neigh, nlist, head_list, rmaxsq, forceA, forceB,
+                                                  out_f64, dest, counts_io);
+        return;
+    }
+    PV pi[R];
+    unsigned head[R];
+    unsigned k[R][2], kt;
+    PV q[R][2], qt;
+    unsigned rl = 0;
+#pragma unroll
+    for (int r = 1; r < R; ++r) rl += lane >= S[r] ? 1u : 0u;
+    unsigned head_l = 0, s_l = 0, nn_l = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        head[r] = head_list[w0 + r + offset];
+        pi[r] = pos[w0 + r + offset];
+        const unsigned *nl = nlist + head[r];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const unsigned j = t * 64 + lane;
+            k[r][t] = nl[min(j, nn[r] - 1u)];
+        }
+        head_l = rl == (unsigned)r ? head[r] : head_l;
+        s_l = rl == (unsigned)r ? S[r] : s_l;
+        nn_l = rl == (unsigned)r ? nn[r] : nn_l;
+    }
+    const bool tail_live = lane < S[R];
+    const unsigned jt = 128u + (lane - s_l);
+    kt = nlist[head_l + (tail_live ? jt : nn_l - 1)];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) q[r][t] = load_neighbor(pos, k[r][t]);
+    qt = load_neighbor(pos, kt);
+    float ax[R], ay[R], az[R], ae[R], bx[R], by[R], bz[R], be[R];
+    unsigned Q[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        float4 *row = STORE ? dest + (size_t)(w0 + r) * NN : nullptr;
+        ax[r] = ay[r] = az[r] = ae[r] = bx[r] = by[r] = bz[r] = be[r] = 0.f;
+        Q[r] = 0;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if ((unsigned)t * 64 >= nn[r]) break; // wave-uniform
+            const unsigned left = nn[r] - (unsigned)t * 64;
+            const unsigned long long valid = left >= 64u ? ~0ull : ((1ull << left) - 1ull);
+            const PV pk = q[r][t];
+            PT dx, dy, dz;
+            const PT rsq = pair_vector_simple<PT>(pk, pi[r], box, dx, dy, dz);
+            const unsigned long long m = ballot64(!(rsq > rmaxsq)) & valid;
+            const unsigned qq = Q[r] + ballot_rank(m);
+            Q[r] += __popcll(m);
+            const bool keep = __builtin_amdgcn_inverse_ballot_w64(m);
+            const float x = (float)dx, y = (float)dy, z = (float)dz;
+            if constexpr (STORE) {
+                unsigned long long ms = m;
+                if (Q[r] > NN) { // (wave-uniform) about to overflow: slots bounded lane by lane; the row is redone below
+                    asm volatile("" ::: "memory");
+                    ms &= ballot64(qq < NN);
+                }
+                if (__builtin_amdgcn_inverse_ballot_w64(ms)) store_stream(&row[qq], make_float4(x, y, z, (float)scalar_as_int(pk.w)));
+            }
+            sweep2_eval<KA>(st, keep, x, y, z, ax[r], ay[r], az[r], ae[r], bx[r], by[r], bz[r], be[r]);
+        }
+    }
+    if (S[R] != 0) { // the shared tail trip
+        PV pil = pi[0];
+#pragma unroll
+        for (int r = 1; r < R; ++r) {
+            pil.x = rl == (unsigned)r ? pi[r].x : pil.x;
+            pil.y = rl == (unsigned)r ? pi[r].y : pil.y;
+            pil.z = rl == (unsigned)r ? pi[r].z : pil.z;
+        }
+        PT dx, dy, dz;
+        const PT rsq = pair_vector_simple<PT>(qt, pil, box, dx, dy, dz);
+        const unsigned long long m = ballot64(!(rsq > rmaxsq)) & (S[R] >= 64u ? ~0ull : ((1ull << S[R]) - 1ull));
+        unsigned base_l = Q[0];
+#pragma unroll
+        for (int r = 1; r < R; ++r) {
+            const unsigned before = (unsigned)__popcll(S[r] >= 64u ? m : (m & ((1ull << S[r]) - 1ull)));
+            base_l = rl == (unsigned)r ? Q[r] - before : base_l;
+        }
+        const unsigned qq = base_l + ballot_rank(m);
+        const bool keep = __builtin_amdgcn_inverse_ballot_w64(m);
+        const float xt = (float)dx, yt = (float)dy, zt = (float)dz;
+        if constexpr (STORE)
+            if (keep && qq < NN) store_stream(dest + (size_t)(w0 + rl) * NN + qq, make_float4(xt, yt, zt, (float)scalar_as_int(qt.w)));
+        float tax = 0.f, tay = 0.f, taz = 0.f, tae = 0.f, tbx = 0.f, tby = 0.f, tbz = 0.f, tbe = 0.f;
+        sweep2_eval<KA>(st, keep, xt, yt, zt, tax, tay, taz, tae, tbx, tby, tbz, tbe);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const bool mine = rl == (unsigned)r;
+            ax[r] += mine ? tax : 0.f; ay[r] += mine ? tay : 0.f; az[r] += mine ? taz : 0.f; ae[r] += mine ? tae : 0.f;
+            bx[r] += mine ? tbx : 0.f; by[r] += mine ? tby : 0.f; bz[r] += mine ? tbz : 0.f; be[r] += mine ? tbe : 0.f;
+            const unsigned long long seg = (S[r + 1] >= 64u ? ~0ull : ((1ull << S[r + 1]) - 1ull)) & ~(S[r] >= 64u ? ~0ull : ((1ull << S[r]) - 1ull));
+            Q[r] += (unsigned)__popcll(m & seg);
+        }
+    }
+    unsigned redo = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const unsigned w = w0 + r;
+        const unsigned filled = Q[r] < NN ? Q[r] : NN;
+        if (Q[r] > NN) { // overflow (an error upstream): the generic routine reproduces the slot wrap -- and its histogram
+            redo |= 1u << r;
+            continue;
+        }
+        if constexpr (STORE) {
+            float4 *row = dest + (size_t)w * NN;
+            const unsigned zero_end = counts_io != nullptr ? counts_io[w] : NN;
+            for (unsigned sl = filled + lane; sl < zero_end; sl += 64) store_stream(&row[sl], make_float4(0.f, 0.f, 0.f, 0.f));
+            if (counts_io != nullptr && lane == 0) counts_io[w] = filled;
+        }
+        sweep2_finish_row(st, w, lane, NN, filled, ax[r], ay[r], az[r], ae[r], bx[r], by[r], bz[r], be[r], forceA, forceB, out_f64);
+    }
+    if (redo != 0) {
+#pragma unroll 1
+        for (unsigned r = 0; r < (unsigned)R; ++r)
+            if ((redo >> r) & 1u) {
+                if constexpr (STORE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (st.do_rdf) {
+                    // the straight-line path has binned EVERY kept candidate of this row before its overflow was known: take them
+                    // out again (the generic routine then bins the NN survivors of the slot wrap)
+                    const unsigned idx = w0 + r + offset;
+                    const unsigned nnr = n_neigh[idx];
+                    const unsigned *nl = nlist + head_list[idx];
+                    const PV pc = pos[idx];
+                    for (unsigned base = 0; base < nnr; base += 64) {
+                        const unsigned j = base + lane;
+                        const PV pk = pos[nl[j < nnr ? j : nnr - 1]];
+                        PT dx, dy, dz;
+                        const PT rsq = pair_vector_simple<PT>(pk, pc, box, dx, dy, dz);
+                        if ((j < nnr) && !(rsq > rmaxsq)) {
+                            const float x = (float)dx, y = (float)dy, z = (float)dz;
+                            sweep2_bin(st, x, y, z, rinv_fwd(x, y, z).rp, 0xFFFFFFFFu);
+                        }
+                    }
+                }
+                sweep2_row_generic<KA, STORE, PT>(st, w0 + r, lane, pos, NN, offset, box, n_neigh, nlist, head_list, rmaxsq, forceA, forceB,
+                                                  out_f64, dest, counts_io);
+            }
+    }
+}
+
+template <int KA, bool STORE, int R, typename PT>
+__global__ __launch_bounds__(256) void fused_forces2_tails_kernel(
+    const typename Vec4<PT>::type *__restrict__ pos, unsigned N, unsigned NN, unsigned offset, unsigned batch,
+    BoxT<PT> box, const unsigned *__restrict__ n_neigh, const unsigned *__restrict__ nlist,
+    const unsigned *__restrict__ head_list, PT rmaxsq, void *__restrict__ forceA, void *__restrict__ forceB,
+    int out_f64, PotParams pa_in, PotParams pb, float *__restrict__ partials, Rdf2 rdf,
+    float4 *__restrict__ dest, unsigned *__restrict__ counts_io) {
+    struct Lds {
+        float edge[kRdfMaxBins2 + 4];
+        unsigned hist[kRdfMaxBins2];
+        float part[4];
+    };
+    __shared__ __attribute__((aligned(16))) Lds lds;
+    Sweep2 st;
+    st.pa = resolve_theta<KA>(pa_in);
+    st.pb = pb;
+    st.edge = lds.edge;
+    st.hist = lds.hist;
+    st.do_rdf = rdf.hist != nullptr;
+    if (st.do_rdf) {
+        for (unsigned i = threadIdx.x; i < rdf.nb; i += blockDim.x) lds.hist[i] = 0;
+        for (unsigned i = threadIdx.x; i <= rdf.nb; i += blockDim.x) lds.edge[i] = rdf.edges[i];
+        __syncthreads();
+    }
+    st.r0 = rdf.r0;
+    st.nb = (int)rdf.nb;
+    st.scale = st.do_rdf ? (float)rdf.nb / (rdf.r1 - rdf.r0) : 0.f;
+    st.bias = -rdf.r0 * st.scale;
+    st.coarse = st.do_rdf && (rdf.r1 - rdf.r0) >= 1e-4f * (float)rdf.nb;
+    st.pad_bin = 0;
+    if (st.do_rdf) {
+        const float fi = floorf((float)rdf.nb * ((0.f - rdf.r0) / (rdf.r1 - rdf.r0)));
+        st.pad_bin = fi < 0.f ? 0 : (fi > (float)(rdf.nb - 1) ? (int)(rdf.nb - 1) : (int)fi);
+    }
+    st.n_lo = st.n_hi = 0;
+    st.cv_wave = 0.f;
+    const unsigned lane = threadIdx.x & 63u, wb = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool simple_box = box.ortho && box.periodic[0] && box.periodic[1] && box.periodic[2];
+    const unsigned ngroups = (batch + R - 1) / R;
+    const unsigned wv = blockIdx.x * 4 + wb, nw = gridDim.x * 4;
+#pragma unroll 1
+    for (unsigned g = wv; g < ngroups; g += nw)
+        sweep2_rows_group_tails<KA, STORE, R, PT>(st, R * g, lane, pos, NN, offset, batch, box, simple_box, n_neigh, nlist, head_list,
+                                                  rmaxsq, forceA, forceB, out_f64, dest, counts_io);
+    if (partials != nullptr) { // one partial per workgroup, waves in a fixed order -> deterministic
+        if (lane == 0) lds.part[wb] = st.cv_wave;
+        __syncthreads();
+        if (threadIdx.x == 0) partials[blockIdx.x] = (lds.part[0] + lds.part[1]) + (lds.part[2] + lds.part[3]);
+    }
+    if (st.do_rdf) {
+        const unsigned n_lo = group_sum_u<64>(st.n_lo), n_hi = group_sum_u<64>(st.n_hi);
+        if (lane == 0) {
+            if (n_lo) atomicAdd(&lds.hist[0], n_lo);
+            if (n_hi) atomicAdd(&lds.hist[rdf.nb - 1], n_hi);
+        }
+        __syncthreads();
+        for (unsigned i = threadIdx.x; i < rdf.nb; i += blockDim.x)
+            if (lds.hist[i]) atomicAdd(&rdf.hist[i], lds.hist[i]);
+    }
+}
+
 // (Measured and removed, commit 17bc8a6: this sweep in the four-rows-per-wave form of fused_rows_group_tails -- all pair vectors
 //  and ballots of a group first, so that an overflowing row is known before anything is stored or binned, then 9 evaluation
 //  trips per four rows instead of 12 and no LDS round trip; same tensor, histogram and forces (the 16 C4 / EDS / RDF parity
@@ -1080,6 +1445,25 @@ static int launch_fused2(const PotParams &pa, const PotParams &pb, const void *p
     const unsigned grid = fused_forces2_num_partials(batch);
     static const char *cenv = getenv("HTF_FUSED2_COMPACT"); // A/B runs: 0 = evaluate the candidates in place
     const bool compact = NN <= 128 && (cenv ? atoi(cenv) != 0 : true);
+    // HTF_FUSED2_ROWS = 4 | 2: the rows-per-wave form with merged tails (fp32 positions and the base potentials that vanish
+    // far out); 0: the compacting persistent kernel
+    static const char *renv = getenv("HTF_FUSED2_ROWS");
+    const int rows = renv ? atoi(renv) : HTF_FUSED2_ROWS_DEFAULT;
+    if constexpr (sizeof(PT) == 4 && (KA == HTF_POT_LJ || KA == HTF_POT_WCA || KA == HTF_POT_LJ_PARAM)) {
+        if (rows == 2 || rows == 4) {
+#define HTF_F2T_LAUNCH(ST, RR)                                                                                         \
+    hipLaunchKernelGGL((fused_forces2_tails_kernel<KA, ST, RR, PT>), dim3(grid), dim3(256), 0, s,                      \
+                       (const typename Vec4<PT>::type *)pos, N, NN, offset, batch, b, n_neigh, nlist, head_list,       \
+                       (PT)(rc * rc), fa, fb, out_f64, pa, pb, partials, rdf, dest, counts_io)
+            if (dest != nullptr) {
+                if (rows == 2) HTF_F2T_LAUNCH(true, 2); else HTF_F2T_LAUNCH(true, 4);
+            } else {
+                if (rows == 2) HTF_F2T_LAUNCH(false, 2); else HTF_F2T_LAUNCH(false, 4);
+            }
+#undef HTF_F2T_LAUNCH
+            return check_launch("fused_forces2_tails_kernel");
+        }
+    }
 #define HTF_F2_LAUNCH(ST, CP)                                                                                          \
     hipLaunchKernelGGL((fused_forces2_kernel<KA, ST, CP, PT>), dim3(grid), dim3(256), 0, s,                            \
                        (const typename Vec4<PT>::type *)pos, N, NN, offset, batch, b, n_neigh, nlist, head_list,       \

@@ -697,7 +697,9 @@ def test_build_eval_forces2_equals_build_then_eval2(htf, cuda, hdt, NN):
     fa2, fb2 = htf.ops.build_eval_forces2(lj, gauss, p4, dnn, dhead, dnl, box, 3.0, NN)
     assert torch.equal(fa2, fa1) and torch.equal(fb2, fb1)
     fa3, _ = htf.ops.build_eval_forces2(lj, gauss, p4, dnn, dhead, dnl, box, 3.0, NN, offset=5, batch_size=30)
-    assert torch.equal(fa3, fa1[5:35])
+    # (the rows-per-wave form merges the tails of a wave's rows into one trip: a row's partial sums then depend on which rows
+    #  share its wave, i.e. on where the batch starts -- summation-order rounding, as for the LJ step)
+    assert float((fa3 - fa1[5:35]).abs().max()) <= 2e-6 * max(1.0, float(fa1.abs().max()))
     with pytest.raises(ValueError):
         htf.ops.build_eval_forces2(lj, lj, p4, dnn, dhead, dnl, box, 3.0, NN)
 
