@@ -185,11 +185,14 @@ def _flat_params(params):
     return np.concatenate([np.asarray(params[k], dtype=np.float64).ravel() for k in ("W1", "b1", "W2", "b2", "W3", "b3")])
 
 
+@pytest.mark.parametrize("precision", ["fp32", "split16"])
 @pytest.mark.parametrize("dims,act,NN", [((32, 64, 64), "tanh", 24), ((12, 20, 28), "tanh", 24), ((32, 64, 64), "linear", 24),
                                          ((32, 64, 64), "tanh", 72), ((32, 64, 64), "tanh", 128)])
-def test_pair_mlp_loss_gradient_matches_double_backward(htf, cuda, dims, act, NN):
+def test_pair_mlp_loss_gradient_matches_double_backward(htf, cuda, dims, act, NN, precision):
     """One sweep (value + r-tangent forward, one reverse) == torch's double backward through
-    the force, for every one of the 6337 weights; ragged widths exercise the zero padding."""
+    the force, for every one of the 6337 weights; ragged widths exercise the zero padding.
+    ``precision``: "fp32" -> mlp_grad_mfma_kernel (fp32 MFMA); "split16" (the default of htf.PairMLP) -> mlp_grad_f16_kernel,
+    the same sweep on the fp16 pipeline with hi + lo operands -- same tolerances."""
     from hoomd_tf_amd import initializers
     K, H1, H2 = dims
     # NN = 72 (3 tiles per row) takes the two-pass route (evaluator, then gradient kernel);
@@ -203,7 +206,7 @@ def test_pair_mlp_loss_gradient_matches_double_backward(htf, cuda, dims, act, NN
     theta = _flat_params(params)
     labels = O.lj_model(nl64) * 0.05
     w = torch.tensor(theta, dtype=torch.float32, device=cuda)
-    pot = htf.Potential.pair_mlp(params, 0.0, 3.0, activation=act, theta=w)
+    pot = htf.Potential.pair_mlp(params, 0.0, 3.0, activation=act, theta=w, precision=precision)
     assert pot.num_params == theta.size == K * H1 + H1 + H1 * H2 + 2 * H2 + 1
     x = torch.from_numpy(nl).to(cuda)
     pred = torch.empty((nl.shape[0], 4), device=cuda)
@@ -227,11 +230,13 @@ def test_pair_mlp_loss_gradient_matches_double_backward(htf, cuda, dims, act, NN
         o += n
 
 
-@pytest.mark.parametrize("route", ["valu", "nofuse", "bf16-images", "split-images"])
+@pytest.mark.parametrize("route", ["valu", "nofuse", "bf16-images", "split-images", "split16-f16-sweep", "split16-fp32-sweep",
+                                   "split16-nofuse"])
 def test_pair_mlp_gradient_alternate_routes(htf, cuda, route, monkeypatch):
     """The first-generation VALU kernel (HTF_MLP_TRAIN_VALU), the two-pass matrix-core route
-    (HTF_MLP_TRAIN_NOFUSE) and bf16- / split-image potentials (which train on their own fp32 image
-    set) all give the default route's loss gradient."""
+    (HTF_MLP_TRAIN_NOFUSE), bf16- / split-image potentials (which train on their own fp32 image
+    set) and the split16 potential -- fp16-pipeline sweep from the evaluator's images, fused and two-pass, or
+    (HTF_MLP_TRAIN_FP32) the fp32 sweep -- all give the default route's loss gradient."""
     from hoomd_tf_amd import initializers
     nl = _case(8, N=33, NN=40)
     params = initializers.mlp_params(seed=12)
@@ -253,10 +258,18 @@ def test_pair_mlp_gradient_alternate_routes(htf, cuda, route, monkeypatch):
         got = grad()
     elif route == "split-images":
         got = grad("split")
+    elif route == "split16-f16-sweep":
+        got = grad("split16")
+    elif route == "split16-fp32-sweep":
+        monkeypatch.setenv("HTF_MLP_TRAIN_FP32", "1")
+        got = grad("split16")
+    elif route == "split16-nofuse":
+        monkeypatch.setenv("HTF_MLP_TRAIN_NOFUSE", "1")
+        got = grad("split16")
     else:
         got = grad("bf16")
     scale = np.abs(base[1:]).max()
-    assert np.abs(got[1:] - base[1:]).max() < 5e-5 * scale
+    assert np.abs(got[1:] - base[1:]).max() < 5e-5 * scale, np.abs(got[1:] - base[1:]).max() / scale
     np.testing.assert_allclose(got[0], base[0], rtol=1e-5)
 
 
@@ -333,8 +346,9 @@ def test_pair_mlp_force_matching_online(htf, cuda):
     np.testing.assert_array_equal(got, want)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "split16"])
 @pytest.mark.parametrize("seed", range(6))
-def test_pair_mlp_gradient_random_shapes(htf, cuda, seed):
+def test_pair_mlp_gradient_random_shapes(htf, cuda, seed, precision):
     """Random widths (zero-padded operand blocks), NN (fused / two-pass route), activation and label
     precision against torch double backward."""
     from hoomd_tf_amd import initializers
@@ -352,7 +366,7 @@ def test_pair_mlp_gradient_random_shapes(htf, cuda, seed):
     labels = O.lj_model(nl64) * 0.05
     lab = torch.from_numpy(labels if rng.integers(0, 2) else labels.astype(np.float32)).to(cuda)
     w = torch.tensor(theta, dtype=torch.float32, device=cuda)
-    pot = htf.Potential.pair_mlp(params, 0.0, 3.0, activation=act, theta=w)
+    pot = htf.Potential.pair_mlp(params, 0.0, 3.0, activation=act, theta=w, precision=precision)
     accum = htf.ops.train_pair_grad(pot, torch.from_numpy(nl).to(cuda), lab).cpu().numpy()
     dims = (K, H1, H2)
     loss, g = G.mse_grad_wrt_params(lambda n, ww: G.pair_mlp_param_forces(n, ww, dims, act=act, create_graph=True),
