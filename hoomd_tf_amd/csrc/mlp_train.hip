@@ -586,7 +586,7 @@ __device__ __forceinline__ float act_scaled(float a) {
 constexpr int kHS = 40;          // published row stride in halfs (80 B)
 constexpr int kHP = 32 * kHS;    // one plane: 32 feature rows
 constexpr int kHB = 2 * kHP;     // one published block: hi plane, lo plane (5120 B)
-constexpr int kSlots16 = 4;      // per wave: A0 A1 | B0 B1  (80 KB + 49 KB of images)
+constexpr int kSlots16 = 5;      // per wave: A0 A1 | B0 B1 | phi  (100 KB + 49 KB of images)
 
 __device__ __forceinline__ void mfma_pair16(f32x16 &acc0, f32x16 &acc1, const float *img, unsigned lane, const Op16 &p0, const Op16 &p1) {
     const f16x8 *p = reinterpret_cast<const f16x8 *>(img) + lane; // [part 2: hi, lo][s 2][lane 64]
@@ -650,8 +650,8 @@ __device__ __forceinline__ float sum_op16(const Op16 &o) {
 // x = hi + lo in fp16, hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 -- 12 MFMAs of 32 cycles per (32 x 32 block, value +
 // tangent) where the fp32 form issues 32 of 64, and for the pair-contracted weight gradients 6 where it issues 16: 192
 // MFMAs x 32 cycles per tile instead of 512 x 64.  Operands are published to LDS as fp16 hi / lo planes ([feature][pair], row
-// stride 80 B: conflict-free ds_read_b128 by feature row), four slots per wave (A0 A1 | B0 B1; phi and its derivative keep
-// their split form in registers and take the A slots for the dW1 contractions).  Reads the split16 evaluator images (forward
+// stride 80 B: conflict-free ds_read_b128 by feature row), five slots per wave (A0 A1 | B0 B1 | phi; phi's derivative keeps
+// its split form in registers and takes an A slot for its dW1 contraction).  Reads the split16 evaluator images (forward
 // blocks and bias tables carry 2 log2(e) for tanh: the accumulator is the exponent; the tangent chain is scaled back).
 template <bool TANH, typename IT, bool FUSED>
 __global__ __launch_bounds__(256, 1) void mlp_grad_f16_kernel(const typename Vec4<IT>::type *__restrict__ nlist,
@@ -709,7 +709,7 @@ __global__ __launch_bounds__(256, 1) void mlp_grad_f16_kernel(const typename Vec
         // written and read only under `live` (wave-uniform): no initialisation -- twelve tiles of v_mov 0
         // per trip are VALU time the fp32 MFMAs cannot hide (pair_mlp.hip)
         f32x16 h1[2], hd1[2];
-        Op16 phi_o, phid_o, hd1o[2], zb2o[2], zdb2o[2];
+        Op16 phid_o, hd1o[2], zb2o[2], zdb2o[2];
         f32x16 q2[2], qd2[2]; // zb2, zdb2
         f32x16 q1[2], qd1[2]; // zb1, zdb1
         float4 part = make_float4(0.f, 0.f, 0.f, 0.f); // this tile's share of (F_i, E_i)
@@ -726,8 +726,9 @@ __global__ __launch_bounds__(256, 1) void mlp_grad_f16_kernel(const typename Vec
                     phid[v] = -2.0f * d * ginv * phi[v];
                 }
             }
-            phi_o = split16(phi);
+            const Op16 phi_o = split16(phi);
             phid_o = split16(phid);
+            publish16(mine + 4 * kHB, p, h, phi_o); // its own slot, read at D3; the derivative keeps its split form in registers
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb) {
                 f32x16 zz = load_tab(lds + I::TabB1, nb, h), zd = zero16();
@@ -879,8 +880,7 @@ __global__ __launch_bounds__(256, 1) void mlp_grad_f16_kernel(const typename Vec
             }
                 }
         // D3: dW1 += phi (x) zb1  (wave w: feature block w&1, tiles 2(w>>1), 2(w>>1)+1)
-        if (live) { // phi and its derivative take the A slots (their consumers of D2 are past the barrier above)
-            publish16(mine + 0 * kHB, p, h, phi_o);
+        if (live) { // phi's derivative takes an A slot (the consumers of D2 are past the barrier above)
             publish16(mine + 1 * kHB, p, h, phid_o);
             publish16(mine + 2 * kHB, p, h, split16(q1[0]));
             publish16(mine + 3 * kHB, p, h, split16(q1[1]));
@@ -890,7 +890,7 @@ __global__ __launch_bounds__(256, 1) void mlp_grad_f16_kernel(const typename Vec
         for (unsigned t = 2 * (w >> 1); t < 2 * (w >> 1) + 2; ++t) {
             if (!live_flag[t]) continue;
             const _Float16 *src = pub + t * kSlots16 * kHB;
-            const Op16 A = load_op16(src + 0 * kHB, p, h), Bm = load_op16(src + (2 + (w & 1u)) * kHB, p, h);
+            const Op16 A = load_op16(src + 4 * kHB, p, h), Bm = load_op16(src + (2 + (w & 1u)) * kHB, p, h);
             outer16_f16(acc1, A, Bm);
             gb1 += sum_op16(Bm);
         }
