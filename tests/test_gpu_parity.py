@@ -240,17 +240,21 @@ def test_pair_vectors_ragged_row_lengths(htf, cuda, hdt, fused):
                 np.testing.assert_array_equal(pv.cpu().numpy(), ref.astype(np.float32))
                 # the C4 sweep (row-pipelined persistent kernel): same tensor, histogram and forces as
                 # build -> eval_forces2 on these rows
-                lj, gauss = htf.Potential.rinv_poly([1.0], [1]), htf.Potential.gauss(1.1, 0.05, 1.0)
-                pv2 = torch.full((bs, NN, 4), 7.0, dtype=torch.float32, device=cuda)
-                h1 = torch.zeros(102, dtype=torch.int32, device=cuda)
-                fa1, fb1 = htf.ops.build_eval_forces2(lj, gauss, p4, dnn, dhead, dnl, box, r_cut, NN, offset=offset,
-                                                      batch_size=bs, rdf=(0.0, 3.5, h1), pair_vectors=pv2)
-                np.testing.assert_array_equal(pv2.cpu().numpy(), ref.astype(np.float32))
-                h0 = torch.zeros(102, dtype=torch.int32, device=cuda)
-                fa0, fb0 = htf.ops.eval_forces2(lj, gauss, pv2, rdf=(0.0, 3.5, h0), out_dtype=p4.dtype)
-                assert torch.equal(h1, h0)
-                for a, b in ((fa1, fa0), (fb1, fb0)):
-                    assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max()))
+                # (base potentials that stay finite on these random rows, self pairs included: r^-1 takes the compacting
+                #  persistent kernel, WCA -- for fp32 positions -- the rows-per-wave form with merged tails, whose generic
+                #  single-row routine and overflow un-binning these rows exercise)
+                for lj in (htf.Potential.rinv_poly([1.0], [1]), htf.Potential.wca(1.0)):
+                    gauss = htf.Potential.gauss(1.1, 0.05, 1.0)
+                    pv2 = torch.full((bs, NN, 4), 7.0, dtype=torch.float32, device=cuda)
+                    h1 = torch.zeros(102, dtype=torch.int32, device=cuda)
+                    fa1, fb1 = htf.ops.build_eval_forces2(lj, gauss, p4, dnn, dhead, dnl, box, r_cut, NN, offset=offset,
+                                                          batch_size=bs, rdf=(0.0, 3.5, h1), pair_vectors=pv2)
+                    np.testing.assert_array_equal(pv2.cpu().numpy(), ref.astype(np.float32))
+                    h0 = torch.zeros(102, dtype=torch.int32, device=cuda)
+                    fa0, fb0 = htf.ops.eval_forces2(lj, gauss, pv2, rdf=(0.0, 3.5, h0), out_dtype=p4.dtype)
+                    assert torch.equal(h1, h0)
+                    for a, b in ((fa1, fa0), (fb1, fb0)):
+                        assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max()))
             else:
                 mc = torch.zeros(1, dtype=torch.int32, device=cuda)
                 out = htf.ops.build_pair_vectors(p4, dnn, dhead, dnl, box, r_cut, NN, offset=offset, batch_size=bs, max_count=mc,
