@@ -166,7 +166,80 @@ def _load():
     return lib
 
 
-lib = _load()
+# ---------------------------------------------------------------------------- the pybind11 binding of the same ABI
+# Every call goes through hoomd_tf_amd/_htf_abi.so (csrc/pybind_abi.cc: one template per C signature, pointers as integers)
+# when that module has been built -- BASELINE's "thin pybind11 C-ABI" -- and through ctypes otherwise (HTF_BINDING=ctypes |
+# pybind11 forces either; HTF_AMD_LIB, an A/B copy of the library, implies ctypes: the module is linked against the default
+# one).  The call sites do not change: the facade below turns what they pass -- ints, None, c_void_p, byref(structure),
+# ctypes arrays -- into addresses.  The GPU suite passes under either binding (tools/evidence_pass.sh runs both).
+def _address(a):
+    if a is None:
+        return 0
+    if type(a) is int:
+        return a
+    if isinstance(a, C.c_void_p):
+        return a.value or 0
+    if isinstance(a, (C.Structure, C.Array)):
+        return C.addressof(a)
+    obj = getattr(a, "_obj", None)  # byref(x)
+    if obj is not None:
+        return C.addressof(obj)
+    if isinstance(a, C._Pointer):
+        return C.cast(a, C.c_void_p).value or 0
+    if isinstance(a, C._SimpleCData):
+        return C.addressof(a)
+    return int(a)
+
+
+def _is_pointer(t):
+    return t is _vp or t is C.c_char_p or (isinstance(t, type) and issubclass(t, C._Pointer))
+
+
+class _PybindLib:
+    """Same attribute surface as the ctypes library object, backed by the pybind11 module."""
+
+    def __init__(self, mod):
+        self._mod = mod
+        for name, (res, args) in list(PROTOTYPES.items()) + list(STANDIN_PROTOTYPES.items()):
+            fn = getattr(mod, name)  # AttributeError if the module lacks a declared symbol
+            ptr_at = tuple(i for i, t in enumerate(args) if _is_pointer(t))
+            setattr(self, name, self._wrap(fn, ptr_at, res is _vp))
+
+    @staticmethod
+    def _wrap(fn, ptr_at, returns_pointer):
+        def call(*a):
+            if ptr_at:
+                a = list(a)
+                for i in ptr_at:
+                    a[i] = _address(a[i])
+            r = fn(*a)
+            return (r or None) if returns_pointer else r
+        return call
+
+
+def _load_pybind():
+    import importlib.util
+    path = os.path.join(_HERE, "_htf_abi.so")
+    if not os.path.exists(path):
+        raise ImportError("hoomd_tf_amd: HTF_BINDING=pybind11 but %s is missing: `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "or `make -C hoomd_tf_amd/csrc pybind`" % path)
+    spec = importlib.util.spec_from_file_location("_htf_abi", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+_ctypes_lib = _load()  # (also what resolves libhtf_amd.so for the pybind11 module: same library, loaded once)
+# default: the pybind11 module when it has been built (build() / make pybind), else ctypes -- both thin, both on the one
+# C ABI; the library itself is never optional (the _load() above has already failed loudly without it)
+BINDING = os.environ.get("HTF_BINDING") or ("pybind11" if os.path.exists(os.path.join(_HERE, "_htf_abi.so")) and not os.environ.get("HTF_AMD_LIB")
+                                              else "ctypes")
+if BINDING == "pybind11":
+    lib = _PybindLib(_load_pybind())
+elif BINDING == "ctypes":
+    lib = _ctypes_lib
+else:
+    raise ImportError("hoomd_tf_amd: HTF_BINDING must be 'ctypes' or 'pybind11', not %r" % BINDING)
 
 
 def last_error():

@@ -4,7 +4,8 @@ set -x
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 F=gpurun_out/final
 mkdir -p $F
-timeout 1500 python -m pytest tests -q -m gpu > $F/pytest_gpu.log 2>&1; tail -2 $F/pytest_gpu.log
+timeout 1500 python -m pytest tests -q -m gpu > $F/pytest_gpu.log 2>&1; tail -2 $F/pytest_gpu.log           # default binding: pybind11 (_htf_abi.so)
+HTF_BINDING=ctypes timeout 1500 python -m pytest tests -q -m gpu > $F/pytest_gpu_ctypes.log 2>&1; tail -1 $F/pytest_gpu_ctypes.log
 python -c "import __graft_entry__ as g; g.smoke()" > $F/smoke.log 2>&1; tail -2 $F/smoke.log
 jl() { grep '^{' | tail -1; }
 timeout 900 python bench.py --steps 20 --warmup 5 2>$F/bench_lj.err | jl > $F/bench_lj.json          # the driver's own command
