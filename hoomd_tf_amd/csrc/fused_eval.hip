@@ -810,7 +810,8 @@ __global__ __launch_bounds__(256) void fused_forces2_kernel(
     const bool simple_box = box.ortho && box.periodic[0] && box.periodic[1] && box.periodic[2];
     const float rdf_scale = do_rdf ? (float)rdf.nb / (rdf.r1 - rdf.r0) : 0.f;
     const float rdf_bias = -rdf.r0 * rdf_scale; // (the guess may be off by one either way: the edge table settles it)
-    const bool coarse_bins = do_rdf && (rdf.r1 - rdf.r0) >= 1e-4f * (float)rdf.nb;
+    // (through readfirstlane: a float compare leaves a LANE MASK, and branching on it cost a v_cndmask + v_cmp per slot)
+    const bool coarse_bins = __builtin_amdgcn_readfirstlane((int)(do_rdf && (rdf.r1 - rdf.r0) >= 1e-4f * (float)rdf.nb)) != 0;
     // bin of a zero pair vector (the padded slots of the tensor are part of compute_rdf's input)
     int pad_bin = 0;
     if (do_rdf) {
@@ -1387,7 +1388,8 @@ __global__ __launch_bounds__(256) void fused_forces2_tails_kernel(
     st.nb = (int)rdf.nb;
     st.scale = st.do_rdf ? (float)rdf.nb / (rdf.r1 - rdf.r0) : 0.f;
     st.bias = -rdf.r0 * st.scale;
-    st.coarse = st.do_rdf && (rdf.r1 - rdf.r0) >= 1e-4f * (float)rdf.nb;
+    // (through readfirstlane: a float compare leaves a LANE MASK, and branching on it cost a v_cndmask + v_cmp per slot)
+    st.coarse = __builtin_amdgcn_readfirstlane((int)(st.do_rdf && (rdf.r1 - rdf.r0) >= 1e-4f * (float)rdf.nb)) != 0;
     st.pad_bin = 0;
     if (st.do_rdf) {
         const float fi = floorf((float)rdf.nb * ((0.f - rdf.r0) / (rdf.r1 - rdf.r0)));
@@ -1429,7 +1431,10 @@ unsigned fused_forces2_num_partials(unsigned batch) {
     const unsigned ngroups = (batch + 3) / 4;
     // persistent workgroups: 4096 = 16 per CU, about twice what is resident -- measured at C4
     // 1024 / 2048 / 4096 / 8192 / 16384 workgroups: 244 / 220 / 204 / 212 / 372 us (every workgroup ends with a
-    // flush of its LDS histogram)
+    // flush of its LDS histogram); the rows-per-wave form, round 3: 1536 / 2560 / 3072 / 4096 / 8192 -> 165 / 165 / 166 /
+    // 169 / 203 us (1792 and 2048, one more workgroup per CU than is resident: 191 / 177) -- flat around the default.
+    // (Also measured and not kept, profiles/r03_c4_kernel_ab.txt: the group loop as a software pipeline -- scalars, list
+    //  entries and gathers of the next one or two groups in flight; 85 / 108 VGPRs, 175 / 187 us against 167.)
     static const char *env = getenv("HTF_FUSED2_GRID");
     const unsigned cap = env ? (unsigned)atoi(env) : 4096u;
     return ngroups < cap ? ngroups : cap;

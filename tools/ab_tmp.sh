@@ -1,7 +1,7 @@
-for rep in 1 2; do
-for lib in base w8 w7 w6; do
-  export HTF_AMD_LIB=build_variants/libhtf_$lib.so
-  python tools/fused_ab.py --relax 100 --tag f32_$lib 2>&1 | tail -1
-  HTF_FUSED_TAILS=2 python tools/fused_ab.py --f64 --relax 100 --tag f64_t2_$lib 2>&1 | tail -1
-  HTF_FUSED_TAILS=4 python tools/fused_ab.py --f64 --relax 100 --tag f64_t4_$lib 2>&1 | tail -1
-done; done
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/c4_pipe.txt; : > $O
+HTF_AMD_LIB=build_variants/libhtf_pipe2.so timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py tests/test_gpu_tensorflow.py -q -m gpu -x -k "eds or c4 or forces2 or rdf or sweep or two" 2>&1 | tail -3 >> $O
+for lib in build_variants/libhtf_pipe2.so hoomd_tf_amd/libhtf_amd.so build_variants/libhtf_pipe2.so hoomd_tf_amd/libhtf_amd.so; do
+  HTF_AMD_LIB=$lib TAG=$(basename $lib) timeout 120 python tools/fused2_ab.py 2>&1 | grep "tensor=" | tr '\n' ' ' >> $O; echo >> $O
+done
+cat $O

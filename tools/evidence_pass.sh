@@ -88,7 +88,7 @@ json.dump(lj, open(F + "/pmc_lj_kernel.json", "w"), indent=1)
 mlp = collect("/tmp/pm_*/**/*counter_collection.csv", want=["pair_mlp_kernel"])
 trn = collect("/tmp/pt_*/**/*counter_collection.csv", want=["mlp_grad", "pair_mlp_kernel"])
 c2 = collect("/tmp/p2_*/**/*counter_collection.csv", want=["fused_forces_rows2_kernel", "fused_forces_tails_kernel"])
-c4 = collect("/tmp/p4_*/**/*counter_collection.csv", want=["fused_forces2_kernel"])
+c4 = collect("/tmp/p4_*/**/*counter_collection.csv", want=["fused_forces2_kernel", "fused_forces2_tails_kernel"])
 json.dump({"C2 (bench.py --workload wca --lattice sc --cells 32)": c2, "C4 (bench.py --workload eds)": c4}, open(F + "/pmc_c2_c4.json", "w"), indent=1)
 json.dump({"evaluator (bench.py --workload mlp, fp32 MFMA + the split variant)": mlp, "training (bench.py --workload mlp-train)": trn,
            "_note": "SQ_INSTS_MFMA: wave-level MFMA instructions; SQ_VALU_MFMA_BUSY_CYCLES: cycles the matrix pipe is busy, summed over SIMDs; "
