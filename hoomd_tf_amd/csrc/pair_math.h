@@ -76,6 +76,13 @@ __device__ __forceinline__ RinvFwd rinv_fwd(float x, float y, float z) {
     f.ty = y + kNormDelta;
     f.tz = z + kNormDelta;
     const float t2 = f.tx * f.tx + f.ty * f.ty + f.tz * f.tz;
+#ifdef HTF_VALU_PAD // experiment: HTF_VALU_PAD independent dummy VALU instructions per slot (does the instruction count bind?)
+    {
+        float pad = f.tx;
+#pragma unroll
+        for (int i = 0; i < HTF_VALU_PAD; ++i) asm volatile("v_mul_f32 %0, %0, %0" : "+v"(pad));
+    }
+#endif
     const float s0 = __builtin_amdgcn_rsqf(t2);
     const float u = kRinvDelta * s0;
     f.rp = t2 * s0;
