@@ -2,7 +2,9 @@
 // host side.  One template turns every entry point into a Python callable -- pointers cross as integers (device pointers,
 // addresses of ctypes structures), everything else as itself -- so the module carries no type the C header does not
 // describe and needs no per-function glue: the list below is the header's symbol list (tests/test_abi.py checks it).
-// hoomd_tf_amd/_lib.py selects it with HTF_BINDING=pybind11 (default: ctypes on the same library).
+// hoomd_tf_amd/_lib.py uses it when it is built (HTF_BINDING=ctypes selects ctypes prototypes of the same library).
+// The GIL is released around every call, as ctypes does: the few entry points that wait (check_nlist's read-back, the halo's
+// end, destroy) do not stall other Python threads.
 //   build: g++ -O2 -shared -fPIC pybind_abi.cc -I<repo>/include $(python -m pybind11 --includes) -L.. -lhtf_amd -o ../_htf_abi.so
 #include <pybind11/pybind11.h>
 
@@ -43,7 +45,12 @@ template <> struct Ret<void> {
 
 template <class R, class... A>
 void bind(py::module &m, const char *name, R (*fn)(A...)) {
-    m.def(name, [fn](typename Wire<A>::type... a) { return Ret<R>::call([&] { return fn(Wire<A>::from(a)...); }); });
+    m.def(name, [fn](typename Wire<A>::type... a) {
+        return Ret<R>::call([&] {
+            py::gil_scoped_release nogil; // (the C side never calls back into Python)
+            return fn(Wire<A>::from(a)...);
+        });
+    });
 }
 } // namespace
 
