@@ -21,6 +21,23 @@ pos = (ijk + 0.5) * a - L / 2
 rng = np.random.default_rng(4)
 pos = pos + 0.05 * a * rng.standard_normal(pos.shape)
 pos -= np.round(pos / L) * L
+order = os.environ.get("ORDER", "lattice")  # particle order in memory: lattice (ijk, z fastest) | morton | cells | random
+if order != "lattice":
+    cw = float(os.environ.get("CW", "1.7"))
+    c = np.floor((pos + L / 2) / cw).astype(np.int64)
+    if order == "random":
+        perm = rng.permutation(len(pos))
+    elif order == "cells":
+        nc = int(np.ceil(L[0] / cw))
+        perm = np.argsort((c[:, 0] * nc + c[:, 1]) * nc + c[:, 2], kind="stable")
+    else:
+        def spread(v):
+            out = np.zeros_like(v)
+            for b in range(10):
+                out |= ((v >> b) & 1) << (3 * b)
+            return out
+        perm = np.argsort(spread(c[:, 0]) << 2 | spread(c[:, 1]) << 1 | spread(c[:, 2]), kind="stable")
+    pos = pos[perm]
 sysm = standin.System(pos, L, dtype=torch.float32, device=dev)
 nl = standin.CellNlist(sysm, r_cut=3.0, r_buff=0.4)
 nl.build()
@@ -57,4 +74,4 @@ def run(with_tensor, with_rdf, reps=30):
 
 for wt in (True, False):
     for wr in (True, False):
-        print("%s tensor=%d rdf=%d: %.1f us" % (os.environ.get("TAG", ""), wt, wr, run(wt, wr)))
+        print("%s order=%s tensor=%d rdf=%d: %.1f us" % (os.environ.get("TAG", ""), order, wt, wr, run(wt, wr)))
