@@ -281,6 +281,13 @@ __global__ __launch_bounds__(256, MlpLaunch<P>::kPerCU) void pair_mlp_kernel(con
             const bool m = r > kRinvDelta;
             if (__ballot(m) == 0ull) continue; // every slot of this tile is padding
 
+#ifdef HTF_MLP_VALU_PAD // experiment: HTF_MLP_VALU_PAD dummy VALU instructions per 32-slot tile (does the instruction count bind?)
+            {
+                float pad = r;
+#pragma unroll
+                for (int i = 0; i < HTF_MLP_VALU_PAD; ++i) asm volatile("v_mul_f32 %0, %0, %0" : "+v"(pad));
+            }
+#endif
             // RBF expansion: lane (p, h) evaluates centres k = f0(v) + 4h, v = 0..15
             f32x16 phi;
 #pragma unroll
