@@ -945,6 +945,47 @@ def run_md(args, E, workload, variants=True, cpu=True):
     ctx.profile_enable(False)
     rebuilds = (builds_now() - builds0) / n_windows  # per window of args.steps steps
 
+    # With slabs: where a step's time goes on rank 0, measured AFTER the timed windows (never part of `value`): host time of
+    # each phase as the loop enqueues it, and the same phases with the device drained after each (GPU-inclusive).  On real
+    # multi-GPU hardware this is what tells a slow halo from a slow host loop.
+    phases = None
+    if world > 1:
+        def phase_pass(drain):
+            acc = {"nlist_check_and_halo_post": 0.0, "forces_interior_halo_wait_boundary": 0.0, "integrate": 0.0}
+            n = 0
+            for _ in range(20):
+                ts = state["ts"]
+                b_before = nl.n_builds
+                t0 = time.perf_counter()
+                nl.compute(ts)
+                if nl.n_builds != state["builds"]:
+                    state["arr"] = arrays()
+                    state["builds"] = nl.n_builds
+                if drain:
+                    torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                ctx.compute_forces_overlapped(ts, state["arr"], nl.domain)
+                if drain:
+                    torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                nve.step()
+                if drain:
+                    torch.cuda.synchronize()
+                t3 = time.perf_counter()
+                state["ts"] = ts + 1
+                if nl.n_builds == b_before:  # steps without a rebuild: the common case, reported; rebuild steps are in `value`
+                    acc["nlist_check_and_halo_post"] += t1 - t0
+                    acc["forces_interior_halo_wait_boundary"] += t2 - t1
+                    acc["integrate"] += t3 - t2
+                    n += 1
+            return {k: v / max(n, 1) * 1e6 for k, v in acc.items()}
+        torch.cuda.synchronize()
+        dist.barrier()
+        phases = {"host_enqueue_us": phase_pass(False), "drained_after_each_phase_us": phase_pass(True),
+                  "note": "rank 0, mean over the steps without a rebuild of a 20-step pass; untimed diagnostics"}
+        torch.cuda.synchronize()
+        dist.barrier()
+
     # sanity: the run must still be a valid simulation
     f = sysm.force
     assert bool(torch.isfinite(f).all()), "non-finite forces"
@@ -1094,7 +1135,8 @@ def run_md(args, E, workload, variants=True, cpu=True):
                                                     "transport": ("RCCL: the library's own communicator and halo stream (csrc/halo.hip)" if nl.domain.transport == "native"
                                                                   else (E.backend if E.backend != "nccl" else "RCCL (torch.distributed nccl backend)")),
                                                     "transport_note": getattr(nl.domain, "transport_note", None),
-                                                    "exchange": "forward ghost positions, grouped send/recv, every step"}},
+                                                    "exchange": "forward ghost positions, grouped send/recv, every step",
+                                                    "step_phases_rank0": phases}},
         # sum over ranks of the algorithmic bytes a step moves (rank 0's count x ranks) / step time
         "hbm_GBps_full_step": world * step_bytes / (elapsed / args.steps) / 1e9,
         "hbm_frac_full_step": step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
