@@ -20,8 +20,22 @@ def _dt(t):
     raise ValueError("expected a float32/float64 tensor, got %s" % t.dtype)
 
 
+# torch.cuda.current_stream() builds a Stream object (and, without an explicit device index, asks the runtime for the device
+# count: ~8 us) every call; the step loop asks four times a step.  The raw handle is one C call.
+_raw_current_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
+def raw_stream(device_index=None):
+    """hipStream_t of torch's current stream on ``device_index`` (default: the current device), as an integer."""
+    if device_index is None:
+        device_index = torch.cuda.current_device()
+    if _raw_current_stream is not None:
+        return _raw_current_stream(device_index)
+    return torch.cuda.current_stream(device_index).cuda_stream
+
+
 def _stream(t):
-    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    return C.c_void_p(raw_stream(t.device.index))
 
 
 def _dev(t, name, dtype=None):
@@ -443,6 +457,7 @@ class Context:
         self.scalar_dtype = scalar_dtype
         self._h = C.c_void_p()
         self._pot = None
+        self._device_index = torch.cuda.current_device()  # htf_create binds the context to the current device
         check(lib.htf_create(C.byref(cfg), C.byref(self._h)))
 
     def __del__(self):
@@ -472,7 +487,7 @@ class Context:
 
     def compute_forces(self, timestep, arrays, stream=None, rows=None):
         """``rows=(begin, count)``: only those particle rows (htf_compute_forces_rows)."""
-        s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        s = stream if stream is not None else raw_stream(self._device_index)
         if rows is None:
             check(lib.htf_compute_forces(self._h, int(timestep), C.byref(arrays), C.c_void_p(s)))
         elif rows[1] > 0:
@@ -521,7 +536,7 @@ class Context:
     def reset_nlist_buffer(self):
         """Call after WRITING into ``nlist_buffer()``: the next step rewrites every row's zero tail in full
         (the context otherwise re-zeroes only the slots a row lost since the previous step)."""
-        check(lib.htf_reset_nlist_buffer(self._h, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        check(lib.htf_reset_nlist_buffer(self._h, C.c_void_p(raw_stream(self._device_index))))
 
     def positions_buffer(self, B, device="cuda"):
         return self._view(lib.htf_get_positions_buffer(self._h), (B, 4), torch.float32, device)

@@ -17,6 +17,7 @@ import torch
 
 from . import _lib, ops
 from ._lib import lib, check
+from .ops import raw_stream
 
 
 def fcc_positions(n_cells, rho):
@@ -210,7 +211,7 @@ class CellNlist:
         n3 = (C.c_int * 3)(*[int(x) for x in n])
         w3 = (C.c_int * 3)(*[int(x) for x in w])
         ncell = int(n[0] * n[1] * n[2])
-        stream = C.c_void_p(torch.cuda.current_stream(s.device).cuda_stream)
+        stream = C.c_void_p(raw_stream(s.device.index))
         if getattr(self, "_scr_n", None) != (Ntot, ncell):
             self._scr_n = (Ntot, ncell)
             self._cell_of = torch.empty(Ntot, dtype=torch.int32, device=s.device)
@@ -293,7 +294,7 @@ class CellNlist:
             self._stat = torch.zeros(2, dtype=torch.int32, device=s.device)  # [largest row of the last rebuild, rebuilds]
             self._stat_host = torch.zeros(2, dtype=torch.int32).pin_memory()
         n3, w3, ncell = self._grid
-        stream = C.c_void_p(torch.cuda.current_stream(s.device).cuda_stream)
+        stream = C.c_void_p(raw_stream(s.device.index))
         self._disp.zero_()
         check(lib.htfs_max_displacement2(s.pos.data_ptr(), self._ref.data_ptr(), s.scalar_code, s.N,
                                          C.byref(s.box), self._disp.data_ptr(), stream))
@@ -321,7 +322,9 @@ class CellNlist:
     def mark_check_enqueued(self):
         """An event behind the check's read-back; _poll_overflow waits for it one check later."""
         self._stat_event = torch.cuda.Event()
-        self._stat_event.record()
+        # (an explicit device index: without one torch asks the runtime for the device count on every call, ~8 us)
+        idx = self.sys.device.index
+        self._stat_event.record(torch.cuda.current_stream(idx if idx is not None else torch.cuda.current_device()))
 
     def device_builds(self):
         """Rebuilds the device has decided on so far (synchronises; for reports, not for the step loop)."""
@@ -342,7 +345,7 @@ class CellNlist:
         buf.zero_()
         check(lib.htfs_max_displacement2(s.pos.data_ptr(), self._ref.data_ptr(), s.scalar_code, s.N,
                                          C.byref(s.box), buf.data_ptr(),
-                                         C.c_void_p(torch.cuda.current_stream(s.device).cuda_stream)))
+                                         C.c_void_p(raw_stream(s.device.index))))
         if self.deferred_reference:
             # the host-decided twin: all-reduce and read NOW (a drained queue per check), same rule, same one-check lag
             dist.all_reduce(buf, op=dist.ReduceOp.MAX, group=self.domain.group)
@@ -356,7 +359,8 @@ class CellNlist:
             host = self._dd_host[self._dd_i % 3]
             host.copy_(buf, non_blocking=True)
             ev = torch.cuda.Event()
-            ev.record()
+            idx = s.device.index
+            ev.record(torch.cuda.current_stream(idx if idx is not None else torch.cuda.current_device()))
             if self._dd_prev is not None:
                 h_prev, ev_prev = self._dd_prev
                 ev_prev.synchronize()  # recorded a whole check period ago
@@ -382,7 +386,7 @@ class CellNlist:
         self._disp.zero_()
         check(lib.htfs_max_displacement2(s.pos.data_ptr(), self._ref.data_ptr(), s.scalar_code, s.N,
                                          C.byref(s.box), self._disp.data_ptr(),
-                                         C.c_void_p(torch.cuda.current_stream(s.device).cuda_stream)))
+                                         C.c_void_p(raw_stream(s.device.index))))
         if self.domain is not None and self.domain.world > 1:
             # every rank must take the same rebuild decision (the rebuild communicates)
             import torch.distributed as dist
@@ -446,7 +450,7 @@ class NVE:
         esz = 4 * (8 if s.dtype == torch.float64 else 4)
         check(lib.htfs_nve_step(s.pos.data_ptr() + first * esz, s.vel.data_ptr() + first * esz,
                                 s.force.data_ptr() + first * esz, s.scalar_code, n,
-                                self.dt, C.byref(s.box), C.c_void_p(torch.cuda.current_stream(s.device).cuda_stream)))
+                                self.dt, C.byref(s.box), C.c_void_p(raw_stream(s.device.index))))
 
 
 # --------------------------------------------------------------------------- run loop
