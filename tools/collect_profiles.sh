@@ -21,5 +21,6 @@ cp $F/pmc_c2_c4.json profiles/${R}_bench_c2_c4_pmc.json
 cp $F/gather_probe2.txt profiles/${R}_gather_probe.txt
 cp $F/store_probe.txt profiles/${R}_store_probe.txt
 cp gpurun_out/parity_stats.json profiles/${R}_parity_stats.json
+for n in soak_nve soak_nve_f64; do [ -s $F/$n.json ] && cp $F/$n.json profiles/${R}_$n.json; done
 for n in pytest_gpu pytest_gpu_ctypes smoke; do [ -s $F/$n.log ] && cp $F/$n.log profiles/${R}_$n.log; done
 tail -2 $F/pytest_gpu.log; tail -1 $F/smoke.log

@@ -30,6 +30,8 @@ HTF_BENCH_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-no
 HTF_BENCH_WATCHDOG=400 HTF_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --workload mlp --steps 10 --warmup 3 --equil 60 --no-cpu-baseline --no-fused 2>/dev/null | jl > $F/bench_rehearsal_2ranks_strong_mlp_gloo.json
 # config 5 at its full size (8 x 131072 = 1.05 M particles, force matching on), the 8 ranks sharing this one GPU
 HTF_BENCH_WATCHDOG=400 HTF_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 8 --scaling weak --workload mlp-train --train-period 10 --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | jl > $F/bench_rehearsal_c5_8ranks_weak_mlptrain_gloo.json
+timeout 300 python tools/soak_nve.py --steps 20000 > $F/soak_nve.json 2>/dev/null          # 20 000 NVE steps at the headline size: energy drift, momentum accounting
+timeout 300 python tools/soak_nve.py --steps 20000 --f64 > $F/soak_nve_f64.json 2>/dev/null
 bash tools/fetch_calib.sh > /dev/null 2>&1; cp gpurun_out/fetch_calib.json $F/fetch_calib.json
 ./tools/gather_probe2 > $F/gather_probe2.txt 2>&1
 ./tools/store_probe > $F/store_probe.txt 2>&1
