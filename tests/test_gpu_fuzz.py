@@ -81,3 +81,97 @@ def test_modes_agree_on_random_systems(htf, cuda, seed):
         if virial:
             vs = max(1.0, float(v0.abs().max()))
             assert float((v2 - v0).abs().max()) <= 1e-4 * vs and float((v1 - v2).abs().max()) <= 1e-4 * vs
+
+
+# --------------------------------------------------------------------------- crafted row lengths, every kernel form
+_LENGTHS = [0, 1, 2, 63, 64, 65, 100, 127, 128, 129, 150, 191, 192, 193, 230]
+
+
+def _crafted_lists(pos, L, r_cut, rng):
+    """HOOMD-layout lists whose row LENGTHS are drawn from the edges of the kernels' trip structure (64-slot trips, the
+    128-entry straight-line part, the 192-entry limit of the merged tail): a row's true neighbors within r_cut + 0.3 first
+    (shuffled), cut short or padded with far particles, which prepareNeighbors drops again (.cc:359)."""
+    nn0, head0, nl0 = brute_nlist(pos, L, r_cut + 0.3, shuffle_seed=5)
+    N = len(pos)
+    rows = []
+    for i in range(N):
+        want = int(rng.choice(_LENGTHS))
+        mine = nl0[head0[i]:head0[i] + nn0[i]].astype(np.int64)
+        if want <= len(mine):
+            row = mine[:want]
+        else:
+            far = rng.integers(0, N, size=want - len(mine))
+            row = rng.permutation(np.concatenate([mine, far]))
+        rows.append(row[row != i] if want else row)
+    nn = np.array([len(r) for r in rows], dtype=np.uint32)
+    head = np.concatenate([[0], np.cumsum(nn)[:-1]]).astype(np.uint32)
+    flat = np.concatenate(rows).astype(np.uint32)
+    return nn, head, flat
+
+
+@pytest.mark.parametrize("hdt", [np.float32, np.float64])
+@pytest.mark.parametrize("NN", [64, 128])
+def test_crafted_row_lengths_body(htf, cuda, hdt, NN):
+    """One-kernel step on lists with crafted row lengths against the oracle: tensor bit for bit (overflowing rows with the
+    reference's slot wrap), forces within the stated tolerance, tensor written or not.  Run as is (the default forms) and, by
+    test_crafted_row_lengths_every_form, in child processes with each rows-per-wave form forced."""
+    from oracle import htf_oracle as O
+
+    def assert_forces_close(got, ref, _nl):
+        # structural errors (a wrong slot, a dropped tail) are O(1); fp32 summation order is 1e-7 of the largest pair term
+        scale = max(1.0, float(np.abs(ref).max()))
+        err = np.abs(got - ref)
+        assert np.all(np.isfinite(got)) and float(err.max()) <= 2e-5 * scale, (float(err.max()), scale)
+
+    rng = np.random.default_rng(77)
+    n, a = 9, 1.12  # 729 particles, 9 = 3 * 3: groups of 2, 3 and 4 rows all end ragged somewhere
+    g = np.stack(np.meshgrid(*[np.arange(n)] * 3, indexing="ij"), -1).reshape(-1, 3).astype(np.float64)
+    L = np.array([n * a] * 3)
+    pos = (g + 0.5) * a - L / 2 + 0.06 * a * rng.standard_normal((n ** 3, 3))
+    pos -= np.round(pos / L) * L
+    pos = pos.astype(hdt).astype(np.float64)
+    N, r_cut = len(pos), 3.0
+    nn, head, nl = _crafted_lists(pos, L, r_cut, rng)
+    types = np.zeros(N, dtype=np.int32)
+    tdt = torch.float64 if hdt == np.float64 else torch.float32
+    p4 = htf.ops.stuff_types(torch.from_numpy(pos).to(cuda), torch.from_numpy(types).to(cuda), tdt)
+    dnn, dhead, dnl = (torch.from_numpy(x.astype(np.int32)).to(cuda) for x in (nn, head, nl))
+    box = O.make_box(L, dtype=hdt)
+    want = O.prepare_neighbors(pos.astype(hdt), types, nn, head, nl, box, r_cut, NN).astype(np.float32)
+    for pot, model in ((htf.Potential.lj(), O.lj_model), (htf.Potential.wca(1.0), lambda t: O.wca_model(t, 1.0))):
+        pv = torch.full((N, NN, 4), 7.0, device=cuda)
+        f_t = htf.ops.fused_forces(pot, p4, dnn, dhead, dnl, box, r_cut, NN, pair_vectors=pv)
+        f_n = htf.ops.fused_forces(pot, p4, dnn, dhead, dnl, box, r_cut, NN)
+        assert np.array_equal(pv.cpu().numpy(), want), "pair-vector tensor"
+        ref = model(want.astype(np.float64))
+        for f in (f_t, f_n):
+            assert_forces_close(f.cpu().numpy().astype(np.float64), ref, want.astype(np.float64))
+        assert float((f_t - f_n).abs().max()) <= 1e-4 * max(1.0, float(f_t.abs().max()))
+    # the same through the context (delta zero-fill of the previous step's rows: second call after the lists change)
+    ctx = htf.Context(r_cut=r_cut, nneighs=NN, scalar_dtype=tdt, max_n=N, fused=2)
+    ctx.set_potential(htf.Potential.lj())
+    force = torch.zeros((N, 4), dtype=tdt, device=cuda)
+    for rep in range(2):
+        nn2, head2, nl2 = _crafted_lists(pos, L, r_cut, np.random.default_rng(100 + rep))
+        d2 = [torch.from_numpy(x.astype(np.int32)).to(cuda) for x in (nn2, head2, nl2)]
+        ctx.compute_forces(rep, ctx.make_arrays(p4, N, d2[0], d2[1], d2[2], box, force))
+        w2 = O.prepare_neighbors(pos.astype(hdt), types, nn2, head2, nl2, box, r_cut, NN).astype(np.float32)
+        assert np.array_equal(ctx.nlist_buffer(N, cuda).cpu().numpy(), w2), "context tensor, call %d" % rep
+        assert_forces_close(force.cpu().numpy().astype(np.float64), O.lj_model(w2.astype(np.float64)), w2.astype(np.float64))
+
+
+@pytest.mark.parametrize("form", ["HTF_FUSED_TAILS=2", "HTF_FUSED_TAILS=3", "HTF_FUSED_TAILS=4", "HTF_FUSED_TAILS=0", "HTF_FUSED_ROWS=4"])
+def test_crafted_row_lengths_every_form(htf, cuda, form):
+    """The defaults pick a rows-per-wave form by batch size; a child process per form runs the crafted-length test with that
+    form forced at this (small) size -- the merged-tail kernels the headline configurations run included."""
+    import subprocess
+    import sys
+    k, v = form.split("=")
+    env = dict(os.environ, **{k: v})
+    if k == "HTF_FUSED_ROWS":
+        env["HTF_FUSED_TAILS"] = "0"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        "-k", "crafted_row_lengths_body"],
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
