@@ -175,3 +175,64 @@ def test_crafted_row_lengths_every_form(htf, cuda, form):
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+@pytest.mark.parametrize("hdt", [np.float32, np.float64])
+@pytest.mark.parametrize("NN", [64, 128])
+def test_crafted_row_lengths_c4_body(htf, cuda, hdt, NN):
+    """Config C4's one-kernel sweep (htf_build_eval_forces2: tensor, LJ + Gaussian forces, CV partials, compute_rdf histogram) on
+    the crafted row lengths against htf_build_pair_vectors -> htf_eval_forces2 and the oracle's tensor: tensor and histogram
+    bit for bit (overflowing rows un-binned and redone with the slot wrap), forces and CV to summation order."""
+    from oracle import htf_oracle as O
+    rng = np.random.default_rng(78)
+    n, a = 9, 1.12
+    g = np.stack(np.meshgrid(*[np.arange(n)] * 3, indexing="ij"), -1).reshape(-1, 3).astype(np.float64)
+    L = np.array([n * a] * 3)
+    pos = (g + 0.5) * a - L / 2 + 0.06 * a * rng.standard_normal((n ** 3, 3))
+    pos -= np.round(pos / L) * L
+    pos = pos.astype(hdt).astype(np.float64)
+    N, r_cut = len(pos), 3.0
+    nn, head, nl = _crafted_lists(pos, L, r_cut, rng)
+    types = np.zeros(N, dtype=np.int32)
+    tdt = torch.float64 if hdt == np.float64 else torch.float32
+    p4 = htf.ops.stuff_types(torch.from_numpy(pos).to(cuda), torch.from_numpy(types).to(cuda), tdt)
+    dnn, dhead, dnl = (torch.from_numpy(x.astype(np.int32)).to(cuda) for x in (nn, head, nl))
+    box = O.make_box(L, dtype=hdt)
+    want = O.prepare_neighbors(pos.astype(hdt), types, nn, head, nl, box, r_cut, NN).astype(np.float32)
+    for base in (htf.Potential.lj(), htf.Potential.wca(1.0)):
+        gauss = htf.Potential.gauss(1.1, 0.05, 1.0)
+        pv = htf.ops.build_pair_vectors(p4, dnn, dhead, dnl, box, r_cut, NN)
+        assert np.array_equal(pv.cpu().numpy(), want)
+        hist0 = torch.zeros(102, dtype=torch.int32, device=cuda)
+        part0 = torch.zeros(htf.ops.num_partials(N, NN), device=cuda)
+        fa0, fb0 = htf.ops.eval_forces2(base, gauss, pv, partials=part0, rdf=(0.0, 3.5, hist0), out_dtype=tdt)
+        hist1 = torch.zeros(102, dtype=torch.int32, device=cuda)
+        part1 = torch.zeros(htf.ops.num_partials_fused(N), device=cuda)
+        pv1 = torch.full_like(pv, 3.0)
+        fa1, fb1 = htf.ops.build_eval_forces2(base, gauss, p4, dnn, dhead, dnl, box, r_cut, NN, partials=part1,
+                                              rdf=(0.0, 3.5, hist1), pair_vectors=pv1)
+        assert np.array_equal(pv1.cpu().numpy(), want), "tensor"
+        assert torch.equal(hist1, hist0) and int(hist0.sum()) == N * NN, "histogram"
+        for x, y in ((fa1, fa0), (fb1, fb0)):
+            assert float((x - y).abs().max()) <= 2e-5 * max(1.0, float(y.abs().max()))
+        assert abs(float(part1.sum()) - float(part0.sum())) <= 2e-5 * max(1.0, abs(float(part0.sum())))
+        fa2, fb2 = htf.ops.build_eval_forces2(base, gauss, p4, dnn, dhead, dnl, box, r_cut, NN)  # nothing stored, no histogram
+        assert float((fa2 - fa1).abs().max()) <= 2e-6 * max(1.0, float(fa1.abs().max()))
+        assert float((fb2 - fb1).abs().max()) <= 2e-6 * max(1.0, float(fb1.abs().max()))
+
+
+@pytest.mark.parametrize("form", ["HTF_FUSED2_ROWS=2", "HTF_FUSED2_ROWS=4", "HTF_FUSED2_ROWS=0", "HTF_FUSED2_COMPACT=0"])
+def test_crafted_row_lengths_c4_every_form(htf, cuda, form):
+    """The C4 sweep's forms (two / four rows per wave with merged tails; the compacting persistent kernel; the same without
+    compaction), each forced in a child process."""
+    import subprocess
+    import sys
+    k, v = form.split("=")
+    env = dict(os.environ, **{k: v})
+    if k == "HTF_FUSED2_COMPACT":
+        env["HTF_FUSED2_ROWS"] = "0"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        "-k", "crafted_row_lengths_c4_body"],
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
