@@ -49,20 +49,6 @@ LaunchEvents &launch_events() {
 
 constexpr int kFChunk = 3; // index loads hoisted per lane per trip (as pair_vectors.hip: n_neigh <= 192 in one trip)
 
-// A neighbor's position for the gather-evaluate kernels: x, y, z and the type bits, which are the LOW dword of w -- for fp64
-// positions 28 of the 32 bytes (a 16-B and a 12-B load instead of two 16-B ones: an eighth less data through the texture path
-// that the fp64 wire keeps busiest, one register less per gathered position)
-__device__ __forceinline__ float4 load_neighbor(const float4 *__restrict__ pos, unsigned k) { return pos[k]; }
-__device__ __forceinline__ double4 load_neighbor(const double4 *__restrict__ pos, unsigned k) {
-    const double *p = reinterpret_cast<const double *>(pos + k);
-    double4 r;
-    r.x = p[0];
-    r.y = p[1];
-    r.z = p[2];
-    r.w = __longlong_as_double((long long)(unsigned)reinterpret_cast<const int *>(p)[6]);
-    return r;
-}
-
 struct FusedAcc {
     float fx = 0.f, fy = 0.f, fz = 0.f, en = 0.f;
     Virial6 v;

@@ -140,6 +140,11 @@ __device__ __forceinline__ void build_row(
 // Measured at C3 with streaming stores (run-to-run spread ~10 %): one row per wave 67-75 us; 2 / 4 / 8
 // rows per wave taken one after the other 74 / 74 / 77 us; loads up front, 2 / 4 / 8 rows: 64-71 /
 // 60-68 / 72 us.
+// (Round 3, measured and removed: the merged-tail form of fused_rows_group_tails as a pure builder -- two straight-line trips per
+//  row and ONE shared trip for the tails of a wave's rows.  Standalone with the full zero fill it won 5 % at two rows per wave
+//  (68.4-69.2 -> 64.6-65.4 us at C3, 344 MB of true traffic = 54.7 us at the sustainable rate; three / four rows 75.5 / 76.8),
+//  but through the context, where counts_io bounds the zero fill, it LOST 5 % (build + evaluator 112.0-112.2 against
+//  106.5-107.1 us on an equilibrated liquid) and in the pair-MLP step 85.7-86.7 against 81.5-81.6.  Tensor digests identical.)
 template <typename PT, typename DT, int R>
 __global__ __launch_bounds__(256) void build_pair_vectors_kernel(
     typename Vec4<DT>::type *__restrict__ dest, const typename Vec4<PT>::type *__restrict__ pos,
@@ -184,7 +189,7 @@ __global__ __launch_bounds__(256) void build_pair_vectors_kernel(
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
-        for (int t = 0; t < kChunk; ++t) pk[r][t] = pos[k[r][t]];
+        for (int t = 0; t < kChunk; ++t) pk[r][t] = load_neighbor(pos, k[r][t]); // (fp64: 28 of the 32 bytes; build + evaluator 122.1 -> 120.4 us)
     unsigned redo = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
