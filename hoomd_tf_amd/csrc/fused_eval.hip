@@ -399,8 +399,12 @@ __device__ __forceinline__ void fused_rows_group_tails(
 #pragma unroll
     for (int r = 1; r < R; ++r) rl += lane >= S[r] ? 1u : 0u;
     unsigned head_l = 0, s_l = 0, nn_l = 0;
+    unsigned zero_end_r[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
+        zero_end_r[r] = NN; // (delta zero fill: where the previous call's row ended -- read with the row's other scalars, used last)
+        if constexpr (STORE)
+            if (counts_io != nullptr) zero_end_r[r] = counts_io[w0 + r];
         head[r] = head_list[w0 + r + offset];
         pi[r] = pos[w0 + r + offset];
         const unsigned *nl = nlist + head[r];
@@ -511,7 +515,7 @@ __device__ __forceinline__ void fused_rows_group_tails(
         const unsigned filled = Q[r] < NN ? Q[r] : NN;
         if constexpr (STORE) {
             float4 *row = dest + (size_t)w * NN;
-            const unsigned zero_end = counts_io != nullptr ? counts_io[w] : NN;
+            const unsigned zero_end = zero_end_r[r];
             for (unsigned sl = filled + lane; sl < zero_end; sl += 64) store_stream(&row[sl], make_float4(0.f, 0.f, 0.f, 0.f));
             if (counts_io != nullptr && lane == 0) counts_io[w] = filled;
         }
