@@ -691,15 +691,36 @@ __global__ __launch_bounds__(256, 1) void mlp_grad_f16_kernel(const typename Vec
     f32x16 gw3[2] = {zero16(), zero16()};
     float gb1 = 0.f, gb2 = 0.f, gb3 = 0.f, loss = 0.f;
 
+    // One wave per SIMD: nothing hides a global load's ~2 us but the wave's own work, so the round's inputs are read a round
+    // ahead (this lane's pair vector of the NEXT tile) and the row's labels at the top of the round, not where they are used.
+    auto read_slot = [&](unsigned long long uu, float &ox, float &oy, float &oz) {
+        ox = oy = oz = 0.f;
+        if (uu < U) {
+            const unsigned sl = tile_of(uu) * 32 + p;
+            if (sl < NN) {
+                const auto v = nlist[(size_t)row_of(uu) * NN + sl];
+                ox = (float)v.x; oy = (float)v.y; oz = (float)v.z;
+            }
+        }
+    };
+    float nx, ny, nz;
+    read_slot((unsigned long long)blockIdx.x * 4 + w, nx, ny, nz);
     for (unsigned long long base = (unsigned long long)blockIdx.x * 4; base < U; base += (unsigned long long)gridDim.x * 4) {
         const unsigned long long u = base + w;
         const bool valid = u < U;
         const unsigned row = valid ? row_of(u) : 0u, tile = valid ? tile_of(u) : 0u;
         const unsigned slot = tile * 32 + p;
-        float x = 0.f, y = 0.f, z = 0.f;
-        if (valid && slot < NN) {
-            const auto v = nlist[(size_t)row * NN + slot];
-            x = (float)v.x; y = (float)v.y; z = (float)v.z;
+        const float x = nx, y = ny, z = nz;
+        read_slot(u + (unsigned long long)gridDim.x * 4, nx, ny, nz);
+        float lx = 0.f, ly = 0.f, lz = 0.f, lw = 0.f; // the row's labels (FUSED: used after the forward pass)
+        if (FUSED) {
+            if (lab_f64) {
+                const double4 l = ((const double4 *)labels)[row];
+                lx = (float)l.x; ly = (float)l.y; lz = (float)l.z; lw = (float)l.w;
+            } else {
+                const float4 l = ((const float4 *)labels)[row];
+                lx = l.x; ly = l.y; lz = l.z; lw = l.w;
+            }
         }
         const float tx = x + kNormDelta, ty = y + kNormDelta, tz = z + kNormDelta;
         const float r = sqrtf(tx * tx + ty * ty + tz * tz);
@@ -795,14 +816,6 @@ __global__ __launch_bounds__(256, 1) void mlp_grad_f16_kernel(const typename Vec
                 }
             }
             if (pred_out && valid && tile == 0 && lane == 0) pred_out[row] = F;
-            float lx, ly, lz, lw;
-            if (lab_f64) {
-                const double4 l = ((const double4 *)labels)[row];
-                lx = (float)l.x; ly = (float)l.y; lz = (float)l.z; lw = (float)l.w;
-            } else {
-                const float4 l = ((const float4 *)labels)[row];
-                lx = l.x; ly = l.y; lz = l.z; lw = l.w;
-            }
             rs = make_float4(F.x - lx, F.y - ly, F.z - lz, F.w - lw);
         } else {
             rs = residual(pred, labels, lab_f64, row);
