@@ -564,6 +564,9 @@ __global__ __launch_bounds__(256, sizeof(PT) == 8 ? HTF_TAILS_MINB_F64 : 1) void
     unsigned *__restrict__ counts_io) {
     const PotParams p = resolve_theta<KIND>(pin);
     const unsigned lane = threadIdx.x & 63u;
+    // (one wave per group of R rows.  Round 3, measured: the same body under a grid-stride loop, waves persistent at 4 ... 32
+    //  workgroups per CU: 60.3-71.4 us against 57.2, and 61.2 with the loop running once -- the loop alone costs the straight-line
+    //  code its schedule; fp64 positions 88.7-93.8 against 67.)
     const unsigned w0 = R * __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     if (w0 >= batch) return;
     fused_rows_group_tails<KIND, STORE, R, PT>(w0, lane, pos, N, NN, offset, batch, box, n_neigh, nlist, head_list, rmaxsq,
