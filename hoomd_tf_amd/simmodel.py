@@ -804,12 +804,13 @@ def masked_nlist(nlist, type_tensor, type_i=None, type_j=None):
 
 def compute_rdf(nlist, r_range, type_tensor=None, nbins=100, type_i=None, type_j=None):
     """simmodel.py:638-673 -> (rdf[nbins], bin midpoints), both fp32 device tensors.
-    One fused histogram pass over the pair vectors (type masking included)."""
+    One fused histogram pass over the pair vectors (type masking included).
+
+    Traced: the untyped form over the step's own neighbor tensor records HOW to redo itself into the same output tensors
+    (``replay``), so that a model which feeds it to a device-side metric (``MeanTensor``) can be replayed from the step
+    plan like the reference's tf.function does -- no Python in the step loop (tfcompute._maybe_install_plan)."""
     t = nlist.tensor if isinstance(nlist, Nlist) else nlist
     ops._dev(t, "nlist")
-    # an observable: a model whose outputs are saved stays on the eager path; when nothing reads the
-    # outputs (save_output_period None) tfcompute may replay the step without it
-    _trace_log().append({"op": "compute_rdf", "observable": True})
     r0, r1 = float(r_range[0]), float(r_range[1])
     hist = torch.zeros(nbins + 2, dtype=torch.int32, device=t.device)
     tt, stride = None, 0
@@ -820,11 +821,26 @@ def compute_rdf(nlist, r_range, type_tensor=None, nbins=100, type_i=None, type_j
             raise ValueError("type_tensor must live on the device")
     else:
         type_i = type_j = None
-    check(lib.htf_rdf_histogram(t.data_ptr(), ops._dt(t), int(t.shape[0]), int(t.shape[1]), r0, r1, nbins + 2,
-                                tt.data_ptr() if tt is not None else None, int(stride),
-                                -1 if type_i is None else int(type_i), -1 if type_j is None else int(type_j),
-                                hist.data_ptr(), ops._stream(t)))
-    return rdf_from_histogram(hist, r0, r1)
+    ti, tj = -1 if type_i is None else int(type_i), -1 if type_j is None else int(type_j)
+    rdf = torch.empty(nbins, dtype=torch.float32, device=t.device)
+    rs = torch.empty(nbins, dtype=torch.float32, device=t.device)
+
+    def fill(src):
+        check(lib.htf_rdf_histogram(src.data_ptr(), ops._dt(src), int(src.shape[0]), int(src.shape[1]), r0, r1, nbins + 2,
+                                    tt.data_ptr() if tt is not None else None, int(stride), ti, tj,
+                                    hist.data_ptr(), ops._stream(src)))
+        check(lib.htf_rdf_finalize(hist.data_ptr(), nbins, r0, r1, rdf.data_ptr(), rs.data_ptr(), ops._stream(hist)))
+
+    def replay(src):  # the same observable of another step's tensor, into the SAME output tensors
+        hist.zero_()
+        fill(src)
+
+    fill(t)
+    # an observable: a model whose outputs are saved stays on the eager path; when nothing reads the
+    # outputs (save_output_period None) tfcompute may replay the step without it -- or, when it can redo itself, with it
+    _trace_log().append({"op": "compute_rdf", "observable": True, "nlist": nlist, "outputs": (rdf, rs),
+                         "replay": replay if tt is None else None})
+    return rdf, rs
 
 
 def rdf_from_histogram(hist, r0, r1):
@@ -835,6 +851,58 @@ def rdf_from_histogram(hist, r0, r1):
     check(lib.htf_rdf_finalize(hist.data_ptr(), nbins, float(r0), float(r1), rdf.data_ptr(), rs.data_ptr(),
                                ops._stream(hist)))
     return rdf, rs
+
+
+class MeanTensor:
+    """tf.keras.metrics.MeanTensor, which examples/01 (Quickstart, cell 3) averages its RDF with: the element-wise running mean
+    of a tensor -- or of a tuple of tensors, stacked as ``compute_rdf``'s [rdf, r] is -- kept on the device.
+
+    ``update_state`` inside ``SimModel.compute`` is recorded in the trace: when every value it takes came out of a replayable
+    observable, the update is replayable too, and tfcompute runs it from the step plan (a few device launches, capturable in a
+    hipGraph) instead of calling ``compute`` again every step."""
+
+    def __init__(self):
+        self.total, self._count = None, None
+
+    def _add(self, vals):
+        for acc, v in zip(self.total, vals):
+            acc.add_(v)
+        self._count.add_(1.0)
+
+    def update_state(self, values):
+        raw = list(values) if isinstance(values, (tuple, list)) else [values]
+        vals = [v.detach() for v in raw]  # (views of the same storage: a replayed observable refills it in place)
+        for v in vals:
+            ops._dev(v, "MeanTensor value")
+        if self.total is None:
+            self.total = [torch.zeros_like(v, dtype=torch.float32) for v in vals]
+            self._count = torch.zeros((), dtype=torch.float32, device=vals[0].device)
+            self._tuple = isinstance(values, (tuple, list))
+        if len(vals) != len(self.total) or any(v.shape != a.shape for v, a in zip(vals, self.total)):
+            raise ValueError("MeanTensor: the shape of the values changed between updates")
+        self._add(vals)
+        produced = [o for e in _trace_log() if e.get("replay") is not None for o in e.get("outputs", ())]
+        replayable = all(any(v is o for o in produced) for v in raw)
+        _trace_log().append({"op": "metric_update", "observable": True,
+                             "replay": (lambda _src, vals=vals: self._add(vals)) if replayable else None})
+
+    @property
+    def count(self):
+        return 0 if self._count is None else int(round(float(self._count)))
+
+    def reset_states(self):
+        if self.total is not None:
+            for acc in self.total:
+                acc.zero_()
+            self._count.zero_()
+
+    reset_state = reset_states
+
+    def result(self):
+        if self.total is None:
+            raise ValueError("MeanTensor.result() before the first update_state()")
+        n = torch.clamp(self._count, min=1.0)
+        return torch.stack(self.total) / n if self._tuple else self.total[0] / n
 
 
 class _LossMetric:

@@ -95,6 +95,8 @@ class tfcompute:
         self.virial = torch.zeros(6 * s.N, dtype=s.dtype, device=s.device)
         self._plan = None
         self._bplan = None  # EDS-biased model replayed as one kernel (see _maybe_install_plan)
+        self._post_ops = []  # replayable observables of the planned step (compute_rdf -> MeanTensor), run after the force kernel
+        self._post_src = None
         self._ctx_ran = False
         self.model._plan = None
         self.log_name = 'tensorflow'  # m_log_name, TensorflowCompute.cc:62
@@ -222,6 +224,12 @@ class tfcompute:
             # interior rows while the ghost halo is in flight, boundary rows after it
             self.cpp_force.compute_forces_overlapped(timestep, self._arrays(), domain)
             self._ctx_ran = True
+            if self._post_ops:
+                src = self._post_src
+                if src is None or src.shape[0] != self.system.N:
+                    src = self._post_src = self.cpp_force.nlist_buffer(self.system.N, self.system.device)
+                for op in self._post_ops:
+                    op(src)
             return
         if domain is not None:
             domain.exchange_end()
@@ -330,13 +338,23 @@ class tfcompute:
     def _maybe_install_plan(self, nbatch):
         log = simmodel._trace_log()
         fused = [e for e in log if "potential" in e]
-        if (self.force_mode_code == _lib.HTF_TF2HOOMD and len(log) == nbatch and len(fused) == nbatch
+        # observables that can redo themselves on the device (compute_rdf of the step's tensor feeding a MeanTensor, example
+        # 01): the step is still ONE fixed launch sequence -- force kernel, then their replays on the tensor it wrote
+        obs = [e for e in log if e.get("observable")]
+        post = []
+        if (obs and nbatch == 1 and len(log) == 1 + len(obs) and all(e.get("replay") is not None for e in obs)
+                and int(self.fused) == 2 and getattr(self._nlist, "domain", None) is None and not self.model._map_nlist):
+            post = [e["replay"] for e in obs]
+        plain = [e for e in log if not e.get("observable")] if post else log
+        self._post_ops, self._post_src = [], None
+        if (self.force_mode_code == _lib.HTF_TF2HOOMD and len(plain) == nbatch and len(fused) == nbatch
                 and all(e.get("is_output") for e in fused) and not self.save_output_period
                 and all(e["virial"] == bool(self.model.virial) for e in fused)
                 and len({id(e["potential"]) for e in fused}) == 1):
             self._plan = fused[0]["potential"]
             self.model._plan = self._plan
             self.cpp_force.set_potential(self._plan)
+            self._post_ops = post
         else:
             # config C4's shape: closed-form base energy + alpha * soft-RDF CV (+ observables nobody
             # saves).  Replayed as htf_build_eval_forces2: tensor, both force sets and the CV partials
@@ -396,6 +414,8 @@ class tfcompute:
         for e in simmodel._trace_log()[mark:]:
             if "forces" in e and len(output) > 0 and output[0] is e["forces"] and e["nlist"] is inputs[0]:
                 e["is_output"] = True
+            if e.get("op") == "compute_rdf" and e.get("nlist") is not inputs[0]:
+                e["replay"] = None  # an RDF of something else than the step's neighbor tensor (a masked or mapped list): eager
         if self.save_output_period and self._calls % self.save_output_period == 0:
             extra = [_np(o)[np.newaxis, ...] for o in output[self._output_offset:]]
             if self.outputs is None:

@@ -270,28 +270,10 @@ class BenchmarkNonlistModel(htf.SimModel):
         return forces
 
 
-class _MeanTensor:
-    """tf.keras.metrics.MeanTensor"""
-
-    def __init__(self):
-        self.total, self.count = None, 0
-
-    def update_state(self, x):
-        x = torch.stack([torch.as_tensor(v) for v in x]).detach().double() if isinstance(x, (tuple, list)) else x.detach().double()
-        self.total = x.clone() if self.total is None else self.total + x
-        self.count += 1
-
-    def reset_states(self):
-        self.total, self.count = None, 0
-
-    def result(self):
-        return self.total / max(self.count, 1)
-
-
 class QuickstartWCA(htf.SimModel):
     # examples/01. Quickstart.ipynb cell 3 (WCAPotential): r^-12 inside 2^(1/6) via a cast mask, an RDF averaged every step
     def setup(self):
-        self.avg_rdf = _MeanTensor()
+        self.avg_rdf = htf.MeanTensor()  # tf.keras.metrics.MeanTensor in the notebook
 
     def compute(self, nlist):
         r12 = htf.nlist_rinv(nlist)**12

@@ -298,6 +298,34 @@ def test_quickstart_example01(htf, cuda):
     assert rdf.shape == (2, 100) and model.avg_rdf.count == 5 and rdf[0].sum() > 0
     ref_rdf, rs = O.compute_rdf(nl, [0, 3.5])
     np.testing.assert_allclose(rs, rdf[1], rtol=1e-6)
+    # The metric lives on the device and its update is part of the step plan (the reference's tf.function traces
+    # tf.keras.metrics.MeanTensor the same way): compute() is not called again after the first step, and the average over the
+    # next steps is the mean of the per-step RDFs of the oracle on each step's own pair vectors.
+    assert tfcompute._plan is not None and len(tfcompute._post_ops) == 2
+    calls = {"n": 0}
+    orig = model.compute
+
+    def counting(*a, **k):
+        calls["n"] += 1
+        return orig(*a, **k)
+    model.compute = counting
+    model.avg_rdf.reset_states()
+    want = []
+    for _ in range(4):
+        sim.run(1)
+        want.append(O.compute_rdf(tfcompute.get_nlist_array().astype(np.float32), [0, 3.5])[0])
+    assert calls["n"] == 0 and model.avg_rdf.count == 4
+    np.testing.assert_allclose(model.avg_rdf.result().cpu().numpy()[0], np.mean(want, axis=0), rtol=2e-5, atol=1e-6)
+    # ... and the whole step, observable included, is a fixed launch sequence: replayed from a hipGraph it leaves the same
+    # average behind as the eager replay of the same steps
+    assert tfcompute.graph_safe()
+    model.avg_rdf.reset_states()
+    sim.run(12, graph=True)
+    assert calls["n"] == 0 and model.avg_rdf.count == 12
+    g_rdf = model.avg_rdf.result().cpu().numpy()
+    assert np.all(np.isfinite(g_rdf)) and g_rdf[0].sum() > 0
+    np.testing.assert_allclose(g_rdf[1], rs, rtol=1e-6)
+    model.compute = orig
     # the lowered potential is the masked polynomial (one evaluator kernel), not the autograd fallback
     from hoomd_tf_amd import simmodel
     pots = [k for k in getattr(simmodel.compute_nlist_forces, "_cache", {}) if k[0] == "poly" and k[-1] is not None]
