@@ -151,6 +151,9 @@ STANDIN_PROTOTYPES = {
 }
 
 
+ABI_VERSION = 2  # include/htf_amd.h HTF_AMD_ABI_VERSION: the struct layouts the ctypes Structures of this file mirror
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(
@@ -161,8 +164,9 @@ def _load():
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.htf_abi_version() != 1:
-        raise ImportError("hoomd_tf_amd: ABI version mismatch (library %d, binding 1)" % lib.htf_abi_version())
+    if lib.htf_abi_version() != ABI_VERSION:
+        raise ImportError("hoomd_tf_amd: ABI version mismatch (library %s: %d, this binding: %d); rebuild with "
+                          "`make -C hoomd_tf_amd/csrc`" % (LIB_PATH, lib.htf_abi_version(), ABI_VERSION))
     return lib
 
 

@@ -149,10 +149,12 @@ __device__ __forceinline__ void pair_eval_f(const RinvFwd &f, float x, float y, 
         const float ex = __builtin_amdgcn_exp2f((d * d) * p.gauss_k_exp);
         const float phi = f.cond ? ex : 0.0f;
         e = p.gauss_coef * phi;
-        // (v_mul_legacy_f32: 0 * inf = 0, so the one unphysical slot with r' = 0 exactly keeps a zero force without a select)
-        float phi_irp;
+        // (v_mul_legacy_f32: 0 times ANYTHING, inf and NaN included, is +0.  The one unphysical slot with r' = 0 exactly --
+        //  x = y = z = -1e-7 -- has irp = inf and, on rinv_fwd's common branch, rp = 0 * inf = NaN, hence d = NaN: both
+        //  products that meet its phi = 0 are legacy multiplies, so its force is an exact zero without a select)
+        float phi_irp, c;
         asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(phi_irp) : "v"(phi), "v"(f.irp));
-        const float c = (p.gauss_k_force * d) * phi_irp;
+        asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(c) : "v"(p.gauss_k_force * d), "v"(phi_irp));
         fx = c * f.tx;
         fy = c * f.ty;
         fz = c * f.tz;

@@ -7,6 +7,7 @@
 // end, destroy) do not stall other Python threads.
 //   build: g++ -O2 -shared -fPIC pybind_abi.cc -I<repo>/include $(python -m pybind11 --includes) -L.. -lhtf_amd -o ../_htf_abi.so
 #include <pybind11/pybind11.h>
+#include <string>
 
 #include <cstdint>
 #include <type_traits>
@@ -124,6 +125,12 @@ void bind(py::module &m, const char *name, R (*fn)(A...)) {
 
 PYBIND11_MODULE(_htf_abi, m) {
     m.doc() = "pybind11 binding of libhtf_amd.so's C ABI: pointers as integers";
+    // a stale module (or library): this module's templates were instantiated from one header, the library it resolved at load
+    // time may have been built from another
+    if (htf_abi_version() != HTF_AMD_ABI_VERSION)
+        throw pybind11::import_error("_htf_abi: built against ABI version " + std::to_string(HTF_AMD_ABI_VERSION) + ", libhtf_amd.so reports " +
+                                     std::to_string(htf_abi_version()) + "; rebuild with `make -C hoomd_tf_amd/csrc pybind`");
+    m.attr("abi_version") = HTF_AMD_ABI_VERSION;
 #define X(fn) bind(m, #fn, &fn);
     HTF_ABI_FUNCTIONS(X)
 #undef X

@@ -204,9 +204,11 @@ class PairNorm(_TorchOperand):
     def __ge__(self, o): return self.ad >= _unwrap(o)
 
 
-class PairMask:
+class PairMask(_TorchOperand):
     """``r < cut`` (and its ``tf.cast(..., tf.float32)``): multiplies a per-pair rinv polynomial into its truncated form --
-    one kernel (HTF_POT_RINV_POLY with ``poly_cut``); anything else gets the torch tensor."""
+    one kernel (HTF_POT_RINV_POLY with ``poly_cut``).  Everything else sees the bool tensor: it is a ``_TorchOperand``
+    (``torch.where(r < cut, ...)``, ``(r < cut).to(...)``, returning it as an output), with the boolean operators a
+    ``a < r < b`` shell needs."""
 
     def __init__(self, nlist, cut):
         self.nlist, self.cut = nlist, cut
@@ -215,12 +217,32 @@ class PairMask:
         t = self.nlist.tensor[:, :, :3]
         return (torch.sqrt((t * t).sum(dim=2)) < self.cut)
 
+    @property
+    def ad(self):
+        return self.tensor()
+
+    shape = property(lambda self: self.nlist.tensor.shape[:2])
+    dtype = torch.bool
+    device = property(lambda self: self.nlist.tensor.device)
+
     def __mul__(self, o):
         if isinstance(o, RinvPoly) and o.nlist is self.nlist and not o.reduced and o.cut in (None, self.cut):
             return RinvPoly(o.nlist, o.terms, cut=self.cut)
+        if isinstance(o, PairMask):
+            return self.tensor() & o.tensor()
         return self.tensor().to(torch.float32) * _unwrap(o)
 
     __rmul__ = __mul__
+
+    def __and__(self, o): return self.tensor() & _unwrap(o)
+    def __or__(self, o): return self.tensor() | _unwrap(o)
+    def __xor__(self, o): return self.tensor() ^ _unwrap(o)
+    __rand__, __ror__, __rxor__ = __and__, __or__, __xor__
+    def __invert__(self): return ~self.tensor()
+    def __getitem__(self, idx): return self.tensor()[idx]
+    def to(self, *a, **k): return self.tensor().to(*a, **k)
+    def float(self): return self.tensor().float()
+    def numpy(self): return self.tensor().cpu().numpy()
 
 
 def cast(x, dtype=None):
@@ -825,21 +847,28 @@ def compute_rdf(nlist, r_range, type_tensor=None, nbins=100, type_i=None, type_j
     rdf = torch.empty(nbins, dtype=torch.float32, device=t.device)
     rs = torch.empty(nbins, dtype=torch.float32, device=t.device)
 
-    def fill(src):
+    def fill(src, types, tstride):
         check(lib.htf_rdf_histogram(src.data_ptr(), ops._dt(src), int(src.shape[0]), int(src.shape[1]), r0, r1, nbins + 2,
-                                    tt.data_ptr() if tt is not None else None, int(stride), ti, tj,
+                                    types.data_ptr() if types is not None else None, int(tstride), ti, tj,
                                     hist.data_ptr(), ops._stream(src)))
         check(lib.htf_rdf_finalize(hist.data_ptr(), nbins, r0, r1, rdf.data_ptr(), rs.data_ptr(), ops._stream(hist)))
 
-    def replay(src):  # the same observable of another step's tensor, into the SAME output tensors
+    def replay(src, pos=None):
+        """The same observable of another step's tensor, into the SAME output tensors.  The typed form reads the row types from
+        column 3 of that step's positions side buffer (fp32 [N, 4]: what ``positions[:, 3]`` is a view of in compute())."""
         hist.zero_()
-        fill(src)
+        if tt is None:
+            fill(src, None, 0)
+        else:
+            fill(src, pos[:, 3], pos.stride(0))
 
-    fill(t)
+    fill(t, tt, stride)
     # an observable: a model whose outputs are saved stays on the eager path; when nothing reads the
-    # outputs (save_output_period None) tfcompute may replay the step without it -- or, when it can redo itself, with it
+    # outputs (save_output_period None) tfcompute may replay the step without it -- or, when it can redo itself, with it.
+    # The typed form (simmodel.py:656-658 masked_nlist) can redo itself when its types are ``positions[:, 3]`` of the step's
+    # own positions tensor: tfcompute._finish_update checks that (``type_tensor``) and withdraws ``replay`` otherwise.
     _trace_log().append({"op": "compute_rdf", "observable": True, "nlist": nlist, "outputs": (rdf, rs),
-                         "replay": replay if tt is None else None})
+                         "type_tensor": type_tensor, "replay": replay})
     return rdf, rs
 
 
@@ -883,8 +912,8 @@ class MeanTensor:
         self._add(vals)
         produced = [o for e in _trace_log() if e.get("replay") is not None for o in e.get("outputs", ())]
         replayable = all(any(v is o for o in produced) for v in raw)
-        _trace_log().append({"op": "metric_update", "observable": True,
-                             "replay": (lambda _src, vals=vals: self._add(vals)) if replayable else None})
+        _trace_log().append({"op": "metric_update", "observable": True, "inputs": raw,
+                             "replay": (lambda _src, _pos=None, vals=vals: self._add(vals)) if replayable else None})
 
     @property
     def count(self):

@@ -226,10 +226,11 @@ class tfcompute:
             self._ctx_ran = True
             if self._post_ops:
                 src = self._post_src
-                if src is None or src.shape[0] != self.system.N:
-                    src = self._post_src = self.cpp_force.nlist_buffer(self.system.N, self.system.device)
+                if src is None or src[0].shape[0] != self.system.N:
+                    src = self._post_src = (self.cpp_force.nlist_buffer(self.system.N, self.system.device),
+                                            self.cpp_force.positions_buffer(self.system.N, self.system.device))
                 for op in self._post_ops:
-                    op(src)
+                    op(src[0], src[1])
             return
         if domain is not None:
             domain.exchange_end()
@@ -341,9 +342,16 @@ class tfcompute:
         # observables that can redo themselves on the device (compute_rdf of the step's tensor feeding a MeanTensor, example
         # 01): the step is still ONE fixed launch sequence -- force kernel, then their replays on the tensor it wrote
         obs = [e for e in log if e.get("observable")]
+        # Only what a traced consumer reads is worth replaying: a bare compute_rdf whose result nothing traced takes -- a list
+        # append, a torch in-place accumulation in model code -- keeps the model on the eager path, as before: after
+        # the plan is installed SimModel.compute is never called again, and only htf.MeanTensor updates survive it.
+        # Under domain decomposition the replays run on the rank's own rows, as the eager path (and the reference: every MPI rank
+        # runs its own model on its local particles, test_mpi_tensorflow.py) does: the global RDF is the sum over ranks.
         post = []
-        if (obs and nbatch == 1 and len(log) == 1 + len(obs) and all(e.get("replay") is not None for e in obs)
-                and int(self.fused) == 2 and getattr(self._nlist, "domain", None) is None and not self.model._map_nlist):
+        consumed = [v for e in obs if e.get("op") == "metric_update" and e.get("replay") is not None for v in e.get("inputs", ())]
+        fed = all(any(o is v for o in e.get("outputs", ()) for v in consumed) for e in obs if e.get("op") == "compute_rdf")
+        if (obs and fed and nbatch == 1 and len(log) == 1 + len(obs) and all(e.get("replay") is not None for e in obs)
+                and int(self.fused) == 2 and not self.model._map_nlist):
             post = [e["replay"] for e in obs]
         plain = [e for e in log if not e.get("observable")] if post else log
         self._post_ops, self._post_src = [], None
@@ -363,7 +371,7 @@ class tfcompute:
             rest = [e for e in log if "biased" not in e and not e.get("observable")]
             if (self.force_mode_code == _lib.HTF_TF2HOOMD and nbatch == 1 and len(biased) == 1 and not rest
                     and biased[0].get("is_output") and not self.save_output_period and not self.model.virial
-                    and not self.model.check_nlist and int(self.fused) == 2 and self.system.dtype == torch.float32
+                    and not self.model.check_nlist and int(self.fused) == 2
                     and getattr(self._nlist, "domain", None) is None and not self.model._map_nlist):
                 self._bplan = dict(biased[0]["biased"])
                 self.model._plan = self._bplan
@@ -414,8 +422,15 @@ class tfcompute:
         for e in simmodel._trace_log()[mark:]:
             if "forces" in e and len(output) > 0 and output[0] is e["forces"] and e["nlist"] is inputs[0]:
                 e["is_output"] = True
-            if e.get("op") == "compute_rdf" and e.get("nlist") is not inputs[0]:
-                e["replay"] = None  # an RDF of something else than the step's neighbor tensor (a masked or mapped list): eager
+            if e.get("op") == "compute_rdf":
+                tt = e.get("type_tensor")
+                if e.get("nlist") is not inputs[0]:
+                    e["replay"] = None  # an RDF of something else than the step's neighbor tensor (a masked or mapped list): eager
+                elif tt is not None and not (isinstance(tt, torch.Tensor) and isinstance(inputs[1], torch.Tensor)
+                                             and tt.dim() == 1 and tt.shape[0] == n and tt.stride(0) == 4
+                                             and tt.data_ptr() == inputs[1].data_ptr() + 3 * inputs[1].element_size()
+                                             and inputs[1].is_contiguous()):
+                    e["replay"] = None  # types from anywhere but positions[:, 3] of this step's positions tensor: eager
         if self.save_output_period and self._calls % self.save_output_period == 0:
             extra = [_np(o)[np.newaxis, ...] for o in output[self._output_offset:]]
             if self.outputs is None:

@@ -26,7 +26,11 @@
 extern "C" {
 #endif
 
-#define HTF_AMD_ABI_VERSION 1
+/* Bumped whenever a struct of this header changes size or layout or an enum gains a value (2: htf_potential_desc gained
+ * poly_cut, htf_mlp_precision gained HTF_MLP_SPLIT16).  Every binding compares the value it was built against with
+ * htf_abi_version() of the library it loaded and refuses a mismatch: hoomd_tf_amd/_lib.py, csrc/pybind_abi.cc,
+ * integration/hoomd_shim/TensorflowComputeAMD.cc. */
+#define HTF_AMD_ABI_VERSION 2
 
 /* the library is built with -fvisibility=hidden (as the reference is,
  * htf/CMakeLists.txt:48); only these entry points are exported */
@@ -119,7 +123,8 @@ typedef struct htf_potential_desc {
     const float *W1, *b1, *W2, *b2, *W3, *b3;
     /* RINV_POLY: optional hard mask `tf.cast(tf.norm(nlist[:, :, :3], axis=2) < poly_cut, tf.float32) * energy`
      * (examples/01. Quickstart.ipynb cell 3: WCA as r^-12 inside 2^(1/6)); the mask carries no gradient.  0 = no mask.
-     * (appended in round 3: a zero-initialised desc of the earlier layout means "no mask") */
+     * (appended with ABI version 2: a caller built against the version-1 layout passes a SHORTER struct and must be rebuilt;
+     *  the version check is what catches it) */
     double poly_cut;
 } htf_potential_desc;
 

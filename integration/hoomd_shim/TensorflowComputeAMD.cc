@@ -25,6 +25,9 @@ TensorflowComputeAMD::TensorflowComputeAMD(pybind11::object &py_self, std::share
       hook(std::make_shared<HalfStepHookWrapper<TensorflowComputeAMD>>(*this)), m_nlist(nlist), m_r_cut(r_cut),
       m_nneighs(nneighs), m_force_mode(force_mode), m_period(period), m_batch_size(batch_size) {
     m_exec_conf->msg->notice(2) << "Starting TensorflowComputeAMD" << std::endl;
+    if (htf_abi_version() != HTF_AMD_ABI_VERSION) // this plugin was compiled against another include/htf_amd.h than the library
+        throw std::runtime_error("TensorflowComputeAMD: compiled against htf_amd ABI version " + std::to_string(HTF_AMD_ABI_VERSION) +
+                                 ", libhtf_amd.so reports " + std::to_string(htf_abi_version()));
     m_cfg.r_cut = r_cut;
     m_cfg.nneighs = nneighs;
     m_cfg.force_mode = force_mode == FORCE_MODE::tf2hoomd ? HTF_TF2HOOMD : HTF_HOOMD2TF;

@@ -62,7 +62,8 @@ class LJRDF(htf.SimModel):
 class LJTypedModel(htf.SimModel):
     # build_examples.py:80-101
     def setup(self):
-        self.rdfa, self.rdfb = [], []
+        self.avg_rdfa = htf.MeanTensor()
+        self.avg_rdfb = htf.MeanTensor()
 
     def compute(self, nlist, positions, box):
         rinv = htf.nlist_rinv(nlist)
@@ -72,8 +73,8 @@ class LJTypedModel(htf.SimModel):
         forces = htf.compute_nlist_forces(nlist, energy)
         rdfa, rs = htf.compute_rdf(nlist, [0, 10], positions[:, 3], type_i=0, type_j=1)
         rdfb, rs = htf.compute_rdf(nlist, [0, 10], positions[:, 3], type_i=1, type_j=0)
-        self.rdfa.append(rdfa)
-        self.rdfb.append(rdfb)
+        self.avg_rdfa.update_state(rdfa)
+        self.avg_rdfb.update_state(rdfb)
         return forces
 
 

@@ -17,6 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import hoomd_tf_amd as htf  # noqa: E402
 from hoomd_tf_amd import _lib, ops, optimizers, standin  # noqa: E402
+from oracle import htf_oracle as O  # noqa: E402  (the checker; this file is test infrastructure)
 
 sys.path.insert(0, sys.argv[1])
 import _hoomd_stub as H  # noqa: E402
@@ -94,6 +95,37 @@ class FakeHoomdRun:
         return view(self.c.virialPtr(), (6, pitch), sdt), pitch
 
 
+def oracle_check(run, virial, batch_size, what):
+    """What the shim left in "HOOMD's" m_force (and, from a zeroed m_virial, in m_virial) against the CPU oracle's
+    computeForces (oracle/htf_oracle.py, TensorflowCompute.cc:129-216) on the same positions and list: SURVEY 8(c)'s bound
+    as stated, plus the named condition term for the virial's cancelling row sums."""
+    s, nlc = run.sysm, run.nl
+    hd = np.float32 if single else np.float64
+    pos = s.pos.cpu().numpy()[:, :3].astype(hd)
+    L = [float(s.box3x3[1][i] - s.box3x3[0][i]) for i in range(3)]
+    model = (lambda x: O.lj_model(x.astype(np.float64), virial=True)) if virial else (lambda x: O.lj_model(x.astype(np.float64)))
+    ref, vref = O.compute_forces(pos, np.zeros(s.N, np.int32), nlc.n_neigh.cpu().numpy().view(np.uint32),
+                                 nlc.head_list.cpu().numpy().view(np.uint32), nlc.nlist.cpu().numpy().view(np.uint32),
+                                 O.make_box(L, dtype=hd), R_CUT, NN, model, batch_size=batch_size, model_dtype=np.float32, virial=virial)
+    got = run.force().cpu().numpy().astype(np.float64)
+    err = np.abs(got - ref)
+    # sum_j |f_ij| per row, the scale two fp32 summation orders differ on (tests/test_gpu_parity.py: cancelling_rows)
+    pv = O.prepare_neighbors(pos, np.zeros(s.N, np.int32), nlc.n_neigh.cpu().numpy().view(np.uint32),
+                             nlc.head_list.cpu().numpy().view(np.uint32), nlc.nlist.cpu().numpy().view(np.uint32),
+                             O.make_box(L, dtype=hd), R_CUT, NN).astype(np.float32).astype(np.float64)
+    sg, tg, rpg, cg = O._rinv_and_grad_factor(pv)
+    cond = np.abs(2.0 * O._grad_from_dEds(2.0 * (2.0 * sg ** 6 - 1.0) * (6.0 * sg ** 5), sg, tg, rpg, cg)).sum(axis=(1, 2))[:, None]
+    assert np.all(err[:, 3] <= 1e-5 + 2e-5 * np.abs(ref[:, 3])), (what, "energies vs oracle, as stated", float(err[:, 3].max()))
+    assert np.all(err <= 1e-5 + 2e-5 * np.abs(ref) + 2e-6 * cond), (what, "forces vs oracle", float(err.max()))
+    if virial:
+        v6, pitch = run.virial6()
+        gotv = v6.cpu().numpy().astype(np.float64)[:, :s.N]
+        refv = np.asarray(vref, dtype=np.float64).reshape(6, s.N)
+        scale = np.abs(refv).max()
+        assert np.all(np.abs(gotv - refv) <= 2e-5 + 5e-5 * np.abs(refv) + 2e-6 * scale), (what, "virial vs oracle", float(np.abs(gotv - refv).max()))
+    return float(err.max())
+
+
 def context_for(run, virial, batch_size=0, period=1):
     ctx = htf.Context(r_cut=R_CUT, nneighs=NN, period=period, batch_size=batch_size, scalar_dtype=sdt, virial=virial,
                       max_n=run.sysm.N, fused=2)
@@ -140,7 +172,14 @@ for virial, batch_size, period in ((True, 0, 1), (False, 0, 1), (True, 300, 1), 
     pv = view(run.c.getNlistBuffer(), (n_b, NN, 4), torch.float32)
     assert torch.equal(pv, ctx.nlist_buffer(n_b, dev))          # the side buffer getNlistBuffer() hands out
     assert abs(run.c.getLogValue("tensorflow", 9) - float(run.force()[:, 3].double().sum())) < 1e-6 * s.N
-    print("OK forces virial=%s batch_size=%d period=%d" % (virial, batch_size, period))
+    # self-standing: one more compute on the moved particles, from a zeroed m_virial, against the CPU oracle
+    if virial:
+        v6.zero_()
+    ts = 10 + (-10) % period
+    run.c.compute(ts)
+    torch.cuda.synchronize()
+    e = oracle_check(run, virial, batch_size, (virial, batch_size, period))
+    print("OK forces virial=%s batch_size=%d period=%d (max err vs oracle %.2e)" % (virial, batch_size, period, e))
 
 # ------------------------------------------------------------------ 2. MaxParticleNumberChange -> reallocate
 run = FakeHoomdRun()

@@ -47,7 +47,9 @@ def test_hot_kernels_use_no_scratch(tmp_path):
         "build_pair_vectors_kernel", "eval_pair_kernel", "eval_pair2_kernel", "train_pair_kernel",
         "mlp_grad_mfma_kernel", "mlp_grad_kernel", "rdf_hist", "nve_step_kernel", "fused_forces_rows2_kernel",
         "fused_forces2_kernel", "build_nlist_kernel", "cell_ranges_kernel", "cell_order_kernel", "topk_mlp_kernel",
-        "topk_values_kernel", "positions_radial_kernel", "commit_rebuild_kernel"))]
+        "topk_values_kernel", "positions_radial_kernel", "commit_rebuild_kernel",
+        # the kernels bench.py times: the one-kernel LJ / WCA step (fp32 and fp64 wire, 2-4 rows per wave) and the C4 sweep
+        "fused_forces_tails_kernel", "fused_forces2_tails_kernel"))]
     # (polynomial + virial + fp64 positions spills a few SGPRs: a rare combination, left alone)
     hot += [n for n in meta if "fused_forces_kernel" in n
             and not re.match(r"_ZN3htf19fused_forces_kernelILi3ELb1ELb[01]EdEE", n)]

@@ -480,26 +480,50 @@ def test_pair_mlp_padded_widths(htf, cuda):
         htf.Potential.pair_mlp(mlp_params(seed=1, K=40), 0, 3)
 
 
-def test_pair_mlp_full_size_rows(htf, cuda):
-    """131072 x 128 through the MFMA kernel; sampled rows vs the oracle, determinism."""
+@pytest.mark.parametrize("precision", ["fp32", "split16", "split"])
+def test_pair_mlp_full_size_rows(htf, cuda, precision):
+    """BASELINE configs[2] at its own size and on its own input: the C3 fcc box (131 072 particles, NN 128), pair vectors from
+    the build kernel, through the MFMA evaluator in every full-precision form -- ``split16`` is the one bench.py times
+    (pair_mlp_kernel<tanh, float, SPLIT16>: persistent blocks, two per CU) -- 512 sampled rows of forces, energies AND the
+    virial against the fp64 oracle (layers.py:46-49 + Keras Dense, simmodel.py:509-555), at the fixture tolerances; then
+    synthetic rows with 70-124 live slots of random directions (every tile-skip pattern), and determinism."""
+    from hoomd_tf_amd import standin
     from hoomd_tf_amd.initializers import mlp_params
-    N, NN = 131072, 128
+    sysm, nlc, L = _jittered(standin, cuda, "fcc", 32, 3)
+    N, NN = sysm.N, 128
+    assert N == 131072
+    pv = htf.ops.build_pair_vectors(sysm.pos, nlc.n_neigh, nlc.head_list, nlc.nlist, sysm.box, 3.0, NN)
+    params = mlp_params(seed=3)
+    pot = htf.Potential.pair_mlp(params, 0.0, 3.0, precision=precision)
+    f, v = htf.ops.eval_forces(pot, pv, virial=True)
+    f0 = htf.ops.eval_forces(pot, pv)
+    assert torch.equal(f, f0) and torch.equal(f0, htf.ops.eval_forces(pot, pv))
+    rows = np.random.default_rng(8).choice(N, 512, replace=False)
+    sub = pv[torch.from_numpy(rows).to(cuda)].cpu().numpy().astype(np.float64)
+    ref, gg = O.pair_mlp_model(sub, params, 0.0, 3.0, "tanh", return_grad=True)
+    cond = np.abs(2 * gg).sum(axis=(1, 2))
+    assert_forces_close("mlp_c3box_%s" % precision, f.cpu().numpy()[rows], ref, cond, atol=2e-5, rtol=5e-5, ctol=5e-6)
+    vref = O.compute_virial(sub, 2.0 * gg)
+    vcond = (np.linalg.norm(2 * gg, axis=2) * np.linalg.norm(sub[:, :, :3], axis=2) / 2).sum(axis=1)
+    assert_forces_close("mlp_c3box_virial_%s" % precision, v.cpu().numpy()[rows], vref, vcond, atol=2e-5, rtol=5e-5, ctol=5e-6)
+    # whole-system property: the energy column of every row against the sampled mean (a dropped or doubled tile shows)
+    e_all = f[:, 3].double()
+    assert torch.isfinite(f).all() and abs(float(e_all.mean()) - float(ref[:, 3].mean())) < 0.05 * abs(float(ref[:, 3].mean())) + 0.05
+    del pv, f, v, f0
     g = torch.Generator(device="cuda").manual_seed(5)
     cnt = torch.randint(70, 125, (N, 1), generator=g, device=cuda)
-    v = torch.randn(N, NN, 3, generator=g, device=cuda)
-    v = v / v.norm(dim=2, keepdim=True)
+    d = torch.randn(N, NN, 3, generator=g, device=cuda)
+    d = d / d.norm(dim=2, keepdim=True)
     r = 0.8 + 2.2 * torch.rand(N, NN, 1, generator=g, device=cuda) ** (1 / 3)
     nl = torch.zeros(N, NN, 4, device=cuda)
-    nl[..., :3] = v * r
+    nl[..., :3] = d * r
     nl *= (torch.arange(NN, device=cuda)[None, :, None] < cnt[:, :, None])
-    params = mlp_params(seed=3)
-    pot = htf.Potential.pair_mlp(params, 0.0, 3.0)
-    f = htf.ops.eval_forces(pot, nl)
-    assert torch.equal(f, htf.ops.eval_forces(pot, nl))
+    fs = htf.ops.eval_forces(pot, nl)
+    assert torch.equal(fs, htf.ops.eval_forces(pot, nl))
     rows = torch.randint(0, N, (96,), generator=g, device=cuda)
     sub = nl[rows].cpu().numpy().astype(np.float64)
     ref, gg = O.pair_mlp_model(sub, params, 0.0, 3.0, "tanh", return_grad=True)
-    assert_forces_close("mlp_full_rows", f[rows].cpu().numpy(), ref, np.abs(2 * gg).sum(axis=(1, 2)),
+    assert_forces_close("mlp_full_rows_%s" % precision, fs[rows].cpu().numpy(), ref, np.abs(2 * gg).sum(axis=(1, 2)),
                         atol=2e-5, rtol=5e-5, ctol=5e-6)
 
 
@@ -539,6 +563,30 @@ def test_gauss_potential_and_eval2(htf, cuda, dtype):
     assert torch.equal(rdf_fused, rdf_plain)
     ref_rdf, _ = O.compute_rdf(nl.astype(np.float32), [0, 3.5], nbins=20)
     np.testing.assert_allclose(rdf_fused.cpu().numpy(), ref_rdf, rtol=1e-4)
+
+
+def test_slot_at_minus_norm_delta_contributes_zero(htf, cuda):
+    """x = y = z = -1e-7 exactly: safe_norm's r' = |x + 1e-7| is 0, 1 / r' is inf and the rsq-based forward's r' is 0 * inf =
+    NaN.  TensorFlow's sqrt gradient is NaN there (the one excluded input); the kernels return an exact
+    zero for that slot -- for every closed form, the Gaussian channel (whose force chain meets the NaN: ADVICE r3) and both
+    outputs of the two-potential sweep -- so one such slot cannot poison a row sum or the CV partial."""
+    nl = _nlist_case(17, N=130, NN=64, rmin=0.8)
+    nl[:, 63] = 0
+    want = torch.from_numpy(nl).to(cuda)
+    nl[5, 63, :3] = np.float32(-1e-7)
+    nl[77, 63, :3] = np.float32(-1e-7)
+    x = torch.from_numpy(nl).to(cuda)
+    pg = htf.Potential.gauss(1.1, 0.05, 1.0)
+    for pot in (pg, htf.Potential.lj(), htf.Potential.wca(1.0), htf.Potential.rinv_poly([1.0, -0.5], [12, 1]), htf.Potential.lj_param(1.3, 0.9)):
+        f, v = htf.ops.eval_forces(pot, x, virial=True)
+        assert torch.isfinite(f).all() and torch.isfinite(v).all(), pot.kind
+        assert torch.equal(f, htf.ops.eval_forces(pot, want)), pot.kind
+    n = htf.ops.num_partials(nl.shape[0], 64)
+    pa, pb = torch.zeros(n, device=cuda), torch.zeros(n, device=cuda)
+    fa, fb = htf.ops.eval_forces2(htf.Potential.lj(), pg, x, partials=pa)
+    wa, wb = htf.ops.eval_forces2(htf.Potential.lj(), pg, want, partials=pb)
+    assert torch.isfinite(fa).all() and torch.isfinite(fb).all() and torch.isfinite(pa).all()
+    assert torch.equal(fa, wa) and torch.equal(fb, wb) and torch.equal(pa, pb)
 
 
 # --------------------------------------------------------------------------- aux kernels
@@ -802,7 +850,7 @@ def test_wca_mask_at_the_cutoff_is_the_sqrt_mask(htf, cuda, sigma):
 
 
 # --------------------------------------------------------------------------- round-2 additions
-@pytest.mark.parametrize("precision", ["fp32", "split"])
+@pytest.mark.parametrize("precision", ["fp32", "split", "split16"])
 @pytest.mark.parametrize("act", ["tanh", "linear"])
 def test_pair_mlp_virial(htf, cuda, act, precision):
     """compute_nlist_forces(nlist, energy, virial=True) works for ANY energy upstream (simmodel.py:552-554,
@@ -929,7 +977,7 @@ def test_topk_mlp_through_the_model_surface(htf, cuda):
     assert_forces_close("nlistnn_model_reweighted", f2.cpu().numpy(), ref2, atol=2e-5, rtol=5e-5)
 
 
-def _liquid(htf, cuda, cells=8, steps=300, seed=9):
+def _liquid(htf, cuda, cells=8, steps=300, seed=9, dtype=torch.float32):
     """An equilibrated LJ liquid (rho 0.8442, kT ~ 1) produced by the stand-in MD itself: the kind of
     configuration the benchmark evaluates, with no overlapping pairs."""
     from hoomd_tf_amd import standin
@@ -937,10 +985,10 @@ def _liquid(htf, cuda, cells=8, steps=300, seed=9):
     rng = np.random.default_rng(seed)
     pos = pos + 0.05 * a * rng.standard_normal(pos.shape)
     pos -= np.round(pos / L) * L
-    sysm = standin.System(pos, L, dtype=torch.float32, device=cuda)
+    sysm = standin.System(pos, L, dtype=dtype, device=cuda)
     sysm.randomize_velocities(kT=1.0, seed=seed)
     nl = standin.CellNlist(sysm, r_cut=3.0, r_buff=0.4, check_period=2)
-    ctx = htf.Context(r_cut=3.0, nneighs=128, max_n=sysm.N, fused=2)
+    ctx = htf.Context(r_cut=3.0, nneighs=128, max_n=sysm.N, fused=2, scalar_dtype=dtype)
     ctx.set_potential(htf.Potential.lj())
     nve = standin.NVE(sysm, 0.005)
     for ts in range(steps):
@@ -1015,16 +1063,26 @@ def test_liquid_configuration_bounds(htf, cuda):
     assert_forces_close("liquid_wca", fw, rw, _cond_scale(pv64, 2 * O._grad_from_dEds(6 * s ** 5, s, t, rp, cnd)), cancelling_rows=LIQUID)
 
 
-def test_liquid_at_headline_size(htf, cuda):
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64], ids=["float32", "float64"])
+def test_liquid_at_headline_size(htf, cuda, dtype):
     """The equilibrated liquid at 55 296 rows (fcc 24^3), a batch that takes the kernel the bench times
     (fused_forces_tails_kernel<LJ, STORE, 4, float>: four rows per wave, merged tails; launch_fused's threshold is 49 152
-    rows): 512 sampled rows against the oracle -- energy as stated, forces with the named condition term and within 3x of
-    an independent fp32 evaluation's own error -- with and without the tensor, and from the context."""
-    sysm, nl, L = _liquid(htf, cuda, cells=24, steps=200, seed=10)
+    rows; ``float64`` = HOOMD built in double precision, TensorflowCompute.h:117-124, the <LJ, STORE, 4, double> form of
+    ``bench.py --f64``): 512 sampled rows against the oracle -- energy as stated, forces with the named condition term and
+    within 3x of an independent fp32 evaluation's own error -- with and without the tensor, and from the context.  The
+    fp64 wire's tensor is the fp64 reference rounded once (simmodel.py:226-227's tf.cast), bit for bit."""
+    sysm, nl, L = _liquid(htf, cuda, cells=24, steps=200, seed=10, dtype=dtype)
     N, NN = sysm.N, 128
-    assert N == 55296
-    pv = htf.ops.build_pair_vectors(sysm.pos, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, 3.0, NN)
+    assert N == 55296 and sysm.pos.dtype == dtype
+    pv = htf.ops.build_pair_vectors(sysm.pos, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, 3.0, NN, out_dtype=torch.float32)
     rows = np.random.default_rng(6).choice(N, 512, replace=False)
+    if dtype == torch.float64:
+        from oracle import c_oracle
+        ref64 = c_oracle.prepare_neighbors(c_oracle.load(), sysm.pos.cpu().numpy(), nl.n_neigh.cpu().numpy().view(np.uint32),
+                                           nl.head_list.cpu().numpy().view(np.uint32), nl.nlist.cpu().numpy().view(np.uint32),
+                                           O.make_box(L, dtype=np.float64), 3.0, NN)
+        np.testing.assert_array_equal(pv.cpu().numpy(), ref64.astype(np.float32))     # every row
+        del ref64
     pv32 = pv.cpu().numpy()[rows]
     pv64 = pv32.astype(np.float64)
     r = np.sqrt((pv64[:, :, :3] ** 2).sum(axis=2))
@@ -1037,15 +1095,18 @@ def test_liquid_at_headline_size(htf, cuda):
     pv2 = torch.empty_like(pv)
     got["one_kernel"] = htf.ops.fused_forces(htf.Potential.lj(), sysm.pos, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, 3.0, NN, pair_vectors=pv2)
     assert torch.equal(pv2, pv)
-    ctx = htf.Context(r_cut=3.0, nneighs=NN, max_n=N, fused=2)
+    ctx = htf.Context(r_cut=3.0, nneighs=NN, max_n=N, fused=2, scalar_dtype=dtype)
     ctx.set_potential(htf.Potential.lj())
-    force = torch.zeros((N, 4), dtype=torch.float32, device=cuda)
+    force = torch.zeros((N, 4), dtype=dtype, device=cuda)
     ctx.compute_forces(0, ctx.make_arrays(sysm.pos, N, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, force))
+    assert torch.equal(ctx.nlist_buffer(N, cuda), pv)
     got["context"] = force
+    tag = "liquid16k_lj" if dtype == torch.float32 else "liquid16k_f64wire_lj"
     for name, f in got.items():
+        assert f.dtype == dtype
         f = f.cpu().numpy()[rows]
-        assert_forces_close("liquid16k_lj_%s_energy" % name, f[:, 3], ref_f[:, 3])
-        assert_forces_close("liquid16k_lj_%s" % name, f[:, :3], ref_f[:, :3], cond, cancelling_rows=LIQUID)
+        assert_forces_close("%s_%s_energy" % (tag, name), f[:, 3], ref_f[:, 3])
+        assert_forces_close("%s_%s" % (tag, name), f[:, :3], ref_f[:, :3], cond, cancelling_rows=LIQUID)
         assert np.abs(f[:, :3] - ref_f[:, :3]).max() <= 3.0 * fp32_err
 
 
@@ -1102,12 +1163,12 @@ def test_nlist_buffer_written_by_the_caller_needs_a_reset(htf, cuda):
         np.testing.assert_array_equal(ctx.nlist_buffer(N, cuda).cpu().numpy(), ref)
 
 
-def _jittered(standin, cuda, lattice, cells, seed):
+def _jittered(standin, cuda, lattice, cells, seed, dtype=torch.float32):
     pos, L, a = (standin.sc_positions if lattice == "sc" else standin.fcc_positions)(cells, 0.8442)
     rng = np.random.default_rng(seed)
     pos = pos + 0.05 * a * rng.standard_normal(pos.shape)
     pos -= np.round(pos / L) * L
-    sysm = standin.System(pos, L, dtype=torch.float32, device=cuda)
+    sysm = standin.System(pos, L, dtype=dtype, device=cuda)
     nl = standin.CellNlist(sysm, r_cut=3.0, r_buff=0.4)
     nl.build()
     return sysm, nl, L
@@ -1199,40 +1260,47 @@ def test_full_size_c4_eds_sweep(htf, cuda):
     np.testing.assert_array_equal(hist.cpu().numpy(), O.histogram_fixed_width(r_all, np.array([0.0, 3.5], np.float32), 102))
 
 
-@pytest.mark.parametrize("lattice,cells", [("sc", 32), ("fcc", 32)])
-def test_full_size_pair_vectors_every_row_bit_exact(htf, cuda, lattice, cells):
+@pytest.mark.parametrize("lattice,cells,dtype", [("sc", 32, torch.float32), ("fcc", 32, torch.float32), ("fcc", 32, torch.float64)],
+                         ids=["sc-32", "fcc-32", "fcc-32-float64"])
+def test_full_size_pair_vectors_every_row_bit_exact(htf, cuda, lattice, cells, dtype):
     """prepareNeighbors at C2 (32 768) and C3 (131 072) size, EVERY row bit for bit: the build kernel, the one-kernel
     step's tensor and the four-rows-per-wave form against the C restatement (itself bit-exact against the numpy
-    oracle, tests/test_oracle_c.py)."""
+    oracle, tests/test_oracle_c.py).  ``float64``: HOOMD built in double precision (TensorflowCompute.h:117-124) -- the
+    tensor is the fp64 restatement rounded once to fp32 (simmodel.py:226-227), and the forces of
+    fused_forces_tails_kernel<LJ, STORE, 4, double> (``bench.py --f64``) meet the oracle at the kernel's own size."""
     from hoomd_tf_amd import standin
     from oracle import c_oracle
-    sysm, nl, L = _jittered(standin, cuda, lattice, cells, 7)
+    sysm, nl, L = _jittered(standin, cuda, lattice, cells, 7, dtype=dtype)
     N, NN = sysm.N, 128
+    f64 = dtype == torch.float64
     ref = c_oracle.prepare_neighbors(c_oracle.load(), sysm.pos.cpu().numpy(), nl.n_neigh.cpu().numpy().view(np.uint32),
                                      nl.head_list.cpu().numpy().view(np.uint32), nl.nlist.cpu().numpy().view(np.uint32),
-                                     O.make_box(L, dtype=np.float32), 3.0, NN)
-    pv = htf.ops.build_pair_vectors(sysm.pos, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, 3.0, NN)
+                                     O.make_box(L, dtype=np.float64 if f64 else np.float32), 3.0, NN)
+    if f64:
+        assert ref.dtype == np.float64
+        ref = ref.astype(np.float32)
+    pv = htf.ops.build_pair_vectors(sysm.pos, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, 3.0, NN, out_dtype=torch.float32)
     np.testing.assert_array_equal(pv.cpu().numpy(), ref)
     pv2 = torch.full_like(pv, 3.0)
     forces = {}
     forces["one_kernel"] = htf.ops.fused_forces(htf.Potential.lj(), sysm.pos, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, 3.0, NN, pair_vectors=pv2)
     assert torch.equal(pv2, pv)
     forces["registers"] = htf.ops.fused_forces(htf.Potential.lj(), sysm.pos, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, 3.0, NN)
-    ctx = htf.Context(r_cut=3.0, nneighs=NN, max_n=N, fused=2)
+    ctx = htf.Context(r_cut=3.0, nneighs=NN, max_n=N, fused=2, scalar_dtype=dtype)
     ctx.set_potential(htf.Potential.lj())
-    f = torch.zeros((N, 4), dtype=torch.float32, device=cuda)
+    f = torch.zeros((N, 4), dtype=dtype, device=cuda)
     for ts in range(2):  # second call: the delta zero-fill path (rows keep their live counts)
         f.zero_()
         ctx.compute_forces(ts, ctx.make_arrays(sysm.pos, N, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, f))
         assert torch.equal(ctx.nlist_buffer(N, cuda), pv)
         forces["context_fused2_call%d" % ts] = f.clone()
-    ctx1 = htf.Context(r_cut=3.0, nneighs=NN, max_n=N, fused=1)
+    ctx1 = htf.Context(r_cut=3.0, nneighs=NN, max_n=N, fused=1, scalar_dtype=dtype)
     ctx1.set_potential(htf.Potential.lj())
-    f1 = torch.zeros((N, 4), dtype=torch.float32, device=cuda)
+    f1 = torch.zeros((N, 4), dtype=dtype, device=cuda)
     ctx1.compute_forces(0, ctx1.make_arrays(sysm.pos, N, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, f1))
     forces["context_fused1"] = f1
-    # The LJ FORCES of the kernel the bench times (N >= 16 384 rows: fused_forces_tails_kernel<LJ, STORE, 4, float>, four
-    # rows per wave with merged tails; with and without the tensor, from the stateless entry point and from the context
+    # The LJ FORCES of the kernel the bench times (N >= 16 384 rows: fused_forces_tails_kernel<LJ, STORE, 4, float / double>,
+    # four rows per wave with merged tails; with and without the tensor, from the stateless entry point and from the context
     # at fused = 2 / 1) against the oracle on 512 sampled rows of the bit-exact tensor; energy column as stated.
     rows = np.random.default_rng(5).choice(N, 512, replace=False)
     sub = ref[rows].astype(np.float64)
@@ -1241,8 +1309,9 @@ def test_full_size_pair_vectors_every_row_bit_exact(htf, cuda, lattice, cells):
     s_, _, _, _ = O._rinv_and_grad_factor(sub)
     e_cond = (2.0 * (s_ ** 12 + s_ ** 6)).sum(axis=1)   # sum_j |e_ij| scale of the energy column's row sum (jitter leaves contacts at r ~ 0.8)
     for name, ff in forces.items():
+        assert ff.dtype == dtype
         got = ff.cpu().numpy()[rows]
-        tag = "full_%s%d_lj_%s" % (lattice, cells, name)
+        tag = "full_%s%d%s_lj_%s" % (lattice, cells, "_f64wire" if f64 else "", name)
         assert_forces_close(tag + "_energy", got[:, 3], ref_f[:, 3], e_cond, cancelling_rows=CONTACTS)
         assert_forces_close(tag, got[:, :3], ref_f[:, :3], cond, cancelling_rows=CONTACTS)
     # every row, not only the sample: the whole-system energy against the C restatement's fp64 sum over the tensor

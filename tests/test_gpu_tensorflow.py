@@ -269,12 +269,78 @@ def test_rdf(htf, cuda):
     tfcompute = htf.tfcompute(model)
     tfcompute.attach(sim.nlist_cell(), r_cut=5.0)
     sim.run(2)
-    np.testing.assert_allclose(model.rdfa[-1].cpu().numpy(), model.rdfb[-1].cpu().numpy(), rtol=1e-6)
-    nl = tfcompute.get_nlist_array().astype(np.float32)
-    pos_t = tfcompute.get_positions_array()[:, 3].astype(np.float32)
-    ref, _ = O.compute_rdf(nl, [0, 10], pos_t, type_i=0, type_j=1)
-    np.testing.assert_allclose(model.rdfa[-1].cpu().numpy(), ref, rtol=1e-4)
-    assert ref.sum() > 0
+    rdfa, rdfb = model.avg_rdfa.result().cpu().numpy(), model.avg_rdfb.result().cpu().numpy()
+    np.testing.assert_allclose(rdfa, rdfb, rtol=1e-6)        # test_tensorflow.py:482-485
+    assert np.sum(rdfa) > 0
+
+
+@pytest.mark.parametrize("sdtype", [torch.float32, torch.float64], ids=["float32", "float64"])
+def test_typed_rdf_replayed_from_the_plan(htf, cuda, sdtype):
+    """build_examples.LJTypedModel as upstream writes it (build_examples.py:80-101: two typed compute_rdf's of
+    ``positions[:, 3]``, each averaged by a MeanTensor; test_tensorflow.py:450-485) stays on the replayed plan: after the
+    first eager step the force kernel is followed by the typed histograms (row types from the positions side buffer) and
+    the metric updates, and SimModel.compute is not called again.  The last step's RDFs against the oracle's masked_nlist +
+    histogram (simmodel.py:656-693) on the step's own tensor and types; a type tensor that is NOT a view of the step's
+    positions keeps the model eager."""
+    types = np.arange(81) % 2
+    sim, system, L = _sim(htf, cuda, 9, 1.5, dtype=sdtype, types=types, kT=0.5, seed=1, dt=0.001, jitter=0.1)
+    model = build_examples.LJTypedModel(64)
+    calls = []
+    inner = model.compute
+    model.compute = lambda *a, **k: (calls.append(1), inner(*a, **k))[1]
+    tfc = htf.tfcompute(model)
+    tfc.attach(sim.nlist_cell(), r_cut=5.0)
+    sim.run(6)
+    assert tfc._plan is not None and len(tfc._post_ops) == 4 and len(calls) == 1
+    assert model.avg_rdfa.count == 6 and model.avg_rdfb.count == 6
+    rdfa, rdfb = model.avg_rdfa.result().cpu().numpy(), model.avg_rdfb.result().cpu().numpy()
+    np.testing.assert_allclose(rdfa, rdfb, rtol=1e-6)
+    model.avg_rdfa.reset_states()
+    model.avg_rdfb.reset_states()
+    sim.run(1)
+    assert len(calls) == 1 and model.avg_rdfa.count == 1
+    nl = tfc.get_nlist_array().astype(np.float32)
+    pos_t = tfc.get_positions_array()[:, 3].astype(np.float32)
+    np.testing.assert_array_equal(pos_t, types.astype(np.float32))
+    for avg, (ti, tj) in ((model.avg_rdfa, (0, 1)), (model.avg_rdfb, (1, 0))):
+        ref, _ = O.compute_rdf(nl, [0, 10], pos_t, type_i=ti, type_j=tj)
+        assert ref.sum() > 0
+        np.testing.assert_allclose(avg.result().cpu().numpy(), ref, rtol=1e-4)
+
+    class DetachedTypes(build_examples.LJTypedModel):
+        def compute(self, nlist, positions, box):
+            energy = htf.reduce_sum(1e-10 * htf.nlist_rinv(nlist) ** 12, axis=1)
+            forces = htf.compute_nlist_forces(nlist, energy)
+            rdfa, _ = htf.compute_rdf(nlist, [0, 10], positions[:, 3].clone(), type_i=0, type_j=1)
+            self.avg_rdfa.update_state(rdfa)
+            return forces
+    sim2, system2, _ = _sim(htf, cuda, 9, 1.5, dtype=sdtype, types=types, kT=0.5, seed=1, dt=0.001, jitter=0.1)
+    m2 = DetachedTypes(64)
+    tfc2 = htf.tfcompute(m2)
+    tfc2.attach(sim2.nlist_cell(), r_cut=5.0)
+    sim2.run(3)
+    assert tfc2._plan is None and m2.avg_rdfa.count == 3
+
+
+def test_bare_observable_keeps_the_model_eager(htf, cuda):
+    """A compute_rdf whose result no traced consumer takes (here: appended to a Python list) is not worth a plan that would
+    stop calling compute(): the model steps eagerly and the list keeps growing."""
+    sim, system, L = _sim(htf, cuda, 9, 1.5, kT=0.5, seed=1, dt=0.001, jitter=0.1)
+
+    class ListRDF(htf.SimModel):
+        def setup(self):
+            self.rdfs = []
+
+        def compute(self, nlist):
+            energy = htf.reduce_sum(1e-10 * htf.nlist_rinv(nlist) ** 12, axis=1)
+            rdf, _ = htf.compute_rdf(nlist, [0, 5])
+            self.rdfs.append(rdf)
+            return htf.compute_nlist_forces(nlist, energy)
+    model = ListRDF(64)
+    tfc = htf.tfcompute(model)
+    tfc.attach(sim.nlist_cell(), r_cut=5.0)
+    sim.run(4)
+    assert tfc._plan is None and not tfc._post_ops and len(model.rdfs) == 4
 
 
 def test_quickstart_example01(htf, cuda):
@@ -360,14 +426,17 @@ def test_eds_rdf_model_steps_match_oracle(htf, cuda):
     np.testing.assert_allclose(tfc.outputs[2][-1], rdf_ref, rtol=1e-4)
 
 
-def test_eds_rdf_model_replayed_as_one_kernel(htf, cuda):
+@pytest.mark.parametrize("sdtype", [torch.float32, torch.float64], ids=["float32", "float64"])
+def test_eds_rdf_model_replayed_as_one_kernel(htf, cuda, sdtype):
     """config C4 with nobody saving the outputs: after the first (eager) step tfcompute replays
     the step as htf_build_eval_forces2 + device-side EDS update.  Every step's forces, cv and
-    alpha against the oracle composite on the same pair vectors, as in the eager test above."""
+    alpha against the oracle composite on the same pair vectors, as in the eager test above.
+    ``float64``: HOOMD built in double precision (TensorflowCompute.h:117-124, the reference's commonest deployment) stays
+    on the replayed plan too -- fp64 positions in, the fp32 tensor of simmodel.py:226-227's cast, fp64 forces out."""
     from hoomd_tf_amd import standin
     pos, L, a = standin.fcc_positions(4, 0.8442)
     pos = pos + 0.03 * a * np.random.default_rng(2).standard_normal(pos.shape)
-    system = standin.System(pos, L, dtype=torch.float32, device=cuda)
+    system = standin.System(pos, L, dtype=sdtype, device=cuda)
     sim = standin.Simulation(system)
     sim.integrate_nve(0.002)
     model = build_examples.EDSRDFModel(64, set_point=9.0, r0=1.1, gap=0.05, period=8, learning_rate=0.5)
@@ -388,11 +457,12 @@ def test_eds_rdf_model_replayed_as_one_kernel(htf, cuda):
         np.testing.assert_allclose(tfc.get_forces_array(), f_ref, rtol=2e-4, atol=2e-3)
         if step > 0:  # the replay's tensor is the build kernel's tensor, bit for bit
             want = htf.ops.build_pair_vectors(pos_before, cell.n_neigh, cell.head_list, cell.nlist, system.box, 2.5, 64)
-            assert torch.equal(tfc._last[0], want)
-            np.testing.assert_array_equal(tfc.get_positions_array()[:, :3], pos_before[:, :3].double().cpu().numpy())
+            assert want.dtype == torch.float32 and torch.equal(tfc._last[0], want)
+            np.testing.assert_array_equal(tfc.get_positions_array()[:, :3], pos_before[:, :3].float().double().cpu().numpy())
+            assert tfc.force.dtype == sdtype
     assert abs(a_ref) > 1e-3
     # the same trajectory as the eager path (summation order differs between the one-kernel and two-kernel sweeps)
-    system2 = standin.System(pos, L, dtype=torch.float32, device=cuda)
+    system2 = standin.System(pos, L, dtype=sdtype, device=cuda)
     sim2 = standin.Simulation(system2)
     sim2.integrate_nve(0.002)
     model2 = build_examples.EDSRDFModel(64, set_point=9.0, r0=1.1, gap=0.05, period=8, learning_rate=0.5)
@@ -404,7 +474,7 @@ def test_eds_rdf_model_replayed_as_one_kernel(htf, cuda):
     np.testing.assert_allclose(float(model.eds_bias.alpha), float(model2.eds_bias.alpha), rtol=1e-3, atol=1e-5)
 
 
-@pytest.mark.parametrize("precision", ["fp32", "split"])
+@pytest.mark.parametrize("precision", ["fp32", "split", "split16"])
 def test_pair_mlp_model_runs_traced(htf, cuda, precision):
     """config-3 style model through SimModel/tfcompute: traced path, forces against the oracle --
     on the fp32 matrix instruction and on the bf16 one with exactly split operands, same tolerance."""
