@@ -24,9 +24,6 @@
 
 namespace htf {
 
-struct MlpDims {
-    int K, H1, H2, oB1, oW2, oB2, oW3, oB3;
-};
 
 template <bool TANH>
 __device__ __forceinline__ float act_val(float z) {
@@ -37,6 +34,7 @@ __device__ __forceinline__ float bcast(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
+#ifdef HTF_AB_VARIANTS // the first-generation VALU sweep: A/B builds only
 template <bool TANH, typename IT>
 __global__ __launch_bounds__(256, 1) void mlp_grad_kernel(const typename Vec4<IT>::type *__restrict__ nlist, unsigned B,
                                                           unsigned NN, const void *__restrict__ labels, int lab_f64,
@@ -156,6 +154,8 @@ __global__ __launch_bounds__(256, 1) void mlp_grad_kernel(const typename Vec4<IT
     }
 }
 
+#endif // HTF_AB_VARIANTS
+
 // ------------------------------------------------------------------ matrix-core version (fp32)
 // The same sweep on the MFMA units.  Layers are computed transposed as in pair_mlp.hip
 // (features on accumulator rows, a tile of 32 pairs on the lanes) for the value chain, its
@@ -224,22 +224,7 @@ __device__ __forceinline__ void outer16(f32x16 &acc, const f32x16 &A, const f32x
     for (int t = 0; t < 16; ++t) acc = HTF_MFMA(A[t], Bm[t], acc);
 }
 
-__device__ __forceinline__ f32x16 zero16() {
-    f32x16 r;
-#pragma unroll
-    for (int v = 0; v < 16; ++v) r[v] = 0.f;
-    return r;
-}
 
-__device__ __forceinline__ float4 residual(const float4 *pred, const void *labels, int lab_f64, unsigned row) {
-    const float4 pr = pred[row];
-    if (lab_f64) {
-        const double4 l = ((const double4 *)labels)[row];
-        return make_float4(pr.x - (float)l.x, pr.y - (float)l.y, pr.z - (float)l.z, pr.w - (float)l.w);
-    }
-    const float4 l = ((const float4 *)labels)[row];
-    return make_float4(pr.x - l.x, pr.y - l.y, pr.z - l.z, pr.w - l.w);
-}
 
 // FUSED (ntiles in {1, 2, 4}, i.e. NN <= 64 or 97..128): the block also forms the row's
 // predicted (F_i, E_i) from the value/tangent outputs it has in hand, so the separate
@@ -543,448 +528,14 @@ __global__ __launch_bounds__(256, 1) void mlp_grad_mfma_kernel(const typename Ve
     for (unsigned c = threadIdx.x; c < stride; c += blockDim.x) out[c] = red[c];
 }
 
-// ------------------------------------------------------------------ matrix-core version (fp16 pipeline, split operands)
-using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
-using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
-using u32x4t = __attribute__((ext_vector_type(4))) unsigned;
-#define HTF_MFMA_H(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
-
-struct Op16 {
-    f16x8 hi[2], lo[2]; // one 32-feature block: accumulator elements 8s .. 8s+7 are k-step s
-};
-
-// x = hi + lo, both fp16 and rounded to nearest: v_cvt_pk_f16_f32 per pair of elements, the residual by v_fma_mix_f32 reading
-// hi from its half of the packed register (pair_mlp.hip prep<HTF_MLP_SPLIT16>)
-__device__ __forceinline__ Op16 split16(const f32x16 &x) {
-    Op16 o;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        u32x4t ph, pl;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float a = x[8 * s + 2 * j], b = x[8 * s + 2 * j + 1];
-            const unsigned hp = __builtin_bit_cast(unsigned, f16x2{(_Float16)a, (_Float16)b});
-            float ra, rb;
-            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(hp), "v"(a));
-            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(hp), "v"(b));
-            ph[j] = hp;
-            pl[j] = __builtin_bit_cast(unsigned, f16x2{(_Float16)ra, (_Float16)rb});
-        }
-        o.hi[s] = __builtin_bit_cast(f16x8, ph);
-        o.lo[s] = __builtin_bit_cast(f16x8, pl);
-    }
-    return o;
-}
-
-// tanh from an accumulator that already carries 2 log2(e) z (the split16 images fold it into the forward blocks)
-template <bool TANH>
-__device__ __forceinline__ float act_scaled(float a) {
-    if constexpr (!TANH) return a;
-    return fmaf(__builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(a) + 1.0f), -2.0f, 1.0f);
-}
-
-constexpr int kHS = 40;          // published row stride in halfs (80 B)
-constexpr int kHP = 32 * kHS;    // one plane: 32 feature rows
-constexpr int kHB = 2 * kHP;     // one published block: hi plane, lo plane (5120 B)
-constexpr int kSlots16 = 5;      // per wave: A0 A1 | B0 B1 | phi  (100 KB + 49 KB of images)
-
-__device__ __forceinline__ void mfma_pair16(f32x16 &acc0, f32x16 &acc1, const float *img, unsigned lane, const Op16 &p0, const Op16 &p1) {
-    const f16x8 *p = reinterpret_cast<const f16x8 *>(img) + lane; // [part 2: hi, lo][s 2][lane 64]
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        const f16x8 ah = p[s * 64], al = p[(2 + s) * 64];
-        acc0 = HTF_MFMA_H(al, p0.hi[s], acc0);
-        acc1 = HTF_MFMA_H(al, p1.hi[s], acc1);
-        acc0 = HTF_MFMA_H(ah, p0.lo[s], acc0);
-        acc1 = HTF_MFMA_H(ah, p1.lo[s], acc1);
-        acc0 = HTF_MFMA_H(ah, p0.hi[s], acc0);
-        acc1 = HTF_MFMA_H(ah, p1.hi[s], acc1);
-    }
-}
-
-// element v of the accumulator order = feature f0(v) + 4h of pair p -> row f0(v) + 4h, column p of both planes
-__device__ __forceinline__ void publish16(_Float16 *blk, unsigned p, unsigned h, const Op16 &o) {
-#pragma unroll
-    for (int v = 0; v < 16; ++v) {
-        const unsigned row = (unsigned)f0(v) + 4u * h;
-        blk[row * kHS + p] = o.hi[v >> 3][v & 7];
-        blk[kHP + row * kHS + p] = o.lo[v >> 3][v & 7];
-    }
-}
-
-// feature row i as an MFMA operand whose k index is the pair: k-step s of lane half h holds pairs 16 s + 8 h .. + 7
-__device__ __forceinline__ Op16 load_op16(const _Float16 *blk, unsigned i, unsigned h) {
-    Op16 o;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        o.hi[s] = *reinterpret_cast<const f16x8 *>(blk + i * kHS + 16 * s + 8 * h);
-        o.lo[s] = *reinterpret_cast<const f16x8 *>(blk + kHP + i * kHS + 16 * s + 8 * h);
-    }
-    return o;
-}
-
-__device__ __forceinline__ void outer16_f16(f32x16 &acc, const Op16 &A, const Op16 &Bm) {
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        acc = HTF_MFMA_H(A.lo[s], Bm.hi[s], acc);
-        acc = HTF_MFMA_H(A.hi[s], Bm.lo[s], acc);
-        acc = HTF_MFMA_H(A.hi[s], Bm.hi[s], acc);
-    }
-}
-
-// sum of the 16 pairs a lane holds of one feature row (hi + lo).  (A v_dot2_f32_f16 form -- two halfs per instruction against
-// a register of ones -- was miscompiled by hipcc 7.2: element 0 of each 128-bit operand summed four times.  Plain converts.)
-__device__ __forceinline__ float sum_op16(const Op16 &o) {
-    float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            s0 += (float)o.hi[q][j];
-            s1 += (float)o.lo[q][j];
-        }
-    return s0 + s1;
-}
-
-// The same sweep with every matrix product on the fp16 pipeline and fp32-level operands (pair_mlp.hip, HTF_MLP_SPLIT16):
-// x = hi + lo in fp16, hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 -- 12 MFMAs of 32 cycles per (32 x 32 block, value +
-// tangent) where the fp32 form issues 32 of 64, and for the pair-contracted weight gradients 6 where it issues 16: 192
-// MFMAs x 32 cycles per tile instead of 512 x 64.  Operands are published to LDS as fp16 hi / lo planes ([feature][pair], row
-// stride 80 B: conflict-free ds_read_b128 by feature row), five slots per wave (A0 A1 | B0 B1 | phi; phi's derivative keeps
-// its split form in registers and takes an A slot for its dW1 contraction).  Reads the split16 evaluator images (forward
-// blocks and bias tables carry 2 log2(e) for tanh: the accumulator is the exponent; the tangent chain is scaled back).
-template <bool TANH, typename IT, bool FUSED>
-__global__ __launch_bounds__(256, 1) void mlp_grad_f16_kernel(const typename Vec4<IT>::type *__restrict__ nlist,
-                                                               unsigned B, unsigned NN,
-                                                               const void *__restrict__ labels, int lab_f64,
-                                                               const float4 *__restrict__ pred,
-                                                               float4 *__restrict__ pred_out,
-                                                               const float *__restrict__ images, MlpDims dm, float gap,
-                                                               float *__restrict__ partial, unsigned stride) {
-    using I = Img<HTF_MLP_SPLIT16>;
-    __shared__ __attribute__((aligned(16))) float lds[I::Floats];
-    __shared__ __attribute__((aligned(16))) _Float16 pub[4 * kSlots16 * kHB];
-    constexpr float kC = TANH ? 2.8853900817779268f : 1.0f, kCinv = TANH ? 1.0f / 2.8853900817779268f : 1.0f;
-    __shared__ int live_flag[4];
-    __shared__ float4 rowsum[4];
-    {
-        const float4 *src = reinterpret_cast<const float4 *>(images);
-        float4 *dst = reinterpret_cast<float4 *>(lds);
-        for (int i = threadIdx.x; i < I::Floats / 4; i += blockDim.x) dst[i] = src[i];
-    }
-    __syncthreads();
-
-    const unsigned lane = threadIdx.x & 63u;
-    const unsigned p = lane & 31u, h = lane >> 5;
-    const unsigned w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const unsigned ntiles = (NN + 31) / 32;
-    const unsigned long long U = (unsigned long long)B * ntiles;
-    // unit -> (row, tile).  FUSED launches have 1, 2 or 4 tiles per row: a shift and a mask instead of
-    // 64-bit divisions (five per trip, each a ~100-instruction emulation)
-    const unsigned tsh = ntiles == 4 ? 2u : (ntiles == 2 ? 1u : 0u);
-    auto row_of = [&](unsigned long long u) { return FUSED ? (unsigned)(u >> tsh) : (unsigned)(u / ntiles); };
-    auto tile_of = [&](unsigned long long u) { return FUSED ? (unsigned)u & (ntiles - 1u) : (unsigned)(u % ntiles); };
-    const float ginv = 1.0f / gap;
-    _Float16 *mine = pub + w * kSlots16 * kHB;
-
-    f32x16 acc2 = zero16(), acc1 = zero16();
-    f32x16 gw3[2] = {zero16(), zero16()};
-    float gb1 = 0.f, gb2 = 0.f, gb3 = 0.f, loss = 0.f;
-
-    // One wave per SIMD: nothing hides a global load's ~2 us but the wave's own work, so the round's inputs are read a round
-    // ahead (this lane's pair vector of the NEXT tile) and the row's labels at the top of the round, not where they are used.
-    auto read_slot = [&](unsigned long long uu, float &ox, float &oy, float &oz) {
-        ox = oy = oz = 0.f;
-        if (uu < U) {
-            const unsigned sl = tile_of(uu) * 32 + p;
-            if (sl < NN) {
-                const auto v = nlist[(size_t)row_of(uu) * NN + sl];
-                ox = (float)v.x; oy = (float)v.y; oz = (float)v.z;
-            }
-        }
-    };
-    float nx, ny, nz;
-    read_slot((unsigned long long)blockIdx.x * 4 + w, nx, ny, nz);
-    for (unsigned long long base = (unsigned long long)blockIdx.x * 4; base < U; base += (unsigned long long)gridDim.x * 4) {
-        const unsigned long long u = base + w;
-        const bool valid = u < U;
-        const unsigned row = valid ? row_of(u) : 0u, tile = valid ? tile_of(u) : 0u;
-        const unsigned slot = tile * 32 + p;
-        const float x = nx, y = ny, z = nz;
-        read_slot(u + (unsigned long long)gridDim.x * 4, nx, ny, nz);
-        float lx = 0.f, ly = 0.f, lz = 0.f, lw = 0.f; // the row's labels (FUSED: used after the forward pass)
-        if (FUSED) {
-            if (lab_f64) {
-                const double4 l = ((const double4 *)labels)[row];
-                lx = (float)l.x; ly = (float)l.y; lz = (float)l.z; lw = (float)l.w;
-            } else {
-                const float4 l = ((const float4 *)labels)[row];
-                lx = l.x; ly = l.y; lz = l.z; lw = l.w;
-            }
-        }
-        const float tx = x + kNormDelta, ty = y + kNormDelta, tz = z + kNormDelta;
-        const float r = sqrtf(tx * tx + ty * ty + tz * tz);
-        const bool m = valid && slot < NN && r > kRinvDelta;
-        const bool live = __ballot(m) != 0ull;
-
-        // written and read only under `live` (wave-uniform): no initialisation -- twelve tiles of v_mov 0
-        // per trip are VALU time the fp32 MFMAs cannot hide (pair_mlp.hip)
-        f32x16 h1[2], hd1[2];
-        Op16 phid_o, hd1o[2], zb2o[2], zdb2o[2];
-        f32x16 q2[2], qd2[2]; // zb2, zdb2
-        f32x16 q1[2], qd1[2]; // zb1, zdb1
-        float4 part = make_float4(0.f, 0.f, 0.f, 0.f); // this tile's share of (F_i, E_i)
-        if (live) {
-            // ---- value + r-tangent, forward.  phi / phid go to LDS at once (needed again only
-            // for dW1 at the end of the round)
-            f32x16 phi, phid;
-            {
-                const f32x16 cen = load_tab(lds + I::TabC, 0, h);
-#pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    const float d = r - cen[v];
-                    phi[v] = __expf(-(d * d) * ginv);
-                    phid[v] = -2.0f * d * ginv * phi[v];
-                }
-            }
-            const Op16 phi_o = split16(phi);
-            phid_o = split16(phid);
-            publish16(mine + 4 * kHB, p, h, phi_o); // its own slot, read at D3; the derivative keeps its split form in registers
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
-                f32x16 zz = load_tab(lds + I::TabB1, nb, h), zd = zero16();
-                mfma_pair16(zz, zd, lds + I::L1 + nb * I::BS, lane, phi_o, phid_o);
-#pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    const float hv = act_scaled<TANH>(zz[v]);
-                    h1[nb][v] = hv;
-                    hd1[nb][v] = TANH ? (1.0f - hv * hv) * (zd[v] * kCinv) : zd[v];
-                }
-            }
-            {
-                // h1 goes to the A slots at once (free since the barrier that closed the previous round); hd1 keeps its split
-                // form in registers until D2
-                const Op16 h1o[2] = {split16(h1[0]), split16(h1[1])};
-                hd1o[0] = split16(hd1[0]);
-                hd1o[1] = split16(hd1[1]);
-                publish16(mine + 0 * kHB, p, h, h1o[0]);
-                publish16(mine + 1 * kHB, p, h, h1o[1]);
-            float upart = 0.f, dpart = 0.f;
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
-                f32x16 zz = load_tab(lds + I::TabB2, nb, h), zd = zero16();
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb) mfma_pair16(zz, zd, lds + I::L2 + (nb * 2 + kb) * I::BS, lane, h1o[kb], hd1o[kb]);
-                const f32x16 w3 = load_tab(lds + I::TabW3, nb, h);
-#pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    const float hv = act_scaled<TANH>(zz[v]);
-                    const float hdv = TANH ? (1.0f - hv * hv) * (zd[v] * kCinv) : zd[v];
-                    q2[nb][v] = hv;   // h2  (becomes zb2 below)
-                    qd2[nb][v] = hdv; // hd2 (becomes zdb2)
-                    upart = fmaf(hv, w3[v], upart);
-                    dpart = fmaf(hdv, w3[v], dpart);
-                }
-            }
-            if (FUSED) { // u = w3 . h2 + b3, u' = w3 . hd2: the prediction itself (pair_mlp.hip)
-                const float uu = sum_xor32(upart) + lds[I::TabB3];
-                const float du = sum_xor32(dpart);
-                if (m && h == 0) {
-                    const float c = du / r;
-                    part = make_float4(c * tx, c * ty, c * tz, 0.5f * uu);
-                }
-            }
-            }
-        }
-        // ---- residual of this wave's row
-        float4 rs;
-        if (FUSED) {
-            // ntiles in {1, 2, 4}: the row's tiles all sit in this round; sum them in wave order
-            part.x = group_sum<64>(part.x);
-            part.y = group_sum<64>(part.y);
-            part.z = group_sum<64>(part.z);
-            part.w = group_sum<64>(part.w);
-            if (lane == 0) rowsum[w] = part;
-            __syncthreads();
-            float4 F = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (unsigned t = 0; t < 4; ++t) {
-                const unsigned long long ut = base + t;
-                if (ut < U && row_of(ut) == row) {
-                    const float4 q = rowsum[t];
-                    F.x += q.x; F.y += q.y; F.z += q.z; F.w += q.w;
-                }
-            }
-            if (pred_out && valid && tile == 0 && lane == 0) pred_out[row] = F;
-            rs = make_float4(F.x - lx, F.y - ly, F.z - lz, F.w - lw);
-        } else {
-            rs = residual(pred, labels, lab_f64, row);
-        }
-        if (valid && tile == 0 && lane == 0) loss += rs.x * rs.x + rs.y * rs.y + rs.z * rs.z + rs.w * rs.w;
-        if (live) {
-            // ---- reverse seed: S = a u' + b u
-            const float aq = m ? 2.0f * (rs.x * tx + rs.y * ty + rs.z * tz) / r : 0.f;
-            const float bq = m ? rs.w : 0.f;
-            if (h == 0) gb3 += bq;
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
-                const f32x16 w3 = load_tab(lds + I::TabW3, nb, h);
-#pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    const float hv = q2[nb][v], hdv = qd2[nb][v];
-                    const float s2 = TANH ? 1.0f - hv * hv : 1.0f;
-                    gw3[nb][v] += bq * hv + aq * hdv;
-                    const float hb = bq * w3[v], hdb = aq * w3[v];
-                    q2[nb][v] = TANH ? hb * s2 - 2.0f * hdb * hv * hdv : hb; // zb2
-                    qd2[nb][v] = hdb * s2;                                     // zdb2
-                }
-                zb2o[nb] = split16(q2[nb]);
-                zdb2o[nb] = split16(qd2[nb]);
-            }
-        }
-        // ---- weight gradients: contractions over the pairs of the block's four tiles
-        if (lane == 0) live_flag[w] = live ? 1 : 0;
-        // D1: dW2 += h1 (x) zb2
-        if (live) { // (h1 sits in the A slots since the forward pass)
-            publish16(mine + 2 * kHB, p, h, zb2o[0]);
-            publish16(mine + 3 * kHB, p, h, zb2o[1]);
-        }
-        __syncthreads();
-        const unsigned f1b = w >> 1, f2b = w & 1u;
-#pragma unroll 1
-        for (unsigned t = 0; t < 4; ++t) {
-            if (!live_flag[t]) continue;
-            const _Float16 *src = pub + t * kSlots16 * kHB;
-            const Op16 A = load_op16(src + f1b * kHB, p, h), Bm = load_op16(src + (2 + f2b) * kHB, p, h);
-            outer16_f16(acc2, A, Bm);
-            if (f1b == 0) gb2 += sum_op16(Bm);
-        }
-        __syncthreads();
-        // D2: dW2 += hd1 (x) zdb2
-        if (live) {
-            publish16(mine + 0 * kHB, p, h, hd1o[0]);
-            publish16(mine + 1 * kHB, p, h, hd1o[1]);
-            publish16(mine + 2 * kHB, p, h, zdb2o[0]);
-            publish16(mine + 3 * kHB, p, h, zdb2o[1]);
-        }
-        __syncthreads();
-#pragma unroll 1
-        for (unsigned t = 0; t < 4; ++t) {
-            if (!live_flag[t]) continue;
-            const _Float16 *src = pub + t * kSlots16 * kHB;
-            const Op16 A = load_op16(src + f1b * kHB, p, h), Bm = load_op16(src + (2 + f2b) * kHB, p, h);
-            outer16_f16(acc2, A, Bm);
-        }
-        __syncthreads();
-        if (live) {
-            // ---- reverse through layer 2: (hb1, hdb1) = W2 (zb2, zdb2), then through act at z1
-#pragma unroll
-            for (int fb = 0; fb < 2; ++fb) {
-                f32x16 hb = zero16(), hdb = zero16();
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb) mfma_pair16(hb, hdb, lds + I::B2 + (fb * 2 + kb) * I::BS, lane, zb2o[kb], zdb2o[kb]);
-#pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    const float hv = h1[fb][v];
-                    const float s1 = TANH ? 1.0f - hv * hv : 1.0f;
-                    q1[fb][v] = TANH ? hb[v] * s1 - 2.0f * hdb[v] * hv * hd1[fb][v] : hb[v]; // zb1
-                    qd1[fb][v] = hdb[v] * s1;                                                  // zdb1
-                }
-            }
-                }
-        // D3: dW1 += phi (x) zb1  (wave w: feature block w&1, tiles 2(w>>1), 2(w>>1)+1)
-        if (live) { // phi's derivative takes an A slot (the consumers of D2 are past the barrier above)
-            publish16(mine + 1 * kHB, p, h, phid_o);
-            publish16(mine + 2 * kHB, p, h, split16(q1[0]));
-            publish16(mine + 3 * kHB, p, h, split16(q1[1]));
-        }
-        __syncthreads();
-#pragma unroll 1
-        for (unsigned t = 2 * (w >> 1); t < 2 * (w >> 1) + 2; ++t) {
-            if (!live_flag[t]) continue;
-            const _Float16 *src = pub + t * kSlots16 * kHB;
-            const Op16 A = load_op16(src + 4 * kHB, p, h), Bm = load_op16(src + (2 + (w & 1u)) * kHB, p, h);
-            outer16_f16(acc1, A, Bm);
-            gb1 += sum_op16(Bm);
-        }
-        __syncthreads();
-        // D4: dW1 += phid (x) zdb1
-        if (live) {
-            publish16(mine + 2 * kHB, p, h, split16(qd1[0]));
-            publish16(mine + 3 * kHB, p, h, split16(qd1[1]));
-        }
-        __syncthreads();
-#pragma unroll 1
-        for (unsigned t = 2 * (w >> 1); t < 2 * (w >> 1) + 2; ++t) {
-            if (!live_flag[t]) continue;
-            const _Float16 *src = pub + t * kSlots16 * kHB;
-            const Op16 A = load_op16(src + 1 * kHB, p, h), Bm = load_op16(src + (2 + (w & 1u)) * kHB, p, h);
-            outer16_f16(acc1, A, Bm);
-        }
-        __syncthreads();
-    }
-
-    // ---- block partial in LDS, waves in a fixed order
-    float *red = reinterpret_cast<float *>(pub); // 1 + P <= 6338 floats
-    for (unsigned c = threadIdx.x; c < stride; c += blockDim.x) red[c] = 0.f;
-    __syncthreads();
-    // gw3: sum over the 32 pairs of each lane half
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int v = 0; v < 16; ++v) {
-            float s = gw3[b][v];
-            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
-            s += __shfl_xor(s, 8); s += __shfl_xor(s, 16);
-            gw3[b][v] = s;
-        }
-    gb1 = sum_xor32(gb1);
-    gb2 = sum_xor32(gb2);
-    gb3 = group_sum<64>(gb3);
-    for (unsigned turn = 0; turn < 4; ++turn) {
-        if (w == turn) {
-            // acc2: lane (j, h) register v = dW2[32 (w>>1) + f0(v) + 4h][32 (w&1) + j]
-            const int f2 = 32 * (int)(w & 1u) + (int)p;
-#pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const int f1 = 32 * (int)(w >> 1) + f0(v) + 4 * (int)h;
-                if (f1 < dm.H1 && f2 < dm.H2) red[1 + dm.oW2 + f1 * dm.H2 + f2] += acc2[v];
-            }
-            // acc1: lane (j, h) register v = dW1[f0(v) + 4h][32 (w&1) + j]
-#pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const int k = f0(v) + 4 * (int)h;
-                if (k < dm.K && f2 < dm.H1) red[1 + k * dm.H1 + f2] += acc1[v];
-            }
-            if (h == 0 && f2 < dm.H1) red[1 + dm.oB1 + f2] += gb1;
-            if (h == 0 && (w >> 1) == 0 && f2 < dm.H2) red[1 + dm.oB2 + f2] += gb2;
-            if (p == 0) {
-#pragma unroll
-                for (int b = 0; b < 2; ++b)
-#pragma unroll
-                    for (int v = 0; v < 16; ++v) {
-                        const int f = 32 * b + f0(v) + 4 * (int)h;
-                        if (f < dm.H2) red[1 + dm.oW3 + f] += gw3[b][v];
-                    }
-            }
-            if (lane == 0) {
-                red[1 + dm.oB3] += gb3;
-                red[0] += loss;
-            }
-        }
-        __syncthreads();
-    }
-    float *out = partial + (size_t)blockIdx.x * stride;
-    for (unsigned c = threadIdx.x; c < stride; c += blockDim.x) out[c] = red[c];
-}
-
-// accum[c] = sum over waves, fixed order
+// accum[c] = sum over the block partials, fixed order; columns >= 1 (the gradient) times 1 / S when the sweep scaled its seeds
 __global__ void mlp_reduce_partials_kernel(const float *__restrict__ partial, unsigned nwaves, unsigned stride,
-                                           unsigned ncols, float *__restrict__ accum) {
+                                           unsigned ncols, float *__restrict__ accum, const float *__restrict__ resid_max) {
     const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= ncols) return;
     float s = 0.f;
     for (unsigned w = 0; w < nwaves; ++w) s += partial[(size_t)w * stride + c];
+    if (resid_max && c > 0) s *= 1.0f / seed_scale(*resid_max); // a power of two: exact
     accum[c] = s;
 }
 
@@ -996,9 +547,10 @@ static unsigned train_waves(const MlpDevice *m, unsigned B) {
 
 static unsigned train_stride(const MlpDevice *m) { return ((unsigned)m->num_params() + 1u + 3u) & ~3u; }
 
+// block partials | prediction [B, 4] (when the caller wants none back) | the largest residual of the launch (1 float + pad)
 size_t mlp_train_scratch_floats(const MlpDevice *m, unsigned B) {
     if (!m) return 0;
-    return (size_t)train_waves(m, B) * train_stride(m) + (size_t)B * 4;
+    return (size_t)train_waves(m, B) * train_stride(m) + (size_t)B * 4 + 4;
 }
 
 int mlp_train_grad(const MlpDevice *m, const void *nlist, int in_dtype, unsigned B, unsigned NN, const void *labels,
@@ -1007,36 +559,41 @@ int mlp_train_grad(const MlpDevice *m, const void *nlist, int in_dtype, unsigned
     const unsigned nw = train_waves(m, B), stride = train_stride(m);
     float *partial = scratch;
     float4 *predbuf = pred ? (float4 *)pred : (float4 *)(scratch + (size_t)nw * stride);
-    const bool force_valu = getenv("HTF_MLP_TRAIN_VALU") != nullptr; // read per call: tests toggle it
-    const bool no_fuse = getenv("HTF_MLP_TRAIN_NOFUSE") != nullptr;
+    float *resid_max = scratch + (size_t)nw * stride + (size_t)B * 4;
     const unsigned ntiles = (NN + 31) / 32;
-    const bool mfma = !force_valu; // bf16-image potentials train on their fp32 image set
-    // split16 potentials: the sweep itself runs on the fp16 pipeline from the evaluator's own images (HTF_MLP_TRAIN_FP32=1:
-    // the fp32-MFMA sweep on the fp32 image set, for A/B runs)
-    const bool f16 = mfma && m->precision == HTF_MLP_SPLIT16 && getenv("HTF_MLP_TRAIN_FP32") == nullptr;
-    const bool fused = mfma && !no_fuse && (ntiles == 1 || ntiles == 2 || ntiles == 4);
+    MlpDims dm{m->K, m->H1, m->H2, m->off_b1(), m->off_W2(), m->off_b2(), m->off_W3(), m->off_b3()};
+    const bool th = m->act == HTF_ACT_TANH;
+    const unsigned ncols = (unsigned)m->num_params() + 1u;
     int rc = HTF_OK;
+#ifdef HTF_AB_VARIANTS // A/B builds only (make variants): the first-generation kernels stay selectable; read per call, tests toggle them
+    const bool force_valu = getenv("HTF_MLP_TRAIN_VALU") != nullptr;
+    const bool no_fuse = getenv("HTF_MLP_TRAIN_NOFUSE") != nullptr;
+    const bool force_fp32 = getenv("HTF_MLP_TRAIN_FP32") != nullptr;
+#else
+    constexpr bool force_valu = false, no_fuse = false, force_fp32 = false;
+#endif
+    // split16 potentials: the sweep runs on the fp16 pipeline from the evaluator's own images, every wave on its own
+    // (mlp_grad_tr16_kernel); every other precision trains on its fp32 image set with the fp32 MFMA
+    if (m->precision == HTF_MLP_SPLIT16 && !force_fp32 && !force_valu) {
+        unsigned nblk = 0;
+        rc = mlp_train_grad16(m, nlist, in_dtype, B, NN, labels, lab_f64, predbuf, partial, stride, resid_max, &nblk, stream);
+        if (rc != HTF_OK) return rc;
+        hipLaunchKernelGGL(mlp_reduce_partials_kernel, dim3((ncols + 63) / 64), dim3(64), 0, stream, partial, nblk, stride,
+                           ncols, accum, resid_max);
+        return check_launch("mlp_reduce_partials_kernel");
+    }
+    const bool fused = !force_valu && !no_fuse && (ntiles == 1 || ntiles == 2 || ntiles == 4);
     if (!fused) {
         rc = mlp_eval(m, nlist, in_dtype, B, NN, predbuf, HTF_F32, nullptr, stream);
         if (rc != HTF_OK) return rc;
     }
-    MlpDims dm{m->K, m->H1, m->H2, m->off_b1(), m->off_W2(), m->off_b2(), m->off_W3(), m->off_b3()};
-    const bool th = m->act == HTF_ACT_TANH;
-    const unsigned ncols = (unsigned)m->num_params() + 1u;
-    // matrix-core kernel; the first-generation VALU kernel stays behind HTF_MLP_TRAIN_VALU=1 (A/B runs)
-    if (mfma) {
+    if (!force_valu) {
         const unsigned long long units = (unsigned long long)B * ntiles;
         unsigned nblk = (unsigned)m->n_cu;
         if ((unsigned long long)nblk * 4 > units) nblk = (unsigned)((units + 3) / 4);
 #define HTF_LAUNCH_MLPM(T, IT, V4, F)                                                                                  \
-    do {                                                                                                               \
-        if (f16)                                                                                                       \
-            hipLaunchKernelGGL((mlp_grad_f16_kernel<T, IT, F>), dim3(nblk), dim3(256), 0, stream, (const V4 *)nlist, B, NN, \
-                               labels, lab_f64, predbuf, (float4 *)pred, m->images, dm, m->gap, partial, stride);      \
-        else                                                                                                           \
-            hipLaunchKernelGGL((mlp_grad_mfma_kernel<T, IT, F>), dim3(nblk), dim3(256), 0, stream, (const V4 *)nlist, B, NN, \
-                               labels, lab_f64, predbuf, (float4 *)pred, m->train_images, dm, m->gap, partial, stride); \
-    } while (0)
+    hipLaunchKernelGGL((mlp_grad_mfma_kernel<T, IT, F>), dim3(nblk), dim3(256), 0, stream, (const V4 *)nlist, B, NN,   \
+                       labels, lab_f64, predbuf, (float4 *)pred, m->train_images, dm, m->gap, partial, stride)
 #define HTF_LAUNCH_MLPM2(T, IT, V4)                                                                                    \
     do {                                                                                                               \
         if (fused) HTF_LAUNCH_MLPM(T, IT, V4, true); else HTF_LAUNCH_MLPM(T, IT, V4, false);                           \
@@ -1051,9 +608,10 @@ int mlp_train_grad(const MlpDevice *m, const void *nlist, int in_dtype, unsigned
         rc = check_launch("mlp_grad_mfma_kernel");
         if (rc != HTF_OK) return rc;
         hipLaunchKernelGGL(mlp_reduce_partials_kernel, dim3((ncols + 63) / 64), dim3(64), 0, stream, partial, nblk, stride,
-                           ncols, accum);
+                           ncols, accum, (const float *)nullptr);
         return check_launch("mlp_reduce_partials_kernel");
     }
+#ifdef HTF_AB_VARIANTS
     const float *tab_c = m->images + (m->precision == HTF_MLP_SPLIT ? Img<2>::TabC
                                       : m->precision == HTF_MLP_BF16 ? Img<1>::TabC
                                       : m->precision == HTF_MLP_SPLIT16 ? Img<3>::TabC : Img<0>::TabC);
@@ -1071,8 +629,11 @@ int mlp_train_grad(const MlpDevice *m, const void *nlist, int in_dtype, unsigned
     rc = check_launch("mlp_grad_kernel");
     if (rc != HTF_OK) return rc;
     hipLaunchKernelGGL(mlp_reduce_partials_kernel, dim3((ncols + 63) / 64), dim3(64), 0, stream, partial, nw, stride,
-                       ncols, accum);
+                       ncols, accum, (const float *)nullptr);
     return check_launch("mlp_reduce_partials_kernel");
+#else
+    return HTF_OK; // (unreachable: force_valu is false in the shipped build)
+#endif
 }
 
 } // namespace htf

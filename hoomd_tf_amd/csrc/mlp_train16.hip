@@ -1,0 +1,471 @@
+// Online force matching for split16 pair-MLP potentials (FORCE_MODE::hoomd2tf, tensorflowcompute.py:347-370): the
+// loss-gradient sweep of mlp_train.hip -- value chain, r-tangent chain, ONE reverse pass over both -- with every matrix product
+// on the fp16 pipeline and fp32-level operands (x = hi + lo in fp16, hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16, as the
+// evaluator pair_mlp.hip HTF_MLP_SPLIT16, whose images it reads: forward blocks and bias tables carry 2 log2(e) for tanh -- the
+// accumulator is the exponent -- and the tangent chain is scaled back).
+// Compiled -fno-slp-vectorize: packed fp32 instructions do not run beside 16-bit MFMA work on gfx950 (tools/mfma_valu_probe2.hip).
+#include "htf_common.h"
+#include "htf_internal.h"
+#include "pair_mlp.h"
+
+namespace htf {
+
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
+using u32x4t = __attribute__((ext_vector_type(4))) unsigned;
+#define HTF_MFMA_H(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+
+struct Op16 {
+    f16x8 hi[2], lo[2]; // one 32-feature block: accumulator elements 8s .. 8s+7 are k-step s
+};
+
+// x = hi + lo, both fp16 and rounded to nearest: v_cvt_pk_f16_f32 per pair of elements, the residual by v_fma_mix_f32 reading
+// hi from its half of the packed register (pair_mlp.hip prep<HTF_MLP_SPLIT16>)
+__device__ __forceinline__ Op16 split16(const f32x16 &x) {
+    Op16 o;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        u32x4t ph, pl;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float a = x[8 * s + 2 * j], b = x[8 * s + 2 * j + 1];
+            const unsigned hp = __builtin_bit_cast(unsigned, f16x2{(_Float16)a, (_Float16)b});
+            float ra, rb;
+            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(hp), "v"(a));
+            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(hp), "v"(b));
+            ph[j] = hp;
+            pl[j] = __builtin_bit_cast(unsigned, f16x2{(_Float16)ra, (_Float16)rb});
+        }
+        o.hi[s] = __builtin_bit_cast(f16x8, ph);
+        o.lo[s] = __builtin_bit_cast(f16x8, pl);
+    }
+    return o;
+}
+
+// tanh from an accumulator that already carries 2 log2(e) z (the split16 images fold it into the forward blocks)
+template <bool TANH>
+__device__ __forceinline__ float act_scaled(float a) {
+    if constexpr (!TANH) return a;
+    return fmaf(__builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(a) + 1.0f), -2.0f, 1.0f);
+}
+
+__device__ __forceinline__ void mfma_pair16(f32x16 &acc0, f32x16 &acc1, const float *img, unsigned lane, const Op16 &p0, const Op16 &p1) {
+    const f16x8 *p = reinterpret_cast<const f16x8 *>(img) + lane; // [part 2: hi, lo][s 2][lane 64]
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const f16x8 ah = p[s * 64], al = p[(2 + s) * 64];
+        acc0 = HTF_MFMA_H(al, p0.hi[s], acc0);
+        acc1 = HTF_MFMA_H(al, p1.hi[s], acc1);
+        acc0 = HTF_MFMA_H(ah, p0.lo[s], acc0);
+        acc1 = HTF_MFMA_H(ah, p1.lo[s], acc1);
+        acc0 = HTF_MFMA_H(ah, p0.hi[s], acc0);
+        acc1 = HTF_MFMA_H(ah, p1.hi[s], acc1);
+    }
+}
+
+// acc[i][n] += sum over the tile's pairs of A[i][pair] B[n][pair], both operands in the F layout (lane = feature, k = pair)
+__device__ __forceinline__ void outer16_f16(f32x16 &acc, const Op16 &A, const Op16 &Bm) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        acc = HTF_MFMA_H(A.lo[s], Bm.hi[s], acc);
+        acc = HTF_MFMA_H(A.hi[s], Bm.lo[s], acc);
+        acc = HTF_MFMA_H(A.hi[s], Bm.hi[s], acc);
+    }
+}
+
+// ---- a wave-private transpose through LDS (no barrier: one wave writes and reads its own scratch; DS operations of a wave
+// complete in issue order).  A 32-feature block of a P-layout quantity (lane = pair, registers = features: an accumulator tile
+// or its split form) is stored as two planes (hi, lo) of [pair 32][feature 32] fp16, 64-byte rows, and read back with
+// ds_read_b64_tr_b16 as the F-layout MFMA operand (lane = feature, k = pair) of the pair-contracted weight gradients.
+// Lane (p, h) owns features 8c + 4h + (0..3), c = 0..3 -- elements 4c..4c+3 of its split form -- i.e. the 8-byte chunk 2c + h of
+// its row; chunk positions are XORed with (pair >> 1) & 7, which makes the ds_write_b64 (16 lanes x 32 banks) and the transposed
+// reads (32 lanes x 64 banks) conflict-free at once.
+constexpr int kTrPlane = 32 * 64;       // bytes: one plane
+constexpr int kTrBlock = 2 * kTrPlane;  // hi plane, lo plane
+constexpr int kTrBlocks = 6;            // per wave: phi, phid | h1[0], h1[1], hd1[0], hd1[1] (then zb2[0..1], zdb2[0..1] in their place)
+using v4h = __fp16 __attribute__((__vector_size__(8)));
+using lds_v4h = __attribute__((address_space(3))) v4h;
+
+__device__ __forceinline__ void tr_write(unsigned char *blk, unsigned p, unsigned h, const Op16 &o) {
+    unsigned char *row = blk + p * 64u;
+    const unsigned sw = (p >> 1) & 7u;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const unsigned off = 8u * ((2u * c + h) ^ sw);
+        const u32x4t hi = __builtin_bit_cast(u32x4t, o.hi[c >> 1]), lo = __builtin_bit_cast(u32x4t, o.lo[c >> 1]);
+        *reinterpret_cast<uint2 *>(row + off) = make_uint2(hi[2 * (c & 1)], hi[2 * (c & 1) + 1]);
+        *reinterpret_cast<uint2 *>(row + kTrPlane + off) = make_uint2(lo[2 * (c & 1)], lo[2 * (c & 1) + 1]);
+    }
+}
+
+// The F-layout operand of the block: lane l holds feature l & 31; element j of k-step s of lane half hh is pair
+// 16 s + 8 (j >> 2) + 4 hh + (j & 3) = f0(8 s + j) + 4 hh -- the pair order of an F-layout ACCUMULATOR's registers, so operands
+// that come from LDS and operands split from an accumulator contract over the same k.  ds_read_b64_tr_b16: lane 4q + pp of a
+// 16-lane group addresses columns 4 pp .. + 3 of row q of a 4 x 16 block and lane i receives column i, row q in element q
+// (tools/tr16_probe.hip checks the map with exact integers).  EXEC is all ones here (wave-uniform control flow only).
+__device__ __forceinline__ Op16 tr_read(const unsigned char *blk, unsigned lane) {
+    const unsigned g = lane >> 4, q = (lane >> 2) & 3u, pp = lane & 3u, hh = lane >> 5;
+    const unsigned ch = 4u * (g & 1u) + pp;
+    Op16 o;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        u32x4t wh, wl;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const unsigned row = 16u * s + 8u * t + 4u * hh + q;
+            const unsigned off = row * 64u + 8u * (ch ^ ((row >> 1) & 7u));
+            const v4h a = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_v4h *)(blk + off));
+            const v4h b = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_v4h *)(blk + kTrPlane + off));
+            const uint2 ua = __builtin_bit_cast(uint2, a), ub = __builtin_bit_cast(uint2, b);
+            wh[2 * t] = ua.x; wh[2 * t + 1] = ua.y;
+            wl[2 * t] = ub.x; wl[2 * t + 1] = ub.y;
+        }
+        o.hi[s] = __builtin_bit_cast(f16x8, wh);
+        o.lo[s] = __builtin_bit_cast(f16x8, wl);
+    }
+    return o;
+}
+
+// compiler-level ordering of the scratch accesses of one wave (the hardware keeps a wave's DS operations in order)
+__device__ __forceinline__ void tr_fence() { asm volatile("" ::: "memory"); }
+
+// D[pair][feature] instead of D[feature][pair]: the SAME image fragment taken as the B operand and the activations as A
+// transposes the product -- the reverse pass through layer 2 lands in the F layout its weight-gradient contraction wants.
+__device__ __forceinline__ void mfma_pair16_t(f32x16 &acc0, f32x16 &acc1, const float *img, unsigned lane, const Op16 &p0, const Op16 &p1) {
+    const f16x8 *p = reinterpret_cast<const f16x8 *>(img) + lane; // [part 2: hi, lo][s 2][lane 64]
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const f16x8 ah = p[s * 64], al = p[(2 + s) * 64];
+        acc0 = HTF_MFMA_H(p0.hi[s], al, acc0);
+        acc1 = HTF_MFMA_H(p1.hi[s], al, acc1);
+        acc0 = HTF_MFMA_H(p0.lo[s], ah, acc0);
+        acc1 = HTF_MFMA_H(p1.lo[s], ah, acc1);
+        acc0 = HTF_MFMA_H(p0.hi[s], ah, acc0);
+        acc1 = HTF_MFMA_H(p1.hi[s], ah, acc1);
+    }
+}
+
+// element e (0..15 = 8 s + j) of an operand as fp32: hi + lo, one v_fma_mix_f32 reading both halves from their packed registers
+__device__ __forceinline__ float op16_elem(const Op16 &o, int e) {
+    const u32x4t ph = __builtin_bit_cast(u32x4t, o.hi[e >> 3]), pl = __builtin_bit_cast(u32x4t, o.lo[e >> 3]);
+    const unsigned a = ph[(e & 7) >> 1], b = pl[(e & 7) >> 1];
+    float r;
+    if (e & 1)
+        asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(b));
+    else
+        asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+__global__ void mlp_resid_max_kernel(const float4 *__restrict__ pred, const void *__restrict__ labels, int lab_f64, unsigned B,
+                                     unsigned *__restrict__ out_bits) {
+    float m = 0.f;
+    for (unsigned row = blockIdx.x * blockDim.x + threadIdx.x; row < B; row += gridDim.x * blockDim.x) {
+        const float4 rs = residual(pred, labels, lab_f64, row);
+        const float a = 2.0f * sqrtf(rs.x * rs.x + rs.y * rs.y + rs.z * rs.z), b = fabsf(rs.w);
+        const float v = a > b ? a : b;
+        m = (v > m || v != v) ? v : m; // a NaN residual wins: the sweep then runs unscaled and the NaN shows in the gradient
+    }
+    // non-negative floats (and NaN above them) order as their bit patterns
+    unsigned u = __float_as_uint(m);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned o = (unsigned)__shfl_xor((int)u, d);
+        u = o > u ? o : u;
+    }
+    if ((threadIdx.x & 63u) == 0) atomicMax(out_bits, u);
+}
+
+// The sweep, round 4: every wave is on its own.  One wave owns whole rows (its tiles one after the other; fully padded tiles are
+// skipped) and the COMPLETE weight-gradient accumulators -- dW2 64 + dW1 32 (+ 32 for the layer-2 bias) accumulator registers --
+// for the whole launch: nothing is shared between waves inside the loop, so there is no workgroup barrier in it (the previous
+// form split the accumulators over the four waves of a block and paid nine barriers per round at one wave per SIMD, with the
+// wave of a mostly padded fourth tile idling), and the [feature][pair] operands of the pair-contracted gradients come from a
+// wave-private LDS transpose (tr_write / tr_read: 8-byte writes, hardware-transposed reads; the previous form scattered 2-byte
+// writes).  The reverse pass through layer 2 is taken with swapped operands so that it lands in that layout by itself.  The
+// prediction comes from the evaluator (mlp_eval: a row's residual needs all of its tiles).
+// Per 32-pair tile: 192 + 8 v_mfma_f32_32x32x16_f16 and ~1 750 vector instructions.
+template <bool TANH, typename IT>
+__global__ __launch_bounds__(256, 1) void mlp_grad_tr16_kernel(const typename Vec4<IT>::type *__restrict__ nlist, unsigned B, unsigned NN,
+                                                               const void *__restrict__ labels, int lab_f64,
+                                                               const float4 *__restrict__ pred, const float *__restrict__ images,
+                                                               MlpDims dm, float gap, const float *__restrict__ resid_max,
+                                                               float *__restrict__ partial, unsigned stride) {
+    using I = Img<HTF_MLP_SPLIT16>;
+    __shared__ __attribute__((aligned(16))) float lds[I::Floats];
+    __shared__ __attribute__((aligned(16))) unsigned char trs[4 * kTrBlocks * kTrBlock];
+    constexpr float kCinv = TANH ? 1.0f / 2.8853900817779268f : 1.0f;
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(images);
+        float4 *dst = reinterpret_cast<float4 *>(lds);
+        for (int i = threadIdx.x; i < I::Floats / 4; i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned p = lane & 31u, h = lane >> 5;
+    const unsigned w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned gw = blockIdx.x * 4u + w, nw = gridDim.x * 4u;
+    const unsigned ntiles = (NN + 31) / 32;
+    const float ginv = 1.0f / gap;
+    const float S = seed_scale(*resid_max);
+    unsigned char *tr_phi = trs + w * (kTrBlocks * kTrBlock); // phi | phid
+    unsigned char *tr_a = tr_phi + 2 * kTrBlock;               // h1[0] h1[1] hd1[0] hd1[1], then zb2[0] zb2[1] zdb2[0] zdb2[1]
+    f16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (_Float16)1.0f;
+
+    f32x16 acc2[2][2] = {{zero16(), zero16()}, {zero16(), zero16()}}; // [f1b][f2b]: lane (f2, h) register v = dW2[32 f1b + f0(v) + 4h][32 f2b + f2]
+    f32x16 acc1[2] = {zero16(), zero16()};                             // [fb]: lane (f1, h) register v = dW1[f0(v) + 4h][32 fb + f1]
+    f32x16 accb[2] = {zero16(), zero16()};                             // [f2b]: every row = sum over pairs of zb2[32 f2b + lane]
+    f32x16 gw3[2] = {zero16(), zero16()};                              // P layout: partial over this lane's pairs
+    float gb1[2] = {0.f, 0.f}, gb3 = 0.f, loss = 0.f;
+
+    // One wave per SIMD: nothing hides a global load but the wave's own work, so a tile's slot (and a row's residual) is read
+    // one tile ahead.
+    auto read_slot = [&](unsigned row, unsigned tile, float &ox, float &oy, float &oz) {
+        ox = oy = oz = 0.f;
+        const unsigned sl = tile * 32 + p;
+        if (row < B && sl < NN) {
+            const auto v = nlist[(size_t)row * NN + sl];
+            ox = (float)v.x; oy = (float)v.y; oz = (float)v.z;
+        }
+    };
+    unsigned row = gw, tile = 0;
+    float nx, ny, nz;
+    read_slot(row, 0, nx, ny, nz);
+    float4 rs = make_float4(0.f, 0.f, 0.f, 0.f), nrs = rs;
+    if (row < B) nrs = residual(pred, labels, lab_f64, row);
+    while (row < B) {
+        const float x = nx, y = ny, z = nz;
+        const unsigned slot = tile * 32 + p;
+        if (tile == 0) {
+            rs = nrs;
+            if (lane == 0) loss += rs.x * rs.x + rs.y * rs.y + rs.z * rs.z + rs.w * rs.w;
+        }
+        // the next unit of this wave
+        unsigned nrow = row, ntile = tile + 1;
+        if (ntile == ntiles) {
+            ntile = 0;
+            nrow = row + nw;
+            if (nrow < B) nrs = residual(pred, labels, lab_f64, nrow);
+        }
+        read_slot(nrow, ntile, nx, ny, nz);
+        row = nrow;
+        const unsigned this_tile = tile;
+        tile = ntile;
+        (void)this_tile;
+
+        const float tx = x + kNormDelta, ty = y + kNormDelta, tz = z + kNormDelta;
+        const float r = sqrtf(tx * tx + ty * ty + tz * tz);
+        const bool m = slot < NN && r > kRinvDelta;
+        if (__ballot(m) == 0ull) continue; // every slot of this tile is padding
+
+        // ---- value + r-tangent, forward (P layout: lane = pair)
+        Op16 h1o[2], hd1o[2];
+        {
+            f32x16 phi, phid;
+            const f32x16 cen = load_tab(lds + I::TabC, 0, h);
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const float d = r - cen[v];
+                phi[v] = __expf(-(d * d) * ginv);
+                phid[v] = -2.0f * d * ginv * phi[v];
+            }
+            const Op16 phi_o = split16(phi), phid_o = split16(phid);
+            tr_write(tr_phi, p, h, phi_o);
+            tr_write(tr_phi + kTrBlock, p, h, phid_o);
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                f32x16 zz = load_tab(lds + I::TabB1, nb, h), zd = zero16();
+                mfma_pair16(zz, zd, lds + I::L1 + nb * I::BS, lane, phi_o, phid_o);
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const float hv = act_scaled<TANH>(zz[v]);
+                    zd[v] = TANH ? (1.0f - hv * hv) * (zd[v] * kCinv) : zd[v];
+                    zz[v] = hv;
+                }
+                h1o[nb] = split16(zz);
+                hd1o[nb] = split16(zd);
+                tr_write(tr_a + nb * kTrBlock, p, h, h1o[nb]);
+                tr_write(tr_a + (2 + nb) * kTrBlock, p, h, hd1o[nb]);
+            }
+        }
+        // ---- layer 2 forward and the reverse seeds: S = a u' + b u  (u = w3 . h2 + b3, u' = w3 . hd2), scaled by the launch's S
+        Op16 zb2o[2], zdb2o[2];
+        {
+            const float aq = m ? S * (2.0f * (rs.x * tx + rs.y * ty + rs.z * tz) / r) : 0.f;
+            const float bq = m ? S * rs.w : 0.f;
+            if (h == 0) gb3 += bq;
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                f32x16 zz = load_tab(lds + I::TabB2, nb, h), zd = zero16();
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) mfma_pair16(zz, zd, lds + I::L2 + (nb * 2 + kb) * I::BS, lane, h1o[kb], hd1o[kb]);
+                const f32x16 w3 = load_tab(lds + I::TabW3, nb, h);
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const float hv = act_scaled<TANH>(zz[v]);
+                    const float s2 = TANH ? 1.0f - hv * hv : 1.0f;
+                    const float hdv = TANH ? s2 * (zd[v] * kCinv) : zd[v];
+                    gw3[nb][v] += bq * hv + aq * hdv;
+                    const float hb = bq * w3[v], hdb = aq * w3[v];
+                    zz[v] = TANH ? hb * s2 - 2.0f * hdb * hv * hdv : hb; // zb2
+                    zd[v] = hdb * s2;                                      // zdb2
+                }
+                zb2o[nb] = split16(zz);
+                zdb2o[nb] = split16(zd);
+            }
+        }
+        // ---- reverse through layer 2 INTO THE F LAYOUT: (hb1, hdb1)[pair][f1] = (zb2, zdb2)^T W2^T.  Issued first: the products
+        // sit in their accumulators while the vector unit does the transposes below, and zb2 / zdb2's split forms die early.
+        f32x16 hb[2] = {zero16(), zero16()}, hdb[2] = {zero16(), zero16()};
+#pragma unroll
+        for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) mfma_pair16_t(hb[fb], hdb[fb], lds + I::B2 + (fb * 2 + kb) * I::BS, lane, zb2o[kb], zdb2o[kb]);
+        // ---- layer 1's activations as [feature][pair] operands; zb2 / zdb2 then take their place in the scratch
+        tr_fence();
+        Op16 h1F[2], hd1F[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            h1F[b] = tr_read(tr_a + b * kTrBlock, lane);
+            hd1F[b] = tr_read(tr_a + (2 + b) * kTrBlock, lane);
+        }
+        tr_fence();
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            tr_write(tr_a + b * kTrBlock, p, h, zb2o[b]);
+            tr_write(tr_a + (2 + b) * kTrBlock, p, h, zdb2o[b]);
+        }
+        tr_fence();
+        // ---- through act at z1: zb1, zdb1 (F layout), layer-1 bias gradient, dW1 += phi (x) zb1 + phid (x) zdb1
+        {
+            const Op16 phiF = tr_read(tr_phi, lane), phidF = tr_read(tr_phi + kTrBlock, lane);
+#pragma unroll
+            for (int fb = 0; fb < 2; ++fb) {
+                float bsum = 0.f;
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const float hv = op16_elem(h1F[fb], v);
+                    const float s1 = TANH ? 1.0f - hv * hv : 1.0f;
+                    const float zb1 = TANH ? hb[fb][v] * s1 - 2.0f * hdb[fb][v] * hv * op16_elem(hd1F[fb], v) : hb[fb][v];
+                    hdb[fb][v] = hdb[fb][v] * s1; // zdb1
+                    hb[fb][v] = zb1;
+                    bsum += zb1;
+                }
+                gb1[fb] += bsum;
+                const Op16 q = split16(hb[fb]), qd = split16(hdb[fb]);
+                outer16_f16(acc1[fb], phiF, q);
+                outer16_f16(acc1[fb], phidF, qd);
+            }
+        }
+        // ---- dW2 += h1 (x) zb2 + hd1 (x) zdb2 (k = the tile's pairs), layer-2 bias gradient as a product with ones
+#pragma unroll
+        for (int f2b = 0; f2b < 2; ++f2b) {
+            const Op16 zF = tr_read(tr_a + f2b * kTrBlock, lane), zdF = tr_read(tr_a + (2 + f2b) * kTrBlock, lane);
+#pragma unroll
+            for (int f1b = 0; f1b < 2; ++f1b) {
+                outer16_f16(acc2[f1b][f2b], h1F[f1b], zF);
+                outer16_f16(acc2[f1b][f2b], hd1F[f1b], zdF);
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                accb[f2b] = HTF_MFMA_H(ones, zF.lo[s], accb[f2b]);
+                accb[f2b] = HTF_MFMA_H(ones, zF.hi[s], accb[f2b]);
+            }
+        }
+        tr_fence(); // the next tile's writes stay behind this tile's reads
+    }
+
+    // ---- block partial in LDS, waves in a fixed order (the scratch is free now)
+    __syncthreads();
+    float *red = reinterpret_cast<float *>(trs); // 1 + P <= 6338 floats
+    for (unsigned c = threadIdx.x; c < stride; c += blockDim.x) red[c] = 0.f;
+    __syncthreads();
+    // gw3: sum over the 32 pairs of each lane half
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            float s = gw3[b][v];
+            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+            s += __shfl_xor(s, 8); s += __shfl_xor(s, 16);
+            gw3[b][v] = s;
+        }
+    gb1[0] = sum_xor32(gb1[0]); // the two lane halves hold the two halves of a feature's pairs
+    gb1[1] = sum_xor32(gb1[1]);
+    gb3 = group_sum<64>(gb3);
+    for (unsigned turn = 0; turn < 4; ++turn) {
+        if (w == turn) {
+#pragma unroll
+            for (int f1b = 0; f1b < 2; ++f1b)
+#pragma unroll
+                for (int f2b = 0; f2b < 2; ++f2b) {
+                    const int f2 = 32 * f2b + (int)p;
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) {
+                        const int f1 = 32 * f1b + f0(v) + 4 * (int)h;
+                        if (f1 < dm.H1 && f2 < dm.H2) red[1 + dm.oW2 + f1 * dm.H2 + f2] += acc2[f1b][f2b][v];
+                    }
+                }
+#pragma unroll
+            for (int fb = 0; fb < 2; ++fb) {
+                const int f1 = 32 * fb + (int)p;
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int k = f0(v) + 4 * (int)h;
+                    if (k < dm.K && f1 < dm.H1) red[1 + k * dm.H1 + f1] += acc1[fb][v];
+                }
+                if (h == 0 && f1 < dm.H1) red[1 + dm.oB1 + f1] += gb1[fb];
+                if (h == 0 && f1 < dm.H2) red[1 + dm.oB2 + f1] += accb[fb][0]; // (f2b = fb, f2 = f1: row 0 of the ones product)
+            }
+            if (p == 0) {
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) {
+                        const int f = 32 * b + f0(v) + 4 * (int)h;
+                        if (f < dm.H2) red[1 + dm.oW3 + f] += gw3[b][v];
+                    }
+            }
+            if (lane == 0) {
+                red[1 + dm.oB3] += gb3;
+                red[0] += loss;
+            }
+        }
+        __syncthreads();
+    }
+    float *out = partial + (size_t)blockIdx.x * stride;
+    for (unsigned c = threadIdx.x; c < stride; c += blockDim.x) out[c] = red[c];
+}
+
+
+int mlp_train_grad16(const MlpDevice *m, const void *nlist, int in_dtype, unsigned B, unsigned NN, const void *labels, int lab_f64,
+                     float4 *predbuf, float *partial, unsigned stride, float *resid_max, unsigned *nblk_out, hipStream_t stream) {
+    int rc = mlp_eval(m, nlist, in_dtype, B, NN, predbuf, HTF_F32, nullptr, stream);
+    if (rc != HTF_OK) return rc;
+    HTF_CHECK_HIP(hipMemsetAsync(resid_max, 0, sizeof(float), stream));
+    unsigned rblk = (B + 255u) / 256u;
+    if (rblk > 1024u) rblk = 1024u;
+    hipLaunchKernelGGL(mlp_resid_max_kernel, dim3(rblk), dim3(256), 0, stream, predbuf, labels, lab_f64, B, (unsigned *)resid_max);
+    rc = check_launch("mlp_resid_max_kernel");
+    if (rc != HTF_OK) return rc;
+    unsigned nblk = (unsigned)m->n_cu; // one 4-wave workgroup per CU (146 KB of LDS), a wave per row at a time
+    if ((unsigned long long)nblk * 4 > B) nblk = (B + 3u) / 4u;
+    MlpDims dm{m->K, m->H1, m->H2, m->off_b1(), m->off_W2(), m->off_b2(), m->off_W3(), m->off_b3()};
+    const bool th = m->act == HTF_ACT_TANH;
+#define HTF_LAUNCH_TR16(T, IT, V4)                                                                                     \
+    hipLaunchKernelGGL((mlp_grad_tr16_kernel<T, IT>), dim3(nblk), dim3(256), 0, stream, (const V4 *)nlist, B, NN, labels, \
+                       lab_f64, predbuf, m->images, dm, m->gap, resid_max, partial, stride)
+    if (in_dtype == HTF_F32) {
+        if (th) HTF_LAUNCH_TR16(true, float, float4); else HTF_LAUNCH_TR16(false, float, float4);
+    } else {
+        if (th) HTF_LAUNCH_TR16(true, double, double4); else HTF_LAUNCH_TR16(false, double, double4);
+    }
+#undef HTF_LAUNCH_TR16
+    *nblk_out = nblk;
+    return check_launch("mlp_grad_tr16_kernel");
+}
+
+} // namespace htf

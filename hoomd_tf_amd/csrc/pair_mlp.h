@@ -88,6 +88,46 @@ __device__ __forceinline__ f32x16 load_tab(const float *tab, int b, unsigned h) 
     return r;
 }
 
+
+// ---- shared by the training sweeps (mlp_train.hip: fp32 MFMA; mlp_train16.hip: fp16 pipeline)
+struct MlpDims {
+    int K, H1, H2, oB1, oW2, oB2, oW3, oB3;
+};
+
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 r;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) r[v] = 0.f;
+    return r;
+}
+
+__device__ __forceinline__ float4 residual(const float4 *pred, const void *labels, int lab_f64, unsigned row) {
+    const float4 pr = pred[row];
+    if (lab_f64) {
+        const double4 l = ((const double4 *)labels)[row];
+        return make_float4(pr.x - (float)l.x, pr.y - (float)l.y, pr.z - (float)l.z, pr.w - (float)l.w);
+    }
+    const float4 l = ((const float4 *)labels)[row];
+    return make_float4(pr.x - l.x, pr.y - l.y, pr.z - l.z, pr.w - l.w);
+}
+
+// Reverse seeds are scaled by a power of two S chosen per launch from the largest residual (mlp_resid_max_kernel) so that the
+// largest |seed| sits in [1, 2): everything downstream of the seeds is linear in them and travels as fp16 hi + lo -- large
+// residuals (early training, close contacts) would leave fp16's range, small ones its normal numbers.  The
+// accumulated gradient is multiplied by 1 / S, exactly, when the block partials are combined.
+__device__ __forceinline__ float seed_scale(float m) {
+    if (!(m > 0.f) || !(m < 3.0e38f)) return 1.0f;
+    int e = 0;
+    (void)frexpf(m, &e); // m = f 2^e, f in [0.5, 1)
+    e = 1 - e;
+    e = e < -100 ? -100 : (e > 100 ? 100 : e);
+    return ldexpf(1.0f, e);
+}
+
+// split16 potentials: prediction (evaluator), the launch's largest residual, the sweep; block partials land in `partial`
+// (nblk_out of them), still scaled by seed_scale(*resid_max)
+int mlp_train_grad16(const MlpDevice *m, const void *nlist, int in_dtype, unsigned B, unsigned NN, const void *labels, int lab_f64,
+                     float4 *predbuf, float *partial, unsigned stride, float *resid_max, unsigned *nblk_out, hipStream_t stream);
 int mlp_refresh(const MlpDevice *m, hipStream_t stream);
 int mlp_train_grad(const MlpDevice *m, const void *nlist, int in_dtype, unsigned B, unsigned NN, const void *labels,
                    int lab_f64, void *pred, float *accum, float *scratch, hipStream_t stream);

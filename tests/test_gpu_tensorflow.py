@@ -458,7 +458,7 @@ def test_eds_rdf_model_replayed_as_one_kernel(htf, cuda, sdtype):
         if step > 0:  # the replay's tensor is the build kernel's tensor, bit for bit
             want = htf.ops.build_pair_vectors(pos_before, cell.n_neigh, cell.head_list, cell.nlist, system.box, 2.5, 64)
             assert want.dtype == torch.float32 and torch.equal(tfc._last[0], want)
-            np.testing.assert_array_equal(tfc.get_positions_array()[:, :3], pos_before[:, :3].float().double().cpu().numpy())
+            np.testing.assert_array_equal(tfc.get_positions_array()[:, :3], pos_before[:, :3].double().cpu().numpy())
             assert tfc.force.dtype == sdtype
     assert abs(a_ref) > 1e-3
     # the same trajectory as the eager path (summation order differs between the one-kernel and two-kernel sweeps)

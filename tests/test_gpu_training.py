@@ -230,6 +230,50 @@ def test_pair_mlp_loss_gradient_matches_double_backward(htf, cuda, dims, act, NN
         o += n
 
 
+@pytest.mark.parametrize("precision", ["split16", "fp32"])
+@pytest.mark.parametrize("regime", ["residuals 1e-6", "residuals 1e-3", "labels 1e4 x LJ", "labels 1e7 x LJ"])
+def test_pair_mlp_gradient_over_the_residual_range(htf, cuda, regime, precision):
+    """The split16 sweep carries everything downstream of the reverse seeds (residual x w3 x act') as fp16 hi + lo: unscaled,
+    a large residual (early training, close contacts) leaves fp16's range -> inf / NaN gradients, a small one its normal
+    numbers -> the gradient loses its bits and vanishes below ~3e-8.  The sweep scales the seeds of a launch by a
+    power of two taken from its largest residual and folds it back out exactly.  Checked over thirteen decades of residual,
+    every weight against torch's fp64 double backward FED THE SWEEP'S OWN fp32 RESIDUAL (labels_eff = fp64 prediction - (GPU
+    prediction - labels)), so that the tolerance stays the fixture's 2e-4 of the gradient scale whatever the residual's size."""
+    from hoomd_tf_amd import initializers
+    dims, NN = (32, 64, 64), 72
+    nl = _case(9, N=25, NN=NN)
+    nl64 = nl.astype(np.float64)
+    params = initializers.mlp_params(seed=13)
+    rng = np.random.default_rng(8)
+    for k in ("b1", "b2", "b3"):
+        params[k] = (0.1 * rng.standard_normal(params[k].shape)).astype(np.float32)
+    theta = _flat_params(params)
+    ref_pred = G.pair_mlp_param_forces(torch.from_numpy(nl64), torch.from_numpy(theta), dims, act="tanh").detach().numpy()
+    if regime.startswith("residuals"):
+        labels = (ref_pred + float(regime.split()[1]) * rng.standard_normal(ref_pred.shape)).astype(np.float32)
+    else:
+        labels = (float(regime.split()[1]) * O.lj_model(nl64)).astype(np.float32)
+    w = torch.tensor(theta, dtype=torch.float32, device=cuda)
+    pot = htf.Potential.pair_mlp(params, 0.0, 3.0, activation="tanh", theta=w, precision=precision)
+    pred = torch.empty((nl.shape[0], 4), device=cuda)
+    accum = htf.ops.train_pair_grad(pot, torch.from_numpy(nl).to(cuda), torch.from_numpy(labels).to(cuda), pred=pred).cpu().numpy()
+    assert np.all(np.isfinite(accum)), regime
+    resid = pred.cpu().numpy() - labels                      # fp32, as the sweep forms it
+    B = nl.shape[0]
+    np.testing.assert_allclose(accum[0] / (4 * B), np.mean(resid.astype(np.float64) ** 2), rtol=1e-5)
+    labels_eff = ref_pred - resid.astype(np.float64)
+    fwd = lambda n, ww: G.pair_mlp_param_forces(n, ww, dims, act="tanh", create_graph=True)
+    _, g = G.mse_grad_wrt_params(fwd, torch.from_numpy(nl64), torch.from_numpy(labels_eff), theta)
+    got = accum[1:] / (4 * B)
+    assert np.abs(g).max() > 0
+    err = np.abs(got - g).max() / np.abs(g).max()
+    assert err < 2e-4, (regime, precision, err)
+    o = 0
+    for n in (32 * 64, 64, 64 * 64, 64, 64, 1):   # every block of theta carries signal at every residual size
+        assert np.abs(got[o:o + n]).max() > 1e-3 * np.abs(g[o:o + n]).max()
+        o += n
+
+
 @pytest.mark.parametrize("route", ["valu", "nofuse", "bf16-images", "split-images", "split16-f16-sweep", "split16-fp32-sweep",
                                    "split16-nofuse"])
 def test_pair_mlp_gradient_alternate_routes(htf, cuda, route, monkeypatch):
