@@ -220,6 +220,9 @@ __global__ __launch_bounds__(256, 1) void mlp_grad_tr16_kernel(const typename Ve
     f32x16 accb[2] = {zero16(), zero16()};                             // [f2b]: every row = sum over pairs of zb2[32 f2b + lane]
     f32x16 gw3[2] = {zero16(), zero16()};                              // P layout: partial over this lane's pairs
     float gb1[2] = {0.f, 0.f}, gb3 = 0.f, loss = 0.f;
+#ifdef HTF_TRAIN_STAMPS
+    unsigned long long stamps[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0, n_live = 0;
+#endif
 
     // One wave per SIMD: nothing hides a global load but the wave's own work, so a tile's slot (and a row's residual) is read
     // one tile ahead.
@@ -260,71 +263,129 @@ __global__ __launch_bounds__(256, 1) void mlp_grad_tr16_kernel(const typename Ve
         const float r = sqrtf(tx * tx + ty * ty + tz * tz);
         const bool m = slot < NN && r > kRinvDelta;
         if (__ballot(m) == 0ull) continue; // every slot of this tile is padding
+#ifdef HTF_TRAIN_STAMPS
+        ++n_live;
+        __builtin_amdgcn_sched_barrier(0);
+        t_prev = __builtin_amdgcn_s_memtime();
+#endif
+        // The phases of a tile are software-pipelined by hand (as the evaluator's, pair_mlp.hip HTF_PIPE): with one wave per SIMD
+        // nothing but the wave's own instruction stream can put vector work under a matrix instruction, and hipcc clusters each
+        // kind into its own phase (measured so: vector unit 52 % busy + matrix pipe 30 % busy + waits = the whole 4.25 ms).  Each
+        // HTF_TPIPE region holds one group of MFMAs and the vector block of the PREVIOUS group's results -- activation, seeds or
+        // zb1 arithmetic and the hi / lo splits -- interleaved one MFMA, then `per` vector instructions.
+#ifdef HTF_TRAIN_STAMPS // experiment (tools/build_obj_variant.sh): per-phase cycle totals of one wave, printed at the end
+#define HTF_STAMP(i)                                                                                                   \
+    do {                                                                                                               \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        stamps[i] += t_ - t_prev;                                                                                      \
+        t_prev = t_;                                                                                                   \
+    } while (0)
+#else
+#define HTF_STAMP(i)
+#endif
+#define HTF_TPIPE(n, per, pt)                                                                                          \
+    _Pragma("unroll") for (int q_ = 0; q_ < (n); ++q_) {                                                               \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                             \
+        if ((pt) < 0) __builtin_amdgcn_sched_group_barrier(0x400, -(pt), 0); /* v_exp / v_rcp: a group of their own, */ \
+        __builtin_amdgcn_sched_group_barrier(0x002, (per), 0);                                                         \
+        if ((pt) > 0) __builtin_amdgcn_sched_group_barrier(0x400, (pt), 0);  /* before or after the plain ones */       \
+    }                                                                                                                  \
+    __builtin_amdgcn_sched_barrier(0)
+        // activation of one 32-feature block of layer 1, in place: zz <- h1, zd <- hd1, then their split forms (kept for layer 2
+        // and written to the scratch for the transposed reads)
+        auto act1 = [&](f32x16 &zz, f32x16 &zd, int nb, Op16 &ho, Op16 &hdo) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const float hv = act_scaled<TANH>(zz[v]);
+                zd[v] = TANH ? fmaf(-hv, hv, 1.0f) * (zd[v] * kCinv) : zd[v];
+                zz[v] = hv;
+            }
+            ho = split16(zz);
+            hdo = split16(zd);
+            tr_write(tr_a + nb * kTrBlock, p, h, ho);
+            tr_write(tr_a + (2 + nb) * kTrBlock, p, h, hdo);
+        };
 
-        // ---- value + r-tangent, forward (P layout: lane = pair)
-        Op16 h1o[2], hd1o[2];
+        // ---- V0: RBF values and r-derivatives (P layout: lane = pair)
+        Op16 phi_o, phid_o;
         {
             f32x16 phi, phid;
             const f32x16 cen = load_tab(lds + I::TabC, 0, h);
+            const float k1 = -1.4426950408889634f * ginv, k2 = -2.0f * ginv;
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
                 const float d = r - cen[v];
-                phi[v] = __expf(-(d * d) * ginv);
-                phid[v] = -2.0f * d * ginv * phi[v];
+                phi[v] = __builtin_amdgcn_exp2f((d * d) * k1);
+                phid[v] = (d * phi[v]) * k2;
             }
-            const Op16 phi_o = split16(phi), phid_o = split16(phid);
+            phi_o = split16(phi);
+            phid_o = split16(phid);
             tr_write(tr_phi, p, h, phi_o);
             tr_write(tr_phi + kTrBlock, p, h, phid_o);
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
-                f32x16 zz = load_tab(lds + I::TabB1, nb, h), zd = zero16();
-                mfma_pair16(zz, zd, lds + I::L1 + nb * I::BS, lane, phi_o, phid_o);
-#pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    const float hv = act_scaled<TANH>(zz[v]);
-                    zd[v] = TANH ? (1.0f - hv * hv) * (zd[v] * kCinv) : zd[v];
-                    zz[v] = hv;
-                }
-                h1o[nb] = split16(zz);
-                hd1o[nb] = split16(zd);
-                tr_write(tr_a + nb * kTrBlock, p, h, h1o[nb]);
-                tr_write(tr_a + (2 + nb) * kTrBlock, p, h, hd1o[nb]);
-            }
         }
-        // ---- layer 2 forward and the reverse seeds: S = a u' + b u  (u = w3 . h2 + b3, u' = w3 . hd2), scaled by the launch's S
+        const float aq = m ? S * (2.0f * (rs.x * tx + rs.y * ty + rs.z * tz) / r) : 0.f; // reverse seeds: S = a u' + b u
+        const float bq = m ? S * rs.w : 0.f;
+        const float aq2 = -2.0f * aq;
+        if (h == 0) gb3 += bq;
+        __builtin_amdgcn_sched_barrier(0);
+        HTF_STAMP(1); // V0
+        // ---- M1a: layer 1, block 0 (value + r-tangent)
+        Op16 h1o[2], hd1o[2];
+        f32x16 z1a = load_tab(lds + I::TabB1, 0, h), d1a = zero16();
+        mfma_pair16(z1a, d1a, lds + I::L1, lane, phi_o, phid_o);
+        __builtin_amdgcn_sched_barrier(0);
+        HTF_STAMP(2); // M1a
+        // ---- M1b: layer 1, block 1  ||  V1a: activation of block 0
+        f32x16 z1b = load_tab(lds + I::TabB1, 1, h), d1b = zero16();
+        mfma_pair16(z1b, d1b, lds + I::L1 + I::BS, lane, phi_o, phid_o);
+        act1(z1a, d1a, 0, h1o[0], hd1o[0]);
+        HTF_TPIPE(12, 13, 3);
+        HTF_STAMP(3); // M1b | V1a
+        // ---- M2a: layer 2 from block 0 of layer 1 (both output blocks)  ||  V1b: activation of block 1
+        f32x16 z2a = load_tab(lds + I::TabB2, 0, h), d2a = zero16(), z2b = load_tab(lds + I::TabB2, 1, h), d2b = zero16();
+        mfma_pair16(z2a, d2a, lds + I::L2 + (0 * 2 + 0) * I::BS, lane, h1o[0], hd1o[0]);
+        mfma_pair16(z2b, d2b, lds + I::L2 + (1 * 2 + 0) * I::BS, lane, h1o[0], hd1o[0]);
+        act1(z1b, d1b, 1, h1o[1], hd1o[1]);
+        HTF_TPIPE(24, 7, 2);
+        HTF_STAMP(4); // M2a | V1b
+        // ---- M2b: layer 2, output block 0, from block 1
+        mfma_pair16(z2a, d2a, lds + I::L2 + (0 * 2 + 1) * I::BS, lane, h1o[1], hd1o[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        HTF_STAMP(5); // M2b
+        // layer 2's activation and the reverse seeds of one block, in place: zz <- zb2, zd <- zdb2 (u = w3 . h2 + b3, u' = w3 . hd2)
         Op16 zb2o[2], zdb2o[2];
-        {
-            const float aq = m ? S * (2.0f * (rs.x * tx + rs.y * ty + rs.z * tz) / r) : 0.f;
-            const float bq = m ? S * rs.w : 0.f;
-            if (h == 0) gb3 += bq;
+        auto seeds = [&](f32x16 &zz, f32x16 &zd, int nb) {
+            const f32x16 w3 = load_tab(lds + I::TabW3, nb, h);
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
-                f32x16 zz = load_tab(lds + I::TabB2, nb, h), zd = zero16();
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb) mfma_pair16(zz, zd, lds + I::L2 + (nb * 2 + kb) * I::BS, lane, h1o[kb], hd1o[kb]);
-                const f32x16 w3 = load_tab(lds + I::TabW3, nb, h);
-#pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    const float hv = act_scaled<TANH>(zz[v]);
-                    const float s2 = TANH ? 1.0f - hv * hv : 1.0f;
-                    const float hdv = TANH ? s2 * (zd[v] * kCinv) : zd[v];
-                    gw3[nb][v] += bq * hv + aq * hdv;
-                    const float hb = bq * w3[v], hdb = aq * w3[v];
-                    zz[v] = TANH ? hb * s2 - 2.0f * hdb * hv * hdv : hb; // zb2
-                    zd[v] = hdb * s2;                                      // zdb2
-                }
-                zb2o[nb] = split16(zz);
-                zdb2o[nb] = split16(zd);
+            for (int v = 0; v < 16; ++v) {
+                const float hv = act_scaled<TANH>(zz[v]);
+                const float s2 = TANH ? fmaf(-hv, hv, 1.0f) : 1.0f;
+                const float hdv = TANH ? s2 * (zd[v] * kCinv) : zd[v];
+                gw3[nb][v] = fmaf(aq, hdv, fmaf(bq, hv, gw3[nb][v]));
+                const float ws = w3[v] * s2;
+                // zb2 = w3 (b s2 - 2 a h2 hd2) (tanh) | w3 b;  zdb2 = a w3 s2
+                zz[v] = TANH ? w3[v] * fmaf(aq2, hv * hdv, bq * s2) : bq * w3[v];
+                zd[v] = aq * ws;
             }
-        }
-        // ---- reverse through layer 2 INTO THE F LAYOUT: (hb1, hdb1)[pair][f1] = (zb2, zdb2)^T W2^T.  Issued first: the products
-        // sit in their accumulators while the vector unit does the transposes below, and zb2 / zdb2's split forms die early.
+            zb2o[nb] = split16(zz);
+            zdb2o[nb] = split16(zd);
+        };
+        // ---- M2c: layer 2, output block 1, from block 1  ||  V2a: seeds of block 0
+        mfma_pair16(z2b, d2b, lds + I::L2 + (1 * 2 + 1) * I::BS, lane, h1o[1], hd1o[1]);
+        seeds(z2a, d2a, 0);
+        HTF_TPIPE(12, 23, -3);
+        HTF_STAMP(6); // M2c | V2a
+        // ---- M3a: reverse through layer 2 INTO THE F LAYOUT, (hb1, hdb1)[pair][f1] = (zb2, zdb2)^T W2^T, from block 0  ||  V2b
         f32x16 hb[2] = {zero16(), zero16()}, hdb[2] = {zero16(), zero16()};
-#pragma unroll
-        for (int fb = 0; fb < 2; ++fb)
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) mfma_pair16_t(hb[fb], hdb[fb], lds + I::B2 + (fb * 2 + kb) * I::BS, lane, zb2o[kb], zdb2o[kb]);
-        // ---- layer 1's activations as [feature][pair] operands; zb2 / zdb2 then take their place in the scratch
+        mfma_pair16_t(hb[0], hdb[0], lds + I::B2 + (0 * 2 + 0) * I::BS, lane, zb2o[0], zdb2o[0]);
+        mfma_pair16_t(hb[1], hdb[1], lds + I::B2 + (1 * 2 + 0) * I::BS, lane, zb2o[0], zdb2o[0]);
+        seeds(z2b, d2b, 1);
+        HTF_TPIPE(24, 11, -2);
+        HTF_STAMP(7); // M3a | V2b
+        // ---- M3b: ... from block 1  ||  layer 1's activations as [feature][pair] operands (transposed reads)
+        mfma_pair16_t(hb[0], hdb[0], lds + I::B2 + (0 * 2 + 1) * I::BS, lane, zb2o[1], zdb2o[1]);
+        mfma_pair16_t(hb[1], hdb[1], lds + I::B2 + (1 * 2 + 1) * I::BS, lane, zb2o[1], zdb2o[1]);
         tr_fence();
         Op16 h1F[2], hd1F[2];
 #pragma unroll
@@ -333,51 +394,74 @@ __global__ __launch_bounds__(256, 1) void mlp_grad_tr16_kernel(const typename Ve
             hd1F[b] = tr_read(tr_a + (2 + b) * kTrBlock, lane);
         }
         tr_fence();
+        // zb2 / zdb2 take their place in the scratch
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             tr_write(tr_a + b * kTrBlock, p, h, zb2o[b]);
             tr_write(tr_a + (2 + b) * kTrBlock, p, h, zdb2o[b]);
         }
         tr_fence();
-        // ---- through act at z1: zb1, zdb1 (F layout), layer-1 bias gradient, dW1 += phi (x) zb1 + phid (x) zdb1
+        __builtin_amdgcn_sched_barrier(0);
+        HTF_STAMP(8); // M3b + transposes
+        // through act at z1, in place: hb <- zb1, hdb <- zdb1 (F layout), the layer-1 bias gradient, their split forms
+        Op16 q[2], qd[2];
+        auto rev1 = [&](int fb) {
+            float bsum = 0.f;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const float hv = op16_elem(h1F[fb], v);
+                const float s1 = TANH ? fmaf(-hv, hv, 1.0f) : 1.0f;
+                const float zb1 = TANH ? fmaf(hdb[fb][v] * -2.0f, hv * op16_elem(hd1F[fb], v), hb[fb][v] * s1) : hb[fb][v];
+                hdb[fb][v] = hdb[fb][v] * s1; // zdb1
+                hb[fb][v] = zb1;
+                bsum += zb1;
+            }
+            gb1[fb] += bsum;
+            q[fb] = split16(hb[fb]);
+            qd[fb] = split16(hdb[fb]);
+        };
+        // ---- M4: dW2 += h1 (x) zb2 + hd1 (x) zdb2 (k = the tile's pairs), layer-2 bias gradient as a product with ones  ||  V3
+        {
+            const Op16 zF[2] = {tr_read(tr_a, lane), tr_read(tr_a + kTrBlock, lane)};
+            const Op16 zdF[2] = {tr_read(tr_a + 2 * kTrBlock, lane), tr_read(tr_a + 3 * kTrBlock, lane)};
+#pragma unroll
+            for (int f2b = 0; f2b < 2; ++f2b) {
+#pragma unroll
+                for (int f1b = 0; f1b < 2; ++f1b) {
+                    outer16_f16(acc2[f1b][f2b], h1F[f1b], zF[f2b]);
+                    outer16_f16(acc2[f1b][f2b], hd1F[f1b], zdF[f2b]);
+                }
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    accb[f2b] = HTF_MFMA_H(ones, zF[f2b].lo[s], accb[f2b]);
+                    accb[f2b] = HTF_MFMA_H(ones, zF[f2b].hi[s], accb[f2b]);
+                }
+            }
+            rev1(0);
+            rev1(1);
+            HTF_TPIPE(56, 8, 0);
+            HTF_STAMP(9); // M4 | V3
+        }
+        // ---- M5: dW1 += phi (x) zb1 + phid (x) zdb1
         {
             const Op16 phiF = tr_read(tr_phi, lane), phidF = tr_read(tr_phi + kTrBlock, lane);
 #pragma unroll
             for (int fb = 0; fb < 2; ++fb) {
-                float bsum = 0.f;
-#pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    const float hv = op16_elem(h1F[fb], v);
-                    const float s1 = TANH ? 1.0f - hv * hv : 1.0f;
-                    const float zb1 = TANH ? hb[fb][v] * s1 - 2.0f * hdb[fb][v] * hv * op16_elem(hd1F[fb], v) : hb[fb][v];
-                    hdb[fb][v] = hdb[fb][v] * s1; // zdb1
-                    hb[fb][v] = zb1;
-                    bsum += zb1;
-                }
-                gb1[fb] += bsum;
-                const Op16 q = split16(hb[fb]), qd = split16(hdb[fb]);
-                outer16_f16(acc1[fb], phiF, q);
-                outer16_f16(acc1[fb], phidF, qd);
+                outer16_f16(acc1[fb], phiF, q[fb]);
+                outer16_f16(acc1[fb], phidF, qd[fb]);
             }
         }
-        // ---- dW2 += h1 (x) zb2 + hd1 (x) zdb2 (k = the tile's pairs), layer-2 bias gradient as a product with ones
-#pragma unroll
-        for (int f2b = 0; f2b < 2; ++f2b) {
-            const Op16 zF = tr_read(tr_a + f2b * kTrBlock, lane), zdF = tr_read(tr_a + (2 + f2b) * kTrBlock, lane);
-#pragma unroll
-            for (int f1b = 0; f1b < 2; ++f1b) {
-                outer16_f16(acc2[f1b][f2b], h1F[f1b], zF);
-                outer16_f16(acc2[f1b][f2b], hd1F[f1b], zdF);
-            }
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                accb[f2b] = HTF_MFMA_H(ones, zF.lo[s], accb[f2b]);
-                accb[f2b] = HTF_MFMA_H(ones, zF.hi[s], accb[f2b]);
-            }
-        }
-        tr_fence(); // the next tile's writes stay behind this tile's reads
+        HTF_STAMP(10); // M5
+#undef HTF_TPIPE
     }
 
+#ifdef HTF_TRAIN_STAMPS
+    if (blockIdx.x == 7 && threadIdx.x == 64) {
+        printf("stamps (cycles per live tile, wave 1 of block 7, %llu tiles):", n_live);
+        for (int i = 1; i <= 10; ++i) printf(" %d:%llu", i, stamps[i] / (n_live ? n_live : 1));
+        printf("\n");
+    }
+#endif
     // ---- block partial in LDS, waves in a fixed order (the scratch is free now)
     __syncthreads();
     float *red = reinterpret_cast<float *>(trs); // 1 + P <= 6338 floats
