@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="lj", choices=["lj", "wca", "mlp", "mlp-fp32", "mlp-split", "mlp-bf16", "mlp-train", "eds", "ref-lj256", "c1", "ex01"])
+    ap.add_argument("--workload", default="lj", choices=["lj", "wca", "mlp", "mlp-fp32", "mlp-split", "mlp-bf16", "mlp-train", "eds", "ref-lj256", "c1", "ex01", "generic-lj"])
     ap.add_argument("--train-period", type=int, default=100, help="mlp-train (C5b): force-matching step every this many MD steps")
     ap.add_argument("--cells", type=int, default=32, help="fcc cells per side (N = 4 cells^3 per rank)")
     ap.add_argument("--lattice", default="fcc", choices=["fcc", "sc"], help="fcc: N = 4 cells^3 (C3, C5); sc: N = cells^3 (C2 = sc 32^3 = 32768)")
@@ -257,6 +257,77 @@ def run_ref_lj256(args, htf, standin, dev):
         "energy_per_particle": float(f[:, 3].double().sum().item()) / sysm.N,
         "roofline": None, "cpu_baseline": None,
         "note": "overhead-bound at this size: the whole step is host enqueue (nlist check + one kernel + integrate)",
+    }
+    print(json.dumps(out))
+
+
+def run_generic_lj(args, htf, standin, dev):
+    """What leaving the zoo costs: the reference's defining capability is an ARBITRARY compute() (htf/simmodel.py:87-121) whose
+    forces come from tf.gradients (simmodel.py:526-555).  Here a model outside the lowered closed forms / MLPs runs as torch
+    eager ops on the zero-copy [N, NN, 4] tensor with torch.autograd for the forces.  The same LJModel twice, at
+    C2 (32 768) and C3 (131 072) size, through tfcompute: written with the htf.* expression layer (lowered to the one-kernel step,
+    replayed without Python) and written in plain torch ops (generic route: build kernel + ~20 eager ops + autograd every step)."""
+    NN, rcut = args.nn, args.rcut
+
+    class LJModel(htf.SimModel):
+        def compute(self, nlist, positions, box):
+            rinv = htf.nlist_rinv(nlist)
+            inv_r6 = rinv**6
+            p_energy = 4.0 / 2.0 * (inv_r6 * inv_r6 - inv_r6)
+            energy = htf.reduce_sum(p_energy, axis=1)
+            return htf.compute_nlist_forces(nlist, energy)
+
+    class TorchLJModel(htf.SimModel):
+        def compute(self, nlist, positions, box):
+            delta = 3e-6  # nlist_rinv op for op (simmodel.py:618-635)
+            r = torch.sqrt(torch.sum((nlist[:, :, :3] + delta / 3 / 10) ** 2, dim=2))
+            rinv = torch.where(r > delta, 1.0 / (r + delta), torch.zeros_like(r))
+            inv_r6 = rinv ** 6
+            p_energy = 4.0 / 2.0 * (inv_r6 * inv_r6 - inv_r6)
+            energy = torch.sum(p_energy, dim=1)
+            return htf.compute_nlist_forces(nlist, energy)
+
+    def one(lattice, cells, model_cls, steps):
+        pos, L, a = (standin.sc_positions if lattice == "sc" else standin.fcc_positions)(cells, 0.8442)
+        rng = np.random.default_rng(7)
+        pos = pos + 0.03 * a * rng.standard_normal(pos.shape)
+        pos -= np.round(pos / L) * L
+        sysm = standin.System(pos, L, dtype=torch.float32, device=dev)
+        sysm.randomize_velocities(kT=1.0, seed=7)
+        sim = standin.Simulation(sysm)
+        sim.integrate_nve(args.dt)
+        tfc = htf.tfcompute(model_cls(NN))
+        tfc.attach(sim.nlist_cell(r_buff=args.rbuff, check_period=args.check_period), r_cut=rcut)
+        sim.run(max(5, args.warmup))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sim.run(steps)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        f = tfc.force
+        assert bool(torch.isfinite(f).all())
+        return {"steps_per_s": steps / el, "ms_per_step": el / steps * 1e3, "particles": sysm.N, "steps": steps,
+                "replayed_without_python": tfc._plan is not None,
+                "energy_per_particle": float(f[:, 3].double().sum().item()) / sysm.N}
+
+    sizes = {}
+    for tag, lattice, cells in (("C2 (sc 32^3 = 32768)", "sc", 32), ("C3 (fcc 32^3 x 4 = 131072)", "fcc", 32)):
+        fast = one(lattice, cells, LJModel, args.steps)
+        gen = one(lattice, cells, TorchLJModel, max(20, args.steps // 10))
+        assert abs(fast["energy_per_particle"] - gen["energy_per_particle"]) < 0.05 * abs(fast["energy_per_particle"]) + 0.05
+        sizes[tag] = {"lowered": fast, "generic": gen, "generic_over_lowered_time": gen["ms_per_step"] / fast["ms_per_step"]}
+    c3 = sizes["C3 (fcc 32^3 x 4 = 131072)"]
+    out = {
+        "metric": "MD steps/sec, LJModel written in plain torch ops (generic autograd route) at 131072 particles NN=%d" % NN,
+        "value": c3["generic"]["steps_per_s"], "unit": "steps/s", "n_gpus": 1, "steps": c3["generic"]["steps"], "warmup": max(5, args.warmup),
+        "ms_per_step": c3["generic"]["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "LJModel through tfcompute, htf.* expression layer (lowered) vs plain torch ops + torch.autograd (generic), "
+                               "jittered lattices at rho 0.8442, r_cut %.1f, r_buff %.1f, NN %d, dt %g" % (rcut, args.rbuff, NN, args.dt)},
+        "sizes": sizes,
+        "note": "the generic route keeps the reference's arbitrary-model capability (htf/simmodel.py:87-121, 526-555); models made of "
+                "nlist_rinv polynomials, WCARepulsion, RBFExpansion + Dense stacks, EDS biases and compute_rdf are lowered to fused kernels",
+        "roofline": None, "cpu_baseline": None,
     }
     print(json.dumps(out))
 
@@ -707,6 +778,9 @@ def main():
         if world > 1:
             raise SystemExit("the C4 workload is a single-GPU configuration")
         return run_eds(args, htf, standin, dev)
+    if args.workload == "generic-lj":
+        run_generic_lj(args, htf, standin, dev)
+        return
     if args.workload == "ref-lj256":
         if world > 1:
             raise SystemExit("the reference's own benchmark is a 256-particle, single-device workload")
@@ -1051,14 +1125,18 @@ def run_md(args, E, workload, variants=True, cpu=True):
                                  "MFMA peak (157.3 TFLOP/s), which the fp32-operand evaluator is priced on, frac would be %.2f" % (ach / 157.3))
     else:
         ach = kern[dom]["GBps"]
+        # `frac` prices the contract's ALGORITHMIC bytes (the padded [N, NN, 4] tensor counts in full) over this run's
+        # launch durations.  `traffic` is null: HBM counters cannot be read from inside the process.  What the memory system
+        # itself moved is in `reference_counters` below -- counters of a SEPARATE rocprofv3 --pmc run of this command, committed
+        # under profiles/ -- and is the number to lead with: the kernel rewrites a row's zero tail only where the row shrank, so
+        # it moves fewer bytes than the contract counts.
         roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBS, "traffic": None}
-        # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
-        # (PMC cannot be read from inside the process); null when the file is absent.
+                "frac": ach / HBM_PEAK_GBS, "frac_is": "algorithmic (contract) bytes / launch duration / 8 TB/s", "traffic": None}
+        refc = None
         try:
             if args.cells != 32 or args.workload != "lj":
                 raise KeyError("PMC passes were collected for the default workload at the default size")
-            pmc_file = next(f for f in ("r03_bench_lj_pmc_hbm.json", "r02_bench_lj_pmc_hbm.json", "r01_bench_lj_pmc_hbm.json")
+            pmc_file = next(f for f in ("r04_bench_lj_pmc_hbm.json", "r03_bench_lj_pmc_hbm.json", "r02_bench_lj_pmc_hbm.json", "r01_bench_lj_pmc_hbm.json")
                             if os.path.exists(os.path.join(ROOT, "profiles", f)))
             pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
             want = {"build_pair_vectors": ("build_pair_vectors_kernel",), "eval_forces": ("eval_pair_kernel<1,",),
@@ -1072,15 +1150,15 @@ def run_md(args, E, workload, variants=True, cpu=True):
             # table and 16 B/lane streams all read known / FETCH_SIZE = 1.99-2.00; WRITE_SIZE is exact (0.993-0.998) for
             # the nontemporal 16-B stores, full rows and live-slot rows alike.
             corr = 2.0
-            roof["traffic"] = (rd * corr + wr) * 1024.0
-            roof["traffic_source"] = ("profiles/%s (FETCH_SIZE x%g + WRITE_SIZE; factor from tools/fetch_calib.hip, "
-                                      "profiles/r03_fetch_calib.json; counters of a separate run of this command, not of this run)" % (pmc_file, corr))
-            # the rate the memory system actually ran at: below `achieved` because the zero tail of a row is
-            # only rewritten where the row shrank since the last step (htf_context keeps per-row counts), so
-            # fewer bytes move than the [N, NN, 4] contract counts
-            roof["traffic_GBps"] = roof["traffic"] / (kern[dom]["avg_us"] * 1e-6) / 1e9
-            roof["traffic_frac"] = roof["traffic_GBps"] / HBM_PEAK_GBS  # what the memory system itself ran at
-            roof["traffic_frac_of_achievable"] = roof["traffic_GBps"] / 6290.0  # 6.29 TB/s: the float4 copy ceiling this part sustains (MI355X_MICROARCH.md)
+            tb = (rd * corr + wr) * 1024.0
+            tg = tb / (kern[dom]["avg_us"] * 1e-6) / 1e9
+            refc = {"what": "HBM bytes of the dominant kernel per launch, from committed counters of a separate run of this same command -- NOT measured by this run",
+                    "source": "profiles/%s (FETCH_SIZE x%g + WRITE_SIZE; factor from tools/fetch_calib.hip, profiles/r03_fetch_calib.json)" % (pmc_file, corr),
+                    "kernel": dom, "traffic_bytes_per_launch": tb,
+                    # those bytes over THIS run's launch duration: the rate the memory system ran at
+                    "traffic_GBps": tg, "traffic_frac": tg / HBM_PEAK_GBS,
+                    "traffic_frac_of_achievable": tg / 6290.0,  # 6.29 TB/s: the float4 copy ceiling this part sustains (MI355X_MICROARCH.md)
+                    "traffic_over_algorithmic_bytes": tb / kern[dom]["algorithmic_bytes"]}
         except (OSError, KeyError, ValueError, StopIteration):
             pass
 
@@ -1142,6 +1220,8 @@ def run_md(args, E, workload, variants=True, cpu=True):
         "kernels": kern,
         "roofline": roof,
     }
+    if not mfma and refc is not None:
+        out["reference_counters"] = refc
     # ---- extras, reported separately and never mixed into `roofline`: the same MD (a) with the
     # reference's two-kernel dataflow (build kernel, then evaluator kernel re-reading the tensor)
     # and (b) with the pair vectors kept in registers and NO tensor.

@@ -603,10 +603,16 @@ static int launch_fused(const void *pos, unsigned N, unsigned NN, unsigned offse
     BoxT<PT> b = make_boxt<PT>(hb);
     PT rc = (PT)rmax;
     if constexpr (!VIRIAL) {
-        static const char *rows_env = getenv("HTF_FUSED_ROWS"); // A/B runs: 1 | 2 | 4 rows per wave
+#ifdef HTF_AB_VARIANTS // A/B builds only (CXXFLAGS_EXTRA=-DHTF_AB_VARIANTS): every form stays selectable
+        static const char *rows_env = getenv("HTF_FUSED_ROWS"); // 1 | 2 | 4 rows per wave
         const int rows = rows_env ? atoi(rows_env) : 2;
-        static const char *grid_env = getenv("HTF_FUSED_GRID"); // A/B runs: workgroups per CU, 0 = one wave per group
+        static const char *grid_env = getenv("HTF_FUSED_GRID"); // workgroups per CU, 0 = one wave per group
         static const int per_cu = grid_env ? atoi(grid_env) : 0;
+        static const char *tails_env = getenv("HTF_FUSED_TAILS");
+#else
+        constexpr int rows = 2, per_cu = 0;
+        constexpr const char *tails_env = nullptr;
+#endif
         static const int n_cu = device_cu_count();
 #define HTF_ROWS_LAUNCH(ST, RR)                                                                                        \
     const unsigned full = ((batch + RR - 1) / RR + 3) / 4;                                                             \
@@ -621,7 +627,6 @@ static int launch_fused(const void *pos, unsigned N, unsigned NN, unsigned offse
         // tail: no gain; at 32 768 rows the four-row form LOSES, 24.0 against 22.8: a quarter of the waves on a grid that
         // barely fills the chip).  HTF_FUSED_TAILS=0 selects the two-row form everywhere, whose forces do not depend on
         // how a step is cut into batches / row ranges, bit for bit.
-        static const char *tails_env = getenv("HTF_FUSED_TAILS");
         // fp64 positions (HOOMD in double precision): two rows per wave with a shared tail trip -- 66.8-69.8 us at C3 against
         // 78.1-78.4 for the plain two-row form and 68.7-72.9 for four rows (82 VGPRs, 83 spilled SGPRs); same-box A/B in
         // profiles/r03_f64_kernel_ab.txt.  Every fp64 VALU instruction of the kernel issues at the fp32 rate
@@ -630,20 +635,41 @@ static int launch_fused(const void *pos, unsigned N, unsigned NN, unsigned offse
         // as many waves on a grid that fills the chip only twice is what the four-row form loses there, so it starts at 49 152.
         // fp64 positions, after the 28-byte neighbor loads (one register less per gathered position): two / three / four rows
         // 68.0-68.8 / 66.1-67.2 / 66.6-67.0 us on one box -- the four-row form for both precisions.
-        const int tails = tails_env ? atoi(tails_env) : (batch >= 16384u ? (batch >= 49152u ? 4 : 2) : 0);
+        // Shipped forms: the plain two-row form for every closed form and batch size (the generic fallback), and the merged-tail
+        // forms -- two rows from 16 384, four rows from 49 152 rows; ~100 KB of straight-line code per instantiation -- for the two
+        // potentials BASELINE's configurations time (LJModel, WCARepulsion); the polynomial, the trainable LJ, the Gaussian and
+        // SimplePotential take the two-row form at every size (~4 % slower at 131 072 rows).  Three rows per wave, four plain rows,
+        // persistent grids and the one-row kernel lost their A/Bs and are compiled in variants builds only.
+        constexpr bool kTails = KIND == HTF_POT_LJ || KIND == HTF_POT_WCA;
+        int tails = batch >= 16384u ? (batch >= 49152u ? 4 : 2) : 0;
+        if (tails_env) tails = atoi(tails_env);
+#ifndef HTF_AB_VARIANTS
+        if (!kTails) tails = 0;
+#endif
         if (tails == 2 || tails == 3 || tails == 4) {
 #define HTF_TAILS_LAUNCH(ST, RR)                                                                                       \
     HTF_LAUNCH_TIMED((fused_forces_tails_kernel<KIND, ST, RR, PT>), dim3(((batch + RR - 1) / RR + 3) / 4), dim3(256), s, \
                        (const typename Vec4<PT>::type *)pos, N, NN, offset, batch, b, n_neigh, nlist, head_list,       \
                        (PT)(rc * rc), force, out_f64, p, check_count, positions_out, dest, counts_io)
+#ifdef HTF_AB_VARIANTS
             if (dest != nullptr) {
                 if (tails == 2) HTF_TAILS_LAUNCH(true, 2); else if (tails == 3) HTF_TAILS_LAUNCH(true, 3); else HTF_TAILS_LAUNCH(true, 4);
             } else {
                 if (tails == 2) HTF_TAILS_LAUNCH(false, 2); else if (tails == 3) HTF_TAILS_LAUNCH(false, 3); else HTF_TAILS_LAUNCH(false, 4);
             }
+#else
+            if constexpr (kTails) {
+                if (dest != nullptr) {
+                    if (tails == 2) HTF_TAILS_LAUNCH(true, 2); else HTF_TAILS_LAUNCH(true, 4);
+                } else {
+                    if (tails == 2) HTF_TAILS_LAUNCH(false, 2); else HTF_TAILS_LAUNCH(false, 4);
+                }
+            }
+#endif
 #undef HTF_TAILS_LAUNCH
             return check_launch("fused_forces_tails_kernel");
         }
+#ifdef HTF_AB_VARIANTS
         if (rows == 2 || rows == 4) {
             if (rows == 2) {
                 if (dest != nullptr) { HTF_ROWS_LAUNCH(true, 2); } else { HTF_ROWS_LAUNCH(false, 2); }
@@ -652,16 +678,25 @@ static int launch_fused(const void *pos, unsigned N, unsigned NN, unsigned offse
             }
             return check_launch("fused_forces_rows2_kernel");
         }
+#else
+        if (dest != nullptr) { HTF_ROWS_LAUNCH(true, 2); } else { HTF_ROWS_LAUNCH(false, 2); }
+        return check_launch("fused_forces_rows2_kernel");
+#endif
 #undef HTF_ROWS_LAUNCH
     }
-    if (dest != nullptr)
-        HTF_LAUNCH_TIMED((fused_forces_kernel<KIND, VIRIAL, true, PT>), dim3((batch + 3) / 4), dim3(256), s,
-                           (const typename Vec4<PT>::type *)pos, N, NN, offset, batch, b, n_neigh, nlist, head_list,
-                           (PT)(rc * rc), force, virial9, out_f64, p, check_count, positions_out, dest, counts_io);
-    else
-        HTF_LAUNCH_TIMED((fused_forces_kernel<KIND, VIRIAL, false, PT>), dim3((batch + 3) / 4), dim3(256), s,
-                           (const typename Vec4<PT>::type *)pos, N, NN, offset, batch, b, n_neigh, nlist, head_list,
-                           (PT)(rc * rc), force, virial9, out_f64, p, check_count, positions_out, dest, counts_io);
+#ifndef HTF_AB_VARIANTS
+    if constexpr (VIRIAL) // (the one-row kernel: every virial request; without a virial only in variants builds, HTF_FUSED_ROWS=1)
+#endif
+    {
+        if (dest != nullptr)
+            HTF_LAUNCH_TIMED((fused_forces_kernel<KIND, VIRIAL, true, PT>), dim3((batch + 3) / 4), dim3(256), s,
+                               (const typename Vec4<PT>::type *)pos, N, NN, offset, batch, b, n_neigh, nlist, head_list,
+                               (PT)(rc * rc), force, virial9, out_f64, p, check_count, positions_out, dest, counts_io);
+        else
+            HTF_LAUNCH_TIMED((fused_forces_kernel<KIND, VIRIAL, false, PT>), dim3((batch + 3) / 4), dim3(256), s,
+                               (const typename Vec4<PT>::type *)pos, N, NN, offset, batch, b, n_neigh, nlist, head_list,
+                               (PT)(rc * rc), force, virial9, out_f64, p, check_count, positions_out, dest, counts_io);
+    }
     return check_launch("fused_forces_kernel");
 }
 
@@ -1428,8 +1463,12 @@ unsigned fused_forces2_num_partials(unsigned batch) {
     // 169 / 203 us (1792 and 2048, one more workgroup per CU than is resident: 191 / 177) -- flat around the default.
     // (Also measured and not kept, profiles/r03_c4_kernel_ab.txt: the group loop as a software pipeline -- scalars, list
     //  entries and gathers of the next one or two groups in flight; 85 / 108 VGPRs, 175 / 187 us against 167.)
+#ifdef HTF_AB_VARIANTS
     static const char *env = getenv("HTF_FUSED2_GRID");
     const unsigned cap = env ? (unsigned)atoi(env) : 4096u;
+#else
+    constexpr unsigned cap = 4096u;
+#endif
     return ngroups < cap ? ngroups : cap;
 }
 
@@ -1441,23 +1480,32 @@ static int launch_fused2(const PotParams &pa, const PotParams &pb, const void *p
     BoxT<PT> b = make_boxt<PT>(hb);
     PT rc = (PT)rmax;
     const unsigned grid = fused_forces2_num_partials(batch);
-    static const char *cenv = getenv("HTF_FUSED2_COMPACT"); // A/B runs: 0 = evaluate the candidates in place
+    // Shipped forms: two rows per wave with merged tails (fp32 positions and the base potentials that vanish far out), the
+    // compacting persistent kernel for everything else.  Variants builds: HTF_FUSED2_ROWS = 4 | 2 | 0, HTF_FUSED2_COMPACT = 0
+    // (evaluate the candidates in place).
+#ifdef HTF_AB_VARIANTS
+    static const char *cenv = getenv("HTF_FUSED2_COMPACT");
     const bool compact = NN <= 128 && (cenv ? atoi(cenv) != 0 : true);
-    // HTF_FUSED2_ROWS = 4 | 2: the rows-per-wave form with merged tails (fp32 positions and the base potentials that vanish
-    // far out); 0: the compacting persistent kernel
     static const char *renv = getenv("HTF_FUSED2_ROWS");
     const int rows = renv ? atoi(renv) : HTF_FUSED2_ROWS_DEFAULT;
+#else
+    constexpr int rows = HTF_FUSED2_ROWS_DEFAULT;
+#endif
     if constexpr (sizeof(PT) == 4 && (KA == HTF_POT_LJ || KA == HTF_POT_WCA || KA == HTF_POT_LJ_PARAM)) {
         if (rows == 2 || rows == 4) {
 #define HTF_F2T_LAUNCH(ST, RR)                                                                                         \
     hipLaunchKernelGGL((fused_forces2_tails_kernel<KA, ST, RR, PT>), dim3(grid), dim3(256), 0, s,                      \
                        (const typename Vec4<PT>::type *)pos, N, NN, offset, batch, b, n_neigh, nlist, head_list,       \
                        (PT)(rc * rc), fa, fb, out_f64, pa, pb, partials, rdf, dest, counts_io)
+#ifdef HTF_AB_VARIANTS
             if (dest != nullptr) {
                 if (rows == 2) HTF_F2T_LAUNCH(true, 2); else HTF_F2T_LAUNCH(true, 4);
             } else {
                 if (rows == 2) HTF_F2T_LAUNCH(false, 2); else HTF_F2T_LAUNCH(false, 4);
             }
+#else
+            if (dest != nullptr) HTF_F2T_LAUNCH(true, HTF_FUSED2_ROWS_DEFAULT); else HTF_F2T_LAUNCH(false, HTF_FUSED2_ROWS_DEFAULT);
+#endif
 #undef HTF_F2T_LAUNCH
             return check_launch("fused_forces2_tails_kernel");
         }
@@ -1466,11 +1514,17 @@ static int launch_fused2(const PotParams &pa, const PotParams &pb, const void *p
     hipLaunchKernelGGL((fused_forces2_kernel<KA, ST, CP, PT>), dim3(grid), dim3(256), 0, s,                            \
                        (const typename Vec4<PT>::type *)pos, N, NN, offset, batch, b, n_neigh, nlist, head_list,       \
                        (PT)(rc * rc), fa, fb, out_f64, pa, pb, partials, rdf, dest, counts_io)
+#ifdef HTF_AB_VARIANTS
     if (dest != nullptr) {
         if (compact) HTF_F2_LAUNCH(true, true); else HTF_F2_LAUNCH(true, false);
     } else {
         if (compact) HTF_F2_LAUNCH(false, true); else HTF_F2_LAUNCH(false, false);
     }
+#else
+    // (the compacting form holds rows of up to 128 slots; the in-place form for longer rows is compiled in variants builds only:
+    //  fused_forces2_impl sends NN > 128 back to the caller, who has htf_build_pair_vectors + htf_eval_forces2)
+    if (dest != nullptr) HTF_F2_LAUNCH(true, true); else HTF_F2_LAUNCH(false, true);
+#endif
 #undef HTF_F2_LAUNCH
     return check_launch("fused_forces2_kernel");
 }
@@ -1485,6 +1539,9 @@ int fused_forces2_impl(const PotParams &pa, const PotParams &pb, const void *pos
     HTF_REQUIRE(offset <= N && batch <= N - offset, "htf_build_eval_forces2: batch [%u, %u) exceeds N=%u", offset, offset + batch, N);
     HTF_REQUIRE(pos_dtype == HTF_F32 || pos_dtype == HTF_F64, "htf_build_eval_forces2: bad position dtype %d", pos_dtype);
     HTF_REQUIRE(pb.kind == HTF_POT_GAUSS, "htf_build_eval_forces2: potB must be HTF_POT_GAUSS");
+#ifndef HTF_AB_VARIANTS
+    HTF_REQUIRE(NN <= 128, "htf_build_eval_forces2: the one-kernel sweep holds rows of up to 128 slots (NN = %u); use htf_build_pair_vectors + htf_eval_forces2", NN);
+#endif
     if (rdf_hist != nullptr)
         HTF_REQUIRE(rdf_nb >= 3 && rdf_nb <= kRdfMaxBins2 && rdf_r1 > rdf_r0, "htf_build_eval_forces2: need 3 <= bins <= %u and r1 > r0", kRdfMaxBins2);
     if (batch == 0) return HTF_OK;

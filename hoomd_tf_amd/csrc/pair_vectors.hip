@@ -252,16 +252,22 @@ static int launch_build(void *dest, const void *pos, unsigned N, unsigned NN, un
     BoxT<PT> b = make_boxt<PT>(hb);
     PT rc = (PT)rmax;
     PT rmaxsq = rc * rc;
-    static const char *rows_env = getenv("HTF_BUILD_ROWS"); // A/B runs: 1 | 2 | 4 | 8 rows per wave
-    const int rows = rows_env ? atoi(rows_env) : (sizeof(PT) == 4 ? 4 : 2); // fp64 positions: 4 rows spill SGPRs
+    // rows per wave: 4 for fp32 positions, 2 for fp64 (4 rows spill SGPRs).  The other geometries lost their A/Bs (header of this
+    // file) and exist in variants builds only (make CXXFLAGS_EXTRA=-DHTF_AB_VARIANTS: HTF_BUILD_ROWS = 1 | 2 | 4 | 8).
 #define HTF_BUILD_LAUNCH(RR)                                                                                           \
     hipLaunchKernelGGL((build_pair_vectors_kernel<PT, DT, RR>), dim3((batch + 4 * RR - 1) / (4 * RR)), dim3(256), 0, stream, \
                        (typename Vec4<DT>::type *)dest, (const typename Vec4<PT>::type *)pos, N, NN, offset, batch, b, \
                        n_neigh, nlist, head_list, rmaxsq, max_count, positions_out, counts_io)
+#ifdef HTF_AB_VARIANTS
+    static const char *rows_env = getenv("HTF_BUILD_ROWS");
+    const int rows = rows_env ? atoi(rows_env) : (sizeof(PT) == 4 ? 4 : 2);
     if (rows == 1) HTF_BUILD_LAUNCH(1);
     else if (rows == 4) HTF_BUILD_LAUNCH(4);
     else if (rows == 8) HTF_BUILD_LAUNCH(8);
     else HTF_BUILD_LAUNCH(2);
+#else
+    if constexpr (sizeof(PT) == 4) HTF_BUILD_LAUNCH(4); else HTF_BUILD_LAUNCH(2);
+#endif
 #undef HTF_BUILD_LAUNCH
     return check_launch("build_pair_vectors_kernel");
 }

@@ -148,6 +148,7 @@ class SlabDomain:
         self.n_interior = 0
         self.n_from_left = self.n_from_right = 0
         self.n_migrated = 0
+        self.local_counts = None                  # [world] particles per rank as of the last rebuild
         self._works = None
 
     @property
@@ -258,6 +259,9 @@ class SlabDomain:
 
         c0, c1, c2, c3 = (int(v) for v in after(self.rank))
         assert c0 + c1 + c2 + c3 == N
+        # every rank's particle count after this migration, from the counts already on the host: what a data-parallel training
+        # step needs to size its global batch without another collective or read-back (tfcompute._train_on_batch)
+        self.local_counts = [int(after(q).sum()) for q in range(self.world)]
         self.class_counts = (c0, c1, c2, c3)
         self.n_interior = c0
         self.send_left = (c0, c0 + c1 + c2)

@@ -328,9 +328,11 @@ class tfcompute:
             # per batch (26 KB for the pair-MLP) keeps the replicas' weights identical; the
             # reference trains each MPI rank's copy independently
             import torch.distributed as dist
-            packed = torch.cat([accum, accum.new_tensor([n_total])])
-            dist.all_reduce(packed, group=domain.group)
-            accum, n_total = packed[:-1].contiguous(), float(packed[-1].item())
+            dist.all_reduce(accum, group=domain.group)
+            # the global batch: every rank's share of this batch, from the per-rank particle counts the last rebuild left on
+            # the host (no count in the message, no read-back -- the training step enqueues and returns)
+            bs = self.batch_size
+            n_total = float(sum(min(max(nq - offset, 0), bs) if bs else nq for nq in domain.local_counts))
         ops.optimizer_step(theta, accum, 1.0 / (4.0 * n_total), self._opt_state, self._opt_desc)
         if hasattr(layer, "after_update"):
             layer.after_update()  # pair-MLP: operand images <- theta, on the device
@@ -371,7 +373,7 @@ class tfcompute:
             rest = [e for e in log if "biased" not in e and not e.get("observable")]
             if (self.force_mode_code == _lib.HTF_TF2HOOMD and nbatch == 1 and len(biased) == 1 and not rest
                     and biased[0].get("is_output") and not self.save_output_period and not self.model.virial
-                    and not self.model.check_nlist and int(self.fused) == 2
+                    and not self.model.check_nlist and int(self.fused) == 2 and self.nneighbor_cutoff <= 128
                     and getattr(self._nlist, "domain", None) is None and not self.model._map_nlist):
                 self._bplan = dict(biased[0]["biased"])
                 self.model._plan = self._bplan

@@ -169,3 +169,17 @@ def build_shim(out_dir, lib_path, single=False):
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-4000:]
     return out_dir
+
+
+# ---- the A/B variants build: every kernel form that lost its A/B, and the getenv switches that select them, are compiled only with
+# -DHTF_AB_VARIANTS (tools/build_variant.sh ab -DHTF_AB_VARIANTS -> build_variants/libhtf_ab.so; __graft_entry__.build() makes it).
+# The shipped libhtf_amd.so carries the default forms and the generic fallback; forced-form tests run a child process on this one.
+VARIANTS_LIB = os.path.join(ROOT, "build_variants", "libhtf_ab.so")
+
+
+def variants_env(**switches):
+    """Environment of a child process that loads the variants build with the given form switches set."""
+    import pytest
+    if not os.path.exists(VARIANTS_LIB):
+        pytest.skip("no variants build (tools/build_variant.sh ab -DHTF_AB_VARIANTS)")
+    return dict(os.environ, HTF_AMD_LIB=VARIANTS_LIB, **switches)

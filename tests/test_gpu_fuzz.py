@@ -166,8 +166,9 @@ def test_crafted_row_lengths_every_form(htf, cuda, form):
     form forced at this (small) size -- the merged-tail kernels the headline configurations run included."""
     import subprocess
     import sys
+    from helpers import variants_env
     k, v = form.split("=")
-    env = dict(os.environ, **{k: v})
+    env = variants_env(**{k: v})   # (the switches exist in the variants build only)
     if k == "HTF_FUSED_ROWS":
         env["HTF_FUSED_TAILS"] = "0"
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
@@ -227,8 +228,9 @@ def test_crafted_row_lengths_c4_every_form(htf, cuda, form):
     compaction), each forced in a child process."""
     import subprocess
     import sys
+    from helpers import variants_env
     k, v = form.split("=")
-    env = dict(os.environ, **{k: v})
+    env = variants_env(**{k: v})
     if k == "HTF_FUSED2_COMPACT":
         env["HTF_FUSED2_ROWS"] = "0"
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",

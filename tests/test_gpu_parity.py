@@ -173,7 +173,8 @@ def test_rows_per_wave_variants_are_bit_identical(htf, cuda, rows):
     fused-vs-two-kernel test are re-run in a child process under each setting."""
     import subprocess
     import sys
-    env = dict(os.environ, HTF_BUILD_ROWS=rows, HTF_FUSED_ROWS=rows if rows != "8" else "4")
+    from helpers import variants_env
+    env = variants_env(HTF_BUILD_ROWS=rows, HTF_FUSED_ROWS=rows if rows != "8" else "4")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
                         "-k", "pair_vectors_bit_exact or ragged_row_lengths or fused_matches_two_kernel"],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)

@@ -274,14 +274,19 @@ def test_pair_mlp_gradient_over_the_residual_range(htf, cuda, regime, precision)
         o += n
 
 
-@pytest.mark.parametrize("route", ["valu", "nofuse", "bf16-images", "split-images", "split16-f16-sweep", "split16-fp32-sweep",
-                                   "split16-nofuse"])
+VARIANT_ROUTES = ("valu", "nofuse", "split16-fp32-sweep")
+
+
+@pytest.mark.parametrize("route", ["valu", "nofuse", "bf16-images", "split-images", "split16-sweep", "split16-fp32-sweep"])
 def test_pair_mlp_gradient_alternate_routes(htf, cuda, route, monkeypatch):
-    """The first-generation VALU kernel (HTF_MLP_TRAIN_VALU), the two-pass matrix-core route
-    (HTF_MLP_TRAIN_NOFUSE), bf16- / split-image potentials (which train on their own fp32 image
-    set) and the split16 potential -- fp16-pipeline sweep from the evaluator's images, fused and two-pass, or
-    (HTF_MLP_TRAIN_FP32) the fp32 sweep -- all give the default route's loss gradient."""
+    """bf16- / split-image potentials (which train on their own fp32 image set with the fp32-MFMA sweep) and the split16
+    potential (the fp16-pipeline sweep, every wave on its own, from the evaluator's images) give the fp32 potential's loss
+    gradient.  In a variants build (-DHTF_AB_VARIANTS; test_alternate_routes_against_the_variants_build runs this test on
+    one) also: the first-generation VALU kernel (HTF_MLP_TRAIN_VALU), the two-pass matrix-core route
+    (HTF_MLP_TRAIN_NOFUSE) and the fp32 sweep for a split16 potential (HTF_MLP_TRAIN_FP32)."""
     from hoomd_tf_amd import initializers
+    if route in VARIANT_ROUTES and "libhtf_ab" not in htf._lib.LIB_PATH:
+        pytest.skip("a switch of the variants build")
     nl = _case(8, N=33, NN=40)
     params = initializers.mlp_params(seed=12)
     theta = _flat_params(params)
@@ -302,19 +307,28 @@ def test_pair_mlp_gradient_alternate_routes(htf, cuda, route, monkeypatch):
         got = grad()
     elif route == "split-images":
         got = grad("split")
-    elif route == "split16-f16-sweep":
+    elif route == "split16-sweep":
         got = grad("split16")
     elif route == "split16-fp32-sweep":
         monkeypatch.setenv("HTF_MLP_TRAIN_FP32", "1")
-        got = grad("split16")
-    elif route == "split16-nofuse":
-        monkeypatch.setenv("HTF_MLP_TRAIN_NOFUSE", "1")
         got = grad("split16")
     else:
         got = grad("bf16")
     scale = np.abs(base[1:]).max()
     assert np.abs(got[1:] - base[1:]).max() < 5e-5 * scale, np.abs(got[1:] - base[1:]).max() / scale
     np.testing.assert_allclose(got[0], base[0], rtol=1e-5)
+
+
+def test_alternate_routes_against_the_variants_build(htf, cuda):
+    """The kernels that lost their A/B (first-generation VALU sweep, two-pass fp32 route, fp32 sweep for split16 potentials) live
+    in the variants build only; the alternate-routes test, all of it, in a child process on that library."""
+    import os
+    import subprocess
+    import sys
+    from helpers import ROOT, variants_env
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        "-k", "gradient_alternate_routes"], cwd=ROOT, env=variants_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and " passed" in r.stdout and "skipped" not in r.stdout.split("\n")[-2], r.stdout[-3000:] + r.stderr[-2000:]
 
 
 def test_pair_mlp_refresh_tracks_device_weights(htf, cuda):

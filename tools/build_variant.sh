@@ -6,6 +6,6 @@ cd "$(dirname "$0")/.."
 NAME=$1; EXTRA=$2
 OUT=build_variants/$NAME
 mkdir -p $OUT
-cp hoomd_tf_amd/csrc/*.hip hoomd_tf_amd/csrc/*.h hoomd_tf_amd/csrc/Makefile $OUT/
+cp -p -u hoomd_tf_amd/csrc/*.hip hoomd_tf_amd/csrc/*.h hoomd_tf_amd/csrc/Makefile $OUT/   # (-p -u: an unchanged source keeps its mtime, make rebuilds only what changed)
 make -s -j8 -C $OUT ROOT=$(pwd) CXXFLAGS_EXTRA="$EXTRA" LIB=../libhtf_$NAME.so
 echo built build_variants/libhtf_$NAME.so
