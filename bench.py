@@ -488,13 +488,16 @@ def run_eds(args, htf, standin, dev):
     rng = np.random.default_rng(4)
     pos = pos + 0.05 * a * rng.standard_normal(pos.shape)
     pos -= np.round(pos / L) * L
-    sysm = standin.System(pos, L, dtype=torch.float32, device=dev)
+    # --f64: HOOMD built in double precision (TensorflowCompute.h:117-124): fp64 positions in, fp64 forces out, the fp32 tensor
+    # of simmodel.py:226-227's cast in between
+    sdt = torch.float64 if args.f64 else torch.float32
+    sysm = standin.System(pos, L, dtype=sdt, device=dev)
     sysm.randomize_velocities(kT=1.0, seed=4)
     nl = standin.CellNlist(sysm, r_cut=args.rcut, r_buff=args.rbuff, check_period=args.check_period)
     nl.build()
     N, NN = sysm.N, args.nn
     pv = torch.zeros((N, NN, 4), dtype=torch.float32, device=dev)
-    bias = torch.empty((N, 4), dtype=torch.float32, device=dev)
+    bias = torch.empty((N, 4), dtype=sdt, device=dev)
     npart = htf.ops.num_partials(N, NN)
     partials = torch.empty(npart, dtype=torch.float32, device=dev)
     cv = torch.zeros(1, dtype=torch.float32, device=dev)
@@ -518,6 +521,7 @@ def run_eds(args, htf, standin, dev):
     rs_out = torch.empty(100, dtype=torch.float32, device=dev)
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     F32 = 0
+    SD = 1 if args.f64 else 0  # htf_dtype of HOOMD's Scalar
     ptr = {"nl": None}
 
     def refresh_ptrs():
@@ -539,20 +543,20 @@ def run_eds(args, htf, standin, dev):
         hist.zero_()
         t0 = mark() if timed else None
         if not args.two_kernel:
-            check(lib.htf_build_eval_forces2(lj.handle, gauss.handle, pv.data_ptr(), sysm.pos.data_ptr(), F32, N, NN, 0, N,
+            check(lib.htf_build_eval_forces2(lj.handle, gauss.handle, pv.data_ptr(), sysm.pos.data_ptr(), SD, N, NN, 0, N,
                                              C.byref(sysm.box), ptr["nl"][0], ptr["nl"][1], ptr["nl"][2], args.rcut,
-                                             sysm.force.data_ptr(), bias.data_ptr(), F32, partials_f.data_ptr(),
+                                             sysm.force.data_ptr(), bias.data_ptr(), SD, partials_f.data_ptr(),
                                              0.0, 3.5, 102, hist.data_ptr(), stream))
             t2 = mark() if timed else None
             if timed:
                 ev["fused2"].append((t0, t2))
             check(lib.htf_reduce_partials(partials_f.data_ptr(), npart_f, 1.0 / N, cv.data_ptr(), stream))
         else:
-            check(lib.htf_build_pair_vectors(pv.data_ptr(), F32, sysm.pos.data_ptr(), F32, N, NN, 0, N, 0, C.byref(sysm.box),
+            check(lib.htf_build_pair_vectors(pv.data_ptr(), F32, sysm.pos.data_ptr(), SD, N, NN, 0, N, 0, C.byref(sysm.box),
                                              ptr["nl"][0], ptr["nl"][1], ptr["nl"][2], args.rcut, None, stream))
             t1 = mark() if timed else None
             check(lib.htf_eval_forces2(lj.handle, gauss.handle, pv.data_ptr(), F32, N, NN, sysm.force.data_ptr(),
-                                       bias.data_ptr(), F32, partials.data_ptr(), 0.0, 3.5, 102, hist.data_ptr(), stream))
+                                       bias.data_ptr(), SD, partials.data_ptr(), 0.0, 3.5, 102, hist.data_ptr(), stream))
             t2 = mark() if timed else None
             if timed:
                 ev["build"].append((t0, t1))
@@ -562,7 +566,7 @@ def run_eds(args, htf, standin, dev):
             check(lib.htf_eds_update(eds.state.data_ptr(), cv.data_ptr(), eds.set_point, eds.period,
                                      eds.learning_rate, eds.cv_scale, stream))
             check(lib.htf_bias_combine(sysm.force.data_ptr(), bias.data_ptr(), eds.state.data_ptr() + 8,
-                                       cv.data_ptr(), F32, N, stream))
+                                       cv.data_ptr(), SD, N, stream))
         # compute_rdf(nlist, [0, 3.5]) every step: histogram fused above, tail here
         check(lib.htf_rdf_finalize(hist.data_ptr(), 100, 0.0, 3.5, rdf_out.data_ptr(), rs_out.data_ptr(), stream))
 
@@ -606,11 +610,12 @@ def run_eds(args, htf, standin, dev):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     assert bool(torch.isfinite(sysm.force).all())
-    eval_b = N * NN * 16 + 2 * N * 16
-    build_b = N * 8 + int(nl.n_neigh.long().sum().item()) * 4 + N * 16 + N * NN * 16
+    s4 = 32 if args.f64 else 16  # bytes of a HOOMD Scalar4
+    eval_b = N * NN * 16 + 2 * N * s4
+    build_b = N * 8 + int(nl.n_neigh.long().sum().item()) * 4 + N * s4 + N * NN * 16
     dom = max(us, key=us.get)
     # the one-kernel sweep is priced against its own compulsory bytes: the build's + the two force writes
-    fused_b = build_b + 2 * N * 16
+    fused_b = build_b + 2 * N * s4
     dom_b = {"build": build_b, "eval2": eval_b, "fused2": fused_b}[dom]
     ach = dom_b / (us[dom] * 1e-6) / 1e9
     names = {"build": ("build_pair_vectors", build_b), "eval2": ("eval_forces2(lj+gauss+rdf)", eval_b),
@@ -622,7 +627,8 @@ def run_eds(args, htf, standin, dev):
         "metric": "MD steps/sec (262144-particle EDS-on-RDF-CV domain steps, NN=128) + achieved HBM GB/s",
         "value": args.steps / elapsed, "unit": "steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32" if not args.f64 else "f32 arithmetic on an f64 wire (HOOMD in double precision: fp64 positions in, fp64 forces out)",
+        "data": "synthetic",
         "config": {"workload": "C4-EDS: sc %d^3 = %d particles, rho 0.8442, r_cut %.1f, r_buff %.1f, NN %d, LJModel + "
                                "EDSLayer(1.02 x natural CV = %.3f, period 25, lr 0.05) on soft RDF bin r0 1.1 gap 0.05, "
                                "compute_rdf [0,3.5] fused into the sweep every step"
@@ -640,7 +646,7 @@ def run_eds(args, htf, standin, dev):
         # histogram) over the same 262 144 x 128 workload, a bounded number of passes
         from oracle import c_oracle
         clib = c_oracle.load()
-        pos4 = sysm.pos.cpu().numpy().astype(np.float32)
+        pos4 = sysm.pos.cpu().numpy().astype(np.float32)  # (the CPU port runs the fp32 wire either way)
         nn_h = nl.n_neigh.cpu().numpy().view(np.uint32)
         head_h = nl.head_list.cpu().numpy().view(np.uint32)
         nl_h = nl.nlist.cpu().numpy().view(np.uint32)

@@ -289,15 +289,26 @@ template <int KA, typename IT>
 static int launch_eval2_k(const void *nlist, unsigned B, unsigned NN, void *fa, void *fb, int out_f64,
                           const PotParams &pa, const PotParams &pb, float *partials, const RdfArgs &rdf,
                           hipStream_t stream) {
+    // 16 lanes per row at every NN: this two-kernel form is the fallback of the one-kernel sweep (fused_eval.hip), which is what
+    // config C4 runs; the 8- and 4-lane groups for short rows exist in variants builds only
+#ifdef HTF_AB_VARIANTS
     switch (pick_group(NN)) {
     case 16: return launch_eval2_g<KA, 16, IT>(nlist, B, NN, fa, fb, out_f64, pa, pb, partials, rdf, stream);
     case 8: return launch_eval2_g<KA, 8, IT>(nlist, B, NN, fa, fb, out_f64, pa, pb, partials, rdf, stream);
     default: return launch_eval2_g<KA, 4, IT>(nlist, B, NN, fa, fb, out_f64, pa, pb, partials, rdf, stream);
     }
+#else
+    return launch_eval2_g<KA, 16, IT>(nlist, B, NN, fa, fb, out_f64, pa, pb, partials, rdf, stream);
+#endif
 }
 
 unsigned eval_pair2_num_partials(unsigned B, unsigned NN) {
+#ifdef HTF_AB_VARIANTS
     const unsigned rows_per_block = 4 * (64 / pick_group(NN));
+#else
+    (void)NN;
+    const unsigned rows_per_block = 4 * (64 / 16);
+#endif
     return (B + rows_per_block - 1) / rows_per_block;
 }
 

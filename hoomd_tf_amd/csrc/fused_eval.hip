@@ -1122,6 +1122,9 @@ __device__ __forceinline__ void sweep2_bin(const Sweep2 &st, float x, float y, f
     const unsigned off = (unsigned)idx << 2;
     const float e0 = *(const float *)((const char *)st.edge + off), e1 = *(const float *)((const char *)st.edge + off + 4);
     const unsigned off2 = off + (sq >= e1 ? 4u : 0u) + (sq < e0 ? (unsigned)-4 : 0u);
+    // One LDS add per live slot into ONE 102-bin table.  Round 4, measured and not kept (profiles/r04_c4_kernel_ab.txt): eight
+    // lane-striped replicas per bin, summed at the workgroup's flush -- 169.2 / 166.9 us against 167.9 / 171.0 on the same box:
+    // the collisions of a wave's 64 adds on ~60 addresses are not what this sweep waits for.
     atomicAdd((unsigned *)((char *)st.hist + off2), delta);
 }
 
@@ -1521,9 +1524,12 @@ static int launch_fused2(const PotParams &pa, const PotParams &pb, const void *p
         if (compact) HTF_F2_LAUNCH(false, true); else HTF_F2_LAUNCH(false, false);
     }
 #else
-    // (the compacting form holds rows of up to 128 slots; the in-place form for longer rows is compiled in variants builds only:
-    //  fused_forces2_impl sends NN > 128 back to the caller, who has htf_build_pair_vectors + htf_eval_forces2)
-    if (dest != nullptr) HTF_F2_LAUNCH(true, true); else HTF_F2_LAUNCH(false, true);
+    // (rows longer than the compaction buffer: NN <= 128 is what the compacting form holds; beyond it the in-place form)
+    if (NN <= 128) {
+        if (dest != nullptr) HTF_F2_LAUNCH(true, true); else HTF_F2_LAUNCH(false, true);
+    } else {
+        if (dest != nullptr) HTF_F2_LAUNCH(true, false); else HTF_F2_LAUNCH(false, false);
+    }
 #endif
 #undef HTF_F2_LAUNCH
     return check_launch("fused_forces2_kernel");
@@ -1539,9 +1545,6 @@ int fused_forces2_impl(const PotParams &pa, const PotParams &pb, const void *pos
     HTF_REQUIRE(offset <= N && batch <= N - offset, "htf_build_eval_forces2: batch [%u, %u) exceeds N=%u", offset, offset + batch, N);
     HTF_REQUIRE(pos_dtype == HTF_F32 || pos_dtype == HTF_F64, "htf_build_eval_forces2: bad position dtype %d", pos_dtype);
     HTF_REQUIRE(pb.kind == HTF_POT_GAUSS, "htf_build_eval_forces2: potB must be HTF_POT_GAUSS");
-#ifndef HTF_AB_VARIANTS
-    HTF_REQUIRE(NN <= 128, "htf_build_eval_forces2: the one-kernel sweep holds rows of up to 128 slots (NN = %u); use htf_build_pair_vectors + htf_eval_forces2", NN);
-#endif
     if (rdf_hist != nullptr)
         HTF_REQUIRE(rdf_nb >= 3 && rdf_nb <= kRdfMaxBins2 && rdf_r1 > rdf_r0, "htf_build_eval_forces2: need 3 <= bins <= %u and r1 > r0", kRdfMaxBins2);
     if (batch == 0) return HTF_OK;

@@ -373,7 +373,7 @@ class tfcompute:
             rest = [e for e in log if "biased" not in e and not e.get("observable")]
             if (self.force_mode_code == _lib.HTF_TF2HOOMD and nbatch == 1 and len(biased) == 1 and not rest
                     and biased[0].get("is_output") and not self.save_output_period and not self.model.virial
-                    and not self.model.check_nlist and int(self.fused) == 2 and self.nneighbor_cutoff <= 128
+                    and not self.model.check_nlist and int(self.fused) == 2
                     and getattr(self._nlist, "domain", None) is None and not self.model._map_nlist):
                 self._bplan = dict(biased[0]["biased"])
                 self.model._plan = self._bplan

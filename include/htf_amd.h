@@ -203,8 +203,7 @@ HTF_API unsigned htf_eval2_num_partials(unsigned B, unsigned NN);
  * vectors are evaluated for both potentials, summed into the CV partials and binned into the
  * compute_rdf histogram while they are in registers; d_dest (nullable, fp32 [batch, NN, 4]) also
  * receives the tensor, bit-identical to htf_build_pair_vectors'.  d_partials: at least
- * htf_build_eval2_num_partials(batch_size) floats (one per persistent block).  NN <= 128 (HTF_ERR_INVALID beyond:
- * the two calls it fuses remain). */
+ * htf_build_eval2_num_partials(batch_size) floats (one per persistent block). */
 HTF_API int htf_build_eval_forces2(const htf_potential *potA, const htf_potential *potB, void *d_dest,
                            const void *d_pos, int pos_dtype, unsigned N, unsigned NN, unsigned offset,
                            unsigned batch_size, const htf_box *box, const unsigned *d_n_neigh,
