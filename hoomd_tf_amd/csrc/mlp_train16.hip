@@ -206,7 +206,6 @@ __global__ __launch_bounds__(256, 1) void mlp_grad_tr16_kernel(const typename Ve
     const unsigned p = lane & 31u, h = lane >> 5;
     const unsigned w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned gw = blockIdx.x * 4u + w, nw = gridDim.x * 4u;
-    const unsigned ntiles = (NN + 31) / 32;
     const float ginv = 1.0f / gap;
     const float S = seed_scale(*resid_max);
     unsigned char *tr_phi = trs + w * (kTrBlocks * kTrBlock); // phi | phid
@@ -224,45 +223,81 @@ __global__ __launch_bounds__(256, 1) void mlp_grad_tr16_kernel(const typename Ve
     unsigned long long stamps[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0, n_live = 0;
 #endif
 
-    // One wave per SIMD: nothing hides a global load but the wave's own work, so a tile's slot (and a row's residual) is read
-    // one tile ahead.
-    auto read_slot = [&](unsigned row, unsigned tile, float &ox, float &oy, float &oz) {
+    // Live pairs are COMPACTED across rows before they become tiles: a pair's share of the gradient depends on its row only
+    // through the row's residual, which is folded into the pair's two reverse seeds when the pair is staged -- so a tile is any
+    // 32 live pairs.  The wave stages its rows chunk by chunk (64 slots: pair distance r and the seeds a, b into a wave-private
+    // LDS ring, live slots only, ballot + mbcnt ranks) and pops 32 at a time: 389 k full tiles at C3 instead of the 424 k
+    // partly filled 32-slot tiles of the rows (a row's ~95 live slots end in a tile with 31, a quarter of the rows add one with
+    // 1-6).  The order of a wave's pairs is fixed, so the sum is deterministic.
+    constexpr unsigned kRing = 128; // >= 31 left over + one chunk of 64
+    __shared__ float ring_all[4][3][kRing];
+    float(&ring)[3][kRing] = ring_all[w];
+    unsigned head = 0, tail = 0; // monotonic, wave-uniform
+    const unsigned nchunks = (NN + 63) / 64;
+    // One wave per SIMD: nothing hides a global load but the wave's own work, so a chunk's slots (and a row's residual) are read
+    // one chunk -- up to two tiles -- ahead.
+    auto read_chunk = [&](unsigned row, unsigned chunk, float &ox, float &oy, float &oz) {
         ox = oy = oz = 0.f;
-        const unsigned sl = tile * 32 + p;
+        const unsigned sl = chunk * 64 + lane;
         if (row < B && sl < NN) {
             const auto v = nlist[(size_t)row * NN + sl];
             ox = (float)v.x; oy = (float)v.y; oz = (float)v.z;
         }
     };
-    unsigned row = gw, tile = 0;
+    unsigned row = gw, chunk = 0;
     float nx, ny, nz;
-    read_slot(row, 0, nx, ny, nz);
+    read_chunk(row, 0, nx, ny, nz);
     float4 rs = make_float4(0.f, 0.f, 0.f, 0.f), nrs = rs;
     if (row < B) nrs = residual(pred, labels, lab_f64, row);
-    while (row < B) {
-        const float x = nx, y = ny, z = nz;
-        const unsigned slot = tile * 32 + p;
-        if (tile == 0) {
-            rs = nrs;
-            if (lane == 0) loss += rs.x * rs.x + rs.y * rs.y + rs.z * rs.z + rs.w * rs.w;
+    while (true) {
+        if (tail - head < 32u && row < B) {
+            // ---- stage one chunk of the current row
+            const float x = nx, y = ny, z = nz;
+            const unsigned slot = chunk * 64 + lane;
+            if (chunk == 0) {
+                rs = nrs;
+                if (lane == 0) loss += rs.x * rs.x + rs.y * rs.y + rs.z * rs.z + rs.w * rs.w;
+            }
+            unsigned nrow = row, nchunk = chunk + 1;
+            if (nchunk == nchunks) {
+                nchunk = 0;
+                nrow = row + nw;
+                if (nrow < B) nrs = residual(pred, labels, lab_f64, nrow);
+            }
+            read_chunk(nrow, nchunk, nx, ny, nz);
+            row = nrow;
+            chunk = nchunk;
+            const float tx = x + kNormDelta, ty = y + kNormDelta, tz = z + kNormDelta;
+            const float rr = sqrtf(tx * tx + ty * ty + tz * tz);
+            const bool live = slot < NN && rr > kRinvDelta;
+            const unsigned long long mask = __ballot(live);
+            if (mask != 0ull) {
+                const float sa = S * (2.0f * (rs.x * tx + rs.y * ty + rs.z * tz) / rr); // reverse seeds: S = a u' + b u
+                const float sb = S * rs.w;
+                const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                if (live) {
+                    const unsigned at = (tail + rank) & (kRing - 1u);
+                    ring[0][at] = rr;
+                    ring[1][at] = sa;
+                    ring[2][at] = sb;
+                    gb3 += sb;
+                }
+                tail += (unsigned)__builtin_popcountll(mask);
+            }
+            tr_fence();
+            continue;
         }
-        // the next unit of this wave
-        unsigned nrow = row, ntile = tile + 1;
-        if (ntile == ntiles) {
-            ntile = 0;
-            nrow = row + nw;
-            if (nrow < B) nrs = residual(pred, labels, lab_f64, nrow);
-        }
-        read_slot(nrow, ntile, nx, ny, nz);
-        row = nrow;
-        const unsigned this_tile = tile;
-        tile = ntile;
-        (void)this_tile;
-
-        const float tx = x + kNormDelta, ty = y + kNormDelta, tz = z + kNormDelta;
-        const float r = sqrtf(tx * tx + ty * ty + tz * tz);
-        const bool m = slot < NN && r > kRinvDelta;
-        if (__ballot(m) == 0ull) continue; // every slot of this tile is padding
+        const unsigned avail = tail - head;
+        if (avail == 0u) break;
+        // ---- pop a tile: 32 pairs (the last one of the wave may be partial: its empty lanes carry zero seeds)
+        const bool m = p < avail;
+        const unsigned at = (head + p) & (kRing - 1u);
+        const float r = m ? ring[0][at] : 1.0f;
+        const float aq = m ? ring[1][at] : 0.f;
+        const float bq = m ? ring[2][at] : 0.f;
+        const float aq2 = -2.0f * aq;
+        head += avail < 32u ? avail : 32u;
+        tr_fence();
 #ifdef HTF_TRAIN_STAMPS
         ++n_live;
         __builtin_amdgcn_sched_barrier(0);
@@ -324,10 +359,6 @@ __global__ __launch_bounds__(256, 1) void mlp_grad_tr16_kernel(const typename Ve
             tr_write(tr_phi, p, h, phi_o);
             tr_write(tr_phi + kTrBlock, p, h, phid_o);
         }
-        const float aq = m ? S * (2.0f * (rs.x * tx + rs.y * ty + rs.z * tz) / r) : 0.f; // reverse seeds: S = a u' + b u
-        const float bq = m ? S * rs.w : 0.f;
-        const float aq2 = -2.0f * aq;
-        if (h == 0) gb3 += bq;
         __builtin_amdgcn_sched_barrier(0);
         HTF_STAMP(1); // V0
         // ---- M1a: layer 1, block 0 (value + r-tangent)
