@@ -451,37 +451,33 @@ __global__ __launch_bounds__(256, 1) void mlp_grad_tr16_kernel(const typename Ve
             q[fb] = split16(hb[fb]);
             qd[fb] = split16(hdb[fb]);
         };
-        // ---- M4: dW2 += h1 (x) zb2 + hd1 (x) zdb2 (k = the tile's pairs), layer-2 bias gradient as a product with ones  ||  V3
-        {
-            const Op16 zF[2] = {tr_read(tr_a, lane), tr_read(tr_a + kTrBlock, lane)};
-            const Op16 zdF[2] = {tr_read(tr_a + 2 * kTrBlock, lane), tr_read(tr_a + 3 * kTrBlock, lane)};
+        // ---- M4 / M5: dW2 += h1 (x) zb2 + hd1 (x) zdb2 (k = the tile's pairs), layer-2 bias gradient as a product with ones,
+        //      dW1 += phi (x) zb1 + phid (x) zdb1  ||  V3: zb1, zdb1 of one block at a time
+        auto dw2 = [&](int f2b) {
+            const Op16 zF = tr_read(tr_a + f2b * kTrBlock, lane), zdF = tr_read(tr_a + (2 + f2b) * kTrBlock, lane);
 #pragma unroll
-            for (int f2b = 0; f2b < 2; ++f2b) {
-#pragma unroll
-                for (int f1b = 0; f1b < 2; ++f1b) {
-                    outer16_f16(acc2[f1b][f2b], h1F[f1b], zF[f2b]);
-                    outer16_f16(acc2[f1b][f2b], hd1F[f1b], zdF[f2b]);
-                }
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    accb[f2b] = HTF_MFMA_H(ones, zF[f2b].lo[s], accb[f2b]);
-                    accb[f2b] = HTF_MFMA_H(ones, zF[f2b].hi[s], accb[f2b]);
-                }
+            for (int f1b = 0; f1b < 2; ++f1b) {
+                outer16_f16(acc2[f1b][f2b], h1F[f1b], zF);
+                outer16_f16(acc2[f1b][f2b], hd1F[f1b], zdF);
             }
-            rev1(0);
-            rev1(1);
-            HTF_TPIPE(56, 8, 0);
-            HTF_STAMP(9); // M4 | V3
-        }
-        // ---- M5: dW1 += phi (x) zb1 + phid (x) zdb1
-        {
-            const Op16 phiF = tr_read(tr_phi, lane), phidF = tr_read(tr_phi + kTrBlock, lane);
 #pragma unroll
-            for (int fb = 0; fb < 2; ++fb) {
-                outer16_f16(acc1[fb], phiF, q[fb]);
-                outer16_f16(acc1[fb], phidF, qd[fb]);
+            for (int s = 0; s < 2; ++s) {
+                accb[f2b] = HTF_MFMA_H(ones, zF.lo[s], accb[f2b]);
+                accb[f2b] = HTF_MFMA_H(ones, zF.hi[s], accb[f2b]);
             }
-        }
+        };
+        dw2(0);
+        rev1(0);
+        HTF_TPIPE(28, 8, 0);
+        HTF_STAMP(9); // M4a | V3a
+        const Op16 phiF = tr_read(tr_phi, lane), phidF = tr_read(tr_phi + kTrBlock, lane);
+        dw2(1);
+        outer16_f16(acc1[0], phiF, q[0]);
+        outer16_f16(acc1[0], phidF, qd[0]);
+        rev1(1);
+        HTF_TPIPE(40, 6, 0);
+        outer16_f16(acc1[1], phiF, q[1]);
+        outer16_f16(acc1[1], phidF, qd[1]);
         HTF_STAMP(10); // M5
 #undef HTF_TPIPE
     }
