@@ -44,6 +44,7 @@ struct MlpDevice {
     int *train_map = nullptr;
     const float *theta = nullptr; // device parameter vector the images are built from
     float *own_theta = nullptr;   // ... owned copy unless the caller supplied d_theta
+    int *range_flag = nullptr;    // split16: host-mapped word the image build sets when a weight left fp16's range (sticky)
     float centers[kK];            // float32 linspace(low, high, K), 0 beyond K
     float gap = 1.f;
     int K = 0, H1 = 0, H2 = 0;
@@ -129,6 +130,7 @@ __device__ __forceinline__ float seed_scale(float m) {
 int mlp_train_grad16(const MlpDevice *m, const void *nlist, int in_dtype, unsigned B, unsigned NN, const void *labels, int lab_f64,
                      float4 *predbuf, float *partial, unsigned stride, float *resid_max, unsigned *nblk_out, hipStream_t stream);
 int mlp_refresh(const MlpDevice *m, hipStream_t stream);
+bool mlp_out_of_range(const MlpDevice *m);
 int mlp_train_grad(const MlpDevice *m, const void *nlist, int in_dtype, unsigned B, unsigned NN, const void *labels,
                    int lab_f64, void *pred, float *accum, float *scratch, hipStream_t stream);
 size_t mlp_train_scratch_floats(const MlpDevice *m, unsigned B);

@@ -547,7 +547,7 @@ static void build_map(const MlpDevice *m, std::vector<int> &map) {
 // backward blocks (B2, B1), w3 and b3 are never scaled.
 template <int P>
 __global__ void mlp_refresh_kernel(float *__restrict__ images, const int *__restrict__ map,
-                                   const float *__restrict__ theta, float fwd_scale) {
+                                   const float *__restrict__ theta, float fwd_scale, int *__restrict__ range_flag) {
     using I = Img<P>;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= kMapN) return;
@@ -559,6 +559,9 @@ __global__ void mlp_refresh_kernel(float *__restrict__ images, const int *__rest
             const unsigned u = __float_as_uint(v);
             reinterpret_cast<unsigned short *>(images)[e] = (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
         } else if constexpr (P == HTF_MLP_SPLIT16) { // hi = fp16(v), lo = fp16(v - hi), round to nearest: see prep<>
+            // a TRAINED weight (device parameter vector: mlp_create cannot see it) that left fp16's range, or is not a number:
+            // sticky, read by the host at the next evaluation / training call
+            if (range_flag != nullptr && !(fabsf(v) < 6.0e4f)) *range_flag = 1;
             const _Float16 hh = (_Float16)v;
             const _Float16 ll = (_Float16)(v - (float)hh);
             unsigned short *blk = reinterpret_cast<unsigned short *>(images) + (size_t)(e >> 10) * 2048 + (e & 1023);
@@ -583,20 +586,23 @@ __global__ void mlp_refresh_kernel(float *__restrict__ images, const int *__rest
     }
 }
 
+// (read without a synchronisation: a violation written by an image build that has not run yet is seen by the call after)
+bool mlp_out_of_range(const MlpDevice *m) { return m->range_flag != nullptr && *(volatile int *)m->range_flag != 0; }
+
 int mlp_refresh(const MlpDevice *m, hipStream_t stream) {
     HTF_REQUIRE(m, "pair-MLP: null potential");
     const unsigned grid = (kMapN + 255) / 256;
     const float fwd_scale = m->act == HTF_ACT_TANH ? 2.8853900817779268f : 1.0f; // bf16-typed images only
     if (m->precision == HTF_MLP_BF16)
-        hipLaunchKernelGGL(mlp_refresh_kernel<HTF_MLP_BF16>, dim3(grid), dim3(256), 0, stream, m->images, m->map, m->theta, fwd_scale);
+        hipLaunchKernelGGL(mlp_refresh_kernel<HTF_MLP_BF16>, dim3(grid), dim3(256), 0, stream, m->images, m->map, m->theta, fwd_scale, (int *)nullptr);
     else if (m->precision == HTF_MLP_SPLIT)
-        hipLaunchKernelGGL(mlp_refresh_kernel<HTF_MLP_SPLIT>, dim3(grid), dim3(256), 0, stream, m->images, m->map, m->theta, fwd_scale);
+        hipLaunchKernelGGL(mlp_refresh_kernel<HTF_MLP_SPLIT>, dim3(grid), dim3(256), 0, stream, m->images, m->map, m->theta, fwd_scale, (int *)nullptr);
     else if (m->precision == HTF_MLP_SPLIT16)
-        hipLaunchKernelGGL(mlp_refresh_kernel<HTF_MLP_SPLIT16>, dim3(grid), dim3(256), 0, stream, m->images, m->map, m->theta, fwd_scale);
+        hipLaunchKernelGGL(mlp_refresh_kernel<HTF_MLP_SPLIT16>, dim3(grid), dim3(256), 0, stream, m->images, m->map, m->theta, fwd_scale, m->range_flag);
     else
-        hipLaunchKernelGGL(mlp_refresh_kernel<HTF_MLP_FP32>, dim3(grid), dim3(256), 0, stream, m->images, m->map, m->theta, 1.0f);
+        hipLaunchKernelGGL(mlp_refresh_kernel<HTF_MLP_FP32>, dim3(grid), dim3(256), 0, stream, m->images, m->map, m->theta, 1.0f, (int *)nullptr);
     if (m->train_images != m->images) // bf16 / split evaluator images: the training sweep reads its own fp32 set
-        hipLaunchKernelGGL(mlp_refresh_kernel<HTF_MLP_FP32>, dim3(grid), dim3(256), 0, stream, m->train_images, m->train_map, m->theta, 1.0f);
+        hipLaunchKernelGGL(mlp_refresh_kernel<HTF_MLP_FP32>, dim3(grid), dim3(256), 0, stream, m->train_images, m->train_map, m->theta, 1.0f, (int *)nullptr);
     return check_launch("mlp_refresh_kernel");
 }
 
@@ -679,6 +685,10 @@ int mlp_create(const htf_potential_desc *d, MlpDevice **out) {
         if (e == hipSuccess) e = hipMemcpy(m->own_theta, th.data(), th.size() * sizeof(float), hipMemcpyHostToDevice);
         m->theta = m->own_theta;
     }
+    if (e == hipSuccess && split16) { // host-mapped: the image build writes it, the host reads it without a synchronisation
+        e = hipHostMalloc((void **)&m->range_flag, sizeof(int), hipHostMallocMapped);
+        if (e == hipSuccess) *m->range_flag = 0;
+    }
     if (e != hipSuccess) {
         set_error("pair-MLP: device upload failed: %s", hipGetErrorString(e));
         mlp_destroy(m);
@@ -708,6 +718,7 @@ void mlp_destroy(MlpDevice *m) {
     if (m->images) (void)hipFree(m->images);
     if (m->map) (void)hipFree(m->map);
     if (m->own_theta) (void)hipFree(m->own_theta);
+    if (m->range_flag) (void)hipHostFree(m->range_flag);
     delete m;
 }
 
@@ -734,6 +745,8 @@ static int launch_mlp(const MlpDevice *m, const void *nlist, int in_dtype, unsig
 int mlp_eval(const MlpDevice *m, const void *nlist, int in_dtype, unsigned B, unsigned NN, void *force,
              int force_dtype, void *virial9, hipStream_t stream) {
     HTF_REQUIRE(m, "pair-MLP: null potential");
+    HTF_REQUIRE(!mlp_out_of_range(m), "pair-MLP: a weight of the device parameter vector left fp16's range (|2.885 w| >= 6e4) or is not a "
+                                      "number: precision 'split16' cannot carry it; use 'split' or 'fp32'");
     const int out_f64 = force_dtype == HTF_F64;
     if (m->precision == HTF_MLP_BF16)
         return m->act == HTF_ACT_TANH ? launch_mlp<true, HTF_MLP_BF16>(m, nlist, in_dtype, B, NN, force, out_f64, virial9, stream)

@@ -331,6 +331,30 @@ def test_alternate_routes_against_the_variants_build(htf, cuda):
     assert r.returncode == 0 and " passed" in r.stdout and "skipped" not in r.stdout.split("\n")[-2], r.stdout[-3000:] + r.stderr[-2000:]
 
 
+def test_split16_weight_range_is_checked_after_an_update(htf, cuda):
+    """Host-supplied weights are checked against fp16's range at creation; a TRAINED device vector cannot be.  The
+    image build flags a weight whose forward operand (x 2 log2 e) leaves the range -- or is not a number -- in a host-mapped
+    word, and the next evaluation / training call refuses with a ValueError instead of producing inf / NaN forces."""
+    from hoomd_tf_amd import initializers
+    params = initializers.mlp_params(seed=3)
+    theta = torch.tensor(_flat_params(params), dtype=torch.float32, device=cuda)
+    pot = htf.Potential.pair_mlp(params, 0.0, 3.0, activation="tanh", precision="split16", theta=theta)
+    x = torch.from_numpy(_case(2, N=16, NN=32)).to(cuda)
+    f0 = htf.ops.eval_forces(pot, x)
+    assert torch.isfinite(f0).all()
+    theta[5] = 3.0e4          # x 2.885 = 8.7e4 > 65504
+    pot.refresh()
+    torch.cuda.synchronize()
+    with pytest.raises(ValueError, match="fp16"):
+        htf.ops.eval_forces(pot, x)
+    with pytest.raises(ValueError, match="fp16"):   # sticky: a potential that overflowed once stays refused
+        htf.ops.train_pair_grad(pot, x, torch.zeros((16, 4), device=cuda))
+    # the exact three-part bf16 split has no range limit
+    theta2 = theta.clone()
+    pot2 = htf.Potential.pair_mlp(params, 0.0, 3.0, activation="tanh", precision="split", theta=theta2)
+    assert torch.isfinite(htf.ops.eval_forces(pot2, x)).all()
+
+
 def test_pair_mlp_refresh_tracks_device_weights(htf, cuda):
     """The persistent potential reads the flat device vector: after an in-place change +
     refresh, the MFMA evaluator gives what a freshly built potential gives."""

@@ -1,9 +1,9 @@
 # copy the evidence pass's outputs (gpurun_out/final, scratch) into profiles/ (tracked), named per round
 set -e
-R=${1:-r03}
+R=${1:-r04}
 cd "$(dirname "$0")/.."
 F=gpurun_out/final
-for n in bench_ref_lj256 bench_lj bench_lj_200 bench_lj_f64 bench_wca bench_wca_c2 bench_mlp bench_mlp_fp32 bench_mlp_bf16 bench_mlp_split bench_c1 bench_ex01 bench_mlp_train bench_rehearsal_2ranks_strong_gloo bench_rehearsal_8ranks_strong_gloo bench_rehearsal_2ranks_weak_gloo bench_rehearsal_c5_8ranks_weak_mlptrain_gloo bench_rehearsal_2ranks_strong_torchrun_gloo bench_rehearsal_2ranks_strong_mlp_gloo; do
+for n in bench_ref_lj256 bench_lj bench_lj_200 bench_lj_f64 bench_wca bench_wca_c2 bench_mlp bench_mlp_fp32 bench_mlp_bf16 bench_mlp_split bench_c1 bench_ex01 bench_mlp_train bench_rehearsal_2ranks_strong_gloo bench_rehearsal_8ranks_strong_gloo bench_rehearsal_2ranks_weak_gloo bench_rehearsal_c5_8ranks_weak_mlptrain_gloo bench_rehearsal_2ranks_strong_torchrun_gloo bench_rehearsal_2ranks_strong_mlp_gloo bench_eds_f64 bench_generic_lj bench_lj_cells16 bench_lj_cells20 bench_lj_cells25; do
   [ -s $F/$n.json ] && cp $F/$n.json profiles/${R}_$n.json
 done
 cp $F/bench_eds.json profiles/${R}_bench_eds_c4.json
@@ -21,6 +21,7 @@ cp $F/pmc_c2_c4.json profiles/${R}_bench_c2_c4_pmc.json
 cp $F/gather_probe2.txt profiles/${R}_gather_probe.txt
 cp $F/store_probe.txt profiles/${R}_store_probe.txt
 cp gpurun_out/parity_stats.json profiles/${R}_parity_stats.json
+[ -s $F/train_sweep_pmc.txt ] && grep -v "^stats\|amdgpu.ids" $F/train_sweep_pmc.txt > profiles/${R}_train_sweep_pmc.txt
 for n in soak_nve soak_nve_f64; do [ -s $F/$n.json ] && cp $F/$n.json profiles/${R}_$n.json; done
 for n in pytest_gpu pytest_gpu_ctypes smoke; do [ -s $F/$n.log ] && cp $F/$n.log profiles/${R}_$n.log; done
 tail -2 $F/pytest_gpu.log; tail -1 $F/smoke.log

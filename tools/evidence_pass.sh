@@ -21,6 +21,12 @@ timeout 900 python bench.py --workload ex01 2>/dev/null | jl > $F/bench_ex01.jso
 timeout 900 python bench.py --workload mlp-split --steps 100 --warmup 10 --no-cpu-baseline 2>/dev/null | jl > $F/bench_mlp_split.json
 timeout 900 python bench.py --workload mlp-train --steps 400 --warmup 20 --no-cpu-baseline 2>/dev/null | jl > $F/bench_mlp_train.json
 timeout 900 python bench.py --workload eds 2>/dev/null | jl > $F/bench_eds.json
+timeout 900 python bench.py --workload eds --f64 --no-cpu-baseline 2>/dev/null | jl > $F/bench_eds_f64.json          # C4 under a HOOMD DOUBLE build
+timeout 900 python bench.py --workload generic-lj 2>/dev/null | jl > $F/bench_generic_lj.json          # what leaving the lowered model zoo costs (torch ops + autograd)
+for c in 16 20 25; do          # the per-rank row counts of the 131k box cut 8 / 4 / 2 ways: inputs of DESIGN 6's predicted scaling table
+  timeout 300 python bench.py --cells $c --steps 200 --warmup 20 --no-mlp --no-cpu-baseline --no-fused 2>/dev/null | jl > $F/bench_lj_cells$c.json
+done
+bash tools/pmc_train.sh > $F/train_sweep_pmc.txt 2>&1          # the training sweep alone (tools/train_probe.py): rocprofv3 duration + SQ counters
 timeout 900 python bench.py --workload ref-lj256 2>/dev/null | jl > $F/bench_ref_lj256.json          # the one workload the reference publishes a number for
 HTF_BENCH_WATCHDOG=400 HTF_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 20 --warmup 5 --no-cpu-baseline --no-fused 2>/dev/null | jl > $F/bench_rehearsal_2ranks_strong_gloo.json
 HTF_BENCH_WATCHDOG=400 HTF_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 8 --steps 20 --warmup 5 --no-cpu-baseline --no-fused 2>/dev/null | jl > $F/bench_rehearsal_8ranks_strong_gloo.json
