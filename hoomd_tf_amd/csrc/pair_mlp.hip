@@ -233,6 +233,10 @@ __device__ __forceinline__ void mfma_blk(f32x16 &acc, const float *img, unsigned
 // spills a handful of registers whichever way its arithmetic is written and is no faster (3.00 ms
 // either way at C3); split with six waves per workgroup spills 50-60 registers: 2.87 ms against
 // 1.92 ms.
+__device__ __forceinline__ float bcast_lane(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
 constexpr int pipe_per(int valu, int mfma) { return (valu + mfma - 1) / mfma > 0 ? (valu + mfma - 1) / mfma : 1; }
 
 #ifndef HTF_MLP16_PER_CU
@@ -259,27 +263,96 @@ __global__ __launch_bounds__(256, MlpLaunch<P>::kPerCU) void pair_mlp_kernel(con
     const unsigned p = lane & 31u, h = lane >> 5;
     const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const unsigned nwaves = (gridDim.x * blockDim.x) >> 6;
-    const unsigned ntiles = (NN + 31) / 32;
     const float ginv = 1.0f / gap;
     const float nginv_l2e = -1.4426950408889634f * ginv;
     const float b3 = lds[I::TabB3];
     const f32x16 cen = load_tab(lds + I::TabC, 0, h); // centers of this lane's 16 RBF indices
 
-    for (unsigned row = wave; row < B; row += nwaves) {
-        const typename Vec4<IT>::type *rp = nlist + (size_t)row * NN;
-        float fx = 0.f, fy = 0.f, fz = 0.f, en = 0.f;
-        Virial6 vir; // _compute_virial (simmodel.py:509-523) works for any energy: -(|nf| / (2 |x|)) x (x) x per slot
-        for (unsigned tile = 0; tile < ntiles; ++tile) {
-            const unsigned slot = tile * 32 + p;
-            float x = 0.f, y = 0.f, z = 0.f;
-            if (slot < NN) {
-                auto v = rp[slot];
-                x = (float)v.x; y = (float)v.y; z = (float)v.z;
+    // Live slots are COMPACTED across a wave's rows before they become 32-pair tiles (round 4): the rows of a liquid hold ~95
+    // live slots of 128, so their third tile carries 31 pairs and a quarter of the rows add a fourth with 1-6 -- 424 k tiles for
+    // the 389 k the C3 box's 12.45 M pairs fill.  The wave stages its rows 64 slots at a time (pair vector and row index of the
+    // live slots into a wave-private LDS ring, ballot + mbcnt ranks) and pops 32 pairs at a time; a tile's per-pair results go
+    // back to their rows through one masked wave sum per row present in the tile (one or two), carried in scalar registers
+    // until the row's last pair has been seen.  The order of a wave's pairs is fixed: deterministic.
+    constexpr unsigned kRing = 96; // >= 31 left over + one chunk of 64
+    __shared__ float ring_all[4][4][kRing];
+    float(&ring)[4][kRing] = ring_all[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
+    unsigned head = 0, count = 0; // head in [0, kRing), wave-uniform
+    const unsigned nchunks = (NN + 63) / 64;
+    auto write_row = [&](unsigned wr, float ofx, float ofy, float ofz, float oen, const float (&v6)[6]) {
+        if (lane == 0) {
+            if (out_f64)
+                ((double4 *)force)[wr] = make_double4(ofx, ofy, ofz, oen);
+            else
+                ((float4 *)force)[wr] = make_float4(ofx, ofy, ofz, oen);
+            if constexpr (VIRIAL) {
+                const float v9[9] = {v6[0], v6[1], v6[2], v6[1], v6[3], v6[4], v6[2], v6[4], v6[5]};
+#pragma unroll
+                for (int c9 = 0; c9 < 9; ++c9) {
+                    if (out_f64)
+                        ((double *)virial9)[(size_t)wr * 9 + c9] = v9[c9];
+                    else
+                        ((float *)virial9)[(size_t)wr * 9 + c9] = v9[c9];
+                }
             }
+        }
+    };
+    // the row whose pairs are being summed: its partial sums live in scalar registers (wave-uniform)
+    unsigned open_row = 0xFFFFFFFFu;
+    float cfx = 0.f, cfy = 0.f, cfz = 0.f, cfe = 0.f, cv6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const float zero6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    unsigned row = wave, chunk = 0;
+    bool row_any = false; // a row without a live slot gets its zeros when its last chunk has been staged
+    while (true) {
+        if (count < 32u && row < B) {
+            // ---- stage 64 slots of the current row
+            const unsigned slot = chunk * 64 + lane;
+            float sx = 0.f, sy = 0.f, sz = 0.f;
+            if (slot < NN) {
+                const auto v = nlist[(size_t)row * NN + slot];
+                sx = (float)v.x; sy = (float)v.y; sz = (float)v.z;
+            }
+            const float ax = sx + kNormDelta, ay = sy + kNormDelta, az = sz + kNormDelta;
+            const bool live = sqrtf(ax * ax + ay * ay + az * az) > kRinvDelta;
+            const unsigned long long mask = __ballot(live);
+            if (mask != 0ull) {
+                row_any = true;
+                const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                if (live) {
+                    unsigned at = head + count + rank;
+                    at = at >= 2 * kRing ? at - 2 * kRing : (at >= kRing ? at - kRing : at);
+                    ring[0][at] = sx;
+                    ring[1][at] = sy;
+                    ring[2][at] = sz;
+                    ring[3][at] = __uint_as_float(row);
+                }
+                count += (unsigned)__builtin_popcountll(mask);
+            }
+            if (++chunk == nchunks) {
+                if (!row_any) write_row(row, 0.f, 0.f, 0.f, 0.f, zero6);
+                row_any = false;
+                chunk = 0;
+                row += nwaves;
+            }
+            asm volatile("" ::: "memory");
+            continue;
+        }
+        if (count == 0u) break;
+        // ---- pop a tile: 32 pairs (the wave's last one may be partial: its empty lanes are padding)
+        const unsigned avail = count < 32u ? count : 32u;
+        const bool have = p < avail;
+        unsigned at = head + p;
+        at = at >= kRing ? at - kRing : at;
+        const float x = have ? ring[0][at] : 0.f, y = have ? ring[1][at] : 0.f, z = have ? ring[2][at] : 0.f;
+        const unsigned my_row = have ? __float_as_uint(ring[3][at]) : 0xFFFFFFFFu;
+        head += avail;
+        head = head >= kRing ? head - kRing : head;
+        count -= avail;
+        asm volatile("" ::: "memory");
+        {
             const float tx = x + kNormDelta, ty = y + kNormDelta, tz = z + kNormDelta;
-            const float r = sqrtf(tx * tx + ty * ty + tz * tz);
-            const bool m = r > kRinvDelta;
-            if (__ballot(m) == 0ull) continue; // every slot of this tile is padding
+            const float r = have ? sqrtf(tx * tx + ty * ty + tz * tz) : 1.0f; // (an empty lane: any finite distance)
+            const bool m = have;
 
 #ifdef HTF_MLP_VALU_PAD // experiment: HTF_MLP_VALU_PAD dummy VALU instructions per 32-slot tile (does the instruction count bind?)
             {
@@ -460,46 +533,40 @@ __global__ __launch_bounds__(256, MlpLaunch<P>::kPerCU) void pair_mlp_kernel(con
             const float dpart = dp2[0] + dp2[1];
             const float dudr = sum_xor32(dpart);
 
-            // E_i += 1/2 u ; F_i += 2 * (1/2) du/dr * t / r   (masked; upper half duplicates)
-            if (m && h == 0) {
-                const float c = dudr / r;
-                fx += c * tx;
-                fy += c * ty;
-                fz += c * tz;
-                en += 0.5f * u;
-                if constexpr (VIRIAL) vir.add(x, y, z, c * tx, c * ty, c * tz);
-            }
-        }
-        fx = group_sum<64>(fx);
-        fy = group_sum<64>(fy);
-        fz = group_sum<64>(fz);
-        en = group_sum<64>(en);
-        float v6[6];
-        if constexpr (VIRIAL) {
-            v6[0] = group_sum<64>(vir.xx);
-            v6[1] = group_sum<64>(vir.xy);
-            v6[2] = group_sum<64>(vir.xz);
-            v6[3] = group_sum<64>(vir.yy);
-            v6[4] = group_sum<64>(vir.yz);
-            v6[5] = group_sum<64>(vir.zz);
-        }
-        if (lane == 0) {
-            if (out_f64)
-                ((double4 *)force)[row] = make_double4(fx, fy, fz, en);
-            else
-                ((float4 *)force)[row] = make_float4(fx, fy, fz, en);
-            if constexpr (VIRIAL) {
-                const float v9[9] = {v6[0], v6[1], v6[2], v6[1], v6[3], v6[4], v6[2], v6[4], v6[5]};
+            // E_i += 1/2 u ; F_i += 2 * (1/2) du/dr * t / r   (upper half duplicates the lower one's pairs)
+            const bool mine = m && h == 0;
+            const float c = dudr / r;
+            const float px = mine ? c * tx : 0.f, py = mine ? c * ty : 0.f, pz = mine ? c * tz : 0.f, pe = mine ? 0.5f * u : 0.f;
+            Virial6 vir; // _compute_virial (simmodel.py:509-523) works for any energy: -(|nf| / (2 |x|)) x (x) x per slot
+            if constexpr (VIRIAL)
+                if (mine) vir.add(x, y, z, c * tx, c * ty, c * tz);
+            // one masked wave sum per row present in the tile, in row order; a row is written when the next one shows up
+            unsigned long long todo = __ballot(mine);
+            while (todo != 0ull) {
+                const unsigned first = (unsigned)__builtin_ctzll(todo);
+                const unsigned rid = (unsigned)__builtin_amdgcn_readlane((int)my_row, (int)first);
+                const bool sel = mine && my_row == rid;
+                const float tot = wave_sum4(sel ? px : 0.f, sel ? py : 0.f, sel ? pz : 0.f, sel ? pe : 0.f); // rows 0..3: x, z, y, e
+                const float sx = bcast_lane(tot, 0), sz = bcast_lane(tot, 16), sy = bcast_lane(tot, 32), se = bcast_lane(tot, 48);
+                if (rid != open_row) {
+                    if (open_row != 0xFFFFFFFFu) write_row(open_row, cfx, cfy, cfz, cfe, cv6);
+                    open_row = rid;
+                    cfx = cfy = cfz = cfe = 0.f;
 #pragma unroll
-                for (int c9 = 0; c9 < 9; ++c9) {
-                    if (out_f64)
-                        ((double *)virial9)[(size_t)row * 9 + c9] = v9[c9];
-                    else
-                        ((float *)virial9)[(size_t)row * 9 + c9] = v9[c9];
+                    for (int i = 0; i < 6; ++i) cv6[i] = 0.f;
                 }
+                cfx += sx; cfy += sy; cfz += sz; cfe += se;
+                if constexpr (VIRIAL) {
+                    const float t1 = wave_sum4(sel ? vir.xx : 0.f, sel ? vir.xy : 0.f, sel ? vir.xz : 0.f, sel ? vir.yy : 0.f);
+                    const float t2 = wave_sum4(sel ? vir.yz : 0.f, sel ? vir.zz : 0.f, 0.f, 0.f);
+                    cv6[0] += bcast_lane(t1, 0); cv6[2] += bcast_lane(t1, 16); cv6[1] += bcast_lane(t1, 32); cv6[3] += bcast_lane(t1, 48);
+                    cv6[4] += bcast_lane(t2, 0); cv6[5] += bcast_lane(t2, 32);
+                }
+                todo &= ~__ballot(sel);
             }
         }
     }
+    if (open_row != 0xFFFFFFFFu) write_row(open_row, cfx, cfy, cfz, cfe, cv6);
 }
 
 // ------------------------------------------------------------------------------ host side
