@@ -1494,7 +1494,7 @@ static int launch_fused2(const PotParams &pa, const PotParams &pb, const void *p
 #else
     constexpr int rows = HTF_FUSED2_ROWS_DEFAULT;
 #endif
-    if constexpr (sizeof(PT) == 4 && (KA == HTF_POT_LJ || KA == HTF_POT_WCA || KA == HTF_POT_LJ_PARAM)) {
+    if constexpr (KA == HTF_POT_LJ || KA == HTF_POT_WCA || KA == HTF_POT_LJ_PARAM) {
         if (rows == 2 || rows == 4) {
 #define HTF_F2T_LAUNCH(ST, RR)                                                                                         \
     hipLaunchKernelGGL((fused_forces2_tails_kernel<KA, ST, RR, PT>), dim3(grid), dim3(256), 0, s,                      \
