@@ -325,82 +325,60 @@ __global__ __launch_bounds__(256) void cell_count_kernel(const unsigned *__restr
 // And 256 threads, not 1024: a 16-wave workgroup needs four wave slots AND 4 x 88 VGPRs on every SIMD of one CU at once, which
 // no CU has while a training wave (383 VGPRs) sits on each of its SIMDs -- the round-3 trace still showed 289 us per call (max
 // 8.4 ms: the end of the sweep) with the LDS gone.  Four waves, one per SIMD, fit beside it.
-constexpr unsigned kScanThreads = 256, kScanPer = 32, kScanChunk = kScanThreads * kScanPer;
-__global__ __launch_bounds__(kScanThreads) void cell_scan_kernel(unsigned *__restrict__ count, unsigned ncell,
+// Round 4: one workgroup PER 2 048 cells instead of one for all of them (32 k cells at C3 took 45 us of dependent chunks, 5 us of
+// every MD step): workgroup b first sums the counts of the cells before its own (at most ncell reads per thread-block, from L2),
+// then scans its chunk.  The counts are no longer zeroed here -- another workgroup may still be summing them -- but by
+// cell_order_kernel, the last kernel of the sort.
+constexpr unsigned kScanThreads = 256, kScanPer = 8, kScanChunk = kScanThreads * kScanPer;
+__global__ __launch_bounds__(kScanThreads) void cell_scan_kernel(const unsigned *__restrict__ count, unsigned ncell,
                                                          unsigned *__restrict__ start, unsigned *__restrict__ cursor, Gate gate) {
     if (gate.closed()) return;
-    __shared__ unsigned s_wave[kScanThreads / 64];
+    __shared__ unsigned s_wave[kScanThreads / 64], s_carry[kScanThreads / 64];
     const unsigned t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-    unsigned carry = 0;
-    for (unsigned base = 0; base < ncell; base += kScanChunk) {
-        const unsigned first = base + t * kScanPer;
-        unsigned c[kScanPer];
-        const bool whole = first + kScanPer <= ncell && (reinterpret_cast<size_t>(count + first) & 15u) == 0;
-        if (whole) { // (wave-divergent only in the last chunk)
-            const uint4 *p = reinterpret_cast<const uint4 *>(count + first);
-#pragma unroll
-            for (unsigned q = 0; q < kScanPer / 4; ++q) {
-                const uint4 v = p[q];
-                c[4 * q] = v.x; c[4 * q + 1] = v.y; c[4 * q + 2] = v.z; c[4 * q + 3] = v.w;
-            }
-        } else {
-#pragma unroll
-            for (unsigned i = 0; i < kScanPer; ++i) c[i] = first + i < ncell ? count[first + i] : 0u;
+    const unsigned base = blockIdx.x * kScanChunk;
+    // the cells before this workgroup's chunk (base is a multiple of 2 048: 16-byte loads)
+    unsigned before_blk = 0;
+    {
+        const uint4 *p = reinterpret_cast<const uint4 *>(count);
+        for (unsigned i = t; i < base / 4; i += kScanThreads) {
+            const uint4 v = p[i];
+            before_blk += (v.x + v.y) + (v.z + v.w);
         }
-        if (whole) { // left zeroed for the next call (htfs_cell_sort)
-            uint4 *p = reinterpret_cast<uint4 *>(count + first);
-#pragma unroll
-            for (unsigned q = 0; q < kScanPer / 4; ++q) p[q] = make_uint4(0u, 0u, 0u, 0u);
-        } else {
-#pragma unroll
-            for (unsigned i = 0; i < kScanPer; ++i)
-                if (first + i < ncell) count[first + i] = 0u;
-        }
-        unsigned sum = 0;
-#pragma unroll
-        for (unsigned i = 0; i < kScanPer; ++i) sum += c[i];
-        unsigned incl = sum; // inclusive scan over the wave's 64 lanes
-#pragma unroll
-        for (unsigned off = 1; off < 64; off <<= 1) {
-            const unsigned v = (unsigned)__shfl_up((int)incl, off);
-            if (lane >= off) incl += v;
-        }
-        if (lane == 63) s_wave[wave] = incl;
-        __syncthreads();
-        unsigned before = 0, total = 0;
-#pragma unroll
-        for (unsigned w = 0; w < kScanThreads / 64; ++w) {
-            const unsigned v = s_wave[w];
-            before += w < wave ? v : 0u;
-            total += v;
-        }
-        unsigned run = carry + before + (incl - sum);
-#pragma unroll
-        for (unsigned i = 0; i < kScanPer; ++i) { // exclusive prefix in place
-            const unsigned v = c[i];
-            c[i] = run;
-            run += v;
-        }
-        if (whole && (reinterpret_cast<size_t>(start + first) & 15u) == 0 && (reinterpret_cast<size_t>(cursor + first) & 15u) == 0) {
-            uint4 *ps = reinterpret_cast<uint4 *>(start + first), *pc = reinterpret_cast<uint4 *>(cursor + first);
-#pragma unroll
-            for (unsigned q = 0; q < kScanPer / 4; ++q) {
-                const uint4 v = make_uint4(c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]);
-                ps[q] = v;
-                pc[q] = v;
-            }
-        } else {
-#pragma unroll
-            for (unsigned i = 0; i < kScanPer; ++i)
-                if (first + i < ncell) {
-                    start[first + i] = c[i];
-                    cursor[first + i] = c[i];
-                }
-        }
-        carry += total;
-        __syncthreads(); // s_wave is rewritten by the next chunk
+        before_blk = group_sum_u<64>(before_blk);
+        if (lane == 0) s_carry[wave] = before_blk;
     }
-    if (t == 0) start[ncell] = carry;
+    const unsigned first = base + t * kScanPer;
+    unsigned c[kScanPer];
+#pragma unroll
+    for (unsigned i = 0; i < kScanPer; ++i) c[i] = first + i < ncell ? count[first + i] : 0u;
+    unsigned sum = 0;
+#pragma unroll
+    for (unsigned i = 0; i < kScanPer; ++i) sum += c[i];
+    unsigned incl = sum; // inclusive scan over the wave's 64 lanes
+#pragma unroll
+    for (unsigned off = 1; off < 64; off <<= 1) {
+        const unsigned v = (unsigned)__shfl_up((int)incl, off);
+        if (lane >= off) incl += v;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    unsigned before = 0, total = 0, carry = 0;
+#pragma unroll
+    for (unsigned w = 0; w < kScanThreads / 64; ++w) {
+        const unsigned v = s_wave[w];
+        before += w < wave ? v : 0u;
+        total += v;
+        carry += s_carry[w];
+    }
+    unsigned run = carry + before + (incl - sum);
+#pragma unroll
+    for (unsigned i = 0; i < kScanPer; ++i) // exclusive prefix
+        if (first + i < ncell) {
+            start[first + i] = run;
+            cursor[first + i] = run;
+            run += c[i];
+        }
+    if (blockIdx.x == gridDim.x - 1 && t == 0) start[ncell] = carry + total;
 }
 
 __global__ __launch_bounds__(256) void cell_scatter_kernel(const unsigned *__restrict__ cell_of, unsigned n,
@@ -412,10 +390,11 @@ __global__ __launch_bounds__(256) void cell_scatter_kernel(const unsigned *__res
 
 // the scatter's order inside a cell depends on the atomics' timing: sort each cell's few members
 __global__ __launch_bounds__(256) void cell_order_kernel(const unsigned *__restrict__ start, unsigned ncell,
-                                                         unsigned *__restrict__ order, Gate gate) {
+                                                         unsigned *__restrict__ order, unsigned *__restrict__ count, Gate gate) {
     if (gate.closed()) return;
     const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= ncell) return;
+    count[c] = 0u; // left zeroed for the next call (htfs_cell_sort)
     const unsigned b = start[c], e = start[c + 1];
     for (unsigned i = b + 1; i < e; ++i) { // insertion sort (cells hold a handful of particles)
         const unsigned v = order[i];
@@ -436,13 +415,13 @@ extern "C" int htfs_cell_sort(const unsigned *d_cell_of, unsigned Ntot, unsigned
     HTF_REQUIRE(ncell > 0, "htfs_cell_sort: no cells");
     hipStream_t s = (hipStream_t)stream;
     unsigned *count = d_scratch, *cursor = d_scratch + ncell;
-    // the counts are left zeroed by every call that runs (cell_scan_kernel) and untouched by one the gate holds back,
+    // the counts are left zeroed by every call that runs (cell_order_kernel) and untouched by one the gate holds back,
     // so a gated call -- always preceded by an ungated one on the same scratch (htf_standin.h) -- needs no memset
     if (!g_gate.disp2) HTF_CHECK_HIP(hipMemsetAsync(count, 0, (size_t)ncell * sizeof(unsigned), s));
     if (Ntot) hipLaunchKernelGGL(cell_count_kernel, dim3((Ntot + 255) / 256), dim3(256), 0, s, d_cell_of, Ntot, count, g_gate);
-    hipLaunchKernelGGL(cell_scan_kernel, dim3(1), dim3(kScanThreads), 0, s, count, ncell, d_cell_start, cursor, g_gate);
+    hipLaunchKernelGGL(cell_scan_kernel, dim3((ncell + kScanChunk - 1) / kScanChunk), dim3(kScanThreads), 0, s, count, ncell, d_cell_start, cursor, g_gate);
     if (Ntot) hipLaunchKernelGGL(cell_scatter_kernel, dim3((Ntot + 255) / 256), dim3(256), 0, s, d_cell_of, Ntot, cursor, d_order, g_gate);
-    hipLaunchKernelGGL(cell_order_kernel, dim3((ncell + 255) / 256), dim3(256), 0, s, d_cell_start, ncell, d_order, g_gate);
+    hipLaunchKernelGGL(cell_order_kernel, dim3((ncell + 255) / 256), dim3(256), 0, s, d_cell_start, ncell, d_order, count, g_gate);
     return check_launch("htfs_cell_sort");
 }
 
