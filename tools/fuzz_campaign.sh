@@ -4,8 +4,12 @@
 # HTF_FUSED_TAILS=2, five assertions of BIT-identity between forms (test_rows_per_wave_variants_are_bit_identical[1,2,8],
 # test_fused_matches_two_kernel_path_and_oracle[128-*]): a call with check_count takes the plain two-row form, whose second
 # row sums its tail in a different order (differences <= 1 ulp of the largest term, 6e-5 on |F| ~ 1e3; measured round 3).
+# Round 4: the forms and their switches exist in the variants build only (tools/build_variant.sh ab -DHTF_AB_VARIANTS, made by
+# __graft_entry__.build()): the campaign loads it through HTF_AMD_LIB.
 #   gpurun -- 'bash tools/fuzz_campaign.sh'   -> gpurun_out/fuzz_campaign.txt
 cd $GRAFT_REPO_ROOT
+export HTF_AMD_LIB=$GRAFT_REPO_ROOT/build_variants/libhtf_ab.so
+[ -f $HTF_AMD_LIB ] || { echo "no variants build: tools/build_variant.sh ab -DHTF_AB_VARIANTS"; exit 1; }
 O=gpurun_out/fuzz_campaign.txt; : > $O
 for t in 2 3 4; do
   echo "== HTF_FUSED_TAILS=$t" >> $O
