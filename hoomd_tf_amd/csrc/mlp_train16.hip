@@ -176,14 +176,14 @@ __global__ void mlp_resid_max_kernel(const float4 *__restrict__ pred, const void
     if ((threadIdx.x & 63u) == 0) atomicMax(out_bits, u);
 }
 
-// The sweep, round 4: every wave is on its own.  One wave owns whole rows (its tiles one after the other; fully padded tiles are
-// skipped) and the COMPLETE weight-gradient accumulators -- dW2 64 + dW1 32 (+ 32 for the layer-2 bias) accumulator registers --
-// for the whole launch: nothing is shared between waves inside the loop, so there is no workgroup barrier in it (the previous
-// form split the accumulators over the four waves of a block and paid nine barriers per round at one wave per SIMD, with the
-// wave of a mostly padded fourth tile idling), and the [feature][pair] operands of the pair-contracted gradients come from a
-// wave-private LDS transpose (tr_write / tr_read: 8-byte writes, hardware-transposed reads; the previous form scattered 2-byte
-// writes).  The reverse pass through layer 2 is taken with swapped operands so that it lands in that layout by itself.  The
-// prediction comes from the evaluator (mlp_eval: a row's residual needs all of its tiles).
+// The sweep, round 4: every wave is on its own.  One wave owns whole rows -- staged chunk by chunk, their live pairs compacted
+// into 32-pair tiles across row boundaries (see the ring below) -- and the COMPLETE weight-gradient accumulators -- dW2 64 + dW1 32
+// (+ 32 for the layer-2 bias) registers -- for the whole launch: nothing is shared between waves inside the loop, so there is no
+// workgroup barrier in it (the previous form split the accumulators over the four waves of a block and paid nine barriers per
+// round at one wave per SIMD, with the wave of a mostly padded fourth tile idling), and the [feature][pair] operands of the
+// pair-contracted gradients come from a wave-private LDS transpose (tr_write / tr_read: 8-byte writes, hardware-transposed
+// reads; the previous form scattered 2-byte writes).  The reverse pass through layer 2 is taken with swapped operands so that it
+// lands in that layout by itself.  The prediction comes from the evaluator (mlp_eval: a row's residual needs all of its pairs).
 // Per 32-pair tile: 192 + 8 v_mfma_f32_32x32x16_f16 and ~1 750 vector instructions.
 template <bool TANH, typename IT>
 __global__ __launch_bounds__(256, 1) void mlp_grad_tr16_kernel(const typename Vec4<IT>::type *__restrict__ nlist, unsigned B, unsigned NN,
