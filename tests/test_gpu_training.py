@@ -274,6 +274,37 @@ def test_pair_mlp_gradient_over_the_residual_range(htf, cuda, regime, precision)
         o += n
 
 
+@pytest.mark.parametrize("NN,N", [(8, 300), (200, 37), (64, 5)])
+def test_pair_mlp_compaction_over_row_shapes(htf, cuda, NN, N):
+    """The split16 evaluator and training sweep stage a row 64 slots at a time and cut the stream of live pairs into tiles of 32
+    wherever they fall: short rows (many rows per tile), rows longer than two chunks, fewer rows than waves, empty rows in between
+    -- forces against the fp64 oracle, the loss gradient against the fp32-MFMA sweep (which walks the rows' own tiles)."""
+    from hoomd_tf_amd import initializers
+    rng = np.random.default_rng(NN)
+    nl, _ = random_nlist(rng, N, NN, fill=0.6, rmin=0.9, rmax=2.8, dtype=np.float32)
+    nl[::7] = 0                                   # empty rows between live ones
+    params = initializers.mlp_params(seed=21)
+    for k in ("b1", "b2", "b3"):
+        params[k] = (0.1 * rng.standard_normal(params[k].shape)).astype(np.float32)
+    theta = _flat_params(params)
+    x = torch.from_numpy(nl).to(cuda)
+    ref = O.pair_mlp_model(nl.astype(np.float64), params, 0.0, 3.0, "tanh")
+    labels = torch.from_numpy((0.05 * O.lj_model(nl.astype(np.float64))).astype(np.float32)).to(cuda)
+    grads = {}
+    for precision in ("split16", "fp32"):
+        w = torch.tensor(theta, dtype=torch.float32, device=cuda)
+        pot = htf.Potential.pair_mlp(params, 0.0, 3.0, activation="tanh", theta=w, precision=precision)
+        f = htf.ops.eval_forces(pot, x).cpu().numpy()
+        np.testing.assert_allclose(f, ref, rtol=2e-4, atol=2e-4 * max(1.0, np.abs(ref).max()))
+        assert np.all(f[::7] == 0)
+        pred = torch.empty((N, 4), device=cuda)
+        grads[precision] = htf.ops.train_pair_grad(pot, x, labels, pred=pred).cpu().numpy()
+        np.testing.assert_allclose(pred.cpu().numpy(), f, rtol=1e-5, atol=1e-5 * max(1.0, np.abs(f).max()))
+    a, b = grads["split16"], grads["fp32"]
+    np.testing.assert_allclose(a[0], b[0], rtol=1e-5)
+    assert np.abs(a[1:] - b[1:]).max() < 1e-4 * np.abs(b[1:]).max()
+
+
 VARIANT_ROUTES = ("valu", "nofuse", "split16-fp32-sweep")
 
 
