@@ -202,7 +202,7 @@ extern "C" int htf_potential_num_params(const htf_potential *pot) {
 
 extern "C" size_t htf_train_scratch_floats(const htf_potential *pot, unsigned B, unsigned NN) {
     if (!pot) return 0;
-    return pot->mlp ? htf::mlp_train_scratch_floats(pot->mlp, B) : htf::train_scratch_floats(pot->pp, B, NN);
+    return pot->mlp ? htf::mlp_train_scratch_floats(pot->mlp, B, NN) : htf::train_scratch_floats(pot->pp, B, NN);
 }
 
 extern "C" int htf_potential_refresh(htf_potential *pot, htf_stream stream) {

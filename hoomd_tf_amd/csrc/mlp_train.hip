@@ -528,38 +528,61 @@ __global__ __launch_bounds__(256, 1) void mlp_grad_mfma_kernel(const typename Ve
     for (unsigned c = threadIdx.x; c < stride; c += blockDim.x) out[c] = red[c];
 }
 
-// accum[c] = sum over the block partials, fixed order; columns >= 1 (the gradient) times 1 / S when the sweep scaled its seeds
-__global__ void mlp_reduce_partials_kernel(const float *__restrict__ partial, unsigned nwaves, unsigned stride,
-                                           unsigned ncols, float *__restrict__ accum, const float *__restrict__ resid_max) {
-    const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= ncols) return;
+// accum[c] = sum over the block partials, fixed order; columns >= 1 (the gradient) times 1 / S when the sweep scaled its seeds.
+// 64 columns x 8 slices of the partials per workgroup (a thread per column walking all 256 partials took 62 us, 2 % of the sweep):
+// slice sums in fixed order, slices combined in fixed order -> deterministic.
+constexpr unsigned kRedSlices = 8;
+__global__ __launch_bounds__(64 * kRedSlices) void mlp_reduce_partials_kernel(const float *__restrict__ partial, unsigned nwaves, unsigned stride,
+                                                                              unsigned ncols, float *__restrict__ accum,
+                                                                              const float *__restrict__ resid_max) {
+    __shared__ float part[kRedSlices][64];
+    const unsigned col = threadIdx.x & 63u, slice = threadIdx.x >> 6;
+    const unsigned c = blockIdx.x * 64 + col;
+    const unsigned per = (nwaves + kRedSlices - 1) / kRedSlices;
+    const unsigned w0 = slice * per, w1 = w0 + per < nwaves ? w0 + per : nwaves;
     float s = 0.f;
-    for (unsigned w = 0; w < nwaves; ++w) s += partial[(size_t)w * stride + c];
+    if (c < ncols)
+        for (unsigned w = w0; w < w1; ++w) s += partial[(size_t)w * stride + c];
+    part[slice][col] = s;
+    __syncthreads();
+    if (slice != 0 || c >= ncols) return;
+#pragma unroll
+    for (unsigned k = 1; k < kRedSlices; ++k) s += part[k][col];
     if (resid_max && c > 0) s *= 1.0f / seed_scale(*resid_max); // a power of two: exact
     accum[c] = s;
 }
 
+// partial slots of a launch: the VALU kernel writes one per wave (n_cu x 4, or the rows rounded up to a multiple of 4), the
+// matrix-core kernels one per workgroup -- up to n_cu of them, sized by the launch's UNITS (rows x tiles for the fp32 sweep:
+// a short batch of long rows has more workgroups than rows / 4; round 4: the scratch had been sized by the rows alone)
 static unsigned train_waves(const MlpDevice *m, unsigned B) {
     unsigned w = (unsigned)m->n_cu * 4u;
     if (w > B) w = (B + 3u) & ~3u;
     return w;
 }
+static unsigned train_slots(const MlpDevice *m, unsigned B, unsigned NN) {
+    const unsigned long long units = (unsigned long long)B * ((NN + 31) / 32);
+    const unsigned long long blocks = (units + 3) / 4 < (unsigned long long)m->n_cu ? (units + 3) / 4 : (unsigned long long)m->n_cu;
+    const unsigned w = train_waves(m, B);
+    return blocks > w ? (unsigned)blocks : w;
+}
 
 static unsigned train_stride(const MlpDevice *m) { return ((unsigned)m->num_params() + 1u + 3u) & ~3u; }
 
 // block partials | prediction [B, 4] (when the caller wants none back) | the largest residual of the launch (1 float + pad)
-size_t mlp_train_scratch_floats(const MlpDevice *m, unsigned B) {
+size_t mlp_train_scratch_floats(const MlpDevice *m, unsigned B, unsigned NN) {
     if (!m) return 0;
-    return (size_t)train_waves(m, B) * train_stride(m) + (size_t)B * 4 + 4;
+    return (size_t)train_slots(m, B, NN) * train_stride(m) + (size_t)B * 4 + 4;
 }
 
 int mlp_train_grad(const MlpDevice *m, const void *nlist, int in_dtype, unsigned B, unsigned NN, const void *labels,
                    int lab_f64, void *pred, float *accum, float *scratch, hipStream_t stream) {
     HTF_REQUIRE(m, "pair-MLP: null potential");
-    const unsigned nw = train_waves(m, B), stride = train_stride(m);
+    const unsigned nw = train_waves(m, B), slots = train_slots(m, B, NN), stride = train_stride(m);
+    (void)nw; // (the VALU kernel's wave count: variants builds)
     float *partial = scratch;
-    float4 *predbuf = pred ? (float4 *)pred : (float4 *)(scratch + (size_t)nw * stride);
-    float *resid_max = scratch + (size_t)nw * stride + (size_t)B * 4;
+    float4 *predbuf = pred ? (float4 *)pred : (float4 *)(scratch + (size_t)slots * stride);
+    float *resid_max = scratch + (size_t)slots * stride + (size_t)B * 4;
     const unsigned ntiles = (NN + 31) / 32;
     MlpDims dm{m->K, m->H1, m->H2, m->off_b1(), m->off_W2(), m->off_b2(), m->off_W3(), m->off_b3()};
     const bool th = m->act == HTF_ACT_TANH;
@@ -578,7 +601,7 @@ int mlp_train_grad(const MlpDevice *m, const void *nlist, int in_dtype, unsigned
         unsigned nblk = 0;
         rc = mlp_train_grad16(m, nlist, in_dtype, B, NN, labels, lab_f64, predbuf, partial, stride, resid_max, &nblk, stream);
         if (rc != HTF_OK) return rc;
-        hipLaunchKernelGGL(mlp_reduce_partials_kernel, dim3((ncols + 63) / 64), dim3(64), 0, stream, partial, nblk, stride,
+        hipLaunchKernelGGL(mlp_reduce_partials_kernel, dim3((ncols + 63) / 64), dim3(64 * kRedSlices), 0, stream, partial, nblk, stride,
                            ncols, accum, resid_max);
         return check_launch("mlp_reduce_partials_kernel");
     }
@@ -607,7 +630,7 @@ int mlp_train_grad(const MlpDevice *m, const void *nlist, int in_dtype, unsigned
 #undef HTF_LAUNCH_MLPM
         rc = check_launch("mlp_grad_mfma_kernel");
         if (rc != HTF_OK) return rc;
-        hipLaunchKernelGGL(mlp_reduce_partials_kernel, dim3((ncols + 63) / 64), dim3(64), 0, stream, partial, nblk, stride,
+        hipLaunchKernelGGL(mlp_reduce_partials_kernel, dim3((ncols + 63) / 64), dim3(64 * kRedSlices), 0, stream, partial, nblk, stride,
                            ncols, accum, (const float *)nullptr);
         return check_launch("mlp_reduce_partials_kernel");
     }
@@ -628,7 +651,7 @@ int mlp_train_grad(const MlpDevice *m, const void *nlist, int in_dtype, unsigned
 #undef HTF_LAUNCH_MLPG
     rc = check_launch("mlp_grad_kernel");
     if (rc != HTF_OK) return rc;
-    hipLaunchKernelGGL(mlp_reduce_partials_kernel, dim3((ncols + 63) / 64), dim3(64), 0, stream, partial, nw, stride,
+    hipLaunchKernelGGL(mlp_reduce_partials_kernel, dim3((ncols + 63) / 64), dim3(64 * kRedSlices), 0, stream, partial, nw, stride,
                        ncols, accum, (const float *)nullptr);
     return check_launch("mlp_reduce_partials_kernel");
 #else

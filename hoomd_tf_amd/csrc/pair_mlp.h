@@ -133,6 +133,6 @@ int mlp_refresh(const MlpDevice *m, hipStream_t stream);
 bool mlp_out_of_range(const MlpDevice *m);
 int mlp_train_grad(const MlpDevice *m, const void *nlist, int in_dtype, unsigned B, unsigned NN, const void *labels,
                    int lab_f64, void *pred, float *accum, float *scratch, hipStream_t stream);
-size_t mlp_train_scratch_floats(const MlpDevice *m, unsigned B);
+size_t mlp_train_scratch_floats(const MlpDevice *m, unsigned B, unsigned NN);
 
 } // namespace htf
