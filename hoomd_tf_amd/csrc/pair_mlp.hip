@@ -137,10 +137,11 @@ __device__ __forceinline__ BOp<P> prep(const f32x16 &x) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) o.b[s][j] = (__bf16)x[8 * s + j];
     } else if constexpr (P == HTF_MLP_SPLIT16) {
-        // x = hi + lo + (<= 2^-22 |x|): hi = fp16(x) and lo = fp16(x - hi), both rounded to nearest, a PAIR of elements per
-        // v_cvt_pk_f16_f32; the residual x - hi is ONE v_fma_mix_f32 that reads hi straight from its half of the packed
-        // register (hi * -1 + x, exact: the difference of an fp32 and its 11-bit rounding fits fp32).  Four instructions per
-        // pair of elements where the three-part bf16 split needs eleven.
+        // x = hi + lo + (<= 2^-22 |x|): hi = fp16(x) and lo = fp16(x - hi), both rounded to nearest.  hi: a PAIR of elements per
+        // v_cvt_pk_f16_f32; lo: ONE v_fma_mixlo / v_fma_mixhi_f16 per element, which reads hi straight from its half of the
+        // packed register (hi * -1 + x in fp32, exact: the difference of an fp32 and its 11-bit rounding fits fp32) and writes
+        // the rounded fp16 into its half of the packed result.  Three instructions per pair of elements (four in round 3, with
+        // the residuals as fp32 and a second v_cvt_pk) where the three-part bf16 split needs eleven.
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             u32x4 ph, pl;
@@ -148,11 +149,11 @@ __device__ __forceinline__ BOp<P> prep(const f32x16 &x) {
             for (int j = 0; j < 4; ++j) {
                 const float a = x[8 * s + 2 * j], b = x[8 * s + 2 * j + 1];
                 const unsigned hp = __builtin_bit_cast(unsigned, f16x2{(_Float16)a, (_Float16)b});
-                float ra, rb;
-                asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(hp), "v"(a));
-                asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(hp), "v"(b));
+                unsigned lp;
+                asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lp) : "v"(hp), "v"(a));
+                asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lp) : "v"(hp), "v"(b));
                 ph[j] = hp;
-                pl[j] = __builtin_bit_cast(unsigned, f16x2{(_Float16)ra, (_Float16)rb});
+                pl[j] = lp;
             }
             o.hi[s] = __builtin_bit_cast(f16x8, ph);
             o.lo[s] = __builtin_bit_cast(f16x8, pl);
@@ -239,13 +240,18 @@ __device__ __forceinline__ float bcast_lane(float v, int lane) {
 
 constexpr int pipe_per(int valu, int mfma) { return (valu + mfma - 1) / mfma > 0 ? (valu + mfma - 1) / mfma : 1; }
 
-#ifndef HTF_MLP16_PER_CU
-#define HTF_MLP16_PER_CU 2
+// split16: ONE workgroup of eight waves per CU (round 4).  The two waves of a SIMD then share LDS, which is what lets them keep
+// pace with each other (see the priority rule at the top of a tile); the image is staged once per CU instead of twice.
+#ifndef HTF_MLP16_WAVES
+#define HTF_MLP16_WAVES 8
 #endif
-template <int P> struct MlpLaunch { static constexpr int kPerCU = P == HTF_MLP_SPLIT16 ? HTF_MLP16_PER_CU : 2; };
+template <int P> struct MlpLaunch {
+    static constexpr int kWaves = P == HTF_MLP_SPLIT16 ? HTF_MLP16_WAVES : 4; // per workgroup
+    static constexpr int kPerCU = 8 / kWaves;                                  // workgroups per CU: two waves per SIMD either way
+};
 
 template <bool TANH, typename IT, int P, bool VIRIAL>
-__global__ __launch_bounds__(256, MlpLaunch<P>::kPerCU) void pair_mlp_kernel(const typename Vec4<IT>::type *__restrict__ nlist,
+__global__ __launch_bounds__(64 * MlpLaunch<P>::kWaves, 2) void pair_mlp_kernel(const typename Vec4<IT>::type *__restrict__ nlist,
                                                           unsigned B, unsigned NN, void *__restrict__ force,
                                                           int out_f64, const float *__restrict__ images, float gap,
                                                           void *__restrict__ virial9) {
@@ -257,6 +263,8 @@ __global__ __launch_bounds__(256, MlpLaunch<P>::kPerCU) void pair_mlp_kernel(con
         float4 *dst = reinterpret_cast<float4 *>(lds);
         for (int i = threadIdx.x; i < I::Floats / 4; i += blockDim.x) dst[i] = src[i];
     }
+    __shared__ unsigned progress[8]; // tiles done, per wave (split16)
+    if (threadIdx.x < 8) progress[threadIdx.x] = 0u;
     __syncthreads();
 
     const unsigned lane = threadIdx.x & 63u;
@@ -275,9 +283,27 @@ __global__ __launch_bounds__(256, MlpLaunch<P>::kPerCU) void pair_mlp_kernel(con
     // back to their rows through one masked wave sum per row present in the tile (one or two), carried in scalar registers
     // until the row's last pair has been seen.  The order of a wave's pairs is fixed: deterministic.
     constexpr unsigned kRing = 96; // >= 31 left over + one chunk of 64
-    __shared__ float ring_all[4][4][kRing];
-    float(&ring)[4][kRing] = ring_all[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
+    constexpr int kWaves = MlpLaunch<P>::kWaves;
+    const unsigned wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    __shared__ float ring_all[kWaves][4][kRing];
+    float(&ring)[4][kRing] = ring_all[wid];
     unsigned head = 0, count = 0; // head in [0, kRing), wave-uniform
+    unsigned tiles_done = 0;
+#ifdef HTF_EVAL_STAMPS // experiment (tools/build_obj_variant.sh): per-phase cycle totals of one wave, printed at the end
+    unsigned long long stamps[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, n_tiles = 0;
+    unsigned long long t_prev = __builtin_amdgcn_s_memtime();
+    const unsigned long long t_begin = t_prev, r_begin = __builtin_amdgcn_s_memrealtime();
+#define HTF_ESTAMP(i)                                                                                                  \
+    do {                                                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        stamps[i] += t_ - t_prev;                                                                                      \
+        t_prev = t_;                                                                                                   \
+    } while (0)
+#else
+#define HTF_ESTAMP(i)
+#endif
     const unsigned nchunks = (NN + 63) / 64;
     auto write_row = [&](unsigned wr, float ofx, float ofy, float ofz, float oen, const float (&v6)[6]) {
         if (lane == 0) {
@@ -303,18 +329,61 @@ __global__ __launch_bounds__(256, MlpLaunch<P>::kPerCU) void pair_mlp_kernel(con
     const float zero6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     unsigned row = wave, chunk = 0;
     bool row_any = false; // a row without a live slot gets its zeros when its last chunk has been staged
+    // The chunk that will be staged next is ALREADY on its way: its load is issued when the chunk before it is taken, one or
+    // two tile bodies ahead of its use, so a wave never sits through an HBM round trip with the SIMD's other wave left alone
+    // (0.67 chunks per tile at C3, each ~2 k cycles of exposed latency before).  It travels global -> LDS directly
+    // (global_load_lds_dwordx4): through registers the loop-carried values are copied at the loop header, and hipcc waits for
+    // the load there, i.e. at once.
+    using V4 = typename Vec4<IT>::type;
+    constexpr int kHalves = sizeof(V4) / 16; // a slot is one (fp32) or two (fp64) 16-byte pieces
+    // (the three-part bf16 images leave no LDS for the staging buffer beside a second workgroup: that precision loads at use)
+#ifdef HTF_MLP_NODMA
+    constexpr bool kDma = false;
+#else
+    constexpr bool kDma = P != HTF_MLP_SPLIT;
+#endif
+    __shared__ __attribute__((aligned(16))) float4 stage_all[kDma ? kWaves : 1][kDma ? kHalves : 1][kDma ? 64 : 1];
+    auto &stage = stage_all[kDma ? wid : 0];
+    auto in_range = [&](unsigned r_, unsigned c_) { return r_ < B && c_ * 64 + lane < NN; };
+    auto request = [&](unsigned r_, unsigned c_) { // global -> LDS without passing through registers: nothing to keep live
+        if (kDma && in_range(r_, c_)) {
+            const char *src = (const char *)(nlist + ((size_t)r_ * NN + c_ * 64 + lane));
+#pragma unroll
+            for (int q = 0; q < kHalves; ++q)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 16 * q),
+                                                 (__attribute__((address_space(3))) void *)&stage[q][0], 16, 0, 0);
+        }
+    };
+    request(row, chunk);
     while (true) {
         if (count < 32u && row < B) {
-            // ---- stage 64 slots of the current row
-            const unsigned slot = chunk * 64 + lane;
+            // ---- stage 64 slots of the current row; request the chunk after it
+            if constexpr (kDma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             float sx = 0.f, sy = 0.f, sz = 0.f;
-            if (slot < NN) {
-                const auto v = nlist[(size_t)row * NN + slot];
-                sx = (float)v.x; sy = (float)v.y; sz = (float)v.z;
+            if (in_range(row, chunk)) {
+                if constexpr (!kDma) {
+                    const auto v = nlist[(size_t)row * NN + chunk * 64 + lane];
+                    sx = (float)v.x; sy = (float)v.y; sz = (float)v.z;
+                } else if constexpr (kHalves == 1) {
+                    const float4 v = stage[0][lane];
+                    sx = v.x; sy = v.y; sz = v.z;
+                } else {
+                    const double2 xy = reinterpret_cast<const double2 *>(&stage[0][0])[lane];
+                    const double2 zw = reinterpret_cast<const double2 *>(&stage[1][0])[lane];
+                    sx = (float)xy.x; sy = (float)xy.y; sz = (float)zw.x;
+                }
+            }
+            const unsigned cur = row;
+            const bool last = ++chunk == nchunks;
+            if (last) {
+                chunk = 0;
+                row += nwaves;
             }
             const float ax = sx + kNormDelta, ay = sy + kNormDelta, az = sz + kNormDelta;
             const bool live = sqrtf(ax * ax + ay * ay + az * az) > kRinvDelta;
             const unsigned long long mask = __ballot(live);
+            if constexpr (kDma) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the staged values are in registers: the buffer may be overwritten
+            request(row, chunk);
             if (mask != 0ull) {
                 row_any = true;
                 const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
@@ -324,20 +393,39 @@ __global__ __launch_bounds__(256, MlpLaunch<P>::kPerCU) void pair_mlp_kernel(con
                     ring[0][at] = sx;
                     ring[1][at] = sy;
                     ring[2][at] = sz;
-                    ring[3][at] = __uint_as_float(row);
+                    ring[3][at] = __uint_as_float(cur);
                 }
                 count += (unsigned)__builtin_popcountll(mask);
             }
-            if (++chunk == nchunks) {
-                if (!row_any) write_row(row, 0.f, 0.f, 0.f, 0.f, zero6);
+            if (last) {
+                if (!row_any) write_row(cur, 0.f, 0.f, 0.f, 0.f, zero6);
                 row_any = false;
-                chunk = 0;
-                row += nwaves;
             }
             asm volatile("" ::: "memory");
+            HTF_ESTAMP(0); // staging
             continue;
         }
         if (count == 0u) break;
+        if constexpr (kWaves == 8) {
+            // Keep pace with the SIMD's other wave.  Between two waves of equal priority the issue arbiter prefers the OLDER
+            // one: it runs at the speed it would have alone (9.4 k cycles per tile, latency-bound) and the younger one gets
+            // what is left (17 k) -- with equal shares of the rows the older wave finished at 0.70 of the kernel and the
+            // younger one ran the rest alone, a third slower per tile than the pair.  Each wave publishes its tile count; the
+            // one behind takes the higher priority for its next tile.  Timing only: what a wave computes does not change.
+            tiles_done = __builtin_amdgcn_readfirstlane(tiles_done + 1u);
+            // (inline asm: a compiler-visible LDS write would be ordered behind the chunk that is in flight to LDS)
+            const unsigned pr0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned *)&progress[0];
+            unsigned seen;
+            asm volatile("ds_write_b32 %1, %2\n\tds_read_b32 %0, %3\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(seen)
+                         : "v"(pr0 + 4u * wid), "v"(tiles_done), "v"(pr0 + 4u * (wid ^ 4u))
+                         : "memory");
+            const unsigned other = __builtin_amdgcn_readfirstlane(seen);
+            if (tiles_done < other) // (scalar: s_setprio is not predicated by exec)
+                __builtin_amdgcn_s_setprio(2);
+            else
+                __builtin_amdgcn_s_setprio(0);
+        }
         // ---- pop a tile: 32 pairs (the wave's last one may be partial: its empty lanes are padding)
         const unsigned avail = count < 32u ? count : 32u;
         const bool have = p < avail;
@@ -377,6 +465,7 @@ __global__ __launch_bounds__(256, MlpLaunch<P>::kPerCU) void pair_mlp_kernel(con
                 }
             }
 
+            HTF_ESTAMP(1); // pop + RBF
             // The chain phi -> L1 -> act -> L2 -> act -> L3 -> backward 2 -> backward 1 is software-pipelined by
             // hand: while the matrix pipe works on one 32-feature block, the wave's VALU turns the PREVIOUS block
             // into the next operand (activation, derivative, operand split).  hipcc clusters each kind of work
@@ -393,8 +482,8 @@ __global__ __launch_bounds__(256, MlpLaunch<P>::kPerCU) void pair_mlp_kernel(con
     }
             constexpr int kM = P == HTF_MLP_FP32 ? 16 : (P == HTF_MLP_BF16 ? 2 : (P == HTF_MLP_SPLIT ? 12 : 6)); // MFMAs per block
             constexpr int kAct = TANH ? 56 : 0;
-            // (split16: 16 v_cvt_pk; its 16 v_fma_mix are inline asm, which the scheduler places by their dependences)
-            constexpr int kPrep = P == HTF_MLP_SPLIT ? 76 : (P == HTF_MLP_BF16 ? 8 : (P == HTF_MLP_SPLIT16 ? 16 : 0));
+            // (split16: 8 v_cvt_pk; its 16 v_fma_mixlo/hi are inline asm, which the scheduler places by their dependences)
+            constexpr int kPrep = P == HTF_MLP_SPLIT ? 76 : (P == HTF_MLP_BF16 ? 8 : (P == HTF_MLP_SPLIT16 ? 8 : 0));
             constexpr int kBwd = TANH ? 16 : 0, kDot = 8;
 
             f32x16 a1[2], a2[2], dphi;
@@ -459,6 +548,7 @@ __global__ __launch_bounds__(256, MlpLaunch<P>::kPerCU) void pair_mlp_kernel(con
             act_tile<TANH, PK>(a1[0]);
             const BOp<P> a1_b0 = prep<P>(a1[0]);
             HTF_PIPE(kM, pipe_per(kAct + kPrep, kM));
+            HTF_ESTAMP(2);
             // ---- layer 2
             a2[0] = load_tab(lds + I::TabB2, 0, h);
             a2[1] = load_tab(lds + I::TabB2, 1, h);
@@ -467,6 +557,7 @@ __global__ __launch_bounds__(256, MlpLaunch<P>::kPerCU) void pair_mlp_kernel(con
             act_tile<TANH, PK>(a1[1]);
             const BOp<P> a1_b1 = prep<P>(a1[1]);
             HTF_PIPE(2 * kM, pipe_per(kAct + kPrep, 2 * kM));
+            HTF_ESTAMP(3);
             mfma_blk<P>(a2[0], lds + I::L2 + (0 * 2 + 1) * I::BS, lane, a1_b1);
             if constexpr (!PK) __builtin_amdgcn_sched_barrier(0);
             // ---- layer 3 (dot with w3) and dz2 = w3 * act'(z2), in place, block 0 under the last L2 block
@@ -479,6 +570,7 @@ __global__ __launch_bounds__(256, MlpLaunch<P>::kPerCU) void pair_mlp_kernel(con
             }
             const BOp<P> dz2_b0 = prep<P>(a2[0]);
             HTF_PIPE(kM, pipe_per(kAct + kDot + kBwd + kPrep, kM));
+            HTF_ESTAMP(4);
             // ---- backward 2: dh1^T = W2 dz2^T, then dz1 = dh1 * act'(z1) into a1
             f32x16 d1[2];
 #pragma unroll
@@ -495,12 +587,14 @@ __global__ __launch_bounds__(256, MlpLaunch<P>::kPerCU) void pair_mlp_kernel(con
             }
             const BOp<P> dz2_b1 = prep<P>(a2[1]);
             HTF_PIPE(2 * kM, pipe_per(kAct + kDot + kBwd + kPrep, 2 * kM));
+            HTF_ESTAMP(5);
             mfma_blk<P>(d1[0], lds + I::B2 + (0 * 2 + 1) * I::BS, lane, dz2_b1);
             if constexpr (!PK) __builtin_amdgcn_sched_barrier(0);
             mfma_blk<P>(d1[1], lds + I::B2 + (1 * 2 + 1) * I::BS, lane, dz2_b1);
             act_bwd_tile<TANH, PK>(a1[0], d1[0]);
             const BOp<P> dz1_b0 = prep<P>(a1[0]);
             HTF_PIPE(kM, pipe_per(kBwd + kPrep, kM));
+            HTF_ESTAMP(6);
             // ---- backward 1: dphi^T = W1 dz1^T
 #pragma unroll
             for (int v = 0; v < 16; ++v) dphi[v] = 0.f;
@@ -510,6 +604,7 @@ __global__ __launch_bounds__(256, MlpLaunch<P>::kPerCU) void pair_mlp_kernel(con
             HTF_PIPE(kM, pipe_per(kBwd + kPrep, kM));
             mfma_blk<P>(dphi, lds + I::B1 + I::BS, lane, dz1_b1);
             if constexpr (!PK) __builtin_amdgcn_sched_barrier(0);
+            HTF_ESTAMP(7);
             }
 #undef HTF_PIPE
             const float upart = up2[0] + up2[1];
@@ -564,8 +659,27 @@ __global__ __launch_bounds__(256, MlpLaunch<P>::kPerCU) void pair_mlp_kernel(con
                 }
                 todo &= ~__ballot(sel);
             }
+            HTF_ESTAMP(8); // du/dr, tile sums, row carries
+#ifdef HTF_EVAL_STAMPS
+            ++n_tiles;
+#endif
         }
     }
+#ifdef HTF_EVAL_STAMPS
+    if (blockIdx.x == 7 && threadIdx.x == 64) {
+        printf("stamps (cycles per tile, wave 1 of block 7, %llu tiles):", n_tiles);
+        for (int i = 0; i <= 8; ++i) printf(" %d:%llu", i, stamps[i] / (n_tiles ? n_tiles : 1));
+        printf("\n");
+    }
+    if (blockIdx.x == 9 && lane == 0)
+        printf("block 9 wave %u: SIMD %u, %llu tiles, %llu ticks\n", wid, __builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4), n_tiles,
+               (unsigned long long)(__builtin_amdgcn_s_memtime() - t_begin));
+    if ((blockIdx.x % 73 == 7 || blockIdx.x == gridDim.x - 1) && threadIdx.x == 64) {
+        const unsigned long long t_end = __builtin_amdgcn_s_memtime(), r_end = __builtin_amdgcn_s_memrealtime();
+        printf("block %u: %llu tiles, memtime %llu ticks, realtime (100 MHz) start %llu + %llu\n", blockIdx.x, n_tiles, t_end - t_begin,
+               r_begin % 100000000ull, r_end - r_begin);
+    }
+#endif
     if (open_row != 0xFFFFFFFFu) write_row(open_row, cfx, cfy, cfz, cfe, cv6);
 }
 
@@ -795,10 +909,11 @@ static int launch_mlp(const MlpDevice *m, const void *nlist, int in_dtype, unsig
     // persistent blocks: 3 per CU (LDS 48.9 KiB each), 4 waves per block, one row per wave trip
     // (bf16 and split: 2 per CU, see MlpLaunch)
     unsigned grid = (unsigned)m->n_cu * (unsigned)MlpLaunch<P>::kPerCU;
-    unsigned need = (B + 3) / 4;
+    constexpr unsigned kW = (unsigned)MlpLaunch<P>::kWaves;
+    unsigned need = (B + kW - 1) / kW;
     if (grid > need) grid = need;
 #define HTF_MLP_LAUNCH(T, V4, VIR)                                                                                     \
-    hipLaunchKernelGGL((pair_mlp_kernel<TANH, T, P, VIR>), dim3(grid), dim3(256), 0, s, (const V4 *)nlist, B, NN, force, \
+    hipLaunchKernelGGL((pair_mlp_kernel<TANH, T, P, VIR>), dim3(grid), dim3(64 * kW), 0, s, (const V4 *)nlist, B, NN, force, \
                        out_f64, m->images, m->gap, virial9)
     if (in_dtype == HTF_F32) {
         if (virial9) HTF_MLP_LAUNCH(float, float4, true); else HTF_MLP_LAUNCH(float, float4, false);
