@@ -126,7 +126,7 @@ template <> struct BOp<HTF_MLP_SPLIT16> { f16x8 hi[2], lo[2]; };
 // Split operands: x = hi + mid + lo EXACTLY, each part 8 significand bits (bf16's), by masking --
 // hi = top 16 bits of x, mid = top 16 bits of x - hi, lo = x - hi - mid (at most 8 bits are left,
 // so its low 16 bits are zero).  v_perm_b32 packs two upper halves into one register.
-template <int P>
+template <int P, bool ASM_HI = false>
 __device__ __forceinline__ BOp<P> prep(const f32x16 &x) {
     BOp<P> o;
     if constexpr (P == HTF_MLP_FP32) {
@@ -137,23 +137,31 @@ __device__ __forceinline__ BOp<P> prep(const f32x16 &x) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) o.b[s][j] = (__bf16)x[8 * s + j];
     } else if constexpr (P == HTF_MLP_SPLIT16) {
-        // x = hi + lo + (<= 2^-22 |x|): hi = fp16(x) and lo = fp16(x - hi), both rounded to nearest.  hi: a PAIR of elements per
-        // v_cvt_pk_f16_f32; lo: ONE v_fma_mixlo / v_fma_mixhi_f16 per element, which reads hi straight from its half of the
-        // packed register (hi * -1 + x in fp32, exact: the difference of an fp32 and its 11-bit rounding fits fp32) and writes
-        // the rounded fp16 into its half of the packed result.  Three instructions per pair of elements (four in round 3, with
-        // the residuals as fp32 and a second v_cvt_pk) where the three-part bf16 split needs eleven.
+        // x = hi + lo + (<= 2^-22 |x|): hi = fp16(x) and lo = fp16(x - hi), both rounded to nearest, a PAIR of elements per
+        // v_cvt_pk_f16_f32; the residual x - hi is ONE v_fma_mix_f32 that reads hi straight from its half of the packed
+        // register (hi * -1 + x, exact: the difference of an fp32 and its 11-bit rounding fits fp32).  Four instructions per
+        // pair of elements where the three-part bf16 split needs eleven.  (v_fma_mixlo / mixhi_f16 would write the rounded
+        // residual directly, three instructions per pair -- but they issue at 8.5 cycles each where v_fma_mix_f32 takes 4.3
+        // and v_cvt_pk_f16_f32 4.0 with two waves on the SIMD: tools/valu_cost_probe.hip.)
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             u32x4 ph, pl;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float a = x[8 * s + 2 * j], b = x[8 * s + 2 * j + 1];
-                const unsigned hp = __builtin_bit_cast(unsigned, f16x2{(_Float16)a, (_Float16)b});
-                unsigned lp;
-                asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lp) : "v"(hp), "v"(a));
-                asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lp) : "v"(hp), "v"(b));
+                // (ASM_HI, the tanh kernels: left to itself hipcc folds tanh's last fma into the conversion -- v_fma_mixlo /
+                //  mixhi_f16, 8.5 cycles each, next to the fp32 fma it still needs for the residual.  Not for values that come
+                //  straight out of an MFMA, the linear kernels': hipcc does not count wait states for inline asm.)
+                unsigned hp;
+                if constexpr (ASM_HI)
+                    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hp) : "v"(a), "v"(b));
+                else
+                    hp = __builtin_bit_cast(unsigned, f16x2{(_Float16)a, (_Float16)b});
+                float ra, rb;
+                asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(hp), "v"(a));
+                asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(hp), "v"(b));
                 ph[j] = hp;
-                pl[j] = lp;
+                pl[j] = __builtin_bit_cast(unsigned, f16x2{(_Float16)ra, (_Float16)rb});
             }
             o.hi[s] = __builtin_bit_cast(f16x8, ph);
             o.lo[s] = __builtin_bit_cast(f16x8, pl);
@@ -247,11 +255,12 @@ constexpr int pipe_per(int valu, int mfma) { return (valu + mfma - 1) / mfma > 0
 #endif
 template <int P> struct MlpLaunch {
     static constexpr int kWaves = P == HTF_MLP_SPLIT16 ? HTF_MLP16_WAVES : 4; // per workgroup
-    static constexpr int kPerCU = 8 / kWaves;                                  // workgroups per CU: two waves per SIMD either way
+    static constexpr int kPerCU = kWaves >= 8 ? 1 : 8 / kWaves;               // workgroups per CU
+    static constexpr int kPerSimd = kWaves * kPerCU / 4;
 };
 
 template <bool TANH, typename IT, int P, bool VIRIAL>
-__global__ __launch_bounds__(64 * MlpLaunch<P>::kWaves, 2) void pair_mlp_kernel(const typename Vec4<IT>::type *__restrict__ nlist,
+__global__ __launch_bounds__(64 * MlpLaunch<P>::kWaves, MlpLaunch<P>::kPerSimd) void pair_mlp_kernel(const typename Vec4<IT>::type *__restrict__ nlist,
                                                           unsigned B, unsigned NN, void *__restrict__ force,
                                                           int out_f64, const float *__restrict__ images, float gap,
                                                           void *__restrict__ virial9) {
@@ -263,8 +272,8 @@ __global__ __launch_bounds__(64 * MlpLaunch<P>::kWaves, 2) void pair_mlp_kernel(
         float4 *dst = reinterpret_cast<float4 *>(lds);
         for (int i = threadIdx.x; i < I::Floats / 4; i += blockDim.x) dst[i] = src[i];
     }
-    __shared__ unsigned progress[8]; // tiles done, per wave (split16)
-    if (threadIdx.x < 8) progress[threadIdx.x] = 0u;
+    __shared__ unsigned progress[12]; // tiles done, per wave (split16)
+    if (threadIdx.x < 12) progress[threadIdx.x] = 0u;
     __syncthreads();
 
     const unsigned lane = threadIdx.x & 63u;
@@ -406,7 +415,7 @@ __global__ __launch_bounds__(64 * MlpLaunch<P>::kWaves, 2) void pair_mlp_kernel(
             continue;
         }
         if (count == 0u) break;
-        if constexpr (kWaves == 8) {
+        if constexpr (kWaves >= 8) {
             // Keep pace with the SIMD's other wave.  Between two waves of equal priority the issue arbiter prefers the OLDER
             // one: it runs at the speed it would have alone (9.4 k cycles per tile, latency-bound) and the younger one gets
             // what is left (17 k) -- with equal shares of the rows the older wave finished at 0.70 of the kernel and the
@@ -415,16 +424,21 @@ __global__ __launch_bounds__(64 * MlpLaunch<P>::kWaves, 2) void pair_mlp_kernel(
             tiles_done = __builtin_amdgcn_readfirstlane(tiles_done + 1u);
             // (inline asm: a compiler-visible LDS write would be ordered behind the chunk that is in flight to LDS)
             const unsigned pr0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned *)&progress[0];
-            unsigned seen;
-            asm volatile("ds_write_b32 %1, %2\n\tds_read_b32 %0, %3\n\ts_waitcnt lgkmcnt(0)"
-                         : "=&v"(seen)
-                         : "v"(pr0 + 4u * wid), "v"(tiles_done), "v"(pr0 + 4u * (wid ^ 4u))
+            const unsigned w1 = wid + 4u >= (unsigned)kWaves ? wid + 4u - kWaves : wid + 4u;
+            const unsigned w2 = wid + 8u >= (unsigned)kWaves ? wid + 8u - kWaves : wid + 8u;
+            unsigned seen, seen2;
+            asm volatile("ds_write_b32 %2, %3\n\tds_read_b32 %0, %4\n\tds_read_b32 %1, %5\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(seen), "=&v"(seen2)
+                         : "v"(pr0 + 4u * wid), "v"(tiles_done), "v"(pr0 + 4u * w1), "v"(pr0 + 4u * w2)
                          : "memory");
-            const unsigned other = __builtin_amdgcn_readfirstlane(seen);
-            if (tiles_done < other) // (scalar: s_setprio is not predicated by exec)
-                __builtin_amdgcn_s_setprio(2);
-            else
+            const unsigned o1 = __builtin_amdgcn_readfirstlane(seen), o2 = __builtin_amdgcn_readfirstlane(seen2);
+            const unsigned ahead = (tiles_done < o1 ? 1u : 0u) + (kWaves == 12 && tiles_done < o2 ? 1u : 0u); // partners ahead of me
+            if (ahead == 0u) // (scalar: s_setprio is not predicated by exec)
                 __builtin_amdgcn_s_setprio(0);
+            else if (ahead == 1u)
+                __builtin_amdgcn_s_setprio(1);
+            else
+                __builtin_amdgcn_s_setprio(2);
         }
         // ---- pop a tile: 32 pairs (the wave's last one may be partial: its empty lanes are padding)
         const unsigned avail = count < 32u ? count : 32u;
@@ -482,8 +496,8 @@ __global__ __launch_bounds__(64 * MlpLaunch<P>::kWaves, 2) void pair_mlp_kernel(
     }
             constexpr int kM = P == HTF_MLP_FP32 ? 16 : (P == HTF_MLP_BF16 ? 2 : (P == HTF_MLP_SPLIT ? 12 : 6)); // MFMAs per block
             constexpr int kAct = TANH ? 56 : 0;
-            // (split16: 8 v_cvt_pk; its 16 v_fma_mixlo/hi are inline asm, which the scheduler places by their dependences)
-            constexpr int kPrep = P == HTF_MLP_SPLIT ? 76 : (P == HTF_MLP_BF16 ? 8 : (P == HTF_MLP_SPLIT16 ? 8 : 0));
+            // (split16: the 8 v_cvt_pk of the lo halves; the hi halves' and the 16 v_fma_mix are inline asm, which the scheduler places by their dependences)
+            constexpr int kPrep = P == HTF_MLP_SPLIT ? 76 : (P == HTF_MLP_BF16 ? 8 : (P == HTF_MLP_SPLIT16 ? (TANH ? 8 : 16) : 0));
             constexpr int kBwd = TANH ? 16 : 0, kDot = 8;
 
             f32x16 a1[2], a2[2], dphi;
@@ -539,14 +553,14 @@ __global__ __launch_bounds__(64 * MlpLaunch<P>::kWaves, 2) void pair_mlp_kernel(
                 }
             } else {
             // ---- layer 1: a1^T[f][p] = b1 + W1^T phi^T
-            const BOp<P> phi_b = prep<P>(phi);
+            const BOp<P> phi_b = prep<P, TANH>(phi);
             a1[0] = load_tab(lds + I::TabB1, 0, h);
             mfma_blk<P>(a1[0], lds + I::L1, lane, phi_b);
             if constexpr (!PK) __builtin_amdgcn_sched_barrier(0);
             a1[1] = load_tab(lds + I::TabB1, 1, h);
             mfma_blk<P>(a1[1], lds + I::L1 + I::BS, lane, phi_b);
             act_tile<TANH, PK>(a1[0]);
-            const BOp<P> a1_b0 = prep<P>(a1[0]);
+            const BOp<P> a1_b0 = prep<P, TANH>(a1[0]);
             HTF_PIPE(kM, pipe_per(kAct + kPrep, kM));
             HTF_ESTAMP(2);
             // ---- layer 2
@@ -555,7 +569,7 @@ __global__ __launch_bounds__(64 * MlpLaunch<P>::kWaves, 2) void pair_mlp_kernel(
             mfma_blk<P>(a2[0], lds + I::L2 + (0 * 2 + 0) * I::BS, lane, a1_b0);
             mfma_blk<P>(a2[1], lds + I::L2 + (1 * 2 + 0) * I::BS, lane, a1_b0);
             act_tile<TANH, PK>(a1[1]);
-            const BOp<P> a1_b1 = prep<P>(a1[1]);
+            const BOp<P> a1_b1 = prep<P, TANH>(a1[1]);
             HTF_PIPE(2 * kM, pipe_per(kAct + kPrep, 2 * kM));
             HTF_ESTAMP(3);
             mfma_blk<P>(a2[0], lds + I::L2 + (0 * 2 + 1) * I::BS, lane, a1_b1);
@@ -568,7 +582,7 @@ __global__ __launch_bounds__(64 * MlpLaunch<P>::kWaves, 2) void pair_mlp_kernel(
                 dot_tile<PK>(up2, a2[0], w3);
                 act_bwd_tile<TANH, PK>(a2[0], w3);
             }
-            const BOp<P> dz2_b0 = prep<P>(a2[0]);
+            const BOp<P> dz2_b0 = prep<P, TANH>(a2[0]);
             HTF_PIPE(kM, pipe_per(kAct + kDot + kBwd + kPrep, kM));
             HTF_ESTAMP(4);
             // ---- backward 2: dh1^T = W2 dz2^T, then dz1 = dh1 * act'(z1) into a1
@@ -585,14 +599,14 @@ __global__ __launch_bounds__(64 * MlpLaunch<P>::kWaves, 2) void pair_mlp_kernel(
                 dot_tile<PK>(up2, a2[1], w3);
                 act_bwd_tile<TANH, PK>(a2[1], w3);
             }
-            const BOp<P> dz2_b1 = prep<P>(a2[1]);
+            const BOp<P> dz2_b1 = prep<P, TANH>(a2[1]);
             HTF_PIPE(2 * kM, pipe_per(kAct + kDot + kBwd + kPrep, 2 * kM));
             HTF_ESTAMP(5);
             mfma_blk<P>(d1[0], lds + I::B2 + (0 * 2 + 1) * I::BS, lane, dz2_b1);
             if constexpr (!PK) __builtin_amdgcn_sched_barrier(0);
             mfma_blk<P>(d1[1], lds + I::B2 + (1 * 2 + 1) * I::BS, lane, dz2_b1);
             act_bwd_tile<TANH, PK>(a1[0], d1[0]);
-            const BOp<P> dz1_b0 = prep<P>(a1[0]);
+            const BOp<P> dz1_b0 = prep<P, TANH>(a1[0]);
             HTF_PIPE(kM, pipe_per(kBwd + kPrep, kM));
             HTF_ESTAMP(6);
             // ---- backward 1: dphi^T = W1 dz1^T
@@ -600,7 +614,7 @@ __global__ __launch_bounds__(64 * MlpLaunch<P>::kWaves, 2) void pair_mlp_kernel(
             for (int v = 0; v < 16; ++v) dphi[v] = 0.f;
             mfma_blk<P>(dphi, lds + I::B1, lane, dz1_b0);
             act_bwd_tile<TANH, PK>(a1[1], d1[1]);
-            const BOp<P> dz1_b1 = prep<P>(a1[1]);
+            const BOp<P> dz1_b1 = prep<P, TANH>(a1[1]);
             HTF_PIPE(kM, pipe_per(kBwd + kPrep, kM));
             mfma_blk<P>(dphi, lds + I::B1 + I::BS, lane, dz1_b1);
             if constexpr (!PK) __builtin_amdgcn_sched_barrier(0);

@@ -1,0 +1,101 @@
+// What does one SIMD need for the pair-MLP evaluator's instruction mix, with nothing in the way?  One CU, W waves per SIMD,
+// each wave running `iters` "tiles" of 72 groups: [one v_mfma_f32_32x32x16_f16] + [6 v_fma_f32, 1 v_cvt_pk_f16_f32,
+// 2 v_fma_mixlo_f16, 1 v_exp_f32, 1 v_rcp_f32] -- the split16 tile's 72 MFMAs, ~650 plain and 144 transcendental vector
+// instructions, all independent (four accumulator chains, sixteen rotating vector registers), no LDS, no memory.
+//   build: hipcc -O3 --offload-arch=gfx950 tools/mlp_mix_probe.hip -o tools/mlp_mix_probe
+// Prints s_memtime ticks per tile per SIMD (wall ticks of the slowest wave / (iters * W)).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+
+// MODE bits: 1 = MFMAs, 2 = plain vector instructions, 4 = transcendentals
+template <int MODE, int CHAIN>
+__global__ __launch_bounds__(768) void mix_kernel(unsigned long long *out, int iters, float seed) {
+    float f[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) f[i] = seed + 0.001f * (float)(threadIdx.x + i);
+    f16x8 a, b;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(seed * 0.01f); b[i] = (_Float16)(seed * 0.02f); }
+    f32x16 acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
+    unsigned pk = 0;
+    __syncthreads();
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int g = 0; g < 72; ++g) {
+            // CHAIN 0: consecutive MFMAs rotate over four accumulators; 1: six in a row on the same one (the kernel's operand-block
+            // chains); 2: as 1, the twelve MFMAs of two chains first and their groups' vector instructions behind them
+            if (MODE & 1) {
+                if (CHAIN == 0) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[g & 3]) : "v"(a), "v"(b));
+                if (CHAIN == 1) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[(g / 6) & 3]) : "v"(a), "v"(b));
+                if (CHAIN == 2 && g % 12 == 0) {
+#pragma unroll
+                    for (int q = 0; q < 12; ++q) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[(q / 6 + g / 12 * 2) & 3]) : "v"(a), "v"(b));
+                }
+            }
+            if (MODE & 2) {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(f[(g * 11 + j) & 15]) : "v"(seed));
+                asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(pk) : "v"(f[(g + 6) & 15]), "v"(f[(g + 7) & 15]));
+                asm volatile("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(pk) : "v"(pk), "v"(f[(g + 8) & 15]));
+                asm volatile("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(pk) : "v"(pk), "v"(f[(g + 9) & 15]));
+            }
+            if (MODE & 4) {
+                asm volatile("v_exp_f32 %0, %0" : "+v"(f[(g * 2 + 10) & 15]));
+                asm volatile("v_rcp_f32 %0, %0" : "+v"(f[(g * 2 + 11) & 15]));
+            }
+        }
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = (float)pk;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += f[i];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) s += acc[c][0] + acc[c][7];
+    if (s == 1.2345f) out[63] = 0;
+    if ((threadIdx.x & 63) == 0) {
+        out[2 * (threadIdx.x >> 6)] = t0;
+        out[2 * (threadIdx.x >> 6) + 1] = t1;
+    }
+}
+
+template <int MODE, int CHAIN = 0>
+static void run(const char *what, unsigned long long *d) {
+    const int iters = 200;
+    for (int W = 1; W <= 3; ++W) {
+        unsigned long long h[64];
+        for (int r = 0; r < 2; ++r) {
+            hipLaunchKernelGGL((mix_kernel<MODE, CHAIN>), dim3(1), dim3(256 * W), 0, 0, d, iters, 1.25f);
+            hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+        }
+        unsigned long long lo = ~0ull, hi = 0;
+        for (int w = 0; w < 4 * W; ++w) {
+            lo = h[2 * w] < lo ? h[2 * w] : lo;
+            hi = h[2 * w + 1] > hi ? h[2 * w + 1] : hi;
+        }
+        printf("%-44s W=%d  %8.0f ticks per tile per SIMD\n", what, W, (double)(hi - lo) / (double)(iters * W));
+    }
+}
+
+int main() {
+    unsigned long long *d;
+    hipMalloc(&d, 64 * 8);
+    run<1>("72 MFMA", d);
+    run<2>("648 plain", d);
+    run<4>("144 transcendental", d);
+    run<6>("648 plain + 144 transcendental", d);
+    run<3>("72 MFMA + 648 plain", d);
+    run<5>("72 MFMA + 144 transcendental", d);
+    run<7>("72 MFMA + 648 plain + 144 transcendental", d);
+    run<1, 1>("72 MFMA in chains of 6", d);
+    run<7, 1>("72 MFMA (chains of 6) + 648 + 144", d);
+    run<7, 2>("72 MFMA (12 at once) + 648 + 144", d);
+    return 0;
+}
