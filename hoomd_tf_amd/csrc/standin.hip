@@ -258,6 +258,178 @@ __global__ __launch_bounds__(256) void build_nlist_kernel(const typename Vec4<T>
 }
 
 
+// One WAVE per cell (round 4).  The kernel above walks, for each of a group's particles, every stencil row as its own run of
+// G-lane trips: a row of the fine grid holds ~21 candidates, so a third of the lanes of its last trip idle, and the per-row
+// bookkeeping (range entry, image shift, trip setup: ~55 instructions) costs as much as two of its three trips -- ~530
+// instructions per particle at C3.  All particles of a cell see the SAME candidates.  Here a wave takes a cell: its <= 50
+// candidate runs (stencil row x {main, wrapped in x}) sit one per lane, an exclusive scan of their lengths numbers the
+// cell's candidates 0..total-1 in walk order, and each trip of 64 finds its candidates' runs by a six-step binary search
+// over the lanes (ds_bpermute) -- full lanes whatever the row lengths, no per-row work.  The trip's candidates are loaded
+// once, moved to the periodic image their run is seen through, and tested against every particle of the cell (up to eight
+// at a time, their coordinates broadcast into registers once per cell): ~16 instructions per 64 tests against ~38.
+// A particle's neighbors come out in the order the walk above gives them (runs in table order, candidates in cell-sorted
+// order), so the list is the same up to the rounding of a shifted image (the shift is applied to the candidate here, to
+// the particle there).
+__device__ __forceinline__ void set_tag(float &w, unsigned tag) { w = __uint_as_float(tag); }
+__device__ __forceinline__ void set_tag(double &w, unsigned tag) { w = __longlong_as_double((long long)tag); }
+__device__ __forceinline__ float bcast_lane_t(float v, unsigned lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (int)lane));
+}
+__device__ __forceinline__ double bcast_lane_t(double v, unsigned lane) {
+    const long long q = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)q, (int)lane);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(q >> 32), (int)lane);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ unsigned bperm_u(unsigned lane_idx, unsigned v) {
+    return (unsigned)__builtin_amdgcn_ds_bpermute((int)(lane_idx << 2), (int)v);
+}
+__device__ __forceinline__ float bperm_t(unsigned lane_idx, float v) { return __uint_as_float(bperm_u(lane_idx, __float_as_uint(v))); }
+__device__ __forceinline__ double bperm_t(unsigned lane_idx, double v) {
+    const unsigned long long q = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = bperm_u(lane_idx, (unsigned)q), hi = bperm_u(lane_idx, (unsigned)(q >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// all lanes hold the (wave-uniform) value in a VECTOR register: a vector instruction with a scalar source issues at about
+// half the rate of one without (tools/valu_cost_probe.hip)
+__device__ __forceinline__ float in_vgpr(float s) {
+    float v;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(s));
+    return v;
+}
+__device__ __forceinline__ double in_vgpr(double s) {
+    const unsigned long long q = (unsigned long long)__double_as_longlong(s);
+    const float lo = in_vgpr(__uint_as_float((unsigned)q)), hi = in_vgpr(__uint_as_float((unsigned)(q >> 32)));
+    return __longlong_as_double((long long)(((unsigned long long)__float_as_uint(hi) << 32) | __float_as_uint(lo)));
+}
+
+constexpr int kCellBatch = 8; // particles of a cell tested per pass over its candidates (a fine-grid cell holds ~4)
+
+template <typename T, bool SHIFT>
+__global__ __launch_bounds__(256) void build_nlist_cells_kernel(const typename Vec4<T>::type *__restrict__ pos_sorted, unsigned N,
+                                                                SBox<T> b, T rl2, unsigned ncell, int nrow,
+                                                                const unsigned *__restrict__ cell_start, unsigned pitch,
+                                                                int type_split, unsigned *__restrict__ n_neigh,
+                                                                unsigned *__restrict__ head_list, unsigned *__restrict__ nlist,
+                                                                unsigned *__restrict__ max_neigh,
+                                                                const uint4 *__restrict__ ranges, Gate gate) {
+    if (gate.closed()) return;
+    using V4 = typename Vec4<T>::type;
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned c = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (c >= ncell) return;
+    const unsigned p_begin = cell_start[c], p_end = cell_start[c + 1];
+    if (p_begin == p_end) return;
+
+    // ---- the cell's candidate runs, one per lane: lane d = 2 row + (0: main run, 1: the run that wraps around the box in x)
+    unsigned beg = 0u, len = 0u;
+    T shx = (T)0, shy = (T)0, shz = (T)0; // what comes off a candidate of this run (the image the cell sees it through)
+    if (lane < 2u * (unsigned)nrow) {
+        const uint4 rg = ranges[(size_t)c * nrow + (lane >> 1)];
+        const bool wrapped = (lane & 1u) != 0u;
+        beg = wrapped ? rg.z : rg.x;
+        len = (wrapped ? rg.w : rg.y) & kRangeLenMask;
+        if (SHIFT) {
+            const unsigned wy_ = (rg.y >> kRangeWrapShift) & 3u, wz_ = rg.y >> (kRangeWrapShift + 2), wx_ = rg.w >> kRangeWrapShift;
+            shy = wy_ == 1u ? b.L[1] : (wy_ == 2u ? -b.L[1] : (T)0);
+            shz = wz_ == 1u ? b.L[2] : (wz_ == 2u ? -b.L[2] : (T)0);
+            shx = !wrapped ? (T)0 : (wx_ == 1u ? b.L[0] : -b.L[0]);
+        }
+    }
+    // exclusive scan of the lengths over the lanes (Hillis-Steele through ds_bpermute: six steps, once per cell)
+    unsigned incl = len;
+#pragma unroll
+    for (unsigned d = 1; d < 64u; d <<= 1) {
+        const unsigned up = bperm_u(lane >= d ? lane - d : lane, incl);
+        incl += lane >= d ? up : 0u;
+    }
+    const unsigned start = incl - len; // non-decreasing over the lanes; == total behind the last run
+    const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+    const bool any_shift = SHIFT && ballot64(len != 0u && (shx != (T)0 || shy != (T)0 || shz != (T)0)) != 0ull;
+
+    for (unsigned pb = p_begin; pb < p_end; pb += kCellBatch) {
+        const unsigned np = min(p_end - pb, (unsigned)kCellBatch);
+        // the batch's particles: lane p loads particle p, then everything about it becomes wave-uniform
+        V4 me;
+        me.x = me.y = me.z = (T)0;
+        set_tag(me.w, ~0u);
+        if (lane < np) me = pos_sorted[pb + lane];
+        const unsigned my_tag = (unsigned)scalar_as_int(me.w);
+        unsigned tag_p[kCellBatch], count[kCellBatch];
+        T px[kCellBatch], py[kCellBatch], pz[kCellBatch];
+        unsigned *row_p[kCellBatch];
+#pragma unroll
+        for (int p = 0; p < kCellBatch; ++p) {
+            tag_p[p] = ~0u; // (past the batch: index >= N, skipped like a ghost)
+            px[p] = py[p] = pz[p] = (T)0;
+            count[p] = 0u;
+            row_p[p] = nlist;
+            if ((unsigned)p < np) { // wave-uniform
+                tag_p[p] = (unsigned)__builtin_amdgcn_readlane((int)my_tag, p);
+                px[p] = in_vgpr(bcast_lane_t(me.x, p));
+                py[p] = in_vgpr(bcast_lane_t(me.y, p));
+                pz[p] = in_vgpr(bcast_lane_t(me.z, p));
+                row_p[p] = nlist + (size_t)(tag_p[p] & ~kTagSide) * pitch;
+            }
+        }
+        for (unsigned q0 = 0; q0 < total; q0 += 64u) {
+            // ---- which run does candidate q belong to: the last lane whose start is <= q
+            const unsigned q = q0 + lane;
+            unsigned at = 0u;
+#pragma unroll
+            for (unsigned step = 32u; step != 0u; step >>= 1) {
+                const unsigned t = at + step;
+                at = bperm_u(t, start) <= q ? t : at;
+            }
+            const bool valid = q < total;
+            const unsigned src = bperm_u(at, beg) + (q - bperm_u(at, start));
+            V4 pk;
+            pk.x = pk.y = pk.z = (T)0;
+            set_tag(pk.w, ~0u);
+            if (valid) pk = pos_sorted[src];
+            if (any_shift) { // wave-uniform: cells within two of a periodic face
+                pk.x -= bperm_t(at, shx);
+                pk.y -= bperm_t(at, shy);
+                pk.z -= bperm_t(at, shz);
+            }
+            const unsigned tag = (unsigned)scalar_as_int(pk.w);
+            const unsigned k = tag & ~kTagSide;
+            const unsigned long long vmask = ballot64(valid);
+#pragma unroll
+            for (int p = 0; p < kCellBatch; ++p) {
+                const unsigned i = tag_p[p] & ~kTagSide;
+                if (i >= N) continue; // wave-uniform: past the batch, or a ghost (candidates for others, no row of its own)
+                T ddx = pk.x - px[p], ddy = pk.y - py[p], ddz = pk.z - pz[p];
+                if (!SHIFT) {
+                    ddx = mimg<T>(ddx, b.L[0], b.Linv[0], b.periodic[0]);
+                    ddy = mimg<T>(ddy, b.L[1], b.Linv[1], b.periodic[1]);
+                    ddz = mimg<T>(ddz, b.L[2], b.Linv[2], b.periodic[2]);
+                }
+                // (no branch: the verdict is the AND of single-compare wave masks, as in the walk above)
+                unsigned long long hits = vmask & ballot64(k != i) & ballot64(ddx * ddx + ddy * ddy + ddz * ddz <= rl2);
+                if (type_split >= 0) { // wave-uniform
+                    asm volatile("" ::: "memory");
+                    hits &= ballot64(((tag ^ tag_p[p]) & kTagSide) == 0u);
+                }
+                const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(hits >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hits, count[p]));
+                if (__builtin_amdgcn_inverse_ballot_w64(hits) && rank < pitch) row_p[p][rank] = k;
+                count[p] += (unsigned)__builtin_popcountll(hits);
+            }
+        }
+        unsigned cnt = 0u;
+#pragma unroll
+        for (int p = 0; p < kCellBatch; ++p) cnt = lane == (unsigned)p ? count[p] : cnt;
+        if (lane < np) {
+            const unsigned i = my_tag & ~kTagSide;
+            if (i < N) {
+                n_neigh[i] = cnt < pitch ? cnt : pitch;
+                head_list[i] = i * pitch;
+                if (cnt > *(volatile unsigned *)max_neigh) atomicMax(max_neigh, cnt);
+            }
+        }
+    }
+}
+
 } // namespace htf
 
 using namespace htf;
@@ -287,9 +459,6 @@ extern "C" int htfs_max_displacement2(const void *d_pos, const void *d_ref, int 
 }
 
 namespace htf {
-__device__ __forceinline__ void set_tag(float &w, unsigned tag) { w = __uint_as_float(tag); }
-__device__ __forceinline__ void set_tag(double &w, unsigned tag) { w = __longlong_as_double((long long)tag); }
-
 template <typename V, bool TAG>
 __global__ void gather4_kernel(V *__restrict__ dest, const V *__restrict__ src, const int *__restrict__ order, unsigned n,
                                int type_split, Gate gate) {
@@ -687,17 +856,35 @@ extern "C" int htfs_build_nlist(const void *d_pos, const void *d_pos_sorted, int
                        (const V4 *)d_pos, (const V4 *)d_pos_sorted, N, make_sbox<T>(box), (T)(r_list * r_list), ncell3[0],  \
                        ncell3[1], ncell3[2], stencil3[0], stencil3[1], stencil3[2], d_cell_start, pitch,      \
                        type_split, d_n_neigh, d_head_list, d_nlist, d_max_neigh, (const uint4 *)d_ranges, g_gate)
+#define HTFS_NLC(T, V4)                                                                                                \
+    if (shift) HTFS_NLC_(T, V4, true); else HTFS_NLC_(T, V4, false)
+#define HTFS_NLC_(T, V4, S)                                                                                            \
+    hipLaunchKernelGGL((build_nlist_cells_kernel<T, S>), dim3((ncell + 3) / 4), dim3(256), 0, (hipStream_t)stream,         \
+                       (const V4 *)d_pos_sorted, N, make_sbox<T>(box), (T)(r_list * r_list), ncell, (int)nrow, d_cell_start, pitch, \
+                       type_split, d_n_neigh, d_head_list, d_nlist, d_max_neigh, (const uint4 *)d_ranges, g_gate)
     // with >= 7 cells along every periodic axis a stencil (<= 2 cells each way, plus a particle's place inside its own cell)
     // never reaches half a box length: the near image of a candidate follows from its cell alone
     bool shift = true;
     for (int d = 0; d < 3; ++d) shift = shift && (!box->periodic[d] || ncell3[d] >= 7);
-    if (dtype == HTF_F32) {
+    // one wave per cell where cells hold a few particles each (any binned system: ~4 on the fine grid, ~30 on the coarse one);
+    // a grid with fewer cells than a wave per SIMD keeps the walk per particle
+#ifdef HTF_AB_VARIANTS
+    static const bool per_particle = std::getenv("HTFS_NLIST_PER_PARTICLE") != nullptr;
+#else
+    constexpr bool per_particle = false;
+#endif
+    const bool by_cell = !per_particle && ncell >= 1024u;
+    if (by_cell) {
+        if (dtype == HTF_F32) { HTFS_NLC(float, float4); } else { HTFS_NLC(double, double4); }
+    } else if (dtype == HTF_F32) {
         if (fine) { HTFS_NL(float, float4, 8); } else { HTFS_NL(float, float4, 16); }
     } else {
         if (fine) { HTFS_NL(double, double4, 8); } else { HTFS_NL(double, double4, 16); }
     }
 #undef HTFS_NL
 #undef HTFS_NL_
+#undef HTFS_NLC
+#undef HTFS_NLC_
     return check_launch("build_nlist_kernel");
 }
 
