@@ -431,6 +431,8 @@ __device__ __forceinline__ void fused_rows_group_tails(
     // tilt and non-periodic cases (12 instructions), the live-entry mask of a trip from scalar arithmetic, and the evaluation
     // WITHOUT a branch -- a dropped candidate is evaluated at x = 1e18, where s^6 underflows and energy and force are
     // exact zeros (pair_eval_if) -- so that only the tensor store is predicated.
+    // (the box lengths in vector registers -- a vector instruction with a scalar source issues at half the rate when two or more
+    //  waves share the SIMD, tools/valu_cost_probe.hip -- bought nothing here: 55.4 / 37.5 us against 55.4 / 37.8, DESIGN A.0)
     auto pair_vec = [&](const PV &pk, const PV &pc, PT &dx, PT &dy, PT &dz) { return pair_vector_simple<PT>(pk, pc, box, dx, dy, dz); };
 #pragma unroll
     for (int r = 0; r < R; ++r) {

@@ -93,6 +93,20 @@ __device__ __forceinline__ float wave_sum4(float a, float b, float c, float d) {
 // the wave ballot of a bool as the compare mask itself (__ballot(int) re-materialises the predicate: two VALU instructions)
 __device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
+// A wave-uniform value held in a VECTOR register by every lane.  hipcc keeps uniform values in scalar registers, and a vector
+// instruction with a scalar source -- a constant multiplier, a mask, a base address -- issues at 4.1-4.4 cycles with two or more
+// waves on the SIMD where one with vector (or inline-constant) sources takes 2.2-2.5: tools/valu_cost_probe.hip.
+__device__ __forceinline__ float in_vgpr(float s) {
+    float v;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(s));
+    return v;
+}
+__device__ __forceinline__ double in_vgpr(double s) {
+    const unsigned long long q = (unsigned long long)__double_as_longlong(s);
+    const float lo = in_vgpr(__uint_as_float((unsigned)q)), hi = in_vgpr(__uint_as_float((unsigned)(q >> 32)));
+    return __longlong_as_double((long long)(((unsigned long long)__float_as_uint(hi) << 32) | __float_as_uint(lo)));
+}
+
 template <int G>
 __device__ __forceinline__ float group_sum(float v) {
     static_assert(G >= 1 && G <= 64 && (G & (G - 1)) == 0, "G must be a power of two <= 64");

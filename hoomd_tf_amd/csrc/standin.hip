@@ -290,19 +290,6 @@ __device__ __forceinline__ double bperm_t(unsigned lane_idx, double v) {
     const unsigned lo = bperm_u(lane_idx, (unsigned)q), hi = bperm_u(lane_idx, (unsigned)(q >> 32));
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
-// all lanes hold the (wave-uniform) value in a VECTOR register: a vector instruction with a scalar source issues at about
-// half the rate of one without (tools/valu_cost_probe.hip)
-__device__ __forceinline__ float in_vgpr(float s) {
-    float v;
-    asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(s));
-    return v;
-}
-__device__ __forceinline__ double in_vgpr(double s) {
-    const unsigned long long q = (unsigned long long)__double_as_longlong(s);
-    const float lo = in_vgpr(__uint_as_float((unsigned)q)), hi = in_vgpr(__uint_as_float((unsigned)(q >> 32)));
-    return __longlong_as_double((long long)(((unsigned long long)__float_as_uint(hi) << 32) | __float_as_uint(lo)));
-}
-
 constexpr int kCellBatch = 8; // particles of a cell tested per pass over its candidates (a fine-grid cell holds ~4)
 
 template <typename T, bool SHIFT>
