@@ -486,18 +486,17 @@ __global__ __launch_bounds__(64 * MlpLaunch<P>::kWaves, MlpLaunch<P>::kPerSimd) 
             // into its own phase otherwise, and with two or three waves per SIMD the phases of different waves
             // rarely complement each other.  HTF_PIPE pins the interleave (one MFMA, then `per` VALU
             // instructions, `n` times) inside a region closed by a full scheduling barrier.
-#ifdef HTF_MLP_NOPIPE
-#define HTF_PIPE(n, per)
-#else
+            // (split16 since round 4: with the SIMD's two waves keeping pace -- see the priority rule above -- hipcc's own order
+            //  inside a block is as good: 1.101 ms against 1.109 with the pinned interleave on tools/mlp_ab.py; the regions stay
+            //  for the bf16-typed precisions)
 #define HTF_PIPE(n, per)                                                                                               \
-    if constexpr (!PK) {                                                                                               \
+    if constexpr (!PK && P != HTF_MLP_SPLIT16) {                                                                                               \
         _Pragma("unroll") for (int q_ = 0; q_ < (n); ++q_) {                                                           \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                         \
             __builtin_amdgcn_sched_group_barrier(0x002, (per), 0);                                                     \
         }                                                                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
     }
-#endif
             constexpr int kM = P == HTF_MLP_FP32 ? 16 : (P == HTF_MLP_BF16 ? 2 : (P == HTF_MLP_SPLIT ? 12 : 6)); // MFMAs per block
             constexpr int kAct = TANH ? 56 : 0;
             // (split16: the 8 v_cvt_pk of the lo halves; the hi halves' and the 16 v_fma_mix are inline asm, which the scheduler places by their dependences)

@@ -855,12 +855,12 @@ extern "C" int htfs_build_nlist(const void *d_pos, const void *d_pos_sorted, int
     for (int d = 0; d < 3; ++d) shift = shift && (!box->periodic[d] || ncell3[d] >= 7);
     // one wave per cell where cells hold a few particles each (any binned system: ~4 on the fine grid, ~30 on the coarse one);
     // a grid with fewer cells than a wave per SIMD keeps the walk per particle
-#ifdef HTF_AB_VARIANTS
-    static const bool per_particle = std::getenv("HTFS_NLIST_PER_PARTICLE") != nullptr;
+#ifdef HTF_AB_VARIANTS // (either kernel on any grid: tests/test_gpu_standin.py runs the random boxes through both)
+    static const bool per_particle = std::getenv("HTFS_NLIST_PER_PARTICLE") != nullptr, per_cell = std::getenv("HTFS_NLIST_PER_CELL") != nullptr;
 #else
-    constexpr bool per_particle = false;
+    constexpr bool per_particle = false, per_cell = false;
 #endif
-    const bool by_cell = !per_particle && ncell >= 1024u;
+    const bool by_cell = per_cell || (!per_particle && ncell >= 1024u);
     if (by_cell) {
         if (dtype == HTF_F32) { HTFS_NLC(float, float4); } else { HTFS_NLC(double, double4); }
     } else if (dtype == HTF_F32) {

@@ -319,6 +319,23 @@ def test_cell_nlist_random_boxes_match_brute_force(htf, cuda, seed):
     assert all(i not in set(g.tolist()) for i, g in enumerate(got[:200]))
 
 
+@pytest.mark.parametrize("kernel", ["HTFS_NLIST_PER_CELL", "HTFS_NLIST_PER_PARTICLE"])
+def test_random_boxes_through_either_search_kernel(kernel):
+    """The stand-in picks its search kernel by grid size (one wave per cell from 1 024 cells, the per-particle walk below): the
+    random boxes above -- both precisions, type splits, axes with fewer than seven cells -- and the lattice cases through EACH
+    kernel, forced in a child process on the variants build (the switch exists there only)."""
+    import os
+    import subprocess
+    import sys
+    from helpers import variants_env
+    env = variants_env(**{kernel: "1"})
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        "-k", "random_boxes_match_brute_force or cell_nlist_matches_brute_force or small_pitch_regrow"],
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
 def test_slab_plan_kernels_match_torch(htf, cuda):
     """The migration / ghost plan of a decomposed rebuild on the device (csrc/standin.hip: slab_classify_kernel,
     htfs_key_sort16, segment_copy_kernel) against plain torch ops on the same data, at a size where one key holds tens of
