@@ -71,7 +71,13 @@ __device__ __forceinline__ void act_tile(f32x16 &a) {
         // bf16-typed images carry 2 log2(e) W and 2 log2(e) b in their forward blocks (mlp_refresh_kernel):
         // the accumulator IS the exponent, one multiply per element less
 #pragma unroll
-        for (int v = 0; v < 16; ++v) a[v] = fmaf(__builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(a[v]) + 1.0f), -2.0f, 1.0f);
+        for (int v = 0; v < 16; ++v) {
+            a[v] = fmaf(__builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(a[v]) + 1.0f), -2.0f, 1.0f);
+            // (an empty asm the value passes through: hipcc otherwise folds this fma into the fp16 conversion of the split16
+            //  operand split -- v_fma_mixlo / mixhi_f16, 8.5 cycles each, next to the fp32 fma it still needs for the residual:
+            //  tools/valu_cost_probe.hip.  No instruction, so nothing for the hazard bookkeeping to miss.)
+            asm("" : "+v"(a[v]));
+        }
     }
 }
 
@@ -91,6 +97,7 @@ __device__ __forceinline__ void act_bwd_tile(f32x16 &h_inout, const f32x16 &g) {
         for (int v = 0; v < 16; ++v) {
             const float hv = h_inout[v];
             h_inout[v] = TANH ? g[v] * fmaf(-hv, hv, 1.0f) : g[v];
+            if constexpr (TANH) asm("" : "+v"(h_inout[v])); // (as in act_tile: keeps the multiply out of the conversion)
         }
     }
 }
@@ -126,7 +133,7 @@ template <> struct BOp<HTF_MLP_SPLIT16> { f16x8 hi[2], lo[2]; };
 // Split operands: x = hi + mid + lo EXACTLY, each part 8 significand bits (bf16's), by masking --
 // hi = top 16 bits of x, mid = top 16 bits of x - hi, lo = x - hi - mid (at most 8 bits are left,
 // so its low 16 bits are zero).  v_perm_b32 packs two upper halves into one register.
-template <int P, bool ASM_HI = false>
+template <int P>
 __device__ __forceinline__ BOp<P> prep(const f32x16 &x) {
     BOp<P> o;
     if constexpr (P == HTF_MLP_FP32) {
@@ -149,14 +156,9 @@ __device__ __forceinline__ BOp<P> prep(const f32x16 &x) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float a = x[8 * s + 2 * j], b = x[8 * s + 2 * j + 1];
-                // (ASM_HI, the tanh kernels: left to itself hipcc folds tanh's last fma into the conversion -- v_fma_mixlo /
-                //  mixhi_f16, 8.5 cycles each, next to the fp32 fma it still needs for the residual.  Not for values that come
-                //  straight out of an MFMA, the linear kernels': hipcc does not count wait states for inline asm.)
-                unsigned hp;
-                if constexpr (ASM_HI)
-                    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hp) : "v"(a), "v"(b));
-                else
-                    hp = __builtin_bit_cast(unsigned, f16x2{(_Float16)a, (_Float16)b});
+                // (compiler-visible on purpose: the packed halves are MFMA operands, and hipcc counts the wait states between a
+                //  vector write and the MFMA that reads it for its own instructions only, not for inline asm)
+                const unsigned hp = __builtin_bit_cast(unsigned, f16x2{(_Float16)a, (_Float16)b});
                 float ra, rb;
                 asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(hp), "v"(a));
                 asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(hp), "v"(b));
@@ -499,8 +501,8 @@ __global__ __launch_bounds__(64 * MlpLaunch<P>::kWaves, MlpLaunch<P>::kPerSimd) 
     }
             constexpr int kM = P == HTF_MLP_FP32 ? 16 : (P == HTF_MLP_BF16 ? 2 : (P == HTF_MLP_SPLIT ? 12 : 6)); // MFMAs per block
             constexpr int kAct = TANH ? 56 : 0;
-            // (split16: the 8 v_cvt_pk of the lo halves; the hi halves' and the 16 v_fma_mix are inline asm, which the scheduler places by their dependences)
-            constexpr int kPrep = P == HTF_MLP_SPLIT ? 76 : (P == HTF_MLP_BF16 ? 8 : (P == HTF_MLP_SPLIT16 ? (TANH ? 8 : 16) : 0));
+            // (split16: 16 v_cvt_pk; its 16 v_fma_mix are inline asm, which the scheduler places by their dependences)
+            constexpr int kPrep = P == HTF_MLP_SPLIT ? 76 : (P == HTF_MLP_BF16 ? 8 : (P == HTF_MLP_SPLIT16 ? 16 : 0));
             constexpr int kBwd = TANH ? 16 : 0, kDot = 8;
 
             f32x16 a1[2], a2[2], dphi;
@@ -556,14 +558,14 @@ __global__ __launch_bounds__(64 * MlpLaunch<P>::kWaves, MlpLaunch<P>::kPerSimd) 
                 }
             } else {
             // ---- layer 1: a1^T[f][p] = b1 + W1^T phi^T
-            const BOp<P> phi_b = prep<P, TANH>(phi);
+            const BOp<P> phi_b = prep<P>(phi);
             a1[0] = load_tab(lds + I::TabB1, 0, h);
             mfma_blk<P>(a1[0], lds + I::L1, lane, phi_b);
             if constexpr (!PK) __builtin_amdgcn_sched_barrier(0);
             a1[1] = load_tab(lds + I::TabB1, 1, h);
             mfma_blk<P>(a1[1], lds + I::L1 + I::BS, lane, phi_b);
             act_tile<TANH, PK>(a1[0]);
-            const BOp<P> a1_b0 = prep<P, TANH>(a1[0]);
+            const BOp<P> a1_b0 = prep<P>(a1[0]);
             HTF_PIPE(kM, pipe_per(kAct + kPrep, kM));
             HTF_ESTAMP(2);
             // ---- layer 2
@@ -572,7 +574,7 @@ __global__ __launch_bounds__(64 * MlpLaunch<P>::kWaves, MlpLaunch<P>::kPerSimd) 
             mfma_blk<P>(a2[0], lds + I::L2 + (0 * 2 + 0) * I::BS, lane, a1_b0);
             mfma_blk<P>(a2[1], lds + I::L2 + (1 * 2 + 0) * I::BS, lane, a1_b0);
             act_tile<TANH, PK>(a1[1]);
-            const BOp<P> a1_b1 = prep<P, TANH>(a1[1]);
+            const BOp<P> a1_b1 = prep<P>(a1[1]);
             HTF_PIPE(2 * kM, pipe_per(kAct + kPrep, 2 * kM));
             HTF_ESTAMP(3);
             mfma_blk<P>(a2[0], lds + I::L2 + (0 * 2 + 1) * I::BS, lane, a1_b1);
@@ -585,7 +587,7 @@ __global__ __launch_bounds__(64 * MlpLaunch<P>::kWaves, MlpLaunch<P>::kPerSimd) 
                 dot_tile<PK>(up2, a2[0], w3);
                 act_bwd_tile<TANH, PK>(a2[0], w3);
             }
-            const BOp<P> dz2_b0 = prep<P, TANH>(a2[0]);
+            const BOp<P> dz2_b0 = prep<P>(a2[0]);
             HTF_PIPE(kM, pipe_per(kAct + kDot + kBwd + kPrep, kM));
             HTF_ESTAMP(4);
             // ---- backward 2: dh1^T = W2 dz2^T, then dz1 = dh1 * act'(z1) into a1
@@ -602,14 +604,14 @@ __global__ __launch_bounds__(64 * MlpLaunch<P>::kWaves, MlpLaunch<P>::kPerSimd) 
                 dot_tile<PK>(up2, a2[1], w3);
                 act_bwd_tile<TANH, PK>(a2[1], w3);
             }
-            const BOp<P> dz2_b1 = prep<P, TANH>(a2[1]);
+            const BOp<P> dz2_b1 = prep<P>(a2[1]);
             HTF_PIPE(2 * kM, pipe_per(kAct + kDot + kBwd + kPrep, 2 * kM));
             HTF_ESTAMP(5);
             mfma_blk<P>(d1[0], lds + I::B2 + (0 * 2 + 1) * I::BS, lane, dz2_b1);
             if constexpr (!PK) __builtin_amdgcn_sched_barrier(0);
             mfma_blk<P>(d1[1], lds + I::B2 + (1 * 2 + 1) * I::BS, lane, dz2_b1);
             act_bwd_tile<TANH, PK>(a1[0], d1[0]);
-            const BOp<P> dz1_b0 = prep<P, TANH>(a1[0]);
+            const BOp<P> dz1_b0 = prep<P>(a1[0]);
             HTF_PIPE(kM, pipe_per(kBwd + kPrep, kM));
             HTF_ESTAMP(6);
             // ---- backward 1: dphi^T = W1 dz1^T
@@ -617,7 +619,7 @@ __global__ __launch_bounds__(64 * MlpLaunch<P>::kWaves, MlpLaunch<P>::kPerSimd) 
             for (int v = 0; v < 16; ++v) dphi[v] = 0.f;
             mfma_blk<P>(dphi, lds + I::B1, lane, dz1_b0);
             act_bwd_tile<TANH, PK>(a1[1], d1[1]);
-            const BOp<P> dz1_b1 = prep<P, TANH>(a1[1]);
+            const BOp<P> dz1_b1 = prep<P>(a1[1]);
             HTF_PIPE(kM, pipe_per(kBwd + kPrep, kM));
             mfma_blk<P>(dphi, lds + I::B1 + I::BS, lane, dz1_b1);
             if constexpr (!PK) __builtin_amdgcn_sched_barrier(0);
