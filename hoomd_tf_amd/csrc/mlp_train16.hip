@@ -46,7 +46,11 @@ __device__ __forceinline__ Op16 split16(const f32x16 &x) {
 template <bool TANH>
 __device__ __forceinline__ float act_scaled(float a) {
     if constexpr (!TANH) return a;
-    return fmaf(__builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(a) + 1.0f), -2.0f, 1.0f);
+    float t = fmaf(__builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(a) + 1.0f), -2.0f, 1.0f);
+    // (an empty asm the value passes through: hipcc otherwise folds this fma into split16()'s conversion as v_fma_mixlo / mixhi_f16
+    //  -- 9.4 cycles each at one wave per SIMD, next to the fp32 fma it still needs -- pair_mlp.hip act_tile)
+    asm("" : "+v"(t));
+    return t;
 }
 
 __device__ __forceinline__ void mfma_pair16(f32x16 &acc0, f32x16 &acc1, const float *img, unsigned lane, const Op16 &p0, const Op16 &p1) {

@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/../hoomd_tf_amd/csrc"
 NAME=$1; STEM=$2; EXTRA=$3
 mkdir -p ../../build_variants
-FP=""; [ "$STEM" = fused_eval ] && FP="-ffp-contract=on"; [ "$STEM" = pair_vectors ] && FP="-ffp-contract=off"; [ "$STEM" = pair_mlp ] && FP="-fno-slp-vectorize"
+FP=""; [ "$STEM" = fused_eval ] && FP="-ffp-contract=on"; [ "$STEM" = pair_vectors ] && FP="-ffp-contract=off"; [ "$STEM" = pair_mlp ] && FP="-fno-slp-vectorize"; [ "$STEM" = mlp_train16 ] && FP="-fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form"
 /opt/rocm/bin/hipcc -std=c++17 -O3 -fPIC --offload-arch=gfx950 -I../../include -I. -w -fvisibility=hidden -DHTF_BUILD $EXTRA $FP \
   -c $STEM.hip -o ../../build_variants/${STEM}_$NAME.o
 OBJS=$(ls *.o | grep -v "^$STEM.o")
