@@ -20,6 +20,7 @@ cp $F/pmc_mlp.json profiles/${R}_bench_mlp_pmc.json
 cp $F/pmc_c2_c4.json profiles/${R}_bench_c2_c4_pmc.json
 cp $F/gather_probe2.txt profiles/${R}_gather_probe.txt
 cp $F/store_probe.txt profiles/${R}_store_probe.txt
+for n in valu_cost_probe mlp_mix_probe; do [ -s $F/$n.txt ] && cp $F/$n.txt profiles/${R}_$n.txt; done
 cp gpurun_out/parity_stats.json profiles/${R}_parity_stats.json
 [ -s $F/train_sweep_pmc.txt ] && grep -v "^stats\|amdgpu.ids" $F/train_sweep_pmc.txt > profiles/${R}_train_sweep_pmc.txt
 for n in soak_nve soak_nve_f64; do [ -s $F/$n.json ] && cp $F/$n.json profiles/${R}_$n.json; done

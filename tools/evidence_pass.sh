@@ -41,6 +41,10 @@ timeout 300 python tools/soak_nve.py --steps 20000 --f64 > $F/soak_nve_f64.json 
 bash tools/fetch_calib.sh > /dev/null 2>&1; cp gpurun_out/fetch_calib.json $F/fetch_calib.json
 ./tools/gather_probe2 > $F/gather_probe2.txt 2>&1
 ./tools/store_probe > $F/store_probe.txt 2>&1
+[ -x tools/valu_cost_probe ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/valu_cost_probe.hip -o tools/valu_cost_probe 2>/dev/null
+[ -x tools/mlp_mix_probe ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/mlp_mix_probe.hip -o tools/mlp_mix_probe 2>/dev/null
+./tools/valu_cost_probe > $F/valu_cost_probe.txt 2>&1     # issue cost of the pair-MLP tile's vector instructions at 1-3 waves per SIMD
+./tools/mlp_mix_probe > $F/mlp_mix_probe.txt 2>&1       # ... and of the tile's whole instruction mix
 # kernel durations: rocprofv3 --kernel-trace --stats of the same commands
 Q="--no-cpu-baseline --no-mlp"
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_lj -o lj -- python3 bench.py $Q > /dev/null 2>&1
