@@ -148,6 +148,8 @@ STANDIN_PROTOTYPES = {
     "htfs_cell_index": (_i, [_vp, _i, _u, C.POINTER(Box), C.POINTER(_i * 3), _vp, _vp]),
     "htfs_set_gate": (_i, [_vp, _d]),
     "htfs_commit_rebuild": (_i, [_vp, _vp, _i, _u, _vp, _vp]),
+    "htfs_rebuild_nlist": (_i, [_vp, _i, _u, C.POINTER(Box), _d, C.POINTER(_i * 3), C.POINTER(_i * 3), _vp, _vp, _vp, _vp, _vp, _u, _i,
+                                _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 
 

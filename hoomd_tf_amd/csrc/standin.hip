@@ -137,12 +137,18 @@ __global__ __launch_bounds__(256) void cell_index_kernel(const typename Vec4<T>:
 // the w of a cell-sorted position (htfs_gather4_tagged): particle index | (type >= type_split) << 31
 constexpr unsigned kTagSide = 1u << 31;
 constexpr unsigned kRangeWrapShift = 28u, kRangeLenMask = (1u << kRangeWrapShift) - 1u;
-__global__ __launch_bounds__(256) void cell_ranges_kernel(int nx, int ny, int nz, int wx, int wy, int wz, int px, int py, int pz,
-                                                          const unsigned *__restrict__ cell_start, uint4 *__restrict__ table,
-                                                          unsigned *__restrict__ max_neigh, Gate gate) {
-    if (gate.closed()) return;
+struct RangesArgs {
+    int nx, ny, nz, wx, wy, wz, px, py, pz;
+    const unsigned *cell_start;
+    uint4 *table;
+    unsigned *max_neigh;
+};
+__device__ __forceinline__ void cell_ranges_body(const unsigned t, const RangesArgs &a) {
+    const int nx = a.nx, ny = a.ny, nz = a.nz, wx = a.wx, wy = a.wy, wz = a.wz, px = a.px, py = a.py, pz = a.pz;
+    const unsigned *__restrict__ cell_start = a.cell_start;
+    uint4 *__restrict__ table = a.table;
+    unsigned *__restrict__ max_neigh = a.max_neigh;
     const int nrow = (2 * wy + 1) * (2 * wz + 1);
-    const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t == 0) *max_neigh = 0u; // the search kernel behind this one accumulates the largest row into it
     const unsigned ncell = (unsigned)(nx * ny * nz);
     if (t >= ncell * (unsigned)nrow) return;
@@ -174,6 +180,10 @@ __global__ __launch_bounds__(256) void cell_ranges_kernel(int nx, int ny, int nz
         }
     }
     table[t] = o;
+}
+__global__ __launch_bounds__(256) void cell_ranges_kernel(RangesArgs a, Gate gate) {
+    if (gate.closed()) return;
+    cell_ranges_body(blockIdx.x * blockDim.x + threadIdx.x, a);
 }
 
 template <typename T, int G, bool SHIFT>
@@ -446,6 +456,46 @@ extern "C" int htfs_max_displacement2(const void *d_pos, const void *d_ref, int 
 }
 
 namespace htf {
+// The tail of the binning in ONE launch (round 4): the candidate-range table (blocks [0, nb_ranges)), the cell-sorted tagged
+// position copy and the new reference positions + rebuild counter (the blocks behind them) -- three kernels of a rebuild that
+// depend on the sort but not on each other.  Each of the small kernels of a rebuild costs its launch, the read of the gate and
+// two or three dependent round trips to memory (7-11 us apiece at C3), whatever little it computes.
+template <typename V>
+__global__ __launch_bounds__(256) void bins_finish_kernel(RangesArgs ra, unsigned nb_ranges, V *__restrict__ dest, const V *__restrict__ src,
+                                                          const int *__restrict__ order, unsigned n, int type_split, V *__restrict__ ref,
+                                                          unsigned n_ref, unsigned *__restrict__ counter, Gate gate) {
+    if (gate.closed()) return;
+    if (blockIdx.x < nb_ranges) {
+        cell_ranges_body(blockIdx.x * blockDim.x + threadIdx.x, ra);
+        return;
+    }
+    const unsigned i = (blockIdx.x - nb_ranges) * blockDim.x + threadIdx.x;
+    if (i == 0 && counter != nullptr) *counter += 1u;
+    if (i >= n) return;
+    const unsigned k = (unsigned)order[i];
+    V p = src[k];
+    if (ref != nullptr && k < n_ref) ref[k] = p; // (order is a permutation: every reference position is written once)
+    set_tag(p.w, k | ((type_split >= 0 && scalar_as_int(p.w) >= type_split) ? kTagSide : 0u));
+    dest[i] = p;
+}
+
+// cell index of every particle and the cells' populations in one pass (htfs_cell_index + the first kernel of htfs_cell_sort)
+template <typename T>
+__global__ __launch_bounds__(256) void cell_index_count_kernel(const typename Vec4<T>::type *__restrict__ pos, unsigned Ntot, SBox<T> b,
+                                                               int nx, int ny, int nz, unsigned *__restrict__ cell_of,
+                                                               unsigned *__restrict__ count, Gate gate) {
+    if (gate.closed()) return;
+    unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Ntot) return;
+    auto p = pos[i];
+    int cx = cell_coord<T>(p.x, b.lo[0], b.Linv[0], nx);
+    int cy = cell_coord<T>(p.y, b.lo[1], b.Linv[1], ny);
+    int cz = cell_coord<T>(p.z, b.lo[2], b.Linv[2], nz);
+    const unsigned c = (unsigned)((cz * ny + cy) * nx + cx);
+    cell_of[i] = c;
+    atomicAdd(&count[c], 1u);
+}
+
 template <typename V, bool TAG>
 __global__ void gather4_kernel(V *__restrict__ dest, const V *__restrict__ src, const int *__restrict__ order, unsigned n,
                                int type_split, Gate gate) {
@@ -795,11 +845,21 @@ extern "C" int htfs_cell_index(const void *d_pos, int dtype, unsigned Ntot, cons
     return check_launch("cell_index_kernel");
 }
 
-extern "C" int htfs_build_nlist(const void *d_pos, const void *d_pos_sorted, int dtype, unsigned N, unsigned Ntot,
-                                const htf_box *box, double r_list, const int *ncell3, const int *stencil3,
-                                const unsigned *d_cell_start, unsigned pitch, int type_split,
-                                unsigned *d_n_neigh, unsigned *d_head_list, unsigned *d_nlist, unsigned *d_max_neigh,
-                                htf_stream stream) {
+// what bins_finish_kernel does beside the range table when the search is part of htfs_rebuild_nlist
+struct FinishArgs {
+    void *pos_sorted;       // <- pos[order], tagged
+    const int *order;
+    unsigned n;             // particles binned
+    void *ref;              // <- pos (nullable)
+    unsigned n_ref;
+    unsigned *counter;      // += 1 (nullable)
+};
+
+static int build_nlist_impl(const void *d_pos, const void *d_pos_sorted, int dtype, unsigned N, unsigned Ntot,
+                            const htf_box *box, double r_list, const int *ncell3, const int *stencil3,
+                            const unsigned *d_cell_start, unsigned pitch, int type_split,
+                            unsigned *d_n_neigh, unsigned *d_head_list, unsigned *d_nlist, unsigned *d_max_neigh,
+                            htf_stream stream, const FinishArgs *fin) {
     (void)Ntot;
     HTF_REQUIRE(d_pos && d_pos_sorted && box && ncell3 && stencil3 && d_cell_start && d_n_neigh && d_head_list && d_nlist && d_max_neigh,
                 "htfs_build_nlist: null pointer");
@@ -832,9 +892,20 @@ extern "C" int htfs_build_nlist(const void *d_pos, const void *d_pos_sorted, int
         HTF_CHECK_HIP(hipMalloc((void **)&d_ranges, (size_t)ncell * nrow * sizeof(uint4)));
         ranges_cap = (size_t)ncell * nrow;
     }
-    hipLaunchKernelGGL(cell_ranges_kernel, dim3((ncell * nrow + 255) / 256), dim3(256), 0, (hipStream_t)stream, ncell3[0], ncell3[1],
-                       ncell3[2], stencil3[0], stencil3[1], stencil3[2], (int)box->periodic[0], (int)box->periodic[1],
-                       (int)box->periodic[2], d_cell_start, d_ranges, d_max_neigh, g_gate);
+    const RangesArgs ra = {ncell3[0], ncell3[1], ncell3[2], stencil3[0], stencil3[1], stencil3[2], (int)box->periodic[0],
+                           (int)box->periodic[1], (int)box->periodic[2], d_cell_start, d_ranges, d_max_neigh};
+    const unsigned nb_ranges = (ncell * nrow + 255) / 256;
+    if (fin == nullptr) {
+        hipLaunchKernelGGL(cell_ranges_kernel, dim3(nb_ranges), dim3(256), 0, (hipStream_t)stream, ra, g_gate);
+    } else {
+        const unsigned nb = nb_ranges + (fin->n + 255) / 256 + (fin->n == 0 ? 1u : 0u);
+        if (dtype == HTF_F32)
+            hipLaunchKernelGGL((bins_finish_kernel<float4>), dim3(nb), dim3(256), 0, (hipStream_t)stream, ra, nb_ranges, (float4 *)fin->pos_sorted,
+                               (const float4 *)d_pos, fin->order, fin->n, type_split, (float4 *)fin->ref, fin->n_ref, fin->counter, g_gate);
+        else
+            hipLaunchKernelGGL((bins_finish_kernel<double4>), dim3(nb), dim3(256), 0, (hipStream_t)stream, ra, nb_ranges, (double4 *)fin->pos_sorted,
+                               (const double4 *)d_pos, fin->order, fin->n, type_split, (double4 *)fin->ref, fin->n_ref, fin->counter, g_gate);
+    }
     const bool fine = stencil3[0] == 2 || stencil3[1] == 2 || stencil3[2] == 2; // short ranges: 8-lane groups waste fewer lanes
 #define HTFS_NL(T, V4, G)                                                                                              \
     if (shift) HTFS_NL_(T, V4, G, true); else HTFS_NL_(T, V4, G, false)
@@ -873,6 +944,48 @@ extern "C" int htfs_build_nlist(const void *d_pos, const void *d_pos_sorted, int
 #undef HTFS_NLC
 #undef HTFS_NLC_
     return check_launch("build_nlist_kernel");
+}
+
+extern "C" int htfs_build_nlist(const void *d_pos, const void *d_pos_sorted, int dtype, unsigned N, unsigned Ntot,
+                                const htf_box *box, double r_list, const int *ncell3, const int *stencil3,
+                                const unsigned *d_cell_start, unsigned pitch, int type_split,
+                                unsigned *d_n_neigh, unsigned *d_head_list, unsigned *d_nlist, unsigned *d_max_neigh,
+                                htf_stream stream) {
+    return build_nlist_impl(d_pos, d_pos_sorted, dtype, N, Ntot, box, r_list, ncell3, stencil3, d_cell_start, pitch, type_split, d_n_neigh,
+                            d_head_list, d_nlist, d_max_neigh, stream, nullptr);
+}
+
+// The whole rebuild of a single-domain list -- htfs_cell_index, htfs_cell_sort, htfs_gather4_tagged, htfs_build_nlist and
+// htfs_commit_rebuild on the same arguments -- in six launches instead of nine (index + count in one kernel; range table,
+// sorted copy and commit in one): the small kernels are launch- and latency-bound, and a gated rebuild pays for every one of
+// them even when the gate is closed.
+extern "C" int htfs_rebuild_nlist(const void *d_pos, int dtype, unsigned N, const htf_box *box, double r_list, const int *ncell3,
+                                  const int *stencil3, unsigned *d_cell_of, unsigned *d_scratch, unsigned *d_cell_start,
+                                  unsigned *d_order, void *d_pos_sorted, unsigned pitch, int type_split, unsigned *d_n_neigh,
+                                  unsigned *d_head_list, unsigned *d_nlist, unsigned *d_max_neigh, void *d_ref,
+                                  unsigned *d_counter, htf_stream stream) {
+    using namespace htf;
+    HTF_REQUIRE(d_pos && box && ncell3 && stencil3 && d_cell_of && d_scratch && d_cell_start && d_order && d_pos_sorted,
+                "htfs_rebuild_nlist: null pointer");
+    if (N == 0) return HTF_OK;
+    const unsigned ncell = (unsigned)(ncell3[0] * ncell3[1] * ncell3[2]);
+    HTF_REQUIRE(ncell > 0, "htfs_rebuild_nlist: no cells");
+    hipStream_t s = (hipStream_t)stream;
+    unsigned *count = d_scratch, *cursor = d_scratch + ncell;
+    if (!g_gate.disp2) HTF_CHECK_HIP(hipMemsetAsync(count, 0, (size_t)ncell * sizeof(unsigned), s)); // (as htfs_cell_sort)
+    const unsigned grid = (N + 255) / 256;
+    if (dtype == HTF_F32)
+        hipLaunchKernelGGL((cell_index_count_kernel<float>), dim3(grid), dim3(256), 0, s, (const float4 *)d_pos, N, make_sbox<float>(box),
+                           ncell3[0], ncell3[1], ncell3[2], d_cell_of, count, g_gate);
+    else
+        hipLaunchKernelGGL((cell_index_count_kernel<double>), dim3(grid), dim3(256), 0, s, (const double4 *)d_pos, N, make_sbox<double>(box),
+                           ncell3[0], ncell3[1], ncell3[2], d_cell_of, count, g_gate);
+    hipLaunchKernelGGL(cell_scan_kernel, dim3((ncell + kScanChunk - 1) / kScanChunk), dim3(kScanThreads), 0, s, count, ncell, d_cell_start, cursor, g_gate);
+    hipLaunchKernelGGL(cell_scatter_kernel, dim3(grid), dim3(256), 0, s, d_cell_of, N, cursor, d_order, g_gate);
+    hipLaunchKernelGGL(cell_order_kernel, dim3((ncell + 255) / 256), dim3(256), 0, s, d_cell_start, ncell, d_order, count, g_gate);
+    const FinishArgs fin = {d_pos_sorted, (const int *)d_order, N, d_ref, N, d_counter};
+    return build_nlist_impl(d_pos, d_pos_sorted, dtype, N, N, box, r_list, ncell3, stencil3, d_cell_start, pitch, type_split, d_n_neigh,
+                            d_head_list, d_nlist, d_max_neigh, stream, &fin);
 }
 
 namespace htf {

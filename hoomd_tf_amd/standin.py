@@ -300,19 +300,12 @@ class CellNlist:
                                          C.byref(s.box), self._disp.data_ptr(), stream))
         check(lib.htfs_set_gate(self._disp.data_ptr(), (self.r_buff / 2.0) ** 2))
         try:
-            check(lib.htfs_cell_index(s.pos.data_ptr(), s.scalar_code, s.N, C.byref(s.box), C.byref(n3),
-                                      self._cell_of.data_ptr(), stream))
-            check(lib.htfs_cell_sort(self._cell_of.data_ptr(), s.N, ncell, self._bin_scratch.data_ptr(),
-                                     self._cell_start.data_ptr(), self._order.data_ptr(), stream))
-            check(lib.htfs_gather4_tagged(self._pos_sorted.data_ptr(), s.pos.data_ptr(), self._order.data_ptr(),
-                                          s.scalar_code, s.N, int(self.type_split), stream))
-            check(lib.htfs_build_nlist(s.pos.data_ptr(), self._pos_sorted.data_ptr(), s.scalar_code, s.N, s.N,
-                                       C.byref(s.box), self.r_list, C.byref(n3), C.byref(w3),
-                                       self._cell_start.data_ptr(), self.pitch, int(self.type_split),
-                                       self.n_neigh.data_ptr(), self.head_list.data_ptr(), self.nlist.data_ptr(),
-                                       self._stat.data_ptr(), stream))
-            check(lib.htfs_commit_rebuild(self._ref.data_ptr(), s.pos.data_ptr(), s.scalar_code, s.N,
-                                          self._stat.data_ptr() + 4, stream))
+            # index + sort + sorted copy + search + commit: one entry point, six launches (htf_standin.h)
+            check(lib.htfs_rebuild_nlist(s.pos.data_ptr(), s.scalar_code, s.N, C.byref(s.box), self.r_list, C.byref(n3), C.byref(w3),
+                                         self._cell_of.data_ptr(), self._bin_scratch.data_ptr(), self._cell_start.data_ptr(),
+                                         self._order.data_ptr(), self._pos_sorted.data_ptr(), self.pitch, int(self.type_split),
+                                         self.n_neigh.data_ptr(), self.head_list.data_ptr(), self.nlist.data_ptr(),
+                                         self._stat.data_ptr(), self._ref.data_ptr(), self._stat.data_ptr() + 4, stream))
         finally:
             check(lib.htfs_set_gate(None, 0.0))
         self._stat_host.copy_(self._stat, non_blocking=True)

@@ -67,6 +67,15 @@ HTF_API int htfs_set_gate(const float *d_disp2, double threshold2);
 HTF_API int htfs_commit_rebuild(void *d_ref, const void *d_pos, int dtype, unsigned N, unsigned *d_counter,
                                 htf_stream stream);
 
+/* htfs_cell_index + htfs_cell_sort + htfs_gather4_tagged + htfs_build_nlist + htfs_commit_rebuild of a single-domain system
+ * (N particles, no ghosts) on the same arguments, in six launches instead of nine; gated like them.  d_scratch: 2 * ncell
+ * words whose first half is zero on entry (left so by every ungated call); d_ref / d_counter nullable. */
+HTF_API int htfs_rebuild_nlist(const void *d_pos, int dtype, unsigned N, const htf_box *box, double r_list, const int *ncell3,
+                               const int *stencil3, unsigned *d_cell_of, unsigned *d_scratch, unsigned *d_cell_start,
+                               unsigned *d_order, void *d_pos_sorted, unsigned pitch, int type_split, unsigned *d_n_neigh,
+                               unsigned *d_head_list, unsigned *d_nlist, unsigned *d_max_neigh, void *d_ref,
+                               unsigned *d_counter, htf_stream stream);
+
 /* Slab decomposition (the stand-in for HOOMD's Communicator; hoomd_tf_amd/domain.py): the migration + ghost plan of a
  * rebuild.  d_key[i] = destination * 4 + ghost class of local particle i (destination: 0 stay, 1 left neighbor,
  * 2 right neighbor, 3 beyond; class in the slab it ends up in: 0 interior, 1 near the left face only, 2 near both,
