@@ -567,6 +567,8 @@ int mlp_train_grad16(const MlpDevice *m, const void *nlist, int in_dtype, unsign
     rc = check_launch("mlp_resid_max_kernel");
     if (rc != HTF_OK) return rc;
     unsigned nblk = (unsigned)m->n_cu; // one 4-wave workgroup per CU (146 KB of LDS), a wave per row at a time
+    // (a sweep on fewer CUs, the rest left to the MD kernels that run beside it: 9.0 k MD steps/s with 256 workgroups, 8.99 / 8.74 /
+    //  8.69 / 8.35 k with 224 / 192 / 160 / 128 on bench.py --workload mlp-train -- the whole chip it is)
     if ((unsigned long long)nblk * 4 > B) nblk = (B + 3u) / 4u;
     MlpDims dm{m->K, m->H1, m->H2, m->off_b1(), m->off_W2(), m->off_b2(), m->off_W3(), m->off_b3()};
     const bool th = m->act == HTF_ACT_TANH;
