@@ -239,24 +239,24 @@ __device__ __forceinline__ void mfma_blk(f32x16 &acc, const float *img, unsigned
     }
 }
 
-// hipcc's second launch bound is waves per SIMD.  Two workgroups of four waves per CU for every
-// precision (LDS images of 49 / 25 / 73 KiB): at three waves per SIMD (168 VGPRs) the fp32 kernel
-// spills a handful of registers whichever way its arithmetic is written and is no faster (3.00 ms
-// either way at C3); split with six waves per workgroup spills 50-60 registers: 2.87 ms against
-// 1.92 ms.
+// hipcc's second launch bound is waves per SIMD: two for every precision (LDS images of 49 / 25 / 73 KiB).  At three
+// waves per SIMD (168 VGPRs) the fp32 kernel spills a handful of registers whichever way its arithmetic is written and is no
+// faster (3.00 ms either way at C3); split with six waves per workgroup spills 50-60 registers: 2.87 ms against 1.92 ms;
+// split16 with twelve waves per CU: 1.14 against 1.15 ms (DESIGN A.0).
 __device__ __forceinline__ float bcast_lane(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
 constexpr int pipe_per(int valu, int mfma) { return (valu + mfma - 1) / mfma > 0 ? (valu + mfma - 1) / mfma : 1; }
 
-// split16: ONE workgroup of eight waves per CU (round 4).  The two waves of a SIMD then share LDS, which is what lets them keep
-// pace with each other (see the priority rule at the top of a tile); the image is staged once per CU instead of twice.
-#ifndef HTF_MLP16_WAVES
-#define HTF_MLP16_WAVES 8
+// ONE workgroup of eight waves per CU (round 4).  The two waves of a SIMD then share LDS, which is what lets them keep pace
+// with each other (see the priority rule at the top of a tile); the image is staged once per CU instead of twice.  Every
+// precision: split16 1.18 -> 1.10 ms, fp32 MFMA 2.73 -> 2.65, bf16 x 3 1.72 -> 1.66, plain bf16 0.74 -> 0.70 (tools/mlp_ab.py).
+#ifndef HTF_MLP_WAVES
+#define HTF_MLP_WAVES 8
 #endif
 template <int P> struct MlpLaunch {
-    static constexpr int kWaves = P == HTF_MLP_SPLIT16 ? HTF_MLP16_WAVES : 4; // per workgroup
+    static constexpr int kWaves = HTF_MLP_WAVES;                               // per workgroup
     static constexpr int kPerCU = kWaves >= 8 ? 1 : 8 / kWaves;               // workgroups per CU
     static constexpr int kPerSimd = kWaves * kPerCU / 4;
 };
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(64 * MlpLaunch<P>::kWaves, MlpLaunch<P>::kPerSimd) 
         float4 *dst = reinterpret_cast<float4 *>(lds);
         for (int i = threadIdx.x; i < I::Floats / 4; i += blockDim.x) dst[i] = src[i];
     }
-    __shared__ unsigned progress[12]; // tiles done, per wave (split16)
+    __shared__ unsigned progress[12]; // tiles done, per wave
     if (threadIdx.x < 12) progress[threadIdx.x] = 0u;
     __syncthreads();
 
@@ -347,11 +347,10 @@ __global__ __launch_bounds__(64 * MlpLaunch<P>::kWaves, MlpLaunch<P>::kPerSimd) 
     // the load there, i.e. at once.
     using V4 = typename Vec4<IT>::type;
     constexpr int kHalves = sizeof(V4) / 16; // a slot is one (fp32) or two (fp64) 16-byte pieces
-    // (the three-part bf16 images leave no LDS for the staging buffer beside a second workgroup: that precision loads at use)
 #ifdef HTF_MLP_NODMA
     constexpr bool kDma = false;
 #else
-    constexpr bool kDma = P != HTF_MLP_SPLIT;
+    constexpr bool kDma = true;
 #endif
     __shared__ __attribute__((aligned(16))) float4 stage_all[kDma ? kWaves : 1][kDma ? kHalves : 1][kDma ? 64 : 1];
     auto &stage = stage_all[kDma ? wid : 0];
@@ -925,8 +924,7 @@ void mlp_destroy(MlpDevice *m) {
 template <bool TANH, int P>
 static int launch_mlp(const MlpDevice *m, const void *nlist, int in_dtype, unsigned B, unsigned NN, void *force,
                       int out_f64, void *virial9, hipStream_t s) {
-    // persistent blocks: 3 per CU (LDS 48.9 KiB each), 4 waves per block, one row per wave trip
-    // (bf16 and split: 2 per CU, see MlpLaunch)
+    // persistent blocks: one of eight waves per CU (MlpLaunch)
     unsigned grid = (unsigned)m->n_cu * (unsigned)MlpLaunch<P>::kPerCU;
     constexpr unsigned kW = (unsigned)MlpLaunch<P>::kWaves;
     unsigned need = (B + kW - 1) / kW;
