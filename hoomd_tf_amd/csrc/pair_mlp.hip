@@ -347,16 +347,11 @@ __global__ __launch_bounds__(64 * MlpLaunch<P>::kWaves, MlpLaunch<P>::kPerSimd) 
     // the load there, i.e. at once.
     using V4 = typename Vec4<IT>::type;
     constexpr int kHalves = sizeof(V4) / 16; // a slot is one (fp32) or two (fp64) 16-byte pieces
-#ifdef HTF_MLP_NODMA
-    constexpr bool kDma = false;
-#else
-    constexpr bool kDma = true;
-#endif
-    __shared__ __attribute__((aligned(16))) float4 stage_all[kDma ? kWaves : 1][kDma ? kHalves : 1][kDma ? 64 : 1];
-    auto &stage = stage_all[kDma ? wid : 0];
+    __shared__ __attribute__((aligned(16))) float4 stage_all[kWaves][kHalves][64];
+    auto &stage = stage_all[wid];
     auto in_range = [&](unsigned r_, unsigned c_) { return r_ < B && c_ * 64 + lane < NN; };
     auto request = [&](unsigned r_, unsigned c_) { // global -> LDS without passing through registers: nothing to keep live
-        if (kDma && in_range(r_, c_)) {
+        if (in_range(r_, c_)) {
             const char *src = (const char *)(nlist + ((size_t)r_ * NN + c_ * 64 + lane));
 #pragma unroll
             for (int q = 0; q < kHalves; ++q)
@@ -368,13 +363,10 @@ __global__ __launch_bounds__(64 * MlpLaunch<P>::kWaves, MlpLaunch<P>::kPerSimd) 
     while (true) {
         if (count < 32u && row < B) {
             // ---- stage 64 slots of the current row; request the chunk after it
-            if constexpr (kDma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             float sx = 0.f, sy = 0.f, sz = 0.f;
             if (in_range(row, chunk)) {
-                if constexpr (!kDma) {
-                    const auto v = nlist[(size_t)row * NN + chunk * 64 + lane];
-                    sx = (float)v.x; sy = (float)v.y; sz = (float)v.z;
-                } else if constexpr (kHalves == 1) {
+                if constexpr (kHalves == 1) {
                     const float4 v = stage[0][lane];
                     sx = v.x; sy = v.y; sz = v.z;
                 } else {
@@ -392,7 +384,7 @@ __global__ __launch_bounds__(64 * MlpLaunch<P>::kWaves, MlpLaunch<P>::kPerSimd) 
             const float ax = sx + kNormDelta, ay = sy + kNormDelta, az = sz + kNormDelta;
             const bool live = sqrtf(ax * ax + ay * ay + az * az) > kRinvDelta;
             const unsigned long long mask = __ballot(live);
-            if constexpr (kDma) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the staged values are in registers: the buffer may be overwritten
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the staged values are in registers: the buffer may be overwritten
             request(row, chunk);
             if (mask != 0ull) {
                 row_any = true;
