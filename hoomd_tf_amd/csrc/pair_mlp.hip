@@ -414,6 +414,8 @@ __global__ __launch_bounds__(64 * MlpLaunch<P>::kWaves, MlpLaunch<P>::kPerSimd) 
             // what is left (17 k) -- with equal shares of the rows the older wave finished at 0.70 of the kernel and the
             // younger one ran the rest alone, a third slower per tile than the pair.  Each wave publishes its tile count; the
             // one behind takes the higher priority for its next tile.  Timing only: what a wave computes does not change.
+            // (Waves w and w + 4 of a workgroup sit on the same SIMD -- read back from HW_ID with -DHTF_EVAL_STAMPS; were a
+            //  dispatcher to place them otherwise, the rule would pace the wrong pairs and cost nothing but its own effect.)
             tiles_done = __builtin_amdgcn_readfirstlane(tiles_done + 1u);
             // (inline asm: a compiler-visible LDS write would be ordered behind the chunk that is in flight to LDS)
             const unsigned pr0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned *)&progress[0];
