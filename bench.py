@@ -223,7 +223,7 @@ def run_ref_lj256(args, htf, standin, dev):
     for _ in range(5):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        sim.run(1000)
+        sim.run(1000, graph=False)  # (step by step; a bare run() of this length would pick the replay by itself)
         torch.cuda.synchronize()
         rounds.append(time.perf_counter() - t0)
     el = float(np.median(rounds))
@@ -403,7 +403,7 @@ def run_small(args, htf, standin, dev):
     for _ in range(5):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        sim.run(steps)
+        sim.run(steps, graph=False)  # (step by step: the replayed loop is the graph_variant below; a bare run() would pick it by itself)
         torch.cuda.synchronize()
         rounds.append(time.perf_counter() - t0)
     el = float(np.median(rounds))
