@@ -287,6 +287,48 @@ def test_graphed_run_equals_stepwise(htf, cuda):
     assert torch.equal(p0, p1) and torch.equal(v0, v1) and torch.equal(f0, f1)
 
 
+def test_default_run_picks_the_replay_and_recaptures_on_a_new_timestep(htf, cuda):
+    """Simulation.run(n) with graph=None: runs of >= 256 qualifying steps are replayed from a hipGraph by themselves, shorter
+    ones step; a captured launch carries dt by value, so a change of it must re-capture -- the trajectory through a dt change
+    equals the stepwise one bit for bit."""
+    from hoomd_tf_amd import standin
+
+    class LJModel(htf.SimModel):
+        def compute(self, nlist, positions, box):
+            rinv = htf.nlist_rinv(nlist)
+            inv_r6 = rinv**6
+            energy = htf.reduce_sum(4.0 / 2.0 * (inv_r6 * inv_r6 - inv_r6), axis=1)
+            return htf.compute_nlist_forces(nlist, energy)
+
+    def run(graph):
+        pos, L, a = standin.fcc_positions(6, 0.8442)
+        rng = np.random.default_rng(12)
+        pos = pos + 0.03 * a * rng.standard_normal(pos.shape)
+        pos -= np.round(pos / L) * L
+        sysm = standin.System(pos, L, dtype=torch.float32, device=cuda)
+        sysm.randomize_velocities(kT=1.0, seed=12)
+        sim = standin.Simulation(sysm)
+        nve = sim.integrate_nve(0.004)
+        tfc = htf.tfcompute(LJModel(96))
+        cell = sim.nlist_cell(r_buff=0.4, check_period=2, pitch=160)
+        tfc.attach(cell, r_cut=2.5)
+        sim.run(6)
+        assert getattr(sim, "_graph", None) is None  # a short run steps
+        sim.run(256, graph=graph)
+        first = getattr(sim, "_graph", None)
+        nve.dt = 0.002
+        sim.run(256, graph=graph)
+        torch.cuda.synchronize()
+        cell._poll_overflow()
+        return sysm.pos.clone(), sysm.vel.clone(), first, getattr(sim, "_graph", None), sysm.timestep
+
+    p0, v0, a0, b0, t0 = run(False)
+    p1, v1, a1, b1, t1 = run(None)
+    assert a0 is None and b0 is None and a1 is not None and b1 is not None and b1 is not a1, "no capture, or no re-capture after dt changed"
+    assert t0 == t1 == 518
+    assert torch.equal(p0, p1) and torch.equal(v0, v1)
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_cell_nlist_random_boxes_match_brute_force(htf, cuda, seed):
     """The binned search on random systems: anisotropic boxes (so that some periodic axes have fewer than 7 search
