@@ -505,7 +505,7 @@ class Simulation:
             return 0
         return nl.check_period
 
-    def _run_graphed(self, nsteps):
+    def _run_graphed(self, nsteps, soft=False):
         """Launch-bound systems (a few thousand particles: a step is ~15 kernels of ~1 us behind ~70 us of host
         enqueue): one check period of steps is captured into a hipGraph once and replayed, one launch per cycle.
         Every kernel reads its decisions from the device (gated rebuild), so the captured sequence is the step."""
@@ -530,6 +530,16 @@ class Simulation:
                 with torch.cuda.graph(g):
                     for _ in range(cycle):
                         self._step()
+            except RuntimeError:
+                if not soft:
+                    raise
+                # soft (run() chose the replay by itself): something in this step does not capture -- an op that synchronises,
+                # say.  Step by step then, and no second attempt.
+                self._no_graph, self._graph, self._graph_key = True, None, None
+                nl._capturing = False
+                s.timestep = ts0
+                torch.cuda.synchronize()
+                return nsteps
             finally:
                 nl._capturing = False
                 s.timestep = ts0  # a capture records, it does not run
@@ -574,9 +584,11 @@ class Simulation:
         milliseconds once per (model, list, integrator) -- unless HTF_RUN_GRAPH=0; graph=False: always step by step."""
         nsteps = int(nsteps)
         env = os.environ.get("HTF_RUN_GRAPH")
+        auto = graph is None and env != "1"
         if graph is None:
-            graph = env == "1" or (env != "0" and nsteps >= 256 and self.system.pos.is_cuda)
+            graph = env == "1" or (env != "0" and nsteps >= 256 and self.system.pos.is_cuda and not getattr(self, "_no_graph", False))
         if graph:
-            nsteps = self._run_graphed(nsteps)
+            # (chosen by default, not asked for: a step that turns out not to capture must still run -- soft)
+            nsteps = self._run_graphed(nsteps, soft=auto)
         for _ in range(nsteps):
             self._step()
