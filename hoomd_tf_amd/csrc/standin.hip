@@ -354,19 +354,19 @@ __global__ __launch_bounds__(256) void build_nlist_cells_kernel(const typename V
         const unsigned my_tag = (unsigned)scalar_as_int(me.w);
         unsigned tag_p[kCellBatch], count[kCellBatch];
         T px[kCellBatch], py[kCellBatch], pz[kCellBatch];
-        unsigned *row_p[kCellBatch];
+        unsigned row_p[kCellBatch]; // first slot of the particle's row (head_list[i] = i * pitch: 32 bits, as the list's own index)
 #pragma unroll
         for (int p = 0; p < kCellBatch; ++p) {
             tag_p[p] = ~0u; // (past the batch: index >= N, skipped like a ghost)
             px[p] = py[p] = pz[p] = (T)0;
             count[p] = 0u;
-            row_p[p] = nlist;
+            row_p[p] = 0u;
             if ((unsigned)p < np) { // wave-uniform
                 tag_p[p] = (unsigned)__builtin_amdgcn_readlane((int)my_tag, p);
                 px[p] = in_vgpr(bcast_lane_t(me.x, p));
                 py[p] = in_vgpr(bcast_lane_t(me.y, p));
                 pz[p] = in_vgpr(bcast_lane_t(me.z, p));
-                row_p[p] = nlist + (size_t)(tag_p[p] & ~kTagSide) * pitch;
+                row_p[p] = (tag_p[p] & ~kTagSide) * pitch;
             }
         }
         for (unsigned q0 = 0; q0 < total; q0 += 64u) {
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(256) void build_nlist_cells_kernel(const typename V
                     hits &= ballot64(((tag ^ tag_p[p]) & kTagSide) == 0u);
                 }
                 const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(hits >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hits, count[p]));
-                if (__builtin_amdgcn_inverse_ballot_w64(hits) && rank < pitch) row_p[p][rank] = k;
+                if (__builtin_amdgcn_inverse_ballot_w64(hits) && rank < pitch) nlist[row_p[p] + rank] = k;
                 count[p] += (unsigned)__builtin_popcountll(hits);
             }
         }
