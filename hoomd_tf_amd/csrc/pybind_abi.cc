@@ -120,6 +120,7 @@ void bind(py::module &m, const char *name, R (*fn)(A...)) {
     X(htfs_set_gate) \
     X(htfs_commit_rebuild) \
     X(htfs_rebuild_nlist) \
+    X(htfs_check_rebuild_nlist) \
     X(htfs_slab_classify) \
     X(htfs_key_sort16) \
     X(htfs_segment_copy)

@@ -988,6 +988,30 @@ extern "C" int htfs_rebuild_nlist(const void *d_pos, int dtype, unsigned N, cons
                             d_head_list, d_nlist, d_max_neigh, stream, &fin);
 }
 
+// A whole check step of a device-decided list in ONE call (the host's share of a small system's step is its enqueue): the
+// displacement word zeroed and filled, the gate set to it, htfs_rebuild_nlist behind the gate, the gate taken off, and the two
+// status words copied to pinned host memory for the NEXT check to read (nullable).
+extern "C" int htfs_check_rebuild_nlist(const void *d_pos, int dtype, unsigned N, const htf_box *box, double r_list, const int *ncell3,
+                                        const int *stencil3, unsigned *d_cell_of, unsigned *d_scratch, unsigned *d_cell_start,
+                                        unsigned *d_order, void *d_pos_sorted, unsigned pitch, int type_split, unsigned *d_n_neigh,
+                                        unsigned *d_head_list, unsigned *d_nlist, unsigned *d_stat2, void *d_ref, float *d_disp2,
+                                        double threshold2, unsigned *h_stat2, htf_stream stream) {
+    HTF_REQUIRE(d_ref && d_disp2 && d_stat2, "htfs_check_rebuild_nlist: null pointer");
+    if (N == 0) return HTF_OK;
+    HTF_CHECK_HIP(hipMemsetAsync(d_disp2, 0, sizeof(float), (hipStream_t)stream));
+    int rc = htfs_max_displacement2(d_pos, d_ref, dtype, N, box, d_disp2, stream);
+    if (rc != HTF_OK) return rc;
+    rc = htfs_set_gate(d_disp2, threshold2);
+    if (rc != HTF_OK) return rc;
+    rc = htfs_rebuild_nlist(d_pos, dtype, N, box, r_list, ncell3, stencil3, d_cell_of, d_scratch, d_cell_start, d_order, d_pos_sorted, pitch,
+                            type_split, d_n_neigh, d_head_list, d_nlist, d_stat2, d_ref, d_stat2 + 1, stream);
+    (void)htfs_set_gate(nullptr, 0.0);
+    if (rc != HTF_OK) return rc;
+    if (h_stat2 != nullptr)
+        HTF_CHECK_HIP(hipMemcpyAsync(h_stat2, d_stat2, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return HTF_OK;
+}
+
 namespace htf {
 // the tail of a (conditional) rebuild: reference positions <- current positions, rebuild counter + 1
 template <typename V>

@@ -295,20 +295,14 @@ class CellNlist:
             self._stat_host = torch.zeros(2, dtype=torch.int32).pin_memory()
         n3, w3, ncell = self._grid
         stream = C.c_void_p(raw_stream(s.device.index))
-        self._disp.zero_()
-        check(lib.htfs_max_displacement2(s.pos.data_ptr(), self._ref.data_ptr(), s.scalar_code, s.N,
-                                         C.byref(s.box), self._disp.data_ptr(), stream))
-        check(lib.htfs_set_gate(self._disp.data_ptr(), (self.r_buff / 2.0) ** 2))
-        try:
-            # index + sort + sorted copy + search + commit: one entry point, six launches (htf_standin.h)
-            check(lib.htfs_rebuild_nlist(s.pos.data_ptr(), s.scalar_code, s.N, C.byref(s.box), self.r_list, C.byref(n3), C.byref(w3),
-                                         self._cell_of.data_ptr(), self._bin_scratch.data_ptr(), self._cell_start.data_ptr(),
-                                         self._order.data_ptr(), self._pos_sorted.data_ptr(), self.pitch, int(self.type_split),
-                                         self.n_neigh.data_ptr(), self.head_list.data_ptr(), self.nlist.data_ptr(),
-                                         self._stat.data_ptr(), self._ref.data_ptr(), self._stat.data_ptr() + 4, stream))
-        finally:
-            check(lib.htfs_set_gate(None, 0.0))
-        self._stat_host.copy_(self._stat, non_blocking=True)
+        # distance check, gate, index + sort + sorted copy + search + commit behind it, status words to pinned memory: one call
+        # (htf_standin.h htfs_check_rebuild_nlist -- a dozen Python-level calls and torch ops before)
+        check(lib.htfs_check_rebuild_nlist(s.pos.data_ptr(), s.scalar_code, s.N, C.byref(s.box), self.r_list, C.byref(n3), C.byref(w3),
+                                           self._cell_of.data_ptr(), self._bin_scratch.data_ptr(), self._cell_start.data_ptr(),
+                                           self._order.data_ptr(), self._pos_sorted.data_ptr(), self.pitch, int(self.type_split),
+                                           self.n_neigh.data_ptr(), self.head_list.data_ptr(), self.nlist.data_ptr(),
+                                           self._stat.data_ptr(), self._ref.data_ptr(), self._disp.data_ptr(),
+                                           (self.r_buff / 2.0) ** 2, self._stat_host.data_ptr(), stream))
         if not capturing:
             self.mark_check_enqueued()
 

@@ -76,6 +76,15 @@ HTF_API int htfs_rebuild_nlist(const void *d_pos, int dtype, unsigned N, const h
                                unsigned *d_head_list, unsigned *d_nlist, unsigned *d_max_neigh, void *d_ref,
                                unsigned *d_counter, htf_stream stream);
 
+/* One check step of a device-decided list in one call: *d_disp2 <- 0, htfs_max_displacement2 into it, htfs_set_gate(d_disp2,
+ * threshold2), htfs_rebuild_nlist (d_stat2[0] = largest row, d_stat2[1] = rebuild counter), htfs_set_gate(NULL, 0), and -- if
+ * h_stat2 (pinned host memory) is given -- an asynchronous copy of the two status words for a later check to read. */
+HTF_API int htfs_check_rebuild_nlist(const void *d_pos, int dtype, unsigned N, const htf_box *box, double r_list, const int *ncell3,
+                                     const int *stencil3, unsigned *d_cell_of, unsigned *d_scratch, unsigned *d_cell_start,
+                                     unsigned *d_order, void *d_pos_sorted, unsigned pitch, int type_split, unsigned *d_n_neigh,
+                                     unsigned *d_head_list, unsigned *d_nlist, unsigned *d_stat2, void *d_ref, float *d_disp2,
+                                     double threshold2, unsigned *h_stat2, htf_stream stream);
+
 /* Slab decomposition (the stand-in for HOOMD's Communicator; hoomd_tf_amd/domain.py): the migration + ghost plan of a
  * rebuild.  d_key[i] = destination * 4 + ghost class of local particle i (destination: 0 stay, 1 left neighbor,
  * 2 right neighbor, 3 beyond; class in the slab it ends up in: 0 interior, 1 near the left face only, 2 near both,
