@@ -41,7 +41,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md "Chip-level parameters")
-PROF_EVERY = 3         # bracket every 3rd force batch with hipEvents inside the timed region (see main)
+PROF_EVERY = 7         # bracket every 7th force batch with hipEvents inside the timed region (see main; 14 samples per 100 steps)
 
 
 def parse():
