@@ -28,7 +28,7 @@ constexpr int kUnroll = 8;
 
 template <typename IT>
 __device__ __forceinline__ float4 load_slot(const typename Vec4<IT>::type *p) {
-    auto v = *p;
+    auto v = load_stream(p);
     return make_float4((float)v.x, (float)v.y, (float)v.z, (float)v.w);
 }
 
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(256) void check_nlist_kernel(const typename Vec4<IT
     unsigned cnt = 0;
     if (row < B) {
         const typename Vec4<IT>::type *rp = nlist + (size_t)row * NN;
-        for (unsigned j = g; j < NN; j += G) cnt += (rp[j].x > (IT)0) ? 1u : 0u;
+        for (unsigned j = g; j < NN; j += G) cnt += (__builtin_nontemporal_load(&rp[j].x) > (IT)0) ? 1u : 0u;
     }
     cnt = group_sum_u<G>(cnt);
     // wave max, then one atomic per wave

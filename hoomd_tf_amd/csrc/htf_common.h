@@ -146,6 +146,18 @@ __device__ __forceinline__ void store_stream(double4 *p, const double4 &v) {
     __builtin_nontemporal_store(v.w, &p->w);
 }
 
+// The pair-vector tensor is read ONCE per step by whatever evaluates it and rewritten by the next step's builder: read with
+// ordinary loads its 268 MB stay in the cache hierarchy, and the builder's streaming stores then take 78-82 us at C3 where they
+// take 52-53 behind non-temporal loads (bench.py --workload mlp, round 4).  Every consumer of the tensor loads it through these.
+__device__ __forceinline__ float4 load_stream(const float4 *p) {
+    return make_float4(__builtin_nontemporal_load(&p->x), __builtin_nontemporal_load(&p->y), __builtin_nontemporal_load(&p->z),
+                       __builtin_nontemporal_load(&p->w));
+}
+__device__ __forceinline__ double4 load_stream(const double4 *p) {
+    return make_double4(__builtin_nontemporal_load(&p->x), __builtin_nontemporal_load(&p->y), __builtin_nontemporal_load(&p->z),
+                        __builtin_nontemporal_load(&p->w));
+}
+
 // tf.norm(nlist[:, :, :3], axis=2) as compute_rdf takes it (simmodel.py:661): sqrt(reduce_sum(square)), every product
 // and sum rounded on its own (no fused multiply-add), correctly rounded square root.  The histogram bin of a pair
 // sitting within an ulp of a bin edge depends on these roundings: at 33 M slots (C4) a contracted x*x + y*y + z*z

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256, 1) void mlp_grad_kernel(const typename Vec4<IT
         loss += rx * rx + ry * ry + rz * rz + re * re;
         const typename Vec4<IT>::type *rp = nlist + (size_t)row * NN;
         for (unsigned j = 0; j < NN; ++j) {
-            const auto v = rp[j];
+            const auto v = load_stream(&rp[j]);
             const float tx = (float)v.x + kNormDelta, ty = (float)v.y + kNormDelta, tz = (float)v.z + kNormDelta;
             const float r = sqrtf(tx * tx + ty * ty + tz * tz);
             if (!(r > kRinvDelta)) continue; // padded slot (wave-uniform)
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256, 1) void mlp_grad_mfma_kernel(const typename Ve
         const unsigned slot = tile * 32 + p;
         float x = 0.f, y = 0.f, z = 0.f;
         if (valid && slot < NN) {
-            const auto v = nlist[(size_t)row * NN + slot];
+            const auto v = load_stream(&nlist[(size_t)row * NN + slot]);
             x = (float)v.x; y = (float)v.y; z = (float)v.z;
         }
         const float tx = x + kNormDelta, ty = y + kNormDelta, tz = z + kNormDelta;

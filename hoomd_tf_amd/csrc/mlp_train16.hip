@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256, 1) void mlp_grad_tr16_kernel(const typename Ve
         ox = oy = oz = 0.f;
         const unsigned sl = chunk * 64 + lane;
         if (row < B && sl < NN) {
-            const auto v = nlist[(size_t)row * NN + sl];
+            const auto v = load_stream(&nlist[(size_t)row * NN + sl]);
             ox = (float)v.x; oy = (float)v.y; oz = (float)v.z;
         }
     };

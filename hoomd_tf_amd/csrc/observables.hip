@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void rdf_hist_kernel(const typename Vec4<IT>::
         const unsigned row = (unsigned)(s / NN);
         // masked_nlist type_i: boolean_mask drops whole rows (simmodel.py:684-686)
         if (type_i >= 0 && type_tensor[(size_t)row * type_stride] != (float)type_i) continue;
-        auto v = nlist[s];
+        auto v = load_stream(&nlist[s]);
         float x = (float)v.x, y = (float)v.y, z = (float)v.z;
         // masked_nlist type_j: nlist * mask zeroes the slot (simmodel.py:687-691)
         if (type_j >= 0 && (float)v.w != (float)type_j) x = y = z = 0.f;

@@ -255,6 +255,7 @@ constexpr int pipe_per(int valu, int mfma) { return (valu + mfma - 1) / mfma > 0
 #ifndef HTF_MLP_WAVES
 #define HTF_MLP_WAVES 8
 #endif
+
 template <int P> struct MlpLaunch {
     static constexpr int kWaves = HTF_MLP_WAVES;                               // per workgroup
     static constexpr int kPerCU = kWaves >= 8 ? 1 : 8 / kWaves;               // workgroups per CU
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(64 * MlpLaunch<P>::kWaves, MlpLaunch<P>::kPerSimd) 
 #pragma unroll
             for (int q = 0; q < kHalves; ++q)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 16 * q),
-                                                 (__attribute__((address_space(3))) void *)&stage[q][0], 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void *)&stage[q][0], 16, 0, 2 /* nt: load_stream, htf_common.h */);
         }
     };
     request(row, chunk);

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void topk_mlp_kernel(const typename Vec4<IT>::
         const unsigned slot = t * 64 + lane;
         x[t] = y[t] = z[t] = 0.f;
         if (slot < NN) {
-            const auto v = rp[slot];
+            const auto v = load_stream(&rp[slot]);
             x[t] = (float)v.x; y[t] = (float)v.y; z[t] = (float)v.z;
         }
         f[t] = rinv_fwd(x[t], y[t], z[t]);

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void train_pair_kernel(const typename Vec4<IT>
 #pragma unroll
     for (int k = 0; k < P; ++k) J[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (unsigned j = g; j < NN; j += G) {
-        auto v = rp[j];
+        auto v = load_stream(&rp[j]);
         float e, fx, fy, fz;
         float4 dd[P];
         pair_eval_grad<KIND>((float)v.x, (float)v.y, (float)v.z, p, e, fx, fy, fz, dd);
