@@ -144,18 +144,18 @@ STANDIN_PROTOTYPES = {
     "htfs_nve_step": (_i, [_vp, _vp, _vp, _i, _u, _d, C.POINTER(Box), _vp]),
     "htfs_max_displacement2": (_i, [_vp, _vp, _i, _u, C.POINTER(Box), _vp, _vp]),
     "htfs_build_nlist": (_i, [_vp, _vp, _i, _u, _u, C.POINTER(Box), _d, C.POINTER(_i * 3), C.POINTER(_i * 3), _vp, _u, _i, _vp, _vp, _vp,
-                              _vp, _vp]),
+                              _vp, _vp, _vp]),
     "htfs_cell_index": (_i, [_vp, _i, _u, C.POINTER(Box), C.POINTER(_i * 3), _vp, _vp]),
     "htfs_set_gate": (_i, [_vp, _d]),
     "htfs_commit_rebuild": (_i, [_vp, _vp, _i, _u, _vp, _vp]),
     "htfs_rebuild_nlist": (_i, [_vp, _i, _u, C.POINTER(Box), _d, C.POINTER(_i * 3), C.POINTER(_i * 3), _vp, _vp, _vp, _vp, _vp, _u, _i,
-                                _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+                                _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "htfs_check_rebuild_nlist": (_i, [_vp, _i, _u, C.POINTER(Box), _d, C.POINTER(_i * 3), C.POINTER(_i * 3), _vp, _vp, _vp, _vp, _vp, _u, _i,
-                                      _vp, _vp, _vp, _vp, _vp, _vp, _d, _vp, _vp]),
+                                      _vp, _vp, _vp, _vp, _vp, _vp, _d, _vp, _vp, _vp]),
 }
 
 
-ABI_VERSION = 2  # include/htf_amd.h HTF_AMD_ABI_VERSION: the struct layouts the ctypes Structures of this file mirror
+ABI_VERSION = 3  # include/htf_amd.h HTF_AMD_ABI_VERSION: the struct layouts the ctypes Structures of this file mirror
 
 
 def _load():

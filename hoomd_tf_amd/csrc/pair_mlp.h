@@ -44,7 +44,7 @@ struct MlpDevice {
     int *train_map = nullptr;
     const float *theta = nullptr; // device parameter vector the images are built from
     float *own_theta = nullptr;   // ... owned copy unless the caller supplied d_theta
-    int *range_flag = nullptr;    // split16: host-mapped word the image build sets when a weight left fp16's range (sticky)
+    int *range_flag = nullptr;    // split16: host-mapped word the image build sets when a weight left fp16's range (cleared by the next build)
     float centers[kK];            // float32 linspace(low, high, K), 0 beyond K
     float gap = 1.f;
     int K = 0, H1 = 0, H2 = 0;

@@ -754,7 +754,7 @@ __global__ void mlp_refresh_kernel(float *__restrict__ images, const int *__rest
             reinterpret_cast<unsigned short *>(images)[e] = (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
         } else if constexpr (P == HTF_MLP_SPLIT16) { // hi = fp16(v), lo = fp16(v - hi), round to nearest: see prep<>
             // a TRAINED weight (device parameter vector: mlp_create cannot see it) that left fp16's range, or is not a number:
-            // sticky, read by the host at the next evaluation / training call
+            // read by the host at the next evaluation / training call, judged afresh by every image build
             if (range_flag != nullptr && !(fabsf(v) < 6.0e4f)) *range_flag = 1;
             const _Float16 hh = (_Float16)v;
             const _Float16 ll = (_Float16)(v - (float)hh);
@@ -780,6 +780,8 @@ __global__ void mlp_refresh_kernel(float *__restrict__ images, const int *__rest
     }
 }
 
+__global__ void mlp_flag_clear_kernel(int *__restrict__ range_flag) { *range_flag = 0; }
+
 // (read without a synchronisation: a violation written by an image build that has not run yet is seen by the call after)
 bool mlp_out_of_range(const MlpDevice *m) { return m->range_flag != nullptr && *(volatile int *)m->range_flag != 0; }
 
@@ -791,9 +793,12 @@ int mlp_refresh(const MlpDevice *m, hipStream_t stream) {
         hipLaunchKernelGGL(mlp_refresh_kernel<HTF_MLP_BF16>, dim3(grid), dim3(256), 0, stream, m->images, m->map, m->theta, fwd_scale, (int *)nullptr);
     else if (m->precision == HTF_MLP_SPLIT)
         hipLaunchKernelGGL(mlp_refresh_kernel<HTF_MLP_SPLIT>, dim3(grid), dim3(256), 0, stream, m->images, m->map, m->theta, fwd_scale, (int *)nullptr);
-    else if (m->precision == HTF_MLP_SPLIT16)
+    else if (m->precision == HTF_MLP_SPLIT16) {
+        // every image build judges the range afresh (the word used to be sticky -- one bad weight, and every later call
+        // failed even after the caller had repaired theta and refreshed): cleared in stream order ahead of the build that may set it
+        if (m->range_flag != nullptr) hipLaunchKernelGGL(mlp_flag_clear_kernel, dim3(1), dim3(1), 0, stream, m->range_flag);
         hipLaunchKernelGGL(mlp_refresh_kernel<HTF_MLP_SPLIT16>, dim3(grid), dim3(256), 0, stream, m->images, m->map, m->theta, fwd_scale, m->range_flag);
-    else
+    } else
         hipLaunchKernelGGL(mlp_refresh_kernel<HTF_MLP_FP32>, dim3(grid), dim3(256), 0, stream, m->images, m->map, m->theta, 1.0f, (int *)nullptr);
     if (m->train_images != m->images) // bf16 / split evaluator images: the training sweep reads its own fp32 set
         hipLaunchKernelGGL(mlp_refresh_kernel<HTF_MLP_FP32>, dim3(grid), dim3(256), 0, stream, m->train_images, m->train_map, m->theta, 1.0f, (int *)nullptr);

@@ -2,6 +2,7 @@
 // check, binned neighbor search.  Outside the drop-in boundary; exists so the force
 // path can be driven and timed as MD without HOOMD-blue in the image.
 #include <cstdlib>
+#include <unordered_map>
 
 #include "htf_common.h"
 #include "box_math.h"
@@ -614,6 +615,21 @@ __global__ __launch_bounds__(256) void cell_order_kernel(const unsigned *__restr
 }
 } // namespace htf
 
+// The first half of a binning scratch (the per-cell counts) is zero on entry: every call that RUNS leaves it so
+// (cell_order_kernel) and a call the gate holds back does not touch it.  A gated call therefore needs no memset -- as long as
+// the last ungated call on this scratch used the same ncell (otherwise the words between the two sizes are stale).
+// Remembered per scratch pointer and calling thread; anything else is zeroed again (an unconditional memset is always right).
+static int zero_counts_if_needed(unsigned *count, unsigned ncell, hipStream_t s) {
+    static thread_local std::unordered_map<const void *, unsigned> zeroed_for;
+    HTF_REQUIRE(((uintptr_t)count & 15) == 0, "binning scratch must be 16-byte aligned (cell_scan_kernel reads it with 16-byte loads)");
+    auto it = zeroed_for.find(count);
+    if (!g_gate.disp2 || it == zeroed_for.end() || it->second != ncell) {
+        HTF_CHECK_HIP(hipMemsetAsync(count, 0, (size_t)ncell * sizeof(unsigned), s));
+        zeroed_for[count] = ncell;
+    }
+    return HTF_OK;
+}
+
 extern "C" int htfs_cell_sort(const unsigned *d_cell_of, unsigned Ntot, unsigned ncell, unsigned *d_scratch,
                               unsigned *d_cell_start, unsigned *d_order, htf_stream stream) {
     using namespace htf;
@@ -621,9 +637,7 @@ extern "C" int htfs_cell_sort(const unsigned *d_cell_of, unsigned Ntot, unsigned
     HTF_REQUIRE(ncell > 0, "htfs_cell_sort: no cells");
     hipStream_t s = (hipStream_t)stream;
     unsigned *count = d_scratch, *cursor = d_scratch + ncell;
-    // the counts are left zeroed by every call that runs (cell_order_kernel) and untouched by one the gate holds back,
-    // so a gated call -- always preceded by an ungated one on the same scratch (htf_standin.h) -- needs no memset
-    if (!g_gate.disp2) HTF_CHECK_HIP(hipMemsetAsync(count, 0, (size_t)ncell * sizeof(unsigned), s));
+    if (int rc = zero_counts_if_needed(count, ncell, s)) return rc;
     if (Ntot) hipLaunchKernelGGL(cell_count_kernel, dim3((Ntot + 255) / 256), dim3(256), 0, s, d_cell_of, Ntot, count, g_gate);
     hipLaunchKernelGGL(cell_scan_kernel, dim3((ncell + kScanChunk - 1) / kScanChunk), dim3(kScanThreads), 0, s, count, ncell, d_cell_start, cursor, g_gate);
     if (Ntot) hipLaunchKernelGGL(cell_scatter_kernel, dim3((Ntot + 255) / 256), dim3(256), 0, s, d_cell_of, Ntot, cursor, d_order, g_gate);
@@ -859,7 +873,7 @@ static int build_nlist_impl(const void *d_pos, const void *d_pos_sorted, int dty
                             const htf_box *box, double r_list, const int *ncell3, const int *stencil3,
                             const unsigned *d_cell_start, unsigned pitch, int type_split,
                             unsigned *d_n_neigh, unsigned *d_head_list, unsigned *d_nlist, unsigned *d_max_neigh,
-                            htf_stream stream, const FinishArgs *fin) {
+                            void *d_ranges_v, htf_stream stream, const FinishArgs *fin) {
     (void)Ntot;
     HTF_REQUIRE(d_pos && d_pos_sorted && box && ncell3 && stencil3 && d_cell_start && d_n_neigh && d_head_list && d_nlist && d_max_neigh,
                 "htfs_build_nlist: null pointer");
@@ -872,26 +886,12 @@ static int build_nlist_impl(const void *d_pos, const void *d_pos_sorted, int dty
                     d, ncell3[d], w, sw, r_list);
     }
     if (N == 0) return HTF_OK;
-    // candidate ranges per cell and stencil row (2.7 MB at C3), kept across calls
+    // candidate ranges per cell and stencil row (2.7 MB at C3): the CALLER's table.  (Until round 5 a thread-local buffer of
+    // this file, freed and re-allocated when a larger grid came along -- under the feet of any hipGraph that had captured it.)
     const unsigned ncell = (unsigned)(ncell3[0] * ncell3[1] * ncell3[2]);
     const unsigned nrow = (unsigned)((2 * stencil3[1] + 1) * (2 * stencil3[2] + 1));
-    static thread_local uint4 *d_ranges = nullptr;
-    static thread_local size_t ranges_cap = 0;
-    static thread_local int ranges_dev = -1;
-    int dev_now = 0;
-    HTF_CHECK_HIP(hipGetDevice(&dev_now));
-    if (dev_now != ranges_dev) { // a buffer of another device is not this call's to use (or to free here)
-        d_ranges = nullptr;
-        ranges_cap = 0;
-        ranges_dev = dev_now;
-    }
-    if ((size_t)ncell * nrow > ranges_cap) {
-        if (d_ranges) (void)hipFree(d_ranges);
-        d_ranges = nullptr;
-        ranges_cap = 0;
-        HTF_CHECK_HIP(hipMalloc((void **)&d_ranges, (size_t)ncell * nrow * sizeof(uint4)));
-        ranges_cap = (size_t)ncell * nrow;
-    }
+    HTF_REQUIRE(d_ranges_v && ((uintptr_t)d_ranges_v & 15) == 0, "htfs_build_nlist: d_ranges must be a 16-byte aligned table of 4 * ncell * rows words");
+    uint4 *d_ranges = (uint4 *)d_ranges_v;
     const RangesArgs ra = {ncell3[0], ncell3[1], ncell3[2], stencil3[0], stencil3[1], stencil3[2], (int)box->periodic[0],
                            (int)box->periodic[1], (int)box->periodic[2], d_cell_start, d_ranges, d_max_neigh};
     const unsigned nb_ranges = (ncell * nrow + 255) / 256;
@@ -950,9 +950,9 @@ extern "C" int htfs_build_nlist(const void *d_pos, const void *d_pos_sorted, int
                                 const htf_box *box, double r_list, const int *ncell3, const int *stencil3,
                                 const unsigned *d_cell_start, unsigned pitch, int type_split,
                                 unsigned *d_n_neigh, unsigned *d_head_list, unsigned *d_nlist, unsigned *d_max_neigh,
-                                htf_stream stream) {
+                                void *d_ranges, htf_stream stream) {
     return build_nlist_impl(d_pos, d_pos_sorted, dtype, N, Ntot, box, r_list, ncell3, stencil3, d_cell_start, pitch, type_split, d_n_neigh,
-                            d_head_list, d_nlist, d_max_neigh, stream, nullptr);
+                            d_head_list, d_nlist, d_max_neigh, d_ranges, stream, nullptr);
 }
 
 // The whole rebuild of a single-domain list -- htfs_cell_index, htfs_cell_sort, htfs_gather4_tagged, htfs_build_nlist and
@@ -963,7 +963,7 @@ extern "C" int htfs_rebuild_nlist(const void *d_pos, int dtype, unsigned N, cons
                                   const int *stencil3, unsigned *d_cell_of, unsigned *d_scratch, unsigned *d_cell_start,
                                   unsigned *d_order, void *d_pos_sorted, unsigned pitch, int type_split, unsigned *d_n_neigh,
                                   unsigned *d_head_list, unsigned *d_nlist, unsigned *d_max_neigh, void *d_ref,
-                                  unsigned *d_counter, htf_stream stream) {
+                                  unsigned *d_counter, void *d_ranges, htf_stream stream) {
     using namespace htf;
     HTF_REQUIRE(d_pos && box && ncell3 && stencil3 && d_cell_of && d_scratch && d_cell_start && d_order && d_pos_sorted,
                 "htfs_rebuild_nlist: null pointer");
@@ -972,7 +972,7 @@ extern "C" int htfs_rebuild_nlist(const void *d_pos, int dtype, unsigned N, cons
     HTF_REQUIRE(ncell > 0, "htfs_rebuild_nlist: no cells");
     hipStream_t s = (hipStream_t)stream;
     unsigned *count = d_scratch, *cursor = d_scratch + ncell;
-    if (!g_gate.disp2) HTF_CHECK_HIP(hipMemsetAsync(count, 0, (size_t)ncell * sizeof(unsigned), s)); // (as htfs_cell_sort)
+    if (int rc = zero_counts_if_needed(count, ncell, s)) return rc; // (as htfs_cell_sort)
     const unsigned grid = (N + 255) / 256;
     if (dtype == HTF_F32)
         hipLaunchKernelGGL((cell_index_count_kernel<float>), dim3(grid), dim3(256), 0, s, (const float4 *)d_pos, N, make_sbox<float>(box),
@@ -985,7 +985,7 @@ extern "C" int htfs_rebuild_nlist(const void *d_pos, int dtype, unsigned N, cons
     hipLaunchKernelGGL(cell_order_kernel, dim3((ncell + 255) / 256), dim3(256), 0, s, d_cell_start, ncell, d_order, count, g_gate);
     const FinishArgs fin = {d_pos_sorted, (const int *)d_order, N, d_ref, N, d_counter};
     return build_nlist_impl(d_pos, d_pos_sorted, dtype, N, N, box, r_list, ncell3, stencil3, d_cell_start, pitch, type_split, d_n_neigh,
-                            d_head_list, d_nlist, d_max_neigh, stream, &fin);
+                            d_head_list, d_nlist, d_max_neigh, d_ranges, stream, &fin);
 }
 
 // A whole check step of a device-decided list in ONE call (the host's share of a small system's step is its enqueue): the
@@ -995,7 +995,7 @@ extern "C" int htfs_check_rebuild_nlist(const void *d_pos, int dtype, unsigned N
                                         const int *stencil3, unsigned *d_cell_of, unsigned *d_scratch, unsigned *d_cell_start,
                                         unsigned *d_order, void *d_pos_sorted, unsigned pitch, int type_split, unsigned *d_n_neigh,
                                         unsigned *d_head_list, unsigned *d_nlist, unsigned *d_stat2, void *d_ref, float *d_disp2,
-                                        double threshold2, unsigned *h_stat2, htf_stream stream) {
+                                        double threshold2, unsigned *h_stat2, void *d_ranges, htf_stream stream) {
     HTF_REQUIRE(d_ref && d_disp2 && d_stat2, "htfs_check_rebuild_nlist: null pointer");
     if (N == 0) return HTF_OK;
     HTF_CHECK_HIP(hipMemsetAsync(d_disp2, 0, sizeof(float), (hipStream_t)stream));
@@ -1004,7 +1004,7 @@ extern "C" int htfs_check_rebuild_nlist(const void *d_pos, int dtype, unsigned N
     rc = htfs_set_gate(d_disp2, threshold2);
     if (rc != HTF_OK) return rc;
     rc = htfs_rebuild_nlist(d_pos, dtype, N, box, r_list, ncell3, stencil3, d_cell_of, d_scratch, d_cell_start, d_order, d_pos_sorted, pitch,
-                            type_split, d_n_neigh, d_head_list, d_nlist, d_stat2, d_ref, d_stat2 + 1, stream);
+                            type_split, d_n_neigh, d_head_list, d_nlist, d_stat2, d_ref, d_stat2 + 1, d_ranges, stream);
     (void)htfs_set_gate(nullptr, 0.0);
     if (rc != HTF_OK) return rc;
     if (h_stat2 != nullptr)

@@ -156,6 +156,7 @@ class Potential:
     def refresh(self):
         """Rebuild derived device data (pair-MLP operand images) from the parameter vector."""
         check(lib.htf_potential_refresh(self._h, _stream(self.theta) if self.theta is not None else None))
+        self.version = getattr(self, "version", 0) + 1
 
 
 def build_pair_vectors(pos, n_neigh, head_list, nlist, box, r_cut, NN, offset=0, batch_size=None,

@@ -210,8 +210,12 @@ class PairMask(_TorchOperand):
     (``torch.where(r < cut, ...)``, ``(r < cut).to(...)``, returning it as an output), with the boolean operators a
     ``a < r < b`` shell needs."""
 
-    def __init__(self, nlist, cut):
-        self.nlist, self.cut = nlist, cut
+    def __init__(self, nlist, cut, as_dtype=None):
+        # as_dtype: what ``cast(mask, dtype)`` asked for.  The mask stays symbolic (so that mask * rinv-polynomial still lowers
+        # to one kernel) but everything that falls through to torch -- ``1.0 - cast(r < cut, float32)``, ``-mask``,
+        # ``mask ** 2``, ``mask * mask`` -- sees a tensor of that dtype, as TensorFlow's cast result would be (ADVICE r4: bool
+        # arithmetic raised, or stayed bool)
+        self.nlist, self.cut, self._as = nlist, cut, as_dtype
 
     def tensor(self):
         t = self.nlist.tensor[:, :, :3]
@@ -219,18 +223,20 @@ class PairMask(_TorchOperand):
 
     @property
     def ad(self):
-        return self.tensor()
+        m = self.tensor()
+        return m if self._as is None else m.to(self._as)
 
     shape = property(lambda self: self.nlist.tensor.shape[:2])
-    dtype = torch.bool
+    dtype = property(lambda self: torch.bool if self._as is None else self._as)
     device = property(lambda self: self.nlist.tensor.device)
 
     def __mul__(self, o):
         if isinstance(o, RinvPoly) and o.nlist is self.nlist and not o.reduced and o.cut in (None, self.cut):
             return RinvPoly(o.nlist, o.terms, cut=self.cut)
         if isinstance(o, PairMask):
-            return self.tensor() & o.tensor()
-        return self.tensor().to(torch.float32) * _unwrap(o)
+            both = self.tensor() & o.tensor()
+            return both if self._as is None and o._as is None else both.to(self._as or o._as)
+        return self.tensor().to(self._as or torch.float32) * _unwrap(o)
 
     __rmul__ = __mul__
 
@@ -248,7 +254,7 @@ class PairMask(_TorchOperand):
 def cast(x, dtype=None):
     """tf.cast for model code: a symbolic mask stays symbolic, tensors are converted."""
     if isinstance(x, PairMask):
-        return x
+        return x if dtype is None or dtype == torch.bool else PairMask(x.nlist, x.cut, as_dtype=dtype)
     t = _unwrap(x)
     return t.to(dtype) if dtype is not None and isinstance(t, torch.Tensor) else t
 

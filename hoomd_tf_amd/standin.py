@@ -212,13 +212,16 @@ class CellNlist:
         w3 = (C.c_int * 3)(*[int(x) for x in w])
         ncell = int(n[0] * n[1] * n[2])
         stream = C.c_void_p(raw_stream(s.device.index))
-        if getattr(self, "_scr_n", None) != (Ntot, ncell):
-            self._scr_n = (Ntot, ncell)
+        if getattr(self, "_scr_n", None) != (Ntot, ncell, int(w[1]), int(w[2])):
+            self._scr_n = (Ntot, ncell, int(w[1]), int(w[2]))
             self._cell_of = torch.empty(Ntot, dtype=torch.int32, device=s.device)
             self._order = torch.empty(Ntot, dtype=torch.int32, device=s.device)
             self._cell_start = torch.empty(ncell + 1, dtype=torch.int32, device=s.device)
             self._bin_scratch = torch.empty(2 * ncell, dtype=torch.int32, device=s.device)
             self._pos_sorted = torch.empty((Ntot, 4), dtype=s.pos.dtype, device=s.device)
+            # candidate ranges per (cell, stencil row): this list's own table (htf_standin.h HTFS_RANGE_WORDS), part of what a
+            # captured step carries by address
+            self._ranges = torch.empty(4 * ncell * int((2 * w[1] + 1) * (2 * w[2] + 1)), dtype=torch.int32, device=s.device)
         cell_of, order, cell_start, pos_sorted = self._cell_of, self._order, self._cell_start, self._pos_sorted
         check(lib.htfs_cell_index(s.pos.data_ptr(), s.scalar_code, Ntot, C.byref(s.box), C.byref(n3),
                                   cell_of.data_ptr(), stream))
@@ -253,7 +256,7 @@ class CellNlist:
             check(lib.htfs_build_nlist(s.pos.data_ptr(), pos_sorted.data_ptr(), s.scalar_code, s.N, Ntot, C.byref(s.box), self.r_list,
                                        C.byref(n3), C.byref(w3), cell_start.data_ptr(), self.pitch, int(self.type_split),
                                        self.n_neigh.data_ptr(), self.head_list.data_ptr(), self.nlist.data_ptr(),
-                                       self._max.data_ptr(), stream))
+                                       self._max.data_ptr(), self._ranges.data_ptr(), stream))
             mx = int(self._max.item())
             if mx <= self.pitch:
                 break
@@ -302,7 +305,7 @@ class CellNlist:
                                            self._order.data_ptr(), self._pos_sorted.data_ptr(), self.pitch, int(self.type_split),
                                            self.n_neigh.data_ptr(), self.head_list.data_ptr(), self.nlist.data_ptr(),
                                            self._stat.data_ptr(), self._ref.data_ptr(), self._disp.data_ptr(),
-                                           (self.r_buff / 2.0) ** 2, self._stat_host.data_ptr(), stream))
+                                           (self.r_buff / 2.0) ** 2, self._stat_host.data_ptr(), self._ranges.data_ptr(), stream))
         if not capturing:
             self.mark_check_enqueued()
 
@@ -312,6 +315,13 @@ class CellNlist:
         # (an explicit device index: without one torch asks the runtime for the device count on every call, ~8 us)
         idx = self.sys.device.index
         self._stat_event.record(torch.cuda.current_stream(idx if idx is not None else torch.cuda.current_device()))
+
+    def graph_key(self):
+        """Addresses of every buffer a captured check + rebuild carries by value (Simulation._run_graphed)."""
+        bufs = (self.n_neigh, self.head_list, self.nlist, self._ref, self._disp, self._stat, self._stat_host,
+                getattr(self, "_cell_of", None), getattr(self, "_order", None), getattr(self, "_cell_start", None),
+                getattr(self, "_bin_scratch", None), getattr(self, "_pos_sorted", None), getattr(self, "_ranges", None))
+        return tuple(0 if b is None else b.data_ptr() for b in bufs) + (int(self.type_split), self.check_period)
 
     def device_builds(self):
         """Rebuilds the device has decided on so far (synchronises; for reports, not for the step loop)."""
@@ -511,14 +521,17 @@ class Simulation:
             self._step()
             nsteps -= 1
         f, nl = self.forces[0], self.forces[0]._nlist
-        # (everything a captured launch carries by value: a change of any of it re-captures)
+        # (everything a captured launch carries by value: a change of any of it re-captures -- sizes, scalars, and the ADDRESS of
+        #  every buffer the step touches: rebinding sysm.pos / vel, a list whose buffers were re-allocated)
         key = (id(f), id(nl), id(self.integrator), cycle, s.N, nl.pitch, f.graph_key(), float(self.integrator.dt), float(nl.r_list),
-               float(nl.r_buff), tuple(float(x) for x in np.asarray(s.box3x3).ravel()))
+               float(nl.r_buff), tuple(float(x) for x in np.asarray(s.box3x3).ravel()), s.pos.data_ptr(), s.vel.data_ptr(),
+               s.force.data_ptr(), nl.graph_key())
         if getattr(self, "_graph_key", None) != key:
             torch.cuda.synchronize()
             nl._poll_overflow()
             g = torch.cuda.CUDAGraph()
             ts0 = s.timestep
+            host_counters = (getattr(f, "_calls", 0), getattr(nl, "_step_done", None))  # what recording the cycle advances
             nl._capturing = True
             try:
                 with torch.cuda.graph(g):
@@ -532,11 +545,13 @@ class Simulation:
                 self._no_graph, self._graph, self._graph_key = True, None, None
                 nl._capturing = False
                 s.timestep = ts0
+                f._calls, nl._step_done = host_counters  # the aborted recording ran no step
                 torch.cuda.synchronize()
                 return nsteps
             finally:
                 nl._capturing = False
                 s.timestep = ts0  # a capture records, it does not run
+            f._calls, nl._step_done = host_counters  # (the replay loop below counts the steps that really run)
             self._graph, self._graph_key = g, key
         # The neighbor-row overflow report (a pinned copy inside the captured cycle) is polled EVERY cycle, on the event
         # recorded two replays earlier -- long since complete, so the host still runs two cycles ahead of the device --

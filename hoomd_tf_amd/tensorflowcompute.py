@@ -203,7 +203,11 @@ class tfcompute:
                 and self.force.shape[0] == self.system.N and not getattr(self, "save_output_period", None))
 
     def graph_key(self):
-        return (id(self._plan), self.force.data_ptr())
+        # the potential object AND its handle / parameter version (a refresh re-images device weights in place: same handle,
+        # same addresses -- kernels resolve them at launch; a new Potential is a new handle), the context, the output arrays
+        p = self._plan
+        return (id(p), getattr(getattr(p, "handle", None), "value", None), getattr(p, "version", 0), id(self.cpp_force),
+                self.force.data_ptr(), self.virial.data_ptr(), int(self.fused), int(self.nneighbor_cutoff), float(self.r_cut))
 
     def compute(self, timestep):
         """ForceCompute::compute -> TensorflowCompute::computeForces (.cc:129-216)."""

@@ -27,10 +27,11 @@ extern "C" {
 #endif
 
 /* Bumped whenever a struct of this header changes size or layout or an enum gains a value (2: htf_potential_desc gained
- * poly_cut, htf_mlp_precision gained HTF_MLP_SPLIT16).  Every binding compares the value it was built against with
+ * poly_cut, htf_mlp_precision gained HTF_MLP_SPLIT16; 3: the stand-in's neighbor-search entry points of htf_standin.h take the
+ * caller's candidate-range table).  Every binding compares the value it was built against with
  * htf_abi_version() of the library it loaded and refuses a mismatch: hoomd_tf_amd/_lib.py, csrc/pybind_abi.cc,
  * integration/hoomd_shim/TensorflowComputeAMD.cc. */
-#define HTF_AMD_ABI_VERSION 2
+#define HTF_AMD_ABI_VERSION 3
 
 /* the library is built with -fvisibility=hidden (as the reference is,
  * htf/CMakeLists.txt:48); only these entry points are exported */
@@ -261,7 +262,11 @@ HTF_API int htf_optimizer_step_n(float *d_theta, unsigned P, const float *d_accu
 /* Pair-MLP potentials created with desc.d_theta (flat Keras get_weights() order: W1 [K][H1] |
  * b1 | W2 [H1][H2] | b2 | W3 [H2] | b3; the host weight pointers may then be NULL) keep reading
  * that caller-owned device vector: after it changes (optimizer step, set_weights), rebuild the
- * MFMA operand images on the device.  A no-op for closed-form potentials. */
+ * MFMA operand images on the device.  A no-op for closed-form potentials.
+ * precision HTF_MLP_SPLIT16 carries every operand as two fp16 halves: each image build checks |2.885 w| < 6e4 and that w is a
+ * number, and reports a violation through a host-mapped word the NEXT evaluation / training call on the potential reads without
+ * synchronising -- i.e. the error (HTF_ERR_ARG, "left fp16's range") surfaces one call late, after a step that ran on saturated
+ * images.  Every refresh judges the range afresh: repair d_theta, refresh, and the potential is usable again. */
 HTF_API int htf_potential_refresh(htf_potential *pot, htf_stream stream);
 
 

@@ -32,18 +32,22 @@ HTF_API int htfs_max_displacement2(const void *d_pos, const void *d_ref, int dty
  * *d_max_neigh is set to the largest count (> pitch means the list overflowed and must be
  * rebuilt with a larger pitch; a call the gate below holds back leaves the previous value).  type_split >= 0: pairs whose types lie on different
  * sides of it are left out (hoomd.md.nlist.rcut set_pair(..., -1) between all-atom and mapped
- * bead types, tensorflowcompute.py:284-305); -1: no type filter. */
+ * bead types, tensorflowcompute.py:284-305); -1: no type filter.
+ * d_ranges: the caller's candidate-range table, 16-byte aligned, 4 * ncell * (2 stencil3[1] + 1) * (2 stencil3[2] + 1) words
+ * (HTFS_RANGE_WORDS).  Every call rewrites it before the search reads it; it belongs to the list (ABI 3: until then a
+ * thread-local buffer of the library, re-allocated under any hipGraph that had captured its address). */
+#define HTFS_RANGE_WORDS(ncell, stencil_y, stencil_z) (4u * (size_t)(ncell) * (2u * (stencil_y) + 1u) * (2u * (stencil_z) + 1u))
 HTF_API int htfs_build_nlist(const void *d_pos, const void *d_pos_sorted, int dtype, unsigned N, unsigned Ntot,
                              const htf_box *box, double r_list, const int *ncell3, const int *stencil3,
                              const unsigned *d_cell_start, unsigned pitch, int type_split,
                              unsigned *d_n_neigh, unsigned *d_head_list, unsigned *d_nlist, unsigned *d_max_neigh,
-                             htf_stream stream);
+                             void *d_ranges, htf_stream stream);
 
 /* dest[i] = src[order[i]] for Scalar4 arrays: the cell-sorted position copy */
 /* Cell binning: d_order <- particle indices sorted by cell (ascending index inside a cell: deterministic),
- * d_cell_start[c] <- first slot of cell c (ncell + 1 entries).  d_scratch: 2 * ncell words; a call under
- * htfs_set_gate must be given the scratch (and ncell) of the last call made outside one -- its first half is
- * left zeroed by every call and a gated call does not clear it again. */
+ * d_cell_start[c] <- first slot of cell c (ncell + 1 entries).  d_scratch: 2 * ncell words, 16-byte aligned (checked).  Its
+ * first half (the per-cell counts) is left zeroed by every call that runs; a call under htfs_set_gate clears it again only
+ * when the calling thread's last call on this scratch used another ncell (or there was none). */
 HTF_API int htfs_cell_sort(const unsigned *d_cell_of, unsigned Ntot, unsigned ncell, unsigned *d_scratch,
                            unsigned *d_cell_start, unsigned *d_order, htf_stream stream);
 HTF_API int htfs_gather4(void *d_dest, const void *d_src, const int *d_order, int dtype, unsigned n, htf_stream stream);
@@ -68,13 +72,13 @@ HTF_API int htfs_commit_rebuild(void *d_ref, const void *d_pos, int dtype, unsig
                                 htf_stream stream);
 
 /* htfs_cell_index + htfs_cell_sort + htfs_gather4_tagged + htfs_build_nlist + htfs_commit_rebuild of a single-domain system
- * (N particles, no ghosts) on the same arguments, in six launches instead of nine; gated like them.  d_scratch: 2 * ncell
- * words whose first half is zero on entry (left so by every ungated call); d_ref / d_counter nullable. */
+ * (N particles, no ghosts) on the same arguments, in six launches instead of nine; gated like them.  d_scratch: as
+ * htfs_cell_sort's; d_ranges: as htfs_build_nlist's; d_ref / d_counter nullable. */
 HTF_API int htfs_rebuild_nlist(const void *d_pos, int dtype, unsigned N, const htf_box *box, double r_list, const int *ncell3,
                                const int *stencil3, unsigned *d_cell_of, unsigned *d_scratch, unsigned *d_cell_start,
                                unsigned *d_order, void *d_pos_sorted, unsigned pitch, int type_split, unsigned *d_n_neigh,
                                unsigned *d_head_list, unsigned *d_nlist, unsigned *d_max_neigh, void *d_ref,
-                               unsigned *d_counter, htf_stream stream);
+                               unsigned *d_counter, void *d_ranges, htf_stream stream);
 
 /* One check step of a device-decided list in one call: *d_disp2 <- 0, htfs_max_displacement2 into it, htfs_set_gate(d_disp2,
  * threshold2), htfs_rebuild_nlist (d_stat2[0] = largest row, d_stat2[1] = rebuild counter), htfs_set_gate(NULL, 0), and -- if
@@ -83,7 +87,7 @@ HTF_API int htfs_check_rebuild_nlist(const void *d_pos, int dtype, unsigned N, c
                                      const int *stencil3, unsigned *d_cell_of, unsigned *d_scratch, unsigned *d_cell_start,
                                      unsigned *d_order, void *d_pos_sorted, unsigned pitch, int type_split, unsigned *d_n_neigh,
                                      unsigned *d_head_list, unsigned *d_nlist, unsigned *d_stat2, void *d_ref, float *d_disp2,
-                                     double threshold2, unsigned *h_stat2, htf_stream stream);
+                                     double threshold2, unsigned *h_stat2, void *d_ranges, htf_stream stream);
 
 /* Slab decomposition (the stand-in for HOOMD's Communicator; hoomd_tf_amd/domain.py): the migration + ghost plan of a
  * rebuild.  d_key[i] = destination * 4 + ghost class of local particle i (destination: 0 stay, 1 left neighbor,

@@ -125,3 +125,23 @@ def test_pair_mask_is_a_tensor_everywhere_but_the_fast_path():
     assert torch.equal(m * want, (want < 2.0).float() * want) and torch.equal(want * m, (want < 2.0).float() * want)
     assert torch.equal(htf.cast(m).tensor(), want < 2.0)
     assert torch.equal(torch.logical_and(m, want > 1.0), (want < 2.0) & (want > 1.0))
+
+
+def test_cast_mask_takes_part_in_arithmetic():
+    """``tf.cast(r < cut, tf.float32)`` in model code: the cast mask still lowers when it multiplies a rinv
+    polynomial, and is a float tensor for everything else -- ``1.0 - cast(mask)``, ``-mask``, ``mask ** 2``, ``mask * mask``."""
+    import hoomd_tf_amd as htf
+    from hoomd_tf_amd.simmodel import PairMask
+    raw = torch.from_numpy(_nl(4))
+    nl = htf.Nlist(raw)
+    r = htf.norm(nl[:, :, :3], axis=2)
+    want = (torch.sqrt((raw[:, :, :3] ** 2).sum(dim=2)) < 2.0).to(torch.float32)
+    m = htf.cast(r < 2.0, torch.float32)
+    assert isinstance(m, PairMask) and m.dtype == torch.float32
+    assert torch.equal(1.0 - m, 1.0 - want) and torch.equal(m - 0.5, want - 0.5)
+    assert torch.equal(-m, -want) and torch.equal(m ** 2, want ** 2)
+    assert torch.equal(m * m, want) and (m * m).dtype == torch.float32
+    assert torch.equal(m + m, 2 * want) and torch.equal(m / 2.0, want / 2.0)
+    assert torch.equal(torch.sum(m), want.sum())
+    assert torch.equal(htf.cast(r < 2.0, torch.float64) * 3.0, want.double() * 3.0)
+    assert htf.cast(r < 2.0).dtype == torch.bool and htf.cast(r < 2.0, torch.bool).dtype == torch.bool

@@ -204,6 +204,146 @@ def test_training_under_slabs_matches_single_domain(htf, cuda):
     assert abs(out[2][3] - out[1][3]) < 2e-3 * abs(out[1][3])
 
 
+def _headline_worker(rank, world, port, q, steps=40):
+    """The strong-scaling geometry of the metric's own box: the C3 fcc box (131 072 particles, L = 53.75, r_cut 3.0 + r_buff 0.4,
+    NN 128) cut into ``world`` slabs -- 65 536 rows + ~16.6 k ghost rows per rank at world 2, the ranks sharing the one GPU -- run
+    for ``steps`` MD steps (migration across both faces, >= 1 rebuild), then forces of 512 sampled rows per rank against
+    O.compute_forces of the UNDIVIDED box (fp64 oracle on the gathered fp32 positions; the row's neighbors from a brute-force
+    list over all 131 072 particles, independent of the stand-in's cell list)."""
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        sys.path.insert(0, ROOT)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import hoomd_tf_amd as htf
+        from hoomd_tf_amd import standin
+        from hoomd_tf_amd.domain import SlabDomain
+        from oracle import htf_oracle as O
+        from test_gpu_parity import LIQUID, _cond_scale, _pair_forces_lj, assert_forces_close
+
+        dev = torch.device("cuda:0")
+        rcut, rbuf, NN = 3.0, 0.4, 128
+        # the bench's own kind of configuration: rank 0 relaxes the jittered lattice into a liquid at kT = 1 (force cap + velocity
+        # rescale, as bench.py's preparation; a jittered 131 072-particle lattice holds pairs at r ~ 0.6 that would blow up plain
+        # NVE) and hands every rank the same positions and velocities
+        pos, L, a = standin.fcc_positions(32, 0.8442)
+        Ng = len(pos)
+        assert Ng == 131072
+        state = torch.zeros((Ng, 6), dtype=torch.float64)
+        if rank == 0:
+            from test_gpu_parity import _liquid
+            lsys, _, _ = _liquid(htf, dev, cells=32, steps=150, seed=3)
+            state[:, :3] = lsys.pos[:Ng, :3].double().cpu()
+            state[:, 3:] = lsys.vel[:Ng, :3].double().cpu()
+            del lsys
+        dist.broadcast(state, src=0)
+        pos = state[:, :3].numpy().copy()
+        ids = np.arange(Ng)
+        vel = np.zeros((Ng, 4))
+        vel[:, :3] = state[:, 3:].numpy()
+        vel[:, 3] = 1.0
+        Lv = np.array([L, L, L], dtype=np.float64) if np.ndim(L) == 0 else np.asarray(L, dtype=np.float64)
+        bounds = -Lv[0] / 2 + np.linspace(0, 1, world + 1) * Lv[0]
+        mine = (pos[:, 0] >= bounds[rank]) & (pos[:, 0] < bounds[rank + 1])
+        sysm = standin.System(pos[mine], L, types=ids[mine], dtype=torch.float32, device=dev)
+        sysm.vel = torch.from_numpy(vel[mine]).to(torch.float32).to(dev)
+        nl = standin.CellNlist(sysm, r_cut=rcut, r_buff=rbuf, check_period=1)
+        nl.domain = SlabDomain(sysm, rank, world, r_ghost=rcut + rbuf)
+        nl.build()
+        if world == 2:
+            assert 60000 < sysm.N < 71000 and 15000 < sysm.n_ghost < 18500, (sysm.N, sysm.n_ghost)
+            assert nl.domain.n_interior > 0.6 * sysm.N                      # slabs 26.9 thick: 0.75 of the rows see no ghost
+        ctx = htf.Context(r_cut=rcut, nneighs=NN, scalar_dtype=torch.float32, max_n=sysm.N)
+        ctx.set_potential(htf.Potential.lj())
+        nve = standin.NVE(sysm, 0.005)
+        builds, arr, overlapped = -1, None, 0
+        for ts in range(steps):
+            nl.compute(ts)
+            if nl.n_builds != builds:
+                arr = ctx.make_arrays(sysm.pos, sysm.N, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, sysm.force)
+                builds = nl.n_builds
+            overlapped += int(nl.domain.pending)
+            ctx.compute_forces_overlapped(ts, arr, nl.domain)
+            if ts < steps - 1:
+                nve.step()
+        torch.cuda.synchronize()
+        assert nl.n_builds >= 2 and overlapped >= steps // 2, (nl.n_builds, overlapped)
+        N = sysm.N
+        my_ids = sysm.types_numpy()
+        loc = torch.zeros((Ng, 3), dtype=torch.float64)
+        loc[my_ids] = sysm.pos[:N, :3].double().cpu()
+        owned = torch.zeros(Ng, dtype=torch.float64)
+        owned[my_ids] = 1
+        dist.all_reduce(loc)
+        dist.all_reduce(owned)
+        assert bool((owned == 1).all()), "particles lost or duplicated"
+        moved = torch.tensor([nl.domain.n_migrated])
+        dist.all_reduce(moved)
+        assert int(moved) > 0, "test must exercise migration"
+        # the oracle on the undivided box, for 512 of this rank's rows
+        allpos = loc.numpy().astype(np.float32)
+        pick = np.random.default_rng(100 + rank).choice(N, 512, replace=False)
+        gid = my_ids[pick]
+        rows = []
+        for c in range(0, 512, 64):                                        # brute force over all particles, 64 rows at a time
+            d = allpos[None, :, :].astype(np.float64) - allpos[gid[c:c + 64], None, :].astype(np.float64)
+            d -= np.round(d / Lv) * Lv
+            m = (d * d).sum(axis=2) <= (rcut + 0.05) ** 2
+            m[np.arange(len(gid[c:c + 64])), gid[c:c + 64]] = False
+            rows += [np.nonzero(r)[0] for r in m]
+        n_neigh = np.array([len(r) for r in rows], dtype=np.uint32)
+        head = np.concatenate([[0], np.cumsum(n_neigh)[:-1]]).astype(np.uint32)
+        flat = np.concatenate(rows)
+        # O.compute_forces evaluates rows [0, n_local): put the sampled particles first
+        order = np.concatenate([gid, np.setdiff1d(np.arange(Ng), gid)])
+        new_of_old = np.empty(Ng, dtype=np.int64)
+        new_of_old[order] = np.arange(Ng)
+        ppos = allpos[order]
+        captured = {}
+
+        def model(x):
+            captured["pv"] = x.astype(np.float64)
+            return O.lj_model(captured["pv"])
+
+        ref, _ = O.compute_forces(ppos, np.zeros(Ng, np.int32), n_neigh, head, new_of_old[flat].astype(np.uint32),
+                                  O.make_box(L, dtype=np.float32), rcut, NN, model, model_dtype=np.float32, n_local=512)
+        pv64 = captured["pv"]
+        assert int((np.abs(pv64[:, :, :3]).sum(axis=2) > 0).sum(axis=1).max()) < NN
+        got = sysm.force[:N].cpu().numpy()[pick]
+        cond = _cond_scale(pv64, _pair_forces_lj(pv64))
+        tag = "slabs%d_c3_geometry_rank%d" % (world, rank)
+        assert_forces_close(tag + "_energy", got[:, 3], ref[:, 3])
+        assert_forces_close(tag, got[:, :3], ref[:, :3], cond, cancelling_rows=LIQUID)
+        import json
+        from test_gpu_parity import STATS
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok", {k: v for k, v in STATS.items() if k.startswith(tag)}))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc(), {}))
+
+
+def test_two_slabs_at_the_headline_geometry(htf, cuda):
+    """the decomposed step at the geometry `bench.py --gpus 2` runs (test_mpi_tensorflow.py:57-79 at the
+    metric's own size) -- 2 x 65 536 rows of the C3 box + 16.6 k ghosts per rank -- against the oracle of the undivided box."""
+    from test_gpu_parity import _record
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_headline_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=900) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg, stats in results:
+        assert msg == "ok", "rank %d failed:\n%s" % (rank, msg)
+        for k, v in stats.items():
+            _record(k, **v)
+
+
 @pytest.mark.parametrize("world,per_slab", [(2, 6), (3, 6), (5, 2)])
 def test_slabs_on_one_gpu(htf, cuda, world, per_slab):
     ctx = mp.get_context("spawn")

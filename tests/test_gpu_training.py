@@ -378,8 +378,14 @@ def test_split16_weight_range_is_checked_after_an_update(htf, cuda):
     torch.cuda.synchronize()
     with pytest.raises(ValueError, match="fp16"):
         htf.ops.eval_forces(pot, x)
-    with pytest.raises(ValueError, match="fp16"):   # sticky: a potential that overflowed once stays refused
+    with pytest.raises(ValueError, match="fp16"):   # refused until an image build finds every weight in range again
         htf.ops.train_pair_grad(pot, x, torch.zeros((16, 4), device=cuda))
+    # repaired and refreshed: every image build judges the range afresh (the word used to be sticky)
+    theta[5] = float(_flat_params(params)[5])
+    pot.refresh()
+    torch.cuda.synchronize()
+    assert torch.equal(htf.ops.eval_forces(pot, x), f0)
+    assert torch.isfinite(htf.ops.train_pair_grad(pot, x, torch.zeros((16, 4), device=cuda))).all()
     # the exact three-part bf16 split has no range limit
     theta2 = theta.clone()
     pot2 = htf.Potential.pair_mlp(params, 0.0, 3.0, activation="tanh", precision="split", theta=theta2)
@@ -487,3 +493,78 @@ def test_pair_mlp_gradient_random_shapes(htf, cuda, seed, precision):
     np.testing.assert_allclose(accum[0] / (4 * N), loss, rtol=3e-4)
     got = accum[1:] / (4 * N)
     assert np.abs(got - g).max() < 3e-4 * max(np.abs(g).max(), 1e-6), (K, H1, H2, NN, act, np.abs(got - g).max(), np.abs(g).max())
+
+
+@pytest.mark.parametrize("precision", ["split16", "fp32"])
+def test_pair_mlp_gradient_full_size(htf, cuda, precision):
+    """The training sweep at the size bench.py times it (C5b: 131 072 x 128, every persistent wave busy, every wave's partial
+    in the reduction) against torch's fp64 double backward (tensorflowcompute.py:347-370 train_on_batch; test_tensorflow.py:400-431).
+    The batch is 64 row-permuted replicas of one 2 048-row block of the C3 fcc box's own pair vectors, so the reference stays a
+    2 048-row double backward: sum of squared residuals and every one of the 6 337 weight gradients == 64 x the block's, the
+    prediction on 512 sampled rows == the fp64 oracle.  Twice: labels = 0.05 x LJ (residuals O(1)) and x 1e4 (the per-launch
+    power-of-two seed scaling of the split16 sweep at size).  As in test_pair_mlp_gradient_over_the_residual_range the reference
+    is fed the sweep's own fp32 residual of the block, so the tolerance is the fixture's 2e-4 of the gradient scale."""
+    from hoomd_tf_amd import initializers, standin
+    from test_gpu_parity import _jittered, _record
+    dims, NN, R, BLOCK = (32, 64, 64), 128, 64, 2048
+    sysm, nlc, L = _jittered(standin, cuda, "fcc", 32, 3)
+    assert sysm.N == R * BLOCK
+    pv = htf.ops.build_pair_vectors(sysm.pos, nlc.n_neigh, nlc.head_list, nlc.nlist, sysm.box, 3.0, NN)
+    rng = np.random.default_rng(17)
+    first = int(rng.integers(0, sysm.N - BLOCK))
+    block = pv[first:first + BLOCK].clone()
+    del pv
+    perm = torch.from_numpy(rng.permutation(R * BLOCK)).to(cuda)
+    src_row = perm % BLOCK                                    # batch row i is block row src_row[i]
+    x = block[src_row].contiguous()
+    assert x.shape == (R * BLOCK, NN, 4)
+    blk = block.cpu().numpy()
+    blk64 = blk.astype(np.float64)
+    live = int((np.abs(blk[:, :, :3]).sum(axis=2) > 0).sum())
+    assert live > 80 * BLOCK                                  # a liquid-density row: ~95 of 128 slots
+    params = initializers.mlp_params(seed=11)
+    for k in ("b1", "b2", "b3"):
+        params[k] = (0.1 * rng.standard_normal(params[k].shape)).astype(np.float32)
+    theta = _flat_params(params)
+    ref_pred = G.pair_mlp_param_forces(torch.from_numpy(blk64), torch.from_numpy(theta), dims).detach().numpy()
+    oracle_pred = O.pair_mlp_model(blk64, params, 0.0, 3.0, "tanh")
+    np.testing.assert_allclose(ref_pred, oracle_pred, rtol=1e-5, atol=1e-5)   # the two restatements (fp32 RBF centres in one)
+    fwd = lambda n, ww: G.pair_mlp_param_forces(n, ww, dims, create_graph=True)
+    for scale in (0.05, 500.0):
+        lab_blk = (scale * O.lj_model(blk64)).astype(np.float32)
+        labels = torch.from_numpy(lab_blk).to(cuda)[src_row].contiguous()
+        w = torch.tensor(theta, dtype=torch.float32, device=cuda)
+        pot = htf.Potential.pair_mlp(params, 0.0, 3.0, activation="tanh", theta=w, precision=precision)
+        pred = torch.empty((R * BLOCK, 4), device=cuda)
+        accum = htf.ops.train_pair_grad(pot, x, labels, pred=pred)
+        again = htf.ops.train_pair_grad(pot, x, labels)
+        assert torch.equal(accum, again)                     # fixed combination order: deterministic at size
+        accum = accum.cpu().numpy().astype(np.float64)
+        assert np.all(np.isfinite(accum))
+        # prediction: every replica of a block row is the same row.  The fp32 sweep walks a row's own tiles -> identical bits;
+        # split16 cuts the stream of live pairs into 32-pair tiles ACROSS rows, so a row's fp32 partial sums depend on where
+        # its pairs fall in the stream -> equal to rounding.  512 sampled rows against the oracle.
+        p = pred.cpu().numpy()
+        inv = torch.argsort(perm).cpu().numpy()               # batch positions ordered by perm value
+        first_replica = p[inv[:BLOCK]]                        # perm values 0..BLOCK-1: block rows in order
+        tiled = first_replica[src_row.cpu().numpy()]
+        if precision == "fp32":
+            assert np.array_equal(p, tiled)
+        else:
+            assert np.abs(p - tiled).max() <= 2e-6 * max(1.0, np.abs(p).max()), np.abs(p - tiled).max()
+        rows = rng.choice(BLOCK, 512, replace=False)
+        np.testing.assert_allclose(first_replica[rows], oracle_pred[rows], rtol=5e-5, atol=2e-5 * max(1.0, np.abs(oracle_pred).max()))
+        resid = first_replica.astype(np.float32) - lab_blk    # fp32, as the sweep forms it
+        want_loss = np.sum((p.astype(np.float32) - lab_blk[src_row.cpu().numpy()]).astype(np.float64) ** 2)
+        loss_err = abs(accum[0] - want_loss) / want_loss
+        assert loss_err < 2e-4, (scale, accum[0], want_loss)
+        _, g = G.mse_grad_wrt_params(fwd, torch.from_numpy(blk64), torch.from_numpy(ref_pred - resid.astype(np.float64)), theta)
+        want = g * (4 * BLOCK) * R                            # mse_grad_wrt_params returns the MEAN's gradient over the block
+        err = np.abs(accum[1:] - want).max() / np.abs(want).max()
+        _record("train_full_size_%s_labels_x%g" % (precision, scale), max_abs_err=np.abs(accum[1:] - want).max(),
+                max_ratio_strict=err / 2e-4, max_ref=np.abs(want).max(), loss_rel_err=loss_err)
+        assert err < 2e-4, (precision, scale, err)
+        o = 0
+        for n in (32 * 64, 64, 64 * 64, 64, 64, 1):           # every block of theta carries signal
+            assert np.abs(accum[1 + o:1 + o + n]).max() > 1e-3 * np.abs(want[o:o + n]).max()
+            o += n
