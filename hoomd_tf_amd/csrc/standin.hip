@@ -7,19 +7,11 @@
 #include "htf_common.h"
 #include "box_math.h"
 #include "htf_standin.h"
+#include "standin_gate.h"
 
 namespace htf {
 
-// Device-side gate of a conditional neighbor-list rebuild: between htfs_set_gate(d_disp2, thr2) and
-// htfs_set_gate(NULL, 0) every binning / search kernel launched through this file returns at entry
-// unless *d_disp2 > thr2 -- the decision NeighborList::distanceCheck takes on the host is taken by the
-// kernels themselves, so the step loop never waits for a read-back.
-struct Gate {
-    const float *disp2;
-    float thr2;
-    __device__ __forceinline__ bool closed() const { return disp2 != nullptr && !(*disp2 > thr2); }
-};
-static thread_local Gate g_gate = {nullptr, 0.f};
+thread_local Gate g_gate = {nullptr, 0.f};
 
 template <typename T>
 struct SBox {
@@ -85,6 +77,7 @@ __global__ __launch_bounds__(1024) void max_disp_kernel(const typename Vec4<T>::
         T dy = mimg<T>(p.y - r.y, b.L[1], b.Linv[1], b.periodic[1]);
         T dz = mimg<T>(p.z - r.z, b.L[2], b.Linv[2], b.periodic[2]);
         d2 = (float)(dx * dx + dy * dy + dz * dz);
+        if (!(d2 == d2)) d2 = 0.f; // an inert row (standin_gate.h) has not moved
     }
     for (int m = 1; m < 64; m <<= 1) d2 = fmaxf(d2, __shfl_xor(d2, m));
     if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = d2;
@@ -113,6 +106,10 @@ __global__ __launch_bounds__(256) void cell_index_kernel(const typename Vec4<T>:
     unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= Ntot) return;
     auto p = pos[i];
+    if (is_inert(p.x)) { // in no cell: never a candidate, never searched for
+        cell_of[i] = kDeadCell;
+        return;
+    }
     int cx = cell_coord<T>(p.x, b.lo[0], b.Linv[0], nx);
     int cy = cell_coord<T>(p.y, b.lo[1], b.Linv[1], ny);
     int cz = cell_coord<T>(p.z, b.lo[2], b.Linv[2], nz);
@@ -200,8 +197,9 @@ __global__ __launch_bounds__(256) void build_nlist_kernel(const typename Vec4<T>
     if (gate.closed()) return;
     const unsigned lane = threadIdx.x & 63u, g = lane % G, sub = lane / G;
     const unsigned i = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * (64 / G) + sub;
-    const bool active = i < N;
-    const auto pi = pos[active ? i : 0];
+    const bool in_range = i < N;
+    const auto pi = pos[in_range ? i : 0];
+    const bool active = in_range && !is_inert(pi.x); // an inert row walks nothing and gets an empty row
     const int cx = cell_coord<T>(pi.x, b.lo[0], b.Linv[0], nx);
     const int cy = cell_coord<T>(pi.y, b.lo[1], b.Linv[1], ny);
     const int cz = cell_coord<T>(pi.z, b.lo[2], b.Linv[2], nz);
@@ -261,7 +259,7 @@ __global__ __launch_bounds__(256) void build_nlist_kernel(const typename Vec4<T>
             }
         }
     }
-    if (active && g == 0) {
+    if (in_range && g == 0) {
         n_neigh[i] = count < pitch ? count : pitch;
         head_list[i] = i * pitch;
         if (count > *(volatile unsigned *)max_neigh) atomicMax(max_neigh, count);
@@ -489,6 +487,10 @@ __global__ __launch_bounds__(256) void cell_index_count_kernel(const typename Ve
     unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= Ntot) return;
     auto p = pos[i];
+    if (is_inert(p.x)) {
+        cell_of[i] = kDeadCell;
+        return;
+    }
     int cx = cell_coord<T>(p.x, b.lo[0], b.Linv[0], nx);
     int cy = cell_coord<T>(p.y, b.lo[1], b.Linv[1], ny);
     int cz = cell_coord<T>(p.z, b.lo[2], b.Linv[2], nz);
@@ -499,10 +501,11 @@ __global__ __launch_bounds__(256) void cell_index_count_kernel(const typename Ve
 
 template <typename V, bool TAG>
 __global__ void gather4_kernel(V *__restrict__ dest, const V *__restrict__ src, const int *__restrict__ order, unsigned n,
-                               int type_split, Gate gate) {
+                               int type_split, Gate gate, const unsigned *__restrict__ n_live = nullptr) {
     if (gate.closed()) return;
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (n_live != nullptr && i >= *n_live) return; // arrays with inert rows: only the binned particles have an entry
     const unsigned k = (unsigned)order[i];
     V p = src[k];
     if (TAG) set_tag(p.w, k | ((type_split >= 0 && scalar_as_int(p.w) >= type_split) ? kTagSide : 0u));
@@ -518,7 +521,7 @@ __global__ __launch_bounds__(256) void cell_count_kernel(const unsigned *__restr
                                                          unsigned *__restrict__ count, Gate gate) {
     if (gate.closed()) return;
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) atomicAdd(&count[cell_of[i]], 1u);
+    if (i < n && cell_of[i] != kDeadCell) atomicAdd(&count[cell_of[i]], 1u);
 }
 
 // exclusive scan of count[0..ncell) into start[0..ncell], one workgroup; cursor <- start.
@@ -592,7 +595,7 @@ __global__ __launch_bounds__(256) void cell_scatter_kernel(const unsigned *__res
                                                            unsigned *__restrict__ cursor, unsigned *__restrict__ order, Gate gate) {
     if (gate.closed()) return;
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) order[atomicAdd(&cursor[cell_of[i]], 1u)] = i;
+    if (i < n && cell_of[i] != kDeadCell) order[atomicAdd(&cursor[cell_of[i]], 1u)] = i;
 }
 
 // the scatter's order inside a cell depends on the atomics' timing: sort each cell's few members
@@ -646,7 +649,7 @@ extern "C" int htfs_cell_sort(const unsigned *d_cell_of, unsigned Ntot, unsigned
 }
 
 static int gather4(void *d_dest, const void *d_src, const int *d_order, int dtype, unsigned n, bool tag, int type_split,
-                   htf_stream stream) {
+                   htf_stream stream, const unsigned *d_n_live = nullptr) {
     using namespace htf;
     HTF_REQUIRE(d_dest && d_src && d_order, "htfs_gather4: null pointer");
     HTF_REQUIRE(!tag || n <= kTagSide, "htfs_gather4_tagged: %u particles do not fit the 31-bit tag", n);
@@ -654,11 +657,11 @@ static int gather4(void *d_dest, const void *d_src, const int *d_order, int dtyp
     const dim3 grid((n + 255) / 256), block(256);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == HTF_F32) {
-        if (tag) hipLaunchKernelGGL((gather4_kernel<float4, true>), grid, block, 0, s, (float4 *)d_dest, (const float4 *)d_src, d_order, n, type_split, g_gate);
-        else hipLaunchKernelGGL((gather4_kernel<float4, false>), grid, block, 0, s, (float4 *)d_dest, (const float4 *)d_src, d_order, n, type_split, g_gate);
+        if (tag) hipLaunchKernelGGL((gather4_kernel<float4, true>), grid, block, 0, s, (float4 *)d_dest, (const float4 *)d_src, d_order, n, type_split, g_gate, d_n_live);
+        else hipLaunchKernelGGL((gather4_kernel<float4, false>), grid, block, 0, s, (float4 *)d_dest, (const float4 *)d_src, d_order, n, type_split, g_gate, d_n_live);
     } else {
-        if (tag) hipLaunchKernelGGL((gather4_kernel<double4, true>), grid, block, 0, s, (double4 *)d_dest, (const double4 *)d_src, d_order, n, type_split, g_gate);
-        else hipLaunchKernelGGL((gather4_kernel<double4, false>), grid, block, 0, s, (double4 *)d_dest, (const double4 *)d_src, d_order, n, type_split, g_gate);
+        if (tag) hipLaunchKernelGGL((gather4_kernel<double4, true>), grid, block, 0, s, (double4 *)d_dest, (const double4 *)d_src, d_order, n, type_split, g_gate, d_n_live);
+        else hipLaunchKernelGGL((gather4_kernel<double4, false>), grid, block, 0, s, (double4 *)d_dest, (const double4 *)d_src, d_order, n, type_split, g_gate, d_n_live);
     }
     return check_launch("gather4_kernel");
 }
@@ -670,6 +673,12 @@ extern "C" int htfs_gather4(void *d_dest, const void *d_src, const int *d_order,
 extern "C" int htfs_gather4_tagged(void *d_dest, const void *d_src, const int *d_order, int dtype, unsigned n, int type_split,
                                    htf_stream stream) {
     return gather4(d_dest, d_src, d_order, dtype, n, true, type_split, stream);
+}
+
+extern "C" int htfs_gather4_tagged_live(void *d_dest, const void *d_src, const int *d_order, int dtype, unsigned n_max,
+                                        const unsigned *d_n_live, int type_split, htf_stream stream) {
+    HTF_REQUIRE(d_n_live, "htfs_gather4_tagged_live: null pointer");
+    return gather4(d_dest, d_src, d_order, dtype, n_max, true, type_split, stream, d_n_live);
 }
 
 // ---------------------------------------------------------------------------- slab decomposition: migration plan

@@ -56,6 +56,12 @@ HTF_API int htfs_gather4(void *d_dest, const void *d_src, const int *d_order, in
 HTF_API int htfs_gather4_tagged(void *d_dest, const void *d_src, const int *d_order, int dtype, unsigned n, int type_split,
                                 htf_stream stream);
 
+/* the same for arrays with INERT rows (x = NaN: fixed-capacity arrays of a decomposed system, hoomd_tf_amd/brick.py -- such rows
+ * are in no cell, htfs_cell_index gives them 0xFFFFFFFF and htfs_cell_sort leaves them out): only the first *d_n_live entries of
+ * d_order exist, d_n_live = d_cell_start + ncell (the binned total), read on the device */
+HTF_API int htfs_gather4_tagged_live(void *d_dest, const void *d_src, const int *d_order, int dtype, unsigned n_max,
+                                     const unsigned *d_n_live, int type_split, htf_stream stream);
+
 /* cell index of every particle (x fastest): d_cell_of[i] */
 HTF_API int htfs_cell_index(const void *d_pos, int dtype, unsigned Ntot, const htf_box *box,
                             const int *ncell3, unsigned *d_cell_of, htf_stream stream);
