@@ -43,6 +43,26 @@ class Box(C.Structure):
                 ("periodic", C.c_int * 3)]
 
 
+BRICK_MAX_MSG, BRICK_MAX_P = 8, 64   # include/htf_standin.h HTFS_BRICK_MAX_MSG / _MAX_P
+BC_N_INT, BC_N_BND, BC_N_CAND, BC_N_ARRIVED, BC_FLAGS, BC_REBUILDS, BC_MSG, BC_CLASS, BC_WORDS = 0, 1, 2, 3, 4, 5, 8, 16, 64
+BF_LOST, BF_MIG_OVERFLOW, BF_INT_OVERFLOW, BF_BND_OVERFLOW, BF_GHOST_OVERFLOW = 1, 2, 4, 8, 16
+
+
+class Brick(C.Structure):
+    """htfs_brick (include/htf_standin.h)."""
+    _fields_ = [("ndim", C.c_int), ("axis", C.c_int * 2), ("p", C.c_int * 2), ("me", C.c_int * 2), ("n_msg", C.c_int),
+                ("r_ghost", C.c_double), ("cap_int", C.c_uint), ("cap_bnd", C.c_uint),
+                ("ghost_cap", C.c_uint * BRICK_MAX_MSG), ("ghost_off", C.c_uint * BRICK_MAX_MSG),
+                ("mig_cap", C.c_uint * BRICK_MAX_MSG), ("mig_off", C.c_uint * BRICK_MAX_MSG),
+                ("shift", (C.c_double * 3) * BRICK_MAX_MSG)]
+
+
+class BrickWork(C.Structure):
+    """htfs_brick_work."""
+    _fields_ = [("key", C.c_void_p), ("order", C.c_void_p), ("sort_scratch", C.c_void_p), ("start1", C.c_void_p),
+                ("start2", C.c_void_p), ("tmp_pos", C.c_void_p), ("tmp_vel", C.c_void_p)]
+
+
 class PotentialDesc(C.Structure):
     _fields_ = [("kind", C.c_int), ("sigma", C.c_double),
                 ("gauss_r0", C.c_double), ("gauss_gap", C.c_double), ("gauss_coef", C.c_double),
@@ -129,6 +149,8 @@ PROTOTYPES = {
     "htf_halo_destroy": (None, [_vp]),
     "htf_halo_exchange_begin": (_i, [_vp, _vp, _i, _i, _i, _u, _u, _u, _u, _u, _u, _u, _u, _vp]),
     "htf_halo_exchange_end": (_i, [_vp, _vp]),
+    "htf_halo_exchange_n": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i]),
+    "htf_halo_allreduce_max_f32": (_i, [_vp, _vp, _u, _vp]),
     "htf_profile_enable": (_i, [_vp, _i]),
     "htf_profile_read": (_i, [_vp, C.POINTER(_d), C.POINTER(_d), C.POINTER(_u)]),
 }
@@ -138,6 +160,10 @@ STANDIN_PROTOTYPES = {
     "htfs_gather4": (_i, [_vp, _vp, _vp, _i, _u, _vp]),
     "htfs_gather4_tagged": (_i, [_vp, _vp, _vp, _i, _u, _i, _vp]),
     "htfs_cell_sort": (_i, [_vp, _u, _u, _vp, _vp, _vp, _vp]),
+    "htfs_gather4_tagged_live": (_i, [_vp, _vp, _vp, _i, _u, _vp, _i, _vp]),
+    "htfs_brick_migrate_pack": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "htfs_brick_migrate_merge": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "htfs_brick_pack_halo": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "htfs_slab_classify": (_i, [_vp, _i, _u, _vp, _i, _i, _d, _vp, _vp]),
     "htfs_segment_copy": (_i, [_vp, _vp, _u, _u, _vp, _vp, _vp, _vp]),
     "htfs_key_sort16": (_i, [_vp, _u, _vp, _vp, _vp, _vp]),

@@ -1,0 +1,372 @@
+// Brick decomposition with fixed-capacity arrays (include/htf_standin.h, hoomd_tf_amd/brick.py): the migration + ghost plan of
+// a rebuild as kernels whose every size is a CAPACITY -- particle counts, message counts and class boundaries never leave the
+// device, so a rebuild needs no host synchronisation and a whole check period of the decomposed step, rebuild included, can be
+// captured into one hipGraph.  The stand-in for HOOMD's Communicator (migrateParticles + exchangeGhosts + the per-step ghost
+// update; the reference inherits them from HOOMD under MPI, test_mpi_tensorflow.py:57-79); outside the drop-in boundary.
+#include "htf_common.h"
+#include "box_math.h"
+#include "htf_standin.h"
+#include "standin_gate.h"
+#include "key_sort.h"
+
+namespace htf {
+
+// by-value copy of htfs_brick in the positions' precision
+template <typename T>
+struct BrickArgs {
+    int ndim, n_msg;
+    int axis[2], p[2], me[2];
+    T r_ghost;
+    unsigned cap_int, cap_bnd;
+    unsigned ghost_cap[HTFS_BRICK_MAX_MSG], ghost_off[HTFS_BRICK_MAX_MSG];
+    unsigned mig_cap[HTFS_BRICK_MAX_MSG], mig_off[HTFS_BRICK_MAX_MSG];
+    T shift[HTFS_BRICK_MAX_MSG][3];
+};
+
+template <typename T>
+static BrickArgs<T> make_args(const htfs_brick *g) {
+    BrickArgs<T> a;
+    a.ndim = g->ndim;
+    a.n_msg = g->n_msg;
+    for (int d = 0; d < 2; ++d) {
+        a.axis[d] = g->axis[d];
+        a.p[d] = g->p[d];
+        a.me[d] = g->me[d];
+    }
+    a.r_ghost = (T)g->r_ghost;
+    a.cap_int = g->cap_int;
+    a.cap_bnd = g->cap_bnd;
+    for (int m = 0; m < HTFS_BRICK_MAX_MSG; ++m) {
+        a.ghost_cap[m] = g->ghost_cap[m];
+        a.ghost_off[m] = g->ghost_off[m];
+        a.mig_cap[m] = g->mig_cap[m];
+        a.mig_off[m] = g->mig_off[m];
+        for (int c = 0; c < 3; ++c) a.shift[m][c] = (T)g->shift[m][c];
+    }
+    return a;
+}
+
+template <typename V>
+__device__ __forceinline__ auto comp(const V &p, int axis) -> decltype(p.x) { return axis == 0 ? p.x : (axis == 1 ? p.y : p.z); }
+
+// offset digit (0, 1, 2 <-> -1, 0, +1) of message m along decomposed axis d
+__device__ __forceinline__ int msg_digit(int m, int ndim, int d) {
+    const int centre = ndim == 1 ? 1 : 4;
+    const int raw = m < centre ? m : m + 1;
+    return d == 0 ? raw % 3 : raw / 3;
+}
+
+// does a particle of class key c (k_0 + 4 k_1) travel in halo message m?
+__device__ __forceinline__ bool msg_takes_class(int m, int ndim, unsigned c) {
+    bool ok = true;
+    for (int d = 0; d < ndim; ++d) {
+        const int o = msg_digit(m, ndim, d) - 1;
+        const unsigned k = (c >> (2 * d)) & 3u;
+        ok = ok && (o == 0 || (o < 0 ? (k == 1u || k == 2u) : (k == 2u || k == 3u)));
+    }
+    return ok;
+}
+
+template <typename V>
+__device__ __forceinline__ V inert_position() {
+    V p;
+    const auto nan = __builtin_nanf("");
+    p.x = nan, p.y = nan, p.z = nan, p.w = 0;
+    return p;
+}
+
+// ---- K1: destination key of every local row: 0 stay | 1 + message index | n_msg + 1 inert.  The arithmetic is SlabDomain's
+// (slab_classify_kernel) per decomposed axis, in the positions' own precision: owner = #(interior cuts <= x).
+template <typename T, typename V4>
+__global__ __launch_bounds__(256) void brick_dest_kernel(const V4 *__restrict__ pos, unsigned cap, BrickArgs<T> a,
+                                                         const T *__restrict__ bounds, unsigned *__restrict__ key,
+                                                         unsigned *__restrict__ counts) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cap) return;
+    const V4 p = pos[i];
+    if (is_inert(p.x)) {
+        key[i] = (unsigned)a.n_msg + 1u;
+        return;
+    }
+    int raw = 0, mul = 1;
+    bool stay = true, lost = false;
+    for (int d = 0; d < a.ndim; ++d) {
+        const T x = comp(p, a.axis[d]);
+        const T *b = bounds + d * (HTFS_BRICK_MAX_P + 1);
+        int owner = 0;
+        for (int c = 1; c < a.p[d]; ++c) owner += (b[c] <= x) ? 1 : 0;
+        int off;
+        if (a.p[d] == 2)
+            off = owner != a.me[d] ? 1 : 0; // both faces lead to the one peer: everything that leaves travels "up"
+        else if (owner == a.me[d])
+            off = 0;
+        else if (owner == (a.me[d] + a.p[d] - 1) % a.p[d])
+            off = -1;
+        else if (owner == (a.me[d] + 1) % a.p[d])
+            off = 1;
+        else {
+            off = 0;
+            lost = true;
+        }
+        stay = stay && off == 0;
+        raw += (off + 1) * mul;
+        mul *= 3;
+    }
+    if (lost) atomicOr(&counts[HTFS_BC_FLAGS], (unsigned)HTFS_BF_LOST);
+    const int centre = a.ndim == 1 ? 1 : 4;
+    key[i] = (stay || lost) ? 0u : 1u + (unsigned)(raw < centre ? raw : raw - 1);
+}
+
+// ---- K3: migrants into their messages; row 0 of a message is its header (count in the first word)
+template <typename T, typename V4>
+__global__ __launch_bounds__(256) void brick_pack_mig_kernel(const V4 *__restrict__ pos, const V4 *__restrict__ vel, BrickArgs<T> a,
+                                                             const unsigned *__restrict__ order, const unsigned *__restrict__ start1,
+                                                             V4 *__restrict__ send, unsigned total_rows, unsigned *__restrict__ counts) {
+    const unsigned r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= total_rows) return;
+    int m = 0;
+    while (m + 1 < a.n_msg && r >= a.mig_off[m + 1]) ++m;
+    const unsigned j = r - a.mig_off[m];
+    const unsigned first = start1[1 + m], n = start1[2 + m] - first;
+    const unsigned room = a.mig_cap[m] - 1u;
+    if (j == 0) {
+        if (n > room) atomicOr(&counts[HTFS_BC_FLAGS], (unsigned)HTFS_BF_MIG_OVERFLOW);
+        *reinterpret_cast<unsigned *>(&send[2 * (size_t)r]) = n < room ? n : room;
+        return;
+    }
+    if (j - 1u >= n) return;
+    const unsigned src = order[first + j - 1u];
+    V4 p = pos[src];
+    p.x += a.shift[m][0], p.y += a.shift[m][1], p.z += a.shift[m][2];
+    send[2 * (size_t)r] = p;
+    send[2 * (size_t)r + 1] = vel[src];
+}
+
+// ---- K4: the candidates of this brick after the exchange -- [stayed | from offset index n_msg-1 | ... | from index 0] -- copied
+// into the scratch arrays with their class key in THIS brick (k_0 + 4 k_1; 4^ndim = nothing here)
+template <typename T, typename V4>
+__global__ __launch_bounds__(256) void brick_home_kernel(const V4 *__restrict__ pos, const V4 *__restrict__ vel, BrickArgs<T> a,
+                                                         const T *__restrict__ bounds, const unsigned *__restrict__ order,
+                                                         const unsigned *__restrict__ start1, const V4 *__restrict__ recv,
+                                                         V4 *__restrict__ tmp_pos, V4 *__restrict__ tmp_vel, unsigned *__restrict__ key2,
+                                                         unsigned cand_cap, unsigned *__restrict__ counts) {
+    const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cand_cap) return;
+    const unsigned dead_key = a.ndim == 1 ? 4u : 16u;
+    const unsigned n_stay = start1[1];
+    V4 p, v;
+    bool live = true;
+    if (c < n_stay) {
+        const unsigned src = order[c];
+        p = pos[src];
+        v = vel[src];
+    } else {
+        unsigned j = c - n_stay, arrived = 0;
+        int m = a.n_msg - 1;
+        live = false;
+        for (; m >= 0; --m) {
+            const unsigned n = *reinterpret_cast<const unsigned *>(&recv[2 * (size_t)a.mig_off[m]]);
+            arrived += n;
+            if (!live && j < n) {
+                live = true;
+                p = recv[2 * (size_t)(a.mig_off[m] + 1u + j)];
+                v = recv[2 * (size_t)(a.mig_off[m] + 1u + j) + 1];
+            }
+            if (!live) j -= n;
+        }
+        if (c == n_stay) { // (one thread: the totals of this rebuild)
+            counts[HTFS_BC_N_CAND] = n_stay + arrived;
+            counts[HTFS_BC_N_ARRIVED] += arrived;
+            counts[HTFS_BC_REBUILDS] += 1u;
+        }
+    }
+    if (!live) {
+        key2[c] = dead_key;
+        return;
+    }
+    unsigned k = 0;
+    for (int d = 0; d < a.ndim; ++d) {
+        const T x = comp(p, a.axis[d]);
+        const T *b = bounds + d * (HTFS_BRICK_MAX_P + 1);
+        const bool near_lo = x < b[a.me[d]] + a.r_ghost, near_hi = x >= b[a.me[d] + 1] - a.r_ghost;
+        k |= (near_lo ? (near_hi ? 2u : 1u) : (near_hi ? 3u : 0u)) << (2 * d);
+    }
+    key2[c] = k;
+    tmp_pos[c] = p;
+    tmp_vel[c] = v;
+}
+
+// ---- K6: the two segments, inert rows behind the particles; counts, class boundaries, message sizes, overflow flags
+template <typename T, typename V4>
+__global__ __launch_bounds__(256) void brick_place_kernel(V4 *__restrict__ pos, V4 *__restrict__ vel, BrickArgs<T> a,
+                                                          const unsigned *__restrict__ order2, const unsigned *__restrict__ start2,
+                                                          const V4 *__restrict__ tmp_pos, const V4 *__restrict__ tmp_vel,
+                                                          unsigned *__restrict__ n_neigh, unsigned *__restrict__ counts) {
+    const unsigned r = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned nclass = a.ndim == 1 ? 4u : 16u;
+    const unsigned n_int = start2[1], n_live = start2[nclass], n_bnd = n_live - n_int;
+    if (r == 0) {
+        counts[HTFS_BC_N_INT] = n_int < a.cap_int ? n_int : a.cap_int;
+        counts[HTFS_BC_N_BND] = n_bnd < a.cap_bnd ? n_bnd : a.cap_bnd;
+        unsigned f = 0;
+        if (n_int > a.cap_int) f |= (unsigned)HTFS_BF_INT_OVERFLOW;
+        if (n_bnd > a.cap_bnd) f |= (unsigned)HTFS_BF_BND_OVERFLOW;
+        if (f) atomicOr(&counts[HTFS_BC_FLAGS], f);
+    }
+    if (r <= nclass) counts[HTFS_BC_CLASS + r] = start2[r];
+    if (r < (unsigned)a.n_msg) {
+        unsigned n = 0;
+        for (unsigned c = 1; c < nclass; ++c)
+            if (msg_takes_class((int)r, a.ndim, c)) n += start2[c + 1] - start2[c];
+        if (n > a.ghost_cap[r]) {
+            atomicOr(&counts[HTFS_BC_FLAGS], (unsigned)HTFS_BF_GHOST_OVERFLOW);
+            n = a.ghost_cap[r];
+        }
+        counts[HTFS_BC_MSG + r] = n;
+    }
+    if (r >= a.cap_int + a.cap_bnd) return;
+    const bool interior = r < a.cap_int;
+    const unsigned j = interior ? r : r - a.cap_int;
+    const bool live = j < (interior ? n_int : n_bnd);
+    if (live) {
+        const unsigned src = order2[(interior ? 0u : n_int) + j];
+        pos[r] = tmp_pos[src];
+        vel[r] = tmp_vel[src];
+    } else {
+        pos[r] = inert_position<V4>();
+        V4 v;
+        v.x = 0, v.y = 0, v.z = 0, v.w = 1;
+        vel[r] = v;
+        if (n_neigh != nullptr) n_neigh[r] = 0u;
+    }
+}
+
+// ---- K8 (every step): the halo messages, packed; a message's rows beyond its count are inert
+template <typename T, typename V4>
+__global__ __launch_bounds__(256) void brick_pack_halo_kernel(const V4 *__restrict__ pos, BrickArgs<T> a, const unsigned *__restrict__ counts,
+                                                              V4 *__restrict__ send, V4 *__restrict__ direct, unsigned total_rows) {
+    const unsigned r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= total_rows) return;
+    int m = 0;
+    while (m + 1 < a.n_msg && r >= a.ghost_off[m + 1]) ++m;
+    unsigned j = r - a.ghost_off[m];
+    V4 p = inert_position<V4>();
+    if (j < counts[HTFS_BC_MSG + m]) {
+        const unsigned nclass = a.ndim == 1 ? 4u : 16u;
+        const unsigned n_int = counts[HTFS_BC_CLASS + 1];
+        for (unsigned c = 1; c < nclass; ++c) {
+            if (!msg_takes_class(m, a.ndim, c)) continue;
+            const unsigned first = counts[HTFS_BC_CLASS + c], n = counts[HTFS_BC_CLASS + c + 1] - first;
+            if (j < n) {
+                p = pos[a.cap_int + (first - n_int) + j];
+                p.x += a.shift[m][0], p.y += a.shift[m][1], p.z += a.shift[m][2];
+                break;
+            }
+            j -= n;
+        }
+    }
+    if (send != nullptr) send[r] = p;
+    // this rank as its own neighbor: message m (to offset o) is what it receives from offset -o, index n_msg - 1 - m
+    if (direct != nullptr) direct[a.ghost_off[a.n_msg - 1 - m] + (r - a.ghost_off[m])] = p;
+}
+
+static int check_geom(const htfs_brick *g, const char *who) {
+    HTF_REQUIRE(g, "%s: null geometry", who);
+    HTF_REQUIRE((g->ndim == 1 && g->n_msg == 2) || (g->ndim == 2 && g->n_msg == 8), "%s: ndim %d with %d messages (1 / 2 or 2 / 8)", who,
+                g->ndim, g->n_msg);
+    for (int d = 0; d < g->ndim; ++d)
+        HTF_REQUIRE(g->axis[d] >= 0 && g->axis[d] < 3 && g->p[d] >= 2 && g->p[d] <= HTFS_BRICK_MAX_P && g->me[d] >= 0 && g->me[d] < g->p[d],
+                    "%s: axis %d: %d bricks, coordinate %d", who, g->axis[d], g->p[d], g->me[d]);
+    for (int m = 0; m < g->n_msg; ++m) {
+        HTF_REQUIRE(g->mig_cap[m] >= 2 && g->ghost_cap[m] >= 1, "%s: message %d has no room", who, m);
+        HTF_REQUIRE(g->ghost_cap[m] == g->ghost_cap[g->n_msg - 1 - m] && g->mig_cap[m] == g->mig_cap[g->n_msg - 1 - m],
+                    "%s: capacities of opposite messages must agree (%d)", who, m);
+        if (m > 0)
+            HTF_REQUIRE(g->mig_off[m] == g->mig_off[m - 1] + g->mig_cap[m - 1] && g->ghost_off[m] == g->ghost_off[m - 1] + g->ghost_cap[m - 1],
+                        "%s: message %d does not follow message %d", who, m, m - 1);
+        else
+            HTF_REQUIRE(g->mig_off[0] == 0 && g->ghost_off[0] == 0, "%s: message 0 must start at row 0", who);
+    }
+    HTF_REQUIRE(g->cap_int + g->cap_bnd > 0, "%s: no local rows", who);
+    return HTF_OK;
+}
+
+} // namespace htf
+
+using namespace htf;
+
+extern "C" int htfs_brick_migrate_pack(const htfs_brick *g, const void *d_pos, const void *d_vel, int dtype, const void *d_bounds,
+                                       const htfs_brick_work *w, void *d_mig_send, unsigned *d_counts, htf_stream stream) {
+    if (int rc = check_geom(g, "htfs_brick_migrate_pack")) return rc;
+    HTF_REQUIRE(d_pos && d_vel && d_bounds && w && w->key && w->order && w->sort_scratch && w->start1 && d_mig_send && d_counts,
+                "htfs_brick_migrate_pack: null pointer");
+    HTF_REQUIRE(dtype == HTF_F32 || dtype == HTF_F64, "htfs_brick_migrate_pack: bad dtype %d", dtype);
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned cap = g->cap_int + g->cap_bnd;
+    const unsigned mig_rows = g->mig_off[g->n_msg - 1] + g->mig_cap[g->n_msg - 1];
+    if (dtype == HTF_F32)
+        hipLaunchKernelGGL((brick_dest_kernel<float, float4>), dim3((cap + 255) / 256), dim3(256), 0, s, (const float4 *)d_pos, cap,
+                           make_args<float>(g), (const float *)d_bounds, w->key, d_counts);
+    else
+        hipLaunchKernelGGL((brick_dest_kernel<double, double4>), dim3((cap + 255) / 256), dim3(256), 0, s, (const double4 *)d_pos, cap,
+                           make_args<double>(g), (const double *)d_bounds, w->key, d_counts);
+    if (int rc = key_sort<16>(w->key, cap, nullptr, w->sort_scratch, w->start1, w->order, s)) return rc;
+    if (dtype == HTF_F32)
+        hipLaunchKernelGGL((brick_pack_mig_kernel<float, float4>), dim3((mig_rows + 255) / 256), dim3(256), 0, s, (const float4 *)d_pos,
+                           (const float4 *)d_vel, make_args<float>(g), w->order, w->start1, (float4 *)d_mig_send, mig_rows, d_counts);
+    else
+        hipLaunchKernelGGL((brick_pack_mig_kernel<double, double4>), dim3((mig_rows + 255) / 256), dim3(256), 0, s, (const double4 *)d_pos,
+                           (const double4 *)d_vel, make_args<double>(g), w->order, w->start1, (double4 *)d_mig_send, mig_rows, d_counts);
+    return check_launch("brick_pack_mig_kernel");
+}
+
+extern "C" int htfs_brick_migrate_merge(const htfs_brick *g, void *d_pos, void *d_vel, int dtype, const void *d_bounds,
+                                        const htfs_brick_work *w, const void *d_mig_recv, unsigned *d_n_neigh, unsigned *d_counts,
+                                        htf_stream stream) {
+    if (int rc = check_geom(g, "htfs_brick_migrate_merge")) return rc;
+    HTF_REQUIRE(d_pos && d_vel && d_bounds && w && w->key && w->order && w->sort_scratch && w->start1 && w->start2 && w->tmp_pos &&
+                    w->tmp_vel && d_mig_recv && d_counts,
+                "htfs_brick_migrate_merge: null pointer");
+    HTF_REQUIRE(dtype == HTF_F32 || dtype == HTF_F64, "htfs_brick_migrate_merge: bad dtype %d", dtype);
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned cap = g->cap_int + g->cap_bnd;
+    const unsigned mig_rows = g->mig_off[g->n_msg - 1] + g->mig_cap[g->n_msg - 1];
+    const unsigned cand = cap + mig_rows;
+    // (w->key and w->order serve both sorts: brick_home_kernel has consumed the first order before the second sort writes its own)
+    if (dtype == HTF_F32)
+        hipLaunchKernelGGL((brick_home_kernel<float, float4>), dim3((cand + 255) / 256), dim3(256), 0, s, (const float4 *)d_pos,
+                           (const float4 *)d_vel, make_args<float>(g), (const float *)d_bounds, w->order, w->start1,
+                           (const float4 *)d_mig_recv, (float4 *)w->tmp_pos, (float4 *)w->tmp_vel, w->key, cand, d_counts);
+    else
+        hipLaunchKernelGGL((brick_home_kernel<double, double4>), dim3((cand + 255) / 256), dim3(256), 0, s, (const double4 *)d_pos,
+                           (const double4 *)d_vel, make_args<double>(g), (const double *)d_bounds, w->order, w->start1,
+                           (const double4 *)d_mig_recv, (double4 *)w->tmp_pos, (double4 *)w->tmp_vel, w->key, cand, d_counts);
+    int rc = g->ndim == 1 ? key_sort<16>(w->key, cand, nullptr, w->sort_scratch, w->start2, w->order, s)
+                          : key_sort<32>(w->key, cand, nullptr, w->sort_scratch, w->start2, w->order, s);
+    if (rc) return rc;
+    const unsigned rows = cap > 64u ? cap : 64u; // (the first threads also publish counts and message sizes)
+    if (dtype == HTF_F32)
+        hipLaunchKernelGGL((brick_place_kernel<float, float4>), dim3((rows + 255) / 256), dim3(256), 0, s, (float4 *)d_pos, (float4 *)d_vel,
+                           make_args<float>(g), w->order, w->start2, (const float4 *)w->tmp_pos, (const float4 *)w->tmp_vel, d_n_neigh,
+                           d_counts);
+    else
+        hipLaunchKernelGGL((brick_place_kernel<double, double4>), dim3((rows + 255) / 256), dim3(256), 0, s, (double4 *)d_pos,
+                           (double4 *)d_vel, make_args<double>(g), w->order, w->start2, (const double4 *)w->tmp_pos,
+                           (const double4 *)w->tmp_vel, d_n_neigh, d_counts);
+    return check_launch("brick_place_kernel");
+}
+
+extern "C" int htfs_brick_pack_halo(const htfs_brick *g, const void *d_pos, int dtype, const unsigned *d_counts, void *d_send,
+                                    void *d_ghost_direct, htf_stream stream) {
+    if (int rc = check_geom(g, "htfs_brick_pack_halo")) return rc;
+    HTF_REQUIRE(d_pos && d_counts && (d_send || d_ghost_direct), "htfs_brick_pack_halo: null pointer");
+    HTF_REQUIRE(dtype == HTF_F32 || dtype == HTF_F64, "htfs_brick_pack_halo: bad dtype %d", dtype);
+    const unsigned rows = g->ghost_off[g->n_msg - 1] + g->ghost_cap[g->n_msg - 1];
+    if (dtype == HTF_F32)
+        hipLaunchKernelGGL((brick_pack_halo_kernel<float, float4>), dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                           (const float4 *)d_pos, make_args<float>(g), d_counts, (float4 *)d_send, (float4 *)d_ghost_direct, rows);
+    else
+        hipLaunchKernelGGL((brick_pack_halo_kernel<double, double4>), dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                           (const double4 *)d_pos, make_args<double>(g), d_counts, (double4 *)d_send, (double4 *)d_ghost_direct, rows);
+    return check_launch("brick_pack_halo_kernel");
+}

@@ -23,7 +23,7 @@ namespace htf {
 
 typedef struct ncclComm *ncclComm_t;
 struct NcclUniqueId { char internal[128]; };
-enum { kNcclSuccess = 0, kNcclChar = 0 };
+enum { kNcclSuccess = 0, kNcclChar = 0, kNcclFloat32 = 7, kNcclMax = 2 };
 
 struct Rccl {
     int (*GetUniqueId)(NcclUniqueId *) = nullptr;
@@ -33,6 +33,7 @@ struct Rccl {
     int (*GroupEnd)() = nullptr;
     int (*Send)(const void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     int (*Recv)(void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
     bool ok = false;
     Rccl() {
@@ -47,8 +48,9 @@ struct Rccl {
         GroupEnd = (decltype(GroupEnd))dlsym(h, "ncclGroupEnd");
         Send = (decltype(Send))dlsym(h, "ncclSend");
         Recv = (decltype(Recv))dlsym(h, "ncclRecv");
+        AllReduce = (decltype(AllReduce))dlsym(h, "ncclAllReduce");
         GetErrorString = (decltype(GetErrorString))dlsym(h, "ncclGetErrorString");
-        ok = GetUniqueId && CommInitRank && CommDestroy && GroupStart && GroupEnd && Send && Recv && GetErrorString;
+        ok = GetUniqueId && CommInitRank && CommDestroy && GroupStart && GroupEnd && Send && Recv && AllReduce && GetErrorString;
     }
 };
 
@@ -166,5 +168,52 @@ extern "C" int htf_halo_exchange_end(htf_halo *h, htf_stream stream) {
     if (!h->pending) return HTF_OK;
     HTF_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, h->done, 0));
     h->pending = false;
+    return HTF_OK;
+}
+
+// Any number of messages in one group (round 5: the brick decomposition's 2 or 8 halo messages, and the fixed-size migration
+// messages of a rebuild -- hoomd_tf_amd/brick.py).  Sends are posted in the order given, then the receives in the order given:
+// the caller orders them so that between any two ranks the k-th send meets the k-th receive.  async != 0: on the halo stream
+// behind everything queued on `stream`, ended by htf_halo_exchange_end (work on `stream` in between overlaps the transfer);
+// async == 0: on `stream` itself.  Both forms are plain stream work: a hipGraph capture of `stream` records them (the halo
+// stream joins the capture through its two events).
+extern "C" int htf_halo_exchange_n(htf_halo *h, int n_send, const void *const *send_ptrs, const size_t *send_bytes, const int *send_peers,
+                                   int n_recv, void *const *recv_ptrs, const size_t *recv_bytes, const int *recv_peers,
+                                   htf_stream stream, int async) {
+    using namespace htf;
+    HTF_REQUIRE(h && (n_send == 0 || (send_ptrs && send_bytes && send_peers)) && (n_recv == 0 || (recv_ptrs && recv_bytes && recv_peers)),
+                "htf_halo_exchange_n: null pointer");
+    HTF_REQUIRE(n_send >= 0 && n_recv >= 0 && n_send <= 64 && n_recv <= 64, "htf_halo_exchange_n: %d sends, %d receives", n_send, n_recv);
+    HTF_REQUIRE(!h->pending, "htf_halo_exchange_n: the previous exchange has not been ended");
+    for (int i = 0; i < n_send; ++i) HTF_REQUIRE(send_peers[i] >= 0 && send_peers[i] < h->world, "htf_halo_exchange_n: peer %d", send_peers[i]);
+    for (int i = 0; i < n_recv; ++i) HTF_REQUIRE(recv_peers[i] >= 0 && recv_peers[i] < h->world, "htf_halo_exchange_n: peer %d", recv_peers[i]);
+    hipStream_t on = (hipStream_t)stream;
+    if (async) {
+        HTF_CHECK_HIP(hipEventRecord(h->ready, (hipStream_t)stream));
+        HTF_CHECK_HIP(hipStreamWaitEvent(h->stream, h->ready, 0));
+        on = h->stream;
+    }
+    HTF_CHECK_NCCL(rccl().GroupStart());
+    int rc = kNcclSuccess;
+    for (int i = 0; i < n_send && rc == kNcclSuccess; ++i)
+        if (send_bytes[i]) rc = rccl().Send(send_ptrs[i], send_bytes[i], kNcclChar, send_peers[i], h->comm, on);
+    for (int i = 0; i < n_recv && rc == kNcclSuccess; ++i)
+        if (recv_bytes[i]) rc = rccl().Recv(recv_ptrs[i], recv_bytes[i], kNcclChar, recv_peers[i], h->comm, on);
+    const int rc_end = rccl().GroupEnd();
+    HTF_CHECK_NCCL(rc);
+    HTF_CHECK_NCCL(rc_end);
+    if (async) {
+        HTF_CHECK_HIP(hipEventRecord(h->done, h->stream));
+        h->pending = true;
+    }
+    return HTF_OK;
+}
+
+// *d_value <- max over ranks, in place, on `stream` (the distance check of a decomposed system: every rank takes the same
+// rebuild decision)
+extern "C" int htf_halo_allreduce_max_f32(htf_halo *h, float *d_value, unsigned n, htf_stream stream) {
+    using namespace htf;
+    HTF_REQUIRE(h && d_value && n > 0, "htf_halo_allreduce_max_f32: null pointer");
+    HTF_CHECK_NCCL(rccl().AllReduce(d_value, d_value, n, kNcclFloat32, kNcclMax, h->comm, (hipStream_t)stream));
     return HTF_OK;
 }

@@ -108,6 +108,8 @@ void bind(py::module &m, const char *name, R (*fn)(A...)) {
     X(htf_halo_destroy) \
     X(htf_halo_exchange_begin) \
     X(htf_halo_exchange_end) \
+    X(htf_halo_exchange_n) \
+    X(htf_halo_allreduce_max_f32) \
     X(htf_profile_enable) \
     X(htf_profile_read) \
     X(htfs_nve_step) \
@@ -116,6 +118,7 @@ void bind(py::module &m, const char *name, R (*fn)(A...)) {
     X(htfs_cell_sort) \
     X(htfs_gather4) \
     X(htfs_gather4_tagged) \
+    X(htfs_gather4_tagged_live) \
     X(htfs_cell_index) \
     X(htfs_set_gate) \
     X(htfs_commit_rebuild) \
@@ -123,7 +126,10 @@ void bind(py::module &m, const char *name, R (*fn)(A...)) {
     X(htfs_check_rebuild_nlist) \
     X(htfs_slab_classify) \
     X(htfs_key_sort16) \
-    X(htfs_segment_copy)
+    X(htfs_segment_copy) \
+    X(htfs_brick_migrate_pack) \
+    X(htfs_brick_migrate_merge) \
+    X(htfs_brick_pack_halo)
 
 PYBIND11_MODULE(_htf_abi, m) {
     m.doc() = "pybind11 binding of libhtf_amd.so's C ABI: pointers as integers";

@@ -8,6 +8,7 @@
 #include "box_math.h"
 #include "htf_standin.h"
 #include "standin_gate.h"
+#include "key_sort.h"
 
 namespace htf {
 
@@ -724,89 +725,10 @@ extern "C" int htfs_slab_classify(const void *d_pos, int dtype, unsigned N, cons
     return check_launch("slab_classify_kernel");
 }
 
-// Stable counting sort over 16 keys with MANY members each (the slab plan's (destination, class) keys: tens of thousands of
-// "stay, interior" particles) -- htfs_cell_sort orders the members of a cell with a one-thread insertion sort, right for cells
-// of a handful of particles and quadratic here.  Tiles of 4096 elements: (1) per-tile histograms, (2) one small block turns
-// them into per-(tile, key) output offsets, key-major, (3) every tile ranks its elements among equals in index order -- a
-// wave ballot per key, wave totals through LDS, 256 elements per round -- and scatters i to order[offset].  Deterministic.
-constexpr unsigned kSortTile = 4096;
-
-__global__ __launch_bounds__(256) void key16_hist_kernel(const unsigned *__restrict__ key, unsigned n, unsigned *__restrict__ tile_hist) {
-    __shared__ unsigned h[16];
-    if (threadIdx.x < 16) h[threadIdx.x] = 0;
-    __syncthreads();
-    const unsigned base = blockIdx.x * kSortTile;
-    for (unsigned r = 0; r < kSortTile / 256; ++r) {
-        const unsigned i = base + r * 256 + threadIdx.x;
-        if (i < n) atomicAdd(&h[key[i] & 15u], 1u);
-    }
-    __syncthreads();
-    if (threadIdx.x < 16) tile_hist[blockIdx.x * 16 + threadIdx.x] = h[threadIdx.x];
-}
-
-__global__ __launch_bounds__(64) void key16_scan_kernel(unsigned *__restrict__ tile_hist, unsigned ntiles, unsigned *__restrict__ start) {
-    // lane k < 16 walks key k's tile counts; the key totals are exchanged through LDS for the key-major base
-    __shared__ unsigned tot[16];
-    const unsigned k = threadIdx.x;
-    unsigned sum = 0;
-    if (k < 16)
-        for (unsigned t = 0; t < ntiles; ++t) sum += tile_hist[t * 16 + k];
-    if (k < 16) tot[k] = sum;
-    __syncthreads();
-    if (k < 16) {
-        unsigned base = 0;
-        for (unsigned j = 0; j < k; ++j) base += tot[j];
-        start[k] = base;
-        if (k == 15) start[16] = base + sum;
-        unsigned run = base;
-        for (unsigned t = 0; t < ntiles; ++t) { // counts -> offsets, in place
-            const unsigned c = tile_hist[t * 16 + k];
-            tile_hist[t * 16 + k] = run;
-            run += c;
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void key16_scatter_kernel(const unsigned *__restrict__ key, unsigned n,
-                                                            const unsigned *__restrict__ tile_off, unsigned *__restrict__ order) {
-    __shared__ unsigned run[16];       // next free output slot of each key in this tile
-    __shared__ unsigned wcnt[4][16];   // this round's per-wave counts
-    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    if (threadIdx.x < 16) run[threadIdx.x] = tile_off[blockIdx.x * 16 + threadIdx.x];
-    __syncthreads();
-    const unsigned base = blockIdx.x * kSortTile;
-    for (unsigned r = 0; r < kSortTile / 256; ++r) {
-        const unsigned i = base + r * 256 + threadIdx.x;
-        const bool live = i < n;
-        const unsigned my = live ? (key[i] & 15u) : 16u;
-        unsigned rank = 0;
-#pragma unroll
-        for (unsigned k = 0; k < 16; ++k) {
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(my == k);
-            if (my == k) rank = ballot_rank(m);
-            if (lane == 0) wcnt[wave][k] = (unsigned)__popcll(m);
-        }
-        __syncthreads();
-        if (live) {
-            unsigned off = run[my] + rank;
-            for (unsigned w = 0; w < wave; ++w) off += wcnt[w][my];
-            order[off] = i;
-        }
-        __syncthreads();
-        if (threadIdx.x < 16) run[threadIdx.x] += wcnt[0][threadIdx.x] + wcnt[1][threadIdx.x] + wcnt[2][threadIdx.x] + wcnt[3][threadIdx.x];
-        __syncthreads();
-    }
-}
-
 extern "C" int htfs_key_sort16(const unsigned *d_key, unsigned N, unsigned *d_scratch, unsigned *d_start, unsigned *d_order,
                                htf_stream stream) {
     HTF_REQUIRE(d_key && d_scratch && d_start && d_order, "htfs_key_sort16: null pointer");
-    const unsigned ntiles = (N + kSortTile - 1) / kSortTile;
-    hipStream_t s = (hipStream_t)stream;
-    if (ntiles) hipLaunchKernelGGL(key16_hist_kernel, dim3(ntiles), dim3(256), 0, s, d_key, N, d_scratch);
-    hipLaunchKernelGGL(key16_scan_kernel, dim3(1), dim3(64), 0, s, d_scratch, ntiles, d_start);
-    if (ntiles) hipLaunchKernelGGL(key16_scatter_kernel, dim3(ntiles), dim3(256), 0, s, d_key, N, d_scratch, d_order);
-    return check_launch("htfs_key_sort16");
+    return htf::key_sort<16>(d_key, N, nullptr, d_scratch, d_start, d_order, (hipStream_t)stream); // csrc/key_sort.h
 }
 
 // up to HTFS_MAX_SEGMENTS row ranges copied in one launch: dst[dst_start[s] + j] = src[src_start[s] + j], j < count[s],

@@ -66,7 +66,8 @@ class _NativeHalo:
     """The per-step halo through libhtf_amd.so's own RCCL communicator (csrc/halo.hip): one grouped
     ncclSend x2 / ncclRecv x2 on a dedicated stream, two events, no Python objects per message."""
 
-    def __init__(self, rank, world, group):
+    def __init__(self, rank, world, group, solo=False):
+        """``solo``: a communicator of one rank (brick.py's replica mode: the rank is its own neighbor), no process group needed."""
         import ctypes as C
         from ._lib import lib, check
         self._C, self._lib, self._check = C, lib, check
@@ -78,7 +79,9 @@ class _NativeHalo:
             if lib.htf_halo_unique_id(buf) == 0:
                 ident[:128] = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8)
                 ident[128] = 1
-        if dist.get_backend(group) == "nccl":  # the id travels through whatever channel the job has
+        if solo:
+            pass
+        elif dist.get_backend(group) == "nccl":  # the id travels through whatever channel the job has
             dev = ident.cuda()
             dist.broadcast(dev, src=0, group=group)
             ident = dev.cpu()
@@ -98,6 +101,33 @@ class _NativeHalo:
             self._h, pos.data_ptr(), ops._dt(pos), int(left), int(right), send_left[0], send_left[1] - send_left[0],
             send_right[0], send_right[1] - send_right[0], recv_left[0], recv_left[1] - recv_left[0],
             recv_right[0], recv_right[1] - recv_right[0], s))
+
+    def exchange(self, send, recv, caps, offs, neighbors, opposite, overlap=True):
+        """brick.py's grouped exchange: message m = rows [offs[m], +caps[m]) of ``send`` to neighbors[m], ascending m; the message
+        from the neighbor at offset index j into rows [offs[j], +caps[j]) of ``recv``, descending j.  ``overlap``: on the halo
+        stream (ended by wait()); else on the current stream."""
+        C = self._C
+        n = len(caps)
+        row = send.shape[1] * send.element_size()
+        key = (send.data_ptr(), recv.data_ptr(), overlap)
+        plan = getattr(self, "_plans", None)
+        if plan is None:
+            plan = self._plans = {}
+        if key not in plan:
+            VP, SZ, IN = C.c_void_p * n, C.c_size_t * n, C.c_int * n
+            order = list(reversed(range(n)))
+            plan[key] = (VP(*[send.data_ptr() + offs[m] * row for m in range(n)]), SZ(*[caps[m] * row for m in range(n)]),
+                         IN(*[neighbors[m] for m in range(n)]),
+                         VP(*[recv.data_ptr() + offs[j] * row for j in order]), SZ(*[caps[j] * row for j in order]),
+                         IN(*[neighbors[j] for j in order]))
+        sp, sb, sr, rp, rb, rr = plan[key]
+        s = C.c_void_p(torch.cuda.current_stream(send.device).cuda_stream)
+        self._check(self._lib.htf_halo_exchange_n(self._h, n, sp, sb, sr, n, rp, rb, rr, s, 1 if overlap else 0))
+        self._overlapped = overlap
+
+    def allreduce_max(self, value):
+        s = self._C.c_void_p(torch.cuda.current_stream(value.device).cuda_stream)
+        self._check(self._lib.htf_halo_allreduce_max_f32(self._h, value.data_ptr(), int(value.numel()), s))
 
     def wait(self):
         # (called from exchange_end on whatever stream is current then)

@@ -239,24 +239,46 @@ class CellNlist:
         check(lib.htfs_cell_sort(cell_of.data_ptr(), Ntot, ncell, self._bin_scratch.data_ptr(), cell_start.data_ptr(),
                                  order.data_ptr(), stream))
         # cell members contiguous: coalesced candidate reads
-        check(lib.htfs_gather4_tagged(pos_sorted.data_ptr(), s.pos.data_ptr(), order.data_ptr(), s.scalar_code, Ntot,
-                                      int(self.type_split), stream))
+        fixed = self.domain is not None and getattr(self.domain, "fixed_capacity", False)
+        if fixed:
+            # fixed-capacity arrays (brick.py): inert rows are in no cell -- only the binned particles have an entry in ``order``
+            check(lib.htfs_gather4_tagged_live(pos_sorted.data_ptr(), s.pos.data_ptr(), order.data_ptr(), s.scalar_code, Ntot,
+                                               cell_start.data_ptr() + 4 * ncell, int(self.type_split), stream))
+        else:
+            check(lib.htfs_gather4_tagged(pos_sorted.data_ptr(), s.pos.data_ptr(), order.data_ptr(), s.scalar_code, Ntot,
+                                          int(self.type_split), stream))
         if self.pitch is None:
             # a sphere of r_list at the mean density, with generous head-room
             L = s.box3x3[1] - s.box3x3[0]
-            rho = Ntot / float(np.prod(L))
+            n_real = getattr(self.domain, "n_global", None) if fixed else None   # (capacity rows are not particles)
+            rho = (n_real if n_real else Ntot) / float(np.prod(L))
             dims = int(np.sum(n > 1)) or 3
             est = rho * (4.0 / 3.0 * math.pi * self.r_list ** 3 if dims == 3 else math.pi * self.r_list ** 2 * L[2])
             self.pitch = max(8, int(math.ceil(est * 1.5 / 8.0)) * 8)
+        capturing = getattr(self, "_capturing", False)
+        if fixed and self.n_builds > 0 and not capturing:
+            self._poll_row_overflow()   # the PREVIOUS build's largest row (pinned copy behind it): no wait
         while True:
+            if self.n_neigh is None or self.n_neigh.shape[0] != s.N:
+                self.n_neigh = torch.zeros(s.N, dtype=torch.int32, device=s.device)
+                self.head_list = torch.zeros(s.N, dtype=torch.int32, device=s.device)
+                if fixed:
+                    self.domain.attach_n_neigh(self.n_neigh)   # a rebuild empties the rows that became inert
             if self.nlist is None or self.nlist.numel() != s.N * self.pitch:
-                self.n_neigh = torch.empty(s.N, dtype=torch.int32, device=s.device)
-                self.head_list = torch.empty(s.N, dtype=torch.int32, device=s.device)
                 self.nlist = torch.empty(s.N * self.pitch, dtype=torch.int32, device=s.device)
             check(lib.htfs_build_nlist(s.pos.data_ptr(), pos_sorted.data_ptr(), s.scalar_code, s.N, Ntot, C.byref(s.box), self.r_list,
                                        C.byref(n3), C.byref(w3), cell_start.data_ptr(), self.pitch, int(self.type_split),
                                        self.n_neigh.data_ptr(), self.head_list.data_ptr(), self.nlist.data_ptr(),
                                        self._max.data_ptr(), self._ranges.data_ptr(), stream))
+            if fixed and self.n_builds > 0:
+                # no read-back in a rebuild of a fixed-capacity system: an overflowing row is reported one build late
+                if getattr(self, "_max_host", None) is None:
+                    self._max_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+                self._max_host.copy_(self._max, non_blocking=True)
+                if not capturing:
+                    self._max_event = torch.cuda.Event()
+                    self._max_event.record(torch.cuda.current_stream(s.device))
+                break
             mx = int(self._max.item())
             if mx <= self.pitch:
                 break
@@ -285,6 +307,15 @@ class CellNlist:
             if int(self._stat_host[0]) > self.pitch:
                 raise RuntimeError("neighbor list row overflow (%d entries, pitch %d) in a device-decided rebuild: "
                                    "construct CellNlist with a larger pitch" % (int(self._stat_host[0]), self.pitch))
+
+    def _poll_row_overflow(self):
+        ev = getattr(self, "_max_event", None)
+        if ev is not None:
+            ev.synchronize()
+            self._max_event = None
+            if int(self._max_host[0]) > self.pitch:
+                raise RuntimeError("neighbor list row overflow (%d entries, pitch %d) in a rebuild without read-back: construct "
+                                   "CellNlist with a larger pitch" % (int(self._max_host[0]), self.pitch))
 
     def check_and_rebuild_on_device(self):
         """NeighborList::compute at a check step with the decision left to the device: distance check, then
@@ -343,16 +374,19 @@ class CellNlist:
         check(lib.htfs_max_displacement2(s.pos.data_ptr(), self._ref.data_ptr(), s.scalar_code, s.N,
                                          C.byref(s.box), buf.data_ptr(),
                                          C.c_void_p(raw_stream(s.device.index))))
+        alone = self.domain.world == 1   # (a replica brick: nobody to agree with)
         if self.deferred_reference:
             # the host-decided twin: all-reduce and read NOW (a drained queue per check), same rule, same one-check lag
-            dist.all_reduce(buf, op=dist.ReduceOp.MAX, group=self.domain.group)
+            if not alone:
+                dist.all_reduce(buf, op=dist.ReduceOp.MAX, group=self.domain.group)
             now = float(np.sqrt(max(float(buf.item()), 0.0)))
             if self._dd_prev is not None:
                 self._rule.push(self._dd_prev)
             self._dd_prev = now
         else:
-            work = dist.all_reduce(buf, op=dist.ReduceOp.MAX, group=self.domain.group, async_op=True)
-            work.wait()  # (RCCL: the current stream waits for the collective; the host does not)
+            if not alone:
+                work = dist.all_reduce(buf, op=dist.ReduceOp.MAX, group=self.domain.group, async_op=True)
+                work.wait()  # (RCCL: the current stream waits for the collective; the host does not)
             host = self._dd_host[self._dd_i % 3]
             host.copy_(buf, non_blocking=True)
             ev = torch.cuda.Event()
@@ -377,7 +411,8 @@ class CellNlist:
     def needs_update(self):
         if self._ref is None:
             return True
-        if self.domain is not None and self.domain.world > 1 and (self.device_decision or self.deferred_reference):
+        if (self.domain is not None and (self.domain.world > 1 or getattr(self.domain, "replica", False))
+                and (self.device_decision or self.deferred_reference)):
             return self._deferred_needs_update()
         s = self.sys
         self._disp.zero_()
@@ -601,3 +636,168 @@ class Simulation:
             nsteps = self._run_graphed(nsteps, soft=auto)
         for _ in range(nsteps):
             self._step()
+
+
+class BrickRun:
+    """The decomposed MD loop over a fixed-capacity ``brick.BrickDomain``: NeighborList::compute (distance check, migration +
+    ghost plan + list rebuild when it trips, else the per-step ghost halo), the force rows that see no ghost while the halo is
+    in flight, the rest behind it, the integrator.
+
+    ``run(n)`` steps eagerly -- about a dozen launches per step from Python, which at 16 k rows per rank is the step's floor
+    (27-32 us measured in round 4 against an 11 us kernel).  ``run(n, graph=True)`` replays whole check periods from TWO
+    hipGraphs per rank, captured once: A = [check, period x (halo | interior rows | boundary rows | integrate)] and
+    B = [check, migrate, re-plan, list rebuild, period x step].  Nothing in either is sized by a count the host knows (fixed
+    capacities, inert rows, device-resident counts), the halo and the migration messages are RCCL calls on the captured streams
+    (csrc/halo.hip) -- or, in replica mode with transport "local", written by the pack kernel itself.  Which graph runs next is
+    decided WITHOUT draining the queue: every cycle's check leaves [largest displacement^2, cycle number] in pinned memory, the
+    host reads the word of the cycle it launched last -- available as soon as the device has STARTED that cycle, i.e. a whole
+    cycle of device work before it is needed -- and feeds DeferredRebuildRule, the rule of the eager no-read-back path: same
+    decisions, same steps rebuilt, bit-identical trajectory (tests/test_gpu_brick.py)."""
+
+    def __init__(self, system, nlist, ctx, integrator):
+        self.sys, self.nl, self.ctx, self.nve = system, nlist, ctx, integrator
+        self.dom = nlist.domain
+        if self.dom is None or not getattr(self.dom, "fixed_capacity", False):
+            raise ValueError("BrickRun drives a CellNlist whose domain is a BrickDomain")
+        self._graphs = None
+        self.n_rebuild_cycles = 0
+        self.n_cycles = 0
+
+    # ------------------------------------------------------------------ pieces of a step
+    def _arrays(self):
+        s, nl = self.sys, self.nl
+        return self.ctx.make_arrays(s.pos, s.N, nl.n_neigh, nl.head_list, nl.nlist, s.box, s.force)
+
+    def _forces(self, ts, overlapped):
+        if overlapped:
+            self.ctx.compute_forces_overlapped(ts, self._arr, self.dom)
+        else:
+            self.dom.exchange_end()
+            self.ctx.compute_forces(ts, self._arr)
+
+    def step(self):
+        """One eager step (what bench.py's loop does)."""
+        s = self.sys
+        ts = s.timestep
+        builds = self.nl.n_builds
+        self.nl.compute(ts)
+        if getattr(self, "_arr", None) is None or self.nl.n_builds != builds:
+            self._arr = self._arrays()
+        self.ctx.compute_forces_overlapped(ts, self._arr, self.dom)
+        self.nve.step()
+        s.timestep += 1
+
+    # ------------------------------------------------------------------ graph replay
+    def _check_kernels(self):
+        """The distance check of a cycle, on the device: largest displacement^2 since the last rebuild, all-reduced, and the cycle
+        counter, copied to pinned memory."""
+        s, nl = self.sys, self.nl
+        self._stat[0:1].zero_()
+        check(lib.htfs_max_displacement2(s.pos.data_ptr(), nl._ref.data_ptr(), s.scalar_code, s.N, C.byref(s.box),
+                                         self._stat.data_ptr(), C.c_void_p(raw_stream(s.device.index))))
+        if self.dom.world > 1:
+            self.dom._native.allreduce_max(self._stat[0:1])
+        self._stat[1:2].add_(1.0)
+        self._stat_host.copy_(self._stat, non_blocking=True)
+
+    def _cycle(self, rebuild):
+        s, nl, P = self.sys, self.nl, self.nl.check_period
+        self._check_kernels()
+        if rebuild:
+            nl.build()               # BrickDomain.rebuild (migration, classes, plan, halo) + the list
+        for i in range(P):
+            if not (rebuild and i == 0):
+                self.dom.exchange_begin()
+            self.ctx.compute_forces_overlapped(s.timestep, self._arr, self.dom)
+            self.nve.step()
+            s.timestep += 1
+
+    def _capture(self):
+        s, nl, dom = self.sys, self.nl, self.dom
+        if not dom.kernels or dom.transport not in ("native", "local"):
+            raise ValueError("graph replay needs the kernels backend and the 'native' (RCCL inside the capture) or 'local' transport")
+        if nl.n_builds < 2:
+            raise RuntimeError("run a few eager steps through a rebuild first (RCCL connects and pinned buffers are made outside a capture)")
+        dom.exchange_end()
+        self._arr = self._arrays()
+        self._stat = torch.zeros(2, dtype=torch.float32, device=s.device)
+        self._stat_host = torch.zeros(2, dtype=torch.float32).pin_memory()
+        self._rule = DeferredRebuildRule(nl.r_buff / 2.0)
+        torch.cuda.synchronize()
+        graphs = {}
+        ts0, builds0, rebuilds0 = s.timestep, nl.n_builds, dom.n_rebuilds
+        nl._capturing = dom._capturing = True
+        try:
+            for rebuild in (False, True):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    self._cycle(rebuild)
+                graphs[rebuild] = g
+                s.timestep = ts0       # a capture records, it does not run
+        finally:
+            nl._capturing = dom._capturing = False
+            s.timestep, nl.n_builds, dom.n_rebuilds = ts0, builds0, rebuilds0
+            nl._step_done = None
+        self._graphs = graphs
+        self._launched = 0          # cycle number of the last launched graph (the device counter counts from 1)
+        self._read = 0              # cycle number whose check the rule has seen
+        self._discard = set()       # cycles whose check was measured against reference positions that a rebuild then replaced
+        self._rebuilt_at = []
+
+    def _read_check(self, cycle):
+        """Wait until the device has started ``cycle`` (its check has landed in pinned memory), then validate everything that
+        finished before it."""
+        h = self._stat_host
+        spins = 0
+        while int(h[1]) < cycle:
+            spins += 1
+            if spins > 50_000_000:
+                raise RuntimeError("the device never reached cycle %d" % cycle)
+        d2 = float(h[0])
+        # cycle - 1 is complete: what its rebuild (if any) reported
+        self.dom._raise_flags(int(self.dom._flags_host[_lib.BC_FLAGS]))
+        mh = getattr(self.nl, "_max_host", None)
+        if mh is not None and int(mh[0]) > self.nl.pitch:
+            raise RuntimeError("neighbor list row overflow (%d entries, pitch %d) in a replayed rebuild" % (int(mh[0]), self.nl.pitch))
+        return d2
+
+    def run(self, nsteps, graph=False):
+        nsteps = int(nsteps)
+        P = self.nl.check_period
+        if not graph:
+            for _ in range(nsteps):
+                self.step()
+            return
+        s = self.sys
+        while s.timestep % P != 0 and nsteps > 0:
+            self.step()
+            nsteps -= 1
+        if self._graphs is None:
+            self._capture()
+        rule = self._rule
+        while nsteps >= P:
+            if self._launched > self._read:
+                # (at most one cycle is ever unread: the one launched last)
+                d2 = self._read_check(self._launched)
+                self._read = self._launched
+                if self._read not in self._discard:
+                    rule.push(float(np.sqrt(max(d2, 0.0))))
+            rebuild = rule.decide()
+            if rebuild:
+                rule.reset()
+                self._discard.add(self._launched + 1)   # that cycle's check runs BEFORE its rebuild: measured against the old reference
+                self.n_rebuild_cycles += 1
+                self._rebuilt_at.append(s.timestep)
+                self.nl.n_builds += 1
+                self.dom.n_rebuilds += 1
+            self._graphs[rebuild].replay()
+            self._launched += 1
+            self.n_cycles += 1
+            s.timestep += P
+            nsteps -= P
+        for _ in range(nsteps):
+            self.step()
+
+    @property
+    def dangerous_builds(self):
+        return self._rule.dangerous if getattr(self, "_rule", None) is not None else self.nl.dangerous_builds

@@ -448,6 +448,17 @@ HTF_API int htf_halo_exchange_begin(htf_halo *halo, void *d_pos, int dtype, int 
                             unsigned recv_right_first, unsigned recv_right_count, htf_stream stream);
 HTF_API int htf_halo_exchange_end(htf_halo *halo, htf_stream stream);
 
+/* Any number of messages in one grouped exchange (2-D brick decompositions talk to 8 neighbors; the fixed-size migration
+ * messages of a rebuild): sends posted in the order given, then receives in the order given -- the caller orders them so that
+ * between any two ranks the k-th send meets the k-th receive.  async != 0: on the halo stream behind everything queued on
+ * `stream`, ended by htf_halo_exchange_end; async == 0: on `stream` itself.  Plain stream work either way: a hipGraph capture of
+ * `stream` records it. */
+HTF_API int htf_halo_exchange_n(htf_halo *halo, int n_send, const void *const *send_ptrs, const size_t *send_bytes,
+                                const int *send_peers, int n_recv, void *const *recv_ptrs, const size_t *recv_bytes,
+                                const int *recv_peers, htf_stream stream, int async);
+/* d_value[0..n) <- element-wise max over the ranks, in place, on `stream` (the all-reduced distance check). */
+HTF_API int htf_halo_allreduce_max_f32(htf_halo *halo, float *d_value, unsigned n, htf_stream stream);
+
 /* Profiler scopes (reference: HOOMD Profiler push/pop "TensorflowCompute::reshapeNeighbors"
  * and "TensorflowCompute::Force Update", TensorflowCompute.cc:164-168,196-206).  When
  * enabled, htf_compute_forces brackets the pair-vector build and the evaluator with

@@ -115,6 +115,85 @@ HTF_API int htfs_key_sort16(const unsigned *d_key, unsigned N, unsigned *d_scrat
 HTF_API int htfs_segment_copy(void *d_dst, const void *d_src, unsigned row_bytes, unsigned n_segments,
                               const unsigned *src_start, const unsigned *dst_start, const unsigned *count, htf_stream stream);
 
+/* ---- Brick decomposition with fixed-capacity arrays (round 5; hoomd_tf_amd/brick.py BrickDomain) --------------------------------
+ * The stand-in for HOOMD's Communicator on a px x py (x 1) grid of ranks, built so that NOTHING a rebuild produces has to be read by
+ * the host: local rows live in [0, cap_int) (particles with no ghost neighbor, then INERT rows) and [cap_int, cap_int + cap_bnd)
+ * (particles within r_ghost of a face, ordered by class, then inert rows); ghosts of message m live in a fixed region of
+ * ghost_cap[m] rows behind them.  An inert row has x = NaN (never a neighbor, in no cell, empty neighbor row, zero velocity), so
+ * every launch is sized by a capacity and particle counts, message counts and class boundaries stay on the device (d_counts).
+ * Messages are numbered by neighbor offset o in {-1, 0, +1}^ndim: index = sum_d (o_d + 1) 3^d with the centre skipped.
+ * Class of a particle along a decomposed axis: 0 away from both faces, 1 within r_ghost of the low face only, 2 of both, 3 of the
+ * high face only; class key = k_0 + 4 k_1; interior = key 0.  Message to offset o carries the rows whose class is near the low
+ * (o_d = -1) / high (o_d = +1) face along every axis with o_d != 0, in row order.
+ * Replica mode: one rank that is its own neighbor in every direction (a p-fold periodic replication of its brick): messages are
+ * shifted by -o_d * width_d (shift[m]), so ghosts and returning migrants appear where a real neighbor's would. */
+#define HTFS_BRICK_MAX_MSG 8
+#define HTFS_BRICK_MAX_P 64
+typedef struct htfs_brick {
+    int ndim;                                   /* decomposed axes: 1 or 2 */
+    int axis[2];                                /* box axis of each (0 x, 1 y, 2 z) */
+    int p[2];                                   /* bricks along it */
+    int me[2];                                  /* this rank's brick coordinate */
+    int n_msg;                                  /* 3^ndim - 1 */
+    double r_ghost;
+    unsigned cap_int, cap_bnd;
+    unsigned ghost_cap[HTFS_BRICK_MAX_MSG];     /* rows of halo message m (sent AND received: capacities are symmetric) */
+    unsigned ghost_off[HTFS_BRICK_MAX_MSG];     /* first row of message m in the packed send buffer; a message RECEIVED from the neighbor
+                                                 * at offset o lands at ghost row ghost_off[index(o)] (source offsets ascending) */
+    unsigned mig_cap[HTFS_BRICK_MAX_MSG];       /* rows of migration message m, its header row included */
+    unsigned mig_off[HTFS_BRICK_MAX_MSG];       /* first row of message m in the migration send buffer / of the message from offset o
+                                                 * in the receive buffer */
+    double shift[HTFS_BRICK_MAX_MSG][3];        /* added to the positions message m carries (replica mode; zeros otherwise) */
+} htfs_brick;
+
+/* device words of d_counts */
+enum {
+    HTFS_BC_N_INT = 0,      /* particles in the interior segment */
+    HTFS_BC_N_BND = 1,      /* particles in the boundary segment */
+    HTFS_BC_N_CAND = 2,     /* stayed + arrived at the last rebuild */
+    HTFS_BC_N_ARRIVED = 3,  /* migrants received, cumulative */
+    HTFS_BC_FLAGS = 4,      /* HTFS_BF_* bits, sticky until the caller clears them */
+    HTFS_BC_REBUILDS = 5,
+    HTFS_BC_MSG = 8,        /* [8, 16): rows of halo message m */
+    HTFS_BC_CLASS = 16,     /* [16, 16 + 18): first candidate of class c in class order (c = 0..16), then the total */
+    HTFS_BC_WORDS = 64
+};
+enum {
+    HTFS_BF_LOST = 1,           /* a particle crossed more than one brick between rebuilds */
+    HTFS_BF_MIG_OVERFLOW = 2,   /* more migrants than a migration message holds */
+    HTFS_BF_INT_OVERFLOW = 4,
+    HTFS_BF_BND_OVERFLOW = 8,
+    HTFS_BF_GHOST_OVERFLOW = 16
+};
+
+/* scratch of a rebuild, all caller-owned: cand = cap_int + cap_bnd + sum_m mig_cap[m] candidate slots */
+typedef struct htfs_brick_work {
+    unsigned *key;          /* [cand] */
+    unsigned *order;        /* [cand] */
+    unsigned *sort_scratch; /* [32 * ceil(cand / 4096)] */
+    unsigned *start1;       /* [17]  destination-key starts of the first sort */
+    unsigned *start2;       /* [33]  class-key starts of the second */
+    void *tmp_pos;          /* [cand] Scalar4 */
+    void *tmp_vel;          /* [cand] Scalar4 */
+} htfs_brick_work;
+
+/* First half of a rebuild: destination of every local particle (d_bounds: per decomposed axis HTFS_BRICK_MAX_P + 1 boundaries in
+ * the positions' dtype, axis-major), stable sort by destination, migrants packed into d_mig_send (rows of 8 scalars: position,
+ * velocity; row 0 of each message = its count), shifted by shift[m]. */
+HTF_API int htfs_brick_migrate_pack(const htfs_brick *g, const void *d_pos, const void *d_vel, int dtype, const void *d_bounds,
+                                    const htfs_brick_work *w, void *d_mig_send, unsigned *d_counts, htf_stream stream);
+/* Second half, after d_mig_recv holds the neighbors' messages: candidates = [stayed | from offset index n_msg-1 | ... | from 0],
+ * classed in this brick, stable sort by class, written into the two segments with inert rows behind them (position NaN, velocity 0,
+ * mass kept; d_n_neigh[row] = 0 if given); counts, class boundaries, halo message sizes and overflow flags into d_counts. */
+HTF_API int htfs_brick_migrate_merge(const htfs_brick *g, void *d_pos, void *d_vel, int dtype, const void *d_bounds,
+                                     const htfs_brick_work *w, const void *d_mig_recv, unsigned *d_n_neigh, unsigned *d_counts,
+                                     htf_stream stream);
+/* Per step: the halo messages packed from the boundary segment (inert rows behind each message's count) into d_send
+ * [sum_m ghost_cap[m]] Scalar4; d_ghost_direct (nullable; replica mode without a transport): also written straight into the ghost
+ * region, message m at the rows its receiver -- this rank -- expects it (source offset -o). */
+HTF_API int htfs_brick_pack_halo(const htfs_brick *g, const void *d_pos, int dtype, const unsigned *d_counts, void *d_send,
+                                 void *d_ghost_direct, htf_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,334 @@
+"""BrickDomain on the GPU: csrc/brick.hip against its torch restatement, the replica mode against the replicated single-domain
+system, slabs against SlabDomain bit for bit, a 4 x 2 cut against the single-domain forces (ranks share the one GPU over gloo)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from helpers import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _brick_of_liquid(htf, cuda, cells, grid, seed=3, steps=60, dtype=torch.float32):
+    """One brick (the middle one) of a small equilibrated LJ liquid whose box is grid x the brick: a configuration that is
+    periodic with the brick's period would need the liquid to be, so the brick comes from a liquid in the BRICK's own periodic
+    box (cells^3 fcc cells), and the logical global box is grid x that."""
+    from test_gpu_parity import _liquid
+    lsys, _, L = _liquid(htf, cuda, cells=cells, steps=steps, seed=seed, dtype=dtype)
+    pos = lsys.pos[:lsys.N, :3].double().cpu().numpy()
+    vel = lsys.vel[:lsys.N].double().cpu().numpy()
+    return pos, vel, np.asarray(L, dtype=np.float64)
+
+
+def _replica_system(standin, pos, vel, Lb, grid, dev, dtype=torch.float32):
+    """The brick placed at coordinate grid // 2 of the logical box grid * Lb (centred on 0)."""
+    grid = np.asarray(grid)
+    Lg = Lb * grid
+    coords = grid // 2
+    lo = -Lg / 2 + coords * Lb
+    p = pos + Lb / 2 + lo            # brick-local [-Lb/2, Lb/2) -> [lo, lo + Lb)
+    sysm = standin.System(p, Lg, types=np.arange(len(p)), dtype=dtype, device=dev)
+    sysm.vel = torch.from_numpy(vel).to(dtype).to(dev)
+    return sysm, Lg, lo
+
+
+def _same(a, b):
+    return torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0)) and torch.equal(torch.isnan(a), torch.isnan(b))
+
+
+@pytest.mark.parametrize("grid", [(8, 1, 1), (4, 2, 1), (3, 1, 1)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_brick_kernels_match_torch(htf, cuda, grid, dtype):
+    """csrc/brick.hip (destination keys, stable sorts, migration messages, class order, inert rows, halo messages, counts) ==
+    the torch restatement, bit for bit, over three move-and-rebuild rounds in replica mode (particles leave through every face
+    and come back through the opposite one, shifted)."""
+    from hoomd_tf_amd import _lib, standin
+    from hoomd_tf_amd.brick import BrickDomain
+    pos, vel, Lb = _brick_of_liquid(htf, cuda, 6, grid, dtype=dtype)
+    out = {}
+    for backend in ("kernels", "torch"):
+        sysm, Lg, lo = _replica_system(standin, pos, vel, Lb, grid, cuda, dtype)
+        dom = BrickDomain(sysm, 0, grid, r_ghost=2.9, r_buff=0.4, replica=True, backend=backend,
+                          transport="local" if backend == "kernels" else "torch")
+        assert dom.kernels == (backend == "kernels")
+        snaps = []
+        for rnd in range(3):
+            dom.rebuild()
+            torch.cuda.synchronize()
+            c = dom.counts_host()
+            snaps.append((sysm.pos.clone(), sysm.vel.clone(), c.copy()))
+            live = dom.live_rows()
+            assert len(live) == len(pos)
+            # move: a big step along the velocities (some particles cross a face), wrap into the LOGICAL global box
+            x = sysm.pos[live, :3] + 0.15 * sysm.vel[live, :3]
+            Lt = torch.as_tensor(Lg, dtype=dtype, device=cuda)
+            x = x - torch.floor((x + Lt / 2) / Lt) * Lt
+            sysm.pos[live, :3] = x
+            dom.exchange()
+            torch.cuda.synchronize()
+            snaps.append((sysm.pos.clone(), None, None))
+        out[backend] = snaps
+        assert dom.n_migrated > 0
+    for (pk, vk, ck), (pt, vt, ct) in zip(out["kernels"], out["torch"]):
+        assert _same(pk, pt)
+        if vk is not None:
+            assert _same(vk, vt)
+            for w in (_lib.BC_N_INT, _lib.BC_N_BND, _lib.BC_N_CAND, _lib.BC_N_ARRIVED, _lib.BC_REBUILDS):
+                assert ck[w] == ct[w], w
+            assert np.array_equal(ck[_lib.BC_MSG:_lib.BC_MSG + 8], ct[_lib.BC_MSG:_lib.BC_MSG + 8])
+            assert np.array_equal(ck[_lib.BC_CLASS:_lib.BC_CLASS + 17], ct[_lib.BC_CLASS:_lib.BC_CLASS + 17])
+
+
+@pytest.mark.parametrize("grid,transport", [((8, 1, 1), "local"), ((4, 2, 1), "local"), ((8, 1, 1), "native"), ((4, 2, 1), "native")])
+def test_replica_brick_forces_equal_the_replicated_box(htf, cuda, grid, transport):
+    """Replica mode is a physical system -- the brick repeated grid times: forces of the one rank's rows (interior rows while the
+    halo is in flight, boundary rows behind it) == the single-domain forces of the replicated box, through an MD run with
+    migration (particles leave through a face and re-enter through the opposite one).  ``native``: the halo and the migration
+    messages travel through RCCL (this rank sending to itself), csrc/halo.hip's grouped exchange."""
+    from hoomd_tf_amd import _lib, standin
+    from hoomd_tf_amd.brick import BrickDomain
+    if transport == "native" and not _lib.lib.htf_halo_available():
+        pytest.skip("librccl not loadable")
+    cells = 6
+    pos, vel, Lb = _brick_of_liquid(htf, cuda, cells, grid)
+    rcut, rbuf, NN = 2.5, 0.4, 96
+    sysm, Lg, lo = _replica_system(standin, pos, vel, Lb, grid, cuda)
+    nl = standin.CellNlist(sysm, r_cut=rcut, r_buff=rbuf, check_period=1)
+    dom = nl.domain = BrickDomain(sysm, 0, grid, r_ghost=rcut + rbuf, r_buff=rbuf, replica=True, transport=transport)
+    nl.build()
+    ctx = htf.Context(r_cut=rcut, nneighs=NN, scalar_dtype=torch.float32, max_n=sysm.N)
+    ctx.set_potential(htf.Potential.lj())
+    nve = standin.NVE(sysm, 0.005)
+    arr = ctx.make_arrays(sysm.pos, sysm.N, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, sysm.force)
+    overlapped = 0
+    for ts in range(60):
+        nl.compute(ts)
+        overlapped += int(dom.pending)
+        ctx.compute_forces_overlapped(ts, arr, dom)
+        if ts < 59:
+            nve.step()
+    torch.cuda.synchronize()
+    assert nl.n_builds >= 3 and overlapped >= 30 and dom.n_migrated > 0, (nl.n_builds, overlapped, dom.n_migrated)
+    live = dom.live_rows()
+    assert len(live) == len(pos)
+    p = sysm.pos[live, :3].double().cpu().numpy()
+    got = sysm.force[live].cpu().numpy()
+    assert np.all(sysm.force[~torch.isin(torch.arange(sysm.N, device=cuda), live)].cpu().numpy() == 0)   # inert rows: zero force
+    # the replicated box, single domain: every brick image of every particle
+    reps = np.stack(np.meshgrid(*[np.arange(g) for g in grid], indexing="ij"), -1).reshape(-1, 3)
+    base = p - lo                                      # brick-local [0, Lb); rows may sit a hair outside after the last step
+    allp = np.concatenate([base + r * Lb - Lg / 2 for r in reps])
+    allp -= np.floor((allp + Lg / 2) / Lg) * Lg
+    ref_sys = standin.System(allp, Lg, dtype=torch.float32, device=cuda)
+    ref_nl = standin.CellNlist(ref_sys, r_cut=rcut, r_buff=rbuf)
+    ref_nl.build()
+    ref_ctx = htf.Context(r_cut=rcut, nneighs=NN, scalar_dtype=torch.float32, max_n=ref_sys.N)
+    ref_ctx.set_potential(htf.Potential.lj())
+    ref_ctx.compute_forces(0, ref_ctx.make_arrays(ref_sys.pos, ref_sys.N, ref_nl.n_neigh, ref_nl.head_list, ref_nl.nlist, ref_sys.box, ref_sys.force))
+    torch.cuda.synchronize()
+    mine = int(np.nonzero((reps == np.asarray(grid) // 2).all(axis=1))[0][0])
+    want = ref_sys.force.cpu().numpy()[mine * len(p):(mine + 1) * len(p)]
+    scale = np.abs(want).max()
+    assert np.abs(got - want).max() < 3e-5 * scale, (np.abs(got - want).max(), scale)
+
+
+def _slab_twin_worker(rank, world, port, q, per_slab):
+    """The same decomposed LJ MD twice -- SlabDomain (variable-length arrays, host-planned rebuild) and BrickDomain(world, 1, 1)
+    (fixed capacity, inert rows, rebuild without a read-back) -- with the host-decided distance check: rebuilt at the same steps,
+    and every particle ends at bit-identical coordinates."""
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        sys.path.insert(0, ROOT)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import hoomd_tf_amd as htf
+        from hoomd_tf_amd import standin
+        from hoomd_tf_amd.brick import BrickDomain
+        from hoomd_tf_amd.domain import SlabDomain
+
+        dev = torch.device("cuda:0")
+        rcut, rbuf, NN = 2.5, 0.4, 80
+        cells = (per_slab * world, 5, 5)
+        a = (4.0 / 0.8442) ** (1.0 / 3.0)
+        base = np.array([[0, 0, 0], [.5, .5, 0], [.5, 0, .5], [0, .5, .5]])
+        grid = np.stack(np.meshgrid(*[np.arange(c) for c in cells], indexing="ij"), -1).reshape(-1, 3)
+        pos0 = ((grid[:, None, :] + base[None]) * a).reshape(-1, 3)
+        L = np.array(cells, dtype=np.float64) * a
+        pos0 = pos0 - L / 2
+        rng = np.random.default_rng(11)
+        pos0 += 0.04 * a * rng.standard_normal(pos0.shape)
+        pos0 -= np.round(pos0 / L) * L
+        Ng = len(pos0)
+        vel0 = np.zeros((Ng, 4))
+        vel0[:, :3] = 1.0 * rng.standard_normal((Ng, 3))
+        vel0[:, 3] = 1.0
+        bounds = -L[0] / 2 + np.linspace(0, 1, world + 1) * L[0]
+        mine = (pos0[:, 0] >= bounds[rank]) & (pos0[:, 0] < bounds[rank + 1])
+        out = {}
+        for kind in ("slab", "brick"):
+            sysm = standin.System(pos0[mine], L, types=np.arange(Ng)[mine], dtype=torch.float32, device=dev)
+            sysm.vel = torch.from_numpy(vel0[mine]).to(torch.float32).to(dev)
+            nl = standin.CellNlist(sysm, r_cut=rcut, r_buff=rbuf, check_period=2)
+            if kind == "slab":
+                nl.domain = SlabDomain(sysm, rank, world, r_ghost=rcut + rbuf)
+            else:
+                nl.domain = BrickDomain(sysm, rank, (world, 1, 1), r_ghost=rcut + rbuf, r_buff=rbuf)
+                assert nl.domain.kernels
+            nl.build()
+            ctx = htf.Context(r_cut=rcut, nneighs=NN, scalar_dtype=torch.float32, max_n=sysm.N)
+            ctx.set_potential(htf.Potential.lj())
+            nve = standin.NVE(sysm, 0.004)
+            builds, arr, steps_built = -1, None, []
+            for ts in range(90):
+                nl.compute(ts)
+                if nl.n_builds != builds:
+                    arr = ctx.make_arrays(sysm.pos, sysm.N, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, sysm.force)
+                    builds = nl.n_builds
+                    steps_built.append(ts)
+                ctx.compute_forces_overlapped(ts, arr, nl.domain)
+                nve.step()
+            torch.cuda.synchronize()
+            assert len(steps_built) >= 4, steps_built
+            if kind == "slab":
+                ids, p, v, f = sysm.types_numpy(), sysm.pos[:sysm.N], sysm.vel, sysm.force[:sysm.N]
+            else:
+                live = nl.domain.live_rows()
+                ids = sysm.pos[live, 3].contiguous().view(torch.int32).cpu().numpy()
+                p, v, f = sysm.pos[live], sysm.vel[live], sysm.force[live]
+                assert nl.domain.n_migrated > 0
+            out[kind] = (steps_built, ids.copy(), p.cpu().numpy().copy(), v.cpu().numpy().copy(), f.cpu().numpy().copy())
+        assert out["slab"][0] == out["brick"][0], (out["slab"][0], out["brick"][0])
+        for k in range(1, 5):
+            np.testing.assert_array_equal(out["slab"][k], out["brick"][k])
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+def _run_ranks(target, world, args, timeout=900):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port, q) + tuple(args)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=timeout) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for res in results:
+        assert res[1] == "ok", "rank %d failed:\n%s" % (res[0], res[1])
+    return results
+
+
+@pytest.mark.parametrize("world,per_slab", [(3, 4), (8, 2)])
+def test_brick_slabs_equal_slab_domain_bit_for_bit(htf, cuda, world, per_slab):
+    """fixed-capacity arrays with inert rows and device-resident counts change nothing a particle sees --
+    trajectories bit-identical to SlabDomain's at world 3 and at world 8 (slabs thinner than 2 r_ghost)."""
+    _run_ranks(_slab_twin_worker, world, (per_slab,))
+
+
+def _brick_md_worker(rank, world, port, q, grid, cells):
+    """80 steps of LJ MD under a px x py cut (migration across both axes and the periodic edges, the halo overlapped with the
+    interior rows), then every rank's forces against the single-domain forces of the gathered configuration."""
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        sys.path.insert(0, ROOT)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import hoomd_tf_amd as htf
+        from hoomd_tf_amd import _lib, standin
+        from hoomd_tf_amd.brick import BrickDomain
+
+        dev = torch.device("cuda:0")
+        rcut, rbuf, NN = 2.5, 0.4, 80
+        a = (4.0 / 0.8442) ** (1.0 / 3.0)
+        base = np.array([[0, 0, 0], [.5, .5, 0], [.5, 0, .5], [0, .5, .5]])
+        gridc = np.stack(np.meshgrid(*[np.arange(c) for c in cells], indexing="ij"), -1).reshape(-1, 3)
+        pos = ((gridc[:, None, :] + base[None]) * a).reshape(-1, 3)
+        L = np.array(cells, dtype=np.float64) * a
+        pos = pos - L / 2
+        rng = np.random.default_rng(5)
+        pos += 0.05 * a * rng.standard_normal(pos.shape)
+        pos -= np.round(pos / L) * L
+        Ng = len(pos)
+        vel = np.zeros((Ng, 4))
+        vel[:, :3] = 1.5 * rng.standard_normal((Ng, 3))
+        vel[:, 3] = 1.0
+        probe = BrickDomain(standin.System(pos[:1], L, dtype=torch.float32, device=dev), rank, grid, r_ghost=rcut + rbuf, n_global=Ng)
+        mine = np.ones(Ng, dtype=bool)
+        for d in probe.axes:
+            mine &= (pos[:, d] >= probe.lo[d]) & (pos[:, d] < probe.hi[d])
+        sysm = standin.System(pos[mine], L, types=np.arange(Ng)[mine], dtype=torch.float32, device=dev)
+        sysm.vel = torch.from_numpy(vel[mine]).to(torch.float32).to(dev)
+        nl = standin.CellNlist(sysm, r_cut=rcut, r_buff=rbuf, check_period=1)
+        dom = nl.domain = BrickDomain(sysm, rank, grid, r_ghost=rcut + rbuf, r_buff=rbuf, n_global=Ng)
+        nl.build()
+        ctx = htf.Context(r_cut=rcut, nneighs=NN, scalar_dtype=torch.float32, max_n=sysm.N)
+        pot = htf.Potential.lj()
+        ctx.set_potential(pot)
+        nve = standin.NVE(sysm, 0.004)
+        arr = ctx.make_arrays(sysm.pos, sysm.N, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, sysm.force)
+        overlapped = 0
+        for ts in range(80):
+            nl.compute(ts)
+            overlapped += int(dom.pending)
+            ctx.compute_forces_overlapped(ts, arr, dom)
+            if ts < 79:
+                nve.step()
+        torch.cuda.synchronize()
+        assert nl.n_builds >= 2 and overlapped >= 20, (nl.n_builds, overlapped)
+        c = dom.counts_host()
+        assert int(c[_lib.BC_N_INT]) > 0                         # a 2-D cut keeps interior rows
+        live = dom.live_rows()
+        my_ids = sysm.pos[live, 3].contiguous().view(torch.int32).cpu().numpy()
+        loc = torch.zeros((Ng, 3), dtype=torch.float64)
+        loc[my_ids] = sysm.pos[live, :3].double().cpu()
+        owned = torch.zeros(Ng, dtype=torch.float64)
+        owned[my_ids] = 1
+        dist.all_reduce(loc)
+        dist.all_reduce(owned)
+        assert bool((owned == 1).all()), "particles lost or duplicated"
+        ref_sys = standin.System(loc.numpy(), L, dtype=torch.float32, device=dev)
+        ref_nl = standin.CellNlist(ref_sys, r_cut=rcut, r_buff=rbuf)
+        ref_nl.build()
+        ref_ctx = htf.Context(r_cut=rcut, nneighs=NN, scalar_dtype=torch.float32, max_n=Ng)
+        ref_ctx.set_potential(pot)
+        ref_ctx.compute_forces(0, ref_ctx.make_arrays(ref_sys.pos, Ng, ref_nl.n_neigh, ref_nl.head_list, ref_nl.nlist, ref_sys.box, ref_sys.force))
+        torch.cuda.synchronize()
+        want = ref_sys.force.cpu().numpy()[my_ids]
+        got = sysm.force[live].cpu().numpy()
+        scale = np.abs(want).max()
+        assert np.abs(got - want).max() < 2e-5 * scale, (np.abs(got - want).max(), scale)
+        moved = torch.tensor([dom.n_migrated])
+        dist.all_reduce(moved)
+        assert int(moved) > 0, "test must exercise migration"
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+@pytest.mark.parametrize("grid,cells", [((4, 2, 1), (16, 8, 5)), ((2, 2, 1), (8, 8, 5)), ((3, 1, 1), (12, 5, 5))])
+def test_bricks_on_one_gpu(htf, cuda, grid, cells):
+    """8 ranks as 4 x 2 (bricks 6.7 x 6.7 sigma against r_ghost 2.9: interior rows), 80 MD steps, forces ==
+    single-domain (test_mpi_tensorflow.py:57-79, ``comm.decomposition(nx=4, ny=2)``)."""
+    _run_ranks(_brick_md_worker, grid[0] * grid[1], (grid, cells))
