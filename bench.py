@@ -49,7 +49,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="lj", choices=["lj", "wca", "mlp", "mlp-fp32", "mlp-split", "mlp-bf16", "mlp-train", "eds", "ref-lj256", "c1", "ex01", "generic-lj"])
+    ap.add_argument("--workload", default="lj", choices=["lj", "wca", "mlp", "mlp-fp32", "mlp-split", "mlp-bf16", "mlp-train", "eds", "ref-lj256", "c1", "ex01", "generic-lj", "dd-self"])
+    ap.add_argument("--grid", default="8x1x1", help="dd-self: the rank grid whose one brick this GPU runs (8x1x1 slabs, 4x2x1 bricks)")
+    ap.add_argument("--transport", default="all", help="dd-self: local | native | all")
     ap.add_argument("--train-period", type=int, default=100, help="mlp-train (C5b): force-matching step every this many MD steps")
     ap.add_argument("--cells", type=int, default=32, help="fcc cells per side (N = 4 cells^3 per rank)")
     ap.add_argument("--lattice", default="fcc", choices=["fcc", "sc"], help="fcc: N = 4 cells^3 (C3, C5); sc: N = cells^3 (C2 = sc 32^3 = 32768)")
@@ -259,6 +261,100 @@ def run_ref_lj256(args, htf, standin, dev):
         "note": "overhead-bound at this size: the whole step is host enqueue (nlist check + one kernel + integrate)",
     }
     print(json.dumps(out))
+
+
+def run_dd_self(args, htf, standin, dev):
+    """One rank's share of the decomposed step at an 8-rank geometry, on the one GPU of this box: BrickDomain in REPLICA mode --
+    the rank is its own neighbor in every direction, its brick repeated px x py times IS the C3 box (fcc 32^3 x 4 = 131 072
+    particles: 16 384 rows per rank + the ghosts of that cut) -- so rows, ghost rows, messages, launches and the rebuild are those
+    of rank k of N.  Timed per transport: ``local`` (the pack kernel writes the ghosts: no communication library, the floor) and
+    ``native`` (grouped ncclSend / ncclRecv of csrc/halo.hip, this rank sending to itself); eagerly (Python issues every launch)
+    and replayed from two hipGraphs per check period (standin.BrickRun).  What crosses xGMI between real ranks is NOT measured."""
+    from hoomd_tf_amd import _lib
+    from hoomd_tf_amd.brick import BrickDomain
+    grid = tuple(int(v) for v in args.grid.lower().split("x"))
+    grid = grid + (1,) * (3 - len(grid))
+    cells = np.array([args.cells // grid[0], args.cells // grid[1], args.cells // grid[2]])
+    assert np.all(cells * np.array(grid) == args.cells), "--cells must be divisible by the grid"
+    a = (4.0 / 0.8442) ** (1.0 / 3.0)
+    base = np.array([[0.25, 0.25, 0.25], [0.75, 0.75, 0.25], [0.75, 0.25, 0.75], [0.25, 0.75, 0.75]])
+    ijk = np.stack(np.meshgrid(*[np.arange(c) for c in cells], indexing="ij"), -1).reshape(-1, 3)
+    Lb = cells * a
+    Lg = Lb * np.array(grid)
+    coords = np.array(grid) // 2
+    lo = -Lg / 2 + coords * Lb
+    rng = np.random.default_rng(3)
+    pos = ((ijk[:, None, :] + base[None]) * a).reshape(-1, 3)
+    pos = pos + 0.05 * a * rng.standard_normal(pos.shape)
+    pos = pos - np.floor(pos / Lb) * Lb + lo
+    n_rank = len(pos)
+    transports = ["local", "native"] if args.transport == "all" else [args.transport]
+    if not _lib.lib.htf_halo_available():
+        transports = [t for t in transports if t != "native"]
+    P = args.check_period
+    results = {}
+    for transport in transports:
+        sysm = standin.System(pos, Lg, dtype=torch.float32, device=dev)
+        sysm.randomize_velocities(kT=1.0, seed=3)
+        nl = standin.CellNlist(sysm, r_cut=args.rcut, r_buff=args.rbuff, check_period=P, device_decision=True)
+        dom = nl.domain = BrickDomain(sysm, 0, grid, r_ghost=args.rcut + args.rbuff, r_buff=args.rbuff, replica=True, transport=transport)
+        nl.build()
+        ctx = htf.Context(r_cut=args.rcut, nneighs=args.nn, scalar_dtype=torch.float32, max_n=sysm.N, check_nlist=False, fused=2)
+        ctx.set_potential(htf.Potential.lj())
+        nve = standin.NVE(sysm, args.dt)
+        run = standin.BrickRun(sysm, nl, ctx, nve)
+        run._arr = run._arrays()
+        # relaxation: force cap + velocity rescale (the jittered lattice holds close pairs), then plain NVE
+        for _ in range(args.equil):
+            ts = sysm.timestep
+            b = nl.n_builds
+            nl.compute(ts)
+            if nl.n_builds != b:
+                run._arr = run._arrays()
+            ctx.compute_forces_overlapped(ts, run._arr, dom)
+            f3 = sysm.force[:, :3]
+            f3.mul_(torch.clamp(200.0 / f3.norm(dim=1, keepdim=True).clamp_min(1e-12), max=1.0))
+            nve.step()
+            v3 = sysm.vel[:, :3]
+            v3.mul_(torch.sqrt(1.0 / ((v3 * v3).sum() / (3.0 * n_rank))))
+            sysm.timestep += 1
+        run.run(args.settle + (-(sysm.timestep + args.settle)) % P)          # plain NVE, ends on a check step
+        rec = {}
+        for mode in ("eager", "graph"):
+            run.run(max(args.warmup, 4 * P) // P * P, graph=(mode == "graph"))
+            wins = []
+            steps = max(args.steps, P) // P * P
+            b0, m0 = nl.n_builds, None
+            for _ in range(args.windows or 5):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                run.run(steps, graph=(mode == "graph"))
+                torch.cuda.synchronize()
+                wins.append((time.perf_counter() - t0) / steps * 1e6)
+            rec[mode] = {"us_per_step": float(np.median(wins)), "windows_us_per_step": wins, "steps": steps,
+                         "rebuilds_per_window": (nl.n_builds - b0) / float(len(wins))}
+        c = dom.counts_host()
+        live = dom.live_rows()
+        e = float(sysm.force[live, 3].double().sum()) / n_rank
+        v3 = sysm.vel[live, :3].double()
+        rec.update({"energy_per_particle": e, "kT": float((v3 * v3).sum() / (3.0 * n_rank)), "dangerous_builds": run.dangerous_builds,
+                    "particles": int(len(live)), "interior_particles": int(c[_lib.BC_N_INT]), "ghosts": dom.n_ghosts,
+                    "rows": sysm.N, "interior_rows": dom.cap_int, "ghost_rows": sysm.n_ghost, "messages_per_halo": dom.n_msg,
+                    "halo_bytes_per_step": dom.n_ghost_cap * 16, "migrated": dom.n_migrated})
+        results[transport] = rec
+        del run, ctx, nl, dom, sysm
+    best = min(results[t]["graph"]["us_per_step"] for t in results)
+    line = {
+        "metric": "MD steps/sec of ONE rank's decomposed step at the %s geometry of the 131072-particle box (replica mode: this GPU is "
+                  "its own neighbor; no byte crosses xGMI)" % args.grid,
+        "value": 1e6 / best, "unit": "steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": best / 1000.0,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "dd-self: brick %s of fcc %d^3 x 4 (%d particles per rank), rho 0.8442, r_cut %.1f, r_buff %.1f, NN %d, "
+                               "check_period %d" % (args.grid, args.cells, n_rank, args.rcut, args.rbuff, args.nn, P),
+                   "value_is": "the fastest transport's replayed (hipGraph) step"},
+        "transports": results,
+    }
+    print(json.dumps(line))
 
 
 def run_generic_lj(args, htf, standin, dev):
@@ -786,6 +882,11 @@ def main():
         return run_eds(args, htf, standin, dev)
     if args.workload == "generic-lj":
         run_generic_lj(args, htf, standin, dev)
+        return
+    if args.workload == "dd-self":
+        if world > 1:
+            raise SystemExit("dd-self is one rank playing every brick")
+        run_dd_self(args, htf, standin, dev)
         return
     if args.workload == "ref-lj256":
         if world > 1:

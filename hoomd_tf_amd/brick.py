@@ -260,9 +260,9 @@ class BrickDomain:
     def _make_native(self):
         from .domain import _NativeHalo
         if self.replica:
-            self._native = _NativeHalo(0, 1, None, solo=True)
+            self._native = _NativeHalo.shared(0, 1, None, solo=True)
         else:
-            self._native = _NativeHalo(self.rank, self.world, self.group)
+            self._native = _NativeHalo.shared(self.rank, self.world, self.group)
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.sys.pos.device).cuda_stream)
@@ -523,7 +523,10 @@ class BrickDomain:
                 return
         else:
             self._pack_halo_torch()
-        self._works = self._exchange(self.halo_send, ghosts, self.ghost_cap, self.ghost_off, TAG_BASE + 16, overlap=True)
+        # (inside a hipGraph capture the RCCL calls stay on the captured stream: on this ROCm, RCCL enqueued on a stream that
+        #  JOINED a capture through an event crashes hipStreamEndCapture -- tools/rccl_graph_probe.py, profiles/r05_rccl_graph_probe.txt)
+        self._works = self._exchange(self.halo_send, ghosts, self.ghost_cap, self.ghost_off, TAG_BASE + 16,
+                                     overlap=not getattr(self, "_capturing", False))
 
     def exchange_end(self):
         if self._works is not None:

@@ -66,6 +66,18 @@ class _NativeHalo:
     """The per-step halo through libhtf_amd.so's own RCCL communicator (csrc/halo.hip): one grouped
     ncclSend x2 / ncclRecv x2 on a dedicated stream, two events, no Python objects per message."""
 
+    _shared = {}
+
+    @classmethod
+    def shared(cls, rank, world, group, solo=False):
+        """One communicator per process and job shape, kept until the process ends: bring-up is a collective (and costs tens of
+        milliseconds), and a second communicator made after the first was destroyed hung the first hipGraph capture that used it
+        (tests/test_gpu_brick.py, round 5)."""
+        key = (int(rank), int(world), id(group), bool(solo))
+        if key not in cls._shared:
+            cls._shared[key] = cls(rank, world, group, solo=solo)
+        return cls._shared[key]
+
     def __init__(self, rank, world, group, solo=False):
         """``solo``: a communicator of one rank (brick.py's replica mode: the rank is its own neighbor), no process group needed."""
         import ctypes as C
@@ -136,9 +148,12 @@ class _NativeHalo:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h and self._lib is not None:
-            self._lib.htf_halo_destroy(h)
-            self._h = None
+        try:
+            if h and self._lib is not None and self not in type(self)._shared.values():
+                self._lib.htf_halo_destroy(h)
+                self._h = None
+        except TypeError:   # interpreter teardown: the binding is already gone
+            pass
 
 
 class SlabDomain:

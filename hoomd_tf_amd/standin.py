@@ -747,12 +747,15 @@ class BrickRun:
     def _read_check(self, cycle):
         """Wait until the device has started ``cycle`` (its check has landed in pinned memory), then validate everything that
         finished before it."""
+        import time
         h = self._stat_host
-        spins = 0
+        spins, t0 = 0, None
         while int(h[1]) < cycle:
             spins += 1
-            if spins > 50_000_000:
-                raise RuntimeError("the device never reached cycle %d" % cycle)
+            if spins % 4096 == 0:   # (a stuck device must not hold the host forever: HTF_BRICK_WAIT_S seconds, default 30)
+                t0 = t0 or time.monotonic()
+                if time.monotonic() - t0 > float(os.environ.get("HTF_BRICK_WAIT_S", "30")):
+                    raise RuntimeError("the device never reached cycle %d (last seen %d)" % (cycle, int(h[1])))
         d2 = float(h[0])
         # cycle - 1 is complete: what its rebuild (if any) reported
         self.dom._raise_flags(int(self.dom._flags_host[_lib.BC_FLAGS]))

@@ -332,3 +332,67 @@ def test_bricks_on_one_gpu(htf, cuda, grid, cells):
     """8 ranks as 4 x 2 (bricks 6.7 x 6.7 sigma against r_ghost 2.9: interior rows), 80 MD steps, forces ==
     single-domain (test_mpi_tensorflow.py:57-79, ``comm.decomposition(nx=4, ny=2)``)."""
     _run_ranks(_brick_md_worker, grid[0] * grid[1], (grid, cells))
+
+
+def _replica_md(htf, cuda, grid, transport, cells=6, period=4):
+    from hoomd_tf_amd import standin
+    from hoomd_tf_amd.brick import BrickDomain
+    pos, vel, Lb = _brick_of_liquid(htf, cuda, cells, grid)
+    rcut, rbuf, NN = 2.5, 0.4, 96
+    sysm, Lg, lo = _replica_system(standin, pos, vel, Lb, grid, cuda)
+    nl = standin.CellNlist(sysm, r_cut=rcut, r_buff=rbuf, check_period=period, device_decision=True)
+    nl.domain = BrickDomain(sysm, 0, grid, r_ghost=rcut + rbuf, r_buff=rbuf, replica=True, transport=transport)
+    nl.build()
+    ctx = htf.Context(r_cut=rcut, nneighs=NN, scalar_dtype=torch.float32, max_n=sysm.N)
+    ctx.set_potential(htf.Potential.lj())
+    run = standin.BrickRun(sysm, nl, ctx, standin.NVE(sysm, 0.005))
+    return sysm, nl, run
+
+
+@pytest.mark.parametrize("grid,transport", [((8, 1, 1), "local"), ((4, 2, 1), "native"), ((8, 1, 1), "native"), ((4, 2, 1), "local")])
+def test_replayed_cycles_equal_the_eager_loop(htf, cuda, grid, transport):
+    """whole check periods of the decomposed step -- distance check, halo, interior rows, boundary rows,
+    integrator, and in the second graph migration + re-plan + list rebuild -- replayed from hipGraphs (with ``native`` the
+    grouped ncclSend / ncclRecv of csrc/halo.hip are INSIDE the capture), the next graph chosen from the pinned word of the
+    cycle before: the trajectory of the eager no-read-back loop, bit for bit, rebuilt at the same steps.  (In a child process
+    with a time limit: a transport that hung inside a replay would otherwise hold the whole session.)"""
+    import subprocess
+    from hoomd_tf_amd import _lib
+    if transport == "native" and not _lib.lib.htf_halo_available():
+        pytest.skip("librccl not loadable")
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import torch, hoomd_tf_amd as htf, test_gpu_brick as t; "
+            "t._replay_body(htf, torch.device('cuda:0'), %r, %r); print('REPLAY OK')" % (ROOT, os.path.join(ROOT, "tests"), grid, transport))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=ROOT,
+                       env=dict(os.environ, HTF_BRICK_WAIT_S="20"))
+    assert r.returncode == 0 and "REPLAY OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+def _replay_body(htf, cuda, grid, transport):
+    P, warm, cycles = 4, 40, 60
+    out = {}
+    for mode in ("eager", "graph"):
+        sysm, nl, run = _replica_md(htf, cuda, grid, transport, period=P)
+        run.run(warm)                      # through a few rebuilds: RCCL connected, pinned buffers made
+        assert nl.n_builds >= 2 and sysm.timestep % P == 0
+        nl.build()                         # both modes start a fresh reference here, with an empty decision history
+        run._arr = run._arrays()
+        b0 = nl.n_builds
+        if mode == "eager":
+            built = []
+            for _ in range(cycles * P):
+                b = nl.n_builds
+                run.step()
+                if nl.n_builds != b:
+                    built.append(sysm.timestep - 1)
+        else:
+            run.run(cycles * P, graph=True)
+            built = list(run._rebuilt_at)
+            assert run.n_cycles == cycles
+        torch.cuda.synchronize()
+        assert nl.n_builds - b0 >= 4 and run.dangerous_builds == 0, (nl.n_builds - b0, run.dangerous_builds)
+        nl.domain.counts_host()            # (raises on an overflow flag)
+        out[mode] = (built, sysm.pos.clone(), sysm.vel.clone(), sysm.force.clone(), nl.domain.n_migrated)
+    assert out["eager"][0] == out["graph"][0], (out["eager"][0], out["graph"][0])
+    for k in (1, 2, 3):
+        assert _same(out["eager"][k], out["graph"][k]), k
+    assert out["eager"][4] == out["graph"][4] > 0
