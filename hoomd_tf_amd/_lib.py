@@ -44,17 +44,17 @@ class Box(C.Structure):
 
 
 BRICK_MAX_MSG, BRICK_MAX_P = 8, 64   # include/htf_standin.h HTFS_BRICK_MAX_MSG / _MAX_P
-BC_N_INT, BC_N_BND, BC_N_CAND, BC_N_ARRIVED, BC_FLAGS, BC_REBUILDS, BC_MSG, BC_CLASS, BC_WORDS = 0, 1, 2, 3, 4, 5, 8, 16, 64
+BC_N_INT, BC_N_BND, BC_N_CAND, BC_N_ARRIVED, BC_FLAGS, BC_REBUILDS, BC_MSG, BC_CLASS, BC_SLOT, BC_WORDS = 0, 1, 2, 3, 4, 5, 8, 16, 64, 192
 BF_LOST, BF_MIG_OVERFLOW, BF_INT_OVERFLOW, BF_BND_OVERFLOW, BF_GHOST_OVERFLOW = 1, 2, 4, 8, 16
 
 
 class Brick(C.Structure):
     """htfs_brick (include/htf_standin.h)."""
     _fields_ = [("ndim", C.c_int), ("axis", C.c_int * 2), ("p", C.c_int * 2), ("me", C.c_int * 2), ("n_msg", C.c_int),
-                ("r_ghost", C.c_double), ("cap_int", C.c_uint), ("cap_bnd", C.c_uint),
+                ("replica", C.c_int), ("r_ghost", C.c_double), ("cap_int", C.c_uint), ("cap_bnd", C.c_uint),
                 ("ghost_cap", C.c_uint * BRICK_MAX_MSG), ("ghost_off", C.c_uint * BRICK_MAX_MSG),
                 ("mig_cap", C.c_uint * BRICK_MAX_MSG), ("mig_off", C.c_uint * BRICK_MAX_MSG),
-                ("shift", (C.c_double * 3) * BRICK_MAX_MSG)]
+                ("shift", (C.c_double * 3) * BRICK_MAX_MSG), ("box_lo", C.c_double * 3), ("box_L", C.c_double * 3)]
 
 
 class BrickWork(C.Structure):
@@ -164,6 +164,7 @@ STANDIN_PROTOTYPES = {
     "htfs_brick_migrate_pack": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "htfs_brick_migrate_merge": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "htfs_brick_pack_halo": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "htfs_brick_nve_halo": (_i, [_vp, _vp, _vp, _vp, _i, _d, C.POINTER(Box), _vp, _vp, _vp, _vp]),
     "htfs_slab_classify": (_i, [_vp, _i, _u, _vp, _i, _i, _d, _vp, _vp]),
     "htfs_segment_copy": (_i, [_vp, _vp, _u, _u, _vp, _vp, _vp, _vp]),
     "htfs_key_sort16": (_i, [_vp, _u, _vp, _vp, _vp, _vp]),

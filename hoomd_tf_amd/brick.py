@@ -212,6 +212,20 @@ class BrickDomain:
     def n_classes(self):
         return 4 ** self.ndim
 
+    def _shifted(self, P, m):
+        """Positions as message m carries them: shifted and wrapped back into the global box (brick.hip ``shifted``)."""
+        if not self.replica:
+            return P
+        P = P.clone()
+        for c in range(3):
+            if self.shift[m, c] != 0.0:
+                dt, dev = P.dtype, P.device
+                lo = torch.as_tensor(float(self.sys.box3x3[0][c]), dtype=dt, device=dev)
+                L = torch.as_tensor(float(self.L[c]), dtype=dt, device=dev)
+                x = P[:, c] + torch.as_tensor(float(self.shift[m, c]), dtype=dt, device=dev)
+                P[:, c] = x - torch.floor((x - lo) * (1.0 / L)) * L
+        return P
+
     def _msg_takes_class(self, m, c):
         for k in range(self.ndim):
             o = self.offsets[m][k]
@@ -227,7 +241,7 @@ class BrickDomain:
         s = self.sys
         dev, dt = s.pos.device, s.pos.dtype
         g = self.geom = _lib.Brick()
-        g.ndim, g.n_msg = self.ndim, self.n_msg
+        g.ndim, g.n_msg, g.replica = self.ndim, self.n_msg, int(self.replica)
         for k, d in enumerate(self.axes):
             g.axis[k], g.p[k], g.me[k] = d, self.grid[d], self.coords[d]
         g.r_ghost = self.r_ghost
@@ -237,13 +251,15 @@ class BrickDomain:
             g.mig_cap[m], g.mig_off[m] = self.mig_cap[m], self.mig_off[m]
             for c in range(3):
                 g.shift[m][c] = float(self.shift[m, c])
+        for c in range(3):
+            g.box_lo[c], g.box_L[c] = float(self.sys.box3x3[0][c]), float(self.L[c])
         b = np.zeros((2, _lib.BRICK_MAX_P + 1))
         for k, d in enumerate(self.axes):
             if self.grid[d] > _lib.BRICK_MAX_P:
                 raise ValueError("at most %d bricks along an axis" % _lib.BRICK_MAX_P)
             b[k, :self.grid[d] + 1] = self.bounds[d]
         self._bounds_dev = torch.as_tensor(b, dtype=dt, device=dev).contiguous()
-        tiles = (self.cand + 4095) // 4096
+        tiles = (self.cand + 1023) // 1024
         self._wk = {"key": torch.empty(self.cand, dtype=torch.int32, device=dev),
                     "order": torch.empty(self.cand, dtype=torch.int32, device=dev),
                     "scratch": torch.zeros(32 * tiles, dtype=torch.int32, device=dev),
@@ -376,6 +392,7 @@ class BrickDomain:
         else:
             self._rebuild_torch()
         self.n_rebuilds += 1
+        self._packed = False   # (whatever the integrator packed describes the rows of the old plan)
         self.exchange()
 
     def _dest_keys_torch(self, P):
@@ -390,8 +407,13 @@ class BrickDomain:
             x = P[:, d].contiguous()
             bnd = torch.as_tensor(self.bounds[d], dtype=P.dtype, device=P.device)
             owner = (x[:, None] >= bnd[None, 1:-1]).sum(dim=1)
-            if p == 2:
+            if p == 2 and not self.replica:
                 off = (owner != me).to(torch.int64)
+            elif p == 2:
+                Lg = bnd[2] - bnd[0]
+                dx = x - 0.5 * (bnd[me] + bnd[me + 1])
+                dx = dx - Lg * torch.round(dx / Lg)
+                off = torch.where(owner != me, torch.where(dx < 0, -1, 1), 0)
             else:
                 left, right = (me - 1) % p, (me + 1) % p
                 off = torch.where(owner == me, 0, torch.where(owner == left, -1, torch.where(owner == right, 1, 0)))
@@ -438,7 +460,7 @@ class BrickDomain:
                 n = room
             rows = order[start[1 + m]:start[1 + m] + n]
             rec = PV[rows].clone()
-            rec[:, :3] += torch.as_tensor(self.shift[m], dtype=dt, device=dev)
+            rec[:, :4] = self._shifted(rec[:, :4], m)
             o = self.mig_off[m]
             self.mig_send[o + 1:o + 1 + n] = rec
             hdr_send[o, 0] = n
@@ -490,7 +512,12 @@ class BrickDomain:
         c[_lib.BC_REBUILDS] = int(prev[_lib.BC_REBUILDS]) + 1
         c[_lib.BC_MSG:_lib.BC_MSG + self.n_msg] = msg
         c[_lib.BC_CLASS:_lib.BC_CLASS + self.n_classes + 1] = cstart
-        self.counts.copy_(torch.as_tensor(c, dtype=torch.int32))
+        c[_lib.BC_SLOT:_lib.BC_SLOT + 16 * _lib.BRICK_MAX_MSG] = 0xFFFFFFFF
+        for cl in range(1, self.n_classes):
+            for m in range(self.n_msg):
+                if self._msg_takes_class(m, cl):
+                    c[_lib.BC_SLOT + cl * _lib.BRICK_MAX_MSG + m] = sum(int(ccnt[cc]) for cc in range(1, cl) if self._msg_takes_class(m, cc))
+        self.counts.copy_(torch.as_tensor((c & 0xFFFFFFFF).astype(np.uint32).view(np.int32)))
 
     # ------------------------------------------------------------------ per-step halo
     def _pack_halo_torch(self):
@@ -504,20 +531,39 @@ class BrickDomain:
             rows = [torch.arange(self.cap_int + cstart[cl] - n_int, self.cap_int + cstart[cl + 1] - n_int, device=s.pos.device)
                     for cl in range(1, self.n_classes) if self._msg_takes_class(m, cl)]
             rows = torch.cat(rows)[:self.ghost_cap[m]]
-            buf = s.pos[rows].clone()
-            buf[:, :3] += torch.as_tensor(self.shift[m], dtype=s.pos.dtype, device=s.pos.device)
+            buf = self._shifted(s.pos[rows], m)
             self.halo_send[self.ghost_off[m]:self.ghost_off[m] + len(rows)] = buf
 
+    def nve_step(self, dt):
+        """The integrator's step over the local rows AND the halo messages of the new positions in one launch
+        (htfs_brick_nve_halo; the kernels backend): the next exchange_begin() finds the messages packed."""
+        s = self.sys
+        direct = self.transport == "local"
+        _lib.check(_lib.lib.htfs_brick_nve_halo(C.byref(self.geom), s.pos.data_ptr(), s.vel.data_ptr(), s.force.data_ptr(), s.scalar_code,
+                                                float(dt), C.byref(s.box), self.counts.data_ptr(),
+                                                None if direct else self.halo_send.data_ptr(),
+                                                s.pos.data_ptr() + self.cap * 4 * s.pos.element_size() if direct else None,
+                                                self._stream()))
+        self._packed = True
+
+    @property
+    def overlaps(self):
+        """Does a posted halo travel while the interior rows are evaluated?  Not when the pack kernel delivers it itself, and not
+        inside a hipGraph capture (where the RCCL calls stay on the captured stream)."""
+        return self.transport != "local" and not getattr(self, "_capturing", False)
+
     def exchange_begin(self):
-        """Post the per-step forward halo: pack the messages from the boundary segment, one grouped exchange into the ghost
-        regions.  Nothing may write ``pos`` until exchange_end()."""
+        """Post the per-step forward halo: pack the messages from the boundary segment (unless nve_step() has), one grouped
+        exchange into the ghost regions.  Nothing may write ``pos`` until exchange_end()."""
         s = self.sys
         ghosts = s.pos[self.cap:]
+        packed, self._packed = getattr(self, "_packed", False), False
         if self.kernels:
             direct = self.transport == "local"
-            _lib.check(_lib.lib.htfs_brick_pack_halo(C.byref(self.geom), s.pos.data_ptr(), s.scalar_code, self.counts.data_ptr(),
-                                                     None if direct else self.halo_send.data_ptr(),
-                                                     ghosts.data_ptr() if direct else None, self._stream()))
+            if not packed:
+                _lib.check(_lib.lib.htfs_brick_pack_halo(C.byref(self.geom), s.pos.data_ptr(), s.scalar_code, self.counts.data_ptr(),
+                                                         None if direct else self.halo_send.data_ptr(),
+                                                         ghosts.data_ptr() if direct else None, self._stream()))
             if direct:
                 self._works = []
                 return

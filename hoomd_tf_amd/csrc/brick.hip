@@ -14,13 +14,14 @@ namespace htf {
 // by-value copy of htfs_brick in the positions' precision
 template <typename T>
 struct BrickArgs {
-    int ndim, n_msg;
+    int ndim, n_msg, replica;
     int axis[2], p[2], me[2];
     T r_ghost;
     unsigned cap_int, cap_bnd;
     unsigned ghost_cap[HTFS_BRICK_MAX_MSG], ghost_off[HTFS_BRICK_MAX_MSG];
     unsigned mig_cap[HTFS_BRICK_MAX_MSG], mig_off[HTFS_BRICK_MAX_MSG];
     T shift[HTFS_BRICK_MAX_MSG][3];
+    T box_lo[3], box_L[3], box_Linv[3];
 };
 
 template <typename T>
@@ -28,6 +29,7 @@ static BrickArgs<T> make_args(const htfs_brick *g) {
     BrickArgs<T> a;
     a.ndim = g->ndim;
     a.n_msg = g->n_msg;
+    a.replica = g->replica;
     for (int d = 0; d < 2; ++d) {
         a.axis[d] = g->axis[d];
         a.p[d] = g->p[d];
@@ -42,6 +44,11 @@ static BrickArgs<T> make_args(const htfs_brick *g) {
         a.mig_cap[m] = g->mig_cap[m];
         a.mig_off[m] = g->mig_off[m];
         for (int c = 0; c < 3; ++c) a.shift[m][c] = (T)g->shift[m][c];
+    }
+    for (int c = 0; c < 3; ++c) {
+        a.box_lo[c] = (T)g->box_lo[c];
+        a.box_L[c] = (T)g->box_L[c];
+        a.box_Linv[c] = (T)1 / a.box_L[c];
     }
     return a;
 }
@@ -67,6 +74,16 @@ __device__ __forceinline__ bool msg_takes_class(int m, int ndim, unsigned c) {
     return ok;
 }
 
+// a position as message m carries it: shifted (replica mode) and wrapped back into the global box, the integrator's wrap
+template <typename T, typename V4>
+__device__ __forceinline__ V4 shifted(V4 p, const BrickArgs<T> &a, int m) {
+    if (!a.replica) return p;
+    if (a.shift[m][0] != (T)0) p.x = wrap1<T>(p.x + a.shift[m][0], a.box_lo[0], a.box_L[0], a.box_Linv[0], 1);
+    if (a.shift[m][1] != (T)0) p.y = wrap1<T>(p.y + a.shift[m][1], a.box_lo[1], a.box_L[1], a.box_Linv[1], 1);
+    if (a.shift[m][2] != (T)0) p.z = wrap1<T>(p.z + a.shift[m][2], a.box_lo[2], a.box_L[2], a.box_Linv[2], 1);
+    return p;
+}
+
 template <typename V>
 __device__ __forceinline__ V inert_position() {
     V p;
@@ -77,44 +94,61 @@ __device__ __forceinline__ V inert_position() {
 
 // ---- K1: destination key of every local row: 0 stay | 1 + message index | n_msg + 1 inert.  The arithmetic is SlabDomain's
 // (slab_classify_kernel) per decomposed axis, in the positions' own precision: owner = #(interior cuts <= x).
+constexpr unsigned kBrickTile = 1024; // rows per sorting tile (a 256-thread block): ~40 tiles at 16 k rows per rank + ghosts
+
 template <typename T, typename V4>
 __global__ __launch_bounds__(256) void brick_dest_kernel(const V4 *__restrict__ pos, unsigned cap, BrickArgs<T> a,
                                                          const T *__restrict__ bounds, unsigned *__restrict__ key,
-                                                         unsigned *__restrict__ counts) {
-    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= cap) return;
-    const V4 p = pos[i];
-    if (is_inert(p.x)) {
-        key[i] = (unsigned)a.n_msg + 1u;
-        return;
-    }
-    int raw = 0, mul = 1;
-    bool stay = true, lost = false;
-    for (int d = 0; d < a.ndim; ++d) {
-        const T x = comp(p, a.axis[d]);
-        const T *b = bounds + d * (HTFS_BRICK_MAX_P + 1);
-        int owner = 0;
-        for (int c = 1; c < a.p[d]; ++c) owner += (b[c] <= x) ? 1 : 0;
-        int off;
-        if (a.p[d] == 2)
-            off = owner != a.me[d] ? 1 : 0; // both faces lead to the one peer: everything that leaves travels "up"
-        else if (owner == a.me[d])
-            off = 0;
-        else if (owner == (a.me[d] + a.p[d] - 1) % a.p[d])
-            off = -1;
-        else if (owner == (a.me[d] + 1) % a.p[d])
-            off = 1;
-        else {
-            off = 0;
-            lost = true;
+                                                         unsigned *__restrict__ tile_hist, unsigned *__restrict__ counts) {
+    __shared__ unsigned h[16];
+    tile_hist_begin<16>(h);
+    for (unsigned r = 0; r < kBrickTile / 256; ++r) {
+        const unsigned i = blockIdx.x * kBrickTile + r * 256 + threadIdx.x;
+        if (i >= cap) continue;
+        const V4 p = pos[i];
+        unsigned k;
+        if (is_inert(p.x)) {
+            k = (unsigned)a.n_msg + 1u;
+        } else {
+            int raw = 0, mul = 1;
+            bool stay = true, lost = false;
+            for (int d = 0; d < a.ndim; ++d) {
+                const T x = comp(p, a.axis[d]);
+                const T *b = bounds + d * (HTFS_BRICK_MAX_P + 1);
+                int owner = 0;
+                for (int c = 1; c < a.p[d]; ++c) owner += (b[c] <= x) ? 1 : 0;
+                int off;
+                if (a.p[d] == 2 && !a.replica)
+                    off = owner != a.me[d] ? 1 : 0; // both faces lead to the one peer: everything that leaves travels "up"
+                else if (a.p[d] == 2) {
+                    // a replica brick is shifted by the face it leaves through: which one, from the side of the brick's centre the
+                    // particle is on (minimum image of the logical box)
+                    const T L = b[2] - b[0];
+                    T dx = x - (T)0.5 * (b[a.me[d]] + b[a.me[d] + 1]);
+                    dx -= L * rint(dx / L);
+                    off = owner != a.me[d] ? (dx < (T)0 ? -1 : 1) : 0;
+                } else if (owner == a.me[d])
+                    off = 0;
+                else if (owner == (a.me[d] + a.p[d] - 1) % a.p[d])
+                    off = -1;
+                else if (owner == (a.me[d] + 1) % a.p[d])
+                    off = 1;
+                else {
+                    off = 0;
+                    lost = true;
+                }
+                stay = stay && off == 0;
+                raw += (off + 1) * mul;
+                mul *= 3;
+            }
+            if (lost) atomicOr(&counts[HTFS_BC_FLAGS], (unsigned)HTFS_BF_LOST);
+            const int centre = a.ndim == 1 ? 1 : 4;
+            k = (stay || lost) ? 0u : 1u + (unsigned)(raw < centre ? raw : raw - 1);
         }
-        stay = stay && off == 0;
-        raw += (off + 1) * mul;
-        mul *= 3;
+        key[i] = k;
+        atomicAdd(&h[k], 1u);
     }
-    if (lost) atomicOr(&counts[HTFS_BC_FLAGS], (unsigned)HTFS_BF_LOST);
-    const int centre = a.ndim == 1 ? 1 : 4;
-    key[i] = (stay || lost) ? 0u : 1u + (unsigned)(raw < centre ? raw : raw - 1);
+    tile_hist_end<16>(h, tile_hist);
 }
 
 // ---- K3: migrants into their messages; row 0 of a message is its header (count in the first word)
@@ -136,64 +170,66 @@ __global__ __launch_bounds__(256) void brick_pack_mig_kernel(const V4 *__restric
     }
     if (j - 1u >= n) return;
     const unsigned src = order[first + j - 1u];
-    V4 p = pos[src];
-    p.x += a.shift[m][0], p.y += a.shift[m][1], p.z += a.shift[m][2];
-    send[2 * (size_t)r] = p;
+    send[2 * (size_t)r] = shifted<T>(pos[src], a, m);
     send[2 * (size_t)r + 1] = vel[src];
 }
 
 // ---- K4: the candidates of this brick after the exchange -- [stayed | from offset index n_msg-1 | ... | from index 0] -- copied
 // into the scratch arrays with their class key in THIS brick (k_0 + 4 k_1; 4^ndim = nothing here)
-template <typename T, typename V4>
+template <typename T, typename V4, unsigned NK>
 __global__ __launch_bounds__(256) void brick_home_kernel(const V4 *__restrict__ pos, const V4 *__restrict__ vel, BrickArgs<T> a,
                                                          const T *__restrict__ bounds, const unsigned *__restrict__ order,
                                                          const unsigned *__restrict__ start1, const V4 *__restrict__ recv,
                                                          V4 *__restrict__ tmp_pos, V4 *__restrict__ tmp_vel, unsigned *__restrict__ key2,
-                                                         unsigned cand_cap, unsigned *__restrict__ counts) {
-    const unsigned c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= cand_cap) return;
+                                                         unsigned cand_cap, unsigned *__restrict__ tile_hist, unsigned *__restrict__ counts) {
+    __shared__ unsigned h[NK];
+    tile_hist_begin<NK>(h);
     const unsigned dead_key = a.ndim == 1 ? 4u : 16u;
     const unsigned n_stay = start1[1];
-    V4 p, v;
-    bool live = true;
-    if (c < n_stay) {
-        const unsigned src = order[c];
-        p = pos[src];
-        v = vel[src];
-    } else {
-        unsigned j = c - n_stay, arrived = 0;
-        int m = a.n_msg - 1;
-        live = false;
-        for (; m >= 0; --m) {
-            const unsigned n = *reinterpret_cast<const unsigned *>(&recv[2 * (size_t)a.mig_off[m]]);
-            arrived += n;
-            if (!live && j < n) {
-                live = true;
-                p = recv[2 * (size_t)(a.mig_off[m] + 1u + j)];
-                v = recv[2 * (size_t)(a.mig_off[m] + 1u + j) + 1];
+    for (unsigned rr = 0; rr < kBrickTile / 256; ++rr) {
+        const unsigned c = blockIdx.x * kBrickTile + rr * 256 + threadIdx.x;
+        if (c >= cand_cap) continue;
+        V4 p, v;
+        bool live = true;
+        if (c < n_stay) {
+            const unsigned src = order[c];
+            p = pos[src];
+            v = vel[src];
+        } else {
+            unsigned j = c - n_stay, arrived = 0;
+            live = false;
+            for (int m = a.n_msg - 1; m >= 0; --m) {
+                const unsigned n = *reinterpret_cast<const unsigned *>(&recv[2 * (size_t)a.mig_off[m]]);
+                arrived += n;
+                if (!live && j < n) {
+                    live = true;
+                    p = recv[2 * (size_t)(a.mig_off[m] + 1u + j)];
+                    v = recv[2 * (size_t)(a.mig_off[m] + 1u + j) + 1];
+                }
+                if (!live) j -= n;
             }
-            if (!live) j -= n;
+            if (c == n_stay) { // (one thread: the totals of this rebuild)
+                counts[HTFS_BC_N_CAND] = n_stay + arrived;
+                counts[HTFS_BC_N_ARRIVED] += arrived;
+                counts[HTFS_BC_REBUILDS] += 1u;
+            }
         }
-        if (c == n_stay) { // (one thread: the totals of this rebuild)
-            counts[HTFS_BC_N_CAND] = n_stay + arrived;
-            counts[HTFS_BC_N_ARRIVED] += arrived;
-            counts[HTFS_BC_REBUILDS] += 1u;
+        unsigned k = dead_key;
+        if (live) {
+            k = 0;
+            for (int d = 0; d < a.ndim; ++d) {
+                const T x = comp(p, a.axis[d]);
+                const T *b = bounds + d * (HTFS_BRICK_MAX_P + 1);
+                const bool near_lo = x < b[a.me[d]] + a.r_ghost, near_hi = x >= b[a.me[d] + 1] - a.r_ghost;
+                k |= (near_lo ? (near_hi ? 2u : 1u) : (near_hi ? 3u : 0u)) << (2 * d);
+            }
+            tmp_pos[c] = p;
+            tmp_vel[c] = v;
         }
+        key2[c] = k;
+        atomicAdd(&h[k], 1u);
     }
-    if (!live) {
-        key2[c] = dead_key;
-        return;
-    }
-    unsigned k = 0;
-    for (int d = 0; d < a.ndim; ++d) {
-        const T x = comp(p, a.axis[d]);
-        const T *b = bounds + d * (HTFS_BRICK_MAX_P + 1);
-        const bool near_lo = x < b[a.me[d]] + a.r_ghost, near_hi = x >= b[a.me[d] + 1] - a.r_ghost;
-        k |= (near_lo ? (near_hi ? 2u : 1u) : (near_hi ? 3u : 0u)) << (2 * d);
-    }
-    key2[c] = k;
-    tmp_pos[c] = p;
-    tmp_vel[c] = v;
+    tile_hist_end<NK>(h, tile_hist);
 }
 
 // ---- K6: the two segments, inert rows behind the particles; counts, class boundaries, message sizes, overflow flags
@@ -223,6 +259,16 @@ __global__ __launch_bounds__(256) void brick_place_kernel(V4 *__restrict__ pos, 
             n = a.ghost_cap[r];
         }
         counts[HTFS_BC_MSG + r] = n;
+    }
+    if (r < 16u * HTFS_BRICK_MAX_MSG) { // where class c starts in message m: what brick_nve_halo_kernel looks a row's slots up in
+        const unsigned c = r / HTFS_BRICK_MAX_MSG, m = r % HTFS_BRICK_MAX_MSG;
+        unsigned first = 0xFFFFFFFFu;
+        if (c >= 1u && c < nclass && m < (unsigned)a.n_msg && msg_takes_class((int)m, a.ndim, c)) {
+            first = 0;
+            for (unsigned cc = 1; cc < c; ++cc)
+                if (msg_takes_class((int)m, a.ndim, cc)) first += start2[cc + 1] - start2[cc];
+        }
+        counts[HTFS_BC_SLOT + r] = first;
     }
     if (r >= a.cap_int + a.cap_bnd) return;
     const bool interior = r < a.cap_int;
@@ -258,8 +304,7 @@ __global__ __launch_bounds__(256) void brick_pack_halo_kernel(const V4 *__restri
             if (!msg_takes_class(m, a.ndim, c)) continue;
             const unsigned first = counts[HTFS_BC_CLASS + c], n = counts[HTFS_BC_CLASS + c + 1] - first;
             if (j < n) {
-                p = pos[a.cap_int + (first - n_int) + j];
-                p.x += a.shift[m][0], p.y += a.shift[m][1], p.z += a.shift[m][2];
+                p = shifted<T>(pos[a.cap_int + (first - n_int) + j], a, m);
                 break;
             }
             j -= n;
@@ -268,6 +313,40 @@ __global__ __launch_bounds__(256) void brick_pack_halo_kernel(const V4 *__restri
     if (send != nullptr) send[r] = p;
     // this rank as its own neighbor: message m (to offset o) is what it receives from offset -o, index n_msg - 1 - m
     if (direct != nullptr) direct[a.ghost_off[a.n_msg - 1 - m] + (r - a.ghost_off[m])] = p;
+}
+
+// ---- every step, instead of nve_step + K8: the leapfrog update of every local row (nve_advance: the stand-in integrator's own
+// arithmetic) and, for a boundary row, its new position straight into every halo message that carries it -- the row knows its
+// class from the class boundaries and its slot in a message from the counts of the classes before it.  One launch where the
+// integrator and the packer were two (each >= 4.5 us inside a hipGraph whatever it moves).  The messages' inert tails were
+// written by the rebuild's own pack and stay put until the next one.
+template <typename T, typename V4>
+__global__ __launch_bounds__(256) void brick_nve_halo_kernel(V4 *__restrict__ pos, V4 *__restrict__ vel, const V4 *__restrict__ force,
+                                                             T dt, SBox<T> box, BrickArgs<T> a, const unsigned *__restrict__ counts,
+                                                             V4 *__restrict__ send, V4 *__restrict__ direct) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.cap_int + a.cap_bnd) return;
+    V4 p = pos[i], v = vel[i];
+    nve_advance<T>(p, v, force[i], dt, box);
+    pos[i] = p;
+    vel[i] = v;
+    if (i < a.cap_int) return;
+    const unsigned j = i - a.cap_int;
+    if (j >= counts[HTFS_BC_N_BND]) return;
+    const unsigned nclass = a.ndim == 1 ? 4u : 16u;
+    const unsigned n_int = counts[HTFS_BC_CLASS + 1];
+    unsigned c = 1;
+    while (c + 1 < nclass && j >= counts[HTFS_BC_CLASS + c + 1] - n_int) ++c;
+    const unsigned in_class = j - (counts[HTFS_BC_CLASS + c] - n_int);
+    for (int m = 0; m < a.n_msg; ++m) {
+        const unsigned first = counts[HTFS_BC_SLOT + c * HTFS_BRICK_MAX_MSG + m]; // (written by the rebuild's place kernel)
+        if (first == 0xFFFFFFFFu) continue;
+        const unsigned slot = first + in_class;
+        if (slot >= counts[HTFS_BC_MSG + m]) continue; // (beyond the message's capacity: flagged by the rebuild)
+        const V4 q = shifted<T>(p, a, m);
+        if (send != nullptr) send[a.ghost_off[m] + slot] = q;
+        if (direct != nullptr) direct[a.ghost_off[a.n_msg - 1 - m] + slot] = q;
+    }
 }
 
 static int check_geom(const htfs_brick *g, const char *who) {
@@ -304,13 +383,14 @@ extern "C" int htfs_brick_migrate_pack(const htfs_brick *g, const void *d_pos, c
     hipStream_t s = (hipStream_t)stream;
     const unsigned cap = g->cap_int + g->cap_bnd;
     const unsigned mig_rows = g->mig_off[g->n_msg - 1] + g->mig_cap[g->n_msg - 1];
+    const unsigned tiles = (cap + kBrickTile - 1) / kBrickTile;
     if (dtype == HTF_F32)
-        hipLaunchKernelGGL((brick_dest_kernel<float, float4>), dim3((cap + 255) / 256), dim3(256), 0, s, (const float4 *)d_pos, cap,
-                           make_args<float>(g), (const float *)d_bounds, w->key, d_counts);
+        hipLaunchKernelGGL((brick_dest_kernel<float, float4>), dim3(tiles), dim3(256), 0, s, (const float4 *)d_pos, cap,
+                           make_args<float>(g), (const float *)d_bounds, w->key, w->sort_scratch, d_counts);
     else
-        hipLaunchKernelGGL((brick_dest_kernel<double, double4>), dim3((cap + 255) / 256), dim3(256), 0, s, (const double4 *)d_pos, cap,
-                           make_args<double>(g), (const double *)d_bounds, w->key, d_counts);
-    if (int rc = key_sort<16>(w->key, cap, nullptr, w->sort_scratch, w->start1, w->order, s)) return rc;
+        hipLaunchKernelGGL((brick_dest_kernel<double, double4>), dim3(tiles), dim3(256), 0, s, (const double4 *)d_pos, cap,
+                           make_args<double>(g), (const double *)d_bounds, w->key, w->sort_scratch, d_counts);
+    if (int rc = key_sort_from_hist<16, kBrickTile>(w->key, cap, w->sort_scratch, w->start1, w->order, s)) return rc;
     if (dtype == HTF_F32)
         hipLaunchKernelGGL((brick_pack_mig_kernel<float, float4>), dim3((mig_rows + 255) / 256), dim3(256), 0, s, (const float4 *)d_pos,
                            (const float4 *)d_vel, make_args<float>(g), w->order, w->start1, (float4 *)d_mig_send, mig_rows, d_counts);
@@ -333,18 +413,21 @@ extern "C" int htfs_brick_migrate_merge(const htfs_brick *g, void *d_pos, void *
     const unsigned mig_rows = g->mig_off[g->n_msg - 1] + g->mig_cap[g->n_msg - 1];
     const unsigned cand = cap + mig_rows;
     // (w->key and w->order serve both sorts: brick_home_kernel has consumed the first order before the second sort writes its own)
-    if (dtype == HTF_F32)
-        hipLaunchKernelGGL((brick_home_kernel<float, float4>), dim3((cand + 255) / 256), dim3(256), 0, s, (const float4 *)d_pos,
-                           (const float4 *)d_vel, make_args<float>(g), (const float *)d_bounds, w->order, w->start1,
-                           (const float4 *)d_mig_recv, (float4 *)w->tmp_pos, (float4 *)w->tmp_vel, w->key, cand, d_counts);
-    else
-        hipLaunchKernelGGL((brick_home_kernel<double, double4>), dim3((cand + 255) / 256), dim3(256), 0, s, (const double4 *)d_pos,
-                           (const double4 *)d_vel, make_args<double>(g), (const double *)d_bounds, w->order, w->start1,
-                           (const double4 *)d_mig_recv, (double4 *)w->tmp_pos, (double4 *)w->tmp_vel, w->key, cand, d_counts);
-    int rc = g->ndim == 1 ? key_sort<16>(w->key, cand, nullptr, w->sort_scratch, w->start2, w->order, s)
-                          : key_sort<32>(w->key, cand, nullptr, w->sort_scratch, w->start2, w->order, s);
+    const unsigned tiles = (cand + kBrickTile - 1) / kBrickTile;
+#define HTFS_HOME(T, V4, NK)                                                                                                       \
+    hipLaunchKernelGGL((brick_home_kernel<T, V4, NK>), dim3(tiles), dim3(256), 0, s, (const V4 *)d_pos, (const V4 *)d_vel, make_args<T>(g), \
+                       (const T *)d_bounds, w->order, w->start1, (const V4 *)d_mig_recv, (V4 *)w->tmp_pos, (V4 *)w->tmp_vel, w->key, cand, \
+                       w->sort_scratch, d_counts)
+    if (dtype == HTF_F32) {
+        if (g->ndim == 1) HTFS_HOME(float, float4, 16); else HTFS_HOME(float, float4, 32);
+    } else {
+        if (g->ndim == 1) HTFS_HOME(double, double4, 16); else HTFS_HOME(double, double4, 32);
+    }
+#undef HTFS_HOME
+    int rc = g->ndim == 1 ? key_sort_from_hist<16, kBrickTile>(w->key, cand, w->sort_scratch, w->start2, w->order, s)
+                          : key_sort_from_hist<32, kBrickTile>(w->key, cand, w->sort_scratch, w->start2, w->order, s);
     if (rc) return rc;
-    const unsigned rows = cap > 64u ? cap : 64u; // (the first threads also publish counts and message sizes)
+    const unsigned rows = cap > 128u ? cap : 128u; // (the first threads also publish counts, message sizes and the slot table)
     if (dtype == HTF_F32)
         hipLaunchKernelGGL((brick_place_kernel<float, float4>), dim3((rows + 255) / 256), dim3(256), 0, s, (float4 *)d_pos, (float4 *)d_vel,
                            make_args<float>(g), w->order, w->start2, (const float4 *)w->tmp_pos, (const float4 *)w->tmp_vel, d_n_neigh,
@@ -369,4 +452,21 @@ extern "C" int htfs_brick_pack_halo(const htfs_brick *g, const void *d_pos, int 
         hipLaunchKernelGGL((brick_pack_halo_kernel<double, double4>), dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                            (const double4 *)d_pos, make_args<double>(g), d_counts, (double4 *)d_send, (double4 *)d_ghost_direct, rows);
     return check_launch("brick_pack_halo_kernel");
+}
+
+extern "C" int htfs_brick_nve_halo(const htfs_brick *g, void *d_pos, void *d_vel, const void *d_force, int dtype, double dt,
+                                   const htf_box *box, const unsigned *d_counts, void *d_send, void *d_ghost_direct, htf_stream stream) {
+    if (int rc = check_geom(g, "htfs_brick_nve_halo")) return rc;
+    HTF_REQUIRE(d_pos && d_vel && d_force && box && d_counts && (d_send || d_ghost_direct), "htfs_brick_nve_halo: null pointer");
+    HTF_REQUIRE(dtype == HTF_F32 || dtype == HTF_F64, "htfs_brick_nve_halo: bad dtype %d", dtype);
+    const unsigned cap = g->cap_int + g->cap_bnd;
+    if (dtype == HTF_F32)
+        hipLaunchKernelGGL((brick_nve_halo_kernel<float, float4>), dim3((cap + 255) / 256), dim3(256), 0, (hipStream_t)stream, (float4 *)d_pos,
+                           (float4 *)d_vel, (const float4 *)d_force, (float)dt, make_sbox<float>(box), make_args<float>(g), d_counts,
+                           (float4 *)d_send, (float4 *)d_ghost_direct);
+    else
+        hipLaunchKernelGGL((brick_nve_halo_kernel<double, double4>), dim3((cap + 255) / 256), dim3(256), 0, (hipStream_t)stream, (double4 *)d_pos,
+                           (double4 *)d_vel, (const double4 *)d_force, dt, make_sbox<double>(box), make_args<double>(g), d_counts,
+                           (double4 *)d_send, (double4 *)d_ghost_direct);
+    return check_launch("brick_nve_halo_kernel");
 }

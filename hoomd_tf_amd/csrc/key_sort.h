@@ -17,15 +17,15 @@ __device__ __forceinline__ unsigned sort_len(unsigned n, const unsigned *n_dev) 
     return n_dev != nullptr ? min(n, *n_dev) : n;
 }
 
-template <unsigned NK>
+template <unsigned NK, unsigned TILE = kSortTile>
 __global__ __launch_bounds__(256) void key_hist_kernel(const unsigned *__restrict__ key, unsigned n_max, const unsigned *__restrict__ n_dev,
                                                        unsigned *__restrict__ tile_hist) {
     __shared__ unsigned h[NK];
     const unsigned n = sort_len(n_max, n_dev);
     if (threadIdx.x < NK) h[threadIdx.x] = 0;
     __syncthreads();
-    const unsigned base = blockIdx.x * kSortTile;
-    for (unsigned r = 0; r < kSortTile / 256; ++r) {
+    const unsigned base = blockIdx.x * TILE;
+    for (unsigned r = 0; r < TILE / 256; ++r) {
         const unsigned i = base + r * 256 + threadIdx.x;
         if (i < n) atomicAdd(&h[key[i] & (NK - 1u)], 1u);
     }
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(64) void key_scan_kernel(unsigned *__restrict__ til
     }
 }
 
-template <unsigned NK>
+template <unsigned NK, unsigned TILE = kSortTile>
 __global__ __launch_bounds__(256) void key_scatter_kernel(const unsigned *__restrict__ key, unsigned n_max, const unsigned *__restrict__ n_dev,
                                                           const unsigned *__restrict__ tile_off, unsigned *__restrict__ order) {
     __shared__ unsigned run[NK];       // next free output slot of each key in this tile
@@ -66,8 +66,8 @@ __global__ __launch_bounds__(256) void key_scatter_kernel(const unsigned *__rest
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     if (threadIdx.x < NK) run[threadIdx.x] = tile_off[blockIdx.x * NK + threadIdx.x];
     __syncthreads();
-    const unsigned base = blockIdx.x * kSortTile;
-    for (unsigned r = 0; r < kSortTile / 256; ++r) {
+    const unsigned base = blockIdx.x * TILE;
+    for (unsigned r = 0; r < TILE / 256; ++r) {
         const unsigned i = base + r * 256 + threadIdx.x;
         const bool live = i < n;
         const unsigned my = live ? (key[i] & (NK - 1u)) : NK;
@@ -90,15 +90,37 @@ __global__ __launch_bounds__(256) void key_scatter_kernel(const unsigned *__rest
     }
 }
 
-// d_scratch: NK * ceil(n_max / 4096) words; d_start: NK + 1 words; three launches
-template <unsigned NK>
+// d_scratch: NK * ceil(n_max / TILE) words; d_start: NK + 1 words; three launches
+template <unsigned NK, unsigned TILE = kSortTile>
 inline int key_sort(const unsigned *d_key, unsigned n_max, const unsigned *d_n, unsigned *d_scratch, unsigned *d_start, unsigned *d_order,
                     hipStream_t s) {
-    const unsigned ntiles = (n_max + kSortTile - 1) / kSortTile;
-    if (ntiles) hipLaunchKernelGGL((key_hist_kernel<NK>), dim3(ntiles), dim3(256), 0, s, d_key, n_max, d_n, d_scratch);
+    const unsigned ntiles = (n_max + TILE - 1) / TILE;
+    if (ntiles) hipLaunchKernelGGL((key_hist_kernel<NK, TILE>), dim3(ntiles), dim3(256), 0, s, d_key, n_max, d_n, d_scratch);
     hipLaunchKernelGGL((key_scan_kernel<NK>), dim3(1), dim3(64), 0, s, d_scratch, ntiles, d_start);
-    if (ntiles) hipLaunchKernelGGL((key_scatter_kernel<NK>), dim3(ntiles), dim3(256), 0, s, d_key, n_max, d_n, d_scratch, d_order);
+    if (ntiles) hipLaunchKernelGGL((key_scatter_kernel<NK, TILE>), dim3(ntiles), dim3(256), 0, s, d_key, n_max, d_n, d_scratch, d_order);
     return check_launch("key_sort");
+}
+
+// the same when the kernel that produced the keys has already left the per-tile histograms in d_scratch (one launch less)
+template <unsigned NK, unsigned TILE>
+inline int key_sort_from_hist(const unsigned *d_key, unsigned n_max, unsigned *d_scratch, unsigned *d_start, unsigned *d_order, hipStream_t s) {
+    const unsigned ntiles = (n_max + TILE - 1) / TILE;
+    hipLaunchKernelGGL((key_scan_kernel<NK>), dim3(1), dim3(64), 0, s, d_scratch, ntiles, d_start);
+    if (ntiles) hipLaunchKernelGGL((key_scatter_kernel<NK, TILE>), dim3(ntiles), dim3(256), 0, s, d_key, n_max, (const unsigned *)nullptr, d_scratch, d_order);
+    return check_launch("key_sort");
+}
+
+// per-tile histogram of keys a kernel has just produced: called by EVERY thread of a 256-thread block that owns tile blockIdx.x
+// (TILE / 256 keys per thread, key = NK for "no element")
+template <unsigned NK>
+__device__ __forceinline__ void tile_hist_begin(unsigned *h) {
+    if (threadIdx.x < NK) h[threadIdx.x] = 0;
+    __syncthreads();
+}
+template <unsigned NK>
+__device__ __forceinline__ void tile_hist_end(unsigned *h, unsigned *__restrict__ tile_hist) {
+    __syncthreads();
+    if (threadIdx.x < NK) tile_hist[blockIdx.x * NK + threadIdx.x] = h[threadIdx.x];
 }
 
 } // namespace htf

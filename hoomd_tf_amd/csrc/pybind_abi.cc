@@ -129,7 +129,8 @@ void bind(py::module &m, const char *name, R (*fn)(A...)) {
     X(htfs_segment_copy) \
     X(htfs_brick_migrate_pack) \
     X(htfs_brick_migrate_merge) \
-    X(htfs_brick_pack_halo)
+    X(htfs_brick_pack_halo) \
+    X(htfs_brick_nve_halo)
 
 PYBIND11_MODULE(_htf_abi, m) {
     m.doc() = "pybind11 binding of libhtf_amd.so's C ABI: pointers as integers";

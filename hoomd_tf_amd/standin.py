@@ -675,6 +675,17 @@ class BrickRun:
             self.dom.exchange_end()
             self.ctx.compute_forces(ts, self._arr)
 
+    def _integrate(self):
+        if self.dom.kernels and self.nve.group is None:
+            self.dom.nve_step(self.nve.dt)   # integrator + next step's halo messages, one launch
+        else:
+            self.nve.step()
+
+    def _force_rows(self, ts):
+        if self.dom.pending and not self.dom.overlaps:
+            self.dom.exchange_end()          # nothing in flight to hide: one launch over all rows
+        self.ctx.compute_forces_overlapped(ts, self._arr, self.dom)
+
     def step(self):
         """One eager step (what bench.py's loop does)."""
         s = self.sys
@@ -683,8 +694,8 @@ class BrickRun:
         self.nl.compute(ts)
         if getattr(self, "_arr", None) is None or self.nl.n_builds != builds:
             self._arr = self._arrays()
-        self.ctx.compute_forces_overlapped(ts, self._arr, self.dom)
-        self.nve.step()
+        self._force_rows(ts)
+        self._integrate()
         s.timestep += 1
 
     # ------------------------------------------------------------------ graph replay
@@ -692,12 +703,11 @@ class BrickRun:
         """The distance check of a cycle, on the device: largest displacement^2 since the last rebuild, all-reduced, and the cycle
         counter, copied to pinned memory."""
         s, nl = self.sys, self.nl
-        self._stat[0:1].zero_()
+        torch.addcmul(self._stat_inc, self._stat, self._stat_inc, out=self._stat)   # [d2, cycle] <- [0, cycle + 1]: one launch
         check(lib.htfs_max_displacement2(s.pos.data_ptr(), nl._ref.data_ptr(), s.scalar_code, s.N, C.byref(s.box),
                                          self._stat.data_ptr(), C.c_void_p(raw_stream(s.device.index))))
         if self.dom.world > 1:
             self.dom._native.allreduce_max(self._stat[0:1])
-        self._stat[1:2].add_(1.0)
         self._stat_host.copy_(self._stat, non_blocking=True)
 
     def _cycle(self, rebuild):
@@ -708,8 +718,8 @@ class BrickRun:
         for i in range(P):
             if not (rebuild and i == 0):
                 self.dom.exchange_begin()
-            self.ctx.compute_forces_overlapped(s.timestep, self._arr, self.dom)
-            self.nve.step()
+            self._force_rows(s.timestep)
+            self._integrate()
             s.timestep += 1
 
     def _capture(self):
@@ -721,6 +731,7 @@ class BrickRun:
         dom.exchange_end()
         self._arr = self._arrays()
         self._stat = torch.zeros(2, dtype=torch.float32, device=s.device)
+        self._stat_inc = torch.tensor([0.0, 1.0], dtype=torch.float32, device=s.device)
         self._stat_host = torch.zeros(2, dtype=torch.float32).pin_memory()
         self._rule = DeferredRebuildRule(nl.r_buff / 2.0)
         torch.cuda.synchronize()

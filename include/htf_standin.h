@@ -135,6 +135,7 @@ typedef struct htfs_brick {
     int p[2];                                   /* bricks along it */
     int me[2];                                  /* this rank's brick coordinate */
     int n_msg;                                  /* 3^ndim - 1 */
+    int replica;                                /* this rank is its own neighbor in every direction (messages are shifted) */
     double r_ghost;
     unsigned cap_int, cap_bnd;
     unsigned ghost_cap[HTFS_BRICK_MAX_MSG];     /* rows of halo message m (sent AND received: capacities are symmetric) */
@@ -144,6 +145,9 @@ typedef struct htfs_brick {
     unsigned mig_off[HTFS_BRICK_MAX_MSG];       /* first row of message m in the migration send buffer / of the message from offset o
                                                  * in the receive buffer */
     double shift[HTFS_BRICK_MAX_MSG][3];        /* added to the positions message m carries (replica mode; zeros otherwise) */
+    double box_lo[3], box_L[3];                 /* the global (in replica mode: logical) periodic box: a shifted position is wrapped
+                                                 * back into it, as the integrator wraps (ghosts and migrants keep coordinates the
+                                                 * cell list can bin; the pair-vector build takes the minimum image anyway) */
 } htfs_brick;
 
 /* device words of d_counts */
@@ -156,7 +160,8 @@ enum {
     HTFS_BC_REBUILDS = 5,
     HTFS_BC_MSG = 8,        /* [8, 16): rows of halo message m */
     HTFS_BC_CLASS = 16,     /* [16, 16 + 18): first candidate of class c in class order (c = 0..16), then the total */
-    HTFS_BC_WORDS = 64
+    HTFS_BC_SLOT = 64,      /* [64, 64 + 16 * 8): first slot of class c in halo message m (word 64 + 8 c + m), 0xFFFFFFFF: not carried */
+    HTFS_BC_WORDS = 192
 };
 enum {
     HTFS_BF_LOST = 1,           /* a particle crossed more than one brick between rebuilds */
@@ -170,7 +175,7 @@ enum {
 typedef struct htfs_brick_work {
     unsigned *key;          /* [cand] */
     unsigned *order;        /* [cand] */
-    unsigned *sort_scratch; /* [32 * ceil(cand / 4096)] */
+    unsigned *sort_scratch; /* [32 * ceil(cand / 1024)] */
     unsigned *start1;       /* [17]  destination-key starts of the first sort */
     unsigned *start2;       /* [33]  class-key starts of the second */
     void *tmp_pos;          /* [cand] Scalar4 */
@@ -193,6 +198,10 @@ HTF_API int htfs_brick_migrate_merge(const htfs_brick *g, void *d_pos, void *d_v
  * region, message m at the rows its receiver -- this rank -- expects it (source offset -o). */
 HTF_API int htfs_brick_pack_halo(const htfs_brick *g, const void *d_pos, int dtype, const unsigned *d_counts, void *d_send,
                                  void *d_ghost_direct, htf_stream stream);
+/* htfs_nve_step over the local rows AND htfs_brick_pack_halo in one launch: every boundary row writes its new position into the
+ * messages that carry it (their inert tails stay as the last rebuild's pack left them).  Same bits as the two calls. */
+HTF_API int htfs_brick_nve_halo(const htfs_brick *g, void *d_pos, void *d_vel, const void *d_force, int dtype, double dt,
+                                const htf_box *box, const unsigned *d_counts, void *d_send, void *d_ghost_direct, htf_stream stream);
 
 #ifdef __cplusplus
 }
