@@ -50,7 +50,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="lj", choices=["lj", "wca", "mlp", "mlp-fp32", "mlp-split", "mlp-bf16", "mlp-train", "eds", "ref-lj256", "c1", "ex01", "generic-lj", "dd-self"])
-    ap.add_argument("--grid", default="8x1x1", help="dd-self: the rank grid whose one brick this GPU runs (8x1x1 slabs, 4x2x1 bricks)")
+    ap.add_argument("--grid", default=None, help="rank grid PXxPYx1: --gpus N > 1: how the box is cut (default: slabs along x; 8 ranks of the "
+                                                 "strong-scaling box: 4x2x1); dd-self: the grid whose one brick this GPU runs (default 8x1x1)")
     ap.add_argument("--transport", default="all", help="dd-self: local | native | all")
     ap.add_argument("--train-period", type=int, default=100, help="mlp-train (C5b): force-matching step every this many MD steps")
     ap.add_argument("--cells", type=int, default=32, help="fcc cells per side (N = 4 cells^3 per rank)")
@@ -85,6 +86,44 @@ def parse():
                          "and model arithmetic (the reference casts the fp64 buffer to the model dtype, simmodel.py:226-238)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
+
+
+def gpu_state(index=0):
+    """Clocks and power cap of the GPU as sysfs shows them right now (a 10 % spread of an MFMA-bound kernel
+    between boxes should be explained by a number).  Best effort: every field is optional."""
+    import glob
+    out = {}
+    cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"))
+    if not cards:
+        return None
+    dev = os.path.dirname(cards[min(index, len(cards) - 1)])
+
+    def read(path):
+        try:
+            with open(path) as f:
+                return f.read().strip()
+        except OSError:
+            return None
+
+    for name in ("pp_dpm_sclk", "pp_dpm_mclk", "pp_dpm_fclk"):
+        txt = read(os.path.join(dev, name))
+        if txt:
+            levels = [l.strip() for l in txt.splitlines()]
+            cur = [l for l in levels if l.endswith("*")]
+            out[name[7:] + "_now"] = cur[0].rstrip(" *").split(":")[-1].strip() if cur else None
+            out[name[7:] + "_max"] = levels[-1].rstrip(" *").split(":")[-1].strip()
+    for hw in glob.glob(os.path.join(dev, "hwmon", "hwmon*")):
+        for key, fname, scale in (("power_cap_W", "power1_cap", 1e-6), ("power_cap_max_W", "power1_cap_max", 1e-6),
+                                  ("power_now_W", "power1_average", 1e-6), ("power_now_W", "power1_input", 1e-6),
+                                  ("temp_edge_C", "temp1_input", 1e-3), ("sclk_hwmon_MHz", "freq1_input", 1e-6)):
+            txt = read(os.path.join(hw, fname))
+            if txt and key not in out:
+                try:
+                    out[key] = round(float(txt) * scale, 1)
+                except ValueError:
+                    pass
+    out["perf_level"] = read(os.path.join(dev, "power_dpm_force_performance_level"))
+    return out or None
 
 
 def make_potential(htf, workload):
@@ -272,6 +311,7 @@ def run_dd_self(args, htf, standin, dev):
     and replayed from two hipGraphs per check period (standin.BrickRun).  What crosses xGMI between real ranks is NOT measured."""
     from hoomd_tf_amd import _lib
     from hoomd_tf_amd.brick import BrickDomain
+    args.grid = args.grid or "8x1x1"
     grid = tuple(int(v) for v in args.grid.lower().split("x"))
     grid = grid + (1,) * (3 - len(grid))
     cells = np.array([args.cells // grid[0], args.cells // grid[1], args.cells // grid[2]])
@@ -383,6 +423,33 @@ def run_generic_lj(args, htf, standin, dev):
             energy = torch.sum(p_energy, dim=1)
             return htf.compute_nlist_forces(nlist, energy)
 
+    class MorseModel(htf.SimModel):
+        """Outside the zoo, written with htf.* ops: a Morse well (D = 1, a = 5, r0 = 1.122) masked to the list's live slots.
+        Traced into a generated kernel (HTF_POT_JIT, hoomd_tf_amd/codegen.py), replayed as the one-kernel step."""
+        def compute(self, nlist, positions, box):
+            r = htf.safe_norm(nlist[:, :, :3], axis=2)
+            live = htf.cast(htf.nlist_rinv(nlist) > 0.0, torch.float32)
+            x = 1.0 - htf.exp(-5.0 * (r - 1.122))
+            energy = htf.reduce_sum(0.5 * live * (x * x - 1.0), axis=1)
+            return htf.compute_nlist_forces(nlist, energy)
+
+    class YukawaLJModel(htf.SimModel):
+        """Outside the zoo: LJ plus a screened Coulomb term 0.5 exp(-r) / r (traced; generated kernel)."""
+        def compute(self, nlist, positions, box):
+            r = htf.safe_norm(nlist[:, :, :3], axis=2)
+            s = htf.nlist_rinv(nlist)
+            energy = htf.reduce_sum(2.0 * (s ** 12 - s ** 6) + 0.25 * htf.exp(-1.0 * r) * s, axis=1)
+            return htf.compute_nlist_forces(nlist, energy)
+
+    class TorchYukawaLJModel(htf.SimModel):
+        def compute(self, nlist, positions, box):
+            delta = 3e-6
+            t = nlist[:, :, :3] + 1e-7
+            r = torch.sqrt(torch.sum(t * t, dim=2))
+            s = torch.where(r > delta, 1.0 / (r + delta), torch.zeros_like(r))
+            energy = torch.sum(2.0 * (s ** 12 - s ** 6) + 0.25 * torch.exp(-1.0 * r) * s, dim=1)
+            return htf.compute_nlist_forces(nlist, energy)
+
     def one(lattice, cells, model_cls, steps):
         pos, L, a = (standin.sc_positions if lattice == "sc" else standin.fcc_positions)(cells, 0.8442)
         rng = np.random.default_rng(7)
@@ -404,6 +471,7 @@ def run_generic_lj(args, htf, standin, dev):
         assert bool(torch.isfinite(f).all())
         return {"steps_per_s": steps / el, "ms_per_step": el / steps * 1e3, "particles": sysm.N, "steps": steps,
                 "replayed_without_python": tfc._plan is not None,
+                "potential_kind": getattr(tfc._plan, "kind", None),
                 "energy_per_particle": float(f[:, 3].double().sum().item()) / sysm.N}
 
     sizes = {}
@@ -411,7 +479,16 @@ def run_generic_lj(args, htf, standin, dev):
         fast = one(lattice, cells, LJModel, args.steps)
         gen = one(lattice, cells, TorchLJModel, max(20, args.steps // 10))
         assert abs(fast["energy_per_particle"] - gen["energy_per_particle"]) < 0.05 * abs(fast["energy_per_particle"]) + 0.05
-        sizes[tag] = {"lowered": fast, "generic": gen, "generic_over_lowered_time": gen["ms_per_step"] / fast["ms_per_step"]}
+        # round 5: models OUTSIDE the zoo written with htf.* ops are traced into generated kernels (HTF_POT_JIT)
+        yuk = one(lattice, cells, YukawaLJModel, args.steps)
+        yuk_torch = one(lattice, cells, TorchYukawaLJModel, max(20, args.steps // 10))
+        morse = one(lattice, cells, MorseModel, args.steps)
+        assert yuk["potential_kind"] == 9 and morse["potential_kind"] == 9
+        assert abs(yuk["energy_per_particle"] - yuk_torch["energy_per_particle"]) < 0.02 * abs(yuk_torch["energy_per_particle"]) + 0.02
+        sizes[tag] = {"lowered": fast, "generic": gen, "generic_over_lowered_time": gen["ms_per_step"] / fast["ms_per_step"],
+                      "traced_yukawa_lj": yuk, "traced_morse": morse, "torch_yukawa_lj": yuk_torch,
+                      "traced_over_lowered_lj_time": yuk["ms_per_step"] / fast["ms_per_step"],
+                      "torch_over_traced_time": yuk_torch["ms_per_step"] / yuk["ms_per_step"]}
     c3 = sizes["C3 (fcc 32^3 x 4 = 131072)"]
     out = {
         "metric": "MD steps/sec, LJModel written in plain torch ops (generic autograd route) at 131072 particles NN=%d" % NN,
@@ -421,6 +498,8 @@ def run_generic_lj(args, htf, standin, dev):
         "config": {"workload": "LJModel through tfcompute, htf.* expression layer (lowered) vs plain torch ops + torch.autograd (generic), "
                                "jittered lattices at rho 0.8442, r_cut %.1f, r_buff %.1f, NN %d, dt %g" % (rcut, args.rbuff, NN, args.dt)},
         "sizes": sizes,
+        "traced_models": "written with htf.* ops outside the zoo (LJ + Yukawa; a masked Morse well): traced, lowered to generated kernels "
+                         "(HTF_POT_JIT: hoomd_tf_amd/codegen.py -> hipcc --genco around csrc/jit_unit.hip), replayed as the one-kernel step",
         "note": "the generic route keeps the reference's arbitrary-model capability (htf/simmodel.py:87-121, 526-555); models made of "
                 "nlist_rinv polynomials, WCARepulsion, RBFExpansion + Dense stacks, EDS biases and compute_rdf are lowered to fused kernels",
         "roofline": None, "cpu_baseline": None,
@@ -905,7 +984,7 @@ def main():
         a2 = copy.copy(args)
         a2.steps, a2.warmup, a2.equil, a2.windows = min(args.steps, 40), min(args.warmup, 5), min(args.equil, 100), 1
         sub = run_md(a2, E, "mlp", variants=not args.no_fused, cpu=not args.no_cpu_baseline)
-        out["mlp"] = {k: sub[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "kernels",
+        out["mlp"] = {k: sub[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "kernels", "gpu_state",
                                          "roofline", "fp32_variant", "split_variant", "cpu_baseline", "energy_per_particle") if k in sub}
     if rank == 0:
         print(json.dumps(out))
@@ -929,6 +1008,16 @@ def run_md(args, E, workload, variants=True, cpu=True):
     # and keeps the particles of its slab.  weak: each rank owns one such block; the global periodic box
     # is `world` blocks side by side along x (config 5 at 8 ranks: 1.05 M particles, 8 x 1 x 1 slabs).
     strong = world > 1 and args.scaling == "strong"
+    # the rank grid: slabs along x, except 8 ranks of the strong-scaling box -- 8 slabs of the 131 072-particle box are 6.72 thick
+    # (< 2 r_ghost: no row without a ghost neighbor), a 4 x 2 cut keeps 37 % of the rows interior; --grid overrides
+    if world > 1 and args.grid:
+        grid = tuple(int(v) for v in args.grid.lower().split("x"))
+        grid = grid + (1,) * (3 - len(grid))
+    else:
+        grid = (4, 2, 1) if (world == 8 and strong) else (world, 1, 1)
+    if int(np.prod(grid)) != world or (not strong and grid != (world, 1, 1)):
+        raise SystemExit("--grid %s does not describe %d ranks (weak scaling: slabs along x)" % (args.grid, world))
+    domain_kind = os.environ.get("HTF_BENCH_DOMAIN", "brick")   # "slab": round 4's variable-length SlabDomain
     pos, L, a = (standin.sc_positions if args.lattice == "sc" else standin.fcc_positions)(args.cells, 0.8442)
     rng = np.random.default_rng(3 + (0 if strong else rank))
     pos = pos + 0.05 * a * rng.standard_normal(pos.shape)
@@ -940,8 +1029,11 @@ def run_md(args, E, workload, variants=True, cpu=True):
         g = torch.Generator(device="cpu").manual_seed(3)
         vel0 = torch.randn((n_block, 3), generator=g, dtype=torch.float64)
         vel0 -= vel0.mean(dim=0, keepdim=True)
-        bounds = -L[0] / 2 + np.linspace(0.0, 1.0, world + 1) * L[0]
-        mine = (pos[:, 0] >= bounds[rank]) & ((pos[:, 0] < bounds[rank + 1]) | (rank == world - 1))
+        mine = np.ones(n_block, dtype=bool)
+        for d in range(3):   # this rank's brick of the grid (slabs: grid = (world, 1, 1))
+            b = -L[d] / 2 + np.linspace(0.0, 1.0, grid[d] + 1) * L[d]
+            c = (rank // int(np.prod(grid[:d]))) % grid[d]
+            mine &= (pos[:, d] >= b[c]) & ((pos[:, d] < b[c + 1]) | (c == grid[d] - 1))
         pos, vel0 = pos[mine], vel0[torch.from_numpy(mine)]
         n_global = n_block
     else:
@@ -962,22 +1054,34 @@ def run_md(args, E, workload, variants=True, cpu=True):
                            # one rank: the rebuild is gated on the device; several ranks: the all-reduced distance check is
                            # read one check late (standin.DeferredRebuildRule) -- no read-back in the step loop either way
                            device_decision=(not args.sort and not args.host_nlist_decision))
-    if world > 1:
+    brick = world > 1 and domain_kind == "brick"
+    if brick:
+        # fixed-capacity arrays with inert rows: no read-back in a rebuild, addresses never change (hoomd_tf_amd/brick.py).
+        # The native RCCL transport (csrc/halo.hip) has never run between two real devices: opt-in until it has
+        from hoomd_tf_amd.brick import BrickDomain
+        tr = os.environ.get("HTF_HALO_TRANSPORT", "torch")
+        nl.domain = BrickDomain(sysm, rank, grid, r_ghost=args.rcut + args.rbuff, r_buff=args.rbuff, n_global=n_global,
+                                transport=tr if tr in ("torch", "native") else "torch")
+    elif world > 1:
         from hoomd_tf_amd.domain import SlabDomain
-        # the native RCCL halo (csrc/halo.hip) has never run between two real devices: opt-in until it has
+        if grid != (world, 1, 1):
+            raise SystemExit("SlabDomain cuts along x only")
         nl.domain = SlabDomain(sysm, rank, world, r_ghost=args.rcut + args.rbuff,
                                transport=os.environ.get("HTF_HALO_TRANSPORT", "torch"))
     nl.build()
-    N, NN = sysm.N, args.nn
+    # rows of the arrays (a capacity under BrickDomain) and particles on this rank
+    N_rows, NN = sysm.N, args.nn
+    N = nl.domain.n_local if brick else sysm.N
 
     # closed-form potentials: ONE kernel builds the pair-vector tensor and evaluates it while it is in
     # registers (htf_config.fused = 2, the tfcompute default); the pair-MLP has its own MFMA evaluator
     closed_form = args.workload in ("lj", "wca", "mlp-train")
     one_kernel = closed_form and not args.two_kernel
-    ctx = htf.Context(r_cut=args.rcut, nneighs=NN, scalar_dtype=sdt, max_n=N, fused=2 if one_kernel else 0)
+    ctx = htf.Context(r_cut=args.rcut, nneighs=NN, scalar_dtype=sdt, max_n=N_rows, fused=2 if one_kernel else 0)
     pot = make_potential(htf, args.workload)
     ctx.set_potential(pot)
     nve = standin.NVE(sysm, args.dt)
+    brun = standin.BrickRun(sysm, nl, ctx, nve) if brick else None
 
     def arrays():
         # N changes when particles migrate between ranks at a rebuild
@@ -1005,7 +1109,7 @@ def run_md(args, E, workload, variants=True, cpu=True):
         cap = int(sysm.N * 1.1) + 1024
         stage_x = torch.empty((cap, NN, 4), dtype=torch.float32, device=dev)
         stage_y = torch.empty((cap, 4), dtype=torch.float32, device=dev)
-        n_global = float(sysm.N)
+        n_global = float(N)
         if dist is not None:
             t = torch.tensor([n_global], dtype=torch.float64, device=dev)
             dist.all_reduce(t)
@@ -1047,10 +1151,17 @@ def run_md(args, E, workload, variants=True, cpu=True):
         if nl.n_builds != state["builds"]:
             state["arr"] = arrays()
             state["builds"] = nl.n_builds
-        ctx.compute_forces_overlapped(ts, state["arr"], nl.domain)
+        if brun is not None:
+            brun._arr = state["arr"]
+            brun._force_rows(ts)       # one launch where nothing is in flight to hide, else interior | halo | boundary
+        else:
+            ctx.compute_forces_overlapped(ts, state["arr"], nl.domain)
         if train is not None and ts % args.train_period == 0:
             train(timed)
-        nve.step()
+        if brun is not None:
+            brun._integrate()          # integrator + the next step's halo messages in one launch
+        else:
+            nve.step()
         state["ts"] = ts + 1
 
     # overflow guard: NN must hold every neighbor within r_cut (check_nlist semantics)
@@ -1074,7 +1185,7 @@ def run_md(args, E, workload, variants=True, cpu=True):
         f3.mul_(torch.clamp(200.0 / fm, max=1.0))
         nve.step()
         v3 = sysm.vel[:, :3]
-        v3.mul_(torch.sqrt(1.0 / ((v3 * v3).sum() / (3.0 * sysm.N))))
+        v3.mul_(torch.sqrt(1.0 / ((v3 * v3).sum() / (3.0 * N))))
         state["ts"] = ts + 1
 
     def builds_now():
@@ -1118,6 +1229,7 @@ def run_md(args, E, workload, variants=True, cpu=True):
     for _ in range(n_windows):
         windows.append(timed_window())
         window_prof.append(ctx.profile_read())  # (build ms, eval ms, bracketed calls) of this window; resets
+    gpu_now = gpu_state(dev.index or 0)   # clocks / power cap right behind the timed windows
     # the kernel durations are those of the window `value` is taken from (the median one)
     elapsed = float(np.median(windows))
     build_ms, eval_ms, ncalls = window_prof[int(np.argsort(windows)[len(windows) // 2])]
@@ -1168,8 +1280,9 @@ def run_md(args, E, workload, variants=True, cpu=True):
     # sanity: the run must still be a valid simulation
     f = sysm.force
     assert bool(torch.isfinite(f).all()), "non-finite forces"
-    e_per_particle = float(f[:, 3].double().sum().item()) / sysm.N
-    kT_final = float((sysm.vel[:, :3].double() ** 2).sum().item()) / (3.0 * sysm.N)
+    n_now = nl.domain.n_local if brick else sysm.N     # (inert rows carry zero force and zero velocity)
+    e_per_particle = float(f[:, 3].double().sum().item()) / n_now
+    kT_final = float((sysm.vel[:, :3].double() ** 2).sum().item()) / (3.0 * n_now)
 
     n_entries = int(nl.n_neigh.long().sum().item())
     eval_b, build_b, integ_b = algorithmic_bytes(N, NN, n_entries, N + sysm.n_ghost, s4)
@@ -1315,20 +1428,25 @@ def run_md(args, E, workload, variants=True, cpu=True):
                                   args.rcut, args.rbuff, NN, args.dt),
                    "preparation": "untimed: %d relaxation steps (force cap + velocity rescale to kT = 1), %d plain NVE steps, then the %d warmup steps"
                                   % (args.equil, args.settle, args.warmup),
-                   "global_particles": n_global, "particles_rank0": N, "parallelism": "dd%dx1x1" % world,
+                   "global_particles": n_global, "particles_rank0": N, "parallelism": "dd%dx%dx%d" % grid if world > 1 else "dd1x1x1",
                    "nlist_rebuilds_per_window": rebuilds, "max_neighbors_within_rcut": max_kept,
                    "nlist_decision": ("device: distance check all-reduced on the device, read one check late (DeferredRebuildRule), "
                                       "dangerous builds: %d" % nl.dangerous_builds) if nl.device_decision and world > 1 and not args.sort
                                      else "device (gated rebuild kernels, no read-back in the step loop)" if nl.device_decision and world == 1 and not args.sort
                                      else "host (distance check read back every %d steps%s)" % (args.check_period, ", all-reduced over ranks" if world > 1 else ""),
-                   "halo": None if world == 1 else {"ghosts_rank0": sysm.n_ghost, "migrated_rank0": nl.domain.n_migrated,
+                   "halo": None if world == 1 else {"ghosts_rank0": nl.domain.n_ghosts if brick else sysm.n_ghost,
+                                                    "migrated_rank0": nl.domain.n_migrated,
                                                     "interior_rows_rank0": nl.domain.n_interior,
+                                                    "domain": ("BrickDomain: fixed-capacity arrays (%d rows + %d ghost rows on rank 0), inert "
+                                                               "rows, no read-back in a rebuild" % (sysm.N, sysm.n_ghost)) if brick
+                                                              else "SlabDomain (variable-length arrays, host-planned rebuild)",
                                                     "transport": ("RCCL: the library's own communicator and halo stream (csrc/halo.hip)" if nl.domain.transport == "native"
                                                                   else (E.backend if E.backend != "nccl" else "RCCL (torch.distributed nccl backend)")),
                                                     "transport_note": getattr(nl.domain, "transport_note", None),
                                                     "exchange": "forward ghost positions, grouped send/recv, every step",
                                                     "step_phases_rank0": phases}},
         # sum over ranks of the algorithmic bytes a step moves (rank 0's count x ranks) / step time
+        "gpu_state": gpu_now,
         "hbm_GBps_full_step": world * step_bytes / (elapsed / args.steps) / 1e9,
         "hbm_frac_full_step": step_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
         "energy_per_particle": e_per_particle, "kT_final": kT_final,

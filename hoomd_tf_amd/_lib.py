@@ -21,7 +21,7 @@ LIB_PATH = os.environ.get("HTF_AMD_LIB") or os.path.join(_HERE, "libhtf_amd.so")
 HTF_OK, HTF_ERR_INVALID, HTF_ERR_DEVICE, HTF_ERR_NLIST_OVERFLOW, HTF_ERR_SKEWED_BOX, HTF_ERR_NOMEM = range(6)
 HTF_F32, HTF_F64 = 0, 1
 HTF_TF2HOOMD, HTF_HOOMD2TF = 0, 1
-POT_NONE, POT_LJ, POT_WCA, POT_RINV_POLY, POT_SIMPLE, POT_PAIR_MLP, POT_GAUSS, POT_LJ_PARAM, POT_TOPK_MLP = range(9)
+POT_NONE, POT_LJ, POT_WCA, POT_RINV_POLY, POT_SIMPLE, POT_PAIR_MLP, POT_GAUSS, POT_LJ_PARAM, POT_TOPK_MLP, POT_JIT = range(10)
 OPT_SGD, OPT_ADAM, OPT_NADAM = range(3)
 OPT_STATE_FLOATS = 24
 ACT_LINEAR, ACT_TANH = 0, 1
@@ -71,7 +71,8 @@ class PotentialDesc(C.Structure):
                 ("K", C.c_int), ("H1", C.c_int), ("H2", C.c_int), ("activation", C.c_int),
                 ("mlp_precision", C.c_int), ("rbf_low", C.c_double), ("rbf_high", C.c_double),
                 ("W1", C.c_void_p), ("b1", C.c_void_p), ("W2", C.c_void_p), ("b2", C.c_void_p),
-                ("W3", C.c_void_p), ("b3", C.c_void_p), ("poly_cut", C.c_double)]
+                ("W3", C.c_void_p), ("b3", C.c_void_p), ("poly_cut", C.c_double),
+                ("jit_image", C.c_void_p), ("jit_image_bytes", C.c_size_t)]
 
 
 class OptimizerDesc(C.Structure):

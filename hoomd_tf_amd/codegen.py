@@ -1,0 +1,355 @@
+"""Generated kernels for TRACED pair energies: the fast path for a model outside the lowered zoo.
+
+The reference's defining capability is an arbitrary ``compute()`` (htf/simmodel.py:87-121): any TF graph of the neighbor tensor is
+legal, and every notebook writes its own energy.  Until round 5 anything that was not LJ / WCA / a rinv polynomial / a Gaussian / an
+MLP ran as ~20 eager torch ops + autograd per step (17-23 x slower than a lowered model at C2 / C3).  Here an ELEMENTWISE pair
+energy -- any expression of ``s = nlist_rinv(nlist)`` and ``r = safe_norm(nlist[:, :, :3], axis=2)`` built from + - * /, integer
+and real powers, exp, log, tanh, sqrt, abs, minimum / maximum, comparisons, ``where`` and cast masks -- is kept symbolic
+(:class:`Node`), differentiated in forward mode with respect to r, emitted as the body of pair_math.h's
+``pair_eval_f<HTF_POT_JIT>`` and compiled for gfx950 with ``hipcc --genco`` around the library's own row loops
+(csrc/jit_unit.hip): the one-kernel step, its virial form, the streaming evaluator -- same launch geometry, same reductions as
+the built-in closed forms.  The code object is cached by the hash of everything that went into it.  No second backend, no
+Triton: the generated text is twenty lines of C in the middle of the hand-written kernels.
+
+Semantics are TensorFlow's for the same expression: ``s`` is exactly 0 on padded and masked slots with d s / d r = -s^2
+elsewhere (simmodel.py:618-635), ``r`` is |x + 1e-7| with gradient t / r (simmodel.py:581-594), comparisons and cast masks carry
+no gradient, nlist_forces = 2 dE/dx (simmodel.py:548).  One restriction: the energy and its derivative must VANISH on a padded
+slot (s = 0, r = sqrt(3) 1e-7) -- the kernels skip the zero padding behind a row's live slots -- which every physical pair
+energy written on ``nlist_rinv`` does; an expression that does not (an unmasked Morse on ``safe_norm`` alone) keeps the torch route.
+"""
+import hashlib
+import math
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+ARCH = "gfx950"
+PAD_R = math.sqrt(3.0) * 1e-7
+
+
+class Node:
+    """One node of an elementwise expression over the pair slot's (s, r, rn): op + children (+ a constant)."""
+    __slots__ = ("op", "args", "value")
+
+    def __init__(self, op, args=(), value=None):
+        self.op, self.args, self.value = op, tuple(args), value
+
+    def key(self):
+        return (self.op, self.value) + tuple(a.key() for a in self.args)
+
+
+def const(v):
+    return Node("const", value=float(v))
+
+
+def wrap(x):
+    if isinstance(x, Node):
+        return x
+    if isinstance(x, (int, float, np.floating, np.integer)):
+        return const(x)
+    if isinstance(x, torch.Tensor) and x.numel() == 1:
+        return const(float(x))
+    raise TypeError("cannot use %r in a traced pair energy (scalars and expressions of nlist_rinv / safe_norm only)" % (type(x),))
+
+
+S, R, RN = Node("s"), Node("r"), Node("rn")   # nlist_rinv, safe_norm, the plain norm (masks only: no gradient)
+UNARY = ("neg", "exp", "log", "tanh", "sqrt", "abs", "square", "mask")
+BINARY = ("add", "sub", "mul", "div", "min", "max")
+COMPARE = ("lt", "le", "gt", "ge")
+
+
+# --------------------------------------------------------------------------- evaluation in torch (the reference, and eager values)
+def evaluate(node, s, r, rn, memo=None):
+    """The expression on torch tensors (any dtype): what the generated kernel computes per slot."""
+    memo = {} if memo is None else memo
+    k = id(node)
+    if k in memo:
+        return memo[k]
+    op = node.op
+    a = [evaluate(x, s, r, rn, memo) for x in node.args]
+    if op == "s":
+        out = s
+    elif op == "r":
+        out = r
+    elif op == "rn":
+        out = rn
+    elif op == "const":
+        out = torch.as_tensor(node.value, dtype=s.dtype, device=s.device)
+    elif op == "neg":
+        out = -a[0]
+    elif op == "exp":
+        out = torch.exp(a[0])
+    elif op == "log":
+        out = torch.log(a[0])
+    elif op == "tanh":
+        out = torch.tanh(a[0])
+    elif op == "sqrt":
+        out = torch.sqrt(a[0])
+    elif op == "abs":
+        out = torch.abs(a[0])
+    elif op == "square":
+        out = a[0] * a[0]
+    elif op == "mask":
+        out = a[0].to(s.dtype)
+    elif op == "add":
+        out = a[0] + a[1]
+    elif op == "sub":
+        out = a[0] - a[1]
+    elif op == "mul":
+        out = a[0] * a[1]
+    elif op == "div":
+        out = a[0] / a[1]
+    elif op == "min":
+        out = torch.minimum(a[0], a[1])
+    elif op == "max":
+        out = torch.maximum(a[0], a[1])
+    elif op == "pow":
+        out = a[0] ** node.value
+    elif op in COMPARE:
+        out = {"lt": torch.lt, "le": torch.le, "gt": torch.gt, "ge": torch.ge}[op](a[0], a[1])
+    elif op == "where":
+        out = torch.where(a[0], a[1], a[2])
+    else:
+        raise ValueError("unknown op %r" % op)
+    memo[k] = out
+    return out
+
+
+# --------------------------------------------------------------------------- forward-mode code generation
+class _Emitter:
+    def __init__(self):
+        self.lines, self.memo, self.n = [], {}, 0
+
+    def tmp(self, expr):
+        name = "t%d" % self.n
+        self.n += 1
+        self.lines.append("const float %s = %s;" % (name, expr))
+        return name
+
+    @staticmethod
+    def lit(v):
+        if v != v or v in (float("inf"), float("-inf")):
+            raise ValueError("non-finite constant in a traced pair energy")
+        return repr(float(np.float32(v))) + "f"   # ('2.0f', '1e-07f': repr of a float always carries a '.' or an exponent)
+
+    def emit(self, node):
+        """-> (value, derivative with respect to r): C expressions naming temporaries; derivative None = identically zero."""
+        k = id(node)
+        if k in self.memo:
+            return self.memo[k]
+        op = node.op
+        if op == "s":
+            out = ("s", "ds")
+        elif op == "r":
+            out = ("r", "1.0f")
+        elif op == "rn":
+            out = (self.tmp("__builtin_amdgcn_sqrtf(x * x + y * y + z * z)"), None)
+        elif op == "const":
+            out = (self.lit(node.value), None)
+        elif op in COMPARE:
+            a, b = self.emit(node.args[0])[0], self.emit(node.args[1])[0]
+            c = {"lt": "<", "le": "<=", "gt": ">", "ge": ">="}[op]
+            name = "c%d" % self.n
+            self.n += 1
+            self.lines.append("const bool %s = %s %s %s;" % (name, a, c, b))
+            out = (name, None)
+        elif op == "mask":
+            out = (self.tmp("%s ? 1.0f : 0.0f" % self.emit(node.args[0])[0]), None)
+        elif op == "where":
+            c = self.emit(node.args[0])[0]
+            (a, da), (b, db) = self.emit(node.args[1]), self.emit(node.args[2])
+            v = self.tmp("%s ? %s : %s" % (c, a, b))
+            d = None if da is None and db is None else self.tmp("%s ? %s : %s" % (c, da or "0.0f", db or "0.0f"))
+            out = (v, d)
+        elif op in ("add", "sub"):
+            (a, da), (b, db) = self.emit(node.args[0]), self.emit(node.args[1])
+            sg = "+" if op == "add" else "-"
+            v = self.tmp("%s %s %s" % (a, sg, b))
+            if da is None and db is None:
+                d = None
+            elif db is None:
+                d = da
+            elif da is None:
+                d = db if op == "add" else self.tmp("-%s" % db)
+            else:
+                d = self.tmp("%s %s %s" % (da, sg, db))
+            out = (v, d)
+        elif op == "mul":
+            (a, da), (b, db) = self.emit(node.args[0]), self.emit(node.args[1])
+            v = self.tmp("%s * %s" % (a, b))
+            terms = [("%s * %s" % (da, b)) if da is not None else None, ("%s * %s" % (a, db)) if db is not None else None]
+            terms = [t for t in terms if t]
+            out = (v, self.tmp(" + ".join(terms)) if terms else None)
+        elif op == "div":
+            (a, da), (b, db) = self.emit(node.args[0]), self.emit(node.args[1])
+            ib = self.tmp("__builtin_amdgcn_rcpf(%s)" % b)
+            v = self.tmp("%s * %s" % (a, ib))
+            if da is None and db is None:
+                d = None
+            elif db is None:
+                d = self.tmp("%s * %s" % (da, ib))
+            elif da is None:
+                d = self.tmp("-(%s * %s) * %s" % (v, ib, db))
+            else:
+                d = self.tmp("(%s - %s * %s) * %s" % (da, v, db, ib))
+            out = (v, d)
+        elif op == "neg":
+            a, da = self.emit(node.args[0])
+            out = (self.tmp("-%s" % a), None if da is None else self.tmp("-%s" % da))
+        elif op == "square":
+            a, da = self.emit(node.args[0])
+            out = (self.tmp("%s * %s" % (a, a)), None if da is None else self.tmp("2.0f * %s * %s" % (a, da)))
+        elif op == "exp":
+            a, da = self.emit(node.args[0])
+            v = self.tmp("__builtin_amdgcn_exp2f(%s * 1.4426950408889634f)" % a)
+            out = (v, None if da is None else self.tmp("%s * %s" % (v, da)))
+        elif op == "log":
+            a, da = self.emit(node.args[0])
+            v = self.tmp("__builtin_amdgcn_logf(%s) * 0.6931471805599453f" % a)
+            out = (v, None if da is None else self.tmp("%s * __builtin_amdgcn_rcpf(%s)" % (da, a)))
+        elif op == "tanh":
+            a, da = self.emit(node.args[0])
+            # tanh(a) = 1 - 2 / (exp(2a) + 1): one v_exp and one v_rcp; saturates cleanly (exp -> inf gives 1, -> 0 gives -1)
+            ex = self.tmp("__builtin_amdgcn_exp2f(%s * 2.8853900817779268f)" % a)
+            v = self.tmp("1.0f - 2.0f * __builtin_amdgcn_rcpf(%s + 1.0f)" % ex)
+            out = (v, None if da is None else self.tmp("(1.0f - %s * %s) * %s" % (v, v, da)))
+        elif op == "sqrt":
+            a, da = self.emit(node.args[0])
+            v = self.tmp("__builtin_amdgcn_sqrtf(%s)" % a)
+            out = (v, None if da is None else self.tmp("0.5f * %s * __builtin_amdgcn_rcpf(%s)" % (da, v)))
+        elif op == "abs":
+            a, da = self.emit(node.args[0])
+            out = (self.tmp("fabsf(%s)" % a), None if da is None else self.tmp("%s < 0.0f ? -%s : (%s > 0.0f ? %s : 0.0f)" % (a, da, a, da)))
+        elif op in ("min", "max"):
+            (a, da), (b, db) = self.emit(node.args[0]), self.emit(node.args[1])
+            cmpop = "<=" if op == "min" else ">="
+            v = self.tmp("%s %s %s ? %s : %s" % (a, cmpop, b, a, b))
+            d = None if da is None and db is None else self.tmp("%s %s %s ? %s : %s" % (a, cmpop, b, da or "0.0f", db or "0.0f"))
+            out = (v, d)
+        elif op == "pow":
+            a, da = self.emit(node.args[0])
+            p = node.value
+            if float(p).is_integer() and 0 <= abs(p) <= 64:
+                n = int(abs(p))
+                if n == 0:
+                    out = ("1.0f", None)
+                    self.memo[k] = out
+                    return out
+                # a^n and a^(n-1) by repeated squaring
+                def ipow(base, e):
+                    acc, cur = None, base
+                    while e:
+                        if e & 1:
+                            acc = cur if acc is None else self.tmp("%s * %s" % (acc, cur))
+                        e >>= 1
+                        if e:
+                            cur = self.tmp("%s * %s" % (cur, cur))
+                    return acc or "1.0f"
+                pm1 = ipow(a, n - 1) if n > 1 else "1.0f"
+                pn = self.tmp("%s * %s" % (pm1, a)) if n > 1 else a
+                if p > 0:
+                    out = (pn, None if da is None else self.tmp("%s * %s * %s" % (self.lit(float(n)), pm1, da)))
+                else:
+                    inv = self.tmp("__builtin_amdgcn_rcpf(%s)" % pn)
+                    out = (inv, None if da is None else self.tmp("-%s * %s * __builtin_amdgcn_rcpf(%s) * %s" % (self.lit(float(n)), inv, a, da)))
+            else:
+                lg = self.tmp("__builtin_amdgcn_logf(%s)" % a)
+                v = self.tmp("__builtin_amdgcn_exp2f(%s * %s)" % (self.lit(p), lg))
+                # d a^p = p a^(p-1): its own exp2 (p v / a would be 0 * inf at a = 0, where TensorFlow's pow gradient is an exact 0 for p > 1)
+                out = (v, None if da is None else self.tmp("%s * __builtin_amdgcn_exp2f(%s * %s) * %s" % (self.lit(p), self.lit(p - 1.0), lg, da)))
+        else:
+            raise ValueError("unknown op %r" % op)
+        self.memo[k] = out
+        return out
+
+
+def generate_body(node):
+    """The statements pair_math.h splices into pair_eval_f<HTF_POT_JIT>: assign ``e`` and ``dedr`` from s, ds, r, x, y, z."""
+    em = _Emitter()
+    v, d = em.emit(node)
+    em.lines.append("e = %s;" % v)
+    em.lines.append("dedr = %s;" % (d or "0.0f"))
+    return "\n".join(em.lines)
+
+
+def vanishes_on_padding(node):
+    """Energy and derivative of a padded slot (s = 0, ds = 0, r = sqrt(3) 1e-7, plain norm 0), in fp64: must be exact zeros."""
+    r = torch.tensor(PAD_R, dtype=torch.float64, requires_grad=True)
+    s = r * 0.0          # (s = 0 with d s / d r = 0, but ON the graph: sqrt(s) has derivative 0 * inf = NaN there, in TF too)
+    rn = torch.zeros((), dtype=torch.float64)
+    try:
+        e = evaluate(node, s, r, rn)
+        if not isinstance(e, torch.Tensor) or not bool(torch.isfinite(e)) or float(e.detach()) != 0.0:
+            return False
+        if e.requires_grad:
+            (g,) = torch.autograd.grad(e, r, allow_unused=True)
+            if g is not None and not float(g) == 0.0:
+                return False
+        return True
+    except Exception:  # noqa: BLE001
+        return False
+
+
+# --------------------------------------------------------------------------- compile + cache
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hoomd_tf_amd.codegen: hipcc not found (set HIPCC); generated kernels need the ROCm compiler at run time")
+
+
+def _cache_dir():
+    d = os.environ.get("HTF_JIT_CACHE") or os.path.join(_HERE, "_jit_cache")
+    try:
+        os.makedirs(d, exist_ok=True)
+        probe = os.path.join(d, ".w%d" % os.getpid())
+        open(probe, "w").close()
+        os.remove(probe)
+        return d
+    except OSError:
+        d = os.path.join(tempfile.gettempdir(), "hoomd_tf_amd_jit_%d" % os.getuid())
+        os.makedirs(d, exist_ok=True)
+        return d
+
+
+_SOURCES = ("jit_unit.hip", "fused_eval.hip", "eval_pair.hip", "pair_math.h", "htf_common.h", "htf_internal.h", "box_math.h")
+FLAGS = ["-std=c++17", "-O3", "-ffp-contract=on", "-DHTF_BUILD"]   # (-ffp-contract=on: as fused_eval.o is built, csrc/Makefile)
+
+
+def _source_digest():
+    h = hashlib.sha256()
+    for name in _SOURCES:
+        with open(os.path.join(_CSRC, name), "rb") as f:
+            h.update(f.read())
+    with open(os.path.join(os.path.dirname(_HERE), "include", "htf_amd.h"), "rb") as f:
+        h.update(f.read())
+    return h.hexdigest()
+
+
+def compile_body(body):
+    """-> (bytes of the gfx950 code object, its cache key).  Compiles on a miss (~6 s), loads from the cache otherwise."""
+    key = hashlib.sha256((body + "\0" + _source_digest() + "\0" + ARCH + " ".join(FLAGS)).encode()).hexdigest()[:24]
+    path = os.path.join(_cache_dir(), key + ".hsaco")
+    if not os.path.exists(path):
+        with tempfile.TemporaryDirectory() as tmp:
+            inc = os.path.join(tmp, "body.inc")
+            with open(inc, "w") as f:
+                f.write("#define HTF_JIT_BODY_TEXT \\\n" + " \\\n".join("    " + l for l in body.splitlines()) + "\n")
+            out = os.path.join(tmp, "unit.hsaco")
+            cmd = [_hipcc(), "--genco", "--offload-arch=" + ARCH] + FLAGS + [
+                "-I" + os.path.join(os.path.dirname(_HERE), "include"), "-I" + _CSRC, "-DHTF_JIT_BODY_FILE=\"%s\"" % inc,
+                os.path.join(_CSRC, "jit_unit.hip"), "-o", out]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0 or not os.path.exists(out):
+                raise RuntimeError("hoomd_tf_amd.codegen: hipcc failed on the generated unit:\n%s\n--- body ---\n%s" % (r.stderr[-3000:], body))
+            tmp_path = path + ".%d.tmp" % os.getpid()
+            with open(out, "rb") as src, open(tmp_path, "wb") as dst:
+                dst.write(src.read())
+            os.replace(tmp_path, path)   # (atomic: several ranks may compile the same expression at once)
+    with open(path, "rb") as f:
+        return f.read(), key

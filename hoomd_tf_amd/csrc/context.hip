@@ -65,6 +65,7 @@ struct htf_potential {
     htf::PotParams pp;
     htf::MlpDevice *mlp = nullptr;
     htf::TopkDevice *topk = nullptr;
+    htf::JitKernels *jit = nullptr;
 };
 
 // potentials with an evaluator of their own (everything else goes through eval_pair_dispatch / the fused kernels)
@@ -175,6 +176,10 @@ extern "C" int htf_potential_create(const htf_potential_desc *d, htf_potential *
     case HTF_POT_TOPK_MLP:
         rc = topk_create(d, &p->topk);
         break;
+    case HTF_POT_JIT:
+        rc = jit_create(d->jit_image, d->jit_image_bytes, &p->jit);
+        p->pp.jit = p->jit;
+        break;
     default:
         set_error("htf_potential_create: unknown potential kind %d", d->kind);
         rc = HTF_ERR_INVALID;
@@ -232,6 +237,7 @@ extern "C" void htf_potential_destroy(htf_potential *pot) {
     if (!pot) return;
     if (pot->mlp) htf::mlp_destroy(pot->mlp);
     if (pot->topk) htf::topk_destroy(pot->topk);
+    if (pot->jit) htf::jit_destroy(pot->jit);
     delete pot;
 }
 

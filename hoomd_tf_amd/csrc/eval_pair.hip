@@ -33,10 +33,10 @@ __device__ __forceinline__ float4 load_slot(const typename Vec4<IT>::type *p) {
 }
 
 template <int KIND, int G, bool VIRIAL, typename IT>
-__global__ __launch_bounds__(256) void eval_pair_kernel(const typename Vec4<IT>::type *__restrict__ nlist,
-                                                        unsigned B, unsigned NN, void *__restrict__ force,
-                                                        void *__restrict__ virial9, int out_f64, PotParams pin,
-                                                        const unsigned *__restrict__ counts) {
+__device__ __forceinline__ void eval_pair_body(const typename Vec4<IT>::type *__restrict__ nlist,
+                                               unsigned B, unsigned NN, void *__restrict__ force,
+                                               void *__restrict__ virial9, int out_f64, PotParams pin,
+                                               const unsigned *__restrict__ counts) {
     constexpr int RPW = 64 / G; // particle rows per wave
     const PotParams p = resolve_theta<KIND>(pin);
     const unsigned lane = threadIdx.x & 63u;
@@ -125,6 +125,18 @@ __global__ __launch_bounds__(256) void eval_pair_kernel(const typename Vec4<IT>:
     }
 }
 
+// (the body is a device function so that a generated unit -- csrc/jit_unit.hip -- can give its instantiations C names)
+template <int KIND, int G, bool VIRIAL, typename IT>
+__global__ __launch_bounds__(256) void eval_pair_kernel(const typename Vec4<IT>::type *__restrict__ nlist,
+                                                        unsigned B, unsigned NN, void *__restrict__ force,
+                                                        void *__restrict__ virial9, int out_f64, PotParams pin,
+                                                        const unsigned *__restrict__ counts) {
+    eval_pair_body<KIND, G, VIRIAL, IT>(nlist, B, NN, force, virial9, out_f64, pin, counts);
+}
+
+#ifdef HTF_JIT_UNIT
+} // namespace htf  (a generated unit takes the templates above and nothing else of this file)
+#else
 template <int KIND, int G, bool VIRIAL, typename IT>
 static int launch_eval_g(const void *nlist, unsigned B, unsigned NN, void *force, void *virial9,
                          int out_f64, const PotParams &p, const unsigned *counts, hipStream_t stream) {
@@ -173,6 +185,7 @@ int eval_pair_dispatch(const PotParams &p, const void *nlist, int in_dtype, unsi
     case HTF_POT_SIMPLE: return launch_eval<HTF_POT_SIMPLE>(nlist, in_dtype, B, NN, force, virial9, out_f64, p, counts, stream);
     case HTF_POT_GAUSS: return launch_eval<HTF_POT_GAUSS>(nlist, in_dtype, B, NN, force, virial9, out_f64, p, counts, stream);
     case HTF_POT_LJ_PARAM: return launch_eval<HTF_POT_LJ_PARAM>(nlist, in_dtype, B, NN, force, virial9, out_f64, p, counts, stream);
+    case HTF_POT_JIT: return jit_launch_eval(p, nlist, in_dtype, B, NN, force, virial9, out_f64, counts, stream);
     default:
         set_error("eval_pair_dispatch: potential kind %d is not a closed-form pair potential", p.kind);
         return HTF_ERR_INVALID;
@@ -456,3 +469,4 @@ extern "C" int htf_bias_combine(void *d_force, const void *d_bias, const float *
     }
     return check_launch("bias_combine_kernel");
 }
+#endif // HTF_JIT_UNIT

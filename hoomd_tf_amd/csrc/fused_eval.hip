@@ -182,7 +182,7 @@ __device__ __forceinline__ void fused_row(const unsigned w, const unsigned lane,
 }
 
 template <int KIND, bool VIRIAL, bool STORE, typename PT>
-__global__ __launch_bounds__(256) void fused_forces_kernel(const typename Vec4<PT>::type *__restrict__ pos, unsigned N,
+__device__ __forceinline__ void fused_forces_body(const typename Vec4<PT>::type *__restrict__ pos, unsigned N,
                                                            unsigned NN, unsigned offset, unsigned batch,
                                                            BoxT<PT> box, const unsigned *__restrict__ n_neigh,
                                                            const unsigned *__restrict__ nlist,
@@ -196,6 +196,21 @@ __global__ __launch_bounds__(256) void fused_forces_kernel(const typename Vec4<P
     if (w >= batch) return;
     fused_row<KIND, VIRIAL, STORE, PT>(w, lane, pos, N, NN, offset, box, n_neigh, nlist, head_list, rmaxsq, force, virial9,
                                        out_f64, p, check_count, positions_out, dest, counts_io);
+}
+
+// (bodies are device functions so that a generated unit -- csrc/jit_unit.hip -- can give its instantiations C names)
+template <int KIND, bool VIRIAL, bool STORE, typename PT>
+__global__ __launch_bounds__(256) void fused_forces_kernel(const typename Vec4<PT>::type *__restrict__ pos, unsigned N,
+                                                           unsigned NN, unsigned offset, unsigned batch,
+                                                           BoxT<PT> box, const unsigned *__restrict__ n_neigh,
+                                                           const unsigned *__restrict__ nlist,
+                                                           const unsigned *__restrict__ head_list, PT rmaxsq,
+                                                           void *__restrict__ force, void *__restrict__ virial9,
+                                                           int out_f64, PotParams pin, unsigned *__restrict__ check_count,
+                                                           float4 *__restrict__ positions_out,
+                                                           float4 *__restrict__ dest, unsigned *__restrict__ counts_io) {
+    fused_forces_body<KIND, VIRIAL, STORE, PT>(pos, N, NN, offset, batch, box, n_neigh, nlist, head_list, rmaxsq, force, virial9, out_f64,
+                                               pin, check_count, positions_out, dest, counts_io);
 }
 
 // Measured alternatives for the fast path below (C3, tensor written / not written), with ordinary
@@ -581,7 +596,7 @@ __global__ __launch_bounds__(256, sizeof(PT) == 8 ? HTF_TAILS_MINB_F64 : 1) void
 // and which has arithmetic to hide its loads under, is best with one group per wave
 // (C3, tensor written: 62.5 us; 4 / 8 / 12 / 16 workgroups per CU: 84 / 78 / 69 / 68 us), the default.
 template <int KIND, bool STORE, int R, typename PT>
-__global__ __launch_bounds__(256) void fused_forces_rows2_kernel(
+__device__ __forceinline__ void fused_forces_rows2_body(
     const typename Vec4<PT>::type *__restrict__ pos, unsigned N, unsigned NN, unsigned offset, unsigned batch,
     BoxT<PT> box, const unsigned *__restrict__ n_neigh, const unsigned *__restrict__ nlist,
     const unsigned *__restrict__ head_list, PT rmaxsq, void *__restrict__ force, int out_f64, PotParams pin,
@@ -597,6 +612,20 @@ __global__ __launch_bounds__(256) void fused_forces_rows2_kernel(
                                              force, out_f64, p, check_count, positions_out, dest, counts_io);
 }
 
+template <int KIND, bool STORE, int R, typename PT>
+__global__ __launch_bounds__(256) void fused_forces_rows2_kernel(
+    const typename Vec4<PT>::type *__restrict__ pos, unsigned N, unsigned NN, unsigned offset, unsigned batch,
+    BoxT<PT> box, const unsigned *__restrict__ n_neigh, const unsigned *__restrict__ nlist,
+    const unsigned *__restrict__ head_list, PT rmaxsq, void *__restrict__ force, int out_f64, PotParams pin,
+    unsigned *__restrict__ check_count, float4 *__restrict__ positions_out, float4 *__restrict__ dest,
+    unsigned *__restrict__ counts_io) {
+    fused_forces_rows2_body<KIND, STORE, R, PT>(pos, N, NN, offset, batch, box, n_neigh, nlist, head_list, rmaxsq, force, out_f64, pin,
+                                                check_count, positions_out, dest, counts_io);
+}
+
+#ifdef HTF_JIT_UNIT
+} // namespace htf  (a generated unit takes the templates above and nothing else of this file)
+#else
 template <int KIND, bool VIRIAL, typename PT>
 static int launch_fused(const void *pos, unsigned N, unsigned NN, unsigned offset, unsigned batch, const htf_box *hb,
                         const unsigned *n_neigh, const unsigned *nlist, const unsigned *head_list, double rmax,
@@ -1592,6 +1621,9 @@ int fused_forces_impl(const PotParams &p, const void *pos, int pos_dtype, unsign
     case HTF_POT_SIMPLE:
         HTF_REQUIRE(virial9 == nullptr, "htf_fused_forces: SimplePotential has no virial");
         return HTF_FK(HTF_POT_SIMPLE);
+    case HTF_POT_JIT: // a generated unit's instantiations of the kernels above (csrc/jit.hip)
+        return jit_launch_fused(p, pos, pos_dtype, N, NN, offset, batch, box, n_neigh, nlist, head_list, rmax, force, virial9, out_f64,
+                                check_count, positions_out, dest, counts_io, s);
     default:
         set_error("htf_fused_forces: potential kind %d has no fused form (the pair-MLP is MFMA-bound, not traffic-bound)", p.kind);
         return HTF_ERR_INVALID;
@@ -1600,3 +1632,4 @@ int fused_forces_impl(const PotParams &p, const void *pos, int pos_dtype, unsign
 }
 
 } // namespace htf
+#endif // HTF_JIT_UNIT

@@ -17,7 +17,19 @@ struct PotParams {
     float coef[HTF_MAX_POLY_TERMS];
     int power[HTF_MAX_POLY_TERMS];
     float poly_cut_r2; // RINV_POLY mask: smallest fp32 t with sqrtf(t) >= poly_cut (0: no mask)
+    const struct JitKernels *jit; // HTF_POT_JIT: the loaded code object's kernels (csrc/jit.hip); host-side only
 };
+
+// HTF_POT_JIT (csrc/jit.hip): a code object built by hoomd_tf_amd/codegen.py from csrc/jit_unit.hip
+struct JitKernels;
+int jit_create(const void *image, size_t bytes, JitKernels **out);
+void jit_destroy(JitKernels *k);
+int jit_launch_fused(const PotParams &p, const void *pos, int pos_dtype, unsigned N, unsigned NN, unsigned offset, unsigned batch,
+                     const htf_box *box, const unsigned *n_neigh, const unsigned *nlist, const unsigned *head_list, double rmax,
+                     void *force, void *virial9, int out_f64, unsigned *check_count, float4 *positions_out, float4 *dest,
+                     unsigned *counts_io, hipStream_t s);
+int jit_launch_eval(const PotParams &p, const void *nlist, int in_dtype, unsigned B, unsigned NN, void *force, void *virial9,
+                    int out_f64, const unsigned *counts, hipStream_t s);
 
 // counts (nullable): live slots per row; slots >= counts[row] are known zero padding and not loaded
 int eval_pair_dispatch(const PotParams &p, const void *nlist, int in_dtype, unsigned B, unsigned NN,

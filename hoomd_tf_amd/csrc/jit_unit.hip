@@ -1,0 +1,57 @@
+// The translation unit hoomd_tf_amd/codegen.py compiles for a TRACED pair energy (HTF_POT_JIT):
+//
+//     hipcc --genco --offload-arch=gfx950 -O3 -DHTF_JIT_BODY_FILE='"<body>.inc"' jit_unit.hip -o <hash>.hsaco
+//
+// -- pair_math.h's pair_eval_f<HTF_POT_JIT> with the generated body spliced in, and, around it, the SAME row loops the built-in
+// closed forms run: the one-kernel step's plain two-row form (tensor written or not, fp32 / fp64 positions), its one-row form
+// for virial requests, and the streaming evaluator over a pair-vector tensor.  The instantiations get C names so that
+// csrc/jit.hip finds them with hipModuleGetFunction.  Nothing of this file is part of libhtf_amd.so.
+#define HTF_JIT_UNIT 1
+#include "htf_common.h"
+// the generated statements: `e = ...; dedr = ...;` in terms of s, ds, r, x, y, z (see pair_math.h)
+#include HTF_JIT_BODY_FILE
+#define HTF_JIT_BODY HTF_JIT_BODY_TEXT
+#include "fused_eval.hip"
+#include "eval_pair.hip"
+
+using namespace htf;
+
+#define HTF_JIT_ROWS2(NAME, STORE, PT)                                                                                              \
+    extern "C" __global__ __launch_bounds__(256) void NAME(                                                                         \
+        const typename Vec4<PT>::type *__restrict__ pos, unsigned N, unsigned NN, unsigned offset, unsigned batch, BoxT<PT> box,    \
+        const unsigned *__restrict__ n_neigh, const unsigned *__restrict__ nlist, const unsigned *__restrict__ head_list,            \
+        PT rmaxsq, void *__restrict__ force, int out_f64, PotParams pin, unsigned *__restrict__ check_count,                        \
+        float4 *__restrict__ positions_out, float4 *__restrict__ dest, unsigned *__restrict__ counts_io) {                          \
+        fused_forces_rows2_body<HTF_POT_JIT, STORE, 2, PT>(pos, N, NN, offset, batch, box, n_neigh, nlist, head_list, rmaxsq, force, \
+                                                           out_f64, pin, check_count, positions_out, dest, counts_io);             \
+    }
+HTF_JIT_ROWS2(htf_jit_rows2_f32_store, true, float)
+HTF_JIT_ROWS2(htf_jit_rows2_f32_nostore, false, float)
+HTF_JIT_ROWS2(htf_jit_rows2_f64_store, true, double)
+HTF_JIT_ROWS2(htf_jit_rows2_f64_nostore, false, double)
+
+#define HTF_JIT_ROW1V(NAME, STORE, PT)                                                                                              \
+    extern "C" __global__ __launch_bounds__(256) void NAME(                                                                         \
+        const typename Vec4<PT>::type *__restrict__ pos, unsigned N, unsigned NN, unsigned offset, unsigned batch, BoxT<PT> box,    \
+        const unsigned *__restrict__ n_neigh, const unsigned *__restrict__ nlist, const unsigned *__restrict__ head_list,            \
+        PT rmaxsq, void *__restrict__ force, void *__restrict__ virial9, int out_f64, PotParams pin,                                \
+        unsigned *__restrict__ check_count, float4 *__restrict__ positions_out, float4 *__restrict__ dest,                          \
+        unsigned *__restrict__ counts_io) {                                                                                         \
+        fused_forces_body<HTF_POT_JIT, true, STORE, PT>(pos, N, NN, offset, batch, box, n_neigh, nlist, head_list, rmaxsq, force,   \
+                                                        virial9, out_f64, pin, check_count, positions_out, dest, counts_io);       \
+    }
+HTF_JIT_ROW1V(htf_jit_row1v_f32_store, true, float)
+HTF_JIT_ROW1V(htf_jit_row1v_f32_nostore, false, float)
+HTF_JIT_ROW1V(htf_jit_row1v_f64_store, true, double)
+HTF_JIT_ROW1V(htf_jit_row1v_f64_nostore, false, double)
+
+#define HTF_JIT_EVAL(NAME, VIRIAL, IT)                                                                                              \
+    extern "C" __global__ __launch_bounds__(256) void NAME(const typename Vec4<IT>::type *__restrict__ nlist, unsigned B,           \
+                                                           unsigned NN, void *__restrict__ force, void *__restrict__ virial9,      \
+                                                           int out_f64, PotParams pin, const unsigned *__restrict__ counts) {      \
+        eval_pair_body<HTF_POT_JIT, 16, VIRIAL, IT>(nlist, B, NN, force, virial9, out_f64, pin, counts);                            \
+    }
+HTF_JIT_EVAL(htf_jit_eval_f32, false, float)
+HTF_JIT_EVAL(htf_jit_eval_f32_virial, true, float)
+HTF_JIT_EVAL(htf_jit_eval_f64, false, double)
+HTF_JIT_EVAL(htf_jit_eval_f64_virial, true, double)

@@ -138,6 +138,27 @@ __device__ __forceinline__ void pair_eval_f(const RinvFwd &f, float x, float y, 
         fy = c * ty;
         fz = c * tz;
         return;
+    } else if constexpr (KIND == HTF_POT_JIT) {
+        // A traced elementwise energy (hoomd_tf_amd/codegen.py): HTF_JIT_BODY is generated code that reads
+        //   s  = nlist_rinv of the slot (0 where masked), with d s / d r' = -s^2 where f.cond,
+        //   r  = safe_norm of the slot (r' = |x + 1e-7|),
+        //   x, y, z (for masks on the plain norm)
+        // and assigns `e` (the slot's energy) and `dedr` (its total derivative with respect to r', forward mode).
+        // nlist_forces = 2 de/dr' t / r' (simmodel.py:548), as every rinv-based closed form above.
+#ifdef HTF_JIT_BODY
+        const float s = f.s, r = f.rp;
+        const float ds = f.cond ? -(s * s) : 0.0f;
+        float dedr = 0.0f;
+        e = 0.0f;
+        { HTF_JIT_BODY }
+        const float c = f.rp > 0.0f ? 2.0f * dedr * f.irp : 0.0f;
+        fx = c * f.tx;
+        fy = c * f.ty;
+        fz = c * f.tz;
+#else
+        e = fx = fy = fz = 0.0f; // (never instantiated outside a generated unit)
+#endif
+        return;
     } else if constexpr (KIND == HTF_POT_GAUSS) {
         // one RBFExpansion channel as a pair energy: r = safe_norm(x) (simmodel.py:581-594),
         // phi = exp(-(r - r0)^2 / gap) (layers.py:46-49), masked with the nlist_rinv criterion.

@@ -131,6 +131,23 @@ class Potential:
         """Trainable LJ of example 06: e = w0 * 4 (q^2 - q) / 2, q = w1^6 / safe_norm(x)^6."""
         return cls(_lib.POT_LJ_PARAM, lj_param=(w0, w1), theta=theta)
 
+    @classmethod
+    def jit(cls, body):
+        """A traced elementwise pair energy as generated kernels (hoomd_tf_amd/codegen.py): ``body`` is the text
+        codegen.generate_body emitted; compiled once per expression (``hipcc --genco``, cached), loaded as HTF_POT_JIT."""
+        from . import codegen
+        image, key = codegen.compile_body(body)
+        self = cls.__new__(cls)
+        d = _lib.PotentialDesc()
+        d.kind = _lib.POT_JIT
+        self._image = C.create_string_buffer(image, len(image))   # (kept alive with the potential)
+        d.jit_image = C.cast(self._image, C.c_void_p)
+        d.jit_image_bytes = len(image)
+        self.theta, self._keep, self.kind, self.jit_key, self.body = None, [], _lib.POT_JIT, key, body
+        self._h = C.c_void_p()
+        check(lib.htf_potential_create(C.byref(d), C.byref(self._h)))
+        return self
+
     @property
     def num_params(self):
         return int(lib.htf_potential_num_params(self._h))

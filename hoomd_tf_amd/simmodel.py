@@ -10,6 +10,7 @@ analogue of ``tf.function`` tracing ``compute`` into a graph.  Names, argument m
 and error behaviour follow the reference (cited per function).
 """
 import ctypes as C
+import os
 import threading
 
 import numpy as np
@@ -253,6 +254,9 @@ class PairMask(_TorchOperand):
 
 def cast(x, dtype=None):
     """tf.cast for model code: a symbolic mask stays symbolic, tensors are converted."""
+    if isinstance(x, PairCond):
+        from . import codegen as cg
+        return PairExpr(x.nlist, cg.Node("mask", (x.node,)))
     if isinstance(x, PairMask):
         return x if dtype is None or dtype == torch.bool else PairMask(x.nlist, x.cut, as_dtype=dtype)
     t = _unwrap(x)
@@ -319,6 +323,10 @@ class RinvPoly(PairEnergy):
             for p, c in other.terms.items():
                 t[p] = t.get(p, 0.0) + sign * c
             return RinvPoly(self.nlist, t, self.reduced and other.reduced, cut=self.cut)
+        if isinstance(other, (PairExpr, SafeNorm)) or (isinstance(other, (int, float)) and not self.reduced):
+            # not a polynomial in rinv any more: a traced expression (generated kernel)
+            e = PairExpr.of(self)
+            return e._with("add" if sign > 0 else "sub", other)
         raise TypeError("cannot combine a rinv polynomial with %r (constants carry no force)" % (other,))
 
     def __add__(self, o):
@@ -349,16 +357,31 @@ class RinvPoly(PairEnergy):
                 for p2, c2 in o.terms.items():
                     t[p1 + p2] = t.get(p1 + p2, 0.0) + c1 * c2
             return RinvPoly(self.nlist, t, cut=self.cut if self.cut is not None else o.cut)
+        if isinstance(o, (PairExpr, SafeNorm)):
+            return PairExpr.of(self) * o
         return NotImplemented
 
     __rmul__ = __mul__
 
     def __truediv__(self, o):
+        if isinstance(o, (PairExpr, SafeNorm, RinvPoly)):
+            return PairExpr.of(self) / o
         return self * (1.0 / o)
+
+    def __rtruediv__(self, o):
+        return PairExpr.of(self).__rtruediv__(o)
+
+    def __rsub__(self, o):
+        return PairExpr.of(self).__rsub__(o)
+
+    def __lt__(self, o): return PairExpr.of(self) < o
+    def __le__(self, o): return PairExpr.of(self) <= o
+    def __gt__(self, o): return PairExpr.of(self) > o
+    def __ge__(self, o): return PairExpr.of(self) >= o
 
     def __pow__(self, n):
         if int(n) != n or n < 1:
-            raise ValueError("only positive integer powers of rinv are supported")
+            return PairExpr.of(self) ** n
         out = self
         for _ in range(int(n) - 1):
             out = out * self
@@ -386,6 +409,194 @@ class RinvPoly(PairEnergy):
         if self.cut is not None:
             out = out * PairMask(self.nlist, self.cut).tensor().to(out.dtype)
         return out.sum(dim=1) if self.reduced else out
+
+
+class PairExpr(PairEnergy):
+    """Any ELEMENTWISE expression of nlist_rinv (s), safe_norm (r) and masks on the plain norm, kept symbolic (round 5:
+    hoomd_tf_amd/codegen.py).  What the zoo above cannot express -- Morse, Yukawa, a switched or tabulated-by-formula potential,
+    whatever a notebook writes -- becomes the body of a generated kernel instead of twenty eager torch ops per step:
+    ``compute_nlist_forces`` lowers it to an ``HTF_POT_JIT`` potential (compiled once per expression, cached on disk), and
+    tfcompute replays it as the one-kernel step like any built-in closed form.  An expression whose energy does not vanish on a
+    padded slot keeps the torch route (codegen.vanishes_on_padding)."""
+    owns_potential = False
+
+    def __init__(self, nlist, node, reduced=False):
+        self.nlist, self.node, self.reduced = nlist, node, reduced
+
+    # ---- construction from the other symbolic types
+    @staticmethod
+    def of(x, nlist=None):
+        from . import codegen as cg
+        if isinstance(x, PairExpr):
+            return x
+        if isinstance(x, RinvPoly):
+            node = None
+            for p_, c_ in sorted(x.terms.items()):
+                term = cg.Node("mul", (cg.const(c_), cg.Node("pow", (cg.S,), value=float(p_)))) if p_ != 1 else cg.Node("mul", (cg.const(c_), cg.S))
+                node = term if node is None else cg.Node("add", (node, term))
+            node = node or cg.const(0.0)
+            if x.cut is not None:
+                node = cg.Node("mul", (cg.Node("mask", (cg.Node("lt", (cg.RN, cg.const(x.cut))),)), node))
+            return PairExpr(x.nlist, node, x.reduced)
+        if isinstance(x, SafeNorm):
+            if x.delta != 1e-7:
+                raise TypeError("only safe_norm's default delta can be traced")
+            return PairExpr(x.nlist, cg.R)
+        if isinstance(x, PairNorm):
+            return PairExpr(x.xyz.parent, cg.RN)
+        if isinstance(x, PairMask):
+            return PairExpr(x.nlist, cg.Node("mask", (cg.Node("lt", (cg.RN, cg.const(x.cut))),)))
+        if nlist is not None:
+            return PairExpr(nlist, cg.wrap(x))
+        raise TypeError("cannot trace %r" % (type(x),))
+
+    def _with(self, op, other=None, swap=False, value=None):
+        from . import codegen as cg
+        if self.reduced:
+            raise TypeError("a per-particle sum is not a per-pair expression any more")
+        if other is None:
+            return PairExpr(self.nlist, cg.Node(op, (self.node,), value=value))
+        o = PairExpr.of(other, self.nlist)
+        if o.nlist is not self.nlist and o.nlist.tensor is not self.nlist.tensor:
+            raise ValueError("expressions come from different neighbor lists")
+        args = (o.node, self.node) if swap else (self.node, o.node)
+        return PairExpr(self.nlist, cg.Node(op, args))
+
+    def __add__(self, o):
+        if isinstance(o, BiasTerm):
+            return NotImplemented
+        return self._with("add", o)
+    def __radd__(self, o): return self._with("add", o, swap=True)
+    def __sub__(self, o): return self._with("sub", o)
+    def __rsub__(self, o): return self._with("sub", o, swap=True)
+    def __mul__(self, o): return self._with("mul", o)
+    def __rmul__(self, o): return self._with("mul", o, swap=True)
+    def __truediv__(self, o): return self._with("div", o)
+    def __rtruediv__(self, o): return self._with("div", o, swap=True)
+    def __neg__(self): return self._with("neg")
+    def __abs__(self): return self._with("abs")
+
+    def __pow__(self, n):
+        if not isinstance(n, (int, float)):
+            raise TypeError("only constant exponents can be traced")
+        return self._with("pow", value=float(n))
+
+    def _cmp(self, op, o): return PairCond(self.nlist, PairExpr.of(self, self.nlist)._with(op, o).node)
+    def __lt__(self, o): return self._cmp("lt", o)
+    def __le__(self, o): return self._cmp("le", o)
+    def __gt__(self, o): return self._cmp("gt", o)
+    def __ge__(self, o): return self._cmp("ge", o)
+
+    # ---- lowering
+    def body(self):
+        from . import codegen as cg
+        if getattr(self, "_body", None) is None:
+            self._body = cg.generate_body(self.node)
+        return self._body
+
+    def lowers(self):
+        from . import codegen as cg
+        if getattr(self, "_lowers", None) is None:
+            self._lowers = os.environ.get("HTF_NO_JIT") != "1" and cg.vanishes_on_padding(self.node)
+        return self._lowers
+
+    def key(self):
+        return ("jit", self.body())
+
+    def potential(self):
+        return ops.Potential.jit(self.body())
+
+    def torch_value(self, nl_tensor):
+        """[N, NN] value from a pair-vector tensor (an autograd leaf for the generic route), in its dtype."""
+        from . import codegen as cg
+        x = nl_tensor[:, :, :3]
+        t = x + 1e-7
+        r = torch.sqrt((t * t).sum(dim=2))
+        ok = r > 3e-6
+        s = torch.where(ok, 1.0 / (torch.where(ok, r, torch.ones_like(r)) + 3e-6), torch.zeros_like(r))
+        rn = torch.sqrt((x * x).sum(dim=2)).detach()
+        return cg.evaluate(self.node, s, r, rn)
+
+    def tensor(self):
+        _trace_log().append({"op": "eager_value"})
+        v = self.torch_value(self.nlist.tensor)
+        return v.sum(dim=1) if self.reduced else v
+
+    @property
+    def ad(self):
+        v = self.torch_value(self.nlist.ad)
+        return v.sum(dim=1) if self.reduced else v
+
+
+class PairCond:
+    """A comparison of traced expressions: the condition of ``where`` / the argument of ``cast`` (no gradient)."""
+
+    def __init__(self, nlist, node):
+        self.nlist, self.node = nlist, node
+
+
+def _sym(x):
+    return isinstance(x, (PairExpr, RinvPoly, SafeNorm))
+
+
+def _unary(op, x, torch_fn):
+    if _sym(x):
+        return PairExpr.of(x)._with(op)
+    return torch_fn(_unwrap(x))
+
+
+def exp(x):
+    """tf.exp for model code: traced on pair expressions, torch otherwise."""
+    return _unary("exp", x, torch.exp)
+
+
+def log(x):
+    return _unary("log", x, torch.log)
+
+
+def tanh(x):
+    return _unary("tanh", x, torch.tanh)
+
+
+def sqrt(x):
+    return _unary("sqrt", x, torch.sqrt)
+
+
+def square(x):
+    return _unary("square", x, torch.square)
+
+
+def abs(x):  # noqa: A001 (tf.abs)
+    return _unary("abs", x, torch.abs)
+
+
+def pow(x, n):  # noqa: A001 (tf.pow)
+    if _sym(x):
+        return PairExpr.of(x) ** n
+    return _unwrap(x) ** n
+
+
+def minimum(a, b):
+    if _sym(a) or _sym(b):
+        e = PairExpr.of(a if _sym(a) else b)
+        return PairExpr.of(a, e.nlist)._with("min", PairExpr.of(b, e.nlist))
+    return torch.minimum(torch.as_tensor(_unwrap(a)), torch.as_tensor(_unwrap(b)))
+
+
+def maximum(a, b):
+    if _sym(a) or _sym(b):
+        e = PairExpr.of(a if _sym(a) else b)
+        return PairExpr.of(a, e.nlist)._with("max", PairExpr.of(b, e.nlist))
+    return torch.maximum(torch.as_tensor(_unwrap(a)), torch.as_tensor(_unwrap(b)))
+
+
+def where(cond, a, b):
+    """tf.where(cond, a, b) for model code: traced when the condition compares traced expressions."""
+    from . import codegen as cg
+    if isinstance(cond, PairCond):
+        ea, eb = PairExpr.of(a, cond.nlist), PairExpr.of(b, cond.nlist)
+        return PairExpr(cond.nlist, cg.Node("where", (cond.node, ea.node, eb.node)))
+    return torch.where(_unwrap(cond), torch.as_tensor(_unwrap(a)), torch.as_tensor(_unwrap(b)))
 
 
 class WCAPair(PairEnergy):
@@ -605,6 +816,22 @@ class SafeNorm:
         t = self.nlist.tensor[:, :, :3] + self.delta
         return torch.sqrt((t * t).sum(dim=2))
 
+    # arithmetic on the distance: a traced expression (round 5; the RBF / MLP layers keep taking the SafeNorm itself)
+    def __add__(self, o): return PairExpr.of(self) + o
+    def __radd__(self, o): return o + PairExpr.of(self)
+    def __sub__(self, o): return PairExpr.of(self) - o
+    def __rsub__(self, o): return o - PairExpr.of(self)
+    def __mul__(self, o): return PairExpr.of(self) * o
+    def __rmul__(self, o): return o * PairExpr.of(self)
+    def __truediv__(self, o): return PairExpr.of(self) / o
+    def __rtruediv__(self, o): return o / PairExpr.of(self)
+    def __neg__(self): return -PairExpr.of(self)
+    def __pow__(self, n): return PairExpr.of(self) ** n
+    def __lt__(self, o): return PairExpr.of(self) < o
+    def __le__(self, o): return PairExpr.of(self) <= o
+    def __gt__(self, o): return PairExpr.of(self) > o
+    def __ge__(self, o): return PairExpr.of(self) >= o
+
 
 def reduce_sum(x, axis=None):
     """tf.reduce_sum for expressions (axis=1: per-particle energy) and tensors."""
@@ -618,6 +845,14 @@ def reduce_sum(x, axis=None):
         if axis not in (1, -1):
             raise ValueError("pair energies reduce over the neighbor axis (axis=1), or over everything (axis=None)")
         return RinvPoly(x.nlist, x.terms, reduced=True, cut=x.cut)
+    if isinstance(x, PairExpr):
+        if axis is None:
+            out = PairExpr(x.nlist, x.node, reduced=True)
+            out.total = True
+            return out
+        if axis not in (1, -1):
+            raise ValueError("pair energies reduce over the neighbor axis (axis=1), or over everything (axis=None)")
+        return PairExpr(x.nlist, x.node, reduced=True)
     if isinstance(x, WCAPair):
         return x
     if isinstance(x, LJParamEnergy):
@@ -649,6 +884,10 @@ def compute_nlist_forces(nlist, energy, virial=False):
         return _autograd_nlist_forces(_as_nlist(nlist), energy, virial)
     if isinstance(energy, DenseOut):
         energy = energy.energy()
+    if isinstance(energy, PairExpr) and not energy.lowers():
+        # (its energy does not vanish on a padded slot, or HTF_NO_JIT=1: the generic route, forces by torch.autograd)
+        nl_ = _as_nlist(nlist)
+        return _autograd_nlist_forces(nl_, energy.torch_value(nl_.ad).sum(dim=1), virial)
     if not isinstance(energy, PairEnergy):
         raise ValueError('Could not find dependence between energy and nlist.'
                          ' Did you put them in wrong order?')

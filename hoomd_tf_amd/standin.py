@@ -620,17 +620,67 @@ class Simulation:
             self.integrator.step()
         self.system.timestep += 1
 
+    def _choose_by_measurement(self, nsteps):
+        """graph=None: which way is this step faster?  Until round 5 the replay was chosen for any run of >= 256 qualifying steps;
+        at C3 size (a step of ~75 us, kernel-bound) the driver's line had the replay 8 % SLOWER than the stepwise loop, while at
+        a few thousand particles (host-enqueue-bound) it is ~2x faster.  So the first long run measures both on its own first
+        steps -- about 32 stepwise, then about 32 replayed (the capture itself is not timed) -- and keeps the faster until
+        something the graph carries by value changes.  Same trajectory either way.  -> steps consumed."""
+        import time
+        cycle = self._graph_cycle()
+        if cycle == 0:
+            return 0
+        s = self.system
+        f, nl = self.forces[0], self.forces[0]._nlist
+        n = max(1, 32 // cycle) * cycle
+        if nsteps < 2 * n + 6 * cycle:
+            return 0
+        done = 0
+        while s.timestep % cycle != 0:
+            self._step()
+            done += 1
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            self._step()
+        torch.cuda.synchronize()
+        t_step = (time.perf_counter() - t0) / n
+        done += n
+        left = self._run_graphed(4 * cycle, soft=True)     # capture (+ a few replays), untimed
+        done += 4 * cycle
+        if left or self._graph is None:                      # did not capture: stepwise it is
+            for _ in range(left):
+                self._step()
+            self.graph_choice = {"use_graph": False, "why": "the step does not capture", "stepwise_us": t_step * 1e6, "key": None}
+            return done
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        self._run_graphed(n)
+        torch.cuda.synchronize()
+        t_graph = (time.perf_counter() - t0) / n
+        done += n
+        self.graph_choice = {"use_graph": t_graph < t_step, "stepwise_us": t_step * 1e6, "graph_us": t_graph * 1e6,
+                             "steps_per_leg": n, "key": self._graph_key}
+        return done
+
     def run(self, nsteps, graph=None):
         """graph=True (or HTF_RUN_GRAPH=1): replay whole check periods as one hipGraph launch where the step
-        qualifies (_graph_cycle); anything else, and the remainder, runs step by step.  graph=None (the default): the
-        replay is chosen for runs of at least 256 steps of a qualifying step -- small systems are bound by the host's
-        enqueue (the reference's own 256-particle benchmark: 18 k steps/s stepwise, 33 k replayed), a capture costs a few
-        milliseconds once per (model, list, integrator) -- unless HTF_RUN_GRAPH=0; graph=False: always step by step."""
+        qualifies (_graph_cycle); anything else, and the remainder, runs step by step.  graph=None (the default): for runs of at
+        least 256 steps of a qualifying step the FASTER of the two, measured once on the run's own first steps
+        (_choose_by_measurement; ``self.graph_choice`` records it) -- small systems are bound by the host's enqueue (the
+        reference's own 256-particle benchmark: 18 k steps/s stepwise, 33 k replayed), at 131 072 particles the kernels bound the
+        step and the stepwise loop is as fast or faster -- unless HTF_RUN_GRAPH=0; graph=False: always step by step."""
         nsteps = int(nsteps)
         env = os.environ.get("HTF_RUN_GRAPH")
         auto = graph is None and env != "1"
         if graph is None:
-            graph = env == "1" or (env != "0" and nsteps >= 256 and self.system.pos.is_cuda and not getattr(self, "_no_graph", False))
+            graph = env == "1"
+            if env not in ("0", "1") and nsteps >= 256 and self.system.pos.is_cuda and not getattr(self, "_no_graph", False):
+                choice = getattr(self, "graph_choice", None)
+                if choice is None or (choice["key"] is not None and choice["key"] != getattr(self, "_graph_key", None)):
+                    nsteps -= self._choose_by_measurement(nsteps)
+                    choice = getattr(self, "graph_choice", None)
+                graph = bool(choice and choice["use_graph"])
         if graph:
             # (chosen by default, not asked for: a step that turns out not to capture must still run -- soft)
             nsteps = self._run_graphed(nsteps, soft=auto)

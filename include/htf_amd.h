@@ -79,9 +79,14 @@ enum htf_potential_kind {
                             * channel (layers.py:46-49) as a pair energy -- the soft RDF bin of config C4 */
     HTF_POT_LJ_PARAM = 7,  /* trainable LJ of example 06 / build_examples.py:336-372 (LJLayer): r = safe_norm(x),
                             * q = w1^6 / r^6 (divide_no_nan), e = w0 * 4 (q^2 - q) / 2; params (w0, w1) */
-    HTF_POT_TOPK_MLP = 8   /* example 08 / build_examples.py:199-218 NlistNN, a per-PARTICLE network:
+    HTF_POT_TOPK_MLP = 8,  /* example 08 / build_examples.py:199-218 NlistNN, a per-PARTICLE network:
                             * top_n = tf.sort(nlist_rinv(nlist), DESCENDING)[:, :K] -> Dense(H1) -> Dense(H2) ->
                             * Dense(1) = E_i.  desc.K = top_neighs (<= 16), H1, H2 <= 64, weights as for PAIR_MLP */
+    HTF_POT_JIT = 9        /* round 5: an elementwise pair energy e(rinv, r) the caller TRACED from model code (htf/simmodel.py:87-121: any
+                            * compute() is legal upstream) and compiled for gfx950 -- hoomd_tf_amd/codegen.py emits the body of
+                            * pair_math.h's pair_eval_f<HTF_POT_JIT> (energy + d/dr, forward-mode), `hipcc --genco` builds the
+                            * kernels of csrc/jit_unit.hip around it, desc.jit_image hands the code object over.  Same row loops,
+                            * same launch geometry as the built-in closed forms; no second backend. */
 };
 
 enum htf_activation { HTF_ACT_LINEAR = 0, HTF_ACT_TANH = 1 };
@@ -127,6 +132,9 @@ typedef struct htf_potential_desc {
      * (appended with ABI version 2: a caller built against the version-1 layout passes a SHORTER struct and must be rebuilt;
      *  the version check is what catches it) */
     double poly_cut;
+    /* HTF_POT_JIT: the code object (appended with ABI version 3) */
+    const void *jit_image;
+    size_t jit_image_bytes;
 } htf_potential_desc;
 
 typedef struct htf_potential htf_potential; /* opaque; owns device copies of weights */
