@@ -1230,12 +1230,18 @@ def run_md(args, E, workload, variants=True, cpu=True):
     for _ in range(n_windows):
         windows.append(timed_window())
         window_prof.append(ctx.profile_read())  # (build ms, eval ms, bracketed calls) of this window; resets
-    gpu_now = gpu_state(dev.index or 0)   # clocks / power cap right behind the timed windows
     # the kernel durations are those of the window `value` is taken from (the median one)
     elapsed = float(np.median(windows))
     build_ms, eval_ms, ncalls = window_prof[int(np.argsort(windows)[len(windows) // 2])]
     ctx.profile_enable(False)
     rebuilds = (builds_now() - builds0) / n_windows  # per window of args.steps steps
+    # clocks / power cap WHILE the loop runs: an extra, untimed stretch of steps with the sysfs read in its middle (behind a
+    # synchronize the part has already clocked down: 158 MHz)
+    for _ in range(30):
+        step()
+    gpu_now = gpu_state(dev.index or 0)
+    for _ in range(30):
+        step()
 
     # With slabs: where a step's time goes on rank 0, measured AFTER the timed windows (never part of `value`): host time of
     # each phase as the loop enqueues it, and the same phases with the device drained after each (GPU-inclusive).  On real
