@@ -54,7 +54,8 @@ class Brick(C.Structure):
                 ("replica", C.c_int), ("r_ghost", C.c_double), ("cap_int", C.c_uint), ("cap_bnd", C.c_uint),
                 ("ghost_cap", C.c_uint * BRICK_MAX_MSG), ("ghost_off", C.c_uint * BRICK_MAX_MSG),
                 ("mig_cap", C.c_uint * BRICK_MAX_MSG), ("mig_off", C.c_uint * BRICK_MAX_MSG),
-                ("shift", (C.c_double * 3) * BRICK_MAX_MSG), ("box_lo", C.c_double * 3), ("box_L", C.c_double * 3)]
+                ("shift", (C.c_double * 3) * BRICK_MAX_MSG), ("mig_shift", (C.c_double * 3) * BRICK_MAX_MSG),
+                ("halo_wrap", C.c_int), ("mig_wrap", C.c_int), ("box_lo", C.c_double * 3), ("box_L", C.c_double * 3)]
 
 
 class BrickWork(C.Structure):

@@ -52,13 +52,18 @@ class BrickDomain:
     fixed_capacity = True
 
     def __init__(self, system, rank, grid, r_ghost, r_buff=0.4, fractions=None, group=None, transport="torch", replica=False,
-                 coords=None, n_global=None, margin=1.25, backend="auto"):
+                 coords=None, n_global=None, margin=1.25, backend="auto", local_grid=None):
         """``grid``: (px, py, pz) ranks per box axis, pz = 1 (at most two decomposed axes).  ``fractions``: per axis, the interior
         cut fractions (``comm.decomposition(x=[0.33])`` style) or None for even cuts.  ``replica``: this one rank is every brick
         of ``grid`` (see the module docstring); ``coords``: its brick coordinate then (default: the middle one).
         ``transport``: "torch" (torch.distributed grouped P2P: RCCL on the GPU box, gloo in the CPU tests), "native"
         (libhtf_amd.so's own RCCL communicator: capturable into a hipGraph) or "local" (replica mode: the pack kernel writes the
-        ghosts itself).  ``backend``: "kernels" (csrc/brick.hip), "torch" (the restatement, any device) or "auto"."""
+        ghosts itself).  ``backend``: "kernels" (csrc/brick.hip), "torch" (the restatement, any device) or "auto".
+        ``local_grid`` (default: on for device arrays): ghosts are delivered NEXT TO the brick -- a halo message that crosses the
+        periodic boundary is shifted by the box vector, as HOOMD wraps its ghosts -- so the neighbor list can be binned on a
+        cell grid of the brick + ghost layer alone (``nlist_box()``), not of the whole box: at 8 ranks 7/8 of the global grid's
+        cells are empty on any one rank, and under weak scaling the global grid grows with the rank count.  Off: ghosts keep
+        their owner's coordinates (SlabDomain's convention; the neighbor ORDER then equals SlabDomain's, bit for bit)."""
         s = self.sys = system
         self.rank = int(rank)
         self.replica = bool(replica)
@@ -146,12 +151,20 @@ class BrickDomain:
         self.n_ghost_cap = int(sum(ghost_cap))
         self.mig_rows = int(sum(mig_cap))
         self.cand = self.cap + self.mig_rows
-        # ---- shifts (replica mode): message to offset o appears at its receiver moved by -o_d * width_d
+        # ---- shifts.  Replica mode: a message to offset o appears at its receiver moved by -o_d * width_d (halo and migration;
+        # a migrant is then wrapped back into the logical box).  Local grid, real ranks: a HALO message that crosses the periodic
+        # boundary is moved by the box vector so that its ghosts sit next to the receiving brick.
+        self.local_grid = bool(s.pos.is_cuda if local_grid is None else local_grid)
         self.shift = np.zeros((self.n_msg, 3))
-        if self.replica:
-            for m, o in enumerate(self.offsets):
-                for k, d in enumerate(self.axes):
-                    self.shift[m, d] = -o[k] * (self.hi[d] - self.lo[d])
+        self.mig_shift = np.zeros((self.n_msg, 3))
+        for m, o in enumerate(self.offsets):
+            for k, d in enumerate(self.axes):
+                if self.replica:
+                    self.shift[m, d] = self.mig_shift[m, d] = -o[k] * (self.hi[d] - self.lo[d])
+                elif self.local_grid and not 0 <= coords[d] + o[k] < grid[d]:
+                    self.shift[m, d] = -o[k] * self.L[d]
+        self.halo_wrap = self.replica and not self.local_grid
+        self.mig_wrap = self.replica
         # ---- adopt the system: fixed-capacity arrays, the particles it came with in the first rows
         dev, dt = s.pos.device, s.pos.dtype
         self.kernels = backend == "kernels" or (backend == "auto" and s.pos.is_cuda and os.environ.get("HTF_DOMAIN_TORCH") != "1")
@@ -212,19 +225,33 @@ class BrickDomain:
     def n_classes(self):
         return 4 ** self.ndim
 
-    def _shifted(self, P, m):
-        """Positions as message m carries them: shifted and wrapped back into the global box (brick.hip ``shifted``)."""
-        if not self.replica:
+    def _shifted(self, P, shift, wrap):
+        """Positions as a message carries them: shifted and, if asked, wrapped back into the global box (brick.hip ``shifted``)."""
+        if not np.any(shift):
             return P
         P = P.clone()
         for c in range(3):
-            if self.shift[m, c] != 0.0:
+            if shift[c] != 0.0:
                 dt, dev = P.dtype, P.device
-                lo = torch.as_tensor(float(self.sys.box3x3[0][c]), dtype=dt, device=dev)
-                L = torch.as_tensor(float(self.L[c]), dtype=dt, device=dev)
-                x = P[:, c] + torch.as_tensor(float(self.shift[m, c]), dtype=dt, device=dev)
-                P[:, c] = x - torch.floor((x - lo) * (1.0 / L)) * L
+                x = P[:, c] + torch.as_tensor(float(shift[c]), dtype=dt, device=dev)
+                if wrap:
+                    lo = torch.as_tensor(float(self.sys.box3x3[0][c]), dtype=dt, device=dev)
+                    L = torch.as_tensor(float(self.L[c]), dtype=dt, device=dev)
+                    x = x - torch.floor((x - lo) * (1.0 / L)) * L
+                P[:, c] = x
         return P
+
+    def nlist_box(self):
+        """The box the neighbor list is binned and searched on: with a local grid the brick + its ghost layer, NOT periodic
+        along the decomposed axes (the ghosts are real images next to the brick); else the global box."""
+        if not self.local_grid:
+            return self.sys.box3x3, self.sys.periodic
+        b = np.array(self.sys.box3x3, dtype=np.float64)
+        per = list(self.sys.periodic)
+        for d in self.axes:
+            b[0][d], b[1][d] = self.lo[d] - self.r_ghost, self.hi[d] + self.r_ghost
+            per[d] = 0
+        return b, tuple(per)
 
     def _msg_takes_class(self, m, c):
         for k in range(self.ndim):
@@ -251,6 +278,8 @@ class BrickDomain:
             g.mig_cap[m], g.mig_off[m] = self.mig_cap[m], self.mig_off[m]
             for c in range(3):
                 g.shift[m][c] = float(self.shift[m, c])
+                g.mig_shift[m][c] = float(self.mig_shift[m, c])
+        g.halo_wrap, g.mig_wrap = int(self.halo_wrap), int(self.mig_wrap)
         for c in range(3):
             g.box_lo[c], g.box_L[c] = float(self.sys.box3x3[0][c]), float(self.L[c])
         b = np.zeros((2, _lib.BRICK_MAX_P + 1))
@@ -460,7 +489,7 @@ class BrickDomain:
                 n = room
             rows = order[start[1 + m]:start[1 + m] + n]
             rec = PV[rows].clone()
-            rec[:, :4] = self._shifted(rec[:, :4], m)
+            rec[:, :4] = self._shifted(rec[:, :4], self.mig_shift[m], self.mig_wrap)
             o = self.mig_off[m]
             self.mig_send[o + 1:o + 1 + n] = rec
             hdr_send[o, 0] = n
@@ -531,7 +560,7 @@ class BrickDomain:
             rows = [torch.arange(self.cap_int + cstart[cl] - n_int, self.cap_int + cstart[cl + 1] - n_int, device=s.pos.device)
                     for cl in range(1, self.n_classes) if self._msg_takes_class(m, cl)]
             rows = torch.cat(rows)[:self.ghost_cap[m]]
-            buf = self._shifted(s.pos[rows], m)
+            buf = self._shifted(s.pos[rows], self.shift[m], self.halo_wrap)
             self.halo_send[self.ghost_off[m]:self.ghost_off[m] + len(rows)] = buf
 
     def nve_step(self, dt):

@@ -20,7 +20,8 @@ struct BrickArgs {
     unsigned cap_int, cap_bnd;
     unsigned ghost_cap[HTFS_BRICK_MAX_MSG], ghost_off[HTFS_BRICK_MAX_MSG];
     unsigned mig_cap[HTFS_BRICK_MAX_MSG], mig_off[HTFS_BRICK_MAX_MSG];
-    T shift[HTFS_BRICK_MAX_MSG][3];
+    T shift[HTFS_BRICK_MAX_MSG][3], mig_shift[HTFS_BRICK_MAX_MSG][3];
+    int halo_wrap, mig_wrap;
     T box_lo[3], box_L[3], box_Linv[3];
 };
 
@@ -43,8 +44,13 @@ static BrickArgs<T> make_args(const htfs_brick *g) {
         a.ghost_off[m] = g->ghost_off[m];
         a.mig_cap[m] = g->mig_cap[m];
         a.mig_off[m] = g->mig_off[m];
-        for (int c = 0; c < 3; ++c) a.shift[m][c] = (T)g->shift[m][c];
+        for (int c = 0; c < 3; ++c) {
+            a.shift[m][c] = (T)g->shift[m][c];
+            a.mig_shift[m][c] = (T)g->mig_shift[m][c];
+        }
     }
+    a.halo_wrap = g->halo_wrap;
+    a.mig_wrap = g->mig_wrap;
     for (int c = 0; c < 3; ++c) {
         a.box_lo[c] = (T)g->box_lo[c];
         a.box_L[c] = (T)g->box_L[c];
@@ -74,13 +80,12 @@ __device__ __forceinline__ bool msg_takes_class(int m, int ndim, unsigned c) {
     return ok;
 }
 
-// a position as message m carries it: shifted (replica mode) and wrapped back into the global box, the integrator's wrap
+// a position as a message carries it: shifted by `sh` and, if asked, wrapped back into the global box (the integrator's wrap)
 template <typename T, typename V4>
-__device__ __forceinline__ V4 shifted(V4 p, const BrickArgs<T> &a, int m) {
-    if (!a.replica) return p;
-    if (a.shift[m][0] != (T)0) p.x = wrap1<T>(p.x + a.shift[m][0], a.box_lo[0], a.box_L[0], a.box_Linv[0], 1);
-    if (a.shift[m][1] != (T)0) p.y = wrap1<T>(p.y + a.shift[m][1], a.box_lo[1], a.box_L[1], a.box_Linv[1], 1);
-    if (a.shift[m][2] != (T)0) p.z = wrap1<T>(p.z + a.shift[m][2], a.box_lo[2], a.box_L[2], a.box_Linv[2], 1);
+__device__ __forceinline__ V4 shifted(V4 p, const BrickArgs<T> &a, const T (&sh)[3], int wrap) {
+    if (sh[0] != (T)0) p.x = wrap ? wrap1<T>(p.x + sh[0], a.box_lo[0], a.box_L[0], a.box_Linv[0], 1) : p.x + sh[0];
+    if (sh[1] != (T)0) p.y = wrap ? wrap1<T>(p.y + sh[1], a.box_lo[1], a.box_L[1], a.box_Linv[1], 1) : p.y + sh[1];
+    if (sh[2] != (T)0) p.z = wrap ? wrap1<T>(p.z + sh[2], a.box_lo[2], a.box_L[2], a.box_Linv[2], 1) : p.z + sh[2];
     return p;
 }
 
@@ -170,7 +175,7 @@ __global__ __launch_bounds__(256) void brick_pack_mig_kernel(const V4 *__restric
     }
     if (j - 1u >= n) return;
     const unsigned src = order[first + j - 1u];
-    send[2 * (size_t)r] = shifted<T>(pos[src], a, m);
+    send[2 * (size_t)r] = shifted<T>(pos[src], a, a.mig_shift[m], a.mig_wrap);
     send[2 * (size_t)r + 1] = vel[src];
 }
 
@@ -304,7 +309,7 @@ __global__ __launch_bounds__(256) void brick_pack_halo_kernel(const V4 *__restri
             if (!msg_takes_class(m, a.ndim, c)) continue;
             const unsigned first = counts[HTFS_BC_CLASS + c], n = counts[HTFS_BC_CLASS + c + 1] - first;
             if (j < n) {
-                p = shifted<T>(pos[a.cap_int + (first - n_int) + j], a, m);
+                p = shifted<T>(pos[a.cap_int + (first - n_int) + j], a, a.shift[m], a.halo_wrap);
                 break;
             }
             j -= n;
@@ -343,7 +348,7 @@ __global__ __launch_bounds__(256) void brick_nve_halo_kernel(V4 *__restrict__ po
         if (first == 0xFFFFFFFFu) continue;
         const unsigned slot = first + in_class;
         if (slot >= counts[HTFS_BC_MSG + m]) continue; // (beyond the message's capacity: flagged by the rebuild)
-        const V4 q = shifted<T>(p, a, m);
+        const V4 q = shifted<T>(p, a, a.shift[m], a.halo_wrap);
         if (send != nullptr) send[a.ghost_off[m] + slot] = q;
         if (direct != nullptr) direct[a.ghost_off[a.n_msg - 1 - m] + slot] = q;
     }

@@ -101,12 +101,68 @@ inline int key_sort(const unsigned *d_key, unsigned n_max, const unsigned *d_n, 
     return check_launch("key_sort");
 }
 
-// the same when the kernel that produced the keys has already left the per-tile histograms in d_scratch (one launch less)
+// Scatter with the scan folded in (round 5: inside a hipGraph a dependent launch costs >= 4.5 us whatever it computes, and the
+// one-block scan computed a few hundred additions): every tile sums, for each key, the key's total over all tiles and its counts
+// in the tiles before its own -- ntiles x NK words from L2 -- and derives its own offsets; block 0 also publishes start[].
+// tile_hist holds COUNTS (left untouched).
+template <unsigned NK, unsigned TILE>
+__global__ __launch_bounds__(256) void key_scan_scatter_kernel(const unsigned *__restrict__ key, unsigned n, const unsigned *__restrict__ tile_hist,
+                                                               unsigned ntiles, unsigned *__restrict__ start, unsigned *__restrict__ order) {
+    __shared__ unsigned run[NK];
+    __shared__ unsigned tot[NK];
+    __shared__ unsigned wcnt[4][NK];
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (threadIdx.x < NK) {
+        unsigned total = 0, before = 0;
+        for (unsigned t = 0; t < ntiles; ++t) {
+            const unsigned c = tile_hist[t * NK + threadIdx.x];
+            total += c;
+            before += t < blockIdx.x ? c : 0u;
+        }
+        tot[threadIdx.x] = total;
+        run[threadIdx.x] = before;
+    }
+    __syncthreads();
+    if (threadIdx.x < NK) {
+        unsigned base = 0;
+        for (unsigned j = 0; j < threadIdx.x; ++j) base += tot[j];
+        run[threadIdx.x] += base;
+        if (blockIdx.x == 0) {
+            start[threadIdx.x] = base;
+            if (threadIdx.x == NK - 1u) start[NK] = base + tot[NK - 1u];
+        }
+    }
+    __syncthreads();
+    const unsigned base = blockIdx.x * TILE;
+    for (unsigned r = 0; r < TILE / 256; ++r) {
+        const unsigned i = base + r * 256 + threadIdx.x;
+        const bool live = i < n;
+        const unsigned my = live ? (key[i] & (NK - 1u)) : NK;
+        unsigned rank = 0;
+#pragma unroll
+        for (unsigned k = 0; k < NK; ++k) {
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(my == k);
+            if (my == k) rank = ballot_rank(m);
+            if (lane == 0) wcnt[wave][k] = (unsigned)__popcll(m);
+        }
+        __syncthreads();
+        if (live) {
+            unsigned off = run[my] + rank;
+            for (unsigned w = 0; w < wave; ++w) off += wcnt[w][my];
+            order[off] = i;
+        }
+        __syncthreads();
+        if (threadIdx.x < NK) run[threadIdx.x] += wcnt[0][threadIdx.x] + wcnt[1][threadIdx.x] + wcnt[2][threadIdx.x] + wcnt[3][threadIdx.x];
+        __syncthreads();
+    }
+}
+
+// the sort when the kernel that produced the keys has already left the per-tile histograms in d_scratch: ONE launch
 template <unsigned NK, unsigned TILE>
 inline int key_sort_from_hist(const unsigned *d_key, unsigned n_max, unsigned *d_scratch, unsigned *d_start, unsigned *d_order, hipStream_t s) {
     const unsigned ntiles = (n_max + TILE - 1) / TILE;
-    hipLaunchKernelGGL((key_scan_kernel<NK>), dim3(1), dim3(64), 0, s, d_scratch, ntiles, d_start);
-    if (ntiles) hipLaunchKernelGGL((key_scatter_kernel<NK, TILE>), dim3(ntiles), dim3(256), 0, s, d_key, n_max, (const unsigned *)nullptr, d_scratch, d_order);
+    hipLaunchKernelGGL((key_scan_scatter_kernel<NK, TILE>), dim3(ntiles > 0 ? ntiles : 1), dim3(256), 0, s, d_key, n_max, (const unsigned *)d_scratch,
+                       ntiles, d_start, d_order);
     return check_launch("key_sort");
 }
 

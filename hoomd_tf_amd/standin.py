@@ -190,7 +190,8 @@ class CellNlist:
     def _ncell(self):
         """cells per direction and stencil half-width: cells at least r_list / 2 wide (5 per direction
         searched) when the box holds >= 5 of them, else at least r_list wide (3 searched), else one."""
-        L = self.sys.box3x3[1] - self.sys.box3x3[0]
+        b3, _ = self._search_box()
+        L = b3[1] - b3[0]
         n = np.ones(3, dtype=int)
         w = np.zeros(3, dtype=int)
         for d in range(3):
@@ -202,10 +203,22 @@ class CellNlist:
                 n[d], w[d] = coarse, 1
         return n, w
 
+    def _search_box(self):
+        """(box3x3, periodic) the list is binned and searched on: the system's box, or -- under a BrickDomain with a local cell
+        grid -- the brick + its ghost layer, not periodic along the decomposed axes (brick.BrickDomain.nlist_box)."""
+        if self.domain is not None and getattr(self.domain, "local_grid", False):
+            return self.domain.nlist_box()
+        return self.sys.box3x3, self.sys.periodic
+
     def build(self):
         s = self.sys
         if self.domain is not None:
             self.domain.rebuild()  # Communicator: migrate particles, re-plan + fill ghosts
+        b3, per = self._search_box()
+        if getattr(self, "_sbox_key", None) != (b3.tobytes(), per):
+            self._sbox_key = (np.asarray(b3).tobytes(), per)
+            self._sbox = _lib.make_box(np.asarray(b3), per)
+        sbox = self._sbox
         Ntot = s.N + s.n_ghost
         n, w = self._ncell()
         n3 = (C.c_int * 3)(*[int(x) for x in n])
@@ -223,7 +236,7 @@ class CellNlist:
             # captured step carries by address
             self._ranges = torch.empty(4 * ncell * int((2 * w[1] + 1) * (2 * w[2] + 1)), dtype=torch.int32, device=s.device)
         cell_of, order, cell_start, pos_sorted = self._cell_of, self._order, self._cell_start, self._pos_sorted
-        check(lib.htfs_cell_index(s.pos.data_ptr(), s.scalar_code, Ntot, C.byref(s.box), C.byref(n3),
+        check(lib.htfs_cell_index(s.pos.data_ptr(), s.scalar_code, Ntot, C.byref(sbox), C.byref(n3),
                                   cell_of.data_ptr(), stream))
         if self.sort_particles and s.N > 0:
             key = cell_of[: s.N].to(torch.int64)
@@ -266,7 +279,7 @@ class CellNlist:
                     self.domain.attach_n_neigh(self.n_neigh)   # a rebuild empties the rows that became inert
             if self.nlist is None or self.nlist.numel() != s.N * self.pitch:
                 self.nlist = torch.empty(s.N * self.pitch, dtype=torch.int32, device=s.device)
-            check(lib.htfs_build_nlist(s.pos.data_ptr(), pos_sorted.data_ptr(), s.scalar_code, s.N, Ntot, C.byref(s.box), self.r_list,
+            check(lib.htfs_build_nlist(s.pos.data_ptr(), pos_sorted.data_ptr(), s.scalar_code, s.N, Ntot, C.byref(sbox), self.r_list,
                                        C.byref(n3), C.byref(w3), cell_start.data_ptr(), self.pitch, int(self.type_split),
                                        self.n_neigh.data_ptr(), self.head_list.data_ptr(), self.nlist.data_ptr(),
                                        self._max.data_ptr(), self._ranges.data_ptr(), stream))

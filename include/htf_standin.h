@@ -144,7 +144,13 @@ typedef struct htfs_brick {
     unsigned mig_cap[HTFS_BRICK_MAX_MSG];       /* rows of migration message m, its header row included */
     unsigned mig_off[HTFS_BRICK_MAX_MSG];       /* first row of message m in the migration send buffer / of the message from offset o
                                                  * in the receive buffer */
-    double shift[HTFS_BRICK_MAX_MSG][3];        /* added to the positions message m carries (replica mode; zeros otherwise) */
+    double shift[HTFS_BRICK_MAX_MSG][3];        /* added to the positions HALO message m carries: replica mode -o_d * brick width; with a
+                                                 * brick-local cell grid also the box vector of a message that crosses the periodic
+                                                 * boundary (ghosts then sit next to the brick, as HOOMD wraps its ghosts) */
+    double mig_shift[HTFS_BRICK_MAX_MSG][3];    /* the same for MIGRATION message m (replica mode only: a real migrant has already been
+                                                 * wrapped into its new owner's brick by the integrator) */
+    int halo_wrap, mig_wrap;                    /* wrap a shifted position back into the global box (halo: only when the list is binned
+                                                 * on the global box's grid; migration: replica mode) */
     double box_lo[3], box_L[3];                 /* the global (in replica mode: logical) periodic box: a shifted position is wrapped
                                                  * back into it, as the integrator wraps (ghosts and migrants keep coordinates the
                                                  * cell list can bin; the pair-vector build takes the minimum image anyway) */

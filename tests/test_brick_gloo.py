@@ -29,7 +29,7 @@ def _ids(w):
     return (w.contiguous().view(torch.int64) & 0xFFFFFFFF).numpy()
 
 
-def _worker(rank, world, port, grid, fractions, q, n, expect_interior):
+def _worker(rank, world, port, grid, fractions, q, n, expect_interior, local_grid=False):
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
@@ -65,11 +65,26 @@ def _worker(rank, world, port, grid, fractions, q, n, expect_interior):
             system = standin.System(pos[mine], L, types=ids[mine], dtype=torch.float64, device="cpu")
             system.vel = torch.from_numpy(vel[mine]).clone()
             if kind == "brick":
-                return system, BrickDomain(system, rank, grid, r_ghost=rcut + rbuf, r_buff=rbuf, fractions=fractions, n_global=n * n)
+                return system, BrickDomain(system, rank, grid, r_ghost=rcut + rbuf, r_buff=rbuf, fractions=fractions, n_global=n * n,
+                                           local_grid=local_grid)
             return system, SlabDomain(system, rank, world, r_ghost=rcut + rbuf, fractions=None if fractions is None else fractions[0])
 
         system, dom = make("brick")
-        slab_sys, slab = make("slab") if grid[1] == 1 else (None, None)
+        slab_sys, slab = make("slab") if grid[1] == 1 and not local_grid else (None, None)
+
+        def ghosts_are_their_owners(g_xyz, gid, global_pos, fresh=False):
+            if not local_grid:
+                np.testing.assert_array_equal(g_xyz, global_pos[gid])
+                return
+            # a local cell grid: a ghost sits NEXT TO the brick -- its owner's position, moved by whole box vectors where its
+            # message crossed the periodic boundary -- inside the brick + ghost layer
+            d = g_xyz - global_pos[gid]
+            k = np.round(d / L)
+            np.testing.assert_allclose(d, k * L, rtol=0, atol=1e-12)
+            assert np.all(np.abs(k) <= 1) and np.all(k[:, 2] == 0)
+            b3, per = dom.nlist_box()
+            for ax in dom.axes:   # (right after a rebuild, which is when the list is binned)
+                assert per[ax] == 0 and (not fresh or np.all((g_xyz[:, ax] >= b3[0][ax]) & (g_xyz[:, ax] < b3[1][ax])))
         cap = dom.cap
         assert system.N == cap and system.n_ghost == dom.n_ghost_cap and system.pos.shape[0] == cap + dom.n_ghost_cap
 
@@ -94,7 +109,7 @@ def _worker(rank, world, port, grid, fractions, q, n, expect_interior):
             g = p_all[cap:]
             glive = ~np.isnan(g[:, 0])
             gid = _ids(system.pos[cap:, 3])[glive]
-            np.testing.assert_array_equal(g[glive, :3], global_pos[gid])
+            ghosts_are_their_owners(g[glive, :3], gid, global_pos, fresh=True)
             np.testing.assert_array_equal(p_all[:cap][live, :3], global_pos[my_ids])
             # (3) forces over local + ghost rows == single-domain forces (inert rows: no neighbors, zero force)
             with np.errstate(invalid="ignore"):
@@ -157,7 +172,7 @@ def _worker(rank, world, port, grid, fractions, q, n, expect_interior):
                 dom.exchange()
             g = system.pos[cap:]
             glive = ~torch.isnan(g[:, 0])
-            np.testing.assert_array_equal(g[glive, :3].numpy(), gpos[_ids(g[:, 3])[glive.numpy()]])
+            ghosts_are_their_owners(g[glive, :3].numpy(), _ids(g[:, 3])[glive.numpy()], gpos)
         ids_after, live = check(gpos)
         slab_same()
         moved = torch.tensor([dom.n_migrated])
@@ -197,13 +212,15 @@ CASES = [((2, 1, 1), None, 32, True), ((2, 1, 1), {0: [0.33], 1: None, 2: None},
          ((3, 2, 1), {0: [0.3, 0.62], 1: [0.45], 2: None}, 40, True)]
 
 
-@pytest.mark.parametrize("grid,fractions,n,interior", CASES)
-def test_brick_domain_gloo(grid, fractions, n, interior):
+@pytest.mark.parametrize("grid,fractions,n,interior,local_grid", [c + (False,) for c in CASES] + [((4, 2, 1), None, 32, True, True),
+                                                                                                   ((3, 1, 1), None, 32, True, True),
+                                                                                                   ((2, 2, 1), None, 32, True, True)])
+def test_brick_domain_gloo(grid, fractions, n, interior, local_grid):
     world = grid[0] * grid[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, grid, fractions, q, n, interior)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, grid, fractions, q, n, interior, local_grid)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=600) for _ in procs]

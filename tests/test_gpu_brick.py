@@ -93,8 +93,9 @@ def test_brick_kernels_match_torch(htf, cuda, grid, dtype):
             assert np.array_equal(ck[_lib.BC_CLASS:_lib.BC_CLASS + 17], ct[_lib.BC_CLASS:_lib.BC_CLASS + 17])
 
 
+@pytest.mark.parametrize("local_grid", [True, False])
 @pytest.mark.parametrize("grid,transport", [((8, 1, 1), "local"), ((4, 2, 1), "local"), ((8, 1, 1), "native"), ((4, 2, 1), "native")])
-def test_replica_brick_forces_equal_the_replicated_box(htf, cuda, grid, transport):
+def test_replica_brick_forces_equal_the_replicated_box(htf, cuda, grid, transport, local_grid):
     """Replica mode is a physical system -- the brick repeated grid times: forces of the one rank's rows (interior rows while the
     halo is in flight, boundary rows behind it) == the single-domain forces of the replicated box, through an MD run with
     migration (particles leave through a face and re-enter through the opposite one).  ``native``: the halo and the migration
@@ -108,8 +109,10 @@ def test_replica_brick_forces_equal_the_replicated_box(htf, cuda, grid, transpor
     rcut, rbuf, NN = 2.5, 0.4, 96
     sysm, Lg, lo = _replica_system(standin, pos, vel, Lb, grid, cuda)
     nl = standin.CellNlist(sysm, r_cut=rcut, r_buff=rbuf, check_period=1)
-    dom = nl.domain = BrickDomain(sysm, 0, grid, r_ghost=rcut + rbuf, r_buff=rbuf, replica=True, transport=transport)
+    dom = nl.domain = BrickDomain(sysm, 0, grid, r_ghost=rcut + rbuf, r_buff=rbuf, replica=True, transport=transport, local_grid=local_grid)
     nl.build()
+    if local_grid:   # the list is binned on the brick + ghost layer alone: 1 / px / py of the logical box's cells (+ the layer)
+        assert nl._grid[2] < 0.6 * np.prod(np.floor(Lg / ((rcut + rbuf) / 2.0)))
     ctx = htf.Context(r_cut=rcut, nneighs=NN, scalar_dtype=torch.float32, max_n=sysm.N)
     ctx.set_potential(htf.Potential.lj())
     nve = standin.NVE(sysm, 0.005)
@@ -130,7 +133,8 @@ def test_replica_brick_forces_equal_the_replicated_box(htf, cuda, grid, transpor
     # everybody is still in the brick (a migrant shifted the wrong way -- both faces of an axis with two bricks lead to the same
     # neighbor, the shift differs -- would sit a brick width outside), give or take what moves between two rebuilds
     for d in dom.axes:
-        assert np.all((p[:, d] >= dom.lo[d] - 0.25) & (p[:, d] < dom.hi[d] + 0.25)), d
+        q = p[:, d] - np.floor((p[:, d] - dom.lo[d] + 1.0) / Lg[d]) * Lg[d]      # (the integrator wraps into the logical box)
+        assert np.all((q >= dom.lo[d] - 0.25) & (q < dom.hi[d] + 0.25)), d
     kT = float((sysm.vel[live, :3].double() ** 2).sum() / (3 * len(live)))
     assert 0.7 < kT < 1.3, kT
     got = sysm.force[live].cpu().numpy()
@@ -193,7 +197,9 @@ def _slab_twin_worker(rank, world, port, q, per_slab):
             if kind == "slab":
                 nl.domain = SlabDomain(sysm, rank, world, r_ghost=rcut + rbuf)
             else:
-                nl.domain = BrickDomain(sysm, rank, (world, 1, 1), r_ghost=rcut + rbuf, r_buff=rbuf)
+                # (ghosts at their owner's coordinates, the list binned on the global box's grid: SlabDomain's conventions, hence
+                #  its neighbor order; the default -- a cell grid local to the brick -- gives the same forces in another order)
+                nl.domain = BrickDomain(sysm, rank, (world, 1, 1), r_ghost=rcut + rbuf, r_buff=rbuf, local_grid=False)
                 assert nl.domain.kernels
             nl.build()
             ctx = htf.Context(r_cut=rcut, nneighs=NN, scalar_dtype=torch.float32, max_n=sysm.N)
