@@ -123,6 +123,7 @@ void bind(py::module &m, const char *name, R (*fn)(A...)) {
     X(htfs_set_gate) \
     X(htfs_commit_rebuild) \
     X(htfs_rebuild_nlist) \
+    X(htfs_rebuild_nlist_ghosts) \
     X(htfs_check_rebuild_nlist) \
     X(htfs_slab_classify) \
     X(htfs_key_sort16) \

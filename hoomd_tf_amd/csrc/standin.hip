@@ -435,7 +435,7 @@ __global__ __launch_bounds__(256) void bins_finish_kernel(RangesArgs ra, unsigne
     }
     const unsigned i = (blockIdx.x - nb_ranges) * blockDim.x + threadIdx.x;
     if (i == 0 && counter != nullptr) *counter += 1u;
-    if (i >= n) return;
+    if (i >= n || i >= ra.cell_start[ra.nx * ra.ny * ra.nz]) return; // (arrays with inert rows: only the binned particles have an entry)
     const unsigned k = (unsigned)order[i];
     V p = src[k];
     if (ref != nullptr && k < n_ref) ref[k] = p; // (order is a permutation: every reference position is written once)
@@ -854,33 +854,54 @@ extern "C" int htfs_build_nlist(const void *d_pos, const void *d_pos_sorted, int
 // htfs_commit_rebuild on the same arguments -- in six launches instead of nine (index + count in one kernel; range table,
 // sorted copy and commit in one): the small kernels are launch- and latency-bound, and a gated rebuild pays for every one of
 // them even when the gate is closed.
-extern "C" int htfs_rebuild_nlist(const void *d_pos, int dtype, unsigned N, const htf_box *box, double r_list, const int *ncell3,
-                                  const int *stencil3, unsigned *d_cell_of, unsigned *d_scratch, unsigned *d_cell_start,
-                                  unsigned *d_order, void *d_pos_sorted, unsigned pitch, int type_split, unsigned *d_n_neigh,
-                                  unsigned *d_head_list, unsigned *d_nlist, unsigned *d_max_neigh, void *d_ref,
-                                  unsigned *d_counter, void *d_ranges, htf_stream stream) {
+static int rebuild_nlist_impl(const void *d_pos, int dtype, unsigned N, unsigned Ntot, const htf_box *box, double r_list, const int *ncell3,
+                              const int *stencil3, unsigned *d_cell_of, unsigned *d_scratch, unsigned *d_cell_start,
+                              unsigned *d_order, void *d_pos_sorted, unsigned pitch, int type_split, unsigned *d_n_neigh,
+                              unsigned *d_head_list, unsigned *d_nlist, unsigned *d_max_neigh, void *d_ref,
+                              unsigned *d_counter, void *d_ranges, htf_stream stream) {
     using namespace htf;
     HTF_REQUIRE(d_pos && box && ncell3 && stencil3 && d_cell_of && d_scratch && d_cell_start && d_order && d_pos_sorted,
                 "htfs_rebuild_nlist: null pointer");
+    HTF_REQUIRE(Ntot >= N, "htfs_rebuild_nlist: Ntot %u < N %u", Ntot, N);
     if (N == 0) return HTF_OK;
     const unsigned ncell = (unsigned)(ncell3[0] * ncell3[1] * ncell3[2]);
     HTF_REQUIRE(ncell > 0, "htfs_rebuild_nlist: no cells");
     hipStream_t s = (hipStream_t)stream;
     unsigned *count = d_scratch, *cursor = d_scratch + ncell;
     if (int rc = zero_counts_if_needed(count, ncell, s)) return rc; // (as htfs_cell_sort)
-    const unsigned grid = (N + 255) / 256;
+    const unsigned grid = (Ntot + 255) / 256;
     if (dtype == HTF_F32)
-        hipLaunchKernelGGL((cell_index_count_kernel<float>), dim3(grid), dim3(256), 0, s, (const float4 *)d_pos, N, make_sbox<float>(box),
+        hipLaunchKernelGGL((cell_index_count_kernel<float>), dim3(grid), dim3(256), 0, s, (const float4 *)d_pos, Ntot, make_sbox<float>(box),
                            ncell3[0], ncell3[1], ncell3[2], d_cell_of, count, g_gate);
     else
-        hipLaunchKernelGGL((cell_index_count_kernel<double>), dim3(grid), dim3(256), 0, s, (const double4 *)d_pos, N, make_sbox<double>(box),
+        hipLaunchKernelGGL((cell_index_count_kernel<double>), dim3(grid), dim3(256), 0, s, (const double4 *)d_pos, Ntot, make_sbox<double>(box),
                            ncell3[0], ncell3[1], ncell3[2], d_cell_of, count, g_gate);
     hipLaunchKernelGGL(cell_scan_kernel, dim3((ncell + kScanChunk - 1) / kScanChunk), dim3(kScanThreads), 0, s, count, ncell, d_cell_start, cursor, g_gate);
-    hipLaunchKernelGGL(cell_scatter_kernel, dim3(grid), dim3(256), 0, s, d_cell_of, N, cursor, d_order, g_gate);
+    hipLaunchKernelGGL(cell_scatter_kernel, dim3(grid), dim3(256), 0, s, d_cell_of, Ntot, cursor, d_order, g_gate);
     hipLaunchKernelGGL(cell_order_kernel, dim3((ncell + 255) / 256), dim3(256), 0, s, d_cell_start, ncell, d_order, count, g_gate);
-    const FinishArgs fin = {d_pos_sorted, (const int *)d_order, N, d_ref, N, d_counter};
-    return build_nlist_impl(d_pos, d_pos_sorted, dtype, N, N, box, r_list, ncell3, stencil3, d_cell_start, pitch, type_split, d_n_neigh,
+    const FinishArgs fin = {d_pos_sorted, (const int *)d_order, Ntot, d_ref, N, d_counter};
+    return build_nlist_impl(d_pos, d_pos_sorted, dtype, N, Ntot, box, r_list, ncell3, stencil3, d_cell_start, pitch, type_split, d_n_neigh,
                             d_head_list, d_nlist, d_max_neigh, d_ranges, stream, &fin);
+}
+
+extern "C" int htfs_rebuild_nlist(const void *d_pos, int dtype, unsigned N, const htf_box *box, double r_list, const int *ncell3,
+                                  const int *stencil3, unsigned *d_cell_of, unsigned *d_scratch, unsigned *d_cell_start,
+                                  unsigned *d_order, void *d_pos_sorted, unsigned pitch, int type_split, unsigned *d_n_neigh,
+                                  unsigned *d_head_list, unsigned *d_nlist, unsigned *d_max_neigh, void *d_ref,
+                                  unsigned *d_counter, void *d_ranges, htf_stream stream) {
+    return rebuild_nlist_impl(d_pos, dtype, N, N, box, r_list, ncell3, stencil3, d_cell_of, d_scratch, d_cell_start, d_order, d_pos_sorted,
+                              pitch, type_split, d_n_neigh, d_head_list, d_nlist, d_max_neigh, d_ref, d_counter, d_ranges, stream);
+}
+
+// the same for a list whose candidates include ghosts behind the N local rows (and inert rows anywhere: a decomposed system's
+// fixed-capacity arrays): Ntot positions binned, N rows searched and committed -- six launches where the separate calls take ten
+extern "C" int htfs_rebuild_nlist_ghosts(const void *d_pos, int dtype, unsigned N, unsigned Ntot, const htf_box *box, double r_list,
+                                         const int *ncell3, const int *stencil3, unsigned *d_cell_of, unsigned *d_scratch,
+                                         unsigned *d_cell_start, unsigned *d_order, void *d_pos_sorted, unsigned pitch, int type_split,
+                                         unsigned *d_n_neigh, unsigned *d_head_list, unsigned *d_nlist, unsigned *d_max_neigh, void *d_ref,
+                                         unsigned *d_counter, void *d_ranges, htf_stream stream) {
+    return rebuild_nlist_impl(d_pos, dtype, N, Ntot, box, r_list, ncell3, stencil3, d_cell_of, d_scratch, d_cell_start, d_order, d_pos_sorted,
+                              pitch, type_split, d_n_neigh, d_head_list, d_nlist, d_max_neigh, d_ref, d_counter, d_ranges, stream);
 }
 
 // A whole check step of a device-decided list in ONE call (the host's share of a small system's step is its enqueue): the

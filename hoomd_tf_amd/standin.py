@@ -236,6 +236,30 @@ class CellNlist:
             # captured step carries by address
             self._ranges = torch.empty(4 * ncell * int((2 * w[1] + 1) * (2 * w[2] + 1)), dtype=torch.int32, device=s.device)
         cell_of, order, cell_start, pos_sorted = self._cell_of, self._order, self._cell_start, self._pos_sorted
+        if (self.domain is not None and getattr(self.domain, "fixed_capacity", False) and self.n_builds > 0 and not self.sort_particles
+                and self._ref is not None and self._ref.shape[0] == s.N and self.nlist is not None and self.nlist.numel() == s.N * self.pitch):
+            # every rebuild after the first of a fixed-capacity system: nothing to size, nothing to read back -- binning, sorted
+            # copy, range table, search and commit in six launches (htfs_rebuild_nlist_ghosts) where the separate calls take ten
+            capturing = getattr(self, "_capturing", False)
+            if not capturing:
+                self._poll_row_overflow()   # the PREVIOUS build's largest row (pinned copy behind it): no wait
+            check(lib.htfs_rebuild_nlist_ghosts(s.pos.data_ptr(), s.scalar_code, s.N, Ntot, C.byref(sbox), self.r_list, C.byref(n3), C.byref(w3),
+                                                cell_of.data_ptr(), self._bin_scratch.data_ptr(), cell_start.data_ptr(), order.data_ptr(),
+                                                pos_sorted.data_ptr(), self.pitch, int(self.type_split), self.n_neigh.data_ptr(),
+                                                self.head_list.data_ptr(), self.nlist.data_ptr(), self._max.data_ptr(), self._ref.data_ptr(),
+                                                None, self._ranges.data_ptr(), stream))
+            if getattr(self, "_max_host", None) is None:
+                self._max_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self._max_host.copy_(self._max, non_blocking=True)
+            if not capturing:
+                self._max_event = torch.cuda.Event()
+                self._max_event.record(torch.cuda.current_stream(s.device))
+            if self._rule is not None:
+                self._rule.reset()
+                self._dd_prev = None
+            self._grid = (n3, w3, ncell)
+            self.n_builds += 1
+            return
         check(lib.htfs_cell_index(s.pos.data_ptr(), s.scalar_code, Ntot, C.byref(sbox), C.byref(n3),
                                   cell_of.data_ptr(), stream))
         if self.sort_particles and s.N > 0:

@@ -86,6 +86,13 @@ HTF_API int htfs_rebuild_nlist(const void *d_pos, int dtype, unsigned N, const h
                                unsigned *d_head_list, unsigned *d_nlist, unsigned *d_max_neigh, void *d_ref,
                                unsigned *d_counter, void *d_ranges, htf_stream stream);
 
+/* the same with ghosts (and inert rows): Ntot >= N positions are binned, the N local rows searched and committed */
+HTF_API int htfs_rebuild_nlist_ghosts(const void *d_pos, int dtype, unsigned N, unsigned Ntot, const htf_box *box, double r_list,
+                                      const int *ncell3, const int *stencil3, unsigned *d_cell_of, unsigned *d_scratch,
+                                      unsigned *d_cell_start, unsigned *d_order, void *d_pos_sorted, unsigned pitch, int type_split,
+                                      unsigned *d_n_neigh, unsigned *d_head_list, unsigned *d_nlist, unsigned *d_max_neigh, void *d_ref,
+                                      unsigned *d_counter, void *d_ranges, htf_stream stream);
+
 /* One check step of a device-decided list in one call: *d_disp2 <- 0, htfs_max_displacement2 into it, htfs_set_gate(d_disp2,
  * threshold2), htfs_rebuild_nlist (d_stat2[0] = largest row, d_stat2[1] = rebuild counter), htfs_set_gate(NULL, 0), and -- if
  * h_stat2 (pinned host memory) is given -- an asynchronous copy of the two status words for a later check to read. */
