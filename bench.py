@@ -50,8 +50,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="lj", choices=["lj", "wca", "mlp", "mlp-fp32", "mlp-split", "mlp-bf16", "mlp-train", "eds", "ref-lj256", "c1", "ex01", "generic-lj", "dd-self"])
-    ap.add_argument("--grid", default=None, help="rank grid PXxPYx1: --gpus N > 1: how the box is cut (default: slabs along x; 8 ranks of the "
-                                                 "strong-scaling box: 4x2x1); dd-self: the grid whose one brick this GPU runs (default 8x1x1)")
+    ap.add_argument("--grid", default=None, help="rank grid PXxPYx1: --gpus N > 1: how the box is cut (default: slabs along x; e.g. 4x2x1 "
+                                                 "for 8 ranks); dd-self: the grid whose one brick this GPU runs (default 8x1x1)")
     ap.add_argument("--transport", default="all", help="dd-self: local | native | all")
     ap.add_argument("--train-period", type=int, default=100, help="mlp-train (C5b): force-matching step every this many MD steps")
     ap.add_argument("--cells", type=int, default=32, help="fcc cells per side (N = 4 cells^3 per rank)")
@@ -1009,13 +1009,15 @@ def run_md(args, E, workload, variants=True, cpu=True):
     # and keeps the particles of its slab.  weak: each rank owns one such block; the global periodic box
     # is `world` blocks side by side along x (config 5 at 8 ranks: 1.05 M particles, 8 x 1 x 1 slabs).
     strong = world > 1 and args.scaling == "strong"
-    # the rank grid: slabs along x, except 8 ranks of the strong-scaling box -- 8 slabs of the 131 072-particle box are 6.72 thick
-    # (< 2 r_ghost: no row without a ghost neighbor), a 4 x 2 cut keeps 37 % of the rows interior; --grid overrides
+    # the rank grid: slabs along x by default; --grid PXxPYx1 cuts bricks.  (8 slabs of the 131 072-particle box are 6.72 thick,
+    # < 2 r_ghost: no row without a ghost neighbor, where a 4 x 2 cut keeps 37 % of the rows interior -- but a grouped RCCL
+    # exchange of 8 messages was measured at 35 us against 17 for 2, profiles/r05_rccl_graph_probe.txt, more than the interior rows
+    # can hide at 16 k rows per rank: DESIGN.md 6.4.  The 2-D cut pays with a latency-free transport or larger bricks.)
     if world > 1 and args.grid:
         grid = tuple(int(v) for v in args.grid.lower().split("x"))
         grid = grid + (1,) * (3 - len(grid))
     else:
-        grid = (4, 2, 1) if (world == 8 and strong) else (world, 1, 1)
+        grid = (world, 1, 1)
     if int(np.prod(grid)) != world or (not strong and grid != (world, 1, 1)):
         raise SystemExit("--grid %s does not describe %d ranks (weak scaling: slabs along x)" % (args.grid, world))
     domain_kind = os.environ.get("HTF_BENCH_DOMAIN", "brick")   # "slab": round 4's variable-length SlabDomain

@@ -452,7 +452,7 @@ def test_deferred_device_decision_equals_host_decided(htf, cuda, world, per_slab
         assert msg == "ok", "rank %d failed:\n%s" % (rank, msg)
 
 
-@pytest.mark.parametrize("args", [["--gpus", "2"], ["--gpus", "3"], ["--gpus", "2", "--scaling", "weak"], ["--gpus", "8"],
+@pytest.mark.parametrize("args", [["--gpus", "2"], ["--gpus", "3"], ["--gpus", "2", "--scaling", "weak"], ["--gpus", "8", "--grid", "4x2x1"],
                                   ["--gpus", "4", "--grid", "2x2x1"]])
 def test_bench_starts_its_own_ranks(htf, cuda, args):
     """`python bench.py --gpus N` with no launcher around it (how the driver calls it): the parent starts the N rank
@@ -476,7 +476,7 @@ def test_bench_starts_its_own_ranks(htf, cuda, args):
     assert d["value"] > 0 and abs(d["value"] * d["config"]["global_particles"] - d["particle_steps_per_s"]) < 1e-6 * d["particle_steps_per_s"]
     assert -7.0 < d["energy_per_particle"] < -4.0 and 0.5 < d["kT_final"] < 1.5   # still the same liquid
     assert d["config"]["halo"]["ghosts_rank0"] > 0 and "BrickDomain" in d["config"]["halo"]["domain"]
-    assert d["config"]["parallelism"] == {"8": "dd4x2x1", "4": "dd2x2x1"}.get(args[1], "dd%sx1x1" % args[1])
+    assert d["config"]["parallelism"] == ("dd" + args[3] if "--grid" in args else "dd%sx1x1" % args[1])
 
 
 def _self_exchange():
