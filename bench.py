@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--workload", default="lj", choices=["lj", "wca", "mlp", "mlp-fp32", "mlp-split", "mlp-bf16", "mlp-train", "eds", "ref-lj256", "c1", "ex01", "generic-lj", "dd-self"])
     ap.add_argument("--grid", default=None, help="rank grid PXxPYx1: --gpus N > 1: how the box is cut (default: slabs along x; e.g. 4x2x1 "
                                                  "for 8 ranks); dd-self: the grid whose one brick this GPU runs (default 8x1x1)")
-    ap.add_argument("--transport", default="all", help="dd-self: local | native | all")
+    ap.add_argument("--transport", default="all", help="dd-self: local | peer | native | all")
     ap.add_argument("--train-period", type=int, default=100, help="mlp-train (C5b): force-matching step every this many MD steps")
     ap.add_argument("--cells", type=int, default=32, help="fcc cells per side (N = 4 cells^3 per rank)")
     ap.add_argument("--lattice", default="fcc", choices=["fcc", "sc"], help="fcc: N = 4 cells^3 (C3, C5); sc: N = cells^3 (C2 = sc 32^3 = 32768)")
@@ -328,7 +328,7 @@ def run_dd_self(args, htf, standin, dev):
     pos = pos + 0.05 * a * rng.standard_normal(pos.shape)
     pos = pos - np.floor(pos / Lb) * Lb + lo
     n_rank = len(pos)
-    transports = ["local", "native"] if args.transport == "all" else [args.transport]
+    transports = ["local", "peer", "native"] if args.transport == "all" else [args.transport]
     if not _lib.lib.htf_halo_available():
         transports = [t for t in transports if t != "native"]
     P = args.check_period

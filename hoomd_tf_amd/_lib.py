@@ -45,7 +45,7 @@ class Box(C.Structure):
 
 BRICK_MAX_MSG, BRICK_MAX_P = 8, 64   # include/htf_standin.h HTFS_BRICK_MAX_MSG / _MAX_P
 BC_N_INT, BC_N_BND, BC_N_CAND, BC_N_ARRIVED, BC_FLAGS, BC_REBUILDS, BC_MSG, BC_CLASS, BC_SLOT, BC_WORDS = 0, 1, 2, 3, 4, 5, 8, 16, 64, 192
-BF_LOST, BF_MIG_OVERFLOW, BF_INT_OVERFLOW, BF_BND_OVERFLOW, BF_GHOST_OVERFLOW = 1, 2, 4, 8, 16
+BF_LOST, BF_MIG_OVERFLOW, BF_INT_OVERFLOW, BF_BND_OVERFLOW, BF_GHOST_OVERFLOW, BF_HALO_TIMEOUT = 1, 2, 4, 8, 16, 32
 
 
 class Brick(C.Structure):
@@ -56,6 +56,12 @@ class Brick(C.Structure):
                 ("mig_cap", C.c_uint * BRICK_MAX_MSG), ("mig_off", C.c_uint * BRICK_MAX_MSG),
                 ("shift", (C.c_double * 3) * BRICK_MAX_MSG), ("mig_shift", (C.c_double * 3) * BRICK_MAX_MSG),
                 ("halo_wrap", C.c_int), ("mig_wrap", C.c_int), ("box_lo", C.c_double * 3), ("box_L", C.c_double * 3)]
+
+
+class Peer(C.Structure):
+    """htfs_peer (transport "peer": the halo as direct stores into the neighbors' inboxes)."""
+    _fields_ = [("inbox", C.c_void_p * BRICK_MAX_MSG), ("signal", C.c_void_p * BRICK_MAX_MSG), ("my_inbox", C.c_void_p),
+                ("my_signal", C.c_void_p), ("state", C.c_void_p), ("spin_limit", C.c_uint)]
 
 
 class BrickWork(C.Structure):
@@ -167,6 +173,9 @@ STANDIN_PROTOTYPES = {
     "htfs_brick_migrate_merge": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "htfs_brick_pack_halo": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "htfs_brick_nve_halo": (_i, [_vp, _vp, _vp, _vp, _i, _d, C.POINTER(Box), _vp, _vp, _vp, _vp]),
+    "htfs_brick_nve_halo_peer": (_i, [_vp, _vp, _vp, _vp, _i, _d, C.POINTER(Box), _vp, _vp, _vp]),
+    "htfs_brick_pack_halo_peer": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
+    "htfs_brick_unpack_halo": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "htfs_slab_classify": (_i, [_vp, _i, _u, _vp, _i, _i, _d, _vp, _vp]),
     "htfs_segment_copy": (_i, [_vp, _vp, _u, _u, _vp, _vp, _vp, _vp]),
     "htfs_key_sort16": (_i, [_vp, _u, _vp, _vp, _vp, _vp]),

@@ -195,12 +195,14 @@ class BrickDomain:
         self.transport = transport
         if transport == "local" and not self.replica:
             raise ValueError("transport='local' delivers a rank's messages to itself: replica mode only")
-        if transport not in ("torch", "native", "local"):
-            raise ValueError("transport must be 'torch', 'native' or 'local'")
+        if transport not in ("torch", "native", "local", "peer"):
+            raise ValueError("transport must be 'torch', 'native', 'local' or 'peer'")
         if self.kernels:
             self._make_device_state()
         if transport == "native":
             self._make_native()
+        if transport == "peer":
+            self._make_peer()
 
     # ------------------------------------------------------------------ geometry helpers
     def _neighbor_rank(self, o):
@@ -309,6 +311,43 @@ class BrickDomain:
         else:
             self._native = _NativeHalo.shared(self.rank, self.world, self.group)
 
+    def _make_peer(self):
+        """Transport "peer": every rank owns an inbox ([2][ghost rows] Scalar4: two halves, by the exchange number's parity) and
+        signal words ({sequence, rows} per incoming message); the packing kernels of its NEIGHBORS store into them directly --
+        the same memory for a replica rank, an IPC mapping of it otherwise (torch's CUDA-IPC reductions: hipIpc handles travelling
+        through the process group) -- and htfs_brick_unpack_halo copies what has arrived into the ghost region.  No communication
+        library in the step; the migration messages of a rebuild keep travelling through torch.distributed."""
+        s = self.sys
+        if not self.kernels:
+            raise ValueError("transport='peer' needs the kernels backend")
+        dev, dt = s.pos.device, s.pos.dtype
+        self._peer_inbox = torch.zeros((2, self.n_ghost_cap, 4), dtype=dt, device=dev)
+        self._peer_signal = torch.zeros(2 * _lib.BRICK_MAX_MSG, dtype=torch.int32, device=dev)
+        self._peer_state = torch.zeros(4, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize(dev)
+        self._peer_maps = {}
+        if self.replica:
+            theirs = {self.rank: (self._peer_inbox, self._peer_signal)}
+        else:
+            from torch.multiprocessing.reductions import reduce_tensor
+            mine = (reduce_tensor(self._peer_inbox), reduce_tensor(self._peer_signal))
+            everybody = [None] * self.world
+            dist.all_gather_object(everybody, mine, group=self.group)
+            theirs = {self.rank: (self._peer_inbox, self._peer_signal)}
+            for q in set(self.neighbors):
+                if q != self.rank:
+                    (fi, ai), (fs, as_) = everybody[q]
+                    theirs[q] = (fi(*ai), fs(*as_))      # the neighbor's memory, mapped into this process
+        self._peer_maps = theirs                          # (kept alive: the mappings)
+        pr = self.peer = _lib.Peer()
+        for m in range(self.n_msg):
+            inbox, signal = theirs[self.neighbors[m]]
+            pr.inbox[m], pr.signal[m] = inbox.data_ptr(), signal.data_ptr()
+        pr.my_inbox, pr.my_signal, pr.state = self._peer_inbox.data_ptr(), self._peer_signal.data_ptr(), self._peer_state.data_ptr()
+        pr.spin_limit = int(os.environ.get("HTF_PEER_SPIN", str(1 << 18)))   # x ~0.5 us a poll: a fraction of a second, then HALO_TIMEOUT
+        if not self.replica:
+            dist.barrier(group=self.group)               # nobody stores into an inbox that is not mapped everywhere yet
+
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.sys.pos.device).cuda_stream)
 
@@ -324,7 +363,9 @@ class BrickDomain:
                                  (_lib.BF_MIG_OVERFLOW, "more migrants than a migration message holds"),
                                  (_lib.BF_INT_OVERFLOW, "more interior particles than cap_int = %d" % self.cap_int),
                                  (_lib.BF_BND_OVERFLOW, "more boundary particles than cap_bnd = %d" % self.cap_bnd),
-                                 (_lib.BF_GHOST_OVERFLOW, "more ghosts than a halo message holds")) if f & bit]
+                                 (_lib.BF_GHOST_OVERFLOW, "more ghosts than a halo message holds"),
+                                 (_lib.BF_HALO_TIMEOUT, "a neighbor's halo message did not arrive (transport 'peer': are all ranks stepping?)"))
+                if f & bit]
         raise RuntimeError("BrickDomain (rank %d): %s; construct it with a larger margin" % (self.rank, "; ".join(what)))
 
     def poll_flags(self):
@@ -378,7 +419,7 @@ class BrickDomain:
         """Message m = rows [offs[m], offs[m] + caps[m]) of ``send`` to the neighbor at offset m; the message FROM the neighbor at
         offset index j lands in rows [offs[j], +caps[j]) of ``recv``.  Sends are posted in ascending offset order, receives in
         descending order: between any two ranks the k-th send meets the k-th receive (RCCL matches by order, not by tag)."""
-        if self.replica and self._native is None:
+        if self.replica and self._native is None:   # (a replica rank without RCCL: "local" and "peer")
             for m in range(self.n_msg):
                 j = self._opposite(m)
                 recv[offs[j]:offs[j] + caps[j]] = send[offs[m]:offs[m] + caps[m]]
@@ -567,6 +608,12 @@ class BrickDomain:
         """The integrator's step over the local rows AND the halo messages of the new positions in one launch
         (htfs_brick_nve_halo; the kernels backend): the next exchange_begin() finds the messages packed."""
         s = self.sys
+        if self.transport == "peer":
+            _lib.check(_lib.lib.htfs_brick_nve_halo_peer(C.byref(self.geom), s.pos.data_ptr(), s.vel.data_ptr(), s.force.data_ptr(),
+                                                         s.scalar_code, float(dt), C.byref(s.box), self.counts.data_ptr(),
+                                                         C.byref(self.peer), self._stream()))
+            self._packed = True
+            return
         direct = self.transport == "local"
         _lib.check(_lib.lib.htfs_brick_nve_halo(C.byref(self.geom), s.pos.data_ptr(), s.vel.data_ptr(), s.force.data_ptr(), s.scalar_code,
                                                 float(dt), C.byref(s.box), self.counts.data_ptr(),
@@ -579,6 +626,8 @@ class BrickDomain:
     def overlaps(self):
         """Does a posted halo travel while the interior rows are evaluated?  Not when the pack kernel delivers it itself, and not
         inside a hipGraph capture (where the RCCL calls stay on the captured stream)."""
+        if self.transport == "peer":
+            return True     # stores into the neighbors' inboxes: in flight while the interior rows run, inside a capture too
         return self.transport != "local" and not getattr(self, "_capturing", False)
 
     def exchange_begin(self):
@@ -587,6 +636,12 @@ class BrickDomain:
         s = self.sys
         ghosts = s.pos[self.cap:]
         packed, self._packed = getattr(self, "_packed", False), False
+        if self.kernels and self.transport == "peer":
+            if not packed:
+                _lib.check(_lib.lib.htfs_brick_pack_halo_peer(C.byref(self.geom), s.pos.data_ptr(), s.scalar_code, self.counts.data_ptr(),
+                                                              C.byref(self.peer), self._stream()))
+            self._works = [self]     # exchange_end(): the unpack kernel
+            return
         if self.kernels:
             direct = self.transport == "local"
             if not packed:
@@ -602,6 +657,12 @@ class BrickDomain:
         #  JOINED a capture through an event crashes hipStreamEndCapture -- tools/rccl_graph_probe.py, profiles/r05_rccl_graph_probe.txt)
         self._works = self._exchange(self.halo_send, ghosts, self.ghost_cap, self.ghost_off, TAG_BASE + 16,
                                      overlap=not getattr(self, "_capturing", False))
+
+    def wait(self):
+        """Transport "peer": the receiving half of an exchange (the stream waits on the device; the host does not)."""
+        s = self.sys
+        _lib.check(_lib.lib.htfs_brick_unpack_halo(C.byref(self.geom), s.pos.data_ptr(), s.scalar_code, C.byref(self.peer),
+                                                   self.counts.data_ptr(), self._stream()))
 
     def exchange_end(self):
         if self._works is not None:

@@ -292,7 +292,124 @@ __global__ __launch_bounds__(256) void brick_place_kernel(V4 *__restrict__ pos, 
     }
 }
 
+// ---- transport "peer": rows stored straight into the receiver's inbox, a signal per message (htf_standin.h htfs_peer)
+struct PeerArgs {
+    void *inbox[HTFS_BRICK_MAX_MSG];
+    unsigned *signal[HTFS_BRICK_MAX_MSG];
+    void *my_inbox;
+    unsigned *my_signal;
+    unsigned *state;      // [0] exchanges done, [1] workgroups finished (this launch), [2] timeouts
+    unsigned spin_limit;
+    unsigned rows;        // ghost rows per half of an inbox (sum of the message capacities)
+};
+
+static PeerArgs make_peer(const htfs_peer *p, const htfs_brick *g) {
+    PeerArgs a;
+    for (int m = 0; m < HTFS_BRICK_MAX_MSG; ++m) {
+        a.inbox[m] = p ? p->inbox[m] : nullptr;
+        a.signal[m] = p ? p->signal[m] : nullptr;
+    }
+    a.my_inbox = p ? p->my_inbox : nullptr;
+    a.my_signal = p ? p->my_signal : nullptr;
+    a.state = p ? p->state : nullptr;
+    a.spin_limit = p ? p->spin_limit : 0u;
+    a.rows = g->ghost_off[g->n_msg - 1] + g->ghost_cap[g->n_msg - 1];
+    return a;
+}
+
+// where row `slot` of MY message m lands in the receiver's inbox: half (seq & 1), the region of source offset n_msg - 1 - m
+template <typename V4>
+__device__ __forceinline__ V4 *peer_slot(const PeerArgs &pa, int m, int n_msg, const unsigned *ghost_off, unsigned seq, unsigned slot) {
+    return reinterpret_cast<V4 *>(pa.inbox[m]) + (size_t)(seq & 1u) * pa.rows + ghost_off[n_msg - 1 - m] + slot;
+}
+
+// Called by EVERY thread at the end of a packing kernel: when the launch's last workgroup has stored its rows, publish each
+// message's row count and the new sequence number to its receiver (release at system scope: the rows are visible before the
+// number is) and advance this rank's own counter.
+__device__ __forceinline__ void peer_publish(const PeerArgs &pa, int n_msg, const unsigned *counts, unsigned seq) {
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const unsigned done = __hip_atomic_fetch_add(&pa.state[1], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (done + 1u != gridDim.x) return;
+    pa.state[1] = 0u;
+    for (int m = 0; m < n_msg; ++m) {
+        unsigned *sig = pa.signal[m] + 2 * (n_msg - 1 - m);
+        __hip_atomic_store(sig + 1, counts[HTFS_BC_MSG + m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(sig, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __hip_atomic_store(&pa.state[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ---- K8 (every step): the halo messages, packed; a message's rows beyond its count are inert
+template <typename T, typename V4>
+__global__ __launch_bounds__(256) void brick_pack_halo_peer_kernel(const V4 *__restrict__ pos, BrickArgs<T> a, const unsigned *__restrict__ counts,
+                                                                   PeerArgs pa, unsigned total_rows) {
+    const unsigned seq = pa.state[0] + 1u; // (every workgroup reads it before the launch's last one advances it)
+    const unsigned r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < total_rows) {
+        int m = 0;
+        while (m + 1 < a.n_msg && r >= a.ghost_off[m + 1]) ++m;
+        unsigned j = r - a.ghost_off[m];
+        const unsigned slot = j;
+        if (j < counts[HTFS_BC_MSG + m]) { // (rows beyond the count are not sent: the receiver fills them from the count)
+            const unsigned nclass = a.ndim == 1 ? 4u : 16u;
+            const unsigned n_int = counts[HTFS_BC_CLASS + 1];
+            for (unsigned c = 1; c < nclass; ++c) {
+                if (!msg_takes_class(m, a.ndim, c)) continue;
+                const unsigned first = counts[HTFS_BC_CLASS + c], n = counts[HTFS_BC_CLASS + c + 1] - first;
+                if (j < n) {
+                    *peer_slot<V4>(pa, m, a.n_msg, a.ghost_off, seq, slot) = shifted<T>(pos[a.cap_int + (first - n_int) + j], a, a.shift[m], a.halo_wrap);
+                    break;
+                }
+                j -= n;
+            }
+        }
+    }
+    peer_publish(pa, a.n_msg, counts, seq);
+}
+
+// the receiving side: wait for the sequence number of every incoming message, then its rows (inert beyond the sender's count)
+// from the inbox half of that number into the ghost region
+template <typename T, typename V4>
+__global__ __launch_bounds__(256) void brick_unpack_halo_kernel(V4 *__restrict__ pos, BrickArgs<T> a, PeerArgs pa, unsigned total_rows,
+                                                                unsigned *__restrict__ counts) {
+    const unsigned seq = pa.state[0]; // (advanced by this step's packing kernel, earlier in the stream)
+    const unsigned r = blockIdx.x * blockDim.x + threadIdx.x;
+    // a 256-row workgroup may straddle two messages: every wave waits for the message of its own first row
+    const unsigned r0 = min(blockIdx.x * blockDim.x + (threadIdx.x & ~63u), total_rows - 1u);
+    int j0 = 0;
+    while (j0 + 1 < a.n_msg && r0 >= a.ghost_off[j0 + 1]) ++j0;
+    int jl = j0;
+    while (jl + 1 < a.n_msg && min(r0 + 63u, total_rows - 1u) >= a.ghost_off[jl + 1]) ++jl;
+    bool late = false;
+    for (int j = j0; j <= jl; ++j) {
+        unsigned n = 0;
+        while ((int)(__hip_atomic_load(pa.my_signal + 2 * j, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
+            if (++n > pa.spin_limit) {
+                late = true;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    if (late && (threadIdx.x & 63u) == 0u) {
+        atomicOr(&counts[HTFS_BC_FLAGS], (unsigned)HTFS_BF_HALO_TIMEOUT);
+        atomicAdd(&pa.state[2], 1u);
+    }
+    if (r >= total_rows) return;
+    int j = j0;
+    while (j + 1 < a.n_msg && r >= a.ghost_off[j + 1]) ++j;
+    const unsigned slot = r - a.ghost_off[j];
+    const unsigned cnt = __hip_atomic_load(pa.my_signal + 2 * j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    V4 p = inert_position<V4>();
+    if (slot < cnt && !late) {
+        // (read past the caches: the rows were written by another agent -- or another process -- behind the acquire above)
+        p = load_stream(reinterpret_cast<const V4 *>(pa.my_inbox) + (size_t)(seq & 1u) * pa.rows + r);
+    }
+    pos[a.cap_int + a.cap_bnd + r] = p;
+}
+
 template <typename T, typename V4>
 __global__ __launch_bounds__(256) void brick_pack_halo_kernel(const V4 *__restrict__ pos, BrickArgs<T> a, const unsigned *__restrict__ counts,
                                                               V4 *__restrict__ send, V4 *__restrict__ direct, unsigned total_rows) {
@@ -325,6 +442,36 @@ __global__ __launch_bounds__(256) void brick_pack_halo_kernel(const V4 *__restri
 // class from the class boundaries and its slot in a message from the counts of the classes before it.  One launch where the
 // integrator and the packer were two (each >= 4.5 us inside a hipGraph whatever it moves).  The messages' inert tails were
 // written by the rebuild's own pack and stay put until the next one.
+template <typename T, typename V4>
+__global__ __launch_bounds__(256) void brick_nve_halo_peer_kernel(V4 *__restrict__ pos, V4 *__restrict__ vel, const V4 *__restrict__ force,
+                                                                  T dt, SBox<T> box, BrickArgs<T> a, const unsigned *__restrict__ counts,
+                                                                  PeerArgs pa) {
+    const unsigned seq = pa.state[0] + 1u;
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < a.cap_int + a.cap_bnd) {
+        V4 p = pos[i], v = vel[i];
+        nve_advance<T>(p, v, force[i], dt, box);
+        pos[i] = p;
+        vel[i] = v;
+        const unsigned j = i - a.cap_int;
+        if (i >= a.cap_int && j < counts[HTFS_BC_N_BND]) {
+            const unsigned nclass = a.ndim == 1 ? 4u : 16u;
+            const unsigned n_int = counts[HTFS_BC_CLASS + 1];
+            unsigned c = 1;
+            while (c + 1 < nclass && j >= counts[HTFS_BC_CLASS + c + 1] - n_int) ++c;
+            const unsigned in_class = j - (counts[HTFS_BC_CLASS + c] - n_int);
+            for (int m = 0; m < a.n_msg; ++m) {
+                const unsigned first = counts[HTFS_BC_SLOT + c * HTFS_BRICK_MAX_MSG + m];
+                if (first == 0xFFFFFFFFu) continue;
+                const unsigned slot = first + in_class;
+                if (slot >= counts[HTFS_BC_MSG + m]) continue;
+                *peer_slot<V4>(pa, m, a.n_msg, a.ghost_off, seq, slot) = shifted<T>(p, a, a.shift[m], a.halo_wrap);
+            }
+        }
+    }
+    peer_publish(pa, a.n_msg, counts, seq);
+}
+
 template <typename T, typename V4>
 __global__ __launch_bounds__(256) void brick_nve_halo_kernel(V4 *__restrict__ pos, V4 *__restrict__ vel, const V4 *__restrict__ force,
                                                              T dt, SBox<T> box, BrickArgs<T> a, const unsigned *__restrict__ counts,
@@ -474,4 +621,57 @@ extern "C" int htfs_brick_nve_halo(const htfs_brick *g, void *d_pos, void *d_vel
                            (double4 *)d_vel, (const double4 *)d_force, dt, make_sbox<double>(box), make_args<double>(g), d_counts,
                            (double4 *)d_send, (double4 *)d_ghost_direct);
     return check_launch("brick_nve_halo_kernel");
+}
+
+static int check_peer(const htfs_peer *p, const htfs_brick *g, const char *who) {
+    HTF_REQUIRE(p && p->my_inbox && p->my_signal && p->state && p->spin_limit > 0, "%s: incomplete htfs_peer", who);
+    for (int m = 0; m < g->n_msg; ++m) HTF_REQUIRE(p->inbox[m] && p->signal[m], "%s: message %d has no destination", who, m);
+    return HTF_OK;
+}
+
+extern "C" int htfs_brick_pack_halo_peer(const htfs_brick *g, const void *d_pos, int dtype, const unsigned *d_counts, const htfs_peer *peer,
+                                         htf_stream stream) {
+    if (int rc = check_geom(g, "htfs_brick_pack_halo_peer")) return rc;
+    if (int rc = check_peer(peer, g, "htfs_brick_pack_halo_peer")) return rc;
+    HTF_REQUIRE(d_pos && d_counts && (dtype == HTF_F32 || dtype == HTF_F64), "htfs_brick_pack_halo_peer: null pointer or bad dtype");
+    const unsigned rows = g->ghost_off[g->n_msg - 1] + g->ghost_cap[g->n_msg - 1];
+    if (dtype == HTF_F32)
+        hipLaunchKernelGGL((brick_pack_halo_peer_kernel<float, float4>), dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                           (const float4 *)d_pos, make_args<float>(g), d_counts, make_peer(peer, g), rows);
+    else
+        hipLaunchKernelGGL((brick_pack_halo_peer_kernel<double, double4>), dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                           (const double4 *)d_pos, make_args<double>(g), d_counts, make_peer(peer, g), rows);
+    return check_launch("brick_pack_halo_peer_kernel");
+}
+
+extern "C" int htfs_brick_unpack_halo(const htfs_brick *g, void *d_pos, int dtype, const htfs_peer *peer, unsigned *d_counts,
+                                      htf_stream stream) {
+    if (int rc = check_geom(g, "htfs_brick_unpack_halo")) return rc;
+    if (int rc = check_peer(peer, g, "htfs_brick_unpack_halo")) return rc;
+    HTF_REQUIRE(d_pos && d_counts && (dtype == HTF_F32 || dtype == HTF_F64), "htfs_brick_unpack_halo: null pointer or bad dtype");
+    const unsigned rows = g->ghost_off[g->n_msg - 1] + g->ghost_cap[g->n_msg - 1];
+    if (dtype == HTF_F32)
+        hipLaunchKernelGGL((brick_unpack_halo_kernel<float, float4>), dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                           (float4 *)d_pos, make_args<float>(g), make_peer(peer, g), rows, d_counts);
+    else
+        hipLaunchKernelGGL((brick_unpack_halo_kernel<double, double4>), dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                           (double4 *)d_pos, make_args<double>(g), make_peer(peer, g), rows, d_counts);
+    return check_launch("brick_unpack_halo_kernel");
+}
+
+extern "C" int htfs_brick_nve_halo_peer(const htfs_brick *g, void *d_pos, void *d_vel, const void *d_force, int dtype, double dt,
+                                        const htf_box *box, const unsigned *d_counts, const htfs_peer *peer, htf_stream stream) {
+    if (int rc = check_geom(g, "htfs_brick_nve_halo_peer")) return rc;
+    if (int rc = check_peer(peer, g, "htfs_brick_nve_halo_peer")) return rc;
+    HTF_REQUIRE(d_pos && d_vel && d_force && box && d_counts && (dtype == HTF_F32 || dtype == HTF_F64), "htfs_brick_nve_halo_peer: null pointer or bad dtype");
+    const unsigned cap = g->cap_int + g->cap_bnd;
+    if (dtype == HTF_F32)
+        hipLaunchKernelGGL((brick_nve_halo_peer_kernel<float, float4>), dim3((cap + 255) / 256), dim3(256), 0, (hipStream_t)stream, (float4 *)d_pos,
+                           (float4 *)d_vel, (const float4 *)d_force, (float)dt, make_sbox<float>(box), make_args<float>(g), d_counts,
+                           make_peer(peer, g));
+    else
+        hipLaunchKernelGGL((brick_nve_halo_peer_kernel<double, double4>), dim3((cap + 255) / 256), dim3(256), 0, (hipStream_t)stream, (double4 *)d_pos,
+                           (double4 *)d_vel, (const double4 *)d_force, dt, make_sbox<double>(box), make_args<double>(g), d_counts,
+                           make_peer(peer, g));
+    return check_launch("brick_nve_halo_peer_kernel");
 }

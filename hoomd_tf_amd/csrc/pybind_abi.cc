@@ -131,7 +131,10 @@ void bind(py::module &m, const char *name, R (*fn)(A...)) {
     X(htfs_brick_migrate_pack) \
     X(htfs_brick_migrate_merge) \
     X(htfs_brick_pack_halo) \
-    X(htfs_brick_nve_halo)
+    X(htfs_brick_nve_halo) \
+    X(htfs_brick_nve_halo_peer) \
+    X(htfs_brick_pack_halo_peer) \
+    X(htfs_brick_unpack_halo)
 
 PYBIND11_MODULE(_htf_abi, m) {
     m.doc() = "pybind11 binding of libhtf_amd.so's C ABI: pointers as integers";

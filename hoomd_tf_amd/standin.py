@@ -769,8 +769,8 @@ class BrickRun:
             self.nve.step()
 
     def _force_rows(self, ts):
-        if self.dom.pending and not self.dom.overlaps:
-            self.dom.exchange_end()          # nothing in flight to hide: one launch over all rows
+        if self.dom.pending and (not self.dom.overlaps or 20 * self.dom.n_interior < self.sys.N):
+            self.dom.exchange_end()          # nothing in flight to hide, or next to no interior rows to hide it behind: one launch
         self.ctx.compute_forces_overlapped(ts, self._arr, self.dom)
 
     def step(self):
@@ -811,8 +811,8 @@ class BrickRun:
 
     def _capture(self):
         s, nl, dom = self.sys, self.nl, self.dom
-        if not dom.kernels or dom.transport not in ("native", "local"):
-            raise ValueError("graph replay needs the kernels backend and the 'native' (RCCL inside the capture) or 'local' transport")
+        if not dom.kernels or dom.transport not in ("native", "local", "peer"):
+            raise ValueError("graph replay needs the kernels backend and the 'native' (RCCL inside the capture), 'peer' or 'local' transport")
         if nl.n_builds < 2:
             raise RuntimeError("run a few eager steps through a rebuild first (RCCL connects and pinned buffers are made outside a capture)")
         dom.exchange_end()

@@ -181,7 +181,8 @@ enum {
     HTFS_BF_MIG_OVERFLOW = 2,   /* more migrants than a migration message holds */
     HTFS_BF_INT_OVERFLOW = 4,
     HTFS_BF_BND_OVERFLOW = 8,
-    HTFS_BF_GHOST_OVERFLOW = 16
+    HTFS_BF_GHOST_OVERFLOW = 16,
+    HTFS_BF_HALO_TIMEOUT = 32   /* transport "peer": a neighbor's message did not arrive within the spin limit */
 };
 
 /* scratch of a rebuild, all caller-owned: cand = cap_int + cap_bnd + sum_m mig_cap[m] candidate slots */
@@ -194,6 +195,22 @@ typedef struct htfs_brick_work {
     void *tmp_pos;          /* [cand] Scalar4 */
     void *tmp_vel;          /* [cand] Scalar4 */
 } htfs_brick_work;
+
+/* The halo WITHOUT a communication library (transport "peer", round 5): the packing kernels store every message row straight
+ * into the RECEIVER's staging buffer -- its own memory for a replica rank, an IPC-mapped buffer of another process / device over xGMI
+ * otherwise -- and the last workgroup to finish publishes, per message, the row count and the exchange's sequence number
+ * (system-scope release); the receiver's htfs_brick_unpack_halo waits for the numbers of its incoming messages (acquire, bounded
+ * spin) and copies the rows into the ghost region.  Everything is ordinary kernel work on ONE stream -- capturable into a hipGraph,
+ * and the stores travel while the interior rows are evaluated.  Staging is double-buffered by the sequence number's parity: a
+ * neighbor that is a step ahead writes the other half.  Every rank performs the same sequence of exchanges (lockstep counters). */
+typedef struct htfs_peer {
+    void *inbox[HTFS_BRICK_MAX_MSG];       /* message m's destination: the inbox of the neighbor at offset m, [2][ghost rows] Scalar4 */
+    unsigned *signal[HTFS_BRICK_MAX_MSG];  /* ... and that neighbor's signal words, [2 * n_msg]: {sequence, rows} per source offset */
+    void *my_inbox;                        /* this rank's own inbox and signal words (what htfs_brick_unpack_halo reads) */
+    unsigned *my_signal;
+    unsigned *state;                       /* this rank's [4]: exchanges done, workgroups finished, timeouts seen, spare */
+    unsigned spin_limit;                   /* polls of a signal word before giving up (HTFS_BF_HALO_TIMEOUT) */
+} htfs_peer;
 
 /* First half of a rebuild: destination of every local particle (d_bounds: per decomposed axis HTFS_BRICK_MAX_P + 1 boundaries in
  * the positions' dtype, axis-major), stable sort by destination, migrants packed into d_mig_send (rows of 8 scalars: position,
@@ -211,10 +228,17 @@ HTF_API int htfs_brick_migrate_merge(const htfs_brick *g, void *d_pos, void *d_v
  * region, message m at the rows its receiver -- this rank -- expects it (source offset -o). */
 HTF_API int htfs_brick_pack_halo(const htfs_brick *g, const void *d_pos, int dtype, const unsigned *d_counts, void *d_send,
                                  void *d_ghost_direct, htf_stream stream);
+/* the same two packers with the rows stored into the neighbors' inboxes and signalled (transport "peer"), and the receiving side */
+HTF_API int htfs_brick_pack_halo_peer(const htfs_brick *g, const void *d_pos, int dtype, const unsigned *d_counts, const htfs_peer *peer,
+                                      htf_stream stream);
+HTF_API int htfs_brick_unpack_halo(const htfs_brick *g, void *d_pos, int dtype, const htfs_peer *peer, unsigned *d_counts,
+                                   htf_stream stream);
 /* htfs_nve_step over the local rows AND htfs_brick_pack_halo in one launch: every boundary row writes its new position into the
  * messages that carry it (their inert tails stay as the last rebuild's pack left them).  Same bits as the two calls. */
 HTF_API int htfs_brick_nve_halo(const htfs_brick *g, void *d_pos, void *d_vel, const void *d_force, int dtype, double dt,
                                 const htf_box *box, const unsigned *d_counts, void *d_send, void *d_ghost_direct, htf_stream stream);
+HTF_API int htfs_brick_nve_halo_peer(const htfs_brick *g, void *d_pos, void *d_vel, const void *d_force, int dtype, double dt,
+                                     const htf_box *box, const unsigned *d_counts, const htfs_peer *peer, htf_stream stream);
 
 #ifdef __cplusplus
 }

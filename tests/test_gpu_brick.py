@@ -94,12 +94,14 @@ def test_brick_kernels_match_torch(htf, cuda, grid, dtype):
 
 
 @pytest.mark.parametrize("local_grid", [True, False])
-@pytest.mark.parametrize("grid,transport", [((8, 1, 1), "local"), ((4, 2, 1), "local"), ((8, 1, 1), "native"), ((4, 2, 1), "native")])
+@pytest.mark.parametrize("grid,transport", [((8, 1, 1), "local"), ((4, 2, 1), "local"), ((8, 1, 1), "native"), ((4, 2, 1), "native"),
+                                            ((8, 1, 1), "peer"), ((4, 2, 1), "peer")])
 def test_replica_brick_forces_equal_the_replicated_box(htf, cuda, grid, transport, local_grid):
     """Replica mode is a physical system -- the brick repeated grid times: forces of the one rank's rows (interior rows while the
     halo is in flight, boundary rows behind it) == the single-domain forces of the replicated box, through an MD run with
     migration (particles leave through a face and re-enter through the opposite one).  ``native``: the halo and the migration
-    messages travel through RCCL (this rank sending to itself), csrc/halo.hip's grouped exchange."""
+    messages travel through RCCL (this rank sending to itself), csrc/halo.hip's grouped exchange.  ``peer``: the packing kernel
+    stores the rows into the receiver's inbox and signals, the unpack kernel waits for the signal -- no library in the step."""
     from hoomd_tf_amd import _lib, standin
     from hoomd_tf_amd.brick import BrickDomain
     if transport == "native" and not _lib.lib.htf_halo_available():
@@ -257,7 +259,7 @@ def test_brick_slabs_equal_slab_domain_bit_for_bit(htf, cuda, world, per_slab):
     _run_ranks(_slab_twin_worker, world, (per_slab,))
 
 
-def _brick_md_worker(rank, world, port, q, grid, cells):
+def _brick_md_worker(rank, world, port, q, grid, cells, transport="torch"):
     """80 steps of LJ MD under a px x py cut (migration across both axes and the periodic edges, the halo overlapped with the
     interior rows), then every rank's forces against the single-domain forces of the gathered configuration."""
     try:
@@ -291,7 +293,7 @@ def _brick_md_worker(rank, world, port, q, grid, cells):
         sysm = standin.System(pos[mine], L, types=np.arange(Ng)[mine], dtype=torch.float32, device=dev)
         sysm.vel = torch.from_numpy(vel[mine]).to(torch.float32).to(dev)
         nl = standin.CellNlist(sysm, r_cut=rcut, r_buff=rbuf, check_period=1)
-        dom = nl.domain = BrickDomain(sysm, rank, grid, r_ghost=rcut + rbuf, r_buff=rbuf, n_global=Ng)
+        dom = nl.domain = BrickDomain(sysm, rank, grid, r_ghost=rcut + rbuf, r_buff=rbuf, n_global=Ng, transport=transport)
         nl.build()
         ctx = htf.Context(r_cut=rcut, nneighs=NN, scalar_dtype=torch.float32, max_n=sysm.N)
         pot = htf.Potential.lj()
@@ -340,6 +342,14 @@ def _brick_md_worker(rank, world, port, q, grid, cells):
         q.put((rank, traceback.format_exc()))
 
 
+@pytest.mark.parametrize("grid,cells", [((2, 2, 1), (8, 8, 5)), ((3, 1, 1), (12, 5, 5))])
+def test_bricks_with_the_peer_transport(htf, cuda, grid, cells):
+    """Transport "peer" between PROCESSES (the ranks share the one GPU; each maps its neighbors' inboxes through CUDA-IPC): the
+    packing kernel of rank A stores into rank B's inbox and signals, B's unpack kernel waits on the device -- 80 MD steps with
+    migration, forces == single-domain.  What an xGMI peer mapping would carry between two devices."""
+    _run_ranks(_brick_md_worker, grid[0] * grid[1], (grid, cells, "peer"))
+
+
 @pytest.mark.parametrize("grid,cells", [((4, 2, 1), (16, 8, 5)), ((2, 2, 1), (8, 8, 5)), ((3, 1, 1), (12, 5, 5))])
 def test_bricks_on_one_gpu(htf, cuda, grid, cells):
     """8 ranks as 4 x 2 (bricks 6.7 x 6.7 sigma against r_ghost 2.9: interior rows), 80 MD steps, forces ==
@@ -362,7 +372,8 @@ def _replica_md(htf, cuda, grid, transport, cells=6, period=4):
     return sysm, nl, run
 
 
-@pytest.mark.parametrize("grid,transport", [((8, 1, 1), "local"), ((4, 2, 1), "native"), ((8, 1, 1), "native"), ((4, 2, 1), "local")])
+@pytest.mark.parametrize("grid,transport", [((8, 1, 1), "local"), ((4, 2, 1), "native"), ((8, 1, 1), "native"), ((4, 2, 1), "local"),
+                                            ((8, 1, 1), "peer"), ((4, 2, 1), "peer")])
 def test_replayed_cycles_equal_the_eager_loop(htf, cuda, grid, transport):
     """whole check periods of the decomposed step -- distance check, halo, interior rows, boundary rows,
     integrator, and in the second graph migration + re-plan + list rebuild -- replayed from hipGraphs (with ``native`` the
@@ -420,7 +431,7 @@ def test_integrate_and_pack_in_one_launch(htf, cuda, grid, dtype):
     from hoomd_tf_amd.brick import BrickDomain
     pos, vel, Lb = _brick_of_liquid(htf, cuda, 6, grid, dtype=dtype)
     res = {}
-    for transport in ("local", "native"):
+    for transport in ("local", "native", "peer"):
         for fused in (False, True):
             sysm, Lg, lo = _replica_system(standin, pos, vel, Lb, grid, cuda, dtype)
             try:
@@ -438,13 +449,15 @@ def test_integrate_and_pack_in_one_launch(htf, cuda, grid, dtype):
                     nve.step()
                 dom.exchange()
             torch.cuda.synchronize()
-            res[(transport, fused)] = (sysm.pos.clone(), sysm.vel.clone(), dom.halo_send.clone() if transport != "local" else None)
-    for transport in ("local", "native"):
+            dom.counts_host()     # (raises on a halo timeout)
+            res[(transport, fused)] = (sysm.pos.clone(), sysm.vel.clone(), dom.halo_send.clone() if transport == "native" else None)
+    for transport in ("local", "native", "peer"):
         if (transport, True) not in res:
             continue
         a, b = res[(transport, False)], res[(transport, True)]
         assert _same(a[0], b[0]) and _same(a[1], b[1])
-        if a[2] is not None:
+        if a[2] is not None and transport == "native":
             assert _same(a[2], b[2])
-    if ("native", True) in res:
-        assert _same(res[("native", True)][0], res[("local", True)][0])
+    for transport in ("native", "peer"):     # every transport delivers the same ghosts
+        if (transport, True) in res:
+            assert _same(res[(transport, True)][0], res[("local", True)][0])
