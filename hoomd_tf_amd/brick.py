@@ -344,7 +344,7 @@ class BrickDomain:
             inbox, signal = theirs[self.neighbors[m]]
             pr.inbox[m], pr.signal[m] = inbox.data_ptr(), signal.data_ptr()
         pr.my_inbox, pr.my_signal, pr.state = self._peer_inbox.data_ptr(), self._peer_signal.data_ptr(), self._peer_state.data_ptr()
-        pr.spin_limit = int(os.environ.get("HTF_PEER_SPIN", str(1 << 18)))   # x ~0.5 us a poll: a fraction of a second, then HALO_TIMEOUT
+        pr.spin_limit = int(os.environ.get("HTF_PEER_SPIN", str(1 << 22)))   # x ~1 us a poll: seconds (ranks start skewed), then HALO_TIMEOUT -- never a hang
         if not self.replica:
             dist.barrier(group=self.group)               # nobody stores into an inbox that is not mapped everywhere yet
 
