@@ -331,9 +331,24 @@ def _source_digest():
     return h.hexdigest()
 
 
+def _key(body):
+    return hashlib.sha256((body + "\0" + _source_digest() + "\0" + ARCH + " ".join(FLAGS)).encode()).hexdigest()[:24]
+
+
+def available(body):
+    """A generated kernel for this body can be had: its code object is cached, or the compiler is there to build it."""
+    if os.path.exists(os.path.join(_cache_dir(), _key(body) + ".hsaco")):
+        return True
+    try:
+        _hipcc()
+        return True
+    except RuntimeError:
+        return False
+
+
 def compile_body(body):
     """-> (bytes of the gfx950 code object, its cache key).  Compiles on a miss (~6 s), loads from the cache otherwise."""
-    key = hashlib.sha256((body + "\0" + _source_digest() + "\0" + ARCH + " ".join(FLAGS)).encode()).hexdigest()[:24]
+    key = _key(body)
     path = os.path.join(_cache_dir(), key + ".hsaco")
     if not os.path.exists(path):
         with tempfile.TemporaryDirectory() as tmp:

@@ -495,9 +495,18 @@ class PairExpr(PairEnergy):
         return self._body
 
     def lowers(self):
+        """Can this expression run as a generated kernel?  It must vanish on a padded slot (codegen.vanishes_on_padding), the ROCm
+        compiler must be there to build the unit (a cached code object needs none), and HTF_NO_JIT must not say otherwise;
+        else the torch route (forces by autograd)."""
         from . import codegen as cg
         if getattr(self, "_lowers", None) is None:
-            self._lowers = os.environ.get("HTF_NO_JIT") != "1" and cg.vanishes_on_padding(self.node)
+            ok = os.environ.get("HTF_NO_JIT") != "1" and cg.vanishes_on_padding(self.node)
+            if ok and not cg.available(self.body()):
+                import warnings
+                warnings.warn("hoomd_tf_amd: hipcc not found (set HIPCC): the traced pair energy runs as torch ops + autograd "
+                              "instead of a generated kernel")
+                ok = False
+            self._lowers = ok
         return self._lowers
 
     def key(self):

@@ -336,7 +336,12 @@ class tfcompute:
             # the global batch: every rank's share of this batch, from the per-rank particle counts the last rebuild left on
             # the host (no count in the message, no read-back -- the training step enqueues and returns)
             bs = self.batch_size
-            n_total = float(sum(min(max(nq - offset, 0), bs) if bs else nq for nq in domain.local_counts))
+            if not bs and getattr(domain, "n_global", None):
+                n_total = float(domain.n_global)      # (fixed-capacity bricks: particles are conserved, no count to gather)
+            else:
+                n_total = float(sum(min(max(nq - offset, 0), bs) if bs else nq for nq in domain.local_counts))
+        elif domain is not None and getattr(domain, "fixed_capacity", False) and not self.batch_size:
+            n_total = float(domain.n_global) / float(np.prod(domain.grid))   # (a replica brick: rows are a capacity, particles are not)
         ops.optimizer_step(theta, accum, 1.0 / (4.0 * n_total), self._opt_state, self._opt_desc)
         if hasattr(layer, "after_update"):
             layer.after_update()  # pair-MLP: operand images <- theta, on the device

@@ -115,7 +115,7 @@ def _worker(rank, world, port, q, per_slab=6):
         q.put((rank, traceback.format_exc()))
 
 
-def _train_worker(rank, world, port, q):
+def _train_worker(rank, world, port, q, kind="slab"):
     """tfcompute-driven online force matching under slabs: LJ drives the MD (traced one-kernel
     path, halo overlapped), a pair-MLP is trained on it every step; the [loss, gradient, count]
     all-reduce must keep every rank's weights bit-identical and equal to single-domain training."""
@@ -154,7 +154,10 @@ def _train_worker(rank, world, port, q):
         sim = standin.Simulation(system)
         sim.integrate_nve(0.002)
         nlist = sim.nlist_cell(check_period=1)
-        if world > 1:
+        if world > 1 and kind == "brick":
+            from hoomd_tf_amd.brick import BrickDomain
+            nlist.domain = BrickDomain(system, rank, (world, 1, 1), r_ghost=rcut + nlist.r_buff, r_buff=nlist.r_buff, n_global=Ng)
+        elif world > 1:
             nlist.domain = SlabDomain(system, rank, world, r_ghost=rcut + nlist.r_buff)
         lj = htf.tfcompute(build_examples.LJModel(NN))
         lj.attach(nlist, r_cut=rcut)
@@ -173,7 +176,7 @@ def _train_worker(rank, world, port, q):
             dist.all_gather(both, torch.from_numpy(w.astype(np.float64)))
             for o in both[1:]:
                 assert torch.equal(o, both[0]), "ranks hold different weights after training"
-            n_all = torch.tensor([system.N])
+            n_all = torch.tensor([nlist.domain.n_local if kind == "brick" else system.N])
             dist.all_reduce(n_all)
             assert int(n_all) == Ng
             dist.barrier()
@@ -184,13 +187,16 @@ def _train_worker(rank, world, port, q):
         q.put((rank, world, None, traceback.format_exc()))
 
 
-def test_training_under_slabs_matches_single_domain(htf, cuda):
+@pytest.mark.parametrize("kind", ["slab", "brick"])
+def test_training_under_slabs_matches_single_domain(htf, cuda, kind):
+    """Online pair-MLP force matching under two slabs -- SlabDomain, and BrickDomain's fixed-capacity arrays (inert rows: zero
+    prediction against a zero label, no gradient; the global batch is the conserved particle count) -- == single-domain training."""
     ctx = mp.get_context("spawn")
     out = {}
     for world in (1, 2):
         q = ctx.Queue()
         port = _free_port()
-        procs = [ctx.Process(target=_train_worker, args=(r, world, port, q)) for r in range(world)]
+        procs = [ctx.Process(target=_train_worker, args=(r, world, port, q, kind)) for r in range(world)]
         for p in procs:
             p.start()
         res = [q.get(timeout=600) for _ in procs]
