@@ -813,6 +813,9 @@ class BrickRun:
         s, nl, dom = self.sys, self.nl, self.dom
         if not dom.kernels or dom.transport not in ("native", "local", "peer"):
             raise ValueError("graph replay needs the kernels backend and the 'native' (RCCL inside the capture), 'peer' or 'local' transport")
+        if dom.world > 1 and dom._native is None:
+            raise ValueError("graph replay over real ranks needs the library's own RCCL communicator for the all-reduced distance check "
+                             "and the migration messages (transport='native'; never run between two devices on this pool)")
         if nl.n_builds < 2:
             raise RuntimeError("run a few eager steps through a rebuild first (RCCL connects and pinned buffers are made outside a capture)")
         dom.exchange_end()
