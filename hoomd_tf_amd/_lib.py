@@ -64,6 +64,14 @@ class Peer(C.Structure):
                 ("my_signal", C.c_void_p), ("state", C.c_void_p), ("spin_limit", C.c_uint)]
 
 
+MIRROR_MAX = 4
+
+
+class Mirror(C.Structure):
+    """htfs_mirror (word ranges the check kernel's last workgroup copies from device to pinned host memory)."""
+    _fields_ = [("src", C.c_void_p * MIRROR_MAX), ("dst", C.c_void_p * MIRROR_MAX), ("words", C.c_uint * MIRROR_MAX), ("n", C.c_uint)]
+
+
 class BrickWork(C.Structure):
     """htfs_brick_work."""
     _fields_ = [("key", C.c_void_p), ("order", C.c_void_p), ("sort_scratch", C.c_void_p), ("start1", C.c_void_p),
@@ -181,6 +189,7 @@ STANDIN_PROTOTYPES = {
     "htfs_key_sort16": (_i, [_vp, _u, _vp, _vp, _vp, _vp]),
     "htfs_nve_step": (_i, [_vp, _vp, _vp, _i, _u, _d, C.POINTER(Box), _vp]),
     "htfs_max_displacement2": (_i, [_vp, _vp, _i, _u, C.POINTER(Box), _vp, _vp]),
+    "htfs_check_displacement2": (_i, [_vp, _vp, _i, _u, C.POINTER(Box), _vp, _vp, _vp, C.POINTER(Mirror), _vp]),
     "htfs_build_nlist": (_i, [_vp, _vp, _i, _u, _u, C.POINTER(Box), _d, C.POINTER(_i * 3), C.POINTER(_i * 3), _vp, _u, _i, _vp, _vp, _vp,
                               _vp, _vp, _vp]),
     "htfs_cell_index": (_i, [_vp, _i, _u, C.POINTER(Box), C.POINTER(_i * 3), _vp, _vp]),
@@ -189,7 +198,7 @@ STANDIN_PROTOTYPES = {
     "htfs_rebuild_nlist": (_i, [_vp, _i, _u, C.POINTER(Box), _d, C.POINTER(_i * 3), C.POINTER(_i * 3), _vp, _vp, _vp, _vp, _vp, _u, _i,
                                 _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "htfs_rebuild_nlist_ghosts": (_i, [_vp, _i, _u, _u, C.POINTER(Box), _d, C.POINTER(_i * 3), C.POINTER(_i * 3), _vp, _vp, _vp, _vp, _vp, _u, _i,
-                                       _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+                                       _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "htfs_check_rebuild_nlist": (_i, [_vp, _i, _u, C.POINTER(Box), _d, C.POINTER(_i * 3), C.POINTER(_i * 3), _vp, _vp, _vp, _vp, _vp, _u, _i,
                                       _vp, _vp, _vp, _vp, _vp, _vp, _d, _vp, _vp, _vp]),
 }

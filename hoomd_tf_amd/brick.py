@@ -420,8 +420,21 @@ class BrickDomain:
         offset index j lands in rows [offs[j], +caps[j]) of ``recv``.  Sends are posted in ascending offset order, receives in
         descending order: between any two ranks the k-th send meets the k-th receive (RCCL matches by order, not by tag)."""
         if self.replica and self._native is None:   # (a replica rank without RCCL: "local" and "peer")
-            for m in range(self.n_msg):
-                j = self._opposite(m)
+            pairs = [(m, self._opposite(m)) for m in range(self.n_msg)]
+            if send.is_cuda and send.shape[0] == recv.shape[0] and all(caps[m] == caps[j] for m, j in pairs):
+                # one gather instead of n_msg slice copies (eight dependent nodes of a captured 2-D rebuild)
+                key = (tuple(int(c) for c in caps), tuple(int(o) for o in offs))
+                perm = self._local_perm.get(key) if hasattr(self, "_local_perm") else None
+                if perm is None:
+                    rows = torch.arange(recv.shape[0], dtype=torch.int64)
+                    for m, j in pairs:
+                        rows[offs[j]:offs[j] + caps[j]] = torch.arange(offs[m], offs[m] + caps[m], dtype=torch.int64)
+                    if not hasattr(self, "_local_perm"):
+                        self._local_perm = {}
+                    perm = self._local_perm[key] = rows.to(send.device)
+                torch.index_select(send, 0, perm, out=recv)
+                return []
+            for m, j in pairs:
                 recv[offs[j]:offs[j] + caps[j]] = send[offs[m]:offs[m] + caps[m]]
             return []
         if self._native is not None:
@@ -455,7 +468,8 @@ class BrickDomain:
                                                          w, self.mig_recv.data_ptr(),
                                                          self._n_neigh.data_ptr() if self._n_neigh is not None else None,
                                                          self.counts.data_ptr(), self._stream()))
-            self._flags_host.copy_(self.counts, non_blocking=True)
+            if not (capturing and getattr(self, "_mirrored", False)):   # (BrickRun: the next check kernel carries them to the host)
+                self._flags_host.copy_(self.counts, non_blocking=True)
             if not capturing:
                 self._flags_event = torch.cuda.Event()
                 self._flags_event.record(torch.cuda.current_stream(s.pos.device))

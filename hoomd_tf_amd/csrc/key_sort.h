@@ -111,16 +111,31 @@ __global__ __launch_bounds__(256) void key_scan_scatter_kernel(const unsigned *_
     __shared__ unsigned run[NK];
     __shared__ unsigned tot[NK];
     __shared__ unsigned wcnt[4][NK];
+    __shared__ unsigned part[2][256];
     const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    if (threadIdx.x < NK) {
+    {
+        // all 256 threads walk the table: thread t takes key t % NK of tiles t / NK, t / NK + 256 / NK, ... (coalesced rows)
+        constexpr unsigned kChunks = 256u / NK;
+        const unsigned k = threadIdx.x & (NK - 1u);
         unsigned total = 0, before = 0;
-        for (unsigned t = 0; t < ntiles; ++t) {
-            const unsigned c = tile_hist[t * NK + threadIdx.x];
+        for (unsigned t = threadIdx.x / NK; t < ntiles; t += kChunks) {
+            const unsigned c = tile_hist[t * NK + k];
             total += c;
             before += t < blockIdx.x ? c : 0u;
         }
-        tot[threadIdx.x] = total;
-        run[threadIdx.x] = before;
+        part[0][threadIdx.x] = total;
+        part[1][threadIdx.x] = before;
+        __syncthreads();
+        if (threadIdx.x < NK) {
+            total = before = 0;
+#pragma unroll
+            for (unsigned q = 0; q < kChunks; ++q) {
+                total += part[0][q * NK + threadIdx.x];
+                before += part[1][q * NK + threadIdx.x];
+            }
+            tot[threadIdx.x] = total;
+            run[threadIdx.x] = before;
+        }
     }
     __syncthreads();
     if (threadIdx.x < NK) {

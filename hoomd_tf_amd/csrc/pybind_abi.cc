@@ -114,6 +114,7 @@ void bind(py::module &m, const char *name, R (*fn)(A...)) {
     X(htf_profile_read) \
     X(htfs_nve_step) \
     X(htfs_max_displacement2) \
+    X(htfs_check_displacement2) \
     X(htfs_build_nlist) \
     X(htfs_cell_sort) \
     X(htfs_gather4) \

@@ -57,6 +57,67 @@ __global__ __launch_bounds__(1024) void max_disp_kernel(const typename Vec4<T>::
     }
 }
 
+// The distance check of a replayed cycle in ONE launch (round 5: inside a hipGraph every dependent node costs >= 4.5 us, and
+// "zero the word, fill it, copy it to the host" was three): the blocks accumulate into work[0] as max_disp_kernel does, the LAST
+// block to finish (ticket in work[1]) publishes out = [largest d^2, cycle number + 1] and leaves both work words zero for the next
+// launch.  The same block is the cycle's mailman: it copies the status words other kernels left on the device (htfs_mirror: the
+// decomposition's counts and flags, the list's largest row) and its own result straight into PINNED HOST memory -- the cycle
+// number last, behind a system-scope fence, so a host that sees cycle c sees everything that belongs to it -- where the captured
+// chain had a copy node each (a second stream forked inside the capture was worse: 29.6 -> 42 us per step, every kernel of a
+// multi-branch graph slower and 16-22 us at each fork).
+template <typename T>
+__global__ __launch_bounds__(1024) void check_disp_kernel(const typename Vec4<T>::type *__restrict__ pos,
+                                                          const typename Vec4<T>::type *__restrict__ ref, unsigned N,
+                                                          SBox<T> b, unsigned *__restrict__ work, float *__restrict__ out,
+                                                          float *__restrict__ h_out, htfs_mirror mirror) {
+    __shared__ float s_max[16];
+    __shared__ unsigned s_last;
+    unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    float d2 = 0.f;
+    if (i < N) {
+        auto p = pos[i];
+        auto r = ref[i];
+        T dx = mimg<T>(p.x - r.x, b.L[0], b.Linv[0], b.periodic[0]);
+        T dy = mimg<T>(p.y - r.y, b.L[1], b.Linv[1], b.periodic[1]);
+        T dz = mimg<T>(p.z - r.z, b.L[2], b.Linv[2], b.periodic[2]);
+        d2 = (float)(dx * dx + dy * dy + dz * dz);
+        if (!(d2 == d2)) d2 = 0.f; // an inert row has not moved
+    }
+    for (int m = 1; m < 64; m <<= 1) d2 = fmaxf(d2, __shfl_xor(d2, m));
+    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = d2;
+    if (threadIdx.x == 0) s_last = 0u;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        d2 = s_max[threadIdx.x];
+        for (int m = 1; m < 16; m <<= 1) d2 = fmaxf(d2, __shfl_xor(d2, m));
+        if (threadIdx.x == 0) {
+            if (__float_as_uint(d2) > *(volatile unsigned *)work) atomicMax(work, __float_as_uint(d2));
+            __threadfence();
+            if (atomicAdd(work + 1, 1u) == gridDim.x - 1u) s_last = 1u; // every other block's maximum is in
+        }
+    }
+    __syncthreads();
+    if (s_last == 0u) return;
+    for (unsigned m = 0; m < mirror.n; ++m) {
+        const unsigned *src = (const unsigned *)mirror.src[m];
+        unsigned *dst = (unsigned *)mirror.dst[m];
+        for (unsigned w = threadIdx.x; w < mirror.words[m]; w += blockDim.x) dst[w] = __builtin_nontemporal_load(src + w);
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float worst = __uint_as_float(atomicExch(work, 0u)), cycle = out[1] + 1.0f;
+        out[0] = worst;
+        out[1] = cycle;
+        work[1] = 0u;
+        if (h_out != nullptr) {
+            h_out[0] = worst;
+            __threadfence_system();
+            *(volatile float *)(h_out + 1) = cycle;
+        }
+    }
+}
+
 template <typename T>
 __device__ __forceinline__ int cell_coord(T x, T lo, T Linv, int n) {
     int c = (int)floor((x - lo) * Linv * (T)n);
@@ -281,6 +342,11 @@ __global__ __launch_bounds__(256) void build_nlist_cells_kernel(const typename V
     if (c >= ncell) return;
     const unsigned p_begin = cell_start[c], p_end = cell_start[c + 1];
     if (p_begin == p_end) return;
+    // a cell of ghosts only (the decomposed step's halo cells: candidates for others, no row of their own) has nothing to search
+    if (p_end - p_begin <= 64u) {
+        const bool local = lane < p_end - p_begin && ((unsigned)scalar_as_int(pos_sorted[p_begin + lane].w) & ~kTagSide) < N;
+        if (ballot64(local) == 0ull) return;
+    }
 
     // ---- the cell's candidate runs, one per lane: lane d = 2 row + (0: main run, 1: the run that wraps around the box in x)
     unsigned beg = 0u, len = 0u;
@@ -316,6 +382,7 @@ __global__ __launch_bounds__(256) void build_nlist_cells_kernel(const typename V
         set_tag(me.w, ~0u);
         if (lane < np) me = pos_sorted[pb + lane];
         const unsigned my_tag = (unsigned)scalar_as_int(me.w);
+        if (ballot64(lane < np && (my_tag & ~kTagSide) < N) == 0ull) continue; // a batch of ghosts
         unsigned tag_p[kCellBatch], count[kCellBatch];
         T px[kCellBatch], py[kCellBatch], pz[kCellBatch];
         unsigned row_p[kCellBatch]; // first slot of the particle's row (head_list[i] = i * pitch: 32 bits, as the list's own index)
@@ -417,6 +484,27 @@ extern "C" int htfs_max_displacement2(const void *d_pos, const void *d_ref, int 
     else
         hipLaunchKernelGGL((max_disp_kernel<double>), dim3(grid), dim3(1024), 0, (hipStream_t)stream, (const double4 *)d_pos, (const double4 *)d_ref, N, make_sbox<double>(box), d_out);
     return check_launch("max_disp_kernel");
+}
+
+extern "C" int htfs_check_displacement2(const void *d_pos, const void *d_ref, int dtype, unsigned N, const htf_box *box,
+                                        unsigned *d_work, float *d_out, float *h_out, const htfs_mirror *mirror, htf_stream stream) {
+    using namespace htf;
+    HTF_REQUIRE(d_pos && d_ref && box && d_work && d_out, "htfs_check_displacement2: null pointer");
+    HTF_REQUIRE(N > 0, "htfs_check_displacement2: no rows");
+    htfs_mirror mr = {};
+    if (mirror != nullptr) {
+        mr = *mirror;
+        HTF_REQUIRE(mr.n <= HTFS_MIRROR_MAX, "htfs_check_displacement2: %u mirrors (at most %d)", mr.n, HTFS_MIRROR_MAX);
+        for (unsigned m = 0; m < mr.n; ++m)
+            HTF_REQUIRE(mr.src[m] && mr.dst[m] && ((uintptr_t)mr.src[m] & 3) == 0 && ((uintptr_t)mr.dst[m] & 3) == 0,
+                        "htfs_check_displacement2: mirror %u: null or unaligned pointer", m);
+    }
+    unsigned grid = (N + 1023) / 1024;
+    if (dtype == HTF_F32)
+        hipLaunchKernelGGL((check_disp_kernel<float>), dim3(grid), dim3(1024), 0, (hipStream_t)stream, (const float4 *)d_pos, (const float4 *)d_ref, N, make_sbox<float>(box), d_work, d_out, h_out, mr);
+    else
+        hipLaunchKernelGGL((check_disp_kernel<double>), dim3(grid), dim3(1024), 0, (hipStream_t)stream, (const double4 *)d_pos, (const double4 *)d_ref, N, make_sbox<double>(box), d_work, d_out, h_out, mr);
+    return check_launch("check_disp_kernel");
 }
 
 namespace htf {
@@ -858,7 +946,7 @@ static int rebuild_nlist_impl(const void *d_pos, int dtype, unsigned N, unsigned
                               const int *stencil3, unsigned *d_cell_of, unsigned *d_scratch, unsigned *d_cell_start,
                               unsigned *d_order, void *d_pos_sorted, unsigned pitch, int type_split, unsigned *d_n_neigh,
                               unsigned *d_head_list, unsigned *d_nlist, unsigned *d_max_neigh, void *d_ref,
-                              unsigned *d_counter, void *d_ranges, htf_stream stream) {
+                              unsigned *d_counter, void *d_ranges, htf_stream stream, bool scratch_clean = false) {
     using namespace htf;
     HTF_REQUIRE(d_pos && box && ncell3 && stencil3 && d_cell_of && d_scratch && d_cell_start && d_order && d_pos_sorted,
                 "htfs_rebuild_nlist: null pointer");
@@ -868,7 +956,8 @@ static int rebuild_nlist_impl(const void *d_pos, int dtype, unsigned N, unsigned
     HTF_REQUIRE(ncell > 0, "htfs_rebuild_nlist: no cells");
     hipStream_t s = (hipStream_t)stream;
     unsigned *count = d_scratch, *cursor = d_scratch + ncell;
-    if (int rc = zero_counts_if_needed(count, ncell, s)) return rc; // (as htfs_cell_sort)
+    if (!scratch_clean)
+        if (int rc = zero_counts_if_needed(count, ncell, s)) return rc; // (as htfs_cell_sort)
     const unsigned grid = (Ntot + 255) / 256;
     if (dtype == HTF_F32)
         hipLaunchKernelGGL((cell_index_count_kernel<float>), dim3(grid), dim3(256), 0, s, (const float4 *)d_pos, Ntot, make_sbox<float>(box),
@@ -899,9 +988,10 @@ extern "C" int htfs_rebuild_nlist_ghosts(const void *d_pos, int dtype, unsigned 
                                          const int *ncell3, const int *stencil3, unsigned *d_cell_of, unsigned *d_scratch,
                                          unsigned *d_cell_start, unsigned *d_order, void *d_pos_sorted, unsigned pitch, int type_split,
                                          unsigned *d_n_neigh, unsigned *d_head_list, unsigned *d_nlist, unsigned *d_max_neigh, void *d_ref,
-                                         unsigned *d_counter, void *d_ranges, htf_stream stream) {
+                                         unsigned *d_counter, void *d_ranges, int scratch_clean, htf_stream stream) {
     return rebuild_nlist_impl(d_pos, dtype, N, Ntot, box, r_list, ncell3, stencil3, d_cell_of, d_scratch, d_cell_start, d_order, d_pos_sorted,
-                              pitch, type_split, d_n_neigh, d_head_list, d_nlist, d_max_neigh, d_ref, d_counter, d_ranges, stream);
+                              pitch, type_split, d_n_neigh, d_head_list, d_nlist, d_max_neigh, d_ref, d_counter, d_ranges, stream,
+                              scratch_clean != 0);
 }
 
 // A whole check step of a device-decided list in ONE call (the host's share of a small system's step is its enqueue): the

@@ -243,14 +243,18 @@ class CellNlist:
             capturing = getattr(self, "_capturing", False)
             if not capturing:
                 self._poll_row_overflow()   # the PREVIOUS build's largest row (pinned copy behind it): no wait
+            # the binning scratch is this object's own and every completed build leaves its counts zero (cell_order_kernel): no memset
+            clean = getattr(self, "_scratch_clean", None) == (self._bin_scratch.data_ptr(), ncell)
             check(lib.htfs_rebuild_nlist_ghosts(s.pos.data_ptr(), s.scalar_code, s.N, Ntot, C.byref(sbox), self.r_list, C.byref(n3), C.byref(w3),
                                                 cell_of.data_ptr(), self._bin_scratch.data_ptr(), cell_start.data_ptr(), order.data_ptr(),
                                                 pos_sorted.data_ptr(), self.pitch, int(self.type_split), self.n_neigh.data_ptr(),
                                                 self.head_list.data_ptr(), self.nlist.data_ptr(), self._max.data_ptr(), self._ref.data_ptr(),
-                                                None, self._ranges.data_ptr(), stream))
+                                                None, self._ranges.data_ptr(), int(clean), stream))
+            self._scratch_clean = (self._bin_scratch.data_ptr(), ncell)
             if getattr(self, "_max_host", None) is None:
                 self._max_host = torch.zeros(1, dtype=torch.int32).pin_memory()
-            self._max_host.copy_(self._max, non_blocking=True)
+            if not (capturing and getattr(self, "_mirrored", False)):   # (BrickRun: the next check kernel carries it to the host)
+                self._max_host.copy_(self._max, non_blocking=True)
             if not capturing:
                 self._max_event = torch.cuda.Event()
                 self._max_event.record(torch.cuda.current_stream(s.device))
@@ -747,6 +751,7 @@ class BrickRun:
         if self.dom is None or not getattr(self.dom, "fixed_capacity", False):
             raise ValueError("BrickRun drives a CellNlist whose domain is a BrickDomain")
         self._graphs = None
+        self._mirror = None
         self.n_rebuild_cycles = 0
         self.n_cycles = 0
 
@@ -790,12 +795,19 @@ class BrickRun:
         """The distance check of a cycle, on the device: largest displacement^2 since the last rebuild, all-reduced, and the cycle
         counter, copied to pinned memory."""
         s, nl = self.sys, self.nl
-        torch.addcmul(self._stat_inc, self._stat, self._stat_inc, out=self._stat)   # [d2, cycle] <- [0, cycle + 1]: one launch
-        check(lib.htfs_max_displacement2(s.pos.data_ptr(), nl._ref.data_ptr(), s.scalar_code, s.N, C.byref(s.box),
-                                         self._stat.data_ptr(), C.c_void_p(raw_stream(s.device.index))))
-        if self.dom.world > 1:
+        # [d2, cycle] <- [largest displacement^2, cycle + 1] in one launch (the accumulator and its reset live in _stat_work); the
+        # same launch carries the status words of the cycle before -- the decomposition's counts and flags, the list's largest row
+        # -- and, on one rank, its own result into pinned memory: no copy node in the chain
+        alone = self.dom.world == 1
+        check(lib.htfs_check_displacement2(s.pos.data_ptr(), nl._ref.data_ptr(), s.scalar_code, s.N, C.byref(s.box),
+                                           self._stat_work.data_ptr(), self._stat.data_ptr(),
+                                           self._stat_host.data_ptr() if (alone and self._mirror is not None) else None,
+                                           C.byref(self._mirror) if self._mirror is not None else None,
+                                           C.c_void_p(raw_stream(s.device.index))))
+        if not alone:
             self.dom._native.allreduce_max(self._stat[0:1])
-        self._stat_host.copy_(self._stat, non_blocking=True)
+        if not alone or self._mirror is None:
+            self._stat_host.copy_(self._stat, non_blocking=True)
 
     def _cycle(self, rebuild):
         s, nl, P = self.sys, self.nl, self.nl.check_period
@@ -821,7 +833,18 @@ class BrickRun:
         dom.exchange_end()
         self._arr = self._arrays()
         self._stat = torch.zeros(2, dtype=torch.float32, device=s.device)
-        self._stat_inc = torch.tensor([0.0, 1.0], dtype=torch.float32, device=s.device)
+        self._stat_work = torch.zeros(2, dtype=torch.int32, device=s.device)
+        # the status words the host reads one cycle late travel with the check kernel (HTF_BRICK_MIRROR=0: a copy node each, as before)
+        self._mirror = None
+        if os.environ.get("HTF_BRICK_MIRROR", "1") != "0":
+            if getattr(nl, "_max_host", None) is None:
+                nl._max_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            m = _lib.Mirror()
+            m.src[0], m.dst[0], m.words[0] = dom.counts.data_ptr(), dom._flags_host.data_ptr(), _lib.BC_WORDS
+            m.src[1], m.dst[1], m.words[1] = nl._max.data_ptr(), nl._max_host.data_ptr(), 1
+            m.n = 2
+            self._mirror = m
+        nl._mirrored = dom._mirrored = self._mirror is not None
         self._stat_host = torch.zeros(2, dtype=torch.float32).pin_memory()
         self._rule = DeferredRebuildRule(nl.r_buff / 2.0)
         torch.cuda.synchronize()
@@ -899,6 +922,10 @@ class BrickRun:
             self.n_cycles += 1
             s.timestep += P
             nsteps -= P
+        if self._mirror is not None and self._launched > self._read:
+            # the last cycle's status words have no later check kernel to carry them: two plain copies behind the last graph
+            self.dom._flags_host.copy_(self.dom.counts, non_blocking=True)
+            self.nl._max_host.copy_(self.nl._max, non_blocking=True)
         for _ in range(nsteps):
             self.step()
 

@@ -21,6 +21,22 @@ HTF_API int htfs_nve_step(void *d_pos, void *d_vel, const void *d_force, int dty
 HTF_API int htfs_max_displacement2(const void *d_pos, const void *d_ref, int dtype, unsigned N,
                                    const htf_box *box, float *d_out, htf_stream stream);
 
+/* The same check for a replayed (hipGraph) cycle in ONE launch: d_work (2 words, zero before the first call and left zero by every
+ * call) accumulates, the last workgroup publishes d_out[0] = the largest squared displacement and d_out[1] += 1 (the cycle number
+ * as a float).  h_out (nullable; PINNED host memory, device-accessible) receives the same two words, the cycle number last behind
+ * a system-scope fence; `mirror` (nullable) lists up to HTFS_MIRROR_MAX word ranges the same workgroup copies from device to
+ * pinned host memory BEFORE that -- status words earlier kernels left behind (htfs_brick counts, the list's largest row) -- so a
+ * host that reads cycle c in h_out reads everything up to the end of cycle c - 1 beside it, without one copy node in the chain. */
+#define HTFS_MIRROR_MAX 4
+typedef struct htfs_mirror {
+    const void *src[HTFS_MIRROR_MAX];
+    void *dst[HTFS_MIRROR_MAX];
+    unsigned words[HTFS_MIRROR_MAX];
+    unsigned n;
+} htfs_mirror;
+HTF_API int htfs_check_displacement2(const void *d_pos, const void *d_ref, int dtype, unsigned N, const htf_box *box,
+                                     unsigned *d_work, float *d_out, float *h_out, const htfs_mirror *mirror, htf_stream stream);
+
 /* Cell-list neighbor search in HOOMD layout (NeighborListGPUBinned analogue).
  * d_pos_sorted [Ntot] (htfs_gather4_tagged: pos[order] with the particle's index in w, so a cell's
  * members are contiguous and one load brings a candidate's position and identity) and d_cell_start
@@ -86,12 +102,15 @@ HTF_API int htfs_rebuild_nlist(const void *d_pos, int dtype, unsigned N, const h
                                unsigned *d_head_list, unsigned *d_nlist, unsigned *d_max_neigh, void *d_ref,
                                unsigned *d_counter, void *d_ranges, htf_stream stream);
 
-/* the same with ghosts (and inert rows): Ntot >= N positions are binned, the N local rows searched and committed */
+/* the same with ghosts (and inert rows): Ntot >= N positions are binned, the N local rows searched and committed.
+ * scratch_clean != 0: the caller guarantees that the first ncell words of d_scratch are zero -- they are after any COMPLETED
+ * htfs_cell_sort / htfs_rebuild_nlist* call on this scratch with the same ncell, as long as nothing else has written the buffer --
+ * and the call skips its memset (two dependent nodes of a captured rebuild). */
 HTF_API int htfs_rebuild_nlist_ghosts(const void *d_pos, int dtype, unsigned N, unsigned Ntot, const htf_box *box, double r_list,
                                       const int *ncell3, const int *stencil3, unsigned *d_cell_of, unsigned *d_scratch,
                                       unsigned *d_cell_start, unsigned *d_order, void *d_pos_sorted, unsigned pitch, int type_split,
                                       unsigned *d_n_neigh, unsigned *d_head_list, unsigned *d_nlist, unsigned *d_max_neigh, void *d_ref,
-                                      unsigned *d_counter, void *d_ranges, htf_stream stream);
+                                      unsigned *d_counter, void *d_ranges, int scratch_clean, htf_stream stream);
 
 /* One check step of a device-decided list in one call: *d_disp2 <- 0, htfs_max_displacement2 into it, htfs_set_gate(d_disp2,
  * threshold2), htfs_rebuild_nlist (d_stat2[0] = largest row, d_stat2[1] = rebuild counter), htfs_set_gate(NULL, 0), and -- if

@@ -461,3 +461,50 @@ def test_integrate_and_pack_in_one_launch(htf, cuda, grid, dtype):
     for transport in ("native", "peer"):     # every transport delivers the same ghosts
         if (transport, True) in res:
             assert _same(res[(transport, True)][0], res[("local", True)][0])
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+def test_check_displacement_in_one_launch(dt):
+    """htfs_check_displacement2 (the replayed cycle's check: accumulate, publish, reset in ONE launch) against
+    htfs_max_displacement2 on the same rows, inert rows included, over consecutive calls that share the two work words."""
+    import ctypes as C
+    from hoomd_tf_amd import _lib
+    from hoomd_tf_amd.ops import raw_stream
+    DEV = torch.device("cuda:0")
+    torch.manual_seed(5)
+    N = 40000          # 40 workgroups: the last one to finish publishes
+    L = 20.0
+    box = _lib.make_box(np.array([[-L / 2] * 3, [L / 2] * 3, [0.0] * 3]), (1, 1, 1))
+    ref = torch.zeros((N, 4), dtype=dt, device=DEV)
+    ref[:, :3] = (torch.rand((N, 3), dtype=torch.float64, device=DEV) * L - L / 2).to(dt)
+    work = torch.zeros(2, dtype=torch.int32, device=DEV)
+    out = torch.zeros(2, dtype=torch.float32, device=DEV)
+    code = _lib.HTF_F32 if dt == torch.float32 else _lib.HTF_F64
+    stream = C.c_void_p(raw_stream(0))
+    h_out = torch.zeros(2, dtype=torch.float32).pin_memory()
+    status = torch.zeros(1000, dtype=torch.int32, device=DEV)
+    h_status = torch.full((302,), -1, dtype=torch.int32).pin_memory()
+    mirror = _lib.Mirror()
+    mirror.src[0], mirror.dst[0], mirror.words[0] = status.data_ptr(), h_status.data_ptr(), 300
+    mirror.src[1], mirror.dst[1], mirror.words[1] = status.data_ptr() + 4 * 777, h_status.data_ptr() + 4 * 300, 1
+    mirror.n = 2
+    for cycle in range(1, 5):
+        pos = ref.clone()
+        pos[:, :3] += (0.05 * cycle * torch.randn((N, 3), dtype=torch.float64, device=DEV)).to(dt)
+        pos[:, :3] -= L * torch.round(pos[:, :3] / L)          # wrapped: the check takes the minimum image
+        pos[7::97, 0] = float("nan")                            # inert rows have not moved
+        one = torch.zeros(1, dtype=torch.float32, device=DEV)
+        _lib.check(_lib.lib.htfs_max_displacement2(pos.data_ptr(), ref.data_ptr(), code, N, C.byref(box), one.data_ptr(), stream))
+        status.random_(0, 1 << 30)
+        _lib.check(_lib.lib.htfs_check_displacement2(pos.data_ptr(), ref.data_ptr(), code, N, C.byref(box), work.data_ptr(),
+                                                     out.data_ptr(), h_out.data_ptr() if cycle % 2 else None,
+                                                     C.byref(mirror) if cycle > 1 else None, stream))
+        torch.cuda.synchronize()
+        assert out[0].item() == one.item() and out[0].item() > 0
+        assert out[1].item() == float(cycle)
+        assert work.tolist() == [0, 0]
+        if cycle % 2:      # the pinned words, written by the kernel itself
+            assert h_out.tolist() == out.tolist()
+        if cycle > 1:      # and the status words it carried along
+            assert torch.equal(h_status[:300], status[:300].cpu()) and torch.equal(h_status[300:301], status[777:778].cpu())
+            assert int(h_status[301]) == -1
