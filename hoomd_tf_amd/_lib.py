@@ -22,6 +22,7 @@ HTF_OK, HTF_ERR_INVALID, HTF_ERR_DEVICE, HTF_ERR_NLIST_OVERFLOW, HTF_ERR_SKEWED_
 HTF_F32, HTF_F64 = 0, 1
 HTF_TF2HOOMD, HTF_HOOMD2TF = 0, 1
 POT_NONE, POT_LJ, POT_WCA, POT_RINV_POLY, POT_SIMPLE, POT_PAIR_MLP, POT_GAUSS, POT_LJ_PARAM, POT_TOPK_MLP, POT_JIT = range(10)
+JIT_READS_OWN_TYPE = 1
 OPT_SGD, OPT_ADAM, OPT_NADAM = range(3)
 OPT_STATE_FLOATS = 24
 ACT_LINEAR, ACT_TANH = 0, 1
@@ -87,7 +88,7 @@ class PotentialDesc(C.Structure):
                 ("mlp_precision", C.c_int), ("rbf_low", C.c_double), ("rbf_high", C.c_double),
                 ("W1", C.c_void_p), ("b1", C.c_void_p), ("W2", C.c_void_p), ("b2", C.c_void_p),
                 ("W3", C.c_void_p), ("b3", C.c_void_p), ("poly_cut", C.c_double),
-                ("jit_image", C.c_void_p), ("jit_image_bytes", C.c_size_t)]
+                ("jit_image", C.c_void_p), ("jit_image_bytes", C.c_size_t), ("jit_flags", C.c_int)]
 
 
 class OptimizerDesc(C.Structure):
@@ -119,6 +120,7 @@ PROTOTYPES = {
     "htf_potential_destroy": (None, [_vp]),
     "htf_build_pair_vectors": (_i, [_vp, _i, _vp, _i, _u, _u, _u, _u, _u, C.POINTER(Box), _vp, _vp, _vp, _d, _vp, _vp]),
     "htf_eval_forces": (_i, [_vp, _vp, _i, _u, _u, _vp, _i, _vp, _vp]),
+    "htf_eval_forces_typed": (_i, [_vp, _vp, _i, _u, _u, _vp, _i, _vp, _i, _vp, _vp]),
     "htf_fused_forces": (_i, [_vp, _vp, _i, _u, _u, _u, _u, C.POINTER(Box), _vp, _vp, _vp, _d, _vp, _i, _vp, _vp, _vp]),
     "htf_build_eval_forces": (_i, [_vp, _vp, _vp, _i, _u, _u, _u, _u, C.POINTER(Box), _vp, _vp, _vp, _d, _vp, _i, _vp, _vp, _vp]),
     "htf_eval_forces2": (_i, [_vp, _vp, _vp, _i, _u, _u, _vp, _vp, _i, _vp, C.c_float, C.c_float, _u, _vp, _vp]),

@@ -58,26 +58,54 @@ def wrap(x):
 
 
 S, R, RN = Node("s"), Node("r"), Node("rn")   # nlist_rinv, safe_norm, the plain norm (masks only: no gradient)
+TJ, TI = Node("tj"), Node("ti")               # the neighbor's type nlist[i, j, 3] and the row particle's own positions[i, 3], as floats
 UNARY = ("neg", "exp", "log", "tanh", "sqrt", "abs", "square", "mask")
 BINARY = ("add", "sub", "mul", "div", "min", "max")
-COMPARE = ("lt", "le", "gt", "ge")
+COMPARE = ("lt", "le", "gt", "ge", "eq", "ne")
+MAX_TABLE = 1024                               # entries of a ``gather`` table (a species-pair parameter matrix)
+
+
+def table(values, index):
+    """``tf.gather(values, index)`` with a constant 1-D ``values`` and an index EXPRESSION (types: ti * ntypes + tj): no gradient
+    flows into an index, and the table is a constant of the generated unit."""
+    vals = tuple(float(v) for v in np.asarray(values, dtype=np.float64).reshape(-1))
+    if not 1 <= len(vals) <= MAX_TABLE:
+        raise ValueError("a traced gather table holds 1..%d constants (got %d)" % (MAX_TABLE, len(vals)))
+    return Node("table", (wrap(index),), value=vals)
+
+
+def reads(node, op, seen=None):
+    """Does the expression contain a node of kind ``op``?"""
+    seen = set() if seen is None else seen
+    if id(node) in seen:
+        return False
+    seen.add(id(node))
+    return node.op == op or any(reads(a, op, seen) for a in node.args)
 
 
 # --------------------------------------------------------------------------- evaluation in torch (the reference, and eager values)
-def evaluate(node, s, r, rn, memo=None):
-    """The expression on torch tensors (any dtype): what the generated kernel computes per slot."""
+def evaluate(node, s, r, rn, memo=None, tj=None, ti=None):
+    """The expression on torch tensors (any dtype): what the generated kernel computes per slot.  ``tj`` / ``ti``: the type
+    leaves (broadcastable to ``s``), needed only by expressions that read them."""
     memo = {} if memo is None else memo
     k = id(node)
     if k in memo:
         return memo[k]
     op = node.op
-    a = [evaluate(x, s, r, rn, memo) for x in node.args]
+    a = [evaluate(x, s, r, rn, memo, tj, ti) for x in node.args]
     if op == "s":
         out = s
     elif op == "r":
         out = r
     elif op == "rn":
         out = rn
+    elif op in ("tj", "ti"):
+        out = tj if op == "tj" else ti
+        if out is None:
+            raise ValueError("the expression reads particle types: evaluate() needs tj / ti")
+    elif op == "table":
+        vals = torch.as_tensor(node.value, dtype=s.dtype, device=s.device)
+        out = vals[a[0].detach().to(torch.int64).clamp(0, len(node.value) - 1)]
     elif op == "const":
         out = torch.as_tensor(node.value, dtype=s.dtype, device=s.device)
     elif op == "neg":
@@ -111,7 +139,7 @@ def evaluate(node, s, r, rn, memo=None):
     elif op == "pow":
         out = a[0] ** node.value
     elif op in COMPARE:
-        out = {"lt": torch.lt, "le": torch.le, "gt": torch.gt, "ge": torch.ge}[op](a[0], a[1])
+        out = {"lt": torch.lt, "le": torch.le, "gt": torch.gt, "ge": torch.ge, "eq": torch.eq, "ne": torch.ne}[op](a[0], a[1])
     elif op == "where":
         out = torch.where(a[0], a[1], a[2])
     else:
@@ -151,9 +179,28 @@ class _Emitter:
             out = (self.tmp("__builtin_amdgcn_sqrtf(x * x + y * y + z * z)"), None)
         elif op == "const":
             out = (self.lit(node.value), None)
+        elif op in ("tj", "ti"):
+            out = (op, None)
+        elif op == "table":
+            # (int)index clamped into the table; a handful of constants become a select chain (v_cndmask, no memory), a
+            # species-pair matrix of more than 16 entries a constant array of the unit
+            n = len(node.value)
+            idx = "i%d" % self.n
+            self.n += 1
+            self.lines.append("const int %s = min(max((int)(%s), 0), %d);" % (idx, self.emit(node.args[0])[0], n - 1))
+            if n <= 16:
+                expr = self.lit(node.value[n - 1])
+                for q in range(n - 2, -1, -1):
+                    expr = "%s == %d ? %s : (%s)" % (idx, q, self.lit(node.value[q]), expr)
+                out = (self.tmp(expr), None)
+            else:
+                arr = "tb%d" % self.n
+                self.n += 1
+                self.lines.append("static constexpr float %s[%d] = {%s};" % (arr, n, ", ".join(self.lit(v) for v in node.value)))
+                out = (self.tmp("%s[%s]" % (arr, idx)), None)
         elif op in COMPARE:
             a, b = self.emit(node.args[0])[0], self.emit(node.args[1])[0]
-            c = {"lt": "<", "le": "<=", "gt": ">", "ge": ">="}[op]
+            c = {"lt": "<", "le": "<=", "gt": ">", "ge": ">=", "eq": "==", "ne": "!="}[op]
             name = "c%d" % self.n
             self.n += 1
             self.lines.append("const bool %s = %s %s %s;" % (name, a, c, b))
@@ -269,7 +316,7 @@ class _Emitter:
 
 
 def generate_body(node):
-    """The statements pair_math.h splices into pair_eval_f<HTF_POT_JIT>: assign ``e`` and ``dedr`` from s, ds, r, x, y, z."""
+    """The statements pair_math.h splices into pair_eval_f<HTF_POT_JIT>: assign ``e`` and ``dedr`` from s, ds, r, x, y, z, tj, ti."""
     em = _Emitter()
     v, d = em.emit(node)
     em.lines.append("e = %s;" % v)
@@ -278,21 +325,23 @@ def generate_body(node):
 
 
 def vanishes_on_padding(node):
-    """Energy and derivative of a padded slot (s = 0, ds = 0, r = sqrt(3) 1e-7, plain norm 0), in fp64: must be exact zeros."""
-    r = torch.tensor(PAD_R, dtype=torch.float64, requires_grad=True)
-    s = r * 0.0          # (s = 0 with d s / d r = 0, but ON the graph: sqrt(s) has derivative 0 * inf = NaN there, in TF too)
-    rn = torch.zeros((), dtype=torch.float64)
-    try:
-        e = evaluate(node, s, r, rn)
-        if not isinstance(e, torch.Tensor) or not bool(torch.isfinite(e)) or float(e.detach()) != 0.0:
-            return False
-        if e.requires_grad:
-            (g,) = torch.autograd.grad(e, r, allow_unused=True)
-            if g is not None and not float(g) == 0.0:
+    """Energy and derivative of a padded slot (s = 0, ds = 0, r = sqrt(3) 1e-7, plain norm 0, neighbor type 0), in fp64: must be
+    exact zeros -- whatever the row particle's own type is (tried for 0..15 when the expression reads it)."""
+    for own in (range(16) if reads(node, "ti") else (0,)):
+        r = torch.tensor(PAD_R, dtype=torch.float64, requires_grad=True)
+        s = r * 0.0          # (s = 0 with d s / d r = 0, but ON the graph: sqrt(s) has derivative 0 * inf = NaN there, in TF too)
+        rn = torch.zeros((), dtype=torch.float64)
+        try:
+            e = evaluate(node, s, r, rn, tj=torch.zeros((), dtype=torch.float64), ti=torch.full((), float(own), dtype=torch.float64))
+            if not isinstance(e, torch.Tensor) or not bool(torch.isfinite(e)) or float(e.detach()) != 0.0:
                 return False
-        return True
-    except Exception:  # noqa: BLE001
-        return False
+            if e.requires_grad:
+                (g,) = torch.autograd.grad(e, r, allow_unused=True)
+                if g is not None and not float(g) == 0.0:
+                    return False
+        except Exception:  # noqa: BLE001
+            return False
+    return True
 
 
 # --------------------------------------------------------------------------- compile + cache

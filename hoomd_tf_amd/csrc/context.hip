@@ -179,6 +179,7 @@ extern "C" int htf_potential_create(const htf_potential_desc *d, htf_potential *
     case HTF_POT_JIT:
         rc = jit_create(d->jit_image, d->jit_image_bytes, &p->jit);
         p->pp.jit = p->jit;
+        p->pp.jit_flags = d->jit_flags;
         break;
     default:
         set_error("htf_potential_create: unknown potential kind %d", d->kind);
@@ -255,7 +256,29 @@ extern "C" int htf_eval_forces(const htf_potential *pot, const void *d_nlist, in
     if (pot->pp.kind == HTF_POT_TOPK_MLP)
         return topk_eval(pot->topk, d_nlist, nlist_dtype, B, NN, d_force, force_dtype, d_virial9, (hipStream_t)stream);
     HTF_REQUIRE(!(pot->pp.kind == HTF_POT_SIMPLE && d_virial9), "htf_eval_forces: SimplePotential has no energy, hence no virial");
+    HTF_REQUIRE(!(pot->pp.kind == HTF_POT_JIT && (pot->pp.jit_flags & HTF_JIT_READS_OWN_TYPE)),
+                "htf_eval_forces: this traced energy reads the row particle's own type: evaluate it with htf_eval_forces_typed "
+                "(positions beside the pair vectors) or through the one-kernel step");
     return eval_pair_dispatch(pot->pp, d_nlist, nlist_dtype, B, NN, d_force, force_dtype, d_virial9, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int htf_eval_forces_typed(const htf_potential *pot, const void *d_nlist, int nlist_dtype, unsigned B, unsigned NN,
+                                     const void *d_positions, int positions_dtype, void *d_force, int force_dtype, void *d_virial9,
+                                     htf_stream stream) {
+    using namespace htf;
+    HTF_REQUIRE(pot, "htf_eval_forces_typed: no potential");
+    if (!(pot->pp.kind == HTF_POT_JIT && (pot->pp.jit_flags & HTF_JIT_READS_OWN_TYPE)))
+        return htf_eval_forces(pot, d_nlist, nlist_dtype, B, NN, d_force, force_dtype, d_virial9, stream);
+    HTF_REQUIRE(d_nlist && d_force && d_positions, "htf_eval_forces_typed: null pointer");
+    HTF_REQUIRE(NN > 0, "htf_eval_forces_typed: NN must be > 0");
+    HTF_REQUIRE(nlist_dtype == HTF_F32 || nlist_dtype == HTF_F64, "htf_eval_forces_typed: bad nlist dtype %d", nlist_dtype);
+    HTF_REQUIRE(positions_dtype == HTF_F32 || positions_dtype == HTF_F64, "htf_eval_forces_typed: bad positions dtype %d", positions_dtype);
+    HTF_REQUIRE(force_dtype == HTF_F32 || force_dtype == HTF_F64, "htf_eval_forces_typed: bad force dtype %d", force_dtype);
+    if (B == 0) return HTF_OK;
+    PotParams pp = pot->pp;
+    pp.own = d_positions;
+    pp.own_f64 = positions_dtype == HTF_F64 ? 1 : 0;
+    return eval_pair_dispatch(pp, d_nlist, nlist_dtype, B, NN, d_force, force_dtype, d_virial9, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int htf_fused_forces(const htf_potential *pot, const void *d_pos, int pos_dtype, unsigned N, unsigned NN,
@@ -538,9 +561,13 @@ static int compute_rows(htf_ctx *ctx, unsigned timestep, const htf_hoomd_arrays 
         if (own_evaluator(ctx->pot))
             rc = htf_eval_forces(ctx->pot, c_nlist, HTF_F32, n, cfg.nneighs, force_out, cfg.scalar_dtype,
                                  cfg.virial ? c_virial : nullptr, stream);
-        else
-            rc = eval_pair_dispatch(ctx->pot->pp, c_nlist, HTF_F32, n, cfg.nneighs, force_out, cfg.scalar_dtype,
+        else {
+            PotParams pp = ctx->pot->pp;
+            pp.own = c_positions; // (the positions side buffer, staged with the pair vectors: what a typed generated body reads)
+            pp.own_f64 = 0;
+            rc = eval_pair_dispatch(pp, c_nlist, HTF_F32, n, cfg.nneighs, force_out, cfg.scalar_dtype,
                                     cfg.virial ? c_virial : nullptr, c_counts, s);
+        }
         if (rc != HTF_OK) return rc;
         if (prof) {
             HTF_CHECK_HIP(hipEventRecord(e2, s));

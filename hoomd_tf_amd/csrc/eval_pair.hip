@@ -52,6 +52,11 @@ __device__ __forceinline__ void eval_pair_body(const typename Vec4<IT>::type *__
 
     float fx = 0.f, fy = 0.f, fz = 0.f, en = 0.f;
     float vxx = 0.f, vxy = 0.f, vxz = 0.f, vyy = 0.f, vyz = 0.f, vzz = 0.f;
+    float own_type = 0.f; // positions[row, 3]: read by generated bodies only
+    if constexpr (KIND == HTF_POT_JIT) {
+        if (pin.own != nullptr && active)
+            own_type = pin.own_f64 ? (float)reinterpret_cast<const double4 *>(pin.own)[row].w : reinterpret_cast<const float4 *>(pin.own)[row].w;
+    }
     // live slots of this row when the producer recorded them (context path): the zero
     // padding behind them contributes nothing and is not fetched
     unsigned cnt = NN;
@@ -70,7 +75,7 @@ __device__ __forceinline__ void eval_pair_body(const typename Vec4<IT>::type *__
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
             float e, ax, ay, az;
-            pair_eval<KIND>(v[u].x, v[u].y, v[u].z, p, e, ax, ay, az);
+            pair_eval<KIND>(v[u].x, v[u].y, v[u].z, p, e, ax, ay, az, v[u].w, own_type);
             fx += ax;
             fy += ay;
             fz += az;

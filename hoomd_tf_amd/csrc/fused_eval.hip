@@ -97,7 +97,7 @@ __device__ __forceinline__ unsigned fused_sweep(FusedAcc &acc, const typename Ve
                 // the model sees the pair vector after tf.cast to fp32 (simmodel.py:226-227)
                 const float x = (float)dx, y = (float)dy, z = (float)dz;
                 float e, ax, ay, az;
-                pair_eval<KIND>(x, y, z, p, e, ax, ay, az);
+                pair_eval<KIND>(x, y, z, p, e, ax, ay, az, (float)scalar_as_int(pk[t].w), (float)scalar_as_int(pi.w));
                 acc.fx += ax;
                 acc.fy += ay;
                 acc.fz += az;
@@ -325,7 +325,7 @@ __device__ __forceinline__ void fused_rows_group(
                 if (__builtin_amdgcn_inverse_ballot_w64(ms)) store_stream(&row[qq], make_float4(x, y, z, (float)scalar_as_int(pk.w)));
             }
             float e, ax, ay, az;
-            pair_eval_if<KIND>(keep, x, y, z, p, e, ax, ay, az);
+            pair_eval_if<KIND>(keep, x, y, z, p, e, ax, ay, az, (float)scalar_as_int(pk.w), (float)scalar_as_int(pi[r].w));
             fx += ax;
             fy += ay;
             fz += az;
@@ -477,7 +477,7 @@ __device__ __forceinline__ void fused_rows_group_tails(
                 if (__builtin_amdgcn_inverse_ballot_w64(ms)) store_stream(&row[qq], make_float4(x, y, z, (float)scalar_as_int(pk.w)));
             }
             float e, ax, ay, az;
-            pair_eval_if<KIND>(keep, x, y, z, p, e, ax, ay, az);
+            pair_eval_if<KIND>(keep, x, y, z, p, e, ax, ay, az, (float)scalar_as_int(pk.w), (float)scalar_as_int(pi[r].w));
             fx[r] += ax;
             fy[r] += ay;
             fz[r] += az;
@@ -492,6 +492,7 @@ __device__ __forceinline__ void fused_rows_group_tails(
             pil.x = rl == (unsigned)r ? pi[r].x : pil.x;
             pil.y = rl == (unsigned)r ? pi[r].y : pil.y;
             pil.z = rl == (unsigned)r ? pi[r].z : pil.z;
+            pil.w = rl == (unsigned)r ? pi[r].w : pil.w; // (read by generated bodies only: dead code for the closed forms)
         }
         PT dx, dy, dz;
         const PT rsq = pair_vec(qt, pil, dx, dy, dz);
@@ -509,7 +510,7 @@ __device__ __forceinline__ void fused_rows_group_tails(
         if constexpr (STORE)
             if (keep && qq < NN) store_stream(dest + (size_t)(w0 + rl) * NN + qq, make_float4(xt, yt, zt, (float)scalar_as_int(qt.w)));
         float e, ax, ay, az;
-        pair_eval_if<KIND>(keep, xt, yt, zt, p, e, ax, ay, az);
+        pair_eval_if<KIND>(keep, xt, yt, zt, p, e, ax, ay, az, (float)scalar_as_int(qt.w), (float)scalar_as_int(pil.w));
         const unsigned px = 0;
 #pragma unroll
         for (int r = 0; r < R; ++r) {

@@ -18,6 +18,9 @@ struct PotParams {
     int power[HTF_MAX_POLY_TERMS];
     float poly_cut_r2; // RINV_POLY mask: smallest fp32 t with sqrtf(t) >= poly_cut (0: no mask)
     const struct JitKernels *jit; // HTF_POT_JIT: the loaded code object's kernels (csrc/jit.hip); host-side only
+    int jit_flags;                // HTF_JIT_READS_OWN_TYPE
+    const void *own;              // streaming evaluator of a generated unit: the rows' positions ([B] x 4, w = type as a float) or null
+    int own_f64;
 };
 
 // HTF_POT_JIT (csrc/jit.hip): a code object built by hoomd_tf_amd/codegen.py from csrc/jit_unit.hip

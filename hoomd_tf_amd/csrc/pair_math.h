@@ -110,7 +110,9 @@ __device__ __forceinline__ RinvFwd rinv_fwd(float x, float y, float z) {
 //  config C4 -- computes it once; pair_eval below is the one-potential form)
 template <int KIND>
 __device__ __forceinline__ void pair_eval_f(const RinvFwd &f, float x, float y, float z, const PotParams &p,
-                                            float &e, float &fx, float &fy, float &fz) {
+                                            float &e, float &fx, float &fy, float &fz, float tj = 0.0f, float ti = 0.0f) {
+    // (tj, ti: the neighbor's and the row particle's own type as floats -- nlist[i, j, 3] and positions[i, 3] -- read by generated
+    //  bodies only; every built-in closed form ignores them and the compiler drops the conversions at its call sites)
     if constexpr (KIND == HTF_POT_SIMPLE) {
         // build_examples.py:9-22: -1 * ((1/|x|) * x), non-finite -> 0 (forward only)
         float rs = sqrtf(x * x + y * y + z * z);
@@ -142,7 +144,7 @@ __device__ __forceinline__ void pair_eval_f(const RinvFwd &f, float x, float y, 
         // A traced elementwise energy (hoomd_tf_amd/codegen.py): HTF_JIT_BODY is generated code that reads
         //   s  = nlist_rinv of the slot (0 where masked), with d s / d r' = -s^2 where f.cond,
         //   r  = safe_norm of the slot (r' = |x + 1e-7|),
-        //   x, y, z (for masks on the plain norm)
+        //   x, y, z (for masks on the plain norm), tj, ti (types: parameter tables by species)
         // and assigns `e` (the slot's energy) and `dedr` (its total derivative with respect to r', forward mode).
         // nlist_forces = 2 de/dr' t / r' (simmodel.py:548), as every rinv-based closed form above.
 #ifdef HTF_JIT_BODY
@@ -240,11 +242,11 @@ __device__ __forceinline__ void pair_eval_f(const RinvFwd &f, float x, float y, 
 
 template <int KIND>
 __device__ __forceinline__ void pair_eval(float x, float y, float z, const PotParams &p,
-                                          float &e, float &fx, float &fy, float &fz) {
+                                          float &e, float &fx, float &fy, float &fz, float tj = 0.0f, float ti = 0.0f) {
     if constexpr (KIND == HTF_POT_SIMPLE || KIND == HTF_POT_LJ_PARAM) {
         pair_eval_f<KIND>(RinvFwd(), x, y, z, p, e, fx, fy, fz); // these two do not use the shared forward
     } else {
-        pair_eval_f<KIND>(rinv_fwd(x, y, z), x, y, z, p, e, fx, fy, fz);
+        pair_eval_f<KIND>(rinv_fwd(x, y, z), x, y, z, p, e, fx, fy, fz, tj, ti);
     }
 }
 
@@ -254,13 +256,13 @@ __device__ __forceinline__ void pair_eval(float x, float y, float z, const PotPa
 // select; the others are evaluated where they are and their four results selected.
 template <int KIND>
 __device__ __forceinline__ void pair_eval_if(bool keep, float x, float y, float z, const PotParams &p, float &e, float &fx,
-                                             float &fy, float &fz) {
+                                             float &fy, float &fz, float tj = 0.0f, float ti = 0.0f) {
     if constexpr (KIND == HTF_POT_LJ || KIND == HTF_POT_WCA || KIND == HTF_POT_LJ_PARAM || KIND == HTF_POT_GAUSS) {
         // far enough that w1^6 / r^6 underflows for any sane w1 (1e18), near enough that (r - r0)^2 / gap stays finite (1e12)
         constexpr float kFar = KIND == HTF_POT_GAUSS ? 1e12f : 1e18f;
         pair_eval<KIND>(keep ? x : kFar, y, z, p, e, fx, fy, fz);
     } else {
-        pair_eval<KIND>(x, y, z, p, e, fx, fy, fz);
+        pair_eval<KIND>(x, y, z, p, e, fx, fy, fz, tj, ti);
         e = keep ? e : 0.0f;
         fx = keep ? fx : 0.0f;
         fy = keep ? fy : 0.0f;

@@ -63,6 +63,7 @@ void bind(py::module &m, const char *name, R (*fn)(A...)) {
     X(htf_potential_destroy) \
     X(htf_build_pair_vectors) \
     X(htf_eval_forces) \
+    X(htf_eval_forces_typed) \
     X(htf_fused_forces) \
     X(htf_build_eval_forces) \
     X(htf_eval_forces2) \

@@ -132,9 +132,10 @@ class Potential:
         return cls(_lib.POT_LJ_PARAM, lj_param=(w0, w1), theta=theta)
 
     @classmethod
-    def jit(cls, body):
+    def jit(cls, body, reads_own_type=False):
         """A traced elementwise pair energy as generated kernels (hoomd_tf_amd/codegen.py): ``body`` is the text
-        codegen.generate_body emitted; compiled once per expression (``hipcc --genco``, cached), loaded as HTF_POT_JIT."""
+        codegen.generate_body emitted; compiled once per expression (``hipcc --genco``, cached), loaded as HTF_POT_JIT.
+        ``reads_own_type``: the body reads ``ti`` (positions[i, 3]) -- the streaming evaluator then needs the positions."""
         from . import codegen
         image, key = codegen.compile_body(body)
         self = cls.__new__(cls)
@@ -143,6 +144,8 @@ class Potential:
         self._image = C.create_string_buffer(image, len(image))   # (kept alive with the potential)
         d.jit_image = C.cast(self._image, C.c_void_p)
         d.jit_image_bytes = len(image)
+        d.jit_flags = _lib.JIT_READS_OWN_TYPE if reads_own_type else 0
+        self.reads_own_type = bool(reads_own_type)
         self.theta, self._keep, self.kind, self.jit_key, self.body = None, [], _lib.POT_JIT, key, body
         self._h = C.c_void_p()
         check(lib.htf_potential_create(C.byref(d), C.byref(self._h)))
@@ -196,9 +199,10 @@ def build_pair_vectors(pos, n_neigh, head_list, nlist, box, r_cut, NN, offset=0,
     return out
 
 
-def eval_forces(potential, nlist, virial=False, out=None, out_dtype=None, virial_out=None):
+def eval_forces(potential, nlist, virial=False, out=None, out_dtype=None, virial_out=None, positions=None):
     """SimModel.compute for a declarative potential: nlist [B,NN,4] -> forces [B,4]
-    (fx, fy, fz, energy) and, if ``virial``, the [B,3,3] virial."""
+    (fx, fy, fz, energy) and, if ``virial``, the [B,3,3] virial.  ``positions`` ([B,4], the tensor compute() receives beside
+    nlist): needed by a traced energy that reads the row particle's own type (htf_eval_forces_typed), ignored otherwise."""
     _dev(nlist, "nlist")
     if nlist.dim() != 3 or nlist.shape[2] != 4:
         raise ValueError("nlist must be [B, NN, 4]")
@@ -211,8 +215,15 @@ def eval_forces(potential, nlist, virial=False, out=None, out_dtype=None, virial
     if virial:
         v = virial_out if virial_out is not None else torch.empty((B, 3, 3), dtype=out.dtype, device=nlist.device)
         _dev(v, "virial_out", out.dtype)
-    check(lib.htf_eval_forces(potential.handle, nlist.data_ptr(), _dt(nlist), B, NN, out.data_ptr(), _dt(out),
-                              v.data_ptr() if v is not None else None, _stream(nlist)))
+    if positions is not None:
+        _dev(positions, "positions")
+        if positions.dim() != 2 or positions.shape[0] < B or positions.shape[1] != 4 or not positions.is_contiguous():
+            raise ValueError("positions must be a contiguous [B, 4] tensor")
+        check(lib.htf_eval_forces_typed(potential.handle, nlist.data_ptr(), _dt(nlist), B, NN, positions.data_ptr(), _dt(positions),
+                                        out.data_ptr(), _dt(out), v.data_ptr() if v is not None else None, _stream(nlist)))
+    else:
+        check(lib.htf_eval_forces(potential.handle, nlist.data_ptr(), _dt(nlist), B, NN, out.data_ptr(), _dt(out),
+                                  v.data_ptr() if v is not None else None, _stream(nlist)))
     return (out, v) if virial else out
 
 

@@ -85,6 +85,10 @@ class Nlist(_TorchOperand):
         full = slice(None)
         if isinstance(idx, tuple) and len(idx) == 3 and idx[0] == full and idx[1] == full and idx[2] == slice(None, 3):
             return NlistXYZ(self)
+        if (isinstance(idx, tuple) and len(idx) == 3 and idx[0] == full and idx[1] == full and isinstance(idx[2], int)
+                and not isinstance(idx[2], bool) and idx[2] == 3):
+            from . import codegen as cg
+            return TypeExpr(cg.TJ, nlist=self)   # the neighbors' types: symbolic for traced energies, a tensor to torch code
         return self.ad[idx]
 
     def numpy(self):
@@ -142,6 +146,128 @@ class Positions(_TorchOperand):
 
     def numpy(self):
         return self.tensor.cpu().numpy()
+
+
+class PositionsInput(torch.Tensor):
+    """The ``N x 4`` positions tensor handed to ``compute`` of a neighbor-list model: a torch tensor in every respect but one --
+    ``positions[:, 3]``, the particles' own types, keeps its identity (:class:`TypeExpr`) so that a traced pair energy can look
+    parameters up by species pair (``htf.gather(table, ti[:, None] * ntypes + tj)``) inside a generated kernel.  Everything
+    computed from it is a plain tensor."""
+
+    @staticmethod
+    def wrap(t):
+        out = t.as_subclass(PositionsInput)
+        out._htf_input = True
+        return out
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*args, **(kwargs or {}))
+
+    def plain(self):
+        return self.as_subclass(torch.Tensor)
+
+    def __getitem__(self, idx):
+        if (getattr(self, "_htf_input", False) and isinstance(idx, tuple) and len(idx) == 2 and idx[0] == slice(None)
+                and isinstance(idx[1], int) and not isinstance(idx[1], bool) and idx[1] == 3):
+            from . import codegen as cg
+            return TypeExpr(cg.TI, positions=self.plain(), expanded=False)
+        return self.plain()[idx]
+
+
+class TypeExpr(_TorchOperand):
+    """An expression of particle TYPES only: ``nlist[:, :, 3]`` (the neighbors', [N, NN]), ``positions[:, 3]`` (the row particles'
+    own, [N]; ``[:, None]`` makes it [N, 1]) and integer arithmetic on them -- the index of a parameter table.  Symbolic until it
+    meets a traced pair expression, ``htf.gather`` or a comparison; torch code sees the tensor it stands for."""
+
+    def __init__(self, node, nlist=None, positions=None, expanded=True):
+        self.node, self.nlist, self.positions, self.expanded = node, nlist, positions, expanded
+
+    __hash__ = object.__hash__
+
+    @property
+    def pair_shaped(self):
+        return self.nlist is not None
+
+    @property
+    def ad(self):
+        from . import codegen as cg
+        tj = self.nlist.tensor[:, :, 3] if self.nlist is not None else None
+        ti = None
+        if self.positions is not None:
+            ti = self.positions[:, 3]
+            ti = ti[:, None] if (self.expanded or self.nlist is not None) else ti
+        ref = tj if tj is not None else ti
+        return cg.evaluate(self.node, ref, ref, ref, tj=tj, ti=ti)
+
+    def tensor(self):
+        return self.ad
+
+    def __getitem__(self, idx):
+        if self.nlist is None and not self.expanded and idx in ((slice(None), None), (Ellipsis, None)):
+            return TypeExpr(self.node, None, self.positions, expanded=True)
+        return self.ad[idx]
+
+    def _join(self, o):
+        if self.nlist is not None and o.nlist is not None and o.nlist is not self.nlist and o.nlist.tensor is not self.nlist.tensor:
+            raise ValueError("expressions come from different neighbor lists")
+        for t in (self, o):
+            if t.nlist is None and not t.expanded and (self.nlist is not None or o.nlist is not None):
+                raise ValueError("positions[:, 3] is [N]: write positions[:, 3][:, None] to combine it with per-neighbor values")
+        return (self.nlist or o.nlist, self.positions if self.positions is not None else o.positions,
+                self.expanded and o.expanded)
+
+    def _bin(self, op, other, swap=False):
+        from . import codegen as cg
+        if isinstance(other, (PairExpr, RinvPoly, SafeNorm, PairNorm, PairMask)):
+            e = PairExpr.of(other)
+            me = PairExpr.of(self, e.nlist)
+            return e._with(op, me) if swap else me._with(op, e)
+        if isinstance(other, TypeExpr):
+            nl, pos, ex = self._join(other)
+            args = (other.node, self.node) if swap else (self.node, other.node)
+            return TypeExpr(cg.Node(op, args), nl, pos, ex)
+        if isinstance(other, (int, float, np.integer, np.floating)) and not isinstance(other, bool):
+            args = (cg.const(other), self.node) if swap else (self.node, cg.const(other))
+            return TypeExpr(cg.Node(op, args), self.nlist, self.positions, self.expanded)
+        a, b = (_unwrap(other), self.ad) if swap else (self.ad, _unwrap(other))   # a tensor: torch from here on
+        return {"add": torch.add, "sub": torch.sub, "mul": torch.mul, "div": torch.div}[op](torch.as_tensor(a), torch.as_tensor(b))
+
+    def __add__(self, o): return self._bin("add", o)
+    def __radd__(self, o): return self._bin("add", o, swap=True)
+    def __sub__(self, o): return self._bin("sub", o)
+    def __rsub__(self, o): return self._bin("sub", o, swap=True)
+    def __mul__(self, o): return self._bin("mul", o)
+    def __rmul__(self, o): return self._bin("mul", o, swap=True)
+    def __truediv__(self, o): return self._bin("div", o)
+    def __rtruediv__(self, o): return self._bin("div", o, swap=True)
+
+    def _cmp(self, op, o):
+        from . import codegen as cg
+        if isinstance(o, TypeExpr) and (self.nlist is not None or o.nlist is not None):
+            nl, pos, _ = self._join(o)
+            return PairCond(nl, cg.Node(op, (self.node, o.node)), pos)
+        if isinstance(o, (int, float, np.integer, np.floating)) and not isinstance(o, bool) and self.nlist is not None:
+            return PairCond(self.nlist, cg.Node(op, (self.node, cg.const(o))), self.positions)
+        # (the particles' own types alone -- ``positions[:, 3] == 0`` -- are not a per-pair condition: the tensor's comparison)
+        return {"lt": torch.lt, "le": torch.le, "gt": torch.gt, "ge": torch.ge, "eq": torch.eq, "ne": torch.ne}[op](self.ad, _unwrap(o))
+
+    def __lt__(self, o): return self._cmp("lt", o)
+    def __le__(self, o): return self._cmp("le", o)
+    def __gt__(self, o): return self._cmp("gt", o)
+    def __ge__(self, o): return self._cmp("ge", o)
+    def __eq__(self, o): return self._cmp("eq", o)
+    def __ne__(self, o): return self._cmp("ne", o)
+
+    # what a tensor offers (``.long()``, ``.shape`` ...): torch code gets the tensor
+    def __getattr__(self, name):
+        if name.startswith("_") or name in ("node", "nlist", "positions", "expanded"):
+            raise AttributeError(name)
+        return getattr(self.ad, name)
+
+    def numpy(self):
+        return self.ad.cpu().numpy()
 
 
 class PosNorm(_TorchOperand):
@@ -256,7 +382,9 @@ def cast(x, dtype=None):
     """tf.cast for model code: a symbolic mask stays symbolic, tensors are converted."""
     if isinstance(x, PairCond):
         from . import codegen as cg
-        return PairExpr(x.nlist, cg.Node("mask", (x.node,)))
+        return PairExpr(x.nlist, cg.Node("mask", (x.node,)), positions=x.positions)
+    if isinstance(x, TypeExpr):
+        return x   # (types are small integers held exactly as floats: an int cast changes nothing the kernel sees)
     if isinstance(x, PairMask):
         return x if dtype is None or dtype == torch.bool else PairMask(x.nlist, x.cut, as_dtype=dtype)
     t = _unwrap(x)
@@ -420,8 +548,9 @@ class PairExpr(PairEnergy):
     padded slot keeps the torch route (codegen.vanishes_on_padding)."""
     owns_potential = False
 
-    def __init__(self, nlist, node, reduced=False):
-        self.nlist, self.node, self.reduced = nlist, node, reduced
+    def __init__(self, nlist, node, reduced=False, positions=None):
+        # positions: the [N, 4] tensor of compute(), kept when the expression reads the row particles' own types (TypeExpr)
+        self.nlist, self.node, self.reduced, self.positions = nlist, node, reduced, positions
 
     # ---- construction from the other symbolic types
     @staticmethod
@@ -446,6 +575,15 @@ class PairExpr(PairEnergy):
             return PairExpr(x.xyz.parent, cg.RN)
         if isinstance(x, PairMask):
             return PairExpr(x.nlist, cg.Node("mask", (cg.Node("lt", (cg.RN, cg.const(x.cut))),)))
+        if isinstance(x, TypeExpr):
+            nl = x.nlist if x.nlist is not None else nlist
+            if nl is None:
+                raise TypeError("an expression of positions[:, 3] alone is not a pair expression")
+            if x.nlist is None and not x.expanded:
+                raise ValueError("positions[:, 3] is [N]: write positions[:, 3][:, None] to combine it with per-neighbor values")
+            return PairExpr(nl, x.node, positions=x.positions)
+        if isinstance(x, PairCond):
+            raise TypeError("a comparison is not a value: htf.cast it, or use it in htf.where")
         if nlist is not None:
             return PairExpr(nlist, cg.wrap(x))
         raise TypeError("cannot trace %r" % (type(x),))
@@ -455,12 +593,12 @@ class PairExpr(PairEnergy):
         if self.reduced:
             raise TypeError("a per-particle sum is not a per-pair expression any more")
         if other is None:
-            return PairExpr(self.nlist, cg.Node(op, (self.node,), value=value))
+            return PairExpr(self.nlist, cg.Node(op, (self.node,), value=value), positions=self.positions)
         o = PairExpr.of(other, self.nlist)
         if o.nlist is not self.nlist and o.nlist.tensor is not self.nlist.tensor:
             raise ValueError("expressions come from different neighbor lists")
         args = (o.node, self.node) if swap else (self.node, o.node)
-        return PairExpr(self.nlist, cg.Node(op, args))
+        return PairExpr(self.nlist, cg.Node(op, args), positions=self.positions if self.positions is not None else o.positions)
 
     def __add__(self, o):
         if isinstance(o, BiasTerm):
@@ -481,7 +619,9 @@ class PairExpr(PairEnergy):
             raise TypeError("only constant exponents can be traced")
         return self._with("pow", value=float(n))
 
-    def _cmp(self, op, o): return PairCond(self.nlist, PairExpr.of(self, self.nlist)._with(op, o).node)
+    def _cmp(self, op, o):
+        e = PairExpr.of(self, self.nlist)._with(op, o)
+        return PairCond(self.nlist, e.node, e.positions)
     def __lt__(self, o): return self._cmp("lt", o)
     def __le__(self, o): return self._cmp("le", o)
     def __gt__(self, o): return self._cmp("gt", o)
@@ -512,8 +652,13 @@ class PairExpr(PairEnergy):
     def key(self):
         return ("jit", self.body())
 
+    @property
+    def reads_own_type(self):
+        from . import codegen as cg
+        return cg.reads(self.node, "ti")
+
     def potential(self):
-        return ops.Potential.jit(self.body())
+        return ops.Potential.jit(self.body(), reads_own_type=self.reads_own_type)
 
     def torch_value(self, nl_tensor):
         """[N, NN] value from a pair-vector tensor (an autograd leaf for the generic route), in its dtype."""
@@ -524,7 +669,8 @@ class PairExpr(PairEnergy):
         ok = r > 3e-6
         s = torch.where(ok, 1.0 / (torch.where(ok, r, torch.ones_like(r)) + 3e-6), torch.zeros_like(r))
         rn = torch.sqrt((x * x).sum(dim=2)).detach()
-        return cg.evaluate(self.node, s, r, rn)
+        ti = self.positions[:nl_tensor.shape[0], 3][:, None].to(nl_tensor.dtype) if self.positions is not None else None
+        return cg.evaluate(self.node, s, r, rn, tj=nl_tensor[:, :, 3].detach(), ti=ti)
 
     def tensor(self):
         _trace_log().append({"op": "eager_value"})
@@ -540,12 +686,56 @@ class PairExpr(PairEnergy):
 class PairCond:
     """A comparison of traced expressions: the condition of ``where`` / the argument of ``cast`` (no gradient)."""
 
-    def __init__(self, nlist, node):
-        self.nlist, self.node = nlist, node
+    def __init__(self, nlist, node, positions=None):
+        self.nlist, self.node, self.positions = nlist, node, positions
+        if nlist is None:
+            raise TypeError("a comparison of positions[:, 3] alone is not a per-pair condition: bring the neighbor types in, or "
+                            "use torch on the tensor")
 
 
 def _sym(x):
     return isinstance(x, (PairExpr, RinvPoly, SafeNorm))
+
+
+def _first_positions(*xs):
+    for x in xs:
+        if getattr(x, "positions", None) is not None:
+            return x.positions
+    return None
+
+
+def gather(params, indices, axis=0):
+    """tf.gather for model code.  A CONSTANT 1-D ``params`` looked up by a traced type expression
+    (``ti[:, None] * ntypes + tj``) becomes a table of the generated kernel: per-species-pair parameters of a traced energy."""
+    from . import codegen as cg
+    if isinstance(indices, (TypeExpr, PairExpr)):
+        vals = params.detach().cpu().numpy() if isinstance(params, torch.Tensor) else np.asarray(params, dtype=np.float64)
+        if vals.ndim == 1 and axis == 0 and 1 <= vals.size <= cg.MAX_TABLE:
+            if isinstance(indices, TypeExpr) and indices.nlist is None:
+                raise TypeError("gather by positions[:, 3] alone is not a per-pair value: index with the neighbor types too, or use torch")
+            e = PairExpr.of(indices)
+            return PairExpr(e.nlist, cg.table(vals, e.node), positions=e.positions)
+    p = torch.as_tensor(_unwrap(params))
+    i = torch.as_tensor(_unwrap(indices)).to(torch.int64)
+    return p[i] if axis == 0 else torch.index_select(p, axis, i.reshape(-1)).reshape(p.shape[:axis] + i.shape + p.shape[axis + 1:])
+
+
+def equal(a, b):
+    """tf.equal: traced on type / pair expressions."""
+    if isinstance(a, (TypeExpr, PairExpr)):
+        return a._cmp("eq", b)
+    if isinstance(b, (TypeExpr, PairExpr)):
+        return b._cmp("eq", a)
+    return torch.eq(torch.as_tensor(_unwrap(a)), torch.as_tensor(_unwrap(b)))
+
+
+def not_equal(a, b):
+    """tf.not_equal: traced on type / pair expressions."""
+    if isinstance(a, (TypeExpr, PairExpr)):
+        return a._cmp("ne", b)
+    if isinstance(b, (TypeExpr, PairExpr)):
+        return b._cmp("ne", a)
+    return torch.ne(torch.as_tensor(_unwrap(a)), torch.as_tensor(_unwrap(b)))
 
 
 def _unary(op, x, torch_fn):
@@ -604,7 +794,7 @@ def where(cond, a, b):
     from . import codegen as cg
     if isinstance(cond, PairCond):
         ea, eb = PairExpr.of(a, cond.nlist), PairExpr.of(b, cond.nlist)
-        return PairExpr(cond.nlist, cg.Node("where", (cond.node, ea.node, eb.node)))
+        return PairExpr(cond.nlist, cg.Node("where", (cond.node, ea.node, eb.node)), positions=_first_positions(cond, ea, eb))
     return torch.where(_unwrap(cond), torch.as_tensor(_unwrap(a)), torch.as_tensor(_unwrap(b)))
 
 
@@ -856,12 +1046,12 @@ def reduce_sum(x, axis=None):
         return RinvPoly(x.nlist, x.terms, reduced=True, cut=x.cut)
     if isinstance(x, PairExpr):
         if axis is None:
-            out = PairExpr(x.nlist, x.node, reduced=True)
+            out = PairExpr(x.nlist, x.node, reduced=True, positions=x.positions)
             out.total = True
             return out
         if axis not in (1, -1):
             raise ValueError("pair energies reduce over the neighbor axis (axis=1), or over everything (axis=None)")
-        return PairExpr(x.nlist, x.node, reduced=True)
+        return PairExpr(x.nlist, x.node, reduced=True, positions=x.positions)
     if isinstance(x, WCAPair):
         return x
     if isinstance(x, LJParamEnergy):
@@ -909,7 +1099,12 @@ def compute_nlist_forces(nlist, energy, virial=False):
             raise ValueError("virial of an EDS-biased energy is not implemented")
         return _biased_forces(nl, energy)
     pot = _potential_of(energy)
-    out = ops.eval_forces(pot, nl.tensor, virial=virial)
+    own = None
+    if isinstance(energy, PairExpr) and energy.reads_own_type:
+        if energy.positions is None:
+            raise ValueError("the traced energy reads the particles' own types but no positions tensor reached it")
+        own = energy.positions[:nl.tensor.shape[0]].to(nl.tensor.dtype).contiguous()
+    out = ops.eval_forces(pot, nl.tensor, virial=virial, positions=own)
     f = out[0] if virial else out
     if getattr(energy, "total", False):
         f[:, 3] = f[:, 3].sum()  # rank-0 energy: the total in every particle's column
@@ -1070,6 +1265,8 @@ def wrap_vector(r, box):
 def masked_nlist(nlist, type_tensor, type_i=None, type_j=None):
     """simmodel.py:676-693 (eager; pure data movement)."""
     t = nlist.tensor if isinstance(nlist, Nlist) else nlist
+    if isinstance(type_tensor, TypeExpr):
+        type_tensor = type_tensor.ad   # (``positions[:, 3]``: the view it stands for)
     _trace_log().append({"op": "masked_nlist"})
     if type_i is not None:
         t = t[type_tensor == type_i]
@@ -1087,6 +1284,8 @@ def compute_rdf(nlist, r_range, type_tensor=None, nbins=100, type_i=None, type_j
     plan like the reference's tf.function does -- no Python in the step loop (tfcompute._maybe_install_plan)."""
     t = nlist.tensor if isinstance(nlist, Nlist) else nlist
     ops._dev(t, "nlist")
+    if isinstance(type_tensor, TypeExpr):
+        type_tensor = type_tensor.ad   # (``positions[:, 3]``: the view of the step's positions tensor it stands for)
     r0, r1 = float(r_range[0]), float(r_range[1])
     hist = torch.zeros(nbins + 2, dtype=torch.int32, device=t.device)
     tt, stride = None, 0
@@ -1341,6 +1540,8 @@ class SimModel:
         positions = positions.to(self.dtype)
         if self.nneighbor_cutoff == 0:
             positions = Positions(positions)  # CV-bias models differentiate w.r.t. positions
+        else:
+            positions = PositionsInput.wrap(positions)   # (a tensor whose [:, 3] keeps its identity for traced energies)
         return [Nlist(nlist.to(self.dtype)), positions, box.to(self.dtype)]
 
     @staticmethod

@@ -135,7 +135,12 @@ typedef struct htf_potential_desc {
     /* HTF_POT_JIT: the code object (appended with ABI version 3) */
     const void *jit_image;
     size_t jit_image_bytes;
+    /* HTF_POT_JIT: HTF_JIT_READS_OWN_TYPE when the traced energy reads the ROW particle's own type (positions[i, 3]: a parameter
+     * table by species pair) -- the streaming evaluator then needs the positions tensor beside the pair vectors
+     * (htf_eval_forces_typed); the one-kernel step has it anyway.  The neighbor's type (nlist[i, j, 3]) is in the tensor. */
+    int jit_flags;
 } htf_potential_desc;
+#define HTF_JIT_READS_OWN_TYPE 1
 
 typedef struct htf_potential htf_potential; /* opaque; owns device copies of weights */
 
@@ -171,6 +176,14 @@ HTF_API int htf_build_pair_vectors(void *dest, int dest_dtype,
  * force_dtype, as _compute_virial returns (simmodel.py:509-523). */
 HTF_API int htf_eval_forces(const htf_potential *pot,
                     const void *d_nlist, int nlist_dtype, unsigned B, unsigned NN,
+                    void *d_force, int force_dtype, void *d_virial9, htf_stream stream);
+
+/* htf_eval_forces for a potential that reads the row particle's own type: d_positions is the [B, 4] tensor compute() receives
+ * beside nlist (simmodel.py:99-105: x, y, z, type as a float), positions_dtype its scalar type.  Any potential may be evaluated
+ * through it (the positions are then ignored); a HTF_JIT_READS_OWN_TYPE potential handed to htf_eval_forces is HTF_ERR_INVALID. */
+HTF_API int htf_eval_forces_typed(const htf_potential *pot,
+                    const void *d_nlist, int nlist_dtype, unsigned B, unsigned NN,
+                    const void *d_positions, int positions_dtype,
                     void *d_force, int force_dtype, void *d_virial9, htf_stream stream);
 
 /* htf_build_pair_vectors + htf_eval_forces in one pass with the pair vectors kept in

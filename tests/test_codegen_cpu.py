@@ -118,3 +118,91 @@ def test_generated_unit_cross_compiles_for_gfx950():
         assert name.encode() in image
     image2, key2 = cg.compile_body(e.body())
     assert key2 == key and image2 == image                     # from the cache
+
+
+TYPED_HARNESS = HARNESS.replace('#include <stdio.h>', '#include <stdio.h>\n#define min(a, b) ((a) < (b) ? (a) : (b))\n#define max(a, b) ((a) > (b) ? (a) : (b))') \
+    .replace("float x, y, z;", "float x, y, z, tj, ti;").replace('scanf("%f %f %f", &x, &y, &z) == 3', 'scanf("%f %f %f %f %f", &x, &y, &z, &tj, &ti) == 5') \
+    .replace("static constexpr", "static const")
+
+
+def _typed_models(htf, x, positions, ntypes, big):
+    """Per-species-pair parameters of a traced energy: tables looked up by (own type, neighbor type)."""
+    s = htf.nlist_rinv(x)
+    r = htf.safe_norm(x[:, :, :3], axis=2)
+    tj = htf.cast(x[:, :, 3], torch.int32)
+    ti = htf.cast(positions[:, 3], torch.int32)
+    idx = ti[:, None] * ntypes + tj
+    rng = np.random.default_rng(7)
+    eps = rng.uniform(0.5, 1.5, ntypes * ntypes)
+    sig = rng.uniform(0.8, 1.1, ntypes * ntypes)
+    models = {
+        "lj_table": 4.0 * htf.gather(eps, idx) * ((htf.gather(sig, idx) * s) ** 12 - (htf.gather(sig, idx) * s) ** 6),
+        "unlike_only": htf.cast(htf.not_equal(tj, ti[:, None]), torch.float32) * 2.0 * htf.exp(-0.5 * r) * s,
+        "neighbor_species": htf.where(tj == 1, 3.0 * s ** 4, 0.5 * s ** 8),
+    }
+    if big:
+        models["wide_table"] = htf.gather(rng.uniform(0.5, 1.5, 64), idx * 3 + 1) * s ** 6     # 64 entries: a constant array of the unit
+    return models
+
+
+def test_typed_expressions_and_their_derivatives():
+    import hoomd_tf_amd as htf
+    from hoomd_tf_amd import codegen as cg
+    from hoomd_tf_amd.simmodel import PairExpr, PositionsInput, TypeExpr
+    rng = np.random.default_rng(3)
+    ntypes = 3
+    nl, _ = random_nlist(rng, 40, 12, fill=0.6, rmin=0.85, rmax=2.9, dtype=np.float64)
+    live = nl[:, :, :3].any(axis=2)
+    nl[:, :, 3] = np.where(live, rng.integers(0, ntypes, live.shape), 0)
+    pos = np.zeros((40, 4))
+    pos[:, 3] = rng.integers(0, ntypes, 40)
+    x = htf.Nlist(torch.from_numpy(nl))
+    P = PositionsInput.wrap(torch.from_numpy(pos))
+    assert isinstance(x[:, :, 3], TypeExpr) and isinstance(P[:, 3], TypeExpr)
+    assert type(P[:, :3]) is torch.Tensor and type(P * 2.0) is torch.Tensor          # everything else: plain tensors
+    assert torch.equal(torch.as_tensor((P[:, 3][:, None] * ntypes + x[:, :, 3]).ad), torch.from_numpy(pos[:, 3:4] * ntypes + nl[:, :, 3]))
+    with pytest.raises(ValueError):
+        P[:, 3] * htf.nlist_rinv(x)                                                       # [N] against [N, NN]: as torch would
+    pts = nl.reshape(-1, 4)
+    own = np.repeat(pos[:, 3], 12)
+    for name, e in _typed_models(htf, x, P, ntypes, big=True).items():
+        assert isinstance(e, PairExpr) and e.lowers(), name
+        assert e.reads_own_type == (name != "neighbor_species"), name
+        t = torch.from_numpy(pts[:, :3] + 1e-7)
+        r = torch.sqrt((t * t).sum(dim=1)).requires_grad_(True)
+        ok = r > 3e-6
+        sv = torch.where(ok, 1.0 / (torch.where(ok, r, torch.ones_like(r)) + 3e-6), torch.zeros_like(r))
+        rn = torch.sqrt((torch.from_numpy(pts[:, :3]) ** 2).sum(dim=1))
+        val = cg.evaluate(e.node, sv, r, rn, tj=torch.from_numpy(pts[:, 3]), ti=torch.from_numpy(own))
+        (grad,) = torch.autograd.grad(val.sum(), r)
+        # == the expression's own torch value through the symbolic layer (what the generic route would differentiate)
+        np.testing.assert_allclose(e.torch_value(torch.from_numpy(nl)).reshape(-1).numpy(), val.detach().numpy(), rtol=1e-12, atol=1e-300)
+        with tempfile.TemporaryDirectory() as tmp:
+            src = os.path.join(tmp, "h.c")
+            with open(src, "w") as f:
+                f.write(TYPED_HARNESS.replace("BODY", e.body().replace("static constexpr", "static const")))
+            exe = os.path.join(tmp, "h")
+            subprocess.check_call(["gcc", "-O1", "-o", exe, src, "-lm"])
+            rows = np.concatenate([pts.astype(np.float32), own[:, None].astype(np.float32)], axis=1)
+            out = subprocess.run([exe], input="\n".join("%.9g %.9g %.9g %.9g %.9g" % tuple(p) for p in rows), capture_output=True,
+                                 text=True, check=True).stdout
+        got = np.array([[float(v) for v in line.split()] for line in out.strip().splitlines()])
+        lv = pts[:, :3].any(axis=1)
+        scale_e, scale_g = np.abs(val.detach().numpy()).max(), np.abs(grad.numpy()).max()
+        assert np.abs(got[:, 0] - val.detach().numpy()).max() < 3e-6 * scale_e, name
+        assert np.abs(got[:, 1] - grad.numpy())[lv].max() < 1e-5 * scale_g, name
+        assert np.all(got[~lv] == 0.0), name
+
+
+def test_typed_unit_cross_compiles_and_a_table_that_leaks_onto_padding_does_not_lower():
+    import hoomd_tf_amd as htf
+    from hoomd_tf_amd import codegen as cg
+    from hoomd_tf_amd.simmodel import PositionsInput
+    x = htf.Nlist(torch.zeros((2, 4, 4)))
+    P = PositionsInput.wrap(torch.zeros((2, 4)))
+    models = _typed_models(htf, x, P, 3, big=True)
+    for name in ("lj_table", "wide_table"):
+        image, key = cg.compile_body(models[name].body())
+        assert b"htf_jit_rows2_f32_store" in image and b"htf_jit_eval_f64_virial" in image, name
+    idx = P[:, 3][:, None] * 3 + x[:, :, 3]
+    assert not (htf.gather([1.0, 2.0, 3.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0], idx) * htf.exp(-htf.safe_norm(x[:, :, :3], axis=2))).lowers()

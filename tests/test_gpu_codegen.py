@@ -83,3 +83,98 @@ def test_traced_model_is_replayed_as_the_one_kernel_step(htf, cuda, name, wire, 
     assert float((p1[:, :3] - p0[:, :3]).abs().max()) < 2e-4          # 30 steps of the same dynamics
     assert float((f1[:, :3] - f0[:, :3]).abs().max()) < 2e-3 * scale
     assert abs(float(f1[:, 3].double().sum()) - float(f0[:, 3].double().sum())) < 1e-4 * abs(float(f0[:, 3].double().sum())) + 1e-3
+
+
+def _typed_inputs(rng, N, NN, ntypes, dtype):
+    nl, _ = random_nlist(rng, N, NN, fill=0.7, rmin=0.85, rmax=3.0, dtype=dtype)
+    live = nl[:, :, :3].any(axis=2)
+    nl[:, :, 3] = np.where(live, rng.integers(0, ntypes, live.shape), 0)
+    pos = np.zeros((N, 4), dtype=dtype)
+    pos[:, :3] = rng.standard_normal((N, 3))
+    pos[:, 3] = rng.integers(0, ntypes, N)
+    return nl, pos
+
+
+@pytest.mark.parametrize("name", ["lj_table", "unlike_only", "neighbor_species", "wide_table"])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_typed_evaluator_matches_autograd(htf, cuda, name, dtype):
+    """Per-species-pair parameters in a generated kernel: tables looked up by (positions[i, 3], nlist[i, j, 3]) -- the streaming
+    evaluator (htf_eval_forces_typed: the positions tensor beside the pair vectors) against torch-fp64 autograd of the same
+    expression; an evaluator call WITHOUT the positions is refused for an energy that reads the row particle's type."""
+    from test_codegen_cpu import _typed_models
+    from test_gpu_parity import CONTACTS, assert_forces_close
+    from hoomd_tf_amd.simmodel import PositionsInput
+    rng = np.random.default_rng(11)
+    ntypes = 3
+    nl, pos = _typed_inputs(rng, 300, 128, ntypes, dtype)
+    nl64, pos64 = nl.astype(np.float32).astype(np.float64), pos.astype(np.float64)
+    e = _typed_models(htf, htf.Nlist(torch.from_numpy(nl64)), PositionsInput.wrap(torch.from_numpy(pos64)), ntypes, big=True)[name]
+    pot = e.potential()
+    x, P = torch.from_numpy(nl).to(cuda), torch.from_numpy(pos).to(cuda)
+    f, v = htf.ops.eval_forces(pot, x, virial=True, positions=P)
+    if e.reads_own_type:
+        with pytest.raises(ValueError, match="own type"):
+            htf.ops.eval_forces(pot, x)
+    else:
+        assert torch.equal(htf.ops.eval_forces(pot, x), f)
+    ref, vref = _ref(htf, e, nl64, virial=True)
+    xx = htf.Nlist(torch.from_numpy(nl64))
+    (g,) = torch.autograd.grad(e.torch_value(xx.ad).sum(), xx.ad)
+    cond = np.abs(2 * g.numpy()[:, :, :3]).sum(axis=(1, 2))
+    assert_forces_close("jit_%s_%s" % (name, dtype.__name__), f.cpu().numpy(), ref, cond, cancelling_rows=CONTACTS)
+    vcond = (np.linalg.norm(2 * g.numpy()[:, :, :3], axis=2) * np.linalg.norm(nl64[:, :, :3], axis=2) / 2).sum(axis=1)
+    assert_forces_close("jit_%s_virial_%s" % (name, dtype.__name__), v.cpu().numpy().reshape(len(nl), 9), vref.reshape(len(nl), 9), vcond,
+                        cancelling_rows=CONTACTS)
+
+
+@pytest.mark.parametrize("wire", [torch.float32, torch.float64])
+def test_typed_model_is_replayed_as_the_one_kernel_step(htf, cuda, wire, monkeypatch):
+    """A three-species mixture whose compute() looks epsilon and sigma up by species pair (tf.gather on ti * ntypes + tj, the
+    way a multi-component model is written against the reference): traced, lowered, replayed as the one-kernel step -- the row
+    particle's type from pos.w, the neighbor's from the gathered position -- equal to the torch-autograd route over 30 steps,
+    and different from the same run with the types ignored."""
+    from hoomd_tf_amd import _lib, standin
+    ntypes = 3
+    rng = np.random.default_rng(7)
+    eps = rng.uniform(0.6, 1.4, (ntypes, ntypes))
+    eps = 0.5 * (eps + eps.T)
+    sig = rng.uniform(0.85, 1.0, (ntypes, ntypes))
+    sig = 0.5 * (sig + sig.T)
+
+    class Mixture(htf.SimModel):
+        def compute(self, nlist, positions, box):
+            s = htf.nlist_rinv(nlist)
+            tj = htf.cast(nlist[:, :, 3], torch.int32)
+            ti = htf.cast(positions[:, 3], torch.int32)
+            idx = ti[:, None] * ntypes + tj
+            q = (htf.gather(sig.reshape(-1), idx) * s) ** 6
+            e = 2.0 * htf.gather(eps.reshape(-1), idx) * (q * q - q)
+            return htf.compute_nlist_forces(nlist, htf.reduce_sum(e, axis=1))
+
+    def run(jit, typed=True):
+        monkeypatch.setenv("HTF_NO_JIT", "0" if jit else "1")
+        pos, L, a = standin.fcc_positions(6, 0.8442)
+        r = np.random.default_rng(2)
+        pos = pos + 0.03 * a * r.standard_normal(pos.shape)
+        pos -= np.round(pos / L) * L
+        types = r.integers(0, ntypes, len(pos)) if typed else np.zeros(len(pos), dtype=np.int64)
+        sysm = standin.System(pos, L, types=types, dtype=wire, device=cuda)
+        sysm.randomize_velocities(kT=0.5, seed=2)
+        sim = standin.Simulation(sysm)
+        sim.integrate_nve(0.002)
+        tfc = htf.tfcompute(Mixture(96))
+        tfc.attach(sim.nlist_cell(r_buff=0.4, check_period=1), r_cut=2.5)
+        sim.run(30, graph=False)
+        torch.cuda.synchronize()
+        return tfc, sysm.pos.clone(), tfc.force.clone()
+
+    tfc, p1, f1 = run(True)
+    assert tfc._plan is not None and tfc._plan.kind == _lib.POT_JIT and tfc.graph_safe()
+    tfc0, p0, f0 = run(False)
+    assert tfc0._plan is None
+    scale = float(f0[:, :3].abs().max())
+    assert float((p1[:, :3] - p0[:, :3]).abs().max()) < 2e-4
+    assert float((f1[:, :3] - f0[:, :3]).abs().max()) < 2e-3 * scale
+    assert abs(float(f1[:, 3].double().sum()) - float(f0[:, 3].double().sum())) < 1e-4 * abs(float(f0[:, 3].double().sum())) + 1e-3
+    _, _, f2 = run(True, typed=False)
+    assert float((f2[:, :3] - f1[:, :3]).abs().max()) > 0.05 * scale      # (the species matter: one-species forces are elsewhere)
