@@ -450,12 +450,36 @@ def run_generic_lj(args, htf, standin, dev):
             energy = torch.sum(2.0 * (s ** 12 - s ** 6) + 0.25 * torch.exp(-1.0 * r) * s, dim=1)
             return htf.compute_nlist_forces(nlist, energy)
 
+    KA_EPS, KA_SIG = [1.0, 1.5, 1.5, 0.5], [1.0, 0.8, 0.8, 0.88]   # Kob-Andersen 80:20 binary LJ: AA, AB, BA, BB
+
+    class MixtureModel(htf.SimModel):
+        """Outside the zoo AND typed: a binary LJ mixture whose epsilon and sigma are looked up by species pair -- tf.gather on
+        ti * 2 + tj, the way a multi-component model is written against the reference -- traced into ONE generated kernel."""
+        def compute(self, nlist, positions, box):
+            s = htf.nlist_rinv(nlist)
+            idx = htf.cast(positions[:, 3], torch.int32)[:, None] * 2 + htf.cast(nlist[:, :, 3], torch.int32)
+            q = (htf.gather(KA_SIG, idx) * s) ** 6
+            energy = htf.reduce_sum(2.0 * htf.gather(KA_EPS, idx) * (q * q - q), axis=1)
+            return htf.compute_nlist_forces(nlist, energy)
+
+    class TorchMixtureModel(htf.SimModel):
+        def compute(self, nlist, positions, box):
+            delta = 3e-6
+            t = nlist[:, :, :3] + 1e-7
+            r = torch.sqrt(torch.sum(t * t, dim=2))
+            s = torch.where(r > delta, 1.0 / (r + delta), torch.zeros_like(r))
+            idx = (positions[:, 3:4] * 2 + nlist[:, :, 3]).detach().long()
+            q = (torch.tensor(KA_SIG, device=s.device)[idx] * s) ** 6
+            energy = torch.sum(2.0 * torch.tensor(KA_EPS, device=s.device)[idx] * (q * q - q), dim=1)
+            return htf.compute_nlist_forces(nlist, energy)
+
     def one(lattice, cells, model_cls, steps):
         pos, L, a = (standin.sc_positions if lattice == "sc" else standin.fcc_positions)(cells, 0.8442)
         rng = np.random.default_rng(7)
         pos = pos + 0.03 * a * rng.standard_normal(pos.shape)
         pos -= np.round(pos / L) * L
-        sysm = standin.System(pos, L, dtype=torch.float32, device=dev)
+        types = (rng.random(len(pos)) < 0.2).astype(np.int32) if model_cls in (MixtureModel, TorchMixtureModel) else None
+        sysm = standin.System(pos, L, types=types, dtype=torch.float32, device=dev)
         sysm.randomize_velocities(kT=1.0, seed=7)
         sim = standin.Simulation(sysm)
         sim.integrate_nve(args.dt)
@@ -484,10 +508,16 @@ def run_generic_lj(args, htf, standin, dev):
         yuk = one(lattice, cells, YukawaLJModel, args.steps)
         yuk_torch = one(lattice, cells, TorchYukawaLJModel, max(20, args.steps // 10))
         morse = one(lattice, cells, MorseModel, args.steps)
-        assert yuk["potential_kind"] == 9 and morse["potential_kind"] == 9
+        mix = one(lattice, cells, MixtureModel, args.steps)
+        mix_torch = one(lattice, cells, TorchMixtureModel, max(20, args.steps // 10))
+        assert yuk["potential_kind"] == 9 and morse["potential_kind"] == 9 and mix["potential_kind"] == 9
+        assert abs(mix["energy_per_particle_after_warmup"] - mix_torch["energy_per_particle_after_warmup"]) < 1e-3 * abs(mix_torch["energy_per_particle_after_warmup"]) + 1e-3
         assert abs(yuk["energy_per_particle_after_warmup"] - yuk_torch["energy_per_particle_after_warmup"]) < 1e-3 * abs(yuk_torch["energy_per_particle_after_warmup"]) + 1e-3
         sizes[tag] = {"lowered": fast, "generic": gen, "generic_over_lowered_time": gen["ms_per_step"] / fast["ms_per_step"],
                       "traced_yukawa_lj": yuk, "traced_morse": morse, "torch_yukawa_lj": yuk_torch,
+                      "traced_binary_mixture": mix, "torch_binary_mixture": mix_torch,
+                      "mixture_over_lowered_lj_time": mix["ms_per_step"] / fast["ms_per_step"],
+                      "torch_over_traced_mixture_time": mix_torch["ms_per_step"] / mix["ms_per_step"],
                       "traced_over_lowered_lj_time": yuk["ms_per_step"] / fast["ms_per_step"],
                       "torch_over_traced_time": yuk_torch["ms_per_step"] / yuk["ms_per_step"]}
     c3 = sizes["C3 (fcc 32^3 x 4 = 131072)"]
@@ -499,7 +529,8 @@ def run_generic_lj(args, htf, standin, dev):
         "config": {"workload": "LJModel through tfcompute, htf.* expression layer (lowered) vs plain torch ops + torch.autograd (generic), "
                                "jittered lattices at rho 0.8442, r_cut %.1f, r_buff %.1f, NN %d, dt %g" % (rcut, args.rbuff, NN, args.dt)},
         "sizes": sizes,
-        "traced_models": "written with htf.* ops outside the zoo (LJ + Yukawa; a masked Morse well): traced, lowered to generated kernels "
+        "traced_models": "written with htf.* ops outside the zoo (LJ + Yukawa; a masked Morse well; a Kob-Andersen binary LJ mixture whose "
+                         "epsilon / sigma are gathered by species pair from positions[:, 3] and nlist[:, :, 3]): traced, lowered to generated kernels "
                          "(HTF_POT_JIT: hoomd_tf_amd/codegen.py -> hipcc --genco around csrc/jit_unit.hip), replayed as the one-kernel step",
         "note": "the generic route keeps the reference's arbitrary-model capability (htf/simmodel.py:87-121, 526-555); models made of "
                 "nlist_rinv polynomials, WCARepulsion, RBFExpansion + Dense stacks, EDS biases and compute_rdf are lowered to fused kernels",
