@@ -451,8 +451,9 @@ class RinvPoly(PairEnergy):
             for p, c in other.terms.items():
                 t[p] = t.get(p, 0.0) + sign * c
             return RinvPoly(self.nlist, t, self.reduced and other.reduced, cut=self.cut)
-        if isinstance(other, (PairExpr, SafeNorm)) or (isinstance(other, (int, float)) and not self.reduced):
-            # not a polynomial in rinv any more: a traced expression (generated kernel)
+        if isinstance(other, (PairExpr, SafeNorm, torch.Tensor)) or (isinstance(other, (int, float)) and not self.reduced):
+            # not a polynomial in rinv any more: a traced expression (generated kernel); with a tensor -- a live weight or per-pair
+            # values -- its torch value (the autograd route)
             e = PairExpr.of(self)
             return e._with("add" if sign > 0 else "sub", other)
         raise TypeError("cannot combine a rinv polynomial with %r (constants carry no force)" % (other,))
@@ -485,14 +486,14 @@ class RinvPoly(PairEnergy):
                 for p2, c2 in o.terms.items():
                     t[p1 + p2] = t.get(p1 + p2, 0.0) + c1 * c2
             return RinvPoly(self.nlist, t, cut=self.cut if self.cut is not None else o.cut)
-        if isinstance(o, (PairExpr, SafeNorm)):
+        if isinstance(o, (PairExpr, SafeNorm, torch.Tensor)):   # (a tensor: a live weight or per-pair values -> the torch route)
             return PairExpr.of(self) * o
         return NotImplemented
 
     __rmul__ = __mul__
 
     def __truediv__(self, o):
-        if isinstance(o, (PairExpr, SafeNorm, RinvPoly)):
+        if isinstance(o, (PairExpr, SafeNorm, RinvPoly, torch.Tensor)):
             return PairExpr.of(self) / o
         return self * (1.0 / o)
 
@@ -594,6 +595,13 @@ class PairExpr(PairEnergy):
             raise TypeError("a per-particle sum is not a per-pair expression any more")
         if other is None:
             return PairExpr(self.nlist, cg.Node(op, (self.node,), value=value), positions=self.positions)
+        if isinstance(other, torch.Tensor) and (other.requires_grad or other.numel() != 1):
+            # a trainable weight, or a tensor of per-particle / per-pair values: not a constant of a generated kernel -- the
+            # expression becomes its torch value here and the model takes the autograd route (folding a weight into the kernel
+            # would freeze it at its traced value)
+            fn = {"add": torch.add, "sub": torch.sub, "mul": torch.mul, "div": torch.div, "min": torch.minimum, "max": torch.maximum,
+                  "lt": torch.lt, "le": torch.le, "gt": torch.gt, "ge": torch.ge, "eq": torch.eq, "ne": torch.ne}[op]
+            return fn(other, self.ad) if swap else fn(self.ad, other)
         o = PairExpr.of(other, self.nlist)
         if o.nlist is not self.nlist and o.nlist.tensor is not self.nlist.tensor:
             raise ValueError("expressions come from different neighbor lists")
@@ -621,6 +629,8 @@ class PairExpr(PairEnergy):
 
     def _cmp(self, op, o):
         e = PairExpr.of(self, self.nlist)._with(op, o)
+        if isinstance(e, torch.Tensor):   # (compared with a tensor: torch from here on)
+            return e
         return PairCond(self.nlist, e.node, e.positions)
     def __lt__(self, o): return self._cmp("lt", o)
     def __le__(self, o): return self._cmp("le", o)

@@ -206,3 +206,32 @@ def test_typed_unit_cross_compiles_and_a_table_that_leaks_onto_padding_does_not_
         assert b"htf_jit_rows2_f32_store" in image and b"htf_jit_eval_f64_virial" in image, name
     idx = P[:, 3][:, None] * 3 + x[:, :, 3]
     assert not (htf.gather([1.0, 2.0, 3.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0], idx) * htf.exp(-htf.safe_norm(x[:, :, :3], axis=2))).lowers()
+
+
+def test_a_trainable_weight_is_not_folded_into_a_generated_kernel():
+    """A torch Parameter (or any tensor that is not a plain constant) multiplied into a traced expression must stay a live value:
+    the expression becomes its torch value there and the model takes the autograd route -- forces AND the weight's gradient."""
+    import hoomd_tf_amd as htf
+    from hoomd_tf_amd.simmodel import PairExpr
+    rng = np.random.default_rng(4)
+    nl, _ = random_nlist(rng, 10, 8, fill=0.6, rmin=0.9, rmax=2.5, dtype=np.float64)
+    x = htf.Nlist(torch.from_numpy(nl))
+    s, r = htf.nlist_rinv(x), htf.safe_norm(x[:, :, :3], axis=2)
+    w = torch.nn.Parameter(torch.tensor(1.7, dtype=torch.float64))
+    traced = htf.exp(-0.7 * r) * s
+    assert isinstance(traced, PairExpr) and isinstance(2.0 * traced, PairExpr)
+    e = w * traced
+    assert isinstance(e, torch.Tensor) and e.requires_grad
+    f = htf.compute_nlist_forces(x, e.sum(dim=1))
+    t = torch.from_numpy(nl)[:, :, :3] + 1e-7
+    rr = torch.sqrt((t * t).sum(dim=2))
+    ss = torch.where(rr > 3e-6, 1.0 / (rr + 3e-6), torch.zeros_like(rr))
+    np.testing.assert_allclose(f[:, 3].detach().numpy(), (1.7 * torch.exp(-0.7 * rr) * ss).sum(dim=1).numpy(), rtol=1e-12)
+    (gw,) = torch.autograd.grad(e.sum(), w)
+    np.testing.assert_allclose(float(gw), float((torch.exp(-0.7 * rr) * ss).sum()), rtol=1e-12)
+    for live in (w * s ** 6, s ** 6 * w, s ** 6 + w, w - s ** 2, s ** 6 / w):      # the zoo's polynomials likewise
+        assert isinstance(live, torch.Tensor) and live.requires_grad
+    assert isinstance(torch.tensor(2.0, dtype=torch.float64) * s ** 6, PairExpr)  # (a plain one-element constant still folds)
+    per_pair = torch.from_numpy(rng.uniform(0.5, 1.5, (10, 8)))
+    assert isinstance(traced * per_pair, torch.Tensor) and isinstance(per_pair * traced, torch.Tensor)
+    assert isinstance(traced < per_pair, torch.Tensor)
