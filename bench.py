@@ -488,14 +488,17 @@ def run_generic_lj(args, htf, standin, dev):
         sim.run(max(5, args.warmup))
         torch.cuda.synchronize()
         e_warm = float(tfc.force[:, 3].double().sum().item()) / sysm.N   # (compared between routes: same step count here)
-        t0 = time.perf_counter()
-        sim.run(steps)
-        torch.cuda.synchronize()
-        el = time.perf_counter() - t0
+        els = []
+        for _ in range(3):   # (windows of 15-400 ms: the median of three keeps a one-off stall -- a lazy module load, the
+            t0 = time.perf_counter()                                       # run loop's own graph-or-not measurement -- out of the line)
+            sim.run(steps)
+            torch.cuda.synchronize()
+            els.append(time.perf_counter() - t0)
+        el = sorted(els)[1]
         f = tfc.force
         assert bool(torch.isfinite(f).all())
         return {"steps_per_s": steps / el, "ms_per_step": el / steps * 1e3, "particles": sysm.N, "steps": steps,
-                "replayed_without_python": tfc._plan is not None,
+                "windows_ms_per_step": [e / steps * 1e3 for e in els], "replayed_without_python": tfc._plan is not None,
                 "potential_kind": getattr(tfc._plan, "kind", None), "energy_per_particle_after_warmup": e_warm,
                 "energy_per_particle": float(f[:, 3].double().sum().item()) / sysm.N}
 

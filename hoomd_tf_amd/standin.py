@@ -245,6 +245,7 @@ class CellNlist:
                 self._poll_row_overflow()   # the PREVIOUS build's largest row (pinned copy behind it): no wait
             # the binning scratch is this object's own and every completed build leaves its counts zero (cell_order_kernel): no memset
             clean = getattr(self, "_scratch_clean", None) == (self._bin_scratch.data_ptr(), ncell)
+            self._scratch_clean = None   # (a call that fails half way leaves the counts dirty: the next one zeroes them again)
             check(lib.htfs_rebuild_nlist_ghosts(s.pos.data_ptr(), s.scalar_code, s.N, Ntot, C.byref(sbox), self.r_list, C.byref(n3), C.byref(w3),
                                                 cell_of.data_ptr(), self._bin_scratch.data_ptr(), cell_start.data_ptr(), order.data_ptr(),
                                                 pos_sorted.data_ptr(), self.pitch, int(self.type_split), self.n_neigh.data_ptr(),
