@@ -381,6 +381,25 @@ def run_dd_self(args, htf, standin, dev):
                     "particles": int(len(live)), "interior_particles": int(c[_lib.BC_N_INT]), "ghosts": dom.n_ghosts,
                     "rows": sysm.N, "interior_rows": dom.cap_int, "ghost_rows": sysm.n_ghost, "messages_per_halo": dom.n_msg,
                     "halo_bytes_per_step": dom.n_ghost_cap * 16, "migrated": dom.n_migrated})
+        if os.environ.get("HTF_DD_PHASES") == "1" and run._graphs is not None:
+            # where a replayed cycle's time goes, without a profiler in the way: each of the two graphs replayed alone, back to
+            # back, nothing read in between (the trajectory is garbage afterwards: this is the last thing done with the system)
+            ph = {}
+            gA, gB = run._graphs[False], run._graphs[True]
+            for name, seq, n in (("rebuild_then_plain_cycle", (gB, gA), 100), ("plain_cycle", (gA,), 200)):
+                for _ in range(4):
+                    for g in seq:
+                        g.replay()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    for g in seq:
+                        g.replay()
+                t_issue = time.perf_counter() - t0
+                torch.cuda.synchronize()
+                ph[name] = {"us": (time.perf_counter() - t0) / n * 1e6, "host_us_to_launch": t_issue / n * 1e6}
+            ph["steps_per_cycle"] = P
+            rec["phases"] = ph
         results[transport] = rec
         del run, ctx, nl, dom, sysm
     best = min(results[t]["graph"]["us_per_step"] for t in results)
@@ -1407,7 +1426,7 @@ def run_md(args, E, workload, variants=True, cpu=True):
         try:
             if args.cells != 32 or args.workload != "lj":
                 raise KeyError("PMC passes were collected for the default workload at the default size")
-            pmc_file = next(f for f in ("r04_bench_lj_pmc_hbm.json", "r03_bench_lj_pmc_hbm.json", "r02_bench_lj_pmc_hbm.json", "r01_bench_lj_pmc_hbm.json")
+            pmc_file = next(f for f in ("r05_bench_lj_pmc_hbm.json", "r04_bench_lj_pmc_hbm.json", "r03_bench_lj_pmc_hbm.json", "r02_bench_lj_pmc_hbm.json", "r01_bench_lj_pmc_hbm.json")
                             if os.path.exists(os.path.join(ROOT, "profiles", f)))
             pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
             want = {"build_pair_vectors": ("build_pair_vectors_kernel",), "eval_forces": ("eval_pair_kernel<1,",),
