@@ -382,7 +382,7 @@ def cast(x, dtype=None):
     """tf.cast for model code: a symbolic mask stays symbolic, tensors are converted."""
     if isinstance(x, PairCond):
         from . import codegen as cg
-        return PairExpr(x.nlist, cg.Node("mask", (x.node,)), positions=x.positions)
+        return PairExpr(x.nlist, cg.Node("mask", (x.node,)), positions=x.positions, folded=x.folded)
     if isinstance(x, TypeExpr):
         return x   # (types are small integers held exactly as floats: an int cast changes nothing the kernel sees)
     if isinstance(x, PairMask):
@@ -549,9 +549,10 @@ class PairExpr(PairEnergy):
     padded slot keeps the torch route (codegen.vanishes_on_padding)."""
     owns_potential = False
 
-    def __init__(self, nlist, node, reduced=False, positions=None):
+    def __init__(self, nlist, node, reduced=False, positions=None, folded=()):
         # positions: the [N, 4] tensor of compute(), kept when the expression reads the row particles' own types (TypeExpr)
-        self.nlist, self.node, self.reduced, self.positions = nlist, node, reduced, positions
+        # folded: ((weight tensor, its _version when its value became a constant of the expression), ...) -- see _with
+        self.nlist, self.node, self.reduced, self.positions, self.folded = nlist, node, reduced, positions, tuple(folded)
 
     # ---- construction from the other symbolic types
     @staticmethod
@@ -585,6 +586,12 @@ class PairExpr(PairEnergy):
             return PairExpr(nl, x.node, positions=x.positions)
         if isinstance(x, PairCond):
             raise TypeError("a comparison is not a value: htf.cast it, or use it in htf.where")
+        if nlist is not None and isinstance(x, torch.Tensor) and (x.requires_grad or x.numel() != 1):
+            fw = _fold_weight(x)
+            if fw is not None:
+                return PairExpr(nlist, cg.const(fw[0]), folded=fw[1])   # (an inference-time weight: see _with)
+            raise TypeError("a trainable weight (while training) or a tensor of per-pair values cannot be an operand of a traced "
+                            "htf.where / minimum / maximum: combine it with arithmetic, or write this part in torch ops")
         if nlist is not None:
             return PairExpr(nlist, cg.wrap(x))
         raise TypeError("cannot trace %r" % (type(x),))
@@ -594,7 +601,15 @@ class PairExpr(PairEnergy):
         if self.reduced:
             raise TypeError("a per-particle sum is not a per-pair expression any more")
         if other is None:
-            return PairExpr(self.nlist, cg.Node(op, (self.node,), value=value), positions=self.positions)
+            return PairExpr(self.nlist, cg.Node(op, (self.node,), value=value), positions=self.positions, folded=self.folded)
+        new_folded = ()
+        fw = _fold_weight(other)
+        if fw is not None:
+            # a one-element WEIGHT (or a scalar computed from weights) while nothing is being trained -- inference MD with a model
+            # that owns Parameters, as every Keras layer upstream does: its current value becomes a constant of the kernel, and
+            # (leaf tensor, _version) pairs are kept so that tfcompute re-traces the model as soon as a weight is written again
+            # (load_weights, an optimizer step)
+            other, new_folded = fw
         if isinstance(other, torch.Tensor) and (other.requires_grad or other.numel() != 1):
             # a trainable weight, or a tensor of per-particle / per-pair values: not a constant of a generated kernel -- the
             # expression becomes its torch value here and the model takes the autograd route (folding a weight into the kernel
@@ -606,7 +621,8 @@ class PairExpr(PairEnergy):
         if o.nlist is not self.nlist and o.nlist.tensor is not self.nlist.tensor:
             raise ValueError("expressions come from different neighbor lists")
         args = (o.node, self.node) if swap else (self.node, o.node)
-        return PairExpr(self.nlist, cg.Node(op, args), positions=self.positions if self.positions is not None else o.positions)
+        return PairExpr(self.nlist, cg.Node(op, args), positions=self.positions if self.positions is not None else o.positions,
+                        folded=self.folded + o.folded + new_folded)
 
     def __add__(self, o):
         if isinstance(o, BiasTerm):
@@ -631,7 +647,7 @@ class PairExpr(PairEnergy):
         e = PairExpr.of(self, self.nlist)._with(op, o)
         if isinstance(e, torch.Tensor):   # (compared with a tensor: torch from here on)
             return e
-        return PairCond(self.nlist, e.node, e.positions)
+        return PairCond(self.nlist, e.node, e.positions, e.folded)
     def __lt__(self, o): return self._cmp("lt", o)
     def __le__(self, o): return self._cmp("le", o)
     def __gt__(self, o): return self._cmp("gt", o)
@@ -696,8 +712,8 @@ class PairExpr(PairEnergy):
 class PairCond:
     """A comparison of traced expressions: the condition of ``where`` / the argument of ``cast`` (no gradient)."""
 
-    def __init__(self, nlist, node, positions=None):
-        self.nlist, self.node, self.positions = nlist, node, positions
+    def __init__(self, nlist, node, positions=None, folded=()):
+        self.nlist, self.node, self.positions, self.folded = nlist, node, positions, tuple(folded)
         if nlist is None:
             raise TypeError("a comparison of positions[:, 3] alone is not a per-pair condition: bring the neighbor types in, or "
                             "use torch on the tensor")
@@ -705,6 +721,37 @@ class PairCond:
 
 def _sym(x):
     return isinstance(x, (PairExpr, RinvPoly, SafeNorm))
+
+
+def _weight_leaves(t):
+    """The leaf tensors (weights) a one-element tensor that requires grad was computed from: ``t`` itself when it is a leaf,
+    otherwise the variables of the AccumulateGrad nodes of its autograd graph.  None when the graph is too large to be a scalar
+    combination of weights (then the value is not folded)."""
+    if t.is_leaf:
+        return (t,)
+    out, seen, alive, todo = [], set(), [], [t.grad_fn]
+    while todo:
+        fn = todo.pop()
+        if fn is None or id(fn) in seen:
+            continue
+        seen.add(id(fn))
+        alive.append(fn)   # (the Python wrappers of graph nodes are made on demand: kept alive so that their ids stay theirs)
+        if len(seen) > 256:
+            return None
+        v = getattr(fn, "variable", None)
+        if v is not None:
+            out.append(v)
+        todo.extend(f for f, _ in fn.next_functions)
+    return tuple(out)
+
+
+def _fold_weight(x):
+    """(value, ((leaf, version), ...)) of a one-element tensor that requires grad, while nothing is being trained; else None."""
+    if (isinstance(x, torch.Tensor) and x.numel() == 1 and x.requires_grad and not getattr(_trace, "training_graph", False)):
+        leaves = _weight_leaves(x)
+        if leaves:
+            return float(x.detach()), tuple((l, l._version) for l in leaves)
+    return None
 
 
 def _first_positions(*xs):
@@ -724,7 +771,7 @@ def gather(params, indices, axis=0):
             if isinstance(indices, TypeExpr) and indices.nlist is None:
                 raise TypeError("gather by positions[:, 3] alone is not a per-pair value: index with the neighbor types too, or use torch")
             e = PairExpr.of(indices)
-            return PairExpr(e.nlist, cg.table(vals, e.node), positions=e.positions)
+            return PairExpr(e.nlist, cg.table(vals, e.node), positions=e.positions, folded=e.folded)
     p = torch.as_tensor(_unwrap(params))
     i = torch.as_tensor(_unwrap(indices)).to(torch.int64)
     return p[i] if axis == 0 else torch.index_select(p, axis, i.reshape(-1)).reshape(p.shape[:axis] + i.shape + p.shape[axis + 1:])
@@ -804,7 +851,8 @@ def where(cond, a, b):
     from . import codegen as cg
     if isinstance(cond, PairCond):
         ea, eb = PairExpr.of(a, cond.nlist), PairExpr.of(b, cond.nlist)
-        return PairExpr(cond.nlist, cg.Node("where", (cond.node, ea.node, eb.node)), positions=_first_positions(cond, ea, eb))
+        return PairExpr(cond.nlist, cg.Node("where", (cond.node, ea.node, eb.node)), positions=_first_positions(cond, ea, eb),
+                        folded=cond.folded + ea.folded + eb.folded)
     return torch.where(_unwrap(cond), torch.as_tensor(_unwrap(a)), torch.as_tensor(_unwrap(b)))
 
 
@@ -1056,12 +1104,12 @@ def reduce_sum(x, axis=None):
         return RinvPoly(x.nlist, x.terms, reduced=True, cut=x.cut)
     if isinstance(x, PairExpr):
         if axis is None:
-            out = PairExpr(x.nlist, x.node, reduced=True, positions=x.positions)
+            out = PairExpr(x.nlist, x.node, reduced=True, positions=x.positions, folded=x.folded)
             out.total = True
             return out
         if axis not in (1, -1):
             raise ValueError("pair energies reduce over the neighbor axis (axis=1), or over everything (axis=None)")
-        return PairExpr(x.nlist, x.node, reduced=True, positions=x.positions)
+        return PairExpr(x.nlist, x.node, reduced=True, positions=x.positions, folded=x.folded)
     if isinstance(x, WCAPair):
         return x
     if isinstance(x, LJParamEnergy):
@@ -1120,7 +1168,7 @@ def compute_nlist_forces(nlist, energy, virial=False):
         f[:, 3] = f[:, 3].sum()  # rank-0 energy: the total in every particle's column
         _trace_log().append({"op": "total_energy"})  # (keeps the step on the eager path)
     _trace_log().append({"potential": pot, "nlist": nl, "virial": virial, "forces": f,
-                         "layer": getattr(energy, "layer", None)})
+                         "layer": getattr(energy, "layer", None), "folded": tuple(getattr(energy, "folded", ()))})
     return out
 
 

@@ -94,6 +94,7 @@ class tfcompute:
         self.force = torch.zeros((s.N, 4), dtype=s.dtype, device=s.device)
         self.virial = torch.zeros(6 * s.N, dtype=s.dtype, device=s.device)
         self._plan = None
+        self._plan_folded = ()   # (weight, _version) pairs whose values are constants of the plan's generated kernel
         self._bplan = None  # EDS-biased model replayed as one kernel (see _maybe_install_plan)
         self._post_ops = []  # replayable observables of the planned step (compute_rdf -> MeanTensor), run after the force kernel
         self._post_src = None
@@ -198,9 +199,14 @@ class tfcompute:
         # (check_nlist reads a count back inside htf_compute_forces -- a host copy and a synchronize, illegal under stream
         #  capture -- so a model that asks for it steps eagerly)
         return (self._plan is not None and self.model._plan is self._plan and self.period == 1 and not self.train
+                and not self._plan_is_stale()
                 and not getattr(self.model, "check_nlist", False)
                 and not self.model._map_nlist and getattr(self._nlist, "domain", None) is None
                 and self.force.shape[0] == self.system.N and not getattr(self, "save_output_period", None))
+
+    def _plan_is_stale(self):
+        """A weight whose value was folded into the plan's generated kernel (simmodel.PairExpr._with) has been written since."""
+        return any(t._version != v for t, v in getattr(self, "_plan_folded", ()))
 
     def graph_key(self):
         # the potential object AND its handle / parameter version (a refresh re-images device weights in place: same handle,
@@ -223,6 +229,9 @@ class tfcompute:
             s = self.system
             self.force = torch.zeros((s.N, 4), dtype=s.dtype, device=s.device)
             self.virial = torch.zeros(6 * s.N, dtype=s.dtype, device=s.device)
+        if self._plan is not None and self._plan_is_stale():
+            self._plan = self.model._plan = None      # (re-traced below with the weights' present values)
+            self._plan_folded = ()
         if self._plan is not None and self.model._plan is self._plan:
             self._calls += 1
             # interior rows while the ghost halo is in flight, boundary rows after it
@@ -371,6 +380,7 @@ class tfcompute:
                 and all(e["virial"] == bool(self.model.virial) for e in fused)
                 and len({id(e["potential"]) for e in fused}) == 1):
             self._plan = fused[0]["potential"]
+            self._plan_folded = tuple(fused[0].get("folded", ()))
             self.model._plan = self._plan
             self.cpp_force.set_potential(self._plan)
             self._post_ops = post

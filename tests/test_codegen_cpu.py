@@ -208,10 +208,13 @@ def test_typed_unit_cross_compiles_and_a_table_that_leaks_onto_padding_does_not_
     assert not (htf.gather([1.0, 2.0, 3.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0], idx) * htf.exp(-htf.safe_norm(x[:, :, :3], axis=2))).lowers()
 
 
-def test_a_trainable_weight_is_not_folded_into_a_generated_kernel():
-    """A torch Parameter (or any tensor that is not a plain constant) multiplied into a traced expression must stay a live value:
-    the expression becomes its torch value there and the model takes the autograd route -- forces AND the weight's gradient."""
+def test_a_weight_is_folded_only_while_nothing_is_trained_and_its_version_is_kept():
+    """A torch Parameter multiplied into a traced expression: during inference (tfcompute(train=False), as here) its present value
+    becomes a constant of the kernel and (tensor, _version) rides along, so that tfcompute can re-trace once the weight is written
+    again; while the model is being trained (simmodel._trace.training_graph) -- and for any tensor that is not a one-element
+    leaf -- the expression becomes its torch value there and the model takes the autograd route: forces AND the weight's gradient."""
     import hoomd_tf_amd as htf
+    from hoomd_tf_amd import simmodel
     from hoomd_tf_amd.simmodel import PairExpr
     rng = np.random.default_rng(4)
     nl, _ = random_nlist(rng, 10, 8, fill=0.6, rmin=0.9, rmax=2.5, dtype=np.float64)
@@ -219,19 +222,36 @@ def test_a_trainable_weight_is_not_folded_into_a_generated_kernel():
     s, r = htf.nlist_rinv(x), htf.safe_norm(x[:, :, :3], axis=2)
     w = torch.nn.Parameter(torch.tensor(1.7, dtype=torch.float64))
     traced = htf.exp(-0.7 * r) * s
-    assert isinstance(traced, PairExpr) and isinstance(2.0 * traced, PairExpr)
-    e = w * traced
-    assert isinstance(e, torch.Tensor) and e.requires_grad
-    f = htf.compute_nlist_forces(x, e.sum(dim=1))
-    t = torch.from_numpy(nl)[:, :, :3] + 1e-7
-    rr = torch.sqrt((t * t).sum(dim=2))
-    ss = torch.where(rr > 3e-6, 1.0 / (rr + 3e-6), torch.zeros_like(rr))
-    np.testing.assert_allclose(f[:, 3].detach().numpy(), (1.7 * torch.exp(-0.7 * rr) * ss).sum(dim=1).numpy(), rtol=1e-12)
-    (gw,) = torch.autograd.grad(e.sum(), w)
-    np.testing.assert_allclose(float(gw), float((torch.exp(-0.7 * rr) * ss).sum()), rtol=1e-12)
-    for live in (w * s ** 6, s ** 6 * w, s ** 6 + w, w - s ** 2, s ** 6 / w):      # the zoo's polynomials likewise
-        assert isinstance(live, torch.Tensor) and live.requires_grad
-    assert isinstance(torch.tensor(2.0, dtype=torch.float64) * s ** 6, PairExpr)  # (a plain one-element constant still folds)
+    assert isinstance(traced, PairExpr) and isinstance(2.0 * traced, PairExpr) and traced.folded == ()
+    # inference: folded, version remembered, propagated through everything built on top
+    e = htf.reduce_sum(htf.where(r < 2.0, w * traced, 0.0 * s) + s ** 6 * w, axis=1)
+    assert isinstance(e, PairExpr) and len(e.folded) == 2 and all(t is w and v == w._version for t, v in e.folded)
+    assert "1.7" in e.body()
+    with torch.no_grad():
+        w.mul_(2.0)
+    assert any(t._version != v for t, v in e.folded)                      # what tfcompute._plan_is_stale looks at
+    cond = r < w
+    assert len(cond.folded) == 1
+    # training: live
+    simmodel._trace.training_graph = True
+    try:
+        e = w * traced
+        assert isinstance(e, torch.Tensor) and e.requires_grad
+        f = htf.compute_nlist_forces(x, e.sum(dim=1))
+        t = torch.from_numpy(nl)[:, :, :3] + 1e-7
+        rr = torch.sqrt((t * t).sum(dim=2))
+        ss = torch.where(rr > 3e-6, 1.0 / (rr + 3e-6), torch.zeros_like(rr))
+        np.testing.assert_allclose(f[:, 3].detach().numpy(), (3.4 * torch.exp(-0.7 * rr) * ss).sum(dim=1).numpy(), rtol=1e-12)
+        (gw,) = torch.autograd.grad(e.sum(), w)
+        np.testing.assert_allclose(float(gw), float((torch.exp(-0.7 * rr) * ss).sum()), rtol=1e-12)
+        for live in (w * s ** 6, s ** 6 * w, s ** 6 + w, w - s ** 2, s ** 6 / w):      # the zoo's polynomials likewise
+            assert isinstance(live, torch.Tensor) and live.requires_grad
+    finally:
+        simmodel._trace.training_graph = False
+    assert isinstance(torch.tensor(2.0, dtype=torch.float64) * s ** 6, PairExpr)  # (a plain one-element constant always folds)
     per_pair = torch.from_numpy(rng.uniform(0.5, 1.5, (10, 8)))
     assert isinstance(traced * per_pair, torch.Tensor) and isinstance(per_pair * traced, torch.Tensor)
     assert isinstance(traced < per_pair, torch.Tensor)
+    w2 = torch.nn.Parameter(torch.tensor(0.5, dtype=torch.float64))
+    e = (-1.0 * w * w2) * traced                                                     # a scalar computed from weights: its leaves are watched
+    assert isinstance(e, PairExpr) and {id(t) for t, _ in e.folded} == {id(w), id(w2)}

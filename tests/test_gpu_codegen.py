@@ -178,3 +178,62 @@ def test_typed_model_is_replayed_as_the_one_kernel_step(htf, cuda, wire, monkeyp
     assert abs(float(f1[:, 3].double().sum()) - float(f0[:, 3].double().sum())) < 1e-4 * abs(float(f0[:, 3].double().sum())) + 1e-3
     _, _, f2 = run(True, typed=False)
     assert float((f2[:, :3] - f1[:, :3]).abs().max()) > 0.05 * scale      # (the species matter: one-species forces are elsewhere)
+
+
+def test_a_model_with_weights_runs_generated_kernels_until_a_weight_is_written(htf, cuda, monkeypatch):
+    """Inference MD with a traced model that owns torch Parameters (what every Keras layer upstream does): the weights' present
+    values are constants of the generated kernel and the model is replayed as the one-kernel step; writing a weight in place
+    (load_weights, an optimizer step) makes the plan stale -- the next step re-traces with the new value, a new kernel -- and the
+    forces follow it: equal to the torch-autograd route with the same weights, before and after."""
+    from hoomd_tf_amd import _lib, standin
+
+    class Morse(htf.SimModel):
+        def setup(self):
+            self.depth = torch.nn.Parameter(torch.tensor(0.8))
+            self.width = torch.nn.Parameter(torch.tensor(4.0))
+
+        def compute(self, nlist, positions, box):
+            r = htf.safe_norm(nlist[:, :, :3], axis=2)
+            live = htf.cast(htf.nlist_rinv(nlist) > 0.0, torch.float32)
+            x = 1.0 - htf.exp(-1.0 * self.width * (r - 1.122))
+            return htf.compute_nlist_forces(nlist, htf.reduce_sum(0.5 * self.depth * live * (x * x - 1.0), axis=1))
+
+    def system():
+        pos, L, a = standin.fcc_positions(6, 0.8442)
+        rng = np.random.default_rng(2)
+        pos = pos + 0.03 * a * rng.standard_normal(pos.shape)
+        pos -= np.round(pos / L) * L
+        sysm = standin.System(pos, L, dtype=torch.float32, device=cuda)
+        sysm.randomize_velocities(kT=0.3, seed=2)
+        sim = standin.Simulation(sysm)
+        sim.integrate_nve(0.002)
+        return sysm, sim
+
+    def run(jit, schedule):
+        monkeypatch.setenv("HTF_NO_JIT", "0" if jit else "1")
+        sysm, sim = system()
+        model = Morse(96)
+        tfc = htf.tfcompute(model)
+        tfc.attach(sim.nlist_cell(r_buff=0.4, check_period=1), r_cut=2.5)
+        out = []
+        for depth in schedule:
+            with torch.no_grad():
+                model.depth.fill_(depth)
+            sim.run(10, graph=False)
+            torch.cuda.synchronize()
+            out.append((tfc._plan, tfc.force.clone(), tfc._plan_is_stale()))
+        return tfc, out
+
+    tfc, got = run(True, [0.8, 1.6, 1.6])
+    _, ref = run(False, [0.8, 1.6, 1.6])
+    plans = [g[0] for g in got]
+    assert all(p is not None and p.kind == _lib.POT_JIT for p in plans) and not any(g[2] for g in got)
+    assert plans[0] is not plans[1] and plans[1] is plans[2]            # re-traced once, when the weight changed; not again
+    assert "0.4" in plans[0].body and "0.8" in plans[1].body               # 0.5 * depth, as a constant of each kernel
+    assert len(tfc._plan_folded) >= 2
+    for (_, f, _), (p0, f0, _) in zip(got, ref):
+        assert p0 is None
+        scale = float(f0[:, :3].abs().max())
+        assert float((f[:, :3] - f0[:, :3]).abs().max()) < 2e-3 * scale
+        assert abs(float(f[:, 3].double().sum()) - float(f0[:, 3].double().sum())) < 1e-4 * abs(float(f0[:, 3].double().sum())) + 1e-3
+    assert float((got[1][1][:, 3].double().sum() / got[0][1][:, 3].double().sum())) > 1.5      # (twice the well depth: the energy followed)
