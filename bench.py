@@ -651,6 +651,17 @@ def run_small(args, htf, standin, dev):
                  "note": "sim.run(n, graph=True): one check period of steps captured once and replayed as one hipGraph launch"}
     else:
         graph = {"value": None, "note": "not a fixed launch sequence"}
+    # what Simulation.run(n) does by itself: its first steps timed both ways, the faster kept (sim.graph_choice)
+    sim.graph_choice = None
+    sim.run(320)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sim.run(steps)
+    torch.cuda.synchronize()
+    ch = dict(getattr(sim, "graph_choice", None) or {})
+    ch.pop("key", None)
+    auto = {"note": "sim.run(n) with graph=None: stepwise or replayed, chosen by timing the run's own first steps both ways",
+            "choice": ch, "value": steps / (time.perf_counter() - t0), "unit": "steps/s"}
     f = tfc.force
     assert bool(torch.isfinite(f).all())
     # cpu_baseline leg: the only place this workload touches oracle/.  It times the numpy oracle on this run's own pair vectors
@@ -698,6 +709,7 @@ def run_small(args, htf, standin, dev):
         "config": {"workload": what, "rounds_s": rounds, "particles": sysm.N, "max_neighbors_listed": int(cell.n_neigh.max())},
         "replayed_as_one_kernel_plan": tfc._plan is not None,
         "graph_variant": graph,
+        "auto_run": auto,
         "energy_per_particle": float(f[:, 3].double().sum().item()) / sysm.N,
         "roofline": None,
         "roofline_note": "host-enqueue-bound at this size: every kernel is ~1-3 us; the step is the launch sequence",
@@ -1622,6 +1634,18 @@ def run_md(args, E, workload, variants=True, cpu=True):
             "value": args.steps / el, "unit": "steps/s", "ms_per_step": el / args.steps * 1e3,
             "replayed": tfc._plan is not None,
             "energy_per_particle": float(tfc.force[:, 3].double().sum().item()) / sysm.N}
+        # what Simulation.run(n) does BY ITSELF on a long run: its first steps timed stepwise and replayed
+        # from a hipGraph, the faster kept (sim.graph_choice); then 400 steps under that choice
+        sim.run(320)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sim.run(400)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        ch = dict(getattr(sim, "graph_choice", None) or {})
+        ch.pop("key", None)
+        out["tfcompute_variant"]["auto_run"] = {"note": "sim.run(n) with graph=None: stepwise or replayed, chosen by timing the run's own first steps both ways",
+                                                "choice": ch, "value": 400 / el, "unit": "steps/s"}
     # (b') the same step loop replayed from a hipGraph: one check period of steps (distance check, gated rebuild, force
     # kernel, integrator) captured once, one launch per period afterwards.  Kernel durations cannot be bracketed inside a
     # replay, so this is reported beside `value`, not as it.

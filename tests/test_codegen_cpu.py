@@ -255,3 +255,74 @@ def test_a_weight_is_folded_only_while_nothing_is_trained_and_its_version_is_kep
     w2 = torch.nn.Parameter(torch.tensor(0.5, dtype=torch.float64))
     e = (-1.0 * w * w2) * traced                                                     # a scalar computed from weights: its leaves are watched
     assert isinstance(e, PairExpr) and {id(t) for t, _ in e.folded} == {id(w), id(w2)}
+
+
+def _random_expression(htf, rng, s, r, tj, ti, depth):
+    """A random elementwise expression of bounded magnitude on 0.85 <= r <= 3 (denominators kept away from zero, exponents small)."""
+    if depth == 0:
+        return [lambda: s, lambda: r, lambda: 0.3 * r + 0.2, lambda: s * s, lambda: float(rng.uniform(0.3, 1.5)) * s,
+                lambda: htf.gather(rng.uniform(0.5, 1.5, 9), ti[:, None] * 3 + tj) * s][rng.integers(0, 6)]()
+    a = _random_expression(htf, rng, s, r, tj, ti, depth - 1)
+    b = _random_expression(htf, rng, s, r, tj, ti, depth - 1)
+    k = rng.integers(0, 12)
+    if k == 0: return a + b
+    if k == 1: return a - 0.5 * b
+    if k == 2: return a * b
+    if k == 3: return a / (1.0 + htf.square(b))
+    if k == 4: return htf.exp(-0.3 * htf.abs(a)) * b
+    if k == 5: return htf.tanh(a) + b
+    if k == 6: return htf.minimum(a, b)
+    if k == 7: return htf.maximum(a, 0.5 * b)
+    if k == 8: return htf.where(a < b, a, b * 0.7)
+    if k == 9: return htf.pow(htf.abs(a) + 0.5, float(rng.uniform(0.5, 2.5))) - b
+    if k == 10: return htf.sqrt(htf.square(a) + 1.0) * htf.cast(htf.equal(tj, int(rng.integers(0, 3))), torch.float32) + b
+    return htf.log(1.0 + htf.square(a)) + a ** int(rng.integers(2, 5)) * 0.1 + b
+
+
+def test_random_expressions_against_autograd():
+    """Thirty random expression trees (every op of the tracer, types and tables included), each masked by s^2 so that it vanishes on
+    padding: the emitted C against torch-fp64 value and derivative, slot by slot."""
+    import hoomd_tf_amd as htf
+    from hoomd_tf_amd import codegen as cg
+    from hoomd_tf_amd.simmodel import PairExpr, PositionsInput
+    rng = np.random.default_rng(2026)
+    nl, _ = random_nlist(rng, 24, 10, fill=0.7, rmin=0.85, rmax=3.0, dtype=np.float64)
+    live = nl[:, :, :3].any(axis=2)
+    nl[:, :, 3] = np.where(live, rng.integers(0, 3, live.shape), 0)
+    pos = np.zeros((24, 4))
+    pos[:, 3] = rng.integers(0, 3, 24)
+    x = htf.Nlist(torch.from_numpy(nl))
+    P = PositionsInput.wrap(torch.from_numpy(pos))
+    s, r = htf.nlist_rinv(x), htf.safe_norm(x[:, :, :3], axis=2)
+    tj, ti = x[:, :, 3], P[:, 3]
+    pts = nl.reshape(-1, 4)
+    own = np.repeat(pos[:, 3], 10)
+    rows = np.concatenate([pts.astype(np.float32), own[:, None].astype(np.float32)], axis=1)
+    feed = "\n".join("%.9g %.9g %.9g %.9g %.9g" % tuple(p) for p in rows)
+    lv = pts[:, :3].any(axis=1)
+    done = 0
+    with tempfile.TemporaryDirectory() as tmp:
+        for trial in range(40):
+            e = htf.square(s) * _random_expression(htf, rng, s, r, tj, ti, int(rng.integers(1, 4)))
+            assert isinstance(e, PairExpr)
+            if not e.lowers():
+                continue                       # (e.g. log / sqrt of something whose derivative is not finite at s = 0: the torch route)
+            t = torch.from_numpy(pts[:, :3] + 1e-7)
+            rr = torch.sqrt((t * t).sum(dim=1)).requires_grad_(True)
+            ok = rr > 3e-6
+            sv = torch.where(ok, 1.0 / (torch.where(ok, rr, torch.ones_like(rr)) + 3e-6), torch.zeros_like(rr))
+            rn = torch.sqrt((torch.from_numpy(pts[:, :3]) ** 2).sum(dim=1))
+            val = cg.evaluate(e.node, sv, rr, rn, tj=torch.from_numpy(pts[:, 3]), ti=torch.from_numpy(own))
+            (grad,) = torch.autograd.grad(val.sum(), rr)
+            src, exe = os.path.join(tmp, "h%d.c" % trial), os.path.join(tmp, "h%d" % trial)
+            with open(src, "w") as f:
+                f.write(TYPED_HARNESS.replace("BODY", e.body().replace("static constexpr", "static const")))
+            subprocess.check_call(["gcc", "-O1", "-o", exe, src, "-lm"])
+            out = subprocess.run([exe], input=feed, capture_output=True, text=True, check=True).stdout
+            got = np.array([[float(v) for v in line.split()] for line in out.strip().splitlines()])
+            scale_e, scale_g = np.abs(val.detach().numpy()).max() + 1e-30, np.abs(grad.numpy()).max() + 1e-30
+            assert np.abs(got[:, 0] - val.detach().numpy()).max() < 1e-5 * scale_e, (trial, e.body())
+            assert np.abs(got[:, 1] - grad.numpy())[lv].max() < 3e-5 * scale_g, (trial, e.body())
+            assert np.all(got[~lv] == 0.0), (trial, e.body())
+            done += 1
+    assert done >= 25

@@ -237,3 +237,33 @@ def test_a_model_with_weights_runs_generated_kernels_until_a_weight_is_written(h
         assert float((f[:, :3] - f0[:, :3]).abs().max()) < 2e-3 * scale
         assert abs(float(f[:, 3].double().sum()) - float(f0[:, 3].double().sum())) < 1e-4 * abs(float(f0[:, 3].double().sum())) + 1e-3
     assert float((got[1][1][:, 3].double().sum() / got[0][1][:, 3].double().sum())) > 1.5      # (twice the well depth: the energy followed)
+
+
+def test_random_expressions_on_the_device(htf, cuda):
+    """Six random expression trees of the tracer's whole op set (tables by species pair included), masked by s^2: the generated
+    streaming evaluator against torch-fp64 autograd of the same tree, forces and energies at the LJ tolerances."""
+    from test_codegen_cpu import _random_expression
+    from test_gpu_parity import CONTACTS, assert_forces_close
+    from hoomd_tf_amd.simmodel import PositionsInput
+    rng = np.random.default_rng(77)
+    nl, pos = _typed_inputs(rng, 200, 64, 3, np.float32)
+    nl64, pos64 = nl.astype(np.float64), pos.astype(np.float64)
+    xs = htf.Nlist(torch.from_numpy(nl64))
+    P = PositionsInput.wrap(torch.from_numpy(pos64))
+    s, r = htf.nlist_rinv(xs), htf.safe_norm(xs[:, :, :3], axis=2)
+    x, Pd = torch.from_numpy(nl).to(cuda), torch.from_numpy(pos).to(cuda)
+    done = 0
+    for trial in range(12):
+        e = htf.square(s) * _random_expression(htf, rng, s, r, xs[:, :, 3], P[:, 3], int(rng.integers(1, 4)))
+        if not e.lowers():
+            continue
+        f = htf.ops.eval_forces(e.potential(), x, positions=Pd)
+        ref = _ref(htf, e, nl64)
+        xx = htf.Nlist(torch.from_numpy(nl64))
+        (g,) = torch.autograd.grad(e.torch_value(xx.ad).sum(), xx.ad)
+        cond = np.abs(2 * g.numpy()[:, :, :3]).sum(axis=(1, 2))
+        assert_forces_close("jit_random_%d" % trial, f.cpu().numpy(), ref, cond, cancelling_rows=CONTACTS)
+        done += 1
+        if done == 6:
+            break
+    assert done == 6
