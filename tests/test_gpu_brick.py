@@ -508,3 +508,64 @@ def test_check_displacement_in_one_launch(dt):
         if cycle > 1:      # and the status words it carried along
             assert torch.equal(h_status[:300], status[:300].cpu()) and torch.equal(h_status[300:301], status[777:778].cpu())
             assert int(h_status[301]) == -1
+
+
+def test_replica_brick_with_a_typed_traced_energy(htf, cuda):
+    """Particle types cross the decomposition: a three-species mixture whose epsilon / sigma are gathered by species pair (a
+    generated kernel, hoomd_tf_amd/codegen.py) on a 4 x 2 brick in replica mode -- the row particle's type from its own position,
+    a GHOST neighbor's from the halo message that delivered it -- against the replicated single-domain box, through an MD run."""
+    from test_codegen_cpu import _typed_models
+    from hoomd_tf_amd import standin
+    from hoomd_tf_amd.brick import BrickDomain
+    from hoomd_tf_amd.simmodel import PositionsInput
+    grid, cells, ntypes = (4, 2, 1), 6, 3
+    pos, vel, Lb = _brick_of_liquid(htf, cuda, cells, grid)
+    rcut, rbuf, NN = 2.5, 0.4, 96
+    Lg = Lb * np.asarray(grid)
+    lo = -Lg / 2 + (np.asarray(grid) // 2) * Lb
+    types = np.random.default_rng(5).integers(0, ntypes, len(pos))
+    sysm = standin.System(pos + Lb / 2 + lo, Lg, types=types, dtype=torch.float32, device=cuda)
+    sysm.vel = torch.from_numpy(vel).float().to(cuda)
+    e = _typed_models(htf, htf.Nlist(torch.zeros((2, 4, 4))), PositionsInput.wrap(torch.zeros((2, 4))), ntypes, big=False)["lj_table"]
+    pot = e.potential()
+    nl = standin.CellNlist(sysm, r_cut=rcut, r_buff=rbuf, check_period=1)
+    dom = nl.domain = BrickDomain(sysm, 0, grid, r_ghost=rcut + rbuf, r_buff=rbuf, replica=True, transport="local")
+    nl.build()
+    ctx = htf.Context(r_cut=rcut, nneighs=NN, scalar_dtype=torch.float32, max_n=sysm.N)
+    ctx.set_potential(pot)
+    nve = standin.NVE(sysm, 0.004)
+    arr = ctx.make_arrays(sysm.pos, sysm.N, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, sysm.force)
+    n_steps = 80
+    for ts in range(n_steps):
+        nl.compute(ts)
+        ctx.compute_forces_overlapped(ts, arr, dom)
+        if ts < n_steps - 1:
+            nve.step()
+    torch.cuda.synchronize()
+    assert nl.n_builds >= 2 and dom.n_migrated > 0
+    live = dom.live_rows()
+    assert len(live) == len(pos)
+    p = sysm.pos[live, :3].double().cpu().numpy()
+    t_live = sysm.pos[live, 3].contiguous().view(torch.int32).cpu().numpy()     # (w carries the type id's bits)
+    assert sorted(t_live.tolist()) == sorted(types.tolist())                       # nobody changed species on the way
+    got = sysm.force[live].cpu().numpy()
+    reps = np.stack(np.meshgrid(*[np.arange(g) for g in grid], indexing="ij"), -1).reshape(-1, 3)
+    base = p - lo
+    allp = np.concatenate([base + r * Lb - Lg / 2 for r in reps])
+    allp -= np.floor((allp + Lg / 2) / Lg) * Lg
+    ref_sys = standin.System(allp, Lg, types=np.tile(t_live, len(reps)), dtype=torch.float32, device=cuda)
+    ref_nl = standin.CellNlist(ref_sys, r_cut=rcut, r_buff=rbuf)
+    ref_nl.build()
+    ref_ctx = htf.Context(r_cut=rcut, nneighs=NN, scalar_dtype=torch.float32, max_n=ref_sys.N)
+    ref_ctx.set_potential(pot)
+    ref_ctx.compute_forces(0, ref_ctx.make_arrays(ref_sys.pos, ref_sys.N, ref_nl.n_neigh, ref_nl.head_list, ref_nl.nlist, ref_sys.box, ref_sys.force))
+    torch.cuda.synchronize()
+    mine = int(np.nonzero((reps == np.asarray(grid) // 2).all(axis=1))[0][0])
+    want = ref_sys.force.cpu().numpy()[mine * len(p):(mine + 1) * len(p)]
+    scale = np.abs(want).max()
+    assert np.abs(got - want).max() < 3e-5 * scale, (np.abs(got - want).max(), scale)
+    # and the species matter: the same rows with every type erased feel different forces
+    ref0 = standin.System(allp, Lg, dtype=torch.float32, device=cuda)
+    ref_ctx.compute_forces(0, ref_ctx.make_arrays(ref0.pos, ref0.N, ref_nl.n_neigh, ref_nl.head_list, ref_nl.nlist, ref0.box, ref0.force))
+    torch.cuda.synchronize()
+    assert np.abs(ref0.force.cpu().numpy()[mine * len(p):(mine + 1) * len(p)] - want).max() > 0.05 * scale

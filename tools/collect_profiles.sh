@@ -12,6 +12,9 @@ cp $F/mt_kernel_stats.csv profiles/${R}_bench_mlp_train_kernel_stats.csv
 cp $F/eds_kernel_stats.csv profiles/${R}_bench_eds_c4_kernel_stats.csv
 [ -s $F/c2_kernel_stats.csv ] && cp $F/c2_kernel_stats.csv profiles/${R}_bench_wca_c2_kernel_stats.csv
 [ -s $F/dd_kernel_stats.csv ] && cp $F/dd_kernel_stats.csv profiles/${R}_bench_dd_self_kernel_stats.csv
+[ -s $F/generic_lj_kernel_stats.csv ] && cp $F/generic_lj_kernel_stats.csv profiles/${R}_bench_generic_lj_kernel_stats.csv
+for n in bench_dd_self_phases_8x1x1 bench_dd_self_phases_4x2x1; do [ -s $F/$n.json ] && cp $F/$n.json profiles/${R}_$n.json; done
+[ -s $F/launch_floor_probe.txt ] && cp $F/launch_floor_probe.txt profiles/${R}_launch_floor_probe.txt
 [ -s $F/rccl_graph_probe.txt ] && cp $F/rccl_graph_probe.txt profiles/${R}_rccl_graph_probe.txt
 [ -s $F/f64_kernel_stats.csv ] && cp $F/f64_kernel_stats.csv profiles/${R}_bench_lj_f64_kernel_stats.csv
 [ -s $F/fetch_calib.json ] && cp $F/fetch_calib.json profiles/${R}_fetch_calib.json

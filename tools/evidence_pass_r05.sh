@@ -44,6 +44,12 @@ timeout 300 python bench.py --workload dd-self --grid 4x2x1 --steps 100 --warmup
 timeout 200 python tools/rccl_graph_probe.py 2>&1 | cut -c1-190 > $F/rccl_graph_probe.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_dd -o dd -- python3 bench.py --workload dd-self --grid 8x1x1 --transport local --steps 200 --warmup 20 --windows 2 > /dev/null 2>&1
 find /tmp/p_dd -name "*kernel_stats.csv" -exec cp {} $F/dd_kernel_stats.csv \;
+# the traced models' generated kernels by name and duration (htf_jit_rows2_f32_store: the two-row one-kernel step around a generated body)
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_gen -o gen -- python3 bench.py --workload generic-lj > /dev/null 2>&1
+find /tmp/p_gen -name "*kernel_stats.csv" -exec cp {} $F/generic_lj_kernel_stats.csv \;
+HTF_DD_PHASES=1 timeout 300 python bench.py --workload dd-self --grid 8x1x1 --transport local 2>/dev/null | jl > $F/bench_dd_self_phases_8x1x1.json
+HTF_DD_PHASES=1 timeout 300 python bench.py --workload dd-self --grid 4x2x1 --transport local 2>/dev/null | jl > $F/bench_dd_self_phases_4x2x1.json
+timeout 100 tools/launch_floor_probe > $F/launch_floor_probe.txt 2>&1
 # kernel durations: rocprofv3 --kernel-trace --stats of the same commands
 Q="--no-cpu-baseline --no-mlp"
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_lj -o lj -- python3 bench.py $Q > /dev/null 2>&1
