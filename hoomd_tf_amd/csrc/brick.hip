@@ -452,29 +452,41 @@ __global__ __launch_bounds__(256) void brick_pack_halo_kernel(const V4 *__restri
 // class from the class boundaries and its slot in a message from the counts of the classes before it.  One launch where the
 // integrator and the packer were two (each >= 4.5 us inside a hipGraph whatever it moves).  The messages' inert tails were
 // written by the rebuild's own pack and stay put until the next one.
+// The counts block (HTFS_BC_WORDS words: class boundaries, message counts, slot table) staged in LDS by the whole workgroup with ONE
+// round of loads, issued beside the rows' own: the per-step kernels used to walk it with dependent global loads -- boundary count ->
+// class boundaries (a loop) -> slot table -> message counts, four or five trips to the L2 in a kernel that is otherwise one.
+__device__ __forceinline__ void stage_counts(unsigned *lds, const unsigned *__restrict__ counts) {
+    for (unsigned w = threadIdx.x; w < (unsigned)HTFS_BC_WORDS; w += blockDim.x) lds[w] = counts[w];
+}
+
 template <typename T, typename V4>
 __global__ __launch_bounds__(256) void brick_nve_halo_peer_kernel(V4 *__restrict__ pos, V4 *__restrict__ vel, const V4 *__restrict__ force,
                                                                   T dt, SBox<T> box, BrickArgs<T> a, const unsigned *__restrict__ counts,
                                                                   PeerArgs pa) {
+    __shared__ unsigned cnt[HTFS_BC_WORDS];
     const unsigned seq = pa.state[0] + 1u;
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < a.cap_int + a.cap_bnd) {
-        V4 p = pos[i], v = vel[i];
-        nve_advance<T>(p, v, force[i], dt, box);
+    const bool row = i < a.cap_int + a.cap_bnd;
+    V4 p, v, f;
+    if (row) p = pos[i], v = vel[i], f = force[i];
+    stage_counts(cnt, counts);
+    __syncthreads();
+    if (row) {
+        nve_advance<T>(p, v, f, dt, box);
         pos[i] = p;
         vel[i] = v;
         const unsigned j = i - a.cap_int;
-        if (i >= a.cap_int && j < counts[HTFS_BC_N_BND]) {
+        if (i >= a.cap_int && j < cnt[HTFS_BC_N_BND]) {
             const unsigned nclass = a.ndim == 1 ? 4u : 16u;
-            const unsigned n_int = counts[HTFS_BC_CLASS + 1];
+            const unsigned n_int = cnt[HTFS_BC_CLASS + 1];
             unsigned c = 1;
-            while (c + 1 < nclass && j >= counts[HTFS_BC_CLASS + c + 1] - n_int) ++c;
-            const unsigned in_class = j - (counts[HTFS_BC_CLASS + c] - n_int);
+            while (c + 1 < nclass && j >= cnt[HTFS_BC_CLASS + c + 1] - n_int) ++c;
+            const unsigned in_class = j - (cnt[HTFS_BC_CLASS + c] - n_int);
             for (int m = 0; m < a.n_msg; ++m) {
-                const unsigned first = counts[HTFS_BC_SLOT + c * HTFS_BRICK_MAX_MSG + m];
+                const unsigned first = cnt[HTFS_BC_SLOT + c * HTFS_BRICK_MAX_MSG + m];
                 if (first == 0xFFFFFFFFu) continue;
                 const unsigned slot = first + in_class;
-                if (slot >= counts[HTFS_BC_MSG + m]) continue;
+                if (slot >= cnt[HTFS_BC_MSG + m]) continue;
                 store_stream(peer_slot<V4>(pa, m, a.n_msg, a.ghost_off, seq, slot), shifted<T>(p, a, a.shift[m], a.halo_wrap));
             }
         }
@@ -486,25 +498,33 @@ template <typename T, typename V4>
 __global__ __launch_bounds__(256) void brick_nve_halo_kernel(V4 *__restrict__ pos, V4 *__restrict__ vel, const V4 *__restrict__ force,
                                                              T dt, SBox<T> box, BrickArgs<T> a, const unsigned *__restrict__ counts,
                                                              V4 *__restrict__ send, V4 *__restrict__ direct) {
+    __shared__ unsigned cnt[HTFS_BC_WORDS];
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.cap_int + a.cap_bnd) return;
-    V4 p = pos[i], v = vel[i];
-    nve_advance<T>(p, v, force[i], dt, box);
+    const bool row = i < a.cap_int + a.cap_bnd;
+    V4 p, v, f;
+    if (row) p = pos[i], v = vel[i], f = force[i];
+    const bool boundary_block = (blockIdx.x + 1u) * blockDim.x > a.cap_int; // (workgroup-uniform: interior-only workgroups skip the table)
+    if (boundary_block) {
+        stage_counts(cnt, counts);
+        __syncthreads();
+    }
+    if (!row) return;
+    nve_advance<T>(p, v, f, dt, box);
     pos[i] = p;
     vel[i] = v;
     if (i < a.cap_int) return;
     const unsigned j = i - a.cap_int;
-    if (j >= counts[HTFS_BC_N_BND]) return;
+    if (j >= cnt[HTFS_BC_N_BND]) return;
     const unsigned nclass = a.ndim == 1 ? 4u : 16u;
-    const unsigned n_int = counts[HTFS_BC_CLASS + 1];
+    const unsigned n_int = cnt[HTFS_BC_CLASS + 1];
     unsigned c = 1;
-    while (c + 1 < nclass && j >= counts[HTFS_BC_CLASS + c + 1] - n_int) ++c;
-    const unsigned in_class = j - (counts[HTFS_BC_CLASS + c] - n_int);
+    while (c + 1 < nclass && j >= cnt[HTFS_BC_CLASS + c + 1] - n_int) ++c;
+    const unsigned in_class = j - (cnt[HTFS_BC_CLASS + c] - n_int);
     for (int m = 0; m < a.n_msg; ++m) {
-        const unsigned first = counts[HTFS_BC_SLOT + c * HTFS_BRICK_MAX_MSG + m]; // (written by the rebuild's place kernel)
+        const unsigned first = cnt[HTFS_BC_SLOT + c * HTFS_BRICK_MAX_MSG + m]; // (written by the rebuild's place kernel)
         if (first == 0xFFFFFFFFu) continue;
         const unsigned slot = first + in_class;
-        if (slot >= counts[HTFS_BC_MSG + m]) continue; // (beyond the message's capacity: flagged by the rebuild)
+        if (slot >= cnt[HTFS_BC_MSG + m]) continue; // (beyond the message's capacity: flagged by the rebuild)
         const V4 q = shifted<T>(p, a, a.shift[m], a.halo_wrap);
         if (send != nullptr) send[a.ghost_off[m] + slot] = q;
         if (direct != nullptr) direct[a.ghost_off[a.n_msg - 1 - m] + slot] = q;
