@@ -334,14 +334,18 @@ __global__ __launch_bounds__(256) void build_nlist_cells_kernel(const typename V
                                                                 int type_split, unsigned *__restrict__ n_neigh,
                                                                 unsigned *__restrict__ head_list, unsigned *__restrict__ nlist,
                                                                 unsigned *__restrict__ max_neigh,
-                                                                const uint4 *__restrict__ ranges, Gate gate) {
+                                                                const uint4 *__restrict__ ranges, unsigned split, Gate gate) {
     if (gate.closed()) return;
     using V4 = typename Vec4<T>::type;
     const unsigned lane = threadIdx.x & 63u;
-    const unsigned c = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    // `split` waves per cell, wave b of a cell taking its batches b, b + split, ... of kCellBatch particles (round 5: on a grid that
+    // does not fill the chip the kernel lasts as long as its longest wave -- one of the few cells with more than one batch -- so a
+    // second wave per cell, which leaves at once where there is no second batch, halves that; same rows, same order, bit for bit)
+    const unsigned wv = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const unsigned c = wv / split, b0 = wv % split;
     if (c >= ncell) return;
     const unsigned p_begin = cell_start[c], p_end = cell_start[c + 1];
-    if (p_begin == p_end) return;
+    if (p_begin + b0 * (unsigned)kCellBatch >= p_end) return;
     // a cell of ghosts only (the decomposed step's halo cells: candidates for others, no row of their own) has nothing to search
     if (p_end - p_begin <= 64u) {
         const bool local = lane < p_end - p_begin && ((unsigned)scalar_as_int(pos_sorted[p_begin + lane].w) & ~kTagSide) < N;
@@ -374,7 +378,7 @@ __global__ __launch_bounds__(256) void build_nlist_cells_kernel(const typename V
     const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
     const bool any_shift = SHIFT && ballot64(len != 0u && (shx != (T)0 || shy != (T)0 || shz != (T)0)) != 0ull;
 
-    for (unsigned pb = p_begin; pb < p_end; pb += kCellBatch) {
+    for (unsigned pb = p_begin + b0 * (unsigned)kCellBatch; pb < p_end; pb += split * (unsigned)kCellBatch) {
         const unsigned np = min(p_end - pb, (unsigned)kCellBatch);
         // the batch's particles: lane p loads particle p, then everything about it becomes wave-uniform
         V4 me;
@@ -900,9 +904,9 @@ static int build_nlist_impl(const void *d_pos, const void *d_pos_sorted, int dty
 #define HTFS_NLC(T, V4)                                                                                                \
     if (shift) HTFS_NLC_(T, V4, true); else HTFS_NLC_(T, V4, false)
 #define HTFS_NLC_(T, V4, S)                                                                                            \
-    hipLaunchKernelGGL((build_nlist_cells_kernel<T, S>), dim3((ncell + 3) / 4), dim3(256), 0, (hipStream_t)stream,         \
+    hipLaunchKernelGGL((build_nlist_cells_kernel<T, S>), dim3((ncell * cell_split + 3) / 4), dim3(256), 0, (hipStream_t)stream, \
                        (const V4 *)d_pos_sorted, N, make_sbox<T>(box), (T)(r_list * r_list), ncell, (int)nrow, d_cell_start, pitch, \
-                       type_split, d_n_neigh, d_head_list, d_nlist, d_max_neigh, (const uint4 *)d_ranges, g_gate)
+                       type_split, d_n_neigh, d_head_list, d_nlist, d_max_neigh, (const uint4 *)d_ranges, cell_split, g_gate)
     // with >= 7 cells along every periodic axis a stencil (<= 2 cells each way, plus a particle's place inside its own cell)
     // never reaches half a box length: the near image of a candidate follows from its cell alone
     bool shift = true;
@@ -915,6 +919,8 @@ static int build_nlist_impl(const void *d_pos, const void *d_pos_sorted, int dty
     constexpr bool per_particle = false, per_cell = false;
 #endif
     const bool by_cell = per_cell || (!per_particle && ncell >= 1024u);
+    // two waves per cell on grids of up to 12 288 cells (a brick + its ghost layer at 16 k rows per rank: 7.7 k; C2: 8 k); the 30 k cells of C3 fill the chip as they are
+    const unsigned cell_split = ncell <= 12288u ? 2u : 1u;
     if (by_cell) {
         if (dtype == HTF_F32) { HTFS_NLC(float, float4); } else { HTFS_NLC(double, double4); }
     } else if (dtype == HTF_F32) {
