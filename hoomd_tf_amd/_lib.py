@@ -121,6 +121,9 @@ PROTOTYPES = {
     "htf_build_pair_vectors": (_i, [_vp, _i, _vp, _i, _u, _u, _u, _u, _u, C.POINTER(Box), _vp, _vp, _vp, _d, _vp, _vp]),
     "htf_eval_forces": (_i, [_vp, _vp, _i, _u, _u, _vp, _i, _vp, _vp]),
     "htf_eval_forces_typed": (_i, [_vp, _vp, _i, _u, _u, _vp, _i, _vp, _i, _vp, _vp]),
+    "htf_jit_available": (_i, []),
+    "htf_jit_compile": (_i, [C.c_char_p, C.c_char_p, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, C.c_size_t]),
+    "htf_jit_free": (None, [_vp]),
     "htf_fused_forces": (_i, [_vp, _vp, _i, _u, _u, _u, _u, C.POINTER(Box), _vp, _vp, _vp, _d, _vp, _i, _vp, _vp, _vp]),
     "htf_build_eval_forces": (_i, [_vp, _vp, _vp, _i, _u, _u, _u, _u, C.POINTER(Box), _vp, _vp, _vp, _d, _vp, _i, _vp, _vp, _vp]),
     "htf_eval_forces2": (_i, [_vp, _vp, _vp, _i, _u, _u, _vp, _vp, _i, _vp, C.c_float, C.c_float, _u, _vp, _vp]),

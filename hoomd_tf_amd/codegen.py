@@ -380,40 +380,101 @@ def _source_digest():
     return h.hexdigest()
 
 
-def _key(body):
-    return hashlib.sha256((body + "\0" + _source_digest() + "\0" + ARCH + " ".join(FLAGS)).encode()).hexdigest()[:24]
+def compiler():
+    """Which compiler builds a generated unit: "hiprtc" -- the library's own htf_jit_compile, libhiprtc in process, sources handed
+    over as text: no compiler driver, no temporary files -- when libhiprtc can be loaded, else "hipcc" (`hipcc --genco` as a
+    subprocess); HTF_JIT_COMPILER forces either.  None: neither is there."""
+    want = os.environ.get("HTF_JIT_COMPILER")
+    if want in ("hiprtc", "hipcc"):
+        return want
+    try:
+        from . import _lib
+        if _lib._ctypes_lib.htf_jit_available():
+            return "hiprtc"
+    except Exception:  # noqa: BLE001
+        pass
+    try:
+        _hipcc()
+        return "hipcc"
+    except RuntimeError:
+        return None
+
+
+def _key(body, how=None):
+    how = how or compiler() or "none"
+    return hashlib.sha256((body + "\0" + _source_digest() + "\0" + ARCH + " ".join(FLAGS) + "\0" + how).encode()).hexdigest()[:24]
 
 
 def available(body):
-    """A generated kernel for this body can be had: its code object is cached, or the compiler is there to build it."""
+    """A generated kernel for this body can be had: its code object is cached, or a compiler is there to build it."""
     if os.path.exists(os.path.join(_cache_dir(), _key(body) + ".hsaco")):
         return True
+    return compiler() is not None
+
+
+def _body_include(body):
+    return "#define HTF_JIT_BODY_TEXT \\\n" + " \\\n".join("    " + l for l in body.splitlines()) + "\n"
+
+
+def _compile_hiprtc(body):
+    """csrc/jit_unit.hip through htf_jit_compile (csrc/jit.hip: hipRTC): every header by name and text."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib._ctypes_lib
+    with open(os.path.join(_CSRC, "jit_unit.hip")) as f:
+        unit = f.read().replace("#include HTF_JIT_BODY_FILE", '#include "htf_jit_body.inc"')
+    headers = {"htf_jit_body.inc": _body_include(body)}
+    for name in _SOURCES[1:]:
+        with open(os.path.join(_CSRC, name)) as f:
+            headers[name] = f.read()
+    with open(os.path.join(os.path.dirname(_HERE), "include", "htf_amd.h")) as f:
+        headers["htf_amd.h"] = f.read()
+    names = (C.c_char_p * len(headers))(*[n.encode() for n in headers])
+    texts = (C.c_char_p * len(headers))(*[t.encode() for t in headers.values()])
+    opts = (C.c_char_p * len(FLAGS))(*[o.encode() for o in FLAGS])
+    image, nbytes = C.c_void_p(), C.c_size_t()
+    log = C.create_string_buffer(16384)
+    rc = lib.htf_jit_compile(unit.encode(), ARCH.encode(), len(headers), C.cast(names, C.c_void_p), C.cast(texts, C.c_void_p), len(FLAGS),
+                             C.cast(opts, C.c_void_p), C.cast(C.byref(image), C.c_void_p), C.cast(C.byref(nbytes), C.c_void_p),
+                             C.cast(log, C.c_void_p), len(log))
+    if rc != 0:
+        raise RuntimeError("hoomd_tf_amd.codegen: hipRTC failed on the generated unit (%s):\n%s\n--- body ---\n%s"
+                           % (lib.htf_last_error().decode(errors="replace"), log.value.decode(errors="replace")[-3000:], body))
     try:
-        _hipcc()
-        return True
-    except RuntimeError:
-        return False
+        return C.string_at(image.value, nbytes.value)
+    finally:
+        lib.htf_jit_free(image)
+
+
+def _compile_hipcc(body):
+    with tempfile.TemporaryDirectory() as tmp:
+        inc = os.path.join(tmp, "body.inc")
+        with open(inc, "w") as f:
+            f.write(_body_include(body))
+        out = os.path.join(tmp, "unit.hsaco")
+        cmd = [_hipcc(), "--genco", "--offload-arch=" + ARCH] + FLAGS + [
+            "-I" + os.path.join(os.path.dirname(_HERE), "include"), "-I" + _CSRC, "-DHTF_JIT_BODY_FILE=\"%s\"" % inc,
+            os.path.join(_CSRC, "jit_unit.hip"), "-o", out]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0 or not os.path.exists(out):
+            raise RuntimeError("hoomd_tf_amd.codegen: hipcc failed on the generated unit:\n%s\n--- body ---\n%s" % (r.stderr[-3000:], body))
+        with open(out, "rb") as f:
+            return f.read()
 
 
 def compile_body(body):
-    """-> (bytes of the gfx950 code object, its cache key).  Compiles on a miss (~6 s), loads from the cache otherwise."""
-    key = _key(body)
+    """-> (bytes of the gfx950 code object, its cache key).  Compiles on a miss (hipRTC in process, ~4 s; or `hipcc --genco`,
+    ~6 s), loads from the cache otherwise."""
+    how = compiler()
+    key = _key(body, how)
     path = os.path.join(_cache_dir(), key + ".hsaco")
     if not os.path.exists(path):
-        with tempfile.TemporaryDirectory() as tmp:
-            inc = os.path.join(tmp, "body.inc")
-            with open(inc, "w") as f:
-                f.write("#define HTF_JIT_BODY_TEXT \\\n" + " \\\n".join("    " + l for l in body.splitlines()) + "\n")
-            out = os.path.join(tmp, "unit.hsaco")
-            cmd = [_hipcc(), "--genco", "--offload-arch=" + ARCH] + FLAGS + [
-                "-I" + os.path.join(os.path.dirname(_HERE), "include"), "-I" + _CSRC, "-DHTF_JIT_BODY_FILE=\"%s\"" % inc,
-                os.path.join(_CSRC, "jit_unit.hip"), "-o", out]
-            r = subprocess.run(cmd, capture_output=True, text=True)
-            if r.returncode != 0 or not os.path.exists(out):
-                raise RuntimeError("hoomd_tf_amd.codegen: hipcc failed on the generated unit:\n%s\n--- body ---\n%s" % (r.stderr[-3000:], body))
-            tmp_path = path + ".%d.tmp" % os.getpid()
-            with open(out, "rb") as src, open(tmp_path, "wb") as dst:
-                dst.write(src.read())
-            os.replace(tmp_path, path)   # (atomic: several ranks may compile the same expression at once)
+        if how is None:
+            raise RuntimeError("hoomd_tf_amd.codegen: neither libhiprtc nor hipcc is available: generated kernels need one of them at run time")
+        image = _compile_hiprtc(body) if how == "hiprtc" else _compile_hipcc(body)
+        tmp_path = path + ".%d.tmp" % os.getpid()
+        with open(tmp_path, "wb") as dst:
+            dst.write(image)
+        os.replace(tmp_path, path)   # (atomic: several ranks may compile the same expression at once)
     with open(path, "rb") as f:
         return f.read(), key

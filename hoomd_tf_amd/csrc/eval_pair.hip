@@ -15,7 +15,9 @@
 // are issued before the first use (128 B in flight per lane).  The pair->particle
 // sum is a DPP row reduction inside the group -- no LDS, no atomics -- and lane 0 of
 // each group stores the Scalar4.  No LDS staging: there is no reuse to exploit.
+#ifndef __HIPCC_RTC__
 #include <cmath>
+#endif
 
 #include "htf_common.h"
 #include "htf_internal.h"

@@ -15,12 +15,14 @@
 // registers -- rows, zero tails and live counts exactly as build_pair_vectors_kernel does
 // (bit-identical tensor) -- so the tensor exists for get_nlist_array / training / observables
 // but is never read back: the evaluator's 268 MB re-read and its launch disappear from the step.
+#ifndef __HIPCC_RTC__
 #include <cstdlib>
 
 #include <cstring>
 #include <hip/hip_ext.h>
 #include <mutex>
 #include <vector>
+#endif
 
 #include "box_math.h"
 #include "htf_common.h"
@@ -29,10 +31,12 @@
 
 namespace htf {
 
+#ifndef __HIPCC_RTC__
 LaunchEvents &launch_events() {
     static thread_local LaunchEvents e;
     return e;
 }
+#endif
 
 // hipLaunchKernelGGL, or -- when the profiler has handed over a pair of events -- the launch that stamps them with the kernel's
 // own begin and end
@@ -314,7 +318,7 @@ __device__ __forceinline__ void fused_rows_group(
             const unsigned long long m = ballot64(!(rsq > rmaxsq)) & valid;
             const unsigned qq = Q + ballot_rank(m);
             Q += __popcll(m);
-            const bool keep = __builtin_amdgcn_inverse_ballot_w64(m);
+            const bool keep = inverse_ballot64(m);
             const float x = (float)dx, y = (float)dy, z = (float)dz;
             if constexpr (STORE) {
                 unsigned long long ms = m;
@@ -322,7 +326,7 @@ __device__ __forceinline__ void fused_rows_group(
                     asm volatile("" ::: "memory");
                     ms &= ballot64(qq < NN);
                 }
-                if (__builtin_amdgcn_inverse_ballot_w64(ms)) store_stream(&row[qq], make_float4(x, y, z, (float)scalar_as_int(pk.w)));
+                if (inverse_ballot64(ms)) store_stream(&row[qq], make_float4(x, y, z, (float)scalar_as_int(pk.w)));
             }
             float e, ax, ay, az;
             pair_eval_if<KIND>(keep, x, y, z, p, e, ax, ay, az, (float)scalar_as_int(pk.w), (float)scalar_as_int(pi[r].w));
@@ -466,7 +470,7 @@ __device__ __forceinline__ void fused_rows_group_tails(
             const unsigned long long m = ballot64(!(rsq > rmaxsq)) & valid;
             const unsigned qq = Q[r] + ballot_rank(m);
             Q[r] += __popcll(m);
-            const bool keep = __builtin_amdgcn_inverse_ballot_w64(m); // the scalar mask read as this lane's predicate: no VALU
+            const bool keep = inverse_ballot64(m); // the scalar mask read as this lane's predicate: no VALU
             const float x = (float)dx, y = (float)dy, z = (float)dz;
             if constexpr (STORE) {
                 unsigned long long ms = m;
@@ -474,7 +478,7 @@ __device__ __forceinline__ void fused_rows_group_tails(
                     asm volatile("" ::: "memory");
                     ms &= ballot64(qq < NN);
                 }
-                if (__builtin_amdgcn_inverse_ballot_w64(ms)) store_stream(&row[qq], make_float4(x, y, z, (float)scalar_as_int(pk.w)));
+                if (inverse_ballot64(ms)) store_stream(&row[qq], make_float4(x, y, z, (float)scalar_as_int(pk.w)));
             }
             float e, ax, ay, az;
             pair_eval_if<KIND>(keep, x, y, z, p, e, ax, ay, az, (float)scalar_as_int(pk.w), (float)scalar_as_int(pi[r].w));
@@ -505,7 +509,7 @@ __device__ __forceinline__ void fused_rows_group_tails(
             base_l = rl == (unsigned)r ? Q[r] - before : base_l;
         }
         const unsigned qq = base_l + ballot_rank(m);
-        const bool keep = __builtin_amdgcn_inverse_ballot_w64(m);
+        const bool keep = inverse_ballot64(m);
         const float xt = (float)dx, yt = (float)dy, zt = (float)dz;
         if constexpr (STORE)
             if (keep && qq < NN) store_stream(dest + (size_t)(w0 + rl) * NN + qq, make_float4(xt, yt, zt, (float)scalar_as_int(qt.w)));
@@ -1007,7 +1011,7 @@ __global__ __launch_bounds__(256) void fused_forces2_kernel(
                 }
                 const unsigned left = nn > (unsigned)t * 64 ? nn - (unsigned)t * 64 : 0u;
                 const unsigned long long m = ballot64(!(rsq > rmaxsq)) & (left >= 64u ? ~0ull : ((1ull << left) - 1ull));
-                keep[t] = __builtin_amdgcn_inverse_ballot_w64(m);
+                keep[t] = inverse_ballot64(m);
                 q[t] = Q + ballot_rank(m);
                 Q += __popcll(m);
             }
@@ -1331,7 +1335,7 @@ __device__ __forceinline__ void sweep2_rows_group_tails(Sweep2 &st, const unsign
             const unsigned long long m = ballot64(!(rsq > rmaxsq)) & valid;
             const unsigned qq = Q[r] + ballot_rank(m);
             Q[r] += __popcll(m);
-            const bool keep = __builtin_amdgcn_inverse_ballot_w64(m);
+            const bool keep = inverse_ballot64(m);
             const float x = (float)dx, y = (float)dy, z = (float)dz;
             if constexpr (STORE) {
                 unsigned long long ms = m;
@@ -1339,7 +1343,7 @@ __device__ __forceinline__ void sweep2_rows_group_tails(Sweep2 &st, const unsign
                     asm volatile("" ::: "memory");
                     ms &= ballot64(qq < NN);
                 }
-                if (__builtin_amdgcn_inverse_ballot_w64(ms)) store_stream(&row[qq], make_float4(x, y, z, (float)scalar_as_int(pk.w)));
+                if (inverse_ballot64(ms)) store_stream(&row[qq], make_float4(x, y, z, (float)scalar_as_int(pk.w)));
             }
             sweep2_eval<KA>(st, keep, x, y, z, ax[r], ay[r], az[r], ae[r], bx[r], by[r], bz[r], be[r]);
         }
@@ -1362,7 +1366,7 @@ __device__ __forceinline__ void sweep2_rows_group_tails(Sweep2 &st, const unsign
             base_l = rl == (unsigned)r ? Q[r] - before : base_l;
         }
         const unsigned qq = base_l + ballot_rank(m);
-        const bool keep = __builtin_amdgcn_inverse_ballot_w64(m);
+        const bool keep = inverse_ballot64(m);
         const float xt = (float)dx, yt = (float)dy, zt = (float)dz;
         if constexpr (STORE)
             if (keep && qq < NN) store_stream(dest + (size_t)(w0 + rl) * NN + qq, make_float4(xt, yt, zt, (float)scalar_as_int(qt.w)));

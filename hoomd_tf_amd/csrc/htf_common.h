@@ -1,14 +1,18 @@
 // Internal helpers shared by the HIP translation units (not part of the ABI).
 #pragma once
+// (__HIPCC_RTC__: a generated unit under hipRTC, csrc/jit.hip -- the device runtime is built in, there is no host side)
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstring>
 #include <string>
+#endif
 
 #include "htf_amd.h"
 
 namespace htf {
 
+#ifndef __HIPCC_RTC__
 void set_error(const char *fmt, ...);
 
 #define HTF_CHECK_HIP(expr)                                                              \
@@ -35,6 +39,17 @@ inline int check_launch(const char *what) {
         return HTF_ERR_DEVICE;
     }
     return HTF_OK;
+}
+#endif // __HIPCC_RTC__
+
+// a scalar lane mask read back as this lane's predicate (no vector instruction where the compiler has the builtin; the hipRTC that
+// ships inside a PyTorch wheel may be a release older than the hipcc the library was built with and lack it)
+__device__ __forceinline__ bool inverse_ballot64(unsigned long long m) {
+#if __has_builtin(__builtin_amdgcn_inverse_ballot_w64)
+    return __builtin_amdgcn_inverse_ballot_w64(m);
+#else
+    return ((m >> __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u))) & 1ull) != 0ull;
+#endif
 }
 
 // reference constants: simmodel.py:627-628 (nlist_rinv), :581 (safe_norm default)
@@ -119,6 +134,7 @@ __device__ __forceinline__ float group_sum(float v) {
     return v;
 }
 
+#ifndef __HIPCC_RTC__
 // compute units of the current device (host side; 256 on MI355X)
 inline int device_cu_count() {
     int dev = 0, n = 0;
@@ -127,6 +143,7 @@ inline int device_cu_count() {
         return 256;
     return n;
 }
+#endif
 
 // Streaming (nontemporal) 16/32-byte store for the pair-vector tensor.  The tensor is 268 MB per step
 // at C3 and is written once; with ordinary (write-back, allocating) stores it sweeps the L2 and the

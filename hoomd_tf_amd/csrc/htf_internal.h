@@ -23,6 +23,7 @@ struct PotParams {
     int own_f64;
 };
 
+#ifndef __HIPCC_RTC__ // (host-side dispatch declarations: nothing a generated unit needs)
 // HTF_POT_JIT (csrc/jit.hip): a code object built by hoomd_tf_amd/codegen.py from csrc/jit_unit.hip
 struct JitKernels;
 int jit_create(const void *image, size_t bytes, JitKernels **out);
@@ -87,5 +88,6 @@ int mlp_create(const htf_potential_desc *d, MlpDevice **out);
 void mlp_destroy(MlpDevice *m);
 int mlp_eval(const MlpDevice *m, const void *nlist, int in_dtype, unsigned B, unsigned NN, void *force,
              int force_dtype, void *virial9, hipStream_t stream);
+#endif // __HIPCC_RTC__
 
 } // namespace htf

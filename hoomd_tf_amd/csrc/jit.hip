@@ -1,11 +1,54 @@
 // HTF_POT_JIT: kernels generated at run time for a traced pair energy (hoomd_tf_amd/codegen.py -> csrc/jit_unit.hip ->
 // `hipcc --genco`): the code object is loaded with the HIP module API and its twelve kernels -- the instantiations of the library's
 // own row loops around the generated pair_eval body -- are launched with the arguments the built-in closed forms get.
+#include <dlfcn.h>
+#include <hip/hiprtc.h>
+
+#include <cstdlib>
+#include <mutex>
+#include <string>
+#include <vector>
+
 #include "box_math.h"
 #include "htf_common.h"
 #include "htf_internal.h"
 
 namespace htf {
+
+// libhiprtc, bound at run time like librccl in halo.hip: a box that never traces a model never loads it
+struct Rtc {
+    bool ok = false;
+    decltype(&hiprtcCreateProgram) Create = nullptr;
+    decltype(&hiprtcCompileProgram) Compile = nullptr;
+    decltype(&hiprtcGetProgramLogSize) LogSize = nullptr;
+    decltype(&hiprtcGetProgramLog) Log = nullptr;
+    decltype(&hiprtcGetCodeSize) CodeSize = nullptr;
+    decltype(&hiprtcGetCode) Code = nullptr;
+    decltype(&hiprtcDestroyProgram) Destroy = nullptr;
+    decltype(&hiprtcGetErrorString) ErrorString = nullptr;
+};
+
+static Rtc &rtc() {
+    static Rtc r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        void *h = nullptr;
+        if (const char *p = std::getenv("HTF_HIPRTC_LIB")) h = dlopen(p, RTLD_NOW | RTLD_GLOBAL);
+        for (const char *name : {"libhiprtc.so", "libhiprtc.so.7", "libhiprtc.so.6", "/opt/rocm/lib/libhiprtc.so"})
+            if (!h) h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return;
+        r.Create = (decltype(r.Create))dlsym(h, "hiprtcCreateProgram");
+        r.Compile = (decltype(r.Compile))dlsym(h, "hiprtcCompileProgram");
+        r.LogSize = (decltype(r.LogSize))dlsym(h, "hiprtcGetProgramLogSize");
+        r.Log = (decltype(r.Log))dlsym(h, "hiprtcGetProgramLog");
+        r.CodeSize = (decltype(r.CodeSize))dlsym(h, "hiprtcGetCodeSize");
+        r.Code = (decltype(r.Code))dlsym(h, "hiprtcGetCode");
+        r.Destroy = (decltype(r.Destroy))dlsym(h, "hiprtcDestroyProgram");
+        r.ErrorString = (decltype(r.ErrorString))dlsym(h, "hiprtcGetErrorString");
+        r.ok = r.Create && r.Compile && r.LogSize && r.Log && r.CodeSize && r.Code && r.Destroy;
+    });
+    return r;
+}
 
 struct JitKernels {
     hipModule_t mod = nullptr;
@@ -99,3 +142,62 @@ int jit_launch_eval(const PotParams &p, const void *nlist, int in_dtype, unsigne
 }
 
 } // namespace htf
+
+extern "C" int htf_jit_available(void) { return htf::rtc().ok ? 1 : 0; }
+
+extern "C" int htf_jit_compile(const char *unit_source, const char *arch, int n_headers, const char *const *header_names,
+                               const char *const *header_texts, int n_options, const char *const *options, void **image,
+                               size_t *image_bytes, char *log, size_t log_bytes) {
+    using namespace htf;
+    HTF_REQUIRE(unit_source && arch && image && image_bytes && n_headers >= 0 && n_options >= 0 && (n_headers == 0 || (header_names && header_texts)) &&
+                    (n_options == 0 || options),
+                "htf_jit_compile: null pointer");
+    if (log && log_bytes) log[0] = 0;
+    *image = nullptr;
+    *image_bytes = 0;
+    Rtc &r = rtc();
+    if (!r.ok) {
+        set_error("htf_jit_compile: libhiprtc could not be loaded (HTF_HIPRTC_LIB names it explicitly)");
+        return HTF_ERR_DEVICE;
+    }
+    hiprtcProgram prog = nullptr;
+    hiprtcResult rc = r.Create(&prog, unit_source, "jit_unit.hip", n_headers, const_cast<const char **>(header_texts),
+                               const_cast<const char **>(header_names));
+    if (rc != HIPRTC_SUCCESS) {
+        set_error("htf_jit_compile: hiprtcCreateProgram failed: %s", r.ErrorString ? r.ErrorString(rc) : "?");
+        return HTF_ERR_DEVICE;
+    }
+    std::vector<const char *> opts;
+    const std::string arch_opt = std::string("--offload-arch=") + arch;
+    opts.push_back(arch_opt.c_str());
+    for (int i = 0; i < n_options; ++i) opts.push_back(options[i]);
+    rc = r.Compile(prog, (int)opts.size(), opts.data());
+    size_t ls = 0;
+    if (log && log_bytes > 1 && r.LogSize(prog, &ls) == HIPRTC_SUCCESS && ls > 1) {
+        std::string text(ls, '\0');
+        if (r.Log(prog, &text[0]) == HIPRTC_SUCCESS) {
+            const size_t n = text.size() < log_bytes - 1 ? text.size() : log_bytes - 1;
+            std::memcpy(log, text.data(), n);
+            log[n] = 0;
+        }
+    }
+    if (rc != HIPRTC_SUCCESS) {
+        set_error("htf_jit_compile: hipRTC could not compile the generated unit: %s (see the log)", r.ErrorString ? r.ErrorString(rc) : "?");
+        r.Destroy(&prog);
+        return HTF_ERR_INVALID;
+    }
+    size_t cs = 0;
+    void *buf = nullptr;
+    if (r.CodeSize(prog, &cs) != HIPRTC_SUCCESS || cs == 0 || !(buf = std::malloc(cs)) || r.Code(prog, (char *)buf) != HIPRTC_SUCCESS) {
+        std::free(buf);
+        r.Destroy(&prog);
+        set_error("htf_jit_compile: no code object came back");
+        return HTF_ERR_DEVICE;
+    }
+    r.Destroy(&prog);
+    *image = buf;
+    *image_bytes = cs;
+    return HTF_OK;
+}
+
+extern "C" void htf_jit_free(void *image) { std::free(image); }

@@ -27,7 +27,7 @@ __host__ __device__ inline float sqrt_threshold(float c) {
         if (sqrtf(tp) >= c) t = tp; else break;
     }
     for (int i = 0; i < 8; ++i) {
-        if (sqrtf(t) < c) t = nextafterf(t, INFINITY); else break;
+        if (sqrtf(t) < c) t = nextafterf(t, __builtin_huge_valf()); else break;
     }
     return t;
 }

@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) void build_pair_vectors_kernel(
             DV out;
             out.x = (DT)dx; out.y = (DT)dy; out.z = (DT)dz;
             out.w = (DT)scalar_as_int(pk[r][t].w);
-            if (__builtin_amdgcn_inverse_ballot_w64(m)) store_stream(&row[q], out);
+            if (inverse_ballot64(m)) store_stream(&row[q], out);
         }
         if (Q > NN) { // overflow (an error upstream): build_row redoes the whole row, slot wrap included
             redo |= 1u << r;

@@ -64,6 +64,9 @@ void bind(py::module &m, const char *name, R (*fn)(A...)) {
     X(htf_build_pair_vectors) \
     X(htf_eval_forces) \
     X(htf_eval_forces_typed) \
+    X(htf_jit_available) \
+    X(htf_jit_compile) \
+    X(htf_jit_free) \
     X(htf_fused_forces) \
     X(htf_build_eval_forces) \
     X(htf_eval_forces2) \

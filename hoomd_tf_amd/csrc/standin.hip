@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256) void build_nlist_kernel(const typename Vec4<T>
                 // the group's G bits of the wave mask: rank and count from two population counts of a 32-bit word
                 const unsigned seg = (unsigned)(hits >> (G * sub)) & (G >= 32 ? ~0u : ((1u << G) - 1u));
                 const unsigned rank = count + (unsigned)__popc(seg & ((1u << g) - 1u));
-                if (__builtin_amdgcn_inverse_ballot_w64(hits) && rank < pitch) row[rank] = k;
+                if (inverse_ballot64(hits) && rank < pitch) row[rank] = k;
                 count += (unsigned)__popc(seg);
             }
         }
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(256) void build_nlist_cells_kernel(const typename V
                     hits &= ballot64(((tag ^ tag_p[p]) & kTagSide) == 0u);
                 }
                 const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(hits >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hits, count[p]));
-                if (__builtin_amdgcn_inverse_ballot_w64(hits) && rank < pitch) nlist[row_p[p] + rank] = k;
+                if (inverse_ballot64(hits) && rank < pitch) nlist[row_p[p] + rank] = k;
                 count[p] += (unsigned)__builtin_popcountll(hits);
             }
         }

@@ -19,8 +19,10 @@
 #ifndef HTF_AMD_H_
 #define HTF_AMD_H_
 
+#ifndef __HIPCC_RTC__ /* (a generated unit compiled by hipRTC: the basic types are built in, there are no system headers) */
 #include <stddef.h>
 #include <stdint.h>
+#endif
 
 #ifdef __cplusplus
 extern "C" {
@@ -84,7 +86,7 @@ enum htf_potential_kind {
                             * Dense(1) = E_i.  desc.K = top_neighs (<= 16), H1, H2 <= 64, weights as for PAIR_MLP */
     HTF_POT_JIT = 9        /* round 5: an elementwise pair energy e(rinv, r) the caller TRACED from model code (htf/simmodel.py:87-121: any
                             * compute() is legal upstream) and compiled for gfx950 -- hoomd_tf_amd/codegen.py emits the body of
-                            * pair_math.h's pair_eval_f<HTF_POT_JIT> (energy + d/dr, forward-mode), `hipcc --genco` builds the
+                            * pair_math.h's pair_eval_f<HTF_POT_JIT> (energy + d/dr, forward-mode), htf_jit_compile (hipRTC) or `hipcc --genco` builds the
                             * kernels of csrc/jit_unit.hip around it, desc.jit_image hands the code object over.  Same row loops,
                             * same launch geometry as the built-in closed forms; no second backend. */
 };
@@ -289,6 +291,18 @@ HTF_API int htf_optimizer_step_n(float *d_theta, unsigned P, const float *d_accu
  * synchronising -- i.e. the error (HTF_ERR_ARG, "left fp16's range") surfaces one call late, after a step that ran on saturated
  * images.  Every refresh judges the range afresh: repair d_theta, refresh, and the potential is usable again. */
 HTF_API int htf_potential_refresh(htf_potential *pot, htf_stream stream);
+
+/* HTF_POT_JIT: the run-time compiler for a generated unit.  hipRTC (libhiprtc, bound with dlopen when first asked for) compiles
+ * `unit_source` -- csrc/jit_unit.hip's text -- for `arch` ("gfx950") with the headers it includes handed over BY TEXT (name as
+ * written in the #include, content): the library's own kernels' sources and the generated body; no compiler driver, no temporary
+ * files, no GPU needed.  On success *image / *image_bytes hold the code object (htf_jit_free releases it) for
+ * htf_potential_desc.jit_image.  `log` (nullable) receives the compiler's diagnostics, truncated to log_bytes.
+ * htf_jit_available() = 1 when libhiprtc could be loaded (HTF_HIPRTC_LIB names it explicitly). */
+HTF_API int htf_jit_available(void);
+HTF_API int htf_jit_compile(const char *unit_source, const char *arch, int n_headers, const char *const *header_names,
+                            const char *const *header_texts, int n_options, const char *const *options,
+                            void **image, size_t *image_bytes, char *log, size_t log_bytes);
+HTF_API void htf_jit_free(void *image);
 
 
 /* Replaces htf_gpu_add_virial (TensorflowCompute.cu:41-71; CPU .cc:284-301):

@@ -107,9 +107,16 @@ def test_an_energy_that_does_not_vanish_on_padding_keeps_the_torch_route():
     np.testing.assert_allclose(f[:, 3].detach().numpy(), en.detach().numpy(), rtol=1e-12)
 
 
-def test_generated_unit_cross_compiles_for_gfx950():
+@pytest.mark.parametrize("how", ["hiprtc", "hipcc"])
+def test_generated_unit_cross_compiles_for_gfx950(how, monkeypatch):
+    """Both run-time compilers, no GPU needed: hipRTC in process through the library's own htf_jit_compile (sources handed over as
+    text; the default when libhiprtc loads) and `hipcc --genco` as a subprocess."""
     import hoomd_tf_amd as htf
-    from hoomd_tf_amd import codegen as cg
+    from hoomd_tf_amd import _lib, codegen as cg
+    if how == "hiprtc" and not _lib._ctypes_lib.htf_jit_available():
+        pytest.skip("libhiprtc not loadable")
+    monkeypatch.setenv("HTF_JIT_COMPILER", how)
+    assert cg.compiler() == how
     x = htf.Nlist(torch.zeros((2, 4, 4)))
     e = _models(htf, x)["yukawa"]
     image, key = cg.compile_body(e.body())
