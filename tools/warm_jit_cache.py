@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Compile, into hoomd_tf_amd/_jit_cache, the generated units the test suite and bench.py's generic-lj line use -- no GPU needed
+(hipRTC or hipcc cross-compile for gfx950): a GPU box that receives the tree then loads them from the cache instead of spending
+~4 s per expression.  Called by __graft_entry__.build() (best effort); the cache key covers the body, every kernel source and the
+compiler, so a stale entry is simply never hit."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import hoomd_tf_amd as htf  # noqa: E402
+from hoomd_tf_amd import codegen as cg  # noqa: E402
+from hoomd_tf_amd.simmodel import PositionsInput  # noqa: E402
+
+
+def bodies():
+    from test_codegen_cpu import _models, _random_expression, _typed_models
+    x = htf.Nlist(torch.zeros((2, 4, 4)))
+    P = PositionsInput.wrap(torch.zeros((2, 4)))
+    out = [e.body() for e in _models(htf, x).values()]
+    out += [e.body() for e in _typed_models(htf, x, P, 3, big=True).values()]
+    s, r = htf.nlist_rinv(x), htf.safe_norm(x[:, :, :3], axis=2)
+    # bench.py --workload generic-lj: Morse, LJ + Yukawa, the Kob-Andersen mixture
+    live = htf.cast(s > 0.0, torch.float32)
+    m = 1.0 - htf.exp(-5.0 * (r - 1.122))
+    out.append(htf.reduce_sum(0.5 * live * (m * m - 1.0), axis=1).body())
+    out.append(htf.reduce_sum(2.0 * (s ** 12 - s ** 6) + 0.25 * htf.exp(-1.0 * r) * s, axis=1).body())
+    idx = htf.cast(P[:, 3], torch.int32)[:, None] * 2 + htf.cast(x[:, :, 3], torch.int32)
+    q = (htf.gather([1.0, 0.8, 0.8, 0.88], idx) * s) ** 6
+    out.append(htf.reduce_sum(2.0 * htf.gather([1.0, 1.5, 1.5, 0.5], idx) * (q * q - q), axis=1).body())
+    # tests/test_gpu_codegen.py: the three-species mixture of test_typed_model_is_replayed..., the random trees
+    rng = np.random.default_rng(7)
+    eps = rng.uniform(0.6, 1.4, (3, 3))
+    eps = 0.5 * (eps + eps.T)
+    sig = rng.uniform(0.85, 1.0, (3, 3))
+    sig = 0.5 * (sig + sig.T)
+    idx3 = htf.cast(P[:, 3], torch.int32)[:, None] * 3 + htf.cast(x[:, :, 3], torch.int32)
+    q = (htf.gather(sig.reshape(-1), idx3) * s) ** 6
+    out.append(htf.reduce_sum(2.0 * htf.gather(eps.reshape(-1), idx3) * (q * q - q), axis=1).body())
+    return out
+
+
+def main():
+    t0, n, hit = time.time(), 0, 0
+    for b in dict.fromkeys(bodies()):
+        path = os.path.join(cg._cache_dir(), cg._key(b) + ".hsaco")
+        hit += os.path.exists(path)
+        cg.compile_body(b)
+        n += 1
+    print("warm_jit_cache: %d units (%d already cached) with %s in %.0f s" % (n, hit, cg.compiler(), time.time() - t0))
+
+
+if __name__ == "__main__":
+    main()
