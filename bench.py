@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--grid", default=None, help="rank grid PXxPYx1: --gpus N > 1: how the box is cut (default: slabs along x; e.g. 4x2x1 "
                                                  "for 8 ranks); dd-self: the grid whose one brick this GPU runs (default 8x1x1)")
     ap.add_argument("--transport", default="all", help="dd-self: local | peer | native | all")
+    ap.add_argument("--replan-every", type=int, default=1, help="dd-self: BrickDomain(replan_every=k): only every k-th rebuild migrates and re-plans")
     ap.add_argument("--train-period", type=int, default=100, help="mlp-train (C5b): force-matching step every this many MD steps")
     ap.add_argument("--cells", type=int, default=32, help="fcc cells per side (N = 4 cells^3 per rank)")
     ap.add_argument("--lattice", default="fcc", choices=["fcc", "sc"], help="fcc: N = 4 cells^3 (C3, C5); sc: N = cells^3 (C2 = sc 32^3 = 32768)")
@@ -337,7 +338,8 @@ def run_dd_self(args, htf, standin, dev):
         sysm = standin.System(pos, Lg, dtype=torch.float32, device=dev)
         sysm.randomize_velocities(kT=1.0, seed=3)
         nl = standin.CellNlist(sysm, r_cut=args.rcut, r_buff=args.rbuff, check_period=P, device_decision=True)
-        dom = nl.domain = BrickDomain(sysm, 0, grid, r_ghost=args.rcut + args.rbuff, r_buff=args.rbuff, replica=True, transport=transport)
+        dom = nl.domain = BrickDomain(sysm, 0, grid, r_ghost=args.rcut + args.rbuff, r_buff=args.rbuff, replica=True, transport=transport,
+                                      replan_every=args.replan_every)
         nl.build()
         ctx = htf.Context(r_cut=args.rcut, nneighs=args.nn, scalar_dtype=torch.float32, max_n=sysm.N, check_nlist=False, fused=2)
         ctx.set_potential(htf.Potential.lj())
@@ -380,7 +382,8 @@ def run_dd_self(args, htf, standin, dev):
         rec.update({"energy_per_particle": e, "kT": float((v3 * v3).sum() / (3.0 * n_rank)), "dangerous_builds": run.dangerous_builds,
                     "particles": int(len(live)), "interior_particles": int(c[_lib.BC_N_INT]), "ghosts": dom.n_ghosts,
                     "rows": sysm.N, "interior_rows": dom.cap_int, "ghost_rows": sysm.n_ghost, "messages_per_halo": dom.n_msg,
-                    "halo_bytes_per_step": dom.n_ghost_cap * 16, "migrated": dom.n_migrated})
+                    "halo_bytes_per_step": dom.n_ghost_cap * 16, "migrated": dom.n_migrated,
+                    "replan_every": dom.replan_every, "rebuilds_without_a_replan": dom.n_light})
         if os.environ.get("HTF_DD_PHASES") == "1" and run._graphs is not None:
             # where a replayed cycle's time goes, without a profiler in the way: each of the two graphs replayed alone, back to
             # back, nothing read in between (the trajectory is garbage afterwards: this is the last thing done with the system)

@@ -203,7 +203,7 @@ STANDIN_PROTOTYPES = {
     "htfs_rebuild_nlist": (_i, [_vp, _i, _u, C.POINTER(Box), _d, C.POINTER(_i * 3), C.POINTER(_i * 3), _vp, _vp, _vp, _vp, _vp, _u, _i,
                                 _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "htfs_rebuild_nlist_ghosts": (_i, [_vp, _i, _u, _u, C.POINTER(Box), _d, C.POINTER(_i * 3), C.POINTER(_i * 3), _vp, _vp, _vp, _vp, _vp, _u, _i,
-                                       _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+                                       _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "htfs_check_rebuild_nlist": (_i, [_vp, _i, _u, C.POINTER(Box), _d, C.POINTER(_i * 3), C.POINTER(_i * 3), _vp, _vp, _vp, _vp, _vp, _u, _i,
                                       _vp, _vp, _vp, _vp, _vp, _vp, _d, _vp, _vp, _vp]),
 }

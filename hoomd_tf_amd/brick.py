@@ -52,7 +52,7 @@ class BrickDomain:
     fixed_capacity = True
 
     def __init__(self, system, rank, grid, r_ghost, r_buff=0.4, fractions=None, group=None, transport="torch", replica=False,
-                 coords=None, n_global=None, margin=1.25, backend="auto", local_grid=None):
+                 coords=None, n_global=None, margin=1.25, backend="auto", local_grid=None, replan_every=1):
         """``grid``: (px, py, pz) ranks per box axis, pz = 1 (at most two decomposed axes).  ``fractions``: per axis, the interior
         cut fractions (``comm.decomposition(x=[0.33])`` style) or None for even cuts.  ``replica``: this one rank is every brick
         of ``grid`` (see the module docstring); ``coords``: its brick coordinate then (default: the middle one).
@@ -63,7 +63,12 @@ class BrickDomain:
         periodic boundary is shifted by the box vector, as HOOMD wraps its ghosts -- so the neighbor list can be binned on a
         cell grid of the brick + ghost layer alone (``nlist_box()``), not of the whole box: at 8 ranks 7/8 of the global grid's
         cells are empty on any one rank, and under weak scaling the global grid grows with the rank count.  Off: ghosts keep
-        their owner's coordinates (SlabDomain's convention; the neighbor ORDER then equals SlabDomain's, bit for bit)."""
+        their owner's coordinates (SlabDomain's convention; the neighbor ORDER then equals SlabDomain's, bit for bit).
+        ``replan_every`` = k > 1: only every k-th rebuild() migrates and re-plans; the others leave rows, classes and messages as
+        they are and only refresh the halo -- the list above them is rebuilt on positions that have drifted for up to k periods
+        since the plan, so the ghost layer is (k - 1) r_buff thicker than ``r_ghost`` (a pair within the list radius at any of
+        those rebuilds had its ghost within r_ghost + (k - 1) r_buff of the face when the plan was made: each side moves at most
+        r_buff / 2 per period) and the local cell grid (k - 1) r_buff wider on each side."""
         s = self.sys = system
         self.rank = int(rank)
         self.replica = bool(replica)
@@ -79,8 +84,15 @@ class BrickDomain:
         self.world = 1 if self.replica else int(np.prod(grid))
         if not self.replica and not 0 <= self.rank < self.world:
             raise ValueError("rank %d outside the %r grid" % (self.rank, grid))
-        self.r_ghost = float(r_ghost)
+        self.replan_every = int(replan_every)
+        if self.replan_every < 1:
+            raise ValueError("replan_every must be >= 1")
         self.r_buff = float(r_buff)
+        self.r_plan = float(r_ghost)                                          # what the caller asked for: the list radius
+        self.r_ghost = float(r_ghost) + (self.replan_every - 1) * self.r_buff   # what the plan uses
+        self._rebuild_index = 0      # rebuild() calls so far; call i re-plans when i % replan_every == 0
+        self._next_light = None      # BrickRun, while capturing: force the kind of the next rebuild (True / False)
+        self.n_light = 0
         lo, hi = np.asarray(s.box3x3[0], dtype=np.float64), np.asarray(s.box3x3[1], dtype=np.float64)
         self.L = hi - lo
         if self.replica:
@@ -141,7 +153,7 @@ class BrickDomain:
             for k, d in enumerate(self.axes):
                 if o[k] != 0:
                     ext[d] = min(self.r_ghost, wmax[d])
-                    face[d] = min(self.r_buff, wmax[d])   # what can cross a face between two rebuilds (< r_buff / 2 each way)
+                    face[d] = min(self.r_buff * self.replan_every, wmax[d])   # what can cross a face between two PLANS (< r_buff / 2 each way and period)
             ghost_cap.append(room(rho * float(np.prod(ext))))
             mig_cap.append(1 + room(rho * float(np.prod(face))))
         self.ghost_cap = ghost_cap
@@ -251,9 +263,14 @@ class BrickDomain:
         b = np.array(self.sys.box3x3, dtype=np.float64)
         per = list(self.sys.periodic)
         for d in self.axes:
-            b[0][d], b[1][d] = self.lo[d] - self.r_ghost, self.hi[d] + self.r_ghost
+            pad = (self.replan_every - 1) * self.r_buff   # (rows and ghosts drift between plans: the grid must still hold them)
+            b[0][d], b[1][d] = self.lo[d] - self.r_ghost - pad, self.hi[d] + self.r_ghost + pad
             per[d] = 0
         return b, tuple(per)
+
+    def image_lengths(self):
+        """With a local grid: the logical box length along every decomposed axis (the period of the coordinates there), else zeros."""
+        return tuple(float(self.L[d]) if (self.local_grid and d in self.axes) else 0.0 for d in range(3))
 
     def _msg_takes_class(self, m, c):
         for k in range(self.ndim):
@@ -456,6 +473,14 @@ class BrickDomain:
         """Communicator::migrateParticles + exchangeGhosts: call before every neighbor-list build."""
         s = self.sys
         capturing = getattr(self, "_capturing", False)   # inside a hipGraph capture (standin.BrickRun): no host-side waits
+        light = self._next_light if self._next_light is not None else (self._rebuild_index % self.replan_every != 0)
+        self._rebuild_index += 1
+        if light:
+            # rows, classes and messages as the last plan left them; only this step's halo (the list is rebuilt by the caller)
+            self.n_rebuilds += 1
+            self.n_light += 1
+            self.exchange()
+            return
         if self.kernels:
             if not capturing:
                 self.poll_flags()

@@ -516,10 +516,22 @@ namespace htf {
 // position copy and the new reference positions + rebuild counter (the blocks behind them) -- three kernels of a rebuild that
 // depend on the sort but not on each other.  Each of the small kernels of a rebuild costs its launch, the read of the gate and
 // two or three dependent round trips to memory (7-11 us apiece at C3), whatever little it computes.
+// Binning on a grid that is NOT periodic along an axis the caller's coordinates are (a decomposed system's brick + ghost layer,
+// htfs_rebuild_nlist_ghosts' image_L): along such an axis a coordinate is first moved to its image nearest the grid's centre -- a
+// row that left the brick through a face on the logical box's boundary has been wrapped to the far side by the integrator, a ghost
+// of such a row arrives a box length away -- for the cell index AND for the sorted copy the search measures plain differences on.
+struct Reimage {
+    double L[3], c[3]; // L = 0: the axis as it is
+};
+template <typename T>
+__device__ __forceinline__ T reimage1(T x, double L, double c) {
+    return L > 0.0 ? (T)((double)x - L * rint(((double)x - c) / L)) : x;
+}
+
 template <typename V>
 __global__ __launch_bounds__(256) void bins_finish_kernel(RangesArgs ra, unsigned nb_ranges, V *__restrict__ dest, const V *__restrict__ src,
                                                           const int *__restrict__ order, unsigned n, int type_split, V *__restrict__ ref,
-                                                          unsigned n_ref, unsigned *__restrict__ counter, Gate gate) {
+                                                          unsigned n_ref, unsigned *__restrict__ counter, Reimage im, Gate gate) {
     if (gate.closed()) return;
     if (blockIdx.x < nb_ranges) {
         cell_ranges_body(blockIdx.x * blockDim.x + threadIdx.x, ra);
@@ -531,6 +543,9 @@ __global__ __launch_bounds__(256) void bins_finish_kernel(RangesArgs ra, unsigne
     const unsigned k = (unsigned)order[i];
     V p = src[k];
     if (ref != nullptr && k < n_ref) ref[k] = p; // (order is a permutation: every reference position is written once)
+    p.x = reimage1(p.x, im.L[0], im.c[0]);
+    p.y = reimage1(p.y, im.L[1], im.c[1]);
+    p.z = reimage1(p.z, im.L[2], im.c[2]);
     set_tag(p.w, k | ((type_split >= 0 && scalar_as_int(p.w) >= type_split) ? kTagSide : 0u));
     dest[i] = p;
 }
@@ -539,7 +554,7 @@ __global__ __launch_bounds__(256) void bins_finish_kernel(RangesArgs ra, unsigne
 template <typename T>
 __global__ __launch_bounds__(256) void cell_index_count_kernel(const typename Vec4<T>::type *__restrict__ pos, unsigned Ntot, SBox<T> b,
                                                                int nx, int ny, int nz, unsigned *__restrict__ cell_of,
-                                                               unsigned *__restrict__ count, Gate gate) {
+                                                               unsigned *__restrict__ count, Reimage im, Gate gate) {
     if (gate.closed()) return;
     unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= Ntot) return;
@@ -548,9 +563,9 @@ __global__ __launch_bounds__(256) void cell_index_count_kernel(const typename Ve
         cell_of[i] = kDeadCell;
         return;
     }
-    int cx = cell_coord<T>(p.x, b.lo[0], b.Linv[0], nx);
-    int cy = cell_coord<T>(p.y, b.lo[1], b.Linv[1], ny);
-    int cz = cell_coord<T>(p.z, b.lo[2], b.Linv[2], nz);
+    int cx = cell_coord<T>(reimage1(p.x, im.L[0], im.c[0]), b.lo[0], b.Linv[0], nx);
+    int cy = cell_coord<T>(reimage1(p.y, im.L[1], im.c[1]), b.lo[1], b.Linv[1], ny);
+    int cz = cell_coord<T>(reimage1(p.z, im.L[2], im.c[2]), b.lo[2], b.Linv[2], nz);
     const unsigned c = (unsigned)((cz * ny + cy) * nx + cx);
     cell_of[i] = c;
     atomicAdd(&count[c], 1u);
@@ -854,6 +869,7 @@ struct FinishArgs {
     void *ref;              // <- pos (nullable)
     unsigned n_ref;
     unsigned *counter;      // += 1 (nullable)
+    htf::Reimage im;
 };
 
 static int build_nlist_impl(const void *d_pos, const void *d_pos_sorted, int dtype, unsigned N, unsigned Ntot,
@@ -888,10 +904,10 @@ static int build_nlist_impl(const void *d_pos, const void *d_pos_sorted, int dty
         const unsigned nb = nb_ranges + (fin->n + 255) / 256 + (fin->n == 0 ? 1u : 0u);
         if (dtype == HTF_F32)
             hipLaunchKernelGGL((bins_finish_kernel<float4>), dim3(nb), dim3(256), 0, (hipStream_t)stream, ra, nb_ranges, (float4 *)fin->pos_sorted,
-                               (const float4 *)d_pos, fin->order, fin->n, type_split, (float4 *)fin->ref, fin->n_ref, fin->counter, g_gate);
+                               (const float4 *)d_pos, fin->order, fin->n, type_split, (float4 *)fin->ref, fin->n_ref, fin->counter, fin->im, g_gate);
         else
             hipLaunchKernelGGL((bins_finish_kernel<double4>), dim3(nb), dim3(256), 0, (hipStream_t)stream, ra, nb_ranges, (double4 *)fin->pos_sorted,
-                               (const double4 *)d_pos, fin->order, fin->n, type_split, (double4 *)fin->ref, fin->n_ref, fin->counter, g_gate);
+                               (const double4 *)d_pos, fin->order, fin->n, type_split, (double4 *)fin->ref, fin->n_ref, fin->counter, fin->im, g_gate);
     }
     const bool fine = stencil3[0] == 2 || stencil3[1] == 2 || stencil3[2] == 2; // short ranges: 8-lane groups waste fewer lanes
 #define HTFS_NL(T, V4, G)                                                                                              \
@@ -918,7 +934,9 @@ static int build_nlist_impl(const void *d_pos, const void *d_pos_sorted, int dty
 #else
     constexpr bool per_particle = false, per_cell = false;
 #endif
-    const bool by_cell = per_cell || (!per_particle && ncell >= 1024u);
+    // (re-imaged coordinates exist in the sorted copy only: the walk per particle reads the particle's own position from d_pos)
+    const bool reimaged = fin != nullptr && (fin->im.L[0] > 0.0 || fin->im.L[1] > 0.0 || fin->im.L[2] > 0.0);
+    const bool by_cell = per_cell || reimaged || (!per_particle && ncell >= 1024u);
     // two waves per cell on grids of up to 12 288 cells (a brick + its ghost layer at 16 k rows per rank: 7.7 k; C2: 8 k); the 30 k cells of C3 fill the chip as they are
     const unsigned cell_split = ncell <= 12288u ? 2u : 1u;
     if (by_cell) {
@@ -952,7 +970,8 @@ static int rebuild_nlist_impl(const void *d_pos, int dtype, unsigned N, unsigned
                               const int *stencil3, unsigned *d_cell_of, unsigned *d_scratch, unsigned *d_cell_start,
                               unsigned *d_order, void *d_pos_sorted, unsigned pitch, int type_split, unsigned *d_n_neigh,
                               unsigned *d_head_list, unsigned *d_nlist, unsigned *d_max_neigh, void *d_ref,
-                              unsigned *d_counter, void *d_ranges, htf_stream stream, bool scratch_clean = false) {
+                              unsigned *d_counter, void *d_ranges, htf_stream stream, bool scratch_clean = false,
+                              const double *image_L = nullptr) {
     using namespace htf;
     HTF_REQUIRE(d_pos && box && ncell3 && stencil3 && d_cell_of && d_scratch && d_cell_start && d_order && d_pos_sorted,
                 "htfs_rebuild_nlist: null pointer");
@@ -965,16 +984,22 @@ static int rebuild_nlist_impl(const void *d_pos, int dtype, unsigned N, unsigned
     if (!scratch_clean)
         if (int rc = zero_counts_if_needed(count, ncell, s)) return rc; // (as htfs_cell_sort)
     const unsigned grid = (Ntot + 255) / 256;
+    Reimage im = {};
+    for (int d = 0; d < 3; ++d) {
+        im.L[d] = image_L != nullptr && !box->periodic[d] ? image_L[d] : 0.0;
+        im.c[d] = 0.5 * (box->lo[d] + box->hi[d]);
+        HTF_REQUIRE(im.L[d] == 0.0 || im.L[d] >= box->hi[d] - box->lo[d], "htfs_rebuild_nlist_ghosts: image length %g along axis %d is shorter than the grid", im.L[d], d);
+    }
     if (dtype == HTF_F32)
         hipLaunchKernelGGL((cell_index_count_kernel<float>), dim3(grid), dim3(256), 0, s, (const float4 *)d_pos, Ntot, make_sbox<float>(box),
-                           ncell3[0], ncell3[1], ncell3[2], d_cell_of, count, g_gate);
+                           ncell3[0], ncell3[1], ncell3[2], d_cell_of, count, im, g_gate);
     else
         hipLaunchKernelGGL((cell_index_count_kernel<double>), dim3(grid), dim3(256), 0, s, (const double4 *)d_pos, Ntot, make_sbox<double>(box),
-                           ncell3[0], ncell3[1], ncell3[2], d_cell_of, count, g_gate);
+                           ncell3[0], ncell3[1], ncell3[2], d_cell_of, count, im, g_gate);
     hipLaunchKernelGGL(cell_scan_kernel, dim3((ncell + kScanChunk - 1) / kScanChunk), dim3(kScanThreads), 0, s, count, ncell, d_cell_start, cursor, g_gate);
     hipLaunchKernelGGL(cell_scatter_kernel, dim3(grid), dim3(256), 0, s, d_cell_of, Ntot, cursor, d_order, g_gate);
     hipLaunchKernelGGL(cell_order_kernel, dim3((ncell + 255) / 256), dim3(256), 0, s, d_cell_start, ncell, d_order, count, g_gate);
-    const FinishArgs fin = {d_pos_sorted, (const int *)d_order, Ntot, d_ref, N, d_counter};
+    const FinishArgs fin = {d_pos_sorted, (const int *)d_order, Ntot, d_ref, N, d_counter, im};
     return build_nlist_impl(d_pos, d_pos_sorted, dtype, N, Ntot, box, r_list, ncell3, stencil3, d_cell_start, pitch, type_split, d_n_neigh,
                             d_head_list, d_nlist, d_max_neigh, d_ranges, stream, &fin);
 }
@@ -994,10 +1019,10 @@ extern "C" int htfs_rebuild_nlist_ghosts(const void *d_pos, int dtype, unsigned 
                                          const int *ncell3, const int *stencil3, unsigned *d_cell_of, unsigned *d_scratch,
                                          unsigned *d_cell_start, unsigned *d_order, void *d_pos_sorted, unsigned pitch, int type_split,
                                          unsigned *d_n_neigh, unsigned *d_head_list, unsigned *d_nlist, unsigned *d_max_neigh, void *d_ref,
-                                         unsigned *d_counter, void *d_ranges, int scratch_clean, htf_stream stream) {
+                                         unsigned *d_counter, void *d_ranges, int scratch_clean, const double *image_L, htf_stream stream) {
     return rebuild_nlist_impl(d_pos, dtype, N, Ntot, box, r_list, ncell3, stencil3, d_cell_of, d_scratch, d_cell_start, d_order, d_pos_sorted,
                               pitch, type_split, d_n_neigh, d_head_list, d_nlist, d_max_neigh, d_ref, d_counter, d_ranges, stream,
-                              scratch_clean != 0);
+                              scratch_clean != 0, image_L);
 }
 
 // A whole check step of a device-decided list in ONE call (the host's share of a small system's step is its enqueue): the

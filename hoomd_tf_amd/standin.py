@@ -203,6 +203,18 @@ class CellNlist:
                 n[d], w[d] = coarse, 1
         return n, w
 
+    def _image_lengths(self):
+        """The period of the coordinates along the axes the domain's local grid is not periodic on (htfs_rebuild_nlist_ghosts'
+        image_L), or None."""
+        fn = getattr(self.domain, "image_lengths", None)
+        if fn is None:
+            return None
+        key = fn()
+        if getattr(self, "_image_key", None) != key:
+            self._image_key = key
+            self._image_arr = (C.c_double * 3)(*key) if any(key) else None
+        return self._image_arr
+
     def _search_box(self):
         """(box3x3, periodic) the list is binned and searched on: the system's box, or -- under a BrickDomain with a local cell
         grid -- the brick + its ghost layer, not periodic along the decomposed axes (brick.BrickDomain.nlist_box)."""
@@ -250,7 +262,7 @@ class CellNlist:
                                                 cell_of.data_ptr(), self._bin_scratch.data_ptr(), cell_start.data_ptr(), order.data_ptr(),
                                                 pos_sorted.data_ptr(), self.pitch, int(self.type_split), self.n_neigh.data_ptr(),
                                                 self.head_list.data_ptr(), self.nlist.data_ptr(), self._max.data_ptr(), self._ref.data_ptr(),
-                                                None, self._ranges.data_ptr(), int(clean), stream))
+                                                None, self._ranges.data_ptr(), int(clean), self._image_lengths(), stream))
             self._scratch_clean = (self._bin_scratch.data_ptr(), ncell)
             if getattr(self, "_max_host", None) is None:
                 self._max_host = torch.zeros(1, dtype=torch.int32).pin_memory()
@@ -814,7 +826,12 @@ class BrickRun:
         s, nl, P = self.sys, self.nl, self.nl.check_period
         self._check_kernels()
         if rebuild:
-            nl.build()               # BrickDomain.rebuild (migration, classes, plan, halo) + the list
+            # (capture: the kind of rebuild this graph holds is named, not taken from the domain's counter)
+            self.dom._next_light = (rebuild == "light") if getattr(self.dom, "_capturing", False) else None
+            try:
+                nl.build()           # BrickDomain.rebuild (migration, classes, plan, halo -- or the halo alone) + the list
+            finally:
+                self.dom._next_light = None
         for i in range(P):
             if not (rebuild and i == 0):
                 self.dom.exchange_begin()
@@ -851,9 +868,12 @@ class BrickRun:
         torch.cuda.synchronize()
         graphs = {}
         ts0, builds0, rebuilds0 = s.timestep, nl.n_builds, dom.n_rebuilds
+        index0, light0 = dom._rebuild_index, dom.n_light
         nl._capturing = dom._capturing = True
         try:
-            for rebuild in (False, True):
+            # A = [check, P steps]; B = [check, migrate + re-plan + list rebuild, P steps]; with BrickDomain(replan_every > 1) also
+            # "light" = [check, list rebuild on the rows and messages as they are, P steps]
+            for rebuild in ((False, True, "light") if dom.replan_every > 1 else (False, True)):
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     self._cycle(rebuild)
@@ -862,6 +882,7 @@ class BrickRun:
         finally:
             nl._capturing = dom._capturing = False
             s.timestep, nl.n_builds, dom.n_rebuilds = ts0, builds0, rebuilds0
+            dom._rebuild_index, dom.n_light = index0, light0
             nl._step_done = None
         self._graphs = graphs
         self._launched = 0          # cycle number of the last launched graph (the device counter counts from 1)
@@ -918,6 +939,11 @@ class BrickRun:
                 self._rebuilt_at.append(s.timestep)
                 self.nl.n_builds += 1
                 self.dom.n_rebuilds += 1
+                # which rebuild: the domain's own rule (every replan_every-th re-plans), kept in step with the eager path
+                if self.dom._rebuild_index % self.dom.replan_every != 0:
+                    rebuild = "light"
+                    self.dom.n_light += 1
+                self.dom._rebuild_index += 1
             self._graphs[rebuild].replay()
             self._launched += 1
             self.n_cycles += 1

@@ -105,12 +105,16 @@ HTF_API int htfs_rebuild_nlist(const void *d_pos, int dtype, unsigned N, const h
 /* the same with ghosts (and inert rows): Ntot >= N positions are binned, the N local rows searched and committed.
  * scratch_clean != 0: the caller guarantees that the first ncell words of d_scratch are zero -- they are after any COMPLETED
  * htfs_cell_sort / htfs_rebuild_nlist* call on this scratch with the same ncell, as long as nothing else has written the buffer --
- * and the call skips its memset (two dependent nodes of a captured rebuild). */
+ * and the call skips its memset (two dependent nodes of a captured rebuild).
+ * image_L (nullable, 3 doubles on the host; 0 = leave the axis alone): along an axis the grid is NOT periodic on, the period the
+ * caller's coordinates have -- the logical box length of a decomposed system -- so that a coordinate is binned, and copied into
+ * d_pos_sorted, as its image nearest the grid's centre (a row that left the brick through a face on the box boundary was wrapped
+ * to the far side by the integrator; the search measures plain differences along such an axis). */
 HTF_API int htfs_rebuild_nlist_ghosts(const void *d_pos, int dtype, unsigned N, unsigned Ntot, const htf_box *box, double r_list,
                                       const int *ncell3, const int *stencil3, unsigned *d_cell_of, unsigned *d_scratch,
                                       unsigned *d_cell_start, unsigned *d_order, void *d_pos_sorted, unsigned pitch, int type_split,
                                       unsigned *d_n_neigh, unsigned *d_head_list, unsigned *d_nlist, unsigned *d_max_neigh, void *d_ref,
-                                      unsigned *d_counter, void *d_ranges, int scratch_clean, htf_stream stream);
+                                      unsigned *d_counter, void *d_ranges, int scratch_clean, const double *image_L, htf_stream stream);
 
 /* One check step of a device-decided list in one call: *d_disp2 <- 0, htfs_max_displacement2 into it, htfs_set_gate(d_disp2,
  * threshold2), htfs_rebuild_nlist (d_stat2[0] = largest row, d_stat2[1] = rebuild counter), htfs_set_gate(NULL, 0), and -- if

@@ -94,14 +94,17 @@ def test_brick_kernels_match_torch(htf, cuda, grid, dtype):
 
 
 @pytest.mark.parametrize("local_grid", [True, False])
-@pytest.mark.parametrize("grid,transport", [((8, 1, 1), "local"), ((4, 2, 1), "local"), ((8, 1, 1), "native"), ((4, 2, 1), "native"),
-                                            ((8, 1, 1), "peer"), ((4, 2, 1), "peer")])
-def test_replica_brick_forces_equal_the_replicated_box(htf, cuda, grid, transport, local_grid):
+@pytest.mark.parametrize("grid,transport,replan", [((8, 1, 1), "local", 1), ((4, 2, 1), "local", 1), ((8, 1, 1), "native", 1), ((4, 2, 1), "native", 1),
+                                                   ((8, 1, 1), "peer", 1), ((4, 2, 1), "peer", 1), ((8, 1, 1), "local", 2), ((4, 2, 1), "local", 2),
+                                                   ((4, 2, 1), "peer", 2), ((8, 1, 1), "local", 3)])
+def test_replica_brick_forces_equal_the_replicated_box(htf, cuda, grid, transport, local_grid, replan):
     """Replica mode is a physical system -- the brick repeated grid times: forces of the one rank's rows (interior rows while the
     halo is in flight, boundary rows behind it) == the single-domain forces of the replicated box, through an MD run with
     migration (particles leave through a face and re-enter through the opposite one).  ``native``: the halo and the migration
     messages travel through RCCL (this rank sending to itself), csrc/halo.hip's grouped exchange.  ``peer``: the packing kernel
-    stores the rows into the receiver's inbox and signals, the unpack kernel waits for the signal -- no library in the step."""
+    stores the rows into the receiver's inbox and signals, the unpack kernel waits for the signal -- no library in the step.
+    ``replan`` = k > 1: only every k-th rebuild migrates and re-plans (BrickDomain(replan_every=k): a ghost layer (k - 1) r_buff
+    thicker); the forces are compared at four different points of the plan's life."""
     from hoomd_tf_amd import _lib, standin
     from hoomd_tf_amd.brick import BrickDomain
     if transport == "native" and not _lib.lib.htf_halo_available():
@@ -111,7 +114,8 @@ def test_replica_brick_forces_equal_the_replicated_box(htf, cuda, grid, transpor
     rcut, rbuf, NN = 2.5, 0.4, 96
     sysm, Lg, lo = _replica_system(standin, pos, vel, Lb, grid, cuda)
     nl = standin.CellNlist(sysm, r_cut=rcut, r_buff=rbuf, check_period=1)
-    dom = nl.domain = BrickDomain(sysm, 0, grid, r_ghost=rcut + rbuf, r_buff=rbuf, replica=True, transport=transport, local_grid=local_grid)
+    dom = nl.domain = BrickDomain(sysm, 0, grid, r_ghost=rcut + rbuf, r_buff=rbuf, replica=True, transport=transport, local_grid=local_grid,
+                                  replan_every=replan)
     nl.build()
     if local_grid:   # the list is binned on the brick + ghost layer alone: 1 / px / py of the logical box's cells (+ the layer)
         assert nl._grid[2] < 0.6 * np.prod(np.floor(Lg / ((rcut + rbuf) / 2.0)))
@@ -121,42 +125,50 @@ def test_replica_brick_forces_equal_the_replicated_box(htf, cuda, grid, transpor
     arr = ctx.make_arrays(sysm.pos, sysm.N, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, sysm.force)
     overlapped = 0
     n_steps = 160
+    checkpoints = (n_steps - 1,) if replan == 1 else (n_steps - 11, n_steps - 8, n_steps - 4, n_steps - 1)
+
+    def compare():
+        torch.cuda.synchronize()
+        live = dom.live_rows()
+        assert len(live) == len(pos)
+        p = sysm.pos[live, :3].double().cpu().numpy()
+        # everybody is still in the brick (a migrant shifted the wrong way -- both faces of an axis with two bricks lead to the same
+        # neighbor, the shift differs -- would sit a brick width outside), give or take what moves between two rebuilds
+        for d in dom.axes:
+            q = p[:, d] - np.floor((p[:, d] - dom.lo[d] + 1.0) / Lg[d]) * Lg[d]      # (the integrator wraps into the logical box)
+            assert np.all((q >= dom.lo[d] - 0.25 * replan) & (q < dom.hi[d] + 0.25 * replan)), d      # (r_buff / 2 per period since the plan)
+        kT = float((sysm.vel[live, :3].double() ** 2).sum() / (3 * len(live)))
+        assert 0.7 < kT < 1.3, kT
+        got = sysm.force[live].cpu().numpy()
+        assert np.all(sysm.force[~torch.isin(torch.arange(sysm.N, device=cuda), live)].cpu().numpy() == 0)   # inert rows: zero force
+        # the replicated box, single domain: every brick image of every particle
+        reps = np.stack(np.meshgrid(*[np.arange(g) for g in grid], indexing="ij"), -1).reshape(-1, 3)
+        base = p - lo                                      # brick-local [0, Lb); rows may sit a hair outside after the last step
+        allp = np.concatenate([base + r * Lb - Lg / 2 for r in reps])
+        allp -= np.floor((allp + Lg / 2) / Lg) * Lg
+        ref_sys = standin.System(allp, Lg, dtype=torch.float32, device=cuda)
+        ref_nl = standin.CellNlist(ref_sys, r_cut=rcut, r_buff=rbuf)
+        ref_nl.build()
+        ref_ctx = htf.Context(r_cut=rcut, nneighs=NN, scalar_dtype=torch.float32, max_n=ref_sys.N)
+        ref_ctx.set_potential(htf.Potential.lj())
+        ref_ctx.compute_forces(0, ref_ctx.make_arrays(ref_sys.pos, ref_sys.N, ref_nl.n_neigh, ref_nl.head_list, ref_nl.nlist, ref_sys.box, ref_sys.force))
+        torch.cuda.synchronize()
+        mine = int(np.nonzero((reps == np.asarray(grid) // 2).all(axis=1))[0][0])
+        want = ref_sys.force.cpu().numpy()[mine * len(p):(mine + 1) * len(p)]
+        scale = np.abs(want).max()
+        assert np.abs(got - want).max() < 3e-5 * scale, (np.abs(got - want).max(), scale)
+
     for ts in range(n_steps):
         nl.compute(ts)
         overlapped += int(dom.pending)
         ctx.compute_forces_overlapped(ts, arr, dom)
+        if ts in checkpoints:
+            compare()
         if ts < n_steps - 1:
             nve.step()
     torch.cuda.synchronize()
     assert nl.n_builds >= 3 and overlapped >= 30 and dom.n_migrated > 5, (nl.n_builds, overlapped, dom.n_migrated)
-    live = dom.live_rows()
-    assert len(live) == len(pos)
-    p = sysm.pos[live, :3].double().cpu().numpy()
-    # everybody is still in the brick (a migrant shifted the wrong way -- both faces of an axis with two bricks lead to the same
-    # neighbor, the shift differs -- would sit a brick width outside), give or take what moves between two rebuilds
-    for d in dom.axes:
-        q = p[:, d] - np.floor((p[:, d] - dom.lo[d] + 1.0) / Lg[d]) * Lg[d]      # (the integrator wraps into the logical box)
-        assert np.all((q >= dom.lo[d] - 0.25) & (q < dom.hi[d] + 0.25)), d
-    kT = float((sysm.vel[live, :3].double() ** 2).sum() / (3 * len(live)))
-    assert 0.7 < kT < 1.3, kT
-    got = sysm.force[live].cpu().numpy()
-    assert np.all(sysm.force[~torch.isin(torch.arange(sysm.N, device=cuda), live)].cpu().numpy() == 0)   # inert rows: zero force
-    # the replicated box, single domain: every brick image of every particle
-    reps = np.stack(np.meshgrid(*[np.arange(g) for g in grid], indexing="ij"), -1).reshape(-1, 3)
-    base = p - lo                                      # brick-local [0, Lb); rows may sit a hair outside after the last step
-    allp = np.concatenate([base + r * Lb - Lg / 2 for r in reps])
-    allp -= np.floor((allp + Lg / 2) / Lg) * Lg
-    ref_sys = standin.System(allp, Lg, dtype=torch.float32, device=cuda)
-    ref_nl = standin.CellNlist(ref_sys, r_cut=rcut, r_buff=rbuf)
-    ref_nl.build()
-    ref_ctx = htf.Context(r_cut=rcut, nneighs=NN, scalar_dtype=torch.float32, max_n=ref_sys.N)
-    ref_ctx.set_potential(htf.Potential.lj())
-    ref_ctx.compute_forces(0, ref_ctx.make_arrays(ref_sys.pos, ref_sys.N, ref_nl.n_neigh, ref_nl.head_list, ref_nl.nlist, ref_sys.box, ref_sys.force))
-    torch.cuda.synchronize()
-    mine = int(np.nonzero((reps == np.asarray(grid) // 2).all(axis=1))[0][0])
-    want = ref_sys.force.cpu().numpy()[mine * len(p):(mine + 1) * len(p)]
-    scale = np.abs(want).max()
-    assert np.abs(got - want).max() < 3e-5 * scale, (np.abs(got - want).max(), scale)
+    assert (dom.n_light >= 2) == (replan > 1), dom.n_light
 
 
 def _slab_twin_worker(rank, world, port, q, per_slab):
@@ -357,14 +369,14 @@ def test_bricks_on_one_gpu(htf, cuda, grid, cells):
     _run_ranks(_brick_md_worker, grid[0] * grid[1], (grid, cells))
 
 
-def _replica_md(htf, cuda, grid, transport, cells=6, period=4):
+def _replica_md(htf, cuda, grid, transport, cells=6, period=4, replan_every=1):
     from hoomd_tf_amd import standin
     from hoomd_tf_amd.brick import BrickDomain
     pos, vel, Lb = _brick_of_liquid(htf, cuda, cells, grid)
     rcut, rbuf, NN = 2.5, 0.4, 96
     sysm, Lg, lo = _replica_system(standin, pos, vel, Lb, grid, cuda)
     nl = standin.CellNlist(sysm, r_cut=rcut, r_buff=rbuf, check_period=period, device_decision=True)
-    nl.domain = BrickDomain(sysm, 0, grid, r_ghost=rcut + rbuf, r_buff=rbuf, replica=True, transport=transport)
+    nl.domain = BrickDomain(sysm, 0, grid, r_ghost=rcut + rbuf, r_buff=rbuf, replica=True, transport=transport, replan_every=replan_every)
     nl.build()
     ctx = htf.Context(r_cut=rcut, nneighs=NN, scalar_dtype=torch.float32, max_n=sysm.N)
     ctx.set_potential(htf.Potential.lj())
@@ -372,30 +384,33 @@ def _replica_md(htf, cuda, grid, transport, cells=6, period=4):
     return sysm, nl, run
 
 
-@pytest.mark.parametrize("grid,transport", [((8, 1, 1), "local"), ((4, 2, 1), "native"), ((8, 1, 1), "native"), ((4, 2, 1), "local"),
-                                            ((8, 1, 1), "peer"), ((4, 2, 1), "peer")])
-def test_replayed_cycles_equal_the_eager_loop(htf, cuda, grid, transport):
+@pytest.mark.parametrize("grid,transport,replan", [((8, 1, 1), "local", 1), ((4, 2, 1), "native", 1), ((8, 1, 1), "native", 1), ((4, 2, 1), "local", 1),
+                                                   ((8, 1, 1), "peer", 1), ((4, 2, 1), "peer", 1), ((8, 1, 1), "local", 2), ((4, 2, 1), "peer", 2),
+                                                   ((4, 2, 1), "native", 2)])
+def test_replayed_cycles_equal_the_eager_loop(htf, cuda, grid, transport, replan):
     """whole check periods of the decomposed step -- distance check, halo, interior rows, boundary rows,
     integrator, and in the second graph migration + re-plan + list rebuild -- replayed from hipGraphs (with ``native`` the
     grouped ncclSend / ncclRecv of csrc/halo.hip are INSIDE the capture), the next graph chosen from the pinned word of the
-    cycle before: the trajectory of the eager no-read-back loop, bit for bit, rebuilt at the same steps.  (In a child process
-    with a time limit: a transport that hung inside a replay would otherwise hold the whole session.)"""
+    cycle before: the trajectory of the eager no-read-back loop, bit for bit, rebuilt at the same steps.  ``replan`` = 2: a third
+    graph -- the list rebuilt on the rows and messages as the last plan left them -- alternates with the full rebuild, as the
+    eager loop alternates them.  (In a child process with a time limit: a transport that hung inside a replay would otherwise
+    hold the whole session.)"""
     import subprocess
     from hoomd_tf_amd import _lib
     if transport == "native" and not _lib.lib.htf_halo_available():
         pytest.skip("librccl not loadable")
     code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import torch, hoomd_tf_amd as htf, test_gpu_brick as t; "
-            "t._replay_body(htf, torch.device('cuda:0'), %r, %r); print('REPLAY OK')" % (ROOT, os.path.join(ROOT, "tests"), grid, transport))
+            "t._replay_body(htf, torch.device('cuda:0'), %r, %r, %r); print('REPLAY OK')" % (ROOT, os.path.join(ROOT, "tests"), grid, transport, replan))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=ROOT,
                        env=dict(os.environ, HTF_BRICK_WAIT_S="20"))
     assert r.returncode == 0 and "REPLAY OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
 
 
-def _replay_body(htf, cuda, grid, transport):
+def _replay_body(htf, cuda, grid, transport, replan=1):
     P, warm, cycles = 4, 40, 60
     out = {}
     for mode in ("eager", "graph"):
-        sysm, nl, run = _replica_md(htf, cuda, grid, transport, period=P)
+        sysm, nl, run = _replica_md(htf, cuda, grid, transport, period=P, replan_every=replan)
         run.run(warm)                      # through a few rebuilds: RCCL connected, pinned buffers made
         assert nl.n_builds >= 2 and sysm.timestep % P == 0
         nl.build()                         # both modes start a fresh reference here, with an empty decision history
@@ -415,8 +430,9 @@ def _replay_body(htf, cuda, grid, transport):
         torch.cuda.synchronize()
         assert nl.n_builds - b0 >= 4 and run.dangerous_builds == 0, (nl.n_builds - b0, run.dangerous_builds)
         nl.domain.counts_host()            # (raises on an overflow flag)
-        out[mode] = (built, sysm.pos.clone(), sysm.vel.clone(), sysm.force.clone(), nl.domain.n_migrated)
+        out[mode] = (built, sysm.pos.clone(), sysm.vel.clone(), sysm.force.clone(), nl.domain.n_migrated, nl.domain.n_light)
     assert out["eager"][0] == out["graph"][0], (out["eager"][0], out["graph"][0])
+    assert out["eager"][5] == out["graph"][5] and (out["graph"][5] >= 2) == (replan > 1), (out["eager"][5], out["graph"][5])
     for k in (1, 2, 3):
         assert _same(out["eager"][k], out["graph"][k]), k
     assert out["eager"][4] == out["graph"][4] > 0

@@ -431,3 +431,49 @@ def test_slab_plan_kernels_match_torch(htf, cuda):
     from hoomd_tf_amd.domain import SlabDomain
     got = SlabDomain._merge_segments_device(None, src, segs[0], segs[1], segs[2])
     assert torch.equal(got, want)
+
+
+def test_rebuild_on_a_non_periodic_grid_takes_the_nearest_image(htf, cuda):
+    """htfs_rebuild_nlist_ghosts' image_L: on a cell grid that is NOT periodic along x while the coordinates are (a decomposed system's
+    brick + ghost layer), rows whose x is a whole period away -- wrapped to the far side of the logical box by the integrator after
+    they left through a face on its boundary, or the ghosts of such rows -- are binned and searched as their image next to the
+    grid: the neighbor rows of EVERY particle equal those of the same configuration with nothing shifted."""
+    from hoomd_tf_amd import standin
+    rng = np.random.default_rng(9)
+    L = np.array([14.0, 12.0, 12.0])
+    pos, _, a = standin.fcc_positions(7, 0.8442)
+    pos = pos[(np.abs(pos) < L / 2 - 0.05).all(axis=1)]
+    pos = pos + 0.03 * a * rng.standard_normal(pos.shape)
+    period = 40.0                                      # the logical box along x; the grid spans 14 of it
+
+    class Domain:                                      # what CellNlist asks a fixed-capacity domain for
+        fixed_capacity, local_grid, world, replica, n_global = True, True, 1, False, len(pos)
+        def rebuild(self): pass
+        def nlist_box(self): return np.array([-L / 2, L / 2, [0.0, 0.0, 0.0]]), (0, 1, 1)
+        def image_lengths(self): return (period, 0.0, 0.0)
+        def attach_n_neigh(self, t): pass
+
+    sysm = standin.System(pos, np.array([period, L[1], L[2]]), dtype=torch.float32, device=cuda)
+    nl = standin.CellNlist(sysm, r_cut=2.5, r_buff=0.4, pitch=128)
+    nl.domain = Domain()
+    nl.build()                                         # (the sizing build: separate calls, everything where it belongs)
+    nl.build()                                         # the fixed-capacity fast path on the same positions
+    torch.cuda.synchronize()
+
+    def rows():
+        n = nl.n_neigh.cpu().numpy()
+        t = nl.nlist.cpu().numpy().reshape(len(n), -1)
+        return [sorted(t[i, :n[i]].tolist()) for i in range(len(n))]
+
+    want = rows()
+    assert sum(len(r) for r in want) > 30 * len(pos)
+    moved = rng.random(len(pos)) < 0.3
+    sysm.pos[torch.from_numpy(moved).to(cuda), 0] += torch.from_numpy(np.where(rng.random(moved.sum()) < 0.5, period, -period)).float().to(cuda)
+    nl.build()
+    torch.cuda.synchronize()
+    assert rows() == want
+    # and without the period the same build loses them (the shifted rows clamp into the edge cells): the parameter is what does it
+    Domain.image_lengths = lambda self: (0.0, 0.0, 0.0)
+    nl.build()
+    torch.cuda.synchronize()
+    assert rows() != want

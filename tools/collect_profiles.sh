@@ -2,7 +2,7 @@
 R=${1:-r05}
 cd "$(dirname "$0")/.."
 F=gpurun_out/final
-for n in bench_ref_lj256 bench_lj bench_lj_200 bench_lj_f64 bench_wca bench_wca_c2 bench_mlp bench_mlp_fp32 bench_mlp_bf16 bench_mlp_split bench_c1 bench_ex01 bench_mlp_train bench_rehearsal_2ranks_strong_gloo bench_rehearsal_8ranks_strong_gloo bench_rehearsal_2ranks_weak_gloo bench_rehearsal_c5_8ranks_weak_mlptrain_gloo bench_rehearsal_2ranks_strong_torchrun_gloo bench_rehearsal_2ranks_strong_mlp_gloo bench_eds_f64 bench_generic_lj bench_lj_cells16 bench_lj_cells20 bench_lj_cells25 bench_dd_self_8x1x1 bench_dd_self_4x2x1; do
+for n in bench_ref_lj256 bench_lj bench_lj_200 bench_lj_f64 bench_wca bench_wca_c2 bench_mlp bench_mlp_fp32 bench_mlp_bf16 bench_mlp_split bench_c1 bench_ex01 bench_mlp_train bench_rehearsal_2ranks_strong_gloo bench_rehearsal_8ranks_strong_gloo bench_rehearsal_2ranks_weak_gloo bench_rehearsal_c5_8ranks_weak_mlptrain_gloo bench_rehearsal_2ranks_strong_torchrun_gloo bench_rehearsal_2ranks_strong_mlp_gloo bench_eds_f64 bench_generic_lj bench_lj_cells16 bench_lj_cells20 bench_lj_cells25 bench_dd_self_8x1x1 bench_dd_self_4x2x1 bench_dd_self_8x1x1_replan2 bench_dd_self_4x2x1_replan2; do
   [ -s $F/$n.json ] && cp $F/$n.json profiles/${R}_$n.json
 done
 cp $F/bench_eds.json profiles/${R}_bench_eds_c4.json

@@ -41,6 +41,9 @@ timeout 300 python tools/soak_nve.py --steps 20000 --f64 > $F/soak_nve_f64.json 
 # round 5: one rank's decomposed step at the 8-rank geometries (replica mode), eager and replayed, local delivery and RCCL
 timeout 300 python bench.py --workload dd-self --grid 8x1x1 --steps 100 --warmup 20 2>/dev/null | jl > $F/bench_dd_self_8x1x1.json
 timeout 300 python bench.py --workload dd-self --grid 4x2x1 --steps 100 --warmup 20 2>/dev/null | jl > $F/bench_dd_self_4x2x1.json
+# ... with a re-plan only every second rebuild (BrickDomain(replan_every=2): a ghost layer r_buff thicker, a third graph)
+timeout 300 python bench.py --workload dd-self --grid 8x1x1 --replan-every 2 --steps 100 --warmup 20 2>/dev/null | jl > $F/bench_dd_self_8x1x1_replan2.json
+timeout 300 python bench.py --workload dd-self --grid 4x2x1 --replan-every 2 --steps 100 --warmup 20 2>/dev/null | jl > $F/bench_dd_self_4x2x1_replan2.json
 timeout 200 python tools/rccl_graph_probe.py 2>&1 | cut -c1-190 > $F/rccl_graph_probe.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_dd -o dd -- python3 bench.py --workload dd-self --grid 8x1x1 --transport local --steps 200 --warmup 20 --windows 2 > /dev/null 2>&1
 find /tmp/p_dd -name "*kernel_stats.csv" -exec cp {} $F/dd_kernel_stats.csv \;

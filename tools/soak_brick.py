@@ -25,6 +25,7 @@ ap.add_argument("--transport", default="local")
 ap.add_argument("--steps", type=int, default=20000)
 ap.add_argument("--every", type=int, default=1000)
 ap.add_argument("--cells", type=int, default=32)
+ap.add_argument("--replan-every", type=int, default=1)
 a = ap.parse_args()
 
 dev = torch.device("cuda:0")
@@ -46,7 +47,7 @@ rcut, rbuff, NN, P, dt = 3.0, 0.4, 128, 5, 0.005
 sysm = standin.System(pos, Lg, dtype=torch.float32, device=dev)
 sysm.randomize_velocities(kT=1.0, seed=3)
 nl = standin.CellNlist(sysm, r_cut=rcut, r_buff=rbuff, check_period=P, device_decision=True)
-dom = nl.domain = BrickDomain(sysm, 0, grid, r_ghost=rcut + rbuff, r_buff=rbuff, replica=True, transport=a.transport)
+dom = nl.domain = BrickDomain(sysm, 0, grid, r_ghost=rcut + rbuff, r_buff=rbuff, replica=True, transport=a.transport, replan_every=a.replan_every)
 nl.build()
 ctx = htf.Context(r_cut=rcut, nneighs=NN, scalar_dtype=torch.float32, max_n=sysm.N, check_nlist=False, fused=2)
 ctx.set_potential(htf.Potential.lj())
@@ -81,7 +82,7 @@ def sample():
     ke = 0.5 * float((v3 * v3).sum()) / n_rank
     return {"step": int(sysm.timestep), "particles": int(len(live)), "E_per_particle": pe + ke, "PE": pe, "kT": 2.0 * ke / 3.0,
             "list_rebuilds": int(nl.n_builds), "rebuild_cycles": int(run.n_rebuild_cycles), "cycles": int(run.n_cycles),
-            "dangerous_builds": int(run.dangerous_builds), "migrated_total": int(dom.n_migrated), "flags": int(c[_lib.BC_FLAGS]),
+            "dangerous_builds": int(run.dangerous_builds), "rebuilds_without_a_replan": int(dom.n_light), "migrated_total": int(dom.n_migrated), "flags": int(c[_lib.BC_FLAGS]),
             "ghosts": int(dom.n_ghosts)}
 
 
