@@ -228,3 +228,99 @@ def test_brick_domain_gloo(grid, fractions, n, interior, local_grid):
         p.join(timeout=60)
     for rank, msg in results:
         assert msg == "ok", "rank %d failed:\n%s" % (rank, msg)
+
+
+def _replan_worker(rank, world, port, grid, n, k, q):
+    """BrickDomain(replan_every=k) between real ranks: particles drift by just under r_buff / 2 per period; after every rebuild --
+    the k - 1 of k that leave the plan alone included -- every pair within the LIST radius of a local row has its partner among
+    this rank's local + ghost rows (the neighbor count of every row equals the undivided box's), and one more period later every
+    pair within r_cut still does (forces == the undivided box's): what the thicker ghost layer is for."""
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        sys.path.insert(0, ROOT)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from hoomd_tf_amd import _lib, standin
+        from hoomd_tf_amd.brick import BrickDomain
+        from oracle import htf_oracle as O
+        a, rcut, rbuf = 1.3, 2.5, 0.4
+        pos, L = sq_lattice(n, a)
+        rng = np.random.default_rng(11)                       # (the same stream on every rank: one global trajectory)
+        pos[:, :2] += 0.08 * rng.standard_normal((n * n, 2))
+        pos = pos - np.floor((pos + L / 2) / L) * L
+        ids = np.arange(n * n)
+        probe = standin.System(pos[:1], L, dtype=torch.float64, device="cpu")
+        d0 = BrickDomain(probe, rank, grid, r_ghost=rcut + rbuf, r_buff=rbuf, n_global=n * n, replan_every=k)
+        mine = np.ones(n * n, dtype=bool)
+        for d in range(2):
+            mine &= (pos[:, d] >= d0.lo[d]) & (pos[:, d] < d0.hi[d])
+        system = standin.System(pos[mine], L, types=ids[mine], dtype=torch.float64, device="cpu")
+        dom = BrickDomain(system, rank, grid, r_ghost=rcut + rbuf, r_buff=rbuf, n_global=n * n, replan_every=k, local_grid=True)
+        assert abs(dom.r_ghost - (rcut + rbuf + (k - 1) * rbuf)) < 1e-12
+        cap = dom.cap
+        gpos = pos.copy()
+
+        def move():
+            nonlocal gpos
+            step = rng.standard_normal((n * n, 3))
+            step[:, 2] = 0.0
+            step *= (0.19 * rng.random((n * n, 1)) ** 0.5) / np.linalg.norm(step, axis=1, keepdims=True)     # |step| < r_buff / 2
+            gpos = gpos + step
+            gpos = gpos - np.floor((gpos + L / 2) / L) * L
+            live = dom.live_rows()
+            my = _ids(system.pos[:cap, 3])[live.numpy()]
+            system.pos[live, :3] = torch.from_numpy(gpos[my])
+
+        def complete(radius, what):
+            p_all = system.pos.numpy()
+            live = ~np.isnan(p_all[:cap, 0])
+            my = _ids(system.pos[:cap, 3])[live]
+            with np.errstate(invalid="ignore"):
+                nn, _, _ = brute_nlist(p_all[:, :3], L, radius, n_local=cap)
+            gn, _, _ = brute_nlist(gpos, L, radius)
+            assert np.array_equal(nn[live], gn[my]), "%s: %d rows miss a partner" % (what, int((nn[live] != gn[my]).sum()))
+
+        n_light = 0
+        for period in range(2 * k + 1):
+            dom.rebuild()                                     # index 0, k, 2k: migrate + re-plan; the others: the halo alone
+            c = dom.counts_host()
+            assert int(c[_lib.BC_FLAGS]) == 0
+            if period % k:
+                n_light += 1
+            else:
+                live = dom.live_rows().numpy()
+                p = system.pos.numpy()[:cap][live]
+                for d in dom.axes:
+                    assert np.all((p[:, d] >= dom.lo[d]) & (p[:, d] < dom.hi[d]))      # a full rebuild leaves everybody at home
+            assert dom.n_light == n_light
+            complete(rcut + rbuf, "list radius at rebuild %d" % period)
+            move()
+            dom.exchange()
+            complete(rcut, "r_cut one period after rebuild %d" % period)
+        assert n_light == 2 * (k - 1)
+        cnt = torch.tensor([int(len(dom.live_rows()))])
+        dist.all_reduce(cnt)
+        assert int(cnt) == n * n
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+@pytest.mark.parametrize("grid,n,k", [((2, 1, 1), 32, 2), ((4, 2, 1), 32, 2), ((3, 1, 1), 32, 3)])
+def test_fewer_replans_keep_every_pair(grid, n, k):
+    world = grid[0] * grid[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_replan_worker, args=(r, world, port, grid, n, k, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in results:
+        assert msg == "ok", "rank %d failed:\n%s" % (rank, msg)
