@@ -53,7 +53,9 @@ def parse():
     ap.add_argument("--grid", default=None, help="rank grid PXxPYx1: --gpus N > 1: how the box is cut (default: slabs along x; e.g. 4x2x1 "
                                                  "for 8 ranks); dd-self: the grid whose one brick this GPU runs (default 8x1x1)")
     ap.add_argument("--transport", default="all", help="dd-self: local | peer | native | all")
-    ap.add_argument("--replan-every", type=int, default=1, help="dd-self: BrickDomain(replan_every=k): only every k-th rebuild migrates and re-plans")
+    ap.add_argument("--replan-every", type=int, default=0,
+                    help="BrickDomain(replan_every=k): only every k-th neighbor-list rebuild migrates and re-plans (a ghost layer (k - 1) r_buff "
+                         "thicker).  0 = the default: 1 for --workload dd-self, 2 for --gpus N > 1 (there a re-plan is a grouped exchange)")
     ap.add_argument("--train-period", type=int, default=100, help="mlp-train (C5b): force-matching step every this many MD steps")
     ap.add_argument("--cells", type=int, default=32, help="fcc cells per side (N = 4 cells^3 per rank)")
     ap.add_argument("--lattice", default="fcc", choices=["fcc", "sc"], help="fcc: N = 4 cells^3 (C3, C5); sc: N = cells^3 (C2 = sc 32^3 = 32768)")
@@ -339,7 +341,7 @@ def run_dd_self(args, htf, standin, dev):
         sysm.randomize_velocities(kT=1.0, seed=3)
         nl = standin.CellNlist(sysm, r_cut=args.rcut, r_buff=args.rbuff, check_period=P, device_decision=True)
         dom = nl.domain = BrickDomain(sysm, 0, grid, r_ghost=args.rcut + args.rbuff, r_buff=args.rbuff, replica=True, transport=transport,
-                                      replan_every=args.replan_every)
+                                      replan_every=args.replan_every or 1)
         nl.build()
         ctx = htf.Context(r_cut=args.rcut, nneighs=args.nn, scalar_dtype=torch.float32, max_n=sysm.N, check_nlist=False, fused=2)
         ctx.set_potential(htf.Potential.lj())
@@ -1132,7 +1134,7 @@ def run_md(args, E, workload, variants=True, cpu=True):
         from hoomd_tf_amd.brick import BrickDomain
         tr = os.environ.get("HTF_HALO_TRANSPORT", "torch")
         nl.domain = BrickDomain(sysm, rank, grid, r_ghost=args.rcut + args.rbuff, r_buff=args.rbuff, n_global=n_global,
-                                transport=tr if tr in ("torch", "native") else "torch")
+                                transport=tr if tr in ("torch", "native") else "torch", replan_every=args.replan_every or 2)
     elif world > 1:
         from hoomd_tf_amd.domain import SlabDomain
         if grid != (world, 1, 1):
@@ -1514,6 +1516,8 @@ def run_md(args, E, workload, variants=True, cpu=True):
                    "halo": None if world == 1 else {"ghosts_rank0": nl.domain.n_ghosts if brick else sysm.n_ghost,
                                                     "migrated_rank0": nl.domain.n_migrated,
                                                     "interior_rows_rank0": nl.domain.n_interior,
+                                                    "replan_every": getattr(nl.domain, "replan_every", 1),
+                                                    "rebuilds_without_a_replan_rank0": getattr(nl.domain, "n_light", 0),
                                                     "domain": ("BrickDomain: fixed-capacity arrays (%d rows + %d ghost rows on rank 0), inert "
                                                                "rows, no read-back in a rebuild" % (sysm.N, sysm.n_ghost)) if brick
                                                               else "SlabDomain (variable-length arrays, host-planned rebuild)",
