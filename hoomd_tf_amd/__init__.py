@@ -13,7 +13,7 @@ from . import standin
 from .simmodel import (SimModel, compute_nlist_forces, compute_positions_forces, nlist_rinv, safe_norm,
                        box_size, wrap_vector, compute_rdf, masked_nlist, reduce_sum, pairwise_unit_forces, Nlist,
                        norm, cast, divide_no_nan, Positions, sort, exp, log, tanh, sqrt, square, pow, abs, minimum, maximum, where,
-                       gather, equal, not_equal,
+                       gather, equal, not_equal, erf, erfc, sigmoid, softplus, sin, cos,
                        MolSimModel, find_molecules, MeanTensor)
 from .layers import RBFExpansion, WCARepulsion, EDSLayer, PairMLP, SoftRDFCV, LJLayer, Dense
 from . import optimizers

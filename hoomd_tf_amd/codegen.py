@@ -4,7 +4,7 @@ The reference's defining capability is an arbitrary ``compute()`` (htf/simmodel.
 legal, and every notebook writes its own energy.  Until round 5 anything that was not LJ / WCA / a rinv polynomial / a Gaussian / an
 MLP ran as ~20 eager torch ops + autograd per step (17-23 x slower than a lowered model at C2 / C3).  Here an ELEMENTWISE pair
 energy -- any expression of ``s = nlist_rinv(nlist)`` and ``r = safe_norm(nlist[:, :, :3], axis=2)`` built from + - * /, integer
-and real powers, exp, log, tanh, sqrt, abs, minimum / maximum, comparisons, ``where`` and cast masks -- is kept symbolic
+and real powers, exp, log, tanh, sqrt, abs, erf / erfc, sigmoid, softplus, sin / cos, minimum / maximum, comparisons, ``where`` and cast masks -- is kept symbolic
 (:class:`Node`), differentiated in forward mode with respect to r, emitted as the body of pair_math.h's
 ``pair_eval_f<HTF_POT_JIT>`` and compiled for gfx950 with ``hipcc --genco`` around the library's own row loops
 (csrc/jit_unit.hip): the one-kernel step, its virial form, the streaming evaluator -- same launch geometry, same reductions as
@@ -59,7 +59,7 @@ def wrap(x):
 
 S, R, RN = Node("s"), Node("r"), Node("rn")   # nlist_rinv, safe_norm, the plain norm (masks only: no gradient)
 TJ, TI = Node("tj"), Node("ti")               # the neighbor's type nlist[i, j, 3] and the row particle's own positions[i, 3], as floats
-UNARY = ("neg", "exp", "log", "tanh", "sqrt", "abs", "square", "mask")
+UNARY = ("neg", "exp", "log", "tanh", "sqrt", "abs", "square", "mask", "erf", "erfc", "sigmoid", "softplus", "sin", "cos")
 BINARY = ("add", "sub", "mul", "div", "min", "max")
 COMPARE = ("lt", "le", "gt", "ge", "eq", "ne")
 MAX_TABLE = 1024                               # entries of a ``gather`` table (a species-pair parameter matrix)
@@ -124,6 +124,18 @@ def evaluate(node, s, r, rn, memo=None, tj=None, ti=None):
         out = a[0] * a[0]
     elif op == "mask":
         out = a[0].to(s.dtype)
+    elif op == "erf":
+        out = torch.erf(a[0])
+    elif op == "erfc":
+        out = torch.erfc(a[0])
+    elif op == "sigmoid":
+        out = torch.sigmoid(a[0])
+    elif op == "softplus":
+        out = torch.nn.functional.softplus(a[0], threshold=1e30)
+    elif op == "sin":
+        out = torch.sin(a[0])
+    elif op == "cos":
+        out = torch.cos(a[0])
     elif op == "add":
         out = a[0] + a[1]
     elif op == "sub":
@@ -272,6 +284,40 @@ class _Emitter:
         elif op == "abs":
             a, da = self.emit(node.args[0])
             out = (self.tmp("fabsf(%s)" % a), None if da is None else self.tmp("%s < 0.0f ? -%s : (%s > 0.0f ? %s : 0.0f)" % (a, da, a, da)))
+        elif op in ("erf", "erfc"):
+            # the real-space part of Ewald / DSF electrostatics: erfc(alpha r) / r.  d erf(a) = 2 / sqrt(pi) exp(-a^2)
+            a, da = self.emit(node.args[0])
+            v = self.tmp("%s(%s)" % ("erff" if op == "erf" else "erfcf", a))
+            if da is None:
+                out = (v, None)
+            else:
+                g = self.tmp("1.1283791670955126f * __builtin_amdgcn_exp2f(-(%s * %s) * 1.4426950408889634f)" % (a, a))
+                out = (v, self.tmp("%s%s * %s" % ("" if op == "erf" else "-", g, da)))
+        elif op == "sigmoid":
+            a, da = self.emit(node.args[0])
+            v = self.tmp("__builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-%s * 1.4426950408889634f))" % a)
+            out = (v, None if da is None else self.tmp("%s * (1.0f - %s) * %s" % (v, v, da)))
+        elif op == "softplus":
+            # log(1 + exp(a)) = max(a, 0) + log(1 + exp(-|a|)): no overflow; its derivative is the sigmoid
+            a, da = self.emit(node.args[0])
+            ex = self.tmp("__builtin_amdgcn_exp2f(-fabsf(%s) * 1.4426950408889634f)" % a)
+            v = self.tmp("fmaxf(%s, 0.0f) + __builtin_amdgcn_logf(1.0f + %s) * 0.6931471805599453f" % (a, ex))
+            if da is None:
+                out = (v, None)
+            else:
+                sg = self.tmp("%s >= 0.0f ? __builtin_amdgcn_rcpf(1.0f + %s) : %s * __builtin_amdgcn_rcpf(1.0f + %s)" % (a, ex, ex, ex))
+                out = (v, self.tmp("%s * %s" % (sg, da)))
+        elif op in ("sin", "cos"):
+            # v_sin_f32 / v_cos_f32 take REVOLUTIONS: the argument is scaled by 1 / 2 pi and reduced to [0, 1) first (v_fract_f32) --
+            # two instructions each, where libm's full-range sinf / cosf is a 500 KB unit; absolute error ~1e-6 + 4e-7 |a|
+            a, da = self.emit(node.args[0])
+            rev = self.tmp("__builtin_amdgcn_fractf(%s * 0.15915494309189535f)" % a)
+            v = self.tmp("__builtin_amdgcn_%s(%s)" % ("sinf" if op == "sin" else "cosf", rev))
+            if da is None:
+                out = (v, None)
+            else:
+                other = self.tmp("__builtin_amdgcn_%s(%s)" % ("cosf" if op == "sin" else "sinf", rev))
+                out = (v, self.tmp("%s%s * %s" % ("" if op == "sin" else "-", other, da)))
         elif op in ("min", "max"):
             (a, da), (b, db) = self.emit(node.args[0]), self.emit(node.args[1])
             cmpop = "<=" if op == "min" else ">="

@@ -826,6 +826,32 @@ def abs(x):  # noqa: A001 (tf.abs)
     return _unary("abs", x, torch.abs)
 
 
+def erf(x):
+    """tf.math.erf (traced on pair expressions)."""
+    return _unary("erf", x, torch.erf)
+
+
+def erfc(x):
+    """tf.math.erfc: the real-space part of Ewald / damped-shifted-force electrostatics, erfc(alpha r) / r."""
+    return _unary("erfc", x, torch.erfc)
+
+
+def sigmoid(x):
+    return _unary("sigmoid", x, torch.sigmoid)
+
+
+def softplus(x):
+    return _unary("softplus", x, lambda t: torch.nn.functional.softplus(t, threshold=1e30))
+
+
+def sin(x):
+    return _unary("sin", x, torch.sin)
+
+
+def cos(x):
+    return _unary("cos", x, torch.cos)
+
+
 def pow(x, n):  # noqa: A001 (tf.pow)
     if _sym(x):
         return PairExpr.of(x) ** n

@@ -22,6 +22,10 @@ def _models(htf, x):
         "switched_lj": htf.where(r < 2.0, 4.0 * (s ** 12 - s ** 6), 0.0 * s),
         "mix": 3.0 * s ** 9 - htf.tanh(r) * s ** 2 + htf.minimum(s ** 3, 2.0 * s) + htf.sqrt(r) * s * htf.log(1.0 + r) / (1.0 + htf.abs(r - 1.5)),
         "real_power": s ** 2.5 * htf.square(htf.maximum(r, 1.0)),
+        # round 5, second half: damped electrostatics (the real-space Ewald term), a soft switch, an oscillatory tail
+        "ewald_real": 1.7 * htf.erfc(0.8 * r) * s,
+        "switches": htf.sigmoid(4.0 * (2.0 - r)) * s ** 6 + 0.3 * htf.softplus(1.5 - r) * s + 0.1 * htf.erf(r - 1.0) * s ** 2,
+        "friedel": htf.cos(2.2 * r + 0.3) * s ** 3 + 0.2 * htf.sin(1.1 * r) * s ** 2,
     }
 
 
@@ -33,6 +37,9 @@ static float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 static float __builtin_amdgcn_sqrtf(float x) { return sqrtf(x); }
 static float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
 static float __builtin_amdgcn_logf(float x) { return log2f(x); }
+static float __builtin_amdgcn_fractf(float x) { return x - floorf(x); }
+static float __builtin_amdgcn_sinf(float x) { return sinf(6.283185307179586f * x); }
+static float __builtin_amdgcn_cosf(float x) { return cosf(6.283185307179586f * x); }
 int main(void) {
     float x, y, z;
     while (scanf("%f %f %f", &x, &y, &z) == 3) {
@@ -271,7 +278,7 @@ def _random_expression(htf, rng, s, r, tj, ti, depth):
                 lambda: htf.gather(rng.uniform(0.5, 1.5, 9), ti[:, None] * 3 + tj) * s][rng.integers(0, 6)]()
     a = _random_expression(htf, rng, s, r, tj, ti, depth - 1)
     b = _random_expression(htf, rng, s, r, tj, ti, depth - 1)
-    k = rng.integers(0, 12)
+    k = rng.integers(0, 15)
     if k == 0: return a + b
     if k == 1: return a - 0.5 * b
     if k == 2: return a * b
@@ -283,6 +290,9 @@ def _random_expression(htf, rng, s, r, tj, ti, depth):
     if k == 8: return htf.where(a < b, a, b * 0.7)
     if k == 9: return htf.pow(htf.abs(a) + 0.5, float(rng.uniform(0.5, 2.5))) - b
     if k == 10: return htf.sqrt(htf.square(a) + 1.0) * htf.cast(htf.equal(tj, int(rng.integers(0, 3))), torch.float32) + b
+    if k == 11: return htf.erfc(0.5 * a) * b + htf.erf(a)
+    if k == 12: return htf.sigmoid(a) * b + htf.softplus(-1.0 * b)
+    if k == 13: return htf.cos(a) + htf.sin(0.7 * b) * a
     return htf.log(1.0 + htf.square(a)) + a ** int(rng.integers(2, 5)) * 0.1 + b
 
 

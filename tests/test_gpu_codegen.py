@@ -23,7 +23,7 @@ def _ref(htf, e, nl64, virial=False):
     return [o.detach().numpy() for o in out] if virial else out.detach().numpy()
 
 
-@pytest.mark.parametrize("name", ["morse", "yukawa", "switched_lj", "mix", "real_power"])
+@pytest.mark.parametrize("name", ["morse", "yukawa", "switched_lj", "mix", "real_power", "ewald_real", "switches", "friedel"])
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_generated_evaluator_matches_autograd(htf, cuda, name, dtype):
     from test_gpu_parity import CONTACTS, assert_forces_close
