@@ -497,12 +497,36 @@ def run_generic_lj(args, htf, standin, dev):
             energy = torch.sum(2.0 * torch.tensor(KA_EPS, device=s.device)[idx] * (q * q - q), dim=1)
             return htf.compute_nlist_forces(nlist, energy)
 
+    class IonicModel(htf.SimModel):
+        """Outside the zoo, typed, with a special function: LJ cores plus the real-space part of Ewald / damped-shifted-force
+        electrostatics between +1 / -1 species, q_i q_j erfc(alpha r) / r, the charges gathered by species pair."""
+        def compute(self, nlist, positions, box):
+            s = htf.nlist_rinv(nlist)
+            r = htf.safe_norm(nlist[:, :, :3], axis=2)
+            idx = htf.cast(positions[:, 3], torch.int32)[:, None] * 2 + htf.cast(nlist[:, :, 3], torch.int32)
+            qq = htf.gather([1.0, -1.0, -1.0, 1.0], idx)
+            energy = htf.reduce_sum(2.0 * (s ** 12 - s ** 6) + 0.5 * 2.0 * qq * htf.erfc(0.35 * r) * s, axis=1)
+            return htf.compute_nlist_forces(nlist, energy)
+
+    class TorchIonicModel(htf.SimModel):
+        def compute(self, nlist, positions, box):
+            delta = 3e-6
+            t = nlist[:, :, :3] + 1e-7
+            r = torch.sqrt(torch.sum(t * t, dim=2))
+            s = torch.where(r > delta, 1.0 / (r + delta), torch.zeros_like(r))
+            idx = (positions[:, 3:4] * 2 + nlist[:, :, 3]).detach().long()
+            qq = torch.tensor([1.0, -1.0, -1.0, 1.0], device=s.device)[idx]
+            energy = torch.sum(2.0 * (s ** 12 - s ** 6) + 0.5 * 2.0 * qq * torch.erfc(0.35 * r) * s, dim=1)
+            return htf.compute_nlist_forces(nlist, energy)
+
     def one(lattice, cells, model_cls, steps):
         pos, L, a = (standin.sc_positions if lattice == "sc" else standin.fcc_positions)(cells, 0.8442)
         rng = np.random.default_rng(7)
         pos = pos + 0.03 * a * rng.standard_normal(pos.shape)
         pos -= np.round(pos / L) * L
         types = (rng.random(len(pos)) < 0.2).astype(np.int32) if model_cls in (MixtureModel, TorchMixtureModel) else None
+        if model_cls in (IonicModel, TorchIonicModel):
+            types = (np.arange(len(pos)) % 2).astype(np.int32)    # (equal numbers of the two species: a neutral system)
         sysm = standin.System(pos, L, types=types, dtype=torch.float32, device=dev)
         sysm.randomize_velocities(kT=1.0, seed=7)
         sim = standin.Simulation(sysm)
@@ -537,12 +561,19 @@ def run_generic_lj(args, htf, standin, dev):
         morse = one(lattice, cells, MorseModel, args.steps)
         mix = one(lattice, cells, MixtureModel, args.steps)
         mix_torch = one(lattice, cells, TorchMixtureModel, max(20, args.steps // 10))
+        ion = one(lattice, cells, IonicModel, args.steps)
+        ion_torch = one(lattice, cells, TorchIonicModel, max(20, args.steps // 10))
+        assert ion["potential_kind"] == 9
+        assert abs(ion["energy_per_particle_after_warmup"] - ion_torch["energy_per_particle_after_warmup"]) < 1e-3 * abs(ion_torch["energy_per_particle_after_warmup"]) + 1e-3
         assert yuk["potential_kind"] == 9 and morse["potential_kind"] == 9 and mix["potential_kind"] == 9
         assert abs(mix["energy_per_particle_after_warmup"] - mix_torch["energy_per_particle_after_warmup"]) < 1e-3 * abs(mix_torch["energy_per_particle_after_warmup"]) + 1e-3
         assert abs(yuk["energy_per_particle_after_warmup"] - yuk_torch["energy_per_particle_after_warmup"]) < 1e-3 * abs(yuk_torch["energy_per_particle_after_warmup"]) + 1e-3
         sizes[tag] = {"lowered": fast, "generic": gen, "generic_over_lowered_time": gen["ms_per_step"] / fast["ms_per_step"],
                       "traced_yukawa_lj": yuk, "traced_morse": morse, "torch_yukawa_lj": yuk_torch,
                       "traced_binary_mixture": mix, "torch_binary_mixture": mix_torch,
+                      "traced_ionic": ion, "torch_ionic": ion_torch,
+                      "ionic_over_lowered_lj_time": ion["ms_per_step"] / fast["ms_per_step"],
+                      "torch_over_traced_ionic_time": ion_torch["ms_per_step"] / ion["ms_per_step"],
                       "mixture_over_lowered_lj_time": mix["ms_per_step"] / fast["ms_per_step"],
                       "torch_over_traced_mixture_time": mix_torch["ms_per_step"] / mix["ms_per_step"],
                       "traced_over_lowered_lj_time": yuk["ms_per_step"] / fast["ms_per_step"],
@@ -557,7 +588,8 @@ def run_generic_lj(args, htf, standin, dev):
                                "jittered lattices at rho 0.8442, r_cut %.1f, r_buff %.1f, NN %d, dt %g" % (rcut, args.rbuff, NN, args.dt)},
         "sizes": sizes,
         "traced_models": "written with htf.* ops outside the zoo (LJ + Yukawa; a masked Morse well; a Kob-Andersen binary LJ mixture whose "
-                         "epsilon / sigma are gathered by species pair from positions[:, 3] and nlist[:, :, 3]): traced, lowered to generated kernels "
+                         "epsilon / sigma are gathered by species pair from positions[:, 3] and nlist[:, :, 3]; LJ cores + erfc-damped electrostatics between "
+                         "two charged species): traced, lowered to generated kernels "
                          "(HTF_POT_JIT: hoomd_tf_amd/codegen.py -> hipcc --genco around csrc/jit_unit.hip), replayed as the one-kernel step",
         "note": "the generic route keeps the reference's arbitrary-model capability (htf/simmodel.py:87-121, 526-555); models made of "
                 "nlist_rinv polynomials, WCARepulsion, RBFExpansion + Dense stacks, EDS biases and compute_rdf are lowered to fused kernels",

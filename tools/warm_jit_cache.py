@@ -33,6 +33,8 @@ def bodies():
     idx = htf.cast(P[:, 3], torch.int32)[:, None] * 2 + htf.cast(x[:, :, 3], torch.int32)
     q = (htf.gather([1.0, 0.8, 0.8, 0.88], idx) * s) ** 6
     out.append(htf.reduce_sum(2.0 * htf.gather([1.0, 1.5, 1.5, 0.5], idx) * (q * q - q), axis=1).body())
+    qq = htf.gather([1.0, -1.0, -1.0, 1.0], idx)
+    out.append(htf.reduce_sum(2.0 * (s ** 12 - s ** 6) + 0.5 * 2.0 * qq * htf.erfc(0.35 * r) * s, axis=1).body())
     # tests/test_gpu_codegen.py: the three-species mixture of test_typed_model_is_replayed..., the random trees
     rng = np.random.default_rng(7)
     eps = rng.uniform(0.6, 1.4, (3, 3))
