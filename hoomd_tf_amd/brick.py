@@ -119,6 +119,12 @@ class BrickDomain:
                 raise ValueError("brick thinner than r_ghost along axis %d: ghosts would have to come from beyond the adjacent brick" % d)
         self.lo = np.array([self.bounds[d][coords[d]] for d in range(3)])
         self.hi = np.array([self.bounds[d][coords[d] + 1] for d in range(3)])
+        if self.replan_every > 1:
+            for d in self.axes:   # (the nearest image must be THE image: brick + ghost layer + drift margin within one period)
+                span = (self.hi[d] - self.lo[d]) + 2.0 * (self.r_ghost + (self.replan_every - 1) * self.r_buff)
+                if span > self.L[d]:
+                    raise ValueError("replan_every=%d needs brick + ghost layer + margin (%.2f) within the box length (%.2f) along axis %d"
+                                     % (self.replan_every, span, self.L[d], d))
         self.xlo, self.xhi = float(self.lo[0]), float(self.hi[0])
         self.offsets = _offsets(self.ndim)
         self.n_msg = len(self.offsets)
@@ -269,8 +275,11 @@ class BrickDomain:
         return b, tuple(per)
 
     def image_lengths(self):
-        """With a local grid: the logical box length along every decomposed axis (the period of the coordinates there), else zeros."""
-        return tuple(float(self.L[d]) if (self.local_grid and d in self.axes) else 0.0 for d in range(3))
+        """The logical box length along every decomposed axis -- the period of the coordinates there -- when the list may be binned on
+        rows that have drifted since the plan (a local grid and replan_every > 1: the binning then takes every coordinate as its image
+        nearest the grid); zeros otherwise (right after a re-plan every row and ghost already sits next to the brick)."""
+        on = self.local_grid and self.replan_every > 1
+        return tuple(float(self.L[d]) if (on and d in self.axes) else 0.0 for d in range(3))
 
     def _msg_takes_class(self, m, c):
         for k in range(self.ndim):

@@ -271,7 +271,7 @@ def test_brick_slabs_equal_slab_domain_bit_for_bit(htf, cuda, world, per_slab):
     _run_ranks(_slab_twin_worker, world, (per_slab,))
 
 
-def _brick_md_worker(rank, world, port, q, grid, cells, transport="torch"):
+def _brick_md_worker(rank, world, port, q, grid, cells, transport="torch", replan_every=1):
     """80 steps of LJ MD under a px x py cut (migration across both axes and the periodic edges, the halo overlapped with the
     interior rows), then every rank's forces against the single-domain forces of the gathered configuration."""
     try:
@@ -305,7 +305,8 @@ def _brick_md_worker(rank, world, port, q, grid, cells, transport="torch"):
         sysm = standin.System(pos[mine], L, types=np.arange(Ng)[mine], dtype=torch.float32, device=dev)
         sysm.vel = torch.from_numpy(vel[mine]).to(torch.float32).to(dev)
         nl = standin.CellNlist(sysm, r_cut=rcut, r_buff=rbuf, check_period=1)
-        dom = nl.domain = BrickDomain(sysm, rank, grid, r_ghost=rcut + rbuf, r_buff=rbuf, n_global=Ng, transport=transport)
+        dom = nl.domain = BrickDomain(sysm, rank, grid, r_ghost=rcut + rbuf, r_buff=rbuf, n_global=Ng, transport=transport,
+                                      replan_every=replan_every)
         nl.build()
         ctx = htf.Context(r_cut=rcut, nneighs=NN, scalar_dtype=torch.float32, max_n=sysm.N)
         pot = htf.Potential.lj()
@@ -321,6 +322,7 @@ def _brick_md_worker(rank, world, port, q, grid, cells, transport="torch"):
                 nve.step()
         torch.cuda.synchronize()
         assert nl.n_builds >= 2 and overlapped >= 20, (nl.n_builds, overlapped)
+        assert (dom.n_light > 0) == (replan_every > 1), dom.n_light
         c = dom.counts_host()
         assert int(c[_lib.BC_N_INT]) > 0                         # a 2-D cut keeps interior rows
         live = dom.live_rows()
@@ -367,6 +369,14 @@ def test_bricks_on_one_gpu(htf, cuda, grid, cells):
     """8 ranks as 4 x 2 (bricks 6.7 x 6.7 sigma against r_ghost 2.9: interior rows), 80 MD steps, forces ==
     single-domain (test_mpi_tensorflow.py:57-79, ``comm.decomposition(nx=4, ny=2)``)."""
     _run_ranks(_brick_md_worker, grid[0] * grid[1], (grid, cells))
+
+
+@pytest.mark.parametrize("grid,cells,transport", [((2, 2, 1), (10, 10, 5), "torch"), ((3, 1, 1), (12, 5, 5), "peer")])
+def test_bricks_with_fewer_replans(htf, cuda, grid, cells, transport):
+    """BrickDomain(replan_every=2) between PROCESSES sharing the GPU (kernels backend, the list on the local grid): every other
+    rebuild leaves rows and messages as they are -- rows that have left their brick, ghosts of rows that have left theirs, wrapped
+    through the periodic boundary or not -- and the forces after 80 MD steps still equal the single-domain ones."""
+    _run_ranks(_brick_md_worker, grid[0] * grid[1], (grid, cells, transport, 2))
 
 
 def _replica_md(htf, cuda, grid, transport, cells=6, period=4, replan_every=1):
