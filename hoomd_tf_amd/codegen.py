@@ -175,7 +175,10 @@ class _Emitter:
     def lit(v):
         if v != v or v in (float("inf"), float("-inf")):
             raise ValueError("non-finite constant in a traced pair energy")
-        return repr(float(np.float32(v))) + "f"   # ('2.0f', '1e-07f': repr of a float always carries a '.' or an exponent)
+        t = repr(float(np.float32(v))) + "f"      # ('2.0f', '1e-07f': repr of a float always carries a '.' or an exponent)
+        # a negative literal travels in parentheses: "-%s" of it would otherwise read "--2.0f" -- the decrement of an rvalue
+        # (neg, sub, abs and sigmoid of a negative constant or folded weight did not compile: ADVICE r5)
+        return "(%s)" % t if t.startswith("-") else t
 
     def emit(self, node):
         """-> (value, derivative with respect to r): C expressions naming temporaries; derivative None = identically zero."""

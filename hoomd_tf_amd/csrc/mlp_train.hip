@@ -532,24 +532,37 @@ __global__ __launch_bounds__(256, 1) void mlp_grad_mfma_kernel(const typename Ve
 // 64 columns x 8 slices of the partials per workgroup (a thread per column walking all 256 partials took 62 us, 2 % of the sweep):
 // slice sums in fixed order, slices combined in fixed order -> deterministic.
 constexpr unsigned kRedSlices = 8;
+// ``windows`` > 1 (the split16 sweep): `partial` holds that many groups of nwaves partials, group w scaled by
+// seed_scale(*resid_max) 2^(kWindowBits w); each group is summed as above, unscaled, and the groups added in order.
 __global__ __launch_bounds__(64 * kRedSlices) void mlp_reduce_partials_kernel(const float *__restrict__ partial, unsigned nwaves, unsigned stride,
                                                                               unsigned ncols, float *__restrict__ accum,
-                                                                              const float *__restrict__ resid_max) {
+                                                                              const float *__restrict__ resid_max, int windows) {
     __shared__ float part[kRedSlices][64];
     const unsigned col = threadIdx.x & 63u, slice = threadIdx.x >> 6;
     const unsigned c = blockIdx.x * 64 + col;
     const unsigned per = (nwaves + kRedSlices - 1) / kRedSlices;
     const unsigned w0 = slice * per, w1 = w0 + per < nwaves ? w0 + per : nwaves;
-    float s = 0.f;
-    if (c < ncols)
-        for (unsigned w = w0; w < w1; ++w) s += partial[(size_t)w * stride + c];
-    part[slice][col] = s;
-    __syncthreads();
-    if (slice != 0 || c >= ncols) return;
+    float total = 0.f;
+    for (int win = 0; win < windows; ++win) {
+        const float *pw = partial + (size_t)win * nwaves * stride;
+        float s = 0.f;
+        if (c < ncols)
+            for (unsigned w = w0; w < w1; ++w) s += pw[(size_t)w * stride + c];
+        __syncthreads();
+        part[slice][col] = s;
+        __syncthreads();
+        if (slice == 0 && c < ncols) {
 #pragma unroll
-    for (unsigned k = 1; k < kRedSlices; ++k) s += part[k][col];
-    if (resid_max && c > 0) s *= 1.0f / seed_scale(*resid_max); // a power of two: exact
-    accum[c] = s;
+            for (unsigned k = 1; k < kRedSlices; ++k) s += part[k][col];
+            if (resid_max && c > 0) {
+                const float R = *resid_max;
+                const float S = (R > 0.f && R < 3.0e38f) ? ldexpf(seed_scale(R), kWindowBits * win) : 1.0f;
+                s *= 1.0f / S; // a power of two: exact
+            }
+            total += s;
+        }
+    }
+    if (slice == 0 && c < ncols) accum[c] = total;
 }
 
 // partial slots of a launch: the VALU kernel writes one per wave (n_cu x 4, or the rows rounded up to a multiple of 4), the
@@ -572,13 +585,16 @@ static unsigned train_stride(const MlpDevice *m) { return ((unsigned)m->num_para
 // block partials | prediction [B, 4] (when the caller wants none back) | the largest residual of the launch (1 float + pad)
 size_t mlp_train_scratch_floats(const MlpDevice *m, unsigned B, unsigned NN) {
     if (!m) return 0;
-    return (size_t)train_slots(m, B, NN) * train_stride(m) + (size_t)B * 4 + 4;
+    // (the split16 sweep writes one group of partials per residual window)
+    const size_t groups = m->precision == HTF_MLP_SPLIT16 ? (size_t)kTrainWindows : 1;
+    return groups * train_slots(m, B, NN) * train_stride(m) + (size_t)B * 4 + 4;
 }
 
 int mlp_train_grad(const MlpDevice *m, const void *nlist, int in_dtype, unsigned B, unsigned NN, const void *labels,
                    int lab_f64, void *pred, float *accum, float *scratch, hipStream_t stream) {
     HTF_REQUIRE(m, "pair-MLP: null potential");
-    const unsigned nw = train_waves(m, B), slots = train_slots(m, B, NN), stride = train_stride(m);
+    const unsigned nw = train_waves(m, B), stride = train_stride(m);
+    const unsigned slots = train_slots(m, B, NN) * (m->precision == HTF_MLP_SPLIT16 ? (unsigned)kTrainWindows : 1u);
     (void)nw; // (the VALU kernel's wave count: variants builds)
     float *partial = scratch;
     float4 *predbuf = pred ? (float4 *)pred : (float4 *)(scratch + (size_t)slots * stride);
@@ -602,7 +618,7 @@ int mlp_train_grad(const MlpDevice *m, const void *nlist, int in_dtype, unsigned
         rc = mlp_train_grad16(m, nlist, in_dtype, B, NN, labels, lab_f64, predbuf, partial, stride, resid_max, &nblk, stream);
         if (rc != HTF_OK) return rc;
         hipLaunchKernelGGL(mlp_reduce_partials_kernel, dim3((ncols + 63) / 64), dim3(64 * kRedSlices), 0, stream, partial, nblk, stride,
-                           ncols, accum, resid_max);
+                           ncols, accum, resid_max, kTrainWindows);
         return check_launch("mlp_reduce_partials_kernel");
     }
     const bool fused = !force_valu && !no_fuse && (ntiles == 1 || ntiles == 2 || ntiles == 4);
@@ -631,7 +647,7 @@ int mlp_train_grad(const MlpDevice *m, const void *nlist, int in_dtype, unsigned
         rc = check_launch("mlp_grad_mfma_kernel");
         if (rc != HTF_OK) return rc;
         hipLaunchKernelGGL(mlp_reduce_partials_kernel, dim3((ncols + 63) / 64), dim3(64 * kRedSlices), 0, stream, partial, nblk, stride,
-                           ncols, accum, (const float *)nullptr);
+                           ncols, accum, (const float *)nullptr, 1);
         return check_launch("mlp_reduce_partials_kernel");
     }
 #ifdef HTF_AB_VARIANTS
@@ -652,7 +668,7 @@ int mlp_train_grad(const MlpDevice *m, const void *nlist, int in_dtype, unsigned
     rc = check_launch("mlp_grad_kernel");
     if (rc != HTF_OK) return rc;
     hipLaunchKernelGGL(mlp_reduce_partials_kernel, dim3((ncols + 63) / 64), dim3(64 * kRedSlices), 0, stream, partial, nw, stride,
-                       ncols, accum, (const float *)nullptr);
+                       ncols, accum, (const float *)nullptr, 1);
     return check_launch("mlp_reduce_partials_kernel");
 #else
     return HTF_OK; // (unreachable: force_valu is false in the shipped build)

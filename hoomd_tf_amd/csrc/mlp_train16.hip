@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256, 1) void mlp_grad_tr16_kernel(const typename Ve
                                                                const void *__restrict__ labels, int lab_f64,
                                                                const float4 *__restrict__ pred, const float *__restrict__ images,
                                                                MlpDims dm, float gap, const float *__restrict__ resid_max,
-                                                               float *__restrict__ partial, unsigned stride) {
+                                                               float *__restrict__ partial, unsigned stride, int window) {
     using I = Img<HTF_MLP_SPLIT16>;
     __shared__ __attribute__((aligned(16))) float lds[I::Floats];
     __shared__ __attribute__((aligned(16))) unsigned char trs[4 * kTrBlocks * kTrBlock];
@@ -211,7 +211,25 @@ __global__ __launch_bounds__(256, 1) void mlp_grad_tr16_kernel(const typename Ve
     const unsigned w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned gw = blockIdx.x * 4u + w, nw = gridDim.x * 4u;
     const float ginv = 1.0f / gap;
-    const float S = seed_scale(*resid_max);
+    // RESIDUAL WINDOWS (round 6).  Everything downstream of a pair's seeds travels as fp16 hi + lo, and the launch-wide power of
+    // two that puts the LARGEST seed into [1, 2) leaves a seed 2^-k of it with an absolute resolution of 2^-24 -- k bits short of
+    // fp32: one outlier row (a close contact under LJ labels: 10^5 x the median residual) cost the other million rows' gradient
+    // 0.5 % of its largest component (tools/train_size_probe.py, profiles/r06_train_size_probe_outlier.txt).  So a sweep is
+    // kTrainWindows launches: launch w takes the rows whose residual measure (mlp_resid_max_kernel's) lies in
+    // (R 2^-kWindowBits (w + 1), R 2^-kWindowBits w] -- the last one everything below -- with its own scale S 2^(kWindowBits w); the
+    // partials of a window are folded back with ITS scale (mlp_reduce_partials_kernel).  A row is swept exactly once.
+    const float Rmax = *resid_max;
+    const bool windowed = Rmax > 0.f && Rmax < 3.0e38f;     // (a NaN or zero maximum: one window takes every row, unscaled, as before)
+    const int eR = windowed ? ilogbf(Rmax) : 0;
+    const float S = windowed ? ldexpf(seed_scale(Rmax), kWindowBits * window) : 1.0f;
+    auto window_of = [&](const float4 &q) -> int {
+        if (!windowed) return 0;
+        const float a = 2.0f * sqrtf(q.x * q.x + q.y * q.y + q.z * q.z), b = fabsf(q.w);
+        const float v = a > b ? a : b;
+        if (!(v > 0.f)) return kTrainWindows - 1;
+        const int d = (eR - ilogbf(v)) / kWindowBits;
+        return d < 0 ? 0 : (d > kTrainWindows - 1 ? kTrainWindows - 1 : d);
+    };
     unsigned char *tr_phi = trs + w * (kTrBlocks * kTrBlock); // phi | phid
     unsigned char *tr_a = tr_phi + 2 * kTrBlock;               // h1[0] h1[1] hd1[0] hd1[1], then zb2[0] zb2[1] zdb2[0] zdb2[1]
     f16x8 ones;
@@ -248,11 +266,40 @@ __global__ __launch_bounds__(256, 1) void mlp_grad_tr16_kernel(const typename Ve
             ox = (float)v.x; oy = (float)v.y; oz = (float)v.z;
         }
     };
-    unsigned row = gw, chunk = 0;
+    // This wave's rows are gw, gw + nw, ...; the ones of THIS launch's window are found 64 candidates at a time (lane l looks at
+    // row base + l nw: its residual stays in the lane, a ballot says which are in the window) and handed out lowest first -- the
+    // residual by v_readlane, so that taking the next row costs no trip to memory.
+    float4 cand_rs = make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned long long cand_mask = 0ull, cand_base = gw;
+    auto refill = [&](unsigned long long base) {
+        const unsigned long long r64 = base + (unsigned long long)lane * nw;
+        const bool valid = r64 < (unsigned long long)B;
+        cand_rs = valid ? residual(pred, labels, lab_f64, (unsigned)r64) : make_float4(0.f, 0.f, 0.f, 0.f);
+        cand_mask = __ballot(valid && window_of(cand_rs) == window);
+        cand_base = base;
+    };
+    auto next_row = [&](float4 &out) -> unsigned {     // -> the next row of this wave in the window (B: none left), its residual
+        while (cand_mask == 0ull) {
+            const unsigned long long nb = cand_base + 64ull * nw;
+            if (nb >= (unsigned long long)B) return B;
+            refill(nb);
+        }
+        const int l = __builtin_ctzll(cand_mask);
+        cand_mask &= cand_mask - 1ull;
+        out.x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cand_rs.x), l));
+        out.y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cand_rs.y), l));
+        out.z = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cand_rs.z), l));
+        out.w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cand_rs.w), l));
+        return (unsigned)(cand_base + (unsigned long long)l * nw);
+    };
+    float4 rs = make_float4(0.f, 0.f, 0.f, 0.f), nrs = rs;
+    unsigned row = B, chunk = 0;
+    if ((unsigned long long)gw < (unsigned long long)B) {
+        refill(gw);
+        row = next_row(nrs);
+    }
     float nx, ny, nz;
     read_chunk(row, 0, nx, ny, nz);
-    float4 rs = make_float4(0.f, 0.f, 0.f, 0.f), nrs = rs;
-    if (row < B) nrs = residual(pred, labels, lab_f64, row);
     while (true) {
         if (tail - head < 32u && row < B) {
             // ---- stage one chunk of the current row
@@ -265,8 +312,7 @@ __global__ __launch_bounds__(256, 1) void mlp_grad_tr16_kernel(const typename Ve
             unsigned nrow = row, nchunk = chunk + 1;
             if (nchunk == nchunks) {
                 nchunk = 0;
-                nrow = row + nw;
-                if (nrow < B) nrs = residual(pred, labels, lab_f64, nrow);
+                nrow = next_row(nrs);
             }
             read_chunk(nrow, nchunk, nx, ny, nz);
             row = nrow;
@@ -574,11 +620,14 @@ int mlp_train_grad16(const MlpDevice *m, const void *nlist, int in_dtype, unsign
     const bool th = m->act == HTF_ACT_TANH;
 #define HTF_LAUNCH_TR16(T, IT, V4)                                                                                     \
     hipLaunchKernelGGL((mlp_grad_tr16_kernel<T, IT>), dim3(nblk), dim3(256), 0, stream, (const V4 *)nlist, B, NN, labels, \
-                       lab_f64, predbuf, m->images, dm, m->gap, resid_max, partial, stride)
-    if (in_dtype == HTF_F32) {
-        if (th) HTF_LAUNCH_TR16(true, float, float4); else HTF_LAUNCH_TR16(false, float, float4);
-    } else {
-        if (th) HTF_LAUNCH_TR16(true, double, double4); else HTF_LAUNCH_TR16(false, double, double4);
+                       lab_f64, predbuf, m->images, dm, m->gap, resid_max, partial + (size_t)win * nblk * stride, stride, win)
+    // one launch per residual window (see the kernel): window `win`'s block partials behind window win - 1's
+    for (int win = 0; win < kTrainWindows; ++win) {
+        if (in_dtype == HTF_F32) {
+            if (th) HTF_LAUNCH_TR16(true, float, float4); else HTF_LAUNCH_TR16(false, float, float4);
+        } else {
+            if (th) HTF_LAUNCH_TR16(true, double, double4); else HTF_LAUNCH_TR16(false, double, double4);
+        }
     }
 #undef HTF_LAUNCH_TR16
     *nblk_out = nblk;

@@ -125,8 +125,13 @@ __device__ __forceinline__ float seed_scale(float m) {
     return ldexpf(1.0f, e);
 }
 
+// The split16 sweep takes its rows in kTrainWindows launches by the size of their residual (windows of 2^kWindowBits below the
+// launch's largest, the last one open-ended), each with its own seed scale -- mlp_train16.hip.
+constexpr int kTrainWindows = 4;
+constexpr int kWindowBits = 6;
+
 // split16 potentials: prediction (evaluator), the launch's largest residual, the sweep; block partials land in `partial`
-// (nblk_out of them), still scaled by seed_scale(*resid_max)
+// (kTrainWindows x nblk_out of them, window by window), window w still scaled by seed_scale(*resid_max) 2^(kWindowBits w)
 int mlp_train_grad16(const MlpDevice *m, const void *nlist, int in_dtype, unsigned B, unsigned NN, const void *labels, int lab_f64,
                      float4 *predbuf, float *partial, unsigned stride, float *resid_max, unsigned *nblk_out, hipStream_t stream);
 int mlp_refresh(const MlpDevice *m, hipStream_t stream);

@@ -106,14 +106,17 @@ __global__ __launch_bounds__(1024) void check_disp_kernel(const typename Vec4<T>
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) {
-        const float worst = __uint_as_float(atomicExch(work, 0u)), cycle = out[1] + 1.0f;
+        // the cycle number is an unsigned WORD in the second slot (bit pattern, not a float value: as a float it stopped counting at
+        // 2^24 -- ten minutes of replayed cycles at 30 us per step).  The host compares modulo 2^32.
+        const float worst = __uint_as_float(atomicExch(work, 0u));
+        const unsigned cycle = __float_as_uint(out[1]) + 1u;
         out[0] = worst;
-        out[1] = cycle;
+        out[1] = __uint_as_float(cycle);
         work[1] = 0u;
         if (h_out != nullptr) {
             h_out[0] = worst;
             __threadfence_system();
-            *(volatile float *)(h_out + 1) = cycle;
+            *(volatile unsigned *)(h_out + 1) = cycle;
         }
     }
 }

@@ -672,6 +672,15 @@ class PairExpr(PairEnergy):
                 warnings.warn("hoomd_tf_amd: hipcc not found (set HIPCC): the traced pair energy runs as torch ops + autograd "
                               "instead of a generated kernel")
                 ok = False
+            if ok:
+                try:
+                    cg.compile_body(self.body())   # (cached: potential() finds the code object)
+                except RuntimeError as e:
+                    # the generated unit does not compile (an emitter bug, a broken toolchain): the model still runs, slower
+                    import warnings
+                    warnings.warn("hoomd_tf_amd: the generated kernel of a traced pair energy did not compile -- torch ops + autograd "
+                                  "instead (%s)" % str(e).splitlines()[0])
+                    ok = False
             self._lowers = ok
         return self._lowers
 
@@ -709,14 +718,58 @@ class PairExpr(PairEnergy):
         return v.sum(dim=1) if self.reduced else v
 
 
-class PairCond:
-    """A comparison of traced expressions: the condition of ``where`` / the argument of ``cast`` (no gradient)."""
+class PairCond(_TorchOperand):
+    """A comparison of traced expressions: the condition of ``htf.where`` / the argument of ``htf.cast`` (no gradient).  Symbolic
+    for those two; to torch code it is the bool tensor it stands for, as :class:`PairMask` is -- the reference's own per-type
+    masking is ``tf.equal(nlist[:, :, 3], type_j)`` fed to ordinary ops (simmodel.py:661-693 masked_nlist), so
+    ``torch.where(nlist[:, :, 3] == k, a, b)``, ``t[nlist[:, :, 3] == k]``, ``(nlist[:, :, 3] == k) & mask`` and ``.float()``
+    must keep working on the eager route."""
 
     def __init__(self, nlist, node, positions=None, folded=()):
         self.nlist, self.node, self.positions, self.folded = nlist, node, positions, tuple(folded)
         if nlist is None:
             raise TypeError("a comparison of positions[:, 3] alone is not a per-pair condition: bring the neighbor types in, or "
                             "use torch on the tensor")
+
+    __hash__ = object.__hash__
+
+    def tensor(self):
+        """The [N, NN] bool tensor: the node evaluated on the pair-vector buffer (codegen.evaluate, the arithmetic a generated
+        kernel would do per slot)."""
+        v = PairExpr(self.nlist, self.node, positions=self.positions).torch_value(self.nlist.tensor)
+        return v if v.dtype == torch.bool else v != 0
+
+    @property
+    def ad(self):
+        return self.tensor()
+
+    shape = property(lambda self: self.nlist.tensor.shape[:2])
+    dtype = property(lambda self: torch.bool)
+    device = property(lambda self: self.nlist.tensor.device)
+
+    def _other(self, o):
+        o = _unwrap(o)
+        return o if isinstance(o, torch.Tensor) else torch.as_tensor(o, device=self.nlist.tensor.device)
+
+    def __and__(self, o): return self.tensor() & self._other(o)
+    def __or__(self, o): return self.tensor() | self._other(o)
+    def __xor__(self, o): return self.tensor() ^ self._other(o)
+    __rand__, __ror__, __rxor__ = __and__, __or__, __xor__
+    def __invert__(self): return ~self.tensor()
+    def __getitem__(self, idx): return self.tensor()[idx]
+    def __mul__(self, o): return self.tensor().to(torch.float32) * _unwrap(o)
+    __rmul__ = __mul__
+    def to(self, *a, **k): return self.tensor().to(*a, **k)
+    def float(self): return self.tensor().float()
+    def double(self): return self.tensor().double()
+    def long(self): return self.tensor().long()
+    def int(self): return self.tensor().int()
+    def bool(self): return self.tensor()
+    def any(self, *a, **k): return self.tensor().any(*a, **k)
+    def all(self, *a, **k): return self.tensor().all(*a, **k)
+    def sum(self, *a, **k): return self.tensor().sum(*a, **k)
+    def nonzero(self, *a, **k): return self.tensor().nonzero(*a, **k)
+    def numpy(self): return self.tensor().cpu().numpy()
 
 
 def _sym(x):
@@ -876,9 +929,15 @@ def where(cond, a, b):
     """tf.where(cond, a, b) for model code: traced when the condition compares traced expressions."""
     from . import codegen as cg
     if isinstance(cond, PairCond):
-        ea, eb = PairExpr.of(a, cond.nlist), PairExpr.of(b, cond.nlist)
-        return PairExpr(cond.nlist, cg.Node("where", (cond.node, ea.node, eb.node)), positions=_first_positions(cond, ea, eb),
-                        folded=cond.folded + ea.folded + eb.folded)
+        try:
+            ea, eb = PairExpr.of(a, cond.nlist), PairExpr.of(b, cond.nlist)
+        except TypeError:
+            if not (isinstance(_unwrap(a), torch.Tensor) or isinstance(_unwrap(b), torch.Tensor)):
+                raise
+            ea = None      # a branch is a tensor of per-pair values: the condition becomes its bool tensor, torch from here on
+        if ea is not None:
+            return PairExpr(cond.nlist, cg.Node("where", (cond.node, ea.node, eb.node)), positions=_first_positions(cond, ea, eb),
+                            folded=cond.folded + ea.folded + eb.folded)
     return torch.where(_unwrap(cond), torch.as_tensor(_unwrap(a)), torch.as_tensor(_unwrap(b)))
 
 

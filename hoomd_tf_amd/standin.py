@@ -864,6 +864,7 @@ class BrickRun:
             self._mirror = m
         nl._mirrored = dom._mirrored = self._mirror is not None
         self._stat_host = torch.zeros(2, dtype=torch.float32).pin_memory()
+        self._stat_host_words = self._stat_host.view(torch.int32)
         self._rule = DeferredRebuildRule(nl.r_buff / 2.0)
         torch.cuda.synchronize()
         graphs = {}
@@ -895,13 +896,15 @@ class BrickRun:
         finished before it."""
         import time
         h = self._stat_host
+        hw = self._stat_host_words          # the same two words as integers: [bits of d2, cycle number (unsigned, wraps at 2^32)]
         spins, t0 = 0, None
-        while int(h[1]) < cycle:
+        # the device counter is compared modulo 2^32 (it is never more than one cycle behind what was launched)
+        while ((int(hw[1]) - cycle) & 0xFFFFFFFF) >= 0x80000000:
             spins += 1
             if spins % 4096 == 0:   # (a stuck device must not hold the host forever: HTF_BRICK_WAIT_S seconds, default 30)
                 t0 = t0 or time.monotonic()
                 if time.monotonic() - t0 > float(os.environ.get("HTF_BRICK_WAIT_S", "30")):
-                    raise RuntimeError("the device never reached cycle %d (last seen %d)" % (cycle, int(h[1])))
+                    raise RuntimeError("the device never reached cycle %d (last seen %d)" % (cycle, int(hw[1]) & 0xFFFFFFFF))
         d2 = float(h[0])
         # cycle - 1 is complete: what its rebuild (if any) reported
         self.dom._raise_flags(int(self.dom._flags_host[_lib.BC_FLAGS]))
@@ -931,12 +934,16 @@ class BrickRun:
                 self._read = self._launched
                 if self._read not in self._discard:
                     rule.push(float(np.sqrt(max(d2, 0.0))))
+                else:
+                    self._discard.discard(self._read)     # (read once: nothing older than _read is ever looked up again)
             rebuild = rule.decide()
             if rebuild:
                 rule.reset()
                 self._discard.add(self._launched + 1)   # that cycle's check runs BEFORE its rebuild: measured against the old reference
                 self.n_rebuild_cycles += 1
                 self._rebuilt_at.append(s.timestep)
+                if len(self._rebuilt_at) > 4096:           # (a report for tests and tools, not a log of a production-length run)
+                    del self._rebuilt_at[:2048]
                 self.nl.n_builds += 1
                 self.dom.n_rebuilds += 1
                 # which rebuild: the domain's own rule (every replan_every-th re-plans), kept in step with the eager path

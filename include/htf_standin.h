@@ -22,8 +22,8 @@ HTF_API int htfs_max_displacement2(const void *d_pos, const void *d_ref, int dty
                                    const htf_box *box, float *d_out, htf_stream stream);
 
 /* The same check for a replayed (hipGraph) cycle in ONE launch: d_work (2 words, zero before the first call and left zero by every
- * call) accumulates, the last workgroup publishes d_out[0] = the largest squared displacement and d_out[1] += 1 (the cycle number
- * as a float).  h_out (nullable; PINNED host memory, device-accessible) receives the same two words, the cycle number last behind
+ * call) accumulates, the last workgroup publishes d_out[0] = the largest squared displacement and d_out[1] += 1 (the cycle number:
+ * an UNSIGNED 32-bit word stored in the float slot's bits, compared modulo 2^32 by the host -- a float value stopped at 2^24).  h_out (nullable; PINNED host memory, device-accessible) receives the same two words, the cycle number last behind
  * a system-scope fence; `mirror` (nullable) lists up to HTFS_MIRROR_MAX word ranges the same workgroup copies from device to
  * pinned host memory BEFORE that -- status words earlier kernels left behind (htfs_brick counts, the list's largest row) -- so a
  * host that reads cycle c in h_out reads everything up to the end of cycle c - 1 beside it, without one copy node in the chain. */

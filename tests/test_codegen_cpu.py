@@ -26,7 +26,29 @@ def _models(htf, x):
         "ewald_real": 1.7 * htf.erfc(0.8 * r) * s,
         "switches": htf.sigmoid(4.0 * (2.0 - r)) * s ** 6 + 0.3 * htf.softplus(1.5 - r) * s + 0.1 * htf.erf(r - 1.0) * s ** 2,
         "friedel": htf.cos(2.2 * r + 0.3) * s ** 3 + 0.2 * htf.sin(1.1 * r) * s ** 2,
+        # negative constants as operands of neg / sub / abs / sigmoid ("-%s" of a literal read "--2.0f")
+        "negatives": (s ** 2 * (-htf.where(r < 1.5, -2.0, -0.5 * s)) + htf.sigmoid(htf.where(r < 2.0, -2.0, 1.0 * s)) * s
+                      - htf.abs(htf.where(r < 1.2, -3.0, s)) * s ** 3 - (-0.25) * s),
     }
+
+
+def test_negative_literals_are_parenthesised():
+    """unary minus, abs and sigmoid of a negative constant node emitted ``--2.0f`` (the decrement of an rvalue)."""
+    from hoomd_tf_amd import codegen as cg
+    for op in ("neg", "abs", "sigmoid", "square", "exp"):
+        body = cg.generate_body(cg.Node("mul", (cg.S, cg.Node(op, (cg.const(-2.0),)))))
+        assert "--" not in body and "(-2.0f)" in body, body
+    body = cg.generate_body(cg.Node("sub", (cg.S, cg.const(-2.0))))
+    assert "--" not in body
+    with tempfile.TemporaryDirectory() as tmp:
+        for k, op in enumerate(("neg", "abs", "sigmoid")):
+            src = os.path.join(tmp, "n%d.c" % k)
+            with open(src, "w") as f:
+                f.write(HARNESS.replace("BODY", cg.generate_body(cg.Node("mul", (cg.S, cg.Node(op, (cg.const(-2.0),)))))))
+            subprocess.check_call(["gcc", "-O1", "-o", os.path.join(tmp, "n%d" % k), src, "-lm"])
+            out = subprocess.run([os.path.join(tmp, "n%d" % k)], input="1.0 0.0 0.0\n", capture_output=True, text=True, check=True).stdout
+            want = {"neg": 2.0, "abs": 2.0, "sigmoid": 1.0 / (1.0 + np.exp(2.0))}[op]
+            assert abs(float(out.split()[0]) - want / (1.0 + 1e-7 + 3e-6)) < 1e-5, (op, out)
 
 
 HARNESS = r"""

@@ -145,3 +145,40 @@ def test_cast_mask_takes_part_in_arithmetic():
     assert torch.equal(torch.sum(m), want.sum())
     assert torch.equal(htf.cast(r < 2.0, torch.float64) * 3.0, want.double() * 3.0)
     assert htf.cast(r < 2.0).dtype == torch.bool and htf.cast(r < 2.0, torch.bool).dtype == torch.bool
+
+
+def test_neighbor_type_comparisons_are_tensors_to_torch_code():
+    """``nlist[:, :, 3] == k`` (simmodel.py:661-693 masks by ``tf.equal(nlist[:, :, 3], type_j)`` and feeds the result to
+    ordinary ops) stays symbolic for htf.where / htf.cast, and is the bool tensor it stands for to everything torch."""
+    import hoomd_tf_amd as htf
+    from hoomd_tf_amd.simmodel import PairCond
+    raw = _nl(3)
+    rng = np.random.default_rng(4)
+    raw[:, :, 3] = rng.integers(0, 3, raw.shape[:2]) * (np.abs(raw[:, :, :3]).sum(axis=2) > 0)
+    t = torch.from_numpy(raw)
+    nl = htf.Nlist(t)
+    want = t[:, :, 3] == 1
+    c = nl[:, :, 3] == 1
+    assert isinstance(c, PairCond) and c.shape == want.shape and c.dtype == torch.bool
+    a, b = torch.ones_like(t[:, :, 0]), torch.zeros_like(t[:, :, 0])
+    assert torch.equal(torch.where(c, a, b), torch.where(want, a, b))
+    assert torch.equal(c.float(), want.float()) and torch.equal(c.to(torch.float64), want.double())
+    assert torch.equal(a[c], a[want]) and torch.equal(t[:, :, 0][nl[:, :, 3] != 1], t[:, :, 0][~want])
+    other = t[:, :, 0] > 0
+    assert torch.equal(c & other, want & other) and torch.equal(other & c, want & other)
+    assert torch.equal(c | other, want | other) and torch.equal(~c, ~want) and torch.equal(c ^ other, want ^ other)
+    assert torch.equal(torch.logical_and(c, other), want & other) and int(c.sum()) == int(want.sum())
+    assert torch.equal((nl[:, :, 3] < 2).float(), (t[:, :, 3] < 2).float()) and torch.equal(c * 2.0, want.float() * 2.0)
+    # htf.where with tensor branches falls through to torch; with constants it stays a traced expression
+    assert torch.equal(htf.where(c, a, b), torch.where(want, a, b))
+    assert not isinstance(htf.where(c, 1.0, 0.0), torch.Tensor)
+    # a per-type masked energy written the reference's way (masked_nlist by hand) on the autograd route
+    r = torch.norm(nl[:, :, :3], dim=2)
+    e = torch.where(c & (r > 0), torch.exp(-r), torch.zeros_like(r))
+    f = htf.compute_nlist_forces(nl, e).detach().numpy()
+    nl2 = htf.Nlist(t.clone())
+    r2 = torch.norm(nl2[:, :, :3], dim=2)
+    e2 = torch.where(want & (r2 > 0), torch.exp(-r2), torch.zeros_like(r2))
+    f2 = htf.compute_nlist_forces(nl2, e2).detach().numpy()
+    assert np.abs(f2[:, :3]).max() > 0
+    np.testing.assert_array_equal(f, f2)

@@ -448,6 +448,31 @@ def _replay_body(htf, cuda, grid, transport, replan=1):
     assert out["eager"][4] == out["graph"][4] > 0
 
 
+def test_replay_counts_cycles_past_2_to_the_24(htf, cuda):
+    """the replayed cycle's counter was a float32 and stopped at 16 777 216 cycles -- ten minutes of a production run --
+    after which every run(graph=True) raised 'the device never reached cycle'.  It is an unsigned word now, compared modulo 2^32:
+    seeded just below 2^24 and just below 2^32, the replay keeps going and keeps deciding rebuilds."""
+    sysm, nl, run = _replica_md(htf, cuda, (8, 1, 1), "local", period=4)
+    run.run(40)
+    run.run(8 * 4, graph=True)
+    torch.cuda.synchronize()
+    for seed in ((1 << 24) - 3, (1 << 32) - 3):
+        # what the device and the host both believe: ``seed`` cycles done
+        torch.cuda.synchronize()
+        word = seed if seed < (1 << 31) else seed - (1 << 32)
+        run._stat.view(torch.int32)[1] = word
+        run._stat_host_words[1] = word
+        run._launched = run._read = seed
+        run._discard.clear()
+        b0 = run.n_rebuild_cycles
+        run.run(30 * 4, graph=True)
+        torch.cuda.synchronize()
+        assert run._launched == seed + 30 and run.n_rebuild_cycles - b0 >= 2
+        assert (int(run._stat_host_words[1]) & 0xFFFFFFFF) == (seed + 30) & 0xFFFFFFFF
+        assert len(run._discard) <= 2
+    nl.domain.counts_host()
+
+
 @pytest.mark.parametrize("grid", [(8, 1, 1), (4, 2, 1)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 def test_integrate_and_pack_in_one_launch(htf, cuda, grid, dtype):
@@ -505,6 +530,10 @@ def test_check_displacement_in_one_launch(dt):
     ref[:, :3] = (torch.rand((N, 3), dtype=torch.float64, device=DEV) * L - L / 2).to(dt)
     work = torch.zeros(2, dtype=torch.int32, device=DEV)
     out = torch.zeros(2, dtype=torch.float32, device=DEV)
+    # the cycle number is an unsigned word in the second slot's BITS (a float value stopped counting at 2^24: ADVICE r5) -- seeded
+    # just below 2^24 here, and in a second pass just below 2^32 (it wraps; the host compares modulo 2^32)
+    seed = (1 << 24) - 2
+    out.view(torch.int32)[1] = seed
     code = _lib.HTF_F32 if dt == torch.float32 else _lib.HTF_F64
     stream = C.c_void_p(raw_stream(0))
     h_out = torch.zeros(2, dtype=torch.float32).pin_memory()
@@ -527,10 +556,10 @@ def test_check_displacement_in_one_launch(dt):
                                                      C.byref(mirror) if cycle > 1 else None, stream))
         torch.cuda.synchronize()
         assert out[0].item() == one.item() and out[0].item() > 0
-        assert out[1].item() == float(cycle)
+        assert (int(out.view(torch.int32)[1].item()) & 0xFFFFFFFF) == seed + cycle       # 2^24 - 1, 2^24, 2^24 + 1, ...: every one distinct
         assert work.tolist() == [0, 0]
         if cycle % 2:      # the pinned words, written by the kernel itself
-            assert h_out.tolist() == out.tolist()
+            assert h_out.view(torch.int32).tolist() == out.view(torch.int32).tolist()
         if cycle > 1:      # and the status words it carried along
             assert torch.equal(h_status[:300], status[:300].cpu()) and torch.equal(h_status[300:301], status[777:778].cpu())
             assert int(h_status[301]) == -1

@@ -107,6 +107,97 @@ def _nobody_outside(dom, sysm, live, Lv, slack):
             "axis %d: a row at %.3f outside [%.3f, %.3f)" % (d, q[np.argmax(np.abs(q - mid))], dom.lo[d], dom.hi[d])
 
 
+IMAGES = ("ghosts that cross the periodic boundary are delivered NEXT TO the brick -- owner + box vector, rounded once in fp32, as HOOMD's "
+          "Communicator wraps its ghosts -- so a pair across that boundary is formed from x_j + L (ulp 1.9e-6 at |x| < 32) where the "
+          "undivided box forms (x_j - x_i) - L (ulp 3.8e-6 at |dx| ~ 53): two valid fp32 evaluations up to 5e-6 apart in |dx|, "
+          "times |df/dr| ~ 500 per first-shell pair")
+
+
+def _rank_arrays(sysm):
+    """What this rank's kernels see: [live local rows | live ghost rows] compacted -> (xyz fp32 [M, 3], particle ids [M], compact
+    index of every row of sysm.pos or -1)."""
+    P = sysm.pos.float().cpu().numpy()
+    alive = ~np.isnan(P[:, 0])
+    idx = np.nonzero(alive)[0]
+    where = -np.ones(len(P), dtype=np.int64)
+    where[idx] = np.arange(len(idx))
+    return np.ascontiguousarray(P[idx, :3]), np.ascontiguousarray(P[idx, 3]).view(np.int32).copy(), where
+
+
+def _sorted_r(pv64):
+    r = np.sqrt((pv64[:, :, :3] ** 2).sum(axis=2))
+    r[r == 0] = np.inf
+    return np.sort(r, axis=1)
+
+
+def _image_term(pair_forces, delta):
+    """-> f(pv64) = sum_j |f_ij(x_ij moved by delta along r) - f_ij(x_ij)| + 2 |f_ij| delta / r: how far a row's force can move when
+    every pair vector moves by ``delta`` (radial part by a finite difference of the model's own pair forces, transverse part from
+    their magnitude)."""
+    def term(pv64):
+        r = np.sqrt((pv64[:, :, :3] ** 2).sum(axis=2))
+        ok = r > 0
+        rs = np.where(ok, r, 1.0)
+        moved = pv64.copy()
+        moved[:, :, :3] *= (1.0 + delta / rs)[:, :, None]
+        f0, f1 = pair_forces(pv64)[:, :, :3], pair_forces(moved)[:, :, :3]
+        rad = np.sqrt(((f1 - f0) ** 2).sum(axis=2))
+        tra = 2.0 * np.sqrt((f0 ** 2).sum(axis=2)) * delta / rs
+        return np.where(ok, rad + tra, 0.0).sum(axis=1)
+    return term
+
+
+def _parity_both_ways(O, tag, sysm, rows, got, owner_pos, owner_of, period, Lbox, model, dev, cond_of, touches_boundary,
+                      image_term=None, tol=None, undivided=None):
+    """The three statements that together say "this rank computes the undivided box's forces":
+    A. forces of the sampled rows == O.compute_forces of THIS RANK'S OWN arrays (live locals + ghosts as delivered, a brute-force
+       list over them): the kernels, the list and the binning, at the stated tolerance (what upstream's test_mpi asserts: both of
+       its runs see the same wrapped ghosts, test_mpi_tensorflow.py:57-79);
+    B. the rank's arrays HOLD the undivided box: every live ghost is a periodic image of its owner's current position (to the one
+       fp32 rounding of the shift), and every sampled row's sorted neighbor distances below 2.999 equal the undivided box's;
+    C. forces == O.compute_forces of the undivided box directly -- as stated for a brick that does not touch the periodic
+       boundary, + the named image-rounding term where it does (IMAGES).
+    ``rows``: sampled row indices into sysm.pos; ``owner_pos`` [n, 3] fp32 / ``owner_of(ids)`` -> row of owner_pos: the undivided
+    box; ``period``: the lattice the images live on (box lengths; brick widths in replica mode); ``undivided``: (positions, gid of
+    the sampled rows) of the box the direct oracle runs on."""
+    from test_gpu_parity import LIQUID, assert_forces_close
+    tol = tol or {}
+    compact, ids, where = _rank_arrays(sysm)
+    ref_r, pv_r = _oracle_rows(O, compact, where[rows], Lbox, model, dev)
+    assert_forces_close(tag + "_own_arrays_energy", got[:, 3], ref_r[:, 3], **tol)
+    assert_forces_close(tag + "_own_arrays", got[:, :3], ref_r[:, :3], cond_of(pv_r), cancelling_rows=LIQUID, **tol)
+    # B: ghosts are images of their owners
+    n_loc = int((where[:sysm.N] >= 0).sum())
+    g_xyz, g_ids = compact[n_loc:].astype(np.float64), ids[n_loc:]
+    d = g_xyz - owner_pos[owner_of(g_ids)].astype(np.float64)
+    per = np.asarray(period, dtype=np.float64)
+    off = np.abs(d - np.round(d / per) * per)
+    # (one rounding of the shift, one of the sum, at the coordinates' own magnitude: ulp 3.8e-6 at 53.7, 3e-5 at the 430 of config 5)
+    ulps = 2.0 ** -23 * (per.max() + np.abs(g_xyz).max())
+    assert len(g_ids) > 0 and off.max() <= ulps, "a ghost is not a periodic image of its owner: off by %.3g (allowed %.3g)" % (off.max(), ulps)
+    all_u, gid_u = undivided
+    ref_u, pv_u = _oracle_rows(O, all_u, gid_u, Lbox, model, dev)
+    ru, rr = _sorted_r(pv_u), _sorted_r(pv_r)
+    n_in = (ru < 2.999).sum(axis=1)
+    assert n_in.min() > 40
+    for k in range(len(rows)):
+        assert np.abs(rr[k, :n_in[k]] - ru[k, :n_in[k]]).max() <= 2e-5, "row %d: the rank's arrays do not hold the undivided box's neighbors" % k
+        assert not np.isfinite(rr[k, n_in[k]:]).any() or rr[k, n_in[k]] >= 2.999 - 2e-5
+    # C: the undivided box's oracle, directly
+    cond_u = cond_of(pv_u)
+    if touches_boundary and image_term is not None:
+        extra = image_term(pv_u)
+        from test_gpu_parity import _record
+        err = np.abs(got[:, :3].astype(np.float64) - ref_u[:, :3])
+        strict = tol.get("atol", 1e-5) + tol.get("rtol", 2e-5) * np.abs(ref_u[:, :3]) + tol.get("ctol", 2e-6) * cond_u[:, None]
+        _record(tag + "_undivided_with_image_term", max_abs_err=err.max(), max_ratio_without_image_term=(err / strict).max(),
+                max_ratio_with_image_term=(err / (strict + extra[:, None])).max(), image_term_used=1.0)
+        assert np.all(err <= strict + extra[:, None]), (tag, (err / (strict + extra[:, None])).max())
+    else:
+        assert_forces_close(tag + "_undivided", got[:, :3], ref_u[:, :3], cond_u, cancelling_rows=LIQUID, **tol)
+    assert_forces_close(tag + "_undivided_energy", got[:, 3], ref_u[:, 3], **{k: v for k, v in tol.items() if k != "ctol"})
+
+
 def _c3_liquid(htf, dev, rank, steps=150):
     """The bench's own kind of configuration: rank 0 relaxes the jittered C3 lattice into a liquid at kT = 1 (force cap + velocity
     rescale, as bench.py's preparation) and hands every rank the same positions and velocities."""
@@ -197,14 +288,15 @@ def _headline_brick_worker(rank, world, port, q, grid, fractions, steps):
         dist.all_reduce(kT)
         kT = float(kT) / (3 * Ng)
         assert 0.85 < kT < 1.15, kT                                 # (the size-dependent bugs of round 5 showed here first: 0.98 -> 1.2)
-        # ---- the oracle on the undivided box, for 512 of this rank's live rows
+        # ---- 512 of this rank's live rows: the oracle on this rank's own arrays, the arrays against the undivided box, and the
+        # oracle on the undivided box directly (_parity_both_ways)
         pick = np.random.default_rng(100 + rank).choice(len(live), 512, replace=False)
-        ref, pv64 = _oracle_rows(O, allpos, my_ids[pick], Lv, O.lj_model, dev)
         got = sysm.force[live].cpu().numpy()[pick]
-        cond = _cond_scale(pv64, _pair_forces_lj(pv64))
         tag = "bricks%dx%dx%d%s_k2_c3_rank%d" % (grid + ("_uneven" if fractions else "", rank))
-        assert_forces_close(tag + "_energy", got[:, 3], ref[:, 3])
-        assert_forces_close(tag, got[:, :3], ref[:, :3], cond, cancelling_rows=LIQUID)
+        touches = any(dom.coords[d] in (0, grid[d] - 1) for d in dom.axes)
+        _parity_both_ways(O, tag, sysm, live.cpu().numpy()[pick], got, allpos, lambda i: i, Lv, Lv, O.lj_model, dev,
+                          lambda pv: _cond_scale(pv, _pair_forces_lj(pv)), touches, image_term=_image_term(_pair_forces_lj, 5e-6),
+                          undivided=(allpos, my_ids[pick]))
         # inert rows carry zero force
         inert = torch.ones(sysm.N, dtype=torch.bool, device=dev)
         inert[live] = False
@@ -322,11 +414,16 @@ def _replica_headline(htf, dev, grid, transport, replayed, tag):
     allp -= np.floor((allp + Lg / 2) / Lg) * Lg
     mine = int(np.nonzero((reps == coords).all(axis=1))[0][0])
     pick = np.random.default_rng(17).choice(nb, 512, replace=False)
-    ref, pv64 = _oracle_rows(O, allp.astype(np.float32), mine * nb + pick, Lg, O.lj_model, dev)
     got = sysm.force[live].cpu().numpy()[pick]
-    cond = _cond_scale(pv64, _pair_forces_lj(pv64))
-    assert_forces_close(tag + "_energy", got[:, 3], ref[:, 3])
-    assert_forces_close(tag, got[:, :3], ref[:, :3], cond, cancelling_rows=LIQUID)
+    own = sysm.pos[live, :3].float().cpu().numpy()
+    own_ids = sysm.pos[live, 3].contiguous().view(torch.int32).cpu().numpy()
+    row_of_id = np.empty(nb, dtype=np.int64)
+    row_of_id[own_ids] = np.arange(nb)
+    # (the images are built from positions wrapped into the logical box; the rank's own rows may sit a hair outside after the last
+    #  steps -- the periodic lattice of images is the same)
+    _parity_both_ways(O, tag, sysm, live.cpu().numpy()[pick], got, own, lambda i: row_of_id[i], Lb, Lg, O.lj_model, dev,
+                      lambda pv: _cond_scale(pv, _pair_forces_lj(pv)), True, image_term=_image_term(_pair_forces_lj, 5e-6),
+                      undivided=(allp.astype(np.float32), mine * nb + pick))
 
 
 @pytest.mark.parametrize("replayed", [False, True], ids=["eager", "replayed"])
@@ -348,7 +445,7 @@ def test_replica_bricks_at_full_brick_size(htf, cuda, grid, transport, replayed)
             "print('STATS ' + json.dumps({k: v for k, v in p.STATS.items() if k.startswith(%r)}))\n"
             % (ROOT, os.path.join(ROOT, "tests"), grid, transport, replayed, tag, tag))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=ROOT,
-                       env=dict(os.environ, HTF_BRICK_WAIT_S="20"))
+                       env=dict(os.environ, HTF_BRICK_WAIT_S="20", HTF_STATS_NO_FILE="1"))
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("STATS ")]
     assert r.returncode == 0 and lines, r.stdout[-1500:] + r.stderr[-3000:]
     for k, v in json.loads(lines[-1][6:]).items():
@@ -424,10 +521,21 @@ def _config5_worker(rank, world, port, q, md_steps):
             captured["gg"] = gg
             return out
 
-        ref, pv64 = _oracle_rows(O, allpos, my_ids[pick], Lg, model, dev)
         got = sysm.force[live].cpu().numpy()[pick]
         tag = "config5_8x131072_rank%d" % rank
-        assert_forces_close(tag, got, ref, np.abs(2 * captured["gg"]).sum(axis=(1, 2)), atol=2e-5, rtol=5e-5, ctol=5e-6)
+
+        def cond_of(pv):
+            model(pv)
+            return np.abs(2 * captured["gg"]).sum(axis=(1, 2))
+
+        def mlp_pair_forces(pv):
+            model(pv)
+            return 2.0 * captured["gg"]
+
+        # (the box is 430 long: coordinates carry ulps of 1.5e-5 - 3e-5 there, eight times the C3 box's)
+        _parity_both_ways(O, tag, sysm, live.cpu().numpy()[pick], got, allpos, lambda i: i, Lg, Lg, model, dev, cond_of,
+                          rank in (0, world - 1), image_term=_image_term(mlp_pair_forces, 4e-5), tol=dict(atol=2e-5, rtol=5e-5, ctol=5e-6),
+                          undivided=(allpos, my_ids[pick]))
         # ---- 5b: one force-matching step (tensorflowcompute.py:347-370 train_on_batch; labels = the LJ forces of this configuration,
         # example 06): sweep over this rank's rows -> all-reduce of [loss, 6 337 gradients] -> Adam on the device
         pv = ctx.nlist_buffer(sysm.N, dev)
@@ -453,21 +561,42 @@ def _config5_worker(rank, world, port, q, md_steps):
         acc_live = htf.ops.train_pair_grad(pot_before(htf, params), lp, labels[live].contiguous()).double().cpu().numpy()
         ma = mine_accum.double().cpu().numpy()
         assert abs(acc_live[0] - ma[0]) <= 1e-4 * abs(ma[0]) and np.abs(acc_live[1:] - ma[1:]).max() <= 2e-4 * np.abs(ma[1:]).max()
-        # the undivided box, single domain, on rank 0: the all-reduced [loss, gradient] == one sweep over all 1 048 576 rows
+        # the undivided box, single domain (every rank builds it: 1 048 576 rows, a 2 GiB pair-vector tensor): this rank's partial ==
+        # the sweep over the undivided box's rows of this rank's particles, and on rank 0 the all-reduced [loss, gradient] == ONE sweep
+        # over all 1 048 576 rows
         stats = {k: v for k, v in STATS.items() if k.startswith(tag)}
+        whole = standin.System(allpos.astype(np.float64), Lg, dtype=torch.float32, device=dev)
+        wnl = standin.CellNlist(whole, r_cut=RCUT, r_buff=RBUF)
+        wnl.build()
+        wpv = htf.ops.build_pair_vectors(whole.pos, wnl.n_neigh, wnl.head_list, wnl.nlist, whole.box, RCUT, NN)
+        wl = htf.ops.eval_forces(lj, wpv)
+        idx = torch.from_numpy(my_ids.astype(np.int64)).to(dev)
+        lab_err = float((labels[live] - wl[idx]).abs().max() / wl.abs().max())
+        part = htf.ops.train_pair_grad(pot_before(htf, params), wpv[idx].contiguous(), wl[idx].contiguous()).double().cpu().numpy()
+        pg = np.abs(part[1:]).max()
+        p_loss, p_grad = abs(part[0] - ma[0]) / part[0], np.abs(part[1:] - ma[1:]).max() / pg
+        stats["config5_train_rank%d_partial_vs_undivided_rows" % rank] = dict(loss_rel_err=p_loss, grad_err_over_max=p_grad, bound=2e-4,
+                                                                              label_err_over_max=lab_err)
+        assert p_loss <= 1e-4 and p_grad <= 2e-4, (rank, p_loss, p_grad, lab_err)
+        # the per-sweep tolerance carried through the 8-term sum: each partial is within 2e-4 max|g_r| of its rows' gradient, so the
+        # all-reduced gradient is within 2e-4 sum_r max|g_r| -- the partials largely CANCEL in the sum (|sum| << sum of |parts|)
+        scale = torch.tensor([pg], dtype=torch.float64)
+        dist.all_reduce(scale)
+        parts_sum = torch.from_numpy(part.copy())
+        dist.all_reduce(parts_sum)
         if rank == 0:
-            whole = standin.System(allpos.astype(np.float64), Lg, dtype=torch.float32, device=dev)
-            wnl = standin.CellNlist(whole, r_cut=RCUT, r_buff=RBUF)
-            wnl.build()
-            wpv = htf.ops.build_pair_vectors(whole.pos, wnl.n_neigh, wnl.head_list, wnl.nlist, whole.box, RCUT, NN)
-            wl = htf.ops.eval_forces(lj, wpv)
             wacc = htf.ops.train_pair_grad(pot_before(htf, params), wpv, wl).double().cpu().numpy()
             gmax = np.abs(wacc[1:]).max()
             assert wacc[0] > 0 and gmax > 0
             loss_err, grad_err = abs(acc_all[0] - wacc[0]) / wacc[0], np.abs(acc_all[1:] - wacc[1:]).max() / gmax
             stats["config5_train_allreduce_vs_single_domain"] = dict(loss_rel_err=loss_err, grad_err_over_max=grad_err, bound=2e-4,
                                                                      loss=wacc[0] / (4.0 * Ng))
-            assert loss_err <= 1e-4 and grad_err <= 2e-4, (loss_err, grad_err)
+            cancel = float(scale) / gmax
+            same_rows = np.abs(parts_sum.numpy()[1:] - wacc[1:]).max() / gmax      # (the undivided box's own rows, swept rank by rank)
+            stats["config5_train_allreduce_vs_single_domain"].update(sum_of_rank_maxima_over_max=cancel, grad_err_over_sum_of_rank_maxima=grad_err / cancel,
+                                                                     undivided_rows_by_rank_vs_one_sweep=same_rows)
+            assert loss_err <= 1e-4 and grad_err <= 2e-4 * cancel, (loss_err, grad_err, cancel, same_rows, p_grad)
+        del wpv, wl, whole, wnl
         dist.barrier()
         dist.destroy_process_group()
         q.put((rank, "ok", stats))

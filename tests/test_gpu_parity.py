@@ -26,6 +26,9 @@ STATS = {}
 
 def _record(name, **kw):
     STATS[name] = {k: float(v) for k, v in kw.items()}
+    import multiprocessing
+    if multiprocessing.current_process().name != "MainProcess" or os.environ.get("HTF_STATS_NO_FILE"):
+        return   # a rank process / child of a test: its records travel back to the test, which writes the file
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
     with open(os.path.join(out, "parity_stats.json"), "w") as f:

@@ -305,6 +305,49 @@ def test_pair_mlp_compaction_over_row_shapes(htf, cuda, NN, N):
     assert np.abs(a[1:] - b[1:]).max() < 1e-4 * np.abs(b[1:]).max()
 
 
+@pytest.mark.parametrize("outlier", [1e4, 1e6, 1e8])
+def test_pair_mlp_gradient_with_residuals_of_mixed_size(htf, cuda, outlier):
+    """Round 6 (found by the config-5 test at 1 048 576 rows): the split16 sweep scaled the seeds of a LAUNCH by one power of two,
+    taken from its largest residual -- a single outlier row (a close contact under LJ labels) 4e5 x the median pushed everybody
+    else's seeds into fp16's subnormals and cost the whole gradient 0.5 % of its largest component.  The sweep now takes its rows
+    in windows by residual size, each with its own scale: the gradient of a batch == the gradient of its outlier rows + the
+    gradient of the rest, each swept on its own (the sweep is linear in the residuals), to 1e-5 of the REST's largest component
+    + 2e-6 of the outliers'; and both against the fp32-MFMA sweep, which has no scale to lose."""
+    from hoomd_tf_amd import initializers
+    N, NN = 4096, 72
+    nl = _case(31, N=N, NN=NN)
+    params = initializers.mlp_params(seed=14)
+    theta = _flat_params(params)
+    x = torch.from_numpy(nl).to(cuda)
+    base = (0.05 * O.lj_model(nl.astype(np.float64))).astype(np.float32)
+    # residual sizes spread over four decades among the ordinary rows, three rows far above them
+    rng = np.random.default_rng(5)
+    base *= (10.0 ** rng.uniform(-2.0, 2.0, size=(N, 1))).astype(np.float32)
+    big = np.array([17, 1234, 4000])
+    scale = np.abs(base).max()
+    lab_all = base.copy()
+    lab_all[big] = (outlier * scale * rng.standard_normal((3, 4))).astype(np.float32)
+    w = torch.tensor(theta, dtype=torch.float32, device=cuda)
+    pot = htf.Potential.pair_mlp(params, 0.0, 3.0, activation="tanh", theta=w, precision="split16")
+    pred = htf.ops.eval_forces(pot, x)
+    # "the rest": the outlier rows' labels equal their prediction (zero residual); "the outliers": everybody else's do
+    lab_rest = torch.from_numpy(lab_all).to(cuda)
+    lab_rest[torch.from_numpy(big).to(cuda)] = pred[torch.from_numpy(big).to(cuda)]
+    lab_out = pred.clone()
+    lab_out[torch.from_numpy(big).to(cuda)] = torch.from_numpy(lab_all[big]).to(cuda)
+    g_all = htf.ops.train_pair_grad(pot, x, torch.from_numpy(lab_all).to(cuda)).double().cpu().numpy()
+    g_rest = htf.ops.train_pair_grad(pot, x, lab_rest).double().cpu().numpy()
+    g_out = htf.ops.train_pair_grad(pot, x, lab_out).double().cpu().numpy()
+    assert np.all(np.isfinite(g_all)) and np.abs(g_rest[1:]).max() > 0 and np.abs(g_out[1:]).max() > 1e2 * np.abs(g_rest[1:]).max()
+    err = np.abs(g_all[1:] - (g_rest[1:] + g_out[1:])).max()
+    assert err <= 1e-5 * np.abs(g_rest[1:]).max() + 2e-6 * np.abs(g_out[1:]).max(), (outlier, err, np.abs(g_rest[1:]).max(), np.abs(g_out[1:]).max())
+    np.testing.assert_allclose(g_all[0], g_rest[0] + g_out[0], rtol=1e-5)
+    w32 = torch.tensor(theta, dtype=torch.float32, device=cuda)
+    pot32 = htf.Potential.pair_mlp(params, 0.0, 3.0, activation="tanh", theta=w32, precision="fp32")
+    r32 = htf.ops.train_pair_grad(pot32, x, lab_rest).double().cpu().numpy()
+    assert np.abs(g_rest[1:] - r32[1:]).max() < 1e-4 * np.abs(r32[1:]).max()
+
+
 VARIANT_ROUTES = ("valu", "nofuse", "split16-fp32-sweep")
 
 
