@@ -1078,17 +1078,38 @@ def main():
         if world > 1:
             raise SystemExit("BASELINE configs[0] is a single-device plumbing case")
         return run_small(args, htf, standin, dev)
-    headline = args.workload == "lj" and world == 1 and not args.f64 and not args.two_kernel
+    headline = args.workload == "lj" and not args.f64 and not args.two_kernel
+    E.live = None
     out = run_md(args, E, args.workload, variants=not args.no_fused, cpu=not args.no_cpu_baseline)
-    if headline and not args.no_mlp and args.cells == 32:
-        # north_star: "LJ AND MLP pair-potential boxes": the same C3 system driven by the pair-MLP in its default
-        # precision (split16; the fp32-MFMA and bf16-split evaluators ride along as variants), a bounded number of steps
+    live = E.live          # the LJ run's objects, for the guarded multi-rank section below
+    if headline and not args.no_mlp and ((world == 1 and args.cells == 32) or (world > 1 and args.scaling == "strong")):
+        # north_star: "LJ AND MLP pair-potential boxes ... at 1/2/4/8": the same C3 system driven by the pair-MLP in its default
+        # precision (split16), a bounded number of steps -- on one GPU with the fp32-MFMA and bf16-split evaluators as variants,
+        # on N ranks the box cut as the LJ run cuts it (per-rank `roofline`: rank 0's share of the evaluator)
         import copy
         a2 = copy.copy(args)
         a2.steps, a2.warmup, a2.equil, a2.windows = min(args.steps, 40), min(args.warmup, 5), min(args.equil, 100), 1
-        sub = run_md(a2, E, "mlp", variants=not args.no_fused, cpu=not args.no_cpu_baseline)
-        out["mlp"] = {k: sub[k] for k in ("value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "kernels", "gpu_state",
-                                         "roofline", "fp32_variant", "split_variant", "cpu_baseline", "energy_per_particle") if k in sub}
+        sub = run_md(a2, E, "mlp", variants=not args.no_fused and world == 1, cpu=not args.no_cpu_baseline, keep_live=False)
+        out["mlp"] = {k: sub[k] for k in ("value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "dtype", "config", "kernels", "gpu_state",
+                                         "roofline", "fp32_variant", "split_variant", "cpu_baseline", "energy_per_particle", "kT_final") if k in sub}
+    if world > 1:
+        from benchlib import multirank
+        # who ran this: device uuid / PCI bus id per rank and what the process group says about itself
+        out["ranks"] = multirank.rank_table(E)
+        if live is not None and os.environ.get("HTF_BENCH_GUARDED", "1") != "0":
+            def emit(extra):
+                print(json.dumps(dict(out, **extra)))
+                sys.stdout.flush()
+            extra = multirank.guarded_section(E, live, out, emit)
+            nat = getattr(live["nl"].domain, "_native", None)
+            if nat is not None:
+                # what RCCL says about the library's communicator, rank by rank
+                mine = multirank.add_native_comm_info({"rank": rank}, nat)
+                table = [None] * world
+                E.dist.all_gather_object(table, mine)
+                for row, t in zip(out["ranks"], table):
+                    row["rccl_communicator"] = t.get("rccl_communicator")
+            out.update(extra)
     if rank == 0:
         print(json.dumps(out))
     if E.dist is not None:
@@ -1096,7 +1117,7 @@ def main():
         E.dist.destroy_process_group()
 
 
-def run_md(args, E, workload, variants=True, cpu=True):
+def run_md(args, E, workload, variants=True, cpu=True, keep_live=True):
     """One MD workload (lj | wca | mlp | mlp-split | mlp-bf16 | mlp-train) on this job's ranks -> the JSON record."""
     import copy
     args = copy.copy(args)
@@ -1737,6 +1758,9 @@ def run_md(args, E, workload, variants=True, cpu=True):
         out["cpu_baseline"] = cpu_baseline(sysm, nl, args)
     elif rank == 0:
         out["cpu_baseline"] = None
+    if keep_live and brick and closed_form and train is None:
+        # benchlib.multirank.guarded_section continues on this system (the native transport's self-test, the replayed step)
+        E.live = {"args": args, "sysm": sysm, "nl": nl, "ctx": ctx, "nve": nve, "brun": brun, "state": state, "step": step}
     return out
 
 

@@ -1,0 +1,240 @@
+"""What `bench.py --gpus N` adds to its line when N > 1, beside `value` (the eager loop over torch.distributed P2P, the safe
+default): a table that proves N RCCL ranks on N devices, and a GUARDED section that takes the decomposed step through the paths
+round 5 built -- the library's own RCCL transport checked against torch's ghosts between the real ranks, whole check periods
+replayed from hipGraphs with the exchange inside (standin.BrickRun), the direct-store `peer` transport -- none of which has ever
+run between two devices on this pool.  A failure or a hang there must cost only its own field, never the JSON line: every rank
+arms the same per-phase watchdog; when one fires, rank 0 prints the line as it stands with the phase's skip reason and every rank
+leaves (os._exit: no re-exec, no new process on a GPU-initialised one).
+
+north_star: "particle-domain decomposition across the 8 GPUs of one node uses RCCL over xGMI only for the ghost-particle halo";
+the exchange is what HOOMD's Communicator does for the reference (htf/TensorflowCompute.cc:143-148 reads the ghosts in place)."""
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+import torch
+
+
+def rank_table(E):
+    """Per rank: the device it computes on (uuid, PCI bus id, name), what its communicators say about themselves.  Gathered into
+    the line so that a scaling run can be audited from the JSON alone."""
+    dev = E.dev
+    props = torch.cuda.get_device_properties(dev)
+    rec = {"rank": E.rank, "local_device_index": dev.index, "device_name": props.name,
+           "device_uuid": str(getattr(props, "uuid", None)),
+           "pci": "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0), getattr(props, "pci_device_id", 0)),
+           "pid": os.getpid(), "backend": E.backend}
+    if E.dist is not None:
+        rec["process_group"] = {"backend": E.dist.get_backend(), "world_size": E.dist.get_world_size(), "rank": E.dist.get_rank()}
+    if E.dist is None:
+        return [rec]
+    table = [None] * E.world
+    E.dist.all_gather_object(table, rec)
+    return table
+
+
+def add_native_comm_info(table_entry, native):
+    """ncclCommCount / UserRank / CuDevice of the library's own communicator (csrc/halo.hip)."""
+    import ctypes as C
+    from hoomd_tf_amd import _lib
+    n, r, d = C.c_int(-1), C.c_int(-1), C.c_int(-1)
+    rc = _lib.lib.htf_halo_comm_info(native._h, C.byref(n), C.byref(r), C.byref(d))
+    table_entry["rccl_communicator"] = ({"nranks": n.value, "rank": r.value, "device": d.value} if rc == 0
+                                        else {"error": _lib.lib.htf_last_error().decode(errors="replace")})
+    return table_entry
+
+
+class PhaseWatchdog:
+    """arm(name, seconds) before a phase that may hang, disarm() behind it.  Every rank arms the same phases in the same order
+    (they are in lockstep at the barrier before each), so a hang is noticed by all of them within the same second: rank 0 prints
+    the line it has (``emit(reason)``), everybody exits with status 0."""
+
+    def __init__(self, rank, emit):
+        self.rank, self.emit = rank, emit
+        self._gen = 0
+        self._lock = threading.Lock()
+        self.fired = None
+
+    def arm(self, name, seconds):
+        with self._lock:
+            self._gen += 1
+            gen = self._gen
+        t = threading.Thread(target=self._wait, args=(gen, name, float(seconds)), daemon=True)
+        t.start()
+
+    def disarm(self):
+        with self._lock:
+            self._gen += 1
+
+    def _wait(self, gen, name, seconds):
+        t_end = time.monotonic() + seconds
+        while time.monotonic() < t_end:
+            time.sleep(0.05)
+            with self._lock:
+                if self._gen != gen:
+                    return
+        with self._lock:
+            if self._gen != gen:
+                return
+            self._gen = -1                       # (nothing may re-arm: we are leaving)
+        reason = "watchdog: phase %r did not finish within %.0f s" % (name, seconds)
+        self.fired = reason
+        try:
+            if self.rank == 0:
+                self.emit(reason)
+            else:
+                time.sleep(0.5)                  # (rank 0's line first)
+        finally:
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(0)
+
+
+def _same(a, b):
+    return bool(torch.equal(torch.isnan(a), torch.isnan(b)) and torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0)))
+
+
+def _agree(E, ok):
+    """Every rank learns whether EVERY rank got through the phase (a MIN all-reduce over the job's own process group)."""
+    t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float32, device=E.dev if E.backend == "nccl" else "cpu")
+    E.dist.all_reduce(t, op=E.dist.ReduceOp.MIN)
+    return bool(t.item() > 0.5)
+
+
+def _timed_replay(E, brun, steps, windows):
+    """`windows` windows of `steps` replayed steps, each bracketed by barrier + synchronize, max over the ranks."""
+    out = []
+    for _ in range(windows):
+        torch.cuda.synchronize()
+        E.dist.barrier()
+        t0 = time.perf_counter()
+        brun.run(steps, graph=True)
+        torch.cuda.synchronize()
+        E.dist.barrier()
+        el = time.perf_counter() - t0
+        t = torch.tensor([el], dtype=torch.float64, device=E.dev if E.backend == "nccl" else "cpu")
+        E.dist.all_reduce(t, op=E.dist.ReduceOp.MAX)
+        out.append(float(t.item()))
+    return out
+
+
+def guarded_section(E, live, out, emit):
+    """-> dict of fields for the line: `native_selftest`, `graph_variant`, `graph_variant_peer`, each a record or a named skip.
+    ``live``: the LJ run's objects as run_md left them (sysm, nl, ctx, nve, brun, state, args, step)."""
+    args, sysm, nl, brun, state = live["args"], live["sysm"], live["nl"], live["brun"], live["state"]
+    dom = nl.domain
+    P = nl.check_period
+    limit = float(os.environ.get("HTF_BENCH_PHASE_S", "60"))
+    res = {}
+    wd = PhaseWatchdog(E.rank, lambda why: emit(dict(res, guarded_section_ended_by=why)))
+    steps = max(args.steps, P) // P * P
+    windows = args.windows if args.windows > 0 else (5 if args.steps <= 50 else 1)
+
+    def phase(name, fn, seconds=limit):
+        """Run fn() on every rank under the watchdog; -> (ok on every rank, this rank's result or error text)."""
+        torch.cuda.synchronize()
+        E.dist.barrier()
+        wd.arm(name, seconds)
+        try:
+            val, err = fn(), None
+        except Exception as e:  # noqa: BLE001
+            val, err = None, "%s: %s" % (type(e).__name__, str(e).splitlines()[0] if str(e) else "")
+        ok = _agree(E, err is None)
+        wd.disarm()
+        if not ok and err is None:
+            err = "another rank failed in this phase"
+        return ok, (val if ok else err)
+
+    # ---- phase 1: the library's own RCCL communicator between the real ranks, its ghosts against the torch transport's
+    def native_selftest():
+        from hoomd_tf_amd import _lib
+        if not _lib.lib.htf_halo_available():
+            raise RuntimeError("librccl could not be loaded by libhtf_amd.so")
+        if E.backend != "nccl" and torch.cuda.device_count() < E.world:
+            raise RuntimeError("%d ranks share %d device(s) (a %s rehearsal): RCCL refuses two ranks on one device"
+                               % (E.world, torch.cuda.device_count(), E.backend))
+        dom.exchange_end()
+        dom._make_native()                         # collective: ncclCommInitRank on every rank
+        nat = dom._native
+        cap = dom.cap
+        bad = 0
+        for _ in range(20):
+            dom._native = None
+            live["step"]()                          # one MD step of the timed loop (torch transport): new positions
+            dom.exchange_end()
+            dom.exchange()
+            torch.cuda.synchronize()
+            want = sysm.pos[cap:].clone()
+            sysm.pos[cap:, :3] = float("nan")       # (what the native exchange must overwrite)
+            dom._native = nat
+            dom.exchange()
+            torch.cuda.synchronize()
+            bad += 0 if _same(want, sysm.pos[cap:]) else 1
+            dom._native = None
+        if bad:
+            raise RuntimeError("%d of 20 native exchanges delivered other ghosts than the torch transport" % bad)
+        dom._native = nat
+        return {"exchanges": 20, "bit_equal_to_torch_transport": True, "messages_per_exchange": dom.n_msg}
+
+    ok, val = phase("native-selftest", native_selftest)
+    if not ok:
+        dom._native = None                          # (the timed loop's transport stays as it was)
+    res["native_selftest"] = val if ok else {"skipped": val}
+    if not ok:
+        res["graph_variant"] = {"skipped": "needs transport 'native' (the all-reduced distance check and the exchanges inside the capture): " + str(val)}
+        res["graph_variant_peer"] = {"skipped": "needs the replayed step"}
+        return res
+
+    def replay(transport):
+        def fn():
+            dom.exchange_end()
+            dom.transport = transport
+            sysm.timestep = state["ts"]
+            brun._graphs = None
+            brun._arr = None
+            brun.run((-sysm.timestep) % P + 4 * P)                      # eager under this transport, ends on a check step
+            brun.run(max(args.warmup, 4 * P) // P * P, graph=True)     # capture + warm replays
+            w = _timed_replay(E, brun, steps, windows)
+            state["ts"] = sysm.timestep
+            torch.cuda.synchronize()
+            dom.counts_host()                                           # (raises on overflow / lost-particle / halo-timeout flags)
+            f = sysm.force
+            if not bool(torch.isfinite(f).all()):
+                raise RuntimeError("non-finite forces after the replay")
+            n_now = dom.n_local
+            t = torch.tensor([float(f[:, 3].double().sum()), float((sysm.vel[:, :3].double() ** 2).sum()), float(n_now)],
+                             dtype=torch.float64, device=E.dev if E.backend == "nccl" else "cpu")
+            E.dist.all_reduce(t)
+            el = float(np.median(w))
+            return {"note": "whole check periods of the decomposed step (check, halo, force rows, integrate-and-pack; migration + re-plan + "
+                            "list rebuild in the second graph) replayed from hipGraphs per rank, transport %r; same decisions as the eager loop" % transport,
+                    "halo": {"transport": transport}, "value": steps / el, "unit": "steps/s", "ms_per_step": el / steps * 1e3,
+                    "windows_ms_per_step": [x / steps * 1e3 for x in w], "rebuild_cycles": brun.n_rebuild_cycles, "dangerous_builds": brun.dangerous_builds,
+                    "energy_per_particle": float(t[0] / t[2]), "kT": float(t[1] / (3.0 * t[2])), "particles": int(t[2])}
+        return fn
+
+    ok, val = phase("graph-replay-native", replay("native"), seconds=2 * limit)
+    res["graph_variant"] = val if ok else {"skipped": val}
+    if not ok:
+        res["graph_variant_peer"] = {"skipped": "the replayed step did not run"}
+        return res
+
+    # ---- phase 3: the halo without a library call (brick.py transport "peer": stores into the neighbors' inboxes)
+    def make_peer():
+        dom.exchange_end()
+        dom._make_peer()                            # collective: inboxes allocated, IPC handles exchanged and mapped
+        return True
+
+    ok, val = phase("peer-mapping", make_peer)
+    if not ok:
+        res["graph_variant_peer"] = {"skipped": "inboxes could not be mapped between the ranks: " + str(val)}
+        dom.transport = "native"
+        return res
+    ok, val = phase("graph-replay-peer", replay("peer"), seconds=2 * limit)
+    if ok:
+        val["halo"]["inbox_memory"] = getattr(dom, "peer_memory", "coarse-grained (torch allocator)")
+    res["graph_variant_peer"] = val if ok else {"skipped": val}
+    return res

@@ -172,6 +172,7 @@ PROTOTYPES = {
     "htf_halo_exchange_end": (_i, [_vp, _vp]),
     "htf_halo_exchange_n": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i]),
     "htf_halo_allreduce_max_f32": (_i, [_vp, _vp, _u, _vp]),
+    "htf_halo_comm_info": (_i, [_vp, _vp, _vp, _vp]),
     "htf_profile_enable": (_i, [_vp, _i]),
     "htf_profile_read": (_i, [_vp, C.POINTER(_d), C.POINTER(_d), C.POINTER(_u)]),
 }
@@ -209,7 +210,7 @@ STANDIN_PROTOTYPES = {
 }
 
 
-ABI_VERSION = 3  # include/htf_amd.h HTF_AMD_ABI_VERSION: the struct layouts the ctypes Structures of this file mirror
+ABI_VERSION = 4  # include/htf_amd.h HTF_AMD_ABI_VERSION: the struct layouts the ctypes Structures of this file mirror
 
 
 def _load():

@@ -35,6 +35,9 @@ struct Rccl {
     int (*Recv)(void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
+    int (*CommCount)(ncclComm_t, int *) = nullptr;      // (queries: optional, htf_halo_comm_info)
+    int (*CommUserRank)(ncclComm_t, int *) = nullptr;
+    int (*CommCuDevice)(ncclComm_t, int *) = nullptr;
     bool ok = false;
     Rccl() {
         void *h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD); // torch's copy, if torch is in the process
@@ -50,6 +53,9 @@ struct Rccl {
         Recv = (decltype(Recv))dlsym(h, "ncclRecv");
         AllReduce = (decltype(AllReduce))dlsym(h, "ncclAllReduce");
         GetErrorString = (decltype(GetErrorString))dlsym(h, "ncclGetErrorString");
+        CommCount = (decltype(CommCount))dlsym(h, "ncclCommCount");
+        CommUserRank = (decltype(CommUserRank))dlsym(h, "ncclCommUserRank");
+        CommCuDevice = (decltype(CommCuDevice))dlsym(h, "ncclCommCuDevice");
         ok = GetUniqueId && CommInitRank && CommDestroy && GroupStart && GroupEnd && Send && Recv && AllReduce && GetErrorString;
     }
 };
@@ -119,6 +125,20 @@ extern "C" int htf_halo_create(const void *id128, int rank, int world, htf_halo 
         return HTF_ERR_DEVICE;
     }
     *out = h;
+    return HTF_OK;
+}
+
+extern "C" int htf_halo_comm_info(htf_halo *h, int *nranks, int *rank, int *device) {
+    using namespace htf;
+    HTF_REQUIRE(h && h->comm, "htf_halo_comm_info: null communicator");
+    HTF_REQUIRE(rccl().CommCount && rccl().CommUserRank && rccl().CommCuDevice, "htf_halo_comm_info: this librccl has no communicator queries");
+    int n = 0, r = 0, d = 0;
+    HTF_CHECK_NCCL(rccl().CommCount(h->comm, &n));
+    HTF_CHECK_NCCL(rccl().CommUserRank(h->comm, &r));
+    HTF_CHECK_NCCL(rccl().CommCuDevice(h->comm, &d));
+    if (nranks) *nranks = n;
+    if (rank) *rank = r;
+    if (device) *device = d;
     return HTF_OK;
 }
 

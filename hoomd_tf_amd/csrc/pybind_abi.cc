@@ -114,6 +114,7 @@ void bind(py::module &m, const char *name, R (*fn)(A...)) {
     X(htf_halo_exchange_end) \
     X(htf_halo_exchange_n) \
     X(htf_halo_allreduce_max_f32) \
+    X(htf_halo_comm_info) \
     X(htf_profile_enable) \
     X(htf_profile_read) \
     X(htfs_nve_step) \

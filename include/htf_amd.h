@@ -33,7 +33,7 @@ extern "C" {
  * caller's candidate-range table).  Every binding compares the value it was built against with
  * htf_abi_version() of the library it loaded and refuses a mismatch: hoomd_tf_amd/_lib.py, csrc/pybind_abi.cc,
  * integration/hoomd_shim/TensorflowComputeAMD.cc. */
-#define HTF_AMD_ABI_VERSION 3
+#define HTF_AMD_ABI_VERSION 4
 
 /* the library is built with -fvisibility=hidden (as the reference is,
  * htf/CMakeLists.txt:48); only these entry points are exported */
@@ -472,6 +472,9 @@ HTF_API int htf_halo_unique_id(void *id128);
 /* collective over the `world` ranks: ncclCommInitRank on the calling thread's current device */
 HTF_API int htf_halo_create(const void *id128, int rank, int world, htf_halo **out);
 HTF_API void htf_halo_destroy(htf_halo *halo);
+/* What RCCL itself says about the communicator (ncclCommCount / ncclCommUserRank / ncclCommCuDevice): the evidence a multi-rank
+ * bench line carries that N ranks really sit on N devices (ABI 4). */
+HTF_API int htf_halo_comm_info(htf_halo *halo, int *nranks, int *rank, int *device);
 /* Send pos[send_left_first, +send_left_count) to rank `left` and pos[send_right_first, +count) to rank `right`;
  * receive the right neighbor's left-going message into pos[recv_right_first, +count) and the left neighbor's
  * right-going one into pos[recv_left_first, +count) (element = Scalar4 of `dtype`).  Starts after everything

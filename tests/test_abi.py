@@ -23,7 +23,7 @@ def test_header_symbols_exported(htf):
         assert hasattr(raw, n), "libhtf_amd.so does not export %s" % n
     # and the python binding covers exactly the declared surface
     assert sorted(htf._lib.PROTOTYPES) == names
-    assert raw.htf_abi_version() == 3
+    assert raw.htf_abi_version() == 4
     standin = _declared_symbols("htf_standin.h")
     assert len(standin) >= 8 and sorted(htf._lib.STANDIN_PROTOTYPES) == standin
     for n in standin:
@@ -88,8 +88,8 @@ def test_pybind11_binding_exports_the_abi_and_runs_host_calls(htf):
         "from hoomd_tf_amd import _lib\n"
         "assert _lib.BINDING == 'pybind11' and type(_lib.lib).__name__ == '_PybindLib'\n"
         "names = list(_lib.PROTOTYPES) + list(_lib.STANDIN_PROTOTYPES)\n"
-        "assert all(hasattr(_lib.lib._mod, n) for n in names) and len(names) == 84\n"
-        "assert _lib.lib.htf_abi_version() == 3 == _lib.ABI_VERSION\n"
+        "assert all(hasattr(_lib.lib._mod, n) for n in names) and len(names) == 85\n"
+        "assert _lib.lib.htf_abi_version() == 4 == _lib.ABI_VERSION\n"
         "p = htf.Potential.rinv_poly([1.0, -0.5], [12, 6], cut=1.1)\n"
         "assert p.handle.value and p.num_params >= 2\n"
         "try:\n"

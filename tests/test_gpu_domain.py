@@ -483,6 +483,15 @@ def test_bench_starts_its_own_ranks(htf, cuda, args):
     assert -7.0 < d["energy_per_particle"] < -4.0 and 0.5 < d["kT_final"] < 1.5   # still the same liquid
     assert d["config"]["halo"]["ghosts_rank0"] > 0 and "BrickDomain" in d["config"]["halo"]["domain"]
     assert d["config"]["parallelism"] == ("dd" + args[3] if "--grid" in args else "dd%sx1x1" % args[1])
+    # who ran it, the MLP box beside the LJ box, and the guarded section's fields (a record or a NAMED skip)
+    assert len(d["ranks"]) == n and [r["rank"] for r in d["ranks"]] == list(range(n))
+    assert all(r["device_uuid"] and r["process_group"]["world_size"] == n for r in d["ranks"])
+    if not weak:
+        m = d["mlp"]
+        assert m["n_gpus"] == n and m["value"] > 0 and m["roofline"]["bound"] == "mfma" and 0.5 < m["kT_final"] < 1.5
+        assert m["config"]["parallelism"] == d["config"]["parallelism"] and m["config"]["halo"]["ghosts_rank0"] > 0
+    for key in ("native_selftest", "graph_variant", "graph_variant_peer"):
+        assert key in d and ("value" in d[key] or "exchanges" in d[key] or d[key].get("skipped")), (key, d.get(key))
 
 
 def _self_exchange():
