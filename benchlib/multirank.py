@@ -148,45 +148,41 @@ def guarded_section(E, live, out, emit):
             err = "another rank failed in this phase"
         return ok, (val if ok else err)
 
-    # ---- phase 1: the library's own RCCL communicator between the real ranks, its ghosts against the torch transport's
-    def native_selftest():
+    def selftest(transport, bring_up):
+        """20 MD steps of the timed loop (torch transport); after each, the ghosts ``transport`` delivers against the torch transport's."""
+        def fn():
+            dom.exchange_end()
+            bring_up()
+            nat = dom._native
+            cap = dom.cap
+            bad = 0
+            for _ in range(20):
+                dom._native, dom.transport = None, "torch"
+                live["step"]()                          # one MD step of the timed loop: new positions
+                dom.exchange_end()
+                dom.exchange()
+                torch.cuda.synchronize()
+                want = sysm.pos[cap:].clone()
+                sysm.pos[cap:, :3] = float("nan")       # (what the exchange under test must overwrite)
+                dom._native, dom.transport = (nat if transport == "native" else None), transport
+                dom.exchange()
+                torch.cuda.synchronize()
+                bad += 0 if _same(want, sysm.pos[cap:]) else 1
+            dom._native, dom.transport = None, "torch"
+            if bad:
+                raise RuntimeError("%d of 20 exchanges delivered other ghosts than the torch transport" % bad)
+            dom._native = nat
+            return {"exchanges": 20, "bit_equal_to_torch_transport": True, "messages_per_exchange": dom.n_msg}
+        return fn
+
+    def native_up():
         from hoomd_tf_amd import _lib
         if not _lib.lib.htf_halo_available():
             raise RuntimeError("librccl could not be loaded by libhtf_amd.so")
         if E.backend != "nccl" and torch.cuda.device_count() < E.world:
             raise RuntimeError("%d ranks share %d device(s) (a %s rehearsal): RCCL refuses two ranks on one device"
                                % (E.world, torch.cuda.device_count(), E.backend))
-        dom.exchange_end()
-        dom._make_native()                         # collective: ncclCommInitRank on every rank
-        nat = dom._native
-        cap = dom.cap
-        bad = 0
-        for _ in range(20):
-            dom._native = None
-            live["step"]()                          # one MD step of the timed loop (torch transport): new positions
-            dom.exchange_end()
-            dom.exchange()
-            torch.cuda.synchronize()
-            want = sysm.pos[cap:].clone()
-            sysm.pos[cap:, :3] = float("nan")       # (what the native exchange must overwrite)
-            dom._native = nat
-            dom.exchange()
-            torch.cuda.synchronize()
-            bad += 0 if _same(want, sysm.pos[cap:]) else 1
-            dom._native = None
-        if bad:
-            raise RuntimeError("%d of 20 native exchanges delivered other ghosts than the torch transport" % bad)
-        dom._native = nat
-        return {"exchanges": 20, "bit_equal_to_torch_transport": True, "messages_per_exchange": dom.n_msg}
-
-    ok, val = phase("native-selftest", native_selftest)
-    if not ok:
-        dom._native = None                          # (the timed loop's transport stays as it was)
-    res["native_selftest"] = val if ok else {"skipped": val}
-    if not ok:
-        res["graph_variant"] = {"skipped": "needs transport 'native' (the all-reduced distance check and the exchanges inside the capture): " + str(val)}
-        res["graph_variant_peer"] = {"skipped": "needs the replayed step"}
-        return res
+        dom._make_native()                              # collective: ncclCommInitRank on every rank
 
     def replay(transport):
         def fn():
@@ -209,6 +205,8 @@ def guarded_section(E, live, out, emit):
                              dtype=torch.float64, device=E.dev if E.backend == "nccl" else "cpu")
             E.dist.all_reduce(t)
             el = float(np.median(w))
+            dom.exchange_end()
+            dom.transport = "torch"                                     # (what the timed loop and the next self-test step with)
             return {"note": "whole check periods of the decomposed step (check, halo, force rows, integrate-and-pack; migration + re-plan + "
                             "list rebuild in the second graph) replayed from hipGraphs per rank, transport %r; same decisions as the eager loop" % transport,
                     "halo": {"transport": transport}, "value": steps / el, "unit": "steps/s", "ms_per_step": el / steps * 1e3,
@@ -216,25 +214,30 @@ def guarded_section(E, live, out, emit):
                     "energy_per_particle": float(t[0] / t[2]), "kT": float(t[1] / (3.0 * t[2])), "particles": int(t[2])}
         return fn
 
-    ok, val = phase("graph-replay-native", replay("native"), seconds=2 * limit)
-    res["graph_variant"] = val if ok else {"skipped": val}
+    # ---- the library's own RCCL communicator between the real ranks: its ghosts against the torch transport's, then the replay
+    ok, val = phase("native-selftest", selftest("native", native_up))
     if not ok:
-        res["graph_variant_peer"] = {"skipped": "the replayed step did not run"}
-        return res
+        dom._native, dom.transport = None, "torch"      # (the timed loop's transport stays as it was)
+    res["native_selftest"] = val if ok else {"skipped": val}
+    if ok:
+        ok, val = phase("graph-replay-native", replay("native"), seconds=2 * limit)
+        res["graph_variant"] = val if ok else {"skipped": val}
+        if not ok:
+            return res                                  # (a replay that failed half way leaves the ranks out of step: stop here)
+    else:
+        res["graph_variant"] = {"skipped": "transport 'native' is not available: " + str(val)}
 
-    # ---- phase 3: the halo without a library call (brick.py transport "peer": stores into the neighbors' inboxes)
-    def make_peer():
-        dom.exchange_end()
-        dom._make_peer()                            # collective: inboxes allocated, IPC handles exchanged and mapped
-        return True
-
-    ok, val = phase("peer-mapping", make_peer)
+    # ---- the halo, the migration messages and the distance check's all-reduce WITHOUT a library (brick.py transport "peer": stores
+    # into the neighbors' memory, csrc/brick.hip *_peer_kernel + csrc/mailbox.hip): mapping, self-test, replay
+    ok, val = phase("peer-selftest", selftest("peer", dom._make_peer))
     if not ok:
-        res["graph_variant_peer"] = {"skipped": "inboxes could not be mapped between the ranks: " + str(val)}
-        dom.transport = "native"
+        dom._native, dom.transport = dom._native, "torch"
+    res["peer_selftest"] = dict(val, inbox_memory=getattr(dom, "peer_memory", None)) if ok else {"skipped": val}
+    if not ok:
+        res["graph_variant_peer"] = {"skipped": "transport 'peer' is not available: " + str(val)}
         return res
     ok, val = phase("graph-replay-peer", replay("peer"), seconds=2 * limit)
     if ok:
-        val["halo"]["inbox_memory"] = getattr(dom, "peer_memory", "coarse-grained (torch allocator)")
+        val["halo"]["inbox_memory"] = getattr(dom, "peer_memory", None)
     res["graph_variant_peer"] = val if ok else {"skipped": val}
     return res

@@ -68,6 +68,21 @@ class Peer(C.Structure):
 MIRROR_MAX = 4
 
 
+MBOX_MAX_MSG, MBOX_MAX_RANKS, IPC_HANDLE_BYTES = 8, 64, 64   # include/htf_standin.h HTFS_MBOX_MAX_MSG / _MAX_RANKS, HTFS_IPC_HANDLE_BYTES
+
+
+class Mailbox(C.Structure):
+    """htfs_mailbox: one rank's view of a message channel between ranks (csrc/mailbox.hip)."""
+    _fields_ = [("remote", C.c_void_p * MBOX_MAX_MSG), ("remote_signal", C.c_void_p * MBOX_MAX_MSG), ("mine", C.c_void_p),
+                ("my_signal", C.c_void_p), ("state", C.c_void_p), ("spin_limit", C.c_uint), ("half_units", C.c_uint)]
+
+
+class ReduceBox(C.Structure):
+    """htfs_reduce_box: the all-to-all table of htfs_mailbox_allreduce_max_f32."""
+    _fields_ = [("remote", C.c_void_p * MBOX_MAX_RANKS), ("mine", C.c_void_p), ("state", C.c_void_p), ("spin_limit", C.c_uint),
+                ("world", C.c_int), ("rank", C.c_int)]
+
+
 class Mirror(C.Structure):
     """htfs_mirror (word ranges the check kernel's last workgroup copies from device to pinned host memory)."""
     _fields_ = [("src", C.c_void_p * MIRROR_MAX), ("dst", C.c_void_p * MIRROR_MAX), ("words", C.c_uint * MIRROR_MAX), ("n", C.c_uint)]
@@ -190,6 +205,14 @@ STANDIN_PROTOTYPES = {
     "htfs_brick_nve_halo_peer": (_i, [_vp, _vp, _vp, _vp, _i, _d, C.POINTER(Box), _vp, _vp, _vp]),
     "htfs_brick_pack_halo_peer": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "htfs_brick_unpack_halo": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
+    "htfs_shared_alloc": (_i, [_sz, _i, _vp]),
+    "htfs_shared_free": (_i, [_vp]),
+    "htfs_ipc_export": (_i, [_vp, _vp]),
+    "htfs_ipc_import": (_i, [_vp, _vp]),
+    "htfs_ipc_close": (_i, [_vp]),
+    "htfs_mailbox_push": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp]),
+    "htfs_mailbox_pull": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _u, _vp]),
+    "htfs_mailbox_allreduce_max_f32": (_i, [_vp, _vp, _vp, _u, _vp]),
     "htfs_slab_classify": (_i, [_vp, _i, _u, _vp, _i, _i, _d, _vp, _vp]),
     "htfs_segment_copy": (_i, [_vp, _vp, _u, _u, _vp, _vp, _vp, _vp]),
     "htfs_key_sort16": (_i, [_vp, _u, _vp, _vp, _vp, _vp]),

@@ -338,41 +338,128 @@ class BrickDomain:
             self._native = _NativeHalo.shared(self.rank, self.world, self.group)
 
     def _make_peer(self):
-        """Transport "peer": every rank owns an inbox ([2][ghost rows] Scalar4: two halves, by the exchange number's parity) and
-        signal words ({sequence, rows} per incoming message); the packing kernels of its NEIGHBORS store into them directly --
-        the same memory for a replica rank, an IPC mapping of it otherwise (torch's CUDA-IPC reductions: hipIpc handles travelling
-        through the process group) -- and htfs_brick_unpack_halo copies what has arrived into the ghost region.  No communication
-        library in the step; the migration messages of a rebuild keep travelling through torch.distributed."""
+        """Transport "peer": NO communication library anywhere in a run.  Every rank owns one block of device memory its
+        neighbors' kernels store into -- fine-grained (hipExtMallocWithFlags(hipDeviceMallocFinegrained): coherent between agents
+        while kernels run, what a mapping across xGMI wants; HTF_PEER_MEMORY=coarse: plain hipMalloc) -- holding
+        * the halo inbox ([2][ghost rows] Scalar4: two halves, by the exchange number's parity) and its signal words ({sequence,
+          rows} per incoming message): the packing kernels of its NEIGHBORS store into them, htfs_brick_unpack_halo copies what has
+          arrived into the ghost region (csrc/brick.hip *_peer_kernel);
+        * the migration mailbox ([2][migration rows] of 8 scalars) and its signal words: a re-plan's messages (csrc/mailbox.hip
+          htfs_mailbox_push / _pull -- until round 6 they travelled through torch.distributed / RCCL);
+        * the all-reduce table ([world][2] 8-byte words): the distance check's maximum over the ranks in one launch
+          (htfs_mailbox_allreduce_max_f32).
+        The block travels as a hipIpc handle through the process group at construction (the same memory for a replica rank); state
+        words stay local.  Everything is ordinary kernel work on ONE stream: whole check periods, re-plan included, capture into
+        hipGraphs (standin.BrickRun) with nothing but this transport."""
         s = self.sys
         if not self.kernels:
             raise ValueError("transport='peer' needs the kernels backend")
+        if getattr(self, "peer", None) is not None:
+            return
         dev, dt = s.pos.device, s.pos.dtype
-        self._peer_inbox = torch.zeros((2, self.n_ghost_cap, 4), dtype=dt, device=dev)
-        self._peer_signal = torch.zeros(2 * _lib.BRICK_MAX_MSG, dtype=torch.int32, device=dev)
-        self._peer_state = torch.zeros(4, dtype=torch.int32, device=dev)
+        esz = 4 * (8 if dt == torch.float64 else 4)                   # bytes of a Scalar4
+        world = self.world
+
+        def up(n, a=256):
+            return (int(n) + a - 1) // a * a
+        lay, off = {}, 0
+        for name, nbytes in (("inbox", 2 * self.n_ghost_cap * esz), ("signal", 2 * _lib.BRICK_MAX_MSG * 4),
+                             ("mig", 2 * self.mig_rows * 2 * esz), ("mig_signal", _lib.MBOX_MAX_MSG * 4),
+                             ("reduce", max(world, 1) * 2 * 8)):
+            lay[name] = off
+            off = up(off + nbytes)
+        self._peer_layout, total = lay, off
+        want_fine = os.environ.get("HTF_PEER_MEMORY", "fine") != "coarse"
+        ptr = C.c_void_p()
+        rc = _lib.lib.htfs_shared_alloc(total, 1 if want_fine else 0, C.byref(ptr))
+        self.peer_memory = "fine-grained (hipExtMallocWithFlags)" if want_fine else "coarse-grained (hipMalloc)"
+        if rc != 0 and want_fine:
+            why = _lib.last_error()
+            _lib.check(_lib.lib.htfs_shared_alloc(total, 0, C.byref(ptr)))
+            self.peer_memory = "coarse-grained (hipMalloc; the fine-grained allocation failed: %s)" % why
+        elif rc != 0:
+            _lib.check(rc)
+        self._peer_block = ptr.value
+        self._peer_state = torch.zeros(12, dtype=torch.int32, device=dev)   # halo [4] | migration [4] | all-reduce [4]
         torch.cuda.synchronize(dev)
-        self._peer_maps = {}
-        if self.replica:
-            theirs = {self.rank: (self._peer_inbox, self._peer_signal)}
-        else:
-            from torch.multiprocessing.reductions import reduce_tensor
-            mine = (reduce_tensor(self._peer_inbox), reduce_tensor(self._peer_signal))
-            everybody = [None] * self.world
-            dist.all_gather_object(everybody, mine, group=self.group)
-            theirs = {self.rank: (self._peer_inbox, self._peer_signal)}
-            for q in set(self.neighbors):
-                if q != self.rank:
-                    (fi, ai), (fs, as_) = everybody[q]
-                    theirs[q] = (fi(*ai), fs(*as_))      # the neighbor's memory, mapped into this process
-        self._peer_maps = theirs                          # (kept alive: the mappings)
+        blocks = {self.rank: self._peer_block}
+        self._peer_opened = []
+        if not self.replica and world > 1:
+            h = (C.c_char * _lib.IPC_HANDLE_BYTES)()
+            _lib.check(_lib.lib.htfs_ipc_export(self._peer_block, h))
+            everybody = [None] * world
+            dist.all_gather_object(everybody, (bytes(h.raw), os.getpid()), group=self.group)
+            for q in range(world):                       # (the all-reduce table is all-to-all: every rank maps every block)
+                if q == self.rank:
+                    continue
+                raw, pid = everybody[q]
+                if pid == os.getpid():
+                    raise RuntimeError("two ranks in one process cannot map each other's memory through IPC")
+                p = C.c_void_p()
+                _lib.check(_lib.lib.htfs_ipc_import((C.c_char * _lib.IPC_HANDLE_BYTES).from_buffer_copy(raw), C.byref(p)))
+                blocks[q] = p.value
+                self._peer_opened.append(p.value)
+        self._peer_blocks = blocks
+        spin = int(os.environ.get("HTF_PEER_SPIN", str(1 << 22)))   # x ~1 us a poll: seconds (ranks start skewed), then a FLAG -- never a hang
+        st = self._peer_state.data_ptr()
         pr = self.peer = _lib.Peer()
+        mb = self.mailbox = _lib.Mailbox()
         for m in range(self.n_msg):
-            inbox, signal = theirs[self.neighbors[m]]
-            pr.inbox[m], pr.signal[m] = inbox.data_ptr(), signal.data_ptr()
-        pr.my_inbox, pr.my_signal, pr.state = self._peer_inbox.data_ptr(), self._peer_signal.data_ptr(), self._peer_state.data_ptr()
-        pr.spin_limit = int(os.environ.get("HTF_PEER_SPIN", str(1 << 22)))   # x ~1 us a poll: seconds (ranks start skewed), then HALO_TIMEOUT -- never a hang
-        if not self.replica:
-            dist.barrier(group=self.group)               # nobody stores into an inbox that is not mapped everywhere yet
+            base = blocks[self.neighbors[m]]
+            pr.inbox[m], pr.signal[m] = base + lay["inbox"], base + lay["signal"]
+            mb.remote[m] = base + lay["mig"]
+            mb.remote_signal[m] = base + lay["mig_signal"] + 4 * self._opposite(m)   # my message m is its message from offset -m
+        pr.my_inbox, pr.my_signal, pr.state = self._peer_block + lay["inbox"], self._peer_block + lay["signal"], st
+        pr.spin_limit = spin
+        mb.mine, mb.my_signal, mb.state = self._peer_block + lay["mig"], self._peer_block + lay["mig_signal"], st + 16
+        mb.spin_limit = spin
+        unit_rows = 2 * esz // 16                                    # 16-byte units per migration row (position + velocity)
+        mb.half_units = self.mig_rows * unit_rows
+        U = C.c_uint * _lib.MBOX_MAX_MSG
+        # message m: rows [mig_off[m], + mig_cap[m]) of mig_send -> the region of source offset -m in the receiver's mailbox, which is
+        # where the receiver's pull finds "the message from the neighbor at offset index j = opposite(m)": rows [mig_off[j], ...)
+        self._mb_send_off = U(*[self.mig_off[m] * unit_rows for m in range(self.n_msg)])
+        self._mb_units = U(*[self.mig_cap[m] * unit_rows for m in range(self.n_msg)])
+        self._mb_box_off = U(*[self.mig_off[self._opposite(m)] * unit_rows for m in range(self.n_msg)])
+        self._mb_recv_off = U(*[self.mig_off[j] * unit_rows for j in range(self.n_msg)])
+        self._mb_recv_box = U(*[self.mig_off[j] * unit_rows for j in range(self.n_msg)])
+        self._mb_row_units = unit_rows
+        for m in range(self.n_msg):
+            if self.mig_cap[m] != self.mig_cap[self._opposite(m)]:
+                raise RuntimeError("migration capacities are not symmetric")   # (they are global: the largest brick's)
+        rb = self.reduce_box = _lib.ReduceBox()
+        ranks = [self.rank] if self.replica else list(range(world))
+        for k, q in enumerate(ranks):
+            rb.remote[k] = blocks[q] + lay["reduce"]
+        rb.mine, rb.state, rb.spin_limit = self._peer_block + lay["reduce"], st + 32, spin
+        rb.world, rb.rank = len(ranks), (0 if self.replica else self.rank)
+        if not self.replica and world > 1:
+            dist.barrier(group=self.group)               # nobody stores into a block that is not mapped everywhere yet
+
+    def __del__(self):
+        try:
+            for p in getattr(self, "_peer_opened", []):
+                _lib.lib.htfs_ipc_close(p)
+            if getattr(self, "_peer_block", None):
+                _lib.lib.htfs_shared_free(self._peer_block)
+                self._peer_block = None
+        except Exception:  # noqa: BLE001  (interpreter teardown)
+            pass
+
+    def allreduce_max(self, value):
+        """value[0] <- its maximum over the ranks, on the current stream: the library's RCCL communicator (transport "native") or one
+        launch through the peers' tables (transport "peer"); None when this domain has no device-side all-reduce of its own."""
+        if self._native is not None and self.transport != "peer":
+            self._native.allreduce_max(value)
+            return True
+        if getattr(self, "reduce_box", None) is not None and self.transport == "peer":
+            _lib.check(_lib.lib.htfs_mailbox_allreduce_max_f32(C.byref(self.reduce_box), value.data_ptr(), self.counts.data_ptr() + 4 * _lib.BC_FLAGS,
+                                                               _lib.BF_HALO_TIMEOUT, self._stream()))
+            return True
+        if self._native is not None:
+            self._native.allreduce_max(value)
+            return True
+        return None
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.sys.pos.device).cuda_stream)
@@ -496,8 +583,17 @@ class BrickDomain:
             g, w = C.byref(self.geom), C.byref(self.work)
             _lib.check(_lib.lib.htfs_brick_migrate_pack(g, s.pos.data_ptr(), s.vel.data_ptr(), s.scalar_code, self._bounds_dev.data_ptr(),
                                                         w, self.mig_send.data_ptr(), self.counts.data_ptr(), self._stream()))
-            for wk in self._exchange(self.mig_send, self.mig_recv, self.mig_cap, self.mig_off, TAG_BASE):
-                wk.wait()
+            if self.transport == "peer":
+                # the migration messages through the neighbors' mailboxes (csrc/mailbox.hip): two launches, no library call
+                mb = C.byref(self.mailbox)
+                _lib.check(_lib.lib.htfs_mailbox_push(mb, self.n_msg, self.mig_send.data_ptr(), self._mb_send_off, self._mb_units,
+                                                      self._mb_box_off, self._mb_row_units, self._stream()))
+                _lib.check(_lib.lib.htfs_mailbox_pull(mb, self.n_msg, self.mig_recv.data_ptr(), self._mb_recv_off, self._mb_units,
+                                                      self._mb_recv_box, self._mb_row_units, self.counts.data_ptr() + 4 * _lib.BC_FLAGS,
+                                                      _lib.BF_HALO_TIMEOUT, self._stream()))
+            else:
+                for wk in self._exchange(self.mig_send, self.mig_recv, self.mig_cap, self.mig_off, TAG_BASE):
+                    wk.wait()
             _lib.check(_lib.lib.htfs_brick_migrate_merge(g, s.pos.data_ptr(), s.vel.data_ptr(), s.scalar_code, self._bounds_dev.data_ptr(),
                                                          w, self.mig_recv.data_ptr(),
                                                          self._n_neigh.data_ptr() if self._n_neigh is not None else None,

@@ -139,6 +139,14 @@ void bind(py::module &m, const char *name, R (*fn)(A...)) {
     X(htfs_brick_pack_halo) \
     X(htfs_brick_nve_halo) \
     X(htfs_brick_nve_halo_peer) \
+    X(htfs_shared_alloc) \
+    X(htfs_shared_free) \
+    X(htfs_ipc_export) \
+    X(htfs_ipc_import) \
+    X(htfs_ipc_close) \
+    X(htfs_mailbox_push) \
+    X(htfs_mailbox_pull) \
+    X(htfs_mailbox_allreduce_max_f32) \
     X(htfs_brick_pack_halo_peer) \
     X(htfs_brick_unpack_halo)
 

@@ -438,7 +438,9 @@ class CellNlist:
                 self._rule.push(self._dd_prev)
             self._dd_prev = now
         else:
-            if not alone:
+            if not alone and getattr(self.domain, "transport", None) == "peer":
+                self.domain.allreduce_max(buf)   # one launch through the peers' tables: no library in the step (csrc/mailbox.hip)
+            elif not alone:
                 work = dist.all_reduce(buf, op=dist.ReduceOp.MAX, group=self.domain.group, async_op=True)
                 work.wait()  # (RCCL: the current stream waits for the collective; the host does not)
             host = self._dd_host[self._dd_i % 3]
@@ -818,7 +820,7 @@ class BrickRun:
                                            C.byref(self._mirror) if self._mirror is not None else None,
                                            C.c_void_p(raw_stream(s.device.index))))
         if not alone:
-            self.dom._native.allreduce_max(self._stat[0:1])
+            self.dom.allreduce_max(self._stat[0:1])     # RCCL on the captured stream ("native"), or one launch through the peers' tables ("peer")
         if not alone or self._mirror is None:
             self._stat_host.copy_(self._stat, non_blocking=True)
 
@@ -843,9 +845,9 @@ class BrickRun:
         s, nl, dom = self.sys, self.nl, self.dom
         if not dom.kernels or dom.transport not in ("native", "local", "peer"):
             raise ValueError("graph replay needs the kernels backend and the 'native' (RCCL inside the capture), 'peer' or 'local' transport")
-        if dom.world > 1 and dom._native is None:
-            raise ValueError("graph replay over real ranks needs the library's own RCCL communicator for the all-reduced distance check "
-                             "and the migration messages (transport='native'; never run between two devices on this pool)")
+        if dom.world > 1 and dom._native is None and dom.transport != "peer":
+            raise ValueError("graph replay over real ranks needs a device-side all-reduce of the distance check and capturable migration "
+                             "messages: transport='native' (the library's own RCCL communicator) or 'peer' (no library at all)")
         if nl.n_builds < 2:
             raise RuntimeError("run a few eager steps through a rebuild first (RCCL connects and pinned buffers are made outside a capture)")
         dom.exchange_end()

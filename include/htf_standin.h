@@ -263,6 +263,50 @@ HTF_API int htfs_brick_nve_halo(const htfs_brick *g, void *d_pos, void *d_vel, c
 HTF_API int htfs_brick_nve_halo_peer(const htfs_brick *g, void *d_pos, void *d_vel, const void *d_force, int dtype, double dt,
                                      const htf_box *box, const unsigned *d_counts, const htfs_peer *peer, htf_stream stream);
 
+/* ---- messages between ranks without a communication library (csrc/mailbox.hip): the migration messages of a re-plan and the
+ * all-reduced distance check of transport "peer", so that every graph of a decomposed run is library-free.  Memory a neighbor's
+ * kernels store into is allocated here -- fine-grained (hipExtMallocWithFlags(hipDeviceMallocFinegrained): coherent between
+ * agents while kernels run, what a mapping across xGMI wants) or ordinary -- zeroed, and travels as a hipIpc handle. */
+#define HTFS_IPC_HANDLE_BYTES 64
+#define HTFS_MBOX_MAX_MSG 8
+#define HTFS_MBOX_MAX_RANKS 64
+HTF_API int htfs_shared_alloc(size_t bytes, int finegrained, void **out);
+HTF_API int htfs_shared_free(void *p);
+HTF_API int htfs_ipc_export(const void *p, void *handle64);          /* HTFS_IPC_HANDLE_BYTES bytes */
+HTF_API int htfs_ipc_import(const void *handle64, void **out);        /* maps another process's allocation on the current device */
+HTF_API int htfs_ipc_close(void *p);
+/* One rank's view of a message channel.  Units are 16 bytes.  Every rank owns a mailbox of [2][half_units] units (two halves, by
+ * the exchange number's parity) and one signal word per incoming message; message m of an exchange is stored at box_off[m] of the
+ * receiver's half and its number published to remote_signal[m].  All ranks perform the same sequence of exchanges. */
+typedef struct htfs_mailbox {
+    void *remote[HTFS_MBOX_MAX_MSG];             /* message m's destination: the receiver's mailbox base */
+    unsigned *remote_signal[HTFS_MBOX_MAX_MSG];  /* ... and the receiver's signal word for it */
+    void *mine;                                  /* this rank's mailbox, */
+    unsigned *my_signal;                         /* its signal words [n_msg], */
+    unsigned *state;                             /* and [4]: exchanges done, workgroups finished, timeouts seen, spare */
+    unsigned spin_limit;
+    unsigned half_units;
+} htfs_mailbox;
+/* message m = units [send_off[m], + units[m]) of d_send -> box_off[m] of its receiver's mailbox.  row_units > 0: a message is rows
+ * of that many units whose row 0 starts with its row count -- only row 0 and that many rows travel. */
+HTF_API int htfs_mailbox_push(const htfs_mailbox *mb, int n_msg, const void *d_send, const unsigned *send_off, const unsigned *units,
+                              const unsigned *box_off, int row_units, htf_stream stream);
+/* the receiving half: message j of THIS exchange (its units at box_off[j] of my mailbox) -> units [recv_off[j], ...) of d_recv, behind
+ * a bounded wait for its number; a message that does not arrive is delivered EMPTY (row count 0) and *d_flags |= flag_bit. */
+HTF_API int htfs_mailbox_pull(const htfs_mailbox *mb, int n_msg, void *d_recv, const unsigned *recv_off, const unsigned *units,
+                              const unsigned *box_off, int row_units, unsigned *d_flags, unsigned flag_bit, htf_stream stream);
+/* d_value[0] <- max over the ranks (non-negative floats), one launch: every rank stores {exchange number, value} as one 8-byte
+ * word into slot `rank` of every rank's table ([world][2] words) and polls its own.  A rank that does not answer within the spin
+ * limit: the result is 3e38 (the caller rebuilds rather than trusts its list) and *d_flags |= flag_bit. */
+typedef struct htfs_reduce_box {
+    void *remote[HTFS_MBOX_MAX_RANKS];   /* rank r's table, r = 0 .. world - 1 (this rank's own included) */
+    void *mine;
+    unsigned *state;                     /* [4] */
+    unsigned spin_limit;
+    int world, rank;
+} htfs_reduce_box;
+HTF_API int htfs_mailbox_allreduce_max_f32(const htfs_reduce_box *rb, float *d_value, unsigned *d_flags, unsigned flag_bit, htf_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

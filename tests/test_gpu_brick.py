@@ -379,6 +379,162 @@ def test_bricks_with_fewer_replans(htf, cuda, grid, cells, transport):
     _run_ranks(_brick_md_worker, grid[0] * grid[1], (grid, cells, transport, 2))
 
 
+def _peer_replay_worker(rank, world, port, q, grid, cells, replan_every, die_at=None):
+    """Real ranks (processes sharing the one GPU), transport "peer" and NOTHING else: the halo through the neighbors' inboxes, a
+    re-plan's migration messages through their mailboxes, the distance check's all-reduce through the ranks' tables (round 6) --
+    the eager no-read-back loop and the replay of whole check periods from hipGraphs give the same trajectory bit for bit, and the
+    forces at the end equal the single-domain ones.  ``die_at``: (rank, step) -- that rank exits there; the others must come back
+    with a RuntimeError that names the missing neighbor within seconds, not hang."""
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        sys.path.insert(0, ROOT)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import time
+        import hoomd_tf_amd as htf
+        from hoomd_tf_amd import standin
+        from hoomd_tf_amd.brick import BrickDomain
+
+        dev = torch.device("cuda:0")
+        rcut, rbuf, NN, P = 2.5, 0.4, 80, 4
+        a = (4.0 / 0.8442) ** (1.0 / 3.0)
+        base = np.array([[0, 0, 0], [.5, .5, 0], [.5, 0, .5], [0, .5, .5]])
+        gridc = np.stack(np.meshgrid(*[np.arange(c) for c in cells], indexing="ij"), -1).reshape(-1, 3)
+        pos = ((gridc[:, None, :] + base[None]) * a).reshape(-1, 3)
+        L = np.array(cells, dtype=np.float64) * a
+        pos = pos - L / 2
+        rng = np.random.default_rng(5)
+        pos += 0.05 * a * rng.standard_normal(pos.shape)
+        pos -= np.round(pos / L) * L
+        Ng = len(pos)
+        vel = np.zeros((Ng, 4))
+        vel[:, :3] = 1.5 * rng.standard_normal((Ng, 3))
+        vel[:, 3] = 1.0
+        probe = BrickDomain(standin.System(pos[:1], L, dtype=torch.float32, device=dev), rank, grid, r_ghost=rcut + rbuf, n_global=Ng,
+                            replan_every=replan_every)
+        mine = np.ones(Ng, dtype=bool)
+        for d in probe.axes:
+            mine &= (pos[:, d] >= probe.lo[d]) & (pos[:, d] < probe.hi[d])
+        out = {}
+        for mode in (("eager",) if die_at else ("eager", "graph")):
+            sysm = standin.System(pos[mine], L, types=np.arange(Ng)[mine], dtype=torch.float32, device=dev)
+            sysm.vel = torch.from_numpy(vel[mine]).to(torch.float32).to(dev)
+            nl = standin.CellNlist(sysm, r_cut=rcut, r_buff=rbuf, check_period=P, device_decision=True)
+            dom = nl.domain = BrickDomain(sysm, rank, grid, r_ghost=rcut + rbuf, r_buff=rbuf, n_global=Ng, transport="peer",
+                                          replan_every=replan_every)
+            assert "fine-grained" in dom.peer_memory, dom.peer_memory
+            nl.build()
+            ctx = htf.Context(r_cut=rcut, nneighs=NN, scalar_dtype=torch.float32, max_n=sysm.N)
+            pot = htf.Potential.lj()
+            ctx.set_potential(pot)
+            run = standin.BrickRun(sysm, nl, ctx, standin.NVE(sysm, 0.004))
+            if die_at:
+                t0 = None
+                try:
+                    for ts in range(400):
+                        if (rank, ts) == tuple(die_at):
+                            torch.cuda.synchronize()
+                            q.put((rank, "died"))
+                            q.close()
+                            q.join_thread()         # (the report must leave this process before it does)
+                            os._exit(0)
+                        if ts == die_at[1]:
+                            t0 = time.monotonic()
+                        run.step()
+                    torch.cuda.synchronize()
+                    dom.counts_host()
+                    q.put((rank, "no error after the neighbor died"))
+                except RuntimeError as e:
+                    took = time.monotonic() - t0
+                    ok = "did not arrive" in str(e) and took < 10.0
+                    q.put((rank, "ok" if ok else "raised %r after %.1f s" % (str(e), took)))
+                return
+            run.run(10 * P)                    # through a few rebuilds
+            assert nl.n_builds >= 2 and sysm.timestep % P == 0
+            nl.build()                         # both modes start a fresh reference here
+            run._arr = run._arrays()
+            b0 = nl.n_builds
+            run.run(40 * P, graph=(mode == "graph"))
+            torch.cuda.synchronize()
+            assert nl.n_builds - b0 >= 4 and run.dangerous_builds <= 1, (nl.n_builds - b0, run.dangerous_builds)
+            dom.counts_host()
+            dom.exchange_end()
+            dom.exchange()
+            ctx.compute_forces(sysm.timestep, run._arrays())
+            torch.cuda.synchronize()
+            out[mode] = (sysm.pos[:dom.cap].clone(), sysm.vel.clone(), sysm.force.clone(), dom.n_migrated, dom.n_light, nl.n_builds)
+            if mode == "graph":
+                # forces against the single-domain forces of the gathered configuration
+                live = dom.live_rows()
+                my_ids = sysm.pos[live, 3].contiguous().view(torch.int32).cpu().numpy()
+                loc = torch.zeros((Ng, 3), dtype=torch.float64)
+                loc[my_ids] = sysm.pos[live, :3].double().cpu()
+                owned = torch.zeros(Ng, dtype=torch.float64)
+                owned[my_ids] = 1
+                dist.all_reduce(loc)
+                dist.all_reduce(owned)
+                assert bool((owned == 1).all()), "particles lost or duplicated"
+                ref_sys = standin.System(loc.numpy(), L, dtype=torch.float32, device=dev)
+                ref_nl = standin.CellNlist(ref_sys, r_cut=rcut, r_buff=rbuf)
+                ref_nl.build()
+                ref_ctx = htf.Context(r_cut=rcut, nneighs=NN, scalar_dtype=torch.float32, max_n=Ng)
+                ref_ctx.set_potential(pot)
+                ref_ctx.compute_forces(0, ref_ctx.make_arrays(ref_sys.pos, Ng, ref_nl.n_neigh, ref_nl.head_list, ref_nl.nlist, ref_sys.box, ref_sys.force))
+                torch.cuda.synchronize()
+                want = ref_sys.force.cpu().numpy()[my_ids]
+                got = sysm.force[live].cpu().numpy()
+                scale = np.abs(want).max()
+                assert np.abs(got - want).max() < 3e-5 * scale, (np.abs(got - want).max(), scale)
+            del run, ctx, nl, dom, sysm
+            dist.barrier()
+        for k in range(3):
+            assert _same(out["eager"][k], out["graph"][k]), k
+        assert out["eager"][3:] == out["graph"][3:] and out["graph"][3] > 0, (out["eager"][3:], out["graph"][3:])
+        assert (out["graph"][4] > 0) == (replan_every > 1)
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+@pytest.mark.parametrize("grid,cells,replan", [((3, 1, 1), (12, 5, 5), 1), ((2, 2, 1), (10, 10, 5), 2), ((4, 2, 1), (16, 10, 5), 2)])
+def test_replayed_cycles_between_processes_with_the_peer_transport(htf, cuda, grid, cells, replan):
+    """a decomposed run between real ranks with NO communication library -- halo, migration messages and the
+    all-reduced distance check are stores into the neighbors' fine-grained memory -- eager and replayed from hipGraphs (three per
+    rank with replan_every = 2), bit-identical, forces == single-domain.  3 slabs, 2 x 2, and 4 x 2 = 8 processes."""
+    _run_ranks(_peer_replay_worker, grid[0] * grid[1], (grid, cells, replan))
+
+
+def test_a_rank_that_dies_is_noticed_by_every_other_rank(htf, cuda):
+    """a neighbor that stops stepping used to leave the others in a collective until somebody killed them.
+    With transport "peer" every wait is a bounded spin on the device: the dead rank's NEIGHBORS miss its halo message, EVERY rank
+    misses its word in the next distance check's all-reduce -- each sets the flag and raises at its next rebuild, seconds later."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    env_before = os.environ.get("HTF_PEER_SPIN")
+    os.environ["HTF_PEER_SPIN"] = "40000"          # ~0.1 s of polling per missing message (children inherit it)
+    try:
+        procs = [ctx.Process(target=_peer_replay_worker, args=(r, 4, port, q, (4, 1, 1), (16, 5, 5), 1, (1, 30))) for r in range(4)]
+        for p in procs:
+            p.start()
+        results = dict(q.get(timeout=120) for _ in procs)
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+    finally:
+        if env_before is None:
+            os.environ.pop("HTF_PEER_SPIN", None)
+        else:
+            os.environ["HTF_PEER_SPIN"] = env_before
+    assert results[1] == "died"
+    for r in (0, 2, 3):                            # rank 3 is NOT a neighbor of rank 1: it learns through the all-reduce
+        assert results[r] == "ok", (r, results[r])
+
+
 def _replica_md(htf, cuda, grid, transport, cells=6, period=4, replan_every=1):
     from hoomd_tf_amd import standin
     from hoomd_tf_amd.brick import BrickDomain

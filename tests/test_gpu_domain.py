@@ -490,8 +490,14 @@ def test_bench_starts_its_own_ranks(htf, cuda, args):
         m = d["mlp"]
         assert m["n_gpus"] == n and m["value"] > 0 and m["roofline"]["bound"] == "mfma" and 0.5 < m["kT_final"] < 1.5
         assert m["config"]["parallelism"] == d["config"]["parallelism"] and m["config"]["halo"]["ghosts_rank0"] > 0
-    for key in ("native_selftest", "graph_variant", "graph_variant_peer"):
+    for key in ("native_selftest", "graph_variant", "peer_selftest", "graph_variant_peer"):
         assert key in d and ("value" in d[key] or "exchanges" in d[key] or d[key].get("skipped")), (key, d.get(key))
+    # ranks sharing one GPU: RCCL refuses (a named skip); the library-free transport runs for real, self-test and replay
+    assert "share" in d["native_selftest"]["skipped"] and d["graph_variant"]["skipped"]
+    assert d["peer_selftest"]["bit_equal_to_torch_transport"] and "fine-grained" in d["peer_selftest"]["inbox_memory"]
+    g = d["graph_variant_peer"]
+    assert g["value"] > 0 and g["halo"]["transport"] == "peer" and g["particles"] == d["config"]["global_particles"]
+    assert -7.0 < g["energy_per_particle"] < -4.0 and 0.5 < g["kT"] < 1.5
 
 
 def _self_exchange():
