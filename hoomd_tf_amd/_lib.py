@@ -68,6 +68,12 @@ class Peer(C.Structure):
 MIRROR_MAX = 4
 
 
+class StepEpilogue(C.Structure):
+    """htfs_step_epilogue: the stand-in integrator (and a brick's halo pack) as the one-kernel step's epilogue."""
+    _fields_ = [("d_vel", C.c_void_p), ("d_pos_next", C.c_void_p), ("dtype", C.c_int), ("dt", C.c_double), ("box", Box),
+                ("brick", C.c_void_p), ("d_row_slots", C.c_void_p), ("d_halo_send", C.c_void_p), ("d_ghost_direct", C.c_void_p)]
+
+
 MBOX_MAX_MSG, MBOX_MAX_RANKS, IPC_HANDLE_BYTES = 8, 64, 64   # include/htf_standin.h HTFS_MBOX_MAX_MSG / _MAX_RANKS, HTFS_IPC_HANDLE_BYTES
 
 
@@ -205,6 +211,9 @@ STANDIN_PROTOTYPES = {
     "htfs_brick_nve_halo_peer": (_i, [_vp, _vp, _vp, _vp, _i, _d, C.POINTER(Box), _vp, _vp, _vp]),
     "htfs_brick_pack_halo_peer": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "htfs_brick_unpack_halo": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
+    "htfs_set_step_epilogue": (_i, [_vp, _i, _vp, _vp]),
+    "htfs_use_step_epilogue": (_i, [_vp, _i]),
+    "htfs_brick_row_slots": (_i, [_vp, _vp, _vp, _vp]),
     "htfs_shared_alloc": (_i, [_sz, _i, _vp]),
     "htfs_shared_free": (_i, [_vp]),
     "htfs_ipc_export": (_i, [_vp, _vp]),

@@ -204,6 +204,7 @@ class BrickDomain:
         self.mig_recv = torch.zeros((self.mig_rows, 8), dtype=dt, device=dev)
         self.halo_send = torch.empty((self.n_ghost_cap, 4), dtype=dt, device=dev)
         self._n_neigh = None
+        self.after_replan = []       # callables run (enqueued) behind every full rebuild (standin.FusedStep: the twin array's ghost tails)
         self.n_interior = self.cap_int            # rows [0, n_interior) have no ghost neighbor (Context.compute_forces_overlapped)
         self.n_rebuilds = 0
         self._works = None
@@ -461,6 +462,16 @@ class BrickDomain:
             return True
         return None
 
+    def enable_row_slots(self):
+        """The table the one-kernel step's epilogue reads (standin.FusedStep): the slot of every boundary row in every halo message,
+        refreshed by every re-plan from now on."""
+        if getattr(self, "row_slots", None) is None:
+            self.row_slots = torch.full((max(self.cap_bnd, 1), _lib.BRICK_MAX_MSG), -1, dtype=torch.int32, device=self.sys.pos.device)
+            self._fill_row_slots()
+
+    def _fill_row_slots(self):
+        _lib.check(_lib.lib.htfs_brick_row_slots(C.byref(self.geom), self.counts.data_ptr(), self.row_slots.data_ptr(), self._stream()))
+
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.sys.pos.device).cuda_stream)
 
@@ -598,6 +609,10 @@ class BrickDomain:
                                                          w, self.mig_recv.data_ptr(),
                                                          self._n_neigh.data_ptr() if self._n_neigh is not None else None,
                                                          self.counts.data_ptr(), self._stream()))
+            if getattr(self, "row_slots", None) is not None:
+                self._fill_row_slots()
+            for fn in self.after_replan:
+                fn()
             if not (capturing and getattr(self, "_mirrored", False)):   # (BrickRun: the next check kernel carries them to the host)
                 self._flags_host.copy_(self.counts, non_blocking=True)
             if not capturing:

@@ -531,6 +531,38 @@ __global__ __launch_bounds__(256) void brick_nve_halo_kernel(V4 *__restrict__ po
     }
 }
 
+// the slot of every boundary row in every halo message, once per re-plan (what brick_nve_halo_kernel works out per row and step):
+// the table the one-kernel step's epilogue reads (htf_internal.h step_epilogue_lane)
+template <typename T>
+__global__ __launch_bounds__(256) void brick_row_slots_kernel(BrickArgs<T> a, const unsigned *__restrict__ counts, unsigned *__restrict__ row_slots) {
+    __shared__ unsigned cnt[HTFS_BC_WORDS];
+    stage_counts(cnt, counts);
+    __syncthreads();
+    const unsigned j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= a.cap_bnd) return;
+    unsigned out[HTFS_BRICK_MAX_MSG];
+#pragma unroll
+    for (int m = 0; m < HTFS_BRICK_MAX_MSG; ++m) out[m] = 0xFFFFFFFFu;
+    if (j < cnt[HTFS_BC_N_BND]) {
+        const unsigned nclass = a.ndim == 1 ? 4u : 16u;
+        const unsigned n_int = cnt[HTFS_BC_CLASS + 1];
+        unsigned c = 1;
+        while (c + 1 < nclass && j >= cnt[HTFS_BC_CLASS + c + 1] - n_int) ++c;
+        const unsigned in_class = j - (cnt[HTFS_BC_CLASS + c] - n_int);
+#pragma unroll
+        for (int m = 0; m < HTFS_BRICK_MAX_MSG; ++m) {
+            if (m >= a.n_msg) continue;
+            const unsigned first = cnt[HTFS_BC_SLOT + c * HTFS_BRICK_MAX_MSG + m];
+            if (first == 0xFFFFFFFFu) continue;
+            const unsigned slot = first + in_class;
+            if (slot < cnt[HTFS_BC_MSG + m]) out[m] = slot;
+        }
+    }
+    uint4 *dst = reinterpret_cast<uint4 *>(row_slots) + (size_t)j * 2;
+    dst[0] = make_uint4(out[0], out[1], out[2], out[3]);
+    dst[1] = make_uint4(out[4], out[5], out[6], out[7]);
+}
+
 static int check_geom(const htfs_brick *g, const char *who) {
     HTF_REQUIRE(g, "%s: null geometry", who);
     HTF_REQUIRE((g->ndim == 1 && g->n_msg == 2) || (g->ndim == 2 && g->n_msg == 8), "%s: ndim %d with %d messages (1 / 2 or 2 / 8)", who,
@@ -657,6 +689,16 @@ static int check_peer(const htfs_peer *p, const htfs_brick *g, const char *who) 
     HTF_REQUIRE(p && p->my_inbox && p->my_signal && p->state && p->spin_limit > 0, "%s: incomplete htfs_peer", who);
     for (int m = 0; m < g->n_msg; ++m) HTF_REQUIRE(p->inbox[m] && p->signal[m], "%s: message %d has no destination", who, m);
     return HTF_OK;
+}
+
+extern "C" int htfs_brick_row_slots(const htfs_brick *g, const unsigned *d_counts, unsigned *d_row_slots, htf_stream stream) {
+    if (int rc = check_geom(g, "htfs_brick_row_slots")) return rc;
+    HTF_REQUIRE(d_counts && d_row_slots, "htfs_brick_row_slots: null pointer");
+    static_assert(HTFS_BRICK_MAX_MSG == 8, "two uint4 per row");
+    if (g->cap_bnd == 0) return HTF_OK;
+    hipLaunchKernelGGL((brick_row_slots_kernel<float>), dim3((g->cap_bnd + 255) / 256), dim3(256), 0, (hipStream_t)stream, make_args<float>(g),
+                       d_counts, d_row_slots);
+    return check_launch("brick_row_slots_kernel");
 }
 
 extern "C" int htfs_brick_pack_halo_peer(const htfs_brick *g, const void *d_pos, int dtype, const unsigned *d_counts, const htfs_peer *peer,

@@ -11,6 +11,7 @@
 
 #include "htf_common.h"
 #include "htf_internal.h"
+#include "htf_standin.h"
 #include "pair_mlp.h"
 #include "pair_math.h"
 
@@ -87,6 +88,11 @@ struct htf_ctx {
     std::vector<char> ev_one_scope; // per triple: the one-kernel step records no middle event
     std::vector<char> ev_complete;  // per triple: the closing event was recorded (an error return in between leaves it 0)
     size_t ev_used = 0;
+    // the stand-in integrator as the one-kernel step's epilogue (htfs_set_step_epilogue)
+    void *d_epilogue[HTFS_EPILOGUE_SLOTS] = {nullptr, nullptr}; // StepEpilogue<Scalar> descriptors in device memory
+    bool epilogue_ok[HTFS_EPILOGUE_SLOTS] = {false, false};
+    int epilogue_level[HTFS_EPILOGUE_SLOTS] = {0, 0};          // 1: the integrator alone, 2: + a brick's halo messages
+    int epilogue_slot = -1;                                     // what the next compute call carries
 };
 
 static hipEvent_t next_event(htf_ctx *c) {
@@ -410,6 +416,8 @@ extern "C" void htf_destroy(htf_ctx *ctx) {
     if (!ctx) return;
     ctx_free(ctx);
     if (ctx->flag) (void)hipFree(ctx->flag);
+    for (void *d : ctx->d_epilogue)
+        if (d) (void)hipFree(d);
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     delete ctx;
 }
@@ -418,6 +426,9 @@ extern "C" int htf_set_potential(htf_ctx *ctx, const htf_potential *pot) {
     using namespace htf;
     HTF_REQUIRE(ctx, "htf_set_potential: null context");
     ctx->pot = pot;
+    // (a registered step epilogue was judged against the potential it was registered under: register it again)
+    ctx->epilogue_slot = -1;
+    for (bool &ok : ctx->epilogue_ok) ok = false;
     return HTF_OK;
 }
 
@@ -504,10 +515,14 @@ static int compute_rows(htf_ctx *ctx, unsigned timestep, const htf_hoomd_arrays 
             }
             if (cfg.check_nlist) HTF_CHECK_HIP(hipMemsetAsync(ctx->flag, 0, sizeof(unsigned), s));
             void *fo = (char *)a->force + (size_t)offset * 4 * ssz;
+            // (the epilogue rides on this launch only: the request is this thread's, cleared behind the call)
+            step_epilogue_request() = ctx->epilogue_slot >= 0 ? ctx->d_epilogue[ctx->epilogue_slot] : nullptr;
+            step_epilogue_level() = ctx->epilogue_slot >= 0 ? ctx->epilogue_level[ctx->epilogue_slot] : 0;
             rc = fused_forces_impl(ctx->pot->pp, a->pos, cfg.scalar_dtype, N, cfg.nneighs, offset, n, &a->box, a->n_neigh,
                                    a->nlist, a->head_list, cfg.r_cut, fo, cfg.scalar_dtype,
                                    cfg.virial ? c_virial : nullptr, cfg.check_nlist ? ctx->flag : nullptr,
                                    c_positions, cfg.fused == 2 ? c_nlist : nullptr, cfg.fused == 2 ? c_counts : nullptr, s);
+            step_epilogue_request() = nullptr;
             const bool stamped = launch_events().used;
             launch_events() = LaunchEvents{};
             if (rc != HTF_OK) return rc;
@@ -579,6 +594,87 @@ static int compute_rows(htf_ctx *ctx, unsigned timestep, const htf_hoomd_arrays 
             if (rc != HTF_OK) return rc;
         }
     }
+    return HTF_OK;
+}
+
+namespace htf {
+// htfs_step_epilogue (host struct, include/htf_standin.h) -> the kernel argument.  The integrator's box is standin_gate.h
+// make_sbox's three expressions on the caller's htf_box, the halo's wrap box brick.hip make_args': the same bits as the separate
+// kernels.  
+template <typename T>
+static StepEpilogue<T> make_step_epilogue(const htfs_step_epilogue *r) {
+    const htf_box *hb = &r->box;
+    StepEpilogue<T> e;
+    for (int d = 0; d < 3; ++d) {
+        e.lo[d] = (T)hb->lo[d];
+        e.L[d] = (T)hb->hi[d] - (T)hb->lo[d];
+        e.Linv[d] = (T)1 / e.L[d];
+        e.periodic[d] = hb->periodic[d];
+    }
+    for (int m = 0; m < 8; ++m) {
+        e.ghost_off[m] = e.ghost_off_opp[m] = 0;
+        for (int c = 0; c < 3; ++c) e.shift[m][c] = (T)0;
+    }
+    e.vel = r->d_vel;
+    e.pos_next = r->d_pos_next;
+    e.dt = (T)r->dt;
+    if (r->brick != nullptr && r->d_row_slots != nullptr && (r->d_halo_send != nullptr || r->d_ghost_direct != nullptr)) {
+        const htfs_brick *g = r->brick;
+        e.row_slots = r->d_row_slots;
+        e.send = r->d_halo_send;
+        e.direct = r->d_ghost_direct;
+        e.cap_int = g->cap_int;
+        e.n_msg = g->n_msg;
+        e.halo_wrap = g->halo_wrap;
+        for (int m = 0; m < HTFS_BRICK_MAX_MSG && m < 8; ++m) {
+            e.ghost_off[m] = g->ghost_off[m];
+            e.ghost_off_opp[m] = m < g->n_msg ? g->ghost_off[g->n_msg - 1 - m] : 0u;
+            for (int c = 0; c < 3; ++c) e.shift[m][c] = (T)g->shift[m][c];
+        }
+    }
+    return e;
+}
+} // namespace htf
+
+extern "C" int htfs_set_step_epilogue(htf_ctx *ctx, int slot, const htfs_step_epilogue *ep, int *applies) {
+    using namespace htf;
+    HTF_REQUIRE(ctx && ep, "htfs_set_step_epilogue: null pointer");
+    HTF_REQUIRE(slot >= 0 && slot < HTFS_EPILOGUE_SLOTS, "htfs_set_step_epilogue: slot %d outside [0, %d)", slot, HTFS_EPILOGUE_SLOTS);
+    if (applies) *applies = 0;
+    HTF_REQUIRE(ep->d_vel && ep->d_pos_next && (ep->dtype == HTF_F32 || ep->dtype == HTF_F64), "htfs_set_step_epilogue: null pointer or bad dtype");
+    HTF_REQUIRE(ep->brick == nullptr || (ep->d_row_slots && (ep->d_halo_send || ep->d_ghost_direct)),
+                "htfs_set_step_epilogue: a brick needs its row slots and a destination for the messages");
+    const htf_config &cfg = ctx->cfg;
+    const htf_potential *pot = ctx->pot;
+    // honoured by: the one-kernel route of LJModel / WCARepulsion (the forms compiled with an epilogue), no virial
+    // (the one-row kernel), unbatched, forces written into HOOMD's array, everything in the context's Scalar
+    const bool ok = cfg.force_mode == HTF_TF2HOOMD && cfg.fused != 0 && cfg.nneighs > 0 && !cfg.virial && cfg.batch_size == 0 &&
+                    cfg.period == 1 && !cfg.check_nlist && ep->dtype == cfg.scalar_dtype && pot != nullptr && !own_evaluator(pot) &&
+                    (pot->pp.kind == HTF_POT_LJ || pot->pp.kind == HTF_POT_WCA) && // (the forms compiled with an epilogue: fused_eval.hip)
+                    (ep->brick == nullptr || !ep->brick->halo_wrap);                // (a replica brick on the GLOBAL cell grid wraps its messages)
+    ctx->epilogue_ok[slot] = false;
+    if (ok) {
+        if (ctx->d_epilogue[slot] == nullptr) HTF_CHECK_HIP(hipMalloc(&ctx->d_epilogue[slot], sizeof(StepEpilogue<double>)));
+        if (ep->dtype == HTF_F64) {
+            const StepEpilogue<double> e = make_step_epilogue<double>(ep);
+            HTF_CHECK_HIP(hipMemcpy(ctx->d_epilogue[slot], &e, sizeof e, hipMemcpyHostToDevice));
+        } else {
+            const StepEpilogue<float> e = make_step_epilogue<float>(ep);
+            HTF_CHECK_HIP(hipMemcpy(ctx->d_epilogue[slot], &e, sizeof e, hipMemcpyHostToDevice));
+        }
+        ctx->epilogue_ok[slot] = true;
+        ctx->epilogue_level[slot] = ep->brick != nullptr ? 2 : 1;
+    }
+    if (applies) *applies = ok ? 1 : 0;
+    return HTF_OK;
+}
+
+extern "C" int htfs_use_step_epilogue(htf_ctx *ctx, int slot) {
+    using namespace htf;
+    HTF_REQUIRE(ctx, "htfs_use_step_epilogue: null context");
+    HTF_REQUIRE(slot >= -1 && slot < HTFS_EPILOGUE_SLOTS, "htfs_use_step_epilogue: slot %d", slot);
+    HTF_REQUIRE(slot < 0 || ctx->epilogue_ok[slot], "htfs_use_step_epilogue: slot %d holds no descriptor this context honours", slot);
+    ctx->epilogue_slot = slot;
     return HTF_OK;
 }
 

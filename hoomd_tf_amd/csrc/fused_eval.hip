@@ -36,6 +36,15 @@ LaunchEvents &launch_events() {
     static thread_local LaunchEvents e;
     return e;
 }
+const void *&step_epilogue_request() {
+    static thread_local const void *r = nullptr;
+    return r;
+}
+int &step_epilogue_level() {
+    static thread_local int l = 0;
+    return l;
+}
+
 #endif
 
 // hipLaunchKernelGGL, or -- when the profiler has handed over a pair of events -- the launch that stamps them with the kernel's
@@ -52,6 +61,61 @@ LaunchEvents &launch_events() {
     } while (0)
 
 constexpr int kFChunk = 3; // index loads hoisted per lane per trip (as pair_vectors.hip: n_neigh <= 192 in one trip)
+
+// A finished row: lanes 0 / 16 / 32 / 48 hold fx, fz, fy, e in `tot` (wave_sum4) and write one component each -- and, when the
+// launch carries a step epilogue (htf_internal.h StepEpilogue), go on with the integrator's update of that component.
+template <typename PT, bool HALO = true>
+__device__ __forceinline__ void store_row_sums(void *__restrict__ force, int out_f64, unsigned w, unsigned idx, unsigned lane, float tot,
+                                               const typename Vec4<PT>::type *__restrict__ pos, const StepEpilogue<PT> *ep) {
+    if ((lane & 15u) == 0u) {
+        const unsigned comp = ((lane >> 4) & 1u) * 2u + (lane >> 5); // 0, 2, 1, 3
+        if (out_f64)
+            ((double *)force)[(size_t)w * 4 + comp] = (double)tot;
+        else
+            ((float *)force)[(size_t)w * 4 + comp] = tot;
+        // (the row's own position is read again here -- one word per lane, an L2 hit -- rather than kept in registers to the row's
+        //  end: holding pi.w and the late pi.xyz cost the four-row form 14 VGPRs, 7 -> 5 waves per SIMD)
+        if (ep != nullptr) {
+            asm volatile("" ::: "memory"); // (the epilogue's loads stay HERE: hoisted over the rows' trips they cost 16 VGPRs)
+            step_epilogue_lane<PT, HALO>(*ep, idx, comp, tot, reinterpret_cast<const PT *>(pos)[(size_t)idx * 4 + comp]);
+        }
+    }
+}
+
+// The step epilogue of a wave's R rows at once (the straight-line row-group forms): lane 4 r + c (< 4 R) owns component c of row r.
+// Its velocity and own-position words are loaded at the HEAD of the wave's work (group_epilogue_load: one coalesced 16-lane load
+// each, two registers for the whole kernel) and its force component comes out of the rows' wave_sum4 results by a cross-lane read
+// (rows 0..3 of `tot`: fx, fz, fy, e), so that behind the last row there is arithmetic and stores, no trip to memory.
+template <typename PT, int R, bool HALO>
+__device__ __forceinline__ void group_epilogue_load(const StepEpilogue<PT> *ep, const typename Vec4<PT>::type *__restrict__ pos, unsigned idx0,
+                                                    unsigned lane, PT &v, PT &own, uint4 &s0, uint4 &s1) {
+    v = own = (PT)0;
+    s0 = s1 = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    if (ep != nullptr && lane < 4u * R) {
+        const size_t o = (size_t)idx0 * 4 + lane; // rows idx0 .. idx0 + R - 1 are consecutive: 4 R consecutive words
+        v = reinterpret_cast<const PT *>(ep->vel)[o];
+        own = reinterpret_cast<const PT *>(pos)[o];
+        if constexpr (HALO) step_epilogue_slots<PT>(*ep, idx0 + (lane >> 2), s0, s1);
+    }
+}
+template <typename PT, int R, bool HALO>
+__device__ __forceinline__ void group_epilogue(const StepEpilogue<PT> *ep, unsigned idx0, unsigned lane, const float (&tot)[R], unsigned skip_rows,
+                                               PT v, PT own, const uint4 &s0, const uint4 &s1) {
+    if (ep == nullptr) return;
+    const unsigned er = lane >> 2, ec = lane & 3u;
+    // component c of a row's sums sits in the 16-lane row {0: fx, 2: fz, 1: fy, 3: e} = lanes +0 / +32 / +16 / +48 of this one
+    const int src = (int)((lane & 15u) + (ec == 1u ? 32u : (ec == 2u ? 16u : (ec == 3u ? 48u : 0u))));
+    float f = 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const float t = __shfl(tot[r], src);
+        f = er == (unsigned)r ? t : f;
+    }
+    if (lane < 4u * R && !((skip_rows >> er) & 1u)) {
+        const PT xn = step_epilogue_core<PT>(*ep, idx0 + er, ec, f, own, v);
+        if constexpr (HALO) step_epilogue_halo<PT>(*ep, s0, s1, ec, xn);
+    }
+}
 
 struct FusedAcc {
     float fx = 0.f, fy = 0.f, fz = 0.f, en = 0.f;
@@ -114,14 +178,15 @@ __device__ __forceinline__ unsigned fused_sweep(FusedAcc &acc, const typename Ve
     return Q;
 }
 
-template <int KIND, bool VIRIAL, bool STORE, typename PT>
+template <int KIND, bool VIRIAL, bool STORE, typename PT, int EPL = 2>
 __device__ __forceinline__ void fused_row(const unsigned w, const unsigned lane, const typename Vec4<PT>::type *__restrict__ pos,
                                           unsigned N, unsigned NN, unsigned offset, const BoxT<PT> &box,
                                           const unsigned *__restrict__ n_neigh, const unsigned *__restrict__ nlist,
                                           const unsigned *__restrict__ head_list, PT rmaxsq, void *__restrict__ force,
                                           void *__restrict__ virial9, int out_f64, const PotParams &p,
                                           unsigned *__restrict__ check_count, float4 *__restrict__ positions_out,
-                                          float4 *__restrict__ dest, unsigned *__restrict__ counts_io) {
+                                          float4 *__restrict__ dest, unsigned *__restrict__ counts_io,
+                                          const StepEpilogue<PT> *ep = nullptr) {
     const unsigned idx = w + offset;
     if (idx >= N) return;
     const unsigned nn = n_neigh[idx];
@@ -150,13 +215,7 @@ __device__ __forceinline__ void fused_row(const unsigned w, const unsigned lane,
     // the four row sums as the row-group forms take them (wave_sum4: rows 0..3 of `tot` hold fx, fz, fy, e), so that a row's
     // force does not depend on which routine computed it
     const float tot = wave_sum4(acc.fx, acc.fy, acc.fz, acc.en);
-    if ((lane & 15u) == 0u) {
-        const unsigned comp = ((lane >> 4) & 1u) * 2u + (lane >> 5); // 0, 2, 1, 3
-        if (out_f64)
-            ((double *)force)[(size_t)w * 4 + comp] = (double)tot;
-        else
-            ((float *)force)[(size_t)w * 4 + comp] = tot;
-    }
+    store_row_sums<PT, (EPL >= 2)>(force, out_f64, w, idx, lane, tot, pos, ep);
     float v6[6];
     if constexpr (VIRIAL) {
         v6[0] = group_sum<64>(acc.v.xx);
@@ -250,13 +309,13 @@ __global__ __launch_bounds__(256) void fused_forces_kernel(const typename Vec4<P
 // unlike the plain build, this kernel has plenty of) runs under the other row's memory latency.
 // Fast path for the common case (every row of the pair has 1..192 list entries and does not
 // overflow NN); anything else is redone by the generic single-row routine.
-template <int KIND, bool STORE, int R, typename PT>
+template <int KIND, bool STORE, int R, typename PT, int EPL = 2>
 __device__ __forceinline__ void fused_rows_group(
     const unsigned w0, const unsigned lane, const typename Vec4<PT>::type *__restrict__ pos, unsigned N, unsigned NN,
     unsigned offset, unsigned batch, const BoxT<PT> &box, const unsigned *__restrict__ n_neigh,
     const unsigned *__restrict__ nlist, const unsigned *__restrict__ head_list, PT rmaxsq, void *__restrict__ force,
     int out_f64, const PotParams &p, unsigned *__restrict__ check_count, float4 *__restrict__ positions_out,
-    float4 *__restrict__ dest, unsigned *__restrict__ counts_io) {
+    float4 *__restrict__ dest, unsigned *__restrict__ counts_io, const StepEpilogue<PT> *ep = nullptr) {
     using PV = typename Vec4<PT>::type;
     unsigned nn[R];
     bool fast = w0 + R <= batch;
@@ -268,11 +327,15 @@ __device__ __forceinline__ void fused_rows_group(
     if (!fast) {
 #pragma unroll 1
         for (unsigned r = 0; r < (unsigned)R && w0 + r < batch; ++r)
-            fused_row<KIND, false, STORE, PT>(w0 + r, lane, pos, N, NN, offset, box, n_neigh, nlist, head_list, rmaxsq,
-                                              force, nullptr, out_f64, p, check_count, positions_out, dest, counts_io);
+            fused_row<KIND, false, STORE, PT, EPL>(w0 + r, lane, pos, N, NN, offset, box, n_neigh, nlist, head_list, rmaxsq,
+                                              force, nullptr, out_f64, p, check_count, positions_out, dest, counts_io, ep);
         return;
     }
     const bool simple_box = box.ortho && box.periodic[0] && box.periodic[1] && box.periodic[2];
+    PT ep_v, ep_own;
+    uint4 ep_s0, ep_s1;
+    group_epilogue_load<PT, R, (EPL >= 2)>(ep, pos, w0 + offset, lane, ep_v, ep_own, ep_s0, ep_s1);
+    float tot_r[R];
     PV pi[R];
     unsigned k[R][kFChunk];
     PV q[R][kFChunk];
@@ -345,29 +408,26 @@ __device__ __forceinline__ void fused_rows_group(
             for (unsigned sl = filled + lane; sl < zero_end; sl += 64) store_stream(&row[sl], make_float4(0.f, 0.f, 0.f, 0.f));
             if (counts_io != nullptr && lane == 0) counts_io[w] = filled;
         }
+        tot_r[r] = 0.f;
         if (Q > NN) { // overflow (an error upstream): the generic routine reproduces the slot wrap
             redo |= 1u << r;
             continue;
         }
         const float tot = wave_sum4(fx, fy, fz, en); // rows 0..3: fx, fz, fy, e
-        if ((lane & 15u) == 0u) {
-            const unsigned comp = ((lane >> 4) & 1u) * 2u + (lane >> 5); // 0, 2, 1, 3
-            if (out_f64)
-                ((double *)force)[(size_t)w * 4 + comp] = (double)tot;
-            else
-                ((float *)force)[(size_t)w * 4 + comp] = tot;
-        }
+        tot_r[r] = tot;
+        store_row_sums<PT>(force, out_f64, w, w + offset, lane, tot, pos, nullptr);
         if (check_count != nullptr) {
             npos = group_sum_u<64>(npos);
             if (lane == 0 && npos > *(volatile unsigned *)check_count) atomicMax(check_count, npos);
         }
     }
+    group_epilogue<PT, R, (EPL >= 2)>(ep, w0 + offset, lane, tot_r, redo, ep_v, ep_own, ep_s0, ep_s1);
 #pragma unroll 1
     for (unsigned r = 0; r < (unsigned)R; ++r) // ONE code copy: a row's result must not depend on its place in the group
         if ((redo >> r) & 1u) {
             if constexpr (STORE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            fused_row<KIND, false, STORE, PT>(w0 + r, lane, pos, N, NN, offset, box, n_neigh, nlist, head_list, rmaxsq,
-                                              force, nullptr, out_f64, p, check_count, positions_out, dest, counts_io);
+            fused_row<KIND, false, STORE, PT, EPL>(w0 + r, lane, pos, N, NN, offset, box, n_neigh, nlist, head_list, rmaxsq,
+                                              force, nullptr, out_f64, p, check_count, positions_out, dest, counts_io, ep);
         }
 }
 
@@ -377,13 +437,13 @@ __device__ __forceinline__ void fused_rows_group(
 // belongs to the row whose tail covers it (prefix sums of the tail lengths; fast path: they fit 64 lanes together).
 // R = 4: 9 trips instead of 12.  Only the shared trip pays for per-lane row selection (list head, own position,
 // rank base, tensor row) and for splitting its contributions over R accumulator sets.
-template <int KIND, bool STORE, int R, typename PT>
+template <int KIND, bool STORE, int R, typename PT, int EPL = 2>
 __device__ __forceinline__ void fused_rows_group_tails(
     const unsigned w0, const unsigned lane, const typename Vec4<PT>::type *__restrict__ pos, unsigned N, unsigned NN,
     unsigned offset, unsigned batch, const BoxT<PT> &box, const unsigned *__restrict__ n_neigh,
     const unsigned *__restrict__ nlist, const unsigned *__restrict__ head_list, PT rmaxsq, void *__restrict__ force,
     int out_f64, const PotParams &p, unsigned *__restrict__ check_count, float4 *__restrict__ positions_out,
-    float4 *__restrict__ dest, unsigned *__restrict__ counts_io) {
+    float4 *__restrict__ dest, unsigned *__restrict__ counts_io, const StepEpilogue<PT> *ep = nullptr) {
     using PV = typename Vec4<PT>::type;
     unsigned nn[R], S[R + 1];
     // the straight-line path is the common case only: an orthorhombic box periodic in x, y and z, no check_nlist count.
@@ -401,14 +461,18 @@ __device__ __forceinline__ void fused_rows_group_tails(
         for (int r = 0; r < R; r += 2)
             if (w0 + r < batch) {
                 if (r + 1 < R)
-                    fused_rows_group<KIND, STORE, 2, PT>(w0 + r, lane, pos, N, NN, offset, batch, box, n_neigh, nlist, head_list,
-                                                         rmaxsq, force, out_f64, p, check_count, positions_out, dest, counts_io);
+                    fused_rows_group<KIND, STORE, 2, PT, EPL>(w0 + r, lane, pos, N, NN, offset, batch, box, n_neigh, nlist, head_list,
+                                                         rmaxsq, force, out_f64, p, check_count, positions_out, dest, counts_io, ep);
                 else // (an odd group's last row: the row after it belongs to the next wave)
-                    fused_row<KIND, false, STORE, PT>(w0 + r, lane, pos, N, NN, offset, box, n_neigh, nlist, head_list, rmaxsq,
-                                                      force, nullptr, out_f64, p, check_count, positions_out, dest, counts_io);
+                    fused_row<KIND, false, STORE, PT, EPL>(w0 + r, lane, pos, N, NN, offset, box, n_neigh, nlist, head_list, rmaxsq,
+                                                      force, nullptr, out_f64, p, check_count, positions_out, dest, counts_io, ep);
             }
         return;
     }
+    PT ep_v, ep_own;
+    uint4 ep_s0, ep_s1;
+    group_epilogue_load<PT, R, (EPL >= 2)>(ep, pos, w0 + offset, lane, ep_v, ep_own, ep_s0, ep_s1);
+    float tot_r[R];
     PV pi[R];
     unsigned head[R];
     unsigned k[R][2], kt;
@@ -541,30 +605,27 @@ __device__ __forceinline__ void fused_rows_group_tails(
             for (unsigned sl = filled + lane; sl < zero_end; sl += 64) store_stream(&row[sl], make_float4(0.f, 0.f, 0.f, 0.f));
             if (counts_io != nullptr && lane == 0) counts_io[w] = filled;
         }
+        tot_r[r] = 0.f;
         if (Q[r] > NN) {
             redo |= 1u << r;
             continue;
         }
         // the row's four sums together: rows 0..3 of `tot` hold fx, fz, fy, e; lanes 0 / 16 / 32 / 48 write one component each
         const float tot = wave_sum4(fx[r], fy[r], fz[r], en[r]);
-        if ((lane & 15u) == 0u) {
-            const unsigned comp = ((lane >> 4) & 1u) * 2u + (lane >> 5); // 0, 2, 1, 3
-            if (out_f64)
-                ((double *)force)[(size_t)w * 4 + comp] = (double)tot;
-            else
-                ((float *)force)[(size_t)w * 4 + comp] = tot;
-        }
+        tot_r[r] = tot;
+        store_row_sums<PT>(force, out_f64, w, w + offset, lane, tot, pos, nullptr);
         if (check_count != nullptr) {
             const unsigned np = group_sum_u<64>(npos[r]);
             if (lane == 0 && np > *(volatile unsigned *)check_count) atomicMax(check_count, np);
         }
     }
+    group_epilogue<PT, R, (EPL >= 2)>(ep, w0 + offset, lane, tot_r, redo, ep_v, ep_own, ep_s0, ep_s1);
 #pragma unroll 1
     for (unsigned r = 0; r < (unsigned)R; ++r)
         if ((redo >> r) & 1u) {
             if constexpr (STORE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            fused_row<KIND, false, STORE, PT>(w0 + r, lane, pos, N, NN, offset, box, n_neigh, nlist, head_list, rmaxsq,
-                                              force, nullptr, out_f64, p, check_count, positions_out, dest, counts_io);
+            fused_row<KIND, false, STORE, PT, EPL>(w0 + r, lane, pos, N, NN, offset, box, n_neigh, nlist, head_list, rmaxsq,
+                                              force, nullptr, out_f64, p, check_count, positions_out, dest, counts_io, ep);
         }
 }
 
@@ -577,13 +638,16 @@ __device__ __forceinline__ void fused_rows_group_tails(
 #ifndef HTF_TAILS_MINB_F64
 #define HTF_TAILS_MINB_F64 1
 #endif
-template <int KIND, bool STORE, int R, typename PT>
+// EP: the launch carries a step epilogue (htf_internal.h StepEpilogue).  A template parameter, not a null test: the epilogue's
+// address arithmetic and loads cost the four-row form 16 VGPRs (69 -> 85: five waves per SIMD instead of seven, 57 -> 60 us at C3
+// with the epilogue switched OFF), so launches without one run the code they always ran.
+template <int KIND, bool STORE, int R, typename PT, int EP = 0>
 __global__ __launch_bounds__(256, sizeof(PT) == 8 ? HTF_TAILS_MINB_F64 : 1) void fused_forces_tails_kernel(
     const typename Vec4<PT>::type *__restrict__ pos, unsigned N, unsigned NN, unsigned offset, unsigned batch,
     BoxT<PT> box, const unsigned *__restrict__ n_neigh, const unsigned *__restrict__ nlist,
     const unsigned *__restrict__ head_list, PT rmaxsq, void *__restrict__ force, int out_f64, PotParams pin,
     unsigned *__restrict__ check_count, float4 *__restrict__ positions_out, float4 *__restrict__ dest,
-    unsigned *__restrict__ counts_io) {
+    unsigned *__restrict__ counts_io, const StepEpilogue<PT> *__restrict__ ep) {
     const PotParams p = resolve_theta<KIND>(pin);
     const unsigned lane = threadIdx.x & 63u;
     // (one wave per group of R rows.  Round 3, measured: the same body under a grid-stride loop, waves persistent at 4 ... 32
@@ -591,8 +655,8 @@ __global__ __launch_bounds__(256, sizeof(PT) == 8 ? HTF_TAILS_MINB_F64 : 1) void
     //  code its schedule; fp64 positions 88.7-93.8 against 67.)
     const unsigned w0 = R * __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     if (w0 >= batch) return;
-    fused_rows_group_tails<KIND, STORE, R, PT>(w0, lane, pos, N, NN, offset, batch, box, n_neigh, nlist, head_list, rmaxsq,
-                                               force, out_f64, p, check_count, positions_out, dest, counts_io);
+    fused_rows_group_tails<KIND, STORE, R, PT, EP>(w0, lane, pos, N, NN, offset, batch, box, n_neigh, nlist, head_list, rmaxsq,
+                                                   force, out_f64, p, check_count, positions_out, dest, counts_io, EP ? ep : nullptr);
 }
 
 // The kernel strides over the row groups so that HTF_FUSED_GRID=<workgroups per CU> can launch it
@@ -600,32 +664,32 @@ __global__ __launch_bounds__(256, sizeof(PT) == 8 ? HTF_TAILS_MINB_F64 : 1) void
 // load-chain + streaming-store kernel (65 -> 46 us); this kernel, whose rows differ in length
 // and which has arithmetic to hide its loads under, is best with one group per wave
 // (C3, tensor written: 62.5 us; 4 / 8 / 12 / 16 workgroups per CU: 84 / 78 / 69 / 68 us), the default.
-template <int KIND, bool STORE, int R, typename PT>
+template <int KIND, bool STORE, int R, typename PT, int EPL = 2>
 __device__ __forceinline__ void fused_forces_rows2_body(
     const typename Vec4<PT>::type *__restrict__ pos, unsigned N, unsigned NN, unsigned offset, unsigned batch,
     BoxT<PT> box, const unsigned *__restrict__ n_neigh, const unsigned *__restrict__ nlist,
     const unsigned *__restrict__ head_list, PT rmaxsq, void *__restrict__ force, int out_f64, PotParams pin,
     unsigned *__restrict__ check_count, float4 *__restrict__ positions_out, float4 *__restrict__ dest,
-    unsigned *__restrict__ counts_io) {
+    unsigned *__restrict__ counts_io, const StepEpilogue<PT> *ep = nullptr) {
     const PotParams p = resolve_theta<KIND>(pin);
     const unsigned lane = threadIdx.x & 63u;
     const unsigned wv = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const unsigned nw = (gridDim.x * blockDim.x) >> 6;
 #pragma unroll 1
     for (unsigned w0 = R * wv; w0 < batch; w0 += R * nw)
-        fused_rows_group<KIND, STORE, R, PT>(w0, lane, pos, N, NN, offset, batch, box, n_neigh, nlist, head_list, rmaxsq,
-                                             force, out_f64, p, check_count, positions_out, dest, counts_io);
+        fused_rows_group<KIND, STORE, R, PT, EPL>(w0, lane, pos, N, NN, offset, batch, box, n_neigh, nlist, head_list, rmaxsq,
+                                             force, out_f64, p, check_count, positions_out, dest, counts_io, ep);
 }
 
-template <int KIND, bool STORE, int R, typename PT>
+template <int KIND, bool STORE, int R, typename PT, int EP = 0>
 __global__ __launch_bounds__(256) void fused_forces_rows2_kernel(
     const typename Vec4<PT>::type *__restrict__ pos, unsigned N, unsigned NN, unsigned offset, unsigned batch,
     BoxT<PT> box, const unsigned *__restrict__ n_neigh, const unsigned *__restrict__ nlist,
     const unsigned *__restrict__ head_list, PT rmaxsq, void *__restrict__ force, int out_f64, PotParams pin,
     unsigned *__restrict__ check_count, float4 *__restrict__ positions_out, float4 *__restrict__ dest,
-    unsigned *__restrict__ counts_io) {
-    fused_forces_rows2_body<KIND, STORE, R, PT>(pos, N, NN, offset, batch, box, n_neigh, nlist, head_list, rmaxsq, force, out_f64, pin,
-                                                check_count, positions_out, dest, counts_io);
+    unsigned *__restrict__ counts_io, const StepEpilogue<PT> *__restrict__ ep) {
+    fused_forces_rows2_body<KIND, STORE, R, PT, EP>(pos, N, NN, offset, batch, box, n_neigh, nlist, head_list, rmaxsq, force, out_f64, pin,
+                                                    check_count, positions_out, dest, counts_io, EP ? ep : nullptr);
 }
 
 #ifdef HTF_JIT_UNIT
@@ -638,6 +702,15 @@ static int launch_fused(const void *pos, unsigned N, unsigned NN, unsigned offse
                         float4 *positions_out, float4 *dest, unsigned *counts_io, hipStream_t s) {
     BoxT<PT> b = make_boxt<PT>(hb);
     PT rc = (PT)rmax;
+    // the stand-in integrator as this launch's epilogue: a descriptor in device memory, built for this context's Scalar when it was
+    // registered (context.hip htfs_set_step_epilogue sets the request around the call; a virial request -- the one-row kernel --
+    // carries none).  A POINTER, not a by-value struct: the row routines take its address, and an address-taken kernel argument is
+    // copied to scratch (312 bytes per lane of private memory for a kernel that had none).
+    const StepEpilogue<PT> *ep = VIRIAL ? nullptr : static_cast<const StepEpilogue<PT> *>(step_epilogue_request());
+    // (the epilogue forms exist for the two potentials BASELINE's configurations time; htfs_set_step_epilogue says so)
+    constexpr bool kEpilogueKind = !VIRIAL && (KIND == HTF_POT_LJ || KIND == HTF_POT_WCA);
+    // level 1: the integrator alone (77 VGPRs in the four-row form, six waves per SIMD); level 2: + a brick's halo messages (82: five)
+    const int ep_level = step_epilogue_level();
     if constexpr (!VIRIAL) {
 #ifdef HTF_AB_VARIANTS // A/B builds only (CXXFLAGS_EXTRA=-DHTF_AB_VARIANTS): every form stays selectable
         static const char *rows_env = getenv("HTF_FUSED_ROWS"); // 1 | 2 | 4 rows per wave
@@ -650,12 +723,22 @@ static int launch_fused(const void *pos, unsigned N, unsigned NN, unsigned offse
         constexpr const char *tails_env = nullptr;
 #endif
         static const int n_cu = device_cu_count();
+#define HTF_ROWS_LAUNCH_EP(ST, RR, EPV, EPP)                                                                           \
+    HTF_LAUNCH_TIMED((fused_forces_rows2_kernel<KIND, ST, RR, PT, kEpilogueKind ? EPV : 0>), dim3(grid), dim3(256), s,  \
+                     (const typename Vec4<PT>::type *)pos, N, NN, offset, batch, b, n_neigh, nlist, head_list,         \
+                     (PT)(rc * rc), force, out_f64, p, check_count, positions_out, dest, counts_io, EPP)
 #define HTF_ROWS_LAUNCH(ST, RR)                                                                                        \
     const unsigned full = ((batch + RR - 1) / RR + 3) / 4;                                                             \
     const unsigned grid = per_cu > 0 && (unsigned)(per_cu * n_cu) < full ? (unsigned)(per_cu * n_cu) : full;           \
-    HTF_LAUNCH_TIMED((fused_forces_rows2_kernel<KIND, ST, RR, PT>), dim3(grid), dim3(256), s, \
-                       (const typename Vec4<PT>::type *)pos, N, NN, offset, batch, b, n_neigh, nlist, head_list,       \
-                       (PT)(rc * rc), force, out_f64, p, check_count, positions_out, dest, counts_io)
+    do {                                                                                                               \
+        if (kEpilogueKind && ep != nullptr && ep_level >= 2) {                                                         \
+            HTF_ROWS_LAUNCH_EP(ST, RR, 2, ep);                                                                         \
+        } else if (kEpilogueKind && ep != nullptr) {                                                                   \
+            HTF_ROWS_LAUNCH_EP(ST, RR, 1, ep);                                                                         \
+        } else {                                                                                                       \
+            HTF_ROWS_LAUNCH_EP(ST, RR, 0, (const StepEpilogue<PT> *)nullptr);                                          \
+        }                                                                                                              \
+    } while (0)
         // default for fp32 positions and batches of >= 16 384 rows (65 536 until the VALU diet of round 2: at 32 000 rows the
         // four-row form now takes 17.8 us against 19.0-19.4): four rows per wave with their tails in one trip
         // (58.0 us against 60.5 for the two-row form at C3 in isolation, 61.5-62.1 against 62.5-63.3 inside the MD loop,
@@ -678,15 +761,29 @@ static int launch_fused(const void *pos, unsigned N, unsigned NN, unsigned offse
         // persistent grids and the one-row kernel lost their A/Bs and are compiled in variants builds only.
         constexpr bool kTails = KIND == HTF_POT_LJ || KIND == HTF_POT_WCA;
         int tails = batch >= 16384u ? (batch >= 49152u ? 4 : 2) : 0;
+        // with a halo-packing epilogue the four-row form needs 82 VGPRs (five waves per SIMD against eight without one), the
+        // two-row form 65: 60.4 us against 71.5 at C3
+        if (kEpilogueKind && ep != nullptr && ep_level >= 2 && tails == 4) tails = 2;
         if (tails_env) tails = atoi(tails_env);
 #ifndef HTF_AB_VARIANTS
         if (!kTails) tails = 0;
 #endif
         if (tails == 2 || tails == 3 || tails == 4) {
+#define HTF_TAILS_LAUNCH_EP(ST, RR, EPV, EPP)                                                                          \
+    HTF_LAUNCH_TIMED((fused_forces_tails_kernel<KIND, ST, RR, PT, kEpilogueKind ? EPV : 0>), grid_t, dim3(256), s,      \
+                     (const typename Vec4<PT>::type *)pos, N, NN, offset, batch, b, n_neigh, nlist, head_list,         \
+                     (PT)(rc * rc), force, out_f64, p, check_count, positions_out, dest, counts_io, EPP)
 #define HTF_TAILS_LAUNCH(ST, RR)                                                                                       \
-    HTF_LAUNCH_TIMED((fused_forces_tails_kernel<KIND, ST, RR, PT>), dim3(((batch + RR - 1) / RR + 3) / 4), dim3(256), s, \
-                       (const typename Vec4<PT>::type *)pos, N, NN, offset, batch, b, n_neigh, nlist, head_list,       \
-                       (PT)(rc * rc), force, out_f64, p, check_count, positions_out, dest, counts_io)
+    do {                                                                                                               \
+        const dim3 grid_t(((batch + RR - 1) / RR + 3) / 4);                                                            \
+        if (kEpilogueKind && ep != nullptr && ep_level >= 2) {                                                         \
+            HTF_TAILS_LAUNCH_EP(ST, RR, 2, ep);                                                                        \
+        } else if (kEpilogueKind && ep != nullptr) {                                                                   \
+            HTF_TAILS_LAUNCH_EP(ST, RR, 1, ep);                                                                        \
+        } else {                                                                                                       \
+            HTF_TAILS_LAUNCH_EP(ST, RR, 0, (const StepEpilogue<PT> *)nullptr);                                         \
+        }                                                                                                              \
+    } while (0)
 #ifdef HTF_AB_VARIANTS
             if (dest != nullptr) {
                 if (tails == 2) HTF_TAILS_LAUNCH(true, 2); else if (tails == 3) HTF_TAILS_LAUNCH(true, 3); else HTF_TAILS_LAUNCH(true, 4);
@@ -703,6 +800,7 @@ static int launch_fused(const void *pos, unsigned N, unsigned NN, unsigned offse
             }
 #endif
 #undef HTF_TAILS_LAUNCH
+#undef HTF_TAILS_LAUNCH_EP
             return check_launch("fused_forces_tails_kernel");
         }
 #ifdef HTF_AB_VARIANTS
@@ -719,6 +817,7 @@ static int launch_fused(const void *pos, unsigned N, unsigned NN, unsigned offse
         return check_launch("fused_forces_rows2_kernel");
 #endif
 #undef HTF_ROWS_LAUNCH
+#undef HTF_ROWS_LAUNCH_EP
     }
 #ifndef HTF_AB_VARIANTS
     if constexpr (VIRIAL) // (the one-row kernel: every virial request; without a virial only in variants builds, HTF_FUSED_ROWS=1)

@@ -139,6 +139,9 @@ void bind(py::module &m, const char *name, R (*fn)(A...)) {
     X(htfs_brick_pack_halo) \
     X(htfs_brick_nve_halo) \
     X(htfs_brick_nve_halo_peer) \
+    X(htfs_set_step_epilogue) \
+    X(htfs_use_step_epilogue) \
+    X(htfs_brick_row_slots) \
     X(htfs_shared_alloc) \
     X(htfs_shared_free) \
     X(htfs_ipc_export) \

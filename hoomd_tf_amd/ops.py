@@ -534,6 +534,29 @@ class Context:
         domain.exchange_end()
         self.compute_forces(timestep, arrays, stream, rows=(n_int, arrays.N - n_int))
 
+    def set_step_epilogue(self, slot, vel, pos_next, dt, box, brick=None, row_slots=None, halo_send=None, ghost_direct=None):
+        """Register a step epilogue (include/htf_standin.h htfs_step_epilogue: the stand-in integrator, and a brick's halo pack, done
+        by the force kernel's own lanes) in descriptor ``slot`` (0 / 1: the two directions of a position ping-pong) -> whether this
+        context's launches will honour it.  A blocking upload: set-up time."""
+        e = _lib.StepEpilogue()
+        e.d_vel, e.d_pos_next = _dev(vel, "vel", self.scalar_dtype).data_ptr(), _dev(pos_next, "pos_next", self.scalar_dtype).data_ptr()
+        e.dtype, e.dt = self.cfg.scalar_dtype, float(dt)
+        e.box = box
+        self._epilogue_keep = getattr(self, "_epilogue_keep", {})
+        self._epilogue_keep[slot] = (vel, pos_next, brick, row_slots, halo_send, ghost_direct)
+        if brick is not None:
+            e.brick = C.addressof(brick)
+            e.d_row_slots = row_slots.data_ptr()
+            e.d_halo_send = halo_send.data_ptr() if halo_send is not None else None
+            e.d_ghost_direct = ghost_direct.data_ptr() if ghost_direct is not None else None
+        ok = C.c_int(0)
+        check(lib.htfs_set_step_epilogue(self._h, int(slot), C.byref(e), C.byref(ok)))
+        return bool(ok.value)
+
+    def use_step_epilogue(self, slot):
+        """The descriptor every later compute_forces of this context carries (-1 / None: none)."""
+        check(lib.htfs_use_step_epilogue(self._h, -1 if slot is None else int(slot)))
+
     def profile_enable(self, on=True):
         """Event-bracket the build and eval scopes (HOOMD Profiler analogue); ``on=k`` (int > 1)
         brackets every k-th batch only."""

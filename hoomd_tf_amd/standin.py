@@ -541,6 +541,98 @@ class NVE:
                                 self.dt, C.byref(s.box), C.c_void_p(raw_stream(s.device.index))))
 
 
+class FusedStep:
+    """One MD step as ONE launch (round 6): the integrator -- and, under a BrickDomain, the pack of the next step's halo messages --
+    as the EPILOGUE of the one-kernel force step (include/htf_standin.h htfs_step_epilogue).  A finished row's lanes go on with
+    v += f dt and x(t + dt) = wrap(x + v dt), the latter written into the OTHER position array (every wave still reads x(t) of
+    everybody): ``System.pos`` and a twin are swapped behind every launch.  Same bits as force kernel + htfs_nve_step
+    (+ htfs_brick_nve_halo): tests/test_gpu_standin.py, test_gpu_brick.py.
+
+    ``available``: whether the context honours the epilogue (a built-in closed form on the one-kernel route, no virial, no batching,
+    plain NVE of every particle, transport other than "peer"); when not, ``step()`` is the classic force launch + integrator launch.
+    ``arrays(pos)``: the htf_hoomd_arrays of the CURRENT position array (one per twin, rebuilt when the list's buffers change)."""
+
+    def __init__(self, system, nlist, ctx, nve):
+        self.sys, self.nl, self.ctx, self.nve = system, nlist, ctx, nve
+        self.dom = nlist.domain
+        self._twin = None
+        self._slot_of = {}
+        self._arr = {}
+        self._arr_key = None
+        self.available = self._register()
+
+    def _register(self):
+        s, dom, ctx = self.sys, self.dom, self.ctx
+        if os.environ.get("HTF_NO_STEP_EPILOGUE") == "1" or self.nve.group is not None or not s.pos.is_cuda:
+            return False
+        fixed = dom is not None and getattr(dom, "fixed_capacity", False)
+        if dom is not None and (not fixed or not dom.kernels or dom.transport == "peer"):
+            return False
+        self._twin = torch.full_like(s.pos, float("nan"))
+        self._twin[:, 3] = s.pos[:, 3]
+        ok = True
+        for slot, (cur, nxt) in enumerate(((s.pos, self._twin), (self._twin, s.pos))):
+            kw = {}
+            if fixed:
+                dom.enable_row_slots()
+                direct = dom.transport == "local"
+                kw = dict(brick=dom.geom, row_slots=dom.row_slots, halo_send=None if direct else dom.halo_send,
+                          ghost_direct=nxt[dom.cap:] if direct else None)
+            ok = ctx.set_step_epilogue(slot, s.vel, nxt, self.nve.dt, s.box, **kw) and ok
+            self._slot_of[cur.data_ptr()] = slot
+        if not ok:
+            self._twin = None
+            return False
+        self._home = s.pos.data_ptr()    # the array every check period starts and ends on (captured cycles carry it by value)
+        if fixed and dom.transport == "local":
+            # a rank that is its own neighbor: the epilogue writes the LIVE rows of a message straight into the other array's ghost
+            # region; the inert rows behind a message's count are the re-plan's business -- in both arrays
+            dom.after_replan.append(lambda: self._twin[dom.cap:, :3].fill_(float("nan")))
+        return True
+
+    def arrays(self):
+        s, nl = self.sys, self.nl
+        key = (nl.n_neigh.data_ptr(), nl.head_list.data_ptr(), nl.nlist.data_ptr(), s.force.data_ptr(), s.N)
+        if key != self._arr_key:
+            self._arr_key, self._arr = key, {}
+        a = self._arr.get(s.pos.data_ptr())
+        if a is None:
+            a = self._arr[s.pos.data_ptr()] = self.ctx.make_arrays(s.pos, s.N, nl.n_neigh, nl.head_list, nl.nlist, s.box, s.force)
+        return a
+
+    def forces_and_integrate(self, ts):
+        """The force rows of step ``ts`` (interior rows while a posted halo is in flight, boundary rows behind it) and the
+        integrator: ONE launch each way, the positions swapped behind it -- except on the last step of a check period that finds
+        the positions in their home array (an odd period: four swaps and one classic step), so that every period starts on the
+        same array whatever the period and wherever the run began: a captured period replays from fixed addresses."""
+        s, dom, ctx = self.sys, self.dom, self.ctx
+        if dom is not None and dom.pending and (not dom.overlaps or 20 * dom.n_interior < s.N):
+            dom.exchange_end()          # nothing in flight to hide, or next to no interior rows to hide it behind: one launch
+        P = self.nl.check_period
+        fused = self.available and not (ts % P == P - 1 and s.pos.data_ptr() == self._home)
+        if fused:
+            ctx.use_step_epilogue(self._slot_of[s.pos.data_ptr()])
+            try:
+                ctx.compute_forces_overlapped(ts, self.arrays(), dom)
+            finally:
+                ctx.use_step_epilogue(None)
+            nxt = self._twin
+            self._twin, s.pos = s.pos, nxt          # x(t + dt) is in the other array now
+            if dom is not None:
+                dom._packed = True                   # (the boundary rows wrote the next step's halo messages)
+            return
+        ctx.compute_forces_overlapped(ts, self.arrays(), dom)
+        if dom is not None and getattr(dom, "kernels", False) and self.nve.group is None:
+            dom.nve_step(self.nve.dt)               # integrator + next step's halo messages, one launch
+        else:
+            self.nve.step()
+
+    def step(self, ts):
+        """NeighborList::compute + the step (what bench.py's loop does on one GPU)."""
+        self.nl.compute(ts)
+        self.forces_and_integrate(ts)
+
+
 # --------------------------------------------------------------------------- run loop
 _current = {"sim": None}
 
@@ -769,18 +861,19 @@ class BrickRun:
         self._mirror = None
         self.n_rebuild_cycles = 0
         self.n_cycles = 0
+        self._fstep = None
 
     # ------------------------------------------------------------------ pieces of a step
-    def _arrays(self):
-        s, nl = self.sys, self.nl
-        return self.ctx.make_arrays(s.pos, s.N, nl.n_neigh, nl.head_list, nl.nlist, s.box, s.force)
+    @property
+    def fstep(self):
+        """The step as one launch where the context honours it (FusedStep: integrator and halo pack as the force kernel's epilogue,
+        positions ping-ponging between two arrays); made on first use -- the list must have been built."""
+        if self._fstep is None:
+            self._fstep = FusedStep(self.sys, self.nl, self.ctx, self.nve)
+        return self._fstep
 
-    def _forces(self, ts, overlapped):
-        if overlapped:
-            self.ctx.compute_forces_overlapped(ts, self._arr, self.dom)
-        else:
-            self.dom.exchange_end()
-            self.ctx.compute_forces(ts, self._arr)
+    def _arrays(self):
+        return self.fstep.arrays()     # (the htf_hoomd_arrays of the CURRENT position array and list buffers)
 
     def _integrate(self):
         if self.dom.kernels and self.nve.group is None:
@@ -789,20 +882,21 @@ class BrickRun:
             self.nve.step()
 
     def _force_rows(self, ts):
+        """The forces of step ``ts`` alone (no integration): interior rows | halo | boundary rows, or one launch."""
         if self.dom.pending and (not self.dom.overlaps or 20 * self.dom.n_interior < self.sys.N):
             self.dom.exchange_end()          # nothing in flight to hide, or next to no interior rows to hide it behind: one launch
-        self.ctx.compute_forces_overlapped(ts, self._arr, self.dom)
+        self.ctx.compute_forces_overlapped(ts, self._arrays(), self.dom)
+
+    def advance(self, ts):
+        """Forces of step ``ts`` + the integrator + the next step's halo messages: one launch (FusedStep) or the three pieces."""
+        self.fstep.forces_and_integrate(ts)
 
     def step(self):
         """One eager step (what bench.py's loop does)."""
         s = self.sys
         ts = s.timestep
-        builds = self.nl.n_builds
         self.nl.compute(ts)
-        if getattr(self, "_arr", None) is None or self.nl.n_builds != builds:
-            self._arr = self._arrays()
-        self._force_rows(ts)
-        self._integrate()
+        self.advance(ts)
         s.timestep += 1
 
     # ------------------------------------------------------------------ graph replay
@@ -837,8 +931,7 @@ class BrickRun:
         for i in range(P):
             if not (rebuild and i == 0):
                 self.dom.exchange_begin()
-            self._force_rows(s.timestep)
-            self._integrate()
+            self.advance(s.timestep)
             s.timestep += 1
 
     def _capture(self):
@@ -851,7 +944,8 @@ class BrickRun:
         if nl.n_builds < 2:
             raise RuntimeError("run a few eager steps through a rebuild first (RCCL connects and pinned buffers are made outside a capture)")
         dom.exchange_end()
-        self._arr = self._arrays()
+        if self.fstep.available and s.pos.data_ptr() != self.fstep._home:
+            raise RuntimeError("a captured cycle must start on the positions' home array (BrickRun.run steps eagerly to a check step first)")
         self._stat = torch.zeros(2, dtype=torch.float32, device=s.device)
         self._stat_work = torch.zeros(2, dtype=torch.int32, device=s.device)
         # the status words the host reads one cycle late travel with the check kernel (HTF_BRICK_MIRROR=0: a copy node each, as before)

@@ -263,6 +263,35 @@ HTF_API int htfs_brick_nve_halo(const htfs_brick *g, void *d_pos, void *d_vel, c
 HTF_API int htfs_brick_nve_halo_peer(const htfs_brick *g, void *d_pos, void *d_vel, const void *d_force, int dtype, double dt,
                                      const htf_box *box, const unsigned *d_counts, const htfs_peer *peer, htf_stream stream);
 
+/* ---- the integrator (and a brick's halo pack) as the EPILOGUE of the one-kernel step (round 6).  The lanes that hold a finished
+ * row's force go on with htfs_nve_step's update of that row -- v += f dt in place, x(t + dt) into d_pos_next, the OTHER position
+ * buffer (every wave still reads x(t) of everybody; the caller swaps the two arrays behind the launch) -- and, for a boundary row of
+ * a brick, with its new position in every halo message that carries it (htfs_brick_nve_halo's rows, found through d_row_slots).
+ * A plain step is then ONE launch where it was force kernel + integrator (+ pack): same bits (tests/test_gpu_standin.py).
+ * A context holds up to HTFS_EPILOGUE_SLOTS descriptors in device memory (the two directions of a ping-pong between two position
+ * arrays): htfs_set_step_epilogue registers one (a blocking upload: set-up time, not the step loop), htfs_use_step_epilogue names
+ * the one every later htf_compute_forces[_rows] of the context carries (-1: none) -- a host-side word, free per step.  The launch
+ * honours it on the one-kernel route without a virial (htf_config.fused != 0, a built-in closed form, batch_size 0, period 1, no
+ * check_nlist, positions and forces in `dtype`); *applies says whether this context will -- when not, the caller integrates as
+ * before. */
+#define HTFS_EPILOGUE_SLOTS 2
+typedef struct htfs_step_epilogue {
+    void *d_vel;                 /* Scalar4[N] */
+    void *d_pos_next;            /* Scalar4[N + ghosts] */
+    int dtype;                   /* HTF_F32 / HTF_F64: the Scalar of both (and of the context) */
+    double dt;
+    htf_box box;                 /* the integrator's box (htfs_nve_step's) */
+    const htfs_brick *brick;     /* NULL: no halo pack */
+    const unsigned *d_row_slots; /* [cap_bnd][HTFS_BRICK_MAX_MSG]: htfs_brick_row_slots */
+    void *d_halo_send;           /* [sum ghost_cap] Scalar4 (a transport sends it), or NULL */
+    void *d_ghost_direct;        /* the ghost region of d_pos_next (this rank is its own neighbor), or NULL */
+} htfs_step_epilogue;
+HTF_API int htfs_set_step_epilogue(htf_ctx *ctx, int slot, const htfs_step_epilogue *ep, int *applies);
+HTF_API int htfs_use_step_epilogue(htf_ctx *ctx, int slot);
+/* d_row_slots[j][m] <- the slot of boundary row j in halo message m, 0xFFFFFFFF where the row is not in it (or beyond the message's
+ * count): the class boundaries and slot table of the last re-plan, once per re-plan instead of once per row and step. */
+HTF_API int htfs_brick_row_slots(const htfs_brick *g, const unsigned *d_counts, unsigned *d_row_slots, htf_stream stream);
+
 /* ---- messages between ranks without a communication library (csrc/mailbox.hip): the migration messages of a re-plan and the
  * all-reduced distance check of transport "peer", so that every graph of a decomposed run is library-free.  Memory a neighbor's
  * kernels store into is allocated here -- fine-grained (hipExtMallocWithFlags(hipDeviceMallocFinegrained): coherent between

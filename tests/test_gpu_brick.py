@@ -535,7 +535,7 @@ def test_a_rank_that_dies_is_noticed_by_every_other_rank(htf, cuda):
         assert results[r] == "ok", (r, results[r])
 
 
-def _replica_md(htf, cuda, grid, transport, cells=6, period=4, replan_every=1):
+def _replica_md(htf, cuda, grid, transport, cells=6, period=4, replan_every=1, fused=0):
     from hoomd_tf_amd import standin
     from hoomd_tf_amd.brick import BrickDomain
     pos, vel, Lb = _brick_of_liquid(htf, cuda, cells, grid)
@@ -544,7 +544,7 @@ def _replica_md(htf, cuda, grid, transport, cells=6, period=4, replan_every=1):
     nl = standin.CellNlist(sysm, r_cut=rcut, r_buff=rbuf, check_period=period, device_decision=True)
     nl.domain = BrickDomain(sysm, 0, grid, r_ghost=rcut + rbuf, r_buff=rbuf, replica=True, transport=transport, replan_every=replan_every)
     nl.build()
-    ctx = htf.Context(r_cut=rcut, nneighs=NN, scalar_dtype=torch.float32, max_n=sysm.N)
+    ctx = htf.Context(r_cut=rcut, nneighs=NN, scalar_dtype=torch.float32, max_n=sysm.N, fused=fused)
     ctx.set_potential(htf.Potential.lj())
     run = standin.BrickRun(sysm, nl, ctx, standin.NVE(sysm, 0.005))
     return sysm, nl, run
@@ -627,6 +627,50 @@ def test_replay_counts_cycles_past_2_to_the_24(htf, cuda):
         assert (int(run._stat_host_words[1]) & 0xFFFFFFFF) == (seed + 30) & 0xFFFFFFFF
         assert len(run._discard) <= 2
     nl.domain.counts_host()
+
+
+@pytest.mark.parametrize("grid,transport,replan", [((8, 1, 1), "local", 1), ((4, 2, 1), "local", 2), ((8, 1, 1), "native", 2), ((4, 2, 1), "native", 1)])
+def test_fused_step_under_a_brick_equals_the_three_pieces(htf, cuda, grid, transport, replan):
+    """Round 6: under a BrickDomain the force kernel's epilogue is the integrator AND the pack of the next step's halo messages --
+    straight into the other array's ghost region (a rank that is its own neighbor) or into the send buffer (a transport) -- where
+    the step was force rows + htfs_brick_nve_halo.  Same trajectory bit for bit, eager and replayed, through re-plans and list-only
+    rebuilds (HTF_NO_STEP_EPILOGUE=1 selects the three pieces)."""
+    import subprocess
+    from hoomd_tf_amd import _lib
+    if transport == "native" and not _lib.lib.htf_halo_available():
+        pytest.skip("librccl not loadable")
+    outs = {}
+    for env_v in ("0", "1"):
+        code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import torch, hoomd_tf_amd as htf, test_gpu_brick as t; "
+                "t._fused_brick_body(htf, torch.device('cuda:0'), %r, %r, %r)" % (ROOT, os.path.join(ROOT, "tests"), grid, transport, replan))
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=ROOT,
+                           env=dict(os.environ, HTF_BRICK_WAIT_S="20", HTF_NO_STEP_EPILOGUE=env_v))
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST ")]
+        assert r.returncode == 0 and lines, r.stdout[-1500:] + r.stderr[-3000:]
+        outs[env_v] = lines[-1]
+    assert "fused=True" in outs["0"] and "fused=False" in outs["1"]
+    assert outs["0"].split("fused=")[0] == outs["1"].split("fused=")[0], (outs["0"], outs["1"])
+
+
+def _fused_brick_body(htf, cuda, grid, transport, replan):
+    import hashlib
+    P = 5                                  # an odd period: four fused steps and a classic one per cycle
+    digest = hashlib.sha256()
+    fused = None
+    for mode in ("eager", "graph"):
+        sysm, nl, run = _replica_md(htf, cuda, grid, transport, period=P, replan_every=replan, fused=2)
+        run.run(8 * P)
+        nl.build()
+        b0 = nl.n_builds
+        run.run(40 * P, graph=(mode == "graph"))
+        torch.cuda.synchronize()
+        assert nl.n_builds - b0 >= 4
+        nl.domain.counts_host()
+        fused = run.fstep.available
+        for t in (sysm.pos[:nl.domain.cap], sysm.vel, sysm.force):
+            digest.update(torch.nan_to_num(t, nan=-7.0).cpu().numpy().tobytes())
+        digest.update(repr((nl.n_builds, nl.domain.n_migrated, nl.domain.n_light)).encode())
+    print("DIGEST %s fused=%s" % (digest.hexdigest(), fused))
 
 
 @pytest.mark.parametrize("grid", [(8, 1, 1), (4, 2, 1)])

@@ -258,16 +258,12 @@ def _headline_brick_worker(rank, world, port, q, grid, fractions, steps):
         ctx.set_potential(htf.Potential.lj())
         nve = standin.NVE(sysm, 0.005)
         brun = standin.BrickRun(sysm, nl, ctx, nve)
-        builds, arr = -1, None
-        for ts in range(steps):
+        assert brun.fstep.available            # (the step bench.py times: integrator + halo pack as the force kernel's epilogue)
+        for ts in range(steps - 1):
             nl.compute(ts)
-            if nl.n_builds != builds:
-                arr = ctx.make_arrays(sysm.pos, sysm.N, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, sysm.force)
-                builds = nl.n_builds
-            brun._arr = arr
-            brun._force_rows(ts)
-            if ts < steps - 1:
-                brun._integrate()
+            brun.advance(ts)
+        nl.compute(steps - 1)
+        brun._force_rows(steps - 1)                # the last step's forces alone: positions and forces of the same instant
         torch.cuda.synchronize()
         c = dom.counts_host()                                     # (raises on an overflow / lost-particle flag)
         full = dom.n_rebuilds - dom.n_light
@@ -492,16 +488,11 @@ def _config5_worker(rank, world, port, q, md_steps):
         ctx.set_potential(pot)
         brun = standin.BrickRun(sysm, nl, ctx, standin.NVE(sysm, 0.005))
         # ---- 5a: the pair-MLP drives the MD
-        builds, arr = -1, None
-        for ts in range(md_steps):
+        for ts in range(md_steps - 1):
             nl.compute(ts)
-            if nl.n_builds != builds:
-                arr = ctx.make_arrays(sysm.pos, sysm.N, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, sysm.force)
-                builds = nl.n_builds
-            brun._arr = arr
-            brun._force_rows(ts)
-            if ts < md_steps - 1:
-                brun._integrate()
+            brun.advance(ts)
+        nl.compute(md_steps - 1)
+        brun._force_rows(md_steps - 1)
         torch.cuda.synchronize()
         c = dom.counts_host()
         assert dom.n_rebuilds >= 2, dom.n_rebuilds

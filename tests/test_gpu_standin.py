@@ -477,3 +477,74 @@ def test_rebuild_on_a_non_periodic_grid_takes_the_nearest_image(htf, cuda):
     nl.build()
     torch.cuda.synchronize()
     assert rows() != want
+
+
+@pytest.mark.parametrize("pot", ["lj", "wca"])
+@pytest.mark.parametrize("cells,period", [(10, 4), (18, 5), (24, 5)])
+@pytest.mark.parametrize("tdt", [torch.float32, torch.float64])
+def test_fused_step_equals_force_kernel_plus_integrator(htf, cuda, tdt, cells, period, pot):
+    """Round 6: the stand-in integrator as the EPILOGUE of the one-kernel force step (standin.FusedStep, include/htf_standin.h
+    htfs_step_epilogue) -- a finished row's lanes go on with v += f dt and x(t + dt) = wrap(x + v dt) into the OTHER position
+    array -- against the force launch + htfs_nve_step launch it replaces: positions, velocities and forces bit for bit over 80
+    steps with device-decided rebuilds, 4 000 (the plain two-row form), 23 328 (two rows with merged tails) and 55 296 rows (four
+    rows), an even check period (every step fused) and an odd one (the period's last step classic: it must end on its home array)."""
+    from hoomd_tf_amd import standin
+    pos, L, a = standin.fcc_positions(cells, 0.8442)
+    rng = np.random.default_rng(cells)
+    pos = pos + 0.03 * a * rng.standard_normal(pos.shape)
+    pos -= np.round(pos / L) * L
+    out = {}
+    for mode in ("classic", "fused"):
+        sysm = standin.System(pos, L, dtype=tdt, device=cuda)
+        sysm.randomize_velocities(kT=1.2, seed=4)
+        nl = standin.CellNlist(sysm, r_cut=2.5, r_buff=0.4, check_period=period, device_decision=True)
+        nl.build()
+        ctx = htf.Context(r_cut=2.5, nneighs=80, scalar_dtype=tdt, max_n=sysm.N, fused=2)
+        ctx.set_potential(htf.Potential.lj() if pot == "lj" else htf.Potential.wca(1.0))
+        nve = standin.NVE(sysm, 0.004)
+        fs = standin.FusedStep(sysm, nl, ctx, nve)
+        assert fs.available
+        home = sysm.pos.data_ptr()
+        swaps = 0
+        for ts in range(80):
+            if mode == "fused":
+                before = sysm.pos.data_ptr()
+                fs.step(ts)
+                swaps += int(sysm.pos.data_ptr() != before)
+                if ts % period == period - 1:
+                    assert sysm.pos.data_ptr() == home
+            else:
+                nl.compute(ts)
+                ctx.compute_forces(ts, fs.arrays())
+                nve.step()
+        torch.cuda.synchronize()
+        assert nl.device_builds() >= 2
+        if mode == "fused":
+            assert swaps == (80 if period % 2 == 0 else 80 - 80 // period)
+        out[mode] = (sysm.pos.clone(), sysm.vel.clone(), sysm.force.clone(), nl.device_builds())
+    assert out["classic"][3] == out["fused"][3]
+    for k in range(3):
+        assert torch.equal(out["classic"][k], out["fused"][k]), k
+
+
+def test_fused_step_is_refused_where_the_kernel_cannot_carry_it(htf, cuda):
+    """A virial request (the one-row kernel), a pair-MLP (its own evaluator), a generated kernel, batching: FusedStep.available is
+    False and step() is the classic pair of launches."""
+    from hoomd_tf_amd import standin
+    from hoomd_tf_amd.initializers import mlp_params
+    pos, L, a = standin.fcc_positions(6, 0.8442)
+    for kw, potf in ((dict(virial=True), lambda: htf.Potential.lj()), (dict(batch_size=256), lambda: htf.Potential.lj()),
+                     (dict(fused=0), lambda: htf.Potential.lj()),
+                     (dict(), lambda: htf.Potential.pair_mlp(mlp_params(seed=3), 0.0, 3.0, activation="tanh", precision="split16"))):
+        sysm = standin.System(pos, L, dtype=torch.float32, device=cuda)
+        sysm.randomize_velocities(kT=1.0, seed=1)
+        nl = standin.CellNlist(sysm, r_cut=2.5, r_buff=0.4)
+        nl.build()
+        ctx = htf.Context(r_cut=2.5, nneighs=80, max_n=sysm.N, **dict(dict(fused=2), **kw))
+        ctx.set_potential(potf())
+        fs = standin.FusedStep(sysm, nl, ctx, standin.NVE(sysm, 0.004))
+        assert not fs.available, kw
+        p0 = sysm.pos.clone()
+        fs.step(0)
+        torch.cuda.synchronize()
+        assert not torch.equal(p0, sysm.pos) and bool(torch.isfinite(sysm.pos).all())
