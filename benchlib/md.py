@@ -338,12 +338,17 @@ def run_md(args, E, workload, variants=True, cpu=True, keep_live=True):
         # its own compulsory traffic only: the build's bytes + the force write (the evaluator's
         # N*NN*16 re-read of SURVEY 8(d) no longer happens and is NOT credited)
         be_b = build_b + N * s4
+        if state["fused_step"]:
+            # the launch also does the integrator's work (velocity read + write, new position write: SURVEY 8(d)'s N * 4 * s * 6 minus
+            # the position and force reads it shares with the force step) -- counted, or `frac` would price a longer kernel on fewer bytes
+            be_b += N * s4 * 3
         kern = {"build_eval_forces": {"avg_us": eval_avg_s * 1e6, "algorithmic_bytes": be_b,
                                       "GBps": be_b / eval_avg_s / 1e9 if eval_avg_s > 0 else None,
                                       # SURVEY 8(d) would credit this launch with the build's AND the evaluator's bytes
                                       "contract_GBps": (build_b + eval_b) / eval_avg_s / 1e9 if eval_avg_s > 0 else None,
                                       "what": "pair-vector build with the evaluator as its epilogue: the [N,NN,4] "
-                                              "tensor is written once (bit-identical) and not re-read"}}
+                                              "tensor is written once (bit-identical) and not re-read"
+                                              + ("; the leapfrog update of the row rides on the same launch" if state["fused_step"] else "")}}
         dom = "build_eval_forces"
     else:
         kern = {

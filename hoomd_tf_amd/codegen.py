@@ -57,6 +57,24 @@ def wrap(x):
     raise TypeError("cannot use %r in a traced pair energy (scalars and expressions of nlist_rinv / safe_norm only)" % (type(x),))
 
 
+def param(k):
+    """Weight k of the traced energy: a kernel ARGUMENT (``p.theta[k]``, the potential's device parameter vector), not a constant
+    of the generated text -- a weight write costs a 4-byte copy, not a recompile, and the energy can be trained (round 6)."""
+    return Node("param", value=int(k))
+
+
+def params_of(node, seen=None, out=None):
+    """The weight indices an expression reads, ascending."""
+    seen, out = (set(), set()) if seen is None else (seen, out)
+    if id(node) not in seen:
+        seen.add(id(node))
+        if node.op == "param":
+            out.add(int(node.value))
+        for a in node.args:
+            params_of(a, seen, out)
+    return sorted(out)
+
+
 S, R, RN = Node("s"), Node("r"), Node("rn")   # nlist_rinv, safe_norm, the plain norm (masks only: no gradient)
 TJ, TI = Node("tj"), Node("ti")               # the neighbor's type nlist[i, j, 3] and the row particle's own positions[i, 3], as floats
 UNARY = ("neg", "exp", "log", "tanh", "sqrt", "abs", "square", "mask", "erf", "erfc", "sigmoid", "softplus", "sin", "cos")
@@ -84,16 +102,21 @@ def reads(node, op, seen=None):
 
 
 # --------------------------------------------------------------------------- evaluation in torch (the reference, and eager values)
-def evaluate(node, s, r, rn, memo=None, tj=None, ti=None):
+def evaluate(node, s, r, rn, memo=None, tj=None, ti=None, params=None):
     """The expression on torch tensors (any dtype): what the generated kernel computes per slot.  ``tj`` / ``ti``: the type
-    leaves (broadcastable to ``s``), needed only by expressions that read them."""
+    leaves (broadcastable to ``s``), needed only by expressions that read them; ``params``: the weights (one-element tensors,
+    on the autograd graph when they are being trained)."""
     memo = {} if memo is None else memo
     k = id(node)
     if k in memo:
         return memo[k]
     op = node.op
-    a = [evaluate(x, s, r, rn, memo, tj, ti) for x in node.args]
-    if op == "s":
+    a = [evaluate(x, s, r, rn, memo, tj, ti, params) for x in node.args]
+    if op == "param":
+        if params is None or node.value >= len(params):
+            raise ValueError("the expression reads weight %d: evaluate() needs params" % node.value)
+        out = params[node.value].reshape(()).to(dtype=s.dtype, device=s.device)
+    elif op == "s":
         out = s
     elif op == "r":
         out = r
@@ -171,6 +194,17 @@ class _Emitter:
         self.lines.append("const float %s = %s;" % (name, expr))
         return name
 
+    def weight(self, k):
+        """w<k> = p.theta[k]: read once per body (a uniform load from the potential's device parameter vector)."""
+        name = "w%d" % int(k)
+        seen = getattr(self, "_weights", None)
+        if seen is None:
+            seen = self._weights = set()
+        if k not in seen:
+            seen.add(k)
+            self.lines.append("const float %s = p.theta[%d];" % (name, int(k)))
+        return name
+
     @staticmethod
     def lit(v):
         if v != v or v in (float("inf"), float("-inf")):
@@ -194,6 +228,8 @@ class _Emitter:
             out = (self.tmp("__builtin_amdgcn_sqrtf(x * x + y * y + z * z)"), None)
         elif op == "const":
             out = (self.lit(node.value), None)
+        elif op == "param":
+            out = (self.weight(node.value), None)
         elif op in ("tj", "ti"):
             out = (op, None)
         elif op == "table":
@@ -373,6 +409,195 @@ def generate_body(node):
     return "\n".join(em.lines)
 
 
+class _JetEmitter(_Emitter):
+    """Forward-mode JETS over (r', w_k) for the training sweep: every node yields (v, v_r, {k: v_w}, {k: v_rw}) -- value, d / dr',
+    d / dw_k and the MIXED second derivative d2 / (dr' dw_k) -- as C expressions (None = identically zero).  The loss is
+    differentiated through a force (tensorflowcompute.py:347-370 via simmodel.py:526-555), i.e. through de/dr': the mixed term is
+    what pair_eval_grad<HTF_POT_JIT> turns into d nlist_forces / d w_k.  One rule per op shape: a unary f with f', f''
+    (v_rw = f'' a_r a_w + f' a_rw), products, selects."""
+
+    def __init__(self, weights):
+        super().__init__()
+        self.W = list(weights)
+        self.jm = {}
+
+    # -- small algebra on optional expressions
+    def m(self, *xs):
+        if any(x is None for x in xs):
+            return None
+        return self.tmp(" * ".join(xs))
+
+    def a(self, *xs):
+        xs = [x for x in xs if x is not None]
+        if not xs:
+            return None
+        return xs[0] if len(xs) == 1 else self.tmp(" + ".join(xs))
+
+    def ng(self, x):
+        return None if x is None else self.tmp("-%s" % x)
+
+    def sel(self, c, x, y):
+        return None if x is None and y is None else self.tmp("%s ? %s : %s" % (c, x or "0.0f", y or "0.0f"))
+
+    def unary(self, A, v, f1, f2):
+        av, ar, aw, arw = A
+        return (v, self.m(f1, ar), {k: self.m(f1, aw.get(k)) for k in self.W},
+                {k: self.a(self.m(f2, ar, aw.get(k)) if f2 is not None else None, self.m(f1, arw.get(k))) for k in self.W})
+
+    def product(self, A, B):
+        (av, ar, aw, arw), (bv, br, bw, brw) = A, B
+        return (self.tmp("%s * %s" % (av, bv)), self.a(self.m(ar, bv), self.m(av, br)),
+                {k: self.a(self.m(aw.get(k), bv), self.m(av, bw.get(k))) for k in self.W},
+                {k: self.a(self.m(arw.get(k), bv), self.m(ar, bw.get(k)), self.m(aw.get(k), br), self.m(av, brw.get(k))) for k in self.W})
+
+    def recip(self, B):
+        inv = self.tmp("__builtin_amdgcn_rcpf(%s)" % B[0])
+        inv2 = self.tmp("%s * %s" % (inv, inv))
+        return self.unary(B, inv, self.tmp("-%s" % inv2), self.tmp("2.0f * %s * %s" % (inv2, inv)))
+
+    def ipow(self, base, e):
+        if e == 0:
+            return "1.0f"
+        acc, cur = None, base
+        while e:
+            if e & 1:
+                acc = cur if acc is None else self.tmp("%s * %s" % (acc, cur))
+            e >>= 1
+            if e:
+                cur = self.tmp("%s * %s" % (cur, cur))
+        return acc
+
+    def power(self, a, q):
+        """a^q for a real constant q (small integers by repeated multiplication, negative ones through v_rcp)."""
+        if float(q).is_integer() and abs(q) <= 64:
+            n = int(abs(q))
+            pn = self.ipow(a, n)
+            return pn if q >= 0 else self.tmp("__builtin_amdgcn_rcpf(%s)" % pn)
+        return self.tmp("__builtin_amdgcn_exp2f(%s * __builtin_amdgcn_logf(%s))" % (self.lit(q), a))
+
+    def jet(self, node):
+        k = id(node)
+        if k in self.jm:
+            return self.jm[k]
+        op, Z = node.op, {}
+        if op == "s":
+            out = ("s", "ds", Z, Z)
+        elif op == "r":
+            out = ("r", "1.0f", Z, Z)
+        elif op == "param":
+            out = (self.weight(node.value), None, {node.value: "1.0f"}, Z)
+        elif op in ("rn", "const", "tj", "ti", "table", "mask") or op in COMPARE:
+            out = (self.emit(node)[0], None, Z, Z)      # (no derivative flows: the base emitter's value)
+        elif op == "where":
+            c = self.emit(node.args[0])[0]
+            A, B = self.jet(node.args[1]), self.jet(node.args[2])
+            out = (self.tmp("%s ? %s : %s" % (c, A[0], B[0])), self.sel(c, A[1], B[1]),
+                   {q: self.sel(c, A[2].get(q), B[2].get(q)) for q in self.W}, {q: self.sel(c, A[3].get(q), B[3].get(q)) for q in self.W})
+        elif op in ("min", "max"):
+            A, B = self.jet(node.args[0]), self.jet(node.args[1])
+            c = self.tmp_bool("%s %s %s" % (A[0], "<=" if op == "min" else ">=", B[0]))
+            out = (self.tmp("%s ? %s : %s" % (c, A[0], B[0])), self.sel(c, A[1], B[1]),
+                   {q: self.sel(c, A[2].get(q), B[2].get(q)) for q in self.W}, {q: self.sel(c, A[3].get(q), B[3].get(q)) for q in self.W})
+        elif op in ("add", "sub"):
+            A, B = self.jet(node.args[0]), self.jet(node.args[1])
+            if op == "sub":
+                B = (B[0], self.ng(B[1]), {q: self.ng(B[2].get(q)) for q in self.W}, {q: self.ng(B[3].get(q)) for q in self.W})
+                v = self.tmp("%s - %s" % (A[0], B[0]))
+            else:
+                v = self.tmp("%s + %s" % (A[0], B[0]))
+            out = (v, self.a(A[1], B[1]), {q: self.a(A[2].get(q), B[2].get(q)) for q in self.W},
+                   {q: self.a(A[3].get(q), B[3].get(q)) for q in self.W})
+        elif op == "mul":
+            out = self.product(self.jet(node.args[0]), self.jet(node.args[1]))
+        elif op == "div":
+            out = self.product(self.jet(node.args[0]), self.recip(self.jet(node.args[1])))
+        elif op == "neg":
+            A = self.jet(node.args[0])
+            out = (self.tmp("-%s" % A[0]), self.ng(A[1]), {q: self.ng(A[2].get(q)) for q in self.W}, {q: self.ng(A[3].get(q)) for q in self.W})
+        elif op == "pow":
+            A, pw = self.jet(node.args[0]), float(node.value)
+            if pw == 0.0:
+                out = ("1.0f", None, Z, Z)
+            else:
+                f1 = self.tmp("%s * %s" % (self.lit(pw), self.power(A[0], pw - 1.0)))
+                f2 = None if pw == 1.0 else self.tmp("%s * %s" % (self.lit(pw * (pw - 1.0)), self.power(A[0], pw - 2.0)))
+                out = self.unary(A, self.power(A[0], pw), f1, f2)
+        else:
+            A = self.jet(node.args[0])
+            a = A[0]
+            if op == "square":
+                out = self.unary(A, self.tmp("%s * %s" % (a, a)), self.tmp("2.0f * %s" % a), "2.0f")
+            elif op == "exp":
+                v = self.tmp("__builtin_amdgcn_exp2f(%s * 1.4426950408889634f)" % a)
+                out = self.unary(A, v, v, v)
+            elif op == "log":
+                ia = self.tmp("__builtin_amdgcn_rcpf(%s)" % a)
+                out = self.unary(A, self.tmp("__builtin_amdgcn_logf(%s) * 0.6931471805599453f" % a), ia, self.tmp("-(%s * %s)" % (ia, ia)))
+            elif op == "tanh":
+                ex = self.tmp("__builtin_amdgcn_exp2f(%s * 2.8853900817779268f)" % a)
+                t = self.tmp("1.0f - 2.0f * __builtin_amdgcn_rcpf(%s + 1.0f)" % ex)
+                u = self.tmp("1.0f - %s * %s" % (t, t))
+                out = self.unary(A, t, u, self.tmp("-2.0f * %s * %s" % (t, u)))
+            elif op == "sqrt":
+                q = self.tmp("__builtin_amdgcn_sqrtf(%s)" % a)
+                iq = self.tmp("__builtin_amdgcn_rcpf(%s)" % q)
+                out = self.unary(A, q, self.tmp("0.5f * %s" % iq), self.tmp("-0.25f * %s * %s * %s" % (iq, iq, iq)))
+            elif op == "abs":
+                out = self.unary(A, self.tmp("fabsf(%s)" % a), self.tmp("%s < 0.0f ? -1.0f : (%s > 0.0f ? 1.0f : 0.0f)" % (a, a)), None)
+            elif op in ("erf", "erfc"):
+                g = self.tmp("1.1283791670955126f * __builtin_amdgcn_exp2f(-(%s * %s) * 1.4426950408889634f)" % (a, a))
+                sg = "" if op == "erf" else "-"
+                out = self.unary(A, self.tmp("%s(%s)" % ("erff" if op == "erf" else "erfcf", a)), self.tmp("%s%s" % (sg, g)) if sg else g,
+                                 self.tmp("%s2.0f * %s * %s" % ("-" if op == "erf" else "", a, g)))
+            elif op == "sigmoid":
+                v = self.tmp("__builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-(%s) * 1.4426950408889634f))" % a)
+                f1 = self.tmp("%s * (1.0f - %s)" % (v, v))
+                out = self.unary(A, v, f1, self.tmp("%s * (1.0f - 2.0f * %s)" % (f1, v)))
+            elif op == "softplus":
+                ex = self.tmp("__builtin_amdgcn_exp2f(-fabsf(%s) * 1.4426950408889634f)" % a)
+                v = self.tmp("fmaxf(%s, 0.0f) + __builtin_amdgcn_logf(1.0f + %s) * 0.6931471805599453f" % (a, ex))
+                sg = self.tmp("%s >= 0.0f ? __builtin_amdgcn_rcpf(1.0f + %s) : %s * __builtin_amdgcn_rcpf(1.0f + %s)" % (a, ex, ex, ex))
+                out = self.unary(A, v, sg, self.tmp("%s * (1.0f - %s)" % (sg, sg)))
+            elif op in ("sin", "cos"):
+                rev = self.tmp("__builtin_amdgcn_fractf(%s * 0.15915494309189535f)" % a)
+                sn, cs = self.tmp("__builtin_amdgcn_sinf(%s)" % rev), self.tmp("__builtin_amdgcn_cosf(%s)" % rev)
+                out = self.unary(A, sn, cs, self.tmp("-%s" % sn)) if op == "sin" else self.unary(A, cs, self.tmp("-%s" % sn), self.tmp("-%s" % cs))
+            else:
+                raise ValueError("unknown op %r" % op)
+        self.jm[k] = out
+        return out
+
+    def tmp_bool(self, expr):
+        name = "c%d" % self.n
+        self.n += 1
+        self.lines.append("const bool %s = %s;" % (name, expr))
+        return name
+
+
+def generate_train_body(node, nparams):
+    """The statements pair_math.h splices into pair_eval_grad<HTF_POT_JIT>: e, dedr and, per weight k < nparams, dedw[k] and
+    d2edrdw[k], from s, ds, r, x, y, z, tj and w_k = p.theta[k]."""
+    em = _JetEmitter(range(int(nparams)))
+    v, vr, vw, vrw = em.jet(node)
+    em.lines.append("e = %s;" % v)
+    em.lines.append("dedr = %s;" % (vr or "0.0f"))
+    for k in range(int(nparams)):
+        em.lines.append("dedw[%d] = %s;" % (k, vw.get(k) or "0.0f"))
+        em.lines.append("d2edrdw[%d] = %s;" % (k, vrw.get(k) or "0.0f"))
+    return "\n".join(em.lines)
+
+
+def unit_text(node):
+    """What identifies (and is compiled into) the generated unit of an expression: its forward body and, when it reads weights, a
+    marker line with their number followed by the training body."""
+    body = generate_body(node)
+    ks = params_of(node)
+    if not ks:
+        return body
+    n = ks[-1] + 1
+    return body + "\n//@train %d\n" % n + generate_train_body(node, n)
+
+
 def vanishes_on_padding(node):
     """Energy and derivative of a padded slot (s = 0, ds = 0, r = sqrt(3) 1e-7, plain norm 0, neighbor type 0), in fp64: must be
     exact zeros -- whatever the row particle's own type is (tried for 0..15 when the expression reads it)."""
@@ -381,7 +606,10 @@ def vanishes_on_padding(node):
         s = r * 0.0          # (s = 0 with d s / d r = 0, but ON the graph: sqrt(s) has derivative 0 * inf = NaN there, in TF too)
         rn = torch.zeros((), dtype=torch.float64)
         try:
-            e = evaluate(node, s, r, rn, tj=torch.zeros((), dtype=torch.float64), ti=torch.full((), float(own), dtype=torch.float64))
+            ks = params_of(node)
+            # (weights: judged at a generic value -- an energy that vanishes on padding only for particular weights does not lower)
+            pr = [torch.tensor(0.7319 + 0.211 * q, dtype=torch.float64) for q in range(ks[-1] + 1)] if ks else None
+            e = evaluate(node, s, r, rn, tj=torch.zeros((), dtype=torch.float64), ti=torch.full((), float(own), dtype=torch.float64), params=pr)
             if not isinstance(e, torch.Tensor) or not bool(torch.isfinite(e)) or float(e.detach()) != 0.0:
                 return False
             if e.requires_grad:
@@ -415,7 +643,7 @@ def _cache_dir():
         return d
 
 
-_SOURCES = ("jit_unit.hip", "fused_eval.hip", "eval_pair.hip", "pair_math.h", "htf_common.h", "htf_internal.h", "box_math.h")
+_SOURCES = ("jit_unit.hip", "fused_eval.hip", "eval_pair.hip", "train_pair.hip", "pair_math.h", "htf_common.h", "htf_internal.h", "box_math.h")
 FLAGS = ["-std=c++17", "-O3", "-ffp-contract=on", "-DHTF_BUILD"]   # (-ffp-contract=on: as fused_eval.o is built, csrc/Makefile)
 
 
@@ -462,7 +690,16 @@ def available(body):
 
 
 def _body_include(body):
-    return "#define HTF_JIT_BODY_TEXT \\\n" + " \\\n".join("    " + l for l in body.splitlines()) + "\n"
+    """The unit's body file: HTF_JIT_BODY_TEXT and, for an energy with weights (unit_text's ``//@train N`` marker), HTF_JIT_NPARAMS
+    and HTF_JIT_TRAIN_BODY_TEXT."""
+    def macro(name, text):
+        return "#define %s \\\n" % name + " \\\n".join("    " + l for l in text.splitlines()) + "\n"
+    fwd, mark, train = body.partition("\n//@train ")
+    out = macro("HTF_JIT_BODY_TEXT", fwd)
+    if mark:
+        n, _, tb = train.partition("\n")
+        out += "#define HTF_JIT_NPARAMS %d\n" % int(n) + macro("HTF_JIT_TRAIN_BODY_TEXT", tb)
+    return out
 
 
 def _compile_hiprtc(body):

@@ -186,6 +186,7 @@ extern "C" int htf_potential_create(const htf_potential_desc *d, htf_potential *
         rc = jit_create(d->jit_image, d->jit_image_bytes, &p->jit);
         p->pp.jit = p->jit;
         p->pp.jit_flags = d->jit_flags;
+        p->pp.n_terms = rc == HTF_OK ? jit_num_params(p->jit) : 0; // (weights the unit was compiled for: 0 = a weight-free energy)
         break;
     default:
         set_error("htf_potential_create: unknown potential kind %d", d->kind);
@@ -646,10 +647,10 @@ extern "C" int htfs_set_step_epilogue(htf_ctx *ctx, int slot, const htfs_step_ep
                 "htfs_set_step_epilogue: a brick needs its row slots and a destination for the messages");
     const htf_config &cfg = ctx->cfg;
     const htf_potential *pot = ctx->pot;
-    // honoured by: the one-kernel route of LJModel / WCARepulsion (the forms compiled with an epilogue), no virial
+    // honoured by: the one-kernel route of LJModel / WCARepulsion on fp32 positions (the forms compiled with an epilogue), no virial
     // (the one-row kernel), unbatched, forces written into HOOMD's array, everything in the context's Scalar
     const bool ok = cfg.force_mode == HTF_TF2HOOMD && cfg.fused != 0 && cfg.nneighs > 0 && !cfg.virial && cfg.batch_size == 0 &&
-                    cfg.period == 1 && !cfg.check_nlist && ep->dtype == cfg.scalar_dtype && pot != nullptr && !own_evaluator(pot) &&
+                    cfg.period == 1 && !cfg.check_nlist && ep->dtype == cfg.scalar_dtype && ep->dtype == HTF_F32 && pot != nullptr && !own_evaluator(pot) &&
                     (pot->pp.kind == HTF_POT_LJ || pot->pp.kind == HTF_POT_WCA) && // (the forms compiled with an epilogue: fused_eval.hip)
                     (ep->brick == nullptr || !ep->brick->halo_wrap);                // (a replica brick on the GLOBAL cell grid wraps its messages)
     ctx->epilogue_ok[slot] = false;

@@ -708,7 +708,9 @@ static int launch_fused(const void *pos, unsigned N, unsigned NN, unsigned offse
     // copied to scratch (312 bytes per lane of private memory for a kernel that had none).
     const StepEpilogue<PT> *ep = VIRIAL ? nullptr : static_cast<const StepEpilogue<PT> *>(step_epilogue_request());
     // (the epilogue forms exist for the two potentials BASELINE's configurations time; htfs_set_step_epilogue says so)
-    constexpr bool kEpilogueKind = !VIRIAL && (KIND == HTF_POT_LJ || KIND == HTF_POT_WCA);
+    // (fp32 positions only: under a HOOMD DOUBLE build the epilogue took the four-row form from 65 to 87 us -- 9.7 k against
+    //  11.1 k steps/s at C3 -- so the fp64 wire keeps the integrator's own launch and no fp64 epilogue form is compiled)
+    constexpr bool kEpilogueKind = !VIRIAL && sizeof(PT) == 4 && (KIND == HTF_POT_LJ || KIND == HTF_POT_WCA);
     // level 1: the integrator alone (77 VGPRs in the four-row form, six waves per SIMD); level 2: + a brick's halo messages (82: five)
     const int ep_level = step_epilogue_level();
     if constexpr (!VIRIAL) {

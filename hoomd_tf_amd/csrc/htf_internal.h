@@ -135,6 +135,10 @@ int jit_launch_fused(const PotParams &p, const void *pos, int pos_dtype, unsigne
                      unsigned *counts_io, hipStream_t s);
 int jit_launch_eval(const PotParams &p, const void *nlist, int in_dtype, unsigned B, unsigned NN, void *force, void *virial9,
                     int out_f64, const unsigned *counts, hipStream_t s);
+// the training sweep of a unit compiled with weights (train_pair.hip's row loop around the generated jets): block partials
+int jit_launch_train(const PotParams &p, const void *nlist, int in_dtype, unsigned B, unsigned NN, const void *labels, int lab_f64,
+                     void *pred, float *partials, unsigned grid, hipStream_t s);
+int jit_num_params(const JitKernels *k);
 
 // counts (nullable): live slots per row; slots >= counts[row] are known zero padding and not loaded
 int eval_pair_dispatch(const PotParams &p, const void *nlist, int in_dtype, unsigned B, unsigned NN,

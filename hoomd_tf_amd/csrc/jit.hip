@@ -55,6 +55,8 @@ struct JitKernels {
     hipFunction_t rows2[2][2] = {}; // [fp64 positions][tensor written]
     hipFunction_t row1v[2][2] = {};
     hipFunction_t eval[2][2] = {};  // [fp64 tensor][virial]
+    hipFunction_t train[2] = {};    // [fp64 tensor]: only in a unit compiled with weights (HTF_JIT_NPARAMS)
+    int nparams = 0;
 };
 
 int jit_create(const void *image, size_t bytes, JitKernels **out) {
@@ -85,9 +87,23 @@ int jit_create(const void *image, size_t bytes, JitKernels **out) {
         delete k;
         return HTF_ERR_INVALID;
     }
+    // optional: the training sweep and its parameter count (a unit traced with weights)
+    hipDeviceptr_t np_ptr = nullptr;
+    size_t np_bytes = 0;
+    if (hipModuleGetFunction(&k->train[0], k->mod, "htf_jit_train_f32") == hipSuccess &&
+        hipModuleGetFunction(&k->train[1], k->mod, "htf_jit_train_f64") == hipSuccess &&
+        hipModuleGetGlobal(&np_ptr, &np_bytes, k->mod, "htf_jit_nparams") == hipSuccess && np_bytes == sizeof(int)) {
+        if (hipMemcpy(&k->nparams, np_ptr, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) k->nparams = 0;
+    } else {
+        k->train[0] = k->train[1] = nullptr;
+        k->nparams = 0;
+    }
+    (void)hipGetLastError();
     *out = k;
     return HTF_OK;
 }
+
+int jit_num_params(const JitKernels *k) { return k ? k->nparams : 0; }
 
 void jit_destroy(JitKernels *k) {
     if (!k) return;
@@ -138,6 +154,16 @@ int jit_launch_eval(const PotParams &p, const void *nlist, int in_dtype, unsigne
     const unsigned grid = (B + 15) / 16; // G = 16 lanes per row: 4 rows per wave, 4 waves per workgroup
     HTF_CHECK_HIP(hipModuleLaunchKernel(p.jit->eval[in_dtype == HTF_F64 ? 1 : 0][virial9 != nullptr ? 1 : 0], grid, 1, 1, 256, 1, 1, 0, s,
                                         args, nullptr));
+    return HTF_OK;
+}
+
+int jit_launch_train(const PotParams &p, const void *nlist, int in_dtype, unsigned B, unsigned NN, const void *labels, int lab_f64,
+                     void *pred, float *partials, unsigned grid, hipStream_t s) {
+    HTF_REQUIRE(p.jit && p.jit->train[0] && p.jit->nparams > 0, "HTF_POT_JIT: this generated unit was compiled without weights: nothing to train");
+    HTF_REQUIRE(p.theta != nullptr, "HTF_POT_JIT: a trainable traced energy needs its device parameter vector (desc.d_theta)");
+    PotParams pp = p;
+    void *args[] = {&nlist, &B, &NN, &labels, &lab_f64, &pred, &pp, &partials};
+    HTF_CHECK_HIP(hipModuleLaunchKernel(p.jit->train[in_dtype == HTF_F64 ? 1 : 0], grid, 1, 1, 256, 1, 1, 0, s, args, nullptr));
     return HTF_OK;
 }
 

@@ -11,6 +11,9 @@
 // the generated statements: `e = ...; dedr = ...;` in terms of s, ds, r, x, y, z (see pair_math.h)
 #include HTF_JIT_BODY_FILE
 #define HTF_JIT_BODY HTF_JIT_BODY_TEXT
+#if defined(HTF_JIT_NPARAMS) && HTF_JIT_NPARAMS > 0   // (before pair_math.h: its pair_eval_grad<HTF_POT_JIT> is conditional on it)
+#define HTF_JIT_TRAIN_BODY HTF_JIT_TRAIN_BODY_TEXT
+#endif
 #include "fused_eval.hip"
 #include "eval_pair.hip"
 
@@ -55,3 +58,18 @@ HTF_JIT_EVAL(htf_jit_eval_f32, false, float)
 HTF_JIT_EVAL(htf_jit_eval_f32_virial, true, float)
 HTF_JIT_EVAL(htf_jit_eval_f64, false, double)
 HTF_JIT_EVAL(htf_jit_eval_f64_virial, true, double)
+
+// A traced energy WITH WEIGHTS (round 6): the body file also defines HTF_JIT_NPARAMS and HTF_JIT_TRAIN_BODY_TEXT -- the same
+// expression as forward-mode jets over (r', w_k) -- and the unit carries the library's training sweep around it.
+#if defined(HTF_JIT_NPARAMS) && HTF_JIT_NPARAMS > 0
+#include "train_pair.hip"
+extern "C" __device__ const int htf_jit_nparams = HTF_JIT_NPARAMS;
+#define HTF_JIT_TRAIN(NAME, IT)                                                                                                     \
+    extern "C" __global__ __launch_bounds__(256) void NAME(const typename Vec4<IT>::type *__restrict__ nlist, unsigned B, unsigned NN, \
+                                                           const void *__restrict__ labels, int lab_f64, void *__restrict__ pred,   \
+                                                           PotParams pin, float *__restrict__ partials) {                           \
+        train_pair_body<HTF_POT_JIT, IT>(nlist, B, NN, labels, lab_f64, pred, pin, partials);                                       \
+    }
+HTF_JIT_TRAIN(htf_jit_train_f32, float)
+HTF_JIT_TRAIN(htf_jit_train_f64, double)
+#endif

@@ -276,14 +276,46 @@ template <int KIND> struct NumParams;
 template <> struct NumParams<HTF_POT_LJ_PARAM> { static constexpr int value = 2; };
 template <> struct NumParams<HTF_POT_WCA> { static constexpr int value = 1; };
 template <> struct NumParams<HTF_POT_RINV_POLY> { static constexpr int value = HTF_MAX_POLY_TERMS; };
+#ifdef HTF_JIT_NPARAMS // a generated unit of a traced energy with weights (hoomd_tf_amd/codegen.py generate_train_body)
+template <> struct NumParams<HTF_POT_JIT> { static constexpr int value = HTF_JIT_NPARAMS; };
+#endif
 
 template <int KIND>
 __device__ __forceinline__ void pair_eval_grad(float x, float y, float z, const PotParams &p, float &e, float &fx,
-                                               float &fy, float &fz, float4 (&dd)[NumParams<KIND>::value]) {
+                                               float &fy, float &fz, float4 (&dd)[NumParams<KIND>::value], float tj = 0.0f) {
     constexpr int P = NumParams<KIND>::value;
 #pragma unroll
     for (int k = 0; k < P; ++k) dd[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if constexpr (KIND == HTF_POT_LJ_PARAM) {
+    if constexpr (KIND == HTF_POT_JIT) {
+        // A traced energy with WEIGHTS (round 6): HTF_JIT_TRAIN_BODY is generated code that reads s, ds, r, x, y, z, tj and the
+        // weights w_k = p.theta[k] and assigns e, dedr (as HTF_JIT_BODY does) AND, per weight k, dedw[k] = d e / d w_k and
+        // d2edrdw[k] = d (de/dr') / d w_k (forward-mode jets over (r', w_k): codegen._JetEmitter).  nlist_forces = 2 de/dr' t / r'
+        // (simmodel.py:548), so d nlist_forces / d w_k = 2 d2edrdw[k] t / r'.
+#ifdef HTF_JIT_TRAIN_BODY
+        const RinvFwd f = rinv_fwd(x, y, z);
+        const float s = f.s, r = f.rp;
+        const float ds = f.cond ? -(s * s) : 0.0f;
+        const float ti = 0.0f; // (a trainable traced energy does not read the row particle's own type: simmodel declines)
+        float dedr = 0.0f, dedw[P], d2edrdw[P];
+#pragma unroll
+        for (int k = 0; k < P; ++k) dedw[k] = d2edrdw[k] = 0.0f;
+        e = 0.0f;
+        { HTF_JIT_TRAIN_BODY }
+        (void)ti;
+        const float g = f.rp > 0.0f ? 2.0f * f.irp : 0.0f;
+        const float c = g * dedr;
+        fx = c * f.tx;
+        fy = c * f.ty;
+        fz = c * f.tz;
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+            const float ck = g * d2edrdw[k];
+            dd[k] = make_float4(ck * f.tx, ck * f.ty, ck * f.tz, dedw[k]);
+        }
+#else
+        e = fx = fy = fz = 0.0f;
+#endif
+    } else if constexpr (KIND == HTF_POT_LJ_PARAM) {
         const float tx = x + kNormDelta, ty = y + kNormDelta, tz = z + kNormDelta;
         const float r = fast_sqrt(tx * tx + ty * ty + tz * tz);
         const bool m = r > kRinvDelta;

@@ -10,7 +10,9 @@
 // Per-block partials are written in a fixed order and reduced by one block (deterministic);
 // the optimizer (Keras SGD / Adam / Nadam rules + NonNeg + L1 regulariser) is a one-thread
 // kernel on the device parameter vector that every evaluation kernel reads at launch.
+#ifndef __HIPCC_RTC__
 #include <cmath>
+#endif
 
 #include "htf_common.h"
 #include "htf_internal.h"
@@ -20,11 +22,12 @@ namespace htf {
 
 constexpr int kTrainG = 16; // lanes per row (as the evaluator at NN = 128); smaller NN just idle lanes
 
+// (the body is a device function so that a generated unit -- csrc/jit_unit.hip -- can give its instantiation a C name)
 template <int KIND, typename IT>
-__global__ __launch_bounds__(256) void train_pair_kernel(const typename Vec4<IT>::type *__restrict__ nlist, unsigned B,
-                                                         unsigned NN, const void *__restrict__ labels, int lab_f64,
-                                                         void *__restrict__ pred, PotParams pin,
-                                                         float *__restrict__ partials) {
+__device__ __forceinline__ void train_pair_body(const typename Vec4<IT>::type *__restrict__ nlist, unsigned B,
+                                                unsigned NN, const void *__restrict__ labels, int lab_f64,
+                                                void *__restrict__ pred, PotParams pin,
+                                                float *__restrict__ partials) {
     constexpr int G = kTrainG, RPW = 64 / G, P = NumParams<KIND>::value;
     __shared__ float s_part[4][1 + P];
     const PotParams p = resolve_theta<KIND>(pin);
@@ -41,7 +44,7 @@ __global__ __launch_bounds__(256) void train_pair_kernel(const typename Vec4<IT>
         auto v = load_stream(&rp[j]);
         float e, fx, fy, fz;
         float4 dd[P];
-        pair_eval_grad<KIND>((float)v.x, (float)v.y, (float)v.z, p, e, fx, fy, fz, dd);
+        pair_eval_grad<KIND>((float)v.x, (float)v.y, (float)v.z, p, e, fx, fy, fz, dd, (float)v.w);
         F[0] += fx; F[1] += fy; F[2] += fz; F[3] += e;
 #pragma unroll
         for (int k = 0; k < P; ++k) {
@@ -86,6 +89,17 @@ __global__ __launch_bounds__(256) void train_pair_kernel(const typename Vec4<IT>
             (s_part[0][threadIdx.x] + s_part[1][threadIdx.x]) + (s_part[2][threadIdx.x] + s_part[3][threadIdx.x]);
 }
 
+template <int KIND, typename IT>
+__global__ __launch_bounds__(256) void train_pair_kernel(const typename Vec4<IT>::type *__restrict__ nlist, unsigned B,
+                                                         unsigned NN, const void *__restrict__ labels, int lab_f64,
+                                                         void *__restrict__ pred, PotParams pin,
+                                                         float *__restrict__ partials) {
+    train_pair_body<KIND, IT>(nlist, B, NN, labels, lab_f64, pred, pin, partials);
+}
+
+#ifdef HTF_JIT_UNIT
+} // namespace htf  (a generated unit takes the sweep above and nothing else of this file)
+#else
 // accum[w] = sum_b partials[b][w]  (one block, fixed order, fp64 accumulation)
 __global__ __launch_bounds__(1024) void reduce_columns_kernel(const float *__restrict__ partials, unsigned nblocks,
                                                               unsigned width, float *__restrict__ accum) {
@@ -126,6 +140,7 @@ int potential_num_params(const PotParams &p) {
     case HTF_POT_LJ_PARAM: return 2;
     case HTF_POT_WCA: return 1;
     case HTF_POT_RINV_POLY: return p.n_terms;
+    case HTF_POT_JIT: return p.n_terms; // (a traced energy's weights: how many the generated unit was compiled for)
     default: return 0;
     }
 }
@@ -134,6 +149,7 @@ static unsigned train_width(const PotParams &p) {
     switch (p.kind) {
     case HTF_POT_LJ_PARAM: return 3;
     case HTF_POT_WCA: return 2;
+    case HTF_POT_JIT: return 1u + (unsigned)p.n_terms;
     default: return 1 + HTF_MAX_POLY_TERMS;
     }
 }
@@ -152,6 +168,14 @@ int train_pair_dispatch(const PotParams &p, const void *nlist, int in_dtype, uns
     case HTF_POT_LJ_PARAM: return launch_train<HTF_POT_LJ_PARAM>(p, nlist, in_dtype, B, NN, labels, lab_f64, pred, accum, scratch, stream);
     case HTF_POT_WCA: return launch_train<HTF_POT_WCA>(p, nlist, in_dtype, B, NN, labels, lab_f64, pred, accum, scratch, stream);
     case HTF_POT_RINV_POLY: return launch_train<HTF_POT_RINV_POLY>(p, nlist, in_dtype, B, NN, labels, lab_f64, pred, accum, scratch, stream);
+    case HTF_POT_JIT: { // the generated unit's instantiation of the sweep above (csrc/jit.hip), then the library's own reduction
+        constexpr unsigned rows_per_block = 4 * (64 / kTrainG);
+        const unsigned grid = (B + rows_per_block - 1) / rows_per_block;
+        int rc = jit_launch_train(p, nlist, in_dtype, B, NN, labels, lab_f64, pred, scratch, grid, stream);
+        if (rc != HTF_OK) return rc;
+        hipLaunchKernelGGL(reduce_columns_kernel, dim3(1), dim3(1024), 0, stream, scratch, grid, 1u + (unsigned)p.n_terms, accum);
+        return check_launch("reduce_columns_kernel");
+    }
     default:
         set_error("htf_train_pair_grad: potential kind %d has no trainable closed form (pair-MLP training: next round)", p.kind);
         return HTF_ERR_INVALID;
@@ -278,3 +302,4 @@ extern "C" int htf_optimizer_step(float *d_theta, unsigned P, const float *d_acc
     hipLaunchKernelGGL(optimizer_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d_theta, P, d_accum, scale, d_state, *desc);
     return check_launch("optimizer_kernel");
 }
+#endif // HTF_JIT_UNIT

@@ -132,21 +132,26 @@ class Potential:
         return cls(_lib.POT_LJ_PARAM, lj_param=(w0, w1), theta=theta)
 
     @classmethod
-    def jit(cls, body, reads_own_type=False):
+    def jit(cls, body, reads_own_type=False, theta=None):
         """A traced elementwise pair energy as generated kernels (hoomd_tf_amd/codegen.py): ``body`` is the text
-        codegen.generate_body emitted; compiled once per expression (``hipcc --genco``, cached), loaded as HTF_POT_JIT.
-        ``reads_own_type``: the body reads ``ti`` (positions[i, 3]) -- the streaming evaluator then needs the positions."""
+        codegen.unit_text emitted; compiled once per expression (hipRTC / ``hipcc --genco``, cached), loaded as HTF_POT_JIT.
+        ``reads_own_type``: the body reads ``ti`` (positions[i, 3]) -- the streaming evaluator then needs the positions.
+        ``theta``: the device float32 vector of the energy's weights (``p.theta[k]`` in the body): kernels read it at launch, the
+        training sweep (htf_train_pair_grad) differentiates with respect to it."""
         from . import codegen
         image, key = codegen.compile_body(body)
         self = cls.__new__(cls)
         d = _lib.PotentialDesc()
+        if theta is not None:
+            _dev(theta, "theta", torch.float32)
+            d.d_theta = theta.data_ptr()
         d.kind = _lib.POT_JIT
         self._image = C.create_string_buffer(image, len(image))   # (kept alive with the potential)
         d.jit_image = C.cast(self._image, C.c_void_p)
         d.jit_image_bytes = len(image)
         d.jit_flags = _lib.JIT_READS_OWN_TYPE if reads_own_type else 0
         self.reads_own_type = bool(reads_own_type)
-        self.theta, self._keep, self.kind, self.jit_key, self.body = None, [], _lib.POT_JIT, key, body
+        self.theta, self._keep, self.kind, self.jit_key, self.body = theta, [], _lib.POT_JIT, key, body
         self._h = C.c_void_p()
         check(lib.htf_potential_create(C.byref(d), C.byref(self._h)))
         return self

@@ -70,6 +70,7 @@ class Nlist(_TorchOperand):
     def __init__(self, tensor):
         self.tensor = tensor
         self._ad = None
+        self._weights = []      # the scalar weights traced expressions of this list read: [(leaf tensor, flat index), ...] -> p.theta[k]
 
     shape = property(lambda self: self.tensor.shape)
     dtype = property(lambda self: self.tensor.dtype)
@@ -80,6 +81,14 @@ class Nlist(_TorchOperand):
         if self._ad is None:
             self._ad = self.tensor.detach().requires_grad_(True)
         return self._ad
+
+    def weight_index(self, leaf, flat):
+        """k of (leaf, flat) in this trace's weight vector (appended on first sight)."""
+        for k, (t, i) in enumerate(self._weights):
+            if t is leaf and i == flat:
+                return k
+        self._weights.append((leaf, int(flat)))
+        return len(self._weights) - 1
 
     def __getitem__(self, idx):
         full = slice(None)
@@ -586,6 +595,9 @@ class PairExpr(PairEnergy):
             return PairExpr(nl, x.node, positions=x.positions)
         if isinstance(x, PairCond):
             raise TypeError("a comparison is not a value: htf.cast it, or use it in htf.where")
+        wn = _weight_node(x, nlist) if nlist is not None else None
+        if wn is not None:
+            return PairExpr(nlist, wn)
         if nlist is not None and isinstance(x, torch.Tensor) and (x.requires_grad or x.numel() != 1):
             fw = _fold_weight(x)
             if fw is not None:
@@ -603,6 +615,11 @@ class PairExpr(PairEnergy):
         if other is None:
             return PairExpr(self.nlist, cg.Node(op, (self.node,), value=value), positions=self.positions, folded=self.folded)
         new_folded = ()
+        wn = _weight_node(other, self.nlist)
+        if wn is not None:
+            # an element of a trainable leaf, or scalar arithmetic on such: weights of the kernel (p.theta[k]), in inference and in
+            # training alike
+            other = PairExpr(self.nlist, wn)
         fw = _fold_weight(other)
         if fw is not None:
             # a one-element WEIGHT (or a scalar computed from weights) while nothing is being trained -- inference MD with a model
@@ -657,8 +674,25 @@ class PairExpr(PairEnergy):
     def body(self):
         from . import codegen as cg
         if getattr(self, "_body", None) is None:
-            self._body = cg.generate_body(self.node)
+            self._body = cg.unit_text(self.node)     # (forward body; + the training jets when the expression reads weights)
         return self._body
+
+    @property
+    def weight_elements(self):
+        """[(leaf, flat index)] the expression's p.theta[0 .. n) stand for (the trace's list, up to the highest index it reads)."""
+        from . import codegen as cg
+        ks = cg.params_of(self.node)
+        return list(self.nlist._weights[:ks[-1] + 1]) if ks else []
+
+    @property
+    def layer(self):
+        """What the training step takes for a trainable layer (TracedWeights), or None for a weight-free energy."""
+        el = self.weight_elements
+        if not el:
+            return None
+        if getattr(self, "_tw", None) is None:
+            self._tw = TracedWeights.of(self.body(), el, self.reads_own_type)
+        return self._tw
 
     def lowers(self):
         """Can this expression run as a generated kernel?  It must vanish on a padded slot (codegen.vanishes_on_padding), the ROCm
@@ -667,6 +701,8 @@ class PairExpr(PairEnergy):
         from . import codegen as cg
         if getattr(self, "_lowers", None) is None:
             ok = os.environ.get("HTF_NO_JIT") != "1" and cg.vanishes_on_padding(self.node)
+            if ok and getattr(_trace, "training_graph", False) and cg.params_of(self.node) and self.reads_own_type:
+                ok = False   # (the training sweep has no positions tensor beside the pair vectors: the torch route trains it)
             if ok and not cg.available(self.body()):
                 import warnings
                 warnings.warn("hoomd_tf_amd: hipcc not found (set HIPCC): the traced pair energy runs as torch ops + autograd "
@@ -693,7 +729,13 @@ class PairExpr(PairEnergy):
         return cg.reads(self.node, "ti")
 
     def potential(self):
+        tw = self.layer
+        if tw is not None:
+            return tw.potential(self.nlist.tensor.device)
         return ops.Potential.jit(self.body(), reads_own_type=self.reads_own_type)
+
+    def _param_tensors(self):
+        return [t.reshape(-1)[i] for t, i in self.weight_elements]
 
     def torch_value(self, nl_tensor):
         """[N, NN] value from a pair-vector tensor (an autograd leaf for the generic route), in its dtype."""
@@ -705,7 +747,7 @@ class PairExpr(PairEnergy):
         s = torch.where(ok, 1.0 / (torch.where(ok, r, torch.ones_like(r)) + 3e-6), torch.zeros_like(r))
         rn = torch.sqrt((x * x).sum(dim=2)).detach()
         ti = self.positions[:nl_tensor.shape[0], 3][:, None].to(nl_tensor.dtype) if self.positions is not None else None
-        return cg.evaluate(self.node, s, r, rn, tj=nl_tensor[:, :, 3].detach(), ti=ti)
+        return cg.evaluate(self.node, s, r, rn, tj=nl_tensor[:, :, 3].detach(), ti=ti, params=self._param_tensors() or None)
 
     def tensor(self):
         _trace_log().append({"op": "eager_value"})
@@ -796,6 +838,151 @@ def _weight_leaves(t):
             out.append(v)
         todo.extend(f for f, _ in fn.next_functions)
     return tuple(out)
+
+
+MAX_TRACED_WEIGHTS = 8     # (htf_optimizer_step's small-vector form; a traced energy with more weights takes the torch route)
+
+
+def _weight_element(x):
+    """(leaf, flat index) when ``x`` is ONE ELEMENT of a trainable leaf tensor -- a one-element Parameter itself, or ``w[k]`` of a
+    weight vector as upstream's layers write it (LJLayer: ``self.w[1] ** 6``, build_examples.py:336-360) -- else None.  Such an
+    operand of a traced pair energy becomes weight k of the generated kernel (``p.theta[k]``: an ARGUMENT, not a constant of the
+    text), so the energy keeps its kernel while the weight changes and can be TRAINED on the fast path (round 6)."""
+    if not (isinstance(x, torch.Tensor) and x.numel() == 1 and x.requires_grad and x.dtype.is_floating_point):
+        return None
+    if x.is_leaf:
+        return (x, 0)
+    fn = x.grad_fn
+    if fn is not None and fn.name() == "SelectBackward0" and len(fn.next_functions) == 1:
+        src = fn.next_functions[0][0]
+        leaf = getattr(src, "variable", None)
+        if leaf is not None and leaf.dim() == 1:
+            i = int(fn._saved_index)
+            return (leaf, i if i >= 0 else i + leaf.numel())
+    return None
+
+
+def _weight_node(x, nlist):
+    """A traced Node for a ONE-ELEMENT tensor computed from trainable leaves by scalar arithmetic -- ``w[0]``, ``2.0 * w[0]``,
+    ``w[1] ** 6``, ``-a / b`` -- or None (then the value is folded / the torch route taken, as before).  The autograd graph is
+    walked, not the tensor: MulBackward / DivBackward save exactly the constant operand the other side's gradient needs,
+    PowBackward its exponent; an Add / Sub with a hidden constant operand cannot be recovered and declines."""
+    from . import codegen as cg
+    if not (isinstance(x, torch.Tensor) and x.numel() == 1 and x.requires_grad and x.dtype.is_floating_point):
+        return None
+    budget = [32]
+
+    def leaf_param(leaf, flat):
+        if not leaf.dtype.is_floating_point:
+            return None
+        known = any(t is leaf and i == flat for t, i in nlist._weights)
+        if not known and len(nlist._weights) >= MAX_TRACED_WEIGHTS:
+            return None
+        return cg.param(nlist.weight_index(leaf, flat))
+
+    def const_of(t):
+        return None if t is None or t.numel() != 1 else cg.const(float(t))
+
+    def walk(fn):
+        budget[0] -= 1
+        if fn is None or budget[0] < 0:
+            return None
+        name = fn.name()
+        if name == "torch::autograd::AccumulateGrad":
+            v = fn.variable
+            return leaf_param(v, 0) if v.numel() == 1 else None
+        if name == "SelectBackward0":
+            src = fn.next_functions[0][0]
+            v = getattr(src, "variable", None)
+            if v is None or v.dim() != 1:
+                return None
+            i = int(fn._saved_index)
+            return leaf_param(v, i if i >= 0 else i + v.numel())
+        kids = [k for k, _ in fn.next_functions]
+        if name in ("MulBackward0", "DivBackward0") and len(kids) == 2:
+            a = walk(kids[0]) if kids[0] is not None else const_of(fn._saved_self)
+            b = walk(kids[1]) if kids[1] is not None else const_of(fn._saved_other)
+            return None if a is None or b is None else cg.Node("mul" if name == "MulBackward0" else "div", (a, b))
+        if name in ("AddBackward0", "SubBackward0") and len(kids) == 2 and kids[0] is not None and kids[1] is not None and float(fn._saved_alpha) == 1.0:
+            a, b = walk(kids[0]), walk(kids[1])
+            return None if a is None or b is None else cg.Node("add" if name == "AddBackward0" else "sub", (a, b))
+        if name == "NegBackward0":
+            a = walk(kids[0])
+            return None if a is None else cg.Node("neg", (a,))
+        if name == "PowBackward0" and len(kids) == 1:
+            a = walk(kids[0])
+            e = fn._saved_exponent
+            return None if a is None or isinstance(e, torch.Tensor) else cg.Node("pow", (a,), value=float(e))
+        if name in ("ExpBackward0", "LogBackward0", "SqrtBackward0", "TanhBackward0") and len(kids) == 1:
+            a = walk(kids[0])
+            return None if a is None else cg.Node({"E": "exp", "L": "log", "S": "sqrt", "T": "tanh"}[name[0]], (a,))
+        return None
+
+    n0 = len(nlist._weights)
+    node = walk(x.grad_fn) if not x.is_leaf else leaf_param(x, 0)
+    if node is None:
+        del nlist._weights[n0:]      # (a partial walk registers nothing)
+    return node
+
+
+class TracedWeights:
+    """The weights of a traced pair energy as the training step sees a trainable layer (tensorflowcompute._train_on_batch:
+    make_trainable / potential / after_update / nonneg_mask / l1_reg): a float32 device vector theta mirroring the (leaf, index)
+    elements in trace order.  The generated kernels read it at launch; the device optimizer updates it and ``after_update`` writes
+    the elements back into the leaves (what ``model.w`` shows the user); a leaf written by anybody else (load_weights, an
+    optimizer of the user's own) is copied in again before the next use (``refresh_if_stale``: no recompile)."""
+    nonneg_mask = 0
+    name = "traced-weights"
+    _cache = {}
+
+    def __init__(self, body, elements, reads_own_type):
+        self.body, self.elements, self.reads_own_type = body, list(elements), bool(reads_own_type)
+        self.l1_reg = (0.0,) * max(len(self.elements), 1)
+        self.theta = None
+        self._pot = None
+        self._seen = None
+
+    @classmethod
+    def of(cls, body, elements, reads_own_type):
+        key = (body, tuple((id(t), i) for t, i in elements))
+        tw = cls._cache.get(key)
+        if tw is None or any(a is not b for (a, _), (b, _) in zip(tw.elements, elements)):
+            if len(cls._cache) > 32:
+                cls._cache.clear()
+            tw = cls._cache[key] = cls(body, elements, reads_own_type)
+        return tw
+
+    def _values(self, device):
+        return torch.stack([t.detach().reshape(-1)[i].to(device=device, dtype=torch.float32) for t, i in self.elements])
+
+    def make_trainable(self, device="cuda"):
+        if self.theta is None:
+            self.theta = self._values(device).contiguous()
+            self._seen = tuple(t._version for t, _ in self.elements)
+        return self.theta
+
+    def refresh_if_stale(self):
+        if self.theta is not None and self._seen != tuple(t._version for t, _ in self.elements):
+            self.theta.copy_(self._values(self.theta.device))
+            self._seen = tuple(t._version for t, _ in self.elements)
+
+    def potential(self, device="cuda"):
+        self.make_trainable(device)
+        self.refresh_if_stale()
+        if self._pot is None:
+            self._pot = ops.Potential.jit(self.body, reads_own_type=self.reads_own_type, theta=self.theta)
+        return self._pot
+
+    def after_update(self):
+        """theta (just stepped by the device optimizer) -> the leaves the user holds."""
+        with torch.no_grad():
+            for k, (t, i) in enumerate(self.elements):
+                t.reshape(-1)[i] = self.theta[k].to(t.dtype)
+        self._seen = tuple(t._version for t, _ in self.elements)
+
+    @property
+    def w(self):
+        return self.theta
 
 
 def _fold_weight(x):

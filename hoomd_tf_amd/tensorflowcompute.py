@@ -232,6 +232,8 @@ class tfcompute:
         if self._plan is not None and self._plan_is_stale():
             self._plan = self.model._plan = None      # (re-traced below with the weights' present values)
             self._plan_folded = ()
+        if self._plan is not None and getattr(self, "_plan_weights", None) is not None:
+            self._plan_weights.refresh_if_stale()     # (weights that are kernel ARGUMENTS: a 4-byte copy each, the plan stays)
         if self._plan is not None and self.model._plan is self._plan:
             self._calls += 1
             # interior rows while the ghost halo is in flight, boundary rows after it
@@ -381,6 +383,8 @@ class tfcompute:
                 and len({id(e["potential"]) for e in fused}) == 1):
             self._plan = fused[0]["potential"]
             self._plan_folded = tuple(fused[0].get("folded", ()))
+            lay = fused[0].get("layer")
+            self._plan_weights = lay if hasattr(lay, "refresh_if_stale") else None
             self.model._plan = self._plan
             self.cpp_force.set_potential(self._plan)
             self._post_ops = post

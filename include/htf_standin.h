@@ -272,7 +272,7 @@ HTF_API int htfs_brick_nve_halo_peer(const htfs_brick *g, void *d_pos, void *d_v
  * arrays): htfs_set_step_epilogue registers one (a blocking upload: set-up time, not the step loop), htfs_use_step_epilogue names
  * the one every later htf_compute_forces[_rows] of the context carries (-1: none) -- a host-side word, free per step.  The launch
  * honours it on the one-kernel route without a virial (htf_config.fused != 0, a built-in closed form, batch_size 0, period 1, no
- * check_nlist, positions and forces in `dtype`); *applies says whether this context will -- when not, the caller integrates as
+ * check_nlist, fp32 positions and forces: the fp64 wire measured slower with it); *applies says whether this context will -- when not, the caller integrates as
  * before. */
 #define HTFS_EPILOGUE_SLOTS 2
 typedef struct htfs_step_epilogue {

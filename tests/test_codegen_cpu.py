@@ -244,53 +244,178 @@ def test_typed_unit_cross_compiles_and_a_table_that_leaks_onto_padding_does_not_
     assert not (htf.gather([1.0, 2.0, 3.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0], idx) * htf.exp(-htf.safe_norm(x[:, :, :3], axis=2))).lowers()
 
 
-def test_a_weight_is_folded_only_while_nothing_is_trained_and_its_version_is_kept():
-    """A torch Parameter multiplied into a traced expression: during inference (tfcompute(train=False), as here) its present value
-    becomes a constant of the kernel and (tensor, _version) rides along, so that tfcompute can re-trace once the weight is written
-    again; while the model is being trained (simmodel._trace.training_graph) -- and for any tensor that is not a one-element
-    leaf -- the expression becomes its torch value there and the model takes the autograd route: forces AND the weight's gradient."""
+TRAIN_HARNESS = r"""
+#include <math.h>
+#include <stdbool.h>
+#include <stdio.h>
+static float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
+static float __builtin_amdgcn_sqrtf(float x) { return sqrtf(x); }
+static float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
+static float __builtin_amdgcn_logf(float x) { return log2f(x); }
+static float __builtin_amdgcn_fractf(float x) { return x - floorf(x); }
+static float __builtin_amdgcn_sinf(float x) { return sinf(6.283185307179586f * x); }
+static float __builtin_amdgcn_cosf(float x) { return cosf(6.283185307179586f * x); }
+struct P { float theta[8]; };
+int main(void) {
+    struct P p = {{ THETA }};
+    float x, y, z;
+    while (scanf("%f %f %f", &x, &y, &z) == 3) {
+        const float tx = x + 1e-7f, ty = y + 1e-7f, tz = z + 1e-7f;
+        const float r = sqrtf(tx * tx + ty * ty + tz * tz);
+        const int cond = r > 3e-6f;
+        const float s = cond ? 1.0f / (r + 3e-6f) : 0.0f;
+        const float ds = cond ? -(s * s) : 0.0f;
+        const float tj = 0.0f, ti = 0.0f;
+        float e = 0.0f, dedr = 0.0f, dedw[NP], d2edrdw[NP];
+        for (int k = 0; k < NP; ++k) dedw[k] = d2edrdw[k] = 0.0f;
+        { BODY }
+        printf("%.9g %.9g", e, dedr);
+        for (int k = 0; k < NP; ++k) printf(" %.9g %.9g", dedw[k], d2edrdw[k]);
+        printf("\n");
+        (void)tj; (void)ti;
+    }
+    return 0;
+}
+"""
+
+
+def _weighted_models(htf, x, w, a, b):
+    """Traced energies with WEIGHTS: a vector weight indexed by element as upstream's LJLayer writes it, scalar Parameters, scalar
+    arithmetic on them, weights inside nonlinear functions, comparisons and selects."""
+    r = htf.safe_norm(x[:, :, :3], axis=2)
+    s = htf.nlist_rinv(x)
+    q = (w[1] * s) ** 6
+    live = htf.cast(s > 0.0, torch.float32)
+    return {
+        "lj_layer": w[0] * 2.0 * (q * q - q),                                                # build_examples.py:349-353, on nlist_rinv
+        "morse": 0.5 * a * live * ((1.0 - htf.exp(-1.0 * b * (r - 1.122))) ** 2 - 1.0),
+        "yukawa_mix": (-a / 2.0) * htf.exp(-1.0 * b * r) * s * w[1] ** 2 + htf.tanh(a * s) * s ** 2,
+        "switched": htf.where(r < b / 2.0, w[0] * s ** 4, htf.sqrt(a * s + 0.3) * s ** 3) + htf.minimum(a * s ** 3, w[1] * s ** 2),
+        "soft": htf.softplus(a - r) * s / b + htf.sigmoid(b * (1.5 - r)) * s ** 2 * w[0] + htf.cos(a * r) * s ** 3 + htf.erfc(b * r / 4.0) * s,
+    }
+
+
+def test_weights_are_kernel_arguments_and_their_jets_match_double_backward():
+    """Round 6: an element of a trainable leaf -- a one-element Parameter, ``w[k]`` of a weight vector, scalar
+    arithmetic on such -- meeting a traced expression is WEIGHT k of the generated kernel (``p.theta[k]``), in inference and in
+    training: the text does not carry its value (a write costs no recompile).  For training the emitter differentiates in forward
+    mode over (r', w_k): value, d/dr', d/dw_k and the mixed d2/(dr' dw_k) -- the loss goes through a force -- each checked here,
+    slot by slot, against torch's fp64 autograd (double backward for the mixed term) on the emitted C run in a host harness."""
     import hoomd_tf_amd as htf
-    from hoomd_tf_amd import simmodel
-    from hoomd_tf_amd.simmodel import PairExpr
-    rng = np.random.default_rng(4)
-    nl, _ = random_nlist(rng, 10, 8, fill=0.6, rmin=0.9, rmax=2.5, dtype=np.float64)
+    from hoomd_tf_amd import codegen as cg
+    from hoomd_tf_amd.simmodel import PairCond, PairExpr
+    rng = np.random.default_rng(5)
+    nl, _ = random_nlist(rng, 24, 12, fill=0.6, rmin=0.85, rmax=2.9, dtype=np.float64)
+    pts = nl.reshape(-1, 4)[:, :3]
+    for name in ("lj_layer", "morse", "yukawa_mix", "switched", "soft"):
+        x = htf.Nlist(torch.from_numpy(nl))
+        w = torch.nn.Parameter(torch.tensor([1.1, 0.95], dtype=torch.float64))
+        a = torch.nn.Parameter(torch.tensor(0.7, dtype=torch.float64))
+        b = torch.nn.Parameter(torch.tensor(2.3, dtype=torch.float64))
+        e = _weighted_models(htf, x, w, a, b)[name]
+        assert isinstance(e, PairExpr) and e.folded == () and e.lowers(), name
+        els = e.weight_elements
+        P = len(els)
+        assert 1 <= P <= 4 and "p.theta[" in e.body() and "//@train %d" % P in e.body(), name
+        body0 = e.body()
+        with torch.no_grad():
+            a.mul_(1.5)                                            # a written weight: the same text, the same kernel
+        x2 = htf.Nlist(torch.from_numpy(nl))
+        assert _weighted_models(htf, x2, w, a, b)[name].body() == body0
+        # reference: torch fp64, every slot
+        t = torch.from_numpy(pts + 1e-7)
+        r = torch.sqrt((t * t).sum(dim=1)).requires_grad_(True)
+        ok = r > 3e-6
+        sv = torch.where(ok, 1.0 / (torch.where(ok, r, torch.ones_like(r)) + 3e-6), torch.zeros_like(r))
+        rn = torch.sqrt((torch.from_numpy(pts) ** 2).sum(dim=1))
+        params = [tt.reshape(-1)[i] for tt, i in els]
+        val = cg.evaluate(e.node, sv, r, rn, tj=torch.zeros_like(r), ti=torch.zeros_like(r), params=params)
+        (gr,) = torch.autograd.grad(val.sum(), r, create_graph=True)
+        leaves = [tt for tt, _ in els]
+        gw, grw = [], []
+        for k, (tt, i) in enumerate(els):
+            # d val / d w_k per slot, and d (d val / d r) / d w_k per slot (the slots are independent: one backward per slot sum is
+            # not enough for the per-slot value, so a unit perturbation through forward differences of autograd's jvp)
+            one = torch.zeros_like(tt)
+            one.reshape(-1)[i] = 1.0
+            _, jv = torch.autograd.functional.jvp(lambda q: cg.evaluate(e.node, sv.detach(), r.detach(), rn, tj=torch.zeros_like(rn), ti=torch.zeros_like(rn),
+                                                                       params=[q.reshape(-1)[ii] if t2 is tt else t2.reshape(-1)[ii] for t2, ii in els]),
+                                                  (tt.detach(),), (one,))
+            gw.append(jv.numpy())
+
+            def dvdr(q, tt=tt):
+                rr = r.detach().clone().requires_grad_(True)
+                ok2 = rr > 3e-6
+                s2 = torch.where(ok2, 1.0 / (torch.where(ok2, rr, torch.ones_like(rr)) + 3e-6), torch.zeros_like(rr))
+                v = cg.evaluate(e.node, s2, rr, rn, tj=torch.zeros_like(rn), ti=torch.zeros_like(rn),
+                                params=[q.reshape(-1)[ii] if t2 is tt else t2.reshape(-1)[ii] for t2, ii in els])
+                (g,) = torch.autograd.grad(v.sum(), rr, create_graph=True)
+                return g
+            _, jv2 = torch.autograd.functional.jvp(dvdr, (tt.detach(),), (one,))
+            grw.append(jv2.numpy())
+        del leaves
+        # the emitted training body, run on the host
+        train = e.body().split("//@train %d\n" % P)[1]
+        with tempfile.TemporaryDirectory() as tmp:
+            src = os.path.join(tmp, "h.c")
+            theta = ", ".join("%.9gf" % float(tt.reshape(-1)[i]) for tt, i in els)
+            with open(src, "w") as f:
+                f.write(TRAIN_HARNESS.replace("BODY", train).replace("THETA", theta).replace("NP", str(P)))
+            exe = os.path.join(tmp, "h")
+            subprocess.check_call(["gcc", "-O1", "-o", exe, src, "-lm"])
+            out = subprocess.run([exe], input="\n".join("%.9g %.9g %.9g" % tuple(pp) for pp in pts.astype(np.float32)), capture_output=True,
+                                 text=True, check=True).stdout
+        got = np.array([[float(v) for v in line.split()] for line in out.strip().splitlines()])
+        live = pts.any(axis=1)
+        ref = [val.detach().numpy(), gr.detach().numpy()]
+        for k in range(P):
+            ref += [gw[k], grw[k]]
+        for c, rf in enumerate(ref):
+            scale = np.abs(rf).max()
+            if scale == 0:
+                assert np.all(got[:, c] == 0), (name, c)
+                continue
+            assert np.abs(got[:, c] - rf)[live].max() < 2e-5 * scale, (name, c, np.abs(got[:, c] - rf)[live].max() / scale)
+        assert np.all(got[~live] == 0.0), name                     # padded slots: exact zeros in every column
+    # comparisons with a weight stay symbolic too; a tensor of per-pair values still goes to torch
     x = htf.Nlist(torch.from_numpy(nl))
-    s, r = htf.nlist_rinv(x), htf.safe_norm(x[:, :, :3], axis=2)
-    w = torch.nn.Parameter(torch.tensor(1.7, dtype=torch.float64))
-    traced = htf.exp(-0.7 * r) * s
-    assert isinstance(traced, PairExpr) and isinstance(2.0 * traced, PairExpr) and traced.folded == ()
-    # inference: folded, version remembered, propagated through everything built on top
-    e = htf.reduce_sum(htf.where(r < 2.0, w * traced, 0.0 * s) + s ** 6 * w, axis=1)
-    assert isinstance(e, PairExpr) and len(e.folded) == 2 and all(t is w and v == w._version for t, v in e.folded)
-    assert "1.7" in e.body()
-    with torch.no_grad():
-        w.mul_(2.0)
-    assert any(t._version != v for t, v in e.folded)                      # what tfcompute._plan_is_stale looks at
-    cond = r < w
-    assert len(cond.folded) == 1
-    # training: live
-    simmodel._trace.training_graph = True
-    try:
-        e = w * traced
-        assert isinstance(e, torch.Tensor) and e.requires_grad
-        f = htf.compute_nlist_forces(x, e.sum(dim=1))
-        t = torch.from_numpy(nl)[:, :, :3] + 1e-7
-        rr = torch.sqrt((t * t).sum(dim=2))
-        ss = torch.where(rr > 3e-6, 1.0 / (rr + 3e-6), torch.zeros_like(rr))
-        np.testing.assert_allclose(f[:, 3].detach().numpy(), (3.4 * torch.exp(-0.7 * rr) * ss).sum(dim=1).numpy(), rtol=1e-12)
-        (gw,) = torch.autograd.grad(e.sum(), w)
-        np.testing.assert_allclose(float(gw), float((torch.exp(-0.7 * rr) * ss).sum()), rtol=1e-12)
-        for live in (w * s ** 6, s ** 6 * w, s ** 6 + w, w - s ** 2, s ** 6 / w):      # the zoo's polynomials likewise
-            assert isinstance(live, torch.Tensor) and live.requires_grad
-    finally:
-        simmodel._trace.training_graph = False
-    assert isinstance(torch.tensor(2.0, dtype=torch.float64) * s ** 6, PairExpr)  # (a plain one-element constant always folds)
-    per_pair = torch.from_numpy(rng.uniform(0.5, 1.5, (10, 8)))
-    assert isinstance(traced * per_pair, torch.Tensor) and isinstance(per_pair * traced, torch.Tensor)
-    assert isinstance(traced < per_pair, torch.Tensor)
-    w2 = torch.nn.Parameter(torch.tensor(0.5, dtype=torch.float64))
-    e = (-1.0 * w * w2) * traced                                                     # a scalar computed from weights: its leaves are watched
-    assert isinstance(e, PairExpr) and {id(t) for t, _ in e.folded} == {id(w), id(w2)}
+    w1 = torch.nn.Parameter(torch.tensor(1.7, dtype=torch.float64))
+    r = htf.safe_norm(x[:, :, :3], axis=2)
+    assert isinstance(r < w1, PairCond) and (r < w1).folded == ()
+    traced = htf.exp(-0.7 * r) * htf.nlist_rinv(x)
+    per_pair = torch.from_numpy(rng.uniform(0.5, 1.5, nl.shape[:2]))
+    assert isinstance(traced * per_pair, torch.Tensor) and isinstance(traced < per_pair, torch.Tensor)
+    assert isinstance(torch.tensor(2.0, dtype=torch.float64) * traced, PairExpr)      # (a plain one-element constant folds)
+    # an Add with a hidden constant cannot be recovered from the autograd graph: folded during inference, as before
+    e = (w1 + 1.0) * traced
+    assert isinstance(e, PairExpr) and len(e.folded) == 1 and e.weight_elements == []
+    # the torch value of a weighted expression carries the weights' gradients (the generic route, e.g. with HTF_NO_JIT=1)
+    x = htf.Nlist(torch.from_numpy(nl))
+    e = w1 * htf.exp(-0.7 * htf.safe_norm(x[:, :, :3], axis=2)) * htf.nlist_rinv(x)
+    (g,) = torch.autograd.grad(e.torch_value(x.ad).sum(), w1)
+    tt = torch.from_numpy(nl)[:, :, :3] + 1e-7
+    rr = torch.sqrt((tt * tt).sum(dim=2))
+    ss = torch.where(rr > 3e-6, 1.0 / (rr + 3e-6), torch.zeros_like(rr))
+    np.testing.assert_allclose(float(g), float((torch.exp(-0.7 * rr) * ss).sum()), rtol=1e-12)
+
+
+@pytest.mark.parametrize("how", ["hiprtc", "hipcc"])
+def test_unit_with_weights_cross_compiles_with_its_training_sweep(how, monkeypatch):
+    import hoomd_tf_amd as htf
+    from hoomd_tf_amd import codegen as cg
+    monkeypatch.setenv("HTF_JIT_COMPILER", how)
+    if cg.compiler() != how:
+        pytest.skip("%s not available" % how)
+    x = htf.Nlist(torch.zeros((2, 4, 4), dtype=torch.float64))
+    w = torch.nn.Parameter(torch.tensor([1.1, 0.95], dtype=torch.float64))
+    a = torch.nn.Parameter(torch.tensor(0.7, dtype=torch.float64))
+    b = torch.nn.Parameter(torch.tensor(2.3, dtype=torch.float64))
+    e = _weighted_models(htf, x, w, a, b)["yukawa_mix"]
+    image, key = cg.compile_body(e.body())
+    assert b"htf_jit_train_f32" in image and b"htf_jit_train_f64" in image and b"htf_jit_nparams" in image and b"htf_jit_rows2_f32_store" in image
+    plain = (htf.exp(-0.7 * htf.safe_norm(x[:, :, :3], axis=2)) * htf.nlist_rinv(x))
+    image2, _ = cg.compile_body(plain.body())
+    assert b"htf_jit_train_f32" not in image2
 
 
 def _random_expression(htf, rng, s, r, tj, ti, depth):

@@ -180,11 +180,12 @@ def test_typed_model_is_replayed_as_the_one_kernel_step(htf, cuda, wire, monkeyp
     assert float((f2[:, :3] - f1[:, :3]).abs().max()) > 0.05 * scale      # (the species matter: one-species forces are elsewhere)
 
 
-def test_a_model_with_weights_runs_generated_kernels_until_a_weight_is_written(htf, cuda, monkeypatch):
-    """Inference MD with a traced model that owns torch Parameters (what every Keras layer upstream does): the weights' present
-    values are constants of the generated kernel and the model is replayed as the one-kernel step; writing a weight in place
-    (load_weights, an optimizer step) makes the plan stale -- the next step re-traces with the new value, a new kernel -- and the
-    forces follow it: equal to the torch-autograd route with the same weights, before and after."""
+def test_a_model_with_weights_keeps_its_kernel_when_a_weight_is_written(htf, cuda, monkeypatch):
+    """Inference MD with a traced model that owns torch Parameters (what every Keras layer upstream does).  Round 6: the weights
+    are ARGUMENTS of the generated kernel (``p.theta[k]``, read at launch), not constants of its text: writing one in place
+    (load_weights, an optimizer step) costs a 4-byte copy before the next launch -- the plan, the potential and the code object stay
+    (round 5 re-traced and compiled a new kernel per value) -- and the forces follow it: equal to the torch-autograd route with the
+    same weights, before and after."""
     from hoomd_tf_amd import _lib, standin
 
     class Morse(htf.SimModel):
@@ -228,15 +229,128 @@ def test_a_model_with_weights_runs_generated_kernels_until_a_weight_is_written(h
     _, ref = run(False, [0.8, 1.6, 1.6])
     plans = [g[0] for g in got]
     assert all(p is not None and p.kind == _lib.POT_JIT for p in plans) and not any(g[2] for g in got)
-    assert plans[0] is not plans[1] and plans[1] is plans[2]            # re-traced once, when the weight changed; not again
-    assert "0.4" in plans[0].body and "0.8" in plans[1].body               # 0.5 * depth, as a constant of each kernel
-    assert len(tfc._plan_folded) >= 2
+    assert plans[0] is plans[1] is plans[2]                                  # ONE potential, one code object, three weight values
+    assert "p.theta[" in plans[0].body and plans[0].num_params == 2 and tfc._plan_folded == ()
+    assert abs(float(tfc._plan_weights.theta[tfc._plan_weights.elements.index((tfc.model.depth, 0))]) - 1.6) < 1e-6
     for (_, f, _), (p0, f0, _) in zip(got, ref):
         assert p0 is None
         scale = float(f0[:, :3].abs().max())
         assert float((f[:, :3] - f0[:, :3]).abs().max()) < 2e-3 * scale
         assert abs(float(f[:, 3].double().sum()) - float(f0[:, 3].double().sum())) < 1e-4 * abs(float(f0[:, 3].double().sum())) + 1e-3
     assert float((got[1][1][:, 3].double().sum() / got[0][1][:, 3].double().sum())) > 1.5      # (twice the well depth: the energy followed)
+
+
+def _traced_forces_fn(htf, make_energy, elements_of):
+    """(nlist fp64 leaf, theta fp64) -> [B, 4] forces with the graph kept: compute_nlist_forces of the traced expression's torch value
+    (simmodel.py:526-555), for torch's double backward."""
+    from hoomd_tf_amd import codegen as cg
+
+    def fwd(n, ww):
+        x = n[:, :, :3]
+        t = x + 1e-7
+        r = torch.sqrt((t * t).sum(dim=2))
+        ok = r > 3e-6
+        s = torch.where(ok, 1.0 / (torch.where(ok, r, torch.ones_like(r)) + 3e-6), torch.zeros_like(r))
+        rn = torch.sqrt((x * x).sum(dim=2)).detach()
+        e = cg.evaluate(make_energy.node, s, r, rn, tj=n[:, :, 3].detach(), ti=None, params=[ww[k] for k in range(len(elements_of))])
+        (g,) = torch.autograd.grad(e.sum(), n, create_graph=True)
+        return torch.cat([2.0 * g[:, :, :3].sum(dim=1), e.sum(dim=1, keepdim=True)], dim=1)
+    return fwd
+
+
+@pytest.mark.parametrize("name", ["lj_layer", "morse", "yukawa_mix", "switched", "soft"])
+def test_traced_energy_with_weights_loss_gradient(htf, cuda, name):
+    """Round 6: htf_train_pair_grad on a GENERATED unit -- the library's training sweep around the emitted jets:
+    prediction, MSE over the four columns, d loss / d w_k -- against torch's fp64 double backward of the same expression, at the
+    trainable closed forms' tolerance (2e-4 of the largest gradient component), 300 x 64 slots, labels = 0.05 x LJ; and the
+    prediction against the generated evaluator."""
+    from oracle import graph_torch as G
+    from oracle import htf_oracle as O
+    from test_codegen_cpu import _weighted_models
+    rng = np.random.default_rng(3)
+    nl, _ = random_nlist(rng, 300, 64, fill=0.7, rmin=0.9, rmax=2.9, dtype=np.float32)
+    x = htf.Nlist(torch.from_numpy(nl).to(cuda))
+    w = torch.nn.Parameter(torch.tensor([1.1, 0.95], device=cuda))
+    a = torch.nn.Parameter(torch.tensor(0.7, device=cuda))
+    b = torch.nn.Parameter(torch.tensor(2.3, device=cuda))
+    e = _weighted_models(htf, x, w, a, b)[name]
+    assert e.lowers()
+    tw = e.layer
+    pot = tw.potential(cuda)
+    P = pot.num_params
+    assert P == len(e.weight_elements) >= 1
+    labels = torch.from_numpy((0.05 * O.lj_model(nl.astype(np.float64))).astype(np.float32)).to(cuda)
+    pred = torch.empty((nl.shape[0], 4), device=cuda)
+    accum = htf.ops.train_pair_grad(pot, x.tensor, labels, pred=pred).double().cpu().numpy()
+    f = htf.ops.eval_forces(pot, x.tensor)
+    assert float((pred - f).abs().max()) <= 2e-5 * float(f.abs().max()) + 1e-6
+    theta = tw.theta.double().cpu().numpy()
+    fwd = _traced_forces_fn(htf, e, e.weight_elements)
+    loss, g = G.mse_grad_wrt_params(fwd, torch.from_numpy(nl.astype(np.float64)), labels.double().cpu(), theta)
+    B = nl.shape[0]
+    np.testing.assert_allclose(accum[0] / (4 * B), loss, rtol=2e-4)
+    got = accum[1:] / (4 * B)
+    used = [k for k in range(P) if np.abs(g[k]) > 0]
+    assert used and np.abs(got - g).max() < 2e-4 * np.abs(g).max(), (name, got, g)
+    assert all(got[k] == 0 for k in range(P) if k not in used)
+
+
+def test_traced_trainable_model_trains_on_the_generated_kernels(htf, cuda):
+    """examples/06 Force Matching as a user writes it with htf.* ops -- a Lennard-Jones energy on nlist_rinv with a trainable weight
+    VECTOR indexed by element, build_examples.py:336-372 -- through tfcompute.attach(train=True): every training step is the
+    generated sweep + the device optimizer (no torch-route step: the trace log shows the JIT potential and its layer), the weights
+    the user holds move toward the reference's (eps, sigma) = (1, 1), and the trajectory of the weights equals the zoo's LJLayer
+    trained the same way."""
+    from hoomd_tf_amd import _lib, standin
+    import build_examples
+
+    class TracedLJ(htf.SimModel):
+        def setup(self, pref, length):
+            self.w = torch.nn.Parameter(torch.tensor([pref, length], device="cuda"))
+
+        def compute(self, nlist, positions, box):
+            q = (self.w[1] * htf.nlist_rinv(nlist)) ** 6
+            return htf.compute_nlist_forces(nlist, htf.reduce_sum(self.w[0] * 2.0 * (q * q - q), axis=1)), self.w
+
+    def run(kind):
+        pos, L, a = standin.fcc_positions(6, 0.8442)
+        rng = np.random.default_rng(2)
+        pos = pos + 0.03 * a * rng.standard_normal(pos.shape)
+        pos -= np.round(pos / L) * L
+        sysm = standin.System(pos, L, dtype=torch.float32, device=cuda)
+        sysm.randomize_velocities(kT=0.5, seed=2)
+        sim = standin.Simulation(sysm)
+        sim.integrate_nve(0.002)
+        nlist = sim.nlist_cell(check_period=1)
+        lj = htf.tfcompute(build_examples.LJModel(96))
+        lj.attach(nlist, r_cut=2.5)
+        # (upstream's LJLayer(sig, eps) holds w = [sig, eps] and uses w[0] as the prefactor, w[1] as the length: build_examples.py:349-350)
+        model = (TracedLJ(96, pref=0.8, length=1.05, output_forces=False) if kind == "traced"
+                 else build_examples.TrainableGraph(96, output_forces=False, sig=0.8, eps=1.05))
+        model.compile(htf.optimizers.Adam(0.01), loss='MeanSquaredError')
+        tfc = htf.tfcompute(model)
+        tfc.attach(nlist, train=True, r_cut=2.5)
+        tfc.set_reference_forces(lj)
+        traj, losses = [], []
+        for _ in range(8):
+            sim.run(5)
+            torch.cuda.synchronize()
+            wv = (model.w if kind == "traced" else model.lj.w).detach().cpu().numpy().copy()
+            traj.append(wv)
+            losses.append(float(tfc._opt_state[20]))
+        return model, tfc, np.array(traj), losses
+
+    model, tfc, traj, loss = run("traced")
+    pot = tfc._train_potential
+    assert pot is not None and pot.kind == _lib.POT_JIT and pot.num_params == 2          # the generated sweep trained it
+    # it learns: the length, which the labels pin hardest, has covered more than half of its way from 1.05 to the reference's 1.0
+    assert np.isfinite(traj).all() and abs(traj[-1, 1] - 1.0) < 0.5 * 0.05 and np.isfinite(loss).all()
+    # the user's Parameter holds what the device optimizer trained (theta is in TRACE order: w[1] is read first)
+    assert np.allclose(np.sort(model.w.detach().cpu().numpy()), np.sort(tfc._train_potential.theta.cpu().numpy()))
+    _, _, ref, loss_ref = run("zoo")
+    # same optimizer, same labels: the same walk (the zoo's kernel takes 1 / r where the traced energy takes nlist_rinv = 1 / (r + 3e-6))
+    assert np.abs(traj - ref).max() < 2e-4, (traj, ref)
+    assert np.abs(np.array(loss) - np.array(loss_ref)).max() < 1e-3 * max(loss_ref) + 1e-9
 
 
 def test_random_expressions_on_the_device(htf, cuda):

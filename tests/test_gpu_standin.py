@@ -503,7 +503,9 @@ def test_fused_step_equals_force_kernel_plus_integrator(htf, cuda, tdt, cells, p
         ctx.set_potential(htf.Potential.lj() if pot == "lj" else htf.Potential.wca(1.0))
         nve = standin.NVE(sysm, 0.004)
         fs = standin.FusedStep(sysm, nl, ctx, nve)
-        assert fs.available
+        # (fp64 positions -- a HOOMD DOUBLE build -- keep the integrator's own launch: the epilogue measured slower there, 9.7 k against
+        #  11.1 k steps/s at C3, and is not compiled; FusedStep then IS the classic pair of launches)
+        assert fs.available == (tdt == torch.float32)
         home = sysm.pos.data_ptr()
         swaps = 0
         for ts in range(80):
@@ -511,7 +513,7 @@ def test_fused_step_equals_force_kernel_plus_integrator(htf, cuda, tdt, cells, p
                 before = sysm.pos.data_ptr()
                 fs.step(ts)
                 swaps += int(sysm.pos.data_ptr() != before)
-                if ts % period == period - 1:
+                if ts % period == period - 1 and fs.available:
                     assert sysm.pos.data_ptr() == home
             else:
                 nl.compute(ts)
@@ -520,7 +522,7 @@ def test_fused_step_equals_force_kernel_plus_integrator(htf, cuda, tdt, cells, p
         torch.cuda.synchronize()
         assert nl.device_builds() >= 2
         if mode == "fused":
-            assert swaps == (80 if period % 2 == 0 else 80 - 80 // period)
+            assert swaps == ((80 if period % 2 == 0 else 80 - 80 // period) if fs.available else 0)
         out[mode] = (sysm.pos.clone(), sysm.vel.clone(), sysm.force.clone(), nl.device_builds())
     assert out["classic"][3] == out["fused"][3]
     for k in range(3):
