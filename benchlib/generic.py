@@ -140,6 +140,60 @@ def run_generic_lj(args, htf, standin, dev):
                 "potential_kind": getattr(tfc._plan, "kind", None), "energy_per_particle_after_warmup": e_warm,
                 "energy_per_particle": float(f[:, 3].double().sum().item()) / sysm.N}
 
+    class TracedLJ(htf.SimModel):
+        """examples/06 Force Matching as a user writes it: a Lennard-Jones energy whose prefactor and length are elements of a
+        trainable weight vector (build_examples.py:336-372).  The weights are kernel arguments of the generated evaluator and
+        of the generated training sweep (forward-mode jets over (r, w_k))."""
+        def setup(self, pref, length):
+            self.w = torch.nn.Parameter(torch.tensor([pref, length], device=dev))
+
+        def compute(self, nlist, positions, box):
+            q = (self.w[1] * htf.nlist_rinv(nlist)) ** 6
+            return htf.compute_nlist_forces(nlist, htf.reduce_sum(self.w[0] * 2.0 * (q * q - q), axis=1)), self.w
+
+    class ZooLJ(htf.SimModel):
+        def setup(self, pref, length):
+            self.lj = htf.LJLayer(pref, length)
+
+        def compute(self, nlist, positions, box):
+            e = htf.reduce_sum(self.lj(htf.safe_norm(nlist[:, :, :3], axis=2)), axis=1)
+            return htf.compute_nlist_forces(nlist, e), self.lj.w
+
+    def train_one(lattice, cells, model_cls, steps):
+        """Force matching on the fly at every MD step: the lowered LJModel drives the run, the trainable model sees the same
+        neighbor table, its loss is the mean squared force difference, Adam on the device (training sweep + optimizer kernel)."""
+        pos, L, a = (standin.sc_positions if lattice == "sc" else standin.fcc_positions)(cells, 0.8442)
+        rng = np.random.default_rng(7)
+        pos = pos + 0.03 * a * rng.standard_normal(pos.shape)
+        pos -= np.round(pos / L) * L
+        sysm = standin.System(pos, L, dtype=torch.float32, device=dev)
+        sysm.randomize_velocities(kT=1.0, seed=7)
+        sim = standin.Simulation(sysm)
+        sim.integrate_nve(args.dt)
+        nlist = sim.nlist_cell(r_buff=args.rbuff, check_period=args.check_period)
+        lj = htf.tfcompute(LJModel(NN))
+        lj.attach(nlist, r_cut=rcut)
+        model = model_cls(NN, pref=0.8, length=1.05, output_forces=False)
+        model.compile(htf.optimizers.Adam(0.001), loss='MeanSquaredError')
+        tfc = htf.tfcompute(model)
+        tfc.attach(nlist, train=True, r_cut=rcut)
+        tfc.set_reference_forces(lj)
+        sim.run(max(5, args.warmup))
+        torch.cuda.synchronize()
+        els = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            sim.run(steps)
+            torch.cuda.synchronize()
+            els.append(time.perf_counter() - t0)
+        el = sorted(els)[1]
+        pot = tfc._train_potential
+        w = (model.w if model_cls is TracedLJ else model.lj.w).detach().cpu().numpy()
+        assert pot is not None and np.isfinite(w).all()
+        return {"steps_per_s": steps / el, "ms_per_step": el / steps * 1e3, "particles": sysm.N, "steps": steps,
+                "windows_ms_per_step": [e / steps * 1e3 for e in els], "train_potential_kind": int(pot.kind),
+                "weights_after": [float(x) for x in w], "loss": float(tfc._opt_state[20])}
+
     sizes = {}
     for tag, lattice, cells in (("C2 (sc 32^3 = 32768)", "sc", 32), ("C3 (fcc 32^3 x 4 = 131072)", "fcc", 32)):
         fast = one(lattice, cells, LJModel, args.steps)
@@ -158,7 +212,13 @@ def run_generic_lj(args, htf, standin, dev):
         assert yuk["potential_kind"] == 9 and morse["potential_kind"] == 9 and mix["potential_kind"] == 9
         assert abs(mix["energy_per_particle_after_warmup"] - mix_torch["energy_per_particle_after_warmup"]) < 1e-3 * abs(mix_torch["energy_per_particle_after_warmup"]) + 1e-3
         assert abs(yuk["energy_per_particle_after_warmup"] - yuk_torch["energy_per_particle_after_warmup"]) < 1e-3 * abs(yuk_torch["energy_per_particle_after_warmup"]) + 1e-3
-        sizes[tag] = {"lowered": fast, "generic": gen, "generic_over_lowered_time": gen["ms_per_step"] / fast["ms_per_step"],
+        tr = train_one(lattice, cells, TracedLJ, args.steps)
+        tr_zoo = train_one(lattice, cells, ZooLJ, args.steps)
+        assert tr["train_potential_kind"] == 9
+        assert abs(tr["weights_after"][1] - tr_zoo["weights_after"][1]) < 2e-3   # the same walk as the zoo's LJLayer
+        sizes[tag] = {"lowered": fast, "traced_trainable": tr, "zoo_trainable": tr_zoo,
+                      "traced_trainable_over_traced_inference_time": tr["ms_per_step"] / yuk["ms_per_step"],
+                      "traced_over_zoo_trainable_time": tr["ms_per_step"] / tr_zoo["ms_per_step"], "generic": gen, "generic_over_lowered_time": gen["ms_per_step"] / fast["ms_per_step"],
                       "traced_yukawa_lj": yuk, "traced_morse": morse, "torch_yukawa_lj": yuk_torch,
                       "traced_binary_mixture": mix, "torch_binary_mixture": mix_torch,
                       "traced_ionic": ion, "torch_ionic": ion_torch,
@@ -181,6 +241,10 @@ def run_generic_lj(args, htf, standin, dev):
                          "epsilon / sigma are gathered by species pair from positions[:, 3] and nlist[:, :, 3]; LJ cores + erfc-damped electrostatics between "
                          "two charged species): traced, lowered to generated kernels "
                          "(HTF_POT_JIT: hoomd_tf_amd/codegen.py -> hipcc --genco around csrc/jit_unit.hip), replayed as the one-kernel step",
+        "traced_trainable": "examples/06's trainable Lennard-Jones written with htf.* ops over a weight vector, trained by force matching at "
+                            "EVERY MD step while the lowered LJModel drives the run: the step is LJ force kernel + integrator + the generated "
+                            "training sweep (weights are kernel arguments; forward-mode jets over (r, w_k)) + the device Adam; zoo_trainable is "
+                            "the same with htf.LJLayer (the library's own closed-form sweep)",
         "note": "the generic route keeps the reference's arbitrary-model capability (htf/simmodel.py:87-121, 526-555); models made of "
                 "nlist_rinv polynomials, WCARepulsion, RBFExpansion + Dense stacks, EDS biases and compute_rdf are lowered to fused kernels",
         "roofline": None, "cpu_baseline": None,

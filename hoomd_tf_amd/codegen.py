@@ -34,13 +34,16 @@ PAD_R = math.sqrt(3.0) * 1e-7
 
 class Node:
     """One node of an elementwise expression over the pair slot's (s, r, rn): op + children (+ a constant)."""
-    __slots__ = ("op", "args", "value")
+    __slots__ = ("op", "args", "value", "_key")
 
     def __init__(self, op, args=(), value=None):
-        self.op, self.args, self.value = op, tuple(args), value
+        self.op, self.args, self.value, self._key = op, tuple(args), value, None
 
     def key(self):
-        return (self.op, self.value) + tuple(a.key() for a in self.args)
+        """Structural identity (hashable; kept on the node: a shared subexpression is walked once)."""
+        if self._key is None:
+            self._key = (self.op, self.value) + tuple(a.key() for a in self.args)
+        return self._key
 
 
 def const(v):
@@ -598,6 +601,24 @@ def unit_text(node):
     return body + "\n//@train %d\n" % n + generate_train_body(node, n)
 
 
+_UNITS = {}
+
+
+def unit_of(node):
+    """What this process already knows about an expression, by structure: {"text": unit_text, "vanishes": vanishes_on_padding,
+    "built": its code object is in the cache}.  A model that is traced at every step (training runs compute() per step) pays for
+    the emitter, the padding probe and the cache look-up once."""
+    k = node.key()
+    u = _UNITS.get(k)
+    if u is None:
+        if len(_UNITS) >= 256:
+            _UNITS.clear()
+        u = _UNITS[k] = {"text": unit_text(node), "vanishes": None, "built": False}
+    if u["vanishes"] is None:
+        u["vanishes"] = vanishes_on_padding(node)
+    return u
+
+
 def vanishes_on_padding(node):
     """Energy and derivative of a padded slot (s = 0, ds = 0, r = sqrt(3) 1e-7, plain norm 0, neighbor type 0), in fp64: must be
     exact zeros -- whatever the row particle's own type is (tried for 0..15 when the expression reads it)."""
@@ -629,8 +650,18 @@ def _hipcc():
     raise RuntimeError("hoomd_tf_amd.codegen: hipcc not found (set HIPCC); generated kernels need the ROCm compiler at run time")
 
 
+_CACHE_DIRS = {}
+
+
 def _cache_dir():
-    d = os.environ.get("HTF_JIT_CACHE") or os.path.join(_HERE, "_jit_cache")
+    want = os.environ.get("HTF_JIT_CACHE") or os.path.join(_HERE, "_jit_cache")
+    d = _CACHE_DIRS.get(want)
+    if d is None or not os.path.isdir(d):
+        d = _CACHE_DIRS[want] = _probe_cache_dir(want)
+    return d
+
+
+def _probe_cache_dir(d):
     try:
         os.makedirs(d, exist_ok=True)
         probe = os.path.join(d, ".w%d" % os.getpid())
@@ -647,7 +678,17 @@ _SOURCES = ("jit_unit.hip", "fused_eval.hip", "eval_pair.hip", "train_pair.hip",
 FLAGS = ["-std=c++17", "-O3", "-ffp-contract=on", "-DHTF_BUILD"]   # (-ffp-contract=on: as fused_eval.o is built, csrc/Makefile)
 
 
+_DIGEST = []
+
+
 def _source_digest():
+    """(once per process: the sources a running library was built from do not change under it)"""
+    if not _DIGEST:
+        _DIGEST.append(_read_source_digest())
+    return _DIGEST[0]
+
+
+def _read_source_digest():
     h = hashlib.sha256()
     for name in _SOURCES:
         with open(os.path.join(_CSRC, name), "rb") as f:
@@ -664,6 +705,16 @@ def compiler():
     want = os.environ.get("HTF_JIT_COMPILER")
     if want in ("hiprtc", "hipcc"):
         return want
+    probe = (os.environ.get("HIPCC"),)
+    if probe not in _COMPILER:
+        _COMPILER[probe] = _find_compiler()
+    return _COMPILER[probe]
+
+
+_COMPILER = {}
+
+
+def _find_compiler():
     try:
         from . import _lib
         if _lib._ctypes_lib.htf_jit_available():

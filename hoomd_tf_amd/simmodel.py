@@ -674,7 +674,7 @@ class PairExpr(PairEnergy):
     def body(self):
         from . import codegen as cg
         if getattr(self, "_body", None) is None:
-            self._body = cg.unit_text(self.node)     # (forward body; + the training jets when the expression reads weights)
+            self._body = cg.unit_of(self.node)["text"]     # (forward body; + the training jets when the expression reads weights)
         return self._body
 
     @property
@@ -700,9 +700,13 @@ class PairExpr(PairEnergy):
         else the torch route (forces by autograd)."""
         from . import codegen as cg
         if getattr(self, "_lowers", None) is None:
-            ok = os.environ.get("HTF_NO_JIT") != "1" and cg.vanishes_on_padding(self.node)
+            unit = cg.unit_of(self.node)
+            ok = os.environ.get("HTF_NO_JIT") != "1" and unit["vanishes"]
             if ok and getattr(_trace, "training_graph", False) and cg.params_of(self.node) and self.reads_own_type:
                 ok = False   # (the training sweep has no positions tensor beside the pair vectors: the torch route trains it)
+            if ok and unit["built"]:
+                self._lowers = True   # (this process has built or loaded it before: a model traced at every step asks every step)
+                return True
             if ok and not cg.available(self.body()):
                 import warnings
                 warnings.warn("hoomd_tf_amd: hipcc not found (set HIPCC): the traced pair energy runs as torch ops + autograd "
@@ -717,6 +721,7 @@ class PairExpr(PairEnergy):
                     warnings.warn("hoomd_tf_amd: the generated kernel of a traced pair energy did not compile -- torch ops + autograd "
                                   "instead (%s)" % str(e).splitlines()[0])
                     ok = False
+            unit["built"] = bool(ok)
             self._lowers = ok
         return self._lowers
 
@@ -975,9 +980,18 @@ class TracedWeights:
 
     def after_update(self):
         """theta (just stepped by the device optimizer) -> the leaves the user holds."""
-        with torch.no_grad():
+        if getattr(self, "_scatter", None) is None:
+            # per leaf: (leaf, its flat indices, the theta slots that go there) -- one index_copy_ per leaf and step
+            by_leaf = {}
             for k, (t, i) in enumerate(self.elements):
-                t.reshape(-1)[i] = self.theta[k].to(t.dtype)
+                by_leaf.setdefault(id(t), (t, [], []))
+                by_leaf[id(t)][1].append(i)
+                by_leaf[id(t)][2].append(k)
+            self._scatter = [(t, torch.tensor(ii, device=t.device), torch.tensor(kk, device=self.theta.device))
+                             for t, ii, kk in by_leaf.values()]
+        with torch.no_grad():
+            for t, ii, kk in self._scatter:
+                t.view(-1).index_copy_(0, ii, self.theta.index_select(0, kk).to(device=t.device, dtype=t.dtype))
         self._seen = tuple(t._version for t, _ in self.elements)
 
     @property

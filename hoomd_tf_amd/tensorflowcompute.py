@@ -13,6 +13,8 @@ TensorflowCompute) and has two execution paths:
 * eager: ``_finish_update(batch_index)`` per batch exactly as the reference orders it:
   compute_inputs -> model(inputs) -> outputs capture -> compute_outputs.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -96,6 +98,8 @@ class tfcompute:
         self._plan = None
         self._plan_folded = ()   # (weight, _version) pairs whose values are constants of the plan's generated kernel
         self._bplan = None  # EDS-biased model replayed as one kernel (see _maybe_install_plan)
+        self._tplan = None  # a training step replayed without calling compute() (see _maybe_install_train_plan)
+        self._train_seen = None
         self._post_ops = []  # replayable observables of the planned step (compute_rdf -> MeanTensor), run after the force kernel
         self._post_src = None
         self._ctx_ran = False
@@ -253,6 +257,10 @@ class tfcompute:
             self._calls += 1
             self._run_biased_plan()
             return
+        if self._tplan is not None:
+            self._calls += 1
+            self._run_train_plan()
+            return
         s = self.system
         bs = s.N if self.batch_size == 0 else self.batch_size
         simmodel._trace_log().clear()
@@ -268,6 +276,8 @@ class tfcompute:
             nbatch += 1
         if not self.train:
             self._maybe_install_plan(nbatch)
+        else:
+            self._maybe_install_train_plan(nbatch)
         simmodel._trace_log().clear()
 
     def _stage_labels(self):
@@ -357,6 +367,32 @@ class tfcompute:
         if hasattr(layer, "after_update"):
             layer.after_update()  # pair-MLP: operand images <- theta, on the device
         self._train_potential = pot  # keep alive until the stream has consumed it
+
+    def _maybe_install_train_plan(self, nbatch):
+        """A training step whose model is ONE trainable pair energy on the step's own neighbor tensor (LJLayer, WCARepulsion, PairMLP,
+        a traced energy with weights) is, from the second step on, a fixed sequence -- pair vectors, training sweep (prediction, loss,
+        parameter gradient), optimizer kernel -- and is replayed without calling compute(): no trace, no separate forward sweep
+        (the training sweep predicts by itself), no per-step host -> device copy of the box (a blocking copy: the host could not
+        run ahead of the device).  Same rule as the inference plan: model code does not run again once the plan is installed, so
+        anything else in the step -- an observable, saved outputs, a mapped or masked list, batches -- keeps the eager path.
+        HTF_NO_TRAIN_PLAN=1 keeps every step eager."""
+        seen, self._train_seen = self._train_seen, None
+        if seen is None or nbatch != 1 or os.environ.get("HTF_NO_TRAIN_PLAN") == "1":
+            return
+        entries, nlist_t, output = seen
+        if (len(entries) == 1 and entries[0].get("layer") is not None and "potential" in entries[0] and not entries[0]["virial"]
+                and entries[0]["nlist"].tensor is nlist_t and len(output) > 0 and output[0] is entries[0]["forces"]
+                and not self.save_output_period and not self.model._map_nlist and self.nneighbor_cutoff > 0 and not self.model.check_nlist
+                and not isinstance(self.model, simmodel.MolSimModel)):
+            self._tplan = {"layer": entries[0]["layer"], "potential": entries[0]["potential"]}
+
+    def _run_train_plan(self):
+        s, nl = self.system, self._nlist
+        self._stage_labels()
+        pv = ops.build_pair_vectors(s.pos, nl.n_neigh, nl.head_list, nl.nlist, s.box, self.r_cut, self.nneighbor_cutoff,
+                                    offset=0, batch_size=s.N, n_local=s.N, out_dtype=torch.float32)
+        self._last = (pv, ops.copy_positions(s.pos, offset=0, N=s.N, unstuff4=True), 0, s.N)
+        self._train_on_batch(pv, 0, s.N, [self._tplan])
 
     def _maybe_install_plan(self, nbatch):
         log = simmodel._trace_log()
@@ -467,6 +503,7 @@ class tfcompute:
                 self._train_generic(output, offset, n)
             else:
                 self._train_on_batch(nlist_t, offset, n, fused_entries)
+                self._train_seen = (list(simmodel._trace_log()[mark:]), nlist_t, output)
             return
         if self.force_mode_code == _lib.HTF_TF2HOOMD:
             f = SimModel.compute_outputs(_t(output[0]).detach(), s.dtype)

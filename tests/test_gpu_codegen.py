@@ -295,6 +295,57 @@ def test_traced_energy_with_weights_loss_gradient(htf, cuda, name):
     assert all(got[k] == 0 for k in range(P) if k not in used)
 
 
+@pytest.mark.parametrize("name", ["lj_layer", "yukawa_mix"])
+def test_traced_energy_with_weights_loss_gradient_full_size(htf, cuda, name):
+    """The generated training sweep at the size bench.py's generic-lj line runs it: 131 072 x 128, the C3 fcc box's own pair vectors.
+    The batch is 64 row-permuted replicas of one 2 048-row block (test_pair_mlp_gradient_full_size's trick), so the reference stays
+    a 2 048-row fp64 double backward: summed squared residual and every weight's gradient == 64 x the block's at 2e-4 of the
+    largest component; every replica of a row predicts the same bits; the sweep is deterministic."""
+    from oracle import graph_torch as G
+    from oracle import htf_oracle as O
+    from hoomd_tf_amd import standin
+    from test_codegen_cpu import _weighted_models
+    from test_gpu_parity import _jittered
+    NN, R, BLOCK = 128, 64, 2048
+    sysm, nlc, L = _jittered(standin, cuda, "fcc", 32, 3)
+    assert sysm.N == R * BLOCK
+    pv = htf.ops.build_pair_vectors(sysm.pos, nlc.n_neigh, nlc.head_list, nlc.nlist, sysm.box, 3.0, NN)
+    rng = np.random.default_rng(17)
+    first = int(rng.integers(0, sysm.N - BLOCK))
+    block = pv[first:first + BLOCK].clone()
+    del pv
+    perm = torch.from_numpy(rng.permutation(R * BLOCK)).to(cuda)
+    src_row = perm % BLOCK
+    x = block[src_row].contiguous()
+    blk = block.cpu().numpy()
+    blk64 = blk.astype(np.float64)
+    w = torch.nn.Parameter(torch.tensor([1.1, 0.95], device=cuda))
+    a = torch.nn.Parameter(torch.tensor(0.7, device=cuda))
+    b = torch.nn.Parameter(torch.tensor(2.3, device=cuda))
+    e = _weighted_models(htf, htf.Nlist(x), w, a, b)[name]
+    assert e.lowers()
+    tw = e.layer
+    pot = tw.potential(cuda)
+    P = pot.num_params
+    lab_blk = (0.05 * O.lj_model(blk64)).astype(np.float32)
+    labels = torch.from_numpy(lab_blk).to(cuda)[src_row].contiguous()
+    pred = torch.empty((R * BLOCK, 4), device=cuda)
+    accum = htf.ops.train_pair_grad(pot, x, labels, pred=pred)
+    assert torch.equal(accum, htf.ops.train_pair_grad(pot, x, labels))
+    accum = accum.double().cpu().numpy()
+    p = pred.cpu().numpy()
+    inv = torch.argsort(perm).cpu().numpy()
+    first_replica = p[inv[:BLOCK]]
+    assert np.array_equal(p, first_replica[src_row.cpu().numpy()])          # a row's sums do not depend on where it sits
+    fwd = _traced_forces_fn(htf, e, e.weight_elements)
+    theta = tw.theta.double().cpu().numpy()
+    loss, g = G.mse_grad_wrt_params(fwd, torch.from_numpy(blk64), torch.from_numpy(lab_blk).double(), theta)
+    n = 4.0 * R * BLOCK
+    np.testing.assert_allclose(accum[0] / n, loss, rtol=2e-4)
+    got = accum[1:1 + P] / n
+    assert np.abs(got - g).max() < 2e-4 * np.abs(g).max(), (name, got, g)
+
+
 def test_traced_trainable_model_trains_on_the_generated_kernels(htf, cuda):
     """examples/06 Force Matching as a user writes it with htf.* ops -- a Lennard-Jones energy on nlist_rinv with a trainable weight
     VECTOR indexed by element, build_examples.py:336-372 -- through tfcompute.attach(train=True): every training step is the

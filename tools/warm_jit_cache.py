@@ -44,7 +44,22 @@ def bodies():
     idx3 = htf.cast(P[:, 3], torch.int32)[:, None] * 3 + htf.cast(x[:, :, 3], torch.int32)
     q = (htf.gather(sig.reshape(-1), idx3) * s) ** 6
     out.append(htf.reduce_sum(2.0 * htf.gather(eps.reshape(-1), idx3) * (q * q - q), axis=1).body())
+    # models with trainable weights (kernel arguments): tests/test_codegen_cpu.py's and test_gpu_codegen.py's, bench generic-lj's
+    from test_codegen_cpu import _weighted_models
+    w = torch.nn.Parameter(torch.tensor([0.8, 1.05]))
+    a, b = torch.nn.Parameter(torch.tensor(1.3)), torch.nn.Parameter(torch.tensor(0.7))
+    out += [htf.reduce_sum(e, axis=1).body() for e in _weighted_models(htf, x, w, a, b).values()]
     return out
+
+
+def hipcc_bodies():
+    """The units tests/test_codegen_cpu.py builds with the FALLBACK compiler (`hipcc --genco`, ~25 s each on a cold cache)."""
+    from test_codegen_cpu import _models, _weighted_models
+    x = htf.Nlist(torch.zeros((2, 4, 4), dtype=torch.float64))
+    w = torch.nn.Parameter(torch.tensor([1.1, 0.95], dtype=torch.float64))
+    a, b = torch.nn.Parameter(torch.tensor(0.7, dtype=torch.float64)), torch.nn.Parameter(torch.tensor(2.3, dtype=torch.float64))
+    return [_models(htf, x)["yukawa"].body(), _weighted_models(htf, x, w, a, b)["yukawa_mix"].body(),
+            (htf.exp(-0.7 * htf.safe_norm(x[:, :, :3], axis=2)) * htf.nlist_rinv(x)).body()]
 
 
 def main():
@@ -54,6 +69,18 @@ def main():
         hit += os.path.exists(path)
         cg.compile_body(b)
         n += 1
+    try:
+        cg._hipcc()
+        os.environ["HTF_JIT_COMPILER"] = "hipcc"
+        for b in hipcc_bodies():
+            path = os.path.join(cg._cache_dir(), cg._key(b) + ".hsaco")
+            hit += os.path.exists(path)
+            cg.compile_body(b)
+            n += 1
+    except RuntimeError:
+        pass
+    finally:
+        os.environ.pop("HTF_JIT_COMPILER", None)
     print("warm_jit_cache: %d units (%d already cached) with %s in %.0f s" % (n, hit, cg.compiler(), time.time() - t0))
 
 
