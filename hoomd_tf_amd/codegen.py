@@ -197,6 +197,33 @@ class _Emitter:
         self.lines.append("const float %s = %s;" % (name, expr))
         return name
 
+    # erfc(x) = t P(t) exp(-x^2), t = 1 / (1 + 0.4 x), P of degree 10 (Chebyshev fit of erfcx(x) / t on t in (0, 1]: 8.5e-9 in
+    # fp64); exp(-x^2) with the rounding of x^2 and of its product with log2(e) carried as a first-order correction.  ~3 ulp to
+    # x = 4 (4e-7 relative; 1.4e-6 at x = 9), 24 vector instructions and two transcendentals where the device libm's erfcf takes
+    # ~3 x that with branches -- and exp(-x^2), which the derivative needs anyway, comes out of it (round 6: the ionic model
+    # 1.35 x lowered LJ -> see DESIGN 3.6).
+    _ERFC_P = (0.225675831, 0.225676317, 0.20760072, 0.171890572, 0.118095123, 0.0871206414, -0.0537931659, 0.146803245, -0.243041731,
+               0.143841069, -0.0298686285)
+
+    def erfc_gauss(self, a):
+        """-> (erfc(a), 2 / sqrt(pi) exp(-a^2)) as temporaries."""
+        ax = self.tmp("fabsf(%s)" % a)
+        t = self.tmp("__builtin_amdgcn_rcpf(fmaf(0.4f, %s, 1.0f))" % ax)
+        poly = "%.9gf" % self._ERFC_P[-1]
+        for c in self._ERFC_P[-2::-1]:
+            poly = "fmaf(%s, %s, %s)" % (poly, t, self.lit(c))
+        pv = self.tmp(poly)
+        sq = self.tmp("%s * %s" % (ax, ax))
+        lo = self.tmp("fmaf(%s, %s, -%s)" % (ax, ax, sq))
+        q = self.tmp("-%s * 1.4426950408889634f" % sq)
+        r1 = self.tmp("fmaf(-%s, 1.4426950408889634f, -%s)" % (sq, q))
+        corr = self.tmp("fmaf(-%s, 1.4426950408889634f, %s)" % (lo, r1))
+        ex = self.tmp("__builtin_amdgcn_exp2f(%s)" % q)
+        e1 = self.tmp("fmaf(%s * %s, 0.6931471805599453f, %s)" % (ex, corr, ex))
+        vp = self.tmp("%s * %s * %s" % (t, pv, e1))
+        v = self.tmp("%s < 0.0f ? 2.0f - %s : %s" % (a, vp, vp))
+        return v, self.tmp("1.1283791670955126f * %s" % e1)
+
     def weight(self, k):
         """w<k> = p.theta[k]: read once per body (a uniform load from the potential's device parameter vector)."""
         name = "w%d" % int(k)
@@ -329,12 +356,16 @@ class _Emitter:
         elif op in ("erf", "erfc"):
             # the real-space part of Ewald / DSF electrostatics: erfc(alpha r) / r.  d erf(a) = 2 / sqrt(pi) exp(-a^2)
             a, da = self.emit(node.args[0])
-            v = self.tmp("%s(%s)" % ("erff" if op == "erf" else "erfcf", a))
-            if da is None:
-                out = (v, None)
+            if op == "erfc":
+                v, g = self.erfc_gauss(a)
+                out = (v, None if da is None else self.tmp("-%s * %s" % (g, da)))
             else:
-                g = self.tmp("1.1283791670955126f * __builtin_amdgcn_exp2f(-(%s * %s) * 1.4426950408889634f)" % (a, a))
-                out = (v, self.tmp("%s%s * %s" % ("" if op == "erf" else "-", g, da)))
+                v = self.tmp("erff(%s)" % a)
+                if da is None:
+                    out = (v, None)
+                else:
+                    g = self.tmp("1.1283791670955126f * __builtin_amdgcn_exp2f(-(%s * %s) * 1.4426950408889634f)" % (a, a))
+                    out = (v, self.tmp("%s * %s" % (g, da)))
         elif op == "sigmoid":
             a, da = self.emit(node.args[0])
             v = self.tmp("__builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-%s * 1.4426950408889634f))" % a)
@@ -548,10 +579,12 @@ class _JetEmitter(_Emitter):
             elif op == "abs":
                 out = self.unary(A, self.tmp("fabsf(%s)" % a), self.tmp("%s < 0.0f ? -1.0f : (%s > 0.0f ? 1.0f : 0.0f)" % (a, a)), None)
             elif op in ("erf", "erfc"):
-                g = self.tmp("1.1283791670955126f * __builtin_amdgcn_exp2f(-(%s * %s) * 1.4426950408889634f)" % (a, a))
-                sg = "" if op == "erf" else "-"
-                out = self.unary(A, self.tmp("%s(%s)" % ("erff" if op == "erf" else "erfcf", a)), self.tmp("%s%s" % (sg, g)) if sg else g,
-                                 self.tmp("%s2.0f * %s * %s" % ("-" if op == "erf" else "", a, g)))
+                if op == "erfc":
+                    v, g = self.erfc_gauss(a)
+                    out = self.unary(A, v, self.tmp("-%s" % g), self.tmp("2.0f * %s * %s" % (a, g)))
+                else:
+                    g = self.tmp("1.1283791670955126f * __builtin_amdgcn_exp2f(-(%s * %s) * 1.4426950408889634f)" % (a, a))
+                    out = self.unary(A, self.tmp("erff(%s)" % a), g, self.tmp("-2.0f * %s * %s" % (a, g)))
             elif op == "sigmoid":
                 v = self.tmp("__builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-(%s) * 1.4426950408889634f))" % a)
                 f1 = self.tmp("%s * (1.0f - %s)" % (v, v))

@@ -54,6 +54,7 @@ struct JitKernels {
     hipModule_t mod = nullptr;
     hipFunction_t rows2[2][2] = {}; // [fp64 positions][tensor written]
     hipFunction_t row1v[2][2] = {};
+    hipFunction_t tails4[2] = {};   // [tensor written]: fp32 positions, four rows per wave with merged tails
     hipFunction_t eval[2][2] = {};  // [fp64 tensor][virial]
     hipFunction_t train[2] = {};    // [fp64 tensor]: only in a unit compiled with weights (HTF_JIT_NPARAMS)
     int nparams = 0;
@@ -81,6 +82,8 @@ int jit_create(const void *image, size_t bytes, JitKernels **out) {
             if (e == hipSuccess) e = hipModuleGetFunction(&k->row1v[a][b], k->mod, row1v[a][b]);
             if (e == hipSuccess) e = hipModuleGetFunction(&k->eval[a][b], k->mod, eval[a][b]);
         }
+    if (e == hipSuccess) e = hipModuleGetFunction(&k->tails4[0], k->mod, "htf_jit_tails4_f32_nostore");
+    if (e == hipSuccess) e = hipModuleGetFunction(&k->tails4[1], k->mod, "htf_jit_tails4_f32_store");
     if (e != hipSuccess) {
         set_error("HTF_POT_JIT: the code object lacks a kernel of csrc/jit_unit.hip: %s", hipGetErrorString(e));
         (void)hipModuleUnload(k->mod);
@@ -124,6 +127,12 @@ static int launch_fused_t(const PotParams &p, const void *pos, unsigned N, unsig
     if (virial9 == nullptr) {
         void *args[] = {&pos, &N, &NN, &offset, &batch, &b, &n_neigh, &nlist, &head_list, &rc2, &force, &out_f64, &pp, &check_count,
                         &positions_out, &dest, &counts_io};
+        static const char *tails_env = getenv("HTF_JIT_TAILS"); // "0": the two-row form at every size (A/B; forces then do not depend on how a step is cut)
+        if (!f64 && batch >= 49152u && !(tails_env && tails_env[0] == '0')) {
+            // launch_fused's rule for the closed forms BASELINE times: four rows per wave, their tails in one trip
+            HTF_CHECK_HIP(hipModuleLaunchKernel(p.jit->tails4[store], ((batch + 3) / 4 + 3) / 4, 1, 1, 256, 1, 1, 0, s, args, nullptr));
+            return HTF_OK;
+        }
         const unsigned grid = ((batch + 1) / 2 + 3) / 4; // two rows per wave, four waves per workgroup (launch_fused's HTF_ROWS_LAUNCH)
         HTF_CHECK_HIP(hipModuleLaunchKernel(p.jit->rows2[f64][store], grid, 1, 1, 256, 1, 1, 0, s, args, nullptr));
     } else {

@@ -33,6 +33,24 @@ HTF_JIT_ROWS2(htf_jit_rows2_f32_nostore, false, float)
 HTF_JIT_ROWS2(htf_jit_rows2_f64_store, true, double)
 HTF_JIT_ROWS2(htf_jit_rows2_f64_nostore, false, double)
 
+// the four-row form with merged tails (fp32 positions, batches of >= 49 152 rows: launch_fused's rule for LJ and WCA) -- round 6
+#define HTF_JIT_TAILS4(NAME, STORE)                                                                                                 \
+    extern "C" __global__ __launch_bounds__(256) void NAME(                                                                         \
+        const float4 *__restrict__ pos, unsigned N, unsigned NN, unsigned offset, unsigned batch, BoxT<float> box,                  \
+        const unsigned *__restrict__ n_neigh, const unsigned *__restrict__ nlist, const unsigned *__restrict__ head_list,            \
+        float rmaxsq, void *__restrict__ force, int out_f64, PotParams pin, unsigned *__restrict__ check_count,                     \
+        float4 *__restrict__ positions_out, float4 *__restrict__ dest, unsigned *__restrict__ counts_io) {                          \
+        const PotParams p = resolve_theta<HTF_POT_JIT>(pin);                                                                        \
+        const unsigned lane = threadIdx.x & 63u;                                                                                    \
+        const unsigned w0 = 4 * __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);                       \
+        if (w0 >= batch) return;                                                                                                    \
+        fused_rows_group_tails<HTF_POT_JIT, STORE, 4, float, 0>(w0, lane, pos, N, NN, offset, batch, box, n_neigh, nlist, head_list, \
+                                                                rmaxsq, force, out_f64, p, check_count, positions_out, dest,       \
+                                                                counts_io, nullptr);                                               \
+    }
+HTF_JIT_TAILS4(htf_jit_tails4_f32_store, true)
+HTF_JIT_TAILS4(htf_jit_tails4_f32_nostore, false)
+
 #define HTF_JIT_ROW1V(NAME, STORE, PT)                                                                                              \
     extern "C" __global__ __launch_bounds__(256) void NAME(                                                                         \
         const typename Vec4<PT>::type *__restrict__ pos, unsigned N, unsigned NN, unsigned offset, unsigned batch, BoxT<PT> box,    \

@@ -82,7 +82,9 @@ static void run16(const char *what, unsigned long long *d) {
 }
 
 // MODE bits: 1 = MFMAs, 2 = plain vector instructions, 4 = transcendentals
-template <int MODE, int CHAIN>
+// FMAS: plain v_fma per group (6 = the shipped tile's 648 plain instructions; 5 = 576, a little more than folding tanh's last fma
+// into the next layer's images would remove (-64); 4 = 504, under the 540 VERDICT r5 item 5 budgets)
+template <int MODE, int CHAIN, int FMAS = 6>
 __global__ __launch_bounds__(768) void mix_kernel(unsigned long long *out, int iters, float seed) {
     float f[16];
 #pragma unroll
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(768) void mix_kernel(unsigned long long *out, int i
             }
             if (MODE & 2) {
 #pragma unroll
-                for (int j = 0; j < 6; ++j) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(f[(g * 11 + j) & 15]) : "v"(seed));
+                for (int j = 0; j < FMAS; ++j) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(f[(g * 11 + j) & 15]) : "v"(seed));
                 asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(pk) : "v"(f[(g + 6) & 15]), "v"(f[(g + 7) & 15]));
                 asm volatile("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(pk) : "v"(pk), "v"(f[(g + 8) & 15]));
                 asm volatile("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(pk) : "v"(pk), "v"(f[(g + 9) & 15]));
@@ -137,13 +139,13 @@ __global__ __launch_bounds__(768) void mix_kernel(unsigned long long *out, int i
     }
 }
 
-template <int MODE, int CHAIN = 0>
+template <int MODE, int CHAIN = 0, int FMAS = 6>
 static void run(const char *what, unsigned long long *d) {
     const int iters = 200;
     for (int W = 1; W <= 3; ++W) {
         unsigned long long h[64];
         for (int r = 0; r < 2; ++r) {
-            hipLaunchKernelGGL((mix_kernel<MODE, CHAIN>), dim3(1), dim3(256 * W), 0, 0, d, iters, 1.25f);
+            hipLaunchKernelGGL((mix_kernel<MODE, CHAIN, FMAS>), dim3(1), dim3(256 * W), 0, 0, d, iters, 1.25f);
             hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
         }
         unsigned long long lo = ~0ull, hi = 0;
@@ -168,6 +170,10 @@ int main() {
     run<1, 1>("72 MFMA in chains of 6", d);
     run<7, 1>("72 MFMA (chains of 6) + 648 + 144", d);
     run<7, 2>("72 MFMA (12 at once) + 648 + 144", d);
+    // round 6: what a smaller plain-instruction count would buy (VERDICT r5 item 5's budget, priced before the kernel is touched)
+    run<7, 1, 5>("72 MFMA (chains of 6) + 576 + 144", d);
+    run<7, 1, 4>("72 MFMA (chains of 6) + 504 + 144", d);
+    run<7, 1, 3>("72 MFMA (chains of 6) + 432 + 144", d);
     // round 5: the same 32 pairs as two 16-pair tiles
     run16<1>("144 MFMA 16x16x32", d);
     run16<3>("144 MFMA 16x16x32 + 648 plain", d);
