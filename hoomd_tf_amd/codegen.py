@@ -78,6 +78,40 @@ def params_of(node, seen=None, out=None):
     return sorted(out)
 
 
+def rowsum(k):
+    """Row sum k of a per-particle expression (round 6): sum over the neighbor axis of a traced pair expression -- the argument of a
+    ROW FUNCTION, energy_i = F(sum_j g(r_ij)) (an embedding term, a coordination-number restraint)."""
+    return Node("rowsum", value=int(k))
+
+
+def rowsums_of(node, seen=None, out=None):
+    """The row-sum indices an expression reads, ascending."""
+    seen, out = (set(), set()) if seen is None else (seen, out)
+    if id(node) not in seen:
+        seen.add(id(node))
+        if node.op == "rowsum":
+            out.add(int(node.value))
+        for a in node.args:
+            rowsums_of(a, seen, out)
+    return sorted(out)
+
+
+def remap_rowsums(node, mapping, memo=None):
+    """The same expression with row sum k renamed mapping[k]."""
+    memo = {} if memo is None else memo
+    if id(node) in memo:
+        return memo[id(node)]
+    if node.op == "rowsum":
+        out = node if mapping[node.value] == node.value else rowsum(mapping[node.value])
+    elif not node.args:
+        out = node
+    else:
+        args = tuple(remap_rowsums(a, mapping, memo) for a in node.args)
+        out = node if all(x is y for x, y in zip(args, node.args)) else Node(node.op, args, node.value)
+    memo[id(node)] = out
+    return out
+
+
 S, R, RN = Node("s"), Node("r"), Node("rn")   # nlist_rinv, safe_norm, the plain norm (masks only: no gradient)
 TJ, TI = Node("tj"), Node("ti")               # the neighbor's type nlist[i, j, 3] and the row particle's own positions[i, 3], as floats
 UNARY = ("neg", "exp", "log", "tanh", "sqrt", "abs", "square", "mask", "erf", "erfc", "sigmoid", "softplus", "sin", "cos")
@@ -105,7 +139,7 @@ def reads(node, op, seen=None):
 
 
 # --------------------------------------------------------------------------- evaluation in torch (the reference, and eager values)
-def evaluate(node, s, r, rn, memo=None, tj=None, ti=None, params=None):
+def evaluate(node, s, r, rn, memo=None, tj=None, ti=None, params=None, rows=None):
     """The expression on torch tensors (any dtype): what the generated kernel computes per slot.  ``tj`` / ``ti``: the type
     leaves (broadcastable to ``s``), needed only by expressions that read them; ``params``: the weights (one-element tensors,
     on the autograd graph when they are being trained)."""
@@ -114,8 +148,12 @@ def evaluate(node, s, r, rn, memo=None, tj=None, ti=None, params=None):
     if k in memo:
         return memo[k]
     op = node.op
-    a = [evaluate(x, s, r, rn, memo, tj, ti, params) for x in node.args]
-    if op == "param":
+    a = [evaluate(x, s, r, rn, memo, tj, ti, params, rows) for x in node.args]
+    if op == "rowsum":
+        if rows is None or node.value >= len(rows):
+            raise ValueError("the expression reads row sum %d: evaluate() needs rows" % node.value)
+        out = rows[node.value]
+    elif op == "param":
         if params is None or node.value >= len(params):
             raise ValueError("the expression reads weight %d: evaluate() needs params" % node.value)
         out = params[node.value].reshape(()).to(dtype=s.dtype, device=s.device)
@@ -256,6 +294,8 @@ class _Emitter:
             out = ("r", "1.0f")
         elif op == "rn":
             out = (self.tmp("__builtin_amdgcn_sqrtf(x * x + y * y + z * z)"), None)
+        elif op == "rowsum":
+            out = ("rho", "1.0f")          # (a row function of ONE sum: the derivative slot is d / d rho)
         elif op == "const":
             out = (self.lit(node.value), None)
         elif op == "param":
@@ -443,6 +483,19 @@ def generate_body(node):
     return "\n".join(em.lines)
 
 
+def generate_row_fn(node):
+    """The statements pair_math.h splices into row_function<HTF_POT_JIT>: ``Fv`` = F(rho) and ``dF`` = F'(rho) of a per-particle
+    function of ONE row sum (rho = sum_j e_ij of the unit's pair body).  The kernels accumulate a row's (2 de/dr rhat, e) as for any
+    pair energy and finish it with forces x dF, energy = Fv (virial x |dF|: simmodel.py:509-523 takes the pair forces' norms)."""
+    if len(rowsums_of(node)) > 1 or any(reads(node, leaf) for leaf in ("s", "r", "rn", "tj", "ti")):
+        raise ValueError("a row function is an expression of one row sum")
+    em = _Emitter()
+    v, d = em.emit(node)
+    em.lines.append("Fv = %s;" % v)
+    em.lines.append("dF = %s;" % (d or "0.0f"))
+    return "\n".join(em.lines)
+
+
 class _JetEmitter(_Emitter):
     """Forward-mode JETS over (r', w_k) for the training sweep: every node yields (v, v_r, {k: v_w}, {k: v_rw}) -- value, d / dr',
     d / dw_k and the MIXED second derivative d2 / (dr' dw_k) -- as C expressions (None = identically zero).  The loss is
@@ -623,10 +676,17 @@ def generate_train_body(node, nparams):
     return "\n".join(em.lines)
 
 
-def unit_text(node):
-    """What identifies (and is compiled into) the generated unit of an expression: its forward body and, when it reads weights, a
-    marker line with their number followed by the training body."""
+def unit_text(node, row=None):
+    """What identifies (and is compiled into) the generated unit of an expression: its forward body; when it reads weights, a
+    marker line with their number followed by the training body; when the per-particle energy is a FUNCTION of the row's sum
+    (``row``: an expression of rowsum(0)), a marker line followed by the row function (no training body then: such a model trains on
+    the torch route)."""
     body = generate_body(node)
+    if row is not None:
+        ks = sorted(set(params_of(node)) | set(params_of(row)))
+        if ks:
+            body += "\n//@weights %d" % (ks[-1] + 1)
+        return body + "\n//@row\n" + generate_row_fn(row)
     ks = params_of(node)
     if not ks:
         return body
@@ -637,16 +697,16 @@ def unit_text(node):
 _UNITS = {}
 
 
-def unit_of(node):
+def unit_of(node, row=None):
     """What this process already knows about an expression, by structure: {"text": unit_text, "vanishes": vanishes_on_padding,
     "built": its code object is in the cache}.  A model that is traced at every step (training runs compute() per step) pays for
     the emitter, the padding probe and the cache look-up once."""
-    k = node.key()
+    k = node.key() if row is None else (node.key(), "row", row.key())
     u = _UNITS.get(k)
     if u is None:
         if len(_UNITS) >= 256:
             _UNITS.clear()
-        u = _UNITS[k] = {"text": unit_text(node), "vanishes": None, "built": False}
+        u = _UNITS[k] = {"text": unit_text(node, row), "vanishes": None, "built": False}
     if u["vanishes"] is None:
         u["vanishes"] = vanishes_on_padding(node)
     return u
@@ -778,11 +838,19 @@ def _body_include(body):
     and HTF_JIT_TRAIN_BODY_TEXT."""
     def macro(name, text):
         return "#define %s \\\n" % name + " \\\n".join("    " + l for l in text.splitlines()) + "\n"
+    body, rmark, row = body.partition("\n//@row\n")
+    body, wmark, nw = body.partition("\n//@weights ")
     fwd, mark, train = body.partition("\n//@train ")
     out = macro("HTF_JIT_BODY_TEXT", fwd)
     if mark:
         n, _, tb = train.partition("\n")
         out += "#define HTF_JIT_NPARAMS %d\n" % int(n) + macro("HTF_JIT_TRAIN_BODY_TEXT", tb)
+    if rmark:
+        # a row function: energy_i = F(sum_j e_ij).  Its weights (if any) are read from p.theta like the body's; HTF_JIT_NWEIGHTS
+        # tells the library how long the vector is (htf_jit_nparams of a unit WITHOUT a training sweep)
+        if wmark:
+            out += "#define HTF_JIT_NWEIGHTS %d\n" % int(nw)
+        out += macro("HTF_JIT_ROW_TEXT", row)
     return out
 
 

@@ -111,6 +111,23 @@ __device__ __forceinline__ void eval_pair_body(const typename Vec4<IT>::type *__
         vzz = group_sum<G>(vzz);
     }
 
+    if constexpr (HasRowFn<KIND>::value) { // (generated units: energy_i = F(sum_j e_ij), pair_math.h row_function)
+        float Fv, dF;
+        row_function<KIND>(p, en, Fv, dF);
+        fx *= dF;
+        fy *= dF;
+        fz *= dF;
+        en = Fv;
+        if constexpr (VIRIAL) {
+            const float a = fabsf(dF);
+            vxx *= a;
+            vxy *= a;
+            vxz *= a;
+            vyy *= a;
+            vyz *= a;
+            vzz *= a;
+        }
+    }
     if (g == 0 && active) {
         if (out_f64) {
             ((double4 *)force)[row] = make_double4(fx, fy, fz, en);

@@ -214,7 +214,8 @@ __device__ __forceinline__ void fused_row(const unsigned w, const unsigned lane,
     }
     // the four row sums as the row-group forms take them (wave_sum4: rows 0..3 of `tot` hold fx, fz, fy, e), so that a row's
     // force does not depend on which routine computed it
-    const float tot = wave_sum4(acc.fx, acc.fy, acc.fz, acc.en);
+    float vscale;
+    const float tot = finish_row_sums<KIND>(p, wave_sum4(acc.fx, acc.fy, acc.fz, acc.en), lane, &vscale);
     store_row_sums<PT, (EPL >= 2)>(force, out_f64, w, idx, lane, tot, pos, ep);
     float v6[6];
     if constexpr (VIRIAL) {
@@ -224,6 +225,11 @@ __device__ __forceinline__ void fused_row(const unsigned w, const unsigned lane,
         v6[3] = group_sum<64>(acc.v.yy);
         v6[4] = group_sum<64>(acc.v.yz);
         v6[5] = group_sum<64>(acc.v.zz);
+        if constexpr (HasRowFn<KIND>::value) {
+            // (simmodel.py:509-523 builds the virial from the NORMS of the pair forces: a row function scales it by |F'(rho)|)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) v6[c] *= vscale;
+        }
     }
     unsigned npos = 0;
     if (check_count != nullptr) npos = group_sum_u<64>(acc.npos);
@@ -413,7 +419,7 @@ __device__ __forceinline__ void fused_rows_group(
             redo |= 1u << r;
             continue;
         }
-        const float tot = wave_sum4(fx, fy, fz, en); // rows 0..3: fx, fz, fy, e
+        const float tot = finish_row_sums<KIND>(p, wave_sum4(fx, fy, fz, en), lane); // rows 0..3: fx, fz, fy, e
         tot_r[r] = tot;
         store_row_sums<PT>(force, out_f64, w, w + offset, lane, tot, pos, nullptr);
         if (check_count != nullptr) {
@@ -611,7 +617,7 @@ __device__ __forceinline__ void fused_rows_group_tails(
             continue;
         }
         // the row's four sums together: rows 0..3 of `tot` hold fx, fz, fy, e; lanes 0 / 16 / 32 / 48 write one component each
-        const float tot = wave_sum4(fx[r], fy[r], fz[r], en[r]);
+        const float tot = finish_row_sums<KIND>(p, wave_sum4(fx[r], fy[r], fz[r], en[r]), lane);
         tot_r[r] = tot;
         store_row_sums<PT>(force, out_f64, w, w + offset, lane, tot, pos, nullptr);
         if (check_count != nullptr) {

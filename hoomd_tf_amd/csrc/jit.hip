@@ -93,14 +93,15 @@ int jit_create(const void *image, size_t bytes, JitKernels **out) {
     // optional: the training sweep and its parameter count (a unit traced with weights)
     hipDeviceptr_t np_ptr = nullptr;
     size_t np_bytes = 0;
-    if (hipModuleGetFunction(&k->train[0], k->mod, "htf_jit_train_f32") == hipSuccess &&
-        hipModuleGetFunction(&k->train[1], k->mod, "htf_jit_train_f64") == hipSuccess &&
-        hipModuleGetGlobal(&np_ptr, &np_bytes, k->mod, "htf_jit_nparams") == hipSuccess && np_bytes == sizeof(int)) {
+    if (hipModuleGetGlobal(&np_ptr, &np_bytes, k->mod, "htf_jit_nparams") == hipSuccess && np_bytes == sizeof(int)) {
         if (hipMemcpy(&k->nparams, np_ptr, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) k->nparams = 0;
     } else {
-        k->train[0] = k->train[1] = nullptr;
         k->nparams = 0;
     }
+    // (a unit with a row function reads weights without carrying a training sweep: such a model trains on the torch route)
+    if (!(hipModuleGetFunction(&k->train[0], k->mod, "htf_jit_train_f32") == hipSuccess &&
+          hipModuleGetFunction(&k->train[1], k->mod, "htf_jit_train_f64") == hipSuccess))
+        k->train[0] = k->train[1] = nullptr;
     (void)hipGetLastError();
     *out = k;
     return HTF_OK;

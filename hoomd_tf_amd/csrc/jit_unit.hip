@@ -14,6 +14,9 @@
 #if defined(HTF_JIT_NPARAMS) && HTF_JIT_NPARAMS > 0   // (before pair_math.h: its pair_eval_grad<HTF_POT_JIT> is conditional on it)
 #define HTF_JIT_TRAIN_BODY HTF_JIT_TRAIN_BODY_TEXT
 #endif
+#ifdef HTF_JIT_ROW_TEXT // (a row function: energy_i = F(sum_j e_ij) -- pair_math.h row_function<HTF_POT_JIT>)
+#define HTF_JIT_ROW_FN HTF_JIT_ROW_TEXT
+#endif
 #include "fused_eval.hip"
 #include "eval_pair.hip"
 
@@ -76,6 +79,11 @@ HTF_JIT_EVAL(htf_jit_eval_f32, false, float)
 HTF_JIT_EVAL(htf_jit_eval_f32_virial, true, float)
 HTF_JIT_EVAL(htf_jit_eval_f64, false, double)
 HTF_JIT_EVAL(htf_jit_eval_f64_virial, true, double)
+
+#if defined(HTF_JIT_NWEIGHTS) && !(defined(HTF_JIT_NPARAMS) && HTF_JIT_NPARAMS > 0)
+// (a row-function unit that reads weights: no training sweep, but the library still wants to know how long p.theta is)
+extern "C" __device__ const int htf_jit_nparams = HTF_JIT_NWEIGHTS;
+#endif
 
 // A traced energy WITH WEIGHTS (round 6): the body file also defines HTF_JIT_NPARAMS and HTF_JIT_TRAIN_BODY_TEXT -- the same
 // expression as forward-mode jets over (r', w_k) -- and the unit carries the library's training sweep around it.

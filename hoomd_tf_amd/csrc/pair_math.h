@@ -104,6 +104,41 @@ __device__ __forceinline__ RinvFwd rinv_fwd(float x, float y, float z) {
     return f;
 }
 
+// A ROW FUNCTION (round 6, generated units only): energy_i = F(rho_i), rho_i = sum_j e_ij of the unit's pair body -- an embedding
+// term, a coordination-number restraint; what the reference gets from tf.gradients of any compute() that feeds a reduce_sum into a
+// nonlinearity (simmodel.py:87-121, 526-555).  The gradient with respect to row i's own pair vectors is F'(rho_i) x the pair
+// body's, so the kernels accumulate a row exactly as for a pair energy and finish it here: forces x dF, energy = Fv.
+template <int KIND> struct HasRowFn { static constexpr bool value = false; };
+#ifdef HTF_JIT_ROW_FN
+template <> struct HasRowFn<HTF_POT_JIT> { static constexpr bool value = true; };
+#endif
+template <int KIND>
+__device__ __forceinline__ void row_function(const PotParams &p, float rho, float &Fv, float &dF) {
+    Fv = rho;
+    dF = 1.0f;
+#ifdef HTF_JIT_ROW_FN
+    if constexpr (KIND == HTF_POT_JIT) {
+        HTF_JIT_ROW_FN
+    }
+#endif
+    (void)p;
+}
+// ... on a finished row as the one-kernel step holds it: lanes 0 / 16 / 32 / 48 of `tot` carry fx, fz, fy, e (wave_sum4)
+template <int KIND>
+__device__ __forceinline__ float finish_row_sums(const PotParams &p, float tot, unsigned lane, float *abs_dF = nullptr) {
+    if constexpr (HasRowFn<KIND>::value) {
+        float Fv, dF;
+        row_function<KIND>(p, __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tot), 48)), Fv, dF);
+        if (abs_dF) *abs_dF = fabsf(dF);
+        return lane >= 48u ? Fv : tot * dF;
+    } else {
+        (void)p;
+        (void)lane;
+        if (abs_dF) *abs_dF = 1.0f;
+        return tot;
+    }
+}
+
 // Each potential returns the pair energy e (its share of E_i) and nlist_forces_ij =
 // 2 * dE/dx_ij (the reference's "nlist_forces", simmodel.py:548) in (fx, fy, fz).
 // (pair_eval_f takes the shared forward f = rinv_fwd(x, y, z) from its caller: a sweep that evaluates two potentials per slot --

@@ -557,6 +557,7 @@ class PairExpr(PairEnergy):
     tfcompute replays it as the one-kernel step like any built-in closed form.  An expression whose energy does not vanish on a
     padded slot keeps the torch route (codegen.vanishes_on_padding)."""
     owns_potential = False
+    trains_on_kernels = True   # (a generated unit with weights carries its training sweep; a row-function unit does not)
 
     def __init__(self, nlist, node, reduced=False, positions=None, folded=()):
         # positions: the [N, 4] tensor of compute(), kept when the expression reads the row particles' own types (TypeExpr)
@@ -611,7 +612,9 @@ class PairExpr(PairEnergy):
     def _with(self, op, other=None, swap=False, value=None):
         from . import codegen as cg
         if self.reduced:
-            raise TypeError("a per-particle sum is not a per-pair expression any more")
+            # a per-particle sum fed into further arithmetic: a ROW expression (an embedding term F(sum_j g(r_ij)), a
+            # coordination-number restraint) -- symbolic still, see RowExpr
+            return RowExpr.of(self)._with(op, other, swap, value)
         if other is None:
             return PairExpr(self.nlist, cg.Node(op, (self.node,), value=value), positions=self.positions, folded=self.folded)
         new_folded = ()
@@ -674,14 +677,21 @@ class PairExpr(PairEnergy):
     def body(self):
         from . import codegen as cg
         if getattr(self, "_body", None) is None:
-            self._body = cg.unit_of(self.node)["text"]     # (forward body; + the training jets when the expression reads weights)
+            self._body = self._unit()["text"]     # (forward body; + the training jets when the expression reads weights)
         return self._body
+
+    def _unit(self):
+        from . import codegen as cg
+        return cg.unit_of(self.node)
+
+    def _weight_indices(self):
+        from . import codegen as cg
+        return cg.params_of(self.node)
 
     @property
     def weight_elements(self):
         """[(leaf, flat index)] the expression's p.theta[0 .. n) stand for (the trace's list, up to the highest index it reads)."""
-        from . import codegen as cg
-        ks = cg.params_of(self.node)
+        ks = self._weight_indices()
         return list(self.nlist._weights[:ks[-1] + 1]) if ks else []
 
     @property
@@ -700,9 +710,9 @@ class PairExpr(PairEnergy):
         else the torch route (forces by autograd)."""
         from . import codegen as cg
         if getattr(self, "_lowers", None) is None:
-            unit = cg.unit_of(self.node)
+            unit = self._unit()
             ok = os.environ.get("HTF_NO_JIT") != "1" and unit["vanishes"]
-            if ok and getattr(_trace, "training_graph", False) and cg.params_of(self.node) and self.reads_own_type:
+            if ok and getattr(_trace, "training_graph", False) and self._weight_indices() and (self.reads_own_type or not self.trains_on_kernels):
                 ok = False   # (the training sweep has no positions tensor beside the pair vectors: the torch route trains it)
             if ok and unit["built"]:
                 self._lowers = True   # (this process has built or loaded it before: a model traced at every step asks every step)
@@ -763,6 +773,173 @@ class PairExpr(PairEnergy):
     def ad(self):
         v = self.torch_value(self.nlist.ad)
         return v.sum(dim=1) if self.reduced else v
+
+
+class RowFnEnergy(PairExpr):
+    """energy_i = F(sum_j g(r_ij)): a traced pair expression g and a ROW FUNCTION F of its per-particle sum (``row``: an expression of
+    codegen.rowsum(0)).  One generated unit: the kernels accumulate row i's (2 dg/dx, g) as for a pair energy and finish the row
+    with forces x F'(rho_i), energy = F(rho_i) (csrc/pair_math.h row_function) -- the one-kernel step, its virial form and the
+    streaming evaluator alike.  Trains on the torch route (the unit carries no training sweep)."""
+    trains_on_kernels = False
+
+    def __init__(self, nlist, node, row, positions=None, folded=()):
+        super().__init__(nlist, node, reduced=True, positions=positions, folded=folded)
+        self.row = row
+
+    def _unit(self):
+        from . import codegen as cg
+        return cg.unit_of(self.node, self.row)
+
+    def _weight_indices(self):
+        from . import codegen as cg
+        return sorted(set(cg.params_of(self.node)) | set(cg.params_of(self.row)))
+
+
+class RowExpr(_TorchOperand):
+    """A per-particle expression of ROW SUMS of traced pair expressions (round 6): what ``htf.reduce_sum(pair_expr, axis=1)`` becomes
+    when model code keeps computing with it -- ``-A * htf.sqrt(rho)`` of an embedded-atom term, ``k * (n - n0) ** 2`` of a
+    coordination-number restraint -- the reference's "any graph of the neighbor tensor" (simmodel.py:87-121) one step past
+    elementwise.  ``node`` is an expression over codegen.rowsum(k) leaves, ``sums[k]`` the (unreduced) pair expression of sum k.
+    ``compute_nlist_forces`` lowers an energy that is a SUM of functions of one row sum each, sum_k F_k(rho_k) (+ plain pair sums),
+    to one generated unit per term (RowFnEnergy); anything else -- a product of two different sums, a tensor operand -- is its torch
+    value and takes the autograd route, as does training."""
+
+    def __init__(self, nlist, node, sums, positions=None, folded=()):
+        self.nlist, self.node, self.sums, self.positions, self.folded = nlist, node, tuple(sums), positions, tuple(folded)
+
+    @staticmethod
+    def of(x, nlist=None):
+        from . import codegen as cg
+        if isinstance(x, RowExpr):
+            return x
+        if isinstance(x, RinvPoly) and x.reduced:
+            x = PairExpr.of(x)
+        if isinstance(x, PairExpr) and x.reduced and not getattr(x, "total", False) and not isinstance(x, RowFnEnergy):
+            return RowExpr(x.nlist, cg.rowsum(0), [PairExpr(x.nlist, x.node, positions=x.positions, folded=x.folded)], x.positions, x.folded)
+        if nlist is not None and isinstance(x, (int, float, np.floating, np.integer)) and not isinstance(x, bool):
+            return RowExpr(nlist, cg.const(x), [])
+        if nlist is not None and isinstance(x, torch.Tensor) and x.numel() == 1:
+            wn = _weight_node(x, nlist)
+            if wn is not None:
+                return RowExpr(nlist, wn, [])
+            fw = _fold_weight(x)
+            if fw is not None:
+                return RowExpr(nlist, cg.const(fw[0]), [], folded=fw[1])
+            if not x.requires_grad:
+                return RowExpr(nlist, cg.const(float(x)), [])
+        raise TypeError("cannot trace %r as a per-particle expression" % (type(x),))
+
+    _TORCH = {"add": torch.add, "sub": torch.sub, "mul": torch.mul, "div": torch.div}
+
+    def _with(self, op, other=None, swap=False, value=None):
+        from . import codegen as cg
+        if other is None:
+            return RowExpr(self.nlist, cg.Node(op, (self.node,), value=value), self.sums, self.positions, self.folded)
+        try:
+            o = RowExpr.of(other, self.nlist)
+        except TypeError:
+            o = None
+        if o is None or (o.sums and o.nlist is not self.nlist and o.nlist.tensor is not self.nlist.tensor) or op not in self._TORCH:
+            a, b = self.ad, _unwrap(other)   # (a tensor of per-particle values, a comparison, another list: torch from here on)
+            fn = self._TORCH.get(op) or {"min": torch.minimum, "max": torch.maximum, "lt": torch.lt, "le": torch.le, "gt": torch.gt,
+                                         "ge": torch.ge, "eq": torch.eq, "ne": torch.ne}[op]
+            b = torch.as_tensor(b, dtype=a.dtype, device=a.device) if not isinstance(b, torch.Tensor) else b
+            return fn(b, a) if swap else fn(a, b)
+        sums, mapping = list(self.sums), {}
+        for k, e in enumerate(o.sums):
+            for j, mine in enumerate(sums):
+                if mine.node.key() == e.node.key():
+                    mapping[k] = j
+                    break
+            else:
+                mapping[k] = len(sums)
+                sums.append(e)
+        onode = cg.remap_rowsums(o.node, mapping) if mapping else o.node
+        args = (onode, self.node) if swap else (self.node, onode)
+        return RowExpr(self.nlist, cg.Node(op, args), sums, self.positions if self.positions is not None else o.positions,
+                       self.folded + o.folded)
+
+    def __add__(self, o):
+        if isinstance(o, BiasTerm):
+            return NotImplemented
+        return self._with("add", o)
+    def __radd__(self, o): return self._with("add", o, swap=True)
+    def __sub__(self, o): return self._with("sub", o)
+    def __rsub__(self, o): return self._with("sub", o, swap=True)
+    def __mul__(self, o): return self._with("mul", o)
+    def __rmul__(self, o): return self._with("mul", o, swap=True)
+    def __truediv__(self, o): return self._with("div", o)
+    def __rtruediv__(self, o): return self._with("div", o, swap=True)
+    def __neg__(self): return self._with("neg")
+    def __abs__(self): return self._with("abs")
+    def __lt__(self, o): return self._with("lt", o)
+    def __le__(self, o): return self._with("le", o)
+    def __gt__(self, o): return self._with("gt", o)
+    def __ge__(self, o): return self._with("ge", o)
+
+    def __pow__(self, n):
+        if not isinstance(n, (int, float)):
+            return self.ad ** _unwrap(n)
+        return self._with("pow", value=float(n))
+
+    # ---- values
+    def torch_value(self, nl_tensor):
+        """[N] value from a pair-vector tensor (an autograd leaf for the generic route), in its dtype."""
+        from . import codegen as cg
+        rows = [e.torch_value(nl_tensor).sum(dim=1) for e in self.sums]
+        like = rows[0] if rows else torch.zeros(nl_tensor.shape[0], dtype=nl_tensor.dtype, device=nl_tensor.device)
+        ks = sorted(set(cg.params_of(self.node)))
+        params = [t.reshape(-1)[i] for t, i in self.nlist._weights[:ks[-1] + 1]] if ks else None
+        out = cg.evaluate(self.node, like, None, None, params=params, rows=rows)
+        return out if out.dim() else out.expand(nl_tensor.shape[0])
+
+    def tensor(self):
+        _trace_log().append({"op": "eager_value"})
+        return self.torch_value(self.nlist.tensor)
+
+    @property
+    def ad(self):
+        return self.torch_value(self.nlist.ad)
+
+    # ---- lowering
+    def groups(self):
+        """The energy as [RowFnEnergy, ...] -- one per row sum, each a function of that sum alone -- or None when some term mixes
+        two different sums (or none carries a sum at all)."""
+        from . import codegen as cg
+        terms = []
+
+        def flatten(n, sign):
+            if n.op == "add":
+                flatten(n.args[0], sign)
+                flatten(n.args[1], sign)
+            elif n.op == "sub":
+                flatten(n.args[0], sign)
+                flatten(n.args[1], -sign)
+            elif n.op == "neg":
+                flatten(n.args[0], -sign)
+            else:
+                terms.append((sign, n))
+        flatten(self.node, 1)
+        by_sum, consts = {}, []
+        for sign, n in terms:
+            ks = cg.rowsums_of(n)
+            if len(ks) > 1:
+                return None
+            (by_sum.setdefault(ks[0], []) if ks else consts).append((sign, n))
+        if not by_sum:
+            return None
+        first = min(by_sum)
+        by_sum[first] += consts          # (a constant per-particle energy: no force; it rides on the first term)
+        out = []
+        for k in sorted(by_sum):
+            f = None
+            for sign, n in by_sum[k]:
+                n = n if sign > 0 else cg.Node("neg", (n,))
+                f = n if f is None else cg.Node("add", (f, n))
+            e = self.sums[k]
+            out.append(RowFnEnergy(self.nlist, e.node, cg.remap_rowsums(f, {k: 0}), positions=e.positions if e.positions is not None else self.positions,
+                                   folded=self.folded + e.folded))
+        return out
 
 
 class PairCond(_TorchOperand):
@@ -1050,6 +1227,8 @@ def not_equal(a, b):
 
 
 def _unary(op, x, torch_fn):
+    if isinstance(x, RowExpr):
+        return x._with(op)
     if _sym(x):
         return PairExpr.of(x)._with(op)
     return torch_fn(_unwrap(x))
@@ -1107,6 +1286,8 @@ def cos(x):
 
 
 def pow(x, n):  # noqa: A001 (tf.pow)
+    if isinstance(x, RowExpr):
+        return x ** n
     if _sym(x):
         return PairExpr.of(x) ** n
     return _unwrap(x) ** n
@@ -1400,6 +1581,8 @@ def reduce_sum(x, axis=None):
         return x
     if isinstance(x, LJParamEnergy):
         return LJParamEnergy(x.nlist, x.layer, reduced=True)
+    if isinstance(x, RowExpr):
+        x = x.ad     # (a total over particles: a torch scalar from here on)
     return x.sum() if axis is None else x.sum(dim=axis)
 
 
@@ -1427,6 +1610,8 @@ def compute_nlist_forces(nlist, energy, virial=False):
         return _autograd_nlist_forces(_as_nlist(nlist), energy, virial)
     if isinstance(energy, DenseOut):
         energy = energy.energy()
+    if isinstance(energy, RowExpr):
+        return _row_forces(_as_nlist(nlist), energy, virial)
     if isinstance(energy, PairExpr) and not energy.lowers():
         # (its energy does not vanish on a padded slot, or HTF_NO_JIT=1: the generic route, forces by torch.autograd)
         nl_ = _as_nlist(nlist)
@@ -1456,6 +1641,37 @@ def compute_nlist_forces(nlist, energy, virial=False):
     _trace_log().append({"potential": pot, "nlist": nl, "virial": virial, "forces": f,
                          "layer": getattr(energy, "layer", None), "folded": tuple(getattr(energy, "folded", ()))})
     return out
+
+
+def _row_forces(nl, energy, virial):
+    """compute_nlist_forces of a RowExpr: one generated unit per term F_k(rho_k) (RowFnEnergy), their outputs added; a single term
+    is logged like any lowered energy (tfcompute replays it as the one-kernel step).  Terms that mix sums, training, HTF_NO_JIT or a
+    pair expression that does not vanish on padding: the torch value and autograd."""
+    if energy.sums and energy.nlist is not nl and energy.nlist.tensor is not nl.tensor:
+        raise ValueError('Could not find dependence between energy and nlist.'
+                         ' Did you put them in wrong order?')
+    groups = energy.groups()
+    # (a virial of several terms: simmodel.py:509-523 takes the norm of a pair's TOTAL force, which separate launches cannot form)
+    if groups is None or (virial and len(groups) > 1) or not all(g.lowers() for g in groups):
+        return _autograd_nlist_forces(nl, energy.torch_value(nl.ad), virial)
+    outs, pots = [], []
+    for g in groups:
+        pot = _potential_of(g)
+        own = None
+        if g.reads_own_type:
+            if g.positions is None:
+                raise ValueError("the traced energy reads the particles' own types but no positions tensor reached it")
+            own = g.positions[:nl.tensor.shape[0]].to(nl.tensor.dtype).contiguous()
+        outs.append(ops.eval_forces(pot, nl.tensor, virial=virial, positions=own))
+        pots.append(pot)
+    if len(groups) == 1:
+        f = outs[0][0] if virial else outs[0]
+        _trace_log().append({"potential": pots[0], "nlist": nl, "virial": virial, "forces": f,
+                             "layer": None if getattr(_trace, "training_graph", False) else groups[0].layer,
+                             "folded": tuple(groups[0].folded)})
+        return outs[0]
+    _trace_log().append({"op": "row_terms", "potentials": pots})   # (several launches per step: the step stays eager)
+    return sum(outs[1:], outs[0])
 
 
 def _potential_of(energy):

@@ -490,3 +490,136 @@ def test_random_expressions_against_autograd():
             assert np.all(got[~lv] == 0.0), (trial, e.body())
             done += 1
     assert done >= 25
+
+
+# --------------------------------------------------------------------------- row functions (round 6)
+ROW_HARNESS = r"""
+#include <math.h>
+#include <stdbool.h>
+#include <stdio.h>
+static float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
+static float __builtin_amdgcn_sqrtf(float x) { return sqrtf(x); }
+static float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
+static float __builtin_amdgcn_logf(float x) { return log2f(x); }
+static float __builtin_amdgcn_fractf(float x) { return x - floorf(x); }
+static float __builtin_amdgcn_sinf(float x) { return sinf(6.283185307179586f * x); }
+static float __builtin_amdgcn_cosf(float x) { return cosf(6.283185307179586f * x); }
+int main(void) {
+    float rho;
+    while (scanf("%f", &rho) == 1) {
+        float Fv = 0.0f, dF = 0.0f;
+        { BODY }
+        printf("%.9g %.9g\n", Fv, dF);
+    }
+    return 0;
+}
+"""
+
+
+def _row_models(htf, x):
+    """Per-particle energies that feed a row sum into a nonlinearity -- what VERDICT r5 'missing 5' names: an embedded-atom term
+    (Finnis-Sinclair: -A sqrt(rho) + pair repulsion), a coordination-number restraint k (n - n0)^2 on a smooth count, a
+    log-density, two embeddings of two different densities, and a product of two different sums (not separable: torch route)."""
+    s = htf.nlist_rinv(x)
+    r = htf.safe_norm(x[:, :, :3], axis=2)
+    live = htf.cast(s > 0.0, torch.float32)
+    rho = htf.reduce_sum(htf.exp(-1.7 * r) * s * s, axis=1)
+    n = htf.reduce_sum(live * htf.sigmoid(6.0 * (1.5 - r)), axis=1)
+    phi = htf.reduce_sum(0.5 * (s ** 12 - s ** 6), axis=1)
+    return {
+        "finnis_sinclair": -1.3 * htf.sqrt(rho) + phi,
+        "coordination": 0.25 * (n - 9.0) ** 2,
+        "log_density": htf.log(1.0 + rho) * 0.7 - 0.2 * rho,
+        "two_embeddings": -1.1 * htf.sqrt(rho) + htf.tanh(0.1 * n) + phi + 0.3,
+        "mixed": rho * n,
+    }
+
+
+def test_row_functions_are_traced_and_split_into_terms_of_one_sum():
+    """Round 6 (VERDICT r5 missing 5): ``htf.reduce_sum(pair_expr, axis=1)`` fed into further htf.* arithmetic stays symbolic
+    (RowExpr; until now a TypeError): an energy that is a sum of functions of ONE row sum each becomes one generated unit per term,
+    its row function -- F and F' of the emitted C, run on the host -- equal to torch-fp64 autograd; the value of the whole
+    expression equals the same energy written in torch ops; a product of two different sums keeps the torch route."""
+    import hoomd_tf_amd as htf
+    from hoomd_tf_amd import codegen as cg
+    from hoomd_tf_amd.simmodel import RowExpr, RowFnEnergy
+    rng = np.random.default_rng(4)
+    nl, _ = random_nlist(rng, 40, 24, fill=0.6, rmin=0.85, rmax=2.9, dtype=np.float64)
+    x = htf.Nlist(torch.from_numpy(nl))
+    models = _row_models(htf, x)
+    want_terms = {"finnis_sinclair": 2, "coordination": 1, "log_density": 1, "two_embeddings": 3, "mixed": None}
+    # the same energies in torch ops
+    xx = torch.from_numpy(nl)
+    t = xx[:, :, :3] + 1e-7
+    rr = torch.sqrt((t * t).sum(dim=2))
+    ss = torch.where(rr > 3e-6, 1.0 / (rr + 3e-6), torch.zeros_like(rr))
+    live = (ss > 0).double()
+    rho = (torch.exp(-1.7 * rr) * ss * ss).sum(dim=1)
+    n = (live * torch.sigmoid(6.0 * (1.5 - rr))).sum(dim=1)
+    phi = (0.5 * (ss ** 12 - ss ** 6)).sum(dim=1)
+    ref = {"finnis_sinclair": -1.3 * torch.sqrt(rho) + phi, "coordination": 0.25 * (n - 9.0) ** 2,
+           "log_density": torch.log(1.0 + rho) * 0.7 - 0.2 * rho, "two_embeddings": -1.1 * torch.sqrt(rho) + torch.tanh(0.1 * n) + phi + 0.3,
+           "mixed": rho * n}
+    for name, e in models.items():
+        assert isinstance(e, RowExpr), name
+        np.testing.assert_allclose(e.torch_value(xx).numpy(), ref[name].numpy(), rtol=1e-12, atol=1e-12)
+        groups = e.groups()
+        if want_terms[name] is None:
+            assert groups is None
+            continue
+        assert len(groups) == want_terms[name] and all(isinstance(g, RowFnEnergy) for g in groups), name
+        total = torch.zeros(len(nl), dtype=torch.float64)
+        for g in groups:
+            assert "//@row" in g.body() and cg.vanishes_on_padding(g.node)
+            row_text = g.body().partition("\n//@row\n")[2]
+            rsum = g.torch_value(xx).sum(dim=1).detach().requires_grad_(True)     # rho of this term, fp64
+            fv = cg.evaluate(g.row, rsum, None, None, rows=[rsum])
+            fv = fv if fv.dim() else fv.expand(len(nl))
+            (dfv,) = torch.autograd.grad(fv.sum(), rsum, allow_unused=True)
+            dfv = torch.zeros_like(rsum) if dfv is None else dfv
+            with tempfile.TemporaryDirectory() as tmp:
+                src = os.path.join(tmp, "h.c")
+                with open(src, "w") as f:
+                    f.write(ROW_HARNESS.replace("BODY", row_text))
+                exe = os.path.join(tmp, "h")
+                subprocess.check_call(["gcc", "-O1", "-o", exe, src, "-lm"])
+                out = subprocess.run([exe], input="\n".join("%.9g" % v for v in rsum.detach().numpy().astype(np.float32)), capture_output=True,
+                                     text=True, check=True).stdout
+            got = np.array([[float(v) for v in line.split()] for line in out.strip().splitlines()])
+            assert np.abs(got[:, 0] - fv.detach().numpy()).max() < 3e-6 * max(1.0, np.abs(fv.detach().numpy()).max()), name
+            assert np.abs(got[:, 1] - dfv.numpy()).max() < 1e-5 * max(1.0, np.abs(dfv.numpy()).max()), name
+            total = total + fv.detach()
+        np.testing.assert_allclose(total.numpy(), ref[name].numpy(), rtol=1e-10, atol=1e-10)   # the terms add up to the energy
+
+
+def test_row_expression_forces_on_the_torch_route_equal_autograd(monkeypatch):
+    """compute_nlist_forces of a row expression with the generated kernels switched off (HTF_NO_JIT=1; also what a product of two
+    sums or a training step takes): torch autograd through the traced expression == the same energy written in torch ops."""
+    import hoomd_tf_amd as htf
+    monkeypatch.setenv("HTF_NO_JIT", "1")
+    rng = np.random.default_rng(6)
+    nl, _ = random_nlist(rng, 20, 16, fill=0.6, rmin=0.85, rmax=2.9, dtype=np.float64)
+    for name in ("finnis_sinclair", "mixed"):
+        x = htf.Nlist(torch.from_numpy(nl))
+        f = htf.compute_nlist_forces(x, _row_models(htf, x)[name])
+        xx = torch.from_numpy(nl).requires_grad_(True)
+        t = xx[:, :, :3] + 1e-7
+        rr = torch.sqrt((t * t).sum(dim=2))
+        ss = torch.where(rr > 3e-6, 1.0 / (rr + 3e-6), torch.zeros_like(rr))
+        rho = (torch.exp(-1.7 * rr) * ss * ss).sum(dim=1)
+        n = ((ss > 0).double() * torch.sigmoid(6.0 * (1.5 - rr))).sum(dim=1)
+        en = -1.3 * torch.sqrt(rho) + (0.5 * (ss ** 12 - ss ** 6)).sum(dim=1) if name == "finnis_sinclair" else rho * n
+        (g,) = torch.autograd.grad(en.sum(), xx)
+        np.testing.assert_allclose(f[:, :3].detach().numpy(), 2.0 * g.sum(dim=1)[:, :3].numpy(), rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(f[:, 3].detach().numpy(), en.detach().numpy(), rtol=1e-12)
+
+
+def test_unit_with_a_row_function_cross_compiles():
+    import hoomd_tf_amd as htf
+    from hoomd_tf_amd import codegen as cg
+    x = htf.Nlist(torch.zeros((2, 4, 4), dtype=torch.float64))
+    g = _row_models(htf, x)["coordination"].groups()[0]
+    assert g.lowers()
+    image, key = cg.compile_body(g.body())
+    assert b"htf_jit_rows2_f32_store" in image and b"htf_jit_tails4_f32_store" in image and b"htf_jit_eval_f64_virial" in image
+    assert b"htf_jit_train_f32" not in image

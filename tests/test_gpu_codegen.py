@@ -23,7 +23,7 @@ def _ref(htf, e, nl64, virial=False):
     return [o.detach().numpy() for o in out] if virial else out.detach().numpy()
 
 
-def _strict_at_the_last_step(htf, tfc, make_energy, tag):
+def _strict_at_the_last_step(htf, tfc, make_energy, tag, row=False):
     """The forces a REPLAYED generated step left after its last launch against torch-fp64 autograd of the same expression on the
     pair-vector tensor that very launch wrote (identical inputs, so the evaluator tests' tolerance applies -- whatever chaos did to
     the trajectory; VERDICT r5 weak 3: the run-against-run comparison alone allowed 2e-3 max|F|)."""
@@ -33,6 +33,11 @@ def _strict_at_the_last_step(htf, tfc, make_energy, tag):
     nl64 = tfc.cpp_force.nlist_buffer(N, dev).double().cpu().numpy().reshape(N, tfc.nneighbor_cutoff, 4)
     pos64 = tfc.cpp_force.positions_buffer(N, dev).double().cpu()
     e = make_energy(htf.Nlist(torch.from_numpy(nl64)), PositionsInput.wrap(pos64))
+    if row:
+        ref, g = _row_ref(htf, e, nl64)
+        cond = np.abs(2 * g[:, :, :3]).sum(axis=(1, 2))
+        assert_forces_close(tag, tfc.force.double().cpu().numpy(), ref, cond, cancelling_rows=CONTACTS)
+        return
     ref = _ref(htf, e, nl64)
     xx = htf.Nlist(torch.from_numpy(nl64))
     (g,) = torch.autograd.grad(e.torch_value(xx.ad).sum(), xx.ad)
@@ -453,3 +458,148 @@ def test_random_expressions_on_the_device(htf, cuda):
         if done == 6:
             break
     assert done == 6
+
+
+# --------------------------------------------------------------------------- row functions (round 6)
+def _row_ref(htf, e, nl64, virial=False):
+    """torch fp64 autograd of a traced ROW expression on the same pair vectors -> forces [N, 4] (, virial), per-pair gradient."""
+    from hoomd_tf_amd.simmodel import _autograd_nlist_forces
+    x = htf.Nlist(torch.from_numpy(nl64))
+    en = e.torch_value(x.ad)
+    (g,) = torch.autograd.grad(en.sum(), x.ad, retain_graph=True)
+    out = _autograd_nlist_forces(x, en, virial)
+    return ([o.detach().numpy() for o in out] if virial else out.detach().numpy()), g.numpy()
+
+
+@pytest.mark.parametrize("name", ["finnis_sinclair", "coordination", "log_density", "two_embeddings"])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_row_function_evaluator_matches_autograd(htf, cuda, name, dtype):
+    """Round 6 (VERDICT r5 missing 5): energies that feed a per-particle reduction into a nonlinearity -- an embedded-atom term, a
+    coordination-number restraint, two embeddings of two densities plus a pair sum -- through compute_nlist_forces on generated
+    units with a ROW FUNCTION (one per term; forces x F'(rho_i), energy F(rho_i), virial x |F'|), against torch-fp64 autograd of the
+    same traced expression: forces, energies, virial."""
+    from test_codegen_cpu import _row_models
+    from test_gpu_parity import CONTACTS, assert_forces_close
+    rng = np.random.default_rng(8)
+    nl, _ = random_nlist(rng, 300, 128, fill=0.7, rmin=0.85, rmax=3.0, dtype=dtype)
+    nl64 = nl.astype(np.float32).astype(np.float64)
+    e64 = _row_models(htf, htf.Nlist(torch.from_numpy(nl64)))[name]
+    (ref, vref), g = _row_ref(htf, e64, nl64, virial=True)
+    x = htf.Nlist(torch.from_numpy(nl).to(cuda))
+    e = _row_models(htf, x)[name]
+    assert all(t.lowers() for t in e.groups())
+    from hoomd_tf_amd import simmodel
+    simmodel._trace_log().clear()
+    f = htf.compute_nlist_forces(x, e)
+    assert not any(en.get("op") == "generic" for en in simmodel._trace_log())           # generated kernels, not autograd
+    cond = np.abs(2 * g[:, :, :3]).sum(axis=(1, 2))
+    assert_forces_close("rowfn_%s_%s" % (name, dtype.__name__), f.cpu().numpy(), ref, cond, cancelling_rows=CONTACTS)
+    if len(e.groups()) > 1:
+        # (the reference's virial takes the norm of a pair's TOTAL force, simmodel.py:509-523: several terms cannot form it in
+        #  separate launches -- a virial request of such an energy takes the autograd route)
+        simmodel._trace_log().clear()
+        f1, v = htf.compute_nlist_forces(x, e, virial=True)
+        assert any(en.get("op") == "generic" for en in simmodel._trace_log())
+        assert np.abs(v.detach().cpu().numpy().reshape(len(nl), 9) - vref.reshape(len(nl), 9)).max() < 1e-4 * np.abs(vref).max()
+        return
+    f1, v = htf.compute_nlist_forces(x, e, virial=True)
+    assert torch.equal(f, f1)
+    vcond = (np.linalg.norm(2 * g[:, :, :3], axis=2) * np.linalg.norm(nl64[:, :, :3], axis=2) / 2).sum(axis=1)
+    assert_forces_close("rowfn_%s_virial_%s" % (name, dtype.__name__), v.cpu().numpy().reshape(len(nl), 9), vref.reshape(len(nl), 9), vcond,
+                        cancelling_rows=CONTACTS)
+
+
+@pytest.mark.parametrize("cells,wire", [(6, torch.float32), (6, torch.float64), (24, torch.float32)])
+def test_row_function_model_is_replayed_as_the_one_kernel_step(htf, cuda, cells, wire, monkeypatch):
+    """A many-body model through tfcompute: E_i = u_i + 0.02 u_i^2 with u_i the particle's Lennard-Jones energy -- one row function
+    of one sum, so the plan is the one-kernel step (tensor written, row finished in the kernel).  30 MD steps: the replayed step's
+    last forces against fp64 autograd on the tensor that launch wrote; the run against the same model on the torch route
+    (HTF_NO_JIT=1); at 55 296 particles the four-row merged-tails form is the one that runs."""
+    from hoomd_tf_amd import _lib, standin
+
+    def energy(nlist, positions=None):
+        s = htf.nlist_rinv(nlist)
+        u = htf.reduce_sum(2.0 * (s ** 12 - s ** 6) * htf.cast(s > 0.4, torch.float32), axis=1)
+        return u + 0.02 * u * u
+
+    class ManyBody(htf.SimModel):
+        def compute(self, nlist, positions, box):
+            return htf.compute_nlist_forces(nlist, energy(nlist))
+
+    def run(jit):
+        monkeypatch.setenv("HTF_NO_JIT", "0" if jit else "1")
+        pos, L, a = standin.fcc_positions(cells, 0.8442)
+        rng = np.random.default_rng(2)
+        pos = pos + 0.03 * a * rng.standard_normal(pos.shape)
+        pos -= np.round(pos / L) * L
+        sysm = standin.System(pos, L, dtype=wire, device=cuda)
+        sysm.randomize_velocities(kT=0.5, seed=2)
+        sim = standin.Simulation(sysm)
+        sim.integrate_nve(0.002)
+        tfc = htf.tfcompute(ManyBody(96))
+        tfc.attach(sim.nlist_cell(r_buff=0.4, check_period=1), r_cut=2.5)
+        sim.run(30, graph=False)
+        torch.cuda.synchronize()
+        return tfc, sysm.pos.clone(), tfc.force.clone()
+
+    tfc, p1, f1 = run(True)
+    assert tfc._plan is not None and tfc._plan.kind == _lib.POT_JIT and "//@row" in tfc._plan.body and tfc.graph_safe()
+    if cells == 6:
+        _strict_at_the_last_step(htf, tfc, energy, "rowfn_replayed_step30_%s" % str(wire).split(".")[-1], row=True)
+        tfc0, p0, f0 = run(False)
+        assert tfc0._plan is None
+        scale = float(f0[:, :3].abs().max())
+        assert float((p1[:, :3] - p0[:, :3]).abs().max()) < 2e-4
+        assert float((f1[:, :3] - f0[:, :3]).abs().max()) < 2e-3 * scale
+        assert abs(float(f1[:, 3].double().sum()) - float(f0[:, 3].double().sum())) < 1e-4 * abs(float(f0[:, 3].double().sum())) + 1e-3
+    else:
+        # the merged-tails form (>= 49 152 rows) against the streaming evaluator on the tensor it wrote: two kernels, one row function
+        N = tfc.system.N
+        assert N >= 49152
+        pv = tfc.cpp_force.nlist_buffer(N, cuda)
+        f2 = htf.ops.eval_forces(tfc._plan, pv)
+        scale = float(f2[:, :3].abs().max())
+        assert float((f1[:, :3].float() - f2[:, :3]).abs().max()) < 2e-5 * scale
+        assert float((f1[:, 3].float() - f2[:, 3]).abs().max()) < 2e-5 * float(f2[:, 3].abs().max())
+        rows = np.random.default_rng(0).choice(N, 256, replace=False)
+        nl64 = pv[rows].double().cpu().numpy()
+        ref, g = _row_ref(htf, energy(htf.Nlist(torch.from_numpy(nl64))), nl64)
+        from test_gpu_parity import CONTACTS, assert_forces_close
+        assert_forces_close("rowfn_tails_55296", f1[rows].double().cpu().numpy(), ref, np.abs(2 * g[:, :, :3]).sum(axis=(1, 2)), cancelling_rows=CONTACTS)
+
+
+def test_row_terms_of_two_sums_run_on_kernels_without_a_plan(htf, cuda, monkeypatch):
+    """Finnis-Sinclair through tfcompute: -A sqrt(rho_i) + pair repulsion = two terms of two different sums -> two generated units
+    per step (the step stays eager: no plan), forces equal to the torch route's."""
+    from hoomd_tf_amd import standin
+    from test_codegen_cpu import _row_models
+
+    class FS(htf.SimModel):
+        def compute(self, nlist, positions, box):
+            return htf.compute_nlist_forces(nlist, _row_models(htf, nlist)["finnis_sinclair"])
+
+    def run(jit):
+        monkeypatch.setenv("HTF_NO_JIT", "0" if jit else "1")
+        pos, L, a = standin.fcc_positions(6, 0.8442)
+        rng = np.random.default_rng(2)
+        pos = pos + 0.03 * a * rng.standard_normal(pos.shape)
+        pos -= np.round(pos / L) * L
+        sysm = standin.System(pos, L, dtype=torch.float32, device=cuda)
+        sysm.randomize_velocities(kT=0.3, seed=2)
+        sim = standin.Simulation(sysm)
+        sim.integrate_nve(0.002)
+        tfc = htf.tfcompute(FS(96))
+        tfc.attach(sim.nlist_cell(r_buff=0.4, check_period=1), r_cut=2.5)
+        from hoomd_tf_amd import simmodel
+        sim.run(1, graph=False)
+        kinds = [e.get("op") for e in simmodel._trace_log()]
+        sim.run(9, graph=False)
+        torch.cuda.synchronize()
+        return tfc, tfc.force.clone(), kinds
+
+    tfc, f1, _ = run(True)
+    assert tfc._plan is None
+    _, f0, _ = run(False)
+    scale = float(f0[:, :3].abs().max())
+    assert float((f1[:, :3] - f0[:, :3]).abs().max()) < 5e-4 * scale
+    assert abs(float(f1[:, 3].double().sum()) - float(f0[:, 3].double().sum())) < 1e-4 * abs(float(f0[:, 3].double().sum())) + 1e-3

@@ -49,6 +49,12 @@ def bodies():
     w = torch.nn.Parameter(torch.tensor([0.8, 1.05]))
     a, b = torch.nn.Parameter(torch.tensor(1.3)), torch.nn.Parameter(torch.tensor(0.7))
     out += [htf.reduce_sum(e, axis=1).body() for e in _weighted_models(htf, x, w, a, b).values()]
+    # row functions (energy_i = F(sum_j g(r_ij)): embedded-atom terms, coordination restraints): the tests' and the bench's
+    from test_codegen_cpu import _row_models
+    for e in _row_models(htf, x).values():
+        out += [t.body() for t in (e.groups() or [])]
+    u = htf.reduce_sum(2.0 * (s ** 12 - s ** 6) * htf.cast(s > 0.4, torch.float32), axis=1)
+    out += [t.body() for t in (u + 0.02 * u * u).groups()]
     return out
 
 
