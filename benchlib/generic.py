@@ -140,6 +140,43 @@ def run_generic_lj(args, htf, standin, dev):
                 "potential_kind": getattr(tfc._plan, "kind", None), "energy_per_particle_after_warmup": e_warm,
                 "energy_per_particle": float(f[:, 3].double().sum().item()) / sysm.N}
 
+    class ManyBodyModel(htf.SimModel):
+        """Outside the zoo AND not elementwise (round 6): E_i = u_i + 0.02 u_i^2 with u_i the particle's Lennard-Jones energy -- a
+        per-row reduction fed into a nonlinearity.  Traced into ONE generated unit with a row function: the one-kernel step."""
+        def compute(self, nlist, positions, box):
+            s = htf.nlist_rinv(nlist)
+            u = htf.reduce_sum(2.0 * (s ** 12 - s ** 6), axis=1)
+            return htf.compute_nlist_forces(nlist, u + 0.02 * u * u)
+
+    class TorchManyBodyModel(htf.SimModel):
+        def compute(self, nlist, positions, box):
+            delta = 3e-6
+            t = nlist[:, :, :3] + 1e-7
+            r = torch.sqrt(torch.sum(t * t, dim=2))
+            s = torch.where(r > delta, 1.0 / (r + delta), torch.zeros_like(r))
+            u = torch.sum(2.0 * (s ** 12 - s ** 6), dim=1)
+            return htf.compute_nlist_forces(nlist, u + 0.02 * u * u)
+
+    class EmbeddedAtomModel(htf.SimModel):
+        """Finnis-Sinclair form: -A sqrt(rho_i) + pair repulsion, rho_i = sum_j exp(-1.7 r) / r^2 -- two terms of two different
+        sums: two generated units; the plan is the one-kernel step of the first + a streaming evaluation of the second."""
+        def compute(self, nlist, positions, box):
+            s = htf.nlist_rinv(nlist)
+            r = htf.safe_norm(nlist[:, :, :3], axis=2)
+            rho = htf.reduce_sum(htf.exp(-1.7 * r) * s * s, axis=1)
+            phi = htf.reduce_sum(2.0 * s ** 12, axis=1)
+            return htf.compute_nlist_forces(nlist, -1.3 * htf.sqrt(rho) + phi)
+
+    class TorchEmbeddedAtomModel(htf.SimModel):
+        def compute(self, nlist, positions, box):
+            delta = 3e-6
+            t = nlist[:, :, :3] + 1e-7
+            r = torch.sqrt(torch.sum(t * t, dim=2))
+            s = torch.where(r > delta, 1.0 / (r + delta), torch.zeros_like(r))
+            rho = torch.sum(torch.exp(-1.7 * r) * s * s, dim=1)
+            # (sqrt'(0) = inf meets the padded slots' zero gradient: a row without neighbors would be NaN in TensorFlow too; none here)
+            return htf.compute_nlist_forces(nlist, -1.3 * torch.sqrt(rho) + torch.sum(2.0 * s ** 12, dim=1))
+
     class TracedLJ(htf.SimModel):
         """examples/06 Force Matching as a user writes it: a Lennard-Jones energy whose prefactor and length are elements of a
         trainable weight vector (build_examples.py:336-372).  The weights are kernel arguments of the generated evaluator and
@@ -212,11 +249,22 @@ def run_generic_lj(args, htf, standin, dev):
         assert yuk["potential_kind"] == 9 and morse["potential_kind"] == 9 and mix["potential_kind"] == 9
         assert abs(mix["energy_per_particle_after_warmup"] - mix_torch["energy_per_particle_after_warmup"]) < 1e-3 * abs(mix_torch["energy_per_particle_after_warmup"]) + 1e-3
         assert abs(yuk["energy_per_particle_after_warmup"] - yuk_torch["energy_per_particle_after_warmup"]) < 1e-3 * abs(yuk_torch["energy_per_particle_after_warmup"]) + 1e-3
+        mb = one(lattice, cells, ManyBodyModel, args.steps)
+        mb_torch = one(lattice, cells, TorchManyBodyModel, max(20, args.steps // 10))
+        eam = one(lattice, cells, EmbeddedAtomModel, args.steps)
+        eam_torch = one(lattice, cells, TorchEmbeddedAtomModel, max(20, args.steps // 10))
+        assert mb["potential_kind"] == 9 and eam["potential_kind"] == 9
+        for a_, b_ in ((mb, mb_torch), (eam, eam_torch)):
+            assert abs(a_["energy_per_particle_after_warmup"] - b_["energy_per_particle_after_warmup"]) < 1e-3 * abs(b_["energy_per_particle_after_warmup"]) + 1e-3
         tr = train_one(lattice, cells, TracedLJ, args.steps)
         tr_zoo = train_one(lattice, cells, ZooLJ, args.steps)
         assert tr["train_potential_kind"] == 9
         assert abs(tr["weights_after"][1] - tr_zoo["weights_after"][1]) < 2e-3   # the same walk as the zoo's LJLayer
         sizes[tag] = {"lowered": fast, "traced_trainable": tr, "zoo_trainable": tr_zoo,
+                      "traced_many_body": mb, "torch_many_body": mb_torch, "traced_embedded_atom": eam, "torch_embedded_atom": eam_torch,
+                      "many_body_over_lowered_lj_time": mb["ms_per_step"] / fast["ms_per_step"],
+                      "torch_over_traced_many_body_time": mb_torch["ms_per_step"] / mb["ms_per_step"],
+                      "torch_over_traced_embedded_atom_time": eam_torch["ms_per_step"] / eam["ms_per_step"],
                       "traced_trainable_over_traced_inference_time": tr["ms_per_step"] / yuk["ms_per_step"],
                       "traced_over_zoo_trainable_time": tr["ms_per_step"] / tr_zoo["ms_per_step"], "generic": gen, "generic_over_lowered_time": gen["ms_per_step"] / fast["ms_per_step"],
                       "traced_yukawa_lj": yuk, "traced_morse": morse, "torch_yukawa_lj": yuk_torch,
@@ -241,6 +289,9 @@ def run_generic_lj(args, htf, standin, dev):
                          "epsilon / sigma are gathered by species pair from positions[:, 3] and nlist[:, :, 3]; LJ cores + erfc-damped electrostatics between "
                          "two charged species): traced, lowered to generated kernels "
                          "(HTF_POT_JIT: hoomd_tf_amd/codegen.py -> hipcc --genco around csrc/jit_unit.hip), replayed as the one-kernel step",
+        "row_functions": "round 6: energies that feed a per-particle reduction into a nonlinearity (traced_many_body: E_i = u_i + 0.02 u_i^2 of the "
+                         "particle's LJ energy, one generated unit with a row function, replayed as the one-kernel step; traced_embedded_atom: "
+                         "-A sqrt(rho_i) + pair repulsion, two units: the one-kernel step of the first term + a streaming evaluation of the second on the tensor it wrote) against the same models in torch ops + autograd",
         "traced_trainable": "examples/06's trainable Lennard-Jones written with htf.* ops over a weight vector, trained by force matching at "
                             "EVERY MD step while the lowered LJModel drives the run: the step is LJ force kernel + integrator + the generated "
                             "training sweep (weights are kernel arguments; forward-mode jets over (r, w_k)) + the device Adam; zoo_trainable is "

@@ -451,6 +451,9 @@ class RinvPoly(PairEnergy):
         self.cut = cut  # hard mask norm(nlist[:, :, :3]) < cut (no gradient), None: unmasked
 
     def _bin(self, other, sign):
+        if isinstance(other, RowExpr) or (self.reduced and not (isinstance(other, RinvPoly) and other.reduced and other.cut == self.cut)):
+            # a per-particle sum meeting anything but another sum of the same kind: a row expression (RowExpr)
+            return RowExpr.of(self)._with("add" if sign > 0 else "sub", other)
         if isinstance(other, RinvPoly):
             if other.nlist is not self.nlist:
                 raise ValueError("expressions come from different neighbor lists")
@@ -483,6 +486,8 @@ class RinvPoly(PairEnergy):
     def __mul__(self, o):
         if isinstance(o, (int, float)):
             return RinvPoly(self.nlist, {p: c * o for p, c in self.terms.items()}, self.reduced, cut=self.cut)
+        if self.reduced or isinstance(o, RowExpr) or (isinstance(o, (RinvPoly, PairExpr)) and o.reduced):
+            return RowExpr.of(self)._with("mul", o)    # (per-particle sums: a row expression)
         if isinstance(o, PairMask):
             return o.__mul__(self)
         if isinstance(o, RinvPoly):
@@ -502,14 +507,20 @@ class RinvPoly(PairEnergy):
     __rmul__ = __mul__
 
     def __truediv__(self, o):
+        if isinstance(o, RowExpr) or (self.reduced and not isinstance(o, (int, float))):
+            return RowExpr.of(self)._with("div", o)
         if isinstance(o, (PairExpr, SafeNorm, RinvPoly, torch.Tensor)):
             return PairExpr.of(self) / o
         return self * (1.0 / o)
 
     def __rtruediv__(self, o):
+        if self.reduced:
+            return RowExpr.of(self)._with("div", o, swap=True)
         return PairExpr.of(self).__rtruediv__(o)
 
     def __rsub__(self, o):
+        if self.reduced:
+            return RowExpr.of(self)._with("sub", o, swap=True)
         return PairExpr.of(self).__rsub__(o)
 
     def __lt__(self, o): return PairExpr.of(self) < o
@@ -518,6 +529,8 @@ class RinvPoly(PairEnergy):
     def __ge__(self, o): return PairExpr.of(self) >= o
 
     def __pow__(self, n):
+        if self.reduced:
+            return self if n == 1 else RowExpr.of(self) ** n
         if int(n) != n or n < 1:
             return PairExpr.of(self) ** n
         out = self
@@ -812,10 +825,22 @@ class RowExpr(_TorchOperand):
         from . import codegen as cg
         if isinstance(x, RowExpr):
             return x
-        if isinstance(x, RinvPoly) and x.reduced:
+        scale = 1.0
+        if isinstance(x, RinvPoly) and x.reduced and not getattr(x, "total", False):
+            # c * sum and sum are the SAME row sum (u + 0.02 * u * u must be a function of one sum): the polynomial travels
+            # normalised to its lowest power's coefficient, the factor stays outside
+            if x.terms:
+                scale = float(x.terms[min(x.terms)])
+                x = RinvPoly(x.nlist, {p_: c_ / scale for p_, c_ in x.terms.items()}, reduced=True, cut=x.cut)
             x = PairExpr.of(x)
         if isinstance(x, PairExpr) and x.reduced and not getattr(x, "total", False) and not isinstance(x, RowFnEnergy):
-            return RowExpr(x.nlist, cg.rowsum(0), [PairExpr(x.nlist, x.node, positions=x.positions, folded=x.folded)], x.positions, x.folded)
+            node = x.node
+            while node.op == "mul" and any(a_.op == "const" for a_ in node.args):    # (constant factors of a traced sum likewise)
+                c_, rest = (node.args[0], node.args[1]) if node.args[0].op == "const" else (node.args[1], node.args[0])
+                scale *= float(c_.value)
+                node = rest
+            out = RowExpr(x.nlist, cg.rowsum(0), [PairExpr(x.nlist, node, positions=x.positions, folded=x.folded)], x.positions, x.folded)
+            return out if scale == 1.0 else out._with("mul", scale, swap=True)
         if nlist is not None and isinstance(x, (int, float, np.floating, np.integer)) and not isinstance(x, bool):
             return RowExpr(nlist, cg.const(x), [])
         if nlist is not None and isinstance(x, torch.Tensor) and x.numel() == 1:
@@ -1670,8 +1695,14 @@ def _row_forces(nl, energy, virial):
                              "layer": None if getattr(_trace, "training_graph", False) else groups[0].layer,
                              "folded": tuple(groups[0].folded)})
         return outs[0]
-    _trace_log().append({"op": "row_terms", "potentials": pots})   # (several launches per step: the step stays eager)
-    return sum(outs[1:], outs[0])
+    # several terms: the first is logged like any lowered energy, the others ride along -- tfcompute's plan is then the one-kernel
+    # step of the first term (which writes the tensor) followed by one streaming evaluation per further term, added in place
+    f = sum(outs[1:], outs[0])
+    typed = [bool(g.reads_own_type) for g in groups]
+    _trace_log().append({"potential": pots[0], "nlist": nl, "virial": False, "forces": f, "layer": None,
+                         "folded": tuple(x for g in groups for x in g.folded),
+                         "extra_potentials": [(p_, t_) for p_, t_ in zip(pots[1:], typed[1:])]})
+    return f
 
 
 def _potential_of(energy):

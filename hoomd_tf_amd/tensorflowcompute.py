@@ -416,14 +416,16 @@ class tfcompute:
         if (self.force_mode_code == _lib.HTF_TF2HOOMD and len(plain) == nbatch and len(fused) == nbatch
                 and all(e.get("is_output") for e in fused) and not self.save_output_period
                 and all(e["virial"] == bool(self.model.virial) for e in fused)
-                and len({id(e["potential"]) for e in fused}) == 1):
+                and len({id(e["potential"]) for e in fused}) == 1
+                and (not fused[0].get("extra_potentials") or (int(self.fused) == 2 and nbatch == 1 and not self.model._map_nlist))):
             self._plan = fused[0]["potential"]
             self._plan_folded = tuple(fused[0].get("folded", ()))
             lay = fused[0].get("layer")
             self._plan_weights = lay if hasattr(lay, "refresh_if_stale") else None
             self.model._plan = self._plan
             self.cpp_force.set_potential(self._plan)
-            self._post_ops = post
+            # an energy of several row terms (simmodel._row_forces): the further terms from the tensor the step's kernel wrote
+            self._post_ops = post + [self._accumulate_term(p_, typed) for p_, typed in (fused[0].get("extra_potentials") or ())]
         else:
             # config C4's shape: closed-form base energy + alpha * soft-RDF CV (+ observables nobody
             # saves).  Replayed as htf_build_eval_forces2: tensor, both force sets and the CV partials
@@ -437,6 +439,19 @@ class tfcompute:
                 self._bplan = dict(biased[0]["biased"])
                 self.model._plan = self._bplan
         log.clear()
+
+    def _accumulate_term(self, pot, typed):
+        """A replayable post-op of the planned step: force += the streaming evaluator of one more term on the step's own tensor."""
+        state = {"buf": None}
+
+        def op(nl_buf, pos_buf):
+            n = nl_buf.shape[0]
+            if state["buf"] is None or state["buf"].shape[0] != n:
+                state["buf"] = torch.empty((n, 4), dtype=self.force.dtype, device=self.force.device)
+            ops.eval_forces(pot, nl_buf, out=state["buf"], positions=pos_buf if typed else None)
+            ops.add_scalar4(self.force, state["buf"])
+        op.potential = pot   # (kept alive with the plan)
+        return op
 
     def _run_biased_plan(self):
         s, nl, bp = self.system, self._nlist, self._bplan

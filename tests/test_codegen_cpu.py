@@ -469,8 +469,10 @@ def test_random_expressions_against_autograd():
         for trial in range(40):
             e = htf.square(s) * _random_expression(htf, rng, s, r, tj, ti, int(rng.integers(1, 4)))
             assert isinstance(e, PairExpr)
-            if not e.lowers():
+            if not cg.unit_of(e.node)["vanishes"]:
                 continue                       # (e.g. log / sqrt of something whose derivative is not finite at s = 0: the torch route)
+            # (the emitted C on the host only: building these units for gfx950 -- ~8 s each -- is test_gpu_codegen.py's
+            #  test_random_expressions_on_the_device, which also runs them)
             t = torch.from_numpy(pts[:, :3] + 1e-7)
             rr = torch.sqrt((t * t).sum(dim=1)).requires_grad_(True)
             ok = rr > 3e-6
