@@ -55,6 +55,10 @@ def bodies():
         out += [t.body() for t in (e.groups() or [])]
     u = htf.reduce_sum(2.0 * (s ** 12 - s ** 6) * htf.cast(s > 0.4, torch.float32), axis=1)
     out += [t.body() for t in (u + 0.02 * u * u).groups()]
+    u = htf.reduce_sum(2.0 * (s ** 12 - s ** 6), axis=1)                         # (bench generic-lj: traced_many_body, traced_embedded_atom)
+    out += [t.body() for t in (u + 0.02 * u * u).groups()]
+    rho = htf.reduce_sum(htf.exp(-1.7 * r) * s * s, axis=1)
+    out += [t.body() for t in (-1.3 * htf.sqrt(rho) + htf.reduce_sum(2.0 * s ** 12, axis=1)).groups()]
     return out
 
 
