@@ -258,6 +258,7 @@ def main():
                 for row, t in zip(out["ranks"], table):
                     row["rccl_communicator"] = t.get("rccl_communicator")
             out.update(extra)
+            multirank.promote_verified(out)
     if rank == 0:
         print(json.dumps(out))
     if E.dist is not None:

@@ -209,7 +209,7 @@ def guarded_section(E, live, out, emit):
             dom.transport = "torch"                                     # (what the timed loop and the next self-test step with)
             return {"note": "whole check periods of the decomposed step (check, halo, force rows, integrate-and-pack; migration + re-plan + "
                             "list rebuild in the second graph) replayed from hipGraphs per rank, transport %r; same decisions as the eager loop" % transport,
-                    "halo": {"transport": transport}, "value": steps / el, "unit": "steps/s", "ms_per_step": el / steps * 1e3,
+                    "halo": {"transport": transport}, "value": steps / el, "unit": "steps/s", "steps": steps, "ms_per_step": el / steps * 1e3,
                     "windows_ms_per_step": [x / steps * 1e3 for x in w], "rebuild_cycles": brun.n_rebuild_cycles, "dangerous_builds": brun.dangerous_builds,
                     "energy_per_particle": float(t[0] / t[2]), "kT": float(t[1] / (3.0 * t[2])), "particles": int(t[2])}
         return fn
@@ -241,3 +241,34 @@ def guarded_section(E, live, out, emit):
         val["halo"]["inbox_memory"] = getattr(dom, "peer_memory", None)
     res["graph_variant_peer"] = val if ok else {"skipped": val}
     return res
+
+
+def promote_verified(out):
+    """`value` is the whole job's throughput on the fastest path that RAN TO THE END on every rank and passed its checks: the eager
+    loop over torch.distributed is what is timed first (nothing in it can hang a node), the replayed decomposed step -- the path
+    the library ships for production, transports `native` / `peer` -- is timed in the guarded section; when a replay timed the
+    same number of steps, kept every particle, and left the system at the eager loop's temperature and energy (NVE: +-10 % / +-5 %
+    between two points of one trajectory), it becomes `value` and the eager figure stays on the line as `eager`."""
+    best, name = None, None
+    for key in ("graph_variant", "graph_variant_peer"):
+        v = out.get(key)
+        if not (isinstance(v, dict) and "value" in v and v.get("steps") == out.get("steps")):
+            continue
+        e0, k0 = out.get("energy_per_particle"), out.get("kT_final")
+        if e0 is None or k0 is None or not (np.isfinite(v["energy_per_particle"]) and np.isfinite(v["kT"])):
+            continue
+        if abs(v["kT"] - k0) > 0.1 * abs(k0) or abs(v["energy_per_particle"] - e0) > 0.05 * abs(e0):
+            continue
+        if v["value"] > out["value"] and (best is None or v["value"] > best["value"]):
+            best, name = v, key
+    if best is None:
+        out["value_path"] = "eager loop (torch.distributed transport)"
+        return out
+    out["eager"] = {"value": out["value"], "ms_per_step": out["ms_per_step"], "unit": out["unit"],
+                    "note": "the same steps driven from Python over the torch.distributed transport (timed first; the safe default)"}
+    out["value"], out["ms_per_step"] = best["value"], best["ms_per_step"]
+    if "particle_steps_per_s" in out and "global_particles" in out.get("config", {}):
+        out["eager"]["particle_steps_per_s"] = out["particle_steps_per_s"]
+        out["particle_steps_per_s"] = out["value"] * out["config"]["global_particles"]
+    out["value_path"] = "%s: whole check periods replayed from hipGraphs per rank, transport %r" % (name, best["halo"]["transport"])
+    return out

@@ -495,6 +495,10 @@ def test_bench_starts_its_own_ranks(htf, cuda, args):
     # ranks sharing one GPU: RCCL refuses (a named skip); the library-free transport runs for real, self-test and replay
     assert "share" in d["native_selftest"]["skipped"] and d["graph_variant"]["skipped"]
     assert d["peer_selftest"]["bit_equal_to_torch_transport"] and "fine-grained" in d["peer_selftest"]["inbox_memory"]
+    # `value` is the fastest path that ran to the end and passed its checks; the eager figure stays on the line
+    assert "value_path" in d
+    if "eager" in d:
+        assert d["value"] >= d["eager"]["value"] and d["value"] in (d["graph_variant"].get("value"), d["graph_variant_peer"].get("value"))
     g = d["graph_variant_peer"]
     assert g["value"] > 0 and g["halo"]["transport"] == "peer" and g["particles"] == d["config"]["global_particles"]
     assert -7.0 < g["energy_per_particle"] < -4.0 and 0.5 < g["kT"] < 1.5
