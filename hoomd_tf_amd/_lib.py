@@ -157,6 +157,7 @@ PROTOTYPES = {
     "htf_potential_num_params": (_i, [_vp]),
     "htf_train_scratch_floats": (_sz, [_vp, _u, _u]),
     "htf_train_pair_grad": (_i, [_vp, _vp, _i, _u, _u, _vp, _i, _vp, _vp, _vp, _vp]),
+    "htf_train_pair_grad_list": (_i, [_vp, _vp, _i, _u, _u, C.POINTER(Box), _vp, _vp, _vp, _d, _vp, _i, _vp, _vp, _vp, _vp]),
     "htf_optimizer_step": (_i, [_vp, _u, _vp, C.c_float, _vp, C.POINTER(OptimizerDesc), _vp]),
     "htf_optimizer_step_n": (_i, [_vp, _u, _vp, C.c_float, _vp, C.POINTER(OptimizerDesc), _vp]),
     "htf_potential_refresh": (_i, [_vp, _vp]),

@@ -241,6 +241,21 @@ extern "C" int htf_train_pair_grad(const htf_potential *pot, const void *d_nlist
                                (hipStream_t)stream);
 }
 
+extern "C" int htf_train_pair_grad_list(const htf_potential *pot, const void *d_pos, int pos_dtype, unsigned B, unsigned NN,
+                                        const htf_box *box, const unsigned *d_n_neigh, const unsigned *d_nlist,
+                                        const unsigned *d_head_list, double rmax, const void *d_labels, int label_dtype,
+                                        void *d_pred, float *d_accum, float *d_scratch, htf_stream stream) {
+    using namespace htf;
+    HTF_REQUIRE(pot, "htf_train_pair_grad_list: no potential");
+    HTF_REQUIRE(d_pos && box && d_n_neigh && d_nlist && d_head_list && d_labels && d_accum && d_scratch, "htf_train_pair_grad_list: null pointer");
+    HTF_REQUIRE(NN > 0 && B > 0, "htf_train_pair_grad_list: empty batch");
+    HTF_REQUIRE(pos_dtype == HTF_F32 || pos_dtype == HTF_F64, "htf_train_pair_grad_list: bad position dtype %d", pos_dtype);
+    HTF_REQUIRE(label_dtype == HTF_F32 || label_dtype == HTF_F64, "htf_train_pair_grad_list: bad label dtype %d", label_dtype);
+    HTF_REQUIRE(!pot->mlp, "htf_train_pair_grad_list: the pair-MLP's training sweep reads the pair-vector tensor (htf_train_pair_grad)");
+    return train_list_dispatch(pot->pp, d_pos, pos_dtype, B, NN, box, d_n_neigh, d_nlist, d_head_list, rmax, d_labels, label_dtype,
+                               d_pred, d_accum, d_scratch, (hipStream_t)stream);
+}
+
 extern "C" void htf_potential_destroy(htf_potential *pot) {
     if (!pot) return;
     if (pot->mlp) htf::mlp_destroy(pot->mlp);

@@ -138,6 +138,12 @@ int jit_launch_eval(const PotParams &p, const void *nlist, int in_dtype, unsigne
 // the training sweep of a unit compiled with weights (train_pair.hip's row loop around the generated jets): block partials
 int jit_launch_train(const PotParams &p, const void *nlist, int in_dtype, unsigned B, unsigned NN, const void *labels, int lab_f64,
                      void *pred, float *partials, unsigned grid, hipStream_t s);
+int jit_launch_train_list(const PotParams &p, const void *pos, int pos_dtype, unsigned B, unsigned NN, const htf_box *box,
+                          const unsigned *n_neigh, const unsigned *nlist, const unsigned *head_list, double rmax, const void *labels,
+                          int lab_f64, void *pred, float *partials, unsigned grid, hipStream_t s);
+int train_list_dispatch(const PotParams &p, const void *pos, int pos_dtype, unsigned B, unsigned NN, const htf_box *box,
+                        const unsigned *n_neigh, const unsigned *nlist, const unsigned *head_list, double rmax, const void *labels,
+                        int label_dtype, void *pred, float *accum, float *scratch, hipStream_t stream);
 int jit_num_params(const JitKernels *k);
 
 // counts (nullable): live slots per row; slots >= counts[row] are known zero padding and not loaded

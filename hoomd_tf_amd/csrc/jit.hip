@@ -57,6 +57,7 @@ struct JitKernels {
     hipFunction_t tails4[2] = {};   // [tensor written]: fp32 positions, four rows per wave with merged tails
     hipFunction_t eval[2][2] = {};  // [fp64 tensor][virial]
     hipFunction_t train[2] = {};    // [fp64 tensor]: only in a unit compiled with weights (HTF_JIT_NPARAMS)
+    hipFunction_t train_list[2] = {}; // [fp64 positions]: the same sweep from the index list
     int nparams = 0;
 };
 
@@ -102,6 +103,9 @@ int jit_create(const void *image, size_t bytes, JitKernels **out) {
     if (!(hipModuleGetFunction(&k->train[0], k->mod, "htf_jit_train_f32") == hipSuccess &&
           hipModuleGetFunction(&k->train[1], k->mod, "htf_jit_train_f64") == hipSuccess))
         k->train[0] = k->train[1] = nullptr;
+    if (!(k->train[0] && hipModuleGetFunction(&k->train_list[0], k->mod, "htf_jit_train_list_f32") == hipSuccess &&
+          hipModuleGetFunction(&k->train_list[1], k->mod, "htf_jit_train_list_f64") == hipSuccess))
+        k->train_list[0] = k->train_list[1] = nullptr;
     (void)hipGetLastError();
     *out = k;
     return HTF_OK;
@@ -174,6 +178,26 @@ int jit_launch_train(const PotParams &p, const void *nlist, int in_dtype, unsign
     PotParams pp = p;
     void *args[] = {&nlist, &B, &NN, &labels, &lab_f64, &pred, &pp, &partials};
     HTF_CHECK_HIP(hipModuleLaunchKernel(p.jit->train[in_dtype == HTF_F64 ? 1 : 0], grid, 1, 1, 256, 1, 1, 0, s, args, nullptr));
+    return HTF_OK;
+}
+
+int jit_launch_train_list(const PotParams &p, const void *pos, int pos_dtype, unsigned B, unsigned NN, const htf_box *box,
+                          const unsigned *n_neigh, const unsigned *nlist, const unsigned *head_list, double rmax, const void *labels,
+                          int lab_f64, void *pred, float *partials, unsigned grid, hipStream_t s) {
+    HTF_REQUIRE(p.jit && p.jit->train_list[0] && p.jit->nparams > 0, "HTF_POT_JIT: this generated unit carries no list-form training sweep");
+    HTF_REQUIRE(p.theta != nullptr, "HTF_POT_JIT: a trainable traced energy needs its device parameter vector (desc.d_theta)");
+    PotParams pp = p;
+    if (pos_dtype == HTF_F32) {
+        BoxT<float> b = make_boxt<float>(box);
+        float rc2 = (float)rmax * (float)rmax;
+        void *args[] = {&pos, &B, &NN, &b, &n_neigh, &nlist, &head_list, &rc2, &labels, &lab_f64, &pred, &pp, &partials};
+        HTF_CHECK_HIP(hipModuleLaunchKernel(p.jit->train_list[0], grid, 1, 1, 256, 1, 1, 0, s, args, nullptr));
+    } else {
+        BoxT<double> b = make_boxt<double>(box);
+        double rc2 = rmax * rmax;
+        void *args[] = {&pos, &B, &NN, &b, &n_neigh, &nlist, &head_list, &rc2, &labels, &lab_f64, &pred, &pp, &partials};
+        HTF_CHECK_HIP(hipModuleLaunchKernel(p.jit->train_list[1], grid, 1, 1, 256, 1, 1, 0, s, args, nullptr));
+    }
     return HTF_OK;
 }
 

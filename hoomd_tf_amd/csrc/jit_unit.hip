@@ -98,4 +98,15 @@ extern "C" __device__ const int htf_jit_nparams = HTF_JIT_NPARAMS;
     }
 HTF_JIT_TRAIN(htf_jit_train_f32, float)
 HTF_JIT_TRAIN(htf_jit_train_f64, double)
+// ... and its list form (no pair-vector tensor: train_pair.hip train_list_body)
+#define HTF_JIT_TRAIN_LIST(NAME, PT)                                                                                                \
+    extern "C" __global__ __launch_bounds__(256) void NAME(const typename Vec4<PT>::type *__restrict__ pos, unsigned B, unsigned NN, \
+                                                           BoxT<PT> box, const unsigned *__restrict__ n_neigh,                     \
+                                                           const unsigned *__restrict__ nlist, const unsigned *__restrict__ head_list, \
+                                                           PT rmaxsq, const void *__restrict__ labels, int lab_f64,                 \
+                                                           void *__restrict__ pred, PotParams pin, float *__restrict__ partials) {  \
+        train_list_body<HTF_POT_JIT, PT>(pos, B, NN, box, n_neigh, nlist, head_list, rmaxsq, labels, lab_f64, pred, pin, partials); \
+    }
+HTF_JIT_TRAIN_LIST(htf_jit_train_list_f32, float)
+HTF_JIT_TRAIN_LIST(htf_jit_train_list_f64, double)
 #endif

@@ -78,6 +78,7 @@ void bind(py::module &m, const char *name, R (*fn)(A...)) {
     X(htf_potential_num_params) \
     X(htf_train_scratch_floats) \
     X(htf_train_pair_grad) \
+    X(htf_train_pair_grad_list) \
     X(htf_optimizer_step) \
     X(htf_optimizer_step_n) \
     X(htf_potential_refresh) \

@@ -16,6 +16,7 @@
 
 #include "htf_common.h"
 #include "htf_internal.h"
+#include "box_math.h"
 #include "pair_math.h"
 
 namespace htf {
@@ -89,6 +90,132 @@ __device__ __forceinline__ void train_pair_body(const typename Vec4<IT>::type *_
             (s_part[0][threadIdx.x] + s_part[1][threadIdx.x]) + (s_part[2][threadIdx.x] + s_part[3][threadIdx.x]);
 }
 
+// The same sweep FROM THE INDEX LIST (round 6): no [B, NN, 4] tensor is written for, or read by, a training step.  Sixteen lanes
+// walk row i's list entries; a neighbor's position is gathered and its pair vector formed in registers exactly as
+// prepareNeighbors forms it (box_math.h pair_vector: minimum image, then the r_cut mask), so a kept pair's (x, y, z, type) are the
+// bits the tensor would hold; a row keeps its first NN neighbors within r_cut -- or, past NN, the LAST NN of them (the
+// reference's slot wrap; the row is then redone with those bounds).  Only the order of a row's fp32 sums differs from the
+// tensor sweep (a pair sits in lane (list position) % 16 instead of (slot) % 16).
+constexpr int kTrainChunk = 4; // list entries per lane gathered ahead of their arithmetic
+
+template <int KIND, typename PT>
+__device__ __forceinline__ void train_list_body(const typename Vec4<PT>::type *__restrict__ pos, unsigned B, unsigned NN,
+                                                BoxT<PT> box, const unsigned *__restrict__ n_neigh,
+                                                const unsigned *__restrict__ nlist, const unsigned *__restrict__ head_list,
+                                                PT rmaxsq, const void *__restrict__ labels, int lab_f64, void *__restrict__ pred,
+                                                PotParams pin, float *__restrict__ partials) {
+    using PV = typename Vec4<PT>::type;
+    constexpr int G = kTrainG, RPW = 64 / G, P = NumParams<KIND>::value;
+    __shared__ float s_part[4][1 + P];
+    const PotParams p = resolve_theta<KIND>(pin);
+    const unsigned lane = threadIdx.x & 63u, g = lane % G, sub = lane / G;
+    const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const unsigned row = wave * RPW + sub;
+    const bool active = row < B;
+    const unsigned r_ = active ? row : B - 1;
+    const unsigned nn = active ? n_neigh[r_] : 0u;
+    const unsigned *nl = nlist + head_list[r_];
+    const PV pi = pos[r_];
+    // the longest list among the wave's four rows bounds the loop (ballots need every lane)
+    unsigned nn_max = nn;
+    for (int m = G; m < 64; m <<= 1) {
+        const unsigned o = (unsigned)__shfl_xor((int)nn_max, m);
+        nn_max = o > nn_max ? o : nn_max;
+    }
+    float F[4];
+    float4 J[P];
+    unsigned q_lo = 0u, q_hi = NN;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+        F[0] = F[1] = F[2] = F[3] = 0.f;
+#pragma unroll
+        for (int k = 0; k < P; ++k) J[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        unsigned Q = 0u;
+        for (unsigned base = 0; base < nn_max; base += kTrainChunk * G) {
+            unsigned idx[kTrainChunk];
+            PV pk[kTrainChunk];
+#pragma unroll
+            for (int t = 0; t < kTrainChunk; ++t) {
+                const unsigned j = base + t * G + g;
+                idx[t] = nn ? nl[j < nn ? j : nn - 1] : 0u;
+            }
+#pragma unroll
+            for (int t = 0; t < kTrainChunk; ++t) pk[t] = nn ? load_neighbor(pos, idx[t]) : pi;
+#pragma unroll
+            for (int t = 0; t < kTrainChunk; ++t) {
+                const unsigned j = base + t * G + g;
+                PT dx, dy, dz;
+                const PT rsq = pair_vector<PT>(pk[t], pi, box, dx, dy, dz);
+                const bool keep = j < nn && !(rsq > rmaxsq);
+                const unsigned bits = (unsigned)(__ballot(keep) >> (G * sub)) & ((1u << G) - 1u);
+                const unsigned q = Q + (unsigned)__popc(bits & ((1u << g) - 1u));
+                Q += (unsigned)__popc(bits);
+                const bool use = keep && q >= q_lo && q < q_hi;
+                // (a slot that is not used is the tensor's zero padding: every trainable form vanishes on it)
+                const float x = use ? (float)dx : 0.f, y = use ? (float)dy : 0.f, z = use ? (float)dz : 0.f;
+                float e, fx, fy, fz;
+                float4 dd[P];
+                pair_eval_grad<KIND>(x, y, z, p, e, fx, fy, fz, dd, use ? (float)scalar_as_int(pk[t].w) : 0.f);
+                F[0] += fx; F[1] += fy; F[2] += fz; F[3] += e;
+#pragma unroll
+                for (int k = 0; k < P; ++k) {
+                    J[k].x += dd[k].x; J[k].y += dd[k].y; J[k].z += dd[k].z; J[k].w += dd[k].w;
+                }
+            }
+        }
+        // more than NN neighbors within r_cut (an error upstream): the tensor holds the last NN of them
+        const bool over = Q > NN;
+        q_lo = over ? Q - NN : 0u;
+        q_hi = over ? Q : NN;
+        if (pass == 1 || __ballot(over) == 0ull) break;
+        if (!over) { q_lo = 0u; q_hi = NN; }   // (a row without overflow is simply redone with the same bounds)
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) F[c] = group_sum<G>(F[c]);
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+        J[k].x = group_sum<G>(J[k].x); J[k].y = group_sum<G>(J[k].y);
+        J[k].z = group_sum<G>(J[k].z); J[k].w = group_sum<G>(J[k].w);
+    }
+    float out[1 + P];
+#pragma unroll
+    for (int k = 0; k <= P; ++k) out[k] = 0.f;
+    if (g == 0 && active) {
+        float Y[4];
+        if (lab_f64) {
+            const double4 y = ((const double4 *)labels)[row];
+            Y[0] = (float)y.x; Y[1] = (float)y.y; Y[2] = (float)y.z; Y[3] = (float)y.w;
+        } else {
+            const float4 y = ((const float4 *)labels)[row];
+            Y[0] = y.x; Y[1] = y.y; Y[2] = y.z; Y[3] = y.w;
+        }
+        const float r0 = F[0] - Y[0], r1 = F[1] - Y[1], r2 = F[2] - Y[2], r3 = F[3] - Y[3];
+        out[0] = r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3;
+#pragma unroll
+        for (int k = 0; k < P; ++k) out[1 + k] = 2.0f * (r0 * J[k].x + r1 * J[k].y + r2 * J[k].z + r3 * J[k].w);
+        if (pred != nullptr) ((float4 *)pred)[row] = make_float4(F[0], F[1], F[2], F[3]);
+    }
+#pragma unroll
+    for (int k = 0; k <= P; ++k) {
+        float v = out[k];
+        for (int m = G; m < 64; m <<= 1) v += __shfl_xor(v, m);
+        if (lane == 0) s_part[threadIdx.x >> 6][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x <= (unsigned)P)
+        partials[(size_t)blockIdx.x * (1 + P) + threadIdx.x] =
+            (s_part[0][threadIdx.x] + s_part[1][threadIdx.x]) + (s_part[2][threadIdx.x] + s_part[3][threadIdx.x]);
+}
+
+template <int KIND, typename PT>
+__global__ __launch_bounds__(256) void train_list_kernel(const typename Vec4<PT>::type *__restrict__ pos, unsigned B, unsigned NN,
+                                                         BoxT<PT> box, const unsigned *__restrict__ n_neigh,
+                                                         const unsigned *__restrict__ nlist, const unsigned *__restrict__ head_list,
+                                                         PT rmaxsq, const void *__restrict__ labels, int lab_f64,
+                                                         void *__restrict__ pred, PotParams pin, float *__restrict__ partials) {
+    train_list_body<KIND, PT>(pos, B, NN, box, n_neigh, nlist, head_list, rmaxsq, labels, lab_f64, pred, pin, partials);
+}
+
 template <int KIND, typename IT>
 __global__ __launch_bounds__(256) void train_pair_kernel(const typename Vec4<IT>::type *__restrict__ nlist, unsigned B,
                                                          unsigned NN, const void *__restrict__ labels, int lab_f64,
@@ -131,6 +258,27 @@ static int launch_train(const PotParams &p, const void *nlist, int in_dtype, uns
         hipLaunchKernelGGL((train_pair_kernel<KIND, double>), dim3(grid), dim3(256), 0, s, (const double4 *)nlist, B, NN, labels, lab_f64, pred, p, scratch);
     int rc = check_launch("train_pair_kernel");
     if (rc != HTF_OK) return rc;
+    hipLaunchKernelGGL(reduce_columns_kernel, dim3(1), dim3(1024), 0, s, scratch, grid, width, accum);
+    return check_launch("reduce_columns_kernel");
+}
+
+template <int KIND>
+static int launch_train_list(const PotParams &p, const void *pos, int pos_dtype, unsigned B, unsigned NN, const htf_box *hb,
+                             const unsigned *n_neigh, const unsigned *nlist, const unsigned *head_list, double rmax,
+                             const void *labels, int lab_f64, void *pred, float *accum, float *scratch, hipStream_t s) {
+    constexpr unsigned rows_per_block = 4 * (64 / kTrainG);
+    constexpr unsigned width = 1 + NumParams<KIND>::value;
+    const unsigned grid = (B + rows_per_block - 1) / rows_per_block;
+    if (pos_dtype == HTF_F32) {
+        const float rc = (float)rmax;
+        hipLaunchKernelGGL((train_list_kernel<KIND, float>), dim3(grid), dim3(256), 0, s, (const float4 *)pos, B, NN, make_boxt<float>(hb),
+                           n_neigh, nlist, head_list, rc * rc, labels, lab_f64, pred, p, scratch);
+    } else {
+        hipLaunchKernelGGL((train_list_kernel<KIND, double>), dim3(grid), dim3(256), 0, s, (const double4 *)pos, B, NN, make_boxt<double>(hb),
+                           n_neigh, nlist, head_list, rmax * rmax, labels, lab_f64, pred, p, scratch);
+    }
+    int rc2 = check_launch("train_list_kernel");
+    if (rc2 != HTF_OK) return rc2;
     hipLaunchKernelGGL(reduce_columns_kernel, dim3(1), dim3(1024), 0, s, scratch, grid, width, accum);
     return check_launch("reduce_columns_kernel");
 }
@@ -180,6 +328,30 @@ int train_pair_dispatch(const PotParams &p, const void *nlist, int in_dtype, uns
         set_error("htf_train_pair_grad: potential kind %d has no trainable closed form (pair-MLP training: next round)", p.kind);
         return HTF_ERR_INVALID;
     }
+}
+
+int train_list_dispatch(const PotParams &p, const void *pos, int pos_dtype, unsigned B, unsigned NN, const htf_box *box,
+                        const unsigned *n_neigh, const unsigned *nlist, const unsigned *head_list, double rmax, const void *labels,
+                        int label_dtype, void *pred, float *accum, float *scratch, hipStream_t stream) {
+    const int lab_f64 = label_dtype == HTF_F64;
+#define HTF_TL(K) launch_train_list<K>(p, pos, pos_dtype, B, NN, box, n_neigh, nlist, head_list, rmax, labels, lab_f64, pred, accum, scratch, stream)
+    switch (p.kind) {
+    case HTF_POT_LJ_PARAM: return HTF_TL(HTF_POT_LJ_PARAM);
+    case HTF_POT_WCA: return HTF_TL(HTF_POT_WCA);
+    case HTF_POT_RINV_POLY: return HTF_TL(HTF_POT_RINV_POLY);
+    case HTF_POT_JIT: {
+        constexpr unsigned rows_per_block = 4 * (64 / kTrainG);
+        const unsigned grid = (B + rows_per_block - 1) / rows_per_block;
+        int rc = jit_launch_train_list(p, pos, pos_dtype, B, NN, box, n_neigh, nlist, head_list, rmax, labels, lab_f64, pred, scratch, grid, stream);
+        if (rc != HTF_OK) return rc;
+        hipLaunchKernelGGL(reduce_columns_kernel, dim3(1), dim3(1024), 0, stream, scratch, grid, 1u + (unsigned)p.n_terms, accum);
+        return check_launch("reduce_columns_kernel");
+    }
+    default:
+        set_error("htf_train_pair_grad_list: potential kind %d has no list-form training sweep (the pair-MLP's reads the tensor)", p.kind);
+        return HTF_ERR_INVALID;
+    }
+#undef HTF_TL
 }
 
 // tf.keras.optimizers.{SGD, Adam, Nadam} (TF 2.3/2.4 optimizer_v2 update rules)

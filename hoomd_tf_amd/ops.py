@@ -361,6 +361,29 @@ def train_pair_grad(potential, nlist, labels, pred=None, accum=None):
     return accum
 
 
+def train_pair_grad_list(potential, pos, n_neigh, head_list, nlist, box, r_cut, NN, labels, n_local=None, pred=None, accum=None,
+                         periodic=(1, 1, 1)):
+    """train_pair_grad from HOOMD's index neighbor list (htf_train_pair_grad_list): no [B, NN, 4] tensor is written or read.
+    Rows 0 .. n_local-1 are trained on.  Closed forms and traced energies with weights."""
+    _dev(pos, "pos")
+    _dev(labels, "labels")
+    B = int(n_neigh.shape[0]) if n_local is None else int(n_local)
+    P = potential.num_params
+    if P == 0:
+        raise ValueError("this potential has no trainable parameters")
+    if accum is None:
+        accum = torch.empty(1 + P, dtype=torch.float32, device=pos.device)
+    scratch = torch.empty(int(lib.htf_train_scratch_floats(potential.handle, B, NN)), dtype=torch.float32, device=pos.device)
+    if pred is not None:
+        _dev(pred, "pred", torch.float32)
+    b = box if isinstance(box, _lib.Box) else _lib.make_box(box, periodic)
+    check(lib.htf_train_pair_grad_list(potential.handle, pos.data_ptr(), _dt(pos), B, int(NN), C.byref(b),
+                                       _u32(n_neigh, "n_neigh").data_ptr(), _u32(nlist, "nlist").data_ptr(),
+                                       _u32(head_list, "head_list").data_ptr(), float(r_cut), labels.data_ptr(), _dt(labels),
+                                       pred.data_ptr() if pred is not None else None, accum.data_ptr(), scratch.data_ptr(), _stream(pos)))
+    return accum
+
+
 def optimizer_step(theta, accum, scale, state, desc):
     """Keras SGD / Adam / Nadam step on the device parameter vector (no host round trip).
     ``state``: optimizer_state_floats(P) zero-initialised floats."""

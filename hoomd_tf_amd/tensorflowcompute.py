@@ -345,7 +345,12 @@ class tfcompute:
         if getattr(self, "_opt_desc", None) is None:
             self._opt_desc = m.optimizer.desc(layer.nonneg_mask, layer.l1_reg)
         labels = self._labels[offset:offset + n]
-        accum = ops.train_pair_grad(pot, nlist_t, labels)
+        if nlist_t is None:     # (the training plan, from the index list: whole-system batches only)
+            s_, nl_ = self.system, self._nlist
+            accum = ops.train_pair_grad_list(pot, s_.pos, nl_.n_neigh, nl_.head_list, nl_.nlist, s_.box, self.r_cut,
+                                             self.nneighbor_cutoff, labels, n_local=s_.N)
+        else:
+            accum = ops.train_pair_grad(pot, nlist_t, labels)
         n_total = float(n)
         domain = getattr(self._nlist, "domain", None)
         if domain is not None and domain.world > 1:
@@ -384,15 +389,34 @@ class tfcompute:
                 and entries[0]["nlist"].tensor is nlist_t and len(output) > 0 and output[0] is entries[0]["forces"]
                 and not self.save_output_period and not self.model._map_nlist and self.nneighbor_cutoff > 0 and not self.model.check_nlist
                 and not isinstance(self.model, simmodel.MolSimModel)):
-            self._tplan = {"layer": entries[0]["layer"], "potential": entries[0]["potential"]}
+            pot = entries[0]["potential"]
+            # closed forms and traced energies train straight from the index list (htf_train_pair_grad_list): the step neither
+            # writes nor re-reads the [N, NN, 4] tensor; the pair-MLP's sweep reads the tensor.  HTF_TRAIN_FROM_TENSOR=1: always.
+            from_list = (pot.kind in (_lib.POT_LJ_PARAM, _lib.POT_WCA, _lib.POT_RINV_POLY, _lib.POT_JIT)
+                         and os.environ.get("HTF_TRAIN_FROM_TENSOR") != "1")
+            self._tplan = {"layer": entries[0]["layer"], "potential": pot, "from_list": from_list}
 
     def _run_train_plan(self):
         s, nl = self.system, self._nlist
         self._stage_labels()
+        if self._tplan["from_list"]:
+            self._last = None          # (get_nlist_array / get_positions_array build the side buffers when somebody asks)
+            self._train_on_batch(None, 0, s.N, [self._tplan])
+            return
         pv = ops.build_pair_vectors(s.pos, nl.n_neigh, nl.head_list, nl.nlist, s.box, self.r_cut, self.nneighbor_cutoff,
                                     offset=0, batch_size=s.N, n_local=s.N, out_dtype=torch.float32)
         self._last = (pv, ops.copy_positions(s.pos, offset=0, N=s.N, unstuff4=True), 0, s.N)
         self._train_on_batch(pv, 0, s.N, [self._tplan])
+
+    def _side_buffers(self):
+        """(nlist tensor, positions, offset, n) of the last batch; after a training step that ran from the index list they are
+        built here, from the arrays as they stand."""
+        if self._last is None:
+            s, nl = self.system, self._nlist
+            pv = ops.build_pair_vectors(s.pos, nl.n_neigh, nl.head_list, nl.nlist, s.box, self.r_cut, self.nneighbor_cutoff,
+                                        offset=0, batch_size=s.N, n_local=s.N, out_dtype=torch.float32)
+            self._last = (pv, ops.copy_positions(s.pos, offset=0, N=s.N, unstuff4=True), 0, s.N)
+        return self._last
 
     def _maybe_install_plan(self, nbatch):
         log = simmodel._trace_log()
@@ -534,7 +558,7 @@ class tfcompute:
         if self._ctx_ran:
             n = self.system.N if self.batch_size == 0 else min(self.batch_size, self.system.N)
             return self.cpp_force.positions_buffer(n, self.system.device).double().cpu().numpy()
-        return self._last[1].double().cpu().numpy()
+        return self._side_buffers()[1].double().cpu().numpy()
 
     def get_nlist_array(self):
         """tensorflowcompute.py:377-381 -> [B, NN, 4]."""
@@ -543,7 +567,7 @@ class tfcompute:
         if self._ctx_ran:
             n = self.system.N if self.batch_size == 0 else min(self.batch_size, self.system.N)
             return self.cpp_force.nlist_buffer(n, self.system.device).double().cpu().numpy()
-        return self._last[0].double().cpu().numpy().reshape(-1, self.nneighbor_cutoff, 4)
+        return self._side_buffers()[0].double().cpu().numpy().reshape(-1, self.nneighbor_cutoff, 4)
 
     def get_forces_array(self):
         """tensorflowcompute.py:383-386."""

@@ -261,6 +261,16 @@ HTF_API int htf_train_pair_grad(const htf_potential *pot, const void *d_nlist, i
                         unsigned B, unsigned NN, const void *d_labels, int label_dtype,
                         void *d_pred, float *d_accum, float *d_scratch, htf_stream stream);
 
+/* The same sweep FROM HOOMD'S INDEX LIST (round 6): positions are gathered and the pair vectors formed in registers exactly as
+ * htf_build_pair_vectors forms them (minimum image, r_cut mask, a row's first NN kept neighbors -- the last NN past an
+ * overflow), so a training step neither writes nor re-reads the [B, NN, 4] tensor.  Rows 0 .. B-1 of the arrays (ghosts
+ * behind them are gathered like any neighbor); d_accum, d_pred, d_scratch (htf_train_scratch_floats) as above.  Closed forms
+ * and generated units with weights; a pair-MLP is HTF_ERR_INVALID (its sweep reads the tensor). */
+HTF_API int htf_train_pair_grad_list(const htf_potential *pot, const void *d_pos, int pos_dtype, unsigned B, unsigned NN,
+                             const htf_box *box, const unsigned *d_n_neigh, const unsigned *d_nlist,
+                             const unsigned *d_head_list, double rmax, const void *d_labels, int label_dtype,
+                             void *d_pred, float *d_accum, float *d_scratch, htf_stream stream);
+
 enum htf_optimizer_kind { HTF_OPT_SGD = 0, HTF_OPT_ADAM = 1, HTF_OPT_NADAM = 2 };
 typedef struct htf_optimizer_desc {
     int kind;                  /* tf.keras.optimizers.{SGD, Adam, Nadam} update rules */

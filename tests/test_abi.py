@@ -88,7 +88,7 @@ def test_pybind11_binding_exports_the_abi_and_runs_host_calls(htf):
         "from hoomd_tf_amd import _lib\n"
         "assert _lib.BINDING == 'pybind11' and type(_lib.lib).__name__ == '_PybindLib'\n"
         "names = list(_lib.PROTOTYPES) + list(_lib.STANDIN_PROTOTYPES)\n"
-        "assert all(hasattr(_lib.lib._mod, n) for n in names) and len(names) == 96\n"
+        "assert all(hasattr(_lib.lib._mod, n) for n in names) and len(names) == 97\n"
         "assert _lib.lib.htf_abi_version() == 4 == _lib.ABI_VERSION\n"
         "p = htf.Potential.rinv_poly([1.0, -0.5], [12, 6], cut=1.1)\n"
         "assert p.handle.value and p.num_params >= 2\n"

@@ -611,3 +611,86 @@ def test_pair_mlp_gradient_full_size(htf, cuda, precision):
         for n in (32 * 64, 64, 64 * 64, 64, 64, 1):           # every block of theta carries signal
             assert np.abs(accum[1 + o:1 + o + n]).max() > 1e-3 * np.abs(want[o:o + n]).max()
             o += n
+
+
+# --------------------------------------------------------------------------- the training sweep from the index list (round 6)
+@pytest.mark.parametrize("kind", ["lj_param", "wca", "rinv_poly", "traced"])
+@pytest.mark.parametrize("NN,wire", [(96, torch.float32), (40, torch.float32), (96, torch.float64)])
+def test_training_sweep_from_the_index_list_equals_the_tensor_sweep(htf, cuda, kind, NN, wire):
+    """htf_train_pair_grad_list -- positions gathered through HOOMD's index list, pair vectors formed in registers, no [N, NN, 4]
+    tensor -- against htf_train_pair_grad on the tensor htf_build_pair_vectors writes from the same arrays: prediction, summed
+    squared residual and every weight's gradient equal to the rounding of a row's fp32 sums (their ORDER is all that differs).  NN =
+    40 at r_cut 2.5 overflows every row of a liquid: the reference's slot wrap keeps the LAST NN neighbors, in both sweeps.
+    (The tensor sweep itself is pinned against fp64 double backward by the tests above.)"""
+    from hoomd_tf_amd import standin
+    pos, L, a = standin.fcc_positions(6, 0.8442)
+    rng = np.random.default_rng(12)
+    pos = pos + 0.04 * a * rng.standard_normal(pos.shape)
+    pos -= np.round(pos / L) * L
+    sysm = standin.System(pos, L, dtype=wire, device=cuda)
+    nl = standin.CellNlist(sysm, r_cut=2.5, r_buff=0.4)
+    nl.build()
+    if kind == "lj_param":
+        pot = htf.Potential.lj_param(0.9, 1.05, theta=torch.tensor([0.9, 1.05], device=cuda))
+    elif kind == "wca":
+        pot = htf.Potential.wca(0.95, theta=torch.tensor([0.95], device=cuda))
+    elif kind == "rinv_poly":
+        pot = htf.Potential.rinv_poly([1.5, -2.5], [12, 6], theta=torch.tensor([1.5, -2.5], device=cuda))
+    else:
+        x0 = htf.Nlist(torch.zeros((2, 4, 4), device=cuda))
+        w = torch.nn.Parameter(torch.tensor([0.8, 1.05], device=cuda))
+        q = (w[1] * htf.nlist_rinv(x0)) ** 6
+        e = htf.reduce_sum(w[0] * 2.0 * (q * q - q), axis=1)
+        assert e.lowers()
+        pot = e.layer.potential(cuda)
+    pv = htf.ops.build_pair_vectors(sysm.pos, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, 2.5, NN)
+    kept = int(((pv[:, :, :3] != 0).any(dim=2)).sum(dim=1).min())
+    assert (kept == NN) if NN == 40 else (kept < NN)                       # NN = 40: every row is full (and overflowed)
+    labels = (0.05 * torch.randn((sysm.N, 4), generator=torch.Generator().manual_seed(3))).to(cuda)
+    p0, p1 = torch.empty((sysm.N, 4), device=cuda), torch.empty((sysm.N, 4), device=cuda)
+    a0 = htf.ops.train_pair_grad(pot, pv, labels, pred=p0)
+    a1 = htf.ops.train_pair_grad_list(pot, sysm.pos, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, 2.5, NN, labels, pred=p1)
+    assert torch.equal(a1, htf.ops.train_pair_grad_list(pot, sysm.pos, nl.n_neigh, nl.head_list, nl.nlist, sysm.box, 2.5, NN, labels))
+    scale = float(p0.abs().max())
+    assert float((p0 - p1).abs().max()) <= 2e-6 * scale + 1e-7, float((p0 - p1).abs().max()) / scale
+    a0, a1 = a0.double().cpu().numpy(), a1.double().cpu().numpy()
+    assert abs(a0[0] - a1[0]) <= 2e-6 * abs(a0[0])
+    assert np.abs(a0[1:] - a1[1:]).max() <= 2e-5 * np.abs(a0[1:]).max() + 1e-6, (a0, a1)
+
+
+def test_training_through_tfcompute_from_the_list_walks_the_tensor_sweeps_weights(htf, cuda, monkeypatch):
+    """examples/06's LJLayer trained by force matching at every MD step: the replayed training step from the index list (default)
+    against the same with HTF_TRAIN_FROM_TENSOR=1 (pair vectors written, then swept): same weights after 40 steps to fp32
+    rounding of the sums, and get_nlist_array() still returns the step's tensor (built on demand)."""
+    from hoomd_tf_amd import standin
+    import build_examples
+
+    def run(from_tensor):
+        monkeypatch.setenv("HTF_TRAIN_FROM_TENSOR", "1" if from_tensor else "0")
+        pos, L, a = standin.fcc_positions(6, 0.8442)
+        rng = np.random.default_rng(2)
+        pos = pos + 0.03 * a * rng.standard_normal(pos.shape)
+        pos -= np.round(pos / L) * L
+        sysm = standin.System(pos, L, dtype=torch.float32, device=cuda)
+        sysm.randomize_velocities(kT=0.5, seed=2)
+        sim = standin.Simulation(sysm)
+        sim.integrate_nve(0.002)
+        nlist = sim.nlist_cell(check_period=1)
+        lj = htf.tfcompute(build_examples.LJModel(96))
+        lj.attach(nlist, r_cut=2.5)
+        model = build_examples.TrainableGraph(96, output_forces=False, sig=0.8, eps=1.05)
+        model.compile(htf.optimizers.Adam(0.01), loss='MeanSquaredError')
+        tfc = htf.tfcompute(model)
+        tfc.attach(nlist, train=True, r_cut=2.5)
+        tfc.set_reference_forces(lj)
+        sim.run(40)
+        torch.cuda.synchronize()
+        return tfc, model.lj.w.detach().cpu().numpy().copy(), float(tfc._opt_state[20])
+
+    tfc, w1, l1 = run(False)
+    assert tfc._tplan is not None and tfc._tplan["from_list"]
+    nl_arr = tfc.get_nlist_array()
+    assert nl_arr.shape == (tfc.system.N, 96, 4) and np.abs(nl_arr).max() > 0
+    tfc0, w0, l0 = run(True)
+    assert tfc0._tplan is not None and not tfc0._tplan["from_list"]
+    assert np.abs(w1 - w0).max() < 2e-5 and abs(l1 - l0) < 1e-4 * abs(l0)
