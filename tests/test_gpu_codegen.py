@@ -607,3 +607,56 @@ def test_row_terms_of_two_sums_are_replayed_as_step_plus_evaluations(htf, cuda, 
     assert float((p1[:, :3] - p0[:, :3]).abs().max()) < 2e-4
     assert float((f1[:, :3] - f0[:, :3]).abs().max()) < 2e-3 * scale
     assert abs(float(f1[:, 3].double().sum()) - float(f0[:, 3].double().sum())) < 1e-4 * abs(float(f0[:, 3].double().sum())) + 1e-3
+
+
+def test_random_row_functions_on_the_device(htf, cuda):
+    """Eight random row functions -- a random chain of the tracer's unary ops, powers and arithmetic applied to the row sum of a
+    random pair expression -- through compute_nlist_forces on generated units, against torch-fp64 autograd of the same traced
+    expression (forces and energies at the evaluator tolerance)."""
+    from test_gpu_parity import CONTACTS, assert_forces_close
+    rng = np.random.default_rng(99)
+    nl, _ = random_nlist(rng, 200, 64, fill=0.7, rmin=0.85, rmax=3.0, dtype=np.float32)
+    nl64 = nl.astype(np.float64)
+
+    def make(x, seed):
+        g = np.random.default_rng(seed)
+        s, r = htf.nlist_rinv(x), htf.safe_norm(x[:, :, :3], axis=2)
+        pair = [lambda: s ** 6, lambda: htf.exp(-1.3 * r) * s * s, lambda: htf.sigmoid(4.0 * (1.6 - r)) * htf.cast(s > 0.0, torch.float32),
+                lambda: 0.5 * (s ** 12 - s ** 6), lambda: htf.tanh(s) * s][g.integers(0, 5)]()
+        rho = htf.reduce_sum(pair, axis=1)
+        a, b, c = (float(v) for v in g.uniform(0.3, 1.5, 3))
+        f = [lambda: a * htf.sqrt(rho * rho + b), lambda: htf.log(1.0 + rho * rho) * a - b * rho, lambda: a * htf.tanh(b * rho) + c * rho ** 2,
+             lambda: htf.exp(-a * htf.square(rho - b)) + c, lambda: a * rho / (1.0 + b * rho * rho), lambda: htf.softplus(a * rho - b) - c * rho,
+             lambda: a * htf.sin(b * rho) + c * htf.cos(rho) + rho, lambda: htf.sigmoid(a * rho) * rho ** 3 * c][g.integers(0, 8)]()
+        return f
+    done = 0
+    for seed in range(12):
+        e64 = make(htf.Nlist(torch.from_numpy(nl64)), seed)
+        x = htf.Nlist(torch.from_numpy(nl).to(cuda))
+        e = make(x, seed)
+        groups = e.groups()
+        if groups is None or not all(t.lowers() for t in groups):
+            continue
+        ref, g = _row_ref(htf, e64, nl64)
+        if not np.all(np.isfinite(ref)):
+            continue
+        f = htf.compute_nlist_forces(x, e)
+        # condition scale: sum_j |f_ij| as for a pair energy, plus what a ROW FUNCTION adds -- the fp32 rounding of rho itself
+        # (eps sum_j |e_ij|) reaches the force through the curvature: |F''(rho)| x sum_j |e_ij| x sum_j |2 dg_ij|
+        cond = np.abs(2 * g[:, :, :3]).sum(axis=(1, 2))
+        from hoomd_tf_amd import codegen as cg
+        xx = htf.Nlist(torch.from_numpy(nl64))
+        for t in e64.groups():
+            pv = t.torch_value(xx.ad)
+            (gp,) = torch.autograd.grad(pv.sum(), xx.ad, retain_graph=True)
+            rho = pv.sum(dim=1).detach().requires_grad_(True)
+            fv = cg.evaluate(t.row, rho, None, None, rows=[rho])
+            (d1,) = torch.autograd.grad((fv if fv.dim() else fv.expand(len(nl))).sum(), rho, create_graph=True, allow_unused=True)
+            d2 = torch.zeros_like(rho) if d1 is None or not d1.requires_grad else torch.autograd.grad(d1.sum(), rho, allow_unused=True)[0]
+            d2 = torch.zeros_like(rho) if d2 is None else d2
+            cond = cond + (d2.abs() * pv.detach().abs().sum(dim=1)).numpy() * np.abs(2 * gp.numpy()[:, :, :3]).sum(axis=(1, 2))
+        assert_forces_close("rowfn_random_%d" % seed, f.cpu().numpy(), ref, cond, cancelling_rows=CONTACTS)
+        done += 1
+        if done == 8:
+            break
+    assert done >= 6
