@@ -40,6 +40,7 @@ constexpr int kMapN = kMapW + kMapT + 1;
 struct MlpDevice {
     float *images = nullptr;      // Img<>::Floats floats, operand order
     int *map = nullptr;           // kMapN ints
+    float *eval_images = nullptr; // split16 + tanh: the EVALUATOR's images in u-form (pair_mlp.hip kUForm); == images otherwise
     float *train_images = nullptr; // fp32 operand images for the training sweep (== images unless bf16)
     int *train_map = nullptr;
     const float *theta = nullptr; // device parameter vector the images are built from

@@ -57,9 +57,27 @@ __device__ __forceinline__ f32x2 pk_rcp(f32x2 x) { return f32x2{__builtin_amdgcn
 
 // tanh(z) = 1 - 2 / (1 + exp(2z)) on a whole accumulator tile: v_mul (2 log2(e) folded into one
 // constant), v_exp_f32, v_add, v_rcp_f32, v_fma per element
-template <bool TANH, bool PK>
+// U (round 6, VERDICT r5 item 5 lever (ii); MEASURED AND NOT SHIPPED -- compiled with -DHTF_MLP_UFORM=1 only:
+// tools/build_obj_variant.sh uform pair_mlp "-DHTF_MLP_UFORM=1"): the split16 tile keeps u = 1 / (1 + exp(2z)) instead of
+// tanh(z) = 1 - 2u -- the fma is gone (16 of a block's vector instructions, 64 of a tile's ~790).  What consumes a tanh output is
+// linear in it, so the images absorb the rest (mlp_refresh_kernel<P, true>): W t + b = (b + sum_k W_k) - 2 W u for the next layer's
+// block and bias table and for the output layer's w3 and b3; backward, 1 - t^2 = 4 u (1 - u) costs the same two instructions as
+// before, its constants folded into the backward blocks (B2 x -2 with w3 x -2, B1 x 4).  Same box, C3, 100 steps, twice each:
+// evaluator 953-955 us against 979-982 (-2.7 %; tools/mlp_mix_probe.hip's slope said -5), 977-979 against 949-955 MD steps/s --
+// and b + sum W - 2 W u CANCELS where W t does not: the energy column's error doubles (eps sum|w3| instead of eps sum|w3 t|) and
+// test_pair_mlp_split_operands[split16-128-tanh] exceeds its strict bound 1.16 x.  Parity is the first gate: off.
+#ifndef HTF_MLP_UFORM
+#define HTF_MLP_UFORM 0
+#endif
+template <bool TANH, int P> struct UForm { static constexpr bool value = HTF_MLP_UFORM && TANH && P == HTF_MLP_SPLIT16; };
+
+template <bool TANH, bool PK, bool U = false>
 __device__ __forceinline__ void act_tile(f32x16 &a) {
-    if constexpr (TANH && PK) {
+    if constexpr (U) {
+        static_assert(TANH && !PK, "u-form: the split16 tanh evaluator");
+#pragma unroll
+        for (int v = 0; v < 16; ++v) a[v] = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(a[v]) + 1.0f);
+    } else if constexpr (TANH && PK) {
 #pragma unroll
         for (int v = 0; v < 16; v += 2) {
             const f32x2 e = pk_exp2(f32x2{a[v], a[v + 1]} * 2.8853900817779268f);
@@ -82,9 +100,16 @@ __device__ __forceinline__ void act_tile(f32x16 &a) {
 }
 
 // d <- g * act'(z) given h = act(z):  g * (1 - h^2)
-template <bool TANH, bool PK>
+template <bool TANH, bool PK, bool U = false>
 __device__ __forceinline__ void act_bwd_tile(f32x16 &h_inout, const f32x16 &g) {
-    if constexpr (TANH && PK) {
+    if constexpr (U) { // g u (1 - u): a quarter of g (1 - t^2); the 4 lives in the next backward block's image
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const float u = h_inout[v];
+            h_inout[v] = g[v] * fmaf(-u, u, u);
+            asm("" : "+v"(h_inout[v])); // (as below: keeps the multiply out of the fp16 conversion)
+        }
+    } else if constexpr (TANH && PK) {
 #pragma unroll
         for (int v = 0; v < 16; v += 2) {
             const f32x2 hv = {h_inout[v], h_inout[v + 1]};
@@ -269,6 +294,7 @@ __global__ __launch_bounds__(64 * MlpLaunch<P>::kWaves, MlpLaunch<P>::kPerSimd) 
                                                           void *__restrict__ virial9) {
     using I = Img<P>;
     constexpr bool PK = P == HTF_MLP_FP32; // packed VALU arithmetic where nothing overlaps with the MFMAs anyway
+    constexpr bool kU = UForm<TANH, P>::value; // activations travel as u = 1 / (1 + exp(2z)); `images` are then the u-form set
     __shared__ __attribute__((aligned(16))) float lds[I::Floats];
     {
         const float4 *src = reinterpret_cast<const float4 *>(images);
@@ -558,7 +584,7 @@ __global__ __launch_bounds__(64 * MlpLaunch<P>::kWaves, MlpLaunch<P>::kPerSimd) 
             if constexpr (!PK) __builtin_amdgcn_sched_barrier(0);
             a1[1] = load_tab(lds + I::TabB1, 1, h);
             mfma_blk<P>(a1[1], lds + I::L1 + I::BS, lane, phi_b);
-            act_tile<TANH, PK>(a1[0]);
+            act_tile<TANH, PK, kU>(a1[0]);
             const BOp<P> a1_b0 = prep<P>(a1[0]);
             HTF_PIPE(kM, pipe_per(kAct + kPrep, kM));
             HTF_ESTAMP(2);
@@ -567,7 +593,7 @@ __global__ __launch_bounds__(64 * MlpLaunch<P>::kWaves, MlpLaunch<P>::kPerSimd) 
             a2[1] = load_tab(lds + I::TabB2, 1, h);
             mfma_blk<P>(a2[0], lds + I::L2 + (0 * 2 + 0) * I::BS, lane, a1_b0);
             mfma_blk<P>(a2[1], lds + I::L2 + (1 * 2 + 0) * I::BS, lane, a1_b0);
-            act_tile<TANH, PK>(a1[1]);
+            act_tile<TANH, PK, kU>(a1[1]);
             const BOp<P> a1_b1 = prep<P>(a1[1]);
             HTF_PIPE(2 * kM, pipe_per(kAct + kPrep, 2 * kM));
             HTF_ESTAMP(3);
@@ -575,11 +601,11 @@ __global__ __launch_bounds__(64 * MlpLaunch<P>::kWaves, MlpLaunch<P>::kPerSimd) 
             if constexpr (!PK) __builtin_amdgcn_sched_barrier(0);
             // ---- layer 3 (dot with w3) and dz2 = w3 * act'(z2), in place, block 0 under the last L2 block
             mfma_blk<P>(a2[1], lds + I::L2 + (1 * 2 + 1) * I::BS, lane, a1_b1);
-            act_tile<TANH, PK>(a2[0]);
+            act_tile<TANH, PK, kU>(a2[0]);
             {
                 const f32x16 w3 = load_tab(lds + I::TabW3, 0, h);
                 dot_tile<PK>(up2, a2[0], w3);
-                act_bwd_tile<TANH, PK>(a2[0], w3);
+                act_bwd_tile<TANH, PK, kU>(a2[0], w3);
             }
             const BOp<P> dz2_b0 = prep<P>(a2[0]);
             HTF_PIPE(kM, pipe_per(kAct + kDot + kBwd + kPrep, kM));
@@ -592,11 +618,11 @@ __global__ __launch_bounds__(64 * MlpLaunch<P>::kWaves, MlpLaunch<P>::kPerSimd) 
                 for (int v = 0; v < 16; ++v) d1[fb][v] = 0.f;
             mfma_blk<P>(d1[0], lds + I::B2 + (0 * 2 + 0) * I::BS, lane, dz2_b0);
             mfma_blk<P>(d1[1], lds + I::B2 + (1 * 2 + 0) * I::BS, lane, dz2_b0);
-            act_tile<TANH, PK>(a2[1]);
+            act_tile<TANH, PK, kU>(a2[1]);
             {
                 const f32x16 w3 = load_tab(lds + I::TabW3, 1, h);
                 dot_tile<PK>(up2, a2[1], w3);
-                act_bwd_tile<TANH, PK>(a2[1], w3);
+                act_bwd_tile<TANH, PK, kU>(a2[1], w3);
             }
             const BOp<P> dz2_b1 = prep<P>(a2[1]);
             HTF_PIPE(2 * kM, pipe_per(kAct + kDot + kBwd + kPrep, 2 * kM));
@@ -604,7 +630,7 @@ __global__ __launch_bounds__(64 * MlpLaunch<P>::kWaves, MlpLaunch<P>::kPerSimd) 
             mfma_blk<P>(d1[0], lds + I::B2 + (0 * 2 + 1) * I::BS, lane, dz2_b1);
             if constexpr (!PK) __builtin_amdgcn_sched_barrier(0);
             mfma_blk<P>(d1[1], lds + I::B2 + (1 * 2 + 1) * I::BS, lane, dz2_b1);
-            act_bwd_tile<TANH, PK>(a1[0], d1[0]);
+            act_bwd_tile<TANH, PK, kU>(a1[0], d1[0]);
             const BOp<P> dz1_b0 = prep<P>(a1[0]);
             HTF_PIPE(kM, pipe_per(kBwd + kPrep, kM));
             HTF_ESTAMP(6);
@@ -612,7 +638,7 @@ __global__ __launch_bounds__(64 * MlpLaunch<P>::kWaves, MlpLaunch<P>::kPerSimd) 
 #pragma unroll
             for (int v = 0; v < 16; ++v) dphi[v] = 0.f;
             mfma_blk<P>(dphi, lds + I::B1, lane, dz1_b0);
-            act_bwd_tile<TANH, PK>(a1[1], d1[1]);
+            act_bwd_tile<TANH, PK, kU>(a1[1], d1[1]);
             const BOp<P> dz1_b1 = prep<P>(a1[1]);
             HTF_PIPE(kM, pipe_per(kBwd + kPrep, kM));
             mfma_blk<P>(dphi, lds + I::B1 + I::BS, lane, dz1_b1);
@@ -739,15 +765,36 @@ static void build_map(const MlpDevice *m, std::vector<int> &map) {
 // fwd_scale: factor on the FORWARD operand blocks (L1, L2: the first six) and on the two bias tables --
 // 2 log2(e) for a tanh network evaluated from bf16-typed images (see act_tile), 1 otherwise.  The
 // backward blocks (B2, B1), w3 and b3 are never scaled.
-template <int P>
+// U: the u-form image set of the split16 tanh evaluator (act_tile): L2 x -2, bias table 2 <- b2 + column sums of W2, w3 x -2,
+// b3 <- b3 + sum of w3, B2 x -2, B1 x 4 (L1 and bias table 1 as they are).
+template <int P, bool U = false>
 __global__ void mlp_refresh_kernel(float *__restrict__ images, const int *__restrict__ map,
-                                   const float *__restrict__ theta, float fwd_scale, int *__restrict__ range_flag) {
+                                   const float *__restrict__ theta, float fwd_scale, int *__restrict__ range_flag, MlpDims dm = MlpDims{}) {
     using I = Img<P>;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= kMapN) return;
     const int idx = map[e];
     const bool fwd = e < 6 * 1024 || (e >= kMapW && e < kMapW + 128);
-    const float v = (idx >= 0 ? theta[idx] : 0.f) * (fwd ? fwd_scale : 1.0f);
+    float v = (idx >= 0 ? theta[idx] : 0.f) * (fwd ? fwd_scale : 1.0f);
+    if constexpr (U) {
+        const int blk = e >> 10;
+        if (e < kMapW) {
+            v *= blk < 2 ? 1.0f : (blk < 10 ? -2.0f : 4.0f);
+        } else if (e >= kMapW + 64 && e < kMapW + 128) {
+            if (idx >= 0) {
+                const int f = idx - dm.oB2;
+                float sum = 0.f;
+                for (int a = 0; a < dm.H1; ++a) sum += theta[dm.oW2 + a * dm.H2 + f];
+                v += fwd_scale * sum;
+            }
+        } else if (e >= kMapW + 128 && e < kMapW + 192) {
+            v *= -2.0f;
+        } else if (e >= kMapW + kMapT) {
+            float sum = 0.f;
+            for (int f = 0; f < dm.H2; ++f) sum += theta[dm.oW3 + f];
+            v += sum;
+        }
+    }
     if (e < kMapW) {
         if constexpr (P == HTF_MLP_BF16) { // round to nearest even (finite weights)
             const unsigned u = __float_as_uint(v);
@@ -790,18 +837,23 @@ int mlp_refresh(const MlpDevice *m, hipStream_t stream) {
     const unsigned grid = (kMapN + 255) / 256;
     const float fwd_scale = m->act == HTF_ACT_TANH ? 2.8853900817779268f : 1.0f; // bf16-typed images only
     if (m->precision == HTF_MLP_BF16)
-        hipLaunchKernelGGL(mlp_refresh_kernel<HTF_MLP_BF16>, dim3(grid), dim3(256), 0, stream, m->images, m->map, m->theta, fwd_scale, (int *)nullptr);
+        hipLaunchKernelGGL(mlp_refresh_kernel<HTF_MLP_BF16>, dim3(grid), dim3(256), 0, stream, m->images, m->map, m->theta, fwd_scale, (int *)nullptr, MlpDims{});
     else if (m->precision == HTF_MLP_SPLIT)
-        hipLaunchKernelGGL(mlp_refresh_kernel<HTF_MLP_SPLIT>, dim3(grid), dim3(256), 0, stream, m->images, m->map, m->theta, fwd_scale, (int *)nullptr);
+        hipLaunchKernelGGL(mlp_refresh_kernel<HTF_MLP_SPLIT>, dim3(grid), dim3(256), 0, stream, m->images, m->map, m->theta, fwd_scale, (int *)nullptr, MlpDims{});
     else if (m->precision == HTF_MLP_SPLIT16) {
         // every image build judges the range afresh (the word used to be sticky -- one bad weight, and every later call
         // failed even after the caller had repaired theta and refreshed): cleared in stream order ahead of the build that may set it
         if (m->range_flag != nullptr) hipLaunchKernelGGL(mlp_flag_clear_kernel, dim3(1), dim3(1), 0, stream, m->range_flag);
-        hipLaunchKernelGGL(mlp_refresh_kernel<HTF_MLP_SPLIT16>, dim3(grid), dim3(256), 0, stream, m->images, m->map, m->theta, fwd_scale, m->range_flag);
+        hipLaunchKernelGGL(mlp_refresh_kernel<HTF_MLP_SPLIT16>, dim3(grid), dim3(256), 0, stream, m->images, m->map, m->theta, fwd_scale, m->range_flag, MlpDims{});
+        if (m->eval_images != m->images) { // the evaluator's u-form set (tanh): see act_tile
+            const MlpDims dm{m->K, m->H1, m->H2, m->off_b1(), m->off_W2(), m->off_b2(), m->off_W3(), m->off_b3()};
+            hipLaunchKernelGGL((mlp_refresh_kernel<HTF_MLP_SPLIT16, true>), dim3(grid), dim3(256), 0, stream, m->eval_images, m->map, m->theta, fwd_scale,
+                               m->range_flag, dm);
+        }
     } else
-        hipLaunchKernelGGL(mlp_refresh_kernel<HTF_MLP_FP32>, dim3(grid), dim3(256), 0, stream, m->images, m->map, m->theta, 1.0f, (int *)nullptr);
+        hipLaunchKernelGGL(mlp_refresh_kernel<HTF_MLP_FP32>, dim3(grid), dim3(256), 0, stream, m->images, m->map, m->theta, 1.0f, (int *)nullptr, MlpDims{});
     if (m->train_images != m->images) // bf16 / split evaluator images: the training sweep reads its own fp32 set
-        hipLaunchKernelGGL(mlp_refresh_kernel<HTF_MLP_FP32>, dim3(grid), dim3(256), 0, stream, m->train_images, m->train_map, m->theta, 1.0f, (int *)nullptr);
+        hipLaunchKernelGGL(mlp_refresh_kernel<HTF_MLP_FP32>, dim3(grid), dim3(256), 0, stream, m->train_images, m->train_map, m->theta, 1.0f, (int *)nullptr, MlpDims{});
     return check_launch("mlp_refresh_kernel");
 }
 
@@ -857,6 +909,12 @@ int mlp_create(const htf_potential_desc *d, MlpDevice **out) {
     if (e == hipSuccess) e = hipMemcpy(m->map, map.data(), map.size() * sizeof(int), hipMemcpyHostToDevice);
     m->train_images = m->images;
     m->train_map = m->map;
+    m->eval_images = m->images;
+    if (e == hipSuccess && split16 && m->act == HTF_ACT_TANH && HTF_MLP_UFORM) {
+        m->eval_images = nullptr;
+        e = hipMalloc((void **)&m->eval_images, img.size() * sizeof(float));
+        if (e == hipSuccess) e = hipMemcpy(m->eval_images, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice); // (the RBF centres)
+    }
     if (e == hipSuccess && bf16) {
         std::vector<float> img32(Img<false>::Floats, 0.f);
         for (int hh = 0; hh < 2; ++hh)
@@ -912,6 +970,7 @@ int mlp_create(const htf_potential_desc *d, MlpDevice **out) {
 
 void mlp_destroy(MlpDevice *m) {
     if (!m) return;
+    if (m->eval_images && m->eval_images != m->images) (void)hipFree(m->eval_images);
     if (m->train_images && m->train_images != m->images) (void)hipFree(m->train_images);
     if (m->train_map && m->train_map != m->map) (void)hipFree(m->train_map);
     if (m->images) (void)hipFree(m->images);
@@ -931,7 +990,7 @@ static int launch_mlp(const MlpDevice *m, const void *nlist, int in_dtype, unsig
     if (grid > need) grid = need;
 #define HTF_MLP_LAUNCH(T, V4, VIR)                                                                                     \
     hipLaunchKernelGGL((pair_mlp_kernel<TANH, T, P, VIR>), dim3(grid), dim3(64 * kW), 0, s, (const V4 *)nlist, B, NN, force, \
-                       out_f64, m->images, m->gap, virial9)
+                       out_f64, m->eval_images, m->gap, virial9)
     if (in_dtype == HTF_F32) {
         if (virial9) HTF_MLP_LAUNCH(float, float4, true); else HTF_MLP_LAUNCH(float, float4, false);
     } else {
