@@ -24,6 +24,15 @@ timeout 900 python bench.py --workload mlp-train --steps 400 --warmup 20 --no-cp
 timeout 900 python bench.py --workload eds 2>/dev/null | jl > $F/bench_eds.json
 timeout 900 python bench.py --workload eds --f64 --no-cpu-baseline 2>/dev/null | jl > $F/bench_eds_f64.json          # C4 under a HOOMD DOUBLE build
 timeout 900 python bench.py --workload generic-lj 2>/dev/null | jl > $F/bench_generic_lj.json          # what leaving the lowered model zoo costs (torch ops + autograd)
+HTF_JIT_TAILS=0 timeout 900 python bench.py --workload generic-lj 2>/dev/null | jl > $F/bench_generic_lj_tails0.json          # ... the generated step in its two-row form at every size
+HTF_TRAIN_FROM_TENSOR=1 timeout 900 python bench.py --workload generic-lj 2>/dev/null | jl > $F/bench_generic_lj_train_from_tensor.json          # ... the training plan with the tensor written and swept
+timeout 120 tools/mlp_mix_probe > $F/mlp_mix_probe.txt 2>&1
+# the pair-MLP evaluator's u-form (lever (ii)) against the shipped t-form, same box, twice each (the variant is built by __graft_entry__.build() when it can)
+if [ -s build_variants/libhtf_uform.so ]; then for i in 1 2; do for lib in "" build_variants/libhtf_uform.so; do
+  HTF_AMD_LIB=$lib HTF_BINDING=ctypes timeout 300 python bench.py --workload mlp --steps 100 --warmup 10 --no-cpu-baseline 2>/dev/null | jl | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('lib=%s' % ('$lib' or 'shipped (t-form)'), 'steps/s %.1f' % d['value'], 'evaluator us %.1f' % d['kernels']['eval_forces']['avg_us'])"
+done; done > $F/mlp_uform_ab.txt; fi
 for c in 16 20 25; do          # the per-rank row counts of the 131k box cut 8 / 4 / 2 ways: inputs of DESIGN 6's predicted scaling table
   timeout 300 python bench.py --cells $c --steps 200 --warmup 20 --no-mlp --no-cpu-baseline --no-fused 2>/dev/null | jl > $F/bench_lj_cells$c.json
 done
