@@ -855,6 +855,21 @@ class RowExpr(_TorchOperand):
         raise TypeError("cannot trace %r as a per-particle expression" % (type(x),))
 
     _TORCH = {"add": torch.add, "sub": torch.sub, "mul": torch.mul, "div": torch.div}
+    _BINARY = {"mul": "mul", "__mul__": "mul", "multiply": "mul", "add": "add", "__add__": "add", "sub": "sub", "__sub__": "sub",
+               "subtract": "sub", "div": "div", "__truediv__": "div", "true_divide": "div", "divide": "div"}
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        # ``weight * row_expr`` reaches torch first (Tensor.__mul__): arithmetic with a one-element tensor -- a weight, a scalar
+        # computed from weights -- stays symbolic; everything else sees the expression's torch value, like the other operands
+        op = cls._BINARY.get(getattr(func, "__name__", ""))
+        if op is not None and len(args) == 2 and not kwargs:
+            a, b = args
+            if isinstance(a, RowExpr):
+                return a._with(op, b)
+            if isinstance(b, RowExpr):
+                return b._with(op, a, swap=True)
+        return func(*_unwrap(args), **{k: _unwrap(v) for k, v in (kwargs or {}).items()})
 
     def _with(self, op, other=None, swap=False, value=None):
         from . import codegen as cg

@@ -660,3 +660,74 @@ def test_random_row_functions_on_the_device(htf, cuda):
         if done == 8:
             break
     assert done >= 6
+
+
+def test_row_function_with_weights_follows_them_and_trains_on_the_torch_route(htf, cuda, monkeypatch):
+    """An embedded-atom term whose prefactor and exponent are torch Parameters: in inference they are kernel arguments of the
+    generated unit (pair body AND row function read p.theta) -- writing one changes the forces without a new kernel, equal to the
+    torch route's; with train=True the model takes the autograd route (a row-function unit carries no training sweep) and its
+    weights move."""
+    from hoomd_tf_amd import _lib, standin
+
+    class EAM(htf.SimModel):
+        def setup(self):
+            self.amp = torch.nn.Parameter(torch.tensor(1.3, device="cuda"))
+            self.decay = torch.nn.Parameter(torch.tensor(1.7, device="cuda"))
+
+        def compute(self, nlist, positions, box):
+            s = htf.nlist_rinv(nlist)
+            r = htf.safe_norm(nlist[:, :, :3], axis=2)
+            rho = htf.reduce_sum(htf.exp(-1.0 * self.decay * r) * s * s, axis=1)
+            return htf.compute_nlist_forces(nlist, -1.0 * self.amp * htf.sqrt(rho + 0.01)), self.amp
+
+    def system():
+        pos, L, a = standin.fcc_positions(6, 0.8442)
+        rng = np.random.default_rng(2)
+        pos = pos + 0.03 * a * rng.standard_normal(pos.shape)
+        pos -= np.round(pos / L) * L
+        sysm = standin.System(pos, L, dtype=torch.float32, device=cuda)
+        sim = standin.Simulation(sysm)
+        sim.integrate_nve(0.0)          # (frozen positions: the forces of both routes are of the same configuration)
+        return sysm, sim
+
+    def forces(jit, amps):
+        monkeypatch.setenv("HTF_NO_JIT", "0" if jit else "1")
+        sysm, sim = system()
+        model = EAM(96)
+        tfc = htf.tfcompute(model)
+        tfc.attach(sim.nlist_cell(r_buff=0.4, check_period=1), r_cut=2.5)
+        out = []
+        for a_ in amps:
+            with torch.no_grad():
+                model.amp.fill_(a_)
+            sim.run(3, graph=False)
+            torch.cuda.synchronize()
+            out.append((tfc._plan, tfc.force.clone()))
+        return out
+
+    got, ref = forces(True, [1.3, 2.6]), forces(False, [1.3, 2.6])
+    assert got[0][0] is not None and got[0][0] is got[1][0] and got[0][0].kind == _lib.POT_JIT and "//@row" in got[0][0].body
+    assert "p.theta[" in got[0][0].body.partition("//@row")[2]                      # the row function reads a weight
+    for (_, f), (p0, f0) in zip(got, ref):
+        assert p0 is None
+        assert float((f - f0).abs().max()) < 2e-5 * float(f0.abs().max())
+    assert abs(float(got[1][1][:, 3].sum() / got[0][1][:, 3].sum()) - 2.0) < 1e-4   # twice the amplitude: twice the energy
+
+    # training: labels = the same model's forces at amp 2.0; starting from 1.3 the amplitude must move toward it
+    monkeypatch.setenv("HTF_NO_JIT", "0")
+    sysm, sim = system()
+    teacher = EAM(96)
+    with torch.no_grad():
+        teacher.amp.fill_(2.0)
+    t = htf.tfcompute(teacher)
+    nlist = sim.nlist_cell(r_buff=0.4, check_period=1)
+    t.attach(nlist, r_cut=2.5)
+    student = EAM(96, output_forces=False)
+    student.compile(htf.optimizers.Adam(0.05), loss='MeanSquaredError')
+    st = htf.tfcompute(student)
+    st.attach(nlist, train=True, r_cut=2.5)
+    st.set_reference_forces(t)
+    sim.run(20, graph=False)
+    torch.cuda.synchronize()
+    assert st._tplan is None                                                       # no kernel plan: the autograd route trains it
+    assert 1.5 < float(student.amp.detach()) < 2.3, float(student.amp.detach())
