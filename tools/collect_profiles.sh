@@ -27,6 +27,6 @@ cp $F/pmc_mlp.json profiles/${R}_bench_mlp_pmc.json
 for n in valu_cost_probe mlp_mix_probe mlp_uform_ab train_size_probe_outlier train_probe; do [ -s $F/$n.txt ] && cp $F/$n.txt profiles/${R}_$n.txt; done
 cp gpurun_out/parity_stats.json profiles/${R}_parity_stats.json
 [ -s $F/train_sweep_pmc.txt ] && grep -v "^stats\|amdgpu.ids" $F/train_sweep_pmc.txt > profiles/${R}_train_sweep_pmc.txt
-for n in soak_nve soak_nve_f64; do [ -s $F/$n.json ] && cp $F/$n.json profiles/${R}_$n.json; done
+for n in soak_nve soak_nve_f64 soak_brick_8x1x1_local soak_brick_8x1x1_peer soak_brick_8x1x1_native soak_brick_4x2x1_local soak_brick_4x2x1_peer; do [ -s $F/$n.json ] && cp $F/$n.json profiles/${R}_$n.json; done
 for n in pytest_gpu pytest_gpu_ctypes smoke; do [ -s $F/$n.log ] && cp $F/$n.log profiles/${R}_$n.log; done
 tail -2 $F/pytest_gpu.log; tail -1 $F/smoke.log

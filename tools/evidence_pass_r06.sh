@@ -61,6 +61,10 @@ for o in 0 1e5 1e7 1e8; do python tools/train_size_probe.py 64 200 $o 2>&1 | gre
 python tools/train_probe.py 2>&1 | grep -v amdgpu > $F/train_probe.txt
 timeout 300 python tools/soak_nve.py --steps 20000 > $F/soak_nve.json 2>/dev/null          # 20 000 NVE steps at the headline size: energy drift, momentum accounting
 timeout 300 python tools/soak_nve.py --steps 20000 --f64 > $F/soak_nve_f64.json 2>/dev/null
+# 20 000 steps of the REPLAYED decomposed step as round 6 runs it (integrator + halo pack in the force kernel; `peer`: halo, migration and
+# all-reduce without a library): energy, particle count, flags
+for t in local peer native; do timeout 300 python tools/soak_brick.py --grid 8x1x1 --transport $t --replan-every 2 2>/dev/null | sed -n '/^{/,/^}/p' > $F/soak_brick_8x1x1_$t.json; done
+for t in local peer; do timeout 300 python tools/soak_brick.py --grid 4x2x1 --transport $t --replan-every 2 2>/dev/null | sed -n '/^{/,/^}/p' > $F/soak_brick_4x2x1_$t.json; done
 # round 5: one rank's decomposed step at the 8-rank geometries (replica mode), eager and replayed, local delivery and RCCL
 timeout 300 python bench.py --workload dd-self --grid 8x1x1 --steps 100 --warmup 20 2>/dev/null | jl > $F/bench_dd_self_8x1x1.json
 timeout 300 python bench.py --workload dd-self --grid 4x2x1 --steps 100 --warmup 20 2>/dev/null | jl > $F/bench_dd_self_4x2x1.json
