@@ -419,8 +419,7 @@ def run_md(args, E, workload, variants=True, cpu=True, keep_live=True):
                     "build_eval_forces": ("fused_forces_tails_kernel<1, true", "fused_forces_rows2_kernel<1, true")}[dom]
             keys = [k for w in want for k in pmc["FETCH_SIZE"] if w in k and k in pmc["WRITE_SIZE"]]
             # (round 6: the launch that carries the integrator as its epilogue is its own instantiation, "..., float, 1>")
-            keys.sort(key=lambda k: (k.rstrip().endswith(", 1>") != bool(state.get("fused_step")), keys.index(k)))
-            key = keys[0]
+            key = sorted(enumerate(keys), key=lambda ik: (ik[1].rstrip().endswith(", 1>") != bool(state.get("fused_step")), ik[0]))[0][1]
             rd, wr = pmc["FETCH_SIZE"][key]["avg_KiB"], pmc["WRITE_SIZE"][key]["avg_KiB"]
             # gfx950: every fabric-side read request of the L2 is 128 B (TCC_EA0_RDREQ_32B = TCC_BUBBLE = 0) and FETCH_SIZE
             # tallies it at 64 B.  Calibrated on known byte counts in THIS kernel's access patterns (tools/fetch_calib.hip,
