@@ -23,8 +23,18 @@ class RBFExpansion:
         return {'low': self.low, 'high': self.high, 'count': self.count}
 
     def __call__(self, inputs):
-        if isinstance(inputs, simmodel.SafeNorm):
-            inputs = inputs.tensor()
+        if isinstance(inputs, simmodel.SafeNorm) or (isinstance(inputs, torch.Tensor) and inputs.requires_grad):
+            # the distances of compute()'s neighbor tensor (or anything else on an autograd graph): the expansion in torch ops, so
+            # that whatever the model builds from it -- a descriptor summed over the neighbors and fed to Dense layers, a per-pair
+            # network written by hand -- is differentiable by compute_nlist_forces (the reference's layer is a TF op like any
+            # other: layers.py:36-49).  [.., count] floats: the generic route, not a fused kernel (htf.PairMLP is that).
+            if isinstance(inputs, simmodel.SafeNorm):
+                t = inputs.nlist.ad[:, :, :3] + inputs.delta
+                inputs = torch.sqrt((t * t).sum(dim=2))
+            simmodel._trace_log().append({"op": "rbf"})
+            c = torch.as_tensor(self.centers, dtype=inputs.dtype, device=inputs.device)
+            d = inputs[..., None] - c
+            return torch.exp(-(d * d) / float(self.gap))
         x = inputs.to(torch.float32).contiguous()
         ops._dev(x, "inputs")
         simmodel._trace_log().append({"op": "rbf"})

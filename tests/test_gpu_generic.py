@@ -223,3 +223,46 @@ def test_tensor_save(htf, cuda):
     sim.run(8)
     array = tfc.outputs[0].reshape(-1, 9)
     assert array.shape == (4, 9)
+
+
+def test_descriptor_network_written_with_the_layers_runs_on_the_generic_route(htf, cuda):
+    """A Behler-Parrinello-style model as a user of the reference writes it -- RBFExpansion of the neighbor distances, summed over
+    the neighbors into a per-particle descriptor, two Dense layers -> the particle's energy, compute_nlist_forces: the layer's output
+    is differentiable (torch ops on the autograd leaf of the pair-vector tensor; until round 6 it was the fused kernel's plain
+    output and compute_nlist_forces found no dependence), forces by autograd == the same network in plain torch fp64."""
+    from helpers import random_nlist
+    rng = np.random.default_rng(21)
+    nl, _ = random_nlist(rng, 120, 32, fill=0.7, rmin=0.85, rmax=2.9, dtype=np.float32)
+
+    class BP(htf.SimModel):
+        def setup(self):
+            self.rbf = htf.RBFExpansion(0.5, 2.5, 16)
+            self.d1 = htf.Dense(24, activation="tanh", seed=1)
+            self.d2 = htf.Dense(1, seed=2)
+
+        def compute(self, nlist, positions, box):
+            r = htf.safe_norm(nlist[:, :, :3], axis=2)
+            live = (htf.nlist_rinv(nlist).tensor() > 0).to(torch.float32)
+            g = (self.rbf(r) * live[..., None]).sum(dim=1)              # [N, 16]: the descriptor
+            e = self.d2(self.d1(g))[:, 0]
+            return htf.compute_nlist_forces(nlist, e)
+
+    m = BP(32)
+    x = torch.from_numpy(nl).to(cuda)
+    out = m([htf.Nlist(x), torch.zeros((len(nl), 4), device=cuda), torch.eye(3, device=cuda)], False)
+    f = (out[0] if isinstance(out, (list, tuple)) else out).detach().double().cpu().numpy()
+    # the same network in torch fp64
+    xx = torch.from_numpy(nl.astype(np.float64)).requires_grad_(True)
+    t = xx[:, :, :3] + 1e-7
+    rr = torch.sqrt((t * t).sum(dim=2))
+    live = (rr > 3e-6).double()
+    c = torch.from_numpy(m.rbf.centers.astype(np.float64))
+    g = (torch.exp(-(rr[..., None] - c) ** 2 / float(m.rbf.gap)) * live[..., None]).sum(dim=1)
+    h = torch.tanh(g @ torch.from_numpy(m.d1.kernel.astype(np.float64)) + torch.from_numpy(m.d1.bias.astype(np.float64)))
+    e = (h @ torch.from_numpy(m.d2.kernel.astype(np.float64)) + torch.from_numpy(m.d2.bias.astype(np.float64)))[:, 0]
+    (gr,) = torch.autograd.grad(e.sum(), xx)
+    ref_f = 2.0 * gr.sum(dim=1)[:, :3].numpy()
+    scale = np.abs(ref_f).max()
+    assert scale > 1e-3
+    assert np.abs(f[:, :3] - ref_f).max() < 2e-5 * scale, np.abs(f[:, :3] - ref_f).max() / scale
+    assert np.abs(f[:, 3] - e.detach().numpy()).max() < 2e-5 * np.abs(e.detach().numpy()).max()
