@@ -625,3 +625,41 @@ def test_unit_with_a_row_function_cross_compiles():
     image, key = cg.compile_body(g.body())
     assert b"htf_jit_rows2_f32_store" in image and b"htf_jit_tails4_f32_store" in image and b"htf_jit_eval_f64_virial" in image
     assert b"htf_jit_train_f32" not in image
+
+
+def test_row_expression_arithmetic_corner_cases(monkeypatch):
+    """What a row expression does when it meets things that are not scalars: a per-particle tensor, a comparison, a torch
+    function, a total over particles -- its torch value from there on (the reference's graph is TF ops either way); scalar
+    multiples of one sum are ONE sum; a weight that comes first in a product stays symbolic."""
+    import hoomd_tf_amd as htf
+    from hoomd_tf_amd.simmodel import RowExpr
+    rng = np.random.default_rng(9)
+    nl, _ = random_nlist(rng, 12, 8, fill=0.6, rmin=0.85, rmax=2.9, dtype=np.float64)
+    x = htf.Nlist(torch.from_numpy(nl))
+    s = htf.nlist_rinv(x)
+    u = htf.reduce_sum(2.0 * (s ** 12 - s ** 6), axis=1)
+    e = u + 0.02 * u * u - (0.5 * u) ** 3 / 7.0
+    assert isinstance(e, RowExpr) and len(e.sums) == 1 and len(e.groups()) == 1            # one sum, whatever its prefactors
+    tt = torch.from_numpy(nl)[:, :, :3] + 1e-7
+    rr = torch.sqrt((tt * tt).sum(dim=2))
+    ss = torch.where(rr > 3e-6, 1.0 / (rr + 3e-6), torch.zeros_like(rr))
+    uu = (2.0 * (ss ** 12 - ss ** 6)).sum(dim=1)
+    np.testing.assert_allclose(e.torch_value(torch.from_numpy(nl)).numpy(), (uu + 0.02 * uu * uu - (0.5 * uu) ** 3 / 7.0).numpy(), rtol=1e-12)
+    per_particle = torch.arange(12, dtype=torch.float64)
+    assert isinstance(e * per_particle, torch.Tensor) and isinstance(per_particle * e, torch.Tensor)
+    np.testing.assert_allclose((per_particle * e).detach().numpy(), (per_particle * e.ad).detach().numpy())
+    assert (e > 0.0).dtype == torch.bool and isinstance(torch.exp(e), torch.Tensor) and isinstance(e ** per_particle, torch.Tensor)
+    assert htf.reduce_sum(e).dim() == 0                                                       # a total: a torch scalar
+    w = torch.nn.Parameter(torch.tensor(0.7, dtype=torch.float64))
+    assert isinstance(w * e, RowExpr) and isinstance(e / w, RowExpr) and isinstance(w - e, RowExpr)
+    np.testing.assert_allclose((w - e).ad.detach().numpy(), (0.7 - e.ad).detach().numpy(), rtol=1e-12)
+    # forces of the whole thing on the torch route (CPU: no kernels) == autograd of the torch-written energy
+    monkeypatch.setenv("HTF_NO_JIT", "1")
+    f = htf.compute_nlist_forces(x, e)
+    xx = torch.from_numpy(nl).requires_grad_(True)
+    t2 = xx[:, :, :3] + 1e-7
+    r2 = torch.sqrt((t2 * t2).sum(dim=2))
+    s2 = torch.where(r2 > 3e-6, 1.0 / (r2 + 3e-6), torch.zeros_like(r2))
+    u2 = (2.0 * (s2 ** 12 - s2 ** 6)).sum(dim=1)
+    (g,) = torch.autograd.grad((u2 + 0.02 * u2 * u2 - (0.5 * u2) ** 3 / 7.0).sum(), xx)
+    np.testing.assert_allclose(f[:, :3].detach().numpy(), 2.0 * g.sum(dim=1)[:, :3].numpy(), rtol=1e-9, atol=1e-10)
