@@ -88,10 +88,10 @@ __device__ __forceinline__ void store_row_sums(void *__restrict__ force, int out
 // (rows 0..3 of `tot`: fx, fz, fy, e), so that behind the last row there is arithmetic and stores, no trip to memory.
 template <typename PT, int R, bool HALO>
 __device__ __forceinline__ void group_epilogue_load(const StepEpilogue<PT> *ep, const typename Vec4<PT>::type *__restrict__ pos, unsigned idx0,
-                                                    unsigned lane, PT &v, PT &own, uint4 &s0, uint4 &s1) {
+                                                    unsigned lane, PT &v, PT &own, uint4 &s0, uint4 &s1, unsigned skip_rows = 0u) {
     v = own = (PT)0;
     s0 = s1 = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-    if (ep != nullptr && lane < 4u * R) {
+    if (ep != nullptr && lane < 4u * R && !((skip_rows >> (lane >> 2)) & 1u)) {
         const size_t o = (size_t)idx0 * 4 + lane; // rows idx0 .. idx0 + R - 1 are consecutive: 4 R consecutive words
         v = reinterpret_cast<const PT *>(ep->vel)[o];
         own = reinterpret_cast<const PT *>(pos)[o];
@@ -186,7 +186,9 @@ __device__ __forceinline__ void fused_row(const unsigned w, const unsigned lane,
                                           void *__restrict__ virial9, int out_f64, const PotParams &p,
                                           unsigned *__restrict__ check_count, float4 *__restrict__ positions_out,
                                           float4 *__restrict__ dest, unsigned *__restrict__ counts_io,
-                                          const StepEpilogue<PT> *ep = nullptr) {
+                                          const StepEpilogue<PT> *ep = nullptr, float *tot_out = nullptr) {
+    // (tot_out: the caller finishes the row itself -- the row-group forms run ONE epilogue for their rows, redone ones included,
+    //  so that this routine's copy of it does not set their register count)
     const unsigned idx = w + offset;
     if (idx >= N) return;
     const unsigned nn = n_neigh[idx];
@@ -216,7 +218,8 @@ __device__ __forceinline__ void fused_row(const unsigned w, const unsigned lane,
     // force does not depend on which routine computed it
     float vscale;
     const float tot = finish_row_sums<KIND>(p, wave_sum4(acc.fx, acc.fy, acc.fz, acc.en), lane, &vscale);
-    store_row_sums<PT, (EPL >= 2)>(force, out_f64, w, idx, lane, tot, pos, ep);
+    if (tot_out != nullptr) *tot_out = tot;
+    store_row_sums<PT, (EPL >= 2)>(force, out_f64, w, idx, lane, tot, pos, EPL ? ep : nullptr);
     float v6[6];
     if constexpr (VIRIAL) {
         v6[0] = group_sum<64>(acc.v.xx);
@@ -321,7 +324,7 @@ __device__ __forceinline__ void fused_rows_group(
     unsigned offset, unsigned batch, const BoxT<PT> &box, const unsigned *__restrict__ n_neigh,
     const unsigned *__restrict__ nlist, const unsigned *__restrict__ head_list, PT rmaxsq, void *__restrict__ force,
     int out_f64, const PotParams &p, unsigned *__restrict__ check_count, float4 *__restrict__ positions_out,
-    float4 *__restrict__ dest, unsigned *__restrict__ counts_io, const StepEpilogue<PT> *ep = nullptr) {
+    float4 *__restrict__ dest, unsigned *__restrict__ counts_io, const StepEpilogue<PT> *ep = nullptr, float *tot_out = nullptr) {
     using PV = typename Vec4<PT>::type;
     unsigned nn[R];
     bool fast = w0 + R <= batch;
@@ -331,16 +334,27 @@ __device__ __forceinline__ void fused_rows_group(
         fast = fast && nn[r] != 0 && nn[r] <= 64 * kFChunk;
     }
     if (!fast) {
+        float tl[R];
+#pragma unroll
+        for (int q_ = 0; q_ < R; ++q_) tl[q_] = 0.f;
 #pragma unroll 1
-        for (unsigned r = 0; r < (unsigned)R && w0 + r < batch; ++r)
+        for (unsigned r = 0; r < (unsigned)R && w0 + r < batch; ++r) {
+            float t = 0.f; // (a scalar and a select chain: an array indexed by the loop counter would live in scratch / LDS)
             fused_row<KIND, false, STORE, PT, EPL>(w0 + r, lane, pos, N, NN, offset, box, n_neigh, nlist, head_list, rmaxsq,
-                                              force, nullptr, out_f64, p, check_count, positions_out, dest, counts_io, ep);
+                                              force, nullptr, out_f64, p, check_count, positions_out, dest, counts_io, ep, &t);
+#pragma unroll
+            for (int q_ = 0; q_ < R; ++q_) tl[q_] = r == (unsigned)q_ ? t : tl[q_];
+        }
+        if (tot_out != nullptr) {
+#pragma unroll
+            for (int q_ = 0; q_ < R; ++q_) tot_out[q_] = tl[q_];
+        }
         return;
     }
     const bool simple_box = box.ortho && box.periodic[0] && box.periodic[1] && box.periodic[2];
-    PT ep_v, ep_own;
-    uint4 ep_s0, ep_s1;
-    group_epilogue_load<PT, R, (EPL >= 2)>(ep, pos, w0 + offset, lane, ep_v, ep_own, ep_s0, ep_s1);
+    PT ep_v = (PT)0, ep_own = (PT)0;
+    uint4 ep_s0 = make_uint4(0, 0, 0, 0), ep_s1 = make_uint4(0, 0, 0, 0);
+    if constexpr (EPL != 0) group_epilogue_load<PT, R, (EPL >= 2)>(ep, pos, w0 + offset, lane, ep_v, ep_own, ep_s0, ep_s1);
     float tot_r[R];
     PV pi[R];
     unsigned k[R][kFChunk];
@@ -427,14 +441,21 @@ __device__ __forceinline__ void fused_rows_group(
             if (lane == 0 && npos > *(volatile unsigned *)check_count) atomicMax(check_count, npos);
         }
     }
-    group_epilogue<PT, R, (EPL >= 2)>(ep, w0 + offset, lane, tot_r, redo, ep_v, ep_own, ep_s0, ep_s1);
+    if constexpr (EPL != 0) group_epilogue<PT, R, (EPL >= 2)>(ep, w0 + offset, lane, tot_r, redo, ep_v, ep_own, ep_s0, ep_s1);
 #pragma unroll 1
     for (unsigned r = 0; r < (unsigned)R; ++r) // ONE code copy: a row's result must not depend on its place in the group
         if ((redo >> r) & 1u) {
             if constexpr (STORE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            float t = 0.f;
             fused_row<KIND, false, STORE, PT, EPL>(w0 + r, lane, pos, N, NN, offset, box, n_neigh, nlist, head_list, rmaxsq,
-                                              force, nullptr, out_f64, p, check_count, positions_out, dest, counts_io, ep);
+                                              force, nullptr, out_f64, p, check_count, positions_out, dest, counts_io, ep, &t);
+#pragma unroll
+            for (int q_ = 0; q_ < R; ++q_) tot_r[q_] = r == (unsigned)q_ ? t : tot_r[q_];
         }
+    if (tot_out != nullptr) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) tot_out[r] = tot_r[r];
+    }
 }
 
 // Tails merged: a row of ~139 candidates is two full trips and a third with ~11 live lanes, and a gather or an
@@ -462,23 +483,38 @@ __device__ __forceinline__ void fused_rows_group_tails(
         fast = fast && nn[r] != 0 && nn[r] <= 192u;
         S[r + 1] = S[r] + (nn[r] > 128u ? nn[r] - 128u : 0u);
     }
+    // The step epilogue of the group's rows is ONE piece of code at the end of this routine (group_epilogue), whichever routine
+    // computed a row: the fallbacks below are compiled WITHOUT one (EPL = 0) and hand their row sums back.  With their own copies
+    // the kernel needed 77 (integrator) / 82 (+ halo) VGPRs against 53 -- six / five waves per SIMD instead of eight -- although
+    // its straight-line path needs no more than without an epilogue (round 6, tools: a 9-second probe unit of this kernel alone).
+    PT ep_v, ep_own;
+    uint4 ep_s0, ep_s1;
+    float tot_r[R];
     if (!fast || S[R] > 64u) { // (wave-uniform) the plain two-rows-at-a-time form handles everything else
+        unsigned absent = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            tot_r[r] = 0.f;
+            absent |= (w0 + r < batch && w0 + r + offset < N) ? 0u : (1u << r);
+        }
 #pragma unroll
         for (int r = 0; r < R; r += 2)
             if (w0 + r < batch) {
                 if (r + 1 < R)
-                    fused_rows_group<KIND, STORE, 2, PT, EPL>(w0 + r, lane, pos, N, NN, offset, batch, box, n_neigh, nlist, head_list,
-                                                         rmaxsq, force, out_f64, p, check_count, positions_out, dest, counts_io, ep);
+                    fused_rows_group<KIND, STORE, 2, PT, 0>(w0 + r, lane, pos, N, NN, offset, batch, box, n_neigh, nlist, head_list,
+                                                       rmaxsq, force, out_f64, p, check_count, positions_out, dest, counts_io, nullptr, &tot_r[r]);
                 else // (an odd group's last row: the row after it belongs to the next wave)
-                    fused_row<KIND, false, STORE, PT, EPL>(w0 + r, lane, pos, N, NN, offset, box, n_neigh, nlist, head_list, rmaxsq,
-                                                      force, nullptr, out_f64, p, check_count, positions_out, dest, counts_io, ep);
+                    fused_row<KIND, false, STORE, PT, 0>(w0 + r, lane, pos, N, NN, offset, box, n_neigh, nlist, head_list, rmaxsq,
+                                                    force, nullptr, out_f64, p, check_count, positions_out, dest, counts_io, nullptr, &tot_r[r]);
             }
+        if constexpr (EPL != 0) {
+            if (ep != nullptr) { // (the rare path: its loads sit where they are needed)
+                group_epilogue_load<PT, R, (EPL >= 2)>(ep, pos, w0 + offset, lane, ep_v, ep_own, ep_s0, ep_s1, absent);
+                group_epilogue<PT, R, (EPL >= 2)>(ep, w0 + offset, lane, tot_r, absent, ep_v, ep_own, ep_s0, ep_s1);
+            }
+        }
         return;
     }
-    PT ep_v, ep_own;
-    uint4 ep_s0, ep_s1;
-    group_epilogue_load<PT, R, (EPL >= 2)>(ep, pos, w0 + offset, lane, ep_v, ep_own, ep_s0, ep_s1);
-    float tot_r[R];
     PV pi[R];
     unsigned head[R];
     unsigned k[R][2], kt;
@@ -558,6 +594,11 @@ __device__ __forceinline__ void fused_rows_group_tails(
             en[r] += e;
         }
     }
+    // the epilogue's inputs (velocity, own position, message slots of lane 4 r + c): loaded HERE -- behind the straight-line part,
+    // whose gathered positions are the kernel's register peak, ahead of the tail trip and the reductions that hide the trip to
+    // memory (at the head of the wave's work they cost 10 VGPRs; behind the last row, 10 % of the kernel's time)
+    asm volatile("" ::: "memory");
+    if constexpr (EPL != 0) group_epilogue_load<PT, R, (EPL >= 2)>(ep, pos, w0 + offset, lane, ep_v, ep_own, ep_s0, ep_s1, 0u);
     // the shared tail trip
     if (S[R] != 0) {
         PV pil = pi[0];
@@ -625,14 +666,17 @@ __device__ __forceinline__ void fused_rows_group_tails(
             if (lane == 0 && np > *(volatile unsigned *)check_count) atomicMax(check_count, np);
         }
     }
-    group_epilogue<PT, R, (EPL >= 2)>(ep, w0 + offset, lane, tot_r, redo, ep_v, ep_own, ep_s0, ep_s1);
 #pragma unroll 1
     for (unsigned r = 0; r < (unsigned)R; ++r)
         if ((redo >> r) & 1u) {
             if constexpr (STORE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            fused_row<KIND, false, STORE, PT, EPL>(w0 + r, lane, pos, N, NN, offset, box, n_neigh, nlist, head_list, rmaxsq,
-                                              force, nullptr, out_f64, p, check_count, positions_out, dest, counts_io, ep);
+            float t = 0.f;
+            fused_row<KIND, false, STORE, PT, 0>(w0 + r, lane, pos, N, NN, offset, box, n_neigh, nlist, head_list, rmaxsq,
+                                            force, nullptr, out_f64, p, check_count, positions_out, dest, counts_io, nullptr, &t);
+#pragma unroll
+            for (int q_ = 0; q_ < R; ++q_) tot_r[q_] = r == (unsigned)q_ ? t : tot_r[q_];
         }
+    if constexpr (EPL != 0) group_epilogue<PT, R, (EPL >= 2)>(ep, w0 + offset, lane, tot_r, 0u, ep_v, ep_own, ep_s0, ep_s1);
 }
 
 // (Measured and removed, commit 6b65261: FOUR INDICES PER LANE -- the wave's four rows own 16 lanes each and a lane reads the

@@ -254,8 +254,17 @@ def _run_ranks(target, world, args, timeout=900):
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=target, args=(r, world, port, q) + tuple(args)) for r in range(world)]
-    for p in procs:
-        p.start()
+    # (the ranks SHARE this GPU: up to eight processes are time-sliced on it, and on a cold box their start-up is seconds apart --
+    #  transport "peer" bounds every wait on the device (~4 s of polling by default, then a flag): give a rehearsal ~30 s)
+    spin_before = os.environ.get("HTF_PEER_SPIN")
+    if spin_before is None:
+        os.environ["HTF_PEER_SPIN"] = str(1 << 25)
+    try:
+        for p in procs:
+            p.start()
+    finally:
+        if spin_before is None:
+            os.environ.pop("HTF_PEER_SPIN", None)
     results = [q.get(timeout=timeout) for _ in procs]
     for p in procs:
         p.join(timeout=60)
