@@ -813,9 +813,13 @@ static int launch_fused(const void *pos, unsigned N, unsigned NN, unsigned offse
         // persistent grids and the one-row kernel lost their A/Bs and are compiled in variants builds only.
         constexpr bool kTails = KIND == HTF_POT_LJ || KIND == HTF_POT_WCA;
         int tails = batch >= 16384u ? (batch >= 49152u ? 4 : 2) : 0;
-        // with a halo-packing epilogue the four-row form needs 82 VGPRs (five waves per SIMD against eight without one), the
-        // two-row form 65: 60.4 us against 71.5 at C3
-        if (kEpilogueKind && ep != nullptr && ep_level >= 2 && tails == 4) tails = 2;
+        // (until the epilogue became ONE copy at the end of a row group the four-row form with a halo-packing epilogue needed 82
+        //  VGPRs -- five waves per SIMD -- and lost to the two-row form, 71.5 us against 60.4 at C3; now 58: -DHTF_HALO_FOUR_ROWS=0
+        //  restores the old rule for A/B runs)
+#ifndef HTF_HALO_FOUR_ROWS
+#define HTF_HALO_FOUR_ROWS 1
+#endif
+        if (!HTF_HALO_FOUR_ROWS && kEpilogueKind && ep != nullptr && ep_level >= 2 && tails == 4) tails = 2;
         if (tails_env) tails = atoi(tails_env);
 #ifndef HTF_AB_VARIANTS
         if (!kTails) tails = 0;
