@@ -665,7 +665,7 @@ extern "C" int htfs_set_step_epilogue(htf_ctx *ctx, int slot, const htfs_step_ep
     // honoured by: the one-kernel route of LJModel / WCARepulsion on fp32 positions (the forms compiled with an epilogue), no virial
     // (the one-row kernel), unbatched, forces written into HOOMD's array, everything in the context's Scalar
     const bool ok = cfg.force_mode == HTF_TF2HOOMD && cfg.fused != 0 && cfg.nneighs > 0 && !cfg.virial && cfg.batch_size == 0 &&
-                    cfg.period == 1 && !cfg.check_nlist && ep->dtype == cfg.scalar_dtype && ep->dtype == HTF_F32 && pot != nullptr && !own_evaluator(pot) &&
+                    cfg.period == 1 && !cfg.check_nlist && ep->dtype == cfg.scalar_dtype && (ep->dtype == HTF_F32 || HTF_EPILOGUE_F64) && pot != nullptr && !own_evaluator(pot) &&
                     (pot->pp.kind == HTF_POT_LJ || pot->pp.kind == HTF_POT_WCA) && // (the forms compiled with an epilogue: fused_eval.hip)
                     (ep->brick == nullptr || !ep->brick->halo_wrap);                // (a replica brick on the GLOBAL cell grid wraps its messages)
     ctx->epilogue_ok[slot] = false;

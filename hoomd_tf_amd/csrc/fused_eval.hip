@@ -760,7 +760,7 @@ static int launch_fused(const void *pos, unsigned N, unsigned NN, unsigned offse
     // (the epilogue forms exist for the two potentials BASELINE's configurations time; htfs_set_step_epilogue says so)
     // (fp32 positions only: under a HOOMD DOUBLE build the epilogue took the four-row form from 65 to 87 us -- 9.7 k against
     //  11.1 k steps/s at C3 -- so the fp64 wire keeps the integrator's own launch and no fp64 epilogue form is compiled)
-    constexpr bool kEpilogueKind = !VIRIAL && sizeof(PT) == 4 && (KIND == HTF_POT_LJ || KIND == HTF_POT_WCA);
+    constexpr bool kEpilogueKind = !VIRIAL && (sizeof(PT) == 4 || HTF_EPILOGUE_F64) && (KIND == HTF_POT_LJ || KIND == HTF_POT_WCA);
     // level 1: the integrator alone (77 VGPRs in the four-row form, six waves per SIMD); level 2: + a brick's halo messages (82: five)
     const int ep_level = step_epilogue_level();
     if constexpr (!VIRIAL) {

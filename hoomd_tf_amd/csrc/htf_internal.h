@@ -28,6 +28,12 @@ struct PotParams {
 // component by component -- written into the OTHER position buffer (every wave still reads x(t) of everybody), and, under a brick
 // decomposition, into the halo messages that carry the row.  A step is then one launch where it was force kernel + integrator (+
 // halo pack).  vel == nullptr: no epilogue.  All fields by value: a kernel argument.
+// the epilogue under a HOOMD DOUBLE build: measured twice in round 6 and OFF -- with the first form of the epilogue 9.7 k against
+// 11.1 k steps/s at C3, with the one-copy form (83 VGPRs against 79, the same six waves per SIMD) 10.55-10.59 k against 10.91-10.95 k:
+// the fp64 four-row kernel takes 74-77 us with it and 65-66 without.  -DHTF_EPILOGUE_F64=1 (context.hip and fused_eval.hip) compiles it.
+#ifndef HTF_EPILOGUE_F64
+#define HTF_EPILOGUE_F64 0
+#endif
 template <typename T>
 struct StepEpilogue {
     void *vel = nullptr;      // Scalar4[N], updated in place

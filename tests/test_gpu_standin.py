@@ -503,8 +503,9 @@ def test_fused_step_equals_force_kernel_plus_integrator(htf, cuda, tdt, cells, p
         ctx.set_potential(htf.Potential.lj() if pot == "lj" else htf.Potential.wca(1.0))
         nve = standin.NVE(sysm, 0.004)
         fs = standin.FusedStep(sysm, nl, ctx, nve)
-        # (fp64 positions -- a HOOMD DOUBLE build -- keep the integrator's own launch: the epilogue measured slower there, 9.7 k against
-        #  11.1 k steps/s at C3, and is not compiled; FusedStep then IS the classic pair of launches)
+        # (fp64 positions -- a HOOMD DOUBLE build -- keep the integrator's own launch: the epilogue measured slower there, twice -- 9.7 k
+        #  against 11.1 k steps/s at C3 in its first form, 10.6 k against 10.9 k in the one-copy form -- and is not compiled;
+        #  FusedStep then IS the classic pair of launches)
         assert fs.available == (tdt == torch.float32)
         home = sysm.pos.data_ptr()
         swaps = 0
