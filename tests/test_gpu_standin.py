@@ -530,6 +530,49 @@ def test_fused_step_equals_force_kernel_plus_integrator(htf, cuda, tdt, cells, p
         assert torch.equal(out["classic"][k], out["fused"][k]), k
 
 
+@pytest.mark.parametrize("lattice,cells,NN,rbuff", [("sc", 27, 40, 0.4), ("sc", 37, 40, 0.4), ("sc", 37, 80, 0.4), ("fcc", 16, 128, 1.5),
+                                                    ("fcc", 24, 128, 1.5)])
+def test_fused_step_on_the_rows_the_fast_path_hands_back(htf, cuda, lattice, cells, NN, rbuff):
+    """The step epilogue is ONE piece of code at the end of a row group; rows the straight-line path does not take hand their sums
+    back to it: rows that OVERFLOW NN (NN = 40 at r_cut 2.5: every row of the liquid, redone by the generic routine), lists longer
+    than 192 entries (r_buff = 1.5: the whole group falls back), a last group with fewer rows than the form takes (19 683 and 50 653
+    particles are odd numbers).  Two-row and four-row merged-tails forms; positions, velocities, forces against force launch +
+    htfs_nve_step bit for bit over 40 steps with rebuilds."""
+    from hoomd_tf_amd import standin
+    pos, L, a = (standin.sc_positions if lattice == "sc" else standin.fcc_positions)(cells, 0.8442)
+    rng = np.random.default_rng(cells)
+    pos = pos + 0.03 * a * rng.standard_normal(pos.shape)
+    pos -= np.round(pos / L) * L
+    out = {}
+    for mode in ("classic", "fused"):
+        sysm = standin.System(pos, L, dtype=torch.float32, device=cuda)
+        sysm.randomize_velocities(kT=1.0, seed=4)
+        nl = standin.CellNlist(sysm, r_cut=2.5, r_buff=rbuff, check_period=4, device_decision=True)
+        nl.build()
+        if rbuff > 1.0:
+            assert int(nl.n_neigh.max()) > 192
+        ctx = htf.Context(r_cut=2.5, nneighs=NN, scalar_dtype=torch.float32, max_n=sysm.N, fused=2)
+        ctx.set_potential(htf.Potential.lj())
+        nve = standin.NVE(sysm, 0.002)
+        fs = standin.FusedStep(sysm, nl, ctx, nve)
+        assert fs.available
+        for ts in range(40):
+            if mode == "fused":
+                fs.step(ts)
+            else:
+                nl.compute(ts)
+                ctx.compute_forces(ts, fs.arrays())
+                nve.step()
+        torch.cuda.synchronize()
+        if NN == 40:     # every row holds NN pairs: the overflow replay ran for all of them
+            pv = ctx.nlist_buffer(sysm.N, cuda)
+            assert int((pv[:, :, :3] != 0).any(dim=2).sum(dim=1).min()) == NN
+        out[mode] = (sysm.pos.clone(), sysm.vel.clone(), sysm.force.clone())
+    assert bool(torch.isfinite(out["fused"][2]).all())
+    for k in range(3):
+        assert torch.equal(out["classic"][k], out["fused"][k]), k
+
+
 def test_fused_step_is_refused_where_the_kernel_cannot_carry_it(htf, cuda):
     """A virial request (the one-row kernel), a pair-MLP (its own evaluator), a generated kernel, batching: FusedStep.available is
     False and step() is the classic pair of launches."""
