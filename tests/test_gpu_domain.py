@@ -468,13 +468,23 @@ def test_bench_starts_its_own_ranks(htf, cuda, args):
     env = dict(os.environ, HTF_BENCH_BACKEND="gloo")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args + ["--cells", "12", "--steps", "10", "--warmup", "3", "--equil", "40",
-                                                                                  "--no-cpu-baseline", "--no-fused", "--windows", "1"],
-                       capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
-    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
-    lines = [l for l in r.stdout.splitlines() if l.strip()]
-    assert len(lines) == 1, r.stdout
-    d = json.loads(lines[0])
+    # (the ranks share ONE GPU here: up to eight processes time-sliced, the library-free transport's bounded waits in flight -- a
+    #  rehearsal now and then runs one of them out, and the guarded section then reports a named skip, as designed; the asserts
+    #  below want to see the transport run, so such a line gets ONE more attempt)
+    env.setdefault("HTF_PEER_SPIN", str(1 << 25))
+    env.setdefault("HTF_BRICK_WAIT_S", "120")
+    for attempt in range(2):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args + ["--cells", "12", "--steps", "10", "--warmup", "3", "--equil", "40",
+                                                                                      "--no-cpu-baseline", "--no-fused", "--windows", "1"],
+                           capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+        lines = [l for l in r.stdout.splitlines() if l.strip()]
+        assert len(lines) == 1, r.stdout
+        d = json.loads(lines[0])
+        skipped = " ".join(str(d.get(k, {}).get("skipped", "")) for k in ("peer_selftest", "graph_variant_peer")) + str(d.get("guarded_section_ended_by", ""))
+        if attempt == 0 and any(w in skipped for w in ("did not arrive", "never reached cycle", "watchdog", "timed out", "another rank failed")):
+            continue
+        break
     n = int(args[1])
     weak = "weak" in args
     assert d["n_gpus"] == n and d["scaling"] == ("weak" if weak else "strong")
