@@ -96,7 +96,18 @@ __device__ __forceinline__ void train_pair_body(const typename Vec4<IT>::type *_
 // bits the tensor would hold; a row keeps its first NN neighbors within r_cut -- or, past NN, the LAST NN of them (the
 // reference's slot wrap; the row is then redone with those bounds).  Only the order of a row's fp32 sums differs from the
 // tensor sweep (a pair sits in lane (list position) % 16 instead of (slot) % 16).
-constexpr int kTrainChunk = 4; // list entries per lane gathered ahead of their arithmetic
+// list entries per lane gathered ahead of their arithmetic.  ONE: the sweep hides its gathers with waves, not with loads in flight per
+// wave -- at C3 (trainable LJ, tools/train_list_probe.py, same box) 1 / 2 / 3 / 4 / 6 entries: 71.7 / 80.8 / 83.5 / 94.6 / 120.9 us
+// (the accumulators of 1 + P columns already fill the registers: 94 VGPRs at 4)
+#ifndef HTF_TRAIN_LIST_CHUNK
+#define HTF_TRAIN_LIST_CHUNK 1
+#endif
+constexpr int kTrainChunk = HTF_TRAIN_LIST_CHUNK;
+// lanes per row of the list sweep
+#ifndef HTF_TRAIN_LIST_G
+#define HTF_TRAIN_LIST_G 16
+#endif
+constexpr int kTrainListG = HTF_TRAIN_LIST_G;
 
 template <int KIND, typename PT>
 __device__ __forceinline__ void train_list_body(const typename Vec4<PT>::type *__restrict__ pos, unsigned B, unsigned NN,
@@ -105,7 +116,7 @@ __device__ __forceinline__ void train_list_body(const typename Vec4<PT>::type *_
                                                 PT rmaxsq, const void *__restrict__ labels, int lab_f64, void *__restrict__ pred,
                                                 PotParams pin, float *__restrict__ partials) {
     using PV = typename Vec4<PT>::type;
-    constexpr int G = kTrainG, RPW = 64 / G, P = NumParams<KIND>::value;
+    constexpr int G = kTrainListG, RPW = 64 / G, P = NumParams<KIND>::value;
     __shared__ float s_part[4][1 + P];
     const PotParams p = resolve_theta<KIND>(pin);
     const unsigned lane = threadIdx.x & 63u, g = lane % G, sub = lane / G;
@@ -147,9 +158,9 @@ __device__ __forceinline__ void train_list_body(const typename Vec4<PT>::type *_
                 PT dx, dy, dz;
                 const PT rsq = pair_vector<PT>(pk[t], pi, box, dx, dy, dz);
                 const bool keep = j < nn && !(rsq > rmaxsq);
-                const unsigned bits = (unsigned)(__ballot(keep) >> (G * sub)) & ((1u << G) - 1u);
-                const unsigned q = Q + (unsigned)__popc(bits & ((1u << g) - 1u));
-                Q += (unsigned)__popc(bits);
+                const unsigned long long bits = (__ballot(keep) >> (G * sub)) & (G == 64 ? ~0ull : ((1ull << G) - 1ull));
+                const unsigned q = Q + (unsigned)__popcll(bits & ((1ull << g) - 1ull));
+                Q += (unsigned)__popcll(bits);
                 const bool use = keep && q >= q_lo && q < q_hi;
                 // (a slot that is not used is the tensor's zero padding: every trainable form vanishes on it)
                 const float x = use ? (float)dx : 0.f, y = use ? (float)dy : 0.f, z = use ? (float)dz : 0.f;
@@ -266,7 +277,7 @@ template <int KIND>
 static int launch_train_list(const PotParams &p, const void *pos, int pos_dtype, unsigned B, unsigned NN, const htf_box *hb,
                              const unsigned *n_neigh, const unsigned *nlist, const unsigned *head_list, double rmax,
                              const void *labels, int lab_f64, void *pred, float *accum, float *scratch, hipStream_t s) {
-    constexpr unsigned rows_per_block = 4 * (64 / kTrainG);
+    constexpr unsigned rows_per_block = 4 * (64 / kTrainListG);
     constexpr unsigned width = 1 + NumParams<KIND>::value;
     const unsigned grid = (B + rows_per_block - 1) / rows_per_block;
     if (pos_dtype == HTF_F32) {
@@ -304,7 +315,7 @@ static unsigned train_width(const PotParams &p) {
 
 size_t train_scratch_floats(const PotParams &p, unsigned B, unsigned NN) {
     (void)NN;
-    const unsigned rows_per_block = 4 * (64 / kTrainG);
+    const unsigned rows_per_block = 4 * (64 / (kTrainG > kTrainListG ? kTrainG : kTrainListG)); // (either sweep's block partials fit)
     return (size_t)((B + rows_per_block - 1) / rows_per_block) * train_width(p);
 }
 
@@ -340,7 +351,7 @@ int train_list_dispatch(const PotParams &p, const void *pos, int pos_dtype, unsi
     case HTF_POT_WCA: return HTF_TL(HTF_POT_WCA);
     case HTF_POT_RINV_POLY: return HTF_TL(HTF_POT_RINV_POLY);
     case HTF_POT_JIT: {
-        constexpr unsigned rows_per_block = 4 * (64 / kTrainG);
+        constexpr unsigned rows_per_block = 4 * (64 / kTrainListG);
         const unsigned grid = (B + rows_per_block - 1) / rows_per_block;
         int rc = jit_launch_train_list(p, pos, pos_dtype, B, NN, box, n_neigh, nlist, head_list, rmax, labels, lab_f64, pred, scratch, grid, stream);
         if (rc != HTF_OK) return rc;
