@@ -1216,6 +1216,17 @@ class TracedWeights:
         return self.theta
 
 
+class _TracedWeightsOfTerms:
+    """The weight vectors of an energy's several row terms, as one thing tfcompute can refresh before a replayed step."""
+
+    def __init__(self, tws):
+        self.tws = list(tws)
+
+    def refresh_if_stale(self):
+        for t in self.tws:
+            t.refresh_if_stale()
+
+
 def _fold_weight(x):
     """(value, ((leaf, version), ...)) of a one-element tensor that requires grad, while nothing is being trained; else None."""
     if (isinstance(x, torch.Tensor) and x.numel() == 1 and x.requires_grad and not getattr(_trace, "training_graph", False)):
@@ -1714,7 +1725,10 @@ def _row_forces(nl, energy, virial):
     # step of the first term (which writes the tensor) followed by one streaming evaluation per further term, added in place
     f = sum(outs[1:], outs[0])
     typed = [bool(g.reads_own_type) for g in groups]
-    _trace_log().append({"potential": pots[0], "nlist": nl, "virial": False, "forces": f, "layer": None,
+    # (weights of the terms are kernel arguments of their units: the plan re-uploads whichever were written since the last step)
+    tws = [g.layer for g in groups if g.layer is not None]
+    _trace_log().append({"potential": pots[0], "nlist": nl, "virial": False, "forces": f,
+                         "layer": _TracedWeightsOfTerms(tws) if tws and not getattr(_trace, "training_graph", False) else None,
                          "folded": tuple(x for g in groups for x in g.folded),
                          "extra_potentials": [(p_, t_) for p_, t_ in zip(pots[1:], typed[1:])]})
     return f

@@ -731,3 +731,48 @@ def test_row_function_with_weights_follows_them_and_trains_on_the_torch_route(ht
     torch.cuda.synchronize()
     assert st._tplan is None                                                       # no kernel plan: the autograd route trains it
     assert 1.5 < float(student.amp.detach()) < 2.3, float(student.amp.detach())
+
+
+def test_weights_of_several_row_terms_are_refreshed_under_the_plan(htf, cuda, monkeypatch):
+    """An energy of TWO row terms whose first carries a weight: the plan is step + streaming evaluation; a weight written in place
+    between steps reaches the replayed kernels (every term's weight vector is refreshed before the launch), forces == torch route."""
+    from hoomd_tf_amd import standin
+
+    class FS(htf.SimModel):
+        def setup(self):
+            self.amp = torch.nn.Parameter(torch.tensor(1.3, device="cuda"))
+
+        def compute(self, nlist, positions, box):
+            s = htf.nlist_rinv(nlist)
+            r = htf.safe_norm(nlist[:, :, :3], axis=2)
+            rho = htf.reduce_sum(htf.exp(-1.7 * r) * s * s, axis=1)
+            phi = htf.reduce_sum(2.0 * s ** 12, axis=1)
+            return htf.compute_nlist_forces(nlist, phi - self.amp * htf.sqrt(rho + 0.01))
+
+    def forces(jit):
+        monkeypatch.setenv("HTF_NO_JIT", "0" if jit else "1")
+        pos, L, a = standin.fcc_positions(6, 0.8442)
+        rng = np.random.default_rng(2)
+        pos = pos + 0.03 * a * rng.standard_normal(pos.shape)
+        pos -= np.round(pos / L) * L
+        sysm = standin.System(pos, L, dtype=torch.float32, device=cuda)
+        sim = standin.Simulation(sysm)
+        sim.integrate_nve(0.0)
+        model = FS(96)
+        tfc = htf.tfcompute(model)
+        tfc.attach(sim.nlist_cell(r_buff=0.4, check_period=1), r_cut=2.5)
+        out = []
+        for a_ in (1.3, 2.6):
+            with torch.no_grad():
+                model.amp.fill_(a_)
+            sim.run(3, graph=False)
+            torch.cuda.synchronize()
+            out.append((tfc._plan, len(tfc._post_ops), tfc.force.clone()))
+        return out
+
+    got, ref = forces(True), forces(False)
+    assert got[0][0] is not None and got[0][0] is got[1][0] and got[0][1] == 1
+    for (_, _, f), (p0, _, f0) in zip(got, ref):
+        assert p0 is None
+        assert float((f - f0).abs().max()) < 2e-5 * float(f0.abs().max())
+    assert float((got[1][2][:, 3] - got[0][2][:, 3]).abs().min()) > 0.5                          # the weight mattered: every particle's embedding energy moved
