@@ -609,6 +609,19 @@ def test_row_terms_of_two_sums_are_replayed_as_step_plus_evaluations(htf, cuda, 
     assert abs(float(f1[:, 3].double().sum()) - float(f0[:, 3].double().sum())) < 1e-4 * abs(float(f0[:, 3].double().sum())) + 1e-3
 
 
+def _random_row_energy(htf, x, seed):
+    """A random row function of the row sum of a random pair expression (tools/warm_jit_cache.py builds the same units ahead)."""
+    g = np.random.default_rng(seed)
+    s, r = htf.nlist_rinv(x), htf.safe_norm(x[:, :, :3], axis=2)
+    pair = [lambda: s ** 6, lambda: htf.exp(-1.3 * r) * s * s, lambda: htf.sigmoid(4.0 * (1.6 - r)) * htf.cast(s > 0.0, torch.float32),
+            lambda: 0.5 * (s ** 12 - s ** 6), lambda: htf.tanh(s) * s][g.integers(0, 5)]()
+    rho = htf.reduce_sum(pair, axis=1)
+    a, b, c = (float(v) for v in g.uniform(0.3, 1.5, 3))
+    return [lambda: a * htf.sqrt(rho * rho + b), lambda: htf.log(1.0 + rho * rho) * a - b * rho, lambda: a * htf.tanh(b * rho) + c * rho ** 2,
+            lambda: htf.exp(-a * htf.square(rho - b)) + c, lambda: a * rho / (1.0 + b * rho * rho), lambda: htf.softplus(a * rho - b) - c * rho,
+            lambda: a * htf.sin(b * rho) + c * htf.cos(rho) + rho, lambda: htf.sigmoid(a * rho) * rho ** 3 * c][g.integers(0, 8)]()
+
+
 def test_random_row_functions_on_the_device(htf, cuda):
     """Eight random row functions -- a random chain of the tracer's unary ops, powers and arithmetic applied to the row sum of a
     random pair expression -- through compute_nlist_forces on generated units, against torch-fp64 autograd of the same traced
@@ -618,17 +631,7 @@ def test_random_row_functions_on_the_device(htf, cuda):
     nl, _ = random_nlist(rng, 200, 64, fill=0.7, rmin=0.85, rmax=3.0, dtype=np.float32)
     nl64 = nl.astype(np.float64)
 
-    def make(x, seed):
-        g = np.random.default_rng(seed)
-        s, r = htf.nlist_rinv(x), htf.safe_norm(x[:, :, :3], axis=2)
-        pair = [lambda: s ** 6, lambda: htf.exp(-1.3 * r) * s * s, lambda: htf.sigmoid(4.0 * (1.6 - r)) * htf.cast(s > 0.0, torch.float32),
-                lambda: 0.5 * (s ** 12 - s ** 6), lambda: htf.tanh(s) * s][g.integers(0, 5)]()
-        rho = htf.reduce_sum(pair, axis=1)
-        a, b, c = (float(v) for v in g.uniform(0.3, 1.5, 3))
-        f = [lambda: a * htf.sqrt(rho * rho + b), lambda: htf.log(1.0 + rho * rho) * a - b * rho, lambda: a * htf.tanh(b * rho) + c * rho ** 2,
-             lambda: htf.exp(-a * htf.square(rho - b)) + c, lambda: a * rho / (1.0 + b * rho * rho), lambda: htf.softplus(a * rho - b) - c * rho,
-             lambda: a * htf.sin(b * rho) + c * htf.cos(rho) + rho, lambda: htf.sigmoid(a * rho) * rho ** 3 * c][g.integers(0, 8)]()
-        return f
+    make = lambda x, seed: _random_row_energy(htf, x, seed)
     done = 0
     for seed in range(12):
         e64 = make(htf.Nlist(torch.from_numpy(nl64)), seed)

@@ -59,6 +59,20 @@ def bodies():
     out += [t.body() for t in (u + 0.02 * u * u).groups()]
     rho = htf.reduce_sum(htf.exp(-1.7 * r) * s * s, axis=1)
     out += [t.body() for t in (-1.3 * htf.sqrt(rho) + htf.reduce_sum(2.0 * s ** 12, axis=1)).groups()]
+    # tests/test_gpu_codegen.py: random row functions, embedded-atom terms with weights (kernel arguments of body and row function)
+    from test_gpu_codegen import _random_row_energy
+    for seed in range(12):
+        out += [t.body() for t in (_random_row_energy(htf, x, seed).groups() or [])]
+    x1 = htf.Nlist(torch.zeros((2, 4, 4)))     # (a fresh trace each: its weight vector starts at index 0, as in the test's compute())
+    s1, r1 = htf.nlist_rinv(x1), htf.safe_norm(x1[:, :, :3], axis=2)
+    amp, decay = torch.nn.Parameter(torch.tensor(1.3)), torch.nn.Parameter(torch.tensor(1.7))
+    rho = htf.reduce_sum(htf.exp(-1.0 * decay * r1) * s1 * s1, axis=1)
+    out += [t.body() for t in (-1.0 * amp * htf.sqrt(rho + 0.01)).groups()]
+    x2 = htf.Nlist(torch.zeros((2, 4, 4)))
+    s2, r2 = htf.nlist_rinv(x2), htf.safe_norm(x2[:, :, :3], axis=2)
+    amp2 = torch.nn.Parameter(torch.tensor(1.3))
+    rho2 = htf.reduce_sum(htf.exp(-1.7 * r2) * s2 * s2, axis=1)
+    out += [t.body() for t in (htf.reduce_sum(2.0 * s2 ** 12, axis=1) - amp2 * htf.sqrt(rho2 + 0.01)).groups()]
     return out
 
 
